@@ -1,0 +1,256 @@
+"""The oracle (oracle/cwn_oracle.py) against (a) the hand-computed expectations the reference's
+own tests hold and (b) golden vectors produced by running the reference itself
+(oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cwn_oracle as O
+from tests._golden import load, T, complex_dict, dummy_complex, params_dict, state_dict
+
+NAMES = ['house', 'bridged', 'fullstop', 'colon', 'square', 'square_dot', 'kite', 'pyramid',
+         'filled_square', 'molecular']
+
+
+def base(prm, **kw):
+    w = prm['x'].size(1)
+    kw = dict(dict(up_msg_size=w, down_msg_size=w), **kw)
+    return O.propagate(prm['x'], prm['up_index'], prm['down_index'], prm['boundary_index'],
+                       up_attr=prm['up_attr'], down_attr=prm['down_attr'],
+                       boundary_attr=prm['boundary_attr'], **kw)
+
+
+# ---- (a) known answers written in the reference's tests -------------------------------------
+def test_house_edges_known_answer():            # mp/test_cell_mp.py:13-35
+    up, down, bnd = base(O.cochain_params(dummy_complex('house'), 1))
+    assert up.flatten().tolist() == [0, 0, 11, 0, 9, 8]
+    assert down.flatten().tolist() == [6, 10, 17, 9, 13, 10]
+    assert bnd.flatten().tolist() == [3, 5, 7, 5, 9, 8]
+
+
+def test_house_vertices_known_answer():         # mp/test_cell_mp.py:38-62
+    up, down, bnd = base(O.cochain_params(dummy_complex('house'), 0))
+    assert up.flatten().tolist() == [6, 4, 11, 9, 7]
+    assert torch.equal(down, torch.zeros(5, 1)) and torch.equal(bnd, torch.zeros(5, 1))
+
+
+def test_house_two_cell_known_answer():         # mp/test_cell_mp.py:65-88
+    up, down, bnd = base(O.cochain_params(dummy_complex('house'), 2))
+    assert torch.equal(up, torch.zeros(1, 1)) and torch.equal(down, torch.zeros(1, 1))
+    assert bnd.flatten().tolist() == [14]
+
+
+def test_two_triangles_known_answer():          # mp/test_cell_mp.py:91-111
+    x = torch.tensor([[32.], [17.]])
+    up, down, _ = O.propagate(x, None, torch.tensor([[0, 1], [1, 0]]), None,
+                              down_attr=torch.tensor([[1], [1]]), up_msg_size=1, down_msg_size=1)
+    assert (up + down).flatten().tolist() == [17, 32]
+
+
+def test_isolated_and_empty():                  # mp/test_cell_mp.py:114-176
+    prm = O.cochain_params(dummy_complex('square_dot'), 0)
+    up, down, _ = base(prm)
+    assert up[4].item() == 0 and all(up[i].item() != 0 for i in range(4))
+    x = torch.tensor([[1.]])
+    up, _, _ = O.propagate(x, torch.empty(2, 0, dtype=torch.long), None, None, up_msg_size=1, down_msg_size=1)
+    assert torch.equal(up, torch.zeros(1, 1))
+    up, _, _ = O.propagate(x, None, None, None, up_msg_size=1, down_msg_size=1)
+    assert torch.equal(up, torch.zeros(1, 1))
+
+
+def test_bridged_multiplicity_known_answer():   # mp/test_cell_mp.py:179-247
+    up, _, _ = base(O.cochain_params(dummy_complex('bridged'), 1))
+    assert up.flatten().tolist() == [24, 22, 20, 18, 22, 20]
+    _, down, bnd = base(O.cochain_params(dummy_complex('bridged'), 2))
+    assert down.flatten().tolist() == [10, 8, 6] and bnd.flatten().tolist() == [16, 16, 10]
+
+
+def test_dummy_layer_known_answers():           # mp/test_layers.py:11-69
+    h = dummy_complex('house')
+    prms = [O.cochain_params(h, d) for d in range(3)]
+    assert O.dummy_cochain_mp(prms[0]).flatten().tolist() == [12, 9, 25, 25, 23]
+    assert O.dummy_cochain_mp(prms[1]).flatten().tolist() == [10, 20, 47, 22, 42, 37]
+    assert O.dummy_cochain_mp(prms[2]).flatten().tolist() == [1]
+    assert O.dummy_cochain_mp(prms[1], True, False).flatten().tolist() == [4, 7, 23, 9, 25, 24]
+    assert O.dummy_cochain_mp(prms[2], True, False).flatten().tolist() == [15]
+    m = dummy_complex('molecular')
+    prms = [O.cochain_params(m, d) for d in range(3)]
+    assert O.dummy_cochain_mp(prms[0], True, True).flatten().tolist() == [12, 24, 24, 15, 25, 31, 47, 24]
+    assert O.dummy_cochain_mp(prms[1], True, True).flatten().tolist() == [35, 79, 41, 27, 66, 70, 92, 82, 53]
+    assert O.dummy_cochain_mp(prms[2], True, True).flatten().tolist() == [15, 33]
+
+
+def test_init_reduce_known_answer():            # mp/test_layers.py:135-149
+    h = dummy_complex('house')
+    p = [O.cochain_params(h, d) for d in range(3)]
+    assert O.init_reduce(p[0]['x'], p[1]['boundary_index']).flatten().tolist() == [3, 5, 7, 5, 9, 8]
+    assert O.init_reduce(p[1]['x'], p[2]['boundary_index']).flatten().tolist() == [14]
+
+
+def test_house_params_known_answer():           # data/test_data.py:6-54
+    h = dummy_complex('house')
+    v, e = O.cochain_params(h, 0), O.cochain_params(h, 1)
+    assert v['up_attr'].flatten().tolist() == [1, 1, 4, 4, 2, 2, 3, 3, 6, 6, 5, 5]
+    assert e['up_attr'].flatten().tolist() == [1] * 6
+    assert e['down_attr'].flatten().tolist() == [2, 2, 1, 1, 3, 3, 3, 3, 4, 4, 4, 4, 3, 3, 4, 4, 5, 5]
+
+
+# ---- (b) golden vectors from the live reference ------------------------------------------------
+@pytest.mark.parametrize('name', NAMES)
+def test_propagate_golden_every_complex(name):
+    g = load('propagate_known_answer.npz')
+    cx = dummy_complex(name)
+    for d in range(cx['dimension'] + 1):
+        prm = O.cochain_params(cx, d)
+        ref = params_dict(g, f'{name}/{d}/params')
+        for k, v in ref.items():
+            assert (v is None) == (prm[k] is None), (name, d, k)
+            if v is not None:
+                assert torch.equal(v, prm[k]), (name, d, k)
+        up, down, bnd = base(prm)
+        assert torch.equal(up, T(g[f'{name}/{d}/up']))
+        assert torch.equal(down, T(g[f'{name}/{d}/down']))
+        assert torch.equal(bnd, T(g[f'{name}/{d}/boundary']))
+    for ub in (0, 1):
+        for ud in (0, 1):
+            for d in range(min(cx['dimension'], 2) + 1):
+                o = O.dummy_cochain_mp(O.cochain_params(cx, d), bool(ub), bool(ud))
+                assert torch.equal(o, T(g[f'{name}/dummy_b{ub}_d{ud}/{d}']))
+
+
+@pytest.mark.parametrize('lname', ['testing', 'testing3', 'mol', 'pair', 'nodes_only'])
+def test_batching_golden_integer_exact(lname):
+    g = load('batching.npz')
+    names = [str(n) for n in g[f'{lname}/names']]
+    md = int(g[f'{lname}/max_dim'])
+    got = O.batch_complexes([dummy_complex(n) for n in names], max_dim=md)
+    ref = complex_dict(g, f'{lname}/batch')
+    assert got['dimension'] == ref['dimension']
+    assert torch.equal(got['y'], ref['y'])
+    for d in range(ref['dimension'] + 1):
+        for k in ('x', 'upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries',
+                  'boundary_index', 'y', 'batch'):
+            a, b = got['cochains'][d][k], ref['cochains'][d][k]
+            assert (a is None) == (b is None), (d, k)
+            if a is not None:
+                assert a.dtype == b.dtype and torch.equal(a, b), (d, k)
+        assert got['cochains'][d]['num_cells'] == ref['cochains'][d]['num_cells']
+    for kw_name, kw in (('full', {}), ('nodown', dict(include_down_features=False))):
+        for d, prm in enumerate(O.all_cochain_params(got, max_dim=md, **kw)):
+            refp = params_dict(g, f'{lname}/params_{kw_name}/{d}')
+            for k, v in refp.items():
+                assert (v is None) == (prm[k] is None), (d, k)
+                if v is not None:
+                    assert torch.equal(v, prm[k]), (d, k)
+
+
+@pytest.mark.parametrize('F', [1, 3, 8, 64, 128])
+def test_propagate_random_golden(F):
+    g = load('propagate_random.npz')
+    for d in range(3):
+        prm = params_dict(g, f'F{F}/{d}/params')
+        for aggr in ('add', 'mean', 'max'):
+            up, down, bnd = base(prm, aggr_up=aggr, aggr_down=aggr, aggr_boundary=aggr)
+            for got, key in ((up, 'up'), (down, 'down'), (bnd, 'boundary')):
+                torch.testing.assert_close(got, T(g[f'F{F}/{d}/{aggr}/{key}']), rtol=0, atol=1e-6)
+        _, down, bnd = base(prm, up_msg_size=F, down_msg_size=5, boundary_msg_size=7,
+                            use_down_msg=False, use_boundary_msg=False)
+        assert list(down.shape) == g[f'F{F}/{d}/flags_off/down_shape'].tolist()
+        assert list(bnd.shape) == g[f'F{F}/{d}/flags_off/boundary_shape'].tolist()
+        o = O.dummy_cochain_mp(prm, True, True)
+        torch.testing.assert_close(o, T(g[f'F{F}/dummy/{d}']), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize('tag', ['mol_cob_bn', 'mol_nocob_bn', 'test_cob_id', 'mol_cob_bn_64'])
+def test_sparse_cin_conv_golden(tag):
+    g = load('sparse_cin_conv.npz')
+    F, H, cob, bn = g[f'{tag}/meta'].tolist()
+    names = [str(n) for n in g[f'{tag}/names']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    for d in range(3):
+        cx['cochains'][d]['x'] = T(g[f'{tag}/x/{d}'])
+    state = state_dict(g, f'{tag}/state')
+    prms = O.all_cochain_params(cx, max_dim=2, include_down_features=False)
+    for mode in ('eval', 'train'):
+        outs = O.sparse_cin_conv(state, prms, bool(cob), training=(mode == 'train'),
+                                 norm='bn' if bn else 'id')
+        for d, o in enumerate(outs):
+            torch.testing.assert_close(o, T(g[f'{tag}/{mode}/{d}']), rtol=1e-5, atol=1e-5)
+
+
+def test_sparse_cin_conv_backward_golden():
+    """Gradients of the oracle (autograd through the restatement) equal the reference's."""
+    tag = 'mol_cob_bn'
+    g = load('sparse_cin_conv.npz')
+    names = [str(n) for n in g[f'{tag}/names']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    xs = [T(g[f'{tag}/x/{d}']).clone().requires_grad_(True) for d in range(3)]
+    for d in range(3):
+        cx['cochains'][d]['x'] = xs[d]
+    state = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v)
+             for k, v in state_dict(g, f'{tag}/state').items()}
+    outs = O.sparse_cin_conv(state, O.all_cochain_params(cx, max_dim=2, include_down_features=False),
+                             True, training=True)
+    sum((o * T(g[f'{tag}/train_w/{d}'])).sum() for d, o in enumerate(outs)).backward()
+    for d in range(3):
+        torch.testing.assert_close(xs[d].grad, T(g[f'{tag}/train_gx/{d}']), rtol=1e-4, atol=1e-5)
+    pre = f'{tag}/train_grad/'
+    n = 0
+    for k, v in g.items():
+        if k.startswith(pre):
+            torch.testing.assert_close(state[k[len(pre):]].grad, T(v), rtol=1e-4, atol=2e-5)
+            n += 1
+    assert n > 20
+
+
+def test_cin_conv_and_orient_golden():
+    g = load('cin_conv.npz')
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/testing']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    for d in range(3):
+        cx['cochains'][d]['x'] = T(g[f'cin/x/{d}'])
+    st = state_dict(g, 'cin/state')
+    p = {k[len('mp_levels.1.'):]: v for k, v in st.items() if k.startswith('mp_levels.1.')}
+    lin = lambda pre: (lambda h: h @ p[pre + '.weight'].t() + p[pre + '.bias'])
+    prm = O.cochain_params(cx, 1)
+    out = O.cin_cochain_conv(prm, lambda h: torch.relu(lin('msg_up_nn.0')(h)),
+                             lambda h: torch.relu(lin('msg_down_nn.0')(h)),
+                             lambda h: torch.relu(lin('update_nn.0')(h)), p['eps'])
+    torch.testing.assert_close(out, T(g['cin/out/1']), rtol=1e-5, atol=1e-5)
+    up, down = O.oriented_conv_messages(prm['x'], prm['up_index'], prm['down_index'],
+                                        T(g['orient/up_orient']), T(g['orient/down_orient']))
+    torch.testing.assert_close(up, T(g['orient/up']), rtol=0, atol=1e-6)
+    torch.testing.assert_close(down, T(g['orient/down']), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag', ['h16_l2', 'h32_l4'])
+def test_embed_sparse_cin_golden(tag):
+    g = load('embed_sparse_cin.npz')
+    H, L = g[f'{tag}/meta'].tolist()
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/mol']]
+    cxs = [dummy_complex(n) for n in names]
+    cx = O.batch_complexes(cxs, max_dim=2)
+    cx['cochains'][0]['x'] = T(g[f'{tag}/v_types'])
+    cx['cochains'][1]['x'] = T(g[f'{tag}/e_types'])
+    cx['cochains'][2]['x'] = None
+    state = state_dict(g, f'{tag}/state')
+    for mode in ('eval', 'train'):
+        y, partial = O.embed_sparse_cin_forward(state, cx, L, training=(mode == 'train'))
+        for k, v in partial.items():
+            torch.testing.assert_close(v, T(g[f'{tag}/{mode}/{k}']), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(y, T(g[f'{tag}/{mode}/out']), rtol=1e-4, atol=1e-4)
+
+
+def test_csr_from_coo_matches_scatter():
+    g = load('propagate_random.npz')
+    prm = params_dict(g, 'F8/1/params')
+    idx = prm['up_index']
+    n = prm['x'].size(0)
+    rowptr, col, perm = O.csr_from_coo(idx, n)
+    assert rowptr[-1].item() == idx.size(1) and rowptr.dtype == torch.int32
+    assert torch.equal(idx[0][perm.long()].int(), col)
+    dst_sorted = idx[1][perm.long()]
+    assert torch.all(dst_sorted[1:] >= dst_sorted[:-1])
+    # stability: inside one destination the original order is kept
+    same = dst_sorted[1:] == dst_sorted[:-1]
+    assert torch.all(perm[1:][same] > perm[:-1][same])
