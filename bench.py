@@ -1,0 +1,319 @@
+#!/usr/bin/env python
+"""bench.py -- cells/sec of the cellular message-passing hot path on N x MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): ZINC-like ring-lifted batch (max_ring 6), 128 complexes per
+GPU, 4-layer EmbedSparseCIN (hidden 128, coboundary messages, edge embedding, BatchNorm;
+exp/scripts/cwn-zinc.sh:14-30), synthetic inputs and random-init weights.
+
+One STEP = one pass of the hot path over one batch with the batch already resident in HBM:
+    per-batch CSR plan build (int64 COO as delivered -> int32 CSR, all adjacencies), then for each
+    of the 4 layers everything CochainMessagePassing.propagate does for the 3 cochain dimensions
+    (12 propagate calls in the reference): the message function (coboundary Linear + ReLU), the
+    gathers incl. the up_attr gather of data/complex.py:579-580, the scatter-adds, the zero fills,
+    plus the GIN self terms that are fused into the same kernel.
+Unit: cell-updates/s = sum_d N_d x layers x steps / wall time, summed over ranks
+(weak scaling: every rank owns its own batches, no data-path collective).
+The JSON line also carries `roofline` (dominant kernel = aggregate_kernel), `cpu_baseline`
+(oracle timed on the host cores, rank 0, N=1 only) and `secondary` (full model forward).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 measured-achievable
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=200)
+    p.add_argument('--warmup', type=int, default=20)
+    p.add_argument('--batch', type=int, default=128, help='complexes per GPU per step')
+    p.add_argument('--hidden', type=int, default=128)
+    p.add_argument('--layers', type=int, default=4)
+    p.add_argument('--num-batches', type=int, default=4, help='distinct synthetic batches cycled')
+    p.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
+    p.add_argument('--no-cpu', action='store_true')
+    p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    p.add_argument('--kernel-reps', type=int, default=200)
+    return p.parse_args()
+
+
+def layer_algorithmic_bytes(stats, F, coboundary=True):
+    """SURVEY.md §8d, per conv layer (all three propagate calls): int64 indices as delivered,
+    gather-counted fp32 rows, two output streams per dimension."""
+    total = 0
+    for d in range(3):
+        e_up, b, n = stats[f'E_up{d}'], stats[f'B{d}'], stats[f'N{d}']
+        total += e_up * (16 + 4 * F) + b * (16 + 4 * F) + 4 * F * n * 2
+        if coboundary:
+            total += e_up * (8 + 4 * F)
+    return total
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    else:
+        dist = None
+
+    from cwn_amd import _ffi, csr, ops
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import batch_stats, zinc_like_batch
+    _ffi.lib()
+
+    H, L = args.hidden, args.layers
+    torch.manual_seed(0)
+    model = EmbedSparseCIN(28, 4, 1, L, H, dropout_rate=0.0, max_dim=2, jump_mode=None,
+                           nonlinearity='relu', readout='sum', train_eps=False,
+                           final_hidden_multiplier=2, final_readout='sum', init_reduce='sum',
+                           embed_edge=True, use_coboundaries=True, graph_norm='bn').to(dev).eval()
+
+    # ---- synthetic batches, resident in HBM ---------------------------------------------------
+    cpu_batches = [zinc_like_batch(args.batch, seed=1000 * rank + i, max_ring=6)
+                   for i in range(args.num_batches)]
+    stats = [batch_stats(b) for b in cpu_batches]
+    types = [(b.cochains[0].x.clone(), b.cochains[1].x.clone()) for b in cpu_batches]
+    batches = [b.to(dev) for b in cpu_batches]
+
+    vt_dev = [vt.to(dev) for vt, _ in types]
+    et_dev = [et.to(dev) for _, et in types]
+
+    def reset_inputs(bi):
+        """model(b) overwrites the container's features; put the integer atom / bond types back."""
+        b = batches[bi]
+        b.cochains[0]._x, b.cochains[1]._x, b.cochains[2]._x = vt_dev[bi], et_dev[bi], None
+        return b
+
+    # per-layer input features of every batch (one full forward each), so the timed region can run
+    # the propagate scope of every layer on the features that layer really sees
+    layer_inputs = []
+    with torch.no_grad():
+        for bi in range(len(batches)):
+            b = reset_inputs(bi)
+            params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+            x0 = [x.contiguous() for x in model.init_conv(*params)]
+            _, res = model(reset_inputs(bi), include_partial=True)
+            layer_inputs.append([x0] + [[res[f'layer{l - 1}_{d}'].contiguous() for d in range(3)]
+                                        for l in range(1, L)])
+    torch.cuda.synchronize()
+
+    def propagate_scope(bi):
+        """One step: fresh plans for the batch, then the propagate scope of every layer."""
+        b, feats = batches[bi], layer_inputs[bi]
+        csr._cache.clear()
+        b.prepare(max_dim=2)
+        outs = None
+        for l, conv in enumerate(model.convs):
+            b.set_xs(feats[l])
+            params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+            streams = [st for d in range(3) for st in conv.mp_levels[d].streams(params[d])]
+            outs = ops.aggregate_many(streams)
+        return outs
+
+    def full_forward(bi):
+        return model(reset_inputs(bi))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup, use_graph):
+        """W warm-up steps, then exactly K timed steps; returns seconds (max over ranks)."""
+        nb = len(batches)
+        graphs = None
+        with torch.no_grad():
+            if use_graph:
+                # one hipGraph per distinct batch: the step's launches are captured from the very
+                # same C-ABI calls (stream capture), replay removes the Python/launch overhead
+                graphs = []
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for bi in range(nb):
+                        fn(bi)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                for bi in range(nb):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        keep = fn(bi)
+                    graphs.append((g, keep))
+            run = (lambda i: graphs[i % nb][0].replay()) if use_graph else (lambda i: fn(i % nb))
+            for i in range(warmup):
+                run(i)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                run(i)
+            barrier()
+            dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    use_graph = not args.no_graph
+    try:
+        dt = timed(propagate_scope, args.steps, args.warmup, use_graph)
+    except Exception as e:   # capture restrictions differ between ROCm builds: say so, run eager
+        if not use_graph:
+            raise
+        print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager', file=sys.stderr)
+        use_graph = False
+        torch.cuda.synchronize()
+        dt = timed(propagate_scope, args.steps, args.warmup, False)
+
+    cells_per_step_local = sum(stats[i % len(stats)]['cells'] for i in range(args.steps)) * L / args.steps
+    cells_total = torch.tensor([cells_per_step_local * args.steps], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(cells_total)
+    value = float(cells_total.item()) / dt
+
+    # secondary: the full model forward (embedding, 4 conv layers incl. MLPs/BN, readout, head)
+    try:
+        dt_full = timed(full_forward, max(args.steps // 4, 10), max(args.warmup // 4, 3), use_graph)
+    except Exception as e:
+        print(f'[bench] full-forward graph capture failed ({type(e).__name__}); eager', file=sys.stderr)
+        torch.cuda.synchronize()
+        dt_full = timed(full_forward, max(args.steps // 4, 10), max(args.warmup // 4, 3), False)
+    full_steps = max(args.steps // 4, 10)
+    full_cells = torch.tensor([sum(stats[i % len(stats)]['cells'] for i in range(full_steps)) * L],
+                              device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(full_cells)
+
+    # ---- roofline of the dominant kernel (aggregate_kernel: one launch per layer) ----------------
+    roofline = None
+    if rank == 0:
+        b, feats = batches[0], layer_inputs[0]
+        with torch.no_grad():
+            csr._cache.clear()
+            b.prepare(max_dim=2)
+            b.set_xs(feats[1])
+            params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+            streams = [st for d in range(3) for st in model.convs[1].mp_levels[d].streams(params[d])]
+            for st in streams:
+                st.validate()
+            specs = []
+            for st in streams:
+                s = ops.AggSpec(adj=st.adj, n_dst=st.n_dst, F=st.width, msg_op=st.msg_op,
+                                reduce=_ffi.REDUCE[st.reduce], self_x=st.self_x, eps=st.eps)
+                if st.adj is not None:
+                    s.A, s.ia = st.A, st.adj.col
+                    if st.msg_op != ops.MSG_A:
+                        s.B, s.ib = st.B, st.adj.aux
+                specs.append(s)
+            ops.run_aggregate(specs, dev)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = args.kernel_reps
+            e0.record()
+            for _ in range(reps):
+                ops.run_aggregate(specs, dev)
+            e1.record()
+            torch.cuda.synchronize()
+            k_us = e0.elapsed_time(e1) * 1e3 / reps
+        alg = layer_algorithmic_bytes(stats[0], H, coboundary=True)
+        achieved = alg / (k_us * 1e-6) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel<4>', 'achieved': round(achieved, 1),
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                    'traffic': None, 'algorithmic_bytes_per_launch': alg,
+                    'avg_launch_us': round(k_us, 3),
+                    'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4),
+                    'note': 'avg over back-to-back launches between two HIP events on the launch '
+                            'stream (includes inter-kernel gaps); batch fits L2/MALL'}
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample -----------------------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import cwn_oracle as O
+        b = cpu_batches[0]
+        feats = [[x.cpu() for x in f] for f in layer_inputs[0]]
+        state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ocx = {'dimension': 2, 'y': None, 'cochains': [
+            {k: b.cochains[d][k] for k in ('x', 'upper_index', 'lower_index', 'shared_boundaries',
+                                           'shared_coboundaries', 'boundary_index', 'y', 'batch')}
+            for d in range(3)]}
+
+        def cpu_step():
+            for l in range(L):
+                for d in range(3):
+                    ocx['cochains'][d]['x'] = feats[l][d]
+                pre = f'convs.{l}.mp_levels.'
+                for d, prm in enumerate(O.all_cochain_params(ocx, 2, include_down_features=False)):
+                    W, bias = state[f'{pre}{d}.msg_up_nn.1.weight'], state[f'{pre}{d}.msg_up_nn.1.bias']
+                    O.propagate(prm['x'], prm['up_index'], None, prm['boundary_index'],
+                                up_attr=prm['up_attr'], boundary_attr=prm['boundary_attr'],
+                                message_up=lambda xj, a: torch.relu(torch.cat([xj, a], -1) @ W.t() + bias),
+                                use_down_msg=False, up_msg_size=H, down_msg_size=H, boundary_msg_size=H)
+        threads = torch.get_num_threads()
+        with torch.no_grad():
+            for _ in range(3):
+                cpu_step()
+            n, t0 = 0, time.perf_counter()
+            while True:
+                cpu_step()
+                n += 1
+                el = time.perf_counter() - t0
+                if el > args.cpu_seconds or n >= 2000:
+                    break
+        cpu_value = stats[0]['cells'] * L * n / el
+        cpu_baseline = {'value': round(cpu_value, 1), 'unit': 'cells/s', 'cores': threads,
+                        'kind': 'port',
+                        'sample': f'{n} passes of the same propagate scope (12 propagate calls incl. '
+                                  f'up_attr gathers) over batch 0 in {el:.1f} s, torch {torch.__version__} '
+                                  f'CPU, {threads} threads of {os.cpu_count()} logical cores',
+                        'gpu_over_cpu': round(value / cpu_value, 1)}
+
+    if rank == 0:
+        s0 = stats[0]
+        out = {
+            'metric': 'cells/sec, propagate scope, ZINC-like ring-lifted batch (max_ring 6)',
+            'value': round(value, 1), 'unit': 'cells/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 5),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'ZINC-like ring-lift (max_ring=6), {L}-layer SparseCIN propagate '
+                                   f'scope (hidden {H}, coboundary messages), batch {args.batch} per GPU',
+                       'batch_per_gpu': args.batch, 'hidden': H, 'layers': L,
+                       'cells_per_batch': s0['cells'], 'N': [s0['N0'], s0['N1'], s0['N2']],
+                       'E_up': [s0['E_up0'], s0['E_up1'], s0['E_up2']],
+                       'B': [s0['B0'], s0['B1'], s0['B2']],
+                       'launch': 'hipGraph replay' if use_graph else 'eager',
+                       'plan_build_in_step': True, 'parallelism': f'replicas x{world} (no data-path collective)'},
+            'roofline': roofline, 'cpu_baseline': cpu_baseline,
+            'secondary': {'full_forward_cells_per_s': round(float(full_cells.item()) / dt_full, 1),
+                          'full_forward_ms': round(dt_full / full_steps * 1e3, 5),
+                          'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '
+                                   'MLPs + BatchNorm(eval), readout, head'},
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

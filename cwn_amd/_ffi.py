@@ -1,0 +1,111 @@
+"""ctypes binding of libcwn_hip.so (C ABI in include/cwn_hip.h).
+
+PyTorch is only the plumbing here: tensors give device pointers (`data_ptr()`), the caching
+allocator gives buffers, `torch.cuda.current_stream()` gives the hipStream_t.  No torch type
+crosses the boundary.  Loading fails loudly: there is NO CPU fallback for the product path.
+"""
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcwn_hip.so')
+
+MAX_DESCS = 8
+MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
+REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
+ABI_VERSION = 1
+
+EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32')
+
+
+class CsrDesc(C.Structure):
+    _fields_ = [('key', C.c_void_p), ('val', C.c_void_p), ('aux', C.c_void_p),
+                ('n_entries', C.c_int64), ('n_dst', C.c_int64), ('n_val', C.c_int64),
+                ('n_aux', C.c_int64), ('rowptr', C.c_void_p), ('col', C.c_void_p),
+                ('perm', C.c_void_p), ('aux_out', C.c_void_p)]
+
+
+class AggDesc(C.Structure):
+    _fields_ = [('rowptr', C.c_void_p), ('ia', C.c_void_p), ('ib', C.c_void_p),
+                ('A', C.c_void_p), ('B', C.c_void_p), ('self_x', C.c_void_p),
+                ('eps', C.c_void_p), ('self_pre', C.c_void_p), ('out', C.c_void_p),
+                ('n_dst', C.c_int64), ('F', C.c_int32), ('b_width', C.c_int32),
+                ('msg_op', C.c_int32), ('reduce', C.c_int32)]
+
+
+class CwnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built (run `python -c "import
+    __graft_entry__ as g; g.build()"` or `make -C cwn_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CwnError(f'{LIB_PATH} is missing: the HIP extension has not been built. '
+                       'There is no CPU fallback; build it with `make -C cwn_amd/csrc`.')
+    L = C.CDLL(LIB_PATH)
+    L.cwn_abi_version.restype = C.c_int
+    L.cwn_error_string.restype = C.c_char_p
+    L.cwn_error_string.argtypes = [C.c_int]
+    L.cwn_target_arch.restype = C.c_char_p
+    L.cwn_csr_workspace_bytes.restype = C.c_size_t
+    L.cwn_csr_workspace_bytes.argtypes = [C.POINTER(CsrDesc), C.c_int]
+    L.cwn_csr_build.restype = C.c_int
+    L.cwn_csr_build.argtypes = [C.POINTER(CsrDesc), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                C.c_void_p]
+    L.cwn_gather_rows_f32.restype = C.c_int
+    L.cwn_gather_rows_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p]
+    L.cwn_aggregate_f32.restype = C.c_int
+    L.cwn_aggregate_f32.argtypes = [C.POINTER(AggDesc), C.c_int, C.c_void_p]
+    if L.cwn_abi_version() != ABI_VERSION:
+        raise CwnError(f'ABI mismatch: library {L.cwn_abi_version()} vs binding {ABI_VERSION}')
+    _lib = L
+    return L
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise CwnError(f'{what}: {lib().cwn_error_string(code).decode()} (code {code})')
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise CwnError(f'{name} is on {t.device}: cwn_amd runs on the GPU only (no CPU fallback). '
+                       'Use oracle/ for CPU checks.')
+
+
+def aggregate(descs: Sequence[AggDesc], device) -> None:
+    """One kernel launch for up to MAX_DESCS descriptors; more are split into several calls."""
+    L = lib()
+    s = stream_ptr(device)
+    for i in range(0, len(descs), MAX_DESCS):
+        chunk = descs[i:i + MAX_DESCS]
+        arr = (AggDesc * len(chunk))(*chunk)
+        check(L.cwn_aggregate_f32(arr, len(chunk), s), 'cwn_aggregate_f32')
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(idx.numel(), src.size(1), dtype=torch.float32, device=src.device)
+    check(lib().cwn_gather_rows_f32(src.data_ptr(), src.size(0), src.size(1), idx.data_ptr(),
+                                    idx.numel(), out.data_ptr(), stream_ptr(src.device)),
+          'cwn_gather_rows_f32')
+    return out

@@ -1,0 +1,163 @@
+"""Adjacency plans: the per-batch int32 CSR structures every aggregation kernel reads.
+
+A COO index of the reference (`upper_index`, `lower_index`, `boundary_index`: int64 `[2, E]`,
+row 0 = source cell j, row 1 = destination cell i under flow source_to_target,
+mp/cell_mp.py:210) is converted ONCE per batch into a destination-sorted CSR
+(`rowptr`, `col`, `perm` [, `aux`]) by the HIP kernels of csrc/cwn_csr.hip and then reused by all
+layers and by the backward pass (which needs the transposed structures, built lazily and in one
+batched call as well).
+"""
+import weakref
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _ffi
+
+VALIDATE_INDICES = True   # one host sync per batched build; turned off inside stream capture
+
+
+class Adjacency:
+    """Destination-sorted CSR of one COO index.
+
+    rowptr[i]:rowptr[i+1]  CSR positions whose destination is i (stable in entry order)
+    col[p]                 source row of position p            (= index[0][perm[p]])
+    perm[p]                original entry id of position p
+    aux[p]                 second gather index of position p   (= aux_index[perm[p]]), optional
+    """
+
+    def __init__(self, key: torch.Tensor, val: torch.Tensor, n_dst: int, n_val: int,
+                 aux_index: Optional[torch.Tensor] = None, n_aux: int = 0):
+        _ffi.require_gpu(key, 'index')
+        assert key.dtype == torch.long and val.dtype == torch.long
+        assert key.dim() == 1 and val.shape == key.shape
+        self.key, self.val, self.aux_index = key.contiguous(), val.contiguous(), aux_index
+        if aux_index is not None:
+            assert aux_index.dtype == torch.long and aux_index.shape == key.shape
+            self.aux_index = aux_index.contiguous()
+        self.n_entries = int(key.numel())
+        self.n_dst, self.n_val, self.n_aux = int(n_dst), int(n_val), int(n_aux)
+        dev = key.device
+        self.device = dev
+        self.rowptr = torch.empty(self.n_dst + 1, dtype=torch.int32, device=dev)
+        self.col = torch.empty(self.n_entries, dtype=torch.int32, device=dev)
+        self.perm = torch.empty(self.n_entries, dtype=torch.int32, device=dev)
+        self.aux = (torch.empty(self.n_entries, dtype=torch.int32, device=dev)
+                    if aux_index is not None else None)
+        self.built = False
+        self._t_src: Optional['Adjacency'] = None
+        self._t_aux: Optional['Adjacency'] = None
+        self._counts: Optional[torch.Tensor] = None
+
+    # ---- construction ------------------------------------------------------------------
+    @classmethod
+    def from_index(cls, index: torch.Tensor, n_dst: int, n_src: int,
+                   aux_index: Optional[torch.Tensor] = None, n_aux: int = 0,
+                   build: bool = True) -> 'Adjacency':
+        """`index` is a reference-style `[2, E]` LongTensor (mp/cell_mp.py:158-160)."""
+        # NB: no strong reference to `index` itself is kept (only row views), so the plan cache's
+        # weakref on the caller's tensor can evict the plan when the batch dies
+        adj = cls(index[1], index[0], n_dst, n_src, aux_index, n_aux)
+        if build:
+            build_many([adj])
+        return adj
+
+    def _desc(self) -> _ffi.CsrDesc:
+        return _ffi.CsrDesc(
+            key=self.key.data_ptr(), val=self.val.data_ptr(), aux=_ffi.ptr(self.aux_index),
+            n_entries=self.n_entries, n_dst=self.n_dst, n_val=self.n_val, n_aux=self.n_aux,
+            rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(), perm=self.perm.data_ptr(),
+            aux_out=_ffi.ptr(self.aux))
+
+    # ---- transposes for the backward pass ----------------------------------------------
+    def transposes(self) -> List['Adjacency']:
+        """The not-yet-built transposed structures this adjacency's backward needs."""
+        todo = []
+        if self._t_src is None:
+            # keyed on the SOURCE cell: col = destination, aux = aux of the same entry
+            self._t_src = Adjacency(self.val, self.key, self.n_val, self.n_dst, self.aux_index,
+                                    self.n_aux)
+            todo.append(self._t_src)
+        if self.aux_index is not None and self._t_aux is None:
+            # keyed on the AUX cell (shared coboundary / boundary): col = destination, aux = source
+            self._t_aux = Adjacency(self.aux_index, self.key, self.n_aux, self.n_dst, self.val,
+                                    self.n_val)
+            todo.append(self._t_aux)
+        return todo
+
+    def _ensure_transposes(self) -> None:
+        self.transposes()
+        build_many([a for a in (self._t_src, self._t_aux) if a is not None])
+
+    @property
+    def t_src(self) -> 'Adjacency':
+        if self._t_src is None or not self._t_src.built:
+            self._ensure_transposes()
+        return self._t_src
+
+    @property
+    def t_aux(self) -> 'Adjacency':
+        assert self.aux_index is not None
+        if self._t_aux is None or not self._t_aux.built:
+            self._ensure_transposes()
+        return self._t_aux
+
+    @property
+    def counts(self) -> torch.Tensor:
+        """Entries per destination row, float32 [n_dst, 1], clamped to >= 1 (mean reduce)."""
+        if self._counts is None:
+            self._counts = (self.rowptr[1:] - self.rowptr[:-1]).clamp(min=1).to(torch.float32).unsqueeze(1)
+        return self._counts
+
+
+def build_many(adjs: Sequence[Adjacency]) -> None:
+    """Build any number of adjacencies with batched C-ABI calls (<= MAX_DESCS per call; each call is
+    one fixed sequence of 5-7 launches whatever the number of index tensors)."""
+    adjs = [a for a in adjs if not a.built]
+    if not adjs:
+        return
+    L = _ffi.lib()
+    dev = adjs[0].device
+    capturing = torch.cuda.is_current_stream_capturing()
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    for i in range(0, len(adjs), _ffi.MAX_DESCS):
+        chunk = adjs[i:i + _ffi.MAX_DESCS]
+        arr = (_ffi.CsrDesc * len(chunk))(*[a._desc() for a in chunk])
+        nbytes = L.cwn_csr_workspace_bytes(arr, len(chunk))
+        ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+        _ffi.check(L.cwn_csr_build(arr, len(chunk), ws.data_ptr(), nbytes, err.data_ptr(),
+                                   _ffi.stream_ptr(dev)), 'cwn_csr_build')
+        for a in chunk:
+            a.built = True
+    if VALIDATE_INDICES and not capturing:
+        flag = int(err.item())
+        if flag:
+            what = [n for b, n in ((1, 'destination index'), (2, 'source index'),
+                                   (4, 'shared (co)boundary index')) if flag & b]
+            raise IndexError('index out of range in adjacency: ' + ', '.join(what))
+
+
+# ---- cache keyed on the identity of the reference-style index tensor ---------------------------
+_cache = {}
+
+
+def cached_adjacency(index: torch.Tensor, n_dst: int, n_src: int,
+                     aux_index: Optional[torch.Tensor] = None, n_aux: int = 0,
+                     build: bool = True) -> Adjacency:
+    """propagate() is called with the same index tensors by every layer (mp/molec_models.py:110);
+    convert each one once.  Keyed on tensor identity + version counter, evicted when the tensor
+    dies.  A plan that carries a shared-cell (aux) index also serves requests without one."""
+    key = id(index)
+    hit = _cache.get(key)
+    ver = (index._version, n_dst, n_src)
+    if hit is not None and hit[0] == ver and hit[1]() is index:
+        adj = hit[2]
+        if aux_index is None or (adj.aux_index is not None and adj.n_aux == n_aux and
+                                 (adj.aux_index is aux_index or
+                                  adj.aux_index.data_ptr() == aux_index.data_ptr())):
+            if build and not adj.built:
+                build_many([adj])
+            return adj
+    adj = Adjacency.from_index(index, n_dst, n_src, aux_index, n_aux, build=build)
+    _cache[key] = (ver, weakref.ref(index, lambda _r, k=key: _cache.pop(k, None)), adj)
+    return adj

@@ -1,0 +1,329 @@
+// cwn_aggregate.hip -- fused gather -> message -> segmented reduce over destination-sorted CSR
+// (K1 + message hook + K2 of SURVEY.md §2.2 in one pass), and the plain row gather (K1).
+//
+// HBM-bound byte work (≈0.25 FLOP/B): no MFMA here.  Mapping for gfx950:
+//   * a GROUP of G lanes (G = power of two, 1..64) owns one destination row; each lane holds a
+//     VEC-wide (16 B when F % 4 == 0) slice of the feature row, so a gathered source row is read
+//     by one fully coalesced wave instruction (G*16 B contiguous) and the output row is written
+//     once, coalesced.  F = 128 -> G = 32: two rows per wavefront; F = 64 -> four rows; F <= 4 ->
+//     one lane per row.
+//   * the segment's indices are fetched by the group cooperatively (one coalesced load of up to
+//     G indices) and broadcast with ds_bpermute (__shfl), so the dependent chain is
+//     index-load -> row-load instead of one round trip per entry; row loads are issued four at a
+//     time before the first add.
+//   * accumulation is sequential in CSR (= original entry) order in registers: deterministic and
+//     bit-identical to a sequential index_add_; no atomics, no zero-fill pass, absent
+//     adjacencies and empty rows write zeros directly.
+//   * one launch covers up to CWN_MAX_DESCS descriptors (all adjacencies of all dimensions of a
+//     layer): blockIdx -> (descriptor, row tile) through a small prefix table in kernel args.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "../../include/cwn_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct AggBatch {
+    cwn_agg_desc d[CWN_MAX_DESCS];
+    int32_t blk_start[CWN_MAX_DESCS + 1];
+    int32_t group[CWN_MAX_DESCS];  // lanes per destination row
+    int32_t n;
+};
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<2> { using T = float2; };
+template <> struct Vec<1> { using T = float; };
+
+template <int VEC> struct Acc { float v[VEC]; };
+
+template <int VEC>
+__device__ __forceinline__ Acc<VEC> ld(const float* p) {
+    Acc<VEC> a;
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        a.v[0] = t.x; a.v[1] = t.y; a.v[2] = t.z; a.v[3] = t.w;
+    } else if constexpr (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        a.v[0] = t.x; a.v[1] = t.y;
+    } else {
+        a.v[0] = *p;
+    }
+    return a;
+}
+
+template <int VEC>
+__device__ __forceinline__ void st(float* p, const Acc<VEC>& a) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(a.v[0], a.v[1]);
+    } else {
+        *p = a.v[0];
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ Acc<VEC> splat(float x) {
+    Acc<VEC> a;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) a.v[k] = x;
+    return a;
+}
+
+// message for one CSR position; `pre` is self_pre[i, f..] (mask form only)
+template <int VEC, int OP>
+__device__ __forceinline__ Acc<VEC> message(const Acc<VEC>& a, const Acc<VEC>& b, const Acc<VEC>& pre) {
+    Acc<VEC> m;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        if constexpr (OP == CWN_MSG_A) m.v[k] = a.v[k];
+        else if constexpr (OP == CWN_MSG_A_PLUS_B) m.v[k] = a.v[k] + b.v[k];
+        else if constexpr (OP == CWN_MSG_A_TIMES_B) m.v[k] = a.v[k] * b.v[k];
+        else if constexpr (OP == CWN_MSG_RELU_A_PLUS_B) m.v[k] = fmaxf(a.v[k] + b.v[k], 0.0f);
+        else m.v[k] = (pre.v[k] + b.v[k] > 0.0f) ? a.v[k] : 0.0f;
+    }
+    return m;
+}
+
+template <int VEC, int RED>
+__device__ __forceinline__ void combine(Acc<VEC>& acc, const Acc<VEC>& m) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        if constexpr (RED == CWN_REDUCE_MAX) acc.v[k] = fmaxf(acc.v[k], m.v[k]);
+        else acc.v[k] = acc.v[k] + m.v[k];
+    }
+}
+
+// One group (G lanes, lane-in-group `gl`) reduces destination row `row` of descriptor D.
+// Every lane of the group runs every loop with the same trip counts (the index fetch and the
+// shuffles need all G lanes); lanes whose feature slice starts past F only skip the loads/stores.
+template <int VEC, int OP, int RED>
+__device__ __forceinline__ void reduce_row(const cwn_agg_desc& D, int64_t row, int G, int gl,
+                                           float self_scale) {
+    constexpr bool kUsesB = (OP != CWN_MSG_A);
+    const int F = D.F;
+    const bool b_scalar = kUsesB && D.b_width == 1;
+    int start = 0, end = 0;
+    if (D.rowptr != nullptr) {
+        start = D.rowptr[row];
+        end = D.rowptr[row + 1];
+    }
+    // feature chunks of G*VEC columns (one chunk when F <= G*VEC, the common case)
+    for (int f0 = 0; f0 < F; f0 += G * VEC) {
+        const int f = f0 + gl * VEC;
+        const bool active = f < F;
+        Acc<VEC> acc = splat<VEC>(RED == CWN_REDUCE_MAX ? -FLT_MAX : 0.0f);
+        Acc<VEC> pre = splat<VEC>(0.0f);
+        if constexpr (OP == CWN_MSG_A_MASK_RELU) {
+            if (active) pre = ld<VEC>(D.self_pre + row * F + f);
+        }
+        for (int base = start; base < end; base += G) {
+            // cooperative index fetch: lane gl holds the indices of CSR position base+gl
+            const int mine = base + gl;
+            int my_ia = 0, my_ib = 0;
+            if (mine < end) {
+                my_ia = D.ia[mine];
+                if constexpr (kUsesB) my_ib = D.ib[mine];
+            }
+            const int cnt = min(G, end - base);
+            int t = 0;
+            for (; t + 4 <= cnt; t += 4) {
+                Acc<VEC> a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ia = __shfl(my_ia, t + u, G);
+                    int ib = 0;
+                    if constexpr (kUsesB) ib = __shfl(my_ib, t + u, G);
+                    a[u] = splat<VEC>(0.0f);
+                    b[u] = splat<VEC>(0.0f);
+                    if (active) {
+                        a[u] = ld<VEC>(D.A + (int64_t)ia * F + f);
+                        if constexpr (kUsesB)
+                            b[u] = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) combine<VEC, RED>(acc, message<VEC, OP>(a[u], b[u], pre));
+            }
+            for (; t < cnt; ++t) {
+                const int ia = __shfl(my_ia, t, G);
+                int ib = 0;
+                if constexpr (kUsesB) ib = __shfl(my_ib, t, G);
+                Acc<VEC> a = splat<VEC>(0.0f), b = splat<VEC>(0.0f);
+                if (active) {
+                    a = ld<VEC>(D.A + (int64_t)ia * F + f);
+                    if constexpr (kUsesB)
+                        b = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
+                }
+                combine<VEC, RED>(acc, message<VEC, OP>(a, b, pre));
+            }
+        }
+        if constexpr (RED == CWN_REDUCE_MEAN) {
+            const float cntf = (float)max(end - start, 1);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] / cntf;
+        }
+        if constexpr (RED == CWN_REDUCE_MAX) {
+            if (end == start) acc = splat<VEC>(0.0f);
+        }
+        if (active) {
+            if (D.self_x != nullptr) {
+                const Acc<VEC> s = ld<VEC>(D.self_x + row * F + f);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] + self_scale * s.v[k];
+            }
+            st<VEC>(D.out + row * F + f, acc);
+        }
+    }
+}
+
+template <int VEC, int OP>
+__device__ __forceinline__ void reduce_row_red(const cwn_agg_desc& D, int64_t row, int G, int gl,
+                                               float self_scale) {
+    switch (D.reduce) {
+        case CWN_REDUCE_MEAN: reduce_row<VEC, OP, CWN_REDUCE_MEAN>(D, row, G, gl, self_scale); break;
+        case CWN_REDUCE_MAX: reduce_row<VEC, OP, CWN_REDUCE_MAX>(D, row, G, gl, self_scale); break;
+        default: reduce_row<VEC, OP, CWN_REDUCE_ADD>(D, row, G, gl, self_scale); break;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void aggregate_kernel(AggBatch B) {
+    int di = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+        if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
+    const cwn_agg_desc& D = B.d[di];
+    const int G = B.group[di];
+    const int rows_per_block = kThreads / G;
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t row = (int64_t)(blockIdx.x - B.blk_start[di]) * rows_per_block + threadIdx.x / G;
+    if (row >= D.n_dst) return;  // whole groups exit together (G divides 64)
+    const float self_scale = 1.0f + (D.eps != nullptr ? *D.eps : 0.0f);
+    switch (D.msg_op) {
+        case CWN_MSG_A_PLUS_B: reduce_row_red<VEC, CWN_MSG_A_PLUS_B>(D, row, G, gl, self_scale); break;
+        case CWN_MSG_A_TIMES_B: reduce_row_red<VEC, CWN_MSG_A_TIMES_B>(D, row, G, gl, self_scale); break;
+        case CWN_MSG_RELU_A_PLUS_B:
+            reduce_row<VEC, CWN_MSG_RELU_A_PLUS_B, CWN_REDUCE_ADD>(D, row, G, gl, self_scale); break;
+        case CWN_MSG_A_MASK_RELU:
+            reduce_row<VEC, CWN_MSG_A_MASK_RELU, CWN_REDUCE_ADD>(D, row, G, gl, self_scale); break;
+        default: reduce_row_red<VEC, CWN_MSG_A>(D, row, G, gl, self_scale); break;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ src,
+                                                               const int64_t* __restrict__ idx,
+                                                               float* __restrict__ out, int64_t n_idx,
+                                                               int F, int G) {
+    const int rows_per_block = kThreads / G;
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t e = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / G;
+    if (e >= n_idx) return;
+    const int64_t r = idx[e];
+    for (int f = gl * VEC; f < F; f += G * VEC) st<VEC>(out + e * F + f, ld<VEC>(src + r * F + f));
+}
+
+inline int pow2_at_least(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+inline int pick_group(int F, int vec) {
+    int g = pow2_at_least((F + vec - 1) / vec);
+    return g > 64 ? 64 : g;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+inline bool aligned8(const void* p) { return ((uintptr_t)p & 7u) == 0; }
+
+}  // namespace
+
+extern "C" int cwn_aggregate_f32(const cwn_agg_desc* descs, int n, cwn_stream_t stream_) {
+    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return CWN_ERR_BAD_ARG;
+    AggBatch B{};
+    B.n = n;
+    int vec = 4;
+    for (int i = 0; i < n; ++i) {
+        const cwn_agg_desc& D = descs[i];
+        if (D.F <= 0 || D.n_dst < 0 || (D.n_dst > 0 && D.out == nullptr)) return CWN_ERR_BAD_ARG;
+        if (D.msg_op < CWN_MSG_A || D.msg_op > CWN_MSG_A_MASK_RELU) return CWN_ERR_BAD_ARG;
+        if (D.reduce < CWN_REDUCE_ADD || D.reduce > CWN_REDUCE_MAX) return CWN_ERR_BAD_ARG;
+        if (D.msg_op >= CWN_MSG_RELU_A_PLUS_B && D.reduce != CWN_REDUCE_ADD) return CWN_ERR_BAD_ARG;
+        if (D.rowptr != nullptr) {
+            if (D.ia == nullptr || D.A == nullptr) return CWN_ERR_BAD_ARG;
+            if (D.msg_op != CWN_MSG_A && (D.ib == nullptr || D.B == nullptr)) return CWN_ERR_BAD_ARG;
+            if (D.msg_op != CWN_MSG_A && D.b_width != D.F && D.b_width != 1) return CWN_ERR_BAD_ARG;
+            if (D.msg_op == CWN_MSG_A_MASK_RELU && D.self_pre == nullptr) return CWN_ERR_BAD_ARG;
+        }
+        if (D.n_dst >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+        // widest vector every pointer and the row stride allow
+        int v = (D.F % 4 == 0) ? 4 : (D.F % 2 == 0 ? 2 : 1);
+        const void* ptrs[] = {D.A, D.b_width == D.F ? (const void*)D.B : nullptr, D.self_x,
+                              D.self_pre, D.out};
+        for (const void* p : ptrs) {
+            if (p == nullptr) continue;
+            if (((uintptr_t)p & 3u) != 0) return CWN_ERR_ALIGN;
+            if (v == 4 && !aligned16(p)) v = aligned8(p) ? 2 : 1;
+            if (v == 2 && !aligned8(p)) v = 1;
+        }
+        if (v < vec) vec = v;
+    }
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        B.d[i] = descs[i];
+        B.group[i] = pick_group(descs[i].F, vec);
+        const int rows_per_block = kThreads / B.group[i];
+        B.blk_start[i] = (int32_t)blocks;
+        blocks += (descs[i].n_dst + rows_per_block - 1) / rows_per_block;
+        if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    }
+    for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
+    if (blocks == 0) return CWN_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((unsigned)blocks), block(kThreads);
+    if (vec == 4) aggregate_kernel<4><<<grid, block, 0, stream>>>(B);
+    else if (vec == 2) aggregate_kernel<2><<<grid, block, 0, stream>>>(B);
+    else aggregate_kernel<1><<<grid, block, 0, stream>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int cwn_gather_rows_f32(const float* src, int64_t n_src, int64_t F, const int64_t* idx,
+                                   int64_t n_idx, float* out, cwn_stream_t stream_) {
+    if (F <= 0 || n_idx < 0 || n_src < 0 || F >= INT32_MAX) return CWN_ERR_BAD_ARG;
+    if (n_idx == 0) return CWN_OK;
+    if (src == nullptr || idx == nullptr || out == nullptr) return CWN_ERR_BAD_ARG;
+    if ((((uintptr_t)src) | ((uintptr_t)out)) & 3u) return CWN_ERR_ALIGN;
+    int vec = (F % 4 == 0) ? 4 : (F % 2 == 0 ? 2 : 1);
+    if (vec == 4 && !(aligned16(src) && aligned16(out))) vec = 2;
+    if (vec == 2 && !(aligned8(src) && aligned8(out))) vec = 1;
+    const int G = pick_group((int)F, vec);
+    const int rows_per_block = kThreads / G;
+    const int64_t blocks = (n_idx + rows_per_block - 1) / rows_per_block;
+    if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((unsigned)blocks), block(kThreads);
+    if (vec == 4) gather_rows_kernel<4><<<grid, block, 0, stream>>>(src, idx, out, n_idx, (int)F, G);
+    else if (vec == 2) gather_rows_kernel<2><<<grid, block, 0, stream>>>(src, idx, out, n_idx, (int)F, G);
+    else gather_rows_kernel<1><<<grid, block, 0, stream>>>(src, idx, out, n_idx, (int)F, G);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int cwn_abi_version(void) { return CWN_ABI_VERSION; }
+
+extern "C" const char* cwn_target_arch(void) { return "gfx950"; }
+
+extern "C" const char* cwn_error_string(int code) {
+    switch (code) {
+        case CWN_OK: return "ok";
+        case CWN_ERR_BAD_ARG: return "bad argument";
+        case CWN_ERR_TOO_LARGE: return "size does not fit int32";
+        case CWN_ERR_WORKSPACE: return "workspace too small";
+        case CWN_ERR_LAUNCH: return "kernel launch failed";
+        case CWN_ERR_ALIGN: return "pointer not 4-byte aligned";
+        default: return "unknown error";
+    }
+}

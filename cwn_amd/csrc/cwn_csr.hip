@@ -1,0 +1,283 @@
+// cwn_csr.hip -- COO (int64, as delivered) -> destination-sorted int32 CSR, gfx950.
+//
+// One fixed launch sequence builds up to CWN_MAX_DESCS structures at once (all adjacencies of a
+// batched complex), so the cost per batch is 5-7 launches regardless of how many index tensors
+// there are:
+//   1. hipMemsetAsync          zero the per-destination counters of every descriptor
+//   2. count_kernel            cnt[key[e]]++ (returned value = arrival slot inside the row)
+//   3. scan (1 or 3 kernels)   rowptr = exclusive scan of cnt
+//   4. place_kernel            tmp[rowptr[key] + slot] = e           (row-grouped, unordered)
+//   5. emit_kernel             rank every entry inside its row by ORIGINAL entry id (counting
+//                              rank, O(sum deg^2) but coalesced/broadcast reads) and write
+//                              perm / col / aux_out in stable order
+// Integer work, HBM/L2-bound; no LDS tiling is needed (rows are short, reads are broadcast).
+#include <hip/hip_runtime.h>
+#include "../../include/cwn_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kScanThreads = 1024;
+constexpr int kScanTile = 4096;        // counts per block in the multi-block scan
+constexpr int64_t kSingleScanMax = 1 << 16;
+
+struct CsrBatch {
+    cwn_csr_desc d[CWN_MAX_DESCS];
+    int32_t* cnt[CWN_MAX_DESCS];        // [n_dst] counters (workspace)
+    int32_t* slot[CWN_MAX_DESCS];       // [E] arrival slot, later reused as tmp (row-grouped ids)
+    int32_t* tmp[CWN_MAX_DESCS];        // [E]
+    int32_t* tile_sums[CWN_MAX_DESCS];  // [tiles] multi-block scan only
+    int64_t blk_start[CWN_MAX_DESCS + 1];  // block prefix for the entry-parallel kernels
+    int64_t tile_start[CWN_MAX_DESCS + 1]; // block prefix for the tile-parallel scan kernels
+    int n;
+};
+
+__device__ __forceinline__ int find_desc(const int64_t* start, int n, int64_t b) {
+    int d = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+        if (i < n && b >= start[i]) d = i;
+    return d;
+}
+
+__global__ __launch_bounds__(kThreads) void count_kernel(CsrBatch B, int32_t* err) {
+    const int di = find_desc(B.blk_start, B.n, blockIdx.x);
+    const cwn_csr_desc& D = B.d[di];
+    const int64_t e = (int64_t)(blockIdx.x - B.blk_start[di]) * kThreads + threadIdx.x;
+    if (e >= D.n_entries) return;
+    const int64_t k = D.key[e];
+    const int64_t v = D.val[e];
+    int bad = 0;
+    if (k < 0 || k >= D.n_dst) bad |= 1;
+    if (v < 0 || v >= D.n_val) bad |= 2;
+    if (D.aux != nullptr) {
+        const int64_t a = D.aux[e];
+        if (a < 0 || a >= D.n_aux) bad |= 4;
+    }
+    if (bad) {
+        atomicOr(err, bad);
+        B.slot[di][e] = -1;
+        return;
+    }
+    B.slot[di][e] = atomicAdd(&B.cnt[di][k], 1);
+}
+
+// ---- exclusive scan, single block per descriptor (n_dst <= kSingleScanMax) -----------------
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* lds /* >= 32 ints */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds[wid] = x;
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    if (wid == 0) {
+        int s = lane < nw ? lds[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            int y = __shfl_up(s, o, 64);
+            if (lane >= o) s += y;
+        }
+        if (lane < nw) lds[16 + lane] = s;  // inclusive wave sums
+    }
+    __syncthreads();
+    const int wave_off = wid == 0 ? 0 : lds[16 + wid - 1];
+    *total = lds[16 + nw - 1];
+    __syncthreads();
+    return wave_off + x - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_single_kernel(CsrBatch B) {
+    __shared__ int lds[32];
+    const int di = blockIdx.x;
+    const cwn_csr_desc& D = B.d[di];
+    const int32_t* cnt = B.cnt[di];
+    int32_t* rowptr = D.rowptr;
+    const int64_t n = D.n_dst;
+    int running = 0;
+    for (int64_t base = 0; base < n; base += kScanThreads) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < n ? cnt[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total, lds);
+        if (i < n) rowptr[i] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) rowptr[n] = running;
+}
+
+// ---- exclusive scan, multi block (tile sums -> scan of sums -> tile scan) ------------------
+__global__ __launch_bounds__(kScanThreads) void tile_sum_kernel(CsrBatch B) {
+    __shared__ int lds[32];
+    const int di = find_desc(B.tile_start, B.n, blockIdx.x);
+    const int64_t tile = blockIdx.x - B.tile_start[di];
+    const int32_t* cnt = B.cnt[di];
+    const int64_t n = B.d[di].n_dst;
+    int v = 0;
+    for (int k = 0; k < kScanTile / kScanThreads; ++k) {
+        const int64_t i = tile * kScanTile + k * kScanThreads + threadIdx.x;
+        if (i < n) v += cnt[i];
+    }
+    int total;
+    block_exclusive_scan(v, &total, lds);
+    if (threadIdx.x == 0) B.tile_sums[di][tile] = total;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_tile_sums_kernel(CsrBatch B) {
+    __shared__ int lds[32];
+    const int di = blockIdx.x;
+    const int64_t tiles = B.tile_start[di + 1] - B.tile_start[di];
+    int32_t* ts = B.tile_sums[di];
+    int running = 0;
+    for (int64_t base = 0; base < tiles; base += kScanThreads) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < tiles ? ts[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total, lds);
+        if (i < tiles) ts[i] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) B.d[di].rowptr[B.d[di].n_dst] = running;
+}
+
+__global__ __launch_bounds__(kScanThreads) void tile_scan_kernel(CsrBatch B) {
+    __shared__ int lds[32];
+    const int di = find_desc(B.tile_start, B.n, blockIdx.x);
+    const int64_t tile = blockIdx.x - B.tile_start[di];
+    const int32_t* cnt = B.cnt[di];
+    int32_t* rowptr = B.d[di].rowptr;
+    const int64_t n = B.d[di].n_dst;
+    int running = B.tile_sums[di][tile];
+    for (int k = 0; k < kScanTile / kScanThreads; ++k) {
+        const int64_t i = tile * kScanTile + k * kScanThreads + threadIdx.x;
+        const int v = i < n ? cnt[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total, lds);
+        if (i < n) rowptr[i] = running + ex;
+        running += total;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void place_kernel(CsrBatch B) {
+    const int di = find_desc(B.blk_start, B.n, blockIdx.x);
+    const cwn_csr_desc& D = B.d[di];
+    const int64_t e = (int64_t)(blockIdx.x - B.blk_start[di]) * kThreads + threadIdx.x;
+    if (e >= D.n_entries) return;
+    const int s = B.slot[di][e];
+    if (s < 0) return;
+    B.tmp[di][D.rowptr[D.key[e]] + s] = (int32_t)e;
+}
+
+__global__ __launch_bounds__(kThreads) void emit_kernel(CsrBatch B) {
+    const int di = find_desc(B.blk_start, B.n, blockIdx.x);
+    const cwn_csr_desc& D = B.d[di];
+    const int64_t p = (int64_t)(blockIdx.x - B.blk_start[di]) * kThreads + threadIdx.x;
+    // valid positions are [0, rowptr[n_dst]); dropped (out-of-range) entries shorten the tail
+    if (p >= D.n_entries || p >= D.rowptr[D.n_dst]) return;
+    const int32_t* tmp = B.tmp[di];
+    const int32_t e = tmp[p];
+    const int64_t r = D.key[e];
+    const int s = D.rowptr[r], t = D.rowptr[r + 1];
+    int rank = 0;
+    for (int q = s; q < t; ++q) rank += (tmp[q] < e) ? 1 : 0;
+    const int P = s + rank;
+    D.perm[P] = e;
+    D.col[P] = (int32_t)D.val[e];
+    if (D.aux_out != nullptr) D.aux_out[P] = (int32_t)D.aux[e];
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct WsLayout {
+    size_t cnt_off[CWN_MAX_DESCS], slot_off[CWN_MAX_DESCS], tmp_off[CWN_MAX_DESCS],
+        tiles_off[CWN_MAX_DESCS];
+    size_t cnt_total;  // the leading region that must be zeroed
+    size_t total;
+};
+
+WsLayout layout(const cwn_csr_desc* d, int n) {
+    WsLayout L{};
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        L.cnt_off[i] = off;
+        off += align_up((size_t)(d[i].n_dst + 1) * 4, 256);
+    }
+    L.cnt_total = off;
+    for (int i = 0; i < n; ++i) {
+        L.slot_off[i] = off;
+        off += align_up((size_t)(d[i].n_entries + 1) * 4, 256);
+        L.tmp_off[i] = off;
+        off += align_up((size_t)(d[i].n_entries + 1) * 4, 256);
+        L.tiles_off[i] = off;
+        off += align_up(((size_t)d[i].n_dst / kScanTile + 2) * 4, 256);
+    }
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t cwn_csr_workspace_bytes(const cwn_csr_desc* descs, int n) {
+    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return 0;
+    return layout(descs, n).total;
+}
+
+extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, size_t ws_bytes,
+                             int32_t* err_flag, cwn_stream_t stream_) {
+    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS || err_flag == nullptr) return CWN_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t max_dst = 0;
+    for (int i = 0; i < n; ++i) {
+        const cwn_csr_desc& D = descs[i];
+        if (D.n_entries < 0 || D.n_dst < 0 || D.rowptr == nullptr) return CWN_ERR_BAD_ARG;
+        if (D.n_entries > 0 && (D.key == nullptr || D.val == nullptr || D.col == nullptr ||
+                                D.perm == nullptr))
+            return CWN_ERR_BAD_ARG;
+        if (D.aux != nullptr && D.aux_out == nullptr) return CWN_ERR_BAD_ARG;
+        if (D.n_entries >= INT32_MAX || D.n_dst >= INT32_MAX || D.n_val >= INT32_MAX ||
+            D.n_aux >= INT32_MAX)
+            return CWN_ERR_TOO_LARGE;
+        if (D.n_dst > max_dst) max_dst = D.n_dst;
+    }
+    const WsLayout L = layout(descs, n);
+    if (workspace == nullptr || ws_bytes < L.total) return CWN_ERR_WORKSPACE;
+
+    CsrBatch B{};
+    B.n = n;
+    char* ws = (char*)workspace;
+    int64_t blocks = 0, tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        B.d[i] = descs[i];
+        B.cnt[i] = (int32_t*)(ws + L.cnt_off[i]);
+        B.slot[i] = (int32_t*)(ws + L.slot_off[i]);
+        B.tmp[i] = (int32_t*)(ws + L.tmp_off[i]);
+        B.tile_sums[i] = (int32_t*)(ws + L.tiles_off[i]);
+        B.blk_start[i] = blocks;
+        B.tile_start[i] = tiles;
+        blocks += (descs[i].n_entries + kThreads - 1) / kThreads;
+        tiles += (descs[i].n_dst + kScanTile - 1) / kScanTile;
+    }
+    for (int i = n; i <= CWN_MAX_DESCS; ++i) {
+        B.blk_start[i] = blocks;
+        B.tile_start[i] = tiles;
+    }
+    if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+
+    if (hipMemsetAsync(ws, 0, L.cnt_total, stream) != hipSuccess) return CWN_ERR_LAUNCH;
+    if (blocks > 0) count_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B, err_flag);
+    if (max_dst <= kSingleScanMax) {
+        scan_single_kernel<<<dim3(n), dim3(kScanThreads), 0, stream>>>(B);
+    } else {
+        tile_sum_kernel<<<dim3((unsigned)tiles), dim3(kScanThreads), 0, stream>>>(B);
+        scan_tile_sums_kernel<<<dim3(n), dim3(kScanThreads), 0, stream>>>(B);
+        tile_scan_kernel<<<dim3((unsigned)tiles), dim3(kScanThreads), 0, stream>>>(B);
+    }
+    if (blocks > 0) {
+        place_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+        emit_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    }
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}

@@ -1,0 +1,177 @@
+"""Callers of the hot path: the molecular SparseCIN model and the mp/nn.py helpers.
+
+`EmbedSparseCIN` mirrors the reference's mp/molec_models.py:12-163 (same constructor arguments,
+parameter names and forward(data, include_partial)) so its state_dict loads unchanged; it exists
+here because BASELINE's configs name it ("ZINC ring-lift, 4-layer SparseCIN") and the parity tests
+pin the whole stack against golden vectors of the reference model.  `SparseCIN` mirrors
+mp/models.py:120-260 for non-embedded inputs (REDDIT-like config).  The readout
+(`pool_complex`, mp/nn.py:50-60) runs on the same segmented-reduce kernel as propagate.
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch.nn import BatchNorm1d as BN, Embedding, Identity, LayerNorm as LN, Linear
+
+from . import ops
+from .complex import ComplexBatch
+from .csr import cached_adjacency
+from .layers import EmbedVEWithReduce, InitReduceConv, SparseCINConv
+
+
+def get_nonlinearity(nonlinearity, return_module=True):
+    """mp/nn.py:7-28."""
+    table = {'relu': (torch.nn.ReLU, F.relu), 'elu': (torch.nn.ELU, F.elu),
+             'id': (torch.nn.Identity, lambda x: x), 'sigmoid': (torch.nn.Sigmoid, torch.sigmoid),
+             'tanh': (torch.nn.Tanh, torch.tanh)}
+    if nonlinearity not in table:
+        raise NotImplementedError(f'Nonlinearity {nonlinearity} is not currently supported.')
+    return table[nonlinearity][0 if return_module else 1]
+
+
+def get_graph_norm(norm):
+    """mp/nn.py:39-47."""
+    if norm == 'bn':
+        return BN
+    if norm == 'ln':
+        return LN
+    if norm == 'id':
+        return Identity
+    raise ValueError(f'Graph Normalisation {norm} not currently supported')
+
+
+def global_pool(x: torch.Tensor, batch: torch.Tensor, size: int, mean: bool = False) -> torch.Tensor:
+    """global_add_pool / global_mean_pool (K11) as a segmented reduce keyed on the batch vector."""
+    ids = getattr(batch, '_cwn_ids', None)
+    if ids is None or ids.numel() != batch.numel():
+        ids = torch.arange(batch.numel(), device=batch.device)
+        index = torch.stack([ids, batch])
+        batch._cwn_ids, batch._cwn_index = ids, index
+    adj = cached_adjacency(batch._cwn_index, size, x.size(0))
+    return ops.aggregate(adj, size, x, reduce='mean' if mean else 'add')
+
+
+def pool_complex(xs: List[torch.Tensor], data: ComplexBatch, max_dim: int, readout_type: str):
+    """mp/nn.py:50-60 -> [max_dim+1, num_complexes, H]; rows of absent dimensions stay zero.
+    The batch size comes from the container instead of `batch.max() + 1` (a device sync)."""
+    if readout_type not in ('sum', 'mean'):
+        raise NotImplementedError(f'Readout {readout_type} is not currently supported.')
+    batch_size = data.num_complexes
+    if batch_size is None:
+        batch_size = int(data.cochains[0].batch.max()) + 1
+    pooled = [global_pool(xs[i], data.cochains[i].batch, batch_size, readout_type == 'mean')
+              for i in range(len(xs))]
+    for _ in range(len(xs), max_dim + 1):
+        pooled.append(torch.zeros_like(pooled[0]))
+    return torch.stack(pooled, dim=0)
+
+
+class EmbedSparseCIN(torch.nn.Module):
+    """mp/molec_models.py:12-163 (jump_mode 'cat' / None, readouts sum / mean)."""
+
+    def __init__(self, atom_types, bond_types, out_size, num_layers, hidden,
+                 dropout_rate: float = 0.5, max_dim: int = 2, jump_mode=None, nonlinearity='relu',
+                 readout='sum', train_eps=False, final_hidden_multiplier: int = 2,
+                 readout_dims=(0, 1, 2), final_readout='sum', apply_dropout_before='lin2',
+                 init_reduce='sum', embed_edge=False, embed_dim=None, use_coboundaries=False,
+                 graph_norm='bn'):
+        super().__init__()
+        self.max_dim = max_dim
+        self.readout_dims = (tuple(d for d in readout_dims if d <= max_dim)
+                             if readout_dims is not None else list(range(max_dim + 1)))
+        if embed_dim is None:
+            embed_dim = hidden
+        self.v_embed_init = Embedding(atom_types, embed_dim)
+        self.e_embed_init = Embedding(bond_types, embed_dim) if embed_edge else None
+        self.reduce_init = InitReduceConv(reduce=init_reduce)
+        self.init_conv = EmbedVEWithReduce(self.v_embed_init, self.e_embed_init, self.reduce_init)
+        self.final_readout = final_readout
+        self.dropout_rate = dropout_rate
+        self.apply_dropout_before = apply_dropout_before
+        self.jump_mode = jump_mode
+        if jump_mode not in (None, 'cat'):
+            raise NotImplementedError("jump_mode must be None or 'cat'")
+        self.convs = torch.nn.ModuleList()
+        self.nonlinearity = nonlinearity
+        self.readout = readout
+        self.graph_norm = get_graph_norm(graph_norm)
+        act_module = get_nonlinearity(nonlinearity, return_module=True)
+        for i in range(num_layers):
+            layer_dim = embed_dim if i == 0 else hidden
+            self.convs.append(SparseCINConv(
+                up_msg_size=layer_dim, down_msg_size=layer_dim, boundary_msg_size=layer_dim,
+                passed_msg_boundaries_nn=None, passed_msg_up_nn=None, passed_update_up_nn=None,
+                passed_update_boundaries_nn=None, train_eps=train_eps, max_dim=self.max_dim,
+                hidden=hidden, act_module=act_module, layer_dim=layer_dim,
+                graph_norm=self.graph_norm, use_coboundaries=use_coboundaries))
+        self.lin1s = torch.nn.ModuleList()
+        for _ in range(max_dim + 1):
+            if jump_mode == 'cat':
+                self.lin1s.append(Linear(num_layers * hidden, final_hidden_multiplier * hidden, bias=False))
+            else:
+                self.lin1s.append(Linear(hidden, final_hidden_multiplier * hidden))
+        self.lin2 = Linear(final_hidden_multiplier * hidden, out_size)
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            for lvl in conv.mp_levels:
+                lvl.reset_parameters()
+        self.init_conv.reset_parameters()
+        for lin in self.lin1s:
+            lin.reset_parameters()
+        self.lin2.reset_parameters()
+
+    def forward(self, data: ComplexBatch, include_partial=False):
+        act = get_nonlinearity(self.nonlinearity, return_module=False)
+        res = {}
+        assert data.cochains[0].x.size(-1) == 1
+        if 1 in data.cochains and data.cochains[1].x is not None:
+            assert data.cochains[1].x.size(-1) == 1
+        params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
+        xs = list(self.init_conv(*params))
+        xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
+        data.set_xs(xs)
+        jump_xs = None
+        for c, conv in enumerate(self.convs):
+            params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
+            xs = conv(*params, start_to_process=0)
+            data.set_xs(xs)
+            if include_partial:
+                for k in range(len(xs)):
+                    res[f'layer{c}_{k}'] = xs[k]
+            if self.jump_mode is not None:
+                if jump_xs is None:
+                    jump_xs = [[] for _ in xs]
+                for i, x in enumerate(xs):
+                    jump_xs[i] += [x]
+        if self.jump_mode is not None:
+            xs = [torch.cat(j, dim=-1) for j in jump_xs]
+        pooled = pool_complex(xs, data, self.max_dim, self.readout)
+        xs = [pooled[i] for i in self.readout_dims]
+        if include_partial:
+            for k in range(len(xs)):
+                res[f'pool_{k}'] = xs[k]
+        new_xs = []
+        for i, x in enumerate(xs):
+            if self.apply_dropout_before == 'lin1':
+                x = F.dropout(x, p=self.dropout_rate, training=self.training)
+            new_xs.append(act(self.lin1s[self.readout_dims[i]](x)))
+        x = torch.stack(new_xs, dim=0)
+        if self.apply_dropout_before == 'final_readout':
+            x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        if self.final_readout == 'mean':
+            x = x.mean(0)
+        elif self.final_readout == 'sum':
+            x = x.sum(0)
+        else:
+            raise NotImplementedError
+        if self.apply_dropout_before not in ['lin1', 'final_readout']:
+            x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        x = self.lin2(x)
+        if include_partial:
+            res['out'] = x
+            return x, res
+        return x
+
+    def __repr__(self):
+        return self.__class__.__name__

@@ -1,0 +1,277 @@
+"""Differentiable ops over the C ABI (include/cwn_hip.h).  Forward AND backward run the HIP
+kernels of csrc/cwn_aggregate.hip: the gradient of a gather is a segmented reduce over the
+transposed CSR and vice versa, so both directions are the same kernel on different plans.
+
+`aggregate_many` runs any number of aggregation STREAMS (one stream = one adjacency of one cochain
+dimension) in ONE kernel launch forward and ONE launch backward; `aggregate` is its single-stream
+form.  There is no CPU path here by design; `oracle/` is the CPU checker.
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _ffi
+from .csr import Adjacency
+
+MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
+
+
+def _f32c(t: Optional[Tensor], name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    _ffi.require_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError(f'{name} must be float32 (got {t.dtype}); the engine computes in fp32')
+    return t.contiguous()
+
+
+@dataclass
+class AggSpec:
+    """One descriptor of cwn_aggregate_f32.  `ia`/`ib` are int32 tensors in CSR order."""
+    adj: Optional[Adjacency]
+    n_dst: int
+    F: int
+    A: Optional[Tensor] = None
+    ia: Optional[Tensor] = None
+    B: Optional[Tensor] = None
+    ib: Optional[Tensor] = None
+    msg_op: int = MSG_A
+    reduce: int = 0
+    self_x: Optional[Tensor] = None
+    eps: Optional[Tensor] = None
+    self_pre: Optional[Tensor] = None
+    out: Optional[Tensor] = None
+
+    def desc(self) -> _ffi.AggDesc:
+        absent = self.adj is None
+        bw = self.F if (self.B is None or self.B.size(1) == self.F) else int(self.B.size(1))
+        return _ffi.AggDesc(
+            rowptr=None if absent else self.adj.rowptr.data_ptr(),
+            ia=_ffi.ptr(self.ia), ib=_ffi.ptr(self.ib), A=_ffi.ptr(self.A), B=_ffi.ptr(self.B),
+            self_x=_ffi.ptr(self.self_x), eps=_ffi.ptr(self.eps), self_pre=_ffi.ptr(self.self_pre),
+            out=self.out.data_ptr(), n_dst=self.n_dst, F=self.F, b_width=bw,
+            msg_op=self.msg_op, reduce=self.reduce)
+
+
+def run_aggregate(specs: Sequence[AggSpec], device) -> List[Tensor]:
+    """Raw launch (no autograd): allocates missing outputs, ONE kernel per <= 8 descriptors."""
+    for s in specs:
+        if s.out is None:
+            s.out = torch.empty(s.n_dst, s.F, dtype=torch.float32, device=device)
+    live = [s for s in specs if s.n_dst > 0]
+    if live:
+        _ffi.aggregate([s.desc() for s in live], device)
+    return [s.out for s in specs]
+
+
+@dataclass
+class Stream:
+    """One aggregation stream:  out = reduce_p msg(A[ia[p]], B[ib[p]])  (+ (1 + eps) * self_x).
+
+    adj      destination-sorted CSR, or None for an ABSENT adjacency (out = zeros + self term,
+             CochainMessagePassing.update's zero fill, mp/cell_mp.py:517-522)
+    ia_mode  'col'  A is a cell-feature matrix gathered through the adjacency's source index
+             'perm' A holds one row per entry (output of a Python message hook; K2 alone)
+    ib_mode  'aux'  B is a cell-feature matrix gathered through the adjacency's shared-cell index
+             'perm' B holds one row per entry (e.g. `up_attr` as data/complex.py:579-580
+                    materialises it)
+    """
+    adj: Optional[Adjacency]
+    n_dst: int
+    width: int
+    A: Optional[Tensor] = None
+    B: Optional[Tensor] = None
+    msg_op: int = MSG_A
+    reduce: str = 'add'
+    ia_mode: str = 'col'
+    ib_mode: str = 'aux'
+    self_x: Optional[Tensor] = None
+    eps: Optional[Tensor] = None
+
+    def validate(self):
+        self.A, self.B = _f32c(self.A, 'A'), _f32c(self.B, 'B')
+        self.self_x, self.eps = _f32c(self.self_x, 'self_x'), _f32c(self.eps, 'eps')
+        adj = self.adj
+        if adj is None:
+            self.A = self.B = None
+            return
+        if self.ia_mode == 'col' and self.A.size(0) != adj.n_val:
+            raise ValueError(f'Encountered tensor with size {self.A.size(0)} in dimension -2, '
+                             f'but expected size {adj.n_val}.')
+        if self.ia_mode == 'perm' and self.A.size(0) != adj.n_entries:
+            raise ValueError(f'expected one message row per entry ({adj.n_entries}), '
+                             f'got {self.A.size(0)}')
+        if self.A.size(1) != self.width:
+            raise ValueError(f'message width {self.A.size(1)} != declared width {self.width}')
+        if self.msg_op != MSG_A:
+            if self.ib_mode == 'aux' and adj.aux is None:
+                raise ValueError('adjacency was built without a shared-cell index')
+            want = adj.n_aux if self.ib_mode == 'aux' else adj.n_entries
+            if self.B.size(0) != want:
+                raise ValueError(f'attribute has {self.B.size(0)} rows, expected {want}')
+            if self.B.size(1) not in (self.width, 1):
+                raise ValueError(f'attribute width {self.B.size(1)} must be {self.width} or 1')
+        else:
+            self.B = None
+        if self.self_x is not None and tuple(self.self_x.shape) != (self.n_dst, self.width):
+            raise ValueError('self term must be [n_dst, width]')
+
+
+class _AggregateMany(torch.autograd.Function):
+    """N streams, one launch forward, one launch backward.  Tensor inputs are flattened four per
+    stream: (A, B, self_x, eps)."""
+
+    @staticmethod
+    def forward(ctx, streams: Tuple[Stream, ...], device, *tensors):
+        specs = []
+        for k, st in enumerate(streams):
+            A, B, self_x, eps = tensors[4 * k: 4 * k + 4]
+            s = AggSpec(adj=st.adj, n_dst=st.n_dst, F=st.width, msg_op=st.msg_op,
+                        reduce=_ffi.REDUCE[st.reduce], self_x=self_x, eps=eps)
+            if st.adj is not None:
+                s.A = A
+                s.ia = st.adj.col if st.ia_mode == 'col' else st.adj.perm
+                if st.msg_op != MSG_A:
+                    s.B = B
+                    s.ib = st.adj.aux if st.ib_mode == 'aux' else st.adj.perm
+            specs.append(s)
+        outs = run_aggregate(specs, device)
+        ctx.streams, ctx.device = streams, device
+        ctx.save_for_backward(*tensors)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        tensors = ctx.saved_tensors
+        grads: List[Optional[Tensor]] = [None] * len(tensors)
+        specs, slots = [], []
+        for k, st in enumerate(ctx.streams):
+            g = gs[k]
+            if g is None:
+                continue
+            A, B, self_x, eps = tensors[4 * k: 4 * k + 4]
+            need_A, need_B, need_self, need_eps = ctx.needs_input_grad[2 + 4 * k: 6 + 4 * k]
+            g = g.contiguous()
+            if self_x is not None:
+                if need_self:
+                    grads[4 * k + 2] = g if eps is None else g * (1 + eps)
+                if need_eps and eps is not None:
+                    grads[4 * k + 3] = (g * self_x).sum().reshape(eps.shape)
+            adj, op = st.adj, st.msg_op
+            if adj is None or not (need_A or need_B):
+                continue
+            if st.reduce == 'max':
+                raise NotImplementedError("gradient of reduce='max' is not implemented "
+                                          "(parity unpinned in the reference, SURVEY.md §8c)")
+            if st.reduce == 'mean':
+                g = g / adj.counts
+            F = g.size(1)
+            if need_A:
+                if st.ia_mode == 'perm':   # A holds one row per ENTRY: dA[e] = g[dst[e]]
+                    grads[4 * k] = _ffi.gather_rows(g, adj.key)
+                else:
+                    t = adj.t_src          # rows of A collect from the destinations they fed
+                    s = AggSpec(adj=t, n_dst=t.n_dst, F=F, A=g, ia=t.col)
+                    if op == MSG_A_TIMES_B:
+                        s.msg_op, s.B = MSG_A_TIMES_B, B
+                        s.ib = t.aux if st.ib_mode == 'aux' else t.perm
+                    elif op == MSG_RELU_A_PLUS_B:
+                        s.msg_op, s.B, s.ib, s.self_pre = MSG_A_MASK_RELU, B, t.aux, A
+                    specs.append(s)
+                    slots.append(4 * k)
+            if need_B:
+                if op == MSG_A_TIMES_B:
+                    raise NotImplementedError(
+                        'no gradient for the multiplicative attribute; route it through the '
+                        'generic (hook) path if it is trainable')
+                if st.ib_mode == 'perm':
+                    grads[4 * k + 1] = _ffi.gather_rows(g, adj.key)
+                else:
+                    t = adj.t_aux          # keyed on the aux cell: col = destination, aux = source
+                    s = AggSpec(adj=t, n_dst=t.n_dst, F=F, A=g, ia=t.col)
+                    if op == MSG_RELU_A_PLUS_B:
+                        s.msg_op, s.B, s.ib, s.self_pre = MSG_A_MASK_RELU, A, t.aux, B
+                    specs.append(s)
+                    slots.append(4 * k + 1)
+        if specs:
+            for slot, o in zip(slots, run_aggregate(specs, ctx.device)):
+                grads[slot] = o
+        return (None, None) + tuple(grads)
+
+
+def aggregate_many(streams: Sequence[Stream]) -> List[Tensor]:
+    """All streams in ONE kernel launch (per <= 8), differentiable w.r.t. A, B, self_x and eps."""
+    device = None
+    flat: List[Optional[Tensor]] = []
+    for st in streams:
+        st.validate()
+        for t in (st.A, st.B, st.self_x, st.eps):
+            if t is not None and device is None:
+                device = t.device
+        flat += [st.A, st.B, st.self_x, st.eps]
+    if device is None:
+        raise ValueError('aggregate_many needs at least one tensor to know the device')
+    # backward needs the transposed plans: build all of them with one batched call, now, so the
+    # backward pass launches no index kernels
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in flat):
+        from .csr import build_many
+        todo = []
+        for st in streams:
+            if st.adj is not None and st.ia_mode == 'col':
+                st.adj.transposes()
+                todo += [a for a in (st.adj._t_src, st.adj._t_aux) if a is not None]
+        build_many(todo)
+    return list(_AggregateMany.apply(tuple(streams), device, *flat))
+
+
+def aggregate(adj: Optional[Adjacency], n_dst: int, A: Optional[Tensor], *, msg_op: int = MSG_A,
+              reduce: str = 'add', ia_mode: str = 'col', B: Optional[Tensor] = None,
+              ib_mode: str = 'aux', self_x: Optional[Tensor] = None,
+              eps: Optional[Tensor] = None, width: Optional[int] = None) -> Tensor:
+    """Single-stream form of aggregate_many (see Stream for the argument meaning)."""
+    ref = A if A is not None else self_x
+    if width is None:
+        width = int(ref.size(1))
+    return aggregate_many([Stream(adj=adj, n_dst=int(n_dst), width=int(width), A=A, B=B,
+                                  msg_op=msg_op, reduce=reduce, ia_mode=ia_mode, ib_mode=ib_mode,
+                                  self_x=self_x, eps=eps)])[0]
+
+
+def zeros_rows(n: int, width: int, device) -> Tensor:
+    """K9: the zero fill for an absent adjacency when nothing else is launched."""
+    return torch.zeros(n, width, dtype=torch.float32, device=device)
+
+
+class _GatherRows(torch.autograd.Function):
+    """K1 (mp/cell_mp.py:198): out[e] = src[idx[e]].  Backward: segmented sum over the CSR keyed on
+    idx (`adj_for_idx().perm` lists, per source row, the entries that read it)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, adj_for_idx):
+        ctx.adj_for_idx = adj_for_idx
+        return _ffi.gather_rows(src, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        t = ctx.adj_for_idx()
+        g = g.contiguous()
+        out, = run_aggregate([AggSpec(adj=t, n_dst=t.n_dst, F=g.size(1), A=g, ia=t.perm)], g.device)
+        return out, None, None
+
+
+def gather_rows(src: Tensor, idx: Tensor, adj_for_idx=None) -> Tensor:
+    """Differentiable row gather.  `adj_for_idx` is a zero-argument callable returning an Adjacency
+    keyed on `idx` (only called in backward); when omitted one is built on demand."""
+    src = _f32c(src, 'src')
+    _ffi.require_gpu(idx, 'idx')
+    if idx.dtype != torch.long:
+        raise TypeError('index must be int64')
+    idx = idx.contiguous()
+    if adj_for_idx is None:
+        n_src = src.size(0)
+
+        def adj_for_idx():
+            return Adjacency.from_index(torch.stack([idx, idx]), n_src, n_src)
+    return _GatherRows.apply(src, idx, adj_for_idx)

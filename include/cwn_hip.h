@@ -1,0 +1,155 @@
+/*
+ * cwn_hip.h -- C ABI of libcwn_hip.so, the MI355X (gfx950) cellular message-passing engine.
+ *
+ * The reference (twitter-research/cwn) has no FFI: its hot path is the Python method
+ * CochainMessagePassing.propagate (mp/cell_mp.py:357-392) whose arithmetic is three PyTorch /
+ * torch-scatter call sites.  Each entry point below replaces one of those call sites (cited per
+ * function, paths relative to the reference root); cwn_amd/cell_mp.py binds them through ctypes
+ * behind the reference's propagate(...) signature.  INTEGRATION.md shows the binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - the caller owns every buffer; entry points never allocate, free or synchronise, so they
+ *     are HIP-graph capturable; work is enqueued on `stream` (a hipStream_t, passed as void*);
+ *   - return value: CWN_OK or an error code (cwn_error_string); device-side index errors are
+ *     reported through a caller-provided int32 error word (see cwn_csr_build);
+ *   - features are fp32 row-major [rows, F]; indices arrive as int64 (the reference asserts
+ *     torch.long, mp/cell_mp.py:158) and are narrowed ONCE to int32 CSR by cwn_csr_build.
+ */
+#ifndef CWN_HIP_H
+#define CWN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CWN_ABI_VERSION 1
+
+typedef void* cwn_stream_t; /* hipStream_t */
+
+enum {
+    CWN_OK = 0,
+    CWN_ERR_BAD_ARG = 1,    /* null pointer, negative size, too many descriptors, F <= 0 ...   */
+    CWN_ERR_TOO_LARGE = 2,  /* E or n_dst does not fit int32                                   */
+    CWN_ERR_WORKSPACE = 3,  /* workspace smaller than cwn_csr_workspace_bytes says             */
+    CWN_ERR_LAUNCH = 4,     /* hipGetLastError() != hipSuccess after a launch                  */
+    CWN_ERR_ALIGN = 5       /* a feature pointer is not 4-byte aligned                          */
+};
+
+#define CWN_MAX_DESCS 8 /* descriptors per batched call (one kernel launch covers all of them) */
+
+int cwn_abi_version(void);
+const char* cwn_error_string(int code);
+/* name of the gfx target the library was compiled for, e.g. "gfx950" */
+const char* cwn_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Index preprocessing: COO (as delivered by data/complex.py) -> destination-sorted CSR.
+ *
+ * Replaces nothing arithmetic in the reference; it is the one-time (per batch) conversion that
+ * lets every later aggregation be an atomic-free segmented reduction.  The order inside a
+ * segment is the ORIGINAL entry order (stable), i.e. the order torch's sequential index_add_
+ * (the scatter under mp/cell_mp.py:439) visits them, so sums are reproducible and the integer
+ * outputs are bit-exact against oracle/cwn_oracle.py::csr_from_coo.
+ *
+ *   key[e]  destination cell of entry e   (upper/lower_index[1], boundary_index[1])
+ *   val[e]  source row of entry e         (index[0])              -> col[p]  = val[perm[p]]
+ *   aux[e]  optional second index         (shared_coboundaries /
+ *                                          shared_boundaries)     -> aux_out[p] = aux[perm[p]]
+ *   rowptr[i]..rowptr[i+1]  the entries whose key is i;  perm[p] = original entry id.
+ *
+ * Passing (key=index[0], val=index[1]) yields the transposed structure used by the backward
+ * pass.  Entries with key outside [0,n_dst) or val outside [0,n_val) set *err_flag (bit 0 / bit 1)
+ * and are dropped; the Python layer turns that into the IndexError index_select would raise.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cwn_csr_desc {
+    const int64_t* key;  /* [E] */
+    const int64_t* val;  /* [E] */
+    const int64_t* aux;  /* [E] or NULL */
+    int64_t n_entries;   /* E >= 0 */
+    int64_t n_dst;       /* rows of the CSR (>= 0) */
+    int64_t n_val;       /* bound for val (rows of the gathered matrix) */
+    int64_t n_aux;       /* bound for aux (ignored when aux == NULL) */
+    int32_t* rowptr;     /* [n_dst + 1] out */
+    int32_t* col;        /* [E] out */
+    int32_t* perm;       /* [E] out */
+    int32_t* aux_out;    /* [E] out or NULL */
+} cwn_csr_desc;
+
+/* Bytes of scratch cwn_csr_build needs for these descriptors (host array of n descriptors). */
+size_t cwn_csr_workspace_bytes(const cwn_csr_desc* descs_host, int n);
+
+/* Build up to CWN_MAX_DESCS CSR structures with one fixed sequence of launches.
+ * `descs_host` is a HOST array (copied into kernel arguments).  `err_flag` is a device int32 the
+ * caller zeroed. */
+int cwn_csr_build(const cwn_csr_desc* descs_host, int n, void* workspace, size_t workspace_bytes,
+                  int32_t* err_flag, cwn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1: row gather.  out[e, :] = src[idx[e], :]
+ * Replaces  src.index_select(node_dim, index[dim])   mp/cell_mp.py:198   (and the up_attr /
+ * down_attr gathers of data/complex.py:579-580, 587-588 when a caller wants them materialised).
+ * Used by the generic path (arbitrary Python message hooks).  idx is int64 as delivered.
+ * ------------------------------------------------------------------------------------------ */
+int cwn_gather_rows_f32(const float* src, int64_t n_src, int64_t F, const int64_t* idx,
+                        int64_t n_idx, float* out, cwn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1+message+K2 fused: segmented gather-reduce over a destination-sorted CSR.
+ *
+ * For every destination row i of every descriptor
+ *     out[i,:] = reduce_{p in [rowptr[i], rowptr[i+1])} msg(p)  [+ (1 + *eps) * self[i,:]]
+ * with msg(p) selected by `msg_op`:
+ *     CWN_MSG_A            A[ia[p], :]                       base-class message (identity),
+ *                                                            mp/cell_mp.py:394-421; with ia=perm
+ *                                                            it is the segment-reduce of rows a
+ *                                                            Python hook produced (K2 alone)
+ *     CWN_MSG_A_PLUS_B     A[ia[p], :] + B[ib[p], :]         DummyCochainMessagePassing,
+ *                                                            mp/layers.py:23-31
+ *     CWN_MSG_A_TIMES_B    A[ia[p], :] * B[ib[p], :]         OrientedConv, mp/layers.py:462-470
+ *                                                            (B has width F or width 1)
+ *     CWN_MSG_RELU_A_PLUS_B relu(A[ia[p], :] + B[ib[p], :])  SparseCIN coboundary message
+ *                                                            ReLU(Linear(cat(x_j, up_attr))),
+ *                                                            mp/layers.py:290-293, restructured as
+ *                                                            A = X_d W1^T + b, B = X_{d+1} W2^T
+ *     CWN_MSG_A_MASK_RELU  A[ia[p], :] * step(self_pre[i,:] + B[ib[p], :] > 0)
+ *                                                            backward of the previous form
+ * and `reduce` one of add / mean / max (mp/cell_mp.py:104-105 -> torch_scatter.scatter, :439):
+ * rows with no entry are 0 for every reduce; mean divides by max(count, 1).
+ * A descriptor with rowptr == NULL is an ABSENT adjacency: out = 0 (+ self term), which is
+ * CochainMessagePassing.update's zero fill (mp/cell_mp.py:517-522) without a separate launch.
+ * The optional self term is the GIN-style  out += (1 + eps) * x  of mp/layers.py:191-192 (eps is a
+ * DEVICE scalar because it may be a trainable parameter; NULL means eps = 0).
+ * All descriptors of one call run in ONE kernel launch.
+ * ------------------------------------------------------------------------------------------ */
+enum { CWN_MSG_A = 0, CWN_MSG_A_PLUS_B = 1, CWN_MSG_A_TIMES_B = 2, CWN_MSG_RELU_A_PLUS_B = 3,
+       CWN_MSG_A_MASK_RELU = 4 };
+enum { CWN_REDUCE_ADD = 0, CWN_REDUCE_MEAN = 1, CWN_REDUCE_MAX = 2 };
+
+typedef struct cwn_agg_desc {
+    const int32_t* rowptr; /* [n_dst+1] or NULL (absent adjacency) */
+    const int32_t* ia;     /* [E] row of A per CSR position */
+    const int32_t* ib;     /* [E] row of B per CSR position, or NULL */
+    const float* A;        /* [rows_a, F] */
+    const float* B;        /* [rows_b, b_width] or NULL */
+    const float* self_x;   /* [n_dst, F] or NULL */
+    const float* eps;      /* device scalar or NULL */
+    const float* self_pre; /* [n_dst, F], CWN_MSG_A_MASK_RELU only */
+    float* out;            /* [n_dst, F] */
+    int64_t n_dst;
+    int32_t F;
+    int32_t b_width;       /* F or 1 */
+    int32_t msg_op;
+    int32_t reduce;
+} cwn_agg_desc;
+
+int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CWN_HIP_H */

@@ -1,0 +1,172 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/cwn_hip.h declares;
+container layout is integer-exact against the golden vectors; host logic (hook routing, errors)
+behaves like the reference contract.  No compute call is made here (no GPU in this container)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from cwn_amd import _ffi
+from cwn_amd.cell_mp import CochainMessagePassing, IndexedRows
+from cwn_amd.complex import Cochain, Complex, ComplexBatch
+from cwn_amd.layers import (SparseCINConv, SparseCINCochainConv, FirstOf, Catter,
+                            DummyCochainMessagePassing, CINConv, OrientedConv)
+from tests._golden import load, T, complex_dict
+from tests._product import dummy_complex, dummy_batch, list_names
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'cwn_hip.h')).read()
+    declared = set(re.findall(r'\b(cwn_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
+    lib = _ffi.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cwn_abi_version() == 1
+    assert lib.cwn_target_arch() == b'gfx950'
+    assert lib.cwn_error_string(0) == b'ok'
+
+
+def test_struct_layout_matches_header():
+    # sizes the C compiler gives for the two descriptor structs (pointers 8 B, int64 8 B, int32 4 B)
+    assert ctypes.sizeof(_ffi.CsrDesc) == 11 * 8
+    assert ctypes.sizeof(_ffi.AggDesc) == 9 * 8 + 8 + 4 * 4
+
+
+def test_argument_errors_without_gpu():
+    lib = _ffi.lib()
+    assert lib.cwn_aggregate_f32(None, 1, None) == 1          # CWN_ERR_BAD_ARG
+    assert lib.cwn_csr_build(None, 1, None, 0, None, None) == 1
+    assert lib.cwn_gather_rows_f32(None, 0, 0, None, 0, None, None) == 1
+    d = (_ffi.CsrDesc * 1)(_ffi.CsrDesc(n_entries=10, n_dst=5))
+    assert lib.cwn_csr_workspace_bytes(d, 1) > 0
+    assert lib.cwn_csr_workspace_bytes(d, 99) == 0
+
+
+def test_cpu_tensors_fail_loudly():
+    from cwn_amd import ops
+    x = torch.randn(4, 8)
+    with pytest.raises(_ffi.CwnError, match='no CPU fallback'):
+        ops.gather_rows(x, torch.tensor([0, 1]))
+    cmp = CochainMessagePassing(8, 8)
+    idx = torch.tensor([[0, 1], [1, 0]])
+    with pytest.raises(_ffi.CwnError):
+        cmp.propagate(idx, None, None, x=x, up_attr=None)
+
+
+@pytest.mark.parametrize('lname', ['testing', 'testing3', 'mol', 'pair', 'nodes_only'])
+def test_batching_layout_integer_exact(lname):
+    g = load('batching.npz')
+    names = [str(n) for n in g[f'{lname}/names']]
+    md = int(g[f'{lname}/max_dim'])
+    b = dummy_batch(names, max_dim=md)
+    ref = complex_dict(g, f'{lname}/batch')
+    assert b.dimension == ref['dimension'] and b.num_complexes == len(names)
+    assert torch.equal(b.y, ref['y'])
+    for d in range(ref['dimension'] + 1):
+        for k in ('x', 'upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries',
+                  'boundary_index', 'y', 'batch'):
+            a, r = b.cochains[d][k], ref['cochains'][d][k]
+            assert (a is None) == (r is None), (d, k)
+            if a is not None:
+                assert a.dtype == r.dtype and torch.equal(a, r), (d, k)
+        assert b.cochains[d].num_cells == ref['cochains'][d]['num_cells']
+    # propagate arguments: indices identical; lazy attributes resolve to the golden gathers
+    for kw_name, kw in (('full', {}), ('nodown', dict(include_down_features=False))):
+        for d, prm in enumerate(b.get_all_cochain_params(max_dim=md, **kw)):
+            pre = f'{lname}/params_{kw_name}/{d}'
+            for k, v in (('x', prm.x), ('up_index', prm.up_index), ('down_index', prm.down_index),
+                         ('boundary_index', prm.boundary_index),
+                         ('boundary_attr', prm.kwargs['boundary_attr'])):
+                assert (v is None) == (f'{pre}/{k}' not in g), (d, k)
+                if v is not None:
+                    assert torch.equal(v, T(g[f'{pre}/{k}'])), (d, k)
+            for k in ('up_attr', 'down_attr'):
+                v = prm.kwargs[k]
+                assert (v is None) == (f'{pre}/{k}' not in g), (d, k)
+                if v is not None:
+                    assert isinstance(v, IndexedRows)
+                    assert torch.equal(v.src.index_select(0, v.index), T(g[f'{pre}/{k}'])), (d, k)
+
+
+def test_house_params_known_answer():           # data/test_data.py:6-54
+    h = dummy_complex('house')
+    v, e = h.get_cochain_params(dim=0), h.get_cochain_params(dim=1)
+    ua = v.kwargs['up_attr']
+    assert ua.src[ua.index].flatten().tolist() == [1, 1, 4, 4, 2, 2, 3, 3, 6, 6, 5, 5]
+    da = e.kwargs['down_attr']
+    assert da.src[da.index].flatten().tolist() == [2, 2, 1, 1, 3, 3, 3, 3, 4, 4, 4, 4, 3, 3, 4, 4, 5, 5]
+    assert e.kwargs['boundary_attr'].flatten().tolist() == [1, 2, 3, 4, 5]
+
+
+def test_index_contract_errors():
+    """mp/cell_mp.py:153-193: AssertionError for dtype / shape, ValueError for foreign index types."""
+    cmp = CochainMessagePassing(1, 1)
+    x = torch.zeros(3, 1)
+    with pytest.raises(AssertionError):
+        cmp.propagate(torch.tensor([[0, 1], [1, 0]], dtype=torch.int32), None, None, x=x, up_attr=None)
+    with pytest.raises(AssertionError):
+        cmp.propagate(torch.tensor([0, 1]), None, None, x=x, up_attr=None)
+    with pytest.raises(AssertionError):
+        cmp.propagate(torch.zeros(3, 2, dtype=torch.long), None, None, x=x, up_attr=None)
+    with pytest.raises(ValueError):
+        cmp.propagate([[0, 1], [1, 0]], None, None, x=x, up_attr=None)
+    with pytest.raises(AssertionError):   # __check_input_together__ (:146-151)
+        i = torch.tensor([[0, 1], [1, 0]])
+        cmp.propagate(i, i, None, up_size=(3, 3), down_size=(4, 3), x=x, up_attr=None, down_attr=None)
+
+
+def test_hook_override_detection():
+    base = CochainMessagePassing(1, 1)
+    assert base._identity_path('up') and base._identity_path('down') and base._identity_path('boundary')
+    assert not (base.fuse_up or base.fuse_down or base.fuse_boundary)
+
+    class Custom(CochainMessagePassing):
+        def message_up(self, up_x_j, up_attr, up_x_i):
+            return up_x_j - up_x_i
+
+    c = Custom(1, 1)
+    assert not c._identity_path('up') and c._identity_path('down')
+    assert c._args_of(['message_up']) == {'up_x_j', 'up_attr', 'up_x_i'}
+    d = DummyCochainMessagePassing(1, 1)
+    assert d.fuse_up and d.fuse_down and not d.fuse_boundary
+    with pytest.raises(TypeError, match='Required parameter'):
+        c._distribute('message_up', {'up_x_j': 1})
+
+
+def test_constructor_contract():
+    with pytest.raises(AssertionError):
+        CochainMessagePassing(1, 1, aggr_up='median')
+    with pytest.raises(AssertionError):
+        CochainMessagePassing(1, 1, flow='sideways')
+    m = CochainMessagePassing(3, 5)
+    assert m.boundary_msg_size == 5 and m.up_msg_size == 3   # boundary defaults to down (:100)
+    assert CochainMessagePassing(3, 5, boundary_msg_size=7).boundary_msg_size == 7
+
+
+def test_sparse_cin_state_dict_matches_reference_names():
+    """Parameter names equal the reference's, so its state_dicts load unchanged."""
+    g = load('sparse_cin_conv.npz')
+    tag = 'mol_cob_bn'
+    F, H, cob, bn = g[f'{tag}/meta'].tolist()
+    conv = SparseCINConv(F, F, F, None, None, None, None, train_eps=True, max_dim=2, hidden=H,
+                         act_module=torch.nn.ReLU, layer_dim=F, use_coboundaries=bool(cob))
+    ref_keys = {k[len(f'{tag}/state/'):] for k in g if k.startswith(f'{tag}/state/')}
+    assert set(conv.state_dict().keys()) == ref_keys
+    lvl = conv.mp_levels[1]
+    assert lvl._up_kind() == 'cat_linear_relu' and lvl._boundary_fusable()
+    nocob = SparseCINConv(F, F, F, None, None, None, None, max_dim=2, hidden=H,
+                          act_module=torch.nn.ReLU, layer_dim=F, use_coboundaries=False)
+    assert nocob.mp_levels[0]._up_kind() == 'first'
+    custom = SparseCINCochainConv(0, F, F, F, lambda xs: xs[0], lambda x: x, torch.nn.Identity(),
+                                  torch.nn.Identity(), torch.nn.Identity())
+    assert custom._up_kind() == 'custom' and not custom._boundary_fusable()
+
+
+def test_complex_prepare_requires_gpu():
+    with pytest.raises(RuntimeError, match='GPU'):
+        dummy_complex('house').prepare()

@@ -1,0 +1,568 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle, the golden vectors produced
+by the live reference and the hand-computed expectations of the reference's tests.
+
+Tolerances: integer structures (CSR) bit-exact; fp32 features |delta| <= 1e-5 (north star), and
+exact equality wherever the arithmetic is exact (integer-valued features) or the summation order
+is provably the oracle's (add-reduce over the stable CSR order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cwn_oracle as O
+from tests._golden import load, T, dummy_complex as o_complex, params_dict, state_dict
+from tests._product import dummy_complex, dummy_batch, list_names
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+NAMES = ['house', 'bridged', 'fullstop', 'colon', 'square', 'square_dot', 'kite', 'pyramid',
+         'filled_square', 'molecular']
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _native_loaded():
+    from cwn_amd import _ffi
+    assert _ffi.lib().cwn_target_arch() == b'gfx950'
+    assert torch.cuda.is_available()
+
+
+def cpu(t):
+    return None if t is None else t.detach().cpu()
+
+
+def run_base(prm, **ctor):
+    from cwn_amd.cell_mp import CochainMessagePassing
+    w = prm.x.size(1)
+    ctor = dict(dict(up_msg_size=w, down_msg_size=w), **ctor)
+    cmp = CochainMessagePassing(**ctor)
+    return cmp.propagate(prm.up_index, prm.down_index, prm.boundary_index, x=prm.x,
+                         up_attr=prm.kwargs['up_attr'], down_attr=prm.kwargs['down_attr'],
+                         boundary_attr=prm.kwargs['boundary_attr'])
+
+
+# ------------------------------------------------------------------------------------------------
+# CSR plans: integer, bit-exact
+# ------------------------------------------------------------------------------------------------
+def _check_adj(adj, index, n_dst, aux=None):
+    rowptr, col, perm = O.csr_from_coo(index.cpu(), n_dst)
+    assert torch.equal(cpu(adj.rowptr), rowptr)
+    assert torch.equal(cpu(adj.col), col)
+    assert torch.equal(cpu(adj.perm), perm)
+    if aux is not None:
+        assert torch.equal(cpu(adj.aux), aux.cpu()[perm.long()].int())
+
+
+def test_csr_build_on_every_batched_index():
+    from cwn_amd.csr import Adjacency
+    b = dummy_batch(list_names('testing'), max_dim=2, device=DEV)
+    for d in range(3):
+        c = b.cochains[d]
+        n = c.num_cells
+        for index, aux, n_src, n_aux in (
+                (c.upper_index, c.shared_coboundaries, n, c.num_cells_up),
+                (c.lower_index, c.shared_boundaries, n, c.num_cells_down),
+                (c.boundary_index, None, c.num_cells_down, 0)):
+            if index is None:
+                continue
+            adj = Adjacency.from_index(index, n, n_src, aux, n_aux or 0)
+            _check_adj(adj, index, n, aux)
+            # transposes used by backward
+            _check_adj(adj.t_src, index.flip(0), n_src, aux)
+            if aux is not None:
+                _check_adj(adj.t_aux, torch.stack([index[1], aux]), n_aux, index[0])
+
+
+@pytest.mark.parametrize('E,n_dst,n_src', [(0, 5, 5), (1, 1, 1), (1000, 7, 300), (50_000, 20_000, 9_000),
+                                           (300_000, 100_000, 100_000)])
+def test_csr_build_random(E, n_dst, n_src):
+    from cwn_amd.csr import Adjacency
+    g = torch.Generator().manual_seed(E + n_dst)
+    index = torch.stack([torch.randint(0, n_src, (E,), generator=g),
+                         torch.randint(0, n_dst, (E,), generator=g)])
+    aux = torch.randint(0, 17, (E,), generator=g)
+    adj = Adjacency.from_index(index.to(DEV), n_dst, n_src, aux.to(DEV), 17)
+    _check_adj(adj, index, n_dst, aux)
+
+
+def test_csr_build_hub_rows_and_batched_call():
+    """Skewed segments (REDDIT-like hubs) and several descriptors in one call."""
+    from cwn_amd.csr import Adjacency, build_many
+    g = torch.Generator().manual_seed(3)
+    n = 4000
+    dst = torch.cat([torch.full((6000,), 17), torch.full((3000,), 3999), torch.randint(0, n, (20_000,), generator=g)])
+    dst = dst[torch.randperm(dst.numel(), generator=g)]
+    src = torch.randint(0, n, (dst.numel(),), generator=g)
+    idx = torch.stack([src, dst])
+    adjs = [Adjacency.from_index(idx.to(DEV), n, n, build=False)]
+    others = []
+    for k in range(10):   # > CWN_MAX_DESCS descriptors -> two C-ABI calls
+        e = 100 * (k + 1)
+        i2 = torch.stack([torch.randint(0, 50, (e,), generator=g), torch.randint(0, 60, (e,), generator=g)])
+        others.append(i2)
+        adjs.append(Adjacency.from_index(i2.to(DEV), 60, 50, build=False))
+    build_many(adjs)
+    _check_adj(adjs[0], idx, n)
+    for a, i2 in zip(adjs[1:], others):
+        _check_adj(a, i2, 60)
+
+
+def test_csr_out_of_range_raises_index_error():
+    from cwn_amd.csr import Adjacency
+    bad = torch.tensor([[0, 1, 7], [1, 0, 2]], device=DEV)
+    with pytest.raises(IndexError, match='source index'):
+        Adjacency.from_index(bad, 3, 3)
+    bad = torch.tensor([[0, 1, 2], [1, 0, 9]], device=DEV)
+    with pytest.raises(IndexError, match='destination index'):
+        Adjacency.from_index(bad, 3, 3)
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 gather
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('F', [1, 2, 3, 4, 8, 64, 127, 128, 130, 512])
+def test_gather_rows_exact(F):
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(F)
+    src = torch.randn(777, F, generator=g)
+    idx = torch.randint(0, 777, (5001,), generator=g)
+    out = ops.gather_rows(src.to(DEV), idx.to(DEV))
+    assert torch.equal(cpu(out), O.lift(src, idx))
+
+
+def test_gather_rows_unaligned_view_and_empty():
+    from cwn_amd import ops
+    src = torch.randn(50, 9, device=DEV)[:, 1:]          # non-contiguous view -> made contiguous
+    idx = torch.tensor([3, 3, 49, 0], device=DEV)
+    assert torch.equal(cpu(ops.gather_rows(src, idx)), cpu(src)[cpu(idx)])
+    assert ops.gather_rows(torch.randn(5, 4, device=DEV), torch.empty(0, dtype=torch.long, device=DEV)).shape == (0, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# propagate: known answers of the reference's tests, on the GPU
+# ------------------------------------------------------------------------------------------------
+def test_house_known_answers_gpu():
+    """mp/test_cell_mp.py:13-88."""
+    h = dummy_complex('house', DEV)
+    up, down, bnd = run_base(h.get_cochain_params(dim=1))
+    assert cpu(up).flatten().tolist() == [0, 0, 11, 0, 9, 8]
+    assert cpu(down).flatten().tolist() == [6, 10, 17, 9, 13, 10]
+    assert cpu(bnd).flatten().tolist() == [3, 5, 7, 5, 9, 8]
+    up, down, bnd = run_base(h.get_cochain_params(dim=0))
+    assert cpu(up).flatten().tolist() == [6, 4, 11, 9, 7]
+    assert torch.equal(cpu(down), torch.zeros(5, 1)) and torch.equal(cpu(bnd), torch.zeros(5, 1))
+    up, down, bnd = run_base(h.get_cochain_params(dim=2))
+    assert torch.equal(cpu(up), torch.zeros(1, 1)) and torch.equal(cpu(down), torch.zeros(1, 1))
+    assert cpu(bnd).flatten().tolist() == [14]
+
+
+def test_two_triangles_and_isolated_gpu():
+    """mp/test_cell_mp.py:91-176."""
+    from cwn_amd.cell_mp import CochainMessagePassing
+    cmp = CochainMessagePassing(up_msg_size=1, down_msg_size=1)
+    x = torch.tensor([[32.], [17.]], device=DEV)
+    down_index = torch.tensor([[0, 1], [1, 0]], device=DEV)
+    up, down, _ = cmp.propagate(None, down_index, None, x=x, down_attr=torch.tensor([[1], [1]], device=DEV))
+    assert cpu(up + down).flatten().tolist() == [17, 32]
+    sd = dummy_complex('square_dot', DEV).get_cochain_params(dim=0)
+    up, down, _ = cmp.propagate(up_index=sd.up_index, down_index=None, boundary_index=None, x=sd.x, up_attr=None)
+    assert cpu(up)[4].item() == 0 and all(cpu(up)[i].item() != 0 for i in range(4))
+    assert torch.equal(cpu(down), torch.zeros(5, 1))
+    for name in ('fullstop', 'colon'):
+        p = dummy_complex(name, DEV).get_cochain_params(dim=0)
+        up, _, _ = cmp.propagate(up_index=p.up_index, down_index=None, boundary_index=None, x=p.x, up_attr=None)
+        assert torch.equal(cpu(up), torch.zeros_like(cpu(p.x)))
+    empty = torch.empty(2, 0, dtype=torch.long, device=DEV)
+    up, _, _ = cmp.propagate(up_index=empty, down_index=None, boundary_index=None, x=x, up_attr=None)
+    assert torch.equal(cpu(up), torch.zeros(2, 1))
+
+
+def test_bridged_multiplicity_gpu():
+    """mp/test_cell_mp.py:179-247: shared (co)boundaries count with multiplicity."""
+    b = dummy_complex('bridged', DEV)
+    up, _, _ = run_base(b.get_cochain_params(dim=1))
+    assert cpu(up).flatten().tolist() == [24, 22, 20, 18, 22, 20]
+    _, down, bnd = run_base(b.get_cochain_params(dim=2))
+    assert cpu(down).flatten().tolist() == [10, 8, 6] and cpu(bnd).flatten().tolist() == [16, 16, 10]
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_propagate_every_complex_exact(name):
+    g = load('propagate_known_answer.npz')
+    cx = dummy_complex(name, DEV)
+    for d in range(cx.dimension + 1):
+        up, down, bnd = run_base(cx.get_cochain_params(dim=d))
+        assert torch.equal(cpu(up), T(g[f'{name}/{d}/up']))
+        assert torch.equal(cpu(down), T(g[f'{name}/{d}/down']))
+        assert torch.equal(cpu(bnd), T(g[f'{name}/{d}/boundary']))
+
+
+@pytest.mark.parametrize('lazy', [True, False])
+@pytest.mark.parametrize('name', NAMES)
+def test_dummy_layer_exact(name, lazy):
+    """mp/test_layers.py:11-69 and every other complex; fused x_j + attr with lazy and with
+    materialised (reference-style) attributes."""
+    from cwn_amd.layers import DummyCellularMessagePassing
+    g = load('propagate_known_answer.npz')
+    cx = dummy_complex(name, DEV)
+    cx.lazy_attrs = lazy
+    prms = [cx.get_cochain_params(dim=d) for d in range(min(cx.dimension, 2) + 1)]
+    for ub in (0, 1):
+        for ud in (0, 1):
+            outs = DummyCellularMessagePassing(use_boundary_msg=bool(ub), use_down_msg=bool(ud)).forward(*prms)
+            for d, o in enumerate(outs):
+                assert torch.equal(cpu(o), T(g[f'{name}/dummy_b{ub}_d{ud}/{d}'])), (ub, ud, d)
+
+
+@pytest.mark.parametrize('F', [1, 3, 8, 64, 128])
+def test_propagate_random_golden_gpu(F):
+    """Batched testing list, random features, all reductions; golden = the live reference."""
+    g = load('propagate_random.npz')
+    b = dummy_batch(list_names('testing'), max_dim=2, device=DEV)
+    for d in range(3):
+        b.cochains[d].x = T(g[f'F{F}/{d}/params/x']).to(DEV)
+    prms = b.get_all_cochain_params(max_dim=2)
+    for d, prm in enumerate(prms):
+        for aggr in ('add', 'mean', 'max'):
+            up, down, bnd = run_base(prm, aggr_up=aggr, aggr_down=aggr, aggr_boundary=aggr)
+            for got, key in ((up, 'up'), (down, 'down'), (bnd, 'boundary')):
+                ref = T(g[f'F{F}/{d}/{aggr}/{key}'])
+                torch.testing.assert_close(cpu(got), ref, rtol=0, atol=1e-5)
+                if aggr != 'mean':   # same summation order as the sequential CPU scatter
+                    assert torch.equal(cpu(got), ref), (d, aggr, key)
+        _, down, bnd = run_base(prm, up_msg_size=F, down_msg_size=5, boundary_msg_size=7,
+                                use_down_msg=False, use_boundary_msg=False)
+        assert list(down.shape) == g[f'F{F}/{d}/flags_off/down_shape'].tolist()
+        assert list(bnd.shape) == g[f'F{F}/{d}/flags_off/boundary_shape'].tolist()
+        assert not down.any() and not bnd.any()
+    from cwn_amd.layers import DummyCellularMessagePassing
+    outs = DummyCellularMessagePassing(input_dim=F, use_boundary_msg=True, use_down_msg=True).forward(*prms)
+    for d, o in enumerate(outs):
+        torch.testing.assert_close(cpu(o), T(g[f'F{F}/dummy/{d}']), rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# generic hook path + gradients
+# ------------------------------------------------------------------------------------------------
+def test_custom_hooks_match_oracle_and_autograd():
+    from cwn_amd.cell_mp import CochainMessagePassing
+
+    class Custom(CochainMessagePassing):
+        def message_up(self, up_x_j, up_x_i, up_attr):
+            return torch.tanh(up_x_j - up_x_i) * up_attr
+
+        def message_boundary(self, boundary_x_j):
+            return boundary_x_j ** 2
+
+    g = load('propagate_random.npz')
+    F = 8
+    b = dummy_batch(list_names('testing'), max_dim=2, device=DEV)
+    xs = [T(g[f'F{F}/{d}/params/x']) for d in range(3)]
+    for d in range(3):
+        b.cochains[d].x = xs[d].to(DEV).requires_grad_(True)
+    prm = b.get_cochain_params(dim=1)
+    layer = Custom(F, F)
+    up, down, bnd = layer.propagate(prm.up_index, prm.down_index, prm.boundary_index, x=prm.x,
+                                    up_attr=prm.kwargs['up_attr'], down_attr=prm.kwargs['down_attr'],
+                                    boundary_attr=prm.kwargs['boundary_attr'])
+    w = torch.randn(3, *up.shape, generator=torch.Generator().manual_seed(0))
+    ((up * w[0].to(DEV)).sum() + (down * w[1].to(DEV)).sum() + (bnd * w[2].to(DEV)).sum()).backward()
+
+    oxs = [x.clone().requires_grad_(True) for x in xs]
+    ocx = O.batch_complexes([o_complex(n) for n in list_names('testing')], max_dim=2)
+    for d in range(3):
+        ocx['cochains'][d]['x'] = oxs[d]
+    op = O.cochain_params(ocx, 1)
+    idx = op['up_index']
+    oup, odown, obnd = O.propagate(
+        op['x'], op['up_index'], op['down_index'], op['boundary_index'], up_attr=op['up_attr'],
+        down_attr=op['down_attr'], boundary_attr=op['boundary_attr'],
+        message_up=lambda xj, a: torch.tanh(xj - op['x'].index_select(0, idx[1])) * a,
+        message_boundary=lambda xj: xj ** 2, up_msg_size=F, down_msg_size=F)
+    ((oup * w[0]).sum() + (odown * w[1]).sum() + (obnd * w[2]).sum()).backward()
+    for got, ref in ((up, oup), (down, odown), (bnd, obnd)):
+        torch.testing.assert_close(cpu(got), ref.detach(), rtol=1e-5, atol=1e-5)
+    for d in range(3):
+        torch.testing.assert_close(cpu(b.cochains[d].x.grad), oxs[d].grad, rtol=1e-5, atol=1e-5)
+
+
+def test_identity_path_gradients_all_reductions():
+    from cwn_amd.cell_mp import CochainMessagePassing
+    g = load('propagate_random.npz')
+    F = 8
+    names = list_names('testing')
+    for aggr in ('add', 'mean'):
+        b = dummy_batch(names, max_dim=2, device=DEV)
+        xs = [T(g[f'F{F}/{d}/params/x']) for d in range(3)]
+        for d in range(3):
+            b.cochains[d].x = xs[d].to(DEV).requires_grad_(True)
+        prm = b.get_cochain_params(dim=1)
+        layer = CochainMessagePassing(F, F, aggr_up=aggr, aggr_down=aggr, aggr_boundary=aggr)
+        outs = layer.propagate(prm.up_index, prm.down_index, prm.boundary_index, x=prm.x,
+                               up_attr=prm.kwargs['up_attr'], down_attr=prm.kwargs['down_attr'],
+                               boundary_attr=prm.kwargs['boundary_attr'])
+        w = torch.randn(3, *outs[0].shape, generator=torch.Generator().manual_seed(1))
+        sum((o * w[k].to(DEV)).sum() for k, o in enumerate(outs)).backward()
+        oxs = [x.clone().requires_grad_(True) for x in xs]
+        ocx = O.batch_complexes([o_complex(n) for n in names], max_dim=2)
+        for d in range(3):
+            ocx['cochains'][d]['x'] = oxs[d]
+        op = O.cochain_params(ocx, 1)
+        oouts = O.propagate(op['x'], op['up_index'], op['down_index'], op['boundary_index'],
+                            up_attr=op['up_attr'], down_attr=op['down_attr'],
+                            boundary_attr=op['boundary_attr'], aggr_up=aggr, aggr_down=aggr,
+                            aggr_boundary=aggr, up_msg_size=F, down_msg_size=F)
+        sum((o * w[k]).sum() for k, o in enumerate(oouts)).backward()
+        for d in (0, 1):
+            torch.testing.assert_close(cpu(b.cochains[d].x.grad), oxs[d].grad, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# layers against the live-reference golden vectors (its state_dict loaded unchanged)
+# ------------------------------------------------------------------------------------------------
+def _sparse_cin(tag, g):
+    from cwn_amd.layers import SparseCINConv
+    from cwn_amd.models import get_graph_norm
+    F, H, cob, bn = g[f'{tag}/meta'].tolist()
+    conv = SparseCINConv(up_msg_size=F, down_msg_size=F, boundary_msg_size=F, passed_msg_up_nn=None,
+                         passed_msg_boundaries_nn=None, passed_update_up_nn=None,
+                         passed_update_boundaries_nn=None, train_eps=True, max_dim=2, hidden=H,
+                         act_module=torch.nn.ReLU, layer_dim=F,
+                         graph_norm=get_graph_norm('bn' if bn else 'id'), use_coboundaries=bool(cob))
+    conv.load_state_dict(state_dict(g, f'{tag}/state'))
+    return conv.to(DEV)
+
+
+@pytest.mark.parametrize('tag', ['mol_cob_bn', 'mol_nocob_bn', 'test_cob_id', 'mol_cob_bn_64'])
+def test_sparse_cin_conv_forward_golden(tag):
+    g = load('sparse_cin_conv.npz')
+    conv = _sparse_cin(tag, g)
+    names = [str(n) for n in g[f'{tag}/names']]
+    for mode in ('eval', 'train'):
+        conv.load_state_dict(state_dict(g, f'{tag}/state'))   # train mode updates running stats
+        conv.train(mode == 'train')
+        b = dummy_batch(names, max_dim=2, device=DEV)
+        for d in range(3):
+            b.cochains[d].x = T(g[f'{tag}/x/{d}']).to(DEV)
+        b.prepare()
+        with torch.no_grad():
+            outs = conv(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+        for d, o in enumerate(outs):
+            torch.testing.assert_close(cpu(o), T(g[f'{tag}/{mode}/{d}']), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('lazy', [True, False])
+def test_sparse_cin_conv_unfused_paths_agree(lazy):
+    """forward_unfused (propagate + fused hooks, reference's sequence) == batched forward; and the
+    dense-attribute form (reference-style up_attr tensors) == the lazy form."""
+    g = load('sparse_cin_conv.npz')
+    tag = 'mol_cob_bn'
+    conv = _sparse_cin(tag, g).eval()
+    b = dummy_batch([str(n) for n in g[f'{tag}/names']], max_dim=2, device=DEV)
+    b.lazy_attrs = lazy
+    for d in range(3):
+        b.cochains[d].x = T(g[f'{tag}/x/{d}']).to(DEV)
+    prms = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+    with torch.no_grad():
+        for d, prm in enumerate(prms):
+            o = conv.mp_levels[d].forward_unfused(prm)
+            torch.testing.assert_close(cpu(o), T(g[f'{tag}/eval/{d}']), rtol=1e-5, atol=1e-5)
+            o = conv.mp_levels[d].forward(prm)
+            torch.testing.assert_close(cpu(o), T(g[f'{tag}/eval/{d}']), rtol=1e-5, atol=1e-5)
+
+
+def test_sparse_cin_conv_custom_message_net_generic_path():
+    """An unrecognised message network (lambda, tanh) runs through gather -> hook -> reduce."""
+    from cwn_amd.layers import SparseCINCochainConv
+    g = load('sparse_cin_conv.npz')
+    tag = 'mol_cob_bn'
+    F = int(g[f'{tag}/meta'][0])
+    b = dummy_batch([str(n) for n in g[f'{tag}/names']], max_dim=2, device=DEV)
+    for d in range(3):
+        b.cochains[d].x = T(g[f'{tag}/x/{d}']).to(DEV)
+    lvl = SparseCINCochainConv(1, F, F, F, msg_up_nn=lambda xs: torch.tanh(xs[0] * xs[1]),
+                               msg_boundaries_nn=lambda x: 2 * x, update_up_nn=torch.nn.Identity(),
+                               update_boundaries_nn=torch.nn.Identity(),
+                               combine_nn=torch.nn.Identity(), eps=0.5).to(DEV)
+    prm = b.get_cochain_params(dim=1, include_down_features=False)
+    out = lvl(prm)
+    ocx = O.batch_complexes([o_complex(str(n)) for n in g[f'{tag}/names']], max_dim=2)
+    for d in range(3):
+        ocx['cochains'][d]['x'] = T(g[f'{tag}/x/{d}'])
+    op = O.cochain_params(ocx, 1, include_down_features=False)
+    up, _, bnd = O.propagate(op['x'], op['up_index'], None, op['boundary_index'], up_attr=op['up_attr'],
+                             boundary_attr=op['boundary_attr'],
+                             message_up=lambda xj, a: torch.tanh(xj * a),
+                             message_boundary=lambda xj: 2 * xj, use_down_msg=False,
+                             up_msg_size=F, down_msg_size=F, boundary_msg_size=F)
+    ref = torch.cat([up + 1.5 * op['x'], bnd + 1.5 * op['x']], dim=-1)
+    torch.testing.assert_close(cpu(out), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_sparse_cin_conv_backward_golden():
+    """Gradients w.r.t. inputs and every parameter equal the reference's (train mode, BN)."""
+    g = load('sparse_cin_conv.npz')
+    tag = 'mol_cob_bn'
+    conv = _sparse_cin(tag, g).train()
+    b = dummy_batch([str(n) for n in g[f'{tag}/names']], max_dim=2, device=DEV)
+    xs = [T(g[f'{tag}/x/{d}']).to(DEV).requires_grad_(True) for d in range(3)]
+    for d in range(3):
+        b.cochains[d].x = xs[d]
+    b.prepare(backward=True)
+    outs = conv(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+    sum((o * T(g[f'{tag}/train_w/{d}']).to(DEV)).sum() for d, o in enumerate(outs)).backward()
+    for d, o in enumerate(outs):
+        torch.testing.assert_close(cpu(o), T(g[f'{tag}/train/{d}']), rtol=1e-5, atol=1e-5)
+    for d in range(3):
+        torch.testing.assert_close(cpu(xs[d].grad), T(g[f'{tag}/train_gx/{d}']), rtol=1e-4, atol=2e-5)
+    pre = f'{tag}/train_grad/'
+    params = dict(conv.named_parameters())
+    n = 0
+    for k, v in g.items():
+        if k.startswith(pre):
+            torch.testing.assert_close(cpu(params[k[len(pre):]].grad), T(v), rtol=1e-4, atol=5e-5)
+            n += 1
+    assert n > 20
+
+
+def test_cin_conv_and_oriented_messages_golden():
+    from cwn_amd.layers import CINConv, OrientedConv
+    g = load('cin_conv.npz')
+    F = 8
+    msg_up = torch.nn.Sequential(torch.nn.Linear(2 * F, F), torch.nn.ReLU())
+    msg_down = torch.nn.Sequential(torch.nn.Linear(2 * F, F), torch.nn.ReLU())
+    upd = torch.nn.Sequential(torch.nn.Linear(F, 12), torch.nn.ReLU())
+    conv = CINConv(F, F, msg_up, msg_down, upd, eps=0.1, train_eps=False, max_dim=2)
+    conv.load_state_dict(state_dict(g, 'cin/state'))
+    conv = conv.to(DEV)
+    b = dummy_batch(list_names('testing'), max_dim=2, device=DEV)
+    for d in range(3):
+        b.cochains[d].x = T(g[f'cin/x/{d}']).to(DEV)
+    prm = b.get_cochain_params(dim=1)
+    with torch.no_grad():
+        out = conv.mp_levels[1].forward(prm)
+    torch.testing.assert_close(cpu(out), T(g['cin/out/1']), rtol=1e-5, atol=1e-5)
+    oc = OrientedConv(1, F, F, update_up_nn=None, update_down_nn=None, update_nn=None, act_fn=None)
+    up, down, _ = oc.propagate(prm.up_index, prm.down_index, None, x=prm.x,
+                               up_attr=T(g['orient/up_orient']).to(DEV).view(-1, 1),
+                               down_attr=T(g['orient/down_orient']).to(DEV).view(-1, 1))
+    torch.testing.assert_close(cpu(up), T(g['orient/up']), rtol=0, atol=1e-6)
+    torch.testing.assert_close(cpu(down), T(g['orient/down']), rtol=0, atol=1e-6)
+
+
+def test_init_reduce_known_answer_gpu():
+    """mp/test_layers.py:135-149."""
+    from cwn_amd.layers import InitReduceConv
+    h = dummy_complex('house', DEV)
+    p = [h.get_cochain_params(dim=d) for d in range(3)]
+    conv = InitReduceConv(reduce='add')
+    assert cpu(conv(p[0].x, p[1].boundary_index)).flatten().tolist() == [3, 5, 7, 5, 9, 8]
+    assert cpu(conv(p[1].x, p[2].boundary_index)).flatten().tolist() == [14]
+
+
+@pytest.mark.parametrize('tag', ['h16_l2', 'h32_l4'])
+def test_embed_sparse_cin_whole_stack_golden(tag):
+    """The reference model's state_dict on the engine: every layer output and the prediction."""
+    from cwn_amd.models import EmbedSparseCIN
+    g = load('embed_sparse_cin.npz')
+    H, L = g[f'{tag}/meta'].tolist()
+    model = EmbedSparseCIN(28, 4, 1, L, H, dropout_rate=0.0, max_dim=2, jump_mode=None,
+                           nonlinearity='relu', readout='sum', train_eps=False,
+                           final_hidden_multiplier=2, final_readout='sum', apply_dropout_before='lin2',
+                           init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn')
+    names = list_names('mol')
+    for mode in ('eval', 'train'):
+        model.load_state_dict(state_dict(g, f'{tag}/state'))
+        model = model.to(DEV).train(mode == 'train')
+        b = dummy_batch(names, max_dim=2)
+        b.cochains[0].x = T(g[f'{tag}/v_types'])
+        b.cochains[1].x = T(g[f'{tag}/e_types'])
+        b.cochains[2]._x = None
+        b = b.to(DEV)
+        with torch.no_grad():
+            y, res = model(b, include_partial=True)
+        for k, v in res.items():
+            torch.testing.assert_close(cpu(v), T(g[f'{tag}/{mode}/{k}']), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(cpu(y), T(g[f'{tag}/{mode}/out']), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE-size properties (ZINC-like batch of 128, F = 128): size-independent checks
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def zinc128():
+    from cwn_amd.synthetic import zinc_like_batch
+    b = zinc_like_batch(128, seed=0, max_ring=6, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    for d in range(3):
+        b.cochains[d].x = torch.randn(b.cochains[d].num_cells, 128, generator=g).to(DEV)
+    return b.prepare(backward=True)
+
+
+def test_full_size_matches_oracle(zinc128):
+    """At this size the oracle still runs in well under a second: direct comparison."""
+    b = zinc128
+    for d in range(3):
+        prm = b.get_cochain_params(dim=d, include_down_features=False)
+        up, down, bnd = run_base(prm)
+        oup, odown, obnd = O.propagate(
+            cpu(prm.x), cpu(prm.up_index), None, cpu(prm.boundary_index),
+            boundary_attr=cpu(prm.kwargs['boundary_attr']), up_msg_size=128, down_msg_size=128)
+        assert torch.equal(cpu(up), oup) and torch.equal(cpu(bnd), obnd) and not down.any()
+
+
+def test_full_size_linearity_and_checksum(zinc128):
+    from cwn_amd import ops
+    from cwn_amd.csr import cached_adjacency
+    b = zinc128
+    c = b.cochains[1]
+    adj = cached_adjacency(c.upper_index, c.num_cells, c.num_cells, c.shared_coboundaries, c.num_cells_up)
+    x, y = c.x, torch.randn_like(c.x)
+    lhs = ops.aggregate(adj, c.num_cells, 2.0 * x - 3.0 * y)
+    rhs = 2.0 * ops.aggregate(adj, c.num_cells, x) - 3.0 * ops.aggregate(adj, c.num_cells, y)
+    torch.testing.assert_close(lhs, rhs, rtol=1e-5, atol=1e-4)
+    # checksum of checksums: column sums of the output == out-degree-weighted column sums of x
+    outdeg = torch.bincount(c.upper_index[0], minlength=c.num_cells).double()
+    want = (outdeg.unsqueeze(1) * x.double()).sum(0)
+    got = ops.aggregate(adj, c.num_cells, x).double().sum(0)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-3)
+    # entry-order independence: shuffling the COO entries changes nothing for integer features
+    perm = torch.randperm(c.upper_index.size(1), device=DEV)
+    xi = torch.randint(-8, 8, x.shape, device=DEV).float()
+    adj2 = cached_adjacency(c.upper_index[:, perm].contiguous(), c.num_cells, c.num_cells)
+    assert torch.equal(ops.aggregate(adj, c.num_cells, xi), ops.aggregate(adj2, c.num_cells, xi))
+
+
+def test_full_size_transpose_identity(zinc128):
+    """<agg(x), w> == <x, agg^T(w)>: the backward kernel is the adjoint of the forward one."""
+    from cwn_amd import ops
+    from cwn_amd.csr import cached_adjacency
+    b = zinc128
+    c = b.cochains[2]
+    adj = cached_adjacency(c.boundary_index, c.num_cells, c.num_cells_down)
+    x = b.cochains[1].x.clone().requires_grad_(True)
+    w = torch.randn(c.num_cells, 128, device=DEV)
+    out = ops.aggregate(adj, c.num_cells, x)
+    (out * w).sum().backward()
+    ref = torch.zeros_like(x).index_add_(0, c.boundary_index[0], w[c.boundary_index[1]])
+    torch.testing.assert_close(x.grad, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_sparse_cin_layer_full_size_vs_oracle(zinc128):
+    """One SparseCIN layer (coboundary messages, BN train mode) at the BASELINE size."""
+    from cwn_amd.layers import SparseCINConv
+    b = zinc128
+    torch.manual_seed(0)
+    conv = SparseCINConv(128, 128, 128, None, None, None, None, max_dim=2, hidden=128,
+                         act_module=torch.nn.ReLU, layer_dim=128, use_coboundaries=True).to(DEV).train()
+    state = {k: v.detach().cpu() for k, v in conv.state_dict().items()}
+    with torch.no_grad():
+        outs = conv(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+    ocx = {'dimension': 2, 'y': None, 'cochains': []}
+    for d in range(3):
+        c = b.cochains[d]
+        ocx['cochains'].append({k: cpu(c[k]) for k in ('x', 'upper_index', 'lower_index',
+                                'shared_boundaries', 'shared_coboundaries', 'boundary_index', 'y', 'batch')})
+    oouts = O.sparse_cin_conv(state, O.all_cochain_params(ocx, 2, include_down_features=False), True,
+                              training=True)
+    for o, r in zip(outs, oouts):
+        torch.testing.assert_close(cpu(o), r, rtol=1e-4, atol=1e-4)
