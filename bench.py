@@ -94,7 +94,8 @@ def main():
                    for i in range(args.num_batches)]
     stats = [batch_stats(b) for b in cpu_batches]
     types = [(b.cochains[0].x.clone(), b.cochains[1].x.clone()) for b in cpu_batches]
-    batches = [b.to(dev) for b in cpu_batches]
+    batches = [zinc_like_batch(args.batch, seed=1000 * rank + i, max_ring=6).to(dev)   # .to() is in place
+               for i in range(args.num_batches)]
 
     vt_dev = [vt.to(dev) for vt, _ in types]
     et_dev = [et.to(dev) for _, et in types]
