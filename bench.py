@@ -47,7 +47,8 @@ def parse():
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
     p.add_argument('--no-cpu', action='store_true')
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
-    p.add_argument('--kernel-reps', type=int, default=200)
+    p.add_argument('--kernel-reps', type=int, default=100)
+    p.add_argument('--only-primary', action='store_true', help='skip secondary / roofline / cpu legs (profiling)')
     return p.parse_args()
 
 
@@ -194,8 +195,14 @@ def main():
     value = float(cells_total.item()) / dt
 
     # secondary: the full model forward (embedding, 4 conv layers incl. MLPs/BN, readout, head)
+    if args.only_primary:
+        args.no_cpu = True
     try:
+        if args.only_primary:
+            raise KeyboardInterrupt
         dt_full = timed(full_forward, max(args.steps // 4, 10), max(args.warmup // 4, 3), use_graph)
+    except KeyboardInterrupt:
+        dt_full = float('nan')
     except Exception as e:
         print(f'[bench] full-forward graph capture failed ({type(e).__name__}); eager', file=sys.stderr)
         torch.cuda.synchronize()
@@ -208,7 +215,7 @@ def main():
 
     # ---- roofline of the dominant kernel (aggregate_kernel: one launch per layer) ----------------
     roofline = None
-    if rank == 0:
+    if rank == 0 and not args.only_primary:
         b, feats = batches[0], layer_inputs[0]
         with torch.no_grad():
             csr._cache.clear()
@@ -229,14 +236,27 @@ def main():
                 specs.append(s)
             ops.run_aggregate(specs, dev)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = args.kernel_reps
-            e0.record()
-            for _ in range(reps):
+            # the launches are replayed from a hipGraph so the host (Python/ctypes, ~15 us per
+            # call) is out of the measurement; the two events sit on the replay stream
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
                 ops.run_aggregate(specs, dev)
+            torch.cuda.current_stream().wait_stream(side)
+            kg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(kg):
+                for _ in range(reps):
+                    ops.run_aggregate(specs, dev)
+            kg.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                kg.replay()
             e1.record()
             torch.cuda.synchronize()
-            k_us = e0.elapsed_time(e1) * 1e3 / reps
+            k_us = e0.elapsed_time(e1) * 1e3 / (5 * reps)
         alg = layer_algorithmic_bytes(stats[0], H, coboundary=True)
         achieved = alg / (k_us * 1e-6) / 1e9
         roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel<4>', 'achieved': round(achieved, 1),
@@ -244,8 +264,9 @@ def main():
                     'traffic': None, 'algorithmic_bytes_per_launch': alg,
                     'avg_launch_us': round(k_us, 3),
                     'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4),
-                    'note': 'avg over back-to-back launches between two HIP events on the launch '
-                            'stream (includes inter-kernel gaps); batch fits L2/MALL'}
+                    'note': 'avg over back-to-back dependent launches replayed from a hipGraph between two '
+                            'HIP events (includes the ~1.5 us inter-kernel boundary; rocprofv3 kernel-only '
+                            'average is in profiles/); the batch fits L2/MALL'}
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample -----------------------------
     cpu_baseline = None
@@ -270,8 +291,23 @@ def main():
                                 up_attr=prm['up_attr'], boundary_attr=prm['boundary_attr'],
                                 message_up=lambda xj, a: torch.relu(torch.cat([xj, a], -1) @ W.t() + bias),
                                 use_down_msg=False, up_msg_size=H, down_msg_size=H, boundary_msg_size=H)
-        threads = torch.get_num_threads()
+        # pick the thread count that is FASTEST for this (small-tensor) workload: all cores is
+        # usually not it, and a baseline slowed down by oversubscription would flatter the GPU
+        max_threads = torch.get_num_threads()
+        trials = {}
         with torch.no_grad():
+            for th in sorted({1, 4, 8, 16, 32, max_threads}):
+                if th > max_threads:
+                    continue
+                torch.set_num_threads(th)
+                cpu_step()
+                k, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < 0.8:
+                    cpu_step()
+                    k += 1
+                trials[th] = k / (time.perf_counter() - t0)
+            threads = max(trials, key=trials.get)
+            torch.set_num_threads(threads)
             for _ in range(3):
                 cpu_step()
             n, t0 = 0, time.perf_counter()
@@ -279,14 +315,16 @@ def main():
                 cpu_step()
                 n += 1
                 el = time.perf_counter() - t0
-                if el > args.cpu_seconds or n >= 2000:
+                if el > args.cpu_seconds or n >= 5000:
                     break
+            torch.set_num_threads(max_threads)
         cpu_value = stats[0]['cells'] * L * n / el
         cpu_baseline = {'value': round(cpu_value, 1), 'unit': 'cells/s', 'cores': threads,
                         'kind': 'port',
                         'sample': f'{n} passes of the same propagate scope (12 propagate calls incl. '
                                   f'up_attr gathers) over batch 0 in {el:.1f} s, torch {torch.__version__} '
-                                  f'CPU, {threads} threads of {os.cpu_count()} logical cores',
+                                  f'CPU, {threads} threads (fastest of {sorted(trials)}; passes/s per thread count: '
+                                  f'{ {k: round(v, 1) for k, v in trials.items()} }) of {os.cpu_count()} logical cores',
                         'gpu_over_cpu': round(value / cpu_value, 1)}
 
     if rank == 0:
