@@ -1,0 +1,116 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: complexes shard disjointly, per-rank batches keep
+the reference index layout, and the single flat-bucket gradient all-reduce reproduces the
+gradient of the mean loss over both shards."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cwn_oracle as O
+from tests._golden import load, T, dummy_complex as o_complex, state_dict
+from tests._product import dummy_complex, list_names
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _loss_and_grads(names, state):
+    """Oracle SparseCIN layer (CPU autograd) on the batch of `names`; returns grads per tensor."""
+    g = load('sparse_cin_conv.npz')
+    cx = O.batch_complexes([o_complex(n) for n in names], max_dim=2)
+    gen = torch.Generator().manual_seed(len(names))
+    for d in range(3):
+        n = cx['cochains'][d]['num_cells']
+        cx['cochains'][d]['x'] = torch.randn(n, 8, generator=torch.Generator().manual_seed(100 + d))[:n]
+    outs = O.sparse_cin_conv(state, O.all_cochain_params(cx, 2, include_down_features=False), True,
+                             training=True)
+    return sum(o.pow(2).mean() for o in outs)
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from cwn_amd.dist import FlatGradBucket, init_from_env, shard, sum_across_ranks
+    r, w = init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    names = list_names('mol')
+    mine = shard(names, rank, world)
+    # per-rank container batch == oracle batch of the same shard (integer layout)
+    from cwn_amd.complex import ComplexBatch
+    b = ComplexBatch.from_complex_list([dummy_complex(n) for n in mine], max_dim=2)
+    ob = O.batch_complexes([o_complex(n) for n in mine], max_dim=2)
+    for d in range(3):
+        for k in ('upper_index', 'shared_coboundaries', 'boundary_index', 'batch'):
+            a, o = b.cochains[d][k], ob['cochains'][d][k]
+            assert (a is None) == (o is None), (rank, d, k)
+            assert a is None or torch.equal(a, o), (rank, d, k)
+    g = load('sparse_cin_conv.npz')
+    state = {k: torch.nn.Parameter(v.clone()) if v.is_floating_point() and 'running' not in k else v
+             for k, v in state_dict(g, 'mol_cob_bn/state').items()}
+    params = [v for v in state.values() if isinstance(v, torch.nn.Parameter)]
+    bucket = FlatGradBucket(params)
+    bucket.zero_()
+    _loss_and_grads(mine, state).backward()
+    local_norm = float(bucket.flat.norm())
+    bucket.all_reduce_mean()
+    total_cells = sum_across_ranks(float(sum(ob['cochains'][d]['num_cells'] for d in range(3))))
+    if rank == 0:
+        ret['flat'] = bucket.flat.clone()
+        ret['cells'] = total_cells
+        ret['local_norm'] = local_norm
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_grad_allreduce():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        flat = ret['flat']
+        cells = ret['cells']
+    # single-process emulation: mean over the two shards of the per-shard gradient
+    from cwn_amd.dist import FlatGradBucket, shard
+    g = load('sparse_cin_conv.npz')
+    names = list_names('mol')
+    ref = None
+    for r in range(world):
+        state = {k: torch.nn.Parameter(v.clone()) if v.is_floating_point() and 'running' not in k else v
+                 for k, v in state_dict(g, 'mol_cob_bn/state').items()}
+        bucket = FlatGradBucket([v for v in state.values() if isinstance(v, torch.nn.Parameter)])
+        bucket.zero_()
+        _loss_and_grads(shard(names, r, world), state).backward()
+        ref = bucket.flat.clone() if ref is None else ref + bucket.flat
+    ref /= world
+    torch.testing.assert_close(flat, ref, rtol=1e-5, atol=1e-7)
+    total = sum(O.batch_complexes([o_complex(n) for n in names], max_dim=2)['cochains'][d]['num_cells']
+                for d in range(3))
+    assert cells == total     # the shards cover every cell exactly once
+
+
+def test_shard_is_a_partition():
+    from cwn_amd.dist import shard
+    items = list(range(23))
+    for world in (1, 2, 4, 8):
+        parts = [shard(items, r, world) for r in range(world)]
+        assert sorted(x for p in parts for x in p) == items
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_bucket_views_are_the_grads():
+    from cwn_amd.dist import FlatGradBucket
+    lin = torch.nn.Linear(3, 2)
+    bucket = FlatGradBucket(lin.parameters())
+    lin(torch.ones(4, 3)).sum().backward()
+    assert bucket.flat.numel() == 8 and bucket.flat.abs().sum() > 0
+    assert lin.weight.grad.data_ptr() == bucket.flat.data_ptr()
+    assert bucket.all_reduce_mean() is None      # no process group: no-op
