@@ -129,8 +129,7 @@ def main():
         for l, conv in enumerate(model.convs):
             b.set_xs(feats[l])
             params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
-            streams = [st for d in range(3) for st in conv.mp_levels[d].streams(params[d])]
-            outs = ops.aggregate_many(streams)
+            _, outs = conv.propagate_all(*params)
         return outs
 
     def full_forward(bi):
@@ -222,7 +221,10 @@ def main():
             b.prepare(max_dim=2)
             b.set_xs(feats[1])
             params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
-            streams = [st for d in range(3) for st in model.convs[1].mp_levels[d].streams(params[d])]
+            lv = model.convs[1].mp_levels
+            ys = ops.gemm_many([sp for d in range(3) for sp in lv[d].gemm_specs(params[d])])
+            streams = (lv[0].streams(params[0], ys[0:2]) + lv[1].streams(params[1], ys[2:4]) +
+                       lv[2].streams(params[2]))
             for st in streams:
                 st.validate()
             specs = []

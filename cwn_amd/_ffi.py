@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 1
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32')
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32')
 
 
 class CsrDesc(C.Structure):
@@ -35,6 +35,16 @@ class AggDesc(C.Structure):
                 ('eps', C.c_void_p), ('self_pre', C.c_void_p), ('out', C.c_void_p),
                 ('n_dst', C.c_int64), ('F', C.c_int32), ('b_width', C.c_int32),
                 ('msg_op', C.c_int32), ('reduce', C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('X2', C.c_void_p), ('W', C.c_void_p), ('bias', C.c_void_p),
+                ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('out_scale', C.c_void_p),
+                ('out_shift', C.c_void_p), ('col_sum', C.c_void_p), ('col_sumsq', C.c_void_p),
+                ('Y', C.c_void_p), ('M', C.c_int64), ('ldx', C.c_int64), ('ldx2', C.c_int64),
+                ('ldw', C.c_int64), ('ldy', C.c_int64), ('N', C.c_int32), ('K', C.c_int32),
+                ('K2', C.c_int32), ('relu', C.c_int32), ('in_relu', C.c_int32),
+                ('reserved', C.c_int32)]
 
 
 class CwnError(RuntimeError):
@@ -68,6 +78,8 @@ def lib():
                                       C.c_void_p, C.c_void_p]
     L.cwn_aggregate_f32.restype = C.c_int
     L.cwn_aggregate_f32.argtypes = [C.POINTER(AggDesc), C.c_int, C.c_void_p]
+    L.cwn_gemm_f32.restype = C.c_int
+    L.cwn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
     if L.cwn_abi_version() != ABI_VERSION:
         raise CwnError(f'ABI mismatch: library {L.cwn_abi_version()} vs binding {ABI_VERSION}')
     _lib = L
@@ -101,6 +113,16 @@ def aggregate(descs: Sequence[AggDesc], device) -> None:
         chunk = descs[i:i + MAX_DESCS]
         arr = (AggDesc * len(chunk))(*chunk)
         check(L.cwn_aggregate_f32(arr, len(chunk), s), 'cwn_aggregate_f32')
+
+
+def gemm(descs: Sequence[GemmDesc], device) -> None:
+    """One kernel launch for up to MAX_DESCS GEMMs; more are split into several calls."""
+    L = lib()
+    s = stream_ptr(device)
+    for i in range(0, len(descs), MAX_DESCS):
+        chunk = descs[i:i + MAX_DESCS]
+        arr = (GemmDesc * len(chunk))(*chunk)
+        check(L.cwn_gemm_f32(arr, len(chunk), s), 'cwn_gemm_f32')
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

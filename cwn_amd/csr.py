@@ -110,6 +110,20 @@ class Adjacency:
         return self._counts
 
 
+_err_flags = {}
+
+
+def _err_flag(dev) -> torch.Tensor:
+    """One sticky int32 error word per device (zeroed once, and again after it has been reported):
+    no per-call fill kernel in front of every plan build."""
+    key = (dev.type, dev.index)
+    f = _err_flags.get(key)
+    if f is None:
+        f = torch.zeros(1, dtype=torch.int32, device=dev)
+        _err_flags[key] = f
+    return f
+
+
 def build_many(adjs: Sequence[Adjacency]) -> None:
     """Build any number of adjacencies with batched C-ABI calls (<= MAX_DESCS per call; each call is
     one fixed sequence of 5-7 launches whatever the number of index tensors)."""
@@ -119,7 +133,7 @@ def build_many(adjs: Sequence[Adjacency]) -> None:
     L = _ffi.lib()
     dev = adjs[0].device
     capturing = torch.cuda.is_current_stream_capturing()
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    err = _err_flag(dev)
     for i in range(0, len(adjs), _ffi.MAX_DESCS):
         chunk = adjs[i:i + _ffi.MAX_DESCS]
         arr = (_ffi.CsrDesc * len(chunk))(*[a._desc() for a in chunk])
@@ -132,6 +146,7 @@ def build_many(adjs: Sequence[Adjacency]) -> None:
     if VALIDATE_INDICES and not capturing:
         flag = int(err.item())
         if flag:
+            err.zero_()
             what = [n for b, n in ((1, 'destination index'), (2, 'source index'),
                                    (4, 'shared (co)boundary index')) if flag & b]
             raise IndexError('index out of range in adjacency: ' + ', '.join(what))

@@ -261,23 +261,38 @@ class SparseCINCochainConv(CochainMessagePassing):
             return 'cat_linear_relu'
         return 'custom'
 
-    def _up_stream(self, adj: Adjacency, x: Tensor, up_attr, self_x=None, eps=None) -> Optional[ops.Stream]:
+    def gemm_specs(self, cochain: CochainMessagePassingParams) -> List[ops.Gemm]:
+        """The dense products the fused coboundary message needs: Y1 = X_d W[:, :F]^T + b and
+        Y2 = X_{d+1} W[:, F:]^T ([] when the message network is another form or there is no upper
+        adjacency).  SparseCINConv groups the specs of all dimensions into one MFMA launch."""
+        x, up_attr = cochain.x, cochain.kwargs.get('up_attr')
+        if (cochain.up_index is None or up_attr is None or self._up_kind() != 'cat_linear_relu'
+                or (self.aggr_up or 'add') != 'add'):
+            return []
+        lin = self.msg_up_nn[1]
+        F = x.size(1)
+        attr_src, _ = _attr_operand(up_attr)
+        if lin.in_features != F + attr_src.size(1):
+            return []
+        return [ops.Gemm(X=x, W=lin.weight[:, :F], bias=lin.bias),
+                ops.Gemm(X=attr_src, W=lin.weight[:, F:])]
+
+    def _up_stream(self, adj: Adjacency, x: Tensor, up_attr, self_x=None, eps=None,
+                   ys: Optional[List[Tensor]] = None) -> Optional[ops.Stream]:
         """The upper-adjacency aggregation as one fused stream, or None when the message network
-        is not a recognised form."""
+        is not a recognised form.  `ys` = precomputed [Y1, Y2] of gemm_specs()."""
         kind = self._up_kind()
-        width = self.up_msg_size
         if kind == 'first':
             return ops.Stream(adj=adj, n_dst=adj.n_dst, width=int(x.size(1)), A=x, self_x=self_x,
                               eps=eps, reduce=self.aggr_up or 'add')
         if kind == 'cat_linear_relu' and up_attr is not None and (self.aggr_up or 'add') == 'add':
-            lin = self.msg_up_nn[1]
-            F = x.size(1)
-            attr_src, mode = _attr_operand(up_attr)
-            if lin.in_features != F + attr_src.size(1):
-                return None
-            y1 = Fn.linear(x, lin.weight[:, :F], lin.bias)            # [N_d, F_out]
-            y2 = Fn.linear(attr_src, lin.weight[:, F:])              # [N_{d+1}, F_out] or [E, F_out]
-            return ops.Stream(adj=adj, n_dst=adj.n_dst, width=int(lin.out_features), A=y1, B=y2,
+            if ys is None:
+                specs = self.gemm_specs(CochainMessagePassingParams(x, adj, up_attr=up_attr))
+                if not specs:
+                    return None
+                ys = ops.gemm_many(specs)
+            _, mode = _attr_operand(up_attr)
+            return ops.Stream(adj=adj, n_dst=adj.n_dst, width=int(ys[0].size(1)), A=ys[0], B=ys[1],
                               msg_op=ops.MSG_RELU_A_PLUS_B, ib_mode=mode, self_x=self_x, eps=eps)
         return None
 
@@ -302,7 +317,8 @@ class SparseCINCochainConv(CochainMessagePassing):
                              ia_mode='perm', reduce=self.aggr_boundary or 'add')
 
     # ---- forward, split so that SparseCINConv can batch all dimensions into one launch ------------
-    def streams(self, cochain: CochainMessagePassingParams) -> Optional[List[ops.Stream]]:
+    def streams(self, cochain: CochainMessagePassingParams,
+                ys: Optional[List[Tensor]] = None) -> Optional[List[ops.Stream]]:
         """[upper stream, boundary stream] with the self terms folded in, or None when a message
         network is not fusable (the caller then uses `forward_unfused`)."""
         x = cochain.x
@@ -312,7 +328,7 @@ class SparseCINCochainConv(CochainMessagePassing):
         if cochain.up_index is not None:
             size = self.__check_input_separately__(cochain.up_index, None)
             up = self._up_stream(self._adjacency(cochain.up_index, 'up', size, kw), x, up_attr,
-                                 self_x=x, eps=self.eps1)
+                                 self_x=x, eps=self.eps1, ys=ys)
             if up is None:
                 return None
         else:
@@ -399,17 +415,32 @@ class SparseCINConv(torch.nn.Module):
                 update_boundaries_nn=update_boundaries_nn, combine_nn=combine_nn, eps=eps,
                 train_eps=train_eps))
 
+    def propagate_all(self, *cochain_params: CochainMessagePassingParams, start_to_process=0):
+        """Everything `propagate` does for all dimensions of this layer (the 3 propagate calls of
+        mp/layers.py:337-341, plus the self terms) in TWO launches: one grouped MFMA GEMM for the
+        coboundary-message products, one fused aggregation.  Returns (plans, outs): plans[dim] is
+        None for dimensions that are not fusable / not processed, outs holds (up, boundary) pairs
+        of the fusable ones in order."""
+        n = len(cochain_params)
+        specs, owner = [], []
+        for dim in range(start_to_process, n):
+            sp = self.mp_levels[dim].gemm_specs(cochain_params[dim])
+            specs += sp
+            owner += [dim] * len(sp)
+        ys = ops.gemm_many(specs) if specs else []
+        plans = [None] * n
+        for dim in range(start_to_process, n):
+            mine = [y for y, o in zip(ys, owner) if o == dim]
+            plans[dim] = self.mp_levels[dim].streams(cochain_params[dim], mine or None)
+        fused = [st for p in plans if p is not None for st in p]
+        outs = ops.aggregate_many(fused) if fused else []
+        return plans, outs
+
     def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0):
         assert len(cochain_params) <= self.max_dim + 1
         n = len(cochain_params)
-        # phase 1: every dimension describes its aggregation streams (tiny GEMMs for Y1 / Y2)
-        plans = [None] * n
-        for dim in range(start_to_process, n):
-            plans[dim] = self.mp_levels[dim].streams(cochain_params[dim])
-        fused = [st for p in plans if p is not None for st in p]
-        # phase 2: ONE launch for all dimensions and adjacencies
-        outs = ops.aggregate_many(fused) if fused else []
-        # phase 3: update / combine networks per dimension
+        plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
+        # update / combine networks per dimension
         out, k = [], 0
         for dim in range(n):
             if dim < start_to_process:

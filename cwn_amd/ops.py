@@ -276,3 +276,120 @@ def gather_rows(src: Tensor, idx: Tensor, adj_for_idx=None) -> Tensor:
         def adj_for_idx():
             return Adjacency.from_index(torch.stack([idx, idx]), n_src, n_src)
     return _GatherRows.apply(src, idx, adj_for_idx)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense parts: grouped fp32-MFMA GEMM (csrc/cwn_gemm.hip)
+# ------------------------------------------------------------------------------------------------
+def _rowmajor(t: Tensor, name: str) -> Tensor:
+    """2-D fp32 GPU tensor whose rows are contiguous (column slices of a Linear weight qualify)."""
+    _ffi.require_gpu(t, name)
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise TypeError(f'{name} must be a 2-D float32 tensor')
+    if t.size(1) > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.size(0) > 1 and t.stride(0) < t.size(1):
+        t = t.contiguous()
+    return t
+
+
+@dataclass
+class Gemm:
+    """Y = epilogue([X | X2] @ W^T + bias): see cwn_gemm_desc in include/cwn_hip.h."""
+    X: Tensor
+    W: Tensor                      # [N, K (+K2)], torch Linear layout (a column slice is fine)
+    bias: Optional[Tensor] = None
+    X2: Optional[Tensor] = None
+    relu: bool = False
+    out_scale: Optional[Tensor] = None   # BatchNorm (eval) folded to a per-column affine; no grad
+    out_shift: Optional[Tensor] = None
+    in_scale: Optional[Tensor] = None    # producer's BatchNorm apply (+ReLU) on the fly; no grad
+    in_shift: Optional[Tensor] = None
+    in_relu: bool = False
+    col_stats: Optional[Tensor] = None   # [2, N] fp32, zeroed by the caller: sum / sum of squares
+
+    def desc(self, Y: Tensor) -> _ffi.GemmDesc:
+        X, W, X2 = self.X, self.W, self.X2
+        K = X.size(1)
+        K2 = X2.size(1) if X2 is not None else 0
+        if W.size(1) != K + K2:
+            raise ValueError(f'weight has {W.size(1)} input columns, operands have {K + K2}')
+        if X2 is not None and X2.size(0) != X.size(0):
+            raise ValueError('X and X2 must have the same number of rows')
+        cs = self.col_stats
+        return _ffi.GemmDesc(
+            X=X.data_ptr(), X2=_ffi.ptr(X2), W=W.data_ptr(), bias=_ffi.ptr(self.bias),
+            in_scale=_ffi.ptr(self.in_scale), in_shift=_ffi.ptr(self.in_shift),
+            out_scale=_ffi.ptr(self.out_scale), out_shift=_ffi.ptr(self.out_shift),
+            col_sum=None if cs is None else cs[0].data_ptr(),
+            col_sumsq=None if cs is None else cs[1].data_ptr(),
+            Y=Y.data_ptr(), M=X.size(0), ldx=X.stride(0) if X.size(0) > 1 else max(K, 1),
+            ldx2=(X2.stride(0) if X2.size(0) > 1 else max(K2, 1)) if X2 is not None else 0,
+            ldw=W.stride(0) if W.size(0) > 1 else W.size(1), ldy=Y.stride(0) if Y.size(0) > 1 else Y.size(1),
+            N=W.size(0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu), reserved=0)
+
+
+def run_gemm(gemms: Sequence[Gemm], device) -> List[Tensor]:
+    """Raw grouped launch (no autograd)."""
+    outs, descs = [], []
+    for gm in gemms:
+        gm.X, gm.W = _rowmajor(gm.X, 'X'), _rowmajor(gm.W, 'W')
+        if gm.X2 is not None:
+            gm.X2 = _rowmajor(gm.X2, 'X2')
+        Y = torch.empty(gm.X.size(0), gm.W.size(0), dtype=torch.float32, device=device)
+        outs.append(Y)
+        if Y.numel():
+            descs.append(gm.desc(Y))
+    if descs:
+        _ffi.gemm(descs, device)
+    return outs
+
+
+class _GemmMany(torch.autograd.Function):
+    """Grouped GEMM forward on the MFMA kernel; tensor inputs flattened (X, X2, W, bias) per GEMM.
+    Backward uses library GEMMs (plain matmuls: rocBLAS) -- dX = g W, dW = g^T [X|X2], db = sum g."""
+
+    @staticmethod
+    def forward(ctx, gemms: Tuple[Gemm, ...], device, *tensors):
+        outs = run_gemm(gemms, device)
+        ctx.gemms = gemms
+        ctx.save_for_backward(*tensors, *outs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = len(ctx.gemms)
+        saved = ctx.saved_tensors
+        tensors, outs = saved[:4 * n], saved[4 * n:]
+        grads: List[Optional[Tensor]] = [None] * (4 * n)
+        for k, gm in enumerate(ctx.gemms):
+            g = gs[k]
+            if g is None:
+                continue
+            X, X2, W, bias = tensors[4 * k: 4 * k + 4]
+            nX, nX2, nW, nb = ctx.needs_input_grad[2 + 4 * k: 6 + 4 * k]
+            if gm.relu:
+                g = g * (outs[k] > 0)
+            if gm.out_scale is not None:
+                g = g * gm.out_scale
+            K = X.size(1)
+            if nX:
+                grads[4 * k] = g @ W[:, :K]
+            if nX2 and X2 is not None:
+                grads[4 * k + 1] = g @ W[:, K:]
+            if nW:
+                grads[4 * k + 2] = g.t() @ (X if X2 is None else torch.cat([X, X2], dim=1))
+            if nb and bias is not None:
+                grads[4 * k + 3] = g.sum(0)
+        return (None, None) + tuple(grads)
+
+
+def gemm_many(gemms: Sequence[Gemm]) -> List[Tensor]:
+    """All GEMMs in ONE launch (per <= 8); differentiable w.r.t. X, X2, W, bias."""
+    flat: List[Optional[Tensor]] = []
+    device = gemms[0].X.device
+    for gm in gemms:
+        if gm.in_scale is not None and torch.is_grad_enabled() and gm.X.requires_grad:
+            raise NotImplementedError('the input-affine prologue has no backward; apply it outside')
+        flat += [gm.X, gm.X2, gm.W, gm.bias]
+    return list(_GemmMany.apply(tuple(gemms), device, *flat))

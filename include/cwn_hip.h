@@ -149,6 +149,44 @@ typedef struct cwn_agg_desc {
 
 int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Dense parts of the path on the matrix cores (fp32 MFMA, exact fp32):
+ *
+ *     Y = epilogue( prologue([X | X2]) . W^T + bias )         up to CWN_MAX_DESCS GEMMs per launch
+ *
+ * Replaces the torch.nn.Linear (+ BatchNorm1d + ReLU) calls of the message / update / combine
+ * networks: msg_up_nn's Linear(2F->F) (mp/layers.py:290-293, evaluated as Y1 = X_d W[:, :F]^T + b
+ * and Y2 = X_{d+1} W[:, F:]^T), update_up_nn / update_boundaries_nn (:303-321), combine_nn
+ * (:322-325, whose torch.cat (:199) becomes the K-concatenation [X | X2]).
+ *   X [M, K] (row stride ldx), X2 [M, K2] optional, W [N, K + K2] (row stride ldw, torch Linear
+ *   layout), Y [M, N] (row stride ldy).
+ *   prologue (optional): x <- x * in_scale[k] + in_shift[k], then ReLU if in_relu  (BatchNorm
+ *                        apply of the producing layer), first input only;
+ *   epilogue: + bias[n]; per-column sum / sum of squares of that value accumulated with atomics
+ *             into col_sum / col_sumsq (BatchNorm batch statistics; caller zeroes them);
+ *             then * out_scale[n] + out_shift[n] (BatchNorm eval), then ReLU if relu.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cwn_gemm_desc {
+    const float* X;
+    const float* X2;        /* or NULL */
+    const float* W;
+    const float* bias;      /* [N] or NULL */
+    const float* in_scale;  /* [K] or NULL */
+    const float* in_shift;  /* [K] or NULL */
+    const float* out_scale; /* [N] or NULL */
+    const float* out_shift; /* [N] or NULL */
+    float* col_sum;         /* [N] or NULL */
+    float* col_sumsq;       /* [N] or NULL */
+    float* Y;
+    int64_t M;
+    int64_t ldx, ldx2, ldw, ldy;
+    int32_t N, K, K2;
+    int32_t relu, in_relu;
+    int32_t reserved;
+} cwn_gemm_desc;
+
+int cwn_gemm_f32(const cwn_gemm_desc* descs_host, int n, cwn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

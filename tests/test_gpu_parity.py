@@ -566,3 +566,95 @@ def test_sparse_cin_layer_full_size_vs_oracle(zinc128):
                               training=True)
     for o, r in zip(outs, oouts):
         torch.testing.assert_close(cpu(o), r, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# grouped fp32-MFMA GEMM (dense parts) against torch matmul in float64
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (33, 128, 128), (3341, 128, 128), (100, 64, 64), (77, 130, 24),
+                                   (50, 16, 10), (5, 256, 128), (0, 128, 128), (1000, 128, 256)])
+def test_gemm_matches_float64(M, N, K):
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = (X.double() @ W.double().t() + b.double())
+    Y, Yr = ops.run_gemm([ops.Gemm(X=X.to(DEV), W=W.to(DEV), bias=b.to(DEV)),
+                          ops.Gemm(X=X.to(DEV), W=W.to(DEV), bias=b.to(DEV), relu=True)], DEV)
+    torch.testing.assert_close(cpu(Y).double(), ref, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(cpu(Yr).double(), ref.clamp(min=0), rtol=1e-5, atol=2e-5)
+
+
+def test_gemm_grouped_concat_affine_stats():
+    """Several GEMMs in one launch; weight column slices (ldw > K); K-concatenation; input affine +
+    ReLU prologue; output affine epilogue; BatchNorm column statistics."""
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    F = 128
+    Wfull = (torch.randn(F, 2 * F, generator=g) / 16).to(DEV)
+    bias = torch.randn(F, generator=g).to(DEV)
+    X0, X1 = torch.randn(3165, F, generator=g).to(DEV), torch.randn(304, F, generator=g).to(DEV)
+    Xa, Xb = torch.randn(500, F, generator=g).to(DEV), torch.randn(500, F, generator=g).to(DEV)
+    isc, ish = torch.rand(F, generator=g).to(DEV) + 0.5, torch.randn(F, generator=g).to(DEV)
+    osc, osh = torch.rand(F, generator=g).to(DEV) + 0.5, torch.randn(F, generator=g).to(DEV)
+    stats = torch.zeros(2, F, device=DEV)
+    outs = ops.run_gemm([
+        ops.Gemm(X=X0, W=Wfull[:, :F], bias=bias),
+        ops.Gemm(X=X1, W=Wfull[:, F:]),
+        ops.Gemm(X=Xa, X2=Xb, W=Wfull, bias=bias, relu=True, out_scale=osc, out_shift=osh),
+        ops.Gemm(X=Xa, W=Wfull[:, :F], bias=bias, in_scale=isc, in_shift=ish, in_relu=True,
+                 col_stats=stats),
+    ], DEV)
+    d = lambda t: t.double()
+    refs = [d(X0) @ d(Wfull[:, :F]).t() + d(bias), d(X1) @ d(Wfull[:, F:]).t(),
+            ((d(torch.cat([Xa, Xb], 1)) @ d(Wfull).t() + d(bias)) * d(osc) + d(osh)).clamp(min=0),
+            (d(Xa) * d(isc) + d(ish)).clamp(min=0) @ d(Wfull[:, :F]).t() + d(bias)]
+    for o, r in zip(outs, refs):
+        torch.testing.assert_close(d(o), r, rtol=1e-5, atol=3e-5)
+    torch.testing.assert_close(d(stats[0]), refs[3].sum(0), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(d(stats[1]), (refs[3] ** 2).sum(0), rtol=1e-4, atol=1e-2)
+
+
+def test_gemm_transpose_detecting_identity():
+    """A = I with an asymmetric B: a swapped output layout cannot pass."""
+    from cwn_amd import ops
+    W = torch.arange(48 * 32, dtype=torch.float32).view(48, 32).to(DEV)     # N=48, K=32
+    X = torch.eye(32, device=DEV)
+    Y, = ops.run_gemm([ops.Gemm(X=X, W=W)], DEV)
+    assert torch.equal(Y, W.t())
+
+
+def test_gemm_autograd_matches_linear():
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(9)
+    lin = torch.nn.Linear(256, 128).to(DEV)
+    Xa = torch.randn(700, 128, generator=g).to(DEV).requires_grad_(True)
+    Xb = torch.randn(300, 128, generator=g).to(DEV).requires_grad_(True)
+    y1, y2 = ops.gemm_many([ops.Gemm(X=Xa, W=lin.weight[:, :128], bias=lin.bias, relu=True),
+                            ops.Gemm(X=Xb, W=lin.weight[:, 128:])])
+    w1, w2 = torch.randn_like(y1), torch.randn_like(y2)
+    ((y1 * w1).sum() + (y2 * w2).sum()).backward()
+    got = [Xa.grad.clone(), Xb.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    for t in (Xa, Xb, lin.weight, lin.bias):
+        t.grad = None
+    r1 = torch.relu(torch.nn.functional.linear(Xa, lin.weight[:, :128], lin.bias))
+    r2 = torch.nn.functional.linear(Xb, lin.weight[:, 128:])
+    ((r1 * w1).sum() + (r2 * w2).sum()).backward()
+    for a, b in zip(got, [Xa.grad, Xb.grad, lin.weight.grad, lin.bias.grad]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_csr_small_path_with_hub_row():
+    """Single-launch LDS path (fits 150 KiB) with one row holding half of the entries."""
+    from cwn_amd.csr import Adjacency
+    g = torch.Generator().manual_seed(11)
+    n = 100
+    dst = torch.cat([torch.full((3000,), 42), torch.randint(0, n, (3000,), generator=g)])
+    dst = dst[torch.randperm(dst.numel(), generator=g)]
+    src = torch.randint(0, 77, (dst.numel(),), generator=g)
+    aux = torch.randint(0, 9, (dst.numel(),), generator=g)
+    idx = torch.stack([src, dst])
+    adj = Adjacency.from_index(idx.to(DEV), n, 77, aux.to(DEV), 9)
+    _check_adj(adj, idx, n, aux)
+    _check_adj(adj.t_src, idx.flip(0), 77, aux)
