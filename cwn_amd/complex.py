@@ -310,10 +310,12 @@ class Complex(object):
         return self
 
     # ---- engine extension: convert every adjacency once per batch -----------------------------
-    def prepare(self, max_dim: int = 2, include_down: bool = False, backward: bool = False):
+    def prepare(self, max_dim: int = 2, include_down: bool = False, backward: bool = False,
+                overlap: bool = False):
         """Build the int32 CSR plans of all upper / boundary (and optionally lower) adjacencies with
         one batched call and register them in the plan cache `propagate` looks up.  Optional: a
-        propagate call on an unprepared complex builds its plans on first use."""
+        propagate call on an unprepared complex builds its plans on first use.  `overlap=True`
+        runs the build on a side stream (see csr.build_many)."""
         from .csr import build_many, cached_adjacency
         todo = []
         for dim in range(min(max_dim, self.dimension) + 1):
@@ -334,7 +336,7 @@ class Complex(object):
                 if backward:
                     adj.transposes()
                     todo += [t for t in (adj._t_src, adj._t_aux) if t is not None]
-        build_many(todo)
+        build_many(todo, overlap=overlap)
         return self
 
     # ---- propagate arguments ------------------------------------------------------------------

@@ -45,6 +45,7 @@ class Adjacency:
         self.aux = (torch.empty(self.n_entries, dtype=torch.int32, device=dev)
                     if aux_index is not None else None)
         self.built = False
+        self.ready = None     # torch.cuda.Event when the plan was built on a side stream
         self._t_src: Optional['Adjacency'] = None
         self._t_aux: Optional['Adjacency'] = None
         self._counts: Optional[torch.Tensor] = None
@@ -124,14 +125,50 @@ def _err_flag(dev) -> torch.Tensor:
     return f
 
 
-def build_many(adjs: Sequence[Adjacency]) -> None:
+_side_streams = {}
+
+
+def side_stream(dev) -> torch.cuda.Stream:
+    key = (dev.type, dev.index)
+    s = _side_streams.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _side_streams[key] = s
+    return s
+
+
+def wait_ready(adjs) -> None:
+    """Make the current stream wait for plans that were built on the side stream (no-op otherwise)."""
+    for a in adjs:
+        if a is not None and a.ready is not None:
+            torch.cuda.current_stream(a.device).wait_event(a.ready)
+            a.ready = None
+
+
+def build_many(adjs: Sequence[Adjacency], overlap: bool = False, validate: bool = True) -> None:
     """Build any number of adjacencies with batched C-ABI calls (<= MAX_DESCS per call; each call is
-    one fixed sequence of 5-7 launches whatever the number of index tensors)."""
+    one launch for small inputs, a fixed sequence of 5-7 launches otherwise, whatever the number of
+    index tensors).  `overlap=True` enqueues the build on a side stream and tags every plan with
+    an event that the first aggregation using it waits on, so the integer work runs underneath
+    whatever dense work the caller issues next (the layer-0 message GEMMs)."""
     adjs = [a for a in adjs if not a.built]
     if not adjs:
         return
-    L = _ffi.lib()
     dev = adjs[0].device
+    if overlap:
+        main, side = torch.cuda.current_stream(dev), side_stream(dev)
+        side.wait_stream(main)          # the index tensors were produced on the main stream
+        with torch.cuda.stream(side):
+            build_many(adjs, overlap=False, validate=False)   # no host sync; see check_errors()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for a in adjs:
+            a.ready = ev
+            for t in (a.rowptr, a.col, a.perm, a.aux):
+                if t is not None:
+                    t.record_stream(main)
+        return
+    L = _ffi.lib()
     capturing = torch.cuda.is_current_stream_capturing()
     err = _err_flag(dev)
     for i in range(0, len(adjs), _ffi.MAX_DESCS):
@@ -143,13 +180,25 @@ def build_many(adjs: Sequence[Adjacency]) -> None:
                                    _ffi.stream_ptr(dev)), 'cwn_csr_build')
         for a in chunk:
             a.built = True
-    if VALIDATE_INDICES and not capturing:
+    if VALIDATE_INDICES and validate and not capturing:
         flag = int(err.item())
         if flag:
             err.zero_()
             what = [n for b, n in ((1, 'destination index'), (2, 'source index'),
                                    (4, 'shared (co)boundary index')) if flag & b]
             raise IndexError('index out of range in adjacency: ' + ', '.join(what))
+
+
+def check_errors(dev) -> None:
+    """Raise the IndexError of any out-of-range index seen by plan builds that skipped the host
+    sync (overlap mode / stream capture).  One device sync."""
+    err = _err_flag(torch.device(dev))
+    flag = int(err.item())
+    if flag:
+        err.zero_()
+        what = [n for b, n in ((1, 'destination index'), (2, 'source index'),
+                               (4, 'shared (co)boundary index')) if flag & b]
+        raise IndexError('index out of range in adjacency: ' + ', '.join(what))
 
 
 # ---- cache keyed on the identity of the reference-style index tensor ---------------------------

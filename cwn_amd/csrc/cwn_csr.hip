@@ -200,7 +200,7 @@ constexpr size_t kSmallLdsBytes = 150 * 1024;
 __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(CsrBatch B, int32_t* err) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ int scan_tmp[32];
-    constexpr int U = 4;   // independent global loads in flight per thread and phase
+    constexpr int U = 8;   // independent global loads in flight per thread and phase
     const int di = blockIdx.x;
     const cwn_csr_desc& D = B.d[di];
     const int n = (int)D.n_dst, E = (int)D.n_entries;

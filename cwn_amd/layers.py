@@ -79,6 +79,46 @@ def _is_cat_linear_relu(nn) -> bool:
             and isinstance(nn[1], Linear) and isinstance(nn[2], ReLU))
 
 
+def _fold_norm(norm, width: int):
+    """Eval-mode normalisation as a per-column affine (scale, shift) for the GEMM epilogue:
+    BatchNorm1d with running statistics -> (w / sqrt(rv + eps), b - rm * scale); Identity ->
+    (None, None).  Cached on the module and refreshed when any of its tensors changes.
+    Returns None when the module cannot be folded (LayerNorm, BatchNorm without running stats)."""
+    if isinstance(norm, torch.nn.Identity):
+        return (None, None)
+    if (not isinstance(norm, BN) or norm.training or norm.running_mean is None
+            or norm.num_features != width):
+        return None     # batch statistics (training) are not a fixed affine
+    tensors = [t for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var) if t is not None]
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    hit = getattr(norm, '_cwn_fold', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        scale = torch.rsqrt(norm.running_var + norm.eps)
+        if norm.weight is not None:
+            scale = scale * norm.weight
+        shift = -norm.running_mean * scale
+        if norm.bias is not None:
+            shift = shift + norm.bias
+        fold = (scale.contiguous(), shift.contiguous())
+    norm._cwn_fold = (key, fold)
+    return fold
+
+
+def _mlp_stages(nn):
+    """[(Linear, norm), ...] of a Sequential of (Linear, norm, ReLU) groups, or None."""
+    if not isinstance(nn, Sequential) or len(nn) % 3 != 0 or len(nn) == 0:
+        return None
+    stages = []
+    for i in range(0, len(nn), 3):
+        lin, norm, act = nn[i], nn[i + 1], nn[i + 2]
+        if not (isinstance(lin, Linear) and isinstance(act, ReLU)):
+            return None
+        stages.append((lin, norm))
+    return stages
+
+
 # ------------------------------------------------------------------------------------------------
 # test / toy layers
 # ------------------------------------------------------------------------------------------------
@@ -436,10 +476,61 @@ class SparseCINConv(torch.nn.Module):
         outs = ops.aggregate_many(fused) if fused else []
         return plans, outs
 
+    def _dense_eval(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
+        """The update / combine networks of ALL dimensions (mp/layers.py:193-199) as three grouped
+        MFMA launches -- [Linear+norm+ReLU] x2 for both branches, then combine with its torch.cat
+        folded into the K-concatenation -- with eval-mode BatchNorm folded into the epilogue.
+        Inference only (no autograd, running statistics); returns None when it does not apply and
+        the caller runs the torch modules instead."""
+        if torch.is_grad_enabled():
+            return None
+        active = list(range(start, len(plans)))
+        if not active or any(plans[d] is None for d in active) or len(outs) != 2 * len(active):
+            return None
+        levels = [self.mp_levels[d] for d in active]
+        chains = []
+        for lvl in levels:
+            up, bd, cb = (_mlp_stages(lvl.update_up_nn), _mlp_stages(lvl.update_boundaries_nn),
+                          _mlp_stages(lvl.combine_nn))
+            if up is None or bd is None or cb is None or len(up) != len(bd) or len(cb) != 1:
+                return None
+            folds = []
+            for stages in (up, bd, cb):
+                fs = [_fold_norm(norm, lin.out_features) for lin, norm in stages]
+                if any(f is None for f in fs):
+                    return None
+                folds.append(fs)
+            chains.append((up, bd, cb, folds))
+        dev = outs[0].device
+        hs_up = [outs[2 * i] for i in range(len(levels))]
+        hs_bd = [outs[2 * i + 1] for i in range(len(levels))]
+        depth = len(chains[0][0])
+        if any(len(c[0]) != depth for c in chains):
+            return None
+        for st in range(depth):
+            gemms = []
+            for i, (up, bd, cb, folds) in enumerate(chains):
+                for hs, stages, fs in ((hs_up, up, folds[0]), (hs_bd, bd, folds[1])):
+                    lin = stages[st][0]
+                    gemms.append(ops.Gemm(X=hs[i], W=lin.weight, bias=lin.bias, relu=True,
+                                          out_scale=fs[st][0], out_shift=fs[st][1]))
+            res = ops.run_gemm(gemms, dev)
+            hs_up, hs_bd = res[0::2], res[1::2]
+        gemms = []
+        for i, (up, bd, cb, folds) in enumerate(chains):
+            lin = cb[0][0]
+            gemms.append(ops.Gemm(X=hs_up[i], X2=hs_bd[i], W=lin.weight, bias=lin.bias, relu=True,
+                                  out_scale=folds[2][0][0], out_shift=folds[2][0][1]))
+        return ops.run_gemm(gemms, dev)
+
     def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0):
         assert len(cochain_params) <= self.max_dim + 1
         n = len(cochain_params)
         plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
+        dense = self._dense_eval(plans, outs, start_to_process)
+        if dense is not None:
+            it = iter(dense)
+            return [cochain_params[dim].x if dim < start_to_process else next(it) for dim in range(n)]
         # update / combine networks per dimension
         out, k = [], 0
         for dim in range(n):

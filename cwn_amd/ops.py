@@ -13,7 +13,7 @@ import torch
 from torch import Tensor
 
 from . import _ffi
-from .csr import Adjacency
+from .csr import Adjacency, wait_ready
 
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 
@@ -63,6 +63,7 @@ def run_aggregate(specs: Sequence[AggSpec], device) -> List[Tensor]:
             s.out = torch.empty(s.n_dst, s.F, dtype=torch.float32, device=device)
     live = [s for s in specs if s.n_dst > 0]
     if live:
+        wait_ready([s.adj for s in live])      # plans built on the side stream (csr.build_many)
         _ffi.aggregate([s.desc() for s in live], device)
     return [s.out for s in specs]
 

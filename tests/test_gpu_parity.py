@@ -658,3 +658,51 @@ def test_csr_small_path_with_hub_row():
     adj = Adjacency.from_index(idx.to(DEV), n, 77, aux.to(DEV), 9)
     _check_adj(adj, idx, n, aux)
     _check_adj(adj.t_src, idx.flip(0), 77, aux)
+
+
+def test_overlapped_plan_build_and_deferred_index_check():
+    """Plans built on the side stream give the same results; index errors surface in check_errors."""
+    from cwn_amd import csr
+    g = load('sparse_cin_conv.npz')
+    tag = 'mol_cob_bn'
+    conv = _sparse_cin(tag, g).eval()
+    b = dummy_batch([str(n) for n in g[f'{tag}/names']], max_dim=2, device=DEV)
+    for d in range(3):
+        b.cochains[d].x = T(g[f'{tag}/x/{d}']).to(DEV)
+    csr._cache.clear()
+    b.prepare(overlap=True)
+    with torch.no_grad():
+        outs = conv(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+    for d, o in enumerate(outs):
+        torch.testing.assert_close(cpu(o), T(g[f'{tag}/eval/{d}']), rtol=1e-5, atol=1e-5)
+    csr.check_errors(DEV)
+    bad = torch.tensor([[0, 1, 7], [1, 0, 2]], device=DEV)
+    adj = csr.Adjacency.from_index(bad, 3, 3, build=False)
+    csr.build_many([adj], overlap=True)
+    with pytest.raises(IndexError, match='source index'):
+        csr.check_errors(DEV)
+
+
+def test_fused_dense_eval_path_is_taken_and_matches_modules():
+    """Eval + no_grad: update / combine MLPs run as grouped MFMA GEMMs with folded BatchNorm; the
+    result equals the torch-module path (grad enabled) and the golden vectors."""
+    g = load('sparse_cin_conv.npz')
+    for tag in ('mol_cob_bn_64', 'test_cob_id'):
+        conv = _sparse_cin(tag, g).eval()
+        b = dummy_batch([str(n) for n in g[f'{tag}/names']], max_dim=2, device=DEV)
+        for d in range(3):
+            b.cochains[d].x = T(g[f'{tag}/x/{d}']).to(DEV)
+        prms = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+        with torch.no_grad():
+            plans, outs = conv.propagate_all(*prms)
+            assert conv._dense_eval(plans, outs, 0) is not None
+            fused = conv(*prms)
+        modules = conv(*prms)            # grad enabled -> torch modules
+        for d in range(3):
+            torch.testing.assert_close(fused[d], modules[d].detach(), rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(cpu(fused[d]), T(g[f'{tag}/eval/{d}']), rtol=1e-5, atol=1e-5)
+        conv.train()
+        with torch.no_grad():
+            plans, outs = conv.propagate_all(*prms)
+            took = conv._dense_eval(plans, outs, 0)
+        assert (took is None) == (tag == 'mol_cob_bn_64')    # BN in training mode is not folded
