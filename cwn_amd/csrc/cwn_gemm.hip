@@ -10,14 +10,16 @@
 //   store per lane per tile, bias / scale / shift are 16-B loads.
 // * K is walked in slabs of 16; inside a slab lane group g = lane>>4 owns k = 4g..4g+3, so both
 //   MFMA fragments are one 16-B read per lane; MFMA step s multiplies the s-th component.
-// * tiles go through LDS: a block stages a 32-row X tile and the 128-row W tile (K chunk of 128,
-//   80 KiB) with row-contiguous, fully coalesced 16-B global reads (a fragment-shaped global load
-//   touches 16 different rows per quarter-wave and is bound by the per-CU address unit: measured
-//   14-17 us vs the 4 us of this form on the ZINC-128 shape), stores them XOR-swizzled
-//   (chunk ^ (row & 15)) and reads fragments with conflict-free ds_read_b128.
-// * blocks are persistent over their descriptor's M tiles, so the W tile is staged once per block
-//   (N <= 128, K <= 128: the shape of every GEMM on the path); at M ~ 1e4 rows the grid is one
-//   tile per block and fills the 256 CUs.
+// * WEIGHTS STATIONARY: each wave keeps the W fragments of its 32 output columns for the whole K in
+//   registers (64 VGPRs at K <= 128) across all tiles of a persistent block; LDS only
+//   double-buffers the 32-row X tile (2 x 16 KiB), so there is ONE barrier per tile and three
+//   blocks fit a CU.  (With the 64-KiB W tile in LDS only two waves per SIMD fit and the MFMA
+//   pipe measured 56 % busy on the 650 k-row shape.)
+// * X tiles (and W, once per block, through the same LDS buffer) are read from global memory
+//   row-contiguously -- a fragment-shaped global load touches 16 different rows per quarter-wave
+//   and is bound by the per-CU address unit (measured 14-17 us vs 4 on the ZINC-128 shape) --
+//   stored XOR-swizzled (chunk ^ (row & 15)) and read back with conflict-free ds_read_b128.
+//   The next tile's loads are in flight during the current tile's MFMAs.
 // * block = 4 waves = 32 rows x 128 columns; each wave 32 x 32 (2 x 2 MFMA tiles, 16 acc VGPRs).
 // * optional fused pieces: K-concatenation of two inputs (combine_nn's cat), per-input-column
 //   affine + ReLU prologue (BatchNorm apply of the producing layer), bias, per-output-column
@@ -33,10 +35,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
 constexpr int BM = 32;    // rows per tile
 constexpr int BN = 128;   // columns per tile (4 waves x 32)
-constexpr int BK = 128;   // K chunk staged in LDS (one 512-B row per tile row)
 constexpr int RT = 2;     // 16-row MFMA tiles per wave
 constexpr int CT = 2;     // 16-col MFMA tiles per wave
-constexpr int kLdsBytes = (BM + BN) * BK * 4;   // 80 KiB: X tile + W tile
+constexpr int kMaxK = 256;  // K + K2 supported (the W tile of the whole K stays in LDS)
 
 struct GemmBatch {
     cwn_gemm_desc d[CWN_MAX_DESCS];
@@ -47,40 +48,42 @@ struct GemmBatch {
     int32_t n;
 };
 
-// LDS image of a tile: row r (512 B) holds 32 chunks of 16 B; chunk c is stored at chunk position
-// c ^ (r & 15).  Fragment reads (16 lanes = 16 different rows, same chunk) then hit 16 different
-// 16-B slots of the 256-B bank row: ds_read_b128 is conflict-free (MI355X_MICROARCH.md, LDS).
+// LDS image of a tile: a row holds KP floats (KP = 128 or 256) = KP/4 chunks of 16 B; chunk c of
+// row r is stored at chunk position c ^ (r & 15).  Fragment reads (16 lanes = 16 different rows,
+// same chunk) then hit 16 different 16-B slots of the 256-B bank row: ds_read_b128 is
+// conflict-free (MI355X_MICROARCH.md, LDS).
+template <int KP>
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // in floats
-    return row * BK + ((chunk ^ (row & 15)) << 2);
+    return row * KP + ((chunk ^ (row & 15)) << 2);
 }
 
-// Staging of a `ROWS` x BK tile, columns [k0, k0+BK) of the (possibly K-concatenated) matrix, in
-// two phases so that EVERY global load of the block's tiles (16 per thread for W, 4 for X) is in
-// flight before the first LDS write.  Global reads are row-contiguous: 32 consecutive lanes read
-// one full 512-B row.
-template <int ROWS>
+// A ROWS x KP tile in registers between its global loads and its LDS stores, so that every load
+// is in flight before the first store (and, for X, during the previous tile's MFMAs).
+template <int ROWS, int KP>
 struct Staged {
-    static constexpr int U = ROWS * (BK / 4) / kThreads;
+    static constexpr int U = ROWS * (KP / 4) / kThreads;
     f32x4 v[U];
 };
 
-template <bool FAST, bool PRO, int ROWS>
-__device__ __forceinline__ void stage_load(Staged<ROWS>& st, int64_t row0, int64_t row_max,
+// Global reads are row-contiguous: KP/4 consecutive lanes read one full row of the tile.
+template <bool FAST, int ROWS, int KP, int U0, int U1>
+__device__ __forceinline__ void stage_load(Staged<ROWS, KP>& st, int64_t row0, int64_t row_max,
                                            const float* __restrict__ P1, int64_t ld1, int K1,
-                                           const float* __restrict__ P2, int64_t ld2, int K2, int k0) {
+                                           const float* __restrict__ P2, int64_t ld2, int K2) {
+    constexpr int CPR = KP / 4;   // chunks per row
 #pragma unroll
-    for (int u = 0; u < Staged<ROWS>::U; ++u) {
+    for (int u = U0; u < U1; ++u) {
         const int q = u * kThreads + threadIdx.x;
-        const int r = q >> 5, c = q & 31;
+        const int r = q / CPR, c = q % CPR;
         const int64_t grow = row0 + r < row_max ? row0 + r : row_max - 1;   // clamped, never faults
-        const int k = k0 + 4 * c;
+        const int k = 4 * c;
         const bool second = K2 > 0 && k >= K1;   // never touch P2 when there is no second input
         const float* base = second ? P2 : P1;
         const int64_t ld = second ? ld2 : ld1;
         const int kk = second ? k - K1 : k;
         const int kmax = second ? K2 : K1;
         if constexpr (FAST) {
-            // kmax % 4 == 0; the column is clamped into range, the zeroing happens at store time
+            // kmax % 4 == 0; the column is clamped into range, zeroing happens at store time
             st.v[u] = *reinterpret_cast<const f32x4*>(base + grow * ld + (kk < kmax ? kk : 0));
         } else {
 #pragma unroll
@@ -89,16 +92,17 @@ __device__ __forceinline__ void stage_load(Staged<ROWS>& st, int64_t row0, int64
     }
 }
 
-template <bool FAST, bool PRO, int ROWS>
-__device__ __forceinline__ void stage_store(float* lds, Staged<ROWS>& st, int K1, int K2, int k0,
+template <bool PRO, int ROWS, int KP, int U0, int U1>
+__device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, int K1, int K2,
                                             const float* __restrict__ in_scale,
                                             const float* __restrict__ in_shift, bool in_relu) {
+    constexpr int CPR = KP / 4;
 #pragma unroll
-    for (int u = 0; u < Staged<ROWS>::U; ++u) {
+    for (int u = U0; u < U1; ++u) {
         const int q = u * kThreads + threadIdx.x;
-        const int r = q >> 5, c = q & 31;
-        const int k = k0 + 4 * c;
-        const bool second = K2 > 0 && k >= K1;   // never touch P2 when there is no second input
+        const int r = q / CPR, c = q % CPR;
+        const int k = 4 * c;
+        const bool second = K2 > 0 && k >= K1;
         const int kk = second ? k - K1 : k;
         const int kmax = second ? K2 : K1;
         f32x4 v = st.v[u];
@@ -113,15 +117,13 @@ __device__ __forceinline__ void stage_store(float* lds, Staged<ROWS>& st, int K1
             }
             v[t] = kk + t < kmax ? x : 0.f;
         }
-        *reinterpret_cast<f32x4*>(lds + lds_off(r, c)) = v;
+        *reinterpret_cast<f32x4*>(lds + lds_off<KP>(r, c)) = v;
     }
 }
 
-template <bool FAST, bool PRO>
-__global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch B) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ldsX = smem;               // [BM][BK]
-    float* ldsW = smem + BM * BK;     // [BN][BK]
+template <bool FAST, bool PRO, int KP>
+__global__ __launch_bounds__(kThreads, (KP == 128 ? 3 : 1)) void gemm_kernel(GemmBatch B) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // two [BM][KP] X buffers
     int di = 0;
 #pragma unroll
     for (int i = 1; i < CWN_MAX_DESCS; ++i)
@@ -141,55 +143,84 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch B) {
     const float* const in_scale = D.in_scale;
     const float* const in_shift = D.in_shift;
     const bool in_relu = D.in_relu != 0;
-    const int kchunks = (Ktot + BK - 1) / BK;
+    const int dbg = D.reserved;   // timing experiments (tools/ubench_gemm.py): 1 no MFMA, 2 no W staging, 4 no store
+    constexpr int SLABS = KP / 16;
+    using SX = Staged<BM, KP>;                 // a 32-row tile in flight: KP/32 x 16 B per thread
 
-    // persistent over the descriptor's tiles, tile_n-major so that consecutive iterations of a
-    // block reuse the W tile already in LDS (always, when N <= 128 and K <= 128)
+    // WEIGHTS STATIONARY: the wave's W fragments for the whole K (its 32 output columns) live in
+    // registers for all tiles of the persistent loop (KP/2 VGPRs), so LDS only double-buffers the
+    // 32-row X tile: one barrier per tile, 32 KiB (K <= 128) per block, three blocks per CU.
+    f32x4 wreg[SLABS][CT];
+
+    // Persistent over the descriptor's tiles, tile_n-major: a block keeps its tile_n (always, when
+    // N <= 128) and reloads W only when it changes.
+    int tile = blockIdx.x - B.blk_start[di];
     int cur_tn = -1;
-    for (int tile = blockIdx.x - B.blk_start[di]; tile < tiles; tile += nblk) {
+    int it = 0;
+    SX sx;
+    if (tile < tiles)
+        stage_load<FAST, BM, KP, 0, SX::U>(sx, (int64_t)(tile / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
+    for (; tile < tiles; tile += nblk, ++it) {
         const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
         const int64_t m_base = (int64_t)tile_m * BM;
         const int n_base = tile_n * BN + wave * (CT * 16);
+
+        if (cur_tn != tile_n && !(dbg & 2)) {
+            // W rows [32p, 32p+32) of this column tile go through LDS buffer 1 with coalesced
+            // row-contiguous reads; wave p then lifts its fragments into registers.
+            // all four passes' global loads are issued before the first LDS store
+            SX sw[BN / BM];
+#pragma unroll
+            for (int p = 0; p < BN / BM; ++p)
+                stage_load<FAST, BM, KP, 0, SX::U>(sw[p], (int64_t)tile_n * BN + p * BM, N, Wp, ldw, Ktot,
+                                                   nullptr, 0, 0);
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < BN / BM; ++p) {
+                stage_store<false, BM, KP, 0, SX::U>(smem + BM * KP, sw[p], Ktot, 0, nullptr, nullptr, false);
+                __syncthreads();
+                if (wave == p) {
+#pragma unroll
+                    for (int sl = 0; sl < SLABS; ++sl)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            wreg[sl][ct] = *reinterpret_cast<const f32x4*>(
+                                smem + BM * KP + lds_off<KP>(ct * 16 + j, 4 * sl + g));
+                }
+                __syncthreads();
+            }
+            cur_tn = tile_n;
+            it = 0;   // buffer parity restarts; buffer 1 was just used for W
+        }
+        float* ldsX = smem + (it & 1) * (BM * KP);
+        stage_store<PRO, BM, KP, 0, SX::U>(ldsX, sx, K1, K2, in_scale, in_shift, in_relu);
+        __syncthreads();                     // tile visible; everyone is done with the other buffer
+        const int next = tile + nblk;
+        if (next < tiles)                    // in flight during the MFMAs below
+            stage_load<FAST, BM, KP, 0, SX::U>(sx, (int64_t)(next / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
 
         f32x4 acc[CT][RT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[ct][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        for (int kc = 0; kc < kchunks; ++kc) {
-            const int k0 = kc * BK;
-            const bool need_w = kchunks > 1 || cur_tn != tile_n;
-            Staged<BN> sw;
-            Staged<BM> sx;
-            if (need_w)
-                stage_load<FAST, false, BN>(sw, (int64_t)tile_n * BN, N, Wp, ldw, Ktot, nullptr, 0, 0, k0);
-            stage_load<FAST, PRO, BM>(sx, m_base, M, Xp, ldx, K1, X2p, ldx2, K2, k0);
-            __syncthreads();                     // previous readers of the LDS tiles are done
-            if (need_w) stage_store<FAST, false, BN>(ldsW, sw, Ktot, 0, k0, nullptr, nullptr, false);
-            stage_store<FAST, PRO, BM>(ldsX, sx, K1, K2, k0, in_scale, in_shift, in_relu);
-            __syncthreads();
-            const int kslabs = (min(BK, Ktot - k0) + 15) / 16;
-            for (int sl = 0; sl < kslabs; ++sl) {
-                f32x4 w[CT], x[RT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    w[ct] = *reinterpret_cast<const f32x4*>(
-                        ldsW + lds_off(wave * (CT * 16) + ct * 16 + j, 4 * sl + g));
+        for (int sl = 0; sl < SLABS; ++sl) {
+            if (sl * 16 < Ktot && !(dbg & 1)) {   // wave-uniform; slabs past K hold zeros anyway
+                f32x4 x[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    x[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off(rt * 16 + j, 4 * sl + g));
+                    x[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(rt * 16 + j, 4 * sl + g));
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
-                            acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][t], x[rt][t],
-                                                                               acc[ct][rt], 0, 0, 0);
+                            acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                wreg[sl][ct][t], x[rt][t], acc[ct][rt], 0, 0, 0);
             }
         }
-        cur_tn = tile_n;
 
         // epilogue: acc[ct][rt][r] = Y[m_base + rt*16 + j][n_base + ct*16 + 4g + r]
         bool xok[RT];
@@ -229,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch B) {
                     y = y * sc[r] + sh[r];
                     v[r] = D.relu ? fmaxf(y, 0.f) : y;
                 }
-                if (!xok[rt]) continue;
+                if (!xok[rt] || (dbg & 4)) continue;
                 float* yp = D.Y + xrow[rt] * ldy + n0;
                 if (full && vec) {
                     *reinterpret_cast<f32x4*>(yp) = v;
@@ -271,6 +302,7 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
     for (int i = 0; i < n; ++i) {
         const cwn_gemm_desc& D = descs[i];
         if (D.M < 0 || D.N <= 0 || D.K <= 0 || D.K2 < 0) return CWN_ERR_BAD_ARG;
+        if (D.K + D.K2 > kMaxK) return CWN_ERR_TOO_LARGE;   // the whole-K W tile must fit in LDS
         if (D.M > 0 && (D.X == nullptr || D.W == nullptr || D.Y == nullptr)) return CWN_ERR_BAD_ARG;
         if (D.K2 > 0 && (D.X2 == nullptr || (D.K % 4) != 0)) return CWN_ERR_BAD_ARG;
         if ((D.in_scale == nullptr) != (D.in_shift == nullptr)) return CWN_ERR_BAD_ARG;
@@ -293,9 +325,13 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         total_tiles += tm * tn;
     }
     if (total_tiles == 0) return CWN_OK;
-    // persistent blocks: at most ~2 per CU in total (80 KiB of LDS each), shared between the
-    // descriptors in proportion to their tile counts; each block walks its descriptor's tiles
-    const int64_t budget = 512;
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) kmax = descs[i].K + descs[i].K2 > kmax ? descs[i].K + descs[i].K2 : kmax;
+    const int KP = kmax <= 128 ? 128 : 256;
+    const int lds_bytes = 2 * BM * KP * 4;           // two X buffers: 32 KiB (K <= 128) or 64 KiB
+    // persistent blocks: what the LDS lets a CU hold, x 256 CUs, shared between the descriptors in
+    // proportion to their tile counts; each block walks its descriptor's tiles
+    const int64_t budget = KP == 128 ? 768 : 512;      // ~3 (2) resident blocks per CU x 256 CUs
     int64_t blocks = 0;
     for (int i = 0; i < n; ++i) {
         int64_t nb = B.n_tiles[i];
@@ -313,20 +349,24 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         fast = fast && B.vec[i] != 0;
         pro = pro || B.d[i].in_scale != nullptr;
     }
+    using Kern = void (*)(GemmBatch);
+    static const Kern kerns[2][2][2] = {
+        {{gemm_kernel<false, false, 128>, gemm_kernel<false, false, 256>},
+         {gemm_kernel<false, true, 128>, gemm_kernel<false, true, 256>}},
+        {{gemm_kernel<true, false, 128>, gemm_kernel<true, false, 256>},
+         {gemm_kernel<true, true, 128>, gemm_kernel<true, true, 256>}}};
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[] = {(const void*)gemm_kernel<true, false>, (const void*)gemm_kernel<true, true>,
-                             (const void*)gemm_kernel<false, false>, (const void*)gemm_kernel<false, true>};
-        for (const void* f : fns)
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess)
-                return CWN_ERR_LAUNCH;
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                for (int c = 0; c < 2; ++c)
+                    if (hipFuncSetAttribute((const void*)kerns[a][b][c],
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            2 * BM * (c ? 256 : 128) * 4) != hipSuccess)
+                        return CWN_ERR_LAUNCH;
         attr_set = true;
     }
-    const dim3 grid((unsigned)blocks), block(kThreads);
-    hipStream_t st = (hipStream_t)stream_;
-    if (fast && !pro) gemm_kernel<true, false><<<grid, block, kLdsBytes, st>>>(B);
-    else if (fast) gemm_kernel<true, true><<<grid, block, kLdsBytes, st>>>(B);
-    else if (!pro) gemm_kernel<false, false><<<grid, block, kLdsBytes, st>>>(B);
-    else gemm_kernel<false, true><<<grid, block, kLdsBytes, st>>>(B);
+    const Kern k = kerns[fast ? 1 : 0][pro ? 1 : 0][KP == 256 ? 1 : 0];
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

@@ -312,7 +312,7 @@ class SparseCINCochainConv(CochainMessagePassing):
         lin = self.msg_up_nn[1]
         F = x.size(1)
         attr_src, _ = _attr_operand(up_attr)
-        if lin.in_features != F + attr_src.size(1):
+        if lin.in_features != F + attr_src.size(1) or max(F, attr_src.size(1)) > ops.GEMM_MAX_K:
             return []
         return [ops.Gemm(X=x, W=lin.weight[:, :F], bias=lin.bias),
                 ops.Gemm(X=attr_src, W=lin.weight[:, F:])]
@@ -493,6 +493,8 @@ class SparseCINConv(torch.nn.Module):
             up, bd, cb = (_mlp_stages(lvl.update_up_nn), _mlp_stages(lvl.update_boundaries_nn),
                           _mlp_stages(lvl.combine_nn))
             if up is None or bd is None or cb is None or len(up) != len(bd) or len(cb) != 1:
+                return None
+            if any(lin.in_features > ops.GEMM_MAX_K for lin, _ in up + bd + cb):
                 return None
             folds = []
             for stages in (up, bd, cb):

@@ -308,6 +308,7 @@ class Gemm:
     in_shift: Optional[Tensor] = None
     in_relu: bool = False
     col_stats: Optional[Tensor] = None   # [2, N] fp32, zeroed by the caller: sum / sum of squares
+    debug: int = 0                       # timing experiments only (tools/ubench_gemm.py)
 
     def desc(self, Y: Tensor) -> _ffi.GemmDesc:
         X, W, X2 = self.X, self.W, self.X2
@@ -327,7 +328,10 @@ class Gemm:
             Y=Y.data_ptr(), M=X.size(0), ldx=X.stride(0) if X.size(0) > 1 else max(K, 1),
             ldx2=(X2.stride(0) if X2.size(0) > 1 else max(K2, 1)) if X2 is not None else 0,
             ldw=W.stride(0) if W.size(0) > 1 else W.size(1), ldy=Y.stride(0) if Y.size(0) > 1 else Y.size(1),
-            N=W.size(0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu), reserved=0)
+            N=W.size(0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu), reserved=int(self.debug))
+
+
+GEMM_MAX_K = 256   # K + K2 the MFMA kernel supports (whole-K weight tile resident in LDS)
 
 
 def run_gemm(gemms: Sequence[Gemm], device) -> List[Tensor]:
