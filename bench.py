@@ -261,9 +261,19 @@ def main():
             k_us = e0.elapsed_time(e1) * 1e3 / (5 * reps)
         alg = layer_algorithmic_bytes(stats[0], H, coboundary=True)
         achieved = alg / (k_us * 1e-6) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same
+        # workload shape); None when no pass exists for this configuration
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as fh:
+                tj = json.load(fh)
+            if tj.get('hidden') == H and str(args.batch) in tj['entries']:
+                traffic = tj['entries'][str(args.batch)]['traffic_bytes']
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel<4>', 'achieved': round(achieved, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                    'traffic': None, 'algorithmic_bytes_per_launch': alg,
+                    'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
                     'avg_launch_us': round(k_us, 3),
                     'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4),
                     'note': 'avg over back-to-back dependent launches replayed from a hipGraph between two '
@@ -320,6 +330,26 @@ def main():
                 if el > args.cpu_seconds or n >= 5000:
                     break
             torch.set_num_threads(max_threads)
+        # secondary scope on the CPU: the oracle's whole EmbedSparseCIN forward, same batch
+        cpu_full = None
+        try:
+            ocx_full = {'dimension': 2, 'y': None, 'num_complexes': b.num_complexes, 'cochains': [
+                {k: b.cochains[d][k] for k in ('x', 'upper_index', 'lower_index', 'shared_boundaries',
+                                               'shared_coboundaries', 'boundary_index', 'y', 'batch')}
+                for d in range(3)]}
+            ocx_full['cochains'][0]['x'], ocx_full['cochains'][1]['x'] = types[0]
+            ocx_full['cochains'][2]['x'] = None
+            with torch.no_grad():
+                torch.set_num_threads(threads)
+                O.embed_sparse_cin_forward(state, ocx_full, L)
+                k, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
+                    O.embed_sparse_cin_forward(state, ocx_full, L)
+                    k += 1
+                cpu_full = stats[0]['cells'] * L * k / (time.perf_counter() - t0)
+                torch.set_num_threads(max_threads)
+        except Exception as e:   # the baseline leg must never take the bench down
+            print(f'[bench] cpu full-forward baseline failed: {type(e).__name__}: {e}', file=sys.stderr)
         cpu_value = stats[0]['cells'] * L * n / el
         cpu_baseline = {'value': round(cpu_value, 1), 'unit': 'cells/s', 'cores': threads,
                         'kind': 'port',
@@ -327,7 +357,8 @@ def main():
                                   f'up_attr gathers) over batch 0 in {el:.1f} s, torch {torch.__version__} '
                                   f'CPU, {threads} threads (fastest of {sorted(trials)}; passes/s per thread count: '
                                   f'{ {k: round(v, 1) for k, v in trials.items()} }) of {os.cpu_count()} logical cores',
-                        'gpu_over_cpu': round(value / cpu_value, 1)}
+                        'gpu_over_cpu': round(value / cpu_value, 1),
+                        'full_forward_cells_per_s': None if cpu_full is None else round(cpu_full, 1)}
 
     if rank == 0:
         s0 = stats[0]

@@ -122,7 +122,7 @@ __device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, in
 }
 
 template <bool FAST, bool PRO, int KP>
-__global__ __launch_bounds__(kThreads, (KP == 128 ? 3 : 1)) void gemm_kernel(GemmBatch B) {
+__global__ __launch_bounds__(kThreads, (KP == 128 ? 2 : 1)) void gemm_kernel(GemmBatch B) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // two [BM][KP] X buffers
     int di = 0;
 #pragma unroll
@@ -157,47 +157,82 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? 3 : 1)) void gemm_kernel(Gem
     int tile = blockIdx.x - B.blk_start[di];
     int cur_tn = -1;
     int it = 0;
-    SX sx;
+    // two X tiles in flight in registers (prefetch distance 2 when K <= 128; 1 for the K = 256 variant,
+    // whose tiles are twice as large)
+    constexpr bool DEEP = KP == 128;
+    SX sx, sx2;
     if (tile < tiles)
         stage_load<FAST, BM, KP, 0, SX::U>(sx, (int64_t)(tile / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
+    if (DEEP && tile + nblk < tiles)
+        stage_load<FAST, BM, KP, 0, SX::U>(sx2, (int64_t)((tile + nblk) / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
     for (; tile < tiles; tile += nblk, ++it) {
         const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
         const int64_t m_base = (int64_t)tile_m * BM;
         const int n_base = tile_n * BN + wave * (CT * 16);
 
         if (cur_tn != tile_n && !(dbg & 2)) {
-            // W rows [32p, 32p+32) of this column tile go through LDS buffer 1 with coalesced
-            // row-contiguous reads; wave p then lifts its fragments into registers.
-            // all four passes' global loads are issued before the first LDS store
-            SX sw[BN / BM];
+            // W fragments into registers, WAVE-PRIVATELY: the wave reads only its own 32 W rows
+            // (row-contiguous 256-B segments, all loads in flight at once), pushes them through an
+            // 8-KiB slice of LDS that no other wave touches and lifts its MFMA fragments back --
+            // no workgroup barrier between the passes (LDS operations of one wave execute in order).
+            constexpr int HW = 64;                  // floats of K per pass
+            constexpr int PASSES = KP / HW;
+            constexpr int LPP = BM * (HW / 4) / 64; // 16-B loads per lane per pass (= 8)
+            float* priv = smem + wave * (BM * HW);
+            __syncthreads();                 // nobody still reads the X buffers we are about to reuse
 #pragma unroll
-            for (int p = 0; p < BN / BM; ++p)
-                stage_load<FAST, BM, KP, 0, SX::U>(sw[p], (int64_t)tile_n * BN + p * BM, N, Wp, ldw, Ktot,
-                                                   nullptr, 0, 0);
-            __syncthreads();
+            for (int ps = 0; ps < PASSES; ++ps) {
+                f32x4 wl[LPP];
+                const int wrow0 = tile_n * BN + wave * (CT * 16);
 #pragma unroll
-            for (int p = 0; p < BN / BM; ++p) {
-                stage_store<false, BM, KP, 0, SX::U>(smem + BM * KP, sw[p], Ktot, 0, nullptr, nullptr, false);
-                __syncthreads();
-                if (wave == p) {
+                for (int i = 0; i < LPP; ++i) {
+                    const int r = (lane >> 4) + 4 * i;
+                    const int k = ps * HW + 4 * (lane & 15);
+                    const int grow = wrow0 + r < N ? wrow0 + r : N - 1;
+                    if constexpr (FAST) {
+                        wl[i] = *reinterpret_cast<const f32x4*>(Wp + (int64_t)grow * ldw + (k < Ktot ? k : 0));
+                    } else {
 #pragma unroll
-                    for (int sl = 0; sl < SLABS; ++sl)
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct)
-                            wreg[sl][ct] = *reinterpret_cast<const f32x4*>(
-                                smem + BM * KP + lds_off<KP>(ct * 16 + j, 4 * sl + g));
+                        for (int t = 0; t < 4; ++t) wl[i][t] = Wp[(int64_t)grow * ldw + (k + t < Ktot ? k + t : 0)];
+                    }
                 }
-                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < LPP; ++i) {
+                    const int r = (lane >> 4) + 4 * i, c = lane & 15;
+                    const int k = ps * HW + 4 * c;
+                    f32x4 v = wl[i];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = k + t < Ktot ? v[t] : 0.f;
+                    *reinterpret_cast<f32x4*>(priv + r * HW + ((c ^ (r & 15)) << 2)) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int sl = 0; sl < HW / 16; ++sl)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const int r = ct * 16 + j, c = 4 * sl + g;
+                        wreg[ps * (HW / 16) + sl][ct] =
+                            *reinterpret_cast<const f32x4*>(priv + r * HW + ((c ^ (r & 15)) << 2));
+                    }
+                __builtin_amdgcn_wave_barrier();
             }
+            __syncthreads();                 // private slices are free again before any X store
             cur_tn = tile_n;
-            it = 0;   // buffer parity restarts; buffer 1 was just used for W
+            it = 0;
         }
         float* ldsX = smem + (it & 1) * (BM * KP);
         stage_store<PRO, BM, KP, 0, SX::U>(ldsX, sx, K1, K2, in_scale, in_shift, in_relu);
         __syncthreads();                     // tile visible; everyone is done with the other buffer
-        const int next = tile + nblk;
-        if (next < tiles)                    // in flight during the MFMAs below
-            stage_load<FAST, BM, KP, 0, SX::U>(sx, (int64_t)(next / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
+        if constexpr (DEEP) {
+            sx = sx2;                        // tile + nblk is already on its way
+            const int next2 = tile + 2 * nblk;
+            if (next2 < tiles)               // two tiles ahead, in flight during two MFMA phases
+                stage_load<FAST, BM, KP, 0, SX::U>(sx2, (int64_t)(next2 / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
+        } else {
+            const int next = tile + nblk;
+            if (next < tiles)                // in flight during the MFMAs below
+                stage_load<FAST, BM, KP, 0, SX::U>(sx, (int64_t)(next / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
+        }
 
         f32x4 acc[CT][RT];
 #pragma unroll
@@ -223,6 +258,7 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? 3 : 1)) void gemm_kernel(Gem
         }
 
         // epilogue: acc[ct][rt][r] = Y[m_base + rt*16 + j][n_base + ct*16 + 4g + r]
+        // bias / affine / ReLU / BatchNorm statistics first, in the MFMA layout
         bool xok[RT];
         int64_t xrow[RT];
 #pragma unroll
@@ -233,44 +269,31 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? 3 : 1)) void gemm_kernel(Gem
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int n0 = n_base + ct * 16 + 4 * g;
-            if (n0 >= N) continue;
-            const bool full = n0 + 3 < N;
             float bias[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (n0 + r < N) {
-                    if (D.bias != nullptr) bias[r] = D.bias[n0 + r];
-                    if (D.out_scale != nullptr) {
-                        sc[r] = D.out_scale[n0 + r];
-                        sh[r] = D.out_shift[n0 + r];
-                    }
+                const int nn = n0 + r < N ? n0 + r : N - 1;       // clamped: unconditional loads
+                if (D.bias != nullptr) bias[r] = D.bias[nn];
+                if (D.out_scale != nullptr) {
+                    sc[r] = D.out_scale[nn];
+                    sh[r] = D.out_shift[nn];
                 }
             }
             float csum[4] = {0.f, 0.f, 0.f, 0.f}, csq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                f32x4 v = acc[ct][rt];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float y = v[r] + bias[r];
+                    float y = acc[ct][rt][r] + bias[r];
                     if (D.col_sum != nullptr && xok[rt]) {   // statistics of the pre-normalisation value
                         csum[r] += y;
                         csq[r] += y * y;
                     }
                     y = y * sc[r] + sh[r];
-                    v[r] = D.relu ? fmaxf(y, 0.f) : y;
-                }
-                if (!xok[rt] || (dbg & 4)) continue;
-                float* yp = D.Y + xrow[rt] * ldy + n0;
-                if (full && vec) {
-                    *reinterpret_cast<f32x4*>(yp) = v;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n0 + r < N) yp[r] = v[r];
+                    acc[ct][rt][r] = D.relu ? fmaxf(y, 0.f) : y;
                 }
             }
-            if (D.col_sum != nullptr) {
+            if (D.col_sum != nullptr && n0 < N) {
                 // reduce over the 16 rows held by lanes j = 0..15 of this lane group, one atomic each
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -285,6 +308,50 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? 3 : 1)) void gemm_kernel(Gem
                         atomicAdd(D.col_sumsq + n0 + r, b);
                     }
                 }
+            }
+        }
+        if (dbg & 4) continue;
+        // Stores.  In the MFMA layout one store instruction would write 16 rows x 64 B (half
+        // lines).  A DPP row_ror:8 exchange between lanes j and j^8 of each 16-lane row (same g)
+        // pairs the two column tiles of a row instead: lanes j < 8 keep (row j, ct 0) and receive
+        // (row j+8, ct 0); lanes j >= 8 receive (row j-8, ct 1) and keep (row j, ct 1).  Each
+        // store instruction then writes 8 rows x 128 B = 8 FULL cache lines.
+        static_assert(CT == 2, "the line-pairing epilogue assumes two column tiles per wave");
+        const bool lo = j < 8;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 send, recv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) send[r] = lo ? acc[1][rt][r] : acc[0][rt][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                recv[r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send[r]), 0x128, 0xf, 0xf, false));
+            // instruction A: rows 0..7 of the 16-row tile; instruction B: rows 8..15
+            f32x4 va, vb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                va[r] = lo ? acc[0][rt][r] : recv[r];      // lo: (row j, ct0)    hi: (row j-8, ct1)
+                vb[r] = lo ? recv[r] : acc[1][rt][r];      // lo: (row j+8, ct0)  hi: (row j, ct1)
+            }
+            const int64_t ra = m_base + rt * 16 + (lo ? j : j - 8);
+            const int64_t rb = m_base + rt * 16 + (lo ? j + 8 : j);
+            const int n0 = n_base + (lo ? 0 : 16) + 4 * g;
+            const bool full = n0 + 3 < N;
+            if (ra < M && n0 < N) {
+                float* yp = D.Y + ra * ldy + n0;
+                if (full && vec) *reinterpret_cast<f32x4*>(yp) = va;
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < N) yp[r] = va[r];
+            }
+            if (rb < M && n0 < N) {
+                float* yp = D.Y + rb * ldy + n0;
+                if (full && vec) *reinterpret_cast<f32x4*>(yp) = vb;
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < N) yp[r] = vb[r];
             }
         }
     }
