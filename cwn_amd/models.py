@@ -66,38 +66,67 @@ def pool_complex(xs: List[torch.Tensor], data: ComplexBatch, max_dim: int, reado
     return torch.stack(pooled, dim=0)
 
 
-class EmbedSparseCIN(torch.nn.Module):
-    """mp/molec_models.py:12-163 (jump_mode 'cat' / None, readouts sum / mean)."""
+ATOM_DIMS = (119, 4, 12, 12, 10, 6, 6, 2, 2)   # OGB convention (third-party)
+BOND_DIMS = (5, 6, 2)
 
-    def __init__(self, atom_types, bond_types, out_size, num_layers, hidden,
-                 dropout_rate: float = 0.5, max_dim: int = 2, jump_mode=None, nonlinearity='relu',
-                 readout='sum', train_eps=False, final_hidden_multiplier: int = 2,
-                 readout_dims=(0, 1, 2), final_readout='sum', apply_dropout_before='lin2',
-                 init_reduce='sum', embed_edge=False, embed_dim=None, use_coboundaries=False,
-                 graph_norm='bn'):
+
+class AtomEncoder(torch.nn.Module):
+    """Sum of one Embedding per integer atom-feature column (the published OGB AtomEncoder form;
+    `ogb` is absent here, parameter names follow it so its state_dicts load)."""
+
+    def __init__(self, emb_dim, dims=ATOM_DIMS):
         super().__init__()
+        self.atom_embedding_list = torch.nn.ModuleList(Embedding(d, emb_dim) for d in dims)
+        for emb in self.atom_embedding_list:
+            torch.nn.init.xavier_uniform_(emb.weight.data)
+
+    def reset_parameters(self):
+        for emb in self.atom_embedding_list:
+            torch.nn.init.xavier_uniform_(emb.weight.data)
+
+    def forward(self, x):
+        return sum(self.atom_embedding_list[i](x[:, i]) for i in range(x.shape[1]))
+
+
+class BondEncoder(torch.nn.Module):
+    def __init__(self, emb_dim, dims=BOND_DIMS):
+        super().__init__()
+        self.bond_embedding_list = torch.nn.ModuleList(Embedding(d, emb_dim) for d in dims)
+        for emb in self.bond_embedding_list:
+            torch.nn.init.xavier_uniform_(emb.weight.data)
+
+    def reset_parameters(self):
+        for emb in self.bond_embedding_list:
+            torch.nn.init.xavier_uniform_(emb.weight.data)
+
+    def forward(self, edge_attr):
+        return sum(self.bond_embedding_list[i](edge_attr[:, i]) for i in range(edge_attr.shape[1]))
+
+
+class _SparseCINStack(torch.nn.Module):
+    """What SparseCIN (mp/models.py:112-260), EmbedSparseCIN (mp/molec_models.py:12-163) and
+    OGBEmbedSparseCIN (mp/molec_models.py:201-352) share: L x SparseCINConv, optional JK-cat,
+    per-dimension readout, lin1s, final readout, lin2.  Subclasses provide the input front."""
+
+    def _build(self, first_dim, out_size, num_layers, hidden, dropout_rate, max_dim, jump_mode,
+               nonlinearity, readout, train_eps, final_hidden_multiplier, readout_dims,
+               final_readout, apply_dropout_before, use_coboundaries, graph_norm):
         self.max_dim = max_dim
         self.readout_dims = (tuple(d for d in readout_dims if d <= max_dim)
                              if readout_dims is not None else list(range(max_dim + 1)))
-        if embed_dim is None:
-            embed_dim = hidden
-        self.v_embed_init = Embedding(atom_types, embed_dim)
-        self.e_embed_init = Embedding(bond_types, embed_dim) if embed_edge else None
-        self.reduce_init = InitReduceConv(reduce=init_reduce)
-        self.init_conv = EmbedVEWithReduce(self.v_embed_init, self.e_embed_init, self.reduce_init)
         self.final_readout = final_readout
         self.dropout_rate = dropout_rate
         self.apply_dropout_before = apply_dropout_before
         self.jump_mode = jump_mode
         if jump_mode not in (None, 'cat'):
             raise NotImplementedError("jump_mode must be None or 'cat'")
-        self.convs = torch.nn.ModuleList()
         self.nonlinearity = nonlinearity
         self.readout = readout
         self.graph_norm = get_graph_norm(graph_norm)
         act_module = get_nonlinearity(nonlinearity, return_module=True)
+        self.convs = torch.nn.ModuleList()
         for i in range(num_layers):
-            layer_dim = embed_dim if i == 0 else hidden
+            layer_dim = first_dim if i == 0 else hidden
             self.convs.append(SparseCINConv(
                 up_msg_size=layer_dim, down_msg_size=layer_dim, boundary_msg_size=layer_dim,
                 passed_msg_boundaries_nn=None, passed_msg_up_nn=None, passed_update_up_nn=None,
@@ -106,35 +135,22 @@ class EmbedSparseCIN(torch.nn.Module):
                 graph_norm=self.graph_norm, use_coboundaries=use_coboundaries))
         self.lin1s = torch.nn.ModuleList()
         for _ in range(max_dim + 1):
-            if jump_mode == 'cat':
+            if jump_mode == 'cat':   # no bias: an absent level contributes exactly zero
                 self.lin1s.append(Linear(num_layers * hidden, final_hidden_multiplier * hidden, bias=False))
             else:
                 self.lin1s.append(Linear(hidden, final_hidden_multiplier * hidden))
         self.lin2 = Linear(final_hidden_multiplier * hidden, out_size)
 
-    def reset_parameters(self):
-        for conv in self.convs:
-            for lvl in conv.mp_levels:
-                lvl.reset_parameters()
-        self.init_conv.reset_parameters()
-        for lin in self.lin1s:
-            lin.reset_parameters()
-        self.lin2.reset_parameters()
+    conv_dropout = False       # OGBEmbedSparseCIN drops out after every conv (:298-300)
 
-    def forward(self, data: ComplexBatch, include_partial=False):
+    def _convs_and_head(self, data: ComplexBatch, include_partial: bool, res: dict):
         act = get_nonlinearity(self.nonlinearity, return_module=False)
-        res = {}
-        assert data.cochains[0].x.size(-1) == 1
-        if 1 in data.cochains and data.cochains[1].x is not None:
-            assert data.cochains[1].x.size(-1) == 1
-        params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
-        xs = list(self.init_conv(*params))
-        xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
-        data.set_xs(xs)
-        jump_xs = None
+        jump_xs, xs = None, None
         for c, conv in enumerate(self.convs):
             params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
             xs = conv(*params, start_to_process=0)
+            if self.conv_dropout:
+                xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
             data.set_xs(xs)
             if include_partial:
                 for k in range(len(xs)):
@@ -175,3 +191,82 @@ class EmbedSparseCIN(torch.nn.Module):
 
     def __repr__(self):
         return self.__class__.__name__
+
+
+class SparseCIN(_SparseCINStack):
+    """mp/models.py:112-260: features are used as given (e.g. REDDIT: constant scalar features)."""
+
+    def __init__(self, num_input_features, num_classes, num_layers, hidden, dropout_rate: float = 0.5,
+                 max_dim: int = 2, jump_mode=None, nonlinearity='relu', readout='sum', train_eps=False,
+                 final_hidden_multiplier: int = 2, use_coboundaries=False, readout_dims=(0, 1, 2),
+                 final_readout='sum', apply_dropout_before='lin2', graph_norm='bn'):
+        super().__init__()
+        self._build(num_input_features, num_classes, num_layers, hidden, dropout_rate, max_dim,
+                    jump_mode, nonlinearity, readout, train_eps, final_hidden_multiplier, readout_dims,
+                    final_readout, apply_dropout_before, use_coboundaries, graph_norm)
+
+    def forward(self, data: ComplexBatch, include_partial=False):
+        return self._convs_and_head(data, include_partial, {})
+
+
+class EmbedSparseCIN(_SparseCINStack):
+    """mp/molec_models.py:12-163 (ZINC: integer atom / bond types embedded, rings initialised by
+    reduction)."""
+
+    def __init__(self, atom_types, bond_types, out_size, num_layers, hidden,
+                 dropout_rate: float = 0.5, max_dim: int = 2, jump_mode=None, nonlinearity='relu',
+                 readout='sum', train_eps=False, final_hidden_multiplier: int = 2,
+                 readout_dims=(0, 1, 2), final_readout='sum', apply_dropout_before='lin2',
+                 init_reduce='sum', embed_edge=False, embed_dim=None, use_coboundaries=False,
+                 graph_norm='bn'):
+        super().__init__()
+        if embed_dim is None:
+            embed_dim = hidden
+        self.v_embed_init = Embedding(atom_types, embed_dim)
+        self.e_embed_init = Embedding(bond_types, embed_dim) if embed_edge else None
+        self.reduce_init = InitReduceConv(reduce=init_reduce)
+        self.init_conv = EmbedVEWithReduce(self.v_embed_init, self.e_embed_init, self.reduce_init)
+        self._build(embed_dim, out_size, num_layers, hidden, dropout_rate, max_dim, jump_mode,
+                    nonlinearity, readout, train_eps, final_hidden_multiplier, readout_dims,
+                    final_readout, apply_dropout_before, use_coboundaries, graph_norm)
+
+    def forward(self, data: ComplexBatch, include_partial=False):
+        assert data.cochains[0].x.size(-1) == 1
+        if 1 in data.cochains and data.cochains[1].x is not None:
+            assert data.cochains[1].x.size(-1) == 1
+        params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
+        xs = list(self.init_conv(*params))
+        xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
+        data.set_xs(xs)
+        return self._convs_and_head(data, include_partial, {})
+
+
+class OGBEmbedSparseCIN(_SparseCINStack):
+    """mp/molec_models.py:201-352 (ogbg-mol*: OGB atom / bond encoders, dropout after each conv)."""
+    conv_dropout = True
+
+    def __init__(self, out_size, num_layers, hidden, dropout_rate: float = 0.5,
+                 indropout_rate: float = 0.0, max_dim: int = 2, jump_mode=None, nonlinearity='relu',
+                 readout='sum', train_eps=False, final_hidden_multiplier: int = 2,
+                 readout_dims=(0, 1, 2), final_readout='sum', apply_dropout_before='lin2',
+                 init_reduce='sum', embed_edge=False, embed_dim=None, use_coboundaries=False,
+                 graph_norm='bn'):
+        super().__init__()
+        from .layers import OGBEmbedVEWithReduce
+        if embed_dim is None:
+            embed_dim = hidden
+        self.v_embed_init = AtomEncoder(embed_dim)
+        self.e_embed_init = BondEncoder(embed_dim) if embed_edge else None
+        self.reduce_init = InitReduceConv(reduce=init_reduce)
+        self.init_conv = OGBEmbedVEWithReduce(self.v_embed_init, self.e_embed_init, self.reduce_init)
+        self.in_dropout_rate = indropout_rate
+        self._build(embed_dim, out_size, num_layers, hidden, dropout_rate, max_dim, jump_mode,
+                    nonlinearity, readout, train_eps, final_hidden_multiplier, readout_dims,
+                    final_readout, apply_dropout_before, use_coboundaries, graph_norm)
+
+    def forward(self, data: ComplexBatch, include_partial=False):
+        params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
+        xs = list(self.init_conv(*params))
+        xs = [F.dropout(x, p=self.in_dropout_rate, training=self.training) for x in xs]
+        data.set_xs(xs)
+        return self._convs_and_head(data, include_partial, {})

@@ -209,3 +209,128 @@ def batch_stats(batch: ComplexBatch) -> dict:
         s[f'B{d}'] = int(c.boundary_index.size(1)) if c.boundary_index is not None else 0
     s['cells'] = sum(s[f'N{d}'] for d in range(batch.dimension + 1))
     return s
+
+
+# ------------------------------------------------------------------------------------------------
+# molhiv-like (BASELINE config 3) and REDDIT-like clique complexes (config 5)
+# ------------------------------------------------------------------------------------------------
+def molhiv_like_complexes(num: int, seed: int = 0, max_ring: int = 6, n_lo: int = 10, n_hi: int = 60,
+                          atom_dims=(119, 4, 12, 12, 10, 6, 6, 2, 2), bond_dims=(5, 6, 2)) -> List[Complex]:
+    """ogbg-molhiv-shaped inputs: 10-60 atoms, 9 integer atom-feature columns, 3 integer bond-feature
+    columns (OGB convention), ring lift with max_ring."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(num):
+        n, bonds = random_molecule(rng, n_lo, n_hi, ring_probs=(0.25, 0.35, 0.25, 0.15))
+        vx = torch.from_numpy(np.stack([rng.integers(0, d, size=n) for d in atom_dims], 1))
+        ex = torch.from_numpy(np.stack([rng.integers(0, d, size=len(bonds)) for d in bond_dims], 1))
+        y = torch.from_numpy(rng.integers(0, 2, size=(1, 1)).astype(np.float32))
+        out.append(ring_lift(n, bonds, vx, ex, max_k=max_ring, y=y))
+    return out
+
+
+def preferential_attachment_graph(rng: np.random.Generator, n: int, m: int = 2, hubs: int = 2,
+                                  hub_degree: int = 100) -> List[Tuple[int, int]]:
+    """A REDDIT-like discussion graph: preferential attachment (each new vertex links to `m`
+    earlier ones, probability ~ degree) with `hubs` vertices forced to degree >= hub_degree."""
+    edges = set()
+    targets = [0, 1]
+    edges.add((0, 1))
+    for v in range(2, n):
+        picks = set()
+        while len(picks) < min(m, v):
+            picks.add(int(targets[int(rng.integers(len(targets)))]))
+        for u in picks:
+            edges.add((min(u, v), max(u, v)))
+            targets += [u, v]
+    deg = np.zeros(n, dtype=np.int64)
+    for u, v in edges:
+        deg[u] += 1
+        deg[v] += 1
+    for h in np.argsort(-deg)[:hubs]:
+        need = hub_degree - int(deg[h])
+        if need > 0:
+            others = [int(v) for v in rng.permutation(n) if v != h and (min(h, v), max(h, v)) not in edges]
+            for v in others[:need]:
+                edges.add((min(int(h), v), max(int(h), v)))
+    return sorted(edges)
+
+
+def clique_lift(n: int, edges: Sequence[Tuple[int, int]], vx: torch.Tensor, max_dim: int = 2,
+                init_method: str = 'sum', y: Optional[torch.Tensor] = None) -> Complex:
+    """compute_clique_complex_with_gudhi (data/utils.py:224-272) restated for expansion_dim <= 2:
+    vertices, edges in lexicographic (u<v) order, triangles in lexicographic order (the order of a
+    gudhi SimplexTree traversal); upper adjacencies as build_adj (:103-138); boundaries of a
+    simplex in itertools.combinations order (:40-42); features of higher cells = reduce of their
+    vertices' features (construct_features, :141-156)."""
+    edges = sorted((min(u, v), max(u, v)) for u, v in edges)
+    edge_id = {e: i for i, e in enumerate(edges)}
+    nbrs = [set() for _ in range(n)]
+    for u, v in edges:
+        nbrs[u].add(v)
+        nbrs[v].add(u)
+    tris = []
+    if max_dim >= 2:
+        for u, v in edges:
+            for w in sorted(nbrs[u] & nbrs[v]):
+                if w > v:
+                    tris.append((u, v, w))
+        tris.sort()
+    tri_edges = [[edge_id[(a, b)], edge_id[(a, c)], edge_id[(b, c)]] for a, b, c in tris]
+
+    def pairs(groups):
+        idx, shared = [], []
+        for gid, members in enumerate(groups):
+            for a, b in itertools.combinations(members, 2):
+                idx += [(a, b), (b, a)]
+                shared += [gid, gid]
+        return idx, shared
+
+    def idx_tensor(lst):
+        return torch.tensor(lst, dtype=torch.long).t().contiguous() if lst else None
+
+    def vec_tensor(lst):
+        return torch.tensor(lst, dtype=torch.long) if lst else None
+
+    def reduce_feats(groups):
+        if not groups:
+            return None
+        g = torch.tensor(groups, dtype=torch.long)
+        f = vx[g]                                    # [cells, k, F]
+        return f.sum(1) if init_method in ('sum', 'add') else f.mean(1)
+
+    dim = 2 if tris else (1 if edges else 0)
+    v_up, v_cob = pairs([list(e) for e in edges])
+    cochains = [Cochain(dim=0, x=vx, upper_index=idx_tensor(v_up), shared_coboundaries=vec_tensor(v_cob),
+                        num_cells=n, num_cells_up=len(edges) if dim >= 1 else 0)]
+    if dim >= 1:
+        e_up, e_cob = pairs(tri_edges)
+        b_index = torch.tensor([[v for e in edges for v in e],
+                                [i for i in range(len(edges)) for _ in range(2)]], dtype=torch.long)
+        cochains.append(Cochain(dim=1, x=reduce_feats([list(e) for e in edges]), upper_index=idx_tensor(e_up),
+                                shared_coboundaries=vec_tensor(e_cob), boundary_index=b_index,
+                                num_cells=len(edges), num_cells_down=n,
+                                num_cells_up=len(tris) if dim >= 2 else 0))
+    if dim >= 2:
+        b_index = torch.tensor([[e for es in tri_edges for e in es],
+                                [i for i in range(len(tris)) for _ in range(3)]], dtype=torch.long)
+        cochains.append(Cochain(dim=2, x=reduce_feats([list(t) for t in tris]), boundary_index=b_index,
+                                num_cells=len(tris), num_cells_down=len(edges), num_cells_up=0))
+    return Complex(*cochains, y=y, dimension=dim)
+
+
+def reddit_like_complexes(num: int = 32, seed: int = 0, n_lo: int = 200, n_hi: int = 1000,
+                          init_method: str = 'mean') -> List[Complex]:
+    """REDDIT-BINARY-shaped inputs (exp/scripts/mpsn-redditb.sh): large irregular graphs with 1-3
+    hubs of degree >= 100, a constant scalar vertex feature, clique lift to dimension 2,
+    higher-cell features by `init_method` (mean -> all ones)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(num):
+        n = int(rng.integers(n_lo, n_hi + 1))
+        edges = preferential_attachment_graph(rng, n, m=int(rng.integers(1, 4)), hubs=int(rng.integers(1, 4)),
+                                              hub_degree=int(rng.integers(100, 200)))
+        vx = torch.ones(n, 1)
+        y = torch.from_numpy(rng.integers(0, 2, size=1))
+        out.append(clique_lift(n, edges, vx, max_dim=2, init_method=init_method, y=y))
+    return out

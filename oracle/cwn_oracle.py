@@ -432,22 +432,44 @@ def embed_ve_with_reduce(v_emb: Tensor, e_emb: Optional[Tensor], params: List[Di
     return out
 
 
-def embed_sparse_cin_forward(state: Dict, cx: Dict, num_layers: int, max_dim: int = 2,
+def _sum_embedding(state: Dict, prefix: str, x: Tensor) -> Tensor:
+    """OGB Atom/BondEncoder convention (third-party, absent from the tree: PARITY UNPINNED for this
+    front-end): sum over integer feature columns of one Embedding table per column."""
+    x = x.long()
+    return sum(state[f'{prefix}.{i}.weight'].index_select(0, x[:, i]) for i in range(x.size(1)))
+
+
+def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: int = 2,
                              use_coboundaries: bool = True, readout: str = 'sum',
-                             final_readout: str = 'sum', training: bool = False,
-                             norm: str = 'bn', init_reduce_mode: str = 'add',
-                             embed_edge: bool = True, readout_dims=(0, 1, 2)):
-    """EmbedSparseCIN.forward, mp/molec_models.py:90-160, with dropout off (p irrelevant in eval;
-    golden vectors use dropout_rate=0) and jump_mode=None.  Returns (out, per-layer xs)."""
+                             final_readout: str = 'sum', training: bool = False, norm: str = 'bn',
+                             jump_mode: Optional[str] = None, embed: Optional[str] = 'zinc',
+                             init_reduce_mode: str = 'add', readout_dims=(0, 1, 2)):
+    """SparseCIN.forward (mp/models.py:195-260), EmbedSparseCIN.forward (mp/molec_models.py:90-160)
+    and OGBEmbedSparseCIN.forward (mp/molec_models.py:281-350) with dropout off and jump_mode in
+    {None, 'cat'}.  `embed`: None (features used as they are), 'zinc' (one Embedding per dimension
+    0/1) or 'ogb' (sum of per-column embeddings).  Returns (out, per-layer / pooled tensors)."""
     cx = {'dimension': cx['dimension'], 'y': cx.get('y'), 'num_complexes': cx.get('num_complexes'),
           'cochains': [dict(c) for c in cx['cochains']]}
-    params = all_cochain_params(cx, max_dim=max_dim, include_down_features=False)
-    xs = embed_ve_with_reduce(state['v_embed_init.weight'],
-                              state['e_embed_init.weight'] if embed_edge else None, params,
-                              init_reduce_mode)
-    for d, x in enumerate(xs):
-        cx['cochains'][d]['x'] = x
     partial = {}
+    if embed is not None:
+        params = all_cochain_params(cx, max_dim=max_dim, include_down_features=False)
+        if embed == 'zinc':
+            xs = embed_ve_with_reduce(state['v_embed_init.weight'], state.get('e_embed_init.weight'),
+                                      params, init_reduce_mode)
+        else:
+            vx = _sum_embedding(state, 'v_embed_init.atom_embedding_list', params[0]['x'])
+            xs = [vx]
+            if len(params) >= 2:
+                reduced = init_reduce(vx, params[1]['boundary_index'], init_reduce_mode)
+                ex = reduced
+                if params[1]['x'] is not None:
+                    ex = _sum_embedding(state, 'e_embed_init.bond_embedding_list', params[1]['x'])
+                xs.append(ex)
+                if len(params) == 3:
+                    xs.append(init_reduce(reduced, params[2]['boundary_index'], init_reduce_mode) / 2.)
+        for d, x in enumerate(xs):
+            cx['cochains'][d]['x'] = x
+    jump = None
     for l in range(num_layers):
         params = all_cochain_params(cx, max_dim=max_dim, include_down_features=False)
         pre = f'convs.{l}.'
@@ -456,14 +478,37 @@ def embed_sparse_cin_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
         for d, x in enumerate(xs):
             cx['cochains'][d]['x'] = x
             partial[f'layer{l}_{d}'] = x
-    nb = int(cx['cochains'][0]['batch'].max()) + 1
-    pooled = pool_complex(xs, [cx['cochains'][d]['batch'] for d in range(len(xs))], nb, max_dim,
-                          readout)
+        if jump_mode is not None:
+            jump = [[] for _ in xs] if jump is None else jump
+            for d, x in enumerate(xs):
+                jump[d].append(x)
+    if jump_mode is not None:
+        xs = [torch.cat(j, dim=-1) for j in jump]
+    nb = cx.get('num_complexes') or int(cx['cochains'][0]['batch'].max()) + 1
+    pooled = pool_complex(xs, [cx['cochains'][d]['batch'] for d in range(len(xs))], nb, max_dim, readout)
     dims = [d for d in readout_dims if d <= max_dim]
-    hs = [torch.relu(_lin(pooled[d], state, f'lin1s.{d}')) for d in dims]
+    for k, d in enumerate(dims):
+        partial[f'pool_{k}'] = pooled[d]
+    hs = []
+    for d in dims:
+        h = pooled[d] @ state[f'lin1s.{d}.weight'].t()
+        if f'lin1s.{d}.bias' in state:
+            h = h + state[f'lin1s.{d}.bias']
+        hs.append(torch.relu(h))
     h = torch.stack(hs, 0)
     h = h.sum(0) if final_readout == 'sum' else h.mean(0)
     return _lin(h, state, 'lin2'), partial
+
+
+def embed_sparse_cin_forward(state: Dict, cx: Dict, num_layers: int, max_dim: int = 2,
+                             use_coboundaries: bool = True, readout: str = 'sum',
+                             final_readout: str = 'sum', training: bool = False,
+                             norm: str = 'bn', init_reduce_mode: str = 'add',
+                             embed_edge: bool = True, readout_dims=(0, 1, 2)):
+    """EmbedSparseCIN.forward, mp/molec_models.py:90-160 (see sparse_cin_model_forward)."""
+    return sparse_cin_model_forward(state, cx, num_layers, max_dim, use_coboundaries, readout,
+                                    final_readout, training, norm, None, 'zinc', init_reduce_mode,
+                                    readout_dims)
 
 
 # --------------------------------------------------------------------------------------------

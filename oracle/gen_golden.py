@@ -326,3 +326,60 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def extra_models():
+    """SparseCIN (mp/models.py, REDDIT-style: F=1 inputs, no coboundaries, norm id, JK cat) and
+    OGBEmbedSparseCIN (mp/molec_models.py, molhiv-style: mean readout) -> sparse_cin_models.npz."""
+    from mp.models import SparseCIN
+    from mp.molec_models import OGBEmbedSparseCIN
+    out = {}
+    gen = torch.Generator().manual_seed(8)
+    torch.manual_seed(31)
+    b = ComplexBatch.from_complex_list([get(n) for n in TESTING_LIST], max_dim=2)
+    model = SparseCIN(1, 2, 3, 16, dropout_rate=0.0, max_dim=2, jump_mode='cat', nonlinearity='relu',
+                      readout='sum', use_coboundaries=False, graph_norm='id', final_readout='sum')
+    model.eval()
+    out.update(state_np(model, 'reddit/state'))
+    for d in range(3):
+        out[f'reddit/x/{d}'] = np_(b.cochains[d].x)
+    with torch.no_grad():
+        y, res = model(b, include_partial=True)
+    out['reddit/out'] = np_(y)
+    for k, v in res.items():
+        out[f'reddit/{k}'] = np_(v)
+
+    torch.manual_seed(32)
+    cxs = [get(n) for n in MOL_LIST]
+    from ogb.graphproppred.mol_encoder import ATOM_DIMS, BOND_DIMS
+    for cx in cxs:
+        n0 = cx.cochains[0].num_cells
+        cx.cochains[0]._Cochain__x = torch.stack([torch.randint(0, d, (n0,), generator=gen) for d in ATOM_DIMS], 1)
+        if cx.dimension >= 1:
+            n1 = cx.cochains[1].num_cells
+            cx.cochains[1]._Cochain__x = torch.stack([torch.randint(0, d, (n1,), generator=gen) for d in BOND_DIMS], 1)
+        if cx.dimension >= 2:
+            cx.cochains[2]._Cochain__x = None
+    b = ComplexBatch.from_complex_list(cxs, max_dim=2)
+    model = OGBEmbedSparseCIN(1, 2, 16, dropout_rate=0.0, indropout_rate=0.0, max_dim=2, jump_mode=None,
+                              nonlinearity='relu', readout='mean', final_readout='sum', init_reduce='sum',
+                              embed_edge=True, use_coboundaries=True, graph_norm='bn')
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(generator=gen)
+                m.running_var.uniform_(0.5, 1.5, generator=gen)
+    model.eval()
+    out.update(state_np(model, 'molhiv/state'))
+    out['molhiv/v_feats'] = np_(b.cochains[0].x)
+    out['molhiv/e_feats'] = np_(b.cochains[1].x)
+    with torch.no_grad():
+        y, res = model(b, include_partial=True)
+    out['molhiv/out'] = np_(y)
+    for k, v in res.items():
+        out[f'molhiv/{k}'] = np_(v)
+    save('sparse_cin_models.npz', out)
+
+
+if __name__ == '__main__' and os.environ.get('CWN_GOLDEN_EXTRA', '1') == '1':
+    extra_models()

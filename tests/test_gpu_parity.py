@@ -706,3 +706,99 @@ def test_fused_dense_eval_path_is_taken_and_matches_modules():
             plans, outs = conv.propagate_all(*prms)
             took = conv._dense_eval(plans, outs, 0)
         assert (took is None) == (tag == 'mol_cob_bn_64')    # BN in training mode is not folded
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs 3 (molhiv-like) and 5 (REDDIT-like clique complexes)
+# ------------------------------------------------------------------------------------------------
+def _oracle_cx(b):
+    return {'dimension': b.dimension, 'y': None, 'num_complexes': b.num_complexes, 'cochains': [
+        {k: cpu(b.cochains[d][k]) for k in ('x', 'upper_index', 'lower_index', 'shared_boundaries',
+                                            'shared_coboundaries', 'boundary_index', 'y', 'batch')}
+        for d in range(b.dimension + 1)]}
+
+
+def test_extra_models_golden_gpu():
+    """SparseCIN (F = 1 inputs, JK cat, no norm) and OGBEmbedSparseCIN (mean readout) with the
+    reference's state_dicts, against the reference's outputs."""
+    from cwn_amd.models import SparseCIN, OGBEmbedSparseCIN
+    g = load('sparse_cin_models.npz')
+    model = SparseCIN(1, 2, 3, 16, dropout_rate=0.0, max_dim=2, jump_mode='cat', readout='sum',
+                      use_coboundaries=False, graph_norm='id')
+    model.load_state_dict(state_dict(g, 'reddit/state'))
+    model = model.to(DEV).eval()
+    b = dummy_batch(list_names('testing'), max_dim=2, device=DEV)
+    for d in range(3):
+        b.cochains[d].x = T(g[f'reddit/x/{d}']).to(DEV)
+    for grad in (False, True):       # fused dense path (no_grad) and module path
+        b2 = dummy_batch(list_names('testing'), max_dim=2, device=DEV)
+        for d in range(3):
+            b2.cochains[d].x = T(g[f'reddit/x/{d}']).to(DEV)
+        with torch.set_grad_enabled(grad):
+            y, res = model(b2, include_partial=True)
+        for k, v in res.items():
+            torch.testing.assert_close(cpu(v), T(g[f'reddit/{k}']), rtol=1e-4, atol=1e-4)
+    model = OGBEmbedSparseCIN(1, 2, 16, dropout_rate=0.0, max_dim=2, readout='mean', init_reduce='sum',
+                              embed_edge=True, use_coboundaries=True, graph_norm='bn')
+    model.load_state_dict(state_dict(g, 'molhiv/state'))
+    model = model.to(DEV).eval()
+    b = dummy_batch(list_names('mol'), max_dim=2)
+    b.cochains[0]._x, b.cochains[1]._x, b.cochains[2]._x = T(g['molhiv/v_feats']), T(g['molhiv/e_feats']), None
+    b = b.to(DEV)
+    with torch.no_grad():
+        y, res = model(b, include_partial=True)
+    for k, v in res.items():
+        torch.testing.assert_close(cpu(v), T(g[f'molhiv/{k}']), rtol=1e-4, atol=1e-4)
+
+
+def test_molhiv_like_full_size_vs_oracle():
+    """BASELINE config 3: ogbg-molhiv-like ring-lift, OGBEmbedSparseCIN hidden 64, 2 layers,
+    readout mean (exp/scripts/cwn-molhiv.sh), batch 512."""
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import OGBEmbedSparseCIN
+    from cwn_amd.synthetic import molhiv_like_complexes
+    torch.manual_seed(0)
+    model = OGBEmbedSparseCIN(1, 2, 64, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum',
+                              init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn').eval()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    b = ComplexBatch.from_complex_list(molhiv_like_complexes(512, seed=3), max_dim=2)
+    ref, rpart = O.sparse_cin_model_forward(state, _oracle_cx(b), 2, readout='mean', embed='ogb')
+    model = model.to(DEV)
+    with torch.no_grad():
+        y, res = model(b.to(DEV), include_partial=True)
+    for k, v in rpart.items():
+        torch.testing.assert_close(cpu(res[k]), v, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(cpu(y), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_reddit_like_full_size_vs_oracle():
+    """BASELINE config 5: REDDIT-like clique complexes (hubs of degree >= 100: skewed segments,
+    F = 1 inputs), SparseCIN hidden 64, 4 layers, no coboundaries, norm id, JK cat, batch 32."""
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import SparseCIN
+    from cwn_amd.synthetic import reddit_like_complexes, batch_stats
+    torch.manual_seed(0)
+    model = SparseCIN(1, 2, 4, 64, dropout_rate=0.0, max_dim=2, jump_mode='cat', readout='sum',
+                      use_coboundaries=False, graph_norm='id').eval()
+    with torch.no_grad():            # keep activations O(1) without a norm layer (degrees reach 300)
+        for p in model.parameters():
+            p.mul_(0.3)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    b = ComplexBatch.from_complex_list(reddit_like_complexes(32, seed=1), max_dim=2)
+    st = batch_stats(b)
+    assert st['cells'] > 30_000
+    ref, rpart = O.sparse_cin_model_forward(state, _oracle_cx(b), 4, use_coboundaries=False, norm='id',
+                                            jump_mode='cat', embed=None)
+    # the propagate outputs of the first layer are integer-valued (all-ones features): exact
+    prm = b.to(DEV).get_cochain_params(dim=0, include_down_features=False)
+    up, _, _ = run_base(prm)
+    deg = torch.bincount(cpu(prm.up_index)[1], minlength=prm.x.size(0)).float().unsqueeze(1)
+    assert torch.equal(cpu(up), deg) and deg.max() >= 100
+    model = model.to(DEV)
+    with torch.no_grad():
+        y, res = model(b, include_partial=True)
+    for k, v in rpart.items():
+        scale = max(1.0, float(v.abs().max()))
+        torch.testing.assert_close(cpu(res[k]) / scale, v / scale, rtol=1e-4, atol=1e-5)
+    scale = max(1.0, float(ref.abs().max()))
+    torch.testing.assert_close(cpu(y) / scale, ref / scale, rtol=1e-4, atol=1e-5)

@@ -254,3 +254,26 @@ def test_csr_from_coo_matches_scatter():
     # stability: inside one destination the original order is kept
     same = dst_sorted[1:] == dst_sorted[:-1]
     assert torch.all(perm[1:][same] > perm[:-1][same])
+
+
+def test_extra_models_golden():
+    """SparseCIN (REDDIT-style) and OGBEmbedSparseCIN (molhiv-style) stacks vs the live reference."""
+    g = load('sparse_cin_models.npz')
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/testing']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    for d in range(3):
+        cx['cochains'][d]['x'] = T(g[f'reddit/x/{d}'])
+    y, partial = O.sparse_cin_model_forward(state_dict(g, 'reddit/state'), cx, 3, use_coboundaries=False,
+                                            norm='id', jump_mode='cat', embed=None)
+    for k, v in partial.items():
+        torch.testing.assert_close(v, T(g[f'reddit/{k}']), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y, T(g['reddit/out']), rtol=1e-4, atol=1e-4)
+
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/mol']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    cx['cochains'][0]['x'], cx['cochains'][1]['x'] = T(g['molhiv/v_feats']), T(g['molhiv/e_feats'])
+    cx['cochains'][2]['x'] = None
+    y, partial = O.sparse_cin_model_forward(state_dict(g, 'molhiv/state'), cx, 2, readout='mean', embed='ogb')
+    for k, v in partial.items():
+        torch.testing.assert_close(v, T(g[f'molhiv/{k}']), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y, T(g['molhiv/out']), rtol=1e-4, atol=1e-4)
