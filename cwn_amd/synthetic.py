@@ -257,7 +257,8 @@ def preferential_attachment_graph(rng: np.random.Generator, n: int, m: int = 2, 
 
 
 def clique_lift(n: int, edges: Sequence[Tuple[int, int]], vx: torch.Tensor, max_dim: int = 2,
-                init_method: str = 'sum', y: Optional[torch.Tensor] = None) -> Complex:
+                init_method: str = 'sum', y: Optional[torch.Tensor] = None,
+                include_down_adj: bool = False) -> Complex:
     """compute_clique_complex_with_gudhi (data/utils.py:224-272) restated for expansion_dim <= 2:
     vertices, edges in lexicographic (u<v) order, triangles in lexicographic order (the order of a
     gudhi SimplexTree traversal); upper adjacencies as build_adj (:103-138); boundaries of a
@@ -299,22 +300,33 @@ def clique_lift(n: int, edges: Sequence[Tuple[int, int]], vx: torch.Tensor, max_
         f = vx[g]                                    # [cells, k, F]
         return f.sum(1) if init_method in ('sum', 'add') else f.mean(1)
 
+    def lower(members_of_cell, n_lower):
+        cof = [[] for _ in range(n_lower)]
+        for cid, members in enumerate(members_of_cell):
+            for m in members:
+                cof[m].append(cid)
+        return pairs(cof)
+
     dim = 2 if tris else (1 if edges else 0)
     v_up, v_cob = pairs([list(e) for e in edges])
     cochains = [Cochain(dim=0, x=vx, upper_index=idx_tensor(v_up), shared_coboundaries=vec_tensor(v_cob),
                         num_cells=n, num_cells_up=len(edges) if dim >= 1 else 0)]
     if dim >= 1:
         e_up, e_cob = pairs(tri_edges)
+        e_down, e_bnd = lower([list(e) for e in edges], n) if include_down_adj else ([], [])
         b_index = torch.tensor([[v for e in edges for v in e],
                                 [i for i in range(len(edges)) for _ in range(2)]], dtype=torch.long)
         cochains.append(Cochain(dim=1, x=reduce_feats([list(e) for e in edges]), upper_index=idx_tensor(e_up),
-                                shared_coboundaries=vec_tensor(e_cob), boundary_index=b_index,
+                                shared_coboundaries=vec_tensor(e_cob), lower_index=idx_tensor(e_down),
+                                shared_boundaries=vec_tensor(e_bnd), boundary_index=b_index,
                                 num_cells=len(edges), num_cells_down=n,
                                 num_cells_up=len(tris) if dim >= 2 else 0))
     if dim >= 2:
+        t_down, t_bnd = lower(tri_edges, len(edges)) if include_down_adj else ([], [])
         b_index = torch.tensor([[e for es in tri_edges for e in es],
                                 [i for i in range(len(tris)) for _ in range(3)]], dtype=torch.long)
-        cochains.append(Cochain(dim=2, x=reduce_feats([list(t) for t in tris]), boundary_index=b_index,
+        cochains.append(Cochain(dim=2, x=reduce_feats([list(t) for t in tris]), lower_index=idx_tensor(t_down),
+                                shared_boundaries=vec_tensor(t_bnd), boundary_index=b_index,
                                 num_cells=len(tris), num_cells_down=len(edges), num_cells_up=0))
     return Complex(*cochains, y=y, dimension=dim)
 
