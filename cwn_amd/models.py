@@ -40,30 +40,43 @@ def get_graph_norm(norm):
     raise ValueError(f'Graph Normalisation {norm} not currently supported')
 
 
-def global_pool(x: torch.Tensor, batch: torch.Tensor, size: int, mean: bool = False) -> torch.Tensor:
-    """global_add_pool / global_mean_pool (K11) as a segmented reduce keyed on the batch vector."""
+def _batch_adjacency(batch: torch.Tensor, size: int, n_rows: int):
+    """CSR keyed on the batch vector (cells of complex b = segment b), cached on the tensor."""
     ids = getattr(batch, '_cwn_ids', None)
     if ids is None or ids.numel() != batch.numel():
         ids = torch.arange(batch.numel(), device=batch.device)
-        index = torch.stack([ids, batch])
-        batch._cwn_ids, batch._cwn_index = ids, index
-    adj = cached_adjacency(batch._cwn_index, size, x.size(0))
-    return ops.aggregate(adj, size, x, reduce='mean' if mean else 'add')
+        batch._cwn_ids, batch._cwn_index = ids, torch.stack([ids, batch])
+    return cached_adjacency(batch._cwn_index, size, n_rows)
 
 
-def pool_complex(xs: List[torch.Tensor], data: ComplexBatch, max_dim: int, readout_type: str):
-    """mp/nn.py:50-60 -> [max_dim+1, num_complexes, H]; rows of absent dimensions stay zero.
-    The batch size comes from the container instead of `batch.max() + 1` (a device sync)."""
+def global_pool(x: torch.Tensor, batch: torch.Tensor, size: int, mean: bool = False) -> torch.Tensor:
+    """global_add_pool / global_mean_pool (K11) as a segmented reduce keyed on the batch vector."""
+    return ops.aggregate(_batch_adjacency(batch, size, x.size(0)), size, x,
+                         reduce='mean' if mean else 'add')
+
+
+def pool_complex_list(xs: List[torch.Tensor], data: ComplexBatch, max_dim: int, readout_type: str):
+    """Per-dimension readout of all dimensions in ONE segmented-reduce launch; absent dimensions
+    give zero rows (mp/nn.py:55-56)."""
     if readout_type not in ('sum', 'mean'):
         raise NotImplementedError(f'Readout {readout_type} is not currently supported.')
     batch_size = data.num_complexes
     if batch_size is None:
         batch_size = int(data.cochains[0].batch.max()) + 1
-    pooled = [global_pool(xs[i], data.cochains[i].batch, batch_size, readout_type == 'mean')
-              for i in range(len(xs))]
+    red = 'mean' if readout_type == 'mean' else 'add'
+    streams = [ops.Stream(adj=_batch_adjacency(data.cochains[i].batch, batch_size, xs[i].size(0)),
+                          n_dst=batch_size, width=int(xs[i].size(1)), A=xs[i], reduce=red)
+               for i in range(len(xs))]
+    pooled = ops.aggregate_many(streams)
     for _ in range(len(xs), max_dim + 1):
         pooled.append(torch.zeros_like(pooled[0]))
-    return torch.stack(pooled, dim=0)
+    return pooled
+
+
+def pool_complex(xs: List[torch.Tensor], data: ComplexBatch, max_dim: int, readout_type: str):
+    """mp/nn.py:50-60 -> [max_dim+1, num_complexes, H]; rows of absent dimensions stay zero.
+    The batch size comes from the container instead of `batch.max() + 1` (a device sync)."""
+    return torch.stack(pool_complex_list(xs, data, max_dim, readout_type), dim=0)
 
 
 ATOM_DIMS = (119, 4, 12, 12, 10, 6, 6, 2, 2)   # OGB convention (third-party; see SURVEY.md §7.2)
@@ -162,28 +175,36 @@ class _SparseCINStack(torch.nn.Module):
                     jump_xs[i] += [x]
         if self.jump_mode is not None:
             xs = [torch.cat(j, dim=-1) for j in jump_xs]
-        pooled = pool_complex(xs, data, self.max_dim, self.readout)
+        pooled = pool_complex_list(xs, data, self.max_dim, self.readout)
         xs = [pooled[i] for i in self.readout_dims]
         if include_partial:
             for k in range(len(xs)):
                 res[f'pool_{k}'] = xs[k]
-        new_xs = []
-        for i, x in enumerate(xs):
-            if self.apply_dropout_before == 'lin1':
-                x = F.dropout(x, p=self.dropout_rate, training=self.training)
-            new_xs.append(act(self.lin1s[self.readout_dims[i]](x)))
-        x = torch.stack(new_xs, dim=0)
-        if self.apply_dropout_before == 'final_readout':
-            x = F.dropout(x, p=self.dropout_rate, training=self.training)
-        if self.final_readout == 'mean':
-            x = x.mean(0)
-        elif self.final_readout == 'sum':
-            x = x.sum(0)
-        else:
+        if self.final_readout not in ('mean', 'sum'):
             raise NotImplementedError
+        lins = [self.lin1s[d] for d in self.readout_dims]
+        dense_head = (self.nonlinearity == 'relu' and xs[0].is_cuda
+                      and max(l.in_features for l in lins + [self.lin2]) <= ops.GEMM_MAX_K)
+        if self.apply_dropout_before == 'lin1':
+            xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
+        if dense_head:     # lin1s of all dimensions (+ReLU) in ONE grouped MFMA launch
+            new_xs = ops.gemm_many([ops.Gemm(X=x, W=l.weight, bias=l.bias, relu=True)
+                                    for x, l in zip(xs, lins)])
+        else:
+            new_xs = [act(l(x)) for x, l in zip(xs, lins)]
+        if self.apply_dropout_before == 'final_readout':
+            new_xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in new_xs]
+        x = new_xs[0]
+        for t in new_xs[1:]:
+            x = x + t
+        if self.final_readout == 'mean':
+            x = x / len(new_xs)
         if self.apply_dropout_before not in ['lin1', 'final_readout']:
             x = F.dropout(x, p=self.dropout_rate, training=self.training)
-        x = self.lin2(x)
+        if dense_head:
+            x, = ops.gemm_many([ops.Gemm(X=x, W=self.lin2.weight, bias=self.lin2.bias)])
+        else:
+            x = self.lin2(x)
         if include_partial:
             res['out'] = x
             return x, res
