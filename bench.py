@@ -161,13 +161,33 @@ def main():
                     with torch.cuda.graph(g):
                         keep = fn(bi)
                     graphs.append((g, keep))
-            run = (lambda i: graphs[i % nb][0].replay()) if use_graph else (lambda i: fn(i % nb))
-            for i in range(warmup):
-                run(i)
+                # a graph launch costs ~9 us of host/queue time whatever it holds, so the steady-state
+                # loop replays ONE graph that holds a step of every distinct batch (nb steps)
+                g_all = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_all):
+                    keep_all = [fn(bi) for bi in range(nb)]
+
+            def run_steps(n_steps, start=0):
+                """exactly n_steps steps, batches cycled"""
+                if not use_graph:
+                    for i in range(n_steps):
+                        fn((start + i) % nb)
+                    return
+                i = 0
+                while i < n_steps and (start + i) % nb != 0:       # align to batch 0
+                    graphs[(start + i) % nb][0].replay()
+                    i += 1
+                while n_steps - i >= nb:
+                    g_all.replay()
+                    i += nb
+                while i < n_steps:
+                    graphs[(start + i) % nb][0].replay()
+                    i += 1
+
+            run_steps(warmup)
             barrier()
             t0 = time.perf_counter()
-            for i in range(steps):
-                run(i)
+            run_steps(steps, start=warmup)
             barrier()
             dt = time.perf_counter() - t0
         if dist is not None:
@@ -187,7 +207,7 @@ def main():
         torch.cuda.synchronize()
         dt = timed(propagate_scope, args.steps, args.warmup, False)
 
-    cells_per_step_local = sum(stats[i % len(stats)]['cells'] for i in range(args.steps)) * L / args.steps
+    cells_per_step_local = sum(stats[(args.warmup + i) % len(stats)]['cells'] for i in range(args.steps)) * L / args.steps
     cells_total = torch.tensor([cells_per_step_local * args.steps], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(cells_total)
@@ -212,9 +232,37 @@ def main():
     if dist is not None:
         dist.all_reduce(full_cells)
 
-    # ---- roofline of the dominant kernel (aggregate_kernel: one launch per layer) ----------------
-    roofline = None
+    # ---- rooflines: both kernels of a layer are measured live; the one with the larger share of the
+    # step is `roofline` (dominant), the other `roofline_other` ---------------------------------------
+    roofline = roofline_other = None
     if rank == 0 and not args.only_primary:
+        MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA, dense
+
+        def replay_us(fn, reps):
+            """Average duration of back-to-back dependent launches replayed from a hipGraph, between
+            two HIP events on the replay stream (the host -- Python/ctypes, ~4 us per call -- is out
+            of the measurement; the ~1.5 us dependent-launch boundary is in)."""
+            fn()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            kg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(kg):
+                for _ in range(reps):
+                    fn()
+            kg.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                kg.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / (5 * reps)
+
         b, feats = batches[0], layer_inputs[0]
         with torch.no_grad():
             csr._cache.clear()
@@ -222,7 +270,8 @@ def main():
             b.set_xs(feats[1])
             params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
             lv = model.convs[1].mp_levels
-            ys = ops.gemm_many([sp for d in range(3) for sp in lv[d].gemm_specs(params[d])])
+            gemms = [sp for d in range(3) for sp in lv[d].gemm_specs(params[d])]
+            ys = ops.run_gemm(gemms, dev)
             streams = (lv[0].streams(params[0], ys[0:2]) + lv[1].streams(params[1], ys[2:4]) +
                        lv[2].streams(params[2]))
             for st in streams:
@@ -236,31 +285,10 @@ def main():
                     if st.msg_op != ops.MSG_A:
                         s.B, s.ib = st.B, st.adj.aux
                 specs.append(s)
-            ops.run_aggregate(specs, dev)
-            torch.cuda.synchronize()
-            reps = args.kernel_reps
-            # the launches are replayed from a hipGraph so the host (Python/ctypes, ~15 us per
-            # call) is out of the measurement; the two events sit on the replay stream
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                ops.run_aggregate(specs, dev)
-            torch.cuda.current_stream().wait_stream(side)
-            kg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(kg):
-                for _ in range(reps):
-                    ops.run_aggregate(specs, dev)
-            kg.replay()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                kg.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            k_us = e0.elapsed_time(e1) * 1e3 / (5 * reps)
+            agg_us = replay_us(lambda: ops.run_aggregate(specs, dev), args.kernel_reps)
+            gemm_us = replay_us(lambda: ops.run_gemm(gemms, dev), args.kernel_reps)
         alg = layer_algorithmic_bytes(stats[0], H, coboundary=True)
-        achieved = alg / (k_us * 1e-6) / 1e9
+        achieved = alg / (agg_us * 1e-6) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same
         # workload shape); None when no pass exists for this configuration
         traffic = None
@@ -271,14 +299,26 @@ def main():
                 traffic = tj['entries'][str(args.batch)]['traffic_bytes']
         except (OSError, ValueError, KeyError):
             traffic = None
-        roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel<4>', 'achieved': round(achieved, 1),
-                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                    'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
-                    'avg_launch_us': round(k_us, 3),
-                    'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4),
-                    'note': 'avg over back-to-back dependent launches replayed from a hipGraph between two '
-                            'HIP events (includes the ~1.5 us inter-kernel boundary; rocprofv3 kernel-only '
-                            'average is in profiles/); the batch fits L2/MALL'}
+        step_us = dt / args.steps * 1e6
+        r_agg = {'bound': 'hbm', 'kernel': 'aggregate_kernel<4> (fused gather-message-reduce, all dims of a layer)',
+                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                 'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(agg_us, 3),
+                 'launches_per_step': L, 'share_of_step': round(L * agg_us / step_us, 3),
+                 'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4)}
+        flops = 2.0 * sum(g.X.size(0) * g.W.size(0) * g.W.size(1) for g in gemms)
+        tf = flops / (gemm_us * 1e-6) / 1e12
+        r_gemm = {'bound': 'mfma', 'kernel': 'gemm_kernel<fast,128> (grouped fp32-MFMA GEMM: coboundary-message products Y1, Y2)',
+                  'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                  'frac': round(tf / MFMA_F32_PEAK_TF, 4), 'traffic': None,
+                  'algorithmic_flops_per_launch': int(flops), 'avg_launch_us': round(gemm_us, 3),
+                  'launches_per_step': L, 'share_of_step': round(L * gemm_us / step_us, 3)}
+        note = ('avg over back-to-back dependent launches replayed from a hipGraph between two HIP events '
+                '(includes the ~1.5 us inter-kernel boundary; rocprofv3 kernel-only averages are in profiles/, '
+                'where few-us kernels read ~1.5-3 us high); batch 128 is latency-bound and L2/MALL-resident')
+        roofline, roofline_other = ((r_gemm, r_agg) if r_gemm['share_of_step'] >= r_agg['share_of_step']
+                                    else (r_agg, r_gemm))
+        roofline['note'] = note
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample -----------------------------
     cpu_baseline = None
@@ -376,7 +416,7 @@ def main():
                        'B': [s0['B0'], s0['B1'], s0['B2']],
                        'launch': 'hipGraph replay' if use_graph else 'eager',
                        'plan_build_in_step': True, 'parallelism': f'replicas x{world} (no data-path collective)'},
-            'roofline': roofline, 'cpu_baseline': cpu_baseline,
+            'roofline': roofline, 'roofline_other': roofline_other, 'cpu_baseline': cpu_baseline,
             'secondary': {'full_forward_cells_per_s': round(float(full_cells.item()) / dt_full, 1),
                           'full_forward_ms': round(dt_full / full_steps * 1e3, 5),
                           'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '

@@ -189,99 +189,150 @@ __global__ __launch_bounds__(kThreads) void emit_kernel(CsrBatch B) {
     if (D.aux_out != nullptr) D.aux_out[P] = (int32_t)D.aux[e];
 }
 
-// ---- small path: ONE launch, one 1024-thread workgroup per descriptor, everything in LDS --------
-// Used when (n_dst + 1 + 3 E) ints fit 150 KiB of the 160 KiB LDS of a CU for every descriptor of the call
-// (a ZINC batch of 128 has E <= 8.2e3, n_dst <= 3.4e3 per adjacency).  At this size the general
-// path is six dependent launches of ~5 us each; here the same four phases are separated by
-// workgroup barriers instead of kernel boundaries.
+// ---- small path: ONE launch, everything in LDS ---------------------------------------------------
+// Used when the per-workgroup LDS need (see small_lds_ints) fits 150 KiB for every descriptor of
+// the call (a ZINC batch of 128 has E <= 8.2e3, n_dst <= 3.4e3 per adjacency).  At this size the
+// general path is six dependent launches; here the phases are separated by workgroup barriers.
+// One workgroup can only pull ~50 GB/s, and an adjacency is ~0.4 MB of index traffic, so each
+// descriptor is split into up to kMaxParts ROW RANGES handled by independent workgroups: a part
+// scans every key (to count the entries of smaller rows -- its base offset -- and to pick its own
+// entries) but touches val / aux and the outputs only for its own rows.  No inter-workgroup
+// communication is needed.
 constexpr int kSmallThreads = 1024;
 constexpr size_t kSmallLdsBytes = 150 * 1024;
+constexpr int kMaxParts = 8;
 
-__global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(CsrBatch B, int32_t* err) {
+struct SmallBatch {
+    cwn_csr_desc d[CWN_MAX_DESCS];
+    int32_t part_start[CWN_MAX_DESCS + 1];   // first workgroup of each descriptor
+    int32_t n;
+};
+
+inline int small_parts(int64_t n_entries, int64_t n_dst) {
+    int64_t p = (n_entries + 1535) / 1536;
+    if (p > kMaxParts) p = kMaxParts;
+    if (p > n_dst) p = n_dst;
+    return p < 1 ? 1 : (int)p;
+}
+
+inline size_t small_lds_ints(int64_t n_entries, int64_t n_dst) {
+    const int parts = small_parts(n_entries, n_dst);
+    const int64_t rows = (n_dst + parts - 1) / parts;
+    return (size_t)(rows + 1 + 3 * n_entries + 8);       // cnt | ent | slot | byrow | misc
+}
+
+__global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, int32_t* err) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ int scan_tmp[32];
     constexpr int U = 8;   // independent global loads in flight per thread and phase
-    const int di = blockIdx.x;
+    int di = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+        if (i < B.n && (int)blockIdx.x >= B.part_start[i]) di = i;
     const cwn_csr_desc& D = B.d[di];
+    const int parts = B.part_start[di + 1] - B.part_start[di];
+    const int part = blockIdx.x - B.part_start[di];
     const int n = (int)D.n_dst, E = (int)D.n_entries;
-    int32_t* cnt = lds;                 // [n + 1]  counters, then exclusive row starts
-    int32_t* slot = lds + (n + 1);      // [E]      arrival slot of entry e inside its row
-    int32_t* byrow = slot + E;          // [E]      entry ids grouped by row (unordered inside)
-    int32_t* key32 = byrow + E;         // [E]      destination of entry e (-1 = dropped)
+    const int rows_per = (n + parts - 1) / parts;
+    const int lo = min(part * rows_per, n), hi = min(lo + rows_per, n);
+    const int rows = hi - lo;
+    int32_t* cnt = lds;                     // [rows + 1] counters, then exclusive row starts
+    int32_t* ent = cnt + (rows_per + 1);    // [E] original id of the part's j-th entry
+    int32_t* slot = ent + E;                // [E] arrival slot of that entry inside its row
+    int32_t* byrow = slot + E;              // [E] local entry ids grouped by row
+    int32_t* misc = byrow + E;              // [0] entries of smaller rows, [1] entries of this part
     const bool has_aux = D.aux != nullptr;
-    for (int i = threadIdx.x; i <= n; i += kSmallThreads) cnt[i] = 0;
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i <= rows; i += kSmallThreads) cnt[i] = 0;
+    if (threadIdx.x < 2) misc[threadIdx.x] = 0;
     __syncthreads();
-    // phase 1: read the COO once (U independent loads per array per thread), count per row
+    // phase 1: every key once (U independent loads per thread); wave-aggregated bookkeeping
+    int below_local = 0;
     for (int base = 0; base < E; base += kSmallThreads * U) {
-        int64_t k[U], v[U], a[U];
+        int64_t k[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e = base + u * kSmallThreads + threadIdx.x;
-            const int ec = e < E ? e : E - 1;          // clamped: unconditional loads
-            k[u] = D.key[ec];
-            v[u] = D.val[ec];
-            a[u] = has_aux ? D.aux[ec] : 0;
+            k[u] = D.key[e < E ? e : E - 1];          // clamped: unconditional loads
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e = base + u * kSmallThreads + threadIdx.x;
-            if (e >= E) continue;
-            int bad = 0;
-            if (k[u] < 0 || k[u] >= D.n_dst) bad |= 1;
-            if (v[u] < 0 || v[u] >= D.n_val) bad |= 2;
-            if (has_aux && (a[u] < 0 || a[u] >= D.n_aux)) bad |= 4;
-            if (bad) {
-                atomicOr(err, bad);
-                key32[e] = -1;
-                slot[e] = -1;
-            } else {
-                key32[e] = (int)k[u];
-                slot[e] = atomicAdd(&cnt[(int)k[u]], 1);
+            const bool live = e < E;
+            const bool bad = live && (k[u] < 0 || k[u] >= D.n_dst);
+            if (bad && part == 0) atomicOr(err, 1);
+            below_local += (live && !bad && k[u] < lo) ? 1 : 0;
+            const bool mine = live && !bad && k[u] >= lo && k[u] < hi;
+            const unsigned long long m = __ballot(mine);
+            int wbase = 0;
+            if (lane == 0 && m) wbase = atomicAdd(&misc[1], __popcll(m));
+            wbase = __shfl(wbase, 0, 64);
+            if (mine) {
+                const int li = wbase + __popcll(m & ((1ull << lane) - 1ull));
+                ent[li] = e;
+                slot[li] = atomicAdd(&cnt[(int)k[u] - lo], 1);
             }
         }
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) below_local += __shfl_xor(below_local, o, 64);
+    if (lane == 0 && below_local) atomicAdd(&misc[0], below_local);
     __syncthreads();
-    // phase 2: exclusive scan of cnt[0..n) in place; cnt[n] = total
+    const int gbase = misc[0], mine_total = misc[1];
+    // phase 2: exclusive scan of the part's counters in place; global row pointers
     int running = 0;
-    for (int base = 0; base < n; base += kSmallThreads) {
+    for (int base = 0; base < rows; base += kSmallThreads) {
         const int i = base + threadIdx.x;
-        const int c = i < n ? cnt[i] : 0;
+        const int c = i < rows ? cnt[i] : 0;
         int total;
         const int ex = block_exclusive_scan(c, &total, scan_tmp);
-        if (i < n) {
+        if (i < rows) {
             cnt[i] = running + ex;
-            D.rowptr[i] = running + ex;
+            D.rowptr[lo + i] = gbase + running + ex;
         }
         running += total;
     }
     if (threadIdx.x == 0) {
-        cnt[n] = running;
-        D.rowptr[n] = running;
+        cnt[rows] = running;
+        if (part == parts - 1) D.rowptr[n] = gbase + running;
     }
     __syncthreads();
-    // phase 3: group entry ids by row (LDS only)
-    for (int e = threadIdx.x; e < E; e += kSmallThreads) {
-        const int s = slot[e];
-        if (s >= 0) byrow[cnt[key32[e]] + s] = e;
-    }
-    __syncthreads();
-    // phase 4: stable rank inside the row (LDS only), then the gathered outputs
-    const int valid = cnt[n];
-    for (int base = 0; base < valid; base += kSmallThreads * U) {
-        int e[U], P[U];
+    // phase 3: group the part's entries by row (LDS only; keys re-read for own entries only)
+    for (int base = 0; base < mine_total; base += kSmallThreads * U) {
+        int64_t k[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = base + u * kSmallThreads + threadIdx.x;
-            e[u] = -1;
+            const int li = base + u * kSmallThreads + threadIdx.x;
+            k[u] = D.key[ent[li < mine_total ? li : 0]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int li = base + u * kSmallThreads + threadIdx.x;
+            if (li < mine_total) byrow[cnt[(int)k[u] - lo] + slot[li]] = li;
+        }
+    }
+    __syncthreads();
+    // phase 4: stable rank inside the row by ORIGINAL entry id, then the gathered outputs.
+    // Position p of byrow belongs to the row r with cnt[r] <= p < cnt[r+1]; instead of searching,
+    // every local entry recomputes its row from its key.
+    for (int base = 0; base < mine_total; base += kSmallThreads * U) {
+        int e[U], P[U];
+        int64_t k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int li = base + u * kSmallThreads + threadIdx.x;
+            e[u] = li < mine_total ? ent[li] : -1;
+            k[u] = D.key[e[u] >= 0 ? e[u] : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             P[u] = 0;
-            if (p < valid) {
-                const int ee = byrow[p];
-                const int r = key32[ee];
+            if (e[u] >= 0) {
+                const int r = (int)k[u] - lo;
                 const int s = cnt[r], t = cnt[r + 1];
                 int rank = 0;
-                for (int q = s; q < t; ++q) rank += (byrow[q] < ee) ? 1 : 0;
-                e[u] = ee;
-                P[u] = s + rank;
+                for (int q = s; q < t; ++q) rank += (ent[byrow[q]] < e[u]) ? 1 : 0;
+                P[u] = gbase + s + rank;
             }
         }
         int64_t v[U], a[U];
@@ -294,9 +345,17 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(CsrBatch B, in
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (e[u] < 0) continue;
+            int bad = 0;
+            if (v[u] < 0 || v[u] >= D.n_val) bad |= 2;
+            if (has_aux && (a[u] < 0 || a[u] >= D.n_aux)) bad |= 4;
+            if (bad) atomicOr(err, bad);
+            // out-of-range values are reported AND clamped, so that a consumer that runs before the
+            // host has looked at the error word (stream capture, overlap mode) can never fault
+            const int64_t vc = v[u] < 0 ? 0 : (v[u] >= D.n_val ? D.n_val - 1 : v[u]);
+            const int64_t ac = a[u] < 0 ? 0 : (a[u] >= D.n_aux ? D.n_aux - 1 : a[u]);
             D.perm[P[u]] = e[u];
-            D.col[P[u]] = (int32_t)v[u];
-            if (D.aux_out != nullptr) D.aux_out[P[u]] = (int32_t)a[u];
+            D.col[P[u]] = (int32_t)vc;
+            if (D.aux_out != nullptr) D.aux_out[P[u]] = (int32_t)ac;
         }
     }
 }
@@ -357,7 +416,7 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
     // small path: no workspace, one launch
     size_t small_bytes = 0;
     for (int i = 0; i < n; ++i) {
-        const size_t need = (size_t)(descs[i].n_dst + 1 + 3 * descs[i].n_entries) * 4;
+        const size_t need = small_lds_ints(descs[i].n_entries, descs[i].n_dst) * 4;
         if (need > small_bytes) small_bytes = need;
     }
     if (small_bytes <= kSmallLdsBytes) {
@@ -369,10 +428,16 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
                 return CWN_ERR_LAUNCH;
             attr_set = true;
         }
-        CsrBatch S{};
+        SmallBatch S{};
         S.n = n;
-        for (int i = 0; i < n; ++i) S.d[i] = descs[i];
-        csr_small_kernel<<<dim3(n), dim3(kSmallThreads), align_up(small_bytes, 16), stream>>>(S, err_flag);
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            S.d[i] = descs[i];
+            S.part_start[i] = blocks;
+            blocks += small_parts(descs[i].n_entries, descs[i].n_dst);
+        }
+        for (int i = n; i <= CWN_MAX_DESCS; ++i) S.part_start[i] = blocks;
+        csr_small_kernel<<<dim3(blocks), dim3(kSmallThreads), align_up(small_bytes, 16), stream>>>(S, err_flag);
         return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
     }
     const WsLayout L = layout(descs, n);
