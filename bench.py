@@ -400,6 +400,43 @@ def main():
                         'gpu_over_cpu': round(value / cpu_value, 1),
                         'full_forward_cells_per_s': None if cpu_full is None else round(cpu_full, 1)}
 
+    # secondary: building the batch itself -- device-side collate from the HBM-resident packed
+    # dataset vs the reference-style CPU collate (oracle restatement of data/complex.py:323-458)
+    collate = None
+    if rank == 0 and not args.only_primary:
+        try:
+            from cwn_amd.packed import PackedComplexes
+            from cwn_amd.synthetic import zinc_like_complexes
+            pool = zinc_like_complexes(4 * args.batch, seed=77)
+            packed = PackedComplexes(pool, dev, max_dim=2)
+            rng_idx = [torch.randperm(len(pool), generator=torch.Generator().manual_seed(i))[:args.batch].tolist()
+                       for i in range(8)]
+            for ix in rng_idx[:2]:
+                packed.collate(ix)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(40):
+                packed.collate(rng_idx[i % 8])
+            torch.cuda.synchronize()
+            dev_ms = (time.perf_counter() - t0) / 40 * 1e3
+            collate = {'device_ms_per_batch': round(dev_ms, 4),
+                       'scope': f'ComplexBatch of {args.batch} complexes from a packed HBM-resident dataset: host '
+                                'segment tables + 1 H2D copy + 1 launch (cwn_collate)'}
+            if not args.no_cpu:
+                from oracle import cwn_oracle as O
+                keys = ('x', 'upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries', 'boundary_index', 'y')
+                odicts = [{'dimension': c.dimension, 'y': c.y, 'cochains': [
+                    dict({k: c.cochains[d][k] for k in keys}, dim=d, num_cells=c.cochains[d].num_cells,
+                         num_cells_up=c.cochains[d].num_cells_up, num_cells_down=c.cochains[d].num_cells_down,
+                         batch=None) for d in range(c.dimension + 1)]} for c in pool]
+                O.batch_complexes([odicts[i] for i in rng_idx[0]], max_dim=2)
+                t0 = time.perf_counter()
+                for i in range(10):
+                    O.batch_complexes([odicts[j] for j in rng_idx[i % 8]], max_dim=2)
+                collate['cpu_oracle_ms_per_batch'] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+        except Exception as e:
+            print(f'[bench] collate leg failed: {type(e).__name__}: {e}', file=sys.stderr)
+
     if rank == 0:
         s0 = stats[0]
         out = {
@@ -420,10 +457,12 @@ def main():
             'secondary': {'full_forward_cells_per_s': round(float(full_cells.item()) / dt_full, 1),
                           'full_forward_ms': round(dt_full / full_steps * 1e3, 5),
                           'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '
-                                   'MLPs + BatchNorm(eval), readout, head'},
+                                   'MLPs + BatchNorm(eval), readout, head',
+                          'collate': collate},
         }
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()      # rank 0 runs the roofline / collate legs alone; leave together
         dist.destroy_process_group()
 
 

@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 1
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32')
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_collate')
 
 
 class CsrDesc(C.Structure):
@@ -45,6 +45,16 @@ class GemmDesc(C.Structure):
                 ('ldw', C.c_int64), ('ldy', C.c_int64), ('N', C.c_int32), ('K', C.c_int32),
                 ('K2', C.c_int32), ('relu', C.c_int32), ('in_relu', C.c_int32),
                 ('reserved', C.c_int32)]
+
+
+class CollateDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('dst_start', C.c_void_p),
+                ('src_start', C.c_void_p), ('add', C.c_void_p), ('src_row_stride', C.c_int64),
+                ('dst_row_stride', C.c_int64), ('n_rows', C.c_int32), ('op', C.c_int32)]
+
+
+COLLATE_COPY32, COLLATE_COPY64, COLLATE_ADD64, COLLATE_SEGID64 = range(4)
+MAX_COLLATE_DESCS = 32
 
 
 class CwnError(RuntimeError):
@@ -80,6 +90,8 @@ def lib():
     L.cwn_aggregate_f32.argtypes = [C.POINTER(AggDesc), C.c_int, C.c_void_p]
     L.cwn_gemm_f32.restype = C.c_int
     L.cwn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
+    L.cwn_collate.restype = C.c_int
+    L.cwn_collate.argtypes = [C.POINTER(CollateDesc), C.c_int, C.c_int64, C.c_void_p]
     if L.cwn_abi_version() != ABI_VERSION:
         raise CwnError(f'ABI mismatch: library {L.cwn_abi_version()} vs binding {ABI_VERSION}')
     _lib = L

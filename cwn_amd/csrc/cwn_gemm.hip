@@ -122,7 +122,16 @@ __device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, in
 }
 
 template <bool FAST, bool PRO, int KP>
-__global__ __launch_bounds__(kThreads, (KP == 128 ? 2 : 1)) void gemm_kernel(GemmBatch B) {
+#ifndef CWN_GEMM_LB
+#define CWN_GEMM_LB 2
+#endif
+#ifndef CWN_GEMM_DEEP
+#define CWN_GEMM_DEEP 1
+#endif
+#ifndef CWN_GEMM_FRAGPF
+#define CWN_GEMM_FRAGPF 0
+#endif
+__global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // two [BM][KP] X buffers
     int di = 0;
 #pragma unroll
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? 2 : 1)) void gemm_kernel(Gem
     int it = 0;
     // two X tiles in flight in registers (prefetch distance 2 when K <= 128; 1 for the K = 256 variant,
     // whose tiles are twice as large)
-    constexpr bool DEEP = KP == 128;
+    constexpr bool DEEP = KP == 128 && CWN_GEMM_DEEP;
     SX sx, sx2;
     if (tile < tiles)
         stage_load<FAST, BM, KP, 0, SX::U>(sx, (int64_t)(tile / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
@@ -239,6 +248,34 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? 2 : 1)) void gemm_kernel(Gem
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[ct][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if CWN_GEMM_FRAGPF
+        {   // explicit software pipeline of the X fragments: slab s+1 is read while slab s multiplies
+            f32x4 xa[RT], xb[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                xa[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(rt * 16 + j, g));
+#pragma unroll
+            for (int sl = 0; sl < SLABS; ++sl) {
+                if (sl * 16 < Ktot && !(dbg & 1)) {
+                    if (sl + 1 < SLABS) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            xb[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(rt * 16 + j, 4 * (sl + 1) + g));
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+                                acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    wreg[sl][ct][t], xa[rt][t], acc[ct][rt], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) xa[rt] = xb[rt];
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int sl = 0; sl < SLABS; ++sl) {
             if (sl * 16 < Ktot && !(dbg & 1)) {   // wave-uniform; slabs past K hold zeros anyway
@@ -256,6 +293,8 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? 2 : 1)) void gemm_kernel(Gem
                                 wreg[sl][ct][t], x[rt][t], acc[ct][rt], 0, 0, 0);
             }
         }
+
+#endif
 
         // epilogue: acc[ct][rt][r] = Y[m_base + rt*16 + j][n_base + ct*16 + 4g + r]
         // bias / affine / ReLU / BatchNorm statistics first, in the MFMA layout

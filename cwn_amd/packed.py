@@ -1,0 +1,196 @@
+"""Device-side batching: a dataset of complexes packed in HBM, batches built by ONE kernel.
+
+The reference collates on the CPU: `ComplexBatch.from_complex_list` (data/complex.py:690-728) ->
+`CochainBatch.from_cochain_list` (:323-458), a Python loop of per-complex tensor adds and one
+`torch.cat` per key, followed by `batch.to(device)`.  Once propagate runs in tens of microseconds
+that loop IS the step.  Here every complex's tensors are uploaded ONCE, concatenated per key
+(288 GB of HBM holds any of the reference's datasets), and `collate(indices)`:
+  * computes the per-array segment tables (lengths, source offsets, running cell offsets of
+    data/complex.py:148-169) on the host from numpy metadata -- no device sync,
+  * uploads them with ONE small H2D copy,
+  * fills every array of the ComplexBatch with ONE launch of cwn_collate.
+The integer layout is bit-exact against the reference's (tests/golden/batching.npz).
+"""
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .complex import Cochain, CochainBatch, Complex, ComplexBatch
+
+_INDEX_KEYS = ('upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries', 'boundary_index')
+_ALL_KEYS = ('x', 'y') + _INDEX_KEYS
+
+
+class _Packed:
+    """One key of one dimension, all complexes concatenated along the last axis."""
+    __slots__ = ('data', 'start', 'length', 'has', 'rows', 'width', 'op')
+
+    def __init__(self, data, start, length, has, rows, width, op):
+        self.data, self.start, self.length, self.has = data, start, length, has
+        self.rows, self.width, self.op = rows, width, op
+
+
+class PackedComplexes:
+    """`complexes` (cwn_amd Complex objects with CPU tensors) packed on `device`."""
+
+    def __init__(self, complexes: Sequence[Complex], device, max_dim: int = 2):
+        self.device = torch.device(device)
+        self.max_dim = max_dim
+        self.num = len(complexes)
+        self.dims = np.array([min(c.dimension, max_dim) for c in complexes], dtype=np.int64)
+        C = self.num
+        D = max_dim + 1
+        self.n_cells = np.zeros((D, C), dtype=np.int64)
+        self.has_cells = np.zeros((D, C), dtype=bool)
+        self.n_up = np.zeros((D, C), dtype=np.int64)
+        self.n_down = np.zeros((D, C), dtype=np.int64)
+        for ci, cx in enumerate(complexes):
+            for d in range(D):
+                if d in cx.cochains and d <= cx.dimension:
+                    c = cx.cochains[d]
+                    n = c.num_cells
+                    self.has_cells[d, ci] = n is not None
+                    self.n_cells[d, ci] = n or 0
+                    self.n_up[d, ci] = c.num_cells_up or 0
+                    self.n_down[d, ci] = (c.num_cells_down or 0) if d > 0 else 0
+                elif d - 1 in cx.cochains:
+                    # a complex without this dimension still shifts later boundary indices by its
+                    # number of (d-1)-cells (data/complex.py:709-716)
+                    self.n_down[d, ci] = cx.cochains[d - 1].num_cells or 0
+        self.keys: List[Dict[str, _Packed]] = []
+        for d in range(D):
+            per_key = {}
+            for key in _ALL_KEYS:
+                items = [(cx.cochains[d][key] if (d in cx.cochains and d <= cx.dimension) else None)
+                         for cx in complexes]
+                if all(t is None for t in items):
+                    continue
+                per_key[key] = self._pack(items, key)
+            self.keys.append(per_key)
+        ys = [cx.y for cx in complexes]
+        self.y = self._pack(ys, 'y') if all(t is not None for t in ys) else None
+
+    def _pack(self, items, key) -> _Packed:
+        ref = next(t for t in items if t is not None)
+        two_rows = key in ('upper_index', 'lower_index', 'boundary_index')
+        width = 1
+        if key == 'x':
+            width = int(ref.size(1)) if ref.dim() == 2 else 1
+        lengths = np.array([0 if t is None else (int(t.size(-1)) if key != 'x' else int(t.size(0)) * width)
+                            for t in items], dtype=np.int64)
+        has = np.array([t is not None for t in items], dtype=bool)
+        start = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+        present = [t for t in items if t is not None]
+        if key == 'x':
+            data = torch.cat([t.reshape(-1) for t in present])
+        else:
+            data = torch.cat([t.unsqueeze(0) if t.dim() == 0 else t for t in present], dim=-1)
+        if data.dtype == torch.float32 or data.dtype == torch.int32:
+            op = _ffi.COLLATE_COPY32
+        elif data.dtype == torch.int64:
+            op = _ffi.COLLATE_ADD64 if key in _INDEX_KEYS else _ffi.COLLATE_COPY64
+        else:
+            raise TypeError(f'{key}: unsupported dtype {data.dtype} (float32 / int32 / int64 only)')
+        return _Packed(data.contiguous().to(self.device), start, lengths, has, 2 if two_rows else 1, width, op)
+
+    # --------------------------------------------------------------------------------------------
+    def collate(self, idx: Sequence[int]) -> ComplexBatch:
+        """The ComplexBatch of complexes `idx` (in that order), on the device."""
+        idx = np.asarray(idx, dtype=np.int64)
+        B = int(idx.size)
+        dimension = int(self.dims[idx].max())
+        dev = self.device
+        tables: List[np.ndarray] = []
+        plan = []           # (packed, out tensor, table offsets (dst_start, src_start, add), out rows stride)
+        cur = 0
+
+        def table(arr):
+            nonlocal cur
+            off = cur
+            tables.append(np.ascontiguousarray(arr, dtype=np.int64).reshape(-1))
+            cur += tables[-1].size
+            return off
+
+        def excl(v):
+            return np.concatenate([[0], np.cumsum(v)[:-1]]).astype(np.int64)
+
+        cochains = []
+        for d in range(dimension + 1):
+            n_sel = self.n_cells[d, idx]
+            off_here, off_down, off_up = excl(n_sel), excl(self.n_down[d, idx]), excl(self.n_up[d, idx])
+            cb = CochainBatch(d)
+            for key, pk in self.keys[d].items():
+                if not pk.has[idx].any():
+                    continue
+                lens = pk.length[idx]
+                total = int(lens.sum())
+                dst_start = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                if key == 'x':
+                    out = torch.empty(total // pk.width, pk.width, dtype=pk.data.dtype, device=dev)
+                elif pk.rows == 2:
+                    out = torch.empty(2, total, dtype=pk.data.dtype, device=dev)
+                else:
+                    out = torch.empty(total, dtype=pk.data.dtype, device=dev)
+                add = None
+                if key in ('upper_index', 'lower_index'):
+                    add = np.stack([off_here, off_here])
+                elif key == 'shared_boundaries':
+                    add = off_down[None]
+                elif key == 'shared_coboundaries':
+                    add = off_up[None]
+                elif key == 'boundary_index':
+                    add = np.stack([off_down, off_here])
+                plan.append((pk, out, table(dst_start), table(pk.start[idx]),
+                             None if add is None else table(add), total))
+                if key == 'x':
+                    cb._x = out
+                else:
+                    setattr(cb, key, out)
+            # batch vector: complexes that have cells of this dimension, numbered by position
+            if self.has_cells[d, idx].any():
+                total = int(n_sel.sum())
+                out = torch.empty(total, dtype=torch.int64, device=dev)
+                plan.append((None, out, table(np.concatenate([[0], np.cumsum(n_sel)])), None, None, total))
+                cb.batch = out
+                cb.ptr = [0] + np.cumsum(n_sel[self.has_cells[d, idx]]).tolist()
+            cb.__num_cells__ = int(n_sel.sum())
+            cb.__num_cells_up__ = int(self.n_up[d, idx].sum())
+            if d > 0:
+                cb.__num_cells_down__ = int(self.n_down[d, idx].sum())
+            cb.__num_cochains__ = B
+            cochains.append(cb)
+        y = None
+        if self.y is not None:
+            lens = self.y.length[idx]
+            y = torch.empty(int(lens.sum()), dtype=self.y.data.dtype, device=dev)
+            plan.append((self.y, y, table(np.concatenate([[0], np.cumsum(lens)])), table(self.y.start[idx]),
+                         None, int(lens.sum())))
+        # one H2D copy for every table, one launch for every array
+        tab = torch.from_numpy(np.concatenate(tables)).to(dev, non_blocking=True)
+        base = tab.data_ptr()
+        descs = []
+        for pk, out, o_dst, o_src, o_add, total in plan:
+            if total == 0:
+                continue
+            if pk is None:
+                descs.append(_ffi.CollateDesc(src=None, dst=out.data_ptr(), dst_start=base + 8 * o_dst,
+                                              src_start=None, add=None, src_row_stride=0, dst_row_stride=0,
+                                              n_rows=1, op=_ffi.COLLATE_SEGID64))
+                continue
+            descs.append(_ffi.CollateDesc(
+                src=pk.data.data_ptr(), dst=out.data_ptr(), dst_start=base + 8 * o_dst,
+                src_start=base + 8 * o_src, add=None if o_add is None else base + 8 * o_add,
+                src_row_stride=pk.data.size(-1) if pk.rows == 2 else 0,
+                dst_row_stride=total if pk.rows == 2 else 0, n_rows=pk.rows, op=pk.op))
+        L = _ffi.lib()
+        s = _ffi.stream_ptr(dev)
+        for i in range(0, len(descs), _ffi.MAX_COLLATE_DESCS):
+            chunk = descs[i:i + _ffi.MAX_COLLATE_DESCS]
+            arr = (_ffi.CollateDesc * len(chunk))(*chunk)
+            _ffi.check(L.cwn_collate(arr, len(chunk), B, s), 'cwn_collate')
+        tab.record_stream(torch.cuda.current_stream(dev))
+        batch = ComplexBatch(*cochains, y=y, num_complexes=B, dimension=dimension)
+        batch._collate_tables = tab     # keep the tables alive until the launch has consumed them
+        return batch

@@ -187,6 +187,38 @@ typedef struct cwn_gemm_desc {
 
 int cwn_gemm_f32(const cwn_gemm_desc* descs_host, int n, cwn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-side batching (collate): build the arrays of a ComplexBatch from a dataset that is
+ * resident in HBM in packed form, with ONE launch.
+ *
+ * Replaces the CPU collate of the reference: CochainBatch.from_cochain_list /
+ * ComplexBatch.from_complex_list (data/complex.py:323-458, 690-728) -- per key, concatenate the
+ * selected complexes' tensors and add the running cell offsets of data/complex.py:148-169.
+ * Every output array is a concatenation of `n_seg` segments (one per selected complex):
+ *     out[r][dst_start[s] + q] = op( src[r][src_start[s] + q], add[r][s], s )   0 <= q < len(s)
+ * with len(s) = dst_start[s+1] - dst_start[s], r < n_rows (2 for [2,E] index tensors).
+ *   CWN_COLLATE_COPY32 / COPY64  plain copy of 4- / 8-byte elements (features, labels)
+ *   CWN_COLLATE_ADD64            int64 element + add[r][s]            (index tensors)
+ *   CWN_COLLATE_SEGID64          int64 segment number s               (the `batch` vector)
+ * Tables (dst_start [n_seg+1], src_start [n_seg], add [n_rows][n_seg]) are int64 device arrays.
+ * ------------------------------------------------------------------------------------------ */
+enum { CWN_COLLATE_COPY32 = 0, CWN_COLLATE_COPY64 = 1, CWN_COLLATE_ADD64 = 2, CWN_COLLATE_SEGID64 = 3 };
+#define CWN_MAX_COLLATE_DESCS 32
+
+typedef struct cwn_collate_desc {
+    const void* src;          /* row r starts at src + r * src_row_stride elements */
+    void* dst;                /* row r starts at dst + r * dst_row_stride elements */
+    const int64_t* dst_start; /* [n_seg + 1] */
+    const int64_t* src_start; /* [n_seg] */
+    const int64_t* add;       /* [n_rows * n_seg] or NULL */
+    int64_t src_row_stride;
+    int64_t dst_row_stride;
+    int32_t n_rows;
+    int32_t op;
+} cwn_collate_desc;
+
+int cwn_collate(const cwn_collate_desc* descs_host, int n, int64_t n_seg, cwn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

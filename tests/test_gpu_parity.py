@@ -802,3 +802,56 @@ def test_reddit_like_full_size_vs_oracle():
         torch.testing.assert_close(cpu(res[k]) / scale, v / scale, rtol=1e-4, atol=1e-5)
     scale = max(1.0, float(ref.abs().max()))
     torch.testing.assert_close(cpu(y) / scale, ref / scale, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side collate: bit-exact against the reference's batching layouts
+# ------------------------------------------------------------------------------------------------
+def _assert_batch_equal(got, ref_cochains, dimension):
+    assert got.dimension == dimension
+    for d in range(dimension + 1):
+        for k in ('x', 'upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries',
+                  'boundary_index', 'y', 'batch'):
+            a, r = got.cochains[d][k], ref_cochains[d][k]
+            assert (a is None) == (r is None), (d, k)
+            if a is not None:
+                assert a.dtype == r.dtype and torch.equal(cpu(a), cpu(r)), (d, k)
+
+
+@pytest.mark.parametrize('lname', ['testing', 'testing3', 'mol', 'pair', 'nodes_only'])
+def test_device_collate_matches_reference_layout(lname):
+    from cwn_amd.packed import PackedComplexes
+    from tests._golden import complex_dict
+    g = load('batching.npz')
+    names = [str(n) for n in g[f'{lname}/names']]
+    md = int(g[f'{lname}/max_dim'])
+    packed = PackedComplexes([dummy_complex(n) for n in names], DEV, max_dim=md)
+    b = packed.collate(range(len(names)))
+    ref = complex_dict(g, f'{lname}/batch')
+    _assert_batch_equal(b, ref['cochains'], ref['dimension'])
+    assert torch.equal(cpu(b.y), ref['y']) and b.num_complexes == len(names)
+    for d in range(ref['dimension'] + 1):
+        assert b.cochains[d].num_cells == ref['cochains'][d]['num_cells']
+
+
+def test_device_collate_subsets_and_forward():
+    """Arbitrary index subsets equal the CPU container collate; the result feeds the engine."""
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.synthetic import zinc_like_complexes
+    cxs = zinc_like_complexes(40, seed=9)
+    packed = PackedComplexes(cxs, DEV, max_dim=2)
+    gsel = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        idx = torch.randperm(40, generator=gsel)[:17].tolist()
+        got = packed.collate(idx)
+        ref = ComplexBatch.from_complex_list([cxs[i] for i in idx], max_dim=2)
+        _assert_batch_equal(got, ref.cochains, ref.dimension)
+        assert torch.equal(cpu(got.y), ref.y)
+    from cwn_amd.models import EmbedSparseCIN
+    torch.manual_seed(0)
+    model = EmbedSparseCIN(28, 4, 1, 2, 32, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV).eval()
+    with torch.no_grad():
+        y1 = model(packed.collate(idx))
+        y2 = model(ComplexBatch.from_complex_list([cxs[i] for i in idx], max_dim=2).to(DEV))
+    assert torch.equal(y1, y2)
