@@ -575,7 +575,10 @@ class CINppCochainConv(SparseCINCochainConv):
     def message_down(self, down_x_j: Tensor, down_attr: Tensor) -> Tensor:
         return self.msg_down_nn((down_x_j, down_attr))
 
-    def streams(self, cochain):
+    def gemm_specs(self, cochain):
+        return []            # three streams: runs through propagate() (fused hooks + generic lower)
+
+    def streams(self, cochain, ys=None):
         return None
 
     def forward(self, cochain: CochainMessagePassingParams):

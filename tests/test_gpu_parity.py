@@ -855,3 +855,30 @@ def test_device_collate_subsets_and_forward():
         y1 = model(packed.collate(idx))
         y2 = model(ComplexBatch.from_complex_list([cxs[i] for i in idx], max_dim=2).to(DEV))
     assert torch.equal(y1, y2)
+
+
+def test_cinpp_quirk_lower_stream_is_always_zero():
+    """CINppCochainConv inherits use_down_msg=False from SparseCINCochainConv
+    (mp/layers.py:167-168, 223-226) and its forward never passes down_attr (:243-247), so the lower
+    stream is zeros whether or not a lower index is supplied."""
+    from cwn_amd.layers import CINppConv
+    torch.manual_seed(0)
+    F = 8
+    conv = CINppConv(F, F, F, None, None, None, None, None, None, max_dim=2, hidden=F,
+                     act_module=torch.nn.ReLU, layer_dim=F, use_coboundaries=True).to(DEV).eval()
+    b = dummy_batch(list_names('mol'), max_dim=2, device=DEV)
+    g = torch.Generator().manual_seed(4)
+    for d in range(3):
+        b.cochains[d].x = torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV)
+    with torch.no_grad():
+        outs = conv(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+        assert all(torch.isfinite(o).all() for o in outs) and outs[1].shape == (b.cochains[1].num_cells, F)
+        prm = b.get_cochain_params(dim=1, include_down_features=False)
+        _, down, _ = conv.mp_levels[1].propagate(prm.up_index, prm.down_index, prm.boundary_index, x=prm.x,
+                                                 up_attr=prm.kwargs['up_attr'],
+                                                 boundary_attr=prm.kwargs['boundary_attr'])
+        assert not down.any()
+        outs2 = conv(*b.get_all_cochain_params(max_dim=2, include_down_features=True))
+        for o, o2 in zip(outs, outs2):
+            assert torch.equal(o, o2)
+        assert conv.mp_levels[1].use_down_msg is False
