@@ -218,7 +218,7 @@ inline int small_parts(int64_t n_entries, int64_t n_dst) {
 inline size_t small_lds_ints(int64_t n_entries, int64_t n_dst) {
     const int parts = small_parts(n_entries, n_dst);
     const int64_t rows = (n_dst + parts - 1) / parts;
-    return (size_t)(rows + 1 + 3 * n_entries + 8);       // cnt | ent | slot | byrow | misc
+    return (size_t)(rows + 1 + 4 * n_entries + 8);       // cnt | ent | slot | byrow | lrow | misc
 }
 
 __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, int32_t* err) {
@@ -240,7 +240,8 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
     int32_t* ent = cnt + (rows_per + 1);    // [E] original id of the part's j-th entry
     int32_t* slot = ent + E;                // [E] arrival slot of that entry inside its row
     int32_t* byrow = slot + E;              // [E] local entry ids grouped by row
-    int32_t* misc = byrow + E;              // [0] entries of smaller rows, [1] entries of this part
+    int32_t* lrow = byrow + E;              // [E] local row (key - lo) of that entry
+    int32_t* misc = lrow + E;               // [0] entries of smaller rows, [1] entries of this part
     const bool has_aux = D.aux != nullptr;
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i <= rows; i += kSmallThreads) cnt[i] = 0;
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
             if (mine) {
                 const int li = wbase + __popcll(m & ((1ull << lane) - 1ull));
                 ent[li] = e;
+                lrow[li] = (int)k[u] - lo;
                 slot[li] = atomicAdd(&cnt[(int)k[u] - lo], 1);
             }
         }
@@ -297,41 +299,24 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
         if (part == parts - 1) D.rowptr[n] = gbase + running;
     }
     __syncthreads();
-    // phase 3: group the part's entries by row (LDS only; keys re-read for own entries only)
-    for (int base = 0; base < mine_total; base += kSmallThreads * U) {
-        int64_t k[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int li = base + u * kSmallThreads + threadIdx.x;
-            k[u] = D.key[ent[li < mine_total ? li : 0]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int li = base + u * kSmallThreads + threadIdx.x;
-            if (li < mine_total) byrow[cnt[(int)k[u] - lo] + slot[li]] = li;
-        }
-    }
+    // phase 3: group the part's entries by row (LDS only)
+    for (int li = threadIdx.x; li < mine_total; li += kSmallThreads) byrow[cnt[lrow[li]] + slot[li]] = li;
     __syncthreads();
-    // phase 4: stable rank inside the row by ORIGINAL entry id, then the gathered outputs.
-    // Position p of byrow belongs to the row r with cnt[r] <= p < cnt[r+1]; instead of searching,
-    // every local entry recomputes its row from its key.
+    // phase 4: stable rank inside the row by ORIGINAL entry id (LDS only), then the gathered outputs
     for (int base = 0; base < mine_total; base += kSmallThreads * U) {
         int e[U], P[U];
-        int64_t k[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int li = base + u * kSmallThreads + threadIdx.x;
-            e[u] = li < mine_total ? ent[li] : -1;
-            k[u] = D.key[e[u] >= 0 ? e[u] : 0];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+            e[u] = -1;
             P[u] = 0;
-            if (e[u] >= 0) {
-                const int r = (int)k[u] - lo;
+            if (li < mine_total) {
+                const int ee = ent[li];
+                const int r = lrow[li];
                 const int s = cnt[r], t = cnt[r + 1];
                 int rank = 0;
-                for (int q = s; q < t; ++q) rank += (ent[byrow[q]] < e[u]) ? 1 : 0;
+                for (int q = s; q < t; ++q) rank += (ent[byrow[q]] < ee) ? 1 : 0;
+                e[u] = ee;
                 P[u] = gbase + s + rank;
             }
         }
