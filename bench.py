@@ -40,9 +40,11 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=200)
     p.add_argument('--warmup', type=int, default=20)
-    p.add_argument('--batch', type=int, default=128, help='complexes per GPU per step')
-    p.add_argument('--hidden', type=int, default=128)
-    p.add_argument('--layers', type=int, default=4)
+    p.add_argument('--workload', choices=['zinc', 'molhiv', 'reddit'], default='zinc',
+                   help='zinc = BASELINE configs[1] (the headline); molhiv = configs[2]; reddit = configs[4]')
+    p.add_argument('--batch', type=int, default=None, help='complexes per GPU per step (default: 128 / 512 / 32)')
+    p.add_argument('--hidden', type=int, default=None)
+    p.add_argument('--layers', type=int, default=None)
     p.add_argument('--num-batches', type=int, default=4, help='distinct synthetic batches cycled')
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
     p.add_argument('--no-cpu', action='store_true')
@@ -79,32 +81,55 @@ def main():
         dist = None
 
     from cwn_amd import _ffi, csr, ops
-    from cwn_amd.models import EmbedSparseCIN
-    from cwn_amd.synthetic import batch_stats, zinc_like_batch
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import EmbedSparseCIN, OGBEmbedSparseCIN, SparseCIN
+    from cwn_amd.synthetic import (batch_stats, zinc_like_complexes, molhiv_like_complexes,
+                                   reddit_like_complexes)
     _ffi.lib()
 
-    H, L = args.hidden, args.layers
+    # workload = (model, generator) of one BASELINE config
+    WL = args.workload
+    defaults = {'zinc': (128, 128, 4), 'molhiv': (512, 64, 2), 'reddit': (32, 64, 4)}[WL]
+    args.batch = args.batch or defaults[0]
+    H, L = args.hidden or defaults[1], args.layers or defaults[2]
+    args.hidden, args.layers = H, L
     torch.manual_seed(0)
-    model = EmbedSparseCIN(28, 4, 1, L, H, dropout_rate=0.0, max_dim=2, jump_mode=None,
-                           nonlinearity='relu', readout='sum', train_eps=False,
-                           final_hidden_multiplier=2, final_readout='sum', init_reduce='sum',
-                           embed_edge=True, use_coboundaries=True, graph_norm='bn').to(dev).eval()
+    if WL == 'zinc':      # exp/scripts/cwn-zinc.sh:14-30
+        model = EmbedSparseCIN(28, 4, 1, L, H, dropout_rate=0.0, max_dim=2, jump_mode=None,
+                               nonlinearity='relu', readout='sum', train_eps=False,
+                               final_hidden_multiplier=2, final_readout='sum', init_reduce='sum',
+                               embed_edge=True, use_coboundaries=True, graph_norm='bn')
+        gen = lambda seed: zinc_like_complexes(args.batch, seed, 6)
+        coboundary = True
+    elif WL == 'molhiv':  # exp/scripts/cwn-molhiv.sh:9-32, batch per BASELINE.json
+        model = OGBEmbedSparseCIN(1, L, H, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum',
+                                  init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn')
+        gen = lambda seed: molhiv_like_complexes(args.batch, seed, 6)
+        coboundary = True
+    else:                 # exp/scripts/mpsn-redditb.sh:6-28
+        model = SparseCIN(1, 2, L, H, dropout_rate=0.0, max_dim=2, jump_mode='cat', readout='sum',
+                          use_coboundaries=False, graph_norm='id')
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.mul_(0.3)      # no norm layer and degrees up to 300: keep activations finite
+        gen = lambda seed: reddit_like_complexes(args.batch, seed)
+        coboundary = False
+    model = model.to(dev).eval()
 
     # ---- synthetic batches, resident in HBM ---------------------------------------------------
-    cpu_batches = [zinc_like_batch(args.batch, seed=1000 * rank + i, max_ring=6)
-                   for i in range(args.num_batches)]
+    cpu_batches = [ComplexBatch.from_complex_list(gen(1000 * rank + i), max_dim=2) for i in range(args.num_batches)]
     stats = [batch_stats(b) for b in cpu_batches]
-    types = [(b.cochains[0].x.clone(), b.cochains[1].x.clone()) for b in cpu_batches]
-    batches = [zinc_like_batch(args.batch, seed=1000 * rank + i, max_ring=6).to(dev)   # .to() is in place
+    types = [tuple(None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3))
+             for b in cpu_batches]
+    batches = [ComplexBatch.from_complex_list(gen(1000 * rank + i), max_dim=2).to(dev)   # .to() is in place
                for i in range(args.num_batches)]
-
-    vt_dev = [vt.to(dev) for vt, _ in types]
-    et_dev = [et.to(dev) for _, et in types]
+    types_dev = [tuple(None if t is None else t.to(dev) for t in ts) for ts in types]
 
     def reset_inputs(bi):
-        """model(b) overwrites the container's features; put the integer atom / bond types back."""
+        """model(b) overwrites the container's features; put the raw input features back."""
         b = batches[bi]
-        b.cochains[0]._x, b.cochains[1]._x, b.cochains[2]._x = vt_dev[bi], et_dev[bi], None
+        for d in range(3):
+            b.cochains[d]._x = types_dev[bi][d]
         return b
 
     # per-layer input features of every batch (one full forward each), so the timed region can run
@@ -113,8 +138,11 @@ def main():
     with torch.no_grad():
         for bi in range(len(batches)):
             b = reset_inputs(bi)
-            params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
-            x0 = [x.contiguous() for x in model.init_conv(*params)]
+            if hasattr(model, 'init_conv'):
+                params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+                x0 = [x.contiguous() for x in model.init_conv(*params)]
+            else:
+                x0 = [b.cochains[d].x.contiguous() for d in range(3)]
             _, res = model(reset_inputs(bi), include_partial=True)
             layer_inputs.append([x0] + [[res[f'layer{l - 1}_{d}'].contiguous() for d in range(3)]
                                         for l in range(1, L)])
@@ -270,10 +298,16 @@ def main():
             b.set_xs(feats[1])
             params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
             lv = model.convs[1].mp_levels
-            gemms = [sp for d in range(3) for sp in lv[d].gemm_specs(params[d])]
-            ys = ops.run_gemm(gemms, dev)
-            streams = (lv[0].streams(params[0], ys[0:2]) + lv[1].streams(params[1], ys[2:4]) +
-                       lv[2].streams(params[2]))
+            gemms, owner = [], []
+            for d in range(3):
+                sp = lv[d].gemm_specs(params[d])
+                gemms += sp
+                owner += [d] * len(sp)
+            ys = ops.run_gemm(gemms, dev) if gemms else []
+            streams = []
+            for d in range(3):
+                mine = [y for y, o in zip(ys, owner) if o == d]
+                streams += lv[d].streams(params[d], mine or None)
             for st in streams:
                 st.validate()
             specs = []
@@ -286,8 +320,8 @@ def main():
                         s.B, s.ib = st.B, st.adj.aux
                 specs.append(s)
             agg_us = replay_us(lambda: ops.run_aggregate(specs, dev), args.kernel_reps)
-            gemm_us = replay_us(lambda: ops.run_gemm(gemms, dev), args.kernel_reps)
-        alg = layer_algorithmic_bytes(stats[0], H, coboundary=True)
+            gemm_us = replay_us(lambda: ops.run_gemm(gemms, dev), args.kernel_reps) if gemms else 0.0
+        alg = layer_algorithmic_bytes(stats[0], H, coboundary=coboundary)
         achieved = alg / (agg_us * 1e-6) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same
         # workload shape); None when no pass exists for this configuration
@@ -295,7 +329,7 @@ def main():
         try:
             with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as fh:
                 tj = json.load(fh)
-            if tj.get('hidden') == H and str(args.batch) in tj['entries']:
+            if WL == 'zinc' and tj.get('hidden') == H and str(args.batch) in tj['entries']:
                 traffic = tj['entries'][str(args.batch)]['traffic_bytes']
         except (OSError, ValueError, KeyError):
             traffic = None
@@ -307,17 +341,17 @@ def main():
                  'launches_per_step': L, 'share_of_step': round(L * agg_us / step_us, 3),
                  'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4)}
         flops = 2.0 * sum(g.X.size(0) * g.W.size(0) * g.W.size(1) for g in gemms)
-        tf = flops / (gemm_us * 1e-6) / 1e12
+        tf = flops / (gemm_us * 1e-6) / 1e12 if gemms else 0.0
         r_gemm = {'bound': 'mfma', 'kernel': 'gemm_kernel<fast,128> (grouped fp32-MFMA GEMM: coboundary-message products Y1, Y2)',
                   'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
                   'frac': round(tf / MFMA_F32_PEAK_TF, 4), 'traffic': None,
                   'algorithmic_flops_per_launch': int(flops), 'avg_launch_us': round(gemm_us, 3),
-                  'launches_per_step': L, 'share_of_step': round(L * gemm_us / step_us, 3)}
+                  'launches_per_step': L if gemms else 0, 'share_of_step': round(L * gemm_us / step_us, 3)}
         note = ('avg over back-to-back dependent launches replayed from a hipGraph between two HIP events '
                 '(includes the ~1.5 us inter-kernel boundary; rocprofv3 kernel-only averages are in profiles/, '
                 'where few-us kernels read ~1.5-3 us high); batch 128 is latency-bound and L2/MALL-resident')
         roofline, roofline_other = ((r_gemm, r_agg) if r_gemm['share_of_step'] >= r_agg['share_of_step']
-                                    else (r_agg, r_gemm))
+                                    else (r_agg, r_gemm if gemms else None))
         roofline['note'] = note
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample -----------------------------
@@ -338,11 +372,16 @@ def main():
                     ocx['cochains'][d]['x'] = feats[l][d]
                 pre = f'convs.{l}.mp_levels.'
                 for d, prm in enumerate(O.all_cochain_params(ocx, 2, include_down_features=False)):
-                    W, bias = state[f'{pre}{d}.msg_up_nn.1.weight'], state[f'{pre}{d}.msg_up_nn.1.bias']
+                    if coboundary:
+                        W, bias = state[f'{pre}{d}.msg_up_nn.1.weight'], state[f'{pre}{d}.msg_up_nn.1.bias']
+                        msg = lambda xj, a: torch.relu(torch.cat([xj, a], -1) @ W.t() + bias)
+                    else:
+                        msg = lambda xj, a: xj
+                    w = prm['x'].size(1)
                     O.propagate(prm['x'], prm['up_index'], None, prm['boundary_index'],
                                 up_attr=prm['up_attr'], boundary_attr=prm['boundary_attr'],
-                                message_up=lambda xj, a: torch.relu(torch.cat([xj, a], -1) @ W.t() + bias),
-                                use_down_msg=False, up_msg_size=H, down_msg_size=H, boundary_msg_size=H)
+                                message_up=msg, use_down_msg=False, up_msg_size=w, down_msg_size=w,
+                                boundary_msg_size=w)
         # pick the thread count that is FASTEST for this (small-tensor) workload: all cores is
         # usually not it, and a baseline slowed down by oversubscription would flatter the GPU
         max_threads = torch.get_num_threads()
@@ -377,14 +416,16 @@ def main():
                 {k: b.cochains[d][k] for k in ('x', 'upper_index', 'lower_index', 'shared_boundaries',
                                                'shared_coboundaries', 'boundary_index', 'y', 'batch')}
                 for d in range(3)]}
-            ocx_full['cochains'][0]['x'], ocx_full['cochains'][1]['x'] = types[0]
-            ocx_full['cochains'][2]['x'] = None
+            for d in range(3):
+                ocx_full['cochains'][d]['x'] = types[0][d]
+            okw = {'zinc': dict(embed='zinc'), 'molhiv': dict(embed='ogb', readout='mean'),
+                   'reddit': dict(embed=None, use_coboundaries=False, norm='id', jump_mode='cat')}[WL]
             with torch.no_grad():
                 torch.set_num_threads(threads)
-                O.embed_sparse_cin_forward(state, ocx_full, L)
+                O.sparse_cin_model_forward(state, ocx_full, L, **okw)
                 k, t0 = 0, time.perf_counter()
                 while time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
-                    O.embed_sparse_cin_forward(state, ocx_full, L)
+                    O.sparse_cin_model_forward(state, ocx_full, L, **okw)
                     k += 1
                 cpu_full = stats[0]['cells'] * L * k / (time.perf_counter() - t0)
                 torch.set_num_threads(max_threads)
@@ -453,7 +494,7 @@ def main():
         try:
             from cwn_amd.packed import PackedComplexes
             from cwn_amd.synthetic import zinc_like_complexes
-            pool = zinc_like_complexes(4 * args.batch, seed=77)
+            pool = [c for i in range(4) for c in gen(770 + i)]
             packed = PackedComplexes(pool, dev, max_dim=2)
             rng_idx = [torch.randperm(len(pool), generator=torch.Generator().manual_seed(i))[:args.batch].tolist()
                        for i in range(8)]
@@ -486,13 +527,12 @@ def main():
     if rank == 0:
         s0 = stats[0]
         out = {
-            'metric': 'cells/sec, propagate scope, ZINC-like ring-lifted batch (max_ring 6)',
+            'metric': 'cells/sec, propagate scope, ' + {'zinc': 'ZINC-like ring-lifted batch (max_ring 6)', 'molhiv': 'molhiv-like ring-lifted batch (max_ring 6)', 'reddit': 'REDDIT-like clique-lifted batch (dim 2)'}[WL],
             'value': round(value, 1), 'unit': 'cells/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 5),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': f'ZINC-like ring-lift (max_ring=6), {L}-layer SparseCIN propagate '
-                                   f'scope (hidden {H}, coboundary messages), batch {args.batch} per GPU',
+            'config': {'workload': {'zinc': f'ZINC-like ring-lift (max_ring=6), {L}-layer SparseCIN propagate scope (hidden {H}, coboundary messages), batch {args.batch} per GPU [BASELINE configs[1]]', 'molhiv': f'ogbg-molhiv-like ring-lift (max_ring=6), {L}-layer OGBEmbedSparseCIN propagate scope (hidden {H}), batch {args.batch} per GPU [BASELINE configs[2]]', 'reddit': f'REDDIT-BINARY-like clique-lift (dim 2, hubs of degree >= 100), {L}-layer SparseCIN propagate scope (hidden {H}, no coboundaries, norm id, JK cat), batch {args.batch} per GPU [BASELINE configs[4]]'}[WL],
                        'batch_per_gpu': args.batch, 'hidden': H, 'layers': L,
                        'cells_per_batch': s0['cells'], 'N': [s0['N0'], s0['N1'], s0['N2']],
                        'E_up': [s0['E_up0'], s0['E_up1'], s0['E_up2']],
