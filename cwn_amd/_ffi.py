@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_collate')
@@ -26,15 +26,18 @@ class CsrDesc(C.Structure):
     _fields_ = [('key', C.c_void_p), ('val', C.c_void_p), ('aux', C.c_void_p),
                 ('n_entries', C.c_int64), ('n_dst', C.c_int64), ('n_val', C.c_int64),
                 ('n_aux', C.c_int64), ('rowptr', C.c_void_p), ('col', C.c_void_p),
-                ('perm', C.c_void_p), ('aux_out', C.c_void_p)]
+                ('perm', C.c_void_p), ('aux_out', C.c_void_p),
+                ('long_rows', C.c_void_p), ('n_long', C.c_void_p)]
 
 
 class AggDesc(C.Structure):
     _fields_ = [('rowptr', C.c_void_p), ('ia', C.c_void_p), ('ib', C.c_void_p),
                 ('A', C.c_void_p), ('B', C.c_void_p), ('self_x', C.c_void_p),
                 ('eps', C.c_void_p), ('self_pre', C.c_void_p), ('out', C.c_void_p),
+                ('long_rows', C.c_void_p), ('n_long', C.c_void_p),
                 ('n_dst', C.c_int64), ('F', C.c_int32), ('b_width', C.c_int32),
-                ('msg_op', C.c_int32), ('reduce', C.c_int32)]
+                ('msg_op', C.c_int32), ('reduce', C.c_int32),
+                ('long_cap', C.c_int32), ('reserved', C.c_int32)]
 
 
 class GemmDesc(C.Structure):

@@ -14,6 +14,8 @@ import torch
 
 from . import _ffi
 
+LONG_ROW = 64             # = CWN_LONG_ROW (include/cwn_hip.h)
+LONG_PARTS = 8            # = CWN_LONG_PARTS
 VALIDATE_INDICES = True   # one host sync per batched build; turned off inside stream capture
 
 
@@ -44,6 +46,13 @@ class Adjacency:
         self.perm = torch.empty(self.n_entries, dtype=torch.int32, device=dev)
         self.aux = (torch.empty(self.n_entries, dtype=torch.int32, device=dev)
                     if aux_index is not None else None)
+        # rows with more than LONG_ROW entries (hubs), listed by the build for the aggregation
+        # kernel's whole-workgroup path; no row can be that long when E <= LONG_ROW
+        self.long_cap = self.n_entries // LONG_ROW + 1
+        self.long_rows = self.n_long = None
+        if self.n_entries > LONG_ROW:       # LONG_PARTS sub-lists + their lengths in one buffer
+            buf = torch.empty(LONG_PARTS * (self.long_cap + 1), dtype=torch.int32, device=dev)
+            self.n_long, self.long_rows = buf[:LONG_PARTS], buf[LONG_PARTS:]
         self.built = False
         self.ready = None     # torch.cuda.Event when the plan was built on a side stream
         self._t_src: Optional['Adjacency'] = None
@@ -68,7 +77,8 @@ class Adjacency:
             key=self.key.data_ptr(), val=self.val.data_ptr(), aux=_ffi.ptr(self.aux_index),
             n_entries=self.n_entries, n_dst=self.n_dst, n_val=self.n_val, n_aux=self.n_aux,
             rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(), perm=self.perm.data_ptr(),
-            aux_out=_ffi.ptr(self.aux))
+            aux_out=_ffi.ptr(self.aux), long_rows=_ffi.ptr(self.long_rows),
+            n_long=_ffi.ptr(self.n_long))
 
     # ---- transposes for the backward pass ----------------------------------------------
     def transposes(self) -> List['Adjacency']:
@@ -102,6 +112,14 @@ class Adjacency:
         if self._t_aux is None or not self._t_aux.built:
             self._ensure_transposes()
         return self._t_aux
+
+    def long_row_list(self) -> torch.Tensor:
+        """Rows with more than LONG_ROW entries (host sync; for tests and diagnostics)."""
+        if self.long_rows is None:
+            return torch.empty(0, dtype=torch.long, device=self.device)
+        n = self.n_long.tolist()
+        lists = self.long_rows.view(LONG_PARTS, self.long_cap)
+        return torch.cat([lists[p, :n[p]] for p in range(LONG_PARTS)]).long()
 
     @property
     def counts(self) -> torch.Tensor:
@@ -164,7 +182,7 @@ def build_many(adjs: Sequence[Adjacency], overlap: bool = False, validate: bool 
             ev.record(side)
         for a in adjs:
             a.ready = ev
-            for t in (a.rowptr, a.col, a.perm, a.aux):
+            for t in (a.rowptr, a.col, a.perm, a.aux, a.n_long):
                 if t is not None:
                     t.record_stream(main)
         return

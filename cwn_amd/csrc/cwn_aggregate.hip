@@ -13,7 +13,9 @@
 //     time before the first add.
 //   * accumulation is sequential in CSR (= original entry) order in registers: deterministic and
 //     bit-identical to a sequential index_add_; no atomics, no zero-fill pass, absent
-//     adjacencies and empty rows write zeros directly.
+//     adjacencies and empty rows write zeros directly.  Rows longer than CWN_LONG_ROW (hubs) are
+//     the one exception: a whole workgroup folds such a row in R chunks combined in chunk order
+//     (still deterministic; equal to the sequential sum up to fp32 re-association).
 //   * one launch covers up to CWN_MAX_DESCS descriptors (all adjacencies of all dimensions of a
 //     layer): blockIdx -> (descriptor, row tile) through a small prefix table in kernel args.
 #include <hip/hip_runtime.h>
@@ -96,120 +98,186 @@ __device__ __forceinline__ void combine(Acc<VEC>& acc, const Acc<VEC>& m) {
     }
 }
 
-// One group (G lanes, lane-in-group `gl`) reduces destination row `row` of descriptor D.
-// Every lane of the group runs every loop with the same trip counts (the index fetch and the
-// shuffles need all G lanes); lanes whose feature slice starts past F only skip the loads/stores.
+// One group (G lanes, lane-in-group `gl`) folds CSR positions [start, end) of one destination
+// row into a register accumulator, in CSR order.  Every lane of the group runs every loop with
+// the same trip counts (the index fetch and the shuffles need all G lanes); lanes whose feature
+// slice starts past F (`!active`) only skip the loads.
 template <int VEC, int OP, int RED>
-__device__ __forceinline__ void reduce_row(const cwn_agg_desc& D, int64_t row, int G, int gl,
-                                           float self_scale) {
+__device__ __forceinline__ Acc<VEC> fold_range(const cwn_agg_desc& D, int start, int end, int G, int gl,
+                                               int f, bool active, const Acc<VEC>& pre) {
     constexpr bool kUsesB = (OP != CWN_MSG_A);
     const int F = D.F;
     const bool b_scalar = kUsesB && D.b_width == 1;
-    int start = 0, end = 0;
-    if (D.rowptr != nullptr) {
-        start = D.rowptr[row];
-        end = D.rowptr[row + 1];
-    }
-    // feature chunks of G*VEC columns (one chunk when F <= G*VEC, the common case)
-    for (int f0 = 0; f0 < F; f0 += G * VEC) {
-        const int f = f0 + gl * VEC;
-        const bool active = f < F;
-        Acc<VEC> acc = splat<VEC>(RED == CWN_REDUCE_MAX ? -FLT_MAX : 0.0f);
-        Acc<VEC> pre = splat<VEC>(0.0f);
-        if constexpr (OP == CWN_MSG_A_MASK_RELU) {
-            if (active) pre = ld<VEC>(D.self_pre + row * F + f);
+    Acc<VEC> acc = splat<VEC>(RED == CWN_REDUCE_MAX ? -FLT_MAX : 0.0f);
+    for (int base = start; base < end; base += G) {
+        // cooperative index fetch: lane gl holds the indices of CSR position base+gl
+        const int mine = base + gl;
+        int my_ia = 0, my_ib = 0;
+        if (mine < end) {
+            my_ia = D.ia[mine];
+            if constexpr (kUsesB) my_ib = D.ib[mine];
         }
-        for (int base = start; base < end; base += G) {
-            // cooperative index fetch: lane gl holds the indices of CSR position base+gl
-            const int mine = base + gl;
-            int my_ia = 0, my_ib = 0;
-            if (mine < end) {
-                my_ia = D.ia[mine];
-                if constexpr (kUsesB) my_ib = D.ib[mine];
-            }
-            const int cnt = min(G, end - base);
-            int t = 0;
-            for (; t + 4 <= cnt; t += 4) {
-                Acc<VEC> a[4], b[4];
+        const int cnt = min(G, end - base);
+        int t = 0;
+        for (; t + 4 <= cnt; t += 4) {
+            Acc<VEC> a[4], b[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ia = __shfl(my_ia, t + u, G);
-                    int ib = 0;
-                    if constexpr (kUsesB) ib = __shfl(my_ib, t + u, G);
-                    a[u] = splat<VEC>(0.0f);
-                    b[u] = splat<VEC>(0.0f);
-                    if (active) {
-                        a[u] = ld<VEC>(D.A + (int64_t)ia * F + f);
-                        if constexpr (kUsesB)
-                            b[u] = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) combine<VEC, RED>(acc, message<VEC, OP>(a[u], b[u], pre));
-            }
-            for (; t < cnt; ++t) {
-                const int ia = __shfl(my_ia, t, G);
+            for (int u = 0; u < 4; ++u) {
+                const int ia = __shfl(my_ia, t + u, G);
                 int ib = 0;
-                if constexpr (kUsesB) ib = __shfl(my_ib, t, G);
-                Acc<VEC> a = splat<VEC>(0.0f), b = splat<VEC>(0.0f);
+                if constexpr (kUsesB) ib = __shfl(my_ib, t + u, G);
+                a[u] = splat<VEC>(0.0f);
+                b[u] = splat<VEC>(0.0f);
                 if (active) {
-                    a = ld<VEC>(D.A + (int64_t)ia * F + f);
+                    a[u] = ld<VEC>(D.A + (int64_t)ia * F + f);
                     if constexpr (kUsesB)
-                        b = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
+                        b[u] = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
                 }
-                combine<VEC, RED>(acc, message<VEC, OP>(a, b, pre));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) combine<VEC, RED>(acc, message<VEC, OP>(a[u], b[u], pre));
+        }
+        for (; t < cnt; ++t) {
+            const int ia = __shfl(my_ia, t, G);
+            int ib = 0;
+            if constexpr (kUsesB) ib = __shfl(my_ib, t, G);
+            Acc<VEC> a = splat<VEC>(0.0f), b = splat<VEC>(0.0f);
+            if (active) {
+                a = ld<VEC>(D.A + (int64_t)ia * F + f);
+                if constexpr (kUsesB)
+                    b = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
+            }
+            combine<VEC, RED>(acc, message<VEC, OP>(a, b, pre));
+        }
+    }
+    return acc;
+}
+
+// mean / empty-max fix-up, self term, one coalesced store of the row slice
+template <int VEC, int RED>
+__device__ __forceinline__ void finish_row(const cwn_agg_desc& D, int64_t row, int f, int len,
+                                           float self_scale, Acc<VEC> acc) {
+    const int F = D.F;
+    if constexpr (RED == CWN_REDUCE_MEAN) {
+        const float cntf = (float)max(len, 1);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] / cntf;
+    }
+    if constexpr (RED == CWN_REDUCE_MAX) {
+        if (len == 0) acc = splat<VEC>(0.0f);
+    }
+    if (D.self_x != nullptr) {
+        const Acc<VEC> s = ld<VEC>(D.self_x + row * F + f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] + self_scale * s.v[k];
+    }
+    st<VEC>(D.out + row * F + f, acc);
+}
+
+// Workgroup `blk` of the `nblk` that serve descriptor D.
+//   1. every lane group reduces its own destination row, sequentially in CSR (= original entry)
+//      order: bit-identical to a sequential index_add_;
+//   2. rows with more than CWN_LONG_ROW entries (hub cells of REDDIT-like complexes; listed by
+//      cwn_csr_build) are skipped in 1 and taken round-robin by whole workgroups here: the R lane
+//      groups of the block fold R contiguous chunks of the row, the partials meet in LDS and are
+//      combined in chunk order -- deterministic, no atomics, and the kernel no longer waits for
+//      one lane group to walk a 300-entry row alone.
+template <int VEC, int OP, int RED>
+__device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nblk, int G, float* part) {
+    const int F = D.F;
+    const int R = kThreads / G;  // lane groups (= rows in flight) per workgroup
+    const int gl = threadIdx.x & (G - 1);
+    const int gq = threadIdx.x / G;
+    const bool has_long = D.long_rows != nullptr && D.n_long != nullptr && D.rowptr != nullptr;
+    int n_long = 0;
+    if (has_long) {
+#pragma unroll
+        for (int p = 0; p < CWN_LONG_PARTS; ++p) n_long += D.n_long[p];
+    }
+    const float self_scale = 1.0f + (D.eps != nullptr ? *D.eps : 0.0f);
+    const int64_t row = (int64_t)blk * R + gq;
+    if (row < D.n_dst) {  // whole groups take the branch together (G divides 64)
+        int start = 0, end = 0;
+        if (D.rowptr != nullptr) {
+            start = D.rowptr[row];
+            end = D.rowptr[row + 1];
+        }
+        if (!(has_long && end - start > CWN_LONG_ROW)) {
+            // feature chunks of G*VEC columns (one chunk when F <= G*VEC, the common case)
+            for (int f0 = 0; f0 < F; f0 += G * VEC) {
+                const int f = f0 + gl * VEC;
+                const bool active = f < F;
+                Acc<VEC> pre = splat<VEC>(0.0f);
+                if constexpr (OP == CWN_MSG_A_MASK_RELU) {
+                    if (active) pre = ld<VEC>(D.self_pre + row * F + f);
+                }
+                const Acc<VEC> acc = fold_range<VEC, OP, RED>(D, start, end, G, gl, f, active, pre);
+                if (active) finish_row<VEC, RED>(D, row, f, end - start, self_scale, acc);
             }
         }
-        if constexpr (RED == CWN_REDUCE_MEAN) {
-            const float cntf = (float)max(end - start, 1);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] / cntf;
-        }
-        if constexpr (RED == CWN_REDUCE_MAX) {
-            if (end == start) acc = splat<VEC>(0.0f);
-        }
-        if (active) {
-            if (D.self_x != nullptr) {
-                const Acc<VEC> s = ld<VEC>(D.self_x + row * F + f);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] + self_scale * s.v[k];
+    }
+    for (int li = blk; li < n_long; li += nblk) {  // uniform over the workgroup
+        int p = 0, k = li;
+        while (k >= D.n_long[p]) k -= D.n_long[p++];  // li-th entry of the concatenated sub-lists
+        const int64_t lrow = D.long_rows[(int64_t)p * D.long_cap + k];
+        const int start = D.rowptr[lrow], end = D.rowptr[lrow + 1];
+        const int chunk = (((end - start + R - 1) / R) + 3) & ~3;
+        const int s = min(end, start + gq * chunk), e = min(end, s + chunk);
+        for (int f0 = 0; f0 < F; f0 += G * VEC) {
+            const int f = f0 + gl * VEC;
+            const bool active = f < F;
+            Acc<VEC> pre = splat<VEC>(0.0f);
+            if constexpr (OP == CWN_MSG_A_MASK_RELU) {
+                if (active) pre = ld<VEC>(D.self_pre + lrow * F + f);
             }
-            st<VEC>(D.out + row * F + f, acc);
+            Acc<VEC> acc = fold_range<VEC, OP, RED>(D, s, e, G, gl, f, active, pre);
+            if (gq != 0) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) part[threadIdx.x * VEC + k] = acc.v[k];
+            }
+            __syncthreads();
+            if (gq == 0 && active) {
+                for (int q = 1; q < R; ++q) {
+                    Acc<VEC> m;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) m.v[k] = part[(q * G + gl) * VEC + k];
+                    combine<VEC, RED>(acc, m);
+                }
+                finish_row<VEC, RED>(D, lrow, f, end - start, self_scale, acc);
+            }
+            __syncthreads();
         }
     }
 }
 
 template <int VEC, int OP>
-__device__ __forceinline__ void reduce_row_red(const cwn_agg_desc& D, int64_t row, int G, int gl,
-                                               float self_scale) {
+__device__ __forceinline__ void run_desc_red(const cwn_agg_desc& D, int blk, int nblk, int G, float* part) {
     switch (D.reduce) {
-        case CWN_REDUCE_MEAN: reduce_row<VEC, OP, CWN_REDUCE_MEAN>(D, row, G, gl, self_scale); break;
-        case CWN_REDUCE_MAX: reduce_row<VEC, OP, CWN_REDUCE_MAX>(D, row, G, gl, self_scale); break;
-        default: reduce_row<VEC, OP, CWN_REDUCE_ADD>(D, row, G, gl, self_scale); break;
+        case CWN_REDUCE_MEAN: run_desc<VEC, OP, CWN_REDUCE_MEAN>(D, blk, nblk, G, part); break;
+        case CWN_REDUCE_MAX: run_desc<VEC, OP, CWN_REDUCE_MAX>(D, blk, nblk, G, part); break;
+        default: run_desc<VEC, OP, CWN_REDUCE_ADD>(D, blk, nblk, G, part); break;
     }
 }
 
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void aggregate_kernel(AggBatch B) {
+    __shared__ float part[kThreads * VEC];
     int di = 0;
 #pragma unroll
     for (int i = 1; i < CWN_MAX_DESCS; ++i)
         if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
     const cwn_agg_desc& D = B.d[di];
     const int G = B.group[di];
-    const int rows_per_block = kThreads / G;
-    const int gl = threadIdx.x & (G - 1);
-    const int64_t row = (int64_t)(blockIdx.x - B.blk_start[di]) * rows_per_block + threadIdx.x / G;
-    if (row >= D.n_dst) return;  // whole groups exit together (G divides 64)
-    const float self_scale = 1.0f + (D.eps != nullptr ? *D.eps : 0.0f);
+    const int blk = blockIdx.x - B.blk_start[di];
+    const int nblk = B.blk_start[di + 1] - B.blk_start[di];
     switch (D.msg_op) {
-        case CWN_MSG_A_PLUS_B: reduce_row_red<VEC, CWN_MSG_A_PLUS_B>(D, row, G, gl, self_scale); break;
-        case CWN_MSG_A_TIMES_B: reduce_row_red<VEC, CWN_MSG_A_TIMES_B>(D, row, G, gl, self_scale); break;
+        case CWN_MSG_A_PLUS_B: run_desc_red<VEC, CWN_MSG_A_PLUS_B>(D, blk, nblk, G, part); break;
+        case CWN_MSG_A_TIMES_B: run_desc_red<VEC, CWN_MSG_A_TIMES_B>(D, blk, nblk, G, part); break;
         case CWN_MSG_RELU_A_PLUS_B:
-            reduce_row<VEC, CWN_MSG_RELU_A_PLUS_B, CWN_REDUCE_ADD>(D, row, G, gl, self_scale); break;
+            run_desc<VEC, CWN_MSG_RELU_A_PLUS_B, CWN_REDUCE_ADD>(D, blk, nblk, G, part); break;
         case CWN_MSG_A_MASK_RELU:
-            reduce_row<VEC, CWN_MSG_A_MASK_RELU, CWN_REDUCE_ADD>(D, row, G, gl, self_scale); break;
-        default: reduce_row_red<VEC, CWN_MSG_A>(D, row, G, gl, self_scale); break;
+            run_desc<VEC, CWN_MSG_A_MASK_RELU, CWN_REDUCE_ADD>(D, blk, nblk, G, part); break;
+        default: run_desc_red<VEC, CWN_MSG_A>(D, blk, nblk, G, part); break;
     }
 }
 

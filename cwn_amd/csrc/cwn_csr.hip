@@ -90,6 +90,17 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* lds 
     return wave_off + x - v;
 }
 
+// general path: every long row goes to sub-list 0 (counter zeroed by an earlier kernel of the
+// same call); the single-launch path keeps one sub-list per workgroup instead
+__device__ __forceinline__ void note_long_row(const cwn_csr_desc& D, int64_t row, int count) {
+    if (count > CWN_LONG_ROW && D.long_rows != nullptr && D.n_long != nullptr)
+        D.long_rows[atomicAdd(D.n_long, 1)] = (int32_t)row;
+}
+
+__device__ __forceinline__ void zero_long_counters(const cwn_csr_desc& D) {
+    if (D.n_long != nullptr && threadIdx.x < CWN_LONG_PARTS) D.n_long[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(kScanThreads) void scan_single_kernel(CsrBatch B) {
     __shared__ int lds[32];
     const int di = blockIdx.x;
@@ -98,12 +109,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_single_kernel(CsrBatch B) {
     int32_t* rowptr = D.rowptr;
     const int64_t n = D.n_dst;
     int running = 0;
+    zero_long_counters(D);
+    __syncthreads();
     for (int64_t base = 0; base < n; base += kScanThreads) {
         const int64_t i = base + threadIdx.x;
         const int v = i < n ? cnt[i] : 0;
         int total;
         const int ex = block_exclusive_scan(v, &total, lds);
-        if (i < n) rowptr[i] = running + ex;
+        if (i < n) {
+            rowptr[i] = running + ex;
+            note_long_row(D, i, v);
+        }
         running += total;
     }
     if (threadIdx.x == 0) rowptr[n] = running;
@@ -132,6 +148,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_tile_sums_kernel(CsrBatch B
     const int64_t tiles = B.tile_start[di + 1] - B.tile_start[di];
     int32_t* ts = B.tile_sums[di];
     int running = 0;
+    zero_long_counters(B.d[di]);   // tile_scan_kernel (next launch) appends the long rows
     for (int64_t base = 0; base < tiles; base += kScanThreads) {
         const int64_t i = base + threadIdx.x;
         const int v = i < tiles ? ts[i] : 0;
@@ -156,7 +173,10 @@ __global__ __launch_bounds__(kScanThreads) void tile_scan_kernel(CsrBatch B) {
         const int v = i < n ? cnt[i] : 0;
         int total;
         const int ex = block_exclusive_scan(v, &total, lds);
-        if (i < n) rowptr[i] = running + ex;
+        if (i < n) {
+            rowptr[i] = running + ex;
+            note_long_row(B.d[di], i, v);
+        }
         running += total;
     }
 }
@@ -200,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void emit_kernel(CsrBatch B) {
 // communication is needed.
 constexpr int kSmallThreads = 1024;
 constexpr size_t kSmallLdsBytes = 150 * 1024;
-constexpr int kMaxParts = 8;
+constexpr int kMaxParts = CWN_LONG_PARTS;
 
 struct SmallBatch {
     cwn_csr_desc d[CWN_MAX_DESCS];
@@ -241,11 +261,12 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
     int32_t* slot = ent + E;                // [E] arrival slot of that entry inside its row
     int32_t* byrow = slot + E;              // [E] local entry ids grouped by row
     int32_t* lrow = byrow + E;              // [E] local row (key - lo) of that entry
-    int32_t* misc = lrow + E;               // [0] entries of smaller rows, [1] entries of this part
+    int32_t* misc = lrow + E;               // [0] entries of smaller rows, [1] entries of this part,
+                                            // [2] long rows of this part
     const bool has_aux = D.aux != nullptr;
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i <= rows; i += kSmallThreads) cnt[i] = 0;
-    if (threadIdx.x < 2) misc[threadIdx.x] = 0;
+    if (threadIdx.x < 3) misc[threadIdx.x] = 0;
     __syncthreads();
     // phase 1: every key once (U independent loads per thread); wave-aggregated bookkeeping
     int below_local = 0;
@@ -291,6 +312,8 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
         if (i < rows) {
             cnt[i] = running + ex;
             D.rowptr[lo + i] = gbase + running + ex;
+            if (c > CWN_LONG_ROW && D.long_rows != nullptr)   // this part's own sub-list
+                D.long_rows[(int64_t)part * (E / CWN_LONG_ROW + 1) + atomicAdd(&misc[2], 1)] = lo + i;
         }
         running += total;
     }
@@ -299,6 +322,10 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
         if (part == parts - 1) D.rowptr[n] = gbase + running;
     }
     __syncthreads();
+    if (D.n_long != nullptr) {
+        if (threadIdx.x == 0) D.n_long[part] = misc[2];
+        if (part == 0 && threadIdx.x >= parts && threadIdx.x < CWN_LONG_PARTS) D.n_long[threadIdx.x] = 0;
+    }
     // phase 3: group the part's entries by row (LDS only)
     for (int li = threadIdx.x; li < mine_total; li += kSmallThreads) byrow[cnt[lrow[li]] + slot[li]] = li;
     __syncthreads();

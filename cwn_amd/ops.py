@@ -52,7 +52,11 @@ class AggSpec:
             rowptr=None if absent else self.adj.rowptr.data_ptr(),
             ia=_ffi.ptr(self.ia), ib=_ffi.ptr(self.ib), A=_ffi.ptr(self.A), B=_ffi.ptr(self.B),
             self_x=_ffi.ptr(self.self_x), eps=_ffi.ptr(self.eps), self_pre=_ffi.ptr(self.self_pre),
-            out=self.out.data_ptr(), n_dst=self.n_dst, F=self.F, b_width=bw,
+            out=self.out.data_ptr(),
+            long_rows=None if absent else _ffi.ptr(self.adj.long_rows),
+            n_long=None if absent else _ffi.ptr(self.adj.n_long),
+            long_cap=0 if absent else self.adj.long_cap,
+            n_dst=self.n_dst, F=self.F, b_width=bw,
             msg_op=self.msg_op, reduce=self.reduce)
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 1
+#define CWN_ABI_VERSION 2
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -78,7 +78,17 @@ typedef struct cwn_csr_desc {
     int32_t* col;        /* [E] out */
     int32_t* perm;       /* [E] out */
     int32_t* aux_out;    /* [E] out or NULL */
+    int32_t* long_rows;  /* [CWN_LONG_PARTS][E / CWN_LONG_ROW + 1] out or NULL: long-row lists */
+    int32_t* n_long;     /* [CWN_LONG_PARTS] out or NULL: length of each list (all eight written) */
 } cwn_csr_desc;
+
+/* Rows with more entries than CWN_LONG_ROW are "long" (REDDIT-like hubs): cwn_csr_build lists
+ * them, and cwn_aggregate_f32 reduces each of them with a whole workgroup instead of one lane
+ * group.  The list comes in CWN_LONG_PARTS independent sub-lists of capacity
+ * long_cap = E / CWN_LONG_ROW + 1 each (the single-launch build fills one per workgroup, so the
+ * counters need no zeroing and no cross-workgroup atomics); order inside a list is unspecified. */
+#define CWN_LONG_ROW 64
+#define CWN_LONG_PARTS 8
 
 /* Bytes of scratch cwn_csr_build needs for these descriptors (host array of n descriptors). */
 size_t cwn_csr_workspace_bytes(const cwn_csr_desc* descs_host, int n);
@@ -140,11 +150,15 @@ typedef struct cwn_agg_desc {
     const float* eps;      /* device scalar or NULL */
     const float* self_pre; /* [n_dst, F], CWN_MSG_A_MASK_RELU only */
     float* out;            /* [n_dst, F] */
+    const int32_t* long_rows; /* from cwn_csr_build, or NULL (every row is reduced by one lane group) */
+    const int32_t* n_long;    /* [CWN_LONG_PARTS] from cwn_csr_build, or NULL */
     int64_t n_dst;
     int32_t F;
     int32_t b_width;       /* F or 1 */
     int32_t msg_op;
     int32_t reduce;
+    int32_t long_cap;      /* capacity of one long-row sub-list (E / CWN_LONG_ROW + 1) */
+    int32_t reserved;
 } cwn_agg_desc;
 
 int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream);

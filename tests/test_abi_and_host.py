@@ -8,7 +8,7 @@ import re
 import pytest
 import torch
 
-from cwn_amd import _ffi
+from cwn_amd import _ffi, csr
 from cwn_amd.cell_mp import CochainMessagePassing, IndexedRows
 from cwn_amd.complex import Cochain, Complex, ComplexBatch
 from cwn_amd.layers import (SparseCINConv, SparseCINCochainConv, FirstOf, Catter,
@@ -26,15 +26,34 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cwn_abi_version() == 1
+    assert lib.cwn_abi_version() == 2
     assert lib.cwn_target_arch() == b'gfx950'
     assert lib.cwn_error_string(0) == b'ok'
 
 
-def test_struct_layout_matches_header():
-    # sizes the C compiler gives for the two descriptor structs (pointers 8 B, int64 8 B, int32 4 B)
-    assert ctypes.sizeof(_ffi.CsrDesc) == 11 * 8
-    assert ctypes.sizeof(_ffi.AggDesc) == 9 * 8 + 8 + 4 * 4
+def test_struct_layout_matches_header(tmp_path):
+    """Compile a probe against include/cwn_hip.h with the host C compiler and compare every
+    field offset and struct size with the ctypes mirror in cwn_amd/_ffi.py."""
+    import subprocess
+    structs = {'cwn_csr_desc': _ffi.CsrDesc, 'cwn_agg_desc': _ffi.AggDesc,
+               'cwn_gemm_desc': _ffi.GemmDesc, 'cwn_collate_desc': _ffi.CollateDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cwn_hip.h"', 'int main(void) {']
+    for cname, st in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0; }']
+    src = tmp_path / 'probe.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'probe'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True,
+                                                   text=True).stdout.splitlines())
+    for cname, st in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(got[f'{cname}.{fname}']) == getattr(st, fname).offset, (cname, fname)
+    assert csr.LONG_ROW == int(re.search(r'#define CWN_LONG_ROW (\d+)', open(os.path.join(ROOT, 'include', 'cwn_hip.h')).read()).group(1))
 
 
 def test_argument_errors_without_gpu():

@@ -50,6 +50,11 @@ def _check_adj(adj, index, n_dst, aux=None):
     assert torch.equal(cpu(adj.perm), perm)
     if aux is not None:
         assert torch.equal(cpu(adj.aux), aux.cpu()[perm.long()].int())
+    # rows longer than CWN_LONG_ROW are listed (any order) for the whole-workgroup reduction
+    from cwn_amd.csr import LONG_ROW
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    want = torch.nonzero(deg > LONG_ROW).flatten()
+    assert torch.equal(cpu(adj.long_row_list()).sort().values, want)
 
 
 def test_csr_build_on_every_batched_index():
@@ -882,3 +887,89 @@ def test_cinpp_quirk_lower_stream_is_always_zero():
         for o, o2 in zip(outs, outs2):
             assert torch.equal(o, o2)
         assert conv.mp_levels[1].use_down_msg is False
+
+
+# ------------------------------------------------------------------------------------------------
+# long rows (hubs): whole-workgroup reduction path of cwn_aggregate_f32
+# ------------------------------------------------------------------------------------------------
+def _hub_index(g, n_dst, n_src, n_aux):
+    # rows 5 and n_dst-1 are hubs (1500 / 700 / 65 / 64 entries: both sides of CWN_LONG_ROW), the rest sparse
+    dst = torch.cat([torch.full((1500,), 5), torch.full((700,), n_dst - 1), torch.full((65,), 9),
+                     torch.full((64,), 10), torch.randint(0, n_dst, (4000,), generator=g)])
+    dst = dst[torch.randperm(dst.numel(), generator=g)]
+    src = torch.randint(0, n_src, (dst.numel(),), generator=g)
+    aux = torch.randint(0, n_aux, (dst.numel(),), generator=g)
+    return torch.stack([src, dst]), aux
+
+
+@pytest.mark.parametrize('F', [1, 3, 8, 64, 128, 130, 512])
+@pytest.mark.parametrize('reduce', ['add', 'mean', 'max'])
+def test_long_rows_identity_message_exact_on_integers(F, reduce):
+    """Integer-valued features: any summation order gives the same fp32 result, so the chunked
+    hub reduction must equal the oracle's sequential scatter bit for bit."""
+    from cwn_amd import ops
+    from cwn_amd.csr import Adjacency
+    g = torch.Generator().manual_seed(F * 7 + len(reduce))
+    n_dst, n_src = 300, 211
+    idx, aux = _hub_index(g, n_dst, n_src, 50)
+    x = torch.randint(-8, 9, (n_src, F), generator=g).float()
+    sx = torch.randint(-3, 4, (n_dst, F), generator=g).float()
+    adj = Adjacency.from_index(idx.to(DEV), n_dst, n_src, aux.to(DEV), 50)
+    assert adj.long_row_list().numel() >= 3
+    got = ops.aggregate(adj, n_dst, x.to(DEV), reduce=reduce, self_x=sx.to(DEV))
+    want = O.scatter_rows(x[idx[0]], idx[1], n_dst, reduce) + sx
+    if reduce == 'mean':
+        torch.testing.assert_close(cpu(got), want, rtol=1e-6, atol=1e-6)
+    else:
+        assert torch.equal(cpu(got), want)
+
+
+@pytest.mark.parametrize('F', [4, 64, 128])
+@pytest.mark.parametrize('op', ['plus', 'times', 'relu_plus'])
+def test_long_rows_two_operand_messages_and_backward(F, op):
+    from cwn_amd import ops
+    from cwn_amd.csr import Adjacency
+    g = torch.Generator().manual_seed(F + len(op))
+    n_dst = n_src = 257
+    n_aux = 91
+    idx, aux = _hub_index(g, n_dst, n_src, n_aux)
+    x = torch.randn(n_src, F, generator=g, dtype=torch.float64)
+    ua = torch.randn(n_aux, F, generator=g, dtype=torch.float64)
+    msg_op = {'plus': ops.MSG_A_PLUS_B, 'times': ops.MSG_A_TIMES_B, 'relu_plus': ops.MSG_RELU_A_PLUS_B}[op]
+
+    def ref(xr, ur):
+        a, b = xr[idx[0]], ur[aux]
+        m = a + b if op == 'plus' else (a * b if op == 'times' else torch.relu(a + b))
+        return torch.zeros(n_dst, F, dtype=m.dtype).index_add_(0, idx[1], m)
+
+    xr, ur = x.clone().requires_grad_(), ua.clone().requires_grad_()
+    want = ref(xr, ur)
+    w = torch.randn(n_dst, F, generator=g, dtype=torch.float64)
+    (want * w).sum().backward()
+    adj = Adjacency.from_index(idx.to(DEV), n_dst, n_src, aux.to(DEV), n_aux)
+    # (the multiplicative attribute has no fused gradient: ops.py routes trainable ones elsewhere)
+    xg, ug = x.float().to(DEV).requires_grad_(), ua.float().to(DEV).requires_grad_(op != 'times')
+    got = ops.aggregate(adj, n_dst, xg, msg_op=msg_op, B=ug)
+    (got * w.float().to(DEV)).sum().backward()
+    # the transposed plans have hubs of their own only where a SOURCE is popular; here the
+    # destination hubs make long rows in forward, and t_aux (91 rows, ~70 entries each) in backward
+    assert adj.t_aux.long_row_list().numel() > 0
+    scale = float(want.detach().abs().max())
+    torch.testing.assert_close(cpu(got).double(), want.detach(), rtol=1e-5, atol=1e-5 * scale)
+    torch.testing.assert_close(cpu(xg.grad).double(), xr.grad, rtol=1e-5, atol=1e-5 * float(xr.grad.abs().max()))
+    if op != 'times':
+        torch.testing.assert_close(cpu(ug.grad).double(), ur.grad, rtol=1e-5,
+                                   atol=1e-5 * float(ur.grad.abs().max()))
+
+
+def test_long_rows_are_deterministic():
+    from cwn_amd import ops
+    from cwn_amd.csr import Adjacency
+    g = torch.Generator().manual_seed(5)
+    idx, aux = _hub_index(g, 300, 211, 50)
+    x = torch.randn(211, 64, generator=g).to(DEV)
+    outs = []
+    for _ in range(3):
+        adj = Adjacency.from_index(idx.to(DEV), 300, 211)     # the long-row LIST order may differ
+        outs.append(ops.aggregate(adj, 300, x))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
