@@ -262,7 +262,7 @@ def main():
 
     # ---- rooflines: both kernels of a layer are measured live; the one with the larger share of the
     # step is `roofline` (dominant), the other `roofline_other` ---------------------------------------
-    roofline = roofline_other = None
+    roofline = roofline_other = r_plan = None
     if rank == 0 and not args.only_primary:
         MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA, dense
 
@@ -321,6 +321,12 @@ def main():
                 specs.append(s)
             agg_us = replay_us(lambda: ops.run_aggregate(specs, dev), args.kernel_reps)
             gemm_us = replay_us(lambda: ops.run_gemm(gemms, dev), args.kernel_reps) if gemms else 0.0
+
+            def rebuild_plans():
+                csr._cache.clear()
+                b.prepare(max_dim=2)
+            plan_us = replay_us(rebuild_plans, max(args.kernel_reps // 4, 4))
+            adjs = list(csr._cache.values())
         alg = layer_algorithmic_bytes(stats[0], H, coboundary=coboundary)
         achieved = alg / (agg_us * 1e-6) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same
@@ -342,11 +348,22 @@ def main():
                  'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4)}
         flops = 2.0 * sum(g.X.size(0) * g.W.size(0) * g.W.size(1) for g in gemms)
         tf = flops / (gemm_us * 1e-6) / 1e12 if gemms else 0.0
-        r_gemm = {'bound': 'mfma', 'kernel': 'gemm_kernel<fast,128> (grouped fp32-MFMA GEMM: coboundary-message products Y1, Y2)',
+        r_gemm = {'bound': 'mfma', 'kernel': f'gemm_kernel ({"64x64" if H <= 64 else "32x128"} tiles; grouped fp32-MFMA GEMM: coboundary-message products Y1, Y2)',
                   'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
                   'frac': round(tf / MFMA_F32_PEAK_TF, 4), 'traffic': None,
                   'algorithmic_flops_per_launch': int(flops), 'avg_launch_us': round(gemm_us, 3),
                   'launches_per_step': L if gemms else 0, 'share_of_step': round(L * gemm_us / step_us, 3)}
+        # plan build (cwn_csr_build): key + val (+ aux) int64 in, rowptr + col + perm (+ aux) int32 out
+        plan_bytes = 0
+        for ent in adjs:
+            a = ent[2]          # csr._cache values are (version, weakref, Adjacency)
+            has_aux = a.aux is not None
+            plan_bytes += a.n_entries * (16 + 8 + (12 if has_aux else 0)) + 4 * (a.n_dst + 1)
+        r_plan = {'bound': 'hbm', 'kernel': 'cwn_csr_build (destination-sorted int32 CSR of every adjacency of the batch, once per step)',
+                  'achieved': round(plan_bytes / (plan_us * 1e-6) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                  'frac': round(plan_bytes / (plan_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
+                  'algorithmic_bytes_per_launch': int(plan_bytes), 'avg_launch_us': round(plan_us, 3),
+                  'launches_per_step': 1, 'share_of_step': round(plan_us / step_us, 3)}
         note = ('avg over back-to-back dependent launches replayed from a hipGraph between two HIP events '
                 '(includes the ~1.5 us inter-kernel boundary; rocprofv3 kernel-only averages are in profiles/, '
                 'where few-us kernels read ~1.5-3 us high); batch 128 is latency-bound and L2/MALL-resident')
@@ -539,7 +556,8 @@ def main():
                        'B': [s0['B0'], s0['B1'], s0['B2']],
                        'launch': 'hipGraph replay' if use_graph else 'eager',
                        'plan_build_in_step': True, 'parallelism': f'replicas x{world} (no data-path collective)'},
-            'roofline': roofline, 'roofline_other': roofline_other, 'cpu_baseline': cpu_baseline,
+            'roofline': roofline, 'roofline_other': roofline_other, 'roofline_plan_build': r_plan,
+            'cpu_baseline': cpu_baseline,
             'secondary': {'full_forward_cells_per_s': round(float(full_cells.item()) / dt_full, 1),
                           'full_forward_ms': round(dt_full / full_steps * 1e3, 5),
                           'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '

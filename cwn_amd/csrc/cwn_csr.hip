@@ -1,17 +1,22 @@
 // cwn_csr.hip -- COO (int64, as delivered) -> destination-sorted int32 CSR, gfx950.
 //
 // One fixed launch sequence builds up to CWN_MAX_DESCS structures at once (all adjacencies of a
-// batched complex), so the cost per batch is 5-7 launches regardless of how many index tensors
-// there are:
+// batched complex), so the cost per batch is 5-6 launches regardless of how many index tensors
+// there are (inputs that fit LDS take the ONE-launch path further down instead):
 //   1. hipMemsetAsync          zero the per-destination counters of every descriptor
-//   2. count_kernel            cnt[key[e]]++ (returned value = arrival slot inside the row)
-//   3. scan (1 or 3 kernels)   rowptr = exclusive scan of cnt
-//   4. place_kernel            tmp[rowptr[key] + slot] = e           (row-grouped, unordered)
+//   2. count_kernel            cnt[key[e]] += ... (one atomic per distinct key per wavefront;
+//                              returned value = arrival slot inside the row)
+//   3. scan (1 or 2 kernels)   rowptr = exclusive scan of cnt; rows longer than CWN_LONG_ROW
+//                              are appended to the long-row list on the way
+//   4. place_kernel            tmp[rowptr[key] + slot] = e, rows[..] = key  (row-grouped, unordered)
 //   5. emit_kernel             rank every entry inside its row by ORIGINAL entry id (counting
-//                              rank, O(sum deg^2) but coalesced/broadcast reads) and write
+//                              rank, O(sum deg^2) but broadcast reads, 8 in flight) and write
 //                              perm / col / aux_out in stable order
-// Integer work, HBM/L2-bound; no LDS tiling is needed (rows are short, reads are broadcast).
+// Integer work, latency- rather than bandwidth-bound at REDDIT-like sizes (a few MB): what
+// matters is the number of DEPENDENT memory round trips (~0.9 us each) per kernel and keeping
+// every wave access coalesced; see the notes at ScanChunk, count_kernel and emit_kernel.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "../../include/cwn_hip.h"
 
 namespace {
@@ -19,17 +24,19 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kScanThreads = 1024;
 constexpr int kScanTile = 4096;        // counts per block in the multi-block scan
-constexpr int64_t kSingleScanMax = 1 << 16;
+constexpr int64_t kSingleScanMax = 1 << 14;   // two trips of the single-block scan; above: tiled
 
 struct CsrBatch {
     cwn_csr_desc d[CWN_MAX_DESCS];
     int32_t* cnt[CWN_MAX_DESCS];        // [n_dst] counters (workspace)
     int32_t* slot[CWN_MAX_DESCS];       // [E] arrival slot, later reused as tmp (row-grouped ids)
     int32_t* tmp[CWN_MAX_DESCS];        // [E]
+    int32_t* rows[CWN_MAX_DESCS];       // [E] destination row of tmp[p] (saves emit a dependent load)
     int32_t* tile_sums[CWN_MAX_DESCS];  // [tiles] multi-block scan only
     int64_t blk_start[CWN_MAX_DESCS + 1];  // block prefix for the entry-parallel kernels
     int64_t tile_start[CWN_MAX_DESCS + 1]; // block prefix for the tile-parallel scan kernels
     int n;
+    int dbg;   // timing experiments (CWN_CSR_DBG): 1 no rowptr stores, 2 no long-row notes, 4 no loads
 };
 
 __device__ __forceinline__ int find_desc(const int64_t* start, int n, int64_t b) {
@@ -40,26 +47,53 @@ __device__ __forceinline__ int find_desc(const int64_t* start, int n, int64_t b)
     return d;
 }
 
+// One atomic per DISTINCT key per wavefront: the lanes that hold the same key elect a leader
+// (lowest lane), which adds the group's size; members take consecutive slots after the returned
+// base.  A hub row (REDDIT-like: one key in half of the lanes of many consecutive waves) then
+// costs 1/32 of the same-address atomics, which is what the kernel's time was going to.
 __global__ __launch_bounds__(kThreads) void count_kernel(CsrBatch B, int32_t* err) {
     const int di = find_desc(B.blk_start, B.n, blockIdx.x);
     const cwn_csr_desc& D = B.d[di];
     const int64_t e = (int64_t)(blockIdx.x - B.blk_start[di]) * kThreads + threadIdx.x;
-    if (e >= D.n_entries) return;
-    const int64_t k = D.key[e];
-    const int64_t v = D.val[e];
+    const bool in = e < D.n_entries;
+    int64_t k = -1;
     int bad = 0;
-    if (k < 0 || k >= D.n_dst) bad |= 1;
-    if (v < 0 || v >= D.n_val) bad |= 2;
-    if (D.aux != nullptr) {
-        const int64_t a = D.aux[e];
-        if (a < 0 || a >= D.n_aux) bad |= 4;
+    if (in) {
+        k = D.key[e];
+        const int64_t v = D.val[e];
+        if (k < 0 || k >= D.n_dst) bad |= 1;
+        if (v < 0 || v >= D.n_val) bad |= 2;
+        if (D.aux != nullptr) {
+            const int64_t a = D.aux[e];
+            if (a < 0 || a >= D.n_aux) bad |= 4;
+        }
+        if (bad) {
+            atomicOr(err, bad);
+            B.slot[di][e] = -1;
+        }
     }
-    if (bad) {
-        atomicOr(err, bad);
-        B.slot[di][e] = -1;
-        return;
+    const int lane = threadIdx.x & 63;
+    const int key32 = (in && !bad) ? (int)k : -1;
+    // 1. group the lanes by key (ALU only, <= 64 wave-uniform trips)
+    unsigned long long todo = __ballot(key32 >= 0);
+    int my_leader = lane, my_rank = 0, my_size = 1;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int cand = __shfl(key32, leader, 64);
+        const unsigned long long same = __ballot(key32 == cand) & todo;
+        if (key32 == cand) {
+            my_leader = leader;
+            my_rank = __popcll(same & ((1ull << lane) - 1ull));
+            my_size = __popcll(same);
+        }
+        todo &= ~same;
     }
-    B.slot[di][e] = atomicAdd(&B.cnt[di][k], 1);
+    // 2. every leader's atomic is in flight at once; 3. members read their leader's base
+    int base = 0;
+    if (key32 >= 0 && lane == my_leader) base = atomicAdd(&B.cnt[di][key32], my_size);
+    base = __shfl(base, my_leader, 64);
+    const int slot = base + my_rank;
+    if (key32 >= 0) B.slot[di][e] = slot;
 }
 
 // ---- exclusive scan, single block per descriptor (n_dst <= kSingleScanMax) -----------------
@@ -91,38 +125,117 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* lds 
 }
 
 // general path: every long row goes to sub-list 0 (counter zeroed by an earlier kernel of the
-// same call); the single-launch path keeps one sub-list per workgroup instead
-__device__ __forceinline__ void note_long_row(const cwn_csr_desc& D, int64_t row, int count) {
-    if (count > CWN_LONG_ROW && D.long_rows != nullptr && D.n_long != nullptr)
-        D.long_rows[atomicAdd(D.n_long, 1)] = (int32_t)row;
+// same call); the single-launch path keeps one sub-list per workgroup instead.  Called by ALL
+// lanes of a wave (`valid` masks the tail): one atomic per wave that holds any long row -- a
+// returning same-address atomic per long row (each in its own divergent branch) cost ~0.3 us
+// apiece and made this the longest kernel of the REDDIT-like build.
+__device__ __forceinline__ void note_long_row(const cwn_csr_desc& D, int64_t row, int count, bool valid) {
+    const bool is_long = valid && count > CWN_LONG_ROW && D.long_rows != nullptr && D.n_long != nullptr;
+    const unsigned long long m = __ballot(is_long);
+    if (m == 0) return;                               // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(D.n_long, __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (is_long) D.long_rows[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)row;
 }
 
 __device__ __forceinline__ void zero_long_counters(const cwn_csr_desc& D) {
     if (D.n_long != nullptr && threadIdx.x < CWN_LONG_PARTS) D.n_long[threadIdx.x] = 0;
 }
 
+// Scan of one block-sized chunk, shared by the single-block and the tiled scan.
+//  * a dependent global load costs ~0.9 us here (the counters were produced by device-scope
+//    atomics, so they come from the memory side, not from this XCD's L2): all of a thread's ITEMS
+//    loads are issued before the first use (clamped index, no guarding branch -- a branch per
+//    load makes hipcc wait for each one);
+//  * every global load / store instruction is a coalesced 256-B wave access (lane l of wave w
+//    touches element w * 64 * ITEMS + u * 64 + l).  Giving each THREAD consecutive counters in
+//    global memory instead makes every instruction touch 64 different lines, the 16 waves thrash
+//    the CU's L1 and one CU re-fetches 32x the data: measured 45 us for a 43 k-row descriptor.
+//  * the scan itself wants consecutive elements per thread (a serial prefix in registers, ONE
+//    cross-lane scan per chunk; ITEMS chained ds_bpermute scans measured 22 us of pure ALU), so
+//    each wave transposes its 64 * ITEMS elements through a private LDS slice, rows padded to
+//    S words so that both access patterns are bank-conflict free.  No barrier: LDS operations
+//    of one wave execute in order.
+// Returns the chunk total; writes rowptr[i] = offset + exclusive prefix.
+template <int ITEMS>
+struct ScanChunk {
+    static constexpr int S = ITEMS > 4 ? ITEMS + 4 : ITEMS;   // padded words per thread
+    static constexpr int kLdsInts = kScanThreads * S;
+    int v[ITEMS];
+
+    __device__ __forceinline__ void load(const cwn_csr_desc& D, const int32_t* __restrict__ cnt,
+                                         int64_t first, int dbg) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int64_t n = D.n_dst;
+        const int64_t w0 = first + (int64_t)wid * (64 * ITEMS) + lane;
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int64_t i = w0 + u * 64;
+            v[u] = (dbg & 4) ? 1 : cnt[i < n ? i : (n > 0 ? n - 1 : 0)];
+        }
+    }
+
+    __device__ __forceinline__ int finish(const cwn_csr_desc& D, int64_t first, int offset, int dbg,
+                                          int* lds, int* xpose) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int64_t n = D.n_dst;
+        const int64_t w0 = first + (int64_t)wid * (64 * ITEMS) + lane;
+        int* my = xpose + wid * (64 * S);
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            v[u] = w0 + u * 64 < n ? v[u] : 0;
+            const int e = u * 64 + lane;
+            my[(e / ITEMS) * S + e % ITEMS] = v[u];
+        }
+        int c[ITEMS];
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            c[k] = my[lane * S + k];
+            mine += c[k];
+        }
+        int total;
+        int p = offset + block_exclusive_scan(mine, &total, lds);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            my[lane * S + k] = p;
+            p += c[k];
+        }
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int64_t i = w0 + u * 64;
+            const int e = u * 64 + lane;
+            const int pre = my[(e / ITEMS) * S + e % ITEMS];
+            if (i < n && !(dbg & 1)) D.rowptr[i] = pre;
+            if (!(dbg & 2)) note_long_row(D, i, v[u], i < n);
+        }
+        return total;
+    }
+};
+
+constexpr int kScanItems = 8;   // single-block scan: 8 k rows per trip
+
 __global__ __launch_bounds__(kScanThreads) void scan_single_kernel(CsrBatch B) {
     __shared__ int lds[32];
+    __shared__ int xpose[ScanChunk<kScanItems>::kLdsInts];
     const int di = blockIdx.x;
     const cwn_csr_desc& D = B.d[di];
-    const int32_t* cnt = B.cnt[di];
-    int32_t* rowptr = D.rowptr;
     const int64_t n = D.n_dst;
+    constexpr int64_t kStep = (int64_t)kScanThreads * kScanItems;
     int running = 0;
     zero_long_counters(D);
     __syncthreads();
-    for (int64_t base = 0; base < n; base += kScanThreads) {
-        const int64_t i = base + threadIdx.x;
-        const int v = i < n ? cnt[i] : 0;
-        int total;
-        const int ex = block_exclusive_scan(v, &total, lds);
-        if (i < n) {
-            rowptr[i] = running + ex;
-            note_long_row(D, i, v);
-        }
-        running += total;
+    ScanChunk<kScanItems> cur, nxt;
+    if (n > 0) cur.load(D, B.cnt[di], 0, B.dbg);
+    for (int64_t base = 0; base < n; base += kStep) {
+        if (base + kStep < n) nxt.load(D, B.cnt[di], base + kStep, B.dbg);   // in flight during this trip
+        running += cur.finish(D, base, running, B.dbg, lds, xpose);
+        cur = nxt;
     }
-    if (threadIdx.x == 0) rowptr[n] = running;
+    if (threadIdx.x == 0) D.rowptr[n] = running;
 }
 
 // ---- exclusive scan, multi block (tile sums -> scan of sums -> tile scan) ------------------
@@ -133,52 +246,40 @@ __global__ __launch_bounds__(kScanThreads) void tile_sum_kernel(CsrBatch B) {
     const int32_t* cnt = B.cnt[di];
     const int64_t n = B.d[di].n_dst;
     int v = 0;
+    int w[kScanTile / kScanThreads];
+#pragma unroll
+    for (int k = 0; k < kScanTile / kScanThreads; ++k) {   // all loads in flight, then the selects
+        const int64_t i = tile * kScanTile + k * kScanThreads + threadIdx.x;
+        w[k] = cnt[i < n ? i : (n > 0 ? n - 1 : 0)];
+    }
+#pragma unroll
     for (int k = 0; k < kScanTile / kScanThreads; ++k) {
         const int64_t i = tile * kScanTile + k * kScanThreads + threadIdx.x;
-        if (i < n) v += cnt[i];
+        v += i < n ? w[k] : 0;
     }
     int total;
     block_exclusive_scan(v, &total, lds);
     if (threadIdx.x == 0) B.tile_sums[di][tile] = total;
+    if (tile == 0) zero_long_counters(B.d[di]);   // tile_scan_kernel (next launch) appends the long rows
 }
 
-__global__ __launch_bounds__(kScanThreads) void scan_tile_sums_kernel(CsrBatch B) {
-    __shared__ int lds[32];
-    const int di = blockIdx.x;
-    const int64_t tiles = B.tile_start[di + 1] - B.tile_start[di];
-    int32_t* ts = B.tile_sums[di];
-    int running = 0;
-    zero_long_counters(B.d[di]);   // tile_scan_kernel (next launch) appends the long rows
-    for (int64_t base = 0; base < tiles; base += kScanThreads) {
-        const int64_t i = base + threadIdx.x;
-        const int v = i < tiles ? ts[i] : 0;
-        int total;
-        const int ex = block_exclusive_scan(v, &total, lds);
-        if (i < tiles) ts[i] = running + ex;
-        running += total;
-    }
-    if (threadIdx.x == 0) B.d[di].rowptr[B.d[di].n_dst] = running;
-}
-
+// Every tile adds up the sums of the tiles before it itself (<= a few hundred values, loaded
+// while its own counters are in flight): no separate scan-of-sums launch between the two.
 __global__ __launch_bounds__(kScanThreads) void tile_scan_kernel(CsrBatch B) {
     __shared__ int lds[32];
+    using Chunk = ScanChunk<kScanTile / kScanThreads>;
+    __shared__ int xpose[Chunk::kLdsInts];
     const int di = find_desc(B.tile_start, B.n, blockIdx.x);
     const int64_t tile = blockIdx.x - B.tile_start[di];
-    const int32_t* cnt = B.cnt[di];
-    int32_t* rowptr = B.d[di].rowptr;
-    const int64_t n = B.d[di].n_dst;
-    int running = B.tile_sums[di][tile];
-    for (int k = 0; k < kScanTile / kScanThreads; ++k) {
-        const int64_t i = tile * kScanTile + k * kScanThreads + threadIdx.x;
-        const int v = i < n ? cnt[i] : 0;
-        int total;
-        const int ex = block_exclusive_scan(v, &total, lds);
-        if (i < n) {
-            rowptr[i] = running + ex;
-            note_long_row(B.d[di], i, v);
-        }
-        running += total;
-    }
+    const int64_t tiles = B.tile_start[di + 1] - B.tile_start[di];
+    Chunk c;
+    c.load(B.d[di], B.cnt[di], tile * kScanTile, B.dbg);
+    int before = 0;
+    for (int64_t t = threadIdx.x; t < tile; t += kScanThreads) before += B.tile_sums[di][t];
+    int offset;
+    block_exclusive_scan(before, &offset, lds);
+    const int total = c.finish(B.d[di], tile * kScanTile, offset, B.dbg, lds, xpose);
+    if (tile == tiles - 1 && threadIdx.x == 0) B.d[di].rowptr[B.d[di].n_dst] = offset + total;
 }
 
 __global__ __launch_bounds__(kThreads) void place_kernel(CsrBatch B) {
@@ -188,7 +289,10 @@ __global__ __launch_bounds__(kThreads) void place_kernel(CsrBatch B) {
     if (e >= D.n_entries) return;
     const int s = B.slot[di][e];
     if (s < 0) return;
-    B.tmp[di][D.rowptr[D.key[e]] + s] = (int32_t)e;
+    const int64_t r = D.key[e];
+    const int pos = D.rowptr[r] + s;
+    B.tmp[di][pos] = (int32_t)e;
+    B.rows[di][pos] = (int32_t)r;
 }
 
 __global__ __launch_bounds__(kThreads) void emit_kernel(CsrBatch B) {
@@ -197,16 +301,30 @@ __global__ __launch_bounds__(kThreads) void emit_kernel(CsrBatch B) {
     const int64_t p = (int64_t)(blockIdx.x - B.blk_start[di]) * kThreads + threadIdx.x;
     // valid positions are [0, rowptr[n_dst]); dropped (out-of-range) entries shorten the tail
     if (p >= D.n_entries || p >= D.rowptr[D.n_dst]) return;
+    // dependent hops (each ~0.9 us): {tmp, rows} -> {rowptr x 2, val, aux} -> rank loop -> stores
     const int32_t* tmp = B.tmp[di];
     const int32_t e = tmp[p];
-    const int64_t r = D.key[e];
+    const int64_t r = B.rows[di][p];
     const int s = D.rowptr[r], t = D.rowptr[r + 1];
+    const int32_t my_val = (int32_t)D.val[e];
+    const int32_t my_aux = D.aux_out != nullptr ? (int32_t)D.aux[e] : 0;
+    // stable rank inside the row by ORIGINAL entry id.  Eight independent loads per trip: the
+    // lanes of a row read the same addresses (broadcast), so a 300-entry hub row is ~40 round
+    // trips to L2, not 300.
     int rank = 0;
-    for (int q = s; q < t; ++q) rank += (tmp[q] < e) ? 1 : 0;
+    int q = s;
+    for (; q + 8 <= t; q += 8) {
+        int w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = tmp[q + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += (w[u] < e) ? 1 : 0;
+    }
+    for (; q < t; ++q) rank += (tmp[q] < e) ? 1 : 0;
     const int P = s + rank;
     D.perm[P] = e;
-    D.col[P] = (int32_t)D.val[e];
-    if (D.aux_out != nullptr) D.aux_out[P] = (int32_t)D.aux[e];
+    D.col[P] = my_val;
+    if (D.aux_out != nullptr) D.aux_out[P] = my_aux;
 }
 
 // ---- small path: ONE launch, everything in LDS ---------------------------------------------------
@@ -376,7 +494,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
     size_t cnt_off[CWN_MAX_DESCS], slot_off[CWN_MAX_DESCS], tmp_off[CWN_MAX_DESCS],
-        tiles_off[CWN_MAX_DESCS];
+        rows_off[CWN_MAX_DESCS], tiles_off[CWN_MAX_DESCS];
     size_t cnt_total;  // the leading region that must be zeroed
     size_t total;
 };
@@ -393,6 +511,8 @@ WsLayout layout(const cwn_csr_desc* d, int n) {
         L.slot_off[i] = off;
         off += align_up((size_t)(d[i].n_entries + 1) * 4, 256);
         L.tmp_off[i] = off;
+        off += align_up((size_t)(d[i].n_entries + 1) * 4, 256);
+        L.rows_off[i] = off;
         off += align_up((size_t)(d[i].n_entries + 1) * 4, 256);
         L.tiles_off[i] = off;
         off += align_up(((size_t)d[i].n_dst / kScanTile + 2) * 4, 256);
@@ -457,6 +577,8 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
 
     CsrBatch B{};
     B.n = n;
+    static const int dbg = getenv("CWN_CSR_DBG") ? atoi(getenv("CWN_CSR_DBG")) : 0;
+    B.dbg = dbg;
     char* ws = (char*)workspace;
     int64_t blocks = 0, tiles = 0;
     for (int i = 0; i < n; ++i) {
@@ -464,11 +586,12 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
         B.cnt[i] = (int32_t*)(ws + L.cnt_off[i]);
         B.slot[i] = (int32_t*)(ws + L.slot_off[i]);
         B.tmp[i] = (int32_t*)(ws + L.tmp_off[i]);
+        B.rows[i] = (int32_t*)(ws + L.rows_off[i]);
         B.tile_sums[i] = (int32_t*)(ws + L.tiles_off[i]);
         B.blk_start[i] = blocks;
         B.tile_start[i] = tiles;
         blocks += (descs[i].n_entries + kThreads - 1) / kThreads;
-        tiles += (descs[i].n_dst + kScanTile - 1) / kScanTile;
+        tiles += descs[i].n_dst > 0 ? (descs[i].n_dst + kScanTile - 1) / kScanTile : 1;   // >= 1: rowptr[0]
     }
     for (int i = n; i <= CWN_MAX_DESCS; ++i) {
         B.blk_start[i] = blocks;
@@ -478,11 +601,12 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
 
     if (hipMemsetAsync(ws, 0, L.cnt_total, stream) != hipSuccess) return CWN_ERR_LAUNCH;
     if (blocks > 0) count_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B, err_flag);
-    if (max_dst <= kSingleScanMax) {
+    static const char* force = getenv("CWN_CSR_SCAN");   // timing experiments: "tiled" / "single"
+    const bool single = force != nullptr ? force[0] == 's' : max_dst <= kSingleScanMax;
+    if (single) {
         scan_single_kernel<<<dim3(n), dim3(kScanThreads), 0, stream>>>(B);
     } else {
         tile_sum_kernel<<<dim3((unsigned)tiles), dim3(kScanThreads), 0, stream>>>(B);
-        scan_tile_sums_kernel<<<dim3(n), dim3(kScanThreads), 0, stream>>>(B);
         tile_scan_kernel<<<dim3((unsigned)tiles), dim3(kScanThreads), 0, stream>>>(B);
     }
     if (blocks > 0) {

@@ -20,7 +20,10 @@
 //   and is bound by the per-CU address unit (measured 14-17 us vs 4 on the ZINC-128 shape) --
 //   stored XOR-swizzled (chunk ^ (row & 15)) and read back with conflict-free ds_read_b128.
 //   The next tile's loads are in flight during the current tile's MFMAs.
-// * block = 4 waves = 32 rows x 128 columns; each wave 32 x 32 (2 x 2 MFMA tiles, 16 acc VGPRs).
+// * block = 4 waves, each wave 32 x 32 outputs (2 x 2 MFMA tiles, 16 acc VGPRs).  Wide layers
+//   (N > 64) arrange the waves 1 x 4: a 32-row x 128-column tile.  Narrow layers (N <= 64: the
+//   hidden-64 models of the MOLHIV / TU configurations) arrange them 2 x 2: 64 rows x 64 columns,
+//   so no wave multiplies columns that do not exist; K <= 64 gets a 64-wide LDS image as well.
 // * optional fused pieces: K-concatenation of two inputs (combine_nn's cat), per-input-column
 //   affine + ReLU prologue (BatchNorm apply of the producing layer), bias, per-output-column
 //   affine (BatchNorm in eval mode), ReLU, and per-column sum / sum-of-squares accumulation
@@ -33,8 +36,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int BM = 32;    // rows per tile
-constexpr int BN = 128;   // columns per tile (4 waves x 32)
 constexpr int RT = 2;     // 16-row MFMA tiles per wave
 constexpr int CT = 2;     // 16-col MFMA tiles per wave
 constexpr int kMaxK = 256;  // K + K2 supported (the W tile of the whole K stays in LDS)
@@ -121,7 +122,7 @@ __device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, in
     }
 }
 
-template <bool FAST, bool PRO, int KP>
+template <bool FAST, bool PRO, int KP, int WN>
 #ifndef CWN_GEMM_LB
 #define CWN_GEMM_LB 2
 #endif
@@ -131,7 +132,9 @@ template <bool FAST, bool PRO, int KP>
 #ifndef CWN_GEMM_FRAGPF
 #define CWN_GEMM_FRAGPF 0
 #endif
-__global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B) {
+__global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B) {
+    constexpr int BM = 32 * (4 / WN);   // rows per tile: WN waves side by side along N, 4/WN along M
+    constexpr int BN = 32 * WN;         // columns per tile
     extern __shared__ __attribute__((aligned(16))) float smem[];   // two [BM][KP] X buffers
     int di = 0;
 #pragma unroll
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_
     const int tiles_n = B.n_tiles_n[di], tiles = B.n_tiles[di];
     const bool vec = FAST;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave % WN, wm = wave / WN;     // the wave's 32 x 32 patch inside the tile
     const int j = lane & 15, g = lane >> 4;
     // descriptor fields into registers once
     const float* const Xp = D.X;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_
     int it = 0;
     // two X tiles in flight in registers (prefetch distance 2 when K <= 128; 1 for the K = 256 variant,
     // whose tiles are twice as large)
-    constexpr bool DEEP = KP == 128 && CWN_GEMM_DEEP;
+    constexpr bool DEEP = KP <= 128 && CWN_GEMM_DEEP;
     SX sx, sx2;
     if (tile < tiles)
         stage_load<FAST, BM, KP, 0, SX::U>(sx, (int64_t)(tile / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_
     for (; tile < tiles; tile += nblk, ++it) {
         const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
         const int64_t m_base = (int64_t)tile_m * BM;
-        const int n_base = tile_n * BN + wave * (CT * 16);
+        const int n_base = tile_n * BN + wn * (CT * 16);
 
         if (cur_tn != tile_n && !(dbg & 2)) {
             // W fragments into registers, WAVE-PRIVATELY: the wave reads only its own 32 W rows
@@ -186,13 +190,13 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_
             // no workgroup barrier between the passes (LDS operations of one wave execute in order).
             constexpr int HW = 64;                  // floats of K per pass
             constexpr int PASSES = KP / HW;
-            constexpr int LPP = BM * (HW / 4) / 64; // 16-B loads per lane per pass (= 8)
-            float* priv = smem + wave * (BM * HW);
+            constexpr int LPP = 32 * (HW / 4) / 64; // 16-B loads per lane per pass (= 8)
+            float* priv = smem + wave * (32 * HW);
             __syncthreads();                 // nobody still reads the X buffers we are about to reuse
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
                 f32x4 wl[LPP];
-                const int wrow0 = tile_n * BN + wave * (CT * 16);
+                const int wrow0 = tile_n * BN + wn * (CT * 16);
 #pragma unroll
                 for (int i = 0; i < LPP; ++i) {
                     const int r = (lane >> 4) + 4 * i;
@@ -253,14 +257,14 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_
             f32x4 xa[RT], xb[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
-                xa[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(rt * 16 + j, g));
+                xa[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(wm * 32 + rt * 16 + j, g));
 #pragma unroll
             for (int sl = 0; sl < SLABS; ++sl) {
                 if (sl * 16 < Ktot && !(dbg & 1)) {
                     if (sl + 1 < SLABS) {
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
-                            xb[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(rt * 16 + j, 4 * (sl + 1) + g));
+                            xb[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(wm * 32 + rt * 16 + j, 4 * (sl + 1) + g));
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_
                 f32x4 x[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    x[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(rt * 16 + j, 4 * sl + g));
+                    x[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(wm * 32 + rt * 16 + j, 4 * sl + g));
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_
         int64_t xrow[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            xrow[rt] = m_base + rt * 16 + j;
+            xrow[rt] = m_base + wm * 32 + rt * 16 + j;
             xok[rt] = xrow[rt] < M;
         }
 #pragma unroll
@@ -372,8 +376,8 @@ __global__ __launch_bounds__(kThreads, (KP == 128 ? CWN_GEMM_LB : 1)) void gemm_
                 va[r] = lo ? acc[0][rt][r] : recv[r];      // lo: (row j, ct0)    hi: (row j-8, ct1)
                 vb[r] = lo ? recv[r] : acc[1][rt][r];      // lo: (row j+8, ct0)  hi: (row j, ct1)
             }
-            const int64_t ra = m_base + rt * 16 + (lo ? j : j - 8);
-            const int64_t rb = m_base + rt * 16 + (lo ? j + 8 : j);
+            const int64_t ra = m_base + wm * 32 + rt * 16 + (lo ? j : j - 8);
+            const int64_t rb = m_base + wm * 32 + rt * 16 + (lo ? j + 8 : j);
             const int n0 = n_base + (lo ? 0 : 16) + 4 * g;
             const bool full = n0 + 3 < N;
             if (ra < M && n0 < N) {
@@ -423,6 +427,18 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
                     D.ldw % 4 == 0 && D.ldy % 4 == 0 && (D.K2 == 0 || D.ldx2 % 4 == 0) &&
                     D.K % 4 == 0 && D.K2 % 4 == 0) ? 1 : 0;
         B.d[i] = D;
+    }
+    // tile shape of the launch: narrow (64 x 64) when no descriptor has more than 64 output columns
+    int kmax = 0, nmax = 0;
+    for (int i = 0; i < n; ++i) {
+        kmax = descs[i].K + descs[i].K2 > kmax ? descs[i].K + descs[i].K2 : kmax;
+        nmax = descs[i].N > nmax ? descs[i].N : nmax;
+    }
+    const bool narrow = nmax <= 64;
+    const int BM = narrow ? 64 : 32, BN = narrow ? 64 : 128;
+    const int KP = kmax <= 64 && narrow ? 64 : (kmax <= 128 ? 128 : 256);
+    for (int i = 0; i < n; ++i) {
+        const cwn_gemm_desc& D = descs[i];
         const int64_t tm = (D.M + BM - 1) / BM;
         const int tn = (D.N + BN - 1) / BN;
         if (tm * tn >= INT32_MAX) return CWN_ERR_TOO_LARGE;
@@ -431,13 +447,12 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         total_tiles += tm * tn;
     }
     if (total_tiles == 0) return CWN_OK;
-    int kmax = 0;
-    for (int i = 0; i < n; ++i) kmax = descs[i].K + descs[i].K2 > kmax ? descs[i].K + descs[i].K2 : kmax;
-    const int KP = kmax <= 128 ? 128 : 256;
-    const int lds_bytes = 2 * BM * KP * 4;           // two X buffers: 32 KiB (K <= 128) or 64 KiB
+    // two X buffers; never less than the four 8-KiB wave-private W staging slices
+    int lds_bytes = 2 * BM * KP * 4;
+    if (lds_bytes < 4 * 32 * 64 * 4) lds_bytes = 4 * 32 * 64 * 4;
     // persistent blocks: what the LDS lets a CU hold, x 256 CUs, shared between the descriptors in
     // proportion to their tile counts; each block walks its descriptor's tiles
-    const int64_t budget = KP == 128 ? 768 : 512;      // ~3 (2) resident blocks per CU x 256 CUs
+    const int64_t budget = lds_bytes <= 32 * 1024 ? 768 : 512;   // ~3 (2) resident blocks per CU x 256 CUs
     int64_t blocks = 0;
     for (int i = 0; i < n; ++i) {
         int64_t nb = B.n_tiles[i];
@@ -456,23 +471,32 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         pro = pro || B.d[i].in_scale != nullptr;
     }
     using Kern = void (*)(GemmBatch);
-    static const Kern kerns[2][2][2] = {
-        {{gemm_kernel<false, false, 128>, gemm_kernel<false, false, 256>},
-         {gemm_kernel<false, true, 128>, gemm_kernel<false, true, 256>}},
-        {{gemm_kernel<true, false, 128>, gemm_kernel<true, false, 256>},
-         {gemm_kernel<true, true, 128>, gemm_kernel<true, true, 256>}}};
+    // shape index: 0 = 32x128 tile, K <= 128;  1 = 32x128, K <= 256;  2 = 64x64, K <= 64;
+    //              3 = 64x64, K <= 128;        4 = 64x64, K <= 256
+    static const Kern kerns[2][2][5] = {
+        {{gemm_kernel<false, false, 128, 4>, gemm_kernel<false, false, 256, 4>, gemm_kernel<false, false, 64, 2>,
+          gemm_kernel<false, false, 128, 2>, gemm_kernel<false, false, 256, 2>},
+         {gemm_kernel<false, true, 128, 4>, gemm_kernel<false, true, 256, 4>, gemm_kernel<false, true, 64, 2>,
+          gemm_kernel<false, true, 128, 2>, gemm_kernel<false, true, 256, 2>}},
+        {{gemm_kernel<true, false, 128, 4>, gemm_kernel<true, false, 256, 4>, gemm_kernel<true, false, 64, 2>,
+          gemm_kernel<true, false, 128, 2>, gemm_kernel<true, false, 256, 2>},
+         {gemm_kernel<true, true, 128, 4>, gemm_kernel<true, true, 256, 4>, gemm_kernel<true, true, 64, 2>,
+          gemm_kernel<true, true, 128, 2>, gemm_kernel<true, true, 256, 2>}}};
+    static const int kShapeLds[5] = {2 * 32 * 128 * 4, 2 * 32 * 256 * 4, 2 * 64 * 64 * 4, 2 * 64 * 128 * 4,
+                                     2 * 64 * 256 * 4};
     static bool attr_set = false;
     if (!attr_set) {
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b)
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 5; ++c)
                     if (hipFuncSetAttribute((const void*)kerns[a][b][c],
                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            2 * BM * (c ? 256 : 128) * 4) != hipSuccess)
+                                            kShapeLds[c]) != hipSuccess)
                         return CWN_ERR_LAUNCH;
         attr_set = true;
     }
-    const Kern k = kerns[fast ? 1 : 0][pro ? 1 : 0][KP == 256 ? 1 : 0];
+    const int shape = narrow ? (KP == 64 ? 2 : (KP == 128 ? 3 : 4)) : (KP == 128 ? 0 : 1);
+    const Kern k = kerns[fast ? 1 : 0][pro ? 1 : 0][shape];
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

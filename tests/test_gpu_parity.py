@@ -577,7 +577,9 @@ def test_sparse_cin_layer_full_size_vs_oracle(zinc128):
 # grouped fp32-MFMA GEMM (dense parts) against torch matmul in float64
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('M,N,K', [(1, 1, 1), (33, 128, 128), (3341, 128, 128), (100, 64, 64), (77, 130, 24),
-                                   (50, 16, 10), (5, 256, 128), (0, 128, 128), (1000, 128, 256)])
+                                   (50, 16, 10), (5, 256, 128), (0, 128, 128), (1000, 128, 256),
+                                   # narrow layers: the 64 x 64 tile shapes (K <= 64 / 128 / 256)
+                                   (1000, 64, 128), (257, 64, 200), (5000, 40, 64), (63, 3, 7), (4097, 64, 64)])
 def test_gemm_matches_float64(M, N, K):
     from cwn_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -973,3 +975,32 @@ def test_long_rows_are_deterministic():
         adj = Adjacency.from_index(idx.to(DEV), 300, 211)     # the long-row LIST order may differ
         outs.append(ops.aggregate(adj, 300, x))
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_gemm_narrow_grouped_concat_affine_stats():
+    """The 64 x 64 tile shape with every fused piece: K-concatenation, input affine + ReLU, output
+    affine, column statistics, row strides (molhiv-like hidden 64)."""
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(123)
+    M, H = 777, 64
+    Xfull = torch.randn(M, 2 * H, generator=g)
+    X = Xfull[:, :H]                                         # ldx = 128
+    X2 = torch.randn(M, H, generator=g)
+    W = torch.randn(H, 2 * H, generator=g) / (2 * H) ** 0.5
+    b = torch.randn(H, generator=g)
+    isc, ish = torch.rand(H, generator=g) + 0.5, torch.randn(H, generator=g)
+    osc, osh = torch.rand(H, generator=g) + 0.5, torch.randn(H, generator=g)
+    Xd, X2d = Xfull.to(DEV)[:, :H], X2.to(DEV)
+    assert Xd.stride(0) == 2 * H
+    stats = (torch.zeros(H, device=DEV), torch.zeros(H, device=DEV))
+    gm = [ops.Gemm(X=Xd, X2=X2d, W=W.to(DEV), bias=b.to(DEV), in_scale=isc.to(DEV), in_shift=ish.to(DEV),
+                   in_relu=True, out_scale=osc.to(DEV), out_shift=osh.to(DEV), relu=True, col_stats=stats),
+          ops.Gemm(X=X2d, W=W[:40, :H].to(DEV), bias=None)]
+    Y, Y2 = ops.run_gemm(gm, DEV)
+    xin = torch.cat([torch.relu(X.double() * isc.double() + ish.double()), X2.double()], 1)
+    pre = xin @ W.double().t() + b.double()
+    ref = torch.relu(pre * osc.double() + osh.double())
+    torch.testing.assert_close(cpu(Y).double(), ref, rtol=1e-5, atol=3e-5)
+    torch.testing.assert_close(cpu(stats[0]).double(), pre.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(cpu(stats[1]).double(), (pre * pre).sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(cpu(Y2).double(), X2.double() @ W[:40, :H].double().t(), rtol=1e-5, atol=2e-5)
