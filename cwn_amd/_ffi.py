@@ -16,10 +16,12 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_collate')
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_collate',
+           'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
+           'cwn_gemm_tn_f32')
 
 
 class CsrDesc(C.Structure):
@@ -42,12 +44,13 @@ class AggDesc(C.Structure):
 
 class GemmDesc(C.Structure):
     _fields_ = [('X', C.c_void_p), ('X2', C.c_void_p), ('W', C.c_void_p), ('bias', C.c_void_p),
-                ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('out_scale', C.c_void_p),
+                ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('in_scale2', C.c_void_p),
+                ('in_shift2', C.c_void_p), ('out_scale', C.c_void_p),
                 ('out_shift', C.c_void_p), ('col_sum', C.c_void_p), ('col_sumsq', C.c_void_p),
                 ('Y', C.c_void_p), ('M', C.c_int64), ('ldx', C.c_int64), ('ldx2', C.c_int64),
                 ('ldw', C.c_int64), ('ldy', C.c_int64), ('N', C.c_int32), ('K', C.c_int32),
                 ('K2', C.c_int32), ('relu', C.c_int32), ('in_relu', C.c_int32),
-                ('reserved', C.c_int32)]
+                ('w_trans', C.c_int32), ('reserved', C.c_int32), ('pad_', C.c_int32)]
 
 
 class CollateDesc(C.Structure):
@@ -56,6 +59,30 @@ class CollateDesc(C.Structure):
                 ('dst_row_stride', C.c_int64), ('n_rows', C.c_int32), ('op', C.c_int32)]
 
 
+class BnDesc(C.Structure):
+    _fields_ = [('col_sum', C.c_void_p), ('col_sumsq', C.c_void_p), ('gamma', C.c_void_p),
+                ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p),
+                ('M', C.c_int64), ('N', C.c_int32), ('eps', C.c_float), ('momentum', C.c_float),
+                ('pad_', C.c_int32)]
+
+
+class NormDesc(C.Structure):
+    _fields_ = [('dy', C.c_void_p), ('z', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('mean', C.c_void_p), ('rstd', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p),
+                ('out', C.c_void_p), ('M', C.c_int64), ('lddy', C.c_int64), ('ldz', C.c_int64),
+                ('ldout', C.c_int64), ('N', C.c_int32), ('relu', C.c_int32)]
+
+
+class GemmTnDesc(C.Structure):
+    _fields_ = [('dZ', C.c_void_p), ('X', C.c_void_p), ('X2', C.c_void_p), ('in_scale', C.c_void_p),
+                ('in_shift', C.c_void_p), ('in_scale2', C.c_void_p), ('in_shift2', C.c_void_p),
+                ('dW', C.c_void_p), ('db', C.c_void_p), ('M', C.c_int64), ('lddz', C.c_int64),
+                ('ldx', C.c_int64), ('ldx2', C.c_int64), ('lddw', C.c_int64), ('N', C.c_int32),
+                ('K', C.c_int32), ('K2', C.c_int32), ('in_relu', C.c_int32)]
+
+
+MAX_NORM_DESCS = 16
 COLLATE_COPY32, COLLATE_COPY64, COLLATE_ADD64, COLLATE_SEGID64 = range(4)
 MAX_COLLATE_DESCS = 32
 
@@ -95,6 +122,13 @@ def lib():
     L.cwn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
     L.cwn_collate.restype = C.c_int
     L.cwn_collate.argtypes = [C.POINTER(CollateDesc), C.c_int, C.c_int64, C.c_void_p]
+    L.cwn_bn_finalize_f32.restype = C.c_int
+    L.cwn_bn_finalize_f32.argtypes = [C.POINTER(BnDesc), C.c_int, C.c_void_p]
+    for name in ('cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32'):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [C.POINTER(NormDesc), C.c_int, C.c_void_p]
+    L.cwn_gemm_tn_f32.restype = C.c_int
+    L.cwn_gemm_tn_f32.argtypes = [C.POINTER(GemmTnDesc), C.c_int, C.c_void_p]
     if L.cwn_abi_version() != ABI_VERSION:
         raise CwnError(f'ABI mismatch: library {L.cwn_abi_version()} vs binding {ABI_VERSION}')
     _lib = L
@@ -146,3 +180,33 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
                                     idx.numel(), out.data_ptr(), stream_ptr(src.device)),
           'cwn_gather_rows_f32')
     return out
+
+
+def _chunked(fn_name: str, struct, descs, device, limit: int) -> None:
+    L = lib()
+    s = stream_ptr(device)
+    fn = getattr(L, fn_name)
+    for i in range(0, len(descs), limit):
+        chunk = descs[i:i + limit]
+        arr = (struct * len(chunk))(*chunk)
+        check(fn(arr, len(chunk), s), fn_name)
+
+
+def bn_finalize(descs: Sequence[BnDesc], device) -> None:
+    _chunked('cwn_bn_finalize_f32', BnDesc, descs, device, MAX_NORM_DESCS)
+
+
+def norm_act(descs: Sequence[NormDesc], device) -> None:
+    _chunked('cwn_norm_act_f32', NormDesc, descs, device, MAX_NORM_DESCS)
+
+
+def norm_bwd_reduce(descs: Sequence[NormDesc], device) -> None:
+    _chunked('cwn_norm_bwd_reduce_f32', NormDesc, descs, device, MAX_NORM_DESCS)
+
+
+def norm_bwd_apply(descs: Sequence[NormDesc], device) -> None:
+    _chunked('cwn_norm_bwd_apply_f32', NormDesc, descs, device, MAX_NORM_DESCS)
+
+
+def gemm_tn(descs: Sequence[GemmTnDesc], device) -> None:
+    _chunked('cwn_gemm_tn_f32', GemmTnDesc, descs, device, MAX_DESCS)

@@ -93,10 +93,17 @@ __device__ __forceinline__ void stage_load(Staged<ROWS, KP>& st, int64_t row0, i
     }
 }
 
+struct Prologue {
+    const float* scale;    // X:  [K] or NULL
+    const float* shift;
+    const float* scale2;   // X2: [K2] or NULL
+    const float* shift2;
+    int relu;              // bit 0: ReLU on X, bit 1: ReLU on X2
+};
+
 template <bool PRO, int ROWS, int KP, int U0, int U1>
 __device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, int K1, int K2,
-                                            const float* __restrict__ in_scale,
-                                            const float* __restrict__ in_shift, bool in_relu) {
+                                            const Prologue& P) {
     constexpr int CPR = KP / 4;
 #pragma unroll
     for (int u = U0; u < U1; ++u) {
@@ -111,9 +118,11 @@ __device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, in
         for (int t = 0; t < 4; ++t) {
             float x = v[t];
             if constexpr (PRO) {
-                if (in_scale != nullptr && !second && kk + t < kmax) {
-                    x = x * in_scale[kk + t] + in_shift[kk + t];
-                    x = in_relu ? fmaxf(x, 0.f) : x;
+                const float* sc = second ? P.scale2 : P.scale;
+                const float* sh = second ? P.shift2 : P.shift;
+                if (kk + t < kmax) {
+                    if (sc != nullptr) x = x * sc[kk + t] + sh[kk + t];
+                    if (P.relu & (second ? 2 : 1)) x = fmaxf(x, 0.f);
                 }
             }
             v[t] = kk + t < kmax ? x : 0.f;
@@ -153,9 +162,8 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
     const float* const Wp = D.W;
     const int64_t ldx = D.ldx, ldx2 = D.ldx2, ldw = D.ldw, ldy = D.ldy, M = D.M;
     const int N = D.N, K1 = D.K, K2 = D.K2, Ktot = D.K + D.K2;
-    const float* const in_scale = D.in_scale;
-    const float* const in_shift = D.in_shift;
-    const bool in_relu = D.in_relu != 0;
+    const Prologue pro{D.in_scale, D.in_shift, D.in_scale2, D.in_shift2, D.in_relu};
+    const bool w_trans = D.w_trans != 0;
     const int dbg = D.reserved;   // timing experiments (tools/ubench_gemm.py): 1 no MFMA, 2 no W staging, 4 no store
     constexpr int SLABS = KP / 16;
     using SX = Staged<BM, KP>;                 // a 32-row tile in flight: KP/32 x 16 B per thread
@@ -195,28 +203,48 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             __syncthreads();                 // nobody still reads the X buffers we are about to reuse
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
-                f32x4 wl[LPP];
                 const int wrow0 = tile_n * BN + wn * (CT * 16);
+                if (!w_trans) {
+                    f32x4 wl[LPP];
 #pragma unroll
-                for (int i = 0; i < LPP; ++i) {
-                    const int r = (lane >> 4) + 4 * i;
-                    const int k = ps * HW + 4 * (lane & 15);
-                    const int grow = wrow0 + r < N ? wrow0 + r : N - 1;
-                    if constexpr (FAST) {
-                        wl[i] = *reinterpret_cast<const f32x4*>(Wp + (int64_t)grow * ldw + (k < Ktot ? k : 0));
-                    } else {
+                    for (int i = 0; i < LPP; ++i) {
+                        const int r = (lane >> 4) + 4 * i;
+                        const int k = ps * HW + 4 * (lane & 15);
+                        const int grow = wrow0 + r < N ? wrow0 + r : N - 1;
+                        if constexpr (FAST) {
+                            wl[i] = *reinterpret_cast<const f32x4*>(Wp + (int64_t)grow * ldw + (k < Ktot ? k : 0));
+                        } else {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) wl[i][t] = Wp[(int64_t)grow * ldw + (k + t < Ktot ? k + t : 0)];
+                            for (int t = 0; t < 4; ++t) wl[i][t] = Wp[(int64_t)grow * ldw + (k + t < Ktot ? k + t : 0)];
+                        }
                     }
-                }
 #pragma unroll
-                for (int i = 0; i < LPP; ++i) {
-                    const int r = (lane >> 4) + 4 * i, c = lane & 15;
-                    const int k = ps * HW + 4 * c;
-                    f32x4 v = wl[i];
+                    for (int i = 0; i < LPP; ++i) {
+                        const int r = (lane >> 4) + 4 * i, c = lane & 15;
+                        const int k = ps * HW + 4 * c;
+                        f32x4 v = wl[i];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = k + t < Ktot ? v[t] : 0.f;
-                    *reinterpret_cast<f32x4*>(priv + r * HW + ((c ^ (r & 15)) << 2)) = v;
+                        for (int t = 0; t < 4; ++t) v[t] = k + t < Ktot ? v[t] : 0.f;
+                        *reinterpret_cast<f32x4*>(priv + r * HW + ((c ^ (r & 15)) << 2)) = v;
+                    }
+                } else {
+                    // W is [Ktot, N]: the wave's 32 output columns are 32 CONSECUTIVE floats of a W
+                    // row, so lanes 0..31 / 32..63 read two 128-B row segments per instruction
+                    // (coalesced) and the transposition happens in the LDS store.
+                    constexpr int NL = 32 * HW / 64;   // 4-B loads per lane per pass (= 32)
+                    float wt[NL];
+                    const int r = lane & 31;
+                    const int gcol = wrow0 + r < N ? wrow0 + r : N - 1;
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) {
+                        const int k = ps * HW + 2 * i + (lane >> 5);
+                        wt[i] = Wp[(int64_t)(k < Ktot ? k : 0) * ldw + gcol];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) {
+                        const int kl = 2 * i + (lane >> 5), k = ps * HW + kl;
+                        priv[r * HW + (((kl >> 2) ^ (r & 15)) << 2) + (kl & 3)] = k < Ktot ? wt[i] : 0.f;
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -234,7 +262,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             it = 0;
         }
         float* ldsX = smem + (it & 1) * (BM * KP);
-        stage_store<PRO, BM, KP, 0, SX::U>(ldsX, sx, K1, K2, in_scale, in_shift, in_relu);
+        stage_store<PRO, BM, KP, 0, SX::U>(ldsX, sx, K1, K2, pro);
         __syncthreads();                     // tile visible; everyone is done with the other buffer
         if constexpr (DEEP) {
             sx = sx2;                        // tile + nblk is already on its way
@@ -322,15 +350,15 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                     sh[r] = D.out_shift[nn];
                 }
             }
-            float csum[4] = {0.f, 0.f, 0.f, 0.f}, csq[4] = {0.f, 0.f, 0.f, 0.f};
+            double csum[4] = {0., 0., 0., 0.}, csq[4] = {0., 0., 0., 0.};   // fp64: see cwn_bn_finalize_f32
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float y = acc[ct][rt][r] + bias[r];
                     if (D.col_sum != nullptr && xok[rt]) {   // statistics of the pre-normalisation value
-                        csum[r] += y;
-                        csq[r] += y * y;
+                        csum[r] += (double)y;
+                        csq[r] += (double)y * (double)y;
                     }
                     y = y * sc[r] + sh[r];
                     acc[ct][rt][r] = D.relu ? fmaxf(y, 0.f) : y;
@@ -340,7 +368,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                 // reduce over the 16 rows held by lanes j = 0..15 of this lane group, one atomic each
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float a = csum[r], b = csq[r];
+                    double a = csum[r], b = csq[r];
 #pragma unroll
                     for (int o = 8; o >= 1; o >>= 1) {
                         a += __shfl_xor(a, o, 16);
@@ -416,9 +444,11 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         if (D.M > 0 && (D.X == nullptr || D.W == nullptr || D.Y == nullptr)) return CWN_ERR_BAD_ARG;
         if (D.K2 > 0 && (D.X2 == nullptr || (D.K % 4) != 0)) return CWN_ERR_BAD_ARG;
         if ((D.in_scale == nullptr) != (D.in_shift == nullptr)) return CWN_ERR_BAD_ARG;
+        if ((D.in_scale2 == nullptr) != (D.in_shift2 == nullptr)) return CWN_ERR_BAD_ARG;
+        if (D.in_scale2 != nullptr && D.K2 == 0) return CWN_ERR_BAD_ARG;
         if ((D.out_scale == nullptr) != (D.out_shift == nullptr)) return CWN_ERR_BAD_ARG;
         if ((D.col_sum == nullptr) != (D.col_sumsq == nullptr)) return CWN_ERR_BAD_ARG;
-        if (D.ldx < D.K || D.ldw < D.K + D.K2 || D.ldy < D.N || (D.K2 > 0 && D.ldx2 < D.K2))
+        if (D.ldx < D.K || D.ldw < (D.w_trans ? D.N : D.K + D.K2) || D.ldy < D.N || (D.K2 > 0 && D.ldx2 < D.K2))
             return CWN_ERR_BAD_ARG;
         const void* ptrs[] = {D.X, D.X2, D.W, D.Y};
         for (const void* p : ptrs)
@@ -468,7 +498,7 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
     bool fast = true, pro = false;
     for (int i = 0; i < n; ++i) {
         fast = fast && B.vec[i] != 0;
-        pro = pro || B.d[i].in_scale != nullptr;
+        pro = pro || B.d[i].in_scale != nullptr || B.d[i].in_scale2 != nullptr || B.d[i].in_relu != 0;
     }
     using Kern = void (*)(GemmBatch);
     // shape index: 0 = 32x128 tile, K <= 128;  1 = 32x128, K <= 256;  2 = 64x64, K <= 64;

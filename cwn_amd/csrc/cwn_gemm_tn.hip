@@ -1,0 +1,224 @@
+// cwn_gemm_tn.hip -- weight gradients of the dense layers on the gfx950 matrix cores:
+//
+//     dW[n, k] += sum_m dZ[m, n] * prologue([X | X2])[m, k]        db[n] += sum_m dZ[m, n]
+//
+// (the backward of torch.nn.Linear inside msg_up_nn / update_up_nn / update_boundaries_nn /
+// combine_nn, mp/layers.py:290-325).  The reduction runs over the M cells of a dimension
+// (thousands) while the output is only hidden x hidden, the opposite shape of cwn_gemm_f32:
+//   * a workgroup owns a 64 x 64 tile of dW and a band of 256 rows of M; its four waves hold
+//     32 x 32 each (2 x 2 v_mfma_f32_16x16x4_f32 tiles, 16 accumulator VGPRs);
+//   * both operands are read ROW-CONTIGUOUSLY from global memory ([m][n] and [m][k] tiles of 64
+//     rows, 16-B loads, next chunk in flight during the MFMAs), staged in LDS with an 80-float row
+//     stride, and the MFMA fragments are 4-B reads of (row 4s + g, column j): lanes j walk
+//     consecutive words and the four lane groups g land 16 banks apart -- conflict-free without a
+//     transposition, because the reduction index m is the ROW of both tiles;
+//   * the bands are combined with fp32 atomics into dW (the caller's zeroed .grad buffer); with M
+//     ~3 k rows that is ~14 adds per element;
+//   * the normalisation + ReLU of the producing layer is applied to X on the way into LDS (the
+//     activation itself is never materialised in the forward pass);
+//   * up to CWN_MAX_DESCS weight gradients per launch.
+#include <hip/hip_runtime.h>
+#include "../../include/cwn_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kTile = 64;        // rows of dW (n) and columns of dW (k) per workgroup
+constexpr int kChunk = 64;       // rows of M per LDS stage
+constexpr int kBandRows = 256;   // rows of M per workgroup
+constexpr int kLd = 80;          // LDS row stride in floats
+constexpr int kU = kChunk * (kTile / 4) / kThreads;   // 16-B loads per thread per tile (= 4)
+
+struct TnBatch {
+    cwn_gemm_tn_desc d[CWN_MAX_DESCS];
+    int32_t blk_start[CWN_MAX_DESCS + 1];
+    int32_t tiles_n[CWN_MAX_DESCS], tiles_k[CWN_MAX_DESCS];
+    int32_t vec[CWN_MAX_DESCS];
+    int32_t n;
+};
+
+struct Src {                 // one logical [M, C1 + C2] operand made of up to two matrices
+    const float* p1;
+    const float* p2;
+    int64_t ld1, ld2;
+    int c1, c2;
+    const float* scale1;     // prologue, or NULL
+    const float* shift1;
+    const float* scale2;
+    const float* shift2;
+    int relu;                // bit 0: first matrix, bit 1: second
+};
+
+template <bool FAST>
+__device__ __forceinline__ void tile_load(f32x4 (&v)[kU], const Src& S, int col0, int64_t row0,
+                                          int64_t row_hi) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+        const int q = u * kThreads + threadIdx.x;
+        const int r = q / (kTile / 4), c = q % (kTile / 4);
+        const int64_t row = row0 + r < row_hi ? row0 + r : row_hi - 1;   // clamped, never faults
+        const int col = col0 + 4 * c;
+        const bool second = S.c2 > 0 && col >= S.c1;
+        const float* base = second ? S.p2 : S.p1;
+        const int64_t ld = second ? S.ld2 : S.ld1;
+        const int cc = second ? col - S.c1 : col;
+        const int cmax = second ? S.c2 : S.c1;
+        if constexpr (FAST) {
+            v[u] = *reinterpret_cast<const f32x4*>(base + row * ld + (cc < cmax ? cc : 0));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[u][t] = base[row * ld + (cc + t < cmax ? cc + t : 0)];
+        }
+    }
+}
+
+__device__ __forceinline__ void tile_store(float* lds, const f32x4 (&v)[kU], const Src& S, int col0,
+                                           int64_t row0, int64_t row_hi) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+        const int q = u * kThreads + threadIdx.x;
+        const int r = q / (kTile / 4), c = q % (kTile / 4);
+        const bool row_ok = row0 + r < row_hi;
+        const int col = col0 + 4 * c;
+        const bool second = S.c2 > 0 && col >= S.c1;
+        const int cc = second ? col - S.c1 : col;
+        const int cmax = second ? S.c2 : S.c1;
+        const float* sc = second ? S.scale2 : S.scale1;
+        const float* sh = second ? S.shift2 : S.shift1;
+        const bool relu = (S.relu & (second ? 2 : 1)) != 0;
+        f32x4 x = v[u];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float y = x[t];
+            const bool ok = row_ok && cc + t < cmax;
+            if (ok && sc != nullptr) y = y * sc[cc + t] + sh[cc + t];
+            if (relu) y = fmaxf(y, 0.f);
+            x[t] = ok ? y : 0.f;      // rows past the band and columns past the matrix add nothing
+        }
+        *reinterpret_cast<f32x4*>(lds + r * kLd + 4 * c) = x;
+    }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TnBatch B) {
+    __shared__ __attribute__((aligned(16))) float zt[kChunk * kLd];
+    __shared__ __attribute__((aligned(16))) float xt[kChunk * kLd];
+    int di = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+        if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
+    const cwn_gemm_tn_desc& D = B.d[di];
+    const int tn = B.tiles_n[di], tk = B.tiles_k[di];
+    int b = blockIdx.x - B.blk_start[di];
+    const int tile_k = b % tk;
+    b /= tk;
+    const int tile_n = b % tn;
+    const int band = b / tn;
+    const int64_t M = D.M;
+    const int64_t row_lo = (int64_t)band * kBandRows;
+    const int64_t row_hi = row_lo + kBandRows < M ? row_lo + kBandRows : M;
+    const int n0 = tile_n * kTile, k0 = tile_k * kTile;
+    const int N = D.N, Ktot = D.K + D.K2;
+    const Src SZ{D.dZ, nullptr, D.lddz, 0, N, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    const Src SX{D.X, D.X2, D.ldx, D.ldx2, D.K, D.K2, D.in_scale, D.in_shift, D.in_scale2, D.in_shift2,
+                 D.in_relu};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const bool do_bias = D.db != nullptr && tile_k == 0;
+
+    f32x4 vz[kU], vx[kU];
+    tile_load<FAST>(vz, SZ, n0, row_lo, row_hi);
+    tile_load<FAST>(vx, SX, k0, row_lo, row_hi);
+    for (int64_t row0 = row_lo; row0 < row_hi; row0 += kChunk) {
+        __syncthreads();                          // everyone is done reading the previous chunk
+        tile_store(zt, vz, SZ, n0, row0, row_hi);
+        tile_store(xt, vx, SX, k0, row0, row_hi);
+        __syncthreads();
+        if (row0 + kChunk < row_hi) {             // next chunk in flight during the MFMAs
+            tile_load<FAST>(vz, SZ, n0, row0 + kChunk, row_hi);
+            tile_load<FAST>(vx, SX, k0, row0 + kChunk, row_hi);
+        }
+        if (do_bias && threadIdx.x < kTile) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < kChunk; ++r) s += zt[r * kLd + threadIdx.x];
+            bsum += s;
+        }
+#pragma unroll
+        for (int s = 0; s < kChunk / 4; ++s) {
+            const int row = 4 * s + g;
+            float a[2], bb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = zt[row * kLd + wn * 32 + t * 16 + j];
+                bb[t] = xt[row * kLd + wk * 32 + t * 16 + j];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt], bb[kt], acc[nt][kt], 0, 0, 0);
+        }
+    }
+    // acc[nt][kt][r] = partial dW[n0 + wn*32 + nt*16 + 4g + r][k0 + wk*32 + kt*16 + j]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 32 + nt * 16 + 4 * g + r;
+                const int k = k0 + wk * 32 + kt * 16 + j;
+                if (n < N && k < Ktot) atomicAdd(D.dW + (int64_t)n * D.lddw + k, acc[nt][kt][r]);
+            }
+    if (do_bias && threadIdx.x < kTile && n0 + (int)threadIdx.x < N) atomicAdd(D.db + n0 + threadIdx.x, bsum);
+}
+
+inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, cwn_stream_t stream_) {
+    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return CWN_ERR_BAD_ARG;
+    TnBatch B{};
+    B.n = n;
+    int64_t blocks = 0;
+    bool fast = true;
+    for (int i = 0; i < n; ++i) {
+        const cwn_gemm_tn_desc& D = descs[i];
+        if (D.M < 0 || D.N <= 0 || D.K <= 0 || D.K2 < 0) return CWN_ERR_BAD_ARG;
+        if (D.dW == nullptr || D.lddw < D.K + D.K2) return CWN_ERR_BAD_ARG;
+        if (D.M > 0 && (D.dZ == nullptr || D.X == nullptr || D.lddz < D.N || D.ldx < D.K)) return CWN_ERR_BAD_ARG;
+        if (D.K2 > 0 && (D.X2 == nullptr || D.ldx2 < D.K2 || D.K % 4 != 0)) return CWN_ERR_BAD_ARG;
+        if ((D.in_scale == nullptr) != (D.in_shift == nullptr)) return CWN_ERR_BAD_ARG;
+        if ((D.in_scale2 == nullptr) != (D.in_shift2 == nullptr)) return CWN_ERR_BAD_ARG;
+        const void* ptrs[] = {D.dZ, D.X, D.X2, D.dW, D.db};
+        for (const void* p : ptrs)
+            if (p != nullptr && ((uintptr_t)p & 3u)) return CWN_ERR_ALIGN;
+        fast = fast && al16(D.dZ) && al16(D.X) && al16(D.X2) && D.lddz % 4 == 0 && D.ldx % 4 == 0 &&
+               (D.K2 == 0 || D.ldx2 % 4 == 0) && D.N % 4 == 0 && D.K % 4 == 0 && D.K2 % 4 == 0;
+        B.d[i] = D;
+        B.tiles_n[i] = (D.N + kTile - 1) / kTile;
+        B.tiles_k[i] = (D.K + D.K2 + kTile - 1) / kTile;
+        const int64_t bands = (D.M + kBandRows - 1) / kBandRows;
+        B.blk_start[i] = (int32_t)blocks;
+        blocks += bands * B.tiles_n[i] * B.tiles_k[i];
+        if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    }
+    for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
+    if (blocks == 0) return CWN_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (fast) gemm_tn_kernel<true><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    else gemm_tn_kernel<false><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}

@@ -1,0 +1,268 @@
+// cwn_norm.hip -- training-mode normalisation + activation around the dense GEMMs, and its
+// backward pass (torch.nn.BatchNorm1d(train) + ReLU of update_up_nn / update_boundaries_nn /
+// combine_nn, mp/layers.py:303-325).
+//
+//   cwn_bn_finalize_f32       batch statistics (fp64 sums from the GEMM epilogue) -> per-column
+//                             affine (scale, shift) + mean / rstd for backward + running statistics
+//   cwn_norm_act_f32          out = act(z * scale + shift)             (materialised last stage)
+//   cwn_norm_bwd_reduce_f32   s1 = sum dyh, s2 = sum dyh * xhat        (= d beta, d gamma)
+//   cwn_norm_bwd_apply_f32    dz = scale * (dyh - s1/M - xhat * s2/M)
+//
+// All of it is HBM/L2-bound elementwise or column-reduction work over [M, N] matrices with
+// N = hidden width (64..256): a workgroup takes a band of rows, 32 lanes x 16 B span 128 columns
+// (one full 512-B row segment per half wave), column reductions go registers -> LDS -> one atomic
+// per column per workgroup.  Up to CWN_MAX_NORM_DESCS matrices (all dimensions and both branches
+// of a layer) per launch.
+#include <hip/hip_runtime.h>
+#include "../../include/cwn_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTPR = 32;                    // threads per row
+constexpr int kRowsPerPass = kThreads / kTPR;   // 8
+constexpr int kBand = 64;                   // rows per workgroup
+
+struct NormBatch {
+    cwn_norm_desc d[CWN_MAX_NORM_DESCS];
+    int32_t blk_start[CWN_MAX_NORM_DESCS + 1];
+    int32_t n;
+};
+
+struct BnBatch {
+    cwn_bn_desc d[CWN_MAX_NORM_DESCS];
+    int32_t n;
+};
+
+__device__ __forceinline__ int find_desc(const int32_t* start, int n, int b) {
+    int d = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_MAX_NORM_DESCS; ++i)
+        if (i < n && b >= start[i]) d = i;
+    return d;
+}
+
+__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(BnBatch B) {
+    const cwn_bn_desc& D = B.d[blockIdx.x];
+    const double invM = 1.0 / (double)D.M;
+    for (int n = threadIdx.x; n < D.N; n += kThreads) {
+        const double mean = D.col_sum[n] * invM;
+        double var = D.col_sumsq[n] * invM - mean * mean;     // biased, as BatchNorm normalises
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)D.eps));
+        const float g = D.gamma != nullptr ? D.gamma[n] : 1.0f;
+        const float b = D.beta != nullptr ? D.beta[n] : 0.0f;
+        const float scale = g * rstd;
+        D.scale[n] = scale;
+        D.shift[n] = b - (float)mean * scale;
+        D.mean[n] = (float)mean;
+        D.rstd[n] = rstd;
+        if (D.running_mean != nullptr) {
+            const float mom = D.momentum;
+            const double unbiased = D.M > 1 ? var * ((double)D.M / (double)(D.M - 1)) : var;
+            D.running_mean[n] = (1.0f - mom) * D.running_mean[n] + mom * (float)mean;
+            D.running_var[n] = (1.0f - mom) * D.running_var[n] + mom * (float)unbiased;
+        }
+    }
+}
+
+// per-column constants of a thread's VEC columns
+template <int VEC>
+struct Cols {
+    float scale[VEC], shift[VEC], mean[VEC], rstd[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ void ld_vec(float (&v)[VEC], const float* p) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void st_vec(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else *p = v[0];
+}
+
+// MODE 0: activation forward; 1: backward reduce; 2: backward apply
+template <int VEC, int MODE>
+__global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
+    __shared__ float red[2][kRowsPerPass][kTPR * 4 + 4];
+    const int di = find_desc(B.blk_start, B.n, blockIdx.x);
+    const cwn_norm_desc& D = B.d[di];
+    const int64_t row0 = (int64_t)(blockIdx.x - B.blk_start[di]) * kBand;
+    const int tc = threadIdx.x % kTPR, tr = threadIdx.x / kTPR;
+    const int N = D.N;
+    const bool has_norm = D.scale != nullptr;
+    const bool relu = D.relu != 0;
+    const float invM = 1.0f / (float)D.M;
+    for (int c0 = 0; c0 < N; c0 += kTPR * VEC) {     // column chunks of 128 (VEC = 4) or 32
+        const int c = c0 + tc * VEC;
+        const bool cok = c < N;                       // N % VEC == 0 (host-checked)
+        float scale[VEC], shift[VEC], mean[VEC], rstd[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            scale[v] = 1.f; shift[v] = 0.f; mean[v] = 0.f; rstd[v] = 0.f; k1[v] = 0.f; k2[v] = 0.f;
+        }
+        if (cok && has_norm) {
+            ld_vec<VEC>(scale, D.scale + c);
+            ld_vec<VEC>(shift, D.shift + c);
+            if constexpr (MODE != 0) {
+                ld_vec<VEC>(mean, D.mean + c);
+                ld_vec<VEC>(rstd, D.rstd + c);
+            }
+            if constexpr (MODE == 2) {
+                ld_vec<VEC>(k1, D.s1 + c);
+                ld_vec<VEC>(k2, D.s2 + c);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    k1[v] *= invM;
+                    k2[v] *= invM;
+                }
+            }
+        }
+        float a1[VEC], a2[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a1[v] = a2[v] = 0.f;
+        // all of a thread's row loads are issued before the first use
+        float z[kBand / kRowsPerPass][VEC], g[kBand / kRowsPerPass][VEC];
+#pragma unroll
+        for (int i = 0; i < kBand / kRowsPerPass; ++i) {
+            const int64_t r = row0 + tr + i * kRowsPerPass;
+            const int64_t rc = r < D.M ? r : D.M - 1;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) z[i][v] = g[i][v] = 0.f;
+            if (cok) {
+                ld_vec<VEC>(z[i], D.z + rc * D.ldz + c);
+                if constexpr (MODE != 0) ld_vec<VEC>(g[i], D.dy + rc * D.lddy + c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kBand / kRowsPerPass; ++i) {
+            const int64_t r = row0 + tr + i * kRowsPerPass;
+            const bool ok = cok && r < D.M;
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float y = z[i][v] * scale[v] + shift[v];
+                if constexpr (MODE == 0) {
+                    o[v] = relu ? fmaxf(y, 0.f) : y;
+                } else {
+                    const float dyh = (!relu || y > 0.f) ? g[i][v] : 0.f;
+                    const float xhat = (z[i][v] - mean[v]) * rstd[v];
+                    if constexpr (MODE == 1) {
+                        if (ok) {
+                            a1[v] += dyh;
+                            a2[v] += dyh * xhat;
+                        }
+                    } else {
+                        o[v] = has_norm ? scale[v] * (dyh - k1[v] - xhat * k2[v]) : dyh;
+                    }
+                }
+            }
+            if constexpr (MODE != 1) {
+                if (ok) st_vec<VEC>(D.out + r * D.ldout + c, o);
+            }
+        }
+        if constexpr (MODE == 1) {
+            // 8 row groups -> one partial per column -> one atomic per column per workgroup
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                red[0][tr][tc * VEC + v] = a1[v];
+                red[1][tr][tc * VEC + v] = a2[v];
+            }
+            __syncthreads();
+            if (threadIdx.x < kTPR * VEC) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < kRowsPerPass; ++q) {
+                    t1 += red[0][q][threadIdx.x];
+                    t2 += red[1][q][threadIdx.x];
+                }
+                const int cc = c0 + threadIdx.x;
+                if (cc < N) {
+                    atomicAdd(D.s1 + cc, t1);
+                    atomicAdd(D.s2 + cc, t2);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15u) == 0; }
+
+template <int MODE>
+int launch_norm(const cwn_norm_desc* descs, int n, cwn_stream_t stream_) {
+    if (descs == nullptr || n <= 0 || n > CWN_MAX_NORM_DESCS) return CWN_ERR_BAD_ARG;
+    NormBatch B{};
+    B.n = n;
+    int64_t blocks = 0;
+    bool vec = true;
+    for (int i = 0; i < n; ++i) {
+        const cwn_norm_desc& D = descs[i];
+        if (D.M < 0 || D.N <= 0) return CWN_ERR_BAD_ARG;
+        if ((D.scale == nullptr) != (D.shift == nullptr)) return CWN_ERR_BAD_ARG;
+        if (D.M > 0) {
+            if (D.z == nullptr || D.ldz < D.N) return CWN_ERR_BAD_ARG;
+            if (MODE != 1 && (D.out == nullptr || D.ldout < D.N)) return CWN_ERR_BAD_ARG;
+            if (MODE != 0 && (D.dy == nullptr || D.lddy < D.N)) return CWN_ERR_BAD_ARG;
+            if (MODE != 0 && D.scale != nullptr &&
+                (D.mean == nullptr || D.rstd == nullptr || D.s1 == nullptr || D.s2 == nullptr))
+                return CWN_ERR_BAD_ARG;
+            if (MODE == 1 && (D.s1 == nullptr || D.s2 == nullptr)) return CWN_ERR_BAD_ARG;
+        }
+        const void* ptrs[] = {D.dy, D.z, D.scale, D.shift, D.mean, D.rstd, D.s1, D.s2, D.out};
+        for (const void* p : ptrs) {
+            if (p != nullptr && ((uintptr_t)p & 3u)) return CWN_ERR_ALIGN;
+            vec = vec && al16(p);
+        }
+        vec = vec && D.N % 4 == 0 && D.ldz % 4 == 0 && (MODE == 0 || D.lddy % 4 == 0) &&
+              (MODE == 1 || D.ldout % 4 == 0);
+        B.d[i] = D;
+        B.blk_start[i] = (int32_t)blocks;
+        blocks += (D.M + kBand - 1) / kBand;
+        if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    }
+    for (int i = n; i <= CWN_MAX_NORM_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
+    if (blocks == 0) return CWN_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (vec) norm_kernel<4, MODE><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    else norm_kernel<1, MODE><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int cwn_bn_finalize_f32(const cwn_bn_desc* descs, int n, cwn_stream_t stream_) {
+    if (descs == nullptr || n <= 0 || n > CWN_MAX_NORM_DESCS) return CWN_ERR_BAD_ARG;
+    BnBatch B{};
+    B.n = n;
+    for (int i = 0; i < n; ++i) {
+        const cwn_bn_desc& D = descs[i];
+        if (D.N <= 0 || D.M <= 0) return CWN_ERR_BAD_ARG;
+        if (D.col_sum == nullptr || D.col_sumsq == nullptr || D.scale == nullptr || D.shift == nullptr ||
+            D.mean == nullptr || D.rstd == nullptr)
+            return CWN_ERR_BAD_ARG;
+        if ((D.running_mean == nullptr) != (D.running_var == nullptr)) return CWN_ERR_BAD_ARG;
+        B.d[i] = D;
+    }
+    bn_finalize_kernel<<<dim3(n), dim3(kThreads), 0, (hipStream_t)stream_>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int cwn_norm_act_f32(const cwn_norm_desc* descs, int n, cwn_stream_t stream) {
+    return launch_norm<0>(descs, n, stream);
+}
+
+extern "C" int cwn_norm_bwd_reduce_f32(const cwn_norm_desc* descs, int n, cwn_stream_t stream) {
+    return launch_norm<1>(descs, n, stream);
+}
+
+extern "C" int cwn_norm_bwd_apply_f32(const cwn_norm_desc* descs, int n, cwn_stream_t stream) {
+    return launch_norm<2>(descs, n, stream);
+}

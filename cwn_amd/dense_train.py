@@ -1,0 +1,332 @@
+"""Training-mode dense networks of a SparseCINConv layer (update_up_nn, update_boundaries_nn,
+combine_nn of every dimension; mp/layers.py:193-199, 303-325) as grouped launches of the C-ABI
+kernels, forward AND backward, behind one torch.autograd.Function.
+
+Forward, per layer (all dimensions and both branches in each launch):
+
+    for every update stage:   cwn_gemm_f32      Z = prologue(previous Z) W^T + b, batch statistics
+                                                of Z accumulated in the epilogue (fp64)
+                              cwn_bn_finalize   statistics -> per-column affine (+ running stats)
+    combine:                  cwn_gemm_f32      Z3 = [A_up | A_bd] Wc^T + bc  (torch.cat = K-concat)
+                              cwn_bn_finalize
+                              cwn_norm_act      H = ReLU(Z3 * scale + shift)
+
+`prologue` is the BatchNorm apply + ReLU of the producing stage, done while the tile is staged, so
+no normalised activation between two Linear layers is ever written to memory.
+
+Backward, per stage from the last to the first:
+
+    cwn_norm_bwd_reduce   s1 = sum dyh, s2 = sum dyh * xhat          (= d beta, d gamma)
+    cwn_norm_bwd_apply    dZ = scale * (dyh - s1/M - xhat * s2/M)
+    cwn_gemm_tn_f32       dW += dZ^T prologue(X),  db += sum dZ      (fp32 atomics, MFMA)
+    cwn_gemm_f32(w_trans) dX = dZ W                                    (the layer's own weight)
+
+Semantics are those of torch.nn.Linear / BatchNorm1d(train) / ReLU; tests/test_gpu_parity.py checks
+outputs, every gradient and the running statistics against the torch modules.
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+from torch.nn import BatchNorm1d, Identity, Linear
+
+from . import _ffi, ops
+
+
+@dataclass
+class Stage:
+    """One Linear -> norm -> ReLU group.  `norm` is a BatchNorm1d in training mode or Identity."""
+    lin: Linear
+    norm: torch.nn.Module
+
+    @property
+    def is_bn(self) -> bool:
+        return isinstance(self.norm, BatchNorm1d)
+
+
+def supported(stages: Sequence[Stage]) -> bool:
+    for st in stages:
+        if not isinstance(st.lin, Linear) or st.lin.in_features > ops.GEMM_MAX_K:
+            return False
+        n = st.norm
+        if isinstance(n, Identity):
+            continue
+        if not isinstance(n, BatchNorm1d):
+            return False
+        if (not n.training or not n.affine or not n.track_running_stats or n.momentum is None
+                or n.num_features != st.lin.out_features):
+            return False
+    return True
+
+
+def _norm_desc(z: Tensor, *, dy: Optional[Tensor] = None, out: Optional[Tensor] = None, aff=None,
+               s12=None, relu: bool = True) -> _ffi.NormDesc:
+    """aff = (scale, shift, mean, rstd) rows of one [4, N] tensor, or None for an identity norm."""
+    M, N = z.shape
+    ld = lambda t: t.stride(0) if t.size(0) > 1 else t.size(1)
+    return _ffi.NormDesc(
+        dy=_ffi.ptr(dy), z=z.data_ptr(),
+        scale=None if aff is None else aff[0].data_ptr(), shift=None if aff is None else aff[1].data_ptr(),
+        mean=None if aff is None else aff[2].data_ptr(), rstd=None if aff is None else aff[3].data_ptr(),
+        s1=None if s12 is None else s12[0].data_ptr(), s2=None if s12 is None else s12[1].data_ptr(),
+        out=_ffi.ptr(out), M=M, lddy=0 if dy is None else ld(dy), ldz=ld(z),
+        ldout=0 if out is None else ld(out), N=N, relu=int(relu))
+
+
+class _Plan:
+    """Static description of one layer's dense networks: per dimension, `depth` update stages for
+    each of the two branches and one combine stage."""
+
+    def __init__(self, up: List[List[Stage]], bd: List[List[Stage]], cb: List[Stage]):
+        self.up, self.bd, self.cb = up, bd, cb
+        self.nd = len(cb)
+        self.depth = len(up[0])
+
+    def stages(self):
+        """Every stage in the flattening order of the Function's tensor arguments."""
+        for i in range(self.nd):
+            for st in self.up[i]:
+                yield st
+            for st in self.bd[i]:
+                yield st
+            yield self.cb[i]
+
+
+def _stage_tensors(st: Stage) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
+    return (st.lin.weight, st.lin.bias, st.norm.weight if st.is_bn else None,
+            st.norm.bias if st.is_bn else None)
+
+
+class _DenseTrain(torch.autograd.Function):
+    """tensors = [out_up_0, out_bd_0, ..., out_up_{nd-1}, out_bd_{nd-1}] + 4 per stage (W, b, gamma,
+    beta) in _Plan.stages() order.  Returns H_0 .. H_{nd-1}."""
+
+    @staticmethod
+    def forward(ctx, plan: _Plan, *tensors):
+        nd, depth = plan.nd, plan.depth
+        dev = tensors[0].device
+        A0 = [[ops._rowmajor(tensors[2 * i], 'out_up'), ops._rowmajor(tensors[2 * i + 1], 'out_boundaries')]
+              for i in range(nd)]
+        stages = list(plan.stages())
+        par = tensors[2 * nd:]
+        P = {id(st): par[4 * k: 4 * k + 4] for k, st in enumerate(stages)}
+        bns = [st for st in stages if st.is_bn]
+        # one zeroed fp64 buffer for all batch statistics, one fp32 buffer for all affines
+        widths = [st.lin.out_features for st in bns]
+        stats = torch.zeros(2 * sum(widths), dtype=torch.float64, device=dev)
+        affs = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
+        stat_of, aff_of, o = {}, {}, 0
+        for st, w in zip(bns, widths):
+            stat_of[id(st)] = stats[2 * o: 2 * o + 2 * w].view(2, w)
+            aff_of[id(st)] = affs[4 * o: 4 * o + 4 * w].view(4, w)
+            o += w
+
+        def finalize(group: Sequence[Tuple[Stage, int]]):
+            descs = []
+            for st, M in group:
+                if not st.is_bn:
+                    continue
+                n, s, a = st.norm, stat_of[id(st)], aff_of[id(st)]
+                W, b, gamma, beta = P[id(st)]
+                descs.append(_ffi.BnDesc(
+                    col_sum=s[0].data_ptr(), col_sumsq=s[1].data_ptr(), gamma=_ffi.ptr(gamma),
+                    beta=_ffi.ptr(beta), running_mean=n.running_mean.data_ptr(),
+                    running_var=n.running_var.data_ptr(), scale=a[0].data_ptr(), shift=a[1].data_ptr(),
+                    mean=a[2].data_ptr(), rstd=a[3].data_ptr(), M=M, N=s.size(1), eps=float(n.eps),
+                    momentum=float(n.momentum)))
+            if descs:
+                _ffi.bn_finalize(descs, dev)
+
+        def prologue(st: Optional[Stage]):
+            """(scale, shift) of the producing stage for the consumer's prologue."""
+            if st is None or not st.is_bn:
+                return None, None
+            a = aff_of[id(st)]
+            return a[0], a[1]
+
+        Z = [[[None] * depth, [None] * depth] for _ in range(nd)]   # Z[dim][branch][stage]
+        for s in range(depth):
+            gemms, group = [], []
+            for i in range(nd):
+                for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
+                    st = chain[s]
+                    W, b, _, _ = P[id(st)]
+                    X = A0[i][br] if s == 0 else Z[i][br][s - 1]
+                    sc, sh = prologue(chain[s - 1] if s > 0 else None)
+                    gemms.append(ops.Gemm(X=X, W=W, bias=b, in_scale=sc, in_shift=sh,
+                                          in_relu=1 if s > 0 else 0,
+                                          col_stats=stat_of.get(id(st))))
+                    group.append((st, X.size(0)))
+            res = ops.run_gemm(gemms, dev)
+            k = 0
+            for i in range(nd):
+                for br in (0, 1):
+                    Z[i][br][s] = res[k]
+                    k += 1
+            finalize(group)
+        gemms, group = [], []
+        for i in range(nd):
+            st = plan.cb[i]
+            W, b, _, _ = P[id(st)]
+            sc, sh = prologue(plan.up[i][-1])
+            sc2, sh2 = prologue(plan.bd[i][-1])
+            gemms.append(ops.Gemm(X=Z[i][0][-1], X2=Z[i][1][-1], W=W, bias=b, in_scale=sc, in_shift=sh,
+                                  in_scale2=sc2, in_shift2=sh2, in_relu=3, col_stats=stat_of.get(id(st))))
+            group.append((st, Z[i][0][-1].size(0)))
+        Z3 = ops.run_gemm(gemms, dev)
+        finalize(group)
+        H = [torch.empty_like(z) for z in Z3]
+        _ffi.norm_act([_norm_desc(z, out=h, aff=aff_of.get(id(plan.cb[i])))
+                       for i, (z, h) in enumerate(zip(Z3, H)) if z.numel()], dev)
+        if bns:
+            torch._foreach_add_([st.norm.num_batches_tracked for st in bns], 1)
+        ctx.plan = plan
+        ctx.aff_of = {k: v for k, v in aff_of.items()}
+        flatZ = [Z[i][br][s] for i in range(nd) for br in (0, 1) for s in range(depth)]
+        ctx.save_for_backward(*[a for pair in A0 for a in pair], *flatZ, *Z3, affs,
+                              *[t for t in par])
+        ctx.n_par = len(par)
+        return tuple(H)
+
+    @staticmethod
+    def backward(ctx, *dH):
+        plan: _Plan = ctx.plan
+        nd, depth = plan.nd, plan.depth
+        saved = ctx.saved_tensors
+        A0 = [[saved[2 * i], saved[2 * i + 1]] for i in range(nd)]
+        o = 2 * nd
+        Z = [[[None] * depth, [None] * depth] for _ in range(nd)]
+        for i in range(nd):
+            for br in (0, 1):
+                for s in range(depth):
+                    Z[i][br][s] = saved[o]
+                    o += 1
+        Z3 = list(saved[o: o + nd])
+        o += nd + 1                                   # + the flat affine buffer (kept alive)
+        par = saved[o: o + ctx.n_par]
+        stages = list(plan.stages())
+        P = {id(st): par[4 * k: 4 * k + 4] for k, st in enumerate(stages)}
+        aff_of = ctx.aff_of
+        dev = Z3[0].device
+        # one zeroed buffer: gradients of every parameter (accumulated by atomics) + s1/s2 of the
+        # identity-normalised stages' absent BatchNorms are simply not allocated
+        sizes = []
+        for st in stages:
+            W, b, gamma, beta = P[id(st)]
+            sizes.append((W.numel(), 0 if b is None else b.numel(), 2 * W.size(0) if st.is_bn else 0))
+        flat = torch.zeros(sum(a + b + c for a, b, c in sizes), dtype=torch.float32, device=dev)
+        G, q = {}, 0
+        for st, (nw, nb, ns) in zip(stages, sizes):
+            W = P[id(st)][0]
+            dW = flat[q: q + nw].view_as(W)
+            q += nw
+            db = flat[q: q + nb] if nb else None
+            q += nb
+            s12 = flat[q: q + ns].view(2, -1) if ns else None
+            q += ns
+            G[id(st)] = (dW, db, s12)
+
+        def norm_backward(items):
+            """items: (stage, dy, z) -> dz list; BatchNorm stages reduce first."""
+            red, app, outs = [], [], []
+            for st, dy, z in items:
+                dz = torch.empty(z.shape, dtype=torch.float32, device=dev)
+                outs.append(dz)
+                if not z.numel():
+                    continue
+                aff = aff_of.get(id(st))
+                s12 = G[id(st)][2]
+                if st.is_bn:
+                    red.append(_norm_desc(z, dy=dy, aff=aff, s12=s12))
+                app.append(_norm_desc(z, dy=dy, out=dz, aff=aff, s12=s12))
+            if red:
+                _ffi.norm_bwd_reduce(red, dev)
+            if app:
+                _ffi.norm_bwd_apply(app, dev)
+            return outs
+
+        def prologue(st: Optional[Stage]):
+            if st is None or not st.is_bn:
+                return None, None
+            a = aff_of[id(st)]
+            return a[0], a[1]
+
+        ld = lambda t: t.stride(0) if t.size(0) > 1 else t.size(1)
+
+        # ---- combine stage -------------------------------------------------------------------
+        dH = [g if g is not None else torch.zeros_like(z) for g, z in zip(dH, Z3)]
+        dH = [ops._rowmajor(g, 'grad') for g in dH]
+        dZ3 = norm_backward([(plan.cb[i], dH[i], Z3[i]) for i in range(nd)])
+        tn, nn = [], []
+        for i in range(nd):
+            st = plan.cb[i]
+            W = P[id(st)][0]
+            dW, db, _ = G[id(st)]
+            Xu, Xb = Z[i][0][-1], Z[i][1][-1]
+            sc, sh = prologue(plan.up[i][-1])
+            sc2, sh2 = prologue(plan.bd[i][-1])
+            if dZ3[i].numel():
+                tn.append(_ffi.GemmTnDesc(
+                    dZ=dZ3[i].data_ptr(), X=Xu.data_ptr(), X2=Xb.data_ptr(), in_scale=_ffi.ptr(sc),
+                    in_shift=_ffi.ptr(sh), in_scale2=_ffi.ptr(sc2), in_shift2=_ffi.ptr(sh2),
+                    dW=dW.data_ptr(), db=_ffi.ptr(db), M=dZ3[i].size(0), lddz=ld(dZ3[i]), ldx=ld(Xu),
+                    ldx2=ld(Xb), lddw=W.size(1), N=W.size(0), K=Xu.size(1), K2=Xb.size(1), in_relu=3))
+            nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
+        if tn:
+            _ffi.gemm_tn(tn, dev)
+        dA = ops.run_gemm(nn, dev)                      # [M, H_up + H_bd] per dimension
+        dy = []
+        for i in range(nd):
+            hu = plan.up[i][-1].lin.out_features
+            dy.append([dA[i][:, :hu], dA[i][:, hu:]])
+        # ---- update stages, last to first ------------------------------------------------------
+        for s in range(depth - 1, -1, -1):
+            items = []
+            for i in range(nd):
+                for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
+                    items.append((chain[s], dy[i][br], Z[i][br][s]))
+            dZ = norm_backward(items)
+            tn, nn, k = [], [], 0
+            for i in range(nd):
+                for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
+                    st = chain[s]
+                    W = P[id(st)][0]
+                    dW, db, _ = G[id(st)]
+                    X = A0[i][br] if s == 0 else Z[i][br][s - 1]
+                    sc, sh = prologue(chain[s - 1] if s > 0 else None)
+                    dz = dZ[k]
+                    k += 1
+                    if dz.numel():
+                        tn.append(_ffi.GemmTnDesc(
+                            dZ=dz.data_ptr(), X=X.data_ptr(), X2=None, in_scale=_ffi.ptr(sc),
+                            in_shift=_ffi.ptr(sh), in_scale2=None, in_shift2=None, dW=dW.data_ptr(),
+                            db=_ffi.ptr(db), M=dz.size(0), lddz=ld(dz), ldx=ld(X), ldx2=0,
+                            lddw=W.size(1), N=W.size(0), K=X.size(1), K2=0, in_relu=1 if s > 0 else 0))
+                    nn.append(ops.Gemm(X=dz, W=W, w_trans=True))
+            if tn:
+                _ffi.gemm_tn(tn, dev)
+            res = ops.run_gemm(nn, dev)
+            k = 0
+            for i in range(nd):
+                for br in (0, 1):
+                    dy[i][br] = res[k]
+                    k += 1
+        grads: List[Optional[Tensor]] = [None]
+        for i in range(nd):
+            grads += [dy[i][0], dy[i][1]]
+        for st in stages:
+            dW, db, s12 = G[id(st)]
+            W, b, gamma, beta = P[id(st)]
+            grads += [dW, db if b is not None else None,
+                      s12[1] if (st.is_bn and gamma is not None) else None,
+                      s12[0] if (st.is_bn and beta is not None) else None]
+        return tuple(grads)
+
+
+def dense_train(plan: _Plan, outs: Sequence[Tensor]) -> List[Tensor]:
+    """outs = [out_up_0, out_bd_0, out_up_1, ...] (what SparseCINConv.propagate_all returns)."""
+    flat = []
+    for st in plan.stages():
+        flat += list(_stage_tensors(st))
+    return list(_DenseTrain.apply(plan, *outs, *flat))

@@ -79,6 +79,9 @@ def _is_cat_linear_relu(nn) -> bool:
             and isinstance(nn[1], Linear) and isinstance(nn[2], ReLU))
 
 
+FUSED_DENSE_TRAINING = True   # set False to run the update / combine networks as torch modules
+
+
 def _fold_norm(norm, width: int):
     """Eval-mode normalisation as a per-column affine (scale, shift) for the GEMM epilogue:
     BatchNorm1d with running statistics -> (w / sqrt(rv + eps), b - rm * scale); Identity ->
@@ -525,11 +528,45 @@ class SparseCINConv(torch.nn.Module):
                                   out_scale=folds[2][0][0], out_shift=folds[2][0][1]))
         return ops.run_gemm(gemms, dev)
 
+    def _dense_train(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
+        """The same networks with autograd and training-mode BatchNorm (batch statistics, running
+        statistics updated) as grouped launches forward and backward: cwn_amd/dense_train.py.
+        Returns None when it does not apply (LayerNorm, custom networks, fewer than two cells in
+        a dimension) and the caller runs the torch modules instead."""
+        from . import dense_train as DT
+        if not torch.is_grad_enabled() or not FUSED_DENSE_TRAINING:
+            return None
+        active = list(range(start, len(plans)))
+        if not active or any(plans[d] is None for d in active) or len(outs) != 2 * len(active):
+            return None
+        if any(o.size(0) < 2 for o in outs):
+            return None      # BatchNorm1d(train) needs more than one row; let torch raise as the reference does
+        ups, bds, cbs = [], [], []
+        for d in active:
+            lvl = self.mp_levels[d]
+            up, bd, cb = (_mlp_stages(lvl.update_up_nn), _mlp_stages(lvl.update_boundaries_nn),
+                          _mlp_stages(lvl.combine_nn))
+            if up is None or bd is None or cb is None or len(up) != len(bd) or len(cb) != 1:
+                return None
+            chains = [[DT.Stage(lin, norm) for lin, norm in st] for st in (up, bd, cb)]
+            if not all(DT.supported(c) for c in chains):
+                return None
+            if any(isinstance(s.norm, BN) and not s.norm.training for c in chains for s in c):
+                return None
+            ups.append(chains[0])
+            bds.append(chains[1])
+            cbs.append(chains[2][0])
+        if len({len(u) for u in ups}) != 1:
+            return None
+        return DT.dense_train(DT._Plan(ups, bds, cbs), outs)
+
     def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0):
         assert len(cochain_params) <= self.max_dim + 1
         n = len(cochain_params)
         plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
         dense = self._dense_eval(plans, outs, start_to_process)
+        if dense is None:
+            dense = self._dense_train(plans, outs, start_to_process)
         if dense is not None:
             it = iter(dense)
             return [cochain_params[dim].x if dim < start_to_process else next(it) for dim in range(n)]

@@ -310,29 +310,36 @@ class Gemm:
     out_shift: Optional[Tensor] = None
     in_scale: Optional[Tensor] = None    # producer's BatchNorm apply (+ReLU) on the fly; no grad
     in_shift: Optional[Tensor] = None
-    in_relu: bool = False
+    in_relu: int = 0                     # bit 0: ReLU on X after the affine, bit 1: on X2
     col_stats: Optional[Tensor] = None   # [2, N] fp32, zeroed by the caller: sum / sum of squares
     debug: int = 0                       # timing experiments only (tools/ubench_gemm.py)
+    in_scale2: Optional[Tensor] = None   # the same prologue for X2
+    in_shift2: Optional[Tensor] = None
+    w_trans: bool = False                # W is [K (+K2), N]: Y = [X | X2] @ W  (dX = dY @ W of a Linear)
+    out: Optional[Tensor] = None         # preallocated Y (may be a column slice of a wider matrix)
 
     def desc(self, Y: Tensor) -> _ffi.GemmDesc:
         X, W, X2 = self.X, self.W, self.X2
         K = X.size(1)
         K2 = X2.size(1) if X2 is not None else 0
-        if W.size(1) != K + K2:
-            raise ValueError(f'weight has {W.size(1)} input columns, operands have {K + K2}')
+        if W.size(0 if self.w_trans else 1) != K + K2:
+            raise ValueError(f'weight has {W.size(0 if self.w_trans else 1)} input columns, '
+                             f'operands have {K + K2}')
         if X2 is not None and X2.size(0) != X.size(0):
             raise ValueError('X and X2 must have the same number of rows')
         cs = self.col_stats
         return _ffi.GemmDesc(
             X=X.data_ptr(), X2=_ffi.ptr(X2), W=W.data_ptr(), bias=_ffi.ptr(self.bias),
             in_scale=_ffi.ptr(self.in_scale), in_shift=_ffi.ptr(self.in_shift),
+            in_scale2=_ffi.ptr(self.in_scale2), in_shift2=_ffi.ptr(self.in_shift2),
             out_scale=_ffi.ptr(self.out_scale), out_shift=_ffi.ptr(self.out_shift),
             col_sum=None if cs is None else cs[0].data_ptr(),
             col_sumsq=None if cs is None else cs[1].data_ptr(),
             Y=Y.data_ptr(), M=X.size(0), ldx=X.stride(0) if X.size(0) > 1 else max(K, 1),
             ldx2=(X2.stride(0) if X2.size(0) > 1 else max(K2, 1)) if X2 is not None else 0,
             ldw=W.stride(0) if W.size(0) > 1 else W.size(1), ldy=Y.stride(0) if Y.size(0) > 1 else Y.size(1),
-            N=W.size(0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu), reserved=int(self.debug))
+            N=W.size(1 if self.w_trans else 0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu),
+            w_trans=int(self.w_trans), reserved=int(self.debug))
 
 
 GEMM_MAX_K = 256   # K + K2 the MFMA kernel supports (whole-K weight tile resident in LDS)
@@ -345,7 +352,10 @@ def run_gemm(gemms: Sequence[Gemm], device) -> List[Tensor]:
         gm.X, gm.W = _rowmajor(gm.X, 'X'), _rowmajor(gm.W, 'W')
         if gm.X2 is not None:
             gm.X2 = _rowmajor(gm.X2, 'X2')
-        Y = torch.empty(gm.X.size(0), gm.W.size(0), dtype=torch.float32, device=device)
+        Y = gm.out
+        if Y is None:
+            Y = torch.empty(gm.X.size(0), gm.W.size(1 if gm.w_trans else 0), dtype=torch.float32,
+                            device=device)
         outs.append(Y)
         if Y.numel():
             descs.append(gm.desc(Y))

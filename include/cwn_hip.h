@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 2
+#define CWN_ABI_VERSION 3
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -174,10 +174,14 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  * (:322-325, whose torch.cat (:199) becomes the K-concatenation [X | X2]).
  *   X [M, K] (row stride ldx), X2 [M, K2] optional, W [N, K + K2] (row stride ldw, torch Linear
  *   layout), Y [M, N] (row stride ldy).
- *   prologue (optional): x <- x * in_scale[k] + in_shift[k], then ReLU if in_relu  (BatchNorm
- *                        apply of the producing layer), first input only;
- *   epilogue: + bias[n]; per-column sum / sum of squares of that value accumulated with atomics
- *             into col_sum / col_sumsq (BatchNorm batch statistics; caller zeroes them);
+ *   With w_trans != 0, W is [K + K2, N] (row stride ldw) and the product is [X | X2] . W: the
+ *   input-gradient GEMM dX = dY . W of a Linear layer reads the layer's own weight, no transposed
+ *   copy.
+ *   prologue (optional): x <- x * in_scale[k] + in_shift[k] for X (in_scale2 / in_shift2 for X2),
+ *                        then ReLU on X if in_relu & 1, on X2 if in_relu & 2 (normalisation +
+ *                        activation of the producing layer applied on the fly);
+ *   epilogue: + bias[n]; per-column sum / sum of squares of that value accumulated with fp64
+ *             atomics into col_sum / col_sumsq (BatchNorm batch statistics; caller zeroes them);
  *             then * out_scale[n] + out_shift[n] (BatchNorm eval), then ReLU if relu.
  * ------------------------------------------------------------------------------------------ */
 typedef struct cwn_gemm_desc {
@@ -187,19 +191,100 @@ typedef struct cwn_gemm_desc {
     const float* bias;      /* [N] or NULL */
     const float* in_scale;  /* [K] or NULL */
     const float* in_shift;  /* [K] or NULL */
+    const float* in_scale2; /* [K2] or NULL */
+    const float* in_shift2; /* [K2] or NULL */
     const float* out_scale; /* [N] or NULL */
     const float* out_shift; /* [N] or NULL */
-    float* col_sum;         /* [N] or NULL */
-    float* col_sumsq;       /* [N] or NULL */
+    double* col_sum;        /* [N] or NULL (fp64: exact enough for var = E[y^2] - mean^2) */
+    double* col_sumsq;      /* [N] or NULL */
     float* Y;
     int64_t M;
     int64_t ldx, ldx2, ldw, ldy;
     int32_t N, K, K2;
     int32_t relu, in_relu;
+    int32_t w_trans;
     int32_t reserved;
+    int32_t pad_;
 } cwn_gemm_desc;
 
 int cwn_gemm_f32(const cwn_gemm_desc* descs_host, int n, cwn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training-mode pieces of the dense networks (torch.nn.BatchNorm1d in train mode + ReLU between
+ * the Linear layers of update_up_nn / update_boundaries_nn / combine_nn, mp/layers.py:303-325,
+ * and their backward pass).  The forward never materialises a normalised activation between two
+ * Linear layers: cwn_gemm_f32 accumulates the batch statistics of its output in the epilogue,
+ * cwn_bn_finalize_f32 turns them into a per-column affine, and the NEXT cwn_gemm_f32 applies
+ * affine + ReLU in its prologue.
+ * ------------------------------------------------------------------------------------------ */
+#define CWN_MAX_NORM_DESCS 16
+
+typedef struct cwn_bn_desc {
+    const double* col_sum;    /* [N] sum_m y[m, n]      (cwn_gemm_f32 epilogue) */
+    const double* col_sumsq;  /* [N] sum_m y[m, n]^2 */
+    const float* gamma;       /* [N] or NULL (= 1) */
+    const float* beta;        /* [N] or NULL (= 0) */
+    float* running_mean;      /* [N] or NULL: <- (1 - momentum) * running + momentum * mean */
+    float* running_var;       /* [N] or NULL: same with the UNBIASED batch variance (torch semantics) */
+    float* scale;             /* [N] out: gamma * rstd */
+    float* shift;             /* [N] out: beta - mean * scale */
+    float* mean;              /* [N] out */
+    float* rstd;              /* [N] out: 1 / sqrt(biased var + eps) */
+    int64_t M;                /* rows the statistics were taken over */
+    int32_t N;
+    float eps;
+    float momentum;
+    int32_t pad_;
+} cwn_bn_desc;
+
+/* One launch for up to CWN_MAX_NORM_DESCS normalisations. */
+int cwn_bn_finalize_f32(const cwn_bn_desc* descs_host, int n, cwn_stream_t stream);
+
+typedef struct cwn_norm_desc {
+    const float* dy;     /* [M, N] gradient w.r.t. the activation output (backward), row stride lddy */
+    const float* z;      /* [M, N] pre-normalisation values, row stride ldz */
+    const float* scale;  /* [N] or NULL: identity normalisation (activation only) */
+    const float* shift;  /* [N] or NULL */
+    const float* mean;   /* [N]  (backward, when scale != NULL) */
+    const float* rstd;   /* [N] */
+    float* s1;           /* [N] sum_m dyh            reduce: accumulated (caller zeroes); apply: read */
+    float* s2;           /* [N] sum_m dyh * xhat */
+    float* out;          /* [M, N] row stride ldout: activation (forward) or dz (backward apply) */
+    int64_t M;
+    int64_t lddy, ldz, ldout;
+    int32_t N;
+    int32_t relu;        /* activation: ReLU (1) or identity (0) */
+} cwn_norm_desc;
+
+/* out = act(z * scale + shift)                                    (the last stage's output) */
+int cwn_norm_act_f32(const cwn_norm_desc* descs_host, int n, cwn_stream_t stream);
+/* dyh = dy * [act'(z * scale + shift)];  s1 += sum dyh;  s2 += sum dyh * (z - mean) * rstd */
+int cwn_norm_bwd_reduce_f32(const cwn_norm_desc* descs_host, int n, cwn_stream_t stream);
+/* out = scale * (dyh - s1 / M - xhat * s2 / M)      (out = dyh when scale == NULL) */
+int cwn_norm_bwd_apply_f32(const cwn_norm_desc* descs_host, int n, cwn_stream_t stream);
+
+/* Weight gradient of a Linear layer on the matrix cores, accumulated:
+ *     dW[n, k] += sum_m dZ[m, n] * prologue([X | X2])[m, k]          db[n] += sum_m dZ[m, n]
+ * dW is [N, K + K2] (row stride lddw, torch Linear layout) and is ADDED to with fp32 atomics (the
+ * M rows are split over workgroups), so it can be the .grad buffer itself; the caller zeroes it.
+ * The prologue is the one of cwn_gemm_f32 (normalisation + ReLU of the producing layer). */
+typedef struct cwn_gemm_tn_desc {
+    const float* dZ;         /* [M, N] row stride lddz */
+    const float* X;          /* [M, K] row stride ldx */
+    const float* X2;         /* [M, K2] or NULL */
+    const float* in_scale;   /* [K] or NULL */
+    const float* in_shift;
+    const float* in_scale2;  /* [K2] or NULL */
+    const float* in_shift2;
+    float* dW;               /* [N, K + K2] accumulated */
+    float* db;               /* [N] accumulated, or NULL */
+    int64_t M;
+    int64_t lddz, ldx, ldx2, lddw;
+    int32_t N, K, K2;
+    int32_t in_relu;         /* bit 0: X, bit 1: X2 */
+} cwn_gemm_tn_desc;
+
+int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs_host, int n, cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side batching (collate): build the arrays of a ComplexBatch from a dataset that is

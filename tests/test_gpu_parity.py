@@ -605,7 +605,7 @@ def test_gemm_grouped_concat_affine_stats():
     Xa, Xb = torch.randn(500, F, generator=g).to(DEV), torch.randn(500, F, generator=g).to(DEV)
     isc, ish = torch.rand(F, generator=g).to(DEV) + 0.5, torch.randn(F, generator=g).to(DEV)
     osc, osh = torch.rand(F, generator=g).to(DEV) + 0.5, torch.randn(F, generator=g).to(DEV)
-    stats = torch.zeros(2, F, device=DEV)
+    stats = torch.zeros(2, F, device=DEV, dtype=torch.float64)
     outs = ops.run_gemm([
         ops.Gemm(X=X0, W=Wfull[:, :F], bias=bias),
         ops.Gemm(X=X1, W=Wfull[:, F:]),
@@ -992,7 +992,7 @@ def test_gemm_narrow_grouped_concat_affine_stats():
     osc, osh = torch.rand(H, generator=g) + 0.5, torch.randn(H, generator=g)
     Xd, X2d = Xfull.to(DEV)[:, :H], X2.to(DEV)
     assert Xd.stride(0) == 2 * H
-    stats = (torch.zeros(H, device=DEV), torch.zeros(H, device=DEV))
+    stats = torch.zeros(2, H, device=DEV, dtype=torch.float64)
     gm = [ops.Gemm(X=Xd, X2=X2d, W=W.to(DEV), bias=b.to(DEV), in_scale=isc.to(DEV), in_shift=ish.to(DEV),
                    in_relu=True, out_scale=osc.to(DEV), out_shift=osh.to(DEV), relu=True, col_stats=stats),
           ops.Gemm(X=X2d, W=W[:40, :H].to(DEV), bias=None)]
@@ -1004,3 +1004,183 @@ def test_gemm_narrow_grouped_concat_affine_stats():
     torch.testing.assert_close(cpu(stats[0]).double(), pre.sum(0), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(cpu(stats[1]).double(), (pre * pre).sum(0), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(cpu(Y2).double(), X2.double() @ W[:40, :H].double().t(), rtol=1e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# training-mode dense path: transposed-weight GEMM, weight-gradient GEMM, BatchNorm pieces, and
+# the whole SparseCINConv layer forward + backward against the torch modules
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (100, 128, 128), (3341, 128, 256), (77, 40, 24), (513, 64, 64),
+                                   (1000, 256, 128)])
+def test_gemm_transposed_weight_matches_float64(M, N, K):
+    """dX = dY @ W with W in Linear layout [K_in_of_this_product = rows, N = cols]."""
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    X = torch.randn(M, K, generator=g)
+    Wt = torch.randn(K, N, generator=g) / K ** 0.5
+    Y, = ops.run_gemm([ops.Gemm(X=X.to(DEV), W=Wt.to(DEV), w_trans=True)], DEV)
+    torch.testing.assert_close(cpu(Y).double(), X.double() @ Wt.double(), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('M,N,K,K2', [(1, 1, 1, 0), (300, 128, 128, 0), (3341, 128, 128, 128), (77, 40, 24, 0),
+                                      (1025, 64, 64, 64), (257, 130, 36, 12), (5000, 128, 128, 0)])
+def test_gemm_tn_weight_gradient(M, N, K, K2):
+    from cwn_amd import _ffi
+    g = torch.Generator().manual_seed(M + N + K + K2)
+    dZ = torch.randn(M, N, generator=g)
+    X = torch.randn(M, K, generator=g)
+    X2 = torch.randn(M, K2, generator=g) if K2 else None
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    dZd, Xd, X2d, scd, shd = dZ.to(DEV), X.to(DEV), None if X2 is None else X2.to(DEV), sc.to(DEV), sh.to(DEV)
+    dW = torch.zeros(N, K + K2, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    _ffi.gemm_tn([_ffi.GemmTnDesc(dZ=dZd.data_ptr(), X=Xd.data_ptr(), X2=_ffi.ptr(X2d), in_scale=scd.data_ptr(),
+                                  in_shift=shd.data_ptr(), in_scale2=None, in_shift2=None, dW=dW.data_ptr(),
+                                  db=db.data_ptr(), M=M, lddz=N, ldx=K, ldx2=K2, lddw=K + K2, N=N, K=K, K2=K2,
+                                  in_relu=1)], DEV)
+    A = torch.relu(X.double() * sc.double() + sh.double())
+    if X2 is not None:
+        A = torch.cat([A, X2.double()], 1)
+    ref = dZ.double().t() @ A
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    torch.testing.assert_close(cpu(dW).double(), ref, rtol=1e-5, atol=tol)
+    torch.testing.assert_close(cpu(db).double(), dZ.double().sum(0), rtol=1e-5, atol=tol)
+
+
+@pytest.mark.parametrize('M,N', [(2, 4), (777, 128), (3341, 64), (100, 30), (5000, 256)])
+def test_batchnorm_relu_pieces_match_torch(M, N):
+    """statistics (GEMM epilogue) -> finalize -> act, and reduce -> apply, against
+    torch.nn.BatchNorm1d(train) + ReLU autograd; running statistics included."""
+    from cwn_amd import _ffi, ops
+    from cwn_amd.dense_train import _norm_desc
+    g = torch.Generator().manual_seed(M + N)
+    K = 32
+    X = torch.randn(M, K, generator=g)
+    lin = torch.nn.Linear(K, N)
+    bn = torch.nn.BatchNorm1d(N)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(N, K, generator=g) / K ** 0.5)
+        lin.bias.copy_(torch.randn(N, generator=g) * 3)          # large mean relative to the spread
+        bn.weight.copy_(torch.rand(N, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(N, generator=g))
+    ref_bn = torch.nn.BatchNorm1d(N)
+    ref_bn.load_state_dict(bn.state_dict())
+    Xr = X.clone().double()
+    lin64, bn64 = torch.nn.Linear(K, N).double(), ref_bn.double()
+    lin64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    z_ref = lin64(Xr).detach().requires_grad_()
+    h_ref = torch.relu(bn64(z_ref))
+    dH = torch.randn(M, N, generator=g)
+    h_ref.backward(dH.double())
+
+    stats = torch.zeros(2, N, dtype=torch.float64, device=DEV)
+    Z, = ops.run_gemm([ops.Gemm(X=X.to(DEV), W=lin.weight.detach().to(DEV), bias=lin.bias.detach().to(DEV),
+                                col_stats=stats)], DEV)
+    aff = torch.empty(4, N, device=DEV)
+    rm, rv = bn.running_mean.clone().to(DEV), bn.running_var.clone().to(DEV)
+    gam, bet = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
+    _ffi.bn_finalize([_ffi.BnDesc(col_sum=stats[0].data_ptr(), col_sumsq=stats[1].data_ptr(), gamma=gam.data_ptr(),
+                                  beta=bet.data_ptr(), running_mean=rm.data_ptr(), running_var=rv.data_ptr(),
+                                  scale=aff[0].data_ptr(), shift=aff[1].data_ptr(), mean=aff[2].data_ptr(),
+                                  rstd=aff[3].data_ptr(), M=M, N=N, eps=bn.eps, momentum=bn.momentum)], DEV)
+    H = torch.empty(M, N, device=DEV)
+    _ffi.norm_act([_norm_desc(Z, out=H, aff=aff)], DEV)
+    torch.testing.assert_close(cpu(H).double(), h_ref.detach(), rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(cpu(rm).double(), bn64.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(cpu(rv).double(), bn64.running_var, rtol=1e-5, atol=1e-6)
+    s12 = torch.zeros(2, N, device=DEV)
+    dHd = dH.to(DEV)
+    dZ = torch.empty(M, N, device=DEV)
+    _ffi.norm_bwd_reduce([_norm_desc(Z, dy=dHd, aff=aff, s12=s12)], DEV)
+    _ffi.norm_bwd_apply([_norm_desc(Z, dy=dHd, out=dZ, aff=aff, s12=s12)], DEV)
+    scale = float(z_ref.grad.abs().max())
+    torch.testing.assert_close(cpu(dZ).double(), z_ref.grad, rtol=1e-4, atol=2e-5 * max(scale, 1.0))
+    torch.testing.assert_close(cpu(s12[1]).double(), bn64.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(cpu(s12[0]).double(), bn64.bias.grad, rtol=1e-4, atol=1e-4)
+
+
+def _train_layer_pair(graph_norm, hidden, use_cob, seed=0):
+    """Two identical SparseCINConv layers in train mode: one takes the fused training path, the
+    other the torch modules (FUSED_DENSE_TRAINING off)."""
+    from cwn_amd import layers
+    kw = dict(passed_msg_up_nn=None, passed_msg_boundaries_nn=None, passed_update_up_nn=None,
+              passed_update_boundaries_nn=None, train_eps=True, max_dim=2, hidden=hidden,
+              act_module=torch.nn.ReLU, layer_dim=hidden, graph_norm=graph_norm, use_coboundaries=use_cob)
+    torch.manual_seed(seed)
+    a = layers.SparseCINConv(hidden, hidden, hidden, **kw).to(DEV).train()
+    b = layers.SparseCINConv(hidden, hidden, hidden, **kw).to(DEV).train()
+    b.load_state_dict(a.state_dict())
+    return a, b
+
+
+@pytest.mark.parametrize('norm,hidden,use_cob', [('bn', 128, True), ('bn', 64, False), ('id', 32, True)])
+def test_fused_training_layer_matches_torch_modules(norm, hidden, use_cob):
+    from cwn_amd import layers
+    from cwn_amd.synthetic import zinc_like_batch
+    gn = torch.nn.BatchNorm1d if norm == 'bn' else torch.nn.Identity
+    fused, plain = _train_layer_pair(gn, hidden, use_cob)
+    b = zinc_like_batch(6, seed=5, device=DEV)     # small: fewer chances of a pre-activation at the kink
+    state0 = {k: v.clone() for k, v in plain.state_dict().items()}
+
+    def run(conv, fused_on):
+        layers.FUSED_DENSE_TRAINING = fused_on
+        try:
+            xin = [x.clone().requires_grad_() for x in xs]
+            b.set_xs(xin)
+            params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+            out = conv(*params)
+            sum((o * w).sum() for o, w in zip(out, ws)).backward()
+        finally:
+            layers.FUSED_DENSE_TRAINING = True
+        return out, xin
+
+    # ReLU is not differentiable at 0: a pre-activation within rounding distance of 0 may land on
+    # either side in the two implementations and legitimately changes a gradient by O(1).  Pick
+    # inputs whose pre-activations (in the torch-module run) all stay clear of the kink.
+    near = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: near.append(float(inp[0].detach().abs().min())))
+             for m in plain.modules() if isinstance(m, torch.nn.ReLU)]
+    for seed in range(1, 40):
+        g = torch.Generator().manual_seed(seed)
+        xs = [torch.randn(b.cochains[d].num_cells, hidden, generator=g).to(DEV) for d in range(3)]
+        ws = [torch.randn(b.cochains[d].num_cells, hidden, generator=g).to(DEV) for d in range(3)]
+        near.clear()
+        plain.load_state_dict(state0)
+        plain.zero_grad(set_to_none=True)
+        out_p, xin_p = run(plain, False)
+        if min(near) > 6e-6:       # the two paths' pre-activations agree to ~3e-6
+            break
+    else:
+        pytest.skip('no kink-free input found')
+    for h in hooks:
+        h.remove()
+
+    called = []
+    from cwn_amd import dense_train as DT
+    orig = DT.dense_train
+    DT.dense_train = lambda *a, **k: (called.append(1), orig(*a, **k))[1]
+    try:
+        out_f, xin_f = run(fused, True)
+    finally:
+        DT.dense_train = orig
+    assert called, 'the fused training path was not taken'
+    for of, op in zip(out_f, out_p):
+        torch.testing.assert_close(of, op, rtol=1e-4, atol=2e-5)
+    for xf, xp in zip(xin_f, xin_p):
+        s = max(1.0, float(xp.grad.abs().max()))
+        torch.testing.assert_close(xf.grad, xp.grad, rtol=1e-4, atol=3e-5 * s)
+    pf, pp = dict(fused.named_parameters()), dict(plain.named_parameters())
+    for name, p in pp.items():
+        if p.grad is None:
+            assert pf[name].grad is None or float(pf[name].grad.abs().max()) == 0.0, name
+            continue
+        s = max(1.0, float(p.grad.abs().max()))
+        if name.endswith(('eps1', 'eps2')):
+            s = 40.0      # a scalar: the sum of ~1e5 products of O(1) terms that cancel
+        torch.testing.assert_close(pf[name].grad, p.grad, rtol=1e-4, atol=5e-5 * s, msg=lambda m, n=name: f'{n}: {m}')
+    bf, bp = dict(fused.named_buffers()), dict(plain.named_buffers())
+    for name, t in bp.items():
+        if t.dtype.is_floating_point:
+            torch.testing.assert_close(bf[name], t, rtol=1e-5, atol=1e-6, msg=lambda m, n=name: f'{n}: {m}')
+        else:
+            assert torch.equal(bf[name], t), name
