@@ -131,7 +131,7 @@ __device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, in
     }
 }
 
-template <bool FAST, bool PRO, int KP, int WN>
+template <bool FAST, bool PRO, int KP, int WN, bool WT>
 #ifndef CWN_GEMM_LB
 #define CWN_GEMM_LB 2
 #endif
@@ -163,7 +163,6 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
     const int64_t ldx = D.ldx, ldx2 = D.ldx2, ldw = D.ldw, ldy = D.ldy, M = D.M;
     const int N = D.N, K1 = D.K, K2 = D.K2, Ktot = D.K + D.K2;
     const Prologue pro{D.in_scale, D.in_shift, D.in_scale2, D.in_shift2, D.in_relu};
-    const bool w_trans = D.w_trans != 0;
     const int dbg = D.reserved;   // timing experiments (tools/ubench_gemm.py): 1 no MFMA, 2 no W staging, 4 no store
     constexpr int SLABS = KP / 16;
     using SX = Staged<BM, KP>;                 // a 32-row tile in flight: KP/32 x 16 B per thread
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
     int it = 0;
     // two X tiles in flight in registers (prefetch distance 2 when K <= 128; 1 for the K = 256 variant,
     // whose tiles are twice as large)
-    constexpr bool DEEP = KP <= 128 && CWN_GEMM_DEEP;
+    constexpr bool DEEP = KP <= 128 && CWN_GEMM_DEEP && !WT;   // (the WT variants have no registers to spare)
     SX sx, sx2;
     if (tile < tiles)
         stage_load<FAST, BM, KP, 0, SX::U>(sx, (int64_t)(tile / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
@@ -201,50 +200,73 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             constexpr int LPP = 32 * (HW / 4) / 64; // 16-B loads per lane per pass (= 8)
             float* priv = smem + wave * (32 * HW);
             __syncthreads();                 // nobody still reads the X buffers we are about to reuse
-#pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps) {
+            if constexpr (WT) {
+                // W is [Ktot, N] (the layer's own weight, read for dX = dY . W): the wave's 32
+                // output columns are 32 CONSECUTIVE floats of every W row.  Stage 32 k-rows per pass
+                // in their natural [k][n] layout (16-B loads and stores, rows padded to 36 floats)
+                // and lift the fragments with 4-B reads -- lanes j walk consecutive words, the lane
+                // groups g land 16 banks apart.  The fragments stay in registers for the whole
+                // block, so the narrow reads are paid once.
+                constexpr int HK = 32, RS = 36;
+                constexpr int WPASSES = KP / HK;
                 const int wrow0 = tile_n * BN + wn * (CT * 16);
-                if (!w_trans) {
-                    f32x4 wl[LPP];
 #pragma unroll
-                    for (int i = 0; i < LPP; ++i) {
-                        const int r = (lane >> 4) + 4 * i;
-                        const int k = ps * HW + 4 * (lane & 15);
-                        const int grow = wrow0 + r < N ? wrow0 + r : N - 1;
-                        if constexpr (FAST) {
-                            wl[i] = *reinterpret_cast<const f32x4*>(Wp + (int64_t)grow * ldw + (k < Ktot ? k : 0));
+                for (int ps = 0; ps < WPASSES; ++ps) {
+                    f32x4 wl[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int kr = (lane >> 3) + 8 * i, c4 = 4 * (lane & 7);
+                        const int k = ps * HK + kr;
+                        const int64_t row = (int64_t)(k < Ktot ? k : 0) * ldw;
+                        if (FAST && wrow0 + c4 + 3 < N) {
+                            wl[i] = *reinterpret_cast<const f32x4*>(Wp + row + wrow0 + c4);
                         } else {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) wl[i][t] = Wp[(int64_t)grow * ldw + (k + t < Ktot ? k + t : 0)];
+                            for (int t = 0; t < 4; ++t) wl[i][t] = Wp[row + (wrow0 + c4 + t < N ? wrow0 + c4 + t : N - 1)];
                         }
                     }
 #pragma unroll
-                    for (int i = 0; i < LPP; ++i) {
-                        const int r = (lane >> 4) + 4 * i, c = lane & 15;
-                        const int k = ps * HW + 4 * c;
+                    for (int i = 0; i < 4; ++i) {
+                        const int kr = (lane >> 3) + 8 * i, c4 = 4 * (lane & 7);
                         f32x4 v = wl[i];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = k + t < Ktot ? v[t] : 0.f;
-                        *reinterpret_cast<f32x4*>(priv + r * HW + ((c ^ (r & 15)) << 2)) = v;
+                        if (ps * HK + kr >= Ktot) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<f32x4*>(priv + kr * RS + c4) = v;
                     }
-                } else {
-                    // W is [Ktot, N]: the wave's 32 output columns are 32 CONSECUTIVE floats of a W
-                    // row, so lanes 0..31 / 32..63 read two 128-B row segments per instruction
-                    // (coalesced) and the transposition happens in the LDS store.
-                    constexpr int NL = 32 * HW / 64;   // 4-B loads per lane per pass (= 32)
-                    float wt[NL];
-                    const int r = lane & 31;
-                    const int gcol = wrow0 + r < N ? wrow0 + r : N - 1;
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int i = 0; i < NL; ++i) {
-                        const int k = ps * HW + 2 * i + (lane >> 5);
-                        wt[i] = Wp[(int64_t)(k < Ktot ? k : 0) * ldw + gcol];
-                    }
+                    for (int sl = 0; sl < HK / 16; ++sl)
 #pragma unroll
-                    for (int i = 0; i < NL; ++i) {
-                        const int kl = 2 * i + (lane >> 5), k = ps * HW + kl;
-                        priv[r * HW + (((kl >> 2) ^ (r & 15)) << 2) + (kl & 3)] = k < Ktot ? wt[i] : 0.f;
+                        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                wreg[ps * (HK / 16) + sl][ct][t] = priv[(16 * sl + 4 * g + t) * RS + ct * 16 + j];
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                f32x4 wl[LPP];
+                const int wrow0 = tile_n * BN + wn * (CT * 16);
+#pragma unroll
+                for (int i = 0; i < LPP; ++i) {
+                    const int r = (lane >> 4) + 4 * i;
+                    const int k = ps * HW + 4 * (lane & 15);
+                    const int grow = wrow0 + r < N ? wrow0 + r : N - 1;
+                    if constexpr (FAST) {
+                        wl[i] = *reinterpret_cast<const f32x4*>(Wp + (int64_t)grow * ldw + (k < Ktot ? k : 0));
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) wl[i][t] = Wp[(int64_t)grow * ldw + (k + t < Ktot ? k + t : 0)];
                     }
+                }
+#pragma unroll
+                for (int i = 0; i < LPP; ++i) {
+                    const int r = (lane >> 4) + 4 * i, c = lane & 15;
+                    const int k = ps * HW + 4 * c;
+                    f32x4 v = wl[i];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = k + t < Ktot ? v[t] : 0.f;
+                    *reinterpret_cast<f32x4*>(priv + r * HW + ((c ^ (r & 15)) << 2)) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -256,6 +278,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                             *reinterpret_cast<const f32x4*>(priv + r * HW + ((c ^ (r & 15)) << 2));
                     }
                 __builtin_amdgcn_wave_barrier();
+            }
             }
             __syncthreads();                 // private slices are free again before any X store
             cur_tn = tile_n;
@@ -365,7 +388,12 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                 }
             }
             if (D.col_sum != nullptr && n0 < N) {
-                // reduce over the 16 rows held by lanes j = 0..15 of this lane group, one atomic each
+                // reduce over the 16 rows held by lanes j = 0..15 of this lane group (both row
+                // tiles are already summed in registers), then ONE plain store per column into
+                // the slot of this wave's 32-row band: no atomics, no zero fill, deterministic.
+                // (fp64 atomics on 2 x N addresses from ~100 workgroups per descriptor serialised
+                // at L2 and cost 20 us of a 30 us launch.)
+                const int64_t slot = m_base / 32 + wm;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     double a = csum[r], b = csq[r];
@@ -374,9 +402,9 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                         a += __shfl_xor(a, o, 16);
                         b += __shfl_xor(b, o, 16);
                     }
-                    if (j == 0 && n0 + r < N) {
-                        atomicAdd(D.col_sum + n0 + r, a);
-                        atomicAdd(D.col_sumsq + n0 + r, b);
+                    if (j == 0 && n0 + r < N && slot < CWN_STAT_ROWS(M)) {
+                        D.col_sum[slot * N + n0 + r] = a;
+                        D.col_sumsq[slot * N + n0 + r] = b;
                     }
                 }
             }
@@ -495,38 +523,46 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         blocks += nb;
     }
     for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
+    // w_trans is a property of the launch (all descriptors or none), and excludes the prologue
+    const bool wt = descs[0].w_trans != 0;
     bool fast = true, pro = false;
     for (int i = 0; i < n; ++i) {
+        if ((descs[i].w_trans != 0) != wt) return CWN_ERR_BAD_ARG;
         fast = fast && B.vec[i] != 0;
         pro = pro || B.d[i].in_scale != nullptr || B.d[i].in_scale2 != nullptr || B.d[i].in_relu != 0;
     }
     using Kern = void (*)(GemmBatch);
     // shape index: 0 = 32x128 tile, K <= 128;  1 = 32x128, K <= 256;  2 = 64x64, K <= 64;
     //              3 = 64x64, K <= 128;        4 = 64x64, K <= 256
-    static const Kern kerns[2][2][5] = {
-        {{gemm_kernel<false, false, 128, 4>, gemm_kernel<false, false, 256, 4>, gemm_kernel<false, false, 64, 2>,
-          gemm_kernel<false, false, 128, 2>, gemm_kernel<false, false, 256, 2>},
-         {gemm_kernel<false, true, 128, 4>, gemm_kernel<false, true, 256, 4>, gemm_kernel<false, true, 64, 2>,
-          gemm_kernel<false, true, 128, 2>, gemm_kernel<false, true, 256, 2>}},
-        {{gemm_kernel<true, false, 128, 4>, gemm_kernel<true, false, 256, 4>, gemm_kernel<true, false, 64, 2>,
-          gemm_kernel<true, false, 128, 2>, gemm_kernel<true, false, 256, 2>},
-         {gemm_kernel<true, true, 128, 4>, gemm_kernel<true, true, 256, 4>, gemm_kernel<true, true, 64, 2>,
-          gemm_kernel<true, true, 128, 2>, gemm_kernel<true, true, 256, 2>}}};
+#define CWN_SHAPES(F, P, T)                                                                     \
+    {gemm_kernel<F, P, 128, 4, T>, gemm_kernel<F, P, 256, 4, T>, gemm_kernel<F, P, 64, 2, T>,  \
+     gemm_kernel<F, P, 128, 2, T>, gemm_kernel<F, P, 256, 2, T>}
+    static const Kern kerns[2][2][5] = {{CWN_SHAPES(false, false, false), CWN_SHAPES(false, true, false)},
+                                        {CWN_SHAPES(true, false, false), CWN_SHAPES(true, true, false)}};
+    // transposed-weight variants (the input-gradient GEMM): no prologue
+    static const Kern kerns_wt[2][5] = {CWN_SHAPES(false, false, true), CWN_SHAPES(true, false, true)};
+#undef CWN_SHAPES
     static const int kShapeLds[5] = {2 * 32 * 128 * 4, 2 * 32 * 256 * 4, 2 * 64 * 64 * 4, 2 * 64 * 128 * 4,
                                      2 * 64 * 256 * 4};
     static bool attr_set = false;
     if (!attr_set) {
-        for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b)
-                for (int c = 0; c < 5; ++c)
+        for (int c = 0; c < 5; ++c) {
+            for (int a = 0; a < 2; ++a) {
+                for (int b = 0; b < 2; ++b)
                     if (hipFuncSetAttribute((const void*)kerns[a][b][c],
                                             hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kShapeLds[c]) != hipSuccess)
                         return CWN_ERR_LAUNCH;
+                if (hipFuncSetAttribute((const void*)kerns_wt[a][c], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        kShapeLds[c]) != hipSuccess)
+                    return CWN_ERR_LAUNCH;
+            }
+        }
         attr_set = true;
     }
+    if (wt && pro) return CWN_ERR_BAD_ARG;
     const int shape = narrow ? (KP == 64 ? 2 : (KP == 128 ? 3 : 4)) : (KP == 128 ? 0 : 1);
-    const Kern k = kerns[fast ? 1 : 0][pro ? 1 : 0][shape];
+    const Kern k = wt ? kerns_wt[fast ? 1 : 0][shape] : kerns[fast ? 1 : 0][pro ? 1 : 0][shape];
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

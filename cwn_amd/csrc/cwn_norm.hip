@@ -2,7 +2,7 @@
 // backward pass (torch.nn.BatchNorm1d(train) + ReLU of update_up_nn / update_boundaries_nn /
 // combine_nn, mp/layers.py:303-325).
 //
-//   cwn_bn_finalize_f32       batch statistics (fp64 sums from the GEMM epilogue) -> per-column
+//   cwn_bn_finalize_f32       batch statistics (fp64 band sums from the GEMM epilogue) -> per-column
 //                             affine (scale, shift) + mean / rstd for backward + running statistics
 //   cwn_norm_act_f32          out = act(z * scale + shift)             (materialised last stage)
 //   cwn_norm_bwd_reduce_f32   s1 = sum dyh, s2 = sum dyh * xhat        (= d beta, d gamma)
@@ -45,16 +45,38 @@ __device__ __forceinline__ int find_desc(const int32_t* start, int n, int b) {
 __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(BnBatch B) {
     const cwn_bn_desc& D = B.d[blockIdx.x];
     const double invM = 1.0 / (double)D.M;
+    const int64_t bands = CWN_STAT_ROWS(D.M);
     for (int n = threadIdx.x; n < D.N; n += kThreads) {
-        const double mean = D.col_sum[n] * invM;
-        double var = D.col_sumsq[n] * invM - mean * mean;     // biased, as BatchNorm normalises
+        // the GEMM epilogue left one partial per 32-row band; consecutive threads read
+        // consecutive columns (coalesced), four bands in flight
+        double s = 0.0, sq = 0.0;
+        int64_t b = 0;
+        for (; b + 4 <= bands; b += 4) {
+            double t[4], u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                t[q] = D.col_sum[(b + q) * D.N + n];
+                u[q] = D.col_sumsq[(b + q) * D.N + n];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s += t[q];
+                sq += u[q];
+            }
+        }
+        for (; b < bands; ++b) {
+            s += D.col_sum[b * D.N + n];
+            sq += D.col_sumsq[b * D.N + n];
+        }
+        const double mean = s * invM;
+        double var = sq * invM - mean * mean;     // biased, as BatchNorm normalises
         var = var > 0.0 ? var : 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)D.eps));
         const float g = D.gamma != nullptr ? D.gamma[n] : 1.0f;
-        const float b = D.beta != nullptr ? D.beta[n] : 0.0f;
+        const float beta = D.beta != nullptr ? D.beta[n] : 0.0f;
         const float scale = g * rstd;
         D.scale[n] = scale;
-        D.shift[n] = b - (float)mean * scale;
+        D.shift[n] = beta - (float)mean * scale;
         D.mean[n] = (float)mean;
         D.rstd[n] = rstd;
         if (D.running_mean != nullptr) {

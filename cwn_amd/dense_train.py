@@ -112,13 +112,21 @@ class _DenseTrain(torch.autograd.Function):
         par = tensors[2 * nd:]
         P = {id(st): par[4 * k: 4 * k + 4] for k, st in enumerate(stages)}
         bns = [st for st in stages if st.is_bn]
-        # one zeroed fp64 buffer for all batch statistics, one fp32 buffer for all affines
+        # one fp64 buffer for all batch statistics (per-band partials written by the GEMM
+        # epilogue: nothing to zero), one fp32 buffer for all affines
+        rows_of = {}
+        for i in range(nd):
+            for st in plan.up[i] + plan.bd[i] + [plan.cb[i]]:
+                rows_of[id(st)] = ops.stat_rows(A0[i][0].size(0))
         widths = [st.lin.out_features for st in bns]
-        stats = torch.zeros(2 * sum(widths), dtype=torch.float64, device=dev)
+        stats = torch.empty(2 * sum(rows_of[id(st)] * w for st, w in zip(bns, widths)),
+                            dtype=torch.float64, device=dev)
         affs = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
-        stat_of, aff_of, o = {}, {}, 0
+        stat_of, aff_of, o, so = {}, {}, 0, 0
         for st, w in zip(bns, widths):
-            stat_of[id(st)] = stats[2 * o: 2 * o + 2 * w].view(2, w)
+            r = rows_of[id(st)]
+            stat_of[id(st)] = stats[so: so + 2 * r * w].view(2, r, w)
+            so += 2 * r * w
             aff_of[id(st)] = affs[4 * o: 4 * o + 4 * w].view(4, w)
             o += w
 
@@ -133,7 +141,7 @@ class _DenseTrain(torch.autograd.Function):
                     col_sum=s[0].data_ptr(), col_sumsq=s[1].data_ptr(), gamma=_ffi.ptr(gamma),
                     beta=_ffi.ptr(beta), running_mean=n.running_mean.data_ptr(),
                     running_var=n.running_var.data_ptr(), scale=a[0].data_ptr(), shift=a[1].data_ptr(),
-                    mean=a[2].data_ptr(), rstd=a[3].data_ptr(), M=M, N=s.size(1), eps=float(n.eps),
+                    mean=a[2].data_ptr(), rstd=a[3].data_ptr(), M=M, N=s.size(2), eps=float(n.eps),
                     momentum=float(n.momentum)))
             if descs:
                 _ffi.bn_finalize(descs, dev)

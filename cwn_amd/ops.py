@@ -311,7 +311,7 @@ class Gemm:
     in_scale: Optional[Tensor] = None    # producer's BatchNorm apply (+ReLU) on the fly; no grad
     in_shift: Optional[Tensor] = None
     in_relu: int = 0                     # bit 0: ReLU on X after the affine, bit 1: on X2
-    col_stats: Optional[Tensor] = None   # [2, N] fp32, zeroed by the caller: sum / sum of squares
+    col_stats: Optional[Tensor] = None   # [2, stat_rows(M), N] fp64 out: per-32-row-band sum / sum of squares
     debug: int = 0                       # timing experiments only (tools/ubench_gemm.py)
     in_scale2: Optional[Tensor] = None   # the same prologue for X2
     in_shift2: Optional[Tensor] = None
@@ -340,6 +340,11 @@ class Gemm:
             ldw=W.stride(0) if W.size(0) > 1 else W.size(1), ldy=Y.stride(0) if Y.size(0) > 1 else Y.size(1),
             N=W.size(1 if self.w_trans else 0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu),
             w_trans=int(self.w_trans), reserved=int(self.debug))
+
+
+def stat_rows(M: int) -> int:
+    """CWN_STAT_ROWS: 32-row bands the statistics epilogue of cwn_gemm_f32 writes partials for."""
+    return (int(M) + 31) // 32
 
 
 GEMM_MAX_K = 256   # K + K2 the MFMA kernel supports (whole-K weight tile resident in LDS)

@@ -180,10 +180,15 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  *   prologue (optional): x <- x * in_scale[k] + in_shift[k] for X (in_scale2 / in_shift2 for X2),
  *                        then ReLU on X if in_relu & 1, on X2 if in_relu & 2 (normalisation +
  *                        activation of the producing layer applied on the fly);
- *   epilogue: + bias[n]; per-column sum / sum of squares of that value accumulated with fp64
- *             atomics into col_sum / col_sumsq (BatchNorm batch statistics; caller zeroes them);
+ *   epilogue: + bias[n]; per-column sum / sum of squares of that value over every 32-row band
+ *             of Y, written (fp64, plain stores: no atomics, nothing to zero, deterministic) to
+ *             col_sum / col_sumsq [CWN_STAT_ROWS(M), N] -- BatchNorm batch statistics, summed over
+ *             the bands by cwn_bn_finalize_f32;
  *             then * out_scale[n] + out_shift[n] (BatchNorm eval), then ReLU if relu.
  * ------------------------------------------------------------------------------------------ */
+/* bands of 32 rows the statistics epilogue writes one partial sum for */
+#define CWN_STAT_ROWS(M) (((M) + 31) / 32)
+
 typedef struct cwn_gemm_desc {
     const float* X;
     const float* X2;        /* or NULL */
@@ -195,8 +200,8 @@ typedef struct cwn_gemm_desc {
     const float* in_shift2; /* [K2] or NULL */
     const float* out_scale; /* [N] or NULL */
     const float* out_shift; /* [N] or NULL */
-    double* col_sum;        /* [N] or NULL (fp64: exact enough for var = E[y^2] - mean^2) */
-    double* col_sumsq;      /* [N] or NULL */
+    double* col_sum;        /* [CWN_STAT_ROWS(M), N] or NULL (fp64: var = E[y^2] - mean^2 is safe) */
+    double* col_sumsq;      /* [CWN_STAT_ROWS(M), N] or NULL */
     float* Y;
     int64_t M;
     int64_t ldx, ldx2, ldw, ldy;
@@ -220,8 +225,8 @@ int cwn_gemm_f32(const cwn_gemm_desc* descs_host, int n, cwn_stream_t stream);
 #define CWN_MAX_NORM_DESCS 16
 
 typedef struct cwn_bn_desc {
-    const double* col_sum;    /* [N] sum_m y[m, n]      (cwn_gemm_f32 epilogue) */
-    const double* col_sumsq;  /* [N] sum_m y[m, n]^2 */
+    const double* col_sum;    /* [CWN_STAT_ROWS(M), N] band sums of y        (cwn_gemm_f32 epilogue) */
+    const double* col_sumsq;  /* [CWN_STAT_ROWS(M), N] band sums of y^2 */
     const float* gamma;       /* [N] or NULL (= 1) */
     const float* beta;        /* [N] or NULL (= 0) */
     float* running_mean;      /* [N] or NULL: <- (1 - momentum) * running + momentum * mean */
