@@ -5,7 +5,7 @@
 // (the backward of torch.nn.Linear inside msg_up_nn / update_up_nn / update_boundaries_nn /
 // combine_nn, mp/layers.py:290-325).  The reduction runs over the M cells of a dimension
 // (thousands) while the output is only hidden x hidden, the opposite shape of cwn_gemm_f32:
-//   * a workgroup owns a 64 x 64 tile of dW and a band of 256 rows of M; its four waves hold
+//   * a workgroup owns a 64 x 64 tile of dW and a band of 128 rows of M; its four waves hold
 //     32 x 32 each (2 x 2 v_mfma_f32_16x16x4_f32 tiles, 16 accumulator VGPRs);
 //   * both operands are read ROW-CONTIGUOUSLY from global memory ([m][n] and [m][k] tiles of 64
 //     rows, 16-B loads, next chunk in flight during the MFMAs), staged in LDS with an 80-float row
@@ -13,7 +13,7 @@
 //     consecutive words and the four lane groups g land 16 banks apart -- conflict-free without a
 //     transposition, because the reduction index m is the ROW of both tiles;
 //   * the bands are combined with fp32 atomics into dW (the caller's zeroed .grad buffer); with M
-//     ~3 k rows that is ~14 adds per element;
+//     ~3 k rows that is ~27 adds per element;
 //   * the normalisation + ReLU of the producing layer is applied to X on the way into LDS (the
 //     activation itself is never materialised in the forward pass);
 //   * up to CWN_MAX_DESCS weight gradients per launch.
@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
 constexpr int kTile = 64;        // rows of dW (n) and columns of dW (k) per workgroup
 constexpr int kChunk = 64;       // rows of M per LDS stage
-constexpr int kBandRows = 256;   // rows of M per workgroup
+constexpr int kBandRows = 128;   // rows of M per workgroup
 constexpr int kLd = 80;          // LDS row stride in floats
 constexpr int kU = kChunk * (kTile / 4) / kThreads;   // 16-B loads per thread per tile (= 4)
 

@@ -42,49 +42,59 @@ __device__ __forceinline__ int find_desc(const int32_t* start, int n, int b) {
     return d;
 }
 
+// grid (column chunk of 64, descriptor).  The GEMM epilogue left one fp64 partial per 32-row band
+// and column; lanes read consecutive columns (coalesced), the four waves take every fourth band
+// with eight loads in flight each (a dependent round trip is ~1 us, and one thread walking 105
+// bands four at a time made this a 12-us kernel), and the four partials meet in LDS.
 __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(BnBatch B) {
-    const cwn_bn_desc& D = B.d[blockIdx.x];
-    const double invM = 1.0 / (double)D.M;
+    __shared__ double part[2][4][64];
+    const cwn_bn_desc& D = B.d[blockIdx.y];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
     const int64_t bands = CWN_STAT_ROWS(D.M);
-    for (int n = threadIdx.x; n < D.N; n += kThreads) {
-        // the GEMM epilogue left one partial per 32-row band; consecutive threads read
-        // consecutive columns (coalesced), four bands in flight
-        double s = 0.0, sq = 0.0;
-        int64_t b = 0;
-        for (; b + 4 <= bands; b += 4) {
-            double t[4], u[4];
+    const bool ok = n < D.N;
+    const int nc = ok ? n : D.N - 1;
+    double s = 0.0, sq = 0.0;
+    for (int64_t b0 = slice; b0 < bands; b0 += 4 * 8) {
+        double t[8], u[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                t[q] = D.col_sum[(b + q) * D.N + n];
-                u[q] = D.col_sumsq[(b + q) * D.N + n];
-            }
+        for (int q = 0; q < 8; ++q) {
+            const int64_t b = b0 + 4 * q;
+            const int64_t bc = b < bands ? b : bands - 1;
+            t[q] = D.col_sum[bc * D.N + nc];
+            u[q] = D.col_sumsq[bc * D.N + nc];
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
+            if (b0 + 4 * q < bands) {
                 s += t[q];
                 sq += u[q];
             }
         }
-        for (; b < bands; ++b) {
-            s += D.col_sum[b * D.N + n];
-            sq += D.col_sumsq[b * D.N + n];
-        }
-        const double mean = s * invM;
-        double var = sq * invM - mean * mean;     // biased, as BatchNorm normalises
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)D.eps));
-        const float g = D.gamma != nullptr ? D.gamma[n] : 1.0f;
-        const float beta = D.beta != nullptr ? D.beta[n] : 0.0f;
-        const float scale = g * rstd;
-        D.scale[n] = scale;
-        D.shift[n] = beta - (float)mean * scale;
-        D.mean[n] = (float)mean;
-        D.rstd[n] = rstd;
-        if (D.running_mean != nullptr) {
-            const float mom = D.momentum;
-            const double unbiased = D.M > 1 ? var * ((double)D.M / (double)(D.M - 1)) : var;
-            D.running_mean[n] = (1.0f - mom) * D.running_mean[n] + mom * (float)mean;
-            D.running_var[n] = (1.0f - mom) * D.running_var[n] + mom * (float)unbiased;
-        }
+    }
+    part[0][slice][threadIdx.x & 63] = s;
+    part[1][slice][threadIdx.x & 63] = sq;
+    __syncthreads();
+    if (slice != 0 || !ok) return;
+    s = part[0][0][threadIdx.x] + part[0][1][threadIdx.x] + part[0][2][threadIdx.x] + part[0][3][threadIdx.x];
+    sq = part[1][0][threadIdx.x] + part[1][1][threadIdx.x] + part[1][2][threadIdx.x] + part[1][3][threadIdx.x];
+    const double invM = 1.0 / (double)D.M;
+    const double mean = s * invM;
+    double var = sq * invM - mean * mean;     // biased, as BatchNorm normalises
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)D.eps));
+    const float g = D.gamma != nullptr ? D.gamma[n] : 1.0f;
+    const float beta = D.beta != nullptr ? D.beta[n] : 0.0f;
+    const float scale = g * rstd;
+    D.scale[n] = scale;
+    D.shift[n] = beta - (float)mean * scale;
+    D.mean[n] = (float)mean;
+    D.rstd[n] = rstd;
+    if (D.running_mean != nullptr) {
+        const float mom = D.momentum;
+        const double unbiased = D.M > 1 ? var * ((double)D.M / (double)(D.M - 1)) : var;
+        D.running_mean[n] = (1.0f - mom) * D.running_mean[n] + mom * (float)mean;
+        D.running_var[n] = (1.0f - mom) * D.running_var[n] + mom * (float)unbiased;
     }
 }
 
@@ -273,7 +283,9 @@ extern "C" int cwn_bn_finalize_f32(const cwn_bn_desc* descs, int n, cwn_stream_t
         if ((D.running_mean == nullptr) != (D.running_var == nullptr)) return CWN_ERR_BAD_ARG;
         B.d[i] = D;
     }
-    bn_finalize_kernel<<<dim3(n), dim3(kThreads), 0, (hipStream_t)stream_>>>(B);
+    int nmax = 0;
+    for (int i = 0; i < n; ++i) nmax = descs[i].N > nmax ? descs[i].N : nmax;
+    bn_finalize_kernel<<<dim3((nmax + 63) / 64, n), dim3(kThreads), 0, (hipStream_t)stream_>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 

@@ -371,7 +371,7 @@ def run_gemm(gemms: Sequence[Gemm], device) -> List[Tensor]:
 
 class _GemmMany(torch.autograd.Function):
     """Grouped GEMM forward on the MFMA kernel; tensor inputs flattened (X, X2, W, bias) per GEMM.
-    Backward uses library GEMMs (plain matmuls: rocBLAS) -- dX = g W, dW = g^T [X|X2], db = sum g."""
+    Backward: dX = g W, dW = g^T [X|X2], db = sum g on the same kernels (see backward)."""
 
     @staticmethod
     def forward(ctx, gemms: Tuple[Gemm, ...], device, *tensors):
@@ -382,10 +382,15 @@ class _GemmMany(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        """Grouped launches again: every dX (and dX2) of the group is one transposed-weight
+        cwn_gemm_f32, every dW / db one cwn_gemm_tn_f32 (accumulating into one zeroed buffer)."""
         n = len(ctx.gemms)
         saved = ctx.saved_tensors
         tensors, outs = saved[:4 * n], saved[4 * n:]
         grads: List[Optional[Tensor]] = [None] * (4 * n)
+        ld = lambda t: t.stride(0) if t.size(0) > 1 else t.size(1)
+        live = []
+        nn_specs, nn_slot, tn_jobs, total = [], [], [], 0
         for k, gm in enumerate(ctx.gemms):
             g = gs[k]
             if g is None:
@@ -396,15 +401,44 @@ class _GemmMany(torch.autograd.Function):
                 g = g * (outs[k] > 0)
             if gm.out_scale is not None:
                 g = g * gm.out_scale
+            g = _rowmajor(g, 'grad')
+            live.append(g)
             K = X.size(1)
             if nX:
-                grads[4 * k] = g @ W[:, :K]
+                nn_specs.append(Gemm(X=g, W=W[:, :K], w_trans=True))
+                nn_slot.append(4 * k)
             if nX2 and X2 is not None:
-                grads[4 * k + 1] = g @ W[:, K:]
-            if nW:
-                grads[4 * k + 2] = g.t() @ (X if X2 is None else torch.cat([X, X2], dim=1))
-            if nb and bias is not None:
-                grads[4 * k + 3] = g.sum(0)
+                nn_specs.append(Gemm(X=g, W=W[:, K:], w_trans=True))
+                nn_slot.append(4 * k + 1)
+            want_b = nb and bias is not None
+            if nW or want_b:
+                tn_jobs.append((k, g, X, X2, W, nW, want_b, total))
+                total += W.numel() + (W.size(0) if want_b else 0)
+        dev = live[0].device if live else None
+        if nn_specs:
+            for slot, y in zip(nn_slot, run_gemm(nn_specs, dev)):
+                grads[slot] = y
+        if tn_jobs:
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            descs = []
+            for k, g, X, X2, W, nW, want_b, off in tn_jobs:
+                Xc = _rowmajor(X, 'X')
+                X2c = None if X2 is None else _rowmajor(X2, 'X2')
+                live += [Xc, X2c]
+                dW = flat[off: off + W.numel()].view(W.size(0), W.size(1))
+                db = flat[off + W.numel(): off + W.numel() + W.size(0)] if want_b else None
+                if nW:
+                    grads[4 * k + 2] = dW
+                if want_b:
+                    grads[4 * k + 3] = db
+                if g.size(0):
+                    descs.append(_ffi.GemmTnDesc(
+                        dZ=g.data_ptr(), X=Xc.data_ptr(), X2=_ffi.ptr(X2c), in_scale=None, in_shift=None,
+                        in_scale2=None, in_shift2=None, dW=dW.data_ptr(), db=_ffi.ptr(db), M=g.size(0),
+                        lddz=ld(g), ldx=ld(Xc), ldx2=0 if X2c is None else ld(X2c), lddw=W.size(1),
+                        N=W.size(0), K=Xc.size(1), K2=0 if X2c is None else X2c.size(1), in_relu=0))
+            if descs:
+                _ffi.gemm_tn(descs, dev)
         return (None, None) + tuple(grads)
 
 

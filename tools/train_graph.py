@@ -15,7 +15,7 @@ torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 model = EmbedSparseCIN(28, 4, 1, 4, 128, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=os.environ.get('CWN_FUSED_ADAM', '1') == '1')
 NB = 4
 batches = [zinc_like_batch(B, seed=i, device=dev) for i in range(NB)]
 types = [(b.cochains[0].x.clone(), b.cochains[1].x.clone()) for b in batches]
