@@ -448,6 +448,28 @@ def main():
                 torch.set_num_threads(max_threads)
         except Exception as e:   # the baseline leg must never take the bench down
             print(f'[bench] cpu full-forward baseline failed: {type(e).__name__}: {e}', file=sys.stderr)
+        # ... and the oracle's forward (training-mode BatchNorm) + backward of the same model
+        cpu_train = None
+        try:
+            st_g = {k: (v.clone().requires_grad_() if v.is_floating_point() and 'running' not in k
+                        else v.clone()) for k, v in state.items()}
+
+            def cpu_train_step():
+                for v in st_g.values():
+                    if v.requires_grad:
+                        v.grad = None
+                out_, _ = O.sparse_cin_model_forward(st_g, ocx_full, L, training=True, **okw)
+                out_.abs().mean().backward()
+            torch.set_num_threads(threads)
+            cpu_train_step()
+            k, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
+                cpu_train_step()
+                k += 1
+            cpu_train = stats[0]['cells'] * L * k / (time.perf_counter() - t0)
+            torch.set_num_threads(max_threads)
+        except Exception as e:
+            print(f'[bench] cpu train-step baseline failed: {type(e).__name__}: {e}', file=sys.stderr)
         cpu_value = stats[0]['cells'] * L * n / el
         cpu_baseline = {'value': round(cpu_value, 1), 'unit': 'cells/s', 'cores': threads,
                         'kind': 'port',
@@ -456,7 +478,8 @@ def main():
                                   f'CPU, {threads} threads (fastest of {sorted(trials)}; passes/s per thread count: '
                                   f'{ {k: round(v, 1) for k, v in trials.items()} }) of {os.cpu_count()} logical cores',
                         'gpu_over_cpu': round(value / cpu_value, 1),
-                        'full_forward_cells_per_s': None if cpu_full is None else round(cpu_full, 1)}
+                        'full_forward_cells_per_s': None if cpu_full is None else round(cpu_full, 1),
+                        'train_fwd_bwd_cells_per_s': None if cpu_train is None else round(cpu_train, 1)}
 
     # secondary: independent batches overlapped on the GPU (serving-style): S streams, each replaying
     # the step graph of its own batch; same kernels, same per-step work, K steps in total
@@ -502,6 +525,55 @@ def main():
                           '(independent batches); the headline value is the sequential single-stream rate'}
         except Exception as e:
             print(f'[bench] concurrent-streams leg failed: {type(e).__name__}: {e}', file=sys.stderr)
+            torch.cuda.synchronize()
+
+    # secondary: the whole optimisation step (plans, forward, L1 loss, backward, fused Adam; for
+    # N > 1 plus the ONE gradient all-reduce over RCCL), graph-captured -- SURVEY.md 8(d)/(e)
+    train = None
+    if not args.only_primary:
+        try:
+            import copy
+            from cwn_amd.train import TrainStep
+            tmodel = copy.deepcopy(model).train()
+            tb = [ComplexBatch.from_complex_list(gen(5000 + 1000 * rank + i), max_dim=2).to(dev)
+                  for i in range(min(2, args.num_batches))]
+            for b_ in tb:                       # targets of the prediction's shape where the
+                if b_.y is None or WL != 'zinc':    # synthetic generator has none
+                    with torch.no_grad():
+                        cs_ = [b_.cochains[d] for d in range(b_.dimension + 1)]
+                        xs_keep = [c._x for c in cs_]
+                        ref_pred = tmodel(b_)
+                        for c, x_ in zip(cs_, xs_keep):
+                            c._x = x_
+                    b_.y = torch.zeros_like(ref_pred)
+            ts = TrainStep(tmodel, tb, task_type='regression', use_graph=use_graph)
+            tsteps = max(args.steps // 4, 10)
+            for i in range(len(tb) + 2):
+                ts.step(i % len(tb))
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(tsteps):
+                ts.step(i % len(tb))
+            barrier()
+            dtt = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dtt], device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtt = float(t.item())
+            tcells = torch.tensor([sum(batch_stats(tb[i % len(tb)])['cells'] for i in range(tsteps)) * L],
+                                  device=dev, dtype=torch.float64)
+            if dist is not None:
+                dist.all_reduce(tcells)
+            train = {'ms_per_step': round(dtt / tsteps * 1e3, 4),
+                     'cells_per_s': round(float(tcells.item()) / dtt, 1), 'steps': tsteps,
+                     'params': int(ts.bucket.flat.numel()),
+                     'scope': 'adjacency plans (forward + transposed), forward, L1 loss, backward, fused Adam'
+                              + (f', one {ts.bucket.flat.numel() * 4 / 1e6:.1f} MB RCCL all-reduce of the flat '
+                                 'gradient bucket' if world > 1 else '')
+                              + ('; hipGraph replay' if use_graph else '; eager')}
+            del ts, tmodel
+        except Exception as e:
+            print(f'[bench] train-step leg failed: {type(e).__name__}: {e}', file=sys.stderr)
             torch.cuda.synchronize()
 
     # secondary: building the batch itself -- device-side collate from the HBM-resident packed
@@ -562,7 +634,7 @@ def main():
                           'full_forward_ms': round(dt_full / full_steps * 1e3, 5),
                           'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '
                                    'MLPs + BatchNorm(eval), readout, head',
-                          'collate': collate, 'concurrent_streams': concurrent},
+                          'collate': collate, 'concurrent_streams': concurrent, 'train_step': train},
         }
         print(json.dumps(out))
     if dist is not None:

@@ -217,19 +217,26 @@ class _DenseTrain(torch.autograd.Function):
         P = {id(st): par[4 * k: 4 * k + 4] for k, st in enumerate(stages)}
         aff_of = ctx.aff_of
         dev = Z3[0].device
-        # one zeroed buffer: gradients of every parameter (accumulated by atomics) + s1/s2 of the
-        # identity-normalised stages' absent BatchNorms are simply not allocated
-        sizes = []
+        # gradient targets.  Weights / biases: the parameter's own .grad when it is allocated
+        # (ops._grad_target: a FlatGradBucket or zero_grad(set_to_none=False)) -- the TN kernel adds
+        # into it and autograd gets None -- else a slice of one zeroed scratch buffer.  The
+        # BatchNorm sums s1 / s2 always go to scratch (the apply kernel needs THIS pass's sums) and
+        # are added to gamma.grad / beta.grad with one multi-tensor add at the end.
+        sizes, targets = [], []
         for st in stages:
             W, b, gamma, beta = P[id(st)]
-            sizes.append((W.numel(), 0 if b is None else b.numel(), 2 * W.size(0) if st.is_bn else 0))
+            tw, tb = ops._grad_target(st.lin.weight), ops._grad_target(st.lin.bias)
+            targets.append((tw, tb))
+            sizes.append((0 if tw is not None else W.numel(),
+                          0 if (b is None or tb is not None) else b.numel(),
+                          2 * W.size(0) if st.is_bn else 0))
         flat = torch.zeros(sum(a + b + c for a, b, c in sizes), dtype=torch.float32, device=dev)
         G, q = {}, 0
-        for st, (nw, nb, ns) in zip(stages, sizes):
-            W = P[id(st)][0]
-            dW = flat[q: q + nw].view_as(W)
+        for st, (nw, nb, ns), (tw, tb) in zip(stages, sizes, targets):
+            W, b = P[id(st)][0], P[id(st)][1]
+            dW = flat[q: q + nw].view_as(W) if tw is None else tw
             q += nw
-            db = flat[q: q + nb] if nb else None
+            db = (flat[q: q + nb] if nb else None) if tb is None else tb
             q += nb
             s12 = flat[q: q + ns].view(2, -1) if ns else None
             q += ns
@@ -279,7 +286,7 @@ class _DenseTrain(torch.autograd.Function):
                     dZ=dZ3[i].data_ptr(), X=Xu.data_ptr(), X2=Xb.data_ptr(), in_scale=_ffi.ptr(sc),
                     in_shift=_ffi.ptr(sh), in_scale2=_ffi.ptr(sc2), in_shift2=_ffi.ptr(sh2),
                     dW=dW.data_ptr(), db=_ffi.ptr(db), M=dZ3[i].size(0), lddz=ld(dZ3[i]), ldx=ld(Xu),
-                    ldx2=ld(Xb), lddw=W.size(1), N=W.size(0), K=Xu.size(1), K2=Xb.size(1), in_relu=3))
+                    ldx2=ld(Xb), lddw=dW.stride(0), N=W.size(0), K=Xu.size(1), K2=Xb.size(1), in_relu=3))
             nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
         if tn:
             _ffi.gemm_tn(tn, dev)
@@ -310,7 +317,7 @@ class _DenseTrain(torch.autograd.Function):
                             dZ=dz.data_ptr(), X=X.data_ptr(), X2=None, in_scale=_ffi.ptr(sc),
                             in_shift=_ffi.ptr(sh), in_scale2=None, in_shift2=None, dW=dW.data_ptr(),
                             db=_ffi.ptr(db), M=dz.size(0), lddz=ld(dz), ldx=ld(X), ldx2=0,
-                            lddw=W.size(1), N=W.size(0), K=X.size(1), K2=0, in_relu=1 if s > 0 else 0))
+                            lddw=dW.stride(0), N=W.size(0), K=X.size(1), K2=0, in_relu=1 if s > 0 else 0))
                     nn.append(ops.Gemm(X=dz, W=W, w_trans=True))
             if tn:
                 _ffi.gemm_tn(tn, dev)
@@ -323,12 +330,29 @@ class _DenseTrain(torch.autograd.Function):
         grads: List[Optional[Tensor]] = [None]
         for i in range(nd):
             grads += [dy[i][0], dy[i][1]]
-        for st in stages:
+        acc_dst, acc_src = [], []
+        for st, (tw, tb) in zip(stages, targets):
             dW, db, s12 = G[id(st)]
             W, b, gamma, beta = P[id(st)]
-            grads += [dW, db if b is not None else None,
-                      s12[1] if (st.is_bn and gamma is not None) else None,
-                      s12[0] if (st.is_bn and beta is not None) else None]
+            gg = gb = None
+            if st.is_bn:
+                tg, tbeta = ops._grad_target(st.norm.weight), ops._grad_target(st.norm.bias)
+                if gamma is not None:
+                    if tg is None:
+                        gg = s12[1]
+                    else:
+                        acc_dst.append(tg)
+                        acc_src.append(s12[1])
+                if beta is not None:
+                    if tbeta is None:
+                        gb = s12[0]
+                    else:
+                        acc_dst.append(tbeta)
+                        acc_src.append(s12[0])
+            grads += [dW if tw is None else None,
+                      (db if tb is None else None) if b is not None else None, gg, gb]
+        if acc_dst:
+            torch._foreach_add_(acc_dst, acc_src)
         return tuple(grads)
 
 

@@ -317,8 +317,9 @@ class SparseCINCochainConv(CochainMessagePassing):
         attr_src, _ = _attr_operand(up_attr)
         if lin.in_features != F + attr_src.size(1) or max(F, attr_src.size(1)) > ops.GEMM_MAX_K:
             return []
-        return [ops.Gemm(X=x, W=lin.weight[:, :F], bias=lin.bias),
-                ops.Gemm(X=attr_src, W=lin.weight[:, F:])]
+        # (column ranges of the one weight: autograd sees the Parameter itself, not two slices)
+        return [ops.Gemm(X=x, W=lin.weight, w_col0=0, bias=lin.bias),
+                ops.Gemm(X=attr_src, W=lin.weight, w_col0=F)]
 
     def _up_stream(self, adj: Adjacency, x: Tensor, up_attr, self_x=None, eps=None,
                    ys: Optional[List[Tensor]] = None) -> Optional[ops.Stream]:

@@ -317,19 +317,24 @@ class Gemm:
     in_shift2: Optional[Tensor] = None
     w_trans: bool = False                # W is [K (+K2), N]: Y = [X | X2] @ W  (dX = dY @ W of a Linear)
     out: Optional[Tensor] = None         # preallocated Y (may be a column slice of a wider matrix)
+    w_col0: Optional[int] = None         # use columns [w_col0, w_col0 + K + K2) of W (not with w_trans):
+                                         # lets autograd see the whole Parameter instead of a slice
 
     def desc(self, Y: Tensor) -> _ffi.GemmDesc:
         X, W, X2 = self.X, self.W, self.X2
         K = X.size(1)
         K2 = X2.size(1) if X2 is not None else 0
-        if W.size(0 if self.w_trans else 1) != K + K2:
+        if self.w_col0 is not None:
+            if self.w_trans or W.size(1) < self.w_col0 + K + K2:
+                raise ValueError('w_col0 selects columns of an untransposed weight')
+        elif W.size(0 if self.w_trans else 1) != K + K2:
             raise ValueError(f'weight has {W.size(0 if self.w_trans else 1)} input columns, '
                              f'operands have {K + K2}')
         if X2 is not None and X2.size(0) != X.size(0):
             raise ValueError('X and X2 must have the same number of rows')
         cs = self.col_stats
         return _ffi.GemmDesc(
-            X=X.data_ptr(), X2=_ffi.ptr(X2), W=W.data_ptr(), bias=_ffi.ptr(self.bias),
+            X=X.data_ptr(), X2=_ffi.ptr(X2), W=W.data_ptr() + 4 * (self.w_col0 or 0), bias=_ffi.ptr(self.bias),
             in_scale=_ffi.ptr(self.in_scale), in_shift=_ffi.ptr(self.in_shift),
             in_scale2=_ffi.ptr(self.in_scale2), in_shift2=_ffi.ptr(self.in_shift2),
             out_scale=_ffi.ptr(self.out_scale), out_shift=_ffi.ptr(self.out_shift),
@@ -369,6 +374,26 @@ def run_gemm(gemms: Sequence[Gemm], device) -> List[Tensor]:
     return outs
 
 
+ACCUMULATE_INTO_GRAD = True
+
+
+def _grad_target(p: Optional[Tensor]) -> Optional[Tensor]:
+    """The tensor a gradient kernel may accumulate into directly: the parameter's existing `.grad`
+    (leaf tensors only; fp32, row-major, same shape), or None.  With a target the backward
+    returns None to autograd for that input: `p.grad += dW` has already happened, without the
+    per-parameter add kernel autograd would launch (265 of them per step for the ZINC model).
+    Only when gradients are being accumulated by a plain .backward(): torch.autograd.grad() callers
+    should switch ACCUMULATE_INTO_GRAD off."""
+    if not ACCUMULATE_INTO_GRAD or p is None or not p.is_leaf or not p.requires_grad:
+        return None
+    g = p.grad
+    if (g is None or g.dtype != torch.float32 or g.shape != p.shape or g.device != p.device
+            or (g.dim() == 2 and (g.stride(1) != 1 or g.stride(0) < g.size(1)))
+            or (g.dim() == 1 and g.stride(0) != 1)):
+        return None
+    return g
+
+
 class _GemmMany(torch.autograd.Function):
     """Grouped GEMM forward on the MFMA kernel; tensor inputs flattened (X, X2, W, bias) per GEMM.
     Backward: dX = g W, dW = g^T [X|X2], db = sum g on the same kernels (see backward)."""
@@ -404,38 +429,58 @@ class _GemmMany(torch.autograd.Function):
             g = _rowmajor(g, 'grad')
             live.append(g)
             K = X.size(1)
+            c0 = gm.w_col0 or 0
             if nX:
-                nn_specs.append(Gemm(X=g, W=W[:, :K], w_trans=True))
+                nn_specs.append(Gemm(X=g, W=W[:, c0:c0 + K], w_trans=True))
                 nn_slot.append(4 * k)
             if nX2 and X2 is not None:
-                nn_specs.append(Gemm(X=g, W=W[:, K:], w_trans=True))
+                nn_specs.append(Gemm(X=g, W=W[:, c0 + K:c0 + K + X2.size(1)], w_trans=True))
                 nn_slot.append(4 * k + 1)
             want_b = nb and bias is not None
             if nW or want_b:
-                tn_jobs.append((k, g, X, X2, W, nW, want_b, total))
-                total += W.numel() + (W.size(0) if want_b else 0)
+                tn_jobs.append((k, g, X, X2, W, bias, nW, want_b, c0))
         dev = live[0].device if live else None
         if nn_specs:
             for slot, y in zip(nn_slot, run_gemm(nn_specs, dev)):
                 grads[slot] = y
         if tn_jobs:
-            flat = torch.zeros(total, dtype=torch.float32, device=dev)
-            descs = []
-            for k, g, X, X2, W, nW, want_b, off in tn_jobs:
+            # gradient targets: the parameter's own .grad when it is allocated (a FlatGradBucket /
+            # zero_grad(set_to_none=False)) and ACCUMULATE_INTO_GRAD is on -- the kernel adds into it
+            # and autograd gets None -- else one zeroed scratch buffer handed back to autograd
+            targets, scratch = [], 0
+            for k, g, X, X2, W, bias, nW, want_b, c0 in tn_jobs:
+                tw = _grad_target(W) if nW else None
+                tb = _grad_target(bias) if want_b else None
+                targets.append((tw, tb))
+                scratch += (W.numel() if nW and tw is None else 0) + (W.size(0) if want_b and tb is None else 0)
+            flat = torch.zeros(scratch, dtype=torch.float32, device=dev) if scratch else None
+            off, descs = 0, []
+            for (k, g, X, X2, W, bias, nW, want_b, c0), (tw, tb) in zip(tn_jobs, targets):
                 Xc = _rowmajor(X, 'X')
                 X2c = None if X2 is None else _rowmajor(X2, 'X2')
                 live += [Xc, X2c]
-                dW = flat[off: off + W.numel()].view(W.size(0), W.size(1))
-                db = flat[off + W.numel(): off + W.numel() + W.size(0)] if want_b else None
+                dW = db = None
                 if nW:
-                    grads[4 * k + 2] = dW
+                    if tw is None:
+                        dW = flat[off: off + W.numel()].view(W.size(0), W.size(1))
+                        off += W.numel()
+                        grads[4 * k + 2] = dW
+                    else:
+                        dW = tw
                 if want_b:
-                    grads[4 * k + 3] = db
+                    if tb is None:
+                        db = flat[off: off + W.size(0)]
+                        off += W.size(0)
+                        grads[4 * k + 3] = db
+                    else:
+                        db = tb
                 if g.size(0):
+                    if dW is None:      # only the bias gradient is wanted: a throw-away dW
+                        dW = torch.zeros(W.size(0), W.size(1), dtype=torch.float32, device=dev)
                     descs.append(_ffi.GemmTnDesc(
                         dZ=g.data_ptr(), X=Xc.data_ptr(), X2=_ffi.ptr(X2c), in_scale=None, in_shift=None,
-                        in_scale2=None, in_shift2=None, dW=dW.data_ptr(), db=_ffi.ptr(db), M=g.size(0),
-                        lddz=ld(g), ldx=ld(Xc), ldx2=0 if X2c is None else ld(X2c), lddw=W.size(1),
+                        in_scale2=None, in_shift2=None, dW=dW.data_ptr() + 4 * c0, db=_ffi.ptr(db), M=g.size(0),
+                        lddz=ld(g), ldx=ld(Xc), ldx2=0 if X2c is None else ld(X2c), lddw=dW.stride(0),
                         N=W.size(0), K=Xc.size(1), K2=0 if X2c is None else X2c.size(1), in_relu=0))
             if descs:
                 _ffi.gemm_tn(descs, dev)

@@ -1,0 +1,123 @@
+"""One optimisation step of a cell-complex model on a GPU-resident batch, as the reference's
+training loop runs it (exp/train_utils.py:57-75: zero_grad, forward, loss, backward, step), laid
+out for MI355X:
+
+  * all gradients live in ONE flat fp32 buffer (dist.FlatGradBucket): zeroing them is one fill,
+    the weight-gradient kernels accumulate straight into it (ops.ACCUMULATE_INTO_GRAD), and the
+    data-parallel collective of a step is a single RCCL all-reduce of that buffer;
+  * the optimiser is torch's fused multi-tensor Adam (a handful of launches for ~265 tensors);
+  * the whole step -- plan reuse, forward, backward, optimiser -- is captured once per distinct batch
+    in a hipGraph and replayed (world size 1), or as two graphs around the eager all-reduce.
+
+Loss functions follow exp/train_utils.py:10-13 (L1 for 'regression', MSE, BCE-with-logits, CE).
+"""
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .dist import FlatGradBucket
+
+_LOSSES: Dict[str, Callable] = {
+    'regression': torch.nn.L1Loss(),                 # reg_criterion
+    'mse_regression': torch.nn.MSELoss(),            # msereg_criterion
+    'bin_classification': torch.nn.BCEWithLogitsLoss(),
+    'classification': torch.nn.CrossEntropyLoss(),
+}
+
+
+class TrainStep:
+    """step(i) runs one optimisation step on batches[i] and returns the (detached) loss.
+
+    `batches` are ComplexBatch objects already on the device; their input features are restored
+    before every step because the models overwrite them layer by layer (set_xs, as the reference
+    does).  With `use_graph` the first call of step(i) for each i captures, later calls replay."""
+
+    def __init__(self, model: torch.nn.Module, batches: Sequence, task_type: str = 'regression',
+                 lr: float = 1e-3, use_graph: bool = True, optimizer: Optional[torch.optim.Optimizer] = None,
+                 rebuild_plans: bool = True):
+        if task_type not in _LOSSES:
+            raise NotImplementedError('Training on task type {} not yet supported.'.format(task_type))
+        self.model, self.batches = model.train(), list(batches)
+        self.loss_fn = _LOSSES[task_type]
+        self.task_type = task_type
+        self.bucket = FlatGradBucket(model.parameters())
+        self.opt = optimizer or torch.optim.Adam(model.parameters(), lr=lr, capturable=True, fused=True)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.use_graph = use_graph
+        self.inputs = [[None if c.x is None else c.x.clone() for c in self._cochains(b)]
+                       for b in self.batches]
+        self._graphs: Dict[int, tuple] = {}
+        self._warm = False
+        # a new batch needs its adjacency plans (forward + transposed) built: part of the step
+        # unless the caller trains on a fixed set of batches and says so
+        self.rebuild_plans = rebuild_plans
+        for b in self.batches:
+            b.prepare(backward=True)
+
+    # ---- pieces ------------------------------------------------------------------------------
+    @staticmethod
+    def _cochains(b):
+        return [b.cochains[d] for d in range(b.dimension + 1)]
+
+    def _restore(self, i: int):
+        b = self.batches[i]
+        for c, x in zip(self._cochains(b), self.inputs[i]):
+            c._x = x
+        return b
+
+    def _forward_backward(self, i: int) -> torch.Tensor:
+        b = self._restore(i)
+        if self.rebuild_plans:
+            from . import csr
+            csr._cache.clear()
+            b.prepare(backward=True)
+        self.bucket.zero_()
+        pred = self.model(b)
+        y = b.y.view(-1,) if self.task_type == 'classification' else b.y.view(pred.shape).to(pred.dtype)
+        loss = self.loss_fn(pred, y)
+        loss.backward()
+        self._restore(i)                          # drop the references to the autograd graph
+        return loss.detach()
+
+    def _eager(self, i: int) -> torch.Tensor:
+        loss = self._forward_backward(i)
+        if self.world > 1:
+            self.bucket.all_reduce_mean()
+        self.opt.step()
+        return loss
+
+    def _capture(self, i: int):
+        if not self._warm:                        # side-stream warm-up of every batch, once
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for k in range(len(self.batches)):
+                    self._eager(k)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self._warm = True
+        g1 = torch.cuda.CUDAGraph()
+        if self.world == 1:
+            with torch.cuda.graph(g1):
+                loss = self._eager(i)
+            return (g1, None, loss)
+        with torch.cuda.graph(g1):
+            loss = self._forward_backward(i)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            self.opt.step()
+        return (g1, g2, loss)
+
+    # ---- the step ----------------------------------------------------------------------------
+    def step(self, i: int) -> torch.Tensor:
+        if not self.use_graph:
+            return self._eager(i)
+        if i not in self._graphs:
+            self._graphs[i] = self._capture(i)
+        g1, g2, loss = self._graphs[i]
+        g1.replay()
+        if g2 is not None:
+            self.bucket.all_reduce_mean()         # the ONE collective of the step (RCCL over xGMI)
+            g2.replay()
+        return loss

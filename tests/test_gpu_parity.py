@@ -1184,3 +1184,39 @@ def test_fused_training_layer_matches_torch_modules(norm, hidden, use_cob):
             torch.testing.assert_close(bf[name], t, rtol=1e-5, atol=1e-6, msg=lambda m, n=name: f'{n}: {m}')
         else:
             assert torch.equal(bf[name], t), name
+
+
+def test_training_accumulates_into_existing_grads():
+    """With .grad buffers allocated (FlatGradBucket), the weight-gradient kernels add into them
+    directly; two backward passes must equal twice one pass, and must match autograd's own
+    accumulation (ACCUMULATE_INTO_GRAD off)."""
+    from cwn_amd import layers, ops
+    from cwn_amd.dist import FlatGradBucket
+    from cwn_amd.synthetic import zinc_like_batch
+    fused, other = _train_layer_pair(torch.nn.BatchNorm1d, 64, True, seed=3)
+    b = zinc_like_batch(8, seed=2, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(b.cochains[d].num_cells, 64, generator=g).to(DEV) for d in range(3)]
+    ws = [torch.randn(b.cochains[d].num_cells, 64, generator=g).to(DEV) for d in range(3)]
+
+    def backward_once(conv):
+        b.set_xs([x.clone() for x in xs])
+        params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+        sum((o * w).sum() for o, w in zip(conv(*params), ws)).backward()
+
+    bucket = FlatGradBucket(fused.parameters())
+    state = {k: v.clone() for k, v in fused.state_dict().items()}
+    backward_once(fused)
+    once = bucket.flat.clone()
+    assert float(once.abs().max()) > 0
+    fused.load_state_dict(state)          # same running statistics / parameters for the second pass
+    backward_once(fused)
+    torch.testing.assert_close(bucket.flat, 2 * once, rtol=1e-5, atol=1e-5 * float(once.abs().max()))
+    # autograd's own accumulation
+    ops.ACCUMULATE_INTO_GRAD = False
+    try:
+        bucket2 = FlatGradBucket(other.parameters())
+        backward_once(other)
+    finally:
+        ops.ACCUMULATE_INTO_GRAD = True
+    torch.testing.assert_close(bucket2.flat, once, rtol=1e-4, atol=2e-5 * float(once.abs().max()))
