@@ -66,6 +66,15 @@ class TrainStep:
             c._x = x
         return b
 
+    def _state_tensors(self) -> List[torch.Tensor]:
+        """Parameters, buffers, then the optimiser's state tensors (in a fixed order)."""
+        ts = list(self.model.parameters()) + list(self.model.buffers())
+        for group in self.opt.param_groups:
+            for p in group['params']:
+                st = self.opt.state.get(p, {})
+                ts += [st[k] for k in sorted(st) if torch.is_tensor(st[k])]
+        return ts
+
     def _forward_backward(self, i: int) -> torch.Tensor:
         b = self._restore(i)
         if self.rebuild_plans:
@@ -88,13 +97,24 @@ class TrainStep:
         return loss
 
     def _capture(self, i: int):
-        if not self._warm:                        # side-stream warm-up of every batch, once
+        if not self._warm:
+            # side-stream warm-up of every batch, once (allocator pools, lazy optimiser state,
+            # plan caches) -- with the model / optimiser state put back afterwards, so that a
+            # graphed run takes exactly the steps an eager run takes
+            keep = [t.detach().clone() for t in self._state_tensors()]
+            n_before = len(keep)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for k in range(len(self.batches)):
                     self._eager(k)
             torch.cuda.current_stream().wait_stream(s)
+            with torch.no_grad():
+                now = self._state_tensors()
+                for t, old in zip(now[:n_before], keep):
+                    t.copy_(old)
+                for t in now[n_before:]:          # optimiser state created by the warm-up
+                    t.zero_()
             torch.cuda.synchronize()
             self._warm = True
         g1 = torch.cuda.CUDAGraph()

@@ -1220,3 +1220,85 @@ def test_training_accumulates_into_existing_grads():
     finally:
         ops.ACCUMULATE_INTO_GRAD = True
     torch.testing.assert_close(bucket2.flat, once, rtol=1e-4, atol=2e-5 * float(once.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# the whole optimisation step (cwn_amd/train.py)
+# ------------------------------------------------------------------------------------------------
+def _train_setup(seed=0, hidden=32, nb=2):
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import zinc_like_batch
+    torch.manual_seed(seed)
+    model = EmbedSparseCIN(28, 4, 1, 2, hidden, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV)
+    batches = [zinc_like_batch(16, seed=10 + i, device=DEV) for i in range(nb)]
+    return model, batches
+
+
+def test_train_step_graph_replay_matches_eager():
+    """Three optimisation steps replayed from hipGraphs leave the model where three eager steps
+    leave it (same kernels, same order; fp32 atomics in the weight gradients allow ~1e-6)."""
+    from cwn_amd.train import TrainStep
+    m1, b1 = _train_setup()
+    m2, b2 = _train_setup()
+    m2.load_state_dict(m1.state_dict())
+    eager = TrainStep(m1, b1, use_graph=False)
+    graph = TrainStep(m2, b2, use_graph=True)
+    for i in range(3):
+        le = eager.step(i % 2)
+        lg = graph.step(i % 2)
+        torch.testing.assert_close(lg, le, rtol=2e-3, atol=1e-4)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (n, p), (_, q) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        if p.dtype.is_floating_point:
+            worst = max(worst, float((p - q).abs().max()) / max(1.0, float(p.abs().max())))
+    assert worst < 5e-3, worst     # Adam's first steps move every weight by ~lr = 1e-3 whatever the gradient
+
+
+def test_train_step_learns_and_keeps_grads_in_the_bucket():
+    from cwn_amd.train import TrainStep
+    model, batches = _train_setup(seed=1)
+    ts = TrainStep(model, batches, lr=3e-3, use_graph=True)
+    first = [float(ts.step(i)) for i in range(2)]
+    for i in range(60):
+        ts.step(i % 2)
+    last = [float(ts.step(i)) for i in range(2)]
+    assert sum(last) < 0.7 * sum(first), (first, last)
+    # every gradient is a view into the one flat buffer (what the DP all-reduce sends)
+    lo, hi = ts.bucket.flat.data_ptr(), ts.bucket.flat.data_ptr() + 4 * ts.bucket.flat.numel()
+    for p in model.parameters():
+        assert p.grad is not None and lo <= p.grad.data_ptr() < hi
+    assert torch.isfinite(ts.bucket.flat).all()
+
+
+def test_model_training_forward_backward_matches_torch_modules():
+    """Whole EmbedSparseCIN in train mode: fused dense path on vs off, loss and flat gradient."""
+    from cwn_amd import layers
+    from cwn_amd.dist import FlatGradBucket
+    m1, b = _train_setup(seed=2, hidden=32, nb=1)
+    m2, _ = _train_setup(seed=2, hidden=32, nb=1)
+    m2.load_state_dict(m1.state_dict())
+    b = b[0]
+    x0 = [None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3)]
+
+    def run(model, fused_on):
+        layers.FUSED_DENSE_TRAINING = fused_on
+        try:
+            for d in range(3):
+                b.cochains[d]._x = x0[d]
+            model.train()
+            bucket = FlatGradBucket(model.parameters())
+            loss = (model(b) - b.y.view(-1, 1)).abs().mean()
+            loss.backward()
+            for d in range(3):
+                b.cochains[d]._x = x0[d]
+            return float(loss.detach()), bucket.flat.clone()
+        finally:
+            layers.FUSED_DENSE_TRAINING = True
+
+    l1, g1 = run(m1, True)
+    l2, g2 = run(m2, False)
+    assert abs(l1 - l2) < 1e-5 * max(1.0, abs(l2))
+    # relative L2 distance of the whole gradient: robust to an isolated ReLU-kink tie
+    rel = float((g1 - g2).norm() / g2.norm())
+    assert rel < 2e-3, rel
