@@ -323,6 +323,41 @@ typedef struct cwn_collate_desc {
 
 int cwn_collate(const cwn_collate_desc* descs_host, int n, int64_t n_seg, cwn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Graph -> 2-complex lifting on the HOST (integer preprocessing that produces the path's inputs;
+ * the reference does it through graph-tool and gudhi):
+ *   CWN_LIFT_RING    data/utils.py:400-498 compute_ring_2complex: 2-cells = chordless cycles with
+ *                    3..max_k vertices (max_k is ignored by the clique lift);
+ *   CWN_LIFT_CLIQUE  data/utils.py:224-272 compute_clique_complex_with_gudhi, expansion_dim 2.
+ * `edges` is [n_edges, 2] (any orientation; sorted and de-duplicated internally).  Cells and
+ * adjacency entries come in the reference's order (build_adj, data/utils.py:103-138).  Read the
+ * results back with cwn_lift_size / cwn_lift_copy; index arrays are [2, L] row-major int64.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cwn_lift_s cwn_lift_t;
+enum { CWN_LIFT_RING = 0, CWN_LIFT_CLIQUE = 1 };
+enum {
+    CWN_LIFT_EDGES = 0,      /* [E, 2]   vertices of edge e                                     */
+    CWN_LIFT_CELLS2_PTR,     /* [C + 1]  offsets into CELLS2_VERTS                              */
+    CWN_LIFT_CELLS2_VERTS,   /*          vertices of every 2-cell (cyclic order for rings)      */
+    CWN_LIFT_UP0,            /* [2, L]   upper_index of the vertices                            */
+    CWN_LIFT_COB0,           /* [L]      shared_coboundaries (edge ids)                         */
+    CWN_LIFT_UP1,            /* [2, L]   upper_index of the edges                               */
+    CWN_LIFT_COB1,           /* [L]      shared_coboundaries (2-cell ids)                       */
+    CWN_LIFT_DOWN1,          /* [2, L]   lower_index of the edges        (include_down only)    */
+    CWN_LIFT_BND1,           /* [L]      shared_boundaries (vertex ids)                         */
+    CWN_LIFT_DOWN2,          /* [2, L]   lower_index of the 2-cells      (include_down only)    */
+    CWN_LIFT_BND2,           /* [L]      shared_boundaries (edge ids)                           */
+    CWN_LIFT_BINDEX1,        /* [2, 2E]  boundary_index of the edges                            */
+    CWN_LIFT_BINDEX2,        /* [2, L]   boundary_index of the 2-cells                          */
+    CWN_LIFT_N_ARRAYS
+};
+/* NULL on invalid input (vertex out of range, self loop, unknown kind). */
+cwn_lift_t* cwn_lift_create(int kind, int64_t n_vertices, const int64_t* edges, int64_t n_edges,
+                            int max_k, int include_down);
+int64_t cwn_lift_size(const cwn_lift_t* lift, int which);          /* int64 elements, -1 on error */
+int cwn_lift_copy(const cwn_lift_t* lift, int which, int64_t* out);
+void cwn_lift_destroy(cwn_lift_t* lift);
+
 #ifdef __cplusplus
 }
 #endif

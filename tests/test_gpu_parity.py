@@ -1302,3 +1302,20 @@ def test_model_training_forward_backward_matches_torch_modules():
     # relative L2 distance of the whole gradient: robust to an isolated ReLU-kink tie
     rel = float((g1 - g2).norm() / g2.norm())
     assert rel < 2e-3, rel
+
+
+def test_train_step_two_graph_form_used_under_data_parallelism():
+    """World size > 1 splits the step into graph(forward + backward) -> all-reduce -> graph(Adam).
+    Exercised here on one GPU by forcing the form (the collective is a no-op without a process
+    group); the result must equal the single-graph step."""
+    from cwn_amd.train import TrainStep
+    m1, b1 = _train_setup(seed=4)
+    m2, b2 = _train_setup(seed=4)
+    m2.load_state_dict(m1.state_dict())
+    one = TrainStep(m1, b1, use_graph=True)
+    two = TrainStep(m2, b2, use_graph=True)
+    two.world = 2
+    for i in range(4):
+        la, lb = one.step(i % 2), two.step(i % 2)
+        torch.testing.assert_close(lb, la, rtol=2e-3, atol=1e-4)
+    assert two._graphs[0][1] is not None and one._graphs[0][1] is None

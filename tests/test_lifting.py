@@ -118,3 +118,92 @@ def test_generators_are_deterministic_and_consistent():
             if c.boundary_index is not None:
                 assert int(c.boundary_index[0].max()) < cx.cochains[d - 1].num_cells
                 assert torch.all(c.boundary_index[1][1:] >= c.boundary_index[1][:-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# the native (C ABI, csrc/cwn_lift.cpp) lifts: same tensors as the restatement above, which is
+# pinned on the reference's expected tensors
+# ------------------------------------------------------------------------------------------------
+KEYS = ('x', 'upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries', 'boundary_index')
+
+
+def _same_complex(a: Complex, b: Complex):
+    assert a.dimension == b.dimension
+    for d in range(a.dimension + 1):
+        ca, cb = a.cochains[d], b.cochains[d]
+        assert (ca.num_cells, ca.num_cells_up, ca.num_cells_down) == (cb.num_cells, cb.num_cells_up, cb.num_cells_down)
+        for k in KEYS:
+            ta, tb = ca[k], cb[k]
+            assert (ta is None) == (tb is None), (d, k)
+            if ta is not None:
+                assert ta.dtype == tb.dtype and torch.equal(ta, tb), (d, k)
+
+
+def test_native_lifts_house_expected_tensors():
+    """data/test_utils.py:40-124, 215-289 through the C ABI."""
+    from cwn_amd import lifting
+    Complex.lazy_attrs = True
+    cx = lifting.clique_lift(5, HOUSE, X, include_down_adj=True, y=torch.tensor([1]))
+    e = cx.get_cochain_params(dim=1)
+    assert e.x.flatten().tolist() == [1, 3, 3, 5, 6, 7]
+    assert e.up_index.tolist() == [[3, 4, 3, 5, 4, 5], [4, 3, 5, 3, 5, 4]]
+    assert e.down_index.tolist() == [[0, 1, 0, 2, 2, 3, 2, 4, 3, 4, 1, 3, 1, 5, 3, 5, 4, 5],
+                                     [1, 0, 2, 0, 3, 2, 4, 2, 4, 3, 3, 1, 5, 1, 5, 3, 5, 4]]
+    assert cx.get_cochain_params(dim=2).kwargs['boundary_index'].tolist() == [[3, 4, 5], [0, 0, 0]]
+    ex = torch.tensor([[1.], [3.], [3.], [5.], [6.], [7.]])
+    rx = torch.tensor([[6.], [9.]])
+    cr = lifting.ring_lift(5, HOUSE, X, ex=ex, rx=rx, max_k=4, include_down_adj=True, y=torch.tensor([1]))
+    e = cr.get_cochain_params(dim=1)
+    assert e.up_index.tolist() == [[0, 1, 0, 2, 0, 3, 1, 2, 1, 3, 2, 3, 3, 4, 3, 5, 4, 5],
+                                   [1, 0, 2, 0, 3, 0, 2, 1, 3, 1, 3, 2, 4, 3, 5, 3, 5, 4]]
+    t = cr.get_cochain_params(dim=2)
+    assert t.down_index.tolist() == [[0, 1], [1, 0]]
+    assert t.kwargs['boundary_index'].tolist() == [[0, 1, 2, 3, 3, 4, 5], [0, 0, 0, 0, 1, 1, 1]]
+    assert lifting.induced_cycles(5, HOUSE, 3) == [(2, 3, 4)]
+    assert lifting.induced_cycles(5, HOUSE, 4) == [(0, 1, 2, 3), (2, 3, 4)]
+    assert lifting.induced_cycles(5, HOUSE, 7) == [(0, 1, 2, 3), (2, 3, 4)]
+
+
+def test_native_ring_lift_equals_restatement_on_random_molecules():
+    from cwn_amd import lifting
+    rng = np.random.default_rng(11)
+    for i in range(40):
+        n, bonds = random_molecule(rng, 6, 40)
+        vx = torch.from_numpy(rng.integers(0, 28, size=(n, 1))).float()
+        ex = torch.from_numpy(rng.integers(0, 4, size=(len(bonds), 1))).float()
+        for k in (3, 5, 6, 8):
+            assert lifting.induced_cycles(n, bonds, k) == induced_cycles(n, bonds, k)
+        down = bool(i % 2)
+        # shuffled, flipped edge list: the lift sorts it (features follow the sorted order)
+        sh = [(v, u) if j % 3 == 0 else (u, v) for j, (u, v) in enumerate(bonds)]
+        order = rng.permutation(len(sh))
+        sh = [sh[j] for j in order]
+        _same_complex(lifting.ring_lift(n, sh, vx, ex, max_k=6, include_down_adj=down),
+                      ring_lift(n, bonds, vx, ex, max_k=6, include_down_adj=down))
+
+
+def test_native_clique_lift_equals_restatement_on_hub_graphs():
+    from cwn_amd import lifting
+    from cwn_amd.synthetic import preferential_attachment_graph
+    rng = np.random.default_rng(3)
+    for i in range(6):
+        n = int(rng.integers(30, 120))
+        edges = preferential_attachment_graph(rng, n)
+        if isinstance(edges, tuple):
+            edges = edges[-1]
+        vx = torch.ones(n, 1)
+        for init in ('sum', 'mean'):
+            _same_complex(lifting.clique_lift(n, edges, vx, init_method=init, include_down_adj=bool(i % 2)),
+                          clique_lift(n, edges, vx, init_method=init, include_down_adj=bool(i % 2)))
+
+
+def test_native_lift_rejects_bad_graphs():
+    from cwn_amd import lifting
+    for bad in ([(0, 5)], [(1, 1)], [(-1, 0)]):
+        try:
+            lifting.ring_lift(3, bad, torch.zeros(3, 1))
+        except ValueError:
+            continue
+        raise AssertionError(f'{bad} accepted')
+    cx = lifting.ring_lift(4, [], torch.zeros(4, 1))          # no edges: a 0-complex
+    assert cx.dimension == 0 and cx.cochains[0].upper_index is None
