@@ -72,11 +72,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    # CWN_BENCH_SHARE_GPU=1 (testing the multi-rank control flow on a one-GPU box): ranks share
+    # device 0 and talk over gloo.  Never set by the driver: one rank per GPU over RCCL otherwise.
+    share = os.environ.get('CWN_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
     else:
         dist = None
 
@@ -242,10 +250,11 @@ def main():
     value = float(cells_total.item()) / dt
 
     # secondary: the full model forward (embedding, 4 conv layers incl. MLPs/BN, readout, head)
+    SKIP = set(filter(None, os.environ.get('CWN_BENCH_SKIP', '').split(',')))   # debugging: legs to skip
     if args.only_primary:
         args.no_cpu = True
     try:
-        if args.only_primary:
+        if args.only_primary or 'full' in SKIP:
             raise KeyboardInterrupt
         dt_full = timed(full_forward, max(args.steps // 4, 10), max(args.warmup // 4, 3), use_graph)
     except KeyboardInterrupt:
@@ -263,7 +272,7 @@ def main():
     # ---- rooflines: both kernels of a layer are measured live; the one with the larger share of the
     # step is `roofline` (dominant), the other `roofline_other` ---------------------------------------
     roofline = roofline_other = r_plan = None
-    if rank == 0 and not args.only_primary:
+    if rank == 0 and not args.only_primary and 'roofline' not in SKIP:
         MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA, dense
 
         def replay_us(fn, reps):
@@ -484,7 +493,7 @@ def main():
     # secondary: independent batches overlapped on the GPU (serving-style): S streams, each replaying
     # the step graph of its own batch; same kernels, same per-step work, K steps in total
     concurrent = None
-    if use_graph and not args.only_primary and len(batches) >= 2:
+    if use_graph and not args.only_primary and len(batches) >= 2 and 'concurrent' not in SKIP:
         try:
             S = min(4, len(batches))
             with torch.no_grad():
@@ -530,7 +539,7 @@ def main():
     # secondary: the whole optimisation step (plans, forward, L1 loss, backward, fused Adam; for
     # N > 1 plus the ONE gradient all-reduce over RCCL), graph-captured -- SURVEY.md 8(d)/(e)
     train = None
-    if not args.only_primary:
+    if not args.only_primary and 'train' not in SKIP:
         try:
             import copy
             from cwn_amd.train import TrainStep
@@ -546,10 +555,19 @@ def main():
                         for c, x_ in zip(cs_, xs_keep):
                             c._x = x_
                     b_.y = torch.zeros_like(ref_pred)
-            ts = TrainStep(tmodel, tb, task_type='regression', use_graph=use_graph)
+            trace = (lambda m: (torch.cuda.synchronize(), print(f'[bench trace r{rank}] {m}', file=sys.stderr, flush=True))) if os.environ.get('CWN_BENCH_TRACE') else (lambda m: None)
+            trace('train: batches ready')
+            # N > 1: eager by default.  The graph-captured data-parallel form (two graphs around the
+            # all-reduce) is covered on one GPU by tests/test_gpu_parity.py, but it has never run over
+            # RCCL on real multi-GPU hardware from this container, and a fault here would take the
+            # scaling run's primary number down with it.  CWN_BENCH_TRAIN_GRAPH=1 opts in.
+            train_graph = use_graph and (world == 1 or os.environ.get('CWN_BENCH_TRAIN_GRAPH') == '1')
+            ts = TrainStep(tmodel, tb, task_type='regression', use_graph=train_graph)
+            trace('train: TrainStep built')
             tsteps = max(args.steps // 4, 10)
             for i in range(len(tb) + 2):
                 ts.step(i % len(tb))
+                trace(f'train: warm step {i}')
             barrier()
             t0 = time.perf_counter()
             for i in range(tsteps):
@@ -570,7 +588,7 @@ def main():
                      'scope': 'adjacency plans (forward + transposed), forward, L1 loss, backward, fused Adam'
                               + (f', one {ts.bucket.flat.numel() * 4 / 1e6:.1f} MB RCCL all-reduce of the flat '
                                  'gradient bucket' if world > 1 else '')
-                              + ('; hipGraph replay' if use_graph else '; eager')}
+                              + ('; hipGraph replay' if train_graph else '; eager launches (host-bound)')}
             del ts, tmodel
         except Exception as e:
             print(f'[bench] train-step leg failed: {type(e).__name__}: {e}', file=sys.stderr)

@@ -11,6 +11,7 @@ out for MI355X:
 
 Loss functions follow exp/train_utils.py:10-13 (L1 for 'regression', MSE, BCE-with-logits, CE).
 """
+import os
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -44,6 +45,8 @@ class TrainStep:
         self.bucket = FlatGradBucket(model.parameters())
         self.opt = optimizer or torch.optim.Adam(model.parameters(), lr=lr, capturable=True, fused=True)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if os.environ.get('CWN_TRAIN_TWO_GRAPH') == '1':     # debugging: the data-parallel form on one rank
+            self.world = max(self.world, 2)
         self.use_graph = use_graph
         self.inputs = [[None if c.x is None else c.x.clone() for c in self._cochains(b)]
                        for b in self.batches]
