@@ -1,0 +1,64 @@
+"""HBM traffic per launch of the hot kernels from the PMC counters, as MI355X_MICROARCH.md's HBM
+section prescribes: separate rocprofv3 passes for FETCH_SIZE and WRITE_SIZE (with --kernel-trace
+only), counters in KiB, gfx950 FETCH_SIZE doubled for wide coalesced streams, WRITE_SIZE as is.
+Run ON the GPU box from the repo root:   python tools/collect_traffic.py [batch ...]
+Writes profiles/r1_pmc_fetch_write_raw.json and profiles/r1_traffic.json."""
+import csv
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name: str) -> str:
+    m = re.search(r'(\w+_kernel(?:<[^>]*>)?)', name)
+    return m.group(1) if m else name[:60]
+
+
+def one_pass(counter: str, batch: int, workload: str):
+    out = f'/tmp/pmc_{counter}_{workload}_{batch}'
+    subprocess.run(['rm', '-rf', out])
+    cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--',
+           sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--steps', '3', '--warmup', '1',
+           '--batch', str(batch), '--num-batches', '1', '--only-primary', '--no-graph']
+    env = dict(os.environ, TMPDIR='/tmp')
+    subprocess.run(cmd, cwd='/tmp', env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    acc = {}
+    for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get('Counter_Name') != counter:
+                    continue
+                k = short(row['Kernel_Name'])
+                a = acc.setdefault(k, [0.0, 0])
+                a[0] += float(row['Counter_Value'])
+                a[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def main():
+    batches = [int(a) for a in sys.argv[1:]] or [128, 8192]
+    raw, traffic = {}, {'_how': __doc__.split('Run ON')[0].strip().replace('\n', ' '),
+                        'kernel': 'aggregate_kernel<4>', 'hidden': 128, 'entries': {}}
+    for b in batches:
+        f, w = one_pass('FETCH_SIZE', b, 'zinc'), one_pass('WRITE_SIZE', b, 'zinc')
+        raw[str(b)] = {k: {'FETCH_SIZE_KB_avg': round(f[k][0], 1), 'launches': f[k][1],
+                           'WRITE_SIZE_KB_avg': round(w.get(k, (0, 0))[0], 1)} for k in f}
+        k = 'aggregate_kernel<4>'
+        if k in f:
+            fb, wb = f[k][0] * 1024, w[k][0] * 1024
+            traffic['entries'][str(b)] = {'fetch_bytes_raw': int(fb), 'write_bytes_raw': int(wb),
+                                          'traffic_bytes': int(2 * fb + wb), 'launches_averaged': f[k][1]}
+    with open(os.path.join(ROOT, 'profiles', 'r1_pmc_fetch_write_raw.json'), 'w') as fh:
+        json.dump(raw, fh, indent=1)
+    with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json'), 'w') as fh:
+        json.dump(traffic, fh, indent=1)
+    print(json.dumps(traffic['entries']))
+
+
+if __name__ == '__main__':
+    main()
