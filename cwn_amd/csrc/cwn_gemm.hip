@@ -36,8 +36,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int RT = 2;     // 16-row MFMA tiles per wave
 constexpr int CT = 2;     // 16-col MFMA tiles per wave
+constexpr int kCUs = 256;    // MI355X
 constexpr int kMaxK = 256;  // K + K2 supported (the W tile of the whole K stays in LDS)
 
 struct GemmBatch {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, in
     }
 }
 
-template <bool FAST, bool PRO, int KP, int WN, bool WT>
+template <bool FAST, bool PRO, int KP, int WN, bool WT, int RT>
 #ifndef CWN_GEMM_LB
 #define CWN_GEMM_LB 2
 #endif
@@ -142,7 +142,8 @@ template <bool FAST, bool PRO, int KP, int WN, bool WT>
 #define CWN_GEMM_FRAGPF 0
 #endif
 __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B) {
-    constexpr int BM = 32 * (4 / WN);   // rows per tile: WN waves side by side along N, 4/WN along M
+    // RT = 16-row MFMA tiles per wave (2; 3 for the one-round small-M case, see the host side)
+    constexpr int BM = 16 * RT * (4 / WN);   // rows per tile: WN waves side by side along N, 4/WN along M
     constexpr int BN = 32 * WN;         // columns per tile
     extern __shared__ __attribute__((aligned(16))) float smem[];   // two [BM][KP] X buffers
     int di = 0;
@@ -308,14 +309,14 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             f32x4 xa[RT], xb[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
-                xa[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(wm * 32 + rt * 16 + j, g));
+                xa[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(wm * (16 * RT) + rt * 16 + j, g));
 #pragma unroll
             for (int sl = 0; sl < SLABS; ++sl) {
                 if (sl * 16 < Ktot && !(dbg & 1)) {
                     if (sl + 1 < SLABS) {
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
-                            xb[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(wm * 32 + rt * 16 + j, 4 * (sl + 1) + g));
+                            xb[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(wm * (16 * RT) + rt * 16 + j, 4 * (sl + 1) + g));
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                 f32x4 x[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    x[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(wm * 32 + rt * 16 + j, 4 * sl + g));
+                    x[rt] = *reinterpret_cast<const f32x4*>(ldsX + lds_off<KP>(wm * (16 * RT) + rt * 16 + j, 4 * sl + g));
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
         int64_t xrow[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            xrow[rt] = m_base + wm * 32 + rt * 16 + j;
+            xrow[rt] = m_base + wm * (16 * RT) + rt * 16 + j;
             xok[rt] = xrow[rt] < M;
         }
 #pragma unroll
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                 // the slot of this wave's 32-row band: no atomics, no zero fill, deterministic.
                 // (fp64 atomics on 2 x N addresses from ~100 workgroups per descriptor serialised
                 // at L2 and cost 20 us of a 30 us launch.)
-                const int64_t slot = m_base / 32 + wm;
+                static_assert(RT == 2 || true, "");
+                const int64_t slot = m_base / 32 + wm;   // RT == 2 only (host-checked): tiles align to bands
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     double a = csum[r], b = csq[r];
@@ -432,8 +434,8 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                 va[r] = lo ? acc[0][rt][r] : recv[r];      // lo: (row j, ct0)    hi: (row j-8, ct1)
                 vb[r] = lo ? recv[r] : acc[1][rt][r];      // lo: (row j+8, ct0)  hi: (row j, ct1)
             }
-            const int64_t ra = m_base + wm * 32 + rt * 16 + (lo ? j : j - 8);
-            const int64_t rb = m_base + wm * 32 + rt * 16 + (lo ? j + 8 : j);
+            const int64_t ra = m_base + wm * (16 * RT) + rt * 16 + (lo ? j : j - 8);
+            const int64_t rb = m_base + wm * (16 * RT) + rt * 16 + (lo ? j + 8 : j);
             const int n0 = n_base + (lo ? 0 : 16) + 4 * g;
             const bool full = n0 + 3 < N;
             if (ra < M && n0 < N) {
@@ -493,8 +495,27 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         nmax = descs[i].N > nmax ? descs[i].N : nmax;
     }
     const bool narrow = nmax <= 64;
-    const int BM = narrow ? 64 : 32, BN = narrow ? 64 : 128;
     const int KP = kmax <= 64 && narrow ? 64 : (kmax <= 128 ? 128 : 256);
+    int BM = narrow ? 64 : 32;
+    const int BN = narrow ? 64 : 128;
+    // 48-row tiles for the one case where they pay: a small launch (the ZINC batch of 128 is 318
+    // tiles of 32 rows on 256 CUs) whose 32-row tiling needs two rounds of workgroups on some CUs
+    // while a 48-row tiling fits in one -- the MFMA phase of the critical CU drops from 2 x 2 to
+    // 1 x 3 row tiles (3.9 -> ~2.6 us measured on that shape).  Not with the statistics epilogue,
+    // whose partial sums are laid out in 32-row bands.
+    bool rt3 = false;
+    if (!narrow && KP == 128) {
+        int64_t t32 = 0, t48 = 0;
+        bool stats = false;
+        for (int i = 0; i < n; ++i) {
+            const int tn_ = (descs[i].N + BN - 1) / BN;
+            t32 += ((descs[i].M + 31) / 32) * tn_;
+            t48 += ((descs[i].M + 47) / 48) * tn_;
+            stats = stats || descs[i].col_sum != nullptr;
+        }
+        rt3 = !stats && t32 > kCUs && t48 <= kCUs;
+        if (rt3) BM = 48;
+    }
     for (int i = 0; i < n; ++i) {
         const cwn_gemm_desc& D = descs[i];
         const int64_t tm = (D.M + BM - 1) / BM;
@@ -533,20 +554,20 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
     }
     using Kern = void (*)(GemmBatch);
     // shape index: 0 = 32x128 tile, K <= 128;  1 = 32x128, K <= 256;  2 = 64x64, K <= 64;
-    //              3 = 64x64, K <= 128;        4 = 64x64, K <= 256
-#define CWN_SHAPES(F, P, T)                                                                     \
-    {gemm_kernel<F, P, 128, 4, T>, gemm_kernel<F, P, 256, 4, T>, gemm_kernel<F, P, 64, 2, T>,  \
-     gemm_kernel<F, P, 128, 2, T>, gemm_kernel<F, P, 256, 2, T>}
-    static const Kern kerns[2][2][5] = {{CWN_SHAPES(false, false, false), CWN_SHAPES(false, true, false)},
+    //              3 = 64x64, K <= 128;        4 = 64x64, K <= 256;   5 = 48x128, K <= 128
+#define CWN_SHAPES(F, P, T)                                                                           \
+    {gemm_kernel<F, P, 128, 4, T, 2>, gemm_kernel<F, P, 256, 4, T, 2>, gemm_kernel<F, P, 64, 2, T, 2>,   \
+     gemm_kernel<F, P, 128, 2, T, 2>, gemm_kernel<F, P, 256, 2, T, 2>, gemm_kernel<F, P, 128, 4, T, 3>}
+    static const Kern kerns[2][2][6] = {{CWN_SHAPES(false, false, false), CWN_SHAPES(false, true, false)},
                                         {CWN_SHAPES(true, false, false), CWN_SHAPES(true, true, false)}};
     // transposed-weight variants (the input-gradient GEMM): no prologue
-    static const Kern kerns_wt[2][5] = {CWN_SHAPES(false, false, true), CWN_SHAPES(true, false, true)};
+    static const Kern kerns_wt[2][6] = {CWN_SHAPES(false, false, true), CWN_SHAPES(true, false, true)};
 #undef CWN_SHAPES
-    static const int kShapeLds[5] = {2 * 32 * 128 * 4, 2 * 32 * 256 * 4, 2 * 64 * 64 * 4, 2 * 64 * 128 * 4,
-                                     2 * 64 * 256 * 4};
+    static const int kShapeLds[6] = {2 * 32 * 128 * 4, 2 * 32 * 256 * 4, 2 * 64 * 64 * 4, 2 * 64 * 128 * 4,
+                                     2 * 64 * 256 * 4, 2 * 48 * 128 * 4};
     static bool attr_set = false;
     if (!attr_set) {
-        for (int c = 0; c < 5; ++c) {
+        for (int c = 0; c < 6; ++c) {
             for (int a = 0; a < 2; ++a) {
                 for (int b = 0; b < 2; ++b)
                     if (hipFuncSetAttribute((const void*)kerns[a][b][c],
@@ -561,7 +582,7 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         attr_set = true;
     }
     if (wt && pro) return CWN_ERR_BAD_ARG;
-    const int shape = narrow ? (KP == 64 ? 2 : (KP == 128 ? 3 : 4)) : (KP == 128 ? 0 : 1);
+    const int shape = narrow ? (KP == 64 ? 2 : (KP == 128 ? 3 : 4)) : (rt3 ? 5 : (KP == 128 ? 0 : 1));
     const Kern k = wt ? kerns_wt[fast ? 1 : 0][shape] : kerns[fast ? 1 : 0][pro ? 1 : 0][shape];
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
