@@ -29,6 +29,7 @@
 //   affine (BatchNorm in eval mode), ReLU, and per-column sum / sum-of-squares accumulation
 //   (BatchNorm batch statistics in training mode).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "../../include/cwn_hip.h"
 
 namespace {
@@ -529,9 +530,13 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
     // two X buffers; never less than the four 8-KiB wave-private W staging slices
     int lds_bytes = 2 * BM * KP * 4;
     if (lds_bytes < 4 * 32 * 64 * 4) lds_bytes = 4 * 32 * 64 * 4;
-    // persistent blocks: what the LDS lets a CU hold, x 256 CUs, shared between the descriptors in
-    // proportion to their tile counts; each block walks its descriptor's tiles
-    const int64_t budget = lds_bytes <= 32 * 1024 ? 768 : 512;   // ~3 (2) resident blocks per CU x 256 CUs
+    // persistent blocks, shared between the descriptors in proportion to their tile counts; each
+    // block walks its descriptor's tiles with its weights stationary
+    static const char* budget_env = getenv("CWN_GEMM_BUDGET");   // timing experiments
+    const int64_t budget = budget_env ? atoi(budget_env) : (lds_bytes <= 48 * 1024 ? 4096 : 512);
+    // (K <= 128: measured on the 650 k-row shape -- 512 blocks 363 us, 768: 331, 1024: 318, 2048: 312,
+    //  4096: 302, 8192: 324, one block per tile: 371; two are resident per CU, the queue behind them
+    //  keeps every CU busy to the end while W is still re-staged only 16 times per CU)
     int64_t blocks = 0;
     for (int i = 0; i < n; ++i) {
         int64_t nb = B.n_tiles[i];
