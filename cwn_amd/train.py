@@ -5,7 +5,8 @@ out for MI355X:
   * all gradients live in ONE flat fp32 buffer (dist.FlatGradBucket): zeroing them is one fill,
     the weight-gradient kernels accumulate straight into it (ops.ACCUMULATE_INTO_GRAD), and the
     data-parallel collective of a step is a single RCCL all-reduce of that buffer;
-  * the optimiser is torch's fused multi-tensor Adam (a handful of launches for ~265 tensors);
+  * the optimiser is Adam over ONE flat parameter buffer (`FlatAdam`, cwn_adam_f32: one launch
+    for the whole model; torch's fused multi-tensor Adam needs 8 x 22 us for the 265 tensors);
   * the whole step -- plan reuse, forward, backward, optimiser -- is captured once per distinct batch
     in a hipGraph and replayed (world size 1), or as two graphs around the eager all-reduce.
 
@@ -17,6 +18,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
+from . import _ffi
 from .dist import FlatGradBucket
 
 _LOSSES: Dict[str, Callable] = {
@@ -25,6 +27,49 @@ _LOSSES: Dict[str, Callable] = {
     'bin_classification': torch.nn.BCEWithLogitsLoss(),
     'classification': torch.nn.CrossEntropyLoss(),
 }
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (no amsgrad) on flat buffers: the parameters of `bucket` are
+    re-homed into one contiguous fp32 buffer (their `.data` become views of it, so modules keep
+    working and state_dicts are unchanged), the moments are two more flat buffers, and `step()` is
+    one kernel launch reading the bucket's flat gradient.  Graph-capturable (the step counter
+    lives on the device)."""
+
+    def __init__(self, bucket: FlatGradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0):
+        self.bucket, self.lr, self.betas, self.eps, self.weight_decay = bucket, lr, betas, eps, weight_decay
+        g = bucket.flat
+        self.flat_p = torch.empty_like(g)
+        off = 0
+        with torch.no_grad():
+            for p in bucket.params:
+                n = p.numel()
+                view = self.flat_p[off:off + n].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                off += n
+        self.exp_avg = torch.zeros_like(g)
+        self.exp_avg_sq = torch.zeros_like(g)
+        self.t = torch.zeros(1, dtype=torch.int32, device=g.device)
+        # what TrainStep snapshots around its warm-up
+        self.param_groups = [{'params': list(bucket.params)}]
+        self.state = {}
+
+    def state_tensors(self) -> List[torch.Tensor]:
+        return [self.exp_avg, self.exp_avg_sq, self.t]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.bucket.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        self.t.add_(1)
+        g = self.bucket.flat
+        _ffi.check(_ffi.lib().cwn_adam_f32(
+            self.flat_p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            g.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+            self.t.data_ptr(), _ffi.stream_ptr(g.device)), 'cwn_adam_f32')
 
 
 class TrainStep:
@@ -43,7 +88,7 @@ class TrainStep:
         self.loss_fn = _LOSSES[task_type]
         self.task_type = task_type
         self.bucket = FlatGradBucket(model.parameters())
-        self.opt = optimizer or torch.optim.Adam(model.parameters(), lr=lr, capturable=True, fused=True)
+        self.opt = optimizer or FlatAdam(self.bucket, lr=lr)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if os.environ.get('CWN_TRAIN_TWO_GRAPH') == '1':     # debugging: the data-parallel form on one rank
             self.world = max(self.world, 2)
@@ -72,6 +117,8 @@ class TrainStep:
     def _state_tensors(self) -> List[torch.Tensor]:
         """Parameters, buffers, then the optimiser's state tensors (in a fixed order)."""
         ts = list(self.model.parameters()) + list(self.model.buffers())
+        if hasattr(self.opt, 'state_tensors'):
+            return ts + self.opt.state_tensors()
         for group in self.opt.param_groups:
             for p in group['params']:
                 st = self.opt.state.get(p, {})

@@ -323,6 +323,14 @@ typedef struct cwn_collate_desc {
 
 int cwn_collate(const cwn_collate_desc* descs_host, int n, int64_t n_seg, cwn_stream_t stream);
 
+/* torch.optim.Adam's update (no amsgrad; weight_decay is the L2 form) for a whole model in one
+ * launch: parameters p, gradients g and the moments m, v are each ONE contiguous fp32 buffer of n
+ * elements (16-B aligned).  `step` is a device int32 holding the 1-based step number (the caller
+ * increments it before the call), so the launch is graph-capturable.  Replaces optimizer.step() of
+ * exp/train_utils.py:75 for the data-parallel training path. */
+int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, const int32_t* step, cwn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Graph -> 2-complex lifting on the HOST (integer preprocessing that produces the path's inputs;
  * the reference does it through graph-tool and gudhi):

@@ -1319,3 +1319,28 @@ def test_train_step_two_graph_form_used_under_data_parallelism():
         la, lb = one.step(i % 2), two.step(i % 2)
         torch.testing.assert_close(lb, la, rtol=2e-3, atol=1e-4)
     assert two._graphs[0][1] is not None and one._graphs[0][1] is None
+
+
+def test_flat_adam_matches_torch_adam():
+    from cwn_amd.dist import FlatGradBucket
+    from cwn_amd.train import FlatAdam
+    torch.manual_seed(0)
+    shapes = [(128, 256), (128,), (7, 3), (1,), (64, 64)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    ref = torch.optim.Adam(pb, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    bucket = FlatGradBucket(pa)
+    opt = FlatAdam(bucket, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    g = torch.Generator().manual_seed(1)
+    for it in range(5):
+        grads = [torch.randn(*s, generator=g).to(DEV) * (10.0 ** (it - 2)) for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad.copy_(gr)
+            q.grad = gr.clone()
+        opt.step()
+        ref.step()
+        for p, q in zip(pa, pb):
+            torch.testing.assert_close(p.data, q.data, rtol=2e-5, atol=2e-6)
+    # parameters are views of one buffer, modules see the updates
+    lo, hi = opt.flat_p.data_ptr(), opt.flat_p.data_ptr() + 4 * opt.flat_p.numel()
+    assert all(lo <= p.data_ptr() < hi for p in pa)
