@@ -171,6 +171,12 @@ __device__ __forceinline__ void finish_row(const cwn_agg_desc& D, int64_t row, i
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] + self_scale * s.v[k];
     }
+    if (D.self_x2 != nullptr) {      // backward: the two GIN self terms of a cell, in one pass
+        const float scale2 = 1.0f + (D.eps2 != nullptr ? *D.eps2 : 0.0f);
+        const Acc<VEC> s = ld<VEC>(D.self_x2 + row * F + f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] + scale2 * s.v[k];
+    }
     st<VEC>(D.out + row * F + f, acc);
 }
 
@@ -331,7 +337,7 @@ extern "C" int cwn_aggregate_f32(const cwn_agg_desc* descs, int n, cwn_stream_t 
         // widest vector every pointer and the row stride allow
         int v = (D.F % 4 == 0) ? 4 : (D.F % 2 == 0 ? 2 : 1);
         const void* ptrs[] = {D.A, D.b_width == D.F ? (const void*)D.B : nullptr, D.self_x,
-                              D.self_pre, D.out};
+                              D.self_pre, D.out, D.self_x2};
         for (const void* p : ptrs) {
             if (p == nullptr) continue;
             if (((uintptr_t)p & 3u) != 0) return CWN_ERR_ALIGN;

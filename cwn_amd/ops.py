@@ -43,6 +43,8 @@ class AggSpec:
     eps: Optional[Tensor] = None
     self_pre: Optional[Tensor] = None
     out: Optional[Tensor] = None
+    self_x2: Optional[Tensor] = None     # second self term: out += (1 + eps2) * self_x2
+    eps2: Optional[Tensor] = None
 
     def desc(self) -> _ffi.AggDesc:
         # an index with E = 0 is legal (mp/test_cell_mp.py:137-176) and behaves like an absent one
@@ -57,7 +59,8 @@ class AggSpec:
             n_long=None if absent else _ffi.ptr(self.adj.n_long),
             long_cap=0 if absent else self.adj.long_cap,
             n_dst=self.n_dst, F=self.F, b_width=bw,
-            msg_op=self.msg_op, reduce=self.reduce)
+            msg_op=self.msg_op, reduce=self.reduce,
+            self_x2=_ffi.ptr(self.self_x2), eps2=_ffi.ptr(self.eps2))
 
 
 def run_aggregate(specs: Sequence[AggSpec], device) -> List[Tensor]:
@@ -150,9 +153,19 @@ class _AggregateMany(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        """One launch.  A cell-feature matrix x usually enters several slots of the same call (the
+        self term of the upper stream, the self term of the boundary stream, the gathered operand
+        of the next dimension's boundary stream: mp/layers.py:185-192), and its gradient is the sum
+        of a transposed aggregation and the scaled self terms.  Those are folded into ONE
+        descriptor (gathered part + up to two self terms) whose result is returned in one slot,
+        None in the others -- instead of one `g * (1 + eps)` kernel per self term plus autograd's
+        add kernels (48 of the ~100 framework launches of a ZINC training step)."""
         tensors = ctx.saved_tensors
         grads: List[Optional[Tensor]] = [None] * len(tensors)
         specs, slots = [], []
+        ident = lambda t: (t.data_ptr(), tuple(t.shape), tuple(t.stride()))   # saved tensors are re-wrapped
+        selfs = {}       # ident(x) -> [(slot, g, eps)] self-term contributions waiting for a host spec
+        gathered = {}    # ident(x) -> index into specs of a gathered contribution to the same tensor
         for k, st in enumerate(ctx.streams):
             g = gs[k]
             if g is None:
@@ -162,7 +175,7 @@ class _AggregateMany(torch.autograd.Function):
             g = g.contiguous()
             if self_x is not None:
                 if need_self:
-                    grads[4 * k + 2] = g if eps is None else g * (1 + eps)
+                    selfs.setdefault(ident(self_x), []).append((4 * k + 2, g, eps))
                 if need_eps and eps is not None:
                     grads[4 * k + 3] = (g * self_x).sum().reshape(eps.shape)
             adj, op = st.adj, st.msg_op
@@ -185,6 +198,7 @@ class _AggregateMany(torch.autograd.Function):
                         s.ib = t.aux if st.ib_mode == 'aux' else t.perm
                     elif op == MSG_RELU_A_PLUS_B:
                         s.msg_op, s.B, s.ib, s.self_pre = MSG_A_MASK_RELU, B, t.aux, A
+                    gathered.setdefault(ident(A), len(specs))
                     specs.append(s)
                     slots.append(4 * k)
             if need_B:
@@ -199,8 +213,25 @@ class _AggregateMany(torch.autograd.Function):
                     s = AggSpec(adj=t, n_dst=t.n_dst, F=F, A=g, ia=t.col)
                     if op == MSG_RELU_A_PLUS_B:
                         s.msg_op, s.B, s.ib, s.self_pre = MSG_A_MASK_RELU, A, t.aux, B
+                    gathered.setdefault(ident(B), len(specs))
                     specs.append(s)
                     slots.append(4 * k + 1)
+        # fold the self terms: two per descriptor, onto a gathered contribution to the same tensor
+        # when there is one, else onto a descriptor without adjacency (zeros + self terms)
+        for key, terms in selfs.items():
+            host = gathered.get(key)
+            while terms:
+                take, terms = terms[:2], terms[2:]
+                if host is None:
+                    _, g0, _ = take[0]
+                    s = AggSpec(adj=None, n_dst=g0.size(0), F=g0.size(1))
+                    specs.append(s)
+                    slots.append(take[0][0])
+                else:
+                    s, host = specs[host], None
+                s.self_x, s.eps = take[0][1], take[0][2]
+                if len(take) == 2:
+                    s.self_x2, s.eps2 = take[1][1], take[1][2]
         if specs:
             for slot, o in zip(slots, run_aggregate(specs, ctx.device)):
                 grads[slot] = o

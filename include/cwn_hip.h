@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 3
+#define CWN_ABI_VERSION 4
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -159,6 +159,8 @@ typedef struct cwn_agg_desc {
     int32_t reduce;
     int32_t long_cap;      /* capacity of one long-row sub-list (E / CWN_LONG_ROW + 1) */
     int32_t reserved;
+    const float* self_x2;  /* [n_dst, F] or NULL: a second self term, out += (1 + *eps2) * self_x2 */
+    const float* eps2;     /* device scalar or NULL (= 0) */
 } cwn_agg_desc;
 
 int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream);
