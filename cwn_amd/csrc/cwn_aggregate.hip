@@ -30,6 +30,7 @@ struct AggBatch {
     cwn_agg_desc d[CWN_MAX_DESCS];
     int32_t blk_start[CWN_MAX_DESCS + 1];
     int32_t group[CWN_MAX_DESCS];  // lanes per destination row
+    int32_t fgroup[CWN_MAX_DESCS]; // of which feature lanes (the rest are entry slots, narrow F only)
     int32_t n;
 };
 
@@ -153,6 +154,71 @@ __device__ __forceinline__ Acc<VEC> fold_range(const cwn_agg_desc& D, int start,
     return acc;
 }
 
+// Narrow features (F <= 16: REDDIT-like inputs have ONE scalar feature per vertex): the G lanes of a
+// group are then S = G / GF entry slots x GF feature lanes, and for rows with more than
+// kSplitRow entries every slot folds every S-th entry; the S partials are combined by a fixed
+// xor tree.  One lane walking a 60-entry row alone is 15 dependent round trips (the F = 1 layer of
+// the REDDIT-like configuration took 30 us, longer than its F = 64 layers).  Rows up to kSplitRow
+// entries keep the sequential order (bit-identical to index_add_), like every row of wide layers.
+constexpr int kSplitRow = 16;
+
+struct Operands {        // the descriptor fields a fold needs, by value (registers)
+    const int32_t* ia;
+    const int32_t* ib;
+    const float* A;
+    const float* B;
+    int F, b_width;
+};
+
+template <int VEC, int OP, int RED>
+__device__ __forceinline__ Acc<VEC> fold_range_split(const Operands D, int start, int end, int G, int GF,
+                                                     int gl, const Acc<VEC>& pre) {
+    constexpr bool kUsesB = (OP != CWN_MSG_A);
+    const int F = D.F;
+    const bool b_scalar = kUsesB && D.b_width == 1;
+    const int S = G / GF, e = gl / GF, f = (gl % GF) * VEC;
+    const bool active = f < F;
+    Acc<VEC> acc = splat<VEC>(RED == CWN_REDUCE_MAX ? -FLT_MAX : 0.0f);
+    for (int base = start; base < end; base += G) {
+        const int mine = base + gl;
+        int my_ia = 0, my_ib = 0;
+        if (mine < end) {
+            my_ia = D.ia[mine];
+            if constexpr (kUsesB) my_ib = D.ib[mine];
+        }
+        const int cnt = min(G, end - base);
+        for (int tb = 0; tb < cnt; tb += 2 * S) {          // uniform trip count over the group
+            Acc<VEC> a[2], b[2];
+            bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = tb + u * S + e;
+                ok[u] = t < cnt;
+                const int ia = __shfl(my_ia, ok[u] ? t : 0, G);
+                int ib = 0;
+                if constexpr (kUsesB) ib = __shfl(my_ib, ok[u] ? t : 0, G);
+                a[u] = splat<VEC>(0.0f);
+                b[u] = splat<VEC>(0.0f);
+                if (active && ok[u]) {
+                    a[u] = ld<VEC>(D.A + (int64_t)ia * F + f);
+                    if constexpr (kUsesB)
+                        b[u] = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (ok[u]) combine<VEC, RED>(acc, message<VEC, OP>(a[u], b[u], pre));
+        }
+    }
+    for (int off = GF; off < G; off <<= 1) {               // entry slots -> slot 0, fixed tree
+        Acc<VEC> o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.v[k] = __shfl_xor(acc.v[k], off, G);
+        combine<VEC, RED>(acc, o);
+    }
+    return acc;
+}
+
 // mean / empty-max fix-up, self term, one coalesced store of the row slice
 template <int VEC, int RED>
 __device__ __forceinline__ void finish_row(const cwn_agg_desc& D, int64_t row, int f, int len,
@@ -189,7 +255,7 @@ __device__ __forceinline__ void finish_row(const cwn_agg_desc& D, int64_t row, i
 //      combined in chunk order -- deterministic, no atomics, and the kernel no longer waits for
 //      one lane group to walk a 300-entry row alone.
 template <int VEC, int OP, int RED>
-__device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nblk, int G, float* part) {
+__device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nblk, int G, int GF, float* part) {
     const int F = D.F;
     const int R = kThreads / G;  // lane groups (= rows in flight) per workgroup
     const int gl = threadIdx.x & (G - 1);
@@ -208,7 +274,19 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
             start = D.rowptr[row];
             end = D.rowptr[row + 1];
         }
-        if (!(has_long && end - start > CWN_LONG_ROW)) {
+        if (has_long && end - start > CWN_LONG_ROW) {
+            // left to the whole-workgroup pass below
+        } else if (GF < G && end - start > kSplitRow) {
+            const int f = (gl % GF) * VEC;
+            const bool active = f < F;
+            Acc<VEC> pre = splat<VEC>(0.0f);
+            if constexpr (OP == CWN_MSG_A_MASK_RELU) {
+                if (active) pre = ld<VEC>(D.self_pre + row * F + f);
+            }
+            const Operands ops{D.ia, D.ib, D.A, D.B, D.F, D.b_width};
+            const Acc<VEC> acc = fold_range_split<VEC, OP, RED>(ops, start, end, G, GF, gl, pre);
+            if (active && gl < GF) finish_row<VEC, RED>(D, row, f, end - start, self_scale, acc);
+        } else {
             // feature chunks of G*VEC columns (one chunk when F <= G*VEC, the common case)
             for (int f0 = 0; f0 < F; f0 += G * VEC) {
                 const int f = f0 + gl * VEC;
@@ -257,33 +335,40 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
 }
 
 template <int VEC, int OP>
-__device__ __forceinline__ void run_desc_red(const cwn_agg_desc& D, int blk, int nblk, int G, float* part) {
+__device__ __forceinline__ void run_desc_red(const cwn_agg_desc& D, int blk, int nblk, int G, int GF, float* part) {
     switch (D.reduce) {
-        case CWN_REDUCE_MEAN: run_desc<VEC, OP, CWN_REDUCE_MEAN>(D, blk, nblk, G, part); break;
-        case CWN_REDUCE_MAX: run_desc<VEC, OP, CWN_REDUCE_MAX>(D, blk, nblk, G, part); break;
-        default: run_desc<VEC, OP, CWN_REDUCE_ADD>(D, blk, nblk, G, part); break;
+        case CWN_REDUCE_MEAN: run_desc<VEC, OP, CWN_REDUCE_MEAN>(D, blk, nblk, G, GF, part); break;
+        case CWN_REDUCE_MAX: run_desc<VEC, OP, CWN_REDUCE_MAX>(D, blk, nblk, G, GF, part); break;
+        default: run_desc<VEC, OP, CWN_REDUCE_ADD>(D, blk, nblk, G, GF, part); break;
     }
 }
 
-template <int VEC>
+// NARROW: some descriptor has fewer than 8 feature lanes (F <= 16 with 16-B vectors): rows get 8
+// lanes and the entry-parallel fold; a separate instantiation so that the wide-feature kernel (every
+// layer of the molecular models) carries none of that code.
+template <int VEC, bool NARROW>
 __global__ __launch_bounds__(kThreads) void aggregate_kernel(AggBatch B) {
     __shared__ float part[kThreads * VEC];
     int di = 0;
 #pragma unroll
     for (int i = 1; i < CWN_MAX_DESCS; ++i)
         if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
-    const cwn_agg_desc& D = B.d[di];
-    const int G = B.group[di];
+    // By VALUE.  hipcc passes the batch struct through a private copy that it normally folds back
+    // into kernarg loads; with `const cwn_agg_desc& D = B.d[di]` and enough inlined uses of D (the
+    // NARROW variant) it stopped doing so and the whole 1.2-KB struct landed in scratch: every
+    // descriptor field became a scratch load and the kernel ran 20x slower (measured: 23 -> 580 us).
+    const cwn_agg_desc D = B.d[di];
+    const int G = B.group[di], GF = NARROW ? B.fgroup[di] : G;
     const int blk = blockIdx.x - B.blk_start[di];
     const int nblk = B.blk_start[di + 1] - B.blk_start[di];
     switch (D.msg_op) {
-        case CWN_MSG_A_PLUS_B: run_desc_red<VEC, CWN_MSG_A_PLUS_B>(D, blk, nblk, G, part); break;
-        case CWN_MSG_A_TIMES_B: run_desc_red<VEC, CWN_MSG_A_TIMES_B>(D, blk, nblk, G, part); break;
+        case CWN_MSG_A_PLUS_B: run_desc_red<VEC, CWN_MSG_A_PLUS_B>(D, blk, nblk, G, GF, part); break;
+        case CWN_MSG_A_TIMES_B: run_desc_red<VEC, CWN_MSG_A_TIMES_B>(D, blk, nblk, G, GF, part); break;
         case CWN_MSG_RELU_A_PLUS_B:
-            run_desc<VEC, CWN_MSG_RELU_A_PLUS_B, CWN_REDUCE_ADD>(D, blk, nblk, G, part); break;
+            run_desc<VEC, CWN_MSG_RELU_A_PLUS_B, CWN_REDUCE_ADD>(D, blk, nblk, G, GF, part); break;
         case CWN_MSG_A_MASK_RELU:
-            run_desc<VEC, CWN_MSG_A_MASK_RELU, CWN_REDUCE_ADD>(D, blk, nblk, G, part); break;
-        default: run_desc_red<VEC, CWN_MSG_A>(D, blk, nblk, G, part); break;
+            run_desc<VEC, CWN_MSG_A_MASK_RELU, CWN_REDUCE_ADD>(D, blk, nblk, G, GF, part); break;
+        default: run_desc_red<VEC, CWN_MSG_A>(D, blk, nblk, G, GF, part); break;
     }
 }
 
@@ -349,7 +434,8 @@ extern "C" int cwn_aggregate_f32(const cwn_agg_desc* descs, int n, cwn_stream_t 
     int64_t blocks = 0;
     for (int i = 0; i < n; ++i) {
         B.d[i] = descs[i];
-        B.group[i] = pick_group(descs[i].F, vec);
+        B.fgroup[i] = pick_group(descs[i].F, vec);
+        B.group[i] = B.fgroup[i] < 8 ? 8 : B.fgroup[i];     // narrow features: 8 lanes per row anyway
         const int rows_per_block = kThreads / B.group[i];
         B.blk_start[i] = (int32_t)blocks;
         blocks += (descs[i].n_dst + rows_per_block - 1) / rows_per_block;
@@ -359,9 +445,17 @@ extern "C" int cwn_aggregate_f32(const cwn_agg_desc* descs, int n, cwn_stream_t 
     if (blocks == 0) return CWN_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((unsigned)blocks), block(kThreads);
-    if (vec == 4) aggregate_kernel<4><<<grid, block, 0, stream>>>(B);
-    else if (vec == 2) aggregate_kernel<2><<<grid, block, 0, stream>>>(B);
-    else aggregate_kernel<1><<<grid, block, 0, stream>>>(B);
+    bool narrow = false;
+    for (int i = 0; i < n; ++i) narrow = narrow || B.fgroup[i] < B.group[i];
+    if (narrow) {
+        if (vec == 4) aggregate_kernel<4, true><<<grid, block, 0, stream>>>(B);
+        else if (vec == 2) aggregate_kernel<2, true><<<grid, block, 0, stream>>>(B);
+        else aggregate_kernel<1, true><<<grid, block, 0, stream>>>(B);
+    } else {
+        if (vec == 4) aggregate_kernel<4, false><<<grid, block, 0, stream>>>(B);
+        else if (vec == 2) aggregate_kernel<2, false><<<grid, block, 0, stream>>>(B);
+        else aggregate_kernel<1, false><<<grid, block, 0, stream>>>(B);
+    }
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 

@@ -1344,3 +1344,41 @@ def test_flat_adam_matches_torch_adam():
     # parameters are views of one buffer, modules see the updates
     lo, hi = opt.flat_p.data_ptr(), opt.flat_p.data_ptr() + 4 * opt.flat_p.numel()
     assert all(lo <= p.data_ptr() < hi for p in pa)
+
+
+@pytest.mark.parametrize('F', [1, 2, 3, 4, 8, 16])
+@pytest.mark.parametrize('op', ['id', 'plus'])
+def test_narrow_feature_medium_rows_entry_parallel(F, op):
+    """Narrow features: rows with 17..64 entries are folded by several lanes (entry slots) and
+    combined by a fixed tree -- equal to the sequential sum up to fp32 re-association, exact on
+    integers, deterministic; rows up to 16 entries stay bit-identical to index_add_."""
+    from cwn_amd import ops
+    from cwn_amd.csr import Adjacency
+    g = torch.Generator().manual_seed(F * 3 + len(op))
+    n_dst, n_src, n_aux = 400, 300, 50
+    deg = torch.randint(0, 65, (n_dst,), generator=g)
+    deg[::7] = torch.randint(0, 17, (deg[::7].numel(),), generator=g)       # some short rows
+    dst = torch.repeat_interleave(torch.arange(n_dst), deg)
+    dst = dst[torch.randperm(dst.numel(), generator=g)]
+    src = torch.randint(0, n_src, (dst.numel(),), generator=g)
+    aux = torch.randint(0, n_aux, (dst.numel(),), generator=g)
+    idx = torch.stack([src, dst])
+    x = torch.randn(n_src, F, generator=g)
+    ua = torch.randn(n_aux, F, generator=g)
+    adj = Adjacency.from_index(idx.to(DEV), n_dst, n_src, aux.to(DEV), n_aux)
+    kw = {} if op == 'id' else dict(msg_op=ops.MSG_A_PLUS_B, B=ua.to(DEV))
+    got = ops.aggregate(adj, n_dst, x.to(DEV), **kw)
+    msg = x[src] if op == 'id' else x[src] + ua[aux]
+    ref64 = torch.zeros(n_dst, F, dtype=torch.float64).index_add_(0, dst, msg.double())
+    torch.testing.assert_close(cpu(got).double(), ref64, rtol=1e-5, atol=1e-5)
+    seq = torch.zeros(n_dst, F).index_add_(0, dst, msg)
+    short = deg <= 16
+    assert torch.equal(cpu(got)[short], seq[short])              # sequential order kept
+    assert torch.equal(got, ops.aggregate(adj, n_dst, x.to(DEV), **kw))   # deterministic
+    xi = torch.randint(-5, 6, (n_src, F), generator=g).float()
+    goti = ops.aggregate(adj, n_dst, xi.to(DEV))
+    assert torch.equal(cpu(goti), torch.zeros(n_dst, F).index_add_(0, dst, xi[src]))
+    for red in ('mean', 'max'):
+        gr = ops.aggregate(adj, n_dst, xi.to(DEV), reduce=red)
+        assert torch.equal(cpu(gr), O.scatter_rows(xi[src], dst, n_dst, red)) or red == 'mean'
+        torch.testing.assert_close(cpu(gr), O.scatter_rows(xi[src], dst, n_dst, red), rtol=1e-6, atol=1e-6)
