@@ -261,19 +261,20 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
     const int gl = threadIdx.x & (G - 1);
     const int gq = threadIdx.x / G;
     const bool has_long = D.long_rows != nullptr && D.n_long != nullptr && D.rowptr != nullptr;
-    int n_long = 0;
-    if (has_long) {
-#pragma unroll
-        for (int p = 0; p < CWN_LONG_PARTS; ++p) n_long += D.n_long[p];
-    }
     const float self_scale = 1.0f + (D.eps != nullptr ? *D.eps : 0.0f);
     const int64_t row = (int64_t)blk * R + gq;
+    int start = 0, end = 0;
+    if (row < D.n_dst && D.rowptr != nullptr) {
+        start = D.rowptr[row];
+        end = D.rowptr[row + 1];
+    }
+    // The long-row counters are only needed after the regular rows.  Loaded here as a VECTOR load
+    // (per-lane index) issued AFTER the row pointers: vector loads return in order, so waiting for
+    // the row pointers does not wait for these, whereas a scalar load joins the kernel-argument
+    // loads in the one out-of-order scalar counter and put a global round trip (~0.5-1 us) in front
+    // of every workgroup's first row.
+    const int nl_lane = has_long ? D.n_long[threadIdx.x & (CWN_LONG_PARTS - 1)] : 0;
     if (row < D.n_dst) {  // whole groups take the branch together (G divides 64)
-        int start = 0, end = 0;
-        if (D.rowptr != nullptr) {
-            start = D.rowptr[row];
-            end = D.rowptr[row + 1];
-        }
         if (has_long && end - start > CWN_LONG_ROW) {
             // left to the whole-workgroup pass below
         } else if (GF < G && end - start > kSplitRow) {
@@ -300,9 +301,17 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
             }
         }
     }
+    int n_long = 0, nl[CWN_LONG_PARTS];
+#pragma unroll
+    for (int p = 0; p < CWN_LONG_PARTS; ++p) {
+        nl[p] = __builtin_amdgcn_readlane(nl_lane, p);
+        n_long += nl[p];
+    }
     for (int li = blk; li < n_long; li += nblk) {  // uniform over the workgroup
         int p = 0, k = li;
-        while (k >= D.n_long[p]) k -= D.n_long[p++];  // li-th entry of the concatenated sub-lists
+#pragma unroll
+        for (int q = 0; q < CWN_LONG_PARTS - 1; ++q)     // li-th entry of the concatenated sub-lists
+            if (p == q && k >= nl[q]) { k -= nl[q]; ++p; }
         const int64_t lrow = D.long_rows[(int64_t)p * D.long_cap + k];
         const int start = D.rowptr[lrow], end = D.rowptr[lrow + 1];
         const int chunk = (((end - start + R - 1) / R) + 3) & ~3;
