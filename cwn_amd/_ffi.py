@@ -21,7 +21,7 @@ ABI_VERSION = 4
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
-           'cwn_gemm_tn_f32', 'cwn_adam_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
+           'cwn_gemm_tn_f32', 'cwn_adam_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
 
 class CsrDesc(C.Structure):
@@ -133,6 +133,9 @@ def lib():
     L.cwn_adam_f32.restype = C.c_int
     L.cwn_adam_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.cwn_embedding_bwd_f32.restype = C.c_int
+    L.cwn_embedding_bwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_int64, C.c_void_p]
     L.cwn_lift_create.restype = C.c_void_p
     L.cwn_lift_create.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
     L.cwn_lift_size.restype = C.c_int64

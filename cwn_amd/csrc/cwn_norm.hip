@@ -369,3 +369,60 @@ extern "C" int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_
                                                                                  eps, weight_decay, step);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
+
+// ---- embedding backward: dW[v, :] += sum over the cells that looked row v up of g[cell, :] ----------
+// (torch.nn.Embedding / OGB Atom-BondEncoder tables: v_embed_init, e_embed_init of
+// mp/molec_models.py:44-52, 237-245.)  The tables are tiny (28 x 128, 173 x 64) and a few rows take
+// almost every lookup (most atoms are carbon), so a transposed CSR would have rows of 10^4 entries
+// and same-address global atomics would serialise: every workgroup accumulates its band of cells
+// into a private copy of the WHOLE table in LDS (ds_add_f32), then adds the non-zero rows to dW
+// once.  fp32 atomics: the order of the band partials varies run to run (like the dW of the Linear
+// layers).
+namespace {
+
+constexpr int kEmbBand = 128;    // cells per workgroup (ZINC-128: 25 + 26 workgroups; 512 left most CUs idle)
+
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ g,
+                                                            const int64_t* __restrict__ src,
+                                                            float* __restrict__ dW, int64_t n_rows, int cols,
+                                                            int H, int64_t V) {
+    extern __shared__ float table[];          // [V][H]
+    const int64_t total = V * H;
+    for (int64_t i = threadIdx.x; i < total; i += 256) table[i] = 0.f;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * kEmbBand;
+    const int64_t r1 = r0 + kEmbBand < n_rows ? r0 + kEmbBand : n_rows;
+    const int lanes = H < 256 ? H : 256;      // threads walking one cell's features
+    const int per = 256 / lanes;              // cells in flight
+    const int h0 = threadIdx.x % lanes, sub = threadIdx.x / lanes;
+    if (sub < per) {
+        for (int64_t r = r0 + sub; r < r1; r += per) {
+            for (int c = 0; c < cols; ++c) {
+                int64_t v = src[r * cols + c];
+                if (v < 0 || v >= V) continue;          // flagged by the forward's plan build
+                for (int h = h0; h < H; h += lanes) atomicAdd(&table[v * H + h], g[r * H + h]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const float t = table[i];
+        if (t != 0.f) atomicAdd(dW + i, t);
+    }
+}
+
+}  // namespace
+
+extern "C" int cwn_embedding_bwd_f32(const float* g, const int64_t* src, float* dW, int64_t n_rows,
+                                     int32_t cols, int32_t H, int64_t V, cwn_stream_t stream_) {
+    if (n_rows < 0 || cols <= 0 || H <= 0 || V <= 0) return CWN_ERR_BAD_ARG;
+    if (n_rows == 0) return CWN_OK;
+    if (g == nullptr || src == nullptr || dW == nullptr) return CWN_ERR_BAD_ARG;
+    const int64_t bytes = V * H * 4;
+    if (bytes > 60 * 1024) return CWN_ERR_TOO_LARGE;       // the table must fit one workgroup's LDS
+    const int64_t blocks = (n_rows + kEmbBand - 1) / kEmbBand;
+    if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    embedding_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), (size_t)bytes, (hipStream_t)stream_>>>(
+        g, src, dW, n_rows, cols, H, V);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}

@@ -740,6 +740,25 @@ class InitReduceConv(torch.nn.Module):
         return ops.aggregate(adj, num_cells, boundary_x, reduce=red)
 
 
+def _embed(layer, idx: Tensor) -> Tensor:
+    """A torch.nn.Embedding, or a module holding a list of them whose outputs are summed over the
+    index columns (the OGB Atom/BondEncoder form), as one fused gather-sum (ops.embedding_sum);
+    anything else is called as it is."""
+    def plain(e):
+        return (isinstance(e, torch.nn.Embedding) and e.padding_idx is None and e.max_norm is None
+                and not e.sparse and not e.scale_grad_by_freq)
+    if idx.is_cuda and idx.numel() > 0:
+        if plain(layer) and idx.dim() == 1:
+            return ops.embedding_sum([layer.weight], idx)
+        tables = None
+        for name in ('atom_embedding_list', 'bond_embedding_list'):
+            if hasattr(layer, name):
+                tables = list(getattr(layer, name))
+        if tables is not None and idx.dim() == 2 and idx.size(1) == len(tables) and all(plain(e) for e in tables):
+            return ops.embedding_sum([e.weight for e in tables], idx)
+    return layer(idx)
+
+
 class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
     """mp/layers.py:490-547."""
 
@@ -763,7 +782,7 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
         v_params = cochain_params[0]
         e_params = cochain_params[1] if len(cochain_params) >= 2 else None
         c_params = cochain_params[2] if len(cochain_params) == 3 else None
-        vx = self.v_embed_layer(self._prepare_v_inputs(v_params))
+        vx = _embed(self.v_embed_layer, self._prepare_v_inputs(v_params))
         out = [vx]
         if e_params is None:
             assert c_params is None
@@ -772,7 +791,7 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
         reduced_ex = self.init_reduce(vx, e_params.boundary_index, n_e)
         ex = reduced_ex
         if e_params.x is not None:
-            ex = self.e_embed_layer(self._prepare_e_inputs(e_params))
+            ex = _embed(self.e_embed_layer, self._prepare_e_inputs(e_params))
             assert ex.size(1) == vx.size(1)
         out.append(ex)
         if c_params is not None:

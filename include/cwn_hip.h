@@ -325,6 +325,14 @@ typedef struct cwn_collate_desc {
 
 int cwn_collate(const cwn_collate_desc* descs_host, int n, int64_t n_seg, cwn_stream_t stream);
 
+/* Backward of an embedding lookup (torch.nn.Embedding; the per-column tables of the OGB
+ * Atom/BondEncoder concatenated row-wise): dW[src[r, c], :] += g[r, :] for every cell r and index
+ * column c.  `src` is int64 [n_rows, cols] with the table offsets already added; dW is [V, H]
+ * (accumulated; the caller zeroes it) and must fit one workgroup's LDS (V * H * 4 <= 60 KiB),
+ * CWN_ERR_TOO_LARGE otherwise (callers then use the transposed aggregation). */
+int cwn_embedding_bwd_f32(const float* g, const int64_t* src, float* dW, int64_t n_rows, int32_t cols,
+                          int32_t H, int64_t V, cwn_stream_t stream);
+
 /* torch.optim.Adam's update (no amsgrad; weight_decay is the L2 form) for a whole model in one
  * launch: parameters p, gradients g and the moments m, v are each ONE contiguous fp32 buffer of n
  * elements (16-B aligned).  `step` is a device int32 holding the 1-based step number (the caller

@@ -1382,3 +1382,27 @@ def test_narrow_feature_medium_rows_entry_parallel(F, op):
         gr = ops.aggregate(adj, n_dst, xi.to(DEV), reduce=red)
         assert torch.equal(cpu(gr), O.scatter_rows(xi[src], dst, n_dst, red)) or red == 'mean'
         torch.testing.assert_close(cpu(gr), O.scatter_rows(xi[src], dst, n_dst, red), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('dims', [(28,), (4,), (119, 5, 12, 12, 10, 6, 6, 2, 2), (5, 6, 2)])
+def test_embedding_sum_matches_torch_embedding(dims):
+    """Forward bit-identical to the sum of torch.nn.Embedding outputs (same order); backward equal
+    to embedding_backward up to fp32 re-association of the very long table rows."""
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(sum(dims))
+    N, H = 3165, 64
+    tables = [torch.randn(d, H, generator=g).to(DEV).requires_grad_() for d in dims]
+    ref_tables = [t.detach().clone().requires_grad_() for t in tables]
+    idx = torch.stack([torch.randint(0, d, (N,), generator=g) for d in dims], 1).to(DEV)
+    out = ops.embedding_sum(tables, idx if len(dims) > 1 else idx[:, 0])
+    ref = sum(torch.nn.functional.embedding(idx[:, c], ref_tables[c]) for c in range(len(dims)))
+    assert torch.equal(out, ref)
+    w = torch.randn(N, H, generator=g).to(DEV)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    for t, r in zip(tables, ref_tables):
+        torch.testing.assert_close(t.grad, r.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(r.grad.abs().max())))
+    with pytest.raises(IndexError):
+        bad = idx.clone()
+        bad[3, 0] = dims[0]
+        ops.embedding_sum(tables, bad if len(dims) > 1 else bad[:, 0])
