@@ -16,12 +16,12 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
-           'cwn_gemm_tn_f32', 'cwn_adam_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
+           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
 
 class CsrDesc(C.Structure):
@@ -129,7 +129,9 @@ def lib():
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [C.POINTER(NormDesc), C.c_int, C.c_void_p]
     L.cwn_gemm_tn_f32.restype = C.c_int
-    L.cwn_gemm_tn_f32.argtypes = [C.POINTER(GemmTnDesc), C.c_int, C.c_void_p]
+    L.cwn_gemm_tn_f32.argtypes = [C.POINTER(GemmTnDesc), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cwn_gemm_tn_workspace_bytes.restype = C.c_size_t
+    L.cwn_gemm_tn_workspace_bytes.argtypes = [C.POINTER(GemmTnDesc), C.c_int]
     L.cwn_adam_f32.restype = C.c_int
     L.cwn_adam_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
@@ -223,5 +225,21 @@ def norm_bwd_apply(descs: Sequence[NormDesc], device) -> None:
     _chunked('cwn_norm_bwd_apply_f32', NormDesc, descs, device, MAX_NORM_DESCS)
 
 
+# False: the row bands of a weight gradient are added with fp32 atomics (fastest: 1.48 ms ZINC training
+# step).  True: per-band partial tiles + a second launch that sums them in band order -- bit-reproducible
+# weight gradients for 0.14 ms more per step (17 extra launches).
+DETERMINISTIC_TN = False
+
+
 def gemm_tn(descs: Sequence[GemmTnDesc], device) -> None:
-    _chunked('cwn_gemm_tn_f32', GemmTnDesc, descs, device, MAX_DESCS)
+    L = lib()
+    s = stream_ptr(device)
+    for i in range(0, len(descs), MAX_DESCS):
+        chunk = descs[i:i + MAX_DESCS]
+        arr = (GemmTnDesc * len(chunk))(*chunk)
+        ws, nbytes = None, 0
+        if DETERMINISTIC_TN:
+            nbytes = L.cwn_gemm_tn_workspace_bytes(arr, len(chunk))
+            ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        check(L.cwn_gemm_tn_f32(arr, len(chunk), None if ws is None else ws.data_ptr(), nbytes, s),
+              'cwn_gemm_tn_f32')

@@ -12,8 +12,9 @@
 //     stride, and the MFMA fragments are 4-B reads of (row 4s + g, column j): lanes j walk
 //     consecutive words and the four lane groups g land 16 banks apart -- conflict-free without a
 //     transposition, because the reduction index m is the ROW of both tiles;
-//   * the bands are combined with fp32 atomics into dW (the caller's zeroed .grad buffer); with M
-//     ~3 k rows that is ~27 adds per element;
+//   * the bands are combined either by a second tiny launch that sums per-band partial tiles in
+//     band order into dW (workspace given: deterministic, no atomics) or with fp32 atomics
+//     straight into dW (no workspace; ~27 same-address adds per element at M ~3 k);
 //   * the normalisation + ReLU of the producing layer is applied to X on the way into LDS (the
 //     activation itself is never materialised in the forward pass);
 //   * up to CWN_MAX_DESCS weight gradients per launch.
@@ -37,6 +38,8 @@ struct TnBatch {
     int32_t tiles_n[CWN_MAX_DESCS], tiles_k[CWN_MAX_DESCS];
     int32_t vec[CWN_MAX_DESCS];
     int32_t n;
+    float* ws[CWN_MAX_DESCS];      // per-band partials [bands][N][K + K2] then [bands][N] (db), or NULL
+    int32_t bands[CWN_MAX_DESCS];
 };
 
 struct Src {                 // one logical [M, C1 + C2] operand made of up to two matrices
@@ -171,6 +174,8 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TnBatch B) {
         }
     }
     // acc[nt][kt][r] = partial dW[n0 + wn*32 + nt*16 + 4g + r][k0 + wk*32 + kt*16 + j]
+    float* const ws = B.ws[di];
+    float* const wsW = ws != nullptr ? ws + (int64_t)band * N * Ktot : nullptr;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -179,17 +184,64 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TnBatch B) {
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wn * 32 + nt * 16 + 4 * g + r;
                 const int k = k0 + wk * 32 + kt * 16 + j;
-                if (n < N && k < Ktot) atomicAdd(D.dW + (int64_t)n * D.lddw + k, acc[nt][kt][r]);
+                if (n < N && k < Ktot) {
+                    if (wsW != nullptr) wsW[(int64_t)n * Ktot + k] = acc[nt][kt][r];   // summed by tn_reduce_kernel
+                    else atomicAdd(D.dW + (int64_t)n * D.lddw + k, acc[nt][kt][r]);
+                }
             }
-    if (do_bias && threadIdx.x < kTile && n0 + (int)threadIdx.x < N) atomicAdd(D.db + n0 + threadIdx.x, bsum);
+    if (do_bias && threadIdx.x < kTile && n0 + (int)threadIdx.x < N) {
+        if (ws != nullptr) ws[(int64_t)B.bands[di] * N * Ktot + (int64_t)band * N + n0 + threadIdx.x] = bsum;
+        else atomicAdd(D.db + n0 + threadIdx.x, bsum);
+    }
+}
+
+// second stage of the deterministic form: dW[n, k] += sum over the bands (in band order) of the
+// partial tiles; db likewise.  One thread per element, bands walked four at a time.
+__global__ __launch_bounds__(kThreads) void tn_reduce_kernel(TnBatch B) {
+    const int di = blockIdx.y;
+    const cwn_gemm_tn_desc& D = B.d[di];
+    const float* ws = B.ws[di];
+    if (ws == nullptr) return;
+    const int N = D.N, Ktot = D.K + D.K2, bands = B.bands[di];
+    const int64_t nk = (int64_t)N * Ktot;
+    const int64_t total = nk + (D.db != nullptr ? N : 0);
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const bool is_b = e >= nk;
+        const float* src = is_b ? ws + (int64_t)bands * nk + (e - nk) : ws + e;
+        const int64_t stride = is_b ? N : nk;
+        float s = 0.f;
+        int b = 0;
+        for (; b + 4 <= bands; b += 4) {
+            const float t0 = src[(int64_t)b * stride], t1 = src[(int64_t)(b + 1) * stride];
+            const float t2 = src[(int64_t)(b + 2) * stride], t3 = src[(int64_t)(b + 3) * stride];
+            s = (((s + t0) + t1) + t2) + t3;
+        }
+        for (; b < bands; ++b) s += src[(int64_t)b * stride];
+        if (is_b) D.db[e - nk] += s;
+        else D.dW[(e / Ktot) * D.lddw + (e % Ktot)] += s;
+    }
 }
 
 inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15u) == 0; }
 
+inline size_t tn_ws_floats(const cwn_gemm_tn_desc& D) {
+    const size_t bands = (size_t)((D.M + kBandRows - 1) / kBandRows);
+    return bands * (size_t)D.N * (size_t)(D.K + D.K2) + bands * (size_t)D.N;
+}
+
 }  // namespace
 
-extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, cwn_stream_t stream_) {
+extern "C" size_t cwn_gemm_tn_workspace_bytes(const cwn_gemm_tn_desc* descs, int n) {
+    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return 0;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (tn_ws_floats(descs[i]) * 4 + 255) / 256 * 256;
+    return total;
+}
+
+extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* workspace, size_t ws_bytes,
+                               cwn_stream_t stream_) {
     if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return CWN_ERR_BAD_ARG;
+    if (workspace != nullptr && ws_bytes < cwn_gemm_tn_workspace_bytes(descs, n)) return CWN_ERR_WORKSPACE;
     TnBatch B{};
     B.n = n;
     int64_t blocks = 0;
@@ -211,14 +263,23 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, cwn_stream_
         B.tiles_n[i] = (D.N + kTile - 1) / kTile;
         B.tiles_k[i] = (D.K + D.K2 + kTile - 1) / kTile;
         const int64_t bands = (D.M + kBandRows - 1) / kBandRows;
+        B.bands[i] = (int32_t)bands;
         B.blk_start[i] = (int32_t)blocks;
         blocks += bands * B.tiles_n[i] * B.tiles_k[i];
         if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     }
     for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
     if (blocks == 0) return CWN_OK;
+    if (workspace != nullptr) {
+        size_t off = 0;
+        for (int i = 0; i < n; ++i) {
+            B.ws[i] = descs[i].M > 0 ? (float*)((char*)workspace + off) : nullptr;
+            off += (tn_ws_floats(descs[i]) * 4 + 255) / 256 * 256;
+        }
+    }
     hipStream_t stream = (hipStream_t)stream_;
     if (fast) gemm_tn_kernel<true><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
     else gemm_tn_kernel<false><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    if (workspace != nullptr) tn_reduce_kernel<<<dim3(64, n), dim3(kThreads), 0, stream>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 4
+#define CWN_ABI_VERSION 5
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -272,8 +272,8 @@ int cwn_norm_bwd_apply_f32(const cwn_norm_desc* descs_host, int n, cwn_stream_t 
 
 /* Weight gradient of a Linear layer on the matrix cores, accumulated:
  *     dW[n, k] += sum_m dZ[m, n] * prologue([X | X2])[m, k]          db[n] += sum_m dZ[m, n]
- * dW is [N, K + K2] (row stride lddw, torch Linear layout) and is ADDED to with fp32 atomics (the
- * M rows are split over workgroups), so it can be the .grad buffer itself; the caller zeroes it.
+ * dW is [N, K + K2] (row stride lddw, torch Linear layout) and is ADDED to (the M rows are split
+ * over workgroups whose partial tiles are then summed), so it can be the .grad buffer itself.
  * The prologue is the one of cwn_gemm_f32 (normalisation + ReLU of the producing layer). */
 typedef struct cwn_gemm_tn_desc {
     const float* dZ;         /* [M, N] row stride lddz */
@@ -291,7 +291,11 @@ typedef struct cwn_gemm_tn_desc {
     int32_t in_relu;         /* bit 0: X, bit 1: X2 */
 } cwn_gemm_tn_desc;
 
-int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs_host, int n, cwn_stream_t stream);
+/* With a workspace of cwn_gemm_tn_workspace_bytes() the row bands are combined in a fixed order by
+ * a second small launch (deterministic); with workspace == NULL they are added with fp32 atomics. */
+size_t cwn_gemm_tn_workspace_bytes(const cwn_gemm_tn_desc* descs_host, int n);
+int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs_host, int n, void* workspace, size_t workspace_bytes,
+                    cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side batching (collate): build the arrays of a ComplexBatch from a dataset that is

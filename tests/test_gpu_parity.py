@@ -1045,6 +1045,22 @@ def test_gemm_tn_weight_gradient(M, N, K, K2):
     tol = 2e-5 * max(1.0, float(ref.abs().max()))
     torch.testing.assert_close(cpu(dW).double(), ref, rtol=1e-5, atol=tol)
     torch.testing.assert_close(cpu(db).double(), dZ.double().sum(0), rtol=1e-5, atol=tol)
+    # the workspace form sums the row bands in a fixed order: bit-reproducible, and it ACCUMULATES
+    dW.zero_(); db.zero_()
+    _ffi.DETERMINISTIC_TN = True
+    first = None
+    desc = lambda: [_ffi.GemmTnDesc(dZ=dZd.data_ptr(), X=Xd.data_ptr(), X2=_ffi.ptr(X2d), in_scale=scd.data_ptr(),
+                                    in_shift=shd.data_ptr(), in_scale2=None, in_shift2=None, dW=dW.data_ptr(),
+                                    db=db.data_ptr(), M=M, lddz=N, ldx=K, ldx2=K2, lddw=K + K2, N=N, K=K, K2=K2,
+                                    in_relu=1)]
+    try:
+        _ffi.gemm_tn(desc(), DEV)
+        first = dW.clone()
+        _ffi.gemm_tn(desc(), DEV)
+    finally:
+        _ffi.DETERMINISTIC_TN = False
+    assert torch.equal(dW, 2 * first)
+    torch.testing.assert_close(cpu(first).double(), ref, rtol=1e-5, atol=tol)
 
 
 @pytest.mark.parametrize('M,N', [(2, 4), (777, 128), (3341, 64), (100, 30), (5000, 256)])
