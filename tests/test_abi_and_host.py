@@ -66,6 +66,20 @@ def test_argument_errors_without_gpu():
     d = (_ffi.CsrDesc * 1)(_ffi.CsrDesc(n_entries=10, n_dst=5))
     assert lib.cwn_csr_workspace_bytes(d, 1) > 0
     assert lib.cwn_csr_workspace_bytes(d, 99) == 0
+    # every launcher validates before it touches the device
+    assert lib.cwn_gemm_f32(None, 1, None) == 1
+    assert lib.cwn_gemm_tn_f32(None, 1, None, 0, None) == 1
+    assert lib.cwn_bn_finalize_f32(None, 1, None) == 1
+    for fn in (lib.cwn_norm_act_f32, lib.cwn_norm_bwd_reduce_f32, lib.cwn_norm_bwd_apply_f32):
+        assert fn(None, 1, None) == 1
+    assert lib.cwn_adam_f32(None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, None, None) == 1
+    assert lib.cwn_embedding_bwd_f32(None, None, None, 8, 1, 64, 28, None) == 1
+    assert lib.cwn_embedding_bwd_f32(None, None, None, 0, 1, 64, 28, None) == 0        # nothing to do
+    g = (_ffi.GemmDesc * 1)(_ffi.GemmDesc(M=4, N=8, K=300, K2=0, ldx=300, ldw=300, ldy=8))
+    assert lib.cwn_gemm_f32(g, 1, None) == 2                       # CWN_ERR_TOO_LARGE: K beyond the kernel
+    t = (_ffi.GemmTnDesc * 1)(_ffi.GemmTnDesc(M=1000, N=128, K=128, K2=128))
+    assert lib.cwn_gemm_tn_workspace_bytes(t, 1) >= 8 * (128 * 256 + 128) * 4
+    assert lib.cwn_lift_create(7, 3, None, 0, 6, 0) is None        # unknown lift kind
 
 
 def test_cpu_tensors_fail_loudly():
