@@ -355,7 +355,9 @@ def main():
                  'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(agg_us, 3),
                  'launches_per_step': L, 'share_of_step': round(L * agg_us / step_us, 3),
                  'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4)}
-        flops = 2.0 * sum(g.X.size(0) * g.W.size(0) * g.W.size(1) for g in gemms)
+        # K from the operands (W may be the whole [N, 2F] weight addressed through w_col0)
+        flops = 2.0 * sum(g.X.size(0) * g.W.size(0) * (g.X.size(1) + (g.X2.size(1) if g.X2 is not None else 0))
+                          for g in gemms)
         tf = flops / (gemm_us * 1e-6) / 1e12 if gemms else 0.0
         r_gemm = {'bound': 'mfma', 'kernel': f'gemm_kernel ({"64x64" if H <= 64 else "32x128"} tiles; grouped fp32-MFMA GEMM: coboundary-message products Y1, Y2)',
                   'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
