@@ -16,12 +16,12 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
-           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
+           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
 
 class CsrDesc(C.Structure):
@@ -135,9 +135,12 @@ def lib():
     L.cwn_adam_f32.restype = C.c_int
     L.cwn_adam_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.cwn_embedding_fwd_f32.restype = C.c_int
+    L.cwn_embedding_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     L.cwn_embedding_bwd_f32.restype = C.c_int
-    L.cwn_embedding_bwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
-                                        C.c_int64, C.c_void_p]
+    L.cwn_embedding_bwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     L.cwn_lift_create.restype = C.c_void_p
     L.cwn_lift_create.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
     L.cwn_lift_size.restype = C.c_int64

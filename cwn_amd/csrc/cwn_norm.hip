@@ -384,6 +384,8 @@ constexpr int kEmbBand = 128;    // cells per workgroup (ZINC-128: 25 + 26 workg
 
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ g,
                                                             const int64_t* __restrict__ src,
+                                                            const int64_t* __restrict__ col_off,
+                                                            const int64_t* __restrict__ col_size,
                                                             float* __restrict__ dW, int64_t n_rows, int cols,
                                                             int H, int64_t V) {
     extern __shared__ float table[];          // [V][H]
@@ -399,7 +401,8 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
         for (int64_t r = r0 + sub; r < r1; r += per) {
             for (int c = 0; c < cols; ++c) {
                 int64_t v = src[r * cols + c];
-                if (v < 0 || v >= V) continue;          // flagged by the forward's plan build
+                if (v < 0 || v >= (col_size != nullptr ? col_size[c] : V)) continue;   // flagged by the forward
+                if (col_off != nullptr) v += col_off[c];
                 for (int h = h0; h < H; h += lanes) atomicAdd(&table[v * H + h], g[r * H + h]);
             }
         }
@@ -413,8 +416,59 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int cwn_embedding_bwd_f32(const float* g, const int64_t* src, float* dW, int64_t n_rows,
-                                     int32_t cols, int32_t H, int64_t V, cwn_stream_t stream_) {
+namespace {
+
+// forward of the same lookup: out[r, :] = sum_c W[src[r, c], :], columns in order (bit-identical to
+// summing the per-column torch.nn.Embedding outputs); an index outside [0, V) sets bit 1 of the
+// sticky error word (the plan builds' flag: raised as IndexError by the host) and is skipped
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* __restrict__ W,
+                                                            const int64_t* __restrict__ src,
+                                                            const int64_t* __restrict__ col_off,
+                                                            const int64_t* __restrict__ col_size,
+                                                            float* __restrict__ out, int64_t n_rows, int cols,
+                                                            int H, int64_t V, int G, int32_t* err) {
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t r = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    if (r >= n_rows) return;
+    for (int h = 4 * gl; h < H; h += 4 * G) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < cols; ++c) {
+            int64_t v = src[r * cols + c];
+            const int64_t lim = col_size != nullptr ? col_size[c] : V;   // per TABLE, not per concatenation
+            if (v < 0 || v >= lim) {
+                if (h == 0) atomicOr(err, 2);
+                continue;
+            }
+            if (col_off != nullptr) v += col_off[c];
+            const float4 w = *reinterpret_cast<const float4*>(W + v * H + h);
+            acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+        }
+        *reinterpret_cast<float4*>(out + r * H + h) = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int cwn_embedding_fwd_f32(const float* W, const int64_t* src, const int64_t* col_off,
+                                     const int64_t* col_size, float* out, int64_t n_rows, int32_t cols,
+                                     int32_t H, int64_t V, int32_t* err_flag, cwn_stream_t stream_) {
+    if (n_rows < 0 || cols <= 0 || H <= 0 || V <= 0 || (H & 3) != 0) return CWN_ERR_BAD_ARG;
+    if (n_rows == 0) return CWN_OK;
+    if (W == nullptr || src == nullptr || out == nullptr || err_flag == nullptr) return CWN_ERR_BAD_ARG;
+    if ((((uintptr_t)W) | ((uintptr_t)out)) & 15u) return CWN_ERR_ALIGN;
+    int G = 1;
+    while (G < H / 4 && G < 64) G <<= 1;
+    const int64_t blocks = (n_rows + 256 / G - 1) / (256 / G);
+    if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    if ((col_off == nullptr) != (col_size == nullptr)) return CWN_ERR_BAD_ARG;
+    embedding_fwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(
+        W, src, col_off, col_size, out, n_rows, cols, H, V, G, err_flag);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int cwn_embedding_bwd_f32(const float* g, const int64_t* src, const int64_t* col_off,
+                                     const int64_t* col_size, float* dW, int64_t n_rows, int32_t cols,
+                                     int32_t H, int64_t V, cwn_stream_t stream_) {
     if (n_rows < 0 || cols <= 0 || H <= 0 || V <= 0) return CWN_ERR_BAD_ARG;
     if (n_rows == 0) return CWN_OK;
     if (g == nullptr || src == nullptr || dW == nullptr) return CWN_ERR_BAD_ARG;
@@ -423,6 +477,6 @@ extern "C" int cwn_embedding_bwd_f32(const float* g, const int64_t* src, float* 
     const int64_t blocks = (n_rows + kEmbBand - 1) / kEmbBand;
     if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     embedding_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), (size_t)bytes, (hipStream_t)stream_>>>(
-        g, src, dW, n_rows, cols, H, V);
+        g, src, col_off, col_size, dW, n_rows, cols, H, V);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

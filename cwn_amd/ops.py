@@ -322,12 +322,12 @@ _arange_cache = {}
 def embedding_sum(weights: Sequence[Tensor], idx: Tensor) -> Tensor:
     """out[i] = sum_c weights[c][idx[i, c]] -- torch.nn.Embedding (one column: v_embed_init /
     e_embed_init of mp/molec_models.py:44-52) and the OGB Atom/BondEncoder form (a sum of one
-    embedding per integer feature column) as ONE fused gather-sum launch over a concatenated table;
-    the backward is the transposed segmented sum (each table row collects the cells that use it:
-    very long rows, folded by whole workgroups) instead of torch's sort-based
-    embedding_backward (154 us per table at ZINC size, 20 % of the training step).
-    Summation order per cell is c = 0, 1, ...: bit-identical to the Python `sum(...)` of the
-    encoders."""
+    embedding per integer feature column) as ONE gather-sum launch over the concatenated tables
+    (cwn_embedding_fwd_f32), and a backward that accumulates the whole table per workgroup in LDS
+    (cwn_embedding_bwd_f32) instead of torch's sort-based embedding_backward (154 us per table at
+    ZINC size, 20 % of the training step).  Summation order per cell is c = 0, 1, ...:
+    bit-identical to the Python `sum(...)` of the encoders.  An index outside its table raises
+    IndexError (at the next validated plan build / csr.check_errors under stream capture)."""
     _ffi.require_gpu(idx, 'idx')
     if idx.dtype != torch.long:
         raise TypeError('index must be int64')
@@ -336,71 +336,74 @@ def embedding_sum(weights: Sequence[Tensor], idx: Tensor) -> Tensor:
     N, Cn = idx.shape
     if len(weights) != Cn:
         raise ValueError(f'{Cn} index columns for {len(weights)} embedding tables')
-    dev = idx.device
-    aux, n_aux = None, 0
-    if Cn == 1:
-        W, src = weights[0], idx.reshape(-1)
-    else:
-        W = torch.cat(list(weights), 0)
-        key = ('offs', tuple(int(w.size(0)) for w in weights), dev)
-        hit = _arange_cache.get(key)
-        if hit is None:
-            dims = [int(w.size(0)) for w in weights]
-            hit = (torch.tensor([sum(dims[:c]) for c in range(Cn)], dtype=torch.long, device=dev),
-                   torch.tensor(dims, dtype=torch.long, device=dev))
-            _arange_cache[key] = hit
-        offs, sizes = hit
+    H = int(weights[0].size(1))
+    V = sum(int(w.size(0)) for w in weights)
+    if H % 4 != 0 or V * H * 4 > 60 * 1024:
+        # a table too wide / too large for the dedicated kernels: generic aggregation over a plan
+        W = weights[0] if Cn == 1 else torch.cat(list(weights), 0)
+        offs = torch.tensor([sum(int(w.size(0)) for w in weights[:c]) for c in range(Cn)],
+                            dtype=torch.long, device=idx.device)
         src = (idx + offs).reshape(-1)
-        # per-table range check, on the device and without a sync: the plan build validates its
-        # auxiliary index, and min(idx, dims[c] - 1 - idx) is negative exactly when idx is outside
-        # ITS table (the offset index alone would silently land in a neighbouring table)
-        aux, n_aux = torch.minimum(idx, sizes - 1 - idx).reshape(-1), max(int(w.size(0)) for w in weights)
-    key = ('dst', N, Cn, dev)
-    dst = _arange_cache.get(key)
-    if dst is None:
-        dst = torch.arange(N, device=dev).repeat_interleave(Cn)
-        if len(_arange_cache) > 64:
-            _arange_cache.clear()
-        _arange_cache[key] = dst
-    src2 = src.view(N, Cn)
-    if int(W.size(0)) * int(W.size(1)) * 4 <= 60 * 1024:
-        return _EmbeddingSum.apply(src2, dst, aux, n_aux, int(W.size(0)), *weights)
-    # a table too large for the LDS-accumulating backward: generic transposed aggregation
-    # (unbuilt: aggregate_many builds the plan together with its transpose in one call)
-    adj = Adjacency.from_index(torch.stack([src, dst]), N, int(W.size(0)), aux, n_aux, build=False)
-    return aggregate(adj, N, W)
+        dst = torch.arange(N, device=idx.device).repeat_interleave(Cn)
+        adj = Adjacency.from_index(torch.stack([src, dst]), N, V, build=False)
+        return aggregate(adj, N, W)
+    return _EmbeddingSum.apply(idx.contiguous(), *weights)
 
 
 class _EmbeddingSum(torch.autograd.Function):
-    """Forward: the fused gather-sum (one plan build + one aggregation launch).  Backward:
-    cwn_embedding_bwd_f32 into one zeroed buffer, handed back as per-table views (or added into the
-    parameters' .grad directly when they are allocated)."""
+    """Forward: cwn_embedding_fwd_f32.  Backward: cwn_embedding_bwd_f32 into one zeroed buffer,
+    handed back as per-table views (or added into the parameters' .grad directly when they are
+    allocated)."""
 
     @staticmethod
-    def forward(ctx, src2, dst, aux, n_aux, V, *weights):
+    def _columns(weights, dev):
+        """(col_off, col_size) device arrays of the table layout, cached; (None, None) for one."""
+        if len(weights) == 1:
+            return None, None
+        dims = tuple(int(w.size(0)) for w in weights)
+        key = ('cols', dims, dev)
+        hit = _arange_cache.get(key)
+        if hit is None:
+            if len(_arange_cache) > 64:
+                _arange_cache.clear()
+            hit = (torch.tensor([sum(dims[:c]) for c in range(len(dims))], dtype=torch.long, device=dev),
+                   torch.tensor(dims, dtype=torch.long, device=dev))
+            _arange_cache[key] = hit
+        return hit
+
+    @staticmethod
+    def forward(ctx, idx, *weights):
+        from .csr import _err_flag, VALIDATE_INDICES, check_errors
+        dev = idx.device
         W = weights[0] if len(weights) == 1 else torch.cat([w.detach() for w in weights], 0)
         W = _f32c(W.detach(), 'embedding table')
-        N = src2.size(0)
-        adj = Adjacency.from_index(torch.stack([src2.reshape(-1), dst]), N, V, aux, n_aux)
-        out, = run_aggregate([AggSpec(adj=adj, n_dst=N, F=W.size(1), A=W, ia=adj.col)], W.device)
-        ctx.save_for_backward(src2)
-        ctx.meta = (V, W.size(1), [int(w.size(0)) for w in weights])
+        off, size = _EmbeddingSum._columns(weights, dev)
+        N, Cn = idx.shape
+        out = torch.empty(N, W.size(1), dtype=torch.float32, device=dev)
+        _ffi.check(_ffi.lib().cwn_embedding_fwd_f32(
+            W.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), out.data_ptr(), N, Cn, W.size(1),
+            W.size(0), _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)), 'cwn_embedding_fwd_f32')
+        if VALIDATE_INDICES and not torch.cuda.is_current_stream_capturing():
+            check_errors(dev)          # one sync, as a validated plan build does; IndexError on a bad index
+        ctx.save_for_backward(idx)
+        ctx.meta = (int(W.size(0)), int(W.size(1)), [int(w.size(0)) for w in weights])
         ctx.tables = weights
         return out
 
     @staticmethod
     def backward(ctx, g):
-        src2, = ctx.saved_tensors
+        idx, = ctx.saved_tensors
         V, H, sizes = ctx.meta
         g = g.contiguous()
+        off, size = _EmbeddingSum._columns(ctx.tables, g.device)
         dW = torch.zeros(V, H, dtype=torch.float32, device=g.device)
-        _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(g.data_ptr(), src2.data_ptr(), dW.data_ptr(), src2.size(0),
-                                                     src2.size(1), H, V, _ffi.stream_ptr(g.device)),
-                   'cwn_embedding_bwd_f32')
-        views, off = [], 0
+        _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
+            g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), dW.data_ptr(), idx.size(0),
+            idx.size(1), H, V, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
+        views, o = [], 0
         for n in sizes:
-            views.append(dW[off:off + n])
-            off += n
+            views.append(dW[o:o + n])
+            o += n
         grads, acc_dst, acc_src = [], [], []
         for w, v in zip(ctx.tables, views):
             t = _grad_target(w)
@@ -412,7 +415,7 @@ class _EmbeddingSum(torch.autograd.Function):
                 grads.append(None)
         if acc_dst:
             torch._foreach_add_(acc_dst, acc_src)
-        return (None, None, None, None, None) + tuple(grads)
+        return (None,) + tuple(grads)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 5
+#define CWN_ABI_VERSION 6
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -329,13 +329,24 @@ typedef struct cwn_collate_desc {
 
 int cwn_collate(const cwn_collate_desc* descs_host, int n, int64_t n_seg, cwn_stream_t stream);
 
-/* Backward of an embedding lookup (torch.nn.Embedding; the per-column tables of the OGB
- * Atom/BondEncoder concatenated row-wise): dW[src[r, c], :] += g[r, :] for every cell r and index
- * column c.  `src` is int64 [n_rows, cols] with the table offsets already added; dW is [V, H]
- * (accumulated; the caller zeroes it) and must fit one workgroup's LDS (V * H * 4 <= 60 KiB),
+/* Embedding lookup with a sum over index columns (torch.nn.Embedding for cols = 1; the OGB
+ * Atom/BondEncoder sum over one table per integer feature column, mp/molec_models.py:44-52, 237-245):
+ *     out[r, :] = sum_c W[col_off[c] + src[r, c], :]
+ * W is the row-wise concatenation of the tables ([V, H], H % 4 == 0); col_off / col_size are device
+ * arrays [cols] (both NULL for one table of V rows).  An index outside its OWN table sets bit 1 of
+ * *err_flag (the sticky word of cwn_csr_build; raised as IndexError by the host) and contributes
+ * nothing.  Columns are added in order: bit-identical to summing the per-column lookups. */
+int cwn_embedding_fwd_f32(const float* W, const int64_t* src, const int64_t* col_off,
+                          const int64_t* col_size, float* out, int64_t n_rows, int32_t cols, int32_t H,
+                          int64_t V, int32_t* err_flag, cwn_stream_t stream);
+
+/* Its backward: dW[col_off[c] + src[r, c], :] += g[r, :].  dW ([V, H], accumulated; the caller
+ * zeroes it) must fit one workgroup's LDS (V * H * 4 <= 60 KiB): every workgroup accumulates its
+ * band of cells into a private copy of the whole table and adds it to dW once;
  * CWN_ERR_TOO_LARGE otherwise (callers then use the transposed aggregation). */
-int cwn_embedding_bwd_f32(const float* g, const int64_t* src, float* dW, int64_t n_rows, int32_t cols,
-                          int32_t H, int64_t V, cwn_stream_t stream);
+int cwn_embedding_bwd_f32(const float* g, const int64_t* src, const int64_t* col_off,
+                          const int64_t* col_size, float* dW, int64_t n_rows, int32_t cols, int32_t H,
+                          int64_t V, cwn_stream_t stream);
 
 /* torch.optim.Adam's update (no amsgrad; weight_decay is the L2 form) for a whole model in one
  * launch: parameters p, gradients g and the moments m, v are each ONE contiguous fp32 buffer of n

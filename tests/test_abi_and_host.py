@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cwn_abi_version() == 5
+    assert lib.cwn_abi_version() == 6
     assert lib.cwn_target_arch() == b'gfx950'
     assert lib.cwn_error_string(0) == b'ok'
 
@@ -73,8 +73,9 @@ def test_argument_errors_without_gpu():
     for fn in (lib.cwn_norm_act_f32, lib.cwn_norm_bwd_reduce_f32, lib.cwn_norm_bwd_apply_f32):
         assert fn(None, 1, None) == 1
     assert lib.cwn_adam_f32(None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, None, None) == 1
-    assert lib.cwn_embedding_bwd_f32(None, None, None, 8, 1, 64, 28, None) == 1
-    assert lib.cwn_embedding_bwd_f32(None, None, None, 0, 1, 64, 28, None) == 0        # nothing to do
+    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 8, 1, 64, 28, None) == 1
+    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 0, 1, 64, 28, None) == 0   # nothing to do
+    assert lib.cwn_embedding_fwd_f32(None, None, None, None, None, 8, 1, 64, 28, None, None) == 1
     g = (_ffi.GemmDesc * 1)(_ffi.GemmDesc(M=4, N=8, K=300, K2=0, ldx=300, ldw=300, ldy=8))
     assert lib.cwn_gemm_f32(g, 1, None) == 2                       # CWN_ERR_TOO_LARGE: K beyond the kernel
     t = (_ffi.GemmTnDesc * 1)(_ffi.GemmTnDesc(M=1000, N=128, K=128, K2=128))
