@@ -587,7 +587,7 @@ def main():
             train = {'ms_per_step': round(dtt / tsteps * 1e3, 4),
                      'cells_per_s': round(float(tcells.item()) / dtt, 1), 'steps': tsteps,
                      'params': int(ts.bucket.flat.numel()),
-                     'scope': 'adjacency plans (forward + transposed), forward, L1 loss, backward, fused Adam'
+                     'scope': 'adjacency plans (forward + transposed), forward, L1 loss, backward, Adam on one flat buffer (cwn_adam_f32)'
                               + (f', one {ts.bucket.flat.numel() * 4 / 1e6:.1f} MB RCCL all-reduce of the flat '
                                  'gradient bucket' if world > 1 else '')
                               + ('; hipGraph replay' if train_graph else '; eager launches (host-bound)')}
