@@ -395,7 +395,6 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                 // the slot of this wave's 32-row band: no atomics, no zero fill, deterministic.
                 // (fp64 atomics on 2 x N addresses from ~100 workgroups per descriptor serialised
                 // at L2 and cost 20 us of a 30 us launch.)
-                static_assert(RT == 2 || true, "");
                 const int64_t slot = m_base / 32 + wm;   // RT == 2 only (host-checked): tiles align to bands
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
