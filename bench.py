@@ -356,12 +356,24 @@ def main():
                  'launches_per_step': L, 'share_of_step': round(L * agg_us / step_us, 3),
                  'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4)}
         # K from the operands (W may be the whole [N, 2F] weight addressed through w_col0)
+        # HBM bytes of the grouped GEMM from the same PMC passes (FETCH_SIZE doubled for 16-B/lane
+        # streams as MI355X_MICROARCH.md prescribes, WRITE_SIZE as is), K <= 128 wide-tile kernel
+        gemm_traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r1_pmc_fetch_write_raw.json')) as fh:
+                raw = json.load(fh).get(str(args.batch), {})
+            if WL == 'zinc' and H == 128:
+                for kname, v in raw.items():
+                    if kname.startswith('gemm_kernel<true, false, 128, 4'):
+                        gemm_traffic = int((2 * v['FETCH_SIZE_KB_avg'] + v['WRITE_SIZE_KB_avg']) * 1024)
+        except (OSError, ValueError, KeyError):
+            gemm_traffic = None
         flops = 2.0 * sum(g.X.size(0) * g.W.size(0) * (g.X.size(1) + (g.X2.size(1) if g.X2 is not None else 0))
                           for g in gemms)
         tf = flops / (gemm_us * 1e-6) / 1e12 if gemms else 0.0
         r_gemm = {'bound': 'mfma', 'kernel': f'gemm_kernel ({"64x64" if H <= 64 else "32x128"} tiles; grouped fp32-MFMA GEMM: coboundary-message products Y1, Y2)',
                   'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
-                  'frac': round(tf / MFMA_F32_PEAK_TF, 4), 'traffic': None,
+                  'frac': round(tf / MFMA_F32_PEAK_TF, 4), 'traffic': gemm_traffic,
                   'algorithmic_flops_per_launch': int(flops), 'avg_launch_us': round(gemm_us, 3),
                   'launches_per_step': L if gemms else 0, 'share_of_step': round(L * gemm_us / step_us, 3)}
         # plan build (cwn_csr_build): key + val (+ aux) int64 in, rowptr + col + perm (+ aux) int32 out
