@@ -66,6 +66,10 @@ def layer_algorithmic_bytes(stats, F, coboundary=True):
     return total
 
 
+# see cwn_amd/train.py: captures must not be invalidated by the RCCL watchdog thread (N > 1)
+CAPTURE_MODE = 'thread_local'
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -194,13 +198,13 @@ def main():
                 torch.cuda.synchronize()
                 for bi in range(nb):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                         keep = fn(bi)
                     graphs.append((g, keep))
                 # a graph launch costs ~9 us of host/queue time whatever it holds, so the steady-state
                 # loop replays ONE graph that holds a step of every distinct batch (nb steps)
                 g_all = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_all):
+                with torch.cuda.graph(g_all, capture_error_mode=CAPTURE_MODE):
                     keep_all = [fn(bi) for bi in range(nb)]
 
             def run_steps(n_steps, start=0):
@@ -287,7 +291,7 @@ def main():
                 fn()
             torch.cuda.current_stream().wait_stream(side)
             kg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(kg):
+            with torch.cuda.graph(kg, capture_error_mode=CAPTURE_MODE):
                 for _ in range(reps):
                     fn()
             kg.replay()
@@ -519,7 +523,7 @@ def main():
                 torch.cuda.synchronize()
                 for si in range(S):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=streams_[si]):
+                    with torch.cuda.graph(g, stream=streams_[si], capture_error_mode=CAPTURE_MODE):
                         keep = propagate_scope(si)
                     cgraphs.append((g, keep))
                 rounds = max(args.steps // S, 5)

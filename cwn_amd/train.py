@@ -21,6 +21,10 @@ import torch.distributed as dist
 from . import _ffi
 from .dist import FlatGradBucket
 
+# 'thread_local': a capture is only invalidated by calls of the capturing thread, not by another
+# thread of the process touching the runtime meanwhile (the RCCL watchdog of torch.distributed)
+CAPTURE_MODE = 'thread_local'
+
 _LOSSES: Dict[str, Callable] = {
     'regression': torch.nn.L1Loss(),                 # reg_criterion
     'mse_regression': torch.nn.MSELoss(),            # msereg_criterion
@@ -169,13 +173,13 @@ class TrainStep:
             self._warm = True
         g1 = torch.cuda.CUDAGraph()
         if self.world == 1:
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
                 loss = self._eager(i)
             return (g1, None, loss)
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
             loss = self._forward_backward(i)
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=g1.pool()):
+        with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
             self.opt.step()
         return (g1, g2, loss)
 
