@@ -1422,3 +1422,15 @@ def test_embedding_sum_matches_torch_embedding(dims):
         bad = idx.clone()
         bad[3, 0] = dims[0]
         ops.embedding_sum(tables, bad if len(dims) > 1 else bad[:, 0])
+
+
+def test_randomised_kernel_cross_check():
+    """tools/fuzz_kernels.py: random shapes / degree distributions / option combinations of the
+    aggregation (forward + backward), GEMM and weight-gradient GEMM kernels vs float64 torch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_kernels.py'), '30', '11'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
