@@ -267,6 +267,22 @@ def main():
         print(f'[bench] full-forward graph capture failed ({type(e).__name__}); eager', file=sys.stderr)
         torch.cuda.synchronize()
         dt_full = timed(full_forward, max(args.steps // 4, 10), max(args.warmup // 4, 3), False)
+    # secondary: the SAME propagate-scope step launched eagerly (Python + ctypes per launch, no graph):
+    # what a caller pays today when every batch has new shapes and nothing can be replayed
+    eager = None
+    if use_graph and not args.only_primary and 'eager' not in SKIP:
+        try:
+            esteps = max(args.steps // 4, 10)
+            dte = timed(propagate_scope, esteps, 3, False)
+            ecells = torch.tensor([sum(stats[(3 + i) % len(stats)]['cells'] for i in range(esteps)) * L],
+                                  device=dev, dtype=torch.float64)
+            if dist is not None:
+                dist.all_reduce(ecells)
+            eager = {'cells_per_s': round(float(ecells.item()) / dte, 1), 'ms_per_step': round(dte / esteps * 1e3, 5),
+                     'note': 'same step, one Python/ctypes call per launch and a validated (synchronising) plan '
+                             'build: host-bound; the headline replays the step from a hipGraph'}
+        except Exception as e:
+            print(f'[bench] eager leg failed: {type(e).__name__}: {e}', file=sys.stderr)
     full_steps = max(args.steps // 4, 10)
     full_cells = torch.tensor([sum(stats[i % len(stats)]['cells'] for i in range(full_steps)) * L],
                               device=dev, dtype=torch.float64)
@@ -670,7 +686,8 @@ def main():
                           'full_forward_ms': round(dt_full / full_steps * 1e3, 5),
                           'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '
                                    'MLPs + BatchNorm(eval), readout, head',
-                          'collate': collate, 'concurrent_streams': concurrent, 'train_step': train},
+                          'collate': collate, 'concurrent_streams': concurrent, 'train_step': train,
+                          'eager_launches': eager},
         }
         print(json.dumps(out))
     if dist is not None:
