@@ -514,8 +514,13 @@ def main():
         except Exception as e:
             print(f'[bench] cpu train-step baseline failed: {type(e).__name__}: {e}', file=sys.stderr)
         cpu_value = stats[0]['cells'] * L * n / el
+        try:
+            with open('/proc/cpuinfo') as fh:
+                cpu_model = next((ln.split(':', 1)[1].strip() for ln in fh if ln.startswith('model name')), 'unknown')
+        except OSError:
+            cpu_model = 'unknown'
         cpu_baseline = {'value': round(cpu_value, 1), 'unit': 'cells/s', 'cores': threads,
-                        'kind': 'port',
+                        'kind': 'port', 'cpu_model': cpu_model,
                         'sample': f'{n} passes of the same propagate scope (12 propagate calls incl. '
                                   f'up_attr gathers) over batch 0 in {el:.1f} s, torch {torch.__version__} '
                                   f'CPU, {threads} threads (fastest of {sorted(trials)}; passes/s per thread count: '

@@ -133,7 +133,7 @@ class _AggregateMany(torch.autograd.Function):
     stream: (A, B, self_x, eps)."""
 
     @staticmethod
-    def forward(ctx, streams: Tuple[Stream, ...], device, *tensors):
+    def specs_of(streams, tensors) -> List[AggSpec]:
         specs = []
         for k, st in enumerate(streams):
             A, B, self_x, eps = tensors[4 * k: 4 * k + 4]
@@ -146,7 +146,11 @@ class _AggregateMany(torch.autograd.Function):
                     s.B = B
                     s.ib = st.adj.aux if st.ib_mode == 'aux' else st.adj.perm
             specs.append(s)
-        outs = run_aggregate(specs, device)
+        return specs
+
+    @staticmethod
+    def forward(ctx, streams: Tuple[Stream, ...], device, *tensors):
+        outs = run_aggregate(_AggregateMany.specs_of(streams, tensors), device)
         ctx.streams, ctx.device = streams, device
         ctx.save_for_backward(*tensors)
         return tuple(outs)
@@ -262,6 +266,9 @@ def aggregate_many(streams: Sequence[Stream]) -> List[Tensor]:
                 todo += [a for a in (st.adj._t_src, st.adj._t_aux) if a is not None and not a.built]
     if todo:
         build_many(todo)
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in flat)):
+        # inference: no autograd node to build (Function.apply alone is ~15 us of host time)
+        return run_aggregate(_AggregateMany.specs_of(streams, flat), device)
     return list(_AggregateMany.apply(tuple(streams), device, *flat))
 
 
@@ -630,4 +637,6 @@ def gemm_many(gemms: Sequence[Gemm]) -> List[Tensor]:
         if gm.in_scale is not None and torch.is_grad_enabled() and gm.X.requires_grad:
             raise NotImplementedError('the input-affine prologue has no backward; apply it outside')
         flat += [gm.X, gm.X2, gm.W, gm.bias]
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in flat)):
+        return run_gemm(gemms, device)
     return list(_GemmMany.apply(tuple(gemms), device, *flat))
