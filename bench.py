@@ -532,7 +532,8 @@ def main():
     # secondary: independent batches overlapped on the GPU (serving-style): S streams, each replaying
     # the step graph of its own batch; same kernels, same per-step work, K steps in total
     concurrent = None
-    if use_graph and not args.only_primary and len(batches) >= 2 and 'concurrent' not in SKIP:
+    # (single-GPU leg: at N > 1 the whole-job number already comes from N processes side by side)
+    if use_graph and not args.only_primary and len(batches) >= 2 and 'concurrent' not in SKIP and world == 1:
         try:
             S = min(4, len(batches))
             with torch.no_grad():
