@@ -206,3 +206,26 @@ def test_sparse_cin_state_dict_matches_reference_names():
 def test_complex_prepare_requires_gpu():
     with pytest.raises(RuntimeError, match='GPU'):
         dummy_complex('house').prepare()
+
+
+def test_bench_contract_static():
+    """bench.py (needs a GPU to run) keeps the driver's contract: flags and the keys of its JSON line."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for flag in ('--gpus', '--steps', '--warmup'):
+        assert f"'{flag}'" in src, flag
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert f"'{key}':" in src, key
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert f"'{key}':" in src, key
+    for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert f"'{key}':" in src, key
+    # nothing under cwn_amd/ imports the oracle (it is the checker, never the product)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'cwn_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text, f
+    # and nothing that runs on the GPU box reads /root/reference
+    for f in ('bench.py', '__graft_entry__.py', os.path.join('tests', 'test_gpu_parity.py')):
+        assert '/root/reference' not in open(os.path.join(ROOT, f)).read(), f
