@@ -178,8 +178,10 @@ class DummyCellularMessagePassing(torch.nn.Module):
 # CIN (upper + lower adjacencies, per-message networks)
 # ------------------------------------------------------------------------------------------------
 class CINCochainConv(CochainMessagePassing):
-    """mp/layers.py:62-103.  The message networks are arbitrary callables on cat(x_j, attr): they
-    run on the generic path (gather kernel -> network -> segmented-reduce kernel)."""
+    """mp/layers.py:62-103.  The message networks are arbitrary callables on cat(x_j, attr): in
+    general they run on the generic path (gather kernel -> network -> segmented-reduce kernel);
+    the Linear -> ReLU -> BatchNorm form the reference's models build (mp/models.py:40-47) has a
+    fused inference path (_fused_inference)."""
 
     def __init__(self, up_msg_size: int, down_msg_size: int, msg_up_nn: Callable,
                  msg_down_nn: Callable, update_nn: Callable, eps: float = 0., train_eps: bool = False):
@@ -195,12 +197,96 @@ class CINCochainConv(CochainMessagePassing):
         self.reset_parameters()
 
     def forward(self, cochain: CochainMessagePassingParams):
+        fused = self._fused_inference(cochain)
+        if fused is not None:
+            return self.update_nn(fused)
         out_up, out_down, _ = self.propagate(cochain.up_index, cochain.down_index, None, x=cochain.x,
                                              up_attr=cochain.kwargs['up_attr'],
                                              down_attr=cochain.kwargs['down_attr'])
         out_up = out_up + (1 + self.eps) * cochain.x
         out_down = out_down + (1 + self.eps) * cochain.x
         return self.update_nn(out_up + out_down)
+
+    # ---- fused inference -------------------------------------------------------------------------
+    @staticmethod
+    def _message_form(nn):
+        """(Linear, (scale, shift) | None) when `nn` is Linear -> ReLU [-> BatchNorm1d(eval) | Identity]
+        (the conv_up / conv_down of mp/models.py:40-47), else None."""
+        if not isinstance(nn, Sequential) or len(nn) not in (2, 3):
+            return None
+        if not (isinstance(nn[0], Linear) and isinstance(nn[1], ReLU)):
+            return None
+        if len(nn) == 2:
+            return nn[0], (None, None)
+        fold = _fold_norm(nn[2], nn[0].out_features)
+        return None if fold is None else (nn[0], fold)
+
+    def _fused_plan(self, cochain: CochainMessagePassingParams):
+        """The dense products and aggregation streams of _fused_inference, unlaunched (CINConv
+        groups the plans of all dimensions into one GEMM launch + one aggregation launch), or None
+        when the fused path does not apply."""
+        x = cochain.x
+        if torch.is_grad_enabled() or x is None or not x.is_cuda:
+            return None
+        if (self.aggr_up or 'add') != 'add' or (self.aggr_down or 'add') != 'add':
+            return None
+        n, F = x.size(0), x.size(1)
+        jobs = []
+        for index, name, attr, nn in ((cochain.up_index, 'up', cochain.kwargs.get('up_attr'), self.msg_up_nn),
+                                      (cochain.down_index, 'down', cochain.kwargs.get('down_attr'), self.msg_down_nn)):
+            if index is None or (name == 'down' and not self.use_down_msg):
+                continue
+            form = self._message_form(nn)
+            if form is None or attr is None:
+                return None
+            lin = form[0]
+            attr_src, mode = _attr_operand(attr)
+            if lin.in_features != F + attr_src.size(1) or lin.out_features != F \
+                    or max(F, attr_src.size(1)) > ops.GEMM_MAX_K:
+                return None
+            jobs.append((index, name, attr_src, mode, form))
+        kw = dict(x=x, up_attr=cochain.kwargs.get('up_attr'), down_attr=cochain.kwargs.get('down_attr'))
+        gemms, adjs = [], []
+        for index, name, attr_src, mode, (lin, _) in jobs:
+            gemms += [ops.Gemm(X=x, W=lin.weight, w_col0=0, bias=lin.bias),
+                      ops.Gemm(X=attr_src, W=lin.weight, w_col0=F)]
+            size = self.__check_input_separately__(index, None)
+            adjs.append(self._adjacency(index, name, size, kw))
+        return dict(x=x, jobs=jobs, gemms=gemms, adjs=adjs)
+
+    def _fused_streams(self, plan, ys: List[Tensor]) -> List[ops.Stream]:
+        x = plan['x']
+        return [ops.Stream(adj=adj, n_dst=x.size(0), width=x.size(1), A=ys[2 * k], B=ys[2 * k + 1],
+                           msg_op=ops.MSG_RELU_A_PLUS_B, ib_mode=job[3])
+                for k, (job, adj) in enumerate(zip(plan['jobs'], plan['adjs']))]
+
+    def _fused_finish(self, plan, outs: List[Tensor]) -> Tensor:
+        """out_up + out_down (with both self terms) from the aggregated ReLU sums."""
+        total = (2 * (1 + self.eps)) * plan['x']
+        for out, adj, job in zip(outs, plan['adjs'], plan['jobs']):
+            scale, shift = job[4][1]
+            if scale is None:
+                total = total + out
+            else:
+                deg = (adj.rowptr[1:] - adj.rowptr[:-1]).to(torch.float32).unsqueeze(1)
+                total = total + out * scale + deg * shift
+        return total
+
+    def _fused_inference(self, cochain: CochainMessagePassingParams) -> Optional[Tensor]:
+        """out_up + out_down of forward() without materialising a message, when nothing needs a
+        gradient and both message networks are Linear -> ReLU -> BatchNorm(eval).  The per-ENTRY
+        network splits exactly:  BN(relu(W [x_j | a_e] + b)) = s * relu(Y1[j] + Y2[c]) + t  with
+        Y1 = X W[:, :F]^T + b, Y2 = X_attr W[:, F:]^T computed once per CELL, so
+            sum_e msg_e = s * (sum_e relu(Y1[j_e] + Y2[c_e])) + deg_i * t
+        -- one grouped GEMM launch and one aggregation launch for both adjacencies.  Returns None
+        when it does not apply (training, other network shapes, CPU tensors)."""
+        plan = self._fused_plan(cochain)
+        if plan is None:
+            return None
+        ys = ops.run_gemm(plan['gemms'], plan['x'].device) if plan['gemms'] else []
+        streams = self._fused_streams(plan, ys)
+        outs = ops.aggregate_many(streams) if streams else []
+        return self._fused_finish(plan, outs)
 
     def reset_parameters(self):
         reset(self.msg_up_nn)
@@ -231,7 +317,26 @@ class CINConv(torch.nn.Module):
 
     def forward(self, *cochain_params: CochainMessagePassingParams):
         assert len(cochain_params) <= self.max_dim + 1
-        return [self.mp_levels[d].forward(cochain_params[d]) for d in range(len(cochain_params))]
+        n = len(cochain_params)
+        # inference: the fused plans of ALL dimensions in one GEMM launch (per <= 8) + one aggregation
+        plans = [self.mp_levels[d]._fused_plan(cochain_params[d]) for d in range(n)]
+        if all(p is not None for p in plans):
+            gemms = [gm for p in plans for gm in p['gemms']]
+            ys = ops.run_gemm(gemms, cochain_params[0].x.device) if gemms else []
+            streams, k = [], 0
+            for d, p in enumerate(plans):
+                m = len(p['gemms'])
+                streams.append(self.mp_levels[d]._fused_streams(p, ys[k:k + m]))
+                k += m
+            flat = [st for sts in streams for st in sts]
+            outs = ops.aggregate_many(flat) if flat else []
+            res, k = [], 0
+            for d, (p, sts) in enumerate(zip(plans, streams)):
+                lvl = self.mp_levels[d]
+                res.append(lvl.update_nn(lvl._fused_finish(p, outs[k:k + len(sts)])))
+                k += len(sts)
+            return res
+        return [self.mp_levels[d].forward(cochain_params[d]) for d in range(n)]
 
 
 class EdgeCINConv(torch.nn.Module):

@@ -1434,3 +1434,48 @@ def test_randomised_kernel_cross_check():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_kernels.py'), '30', '11'],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('with_bn', [True, False])
+def test_cin_conv_fused_inference_matches_generic_path(with_bn):
+    """CINConv (mp/layers.py:62-124) with the message networks of mp/models.py:40-47
+    (Linear -> ReLU -> BatchNorm): the fused inference path (per-cell GEMMs + one aggregation + the
+    degree-weighted BatchNorm shift) against the generic gather -> network -> scatter path."""
+    from cwn_amd.layers import CINConv
+    from cwn_amd.synthetic import zinc_like_batch
+    torch.manual_seed(0)
+    F = 64
+    def net():
+        mods = [torch.nn.Linear(2 * F, F), torch.nn.ReLU()]
+        if with_bn:
+            bn = torch.nn.BatchNorm1d(F)
+            with torch.no_grad():
+                bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+            mods.append(bn)
+        return torch.nn.Sequential(*mods)
+    upd = torch.nn.Sequential(torch.nn.Linear(F, F), torch.nn.ReLU(), torch.nn.Linear(F, F), torch.nn.ReLU(),
+                              torch.nn.BatchNorm1d(F))
+    conv = CINConv(F, F, net(), net(), upd, eps=0.1, train_eps=False, max_dim=2).to(DEV).eval()
+    b = zinc_like_batch(32, seed=3, device=DEV, include_down_adj=True)
+    g = torch.Generator().manual_seed(2)
+    xs = [torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV) for d in range(3)]
+    b.set_xs(xs)
+    params = b.get_all_cochain_params(max_dim=2, include_down_features=True)
+    called = []
+    lvl = conv.mp_levels[1]
+    orig = type(lvl)._fused_finish
+    type(lvl)._fused_finish = lambda self, p, o: (called.append(1), orig(self, p, o))[1]
+    try:
+        with torch.no_grad():
+            fused = conv(*params)
+            single = conv.mp_levels[1].forward(params[1])        # the per-dimension entry point
+    finally:
+        type(lvl)._fused_finish = orig
+    assert len(called) == 4
+    torch.testing.assert_close(single, fused[1], rtol=1e-6, atol=1e-6)
+    b.set_xs([x.clone().requires_grad_() for x in xs])           # gradients wanted -> generic path
+    params = b.get_all_cochain_params(max_dim=2, include_down_features=True)
+    generic = conv(*params)
+    for d, (f, gnr) in enumerate(zip(fused, generic)):
+        torch.testing.assert_close(f, gnr.detach(), rtol=1e-4, atol=1e-4, msg=lambda m, d=d: f'dim {d}: {m}')
