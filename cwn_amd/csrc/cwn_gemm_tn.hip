@@ -19,6 +19,7 @@
 //     activation itself is never materialised in the forward pass);
 //   * up to CWN_MAX_DESCS weight gradients per launch.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "../../include/cwn_hip.h"
 
 namespace {
@@ -40,6 +41,7 @@ struct TnBatch {
     int32_t n;
     float* ws[CWN_MAX_DESCS];      // per-band partials [bands][N][K + K2] then [bands][N] (db), or NULL
     int32_t bands[CWN_MAX_DESCS];
+    int32_t dbg;       // timing experiments (CWN_TN_DBG): 1 no output, 2 no MFMA, 4 no bias sum
 };
 
 struct Src {                 // one logical [M, C1 + C2] operand made of up to two matrices
@@ -151,12 +153,13 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TnBatch B) {
             tile_load<FAST>(vz, SZ, n0, row0 + kChunk, row_hi);
             tile_load<FAST>(vx, SX, k0, row0 + kChunk, row_hi);
         }
-        if (do_bias && threadIdx.x < kTile) {
+        if (do_bias && threadIdx.x < kTile && !(B.dbg & 4)) {
             float s = 0.f;
 #pragma unroll 8
             for (int r = 0; r < kChunk; ++r) s += zt[r * kLd + threadIdx.x];
             bsum += s;
         }
+        if (!(B.dbg & 2))
 #pragma unroll
         for (int s = 0; s < kChunk / 4; ++s) {
             const int row = 4 * s + g;
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TnBatch B) {
         }
     }
     // acc[nt][kt][r] = partial dW[n0 + wn*32 + nt*16 + 4g + r][k0 + wk*32 + kt*16 + j]
+    if (B.dbg & 1) return;
     float* const ws = B.ws[di];
     float* const wsW = ws != nullptr ? ws + (int64_t)band * N * Ktot : nullptr;
 #pragma unroll
@@ -270,6 +274,8 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
     }
     for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
     if (blocks == 0) return CWN_OK;
+    static const int dbg = getenv("CWN_TN_DBG") ? atoi(getenv("CWN_TN_DBG")) : 0;
+    B.dbg = dbg;
     if (workspace != nullptr) {
         size_t off = 0;
         for (int i = 0; i < n; ++i) {
