@@ -339,6 +339,23 @@ class Complex(object):
         build_many(todo, overlap=overlap)
         return self
 
+    def forget_plans(self):
+        """Drop this complex's plans from the plan cache (the next prepare() / propagate rebuilds
+        them): what a training loop does when a batch object is refilled, without touching the
+        plans of other batches."""
+        from . import csr
+        for c in self.cochains.values():
+            for index in (c.upper_index, c.lower_index, c.boundary_index):
+                if index is not None:
+                    csr._cache.pop(id(index), None)
+                    flipped = getattr(index, '_cwn_flipped', None)
+                    if flipped is not None:
+                        csr._cache.pop(id(flipped), None)
+            pooled = getattr(getattr(c, 'batch', None), '_cwn_index', None)     # the readout's plan
+            if pooled is not None:
+                csr._cache.pop(id(pooled), None)
+        return self
+
     # ---- propagate arguments ------------------------------------------------------------------
     def get_cochain_params(self, dim: int, max_dim: int = 2, include_top_features=True,
                            include_down_features=True,

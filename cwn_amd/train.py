@@ -132,9 +132,7 @@ class TrainStep:
     def _forward_backward(self, i: int) -> torch.Tensor:
         b = self._restore(i)
         if self.rebuild_plans:
-            from . import csr
-            csr._cache.clear()
-            b.prepare(backward=True)
+            b.forget_plans().prepare(backward=True)
         self.bucket.zero_()
         pred = self.model(b)
         y = b.y.view(-1,) if self.task_type == 'classification' else b.y.view(pred.shape).to(pred.dtype)
