@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_collate',
@@ -39,7 +39,7 @@ class AggDesc(C.Structure):
                 ('long_rows', C.c_void_p), ('n_long', C.c_void_p),
                 ('n_dst', C.c_int64), ('F', C.c_int32), ('b_width', C.c_int32),
                 ('msg_op', C.c_int32), ('reduce', C.c_int32),
-                ('long_cap', C.c_int32), ('reserved', C.c_int32),
+                ('long_cap', C.c_int32), ('flags', C.c_int32),
                 ('self_x2', C.c_void_p), ('eps2', C.c_void_p)]
 
 

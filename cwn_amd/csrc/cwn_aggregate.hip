@@ -75,6 +75,24 @@ __device__ __forceinline__ Acc<VEC> splat(float x) {
     return a;
 }
 
+// Address of columns f.. of row `idx` of a row-major [*, F] fp32 matrix.  SMALL (every operand of
+// the launch lies within 4 GiB of its base pointer: CWN_AGG_SMALL_OPERANDS + the output size): a
+// 32-bit byte offset on the scalar base -- the global_load saddr form, one address register per
+// load in flight instead of two and no 64-bit multiply (quarter rate) per gathered row.
+template <bool SMALL>
+__device__ __forceinline__ const float* row_at(const float* base, int64_t idx, int F, int f) {
+    if constexpr (SMALL) {
+        const uint32_t off = ((uint32_t)idx * (uint32_t)F + (uint32_t)f) << 2;
+        return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off);
+    } else {
+        return base + idx * F + f;
+    }
+}
+template <bool SMALL>
+__device__ __forceinline__ float* row_at(float* base, int64_t idx, int F, int f) {
+    return const_cast<float*>(row_at<SMALL>(const_cast<const float*>(base), idx, F, f));
+}
+
 // message for one CSR position; `pre` is self_pre[i, f..] (mask form only)
 template <int VEC, int OP>
 __device__ __forceinline__ Acc<VEC> message(const Acc<VEC>& a, const Acc<VEC>& b, const Acc<VEC>& pre) {
@@ -103,7 +121,7 @@ __device__ __forceinline__ void combine(Acc<VEC>& acc, const Acc<VEC>& m) {
 // row into a register accumulator, in CSR order.  Every lane of the group runs every loop with
 // the same trip counts (the index fetch and the shuffles need all G lanes); lanes whose feature
 // slice starts past F (`!active`) only skip the loads.
-template <int VEC, int OP, int RED>
+template <int VEC, int OP, int RED, bool SMALL>
 __device__ __forceinline__ Acc<VEC> fold_range(const cwn_agg_desc& D, int start, int end, int G, int gl,
                                                int f, bool active, const Acc<VEC>& pre) {
     constexpr bool kUsesB = (OP != CWN_MSG_A);
@@ -130,9 +148,10 @@ __device__ __forceinline__ Acc<VEC> fold_range(const cwn_agg_desc& D, int start,
                 a[u] = splat<VEC>(0.0f);
                 b[u] = splat<VEC>(0.0f);
                 if (active) {
-                    a[u] = ld<VEC>(D.A + (int64_t)ia * F + f);
+                    a[u] = ld<VEC>(row_at<SMALL>(D.A, ia, F, f));
                     if constexpr (kUsesB)
-                        b[u] = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
+                        b[u] = b_scalar ? splat<VEC>(*row_at<SMALL>(D.B, ib, 1, 0))
+                                        : ld<VEC>(row_at<SMALL>(D.B, ib, F, f));
                 }
             }
 #pragma unroll
@@ -144,9 +163,9 @@ __device__ __forceinline__ Acc<VEC> fold_range(const cwn_agg_desc& D, int start,
             if constexpr (kUsesB) ib = __shfl(my_ib, t, G);
             Acc<VEC> a = splat<VEC>(0.0f), b = splat<VEC>(0.0f);
             if (active) {
-                a = ld<VEC>(D.A + (int64_t)ia * F + f);
+                a = ld<VEC>(row_at<SMALL>(D.A, ia, F, f));
                 if constexpr (kUsesB)
-                    b = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
+                    b = b_scalar ? splat<VEC>(*row_at<SMALL>(D.B, ib, 1, 0)) : ld<VEC>(row_at<SMALL>(D.B, ib, F, f));
             }
             combine<VEC, RED>(acc, message<VEC, OP>(a, b, pre));
         }
@@ -170,7 +189,7 @@ struct Operands {        // the descriptor fields a fold needs, by value (regist
     int F, b_width;
 };
 
-template <int VEC, int OP, int RED>
+template <int VEC, int OP, int RED, bool SMALL>
 __device__ __forceinline__ Acc<VEC> fold_range_split(const Operands D, int start, int end, int G, int GF,
                                                      int gl, const Acc<VEC>& pre) {
     constexpr bool kUsesB = (OP != CWN_MSG_A);
@@ -200,9 +219,10 @@ __device__ __forceinline__ Acc<VEC> fold_range_split(const Operands D, int start
                 a[u] = splat<VEC>(0.0f);
                 b[u] = splat<VEC>(0.0f);
                 if (active && ok[u]) {
-                    a[u] = ld<VEC>(D.A + (int64_t)ia * F + f);
+                    a[u] = ld<VEC>(row_at<SMALL>(D.A, ia, F, f));
                     if constexpr (kUsesB)
-                        b[u] = b_scalar ? splat<VEC>(D.B[ib]) : ld<VEC>(D.B + (int64_t)ib * F + f);
+                        b[u] = b_scalar ? splat<VEC>(*row_at<SMALL>(D.B, ib, 1, 0))
+                                        : ld<VEC>(row_at<SMALL>(D.B, ib, F, f));
                 }
             }
 #pragma unroll
@@ -219,10 +239,28 @@ __device__ __forceinline__ Acc<VEC> fold_range_split(const Operands D, int start
     return acc;
 }
 
-// mean / empty-max fix-up, self term, one coalesced store of the row slice
-template <int VEC, int RED>
-__device__ __forceinline__ void finish_row(const cwn_agg_desc& D, int64_t row, int f, int len,
-                                           float self_scale, Acc<VEC> acc) {
+// The self terms of a row slice ((1 + eps) x_i; in backward the two GIN self terms of a cell).  For
+// the one-operand message they are loaded BEFORE the fold, next to the row pointers they do not
+// depend on: fetched at the end they are a fourth dependent round trip (row pointers -> indices ->
+// rows -> self) of a lane group that lives for one row.  The two-operand messages set the kernel's
+// register count (72 = 7 waves per SIMD, see aggregate_kernel) and have no room for 8 more live
+// registers: they load late.
+template <int VEC> struct SelfTerms { Acc<VEC> s1, s2; };
+
+template <int VEC, int OP, bool SMALL>
+__device__ __forceinline__ SelfTerms<VEC> load_self_early(const cwn_agg_desc& D, int64_t row, int f, bool active) {
+    SelfTerms<VEC> t{splat<VEC>(0.0f), splat<VEC>(0.0f)};
+    if constexpr (OP == CWN_MSG_A) {
+        if (active && D.self_x != nullptr) t.s1 = ld<VEC>(row_at<SMALL>(D.self_x, row, D.F, f));
+        if (active && D.self_x2 != nullptr) t.s2 = ld<VEC>(row_at<SMALL>(D.self_x2, row, D.F, f));
+    }
+    return t;
+}
+
+// mean / empty-max fix-up, self terms, one coalesced store of the row slice
+template <int VEC, int OP, int RED, bool SMALL>
+__device__ __forceinline__ void finish_row(const cwn_agg_desc& D, int64_t row, int f, int len, float scale1,
+                                           Acc<VEC> acc, const SelfTerms<VEC>& self) {
     const int F = D.F;
     if constexpr (RED == CWN_REDUCE_MEAN) {
         const float cntf = (float)max(len, 1);
@@ -233,17 +271,17 @@ __device__ __forceinline__ void finish_row(const cwn_agg_desc& D, int64_t row, i
         if (len == 0) acc = splat<VEC>(0.0f);
     }
     if (D.self_x != nullptr) {
-        const Acc<VEC> s = ld<VEC>(D.self_x + row * F + f);
+        const Acc<VEC> s1 = OP == CWN_MSG_A ? self.s1 : ld<VEC>(row_at<SMALL>(D.self_x, row, F, f));
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] + self_scale * s.v[k];
+        for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] + scale1 * s1.v[k];
     }
     if (D.self_x2 != nullptr) {      // backward: the two GIN self terms of a cell, in one pass
         const float scale2 = 1.0f + (D.eps2 != nullptr ? *D.eps2 : 0.0f);
-        const Acc<VEC> s = ld<VEC>(D.self_x2 + row * F + f);
+        const Acc<VEC> s2 = OP == CWN_MSG_A ? self.s2 : ld<VEC>(row_at<SMALL>(D.self_x2, row, F, f));
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] + scale2 * s.v[k];
+        for (int k = 0; k < VEC; ++k) acc.v[k] = acc.v[k] + scale2 * s2.v[k];
     }
-    st<VEC>(D.out + row * F + f, acc);
+    st<VEC>(row_at<SMALL>(D.out, row, F, f), acc);
 }
 
 // Workgroup `blk` of the `nblk` that serve descriptor D.
@@ -254,26 +292,28 @@ __device__ __forceinline__ void finish_row(const cwn_agg_desc& D, int64_t row, i
 //      groups of the block fold R contiguous chunks of the row, the partials meet in LDS and are
 //      combined in chunk order -- deterministic, no atomics, and the kernel no longer waits for
 //      one lane group to walk a 300-entry row alone.
-template <int VEC, int OP, int RED>
+template <int VEC, int OP, int RED, bool SMALL>
 __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nblk, int G, int GF, float* part) {
     const int F = D.F;
     const int R = kThreads / G;  // lane groups (= rows in flight) per workgroup
     const int gl = threadIdx.x & (G - 1);
     const int gq = threadIdx.x / G;
     const bool has_long = D.long_rows != nullptr && D.n_long != nullptr && D.rowptr != nullptr;
-    const float self_scale = 1.0f + (D.eps != nullptr ? *D.eps : 0.0f);
     const int64_t row = (int64_t)blk * R + gq;
     int start = 0, end = 0;
     if (row < D.n_dst && D.rowptr != nullptr) {
         start = D.rowptr[row];
         end = D.rowptr[row + 1];
     }
-    // The long-row counters are only needed after the regular rows.  Loaded here as a VECTOR load
-    // (per-lane index) issued AFTER the row pointers: vector loads return in order, so waiting for
-    // the row pointers does not wait for these, whereas a scalar load joins the kernel-argument
-    // loads in the one out-of-order scalar counter and put a global round trip (~0.5-1 us) in front
-    // of every workgroup's first row.
+    // The long-row counters are only needed after the regular rows, eps at the end of a row.
+    // Loaded here as VECTOR loads (per-lane address) issued AFTER the row pointers: vector loads
+    // return in order, so waiting for the row pointers does not wait for these, whereas a scalar
+    // load joins the kernel-argument loads in the one out-of-order scalar counter and puts a global
+    // round trip (~0.5-1 us) in front of every workgroup's first row.
     const int nl_lane = has_long ? D.n_long[threadIdx.x & (CWN_LONG_PARTS - 1)] : 0;
+    int z = 0;
+    asm volatile("" : "+v"(z));  // a zero the compiler cannot fold: keeps the eps loads in VMEM
+    const float self_scale = 1.0f + (D.eps != nullptr ? D.eps[z] : 0.0f);
     if (row < D.n_dst) {  // whole groups take the branch together (G divides 64)
         if (has_long && end - start > CWN_LONG_ROW) {
             // left to the whole-workgroup pass below
@@ -282,11 +322,13 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
             const bool active = f < F;
             Acc<VEC> pre = splat<VEC>(0.0f);
             if constexpr (OP == CWN_MSG_A_MASK_RELU) {
-                if (active) pre = ld<VEC>(D.self_pre + row * F + f);
+                if (active) pre = ld<VEC>(row_at<SMALL>(D.self_pre, row, F, f));
             }
+            const SelfTerms<VEC> self = load_self_early<VEC, OP, SMALL>(D, row, f, active && gl < GF);
             const Operands ops{D.ia, D.ib, D.A, D.B, D.F, D.b_width};
-            const Acc<VEC> acc = fold_range_split<VEC, OP, RED>(ops, start, end, G, GF, gl, pre);
-            if (active && gl < GF) finish_row<VEC, RED>(D, row, f, end - start, self_scale, acc);
+            const Acc<VEC> acc = fold_range_split<VEC, OP, RED, SMALL>(ops, start, end, G, GF, gl, pre);
+            if (active && gl < GF)
+                finish_row<VEC, OP, RED, SMALL>(D, row, f, end - start, self_scale, acc, self);
         } else {
             // feature chunks of G*VEC columns (one chunk when F <= G*VEC, the common case)
             for (int f0 = 0; f0 < F; f0 += G * VEC) {
@@ -294,10 +336,11 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
                 const bool active = f < F;
                 Acc<VEC> pre = splat<VEC>(0.0f);
                 if constexpr (OP == CWN_MSG_A_MASK_RELU) {
-                    if (active) pre = ld<VEC>(D.self_pre + row * F + f);
+                    if (active) pre = ld<VEC>(row_at<SMALL>(D.self_pre, row, F, f));
                 }
-                const Acc<VEC> acc = fold_range<VEC, OP, RED>(D, start, end, G, gl, f, active, pre);
-                if (active) finish_row<VEC, RED>(D, row, f, end - start, self_scale, acc);
+                const SelfTerms<VEC> self = load_self_early<VEC, OP, SMALL>(D, row, f, active);
+                const Acc<VEC> acc = fold_range<VEC, OP, RED, SMALL>(D, start, end, G, gl, f, active, pre);
+                if (active) finish_row<VEC, OP, RED, SMALL>(D, row, f, end - start, self_scale, acc, self);
             }
         }
     }
@@ -321,9 +364,9 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
             const bool active = f < F;
             Acc<VEC> pre = splat<VEC>(0.0f);
             if constexpr (OP == CWN_MSG_A_MASK_RELU) {
-                if (active) pre = ld<VEC>(D.self_pre + lrow * F + f);
+                if (active) pre = ld<VEC>(row_at<SMALL>(D.self_pre, lrow, F, f));
             }
-            Acc<VEC> acc = fold_range<VEC, OP, RED>(D, s, e, G, gl, f, active, pre);
+            Acc<VEC> acc = fold_range<VEC, OP, RED, SMALL>(D, s, e, G, gl, f, active, pre);
             if (gq != 0) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) part[threadIdx.x * VEC + k] = acc.v[k];
@@ -336,27 +379,35 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
                     for (int k = 0; k < VEC; ++k) m.v[k] = part[(q * G + gl) * VEC + k];
                     combine<VEC, RED>(acc, m);
                 }
-                finish_row<VEC, RED>(D, lrow, f, end - start, self_scale, acc);
+                const SelfTerms<VEC> self = load_self_early<VEC, OP, SMALL>(D, lrow, f, true);
+                finish_row<VEC, OP, RED, SMALL>(D, lrow, f, end - start, self_scale, acc, self);
             }
             __syncthreads();
         }
     }
 }
 
-template <int VEC, int OP>
+template <int VEC, int OP, bool SMALL>
 __device__ __forceinline__ void run_desc_red(const cwn_agg_desc& D, int blk, int nblk, int G, int GF, float* part) {
     switch (D.reduce) {
-        case CWN_REDUCE_MEAN: run_desc<VEC, OP, CWN_REDUCE_MEAN>(D, blk, nblk, G, GF, part); break;
-        case CWN_REDUCE_MAX: run_desc<VEC, OP, CWN_REDUCE_MAX>(D, blk, nblk, G, GF, part); break;
-        default: run_desc<VEC, OP, CWN_REDUCE_ADD>(D, blk, nblk, G, GF, part); break;
+        case CWN_REDUCE_MEAN: run_desc<VEC, OP, CWN_REDUCE_MEAN, SMALL>(D, blk, nblk, G, GF, part); break;
+        case CWN_REDUCE_MAX: run_desc<VEC, OP, CWN_REDUCE_MAX, SMALL>(D, blk, nblk, G, GF, part); break;
+        default: run_desc<VEC, OP, CWN_REDUCE_ADD, SMALL>(D, blk, nblk, G, GF, part); break;
     }
 }
 
+// Registers decide this kernel's speed: the gathers are latency-bound, so throughput follows the
+// number of loads in flight = waves per SIMD x 4..8.  Measured on the same code, 73 VGPRs (6 waves)
+// vs 71 (7 waves): 6.5 vs 5.9 us at ZINC-128, 333 vs 298 us at batch 8192.  Forcing a budget with
+// amdgpu_waves_per_eu on the 64-bit-address code is not the answer (12 bytes of scratch cost more
+// than the wave gained); the SMALL addressing is: 64 VGPRs against 75, and with the attribute (it
+// also holds the SGPRs under 96) 8 waves without a spill.
 // NARROW: some descriptor has fewer than 8 feature lanes (F <= 16 with 16-B vectors): rows get 8
 // lanes and the entry-parallel fold; a separate instantiation so that the wide-feature kernel (every
 // layer of the molecular models) carries none of that code.
-template <int VEC, bool NARROW>
-__global__ __launch_bounds__(kThreads) void aggregate_kernel(AggBatch B) {
+template <int VEC, bool NARROW, bool SMALL>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(SMALL ? 8 : 1, 8)))
+void aggregate_kernel(AggBatch B) {
     __shared__ float part[kThreads * VEC];
     int di = 0;
 #pragma unroll
@@ -371,13 +422,13 @@ __global__ __launch_bounds__(kThreads) void aggregate_kernel(AggBatch B) {
     const int blk = blockIdx.x - B.blk_start[di];
     const int nblk = B.blk_start[di + 1] - B.blk_start[di];
     switch (D.msg_op) {
-        case CWN_MSG_A_PLUS_B: run_desc_red<VEC, CWN_MSG_A_PLUS_B>(D, blk, nblk, G, GF, part); break;
-        case CWN_MSG_A_TIMES_B: run_desc_red<VEC, CWN_MSG_A_TIMES_B>(D, blk, nblk, G, GF, part); break;
+        case CWN_MSG_A_PLUS_B: run_desc_red<VEC, CWN_MSG_A_PLUS_B, SMALL>(D, blk, nblk, G, GF, part); break;
+        case CWN_MSG_A_TIMES_B: run_desc_red<VEC, CWN_MSG_A_TIMES_B, SMALL>(D, blk, nblk, G, GF, part); break;
         case CWN_MSG_RELU_A_PLUS_B:
-            run_desc<VEC, CWN_MSG_RELU_A_PLUS_B, CWN_REDUCE_ADD>(D, blk, nblk, G, GF, part); break;
+            run_desc<VEC, CWN_MSG_RELU_A_PLUS_B, CWN_REDUCE_ADD, SMALL>(D, blk, nblk, G, GF, part); break;
         case CWN_MSG_A_MASK_RELU:
-            run_desc<VEC, CWN_MSG_A_MASK_RELU, CWN_REDUCE_ADD>(D, blk, nblk, G, GF, part); break;
-        default: run_desc_red<VEC, CWN_MSG_A>(D, blk, nblk, G, GF, part); break;
+            run_desc<VEC, CWN_MSG_A_MASK_RELU, CWN_REDUCE_ADD, SMALL>(D, blk, nblk, G, GF, part); break;
+        default: run_desc_red<VEC, CWN_MSG_A, SMALL>(D, blk, nblk, G, GF, part); break;
     }
 }
 
@@ -454,16 +505,29 @@ extern "C" int cwn_aggregate_f32(const cwn_agg_desc* descs, int n, cwn_stream_t 
     if (blocks == 0) return CWN_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((unsigned)blocks), block(kThreads);
-    bool narrow = false;
-    for (int i = 0; i < n; ++i) narrow = narrow || B.fgroup[i] < B.group[i];
-    if (narrow) {
-        if (vec == 4) aggregate_kernel<4, true><<<grid, block, 0, stream>>>(B);
-        else if (vec == 2) aggregate_kernel<2, true><<<grid, block, 0, stream>>>(B);
-        else aggregate_kernel<1, true><<<grid, block, 0, stream>>>(B);
-    } else {
-        if (vec == 4) aggregate_kernel<4, false><<<grid, block, 0, stream>>>(B);
-        else if (vec == 2) aggregate_kernel<2, false><<<grid, block, 0, stream>>>(B);
-        else aggregate_kernel<1, false><<<grid, block, 0, stream>>>(B);
+    bool narrow = false, small = true;
+    for (int i = 0; i < n; ++i) {
+        narrow = narrow || B.fgroup[i] < B.group[i];
+        // 32-bit byte offsets: the caller vouches for the gathered operands, the row-aligned ones
+        // (out, self_x, self_x2, self_pre: [n_dst, F]) are checked here
+        small = small && (descs[i].flags & CWN_AGG_SMALL_OPERANDS) != 0 &&
+                (uint64_t)descs[i].n_dst * (uint64_t)descs[i].F * 4u < (1ull << 32);
+    }
+    auto launch = [&](auto kernel) { kernel<<<grid, block, 0, stream>>>(B); };
+    const int variant = (vec == 4 ? 0 : vec == 2 ? 1 : 2) * 4 + (narrow ? 2 : 0) + (small ? 1 : 0);
+    switch (variant) {
+        case 0: launch(aggregate_kernel<4, false, false>); break;
+        case 1: launch(aggregate_kernel<4, false, true>); break;
+        case 2: launch(aggregate_kernel<4, true, false>); break;
+        case 3: launch(aggregate_kernel<4, true, true>); break;
+        case 4: launch(aggregate_kernel<2, false, false>); break;
+        case 5: launch(aggregate_kernel<2, false, true>); break;
+        case 6: launch(aggregate_kernel<2, true, false>); break;
+        case 7: launch(aggregate_kernel<2, true, true>); break;
+        case 8: launch(aggregate_kernel<1, false, false>); break;
+        case 9: launch(aggregate_kernel<1, false, true>); break;
+        case 10: launch(aggregate_kernel<1, true, false>); break;
+        default: launch(aggregate_kernel<1, true, true>); break;
     }
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

@@ -9,6 +9,8 @@ form.  There is no CPU path here by design; `oracle/` is the CPU checker.
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -25,6 +27,11 @@ def _f32c(t: Optional[Tensor], name: str) -> Optional[Tensor]:
     if t.dtype != torch.float32:
         raise TypeError(f'{name} must be float32 (got {t.dtype}); the engine computes in fp32')
     return t.contiguous()
+
+
+AGG_SMALL_OPERANDS = 1      # = CWN_AGG_SMALL_OPERANDS (include/cwn_hip.h)
+# tests (and CWN_AGG_WIDE=1, for A/B timing) turn this off to run the 64-bit-address kernels on small inputs
+ALLOW_SMALL_OPERANDS = os.environ.get('CWN_AGG_WIDE') != '1'
 
 
 @dataclass
@@ -50,7 +57,10 @@ class AggSpec:
         # an index with E = 0 is legal (mp/test_cell_mp.py:137-176) and behaves like an absent one
         absent = self.adj is None or self.adj.n_entries == 0
         bw = self.F if (self.B is None or self.B.size(1) == self.F) else int(self.B.size(1))
+        # gathered operands within 4 GiB of their base pointers: 32-bit row offsets in the kernel
+        small = ALLOW_SMALL_OPERANDS and all(t is None or t.numel() * 4 < (1 << 32) for t in (self.A, self.B))
         return _ffi.AggDesc(
+            flags=AGG_SMALL_OPERANDS if small else 0,
             rowptr=None if absent else self.adj.rowptr.data_ptr(),
             ia=_ffi.ptr(self.ia), ib=_ffi.ptr(self.ib), A=_ffi.ptr(self.A), B=_ffi.ptr(self.B),
             self_x=_ffi.ptr(self.self_x), eps=_ffi.ptr(self.eps), self_pre=_ffi.ptr(self.self_pre),

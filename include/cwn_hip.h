@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 6
+#define CWN_ABI_VERSION 7
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -140,6 +140,12 @@ enum { CWN_MSG_A = 0, CWN_MSG_A_PLUS_B = 1, CWN_MSG_A_TIMES_B = 2, CWN_MSG_RELU_
        CWN_MSG_A_MASK_RELU = 4 };
 enum { CWN_REDUCE_ADD = 0, CWN_REDUCE_MEAN = 1, CWN_REDUCE_MAX = 2 };
 
+/* cwn_agg_desc.flags.  SMALL_OPERANDS: the caller vouches that every element of A and of B that an
+ * index can address lies within 4 GiB of its base pointer (rows_a * F * 4 and rows_b * b_width * 4
+ * below 2^32); when all descriptors of a launch say so the kernel addresses rows with 32-bit byte
+ * offsets (one address register per load in flight instead of two).  Never required. */
+#define CWN_AGG_SMALL_OPERANDS 1
+
 typedef struct cwn_agg_desc {
     const int32_t* rowptr; /* [n_dst+1] or NULL (absent adjacency) */
     const int32_t* ia;     /* [E] row of A per CSR position */
@@ -158,7 +164,7 @@ typedef struct cwn_agg_desc {
     int32_t msg_op;
     int32_t reduce;
     int32_t long_cap;      /* capacity of one long-row sub-list (E / CWN_LONG_ROW + 1) */
-    int32_t reserved;
+    int32_t flags;         /* CWN_AGG_* bits (0: none) */
     const float* self_x2;  /* [n_dst, F] or NULL: a second self term, out += (1 + *eps2) * self_x2 */
     const float* eps2;     /* device scalar or NULL (= 0) */
 } cwn_agg_desc;

@@ -964,6 +964,46 @@ def test_long_rows_two_operand_messages_and_backward(F, op):
                                    atol=1e-5 * float(ur.grad.abs().max()))
 
 
+@pytest.mark.parametrize('F', [1, 3, 8, 64, 128, 130])
+@pytest.mark.parametrize('op', ['id', 'plus', 'times', 'relu_plus'])
+def test_wide_and_small_addressing_are_bit_identical(F, op):
+    """cwn_aggregate_f32 has two addressing variants (32-bit byte offsets when the caller sets
+    CWN_AGG_SMALL_OPERANDS, 64-bit otherwise): same arithmetic, same order -- forward and the
+    backward kernels (transposed plans, ReLU mask form) must agree bit for bit."""
+    from cwn_amd import ops
+    from cwn_amd.csr import Adjacency
+    g = torch.Generator().manual_seed(11 * F + len(op))
+    n_dst, n_src, n_aux = 300, 211, 50
+    idx, aux = _hub_index(g, n_dst, n_src, n_aux)
+    x = torch.randn(n_src, F, generator=g)
+    ua = torch.randn(n_aux, F, generator=g)
+    sx = torch.randn(n_dst, F, generator=g)
+    eps = torch.tensor([0.25])
+    w = torch.randn(n_dst, F, generator=g).to(DEV)
+    msg_op = {'id': ops.MSG_A, 'plus': ops.MSG_A_PLUS_B, 'times': ops.MSG_A_TIMES_B,
+              'relu_plus': ops.MSG_RELU_A_PLUS_B}[op]
+    res = []
+    for small in (True, False):
+        ops.ALLOW_SMALL_OPERANDS = small
+        try:
+            adj = Adjacency.from_index(idx.to(DEV), n_dst, n_src, aux.to(DEV), n_aux)
+            xg = x.to(DEV).requires_grad_()
+            ug = ua.to(DEV).requires_grad_(op in ('plus', 'relu_plus'))
+            sg = sx.to(DEV).requires_grad_()
+            got = ops.aggregate(adj, n_dst, xg, msg_op=msg_op, B=None if op == 'id' else ug,
+                                self_x=sg, eps=eps.to(DEV))
+            (got * w).sum().backward()
+            res.append([got.detach(), xg.grad, sg.grad] + ([ug.grad] if ug.requires_grad else []))
+        finally:
+            ops.ALLOW_SMALL_OPERANDS = True
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    a, b = x[idx[0]], ua[aux]
+    m = a if op == 'id' else (a + b if op == 'plus' else (a * b if op == 'times' else torch.relu(a + b)))
+    want = torch.zeros(n_dst, F).index_add_(0, idx[1], m) + 1.25 * sx
+    torch.testing.assert_close(cpu(res[0][0]), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+
+
 def test_long_rows_are_deterministic():
     from cwn_amd import ops
     from cwn_amd.csr import Adjacency

@@ -39,6 +39,7 @@ def rand_index(n_dst, n_src, n_aux):
 
 
 def check_aggregate():
+    ops.ALLOW_SMALL_OPERANDS = bool(rng.integers(0, 2))      # both addressing variants of the kernel
     n_dst, n_src, n_aux = int(rng.integers(1, 900)), int(rng.integers(1, 700)), int(rng.integers(1, 300))
     F = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 31, 32, 64, 100, 128, 130, 256]))
     idx, aux = rand_index(n_dst, n_src, n_aux)
@@ -136,6 +137,7 @@ def check_tn():
 
 
 def check_aggregate_backward():
+    ops.ALLOW_SMALL_OPERANDS = bool(rng.integers(0, 2))
     n_dst, n_src, n_aux = int(rng.integers(1, 500)), int(rng.integers(1, 400)), int(rng.integers(1, 200))
     F = int(rng.choice([1, 3, 4, 16, 64, 128]))
     idx, aux = rand_index(n_dst, n_src, n_aux)
