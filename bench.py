@@ -160,11 +160,17 @@ def main():
                                         for l in range(1, L)])
     torch.cuda.synchronize()
 
+    # CWN_BENCH_OVERLAP=1: the plan build on a side stream underneath the layer-0 message GEMMs, which
+    # do not need it (csr.build_many(overlap=True)).  Off by default: inside a hipGraph the fork/join
+    # costs more than the 10 us it hides (measured: ZINC-128 80.8 -> 89.6 us/step, MOLHIV 83.9 -> 86.5,
+    # REDDIT-like and batch 8192 unchanged); it pays in eager mode only.
+    OVERLAP_PLAN_BUILD = os.environ.get('CWN_BENCH_OVERLAP', '0') == '1'
+
     def propagate_scope(bi):
         """One step: fresh plans for the batch, then the propagate scope of every layer."""
         b, feats = batches[bi], layer_inputs[bi]
         csr._cache.clear()
-        b.prepare(max_dim=2)
+        b.prepare(max_dim=2, overlap=OVERLAP_PLAN_BUILD)
         outs = None
         for l, conv in enumerate(model.convs):
             b.set_xs(feats[l])
