@@ -229,3 +229,21 @@ def test_bench_contract_static():
     # and nothing that runs on the GPU box reads /root/reference
     for f in ('bench.py', '__graft_entry__.py', os.path.join('tests', 'test_gpu_parity.py')):
         assert '/root/reference' not in open(os.path.join(ROOT, f)).read(), f
+
+
+def test_integration_stub_structs_match_the_header():
+    """INTEGRATION.md shows the ctypes binding a maintainer of the reference would paste: its struct
+    layouts must be the library's (a stale stub corrupts memory silently)."""
+    import ctypes as C
+    import re
+    from cwn_amd import _ffi
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    found = {}
+    code = re.sub(r'#[^\n]*', '', text)
+    for name, body in re.findall(r'class (\w+)\(C\.Structure\):\s*\n\s+_fields_ = \[(.*?)\]\s*\n', code, re.S):
+        found[name] = eval('[' + body + ']', {'C': C})
+    assert {'CsrDesc', 'AggDesc'} <= set(found)
+    for name, fields in found.items():
+        assert fields == list(getattr(_ffi, name)._fields_), name
+    m = re.search(r'_L\.cwn_abi_version\(\) == (\d+)', text)
+    assert m and int(m.group(1)) == _ffi.ABI_VERSION

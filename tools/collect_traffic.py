@@ -48,15 +48,20 @@ def main():
         f, w = one_pass('FETCH_SIZE', b, 'zinc'), one_pass('WRITE_SIZE', b, 'zinc')
         raw[str(b)] = {k: {'FETCH_SIZE_KB_avg': round(f[k][0], 1), 'launches': f[k][1],
                            'WRITE_SIZE_KB_avg': round(w.get(k, (0, 0))[0], 1)} for k in f}
-        k = 'aggregate_kernel<4>'
-        if k in f:
+        cands = [n for n in f if n.startswith('aggregate_kernel<4') and n in w]
+        if cands:
+            k = max(cands, key=lambda n: f[n][1])      # the layer launches (most frequent variant)
+            traffic['kernel'] = k
             fb, wb = f[k][0] * 1024, w[k][0] * 1024
             traffic['entries'][str(b)] = {'fetch_bytes_raw': int(fb), 'write_bytes_raw': int(wb),
                                           'traffic_bytes': int(2 * fb + wb), 'launches_averaged': f[k][1]}
-    with open(os.path.join(ROOT, 'profiles', 'r1_pmc_fetch_write_raw.json'), 'w') as fh:
-        json.dump(raw, fh, indent=1)
-    with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json'), 'w') as fh:
-        json.dump(traffic, fh, indent=1)
+    # profiles/ is what bench.py reads; gpurun_out/ is what travels back from the GPU box
+    for d in ('profiles', 'gpurun_out'):
+        os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+        with open(os.path.join(ROOT, d, 'r1_pmc_fetch_write_raw.json'), 'w') as fh:
+            json.dump(raw, fh, indent=1)
+        with open(os.path.join(ROOT, d, 'r1_traffic.json'), 'w') as fh:
+            json.dump(traffic, fh, indent=1)
     print(json.dumps(traffic['entries']))
 
 
