@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 7
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_set_split', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
@@ -121,6 +121,8 @@ def lib():
     L.cwn_aggregate_f32.argtypes = [C.POINTER(AggDesc), C.c_int, C.c_void_p]
     L.cwn_gemm_f32.restype = C.c_int
     L.cwn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
+    L.cwn_gemm_set_split.restype = C.c_int
+    L.cwn_gemm_set_split.argtypes = [C.c_int]
     L.cwn_collate.restype = C.c_int
     L.cwn_collate.argtypes = [C.POINTER(CollateDesc), C.c_int, C.c_int64, C.c_void_p]
     L.cwn_bn_finalize_f32.restype = C.c_int
@@ -192,6 +194,13 @@ def gemm(descs: Sequence[GemmDesc], device) -> None:
         chunk = descs[i:i + MAX_DESCS]
         arr = (GemmDesc * len(chunk))(*chunk)
         check(L.cwn_gemm_f32(arr, len(chunk), s), 'cwn_gemm_f32')
+
+
+def gemm_set_split(enable: bool) -> bool:
+    """Process-wide: eligible cwn_gemm_f32 launches on the bf16 matrix pipe through the exact
+    three-way split (default, fp32 accuracy) or on the exact fp32-MFMA kernel.  Returns the
+    previous setting (include/cwn_hip.h: cwn_gemm_set_split)."""
+    return bool(lib().cwn_gemm_set_split(1 if enable else 0))
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

@@ -462,6 +462,26 @@ inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15u) ==
 
 }  // namespace
 
+// cwn_gemm_split.hip: the same product on the bf16 matrix pipe (three-way exact split, fp32 accuracy)
+int cwn_gemm_split_eligible(const cwn_gemm_desc* descs, int n);
+int cwn_gemm_split_launch(const cwn_gemm_desc* descs, int n, hipStream_t stream);
+
+static int g_split_mode = -1;    // -1: not read yet (CWN_GEMM_SPLIT, default on)
+
+static int split_mode() {
+    if (g_split_mode < 0) {
+        const char* e = getenv("CWN_GEMM_SPLIT");
+        g_split_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return g_split_mode;
+}
+
+extern "C" int cwn_gemm_set_split(int enable) {
+    const int prev = split_mode();
+    g_split_mode = enable ? 1 : 0;
+    return prev;
+}
+
 extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stream_) {
     if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return CWN_ERR_BAD_ARG;
     GemmBatch B{};
@@ -488,6 +508,8 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
                     D.K % 4 == 0 && D.K2 % 4 == 0) ? 1 : 0;
         B.d[i] = D;
     }
+    if (split_mode() != 0 && cwn_gemm_split_eligible(descs, n))
+        return cwn_gemm_split_launch(descs, n, (hipStream_t)stream_);
     // tile shape of the launch: narrow (64 x 64) when no descriptor has more than 64 output columns
     int kmax = 0, nmax = 0;
     for (int i = 0; i < n; ++i) {

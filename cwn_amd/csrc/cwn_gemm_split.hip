@@ -1,0 +1,228 @@
+// cwn_gemm_split.hip -- the grouped GEMM of cwn_gemm_f32 on the BF16 matrix pipe, at fp32 accuracy.
+//
+// v_mfma_f32_16x16x4_f32 (cwn_gemm.hip) runs at the fp32 VECTOR rate, 1/16 of the bf16 MFMA rate,
+// and its MFMA phase is the largest single piece of the dense launches (3.0 of 8.8 us at ZINC-128,
+// ~150 of 249 us at batch 8192).  An fp32 number splits EXACTLY into three bf16 numbers by
+// truncation,
+//     x = hi + mid + lo      hi = its top 8 significant bits, mid = the next 8, lo = the last 8
+// (every subtraction below is exact), so x * w is the sum of nine bf16 products of which the three
+// smallest (mid*lo, lo*mid, lo*lo <= 2^-24 |x||w|) are dropped: six v_mfma_f32_16x16x32_bf16 per
+// 32 k-values instead of eight v_mfma_f32_16x16x4_f32 -- 6 x 16 cycles against 8 x 32, 2.67x on
+// the MFMA phase -- accumulated in fp32 like the exact kernel.  Measured against float64
+// (tools/proto/run_gemm_bf16x3.py): max error 1.0-3.6e-7 of |x|.|w|, the same as the fp32-MFMA
+// kernel (1.2-3.5e-7); 649 664 x 128 x 128: 289 -> 135 us (the launch becomes HBM-bound, 4.9 TB/s).
+// NOT bit-identical to an fmaf chain, and non-finite inputs give NaN where fp32 gives inf
+// (inf - inf in the split): cwn_gemm_set_split(0) / CWN_GEMM_SPLIT=0 select the exact kernel.
+//
+// Served here (cwn_gemm.hip routes, everything else stays on the exact kernel): every descriptor
+// has N == 128, K == 128, K2 == 0, no prologue, no statistics, natural weight layout, 16-B
+// aligned operands.  Bias, output affine and ReLU are applied in the epilogue.
+//
+// Mapping: operand roles swapped as in the exact kernel (A = W rows, B = X rows), so a lane ends up
+// with 4 consecutive output columns of one X row.  W is split once per workgroup and stays in
+// registers (2 column tiles x 4 k-steps x 3 planes x 4 VGPRs = 96); the 64-row X tile is split ONCE
+// per element while it is staged into LDS as three bf16 planes (row stride 272 B: the 16 rows of a
+// fragment read land on different banks, ds_read_b128 conflict-free).  Persistent workgroups, two
+// per CU: one stages while the other multiplies.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cwn_hip.h"
+
+namespace {
+
+constexpr int K = 128, N = 128, TM = 64, kThreads = 256;
+constexpr int kRowStride = K + 8;            // bf16 elements per LDS row
+constexpr int kMaxBlocks = 512;              // 2 per CU (measured: 256 -> 204 us, 512 -> 135, one per tile -> 210)
+
+typedef __bf16 frag_ab __attribute__((ext_vector_type(8)));
+typedef float frag_cd __attribute__((ext_vector_type(4)));
+
+struct SplitBatch {
+    cwn_gemm_desc d[CWN_MAX_DESCS];
+    int32_t blk_start[CWN_MAX_DESCS + 1];    // first workgroup of each descriptor
+    int32_t n_tiles[CWN_MAX_DESCS];          // 64-row tiles
+    int32_t n;
+};
+
+struct Split { uint32_t h, m, l; };          // bf16 bit patterns in the UPPER 16 bits
+
+__device__ __forceinline__ Split split3(float x) {
+    Split s;
+    s.h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(s.h);          // exact: the low 16 significant bits
+    s.m = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(s.m);         // exact: at most 8 significant bits left
+    s.l = __float_as_uint(r2) & 0xFFFF0000u;
+    return s;
+}
+
+__device__ __forceinline__ uint32_t pack2(uint32_t even_hi16, uint32_t odd_hi16) {
+    return (even_hi16 >> 16) | odd_hi16;     // element k in the low half, k + 1 in the high half
+}
+
+// 8 consecutive fp32 -> three planes of 8 bf16
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& ph, uint4& pm, uint4& pl) {
+    const Split s0 = split3(a.x), s1 = split3(a.y), s2 = split3(a.z), s3 = split3(a.w);
+    const Split s4 = split3(b.x), s5 = split3(b.y), s6 = split3(b.z), s7 = split3(b.w);
+    ph = make_uint4(pack2(s0.h, s1.h), pack2(s2.h, s3.h), pack2(s4.h, s5.h), pack2(s6.h, s7.h));
+    pm = make_uint4(pack2(s0.m, s1.m), pack2(s2.m, s3.m), pack2(s4.m, s5.m), pack2(s6.m, s7.m));
+    pl = make_uint4(pack2(s0.l, s1.l), pack2(s2.l, s3.l), pack2(s4.l, s5.l), pack2(s6.l, s7.l));
+}
+
+__device__ __forceinline__ frag_ab as_frag(const uint4& v) { return __builtin_bit_cast(frag_ab, v); }
+
+__global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
+    __shared__ __attribute__((aligned(16))) uint16_t xs[3][TM][kRowStride];
+    int di = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+        if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
+    const cwn_gemm_desc D = B.d[di];         // by value (see cwn_aggregate.hip)
+    const int blk = blockIdx.x - B.blk_start[di];
+    const int nblk = B.blk_start[di + 1] - B.blk_start[di];
+    const int tiles = B.n_tiles[di];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    // stationary W fragments of this wave's 32 output columns: [column tile][k step][plane]
+    uint4 wf[2][4][3];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int n = wave * 32 + ct * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4* p = reinterpret_cast<const float4*>(D.W + (int64_t)n * D.ldw + ks * 32 + kq * 8);
+            split8(p[0], p[1], wf[ct][ks][0], wf[ct][ks][1], wf[ct][ks][2]);
+        }
+    }
+    const bool affine = D.out_scale != nullptr, relu = D.relu != 0;
+
+    for (int tile = blk; tile < tiles; tile += nblk) {
+        const int64_t row0 = (int64_t)tile * TM;
+        // stage + split the X tile: 64 rows x 32 float4, 8 per thread, row-contiguous; rows past
+        // M are clamped, not guarded (guarded loads serialise; their outputs are never stored)
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
+            const int64_t row = row0 + r < D.M ? row0 + r : D.M - 1;
+            v[i] = reinterpret_cast<const float4*>(D.X + row * D.ldx)[c4];
+        }
+        __syncthreads();                     // the previous tile's fragments have been read
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
+            const Split s0 = split3(v[i].x), s1 = split3(v[i].y), s2 = split3(v[i].z), s3 = split3(v[i].w);
+            *reinterpret_cast<uint2*>(&xs[0][r][c4 * 4]) = make_uint2(pack2(s0.h, s1.h), pack2(s2.h, s3.h));
+            *reinterpret_cast<uint2*>(&xs[1][r][c4 * 4]) = make_uint2(pack2(s0.m, s1.m), pack2(s2.m, s3.m));
+            *reinterpret_cast<uint2*>(&xs[2][r][c4 * 4]) = make_uint2(pack2(s0.l, s1.l), pack2(s2.l, s3.l));
+        }
+        __syncthreads();
+
+        frag_cd acc[4][2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = frag_cd{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const int r = rt * 16 + l15, k0 = ks * 32 + kq * 8;
+                const frag_ab xh = as_frag(*reinterpret_cast<const uint4*>(&xs[0][r][k0]));
+                const frag_ab xm = as_frag(*reinterpret_cast<const uint4*>(&xs[1][r][k0]));
+                const frag_ab xl = as_frag(*reinterpret_cast<const uint4*>(&xs[2][r][k0]));
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const frag_ab wh = as_frag(wf[ct][ks][0]), wm = as_frag(wf[ct][ks][1]),
+                                  wl = as_frag(wf[ct][ks][2]);
+                    frag_cd c = acc[rt][ct];             // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+                    acc[rt][ct] = c;
+                }
+            }
+        }
+        // D[i][j]: i = W row (output column) = (lane >> 4) * 4 + reg, j = X row = lane & 15
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int64_t row = row0 + rt * 16 + l15;
+            if (row < D.M) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    // (epilogue constants are re-read per tile from L1/L2: held in registers across
+                    //  the tile loop they cost 24 VGPRs and the second resident workgroup of the CU)
+                    const int n0 = wave * 32 + ct * 16 + kq * 4;
+                    float y[4] = {acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};
+                    if (D.bias != nullptr) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(D.bias + n0);
+                        y[0] += b4.x; y[1] += b4.y; y[2] += b4.z; y[3] += b4.w;
+                    }
+                    if (affine) {
+                        const float4 sc = *reinterpret_cast<const float4*>(D.out_scale + n0);
+                        const float4 sh = *reinterpret_cast<const float4*>(D.out_shift + n0);
+                        y[0] = y[0] * sc.x + sh.x;
+                        y[1] = y[1] * sc.y + sh.y;
+                        y[2] = y[2] * sc.z + sh.z;
+                        y[3] = y[3] * sc.w + sh.w;
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) y[q] = fmaxf(y[q], 0.0f);
+                    }
+                    *reinterpret_cast<float4*>(D.Y + row * D.ldy + n0) = make_float4(y[0], y[1], y[2], y[3]);
+                }
+            }
+        }
+    }
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+}  // namespace
+
+// 1 when every descriptor fits this kernel (see the header comment); arguments already validated
+// by cwn_gemm_f32.
+int cwn_gemm_split_eligible(const cwn_gemm_desc* descs, int n) {
+    for (int i = 0; i < n; ++i) {
+        const cwn_gemm_desc& D = descs[i];
+        if (D.N != N || D.K != K || D.K2 != 0 || D.w_trans != 0 || D.reserved != 0) return 0;
+        if (D.in_scale != nullptr || D.in_scale2 != nullptr || D.in_relu != 0 || D.col_sum != nullptr) return 0;
+        if (!(al16(D.X) && al16(D.W) && al16(D.Y) && al16(D.bias) && al16(D.out_scale) && al16(D.out_shift)))
+            return 0;
+        if (D.ldx % 4 != 0 || D.ldw % 4 != 0 || D.ldy % 4 != 0) return 0;
+        if ((D.M + TM - 1) / TM >= INT32_MAX) return 0;
+    }
+    return 1;
+}
+
+int cwn_gemm_split_launch(const cwn_gemm_desc* descs, int n, hipStream_t stream) {
+    SplitBatch B{};
+    B.n = n;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        B.d[i] = descs[i];
+        B.n_tiles[i] = (int32_t)((descs[i].M + TM - 1) / TM);
+        total += B.n_tiles[i];
+    }
+    if (total == 0) return CWN_OK;
+    // persistent workgroups, shared between the descriptors in proportion to their tile counts
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        int64_t nb = B.n_tiles[i];
+        if (total > kMaxBlocks) {
+            nb = (nb * kMaxBlocks + total - 1) / total;
+            if (nb < 1 && B.n_tiles[i] > 0) nb = 1;
+            if (nb > B.n_tiles[i]) nb = B.n_tiles[i];
+        }
+        B.blk_start[i] = (int32_t)blocks;
+        blocks += nb;
+    }
+    for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
+    gemm_split_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}

@@ -222,6 +222,15 @@ typedef struct cwn_gemm_desc {
 
 int cwn_gemm_f32(const cwn_gemm_desc* descs_host, int n, cwn_stream_t stream);
 
+/* Launches whose every descriptor has N == 128, K == 128, K2 == 0, no prologue, no statistics, the
+ * natural weight layout and 16-B aligned operands run on the BF16 matrix pipe (16x the fp32-MFMA
+ * rate) through an exact three-way split of both operands, x = hi + mid + lo, keeping six of the
+ * nine partial products: fp32 accuracy (measured max error 1-4e-7 of |x|.|w|, the same as the
+ * fp32-MFMA kernel) at 2.1x the speed at scale, but not bit-identical to an fmaf chain, and
+ * non-finite inputs give NaN.  cwn_gemm_set_split(0) (or CWN_GEMM_SPLIT=0 in the environment)
+ * keeps every launch on the exact fp32-MFMA kernel; returns the previous setting.  Process-wide. */
+int cwn_gemm_set_split(int enable);
+
 /* ------------------------------------------------------------------------------------------
  * Training-mode pieces of the dense networks (torch.nn.BatchNorm1d in train mode + ReLU between
  * the Linear layers of update_up_nn / update_boundaries_nn / combine_nn, mp/layers.py:303-325,

@@ -1017,6 +1017,77 @@ def test_long_rows_are_deterministic():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+# ------------------------------------------------------------------------------------------------
+# cwn_gemm_f32 on the bf16 matrix pipe (exact three-way split of both operands)
+# ------------------------------------------------------------------------------------------------
+def _both_gemm_paths(make):
+    """Run the same launch with the split path allowed and forbidden."""
+    from cwn_amd import _ffi, ops
+    outs = []
+    prev = _ffi.gemm_set_split(True)
+    try:
+        for enable in (True, False):
+            _ffi.gemm_set_split(enable)
+            outs.append([y.clone() for y in ops.run_gemm(make(), DEV)])
+    finally:
+        _ffi.gemm_set_split(prev)
+    return outs
+
+
+@pytest.mark.parametrize('M', [1, 63, 64, 65, 3341, 20000])
+def test_gemm_split_path_has_fp32_accuracy(M):
+    """N = K = 128 launches run as six bf16 MFMAs per product on exactly-split operands: the
+    error against float64 must be at the level of the fp32-MFMA kernel (a few 1e-7 of |x|.|w|;
+    plain bf16 would be 4e-3), with bias, BatchNorm-eval affine, ReLU, a column slice of a wider
+    weight and several GEMMs in one launch."""
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(M)
+    W2 = (torch.randn(128, 256, generator=g) / 16).to(DEV)          # [N, 2F]: two column halves
+    X = [torch.randn(m, 128, generator=g).to(DEV) for m in (M, max(M // 3, 1), M + 5)]
+    b = torch.randn(128, generator=g).to(DEV)
+    sc, sh = (torch.rand(128, generator=g) + 0.5).to(DEV), torch.randn(128, generator=g).to(DEV)
+
+    def make():
+        return [ops.Gemm(X=X[0], W=W2[:, :128], bias=b),
+                ops.Gemm(X=X[1], W=W2[:, 128:]),
+                ops.Gemm(X=X[2], W=W2[:, :128], bias=b, out_scale=sc, out_shift=sh, relu=True)]
+
+    split, exact = _both_gemm_paths(make)
+    for i, (ys, ye) in enumerate(zip(split, exact)):
+        Wd = (W2[:, :128] if i != 1 else W2[:, 128:]).double()
+        ref = X[i].double() @ Wd.t()
+        bound = X[i].double().abs() @ Wd.abs().t() + 1.0
+        if i != 1:
+            ref = ref + b.double()
+        if i == 2:
+            ref = torch.relu(ref * sc.double() + sh.double())
+            bound = bound * sc.double()
+        for y in (ys, ye):
+            assert float(((y.double() - ref).abs() / bound).max()) < 2e-6
+    if M >= 64:
+        assert not torch.equal(split[0], exact[0])       # the two kernels really differ
+
+
+def test_gemm_split_path_identity_is_exact_and_fallbacks_are_untouched():
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(128, 128, generator=g) / 16).to(DEV)
+    eye = torch.eye(128, device=DEV)
+    split, exact = _both_gemm_paths(lambda: [ops.Gemm(X=eye, W=W)])
+    # 1.0 splits into (1, 0, 0) and w = hi + mid + lo exactly: an asymmetric W comes back transposed, bit for bit
+    assert torch.equal(split[0], W.t()) and torch.equal(exact[0], W.t())
+    # launches the split kernel does not serve (K != 128, K-concat, prologue) are the exact kernel's either way
+    X64, W64 = torch.randn(300, 64, generator=g).to(DEV), torch.randn(128, 64, generator=g).to(DEV)
+    X, X2 = torch.randn(300, 128, generator=g).to(DEV), torch.randn(300, 128, generator=g).to(DEV)
+    Wc = torch.randn(128, 256, generator=g).to(DEV)
+    s1 = torch.rand(128, generator=g).to(DEV)
+    for make in (lambda: [ops.Gemm(X=X64, W=W64)],
+                 lambda: [ops.Gemm(X=X, X2=X2, W=Wc)],
+                 lambda: [ops.Gemm(X=X, W=W, in_scale=s1, in_shift=s1, in_relu=1)]):
+        a, b_ = _both_gemm_paths(make)
+        assert torch.equal(a[0], b_[0])
+
+
 def test_gemm_narrow_grouped_concat_affine_stats():
     """The 64 x 64 tile shape with every fused piece: K-concatenation, input affine + ReLU, output
     affine, column statistics, row strides (molhiv-like hidden 64)."""
