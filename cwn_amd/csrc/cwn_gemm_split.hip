@@ -210,14 +210,17 @@ int cwn_gemm_split_launch(const cwn_gemm_desc* descs, int n, hipStream_t stream)
         total += B.n_tiles[i];
     }
     if (total == 0) return CWN_OK;
-    // persistent workgroups, shared between the descriptors in proportion to their tile counts
+    // persistent workgroups, shared between the descriptors in proportion to their tile counts and
+    // NEVER more than the 2 x 256 that are resident at once: rounding the shares up gave 514 for the
+    // four GEMMs of a batch-8192 layer, and the two workgroups that had to wait for a free slot
+    // walked their 19 tiles after everyone else had finished (205 us instead of ~140)
+    const int64_t cap = kMaxBlocks - n;
     int64_t blocks = 0;
     for (int i = 0; i < n; ++i) {
         int64_t nb = B.n_tiles[i];
-        if (total > kMaxBlocks) {
-            nb = (nb * kMaxBlocks + total - 1) / total;
+        if (total > cap) {
+            nb = nb * cap / total;
             if (nb < 1 && B.n_tiles[i] > 0) nb = 1;
-            if (nb > B.n_tiles[i]) nb = B.n_tiles[i];
         }
         B.blk_start[i] = (int32_t)blocks;
         blocks += nb;
