@@ -70,6 +70,34 @@ def layer_algorithmic_bytes(stats, F, coboundary=True):
 CAPTURE_MODE = 'thread_local'
 
 
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA, dense
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (never the 2:1-sparsity figure)
+
+
+def gemm_roofline(flops, us, split, io_bytes, narrow, traffic):
+    """Roofline entry of the grouped message GEMM.  The exact kernel is priced against the fp32-MFMA
+    peak.  The split kernel (cwn_gemm_split.hip) issues SIX bf16 MFMAs per fp32-accurate product
+    term, so its matrix-pipe ceiling is bf16 peak / 6 = 417 TFLOP/s of fp32-equivalent work; with
+    N = K = 128 that floor (79 ps per row) lies BELOW the HBM floor of reading X and writing Y once
+    (1 KiB per row: 128 ps), so the kernel is priced against HBM and the matrix-pipe figures are
+    given beside it."""
+    tf = flops / (us * 1e-6) / 1e12 if us > 0 else 0.0
+    if not split:
+        return {'bound': 'mfma', 'kernel': f'gemm_kernel ({"64x64" if narrow else "32x128"} tiles; grouped fp32-MFMA '
+                                           'GEMM: coboundary-message products Y1, Y2)',
+                'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                'frac': round(tf / MFMA_F32_PEAK_TF, 4), 'traffic': traffic, 'algorithmic_flops_per_launch': int(flops)}
+    gbs = io_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    eq_peak = MFMA_BF16_PEAK_TF / 6.0
+    return {'bound': 'hbm', 'kernel': 'gemm_split_kernel (64x128 tiles; grouped GEMM on the bf16 matrix pipe, exact '
+                                      '3-way operand split, fp32 accuracy: coboundary-message products Y1, Y2)',
+            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+            'traffic': traffic, 'algorithmic_bytes_per_launch': int(io_bytes),
+            'algorithmic_flops_per_launch': int(flops), 'fp32_equivalent_tflops': round(tf, 2),
+            'matrix_pipe_ceiling_tflops': round(eq_peak, 1), 'frac_of_matrix_pipe_ceiling': round(tf / eq_peak, 4),
+            'frac_of_fp32_mfma_peak_157': round(tf / MFMA_F32_PEAK_TF, 4)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -299,7 +327,6 @@ def main():
     # step is `roofline` (dominant), the other `roofline_other` ---------------------------------------
     roofline = roofline_other = r_plan = None
     if rank == 0 and not args.only_primary and 'roofline' not in SKIP:
-        MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA, dense
 
         def replay_us(fn, reps):
             """Average duration of back-to-back dependent launches replayed from a hipGraph, between
@@ -390,18 +417,19 @@ def main():
                 raw = json.load(fh).get(str(args.batch), {})
             if WL == 'zinc' and H == 128:
                 for kname, v in raw.items():
-                    if kname.startswith('gemm_kernel<true, false, 128, 4'):
+                    if kname.startswith('gemm_split_kernel') or (gemm_traffic is None and kname.startswith('gemm_kernel<true, false, 128, 4')):
                         gemm_traffic = int((2 * v['FETCH_SIZE_KB_avg'] + v['WRITE_SIZE_KB_avg']) * 1024)
         except (OSError, ValueError, KeyError):
             gemm_traffic = None
         flops = 2.0 * sum(g.X.size(0) * g.W.size(0) * (g.X.size(1) + (g.X2.size(1) if g.X2 is not None else 0))
                           for g in gemms)
         tf = flops / (gemm_us * 1e-6) / 1e12 if gemms else 0.0
-        r_gemm = {'bound': 'mfma', 'kernel': f'gemm_kernel ({"64x64" if H <= 64 else "32x128"} tiles; grouped fp32-MFMA GEMM: coboundary-message products Y1, Y2)',
-                  'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
-                  'frac': round(tf / MFMA_F32_PEAK_TF, 4), 'traffic': gemm_traffic,
-                  'algorithmic_flops_per_launch': int(flops), 'avg_launch_us': round(gemm_us, 3),
-                  'launches_per_step': L if gemms else 0, 'share_of_step': round(L * gemm_us / step_us, 3)}
+        r_gemm = gemm_roofline(flops=flops, us=gemm_us, split=bool(gemms) and ops.gemm_uses_split(gemms, dev),
+                               io_bytes=sum(4 * (g.X.numel() + g.X.size(0) * g.W.size(0) + g.W.size(0) * g.X.size(1)
+                                                 + (g.W.size(0) if g.bias is not None else 0)) for g in gemms),
+                               narrow=H <= 64, traffic=gemm_traffic)
+        r_gemm.update({'avg_launch_us': round(gemm_us, 3), 'launches_per_step': L if gemms else 0,
+                       'share_of_step': round(L * gemm_us / step_us, 3)})
         # plan build (cwn_csr_build): key + val (+ aux) int64 in, rowptr + col + perm (+ aux) int32 out
         plan_bytes = 0
         for ent in adjs:

@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 7
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_set_split', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_set_split', 'cwn_gemm_would_split', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
@@ -123,6 +123,8 @@ def lib():
     L.cwn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
     L.cwn_gemm_set_split.restype = C.c_int
     L.cwn_gemm_set_split.argtypes = [C.c_int]
+    L.cwn_gemm_would_split.restype = C.c_int
+    L.cwn_gemm_would_split.argtypes = [C.POINTER(GemmDesc), C.c_int]
     L.cwn_collate.restype = C.c_int
     L.cwn_collate.argtypes = [C.POINTER(CollateDesc), C.c_int, C.c_int64, C.c_void_p]
     L.cwn_bn_finalize_f32.restype = C.c_int
@@ -201,6 +203,12 @@ def gemm_set_split(enable: bool) -> bool:
     three-way split (default, fp32 accuracy) or on the exact fp32-MFMA kernel.  Returns the
     previous setting (include/cwn_hip.h: cwn_gemm_set_split)."""
     return bool(lib().cwn_gemm_set_split(1 if enable else 0))
+
+
+def gemm_would_split(descs: Sequence[GemmDesc]) -> bool:
+    """Would cwn_gemm_f32 run this launch (<= MAX_DESCS descriptors) on the bf16-split kernel?"""
+    arr = (GemmDesc * len(descs))(*descs)
+    return bool(lib().cwn_gemm_would_split(arr, len(descs)))
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

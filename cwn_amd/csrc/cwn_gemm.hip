@@ -482,6 +482,11 @@ extern "C" int cwn_gemm_set_split(int enable) {
     return prev;
 }
 
+extern "C" int cwn_gemm_would_split(const cwn_gemm_desc* descs, int n) {
+    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return 0;
+    return split_mode() != 0 && cwn_gemm_split_eligible(descs, n) ? 1 : 0;
+}
+
 extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stream_) {
     if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return CWN_ERR_BAD_ARG;
     GemmBatch B{};

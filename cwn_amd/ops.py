@@ -526,6 +526,17 @@ def run_gemm(gemms: Sequence[Gemm], device) -> List[Tensor]:
     return outs
 
 
+def gemm_uses_split(gemms: Sequence[Gemm], device) -> bool:
+    """True when run_gemm(gemms) is served by the bf16-split kernel (cwn_gemm_split.hip)."""
+    descs = []
+    for gm in gemms:
+        Y = gm.out if gm.out is not None else torch.empty(gm.X.size(0), gm.W.size(1 if gm.w_trans else 0),
+                                                          dtype=torch.float32, device=device)
+        if Y.numel():
+            descs.append(gm.desc(Y))
+    return bool(descs) and len(descs) <= _ffi.MAX_DESCS and _ffi.gemm_would_split(descs)
+
+
 ACCUMULATE_INTO_GRAD = True
 
 

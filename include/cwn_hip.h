@@ -230,6 +230,8 @@ int cwn_gemm_f32(const cwn_gemm_desc* descs_host, int n, cwn_stream_t stream);
  * non-finite inputs give NaN.  cwn_gemm_set_split(0) (or CWN_GEMM_SPLIT=0 in the environment)
  * keeps every launch on the exact fp32-MFMA kernel; returns the previous setting.  Process-wide. */
 int cwn_gemm_set_split(int enable);
+/* 1 when cwn_gemm_f32 would run these descriptors on that path (measurement / tests), else 0. */
+int cwn_gemm_would_split(const cwn_gemm_desc* descs_host, int n);
 
 /* ------------------------------------------------------------------------------------------
  * Training-mode pieces of the dense networks (torch.nn.BatchNorm1d in train mode + ReLU between

@@ -1076,6 +1076,7 @@ def test_gemm_split_path_identity_is_exact_and_fallbacks_are_untouched():
     split, exact = _both_gemm_paths(lambda: [ops.Gemm(X=eye, W=W)])
     # 1.0 splits into (1, 0, 0) and w = hi + mid + lo exactly: an asymmetric W comes back transposed, bit for bit
     assert torch.equal(split[0], W.t()) and torch.equal(exact[0], W.t())
+    assert ops.gemm_uses_split([ops.Gemm(X=eye, W=W)], DEV)
     # launches the split kernel does not serve (K != 128, K-concat, prologue) are the exact kernel's either way
     X64, W64 = torch.randn(300, 64, generator=g).to(DEV), torch.randn(128, 64, generator=g).to(DEV)
     X, X2 = torch.randn(300, 128, generator=g).to(DEV), torch.randn(300, 128, generator=g).to(DEV)
@@ -1084,6 +1085,7 @@ def test_gemm_split_path_identity_is_exact_and_fallbacks_are_untouched():
     for make in (lambda: [ops.Gemm(X=X64, W=W64)],
                  lambda: [ops.Gemm(X=X, X2=X2, W=Wc)],
                  lambda: [ops.Gemm(X=X, W=W, in_scale=s1, in_shift=s1, in_relu=1)]):
+        assert not ops.gemm_uses_split(make(), DEV)
         a, b_ = _both_gemm_paths(make)
         assert torch.equal(a[0], b_[0])
 
