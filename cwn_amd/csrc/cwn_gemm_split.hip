@@ -71,6 +71,12 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
 
 __device__ __forceinline__ frag_ab as_frag(const uint4& v) { return __builtin_bit_cast(frag_ab, v); }
 
+// MULTI: workgroups walk several tiles (more tiles than resident workgroups): the next tile's
+// loads are issued right after the current one has been written to LDS and fly under its MFMAs
+// (batch 8192 in tools/check_gemm_split.py: 199 -> 175 us).  Not for one-tile workgroups, where the
+// same restructuring measured 8.7 -> 9.2 us on the ZINC-128 launch: that launch keeps the plain
+// load -> split -> multiply order the compiler schedules best.
+template <bool MULTI>
 __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
     __shared__ __attribute__((aligned(16))) uint16_t xs[3][TM][kRowStride];
     int di = 0;
@@ -84,6 +90,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
 
+    // stage: 64 rows x 32 float4, 8 per thread, row-contiguous; rows past M are clamped, not
+    // guarded (guarded loads serialise; their outputs are never stored)
+    float4 v[8];
+    auto request_tile = [&](int tile) {
+        const int64_t row0 = (int64_t)tile * TM;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
+            const int64_t row = row0 + r < D.M ? row0 + r : D.M - 1;
+            v[i] = reinterpret_cast<const float4*>(D.X + row * D.ldx)[c4];
+        }
+    };
     // stationary W fragments of this wave's 32 output columns: [column tile][k step][plane]
     uint4 wf[2][4][3];
 #pragma unroll
@@ -96,19 +114,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
         }
     }
     const bool affine = D.out_scale != nullptr, relu = D.relu != 0;
+    if constexpr (MULTI) {
+        if (blk < tiles) request_tile(blk);
+    }
 
     for (int tile = blk; tile < tiles; tile += nblk) {
         const int64_t row0 = (int64_t)tile * TM;
-        // stage + split the X tile: 64 rows x 32 float4, 8 per thread, row-contiguous; rows past
-        // M are clamped, not guarded (guarded loads serialise; their outputs are never stored)
-        float4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
-            const int64_t row = row0 + r < D.M ? row0 + r : D.M - 1;
-            v[i] = reinterpret_cast<const float4*>(D.X + row * D.ldx)[c4];
-        }
+        if constexpr (!MULTI) request_tile(tile);
         __syncthreads();                     // the previous tile's fragments have been read
+        // split the tile ONCE per element into the three bf16 planes
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
@@ -118,6 +132,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
             *reinterpret_cast<uint2*>(&xs[2][r][c4 * 4]) = make_uint2(pack2(s0.l, s1.l), pack2(s2.l, s3.l));
         }
         __syncthreads();
+        if constexpr (MULTI) {
+            if (tile + nblk < tiles) request_tile(tile + nblk);     // in flight under this tile's MFMAs
+        }
 
         frag_cd acc[4][2];
 #pragma unroll
@@ -226,6 +243,7 @@ int cwn_gemm_split_launch(const cwn_gemm_desc* descs, int n, hipStream_t stream)
         blocks += nb;
     }
     for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
-    gemm_split_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    if (total > blocks) gemm_split_kernel<true><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    else gemm_split_kernel<false><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
