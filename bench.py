@@ -707,6 +707,15 @@ def main():
 
     if rank == 0:
         s0 = stats[0]
+        try:
+            split_on = _ffi.gemm_set_split(True)      # read the process-wide setting (and put it back)
+            _ffi.gemm_set_split(split_on)
+        except Exception:                             # never lose the bench line over a label
+            split_on = False
+        dense = ('fp32 in / fp32 out; N = K = 128 products as exact 3-way bf16 operand splits on the bf16 MFMA pipe '
+                 '(6 MFMAs per term, fp32 accumulate, max error 4e-7 of |x|.|w| vs float64 = the fp32-MFMA kernel\'s), '
+                 'every other GEMM on fp32 MFMA; CWN_GEMM_SPLIT=0 runs all of them on fp32 MFMA'
+                 if split_on and H == 128 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32')
         out = {
             'metric': 'cells/sec, propagate scope, ' + {'zinc': 'ZINC-like ring-lifted batch (max_ring 6)', 'molhiv': 'molhiv-like ring-lifted batch (max_ring 6)', 'reddit': 'REDDIT-like clique-lifted batch (dim 2)'}[WL],
             'value': round(value, 1), 'unit': 'cells/s', 'n_gpus': world, 'steps': args.steps,
@@ -719,7 +728,8 @@ def main():
                        'E_up': [s0['E_up0'], s0['E_up1'], s0['E_up2']],
                        'B': [s0['B0'], s0['B1'], s0['B2']],
                        'launch': 'hipGraph replay' if use_graph else 'eager',
-                       'plan_build_in_step': True, 'parallelism': f'replicas x{world} (no data-path collective)'},
+                       'plan_build_in_step': True, 'dense_arithmetic': dense,
+                       'parallelism': f'replicas x{world} (no data-path collective)'},
             'roofline': roofline, 'roofline_other': roofline_other, 'roofline_plan_build': r_plan,
             'cpu_baseline': cpu_baseline,
             'secondary': {'full_forward_cells_per_s': round(float(full_cells.item()) / dt_full, 1),
