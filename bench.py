@@ -732,8 +732,9 @@ def main():
                        'parallelism': f'replicas x{world} (no data-path collective)'},
             'roofline': roofline, 'roofline_other': roofline_other, 'roofline_plan_build': r_plan,
             'cpu_baseline': cpu_baseline,
-            'secondary': {'full_forward_cells_per_s': round(float(full_cells.item()) / dt_full, 1),
-                          'full_forward_ms': round(dt_full / full_steps * 1e3, 5),
+            'secondary': {'full_forward_cells_per_s': (round(float(full_cells.item()) / dt_full, 1)
+                                                       if dt_full == dt_full else None),     # leg skipped: null, not NaN
+                          'full_forward_ms': round(dt_full / full_steps * 1e3, 5) if dt_full == dt_full else None,
                           'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '
                                    'MLPs + BatchNorm(eval), readout, head',
                           'collate': collate, 'concurrent_streams': concurrent, 'train_step': train,
