@@ -231,6 +231,29 @@ def test_bench_contract_static():
         assert '/root/reference' not in open(os.path.join(ROOT, f)).read(), f
 
 
+def test_bench_gemm_roofline_pricing():
+    """The roofline entry of the message GEMM: the exact kernel against the fp32-MFMA peak, the split
+    kernel against HBM (its matrix-pipe floor, bf16 peak / 6, lies below the HBM floor at N = K = 128)
+    with the matrix-pipe figures beside it; every contract key present either way."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                       # defines functions only (main() is guarded)
+    rows = 10151
+    flops, io = 2.0 * rows * 128 * 128, 4 * (2 * rows * 128 + 4 * 128 * 128)
+    exact = mod.gemm_roofline(flops=flops, us=8.8, split=False, io_bytes=io, narrow=False, traffic=123)
+    split = mod.gemm_roofline(flops=flops, us=8.4, split=True, io_bytes=io, narrow=False, traffic=None)
+    for r in (exact, split):
+        assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel'} <= set(r)
+        assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] < 1
+    assert exact['bound'] == 'mfma' and exact['unit'] == 'TFLOP/s' and exact['peak'] == 157.3
+    assert split['bound'] == 'hbm' and split['unit'] == 'GB/s' and split['peak'] == 8000.0
+    assert abs(split['achieved'] - io / 8.4e-6 / 1e9) < 1.0
+    assert abs(split['matrix_pipe_ceiling_tflops'] - 2500.0 / 6) < 0.1
+    # the reason for the choice of bound: per row, six bf16 MFMAs per term cost less than 1 KiB of HBM
+    assert (2 * 128 * 128) / (2500e12 / 6) < 1024 / 8e12
+
+
 def test_integration_stub_structs_match_the_header():
     """INTEGRATION.md shows the ctypes binding a maintainer of the reference would paste: its struct
     layouts must be the library's (a stale stub corrupts memory silently)."""
