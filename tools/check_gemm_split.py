@@ -63,6 +63,41 @@ Y = ops.run_gemm([ops.Gemm(X=torch.eye(128, device=dev), W=W)], dev)[0]
 print('identity exact:', bool(torch.equal(Y, W.t())))
 ok = ok and bool(torch.equal(Y, W.t()))
 
+# The candidate kernel (csrc/cwn_gemm_split_v2.hip, `make -C cwn_amd/csrc v2`, CWN_HIP_LIB=.../libcwn_hip_v2.so)
+# also serves the BatchNorm prologue, the band statistics and w_trans: each against the exact kernel.
+if os.environ.get('CWN_HIP_LIB', '').endswith('_v2.so'):
+    for M in (1, 95, 3341, 70_000):
+        X = torch.randn(M, 128, device=dev)
+        sc, sh = torch.rand(128, device=dev) + 0.5, torch.randn(128, device=dev)
+        cases = {
+            'prologue+relu': lambda: ops.Gemm(X=X, W=W, bias=b, in_scale=sc, in_shift=sh, in_relu=1),
+            'statistics': lambda: ops.Gemm(X=X, W=W, bias=b,
+                                           col_stats=torch.zeros(2, ops.stat_rows(M), 128, dtype=torch.float64, device=dev)),
+            'prologue+statistics': lambda: ops.Gemm(X=X, W=W, in_scale=sc, in_shift=sh, in_relu=1,
+                                                    col_stats=torch.zeros(2, ops.stat_rows(M), 128, dtype=torch.float64, device=dev)),
+            'w_trans': lambda: ops.Gemm(X=X, W=W, w_trans=True),
+        }
+        for cname, make in cases.items():
+            got = {}
+            for label, en in (('split', True), ('exact', False)):
+                _ffi.gemm_set_split(en)
+                g = make()
+                if en:
+                    assert ops.gemm_uses_split([g], dev), cname
+                y = ops.run_gemm([g], dev)[0]
+                got[label] = (y.clone(), None if g.col_stats is None else g.col_stats.clone())
+            _ffi.gemm_set_split(True)
+            ys, ye = got['split'][0].double(), got['exact'][0].double()
+            e = float((ys - ye).abs().max() / (ye.abs().max() + 1e-30))
+            good = e < 2e-6
+            if got['split'][1] is not None:
+                ss, se = got['split'][1], got['exact'][1]
+                es = float(((ss - se).abs() / (se.abs() + 1.0)).max())
+                good = good and es < 1e-5
+                cname += f' (stats rel {es:.1e})'
+            ok = ok and good
+            print(f'v2 M={M} {cname}: max |split - exact| / max|exact| = {e:.2e}  {"ok" if good else "FAIL"}')
+
 for name, Ms, reps in (('zinc128', [3165, 3341, 3341, 304], 50), ('x64', [202560, 213824, 213824, 19456], 5)):
     Xs, gs = gemms(Ms)
     outs = [torch.empty(m, 128, device=dev) for m in Ms]
