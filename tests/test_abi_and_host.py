@@ -231,6 +231,32 @@ def test_bench_contract_static():
         assert '/root/reference' not in open(os.path.join(ROOT, f)).read(), f
 
 
+def test_aggregate_descriptor_small_operand_flag():
+    """ops.AggSpec vouches for 32-bit row offsets (CWN_AGG_SMALL_OPERANDS) exactly when the gathered
+    operands lie within 4 GiB of their base pointers; the test switch turns it off."""
+    import re
+    import torch
+    from cwn_amd import ops
+    hdr = open(os.path.join(ROOT, 'include', 'cwn_hip.h')).read()
+    assert ops.AGG_SMALL_OPERANDS == int(re.search(r'#define CWN_AGG_SMALL_OPERANDS (\d+)', hdr).group(1))
+    A, out = torch.zeros(10, 8), torch.zeros(4, 8)
+    spec = ops.AggSpec(adj=None, n_dst=4, F=8, A=A, out=out)
+    assert spec.desc().flags == ops.AGG_SMALL_OPERANDS
+
+    class Huge:                      # a stand-in with the size of a > 4 GiB operand
+        def numel(self): return (1 << 30) + 1
+        def size(self, d): return 8
+        def data_ptr(self): return A.data_ptr()
+    big = ops.AggSpec(adj=None, n_dst=4, F=8, A=Huge(), out=out)
+    assert big.desc().flags == 0
+    prev = ops.ALLOW_SMALL_OPERANDS
+    try:
+        ops.ALLOW_SMALL_OPERANDS = False
+        assert spec.desc().flags == 0
+    finally:
+        ops.ALLOW_SMALL_OPERANDS = prev
+
+
 def test_bench_gemm_roofline_pricing():
     """The roofline entry of the message GEMM: the exact kernel against the fp32-MFMA peak, the split
     kernel against HBM (its matrix-pipe floor, bf16 peak / 6, lies below the HBM floor at N = K = 128)
