@@ -36,11 +36,15 @@
 // per CU: one stages while the other multiplies.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/cwn_hip.h"
 
 namespace {
 
-constexpr int K = 128, N = 128, TM = 64, kThreads = 256;
+constexpr int K = 128, N = 128, kThreads = 256;
+// rows per workgroup tile = 16 * RT: 64 (RT = 4) by default; 32 (RT = 2) when 64-row tiles would leave
+// CUs idle (ZINC-128: 161 tiles of 64 rows on 256 CUs; 318 of 32 rows, two co-resident per CU) --
+// CWN_SPLIT_TM32=1, to be measured (tools/check_gemm_split.py prints both).
 constexpr int kRowStride = K + 8;            // bf16 elements per LDS row
 constexpr int kMaxBlocks = 512;              // 2 per CU (measured: 256 -> 204 us, 512 -> 135, one per tile -> 210)
 
@@ -88,8 +92,11 @@ __device__ __forceinline__ frag_ab as_frag(const uint4& v) { return __builtin_bi
 // load -> split -> multiply order the compiler schedules best.
 // PRO / STATS: the prologue and the statistics epilogue are separate instantiations -- as run-time
 // branches they cost the plain kernel its registers (256 VGPRs + 36 B of scratch in the MULTI form).
-template <bool MULTI, bool PRO, bool STATS>
+template <int RT, bool MULTI, bool PRO, bool STATS>
 __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
+    constexpr int TM = 16 * RT;              // rows per tile
+    constexpr int U = TM * 32 / kThreads;    // float4 per thread of a staged tile (8 or 4)
+    static_assert(RT == 4 || RT == 2, "tiles are one or two 32-row statistics bands");
     __shared__ __attribute__((aligned(16))) uint16_t xs[3][TM][kRowStride];
     int di = 0;
 #pragma unroll
@@ -104,11 +111,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
 
     // stage: 64 rows x 32 float4, 8 per thread, row-contiguous; rows past M are clamped, not
     // guarded (guarded loads serialise; their outputs are never stored)
-    float4 v[8];
+    float4 v[U];
     auto request_tile = [&](int tile) {
         const int64_t row0 = (int64_t)tile * TM;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < U; ++i) {
             const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
             const int64_t row = row0 + r < D.M ? row0 + r : D.M - 1;
             v[i] = reinterpret_cast<const float4*>(D.X + row * D.ldx)[c4];
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
             psh = reinterpret_cast<const float4*>(D.in_shift)[threadIdx.x & 31];
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < U; ++i) {
             const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
             float4 x = v[i];
             if (pro_affine) {                // same operation order as the exact kernel's stage_store
@@ -175,15 +182,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
             if (tile + nblk < tiles) request_tile(tile + nblk);     // in flight under this tile's MFMAs
         }
 
-        frag_cd acc[4][2];
+        frag_cd acc[RT][2];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = frag_cd{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const int r = rt * 16 + l15, k0 = ks * 32 + kq * 8;
                 const frag_ab xh = as_frag(*reinterpret_cast<const uint4*>(&xs[0][r][k0]));
                 const frag_ab xm = as_frag(*reinterpret_cast<const uint4*>(&xs[1][r][k0]));
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
                 sh = *reinterpret_cast<const float4*>(D.out_shift + n0);
             }
 #pragma unroll
-            for (int band = 0; band < 2; ++band) {
+            for (int band = 0; band < RT / 2; ++band) {
                 double csum[4] = {0., 0., 0., 0.}, csq[4] = {0., 0., 0., 0.};
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
                         *reinterpret_cast<float4*>(D.Y + row * D.ldy + n0) = make_float4(y[0], y[1], y[2], y[3]);
                 }
                 if (STATS && D.col_sum != nullptr) {
-                    const int64_t slot = (row0 >> 5) + band;        // TM = 64: tiles align to 32-row bands
+                    const int64_t slot = (row0 >> 5) + band;        // tiles align to 32-row bands
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         double a = csum[q], b = csq[q];
@@ -285,7 +292,7 @@ int cwn_gemm_split_eligible(const cwn_gemm_desc* descs, int n) {
               al16(D.in_scale) && al16(D.in_shift)))
             return 0;
         if (D.ldx % 4 != 0 || D.ldw % 4 != 0 || D.ldy % 4 != 0) return 0;
-        if ((D.M + TM - 1) / TM >= INT32_MAX) return 0;
+        if ((D.M + 31) / 32 >= INT32_MAX) return 0;
     }
     return 1;
 }
@@ -293,6 +300,12 @@ int cwn_gemm_split_eligible(const cwn_gemm_desc* descs, int n) {
 int cwn_gemm_split_launch(const cwn_gemm_desc* descs, int n, hipStream_t stream) {
     SplitBatch B{};
     B.n = n;
+    static const char* tm32_env = getenv("CWN_SPLIT_TM32");
+    int64_t tiles64 = 0;
+    for (int i = 0; i < n; ++i) tiles64 += (descs[i].M + 63) / 64;
+    // 32-row tiles only for launches whose 64-row tiles do not fill the chip
+    const bool tm32 = tm32_env != nullptr && tm32_env[0] == '1' && tiles64 < 256;
+    const int TM = tm32 ? 32 : 64;
     int64_t total = 0;
     for (int i = 0; i < n; ++i) {
         B.d[i] = descs[i];
@@ -322,12 +335,14 @@ int cwn_gemm_split_launch(const cwn_gemm_desc* descs, int n, hipStream_t stream)
         stats = stats || descs[i].col_sum != nullptr;
     }
     using Kern = void (*)(SplitBatch);
-    static const Kern kerns[2][2][2] = {
-        {{gemm_split_kernel<false, false, false>, gemm_split_kernel<false, false, true>},
-         {gemm_split_kernel<false, true, false>, gemm_split_kernel<false, true, true>}},
-        {{gemm_split_kernel<true, false, false>, gemm_split_kernel<true, false, true>},
-         {gemm_split_kernel<true, true, false>, gemm_split_kernel<true, true, true>}}};
-    hipLaunchKernelGGL(kerns[total > blocks ? 1 : 0][pro ? 1 : 0][stats ? 1 : 0], dim3((unsigned)blocks),
-                       dim3(kThreads), 0, stream, B);
+#define CWN_SPLIT_KERNS(RT)                                                                            \
+    {{{gemm_split_kernel<RT, false, false, false>, gemm_split_kernel<RT, false, false, true>},         \
+      {gemm_split_kernel<RT, false, true, false>, gemm_split_kernel<RT, false, true, true>}},          \
+     {{gemm_split_kernel<RT, true, false, false>, gemm_split_kernel<RT, true, false, true>},           \
+      {gemm_split_kernel<RT, true, true, false>, gemm_split_kernel<RT, true, true, true>}}}
+    static const Kern kerns[2][2][2][2] = {CWN_SPLIT_KERNS(4), CWN_SPLIT_KERNS(2)};
+#undef CWN_SPLIT_KERNS
+    hipLaunchKernelGGL(kerns[tm32 ? 1 : 0][total > blocks ? 1 : 0][pro ? 1 : 0][stats ? 1 : 0],
+                       dim3((unsigned)blocks), dim3(kThreads), 0, stream, B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

@@ -109,4 +109,7 @@ for name, Ms, reps in (('zinc128', [3165, 3341, 3341, 304], 50), ('x64', [202560
         t[label] = graph_us(lambda: ops.run_gemm(gs, dev), reps)
     _ffi.gemm_set_split(True)
     print(f'{name:8s} split {t["split"]:8.2f} us   exact {t["exact"]:8.2f} us')
+if os.environ.get('CWN_HIP_LIB', '').endswith('_v2.so'):
+    print('(v2: re-run with CWN_SPLIT_TM32=1 for 32-row tiles on launches that do not fill the chip; '
+          f'this run: CWN_SPLIT_TM32={os.environ.get("CWN_SPLIT_TM32", "0")})')
 print('ALL OK' if ok else 'FAILED')
