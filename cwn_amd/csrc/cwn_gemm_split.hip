@@ -6,7 +6,7 @@
 // truncation,
 //     x = hi + mid + lo      hi = its top 8 significant bits, mid = the next 8, lo = the last 8
 // (every subtraction below is exact), so x * w is the sum of nine bf16 products of which the three
-// smallest (mid*lo, lo*mid, lo*lo <= 2^-24 |x||w|) are dropped: six v_mfma_f32_16x16x32_bf16 per
+// smallest (mid*lo, lo*mid, lo*lo: <= 2^-22 |x||w| each, ~2^-24 typically) are dropped: six v_mfma_f32_16x16x32_bf16 per
 // 32 k-values instead of eight v_mfma_f32_16x16x4_f32 -- 6 x 16 cycles against 8 x 32, 2.67x on
 // the MFMA phase -- accumulated in fp32 like the exact kernel.  Measured against float64
 // (tools/proto/run_gemm_bf16x3.py): max error 1.0-3.6e-7 of |x|.|w|, the same as the fp32-MFMA

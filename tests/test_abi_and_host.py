@@ -296,3 +296,41 @@ def test_integration_stub_structs_match_the_header():
         assert fields == list(getattr(_ffi, name)._fields_), name
     m = re.search(r'_L\.cwn_abi_version\(\) == (\d+)', text)
     assert m and int(m.group(1)) == _ffi.ABI_VERSION
+
+
+def test_three_way_bf16_split_is_exact_numpy_model():
+    """The arithmetic identity cwn_gemm_split.hip rests on, modelled in numpy float32 / uint32:
+    x = hi + mid + lo EXACTLY with every piece a bf16 number (low 16 bits clear), so that the six
+    products the kernel keeps differ from x * w by the three dropped ones, each <= 2^-24 |x||w|."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(200_000), rng.standard_normal(200_000) * 1e-20,
+                        rng.standard_normal(200_000) * 1e20, [0.0, -0.0, 1.0, -1.0, 3.0, 2.0 ** -100,
+                                                               np.float32(16777215.0), 1.0 + 2.0 ** -23]]).astype(np.float32)
+
+    def split3(v):
+        mask = np.uint32(0xFFFF0000)
+        h = (v.view(np.uint32) & mask).view(np.float32)
+        r1 = (v - h).astype(np.float32)
+        m = (r1.view(np.uint32) & mask).view(np.float32)
+        r2 = (r1 - m).astype(np.float32)
+        l = (r2.view(np.uint32) & mask).view(np.float32)
+        return h, m, l, r2
+
+    h, m, l, r2 = split3(x)
+    assert np.array_equal(l, r2)                                        # the last piece is not a truncation
+    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), x.astype(np.float64))
+    for piece in (h, m, l):
+        assert not np.any(piece.view(np.uint32) & np.uint32(0xFFFF))    # representable in bf16
+        assert np.all(np.abs(piece) <= np.abs(x))
+    # magnitudes: mid <= 2^-8 |x|, lo <= 2^-16 |x| (normal range)
+    ax = np.abs(x.astype(np.float64))
+    assert np.all(np.abs(m.astype(np.float64)) <= ax * 2.0 ** -7) and np.all(np.abs(l.astype(np.float64)) <= ax * 2.0 ** -15)
+    # the six kept products against the exact product
+    w = (rng.standard_normal(x.size) / 16).astype(np.float32)
+    wh, wm, wl, _ = split3(w)
+    f = lambda a: a.astype(np.float64)
+    kept = f(wl) * f(h) + f(wh) * f(l) + f(wm) * f(m) + f(wm) * f(h) + f(wh) * f(m) + f(wh) * f(h)
+    err = np.abs(kept - f(x) * f(w))
+    assert np.all(err <= 3.1 * 2.0 ** -22 * np.abs(f(x) * f(w)) + 1e-300)
+    assert np.median(err / (np.abs(f(x) * f(w)) + 1e-300)) < 2.0 ** -24

@@ -6,9 +6,9 @@
 // batch 8192).  An fp32 number splits EXACTLY into three bf16 numbers by truncation
 //     x = hi + mid + lo,   hi = top 8 significant bits, mid = the next 8, lo = the last 8
 // (each subtraction is exact), so x*w = sum of 9 bf16 products, of which the three smallest
-// (mid*lo, lo*mid, lo*lo <= 2^-24 |x||w|) are dropped: 6 v_mfma_f32_16x16x32_bf16 per 32 k-values
+// (mid*lo, lo*mid, lo*lo: <= 2^-22 |x||w| each, ~2^-24 typically) are dropped: 6 v_mfma_f32_16x16x32_bf16 per 32 k-values
 // instead of 8 v_mfma_f32_16x16x4_f32 -> 6*16 cycles against 8*32: 2.67x on the MFMA phase, error
-// ~3*2^-24 relative to |x||w| per term before fp32 accumulation (the accumulator is fp32 in both).
+// a few 2^-24 relative to |x||w| per term before fp32 accumulation (the accumulator is fp32 in both).
 //
 // Shape of the experiment: roles swapped as in the production kernel (A = W rows, B = X rows) so a
 // lane ends up with 4 consecutive output columns of one X row; W split once per workgroup and kept
