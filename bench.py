@@ -194,11 +194,22 @@ def main():
     # REDDIT-like and batch 8192 unchanged); it pays in eager mode only.
     OVERLAP_PLAN_BUILD = os.environ.get('CWN_BENCH_OVERLAP', '0') == '1'
 
-    def propagate_scope(bi):
-        """One step: fresh plans for the batch, then the propagate scope of every layer."""
-        b, feats = batches[bi], layer_inputs[bi]
+    # Does this configuration run the complex-blocked layer kernel (csrc/cwn_layer.hip: one launch per
+    # layer straight from the int64 COO indices, no CSR plan)?  Probed once, outside the timed region.
+    with torch.no_grad():
+        b0 = batches[0]
+        b0.set_xs(layer_inputs[0][0])
+        probe_plans, _ = model.convs[0].propagate_all(*b0.get_all_cochain_params(max_dim=2, include_down_features=False))
+        BLOCKED = probe_plans[0] == 'blocked'
         csr._cache.clear()
-        b.prepare(max_dim=2, overlap=OVERLAP_PLAN_BUILD)
+    torch.cuda.synchronize()
+
+    def propagate_scope(bi):
+        """One step: (CSR path only: fresh plans for the batch, then) the propagate scope of every layer."""
+        b, feats = batches[bi], layer_inputs[bi]
+        if not BLOCKED:
+            csr._cache.clear()
+            b.prepare(max_dim=2, overlap=OVERLAP_PLAN_BUILD)
         outs = None
         for l, conv in enumerate(model.convs):
             b.set_xs(feats[l])
@@ -707,11 +718,7 @@ def main():
 
     if rank == 0:
         s0 = stats[0]
-        try:
-            split_on = _ffi.gemm_set_split(True)      # read the process-wide setting (and put it back)
-            _ffi.gemm_set_split(split_on)
-        except Exception:                             # never lose the bench line over a label
-            split_on = False
+        split_on = not ops.GEMM_EXACT
         dense = ('fp32 in / fp32 out; N = K = 128 products as exact 3-way bf16 operand splits on the bf16 MFMA pipe '
                  '(6 MFMAs per term, fp32 accumulate, max error 4e-7 of |x|.|w| vs float64 = the fp32-MFMA kernel\'s), '
                  'every other GEMM on fp32 MFMA; CWN_GEMM_SPLIT=0 runs all of them on fp32 MFMA'

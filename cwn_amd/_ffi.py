@@ -16,10 +16,10 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_set_split', 'cwn_gemm_would_split', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
@@ -51,7 +51,21 @@ class GemmDesc(C.Structure):
                 ('Y', C.c_void_p), ('M', C.c_int64), ('ldx', C.c_int64), ('ldx2', C.c_int64),
                 ('ldw', C.c_int64), ('ldy', C.c_int64), ('N', C.c_int32), ('K', C.c_int32),
                 ('K2', C.c_int32), ('relu', C.c_int32), ('in_relu', C.c_int32),
-                ('w_trans', C.c_int32), ('reserved', C.c_int32), ('pad_', C.c_int32)]
+                ('w_trans', C.c_int32), ('flags', C.c_int32), ('pad_', C.c_int32)]
+
+
+GEMM_EXACT = 1            # = CWN_GEMM_EXACT (cwn_gemm_desc.flags)
+
+
+class LayerDim(C.Structure):
+    """cwn_layer_dim (include/cwn_hip.h)."""
+    _fields_ = [('x', C.c_void_p), ('up_index', C.c_void_p), ('up_shared', C.c_void_p),
+                ('b_index', C.c_void_p), ('msg_w', C.c_void_p), ('msg_bias', C.c_void_p),
+                ('eps1', C.c_void_p), ('eps2', C.c_void_p), ('out_up', C.c_void_p),
+                ('out_b', C.c_void_p), ('n_cells', C.c_int64), ('e_up', C.c_int64), ('n_b', C.c_int64)]
+
+
+ERR_BIT_BLOCK = 8         # = CWN_ERR_BIT_BLOCK
 
 
 class CollateDesc(C.Structure):
@@ -121,8 +135,11 @@ def lib():
     L.cwn_aggregate_f32.argtypes = [C.POINTER(AggDesc), C.c_int, C.c_void_p]
     L.cwn_gemm_f32.restype = C.c_int
     L.cwn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
-    L.cwn_gemm_set_split.restype = C.c_int
-    L.cwn_gemm_set_split.argtypes = [C.c_int]
+    L.cwn_layer_fused_f32.restype = C.c_int
+    L.cwn_layer_fused_f32.argtypes = [C.POINTER(LayerDim), C.c_int, C.c_int32, C.c_void_p, C.c_int64,
+                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.cwn_layer_fused_lds_bytes.restype = C.c_size_t
+    L.cwn_layer_fused_lds_bytes.argtypes = [C.c_int32, C.c_int32]
     L.cwn_gemm_would_split.restype = C.c_int
     L.cwn_gemm_would_split.argtypes = [C.POINTER(GemmDesc), C.c_int]
     L.cwn_collate.restype = C.c_int
@@ -196,13 +213,6 @@ def gemm(descs: Sequence[GemmDesc], device) -> None:
         chunk = descs[i:i + MAX_DESCS]
         arr = (GemmDesc * len(chunk))(*chunk)
         check(L.cwn_gemm_f32(arr, len(chunk), s), 'cwn_gemm_f32')
-
-
-def gemm_set_split(enable: bool) -> bool:
-    """Process-wide: eligible cwn_gemm_f32 launches on the bf16 matrix pipe through the exact
-    three-way split (default, fp32 accuracy) or on the exact fp32-MFMA kernel.  Returns the
-    previous setting (include/cwn_hip.h: cwn_gemm_set_split)."""
-    return bool(lib().cwn_gemm_set_split(1 if enable else 0))
 
 
 def gemm_would_split(descs: Sequence[GemmDesc]) -> bool:

@@ -231,8 +231,18 @@ class CochainBatch(Cochain):
             'shared_coboundaries': lambda i: off_up[i],
             'boundary_index': lambda i: (off_down[i], off_here[i]),
         }
+        slices = {}
         for key in ('x', 'y', 'upper_orient', 'lower_orient') + INDEX_KEYS:
             present = [(i, c[key]) for i, c in enumerate(data_list) if c[key] is not None]
+            if key in INDEX_KEYS:
+                # data/complex.py:349-394 `__slices__`: where each complex's entries start in the
+                # batched index (a complex without the key contributes an empty range)
+                run, offs = 0, [0]
+                for c in data_list:
+                    t = c[key]
+                    run += 0 if t is None else int(t.size(-1))
+                    offs.append(run)
+                slices[key] = offs
             if not present:
                 continue
             items = [t.unsqueeze(0) if t.dim() == 0 else t for _, t in present]
@@ -260,6 +270,7 @@ class CochainBatch(Cochain):
         if dim > 0:
             out.__num_cells_down__ = sum(inc_down)
         out.__num_cells_list__ = n_here
+        out.__slices__ = slices
         return out
 
     @property
@@ -393,7 +404,23 @@ class Complex(object):
                                              boundary_attr=boundary_features,
                                              boundary_index=boundary_index)
         params.num_cells = cells.num_cells   # engine extension: sizes without a device sync
+        params.block_plan = self.block_plan()  # engine extension: the batch's item table (or None)
         return params
+
+    def block_plan(self):
+        """The per-complex partition of this (batched) complex for the complex-blocked layer kernel
+        (cwn_amd/blockplan.py), from the collate's `ptr` / `__slices__` tables; None for a complex
+        that does not carry them or is not on the GPU."""
+        x0 = next((c.upper_index if c.upper_index is not None else c.x for c in self.cochains.values()
+                   if c.upper_index is not None or c.x is not None), None)
+        if x0 is None or not x0.is_cuda:
+            return None
+        cached = getattr(self, '_block_plan', None)
+        if cached is None or cached[0] != x0.device:
+            from .blockplan import BlockPlan
+            cached = (x0.device, BlockPlan.from_batch(self))
+            self._block_plan = cached
+        return cached[1]
 
     def get_all_cochain_params(self, max_dim: int = 2, include_top_features=True,
                                include_down_features=True,

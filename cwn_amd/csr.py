@@ -202,9 +202,14 @@ def build_many(adjs: Sequence[Adjacency], overlap: bool = False, validate: bool 
         flag = int(err.item())
         if flag:
             err.zero_()
-            what = [n for b, n in ((1, 'destination index'), (2, 'source index'),
-                                   (4, 'shared (co)boundary index')) if flag & b]
-            raise IndexError('index out of range in adjacency: ' + ', '.join(what))
+            raise IndexError(_describe(flag))
+
+
+def _describe(flag: int) -> str:
+    what = [n for b, n in ((1, 'destination index'), (2, 'source index'), (4, 'shared (co)boundary index'),
+                           (8, 'an index outside its complex (batch not block-diagonal, or a stale item table)'))
+            if flag & b]
+    return 'index out of range in adjacency: ' + ', '.join(what)
 
 
 def check_errors(dev) -> None:
@@ -214,9 +219,7 @@ def check_errors(dev) -> None:
     flag = int(err.item())
     if flag:
         err.zero_()
-        what = [n for b, n in ((1, 'destination index'), (2, 'source index'),
-                               (4, 'shared (co)boundary index')) if flag & b]
-        raise IndexError('index out of range in adjacency: ' + ', '.join(what))
+        raise IndexError(_describe(flag))
 
 
 # ---- cache keyed on the identity of the reference-style index tensor ---------------------------

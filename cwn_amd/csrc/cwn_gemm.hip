@@ -29,6 +29,7 @@
 //   affine (BatchNorm in eval mode), ReLU, and per-column sum / sum-of-squares accumulation
 //   (BatchNorm batch statistics in training mode).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdlib.h>
 #include "../../include/cwn_hip.h"
 
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
     const int64_t ldx = D.ldx, ldx2 = D.ldx2, ldw = D.ldw, ldy = D.ldy, M = D.M;
     const int N = D.N, K1 = D.K, K2 = D.K2, Ktot = D.K + D.K2;
     const Prologue pro{D.in_scale, D.in_shift, D.in_scale2, D.in_shift2, D.in_relu};
-    const int dbg = D.reserved;   // timing experiments (tools/ubench_gemm.py): 1 no MFMA, 2 no W staging, 4 no store
+    const int dbg = D.flags >> 8;   // timing experiments (tools/ubench_gemm.py): 1 no MFMA, 2 no W staging, 4 no store
     constexpr int SLABS = KP / 16;
     using SX = Staged<BM, KP>;                 // a 32-row tile in flight: KP/32 x 16 B per thread
 
@@ -466,25 +467,11 @@ inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15u) ==
 int cwn_gemm_split_eligible(const cwn_gemm_desc* descs, int n);
 int cwn_gemm_split_launch(const cwn_gemm_desc* descs, int n, hipStream_t stream);
 
-static int g_split_mode = -1;    // -1: not read yet (CWN_GEMM_SPLIT, default on)
-
-static int split_mode() {
-    if (g_split_mode < 0) {
-        const char* e = getenv("CWN_GEMM_SPLIT");
-        g_split_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
-    }
-    return g_split_mode;
-}
-
-extern "C" int cwn_gemm_set_split(int enable) {
-    const int prev = split_mode();
-    g_split_mode = enable ? 1 : 0;
-    return prev;
-}
-
 extern "C" int cwn_gemm_would_split(const cwn_gemm_desc* descs, int n) {
     if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return 0;
-    return split_mode() != 0 && cwn_gemm_split_eligible(descs, n) ? 1 : 0;
+    for (int i = 0; i < n; ++i)
+        if (descs[i].flags & CWN_GEMM_EXACT) return 0;
+    return cwn_gemm_split_eligible(descs, n) ? 1 : 0;
 }
 
 extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stream_) {
@@ -513,8 +500,9 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
                     D.K % 4 == 0 && D.K2 % 4 == 0) ? 1 : 0;
         B.d[i] = D;
     }
-    if (split_mode() != 0 && cwn_gemm_split_eligible(descs, n))
-        return cwn_gemm_split_launch(descs, n, (hipStream_t)stream_);
+    // precision policy is PER CALL (no process-wide state): CWN_GEMM_EXACT on any descriptor keeps the
+    // launch on the exact fp32-MFMA kernel below
+    if (cwn_gemm_would_split(descs, n)) return cwn_gemm_split_launch(descs, n, (hipStream_t)stream_);
     // tile shape of the launch: narrow (64 x 64) when no descriptor has more than 64 output columns
     int kmax = 0, nmax = 0;
     for (int i = 0; i < n; ++i) {
@@ -558,8 +546,7 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
     if (lds_bytes < 4 * 32 * 64 * 4) lds_bytes = 4 * 32 * 64 * 4;
     // persistent blocks, shared between the descriptors in proportion to their tile counts; each
     // block walks its descriptor's tiles with its weights stationary
-    static const char* budget_env = getenv("CWN_GEMM_BUDGET");   // timing experiments
-    const int64_t budget = budget_env ? atoi(budget_env) : (lds_bytes <= 48 * 1024 ? 4096 : 512);
+    const int64_t budget = lds_bytes <= 48 * 1024 ? 4096 : 512;
     // (K <= 128: measured on the 650 k-row shape -- 512 blocks 363 us, 768: 331, 1024: 318, 2048: 312,
     //  4096: 302, 8192: 324, one block per tile: 371; two are resident per CU, the queue behind them
     //  keeps every CU busy to the end while W is still re-staged only 16 times per CU)
@@ -596,22 +583,21 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
 #undef CWN_SHAPES
     static const int kShapeLds[6] = {2 * 32 * 128 * 4, 2 * 32 * 256 * 4, 2 * 64 * 64 * 4, 2 * 64 * 128 * 4,
                                      2 * 64 * 256 * 4, 2 * 48 * 128 * 4};
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (int c = 0; c < 6; ++c) {
+    static std::once_flag attr_once;        // thread-safe, once per process
+    static bool attr_ok = true;
+    std::call_once(attr_once, [&] {
+        for (int c = 0; c < 6; ++c)
             for (int a = 0; a < 2; ++a) {
                 for (int b = 0; b < 2; ++b)
-                    if (hipFuncSetAttribute((const void*)kerns[a][b][c],
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            kShapeLds[c]) != hipSuccess)
-                        return CWN_ERR_LAUNCH;
-                if (hipFuncSetAttribute((const void*)kerns_wt[a][c], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        kShapeLds[c]) != hipSuccess)
-                    return CWN_ERR_LAUNCH;
+                    attr_ok = attr_ok && hipFuncSetAttribute((const void*)kerns[a][b][c],
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             kShapeLds[c]) == hipSuccess;
+                attr_ok = attr_ok && hipFuncSetAttribute((const void*)kerns_wt[a][c],
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         kShapeLds[c]) == hipSuccess;
             }
-        }
-        attr_set = true;
-    }
+    });
+    if (!attr_ok) return CWN_ERR_LAUNCH;
     if (wt && pro) return CWN_ERR_BAD_ARG;
     const int shape = narrow ? (KP == 64 ? 2 : (KP == 128 ? 3 : 4)) : (rt3 ? 5 : (KP == 128 ? 0 : 1));
     const Kern k = wt ? kerns_wt[fast ? 1 : 0][shape] : kerns[fast ? 1 : 0][pro ? 1 : 0][shape];

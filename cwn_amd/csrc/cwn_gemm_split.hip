@@ -2,17 +2,16 @@
 //
 // v_mfma_f32_16x16x4_f32 (cwn_gemm.hip) runs at the fp32 VECTOR rate, 1/16 of the bf16 MFMA rate,
 // and its MFMA phase is the largest single piece of the dense launches (3.0 of 8.8 us at ZINC-128,
-// ~150 of 249 us at batch 8192).  An fp32 number splits EXACTLY into three bf16 numbers by
-// truncation,
-//     x = hi + mid + lo      hi = its top 8 significant bits, mid = the next 8, lo = the last 8
-// (every subtraction below is exact), so x * w is the sum of nine bf16 products of which the three
-// smallest (mid*lo, lo*mid, lo*lo: <= 2^-22 |x||w| each, ~2^-24 typically) are dropped: six v_mfma_f32_16x16x32_bf16 per
-// 32 k-values instead of eight v_mfma_f32_16x16x4_f32 -- 6 x 16 cycles against 8 x 32, 2.67x on
-// the MFMA phase -- accumulated in fp32 like the exact kernel.  Measured against float64
-// (tools/proto/run_gemm_bf16x3.py): max error 1.0-3.6e-7 of |x|.|w|, the same as the fp32-MFMA
-// kernel (1.2-3.5e-7); 649 664 x 128 x 128: 289 -> 135 us (the launch becomes HBM-bound, 4.9 TB/s).
-// NOT bit-identical to an fmaf chain, and non-finite inputs give NaN where fp32 gives inf
-// (inf - inf in the split): cwn_gemm_set_split(0) / CWN_GEMM_SPLIT=0 select the exact kernel.
+// ~150 of 249 us at batch 8192).  An fp32 number splits EXACTLY into three bf16 numbers,
+//     x = hi + mid + lo      (csrc/cwn_split.h: round-to-nearest at every step, every subtraction exact)
+// so x * w is the sum of nine bf16 products of which the three smallest (mid*lo, lo*mid, lo*lo:
+// <= 2^-26 |x||w| together) are dropped: six v_mfma_f32_16x16x32_bf16 per 32 k-values instead of
+// eight v_mfma_f32_16x16x4_f32 -- 6 x 16 cycles against 8 x 32, 2.67x on the MFMA phase --
+// accumulated in fp32 like the exact kernel.  Measured against float64: max error 1-4e-7 of
+// |x|.|w|, the same as the fp32-MFMA kernel; 649 664 x 128 x 128: 289 -> 135 us (the launch becomes
+// HBM-bound).  NOT bit-identical to an fmaf chain, and non-finite inputs give NaN where fp32 gives
+// inf (inf - inf in the split): the per-call CWN_GEMM_EXACT flag (cwn_gemm_desc.flags)
+// selects the exact kernel.
 //
 // Served here (cwn_gemm.hip routes, everything else stays on the exact kernel): every descriptor
 // has N == 128, K == 128, K2 == 0, no prologue, no statistics, natural weight layout, 16-B
@@ -27,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/cwn_hip.h"
+#include "cwn_split.h"
 
 namespace {
 
@@ -34,8 +34,7 @@ constexpr int K = 128, N = 128, TM = 64, kThreads = 256;
 constexpr int kRowStride = K + 8;            // bf16 elements per LDS row
 constexpr int kMaxBlocks = 512;              // 2 per CU (measured: 256 -> 204 us, 512 -> 135, one per tile -> 210)
 
-typedef __bf16 frag_ab __attribute__((ext_vector_type(8)));
-typedef float frag_cd __attribute__((ext_vector_type(4)));
+using cwn::frag_cd;
 
 struct SplitBatch {
     cwn_gemm_desc d[CWN_MAX_DESCS];
@@ -43,33 +42,6 @@ struct SplitBatch {
     int32_t n_tiles[CWN_MAX_DESCS];          // 64-row tiles
     int32_t n;
 };
-
-struct Split { uint32_t h, m, l; };          // bf16 bit patterns in the UPPER 16 bits
-
-__device__ __forceinline__ Split split3(float x) {
-    Split s;
-    s.h = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(s.h);          // exact: the low 16 significant bits
-    s.m = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(s.m);         // exact: at most 8 significant bits left
-    s.l = __float_as_uint(r2) & 0xFFFF0000u;
-    return s;
-}
-
-__device__ __forceinline__ uint32_t pack2(uint32_t even_hi16, uint32_t odd_hi16) {
-    return (even_hi16 >> 16) | odd_hi16;     // element k in the low half, k + 1 in the high half
-}
-
-// 8 consecutive fp32 -> three planes of 8 bf16
-__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& ph, uint4& pm, uint4& pl) {
-    const Split s0 = split3(a.x), s1 = split3(a.y), s2 = split3(a.z), s3 = split3(a.w);
-    const Split s4 = split3(b.x), s5 = split3(b.y), s6 = split3(b.z), s7 = split3(b.w);
-    ph = make_uint4(pack2(s0.h, s1.h), pack2(s2.h, s3.h), pack2(s4.h, s5.h), pack2(s6.h, s7.h));
-    pm = make_uint4(pack2(s0.m, s1.m), pack2(s2.m, s3.m), pack2(s4.m, s5.m), pack2(s6.m, s7.m));
-    pl = make_uint4(pack2(s0.l, s1.l), pack2(s2.l, s3.l), pack2(s4.l, s5.l), pack2(s6.l, s7.l));
-}
-
-__device__ __forceinline__ frag_ab as_frag(const uint4& v) { return __builtin_bit_cast(frag_ab, v); }
 
 // MULTI: workgroups walk several tiles (more tiles than resident workgroups): the next tile's
 // loads are issued right after the current one has been written to LDS and fly under its MFMAs
@@ -110,7 +82,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const float4* p = reinterpret_cast<const float4*>(D.W + (int64_t)n * D.ldw + ks * 32 + kq * 8);
-            split8(p[0], p[1], wf[ct][ks][0], wf[ct][ks][1], wf[ct][ks][2]);
+            cwn::split8(p[0], p[1], wf[ct][ks][0], wf[ct][ks][1], wf[ct][ks][2]);
         }
     }
     const bool affine = D.out_scale != nullptr, relu = D.relu != 0;
@@ -126,10 +98,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
-            const Split s0 = split3(v[i].x), s1 = split3(v[i].y), s2 = split3(v[i].z), s3 = split3(v[i].w);
-            *reinterpret_cast<uint2*>(&xs[0][r][c4 * 4]) = make_uint2(pack2(s0.h, s1.h), pack2(s2.h, s3.h));
-            *reinterpret_cast<uint2*>(&xs[1][r][c4 * 4]) = make_uint2(pack2(s0.m, s1.m), pack2(s2.m, s3.m));
-            *reinterpret_cast<uint2*>(&xs[2][r][c4 * 4]) = make_uint2(pack2(s0.l, s1.l), pack2(s2.l, s3.l));
+            uint2 ph, pm, pl;
+            cwn::split4(v[i], ph, pm, pl);
+            *reinterpret_cast<uint2*>(&xs[0][r][c4 * 4]) = ph;
+            *reinterpret_cast<uint2*>(&xs[1][r][c4 * 4]) = pm;
+            *reinterpret_cast<uint2*>(&xs[2][r][c4 * 4]) = pl;
         }
         __syncthreads();
         if constexpr (MULTI) {
@@ -146,22 +119,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 const int r = rt * 16 + l15, k0 = ks * 32 + kq * 8;
-                const frag_ab xh = as_frag(*reinterpret_cast<const uint4*>(&xs[0][r][k0]));
-                const frag_ab xm = as_frag(*reinterpret_cast<const uint4*>(&xs[1][r][k0]));
-                const frag_ab xl = as_frag(*reinterpret_cast<const uint4*>(&xs[2][r][k0]));
+                const uint4 xh = *reinterpret_cast<const uint4*>(&xs[0][r][k0]);
+                const uint4 xm = *reinterpret_cast<const uint4*>(&xs[1][r][k0]);
+                const uint4 xl = *reinterpret_cast<const uint4*>(&xs[2][r][k0]);
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const frag_ab wh = as_frag(wf[ct][ks][0]), wm = as_frag(wf[ct][ks][1]),
-                                  wl = as_frag(wf[ct][ks][2]);
-                    frag_cd c = acc[rt][ct];             // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
-                    acc[rt][ct] = c;
-                }
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[rt][ct] = cwn::mfma_split6(wf[ct][ks][0], wf[ct][ks][1], wf[ct][ks][2], xh, xm, xl,
+                                                   acc[rt][ct]);
             }
         }
         // D[i][j]: i = W row (output column) = (lane >> 4) * 4 + reg, j = X row = lane & 15
@@ -207,7 +171,7 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 int cwn_gemm_split_eligible(const cwn_gemm_desc* descs, int n) {
     for (int i = 0; i < n; ++i) {
         const cwn_gemm_desc& D = descs[i];
-        if (D.N != N || D.K != K || D.K2 != 0 || D.w_trans != 0 || D.reserved != 0) return 0;
+        if (D.N != N || D.K != K || D.K2 != 0 || D.w_trans != 0 || (D.flags >> 8) != 0) return 0;
         if (D.in_scale != nullptr || D.in_scale2 != nullptr || D.in_relu != 0 || D.col_sum != nullptr) return 0;
         if (!(al16(D.X) && al16(D.W) && al16(D.Y) && al16(D.bias) && al16(D.out_scale) && al16(D.out_shift)))
             return 0;

@@ -80,6 +80,7 @@ def _is_cat_linear_relu(nn) -> bool:
 
 
 FUSED_DENSE_TRAINING = True   # set False to run the update / combine networks as torch modules
+BLOCKED_LAYER = True          # set False to run the propagate scope as grouped GEMM + CSR aggregation
 
 
 def _fold_norm(norm, width: int):
@@ -571,6 +572,9 @@ class SparseCINConv(torch.nn.Module):
         None for dimensions that are not fusable / not processed, outs holds (up, boundary) pairs
         of the fusable ones in order."""
         n = len(cochain_params)
+        fused = self._propagate_blocked(cochain_params, start_to_process)
+        if fused is not None:
+            return ['blocked'] * n, fused
         specs, owner = [], []
         for dim in range(start_to_process, n):
             sp = self.mp_levels[dim].gemm_specs(cochain_params[dim])
@@ -584,6 +588,65 @@ class SparseCINConv(torch.nn.Module):
         fused = [st for p in plans if p is not None for st in p]
         outs = ops.aggregate_many(fused) if fused else []
         return plans, outs
+
+    def _propagate_blocked(self, cochain_params, start_to_process) -> Optional[List[Tensor]]:
+        """The whole propagate scope of this layer in ONE launch (csrc/cwn_layer.hip): Y1 / Y2 on
+        the matrix cores into LDS, the batch's COO entries sorted per complex in LDS, both
+        aggregations and the self terms out of LDS; no CSR plan, nothing but the two output
+        streams written.  Applies to the form the reference's molecular models build (coboundary
+        message ReLU(Linear(cat(x_j, up_attr))), identity boundary message, 'add' everywhere,
+        mp/layers.py:286-299) on a batch that carries its per-complex tables, without autograd;
+        None otherwise (the caller then runs the grouped GEMM + CSR aggregation)."""
+        if not BLOCKED_LAYER or ops.GEMM_EXACT or start_to_process != 0:
+            return None
+        n = len(cochain_params)
+        plan = getattr(cochain_params[0], 'block_plan', None)
+        if plan is None or n > 3 or n != plan.n_dims:
+            return None
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                        or any(c.x.requires_grad for c in cochain_params)):
+            return None
+        F = int(cochain_params[0].x.size(1))
+        if F not in (64, 128):
+            return None
+        dims, has_up = [], []
+        for d, c in enumerate(cochain_params):
+            lvl = self.mp_levels[d]
+            x = c.x
+            if (not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != F
+                    or (lvl.aggr_up or 'add') != 'add' or (lvl.aggr_boundary or 'add') != 'add'
+                    or not lvl._boundary_fusable() or lvl.up_msg_size != F):
+                return None
+            D = ops.LayerDim(x=x, eps1=lvl.eps1, eps2=lvl.eps2)
+            up = c.up_index is not None and c.up_index.size(1) > 0
+            if c.up_index is not None:
+                attr = c.kwargs.get('up_attr')
+                lin = lvl.msg_up_nn[1] if lvl._up_kind() == 'cat_linear_relu' else None
+                if (lin is None or not isinstance(attr, IndexedRows) or d + 1 >= n
+                        or attr.src is not cochain_params[d + 1].x or lin.in_features != 2 * F
+                        or lin.out_features != F or c.up_index.dtype != torch.long):
+                    return None
+                D.up_index, D.up_shared = c.up_index, attr.index
+                D.msg_w, D.msg_bias = lin.weight, lin.bias
+            b_index, b_attr = c.boundary_index, c.kwargs.get('boundary_attr')
+            if lvl.use_boundary_msg and b_attr is not None and b_index is not None:
+                if d == 0 or b_attr is not cochain_params[d - 1].x:
+                    return None
+                D.b_index = b_index
+            elif lvl.use_boundary_msg and b_attr is not None:
+                return None
+            dims.append(D)
+            has_up.append(bool(up))
+        tab = plan.items(F, has_up)
+        if tab is None:
+            return None
+        items, max_rows = tab
+        outs = ops.layer_fused(dims, items, max_rows)
+        if not getattr(plan, 'validated', False) and not torch.cuda.is_current_stream_capturing():
+            from . import csr
+            csr.check_errors(x.device)     # once per batch: the table belongs to these index tensors
+            plan.validated = True
+        return outs
 
     def _dense_eval(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
         """The update / combine networks of ALL dimensions (mp/layers.py:193-199) as three grouped

@@ -465,6 +465,7 @@ class Gemm:
     in_relu: int = 0                     # bit 0: ReLU on X after the affine, bit 1: on X2
     col_stats: Optional[Tensor] = None   # [2, stat_rows(M), N] fp64 out: per-32-row-band sum / sum of squares
     debug: int = 0                       # timing experiments only (tools/ubench_gemm.py)
+    exact: bool = False                  # keep the launch on the exact fp32-MFMA kernel (CWN_GEMM_EXACT)
     in_scale2: Optional[Tensor] = None   # the same prologue for X2
     in_shift2: Optional[Tensor] = None
     w_trans: bool = False                # W is [K (+K2), N]: Y = [X | X2] @ W  (dX = dY @ W of a Linear)
@@ -496,7 +497,8 @@ class Gemm:
             ldx2=(X2.stride(0) if X2.size(0) > 1 else max(K2, 1)) if X2 is not None else 0,
             ldw=W.stride(0) if W.size(0) > 1 else W.size(1), ldy=Y.stride(0) if Y.size(0) > 1 else Y.size(1),
             N=W.size(1 if self.w_trans else 0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu),
-            w_trans=int(self.w_trans), reserved=int(self.debug))
+            w_trans=int(self.w_trans),
+            flags=(_ffi.GEMM_EXACT if (self.exact or GEMM_EXACT) else 0) | (int(self.debug) << 8))
 
 
 def stat_rows(M: int) -> int:
@@ -505,6 +507,20 @@ def stat_rows(M: int) -> int:
 
 
 GEMM_MAX_K = 256   # K + K2 the MFMA kernel supports (whole-K weight tile resident in LDS)
+
+# Precision policy of the dense launches, applied PER CALL through cwn_gemm_desc.flags (the library
+# keeps no state): False (default) = eligible launches run on the bf16 matrix pipe through the exact
+# three-way split (fp32 accuracy, csrc/cwn_split.h); True (or CWN_GEMM_SPLIT=0 in the environment) =
+# every launch on the exact fp32-MFMA kernel, and the complex-blocked layer kernel (which has only
+# the split form) is not used.
+GEMM_EXACT = os.environ.get('CWN_GEMM_SPLIT') == '0'
+
+
+def set_gemm_exact(exact: bool) -> bool:
+    """Set the module's dense precision policy; returns the previous value."""
+    global GEMM_EXACT
+    prev, GEMM_EXACT = GEMM_EXACT, bool(exact)
+    return prev
 
 
 def run_gemm(gemms: Sequence[Gemm], device) -> List[Tensor]:
@@ -661,3 +677,55 @@ def gemm_many(gemms: Sequence[Gemm]) -> List[Tensor]:
     if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in flat)):
         return run_gemm(gemms, device)
     return list(_GemmMany.apply(tuple(gemms), device, *flat))
+
+
+# ------------------------------------------------------------------------------------------------
+# One SparseCIN propagate step of a layer in one launch (csrc/cwn_layer.hip)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class LayerDim:
+    """One cochain dimension of cwn_layer_fused_f32 (cwn_layer_dim in include/cwn_hip.h)."""
+    x: Tensor
+    up_index: Optional[Tensor] = None       # [2, E] int64
+    up_shared: Optional[Tensor] = None      # [E] int64 (shared_coboundaries)
+    b_index: Optional[Tensor] = None        # [2, B] int64
+    msg_w: Optional[Tensor] = None          # [F, 2F]
+    msg_bias: Optional[Tensor] = None
+    eps1: Optional[Tensor] = None
+    eps2: Optional[Tensor] = None
+
+
+def layer_fused(dims: Sequence[LayerDim], items: Tensor, max_gemm_rows: int) -> List[Tensor]:
+    """[out_up_0, out_b_0, out_up_1, out_b_1, ...]; no autograd (inference path).  `items` is the
+    batch's item table (cwn_amd/blockplan.py).  Index errors go to the sticky error word of
+    cwn_amd/csr.py (`csr.check_errors`)."""
+    from .csr import _err_flag
+    dev = dims[0].x.device
+    F = int(dims[0].x.size(1))
+    outs, arr = [], (_ffi.LayerDim * len(dims))()
+    keep = []
+    for d, D in enumerate(dims):
+        x = _f32c(D.x, 'x')
+        if x.size(1) != F:
+            raise ValueError('every dimension must have the same feature width')
+        up, sh, bi = D.up_index, D.up_shared, D.b_index
+        for t, name in ((up, 'up_index'), (sh, 'up_shared'), (bi, 'b_index')):
+            if t is not None and (t.dtype != torch.long or not t.is_cuda or not t.is_contiguous()):
+                raise TypeError(f'{name} must be a contiguous int64 GPU tensor')
+        w, b = _f32c(D.msg_w, 'msg_w'), _f32c(D.msg_bias, 'msg_bias')
+        e1, e2 = _f32c(D.eps1, 'eps1'), _f32c(D.eps2, 'eps2')
+        out_up = torch.empty_like(x)
+        out_b = torch.empty_like(x)
+        outs += [out_up, out_b]
+        keep += [x, w, b, e1, e2]
+        e_up = 0 if up is None else int(up.size(1))
+        arr[d] = _ffi.LayerDim(x=x.data_ptr(), up_index=_ffi.ptr(up) if e_up else None,
+                               up_shared=_ffi.ptr(sh) if e_up else None,
+                               b_index=_ffi.ptr(bi) if bi is not None and bi.size(1) else None,
+                               msg_w=_ffi.ptr(w), msg_bias=_ffi.ptr(b), eps1=_ffi.ptr(e1), eps2=_ffi.ptr(e2),
+                               out_up=out_up.data_ptr(), out_b=out_b.data_ptr(), n_cells=x.size(0),
+                               e_up=e_up, n_b=0 if bi is None else int(bi.size(1)))
+    _ffi.check(_ffi.lib().cwn_layer_fused_f32(arr, len(dims), F, items.data_ptr(), items.size(0),
+                                               int(max_gemm_rows), 0, _err_flag(dev).data_ptr(),
+                                               _ffi.stream_ptr(dev)), 'cwn_layer_fused_f32')
+    return outs

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 7
+#define CWN_ABI_VERSION 8
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -172,6 +172,80 @@ typedef struct cwn_agg_desc {
 int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A whole SparseCIN propagate step of one layer in ONE launch (inference / no-grad):
+ * everything SparseCINConv.forward does before the update networks (mp/layers.py:333-342 ->
+ * :184-192 per dimension -> CochainMessagePassing.propagate, mp/cell_mp.py:357-392), for all
+ * cochain dimensions, straight from the reference's int64 COO indices -- no CSR plan, no
+ * intermediate in HBM:
+ *
+ *     out_up_d[i] = sum_{e: up_index_d[1,e] = i} relu( W_d [x_d[up_index_d[0,e]] | x_{d+1}[shared_d[e]]] + b_d )
+ *                   + (1 + eps1_d) x_d[i]                  (zeros + self term when d has no upper adjacency)
+ *     out_b_d[i]  = sum_{e: b_index_d[1,e] = i} x_{d-1}[b_index_d[0,e]]  + (1 + eps2_d) x_d[i]
+ *
+ * i.e. message_up = msg_up_nn = ReLU(Linear(cat(x_j, up_attr))) (mp/layers.py:290-295) with
+ * up_attr = x_{d+1}[shared_coboundaries] (data/complex.py:579-580), message_boundary = identity
+ * (:299), both aggregations 'add', absent adjacency = zeros (mp/cell_mp.py:517-522), plus the GIN
+ * self terms of mp/layers.py:191-192.
+ *
+ * A batched complex is a disjoint union (data/complex.py:148-169: every index is offset per
+ * complex), so adjacency is block-diagonal and the cells / entries of one complex are contiguous
+ * in every tensor.  The launch is cut into ITEMS -- one workgroup each -- that own a contiguous
+ * range of complexes for a set of dimensions: the workgroup stages the item's rows of x_d and
+ * x_{d+1}, forms Y1 = x_d W[:, :F]^T + b and Y2 = x_{d+1} W[:, F:]^T on the matrix cores into LDS
+ * (exact three-way bf16 split, fp32 accuracy: csrc/cwn_split.h), sorts the item's COO entries by
+ * destination in LDS (stable: sums run in the original entry order, like a sequential
+ * index_add_), reduces relu(Y1[j] + Y2[c]) out of LDS and writes only the two output streams.
+ *
+ * The item table (device, int32[n_items][CWN_LAYER_ITEM_INTS]) is a property of the BATCH, built
+ * once from the per-complex sizes the reference's collate keeps (`ptr`, `__slices__`,
+ * data/complex.py:344-441): cwn_amd/blockplan.py.  Record layout (all offsets are into the batched
+ * tensors):
+ *   [0] flags      bit 0: the item has a GEMM dimension g (an upper adjacency with coboundary features)
+ *   [1] g          [2] first cell of dim g   [3] number of cells of dim g
+ *   [4] first cell of dim g+1                [5] number of cells of dim g+1
+ *   [6] first entry of up_index_g            [7] number of entries
+ *   [8] number of tasks (1 or 2); task t at [9 + 7 t]:
+ *       +0 dim d  +1 first cell  +2 number of cells (outputs out_up_d / out_b_d of these rows)
+ *       +3 first entry of b_index_d  +4 number of entries
+ *       +5 first cell of dim d-1     +6 number of cells of dim d-1      (boundary sources)
+ *   A task whose dim is g reduces the upper adjacency out of LDS; any other task must belong to a
+ *   dimension without upper adjacency (out_up = self term).  Limits per item: padded GEMM rows
+ *   16*ceil(n_g/16) + 16*ceil(n_{g+1}/16) <= CWN_LAYER_GEMM_ROWS(F); cells per task <=
+ *   CWN_LAYER_TASK_ROWS; entries of all its adjacencies together <= CWN_LAYER_MAX_ENTRIES.
+ * An index that leaves its item's ranges (the batch is not block-diagonal, or the table does not
+ * belong to it) sets bit 3 of *err_flag (the sticky word of cwn_csr_build) and is clamped.
+ * F must be 64 or 128; every pointer 16-B aligned; one launch, no workspace, no host sync.
+ * ------------------------------------------------------------------------------------------ */
+#define CWN_LAYER_MAX_DIMS 3
+#define CWN_LAYER_ITEM_INTS 32
+#define CWN_LAYER_GEMM_ROWS(F) (12288 / (F))   /* 96 at F = 128, 192 at F = 64 */
+#define CWN_LAYER_TASK_ROWS 192
+#define CWN_LAYER_MAX_ENTRIES 1024
+#define CWN_ERR_BIT_BLOCK 8                    /* *err_flag bit: index outside its item */
+
+typedef struct cwn_layer_dim {
+    const float* x;            /* [n_cells, F] */
+    const int64_t* up_index;   /* [2, e_up] upper_index (row 0 source, row 1 destination) or NULL */
+    const int64_t* up_shared;  /* [e_up] shared_coboundaries or NULL */
+    const int64_t* b_index;    /* [2, n_b] boundary_index (row 0 boundary cell, row 1 cell) or NULL */
+    const float* msg_w;        /* [F, 2F] weight of msg_up_nn's Linear (torch layout) or NULL */
+    const float* msg_bias;     /* [F] or NULL */
+    const float* eps1;         /* device scalar or NULL (= 0) */
+    const float* eps2;
+    float* out_up;             /* [n_cells, F] */
+    float* out_b;              /* [n_cells, F] */
+    int64_t n_cells, e_up, n_b;
+} cwn_layer_dim;
+
+/* max_gemm_rows: an upper bound (multiple of 16) of the padded GEMM rows of any item -- sizes the
+ * LDS of the launch.  flags: reserved, 0. */
+int cwn_layer_fused_f32(const cwn_layer_dim* dims_host, int n_dims, int32_t F, const int32_t* items,
+                        int64_t n_items, int32_t max_gemm_rows, int32_t flags, int32_t* err_flag,
+                        cwn_stream_t stream);
+/* dynamic LDS bytes such a launch uses (<= 160 KiB), 0 for unsupported arguments */
+size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows);
+
+/* ------------------------------------------------------------------------------------------
  * Dense parts of the path on the matrix cores (fp32 MFMA, exact fp32):
  *
  *     Y = epilogue( prologue([X | X2]) . W^T + bias )         up to CWN_MAX_DESCS GEMMs per launch
@@ -216,21 +290,25 @@ typedef struct cwn_gemm_desc {
     int32_t N, K, K2;
     int32_t relu, in_relu;
     int32_t w_trans;
-    int32_t reserved;
+    int32_t flags;          /* CWN_GEMM_* bits, 0: none */
     int32_t pad_;
 } cwn_gemm_desc;
+
+/* cwn_gemm_desc.flags.  EXACT: keep this launch on the exact fp32-MFMA kernel (bitwise an fmaf chain
+ * per output element; inf / NaN inputs propagate as in fp32) even when it is eligible for the
+ * bf16-split path below.  Per call: the library keeps no precision state. */
+#define CWN_GEMM_EXACT 1
 
 int cwn_gemm_f32(const cwn_gemm_desc* descs_host, int n, cwn_stream_t stream);
 
 /* Launches whose every descriptor has N == 128, K == 128, K2 == 0, no prologue, no statistics, the
- * natural weight layout and 16-B aligned operands run on the BF16 matrix pipe (16x the fp32-MFMA
- * rate) through an exact three-way split of both operands, x = hi + mid + lo, keeping six of the
- * nine partial products: fp32 accuracy (measured max error 1-4e-7 of |x|.|w|, the same as the
- * fp32-MFMA kernel) at 2.1x the speed at scale, but not bit-identical to an fmaf chain, and
- * non-finite inputs give NaN.  cwn_gemm_set_split(0) (or CWN_GEMM_SPLIT=0 in the environment)
- * keeps every launch on the exact fp32-MFMA kernel; returns the previous setting.  Process-wide. */
-int cwn_gemm_set_split(int enable);
-/* 1 when cwn_gemm_f32 would run these descriptors on that path (measurement / tests), else 0. */
+ * natural weight layout, 16-B aligned operands and no CWN_GEMM_EXACT flag run on the BF16 matrix pipe
+ * (16x the fp32-MFMA rate) through an exact three-way split of both operands, x = hi + mid + lo
+ * (round-to-nearest pieces, csrc/cwn_split.h), keeping six of the nine partial products (dropped:
+ * <= 2^-26 |x||w|): fp32 accuracy (measured max error 1-4e-7 of |x|.|w|, the same as the fp32-MFMA
+ * kernel) at 2.1x the speed at scale, but not bit-identical to an fmaf chain, and non-finite inputs
+ * give NaN.  1 when cwn_gemm_f32 would run these descriptors on that path, else 0 (a pure function
+ * of its arguments). */
 int cwn_gemm_would_split(const cwn_gemm_desc* descs_host, int n);
 
 /* ------------------------------------------------------------------------------------------

@@ -1,0 +1,223 @@
+"""The complex-blocked layer kernel (csrc/cwn_layer.hip, `cwn_layer_fused_f32`) through the C ABI:
+
+  * against the CPU oracle's propagate (mp/cell_mp.py:357-392 restated) evaluated in FLOAT64 with the
+    reference's coboundary message ReLU(Linear(cat(x_j, up_attr))) (mp/layers.py:290-295) and the
+    self terms of mp/layers.py:191-192 -- gate: max|delta| <= 1e-5 * max(1, |ref|_inf) (north star);
+  * bit-for-bit against the two-kernel path (grouped split GEMM + CSR aggregation) at F = 128: same
+    split, same MFMA order, same epilogue arithmetic, same entry order;
+  * exactly (torch.equal) against the oracle on integer-valued features and weights;
+  * its failure modes: an index that crosses complexes, a table that is not the batch's."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cwn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def cpu(t):
+    return None if t is None else t.detach().cpu()
+
+
+def _conv(F, seed=0, eps=0.0, train_eps=False):
+    from cwn_amd.layers import SparseCINConv
+    torch.manual_seed(seed)
+    conv = SparseCINConv(F, F, F, None, None, None, None, max_dim=2, hidden=F, eps=eps, train_eps=train_eps,
+                         act_module=torch.nn.ReLU, layer_dim=F, use_coboundaries=True)
+    return conv.to(DEV).eval()
+
+
+def _batch(kind, n, F, seed=0, integer=False):
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes, molhiv_like_complexes
+    gen = zinc_like_complexes if kind == 'zinc' else molhiv_like_complexes
+    b = ComplexBatch.from_complex_list(gen(n, seed, 6), max_dim=2).to(DEV)
+    g = torch.Generator().manual_seed(seed + 17)
+    for d in range(3):
+        n_d = b.cochains[d].num_cells
+        x = (torch.randint(-3, 4, (n_d, F), generator=g).float() if integer
+             else torch.randn(n_d, F, generator=g))
+        b.cochains[d].x = x.to(DEV)
+    return b
+
+
+def _oracle_scope(conv, b, dtype=torch.float64):
+    """[(out_up, out_b)] per dimension: the oracle's propagate + self terms, in `dtype`."""
+    outs = []
+    for d in range(3):
+        c = b.cochains[d]
+        lvl = conv.mp_levels[d]
+        x = cpu(c.x).to(dtype)
+        W = cpu(lvl.msg_up_nn[1].weight).to(dtype)
+        bias = cpu(lvl.msg_up_nn[1].bias).to(dtype)
+        up_index = cpu(c.upper_index) if (d + 1) in b.cochains else None
+        up_attr = None
+        if up_index is not None:
+            up_attr = cpu(b.cochains[d + 1].x).to(dtype)[cpu(c.shared_coboundaries)]
+        b_attr = cpu(b.cochains[d - 1].x).to(dtype) if d > 0 else None
+        msg = lambda xj, a: torch.relu(torch.cat([xj, a], -1) @ W.t() + bias)
+        F = x.size(1)
+        up, _, bnd = O.propagate(x, up_index, None, cpu(c.boundary_index) if d > 0 else None,
+                                 up_attr=up_attr, boundary_attr=b_attr, message_up=msg,
+                                 use_down_msg=False, up_msg_size=F, down_msg_size=F, boundary_msg_size=F)
+        up, bnd = up.to(dtype), bnd.to(dtype)
+        e1, e2 = float(lvl.eps1), float(lvl.eps2)
+        outs.append((up + (1 + e1) * x, bnd + (1 + e2) * x))
+    return outs
+
+
+def _run(conv, b, blocked):
+    from cwn_amd import layers
+    prev = layers.BLOCKED_LAYER
+    layers.BLOCKED_LAYER = blocked
+    try:
+        with torch.no_grad():
+            params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+            plans, outs = conv.propagate_all(*params)
+        assert (plans[0] == 'blocked') == blocked
+    finally:
+        layers.BLOCKED_LAYER = prev
+    return outs
+
+
+def _gate(got, ref64, what):
+    ref = ref64
+    err = (cpu(got).double() - ref).abs().max().item() if ref.numel() else 0.0
+    bound = 1e-5 * max(1.0, ref.abs().max().item() if ref.numel() else 1.0)
+    print(f'{what}: max|delta| = {err:.3e}  (gate {bound:.3e}, |ref|_inf = {bound / 1e-5:.3f})')
+    assert err <= bound, (what, err, bound)
+
+
+@pytest.mark.parametrize('kind,n,F', [('zinc', 128, 128), ('zinc', 7, 128), ('molhiv', 512, 64), ('zinc', 37, 64),
+                                      ('zinc', 300, 128)])
+def test_blocked_layer_vs_float64_oracle(kind, n, F):
+    b = _batch(kind, n, F, seed=1)
+    conv = _conv(F, seed=2, eps=0.25)
+    outs = _run(conv, b, blocked=True)
+    ref = _oracle_scope(conv, b)
+    for d in range(3):
+        _gate(outs[2 * d], ref[d][0], f'{kind}-{n} F={F} out_up[{d}]')
+        _gate(outs[2 * d + 1], ref[d][1], f'{kind}-{n} F={F} out_b[{d}]')
+
+
+@pytest.mark.parametrize('kind,n', [('zinc', 128), ('zinc', 300), ('zinc', 1)])
+def test_blocked_layer_bit_identical_to_two_kernel_path(kind, n):
+    """F = 128: the grouped GEMM runs the same bf16-split arithmetic, the CSR aggregation the same
+    sequential entry order -> every output bit must agree."""
+    from cwn_amd import csr
+    b = _batch(kind, n, 128, seed=3)
+    conv = _conv(128, seed=4, eps=0.5)
+    fused = _run(conv, b, blocked=True)
+    csr._cache.clear()
+    plain = _run(conv, b, blocked=False)
+    for i, (f, p) in enumerate(zip(fused, plain)):
+        assert torch.equal(f, p), (i, (f - p).abs().max().item())
+
+
+@pytest.mark.parametrize('F', [64, 128])
+def test_blocked_layer_exact_on_integers(F):
+    """Integer features and weights: every bf16 piece, product and partial sum is exact, so the
+    kernel must reproduce the oracle's fp32 result exactly."""
+    b = _batch('zinc', 50, F, seed=5, integer=True)
+    conv = _conv(F, seed=6)
+    with torch.no_grad():
+        for lvl in conv.mp_levels:
+            lin = lvl.msg_up_nn[1]
+            lin.weight.copy_(torch.randint(-2, 3, lin.weight.shape).float())
+            lin.bias.copy_(torch.randint(-2, 3, lin.bias.shape).float())
+    outs = _run(conv, b, blocked=True)
+    ref = _oracle_scope(conv, b, dtype=torch.float32)
+    for d in range(3):
+        assert torch.equal(cpu(outs[2 * d]), ref[d][0]), d
+        assert torch.equal(cpu(outs[2 * d + 1]), ref[d][1]), d
+
+
+def test_blocked_layer_entry_order_and_empty_parts():
+    """Shuffled COO entries inside each complex give the same integers; complexes without rings
+    (no 2-cells, empty upper adjacency of the edges) and a batch of one are handled."""
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    cs = zinc_like_complexes(9, 11, 6)
+    b = ComplexBatch.from_complex_list(cs, max_dim=2).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randint(-3, 4, (b.cochains[d].num_cells, 128), generator=g).float().to(DEV) for d in range(3)]
+    b.set_xs(xs)
+    conv = _conv(128, seed=8)
+    with torch.no_grad():
+        for lvl in conv.mp_levels:
+            lin = lvl.msg_up_nn[1]
+            lin.weight.copy_(torch.randint(-1, 2, lin.weight.shape).float())
+    ref = _run(conv, b, blocked=True)
+    # shuffle entries within each complex's slice of every index
+    b2 = ComplexBatch.from_complex_list(cs, max_dim=2).to(DEV)
+    b2.set_xs(xs)
+    rng = np.random.default_rng(0)
+    for d in range(3):
+        c = b2.cochains[d]
+        for key, extra in (('upper_index', 'shared_coboundaries'), ('boundary_index', None)):
+            idx = c[key]
+            if idx is None:
+                continue
+            sl = c.__slices__[key]
+            perm = np.concatenate([s + rng.permutation(e - s) for s, e in zip(sl[:-1], sl[1:])]) if len(sl) > 1 else []
+            perm = torch.as_tensor(perm, dtype=torch.long, device=DEV)
+            setattr(c, key, idx[:, perm].contiguous())
+            if extra is not None:
+                setattr(c, extra, c[extra][perm].contiguous())
+    got = _run(conv, b2, blocked=True)
+    for r, o in zip(ref, got):
+        assert torch.equal(r, o)
+    one = ComplexBatch.from_complex_list(cs[:1], max_dim=2).to(DEV)
+    one.set_xs([x[:one.cochains[d].num_cells] for d, x in enumerate(xs)])
+    o1 = _run(conv, one, blocked=True)
+    for d in range(3):
+        n = one.cochains[d].num_cells
+        assert torch.equal(o1[2 * d], ref[2 * d][:n]) and torch.equal(o1[2 * d + 1], ref[2 * d + 1][:n])
+
+
+def test_blocked_layer_reports_indices_that_leave_their_complex():
+    from cwn_amd import csr
+    b = _batch('zinc', 12, 128, seed=9)
+    conv = _conv(128, seed=10)
+    _run(conv, b, blocked=True)           # fine as built
+    c = b.cochains[0]
+    bad = c.upper_index.clone()
+    bad[0, 3] = c.num_cells - 1           # source vertex of complex 0's entry -> last complex
+    c.upper_index = bad
+    b._block_plan = None                  # fresh plan object (unvalidated) for the edited batch
+    with pytest.raises(IndexError, match='outside its complex'):
+        _run(conv, b, blocked=True)
+    csr.check_errors(DEV)                 # the sticky word was cleared by the raise
+
+
+def test_blocked_layer_c_abi_argument_checks():
+    import ctypes as C
+    from cwn_amd import _ffi
+    L = _ffi.lib()
+    assert L.cwn_layer_fused_lds_bytes(128, 96) > 0 and L.cwn_layer_fused_lds_bytes(128, 96) <= 160 * 1024
+    assert L.cwn_layer_fused_lds_bytes(64, 192) > 0 and L.cwn_layer_fused_lds_bytes(64, 192) <= 160 * 1024
+    assert L.cwn_layer_fused_lds_bytes(128, 112) == 0 and L.cwn_layer_fused_lds_bytes(32, 16) == 0
+    arr = (_ffi.LayerDim * 1)()
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    items = torch.zeros(1, 32, dtype=torch.int32, device=DEV)
+    s = _ffi.stream_ptr(torch.device(DEV))
+    assert L.cwn_layer_fused_f32(arr, 1, 96, items.data_ptr(), 1, 16, 0, err.data_ptr(), s) == 1     # F
+    assert L.cwn_layer_fused_f32(arr, 4, 128, items.data_ptr(), 1, 16, 0, err.data_ptr(), s) == 1    # n_dims
+    assert L.cwn_layer_fused_f32(arr, 1, 128, items.data_ptr(), 0, 16, 0, err.data_ptr(), s) == 0    # nothing to do
+    assert L.cwn_layer_fused_f32(arr, 1, 128, None, 1, 16, 0, err.data_ptr(), s) == 1
+
+
+def test_blocked_layer_falls_back_when_a_complex_exceeds_one_workgroup():
+    """molhiv-like complexes of up to 60 atoms do not fit the F = 128 row cap: the layer must take
+    the CSR path (and still match the oracle)."""
+    b = _batch('molhiv', 40, 128, seed=12)
+    conv = _conv(128, seed=13)
+    with torch.no_grad():
+        plans, outs = conv.propagate_all(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+    assert plans[0] != 'blocked'
+    ref = _oracle_scope(conv, b)
+    for d in range(3):
+        _gate(outs[2 * d], ref[d][0], f'fallback out_up[{d}]')
+        _gate(outs[2 * d + 1], ref[d][1], f'fallback out_b[{d}]')

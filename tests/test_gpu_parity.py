@@ -1024,13 +1024,13 @@ def _both_gemm_paths(make):
     """Run the same launch with the split path allowed and forbidden."""
     from cwn_amd import _ffi, ops
     outs = []
-    prev = _ffi.gemm_set_split(True)
+    prev = ops.set_gemm_exact(False)
     try:
-        for enable in (True, False):
-            _ffi.gemm_set_split(enable)
+        for exact in (False, True):
+            ops.set_gemm_exact(exact)
             outs.append([y.clone() for y in ops.run_gemm(make(), DEV)])
     finally:
-        _ffi.gemm_set_split(prev)
+        ops.set_gemm_exact(prev)
     return outs
 
 

@@ -41,12 +41,12 @@ for Ms in ([1], [63, 64, 65], [3165, 3341, 3341, 304], [100_000, 7], [40_000, 40
     Xs, _ = gemms(Ms)
     res = {}
     for name, en in (('split', True), ('exact', False)):
-        _ffi.gemm_set_split(en)
+        ops.set_gemm_exact(not en)
         _, gs = gemms(Ms, Xs)
         if en:
             assert ops.gemm_uses_split(gs, dev)
         res[name] = [y.clone() for y in ops.run_gemm(gs, dev)]
-    _ffi.gemm_set_split(True)
+    ops.set_gemm_exact(False)
     worst = {}
     for i, x in enumerate(Xs):
         Wd = (W2[:, :128] if i % 2 == 0 else W2[:, 128:]).double()
@@ -80,13 +80,13 @@ if os.environ.get('CWN_HIP_LIB', '').endswith('_v2.so'):
         for cname, make in cases.items():
             got = {}
             for label, en in (('split', True), ('exact', False)):
-                _ffi.gemm_set_split(en)
+                ops.set_gemm_exact(not en)
                 g = make()
                 if en:
                     assert ops.gemm_uses_split([g], dev), cname
                 y = ops.run_gemm([g], dev)[0]
                 got[label] = (y.clone(), None if g.col_stats is None else g.col_stats.clone())
-            _ffi.gemm_set_split(True)
+            ops.set_gemm_exact(False)
             ys, ye = got['split'][0].double(), got['exact'][0].double()
             e = float((ys - ye).abs().max() / (ye.abs().max() + 1e-30))
             good = e < 2e-6
@@ -105,9 +105,9 @@ for name, Ms, reps in (('zinc128', [3165, 3341, 3341, 304], 50), ('x64', [202560
         g.out = o
     t = {}
     for label, en in (('split', True), ('exact', False)):
-        _ffi.gemm_set_split(en)
+        ops.set_gemm_exact(not en)
         t[label] = graph_us(lambda: ops.run_gemm(gs, dev), reps)
-    _ffi.gemm_set_split(True)
+    ops.set_gemm_exact(False)
     print(f'{name:8s} split {t["split"]:8.2f} us   exact {t["exact"]:8.2f} us')
 if os.environ.get('CWN_HIP_LIB', '').endswith('_v2.so'):
     print('(v2: re-run with CWN_SPLIT_TM32=1 for 32-row tiles on launches that do not fill the chip; '
