@@ -201,6 +201,9 @@ def main():
         b0.set_xs(layer_inputs[0][0])
         probe_plans, _ = model.convs[0].propagate_all(*b0.get_all_cochain_params(max_dim=2, include_down_features=False))
         BLOCKED = probe_plans[0] == 'blocked'
+        if rank == 0:
+            print(f'[bench] complex-blocked layer kernel: {BLOCKED}'
+                  + ('' if BLOCKED else f' ({model.convs[0].blocked_reason})'), file=sys.stderr)
         csr._cache.clear()
     torch.cuda.synchronize()
 
@@ -735,7 +738,7 @@ def main():
                        'E_up': [s0['E_up0'], s0['E_up1'], s0['E_up2']],
                        'B': [s0['B0'], s0['B1'], s0['B2']],
                        'launch': 'hipGraph replay' if use_graph else 'eager',
-                       'plan_build_in_step': True, 'dense_arithmetic': dense,
+                       'plan_build_in_step': not BLOCKED, 'layer_kernel': 'complex-blocked (1 launch per layer, COO in, no CSR plan)' if BLOCKED else 'grouped GEMM + CSR aggregation (2 launches per layer + 1 plan build per batch)', 'dense_arithmetic': dense,
                        'parallelism': f'replicas x{world} (no data-path collective)'},
             'roofline': roofline, 'roofline_other': roofline_other, 'roofline_plan_build': r_plan,
             'cpu_baseline': cpu_baseline,

@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 8
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
@@ -60,7 +60,7 @@ GEMM_EXACT = 1            # = CWN_GEMM_EXACT (cwn_gemm_desc.flags)
 class LayerDim(C.Structure):
     """cwn_layer_dim (include/cwn_hip.h)."""
     _fields_ = [('x', C.c_void_p), ('up_index', C.c_void_p), ('up_shared', C.c_void_p),
-                ('b_index', C.c_void_p), ('msg_w', C.c_void_p), ('msg_bias', C.c_void_p),
+                ('b_index', C.c_void_p), ('msg_w_packed', C.c_void_p), ('msg_bias', C.c_void_p),
                 ('eps1', C.c_void_p), ('eps2', C.c_void_p), ('out_up', C.c_void_p),
                 ('out_b', C.c_void_p), ('n_cells', C.c_int64), ('e_up', C.c_int64), ('n_b', C.c_int64)]
 
@@ -137,9 +137,13 @@ def lib():
     L.cwn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
     L.cwn_layer_fused_f32.restype = C.c_int
     L.cwn_layer_fused_f32.argtypes = [C.POINTER(LayerDim), C.c_int, C.c_int32, C.c_void_p, C.c_int64,
-                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.cwn_layer_packed_weight_bytes.restype = C.c_size_t
+    L.cwn_layer_packed_weight_bytes.argtypes = [C.c_int32]
+    L.cwn_layer_pack_weights_f32.restype = C.c_int
+    L.cwn_layer_pack_weights_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_layer_fused_lds_bytes.restype = C.c_size_t
-    L.cwn_layer_fused_lds_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.cwn_layer_fused_lds_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.cwn_gemm_would_split.restype = C.c_int
     L.cwn_gemm_would_split.argtypes = [C.POINTER(GemmDesc), C.c_int]
     L.cwn_collate.restype = C.c_int

@@ -22,11 +22,25 @@ TARGET_ITEMS = 128             # per GEMM dimension: ~one workgroup per CU over 
 
 
 def gemm_rows_cap(F: int) -> int:
-    return 12288 // F          # = CWN_LAYER_GEMM_ROWS(F)
+    return 12288 // F          # = CWN_LAYER_GEMM_ROWS(F) = CWN_LAYER_SOURCE_ROWS(F)
+
+
+LDS_BYTES = 160 * 1024
+_IDX_BYTES = (MAX_ENTRIES * 4 + 5 * MAX_ENTRIES * 2 + 3 * (TASK_ROWS + 2) * 2 + 15) // 16 * 16
+
+
+def lds_bytes(F: int, gemm_rows: int, source_rows: int) -> int:
+    """= cwn_layer_fused_lds_bytes: bf16 planes of the GEMM rows (Y overwrites them) + fp32 boundary
+    sources + index scratch."""
+    return 3 * gemm_rows * (F + 8) * 2 + source_rows * F * 4 + _IDX_BYTES
 
 
 def _pad16(n: int) -> int:
     return (n + 15) // 16 * 16
+
+
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
 
 
 class BlockPlan:
@@ -88,8 +102,8 @@ class BlockPlan:
         return sets
 
     def items(self, F: int, has_up: Sequence[bool]):
-        """(table int32 [n_items, ITEM_INTS] on the plan's device, max padded GEMM rows) for feature
-        width F, or None when some complex does not fit one workgroup's LDS (hub complexes: the
+        """(table int32 [n_items, ITEM_INTS] on the plan's device, max padded GEMM rows, max boundary
+        source rows) for feature width F, or None when some complex does not fit one workgroup's LDS (hub complexes: the
         caller then runs the CSR path).  `has_up[d]`: dimension d reduces an upper adjacency with
         coboundary features (needs d + 1 < n_dims)."""
         key = (F, tuple(bool(h) for h in has_up))
@@ -97,16 +111,21 @@ class BlockPlan:
             return self._tables[key]
         out = self._build(F, key[1])
         if out is not None:
-            table, max_rows = out
+            table, max_rows, max_src = out
             t = torch.from_numpy(table)
             if self.device is not None:
                 t = t.to(self.device)
-            out = (t, max_rows)
+            out = (t, max_rows, max_src)
         self._tables[key] = out
         return out
 
     def _build(self, F: int, has_up):
         cap = gemm_rows_cap(F)
+        ng_round = 2048 // F       # rows per round of the kernel: the coface block starts at a multiple
+
+        def staged(n_g: int, n_c: int) -> int:
+            r1 = _pad16(n_g)
+            return (r1 + ng_round - 1) // ng_round * ng_round + _pad16(n_c) if n_c > 0 else r1
         C = self.C
         if C == 0:
             return None
@@ -115,9 +134,9 @@ class BlockPlan:
                 return None
         gmax = max(1, C // TARGET_ITEMS)
         recs: List[np.ndarray] = []
-        max_rows = 0
+        max_rows = max_src = 0
         zero = np.zeros(C + 1, dtype=np.int64)
-        for g, tasks in self._sets(has_up):
+        for set_id, (g, tasks) in enumerate(self._sets(has_up)):
             n_g = self.cells[g] if g is not None else None
             n_c = self.cells[g + 1] if g is not None else None
             up = self.up_ptr[g] if g is not None else zero
@@ -127,30 +146,36 @@ class BlockPlan:
                 c1 = c0
                 while c1 < C and c1 - c0 < gmax:
                     nxt = c1 + 1
-                    ok = True
                     if g is not None:
-                        rows = _pad16(int(self.cell_ptr[g][nxt] - self.cell_ptr[g][c0])) + \
-                            _pad16(int(self.cell_ptr[g + 1][nxt] - self.cell_ptr[g + 1][c0]))
-                        ok = rows <= cap
-                    ents = int(up[nxt] - up[c0]) + sum(int(bp[nxt] - bp[c0]) for bp in bps)
-                    ok = ok and ents <= MAX_ENTRIES
-                    ok = ok and all(int(self.cell_ptr[d][nxt] - self.cell_ptr[d][c0]) <= TASK_ROWS for d in tasks)
-                    ok = ok and all(d == 0 or int(self.cell_ptr[d - 1][nxt] - self.cell_ptr[d - 1][c0]) <= 65535
-                                    for d in tasks)
+                        rows = staged(int(self.cell_ptr[g][nxt] - self.cell_ptr[g][c0]),
+                                      int(self.cell_ptr[g + 1][nxt] - self.cell_ptr[g + 1][c0]))
+                    else:
+                        rows = staged(int(self.cell_ptr[tasks[0]][nxt] - self.cell_ptr[tasks[0]][c0]), 0)
+                    # cells of dim d-1 the boundary streams read (staged in LDS), entries padded to 4
+                    src = sum(int(self.cell_ptr[d - 1][nxt] - self.cell_ptr[d - 1][c0])
+                              for d, bp in zip(tasks, bps) if d > 0 and bp[nxt] > bp[c0])
+                    ents = _pad4(int(up[nxt] - up[c0])) + sum(_pad4(int(bp[nxt] - bp[c0])) for bp in bps)
+                    ok = (rows <= cap and src <= cap and lds_bytes(F, rows, src) <= LDS_BYTES
+                          and ents <= MAX_ENTRIES
+                          and all(int(self.cell_ptr[d][nxt] - self.cell_ptr[d][c0]) <= TASK_ROWS for d in tasks))
                     if not ok:
                         break
                     c1 = nxt
                 if c1 == c0:
                     return None                 # a single complex exceeds the caps
                 r = np.zeros(ITEM_INTS, dtype=np.int32)
+                r[0] = set_id << 8
                 if g is not None:
                     ng = int(self.cell_ptr[g][c1] - self.cell_ptr[g][c0])
                     nc = int(self.cell_ptr[g + 1][c1] - self.cell_ptr[g + 1][c0])
-                    r[0] = 1 if ng > 0 else 0
+                    r[0] |= 1 if ng > 0 else 0
                     r[1:8] = [g, self.cell_ptr[g][c0], ng, self.cell_ptr[g + 1][c0], nc, up[c0], up[c1] - up[c0]]
                     if ng > 0:
-                        max_rows = max(max_rows, _pad16(ng) + _pad16(nc))
+                        max_rows = max(max_rows, staged(ng, nc))
+                else:
+                    max_rows = max(max_rows, staged(int(self.cell_ptr[tasks[0]][c1] - self.cell_ptr[tasks[0]][c0]), 0))
                 r[8] = len(tasks)
+                src = 0
                 for t, d in enumerate(tasks):
                     bp = bps[t]
                     o = 9 + 7 * t
@@ -159,9 +184,12 @@ class BlockPlan:
                     if d > 0:
                         r[o + 5] = self.cell_ptr[d - 1][c0]
                         r[o + 6] = self.cell_ptr[d - 1][c1] - self.cell_ptr[d - 1][c0]
+                        if bp[c1] > bp[c0]:
+                            src += int(r[o + 6])
+                max_src = max(max_src, src)
                 recs.append(r)
                 c0 = c1
         # heavy items first: a workgroup with four row tiles should not start behind the short ones
         table = np.stack(recs)
         order = np.argsort(-(table[:, 3].astype(np.int64) + table[:, 5]) * (table[:, 0] & 1), kind='stable')
-        return np.ascontiguousarray(table[order]), max(max_rows, 16)
+        return np.ascontiguousarray(table[order]), max(max_rows, 16), max_src

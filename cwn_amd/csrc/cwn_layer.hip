@@ -11,25 +11,47 @@
 // A batched complex is block-diagonal and per-complex contiguous (data/complex.py:148-169), a
 // ZINC-like complex is ~55 cells x 512 B.  So a workgroup (512 threads, 8 waves) OWNS a range of
 // complexes for one "GEMM dimension" g (plus, as a second task, the top dimension that has no
-// upper adjacency) and never leaves the CU's LDS between the dense and the sparse half:
+// upper adjacency) and never leaves the CU's LDS between the dense and the sparse half.  The
+// kernel is a latency chain, built around one rule: after the item record, every global load of
+// the item is issued in ONE branch-free run, and nothing after that touches memory again until
+// the output rows are stored --
 //
-//   1. item record (96 B, scalar loads)                                  1st dependent round trip
-//   2. all global loads of the item at once: its COO entries (int64, as  2nd (and last) round trip
-//      delivered), its rows of x_g and x_{g+1}, this wave's slice of W    before the epilogue gathers
-//   3. COO -> LDS, stable counting rank by destination (P lanes per entry scan the keys, combined
-//      by shuffles) -> per-item CSR in LDS (rowptr, col, aux as 16-bit LOCAL row numbers)
-//   4. x rows -> exact 3-way bf16 split (cwn_split.h) -> three bf16 planes in LDS
-//   5. boundary stream + self terms of every task (global gathers of rows this CU just touched)
+//   1. item record: one lane-parallel load, fields by v_readlane; the set record (all pointers of
+//      this item's GEMM dimension) by scalar loads from the kernel-argument segment
+//   2. loads, in order of use: COO entries (int64, as delivered), eps, bias, this wave's slice of
+//      the PRE-PACKED weight (bf16 hi/mid/lo planes in MFMA-fragment order: 1 KiB contiguous per
+//      instruction), the rows of x_g and x_{g+1} (GEMM operands; also the self terms, see below),
+//      the rows of x_{g-1} the boundary stream reads
+//   3. COO -> LDS; stable rank by destination: one 32-bit key (row << 11 | entry) per entry, P
+//      lanes per entry count the smaller keys of their share (ds_read_b128, 4 keys a read), shuffle
+//      reduce -> per-item CSR in LDS (rowptr, col, aux as 16-bit LOCAL row numbers)
+//   4. GEMM rows -> exact 3-way bf16 split (cwn_split.h) -> three bf16 planes in LDS; boundary-source
+//      rows -> fp32 in LDS
+//   5. boundary stream + self terms of every task, out of LDS and registers
 //   6. Y1 = x_g W[:, :F]^T + b,  Y2 = x_{g+1} W[:, F:]^T : v_mfma_f32_16x16x32_bf16, six per 32
-//      k-values, wave w owns output columns 16w..16w+15 (F = 128) for every row tile -> fp32 in LDS
+//      k-values, wave w owns output columns 16w..16w+15 (F = 128) for every row tile; the fp32
+//      result overwrites the planes (dead by then)
 //   7. out_up[i] = sum_p relu(Y1[col[p]] + Y2[aux[p]]) + (1 + eps1) x_i out of LDS, in entry order
 //
+// Thread t loads float4 number t of row (t / (F/4)) + NG*i of the staged block, and the lane group
+// that later FINISHES output row r is exactly the one that loaded x row r (same rows, same columns):
+// the self terms are the load registers themselves, nothing is read twice.
+//
+// What the measurements said on the way here (tools/time_layer_phases.py, shader-clock stamps per
+// phase and workgroup; ZINC-128, one complex per workgroup):
+//   * 19 us/launch: item fields read as `it[k]` behind conditionals -> one global load + vmcnt(0) per
+//     field, twelve serial round trips;
+//   * pointers rebuilt from integers dereference as FLAT loads, and loads behind branches make the
+//     compiler wait with vmcnt(0) (= for the 200 KB issued later) wherever an early result is used;
+//   * fragment-shaped loads of the fp32 weight (16 rows x 32 B per quarter wave) run the address unit
+//     at 1/8 rate: issuing the loads alone took 6 us.  Hence the packed weight.
 // HBM traffic = the item's x rows once, its COO entries once, the two output streams once.  No
 // atomics, no zero-fill pass; sums are sequential in the original entry order (deterministic, the
 // order a sequential index_add_ visits them).  Results are bit-identical to the two-kernel path
 // (cwn_gemm_split.hip + cwn_aggregate.hip): same split, same MFMA order, same epilogue arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 #include <mutex>
 #include "../../include/cwn_hip.h"
 #include "cwn_split.h"
@@ -41,22 +63,45 @@ using cwn::frag_cd;
 constexpr int kThreads = 512;
 constexpr int kEcap = CWN_LAYER_MAX_ENTRIES;
 constexpr int kTaskRows = CWN_LAYER_TASK_ROWS;
-constexpr int kNX = 6;                      // float4 of x per thread at the row cap (12288 / F rows)
+constexpr int kNX = 6;                      // float4 of staged rows per thread at the row cap (12288 / F rows)
+constexpr int kNE = 6;                      // float4 of boundary-source rows per thread (12288 / F rows)
 
 // item record fields (include/cwn_hip.h)
 enum { I_FLAGS = 0, I_G, I_GR0, I_GN, I_CR0, I_CN, I_UE0, I_UNE, I_NT, I_TASK0 };
 enum { T_DIM = 0, T_R0, T_N, T_BE0, T_BNE, T_SR0, T_SN, T_INTS };
 
+// One SET = the items that share a GEMM dimension (cwn_amd/blockplan.py): the launcher resolves every
+// pointer such an item needs into one flat record of 8-byte fields, and a workgroup reads the record
+// of ITS set from the kernel-argument segment at a run-time offset (scalar loads).  With the
+// per-dimension descriptors selected field by field in the kernel (dim == 0 ? .. : ..) the compiler
+// ran out of SGPRs and reloaded kernel arguments ten times, one wait each.
+enum { S_XG = 0, S_XC, S_UP_INDEX, S_UP_SHARED, S_UP_E, S_WP, S_MSG_BIAS, S_NG_NC, S_TASK0 };
+enum { ST_X = 0, ST_XS, ST_OUT_UP, ST_OUT_B, ST_B_INDEX, ST_B_E, ST_EPS1, ST_EPS2, ST_N_NS, ST_FIELDS };
+constexpr int kSetFields = S_TASK0 + 2 * ST_FIELDS;         // 26 fields of 8 bytes
+// S_NG_NC / ST_N_NS pack two int32 cell counts (low: this dimension, high: dimension + 1 / - 1): every
+// range an item names is checked against them before a single address is formed
+constexpr int kMaxSets = CWN_LAYER_MAX_DIMS;
+
 struct LayerArgs {
-    cwn_layer_dim d[CWN_LAYER_MAX_DIMS];
+    uint64_t set[kMaxSets][kSetFields];      // MUST stay first: read through the kernarg segment pointer
     const int32_t* items;
     int32_t* err;
-    int32_t rows_cap;                        // padded GEMM rows the LDS of this launch holds
+    int32_t rows_cap;                        // staged rows (GEMM operands) the LDS of this launch holds
+    int32_t xrows_cap;                       // boundary-source rows it holds
+#ifdef CWN_LAYER_TIMING
+    unsigned long long* stamps;              // [n_items][16] shader-clock stamps of workgroup phase ends
+#endif
 };
 
-// Field-wise select instead of d[dim]: a dynamically indexed by-value struct lands in scratch
-// (cwn_aggregate.hip has the measurement).
-#define CWN_PICK(field, dim) ((dim) == 0 ? A.d[0].field : (dim) == 1 ? A.d[1].field : A.d[2].field)
+#ifdef CWN_LAYER_TIMING
+#define CWN_STAMP(k)                                                                   \
+    do {                                                                               \
+        if (threadIdx.x == 0 && A.stamps != nullptr)                                   \
+            A.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
+#else
+#define CWN_STAMP(k) do { } while (0)
+#endif
 
 template <int F> struct Geo {
     static constexpr int kPlaneStride = F + 8;              // bf16 elements per plane row
@@ -64,22 +109,59 @@ template <int F> struct Geo {
     static constexpr int kKS = F / 32;                      // k-steps of 32
     static constexpr int kNCT = F / 16;                     // column tiles
     static constexpr int kWPC = 8 / kNCT;                   // waves sharing a column tile (row-tile parity)
-    static constexpr int kG = F / 4;                        // lanes per row in the reduce phases
-    static constexpr int kNG = kThreads / kG;               // rows in flight
-    static constexpr int kF4 = F / 4;                       // float4 per row
+    static constexpr int kG = F / 4;                        // lanes per row
+    static constexpr int kNG = kThreads / kG;               // rows per round (16 at F = 128, 32 at F = 64)
+    static constexpr int kWChunks = 2 * kKS * 3;            // 1-KiB chunks of the packed weight per column tile
+    // planes [3][rows][F + 8] bf16, overwritten by Y [rows][F + 4] fp32 once the MFMAs have read them
     __host__ __device__ static constexpr size_t planes_bytes(int rows) { return (size_t)3 * rows * kPlaneStride * 2; }
-    __host__ __device__ static constexpr size_t y_bytes(int rows) { return (size_t)rows * kYStride * 4; }
+    __host__ __device__ static constexpr size_t xrows_bytes(int rows) { return (size_t)rows * F * 4; }
 };
 
-// index scratch behind the planes and Y: six u16 arrays of kEcap + three row-pointer arrays
-constexpr size_t kIdxBytes = (size_t)6 * kEcap * 2 + (size_t)3 * (kTaskRows + 2) * 2;
+// index scratch: u32 keys, five u16 arrays of kEcap, three row-pointer arrays
+constexpr int kRpStride = kTaskRows + 2;
+constexpr size_t kIdxBytes = (size_t)kEcap * 4 + (size_t)5 * kEcap * 2 + (size_t)3 * kRpStride * 2;
 
 template <int F>
-__host__ __device__ constexpr size_t lds_bytes(int rows) {
-    return Geo<F>::planes_bytes(rows) + Geo<F>::y_bytes(rows) + ((kIdxBytes + 15) & ~(size_t)15);
+__host__ __device__ constexpr size_t lds_bytes(int rows, int xrows) {
+    return Geo<F>::planes_bytes(rows) + Geo<F>::xrows_bytes(xrows) + ((kIdxBytes + 15) & ~(size_t)15);
 }
 
-__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Pointers rebuilt from the 8-byte fields of a set record carry no address space: dereferenced as
+// plain C++ pointers they compile to FLAT loads (which also count against lgkmcnt and made the
+// compiler wait for vmcnt(0) AND lgkmcnt(0) between them).  These types pin them to global memory.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) float* gcf_p;
+typedef __attribute__((address_space(1))) float* gf_p;
+typedef const __attribute__((address_space(1))) int64_t* gci64_p;
+typedef const __attribute__((address_space(1))) v4f* gcv4_p;
+typedef const __attribute__((address_space(1))) v4u* gcu4_p;
+typedef __attribute__((address_space(1))) v4f* gv4_p;
+typedef const __attribute__((address_space(1))) unsigned char* gcb_p;
+
+__device__ __forceinline__ float4 ldg4(gcf_p p) {
+    const v4f v = *(gcv4_p)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 ldgu4(gcb_p p) {
+    const v4u v = *(gcu4_p)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stg4(gf_p p, const float4& a) {
+    const v4f v = {a.x, a.y, a.z, a.w};
+    *(gv4_p)p = v;
+}
+__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 sel4(bool c, const float4& a, const float4& b) {
+    return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+// xv[k] for a run-time k: a chain of selects on registers (an indexed array would live in scratch)
+__device__ __forceinline__ float4 pick(const float4 (&xv)[kNX], int k) {
+    float4 r = xv[0];
+#pragma unroll
+    for (int i = 1; i < kNX; ++i) r = sel4(k == i, xv[i], r);
+    return r;
+}
 
 template <int F>
 __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
@@ -90,334 +172,479 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     const int rows_cap = A.rows_cap;
 
     uint16_t* const planes = reinterpret_cast<uint16_t*>(smem);                    // [3][rows_cap][F + 8]
-    float* const Y = reinterpret_cast<float*>(smem + G::planes_bytes(rows_cap));   // [rows_cap][F + 4]
-    uint16_t* const idx = reinterpret_cast<uint16_t*>(smem + G::planes_bytes(rows_cap) + G::y_bytes(rows_cap));
-    uint16_t* const ukey = idx;                 // unsorted local destination / source / shared row
-    uint16_t* const uval = idx + kEcap;
-    uint16_t* const uaux = idx + 2 * kEcap;
-    uint16_t* const skey = idx + 3 * kEcap;     // sorted by destination, stable
-    uint16_t* const scol = idx + 4 * kEcap;
-    uint16_t* const saux = idx + 5 * kEcap;
-    uint16_t* const rowptr = idx + 6 * kEcap;   // [3][kTaskRows + 2]: upper, boundary of task 0, of task 1
+    float* const Y = reinterpret_cast<float*>(smem);                               // [rows_cap][F + 4], later
+    float* const xsrc = reinterpret_cast<float*>(smem + G::planes_bytes(rows_cap)); // [xrows_cap][F]
+    unsigned char* const idx = smem + G::planes_bytes(rows_cap) + G::xrows_bytes(A.xrows_cap);
+    uint32_t* const ukey = reinterpret_cast<uint32_t*>(idx);        // (local destination << 11) | entry
+    uint16_t* const uval = reinterpret_cast<uint16_t*>(idx + (size_t)kEcap * 4);   // local source row
+    uint16_t* const uaux = uval + kEcap;                            // local shared (coface) row
+    uint16_t* const skey = uval + 2 * kEcap;                        // sorted by destination, stable
+    uint16_t* const scol = uval + 3 * kEcap;
+    uint16_t* const saux = uval + 4 * kEcap;
+    uint16_t* const rowptr = uval + 5 * kEcap;   // [3][kRpStride]: upper, boundary of task 0, of task 1
 
-    // ---- 1. item record (uniform address: scalar loads) -------------------------------------------
-    const int32_t* it = A.items + (size_t)blockIdx.x * CWN_LAYER_ITEM_INTS;
-    const int flags = it[I_FLAGS];
+    CWN_STAMP(0);
+    // ---- 1. item record: ONE load (lane l reads word l), fields broadcast with v_readlane -----------
+    const int32_t itv = A.items[(size_t)blockIdx.x * CWN_LAYER_ITEM_INTS + (lane & (CWN_LAYER_ITEM_INTS - 1))];
+    auto fld = [&](int k) { return __builtin_amdgcn_readlane(itv, k); };
+    const int flags = fld(I_FLAGS);
     const bool has_gemm = (flags & 1) != 0;
-    const int g = it[I_G], g_r0 = it[I_GR0], g_n = has_gemm ? it[I_GN] : 0;
-    const int c_r0 = it[I_CR0], c_n = has_gemm ? it[I_CN] : 0;
-    const int u_e0 = it[I_UE0], u_ne = has_gemm ? it[I_UNE] : 0;
-    const int n_tasks = it[I_NT];
-    int t_dim[2], t_r0[2], t_n[2], t_be0[2], t_bne[2], t_sr0[2], t_sn[2];
+    const int set = (flags >> 8) & 3;
+    const int n_tasks = fld(I_NT);
+    CWN_STAMP(9);
+    int t_r0[2], t_n[2], t_be0[2], t_bne[2], t_sr0[2], t_sn[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int32_t* tk = it + I_TASK0 + t * T_INTS;
+        const int o = I_TASK0 + t * T_INTS;
         const bool on = t < n_tasks;
-        t_dim[t] = on ? tk[T_DIM] : 0;
-        t_r0[t] = tk[T_R0];
-        t_n[t] = on ? tk[T_N] : 0;
-        t_be0[t] = tk[T_BE0];
-        t_bne[t] = on ? tk[T_BNE] : 0;
-        t_sr0[t] = tk[T_SR0];
-        t_sn[t] = tk[T_SN];
+        t_r0[t] = fld(o + T_R0);
+        t_n[t] = on ? fld(o + T_N) : 0;
+        t_be0[t] = fld(o + T_BE0);
+        t_bne[t] = on ? fld(o + T_BNE) : 0;
+        t_sr0[t] = fld(o + T_SR0);
+        t_sn[t] = (on && t_bne[t] > 0) ? fld(o + T_SN) : 0;  // source rows are staged only when used
     }
-    const int T1 = (g_n + 15) >> 4, T2 = (c_n + 15) >> 4;      // row tiles of Y1, Y2
-    const int rows_pad = (T1 + T2) << 4;
-    // segments of the item's combined entry list: [0, s1) upper, [s1, s2) boundary 0, [s2, s3) boundary 1
-    const int s1 = u_ne, s2 = s1 + t_bne[0], s3 = s2 + t_bne[1];
-    // a record that does not fit the launch's LDS: report and leave (uniform over the workgroup)
-    if (rows_pad > rows_cap || s3 > kEcap || s1 < 0 || s2 < s1 || s3 < s2 || t_n[0] > kTaskRows ||
-        t_n[1] > kTaskRows || g_n > kTaskRows || (has_gemm && (g < 0 || g > 1))) {
-        if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
-        return;
+    // staged rows: [0, g_n) the cells of task 0 (the GEMM dimension g when the item has one), then, from
+    // row R1 (a multiple of the rows-per-round, so that lane groups line up), the c_n cells of g + 1
+    const int g_r0 = has_gemm ? fld(I_GR0) : t_r0[0], g_n = has_gemm ? fld(I_GN) : t_n[0];
+    const int c_r0 = fld(I_CR0), c_n = has_gemm ? fld(I_CN) : 0;
+    const int u_e0 = fld(I_UE0), u_ne = has_gemm ? fld(I_UNE) : 0;
+    const int T1 = (g_n + 15) >> 4, T2 = (c_n + 15) >> 4;      // 16-row tiles of Y1, Y2
+    const int R1 = (T1 * 16 + G::kNG - 1) / G::kNG * G::kNG;   // first staged row of the cofaces
+    const int rows_pad = c_n > 0 ? R1 + T2 * 16 : T1 * 16;
+    // segments of the item's combined entry list, each starting at a multiple of 4 (ds_read_b128 of
+    // four keys): [0, s1) upper, [b1, s2) boundary of task 0, [b2, s3) boundary of task 1
+    const int s1 = u_ne, b1 = (s1 + 3) & ~3, s2 = b1 + t_bne[0], b2 = (s2 + 3) & ~3, s3 = b2 + t_bne[1];
+    const int total = (s3 + 3) & ~3;
+    // boundary sources in LDS: [0, t_sn[0]) cells of dim g-1 (loaded), then the g_n cells of dim g (copied
+    // from the staged rows) when task 1 reads them
+    const int x_rows = t_sn[0] + t_sn[1];
+    const int gl = tid % G::kG, gq = tid / G::kG, f = gl * 4;  // lane group gq finishes rows gq, gq + kNG, ...
+
+    // the set record of this item: scalar loads from the kernel-argument segment at a run-time offset
+    typedef const uint64_t __attribute__((address_space(4))) karg_u64;
+    karg_u64* const sd = (karg_u64*)__builtin_amdgcn_kernarg_segment_ptr() + min(set, kMaxSets - 1) * kSetFields;
+    const gcf_p xg = (gcf_p)sd[S_XG];
+    const gcf_p xc = (gcf_p)sd[S_XC];                          // x_{g+1}
+    const gci64_p up_index = (gci64_p)sd[S_UP_INDEX];
+    const gci64_p up_shared = (gci64_p)sd[S_UP_SHARED];
+    const int64_t up_E = (int64_t)sd[S_UP_E];
+    const gcb_p wp = (gcb_p)sd[S_WP];
+    const gcf_p bias = (gcf_p)sd[S_MSG_BIAS];
+    const uint64_t ng_nc = sd[S_NG_NC];
+    const gcf_p xs_t0 = (gcf_p)sd[S_TASK0 + ST_XS];            // x_{g-1}: boundary sources of task 0
+    const gci64_p b_index0 = (gci64_p)sd[S_TASK0 + ST_B_INDEX];
+    const gci64_p b_index1 = (gci64_p)sd[S_TASK0 + ST_FIELDS + ST_B_INDEX];
+    const int64_t b_E0 = (int64_t)sd[S_TASK0 + ST_B_E], b_E1 = (int64_t)sd[S_TASK0 + ST_FIELDS + ST_B_E];
+    const uint64_t n_ns0 = sd[S_TASK0 + ST_N_NS], n_ns1 = sd[S_TASK0 + ST_FIELDS + ST_N_NS];
+    const gf_p out_up0 = (gf_p)sd[S_TASK0 + ST_OUT_UP];
+    const gf_p out_up1 = (gf_p)sd[S_TASK0 + ST_FIELDS + ST_OUT_UP];
+    const gf_p out_b0 = (gf_p)sd[S_TASK0 + ST_OUT_B];
+    const gf_p out_b1 = (gf_p)sd[S_TASK0 + ST_FIELDS + ST_OUT_B];
+    const gcf_p e0p = (gcf_p)sd[S_TASK0 + ST_EPS1], e1p = (gcf_p)sd[S_TASK0 + ST_EPS2];
+    const gcf_p e2p = (gcf_p)sd[S_TASK0 + ST_FIELDS + ST_EPS1], e3p = (gcf_p)sd[S_TASK0 + ST_FIELDS + ST_EPS2];
+
+    CWN_STAMP(10);
+    // A record that does not fit the launch's LDS, or names cells / entries the tensors do not have:
+    // report and leave (uniform over the workgroup) BEFORE any address is formed from it.
+    {
+        auto in_range = [](int64_t first, int64_t count, int64_t size) { return first >= 0 && count >= 0 && first + count <= size; };
+        bool ok = set < kMaxSets && rows_pad <= rows_cap && x_rows <= A.xrows_cap && total <= kEcap &&
+                  u_ne >= 0 && t_bne[0] >= 0 && t_bne[1] >= 0 && t_n[0] <= kTaskRows && t_n[1] <= kTaskRows &&
+                  g_n <= kTaskRows;
+        // task 0 IS the staged block [0, g_n); task 1 (if any) is the coface block and reads task 0's cells
+        ok = ok && g_r0 == t_r0[0] && g_n == t_n[0];
+        ok = ok && (n_tasks < 2 || (has_gemm && t_r0[1] == c_r0 && t_n[1] == c_n &&
+                                    (t_bne[1] == 0 || (t_sr0[1] == g_r0 && t_sn[1] == g_n))));
+        ok = ok && in_range(g_r0, g_n, (int32_t)n_ns0) && in_range(t_sr0[0], t_sn[0], (int32_t)(n_ns0 >> 32)) &&
+             in_range(t_be0[0], t_bne[0], b_E0);
+        ok = ok && (!has_gemm || (in_range(g_r0, g_n, (int32_t)ng_nc) && in_range(c_r0, c_n, (int32_t)(ng_nc >> 32)) &&
+                                  in_range(u_e0, u_ne, up_E)));
+        ok = ok && (n_tasks < 2 || (in_range(t_r0[1], t_n[1], (int32_t)n_ns1) && in_range(t_be0[1], t_bne[1], b_E1)));
+        if (!ok) {
+            if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
+            return;
+        }
     }
     bool bad = false;
 
-    // ---- 2. every global load of the item, entries first (vector loads return in order) ------------
-    const float* xg = CWN_PICK(x, g);
-    const float* xc = g == 0 ? A.d[1].x : A.d[2].x;           // x_{g+1}
-    const int64_t* up_index = CWN_PICK(up_index, g);
-    const int64_t* up_shared = CWN_PICK(up_shared, g);
-    const int64_t up_E = CWN_PICK(e_up, g);
-    const int64_t* b_index0 = CWN_PICK(b_index, t_dim[0]);
-    const int64_t* b_index1 = CWN_PICK(b_index, t_dim[1]);
-    const int64_t b_E0 = CWN_PICK(n_b, t_dim[0]), b_E1 = CWN_PICK(n_b, t_dim[1]);
-
+    // ---- 2. every global load of the item, in ONE branch-free run --------------------------------------
+    // No load sits behind a branch: a lane with nothing to fetch reads a harmless valid address (the
+    // item table) instead.  Behind branches the compiler cannot count the loads in flight and waits
+    // with vmcnt(0) -- i.e. for the 200 KB of rows and weights issued after the entries -- wherever
+    // an early result is used (measured: entries -> LDS and the rank each sat 2 us on such waits).
+    const gcf_p dummy = (gcf_p)A.items;                      // >= 128 readable bytes, 16-B aligned
+    const int ct = wave % G::kNCT, rt_par = wave / G::kNCT;
     int64_t ek[2], ev[2], ea[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int w = tid + i * kThreads;
-        ek[i] = ev[i] = ea[i] = 0;
-        if (w < s1) {
-            const int64_t e = (int64_t)u_e0 + w;
-            ev[i] = up_index[e];
-            ek[i] = up_index[up_E + e];
-            ea[i] = up_shared[e];
-        } else if (w < s2) {
-            const int64_t e = (int64_t)t_be0[0] + (w - s1);
-            ev[i] = b_index0[e];
-            ek[i] = b_index0[b_E0 + e];
-        } else if (w < s3) {
-            const int64_t e = (int64_t)t_be0[1] + (w - s2);
-            ev[i] = b_index1[e];
-            ek[i] = b_index1[b_E1 + e];
-        }
+        const bool in_up = w < s1, in_b0 = w >= b1 && w < s2, in_b1 = w >= b2 && w < s3;
+        const gci64_p src = in_up ? up_index : in_b0 ? b_index0 : in_b1 ? b_index1 : (gci64_p)A.items;
+        const int64_t E = in_up ? up_E : in_b0 ? b_E0 : in_b1 ? b_E1 : 0;
+        const int64_t e = in_up ? (int64_t)u_e0 + w : in_b0 ? (int64_t)t_be0[0] + (w - b1)
+                                                   : in_b1 ? (int64_t)t_be0[1] + (w - b2) : 0;
+        ev[i] = src[e];
+        ek[i] = src[E + e];
+        ea[i] = (in_up ? up_shared : (gci64_p)A.items)[in_up ? e : 0];
     }
-    // x rows of the GEMM operands: rows [0, 16 T1) from x_g, [16 T1, rows_pad) from x_{g+1}; rows past
-    // the real ones are clamped to the last real row (never stored; guarded loads serialise)
-    float4 xv[kNX];
-    const int nx = (rows_pad * G::kF4 + kThreads - 1) / kThreads;
-#pragma unroll
-    for (int i = 0; i < kNX; ++i) {
-        xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nx) {
-            const int q = tid + i * kThreads, row = q / G::kF4, c4 = q % G::kF4;
-            const bool first = row < (T1 << 4);
-            const int r = first ? min(row, g_n - 1) : min(row - (T1 << 4), c_n - 1);
-            const float* base = first ? xg + (int64_t)(g_r0 + r) * F : xc + (int64_t)(c_r0 + max(r, 0)) * F;
-            if (row < rows_pad) xv[i] = ldg4(base + c4 * 4);
-        }
+    float epsv;
+    {   // lane 0..3 of every wave -> eps1, eps2 of task 0, eps1, eps2 of task 1 (NULL = 0)
+        const gcf_p ep = lane == 0 ? e0p : lane == 1 ? e1p : lane == 2 ? e2p : lane == 3 ? e3p : (gcf_p)0;
+        const float v = *(ep != (gcf_p)0 ? ep : dummy);
+        epsv = ep != (gcf_p)0 ? v : 0.0f;
     }
-    // this wave's slice of W: output columns ct*16 .. +15, both halves of the [F, 2F] weight
-    const int ct = wave % G::kNCT, rt_par = wave / G::kNCT;
-    float4 wraw[2][G::kKS][2];
-    if (has_gemm) {
-        const float* msg_w = CWN_PICK(msg_w, g);
-        const float* wrow = msg_w + (int64_t)(ct * 16 + l15) * (2 * F) + kq * 8;
+    const bool has_bias = has_gemm && bias != (gcf_p)0;
+    float4 b4 = ldg4(has_bias ? bias + ct * 16 + kq * 4 : dummy);
+    if (!has_bias) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    CWN_STAMP(11);
+    // this wave's slice of the packed weight: kWChunks chunks of 1 KiB, lane l takes bytes 16 l .. 16 l + 15
+    uint4 wsp[2][G::kKS][3];
+    {
+        const gcb_p wbase = has_gemm ? wp + (size_t)ct * G::kWChunks * 1024 + lane * 16 : (gcb_p)A.items;
+        const int on = has_gemm ? 1024 : 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int ks = 0; ks < G::kKS; ++ks) {
-                wraw[h][ks][0] = ldg4(wrow + h * F + ks * 32);
-                wraw[h][ks][1] = ldg4(wrow + h * F + ks * 32 + 4);
-            }
+            for (int ks = 0; ks < G::kKS; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wsp[h][ks][pl] = ldgu4(wbase + ((h * G::kKS + ks) * 3 + pl) * on);
     }
+    CWN_STAMP(12);
+    // the staged rows; rows past the real ones re-read the last real row (never used)
+    float4 xv[kNX];
+#pragma unroll
+    for (int i = 0; i < kNX; ++i) {
+        const int row = min(gq + i * G::kNG, rows_pad - 1);
+        const bool second = c_n > 0 && row >= R1;
+        const int r = second ? min(row - R1, c_n - 1) : min(row, g_n - 1);
+        const gcf_p base = (rows_pad <= 0 || g_n <= 0) ? dummy
+                         : second ? xc + (int64_t)(c_r0 + r) * F + f : xg + (int64_t)(g_r0 + r) * F + f;
+        xv[i] = ldg4(base);
+    }
+    // rows the boundary stream of task 0 gathers from
+    float4 ev4[kNE];
+#pragma unroll
+    for (int i = 0; i < kNE; ++i) {
+        const int row = min(gq + i * G::kNG, t_sn[0] - 1);
+        ev4[i] = ldg4(t_sn[0] <= 0 ? dummy : xs_t0 + (int64_t)(t_sr0[0] + row) * F + f);
+    }
+    CWN_STAMP(1);
 
     // ---- 3a. entries -> LDS as local row numbers, range-checked --------------------------------------
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int w = tid + i * kThreads;
-        if (w < s3 && w < kEcap) {
-            int64_t k, v, a = 0;
-            int64_t nk, nv, na = 1;
+        if (w < total) {
+            int64_t k = 0, v = 0, a = 0, nk = 1, nv = 1, na = 1;
+            bool live = true;
             if (w < s1) {
                 k = ek[i] - g_r0; v = ev[i] - g_r0; a = ea[i] - c_r0;
                 nk = g_n; nv = g_n; na = c_n;
-            } else if (w < s2) {
+            } else if (w >= b1 && w < s2) {
                 k = ek[i] - t_r0[0]; v = ev[i] - t_sr0[0];
                 nk = t_n[0]; nv = t_sn[0];
-            } else {
+            } else if (w >= b2 && w < s3) {
                 k = ek[i] - t_r0[1]; v = ev[i] - t_sr0[1];
-                nk = t_n[1]; nv = t_sn[1];
+                nk = t_n[1];
+                v = (v >= 0 && v < t_sn[1]) ? v + t_sn[0] : -1;   // row in the staged source block
+                nv = t_sn[0] + t_sn[1];
+            } else {
+                live = false;                  // padding slot between two segments: sorts after everything
             }
-            if (k < 0 || k >= nk || v < 0 || v >= nv || v > 65535 || a < 0 || a >= na) {
+            if (live && (k < 0 || k >= nk || v < 0 || v >= nv || a < 0 || a >= na)) {
                 bad = true;
                 k = 0; v = 0; a = 0;
             }
-            ukey[w] = (uint16_t)k;
+            ukey[w] = live ? ((uint32_t)k << 11) | (uint32_t)w : 0xFFFFFFFFu;
             uval[w] = (uint16_t)v;
             uaux[w] = (uint16_t)a;
         }
     }
     if (bad) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
     __syncthreads();
+    CWN_STAMP(2);
 
-    // ---- 3b. stable rank by destination: P lanes per entry, each scans 1/P of the entry's segment ----
-    const int total = min(s3, kEcap);
+    // ---- 3b. stable rank by destination: P lanes per entry, each counts the smaller keys of its share --
     {
         int P = 1;
         while (P < 8 && total * (P * 2) <= kThreads) P *= 2;
         const int per_pass = kThreads / P;
         for (int base = 0; base < total; base += per_pass) {
             const int w = base + tid / P, sub = tid % P;
-            int cnt = 0, k = 0, seg0 = 0;
-            const bool live = w < total;
-            if (live) {
-                seg0 = w < s1 ? 0 : (w < s2 ? s1 : s2);
-                const int seg1 = w < s1 ? s1 : (w < s2 ? s2 : s3);
-                k = ukey[w];
-                const int len = seg1 - seg0, chunk = (len + P - 1) / P;
-                const int lo = seg0 + sub * chunk, hi = min(seg1, lo + chunk);
-                for (int e = lo; e < hi; ++e) {
-                    const int ke = ukey[e];
-                    cnt += (ke < k || (ke == k && e < w)) ? 1 : 0;
+            int cnt = 0, seg0 = 0;
+            uint32_t key = 0xFFFFFFFFu;
+            if (w < total) {
+                seg0 = w < b1 ? 0 : (w < b2 ? b1 : b2);
+                const int seg1 = w < b1 ? b1 : (w < b2 ? b2 : total);          // padded end: multiple of 4
+                key = ukey[w];
+                const int len4 = (seg1 - seg0) >> 2, chunk4 = (len4 + P - 1) / P;
+                const int lo = seg0 + 4 * sub * chunk4, hi = min(seg1, lo + 4 * chunk4);
+                // four reads in flight per step (a read a step is one LDS round trip per four keys)
+                for (int e = lo; e < hi; e += 16) {
+                    uint4 kk[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        kk[u] = *reinterpret_cast<const uint4*>(ukey + min(e + 4 * u, seg1 - 4));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = (kk[u].x < key) + (kk[u].y < key) + (kk[u].z < key) + (kk[u].w < key);
+                        cnt += e + 4 * u < hi ? c : 0;
+                    }
                 }
             }
             for (int off = 1; off < P; off <<= 1) cnt += __shfl_xor(cnt, off, 64);
-            if (live && sub == 0) {
+            if (key != 0xFFFFFFFFu && sub == 0) {
                 const int pos = seg0 + cnt;
-                skey[pos] = (uint16_t)k;
+                skey[pos] = (uint16_t)(key >> 11);
                 scol[pos] = uval[w];
                 saux[pos] = uaux[w];
             }
         }
     }
     __syncthreads();
+    CWN_STAMP(3);
 
     // ---- 3c. row pointers from the sorted keys (run boundaries), empty rows included -----------------
-    for (int p = tid; p < total; p += kThreads) {
-        const int which = p < s1 ? 0 : (p < s2 ? 1 : 2);
-        const int seg0 = which == 0 ? 0 : (which == 1 ? s1 : s2);
+    for (int p = tid; p < s3; p += kThreads) {
+        const int which = p < b1 ? 0 : (p < b2 ? 1 : 2);
+        const int seg0 = which == 0 ? 0 : (which == 1 ? b1 : b2);
         const int seg1 = which == 0 ? s1 : (which == 1 ? s2 : s3);
-        const int n_rows = which == 0 ? g_n : t_n[which - 1];
-        uint16_t* rp = rowptr + which * (kTaskRows + 2);
-        const int k = skey[p];
-        const int kprev = p > seg0 ? (int)skey[p - 1] : -1;
-        for (int r = kprev + 1; r <= k; ++r) rp[r] = (uint16_t)(p - seg0);
-        if (p == seg1 - 1)
-            for (int r = k + 1; r <= n_rows; ++r) rp[r] = (uint16_t)(seg1 - seg0);
+        if (p < seg1) {
+            const int n_rows = which == 0 ? g_n : t_n[which - 1];
+            uint16_t* rp = rowptr + which * kRpStride;
+            const int k = skey[p];
+            const int kprev = p > seg0 ? (int)skey[p - 1] : -1;
+            for (int r = kprev + 1; r <= k; ++r) rp[r] = (uint16_t)(p - seg0);
+            if (p == seg1 - 1)
+                for (int r = k + 1; r <= n_rows; ++r) rp[r] = (uint16_t)(seg1 - seg0);
+        }
     }
     if (s1 == 0)
         for (int r = tid; r <= g_n; r += kThreads) rowptr[r] = 0;
-    if (s2 == s1)
-        for (int r = tid; r <= t_n[0]; r += kThreads) rowptr[(kTaskRows + 2) + r] = 0;
-    if (s3 == s2)
-        for (int r = tid; r <= t_n[1]; r += kThreads) rowptr[2 * (kTaskRows + 2) + r] = 0;
+    if (s2 == b1)
+        for (int r = tid; r <= t_n[0]; r += kThreads) rowptr[kRpStride + r] = 0;
+    if (s3 == b2)
+        for (int r = tid; r <= t_n[1]; r += kThreads) rowptr[2 * kRpStride + r] = 0;
 
-    // ---- 4. x rows -> three bf16 planes ---------------------------------------------------------------
+    // ---- 4. GEMM rows -> three bf16 planes; boundary-source rows -> fp32 -------------------------------
+    {
+        const size_t plane = (size_t)rows_cap * G::kPlaneStride;
+        const bool copy_src = t_sn[1] > 0;      // task 1 gathers the staged cells of g: keep them as fp32 too
 #pragma unroll
-    for (int i = 0; i < kNX; ++i) {
-        if (i < nx) {
-            const int q = tid + i * kThreads, row = q / G::kF4, c4 = q % G::kF4;
-            if (row < rows_pad) {
+        for (int i = 0; i < kNX; ++i) {
+            const int row = gq + i * G::kNG;
+            if (has_gemm && row < rows_pad) {
                 uint2 ph, pm, pl;
                 cwn::split4(xv[i], ph, pm, pl);
-                const size_t plane = (size_t)rows_cap * G::kPlaneStride;
-                uint16_t* dst = planes + (size_t)row * G::kPlaneStride + c4 * 4;
+                uint16_t* dst = planes + (size_t)row * G::kPlaneStride + f;
                 *reinterpret_cast<uint2*>(dst) = ph;
                 *reinterpret_cast<uint2*>(dst + plane) = pm;
                 *reinterpret_cast<uint2*>(dst + 2 * plane) = pl;
             }
+            if (copy_src && row < g_n) *reinterpret_cast<float4*>(xsrc + (size_t)(t_sn[0] + row) * F + f) = xv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kNE; ++i) {
+            const int row = gq + i * G::kNG;
+            if (row < t_sn[0]) *reinterpret_cast<float4*>(xsrc + (size_t)row * F + f) = ev4[i];
         }
     }
     __syncthreads();
+    CWN_STAMP(4);
 
-    // ---- 5. boundary stream and self terms of every task ---------------------------------------------
-    const int gl = tid % G::kG, gq = tid / G::kG, f = gl * 4;
-    int z = 0;
-    asm volatile("" : "+v"(z));              // keeps the eps loads in VMEM (see cwn_aggregate.hip)
+    // ---- 5. boundary stream and self terms of every task, out of LDS -----------------------------------
+    float eps1[2], eps2[2];
+    eps1[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 0));
+    eps2[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 1));
+    eps1[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 2));
+    eps2[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 3));
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         if (t < n_tasks) {
-            const int d = t_dim[t];
-            const float* x = CWN_PICK(x, d);
-            const float* xs = d == 1 ? A.d[0].x : A.d[1].x;          // x_{d-1} (unused when d == 0)
-            float* out_up = CWN_PICK(out_up, d);
-            float* out_b = CWN_PICK(out_b, d);
-            const float* e1p = CWN_PICK(eps1, d);
-            const float* e2p = CWN_PICK(eps2, d);
-            const float scale1 = 1.0f + (e1p != nullptr ? e1p[z] : 0.0f);
-            const float scale2 = 1.0f + (e2p != nullptr ? e2p[z] : 0.0f);
-            const uint16_t* rp = rowptr + (t + 1) * (kTaskRows + 2);
-            const uint16_t* col = scol + (t == 0 ? s1 : s2);
-            const bool up_here = has_gemm && d == g;
-            for (int r = gq; r < t_n[t]; r += G::kNG) {
+            const gf_p out_up = t == 0 ? out_up0 : out_up1;
+            const gf_p out_b = t == 0 ? out_b0 : out_b1;
+            const float scale1 = 1.0f + eps1[t], scale2 = 1.0f + eps2[t];
+            const uint16_t* rp = rowptr + (t + 1) * kRpStride;
+            const uint16_t* col = scol + (t == 0 ? b1 : b2);
+            const bool up_here = has_gemm && t == 0;   // the GEMM dimension is task 0 (blockplan.py)
+            const int k0 = t == 0 ? 0 : R1 / G::kNG;   // first staged round of this task's cells
+            for (int k = 0; gq + k * G::kNG < t_n[t]; ++k) {
+                const int r = gq + k * G::kNG;
+                const float4 xi = pick(xv, k0 + k);      // the self term: this lane group loaded that row
                 const int start = rp[r], end = rp[r + 1];
                 const int64_t row = (int64_t)(t_r0[t] + r) * F + f;
-                const float4 xi = ldg4(x + row);
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                int p = start;
-                for (; p + 4 <= end; p += 4) {
+                // four entries in flight; added in entry order (a skipped slot adds +0: exact)
+                for (int p = start; p < end; p += 4) {
+                    int c[4];
                     float4 a[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) a[u] = ldg4(xs + (int64_t)(t_sr0[t] + col[p + u]) * F + f);
+                    for (int u = 0; u < 4; ++u) c[u] = col[min(p + u, end - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = lds4(xsrc + (size_t)c[u] * F + f);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        acc.x += a[u].x; acc.y += a[u].y; acc.z += a[u].z; acc.w += a[u].w;
+                        const bool on = p + u < end;
+                        acc.x += on ? a[u].x : 0.0f;
+                        acc.y += on ? a[u].y : 0.0f;
+                        acc.z += on ? a[u].z : 0.0f;
+                        acc.w += on ? a[u].w : 0.0f;
                     }
                 }
-                for (; p < end; ++p) {
-                    const float4 a = ldg4(xs + (int64_t)(t_sr0[t] + col[p]) * F + f);
-                    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
-                }
-                *reinterpret_cast<float4*>(out_b + row) =
-                    make_float4(acc.x + scale2 * xi.x, acc.y + scale2 * xi.y, acc.z + scale2 * xi.z,
-                                acc.w + scale2 * xi.w);
+                stg4(out_b + row, make_float4(acc.x + scale2 * xi.x, acc.y + scale2 * xi.y, acc.z + scale2 * xi.z,
+                                              acc.w + scale2 * xi.w));
                 if (!up_here)        // no upper adjacency in this dimension: zeros + self term
-                    *reinterpret_cast<float4*>(out_up + row) =
-                        make_float4(0.0f + scale1 * xi.x, 0.0f + scale1 * xi.y, 0.0f + scale1 * xi.z,
-                                    0.0f + scale1 * xi.w);
+                    stg4(out_up + row, make_float4(0.0f + scale1 * xi.x, 0.0f + scale1 * xi.y, 0.0f + scale1 * xi.z,
+                                                   0.0f + scale1 * xi.w));
             }
         }
     }
+    CWN_STAMP(5);
     if (!has_gemm) return;
 
     // ---- 6. Y1 | Y2 on the matrix cores ---------------------------------------------------------------
     {
         const size_t plane = (size_t)rows_cap * G::kPlaneStride;
-        const float* bias = CWN_PICK(msg_bias, g);
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias != nullptr) b4 = ldg4(bias + ct * 16 + kq * 4);
+        // this wave's row tiles: at most kMaxT per half (six 16-row tiles in all at the row cap); the
+        // accumulators wait in registers until every wave has read its fragments, because Y
+        // overwrites the planes.  Tiles go in PAIRS (two independent MFMA chains in flight).
+        constexpr int kMaxT = 12288 / F / 16 / G::kWPC;
+        static_assert(kMaxT % 2 == 0, "tiles are processed in pairs");
+        static_assert(offsetof(LayerArgs, set) == 0, "read through the kernarg segment pointer");
+        frag_cd acc[2][kMaxT];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            uint4 wf[G::kKS][3];
-#pragma unroll
-            for (int ks = 0; ks < G::kKS; ++ks)
-                cwn::split8(wraw[h][ks][0], wraw[h][ks][1], wf[ks][0], wf[ks][1], wf[ks][2]);
-            const int rt0 = h == 0 ? 0 : T1, rt1 = h == 0 ? T1 : T1 + T2;
+            const uint4 (&wf)[G::kKS][3] = wsp[h];
+            const int rt0 = h == 0 ? 0 : R1 / 16, rt1 = rt0 + (h == 0 ? T1 : T2);
             // row tiles of this half that are this wave's (F = 64: two waves share a column tile)
-            int rt = rt0 + ((rt_par - rt0) % G::kWPC + G::kWPC) % G::kWPC;
-            for (; rt < rt1; rt += 2 * G::kWPC) {
-                const bool two = rt + G::kWPC < rt1;
-                frag_cd c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-                const uint16_t* p0 = planes + (size_t)(rt * 16 + l15) * G::kPlaneStride + kq * 8;
-                const uint16_t* p1 = p0 + (size_t)(two ? G::kWPC * 16 : 0) * G::kPlaneStride;
+            const int first = rt0 + ((rt_par - rt0) % G::kWPC + G::kWPC) % G::kWPC;
 #pragma unroll
-                for (int ks = 0; ks < G::kKS; ++ks) {
-                    const uint4 xh0 = *reinterpret_cast<const uint4*>(p0 + ks * 32);
-                    const uint4 xm0 = *reinterpret_cast<const uint4*>(p0 + plane + ks * 32);
-                    const uint4 xl0 = *reinterpret_cast<const uint4*>(p0 + 2 * plane + ks * 32);
-                    const uint4 xh1 = *reinterpret_cast<const uint4*>(p1 + ks * 32);
-                    const uint4 xm1 = *reinterpret_cast<const uint4*>(p1 + plane + ks * 32);
-                    const uint4 xl1 = *reinterpret_cast<const uint4*>(p1 + 2 * plane + ks * 32);
-                    c0 = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh0, xm0, xl0, c0);
-                    c1 = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh1, xm1, xl1, c1);
+            for (int j = 0; j < kMaxT; j += 2) {
+                const int rta = first + j * G::kWPC, rtb = rta + G::kWPC;
+                if (rtb < rt1) {                 // two tiles: two independent MFMA chains (uniform over the wave)
+                    frag_cd c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                    const uint16_t* p0 = planes + (size_t)(rta * 16 + l15) * G::kPlaneStride + kq * 8;
+                    const uint16_t* p1 = planes + (size_t)(rtb * 16 + l15) * G::kPlaneStride + kq * 8;
+#pragma unroll
+                    for (int ks = 0; ks < G::kKS; ++ks) {
+                        const uint4 xh0 = *reinterpret_cast<const uint4*>(p0 + ks * 32);
+                        const uint4 xm0 = *reinterpret_cast<const uint4*>(p0 + plane + ks * 32);
+                        const uint4 xl0 = *reinterpret_cast<const uint4*>(p0 + 2 * plane + ks * 32);
+                        const uint4 xh1 = *reinterpret_cast<const uint4*>(p1 + ks * 32);
+                        const uint4 xm1 = *reinterpret_cast<const uint4*>(p1 + plane + ks * 32);
+                        const uint4 xl1 = *reinterpret_cast<const uint4*>(p1 + 2 * plane + ks * 32);
+                        c0 = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh0, xm0, xl0, c0);
+                        c1 = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh1, xm1, xl1, c1);
+                    }
+                    acc[h][j] = c0;
+                    acc[h][j + 1] = c1;
+                } else if (rta < rt1) {          // the odd tile of this half
+                    frag_cd c0 = {0.f, 0.f, 0.f, 0.f};
+                    const uint16_t* p0 = planes + (size_t)(rta * 16 + l15) * G::kPlaneStride + kq * 8;
+#pragma unroll
+                    for (int ks = 0; ks < G::kKS; ++ks) {
+                        const uint4 xh0 = *reinterpret_cast<const uint4*>(p0 + ks * 32);
+                        const uint4 xm0 = *reinterpret_cast<const uint4*>(p0 + plane + ks * 32);
+                        const uint4 xl0 = *reinterpret_cast<const uint4*>(p0 + 2 * plane + ks * 32);
+                        c0 = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh0, xm0, xl0, c0);
+                    }
+                    acc[h][j] = c0;
                 }
-                // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = x row (lane & 15)
-                if (h == 0 && bias != nullptr) {       // Y1 carries the Linear's bias
-                    c0[0] += b4.x; c0[1] += b4.y; c0[2] += b4.z; c0[3] += b4.w;
-                    c1[0] += b4.x; c1[1] += b4.y; c1[2] += b4.z; c1[3] += b4.w;
+            }
+        }
+        __syncthreads();                     // every wave has read its fragments: Y may overwrite the planes
+        CWN_STAMP(6);
+        // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = x row (lane & 15); Y1 carries the bias
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rt0 = h == 0 ? 0 : R1 / 16, rt1 = rt0 + (h == 0 ? T1 : T2);
+            const int first = rt0 + ((rt_par - rt0) % G::kWPC + G::kWPC) % G::kWPC;
+#pragma unroll
+            for (int j = 0; j < kMaxT; ++j) {
+                const int rt = first + j * G::kWPC;
+                if (rt < rt1) {
+                    frag_cd c = acc[h][j];
+                    if (h == 0 && has_bias) {
+                        c[0] += b4.x; c[1] += b4.y; c[2] += b4.z; c[3] += b4.w;
+                    }
+                    float* y0 = Y + (size_t)(rt * 16 + l15) * G::kYStride + ct * 16 + kq * 4;
+                    *reinterpret_cast<float4*>(y0) = make_float4(c[0], c[1], c[2], c[3]);
                 }
-                float* y0 = Y + (size_t)(rt * 16 + l15) * G::kYStride + ct * 16 + kq * 4;
-                *reinterpret_cast<float4*>(y0) = make_float4(c0[0], c0[1], c0[2], c0[3]);
-                if (two)
-                    *reinterpret_cast<float4*>(y0 + (size_t)(G::kWPC * 16) * G::kYStride) =
-                        make_float4(c1[0], c1[1], c1[2], c1[3]);
             }
         }
     }
     __syncthreads();
+    CWN_STAMP(7);
 
     // ---- 7. upper stream out of LDS: out_up[i] = sum_p relu(Y1[col[p]] + Y2[aux[p]]) + (1 + eps1) x_i -
     {
-        float* out_up = CWN_PICK(out_up, g);
-        const float* e1p = CWN_PICK(eps1, g);
-        const float scale1 = 1.0f + (e1p != nullptr ? e1p[z] : 0.0f);
-        const float* Y2 = Y + (size_t)(T1 << 4) * G::kYStride;
-        for (int r = gq; r < g_n; r += G::kNG) {
+        const float scale1 = 1.0f + eps1[0];
+        const float* Y2 = Y + (size_t)R1 * G::kYStride;
+        for (int k = 0; gq + k * G::kNG < g_n; ++k) {
+            const int r = gq + k * G::kNG;
+            const float4 xi = pick(xv, k);
             const int start = rowptr[r], end = rowptr[r + 1];
             const int64_t row = (int64_t)(g_r0 + r) * F + f;
-            const float4 xi = ldg4(xg + row);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int p = start; p < end; ++p) {
-                const float4 a = *reinterpret_cast<const float4*>(Y + (size_t)scol[p] * G::kYStride + f);
-                const float4 b = *reinterpret_cast<const float4*>(Y2 + (size_t)saux[p] * G::kYStride + f);
-                acc.x += fmaxf(a.x + b.x, 0.0f);
-                acc.y += fmaxf(a.y + b.y, 0.0f);
-                acc.z += fmaxf(a.z + b.z, 0.0f);
-                acc.w += fmaxf(a.w + b.w, 0.0f);
+            for (int p = start; p < end; p += 4) {
+                int cj[4], cc[4];
+                float4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    cj[u] = scol[min(p + u, end - 1)];
+                    cc[u] = saux[min(p + u, end - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = lds4(Y + (size_t)cj[u] * G::kYStride + f);
+                    b[u] = lds4(Y2 + (size_t)cc[u] * G::kYStride + f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool on = p + u < end;
+                    acc.x += on ? fmaxf(a[u].x + b[u].x, 0.0f) : 0.0f;
+                    acc.y += on ? fmaxf(a[u].y + b[u].y, 0.0f) : 0.0f;
+                    acc.z += on ? fmaxf(a[u].z + b[u].z, 0.0f) : 0.0f;
+                    acc.w += on ? fmaxf(a[u].w + b[u].w, 0.0f) : 0.0f;
+                }
             }
-            *reinterpret_cast<float4*>(out_up + row) =
-                make_float4(acc.x + scale1 * xi.x, acc.y + scale1 * xi.y, acc.z + scale1 * xi.z,
-                            acc.w + scale1 * xi.w);
+            stg4(out_up0 + row, make_float4(acc.x + scale1 * xi.x, acc.y + scale1 * xi.y, acc.z + scale1 * xi.z,
+                                            acc.w + scale1 * xi.w));
         }
     }
+    CWN_STAMP(8);
+}
+
+// fp32 [F, 2F] weight of the message Linear -> bf16 hi / mid / lo planes in MFMA-fragment order: chunk
+// ((ct * 2 + h) * KS + ks) * 3 + plane holds, for lane l = kq * 16 + n, the eight k-values
+// W[ct * 16 + n][h * F + ks * 32 + kq * 8 ..] of that plane (16 bytes per lane, 1 KiB per chunk).
+template <int F>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ W, int64_t ldw,
+                                                           unsigned char* __restrict__ out) {
+    constexpr int KS = F / 32, NCT = F / 16;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (ct, h, ks, lane)
+    if (g >= NCT * 2 * KS * 64) return;
+    const int lane = g & 63, chunk3 = g >> 6;                     // chunk3 = (ct * 2 + h) * KS + ks
+    const int ks = chunk3 % KS, h = (chunk3 / KS) & 1, ct = chunk3 / (2 * KS);
+    const float* src = W + (int64_t)(ct * 16 + (lane & 15)) * ldw + h * F + ks * 32 + (lane >> 4) * 8;
+    const float4 a = make_float4(src[0], src[1], src[2], src[3]), b = make_float4(src[4], src[5], src[6], src[7]);
+    uint4 ph, pm, pl;
+    cwn::split8(a, b, ph, pm, pl);
+    unsigned char* dst = out + (size_t)chunk3 * 3 * 1024 + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = ph;
+    *reinterpret_cast<uint4*>(dst + 1024) = pm;
+    *reinterpret_cast<uint4*>(dst + 2048) = pl;
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
+#ifdef CWN_LAYER_TIMING
+unsigned long long* g_stamps = nullptr;
+#endif
+
 template <int F>
-int launch(const LayerArgs& A, int64_t n_items, hipStream_t stream) {
+int launch(LayerArgs& A, int64_t n_items, hipStream_t stream) {
     static std::once_flag once;            // raise the dynamic-LDS limit of this instantiation, once
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
@@ -425,47 +652,110 @@ int launch(const LayerArgs& A, int64_t n_items, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
-    const size_t lds = lds_bytes<F>(A.rows_cap);
+#ifdef CWN_LAYER_TIMING
+    A.stamps = g_stamps;
+#endif
+    const size_t lds = lds_bytes<F>(A.rows_cap, A.xrows_cap);
     layer_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), lds, stream>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
 }  // namespace
 
-extern "C" size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows) {
-    if (max_gemm_rows < 0 || max_gemm_rows % 16 != 0) return 0;
-    if (F == 128 && max_gemm_rows <= CWN_LAYER_GEMM_ROWS(128)) return lds_bytes<128>(max_gemm_rows);
-    if (F == 64 && max_gemm_rows <= CWN_LAYER_GEMM_ROWS(64)) return lds_bytes<64>(max_gemm_rows);
-    return 0;
+#ifdef CWN_LAYER_TIMING
+extern "C" void cwn_layer_debug_stamps(unsigned long long* buf) { g_stamps = buf; }
+#endif
+
+extern "C" size_t cwn_layer_packed_weight_bytes(int32_t F) {
+    return (F == 64 || F == 128) ? (size_t)F * 2 * F * 6 : 0;
+}
+
+extern "C" int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream_) {
+    if ((F != 64 && F != 128) || W == nullptr || out == nullptr || ldw < 2 * F) return CWN_ERR_BAD_ARG;
+    if (((uintptr_t)W & 3u) || !al16(out)) return CWN_ERR_ALIGN;
+    const int threads = (F / 16) * 2 * (F / 32) * 64;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (F == 128) pack_weights_kernel<128><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
+    else pack_weights_kernel<64><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows) {
+    if (max_gemm_rows < 0 || max_gemm_rows % 16 != 0 || max_source_rows < 0) return 0;
+    size_t b = 0;
+    if (F == 128 && max_gemm_rows <= CWN_LAYER_GEMM_ROWS(128) && max_source_rows <= 2 * CWN_LAYER_SOURCE_ROWS(128))
+        b = lds_bytes<128>(max_gemm_rows, max_source_rows);
+    if (F == 64 && max_gemm_rows <= CWN_LAYER_GEMM_ROWS(64) && max_source_rows <= 2 * CWN_LAYER_SOURCE_ROWS(64))
+        b = lds_bytes<64>(max_gemm_rows, max_source_rows);
+    return b <= 160 * 1024 ? b : 0;
 }
 
 extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_t F, const int32_t* items,
-                                   int64_t n_items, int32_t max_gemm_rows, int32_t flags, int32_t* err_flag,
-                                   cwn_stream_t stream_) {
+                                   int64_t n_items, int32_t max_gemm_rows, int32_t max_source_rows,
+                                   int32_t flags, int32_t* err_flag, cwn_stream_t stream_) {
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS || n_items < 0 || flags != 0)
         return CWN_ERR_BAD_ARG;
     if (F != 64 && F != 128) return CWN_ERR_BAD_ARG;
     if (n_items == 0) return CWN_OK;
     if (items == nullptr || err_flag == nullptr) return CWN_ERR_BAD_ARG;
     if (n_items >= INT32_MAX) return CWN_ERR_TOO_LARGE;
-    if (cwn_layer_fused_lds_bytes(F, max_gemm_rows) == 0) return CWN_ERR_BAD_ARG;
+    if (cwn_layer_fused_lds_bytes(F, max_gemm_rows, max_source_rows) == 0) return CWN_ERR_BAD_ARG;
+    if (!al16(items)) return CWN_ERR_ALIGN;
     LayerArgs A{};
+    bool has_up[CWN_LAYER_MAX_DIMS] = {false, false, false};
     for (int d = 0; d < n_dims; ++d) {
         const cwn_layer_dim& D = dims[d];
         if (D.n_cells < 0 || D.e_up < 0 || D.n_b < 0) return CWN_ERR_BAD_ARG;
         if (D.n_cells >= INT32_MAX || D.e_up >= INT32_MAX || D.n_b >= INT32_MAX) return CWN_ERR_TOO_LARGE;
         if (D.n_cells > 0 && (D.x == nullptr || D.out_up == nullptr || D.out_b == nullptr)) return CWN_ERR_BAD_ARG;
-        if (D.e_up > 0 && (D.up_index == nullptr || D.up_shared == nullptr || D.msg_w == nullptr ||
+        if (D.e_up > 0 && (D.up_index == nullptr || D.up_shared == nullptr || D.msg_w_packed == nullptr ||
                            d + 1 >= n_dims))
             return CWN_ERR_BAD_ARG;
         if (D.n_b > 0 && (D.b_index == nullptr || d == 0)) return CWN_ERR_BAD_ARG;
-        if (!(al16(D.x) && al16(D.out_up) && al16(D.out_b) && al16(D.msg_w) && al16(D.msg_bias)))
+        if (!(al16(D.x) && al16(D.out_up) && al16(D.out_b) && al16(D.msg_w_packed) && al16(D.msg_bias)))
             return CWN_ERR_ALIGN;
-        A.d[d] = D;
+        has_up[d] = D.e_up > 0;
+    }
+    // the sets, in the order the item table numbers them (include/cwn_hip.h): every dimension with an
+    // upper adjacency is the GEMM dimension of a set; the top dimension without one rides as its
+    // neighbour's second task; any other dimension without one is a set of its own
+    int n_sets = 0;
+    for (int d = 0; d < n_dims;) {
+        uint64_t* S = A.set[n_sets++];
+        int tasks[2] = {d, -1};
+        S[S_XG] = (uint64_t)(uintptr_t)dims[d].x;               // the staged block is task 0's cells
+        if (has_up[d]) {
+            const cwn_layer_dim& D = dims[d];
+            S[S_XC] = (uint64_t)(uintptr_t)dims[d + 1].x;
+            S[S_UP_INDEX] = (uint64_t)(uintptr_t)D.up_index;
+            S[S_UP_SHARED] = (uint64_t)(uintptr_t)D.up_shared;
+            S[S_UP_E] = (uint64_t)D.e_up;
+            S[S_WP] = (uint64_t)(uintptr_t)D.msg_w_packed;
+            S[S_MSG_BIAS] = (uint64_t)(uintptr_t)D.msg_bias;
+            S[S_NG_NC] = (uint64_t)(uint32_t)D.n_cells | ((uint64_t)(uint32_t)dims[d + 1].n_cells << 32);
+            if (d + 1 < n_dims && !has_up[d + 1] && d + 2 >= n_dims) tasks[1] = d + 1;
+        }
+        for (int t = 0; t < 2; ++t) {
+            if (tasks[t] < 0) continue;
+            const cwn_layer_dim& D = dims[tasks[t]];
+            uint64_t* T = S + S_TASK0 + t * ST_FIELDS;
+            T[ST_X] = (uint64_t)(uintptr_t)D.x;
+            T[ST_XS] = tasks[t] > 0 ? (uint64_t)(uintptr_t)dims[tasks[t] - 1].x : 0;
+            T[ST_OUT_UP] = (uint64_t)(uintptr_t)D.out_up;
+            T[ST_OUT_B] = (uint64_t)(uintptr_t)D.out_b;
+            T[ST_B_INDEX] = (uint64_t)(uintptr_t)D.b_index;
+            T[ST_B_E] = (uint64_t)D.n_b;
+            T[ST_EPS1] = (uint64_t)(uintptr_t)D.eps1;
+            T[ST_EPS2] = (uint64_t)(uintptr_t)D.eps2;
+            T[ST_N_NS] = (uint64_t)(uint32_t)D.n_cells |
+                         ((uint64_t)(uint32_t)(tasks[t] > 0 ? dims[tasks[t] - 1].n_cells : 0) << 32);
+        }
+        d += tasks[1] >= 0 ? 2 : 1;
     }
     A.items = items;
     A.err = err_flag;
     A.rows_cap = max_gemm_rows;
+    A.xrows_cap = max_source_rows;
     hipStream_t stream = (hipStream_t)stream_;
     return F == 128 ? launch<128>(A, n_items, stream) : launch<64>(A, n_items, stream);
 }

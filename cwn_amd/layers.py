@@ -596,57 +596,72 @@ class SparseCINConv(torch.nn.Module):
         streams written.  Applies to the form the reference's molecular models build (coboundary
         message ReLU(Linear(cat(x_j, up_attr))), identity boundary message, 'add' everywhere,
         mp/layers.py:286-299) on a batch that carries its per-complex tables, without autograd;
-        None otherwise (the caller then runs the grouped GEMM + CSR aggregation)."""
-        if not BLOCKED_LAYER or ops.GEMM_EXACT or start_to_process != 0:
+        None otherwise (the caller then runs the grouped GEMM + CSR aggregation;
+        `self.blocked_reason` says why)."""
+        args = self._blocked_args(cochain_params, start_to_process)
+        if isinstance(args, str):
+            self.blocked_reason = args
             return None
+        self.blocked_reason = None
+        dims, plan, (items, max_rows, max_src) = args
+        outs = ops.layer_fused(dims, items, max_rows, max_src)
+        if not getattr(plan, 'validated', False) and not torch.cuda.is_current_stream_capturing():
+            from . import csr
+            csr.check_errors(dims[0].x.device)     # once per batch: the table belongs to these index tensors
+            plan.validated = True
+        return outs
+
+    def _blocked_args(self, cochain_params, start_to_process):
+        if not BLOCKED_LAYER:
+            return 'layers.BLOCKED_LAYER is off'
+        if ops.GEMM_EXACT:
+            return 'exact fp32 GEMMs requested (the blocked kernel has only the split form)'
+        if start_to_process != 0:
+            return 'start_to_process != 0'
         n = len(cochain_params)
         plan = getattr(cochain_params[0], 'block_plan', None)
-        if plan is None or n > 3 or n != plan.n_dims:
-            return None
+        if plan is None:
+            return 'the batch carries no per-complex tables (ptr / __slices__)'
+        if n > 3 or n != plan.n_dims:
+            return 'dimension count'
         if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
                                         or any(c.x.requires_grad for c in cochain_params)):
-            return None
+            return 'autograd is recording (inference path only)'
         F = int(cochain_params[0].x.size(1))
         if F not in (64, 128):
-            return None
+            return f'feature width {F} (64 or 128)'
         dims, has_up = [], []
         for d, c in enumerate(cochain_params):
             lvl = self.mp_levels[d]
             x = c.x
-            if (not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != F
-                    or (lvl.aggr_up or 'add') != 'add' or (lvl.aggr_boundary or 'add') != 'add'
-                    or not lvl._boundary_fusable() or lvl.up_msg_size != F):
-                return None
+            if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != F:
+                return f'dim {d}: features must be fp32 [n, {F}] on the GPU'
+            if (lvl.aggr_up or 'add') != 'add' or (lvl.aggr_boundary or 'add') != 'add':
+                return f'dim {d}: reduce is not add'
+            if not lvl._boundary_fusable() or lvl.up_msg_size != F:
+                return f'dim {d}: boundary message network / message width'
             D = ops.LayerDim(x=x, eps1=lvl.eps1, eps2=lvl.eps2)
             up = c.up_index is not None and c.up_index.size(1) > 0
             if c.up_index is not None:
                 attr = c.kwargs.get('up_attr')
                 lin = lvl.msg_up_nn[1] if lvl._up_kind() == 'cat_linear_relu' else None
-                if (lin is None or not isinstance(attr, IndexedRows) or d + 1 >= n
-                        or attr.src is not cochain_params[d + 1].x or lin.in_features != 2 * F
-                        or lin.out_features != F or c.up_index.dtype != torch.long):
-                    return None
+                if lin is None or lin.in_features != 2 * F or lin.out_features != F:
+                    return f'dim {d}: message network is not ReLU(Linear(cat))'
+                if not isinstance(attr, IndexedRows) or d + 1 >= n or attr.src is not cochain_params[d + 1].x:
+                    return f'dim {d}: up_attr is not the lazy gather of the next dimension\'s features'
                 D.up_index, D.up_shared = c.up_index, attr.index
-                D.msg_w, D.msg_bias = lin.weight, lin.bias
+                D.msg_w_packed, D.msg_bias = ops.pack_layer_weight(lin.weight), lin.bias
             b_index, b_attr = c.boundary_index, c.kwargs.get('boundary_attr')
-            if lvl.use_boundary_msg and b_attr is not None and b_index is not None:
-                if d == 0 or b_attr is not cochain_params[d - 1].x:
-                    return None
+            if lvl.use_boundary_msg and b_attr is not None:
+                if b_index is None or d == 0 or b_attr is not cochain_params[d - 1].x:
+                    return f'dim {d}: boundary_attr is not the previous dimension\'s features'
                 D.b_index = b_index
-            elif lvl.use_boundary_msg and b_attr is not None:
-                return None
             dims.append(D)
             has_up.append(bool(up))
         tab = plan.items(F, has_up)
         if tab is None:
-            return None
-        items, max_rows = tab
-        outs = ops.layer_fused(dims, items, max_rows)
-        if not getattr(plan, 'validated', False) and not torch.cuda.is_current_stream_capturing():
-            from . import csr
-            csr.check_errors(x.device)     # once per batch: the table belongs to these index tensors
-            plan.validated = True
-        return outs
+            return 'a complex does not fit one workgroup (row / entry caps)'
+        return dims, plan, tab
 
     def _dense_eval(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
         """The update / combine networks of ALL dimensions (mp/layers.py:193-199) as three grouped

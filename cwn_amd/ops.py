@@ -689,13 +689,40 @@ class LayerDim:
     up_index: Optional[Tensor] = None       # [2, E] int64
     up_shared: Optional[Tensor] = None      # [E] int64 (shared_coboundaries)
     b_index: Optional[Tensor] = None        # [2, B] int64
-    msg_w: Optional[Tensor] = None          # [F, 2F]
+    msg_w_packed: Optional[Tensor] = None   # pack_layer_weight(Linear(2F -> F).weight)
     msg_bias: Optional[Tensor] = None
     eps1: Optional[Tensor] = None
     eps2: Optional[Tensor] = None
 
 
-def layer_fused(dims: Sequence[LayerDim], items: Tensor, max_gemm_rows: int) -> List[Tensor]:
+_packed_weights = {}
+
+
+def pack_layer_weight(weight: Tensor) -> Tensor:
+    """The message Linear's weight [F, 2F] in the form cwn_layer_fused_f32 reads (bf16 hi / mid / lo
+    planes in MFMA-fragment order, include/cwn_hip.h: cwn_layer_pack_weights_f32): one small launch
+    per weight VERSION, cached on (storage, version) -- an optimizer step bumps the version and the
+    next forward re-packs.  Weight preparation (like folding BatchNorm into an affine), not per step."""
+    import weakref
+    w = weight.detach()
+    key = id(weight)
+    ver = (w.data_ptr(), weight._version, tuple(w.shape), w.device)
+    hit = _packed_weights.get(key)
+    if hit is not None and hit[0] == ver and hit[1]() is weight:
+        return hit[2]
+    w = _f32c(w, 'weight')
+    F = int(w.size(0))
+    if w.dim() != 2 or w.size(1) != 2 * F:
+        raise ValueError('expected the [F, 2F] weight of Linear(2F -> F)')
+    L = _ffi.lib()
+    out = torch.empty(int(L.cwn_layer_packed_weight_bytes(F)), dtype=torch.uint8, device=w.device)
+    _ffi.check(L.cwn_layer_pack_weights_f32(w.data_ptr(), w.stride(0), F, out.data_ptr(), _ffi.stream_ptr(w.device)),
+               'cwn_layer_pack_weights_f32')
+    _packed_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_weights.pop(k, None)), out)
+    return out
+
+
+def layer_fused(dims: Sequence[LayerDim], items: Tensor, max_gemm_rows: int, max_source_rows: int) -> List[Tensor]:
     """[out_up_0, out_b_0, out_up_1, out_b_1, ...]; no autograd (inference path).  `items` is the
     batch's item table (cwn_amd/blockplan.py).  Index errors go to the sticky error word of
     cwn_amd/csr.py (`csr.check_errors`)."""
@@ -712,7 +739,7 @@ def layer_fused(dims: Sequence[LayerDim], items: Tensor, max_gemm_rows: int) -> 
         for t, name in ((up, 'up_index'), (sh, 'up_shared'), (bi, 'b_index')):
             if t is not None and (t.dtype != torch.long or not t.is_cuda or not t.is_contiguous()):
                 raise TypeError(f'{name} must be a contiguous int64 GPU tensor')
-        w, b = _f32c(D.msg_w, 'msg_w'), _f32c(D.msg_bias, 'msg_bias')
+        w, b = D.msg_w_packed, _f32c(D.msg_bias, 'msg_bias')
         e1, e2 = _f32c(D.eps1, 'eps1'), _f32c(D.eps2, 'eps2')
         out_up = torch.empty_like(x)
         out_b = torch.empty_like(x)
@@ -722,10 +749,11 @@ def layer_fused(dims: Sequence[LayerDim], items: Tensor, max_gemm_rows: int) -> 
         arr[d] = _ffi.LayerDim(x=x.data_ptr(), up_index=_ffi.ptr(up) if e_up else None,
                                up_shared=_ffi.ptr(sh) if e_up else None,
                                b_index=_ffi.ptr(bi) if bi is not None and bi.size(1) else None,
-                               msg_w=_ffi.ptr(w), msg_bias=_ffi.ptr(b), eps1=_ffi.ptr(e1), eps2=_ffi.ptr(e2),
+                               msg_w_packed=_ffi.ptr(w), msg_bias=_ffi.ptr(b), eps1=_ffi.ptr(e1), eps2=_ffi.ptr(e2),
                                out_up=out_up.data_ptr(), out_b=out_b.data_ptr(), n_cells=x.size(0),
                                e_up=e_up, n_b=0 if bi is None else int(bi.size(1)))
     _ffi.check(_ffi.lib().cwn_layer_fused_f32(arr, len(dims), F, items.data_ptr(), items.size(0),
-                                               int(max_gemm_rows), 0, _err_flag(dev).data_ptr(),
+                                               int(max_gemm_rows), int(max_source_rows), 0,
+                                               _err_flag(dev).data_ptr(),
                                                _ffi.stream_ptr(dev)), 'cwn_layer_fused_f32')
     return outs

@@ -200,7 +200,11 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  * once from the per-complex sizes the reference's collate keeps (`ptr`, `__slices__`,
  * data/complex.py:344-441): cwn_amd/blockplan.py.  Record layout (all offsets are into the batched
  * tensors):
- *   [0] flags      bit 0: the item has a GEMM dimension g (an upper adjacency with coboundary features)
+ *   [0] flags      bit 0: the item has a GEMM dimension g (an upper adjacency with coboundary features);
+ *                  bits 8-9: its SET -- sets are numbered over the dimensions in ascending order: a
+ *                  dimension with e_up > 0 opens a set as its GEMM dimension (the top dimension rides as
+ *                  its second task when it has no upper adjacency itself), any other dimension is a set
+ *                  of its own
  *   [1] g          [2] first cell of dim g   [3] number of cells of dim g
  *   [4] first cell of dim g+1                [5] number of cells of dim g+1
  *   [6] first entry of up_index_g            [7] number of entries
@@ -209,9 +213,12 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  *       +3 first entry of b_index_d  +4 number of entries
  *       +5 first cell of dim d-1     +6 number of cells of dim d-1      (boundary sources)
  *   A task whose dim is g reduces the upper adjacency out of LDS; any other task must belong to a
- *   dimension without upper adjacency (out_up = self term).  Limits per item: padded GEMM rows
- *   16*ceil(n_g/16) + 16*ceil(n_{g+1}/16) <= CWN_LAYER_GEMM_ROWS(F); cells per task <=
- *   CWN_LAYER_TASK_ROWS; entries of all its adjacencies together <= CWN_LAYER_MAX_ENTRIES.
+ *   dimension without upper adjacency (out_up = self term); the GEMM dimension is task 0.  Limits
+ *   per item: staged rows R1 + 16*ceil(n_{g+1}/16) <= CWN_LAYER_GEMM_ROWS(F), where R1 is
+ *   16*ceil(n_g/16) rounded up to a multiple of 2048/F (for an item without GEMM: 16*ceil(n/16));
+ *   boundary-source cells of its tasks together <= CWN_LAYER_SOURCE_ROWS(F); LDS of both within
+ *   160 KiB (cwn_layer_fused_lds_bytes); cells per task <= CWN_LAYER_TASK_ROWS; entries of all its
+ *   adjacencies together (each padded to a multiple of 4) <= CWN_LAYER_MAX_ENTRIES.
  * An index that leaves its item's ranges (the batch is not block-diagonal, or the table does not
  * belong to it) sets bit 3 of *err_flag (the sticky word of cwn_csr_build) and is clamped.
  * F must be 64 or 128; every pointer 16-B aligned; one launch, no workspace, no host sync.
@@ -219,6 +226,7 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
 #define CWN_LAYER_MAX_DIMS 3
 #define CWN_LAYER_ITEM_INTS 32
 #define CWN_LAYER_GEMM_ROWS(F) (12288 / (F))   /* 96 at F = 128, 192 at F = 64 */
+#define CWN_LAYER_SOURCE_ROWS(F) (12288 / (F)) /* cells of dim d-1 the boundary streams of an item read */
 #define CWN_LAYER_TASK_ROWS 192
 #define CWN_LAYER_MAX_ENTRIES 1024
 #define CWN_ERR_BIT_BLOCK 8                    /* *err_flag bit: index outside its item */
@@ -228,7 +236,7 @@ typedef struct cwn_layer_dim {
     const int64_t* up_index;   /* [2, e_up] upper_index (row 0 source, row 1 destination) or NULL */
     const int64_t* up_shared;  /* [e_up] shared_coboundaries or NULL */
     const int64_t* b_index;    /* [2, n_b] boundary_index (row 0 boundary cell, row 1 cell) or NULL */
-    const float* msg_w;        /* [F, 2F] weight of msg_up_nn's Linear (torch layout) or NULL */
+    const void* msg_w_packed;  /* msg_up_nn's Linear weight [F, 2F] packed by cwn_layer_pack_weights_f32, or NULL */
     const float* msg_bias;     /* [F] or NULL */
     const float* eps1;         /* device scalar or NULL (= 0) */
     const float* eps2;
@@ -237,13 +245,24 @@ typedef struct cwn_layer_dim {
     int64_t n_cells, e_up, n_b;
 } cwn_layer_dim;
 
-/* max_gemm_rows: an upper bound (multiple of 16) of the padded GEMM rows of any item -- sizes the
- * LDS of the launch.  flags: reserved, 0. */
+/* The weight of the message Linear in the form the kernel's matrix-core loop reads it: the exact
+ * three-way bf16 split (csrc/cwn_split.h) of W [F, 2F] (torch layout, row stride ldw), the pieces
+ * laid out in MFMA-fragment order so that every wave instruction fetches 1 KiB of contiguous memory
+ * (a fragment-shaped read of the fp32 weight -- 16 rows x 32 B per quarter wave -- runs the address
+ * unit at 1/8 rate and re-splits the same numbers in every workgroup).  One small launch per weight
+ * VERSION (the caller re-packs after an optimizer step); out: cwn_layer_packed_weight_bytes(F) bytes,
+ * 16-B aligned.  Weight preparation, like folding BatchNorm into an affine: not part of a step. */
+size_t cwn_layer_packed_weight_bytes(int32_t F);
+int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream);
+
+/* max_gemm_rows: an upper bound (multiple of 16) of the padded GEMM rows of any item;
+ * max_source_rows: an upper bound of the boundary-source cells of any item (summed over its tasks
+ * that have boundary entries).  Together they size the LDS of the launch.  flags: reserved, 0. */
 int cwn_layer_fused_f32(const cwn_layer_dim* dims_host, int n_dims, int32_t F, const int32_t* items,
-                        int64_t n_items, int32_t max_gemm_rows, int32_t flags, int32_t* err_flag,
-                        cwn_stream_t stream);
-/* dynamic LDS bytes such a launch uses (<= 160 KiB), 0 for unsupported arguments */
-size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows);
+                        int64_t n_items, int32_t max_gemm_rows, int32_t max_source_rows, int32_t flags,
+                        int32_t* err_flag, cwn_stream_t stream);
+/* dynamic LDS bytes such a launch uses, 0 for unsupported arguments or more than 160 KiB */
+size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows);
 
 /* ------------------------------------------------------------------------------------------
  * Dense parts of the path on the matrix cores (fp32 MFMA, exact fp32):

@@ -81,8 +81,8 @@ def test_argument_errors_without_gpu():
     t = (_ffi.GemmTnDesc * 1)(_ffi.GemmTnDesc(M=1000, N=128, K=128, K2=128))
     assert lib.cwn_gemm_tn_workspace_bytes(t, 1) >= 8 * (128 * 256 + 128) * 4
     assert lib.cwn_lift_create(7, 3, None, 0, 6, 0) is None        # unknown lift kind
-    assert lib.cwn_layer_fused_f32(None, 1, 128, None, 1, 16, 0, None, None) == 1
-    assert lib.cwn_layer_fused_lds_bytes(128, 96) == 3 * 96 * 136 * 2 + 96 * 132 * 4 + 13456
+    assert lib.cwn_layer_fused_f32(None, 1, 128, None, 1, 16, 0, 0, None, None) == 1
+    assert lib.cwn_layer_fused_lds_bytes(128, 96, 64) == 3 * 96 * 136 * 2 + 64 * 128 * 4 + 15504
 
 
 def test_cpu_tensors_fail_loudly():

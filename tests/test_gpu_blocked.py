@@ -149,6 +149,7 @@ def test_blocked_layer_entry_order_and_empty_parts():
         for lvl in conv.mp_levels:
             lin = lvl.msg_up_nn[1]
             lin.weight.copy_(torch.randint(-1, 2, lin.weight.shape).float())
+            lin.bias.copy_(torch.randint(-2, 3, lin.bias.shape).float())
     ref = _run(conv, b, blocked=True)
     # shuffle entries within each complex's slice of every index
     b2 = ComplexBatch.from_complex_list(cs, max_dim=2).to(DEV)
@@ -196,17 +197,17 @@ def test_blocked_layer_c_abi_argument_checks():
     import ctypes as C
     from cwn_amd import _ffi
     L = _ffi.lib()
-    assert L.cwn_layer_fused_lds_bytes(128, 96) > 0 and L.cwn_layer_fused_lds_bytes(128, 96) <= 160 * 1024
-    assert L.cwn_layer_fused_lds_bytes(64, 192) > 0 and L.cwn_layer_fused_lds_bytes(64, 192) <= 160 * 1024
-    assert L.cwn_layer_fused_lds_bytes(128, 112) == 0 and L.cwn_layer_fused_lds_bytes(32, 16) == 0
+    assert 0 < L.cwn_layer_fused_lds_bytes(128, 96, 96) <= 160 * 1024
+    assert 0 < L.cwn_layer_fused_lds_bytes(64, 192, 192) <= 160 * 1024
+    assert L.cwn_layer_fused_lds_bytes(128, 112, 0) == 0 and L.cwn_layer_fused_lds_bytes(32, 16, 0) == 0
     arr = (_ffi.LayerDim * 1)()
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
     items = torch.zeros(1, 32, dtype=torch.int32, device=DEV)
     s = _ffi.stream_ptr(torch.device(DEV))
-    assert L.cwn_layer_fused_f32(arr, 1, 96, items.data_ptr(), 1, 16, 0, err.data_ptr(), s) == 1     # F
-    assert L.cwn_layer_fused_f32(arr, 4, 128, items.data_ptr(), 1, 16, 0, err.data_ptr(), s) == 1    # n_dims
-    assert L.cwn_layer_fused_f32(arr, 1, 128, items.data_ptr(), 0, 16, 0, err.data_ptr(), s) == 0    # nothing to do
-    assert L.cwn_layer_fused_f32(arr, 1, 128, None, 1, 16, 0, err.data_ptr(), s) == 1
+    assert L.cwn_layer_fused_f32(arr, 1, 96, items.data_ptr(), 1, 16, 0, 0, err.data_ptr(), s) == 1     # F
+    assert L.cwn_layer_fused_f32(arr, 4, 128, items.data_ptr(), 1, 16, 0, 0, err.data_ptr(), s) == 1    # n_dims
+    assert L.cwn_layer_fused_f32(arr, 1, 128, items.data_ptr(), 0, 16, 0, 0, err.data_ptr(), s) == 0    # nothing to do
+    assert L.cwn_layer_fused_f32(arr, 1, 128, None, 1, 16, 0, 0, err.data_ptr(), s) == 1
 
 
 def test_blocked_layer_falls_back_when_a_complex_exceeds_one_workgroup():
