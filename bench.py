@@ -210,7 +210,9 @@ def main():
     def propagate_scope(bi):
         """One step: (CSR path only: fresh plans for the batch, then) the propagate scope of every layer."""
         b, feats = batches[bi], layer_inputs[bi]
-        if not BLOCKED:
+        if BLOCKED:
+            b.block_plan().forget_csr()      # a step starts from the int64 COO entries, like a new batch
+        else:
             csr._cache.clear()
             b.prepare(max_dim=2, overlap=OVERLAP_PLAN_BUILD)
         outs = None

@@ -65,7 +65,17 @@ class LayerDim(C.Structure):
                 ('out_b', C.c_void_p), ('n_cells', C.c_int64), ('e_up', C.c_int64), ('n_b', C.c_int64)]
 
 
+class LayerPlan(C.Structure):
+    """cwn_layer_plan (include/cwn_hip.h)."""
+    _fields_ = [('items', C.c_void_p), ('csr_cache', C.c_void_p), ('n_items', C.c_int64),
+                ('set_start', C.c_int32 * 4), ('max_gemm_rows', C.c_int32), ('max_source_rows', C.c_int32),
+                ('pad_', C.c_int32), ('cells_end', C.c_int64 * 3), ('up_end', C.c_int64 * 3),
+                ('b_end', C.c_int64 * 3)]
+
+
 ERR_BIT_BLOCK = 8         # = CWN_ERR_BIT_BLOCK
+LAYER_CSR_STORE, LAYER_CSR_LOAD = 1, 2
+LAYER_CSR_SLOT_BYTES = 5264
 
 
 class CollateDesc(C.Structure):
@@ -136,8 +146,8 @@ def lib():
     L.cwn_gemm_f32.restype = C.c_int
     L.cwn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
     L.cwn_layer_fused_f32.restype = C.c_int
-    L.cwn_layer_fused_f32.argtypes = [C.POINTER(LayerDim), C.c_int, C.c_int32, C.c_void_p, C.c_int64,
-                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.cwn_layer_fused_f32.argtypes = [C.POINTER(LayerDim), C.c_int, C.c_int32, C.POINTER(LayerPlan), C.c_int32,
+                                      C.c_void_p, C.c_void_p]
     L.cwn_layer_packed_weight_bytes.restype = C.c_size_t
     L.cwn_layer_packed_weight_bytes.argtypes = [C.c_int32]
     L.cwn_layer_pack_weights_f32.restype = C.c_int

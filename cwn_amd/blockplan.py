@@ -18,6 +18,7 @@ import torch
 ITEM_INTS = 32                 # = CWN_LAYER_ITEM_INTS
 TASK_ROWS = 192                # = CWN_LAYER_TASK_ROWS
 MAX_ENTRIES = 1024             # = CWN_LAYER_MAX_ENTRIES
+CSR_SLOT_BYTES = 5264          # = CWN_LAYER_CSR_SLOT_BYTES
 TARGET_ITEMS = 128             # per GEMM dimension: ~one workgroup per CU over the two sets of a 2-complex
 
 
@@ -43,6 +44,35 @@ def _pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
+class ItemTable:
+    """One table (feature width F, which dimensions reduce an upper adjacency) + what the launcher
+    needs to know about it (cwn_layer_plan) + the per-item CSR cache and its validity."""
+
+    def __init__(self, table: np.ndarray, set_start: List[int], max_rows: int, max_src: int,
+                 cells_end, up_end, b_end, device):
+        self.n_items = int(table.shape[0])
+        self.items = torch.from_numpy(table)
+        if device is not None:
+            self.items = self.items.to(device)
+        self.set_start, self.max_rows, self.max_src = set_start, int(max_rows), int(max_src)
+        self.cells_end, self.up_end, self.b_end = cells_end, up_end, b_end
+        self.device = device
+        self.csr_cache: Optional[torch.Tensor] = None
+        self.csr_key = None          # identity + version of the index tensors the cache was built from
+
+    def c_plan(self, with_cache: bool):
+        from . import _ffi
+        if with_cache and self.csr_cache is None:
+            self.csr_cache = torch.empty(self.n_items * CSR_SLOT_BYTES, dtype=torch.uint8, device=self.device)
+        p = _ffi.LayerPlan(items=self.items.data_ptr(), csr_cache=_ffi.ptr(self.csr_cache) if with_cache else None,
+                           n_items=self.n_items, max_gemm_rows=self.max_rows, max_source_rows=self.max_src)
+        for i, v in enumerate(self.set_start[:4]):
+            p.set_start[i] = int(v)
+        for d in range(len(self.cells_end)):
+            p.cells_end[d], p.up_end[d], p.b_end[d] = int(self.cells_end[d]), int(self.up_end[d]), int(self.b_end[d])
+        return p
+
+
 class BlockPlan:
     """Host-side description of a batch + the item tables cut from it (one per feature width)."""
 
@@ -59,6 +89,7 @@ class BlockPlan:
         self.b_ptr = [None if p is None else np.asarray(p, dtype=np.int64) for p in b_ptr]
         self.device = device
         self._tables = {}
+        self.validated = False
 
     # ---- construction from a batch ----------------------------------------------------------------
     @classmethod
@@ -83,6 +114,13 @@ class BlockPlan:
         dev = next((c.upper_index.device for c in batch.cochains.values() if c.upper_index is not None), None)
         return cls(cells, up_ptr, b_ptr, device=dev)
 
+    def forget_csr(self) -> None:
+        """Drop the cached per-item CSRs (the index tensors changed, or a caller wants a step that
+        starts from the COO entries again)."""
+        for t in self._tables.values():
+            if t is not None:
+                t.csr_key = None
+
     # ---- items ------------------------------------------------------------------------------------
     def _sets(self, has_up: Sequence[bool]):
         """[(g or None, [task dims])]: every dimension with an upper adjacency is the GEMM dimension
@@ -101,25 +139,16 @@ class BlockPlan:
                 d += 1
         return sets
 
-    def items(self, F: int, has_up: Sequence[bool]):
-        """(table int32 [n_items, ITEM_INTS] on the plan's device, max padded GEMM rows, max boundary
-        source rows) for feature width F, or None when some complex does not fit one workgroup's LDS (hub complexes: the
-        caller then runs the CSR path).  `has_up[d]`: dimension d reduces an upper adjacency with
-        coboundary features (needs d + 1 < n_dims)."""
+    def items(self, F: int, has_up: Sequence[bool]) -> Optional[ItemTable]:
+        """The item table for feature width F, or None when some complex does not fit one
+        workgroup's LDS (hub complexes: the caller then runs the CSR path).  `has_up[d]`: dimension d
+        reduces an upper adjacency with coboundary features (needs d + 1 < n_dims)."""
         key = (F, tuple(bool(h) for h in has_up))
-        if key in self._tables:
-            return self._tables[key]
-        out = self._build(F, key[1])
-        if out is not None:
-            table, max_rows, max_src = out
-            t = torch.from_numpy(table)
-            if self.device is not None:
-                t = t.to(self.device)
-            out = (t, max_rows, max_src)
-        self._tables[key] = out
-        return out
+        if key not in self._tables:
+            self._tables[key] = self._build(F, key[1])
+        return self._tables[key]
 
-    def _build(self, F: int, has_up):
+    def _build(self, F: int, has_up) -> Optional[ItemTable]:
         cap = gemm_rows_cap(F)
         ng_round = 2048 // F       # rows per round of the kernel: the coface block starts at a multiple
 
@@ -133,31 +162,30 @@ class BlockPlan:
             if has_up[d] and (d + 1 >= self.n_dims or self.up_ptr[d] is None):
                 return None
         gmax = max(1, C // TARGET_ITEMS)
-        recs: List[np.ndarray] = []
+        tables: List[np.ndarray] = []
+        set_start = []
         max_rows = max_src = 0
         zero = np.zeros(C + 1, dtype=np.int64)
+        cp = self.cell_ptr
         for set_id, (g, tasks) in enumerate(self._sets(has_up)):
-            n_g = self.cells[g] if g is not None else None
-            n_c = self.cells[g + 1] if g is not None else None
             up = self.up_ptr[g] if g is not None else zero
             bps = [self.b_ptr[d] if (self.b_ptr[d] is not None and d > 0) else zero for d in tasks]
+            d0 = tasks[0]
+            recs: List[np.ndarray] = []
             c0 = 0
             while c0 < C:
                 c1 = c0
                 while c1 < C and c1 - c0 < gmax:
                     nxt = c1 + 1
-                    if g is not None:
-                        rows = staged(int(self.cell_ptr[g][nxt] - self.cell_ptr[g][c0]),
-                                      int(self.cell_ptr[g + 1][nxt] - self.cell_ptr[g + 1][c0]))
-                    else:
-                        rows = staged(int(self.cell_ptr[tasks[0]][nxt] - self.cell_ptr[tasks[0]][c0]), 0)
+                    rows = staged(int(cp[d0][nxt] - cp[d0][c0]),
+                                  int(cp[g + 1][nxt] - cp[g + 1][c0]) if g is not None else 0)
                     # cells of dim d-1 the boundary streams read (staged in LDS), entries padded to 4
-                    src = sum(int(self.cell_ptr[d - 1][nxt] - self.cell_ptr[d - 1][c0])
-                              for d, bp in zip(tasks, bps) if d > 0 and bp[nxt] > bp[c0])
+                    src = sum(int(cp[d - 1][nxt] - cp[d - 1][c0]) for d, bp in zip(tasks, bps)
+                              if d > 0 and bp[nxt] > bp[c0])
                     ents = _pad4(int(up[nxt] - up[c0])) + sum(_pad4(int(bp[nxt] - bp[c0])) for bp in bps)
                     ok = (rows <= cap and src <= cap and lds_bytes(F, rows, src) <= LDS_BYTES
                           and ents <= MAX_ENTRIES
-                          and all(int(self.cell_ptr[d][nxt] - self.cell_ptr[d][c0]) <= TASK_ROWS for d in tasks))
+                          and all(int(cp[d][nxt] - cp[d][c0]) <= TASK_ROWS for d in tasks))
                     if not ok:
                         break
                     c1 = nxt
@@ -165,31 +193,35 @@ class BlockPlan:
                     return None                 # a single complex exceeds the caps
                 r = np.zeros(ITEM_INTS, dtype=np.int32)
                 r[0] = set_id << 8
+                n0 = int(cp[d0][c1] - cp[d0][c0])
+                nc = 0
                 if g is not None:
-                    ng = int(self.cell_ptr[g][c1] - self.cell_ptr[g][c0])
-                    nc = int(self.cell_ptr[g + 1][c1] - self.cell_ptr[g + 1][c0])
-                    r[0] |= 1 if ng > 0 else 0
-                    r[1:8] = [g, self.cell_ptr[g][c0], ng, self.cell_ptr[g + 1][c0], nc, up[c0], up[c1] - up[c0]]
-                    if ng > 0:
-                        max_rows = max(max_rows, staged(ng, nc))
-                else:
-                    max_rows = max(max_rows, staged(int(self.cell_ptr[tasks[0]][c1] - self.cell_ptr[tasks[0]][c0]), 0))
+                    nc = int(cp[g + 1][c1] - cp[g + 1][c0])
+                    r[0] |= 1 if n0 > 0 else 0
+                    r[1:8] = [g, cp[g][c0], n0, cp[g + 1][c0], nc, up[c0], up[c1] - up[c0]]
+                max_rows = max(max_rows, staged(n0, nc))
                 r[8] = len(tasks)
                 src = 0
                 for t, d in enumerate(tasks):
                     bp = bps[t]
                     o = 9 + 7 * t
-                    r[o:o + 5] = [d, self.cell_ptr[d][c0], self.cell_ptr[d][c1] - self.cell_ptr[d][c0],
-                                  bp[c0], bp[c1] - bp[c0]]
+                    r[o:o + 5] = [d, cp[d][c0], cp[d][c1] - cp[d][c0], bp[c0], bp[c1] - bp[c0]]
                     if d > 0:
-                        r[o + 5] = self.cell_ptr[d - 1][c0]
-                        r[o + 6] = self.cell_ptr[d - 1][c1] - self.cell_ptr[d - 1][c0]
+                        r[o + 5] = cp[d - 1][c0]
+                        r[o + 6] = cp[d - 1][c1] - cp[d - 1][c0]
                         if bp[c1] > bp[c0]:
                             src += int(r[o + 6])
                 max_src = max(max_src, src)
                 recs.append(r)
                 c0 = c1
-        # heavy items first: a workgroup with four row tiles should not start behind the short ones
-        table = np.stack(recs)
-        order = np.argsort(-(table[:, 3].astype(np.int64) + table[:, 5]) * (table[:, 0] & 1), kind='stable')
-        return np.ascontiguousarray(table[order]), max(max_rows, 16), max_src
+            # heavy items first within the set: a workgroup with five row tiles should not start last
+            tab = np.stack(recs)
+            order = np.argsort(-(tab[:, 11].astype(np.int64) + tab[:, 5]), kind='stable')
+            set_start.append(sum(t.shape[0] for t in tables))
+            tables.append(tab[order])
+        table = np.ascontiguousarray(np.concatenate(tables))
+        cells_end = [int(cp[d][-1]) for d in range(self.n_dims)]
+        up_end = [int(self.up_ptr[d][-1]) if (has_up[d] and self.up_ptr[d] is not None) else 0
+                  for d in range(self.n_dims)]
+        b_end = [int(self.b_ptr[d][-1]) if (self.b_ptr[d] is not None and d > 0) else 0 for d in range(self.n_dims)]
+        return ItemTable(table, set_start, max(max_rows, 16), max_src, cells_end, up_end, b_end, self.device)

@@ -355,6 +355,9 @@ class Complex(object):
         them): what a training loop does when a batch object is refilled, without touching the
         plans of other batches."""
         from . import csr
+        bp = getattr(self, '_block_plan', None)
+        if bp is not None and bp[1] is not None:
+            bp[1].forget_csr()
         for c in self.cochains.values():
             for index in (c.upper_index, c.lower_index, c.boundary_index):
                 if index is not None:

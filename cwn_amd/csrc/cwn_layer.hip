@@ -75,19 +75,19 @@ enum { T_DIM = 0, T_R0, T_N, T_BE0, T_BNE, T_SR0, T_SN, T_INTS };
 // of ITS set from the kernel-argument segment at a run-time offset (scalar loads).  With the
 // per-dimension descriptors selected field by field in the kernel (dim == 0 ? .. : ..) the compiler
 // ran out of SGPRs and reloaded kernel arguments ten times, one wait each.
-enum { S_XG = 0, S_XC, S_UP_INDEX, S_UP_SHARED, S_UP_E, S_WP, S_MSG_BIAS, S_NG_NC, S_TASK0 };
-enum { ST_X = 0, ST_XS, ST_OUT_UP, ST_OUT_B, ST_B_INDEX, ST_B_E, ST_EPS1, ST_EPS2, ST_N_NS, ST_FIELDS };
-constexpr int kSetFields = S_TASK0 + 2 * ST_FIELDS;         // 26 fields of 8 bytes
-// S_NG_NC / ST_N_NS pack two int32 cell counts (low: this dimension, high: dimension + 1 / - 1): every
-// range an item names is checked against them before a single address is formed
+enum { S_XG = 0, S_XC, S_UP_INDEX, S_UP_SHARED, S_UP_E, S_WP, S_MSG_BIAS, S_PAD, S_TASK0 };
+enum { ST_X = 0, ST_XS, ST_OUT_UP, ST_OUT_B, ST_B_INDEX, ST_B_E, ST_EPS1, ST_EPS2, ST_FIELDS };
+constexpr int kSetFields = S_TASK0 + 2 * ST_FIELDS;         // 24 fields of 8 bytes
 constexpr int kMaxSets = CWN_LAYER_MAX_DIMS;
 
 struct LayerArgs {
     uint64_t set[kMaxSets][kSetFields];      // MUST stay first: read through the kernarg segment pointer
     const int32_t* items;
     int32_t* err;
+    unsigned char* csr_cache;                // [n_items][kCsrSlot] per-item CSR images, or NULL
     int32_t rows_cap;                        // staged rows (GEMM operands) the LDS of this launch holds
     int32_t xrows_cap;                       // boundary-source rows it holds
+    int32_t set_start1, set_start2;          // first workgroup of set 1 / set 2 (items are ordered by set)
 #ifdef CWN_LAYER_TIMING
     unsigned long long* stamps;              // [n_items][16] shader-clock stamps of workgroup phase ends
 #endif
@@ -117,9 +117,15 @@ template <int F> struct Geo {
     __host__ __device__ static constexpr size_t xrows_bytes(int rows) { return (size_t)rows * F * 4; }
 };
 
-// index scratch: u32 keys, five u16 arrays of kEcap, three row-pointer arrays
+// index scratch: u32 keys, five u16 arrays of kEcap, three row-pointer arrays.  The tail [scol | saux |
+// rowptr] is the item's finished CSR: one contiguous image, kCsrSlot bytes, that the first layer of a
+// batch can store (CWN_LAYER_CSR_STORE) and the following layers load back (CWN_LAYER_CSR_LOAD)
+// instead of sorting the same entries again.
 constexpr int kRpStride = kTaskRows + 2;
 constexpr size_t kIdxBytes = (size_t)kEcap * 4 + (size_t)5 * kEcap * 2 + (size_t)3 * kRpStride * 2;
+constexpr int kCsrSlot = CWN_LAYER_CSR_SLOT_BYTES;
+static_assert(kCsrSlot >= 2 * kEcap * 2 + 3 * kRpStride * 2 && kCsrSlot % 16 == 0, "slot holds scol, saux, rowptr");
+enum { kSort = 0, kSortStore = 1, kLoad = 2 };
 
 template <int F>
 __host__ __device__ constexpr size_t lds_bytes(int rows, int xrows) {
@@ -138,6 +144,9 @@ typedef const __attribute__((address_space(1))) v4f* gcv4_p;
 typedef const __attribute__((address_space(1))) v4u* gcu4_p;
 typedef __attribute__((address_space(1))) v4f* gv4_p;
 typedef const __attribute__((address_space(1))) unsigned char* gcb_p;
+typedef __attribute__((address_space(1))) unsigned char* gb_p;
+typedef const __attribute__((address_space(1))) uint64_t* gcu64_p;
+typedef __attribute__((address_space(1))) v4u* gu4_p;
 
 __device__ __forceinline__ float4 ldg4(gcf_p p) {
     const v4f v = *(gcv4_p)p;
@@ -163,7 +172,7 @@ __device__ __forceinline__ float4 pick(const float4 (&xv)[kNX], int k) {
     return r;
 }
 
-template <int F>
+template <int F, int MODE>
 __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     using G = Geo<F>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -184,12 +193,23 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     uint16_t* const rowptr = uval + 5 * kEcap;   // [3][kRpStride]: upper, boundary of task 0, of task 1
 
     CWN_STAMP(0);
-    // ---- 1. item record: ONE load (lane l reads word l), fields broadcast with v_readlane -----------
+    // ---- 1. item record and set record: ONE round trip ------------------------------------------------
+    // lane l reads word l of the item and 8-byte field l of the set record (the kernel-argument segment
+    // is ordinary global memory); fields are broadcast with v_readlane where they are used, so they
+    // occupy two VGPRs instead of ~60 SGPRs (the scalar-load form of this spilled SGPRs to VGPR lanes
+    // and back: 130 v_readlane / v_writelane in the load phase alone).  The set follows from the
+    // workgroup index (items are ordered by set), so the two loads do not depend on each other.
+    const int set = ((int)blockIdx.x >= A.set_start1 ? 1 : 0) + ((int)blockIdx.x >= A.set_start2 ? 1 : 0);
     const int32_t itv = A.items[(size_t)blockIdx.x * CWN_LAYER_ITEM_INTS + (lane & (CWN_LAYER_ITEM_INTS - 1))];
+    const uint64_t srec = ((gcu64_p)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr())[set * kSetFields + min(lane, kSetFields - 1)];
+    const int srec_lo = (int)(uint32_t)srec, srec_hi = (int)(uint32_t)(srec >> 32);
     auto fld = [&](int k) { return __builtin_amdgcn_readlane(itv, k); };
+    auto sfld = [&](int k) {
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readlane(srec_lo, k) |
+               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(srec_hi, k) << 32);
+    };
     const int flags = fld(I_FLAGS);
     const bool has_gemm = (flags & 1) != 0;
-    const int set = (flags >> 8) & 3;
     const int n_tasks = fld(I_NT);
     CWN_STAMP(9);
     int t_r0[2], t_n[2], t_be0[2], t_bne[2], t_sr0[2], t_sn[2];
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     }
     // staged rows: [0, g_n) the cells of task 0 (the GEMM dimension g when the item has one), then, from
     // row R1 (a multiple of the rows-per-round, so that lane groups line up), the c_n cells of g + 1
-    const int g_r0 = has_gemm ? fld(I_GR0) : t_r0[0], g_n = has_gemm ? fld(I_GN) : t_n[0];
+    const int g_r0 = t_r0[0], g_n = t_n[0];
     const int c_r0 = fld(I_CR0), c_n = has_gemm ? fld(I_CN) : 0;
     const int u_e0 = fld(I_UE0), u_ne = has_gemm ? fld(I_UNE) : 0;
     const int T1 = (g_n + 15) >> 4, T2 = (c_n + 15) >> 4;      // 16-row tiles of Y1, Y2
@@ -220,80 +240,60 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // from the staged rows) when task 1 reads them
     const int x_rows = t_sn[0] + t_sn[1];
     const int gl = tid % G::kG, gq = tid / G::kG, f = gl * 4;  // lane group gq finishes rows gq, gq + kNG, ...
-
-    // the set record of this item: scalar loads from the kernel-argument segment at a run-time offset
-    typedef const uint64_t __attribute__((address_space(4))) karg_u64;
-    karg_u64* const sd = (karg_u64*)__builtin_amdgcn_kernarg_segment_ptr() + min(set, kMaxSets - 1) * kSetFields;
-    const gcf_p xg = (gcf_p)sd[S_XG];
-    const gcf_p xc = (gcf_p)sd[S_XC];                          // x_{g+1}
-    const gci64_p up_index = (gci64_p)sd[S_UP_INDEX];
-    const gci64_p up_shared = (gci64_p)sd[S_UP_SHARED];
-    const int64_t up_E = (int64_t)sd[S_UP_E];
-    const gcb_p wp = (gcb_p)sd[S_WP];
-    const gcf_p bias = (gcf_p)sd[S_MSG_BIAS];
-    const uint64_t ng_nc = sd[S_NG_NC];
-    const gcf_p xs_t0 = (gcf_p)sd[S_TASK0 + ST_XS];            // x_{g-1}: boundary sources of task 0
-    const gci64_p b_index0 = (gci64_p)sd[S_TASK0 + ST_B_INDEX];
-    const gci64_p b_index1 = (gci64_p)sd[S_TASK0 + ST_FIELDS + ST_B_INDEX];
-    const int64_t b_E0 = (int64_t)sd[S_TASK0 + ST_B_E], b_E1 = (int64_t)sd[S_TASK0 + ST_FIELDS + ST_B_E];
-    const uint64_t n_ns0 = sd[S_TASK0 + ST_N_NS], n_ns1 = sd[S_TASK0 + ST_FIELDS + ST_N_NS];
-    const gf_p out_up0 = (gf_p)sd[S_TASK0 + ST_OUT_UP];
-    const gf_p out_up1 = (gf_p)sd[S_TASK0 + ST_FIELDS + ST_OUT_UP];
-    const gf_p out_b0 = (gf_p)sd[S_TASK0 + ST_OUT_B];
-    const gf_p out_b1 = (gf_p)sd[S_TASK0 + ST_FIELDS + ST_OUT_B];
-    const gcf_p e0p = (gcf_p)sd[S_TASK0 + ST_EPS1], e1p = (gcf_p)sd[S_TASK0 + ST_EPS2];
-    const gcf_p e2p = (gcf_p)sd[S_TASK0 + ST_FIELDS + ST_EPS1], e3p = (gcf_p)sd[S_TASK0 + ST_FIELDS + ST_EPS2];
-
     CWN_STAMP(10);
-    // A record that does not fit the launch's LDS, or names cells / entries the tensors do not have:
-    // report and leave (uniform over the workgroup) BEFORE any address is formed from it.
-    {
-        auto in_range = [](int64_t first, int64_t count, int64_t size) { return first >= 0 && count >= 0 && first + count <= size; };
-        bool ok = set < kMaxSets && rows_pad <= rows_cap && x_rows <= A.xrows_cap && total <= kEcap &&
-                  u_ne >= 0 && t_bne[0] >= 0 && t_bne[1] >= 0 && t_n[0] <= kTaskRows && t_n[1] <= kTaskRows &&
-                  g_n <= kTaskRows;
-        // task 0 IS the staged block [0, g_n); task 1 (if any) is the coface block and reads task 0's cells
-        ok = ok && g_r0 == t_r0[0] && g_n == t_n[0];
-        ok = ok && (n_tasks < 2 || (has_gemm && t_r0[1] == c_r0 && t_n[1] == c_n &&
-                                    (t_bne[1] == 0 || (t_sr0[1] == g_r0 && t_sn[1] == g_n))));
-        ok = ok && in_range(g_r0, g_n, (int32_t)n_ns0) && in_range(t_sr0[0], t_sn[0], (int32_t)(n_ns0 >> 32)) &&
-             in_range(t_be0[0], t_bne[0], b_E0);
-        ok = ok && (!has_gemm || (in_range(g_r0, g_n, (int32_t)ng_nc) && in_range(c_r0, c_n, (int32_t)(ng_nc >> 32)) &&
-                                  in_range(u_e0, u_ne, up_E)));
-        ok = ok && (n_tasks < 2 || (in_range(t_r0[1], t_n[1], (int32_t)n_ns1) && in_range(t_be0[1], t_bne[1], b_E1)));
-        if (!ok) {
-            if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
-            return;
-        }
+    // What the HOST cannot check for the caller (cwn_layer_fused_f32 compares the table's summary with
+    // the tensors): that this record fits the LDS this launch was given, and that its second task is
+    // the coface block.  Uniform over the workgroup.
+    if (rows_pad > rows_cap || x_rows > A.xrows_cap || total > kEcap || u_ne < 0 || t_bne[0] < 0 || t_bne[1] < 0 ||
+        t_n[0] > kTaskRows || t_n[1] > kTaskRows || g_n < 0 || c_n < 0 ||
+        (n_tasks > 1 && (t_n[1] != c_n || (t_bne[1] > 0 && t_sn[1] != g_n)))) {
+        if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
+        return;
     }
     bool bad = false;
 
-    // ---- 2. every global load of the item, in ONE branch-free run --------------------------------------
-    // No load sits behind a branch: a lane with nothing to fetch reads a harmless valid address (the
-    // item table) instead.  Behind branches the compiler cannot count the loads in flight and waits
-    // with vmcnt(0) -- i.e. for the 200 KB of rows and weights issued after the entries -- wherever
-    // an early result is used (measured: entries -> LDS and the rank each sat 2 us on such waits).
+    // ---- 2. every global load of the item, in one run; no load behind a DIVERGENT branch ---------------
+    // A lane with nothing to fetch reads a harmless valid address (the item table) instead.  Behind
+    // divergent branches the compiler cannot count the loads in flight and waits with vmcnt(0) -- i.e.
+    // for the 200 KB of rows and weights issued after the entries -- wherever an early result is used
+    // (measured: entries -> LDS and the rank each sat 2 us on such waits).  The row loads that only
+    // large items need sit behind UNIFORM guards at the very end of the run, where no earlier load
+    // has to be counted past them.
     const gcf_p dummy = (gcf_p)A.items;                      // >= 128 readable bytes, 16-B aligned
     const int ct = wave % G::kNCT, rt_par = wave / G::kNCT;
     int64_t ek[2], ev[2], ea[2];
+    if constexpr (MODE != kLoad) {
+        const gci64_p up_index = (gci64_p)sfld(S_UP_INDEX), up_shared = (gci64_p)sfld(S_UP_SHARED);
+        const gci64_p b_index0 = (gci64_p)sfld(S_TASK0 + ST_B_INDEX);
+        const gci64_p b_index1 = (gci64_p)sfld(S_TASK0 + ST_FIELDS + ST_B_INDEX);
+        const int64_t up_E = (int64_t)sfld(S_UP_E);
+        const int64_t b_E0 = (int64_t)sfld(S_TASK0 + ST_B_E), b_E1 = (int64_t)sfld(S_TASK0 + ST_FIELDS + ST_B_E);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int w = tid + i * kThreads;
-        const bool in_up = w < s1, in_b0 = w >= b1 && w < s2, in_b1 = w >= b2 && w < s3;
-        const gci64_p src = in_up ? up_index : in_b0 ? b_index0 : in_b1 ? b_index1 : (gci64_p)A.items;
-        const int64_t E = in_up ? up_E : in_b0 ? b_E0 : in_b1 ? b_E1 : 0;
-        const int64_t e = in_up ? (int64_t)u_e0 + w : in_b0 ? (int64_t)t_be0[0] + (w - b1)
-                                                   : in_b1 ? (int64_t)t_be0[1] + (w - b2) : 0;
-        ev[i] = src[e];
-        ek[i] = src[E + e];
-        ea[i] = (in_up ? up_shared : (gci64_p)A.items)[in_up ? e : 0];
+        for (int i = 0; i < 2; ++i) {
+            const int w = tid + i * kThreads;
+            const bool in_up = w < s1, in_b0 = w >= b1 && w < s2, in_b1 = w >= b2 && w < s3;
+            const gci64_p src = in_up ? up_index : in_b0 ? b_index0 : in_b1 ? b_index1 : (gci64_p)A.items;
+            const int64_t E = in_up ? up_E : in_b0 ? b_E0 : in_b1 ? b_E1 : 0;
+            const int64_t e = in_up ? (int64_t)u_e0 + w : in_b0 ? (int64_t)t_be0[0] + (w - b1)
+                                                       : in_b1 ? (int64_t)t_be0[1] + (w - b2) : 0;
+            ev[i] = src[e];
+            ek[i] = src[E + e];
+            ea[i] = (in_up ? up_shared : (gci64_p)A.items)[in_up ? e : 0];
+        }
     }
+    uint4 csr_img = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (MODE == kLoad)      // the item's finished CSR, stored by an earlier layer of this batch
+        csr_img = ldgu4((gcb_p)A.csr_cache + (size_t)blockIdx.x * kCsrSlot + (size_t)min(tid, kCsrSlot / 16 - 1) * 16);
     float epsv;
     {   // lane 0..3 of every wave -> eps1, eps2 of task 0, eps1, eps2 of task 1 (NULL = 0)
-        const gcf_p ep = lane == 0 ? e0p : lane == 1 ? e1p : lane == 2 ? e2p : lane == 3 ? e3p : (gcf_p)0;
+        const int k = S_TASK0 + ((lane & 2) ? ST_FIELDS : 0) + ST_EPS1 + (lane & 1);
+        const uint64_t bits = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(4 * k, srec_lo) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(4 * k, srec_hi) << 32);
+        const gcf_p ep = lane < 4 ? (gcf_p)bits : (gcf_p)0;
         const float v = *(ep != (gcf_p)0 ? ep : dummy);
         epsv = ep != (gcf_p)0 ? v : 0.0f;
     }
+    const gcf_p bias = (gcf_p)sfld(S_MSG_BIAS);
     const bool has_bias = has_gemm && bias != (gcf_p)0;
     float4 b4 = ldg4(has_bias ? bias + ct * 16 + kq * 4 : dummy);
     if (!has_bias) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -301,6 +301,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // this wave's slice of the packed weight: kWChunks chunks of 1 KiB, lane l takes bytes 16 l .. 16 l + 15
     uint4 wsp[2][G::kKS][3];
     {
+        const gcb_p wp = (gcb_p)sfld(S_WP);
         const gcb_p wbase = has_gemm ? wp + (size_t)ct * G::kWChunks * 1024 + lane * 16 : (gcb_p)A.items;
         const int on = has_gemm ? 1024 : 0;
 #pragma unroll
@@ -311,121 +312,133 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
                 for (int pl = 0; pl < 3; ++pl) wsp[h][ks][pl] = ldgu4(wbase + ((h * G::kKS + ks) * 3 + pl) * on);
     }
     CWN_STAMP(12);
-    // the staged rows; rows past the real ones re-read the last real row (never used)
-    float4 xv[kNX];
+    // the staged rows (rows past the real ones re-read the last real row, never used), then the rows the
+    // boundary stream of task 0 gathers from; round i is skipped when no item row falls into it
+    float4 xv[kNX], ev4[kNE];
+    {
+        const gcf_p xg = (gcf_p)sfld(S_XG), xc = (gcf_p)sfld(S_XC), xs_t0 = (gcf_p)sfld(S_TASK0 + ST_XS);
+        const int nxr = (rows_pad + G::kNG - 1) / G::kNG, ner = (t_sn[0] + G::kNG - 1) / G::kNG;
 #pragma unroll
-    for (int i = 0; i < kNX; ++i) {
-        const int row = min(gq + i * G::kNG, rows_pad - 1);
-        const bool second = c_n > 0 && row >= R1;
-        const int r = second ? min(row - R1, c_n - 1) : min(row, g_n - 1);
-        const gcf_p base = (rows_pad <= 0 || g_n <= 0) ? dummy
-                         : second ? xc + (int64_t)(c_r0 + r) * F + f : xg + (int64_t)(g_r0 + r) * F + f;
-        xv[i] = ldg4(base);
-    }
-    // rows the boundary stream of task 0 gathers from
-    float4 ev4[kNE];
+        for (int i = 0; i < kNX; ++i) {
+            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nxr) {
+                const int row = min(gq + i * G::kNG, rows_pad - 1);
+                const bool second = c_n > 0 && row >= R1;
+                const int r = second ? min(row - R1, c_n - 1) : min(row, g_n - 1);
+                xv[i] = ldg4(g_n <= 0 ? dummy : second ? xc + (int64_t)(c_r0 + r) * F + f : xg + (int64_t)(g_r0 + r) * F + f);
+            }
+        }
 #pragma unroll
-    for (int i = 0; i < kNE; ++i) {
-        const int row = min(gq + i * G::kNG, t_sn[0] - 1);
-        ev4[i] = ldg4(t_sn[0] <= 0 ? dummy : xs_t0 + (int64_t)(t_sr0[0] + row) * F + f);
+        for (int i = 0; i < kNE; ++i) {
+            ev4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < ner) ev4[i] = ldg4(xs_t0 + (int64_t)(t_sr0[0] + min(gq + i * G::kNG, t_sn[0] - 1)) * F + f);
+        }
     }
     CWN_STAMP(1);
 
-    // ---- 3a. entries -> LDS as local row numbers, range-checked --------------------------------------
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int w = tid + i * kThreads;
-        if (w < total) {
-            int64_t k = 0, v = 0, a = 0, nk = 1, nv = 1, na = 1;
-            bool live = true;
-            if (w < s1) {
-                k = ek[i] - g_r0; v = ev[i] - g_r0; a = ea[i] - c_r0;
-                nk = g_n; nv = g_n; na = c_n;
-            } else if (w >= b1 && w < s2) {
-                k = ek[i] - t_r0[0]; v = ev[i] - t_sr0[0];
-                nk = t_n[0]; nv = t_sn[0];
-            } else if (w >= b2 && w < s3) {
-                k = ek[i] - t_r0[1]; v = ev[i] - t_sr0[1];
-                nk = t_n[1];
-                v = (v >= 0 && v < t_sn[1]) ? v + t_sn[0] : -1;   // row in the staged source block
-                nv = t_sn[0] + t_sn[1];
-            } else {
-                live = false;                  // padding slot between two segments: sorts after everything
-            }
-            if (live && (k < 0 || k >= nk || v < 0 || v >= nv || a < 0 || a >= na)) {
-                bad = true;
-                k = 0; v = 0; a = 0;
-            }
-            ukey[w] = live ? ((uint32_t)k << 11) | (uint32_t)w : 0xFFFFFFFFu;
-            uval[w] = (uint16_t)v;
-            uaux[w] = (uint16_t)a;
-        }
-    }
-    if (bad) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
-    __syncthreads();
-    CWN_STAMP(2);
-
-    // ---- 3b. stable rank by destination: P lanes per entry, each counts the smaller keys of its share --
-    {
-        int P = 1;
-        while (P < 8 && total * (P * 2) <= kThreads) P *= 2;
-        const int per_pass = kThreads / P;
-        for (int base = 0; base < total; base += per_pass) {
-            const int w = base + tid / P, sub = tid % P;
-            int cnt = 0, seg0 = 0;
-            uint32_t key = 0xFFFFFFFFu;
+    unsigned char* const csr_lds = reinterpret_cast<unsigned char*>(scol);     // [scol | saux | rowptr]
+    if constexpr (MODE == kLoad) {
+        // ---- 3'. the finished CSR of this item comes back from the cache: one 16-byte load per thread ---
+        if (tid < kCsrSlot / 16) *reinterpret_cast<uint4*>(csr_lds + (size_t)tid * 16) = csr_img;
+        CWN_STAMP(2);
+        CWN_STAMP(3);
+    } else {
+        // ---- 3a. entries -> LDS as local row numbers, range-checked --------------------------------------
+    #pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int w = tid + i * kThreads;
             if (w < total) {
-                seg0 = w < b1 ? 0 : (w < b2 ? b1 : b2);
-                const int seg1 = w < b1 ? b1 : (w < b2 ? b2 : total);          // padded end: multiple of 4
-                key = ukey[w];
-                const int len4 = (seg1 - seg0) >> 2, chunk4 = (len4 + P - 1) / P;
-                const int lo = seg0 + 4 * sub * chunk4, hi = min(seg1, lo + 4 * chunk4);
-                // four reads in flight per step (a read a step is one LDS round trip per four keys)
-                for (int e = lo; e < hi; e += 16) {
-                    uint4 kk[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        kk[u] = *reinterpret_cast<const uint4*>(ukey + min(e + 4 * u, seg1 - 4));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int c = (kk[u].x < key) + (kk[u].y < key) + (kk[u].z < key) + (kk[u].w < key);
-                        cnt += e + 4 * u < hi ? c : 0;
+                int64_t k = 0, v = 0, a = 0, nk = 1, nv = 1, na = 1;
+                bool live = true;
+                if (w < s1) {
+                    k = ek[i] - g_r0; v = ev[i] - g_r0; a = ea[i] - c_r0;
+                    nk = g_n; nv = g_n; na = c_n;
+                } else if (w >= b1 && w < s2) {
+                    k = ek[i] - t_r0[0]; v = ev[i] - t_sr0[0];
+                    nk = t_n[0]; nv = t_sn[0];
+                } else if (w >= b2 && w < s3) {
+                    k = ek[i] - t_r0[1]; v = ev[i] - t_sr0[1];
+                    nk = t_n[1];
+                    v = (v >= 0 && v < t_sn[1]) ? v + t_sn[0] : -1;   // row in the staged source block
+                    nv = t_sn[0] + t_sn[1];
+                } else {
+                    live = false;                  // padding slot between two segments: sorts after everything
+                }
+                if (live && (k < 0 || k >= nk || v < 0 || v >= nv || a < 0 || a >= na)) {
+                    bad = true;
+                    k = 0; v = 0; a = 0;
+                }
+                ukey[w] = live ? ((uint32_t)k << 11) | (uint32_t)w : 0xFFFFFFFFu;
+                uval[w] = (uint16_t)v;
+                uaux[w] = (uint16_t)a;
+            }
+        }
+        if (bad) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
+        __syncthreads();
+        CWN_STAMP(2);
+
+        // ---- 3b. stable rank by destination: P lanes per entry, each counts the smaller keys of its share --
+        {
+            int P = 1;
+            while (P < 8 && total * (P * 2) <= kThreads) P *= 2;
+            const int per_pass = kThreads / P;
+            for (int base = 0; base < total; base += per_pass) {
+                const int w = base + tid / P, sub = tid % P;
+                int cnt = 0, seg0 = 0;
+                uint32_t key = 0xFFFFFFFFu;
+                if (w < total) {
+                    seg0 = w < b1 ? 0 : (w < b2 ? b1 : b2);
+                    const int seg1 = w < b1 ? b1 : (w < b2 ? b2 : total);          // padded end: multiple of 4
+                    key = ukey[w];
+                    const int len4 = (seg1 - seg0) >> 2, chunk4 = (len4 + P - 1) / P;
+                    const int lo = seg0 + 4 * sub * chunk4, hi = min(seg1, lo + 4 * chunk4);
+                    // four reads in flight per step (a read a step is one LDS round trip per four keys)
+                    for (int e = lo; e < hi; e += 16) {
+                        uint4 kk[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            kk[u] = *reinterpret_cast<const uint4*>(ukey + min(e + 4 * u, seg1 - 4));
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = (kk[u].x < key) + (kk[u].y < key) + (kk[u].z < key) + (kk[u].w < key);
+                            cnt += e + 4 * u < hi ? c : 0;
+                        }
                     }
                 }
-            }
-            for (int off = 1; off < P; off <<= 1) cnt += __shfl_xor(cnt, off, 64);
-            if (key != 0xFFFFFFFFu && sub == 0) {
-                const int pos = seg0 + cnt;
-                skey[pos] = (uint16_t)(key >> 11);
-                scol[pos] = uval[w];
-                saux[pos] = uaux[w];
+                for (int off = 1; off < P; off <<= 1) cnt += __shfl_xor(cnt, off, 64);
+                if (key != 0xFFFFFFFFu && sub == 0) {
+                    const int pos = seg0 + cnt;
+                    skey[pos] = (uint16_t)(key >> 11);
+                    scol[pos] = uval[w];
+                    saux[pos] = uaux[w];
+                }
             }
         }
-    }
-    __syncthreads();
-    CWN_STAMP(3);
+        __syncthreads();
+        CWN_STAMP(3);
 
-    // ---- 3c. row pointers from the sorted keys (run boundaries), empty rows included -----------------
-    for (int p = tid; p < s3; p += kThreads) {
-        const int which = p < b1 ? 0 : (p < b2 ? 1 : 2);
-        const int seg0 = which == 0 ? 0 : (which == 1 ? b1 : b2);
-        const int seg1 = which == 0 ? s1 : (which == 1 ? s2 : s3);
-        if (p < seg1) {
-            const int n_rows = which == 0 ? g_n : t_n[which - 1];
-            uint16_t* rp = rowptr + which * kRpStride;
-            const int k = skey[p];
-            const int kprev = p > seg0 ? (int)skey[p - 1] : -1;
-            for (int r = kprev + 1; r <= k; ++r) rp[r] = (uint16_t)(p - seg0);
-            if (p == seg1 - 1)
-                for (int r = k + 1; r <= n_rows; ++r) rp[r] = (uint16_t)(seg1 - seg0);
+        // ---- 3c. row pointers from the sorted keys (run boundaries), empty rows included -----------------
+        for (int p = tid; p < s3; p += kThreads) {
+            const int which = p < b1 ? 0 : (p < b2 ? 1 : 2);
+            const int seg0 = which == 0 ? 0 : (which == 1 ? b1 : b2);
+            const int seg1 = which == 0 ? s1 : (which == 1 ? s2 : s3);
+            if (p < seg1) {
+                const int n_rows = which == 0 ? g_n : t_n[which - 1];
+                uint16_t* rp = rowptr + which * kRpStride;
+                const int k = skey[p];
+                const int kprev = p > seg0 ? (int)skey[p - 1] : -1;
+                for (int r = kprev + 1; r <= k; ++r) rp[r] = (uint16_t)(p - seg0);
+                if (p == seg1 - 1)
+                    for (int r = k + 1; r <= n_rows; ++r) rp[r] = (uint16_t)(seg1 - seg0);
+            }
         }
+        if (s1 == 0)
+            for (int r = tid; r <= g_n; r += kThreads) rowptr[r] = 0;
+        if (s2 == b1)
+            for (int r = tid; r <= t_n[0]; r += kThreads) rowptr[kRpStride + r] = 0;
+        if (s3 == b2)
+            for (int r = tid; r <= t_n[1]; r += kThreads) rowptr[2 * kRpStride + r] = 0;
     }
-    if (s1 == 0)
-        for (int r = tid; r <= g_n; r += kThreads) rowptr[r] = 0;
-    if (s2 == b1)
-        for (int r = tid; r <= t_n[0]; r += kThreads) rowptr[kRpStride + r] = 0;
-    if (s3 == b2)
-        for (int r = tid; r <= t_n[1]; r += kThreads) rowptr[2 * kRpStride + r] = 0;
 
     // ---- 4. GEMM rows -> three bf16 planes; boundary-source rows -> fp32 -------------------------------
     {
@@ -451,6 +464,13 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         }
     }
     __syncthreads();
+    if constexpr (MODE == kSortStore) {     // the finished CSR goes to the cache for the next layers of this batch
+        if (tid < kCsrSlot / 16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(csr_lds + (size_t)tid * 16);
+            const v4u vv = {v.x, v.y, v.z, v.w};
+            *(gu4_p)((gb_p)A.csr_cache + (size_t)blockIdx.x * kCsrSlot + (size_t)tid * 16) = vv;
+        }
+    }
     CWN_STAMP(4);
 
     // ---- 5. boundary stream and self terms of every task, out of LDS -----------------------------------
@@ -462,41 +482,55 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         if (t < n_tasks) {
-            const gf_p out_up = t == 0 ? out_up0 : out_up1;
-            const gf_p out_b = t == 0 ? out_b0 : out_b1;
+            const gf_p out_up = (gf_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_UP);
+            const gf_p out_b = (gf_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_B);
             const float scale1 = 1.0f + eps1[t], scale2 = 1.0f + eps2[t];
             const uint16_t* rp = rowptr + (t + 1) * kRpStride;
             const uint16_t* col = scol + (t == 0 ? b1 : b2);
             const bool up_here = has_gemm && t == 0;   // the GEMM dimension is task 0 (blockplan.py)
             const int k0 = t == 0 ? 0 : R1 / G::kNG;   // first staged round of this task's cells
-            for (int k = 0; gq + k * G::kNG < t_n[t]; ++k) {
-                const int r = gq + k * G::kNG;
-                const float4 xi = pick(xv, k0 + k);      // the self term: this lane group loaded that row
-                const int start = rp[r], end = rp[r + 1];
-                const int64_t row = (int64_t)(t_r0[t] + r) * F + f;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                // four entries in flight; added in entry order (a skipped slot adds +0: exact)
-                for (int p = start; p < end; p += 4) {
+            // TWO rows per lane group in flight (rounds k and k + 1): the chain row pointers -> source
+            // numbers -> source rows is three LDS round trips, and a group has up to six rounds
+            for (int k = 0; gq + k * G::kNG < t_n[t]; k += 2) {
+                const int ra = gq + k * G::kNG, rb = ra + G::kNG;
+                const bool hb = rb < t_n[t];
+                const float4 xa = pick(xv, k0 + k), xb = pick(xv, k0 + k + 1);   // self terms: this group loaded them
+                const int sa = rp[ra], ea_ = rp[ra + 1];
+                const int sb = hb ? rp[rb] : 0, eb = hb ? rp[rb + 1] : 0;
+                float4 acca = make_float4(0.f, 0.f, 0.f, 0.f), accb = acca;
+                const int steps = max(ea_ - sa, eb - sb);
+                for (int q = 0; q < steps; q += 2) {    // two entries of each row per step, added in entry order
                     int c[4];
                     float4 a[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) c[u] = col[min(p + u, end - 1)];
+                    for (int u = 0; u < 2; ++u) {
+                        c[u] = col[min(sa + q + u, max(ea_ - 1, 0))];
+                        c[2 + u] = col[min(sb + q + u, max(eb - 1, 0))];
+                    }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) a[u] = lds4(xsrc + (size_t)c[u] * F + f);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool on = p + u < end;
-                        acc.x += on ? a[u].x : 0.0f;
-                        acc.y += on ? a[u].y : 0.0f;
-                        acc.z += on ? a[u].z : 0.0f;
-                        acc.w += on ? a[u].w : 0.0f;
+                    for (int u = 0; u < 2; ++u) {      // a skipped slot adds +0: exact
+                        const bool ona = sa + q + u < ea_, onb = sb + q + u < eb;
+                        acca.x += ona ? a[u].x : 0.0f; acca.y += ona ? a[u].y : 0.0f;
+                        acca.z += ona ? a[u].z : 0.0f; acca.w += ona ? a[u].w : 0.0f;
+                        accb.x += onb ? a[2 + u].x : 0.0f; accb.y += onb ? a[2 + u].y : 0.0f;
+                        accb.z += onb ? a[2 + u].z : 0.0f; accb.w += onb ? a[2 + u].w : 0.0f;
                     }
                 }
-                stg4(out_b + row, make_float4(acc.x + scale2 * xi.x, acc.y + scale2 * xi.y, acc.z + scale2 * xi.z,
-                                              acc.w + scale2 * xi.w));
-                if (!up_here)        // no upper adjacency in this dimension: zeros + self term
-                    stg4(out_up + row, make_float4(0.0f + scale1 * xi.x, 0.0f + scale1 * xi.y, 0.0f + scale1 * xi.z,
-                                                   0.0f + scale1 * xi.w));
+                const int64_t rowa = (int64_t)(t_r0[t] + ra) * F + f, rowb = (int64_t)(t_r0[t] + rb) * F + f;
+                stg4(out_b + rowa, make_float4(acca.x + scale2 * xa.x, acca.y + scale2 * xa.y, acca.z + scale2 * xa.z,
+                                               acca.w + scale2 * xa.w));
+                if (hb)
+                    stg4(out_b + rowb, make_float4(accb.x + scale2 * xb.x, accb.y + scale2 * xb.y,
+                                                   accb.z + scale2 * xb.z, accb.w + scale2 * xb.w));
+                if (!up_here) {      // no upper adjacency in this dimension: zeros + self term
+                    stg4(out_up + rowa, make_float4(0.0f + scale1 * xa.x, 0.0f + scale1 * xa.y, 0.0f + scale1 * xa.z,
+                                                    0.0f + scale1 * xa.w));
+                    if (hb)
+                        stg4(out_up + rowb, make_float4(0.0f + scale1 * xb.x, 0.0f + scale1 * xb.y,
+                                                        0.0f + scale1 * xb.z, 0.0f + scale1 * xb.w));
+                }
             }
         }
     }
@@ -512,6 +546,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         constexpr int kMaxT = 12288 / F / 16 / G::kWPC;
         static_assert(kMaxT % 2 == 0, "tiles are processed in pairs");
         static_assert(offsetof(LayerArgs, set) == 0, "read through the kernarg segment pointer");
+        static_assert(kSetFields <= 64 && CWN_LAYER_ITEM_INTS <= 64, "one lane per field");
         frag_cd acc[2][kMaxT];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -579,21 +614,25 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
 
     // ---- 7. upper stream out of LDS: out_up[i] = sum_p relu(Y1[col[p]] + Y2[aux[p]]) + (1 + eps1) x_i -
     {
+        const gf_p out_up0 = (gf_p)sfld(S_TASK0 + ST_OUT_UP);
         const float scale1 = 1.0f + eps1[0];
         const float* Y2 = Y + (size_t)R1 * G::kYStride;
-        for (int k = 0; gq + k * G::kNG < g_n; ++k) {
-            const int r = gq + k * G::kNG;
-            const float4 xi = pick(xv, k);
-            const int start = rowptr[r], end = rowptr[r + 1];
-            const int64_t row = (int64_t)(g_r0 + r) * F + f;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int p = start; p < end; p += 4) {
+        for (int k = 0; gq + k * G::kNG < g_n; k += 2) {      // two rows per lane group in flight
+            const int ra = gq + k * G::kNG, rb = ra + G::kNG;
+            const bool hb = rb < g_n;
+            const float4 xa = pick(xv, k), xb = pick(xv, k + 1);
+            const int sa = rowptr[ra], ea_ = rowptr[ra + 1];
+            const int sb = hb ? rowptr[rb] : 0, eb = hb ? rowptr[rb + 1] : 0;
+            float4 acca = make_float4(0.f, 0.f, 0.f, 0.f), accb = acca;
+            const int steps = max(ea_ - sa, eb - sb);
+            for (int q = 0; q < steps; q += 2) {
                 int cj[4], cc[4];
                 float4 a[4], b[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    cj[u] = scol[min(p + u, end - 1)];
-                    cc[u] = saux[min(p + u, end - 1)];
+                for (int u = 0; u < 2; ++u) {
+                    const int pa = min(sa + q + u, max(ea_ - 1, 0)), pb = min(sb + q + u, max(eb - 1, 0));
+                    cj[u] = scol[pa]; cc[u] = saux[pa];
+                    cj[2 + u] = scol[pb]; cc[2 + u] = saux[pb];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -601,16 +640,25 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
                     b[u] = lds4(Y2 + (size_t)cc[u] * G::kYStride + f);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool on = p + u < end;
-                    acc.x += on ? fmaxf(a[u].x + b[u].x, 0.0f) : 0.0f;
-                    acc.y += on ? fmaxf(a[u].y + b[u].y, 0.0f) : 0.0f;
-                    acc.z += on ? fmaxf(a[u].z + b[u].z, 0.0f) : 0.0f;
-                    acc.w += on ? fmaxf(a[u].w + b[u].w, 0.0f) : 0.0f;
+                for (int u = 0; u < 2; ++u) {
+                    const bool ona = sa + q + u < ea_, onb = sb + q + u < eb;
+                    acca.x += ona ? fmaxf(a[u].x + b[u].x, 0.0f) : 0.0f;
+                    acca.y += ona ? fmaxf(a[u].y + b[u].y, 0.0f) : 0.0f;
+                    acca.z += ona ? fmaxf(a[u].z + b[u].z, 0.0f) : 0.0f;
+                    acca.w += ona ? fmaxf(a[u].w + b[u].w, 0.0f) : 0.0f;
+                    accb.x += onb ? fmaxf(a[2 + u].x + b[2 + u].x, 0.0f) : 0.0f;
+                    accb.y += onb ? fmaxf(a[2 + u].y + b[2 + u].y, 0.0f) : 0.0f;
+                    accb.z += onb ? fmaxf(a[2 + u].z + b[2 + u].z, 0.0f) : 0.0f;
+                    accb.w += onb ? fmaxf(a[2 + u].w + b[2 + u].w, 0.0f) : 0.0f;
                 }
             }
-            stg4(out_up0 + row, make_float4(acc.x + scale1 * xi.x, acc.y + scale1 * xi.y, acc.z + scale1 * xi.z,
-                                            acc.w + scale1 * xi.w));
+            stg4(out_up0 + (int64_t)(g_r0 + ra) * F + f,
+                 make_float4(acca.x + scale1 * xa.x, acca.y + scale1 * xa.y, acca.z + scale1 * xa.z,
+                             acca.w + scale1 * xa.w));
+            if (hb)
+                stg4(out_up0 + (int64_t)(g_r0 + rb) * F + f,
+                     make_float4(accb.x + scale1 * xb.x, accb.y + scale1 * xb.y, accb.z + scale1 * xb.z,
+                                 accb.w + scale1 * xb.w));
         }
     }
     CWN_STAMP(8);
@@ -643,12 +691,12 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 unsigned long long* g_stamps = nullptr;
 #endif
 
-template <int F>
+template <int F, int MODE>
 int launch(LayerArgs& A, int64_t n_items, hipStream_t stream) {
     static std::once_flag once;            // raise the dynamic-LDS limit of this instantiation, once
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel<F>),
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel<F, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
@@ -656,7 +704,7 @@ int launch(LayerArgs& A, int64_t n_items, hipStream_t stream) {
     A.stamps = g_stamps;
 #endif
     const size_t lds = lds_bytes<F>(A.rows_cap, A.xrows_cap);
-    layer_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), lds, stream>>>(A);
+    layer_kernel<F, MODE><<<dim3((unsigned)n_items), dim3(kThreads), lds, stream>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
@@ -690,17 +738,21 @@ extern "C" size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, in
     return b <= 160 * 1024 ? b : 0;
 }
 
-extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_t F, const int32_t* items,
-                                   int64_t n_items, int32_t max_gemm_rows, int32_t max_source_rows,
+extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_t F, const cwn_layer_plan* plan,
                                    int32_t flags, int32_t* err_flag, cwn_stream_t stream_) {
-    if (dims == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS || n_items < 0 || flags != 0)
+    if (dims == nullptr || plan == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS || plan->n_items < 0)
+        return CWN_ERR_BAD_ARG;
+    if ((flags & ~(CWN_LAYER_CSR_STORE | CWN_LAYER_CSR_LOAD)) != 0 ||
+        (flags & (CWN_LAYER_CSR_STORE | CWN_LAYER_CSR_LOAD)) == (CWN_LAYER_CSR_STORE | CWN_LAYER_CSR_LOAD))
         return CWN_ERR_BAD_ARG;
     if (F != 64 && F != 128) return CWN_ERR_BAD_ARG;
+    const int64_t n_items = plan->n_items;
     if (n_items == 0) return CWN_OK;
-    if (items == nullptr || err_flag == nullptr) return CWN_ERR_BAD_ARG;
+    if (plan->items == nullptr || err_flag == nullptr) return CWN_ERR_BAD_ARG;
+    if (flags != 0 && plan->csr_cache == nullptr) return CWN_ERR_BAD_ARG;
     if (n_items >= INT32_MAX) return CWN_ERR_TOO_LARGE;
-    if (cwn_layer_fused_lds_bytes(F, max_gemm_rows, max_source_rows) == 0) return CWN_ERR_BAD_ARG;
-    if (!al16(items)) return CWN_ERR_ALIGN;
+    if (cwn_layer_fused_lds_bytes(F, plan->max_gemm_rows, plan->max_source_rows) == 0) return CWN_ERR_BAD_ARG;
+    if (!al16(plan->items) || !al16(plan->csr_cache)) return CWN_ERR_ALIGN;
     LayerArgs A{};
     bool has_up[CWN_LAYER_MAX_DIMS] = {false, false, false};
     for (int d = 0; d < n_dims; ++d) {
@@ -714,6 +766,10 @@ extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_
         if (D.n_b > 0 && (D.b_index == nullptr || d == 0)) return CWN_ERR_BAD_ARG;
         if (!(al16(D.x) && al16(D.out_up) && al16(D.out_b) && al16(D.msg_w_packed) && al16(D.msg_bias)))
             return CWN_ERR_ALIGN;
+        // the table may not address more than the tensors hold: the kernel forms addresses from it
+        if (plan->cells_end[d] < 0 || plan->cells_end[d] > D.n_cells || plan->up_end[d] < 0 ||
+            plan->up_end[d] > D.e_up || plan->b_end[d] < 0 || plan->b_end[d] > D.n_b)
+            return CWN_ERR_BAD_ARG;
         has_up[d] = D.e_up > 0;
     }
     // the sets, in the order the item table numbers them (include/cwn_hip.h): every dimension with an
@@ -732,7 +788,6 @@ extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_
             S[S_UP_E] = (uint64_t)D.e_up;
             S[S_WP] = (uint64_t)(uintptr_t)D.msg_w_packed;
             S[S_MSG_BIAS] = (uint64_t)(uintptr_t)D.msg_bias;
-            S[S_NG_NC] = (uint64_t)(uint32_t)D.n_cells | ((uint64_t)(uint32_t)dims[d + 1].n_cells << 32);
             if (d + 1 < n_dims && !has_up[d + 1] && d + 2 >= n_dims) tasks[1] = d + 1;
         }
         for (int t = 0; t < 2; ++t) {
@@ -747,15 +802,30 @@ extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_
             T[ST_B_E] = (uint64_t)D.n_b;
             T[ST_EPS1] = (uint64_t)(uintptr_t)D.eps1;
             T[ST_EPS2] = (uint64_t)(uintptr_t)D.eps2;
-            T[ST_N_NS] = (uint64_t)(uint32_t)D.n_cells |
-                         ((uint64_t)(uint32_t)(tasks[t] > 0 ? dims[tasks[t] - 1].n_cells : 0) << 32);
         }
         d += tasks[1] >= 0 ? 2 : 1;
     }
-    A.items = items;
+    // items are ordered by set: set_start[s] is the first item of set s
+    for (int s_ = 0; s_ <= n_sets; ++s_) {
+        const int32_t lo = s_ == 0 ? 0 : plan->set_start[s_ - 1];
+        const int32_t v = s_ == n_sets ? (int32_t)n_items : plan->set_start[s_];
+        if ((s_ == 0 && plan->set_start[0] != 0) || v < lo || v > n_items) return CWN_ERR_BAD_ARG;
+    }
+    A.set_start1 = n_sets > 1 ? plan->set_start[1] : INT32_MAX;
+    A.set_start2 = n_sets > 2 ? plan->set_start[2] : INT32_MAX;
+    A.items = plan->items;
     A.err = err_flag;
-    A.rows_cap = max_gemm_rows;
-    A.xrows_cap = max_source_rows;
+    A.csr_cache = static_cast<unsigned char*>(plan->csr_cache);
+    A.rows_cap = plan->max_gemm_rows;
+    A.xrows_cap = plan->max_source_rows;
     hipStream_t stream = (hipStream_t)stream_;
-    return F == 128 ? launch<128>(A, n_items, stream) : launch<64>(A, n_items, stream);
+    const int mode = (flags & CWN_LAYER_CSR_LOAD) ? kLoad : (flags & CWN_LAYER_CSR_STORE) ? kSortStore : kSort;
+    if (F == 128) {
+        if (mode == kLoad) return launch<128, kLoad>(A, n_items, stream);
+        if (mode == kSortStore) return launch<128, kSortStore>(A, n_items, stream);
+        return launch<128, kSort>(A, n_items, stream);
+    }
+    if (mode == kLoad) return launch<64, kLoad>(A, n_items, stream);
+    if (mode == kSortStore) return launch<64, kSortStore>(A, n_items, stream);
+    return launch<64, kSort>(A, n_items, stream);
 }

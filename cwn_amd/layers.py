@@ -81,6 +81,7 @@ def _is_cat_linear_relu(nn) -> bool:
 
 FUSED_DENSE_TRAINING = True   # set False to run the update / combine networks as torch modules
 BLOCKED_LAYER = True          # set False to run the propagate scope as grouped GEMM + CSR aggregation
+CSR_REUSE = True              # blocked layer kernel: sort a batch's adjacencies once, later layers load the result
 
 
 def _fold_norm(norm, width: int):
@@ -603,9 +604,15 @@ class SparseCINConv(torch.nn.Module):
             self.blocked_reason = args
             return None
         self.blocked_reason = None
-        dims, plan, (items, max_rows, max_src) = args
-        outs = ops.layer_fused(dims, items, max_rows, max_src)
-        if not getattr(plan, 'validated', False) and not torch.cuda.is_current_stream_capturing():
+        dims, plan, table, key = args
+        # the layers of one forward share their index tensors (mp/molec_models.py:110-116): the first
+        # launch on them stores every item's sorted adjacency, the following ones load it back
+        from . import _ffi
+        mode = _ffi.LAYER_CSR_LOAD if (CSR_REUSE and table.csr_key == key) else (_ffi.LAYER_CSR_STORE if CSR_REUSE else 0)
+        outs = ops.layer_fused(dims, table, mode)
+        if mode == _ffi.LAYER_CSR_STORE:
+            table.csr_key = key
+        if not plan.validated and not torch.cuda.is_current_stream_capturing():
             from . import csr
             csr.check_errors(dims[0].x.device)     # once per batch: the table belongs to these index tensors
             plan.validated = True
@@ -658,10 +665,11 @@ class SparseCINConv(torch.nn.Module):
                 D.b_index = b_index
             dims.append(D)
             has_up.append(bool(up))
-        tab = plan.items(F, has_up)
-        if tab is None:
+        table = plan.items(F, has_up)
+        if table is None:
             return 'a complex does not fit one workgroup (row / entry caps)'
-        return dims, plan, tab
+        key = tuple((id(t), t._version) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
+        return dims, plan, table, key
 
     def _dense_eval(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
         """The update / combine networks of ALL dimensions (mp/layers.py:193-199) as three grouped

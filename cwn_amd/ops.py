@@ -722,10 +722,12 @@ def pack_layer_weight(weight: Tensor) -> Tensor:
     return out
 
 
-def layer_fused(dims: Sequence[LayerDim], items: Tensor, max_gemm_rows: int, max_source_rows: int) -> List[Tensor]:
-    """[out_up_0, out_b_0, out_up_1, out_b_1, ...]; no autograd (inference path).  `items` is the
-    batch's item table (cwn_amd/blockplan.py).  Index errors go to the sticky error word of
-    cwn_amd/csr.py (`csr.check_errors`)."""
+def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tensor]:
+    """[out_up_0, out_b_0, out_up_1, out_b_1, ...]; no autograd (inference path).  `table` is one of the
+    batch's item tables (cwn_amd/blockplan.py: ItemTable); csr_mode 0 sorts the COO entries in the
+    kernel, _ffi.LAYER_CSR_STORE also stores every item's CSR in the table's cache, _ffi.LAYER_CSR_LOAD
+    reads it back instead (same index tensors as the storing call).  Index errors go to the sticky
+    error word of cwn_amd/csr.py (`csr.check_errors`)."""
     from .csr import _err_flag
     dev = dims[0].x.device
     F = int(dims[0].x.size(1))
@@ -752,8 +754,7 @@ def layer_fused(dims: Sequence[LayerDim], items: Tensor, max_gemm_rows: int, max
                                msg_w_packed=_ffi.ptr(w), msg_bias=_ffi.ptr(b), eps1=_ffi.ptr(e1), eps2=_ffi.ptr(e2),
                                out_up=out_up.data_ptr(), out_b=out_b.data_ptr(), n_cells=x.size(0),
                                e_up=e_up, n_b=0 if bi is None else int(bi.size(1)))
-    _ffi.check(_ffi.lib().cwn_layer_fused_f32(arr, len(dims), F, items.data_ptr(), items.size(0),
-                                               int(max_gemm_rows), int(max_source_rows), 0,
-                                               _err_flag(dev).data_ptr(),
+    plan = table.c_plan(with_cache=csr_mode != 0)
+    _ffi.check(_ffi.lib().cwn_layer_fused_f32(arr, len(dims), F, plan, int(csr_mode), _err_flag(dev).data_ptr(),
                                                _ffi.stream_ptr(dev)), 'cwn_layer_fused_f32')
     return outs

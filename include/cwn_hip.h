@@ -201,10 +201,10 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  * data/complex.py:344-441): cwn_amd/blockplan.py.  Record layout (all offsets are into the batched
  * tensors):
  *   [0] flags      bit 0: the item has a GEMM dimension g (an upper adjacency with coboundary features);
- *                  bits 8-9: its SET -- sets are numbered over the dimensions in ascending order: a
- *                  dimension with e_up > 0 opens a set as its GEMM dimension (the top dimension rides as
- *                  its second task when it has no upper adjacency itself), any other dimension is a set
- *                  of its own
+ *                  bits 8-9: its SET (informative; the kernel derives it from cwn_layer_plan.set_start)
+ *                  -- sets are numbered over the dimensions in ascending order: a dimension with
+ *                  e_up > 0 opens a set as its GEMM dimension (the top dimension rides as its second
+ *                  task when it has no upper adjacency itself), any other dimension is a set of its own
  *   [1] g          [2] first cell of dim g   [3] number of cells of dim g
  *   [4] first cell of dim g+1                [5] number of cells of dim g+1
  *   [6] first entry of up_index_g            [7] number of entries
@@ -255,12 +255,35 @@ typedef struct cwn_layer_dim {
 size_t cwn_layer_packed_weight_bytes(int32_t F);
 int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream);
 
-/* max_gemm_rows: an upper bound (multiple of 16) of the padded GEMM rows of any item;
- * max_source_rows: an upper bound of the boundary-source cells of any item (summed over its tasks
- * that have boundary entries).  Together they size the LDS of the launch.  flags: reserved, 0. */
-int cwn_layer_fused_f32(const cwn_layer_dim* dims_host, int n_dims, int32_t F, const int32_t* items,
-                        int64_t n_items, int32_t max_gemm_rows, int32_t max_source_rows, int32_t flags,
-                        int32_t* err_flag, cwn_stream_t stream);
+/* The item table and what the launcher needs to know about it (HOST struct; built by
+ * cwn_amd/blockplan.py).  Items are ordered by set.  The *_end fields summarise what the table
+ * addresses; the launcher checks them against the tensors, so that the kernel can form addresses
+ * from a record without re-validating it (the caller vouches that the summary describes the table).
+ * What only the device can see -- the VALUES of the int64 indices -- is checked in the kernel.
+ * csr_cache (optional, n_items * CWN_LAYER_CSR_SLOT_BYTES device bytes): with CWN_LAYER_CSR_STORE
+ * every workgroup also stores its item's finished CSR there, with CWN_LAYER_CSR_LOAD it loads it
+ * back instead of reading and sorting the COO entries again -- the layers of one forward share
+ * their index tensors (mp/molec_models.py:110-116), so layer 0 stores and layers 1.. load; the
+ * caller invalidates (stores again) whenever the index tensors change. */
+#define CWN_LAYER_CSR_SLOT_BYTES 5264          /* 2 * 2 * MAX_ENTRIES + 3 * 2 * (TASK_ROWS + 2), 16-B multiple */
+#define CWN_LAYER_CSR_STORE 1
+#define CWN_LAYER_CSR_LOAD 2
+
+typedef struct cwn_layer_plan {
+    const int32_t* items;                       /* device int32 [n_items][CWN_LAYER_ITEM_INTS] */
+    void* csr_cache;                            /* device or NULL */
+    int64_t n_items;
+    int32_t set_start[CWN_LAYER_MAX_DIMS + 1];  /* first item of set s (set_start[0] = 0) */
+    int32_t max_gemm_rows;                      /* bound (multiple of 16) of the staged rows of any item */
+    int32_t max_source_rows;                    /* bound of the boundary-source cells of any item */
+    int32_t pad_;
+    int64_t cells_end[CWN_LAYER_MAX_DIMS];      /* max (first cell + count) the table names, per dimension */
+    int64_t up_end[CWN_LAYER_MAX_DIMS];         /* max (first entry + count) of up_index_d */
+    int64_t b_end[CWN_LAYER_MAX_DIMS];          /* max (first entry + count) of b_index_d */
+} cwn_layer_plan;
+
+int cwn_layer_fused_f32(const cwn_layer_dim* dims_host, int n_dims, int32_t F, const cwn_layer_plan* plan_host,
+                        int32_t flags, int32_t* err_flag, cwn_stream_t stream);
 /* dynamic LDS bytes such a launch uses, 0 for unsupported arguments or more than 160 KiB */
 size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows);
 

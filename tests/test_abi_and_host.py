@@ -38,7 +38,8 @@ def test_struct_layout_matches_header(tmp_path):
     structs = {'cwn_csr_desc': _ffi.CsrDesc, 'cwn_agg_desc': _ffi.AggDesc,
                'cwn_gemm_desc': _ffi.GemmDesc, 'cwn_collate_desc': _ffi.CollateDesc,
                'cwn_bn_desc': _ffi.BnDesc, 'cwn_norm_desc': _ffi.NormDesc,
-               'cwn_gemm_tn_desc': _ffi.GemmTnDesc, 'cwn_layer_dim': _ffi.LayerDim}
+               'cwn_gemm_tn_desc': _ffi.GemmTnDesc, 'cwn_layer_dim': _ffi.LayerDim,
+               'cwn_layer_plan': _ffi.LayerPlan}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cwn_hip.h"', 'int main(void) {']
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -81,7 +82,9 @@ def test_argument_errors_without_gpu():
     t = (_ffi.GemmTnDesc * 1)(_ffi.GemmTnDesc(M=1000, N=128, K=128, K2=128))
     assert lib.cwn_gemm_tn_workspace_bytes(t, 1) >= 8 * (128 * 256 + 128) * 4
     assert lib.cwn_lift_create(7, 3, None, 0, 6, 0) is None        # unknown lift kind
-    assert lib.cwn_layer_fused_f32(None, 1, 128, None, 1, 16, 0, 0, None, None) == 1
+    assert lib.cwn_layer_fused_f32(None, 1, 128, None, 0, None, None) == 1
+    assert lib.cwn_layer_pack_weights_f32(None, 256, 128, None, None) == 1
+    assert lib.cwn_layer_packed_weight_bytes(128) == 128 * 256 * 6 and lib.cwn_layer_packed_weight_bytes(96) == 0
     assert lib.cwn_layer_fused_lds_bytes(128, 96, 64) == 3 * 96 * 136 * 2 + 64 * 128 * 4 + 15504
 
 

@@ -194,7 +194,6 @@ def test_blocked_layer_reports_indices_that_leave_their_complex():
 
 
 def test_blocked_layer_c_abi_argument_checks():
-    import ctypes as C
     from cwn_amd import _ffi
     L = _ffi.lib()
     assert 0 < L.cwn_layer_fused_lds_bytes(128, 96, 96) <= 160 * 1024
@@ -204,10 +203,44 @@ def test_blocked_layer_c_abi_argument_checks():
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
     items = torch.zeros(1, 32, dtype=torch.int32, device=DEV)
     s = _ffi.stream_ptr(torch.device(DEV))
-    assert L.cwn_layer_fused_f32(arr, 1, 96, items.data_ptr(), 1, 16, 0, 0, err.data_ptr(), s) == 1     # F
-    assert L.cwn_layer_fused_f32(arr, 4, 128, items.data_ptr(), 1, 16, 0, 0, err.data_ptr(), s) == 1    # n_dims
-    assert L.cwn_layer_fused_f32(arr, 1, 128, items.data_ptr(), 0, 16, 0, 0, err.data_ptr(), s) == 0    # nothing to do
-    assert L.cwn_layer_fused_f32(arr, 1, 128, None, 1, 16, 0, 0, err.data_ptr(), s) == 1
+    plan = _ffi.LayerPlan(items=items.data_ptr(), n_items=1, max_gemm_rows=16, max_source_rows=0)
+    assert L.cwn_layer_fused_f32(arr, 1, 96, plan, 0, err.data_ptr(), s) == 1       # F
+    assert L.cwn_layer_fused_f32(arr, 4, 128, plan, 0, err.data_ptr(), s) == 1      # n_dims
+    assert L.cwn_layer_fused_f32(arr, 1, 128, plan, 3, err.data_ptr(), s) == 1      # store AND load
+    assert L.cwn_layer_fused_f32(arr, 1, 128, plan, 1, err.data_ptr(), s) == 1      # store without a cache
+    plan.cells_end[0] = 5                                                           # table names 5 cells, tensor has 0
+    assert L.cwn_layer_fused_f32(arr, 1, 128, plan, 0, err.data_ptr(), s) == 1
+    empty = _ffi.LayerPlan(n_items=0)
+    assert L.cwn_layer_fused_f32(arr, 1, 128, empty, 0, err.data_ptr(), s) == 0     # nothing to do
+
+
+def test_blocked_layer_csr_cache_store_and_load_are_bit_identical():
+    """Layer 0 of a forward stores every item's sorted adjacency, later layers load it: same bits as
+    sorting again; the cache is dropped when the index tensors change."""
+    from cwn_amd import layers
+    b = _batch('zinc', 77, 128, seed=21)
+    conv = _conv(128, seed=22, eps=0.1)
+    prev = layers.CSR_REUSE
+    try:
+        layers.CSR_REUSE = False
+        ref = _run(conv, b, blocked=True)
+        layers.CSR_REUSE = True
+        first = _run(conv, b, blocked=True)       # stores
+        table = next(t for t in b.block_plan()._tables.values() if t is not None)
+        assert table.csr_key is not None
+        again = _run(conv, b, blocked=True)       # loads
+        for r, f, a in zip(ref, first, again):
+            assert torch.equal(r, f) and torch.equal(r, a)
+        # new index tensors (same values): the key changes, the launch sorts and stores again
+        c = b.cochains[1]
+        c.boundary_index = c.boundary_index.clone()
+        key_before = table.csr_key
+        third = _run(conv, b, blocked=True)
+        assert table.csr_key != key_before
+        for r, t in zip(ref, third):
+            assert torch.equal(r, t)
+    finally:
+        layers.CSR_REUSE = prev
 
 
 def test_blocked_layer_falls_back_when_a_complex_exceeds_one_workgroup():

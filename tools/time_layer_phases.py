@@ -32,19 +32,22 @@ params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
 with torch.no_grad():
     args = conv._blocked_args(params, 0)
 assert not isinstance(args, str), args
-dims, plan, (items, mr, ms) = args
-REP = int(os.environ.get('REP', '1'))      # REP=2: every item twice -> the second round of workgroups runs with a warm I-cache
-items = items.repeat(REP, 1).contiguous()
+dims, plan, table, key = args
+items, mr, ms = table.items, table.max_rows, table.max_src
+MODE = int(os.environ.get('MODE', '0'))   # 0 sort, 1 sort + store, 2 load (after one storing launch)
+REP = 1
 stamps = torch.zeros(items.size(0), 16, dtype=torch.int64, device=dev)
 L.cwn_layer_debug_stamps(stamps.data_ptr())
 with torch.no_grad():
+    if MODE == 2:
+        ops.layer_fused(dims, table, 1)
     for _ in range(5):
-        ops.layer_fused(dims, items, mr, ms)
+        ops.layer_fused(dims, table, MODE)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        ops.layer_fused(dims, items, mr, ms)
+        ops.layer_fused(dims, table, MODE)
     e1.record()
     torch.cuda.synchronize()
 print(f'items {items.size(0)}  rows_cap {mr}  src_cap {ms}  lds {L.cwn_layer_fused_lds_bytes(F, mr, ms)}  '
