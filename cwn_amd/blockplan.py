@@ -32,8 +32,8 @@ _IDX_BYTES = (MAX_ENTRIES * 4 + 5 * MAX_ENTRIES * 2 + 3 * (TASK_ROWS + 2) * 2 + 
 
 def lds_bytes(F: int, gemm_rows: int, source_rows: int) -> int:
     """= cwn_layer_fused_lds_bytes: bf16 planes of the GEMM rows (Y overwrites them) + fp32 boundary
-    sources + index scratch."""
-    return 3 * gemm_rows * (F + 8) * 2 + source_rows * F * 4 + _IDX_BYTES
+    sources (+ one row of zeros) + index scratch."""
+    return 3 * gemm_rows * (F + 8) * 2 + (source_rows + 1) * F * 4 + _IDX_BYTES
 
 
 def _pad16(n: int) -> int:

@@ -114,7 +114,8 @@ template <int F> struct Geo {
     static constexpr int kWChunks = 2 * kKS * 3;            // 1-KiB chunks of the packed weight per column tile
     // planes [3][rows][F + 8] bf16, overwritten by Y [rows][F + 4] fp32 once the MFMAs have read them
     __host__ __device__ static constexpr size_t planes_bytes(int rows) { return (size_t)3 * rows * kPlaneStride * 2; }
-    __host__ __device__ static constexpr size_t xrows_bytes(int rows) { return (size_t)rows * F * 4; }
+    // fp32 boundary-source rows + one row of zeros (a reduce slot past the end of a row reads it)
+    __host__ __device__ static constexpr size_t xrows_bytes(int rows) { return (size_t)(rows + 1) * F * 4; }
 };
 
 // index scratch: u32 keys, five u16 arrays of kEcap, three row-pointer arrays.  The tail [scol | saux |
@@ -170,6 +171,102 @@ __device__ __forceinline__ float4 pick(const float4 (&xv)[kNX], int k) {
 #pragma unroll
     for (int i = 1; i < kNX; ++i) r = sel4(k == i, xv[i], r);
     return r;
+}
+
+// Reduce phases: a lane group (F/4 lanes, one float4 each) finishes NR destination rows AT ONCE -- rows
+// r0, r0 + NG, ... -- so that the chain row pointers -> source numbers -> source rows (three LDS round
+// trips a step) runs NR x 2 times in parallel instead of once: these phases are latency-bound (one
+// complex gives a lane group two or three rows of two to six entries).  Entries are added in entry
+// order; a slot past the end of its row reads a row of zeros (+0: exact).
+template <int NR>
+struct RowSet { int s[NR], e[NR]; bool on[NR]; };
+
+template <int NR, int NG>
+__device__ __forceinline__ int row_ranges(RowSet<NR>& R, const uint16_t* rp, int r0, int n_rows) {
+    int steps = 0;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int r = r0 + u * NG;
+        R.on[u] = r < n_rows;
+        const int rr = R.on[u] ? r : 0;
+        const int s = rp[rr], e = rp[rr + 1];
+        R.s[u] = R.on[u] ? s : 0;
+        R.e[u] = R.on[u] ? e : 0;
+        steps = max(steps, R.e[u] - R.s[u]);
+    }
+    return steps;
+}
+
+// sum of rows src[col[p]] over each row's entries
+template <int NR, int NG, int F>
+__device__ __forceinline__ void gather_sum(float4 (&acc)[NR], const RowSet<NR>& R, int steps, const uint16_t* col,
+                                           const float* src, int zero_row, int f) {
+#pragma unroll
+    for (int u = 0; u < NR; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < steps; q += 2) {
+        int c[NR][2];
+        float4 a[NR][2];
+#pragma unroll
+        for (int u = 0; u < NR; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int p = R.s[u] + q + v;
+                const int cv = col[min(p, max(R.e[u] - 1, 0))];
+                c[u][v] = p < R.e[u] ? cv : zero_row;
+            }
+#pragma unroll
+        for (int u = 0; u < NR; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) a[u][v] = lds4(src + (size_t)c[u][v] * F + f);
+#pragma unroll
+        for (int u = 0; u < NR; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                acc[u].x += a[u][v].x; acc[u].y += a[u][v].y; acc[u].z += a[u][v].z; acc[u].w += a[u][v].w;
+            }
+    }
+}
+
+// sum of relu(Y1[col[p]] + Y2[aux[p]]) over each row's entries (y2_off = first Y2 row - 0)
+template <int NR, int NG, int YS>
+__device__ __forceinline__ void gather_relu_sum(float4 (&acc)[NR], const RowSet<NR>& R, int steps, const uint16_t* col,
+                                                const uint16_t* aux, const float* Y1, const float* Y2, int zero1,
+                                                int zero2, int f) {
+#pragma unroll
+    for (int u = 0; u < NR; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < steps; q += 2) {
+        int cj[NR][2], cc[NR][2];
+        float4 a[NR][2], b[NR][2];
+#pragma unroll
+        for (int u = 0; u < NR; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int p = R.s[u] + q + v, pc = min(p, max(R.e[u] - 1, 0));
+                const int j = col[pc], c = aux[pc];
+                cj[u][v] = p < R.e[u] ? j : zero1;
+                cc[u][v] = p < R.e[u] ? c : zero2;
+            }
+#pragma unroll
+        for (int u = 0; u < NR; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                a[u][v] = lds4(Y1 + (size_t)cj[u][v] * YS + f);
+                b[u][v] = lds4(Y2 + (size_t)cc[u][v] * YS + f);
+            }
+#pragma unroll
+        for (int u = 0; u < NR; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                acc[u].x += fmaxf(a[u][v].x + b[u][v].x, 0.0f);
+                acc[u].y += fmaxf(a[u][v].y + b[u][v].y, 0.0f);
+                acc[u].z += fmaxf(a[u][v].z + b[u][v].z, 0.0f);
+                acc[u].w += fmaxf(a[u][v].w + b[u][v].w, 0.0f);
+            }
+    }
+}
+
+__device__ __forceinline__ float4 axpy4(const float4& acc, float s, const float4& x) {   // acc + s * x, unfused
+    return make_float4(acc.x + s * x.x, acc.y + s * x.y, acc.z + s * x.z, acc.w + s * x.w);
 }
 
 template <int F, int MODE>
@@ -298,20 +395,6 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     float4 b4 = ldg4(has_bias ? bias + ct * 16 + kq * 4 : dummy);
     if (!has_bias) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     CWN_STAMP(11);
-    // this wave's slice of the packed weight: kWChunks chunks of 1 KiB, lane l takes bytes 16 l .. 16 l + 15
-    uint4 wsp[2][G::kKS][3];
-    {
-        const gcb_p wp = (gcb_p)sfld(S_WP);
-        const gcb_p wbase = has_gemm ? wp + (size_t)ct * G::kWChunks * 1024 + lane * 16 : (gcb_p)A.items;
-        const int on = has_gemm ? 1024 : 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int ks = 0; ks < G::kKS; ++ks)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wsp[h][ks][pl] = ldgu4(wbase + ((h * G::kKS + ks) * 3 + pl) * on);
-    }
-    CWN_STAMP(12);
     // the staged rows (rows past the real ones re-read the last real row, never used), then the rows the
     // boundary stream of task 0 gathers from; round i is skipped when no item row falls into it
     float4 xv[kNX], ev4[kNE];
@@ -333,6 +416,22 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
             ev4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < ner) ev4[i] = ldg4(xs_t0 + (int64_t)(t_sr0[0] + min(gq + i * G::kNG, t_sn[0] - 1)) * F + f);
         }
+    }
+    CWN_STAMP(12);
+    // this wave's slice of the packed weight: kWChunks chunks of 1 KiB, lane l takes bytes 16 l .. 16 l + 15.
+    // LAST: it is the bulk of the bytes (192 KB per workgroup at F = 128) and only the matrix cores
+    // need it, so the rows are split and phase 5 runs while it is still landing
+    uint4 wsp[2][G::kKS][3];
+    {
+        const gcb_p wp = (gcb_p)sfld(S_WP);
+        const gcb_p wbase = has_gemm ? wp + (size_t)ct * G::kWChunks * 1024 + lane * 16 : (gcb_p)A.items;
+        const int on = has_gemm ? 1024 : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < G::kKS; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wsp[h][ks][pl] = ldgu4(wbase + ((h * G::kKS + ks) * 3 + pl) * on);
     }
     CWN_STAMP(1);
 
@@ -462,6 +561,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
             const int row = gq + i * G::kNG;
             if (row < t_sn[0]) *reinterpret_cast<float4*>(xsrc + (size_t)row * F + f) = ev4[i];
         }
+        if (gq == 0) *reinterpret_cast<float4*>(xsrc + (size_t)x_rows * F + f) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     if constexpr (MODE == kSortStore) {     // the finished CSR goes to the cache for the next layers of this batch
@@ -473,12 +573,16 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     }
     CWN_STAMP(4);
 
-    // ---- 5. boundary stream and self terms of every task, out of LDS -----------------------------------
     float eps1[2], eps2[2];
     eps1[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 0));
     eps2[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 1));
     eps1[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 2));
     eps2[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 3));
+    // ---- 5. boundary stream and self terms of every task, out of LDS (while W is still landing) --------
+#ifndef CWN_LAYER_NR
+#define CWN_LAYER_NR 2
+#endif
+    constexpr int kNR = CWN_LAYER_NR;                          // destination rows per lane group in flight
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         if (t < n_tasks) {
@@ -489,47 +593,21 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
             const uint16_t* col = scol + (t == 0 ? b1 : b2);
             const bool up_here = has_gemm && t == 0;   // the GEMM dimension is task 0 (blockplan.py)
             const int k0 = t == 0 ? 0 : R1 / G::kNG;   // first staged round of this task's cells
-            // TWO rows per lane group in flight (rounds k and k + 1): the chain row pointers -> source
-            // numbers -> source rows is three LDS round trips, and a group has up to six rounds
-            for (int k = 0; gq + k * G::kNG < t_n[t]; k += 2) {
-                const int ra = gq + k * G::kNG, rb = ra + G::kNG;
-                const bool hb = rb < t_n[t];
-                const float4 xa = pick(xv, k0 + k), xb = pick(xv, k0 + k + 1);   // self terms: this group loaded them
-                const int sa = rp[ra], ea_ = rp[ra + 1];
-                const int sb = hb ? rp[rb] : 0, eb = hb ? rp[rb + 1] : 0;
-                float4 acca = make_float4(0.f, 0.f, 0.f, 0.f), accb = acca;
-                const int steps = max(ea_ - sa, eb - sb);
-                for (int q = 0; q < steps; q += 2) {    // two entries of each row per step, added in entry order
-                    int c[4];
-                    float4 a[4];
+            for (int k = 0; gq + k * G::kNG < t_n[t]; k += kNR) {
+                RowSet<kNR> R;
+                float4 acc[kNR], xi[kNR];
+                const int steps = row_ranges<kNR, G::kNG>(R, rp, gq + k * G::kNG, t_n[t]);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        c[u] = col[min(sa + q + u, max(ea_ - 1, 0))];
-                        c[2 + u] = col[min(sb + q + u, max(eb - 1, 0))];
+                for (int u = 0; u < kNR; ++u) xi[u] = pick(xv, k0 + k + u);      // self terms: this group loaded them
+                gather_sum<kNR, G::kNG, F>(acc, R, steps, col, xsrc, x_rows, f);
+#pragma unroll
+                for (int u = 0; u < kNR; ++u) {
+                    if (R.on[u]) {
+                        const int64_t row = (int64_t)(t_r0[t] + gq + (k + u) * G::kNG) * F + f;
+                        stg4(out_b + row, axpy4(acc[u], scale2, xi[u]));
+                        if (!up_here)        // no upper adjacency in this dimension: zeros + self term
+                            stg4(out_up + row, axpy4(make_float4(0.f, 0.f, 0.f, 0.f), scale1, xi[u]));
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) a[u] = lds4(xsrc + (size_t)c[u] * F + f);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {      // a skipped slot adds +0: exact
-                        const bool ona = sa + q + u < ea_, onb = sb + q + u < eb;
-                        acca.x += ona ? a[u].x : 0.0f; acca.y += ona ? a[u].y : 0.0f;
-                        acca.z += ona ? a[u].z : 0.0f; acca.w += ona ? a[u].w : 0.0f;
-                        accb.x += onb ? a[2 + u].x : 0.0f; accb.y += onb ? a[2 + u].y : 0.0f;
-                        accb.z += onb ? a[2 + u].z : 0.0f; accb.w += onb ? a[2 + u].w : 0.0f;
-                    }
-                }
-                const int64_t rowa = (int64_t)(t_r0[t] + ra) * F + f, rowb = (int64_t)(t_r0[t] + rb) * F + f;
-                stg4(out_b + rowa, make_float4(acca.x + scale2 * xa.x, acca.y + scale2 * xa.y, acca.z + scale2 * xa.z,
-                                               acca.w + scale2 * xa.w));
-                if (hb)
-                    stg4(out_b + rowb, make_float4(accb.x + scale2 * xb.x, accb.y + scale2 * xb.y,
-                                                   accb.z + scale2 * xb.z, accb.w + scale2 * xb.w));
-                if (!up_here) {      // no upper adjacency in this dimension: zeros + self term
-                    stg4(out_up + rowa, make_float4(0.0f + scale1 * xa.x, 0.0f + scale1 * xa.y, 0.0f + scale1 * xa.z,
-                                                    0.0f + scale1 * xa.w));
-                    if (hb)
-                        stg4(out_up + rowb, make_float4(0.0f + scale1 * xb.x, 0.0f + scale1 * xb.y,
-                                                        0.0f + scale1 * xb.z, 0.0f + scale1 * xb.w));
                 }
             }
         }
@@ -590,6 +668,9 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         }
         __syncthreads();                     // every wave has read its fragments: Y may overwrite the planes
         CWN_STAMP(6);
+        // one row of zeros behind the Y rows (row rows_cap of the region: the planes are 816 B a row, Y
+        // 528 B): a reduce slot past the end of its row reads it for Y1 and for Y2, relu(0 + 0) = 0
+        if (gq == 0) *reinterpret_cast<float4*>(Y + (size_t)rows_cap * G::kYStride + f) = make_float4(0.f, 0.f, 0.f, 0.f);
         // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = x row (lane & 15); Y1 carries the bias
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -617,48 +698,17 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         const gf_p out_up0 = (gf_p)sfld(S_TASK0 + ST_OUT_UP);
         const float scale1 = 1.0f + eps1[0];
         const float* Y2 = Y + (size_t)R1 * G::kYStride;
-        for (int k = 0; gq + k * G::kNG < g_n; k += 2) {      // two rows per lane group in flight
-            const int ra = gq + k * G::kNG, rb = ra + G::kNG;
-            const bool hb = rb < g_n;
-            const float4 xa = pick(xv, k), xb = pick(xv, k + 1);
-            const int sa = rowptr[ra], ea_ = rowptr[ra + 1];
-            const int sb = hb ? rowptr[rb] : 0, eb = hb ? rowptr[rb + 1] : 0;
-            float4 acca = make_float4(0.f, 0.f, 0.f, 0.f), accb = acca;
-            const int steps = max(ea_ - sa, eb - sb);
-            for (int q = 0; q < steps; q += 2) {
-                int cj[4], cc[4];
-                float4 a[4], b[4];
+        for (int k = 0; gq + k * G::kNG < g_n; k += kNR) {
+            RowSet<kNR> R;
+            float4 acc[kNR], xi[kNR];
+            const int steps = row_ranges<kNR, G::kNG>(R, rowptr, gq + k * G::kNG, g_n);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int pa = min(sa + q + u, max(ea_ - 1, 0)), pb = min(sb + q + u, max(eb - 1, 0));
-                    cj[u] = scol[pa]; cc[u] = saux[pa];
-                    cj[2 + u] = scol[pb]; cc[2 + u] = saux[pb];
-                }
+            for (int u = 0; u < kNR; ++u) xi[u] = pick(xv, k + u);
+            gather_relu_sum<kNR, G::kNG, G::kYStride>(acc, R, steps, scol, saux, Y, Y2, rows_cap, rows_cap - R1, f);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    a[u] = lds4(Y + (size_t)cj[u] * G::kYStride + f);
-                    b[u] = lds4(Y2 + (size_t)cc[u] * G::kYStride + f);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const bool ona = sa + q + u < ea_, onb = sb + q + u < eb;
-                    acca.x += ona ? fmaxf(a[u].x + b[u].x, 0.0f) : 0.0f;
-                    acca.y += ona ? fmaxf(a[u].y + b[u].y, 0.0f) : 0.0f;
-                    acca.z += ona ? fmaxf(a[u].z + b[u].z, 0.0f) : 0.0f;
-                    acca.w += ona ? fmaxf(a[u].w + b[u].w, 0.0f) : 0.0f;
-                    accb.x += onb ? fmaxf(a[2 + u].x + b[2 + u].x, 0.0f) : 0.0f;
-                    accb.y += onb ? fmaxf(a[2 + u].y + b[2 + u].y, 0.0f) : 0.0f;
-                    accb.z += onb ? fmaxf(a[2 + u].z + b[2 + u].z, 0.0f) : 0.0f;
-                    accb.w += onb ? fmaxf(a[2 + u].w + b[2 + u].w, 0.0f) : 0.0f;
-                }
-            }
-            stg4(out_up0 + (int64_t)(g_r0 + ra) * F + f,
-                 make_float4(acca.x + scale1 * xa.x, acca.y + scale1 * xa.y, acca.z + scale1 * xa.z,
-                             acca.w + scale1 * xa.w));
-            if (hb)
-                stg4(out_up0 + (int64_t)(g_r0 + rb) * F + f,
-                     make_float4(accb.x + scale1 * xb.x, accb.y + scale1 * xb.y, accb.z + scale1 * xb.z,
-                                 accb.w + scale1 * xb.w));
+            for (int u = 0; u < kNR; ++u)
+                if (R.on[u])
+                    stg4(out_up0 + (int64_t)(g_r0 + gq + (k + u) * G::kNG) * F + f, axpy4(acc[u], scale1, xi[u]));
         }
     }
     CWN_STAMP(8);
