@@ -370,99 +370,160 @@ def main():
             return e0.elapsed_time(e1) * 1e3 / (5 * reps)
 
         b, feats = batches[0], layer_inputs[0]
-        with torch.no_grad():
-            csr._cache.clear()
-            b.prepare(max_dim=2)
-            b.set_xs(feats[1])
-            params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
-            lv = model.convs[1].mp_levels
-            gemms, owner = [], []
-            for d in range(3):
-                sp = lv[d].gemm_specs(params[d])
-                gemms += sp
-                owner += [d] * len(sp)
-            ys = ops.run_gemm(gemms, dev) if gemms else []
-            streams = []
-            for d in range(3):
-                mine = [y for y, o in zip(ys, owner) if o == d]
-                streams += lv[d].streams(params[d], mine or None)
-            for st in streams:
-                st.validate()
-            specs = []
-            for st in streams:
-                s = ops.AggSpec(adj=st.adj, n_dst=st.n_dst, F=st.width, msg_op=st.msg_op,
-                                reduce=_ffi.REDUCE[st.reduce], self_x=st.self_x, eps=st.eps)
-                if st.adj is not None:
-                    s.A, s.ia = st.A, st.adj.col
-                    if st.msg_op != ops.MSG_A:
-                        s.B, s.ib = st.B, st.adj.aux
-                specs.append(s)
-            agg_us = replay_us(lambda: ops.run_aggregate(specs, dev), args.kernel_reps)
-            gemm_us = replay_us(lambda: ops.run_gemm(gemms, dev), args.kernel_reps) if gemms else 0.0
-
-            def rebuild_plans():
+        step_us = dt / args.steps * 1e6
+        alg = layer_algorithmic_bytes(stats[0], H, coboundary=coboundary)
+        if BLOCKED:
+            # ONE kernel per layer: layer_kernel (csrc/cwn_layer.hip).  Launch 0 of a step reads and sorts
+            # the COO entries and stores every item's CSR ("store"), launches 1.. load it back ("load").
+            with torch.no_grad():
+                b.set_xs(feats[1])
+                params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+                dims, plan_, table, _key = model.convs[1]._blocked_args(params, 0)
+                ops.layer_fused(dims, table, _ffi.LAYER_CSR_STORE)
+                load_us = replay_us(lambda: ops.layer_fused(dims, table, _ffi.LAYER_CSR_LOAD), args.kernel_reps)
+                store_us = replay_us(lambda: ops.layer_fused(dims, table, _ffi.LAYER_CSR_STORE), args.kernel_reps)
+            s0_ = stats[0]
+            gemm_rows = (s0_['N0'] + s0_['N1']) + (s0_['N1'] + s0_['N2'])      # Y1 | Y2 rows of both GEMM dimensions
+            flops = 2.0 * gemm_rows * H * H
+            # compulsory bytes: every feature row the launch needs once, the entries once, both outputs once
+            compulsory = (4 * H * (gemm_rows + s0_['N0']) + 24 * (s0_['E_up0'] + s0_['E_up1'])
+                          + 16 * (s0_['B1'] + s0_['B2']) + 2 * 4 * H * s0_['cells'])
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as fh:
+                    tj = json.load(fh)
+                if WL == 'zinc' and tj.get('hidden') == H and str(args.batch) in tj['entries']:
+                    traffic = tj['entries'][str(args.batch)]['traffic_bytes']
+            except (OSError, ValueError, KeyError):
+                traffic = None
+            gbs = alg / (load_us * 1e-6) / 1e9
+            tf = flops / (load_us * 1e-6) / 1e12
+            layer_us = ((L - 1) * load_us + store_us) / L
+            roofline = {
+                'bound': 'hbm',
+                'kernel': f'layer_kernel<{H}, load> (complex-blocked SparseCIN propagate step: message GEMMs on the '
+                          'bf16 matrix pipe into LDS, per-complex CSR, both reductions + self terms out of LDS)',
+                'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                'traffic': traffic,
+                'frac_vs_pmc_traffic': None if traffic is None else round(traffic / (load_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                'algorithmic_bytes_per_launch': alg, 'compulsory_bytes_per_launch': int(compulsory),
+                'avg_launch_us': round(load_us, 3), 'avg_launch_us_store_variant': round(store_us, 3),
+                'launches_per_step': L, 'share_of_step': round(L * layer_us / step_us, 3),
+                'frac_of_measured_achievable_6290': round(gbs / 6290.0, 4),
+                'note': 'algorithmic bytes = SURVEY.md 8(d), gather-counted (a row is counted once per entry that '
+                        'reads it); the kernel reads each row once per workgroup, so its real traffic (`traffic`, PMC) '
+                        'is the compulsory figure plus the packed weights; avg over back-to-back dependent launches '
+                        'replayed from a hipGraph between two HIP events'}
+            eq_peak = MFMA_BF16_PEAK_TF / 6.0
+            roofline_other = {
+                'bound': 'mfma', 'kernel': 'the same launch against the matrix pipe: six v_mfma_f32_16x16x32_bf16 per '
+                                           'fp32-accurate product term (bf16 peak / 6)',
+                'achieved': round(tf, 2), 'peak': round(eq_peak, 1), 'unit': 'TFLOP/s', 'frac': round(tf / eq_peak, 4),
+                'traffic': None, 'algorithmic_flops_per_launch': int(flops),
+                'frac_of_fp32_mfma_peak_157': round(tf / MFMA_F32_PEAK_TF, 4)}
+        else:
+            with torch.no_grad():
                 csr._cache.clear()
                 b.prepare(max_dim=2)
-            plan_us = replay_us(rebuild_plans, max(args.kernel_reps // 4, 4))
-            adjs = list(csr._cache.values())
-        alg = layer_algorithmic_bytes(stats[0], H, coboundary=coboundary)
-        achieved = alg / (agg_us * 1e-6) / 1e9
-        # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same
-        # workload shape); None when no pass exists for this configuration
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as fh:
-                tj = json.load(fh)
-            if WL == 'zinc' and tj.get('hidden') == H and str(args.batch) in tj['entries']:
-                traffic = tj['entries'][str(args.batch)]['traffic_bytes']
-        except (OSError, ValueError, KeyError):
+                b.set_xs(feats[1])
+                params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+                lv = model.convs[1].mp_levels
+                gemms, owner = [], []
+                for d in range(3):
+                    sp = lv[d].gemm_specs(params[d])
+                    gemms += sp
+                    owner += [d] * len(sp)
+                ys = ops.run_gemm(gemms, dev) if gemms else []
+                streams = []
+                for d in range(3):
+                    mine = [y for y, o in zip(ys, owner) if o == d]
+                    streams += lv[d].streams(params[d], mine or None)
+                for st in streams:
+                    st.validate()
+                specs = []
+                for st in streams:
+                    s = ops.AggSpec(adj=st.adj, n_dst=st.n_dst, F=st.width, msg_op=st.msg_op,
+                                    reduce=_ffi.REDUCE[st.reduce], self_x=st.self_x, eps=st.eps)
+                    if st.adj is not None:
+                        s.A, s.ia = st.A, st.adj.col
+                        if st.msg_op != ops.MSG_A:
+                            s.B, s.ib = st.B, st.adj.aux
+                    specs.append(s)
+                agg_us = replay_us(lambda: ops.run_aggregate(specs, dev), args.kernel_reps)
+                gemm_us = replay_us(lambda: ops.run_gemm(gemms, dev), args.kernel_reps) if gemms else 0.0
+
+                def rebuild_plans():
+                    csr._cache.clear()
+                    b.prepare(max_dim=2)
+                plan_us = replay_us(rebuild_plans, max(args.kernel_reps // 4, 4))
+                adjs = list(csr._cache.values())
+            achieved = alg / (agg_us * 1e-6) / 1e9
+            # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same
+            # workload shape); None when no pass exists for this configuration
             traffic = None
-        step_us = dt / args.steps * 1e6
-        r_agg = {'bound': 'hbm', 'kernel': 'aggregate_kernel<4> (fused gather-message-reduce, all dims of a layer)',
-                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                 'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(agg_us, 3),
-                 'launches_per_step': L, 'share_of_step': round(L * agg_us / step_us, 3),
-                 'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4)}
-        # K from the operands (W may be the whole [N, 2F] weight addressed through w_col0)
-        # HBM bytes of the grouped GEMM from the same PMC passes (FETCH_SIZE doubled for 16-B/lane
-        # streams as MI355X_MICROARCH.md prescribes, WRITE_SIZE as is), K <= 128 wide-tile kernel
-        gemm_traffic = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r1_pmc_fetch_write_raw.json')) as fh:
-                raw = json.load(fh).get(str(args.batch), {})
-            if WL == 'zinc' and H == 128:
-                for kname, v in raw.items():
-                    if kname.startswith('gemm_split_kernel') or (gemm_traffic is None and kname.startswith('gemm_kernel<true, false, 128, 4')):
-                        gemm_traffic = int((2 * v['FETCH_SIZE_KB_avg'] + v['WRITE_SIZE_KB_avg']) * 1024)
-        except (OSError, ValueError, KeyError):
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as fh:
+                    tj = json.load(fh)
+                if WL == 'zinc' and tj.get('hidden') == H and str(args.batch) in tj['entries']:
+                    traffic = tj['entries'][str(args.batch)]['traffic_bytes']
+            except (OSError, ValueError, KeyError):
+                traffic = None
+            r_agg = {'bound': 'hbm', 'kernel': 'aggregate_kernel<4> (fused gather-message-reduce, all dims of a layer)',
+                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                     'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(agg_us, 3),
+                     'launches_per_step': L, 'share_of_step': round(L * agg_us / step_us, 3),
+                     'frac_of_measured_achievable_6290': round(achieved / 6290.0, 4)}
+            # K from the operands (W may be the whole [N, 2F] weight addressed through w_col0)
+            # HBM bytes of the grouped GEMM from the same PMC passes (FETCH_SIZE doubled for 16-B/lane
+            # streams as MI355X_MICROARCH.md prescribes, WRITE_SIZE as is), K <= 128 wide-tile kernel
             gemm_traffic = None
-        flops = 2.0 * sum(g.X.size(0) * g.W.size(0) * (g.X.size(1) + (g.X2.size(1) if g.X2 is not None else 0))
-                          for g in gemms)
-        tf = flops / (gemm_us * 1e-6) / 1e12 if gemms else 0.0
-        r_gemm = gemm_roofline(flops=flops, us=gemm_us, split=bool(gemms) and ops.gemm_uses_split(gemms, dev),
-                               io_bytes=sum(4 * (g.X.numel() + g.X.size(0) * g.W.size(0) + g.W.size(0) * g.X.size(1)
-                                                 + (g.W.size(0) if g.bias is not None else 0)) for g in gemms),
-                               narrow=H <= 64, traffic=gemm_traffic)
-        r_gemm.update({'avg_launch_us': round(gemm_us, 3), 'launches_per_step': L if gemms else 0,
-                       'share_of_step': round(L * gemm_us / step_us, 3)})
-        # plan build (cwn_csr_build): key + val (+ aux) int64 in, rowptr + col + perm (+ aux) int32 out
-        plan_bytes = 0
-        for ent in adjs:
-            a = ent[2]          # csr._cache values are (version, weakref, Adjacency)
-            has_aux = a.aux is not None
-            plan_bytes += a.n_entries * (16 + 8 + (12 if has_aux else 0)) + 4 * (a.n_dst + 1)
-        r_plan = {'bound': 'hbm', 'kernel': 'cwn_csr_build (destination-sorted int32 CSR of every adjacency of the batch, once per step)',
-                  'achieved': round(plan_bytes / (plan_us * 1e-6) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                  'frac': round(plan_bytes / (plan_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
-                  'algorithmic_bytes_per_launch': int(plan_bytes), 'avg_launch_us': round(plan_us, 3),
-                  'launches_per_step': 1, 'share_of_step': round(plan_us / step_us, 3)}
-        note = ('avg over back-to-back dependent launches replayed from a hipGraph between two HIP events '
-                '(includes the ~1.5 us inter-kernel boundary; rocprofv3 kernel-only averages are in profiles/, '
-                'where few-us kernels read ~1.5-3 us high); batch 128 is latency-bound and L2/MALL-resident')
-        roofline, roofline_other = ((r_gemm, r_agg) if r_gemm['share_of_step'] >= r_agg['share_of_step']
-                                    else (r_agg, r_gemm if gemms else None))
-        roofline['note'] = note
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'r1_pmc_fetch_write_raw.json')) as fh:
+                    raw = json.load(fh).get(str(args.batch), {})
+                if WL == 'zinc' and H == 128:
+                    for kname, v in raw.items():
+                        if kname.startswith('gemm_split_kernel') or (gemm_traffic is None and kname.startswith('gemm_kernel<true, false, 128, 4')):
+                            gemm_traffic = int((2 * v['FETCH_SIZE_KB_avg'] + v['WRITE_SIZE_KB_avg']) * 1024)
+            except (OSError, ValueError, KeyError):
+                gemm_traffic = None
+            flops = 2.0 * sum(g.X.size(0) * g.W.size(0) * (g.X.size(1) + (g.X2.size(1) if g.X2 is not None else 0))
+                              for g in gemms)
+            tf = flops / (gemm_us * 1e-6) / 1e12 if gemms else 0.0
+            r_gemm = gemm_roofline(flops=flops, us=gemm_us, split=bool(gemms) and ops.gemm_uses_split(gemms, dev),
+                                   io_bytes=sum(4 * (g.X.numel() + g.X.size(0) * g.W.size(0) + g.W.size(0) * g.X.size(1)
+                                                     + (g.W.size(0) if g.bias is not None else 0)) for g in gemms),
+                                   narrow=H <= 64, traffic=gemm_traffic)
+            r_gemm.update({'avg_launch_us': round(gemm_us, 3), 'launches_per_step': L if gemms else 0,
+                           'share_of_step': round(L * gemm_us / step_us, 3)})
+            # plan build (cwn_csr_build): key + val (+ aux) int64 in, rowptr + col + perm (+ aux) int32 out
+            plan_bytes = 0
+            for ent in adjs:
+                a = ent[2]          # csr._cache values are (version, weakref, Adjacency)
+                has_aux = a.aux is not None
+                plan_bytes += a.n_entries * (16 + 8 + (12 if has_aux else 0)) + 4 * (a.n_dst + 1)
+            r_plan = {'bound': 'hbm', 'kernel': 'cwn_csr_build (destination-sorted int32 CSR of every adjacency of the batch, once per step)',
+                      'achieved': round(plan_bytes / (plan_us * 1e-6) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                      'frac': round(plan_bytes / (plan_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
+                      'algorithmic_bytes_per_launch': int(plan_bytes), 'avg_launch_us': round(plan_us, 3),
+                      'launches_per_step': 1, 'share_of_step': round(plan_us / step_us, 3)}
+            note = ('avg over back-to-back dependent launches replayed from a hipGraph between two HIP events '
+                    '(includes the ~1.5 us inter-kernel boundary; rocprofv3 kernel-only averages are in profiles/, '
+                    'where few-us kernels read ~1.5-3 us high); batch 128 is latency-bound and L2/MALL-resident')
+            roofline, roofline_other = ((r_gemm, r_agg) if r_gemm['share_of_step'] >= r_agg['share_of_step']
+                                        else (r_agg, r_gemm if gemms else None))
+            roofline['note'] = note
+
+    # the number a faster step moves: algorithmic bytes of the WHOLE step over the step time
+    roofline_step = None
+    if rank == 0:
+        step_bytes = L * layer_algorithmic_bytes(stats[0], H, coboundary=coboundary)
+        sgbs = step_bytes / (dt / args.steps) / 1e9
+        roofline_step = {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes), 'achieved': round(sgbs, 1),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(sgbs / HBM_PEAK_GBS, 4),
+                         'frac_of_measured_achievable_6290': round(sgbs / 6290.0, 4),
+                         'cells_per_s_at_6290': round(stats[0]['cells'] * L / (step_bytes / 6290e9), 1),
+                         'note': 'SURVEY.md 8(d): gather-counted bytes of all layers of one step / ms_per_step'}
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample -----------------------------
     cpu_baseline = None
@@ -743,6 +804,7 @@ def main():
                        'plan_build_in_step': not BLOCKED, 'layer_kernel': 'complex-blocked (1 launch per layer, COO in, no CSR plan)' if BLOCKED else 'grouped GEMM + CSR aggregation (2 launches per layer + 1 plan build per batch)', 'dense_arithmetic': dense,
                        'parallelism': f'replicas x{world} (no data-path collective)'},
             'roofline': roofline, 'roofline_other': roofline_other, 'roofline_plan_build': r_plan,
+            'roofline_step': roofline_step,
             'cpu_baseline': cpu_baseline,
             'secondary': {'full_forward_cells_per_s': (round(float(full_cells.item()) / dt_full, 1)
                                                        if dt_full == dt_full else None),     # leg skipped: null, not NaN

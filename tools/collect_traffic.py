@@ -2,7 +2,9 @@
 section prescribes: separate rocprofv3 passes for FETCH_SIZE and WRITE_SIZE (with --kernel-trace
 only), counters in KiB, gfx950 FETCH_SIZE doubled for wide coalesced streams, WRITE_SIZE as is.
 Run ON the GPU box from the repo root:   python tools/collect_traffic.py [batch ...]
-Writes profiles/r1_pmc_fetch_write_raw.json and profiles/r1_traffic.json."""
+Writes profiles/r2_pmc_fetch_write_raw.json and profiles/r2_traffic.json (the dominant kernel of the
+propagate scope: layer_kernel<F, 2>, the variant that loads the per-item CSR; the first launch of a
+step is layer_kernel<F, 1>)."""
 import csv
 import glob
 import json
@@ -15,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name: str) -> str:
-    m = re.search(r'(\w+_kernel(?:<[^>]*>)?)', name)
+    m = re.search(r'(\w+_kernel(?:<[^>]*>)?)', name.replace('(anonymous namespace)::', ''))
     return m.group(1) if m else name[:60]
 
 
@@ -43,12 +45,13 @@ def one_pass(counter: str, batch: int, workload: str):
 def main():
     batches = [int(a) for a in sys.argv[1:]] or [128, 8192]
     raw, traffic = {}, {'_how': __doc__.split('Run ON')[0].strip().replace('\n', ' '),
-                        'kernel': 'aggregate_kernel<4>', 'hidden': 128, 'entries': {}}
+                        'kernel': 'layer_kernel<128, 2>', 'hidden': 128, 'entries': {}}
     for b in batches:
         f, w = one_pass('FETCH_SIZE', b, 'zinc'), one_pass('WRITE_SIZE', b, 'zinc')
         raw[str(b)] = {k: {'FETCH_SIZE_KB_avg': round(f[k][0], 1), 'launches': f[k][1],
                            'WRITE_SIZE_KB_avg': round(w.get(k, (0, 0))[0], 1)} for k in f}
-        cands = [n for n in f if n.startswith('aggregate_kernel<4') and n in w]
+        cands = [n for n in f if n.startswith('layer_kernel<128, 2') and n in w] or \
+            [n for n in f if n.startswith('aggregate_kernel<4') and n in w]
         if cands:
             k = max(cands, key=lambda n: f[n][1])      # the layer launches (most frequent variant)
             traffic['kernel'] = k
@@ -58,9 +61,9 @@ def main():
     # profiles/ is what bench.py reads; gpurun_out/ is what travels back from the GPU box
     for d in ('profiles', 'gpurun_out'):
         os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-        with open(os.path.join(ROOT, d, 'r1_pmc_fetch_write_raw.json'), 'w') as fh:
+        with open(os.path.join(ROOT, d, 'r2_pmc_fetch_write_raw.json'), 'w') as fh:
             json.dump(raw, fh, indent=1)
-        with open(os.path.join(ROOT, d, 'r1_traffic.json'), 'w') as fh:
+        with open(os.path.join(ROOT, d, 'r2_traffic.json'), 'w') as fh:
             json.dump(traffic, fh, indent=1)
     print(json.dumps(traffic['entries']))
 
