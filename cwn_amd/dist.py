@@ -51,7 +51,10 @@ class FlatGradBucket:
             raise ValueError('no trainable parameters')
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        # one extra element behind the gradients carries the rank's sample count through the SAME
+        # all-reduce (weighted mean over ranks with unequal shards, still one collective)
+        self._buf = torch.zeros(total + 1, dtype=dt, device=dev)
+        self.flat = self._buf[:total]
         off = 0
         for p in self.params:
             n = p.numel()
@@ -61,16 +64,22 @@ class FlatGradBucket:
     def zero_(self):
         self.flat.zero_()
 
-    def all_reduce_mean(self, group=None, async_op: bool = False):
+    def all_reduce_mean(self, group=None, async_op: bool = False, n_local: Optional[int] = None):
+        """Mean of the per-rank gradients, weighted by `n_local` (the number of samples the rank's loss
+        averaged over; None = equal weights): sum_r n_r g_r / sum_r n_r, the gradient of the mean loss
+        over the GLOBAL batch, which is what the single-process reference computes."""
         if not (dist.is_available() and dist.is_initialized()):
             return None
         world = dist.get_world_size(group)
         if world == 1:
             return None
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        w = float(1 if n_local is None else n_local)
+        self.flat.mul_(w)
+        self._buf[-1] = w
+        work = dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if async_op:
             return work, world
-        self.flat.div_(world)
+        self.flat.div_(self._buf[-1])
         return None
 
     def finish(self, handle):
@@ -78,7 +87,7 @@ class FlatGradBucket:
         if handle is not None:
             work, world = handle
             work.wait()
-            self.flat.div_(world)
+            self.flat.div_(self._buf[-1])
 
 
 def sum_across_ranks(value: float, device=None) -> float:

@@ -162,8 +162,28 @@ class _AggregateMany(torch.autograd.Function):
     def forward(ctx, streams: Tuple[Stream, ...], device, *tensors):
         outs = run_aggregate(_AggregateMany.specs_of(streams, tensors), device)
         ctx.streams, ctx.device = streams, device
-        ctx.save_for_backward(*tensors)
+        ctx.n_in = len(tensors)
+        keep = [o for o, st in zip(outs, streams) if st.reduce == 'max']     # arg-max recovery in backward
+        ctx.save_for_backward(*tensors, *keep)
         return tuple(outs)
+
+    @staticmethod
+    def _max_backward(st: Stream, A: Tensor, out: Tensor, g: Tensor) -> Tensor:
+        """Gradient of out[i] = max_p A[ia[p]] w.r.t. A: g[i, f] goes to ONE entry of the row, the first
+        (in entry order) that attains the maximum -- torch-scatter's arg-max rule, the library behind
+        mp/cell_mp.py:104-105, 439; torch's own amax spreads it over ties, identical without ties.
+        Plain tensor ops: the mode is exercised by no reference test (parity unpinned), not a hot path."""
+        adj = st.adj
+        E = adj.n_entries
+        src = (adj.col if st.ia_mode == 'col' else adj.perm).long()
+        counts = (adj.rowptr[1:] - adj.rowptr[:-1]).long()
+        rowid = torch.repeat_interleave(torch.arange(adj.n_dst, device=g.device), counts, output_size=E)
+        eq = A[src] == out[rowid]
+        c = eq.to(torch.int32).cumsum(0)
+        start = adj.rowptr[:-1].long()[rowid]
+        base = torch.where((start > 0).unsqueeze(1), c[(start - 1).clamp(min=0)], torch.zeros_like(c))
+        first = eq & ((c - base) == 1)
+        return torch.zeros_like(A).index_add_(0, src, g[rowid] * first)
 
     @staticmethod
     def backward(ctx, *gs):
@@ -174,7 +194,8 @@ class _AggregateMany(torch.autograd.Function):
         descriptor (gathered part + up to two self terms) whose result is returned in one slot,
         None in the others -- instead of one `g * (1 + eps)` kernel per self term plus autograd's
         add kernels (48 of the ~100 framework launches of a ZINC training step)."""
-        tensors = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        tensors, max_outs = saved[:ctx.n_in], list(saved[ctx.n_in:])
         grads: List[Optional[Tensor]] = [None] * len(tensors)
         specs, slots = [], []
         ident = lambda t: (t.data_ptr(), tuple(t.shape), tuple(t.stride()))   # saved tensors are re-wrapped
@@ -196,8 +217,13 @@ class _AggregateMany(torch.autograd.Function):
             if adj is None or not (need_A or need_B):
                 continue
             if st.reduce == 'max':
-                raise NotImplementedError("gradient of reduce='max' is not implemented "
-                                          "(parity unpinned in the reference, SURVEY.md §8c)")
+                out_k = max_outs[sum(1 for s_ in ctx.streams[:k] if s_.reduce == 'max')]
+                if op != MSG_A:
+                    raise NotImplementedError("gradient of reduce='max' with a two-operand fused message: "
+                                              'route the message through the generic (hook) path')
+                if need_A:
+                    grads[4 * k] = _AggregateMany._max_backward(st, A, out_k, g)
+                continue
             if st.reduce == 'mean':
                 g = g / adj.counts
             F = g.size(1)
@@ -211,7 +237,10 @@ class _AggregateMany(torch.autograd.Function):
                         s.msg_op, s.B = MSG_A_TIMES_B, B
                         s.ib = t.aux if st.ib_mode == 'aux' else t.perm
                     elif op == MSG_RELU_A_PLUS_B:
-                        s.msg_op, s.B, s.ib, s.self_pre = MSG_A_MASK_RELU, B, t.aux, A
+                        # B per shared cell (lazy up_attr) or per ENTRY (a materialised up_attr): the
+                        # transposed plan's perm is the entry id of each of its positions
+                        s.msg_op, s.B, s.self_pre = MSG_A_MASK_RELU, B, A
+                        s.ib = t.aux if st.ib_mode == 'aux' else t.perm
                     gathered.setdefault(ident(A), len(specs))
                     specs.append(s)
                     slots.append(4 * k)
@@ -221,7 +250,10 @@ class _AggregateMany(torch.autograd.Function):
                         'no gradient for the multiplicative attribute; route it through the '
                         'generic (hook) path if it is trainable')
                 if st.ib_mode == 'perm':
-                    grads[4 * k + 1] = _ffi.gather_rows(g, adj.key)
+                    gB = _ffi.gather_rows(g, adj.key)          # dB[e] = g[dst[e]] ...
+                    if op == MSG_RELU_A_PLUS_B:                # ... where the entry's pre-activation is positive
+                        gB = gB * ((_ffi.gather_rows(A, adj.val) + B) > 0)
+                    grads[4 * k + 1] = gB
                 else:
                     t = adj.t_aux          # keyed on the aux cell: col = destination, aux = source
                     s = AggSpec(adj=t, n_dst=t.n_dst, F=F, A=g, ia=t.col)
@@ -553,7 +585,28 @@ def gemm_uses_split(gemms: Sequence[Gemm], device) -> bool:
     return bool(descs) and len(descs) <= _ffi.MAX_DESCS and _ffi.gemm_would_split(descs)
 
 
-ACCUMULATE_INTO_GRAD = True
+# Off by default: adding dW straight into an existing `.grad` and returning None to autograd skips
+# parameter grad hooks (DDP's reducer), breaks torch.autograd.grad() and gradient checkpointing.
+# cwn_amd.train.TrainStep -- which owns the flat gradient bucket and the all-reduce -- turns it on
+# around its own backward with `accumulate_into_grad()`.
+ACCUMULATE_INTO_GRAD = False
+
+
+class accumulate_into_grad:
+    """Context manager: inside, the weight-gradient kernels add into existing `.grad` buffers directly."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        global ACCUMULATE_INTO_GRAD
+        self.prev, ACCUMULATE_INTO_GRAD = ACCUMULATE_INTO_GRAD, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global ACCUMULATE_INTO_GRAD
+        ACCUMULATE_INTO_GRAD = self.prev
+        return False
 
 
 def _grad_target(p: Optional[Tensor]) -> Optional[Tensor]:
@@ -561,8 +614,7 @@ def _grad_target(p: Optional[Tensor]) -> Optional[Tensor]:
     (leaf tensors only; fp32, row-major, same shape), or None.  With a target the backward
     returns None to autograd for that input: `p.grad += dW` has already happened, without the
     per-parameter add kernel autograd would launch (265 of them per step for the ZINC model).
-    Only when gradients are being accumulated by a plain .backward(): torch.autograd.grad() callers
-    should switch ACCUMULATE_INTO_GRAD off."""
+    Only inside `accumulate_into_grad()` (a plain .backward() into buffers the caller owns)."""
     if not ACCUMULATE_INTO_GRAD or p is None or not p.is_leaf or not p.requires_grad:
         return None
     g = p.grad

@@ -16,6 +16,8 @@ import os
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
+
+from . import ops
 import torch.distributed as dist
 
 from . import _ffi
@@ -137,14 +139,15 @@ class TrainStep:
         pred = self.model(b)
         y = b.y.view(-1,) if self.task_type == 'classification' else b.y.view(pred.shape).to(pred.dtype)
         loss = self.loss_fn(pred, y)
-        loss.backward()
+        with ops.accumulate_into_grad():        # gradients are views into self.bucket: kernels add in place
+            loss.backward()
         self._restore(i)                          # drop the references to the autograd graph
         return loss.detach()
 
     def _eager(self, i: int) -> torch.Tensor:
         loss = self._forward_backward(i)
         if self.world > 1:
-            self.bucket.all_reduce_mean()
+            self.bucket.all_reduce_mean(n_local=self.batches[i].num_complexes)
         self.opt.step()
         return loss
 
@@ -190,6 +193,6 @@ class TrainStep:
         g1, g2, loss = self._graphs[i]
         g1.replay()
         if g2 is not None:
-            self.bucket.all_reduce_mean()         # the ONE collective of the step (RCCL over xGMI)
+            self.bucket.all_reduce_mean(n_local=self.batches[i].num_complexes)   # the ONE collective of the step (RCCL over xGMI)
             g2.replay()
         return loss

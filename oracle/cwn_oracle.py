@@ -126,11 +126,11 @@ def propagate(x: Tensor,
     if boundary_msg_size is None:
         boundary_msg_size = down_msg_size
     if up_out is None:
-        up_out = torch.zeros(n, up_msg_size)
+        up_out = torch.zeros(n, up_msg_size, dtype=x.dtype)
     if down_out is None:
-        down_out = torch.zeros(n, down_msg_size)
+        down_out = torch.zeros(n, down_msg_size, dtype=x.dtype)
     if boundary_out is None:
-        boundary_out = torch.zeros(n, boundary_msg_size)
+        boundary_out = torch.zeros(n, boundary_msg_size, dtype=x.dtype)
     return up_out, down_out, boundary_out
 
 
@@ -407,7 +407,7 @@ def oriented_conv_messages(x: Tensor, up_index, down_index, up_orient, down_orie
 def pool_complex(xs: List[Tensor], batches: List[Tensor], num_complexes: int, max_dim: int,
                  readout: str = 'sum') -> Tensor:
     """mp/nn.py:50-60: per-dimension global add / mean pool into [max_dim+1, B, H]."""
-    out = torch.zeros(max_dim + 1, num_complexes, xs[0].size(-1))
+    out = torch.zeros(max_dim + 1, num_complexes, xs[0].size(-1), dtype=xs[0].dtype)
     for d, x in enumerate(xs):
         out[d] = scatter_rows(x, batches[d], num_complexes, 'add' if readout == 'sum' else 'mean')
     return out

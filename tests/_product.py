@@ -27,3 +27,23 @@ def dummy_batch(names, max_dim=2, device=None) -> ComplexBatch:
 
 def list_names(which: str):
     return [str(n) for n in load('dummy_complexes.npz')[f'lists/{which}']]
+
+
+def gate(got, ref, what: str = '', tol: float = 1e-5) -> float:
+    """The north-star parity gate: max|got - ref| <= tol * max(1, |ref|_inf), with the observed maximum
+    printed into the test log (pytest -s / -rP shows it).  `ref` is the oracle (preferably evaluated in
+    float64) or a reference-generated fixture."""
+    g = got.detach().cpu().double()
+    r = ref.detach().cpu().double()
+    assert g.shape == r.shape, (what, tuple(g.shape), tuple(r.shape))
+    err = float((g - r).abs().max()) if r.numel() else 0.0
+    scale = max(1.0, float(r.abs().max())) if r.numel() else 1.0
+    print(f'[gate] {what}: max|delta| = {err:.3e}  |ref|_inf = {scale:.3g}  bound = {tol * scale:.3e}')
+    assert err <= tol * scale, f'{what}: max|delta| {err:.3e} > {tol * scale:.3e}'
+    return err
+
+
+def to_double(state: dict) -> dict:
+    """A state_dict (or any dict of tensors) with its floating tensors in float64: the oracle then runs
+    in double precision and the gate measures the product's own rounding, not the checker's."""
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in state.items()}

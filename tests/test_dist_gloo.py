@@ -60,10 +60,18 @@ def _worker(rank, world, port, ret):
     bucket.zero_()
     _loss_and_grads(mine, state).backward()
     local_norm = float(bucket.flat.norm())
+    local = bucket.flat.clone()
     bucket.all_reduce_mean()
+    plain = bucket.flat.clone()
+    # the same gradients as a mean WEIGHTED by the shard sizes (unequal shards): still one collective
+    bucket.flat.copy_(local)
+    bucket.all_reduce_mean(n_local=len(mine) + rank)      # + rank: make the weights differ
+    weighted = bucket.flat.clone()
+    bucket.flat.copy_(plain)
     total_cells = sum_across_ranks(float(sum(ob['cochains'][d]['num_cells'] for d in range(3))))
     if rank == 0:
         ret['flat'] = bucket.flat.clone()
+        ret['flat_weighted'] = weighted
         ret['cells'] = total_cells
         ret['local_norm'] = local_norm
     dist.barrier()
@@ -77,12 +85,13 @@ def test_two_rank_shard_and_grad_allreduce():
         ret = m.dict()
         mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
         flat = ret['flat']
+        flat_w = ret['flat_weighted']
         cells = ret['cells']
     # single-process emulation: mean over the two shards of the per-shard gradient
     from cwn_amd.dist import FlatGradBucket, shard
     g = load('sparse_cin_conv.npz')
     names = list_names('mol')
-    ref = None
+    ref, ref_w, wsum = None, None, 0.0
     for r in range(world):
         state = {k: torch.nn.Parameter(v.clone()) if v.is_floating_point() and 'running' not in k else v
                  for k, v in state_dict(g, 'mol_cob_bn/state').items()}
@@ -90,8 +99,12 @@ def test_two_rank_shard_and_grad_allreduce():
         bucket.zero_()
         _loss_and_grads(shard(names, r, world), state).backward()
         ref = bucket.flat.clone() if ref is None else ref + bucket.flat
+        w_r = float(len(shard(names, r, world)) + r)
+        ref_w = w_r * bucket.flat if ref_w is None else ref_w + w_r * bucket.flat
+        wsum += w_r
     ref /= world
     torch.testing.assert_close(flat, ref, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(flat_w, ref_w / wsum, rtol=1e-5, atol=1e-7)
     total = sum(O.batch_complexes([o_complex(n) for n in names], max_dim=2)['cochains'][d]['num_cells']
                 for d in range(3))
     assert cells == total     # the shards cover every cell exactly once

@@ -10,7 +10,7 @@ import torch
 
 from oracle import cwn_oracle as O
 from tests._golden import load, T, dummy_complex as o_complex, params_dict, state_dict
-from tests._product import dummy_complex, dummy_batch, list_names
+from tests._product import dummy_complex, dummy_batch, list_names, gate, to_double
 
 pytestmark = pytest.mark.gpu
 
@@ -486,8 +486,8 @@ def test_embed_sparse_cin_whole_stack_golden(tag):
         with torch.no_grad():
             y, res = model(b, include_partial=True)
         for k, v in res.items():
-            torch.testing.assert_close(cpu(v), T(g[f'{tag}/{mode}/{k}']), rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(cpu(y), T(g[f'{tag}/{mode}/out']), rtol=1e-4, atol=1e-4)
+            gate(v, T(g[f'{tag}/{mode}/{k}']), f'{tag} {mode} {k}')
+        gate(y, T(g[f'{tag}/{mode}/out']), f'{tag} {mode} out')
 
 
 # ------------------------------------------------------------------------------------------------
@@ -567,10 +567,12 @@ def test_sparse_cin_layer_full_size_vs_oracle(zinc128):
         c = b.cochains[d]
         ocx['cochains'].append({k: cpu(c[k]) for k in ('x', 'upper_index', 'lower_index',
                                 'shared_boundaries', 'shared_coboundaries', 'boundary_index', 'y', 'batch')})
-    oouts = O.sparse_cin_conv(state, O.all_cochain_params(ocx, 2, include_down_features=False), True,
+    for c in ocx['cochains']:
+        c['x'] = c['x'].double()
+    oouts = O.sparse_cin_conv(to_double(state), O.all_cochain_params(ocx, 2, include_down_features=False), True,
                               training=True)
-    for o, r in zip(outs, oouts):
-        torch.testing.assert_close(cpu(o), r, rtol=1e-4, atol=1e-4)
+    for d, (o, r) in enumerate(zip(outs, oouts)):
+        gate(o, r, f'ZINC-128 SparseCIN layer (BN train mode) dim {d} vs float64 oracle')
 
 
 # ------------------------------------------------------------------------------------------------
@@ -744,7 +746,7 @@ def test_extra_models_golden_gpu():
         with torch.set_grad_enabled(grad):
             y, res = model(b2, include_partial=True)
         for k, v in res.items():
-            torch.testing.assert_close(cpu(v), T(g[f'reddit/{k}']), rtol=1e-4, atol=1e-4)
+            gate(v, T(g[f'reddit/{k}']), f'SparseCIN fixture {k} (grad={grad})')
     model = OGBEmbedSparseCIN(1, 2, 16, dropout_rate=0.0, max_dim=2, readout='mean', init_reduce='sum',
                               embed_edge=True, use_coboundaries=True, graph_norm='bn')
     model.load_state_dict(state_dict(g, 'molhiv/state'))
@@ -755,7 +757,7 @@ def test_extra_models_golden_gpu():
     with torch.no_grad():
         y, res = model(b, include_partial=True)
     for k, v in res.items():
-        torch.testing.assert_close(cpu(v), T(g[f'molhiv/{k}']), rtol=1e-4, atol=1e-4)
+        gate(v, T(g[f'molhiv/{k}']), f'OGBEmbedSparseCIN fixture {k}')
 
 
 def test_molhiv_like_full_size_vs_oracle():
@@ -769,13 +771,13 @@ def test_molhiv_like_full_size_vs_oracle():
                               init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn').eval()
     state = {k: v.clone() for k, v in model.state_dict().items()}
     b = ComplexBatch.from_complex_list(molhiv_like_complexes(512, seed=3), max_dim=2)
-    ref, rpart = O.sparse_cin_model_forward(state, _oracle_cx(b), 2, readout='mean', embed='ogb')
+    ref, rpart = O.sparse_cin_model_forward(to_double(state), _oracle_cx(b), 2, readout='mean', embed='ogb')
     model = model.to(DEV)
     with torch.no_grad():
         y, res = model(b.to(DEV), include_partial=True)
     for k, v in rpart.items():
-        torch.testing.assert_close(cpu(res[k]), v, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(cpu(y), ref, rtol=1e-4, atol=1e-4)
+        gate(res[k], v, f'molhiv-512 {k} vs float64 oracle')
+    gate(y, ref, 'molhiv-512 prediction vs float64 oracle')
 
 
 def test_reddit_like_full_size_vs_oracle():
@@ -794,7 +796,10 @@ def test_reddit_like_full_size_vs_oracle():
     b = ComplexBatch.from_complex_list(reddit_like_complexes(32, seed=1), max_dim=2)
     st = batch_stats(b)
     assert st['cells'] > 30_000
-    ref, rpart = O.sparse_cin_model_forward(state, _oracle_cx(b), 4, use_coboundaries=False, norm='id',
+    ocx = _oracle_cx(b)
+    for c in ocx['cochains']:
+        c['x'] = c['x'].double()
+    ref, rpart = O.sparse_cin_model_forward(to_double(state), ocx, 4, use_coboundaries=False, norm='id',
                                             jump_mode='cat', embed=None)
     # the propagate outputs of the first layer are integer-valued (all-ones features): exact
     prm = b.to(DEV).get_cochain_params(dim=0, include_down_features=False)
@@ -805,10 +810,8 @@ def test_reddit_like_full_size_vs_oracle():
     with torch.no_grad():
         y, res = model(b, include_partial=True)
     for k, v in rpart.items():
-        scale = max(1.0, float(v.abs().max()))
-        torch.testing.assert_close(cpu(res[k]) / scale, v / scale, rtol=1e-4, atol=1e-5)
-    scale = max(1.0, float(ref.abs().max()))
-    torch.testing.assert_close(cpu(y) / scale, ref / scale, rtol=1e-4, atol=1e-5)
+        gate(res[k], v, f'REDDIT-32 {k} vs float64 oracle')
+    gate(y, ref, 'REDDIT-32 prediction vs float64 oracle')
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1335,19 +1338,17 @@ def test_training_accumulates_into_existing_grads():
 
     bucket = FlatGradBucket(fused.parameters())
     state = {k: v.clone() for k, v in fused.state_dict().items()}
-    backward_once(fused)
-    once = bucket.flat.clone()
-    assert float(once.abs().max()) > 0
-    fused.load_state_dict(state)          # same running statistics / parameters for the second pass
-    backward_once(fused)
+    with ops.accumulate_into_grad():
+        backward_once(fused)
+        once = bucket.flat.clone()
+        assert float(once.abs().max()) > 0
+        fused.load_state_dict(state)          # same running statistics / parameters for the second pass
+        backward_once(fused)
     torch.testing.assert_close(bucket.flat, 2 * once, rtol=1e-5, atol=1e-5 * float(once.abs().max()))
-    # autograd's own accumulation
-    ops.ACCUMULATE_INTO_GRAD = False
-    try:
-        bucket2 = FlatGradBucket(other.parameters())
-        backward_once(other)
-    finally:
-        ops.ACCUMULATE_INTO_GRAD = True
+    # autograd's own accumulation (the default: grad hooks fire, torch.autograd.grad works)
+    assert not ops.ACCUMULATE_INTO_GRAD
+    bucket2 = FlatGradBucket(other.parameters())
+    backward_once(other)
     torch.testing.assert_close(bucket2.flat, once, rtol=1e-4, atol=2e-5 * float(once.abs().max()))
 
 
@@ -1592,3 +1593,129 @@ def test_cin_conv_fused_inference_matches_generic_path(with_bn):
     generic = conv(*params)
     for d, (f, gnr) in enumerate(zip(fused, generic)):
         torch.testing.assert_close(f, gnr.detach(), rtol=1e-4, atol=1e-4, msg=lambda m, d=d: f'dim {d}: {m}')
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 2 end to end at full size: 4-layer hidden-128 EmbedSparseCIN, batch 128, eval forward
+# (the path bench.py times as secondary.full_forward) against the oracle evaluated in float64
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('path', ['blocked+split', 'csr+split', 'csr+exact'])
+def test_config2_eval_forward_full_size_vs_float64_oracle(path):
+    """mp/molec_models.py:90-160 on a ZINC-like batch of 128: every layer output, the pooled vectors and
+    the prediction, gate 1e-5 * max(1, |ref|_inf).  'blocked': the complex-blocked layer kernel;
+    'csr': grouped GEMM + CSR aggregation; 'split' / 'exact': the dense arithmetic of the N = K = 128
+    launches (three-way bf16 split on the matrix pipe, or fp32 MFMA)."""
+    from cwn_amd import layers, ops
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import zinc_like_complexes
+    torch.manual_seed(0)
+    model = EmbedSparseCIN(28, 4, 1, 4, 128, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu',
+                           readout='sum', train_eps=False, final_hidden_multiplier=2, final_readout='sum',
+                           init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn').eval()
+    with torch.no_grad():       # running statistics of a trained model are not (0, 1): make BatchNorm do work
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    b = ComplexBatch.from_complex_list(zinc_like_complexes(128, 0, 6), max_dim=2)
+    ref, rpart = O.sparse_cin_model_forward(to_double(state), _oracle_cx(b), 4)
+    model = model.to(DEV)
+    prev_b, prev_e = layers.BLOCKED_LAYER, ops.set_gemm_exact(path.endswith('exact'))
+    layers.BLOCKED_LAYER = path.startswith('blocked')
+    try:
+        with torch.no_grad():
+            y, res = model(b.to(DEV), include_partial=True)
+        assert (model.convs[0].blocked_reason is None) == path.startswith('blocked'), model.convs[0].blocked_reason
+    finally:
+        layers.BLOCKED_LAYER = prev_b
+        ops.set_gemm_exact(prev_e)
+    for k, v in rpart.items():
+        gate(res[k], v, f'config 2 [{path}] {k}')
+    gate(y, ref, f'config 2 [{path}] prediction')
+
+
+def test_sparse_cin_backward_with_materialised_up_attr():
+    """up_attr as a dense [E, F] tensor (Complex.lazy_attrs = False, or a reference-style
+    CochainMessagePassingParams) runs the fused coboundary message with a per-ENTRY B operand; its
+    backward must mask with THAT entry's pre-activation.  Gradients of x, up_attr and the message
+    Linear against CPU autograd of the reference formulation, with and without prepare()."""
+    from cwn_amd.complex import Complex
+    from cwn_amd.layers import SparseCINConv
+    from cwn_amd.synthetic import zinc_like_batch
+    F = 16
+    for prepared in (False, True):
+        torch.manual_seed(0)
+        conv = SparseCINConv(F, F, F, None, None, None, None, max_dim=2, hidden=F, act_module=torch.nn.ReLU,
+                             layer_dim=F, use_coboundaries=True, graph_norm=torch.nn.Identity).train()
+        state = {k: v.clone() for k, v in conv.state_dict().items()}
+        b = zinc_like_batch(6, seed=4, max_ring=6)
+        g = torch.Generator().manual_seed(1)
+        xs = [torch.randn(b.cochains[d].num_cells, F, generator=g) for d in range(3)]
+        # CPU reference: the oracle's layer with autograd
+        ocx = {'dimension': 2, 'y': None, 'cochains': []}
+        xs_ref = [x.clone().double().requires_grad_(True) for x in xs]
+        for d in range(3):
+            c = b.cochains[d]
+            ocx['cochains'].append(dict({k: c[k] for k in ('upper_index', 'lower_index', 'shared_boundaries',
+                                                           'shared_coboundaries', 'boundary_index', 'y', 'batch')},
+                                        x=xs_ref[d]))
+        pstate = {k: torch.nn.Parameter(v.double()) if v.is_floating_point() else v for k, v in state.items()}
+        oouts = O.sparse_cin_conv(pstate, O.all_cochain_params(ocx, 2, include_down_features=False), True,
+                                  training=True, norm='id')
+        sum((o * (i + 1)).sum() for i, o in enumerate(oouts)).backward()
+        # product: dense attributes
+        prev = Complex.lazy_attrs
+        Complex.lazy_attrs = False
+        try:
+            conv = conv.to(DEV)
+            bd = zinc_like_batch(6, seed=4, max_ring=6, device=DEV)
+            if prepared:
+                bd.prepare(backward=True)
+            xd = [x.clone().to(DEV).requires_grad_(True) for x in xs]
+            bd.set_xs(xd)
+            params = bd.get_all_cochain_params(max_dim=2, include_down_features=False)
+            assert torch.is_tensor(params[0].kwargs['up_attr'])          # dense, one row per entry
+            outs = conv(*params)
+            sum((o * (i + 1)).sum() for i, o in enumerate(outs)).backward()
+        finally:
+            Complex.lazy_attrs = prev
+        for d in range(3):
+            gate(outs[d], oouts[d], f'dense up_attr (prepared={prepared}) out[{d}]')
+            gate(xd[d].grad, xs_ref[d].grad, f'dense up_attr (prepared={prepared}) dL/dx[{d}]', tol=2e-5)
+        for k, p_ in conv.named_parameters():
+            if p_.grad is not None and pstate[k].grad is not None:
+                gate(p_.grad, pstate[k].grad, f'dense up_attr (prepared={prepared}) dL/d{k}', tol=2e-5)
+
+
+@pytest.mark.parametrize('ia_mode', ['col', 'perm'])
+def test_reduce_max_backward_matches_cpu_autograd(ia_mode):
+    """reduce='max' (mp/cell_mp.py:104-105 -> torch_scatter.scatter(reduce='max'), :439): forward
+    against scatter_reduce_('amax'), backward against its CPU autograd on tie-free data, and the
+    arg-max rule on ties (the FIRST entry that attains the maximum takes the gradient)."""
+    from cwn_amd import ops
+    from cwn_amd.csr import Adjacency
+    g = torch.Generator().manual_seed(0)
+    n_src, n_dst, E, F = 40, 25, 300, 12
+    idx = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst - 3, (E,), generator=g)])
+    rows = E if ia_mode == 'perm' else n_src
+    x = torch.randn(rows, F, generator=g)
+    w = torch.randn(n_dst, F, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    msg = xr if ia_mode == 'perm' else xr[idx[0]]
+    ref = torch.zeros(n_dst, F, dtype=torch.float64).scatter_reduce(0, idx[1].unsqueeze(1).expand(-1, F), msg,
+                                                                    'amax', include_self=False)
+    (ref * w.double()).sum().backward()
+    adj = Adjacency.from_index(idx.to(DEV), n_dst, n_src)
+    xd = x.clone().to(DEV).requires_grad_(True)
+    out = ops.aggregate(adj, n_dst, xd, reduce='max', ia_mode=ia_mode)
+    (out * w.to(DEV)).sum().backward()
+    assert torch.equal(cpu(out).double(), ref.detach())
+    gate(xd.grad, xr.grad, f'max backward ({ia_mode})')
+    # ties: two entries of one row carry the same maximal value -> the first one gets the gradient
+    idx2 = torch.tensor([[0, 1, 2], [0, 0, 0]])
+    a = torch.tensor([[5.0], [5.0], [1.0]], device=DEV, requires_grad=True)
+    adj2 = Adjacency.from_index(idx2.to(DEV), 1, 3)
+    ops.aggregate(adj2, 1, a, reduce='max').sum().backward()
+    assert cpu(a.grad).flatten().tolist() == [1.0, 0.0, 0.0]
