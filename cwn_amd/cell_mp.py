@@ -338,6 +338,38 @@ class CochainMessagePassing(torch.nn.Module):
                     outs[a] = o
         return self.update(outs['up'], outs['down'], outs['boundary'], **upd_kwargs)
 
+    # ---- co-boundary stream (engine extension) ------------------------------------
+    def propagate_coboundary(self, boundary_index_up: Tensor, coboundary_attr: Tensor, n_cells: int,
+                             reduce: str = 'add') -> Tensor:
+        """out[i] = reduce over the cofaces c of cell i of message_coboundary(coboundary_attr[c]).
+
+        The aggregation the reference leaves as a TODO (mp/cell_mp.py:44 "Add support for co-boundary
+        adjacencies", README.md:178): cells of dimension d receive from the (d+1)-cells they bound.
+        `boundary_index_up` is the NEXT dimension's `boundary_index` exactly as data/complex.py
+        delivers it ([2, B], row 0 = cell of this dimension, row 1 = its coface); the stream runs
+        over the transposed plan of that adjacency -- the structure the backward pass of the
+        boundary stream already uses -- so nothing new is built for a batch that trains.
+        It is the ADJOINT of the boundary stream of dimension d+1: <cob(v), w> = <v, bnd(w)>.
+        No reference oracle exists: parity unpinned (property-tested: adjointness, exact integers)."""
+        if boundary_index_up.dtype != torch.long or boundary_index_up.dim() != 2 or boundary_index_up.size(0) != 2:
+            raise AssertionError('boundary_index_up must be a [2, B] LongTensor')
+        if coboundary_attr.dim() != 2:
+            raise ValueError('coboundary_attr must be [cells of dimension d+1, features]')
+        n_up = int(coboundary_attr.size(0))
+        adj = cached_adjacency(boundary_index_up, n_up, int(n_cells))      # keyed on the coface (row 1)
+        t = adj.t_src                                                       # keyed on this dimension's cell
+        msg = self.message_coboundary(coboundary_attr) if type(self).message_coboundary is not \
+            CochainMessagePassing.message_coboundary else None
+        if msg is None:       # identity message: fused gather-reduce through the transposed plan
+            return ops.aggregate(t, int(n_cells), coboundary_attr, reduce=reduce)
+        if msg.size(0) != n_up:
+            raise ValueError('message_coboundary must return one row per (d+1)-cell')
+        return ops.aggregate(t, int(n_cells), msg, reduce=reduce)
+
+    def message_coboundary(self, coboundary_x_j: Tensor) -> Tensor:
+        """Per COFACE (not per entry: the message of a coface is the same for every cell it sends to)."""
+        return coboundary_x_j
+
     # ---- overridable hooks (same names / signatures as mp/cell_mp.py:394-524) -------------------
     def message_up(self, up_x_j: Tensor, up_attr: Tensor) -> Tensor:
         return up_x_j

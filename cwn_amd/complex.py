@@ -406,6 +406,13 @@ class Complex(object):
                                              down_attr=lower_features,
                                              boundary_attr=boundary_features,
                                              boundary_index=boundary_index)
+        # engine extension: what the co-boundary stream of this dimension reads -- the
+        # next dimension's boundary_index (row 0 = a cell of THIS dimension, row 1 = its coface) and the
+        # cofaces' features.  Plain attributes: the reference's kwargs are left as they are.
+        params.coboundary_index = params.coboundary_attr = None
+        if (dim + 1) in self.cochains and self.cochains[dim + 1].boundary_index is not None:
+            params.coboundary_index = self.cochains[dim + 1].boundary_index
+            params.coboundary_attr = self.cochains[dim + 1].x
         params.num_cells = cells.num_cells   # engine extension: sizes without a device sync
         params.block_plan = self.block_plan()  # engine extension: the batch's item table (or None)
         return params

@@ -779,20 +779,34 @@ class SparseCINConv(torch.nn.Module):
 # CIN++ (upper + lower + boundary)
 # ------------------------------------------------------------------------------------------------
 class CINppCochainConv(SparseCINCochainConv):
-    """mp/layers.py:216-260.  Quirk kept: forward does not pass `down_attr` (:244-247), and the
-    molecular CIN++ models ask for include_down_features=False, so the lower stream is zeros there
-    (SURVEY.md §8a)."""
+    """mp/layers.py:216-260.  Quirk kept by default: forward does not pass `down_attr` (:244-247), and
+    the molecular CIN++ models ask for include_down_features=False, so the lower stream is zeros
+    there.  Two explicit switches do it properly (no reference oracle
+    for either: parity unpinned, property-tested):
+      feed_down_attr=True       `down_attr` reaches message_down -- the lower-adjacency stream CIN++
+                                describes, msg_down_nn((x_j, shared-boundary features));
+      coboundary_stream=True    a FOURTH stream: the sum over the cofaces of a cell (the co-boundary
+                                aggregation mp/cell_mp.py:44 leaves as a TODO), with its own eps and
+                                update network, concatenated before combine_nn (which then takes
+                                4 * hidden inputs).  Needs params from Complex.get_cochain_params
+                                (they carry `coboundary_index` / `coboundary_attr`)."""
 
     def __init__(self, dim: int, up_msg_size: int, down_msg_size: int, boundary_msg_size: int,
                  msg_up_nn: Callable[..., Any], msg_boundaries_nn: Callable[..., Any],
                  msg_down_nn: Callable[..., Any], update_up_nn: Callable[..., Any],
                  update_boundaries_nn: Callable[..., Any], update_down_nn: Callable[..., Any],
-                 combine_nn: Callable[..., Any], eps: float = 0, train_eps: bool = False):
+                 combine_nn: Callable[..., Any], eps: float = 0, train_eps: bool = False,
+                 feed_down_attr: bool = False, update_coboundaries_nn: Optional[Callable[..., Any]] = None):
         super().__init__(dim, up_msg_size, down_msg_size, boundary_msg_size, msg_up_nn,
                          msg_boundaries_nn, update_up_nn, update_boundaries_nn, combine_nn, eps,
                          train_eps)
+        # the reference inherits use_down_msg=False from SparseCINCochainConv (mp/layers.py:167-168): the
+        # lower stream is OFF unless the caller asks for the proper form
+        self.use_down_msg = bool(feed_down_attr)
         self.msg_down_nn = msg_down_nn
         self.update_down_nn = update_down_nn
+        self.feed_down_attr = feed_down_attr
+        self.update_coboundaries_nn = update_coboundaries_nn       # not None = the fourth stream is on
         if train_eps:
             self.eps3 = torch.nn.Parameter(torch.Tensor([eps]))
         else:
@@ -800,6 +814,12 @@ class CINppCochainConv(SparseCINCochainConv):
         reset(self.msg_down_nn)
         reset(self.update_down_nn)
         self.eps3.data.fill_(self.initial_eps)
+        if update_coboundaries_nn is not None:
+            if train_eps:
+                self.eps4 = torch.nn.Parameter(torch.Tensor([eps]))
+            else:
+                self.register_buffer('eps4', torch.Tensor([eps]))
+            reset(self.update_coboundaries_nn)
 
     def message_down(self, down_x_j: Tensor, down_attr: Tensor) -> Tensor:
         return self.msg_down_nn((down_x_j, down_attr))
@@ -811,22 +831,30 @@ class CINppCochainConv(SparseCINCochainConv):
         return None
 
     def forward(self, cochain: CochainMessagePassingParams):
-        out_up, out_down, out_boundaries = self.propagate(
-            cochain.up_index, cochain.down_index, cochain.boundary_index, x=cochain.x,
-            up_attr=cochain.kwargs['up_attr'], boundary_attr=cochain.kwargs['boundary_attr'])
+        kw = dict(x=cochain.x, up_attr=cochain.kwargs['up_attr'], boundary_attr=cochain.kwargs['boundary_attr'])
+        down_index = cochain.down_index
+        if self.feed_down_attr:
+            kw['down_attr'] = cochain.kwargs.get('down_attr')
+        out_up, out_down, out_boundaries = self.propagate(cochain.up_index, down_index, cochain.boundary_index, **kw)
         out_up = out_up + (1 + self.eps1) * cochain.x
         out_down = out_down + (1 + self.eps2) * cochain.x
         out_boundaries = out_boundaries + (1 + self.eps3) * cochain.x
-        out_up = self.update_up_nn(out_up)
-        out_down = self.update_down_nn(out_down)
-        out_boundaries = self.update_boundaries_nn(out_boundaries)
-        return self.combine_nn(torch.cat([out_up, out_down, out_boundaries], dim=-1))
+        parts = [self.update_up_nn(out_up), self.update_down_nn(out_down), self.update_boundaries_nn(out_boundaries)]
+        if self.update_coboundaries_nn is not None:
+            cob_index = getattr(cochain, 'coboundary_index', None)
+            cob_attr = getattr(cochain, 'coboundary_attr', None)
+            if cob_index is not None and cob_attr is not None:
+                out_cob = self.propagate_coboundary(cob_index, cob_attr, cochain.x.size(0))
+            else:
+                out_cob = ops.zeros_rows(cochain.x.size(0), cochain.x.size(1), cochain.x.device)
+            parts.append(self.update_coboundaries_nn(out_cob + (1 + self.eps4) * cochain.x))
+        return self.combine_nn(torch.cat(parts, dim=-1))
 
     forward_unfused = forward
 
 
 class CINppConv(SparseCINConv):
-    """mp/layers.py:344-427."""
+    """mp/layers.py:344-427; `feed_down_attr` / `coboundary_stream`: see CINppCochainConv."""
 
     def __init__(self, up_msg_size: int, down_msg_size: int, boundary_msg_size: Optional[int],
                  passed_msg_up_nn: Optional[Callable], passed_msg_down_nn: Optional[Callable],
@@ -834,12 +862,13 @@ class CINppConv(SparseCINConv):
                  passed_update_up_nn: Optional[Callable], passed_update_down_nn: Optional[Callable],
                  passed_update_boundaries_nn: Optional[Callable], eps: float = 0.,
                  train_eps: bool = False, max_dim: int = 2, graph_norm=BN, use_coboundaries=False,
-                 **kwargs):
+                 feed_down_attr: bool = False, coboundary_stream: bool = False, **kwargs):
         super().__init__(up_msg_size, down_msg_size, boundary_msg_size, passed_msg_up_nn,
                          passed_msg_boundaries_nn, passed_update_up_nn, passed_update_boundaries_nn,
                          eps, train_eps, max_dim, graph_norm, use_coboundaries, **kwargs)
         self.mp_levels = torch.nn.ModuleList()
         ld, hid, act = kwargs['layer_dim'], kwargs['hidden'], kwargs['act_module']
+        n_streams = 4 if coboundary_stream else 3
         for dim in range(max_dim + 1):
             def msg_net(passed):
                 if passed is not None:
@@ -852,8 +881,9 @@ class CINppConv(SparseCINConv):
                 update_up_nn=passed_update_up_nn or _update_mlp(ld, hid, graph_norm, act),
                 update_down_nn=passed_update_down_nn or _update_mlp(ld, hid, graph_norm, act),
                 update_boundaries_nn=passed_update_boundaries_nn or _update_mlp(ld, hid, graph_norm, act),
-                combine_nn=Sequential(Linear(hid * 3, hid), graph_norm(hid), act()),
-                eps=eps, train_eps=train_eps))
+                combine_nn=Sequential(Linear(hid * n_streams, hid), graph_norm(hid), act()),
+                eps=eps, train_eps=train_eps, feed_down_attr=feed_down_attr,
+                update_coboundaries_nn=_update_mlp(ld, hid, graph_norm, act) if coboundary_stream else None))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1719,3 +1719,76 @@ def test_reduce_max_backward_matches_cpu_autograd(ia_mode):
     adj2 = Adjacency.from_index(idx2.to(DEV), 1, 3)
     ops.aggregate(adj2, 1, a, reduce='max').sum().backward()
     assert cpu(a.grad).flatten().tolist() == [1.0, 0.0, 0.0]
+
+
+# ------------------------------------------------------------------------------------------------
+# the co-boundary stream and CIN++ with a real lower stream (engine extensions; the
+# reference has neither -- mp/cell_mp.py:44 TODO, mp/layers.py:244-247 -- so PARITY IS UNPINNED:
+# property tests only)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['house', 'bridged', 'molecular', 'filled_square'])
+def test_coboundary_stream_exact_on_integers_and_adjoint_to_the_boundary_stream(name):
+    from cwn_amd.cell_mp import CochainMessagePassing
+    cx = dummy_complex(name, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    F = 8
+    for d in range(cx.dimension):
+        c, up = cx.cochains[d], cx.cochains[d + 1]
+        if up.boundary_index is None:
+            continue
+        n, n_up = c.num_cells, up.num_cells
+        v = torch.randint(-4, 5, (n_up, F), generator=g).float().to(DEV)      # on the cofaces
+        mp_ = CochainMessagePassing(F, F)
+        out = mp_.propagate_coboundary(up.boundary_index, v, n)
+        # direct restatement: every (boundary cell, coface) pair of boundary_index sends v[coface] to the cell
+        bi = cpu(up.boundary_index)
+        want = torch.zeros(n, F).index_add_(0, bi[0], cpu(v)[bi[1]])
+        assert torch.equal(cpu(out), want), (name, d)
+        # adjoint of the boundary stream of dimension d+1:  <cob(v), w> == <v, bnd(w)>
+        w = torch.randint(-4, 5, (n, F), generator=g).float().to(DEV)         # on this dimension's cells
+        _, _, bnd = mp_.propagate(None, None, up.boundary_index, x=v, boundary_attr=w)
+        assert float((out * w).sum()) == float((v * bnd).sum())
+        # differentiable: d/dv <cob(v), w> = bnd(w)
+        vv = v.clone().requires_grad_(True)
+        (mp_.propagate_coboundary(up.boundary_index, vv, n) * w).sum().backward()
+        assert torch.equal(vv.grad, bnd)
+
+
+def test_cinpp_with_a_real_lower_stream_and_coboundary_stream():
+    """feed_down_attr=True: the lower stream equals the oracle's propagate with down_attr and the
+    layer's own msg_down_nn; coboundary_stream=True: a fourth stream, zero on the top dimension,
+    equal to the transposed boundary aggregation elsewhere; the default layer keeps the quirk."""
+    from cwn_amd.layers import CINppConv
+    torch.manual_seed(0)
+    F = 8
+    b = dummy_batch(list_names('mol'), max_dim=2, device=DEV)
+    g = torch.Generator().manual_seed(4)
+    for d in range(3):
+        b.cochains[d].x = torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV)
+    conv = CINppConv(F, F, F, None, None, None, None, None, None, max_dim=2, hidden=F, act_module=torch.nn.ReLU,
+                     layer_dim=F, use_coboundaries=True, feed_down_attr=True, coboundary_stream=True).to(DEV).eval()
+    assert conv.mp_levels[1].use_down_msg and conv.mp_levels[1].combine_nn[0].in_features == 4 * F
+    params = b.get_all_cochain_params(max_dim=2, include_down_features=True)
+    with torch.no_grad():
+        outs = conv(*params)
+        assert all(torch.isfinite(o).all() for o in outs)
+        lvl, prm = conv.mp_levels[1], params[1]
+        _, down, _ = lvl.propagate(prm.up_index, prm.down_index, prm.boundary_index, x=prm.x,
+                                   up_attr=prm.kwargs['up_attr'], down_attr=prm.kwargs['down_attr'],
+                                   boundary_attr=prm.kwargs['boundary_attr'])
+    W, bias = cpu(lvl.msg_down_nn[1].weight).double(), cpu(lvl.msg_down_nn[1].bias).double()
+    x = cpu(prm.x).double()
+    down_attr = cpu(b.cochains[0].x).double()[cpu(b.cochains[1].shared_boundaries)]
+    _, odown, _ = O.propagate(x, None, cpu(prm.down_index), None, down_attr=down_attr,
+                              message_down=lambda xj, a: torch.relu(torch.cat([xj, a], -1) @ W.t() + bias),
+                              up_msg_size=F, down_msg_size=F)
+    assert down.abs().max() > 0
+    gate(down, odown, 'CIN++ lower stream with down_attr vs the oracle propagate (float64)')
+    # the fourth stream of dimension 0: sum over incident edges of the edge features
+    with torch.no_grad():
+        cob0 = conv.mp_levels[0].propagate_coboundary(params[0].coboundary_index, params[0].coboundary_attr,
+                                                      params[0].x.size(0))
+    bi = cpu(b.cochains[1].boundary_index)
+    want = torch.zeros(b.cochains[0].num_cells, F, dtype=torch.float64).index_add_(0, bi[0], cpu(b.cochains[1].x).double()[bi[1]])
+    gate(cob0, want, 'co-boundary stream of the vertices')
+    assert params[2].coboundary_index is None        # nothing above the top dimension
