@@ -810,3 +810,62 @@ def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tens
     _ffi.check(_ffi.lib().cwn_layer_fused_f32(arr, len(dims), F, plan, int(csr_mode), _err_flag(dev).data_ptr(),
                                                _ffi.stream_ptr(dev)), 'cwn_layer_fused_f32')
     return outs
+
+
+class LayerLaunch:
+    """A prepared cwn_layer_fused_f32 call for one (layer, batch): the descriptor array with everything
+    that does not change between calls filled in once (indices, packed weights, eps, sizes) and the
+    cwn_layer_plan of the batch's item table.  `run(xs, csr_mode)` fills in the feature and output
+    pointers and launches: ~10 us of host time instead of ~60."""
+
+    def __init__(self, dims: Sequence[LayerDim], table):
+        self.table = table
+        self.n = len(dims)
+        self.F = int(dims[0].x.size(1))
+        self.arr = (_ffi.LayerDim * self.n)()
+        self.keep = []
+        self.rows = []
+        for d, D in enumerate(dims):
+            up, sh, bi = D.up_index, D.up_shared, D.b_index
+            for t, name in ((up, 'up_index'), (sh, 'up_shared'), (bi, 'b_index')):
+                if t is not None and (t.dtype != torch.long or not t.is_cuda or not t.is_contiguous()):
+                    raise TypeError(f'{name} must be a contiguous int64 GPU tensor')
+            w, b = D.msg_w_packed, _f32c(D.msg_bias, 'msg_bias')
+            e1, e2 = _f32c(D.eps1, 'eps1'), _f32c(D.eps2, 'eps2')
+            self.keep += [up, sh, bi, w, b, e1, e2]
+            e_up = 0 if up is None else int(up.size(1))
+            self.arr[d] = _ffi.LayerDim(up_index=_ffi.ptr(up) if e_up else None, up_shared=_ffi.ptr(sh) if e_up else None,
+                                        b_index=_ffi.ptr(bi) if bi is not None and bi.size(1) else None,
+                                        msg_w_packed=_ffi.ptr(w), msg_bias=_ffi.ptr(b), eps1=_ffi.ptr(e1),
+                                        eps2=_ffi.ptr(e2), n_cells=int(D.x.size(0)), e_up=e_up,
+                                        n_b=0 if bi is None else int(bi.size(1)))
+            self.rows.append(int(D.x.size(0)))
+        self.total_rows = sum(self.rows)
+        self.dev = dims[0].x.device
+        self._plans = {}
+        from .csr import _err_flag
+        self.err = _err_flag(self.dev)
+        self.fn = _ffi.lib().cwn_layer_fused_f32
+
+    def run(self, xs: Sequence[Tensor], csr_mode: int = 0) -> List[Tensor]:
+        F = self.F
+        buf = torch.empty(2 * self.total_rows, F, dtype=torch.float32, device=self.dev)   # all six outputs
+        outs, off = [], 0
+        for d in range(self.n):
+            x = xs[d]
+            if not x.is_contiguous():
+                x = x.contiguous()
+            if x.size(0) != self.rows[d]:
+                raise ValueError('feature rows do not match the batch this launch was prepared for')
+            r = self.rows[d]
+            out_up, out_b = buf[off:off + r], buf[off + r:off + 2 * r]
+            off += 2 * r
+            a = self.arr[d]
+            a.x, a.out_up, a.out_b = x.data_ptr(), out_up.data_ptr(), out_b.data_ptr()
+            outs += [out_up, out_b]
+        plan = self._plans.get(csr_mode != 0)
+        if plan is None:
+            plan = self._plans[csr_mode != 0] = self.table.c_plan(with_cache=csr_mode != 0)
+        _ffi.check(self.fn(self.arr, self.n, F, plan, int(csr_mode), self.err.data_ptr(), _ffi.stream_ptr(self.dev)),
+                   'cwn_layer_fused_f32')
+        return outs

@@ -1,0 +1,126 @@
+"""One captured hipGraph for batches of DIFFERENT shapes (propagate scope of a stack of SparseCIN layers).
+
+A hipGraph bakes pointers, grid sizes and kernel arguments in.  The complex-blocked layer kernel
+(csrc/cwn_layer.hip) needs none of a batch's sizes in its arguments: which cells and entries a
+workgroup touches is written in the item table, and the table lives in device memory.  So the graph
+is captured ONCE over capacity-sized buffers -- features [cap_d, F], indices [2, cap] with the second
+row at a fixed offset, an item table with a fixed region per set -- and a new batch is served by
+copying its tensors and its table into those buffers and replaying.  Records past the batch's own are
+empty (flags 0, no task): their workgroups leave at once.  Real ZINC training
+(exp/train_utils.py:35: every batch has its own cell and entry counts) replays instead of launching
+eagerly; a handful of capacity buckets covers a dataset.
+"""
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _ffi, ops
+from .blockplan import CSR_SLOT_BYTES, ITEM_INTS, ItemTable, gemm_rows_cap
+from .complex import ComplexBatch
+
+CAPTURE_MODE = 'thread_local'
+
+
+class StaticPropagate:
+    """propagate scope of `convs` (SparseCINConv modules with the coboundary message; no autograd) over
+    static buffers.  caps: cells per dimension, upper entries per dimension (dims 0, 1), boundary entries
+    (dims 1, 2), items per set (sets of dims 0 and 1)."""
+
+    def __init__(self, convs: Sequence[torch.nn.Module], F: int, cap_cells: Sequence[int], cap_up: Sequence[int],
+                 cap_b: Sequence[int], cap_items: Sequence[int], device):
+        self.convs, self.F, self.dev = list(convs), F, torch.device(device)
+        self.cap_cells, self.cap_up, self.cap_b, self.cap_items = list(cap_cells), list(cap_up), list(cap_b), list(cap_items)
+        dev = self.dev
+        L = len(self.convs)
+        # inputs of every layer (the propagate scope takes each layer's own input features)
+        self.x = [[torch.zeros(n, F, device=dev) for n in self.cap_cells] for _ in range(L)]
+        self.up_index = [torch.zeros(2, max(e, 1), dtype=torch.long, device=dev) for e in self.cap_up]
+        self.up_shared = [torch.zeros(max(e, 1), dtype=torch.long, device=dev) for e in self.cap_up]
+        self.b_index = [None] + [torch.zeros(2, max(e, 1), dtype=torch.long, device=dev) for e in self.cap_b]
+        n_items = sum(self.cap_items)
+        self.items = torch.zeros(n_items, ITEM_INTS, dtype=torch.int32, device=dev)
+        self.set_start = [0, self.cap_items[0]]
+        cap = gemm_rows_cap(F)
+        self.table = ItemTable(np.zeros((n_items, ITEM_INTS), dtype=np.int32), self.set_start, cap, cap,
+                               list(self.cap_cells), list(self.cap_up) + [0], [0] + list(self.cap_b), dev)
+        self.table.items = self.items          # the launch reads THIS buffer; `load` rewrites it
+        self.launches: List[ops.LayerLaunch] = []
+        for l, conv in enumerate(self.convs):
+            dims = []
+            for d in range(3):
+                lvl = conv.mp_levels[d]
+                D = ops.LayerDim(x=self.x[l][d], eps1=lvl.eps1, eps2=lvl.eps2)
+                if d < 2:
+                    lin = lvl.msg_up_nn[1]
+                    D.up_index, D.up_shared = self.up_index[d], self.up_shared[d]
+                    D.msg_w_packed, D.msg_bias = ops.pack_layer_weight(lin.weight), lin.bias
+                if d > 0:
+                    D.b_index = self.b_index[d]
+                dims.append(D)
+            self.launches.append(ops.LayerLaunch(dims, self.table))
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.outs: Optional[List[List[torch.Tensor]]] = None
+        self.n_cells = [0, 0, 0]
+
+    # ---- a batch into the static buffers ------------------------------------------------------------
+    def load(self, batch: ComplexBatch, feats: Sequence[Sequence[torch.Tensor]]) -> None:
+        """Copy `batch`'s indices, its item table and the per-layer input features (feats[l][d]) into the
+        static buffers.  Raises when the batch exceeds a capacity (pick a larger bucket)."""
+        plan = batch.block_plan()
+        table = plan.items(self.F, [True, True, False]) if plan is not None else None
+        if table is None:
+            raise ValueError('the batch has no item table for this feature width (hub complexes?)')
+        cnt = [table.set_start[1], table.n_items - table.set_start[1]]
+        if any(c > cap for c, cap in zip(cnt, self.cap_items)):
+            raise ValueError(f'items per set {cnt} exceed the capacity {self.cap_items}')
+        host = torch.zeros(sum(self.cap_items), ITEM_INTS, dtype=torch.int32)
+        src = table.items.cpu()
+        host[:cnt[0]] = src[:cnt[0]]
+        host[self.cap_items[0]:self.cap_items[0] + cnt[1]] = src[cnt[0]:]
+        self.items.copy_(host, non_blocking=True)
+        for d in range(3):
+            c = batch.cochains[d]
+            n = c.num_cells
+            if n > self.cap_cells[d]:
+                raise ValueError(f'{n} cells of dimension {d} exceed the capacity {self.cap_cells[d]}')
+            self.n_cells[d] = n
+            for l in range(len(self.convs)):
+                self.x[l][d][:n].copy_(feats[l][d])
+            if d < 2:
+                e = c.upper_index.size(1)
+                if e > self.cap_up[d]:
+                    raise ValueError(f'{e} upper entries of dimension {d} exceed the capacity {self.cap_up[d]}')
+                self.up_index[d][:, :e].copy_(c.upper_index)          # row 1 stays at offset cap: [2, cap] layout
+                self.up_shared[d][:e].copy_(c.shared_coboundaries)
+            if d > 0:
+                e = c.boundary_index.size(1)
+                if e > self.cap_b[d - 1]:
+                    raise ValueError(f'{e} boundary entries of dimension {d} exceed the capacity {self.cap_b[d - 1]}')
+                self.b_index[d][:, :e].copy_(c.boundary_index)
+        self.table.csr_key = None
+
+    # ---- run ----------------------------------------------------------------------------------------
+    def _run(self) -> List[List[torch.Tensor]]:
+        outs = []
+        for l, launch in enumerate(self.launches):
+            mode = _ffi.LAYER_CSR_STORE if l == 0 else _ffi.LAYER_CSR_LOAD      # the layers share the indices
+            outs.append(launch.run(self.x[l], mode))
+        return outs
+
+    def replay(self) -> List[List[torch.Tensor]]:
+        """[layer][out_up_0, out_b_0, out_up_1, ...] restricted to the loaded batch's cells.  The first
+        call captures the graph; every later call (any batch that fits) replays it."""
+        with torch.no_grad():
+            if self.graph is None:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._run()                       # warm-up outside the capture
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
+                    self.outs = self._run()
+            self.graph.replay()
+        return [[o[:self.n_cells[i // 2]] for i, o in enumerate(lo)] for lo in self.outs]

@@ -255,3 +255,41 @@ def test_blocked_layer_falls_back_when_a_complex_exceeds_one_workgroup():
     for d in range(3):
         _gate(outs[2 * d], ref[d][0], f'fallback out_up[{d}]')
         _gate(outs[2 * d + 1], ref[d][1], f'fallback out_b[{d}]')
+
+
+def test_one_captured_graph_serves_batches_of_different_shapes():
+    """cwn_amd/static_graph.py: the propagate scope of a 3-layer stack captured ONCE over capacity-sized
+    buffers, replayed for batches of 100, 128, 77 and 5 complexes (different cell, entry and item counts)
+    -- every output against the float64 oracle, and bit-identical to the eager per-batch launch."""
+    from cwn_amd import csr
+    from cwn_amd.static_graph import StaticPropagate
+    F, L = 128, 3
+    convs = [_conv(F, seed=30 + l, eps=0.1 * l) for l in range(L)]
+    batches = [_batch('zinc', n, F, seed=40 + i) for i, n in enumerate((100, 128, 77, 5))]
+    g = torch.Generator().manual_seed(5)
+    feats = [[[torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV) for d in range(3)] for _ in range(L)]
+             for b in batches]
+    from cwn_amd.synthetic import batch_stats
+    st = [batch_stats(b) for b in batches]
+    sp = StaticPropagate(convs, F, cap_cells=[max(s[f'N{d}'] for s in st) + 7 for d in range(3)],
+                         cap_up=[max(s[f'E_up{d}'] for s in st) + 3 for d in range(2)],
+                         cap_b=[max(s[f'B{d}'] for s in st) + 5 for d in (1, 2)], cap_items=[130, 131], device=DEV)
+    graphs_seen = set()
+    for order in ((0, 1, 2, 3), (3, 1)):
+        for i in order:
+            b = batches[i]
+            sp.load(b, feats[i])
+            outs = sp.replay()
+            graphs_seen.add(id(sp.graph))
+            for l in range(L):
+                b.set_xs(feats[i][l])
+                ref = _oracle_scope(convs[l], b)
+                eager = _run(convs[l], b, blocked=True)
+                for d in range(3):
+                    _gate(outs[l][2 * d], ref[d][0], f'static graph batch {i} layer {l} out_up[{d}]')
+                    _gate(outs[l][2 * d + 1], ref[d][1], f'static graph batch {i} layer {l} out_b[{d}]')
+                    assert torch.equal(outs[l][2 * d], eager[2 * d]) and torch.equal(outs[l][2 * d + 1], eager[2 * d + 1])
+    csr.check_errors(DEV)
+    assert len(graphs_seen) == 1                          # captured once
+    with pytest.raises(ValueError, match='exceed the capacity'):
+        sp.load(_batch('zinc', 140, F, seed=50), feats[0])

@@ -1792,3 +1792,33 @@ def test_cinpp_with_a_real_lower_stream_and_coboundary_stream():
     want = torch.zeros(b.cochains[0].num_cells, F, dtype=torch.float64).index_add_(0, bi[0], cpu(b.cochains[1].x).double()[bi[1]])
     gate(cob0, want, 'co-boundary stream of the vertices')
     assert params[2].coboundary_index is None        # nothing above the top dimension
+
+
+def test_bench_multi_rank_control_flow_on_one_gpu(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per
+    rank), with both ranks sharing this box's single GPU over gloo (CWN_BENCH_SHARE_GPU=1): barriers,
+    the max-over-ranks time, the all-reduced cell count and the rank-0-only legs all run."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CWN_BENCH_SHARE_GPU='1', CWN_BENCH_SKIP='train,concurrent,full,eager')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+           '--gpus', '2', '--steps', '8', '--warmup', '2', '--no-cpu', '--kernel-reps', '4']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]            # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 8 and d['warmup'] == 2 and d['scaling'] == 'weak'
+    assert d['value'] > 0 and d['unit'] == 'cells/s' and d['cpu_baseline'] is None
+    # whole-job value: both ranks' cells over the slower rank's time
+    assert abs(d['value'] - 2 * d['config']['cells_per_batch'] * d['config']['layers'] / (d['ms_per_step'] * 1e-3)) \
+        < 0.2 * d['value']
+    assert d['roofline'] is not None and 0 < d['roofline']['frac'] < 1

@@ -14,19 +14,10 @@ T = {}
 def tick(name, t0):
     T[name] = T.get(name, 0.0) + time.perf_counter() - t0
 def step():
-    t = time.perf_counter(); csr._cache.clear(); b.prepare(max_dim=2); tick('prepare (plan build call)', t)
+    t = time.perf_counter(); b.block_plan().forget_csr(); tick('forget_csr', t)
     for conv in model.convs:
         t = time.perf_counter(); b.set_xs(feats); params = b.get_all_cochain_params(max_dim=2, include_down_features=False); tick('set_xs + get_all_cochain_params', t)
-        t = time.perf_counter()
-        specs, owner = [], []
-        for dim in range(3):
-            sp = conv.mp_levels[dim].gemm_specs(params[dim]); specs += sp; owner += [dim] * len(sp)
-        tick('gemm_specs', t)
-        t = time.perf_counter(); ys = ops.gemm_many(specs); tick('gemm_many (launch)', t)
-        t = time.perf_counter()
-        plans = [conv.mp_levels[dim].streams(params[dim], [y for y, o in zip(ys, owner) if o == dim] or None) for dim in range(3)]
-        tick('streams()', t)
-        t = time.perf_counter(); ops.aggregate_many([st for p in plans for st in p]); tick('aggregate_many (launch)', t)
+        t = time.perf_counter(); conv._propagate_blocked(params, 0); tick('_propagate_blocked', t)
 with torch.no_grad():
     for _ in range(20): step()
     torch.cuda.synchronize(); T.clear()
@@ -37,3 +28,10 @@ with torch.no_grad():
 print(f'total {total:.0f} us/step (host-bound)')
 for k, v in sorted(T.items(), key=lambda kv: -kv[1]):
     print(f'  {v / 200 * 1e6:7.1f} us  {k}')
+import cProfile, pstats
+pr = cProfile.Profile()
+with torch.no_grad():
+    pr.enable()
+    for _ in range(100): step()
+    pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
