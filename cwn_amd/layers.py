@@ -18,6 +18,7 @@ unchanged.  What changes is HOW a layer runs:
     gather-kernel -> hook -> segmented-reduce-kernel path of CochainMessagePassing and is still
     correct.
 """
+import os
 from abc import ABC, abstractmethod
 from typing import Any, Callable, List, Optional
 
@@ -80,8 +81,12 @@ def _is_cat_linear_relu(nn) -> bool:
 
 
 FUSED_DENSE_TRAINING = True   # set False to run the update / combine networks as torch modules
-BLOCKED_LAYER = True          # set False to run the propagate scope as grouped GEMM + CSR aggregation
+BLOCKED_LAYER = os.environ.get('CWN_BLOCKED_LAYER') != '0'   # False: propagate scope as grouped GEMM + CSR aggregation
 CSR_REUSE = True              # blocked layer kernel: sort a batch's adjacencies once, later layers load the result
+# One workgroup per item and one item per CU at a time: the blocked kernel wins while the items fit the chip
+# a few times over (measured on ZINC-like batches, M cells/s blocked vs CSR path: 256 complexes 594 vs 423,
+# 512: 695 vs 588, 2048: 796 vs 886, 8192: 871 vs 973); beyond that the two-kernel path's streaming wins.
+BLOCKED_MAX_ITEMS = 1400
 
 
 def _fold_norm(norm, width: int):
@@ -715,6 +720,8 @@ class SparseCINConv(torch.nn.Module):
         table = plan.items(F, has_up)
         if table is None:
             return 'a complex does not fit one workgroup (row / entry caps)'
+        if table.n_items > BLOCKED_MAX_ITEMS:
+            return f'{table.n_items} items: beyond the range where one workgroup per item beats the streaming CSR path'
         key = tuple((id(t), t._version) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
         return dims, plan, table, key
 
