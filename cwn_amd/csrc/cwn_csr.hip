@@ -67,13 +67,15 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CsrBatch B, int32_t* er
             const int64_t a = D.aux[e];
             if (a < 0 || a >= D.n_aux) bad |= 4;
         }
-        if (bad) {
-            atomicOr(err, bad);
-            B.slot[di][e] = -1;
-        }
+        // Both build paths treat bad indices alike: every one is REPORTED; an entry whose
+        // destination is out of range cannot be placed and is dropped; a source / shared index out of
+        // range is clamped when it is emitted, so a consumer that runs before the host has looked at the
+        // error word (stream capture, overlap mode) can never fault.
+        if (bad) atomicOr(err, bad);
+        if (bad & 1) B.slot[di][e] = -1;
     }
     const int lane = threadIdx.x & 63;
-    const int key32 = (in && !bad) ? (int)k : -1;
+    const int key32 = (in && !(bad & 1)) ? (int)k : -1;
     // 1. group the lanes by key (ALU only, <= 64 wave-uniform trips)
     unsigned long long todo = __ballot(key32 >= 0);
     int my_leader = lane, my_rank = 0, my_size = 1;
@@ -306,8 +308,9 @@ __global__ __launch_bounds__(kThreads) void emit_kernel(CsrBatch B) {
     const int32_t e = tmp[p];
     const int64_t r = B.rows[di][p];
     const int s = D.rowptr[r], t = D.rowptr[r + 1];
-    const int32_t my_val = (int32_t)D.val[e];
-    const int32_t my_aux = D.aux_out != nullptr ? (int32_t)D.aux[e] : 0;
+    const int64_t v64 = D.val[e], a64 = D.aux_out != nullptr ? D.aux[e] : 0;
+    const int32_t my_val = (int32_t)(v64 < 0 ? 0 : (v64 >= D.n_val ? D.n_val - 1 : v64));      // reported in count_kernel
+    const int32_t my_aux = (int32_t)(a64 < 0 ? 0 : (a64 >= D.n_aux ? D.n_aux - 1 : a64));
     // stable rank inside the row by ORIGINAL entry id.  Eight independent loads per trip: the
     // lanes of a row read the same addresses (broadcast), so a 300-entry hub row is ~40 round
     // trips to L2, not 300.

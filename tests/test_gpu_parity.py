@@ -1822,3 +1822,33 @@ def test_bench_multi_rank_control_flow_on_one_gpu(tmp_path):
     assert abs(d['value'] - 2 * d['config']['cells_per_batch'] * d['config']['layers'] / (d['ms_per_step'] * 1e-3)) \
         < 0.2 * d['value']
     assert d['roofline'] is not None and 0 < d['roofline']['frac'] < 1
+
+
+@pytest.mark.parametrize('E,n_dst,n_src', [(60, 9, 11), (300_000, 5000, 7000)])
+def test_both_csr_build_paths_treat_bad_indices_alike(E, n_dst, n_src):
+    """the one-launch LDS path (small inputs) and the general path must produce the SAME
+    integers on out-of-range input: every bad index is reported, an entry with a bad destination is
+    dropped, a bad source / shared index is clamped into range."""
+    from cwn_amd import csr
+    from cwn_amd.csr import Adjacency, build_many
+    g = torch.Generator().manual_seed(E)
+    key = torch.randint(0, n_dst, (E,), generator=g)
+    val = torch.randint(0, n_src, (E,), generator=g)
+    aux = torch.randint(0, 13, (E,), generator=g)
+    key[[3, E // 2]] = torch.tensor([n_dst + 5, -2])          # bad destinations: dropped
+    val[[5, E - 1]] = torch.tensor([n_src + 9, -7])           # bad sources: clamped to n_src - 1 / 0
+    aux[7] = 99                                               # bad shared index: clamped to 12
+    adj = Adjacency(key.to(DEV), val.to(DEV), n_dst, n_src, aux.to(DEV), 13)
+    build_many([adj], validate=False)
+    with pytest.raises(IndexError, match='destination index, source index, shared'):
+        csr.check_errors(DEV)
+    keep = (key >= 0) & (key < n_dst)
+    ids = torch.nonzero(keep).flatten()
+    order = ids[torch.argsort(key[ids], stable=True)]
+    want_rowptr = torch.zeros(n_dst + 1, dtype=torch.int64)
+    want_rowptr[1:] = torch.bincount(key[ids], minlength=n_dst).cumsum(0)
+    n_ok = int(want_rowptr[-1])
+    assert torch.equal(cpu(adj.rowptr).long(), want_rowptr)
+    assert torch.equal(cpu(adj.perm)[:n_ok].long(), order)
+    assert torch.equal(cpu(adj.col)[:n_ok].long(), val[order].clamp(0, n_src - 1))
+    assert torch.equal(cpu(adj.aux)[:n_ok].long(), aux[order].clamp(0, 12))
