@@ -19,6 +19,7 @@ unchanged.  What changes is HOW a layer runs:
     correct.
 """
 import os
+import weakref
 from abc import ABC, abstractmethod
 from typing import Any, Callable, List, Optional
 
@@ -87,6 +88,8 @@ CSR_REUSE = True              # blocked layer kernel: sort a batch's adjacencies
 # a few times over (measured on ZINC-like batches, M cells/s blocked vs CSR path: 256 complexes 594 vs 423,
 # 512: 695 vs 588, 2048: 796 vs 886, 8192: 871 vs 973); beyond that the two-kernel path's streaming wins.
 BLOCKED_MAX_ITEMS = 1400
+# prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
+_BLOCKED_CACHE = weakref.WeakKeyDictionary()
 
 
 def _fold_norm(norm, width: int):
@@ -613,7 +616,7 @@ class SparseCINConv(torch.nn.Module):
             # checked and laid out once (`_blocked_args`); per call only the feature tensors are looked at
             ckey = (id(plan),) + tuple(id(t) for c in cochain_params for t in
                                        (c.up_index, c.boundary_index, getattr(c.kwargs.get('up_attr'), 'index', None)))
-            ent = self._blocked_cache.get(ckey) if hasattr(self, '_blocked_cache') else None
+            ent = _BLOCKED_CACHE.get(self, {}).get(ckey)
             if ent is not None and not self._blocked_still_valid(ent, cochain_params):
                 ent = None
         if ent is None:
@@ -627,11 +630,10 @@ class SparseCINConv(torch.nn.Module):
                        wver=[self.mp_levels[d].msg_up_nn[1].weight._version for d, D in enumerate(dims)
                              if D.msg_w_packed is not None],
                        launch=ops.LayerLaunch(dims, table))
-            if not hasattr(self, '_blocked_cache'):
-                self._blocked_cache = {}
-            if len(self._blocked_cache) > 64:
-                self._blocked_cache.clear()
-            self._blocked_cache[ckey] = ent
+            cache = _BLOCKED_CACHE.setdefault(self, {})
+            if len(cache) > 64:
+                cache.clear()
+            cache[ckey] = ent
         self.blocked_reason = None
         table, key = ent['table'], ent['key']
         # the layers of one forward share their index tensors (mp/molec_models.py:110-116): the first

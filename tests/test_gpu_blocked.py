@@ -293,3 +293,15 @@ def test_one_captured_graph_serves_batches_of_different_shapes():
     assert len(graphs_seen) == 1                          # captured once
     with pytest.raises(ValueError, match='exceed the capacity'):
         sp.load(_batch('zinc', 140, F, seed=50), feats[0])
+
+
+def test_layers_with_prepared_launches_still_deepcopy_and_pickle():
+    import copy
+    import pickle
+    b = _batch('zinc', 6, 128, seed=70)
+    conv = _conv(128, seed=71)
+    ref = _run(conv, b, blocked=True)
+    twin = copy.deepcopy(conv)
+    pickle.loads(pickle.dumps(conv.state_dict()))
+    for r, o in zip(ref, _run(twin, b, blocked=True)):
+        assert torch.equal(r, o)

@@ -8,15 +8,15 @@ TAG=${1:-x}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q 2>&1 | tail -1 | tee "$OUT/r1_${TAG}_pytest_gpu.txt"
+python -m pytest tests -m gpu -q 2>&1 | tail -1 | tee "$OUT/r2_${TAG}_pytest_gpu.txt"
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-python bench.py > "$OUT/r1_${TAG}_bench_zinc.json" 2> "$OUT/bench_zinc.err"
-python bench.py --workload molhiv > "$OUT/r1_${TAG}_bench_molhiv.json" 2> /dev/null
-python bench.py --workload reddit > "$OUT/r1_${TAG}_bench_reddit.json" 2> /dev/null
-python bench.py --batch 8192 --num-batches 1 --steps 20 --warmup 3 > "$OUT/r1_${TAG}_bench_zinc_batch8192.json" 2> /dev/null
-for w in zinc molhiv reddit zinc_batch8192; do tail -1 "$OUT/r1_${TAG}_bench_$w.json" | python -c "
+python bench.py > "$OUT/r2_${TAG}_bench_zinc.json" 2> "$OUT/bench_zinc.err"
+python bench.py --workload molhiv > "$OUT/r2_${TAG}_bench_molhiv.json" 2> /dev/null
+python bench.py --workload reddit > "$OUT/r2_${TAG}_bench_reddit.json" 2> /dev/null
+python bench.py --batch 8192 --num-batches 1 --steps 20 --warmup 3 > "$OUT/r2_${TAG}_bench_zinc_batch8192.json" 2> /dev/null
+for w in zinc molhiv reddit zinc_batch8192; do tail -1 "$OUT/r2_${TAG}_bench_$w.json" | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$w', d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('roofline_other',{}).get('frac'), d.get('cpu_baseline',{}).get('value'))"; done
+d=json.loads(sys.stdin.read()); print('$w', d['value'], d['ms_per_step'], d['roofline']['frac'], (d.get('roofline_other') or {}).get('frac'), (d.get('roofline_step') or {}).get('frac'), (d.get('cpu_baseline') or {}).get('value'))"; done
 # the same commands under rocprofv3 (kernel trace only)
 ROOT=$PWD
 cd /tmp
@@ -24,6 +24,6 @@ rm -rf /tmp/prof_full /tmp/prof_scope
 rocprofv3 --kernel-trace --stats -d /tmp/prof_full -- python "$ROOT/bench.py" --no-cpu > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/prof_scope -- python "$ROOT/bench.py" --only-primary > /dev/null 2>&1
 cd "$ROOT"
-python profiles/summarize_rocprof.py "$(ls /tmp/prof_full/*/*results.db | head -1)" > "$OUT/r1_${TAG}_full_bench.md"
-python profiles/summarize_rocprof.py "$(ls /tmp/prof_scope/*/*results.db | head -1)" 30 > "$OUT/r1_${TAG}_propagate_scope.md"
-head -8 "$OUT/r1_${TAG}_propagate_scope.md"
+python profiles/summarize_rocprof.py "$(ls /tmp/prof_full/*/*results.db | head -1)" > "$OUT/r2_${TAG}_full_bench.md"
+python profiles/summarize_rocprof.py "$(ls /tmp/prof_scope/*/*results.db | head -1)" 30 > "$OUT/r2_${TAG}_propagate_scope.md"
+head -8 "$OUT/r2_${TAG}_propagate_scope.md"
