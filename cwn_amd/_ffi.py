@@ -16,10 +16,10 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_items_check', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
@@ -154,6 +154,10 @@ def lib():
     L.cwn_layer_pack_weights_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_layer_fused_lds_bytes.restype = C.c_size_t
     L.cwn_layer_fused_lds_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.cwn_layer_round_rows.restype = C.c_int32
+    L.cwn_layer_round_rows.argtypes = [C.c_int32]
+    L.cwn_layer_items_check.restype = C.c_int
+    L.cwn_layer_items_check.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(LayerPlan)]
     L.cwn_gemm_would_split.restype = C.c_int
     L.cwn_gemm_would_split.argtypes = [C.POINTER(GemmDesc), C.c_int]
     L.cwn_collate.restype = C.c_int

@@ -150,11 +150,17 @@ class BlockPlan:
 
     def _build(self, F: int, has_up) -> Optional[ItemTable]:
         cap = gemm_rows_cap(F)
-        ng_round = 2048 // F       # rows per round of the kernel: the coface block starts at a multiple
+        from . import _ffi
+        ng_round = int(_ffi.lib().cwn_layer_round_rows(F))   # rows per round of the kernel: the coface block starts at a multiple
+        if ng_round <= 0:
+            return None
+
+        def first_coface_row(n_g: int, n_c: int) -> int:
+            r1 = _pad16(n_g)
+            return (r1 + ng_round - 1) // ng_round * ng_round if n_c > 0 else r1
 
         def staged(n_g: int, n_c: int) -> int:
-            r1 = _pad16(n_g)
-            return (r1 + ng_round - 1) // ng_round * ng_round + _pad16(n_c) if n_c > 0 else r1
+            return first_coface_row(n_g, n_c) + _pad16(n_c) if n_c > 0 else _pad16(n_g)
         C = self.C
         if C == 0:
             return None
@@ -194,24 +200,35 @@ class BlockPlan:
                 r = np.zeros(ITEM_INTS, dtype=np.int32)
                 r[0] = set_id << 8
                 n0 = int(cp[d0][c1] - cp[d0][c0])
-                nc = 0
+                nc = une = 0
+                live = tasks
                 if g is not None:
-                    nc = int(cp[g + 1][c1] - cp[g + 1][c0])
-                    r[0] |= 1 if n0 > 0 else 0
-                    r[1:8] = [g, cp[g][c0], n0, cp[g + 1][c0], nc, up[c0], up[c1] - up[c0]]
+                    r[1] = g
+                    if n0 > 0:
+                        nc, une = int(cp[g + 1][c1] - cp[g + 1][c0]), int(up[c1] - up[c0])
+                        r[0] |= 1
+                        r[2:8] = [cp[g][c0], n0, cp[g + 1][c0], nc, up[c0], une]
+                    else:
+                        if any(int(cp[d][c1] - cp[d][c0]) > 0 for d in tasks[1:]):
+                            return None             # cells of g + 1 without cells of g: not a cell complex
+                        live = tasks[:1]
                 max_rows = max(max_rows, staged(n0, nc))
-                r[8] = len(tasks)
-                src = 0
-                for t, d in enumerate(tasks):
+                r[8] = len(live)
+                src, bnes = 0, [0, 0]
+                for t, d in enumerate(live):
                     bp = bps[t]
                     o = 9 + 7 * t
-                    r[o:o + 5] = [d, cp[d][c0], cp[d][c1] - cp[d][c0], bp[c0], bp[c1] - bp[c0]]
-                    if d > 0:
+                    bnes[t] = int(bp[c1] - bp[c0])
+                    r[o:o + 5] = [d, cp[d][c0], cp[d][c1] - cp[d][c0], bp[c0], bnes[t]]
+                    if d > 0 and bnes[t] > 0:       # boundary sources are staged only when read
                         r[o + 5] = cp[d - 1][c0]
                         r[o + 6] = cp[d - 1][c1] - cp[d - 1][c0]
-                        if bp[c1] > bp[c0]:
-                            src += int(r[o + 6])
+                        src += int(r[o + 6])
                 max_src = max(max_src, src)
+                # derived fields (include/cwn_hip.h): the kernel reads them instead of re-deriving them
+                b1 = _pad4(une)
+                b2 = _pad4(b1 + bnes[0])
+                r[23:28] = [first_coface_row(n0, nc), staged(n0, nc), b1, b2, _pad4(b2 + bnes[1])]
                 recs.append(r)
                 c0 = c1
             # heavy items first within the set: a workgroup with five row tiles should not start last
@@ -224,4 +241,8 @@ class BlockPlan:
         up_end = [int(self.up_ptr[d][-1]) if (has_up[d] and self.up_ptr[d] is not None) else 0
                   for d in range(self.n_dims)]
         b_end = [int(self.b_ptr[d][-1]) if (self.b_ptr[d] is not None and d > 0) else 0 for d in range(self.n_dims)]
-        return ItemTable(table, set_start, max(max_rows, 16), max_src, cells_end, up_end, b_end, self.device)
+        out = ItemTable(table, set_start, max(max_rows, 16), max_src, cells_end, up_end, b_end, self.device)
+        rc = _ffi.lib().cwn_layer_items_check(table.ctypes.data, table.shape[0], F, out.c_plan(False))
+        if rc != 0:
+            raise _ffi.CwnError(f'item table failed cwn_layer_items_check ({rc})')
+        return out

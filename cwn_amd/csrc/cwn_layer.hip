@@ -60,14 +60,31 @@ namespace {
 
 using cwn::frag_cd;
 
-constexpr int kThreads = 512;
+// 1024 threads = 16 waves = four per SIMD, at most 128 VGPRs each: the kernel is a chain of phases that
+// are each bound by instruction latency, not by a pipe, so twice the waves finish every thread-parallel
+// phase (split, boundary stream, reduce) in about half the time.  What pays for it: a wave holds the
+// packed weight of ONE of the two products (Y1 or Y2) -- 48 registers instead of 96.
+#ifndef CWN_LAYER_THREADS
+#define CWN_LAYER_THREADS 1024
+#endif
+#ifndef CWN_LAYER_WEARLY
+#define CWN_LAYER_WEARLY 2                  // k-steps of the packed weight requested before the item record arrives
+#endif
+#ifndef CWN_LAYER_WBAR
+#define CWN_LAYER_WBAR 1                    // line the waves up between the row loads and the weight loads
+#endif
+constexpr int kThreads = CWN_LAYER_THREADS;
+static_assert(kThreads == 512 || kThreads == 1024, "8 or 16 waves");
+constexpr int kWaves = kThreads / 64;
+constexpr int kHS = kThreads == 1024 ? 2 : 1;   // 2: a wave computes Y1 OR Y2; 1: both
 constexpr int kEcap = CWN_LAYER_MAX_ENTRIES;
+constexpr int kEI = kEcap / kThreads;       // COO entries per thread
 constexpr int kTaskRows = CWN_LAYER_TASK_ROWS;
-constexpr int kNX = 6;                      // float4 of staged rows per thread at the row cap (12288 / F rows)
-constexpr int kNE = 6;                      // float4 of boundary-source rows per thread (12288 / F rows)
+constexpr int kNX = 12288 / 4 / kThreads;   // float4 of staged rows per thread at the row cap (12288 / F rows)
+constexpr int kNE = kNX;                    // float4 of boundary-source rows per thread (12288 / F rows)
 
 // item record fields (include/cwn_hip.h)
-enum { I_FLAGS = 0, I_G, I_GR0, I_GN, I_CR0, I_CN, I_UE0, I_UNE, I_NT, I_TASK0 };
+enum { I_FLAGS = 0, I_G, I_GR0, I_GN, I_CR0, I_CN, I_UE0, I_UNE, I_NT, I_TASK0, I_R1 = 23, I_ROWS, I_B1, I_B2, I_TOTAL };
 enum { T_DIM = 0, T_R0, T_N, T_BE0, T_BNE, T_SR0, T_SN, T_INTS };
 
 // One SET = the items that share a GEMM dimension (cwn_amd/blockplan.py): the launcher resolves every
@@ -108,9 +125,9 @@ template <int F> struct Geo {
     static constexpr int kYStride = F + 4;                  // floats per Y row
     static constexpr int kKS = F / 32;                      // k-steps of 32
     static constexpr int kNCT = F / 16;                     // column tiles
-    static constexpr int kWPC = 8 / kNCT;                   // waves sharing a column tile (row-tile parity)
+    static constexpr int kWPC = kWaves / kNCT / kHS;        // waves sharing a column tile of a product (row-tile parity)
     static constexpr int kG = F / 4;                        // lanes per row
-    static constexpr int kNG = kThreads / kG;               // rows per round (16 at F = 128, 32 at F = 64)
+    static constexpr int kNG = kThreads / kG;               // rows per round (1024 threads: 32 at F = 128, 64 at F = 64)
     static constexpr int kWChunks = 2 * kKS * 3;            // 1-KiB chunks of the packed weight per column tile
     // planes [3][rows][F + 8] bf16, overwritten by Y [rows][F + 4] fp32 once the MFMAs have read them
     __host__ __device__ static constexpr size_t planes_bytes(int rows) { return (size_t)3 * rows * kPlaneStride * 2; }
@@ -161,6 +178,15 @@ __device__ __forceinline__ void stg4(gf_p p, const float4& a) {
     const v4f v = {a.x, a.y, a.z, a.w};
     *(gv4_p)p = v;
 }
+// uniform base (SGPR pair) + per-lane 32-bit byte offset: one address instruction instead of a 64-bit add chain
+__device__ __forceinline__ float4 ldg4o(gcb_p base, uint32_t off) {
+    const v4f v = *(gcv4_p)(base + off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stg4o(gb_p base, uint32_t off, const float4& a) {
+    const v4f v = {a.x, a.y, a.z, a.w};
+    *(gv4_p)(base + off) = v;
+}
 __device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 sel4(bool c, const float4& a, const float4& b) {
     return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
@@ -198,9 +224,9 @@ __device__ __forceinline__ int row_ranges(RowSet<NR>& R, const uint16_t* rp, int
 }
 
 // sum of rows src[col[p]] over each row's entries
-template <int NR, int NG, int F>
-__device__ __forceinline__ void gather_sum(float4 (&acc)[NR], const RowSet<NR>& R, int steps, const uint16_t* col,
-                                           const float* src, int zero_row, int f) {
+template <int NR, int F>
+__device__ __forceinline__ void gather_sum(float4 (&acc)[NR], const RowSet<NR>& R, int steps,
+                                           const uint16_t* const (&cols)[NR], const float* src, int zero_row, int f) {
 #pragma unroll
     for (int u = 0; u < NR; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int q = 0; q < steps; q += 2) {
@@ -211,7 +237,7 @@ __device__ __forceinline__ void gather_sum(float4 (&acc)[NR], const RowSet<NR>& 
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 const int p = R.s[u] + q + v;
-                const int cv = col[min(p, max(R.e[u] - 1, 0))];
+                const int cv = cols[u][min(p, max(R.e[u] - 1, 0))];
                 c[u][v] = p < R.e[u] ? cv : zero_row;
             }
 #pragma unroll
@@ -299,51 +325,70 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     const int set = ((int)blockIdx.x >= A.set_start1 ? 1 : 0) + ((int)blockIdx.x >= A.set_start2 ? 1 : 0);
     const int32_t itv = A.items[(size_t)blockIdx.x * CWN_LAYER_ITEM_INTS + (lane & (CWN_LAYER_ITEM_INTS - 1))];
     const uint64_t srec = ((gcu64_p)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr())[set * kSetFields + min(lane, kSetFields - 1)];
+    // The packed weight depends on the SET only, and while the two records travel (and are taken apart) the
+    // address unit of this CU has nothing to do: the first kWEarly k-steps of this wave's slice are requested
+    // now, their address from ONE scalar load of the set record's weight field.  (All of it here was
+    // measured worse: the rows then queue behind 192 KB.)
+    const int ct = wave % G::kNCT, w2 = wave / G::kNCT;
+    const int my_h = kHS == 2 ? (w2 & 1) : 0, rt_par = w2 / kHS;   // this wave's product (kHS == 2), row-tile parity
+    uint4 wsp[2 / kHS][G::kKS][3];
+    constexpr int kWEarly = CWN_LAYER_WEARLY < G::kKS ? CWN_LAYER_WEARLY : G::kKS;
+    __builtin_amdgcn_sched_barrier(0);       // both record loads leave before the scalar load below is waited for
+    const uint64_t wp_bits =
+        ((const __attribute__((address_space(4))) uint64_t*)__builtin_amdgcn_kernarg_segment_ptr())[set * kSetFields + S_WP];
+    // chunk (ks, plane) of product h and column tile ct is the 1-KiB block number ((ks * 3 + plane) * 2 + h) * kNCT + ct:
+    // the waves of a workgroup, which walk their chunks in step, read CONSECUTIVE kilobytes (all L2 channels)
+    // instead of sixteen blocks 24 KB apart (a multiple of the channel interleave: the same few channels)
+    const gcb_p wbase = wp_bits != 0 ? (gcb_p)wp_bits + (size_t)ct * 1024 + lane * 16 : (gcb_p)A.items;
+    const int won = wp_bits != 0 ? 1024 : 0;
+    auto wchunk = [&](int h, int ks, int pl) { return wbase + (((ks * 3 + pl) * 2 + h) * G::kNCT) * won; };
+#pragma unroll
+    for (int hh = 0; hh < 2 / kHS; ++hh) {
+        const int h = kHS == 2 ? my_h : hh;
+#pragma unroll
+        for (int ks = 0; ks < kWEarly; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wsp[hh][ks][pl] = ldgu4(wchunk(h, ks, pl));
+    }
     const int srec_lo = (int)(uint32_t)srec, srec_hi = (int)(uint32_t)(srec >> 32);
     auto fld = [&](int k) { return __builtin_amdgcn_readlane(itv, k); };
     auto sfld = [&](int k) {
         return (uint64_t)(uint32_t)__builtin_amdgcn_readlane(srec_lo, k) |
                ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(srec_hi, k) << 32);
     };
-    const int flags = fld(I_FLAGS);
-    const bool has_gemm = (flags & 1) != 0;
-    const int n_tasks = fld(I_NT);
+    // The record carries every number the workgroup would otherwise DERIVE (first coface row, staged rows,
+    // entry segments: written by the table builder, checked on the host by cwn_layer_items_check): with
+    // four waves per SIMD an instruction costs an issue slot in each of them, and 16 waves deriving the
+    // same scalars took longer than the loads they lead to.  Absent tasks / products are all-zero fields.
+    const bool has_gemm = (fld(I_FLAGS) & 1) != 0;
     CWN_STAMP(9);
-    int t_r0[2], t_n[2], t_be0[2], t_bne[2], t_sr0[2], t_sn[2];
+    int t_r0[2], t_n[2], t_bne[2], t_sn[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int o = I_TASK0 + t * T_INTS;
-        const bool on = t < n_tasks;
         t_r0[t] = fld(o + T_R0);
-        t_n[t] = on ? fld(o + T_N) : 0;
-        t_be0[t] = fld(o + T_BE0);
-        t_bne[t] = on ? fld(o + T_BNE) : 0;
-        t_sr0[t] = fld(o + T_SR0);
-        t_sn[t] = (on && t_bne[t] > 0) ? fld(o + T_SN) : 0;  // source rows are staged only when used
+        t_n[t] = fld(o + T_N);
+        t_bne[t] = fld(o + T_BNE);
+        t_sn[t] = fld(o + T_SN);                 // 0 unless the task has boundary entries (sources are staged)
     }
     // staged rows: [0, g_n) the cells of task 0 (the GEMM dimension g when the item has one), then, from
     // row R1 (a multiple of the rows-per-round, so that lane groups line up), the c_n cells of g + 1
-    const int g_r0 = t_r0[0], g_n = t_n[0];
-    const int c_r0 = fld(I_CR0), c_n = has_gemm ? fld(I_CN) : 0;
-    const int u_e0 = fld(I_UE0), u_ne = has_gemm ? fld(I_UNE) : 0;
-    const int T1 = (g_n + 15) >> 4, T2 = (c_n + 15) >> 4;      // 16-row tiles of Y1, Y2
-    const int R1 = (T1 * 16 + G::kNG - 1) / G::kNG * G::kNG;   // first staged row of the cofaces
-    const int rows_pad = c_n > 0 ? R1 + T2 * 16 : T1 * 16;
+    const int g_n = t_n[0], c_n = fld(I_CN);
+    const int R1 = fld(I_R1), rows_pad = fld(I_ROWS);
     // segments of the item's combined entry list, each starting at a multiple of 4 (ds_read_b128 of
-    // four keys): [0, s1) upper, [b1, s2) boundary of task 0, [b2, s3) boundary of task 1
-    const int s1 = u_ne, b1 = (s1 + 3) & ~3, s2 = b1 + t_bne[0], b2 = (s2 + 3) & ~3, s3 = b2 + t_bne[1];
-    const int total = (s3 + 3) & ~3;
+    // four keys): [0, u_ne) upper, [b1, b1 + t_bne[0]) boundary of task 0, [b2, b2 + t_bne[1]) of task 1
+    const int b1 = fld(I_B1), b2 = fld(I_B2), total = fld(I_TOTAL);
     // boundary sources in LDS: [0, t_sn[0]) cells of dim g-1 (loaded), then the g_n cells of dim g (copied
     // from the staged rows) when task 1 reads them
     const int x_rows = t_sn[0] + t_sn[1];
     const int gl = tid % G::kG, gq = tid / G::kG, f = gl * 4;  // lane group gq finishes rows gq, gq + kNG, ...
+    constexpr uint32_t kRowB = F * 4;                          // bytes per row
+    const uint32_t fB = (uint32_t)f * 4;
     CWN_STAMP(10);
-    // What the HOST cannot check for the caller (cwn_layer_fused_f32 compares the table's summary with
-    // the tensors): that this record fits the LDS this launch was given, and that its second task is
-    // the coface block.  Uniform over the workgroup.
-    if (rows_pad > rows_cap || x_rows > A.xrows_cap || total > kEcap || u_ne < 0 || t_bne[0] < 0 || t_bne[1] < 0 ||
-        t_n[0] > kTaskRows || t_n[1] > kTaskRows || g_n < 0 || c_n < 0 ||
-        (n_tasks > 1 && (t_n[1] != c_n || (t_bne[1] > 0 && t_sn[1] != g_n)))) {
+    // What stays checked here: that the record fits the LDS of this launch (memory safety inside the
+    // workgroup).  Uniform over the workgroup; unsigned compares also catch negative fields.
+    if ((unsigned)rows_pad > (unsigned)rows_cap || (unsigned)x_rows > (unsigned)A.xrows_cap || (unsigned)total > (unsigned)kEcap ||
+        (unsigned)t_n[0] > (unsigned)kTaskRows || (unsigned)t_n[1] > (unsigned)kTaskRows || (unsigned)R1 > (unsigned)rows_pad) {
         if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
         return;
     }
@@ -357,16 +402,18 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // large items need sit behind UNIFORM guards at the very end of the run, where no earlier load
     // has to be counted past them.
     const gcf_p dummy = (gcf_p)A.items;                      // >= 128 readable bytes, 16-B aligned
-    const int ct = wave % G::kNCT, rt_par = wave / G::kNCT;
-    int64_t ek[2], ev[2], ea[2];
+    int64_t ek[kEI], ev[kEI], ea[kEI];
+    int s1 = 0, s2 = 0, s3 = 0;
     if constexpr (MODE != kLoad) {
+        const int u_e0 = fld(I_UE0), t_be0[2] = {fld(I_TASK0 + T_BE0), fld(I_TASK0 + T_INTS + T_BE0)};
+        s1 = fld(I_UNE), s2 = b1 + t_bne[0], s3 = b2 + t_bne[1];
         const gci64_p up_index = (gci64_p)sfld(S_UP_INDEX), up_shared = (gci64_p)sfld(S_UP_SHARED);
         const gci64_p b_index0 = (gci64_p)sfld(S_TASK0 + ST_B_INDEX);
         const gci64_p b_index1 = (gci64_p)sfld(S_TASK0 + ST_FIELDS + ST_B_INDEX);
         const int64_t up_E = (int64_t)sfld(S_UP_E);
         const int64_t b_E0 = (int64_t)sfld(S_TASK0 + ST_B_E), b_E1 = (int64_t)sfld(S_TASK0 + ST_FIELDS + ST_B_E);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kEI; ++i) {
             const int w = tid + i * kThreads;
             const bool in_up = w < s1, in_b0 = w >= b1 && w < s2, in_b1 = w >= b2 && w < s3;
             const gci64_p src = in_up ? up_index : in_b0 ? b_index0 : in_b1 ? b_index1 : (gci64_p)A.items;
@@ -392,46 +439,48 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     }
     const gcf_p bias = (gcf_p)sfld(S_MSG_BIAS);
     const bool has_bias = has_gemm && bias != (gcf_p)0;
-    float4 b4 = ldg4(has_bias ? bias + ct * 16 + kq * 4 : dummy);
-    if (!has_bias) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     CWN_STAMP(11);
     // the staged rows (rows past the real ones re-read the last real row, never used), then the rows the
     // boundary stream of task 0 gathers from; round i is skipped when no item row falls into it
+    // (no zero fill: merging a constant with a load result made the compiler copy the loaded register right
+    // behind the load -- s_waitcnt vmcnt(0) in the middle of the run)
     float4 xv[kNX], ev4[kNE];
     {
-        const gcf_p xg = (gcf_p)sfld(S_XG), xc = (gcf_p)sfld(S_XC), xs_t0 = (gcf_p)sfld(S_TASK0 + ST_XS);
+        // uniform base of the block (SGPR pair) + a 32-bit byte offset per lane.  Round i belongs to the
+        // coface block iff i >= R1 / kNG (R1 is a multiple of kNG): a scalar decision per round.
+        const gcb_p xg = (gcb_p)sfld(S_XG) + (size_t)t_r0[0] * kRowB, xc = (gcb_p)sfld(S_XC) + (size_t)fld(I_CR0) * kRowB;
+        const gcb_p xs = (gcb_p)sfld(S_TASK0 + ST_XS) + (size_t)fld(I_TASK0 + T_SR0) * kRowB;
+        const int k0 = R1 / G::kNG;
         const int nxr = (rows_pad + G::kNG - 1) / G::kNG, ner = (t_sn[0] + G::kNG - 1) / G::kNG;
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
-            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < nxr) {
-                const int row = min(gq + i * G::kNG, rows_pad - 1);
-                const bool second = c_n > 0 && row >= R1;
-                const int r = second ? min(row - R1, c_n - 1) : min(row, g_n - 1);
-                xv[i] = ldg4(g_n <= 0 ? dummy : second ? xc + (int64_t)(c_r0 + r) * F + f : xg + (int64_t)(g_r0 + r) * F + f);
+            if (i < nxr) {           // a skipped round leaves xv[i] unset: it is never read (rows >= rows_pad)
+                const bool second = c_n > 0 && i >= k0;
+                const int n = second ? c_n : g_n;
+                const int r = min(gq + (second ? i - k0 : i) * G::kNG, n - 1);
+                xv[i] = ldg4o(second ? xc : xg, (uint32_t)r * kRowB + fB);
             }
         }
 #pragma unroll
         for (int i = 0; i < kNE; ++i) {
-            ev4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < ner) ev4[i] = ldg4(xs_t0 + (int64_t)(t_sr0[0] + min(gq + i * G::kNG, t_sn[0] - 1)) * F + f);
+            if (i < ner) ev4[i] = ldg4o(xs, (uint32_t)min(gq + i * G::kNG, t_sn[0] - 1) * kRowB + fB);
         }
     }
     CWN_STAMP(12);
-    // this wave's slice of the packed weight: kWChunks chunks of 1 KiB, lane l takes bytes 16 l .. 16 l + 15.
-    // LAST: it is the bulk of the bytes (192 KB per workgroup at F = 128) and only the matrix cores
-    // need it, so the rows are split and phase 5 runs while it is still landing
-    uint4 wsp[2][G::kKS][3];
-    {
-        const gcb_p wp = (gcb_p)sfld(S_WP);
-        const gcb_p wbase = has_gemm ? wp + (size_t)ct * G::kWChunks * 1024 + lane * 16 : (gcb_p)A.items;
-        const int on = has_gemm ? 1024 : 0;
+    // the rest of this wave's slice of the packed weight: chunks of 1 KiB, lane l takes bytes 16 l .. 16 l + 15.
+    // LAST: it is the bulk of the bytes (192 KB per workgroup at F = 128) and only the matrix cores need it,
+    // so the rows are split and phase 5 runs while it is still landing.  The barrier (no memory wait: it only
+    // lines the waves up) keeps every wave's ROW requests ahead of every wave's weight requests in the
+    // address unit's queue -- without it the rows of the wave that issues last arrive behind the weights
+    // of the fifteen others, and the split phase waits for most of the weight (measured: 3.3 k cycles).
+    if (CWN_LAYER_WBAR) __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+    for (int hh = 0; hh < 2 / kHS; ++hh) {
+        const int h = kHS == 2 ? my_h : hh;
 #pragma unroll
-            for (int ks = 0; ks < G::kKS; ++ks)
+        for (int ks = kWEarly; ks < G::kKS; ++ks)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wsp[h][ks][pl] = ldgu4(wbase + ((h * G::kKS + ks) * 3 + pl) * on);
+            for (int pl = 0; pl < 3; ++pl) wsp[hh][ks][pl] = ldgu4(wchunk(h, ks, pl));
     }
     CWN_STAMP(1);
 
@@ -443,8 +492,10 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         CWN_STAMP(3);
     } else {
         // ---- 3a. entries -> LDS as local row numbers, range-checked --------------------------------------
+        const int g_r0 = t_r0[0], c_r0 = fld(I_CR0);
+        const int t_sr0[2] = {fld(I_TASK0 + T_SR0), fld(I_TASK0 + T_INTS + T_SR0)};
     #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kEI; ++i) {
             const int w = tid + i * kThreads;
             if (w < total) {
                 int64_t k = 0, v = 0, a = 0, nk = 1, nv = 1, na = 1;
@@ -578,36 +629,52 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     eps2[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 1));
     eps1[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 2));
     eps2[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 3));
-    // ---- 5. boundary stream and self terms of every task, out of LDS (while W is still landing) --------
+    // ---- 5. boundary stream and self terms of BOTH tasks in one pass, out of LDS (W is still landing) ---
+    // Lane group gq finishes row gq + k kNG of task 0 and of task 1 together: two independent chains
+    // (row pointers -> source numbers -> source rows) in flight, where two passes ran them one after the
+    // other (measured: 4.1 k cycles for an edges + rings item, most of it LDS round trips).
 #ifndef CWN_LAYER_NR
-#define CWN_LAYER_NR 2
+#define CWN_LAYER_NR (CWN_LAYER_THREADS == 1024 ? 1 : 2)
 #endif
-    constexpr int kNR = CWN_LAYER_NR;                          // destination rows per lane group in flight
+    constexpr int kNR = CWN_LAYER_NR;                          // destination rows per lane group in flight (phase 7)
+    {
+        gb_p out_up[2], out_b[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (t < n_tasks) {
-            const gf_p out_up = (gf_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_UP);
-            const gf_p out_b = (gf_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_B);
-            const float scale1 = 1.0f + eps1[t], scale2 = 1.0f + eps2[t];
-            const uint16_t* rp = rowptr + (t + 1) * kRpStride;
-            const uint16_t* col = scol + (t == 0 ? b1 : b2);
-            const bool up_here = has_gemm && t == 0;   // the GEMM dimension is task 0 (blockplan.py)
-            const int k0 = t == 0 ? 0 : R1 / G::kNG;   // first staged round of this task's cells
-            for (int k = 0; gq + k * G::kNG < t_n[t]; k += kNR) {
-                RowSet<kNR> R;
-                float4 acc[kNR], xi[kNR];
-                const int steps = row_ranges<kNR, G::kNG>(R, rp, gq + k * G::kNG, t_n[t]);
+        for (int t = 0; t < 2; ++t) {
+            out_up[t] = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_UP) + (size_t)t_r0[t] * kRowB;
+            out_b[t] = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_B) + (size_t)t_r0[t] * kRowB;
+        }
+        const uint16_t* const cols[2] = {scol + b1, scol + b2};
+        const int k0 = R1 / G::kNG;                 // first staged round of task 1's cells
+        const bool any_b = t_bne[0] + t_bne[1] > 0; // no boundary entries at all (vertices): self terms only
+        const int rounds = (max(t_n[0], t_n[1]) + G::kNG - 1) / G::kNG;
+        for (int k = 0; k < rounds; ++k) {
+            const int r = gq + k * G::kNG;
+            RowSet<2> R;
+            int steps = 0;
 #pragma unroll
-                for (int u = 0; u < kNR; ++u) xi[u] = pick(xv, k0 + k + u);      // self terms: this group loaded them
-                gather_sum<kNR, G::kNG, F>(acc, R, steps, col, xsrc, x_rows, f);
+            for (int t = 0; t < 2; ++t) {
+                R.on[t] = r < t_n[t];
+                R.s[t] = R.e[t] = 0;
+                if (any_b) {
+                    const uint16_t* rp = rowptr + (t + 1) * kRpStride;
+                    const int rr = R.on[t] ? r : 0;
+                    const int s_ = rp[rr], e_ = rp[rr + 1];
+                    R.s[t] = R.on[t] ? s_ : 0;
+                    R.e[t] = R.on[t] ? e_ : 0;
+                    steps = max(steps, R.e[t] - R.s[t]);
+                }
+            }
+            float4 acc[2];
+            const float4 xi[2] = {pick(xv, k), pick(xv, k0 + k)};     // self terms: this group loaded them
+            gather_sum<2, F>(acc, R, steps, cols, xsrc, x_rows, f);
+            const uint32_t off = (uint32_t)r * kRowB + fB;
 #pragma unroll
-                for (int u = 0; u < kNR; ++u) {
-                    if (R.on[u]) {
-                        const int64_t row = (int64_t)(t_r0[t] + gq + (k + u) * G::kNG) * F + f;
-                        stg4(out_b + row, axpy4(acc[u], scale2, xi[u]));
-                        if (!up_here)        // no upper adjacency in this dimension: zeros + self term
-                            stg4(out_up + row, axpy4(make_float4(0.f, 0.f, 0.f, 0.f), scale1, xi[u]));
-                    }
+            for (int t = 0; t < 2; ++t) {
+                if (R.on[t]) {
+                    stg4o(out_b[t], off, axpy4(acc[t], 1.0f + eps2[t], xi[t]));
+                    if (!(has_gemm && t == 0))   // no upper adjacency in this dimension: zeros + self term
+                        stg4o(out_up[t], off, axpy4(make_float4(0.f, 0.f, 0.f, 0.f), 1.0f + eps1[t], xi[t]));
                 }
             }
         }
@@ -616,6 +683,11 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     if (!has_gemm) return;
 
     // ---- 6. Y1 | Y2 on the matrix cores ---------------------------------------------------------------
+    // the bias of this wave's output columns: needed after the MFMAs, requested here (four registers that
+    // would otherwise be held through the whole load run, where the register file is full)
+    float4 b4 = ldg4(has_bias ? bias + ct * 16 + kq * 4 : dummy);
+    if (!has_bias) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int T1 = (g_n + 15) >> 4, T2 = (c_n + 15) >> 4;      // 16-row tiles of Y1, Y2
     {
         const size_t plane = (size_t)rows_cap * G::kPlaneStride;
         // this wave's row tiles: at most kMaxT per half (six 16-row tiles in all at the row cap); the
@@ -625,10 +697,11 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         static_assert(kMaxT % 2 == 0, "tiles are processed in pairs");
         static_assert(offsetof(LayerArgs, set) == 0, "read through the kernarg segment pointer");
         static_assert(kSetFields <= 64 && CWN_LAYER_ITEM_INTS <= 64, "one lane per field");
-        frag_cd acc[2][kMaxT];
+        frag_cd acc[2 / kHS][kMaxT];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint4 (&wf)[G::kKS][3] = wsp[h];
+        for (int hh = 0; hh < 2 / kHS; ++hh) {
+            const int h = kHS == 2 ? my_h : hh;
+            const uint4 (&wf)[G::kKS][3] = wsp[hh];
             const int rt0 = h == 0 ? 0 : R1 / 16, rt1 = rt0 + (h == 0 ? T1 : T2);
             // row tiles of this half that are this wave's (F = 64: two waves share a column tile)
             const int first = rt0 + ((rt_par - rt0) % G::kWPC + G::kWPC) % G::kWPC;
@@ -650,8 +723,8 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
                         c0 = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh0, xm0, xl0, c0);
                         c1 = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh1, xm1, xl1, c1);
                     }
-                    acc[h][j] = c0;
-                    acc[h][j + 1] = c1;
+                    acc[hh][j] = c0;
+                    acc[hh][j + 1] = c1;
                 } else if (rta < rt1) {          // the odd tile of this half
                     frag_cd c0 = {0.f, 0.f, 0.f, 0.f};
                     const uint16_t* p0 = planes + (size_t)(rta * 16 + l15) * G::kPlaneStride + kq * 8;
@@ -662,7 +735,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
                         const uint4 xl0 = *reinterpret_cast<const uint4*>(p0 + 2 * plane + ks * 32);
                         c0 = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh0, xm0, xl0, c0);
                     }
-                    acc[h][j] = c0;
+                    acc[hh][j] = c0;
                 }
             }
         }
@@ -673,14 +746,15 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         if (gq == 0) *reinterpret_cast<float4*>(Y + (size_t)rows_cap * G::kYStride + f) = make_float4(0.f, 0.f, 0.f, 0.f);
         // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = x row (lane & 15); Y1 carries the bias
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int hh = 0; hh < 2 / kHS; ++hh) {
+            const int h = kHS == 2 ? my_h : hh;
             const int rt0 = h == 0 ? 0 : R1 / 16, rt1 = rt0 + (h == 0 ? T1 : T2);
             const int first = rt0 + ((rt_par - rt0) % G::kWPC + G::kWPC) % G::kWPC;
 #pragma unroll
             for (int j = 0; j < kMaxT; ++j) {
                 const int rt = first + j * G::kWPC;
                 if (rt < rt1) {
-                    frag_cd c = acc[h][j];
+                    frag_cd c = acc[hh][j];
                     if (h == 0 && has_bias) {
                         c[0] += b4.x; c[1] += b4.y; c[2] += b4.z; c[3] += b4.w;
                     }
@@ -695,7 +769,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
 
     // ---- 7. upper stream out of LDS: out_up[i] = sum_p relu(Y1[col[p]] + Y2[aux[p]]) + (1 + eps1) x_i -
     {
-        const gf_p out_up0 = (gf_p)sfld(S_TASK0 + ST_OUT_UP);
+        const gb_p out_up0 = (gb_p)sfld(S_TASK0 + ST_OUT_UP) + (size_t)t_r0[0] * kRowB;
         const float scale1 = 1.0f + eps1[0];
         const float* Y2 = Y + (size_t)R1 * G::kYStride;
         for (int k = 0; gq + k * G::kNG < g_n; k += kNR) {
@@ -708,15 +782,15 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
 #pragma unroll
             for (int u = 0; u < kNR; ++u)
                 if (R.on[u])
-                    stg4(out_up0 + (int64_t)(g_r0 + gq + (k + u) * G::kNG) * F + f, axpy4(acc[u], scale1, xi[u]));
+                    stg4o(out_up0, (uint32_t)(gq + (k + u) * G::kNG) * kRowB + fB, axpy4(acc[u], scale1, xi[u]));
         }
     }
     CWN_STAMP(8);
 }
 
-// fp32 [F, 2F] weight of the message Linear -> bf16 hi / mid / lo planes in MFMA-fragment order: chunk
-// ((ct * 2 + h) * KS + ks) * 3 + plane holds, for lane l = kq * 16 + n, the eight k-values
-// W[ct * 16 + n][h * F + ks * 32 + kq * 8 ..] of that plane (16 bytes per lane, 1 KiB per chunk).
+// fp32 [F, 2F] weight of the message Linear -> bf16 hi / mid / lo planes in MFMA-fragment order: the 1-KiB
+// chunk number ((ks * 3 + plane) * 2 + h) * NCT + ct holds, for lane l = kq * 16 + n, the eight k-values
+// W[ct * 16 + n][h * F + ks * 32 + kq * 8 ..] of that plane (16 bytes per lane).
 template <int F>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ W, int64_t ldw,
                                                            unsigned char* __restrict__ out) {
@@ -729,10 +803,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const float4 a = make_float4(src[0], src[1], src[2], src[3]), b = make_float4(src[4], src[5], src[6], src[7]);
     uint4 ph, pm, pl;
     cwn::split8(a, b, ph, pm, pl);
-    unsigned char* dst = out + (size_t)chunk3 * 3 * 1024 + lane * 16;
+    unsigned char* dst = out + ((size_t)(ks * 3 * 2 + h) * NCT + ct) * 1024 + lane * 16;
+    constexpr size_t kPlane = (size_t)2 * NCT * 1024;     // from a chunk to the same chunk of the next plane
     *reinterpret_cast<uint4*>(dst) = ph;
-    *reinterpret_cast<uint4*>(dst + 1024) = pm;
-    *reinterpret_cast<uint4*>(dst + 2048) = pl;
+    *reinterpret_cast<uint4*>(dst + kPlane) = pm;
+    *reinterpret_cast<uint4*>(dst + 2 * kPlane) = pl;
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
@@ -776,6 +851,68 @@ extern "C" int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F
     if (F == 128) pack_weights_kernel<128><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
     else pack_weights_kernel<64><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int32_t cwn_layer_round_rows(int32_t F) {
+    return (F == 64 || F == 128) ? kThreads / (F / 4) : 0;
+}
+
+// Host-side check of a HOST copy of the item table against its plan: every derived field is what
+// include/cwn_hip.h defines, every range lies inside the plan's summary, every item fits the caps.  The
+// kernel itself re-checks only what keeps a workgroup inside its LDS.
+extern "C" int cwn_layer_items_check(const int32_t* items, int64_t n_items, int32_t F, const cwn_layer_plan* plan) {
+    if (plan == nullptr || n_items < 0 || (n_items > 0 && items == nullptr) || (F != 64 && F != 128)) return CWN_ERR_BAD_ARG;
+    if (plan->n_items != n_items) return CWN_ERR_BAD_ARG;
+    const int ng = kThreads / (F / 4);
+    auto pad16 = [](int64_t n) { return (n + 15) / 16 * 16; };
+    auto pad4 = [](int64_t n) { return (n + 3) / 4 * 4; };
+    for (int64_t it = 0; it < n_items; ++it) {
+        const int32_t* r = items + it * CWN_LAYER_ITEM_INTS;
+        const bool has_gemm = (r[I_FLAGS] & 1) != 0;
+        const int nt = r[I_NT];
+        if (nt < 0 || nt > 2) return CWN_ERR_BAD_ARG;
+        int64_t bne[2] = {0, 0}, sn = 0;
+        for (int t = 0; t < 2; ++t) {
+            const int32_t* T = r + I_TASK0 + t * T_INTS;
+            if (t >= nt) {
+                for (int k = 0; k < T_INTS; ++k)
+                    if (T[k] != 0) return CWN_ERR_BAD_ARG;
+                continue;
+            }
+            const int d = T[T_DIM];
+            if (d < 0 || d >= CWN_LAYER_MAX_DIMS || T[T_R0] < 0 || T[T_N] < 0 || T[T_N] > CWN_LAYER_TASK_ROWS ||
+                T[T_BE0] < 0 || T[T_BNE] < 0 || T[T_SR0] < 0 || T[T_SN] < 0)
+                return CWN_ERR_BAD_ARG;
+            if ((int64_t)T[T_R0] + T[T_N] > plan->cells_end[d] || (int64_t)T[T_BE0] + T[T_BNE] > plan->b_end[d]) return CWN_ERR_BAD_ARG;
+            if (T[T_BNE] == 0 ? T[T_SN] != 0 : (d == 0 || (int64_t)T[T_SR0] + T[T_SN] > plan->cells_end[d - 1])) return CWN_ERR_BAD_ARG;
+            bne[t] = T[T_BNE];
+            sn += T[T_SN];
+        }
+        const int32_t* T0 = r + I_TASK0;
+        const int32_t* T1r = T0 + T_INTS;
+        int64_t n0 = nt > 0 ? T0[T_N] : 0, nc = 0, une = 0;
+        if (has_gemm) {
+            const int g = r[I_G];
+            if (nt < 1 || g != T0[T_DIM] || g + 1 >= CWN_LAYER_MAX_DIMS || r[I_GR0] != T0[T_R0] || r[I_GN] != T0[T_N] || n0 <= 0 ||
+                r[I_CR0] < 0 || r[I_CN] < 0 || r[I_UE0] < 0 || r[I_UNE] < 0)
+                return CWN_ERR_BAD_ARG;
+            nc = r[I_CN];
+            une = r[I_UNE];
+            if ((int64_t)r[I_CR0] + nc > plan->cells_end[g + 1] || (int64_t)r[I_UE0] + une > plan->up_end[g]) return CWN_ERR_BAD_ARG;
+            // a second task is the coface block, and gathers from the staged cells of g
+            if (nt > 1 && (T1r[T_DIM] != g + 1 || T1r[T_R0] != r[I_CR0] || T1r[T_N] != nc ||
+                           (T1r[T_BNE] > 0 && (T1r[T_SR0] != T0[T_R0] || T1r[T_SN] != T0[T_N]))))
+                return CWN_ERR_BAD_ARG;
+        } else {
+            if (r[I_CN] != 0 || r[I_UNE] != 0 || nt > 1) return CWN_ERR_BAD_ARG;
+        }
+        const int64_t r1 = nc > 0 ? (pad16(n0) + ng - 1) / ng * ng : pad16(n0);
+        const int64_t rows = nc > 0 ? r1 + pad16(nc) : pad16(n0);
+        const int64_t b1 = pad4(une), b2 = pad4(b1 + bne[0]), total = pad4(b2 + bne[1]);
+        if (r[I_R1] != r1 || r[I_ROWS] != rows || r[I_B1] != b1 || r[I_B2] != b2 || r[I_TOTAL] != total) return CWN_ERR_BAD_ARG;
+        if (rows > plan->max_gemm_rows || sn > plan->max_source_rows || total > CWN_LAYER_MAX_ENTRIES) return CWN_ERR_BAD_ARG;
+    }
+    return cwn_layer_fused_lds_bytes(F, plan->max_gemm_rows, plan->max_source_rows) != 0 ? CWN_OK : CWN_ERR_BAD_ARG;
 }
 
 extern "C" size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows) {

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 8
+#define CWN_ABI_VERSION 9
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -208,17 +208,25 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  *   [1] g          [2] first cell of dim g   [3] number of cells of dim g
  *   [4] first cell of dim g+1                [5] number of cells of dim g+1
  *   [6] first entry of up_index_g            [7] number of entries
- *   [8] number of tasks (1 or 2); task t at [9 + 7 t]:
+ *   [8] number of tasks (0 = empty record, the workgroup leaves at once; 1 or 2); task t at [9 + 7 t],
+ *       all seven fields 0 for an absent task:
  *       +0 dim d  +1 first cell  +2 number of cells (outputs out_up_d / out_b_d of these rows)
  *       +3 first entry of b_index_d  +4 number of entries
- *       +5 first cell of dim d-1     +6 number of cells of dim d-1      (boundary sources)
+ *       +5 first cell of dim d-1     +6 number of cells of dim d-1 (boundary sources; 0 when the task has
+ *          no boundary entries: sources are staged only when read)
+ *   [23] R1: first staged row of the cells of g+1 = 16*ceil(n_g/16) rounded up to a multiple of
+ *        cwn_layer_round_rows(F) (16*ceil(n/16) when there are no cells of g+1)
+ *   [24] staged rows = R1 + 16*ceil(n_{g+1}/16) (16*ceil(n/16) without cells of g+1)
+ *   [25] b1 = entries of up_index padded to 4   [26] b2 = (b1 + boundary entries of task 0) padded to 4
+ *   [27] total = (b2 + boundary entries of task 1) padded to 4          [28..31] 0
+ *   The derived fields [23..27] are part of the record so that sixteen waves do not each re-derive them;
+ *   cwn_layer_items_check validates a host copy of the table (derived fields, ranges against the plan's
+ *   summary, caps).  Without bit 0 of [0], fields [4..7] are 0.
  *   A task whose dim is g reduces the upper adjacency out of LDS; any other task must belong to a
- *   dimension without upper adjacency (out_up = self term); the GEMM dimension is task 0.  Limits
- *   per item: staged rows R1 + 16*ceil(n_{g+1}/16) <= CWN_LAYER_GEMM_ROWS(F), where R1 is
- *   16*ceil(n_g/16) rounded up to a multiple of 2048/F (for an item without GEMM: 16*ceil(n/16));
- *   boundary-source cells of its tasks together <= CWN_LAYER_SOURCE_ROWS(F); LDS of both within
- *   160 KiB (cwn_layer_fused_lds_bytes); cells per task <= CWN_LAYER_TASK_ROWS; entries of all its
- *   adjacencies together (each padded to a multiple of 4) <= CWN_LAYER_MAX_ENTRIES.
+ *   dimension without upper adjacency (out_up = self term); the GEMM dimension is task 0, a second task is
+ *   the block of g+1.  Limits per item: staged rows <= CWN_LAYER_GEMM_ROWS(F); boundary-source cells of its
+ *   tasks together <= CWN_LAYER_SOURCE_ROWS(F); LDS of both within 160 KiB (cwn_layer_fused_lds_bytes);
+ *   cells per task <= CWN_LAYER_TASK_ROWS; total <= CWN_LAYER_MAX_ENTRIES.
  * An index that leaves its item's ranges (the batch is not block-diagonal, or the table does not
  * belong to it) sets bit 3 of *err_flag (the sticky word of cwn_csr_build) and is clamped.
  * F must be 64 or 128; every pointer 16-B aligned; one launch, no workspace, no host sync.
@@ -284,6 +292,11 @@ typedef struct cwn_layer_plan {
 
 int cwn_layer_fused_f32(const cwn_layer_dim* dims_host, int n_dims, int32_t F, const cwn_layer_plan* plan_host,
                         int32_t flags, int32_t* err_flag, cwn_stream_t stream);
+/* HOST check of a host copy of the item table against its plan (record layout above): CWN_OK or
+ * CWN_ERR_BAD_ARG.  The kernel re-checks only what keeps a workgroup inside its LDS. */
+int cwn_layer_items_check(const int32_t* items_host, int64_t n_items, int32_t F, const cwn_layer_plan* plan_host);
+/* rows a workgroup stages per round (threads / (F / 4)): the coface block of an item starts at a multiple of it */
+int32_t cwn_layer_round_rows(int32_t F);
 /* dynamic LDS bytes such a launch uses, 0 for unsupported arguments or more than 160 KiB */
 size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows);
 

@@ -55,8 +55,7 @@ print(f'items {items.size(0)}  rows_cap {mr}  src_cap {ms}  lds {L.cwn_layer_fus
 st = stamps.cpu().numpy().astype(np.int64)
 it = items.cpu().numpy()
 names = ['item+issue loads', 'entries->LDS', 'rank', 'rowptr+split+stage', 'boundary+self', 'MFMA', 'Y write', 'upper reduce']
-t0 = st[:, 0].min()
-print(f'start spread: {(st[:, 0].max() - t0)} ticks; kernel span (first start -> last end): {st[:, :9].max() - t0} ticks')
+# (the shader-clock counters of different XCDs are not synchronised: no chip-wide span from the stamps)
 n1 = it.shape[0] // REP
 rnd = np.arange(it.shape[0]) // n1
 for kind, mask in [(f'g={g} items, round {r}', (it[:, 0] & 1 == 1) & (it[:, 1] == g) & (rnd == r)) for r in range(REP) for g in (0, 1)]:
