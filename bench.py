@@ -392,8 +392,9 @@ def main():
             try:
                 with open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as fh:
                     tj = json.load(fh)
-                if WL == 'zinc' and tj.get('hidden') == H and str(args.batch) in tj['entries']:
-                    traffic = tj['entries'][str(args.batch)]['traffic_bytes']
+                ent = tj['entries'].get(str(args.batch))
+                if WL == 'zinc' and tj.get('hidden') == H and ent and ent.get('kernel', '').startswith('layer_kernel'):
+                    traffic = ent['traffic_bytes']
             except (OSError, ValueError, KeyError):
                 traffic = None
             gbs = alg / (load_us * 1e-6) / 1e9
@@ -462,10 +463,11 @@ def main():
             # workload shape); None when no pass exists for this configuration
             traffic = None
             try:
-                with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as fh:
+                with open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as fh:
                     tj = json.load(fh)
-                if WL == 'zinc' and tj.get('hidden') == H and str(args.batch) in tj['entries']:
-                    traffic = tj['entries'][str(args.batch)]['traffic_bytes']
+                ent = tj['entries'].get(str(args.batch))
+                if WL == 'zinc' and tj.get('hidden') == H and ent and ent.get('kernel', '').startswith('aggregate_kernel'):
+                    traffic = ent['traffic_bytes']
             except (OSError, ValueError, KeyError):
                 traffic = None
             r_agg = {'bound': 'hbm', 'kernel': 'aggregate_kernel<4> (fused gather-message-reduce, all dims of a layer)',
@@ -479,7 +481,7 @@ def main():
             # streams as MI355X_MICROARCH.md prescribes, WRITE_SIZE as is), K <= 128 wide-tile kernel
             gemm_traffic = None
             try:
-                with open(os.path.join(ROOT, 'profiles', 'r1_pmc_fetch_write_raw.json')) as fh:
+                with open(os.path.join(ROOT, 'profiles', 'r2_pmc_fetch_write_raw.json')) as fh:
                     raw = json.load(fh).get(str(args.batch), {})
                 if WL == 'zinc' and H == 128:
                     for kname, v in raw.items():

@@ -68,7 +68,7 @@ using cwn::frag_cd;
 #define CWN_LAYER_THREADS 1024
 #endif
 #ifndef CWN_LAYER_WEARLY
-#define CWN_LAYER_WEARLY 2                  // k-steps of the packed weight requested before the item record arrives
+#define CWN_LAYER_WEARLY -1                 // k-steps of the packed weight requested before the item record arrives (-1: half)
 #endif
 #ifndef CWN_LAYER_WBAR
 #define CWN_LAYER_WBAR 1                    // line the waves up between the row loads and the weight loads
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     const int ct = wave % G::kNCT, w2 = wave / G::kNCT;
     const int my_h = kHS == 2 ? (w2 & 1) : 0, rt_par = w2 / kHS;   // this wave's product (kHS == 2), row-tile parity
     uint4 wsp[2 / kHS][G::kKS][3];
-    constexpr int kWEarly = CWN_LAYER_WEARLY < G::kKS ? CWN_LAYER_WEARLY : G::kKS;
+    constexpr int kWEarly = CWN_LAYER_WEARLY < 0 ? G::kKS / 2 : (CWN_LAYER_WEARLY < G::kKS ? CWN_LAYER_WEARLY : G::kKS);
     __builtin_amdgcn_sched_barrier(0);       // both record loads leave before the scalar load below is waited for
     const uint64_t wp_bits =
         ((const __attribute__((address_space(4))) uint64_t*)__builtin_amdgcn_kernarg_segment_ptr())[set * kSetFields + S_WP];
@@ -597,7 +597,9 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
             const int row = gq + i * G::kNG;
-            if (has_gemm && row < rows_pad) {
+            // padding rows of a tile are left as they are: a column of the X operand reaches only its own
+            // column of the product, and no entry names a padding row
+            if (has_gemm && (row < g_n || (row >= R1 && row < R1 + c_n))) {
                 uint2 ph, pm, pl;
                 cwn::split4(xv[i], ph, pm, pl);
                 uint16_t* dst = planes + (size_t)row * G::kPlaneStride + f;
@@ -910,6 +912,8 @@ extern "C" int cwn_layer_items_check(const int32_t* items, int64_t n_items, int3
         const int64_t rows = nc > 0 ? r1 + pad16(nc) : pad16(n0);
         const int64_t b1 = pad4(une), b2 = pad4(b1 + bne[0]), total = pad4(b2 + bne[1]);
         if (r[I_R1] != r1 || r[I_ROWS] != rows || r[I_B1] != b1 || r[I_B2] != b2 || r[I_TOTAL] != total) return CWN_ERR_BAD_ARG;
+        for (int k = I_TOTAL + 1; k < CWN_LAYER_ITEM_INTS; ++k)
+            if (r[k] != 0) return CWN_ERR_BAD_ARG;
         if (rows > plan->max_gemm_rows || sn > plan->max_source_rows || total > CWN_LAYER_MAX_ENTRIES) return CWN_ERR_BAD_ARG;
     }
     return cwn_layer_fused_lds_bytes(F, plan->max_gemm_rows, plan->max_source_rows) != 0 ? CWN_OK : CWN_ERR_BAD_ARG;

@@ -87,7 +87,7 @@ CSR_REUSE = True              # blocked layer kernel: sort a batch's adjacencies
 # One workgroup per item and one item per CU at a time: the blocked kernel wins while the items fit the chip
 # a few times over (measured on ZINC-like batches, M cells/s blocked vs CSR path: 256 complexes 594 vs 423,
 # 512: 695 vs 588, 2048: 796 vs 886, 8192: 871 vs 973); beyond that the two-kernel path's streaming wins.
-BLOCKED_MAX_ITEMS = 1400
+BLOCKED_MAX_ITEMS = int(os.environ.get('CWN_BLOCKED_MAX_ITEMS', '1400'))
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
 _BLOCKED_CACHE = weakref.WeakKeyDictionary()
 

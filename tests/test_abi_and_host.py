@@ -345,3 +345,47 @@ def test_three_way_bf16_split_is_exact_numpy_model():
     # and the residuals are not of one sign (the truncating split of round 1 had a bias)
     nz = np.abs(kept - exact) > 0
     assert 0.3 < np.mean((kept - exact)[nz] > 0) < 0.7
+
+
+def test_item_table_derived_fields_and_host_check():
+    """cwn_amd/blockplan.py writes the derived record fields the layer kernel reads instead of re-deriving
+    them (include/cwn_hip.h: R1, staged rows, entry segments); cwn_layer_items_check accepts the builder's
+    tables and rejects every single-field corruption that changes what the kernel would do."""
+    import numpy as np
+    from cwn_amd import _ffi
+    from cwn_amd.blockplan import BlockPlan, ITEM_INTS
+    from cwn_amd.synthetic import zinc_like_batch
+    L = _ffi.lib()
+    b = zinc_like_batch(24, seed=5)
+    plan = BlockPlan.from_batch(b)
+    for F in (64, 128):
+        ng = L.cwn_layer_round_rows(F)
+        assert ng == 1024 // (F // 4) or ng == 512 // (F // 4)
+        t = plan.items(F, [True, True, False])
+        tab = t.items.numpy()
+        assert tab.shape[1] == ITEM_INTS and t.n_items == tab.shape[0]
+        cplan = t.c_plan(False)
+        assert L.cwn_layer_items_check(tab.ctypes.data, tab.shape[0], F, cplan) == 0
+        pad16 = lambda n: (n + 15) // 16 * 16
+        pad4 = lambda n: (n + 3) // 4 * 4
+        for r in tab:
+            n0, nc, une = int(r[11]), int(r[5]), int(r[7])
+            r1 = (pad16(n0) + ng - 1) // ng * ng if nc > 0 else pad16(n0)
+            assert r[23] == r1 and r[24] == (r1 + pad16(nc) if nc > 0 else pad16(n0))
+            assert r[25] == pad4(une) and r[26] == pad4(r[25] + r[13]) and r[27] == pad4(r[26] + r[20])
+            assert not r[28:].any()
+            for t_ in range(2):                    # sources are staged only when the task has boundary entries
+                o = 9 + 7 * t_
+                assert (r[o + 6] > 0) == (r[o + 4] > 0)
+        rng = np.random.default_rng(0)
+        for col in (3, 5, 7, 11, 13, 15, 23, 24, 25, 26, 27, 28):
+            bad = tab.copy()
+            bad[rng.integers(0, tab.shape[0]), col] += 4
+            assert L.cwn_layer_items_check(bad.ctypes.data, bad.shape[0], F, cplan) != 0, col
+        neg = tab.copy()
+        neg[0, 11] = -1
+        assert L.cwn_layer_items_check(neg.ctypes.data, neg.shape[0], F, cplan) != 0
+        assert L.cwn_layer_items_check(tab.ctypes.data, tab.shape[0] - 1, F, cplan) != 0      # n_items mismatch
+        empty = np.zeros((3, ITEM_INTS), dtype=np.int32)                                       # static-graph filler
+        cplan.n_items = 3
+        assert L.cwn_layer_items_check(empty.ctypes.data, 3, F, cplan) == 0
