@@ -199,7 +199,14 @@ def check(code: int, what: str):
         raise CwnError(f'{what}: {lib().cwn_error_string(code).decode()} (code {code})')
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr(device=None) -> int:
+    """The current HIP stream of `device` as an integer handle (the raw getter costs ~0.2 us, the Stream
+    object ~2 us per call)."""
+    if _raw_stream is not None and isinstance(device, torch.device) and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -76,7 +76,7 @@ class Cochain(object):
     @x.setter
     def x(self, new_x):
         if new_x is not None:
-            assert self.num_cells == len(new_x)
+            assert self.num_cells == (new_x.size(0) if torch.is_tensor(new_x) else len(new_x))
         self._x = new_x
 
     @property
@@ -373,35 +373,37 @@ class Complex(object):
     # ---- propagate arguments ------------------------------------------------------------------
     def get_cochain_params(self, dim: int, max_dim: int = 2, include_top_features=True,
                            include_down_features=True,
-                           include_boundary_features=True) -> CochainMessagePassingParams:
+                           include_boundary_features=True, _plan=False) -> CochainMessagePassingParams:
         """data/complex.py:548-602."""
         if dim not in self.cochains:
             raise NotImplementedError(f'Dim {dim} is not present in the complex or not yet supported.')
-        cells = self.cochains[dim]
-        x = cells.x
+        cochains = self.cochains
+        cells = cochains[dim]
+        x = cells._x
+        lazy = self.lazy_attrs
 
         def rows(src, index):
-            if self.lazy_attrs:
-                return IndexedRows(src, index)
             from . import ops
             return ops.gather_rows(src, index)   # HIP gather kernel; GPU only, like everything else
 
         upper_index, upper_features = None, None
-        if cells.upper_index is not None and (dim + 1) in self.cochains:
+        up_c = cochains.get(dim + 1)
+        if cells.upper_index is not None and up_c is not None:
             upper_index = cells.upper_index
-            xu = self.cochains[dim + 1].x
+            xu = up_c._x
             if xu is not None and (dim < max_dim or include_top_features):
-                upper_features = rows(xu, cells.shared_coboundaries)
+                upper_features = IndexedRows(xu, cells.shared_coboundaries) if lazy else rows(xu, cells.shared_coboundaries)
         lower_index, lower_features = None, None
+        down_x = cochains[dim - 1]._x if dim > 0 else None
         if include_down_features and cells.lower_index is not None:
             lower_index = cells.lower_index
-            if dim > 0 and self.cochains[dim - 1].x is not None:
-                lower_features = rows(self.cochains[dim - 1].x, cells.shared_boundaries)
+            if down_x is not None:
+                lower_features = IndexedRows(down_x, cells.shared_boundaries) if lazy else rows(down_x, cells.shared_boundaries)
         boundary_index, boundary_features = None, None
         if include_boundary_features and cells.boundary_index is not None:
             boundary_index = cells.boundary_index
-            if dim > 0 and self.cochains[dim - 1].x is not None:
-                boundary_features = self.cochains[dim - 1].x
+            if down_x is not None:
+                boundary_features = down_x
         params = CochainMessagePassingParams(x, upper_index, lower_index, up_attr=upper_features,
                                              down_attr=lower_features,
                                              boundary_attr=boundary_features,
@@ -410,11 +412,11 @@ class Complex(object):
         # next dimension's boundary_index (row 0 = a cell of THIS dimension, row 1 = its coface) and the
         # cofaces' features.  Plain attributes: the reference's kwargs are left as they are.
         params.coboundary_index = params.coboundary_attr = None
-        if (dim + 1) in self.cochains and self.cochains[dim + 1].boundary_index is not None:
-            params.coboundary_index = self.cochains[dim + 1].boundary_index
-            params.coboundary_attr = self.cochains[dim + 1].x
+        if up_c is not None and up_c.boundary_index is not None:
+            params.coboundary_index = up_c.boundary_index
+            params.coboundary_attr = up_c._x
         params.num_cells = cells.num_cells   # engine extension: sizes without a device sync
-        params.block_plan = self.block_plan()  # engine extension: the batch's item table (or None)
+        params.block_plan = self.block_plan() if _plan is False else _plan  # engine extension: the batch's item table (or None)
         return params
 
     def block_plan(self):
@@ -436,10 +438,11 @@ class Complex(object):
                                include_down_features=True,
                                include_boundary_features=True) -> List[CochainMessagePassingParams]:
         """data/complex.py:604-626."""
+        plan = self.block_plan()
         return [self.get_cochain_params(d, max_dim=max_dim,
                                         include_top_features=include_top_features,
                                         include_down_features=include_down_features,
-                                        include_boundary_features=include_boundary_features)
+                                        include_boundary_features=include_boundary_features, _plan=plan)
                 for d in range(min(max_dim, self.dimension) + 1)]
 
     def get_labels(self, dim=None):

@@ -85,9 +85,10 @@ FUSED_DENSE_TRAINING = True   # set False to run the update / combine networks a
 BLOCKED_LAYER = os.environ.get('CWN_BLOCKED_LAYER') != '0'   # False: propagate scope as grouped GEMM + CSR aggregation
 CSR_REUSE = True              # blocked layer kernel: sort a batch's adjacencies once, later layers load the result
 # One workgroup per item and one item per CU at a time: the blocked kernel wins while the items fit the chip
-# a few times over (measured on ZINC-like batches, M cells/s blocked vs CSR path: 256 complexes 594 vs 423,
-# 512: 695 vs 588, 2048: 796 vs 886, 8192: 871 vs 973); beyond that the two-kernel path's streaming wins.
-BLOCKED_MAX_ITEMS = int(os.environ.get('CWN_BLOCKED_MAX_ITEMS', '1400'))
+# a few times over (measured on ZINC-like batches, tools/range_of_use.sh, M cells/s blocked vs CSR path: 256
+# complexes 646 vs 428, 512: 761 vs 588, 1024: 788 vs 759, 2048: 836 vs 900, 8192: 863 vs 981); beyond
+# ~2600 items (two per complex) the two-kernel path's streaming wins.
+BLOCKED_MAX_ITEMS = int(os.environ.get('CWN_BLOCKED_MAX_ITEMS', '2600'))
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
 _BLOCKED_CACHE = weakref.WeakKeyDictionary()
 
@@ -613,9 +614,8 @@ class SparseCINConv(torch.nn.Module):
         ent = None
         if plan is not None and BLOCKED_LAYER and not ops.GEMM_EXACT and start_to_process == 0:
             # fast path: everything about (this layer, this batch) that does not change between calls was
-            # checked and laid out once (`_blocked_args`); per call only the feature tensors are looked at
-            ckey = (id(plan),) + tuple(id(t) for c in cochain_params for t in
-                                       (c.up_index, c.boundary_index, getattr(c.kwargs.get('up_attr'), 'index', None)))
+            # checked and laid out once (`_blocked_args`); per call only identities and the features are looked at
+            ckey = id(plan)
             ent = _BLOCKED_CACHE.get(self, {}).get(ckey)
             if ent is not None and not self._blocked_still_valid(ent, cochain_params):
                 ent = None
@@ -625,7 +625,10 @@ class SparseCINConv(torch.nn.Module):
                 self.blocked_reason = args
                 return None
             dims, plan, table, key = args
+            ckey = id(plan)
             ent = dict(plan=plan, table=table, key=key, F=int(dims[0].x.size(1)),
+                       idx=[(c.up_index, c.boundary_index, getattr(c.kwargs.get('up_attr'), 'index', None))
+                            for c in cochain_params],
                        lins=[(d, self.mp_levels[d].msg_up_nn[1]) for d, D in enumerate(dims) if D.msg_w_packed is not None],
                        wver=[self.mp_levels[d].msg_up_nn[1].weight._version for d, D in enumerate(dims)
                              if D.msg_w_packed is not None],
@@ -656,7 +659,12 @@ class SparseCINConv(torch.nn.Module):
                                         or any(c.x.requires_grad for c in cochain_params)):
             return False
         F, n = ent['F'], len(cochain_params)
+        if n != len(ent['idx']) or cochain_params[0].block_plan is not ent['plan']:
+            return False
         for d, c in enumerate(cochain_params):
+            up, bi, sh = ent['idx'][d]
+            if c.up_index is not up or c.boundary_index is not bi or getattr(c.kwargs.get('up_attr'), 'index', None) is not sh:
+                return False          # other index tensors than the prepared launch points at
             x = c.x
             if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != F:
                 return False

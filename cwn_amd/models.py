@@ -131,8 +131,10 @@ class _SparseCINStack(torch.nn.Module):
         self.dropout_rate = dropout_rate
         self.apply_dropout_before = apply_dropout_before
         self.jump_mode = jump_mode
-        if jump_mode not in (None, 'cat'):
-            raise NotImplementedError("jump_mode must be None or 'cat'")
+        # torch_geometric's JumpingKnowledge as the reference constructs it (mp/models.py:351: no `channels`,
+        # so 'lstm' cannot be built there either): 'cat' and the elementwise 'max' over the layers
+        if jump_mode not in (None, 'cat', 'max'):
+            raise NotImplementedError("jump_mode must be None, 'cat' or 'max'")
         self.nonlinearity = nonlinearity
         self.readout = readout
         self.graph_norm = get_graph_norm(graph_norm)
@@ -173,8 +175,10 @@ class _SparseCINStack(torch.nn.Module):
                     jump_xs = [[] for _ in xs]
                 for i, x in enumerate(xs):
                     jump_xs[i] += [x]
-        if self.jump_mode is not None:
+        if self.jump_mode == 'cat':
             xs = [torch.cat(j, dim=-1) for j in jump_xs]
+        elif self.jump_mode == 'max':
+            xs = [torch.stack(j, dim=-1).max(dim=-1)[0] for j in jump_xs]
         pooled = pool_complex_list(xs, data, self.max_dim, self.readout)
         xs = [pooled[i] for i in self.readout_dims]
         if include_partial:

@@ -841,31 +841,34 @@ class LayerLaunch:
                                         n_b=0 if bi is None else int(bi.size(1)))
             self.rows.append(int(D.x.size(0)))
         self.total_rows = sum(self.rows)
+        self._sizes = [r for r in self.rows for _ in range(2)]          # rows of out_up_d, out_b_d, in output order
+        self._off = [sum(self._sizes[:i]) for i in range(len(self._sizes))]
         self.dev = dims[0].x.device
         self._plans = {}
         from .csr import _err_flag
         self.err = _err_flag(self.dev)
+        self._err_ptr = self.err.data_ptr()
         self.fn = _ffi.lib().cwn_layer_fused_f32
 
     def run(self, xs: Sequence[Tensor], csr_mode: int = 0) -> List[Tensor]:
         F = self.F
         buf = torch.empty(2 * self.total_rows, F, dtype=torch.float32, device=self.dev)   # all six outputs
-        outs, off = [], 0
+        outs = buf.split(self._sizes)                       # one call: [out_up_0, out_b_0, out_up_1, ...]
+        base, row_b = buf.data_ptr(), 4 * F
         for d in range(self.n):
             x = xs[d]
             if not x.is_contiguous():
                 x = x.contiguous()
             if x.size(0) != self.rows[d]:
                 raise ValueError('feature rows do not match the batch this launch was prepared for')
-            r = self.rows[d]
-            out_up, out_b = buf[off:off + r], buf[off + r:off + 2 * r]
-            off += 2 * r
             a = self.arr[d]
-            a.x, a.out_up, a.out_b = x.data_ptr(), out_up.data_ptr(), out_b.data_ptr()
-            outs += [out_up, out_b]
+            a.x = x.data_ptr()
+            a.out_up = base + self._off[2 * d] * row_b
+            a.out_b = base + self._off[2 * d + 1] * row_b
         plan = self._plans.get(csr_mode != 0)
         if plan is None:
             plan = self._plans[csr_mode != 0] = self.table.c_plan(with_cache=csr_mode != 0)
-        _ffi.check(self.fn(self.arr, self.n, F, plan, int(csr_mode), self.err.data_ptr(), _ffi.stream_ptr(self.dev)),
-                   'cwn_layer_fused_f32')
-        return outs
+        rc = self.fn(self.arr, self.n, F, plan, int(csr_mode), self._err_ptr, _ffi.stream_ptr(self.dev))
+        if rc != 0:
+            _ffi.check(rc, 'cwn_layer_fused_f32')
+        return list(outs)

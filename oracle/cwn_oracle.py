@@ -446,7 +446,7 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
                              init_reduce_mode: str = 'add', readout_dims=(0, 1, 2)):
     """SparseCIN.forward (mp/models.py:195-260), EmbedSparseCIN.forward (mp/molec_models.py:90-160)
     and OGBEmbedSparseCIN.forward (mp/molec_models.py:281-350) with dropout off and jump_mode in
-    {None, 'cat'}.  `embed`: None (features used as they are), 'zinc' (one Embedding per dimension
+    {None, 'cat', 'max'}.  `embed`: None (features used as they are), 'zinc' (one Embedding per dimension
     0/1) or 'ogb' (sum of per-column embeddings).  Returns (out, per-layer / pooled tensors)."""
     cx = {'dimension': cx['dimension'], 'y': cx.get('y'), 'num_complexes': cx.get('num_complexes'),
           'cochains': [dict(c) for c in cx['cochains']]}
@@ -482,8 +482,14 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
             jump = [[] for _ in xs] if jump is None else jump
             for d, x in enumerate(xs):
                 jump[d].append(x)
-    if jump_mode is not None:
+    if jump_mode == 'cat':
         xs = [torch.cat(j, dim=-1) for j in jump]
+    elif jump_mode == 'max':
+        # torch_geometric.nn.JumpingKnowledge('max') (torch_geometric is not in /root/reference nor in this
+        # image: its published forward is `torch.stack(xs, dim=-1).max(dim=-1)[0]`; parity unpinned for this mode)
+        xs = [torch.stack(j, dim=-1).max(dim=-1)[0] for j in jump]
+    elif jump_mode is not None:
+        raise NotImplementedError(jump_mode)
     nb = cx.get('num_complexes') or int(cx['cochains'][0]['batch'].max()) + 1
     pooled = pool_complex(xs, [cx['cochains'][d]['batch'] for d in range(len(xs))], nb, max_dim, readout)
     dims = [d for d in readout_dims if d <= max_dim]

@@ -780,6 +780,34 @@ def test_molhiv_like_full_size_vs_oracle():
     gate(y, ref, 'molhiv-512 prediction vs float64 oracle')
 
 
+def test_jumping_knowledge_max_vs_oracle():
+    """mp/models.py:51, 92-99 with jump_mode='max' (torch_geometric's JumpingKnowledge('max'): elementwise
+    maximum over the layers' outputs, per dimension).  The oracle restates the published one-liner; no
+    reference-generated fixture exists for it (torch_geometric is absent): parity unpinned, stated."""
+    from cwn_amd.models import SparseCIN
+    torch.manual_seed(3)
+    model = SparseCIN(1, 2, 3, 16, dropout_rate=0.0, max_dim=2, jump_mode='max', readout='sum',
+                      use_coboundaries=True, graph_norm='id').eval()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    b = dummy_batch(list_names('testing'), max_dim=2)
+    g = torch.Generator().manual_seed(5)
+    for d in range(3):
+        b.cochains[d].x = torch.randn(b.cochains[d].num_cells, 1, generator=g)
+    ocx = _oracle_cx(b)
+    for c in ocx['cochains']:
+        c['x'] = c['x'].double()
+    ref, rpart = O.sparse_cin_model_forward(to_double(state), ocx, 3, use_coboundaries=True, norm='id',
+                                            jump_mode='max', embed=None)
+    model = model.to(DEV)
+    with torch.no_grad():
+        y, res = model(b.to(DEV), include_partial=True)
+    for k, v in rpart.items():
+        gate(res[k], v, f'JK-max {k} vs float64 oracle')
+    gate(y, ref, 'JK-max prediction vs float64 oracle')
+    with pytest.raises(NotImplementedError):
+        SparseCIN(1, 2, 3, 16, jump_mode='lstm')
+
+
 def test_reddit_like_full_size_vs_oracle():
     """BASELINE config 5: REDDIT-like clique complexes (hubs of degree >= 100: skewed segments,
     F = 1 inputs), SparseCIN hidden 64, 4 layers, no coboundaries, norm id, JK cat, batch 32."""
@@ -1432,6 +1460,40 @@ def test_model_training_forward_backward_matches_torch_modules():
     # relative L2 distance of the whole gradient: robust to an isolated ReLU-kink tie
     rel = float((g1 - g2).norm() / g2.norm())
     assert rel < 2e-3, rel
+
+
+def test_model_training_gradients_match_float64_oracle_autograd():
+    """An independent pin of the fused training path (BatchNorm statistics in the GEMM epilogue, MFMA weight
+    gradients, aggregation backward, embedding backward): every parameter gradient of a train-mode
+    EmbedSparseCIN step against torch autograd run over the ORACLE's forward in float64 on the CPU --
+    not against torch modules on the same GPU."""
+    model, bs = _train_setup(seed=6, hidden=32, nb=1)
+    b = bs[0]
+    model.train()
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ocx = _oracle_cx(b)
+    leaves = {k: v.double().requires_grad_(True) for k, v in state.items() if v.is_floating_point() and 'running' not in k}
+    ostate = dict(to_double(state))
+    ostate.update(leaves)
+    ref_out, _ = O.sparse_cin_model_forward(ostate, ocx, 2, use_coboundaries=True, training=True, norm='bn', embed='zinc')
+    y = cpu(b.y).double().view(-1, 1)
+    ref_loss = (ref_out - y).abs().mean()
+    ref_loss.backward()
+    x0 = [None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3)]
+    loss = (model(b) - b.y.view(-1, 1)).abs().mean()
+    loss.backward()
+    for d in range(3):
+        b.cochains[d]._x = x0[d]
+    gate(loss.detach().view(1), ref_loss.detach().view(1), 'train-mode loss vs float64 oracle')
+    worst = 0.0
+    for name, p in model.named_parameters():
+        r = leaves[name].grad
+        if r is None:            # a parameter the loss does not reach (e.g. an unused embedding row table)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        worst = max(worst, gate(p.grad, r, f'grad {name}', tol=2e-5))
+    print(f'[gate] training gradients vs float64 oracle autograd: worst max|delta| = {worst:.3e}')
 
 
 def test_train_step_two_graph_form_used_under_data_parallelism():

@@ -8,7 +8,7 @@ TAG=${1:-x}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q 2>&1 | tail -1 | tee "$OUT/r2_${TAG}_pytest_gpu.txt"
+python -m pytest tests -m gpu -q -rP 2>&1 | grep -E "^\[gate\]|^\[invariance\]| passed| failed|^FAILED|^ERROR" > "$OUT/r2_${TAG}_pytest_gpu.txt"; tail -1 "$OUT/r2_${TAG}_pytest_gpu.txt"
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 python bench.py > "$OUT/r2_${TAG}_bench_zinc.json" 2> "$OUT/bench_zinc.err"
 python bench.py --workload molhiv > "$OUT/r2_${TAG}_bench_molhiv.json" 2> /dev/null

@@ -6,7 +6,7 @@ TAG=${1:-x}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q 2>&1 | tail -1 | tee "$OUT/r2_${TAG}_pytest_gpu.txt"
+python -m pytest tests -m gpu -q -rP 2>&1 | grep -E "^\[gate\]|^\[invariance\]| passed| failed|^FAILED|^ERROR" > "$OUT/r2_${TAG}_pytest_gpu.txt"; tail -1 "$OUT/r2_${TAG}_pytest_gpu.txt"
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 python bench.py > "$OUT/r2_${TAG}_bench_zinc.json" 2> /dev/null
 CWN_BENCH_SKIP=eager,concurrent,train python bench.py --batch 8192 --num-batches 1 --steps 20 --warmup 3 --no-cpu > "$OUT/r2_${TAG}_bench_zinc_batch8192.json" 2> /dev/null
