@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include "../../include/cwn_hip.h"
+#include "cwn_mem.h"
 
 namespace {
 
@@ -59,7 +60,7 @@ __device__ __forceinline__ Acc<VEC> ld(const float* p) {
 template <int VEC>
 __device__ __forceinline__ void st(float* p, const Acc<VEC>& a) {
     if constexpr (VEC == 4) {
-        *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+        cwn::store_result4(p, a.v[0], a.v[1], a.v[2], a.v[3]);
     } else if constexpr (VEC == 2) {
         *reinterpret_cast<float2*>(p) = make_float2(a.v[0], a.v[1]);
     } else {

@@ -32,6 +32,7 @@
 #include <mutex>
 #include <stdlib.h>
 #include "../../include/cwn_hip.h"
+#include "cwn_mem.h"
 
 namespace {
 
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             const bool full = n0 + 3 < N;
             if (ra < M && n0 < N) {
                 float* yp = D.Y + ra * ldy + n0;
-                if (full && vec) *reinterpret_cast<f32x4*>(yp) = va;
+                if (full && vec) cwn::store_result4(yp, va[0], va[1], va[2], va[3]);
                 else
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             }
             if (rb < M && n0 < N) {
                 float* yp = D.Y + rb * ldy + n0;
-                if (full && vec) *reinterpret_cast<f32x4*>(yp) = vb;
+                if (full && vec) cwn::store_result4(yp, vb[0], vb[1], vb[2], vb[3]);
                 else
 #pragma unroll
                     for (int r = 0; r < 4; ++r)

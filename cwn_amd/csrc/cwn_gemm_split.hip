@@ -27,6 +27,7 @@
 #include <stdint.h>
 #include "../../include/cwn_hip.h"
 #include "cwn_split.h"
+#include "cwn_mem.h"
 
 namespace {
 
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) y[q] = fmaxf(y[q], 0.0f);
                     }
-                    *reinterpret_cast<float4*>(D.Y + row * D.ldy + n0) = make_float4(y[0], y[1], y[2], y[3]);
+                    cwn::store_result4(D.Y + row * D.ldy + n0, y[0], y[1], y[2], y[3]);
                 }
             }
         }

@@ -15,6 +15,7 @@
 // of a layer) per launch.
 #include <hip/hip_runtime.h>
 #include "../../include/cwn_hip.h"
+#include "cwn_mem.h"
 
 namespace {
 
@@ -116,7 +117,7 @@ __device__ __forceinline__ void ld_vec(float (&v)[VEC], const float* p) {
 
 template <int VEC>
 __device__ __forceinline__ void st_vec(float* p, const float (&v)[VEC]) {
-    if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (VEC == 4) cwn::store_result4(p, v[0], v[1], v[2], v[3]);
     else *p = v[0];
 }
 
