@@ -53,6 +53,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <mutex>
+#include <type_traits>
 #include "../../include/cwn_hip.h"
 #include "cwn_split.h"
 
@@ -113,7 +114,7 @@ struct LayerArgs {
     int32_t xrows_cap;                       // boundary-source rows it holds
     int32_t set_start1, set_start2;          // first workgroup of set 1 / set 2 (items are ordered by set)
 #ifdef CWN_LAYER_TIMING
-    unsigned long long* stamps;              // [n_items][16] shader-clock stamps of workgroup phase ends
+    unsigned long long* stamps;              // [n_items][64]: [0, 16) phase ends seen by wave 0, [16 + 16 k + w] point k of wave w
 #endif
 };
 
@@ -121,10 +122,16 @@ struct LayerArgs {
 #define CWN_STAMP(k)                                                                   \
     do {                                                                               \
         if (threadIdx.x == 0 && A.stamps != nullptr)                                   \
-            A.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();    \
+            A.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
+#define CWN_WSTAMP(k)                                                                  \
+    do {                                                                               \
+        if ((threadIdx.x & 63) == 0 && A.stamps != nullptr)                            \
+            A.stamps[(size_t)blockIdx.x * 64 + 16 + 16 * (k) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define CWN_STAMP(k) do { } while (0)
+#define CWN_WSTAMP(k) do { } while (0)
 #endif
 
 template <int F> struct Geo {
@@ -189,6 +196,10 @@ __device__ __forceinline__ void stg4(gf_p p, const float4& a) {
 __device__ __forceinline__ float4 ldg4o(gcb_p base, uint32_t off) {
     const v4f v = *(gcv4_p)(base + off);
     return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 ldgu4o(gcb_p base, uint32_t off) {
+    const v4u v = *(gcu4_p)(base + off);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void stg4o(gb_p base, uint32_t off, const float4& a) {
     const v4f v = {a.x, a.y, a.z, a.w};
@@ -327,6 +338,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     uint16_t* const rowptr = uval + 5 * kEcap;   // [3][kRpStride]: upper, boundary of task 0, of task 1
 
     CWN_STAMP(0);
+    CWN_WSTAMP(0);           // every wave: when it starts
     // ---- 1. item record and set record: ONE round trip ------------------------------------------------
     // lane l reads word l of the item and 8-byte field l of the set record (the kernel-argument segment
     // is ordinary global memory); fields are broadcast with v_readlane where they are used, so they
@@ -340,7 +352,8 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // address unit of this CU has nothing to do: the first kWEarly k-steps of this wave's slice are requested
     // now, their address from ONE scalar load of the set record's weight field.  (All of it here was
     // measured worse: the rows then queue behind 192 KB.)
-    const int ct = wave % G::kNCT, w2 = wave / G::kNCT;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // wave-uniform: scalar registers from here on
+    const int ct = wave_u % G::kNCT, w2 = wave_u / G::kNCT;
     const int my_h = kHS == 2 ? (w2 & 1) : 0, rt_par = w2 / kHS;   // this wave's product (kHS == 2), row-tile parity
     uint4 wsp[2 / kHS][G::kKS][3];
     constexpr int kWEarly = CWN_LAYER_WEARLY < 0 ? G::kKS / 2 : (CWN_LAYER_WEARLY < G::kKS ? CWN_LAYER_WEARLY : G::kKS);
@@ -350,17 +363,22 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // chunk (ks, plane) of product h and column tile ct is the 1-KiB block number ((ks * 3 + plane) * 2 + h) * kNCT + ct:
     // the waves of a workgroup, which walk their chunks in step, read CONSECUTIVE kilobytes (all L2 channels)
     // instead of sixteen blocks 24 KB apart (a multiple of the channel interleave: the same few channels)
-    const gcb_p wbase = wp_bits != 0 ? (gcb_p)wp_bits + (size_t)ct * 1024 + lane * 16 : (gcb_p)A.items;
-    const int won = wp_bits != 0 ? 1024 : 0;
-    auto wchunk = [&](int h, int ks, int pl) { return wbase + (((ks * 3 + pl) * 2 + h) * G::kNCT) * won; };
+    // address = scalar base of (column tile, product) + one 32-bit offset per lane and chunk (an add each)
+    const gcb_p wbase = wp_bits != 0 ? (gcb_p)wp_bits + (size_t)ct * 1024 : (gcb_p)A.items;
+    const uint32_t won = wp_bits != 0 ? 1024u : 0u;
+    const uint32_t wlane = (uint32_t)lane * 16;
+    auto wload = [&](int h, int ks, int pl) {
+        return ldgu4o(wbase, wlane + (uint32_t)(((ks * 3 + pl) * 2 + h) * G::kNCT) * won);
+    };
 #pragma unroll
     for (int hh = 0; hh < 2 / kHS; ++hh) {
         const int h = kHS == 2 ? my_h : hh;
 #pragma unroll
         for (int ks = 0; ks < kWEarly; ++ks)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wsp[hh][ks][pl] = ldgu4(wchunk(h, ks, pl));
+            for (int pl = 0; pl < 3; ++pl) wsp[hh][ks][pl] = wload(h, ks, pl);
     }
+    __builtin_amdgcn_sched_barrier(0);       // ... and the early weight requests leave before the records are waited for
     const int srec_lo = (int)(uint32_t)srec, srec_hi = (int)(uint32_t)(srec >> 32);
     auto fld = [&](int k) { return __builtin_amdgcn_readlane(itv, k); };
     auto sfld = [&](int k) {
@@ -461,15 +479,18 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         // coface block iff i >= R1 / kNG (R1 is a multiple of kNG): a scalar decision per round.
         const gcb_p xg = (gcb_p)sfld(S_XG) + (size_t)t_r0[0] * kRowB, xc = (gcb_p)sfld(S_XC) + (size_t)fld(I_CR0) * kRowB;
         const gcb_p xs = (gcb_p)sfld(S_TASK0 + ST_XS) + (size_t)fld(I_TASK0 + T_SR0) * kRowB;
-        const int k0 = R1 / G::kNG;
         const int nxr = (rows_pad + G::kNG - 1) / G::kNG, ner = (t_sn[0] + G::kNG - 1) / G::kNG;
+        // Round i belongs to the coface block iff i >= k0 (= R1 / kNG; no coface block: never): base, row
+        // count and first row of the round are chosen by scalar selects, one compare per round
+        const int k0 = c_n > 0 ? R1 / G::kNG : kNX;
+        const uint64_t xg_b = (uint64_t)(uintptr_t)xg, xc_b = (uint64_t)(uintptr_t)xc;
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
             if (i < nxr) {           // a skipped round leaves xv[i] unset: it is never read (rows >= rows_pad)
-                const bool second = c_n > 0 && i >= k0;
-                const int n = second ? c_n : g_n;
-                const int r = min(gq + (second ? i - k0 : i) * G::kNG, n - 1);
-                xv[i] = ldg4o(second ? xc : xg, (uint32_t)r * kRowB + fB);
+                const bool second = i >= k0;
+                const gcb_p base = (gcb_p)(second ? xc_b : xg_b);
+                const int last = (second ? c_n : g_n) - 1, first = (second ? i - k0 : i) * G::kNG;
+                xv[i] = ldg4o(base, (uint32_t)min(gq + first, last) * kRowB + fB);
             }
         }
 #pragma unroll
@@ -484,6 +505,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // lines the waves up) keeps every wave's ROW requests ahead of every wave's weight requests in the
     // address unit's queue -- without it the rows of the wave that issues last arrive behind the weights
     // of the fifteen others, and the split phase waits for most of the weight (measured: 3.3 k cycles).
+    CWN_WSTAMP(1);           // every wave: its row requests are out
     if (CWN_LAYER_WBAR) __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int hh = 0; hh < 2 / kHS; ++hh) {
@@ -491,7 +513,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
 #pragma unroll
         for (int ks = kWEarly; ks < G::kKS; ++ks)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wsp[hh][ks][pl] = ldgu4(wchunk(h, ks, pl));
+            for (int pl = 0; pl < 3; ++pl) wsp[hh][ks][pl] = wload(h, ks, pl);
     }
     CWN_STAMP(1);
 
@@ -627,6 +649,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         }
         if (gq == 0) *reinterpret_cast<float4*>(xsrc + (size_t)x_rows * F + f) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    CWN_WSTAMP(2);           // every wave: its rows are split and staged
     __syncthreads();
     if constexpr (MODE == kSortStore) {     // the finished CSR goes to the cache for the next layers of this batch
         if (tid < kCsrSlot / 16) {

@@ -36,7 +36,7 @@ dims, plan, table, key = args
 items, mr, ms = table.items, table.max_rows, table.max_src
 MODE = int(os.environ.get('MODE', '0'))   # 0 sort, 1 sort + store, 2 load (after one storing launch)
 REP = 1
-stamps = torch.zeros(items.size(0), 16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(items.size(0), 64, dtype=torch.int64, device=dev)
 L.cwn_layer_debug_stamps(stamps.data_ptr())
 with torch.no_grad():
     if MODE == 2:
@@ -71,3 +71,10 @@ for kind, mask in [(f'g={g} items, round {r}', (it[:, 0] & 1 == 1) & (it[:, 1] =
         dd = np.diff(sub, axis=1)
         for k, nm in enumerate(['item record arrives', 'set record (scalar)', 'check + entries/eps/bias issued', 'W issued', 'rows issued']):
             print(f'      - {nm:32s} mean {dd[:, k].mean():8.0f}  max {dd[:, k].max():8d}')
+# per-wave points (16-wave build): when each wave starts, has its row requests out, has its rows staged
+w = st[:, 16:64].reshape(-1, 3, 16)
+if (w[:, 0, :] > 0).all():
+    rel = w - st[:, 0][:, None, None]
+    for k, nm in enumerate(['wave start', 'row requests out', 'rows split + staged']):
+        r = rel[:, k, :]
+        print(f'{nm:22s} per wave, mean over workgroups: ' + ' '.join(f'{v:5.0f}' for v in r.mean(axis=0)) + f'   | last wave mean {r.max(axis=1).mean():.0f}')
