@@ -305,3 +305,42 @@ def test_layers_with_prepared_launches_still_deepcopy_and_pickle():
     pickle.loads(pickle.dumps(conv.state_dict()))
     for r, o in zip(ref, _run(twin, b, blocked=True)):
         assert torch.equal(r, o)
+
+
+def test_blocked_kernel_refuses_records_that_do_not_fit_its_lds():
+    """The derived record fields come from the table builder and are validated on the HOST
+    (cwn_layer_items_check); what the KERNEL still checks is what keeps a workgroup inside its LDS.  A device
+    table tampered with after the host check (staged rows beyond the launch's cap; entries beyond the
+    scratch; a first coface row behind the staged rows) must set the sticky error bit, leave the item's
+    rows unwritten and not fault -- and the other items are still correct."""
+    from cwn_amd import _ffi, csr, ops
+    b = _batch('zinc', 6, 128, seed=21)
+    conv = _conv(128, seed=22)
+    good = [o.clone() for o in _run(conv, b, blocked=True)]
+    params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+    with torch.no_grad():
+        dims, plan, table, key = conv._blocked_args(params, 0)
+    keep = table.items.clone()
+    for col, val in ((24, 4096), (27, 2048), (23, 4000)):
+        table.items.copy_(keep)
+        table.items[1, col] = val                      # item 1 only
+        table.csr_key = None
+        with torch.no_grad():
+            outs = ops.layer_fused(dims, table, 0)
+        with pytest.raises(IndexError):
+            csr.check_errors(DEV)
+        it = keep[1].tolist()
+        r0, n = it[10], it[11]                          # task 0 of item 1: its rows are not trusted
+        mask = torch.ones(outs[0].size(0), dtype=torch.bool, device=DEV)
+        if it[0] >> 8 == 0:
+            mask[r0:r0 + n] = False
+            assert torch.equal(outs[0][mask], good[0][mask]) and torch.equal(outs[1][mask], good[1][mask])
+        for k in range(2, 6):                           # the other dimensions' items are untouched
+            assert torch.equal(outs[k], good[k])
+    table.items.copy_(keep)
+    table.csr_key = None
+    with torch.no_grad():
+        outs = ops.layer_fused(dims, table, 0)
+    csr.check_errors(DEV)
+    for o, g in zip(outs, good):
+        assert torch.equal(o, g)
