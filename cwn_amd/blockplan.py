@@ -27,7 +27,7 @@ def gemm_rows_cap(F: int) -> int:
 
 
 LDS_BYTES = 160 * 1024
-_IDX_BYTES = (MAX_ENTRIES * 4 + 5 * MAX_ENTRIES * 2 + 3 * (TASK_ROWS + 2) * 2 + 15) // 16 * 16
+_IDX_BYTES = ((3 * (TASK_ROWS + 2) * 4 + 15) // 16 * 16 + 3 * MAX_ENTRIES * 2 + 3 * (TASK_ROWS + 2) * 2 + 15) // 16 * 16
 
 
 def lds_bytes(F: int, gemm_rows: int, source_rows: int) -> int:

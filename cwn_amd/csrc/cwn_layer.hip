@@ -22,9 +22,9 @@
 //      the PRE-PACKED weight (bf16 hi/mid/lo planes in MFMA-fragment order: 1 KiB contiguous per
 //      instruction), the rows of x_g and x_{g+1} (GEMM operands; also the self terms, see below),
 //      the rows of x_{g-1} the boundary stream reads
-//   3. COO -> LDS; stable rank by destination: one 32-bit key (row << 11 | entry) per entry, P
-//      lanes per entry count the smaller keys of their share (ds_read_b128, 4 keys a read), shuffle
-//      reduce -> per-item CSR in LDS (rowptr, col, aux as 16-bit LOCAL row numbers)
+//   3. COO -> per-item CSR in LDS (rowptr, col, aux as 16-bit LOCAL row numbers), stable by destination: a
+//      bucket sort -- an LDS atomic per entry counts its row, a scan of the counters gives the row
+//      pointers, the entries of a row order themselves by entry number
 //   4. GEMM rows -> exact 3-way bf16 split (cwn_split.h) -> three bf16 planes in LDS; boundary-source
 //      rows -> fp32 in LDS
 //   5. boundary stream + self terms of every task, out of LDS and registers
@@ -149,12 +149,13 @@ template <int F> struct Geo {
     __host__ __device__ static constexpr size_t xrows_bytes(int rows) { return (size_t)(rows + 1) * F * 4; }
 };
 
-// index scratch: u32 keys, five u16 arrays of kEcap, three row-pointer arrays.  The tail [scol | saux |
-// rowptr] is the item's finished CSR: one contiguous image, kCsrSlot bytes, that the first layer of a
-// batch can store (CWN_LAYER_CSR_STORE) and the following layers load back (CWN_LAYER_CSR_LOAD)
+// index scratch: [row counters u32 [3][kRpStride] | entry slots u16 [kEcap] | scol | saux | rowptr].  The tail
+// [scol | saux | rowptr] is the item's finished CSR: one contiguous image, kCsrSlot bytes, that the first
+// layer of a batch can store (CWN_LAYER_CSR_STORE) and the following layers load back (CWN_LAYER_CSR_LOAD)
 // instead of sorting the same entries again.
 constexpr int kRpStride = kTaskRows + 2;
-constexpr size_t kIdxBytes = (size_t)kEcap * 4 + (size_t)5 * kEcap * 2 + (size_t)3 * kRpStride * 2;
+constexpr size_t kCntBytes = ((size_t)3 * kRpStride * 4 + 15) & ~(size_t)15;
+constexpr size_t kIdxBytes = kCntBytes + (size_t)3 * kEcap * 2 + (size_t)3 * kRpStride * 2;
 constexpr int kCsrSlot = CWN_LAYER_CSR_SLOT_BYTES;
 static_assert(kCsrSlot >= 2 * kEcap * 2 + 3 * kRpStride * 2 && kCsrSlot % 16 == 0, "slot holds scol, saux, rowptr");
 enum { kSort = 0, kSortStore = 1, kLoad = 2 };
@@ -329,13 +330,11 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     float* const Y = reinterpret_cast<float*>(smem);                               // [rows_cap][F + 4], later
     float* const xsrc = reinterpret_cast<float*>(smem + G::planes_bytes(rows_cap)); // [xrows_cap][F]
     unsigned char* const idx = smem + G::planes_bytes(rows_cap) + G::xrows_bytes(A.xrows_cap);
-    uint32_t* const ukey = reinterpret_cast<uint32_t*>(idx);        // (local destination << 11) | entry
-    uint16_t* const uval = reinterpret_cast<uint16_t*>(idx + (size_t)kEcap * 4);   // local source row
-    uint16_t* const uaux = uval + kEcap;                            // local shared (coface) row
-    uint16_t* const skey = uval + 2 * kEcap;                        // sorted by destination, stable
-    uint16_t* const scol = uval + 3 * kEcap;
-    uint16_t* const saux = uval + 4 * kEcap;
-    uint16_t* const rowptr = uval + 5 * kEcap;   // [3][kRpStride]: upper, boundary of task 0, of task 1
+    uint32_t* const ecnt = reinterpret_cast<uint32_t*>(idx);        // [3][kRpStride] entries per destination row (sort modes)
+    uint16_t* const eslot = reinterpret_cast<uint16_t*>(idx + kCntBytes);   // [kEcap] entry numbers grouped by row (sort modes)
+    uint16_t* const scol = eslot + kEcap;                           // sorted by destination, stable: local source row
+    uint16_t* const saux = eslot + 2 * kEcap;                       //                                 local shared (coface) row
+    uint16_t* const rowptr = eslot + 3 * kEcap;  // [3][kRpStride]: upper, boundary of task 0, of task 1
 
     CWN_STAMP(0);
     CWN_WSTAMP(0);           // every wave: when it starts
@@ -422,6 +421,12 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         return;
     }
     bool bad = false;
+    // sort modes: the per-row entry counters of the three adjacencies are zeroed here and visible to every wave
+    // behind the barrier in front of the late weight requests
+    if constexpr (MODE != kLoad) {
+        static_assert(3 * kRpStride <= kThreads, "one counter per thread");
+        if (tid < 3 * kRpStride) ecnt[tid] = 0u;
+    }
 
     // ---- 2. every global load of the item, in one run; no load behind a DIVERGENT branch ---------------
     // A lane with nothing to fetch reads a harmless valid address (the item table) instead.  Behind
@@ -506,7 +511,12 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // address unit's queue -- without it the rows of the wave that issues last arrive behind the weights
     // of the fifteen others, and the split phase waits for most of the weight (measured: 3.3 k cycles).
     CWN_WSTAMP(1);           // every wave: its row requests are out
-    if (CWN_LAYER_WBAR) __builtin_amdgcn_s_barrier();
+    if constexpr (MODE != kLoad) {           // the zeroed counters must have landed before any wave adds to them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else if (CWN_LAYER_WBAR) {
+        __builtin_amdgcn_s_barrier();
+    }
 #pragma unroll
     for (int hh = 0; hh < 2 / kHS; ++hh) {
         const int h = kHS == 2 ? my_h : hh;
@@ -524,103 +534,105 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         CWN_STAMP(2);
         CWN_STAMP(3);
     } else {
-        // ---- 3a. entries -> LDS as local row numbers, range-checked --------------------------------------
+        // ---- 3a. entries as local row numbers, range-checked; counted per destination row --------------------
+        // Stable sort by destination as a BUCKET sort: an LDS atomic per entry counts its row and hands the
+        // entry a slot in it (arrival order); a scan of the counters gives the row pointers; the entries of
+        // a row then order themselves by entry number (a row has a handful of entries: each compares itself
+        // with its row mates).  The first form ranked every entry against its whole adjacency -- ~200
+        // instructions per wave where this takes ~50; the order of the result is the same.
         const int g_r0 = t_r0[0], c_r0 = fld(I_CR0);
         const int t_sr0[2] = {fld(I_TASK0 + T_SR0), fld(I_TASK0 + T_INTS + T_SR0)};
+        int e_seg[kEI], e_row[kEI], e_val[kEI], e_aux[kEI], e_pos[kEI];
     #pragma unroll
         for (int i = 0; i < kEI; ++i) {
             const int w = tid + i * kThreads;
+            e_seg[i] = -1;
+            e_row[i] = e_val[i] = e_aux[i] = e_pos[i] = 0;
             if (w < total) {
                 int64_t k = 0, v = 0, a = 0, nk = 1, nv = 1, na = 1;
-                bool live = true;
+                int seg = -1;
                 if (w < s1) {
+                    seg = 0;
                     k = ek[i] - g_r0; v = ev[i] - g_r0; a = ea[i] - c_r0;
                     nk = g_n; nv = g_n; na = c_n;
                 } else if (w >= b1 && w < s2) {
+                    seg = 1;
                     k = ek[i] - t_r0[0]; v = ev[i] - t_sr0[0];
                     nk = t_n[0]; nv = t_sn[0];
                 } else if (w >= b2 && w < s3) {
+                    seg = 2;
                     k = ek[i] - t_r0[1]; v = ev[i] - t_sr0[1];
                     nk = t_n[1];
                     v = (v >= 0 && v < t_sn[1]) ? v + t_sn[0] : -1;   // row in the staged source block
                     nv = t_sn[0] + t_sn[1];
-                } else {
-                    live = false;                  // padding slot between two segments: sorts after everything
-                }
-                if (live && (k < 0 || k >= nk || v < 0 || v >= nv || a < 0 || a >= na)) {
+                }                                  // else: a padding slot between two segments
+                if (seg >= 0 && (k < 0 || k >= nk || v < 0 || v >= nv || a < 0 || a >= na)) {
                     bad = true;
                     k = 0; v = 0; a = 0;
                 }
-                ukey[w] = live ? ((uint32_t)k << 11) | (uint32_t)w : 0xFFFFFFFFu;
-                uval[w] = (uint16_t)v;
-                uaux[w] = (uint16_t)a;
+                if (seg >= 0) {
+                    e_seg[i] = seg; e_row[i] = (int)k; e_val[i] = (int)v; e_aux[i] = (int)a;
+                    e_pos[i] = (int)atomicAdd(&ecnt[seg * kRpStride + (int)k], 1u);
+                }
             }
         }
         if (bad) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
         __syncthreads();
         CWN_STAMP(2);
 
-        // ---- 3b. stable rank by destination: P lanes per entry, each counts the smaller keys of its share --
-        {
-            int P = 1;
-            while (P < 8 && total * (P * 2) <= kThreads) P *= 2;
-            const int per_pass = kThreads / P;
-            for (int base = 0; base < total; base += per_pass) {
-                const int w = base + tid / P, sub = tid % P;
-                int cnt = 0, seg0 = 0;
-                uint32_t key = 0xFFFFFFFFu;
-                if (w < total) {
-                    seg0 = w < b1 ? 0 : (w < b2 ? b1 : b2);
-                    const int seg1 = w < b1 ? b1 : (w < b2 ? b2 : total);          // padded end: multiple of 4
-                    key = ukey[w];
-                    const int len4 = (seg1 - seg0) >> 2, chunk4 = (len4 + P - 1) / P;
-                    const int lo = seg0 + 4 * sub * chunk4, hi = min(seg1, lo + 4 * chunk4);
-                    // four reads in flight per step (a read a step is one LDS round trip per four keys)
-                    for (int e = lo; e < hi; e += 16) {
-                        uint4 kk[4];
+        // ---- 3b. row pointers: exclusive scan of the counters, one wave per adjacency ---------------------
+        if (wave < 3) {
+            static_assert(kRpStride <= 4 * 64, "four rows per lane");
+            const int n_rows = wave == 0 ? g_n : t_n[wave - 1];
+            const uint32_t* c = ecnt + wave * kRpStride;
+            uint16_t* rp = rowptr + wave * kRpStride;
+            int cj[4], sum = 0;
     #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            kk[u] = *reinterpret_cast<const uint4*>(ukey + min(e + 4 * u, seg1 - 4));
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * lane + j;
+                cj[j] = r < n_rows ? (int)c[r] : 0;
+                sum += cj[j];
+            }
+            int incl = sum;
     #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int c = (kk[u].x < key) + (kk[u].y < key) + (kk[u].z < key) + (kk[u].w < key);
-                            cnt += e + 4 * u < hi ? c : 0;
-                        }
-                    }
-                }
-                for (int off = 1; off < P; off <<= 1) cnt += __shfl_xor(cnt, off, 64);
-                if (key != 0xFFFFFFFFu && sub == 0) {
-                    const int pos = seg0 + cnt;
-                    skey[pos] = (uint16_t)(key >> 11);
-                    scol[pos] = uval[w];
-                    saux[pos] = uaux[w];
-                }
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            int run = incl - sum;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * lane + j;
+                if (r <= n_rows) rp[r] = (uint16_t)run;      // rp[n_rows] = number of entries
+                run += cj[j];
             }
         }
         __syncthreads();
-        CWN_STAMP(3);
 
-        // ---- 3c. row pointers from the sorted keys (run boundaries), empty rows included -----------------
-        for (int p = tid; p < s3; p += kThreads) {
-            const int which = p < b1 ? 0 : (p < b2 ? 1 : 2);
-            const int seg0 = which == 0 ? 0 : (which == 1 ? b1 : b2);
-            const int seg1 = which == 0 ? s1 : (which == 1 ? s2 : s3);
-            if (p < seg1) {
-                const int n_rows = which == 0 ? g_n : t_n[which - 1];
-                uint16_t* rp = rowptr + which * kRpStride;
-                const int k = skey[p];
-                const int kprev = p > seg0 ? (int)skey[p - 1] : -1;
-                for (int r = kprev + 1; r <= k; ++r) rp[r] = (uint16_t)(p - seg0);
-                if (p == seg1 - 1)
-                    for (int r = k + 1; r <= n_rows; ++r) rp[r] = (uint16_t)(seg1 - seg0);
+        // ---- 3c. entries into their rows (arrival order) ... ------------------------------------------------
+    #pragma unroll
+        for (int i = 0; i < kEI; ++i) {
+            if (e_seg[i] >= 0) {
+                const int seg0 = e_seg[i] == 0 ? 0 : (e_seg[i] == 1 ? b1 : b2);
+                eslot[seg0 + rowptr[e_seg[i] * kRpStride + e_row[i]] + e_pos[i]] = (uint16_t)(tid + i * kThreads);
             }
         }
-        if (s1 == 0)
-            for (int r = tid; r <= g_n; r += kThreads) rowptr[r] = 0;
-        if (s2 == b1)
-            for (int r = tid; r <= t_n[0]; r += kThreads) rowptr[kRpStride + r] = 0;
-        if (s3 == b2)
-            for (int r = tid; r <= t_n[1]; r += kThreads) rowptr[2 * kRpStride + r] = 0;
+        __syncthreads();
+        // ---- ... and into entry order inside the row: its position = the row mates with a smaller number ---
+    #pragma unroll
+        for (int i = 0; i < kEI; ++i) {
+            if (e_seg[i] >= 0) {
+                const int w = tid + i * kThreads;
+                const int seg0 = e_seg[i] == 0 ? 0 : (e_seg[i] == 1 ? b1 : b2);
+                const uint16_t* rp = rowptr + e_seg[i] * kRpStride + e_row[i];
+                const int lo = seg0 + rp[0], hi = seg0 + rp[1];
+                int less = 0;
+                for (int p = lo; p < hi; ++p) less += (int)eslot[p] < w ? 1 : 0;
+                scol[lo + less] = (uint16_t)e_val[i];
+                saux[lo + less] = (uint16_t)e_aux[i];
+            }
+        }
+        CWN_STAMP(3);
     }
 
     // ---- 4. GEMM rows -> three bf16 planes; boundary-source rows -> fp32 -------------------------------
