@@ -9,28 +9,28 @@
 // 161 of 256 CUs.
 //
 // A batched complex is block-diagonal and per-complex contiguous (data/complex.py:148-169), a
-// ZINC-like complex is ~55 cells x 512 B.  So a workgroup (512 threads, 8 waves) OWNS a range of
+// ZINC-like complex is ~55 cells x 512 B.  So a workgroup (1024 threads, 16 waves) OWNS a range of
 // complexes for one "GEMM dimension" g (plus, as a second task, the top dimension that has no
 // upper adjacency) and never leaves the CU's LDS between the dense and the sparse half.  The
 // kernel is a latency chain, built around one rule: after the item record, every global load of
 // the item is issued in ONE branch-free run, and nothing after that touches memory again until
 // the output rows are stored --
 //
-//   1. item record: one lane-parallel load, fields by v_readlane; the set record (all pointers of
-//      this item's GEMM dimension) by scalar loads from the kernel-argument segment
-//   2. loads, in order of use: COO entries (int64, as delivered), eps, bias, this wave's slice of
-//      the PRE-PACKED weight (bf16 hi/mid/lo planes in MFMA-fragment order: 1 KiB contiguous per
-//      instruction), the rows of x_g and x_{g+1} (GEMM operands; also the self terms, see below),
-//      the rows of x_{g-1} the boundary stream reads
+//   1. item record and set record (all pointers of this item's GEMM dimension): one lane-parallel
+//      load each, fields by v_readlane; while they travel, half of this wave's slice of the PRE-PACKED
+//      weight (bf16 hi/mid/lo planes in MFMA-fragment order: 1 KiB contiguous per instruction)
+//   2. loads, in order of use: COO entries (int64, as delivered; or the item's cached CSR), eps, the
+//      rows of x_g and x_{g+1} (GEMM operands; also the self terms, see below), the rows of x_{g-1}
+//      the boundary stream reads, the other half of the weight slice
 //   3. COO -> per-item CSR in LDS (rowptr, col, aux as 16-bit LOCAL row numbers), stable by destination: a
 //      bucket sort -- an LDS atomic per entry counts its row, a scan of the counters gives the row
 //      pointers, the entries of a row order themselves by entry number
 //   4. GEMM rows -> exact 3-way bf16 split (cwn_split.h) -> three bf16 planes in LDS; boundary-source
 //      rows -> fp32 in LDS
-//   5. boundary stream + self terms of every task, out of LDS and registers
+//   5. boundary stream + self terms of both tasks in one pass, out of LDS and registers
 //   6. Y1 = x_g W[:, :F]^T + b,  Y2 = x_{g+1} W[:, F:]^T : v_mfma_f32_16x16x32_bf16, six per 32
-//      k-values, wave w owns output columns 16w..16w+15 (F = 128) for every row tile; the fp32
-//      result overwrites the planes (dead by then)
+//      k-values; a wave owns 16 output columns of ONE of the two products for every row tile; the
+//      fp32 result overwrites the planes (dead by then)
 //   7. out_up[i] = sum_p relu(Y1[col[p]] + Y2[aux[p]]) + (1 + eps1) x_i out of LDS, in entry order
 //
 // Thread t loads float4 number t of row (t / (F/4)) + NG*i of the staged block, and the lane group
@@ -45,8 +45,9 @@
 //     compiler wait with vmcnt(0) (= for the 200 KB issued later) wherever an early result is used;
 //   * fragment-shaped loads of the fp32 weight (16 rows x 32 B per quarter wave) run the address unit
 //     at 1/8 rate: issuing the loads alone took 6 us.  Hence the packed weight.
+//   (the rest of the list: DESIGN.md 4.0)
 // HBM traffic = the item's x rows once, its COO entries once, the two output streams once.  No
-// atomics, no zero-fill pass; sums are sequential in the original entry order (deterministic, the
+// global atomics, no zero-fill pass; sums are sequential in the original entry order (deterministic, the
 // order a sequential index_add_ visits them).  Results are bit-identical to the two-kernel path
 // (cwn_gemm_split.hip + cwn_aggregate.hip): same split, same MFMA order, same epilogue arithmetic.
 #include <hip/hip_runtime.h>
