@@ -491,7 +491,8 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         if (D.in_scale2 != nullptr && D.K2 == 0) return CWN_ERR_BAD_ARG;
         if ((D.out_scale == nullptr) != (D.out_shift == nullptr)) return CWN_ERR_BAD_ARG;
         if ((D.col_sum == nullptr) != (D.col_sumsq == nullptr)) return CWN_ERR_BAD_ARG;
-        if (D.ldx < D.K || D.ldw < (D.w_trans ? D.N : D.K + D.K2) || D.ldy < D.N || (D.K2 > 0 && D.ldx2 < D.K2))
+        if (D.ldx < D.K || (D.ldw < (D.w_trans ? D.N : D.K + D.K2) && !(D.flags & CWN_GEMM_W_PACKED)) || D.ldy < D.N ||
+            (D.K2 > 0 && D.ldx2 < D.K2))
             return CWN_ERR_BAD_ARG;
         const void* ptrs[] = {D.X, D.X2, D.W, D.Y};
         for (const void* p : ptrs)
@@ -504,6 +505,8 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
     // precision policy is PER CALL (no process-wide state): CWN_GEMM_EXACT on any descriptor keeps the
     // launch on the exact fp32-MFMA kernel below
     if (cwn_gemm_would_split(descs, n)) return cwn_gemm_split_launch(descs, n, (hipStream_t)stream_);
+    for (int i = 0; i < n; ++i)              // a packed weight exists in the split kernel's form only
+        if (descs[i].flags & CWN_GEMM_W_PACKED) return CWN_ERR_BAD_ARG;
     // tile shape of the launch: narrow (64 x 64) when no descriptor has more than 64 output columns
     int kmax = 0, nmax = 0;
     for (int i = 0; i < n; ++i) {

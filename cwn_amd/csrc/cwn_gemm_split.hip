@@ -33,6 +33,7 @@ namespace {
 
 constexpr int K = 128, N = 128, TM = 64, kThreads = 256;
 constexpr int kRowStride = K + 8;            // bf16 elements per LDS row
+constexpr int kChunksPerTile = 4 * 3;        // packed weight: 1-KiB chunks per 16-column tile (k steps x planes)
 constexpr int kMaxBlocks = 512;              // 2 per CU (measured: 256 -> 204 us, 512 -> 135, one per tile -> 210)
 
 using cwn::frag_cd;
@@ -77,13 +78,28 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
     };
     // stationary W fragments of this wave's 32 output columns: [column tile][k step][plane]
     uint4 wf[2][4][3];
+    if (D.flags & CWN_GEMM_W_PACKED) {
+        // the weight was split and laid out in fragment order once per weight version
+        // (cwn_gemm_pack_weights_f32): 1 KiB contiguous per instruction and no split arithmetic, where the
+        // fp32 form costs fragment-shaped loads (16 rows x 32 B per quarter wave) and ~320 VALU
+        // instructions per wave in EVERY workgroup
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(D.W) + (size_t)wave * 2 * kChunksPerTile * 1024 + lane * 16;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int n = wave * 32 + ct * 16 + l15;
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const float4* p = reinterpret_cast<const float4*>(D.W + (int64_t)n * D.ldw + ks * 32 + kq * 8);
-            cwn::split8(p[0], p[1], wf[ct][ks][0], wf[ct][ks][1], wf[ct][ks][2]);
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    wf[ct][ks][pl] = *reinterpret_cast<const uint4*>(wp + ((ct * 4 + ks) * 3 + pl) * 1024);
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int n = wave * 32 + ct * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float4* p = reinterpret_cast<const float4*>(D.W + (int64_t)n * D.ldw + ks * 32 + kq * 8);
+                cwn::split8(p[0], p[1], wf[ct][ks][0], wf[ct][ks][1], wf[ct][ks][2]);
+            }
         }
     }
     const bool affine = D.out_scale != nullptr, relu = D.relu != 0;
@@ -163,9 +179,37 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
     }
 }
 
+// fp32 [128, 128] weight (row stride ldw) -> bf16 hi / mid / lo planes in MFMA-fragment order: the 1-KiB chunk
+// number ((tile * 4 + ks) * 3 + plane) holds, for lane l = kq * 16 + n, the eight k-values
+// W[tile * 16 + n][ks * 32 + kq * 8 ..] of that plane.  One thread per (tile, ks, lane).
+__global__ __launch_bounds__(256) void pack_gemm_weights_kernel(const float* __restrict__ W, int64_t ldw,
+                                                                unsigned char* __restrict__ out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (N / 16) * 4 * 64) return;
+    const int lane = g & 63, ks = (g >> 6) & 3, tile = g >> 8;
+    const float* src = W + (int64_t)(tile * 16 + (lane & 15)) * ldw + ks * 32 + (lane >> 4) * 8;
+    const float4 a = make_float4(src[0], src[1], src[2], src[3]), b = make_float4(src[4], src[5], src[6], src[7]);
+    uint4 ph, pm, pl;
+    cwn::split8(a, b, ph, pm, pl);
+    unsigned char* dst = out + ((size_t)(tile * 4 + ks) * 3) * 1024 + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = ph;
+    *reinterpret_cast<uint4*>(dst + 1024) = pm;
+    *reinterpret_cast<uint4*>(dst + 2048) = pl;
+}
+
 inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
+
+extern "C" size_t cwn_gemm_packed_weight_bytes(void) { return (size_t)N * K * 6; }
+
+extern "C" int cwn_gemm_pack_weights_f32(const float* W, int64_t ldw, void* out, cwn_stream_t stream_) {
+    if (W == nullptr || out == nullptr || ldw < K) return CWN_ERR_BAD_ARG;
+    if (((uintptr_t)W & 3u) || !al16(out)) return CWN_ERR_ALIGN;
+    const int threads = (N / 16) * 4 * 64;
+    pack_gemm_weights_kernel<<<dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream_>>>(W, ldw, (unsigned char*)out);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
 
 // 1 when every descriptor fits this kernel (see the header comment); arguments already validated
 // by cwn_gemm_f32.
@@ -176,7 +220,7 @@ int cwn_gemm_split_eligible(const cwn_gemm_desc* descs, int n) {
         if (D.in_scale != nullptr || D.in_scale2 != nullptr || D.in_relu != 0 || D.col_sum != nullptr) return 0;
         if (!(al16(D.X) && al16(D.W) && al16(D.Y) && al16(D.bias) && al16(D.out_scale) && al16(D.out_shift)))
             return 0;
-        if (D.ldx % 4 != 0 || D.ldw % 4 != 0 || D.ldy % 4 != 0) return 0;
+        if (D.ldx % 4 != 0 || (D.ldw % 4 != 0 && !(D.flags & CWN_GEMM_W_PACKED)) || D.ldy % 4 != 0) return 0;
         if ((D.M + TM - 1) / TM >= INT32_MAX) return 0;
     }
     return 1;

@@ -774,7 +774,8 @@ class SparseCINConv(torch.nn.Module):
                 for hs, stages, fs in ((hs_up, up, folds[0]), (hs_bd, bd, folds[1])):
                     lin = stages[st][0]
                     gemms.append(ops.Gemm(X=hs[i], W=lin.weight, bias=lin.bias, relu=True,
-                                          out_scale=fs[st][0], out_shift=fs[st][1]))
+                                          out_scale=fs[st][0], out_shift=fs[st][1],
+                                          w_packed=ops.pack_gemm_weight(lin.weight)))
             res = ops.run_gemm(gemms, dev)
             hs_up, hs_bd = res[0::2], res[1::2]
         gemms = []

@@ -504,9 +504,12 @@ class Gemm:
     out: Optional[Tensor] = None         # preallocated Y (may be a column slice of a wider matrix)
     w_col0: Optional[int] = None         # use columns [w_col0, w_col0 + K + K2) of W (not with w_trans):
                                          # lets autograd see the whole Parameter instead of a slice
+    w_packed: Optional[Tensor] = None    # pack_gemm_weight(W): used when the launch runs on the bf16-split path
+                                         # (inference: one split per weight version, not per workgroup)
 
-    def desc(self, Y: Tensor) -> _ffi.GemmDesc:
+    def desc(self, Y: Tensor, packed: bool = False) -> _ffi.GemmDesc:
         X, W, X2 = self.X, self.W, self.X2
+        packed = packed and self.w_packed is not None
         K = X.size(1)
         K2 = X2.size(1) if X2 is not None else 0
         if self.w_col0 is not None:
@@ -519,7 +522,8 @@ class Gemm:
             raise ValueError('X and X2 must have the same number of rows')
         cs = self.col_stats
         return _ffi.GemmDesc(
-            X=X.data_ptr(), X2=_ffi.ptr(X2), W=W.data_ptr() + 4 * (self.w_col0 or 0), bias=_ffi.ptr(self.bias),
+            X=X.data_ptr(), X2=_ffi.ptr(X2), W=self.w_packed.data_ptr() if packed else W.data_ptr() + 4 * (self.w_col0 or 0),
+            bias=_ffi.ptr(self.bias),
             in_scale=_ffi.ptr(self.in_scale), in_shift=_ffi.ptr(self.in_shift),
             in_scale2=_ffi.ptr(self.in_scale2), in_shift2=_ffi.ptr(self.in_shift2),
             out_scale=_ffi.ptr(self.out_scale), out_shift=_ffi.ptr(self.out_shift),
@@ -530,7 +534,8 @@ class Gemm:
             ldw=W.stride(0) if W.size(0) > 1 else W.size(1), ldy=Y.stride(0) if Y.size(0) > 1 else Y.size(1),
             N=W.size(1 if self.w_trans else 0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu),
             w_trans=int(self.w_trans),
-            flags=(_ffi.GEMM_EXACT if (self.exact or GEMM_EXACT) else 0) | (int(self.debug) << 8))
+            flags=(_ffi.GEMM_EXACT if (self.exact or GEMM_EXACT) else 0) | (_ffi.GEMM_W_PACKED if packed else 0)
+            | (int(self.debug) << 8))
 
 
 def stat_rows(M: int) -> int:
@@ -570,6 +575,9 @@ def run_gemm(gemms: Sequence[Gemm], device) -> List[Tensor]:
         if Y.numel():
             descs.append(gm.desc(Y))
     if descs:
+        # packed weights exist in the split kernel's form only: use them when this launch runs there
+        if any(gm.w_packed is not None for gm in gemms) and len(descs) <= _ffi.MAX_DESCS and _ffi.gemm_would_split(descs):
+            descs = [gm.desc(Y, packed=True) for gm, Y in zip(gemms, outs) if Y.numel()]
         _ffi.gemm(descs, device)
     return outs
 
@@ -771,6 +779,31 @@ def pack_layer_weight(weight: Tensor) -> Tensor:
     _ffi.check(L.cwn_layer_pack_weights_f32(w.data_ptr(), w.stride(0), F, out.data_ptr(), _ffi.stream_ptr(w.device)),
                'cwn_layer_pack_weights_f32')
     _packed_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_weights.pop(k, None)), out)
+    return out
+
+
+_packed_gemm_weights = {}
+
+
+def pack_gemm_weight(weight: Tensor) -> Optional[Tensor]:
+    """A Linear(128 -> 128) weight in the form the bf16-split GEMM reads its stationary operand
+    (include/cwn_hip.h: cwn_gemm_pack_weights_f32), cached per weight version like pack_layer_weight;
+    None for any other shape (the launch then takes the fp32 weight)."""
+    import weakref
+    w = weight.detach()
+    if w.dim() != 2 or tuple(w.shape) != (128, 128) or not w.is_cuda or w.dtype != torch.float32:
+        return None
+    key = id(weight)
+    ver = (w.data_ptr(), weight._version, w.device)
+    hit = _packed_gemm_weights.get(key)
+    if hit is not None and hit[0] == ver and hit[1]() is weight:
+        return hit[2]
+    w = _rowmajor(w, 'W')
+    L = _ffi.lib()
+    out = torch.empty(int(L.cwn_gemm_packed_weight_bytes()), dtype=torch.uint8, device=w.device)
+    _ffi.check(L.cwn_gemm_pack_weights_f32(w.data_ptr(), w.stride(0), out.data_ptr(), _ffi.stream_ptr(w.device)),
+               'cwn_gemm_pack_weights_f32')
+    _packed_gemm_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_gemm_weights.pop(k, None)), out)
     return out
 
 

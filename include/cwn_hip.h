@@ -353,6 +353,14 @@ typedef struct cwn_gemm_desc {
  * per output element; inf / NaN inputs propagate as in fp32) even when it is eligible for the
  * bf16-split path below.  Per call: the library keeps no precision state. */
 #define CWN_GEMM_EXACT 1
+/* W_PACKED: `W` of this descriptor is not the fp32 weight but the buffer cwn_gemm_pack_weights_f32 made of
+ * it ([128, 128] weights only; ldw is ignored).  Valid only in launches that run on the bf16-split path
+ * (cwn_gemm_would_split; otherwise CWN_ERR_BAD_ARG); results are bit-identical to passing the fp32 weight.
+ * Weight preparation for inference: one small launch per weight VERSION instead of a split of the same
+ * numbers in every workgroup of every launch. */
+#define CWN_GEMM_W_PACKED 2
+size_t cwn_gemm_packed_weight_bytes(void);
+int cwn_gemm_pack_weights_f32(const float* W, int64_t ldw, void* out, cwn_stream_t stream);
 
 int cwn_gemm_f32(const cwn_gemm_desc* descs_host, int n, cwn_stream_t stream);
 

@@ -1099,6 +1099,53 @@ def test_gemm_split_path_has_fp32_accuracy(M):
         assert not torch.equal(split[0], exact[0])       # the two kernels really differ
 
 
+@pytest.mark.parametrize('M', [1, 64, 3341, 20000])
+def test_gemm_split_packed_weight_is_bit_identical(M):
+    """cwn_gemm_pack_weights_f32 + CWN_GEMM_W_PACKED: the stationary operand split once per weight version
+    instead of in every workgroup -- the same numbers in the same MFMA order, so the results are the
+    fp32-weight launch's bit for bit (bias, BatchNorm-eval affine, ReLU, several GEMMs per launch); a packed
+    weight in a launch that does not run on the split path is an argument error, and the Python layer
+    falls back to the fp32 weight there."""
+    import ctypes as C
+    from cwn_amd import _ffi, ops
+    g = torch.Generator().manual_seed(100 + M)
+    Ws = [torch.nn.Parameter((torch.randn(128, 128, generator=g) / 16).to(DEV)) for _ in range(2)]
+    X = [torch.randn(m, 128, generator=g).to(DEV) for m in (M, M + 7)]
+    b = torch.randn(128, generator=g).to(DEV)
+    sc, sh = (torch.rand(128, generator=g) + 0.5).to(DEV), torch.randn(128, generator=g).to(DEV)
+
+    def make(packed):
+        pk = [ops.pack_gemm_weight(w) if packed else None for w in Ws]
+        return [ops.Gemm(X=X[0], W=Ws[0], bias=b, relu=True, out_scale=sc, out_shift=sh, w_packed=pk[0]),
+                ops.Gemm(X=X[1], W=Ws[1], w_packed=pk[1])]
+
+    with torch.no_grad():
+        plain = ops.run_gemm(make(False), DEV)
+        packed = ops.run_gemm(make(True), DEV)
+        assert ops.pack_gemm_weight(Ws[0]) is ops.pack_gemm_weight(Ws[0])          # cached per version
+        for a, c in zip(plain, packed):
+            assert torch.equal(a, c)
+        # a new weight version is packed again
+        old = ops.pack_gemm_weight(Ws[0])
+        Ws[0].mul_(2.0)
+        assert ops.pack_gemm_weight(Ws[0]) is not old
+        assert torch.equal(ops.run_gemm(make(True), DEV)[0], ops.run_gemm(make(False), DEV)[0])
+        # exact launches take the fp32 weight (the Python layer does not pass the packed one) ...
+        ex = make(True)
+        for gm in ex:
+            gm.exact = True
+        exact = ops.run_gemm(ex, DEV)
+        assert float((exact[1] - packed[1]).abs().max()) < 1e-4
+        # ... and the C ABI refuses a packed weight outside the split path
+        Y = torch.empty(M + 7, 128, device=DEV)
+        d = make(True)[1].desc(Y, packed=True)
+        d.flags |= _ffi.GEMM_EXACT
+        arr = (_ffi.GemmDesc * 1)(d)
+        assert _ffi.lib().cwn_gemm_f32(arr, 1, _ffi.stream_ptr(torch.device(DEV))) != 0
+    assert ops.pack_gemm_weight(torch.nn.Parameter(torch.zeros(64, 128, device=DEV))) is None
+    assert _ffi.lib().cwn_gemm_packed_weight_bytes() == 128 * 128 * 6
+
+
 def test_gemm_split_path_identity_is_exact_and_fallbacks_are_untouched():
     from cwn_amd import ops
     g = torch.Generator().manual_seed(3)
