@@ -344,3 +344,78 @@ def test_blocked_kernel_refuses_records_that_do_not_fit_its_lds():
     csr.check_errors(DEV)
     for o, g in zip(outs, good):
         assert torch.equal(o, g)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_blocked_layer_random_structures_vs_oracle(seed):
+    """Differential test over structures the molecular generator does not produce: small clique complexes
+    (triangles as 2-cells: every edge of a triangle is upper-adjacent to the two others through it),
+    ring complexes of odd sizes, single bonds, isolated vertices, and DUPLICATED index entries (summed
+    with multiplicity, mp/test_cell_mp.py:179-269) -- integer-valued features and weights, so the blocked
+    kernel must reproduce the oracle exactly, in both CSR modes."""
+    from cwn_amd import lifting
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import random_molecule
+    rng = np.random.default_rng(1000 + seed)
+    cs = []
+    for _ in range(int(rng.integers(3, 9))):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:                                         # random graph, clique lift (triangles)
+            n = int(rng.integers(3, 14))
+            p = float(rng.uniform(0.2, 0.6))
+            edges = [(i, j) for i in range(n) for j in range(i + 1, n) if rng.random() < p] or [(0, 1)]
+            cs.append(lifting.clique_lift(n, edges, torch.zeros(n, 1), max_dim=2, y=torch.zeros(1)))
+        elif kind == 1:                                       # molecule, rings up to 8
+            n, bonds = random_molecule(rng, 5, 20)
+            cs.append(lifting.ring_lift(n, bonds, torch.zeros(n, 1), torch.zeros(len(bonds), 1), max_k=8,
+                                        y=torch.zeros(1)))
+        elif kind == 2:                                       # a path (no 2-cells), possibly one bond
+            n = int(rng.integers(2, 7))
+            bonds = [(i, i + 1) for i in range(n - 1)]
+            cs.append(lifting.ring_lift(n, bonds, torch.zeros(n, 1), torch.zeros(len(bonds), 1), max_k=6,
+                                        y=torch.zeros(1)))
+        else:                                                 # one big ring
+            n = int(rng.integers(3, 9))
+            bonds = sorted((min(i, (i + 1) % n), max(i, (i + 1) % n)) for i in range(n))
+            cs.append(lifting.ring_lift(n, bonds, torch.zeros(n, 1), torch.zeros(n, 1), max_k=8, y=torch.zeros(1)))
+    if all(c.dimension < 2 for c in cs):
+        n, bonds = 3, [(0, 1), (0, 2), (1, 2)]
+        cs.append(lifting.ring_lift(n, bonds, torch.zeros(n, 1), torch.zeros(3, 1), max_k=6, y=torch.zeros(1)))
+    b = ComplexBatch.from_complex_list(cs, max_dim=2)
+    # duplicate a few entries inside their complex's slice (kept grouped: the table is per complex)
+    for d in range(2):
+        c = b.cochains[d]
+        if c.upper_index is None or c.upper_index.size(1) == 0:
+            continue
+        sl = list(c.__slices__['upper_index'])
+        cols, new_sl = [], [0]
+        for s0, e0 in zip(sl[:-1], sl[1:]):
+            idx = list(range(s0, e0))
+            if idx and rng.random() < 0.5:
+                idx += [int(rng.choice(idx))] * int(rng.integers(1, 3))
+            cols += idx
+            new_sl.append(len(cols))
+        perm = torch.tensor(cols, dtype=torch.long)
+        c.upper_index = c.upper_index[:, perm].contiguous()
+        c.shared_coboundaries = c.shared_coboundaries[perm].contiguous()
+        c.__slices__['upper_index'] = new_sl
+        if 'shared_coboundaries' in c.__slices__:
+            c.__slices__['shared_coboundaries'] = new_sl
+    b = b.to(DEV)
+    F = 128 if seed % 2 == 0 else 64
+    g = torch.Generator().manual_seed(seed)
+    for d in range(3):
+        b.cochains[d].x = torch.randint(-3, 4, (b.cochains[d].num_cells, F), generator=g).float().to(DEV)
+    conv = _conv(F, seed=seed, eps=0.0)
+    with torch.no_grad():
+        for lvl in conv.mp_levels:
+            lin = lvl.msg_up_nn[1]
+            lin.weight.copy_(torch.randint(-1, 2, lin.weight.shape).float())
+            lin.bias.copy_(torch.randint(-2, 3, lin.bias.shape).float())
+    ref = _oracle_scope(conv, b, dtype=torch.float32)
+    for _ in range(2):                                        # first call sorts and stores, second loads
+        outs = _run(conv, b, blocked=True)
+        for d in range(3):
+            assert torch.equal(cpu(outs[2 * d]), ref[d][0]), (seed, d, 'up')
+            assert torch.equal(cpu(outs[2 * d + 1]), ref[d][1]), (seed, d, 'boundary')
+    assert conv.blocked_reason is None
