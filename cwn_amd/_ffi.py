@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 9
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_items_check', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_items_check', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
@@ -72,6 +72,13 @@ class LayerPlan(C.Structure):
                 ('set_start', C.c_int32 * 4), ('max_gemm_rows', C.c_int32), ('max_source_rows', C.c_int32),
                 ('pad_', C.c_int32), ('cells_end', C.c_int64 * 3), ('up_end', C.c_int64 * 3),
                 ('b_end', C.c_int64 * 3)]
+
+
+class MlpDim(C.Structure):
+    """cwn_mlp_dim (include/cwn_hip.h)."""
+    _fields_ = [('x_up', C.c_void_p), ('x_b', C.c_void_p), ('w_packed', C.c_void_p * 6),
+                ('bias', C.c_void_p * 5), ('scale', C.c_void_p * 5), ('shift', C.c_void_p * 5),
+                ('y', C.c_void_p), ('M', C.c_int64), ('ldx_up', C.c_int64), ('ldx_b', C.c_int64), ('ldy', C.c_int64)]
 
 
 ERR_BIT_BLOCK = 8         # = CWN_ERR_BIT_BLOCK
@@ -155,6 +162,9 @@ def lib():
     L.cwn_layer_pack_weights_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_layer_fused_lds_bytes.restype = C.c_size_t
     L.cwn_layer_fused_lds_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.cwn_update_mlp_f32.argtypes = [C.POINTER(MlpDim), C.c_int, C.c_void_p]
+    L.cwn_update_mlp_max_rows.restype = C.c_int64
+    L.cwn_update_mlp_max_rows.argtypes = []
     L.cwn_gemm_packed_weight_bytes.restype = C.c_size_t
     L.cwn_gemm_packed_weight_bytes.argtypes = []
     L.cwn_gemm_pack_weights_f32.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]

@@ -82,6 +82,7 @@ def _is_cat_linear_relu(nn) -> bool:
 
 
 FUSED_DENSE_TRAINING = True   # set False to run the update / combine networks as torch modules
+FUSED_UPDATE_MLP = os.environ.get('CWN_FUSED_UPDATE_MLP') != '0'   # False: the update / combine networks as three grouped GEMM launches
 BLOCKED_LAYER = os.environ.get('CWN_BLOCKED_LAYER') != '0'   # False: propagate scope as grouped GEMM + CSR aggregation
 CSR_REUSE = True              # blocked layer kernel: sort a batch's adjacencies once, later layers load the result
 # One workgroup per item and one item per CU at a time: the blocked kernel wins while the items fit the chip
@@ -768,6 +769,15 @@ class SparseCINConv(torch.nn.Module):
         depth = len(chains[0][0])
         if any(len(c[0]) != depth for c in chains):
             return None
+        if FUSED_UPDATE_MLP and depth == 2 and not ops.GEMM_EXACT:
+            # all five Linear layers of every dimension in ONE launch (csrc/cwn_mlp.hip): the activations
+            # between them stay in LDS
+            mdims = [ops.MlpDim(x_up=hs_up[i], x_b=hs_bd[i],
+                                linears=[up[0][0], up[1][0], bd[0][0], bd[1][0], cb[0][0]],
+                                folds=[folds[0][0], folds[0][1], folds[1][0], folds[1][1], folds[2][0]])
+                     for i, (up, bd, cb, folds) in enumerate(chains)]
+            if ops.update_mlp_applies(mdims):
+                return ops.update_mlp(mdims)
         for st in range(depth):
             gemms = []
             for i, (up, bd, cb, folds) in enumerate(chains):

@@ -807,6 +807,81 @@ def pack_gemm_weight(weight: Tensor) -> Optional[Tensor]:
     return out
 
 
+@dataclass
+class MlpDim:
+    """One cochain dimension of cwn_update_mlp_f32 (cwn_mlp_dim in include/cwn_hip.h): the two outputs of
+    the propagate step, the five Linear layers (order 1u, 2u, 1b, 2b, combine) and their folded norms."""
+    x_up: Tensor
+    x_b: Tensor
+    linears: Sequence[torch.nn.Linear]                         # five modules
+    folds: Sequence[tuple]                                     # five (scale, shift) pairs, (None, None) = identity
+
+
+def update_mlp_applies(dims: Sequence[MlpDim]) -> bool:
+    """The fused update / combine launch serves 128-wide networks on small launches (include/cwn_hip.h)."""
+    cap = int(_ffi.lib().cwn_update_mlp_max_rows())
+    for D in dims:
+        if D.x_up.size(0) > cap or D.x_up.size(1) != 128 or D.x_b.size(1) != 128 or len(D.linears) != 5:
+            return False
+        if any(tuple(l.weight.shape) != (128, 128) for l in D.linears[:4]) or tuple(D.linears[4].weight.shape) != (128, 256):
+            return False
+    return True
+
+
+def update_mlp(dims: Sequence[MlpDim]) -> List[Tensor]:
+    """mp/layers.py:193-199 for every dimension in ONE launch (csrc/cwn_mlp.hip); inference only."""
+    dev = dims[0].x_up.device
+    arr = (_ffi.MlpDim * len(dims))()
+    outs, keep = [], []
+    for i, D in enumerate(dims):
+        xu, xb = _rowmajor(D.x_up, 'x_up'), _rowmajor(D.x_b, 'x_b')
+        y = torch.empty(xu.size(0), 128, dtype=torch.float32, device=dev)
+        outs.append(y)
+        a = arr[i]
+        a.x_up, a.x_b, a.y, a.M = xu.data_ptr(), xb.data_ptr(), y.data_ptr(), xu.size(0)
+        a.ldx_up = xu.stride(0) if xu.size(0) > 1 else 128
+        a.ldx_b = xb.stride(0) if xb.size(0) > 1 else 128
+        a.ldy = 128
+        packed = [pack_gemm_weight(l.weight) for l in D.linears[:4]]
+        packed += list(pack_combine_weight(D.linears[4].weight))
+        for k, pk in enumerate(packed):
+            a.w_packed[k] = pk.data_ptr()
+        for s_, (lin, (sc, sh)) in enumerate(zip(D.linears, D.folds)):
+            b = None if lin.bias is None else _f32c(lin.bias, 'bias')
+            a.bias[s_], a.scale[s_], a.shift[s_] = _ffi.ptr(b), _ffi.ptr(sc), _ffi.ptr(sh)
+            keep += [b, sc, sh]
+        keep += packed + [xu, xb]
+    _ffi.check(_ffi.lib().cwn_update_mlp_f32(arr, len(dims), _ffi.stream_ptr(dev)), 'cwn_update_mlp_f32')
+    return outs
+
+
+_packed_combine_weights = {}
+
+
+def pack_combine_weight(weight: Tensor):
+    """The two column halves of a combine Linear(256 -> 128) weight, each packed like a 128 x 128 weight
+    (cwn_gemm_pack_weights_f32 with ldw = 256); cached per weight version."""
+    import weakref
+    w = weight.detach()
+    key = id(weight)
+    ver = (w.data_ptr(), weight._version, w.device)
+    hit = _packed_combine_weights.get(key)
+    if hit is not None and hit[0] == ver and hit[1]() is weight:
+        return hit[2]
+    w = _rowmajor(w, 'W')
+    L = _ffi.lib()
+    n = int(L.cwn_gemm_packed_weight_bytes())
+    halves = []
+    for c0 in (0, 128):
+        out = torch.empty(n, dtype=torch.uint8, device=w.device)
+        _ffi.check(L.cwn_gemm_pack_weights_f32(w.data_ptr() + 4 * c0, w.stride(0), out.data_ptr(), _ffi.stream_ptr(w.device)),
+                   'cwn_gemm_pack_weights_f32')
+        halves.append(out)
+    halves = tuple(halves)
+    _packed_combine_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_combine_weights.pop(k, None)), halves)
+    return halves
+
+
 def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tensor]:
     """[out_up_0, out_b_0, out_up_1, out_b_1, ...]; no autograd (inference path).  `table` is one of the
     batch's item tables (cwn_amd/blockplan.py: ItemTable); csr_mode 0 sorts the COO entries in the

@@ -301,6 +301,38 @@ int32_t cwn_layer_round_rows(int32_t F);
 size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows);
 
 /* ------------------------------------------------------------------------------------------
+ * The update / combine networks of a SparseCIN layer, all dimensions, in ONE launch (inference):
+ *
+ *     h_up = relu(bn(W2u relu(bn(W1u x_up + b1u)) + b2u))          update_up_nn          (mp/layers.py:303-311)
+ *     h_b  = relu(bn(W2b relu(bn(W1b x_b  + b1b)) + b2b))          update_boundaries_nn  (:312-321)
+ *     y    = relu(bn(Wc [h_up | h_b] + bc))                        combine_nn            (:322-325, :193-199)
+ *
+ * with every Linear 128 wide (Wc: 256 -> 128), BatchNorm in eval mode folded into a per-column
+ * (scale, shift) or absent (NULL pair), ReLU after every stage.  x_up / x_b are the two outputs of the
+ * propagate step (cwn_layer_fused_f32: out_up, out_b).  A workgroup takes 32 rows through all five
+ * Linear layers without leaving the CU: the intermediate activations never reach HBM.  Products on the
+ * bf16 matrix pipe through the exact three-way operand split (fp32 accuracy, csrc/cwn_split.h).
+ * w_packed: cwn_gemm_pack_weights_f32 of W1u, W2u, W1b, W2b, Wc[:, :128], Wc[:, 128:] (the last two: the
+ * column halves of the combine weight, ldw = 256); bias / scale / shift per stage in the order
+ * (1u, 2u, 1b, 2b, c), bias may be NULL.  For launches of at most cwn_update_mlp_max_rows() rows per
+ * dimension (every workgroup streams all six weights; larger launches: cwn_gemm_f32, weight-stationary).
+ * Every pointer 16-B aligned, row strides multiples of 4; no workspace, no host sync.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cwn_mlp_dim {
+    const float* x_up;          /* [M, 128], row stride ldx_up */
+    const float* x_b;           /* [M, 128], row stride ldx_b */
+    const void* w_packed[6];
+    const float* bias[5];       /* [128] or NULL */
+    const float* scale[5];      /* [128] or NULL (then shift NULL too) */
+    const float* shift[5];
+    float* y;                   /* [M, 128], row stride ldy */
+    int64_t M, ldx_up, ldx_b, ldy;
+} cwn_mlp_dim;
+
+int cwn_update_mlp_f32(const cwn_mlp_dim* dims_host, int n_dims, cwn_stream_t stream);
+int64_t cwn_update_mlp_max_rows(void);
+
+/* ------------------------------------------------------------------------------------------
  * Dense parts of the path on the matrix cores (fp32 MFMA, exact fp32):
  *
  *     Y = epilogue( prologue([X | X2]) . W^T + bias )         up to CWN_MAX_DESCS GEMMs per launch

@@ -39,7 +39,7 @@ def test_struct_layout_matches_header(tmp_path):
                'cwn_gemm_desc': _ffi.GemmDesc, 'cwn_collate_desc': _ffi.CollateDesc,
                'cwn_bn_desc': _ffi.BnDesc, 'cwn_norm_desc': _ffi.NormDesc,
                'cwn_gemm_tn_desc': _ffi.GemmTnDesc, 'cwn_layer_dim': _ffi.LayerDim,
-               'cwn_layer_plan': _ffi.LayerPlan}
+               'cwn_layer_plan': _ffi.LayerPlan, 'cwn_mlp_dim': _ffi.MlpDim}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cwn_hip.h"', 'int main(void) {']
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
