@@ -17,13 +17,14 @@
 // cwn_gemm_split.hip, so stage 1 and 2 are bit-identical to the launches they replace; the combine,
 // formerly on fp32 MFMA, is now on the same path: fp32 accuracy, not bit-identical to an fmaf chain).
 //
-//   x_up --W1u--> relu(bn) --W2u--> relu(bn) = h_up \
-//                                                     Wc[:, :128] h_up + Wc[:, 128:] h_b --> relu(bn) = y
-//   x_b  --W1b--> relu(bn) --W2b--> relu(bn) = h_b  /
+//   x_up --W1u--> relu(bn) --W2u--> relu(bn) = h_up --+
+//                                                      +-- Wc[:, :128] h_up + Wc[:, 128:] h_b --> relu(bn) = y
+//   x_b  --W1b--> relu(bn) --W2b--> relu(bn) = h_b  --+
 //
-// For launches of at most a few thousand rows per dimension (every workgroup streams all six weights:
-// 576 KB out of L2); larger ones keep the weight-stationary grouped GEMMs (the caller decides:
-// cwn_update_mlp_max_rows).
+// Every workgroup streams all six weights (576 KB out of L2); measured against the three weight-stationary
+// grouped GEMM launches on the full forward (tools/mlp_crossover.sh, ms): batch 128 0.172 vs 0.245, 1024
+// 0.71 vs 0.96, 8192 4.57 vs 5.79 -- the HBM round trips of the intermediates cost more than the weight
+// stream at every size measured.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
@@ -35,38 +36,64 @@ namespace {
 
 using cwn::frag_cd;
 
-constexpr int K = 128, N = 128, TM = 32, kThreads = 256;
+constexpr int K = 128, N = 128, TM = 32, kThreads = 512;
 constexpr int kRowStride = K + 8;                 // bf16 elements per LDS row (272 B: fragment reads conflict-free)
 constexpr int kV = TM * 32 / kThreads;            // float4 of an input tile per thread
 constexpr int kRT = TM / 16;                      // 16-row tiles per workgroup
 constexpr int kChunksPerTile = 4 * 3;             // packed weight: 1-KiB chunks per 16-column tile (k steps x planes)
 constexpr size_t kPlaneElems = (size_t)TM * kRowStride;
 constexpr size_t kBufBytes = 3 * kPlaneElems * 2;  // three planes
-constexpr size_t kLdsBytes = 3 * kBufBytes;        // ping, pong, kept h_up
+constexpr size_t kLdsBytes = 5 * kBufBytes;        // x_up / h_b, x_b, h1_up, h1_b, h_up
 
 struct MlpBatch {
     cwn_mlp_dim d[CWN_LAYER_MAX_DIMS];
     int32_t blk_start[CWN_LAYER_MAX_DIMS + 1];
     int32_t n;
+#ifdef CWN_MLP_TIMING
+    unsigned long long* stamps;              // [workgroups][16] shader-clock stamps (instrumented build only)
+#endif
 };
 
-__global__ __launch_bounds__(kThreads, 2) void update_mlp_kernel(MlpBatch B) {
+#ifdef CWN_MLP_TIMING
+#define MLP_STAMP(k)                                                                           \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && B.stamps != nullptr)                                           \
+            B.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();            \
+    } while (0)
+unsigned long long* g_mlp_stamps = nullptr;
+#else
+#define MLP_STAMP(k) do { } while (0)
+#endif
+
+// One workgroup per CU, EIGHT waves: wave w owns the 16 output columns of column tile w for both 16-row tiles
+// and the registers of that column tile's weight, TWICE (the weight of stage k + 1 is requested into the
+// second set before the MFMAs of stage k).  What was measured on the way (per launch at the ZINC batch of
+// 128, 214 workgroups): four waves x 32 columns, one or two register sets: 20.7 - 21.7 us (one wave per SIMD:
+// every split / epilogue instruction and every dependent MFMA waits out its own latency); sixteen waves x one
+// 16 x 16 tile: 21.0 us -- two waves per column tile request the same weight, 192 KB a stage, and the address
+// unit (64 B per clock and CU) became the bound; and in every form the epilogue constants requested BEHIND
+// the next weight made each stage wait for that weight (loads return in order).
+__global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t* const bufA = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* const bufB = reinterpret_cast<uint16_t*>(smem + kBufBytes);
-    uint16_t* const bufU = reinterpret_cast<uint16_t*>(smem + 2 * kBufBytes);
+    uint16_t* const bufA = reinterpret_cast<uint16_t*>(smem);                   // x_up, later h_b
+    uint16_t* const bufC = reinterpret_cast<uint16_t*>(smem + kBufBytes);       // x_b
+    uint16_t* const bufB = reinterpret_cast<uint16_t*>(smem + 2 * kBufBytes);   // stage-1 output, upper branch
+    uint16_t* const bufD = reinterpret_cast<uint16_t*>(smem + 3 * kBufBytes);   // stage-1 output, boundary branch
+    uint16_t* const bufU = reinterpret_cast<uint16_t*>(smem + 4 * kBufBytes);   // h_up
     int di = 0;
 #pragma unroll
     for (int i = 1; i < CWN_LAYER_MAX_DIMS; ++i)
         if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
     const cwn_mlp_dim& D = B.d[di];
     const int64_t row0 = (int64_t)((int)blockIdx.x - B.blk_start[di]) * TM;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, ct = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
+    static_assert(kRT == 2 && kThreads == 512 && kV == 2, "one column tile per wave, two row tiles");
 
-    // an input tile: TM rows x 32 float4, kV per thread, row-contiguous; rows past M are clamped, not guarded
-    float4 v[kV];
-    auto request_rows = [&](const float* X, int64_t ld) {
+    // an input tile: TM rows x 32 float4, two per thread, row-contiguous; rows past M are clamped, not guarded
+    typedef float4 RowRegs[kV];
+    RowRegs vU, vB;
+    auto request_rows = [&](RowRegs& v, const float* X, int64_t ld) {
 #pragma unroll
         for (int i = 0; i < kV; ++i) {
             const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
@@ -74,7 +101,7 @@ __global__ __launch_bounds__(kThreads, 2) void update_mlp_kernel(MlpBatch B) {
             v[i] = reinterpret_cast<const float4*>(X + row * ld)[c4];
         }
     };
-    auto stage_rows = [&](uint16_t* buf) {          // split the tile ONCE per element into the three planes
+    auto stage_rows = [&](const RowRegs& v, uint16_t* buf) {   // split the tile ONCE per element into the three planes
 #pragma unroll
         for (int i = 0; i < kV; ++i) {
             const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
@@ -86,27 +113,38 @@ __global__ __launch_bounds__(kThreads, 2) void update_mlp_kernel(MlpBatch B) {
             *reinterpret_cast<uint2*>(dst + 2 * kPlaneElems) = pl;
         }
     };
-    // the stationary operand of a stage: this wave's 32 output columns, [column tile][k step][plane]
-    uint4 wf[2][4][3];
-    auto request_weight = [&](int k) {
+    // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL
+    // load (s_waitcnt vmcnt(0)) -- here the next stage's weight, which is meant to keep streaming across the
+    // barrier (measured: 3.3 k cycles per stage spent in that wait)
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // the stationary operand of a stage: this wave's 16 output columns, [k step][plane]; two sets
+    typedef uint4 WeightRegs[4][3];
+    WeightRegs wfA, wfB;
+    auto request_kstep = [&](WeightRegs& wf, int k, int ks) {
         const unsigned char* wp = reinterpret_cast<const unsigned char*>(D.w_packed[k]) +
-                                  (size_t)wave * 2 * kChunksPerTile * 1024 + lane * 16;
+                                  (size_t)ct * kChunksPerTile * 1024 + lane * 16;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    wf[ct][ks][pl] = *reinterpret_cast<const uint4*>(wp + ((ct * 4 + ks) * 3 + pl) * 1024);
+        for (int pl = 0; pl < 3; ++pl) wf[ks][pl] = *reinterpret_cast<const uint4*>(wp + (ks * 3 + pl) * 1024);
     };
-    frag_cd acc[kRT][2];
-    auto clear = [&]() {
+    auto request_weight = [&](WeightRegs& wf, int k) {
 #pragma unroll
-        for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = frag_cd{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 4; ++ks) request_kstep(wf, k, ks);
     };
-    auto multiply = [&](const uint16_t* buf) {      // acc += buf x W^T: same loop order as cwn_gemm_split.hip
+    typedef frag_cd AccRegs[kRT];
+    AccRegs accU, accB;                          // the two branches alternate (see the chain below)
+    auto clear = [&](AccRegs& acc) {
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
+    };
+    // acc += buf x W^T (k steps in order, six terms each: cwn_split.h).  `next` >= 0: the k steps of weight
+    // `next` are requested into the OTHER register set one by one between this stage's MFMAs -- three 1-KiB
+    // loads a wave at a time, which the address unit takes without making the wave wait (requested twelve at
+    // once after the stage, the waves sat in the issue of their loads for 1.5 k cycles while the matrix pipe
+    // idled, and then multiplied while the address unit idled)
+    auto multiply = [&](AccRegs& acc, const uint16_t* buf, const WeightRegs& wf, WeightRegs& wnext, int next) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -115,86 +153,110 @@ __global__ __launch_bounds__(kThreads, 2) void update_mlp_kernel(MlpBatch B) {
                 const uint4 xh = *reinterpret_cast<const uint4*>(p);
                 const uint4 xm = *reinterpret_cast<const uint4*>(p + kPlaneElems);
                 const uint4 xl = *reinterpret_cast<const uint4*>(p + 2 * kPlaneElems);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[rt][ct] = cwn::mfma_split6(wf[ct][ks][0], wf[ct][ks][1], wf[ct][ks][2], xh, xm, xl, acc[rt][ct]);
+                acc[rt] = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh, xm, xl, acc[rt]);
             }
+            if (next >= 0) request_kstep(wnext, next, ks);
+        }
+    };
+    // the epilogue constants of a stage are requested BEFORE its MFMAs (and so before the next weight): loads
+    // return in order, a constant behind 96 KB of weight is a wait for the weight (measured: 4.4 k cycles a stage)
+    struct Consts { float4 b, sc, sh; bool affine; };
+    Consts cU, cB;
+    auto request_consts = [&](Consts& c, int s) {
+        const int n0 = ct * 16 + kq * 4;
+        c.b = make_float4(0.f, 0.f, 0.f, 0.f);
+        c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        c.sh = c.b;
+        if (D.bias[s] != nullptr) c.b = *reinterpret_cast<const float4*>(D.bias[s] + n0);
+        c.affine = D.scale[s] != nullptr;
+        if (c.affine) {
+            c.sc = *reinterpret_cast<const float4*>(D.scale[s] + n0);
+            c.sh = *reinterpret_cast<const float4*>(D.shift[s] + n0);
         }
     };
     // epilogue of stage s: + bias, folded BatchNorm, ReLU; then either into the planes of `buf` (the next
     // stage's operand) or, for the last stage, to y.  D[i][j]: i = output column (lane >> 4) * 4 + reg,
     // j = row (lane & 15): a lane holds 4 consecutive columns of one row.
-    auto finish = [&](int s, uint16_t* buf) {
+    auto finish = [&](const AccRegs& acc, const Consts& c, uint16_t* buf) {
+        const int n0 = ct * 16 + kq * 4;
+        const float4 b4 = c.b, sc = c.sc, sh = c.sh;
+        const bool affine = c.affine;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int n0 = wave * 32 + ct * 16 + kq * 4;
-            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = b4;
-            if (D.bias[s] != nullptr) b4 = *reinterpret_cast<const float4*>(D.bias[s] + n0);
-            const bool affine = D.scale[s] != nullptr;
+        for (int rt = 0; rt < kRT; ++rt) {
+            float y[4] = {acc[rt][0] + b4.x, acc[rt][1] + b4.y, acc[rt][2] + b4.z, acc[rt][3] + b4.w};
             if (affine) {
-                sc = *reinterpret_cast<const float4*>(D.scale[s] + n0);
-                sh = *reinterpret_cast<const float4*>(D.shift[s] + n0);
+                y[0] = y[0] * sc.x + sh.x;
+                y[1] = y[1] * sc.y + sh.y;
+                y[2] = y[2] * sc.z + sh.z;
+                y[3] = y[3] * sc.w + sh.w;
             }
 #pragma unroll
-            for (int rt = 0; rt < kRT; ++rt) {
-                float y[4] = {acc[rt][ct][0] + b4.x, acc[rt][ct][1] + b4.y, acc[rt][ct][2] + b4.z, acc[rt][ct][3] + b4.w};
-                if (affine) {
-                    y[0] = y[0] * sc.x + sh.x;
-                    y[1] = y[1] * sc.y + sh.y;
-                    y[2] = y[2] * sc.z + sh.z;
-                    y[3] = y[3] * sc.w + sh.w;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) y[q] = fmaxf(y[q], 0.0f);
-                const int r = rt * 16 + l15;
-                if (buf != nullptr) {
-                    uint2 ph, pm, pl;
-                    cwn::split4(make_float4(y[0], y[1], y[2], y[3]), ph, pm, pl);
-                    uint16_t* dst = buf + (size_t)r * kRowStride + n0;
-                    *reinterpret_cast<uint2*>(dst) = ph;
-                    *reinterpret_cast<uint2*>(dst + kPlaneElems) = pm;
-                    *reinterpret_cast<uint2*>(dst + 2 * kPlaneElems) = pl;
-                } else if (row0 + r < D.M) {
-                    cwn::store_result4(D.y + (row0 + r) * D.ldy + n0, y[0], y[1], y[2], y[3]);
-                }
+            for (int q = 0; q < 4; ++q) y[q] = fmaxf(y[q], 0.0f);
+            const int r = rt * 16 + l15;
+            if (buf != nullptr) {
+                uint2 ph, pm, pl;
+                cwn::split4(make_float4(y[0], y[1], y[2], y[3]), ph, pm, pl);
+                uint16_t* dst = buf + (size_t)r * kRowStride + n0;
+                *reinterpret_cast<uint2*>(dst) = ph;
+                *reinterpret_cast<uint2*>(dst + kPlaneElems) = pm;
+                *reinterpret_cast<uint2*>(dst + 2 * kPlaneElems) = pl;
+            } else if (row0 + r < D.M) {
+                cwn::store_result4(D.y + (row0 + r) * D.ldy + n0, y[0], y[1], y[2], y[3]);
             }
         }
     };
 
-    // ---- the chain; a stage's weight is requested as soon as the previous stage's MFMAs have been issued ----
-    request_rows(D.x_up, D.ldx_up);
-    request_weight(0);
-    stage_rows(bufA);
-    __syncthreads();
-    clear(); multiply(bufA);                 // stage 1, upper branch
-    request_weight(1);
-    request_rows(D.x_b, D.ldx_b);            // the boundary branch's rows fly under two stages
-    finish(0, bufB);
-    __syncthreads();
-    clear(); multiply(bufB);                 // stage 2, upper branch
-    request_weight(2);
-    finish(1, bufU);                         // h_up stays in LDS until the combine
-    stage_rows(bufA);                        // (bufA was last read before the previous barrier)
-    __syncthreads();
-    clear(); multiply(bufA);                 // stage 1, boundary branch
-    request_weight(3);
-    finish(2, bufB);
-    __syncthreads();
-    clear(); multiply(bufB);                 // stage 2, boundary branch
-    request_weight(4);
-    finish(3, bufA);                         // h_b
-    __syncthreads();
-    clear(); multiply(bufU);                 // combine: Wc[:, :128] h_up ...
-    request_weight(5);
-    multiply(bufA);                          // ... + Wc[:, 128:] h_b (cat order of mp/layers.py:199)
-    finish(4, nullptr);
+    // ---- the chain ----------------------------------------------------------------------------------------------
+    // The two branches are independent until the combine, so their stages ALTERNATE: the epilogue of a stage
+    // (VALU + LDS: bias, folded norm, ReLU, split into planes) sits in the instruction stream behind the MFMAs
+    // of the OTHER branch's stage and runs while the matrix pipe works on them; the weight of the next
+    // multiplication streams in k step by k step meanwhile.  Weight order: 1u, 1b, 2u, 2b, c(up half), c(b half).
+    MLP_STAMP(0);
+    request_rows(vU, D.x_up, D.ldx_up);
+    request_consts(cU, 0);
+    request_weight(wfA, 0);
+    request_rows(vB, D.x_b, D.ldx_b);
+    request_consts(cB, 2);
+    stage_rows(vU, bufA);
+    stage_rows(vB, bufC);
+    lds_barrier();
+    MLP_STAMP(1);
+    clear(accU); multiply(accU, bufA, wfA, wfB, 2);     // stage 1, upper branch     (W1b streams in)
+    MLP_STAMP(2);
+    clear(accB); multiply(accB, bufC, wfB, wfA, 1);     // stage 1, boundary branch  (W2u streams in) ...
+    finish(accU, cU, bufB);                             // ... over the epilogue of stage 1, upper branch
+    request_consts(cU, 1);
+    lds_barrier();
+    MLP_STAMP(3);
+    clear(accU); multiply(accU, bufB, wfA, wfB, 3);     // stage 2, upper branch     (W2b streams in)
+    finish(accB, cB, bufD);
+    request_consts(cB, 3);
+    lds_barrier();
+    MLP_STAMP(4);
+    clear(accB); multiply(accB, bufD, wfB, wfA, 4);     // stage 2, boundary branch  (Wc, upper half)
+    finish(accU, cU, bufU);                             // h_up
+    request_consts(cU, 4);
+    lds_barrier();
+    MLP_STAMP(5);
+    clear(accU); multiply(accU, bufU, wfA, wfB, 5);     // combine: Wc[:, :128] h_up (Wc, boundary half) ...
+    finish(accB, cB, bufA);                             // h_b (x_up's planes are long dead)
+    lds_barrier();
+    MLP_STAMP(6);
+    multiply(accU, bufA, wfB, wfA, -1);                 // ... + Wc[:, 128:] h_b (cat order of mp/layers.py:199)
+    MLP_STAMP(7);
+    finish(accU, cU, nullptr);
+    MLP_STAMP(8);
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
 
-extern "C" int64_t cwn_update_mlp_max_rows(void) { return 32768; }
+#ifdef CWN_MLP_TIMING
+extern "C" void cwn_mlp_debug_stamps(unsigned long long* buf) { g_mlp_stamps = buf; }
+#endif
+
+extern "C" int64_t cwn_update_mlp_max_rows(void) { return 1 << 20; }
 
 extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, cwn_stream_t stream_) {
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS) return CWN_ERR_BAD_ARG;
@@ -231,6 +293,9 @@ extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, cwn_strea
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     });
     if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
+#ifdef CWN_MLP_TIMING
+    B.stamps = g_mlp_stamps;
+#endif
     update_mlp_kernel<<<dim3((unsigned)blocks), dim3(kThreads), kLdsBytes, (hipStream_t)stream_>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

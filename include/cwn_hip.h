@@ -314,8 +314,8 @@ size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_s
  * bf16 matrix pipe through the exact three-way operand split (fp32 accuracy, csrc/cwn_split.h).
  * w_packed: cwn_gemm_pack_weights_f32 of W1u, W2u, W1b, W2b, Wc[:, :128], Wc[:, 128:] (the last two: the
  * column halves of the combine weight, ldw = 256); bias / scale / shift per stage in the order
- * (1u, 2u, 1b, 2b, c), bias may be NULL.  For launches of at most cwn_update_mlp_max_rows() rows per
- * dimension (every workgroup streams all six weights; larger launches: cwn_gemm_f32, weight-stationary).
+ * (1u, 2u, 1b, 2b, c), bias may be NULL.  At most cwn_update_mlp_max_rows() rows per dimension
+ * (CWN_ERR_TOO_LARGE beyond; the same networks as grouped launches: cwn_gemm_f32).
  * Every pointer 16-B aligned, row strides multiples of 4; no workspace, no host sync.
  * ------------------------------------------------------------------------------------------ */
 typedef struct cwn_mlp_dim {
