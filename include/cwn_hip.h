@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 9
+#define CWN_ABI_VERSION 10
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
