@@ -341,8 +341,10 @@ def main():
             if dist is not None:
                 dist.all_reduce(ecells)
             eager = {'cells_per_s': round(float(ecells.item()) / dte, 1), 'ms_per_step': round(dte / esteps * 1e3, 5),
-                     'note': 'same step, one Python/ctypes call per launch and a validated (synchronising) plan '
-                             'build: host-bound; the headline replays the step from a hipGraph'}
+                     'note': ('same step through the reference-shaped API (set_xs, get_all_cochain_params, conv): one '
+                              'Python/ctypes call per layer launch' if BLOCKED else
+                              'same step, one Python/ctypes call per launch and a validated (synchronising) plan build')
+                             + ': host-bound; the headline replays the step from a hipGraph'}
         except Exception as e:
             print(f'[bench] eager leg failed: {type(e).__name__}: {e}', file=sys.stderr)
     full_steps = max(args.steps // 4, 10)
