@@ -259,7 +259,9 @@ def main():
                 # ... and, when the timed region is long enough, one that holds several such rounds (the gap
                 # between two graph launches is ~8 us of GPU time: 5 % of a 4-step graph of the blocked path)
                 # (small batches only: a captured step keeps its output tensors alive)
-                rounds = min(steps, 32) // nb if max(st_['cells'] for st_ in stats) <= 50_000 else 0
+                # one round fewer than the timed region holds: a SMALL graph goes first (a graph's packets are
+                # written before its first kernel starts: ~0.5 us a node), the large ones are enqueued behind it
+                rounds = min(steps - nb, 32) // nb if max(st_['cells'] for st_ in stats) <= 50_000 else 0
                 g_big = None
                 if rounds >= 2:
                     g_big = torch.cuda.CUDAGraph()
@@ -276,6 +278,9 @@ def main():
                 while i < n_steps and (start + i) % nb != 0:       # align to batch 0
                     graphs[(start + i) % nb][0].replay()
                     i += 1
+                if g_big is not None and n_steps - i >= (rounds + 1) * nb:
+                    g_all.replay()                                 # short enqueue: the GPU starts early
+                    i += nb
                 while g_big is not None and n_steps - i >= rounds * nb:
                     g_big.replay()
                     i += rounds * nb
@@ -290,6 +295,12 @@ def main():
             barrier()
             t0 = time.perf_counter()
             run_steps(steps, start=warmup)
+            # poll for the end of the stream before the (blocking) synchronize of barrier(): a blocked host
+            # thread is woken tens of microseconds after the GPU is done -- 5 % of a 20-step timed region
+            done = torch.cuda.Event()
+            done.record()
+            while not done.query():
+                pass
             barrier()
             dt = time.perf_counter() - t0
         if dist is not None:
