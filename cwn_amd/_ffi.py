@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 10
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_items_check', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_items_check', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
 
@@ -162,7 +162,10 @@ def lib():
     L.cwn_layer_pack_weights_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_layer_fused_lds_bytes.restype = C.c_size_t
     L.cwn_layer_fused_lds_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
-    L.cwn_update_mlp_f32.argtypes = [C.POINTER(MlpDim), C.c_int, C.c_void_p]
+    L.cwn_update_mlp_f32.argtypes = [C.POINTER(MlpDim), C.c_int, C.c_int32, C.c_void_p]
+    L.cwn_update_mlp_packed_weight_bytes.restype = C.c_size_t
+    L.cwn_update_mlp_packed_weight_bytes.argtypes = [C.c_int32]
+    L.cwn_update_mlp_pack_weights_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_update_mlp_max_rows.restype = C.c_int64
     L.cwn_update_mlp_max_rows.argtypes = []
     L.cwn_gemm_packed_weight_bytes.restype = C.c_size_t

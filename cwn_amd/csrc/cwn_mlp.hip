@@ -36,14 +36,24 @@ namespace {
 
 using cwn::frag_cd;
 
-constexpr int K = 128, N = 128, TM = 32, kThreads = 512;
-constexpr int kRowStride = K + 8;                 // bf16 elements per LDS row (272 B: fragment reads conflict-free)
-constexpr int kV = TM * 32 / kThreads;            // float4 of an input tile per thread
-constexpr int kRT = TM / 16;                      // 16-row tiles per workgroup
-constexpr int kChunksPerTile = 4 * 3;             // packed weight: 1-KiB chunks per 16-column tile (k steps x planes)
-constexpr size_t kPlaneElems = (size_t)TM * kRowStride;
-constexpr size_t kBufBytes = 3 * kPlaneElems * 2;  // three planes
-constexpr size_t kLdsBytes = 5 * kBufBytes;        // x_up / h_b, x_b, h1_up, h1_b, h_up
+constexpr int kThreads = 512;
+constexpr int kV = 2;                             // float4 of an input tile per thread
+constexpr int kRT = 2;                            // 16-row tiles per wave
+
+// F = the width of every Linear (64 or 128).  A workgroup takes TM = 4096 / F rows (32 / 64): 8 waves x two
+// 16 x 16 tiles cover its TM x F output either way -- wave w owns column tile w % (F / 16) and the row tiles
+// 2 (w / (F / 16)), + 1.
+template <int F> struct Shape {
+    static constexpr int kTM = 4096 / F;
+    static constexpr int kNCT = F / 16;
+    static constexpr int kKS = F / 32;
+    static constexpr int kRowStride = F + 8;          // bf16 elements per LDS row (fragment reads conflict-free)
+    static constexpr int kChunksPerTile = kKS * 3;    // packed weight: 1-KiB chunks per 16-column tile (k steps x planes)
+    static constexpr size_t kPlaneElems = (size_t)kTM * kRowStride;
+    static constexpr size_t kBufBytes = 3 * kPlaneElems * 2;   // three planes
+    static constexpr size_t kLdsBytes = 5 * kBufBytes;         // x_up / h_b, x_b, h1_up, h1_b, h_up
+    static_assert(kTM * (F / 4) == kV * kThreads && (kTM / 16) * kNCT == 8 * kRT, "tile shape");
+};
 
 struct MlpBatch {
     cwn_mlp_dim d[CWN_LAYER_MAX_DIMS];
@@ -73,7 +83,11 @@ unsigned long long* g_mlp_stamps = nullptr;
 // 16 x 16 tile: 21.0 us -- two waves per column tile request the same weight, 192 KB a stage, and the address
 // unit (64 B per clock and CU) became the bound; and in every form the epilogue constants requested BEHIND
 // the next weight made each stage wait for that weight (loads return in order).
+template <int F>
 __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
+    using S = Shape<F>;
+    constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
+    constexpr size_t kPlaneElems = S::kPlaneElems, kBufBytes = S::kBufBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* const bufA = reinterpret_cast<uint16_t*>(smem);                   // x_up, later h_b
     uint16_t* const bufC = reinterpret_cast<uint16_t*>(smem + kBufBytes);       // x_b
@@ -86,9 +100,9 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
         if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
     const cwn_mlp_dim& D = B.d[di];
     const int64_t row0 = (int64_t)((int)blockIdx.x - B.blk_start[di]) * TM;
-    const int lane = threadIdx.x & 63, ct = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ct = wave % S::kNCT, rt0 = (wave / S::kNCT) * kRT;
     const int l15 = lane & 15, kq = lane >> 4;
-    static_assert(kRT == 2 && kThreads == 512 && kV == 2, "one column tile per wave, two row tiles");
 
     // an input tile: TM rows x 32 float4, two per thread, row-contiguous; rows past M are clamped, not guarded
     typedef float4 RowRegs[kV];
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
     auto request_rows = [&](RowRegs& v, const float* X, int64_t ld) {
 #pragma unroll
         for (int i = 0; i < kV; ++i) {
-            const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
+            const int idx = threadIdx.x + i * kThreads, r = idx / (F / 4), c4 = idx % (F / 4);
             const int64_t row = row0 + r < D.M ? row0 + r : D.M - 1;
             v[i] = reinterpret_cast<const float4*>(X + row * ld)[c4];
         }
@@ -104,7 +118,7 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
     auto stage_rows = [&](const RowRegs& v, uint16_t* buf) {   // split the tile ONCE per element into the three planes
 #pragma unroll
         for (int i = 0; i < kV; ++i) {
-            const int idx = threadIdx.x + i * kThreads, r = idx >> 5, c4 = idx & 31;
+            const int idx = threadIdx.x + i * kThreads, r = idx / (F / 4), c4 = idx % (F / 4);
             uint2 ph, pm, pl;
             cwn::split4(v[i], ph, pm, pl);
             uint16_t* dst = buf + (size_t)r * kRowStride + c4 * 4;
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
         __builtin_amdgcn_s_barrier();
     };
     // the stationary operand of a stage: this wave's 16 output columns, [k step][plane]; two sets
-    typedef uint4 WeightRegs[4][3];
+    typedef uint4 WeightRegs[kKS][3];
     WeightRegs wfA, wfB;
     auto request_kstep = [&](WeightRegs& wf, int k, int ks) {
         const unsigned char* wp = reinterpret_cast<const unsigned char*>(D.w_packed[k]) +
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
     };
     auto request_weight = [&](WeightRegs& wf, int k) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) request_kstep(wf, k, ks);
+        for (int ks = 0; ks < kKS; ++ks) request_kstep(wf, k, ks);
     };
     typedef frag_cd AccRegs[kRT];
     AccRegs accU, accB;                          // the two branches alternate (see the chain below)
@@ -146,10 +160,10 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
     // idled, and then multiplied while the address unit idled)
     auto multiply = [&](AccRegs& acc, const uint16_t* buf, const WeightRegs& wf, WeightRegs& wnext, int next) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < kKS; ++ks) {
 #pragma unroll
             for (int rt = 0; rt < kRT; ++rt) {
-                const uint16_t* p = buf + (size_t)(rt * 16 + l15) * kRowStride + ks * 32 + kq * 8;
+                const uint16_t* p = buf + (size_t)((rt0 + rt) * 16 + l15) * kRowStride + ks * 32 + kq * 8;
                 const uint4 xh = *reinterpret_cast<const uint4*>(p);
                 const uint4 xm = *reinterpret_cast<const uint4*>(p + kPlaneElems);
                 const uint4 xl = *reinterpret_cast<const uint4*>(p + 2 * kPlaneElems);
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) y[q] = fmaxf(y[q], 0.0f);
-            const int r = rt * 16 + l15;
+            const int r = (rt0 + rt) * 16 + l15;
             if (buf != nullptr) {
                 uint2 ph, pm, pl;
                 cwn::split4(make_float4(y[0], y[1], y[2], y[3]), ph, pm, pl);
@@ -258,19 +272,73 @@ extern "C" void cwn_mlp_debug_stamps(unsigned long long* buf) { g_mlp_stamps = b
 
 extern "C" int64_t cwn_update_mlp_max_rows(void) { return 1 << 20; }
 
-extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, cwn_stream_t stream_) {
-    if (dims == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS) return CWN_ERR_BAD_ARG;
+extern "C" size_t cwn_update_mlp_packed_weight_bytes(int32_t F) { return (F == 64 || F == 128) ? (size_t)F * F * 6 : 0; }
+
+namespace {
+
+// fp32 [F, F] weight (row stride ldw) -> bf16 hi / mid / lo planes in MFMA-fragment order: the 1-KiB chunk number
+// ((tile * KS + ks) * 3 + plane) holds, for lane l = kq * 16 + n, the eight k-values
+// W[tile * 16 + n][ks * 32 + kq * 8 ..] of that plane (F = 128: the layout of cwn_gemm_pack_weights_f32).
+template <int F>
+__global__ __launch_bounds__(256) void pack_mlp_weights_kernel(const float* __restrict__ W, int64_t ldw,
+                                                               unsigned char* __restrict__ out) {
+    constexpr int KS = F / 32;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (tile, ks, lane)
+    if (g >= (F / 16) * KS * 64) return;
+    const int lane = g & 63, ks = (g >> 6) % KS, tile = (g >> 6) / KS;
+    const float* src = W + (int64_t)(tile * 16 + (lane & 15)) * ldw + ks * 32 + (lane >> 4) * 8;
+    const float4 a = make_float4(src[0], src[1], src[2], src[3]), b = make_float4(src[4], src[5], src[6], src[7]);
+    uint4 ph, pm, pl;
+    cwn::split8(a, b, ph, pm, pl);
+    unsigned char* dst = out + ((size_t)(tile * KS + ks) * 3) * 1024 + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = ph;
+    *reinterpret_cast<uint4*>(dst + 1024) = pm;
+    *reinterpret_cast<uint4*>(dst + 2048) = pl;
+}
+
+template <int F>
+int launch_mlp(MlpBatch& B, int64_t blocks, hipStream_t stream) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&update_mlp_kernel<F>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Shape<F>::kLdsBytes);
+    });
+    if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
+#ifdef CWN_MLP_TIMING
+    B.stamps = g_mlp_stamps;
+#endif
+    update_mlp_kernel<F><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F>::kLdsBytes, stream>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int cwn_update_mlp_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream_) {
+    if ((F != 64 && F != 128) || W == nullptr || out == nullptr || ldw < F) return CWN_ERR_BAD_ARG;
+    if (((uintptr_t)W & 3u) || !al16(out)) return CWN_ERR_ALIGN;
+    const int threads = (F / 16) * (F / 32) * 64;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (F == 128) pack_mlp_weights_kernel<128><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
+    else pack_mlp_weights_kernel<64><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, int32_t F, cwn_stream_t stream_) {
+    if (dims == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS || (F != 64 && F != 128)) return CWN_ERR_BAD_ARG;
+    const int TM = 4096 / F;
     MlpBatch B{};
     B.n = n_dims;
-    int64_t blocks = 0, rows = 0;
+    int64_t blocks = 0;
     for (int i = 0; i < n_dims; ++i) {
         const cwn_mlp_dim& D = dims[i];
         if (D.M < 0) return CWN_ERR_BAD_ARG;
+        if (D.M > cwn_update_mlp_max_rows()) return CWN_ERR_TOO_LARGE;
         B.blk_start[i] = (int32_t)blocks;
         B.d[i] = D;
         if (D.M == 0) continue;
         if (D.x_up == nullptr || D.x_b == nullptr || D.y == nullptr) return CWN_ERR_BAD_ARG;
-        if (D.ldx_up < K || D.ldx_b < K || D.ldy < N || D.ldx_up % 4 || D.ldx_b % 4 || D.ldy % 4) return CWN_ERR_BAD_ARG;
+        if (D.ldx_up < F || D.ldx_b < F || D.ldy < F || D.ldx_up % 4 || D.ldx_b % 4 || D.ldy % 4) return CWN_ERR_BAD_ARG;
         if (!(al16(D.x_up) && al16(D.x_b) && al16(D.y))) return CWN_ERR_ALIGN;
         for (int k = 0; k < 6; ++k) {
             if (D.w_packed[k] == nullptr) return CWN_ERR_BAD_ARG;
@@ -281,21 +349,8 @@ extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, cwn_strea
             if (!(al16(D.bias[s]) && al16(D.scale[s]) && al16(D.shift[s]))) return CWN_ERR_ALIGN;
         }
         blocks += (D.M + TM - 1) / TM;
-        rows += D.M;
     }
     for (int i = n_dims; i <= CWN_LAYER_MAX_DIMS; ++i) B.blk_start[i] = (int32_t)blocks;
-    if (rows > cwn_update_mlp_max_rows() * CWN_LAYER_MAX_DIMS) return CWN_ERR_TOO_LARGE;
     if (blocks == 0) return CWN_OK;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&update_mlp_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    });
-    if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
-#ifdef CWN_MLP_TIMING
-    B.stamps = g_mlp_stamps;
-#endif
-    update_mlp_kernel<<<dim3((unsigned)blocks), dim3(kThreads), kLdsBytes, (hipStream_t)stream_>>>(B);
-    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+    return F == 128 ? launch_mlp<128>(B, blocks, (hipStream_t)stream_) : launch_mlp<64>(B, blocks, (hipStream_t)stream_);
 }

@@ -818,12 +818,15 @@ class MlpDim:
 
 
 def update_mlp_applies(dims: Sequence[MlpDim]) -> bool:
-    """The fused update / combine launch serves 128-wide networks on small launches (include/cwn_hip.h)."""
+    """The fused update / combine launch serves networks whose Linear layers are all 64 or all 128 wide."""
     cap = int(_ffi.lib().cwn_update_mlp_max_rows())
+    F = int(dims[0].x_up.size(1))
+    if F not in (64, 128):
+        return False
     for D in dims:
-        if D.x_up.size(0) > cap or D.x_up.size(1) != 128 or D.x_b.size(1) != 128 or len(D.linears) != 5:
+        if D.x_up.size(0) > cap or D.x_up.size(1) != F or D.x_b.size(1) != F or len(D.linears) != 5:
             return False
-        if any(tuple(l.weight.shape) != (128, 128) for l in D.linears[:4]) or tuple(D.linears[4].weight.shape) != (128, 256):
+        if any(tuple(l.weight.shape) != (F, F) for l in D.linears[:4]) or tuple(D.linears[4].weight.shape) != (F, 2 * F):
             return False
     return True
 
@@ -831,19 +834,22 @@ def update_mlp_applies(dims: Sequence[MlpDim]) -> bool:
 def update_mlp(dims: Sequence[MlpDim]) -> List[Tensor]:
     """mp/layers.py:193-199 for every dimension in ONE launch (csrc/cwn_mlp.hip); inference only."""
     dev = dims[0].x_up.device
+    F = int(dims[0].x_up.size(1))
     arr = (_ffi.MlpDim * len(dims))()
     outs, keep = [], []
     for i, D in enumerate(dims):
         xu, xb = _rowmajor(D.x_up, 'x_up'), _rowmajor(D.x_b, 'x_b')
-        y = torch.empty(xu.size(0), 128, dtype=torch.float32, device=dev)
+        y = torch.empty(xu.size(0), F, dtype=torch.float32, device=dev)
         outs.append(y)
         a = arr[i]
         a.x_up, a.x_b, a.y, a.M = xu.data_ptr(), xb.data_ptr(), y.data_ptr(), xu.size(0)
-        a.ldx_up = xu.stride(0) if xu.size(0) > 1 else 128
-        a.ldx_b = xb.stride(0) if xb.size(0) > 1 else 128
-        a.ldy = 128
-        packed = [pack_gemm_weight(l.weight) for l in D.linears[:4]]
-        packed += list(pack_combine_weight(D.linears[4].weight))
+        a.ldx_up = xu.stride(0) if xu.size(0) > 1 else F
+        a.ldx_b = xb.stride(0) if xb.size(0) > 1 else F
+        a.ldy = F
+        packed = []
+        for l in D.linears[:4]:
+            packed += list(pack_mlp_weight(l.weight))
+        packed += list(pack_mlp_weight(D.linears[4].weight))
         for k, pk in enumerate(packed):
             a.w_packed[k] = pk.data_ptr()
         for s_, (lin, (sc, sh)) in enumerate(zip(D.linears, D.folds)):
@@ -851,35 +857,38 @@ def update_mlp(dims: Sequence[MlpDim]) -> List[Tensor]:
             a.bias[s_], a.scale[s_], a.shift[s_] = _ffi.ptr(b), _ffi.ptr(sc), _ffi.ptr(sh)
             keep += [b, sc, sh]
         keep += packed + [xu, xb]
-    _ffi.check(_ffi.lib().cwn_update_mlp_f32(arr, len(dims), _ffi.stream_ptr(dev)), 'cwn_update_mlp_f32')
+    _ffi.check(_ffi.lib().cwn_update_mlp_f32(arr, len(dims), F, _ffi.stream_ptr(dev)), 'cwn_update_mlp_f32')
     return outs
 
 
-_packed_combine_weights = {}
+_packed_mlp_weights = {}
 
 
-def pack_combine_weight(weight: Tensor):
-    """The two column halves of a combine Linear(256 -> 128) weight, each packed like a 128 x 128 weight
-    (cwn_gemm_pack_weights_f32 with ldw = 256); cached per weight version."""
+def pack_mlp_weight(weight: Tensor):
+    """An [F, F] weight -- or the column halves of an [F, 2F] combine weight -- in the form cwn_update_mlp_f32
+    streams (cwn_update_mlp_pack_weights_f32); a tuple of one or two buffers, cached per weight version."""
     import weakref
     w = weight.detach()
     key = id(weight)
-    ver = (w.data_ptr(), weight._version, w.device)
-    hit = _packed_combine_weights.get(key)
+    ver = (w.data_ptr(), weight._version, tuple(w.shape), w.device)
+    hit = _packed_mlp_weights.get(key)
     if hit is not None and hit[0] == ver and hit[1]() is weight:
         return hit[2]
     w = _rowmajor(w, 'W')
+    F = int(w.size(0))
     L = _ffi.lib()
-    n = int(L.cwn_gemm_packed_weight_bytes())
-    halves = []
-    for c0 in (0, 128):
+    n = int(L.cwn_update_mlp_packed_weight_bytes(F))
+    if n == 0 or w.size(1) not in (F, 2 * F):
+        raise ValueError('expected an [F, F] or [F, 2F] weight with F in (64, 128)')
+    parts = []
+    for c0 in range(0, w.size(1), F):
         out = torch.empty(n, dtype=torch.uint8, device=w.device)
-        _ffi.check(L.cwn_gemm_pack_weights_f32(w.data_ptr() + 4 * c0, w.stride(0), out.data_ptr(), _ffi.stream_ptr(w.device)),
-                   'cwn_gemm_pack_weights_f32')
-        halves.append(out)
-    halves = tuple(halves)
-    _packed_combine_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_combine_weights.pop(k, None)), halves)
-    return halves
+        _ffi.check(L.cwn_update_mlp_pack_weights_f32(w.data_ptr() + 4 * c0, w.stride(0), F, out.data_ptr(),
+                                                     _ffi.stream_ptr(w.device)), 'cwn_update_mlp_pack_weights_f32')
+        parts.append(out)
+    parts = tuple(parts)
+    _packed_mlp_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_mlp_weights.pop(k, None)), parts)
+    return parts
 
 
 def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tensor]:

@@ -307,30 +307,35 @@ size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_s
  *     h_b  = relu(bn(W2b relu(bn(W1b x_b  + b1b)) + b2b))          update_boundaries_nn  (:312-321)
  *     y    = relu(bn(Wc [h_up | h_b] + bc))                        combine_nn            (:322-325, :193-199)
  *
- * with every Linear 128 wide (Wc: 256 -> 128), BatchNorm in eval mode folded into a per-column
+ * with every Linear F wide (Wc: 2F -> F; F = 64 or 128), BatchNorm in eval mode folded into a per-column
  * (scale, shift) or absent (NULL pair), ReLU after every stage.  x_up / x_b are the two outputs of the
- * propagate step (cwn_layer_fused_f32: out_up, out_b).  A workgroup takes 32 rows through all five
+ * propagate step (cwn_layer_fused_f32: out_up, out_b).  A workgroup takes 4096 / F rows through all five
  * Linear layers without leaving the CU: the intermediate activations never reach HBM.  Products on the
  * bf16 matrix pipe through the exact three-way operand split (fp32 accuracy, csrc/cwn_split.h).
- * w_packed: cwn_gemm_pack_weights_f32 of W1u, W2u, W1b, W2b, Wc[:, :128], Wc[:, 128:] (the last two: the
- * column halves of the combine weight, ldw = 256); bias / scale / shift per stage in the order
+ * w_packed: cwn_update_mlp_pack_weights_f32 of W1u, W2u, W1b, W2b, Wc[:, :F], Wc[:, F:] (the last two: the
+ * column halves of the combine weight, ldw = 2F; at F = 128 cwn_gemm_pack_weights_f32 gives the same
+ * layout); bias / scale / shift per stage in the order
  * (1u, 2u, 1b, 2b, c), bias may be NULL.  At most cwn_update_mlp_max_rows() rows per dimension
  * (CWN_ERR_TOO_LARGE beyond; the same networks as grouped launches: cwn_gemm_f32).
  * Every pointer 16-B aligned, row strides multiples of 4; no workspace, no host sync.
  * ------------------------------------------------------------------------------------------ */
 typedef struct cwn_mlp_dim {
-    const float* x_up;          /* [M, 128], row stride ldx_up */
-    const float* x_b;           /* [M, 128], row stride ldx_b */
+    const float* x_up;          /* [M, F], row stride ldx_up */
+    const float* x_b;           /* [M, F], row stride ldx_b */
     const void* w_packed[6];
-    const float* bias[5];       /* [128] or NULL */
-    const float* scale[5];      /* [128] or NULL (then shift NULL too) */
+    const float* bias[5];       /* [F] or NULL */
+    const float* scale[5];      /* [F] or NULL (then shift NULL too) */
     const float* shift[5];
-    float* y;                   /* [M, 128], row stride ldy */
+    float* y;                   /* [M, F], row stride ldy */
     int64_t M, ldx_up, ldx_b, ldy;
 } cwn_mlp_dim;
 
-int cwn_update_mlp_f32(const cwn_mlp_dim* dims_host, int n_dims, cwn_stream_t stream);
+int cwn_update_mlp_f32(const cwn_mlp_dim* dims_host, int n_dims, int32_t F, cwn_stream_t stream);
 int64_t cwn_update_mlp_max_rows(void);
+/* an [F, F] weight (row stride ldw) in the form the kernel streams it: cwn_update_mlp_packed_weight_bytes(F)
+ * bytes, 16-B aligned; one small launch per weight VERSION */
+size_t cwn_update_mlp_packed_weight_bytes(int32_t F);
+int cwn_update_mlp_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense parts of the path on the matrix cores (fp32 MFMA, exact fp32):

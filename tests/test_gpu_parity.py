@@ -1148,15 +1148,15 @@ def test_gemm_split_packed_weight_is_bit_identical(M):
     assert _ffi.lib().cwn_gemm_packed_weight_bytes() == 128 * 128 * 6
 
 
-@pytest.mark.parametrize('rows', [(3165, 3341, 304), (1, 33, 0), (64, 31, 32)])
-def test_fused_update_mlp_vs_float64_and_three_launch_path(rows):
+@pytest.mark.parametrize('F', [128, 64])
+@pytest.mark.parametrize('rows', [(3165, 3341, 304), (1, 33, 0), (64, 31, 32), (65, 129, 63)])
+def test_fused_update_mlp_vs_float64_and_three_launch_path(rows, F):
     """cwn_update_mlp_f32 (csrc/cwn_mlp.hip): update_up_nn, update_boundaries_nn and combine_nn of every
     dimension (mp/layers.py:193-199, :303-325) in one launch, against the same networks evaluated in float64
     on the CPU (north-star gate) and against the three grouped GEMM launches it replaces."""
     from cwn_amd import layers
     from cwn_amd.layers import SparseCINConv
-    torch.manual_seed(sum(rows))
-    F = 128
+    torch.manual_seed(sum(rows) + F)
     conv = SparseCINConv(F, F, F, None, None, None, None, max_dim=2, hidden=F, act_module=torch.nn.ReLU,
                          layer_dim=F, use_coboundaries=True, graph_norm=torch.nn.BatchNorm1d).eval()
     with torch.no_grad():                                # non-trivial BatchNorm statistics and affine
