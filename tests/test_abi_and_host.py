@@ -86,6 +86,23 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_layer_pack_weights_f32(None, 256, 128, None, None) == 1
     assert lib.cwn_layer_packed_weight_bytes(128) == 128 * 256 * 6 and lib.cwn_layer_packed_weight_bytes(96) == 0
     assert lib.cwn_layer_fused_lds_bytes(128, 96, 64) == 3 * 96 * 136 * 2 + 65 * 128 * 4 + 9648
+    # round-2 additions
+    assert lib.cwn_update_mlp_f32(None, 1, 128, None) == 1
+    m = (_ffi.MlpDim * 1)(_ffi.MlpDim(M=0))
+    assert lib.cwn_update_mlp_f32(m, 1, 96, None) == 1               # widths other than 64 / 128
+    assert lib.cwn_update_mlp_f32(m, 1, 64, None) == 0               # nothing to do
+    m[0].M = 5                                                        # rows but no operands
+    assert lib.cwn_update_mlp_f32(m, 1, 128, None) == 1
+    m[0].M = lib.cwn_update_mlp_max_rows() + 1
+    assert lib.cwn_update_mlp_f32(m, 1, 128, None) == 2              # CWN_ERR_TOO_LARGE
+    assert lib.cwn_update_mlp_packed_weight_bytes(64) == 64 * 64 * 6 and lib.cwn_update_mlp_packed_weight_bytes(32) == 0
+    assert lib.cwn_update_mlp_pack_weights_f32(None, 128, 128, None, None) == 1
+    assert lib.cwn_gemm_packed_weight_bytes() == 128 * 128 * 6
+    assert lib.cwn_gemm_pack_weights_f32(None, 128, None, None) == 1
+    assert lib.cwn_layer_items_check(None, 0, 128, None) == 1
+    assert lib.cwn_layer_round_rows(128) in (16, 32) and lib.cwn_layer_round_rows(100) == 0
+    g = (_ffi.GemmDesc * 1)(_ffi.GemmDesc(M=4, N=64, K=64, K2=0, ldx=64, ldw=64, ldy=64, flags=_ffi.GEMM_W_PACKED))
+    assert lib.cwn_gemm_would_split(g, 1) == 0                       # not the split kernel's shape ...
 
 
 def test_cpu_tensors_fail_loudly():
