@@ -23,7 +23,7 @@ TARGET_ITEMS = 128             # per GEMM dimension: ~one workgroup per CU over 
 
 
 def gemm_rows_cap(F: int) -> int:
-    return 12288 // F          # = CWN_LAYER_GEMM_ROWS(F) = CWN_LAYER_SOURCE_ROWS(F)
+    return 256 if F == 64 else 96          # = CWN_LAYER_GEMM_ROWS(F) = CWN_LAYER_SOURCE_ROWS(F)
 
 
 LDS_BYTES = 160 * 1024
@@ -149,7 +149,27 @@ class BlockPlan:
         return self._tables[key]
 
     def _build(self, F: int, has_up) -> Optional[ItemTable]:
+        # one launch = one LDS size: the planes for the LARGEST staged block of any item plus the sources of
+        # the item with the most of them (different items, in general: vertices + edges items want rows, edges +
+        # rings items want sources).  A few splits of the LDS between the two are tried -- row cap from the top
+        # down, the source cap = what is left -- and the one with the fewest items wins
         cap = gemm_rows_cap(F)
+        step = max(16, cap // 8)
+        best = None
+        for row_cap in range(cap, step - 1, -step):
+            src_cap = min(cap, (LDS_BYTES - 3 * row_cap * (F + 8) * 2 - _IDX_BYTES) // (F * 4) - 1)
+            if src_cap < 16:
+                continue
+            t = self._build_with(F, has_up, row_cap, src_cap)
+            if t is None or lds_bytes(F, t.max_rows, t.max_src) > LDS_BYTES:
+                continue
+            if best is None or t.n_items < best.n_items:
+                best = t
+            elif t.n_items > best.n_items + best.n_items // 8:
+                break                               # getting worse: smaller row caps only split more
+        return best
+
+    def _build_with(self, F: int, has_up, row_cap: int, src_cap: int) -> Optional[ItemTable]:
         from . import _ffi
         ng_round = int(_ffi.lib().cwn_layer_round_rows(F))   # rows per round of the kernel: the coface block starts at a multiple
         if ng_round <= 0:
@@ -189,7 +209,7 @@ class BlockPlan:
                     src = sum(int(cp[d - 1][nxt] - cp[d - 1][c0]) for d, bp in zip(tasks, bps)
                               if d > 0 and bp[nxt] > bp[c0])
                     ents = _pad4(int(up[nxt] - up[c0])) + sum(_pad4(int(bp[nxt] - bp[c0])) for bp in bps)
-                    ok = (rows <= cap and src <= cap and lds_bytes(F, rows, src) <= LDS_BYTES
+                    ok = (rows <= row_cap and src <= src_cap and lds_bytes(F, rows, src) <= LDS_BYTES
                           and ents <= MAX_ENTRIES
                           and all(int(cp[d][nxt] - cp[d][c0]) <= TASK_ROWS for d in tasks))
                     if not ok:
@@ -242,6 +262,8 @@ class BlockPlan:
                   for d in range(self.n_dims)]
         b_end = [int(self.b_ptr[d][-1]) if (self.b_ptr[d] is not None and d > 0) else 0 for d in range(self.n_dims)]
         out = ItemTable(table, set_start, max(max_rows, 16), max_src, cells_end, up_end, b_end, self.device)
+        if lds_bytes(F, out.max_rows, out.max_src) > LDS_BYTES:
+            return out                          # the caller lowers the row cap and builds again
         rc = _ffi.lib().cwn_layer_items_check(table.ctypes.data, table.shape[0], F, out.c_plan(False))
         if rc != 0:
             raise _ffi.CwnError(f'item table failed cwn_layer_items_check ({rc})')

@@ -89,8 +89,6 @@ constexpr int kHS = kThreads == 1024 ? 2 : 1;   // 2: a wave computes Y1 OR Y2; 
 constexpr int kEcap = CWN_LAYER_MAX_ENTRIES;
 constexpr int kEI = kEcap / kThreads;       // COO entries per thread
 constexpr int kTaskRows = CWN_LAYER_TASK_ROWS;
-constexpr int kNX = 12288 / 4 / kThreads;   // float4 of staged rows per thread at the row cap (12288 / F rows)
-constexpr int kNE = kNX;                    // float4 of boundary-source rows per thread (12288 / F rows)
 
 // item record fields (include/cwn_hip.h)
 enum { I_FLAGS = 0, I_G, I_GR0, I_GN, I_CR0, I_CN, I_UE0, I_UNE, I_NT, I_TASK0, I_R1 = 23, I_ROWS, I_B1, I_B2, I_TOTAL };
@@ -143,6 +141,9 @@ template <int F> struct Geo {
     static constexpr int kWPC = kWaves / kNCT / kHS;        // waves sharing a column tile of a product (row-tile parity)
     static constexpr int kG = F / 4;                        // lanes per row
     static constexpr int kNG = kThreads / kG;               // rows per round (1024 threads: 32 at F = 128, 64 at F = 64)
+    static constexpr int kNX = CWN_LAYER_GEMM_ROWS(F) / kNG;     // float4 of staged rows per thread at the row cap
+    static constexpr int kNE = CWN_LAYER_SOURCE_ROWS(F) / kNG;   // float4 of boundary-source rows per thread at the cap
+    static_assert(CWN_LAYER_GEMM_ROWS(F) % kNG == 0 && CWN_LAYER_SOURCE_ROWS(F) % kNG == 0, "caps are whole rounds");
     static constexpr int kWChunks = 2 * kKS * 3;            // 1-KiB chunks of the packed weight per column tile
     // planes [3][rows][F + 8] bf16, overwritten by Y [rows][F + 4] fp32 once the MFMAs have read them
     __host__ __device__ static constexpr size_t planes_bytes(int rows) { return (size_t)3 * rows * kPlaneStride * 2; }
@@ -216,10 +217,11 @@ __device__ __forceinline__ float4 sel4(bool c, const float4& a, const float4& b)
     return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
 }
 // xv[k] for a run-time k: a chain of selects on registers (an indexed array would live in scratch)
-__device__ __forceinline__ float4 pick(const float4 (&xv)[kNX], int k) {
+template <int NX>
+__device__ __forceinline__ float4 pick(const float4 (&xv)[NX], int k) {
     float4 r = xv[0];
 #pragma unroll
-    for (int i = 1; i < kNX; ++i) r = sel4(k == i, xv[i], r);
+    for (int i = 1; i < NX; ++i) r = sel4(k == i, xv[i], r);
     return r;
 }
 
@@ -479,6 +481,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // boundary stream of task 0 gathers from; round i is skipped when no item row falls into it
     // (no zero fill: merging a constant with a load result made the compiler copy the loaded register right
     // behind the load -- s_waitcnt vmcnt(0) in the middle of the run)
+    constexpr int kNX = G::kNX, kNE = G::kNE;
     float4 xv[kNX], ev4[kNE];
     {
         // uniform base of the block (SGPR pair) + a 32-bit byte offset per lane.  Round i belongs to the
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         // this wave's row tiles: at most kMaxT per half (six 16-row tiles in all at the row cap); the
         // accumulators wait in registers until every wave has read its fragments, because Y
         // overwrites the planes.  Tiles go in PAIRS (two independent MFMA chains in flight).
-        constexpr int kMaxT = 12288 / F / 16 / G::kWPC;
+        constexpr int kMaxT = CWN_LAYER_GEMM_ROWS(F) / 16 / G::kWPC;
         static_assert(kMaxT % 2 == 0, "tiles are processed in pairs");
         static_assert(offsetof(LayerArgs, set) == 0, "read through the kernarg segment pointer");
         static_assert(kSetFields <= 64 && CWN_LAYER_ITEM_INTS <= 64, "one lane per field");

@@ -233,8 +233,8 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  * ------------------------------------------------------------------------------------------ */
 #define CWN_LAYER_MAX_DIMS 3
 #define CWN_LAYER_ITEM_INTS 32
-#define CWN_LAYER_GEMM_ROWS(F) (12288 / (F))   /* 96 at F = 128, 192 at F = 64 */
-#define CWN_LAYER_SOURCE_ROWS(F) (12288 / (F)) /* cells of dim d-1 the boundary streams of an item read */
+#define CWN_LAYER_GEMM_ROWS(F) ((F) == 64 ? 256 : 96)    /* staged rows of an item (whole rounds of cwn_layer_round_rows) */
+#define CWN_LAYER_SOURCE_ROWS(F) ((F) == 64 ? 256 : 96)  /* cells of dim d-1 the boundary stream of an item's first task reads */
 #define CWN_LAYER_TASK_ROWS 192
 #define CWN_LAYER_MAX_ENTRIES 1024
 #define CWN_ERR_BIT_BLOCK 8                    /* *err_flag bit: index outside its item */
