@@ -139,6 +139,16 @@ class BlockPlan:
                 d += 1
         return sets
 
+    def at_least(self, F: int, has_up: Sequence[bool]) -> int:
+        """A lower bound of the number of items (staged rows of all complexes / the row cap, per set), in O(1):
+        lets a caller with an item limit skip building the table of a very large batch."""
+        cap = gemm_rows_cap(F)
+        n = 0
+        for g, tasks in self._sets(has_up):
+            rows = int(self.cell_ptr[tasks[0]][-1]) + (int(self.cell_ptr[g + 1][-1]) if g is not None else 0)
+            n += max(1, -(-rows // cap)) if self.C else 0
+        return n
+
     def items(self, F: int, has_up: Sequence[bool]) -> Optional[ItemTable]:
         """The item table for feature width F, or None when some complex does not fit one
         workgroup's LDS (hub complexes: the caller then runs the CSR path).  `has_up[d]`: dimension d

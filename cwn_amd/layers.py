@@ -728,6 +728,8 @@ class SparseCINConv(torch.nn.Module):
                 D.b_index = b_index
             dims.append(D)
             has_up.append(bool(up))
+        if plan.at_least(F, has_up) > BLOCKED_MAX_ITEMS:
+            return f'more than {BLOCKED_MAX_ITEMS} items: beyond the range where one workgroup per item beats the streaming CSR path'
         table = plan.items(F, has_up)
         if table is None:
             return 'a complex does not fit one workgroup (row / entry caps)'
