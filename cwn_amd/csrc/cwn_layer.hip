@@ -427,8 +427,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // sort modes: the per-row entry counters of the three adjacencies are zeroed here and visible to every wave
     // behind the barrier in front of the late weight requests
     if constexpr (MODE != kLoad) {
-        static_assert(3 * kRpStride <= kThreads, "one counter per thread");
-        if (tid < 3 * kRpStride) ecnt[tid] = 0u;
+        for (int i = tid; i < 3 * kRpStride; i += kThreads) ecnt[i] = 0u;
     }
 
     // ---- 2. every global load of the item, in one run; no load behind a DIVERGENT branch ---------------
