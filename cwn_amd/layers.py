@@ -24,7 +24,6 @@ from abc import ABC, abstractmethod
 from typing import Any, Callable, List, Optional
 
 import torch
-import torch.nn.functional as Fn
 from torch import Tensor
 from torch.nn import BatchNorm1d as BN, Linear, ReLU, Sequential
 

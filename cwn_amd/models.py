@@ -7,7 +7,7 @@ pin the whole stack against golden vectors of the reference model.  `SparseCIN` 
 mp/models.py:120-260 for non-embedded inputs (REDDIT-like config).  The readout
 (`pool_complex`, mp/nn.py:50-60) runs on the same segmented-reduce kernel as propagate.
 """
-from typing import List, Optional
+from typing import List
 
 import torch
 import torch.nn.functional as F

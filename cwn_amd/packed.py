@@ -11,13 +11,13 @@ that loop IS the step.  Here every complex's tensors are uploaded ONCE, concaten
   * fills every array of the ComplexBatch with ONE launch of cwn_collate.
 The integer layout is bit-exact against the reference's (tests/golden/batching.npz).
 """
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Sequence
 
 import numpy as np
 import torch
 
 from . import _ffi
-from .complex import Cochain, CochainBatch, Complex, ComplexBatch
+from .complex import CochainBatch, Complex, ComplexBatch
 
 _INDEX_KEYS = ('upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries', 'boundary_index')
 _ALL_KEYS = ('x', 'y') + _INDEX_KEYS

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _ffi, ops
-from .blockplan import CSR_SLOT_BYTES, ITEM_INTS, ItemTable, gemm_rows_cap
+from .blockplan import ITEM_INTS, ItemTable, gemm_rows_cap
 from .complex import ComplexBatch
 
 CAPTURE_MODE = 'thread_local'
