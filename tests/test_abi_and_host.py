@@ -406,3 +406,63 @@ def test_item_table_derived_fields_and_host_check():
         empty = np.zeros((3, ITEM_INTS), dtype=np.int32)                                       # static-graph filler
         cplan.n_items = 3
         assert L.cwn_layer_items_check(empty.ctypes.data, 3, F, cplan) == 0
+
+
+def test_block_plan_covers_every_complex_once_and_fits_the_launch():
+    """cwn_amd/blockplan.py on random per-complex size tables (no tensors, no GPU): the items of a set are
+    contiguous ranges of complexes that cover the batch exactly once, every item respects the caps, ONE LDS
+    size serves the whole launch (the builder's split between staged rows and boundary sources), the count is
+    at least the O(1) lower bound, and a complex that cannot fit gives no table at all."""
+    import numpy as np
+    from cwn_amd import _ffi
+    from cwn_amd.blockplan import BlockPlan, LDS_BYTES, MAX_ENTRIES, TASK_ROWS, gemm_rows_cap, lds_bytes
+    rng = np.random.default_rng(7)
+    L = _ffi.lib()
+    for trial in range(40):
+        C = int(rng.integers(1, 400))
+        big = trial % 5 == 0
+        n0 = rng.integers(1, 60 if big else 30, size=C)
+        n1 = n0 + rng.integers(-1, 4, size=C).clip(min=0)           # edges ~ vertices
+        n2 = rng.integers(0, 4, size=C)
+        n2[n1 == 0] = 0
+        up0 = 2 * n1                                                # two directed entries per edge
+        up1 = n2 * rng.integers(6, 31, size=C)                      # edges sharing a ring
+        b1 = 2 * n1
+        b2 = n2 * rng.integers(3, 7, size=C)
+        ptr = lambda v: np.concatenate([[0], np.cumsum(v)])
+        plan = BlockPlan([n0, n1, n2], [ptr(up0), ptr(up1), None], [None, ptr(b1), ptr(b2)])
+        for F in (64, 128):
+            t = plan.items(F, [True, True, False])
+            cap = gemm_rows_cap(F)
+            if t is None:
+                # only legitimate when some single complex exceeds a cap
+                def staged(a, b):
+                    ng = L.cwn_layer_round_rows(F)
+                    r1 = (a + 15) // 16 * 16
+                    return ((r1 + ng - 1) // ng * ng + (b + 15) // 16 * 16) if b > 0 else r1
+                too_big = any(staged(int(a), int(b)) > cap or staged(int(b), int(c)) > cap or int(u0) + 3 > MAX_ENTRIES
+                              or int(u1) + int(e1) + int(e2) + 9 > MAX_ENTRIES or int(a) + int(b) > cap
+                              or lds_bytes(F, staged(int(b), int(c)), int(a) + int(b)) > LDS_BYTES
+                              for a, b, c, u0, u1, e1, e2 in zip(n0, n1, n2, up0, up1, b1, b2))
+                assert too_big, (trial, F)
+                continue
+            tab = t.items.numpy()
+            assert t.n_items >= plan.at_least(F, [True, True, False]) or t.n_items >= 2
+            assert lds_bytes(F, t.max_rows, t.max_src) <= LDS_BYTES
+            assert L.cwn_layer_fused_lds_bytes(F, t.max_rows, t.max_src) == lds_bytes(F, t.max_rows, t.max_src)
+            assert tab[:, 24].max() <= t.max_rows <= cap and tab[:, 27].max() <= MAX_ENTRIES
+            assert tab[:, 11].max() <= TASK_ROWS and tab[:, 18].max() <= TASK_ROWS
+            # coverage: per set, the task-0 cell ranges tile [0, N_d) exactly once
+            for s_, d0 in ((0, 0), (1, 1)):
+                lo, hi = t.set_start[s_], (t.set_start[s_ + 1] if s_ + 1 < len(t.set_start) else t.n_items)
+                rows = tab[lo:hi]
+                assert ((rows[:, 0] >> 8) == s_).all()
+                order = np.argsort(rows[:, 10], kind='stable')
+                starts, counts = rows[order, 10], rows[order, 11]
+                total = int([n0, n1][d0].sum())
+                live = counts > 0
+                assert int(counts.sum()) == total
+                assert (starts[live][1:] == (starts[live] + counts[live])[:-1]).all() and (total == 0 or starts[live][0] == 0)
+            # the rings ride as the second task of the edges' items, the same complexes
+            rows = tab[t.set_start[1]:]
+            assert int(rows[:, 18].sum()) == int(n2.sum())
