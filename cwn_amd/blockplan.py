@@ -6,9 +6,11 @@ complex are contiguous in every batched tensor.  The reference's collate records
 `ptr` (cells, data/complex.py:344, 432) and `__slices__` (entries per key, :349-394).  From those
 host-side tables this module cuts a batch into ITEMS -- contiguous ranges of complexes for one
 "GEMM dimension" (a dimension with an upper adjacency whose message needs the Y1 / Y2 products) --
-one workgroup each; record layout in include/cwn_hip.h.  The table is a property of the batch
-(like `batch` / `ptr`), built once on the host and kept on the device next to the index tensors;
-every layer of every forward reuses it.  No device work, no sync.
+one workgroup each; record layout in include/cwn_hip.h.  The cut itself is `cwn_layer_items_build`
+(csrc/cwn_blockplan.cpp, host C++: ~0.3 ms for a batch of 128 with this wrapper, where a first
+Python version took 11 ms); this module gathers the prefix sums and holds the result.  The table is
+a property of the batch (like `batch` / `ptr`), built once on the host and kept on the device next
+to the index tensors; every layer of every forward reuses it.  No device work, no sync.
 """
 from typing import List, Optional, Sequence
 
@@ -159,122 +161,41 @@ class BlockPlan:
         return self._tables[key]
 
     def _build(self, F: int, has_up) -> Optional[ItemTable]:
-        # one launch = one LDS size: the planes for the LARGEST staged block of any item plus the sources of
-        # the item with the most of them (different items, in general: vertices + edges items want rows, edges +
-        # rings items want sources).  A few splits of the LDS between the two are tried -- row cap from the top
-        # down, the source cap = what is left -- and the one with the fewest items wins
-        cap = gemm_rows_cap(F)
-        step = max(16, cap // 8)
-        best = None
-        for row_cap in range(cap, step - 1, -step):
-            src_cap = min(cap, (LDS_BYTES - 3 * row_cap * (F + 8) * 2 - _IDX_BYTES) // (F * 4) - 1)
-            if src_cap < 16:
-                continue
-            t = self._build_with(F, has_up, row_cap, src_cap)
-            if t is None or lds_bytes(F, t.max_rows, t.max_src) > LDS_BYTES:
-                continue
-            if best is None or t.n_items < best.n_items:
-                best = t
-            elif t.n_items > best.n_items + best.n_items // 8:
-                break                               # getting worse: smaller row caps only split more
-        return best
-
-    def _build_with(self, F: int, has_up, row_cap: int, src_cap: int) -> Optional[ItemTable]:
+        """cwn_layer_items_build (csrc/cwn_blockplan.cpp, host C++): the greedy cut under the kernel's caps and
+        the split of one launch's LDS between staged rows and boundary sources that gives the fewest items.  (A
+        Python version of the same took 11 ms for a ZINC-like batch of 128 -- tests/_blockplan_ref.py keeps it as
+        the independent restatement the C++ one is checked against.)"""
         from . import _ffi
-        ng_round = int(_ffi.lib().cwn_layer_round_rows(F))   # rows per round of the kernel: the coface block starts at a multiple
-        if ng_round <= 0:
-            return None
-
-        def first_coface_row(n_g: int, n_c: int) -> int:
-            r1 = _pad16(n_g)
-            return (r1 + ng_round - 1) // ng_round * ng_round if n_c > 0 else r1
-
-        def staged(n_g: int, n_c: int) -> int:
-            return first_coface_row(n_g, n_c) + _pad16(n_c) if n_c > 0 else _pad16(n_g)
         C = self.C
         if C == 0:
             return None
         for d in range(self.n_dims):
             if has_up[d] and (d + 1 >= self.n_dims or self.up_ptr[d] is None):
                 return None
-        gmax = max(1, C // TARGET_ITEMS)
-        tables: List[np.ndarray] = []
-        set_start = []
-        max_rows = max_src = 0
-        zero = np.zeros(C + 1, dtype=np.int64)
-        cp = self.cell_ptr
-        for set_id, (g, tasks) in enumerate(self._sets(has_up)):
-            up = self.up_ptr[g] if g is not None else zero
-            bps = [self.b_ptr[d] if (self.b_ptr[d] is not None and d > 0) else zero for d in tasks]
-            d0 = tasks[0]
-            recs: List[np.ndarray] = []
-            c0 = 0
-            while c0 < C:
-                c1 = c0
-                while c1 < C and c1 - c0 < gmax:
-                    nxt = c1 + 1
-                    rows = staged(int(cp[d0][nxt] - cp[d0][c0]),
-                                  int(cp[g + 1][nxt] - cp[g + 1][c0]) if g is not None else 0)
-                    # cells of dim d-1 the boundary streams read (staged in LDS), entries padded to 4
-                    src = sum(int(cp[d - 1][nxt] - cp[d - 1][c0]) for d, bp in zip(tasks, bps)
-                              if d > 0 and bp[nxt] > bp[c0])
-                    ents = _pad4(int(up[nxt] - up[c0])) + sum(_pad4(int(bp[nxt] - bp[c0])) for bp in bps)
-                    ok = (rows <= row_cap and src <= src_cap and lds_bytes(F, rows, src) <= LDS_BYTES
-                          and ents <= MAX_ENTRIES
-                          and all(int(cp[d][nxt] - cp[d][c0]) <= TASK_ROWS for d in tasks))
-                    if not ok:
-                        break
-                    c1 = nxt
-                if c1 == c0:
-                    return None                 # a single complex exceeds the caps
-                r = np.zeros(ITEM_INTS, dtype=np.int32)
-                r[0] = set_id << 8
-                n0 = int(cp[d0][c1] - cp[d0][c0])
-                nc = une = 0
-                live = tasks
-                if g is not None:
-                    r[1] = g
-                    if n0 > 0:
-                        nc, une = int(cp[g + 1][c1] - cp[g + 1][c0]), int(up[c1] - up[c0])
-                        r[0] |= 1
-                        r[2:8] = [cp[g][c0], n0, cp[g + 1][c0], nc, up[c0], une]
-                    else:
-                        if any(int(cp[d][c1] - cp[d][c0]) > 0 for d in tasks[1:]):
-                            return None             # cells of g + 1 without cells of g: not a cell complex
-                        live = tasks[:1]
-                max_rows = max(max_rows, staged(n0, nc))
-                r[8] = len(live)
-                src, bnes = 0, [0, 0]
-                for t, d in enumerate(live):
-                    bp = bps[t]
-                    o = 9 + 7 * t
-                    bnes[t] = int(bp[c1] - bp[c0])
-                    r[o:o + 5] = [d, cp[d][c0], cp[d][c1] - cp[d][c0], bp[c0], bnes[t]]
-                    if d > 0 and bnes[t] > 0:       # boundary sources are staged only when read
-                        r[o + 5] = cp[d - 1][c0]
-                        r[o + 6] = cp[d - 1][c1] - cp[d - 1][c0]
-                        src += int(r[o + 6])
-                max_src = max(max_src, src)
-                # derived fields (include/cwn_hip.h): the kernel reads them instead of re-deriving them
-                b1 = _pad4(une)
-                b2 = _pad4(b1 + bnes[0])
-                r[23:28] = [first_coface_row(n0, nc), staged(n0, nc), b1, b2, _pad4(b2 + bnes[1])]
-                recs.append(r)
-                c0 = c1
-            # heavy items first within the set: a workgroup with five row tiles should not start last
-            tab = np.stack(recs)
-            order = np.argsort(-(tab[:, 11].astype(np.int64) + tab[:, 5]), kind='stable')
-            set_start.append(sum(t.shape[0] for t in tables))
-            tables.append(tab[order])
-        table = np.ascontiguousarray(np.concatenate(tables))
-        cells_end = [int(cp[d][-1]) for d in range(self.n_dims)]
-        up_end = [int(self.up_ptr[d][-1]) if (has_up[d] and self.up_ptr[d] is not None) else 0
-                  for d in range(self.n_dims)]
-        b_end = [int(self.b_ptr[d][-1]) if (self.b_ptr[d] is not None and d > 0) else 0 for d in range(self.n_dims)]
-        out = ItemTable(table, set_start, max(max_rows, 16), max_src, cells_end, up_end, b_end, self.device)
-        if lds_bytes(F, out.max_rows, out.max_src) > LDS_BYTES:
-            return out                          # the caller lowers the row cap and builds again
-        rc = _ffi.lib().cwn_layer_items_check(table.ctypes.data, table.shape[0], F, out.c_plan(False))
+        sizes = _ffi.LayerSizes(n_complexes=C, n_dims=self.n_dims)
+        keep = []
+        for d in range(self.n_dims):
+            sizes.has_up[d] = 1 if has_up[d] else 0
+            for name, arr in (('cell_ptr', self.cell_ptr[d]), ('up_ptr', self.up_ptr[d]), ('b_ptr', self.b_ptr[d])):
+                if arr is not None:
+                    a = np.ascontiguousarray(arr, dtype=np.int64)
+                    keep.append(a)
+                    getattr(sizes, name)[d] = a.ctypes.data
+        cap_items = self.n_dims * C
+        table = np.zeros((cap_items, ITEM_INTS), dtype=np.int32)
+        plan = _ffi.LayerPlan()
+        n = int(_ffi.lib().cwn_layer_items_build(sizes, F, table.ctypes.data, cap_items, plan))
+        if n == _ffi.LAYER_ITEMS_TOO_LARGE or n == 0:
+            return None                 # a single complex exceeds the caps (or nothing to do): the caller runs the CSR path
+        if n < 0:
+            raise _ffi.CwnError(f'cwn_layer_items_build failed ({n})')
+        table = np.ascontiguousarray(table[:n])
+        n_sets = len(self._sets(has_up))
+        out = ItemTable(table, [int(plan.set_start[i]) for i in range(n_sets)], int(plan.max_gemm_rows),
+                        int(plan.max_source_rows), [int(plan.cells_end[d]) for d in range(self.n_dims)],
+                        [int(plan.up_end[d]) for d in range(self.n_dims)], [int(plan.b_end[d]) for d in range(self.n_dims)],
+                        self.device)
+        rc = _ffi.lib().cwn_layer_items_check(table.ctypes.data, n, F, out.c_plan(False))
         if rc != 0:
             raise _ffi.CwnError(f'item table failed cwn_layer_items_check ({rc})')
         return out

@@ -1,0 +1,218 @@
+// cwn_blockplan.cpp -- the item table of the complex-blocked layer kernel, built on the HOST (no GPU code).
+//
+// A batched complex is a disjoint union: the reference's collate offsets every index per complex
+// (data/complex.py:148-169) and records where each complex's cells and index entries lie (`ptr`, data/complex.py:344,
+// 432; `__slices__`, :349-394).  From those per-complex prefix sums this file cuts a batch into ITEMS -- contiguous
+// ranges of complexes for one GEMM dimension, one workgroup each (record layout: include/cwn_hip.h) -- greedily
+// under the caps of the kernel, and chooses how one launch's LDS is split between staged rows and boundary sources
+// so that the items are as few as they can be.  A first version did this in Python (11 ms for a ZINC-like batch of
+// 128, 90 ms for 1024: more than the forward pass it prepares); this one is a few tens of microseconds.
+#include <stdint.h>
+#include <stddef.h>
+#include <algorithm>
+#include <vector>
+#include "../../include/cwn_hip.h"
+
+namespace {
+
+constexpr int kInts = CWN_LAYER_ITEM_INTS;
+constexpr int64_t kLds = 160 * 1024;
+constexpr int kTargetItems = 128;      // per GEMM dimension: ~one workgroup per CU over the two sets of a 2-complex
+
+inline int64_t pad16(int64_t n) { return (n + 15) / 16 * 16; }
+inline int64_t pad4(int64_t n) { return (n + 3) / 4 * 4; }
+
+struct Shape {
+    int F, round_rows;
+    int64_t first_coface_row(int64_t n_g, int64_t n_c) const {
+        const int64_t r1 = pad16(n_g);
+        return n_c > 0 ? (r1 + round_rows - 1) / round_rows * round_rows : r1;
+    }
+    int64_t staged(int64_t n_g, int64_t n_c) const { return n_c > 0 ? first_coface_row(n_g, n_c) + pad16(n_c) : pad16(n_g); }
+    // = cwn_layer_fused_lds_bytes without its argument checks
+    int64_t lds(int64_t rows, int64_t src) const {
+        static const int64_t idx = (int64_t)cwn_layer_fused_lds_bytes(128, 16, 0) - 3 * 16 * (128 + 8) * 2 - 128 * 4;
+        return 3 * rows * (F + 8) * 2 + (src + 1) * F * 4 + idx;
+    }
+};
+
+struct Set { int g; int tasks[2]; int n_tasks; };
+
+// sets in ascending order of dimension: a dimension with an upper adjacency is the GEMM dimension of a set (the top
+// dimension rides as its second task when it has none itself), any other dimension is a set of its own
+int make_sets(const cwn_layer_sizes& in, Set (&sets)[CWN_LAYER_MAX_DIMS]) {
+    int n = 0;
+    for (int d = 0; d < in.n_dims;) {
+        Set& s = sets[n++];
+        s.tasks[0] = d;
+        s.n_tasks = 1;
+        if (in.has_up[d]) {
+            s.g = d;
+            if (d + 1 < in.n_dims && !in.has_up[d + 1] && d + 2 >= in.n_dims) s.tasks[s.n_tasks++] = d + 1;
+        } else {
+            s.g = -1;
+        }
+        d += s.n_tasks;
+    }
+    return n;
+}
+
+// one greedy cut under (row_cap, src_cap).  >= 1 items, 0 nothing to do / bad input, -1 a single complex exceeds a cap
+int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, int64_t src_cap, std::vector<int32_t>& out,
+                   cwn_layer_plan& plan) {
+    const int64_t C = in.n_complexes;
+    out.clear();
+    Set sets[CWN_LAYER_MAX_DIMS];
+    const int n_sets = make_sets(in, sets);
+    const int64_t gmax = std::max<int64_t>(1, C / kTargetItems);
+    int64_t max_rows = 0, max_src = 0;
+    std::vector<int32_t> recs;
+    std::vector<int64_t> weight;
+    std::vector<int64_t> order;
+    for (int s_ = 0; s_ < n_sets; ++s_) {
+        const Set& S = sets[s_];
+        const int g = S.g, d0 = S.tasks[0];
+        const int64_t* up = g >= 0 ? in.up_ptr[g] : nullptr;
+        const int64_t* bp[2] = {nullptr, nullptr};
+        for (int t = 0; t < S.n_tasks; ++t)
+            if (S.tasks[t] > 0) bp[t] = in.b_ptr[S.tasks[t]];
+        auto cells = [&](int d, int64_t a, int64_t b) { return in.cell_ptr[d][b] - in.cell_ptr[d][a]; };
+        auto span = [](const int64_t* p, int64_t a, int64_t b) { return p ? p[b] - p[a] : (int64_t)0; };
+        recs.clear();
+        weight.clear();
+        for (int64_t c0 = 0; c0 < C;) {
+            int64_t c1 = c0;
+            while (c1 < C && c1 - c0 < gmax) {
+                const int64_t nxt = c1 + 1;
+                const int64_t rows = sh.staged(cells(d0, c0, nxt), g >= 0 ? cells(g + 1, c0, nxt) : 0);
+                int64_t src = 0, ents = pad4(span(up, c0, nxt));
+                bool ok = true;
+                for (int t = 0; t < S.n_tasks; ++t) {
+                    const int d = S.tasks[t];
+                    if (d > 0 && span(bp[t], c0, nxt) > 0) src += cells(d - 1, c0, nxt);
+                    ents += pad4(span(bp[t], c0, nxt));
+                    ok = ok && cells(d, c0, nxt) <= CWN_LAYER_TASK_ROWS;
+                }
+                ok = ok && rows <= row_cap && src <= src_cap && sh.lds(rows, src) <= kLds && ents <= CWN_LAYER_MAX_ENTRIES;
+                if (!ok) break;
+                c1 = nxt;
+            }
+            if (c1 == c0) return -1;
+            int32_t r[kInts] = {0};
+            r[0] = s_ << 8;
+            const int64_t n0 = cells(d0, c0, c1);
+            int64_t nc = 0, une = 0;
+            int live = S.n_tasks;
+            if (g >= 0) {
+                r[1] = g;
+                if (n0 > 0) {
+                    nc = cells(g + 1, c0, c1);
+                    une = span(up, c0, c1);
+                    r[0] |= 1;
+                    r[2] = (int32_t)in.cell_ptr[g][c0];
+                    r[3] = (int32_t)n0;
+                    r[4] = (int32_t)in.cell_ptr[g + 1][c0];
+                    r[5] = (int32_t)nc;
+                    r[6] = (int32_t)(up ? up[c0] : 0);
+                    r[7] = (int32_t)une;
+                } else {
+                    for (int t = 1; t < S.n_tasks; ++t)
+                        if (cells(S.tasks[t], c0, c1) > 0) return -1;   // cells of g + 1 without cells of g: not a cell complex
+                    live = 1;
+                }
+            }
+            max_rows = std::max(max_rows, sh.staged(n0, nc));
+            r[8] = live;
+            int64_t src = 0, bne[2] = {0, 0};
+            for (int t = 0; t < live; ++t) {
+                const int d = S.tasks[t], o = 9 + 7 * t;
+                bne[t] = span(bp[t], c0, c1);
+                r[o] = d;
+                r[o + 1] = (int32_t)in.cell_ptr[d][c0];
+                r[o + 2] = (int32_t)cells(d, c0, c1);
+                r[o + 3] = (int32_t)(bp[t] ? bp[t][c0] : 0);
+                r[o + 4] = (int32_t)bne[t];
+                if (d > 0 && bne[t] > 0) {          // boundary sources are staged only when read
+                    r[o + 5] = (int32_t)in.cell_ptr[d - 1][c0];
+                    r[o + 6] = (int32_t)cells(d - 1, c0, c1);
+                    src += r[o + 6];
+                }
+            }
+            max_src = std::max(max_src, src);
+            const int64_t b1 = pad4(une), b2 = pad4(b1 + bne[0]);
+            r[23] = (int32_t)sh.first_coface_row(n0, nc);
+            r[24] = (int32_t)sh.staged(n0, nc);
+            r[25] = (int32_t)b1;
+            r[26] = (int32_t)b2;
+            r[27] = (int32_t)pad4(b2 + bne[1]);
+            recs.insert(recs.end(), r, r + kInts);
+            weight.push_back((int64_t)r[11] + r[5]);
+            c0 = c1;
+        }
+        // heavy items first within the set: a workgroup with five row tiles should not start last
+        const int64_t n = (int64_t)weight.size();
+        order.resize(n);
+        for (int64_t i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return weight[a] > weight[b]; });
+        plan.set_start[s_] = (int32_t)(out.size() / kInts);
+        for (int64_t i = 0; i < n; ++i) out.insert(out.end(), recs.begin() + order[i] * kInts, recs.begin() + (order[i] + 1) * kInts);
+    }
+    for (int s_ = n_sets; s_ <= CWN_LAYER_MAX_DIMS; ++s_) plan.set_start[s_] = 0;
+    plan.n_items = (int64_t)(out.size() / kInts);
+    plan.max_gemm_rows = (int32_t)std::max<int64_t>(max_rows, 16);
+    plan.max_source_rows = (int32_t)max_src;
+    plan.pad_ = 0;
+    for (int d = 0; d < CWN_LAYER_MAX_DIMS; ++d) {
+        const bool on = d < in.n_dims;
+        plan.cells_end[d] = on ? in.cell_ptr[d][C] : 0;
+        plan.up_end[d] = on && in.has_up[d] && in.up_ptr[d] ? in.up_ptr[d][C] : 0;
+        plan.b_end[d] = on && d > 0 && in.b_ptr[d] ? in.b_ptr[d][C] : 0;
+    }
+    return plan.n_items;
+}
+
+}  // namespace
+
+extern "C" int64_t cwn_layer_items_build(const cwn_layer_sizes* in, int32_t F, int32_t* items, int64_t cap_items,
+                                         cwn_layer_plan* plan) {
+    if (in == nullptr || plan == nullptr || (F != 64 && F != 128) || in->n_dims < 1 || in->n_dims > CWN_LAYER_MAX_DIMS ||
+        in->n_complexes < 0 || (cap_items > 0 && items == nullptr))
+        return CWN_LAYER_ITEMS_BAD_ARG;
+    if (in->n_complexes == 0) return 0;
+    for (int d = 0; d < in->n_dims; ++d) {
+        if (in->cell_ptr[d] == nullptr) return CWN_LAYER_ITEMS_BAD_ARG;
+        if (in->has_up[d] && (d + 1 >= in->n_dims || in->up_ptr[d] == nullptr)) return CWN_LAYER_ITEMS_BAD_ARG;
+    }
+    const Shape sh{F, cwn_layer_round_rows(F)};
+    if (sh.round_rows <= 0) return CWN_LAYER_ITEMS_BAD_ARG;
+    // one launch = one LDS size: the planes for the LARGEST staged block of any item plus the sources of the item with
+    // the most of them (different items, in general).  A few splits of the LDS between the two are tried -- row cap
+    // from the top down, the source cap = what is left -- and the one with the fewest items wins
+    const int64_t cap = CWN_LAYER_GEMM_ROWS(F), src_max = CWN_LAYER_SOURCE_ROWS(F), step = std::max<int64_t>(16, cap / 8);
+    std::vector<int32_t> cur, best;
+    cwn_layer_plan pc = *plan, pb = *plan;
+    bool have = false, too_big = false;
+    for (int64_t row_cap = cap; row_cap >= step; row_cap -= step) {
+        const int64_t src_cap = std::min(src_max, (kLds - sh.lds(row_cap, -1)) / (F * 4) - 1);
+        if (src_cap < 16) continue;
+        const int64_t n = build_with(*in, sh, row_cap, src_cap, cur, pc);
+        if (n < 0) { too_big = true; continue; }
+        if (n == 0 || sh.lds(pc.max_gemm_rows, pc.max_source_rows) > kLds) continue;
+        if (!have || n < pb.n_items) {
+            best.swap(cur);
+            pb = pc;
+            have = true;
+        } else if (n > pb.n_items + pb.n_items / 8) {
+            break;                               // getting worse: smaller row caps only split more
+        }
+    }
+    if (!have) return too_big ? CWN_LAYER_ITEMS_TOO_LARGE : 0;
+    if (pb.n_items > cap_items) return CWN_LAYER_ITEMS_BAD_ARG;
+    std::copy(best.begin(), best.end(), items);
+    const int32_t* keep_items = plan->items;
+    void* keep_cache = plan->csr_cache;
+    *plan = pb;
+    plan->items = keep_items;
+    plan->csr_cache = keep_cache;
+    return pb.n_items;
+}

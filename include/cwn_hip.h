@@ -198,7 +198,7 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  *
  * The item table (device, int32[n_items][CWN_LAYER_ITEM_INTS]) is a property of the BATCH, built
  * once from the per-complex sizes the reference's collate keeps (`ptr`, `__slices__`,
- * data/complex.py:344-441): cwn_amd/blockplan.py.  Record layout (all offsets are into the batched
+ * data/complex.py:344-441): cwn_layer_items_build below.  Record layout (all offsets are into the batched
  * tensors):
  *   [0] flags      bit 0: the item has a GEMM dimension g (an upper adjacency with coboundary features);
  *                  bits 8-9: its SET (informative; the kernel derives it from cwn_layer_plan.set_start)
@@ -264,7 +264,7 @@ size_t cwn_layer_packed_weight_bytes(int32_t F);
 int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream);
 
 /* The item table and what the launcher needs to know about it (HOST struct; built by
- * cwn_amd/blockplan.py).  Items are ordered by set.  The *_end fields summarise what the table
+ * cwn_layer_items_build).  Items are ordered by set.  The *_end fields summarise what the table
  * addresses; the launcher checks them against the tensors, so that the kernel can form addresses
  * from a record without re-validating it (the caller vouches that the summary describes the table).
  * What only the device can see -- the VALUES of the int64 indices -- is checked in the kernel.
@@ -292,6 +292,26 @@ typedef struct cwn_layer_plan {
 
 int cwn_layer_fused_f32(const cwn_layer_dim* dims_host, int n_dims, int32_t F, const cwn_layer_plan* plan_host,
                         int32_t flags, int32_t* err_flag, cwn_stream_t stream);
+/* The item table, built on the HOST from the per-complex prefix sums the reference's collate keeps (`ptr`:
+ * data/complex.py:344, 432; `__slices__`: :349-394): contiguous ranges of complexes per set, greedily under the
+ * limits above, with ONE launch's LDS split between staged rows and boundary sources so that the items are as
+ * few as possible; heavy items first within a set.  Fills items[0 .. n) (host memory, cap_items records) and every
+ * field of *plan but `items` / `csr_cache`.  Returns n >= 1, 0 for an empty batch, CWN_LAYER_ITEMS_TOO_LARGE when
+ * a single complex exceeds what a workgroup holds (the caller uses cwn_csr_build + cwn_gemm_f32 +
+ * cwn_aggregate_f32), CWN_LAYER_ITEMS_BAD_ARG otherwise.  Tens of microseconds for a batch of 128. */
+typedef struct cwn_layer_sizes {
+    int64_t n_complexes;
+    int32_t n_dims;
+    int32_t has_up[CWN_LAYER_MAX_DIMS];             /* dimension d reduces an upper adjacency with coboundary features */
+    const int64_t* cell_ptr[CWN_LAYER_MAX_DIMS];    /* [n_complexes + 1] prefix sums of the cells per complex */
+    const int64_t* up_ptr[CWN_LAYER_MAX_DIMS];      /* the same for the entries of upper_index_d, or NULL */
+    const int64_t* b_ptr[CWN_LAYER_MAX_DIMS];       /* the same for the entries of boundary_index_d, or NULL */
+} cwn_layer_sizes;
+#define CWN_LAYER_ITEMS_TOO_LARGE (-1)
+#define CWN_LAYER_ITEMS_BAD_ARG (-2)
+int64_t cwn_layer_items_build(const cwn_layer_sizes* sizes_host, int32_t F, int32_t* items_host, int64_t cap_items,
+                              cwn_layer_plan* plan_host);
+
 /* HOST check of a host copy of the item table against its plan (record layout above): CWN_OK or
  * CWN_ERR_BAD_ARG.  The kernel re-checks only what keeps a workgroup inside its LDS. */
 int cwn_layer_items_check(const int32_t* items_host, int64_t n_items, int32_t F, const cwn_layer_plan* plan_host);

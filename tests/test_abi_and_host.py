@@ -39,7 +39,7 @@ def test_struct_layout_matches_header(tmp_path):
                'cwn_gemm_desc': _ffi.GemmDesc, 'cwn_collate_desc': _ffi.CollateDesc,
                'cwn_bn_desc': _ffi.BnDesc, 'cwn_norm_desc': _ffi.NormDesc,
                'cwn_gemm_tn_desc': _ffi.GemmTnDesc, 'cwn_layer_dim': _ffi.LayerDim,
-               'cwn_layer_plan': _ffi.LayerPlan, 'cwn_mlp_dim': _ffi.MlpDim}
+               'cwn_layer_plan': _ffi.LayerPlan, 'cwn_mlp_dim': _ffi.MlpDim, 'cwn_layer_sizes': _ffi.LayerSizes}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cwn_hip.h"', 'int main(void) {']
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -100,6 +100,7 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_gemm_packed_weight_bytes() == 128 * 128 * 6
     assert lib.cwn_gemm_pack_weights_f32(None, 128, None, None) == 1
     assert lib.cwn_layer_items_check(None, 0, 128, None) == 1
+    assert lib.cwn_layer_items_build(None, 128, None, 0, None) == _ffi.LAYER_ITEMS_BAD_ARG
     assert lib.cwn_layer_round_rows(128) in (16, 32) and lib.cwn_layer_round_rows(100) == 0
     g = (_ffi.GemmDesc * 1)(_ffi.GemmDesc(M=4, N=64, K=64, K2=0, ldx=64, ldw=64, ldy=64, flags=_ffi.GEMM_W_PACKED))
     assert lib.cwn_gemm_would_split(g, 1) == 0                       # not the split kernel's shape ...
@@ -416,6 +417,7 @@ def test_block_plan_covers_every_complex_once_and_fits_the_launch():
     import numpy as np
     from cwn_amd import _ffi
     from cwn_amd.blockplan import BlockPlan, LDS_BYTES, MAX_ENTRIES, TASK_ROWS, gemm_rows_cap, lds_bytes
+    from tests import _blockplan_ref
     rng = np.random.default_rng(7)
     L = _ffi.lib()
     for trial in range(40):
@@ -434,6 +436,12 @@ def test_block_plan_covers_every_complex_once_and_fits_the_launch():
         for F in (64, 128):
             t = plan.items(F, [True, True, False])
             cap = gemm_rows_cap(F)
+            # the C++ builder (cwn_layer_items_build) against its Python restatement: the same table, field for field
+            r = _blockplan_ref.build(plan, F, (True, True, False))
+            assert (t is None) == (r is None), (trial, F)
+            if t is not None:
+                assert np.array_equal(t.items.numpy(), r.items.numpy()) and t.set_start == r.set_start
+                assert (t.max_rows, t.max_src, t.cells_end, t.up_end, t.b_end) == (r.max_rows, r.max_src, r.cells_end, r.up_end, r.b_end)
             if t is None:
                 # only legitimate when some single complex exceeds a cap
                 def staged(a, b):
