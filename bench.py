@@ -794,6 +794,16 @@ def main():
             collate = {'device_ms_per_batch': round(dev_ms, 4),
                        'scope': f'ComplexBatch of {args.batch} complexes from a packed HBM-resident dataset: host '
                                 'segment tables + 1 H2D copy + 1 launch (cwn_collate)'}
+            # the item table of the blocked layer kernel for such a batch (host: prefix sums -> cwn_layer_items_build
+            # -> one H2D copy), rebuilt from scratch each time: what a new batch costs besides its collate
+            if BLOCKED:
+                nb_ = packed.collate(rng_idx[0])
+                t0 = time.perf_counter()
+                for i in range(20):
+                    nb_._block_plan = None
+                    nb_.block_plan().items(H, [True, True, False])
+                torch.cuda.synchronize()
+                collate['item_table_host_ms_per_batch'] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
             if not args.no_cpu:
                 from oracle import cwn_oracle as O
                 keys = ('x', 'upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries', 'boundary_index', 'y')

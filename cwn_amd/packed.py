@@ -121,6 +121,10 @@ class PackedComplexes:
             n_sel = self.n_cells[d, idx]
             off_here, off_down, off_up = excl(n_sel), excl(self.n_down[d, idx]), excl(self.n_up[d, idx])
             cb = CochainBatch(d)
+            # the per-complex tables the reference's collate keeps (data/complex.py:344-441): the blocked layer
+            # kernel's item table is cut from them (cwn_amd/blockplan.py)
+            cb.__num_cells_list__ = n_sel.tolist()
+            cb.__slices__ = {}
             for key, pk in self.keys[d].items():
                 if not pk.has[idx].any():
                     continue
@@ -144,6 +148,8 @@ class PackedComplexes:
                     add = np.stack([off_down, off_here])
                 plan.append((pk, out, table(dst_start), table(pk.start[idx]),
                              None if add is None else table(add), total))
+                if key != 'x':
+                    cb.__slices__[key] = dst_start.tolist()
                 if key == 'x':
                     cb._x = out
                 else:

@@ -876,6 +876,7 @@ def test_device_collate_matches_reference_layout(lname):
 
 def test_device_collate_subsets_and_forward():
     """Arbitrary index subsets equal the CPU container collate; the result feeds the engine."""
+    from cwn_amd.blockplan import BlockPlan
     from cwn_amd.complex import ComplexBatch
     from cwn_amd.packed import PackedComplexes
     from cwn_amd.synthetic import zinc_like_complexes
@@ -888,9 +889,16 @@ def test_device_collate_subsets_and_forward():
         ref = ComplexBatch.from_complex_list([cxs[i] for i in idx], max_dim=2)
         _assert_batch_equal(got, ref.cochains, ref.dimension)
         assert torch.equal(cpu(got.y), ref.y)
+        # the per-complex tables travel too, so the blocked layer kernel serves device-collated batches
+        pg, pr = got.block_plan(), BlockPlan.from_batch(ref)
+        assert pg is not None and pr is not None and pg.C == pr.C == 17
+        for d in range(3):
+            assert np.array_equal(pg.cells[d], pr.cells[d])
+            for a, b_ in ((pg.up_ptr[d], pr.up_ptr[d]), (pg.b_ptr[d], pr.b_ptr[d])):
+                assert (a is None) == (b_ is None) and (a is None or np.array_equal(a, b_))
     from cwn_amd.models import EmbedSparseCIN
     torch.manual_seed(0)
-    model = EmbedSparseCIN(28, 4, 1, 2, 32, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV).eval()
+    model = EmbedSparseCIN(28, 4, 1, 2, 64, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV).eval()
     with torch.no_grad():
         y1 = model(packed.collate(idx))
         y2 = model(ComplexBatch.from_complex_list([cxs[i] for i in idx], max_dim=2).to(DEV))
