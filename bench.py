@@ -762,10 +762,12 @@ def main():
                 dist.all_reduce(tcells)
             train = {'ms_per_step': round(dtt / tsteps * 1e3, 4),
                      'cells_per_s': round(float(tcells.item()) / dtt, 1), 'steps': tsteps,
-                     'params': int(ts.bucket.flat.numel()),
+                     'params': int(sum(p.numel() for p in ts.bucket.params)),
+                     'backward_pieces': int(ts.n_stages),
                      'scope': 'adjacency plans (forward + transposed), forward, L1 loss, backward, Adam on one flat buffer (cwn_adam_f32)'
-                              + (f', one {ts.bucket.flat.numel() * 4 / 1e6:.1f} MB RCCL all-reduce of the flat '
-                                 'gradient bucket' if world > 1 else '')
+                              + (f', {ts.bucket.flat.numel() * 4 / 1e6:.1f} MB flat gradient bucket all-reduced over RCCL in '
+                                 f'{ts.n_stages} chunk(s), each issued as soon as the backward has left its layers'
+                                 if world > 1 else '')
                               + ('; hipGraph replay' if train_graph else '; eager launches (host-bound)')}
             del ts, tmodel
         except Exception as e:

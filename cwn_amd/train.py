@@ -8,7 +8,11 @@ out for MI355X:
   * the optimiser is Adam over ONE flat parameter buffer (`FlatAdam`, cwn_adam_f32: one launch
     for the whole model; torch's fused multi-tensor Adam needs 8 x 22 us for the 265 tensors);
   * the whole step -- plan reuse, forward, backward, optimiser -- is captured once per distinct batch
-    in a hipGraph and replayed (world size 1), or as two graphs around the eager all-reduce.
+    in a hipGraph and replayed (world size 1);
+  * under data parallelism the backward is cut at the outputs of the message-passing layers into S pieces
+    (dist.StagedBackward), one hipGraph each, and the gradients of a piece are all-reduced (asynchronously, on
+    RCCL's stream) while the next piece replays: only the last chunk's collective -- the first layer and the
+    embeddings -- is exposed before the optimiser graph.
 
 Loss functions follow exp/train_utils.py:10-13 (L1 for 'regression', MSE, BCE-with-logits, CE).
 """
@@ -21,7 +25,7 @@ from . import ops
 import torch.distributed as dist
 
 from . import _ffi
-from .dist import FlatGradBucket
+from .dist import FlatGradBucket, StagedBackward
 
 # 'thread_local': a capture is only invalidated by calls of the capturing thread, not by another
 # thread of the process touching the runtime meanwhile (the RCCL watchdog of torch.distributed)
@@ -47,14 +51,12 @@ class FlatAdam:
         self.bucket, self.lr, self.betas, self.eps, self.weight_decay = bucket, lr, betas, eps, weight_decay
         g = bucket.flat
         self.flat_p = torch.empty_like(g)
-        off = 0
+        self.flat_p.zero_()                     # the pad elements between parameters (bucket.offsets) stay zero
         with torch.no_grad():
-            for p in bucket.params:
-                n = p.numel()
-                view = self.flat_p[off:off + n].view_as(p)
+            for p, off in zip(bucket.params, bucket.offsets):
+                view = self.flat_p[off:off + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
-                off += n
         self.exp_avg = torch.zeros_like(g)
         self.exp_avg_sq = torch.zeros_like(g)
         self.t = torch.zeros(1, dtype=torch.int32, device=g.device)
@@ -87,27 +89,65 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, batches: Sequence, task_type: str = 'regression',
                  lr: float = 1e-3, use_graph: bool = True, optimizer: Optional[torch.optim.Optimizer] = None,
-                 rebuild_plans: bool = True):
+                 rebuild_plans: bool = True, stages: Optional[int] = None):
+        """`stages`: number of pieces the backward is cut into so that the gradient all-reduce overlaps with it
+        (None: one per message-passing layer, at most 4, when the process group has more than one rank, else 1;
+        env CWN_TRAIN_STAGES overrides).  Needs `model.convs`; a network whose layers cannot be cut (see
+        dist.StagedBackward.stages) falls back to 1."""
         if task_type not in _LOSSES:
             raise NotImplementedError('Training on task type {} not yet supported.'.format(task_type))
         self.model, self.batches = model.train(), list(batches)
         self.loss_fn = _LOSSES[task_type]
         self.task_type = task_type
-        self.bucket = FlatGradBucket(model.parameters())
-        self.opt = optimizer or FlatAdam(self.bucket, lr=lr)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            # a rank with fewer batches would leave the others waiting in a collective
+            n = torch.tensor([len(self.batches), -len(self.batches)], dtype=torch.int64,
+                             device=next(model.parameters()).device)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            if int(n[0]) != -int(n[1]):
+                raise ValueError('TrainStep: every rank must hold the same number of batches '
+                                 f'(this rank {len(self.batches)}, max {int(n[0])}, min {-int(n[1])})')
+        for b in self.batches:
+            b.prepare(backward=True)
+        self.inputs = [[None if c.x is None else c.x.clone() for c in self._cochains(b)]
+                       for b in self.batches]
+        if os.environ.get('CWN_TRAIN_STAGES'):
+            stages = int(os.environ['CWN_TRAIN_STAGES'])
+        convs = list(getattr(model, 'convs', []))
+        if stages is None:
+            stages = min(len(convs), 4) if self.world > 1 else 1
+        stages = max(1, min(int(stages), len(convs)))
+        self.staged, stage_of = None, None
+        if stages > 1 and self.batches:
+            # cuts behind layers k_1 > k_2 > ...: evenly spread over layers 0 .. L-2 (the head rides with the last layer)
+            L = len(convs)
+            ks = sorted({round(v * (L - 2) / max(1, stages - 2)) for v in range(stages - 1)} if stages > 2 else {0})
+            self.staged = StagedBackward([convs[k] for k in ks])
+            stage_of = self._probe_stages(convs, ks)
+            if stage_of is None:
+                self.staged.remove()
+                self.staged = None
+        self.n_stages = self.staged.n_stages if self.staged is not None else 1
+        self.bucket = FlatGradBucket(model.parameters(), stage_of, self.n_stages)
+        if self.world > 1:
+            # the ranks reduce the bucket chunk by chunk: its layout must be the same everywhere
+            lay = torch.tensor([hi for _, hi in self.bucket.chunks], dtype=torch.int64, device=self.bucket.flat.device)
+            lay = torch.cat([lay, -lay])
+            dist.all_reduce(lay, op=dist.ReduceOp.MAX)
+            if not torch.equal(lay[:self.n_stages], -lay[self.n_stages:]):
+                raise RuntimeError('TrainStep: the gradient bucket is laid out differently on different ranks')
+        self.stage_params = [[p for p in self.bucket.params if stage_of[id(p)] == self.n_stages - 1 - j]
+                             for j in range(self.n_stages)] if stage_of is not None else None
+        self.opt = optimizer or FlatAdam(self.bucket, lr=lr)
         if os.environ.get('CWN_TRAIN_TWO_GRAPH') == '1':     # debugging: the data-parallel form on one rank
             self.world = max(self.world, 2)
         self.use_graph = use_graph
-        self.inputs = [[None if c.x is None else c.x.clone() for c in self._cochains(b)]
-                       for b in self.batches]
         self._graphs: Dict[int, tuple] = {}
         self._warm = False
         # a new batch needs its adjacency plans (forward + transposed) built: part of the step
         # unless the caller trains on a fixed set of batches and says so
         self.rebuild_plans = rebuild_plans
-        for b in self.batches:
-            b.prepare(backward=True)
 
     # ---- pieces ------------------------------------------------------------------------------
     @staticmethod
@@ -131,23 +171,92 @@ class TrainStep:
                 ts += [st[k] for k in sorted(st) if torch.is_tensor(st[k])]
         return ts
 
-    def _forward_backward(self, i: int) -> torch.Tensor:
-        b = self._restore(i)
-        if self.rebuild_plans:
-            b.forget_plans().prepare(backward=True)
-        self.bucket.zero_()
+    def _probe_stages(self, convs, ks) -> Optional[dict]:
+        """{id(parameter): stage}, the same on every rank, or None when the network cannot be cut behind the
+        layers `ks`.  The parameters of a layer take the stage of the layer; every other parameter (embeddings,
+        head) the stage one forward per batch (buffers put back afterwards) finds it at in the autograd graph --
+        the maximum over the ranks, whose batches may reach different parameters (a shard without 2-cells) --
+        and stage 0, reduced last, when no batch of any rank reaches it."""
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        keep = [t.detach().clone() for t in self.model.buffers()]
+        reached, ok = {}, True
+        for i in range(len(self.batches)):
+            self.staged.begin()
+            loss = self._loss(self._restore(i))
+            so = self.staged.stages(loss, params, default=None)
+            del loss
+            self.staged._cuts = []
+            self._restore(i)
+            if so is None:
+                ok = False
+                break
+            ok = ok and all(reached.setdefault(k, v) == v for k, v in so.items())
+        with torch.no_grad():
+            for t, old in zip(self.model.buffers(), keep):
+                t.copy_(old)
+        for k, conv in enumerate(convs):
+            st = sum(1 for c in ks if c < k)
+            ok = ok and all(reached.setdefault(id(p), st) == st for p in conv.parameters() if p.requires_grad)
+        mine = torch.tensor([reached.get(id(p), -1) for p in params] + [0 if ok else 1], dtype=torch.int64,
+                            device=params[0].device)
+        if self.world > 1:
+            both = mine.clone()
+            dist.all_reduce(both, op=dist.ReduceOp.MAX)
+            clash = ((mine >= 0) & (mine != both)).any().to(torch.int64).view(1)
+            dist.all_reduce(clash, op=dist.ReduceOp.MAX)
+            both[-1] = torch.maximum(both[-1], clash[0])
+            mine = both
+        mine = mine.tolist()
+        if mine[-1] != 0:
+            return None
+        return {id(p): max(0, st) for p, st in zip(params, mine)}
+
+    def _loss(self, b) -> torch.Tensor:
         pred = self.model(b)
         y = b.y.view(-1,) if self.task_type == 'classification' else b.y.view(pred.shape).to(pred.dtype)
-        loss = self.loss_fn(pred, y)
-        with ops.accumulate_into_grad():        # gradients are views into self.bucket: kernels add in place
-            loss.backward()
-        self._restore(i)                          # drop the references to the autograd graph
-        return loss.detach()
+        return self.loss_fn(pred, y)
+
+    def _forward_backward(self, i: int, pieces: Optional[Sequence[int]] = None):
+        """zero the gradients, forward, backward.  With a staged backward `pieces` selects what runs now:
+        [0] = zero + forward + the first piece (returns the loss, which the later pieces need), [j] = piece j."""
+        if self.staged is None:
+            b = self._restore(i)
+            if self.rebuild_plans:
+                b.forget_plans().prepare(backward=True)
+            self.bucket.zero_()
+            loss = self._loss(b)
+            with ops.accumulate_into_grad():        # gradients are views into self.bucket: kernels add in place
+                loss.backward()
+            self._restore(i)                          # drop the references to the autograd graph
+            return loss.detach()
+        S = self.n_stages
+        for j in (range(S) if pieces is None else pieces):
+            if j == 0:
+                b = self._restore(i)
+                if self.rebuild_plans:
+                    b.forget_plans().prepare(backward=True)
+                self.bucket.zero_()
+                self.staged.begin()
+                self._live_loss = self._loss(b)
+            with ops.accumulate_into_grad():
+                self.staged.piece(j, self._live_loss, self.stage_params[j])
+            if j == S - 1:
+                loss, self._live_loss = self._live_loss.detach(), None
+                self._restore(i)
+                return loss
+        return self._live_loss.detach()
 
     def _eager(self, i: int) -> torch.Tensor:
-        loss = self._forward_backward(i)
-        if self.world > 1:
-            self.bucket.all_reduce_mean(n_local=self.batches[i].num_complexes)
+        n_local = self.batches[i].num_complexes
+        if self.staged is None:
+            loss = self._forward_backward(i)
+            if self.world > 1:
+                self.bucket.all_reduce_mean(n_local=n_local)
+        else:
+            for j in range(self.n_stages):
+                loss = self._forward_backward(i, [j])
+                self.bucket.reduce_chunk(j, n_local)      # overlaps with piece j + 1
+            self.bucket.finish()
         self.opt.step()
         return loss
 
@@ -173,16 +282,23 @@ class TrainStep:
             torch.cuda.synchronize()
             self._warm = True
         g1 = torch.cuda.CUDAGraph()
-        if self.world == 1:
+        if self.world == 1 and self.staged is None:
             with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
                 loss = self._eager(i)
-            return (g1, None, loss)
+            return ([g1], None, loss)
+        # data parallel: graph(s) of forward + backward, the collective(s) issued eagerly between them, graph(Adam)
+        pieces = [g1]
         with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
-            loss = self._forward_backward(i)
+            loss = self._forward_backward(i, None if self.staged is None else [0])
+        for j in range(1, self.n_stages):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
+                self._forward_backward(i, [j])
+            pieces.append(g)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
             self.opt.step()
-        return (g1, g2, loss)
+        return (pieces, g2, loss)
 
     # ---- the step ----------------------------------------------------------------------------
     def step(self, i: int) -> torch.Tensor:
@@ -190,9 +306,18 @@ class TrainStep:
             return self._eager(i)
         if i not in self._graphs:
             self._graphs[i] = self._capture(i)
-        g1, g2, loss = self._graphs[i]
-        g1.replay()
-        if g2 is not None:
-            self.bucket.all_reduce_mean(n_local=self.batches[i].num_complexes)   # the ONE collective of the step (RCCL over xGMI)
-            g2.replay()
+        pieces, g2, loss = self._graphs[i]
+        if g2 is None:
+            pieces[0].replay()
+            return loss
+        n_local = self.batches[i].num_complexes
+        if self.staged is None:
+            pieces[0].replay()
+            self.bucket.all_reduce_mean(n_local=n_local)   # the ONE collective of the step (RCCL over xGMI)
+        else:
+            for j, g in enumerate(pieces):
+                g.replay()
+                self.bucket.reduce_chunk(j, n_local)        # on RCCL's stream, while the next piece replays
+            self.bucket.finish()
+        g2.replay()
         return loss

@@ -124,6 +124,109 @@ def test_bucket_views_are_the_grads():
     lin = torch.nn.Linear(3, 2)
     bucket = FlatGradBucket(lin.parameters())
     lin(torch.ones(4, 3)).sum().backward()
-    assert bucket.flat.numel() == 8 and bucket.flat.abs().sum() > 0
+    assert bucket.flat.numel() == 12 and bucket.flat.abs().sum() > 0
     assert lin.weight.grad.data_ptr() == bucket.flat.data_ptr()
     assert bucket.all_reduce_mean() is None      # no process group: no-op
+
+
+class _Layered(torch.nn.Module):
+    """A layered toy network with the attribute the trainer cuts at (`convs`), an embedding in front, a head
+    behind and a parameter the loss never reaches."""
+
+    def __init__(self):
+        super().__init__()
+        self.head = torch.nn.Linear(4, 1)
+        self.convs = torch.nn.ModuleList(torch.nn.Linear(4, 4) for _ in range(4))
+        self.embed = torch.nn.Embedding(5, 4)
+        self.unused = torch.nn.Linear(2, 2)
+
+    def forward(self, idx, skip=False, jk=False):
+        x = x0 = self.embed(idx)
+        js = []
+        for c in self.convs:
+            x = c(x).relu()
+            js.append(x)
+        y = self.head(torch.stack(js, -1).max(-1)[0] if jk else x).pow(2).sum()
+        return y + (x0.sum() if skip else 0)
+
+
+def _staged_setup(seed=0):
+    from cwn_amd.dist import FlatGradBucket, StagedBackward
+    torch.manual_seed(seed)
+    net = _Layered()
+    st = StagedBackward([net.convs[0], net.convs[2]])
+    st.begin()
+    so = st.stages(net(torch.tensor([0, 1, 1, 4])), list(net.parameters()))
+    bucket = FlatGradBucket(net.parameters(), so, st.n_stages)
+    sp = [[p for p in bucket.params if so[id(p)] == st.n_stages - 1 - j] for j in range(st.n_stages)]
+    return net, st, so, bucket, sp
+
+
+def test_staged_backward_equals_the_monolithic_backward():
+    """The backward in three pieces cut behind layers 2 and 0: stages read off the autograd graph, every chunk of
+    the bucket untouched until its piece has run, the result bit-identical to loss.backward(); networks whose
+    layers cannot be cut (a skip connection around the layers, jumping knowledge) are recognised."""
+    net, st, so, bucket, sp = _staged_setup()
+    stage = {n: so[id(p)] for n, p in net.named_parameters()}
+    assert stage['head.weight'] == stage['convs.3.bias'] == 2 and stage['convs.2.weight'] == stage['convs.1.weight'] == 1
+    assert stage['convs.0.weight'] == stage['embed.weight'] == stage['unused.weight'] == 0
+    assert [hi - lo for lo, hi in bucket.chunks] == [28, 40, 48] and bucket.chunks[0][0] == 0
+    idx = torch.tensor([0, 3, 3, 2])
+    bucket.zero_()
+    st.begin()
+    loss = net(idx)
+    for j in range(st.n_stages):
+        st.piece(j, loss, sp[j])
+        assert bucket.chunk(j).any()
+        assert not any(bucket.chunk(c).any() for c in range(j + 1, st.n_stages)), j
+    got = bucket.flat.clone()
+    bucket.zero_()
+    net(idx).backward()
+    assert torch.equal(got, bucket.flat)
+    for kw in (dict(skip=True), dict(jk=True)):
+        st.begin()
+        assert st.stages(net(idx, **kw), list(net.parameters())) is None, kw
+    with pytest.raises(ValueError):
+        from cwn_amd.dist import FlatGradBucket
+        FlatGradBucket(net.parameters(), {id(net.head.weight): 3}, 3)
+
+
+def _staged_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from cwn_amd.dist import init_from_env
+    init_from_env('gloo')
+    net, st, so, bucket, sp = _staged_setup()
+    idx = torch.tensor([[0, 1, 1, 4], [2, 2, 3, 0]][rank])
+    n_local = 3 + 2 * rank
+    bucket.zero_()
+    st.begin()
+    loss = net(idx)
+    for j in range(st.n_stages):
+        st.piece(j, loss, sp[j])
+        bucket.reduce_chunk(j, n_local)          # in flight while the next piece runs
+    bucket.finish()
+    if rank == 0:
+        ret['flat'] = bucket.flat.clone()
+        ret['order'] = [so[id(p)] for p in bucket.params]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_chunked_reduce_inside_the_backward():
+    """reduce_chunk after every piece of the staged backward == the weighted mean of the per-rank gradients
+    (what all_reduce_mean gives after a monolithic backward), count element riding with the last chunk."""
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_staged_worker, args=(world, port, ret), nprocs=world, join=True)
+        flat, order = ret['flat'], ret['order']
+    assert order == sorted(order, reverse=True)
+    ref, wsum = None, 0.0
+    for r in range(world):
+        net, st, so, bucket, sp = _staged_setup()
+        bucket.zero_()
+        net(torch.tensor([[0, 1, 1, 4], [2, 2, 3, 0]][r])).backward()
+        w = 3.0 + 2 * r
+        ref = w * bucket.flat if ref is None else ref + w * bucket.flat
+        wsum += w
+    torch.testing.assert_close(flat, ref / wsum, rtol=1e-6, atol=1e-7)

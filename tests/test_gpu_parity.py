@@ -1632,6 +1632,98 @@ def test_train_step_two_graph_form_used_under_data_parallelism():
     assert two._graphs[0][1] is not None and one._graphs[0][1] is None
 
 
+def test_train_step_staged_backward_matches_the_monolithic_step():
+    """Data parallelism cuts the backward behind the message-passing layers (one hipGraph per piece, the
+    all-reduce of a piece's gradients issued while the next piece runs).  On one GPU the collectives are no-ops,
+    so the staged step must equal the single-graph step: stages read off the autograd graph, every chunk of the
+    gradient bucket untouched until its piece has run, gradients equal up to the fp32-atomic summation noise."""
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import zinc_like_batch
+    from cwn_amd.train import TrainStep
+
+    def setup():
+        torch.manual_seed(5)
+        m = EmbedSparseCIN(28, 4, 1, 4, 32, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV)
+        return m, [zinc_like_batch(16, seed=30 + i, device=DEV) for i in range(2)]
+    m1, b1 = setup()
+    m2, b2 = setup()
+    m2.load_state_dict(m1.state_dict())
+    one = TrainStep(m1, b1, use_graph=True)
+    cut = TrainStep(m2, b2, use_graph=True, stages=4)
+    assert one.n_stages == 1 and cut.n_stages == 4 and len(cut.bucket.chunks) == 4
+    names = {id(p): n for n, p in m2.named_parameters()}
+    for j, ps in enumerate(cut.stage_params):
+        got = {names[id(p)].split('.')[0] + '.' + names[id(p)].split('.')[1] for p in ps if names[id(p)].startswith('convs')}
+        # a layer's parameters ride with the layer, reached or not (the reference constructs unused networks too:
+        # lower-adjacency messages, the top dimension's coboundary message)
+        assert got == {f'convs.{3 - j}'}, (j, got)
+    assert any(names[id(p)].startswith('lin2') for p in cut.stage_params[0])
+    assert any('embed' in names[id(p)] for p in cut.stage_params[3])
+    # buffers untouched by the probe forward
+    for (n, a), (_, b) in zip(m1.named_buffers(), m2.named_buffers()):
+        assert torch.equal(a, b), n
+    # eager pieces: a chunk is written by its own piece only
+    for j in range(4):
+        cut._forward_backward(0, [j])
+        assert cut.bucket.chunk(j).any()
+        assert not any(cut.bucket.chunk(c).any() for c in range(j + 1, 4)), j
+    one._forward_backward(0)
+    # whole-gradient distances: a bias in front of a BatchNorm has a true gradient of zero and a computed one of
+    # summation noise, so per-parameter ratios mean nothing
+    ga = torch.cat([p.grad.flatten() for p in m1.parameters()])
+    gb = torch.cat([q.grad.flatten() for q in m2.parameters()])
+    rel, top = float((ga - gb).norm() / ga.norm()), float((ga - gb).abs().max() / ga.abs().max())
+    print(f'[train] staged vs monolithic backward: relative L2 distance {rel:.3e}, max|delta| / max|g| {top:.3e}')
+    assert rel < 1e-5 and top < 1e-5, (rel, top)
+    for (n, a), (_, b) in zip(m1.named_buffers(), m2.named_buffers()):
+        a.copy_(b)
+    for i in range(4):
+        la, lb = one.step(i % 2), cut.step(i % 2)
+        torch.testing.assert_close(lb, la, rtol=2e-3, atol=1e-4)
+    torch.cuda.synchronize()
+    pieces, g2, _ = cut._graphs[0]
+    assert len(pieces) == 4 and g2 is not None
+    worst = 0.0
+    for (n, p), (_, q) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        if p.dtype.is_floating_point:
+            worst = max(worst, float((p - q).abs().max()) / max(1.0, float(p.abs().max())))
+    print(f'[train] staged graphs vs single graph after 4 steps: worst relative parameter distance {worst:.3e}')
+    assert worst < 2 * 1e-3 * 4 * 1.1, worst     # the Adam sign-flip bound of test_train_step_graph_replay_matches_eager
+    # a network with jumping knowledge cannot be cut: one stage, same result as ever
+    torch.manual_seed(5)
+    mj = EmbedSparseCIN(28, 4, 1, 3, 32, dropout_rate=0.0, embed_edge=True, use_coboundaries=True, jump_mode='cat').to(DEV)
+    tj = TrainStep(mj, b1, use_graph=False, stages=3)
+    assert tj.n_stages == 1 and tj.staged is None
+    assert torch.isfinite(tj.step(0))
+
+
+def test_two_rank_train_step_reduces_inside_the_backward():
+    """Two ranks sharing this box's GPU over gloo (tools/train_2rank_check.py compare): the staged step --
+    backward in pieces, each piece's gradients all-reduced while the next one runs -- leaves both ranks with the
+    same model as the step with one all-reduce behind the backward, replayed from hipGraphs and eagerly."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LAYERS='3')
+    env.pop('CWN_TRAIN_STAGES', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'tools', 'train_2rank_check.py'), 'compare']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        print(out.stdout[-3000:], out.stderr[-6000:])
+    assert out.returncode == 0, [l for l in out.stderr.splitlines() if 'Error' in l or 'error' in l][-5:]
+    ok = [l for l in out.stdout.splitlines() if l.startswith('compare OK')]
+    assert len(ok) == 2, out.stdout[-2000:]
+    print('[train] ' + ' | '.join(ok))
+
+
 def test_flat_adam_matches_torch_adam():
     from cwn_amd.dist import FlatGradBucket
     from cwn_amd.train import FlatAdam
