@@ -179,9 +179,18 @@ extern "C" int64_t cwn_layer_items_build(const cwn_layer_sizes* in, int32_t F, i
         in->n_complexes < 0 || (cap_items > 0 && items == nullptr))
         return CWN_LAYER_ITEMS_BAD_ARG;
     if (in->n_complexes == 0) return 0;
+    // every table is a prefix sum: starts at 0, never decreases, and its total fits the int32 fields of a record
+    auto prefix_sum = [n = in->n_complexes](const int64_t* p) {
+        if (p[0] != 0) return false;
+        for (int64_t c = 0; c < n; ++c)
+            if (p[c + 1] < p[c]) return false;
+        return p[n] <= INT32_MAX;
+    };
     for (int d = 0; d < in->n_dims; ++d) {
-        if (in->cell_ptr[d] == nullptr) return CWN_LAYER_ITEMS_BAD_ARG;
+        if (in->cell_ptr[d] == nullptr || !prefix_sum(in->cell_ptr[d])) return CWN_LAYER_ITEMS_BAD_ARG;
         if (in->has_up[d] && (d + 1 >= in->n_dims || in->up_ptr[d] == nullptr)) return CWN_LAYER_ITEMS_BAD_ARG;
+        if (in->up_ptr[d] != nullptr && !prefix_sum(in->up_ptr[d])) return CWN_LAYER_ITEMS_BAD_ARG;
+        if (in->b_ptr[d] != nullptr && !prefix_sum(in->b_ptr[d])) return CWN_LAYER_ITEMS_BAD_ARG;
     }
     const Shape sh{F, cwn_layer_round_rows(F)};
     if (sh.round_rows <= 0) return CWN_LAYER_ITEMS_BAD_ARG;

@@ -106,6 +106,34 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_gemm_would_split(g, 1) == 0                       # not the split kernel's shape ...
 
 
+def test_item_table_builder_rejects_tables_that_are_not_prefix_sums():
+    """cwn_layer_items_build (host C++) reads caller-provided per-complex tables: one that does not start at 0,
+    decreases, or sums past the int32 record fields is refused, not cut into records with negative counts."""
+    import numpy as np
+    from cwn_amd.blockplan import ITEM_INTS
+    lib = _ffi.lib()
+    good = dict(cells=[[0, 5, 9], [0, 6, 10]], up=[0, 12, 20], b=[0, 12, 20])
+
+    def build(cells, up, b, cap=4):
+        keep = [np.asarray(a, dtype=np.int64) for a in (cells[0], cells[1], up, b)]
+        sizes = _ffi.LayerSizes(n_complexes=2, n_dims=2)
+        sizes.has_up[0], sizes.has_up[1] = 1, 0
+        sizes.cell_ptr[0], sizes.cell_ptr[1] = keep[0].ctypes.data, keep[1].ctypes.data
+        sizes.up_ptr[0] = keep[2].ctypes.data
+        sizes.b_ptr[1] = keep[3].ctypes.data
+        table = np.zeros((cap, ITEM_INTS), dtype=np.int32)
+        return int(lib.cwn_layer_items_build(sizes, 64, table.ctypes.data, cap, _ffi.LayerPlan())), table
+    n, table = build(good['cells'], good['up'], good['b'])
+    assert n >= 1 and int(table[:n, 3].sum()) == 9            # every vertex in exactly one record
+    bad = [dict(good, cells=[[1, 5, 9], [0, 6, 10]]),        # does not start at 0
+           dict(good, cells=[[0, 5, 9], [0, 6, 4]]),         # decreases
+           dict(good, up=[0, 12, 7]),
+           dict(good, b=[0, -3, 20]),
+           dict(good, up=[0, 12, 2 ** 31])]                  # past the int32 fields of a record
+    for kw in bad:
+        assert build(kw['cells'], kw['up'], kw['b'])[0] == _ffi.LAYER_ITEMS_BAD_ARG, kw
+
+
 def test_cpu_tensors_fail_loudly():
     from cwn_amd import ops
     x = torch.randn(4, 8)
