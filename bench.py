@@ -714,6 +714,62 @@ def main():
             print(f'[bench] concurrent-streams leg failed: {type(e).__name__}: {e}', file=sys.stderr)
             torch.cuda.synchronize()
 
+    full_cells_total = float(full_cells.item())      # read here: result_line may run on the deadline thread, which must not touch the device
+
+    def result_line(train, collate):
+        """The ONE JSON line of rank 0 (everything but the last two legs is known before they start)."""
+        s0 = stats[0]
+        split_on = not ops.GEMM_EXACT
+        dense = ('fp32 in / fp32 out; N = K = 128 products as exact 3-way bf16 operand splits on the bf16 MFMA pipe '
+                 '(6 MFMAs per term, fp32 accumulate, max error 4e-7 of |x|.|w| vs float64 = the fp32-MFMA kernel\'s), '
+                 'every other GEMM on fp32 MFMA; CWN_GEMM_SPLIT=0 runs all of them on fp32 MFMA'
+                 if split_on and H == 128 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32')
+        out = {
+            'metric': 'cells/sec, propagate scope, ' + {'zinc': 'ZINC-like ring-lifted batch (max_ring 6)', 'molhiv': 'molhiv-like ring-lifted batch (max_ring 6)', 'reddit': 'REDDIT-like clique-lifted batch (dim 2)'}[WL],
+            'value': round(value, 1), 'unit': 'cells/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 5),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': {'zinc': f'ZINC-like ring-lift (max_ring=6), {L}-layer SparseCIN propagate scope (hidden {H}, coboundary messages), batch {args.batch} per GPU [BASELINE configs[1]]', 'molhiv': f'ogbg-molhiv-like ring-lift (max_ring=6), {L}-layer OGBEmbedSparseCIN propagate scope (hidden {H}), batch {args.batch} per GPU [BASELINE configs[2]]', 'reddit': f'REDDIT-BINARY-like clique-lift (dim 2, hubs of degree >= 100), {L}-layer SparseCIN propagate scope (hidden {H}, no coboundaries, norm id, JK cat), batch {args.batch} per GPU [BASELINE configs[4]]'}[WL],
+                       'batch_per_gpu': args.batch, 'hidden': H, 'layers': L,
+                       'cells_per_batch': s0['cells'], 'N': [s0['N0'], s0['N1'], s0['N2']],
+                       'E_up': [s0['E_up0'], s0['E_up1'], s0['E_up2']],
+                       'B': [s0['B0'], s0['B1'], s0['B2']],
+                       'launch': 'hipGraph replay' if use_graph else 'eager',
+                       'plan_build_in_step': not BLOCKED, 'layer_kernel': 'complex-blocked (1 launch per layer, COO in, no CSR plan)' if BLOCKED else 'grouped GEMM + CSR aggregation (2 launches per layer + 1 plan build per batch)', 'dense_arithmetic': dense,
+                       'parallelism': f'replicas x{world} (no data-path collective)'},
+            'roofline': roofline, 'roofline_other': roofline_other, 'roofline_plan_build': r_plan,
+            'roofline_step': roofline_step,
+            'cpu_baseline': cpu_baseline,
+            'secondary': {'full_forward_cells_per_s': (round(full_cells_total / dt_full, 1)
+                                                       if dt_full == dt_full else None),     # leg skipped: null, not NaN
+                          'full_forward_ms': round(dt_full / full_steps * 1e3, 5) if dt_full == dt_full else None,
+                          'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '
+                                   'MLPs + BatchNorm(eval), readout, head',
+                          'collate': collate, 'concurrent_streams': concurrent, 'train_step': train,
+                          'eager_launches': eager},
+        }
+        return out
+
+    # N > 1: the legs from here on hold the job's only collectives over RCCL (the data-parallel training step, the
+    # barrier at the end).  The headline number is complete at this point; should a collective never return
+    # (nothing in this container can run more than one GPU), the line is printed without those legs and every
+    # rank leaves, instead of the job dying in the RCCL watchdog with nothing on stdout.
+    import threading
+    printed, finished = threading.Event(), threading.Event()
+    if world > 1:
+        deadline = float(os.environ.get('CWN_BENCH_DP_DEADLINE_S', '240'))
+
+        def _deadline():
+            if finished.wait(deadline):
+                return
+            if rank == 0 and not printed.is_set():
+                why = f'not finished {deadline:.0f} s after the single-GPU legs: skipped'
+                print(json.dumps(result_line({'skipped': why}, None)), flush=True)
+            print(f'[bench] rank {rank}: data-parallel legs passed their deadline, leaving', file=sys.stderr, flush=True)
+            os._exit(0)
+        threading.Thread(target=_deadline, daemon=True).start()
+
     # secondary: the whole optimisation step (plans, forward, L1 loss, backward, fused Adam; for
     # N > 1 plus the ONE gradient all-reduce over RCCL), graph-captured -- SURVEY.md 8(d)/(e)
     train = None
@@ -822,40 +878,11 @@ def main():
             print(f'[bench] collate leg failed: {type(e).__name__}: {e}', file=sys.stderr)
 
     if rank == 0:
-        s0 = stats[0]
-        split_on = not ops.GEMM_EXACT
-        dense = ('fp32 in / fp32 out; N = K = 128 products as exact 3-way bf16 operand splits on the bf16 MFMA pipe '
-                 '(6 MFMAs per term, fp32 accumulate, max error 4e-7 of |x|.|w| vs float64 = the fp32-MFMA kernel\'s), '
-                 'every other GEMM on fp32 MFMA; CWN_GEMM_SPLIT=0 runs all of them on fp32 MFMA'
-                 if split_on and H == 128 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32')
-        out = {
-            'metric': 'cells/sec, propagate scope, ' + {'zinc': 'ZINC-like ring-lifted batch (max_ring 6)', 'molhiv': 'molhiv-like ring-lifted batch (max_ring 6)', 'reddit': 'REDDIT-like clique-lifted batch (dim 2)'}[WL],
-            'value': round(value, 1), 'unit': 'cells/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 5),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-            'data': 'synthetic',
-            'config': {'workload': {'zinc': f'ZINC-like ring-lift (max_ring=6), {L}-layer SparseCIN propagate scope (hidden {H}, coboundary messages), batch {args.batch} per GPU [BASELINE configs[1]]', 'molhiv': f'ogbg-molhiv-like ring-lift (max_ring=6), {L}-layer OGBEmbedSparseCIN propagate scope (hidden {H}), batch {args.batch} per GPU [BASELINE configs[2]]', 'reddit': f'REDDIT-BINARY-like clique-lift (dim 2, hubs of degree >= 100), {L}-layer SparseCIN propagate scope (hidden {H}, no coboundaries, norm id, JK cat), batch {args.batch} per GPU [BASELINE configs[4]]'}[WL],
-                       'batch_per_gpu': args.batch, 'hidden': H, 'layers': L,
-                       'cells_per_batch': s0['cells'], 'N': [s0['N0'], s0['N1'], s0['N2']],
-                       'E_up': [s0['E_up0'], s0['E_up1'], s0['E_up2']],
-                       'B': [s0['B0'], s0['B1'], s0['B2']],
-                       'launch': 'hipGraph replay' if use_graph else 'eager',
-                       'plan_build_in_step': not BLOCKED, 'layer_kernel': 'complex-blocked (1 launch per layer, COO in, no CSR plan)' if BLOCKED else 'grouped GEMM + CSR aggregation (2 launches per layer + 1 plan build per batch)', 'dense_arithmetic': dense,
-                       'parallelism': f'replicas x{world} (no data-path collective)'},
-            'roofline': roofline, 'roofline_other': roofline_other, 'roofline_plan_build': r_plan,
-            'roofline_step': roofline_step,
-            'cpu_baseline': cpu_baseline,
-            'secondary': {'full_forward_cells_per_s': (round(float(full_cells.item()) / dt_full, 1)
-                                                       if dt_full == dt_full else None),     # leg skipped: null, not NaN
-                          'full_forward_ms': round(dt_full / full_steps * 1e3, 5) if dt_full == dt_full else None,
-                          'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '
-                                   'MLPs + BatchNorm(eval), readout, head',
-                          'collate': collate, 'concurrent_streams': concurrent, 'train_step': train,
-                          'eager_launches': eager},
-        }
-        print(json.dumps(out))
+        printed.set()
+        print(json.dumps(result_line(train, collate)), flush=True)
     if dist is not None:
         dist.barrier()      # rank 0 runs the roofline / collate legs alone; leave together
+        finished.set()
         dist.destroy_process_group()
 
 

@@ -565,7 +565,7 @@ extern "C" const char* cwn_error_string(int code) {
         case CWN_ERR_TOO_LARGE: return "size does not fit int32";
         case CWN_ERR_WORKSPACE: return "workspace too small";
         case CWN_ERR_LAUNCH: return "kernel launch failed";
-        case CWN_ERR_ALIGN: return "pointer not 4-byte aligned";
+        case CWN_ERR_ALIGN: return "pointer misses its alignment (4 bytes; 16 for outputs, weights and packed buffers of the vectorised kernels)";
         default: return "unknown error";
     }
 }

@@ -37,7 +37,7 @@ enum {
     CWN_ERR_TOO_LARGE = 2,  /* E or n_dst does not fit int32                                   */
     CWN_ERR_WORKSPACE = 3,  /* workspace smaller than cwn_csr_workspace_bytes says             */
     CWN_ERR_LAUNCH = 4,     /* hipGetLastError() != hipSuccess after a launch                  */
-    CWN_ERR_ALIGN = 5       /* a feature pointer is not 4-byte aligned                          */
+    CWN_ERR_ALIGN = 5       /* a pointer misses its alignment: 4 bytes, or 16 where an entry says so */
 };
 
 #define CWN_MAX_DESCS 8 /* descriptors per batched call (one kernel launch covers all of them) */
