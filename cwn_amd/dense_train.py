@@ -189,6 +189,7 @@ class _DenseTrain(torch.autograd.Function):
                        for i, (z, h) in enumerate(zip(Z3, H)) if z.numel()], dev)
         if bns:
             torch._foreach_add_([st.norm.num_batches_tracked for st in bns], 1)
+            ops.state_changed()      # bn_finalize wrote the running statistics through raw pointers
         ctx.plan = plan
         ctx.aff_of = {k: v for k, v in aff_of.items()}
         flatZ = [Z[i][br][s] for i in range(nd) for br in (0, 1) for s in range(depth)]

@@ -104,7 +104,7 @@ def _fold_norm(norm, width: int):
             or norm.num_features != width):
         return None     # batch statistics (training) are not a fixed affine
     tensors = [t for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var) if t is not None]
-    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    key = (ops.STATE_EPOCH,) + tuple((t.data_ptr(), t._version) for t in tensors)
     hit = getattr(norm, '_cwn_fold', None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -626,7 +626,7 @@ class SparseCINConv(torch.nn.Module):
                 return None
             dims, plan, table, key = args
             ckey = id(plan)
-            ent = dict(plan=plan, table=table, key=key, F=int(dims[0].x.size(1)),
+            ent = dict(plan=plan, table=table, key=key, F=int(dims[0].x.size(1)), epoch=ops.STATE_EPOCH,
                        idx=[(c.up_index, c.boundary_index, getattr(c.kwargs.get('up_attr'), 'index', None))
                             for c in cochain_params],
                        lins=[(d, self.mp_levels[d].msg_up_nn[1]) for d, D in enumerate(dims) if D.msg_w_packed is not None],
@@ -675,6 +675,8 @@ class SparseCINConv(torch.nn.Module):
             b_attr = c.kwargs.get('boundary_attr')
             if b_attr is not None and (d == 0 or b_attr is not cochain_params[d - 1].x):
                 return False
+        if ent['epoch'] != ops.STATE_EPOCH:
+            return False              # a training kernel wrote the parameters (ops.state_changed)
         for (d, lin), ver in zip(ent['lins'], ent['wver']):
             if lin.weight._version != ver:
                 return False          # weights changed: rebuild (re-pack) through _blocked_args

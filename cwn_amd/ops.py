@@ -755,6 +755,20 @@ class LayerDim:
     eps2: Optional[Tensor] = None
 
 
+# Prepared forms of model state -- packed weights, BatchNorm folded into an affine, prepared launches -- are
+# cached on (storage, tensor version).  The library's own training kernels write parameters and running
+# statistics through raw pointers (cwn_adam_f32, the BatchNorm-statistics epilogue), also from replayed hipGraphs,
+# where no Python runs at all: tensor versions do not see those writes.  Every such writer calls
+# state_changed(); the epoch is part of every cache key.  (A caller who replays its own graph of training kernels
+# calls it too.)
+STATE_EPOCH = 0
+
+
+def state_changed() -> None:
+    global STATE_EPOCH
+    STATE_EPOCH += 1
+
+
 _packed_weights = {}
 
 
@@ -766,7 +780,7 @@ def pack_layer_weight(weight: Tensor) -> Tensor:
     import weakref
     w = weight.detach()
     key = id(weight)
-    ver = (w.data_ptr(), weight._version, tuple(w.shape), w.device)
+    ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
     hit = _packed_weights.get(key)
     if hit is not None and hit[0] == ver and hit[1]() is weight:
         return hit[2]
@@ -794,7 +808,7 @@ def pack_gemm_weight(weight: Tensor) -> Optional[Tensor]:
     if w.dim() != 2 or tuple(w.shape) != (128, 128) or not w.is_cuda or w.dtype != torch.float32:
         return None
     key = id(weight)
-    ver = (w.data_ptr(), weight._version, w.device)
+    ver = (w.data_ptr(), weight._version, STATE_EPOCH, w.device)
     hit = _packed_gemm_weights.get(key)
     if hit is not None and hit[0] == ver and hit[1]() is weight:
         return hit[2]
@@ -870,7 +884,7 @@ def pack_mlp_weight(weight: Tensor):
     import weakref
     w = weight.detach()
     key = id(weight)
-    ver = (w.data_ptr(), weight._version, tuple(w.shape), w.device)
+    ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
     hit = _packed_mlp_weights.get(key)
     if hit is not None and hit[0] == ver and hit[1]() is weight:
         return hit[2]
@@ -976,8 +990,10 @@ class LayerLaunch:
             x = xs[d]
             if not x.is_contiguous():
                 x = x.contiguous()
-            if x.size(0) != self.rows[d]:
-                raise ValueError('feature rows do not match the batch this launch was prepared for')
+            if x.size(0) != self.rows[d] or x.size(1) != F:
+                raise ValueError('feature rows / width do not match the batch this launch was prepared for')
+            if x.dtype != torch.float32 or x.device != self.dev:
+                raise TypeError('features must be float32 tensors on the GPU this launch was prepared for')
             a = self.arr[d]
             a.x = x.data_ptr()
             a.out_up = base + self._off[2 * d] * row_b

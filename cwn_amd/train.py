@@ -78,6 +78,7 @@ class FlatAdam:
             self.flat_p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
             g.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
             self.t.data_ptr(), _ffi.stream_ptr(g.device)), 'cwn_adam_f32')
+        ops.state_changed()          # the parameters were written through a raw pointer: tensor versions did not move
 
 
 class TrainStep:
@@ -307,6 +308,7 @@ class TrainStep:
         if i not in self._graphs:
             self._graphs[i] = self._capture(i)
         pieces, g2, loss = self._graphs[i]
+        ops.state_changed()          # a replay runs no Python: caches of packed weights / folded BatchNorm must not survive it
         if g2 is None:
             pieces[0].replay()
             return loss

@@ -1724,6 +1724,36 @@ def test_two_rank_train_step_reduces_inside_the_backward():
     print('[train] ' + ' | '.join(ok))
 
 
+def test_eval_after_training_sees_the_trained_weights():
+    """Packed weights, folded BatchNorm and prepared launches are cached per tensor version -- but the training
+    kernels (cwn_adam_f32, the BatchNorm-statistics epilogue) write through raw pointers, and a replayed hipGraph
+    runs no Python at all.  eval -> train (graph replays) -> eval must equal a freshly built model holding the
+    trained state (mp/molec_models.py:90-160 evaluated after exp/train_utils.py:57-75)."""
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import zinc_like_batch
+    from cwn_amd.train import TrainStep
+
+    def build():
+        return EmbedSparseCIN(28, 4, 1, 2, 64, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV)
+    torch.manual_seed(8)
+    model = build()
+    fresh_batch = lambda: zinc_like_batch(16, seed=77, device=DEV)
+    with torch.no_grad():
+        y0 = model.eval()(fresh_batch())                  # fills every cache with the initial state
+    for use_graph in (True, False):
+        ts = TrainStep(model, [zinc_like_batch(16, seed=78, device=DEV)], lr=1e-2, use_graph=use_graph)
+        for _ in range(3):
+            ts.step(0)
+        with torch.no_grad():
+            y1 = model.eval()(fresh_batch())
+            ref = build()
+            ref.load_state_dict(model.state_dict())
+            y2 = ref.eval()(fresh_batch())
+        assert torch.equal(y1, y2), (use_graph, float((y1 - y2).abs().max()))
+        assert float((y1 - y0).abs().max()) > 1e-3       # and the training did move the output
+        y0 = y1
+
+
 def test_flat_adam_matches_torch_adam():
     from cwn_amd.dist import FlatGradBucket
     from cwn_amd.train import FlatAdam
