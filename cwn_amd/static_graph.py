@@ -62,6 +62,10 @@ class StaticPropagate:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.outs: Optional[List[List[torch.Tensor]]] = None
         self.n_cells = [0, 0, 0]
+        # the packed weights above are baked into the launches (and later the graph): inference over fixed weights
+        self._weights = [(conv.mp_levels[d].msg_up_nn[1].weight, conv.mp_levels[d].msg_up_nn[1].weight._version)
+                         for conv in self.convs for d in range(2)]
+        self._epoch = ops.STATE_EPOCH
 
     # ---- a batch into the static buffers ------------------------------------------------------------
     def load(self, batch: ComplexBatch, feats: Sequence[Sequence[torch.Tensor]]) -> None:
@@ -111,6 +115,8 @@ class StaticPropagate:
     def replay(self) -> List[List[torch.Tensor]]:
         """[layer][out_up_0, out_b_0, out_up_1, ...] restricted to the loaded batch's cells.  The first
         call captures the graph; every later call (any batch that fits) replays it."""
+        if self._epoch != ops.STATE_EPOCH or any(w._version != v for w, v in self._weights):
+            raise RuntimeError('StaticPropagate: the layer weights changed since this object packed them; build a new one')
         with torch.no_grad():
             if self.graph is None:
                 s = torch.cuda.Stream()
