@@ -16,12 +16,13 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
-           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy')
+           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
+           'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
 
 
 class CsrDesc(C.Structure):
@@ -216,6 +217,16 @@ def lib():
     L.cwn_lift_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.cwn_lift_destroy.restype = None
     L.cwn_lift_destroy.argtypes = [C.c_void_p]
+    L.cwn_lift_many.restype = C.c_void_p
+    L.cwn_lift_many.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.cwn_lift_many_count.restype = C.c_int64
+    L.cwn_lift_many_count.argtypes = [C.c_void_p]
+    L.cwn_lift_many_lengths.restype = C.c_int
+    L.cwn_lift_many_lengths.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.cwn_lift_many_copy.restype = C.c_int
+    L.cwn_lift_many_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.cwn_lift_many_destroy.restype = None
+    L.cwn_lift_many_destroy.argtypes = [C.c_void_p]
     if L.cwn_abi_version() != ABI_VERSION:
         raise CwnError(f'ABI mismatch: library {L.cwn_abi_version()} vs binding {ABI_VERSION}')
     _lib = L

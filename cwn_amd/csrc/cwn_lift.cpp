@@ -13,7 +13,9 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <thread>
 #include <vector>
 #include "../../include/cwn_hip.h"
 
@@ -230,3 +232,101 @@ extern "C" int cwn_lift_copy(const cwn_lift_t* L, int which, int64_t* out) {
 }
 
 extern "C" void cwn_lift_destroy(cwn_lift_t* L) { delete L; }
+
+// ---- a whole dataset at once ------------------------------------------------------------------------------
+// The reference lifts a dataset graph by graph under joblib (data/utils.py:501-560 convert_graph_dataset_with_rings,
+// n_jobs processes); a Python loop over cwn_lift_create costs ~115 us per ZINC-sized molecule, of which the
+// lifting is ~15.  Here the graphs of a dataset are lifted by host threads and handed back CONCATENATED per array,
+// in the layout the HBM-resident packed dataset wants (cwn_amd/packed.py): no per-complex objects in between.
+struct cwn_lift_set_s {
+    std::vector<cwn_lift_s*> lifts;
+    ~cwn_lift_set_s() { for (auto* l : lifts) delete l; }
+};
+
+namespace {
+inline bool two_rows(int which) {
+    return which == CWN_LIFT_UP0 || which == CWN_LIFT_UP1 || which == CWN_LIFT_DOWN1 || which == CWN_LIFT_DOWN2 ||
+           which == CWN_LIFT_BINDEX1 || which == CWN_LIFT_BINDEX2;
+}
+}  // namespace
+
+extern "C" cwn_lift_set_t* cwn_lift_many(int kind, int64_t n_graphs, const int64_t* n_vertices, const int64_t* edge_ptr,
+                                         const int64_t* edges, int max_k, int include_down, int n_threads) {
+    if (n_graphs < 0 || (n_graphs > 0 && (n_vertices == nullptr || edge_ptr == nullptr))) return nullptr;
+    if (kind != CWN_LIFT_RING && kind != CWN_LIFT_CLIQUE) return nullptr;
+    for (int64_t g = 0; g < n_graphs; ++g)
+        if (edge_ptr[g + 1] < edge_ptr[g] || edge_ptr[0] != 0) return nullptr;
+    if (n_graphs > 0 && edge_ptr[n_graphs] > 0 && edges == nullptr) return nullptr;
+    auto* S = new cwn_lift_set_s();
+    S->lifts.assign((size_t)n_graphs, nullptr);
+    std::atomic<int64_t> next{0};
+    std::atomic<bool> bad{false};
+    auto work = [&] {
+        for (;;) {
+            const int64_t g0 = next.fetch_add(64);          // chunks: molecules are tiny
+            if (g0 >= n_graphs || bad.load()) return;
+            for (int64_t g = g0; g < std::min(g0 + 64, n_graphs); ++g) {
+                cwn_lift_s* l = cwn_lift_create(kind, n_vertices[g], edges + 2 * edge_ptr[g], edge_ptr[g + 1] - edge_ptr[g],
+                                                max_k, include_down);
+                if (l == nullptr) { bad.store(true); return; }
+                S->lifts[(size_t)g] = l;
+            }
+        }
+    };
+    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(T, (n_graphs + 63) / 64));
+    if (T == 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back(work);
+        for (auto& th : pool) th.join();
+    }
+    if (bad.load()) { delete S; return nullptr; }
+    return S;
+}
+
+extern "C" int64_t cwn_lift_many_count(const cwn_lift_set_t* S) { return S ? (int64_t)S->lifts.size() : -1; }
+
+// per graph: the columns L of a [2, L] array, the elements of any other
+extern "C" int cwn_lift_many_lengths(const cwn_lift_set_t* S, int which, int64_t* out) {
+    if (S == nullptr || which < 0 || which >= CWN_LIFT_N_ARRAYS || (out == nullptr && !S->lifts.empty())) return CWN_ERR_BAD_ARG;
+    for (size_t g = 0; g < S->lifts.size(); ++g) {
+        const int64_t n = (int64_t)S->lifts[g]->out[which].size();
+        out[g] = two_rows(which) ? n / 2 : n;
+    }
+    return CWN_OK;
+}
+
+// every graph's array `which` in graph order; a [2, L] array comes out as ONE [2, sum L] array (row 0 of every graph,
+// then row 1 of every graph): torch.cat(per-graph arrays, dim=-1).  Vertex / cell ids stay local to their graph.
+extern "C" int cwn_lift_many_copy(const cwn_lift_set_t* S, int which, int64_t* out) {
+    if (S == nullptr || which < 0 || which >= CWN_LIFT_N_ARRAYS) return CWN_ERR_BAD_ARG;
+    int64_t total = 0;
+    for (auto* l : S->lifts) total += (int64_t)l->out[which].size();
+    if (total == 0) return CWN_OK;
+    if (out == nullptr) return CWN_ERR_BAD_ARG;
+    if (!two_rows(which)) {
+        for (auto* l : S->lifts) {
+            const Vec& v = l->out[which];
+            if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(int64_t));
+            out += v.size();
+        }
+        return CWN_OK;
+    }
+    int64_t* r0 = out;
+    int64_t* r1 = out + total / 2;
+    for (auto* l : S->lifts) {
+        const Vec& v = l->out[which];
+        const size_t L = v.size() / 2;
+        if (L) {
+            std::memcpy(r0, v.data(), L * sizeof(int64_t));
+            std::memcpy(r1, v.data() + L, L * sizeof(int64_t));
+        }
+        r0 += L;
+        r1 += L;
+    }
+    return CWN_OK;
+}
+
+extern "C" void cwn_lift_many_destroy(cwn_lift_set_t* S) { delete S; }

@@ -72,6 +72,51 @@ class PackedComplexes:
         ys = [cx.y for cx in complexes]
         self.y = self._pack(ys, 'y') if all(t is not None for t in ys) else None
 
+    @classmethod
+    def from_arrays(cls, device, max_dim: int, dims, n_cells, has_cells, n_up, n_down, keys, y=None) -> 'PackedComplexes':
+        """A packed dataset from arrays that are ALREADY concatenated per key (cwn_amd.lifting.pack_graph_dataset_*:
+        a dataset lifted by cwn_lift_many goes from graphs to HBM without per-complex Python objects).
+        keys[d][name] = (data, lengths, has): `data` as the constructor would concatenate it (x: [rows, width] or flat;
+        a two-row index: [2, total]; else 1-D), `lengths` per complex in the constructor's units (x: rows * width; an
+        index: columns), `has` per complex."""
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        self.max_dim = max_dim
+        self.dims = np.minimum(np.asarray(dims, dtype=np.int64), max_dim)
+        self.num = int(self.dims.size)
+        D = max_dim + 1
+        self.n_cells = np.asarray(n_cells, dtype=np.int64)[:D]
+        self.has_cells = np.asarray(has_cells, dtype=bool)[:D]
+        self.n_up = np.asarray(n_up, dtype=np.int64)[:D]
+        self.n_down = np.asarray(n_down, dtype=np.int64)[:D]
+        self.keys = []
+        for d in range(D):
+            per_key = {}
+            for key in _ALL_KEYS:            # the constructor's key order
+                if key in keys[d] and np.asarray(keys[d][key][2], dtype=bool).any():
+                    per_key[key] = self._packed(*keys[d][key], key)
+            self.keys.append(per_key)
+        self.y = self._packed(*y, 'y') if y is not None else None
+        return self
+
+    def _packed(self, data: torch.Tensor, lengths, has, key) -> _Packed:
+        lengths = np.asarray(lengths, dtype=np.int64)
+        width = 1
+        if key == 'x':
+            width = int(data.size(1)) if data.dim() == 2 else 1
+            data = data.reshape(-1)
+        start = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+        return _Packed(data.contiguous().to(self.device), start, lengths, np.asarray(has, dtype=bool),
+                       2 if key in ('upper_index', 'lower_index', 'boundary_index') else 1, width, self._op(data, key))
+
+    @staticmethod
+    def _op(data: torch.Tensor, key: str) -> int:
+        if data.dtype == torch.float32 or data.dtype == torch.int32:
+            return _ffi.COLLATE_COPY32
+        if data.dtype == torch.int64:
+            return _ffi.COLLATE_ADD64 if key in _INDEX_KEYS else _ffi.COLLATE_COPY64
+        raise TypeError(f'{key}: unsupported dtype {data.dtype} (float32 / int32 / int64 only)')
+
     def _pack(self, items, key) -> _Packed:
         ref = next(t for t in items if t is not None)
         two_rows = key in ('upper_index', 'lower_index', 'boundary_index')
@@ -87,13 +132,8 @@ class PackedComplexes:
             data = torch.cat([t.reshape(-1) for t in present])
         else:
             data = torch.cat([t.unsqueeze(0) if t.dim() == 0 else t for t in present], dim=-1)
-        if data.dtype == torch.float32 or data.dtype == torch.int32:
-            op = _ffi.COLLATE_COPY32
-        elif data.dtype == torch.int64:
-            op = _ffi.COLLATE_ADD64 if key in _INDEX_KEYS else _ffi.COLLATE_COPY64
-        else:
-            raise TypeError(f'{key}: unsupported dtype {data.dtype} (float32 / int32 / int64 only)')
-        return _Packed(data.contiguous().to(self.device), start, lengths, has, 2 if two_rows else 1, width, op)
+        return _Packed(data.contiguous().to(self.device), start, lengths, has, 2 if two_rows else 1, width,
+                       self._op(data, key))
 
     # --------------------------------------------------------------------------------------------
     def collate(self, idx: Sequence[int]) -> ComplexBatch:

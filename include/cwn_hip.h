@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 10
+#define CWN_ABI_VERSION 11
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -605,6 +605,23 @@ cwn_lift_t* cwn_lift_create(int kind, int64_t n_vertices, const int64_t* edges, 
 int64_t cwn_lift_size(const cwn_lift_t* lift, int which);          /* int64 elements, -1 on error */
 int cwn_lift_copy(const cwn_lift_t* lift, int which, int64_t* out);
 void cwn_lift_destroy(cwn_lift_t* lift);
+
+/* A whole dataset at once (data/utils.py:501-560 convert_graph_dataset_with_rings / :275-297
+ * convert_graph_dataset_with_gudhi lift graph by graph under joblib): graph g has n_vertices[g] vertices and the
+ * edges edges[2 * edge_ptr[g] .. 2 * edge_ptr[g + 1]) (pairs of vertex ids LOCAL to the graph; edge_ptr[0] = 0), lifted
+ * by up to n_threads host threads (<= 0: all hardware threads).  NULL on bad arguments or when any graph is invalid.
+ * Results come back concatenated over the graphs, in graph order, ids still local to their graph:
+ *   cwn_lift_many_lengths  per graph: the columns L_g of a [2, L_g] array, the elements of any other array;
+ *   cwn_lift_many_copy     a [2, L_g] array as ONE [2, sum L_g] row-major array (row 0 of every graph, then row 1
+ *                          of every graph), any other array end to end -- the layout of the HBM-resident packed
+ *                          dataset (cwn_amd/packed.py), with no per-complex object in between. */
+typedef struct cwn_lift_set_s cwn_lift_set_t;
+cwn_lift_set_t* cwn_lift_many(int kind, int64_t n_graphs, const int64_t* n_vertices, const int64_t* edge_ptr,
+                              const int64_t* edges, int max_k, int include_down, int n_threads);
+int64_t cwn_lift_many_count(const cwn_lift_set_t* set);                       /* graphs, -1 on NULL */
+int cwn_lift_many_lengths(const cwn_lift_set_t* set, int which, int64_t* out /* [n_graphs] */);
+int cwn_lift_many_copy(const cwn_lift_set_t* set, int which, int64_t* out);
+void cwn_lift_many_destroy(cwn_lift_set_t* set);
 
 #ifdef __cplusplus
 }

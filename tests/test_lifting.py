@@ -207,3 +207,123 @@ def test_native_lift_rejects_bad_graphs():
         raise AssertionError(f'{bad} accepted')
     cx = lifting.ring_lift(4, [], torch.zeros(4, 1))          # no edges: a 0-complex
     assert cx.dimension == 0 and cx.cochains[0].upper_index is None
+
+
+# ---- a whole dataset at once (cwn_lift_many -> PackedComplexes.from_arrays) --------------------------------
+def _pyg_like(rng, n, bonds, with_attr=True, y_kind='graph', long_x=False):
+    """A PyG-Data-like dict: edge_index with BOTH directions in shuffled order, edge_attr per directed entry."""
+    und = np.asarray(bonds, dtype=np.int64).reshape(-1, 2)
+    attr_und = rng.integers(0, 4, size=(und.shape[0], 1))
+    ei = np.concatenate([und, und[:, ::-1]], axis=0)
+    ea = np.concatenate([attr_und, attr_und], axis=0)
+    order = rng.permutation(ei.shape[0])
+    x = torch.from_numpy(rng.integers(0, 28, size=(n, 1)))
+    g = dict(x=x if long_x else x.float(), edge_index=torch.from_numpy(ei[order].T.copy()), num_nodes=n,
+             edge_attr=torch.from_numpy(ea[order]).float() if with_attr else None,
+             y={'graph': torch.tensor([float(n)]), 'vertex': torch.arange(n).float() + 0.5, 'none': None}[y_kind])
+    srt = np.lexsort((und.max(1), und.min(1)))                # features of the sorted (u < v) edges
+    return g, torch.from_numpy(attr_und[srt]).float()
+
+
+def _same_packed(a, b):
+    assert a.num == b.num and a.max_dim == b.max_dim
+    for name in ('dims', 'n_cells', 'has_cells', 'n_up', 'n_down'):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert (a.y is None) == (b.y is None)
+    pairs = [(a.y, b.y, 'y')] if a.y is not None else []
+    for d in range(a.max_dim + 1):
+        assert list(a.keys[d].keys()) == list(b.keys[d].keys()), (d, list(a.keys[d]), list(b.keys[d]))
+        pairs += [(a.keys[d][k], b.keys[d][k], f'{d}/{k}') for k in a.keys[d]]
+    for p, q, what in pairs:
+        assert p.data.dtype == q.data.dtype and torch.equal(p.data, q.data), what
+        for f in ('start', 'length', 'has'):
+            assert np.array_equal(getattr(p, f), getattr(q, f)), (what, f)
+        assert (p.rows, p.width, p.op) == (q.rows, q.width, q.op), what
+
+
+def test_dataset_ring_lift_packs_what_the_per_graph_lift_packs():
+    """pack_graph_dataset_with_rings (graphs -> host threads -> concatenated arrays -> packed dataset) against
+    PackedComplexes over per-graph `ring_lift` complexes: every array, table and flag of the packed dataset --
+    molecules with and without rings, a graph without edges, both edge directions in shuffled order."""
+    from cwn_amd import lifting
+    from cwn_amd.packed import PackedComplexes
+    rng = np.random.default_rng(21)
+    for trial, (down, init_rings, with_attr, long_x) in enumerate(
+            [(False, False, True, False), (True, True, True, False), (False, True, False, False), (True, False, True, True)]):
+        graphs, ref = [], []
+        for i in range(70):
+            n, bonds = random_molecule(rng, 6, 40)
+            if i % 9 == 4:                                # a tree: no ring, dimension 1
+                bonds = [(j, j + 1) for j in range(n - 1)]
+            if i % 17 == 6:                               # isolated atoms: dimension 0
+                bonds = []
+            g, ex_sorted = _pyg_like(rng, n, bonds, with_attr=with_attr, long_x=long_x)
+            graphs.append(g)
+            vx = g['x']
+            pairs = sorted({(min(u, v), max(u, v)) for u, v in bonds})
+            if not with_attr:
+                ex_sorted = (vx[torch.tensor(pairs, dtype=torch.long)].sum(1) if pairs else None)
+            cx = lifting.ring_lift(n, bonds, vx, ex_sorted if pairs else None, max_k=6, include_down_adj=down, y=g['y'])
+            if init_rings and cx.dimension == 2:
+                rings = lifting.induced_cycles(n, bonds, 6)
+                cx.cochains[2].x = torch.stack([vx[list(r)].sum(0) for r in rings])
+            ref.append(cx)
+        want = PackedComplexes(ref, 'cpu', max_dim=2)
+        for threads in (1, 3):
+            got, dimension, feats = lifting.pack_graph_dataset_with_rings(
+                graphs, max_ring_size=6, include_down_adj=down, init_method='sum', init_edges=True,
+                init_rings=init_rings, n_threads=threads, device='cpu')
+            _same_packed(got, want)
+            assert dimension == 2 and feats[0] == 1
+        # the same dataset handed over the way a PyG InMemoryDataset stores itself (data + slices)
+        sl = dict(x=np.concatenate([[0], np.cumsum([g['num_nodes'] for g in graphs])]),
+                  edge_index=np.concatenate([[0], np.cumsum([g['edge_index'].size(1) for g in graphs])]),
+                  y=np.arange(len(graphs) + 1))
+        got, _, _ = lifting.pack_collated_dataset_with_rings(
+            torch.cat([g['x'] for g in graphs]), torch.cat([g['edge_index'] for g in graphs], dim=1),
+            torch.cat([g['edge_attr'] for g in graphs if g['edge_attr'] is not None]) if with_attr else None,
+            torch.cat([g['y'] for g in graphs]), sl, max_ring_size=6, include_down_adj=down, init_rings=init_rings,
+            n_threads=2, device='cpu')
+        _same_packed(got, want)
+    # vertex labels ride with the vertices (extract_labels, data/utils.py:158-174); no graph label then
+    gs = [_pyg_like(rng, *random_molecule(rng, 6, 20), y_kind='vertex')[0] for _ in range(5)]
+    p, _, _ = lifting.pack_graph_dataset_with_rings(gs, max_ring_size=6, device='cpu')
+    assert p.y is None and 'y' in p.keys[0] and int(p.keys[0]['y'].length.sum()) == int(p.n_cells[0].sum())
+    # the two directions of an edge must carry the same features (data/utils.py:468)
+    bad = _pyg_like(rng, 3, [(0, 1), (1, 2)])[0]
+    bad['edge_attr'][0] += 1
+    try:
+        lifting.pack_graph_dataset_with_rings([bad], device='cpu')
+    except ValueError:
+        pass
+    else:
+        raise AssertionError('asymmetric edge_attr accepted')
+    try:
+        lifting.pack_graph_dataset_with_rings([dict(x=torch.zeros(2, 1), edge_index=torch.tensor([[0], [5]]), num_nodes=2,
+                                                    edge_attr=None, y=None)], device='cpu')
+    except ValueError:
+        pass
+    else:
+        raise AssertionError('vertex out of range accepted')
+
+
+def test_dataset_clique_lift_packs_what_the_per_graph_lift_packs():
+    from cwn_amd import lifting
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.synthetic import preferential_attachment_graph
+    rng = np.random.default_rng(5)
+    graphs, ref = [], []
+    for i in range(12):
+        n = int(rng.integers(20, 90))
+        edges = preferential_attachment_graph(rng, n)
+        if isinstance(edges, tuple):
+            edges = edges[-1]
+        vx = torch.from_numpy(rng.integers(1, 5, size=(n, 2))).float()
+        und = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+        graphs.append(dict(x=vx, edge_index=torch.from_numpy(np.concatenate([und, und[:, ::-1]]).T.copy()), num_nodes=n,
+                           edge_attr=None, y=torch.tensor([i % 2])))
+        ref.append(lifting.clique_lift(n, edges, vx, init_method='sum', include_down_adj=True, y=torch.tensor([i % 2])))
+    got, dimension, feats = lifting.pack_graph_dataset_with_cliques(graphs, expansion_dim=2, include_down_adj=True,
+                                                                    n_threads=2, device='cpu')
+    _same_packed(got, PackedComplexes(ref, 'cpu', max_dim=2))
+    assert dimension == 2 and feats == [2, 2, 2]
