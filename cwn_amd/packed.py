@@ -240,3 +240,52 @@ class PackedComplexes:
         batch = ComplexBatch(*cochains, y=y, num_complexes=B, dimension=dimension)
         batch._collate_tables = tab     # keep the tables alive until the launch has consumed them
         return batch
+
+
+class PackedLoader:
+    """The reference's DataLoader (data/data_loading.py:84-111: `for batch in loader` of exp/train_utils.py:35)
+    over an HBM-resident packed dataset: every batch is one `collate(indices)` launch on the device, no worker
+    processes, no host collate.  `indices` selects a split (train / valid / test ids, data/datasets/dataset.py
+    get_idx_split); `shuffle` draws a new permutation per epoch from `seed + epoch` (every rank draws the same one);
+    with world > 1 rank r takes permutation entries r, r + world, ... of each GLOBAL batch -- the complexes of a
+    batch shard across the ranks (cwn_amd/dist.py), and every rank sees the same number of batches (the tail that
+    does not fill one complex per rank is dropped, as is an incomplete last batch with drop_last)."""
+
+    def __init__(self, packed: PackedComplexes, batch_size: int = 1, shuffle: bool = False,
+                 indices: Sequence[int] = None, drop_last: bool = False, seed: int = 0, rank: int = 0, world: int = 1):
+        if batch_size < 1 or world < 1 or not (0 <= rank < world):
+            raise ValueError('batch_size >= 1, world >= 1, 0 <= rank < world')
+        self.packed, self.batch_size, self.shuffle, self.drop_last = packed, int(batch_size), shuffle, drop_last
+        self.indices = np.arange(packed.num, dtype=np.int64) if indices is None else np.asarray(indices, dtype=np.int64)
+        if self.indices.size and (self.indices.min() < 0 or self.indices.max() >= packed.num):
+            raise IndexError('split index outside the dataset')
+        self.seed, self.rank, self.world = int(seed), int(rank), int(world)
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def batches(self) -> List[np.ndarray]:
+        """This rank's index lists for the current epoch."""
+        order = self.indices
+        if self.shuffle:
+            order = order[np.random.default_rng(self.seed + self.epoch).permutation(order.size)]
+        out = []
+        for lo in range(0, order.size, self.batch_size):
+            glob = order[lo:lo + self.batch_size]
+            if glob.size < self.batch_size and self.drop_last:
+                break
+            if glob.size < self.world:          # not one complex per rank: a rank would sit out a collective
+                break
+            out.append(glob[self.rank::self.world])
+        return out
+
+    def __len__(self) -> int:
+        n, b = self.indices.size, self.batch_size
+        full, tail = divmod(n, b)
+        return full + (1 if tail and not self.drop_last and tail >= self.world else 0) if b >= self.world else 0
+
+    def __iter__(self):
+        for idx in self.batches():
+            yield self.packed.collate(idx)
+        self.epoch += 1

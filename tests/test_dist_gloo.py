@@ -230,3 +230,43 @@ def test_two_rank_chunked_reduce_inside_the_backward():
         ref = w * bucket.flat if ref is None else ref + w * bucket.flat
         wsum += w
     torch.testing.assert_close(flat, ref / wsum, rtol=1e-6, atol=1e-7)
+
+
+def test_packed_loader_shards_every_global_batch_across_the_ranks():
+    """cwn_amd.packed.PackedLoader (the DataLoader of data/data_loading.py:84-111 over the packed dataset): the ranks
+    split each global batch, see the same number of batches, cover a split exactly once per epoch, and reshuffle
+    identically (seed + epoch) -- index logic only, the collate itself is a GPU test."""
+    import numpy as np
+    from cwn_amd.packed import PackedLoader
+
+    class Fake:
+        num = 103
+
+        def collate(self, idx):
+            return [int(i) for i in idx]
+    split = np.arange(3, 103, dtype=np.int64)[::-1].copy()                 # a 'train' split of 100 ids
+    for world in (1, 2, 4):
+        for bs, shuffle, drop in ((10, False, False), (16, True, True), (16, True, False), (7, False, False)):
+            loaders = [PackedLoader(Fake(), bs, shuffle, indices=split, drop_last=drop, seed=5, rank=r, world=world)
+                       for r in range(world)]
+            epochs = []
+            for _ in range(2):
+                per = [list(l) for l in loaders]
+                assert len({len(p) for p in per}) == 1 and all(len(p) == len(l) for p, l in zip(per, loaders))
+                # batch k of all ranks together = global batch k: disjoint, sizes within one of each other
+                for k in range(len(per[0])):
+                    parts = [p[k] for p in per]
+                    assert max(map(len, parts)) - min(map(len, parts)) <= 1 and sum(map(len, parts)) <= bs
+                seen = sorted(i for p in per for b in p for i in b)
+                assert len(seen) == len(set(seen)) and set(seen) <= set(split.tolist())
+                full = (100 // bs) * bs
+                assert len(seen) == (full if drop or (100 - full) < world else 100)
+                epochs.append(per)
+            assert (epochs[0] != epochs[1]) == shuffle                      # a new permutation per epoch
+            if not shuffle and world == 1:
+                assert epochs[0][0][0] == split[:bs].tolist()
+    with pytest.raises(IndexError):
+        PackedLoader(Fake(), 4, indices=[0, 103])
+    with pytest.raises(ValueError):
+        PackedLoader(Fake(), 4, rank=2, world=2)
+    assert len(PackedLoader(Fake(), 3, world=4)) == 0                       # a batch smaller than the world: nothing to shard
