@@ -71,6 +71,7 @@ class PackedComplexes:
             self.keys.append(per_key)
         ys = [cx.y for cx in complexes]
         self.y = self._pack(ys, 'y') if all(t is not None for t in ys) else None
+        self._finalise()
 
     @classmethod
     def from_arrays(cls, device, max_dim: int, dims, n_cells, has_cells, n_up, n_down, keys, y=None) -> 'PackedComplexes':
@@ -97,6 +98,7 @@ class PackedComplexes:
                     per_key[key] = self._packed(*keys[d][key], key)
             self.keys.append(per_key)
         self.y = self._packed(*y, 'y') if y is not None else None
+        self._finalise()
         return self
 
     def _packed(self, data: torch.Tensor, lengths, has, key) -> _Packed:
@@ -136,85 +138,107 @@ class PackedComplexes:
                        self._op(data, key))
 
     # --------------------------------------------------------------------------------------------
-    def collate(self, idx: Sequence[int]) -> ComplexBatch:
-        """The ComplexBatch of complexes `idx` (in that order), on the device."""
+    def _finalise(self) -> None:
+        """Per-complex metadata of every key stacked into matrices: a batch's tables are then a dozen numpy calls
+        in all (the first form made ~100 small ones, 150 us of host time per batch of 128 -- four propagate
+        steps)."""
+        D = self.max_dim + 1
+        self._klist = [(d, key, pk) for d in range(D) for key, pk in self.keys[d].items()]
+        if self.y is not None:
+            self._klist.append((-1, 'y', self.y))
+        # one row per complex: [cells, down, up] of every dimension, then length / start / has of every key -- a
+        # batch needs ONE gather of its rows
+        cols = [np.stack([self.n_cells, self.n_down, self.n_up], axis=1).reshape(3 * D, self.num)]
+        for f in ('length', 'start', 'has'):
+            cols += [np.asarray(getattr(pk, f), dtype=np.int64)[None] for _, _, pk in self._klist]
+        self._meta = np.ascontiguousarray(np.concatenate(cols, axis=0).T)                  # [num, 3D + 3K]
+
+    # add-table of a key inside a dimension's block of five offset rows (here, here, down, here, up), in rows
+    _ADD_ROW = {'upper_index': 0, 'lower_index': 0, 'shared_boundaries': 2, 'shared_coboundaries': 4, 'boundary_index': 2}
+
+    def _prepare(self, idx):
+        """Host half of collate: output tensors (uninitialised), ONE int64 array holding every segment table, and
+        the launch plan -- entries (packed or None, out, offset of dst_start [B + 1], offset of src_start [B] or None,
+        offset of the add rows or None, total elements per row)."""
         idx = np.asarray(idx, dtype=np.int64)
         B = int(idx.size)
+        if B == 0:
+            raise ValueError('collate of an empty index list')
         dimension = int(self.dims[idx].max())
         dev = self.device
-        tables: List[np.ndarray] = []
-        plan = []           # (packed, out tensor, table offsets (dst_start, src_start, add), out rows stride)
-        cur = 0
-
-        def table(arr):
-            nonlocal cur
-            off = cur
-            tables.append(np.ascontiguousarray(arr, dtype=np.int64).reshape(-1))
-            cur += tables[-1].size
-            return off
-
-        def excl(v):
-            return np.concatenate([[0], np.cumsum(v)[:-1]]).astype(np.int64)
-
-        cochains = []
-        for d in range(dimension + 1):
-            n_sel = self.n_cells[d, idx]
-            off_here, off_down, off_up = excl(n_sel), excl(self.n_down[d, idx]), excl(self.n_up[d, idx])
-            cb = CochainBatch(d)
+        D, K = self.max_dim + 1, len(self._klist)
+        m = self._meta[idx]                                               # [B, 3D + 3K]
+        cs = np.cumsum(m[:, :3 * D + K], axis=0)
+        # running cell offsets of data/complex.py:148-169, all dimensions at once: [D, (here, down, up), B]
+        cnt = np.ascontiguousarray(m[:, :3 * D].T).reshape(D, 3, B)
+        end = np.ascontiguousarray(cs[:, :3 * D].T).reshape(D, 3, B)
+        off = end - cnt
+        tot = end[:, :, -1].tolist()
+        dst = np.zeros((K, B + 1), dtype=np.int64)
+        dst[:, 1:] = cs[:, 3 * D:].T
+        totals = dst[:, -1].tolist()
+        present = m[:, 3 * D + 2 * K:].any(axis=0).tolist()
+        seg = np.concatenate([off[:, 0, :], end[:, 0, -1:]], axis=1)                   # [D, B + 1]: batch-vector segments
+        o_src = K * (B + 1)
+        o_off = o_src + K * B
+        o_seg = o_off + D * 5 * B
+        tables = np.concatenate([dst.reshape(-1), m[:, 3 * D + K:3 * D + 2 * K].T.reshape(-1),
+                                 off[:, (0, 0, 1, 0, 2), :].reshape(-1), seg.reshape(-1)])
+        plan = []
+        cochains = [CochainBatch(d) for d in range(dimension + 1)]
+        for cb in cochains:
+            cb.__slices__ = {}
+        y = None
+        for k, (d, key, pk) in enumerate(self._klist):
+            if d > dimension:
+                continue
+            total = totals[k]
+            if d < 0:                       # the complexes' labels
+                y = torch.empty(total, dtype=pk.data.dtype, device=dev)
+                plan.append((pk, y, k * (B + 1), o_src + k * B, None, total))
+                continue
+            if not present[k]:
+                continue
+            if key == 'x':
+                out = torch.empty(total // pk.width, pk.width, dtype=pk.data.dtype, device=dev)
+            elif pk.rows == 2:
+                out = torch.empty(2, total, dtype=pk.data.dtype, device=dev)
+            else:
+                out = torch.empty(total, dtype=pk.data.dtype, device=dev)
+            row = self._ADD_ROW.get(key)
+            plan.append((pk, out, k * (B + 1), o_src + k * B, None if row is None else o_off + (d * 5 + row) * B, total))
+            cb = cochains[d]
+            if key == 'x':
+                cb._x = out
+            else:
+                cb.__slices__[key] = dst[k].tolist()
+                setattr(cb, key, out)
+        for d, cb in enumerate(cochains):
+            n_sel = cnt[d, 0]
             # the per-complex tables the reference's collate keeps (data/complex.py:344-441): the blocked layer
             # kernel's item table is cut from them (cwn_amd/blockplan.py)
             cb.__num_cells_list__ = n_sel.tolist()
-            cb.__slices__ = {}
-            for key, pk in self.keys[d].items():
-                if not pk.has[idx].any():
-                    continue
-                lens = pk.length[idx]
-                total = int(lens.sum())
-                dst_start = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-                if key == 'x':
-                    out = torch.empty(total // pk.width, pk.width, dtype=pk.data.dtype, device=dev)
-                elif pk.rows == 2:
-                    out = torch.empty(2, total, dtype=pk.data.dtype, device=dev)
-                else:
-                    out = torch.empty(total, dtype=pk.data.dtype, device=dev)
-                add = None
-                if key in ('upper_index', 'lower_index'):
-                    add = np.stack([off_here, off_here])
-                elif key == 'shared_boundaries':
-                    add = off_down[None]
-                elif key == 'shared_coboundaries':
-                    add = off_up[None]
-                elif key == 'boundary_index':
-                    add = np.stack([off_down, off_here])
-                plan.append((pk, out, table(dst_start), table(pk.start[idx]),
-                             None if add is None else table(add), total))
-                if key != 'x':
-                    cb.__slices__[key] = dst_start.tolist()
-                if key == 'x':
-                    cb._x = out
-                else:
-                    setattr(cb, key, out)
-            # batch vector: complexes that have cells of this dimension, numbered by position
-            if self.has_cells[d, idx].any():
-                total = int(n_sel.sum())
-                out = torch.empty(total, dtype=torch.int64, device=dev)
-                plan.append((None, out, table(np.concatenate([[0], np.cumsum(n_sel)])), None, None, total))
+            has = self.has_cells[d, idx]
+            if has.any():
+                # batch vector: complexes that have cells of this dimension, numbered by position
+                out = torch.empty(tot[d][0], dtype=torch.int64, device=dev)
+                plan.append((None, out, o_seg + d * (B + 1), None, None, tot[d][0]))
                 cb.batch = out
-                cb.ptr = [0] + np.cumsum(n_sel[self.has_cells[d, idx]]).tolist()
-            cb.__num_cells__ = int(n_sel.sum())
-            cb.__num_cells_up__ = int(self.n_up[d, idx].sum())
+                cb.ptr = [0] + np.cumsum(n_sel[has]).tolist()
+            cb.__num_cells__ = tot[d][0]
+            cb.__num_cells_up__ = tot[d][2]
             if d > 0:
-                cb.__num_cells_down__ = int(self.n_down[d, idx].sum())
+                cb.__num_cells_down__ = tot[d][1]
             cb.__num_cochains__ = B
-            cochains.append(cb)
-        y = None
-        if self.y is not None:
-            lens = self.y.length[idx]
-            y = torch.empty(int(lens.sum()), dtype=self.y.data.dtype, device=dev)
-            plan.append((self.y, y, table(np.concatenate([[0], np.cumsum(lens)])), table(self.y.start[idx]),
-                         None, int(lens.sum())))
+        return cochains, y, tables, plan
+
+    def collate(self, idx: Sequence[int]) -> ComplexBatch:
+        """The ComplexBatch of complexes `idx` (in that order), on the device."""
+        cochains, y, tables, plan = self._prepare(idx)
+        B = cochains[0].__num_cochains__
+        dev = self.device
         # one H2D copy for every table, one launch for every array
-        tab = torch.from_numpy(np.concatenate(tables)).to(dev, non_blocking=True)
+        tab = torch.from_numpy(tables).to(dev, non_blocking=True)
         base = tab.data_ptr()
         descs = []
         for pk, out, o_dst, o_src, o_add, total in plan:
@@ -237,7 +261,7 @@ class PackedComplexes:
             arr = (_ffi.CollateDesc * len(chunk))(*chunk)
             _ffi.check(L.cwn_collate(arr, len(chunk), B, s), 'cwn_collate')
         tab.record_stream(torch.cuda.current_stream(dev))
-        batch = ComplexBatch(*cochains, y=y, num_complexes=B, dimension=dimension)
+        batch = ComplexBatch(*cochains, y=y, num_complexes=B, dimension=len(cochains) - 1)
         batch._collate_tables = tab     # keep the tables alive until the launch has consumed them
         return batch
 

@@ -502,3 +502,58 @@ def test_block_plan_covers_every_complex_once_and_fits_the_launch():
             # the rings ride as the second task of the edges' items, the same complexes
             rows = tab[t.set_start[1]:]
             assert int(rows[:, 18].sum()) == int(n2.sum())
+
+
+def test_collate_host_half_equals_its_first_form():
+    """PackedComplexes._prepare (all tables of a batch from stacked metadata, a dozen numpy calls) against the
+    first, per-key form kept in tests/_collate_ref.py: same output tensors, same descriptors, the same table
+    CONTENTS behind every descriptor, the same bookkeeping on the CochainBatch objects -- for mixed datasets
+    (complexes of dimension 0, 1, 2; with / without lower adjacencies; labels or none) and arbitrary index subsets
+    with repeats.  CPU-resident packed dataset: the launch itself is a GPU test."""
+    import numpy as np
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.synthetic import zinc_like_complexes, ring_lift
+    from tests import _collate_ref
+    from tests._product import dummy_complex, list_names
+    pools = {
+        'zinc': zinc_like_complexes(60, seed=3),
+        'zinc_down': zinc_like_complexes(30, seed=4, include_down_adj=True),
+        'dummies': [dummy_complex(n) for n in list_names('testing')],
+        'mixed_dims': [ring_lift(4, [], torch.zeros(4, 1), y=torch.tensor([1.0])),                       # dimension 0
+                       ring_lift(5, [(0, 1), (1, 2), (2, 3), (3, 4)], torch.ones(5, 1), torch.ones(4, 1), y=torch.tensor([2.0])),
+                       *zinc_like_complexes(6, seed=5)],
+    }
+    rng = np.random.default_rng(0)
+    for name, pool in pools.items():
+        p = PackedComplexes(pool, 'cpu', max_dim=2)
+        subsets = [list(range(len(pool))), [0], [len(pool) - 1, 0, 0]] + \
+                  [rng.integers(0, len(pool), size=int(rng.integers(1, 2 * len(pool)))).tolist() for _ in range(6)]
+        if name == 'mixed_dims':
+            subsets += [[0, 0], [1, 0], [0, 1, 0]]             # batches whose dimension is below the dataset's
+        for idx in subsets:
+            c_new, y_new, t_new, plan_new = p._prepare(idx)
+            c_old, y_old, t_old, plan_old = _collate_ref.prepare(p, idx)
+            B = len(idx)
+            assert len(c_new) == len(c_old) and (y_new is None) == (y_old is None)
+            if y_new is not None:
+                assert y_new.shape == y_old.shape and y_new.dtype == y_old.dtype
+
+            def content(plan, tables):
+                out = []
+                for pk, t, o_dst, o_src, o_add, total in plan:
+                    rows = 0 if pk is None else pk.rows
+                    out.append((id(pk), tuple(t.shape), t.dtype, total, tables[o_dst:o_dst + B + 1].tolist(),
+                                None if o_src is None else tables[o_src:o_src + B].tolist(),
+                                None if o_add is None else tables[o_add:o_add + rows * B].tolist()))
+                return sorted(out, key=lambda e: (e[0], e[1]))
+            assert content(plan_new, t_new) == content(plan_old, t_old), (name, idx)
+            for a, b in zip(c_new, c_old):
+                for attr in ('__num_cells_list__', '__slices__', '__num_cells__', '__num_cells_up__', '__num_cochains__', 'ptr'):
+                    assert getattr(a, attr, None) == getattr(b, attr, None), (name, attr)
+                assert getattr(a, '__num_cells_down__', None) == getattr(b, '__num_cells_down__', None)
+                for key in ('x', 'upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries', 'boundary_index', 'batch'):
+                    ta, tb = a[key] if key != 'x' else a._x, b[key] if key != 'x' else b._x
+                    assert (ta is None) == (tb is None), (name, key)
+                    assert ta is None or (ta.shape == tb.shape and ta.dtype == tb.dtype), (name, key)
+    with pytest.raises(ValueError):
+        p._prepare([])
