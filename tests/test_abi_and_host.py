@@ -523,9 +523,15 @@ def test_collate_host_half_equals_its_first_form():
                        ring_lift(5, [(0, 1), (1, 2), (2, 3), (3, 4)], torch.ones(5, 1), torch.ones(4, 1), y=torch.tensor([2.0])),
                        *zinc_like_complexes(6, seed=5)],
     }
+    # the five lists (and their max_dim) of the reference's batching tests, the ones the GPU layout test collates
+    g = load('batching.npz')
+    dims = {}
+    for lname in ('testing', 'testing3', 'mol', 'pair', 'nodes_only'):
+        pools['golden_' + lname] = [dummy_complex(str(n)) for n in g[f'{lname}/names']]
+        dims['golden_' + lname] = int(g[f'{lname}/max_dim'])
     rng = np.random.default_rng(0)
     for name, pool in pools.items():
-        p = PackedComplexes(pool, 'cpu', max_dim=2)
+        p = PackedComplexes(pool, 'cpu', max_dim=dims.get(name, 2))
         subsets = [list(range(len(pool))), [0], [len(pool) - 1, 0, 0]] + \
                   [rng.integers(0, len(pool), size=int(rng.integers(1, 2 * len(pool)))).tolist() for _ in range(6)]
         if name == 'mixed_dims':
@@ -557,3 +563,65 @@ def test_collate_host_half_equals_its_first_form():
                     assert ta is None or (ta.shape == tb.shape and ta.dtype == tb.dtype), (name, key)
     with pytest.raises(ValueError):
         p._prepare([])
+
+
+def _interpret_collate(plan, tables, B):
+    """What csrc/cwn_collate.hip::collate_kernel does with the descriptors PackedComplexes.collate makes of `plan`,
+    on the CPU: per descriptor and segment s, dst[r, d0:d0+len] = src[r, s0:s0+len] (+ add[r * B + s] for index
+    arrays), or = s for a batch vector."""
+    for pk, out, o_dst, o_src, o_add, total in plan:
+        if total == 0:
+            continue
+        dst_start = tables[o_dst:o_dst + B + 1]
+        flat = out.view(-1)
+        if pk is None:
+            for s in range(B):
+                flat[dst_start[s]:dst_start[s + 1]] = s
+            continue
+        src_start = tables[o_src:o_src + B]
+        src = pk.data.view(-1)
+        s_stride = pk.data.size(-1) if pk.rows == 2 else 0
+        d_stride = total if pk.rows == 2 else 0
+        add64 = pk.op == _ffi.COLLATE_ADD64
+        assert not add64 or o_add is not None          # cwn_collate rejects ADD64 without an add table
+        for s in range(B):
+            d0, n = int(dst_start[s]), int(dst_start[s + 1] - dst_start[s])
+            for r in range(pk.rows):
+                a = int(tables[o_add + r * B + s]) if add64 else 0
+                seg = src[r * s_stride + int(src_start[s]): r * s_stride + int(src_start[s]) + n]
+                flat[r * d_stride + d0: r * d_stride + d0 + n] = seg + a if add64 else seg
+
+
+def test_device_collate_descriptors_reproduce_the_reference_layout_on_the_cpu():
+    """The whole device collate minus the launch: PackedComplexes._prepare's descriptors, executed by a CPU
+    restatement of collate_kernel, must give the batch `ComplexBatch.from_complex_list` gives (itself pinned on the
+    reference's batching fixtures) -- index arrays with their per-complex offsets, features, batch vectors, labels."""
+    import numpy as np
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.synthetic import zinc_like_complexes
+    g = load('batching.npz')
+    pools = {'zinc': (zinc_like_complexes(40, seed=11, include_down_adj=True), 2)}
+    for lname in ('testing', 'testing3', 'mol', 'pair', 'nodes_only'):
+        pools[lname] = ([dummy_complex(str(n)) for n in g[f'{lname}/names']], int(g[f'{lname}/max_dim']))
+    rng = np.random.default_rng(3)
+    for name, (pool, md) in pools.items():
+        p = PackedComplexes(pool, 'cpu', max_dim=md)
+        for idx in [list(range(len(pool)))] + [rng.permutation(len(pool))[:max(1, len(pool) // 2)].tolist() for _ in range(3)]:
+            cochains, y, tables, plan = p._prepare(idx)
+            _interpret_collate(plan, tables, len(idx))
+            ref = ComplexBatch.from_complex_list([pool[i] for i in idx], max_dim=md)
+            assert len(cochains) == ref.dimension + 1, name
+            assert (y is None) == (ref.y is None) and (y is None or torch.equal(y.view(-1), ref.y.view(-1).to(y.dtype)))
+            for d, cb in enumerate(cochains):
+                rc = ref.cochains[d]
+                for key in ('upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries', 'boundary_index', 'batch'):
+                    a, b = cb[key], rc[key]
+                    assert (a is None) == (b is None), (name, d, key)
+                    assert a is None or torch.equal(a, b), (name, d, key)
+                assert (cb._x is None) == (rc.x is None) and (cb._x is None or torch.equal(cb._x, rc.x)), (name, d)
+                assert cb.num_cells == rc.num_cells
+                for key, sl in cb.__slices__.items():          # per-complex entry offsets: what the item table is cut from
+                    assert key not in rc.__slices__ or sl == rc.__slices__[key], (name, d, key)
+                yv, ry = cb['y'], rc['y']
+                assert (yv is None) == (ry is None) and (yv is None or torch.equal(yv.view(-1), ry.view(-1))), (name, d)
