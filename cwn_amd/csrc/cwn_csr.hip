@@ -15,6 +15,7 @@
 // Integer work, latency- rather than bandwidth-bound at REDDIT-like sizes (a few MB): what
 // matters is the number of DEPENDENT memory round trips (~0.9 us each) per kernel and keeping
 // every wave access coalesced; see the notes at ScanChunk, count_kernel and emit_kernel.
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "../../include/cwn_hip.h"
@@ -555,14 +556,13 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
         if (need > small_bytes) small_bytes = need;
     }
     if (small_bytes <= kSmallLdsBytes) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)csr_small_kernel,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)kSmallLdsBytes) != hipSuccess)
-                return CWN_ERR_LAUNCH;
-            attr_set = true;
-        }
+        static std::once_flag attr_once;        // thread-safe, once per process (the library keeps no other state)
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(attr_once, [] {
+            attr_err = hipFuncSetAttribute((const void*)csr_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kSmallLdsBytes);
+        });
+        if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
         SmallBatch S{};
         S.n = n;
         int blocks = 0;
