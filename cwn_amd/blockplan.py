@@ -141,7 +141,7 @@ class BlockPlan:
                 d += 1
         return sets
 
-    def at_least(self, F: int, has_up: Sequence[bool]) -> int:
+    def at_least(self, F: int, has_up: Sequence[bool], has_b: Optional[Sequence[bool]] = None) -> int:
         """A lower bound of the number of items (staged rows of all complexes / the row cap, per set), in O(1):
         lets a caller with an item limit skip building the table of a very large batch."""
         cap = gemm_rows_cap(F)
@@ -151,16 +151,22 @@ class BlockPlan:
             n += max(1, -(-rows // cap)) if self.C else 0
         return n
 
-    def items(self, F: int, has_up: Sequence[bool]) -> Optional[ItemTable]:
+    def items(self, F: int, has_up: Sequence[bool], has_b: Optional[Sequence[bool]] = None) -> Optional[ItemTable]:
         """The item table for feature width F, or None when some complex does not fit one
         workgroup's LDS (hub complexes: the caller then runs the CSR path).  `has_up[d]`: dimension d
-        reduces an upper adjacency with coboundary features (needs d + 1 < n_dims)."""
-        key = (F, tuple(bool(h) for h in has_up))
+        reduces an upper adjacency with coboundary features (needs d + 1 < n_dims).  `has_b[d]`: the
+        layer runs the boundary stream of dimension d (default: wherever the batch has a
+        boundary_index) -- a layer without it (use_boundary_msg=False, include_boundary_features=False)
+        gets a table whose records carry no boundary entries, so the launcher is never handed entry
+        ranges of an index it was not given."""
+        if has_b is None:
+            has_b = [p is not None for p in self.b_ptr]
+        key = (F, tuple(bool(h) for h in has_up), tuple(bool(h) and self.b_ptr[d] is not None for d, h in enumerate(has_b)))
         if key not in self._tables:
-            self._tables[key] = self._build(F, key[1])
+            self._tables[key] = self._build(F, key[1], key[2])
         return self._tables[key]
 
-    def _build(self, F: int, has_up) -> Optional[ItemTable]:
+    def _build(self, F: int, has_up, has_b) -> Optional[ItemTable]:
         """cwn_layer_items_build (csrc/cwn_blockplan.cpp, host C++): the greedy cut under the kernel's caps and
         the split of one launch's LDS between staged rows and boundary sources that gives the fewest items.  (A
         Python version of the same took 11 ms for a ZINC-like batch of 128 -- tests/_blockplan_ref.py keeps it as
@@ -176,7 +182,8 @@ class BlockPlan:
         keep = []
         for d in range(self.n_dims):
             sizes.has_up[d] = 1 if has_up[d] else 0
-            for name, arr in (('cell_ptr', self.cell_ptr[d]), ('up_ptr', self.up_ptr[d]), ('b_ptr', self.b_ptr[d])):
+            for name, arr in (('cell_ptr', self.cell_ptr[d]), ('up_ptr', self.up_ptr[d]),
+                              ('b_ptr', self.b_ptr[d] if has_b[d] else None)):
                 if arr is not None:
                     a = np.ascontiguousarray(arr, dtype=np.int64)
                     keep.append(a)

@@ -355,9 +355,11 @@ class Complex(object):
         them): what a training loop does when a batch object is refilled, without touching the
         plans of other batches."""
         from . import csr
-        bp = getattr(self, '_block_plan', None)
-        if bp is not None and bp[1] is not None:
-            bp[1].forget_csr()
+        # the per-complex tables are cut from THESE index tensors (`__slices__` / `ptr`): a refilled batch
+        # gets a fresh plan, re-validated against its entries on the next launch (ADVICE r2: a stale table
+        # would have the kernel drop entries outside their complex without any host-side error)
+        if getattr(self, '_block_plan', None) is not None:
+            self._block_plan = None
         for c in self.cochains.values():
             for index in (c.upper_index, c.lower_index, c.boundary_index):
                 if index is not None:

@@ -544,6 +544,9 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
                                 D.perm == nullptr))
             return CWN_ERR_BAD_ARG;
         if (D.aux != nullptr && D.aux_out == nullptr) return CWN_ERR_BAD_ARG;
+        // entries that name rows of an EMPTY source (or shared-cell) matrix cannot be clamped into it: refused here,
+        // so that "reported and clamped: no consumer can fault" holds for every plan this call produces
+        if (D.n_entries > 0 && (D.n_val <= 0 || (D.aux != nullptr && D.n_aux <= 0))) return CWN_ERR_BAD_ARG;
         if (D.n_entries >= INT32_MAX || D.n_dst >= INT32_MAX || D.n_val >= INT32_MAX ||
             D.n_aux >= INT32_MAX)
             return CWN_ERR_TOO_LARGE;

@@ -191,9 +191,11 @@ class StagedBackward:
     two cuts, each once (backward(inputs=non-leaf) would also execute the producer of the cut tensor, and run
     it a second time in the next piece).
 
-    A cut is valid when every path from the loss to an earlier parameter passes through the cut tensors (a
-    layered network without skip connections around whole layers; jumping knowledge is fine, it consumes the
-    layer outputs).  `stages()` checks that on the autograd graph and returns the stage of every parameter."""
+    A cut is valid when every path from the loss to an earlier parameter passes through the cut tensors: a
+    layered network without skip connections around whole layers.  Jumping knowledge is NOT such a network --
+    the loss reads every layer's output directly, so a layer's parameters are reached in two pieces -- and
+    `stages()` returns None for it (the caller keeps the one-collective step and says so, train.py).
+    `stages()` checks validity on the autograd graph and returns the stage of every parameter."""
 
     def __init__(self, cut_modules: Sequence[torch.nn.Module]):
         self.cut_modules = list(cut_modules)

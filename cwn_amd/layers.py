@@ -729,10 +729,11 @@ class SparseCINConv(torch.nn.Module):
                 D.b_index = b_index
             dims.append(D)
             has_up.append(bool(up))
-        if plan.at_least(F, has_up) > BLOCKED_MAX_ITEMS:
+        has_b = [D.b_index is not None for D in dims]
+        if plan.at_least(F, has_up, has_b) > BLOCKED_MAX_ITEMS:
             return f'more than {BLOCKED_MAX_ITEMS} items: beyond the range where one workgroup per item beats the streaming CSR path'
-        table = plan.items(F, has_up)
-        if table is None:
+        table = plan.items(F, has_up, has_b)     # keyed on the streams THIS layer runs (a layer without
+        if table is None:                        # the boundary stream must not get records that carry boundary entries)
             return 'a complex does not fit one workgroup (row / entry caps)'
         if table.n_items > BLOCKED_MAX_ITEMS:
             return f'{table.n_items} items: beyond the range where one workgroup per item beats the streaming CSR path'

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _ffi, ops
-from .blockplan import ITEM_INTS, ItemTable, gemm_rows_cap
+from .blockplan import ITEM_INTS, LDS_BYTES, ItemTable, gemm_rows_cap, lds_bytes
 from .complex import ComplexBatch
 
 CAPTURE_MODE = 'thread_local'
@@ -41,8 +41,14 @@ class StaticPropagate:
         n_items = sum(self.cap_items)
         self.items = torch.zeros(n_items, ITEM_INTS, dtype=torch.int32, device=dev)
         self.set_start = [0, self.cap_items[0]]
+        # one launch = one LDS size for every batch this graph will serve: the full row cap, and for the boundary
+        # sources what is left of the 160 KiB (F = 64: 256 staged rows leave room for ~170 source rows, not 256 --
+        # the first form asked for 186 KB and failed at the first replay)
         cap = gemm_rows_cap(F)
-        self.table = ItemTable(np.zeros((n_items, ITEM_INTS), dtype=np.int32), self.set_start, cap, cap,
+        src_cap = min(cap, (LDS_BYTES - lds_bytes(F, cap, 0)) // (F * 4))
+        if src_cap < 16 or _ffi.lib().cwn_layer_fused_lds_bytes(F, cap, src_cap) == 0:
+            raise ValueError(f'StaticPropagate: no LDS split for feature width {F}')
+        self.table = ItemTable(np.zeros((n_items, ITEM_INTS), dtype=np.int32), self.set_start, cap, src_cap,
                                list(self.cap_cells), list(self.cap_up) + [0], [0] + list(self.cap_b), dev)
         self.table.items = self.items          # the launch reads THIS buffer; `load` rewrites it
         self.launches: List[ops.LayerLaunch] = []
@@ -75,6 +81,9 @@ class StaticPropagate:
         table = plan.items(self.F, [True, True, False]) if plan is not None else None
         if table is None:
             raise ValueError('the batch has no item table for this feature width (hub complexes?)')
+        if table.max_rows > self.table.max_rows or table.max_src > self.table.max_src:
+            raise ValueError(f'an item of this batch needs {table.max_rows} staged / {table.max_src} source rows; the '
+                             f'captured launch holds {self.table.max_rows} / {self.table.max_src}')
         cnt = [table.set_start[1], table.n_items - table.set_start[1]]
         if any(c > cap for c, cap in zip(cnt, self.cap_items)):
             raise ValueError(f'items per set {cnt} exceed the capacity {self.cap_items}')

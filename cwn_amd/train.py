@@ -127,6 +127,10 @@ class TrainStep:
             self.staged = StagedBackward([convs[k] for k in ks])
             stage_of = self._probe_stages(convs, ks)
             if stage_of is None:
+                import warnings
+                warnings.warn('TrainStep: the backward cannot be cut behind the message-passing layers (jumping '
+                              'knowledge / a skip connection around layers): the gradient all-reduce runs as ONE '
+                              'collective after the backward, without overlap')
                 self.staged.remove()
                 self.staged = None
         self.n_stages = self.staged.n_stages if self.staged is not None else 1
@@ -180,6 +184,10 @@ class TrainStep:
         and stage 0, reduced last, when no batch of any rank reaches it."""
         params = [p for p in self.model.parameters() if p.requires_grad]
         keep = [t.detach().clone() for t in self.model.buffers()]
+        # the probe forwards run in training mode: the dropout masks they draw must not move the caller's
+        # random stream (ADVICE r2) -- the generator states are put back like the buffers
+        rng_cpu = torch.get_rng_state()
+        rng_dev = torch.cuda.get_rng_state(params[0].device) if params and params[0].is_cuda else None
         reached, ok = {}, True
         for i in range(len(self.batches)):
             self.staged.begin()
@@ -195,6 +203,9 @@ class TrainStep:
         with torch.no_grad():
             for t, old in zip(self.model.buffers(), keep):
                 t.copy_(old)
+        torch.set_rng_state(rng_cpu)
+        if rng_dev is not None:
+            torch.cuda.set_rng_state(rng_dev, params[0].device)
         for k, conv in enumerate(convs):
             st = sum(1 for c in ks if c < k)
             ok = ok and all(reached.setdefault(id(p), st) == st for p in conv.parameters() if p.requires_grad)

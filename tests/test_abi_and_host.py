@@ -437,6 +437,35 @@ def test_item_table_derived_fields_and_host_check():
         assert L.cwn_layer_items_check(empty.ctypes.data, 3, F, cplan) == 0
 
 
+def test_item_table_is_keyed_on_the_boundary_streams_the_layer_runs():
+    """a layer that does not run the boundary stream of a dimension (use_boundary_msg=False,
+    get_all_cochain_params(include_boundary_features=False)) hands the launcher no boundary_index for it, so its
+    table may not carry boundary entries for it: `has_b` is part of the table key, and the records / the plan
+    summary of a dimension that is off name no entry of its index."""
+    import numpy as np
+    from cwn_amd import _ffi
+    from cwn_amd.blockplan import BlockPlan
+    from cwn_amd.synthetic import zinc_like_batch
+    L = _ffi.lib()
+    plan = BlockPlan.from_batch(zinc_like_batch(24, seed=5))
+    for F in (64, 128):
+        full = plan.items(F, [True, True, False])
+        assert plan.items(F, [True, True, False], [False, True, True]) is full         # dim 0 never has one
+        assert full.b_end[1] > 0 and full.b_end[2] > 0
+        for has_b in ([False, False, False], [False, True, False], [False, False, True]):
+            t = plan.items(F, [True, True, False], has_b)
+            assert t is not full and plan.items(F, [True, True, False], has_b) is t  # cached under its own key
+            tab = t.items.numpy()
+            assert L.cwn_layer_items_check(tab.ctypes.data, tab.shape[0], F, t.c_plan(False)) == 0
+            for d in (1, 2):
+                recs = [(r, o) for r in tab for o in (9, 16) if r[8] > (o - 9) // 7 and r[o] == d]
+                assert recs
+                if has_b[d]:
+                    assert t.b_end[d] == full.b_end[d] and sum(int(r[o + 4]) for r, o in recs) == full.b_end[d]
+                else:
+                    assert t.b_end[d] == 0 and all(r[o + 4] == 0 and r[o + 6] == 0 for r, o in recs)
+
+
 def test_block_plan_covers_every_complex_once_and_fits_the_launch():
     """cwn_amd/blockplan.py on random per-complex size tables (no tensors, no GPU): the items of a set are
     contiguous ranges of complexes that cover the batch exactly once, every item respects the caps, ONE LDS

@@ -419,3 +419,62 @@ def test_blocked_layer_random_structures_vs_oracle(seed):
             assert torch.equal(cpu(outs[2 * d]), ref[d][0]), (seed, d, 'up')
             assert torch.equal(cpu(outs[2 * d + 1]), ref[d][1]), (seed, d, 'boundary')
     assert conv.blocked_reason is None
+
+
+@pytest.mark.parametrize('off', ['params', 'level'])
+def test_blocked_layer_without_the_boundary_stream(off):
+    """a legal reference configuration -- get_all_cochain_params(include_boundary_features=False), or a
+    level built with use_boundary_msg=False -- runs the blocked kernel with a table that carries no boundary
+    entries (it used to raise CWN_ERR_BAD_ARG from the launcher), bit-identical to the CSR path; out_b is the
+    self term alone (mp/cell_mp.py:380-382, :517-522)."""
+    from cwn_amd import csr, layers
+    b = _batch('zinc', 40, 128, seed=11)
+    conv = _conv(128, seed=12, eps=0.125)
+    if off == 'level':
+        for lvl in conv.mp_levels:
+            lvl.use_boundary_msg = False
+    kw = dict(max_dim=2, include_down_features=False, include_boundary_features=(off != 'params'))
+    res = {}
+    for blocked in (True, False):
+        prev, layers.BLOCKED_LAYER = layers.BLOCKED_LAYER, blocked
+        try:
+            csr._cache.clear()
+            with torch.no_grad():
+                plans, outs = conv.propagate_all(*b.get_all_cochain_params(**kw))
+            assert (plans[0] == 'blocked') == blocked, conv.blocked_reason
+        finally:
+            layers.BLOCKED_LAYER = prev
+        res[blocked] = outs
+    for i, (f, p) in enumerate(zip(res[True], res[False])):
+        assert torch.equal(f, p), (i, (f - p).abs().max().item())
+    for d in range(3):
+        x = b.cochains[d].x
+        assert torch.equal(res[True][2 * d + 1], (1 + float(conv.mp_levels[d].eps2)) * x)
+
+
+def test_forget_plans_drops_the_block_plan():
+    """a batch object refilled with new index tensors gets a fresh per-complex table (validated again)."""
+    b = _batch('zinc', 8, 128, seed=13)
+    p0 = b.block_plan()
+    p0.validated = True
+    b.forget_plans()
+    p1 = b.block_plan()
+    assert p1 is not p0 and not p1.validated
+
+
+def test_static_graph_at_width_64():
+    """StaticPropagate at F = 64 (it asked for 186 KB of LDS and failed at the first replay): one graph
+    over two batches, bit-identical to per-batch launches."""
+    from cwn_amd.static_graph import StaticPropagate
+    F = 64
+    conv = _conv(F, seed=21, eps=0.5)
+    bs = [_batch('zinc', n, F, seed=22 + n) for n in (40, 25)]
+    caps = [max(b.cochains[d].num_cells for b in bs) + 8 for d in range(3)]
+    sp = StaticPropagate([conv], F, caps, [max(b.cochains[d].upper_index.size(1) for b in bs) + 8 for d in range(2)],
+                         [max(b.cochains[d].boundary_index.size(1) for b in bs) + 8 for d in (1, 2)], [48, 48], DEV)
+    for b in bs:
+        sp.load(b, [[b.cochains[d].x for d in range(3)]])
+        got = sp.replay()[0]
+        want = _run(conv, b, blocked=True)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert torch.equal(g, w), (i, (g - w).abs().max().item())
