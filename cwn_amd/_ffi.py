@@ -16,12 +16,12 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
-           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
+           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
 
 
@@ -89,6 +89,18 @@ class MlpDim(C.Structure):
     _fields_ = [('x_up', C.c_void_p), ('x_b', C.c_void_p), ('w_packed', C.c_void_p * 6),
                 ('bias', C.c_void_p * 5), ('scale', C.c_void_p * 5), ('shift', C.c_void_p * 5),
                 ('y', C.c_void_p), ('M', C.c_int64), ('ldx_up', C.c_int64), ('ldx_b', C.c_int64), ('ldy', C.c_int64)]
+
+
+class EmbedTable(C.Structure):
+    """cwn_embed_table (include/cwn_hip.h)."""
+    _fields_ = [('W', C.c_void_p), ('src', C.c_void_p), ('col_off', C.c_void_p), ('col_size', C.c_void_p),
+                ('V', C.c_int64), ('cols', C.c_int32), ('src_is_f32', C.c_int32)]
+
+
+class HeadDim(C.Structure):
+    """cwn_head_dim (include/cwn_hip.h)."""
+    _fields_ = [('x', C.c_void_p), ('cell_ptr', C.c_void_p), ('w1t', C.c_void_p), ('b1', C.c_void_p),
+                ('pooled_out', C.c_void_p), ('n_cells', C.c_int64), ('ldx', C.c_int64)]
 
 
 ERR_BIT_BLOCK = 8         # = CWN_ERR_BIT_BLOCK
@@ -209,6 +221,13 @@ def lib():
     L.cwn_embedding_bwd_f32.restype = C.c_int
     L.cwn_embedding_bwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    L.cwn_embed_front_f32.restype = C.c_int
+    L.cwn_embed_front_f32.argtypes = [C.POINTER(EmbedTable), C.c_int64, C.c_void_p, C.POINTER(EmbedTable), C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.cwn_head_f32.restype = C.c_int
+    L.cwn_head_f32.argtypes = [C.POINTER(HeadDim), C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_lift_create.restype = C.c_void_p
     L.cwn_lift_create.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
     L.cwn_lift_size.restype = C.c_int64

@@ -116,6 +116,15 @@ class BlockPlan:
         dev = next((c.upper_index.device for c in batch.cochains.values() if c.upper_index is not None), None)
         return cls(cells, up_ptr, b_ptr, device=dev)
 
+    def cell_ptr_device(self, d: int, device) -> torch.Tensor:
+        """`ptr` of dimension d (data/complex.py:344, 432: cells of complex c = rows ptr[c] .. ptr[c+1]) as a device
+        int64 tensor, uploaded once per batch (the fused head reads it: cwn_head_f32)."""
+        cache = self.__dict__.setdefault('_cell_ptr_dev', {})
+        key = (d, str(device))
+        if key not in cache:
+            cache[key] = torch.from_numpy(np.ascontiguousarray(self.cell_ptr[d], dtype=np.int64)).to(device)
+        return cache[key]
+
     def forget_csr(self) -> None:
         """Drop the cached per-item CSRs (the index tensors changed, or a caller wants a step that
         starts from the COO entries again)."""

@@ -1,0 +1,383 @@
+// cwn_ends.hip -- the two ends of a model forward around the message-passing layers, one launch each (inference).
+//
+// FRONT  cwn_embed_front_f32: the input features of all three cochain dimensions
+//     x0[v] = sum_c Tv_c[ids0[v, c]]                                 v_embed_init / OGB AtomEncoder
+//     x1[e] = sum_c Te_c[ids1[e, c]]      (or red1[e] without an edge table)   e_embed_init / BondEncoder
+//     x2[r] = 1/2 sum_{e in boundary(r)} red1[e],   red1[e] = sum_{v in boundary(e)} x0[v]
+//   = EmbedVEWithReduce.forward / OGBEmbedVEWithReduce.forward (mp/layers.py:490-593: embed, InitReduceConv of the
+//   vertex embeddings onto the edges :526, InitReduceConv of THAT onto the rings, halved :538-540; InitReduceConv
+//   itself :473-487).  The library ran this as 8 launches (two embedding gathers, two dtype conversions, two
+//   segmented reductions, a copy, a scale): 29 us of a 167 us forward at the ZINC batch of 128, every one of them a
+//   few microseconds of latency for a few hundred kilobytes.  Here a ring row walks its boundary edges and their
+//   boundary vertices itself (a ring has ~6 edges x 2 vertices: twelve table rows out of L2), in CSR order -- the
+//   order the segmented reduction adds them in, so the result is bit-identical to the launches it replaces.
+//
+// HEAD   cwn_head_f32: readout + lin1s + final readout + lin2 (mp/nn.py:50-60, mp/molec_models.py:129-156 /
+//   mp/models.py:222-253), one workgroup per complex:
+//     pooled_d[c] = sum (or mean) of the rows of x_d that belong to complex c        pool_complex
+//     h_d = relu(W1_d pooled_d + b1_d);  s = sum_d h_d (or mean);  out[c] = W2 s + b2
+//   The library ran this as one segmented-reduce launch, one grouped GEMM, two adds and a 256 -> 1 GEMM that alone
+//   took 19.9 us (two workgroups walking K = 256): 43 us of the 167.  The cells of a complex are contiguous in every
+//   x_d (data/complex.py:148-169; `ptr`, :344, 432), so a workgroup sums its complex's rows with coalesced loads and
+//   keeps everything after that in LDS; the weights (lin1s transposed once per weight version: [K, H2], coalesced
+//   over the outputs) come out of L2.  fp32 FMA chains in a fixed order: deterministic, and a complex's result does
+//   not depend on what else is in the batch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cwn_hip.h"
+#include "cwn_mem.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// front
+// ---------------------------------------------------------------------------------------------------------------
+struct FrontArgs {
+    cwn_embed_table tv, te;
+    float* x0; float* x1; float* x2;
+    const int32_t* rowptr1; const int32_t* col1;
+    const int32_t* rowptr2; const int32_t* col2;
+    int64_t n0, n1, n2;
+    int32_t H, G, has_te, halve;
+    int32_t* err;
+};
+
+// sum over the index columns of one row of a table set, 4 features at h.  An index outside its own table sets
+// bit 1 of the sticky word and contributes nothing (as cwn_embedding_fwd_f32).
+__device__ __forceinline__ float4 emb_row(const cwn_embed_table& T, int64_t r, int H, int h, int32_t* err) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < T.cols; ++c) {
+        int64_t v;
+        if (T.src_is_f32) v = (int64_t)reinterpret_cast<const float*>(T.src)[r * T.cols + c];     // .to(torch.long): truncation
+        else v = reinterpret_cast<const int64_t*>(T.src)[r * T.cols + c];
+        const int64_t lim = T.col_size != nullptr ? T.col_size[c] : T.V;
+        if (v < 0 || v >= lim) {
+            if (h == 0) atomicOr(err, 2);
+            continue;
+        }
+        if (T.col_off != nullptr) v += T.col_off[c];
+        const float4 w = *reinterpret_cast<const float4*>(T.W + v * H + h);
+        acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+    }
+    return acc;
+}
+
+// red1[e] = sum of the embedded boundary vertices of edge e, in CSR order
+__device__ __forceinline__ float4 reduce_edge(const FrontArgs& A, int64_t e, int h) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (A.rowptr1 == nullptr) return acc;
+    const int s = A.rowptr1[e], t = A.rowptr1[e + 1];
+    for (int p = s; p < t; ++p) {
+        int64_t v = A.col1[p];
+        v = v < 0 ? 0 : (v >= A.n0 ? A.n0 - 1 : v);          // the plan build reported it; never fault
+        const float4 w = emb_row(A.tv, v, A.H, h, A.err);
+        acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+    }
+    return acc;
+}
+
+// The same sums for up to kChunk boundary edges of a ring AT ONCE.  A ring row is a chain of six dependent loads
+// (rowptr2 -> col2 -> rowptr1 -> col1 -> integer feature -> table row); walked edge by edge and vertex by vertex a
+// hexagon was 42 round trips to L2 (12 us for a launch that moves 3 MB).  Here every level is issued for all edges
+// of the chunk before the next level needs it, and only the ADDS run in CSR order (the result is bit-identical to the
+// sequential walk).  An edge has two boundary vertices; further ones (any other CSR1) take the sequential tail.
+constexpr int kChunk = 8;
+
+__device__ __forceinline__ int64_t clampi(int64_t v, int64_t n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+
+__device__ __forceinline__ float4 ring_chunk(const FrontArgs& A, int p0, int n, int h, float4 acc) {
+    const bool one_col = A.tv.cols == 1;
+    int64_t e[kChunk];
+    int s1[kChunk], t1[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) e[u] = clampi(A.col2[p0 + (u < n ? u : 0)], A.n1);
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) { s1[u] = A.rowptr1[e[u]]; t1[u] = A.rowptr1[e[u] + 1]; }
+    if (one_col) {
+        // one table (ZINC): vertex numbers, integer features and table rows of both endpoints of every edge, level by level
+        int64_t v[kChunk][2], id[kChunk][2];
+        float4 w[kChunk][2];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) v[u][q] = clampi(A.col1[s1[u] + q < t1[u] ? s1[u] + q : (t1[u] > s1[u] ? t1[u] - 1 : 0)], A.n0);
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                id[u][q] = A.tv.src_is_f32 ? (int64_t)reinterpret_cast<const float*>(A.tv.src)[v[u][q]]
+                                           : reinterpret_cast<const int64_t*>(A.tv.src)[v[u][q]];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool ok = id[u][q] >= 0 && id[u][q] < A.tv.V;
+                if (!ok && h == 0 && u < n && s1[u] + q < t1[u]) atomicOr(A.err, 2);
+                w[u][q] = *reinterpret_cast<const float4*>(A.tv.W + (ok ? id[u][q] : 0) * A.H + h);
+                if (!ok) w[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            if (u >= n) break;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (s1[u] + q < t1[u]) { r.x += w[u][q].x; r.y += w[u][q].y; r.z += w[u][q].z; r.w += w[u][q].w; }
+            for (int p = s1[u] + 2; p < t1[u]; ++p) {                   // not a 1-cell's boundary: the plain walk
+                const float4 x = emb_row(A.tv, clampi(A.col1[p], A.n0), A.H, h, A.err);
+                r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
+            }
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+    } else {
+        for (int u = 0; u < n; ++u) {                                   // several tables per vertex (OGB): edge by edge
+            const float4 r = reduce_edge(A, e[u], h);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void embed_front_kernel(FrontArgs A) {
+    const int G = A.G, gl = threadIdx.x & (G - 1);
+    const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    if (row >= A.n0 + A.n1 + A.n2) return;
+    for (int h = 4 * gl; h < A.H; h += 4 * G) {
+        float4 v;
+        float* dst;
+        if (row < A.n0) {
+            v = emb_row(A.tv, row, A.H, h, A.err);
+            dst = A.x0 + row * A.H + h;
+        } else if (row < A.n0 + A.n1) {
+            const int64_t e = row - A.n0;
+            v = A.has_te ? emb_row(A.te, e, A.H, h, A.err) : reduce_edge(A, e, h);
+            dst = A.x1 + e * A.H + h;
+        } else {
+            const int64_t r = row - A.n0 - A.n1;
+            v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (A.rowptr2 != nullptr && A.rowptr1 != nullptr) {
+                const int s = A.rowptr2[r], t = A.rowptr2[r + 1];
+                for (int p = s; p < t; p += kChunk) v = ring_chunk(A, p, min(kChunk, t - p), h, v);
+            }
+            if (A.halve) { v.x *= 0.5f; v.y *= 0.5f; v.z *= 0.5f; v.w *= 0.5f; }
+            dst = A.x2 + r * A.H + h;
+        }
+        cwn::store_result4(dst, v.x, v.y, v.z, v.w);
+    }
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+inline bool table_ok(const cwn_embed_table& T) {
+    return T.W != nullptr && T.src != nullptr && T.cols > 0 && T.V > 0 && (T.col_off == nullptr) == (T.col_size == nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// head
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kHeadThreads = 512;
+constexpr int kPartFloats = 4 * kHeadThreads;          // partial row sums of one dimension: [row groups][K] <= 512 float4
+
+struct HeadArgs {
+    cwn_head_dim d[CWN_HEAD_MAX_DIMS];
+    const float* w2; const float* b2; float* out;
+    int64_t C;
+    int32_t n_dims, K, H2, O, mean_readout, mean_final;
+};
+
+__host__ __device__ constexpr size_t head_lds_floats(int K, int H2) {
+    return (size_t)CWN_HEAD_MAX_DIMS * kPartFloats + (size_t)CWN_HEAD_MAX_DIMS * K + (size_t)CWN_HEAD_MAX_DIMS * 4 * kHeadThreads + H2;
+}
+
+__global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int K = A.K, H2 = A.H2, nd = A.n_dims;
+    float* const part = sm;                                                    // [3][NG][K]
+    float* const pooled = part + CWN_HEAD_MAX_DIMS * kPartFloats;              // [3][K]
+    float* const hpart = pooled + CWN_HEAD_MAX_DIMS * K;                       // [3][S][H2], S * H2 <= 4 * 512
+    float* const sbuf = hpart + CWN_HEAD_MAX_DIMS * 4 * kHeadThreads;          // [H2]
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.x;
+
+    // ---- 1. pooled_d = sum of this complex's rows of x_d: K / 4 lanes a row, row groups side by side ------------
+    const int G = K / 4, NG = kHeadThreads / G;
+    const int g = tid / G, l = tid - g * G;
+    int64_t r0[CWN_HEAD_MAX_DIMS], r1[CWN_HEAD_MAX_DIMS];
+#pragma unroll
+    for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d) {
+        r0[d] = r1[d] = 0;
+        if (d < nd && A.d[d].x != nullptr && A.d[d].n_cells > 0) {
+            const int64_t a = A.d[d].cell_ptr[c], b = A.d[d].cell_ptr[c + 1];
+            r0[d] = a < 0 ? 0 : (a > A.d[d].n_cells ? A.d[d].n_cells : a);      // a table that is not this batch's cannot fault
+            r1[d] = b < r0[d] ? r0[d] : (b > A.d[d].n_cells ? A.d[d].n_cells : b);
+        }
+    }
+    if (g < NG) {
+        // the first two rows of every dimension are requested before any is added: a molecule gives a row group one
+        // or two rows per dimension, and three dimensions one after the other would be three memory round trips
+        float4 v[CWN_HEAD_MAX_DIMS][2];
+#pragma unroll
+        for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                v[d][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int64_t r = r0[d] + g + (int64_t)u * NG;
+                if (r < r1[d]) v[d][u] = *reinterpret_cast<const float4*>(A.d[d].x + r * A.d[d].ldx + 4 * l);
+            }
+#pragma unroll
+        for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d) {
+            float4 acc = v[d][0];
+            acc.x += v[d][1].x; acc.y += v[d][1].y; acc.z += v[d][1].z; acc.w += v[d][1].w;
+            for (int64_t r = r0[d] + g + 2 * (int64_t)NG; r < r1[d]; r += 4 * (int64_t)NG) {       // large complexes
+                float4 w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t ru = r + (int64_t)u * NG;
+                    w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ru < r1[d]) w[u] = *reinterpret_cast<const float4*>(A.d[d].x + ru * A.d[d].ldx + 4 * l);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += w[u].x; acc.y += w[u].y; acc.z += w[u].z; acc.w += w[u].w; }
+            }
+            *reinterpret_cast<float4*>(part + (size_t)d * kPartFloats + (size_t)g * K + 4 * l) = acc;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < CWN_HEAD_MAX_DIMS * K; i += kHeadThreads) {
+        const int d = i / K, k = i - d * K;
+        float s = 0.f;
+        for (int q = 0; q < NG; ++q) s += part[(size_t)d * kPartFloats + (size_t)q * K + k];     // fixed order
+        if (A.mean_readout) {
+            const int64_t n = r1[d] - r0[d];
+            s = s / (float)(n > 0 ? n : 1);
+        }
+        pooled[i] = s;
+        if (d < nd && A.d[d].pooled_out != nullptr) A.d[d].pooled_out[c * K + k] = s;
+    }
+    __syncthreads();
+
+    // ---- 2. h_d = W1_d pooled_d.  A thread owns FOUR consecutive outputs (one 16-byte load of the transposed weight
+    // per k: the form the memory pipeline takes at full rate -- with 4-byte loads this phase was 8 of the launch's
+    // 15 us) and one of the S = 512 / (H2 / 4) slices of the K range; every load of a slice is in flight before the
+    // first FMA.  The slices' partial sums meet in LDS, in slice order.
+    const int JQ = H2 / 4, S = kHeadThreads / JQ;
+    const int jq = tid % JQ, kh = tid / JQ;
+    if (kh < S) {
+        const int kb = (K + S - 1) / S, k0 = min(K, kh * kb), k1 = min(K, k0 + kb);
+#pragma unroll
+        for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d < nd) {
+                const float* w = A.d[d].w1t + (size_t)k0 * H2 + 4 * jq;
+                const float* p = pooled + d * K + k0;
+                int k = 0;
+                for (; k + 8 <= k1 - k0; k += 8) {
+                    float4 wv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const float4*>(w + (size_t)(k + u) * H2);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float pk = p[k + u];
+                        a.x = __builtin_fmaf(wv[u].x, pk, a.x); a.y = __builtin_fmaf(wv[u].y, pk, a.y);
+                        a.z = __builtin_fmaf(wv[u].z, pk, a.z); a.w = __builtin_fmaf(wv[u].w, pk, a.w);
+                    }
+                }
+                for (; k < k1 - k0; ++k) {
+                    const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)k * H2);
+                    const float pk = p[k];
+                    a.x = __builtin_fmaf(wv.x, pk, a.x); a.y = __builtin_fmaf(wv.y, pk, a.y);
+                    a.z = __builtin_fmaf(wv.z, pk, a.z); a.w = __builtin_fmaf(wv.w, pk, a.w);
+                }
+            }
+            *reinterpret_cast<float4*>(hpart + (size_t)d * 4 * kHeadThreads + (size_t)kh * H2 + 4 * jq) = a;
+        }
+    }
+    __syncthreads();
+    if (tid < H2) {
+        float s = 0.f;
+        for (int d = 0; d < nd; ++d) {
+            float h = 0.f;
+            for (int q = 0; q < S; ++q) h += hpart[(size_t)d * 4 * kHeadThreads + q * H2 + tid];
+            if (A.d[d].b1 != nullptr) h += A.d[d].b1[tid];
+            s += fmaxf(h, 0.f);
+        }
+        if (A.mean_final) s = s / (float)nd;
+        sbuf[tid] = s;
+    }
+    __syncthreads();
+
+    // ---- 3. out[c] = W2 s + b2: one wave per output, lanes stride the H2 terms, fixed xor tree ------------------
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int o = wave; o < A.O; o += kHeadThreads / 64) {
+        float v = 0.f;
+        for (int q = lane; q < H2; q += 64) v = __builtin_fmaf(A.w2[(size_t)o * H2 + q], sbuf[q], v);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) A.out[c * A.O + o] = v + (A.b2 != nullptr ? A.b2[o] : 0.f);
+    }
+}
+
+}  // namespace
+
+extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, float* x0, const cwn_embed_table* e_tab,
+                                   int64_t n1, float* x1, const int32_t* rowptr1, const int32_t* col1, int64_t nb1, int64_t n2,
+                                   float* x2, const int32_t* rowptr2, const int32_t* col2, int64_t nb2, int32_t H,
+                                   int32_t halve, int32_t* err_flag, cwn_stream_t stream_) {
+    if (v_tab == nullptr || n0 < 0 || n1 < 0 || n2 < 0 || H <= 0 || (H & 3) != 0 || err_flag == nullptr) return CWN_ERR_BAD_ARG;
+    if (n0 + n1 + n2 == 0) return CWN_OK;
+    if (nb1 < 0 || nb2 < 0) return CWN_ERR_BAD_ARG;
+    if (nb1 == 0) rowptr1 = nullptr, col1 = nullptr;          // a plan without entries reduces nothing: zeros
+    if (nb2 == 0) rowptr2 = nullptr, col2 = nullptr;
+    if (!table_ok(*v_tab) || (e_tab != nullptr && !table_ok(*e_tab))) return CWN_ERR_BAD_ARG;
+    if ((n0 > 0 && x0 == nullptr) || (n1 > 0 && x1 == nullptr) || (n2 > 0 && x2 == nullptr)) return CWN_ERR_BAD_ARG;
+    if ((rowptr1 == nullptr) != (col1 == nullptr) || (rowptr2 == nullptr) != (col2 == nullptr)) return CWN_ERR_BAD_ARG;
+    // a reduction onto the edges / rings walks into the vertex table: it needs vertices (and the rings need the edges' CSR)
+    if ((rowptr1 != nullptr || rowptr2 != nullptr) && n0 == 0) return CWN_ERR_BAD_ARG;
+    if (rowptr2 != nullptr && n1 == 0) return CWN_ERR_BAD_ARG;
+    if (!(al16(v_tab->W) && al16(x0) && al16(x1) && al16(x2) && (e_tab == nullptr || al16(e_tab->W)))) return CWN_ERR_ALIGN;
+    FrontArgs A{};
+    A.tv = *v_tab;
+    if (e_tab != nullptr) A.te = *e_tab;
+    A.has_te = e_tab != nullptr ? 1 : 0;
+    A.x0 = x0; A.x1 = x1; A.x2 = x2;
+    A.rowptr1 = rowptr1; A.col1 = col1; A.rowptr2 = rowptr2; A.col2 = col2;
+    A.n0 = n0; A.n1 = n1; A.n2 = n2;
+    A.H = H;
+    A.halve = halve ? 1 : 0;
+    A.err = err_flag;
+    int G = 1;
+    while (G < H / 4 && G < 64) G <<= 1;
+    A.G = G;
+    const int64_t rows = n0 + n1 + n2, per = 256 / G, blocks = (rows + per - 1) / per;
+    if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    embed_front_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(A);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
+                            int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out,
+                            cwn_stream_t stream_) {
+    if (dims == nullptr || n_dims < 1 || n_dims > CWN_HEAD_MAX_DIMS || C < 0 || O < 1) return CWN_ERR_BAD_ARG;
+    // K / 4 lanes a row inside 512 threads; output j by thread j
+    if (K < 4 || (K & 3) != 0 || K > 4 * kHeadThreads || H2 < 4 || (H2 & 3) != 0 || H2 > kHeadThreads) return CWN_ERR_BAD_ARG;
+    if (C == 0) return CWN_OK;
+    if (C >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    if (w2 == nullptr || out == nullptr) return CWN_ERR_BAD_ARG;
+    HeadArgs A{};
+    for (int d = 0; d < n_dims; ++d) {
+        const cwn_head_dim& D = dims[d];
+        if (D.w1t == nullptr || D.n_cells < 0) return CWN_ERR_BAD_ARG;
+        if (D.x != nullptr && D.n_cells > 0 && (D.cell_ptr == nullptr || D.ldx < K || (D.ldx & 3) != 0)) return CWN_ERR_BAD_ARG;
+        if (!al16(D.x) || !al16(D.w1t)) return CWN_ERR_ALIGN;
+        A.d[d] = D;
+    }
+    A.w2 = w2; A.b2 = b2; A.out = out;
+    A.C = C;
+    A.n_dims = n_dims; A.K = K; A.H2 = H2; A.O = O;
+    A.mean_readout = mean_readout ? 1 : 0;
+    A.mean_final = mean_final ? 1 : 0;
+    const size_t lds = head_lds_floats(K, H2) * sizeof(float);
+    if (lds > 64 * 1024) return CWN_ERR_BAD_ARG;
+    head_kernel<<<dim3((unsigned)C), dim3(kHeadThreads), lds, (hipStream_t)stream_>>>(A);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}

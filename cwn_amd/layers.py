@@ -1077,11 +1077,20 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
     def _prepare_e_inputs(self, e_params):
         pass
 
+    def _check_v_inputs(self, v_params):      # the shape asserts of _prepare_*_inputs without the dtype conversion
+        assert v_params.x is not None and v_params.x.dim() == 2
+
+    def _check_e_inputs(self, e_params):
+        assert self.e_embed_layer is not None and e_params.x.dim() == 2
+
     def forward(self, *cochain_params: CochainMessagePassingParams):
         assert 1 <= len(cochain_params) <= 3
         v_params = cochain_params[0]
         e_params = cochain_params[1] if len(cochain_params) >= 2 else None
         c_params = cochain_params[2] if len(cochain_params) == 3 else None
+        fused = self._forward_fused(v_params, e_params, c_params)
+        if fused is not None:
+            return fused
         vx = _embed(self.v_embed_layer, self._prepare_v_inputs(v_params))
         out = [vx]
         if e_params is None:
@@ -1100,24 +1109,88 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
             out.append(self.init_reduce(reduced_ex, c_params.boundary_index, n_c) / 2.)
         return out
 
+    def _forward_fused(self, v_params, e_params, c_params) -> Optional[List[Tensor]]:
+        """The whole front in ONE launch (ops.embed_front, csrc/cwn_ends.hip): both embeddings, the reduction of
+        the vertex embeddings onto the edges and of that onto the rings, halved -- the 8 launches below it were 29 us
+        of a 167 us forward at the ZINC batch of 128.  Inference with plain embedding tables and 'sum' reduction;
+        None otherwise (the caller runs the separate launches, which also carry the autograd)."""
+        if not ops.FUSED_ENDS or e_params is None or v_params.x is None or not v_params.x.is_cuda:
+            return None
+        if self.init_reduce.reduce not in ('add', 'sum'):
+            return None
+        vt = _embedding_tables(self.v_embed_layer)
+        et = _embedding_tables(self.e_embed_layer) if e_params.x is not None else None
+        if vt is None or (e_params.x is not None and et is None):
+            return None
+        if torch.is_grad_enabled() and any(w.requires_grad for w in vt + (et or [])):
+            return None
+        H = int(vt[0].size(1))
+        if H % 4 != 0 or any(w.size(1) != H or not w.is_cuda or w.dtype != torch.float32 for w in vt + (et or [])):
+            return None
+        self._check_v_inputs(v_params)
+        if e_params.x is not None:
+            self._check_e_inputs(e_params)
+        from .csr import cached_adjacency
+        n0 = int(v_params.x.size(0))
+        n1 = getattr(e_params, 'num_cells', None) or (e_params.x.size(0) if e_params.x is not None else None)
+        if n1 is None or n0 == 0:
+            return None
+        n1 = int(n1)
+        adj1 = cached_adjacency(e_params.boundary_index, n1, n0) if e_params.boundary_index is not None and n1 > 0 else None
+        n2, adj2 = 0, None
+        if c_params is not None:
+            n2 = getattr(c_params, 'num_cells', None) or (c_params.x.size(0) if c_params.x is not None else None)
+            if n2 is None:
+                return None
+            n2 = int(n2)
+            if c_params.boundary_index is not None and n2 > 0 and n1 > 0:
+                adj2 = cached_adjacency(c_params.boundary_index, n2, n1)
+        if e_params.x is None and adj1 is None:
+            return None                   # edges without features and without boundaries: let the plain path raise
+        xs = ops.embed_front(vt, v_params.x, et, e_params.x if et is not None else None, n1, adj1, n2, adj2, halve=True)
+        return xs if c_params is not None else xs[:2]
+
     def reset_parameters(self):
         reset(self.v_embed_layer)
         reset(self.e_embed_layer)
 
 
+def _embedding_tables(layer) -> Optional[List[Tensor]]:
+    """The weight(s) of a plain torch.nn.Embedding or of an OGB-style encoder (a list of them, summed over the
+    feature columns); None for anything else."""
+    def plain(e):
+        return (isinstance(e, torch.nn.Embedding) and e.padding_idx is None and e.max_norm is None
+                and not e.sparse and not e.scale_grad_by_freq)
+    if layer is None:
+        return None
+    if plain(layer):
+        return [layer.weight]
+    for name in ('atom_embedding_list', 'bond_embedding_list'):
+        if hasattr(layer, name):
+            tables = list(getattr(layer, name))
+            return [e.weight for e in tables] if tables and all(plain(e) for e in tables) else None
+    return None
+
+
 class EmbedVEWithReduce(AbstractEmbedVEWithReduce):
     """mp/layers.py:550-570."""
 
-    def _prepare_v_inputs(self, v_params):
+    def _check_v_inputs(self, v_params):
         assert v_params.x is not None
         assert v_params.x.dim() == 2
         assert v_params.x.size(1) == 1
-        return v_params.x.squeeze(1).to(dtype=torch.long)
 
-    def _prepare_e_inputs(self, e_params):
+    def _check_e_inputs(self, e_params):
         assert self.e_embed_layer is not None
         assert e_params.x.dim() == 2
         assert e_params.x.size(1) == 1
+
+    def _prepare_v_inputs(self, v_params):
+        self._check_v_inputs(v_params)
+        return v_params.x.squeeze(1).to(dtype=torch.long)
+
+    def _prepare_e_inputs(self, e_params):
+        self._check_e_inputs(e_params)
         return e_params.x.squeeze(1).to(dtype=torch.long)
 
 
@@ -1125,12 +1198,18 @@ class OGBEmbedVEWithReduce(AbstractEmbedVEWithReduce):
     """mp/layers.py:573-593 (the OGB Atom/Bond encoders themselves are third-party; any module
     mapping integer feature columns to embeddings fits)."""
 
-    def _prepare_v_inputs(self, v_params):
+    def _check_v_inputs(self, v_params):
         assert v_params.x is not None
         assert v_params.x.dim() == 2
+
+    def _check_e_inputs(self, e_params):
+        assert self.e_embed_layer is not None
+        assert e_params.x.dim() == 2
+
+    def _prepare_v_inputs(self, v_params):
+        self._check_v_inputs(v_params)
         return v_params.x.to(dtype=torch.long)
 
     def _prepare_e_inputs(self, e_params):
-        assert self.e_embed_layer is not None
-        assert e_params.x.dim() == 2
+        self._check_e_inputs(e_params)
         return e_params.x.to(dtype=torch.long)

@@ -179,6 +179,12 @@ class _SparseCINStack(torch.nn.Module):
             xs = [torch.cat(j, dim=-1) for j in jump_xs]
         elif self.jump_mode == 'max':
             xs = [torch.stack(j, dim=-1).max(dim=-1)[0] for j in jump_xs]
+        fused = self._head_fused(xs, data, include_partial, res)
+        if fused is not None:
+            if include_partial:
+                res['out'] = fused
+                return fused, res
+            return fused
         pooled = pool_complex_list(xs, data, self.max_dim, self.readout)
         xs = [pooled[i] for i in self.readout_dims]
         if include_partial:
@@ -213,6 +219,46 @@ class _SparseCINStack(torch.nn.Module):
             res['out'] = x
             return x, res
         return x
+
+    def _head_fused(self, xs, data: ComplexBatch, include_partial: bool, res: dict):
+        """Readout, lin1s (+ReLU), final readout and lin2 in ONE launch, one workgroup per complex (ops.head,
+        csrc/cwn_ends.hip) -- 5 launches / 43 us of a 167 us forward at the ZINC batch of 128 before.  Inference
+        (no autograd, no active dropout) on a batch that carries the collate's per-complex tables; None otherwise."""
+        if not ops.FUSED_ENDS or self.nonlinearity != 'relu' or not xs or not xs[0].is_cuda:
+            return None
+        if self.readout not in ('sum', 'mean') or self.final_readout not in ('sum', 'mean'):
+            return None
+        if self.training and self.dropout_rate > 0:
+            return None
+        rd = list(self.readout_dims)
+        if not rd or len(rd) > 3:
+            return None
+        lins = [self.lin1s[d] for d in rd]
+        if torch.is_grad_enabled() and (any(p.requires_grad for l in lins + [self.lin2] for p in l.parameters())
+                                        or any(x.requires_grad for x in xs)):
+            return None
+        plan = data.block_plan()
+        if plan is None or data.num_complexes is None or plan.C != data.num_complexes:
+            return None
+        K, H2 = lins[0].in_features, lins[0].out_features
+        if K % 4 != 0 or K > 2048 or H2 % 4 != 0 or H2 > 512 or any(l.in_features != K or l.out_features != H2 for l in lins):
+            return None
+        if any(x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != K for x in xs):
+            return None
+        dev = xs[0].device
+        hx = [xs[d] if d < len(xs) and d < plan.n_dims and xs[d].size(0) == int(plan.cell_ptr[d][-1]) else None for d in rd]
+        if any(d < len(xs) and h is None for d, h in zip(rd, hx)):
+            return None                    # a feature matrix that is not the batch's own rows
+        ptrs = [plan.cell_ptr_device(d, dev) if h is not None else None for d, h in zip(rd, hx)]
+        got = ops.head(hx, ptrs, plan.C, [l.weight for l in lins], [l.bias for l in lins], self.lin2.weight, self.lin2.bias,
+                       mean_readout=self.readout == 'mean', mean_final=self.final_readout == 'mean',
+                       want_pooled=include_partial)
+        if include_partial:
+            out, pooled = got
+            for k in range(len(rd)):
+                res[f'pool_{k}'] = pooled[k]
+            return out
+        return got
 
     def __repr__(self):
         return self.__class__.__name__

@@ -10,6 +10,7 @@ from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
 import os
+import weakref
 
 import torch
 from torch import Tensor
@@ -465,6 +466,126 @@ class _EmbeddingSum(torch.autograd.Function):
         if acc_dst:
             torch._foreach_add_(acc_dst, acc_src)
         return (None,) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# the two ends of a model forward, one launch each (csrc/cwn_ends.hip; inference)
+# ------------------------------------------------------------------------------------------------
+FUSED_ENDS = True            # False: the front / head run as the separate launches they replace (A/B, tests)
+
+_table_cache = {}            # concatenated embedding tables, keyed on the weights' identities and versions
+
+
+def _embed_table(weights: Sequence[Tensor], feats: Tensor, keep: list) -> _ffi.EmbedTable:
+    """cwn_embed_table of one table set + the integer features as the container delivers them (float32 or int64,
+    [n] or [n, cols])."""
+    dev = feats.device
+    if len(weights) == 1:
+        W = _f32c(weights[0].detach(), 'embedding table')
+    else:
+        key = tuple((id(w), w._version) for w in weights) + (STATE_EPOCH,)
+        hit = _table_cache.get(key)
+        if hit is None:
+            if len(_table_cache) > 32:
+                _table_cache.clear()
+            hit = (torch.cat([w.detach() for w in weights], 0).contiguous(), [weakref.ref(w) for w in weights])
+            _table_cache[key] = hit
+        W = hit[0]
+    off, size = _EmbeddingSum._columns(weights, dev)
+    if feats.dim() == 1:
+        feats = feats.unsqueeze(1)
+    if feats.dtype not in (torch.float32, torch.long):
+        feats = feats.to(torch.long)
+    feats = feats.contiguous()
+    if feats.size(1) != len(weights):
+        raise ValueError(f'{feats.size(1)} index columns for {len(weights)} embedding tables')
+    keep += [W, off, size, feats]
+    return _ffi.EmbedTable(W=W.data_ptr(), src=feats.data_ptr(), col_off=_ffi.ptr(off), col_size=_ffi.ptr(size),
+                           V=int(W.size(0)), cols=int(feats.size(1)), src_is_f32=1 if feats.dtype == torch.float32 else 0)
+
+
+def embed_front(v_weights: Sequence[Tensor], v_feats: Tensor, e_weights: Optional[Sequence[Tensor]],
+                e_feats: Optional[Tensor], n1: int, adj1, n2: int, adj2, halve: bool = True) -> List[Tensor]:
+    """[x0, x1, x2] of EmbedVEWithReduce.forward (mp/layers.py:509-547) in ONE launch (cwn_embed_front_f32):
+    embedded vertices, embedded edges (or, without an edge table, the sum of their embedded boundary vertices), rings
+    = half the sum over their boundary edges of THOSE sums.  adj1 / adj2: the destination-sorted plans of
+    boundary_index_1 / _2 (csr.cached_adjacency), None = no reduction.  No autograd (the caller checks)."""
+    from .csr import _err_flag, VALIDATE_INDICES, check_errors
+    _ffi.require_gpu(v_feats, 'vertex features')
+    dev = v_feats.device
+    H = int(v_weights[0].size(1))
+    keep: list = []
+    tv = _embed_table(v_weights, v_feats, keep)
+    te = _embed_table(e_weights, e_feats, keep) if e_weights is not None else None
+    n0 = int(v_feats.size(0))
+    # one allocation for the three outputs (rows of H floats: every block 16-B aligned)
+    buf = torch.empty(n0 + n1 + n2, H, dtype=torch.float32, device=dev)
+    x0, x1, x2 = buf[:n0], buf[n0:n0 + n1], buf[n0 + n1:]
+    for adj in (adj1, adj2):
+        if adj is not None and adj.ready is not None:
+            torch.cuda.current_stream(dev).wait_event(adj.ready)
+    _ffi.check(_ffi.lib().cwn_embed_front_f32(
+        tv, n0, x0.data_ptr(), te, n1, x1.data_ptr(),
+        _ffi.ptr(adj1.rowptr) if adj1 is not None else None, _ffi.ptr(adj1.col) if adj1 is not None else None,
+        adj1.n_entries if adj1 is not None else 0, n2, x2.data_ptr(),
+        _ffi.ptr(adj2.rowptr) if adj2 is not None else None, _ffi.ptr(adj2.col) if adj2 is not None else None,
+        adj2.n_entries if adj2 is not None else 0, H, 1 if halve else 0, _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)), 'cwn_embed_front_f32')
+    if VALIDATE_INDICES and not torch.cuda.is_current_stream_capturing():
+        check_errors(dev)
+    return [x0, x1, x2]
+
+
+_w1t_cache = {}
+
+
+def _transposed(weight: Tensor) -> Tensor:
+    """lin1's weight [H2, K] as [K, H2] (what cwn_head_f32 reads coalesced), once per weight version."""
+    key = id(weight)
+    hit = _w1t_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, STATE_EPOCH):
+        return hit[2]
+    if len(_w1t_cache) > 64:
+        _w1t_cache.clear()
+    t = _f32c(weight.detach(), 'lin1 weight').t().contiguous()
+    _w1t_cache[key] = (weakref.ref(weight), (weight._version, STATE_EPOCH), t)
+    return t
+
+
+def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexes: int, lin1_weights: Sequence[Tensor],
+         lin1_biases: Sequence[Optional[Tensor]], lin2_weight: Tensor, lin2_bias: Optional[Tensor],
+         mean_readout: bool = False, mean_final: bool = False, want_pooled: bool = False):
+    """pool_complex + lin1s (+ReLU) + final readout + lin2 in ONE launch (cwn_head_f32), one workgroup per complex.
+    xs[d]: [N_d, K] or None (dimension absent from the batch: pooled zeros, mp/nn.py:55-56); cell_ptrs[d]: device
+    int64 [C + 1], the collate's `ptr`.  Returns out [C, O] (and the pooled [C, K] per dimension)."""
+    x0 = next(x for x in xs if x is not None)
+    _ffi.require_gpu(x0, 'x')
+    dev = x0.device
+    K, H2, O = int(lin1_weights[0].size(1)), int(lin1_weights[0].size(0)), int(lin2_weight.size(0))
+    keep, dims, pooled = [], [], []
+    for d, x in enumerate(xs):
+        D = _ffi.HeadDim()
+        if x is not None:
+            x = _f32c(x, 'x')
+            if x.size(1) != K:
+                raise ValueError(f'dim {d}: {x.size(1)} features for a lin1 of {K} inputs')
+            D.x, D.cell_ptr, D.n_cells, D.ldx = x.data_ptr(), cell_ptrs[d].data_ptr(), int(x.size(0)), int(x.stride(0))
+        w1t = _transposed(lin1_weights[d])
+        b1 = None if lin1_biases[d] is None else _f32c(lin1_biases[d].detach(), 'lin1 bias')
+        D.w1t, D.b1 = w1t.data_ptr(), _ffi.ptr(b1)
+        if want_pooled:
+            po = torch.empty(n_complexes, K, dtype=torch.float32, device=dev)
+            pooled.append(po)
+            D.pooled_out = po.data_ptr()
+        keep += [x, w1t, b1]
+        dims.append(D)
+    w2 = _f32c(lin2_weight.detach(), 'lin2 weight')
+    b2 = None if lin2_bias is None else _f32c(lin2_bias.detach(), 'lin2 bias')
+    out = torch.empty(n_complexes, O, dtype=torch.float32, device=dev)
+    arr = (_ffi.HeadDim * len(dims))(*dims)
+    _ffi.check(_ffi.lib().cwn_head_f32(arr, len(dims), n_complexes, K, H2, 1 if mean_readout else 0,
+                                       1 if mean_final else 0, w2.data_ptr(), _ffi.ptr(b2), O, out.data_ptr(),
+                                       _ffi.stream_ptr(dev)), 'cwn_head_f32')
+    return (out, pooled) if want_pooled else out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 11
+#define CWN_ABI_VERSION 12
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -562,6 +562,62 @@ int cwn_embedding_fwd_f32(const float* W, const int64_t* src, const int64_t* col
 int cwn_embedding_bwd_f32(const float* g, const int64_t* src, const int64_t* col_off,
                           const int64_t* col_size, float* dW, int64_t n_rows, int32_t cols, int32_t H,
                           int64_t V, cwn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The two ends of a model forward, one launch each (inference; csrc/cwn_ends.hip).
+ *
+ * FRONT -- EmbedVEWithReduce.forward / OGBEmbedVEWithReduce.forward (mp/layers.py:490-593), i.e.
+ * v_embed_init / e_embed_init (mp/molec_models.py:44-52, 237-245) + InitReduceConv('sum') twice
+ * (mp/layers.py:473-487, :526, :538-540):
+ *     x0[v] = sum_c Tv_c[ids0[v, c]]
+ *     x1[e] = sum_c Te_c[ids1[e, c]]            (e_tab == NULL: x1[e] = red1[e])
+ *     x2[r] = (halve ? 1/2 : 1) * sum_{e in row r of CSR2} red1[e],   red1[e] = sum_{v in row e of CSR1} x0[v]
+ * A table set is cwn_embedding_fwd_f32's (concatenated tables [V, H], per-column offsets / sizes, both NULL for
+ * one table); `src` holds the integer features as int64 or -- as the reference's containers deliver them before
+ * `.to(torch.long)` (mp/layers.py:556, :566) -- as float32 (src_is_f32: converted by truncation).  CSR1 / CSR2
+ * are the destination-sorted plans cwn_csr_build makes of boundary_index_1 / boundary_index_2 (rowptr, col:
+ * int32; nb1 / nb2 = their entry counts; a NULL pair or no entries = no reduction: zeros); sums run in CSR (= entry)
+ * order.  H % 4 == 0; outputs [n_d, H]
+ * contiguous, 16-B aligned.  An index outside its own table sets bit 1 of *err_flag and contributes nothing.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cwn_embed_table {
+    const float* W;            /* [V, H]: the row-wise concatenation of the tables */
+    const void* src;           /* [n_rows, cols] integer features: int64, or float32 when src_is_f32 */
+    const int64_t* col_off;    /* device [cols] or NULL */
+    const int64_t* col_size;   /* device [cols] or NULL (both or neither) */
+    int64_t V;
+    int32_t cols;
+    int32_t src_is_f32;
+} cwn_embed_table;
+
+int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, float* x0, const cwn_embed_table* e_tab,
+                        int64_t n1, float* x1, const int32_t* rowptr1, const int32_t* col1, int64_t nb1, int64_t n2,
+                        float* x2, const int32_t* rowptr2, const int32_t* col2, int64_t nb2, int32_t H, int32_t halve,
+                        int32_t* err_flag, cwn_stream_t stream);
+
+/* HEAD -- pool_complex (mp/nn.py:50-60) + lin1s + final readout + lin2 (mp/molec_models.py:129-156,
+ * mp/models.py:222-253), one workgroup per complex:
+ *     pooled_d[c] = sum (mean_readout: mean, count clamped to 1) of rows cell_ptr_d[c] .. cell_ptr_d[c+1] of x_d
+ *     out[c] = W2 (sum_d relu(W1_d pooled_d[c] + b1_d)  [/ n_dims when mean_final]) + b2
+ * The cells of a complex are contiguous in a batched cochain (data/complex.py:148-169); cell_ptr_d is the
+ * collate's `ptr` (data/complex.py:344, 432) as a device int64 [C + 1] array.  x == NULL: the dimension is
+ * absent from the batch, pooled = 0 (mp/nn.py:55-56) and lin1 still contributes relu(b1).  w1t = the TRANSPOSE
+ * of lin1s[d].weight, [K, H2] row-major (prepared once per weight version: coalesced over the outputs); w2
+ * [O, H2] torch layout.  K % 4 == 0, K <= 2048, H2 % 4 == 0, H2 <= 512.  pooled_out (optional): [C, K].  fp32 FMA chains in a
+ * fixed order; a complex's result does not depend on the rest of the batch.
+ * ------------------------------------------------------------------------------------------ */
+#define CWN_HEAD_MAX_DIMS 3
+typedef struct cwn_head_dim {
+    const float* x;             /* [n_cells, K], row stride ldx (multiple of 4), or NULL */
+    const int64_t* cell_ptr;    /* device [C + 1] */
+    const float* w1t;           /* [K, H2] */
+    const float* b1;            /* [H2] or NULL */
+    float* pooled_out;          /* [C, K] or NULL */
+    int64_t n_cells, ldx;
+} cwn_head_dim;
+
+int cwn_head_f32(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
+                 int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, cwn_stream_t stream);
 
 /* torch.optim.Adam's update (no amsgrad; weight_decay is the L2 form) for a whole model in one
  * launch: parameters p, gradients g and the moments m, v are each ONE contiguous fp32 buffer of n

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cwn_abi_version() == 11
+    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 12
     assert lib.cwn_target_arch() == b'gfx950'
     assert lib.cwn_error_string(0) == b'ok'
 
@@ -39,7 +39,8 @@ def test_struct_layout_matches_header(tmp_path):
                'cwn_gemm_desc': _ffi.GemmDesc, 'cwn_collate_desc': _ffi.CollateDesc,
                'cwn_bn_desc': _ffi.BnDesc, 'cwn_norm_desc': _ffi.NormDesc,
                'cwn_gemm_tn_desc': _ffi.GemmTnDesc, 'cwn_layer_dim': _ffi.LayerDim,
-               'cwn_layer_plan': _ffi.LayerPlan, 'cwn_mlp_dim': _ffi.MlpDim, 'cwn_layer_sizes': _ffi.LayerSizes}
+               'cwn_layer_plan': _ffi.LayerPlan, 'cwn_mlp_dim': _ffi.MlpDim, 'cwn_layer_sizes': _ffi.LayerSizes,
+               'cwn_embed_table': _ffi.EmbedTable, 'cwn_head_dim': _ffi.HeadDim}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cwn_hip.h"', 'int main(void) {']
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -104,6 +105,19 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_layer_round_rows(128) in (16, 32) and lib.cwn_layer_round_rows(100) == 0
     g = (_ffi.GemmDesc * 1)(_ffi.GemmDesc(M=4, N=64, K=64, K2=0, ldx=64, ldw=64, ldy=64, flags=_ffi.GEMM_W_PACKED))
     assert lib.cwn_gemm_would_split(g, 1) == 0                       # not the split kernel's shape ...
+    # round-3 additions: the fused ends (csrc/cwn_ends.hip)
+    tv = _ffi.EmbedTable(V=28, cols=1)
+    assert lib.cwn_embed_front_f32(None, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, None, None) == 1
+    assert lib.cwn_embed_front_f32(tv, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 66, 1, None, None) == 1   # H % 4
+    err = ctypes.c_int32(0)
+    assert lib.cwn_embed_front_f32(tv, 0, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, ctypes.byref(err), None) == 0  # nothing to do
+    assert lib.cwn_embed_front_f32(tv, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, ctypes.byref(err), None) == 1  # rows, no table
+    hd = (_ffi.HeadDim * 1)(_ffi.HeadDim())
+    assert lib.cwn_head_f32(None, 1, 4, 128, 256, 0, 0, None, None, 1, None, None) == 1
+    assert lib.cwn_head_f32(hd, 1, 0, 128, 256, 0, 0, None, None, 1, None, None) == 0          # no complexes
+    assert lib.cwn_head_f32(hd, 1, 4, 130, 256, 0, 0, None, None, 1, None, None) == 1          # K % 4
+    assert lib.cwn_head_f32(hd, 1, 4, 128, 1024, 0, 0, None, None, 1, None, None) == 1         # H2 beyond a workgroup
+    assert lib.cwn_head_f32(hd, 4, 4, 128, 256, 0, 0, None, None, 1, None, None) == 1          # more than 3 dimensions
 
 
 def test_item_table_builder_rejects_tables_that_are_not_prefix_sums():

@@ -1,0 +1,175 @@
+"""The two ends of a model forward as single launches (csrc/cwn_ends.hip) through the C ABI:
+
+  * FRONT `cwn_embed_front_f32` (EmbedVEWithReduce.forward, mp/layers.py:490-593) against the separate launches it
+    replaces -- bit for bit: same tables, same CSR (= entry) order of every sum -- and against a float64 restatement;
+  * HEAD `cwn_head_f32` (pool_complex + lin1s + final readout + lin2, mp/nn.py:50-60, mp/molec_models.py:129-156)
+    against the same computation in float64 (gate 1e-5 * max(1, |ref|_inf)) and against the unfused path;
+  * the properties the reference tests: a complex's prediction does not depend on the rest of the batch
+    (mp/test_molec_models.py:11-68), absent dimensions contribute relu(b1) (mp/nn.py:55-56)."""
+import pytest
+import torch
+
+from tests._product import gate
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _zinc_model(hidden=128, layers=2, readout='sum', final_readout='sum', jump_mode=None, seed=0):
+    from cwn_amd.models import EmbedSparseCIN
+    torch.manual_seed(seed)
+    return EmbedSparseCIN(28, 4, 1, layers, hidden, dropout_rate=0.0, max_dim=2, jump_mode=jump_mode, nonlinearity='relu',
+                          readout=readout, final_readout=final_readout, embed_edge=True, use_coboundaries=True,
+                          graph_norm='bn').to(DEV).eval()
+
+
+def _ends(on):
+    from cwn_amd import ops
+
+    class _Ctx:
+        def __enter__(self):
+            self.prev, ops.FUSED_ENDS = ops.FUSED_ENDS, on
+
+        def __exit__(self, *a):
+            ops.FUSED_ENDS = self.prev
+    return _Ctx()
+
+
+@pytest.mark.parametrize('kind', ['zinc', 'molhiv', 'zinc_no_edge_table'])
+def test_front_bit_identical_to_the_launches_it_replaces(kind):
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.layers import EmbedVEWithReduce, InitReduceConv, OGBEmbedVEWithReduce
+    from cwn_amd.models import AtomEncoder, BondEncoder
+    from cwn_amd.synthetic import molhiv_like_complexes, zinc_like_complexes
+    torch.manual_seed(3)
+    H = 64 if kind == 'molhiv' else 128
+    if kind == 'molhiv':
+        front = OGBEmbedVEWithReduce(AtomEncoder(H), BondEncoder(H), InitReduceConv('sum')).to(DEV)
+        b = ComplexBatch.from_complex_list(molhiv_like_complexes(40, 5, 6), max_dim=2).to(DEV)
+    else:
+        e = torch.nn.Embedding(4, H) if kind == 'zinc' else None
+        front = EmbedVEWithReduce(torch.nn.Embedding(28, H), e, InitReduceConv('sum')).to(DEV)
+        b = ComplexBatch.from_complex_list(zinc_like_complexes(40, 5, 6), max_dim=2).to(DEV)
+        if kind == 'zinc_no_edge_table':
+            b.cochains[1]._x = None
+    with torch.no_grad():
+        with _ends(True):
+            got = front(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+        with _ends(False):
+            want = front(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+    assert len(got) == len(want) == 3
+    for d, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape and torch.equal(g, w), (d, (g - w).abs().max().item())
+    # and against a float64 restatement of mp/layers.py:509-547
+    vt = [w.detach().double().cpu() for w in ([front.v_embed_layer.weight] if kind != 'molhiv'
+                                              else [e_.weight for e_ in front.v_embed_layer.atom_embedding_list])]
+    ids0 = b.cochains[0].x.long().cpu()
+    x0 = sum(vt[c][ids0[:, c]] for c in range(len(vt)))
+    bi1, bi2 = b.cochains[1].boundary_index.cpu(), b.cochains[2].boundary_index.cpu()
+    red1 = torch.zeros(b.cochains[1].num_cells, H, dtype=torch.float64).index_add_(0, bi1[1], x0[bi1[0]])
+    x2 = torch.zeros(b.cochains[2].num_cells, H, dtype=torch.float64).index_add_(0, bi2[1], red1[bi2[0]]) / 2
+    gate(got[0], x0, f'{kind} x0')
+    gate(got[2], x2, f'{kind} x2')
+    if kind == 'zinc_no_edge_table':
+        gate(got[1], red1, f'{kind} x1 = reduced')
+
+
+def test_front_reports_an_index_outside_its_table():
+    from cwn_amd import csr
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.layers import EmbedVEWithReduce, InitReduceConv
+    from cwn_amd.synthetic import zinc_like_complexes
+    front = EmbedVEWithReduce(torch.nn.Embedding(28, 64), torch.nn.Embedding(4, 64), InitReduceConv('sum')).to(DEV)
+    b = ComplexBatch.from_complex_list(zinc_like_complexes(4, 6, 6), max_dim=2).to(DEV)
+    b.cochains[0].x[3, 0] = 28.0
+    with torch.no_grad(), pytest.raises(IndexError):
+        front(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+    csr._err_flag(torch.device(DEV)).zero_()       # the sticky word is clean again for the next test
+
+
+def _head_reference(model, xs, b, readout, final_readout):
+    """float64 restatement of mp/nn.py:50-60 + mp/molec_models.py:129-156 on the CPU."""
+    C = b.num_complexes
+    outs = []
+    for d in model.readout_dims:
+        lin = model.lin1s[d]
+        if d < len(xs):
+            x = xs[d].double().cpu()
+            bv = b.cochains[d].batch.cpu()
+            p = torch.zeros(C, x.size(1), dtype=torch.float64).index_add_(0, bv, x)
+            if readout == 'mean':
+                p = p / torch.bincount(bv, minlength=C).clamp(min=1).double().unsqueeze(1)
+        else:
+            p = torch.zeros(C, lin.in_features, dtype=torch.float64)
+        bias = lin.bias.detach().double().cpu() if lin.bias is not None else 0.0
+        outs.append((p, torch.relu(p @ lin.weight.detach().double().cpu().t() + bias)))
+    s = sum(h for _, h in outs)
+    if final_readout == 'mean':
+        s = s / len(outs)
+    return [p for p, _ in outs], s @ model.lin2.weight.detach().double().cpu().t() + model.lin2.bias.detach().double().cpu()
+
+
+@pytest.mark.parametrize('hidden,readout,final_readout,jump', [(128, 'sum', 'sum', None), (64, 'mean', 'sum', None),
+                                                              (64, 'sum', 'mean', 'cat'), (128, 'mean', 'mean', None)])
+def test_head_vs_float64_and_vs_the_unfused_launches(hidden, readout, final_readout, jump):
+    from cwn_amd.synthetic import zinc_like_batch
+    model = _zinc_model(hidden, layers=3 if jump else 2, readout=readout, final_readout=final_readout, jump_mode=jump, seed=4)
+    b = zinc_like_batch(33, seed=8, device=DEV)
+    K = model.lin1s[0].in_features
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(b.cochains[d].num_cells, K, generator=g).to(DEV) for d in range(3)]
+    res = {}
+    with torch.no_grad():
+        out = model._head_fused(xs, b, True, res)
+    assert out is not None
+    pooled, want = _head_reference(model, xs, b, readout, final_readout)
+    for k in range(3):
+        gate(res[f'pool_{k}'], pooled[k], f'pool_{k} ({readout})')
+    gate(out, want, f'head out (hidden {hidden}, {readout}/{final_readout}, jump {jump})')
+
+
+def test_model_forward_fused_ends_vs_separate_launches():
+    """The whole EmbedSparseCIN forward with and without the fused ends: same layers in between, so the difference is
+    the ends' own (fp32 re-association of the pooled sums and the GEMV order): inside the gate."""
+    from cwn_amd.synthetic import zinc_like_batch
+    model = _zinc_model(128, layers=2, seed=11)
+    outs = {}
+    for on in (True, False):
+        b = zinc_like_batch(50, seed=12, device=DEV)
+        with torch.no_grad(), _ends(on):
+            out, res = model(b, include_partial=True)
+        outs[on] = (out, res)
+    for k in ('layer0_0', 'layer1_1', 'layer1_2'):
+        assert torch.equal(outs[True][1][k], outs[False][1][k]), k       # the front is bit-identical, so are the layers
+    for k in ('pool_0', 'pool_1', 'pool_2'):
+        gate(outs[True][1][k], outs[False][1][k].double(), k)
+    gate(outs[True][0], outs[False][0].double(), 'prediction')
+
+
+def test_head_absent_dimension_and_batch_independence():
+    """A batch without 2-cells: dimension 2 contributes relu(b1) (pooled zeros, mp/nn.py:55-56); and the prediction of
+    a complex is bit-identical whatever else is in the batch (one workgroup per complex, fixed summation order)."""
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    model = _zinc_model(64, layers=1, seed=13)
+    cxs = zinc_like_complexes(12, 14, 6)
+    K = 64
+    g = torch.Generator().manual_seed(15)
+    feats = [[torch.randn(c.cochains[d].num_cells, K, generator=g) for d in range(c.dimension + 1)] for c in cxs]
+
+    def run(ids):
+        b = ComplexBatch.from_complex_list([cxs[i] for i in ids], max_dim=2).to(DEV)
+        xs = [torch.cat([feats[i][d] for i in ids if d < len(feats[i])]).to(DEV) for d in range(b.dimension + 1)]
+        with torch.no_grad():
+            out = model._head_fused(xs, b, False, {})
+        assert out is not None
+        return out, xs, b
+
+    full, xs, b = run(list(range(12)))
+    part, _, _ = run([7, 2, 9])
+    assert torch.equal(part, full[[7, 2, 9]])
+    # two dimensions only
+    with torch.no_grad():
+        out2 = model._head_fused(xs[:2], b, False, {})
+    _, want2 = _head_reference(model, xs[:2], b, 'sum', 'sum')
+    gate(out2, want2, 'head without dimension 2')
