@@ -203,6 +203,11 @@ def main():
         b0.set_xs(layer_inputs[0][0])
         probe_plans, _ = model.convs[0].propagate_all(*b0.get_all_cochain_params(max_dim=2, include_down_features=False))
         BLOCKED = probe_plans[0] == 'blocked'
+        FORM = None
+        if BLOCKED:
+            t_ = model.convs[0]._blocked_args(b0.get_all_cochain_params(max_dim=2, include_down_features=False), 0)[2]
+            FORM = {'variant': t_.variant, 'items_per_launch': t_.n_items,
+                    'form': '16 waves, one workgroup per CU' if t_.variant == 0 else '8 waves <= 128 VGPRs <= 80 KiB LDS, two workgroups per CU'}
         if rank == 0:
             print(f'[bench] complex-blocked layer kernel: {BLOCKED}'
                   + ('' if BLOCKED else f' ({model.convs[0].blocked_reason})'), file=sys.stderr)
@@ -407,6 +412,7 @@ def main():
     # ---- rooflines: both kernels of a layer are measured live; the one with the larger share of the
     # step is `roofline` (dominant), the other `roofline_other` ---------------------------------------
     roofline = roofline_other = r_plan = roofline_mlp = None
+    forward_breakdown = {}
     if rank == 0 and not args.only_primary and 'roofline' not in SKIP:
 
         def replay_us(fn, reps):
@@ -503,6 +509,22 @@ def main():
                                     'weights out of L2 (weight_stream_bytes_per_launch), which is what bounds it at this batch size'}
             except Exception as e:
                 print(f'[bench] update-mlp roofline failed: {type(e).__name__}: {e}', file=sys.stderr)
+            # where a full forward goes, launch by launch (the same back-to-back replay measurement)
+            try:
+                with torch.no_grad():
+                    bb = reset_inputs(0)
+                    prm0 = bb.get_all_cochain_params(max_dim=2, include_down_features=False)
+                    if hasattr(model, 'init_conv'):
+                        front_us = replay_us(lambda: model.init_conv(*prm0), args.kernel_reps)
+                        forward_breakdown['front_us'] = round(front_us, 3)
+                    xs_ = [x.contiguous() for x in layer_inputs[0][L - 1]]
+                    if model._head_fused(xs_, bb, False, {}) is not None:
+                        forward_breakdown['head_us'] = round(replay_us(lambda: model._head_fused(xs_, bb, False, {}), args.kernel_reps), 3)
+                    forward_breakdown['propagate_us_per_layer'] = round(load_us, 3)
+                    if roofline_mlp is not None:
+                        forward_breakdown['update_mlp_us_per_layer'] = roofline_mlp['avg_launch_us']
+            except Exception as e:
+                print(f'[bench] forward breakdown failed: {type(e).__name__}: {e}', file=sys.stderr)
             eq_peak = MFMA_BF16_PEAK_TF / 6.0
             roofline_other = {
                 'bound': 'mfma', 'kernel': 'the same launch against the matrix pipe: six v_mfma_f32_16x16x32_bf16 per '
@@ -799,7 +821,7 @@ def main():
                        'E_up': [s0['E_up0'], s0['E_up1'], s0['E_up2']],
                        'B': [s0['B0'], s0['B1'], s0['B2']],
                        'launch': 'hipGraph replay' if use_graph else 'eager',
-                       'plan_build_in_step': not BLOCKED, 'layer_kernel': 'complex-blocked (1 launch per layer, COO in, no CSR plan)' if BLOCKED else 'grouped GEMM + CSR aggregation (2 launches per layer + 1 plan build per batch)', 'dense_arithmetic': dense,
+                       'plan_build_in_step': not BLOCKED, 'layer_kernel_form': FORM, 'layer_kernel': 'complex-blocked (1 launch per layer, COO in, no CSR plan)' if BLOCKED else 'grouped GEMM + CSR aggregation (2 launches per layer + 1 plan build per batch)', 'dense_arithmetic': dense,
                        'parallelism': f'replicas x{world} (no data-path collective)'},
             'roofline': roofline, 'roofline_other': roofline_other, 'roofline_mlp': roofline_mlp, 'roofline_plan_build': r_plan,
             'roofline_step': roofline_step,
@@ -809,6 +831,7 @@ def main():
                           'full_forward_ms': round(dt_full / full_steps * 1e3, 5) if dt_full == dt_full else None,
                           'scope': 'EmbedSparseCIN forward: embedding, 4 conv layers incl. update '
                                    'MLPs + BatchNorm(eval), readout, head',
+                          'forward_breakdown': forward_breakdown or None,
                           'collate': collate, 'concurrent_streams': concurrent, 'train_step': train,
                           'eager_launches': eager},
         }

@@ -16,14 +16,15 @@
 namespace {
 
 constexpr int kInts = CWN_LAYER_ITEM_INTS;
-constexpr int64_t kLds = 160 * 1024;
 constexpr int kTargetItems = 128;      // per GEMM dimension: ~one workgroup per CU over the two sets of a 2-complex
 
 inline int64_t pad16(int64_t n) { return (n + 15) / 16 * 16; }
 inline int64_t pad4(int64_t n) { return (n + 3) / 4 * 4; }
 
 struct Shape {
-    int F, round_rows;
+    int F, round_rows, variant;
+    int64_t kLds;                      // LDS budget of a workgroup of this variant
+    int64_t half_cap;                  // bound of the (padded) rows of ONE product, or 0: only the sum is bounded
     int64_t first_coface_row(int64_t n_g, int64_t n_c) const {
         const int64_t r1 = pad16(n_g);
         return n_c > 0 ? (r1 + round_rows - 1) / round_rows * round_rows : r1;
@@ -31,7 +32,7 @@ struct Shape {
     int64_t staged(int64_t n_g, int64_t n_c) const { return n_c > 0 ? first_coface_row(n_g, n_c) + pad16(n_c) : pad16(n_g); }
     // = cwn_layer_fused_lds_bytes without its argument checks
     int64_t lds(int64_t rows, int64_t src) const {
-        static const int64_t idx = (int64_t)cwn_layer_fused_lds_bytes(128, 16, 0) - 3 * 16 * (128 + 8) * 2 - 128 * 4;
+        static const int64_t idx = (int64_t)cwn_layer_fused_lds_bytes(128, 16, 0) - 3 * 16 * (128 + 8) * 2 - 128 * 4;   // same in both variants
         return 3 * rows * (F + 8) * 2 + (src + 1) * F * 4 + idx;
     }
 };
@@ -64,8 +65,8 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
     out.clear();
     Set sets[CWN_LAYER_MAX_DIMS];
     const int n_sets = make_sets(in, sets);
-    const int64_t gmax = std::max<int64_t>(1, C / kTargetItems);
-    int64_t max_rows = 0, max_src = 0;
+    const int64_t gmax = std::max<int64_t>(1, C / (sh.variant == 1 ? 2 * kTargetItems : kTargetItems));   // two workgroups a CU
+    int64_t max_rows = 0, max_src = 0, max_item_lds = 0;
     std::vector<int32_t> recs;
     std::vector<int64_t> weight;
     std::vector<int64_t> order;
@@ -89,11 +90,14 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
                 bool ok = true;
                 for (int t = 0; t < S.n_tasks; ++t) {
                     const int d = S.tasks[t];
-                    if (d > 0 && span(bp[t], c0, nxt) > 0) src += cells(d - 1, c0, nxt);
+                    // (two-per-CU form: only task 0's sources are loaded into LDS; task 1 reads the staged cells of g)
+                    if (d > 0 && span(bp[t], c0, nxt) > 0 && (sh.variant == 0 || t == 0)) src += cells(d - 1, c0, nxt);
                     ents += pad4(span(bp[t], c0, nxt));
                     ok = ok && cells(d, c0, nxt) <= CWN_LAYER_TASK_ROWS;
                 }
-                ok = ok && rows <= row_cap && src <= src_cap && sh.lds(rows, src) <= kLds && ents <= CWN_LAYER_MAX_ENTRIES;
+                ok = ok && rows <= row_cap && src <= src_cap && sh.lds(rows, src) <= sh.kLds && ents <= CWN_LAYER_MAX_ENTRIES;
+                if (sh.half_cap > 0 && g >= 0)
+                    ok = ok && pad16(cells(d0, c0, nxt)) <= sh.half_cap && pad16(cells(g + 1, c0, nxt)) <= sh.half_cap;
                 if (!ok) break;
                 c1 = nxt;
             }
@@ -123,7 +127,7 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
             }
             max_rows = std::max(max_rows, sh.staged(n0, nc));
             r[8] = live;
-            int64_t src = 0, bne[2] = {0, 0};
+            int64_t src = 0, src_lds = 0, bne[2] = {0, 0};
             for (int t = 0; t < live; ++t) {
                 const int d = S.tasks[t], o = 9 + 7 * t;
                 bne[t] = span(bp[t], c0, c1);
@@ -136,9 +140,11 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
                     r[o + 5] = (int32_t)in.cell_ptr[d - 1][c0];
                     r[o + 6] = (int32_t)cells(d - 1, c0, c1);
                     src += r[o + 6];
+                    if (sh.variant == 0 || t == 0) src_lds += r[o + 6];
                 }
             }
-            max_src = std::max(max_src, src);
+            max_src = std::max(max_src, sh.variant == 0 ? src : src_lds);
+            max_item_lds = std::max(max_item_lds, sh.lds(sh.staged(n0, nc), src_lds));
             const int64_t b1 = pad4(une), b2 = pad4(b1 + bne[0]);
             r[23] = (int32_t)sh.first_coface_row(n0, nc);
             r[24] = (int32_t)sh.staged(n0, nc);
@@ -161,7 +167,8 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
     plan.n_items = (int64_t)(out.size() / kInts);
     plan.max_gemm_rows = (int32_t)std::max<int64_t>(max_rows, 16);
     plan.max_source_rows = (int32_t)max_src;
-    plan.pad_ = 0;
+    plan.variant = sh.variant;
+    plan.lds_bytes = sh.variant == 1 ? max_item_lds : 0;
     for (int d = 0; d < CWN_LAYER_MAX_DIMS; ++d) {
         const bool on = d < in.n_dims;
         plan.cells_end[d] = on ? in.cell_ptr[d][C] : 0;
@@ -192,21 +199,29 @@ extern "C" int64_t cwn_layer_items_build(const cwn_layer_sizes* in, int32_t F, i
         if (in->up_ptr[d] != nullptr && !prefix_sum(in->up_ptr[d])) return CWN_LAYER_ITEMS_BAD_ARG;
         if (in->b_ptr[d] != nullptr && !prefix_sum(in->b_ptr[d])) return CWN_LAYER_ITEMS_BAD_ARG;
     }
-    const Shape sh{F, cwn_layer_round_rows(F)};
+    const int variant = plan->variant;
+    if (variant != 0 && variant != 1) return CWN_LAYER_ITEMS_BAD_ARG;
+    const Shape sh{F, cwn_layer_variant_round_rows(F, variant), variant, variant == 1 ? (int64_t)CWN_LAYER_W8_LDS_BYTES : (int64_t)160 * 1024,
+                   variant == 1 ? (int64_t)CWN_LAYER_W8_HALF_ROWS(F) : (int64_t)0};
+    const int64_t kLds = sh.kLds;
     if (sh.round_rows <= 0) return CWN_LAYER_ITEMS_BAD_ARG;
     // one launch = one LDS size: the planes for the LARGEST staged block of any item plus the sources of the item with
     // the most of them (different items, in general).  A few splits of the LDS between the two are tried -- row cap
     // from the top down, the source cap = what is left -- and the one with the fewest items wins
-    const int64_t cap = CWN_LAYER_GEMM_ROWS(F), src_max = CWN_LAYER_SOURCE_ROWS(F), step = std::max<int64_t>(16, cap / 8);
+    const int64_t cap = variant == 1 ? CWN_LAYER_W8_GEMM_ROWS(F) : CWN_LAYER_GEMM_ROWS(F);
+    const int64_t src_max = variant == 1 ? CWN_LAYER_W8_SOURCE_ROWS(F) : CWN_LAYER_SOURCE_ROWS(F), step = std::max<int64_t>(16, cap / 8);
     std::vector<int32_t> cur, best;
     cwn_layer_plan pc = *plan, pb = *plan;
     bool have = false, too_big = false;
     for (int64_t row_cap = cap; row_cap >= step; row_cap -= step) {
-        const int64_t src_cap = std::min(src_max, (kLds - sh.lds(row_cap, -1)) / (F * 4) - 1);
+        // variant 1: every item lays out its own rows, so rows and sources are coupled per ITEM (inside build_with) and
+        // one pass with both caps at their maxima is the whole search
+        const int64_t src_cap = variant == 1 ? src_max : std::min(src_max, (kLds - sh.lds(row_cap, -1)) / (F * 4) - 1);
         if (src_cap < 16) continue;
         const int64_t n = build_with(*in, sh, row_cap, src_cap, cur, pc);
-        if (n < 0) { too_big = true; continue; }
-        if (n == 0 || sh.lds(pc.max_gemm_rows, pc.max_source_rows) > kLds) continue;
+        if (n < 0) { too_big = true; if (variant == 1) break; continue; }
+        if (n == 0 || (variant == 0 && sh.lds(pc.max_gemm_rows, pc.max_source_rows) > kLds)) continue;
+        if (variant == 1) { best.swap(cur); pb = pc; have = true; break; }
         if (!have || n < pb.n_items) {
             best.swap(cur);
             pb = pc;

@@ -66,6 +66,22 @@ using cwn::frag_cd;
 // are each bound by instruction latency, not by a pipe, so twice the waves finish every thread-parallel
 // phase (split, boundary stream, reduce) in about half the time.  What pays for it: a wave holds the
 // packed weight of ONE of the two products (Y1 or Y2) -- 48 registers instead of 96.
+// CWN_LAYER_W8 (a second compilation of this file, csrc/Makefile: cwn_layer_w8.o): the TWO-PER-CU form.  512
+// threads = 8 waves at <= 128 VGPRs and <= 80 KiB of LDS, so that two workgroups are resident on a CU and one
+// item's load / sort phases run under the other's matrix-core / reduce phases.  The 16-wave form owns a CU
+// (register file and LDS) for the whole of its ~6 us chain: fine while a launch has no more items than the chip has
+// CUs, 0.54 - 0.62 of the achievable rate beyond that (863 M cells/s at batch 8192 against 981 M of the
+// streaming CSR path).  What differs from the 16-wave form is marked `kW8`: a wave multiplies BOTH products of its
+// column tile, one after the other, through ONE set of weight registers (the k steps of the second weight are
+// requested into the registers the first product has finished with), and the self terms of the upper reduce are
+// read again instead of being held in registers across the matrix-core phase.
+#ifdef CWN_LAYER_W8
+#undef CWN_LAYER_THREADS
+#define CWN_LAYER_THREADS 512
+#define CWN_W8 1
+#else
+#define CWN_W8 0
+#endif
 #ifndef CWN_LAYER_THREADS
 #define CWN_LAYER_THREADS 1024
 #endif
@@ -85,7 +101,13 @@ using cwn::frag_cd;
 constexpr int kThreads = CWN_LAYER_THREADS;
 static_assert(kThreads == 512 || kThreads == 1024, "8 or 16 waves");
 constexpr int kWaves = kThreads / 64;
-constexpr int kHS = kThreads == 1024 ? 2 : 1;   // 2: a wave computes Y1 OR Y2; 1: both
+constexpr bool kW8 = CWN_W8 != 0;
+constexpr int kHS = kThreads == 1024 ? 2 : 1;   // 2: a wave computes Y1 OR Y2; 1: both (kW8: one after the other)
+constexpr int kWSets = kW8 ? 1 : 2 / kHS;       // register sets of packed weight a wave holds
+// caps of an item (include/cwn_hip.h): the 16-wave form's, or the two-per-CU form's
+constexpr size_t kLdsBudget = kW8 ? CWN_LAYER_W8_LDS_BYTES : 160 * 1024;
+__host__ __device__ constexpr int gemm_rows_cap(int F) { return kW8 ? CWN_LAYER_W8_GEMM_ROWS(F) : CWN_LAYER_GEMM_ROWS(F); }
+__host__ __device__ constexpr int source_rows_cap(int F) { return kW8 ? CWN_LAYER_W8_SOURCE_ROWS(F) : CWN_LAYER_SOURCE_ROWS(F); }
 constexpr int kEcap = CWN_LAYER_MAX_ENTRIES;
 constexpr int kEI = kEcap / kThreads;       // COO entries per thread
 constexpr int kTaskRows = CWN_LAYER_TASK_ROWS;
@@ -112,6 +134,7 @@ struct LayerArgs {
     int32_t rows_cap;                        // staged rows (GEMM operands) the LDS of this launch holds
     int32_t xrows_cap;                       // boundary-source rows it holds
     int32_t set_start1, set_start2;          // first workgroup of set 1 / set 2 (items are ordered by set)
+    int32_t lds_limit;                       // dynamic LDS bytes of this launch (kW8: every item lays out its own rows inside it)
 #ifdef CWN_LAYER_TIMING
     unsigned long long* stamps;              // [n_items][64]: [0, 16) phase ends seen by wave 0, [16 + 16 k + w] point k of wave w
 #endif
@@ -141,9 +164,12 @@ template <int F> struct Geo {
     static constexpr int kWPC = kWaves / kNCT / kHS;        // waves sharing a column tile of a product (row-tile parity)
     static constexpr int kG = F / 4;                        // lanes per row
     static constexpr int kNG = kThreads / kG;               // rows per round (1024 threads: 32 at F = 128, 64 at F = 64)
-    static constexpr int kNX = CWN_LAYER_GEMM_ROWS(F) / kNG;     // float4 of staged rows per thread at the row cap
-    static constexpr int kNE = CWN_LAYER_SOURCE_ROWS(F) / kNG;   // float4 of boundary-source rows per thread at the cap
-    static_assert(CWN_LAYER_GEMM_ROWS(F) % kNG == 0 && CWN_LAYER_SOURCE_ROWS(F) % kNG == 0, "caps are whole rounds");
+    static constexpr int kNX = gemm_rows_cap(F) / kNG;           // float4 of staged rows per thread at the row cap
+    static constexpr int kNE = source_rows_cap(F) / kNG;         // float4 of boundary-source rows per thread at the cap
+    static_assert(gemm_rows_cap(F) % kNG == 0 && source_rows_cap(F) % kNG == 0, "caps are whole rounds");
+    // 16-row tiles of ONE product a wave multiplies (its accumulators wait in registers until every wave has read its
+    // fragments); the two-per-CU form bounds the rows of each product separately (CWN_LAYER_W8_HALF_ROWS)
+    static constexpr int kMaxT = kW8 ? CWN_LAYER_W8_HALF_ROWS(F) / 16 / kWPC : gemm_rows_cap(F) / 16 / kWPC;
     static constexpr int kWChunks = 2 * kKS * 3;            // 1-KiB chunks of the packed weight per column tile
     // planes [3][rows][F + 8] bf16, overwritten by Y [rows][F + 4] fp32 once the MFMAs have read them
     __host__ __device__ static constexpr size_t planes_bytes(int rows) { return (size_t)3 * rows * kPlaneStride * 2; }
@@ -279,6 +305,52 @@ __device__ __forceinline__ void gather_sum(float4 (&acc)[NR], const RowSet<NR>& 
     }
 }
 
+// Two-per-CU form of the boundary pass: chain 0 (task 0) reads fp32 source rows as above; chain 1 (task 1: the top
+// dimension, whose sources are the STAGED cells of g) reads them out of the three bf16 planes -- source number
+// v >= first1 is staged row v - first1, and hi + mid + lo is the fp32 value bit for bit (cwn_split.h: every step of
+// the split is exact) -- so that no second fp32 copy of those rows occupies LDS.  Same entry order, same sums.
+template <int F>
+__device__ __forceinline__ void gather_sum_planes(float4 (&acc)[2], const RowSet<2>& R, int steps,
+                                                  const uint16_t* const (&cols)[2], const float* src, int zero_row,
+                                                  const uint16_t* planes, size_t plane, int first1, int f) {
+    constexpr int kPS = F + 8;
+    acc[0] = acc[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto up = [](uint32_t w, bool hi) { return __uint_as_float(hi ? (w & 0xFFFF0000u) : (w << 16)); };
+    for (int q = 0; q < steps; q += 2) {
+        int c0[2], c1[2];
+        bool on1[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int p0 = R.s[0] + q + v, p1 = R.s[1] + q + v;
+            const int a = cols[0][min(p0, max(R.e[0] - 1, 0))], b = cols[1][min(p1, max(R.e[1] - 1, 0))];
+            c0[v] = p0 < R.e[0] ? a : zero_row;
+            on1[v] = p1 < R.e[1];
+            c1[v] = on1[v] ? b - first1 : 0;
+        }
+        float4 a0[2];
+        uint2 h[2], m[2], l[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            a0[v] = lds4(src + (size_t)c0[v] * F + f);
+            const uint16_t* pr = planes + (size_t)c1[v] * kPS + f;
+            h[v] = *reinterpret_cast<const uint2*>(pr);
+            m[v] = *reinterpret_cast<const uint2*>(pr + plane);
+            l[v] = *reinterpret_cast<const uint2*>(pr + 2 * plane);
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            acc[0].x += a0[v].x; acc[0].y += a0[v].y; acc[0].z += a0[v].z; acc[0].w += a0[v].w;
+            float4 x;
+            x.x = (up(h[v].x, false) + up(m[v].x, false)) + up(l[v].x, false);
+            x.y = (up(h[v].x, true) + up(m[v].x, true)) + up(l[v].x, true);
+            x.z = (up(h[v].y, false) + up(m[v].y, false)) + up(l[v].y, false);
+            x.w = (up(h[v].y, true) + up(m[v].y, true)) + up(l[v].y, true);
+            x = sel4(on1[v], x, make_float4(0.f, 0.f, 0.f, 0.f));
+            acc[1].x += x.x; acc[1].y += x.y; acc[1].z += x.z; acc[1].w += x.w;
+        }
+    }
+}
+
 // sum of relu(Y1[col[p]] + Y2[aux[p]]) over each row's entries (y2_off = first Y2 row - 0)
 template <int NR, int NG, int YS>
 __device__ __forceinline__ void gather_relu_sum(float4 (&acc)[NR], const RowSet<NR>& R, int steps, const uint16_t* col,
@@ -321,23 +393,17 @@ __device__ __forceinline__ float4 axpy4(const float4& acc, float s, const float4
     return make_float4(acc.x + s * x.x, acc.y + s * x.y, acc.z + s * x.z, acc.w + s * x.w);
 }
 
+#if CWN_W8
+#define CWN_LAYER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs: two workgroups of 8 waves a CU
+#else
+#define CWN_LAYER_OCCUPANCY
+#endif
 template <int F, int MODE>
-__global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
+__global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(LayerArgs A) {
     using G = Geo<F>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int rows_cap = A.rows_cap;
-
-    uint16_t* const planes = reinterpret_cast<uint16_t*>(smem);                    // [3][rows_cap][F + 8]
-    float* const Y = reinterpret_cast<float*>(smem);                               // [rows_cap][F + 4], later
-    float* const xsrc = reinterpret_cast<float*>(smem + G::planes_bytes(rows_cap)); // [xrows_cap][F]
-    unsigned char* const idx = smem + G::planes_bytes(rows_cap) + G::xrows_bytes(A.xrows_cap);
-    uint32_t* const ecnt = reinterpret_cast<uint32_t*>(idx);        // [3][kRpStride] entries per destination row (sort modes)
-    uint16_t* const eslot = reinterpret_cast<uint16_t*>(idx + kCntBytes);   // [kEcap] entry numbers grouped by row (sort modes)
-    uint16_t* const scol = eslot + kEcap;                           // sorted by destination, stable: local source row
-    uint16_t* const saux = eslot + 2 * kEcap;                       //                                 local shared (coface) row
-    uint16_t* const rowptr = eslot + 3 * kEcap;  // [3][kRpStride]: upper, boundary of task 0, of task 1
 
     CWN_STAMP(0);
     CWN_WSTAMP(0);           // every wave: when it starts
@@ -357,7 +423,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // wave-uniform: scalar registers from here on
     const int ct = wave_u % G::kNCT, w2 = wave_u / G::kNCT;
     const int my_h = kHS == 2 ? (w2 & 1) : 0, rt_par = w2 / kHS;   // this wave's product (kHS == 2), row-tile parity
-    uint4 wsp[2 / kHS][G::kKS][3];
+    uint4 wsp[kWSets][G::kKS][3];
     constexpr int kWEarly = CWN_LAYER_WEARLY < 0 ? G::kKS / 2 : (CWN_LAYER_WEARLY < G::kKS ? CWN_LAYER_WEARLY : G::kKS);
     __builtin_amdgcn_sched_barrier(0);       // both record loads leave before the scalar load below is waited for
     const uint64_t wp_bits =
@@ -373,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         return ldgu4o(wbase, wlane + (uint32_t)(((ks * 3 + pl) * 2 + h) * G::kNCT) * won);
     };
 #pragma unroll
-    for (int hh = 0; hh < 2 / kHS; ++hh) {
+    for (int hh = 0; hh < kWSets; ++hh) {
         const int h = kHS == 2 ? my_h : hh;
 #pragma unroll
         for (int ks = 0; ks < kWEarly; ++ks)
@@ -411,14 +477,33 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     const int b1 = fld(I_B1), b2 = fld(I_B2), total = fld(I_TOTAL);
     // boundary sources in LDS: [0, t_sn[0]) cells of dim g-1 (loaded), then the g_n cells of dim g (copied
     // from the staged rows) when task 1 reads them
-    const int x_rows = t_sn[0] + t_sn[1];
+    // (two-per-CU form: task 1 reads the cells of g out of the bf16 planes -- hi + mid + lo is x, exactly -- so that
+    // only the loaded sources take LDS; 80 KiB do not hold a second fp32 copy of the edges)
+    const int x_rows = kW8 ? t_sn[0] : t_sn[0] + t_sn[1];
+    // LDS layout.  16-wave form: one layout per LAUNCH (the largest staged block and the most sources of any item).
+    // Two-per-CU form: every item lays out ITS OWN rows (a vertex item has many staged rows and no sources, an
+    // edges + rings item the other way round: one shared layout would need the sum of both maxima).
+    const int rows_cap = kW8 ? rows_pad : A.rows_cap;
+    const int xrows_cap = kW8 ? x_rows : A.xrows_cap;
+    uint16_t* const planes = reinterpret_cast<uint16_t*>(smem);                    // [3][rows_cap][F + 8]
+    float* const Y = reinterpret_cast<float*>(smem);                               // [rows_cap][F + 4], later
+    float* const xsrc = reinterpret_cast<float*>(smem + G::planes_bytes(rows_cap)); // [xrows_cap][F]
+    unsigned char* const idx = smem + G::planes_bytes(rows_cap) + G::xrows_bytes(xrows_cap);
+    uint32_t* const ecnt = reinterpret_cast<uint32_t*>(idx);        // [3][kRpStride] entries per destination row (sort modes)
+    uint16_t* const eslot = reinterpret_cast<uint16_t*>(idx + kCntBytes);   // [kEcap] entry numbers grouped by row (sort modes)
+    uint16_t* const scol = eslot + kEcap;                           // sorted by destination, stable: local source row
+    uint16_t* const saux = eslot + 2 * kEcap;                       //                                 local shared (coface) row
+    uint16_t* const rowptr = eslot + 3 * kEcap;  // [3][kRpStride]: upper, boundary of task 0, of task 1
     const int gl = tid % G::kG, gq = tid / G::kG, f = gl * 4;  // lane group gq finishes rows gq, gq + kNG, ...
     constexpr uint32_t kRowB = F * 4;                          // bytes per row
     const uint32_t fB = (uint32_t)f * 4;
     CWN_STAMP(10);
     // What stays checked here: that the record fits the LDS of this launch (memory safety inside the
     // workgroup).  Uniform over the workgroup; unsigned compares also catch negative fields.
-    if ((unsigned)rows_pad > (unsigned)rows_cap || (unsigned)x_rows > (unsigned)A.xrows_cap || (unsigned)total > (unsigned)kEcap ||
+    const bool fits = kW8 ? ((unsigned)rows_pad <= (unsigned)gemm_rows_cap(F) && (unsigned)x_rows <= (unsigned)source_rows_cap(F) &&
+                             lds_bytes<F>(rows_pad, x_rows) <= (size_t)A.lds_limit)
+                          : ((unsigned)rows_pad <= (unsigned)rows_cap && (unsigned)x_rows <= (unsigned)xrows_cap);
+    if (!fits || (unsigned)total > (unsigned)kEcap ||
         (unsigned)t_n[0] > (unsigned)kTaskRows || (unsigned)t_n[1] > (unsigned)kTaskRows || (unsigned)R1 > (unsigned)rows_pad) {
         if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
         return;
@@ -521,7 +606,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
-    for (int hh = 0; hh < 2 / kHS; ++hh) {
+    for (int hh = 0; hh < kWSets; ++hh) {
         const int h = kHS == 2 ? my_h : hh;
 #pragma unroll
         for (int ks = kWEarly; ks < G::kKS; ++ks)
@@ -641,7 +726,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     // ---- 4. GEMM rows -> three bf16 planes; boundary-source rows -> fp32 -------------------------------
     {
         const size_t plane = (size_t)rows_cap * G::kPlaneStride;
-        const bool copy_src = t_sn[1] > 0;      // task 1 gathers the staged cells of g: keep them as fp32 too
+        const bool copy_src = !kW8 && t_sn[1] > 0;      // task 1 gathers the staged cells of g: keep them as fp32 too
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
             const int row = gq + i * G::kNG;
@@ -722,7 +807,10 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
             }
             float4 acc[2];
             const float4 xi[2] = {pick(xv, k), pick(xv, k0 + k)};     // self terms: this group loaded them
-            gather_sum<2, F>(acc, R, steps, cols, xsrc, x_rows, f);
+            if constexpr (kW8)
+                gather_sum_planes<F>(acc, R, steps, cols, xsrc, x_rows, planes, (size_t)rows_cap * G::kPlaneStride, t_sn[0], f);
+            else
+                gather_sum<2, F>(acc, R, steps, cols, xsrc, x_rows, f);
             const uint32_t off = (uint32_t)r * kRowB + fB;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -743,18 +831,75 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     float4 b4 = ldg4(has_bias ? bias + ct * 16 + kq * 4 : dummy);
     if (!has_bias) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int T1 = (g_n + 15) >> 4, T2 = (c_n + 15) >> 4;      // 16-row tiles of Y1, Y2
-    {
+    if constexpr (kW8) {
+        // Two-per-CU form: this wave multiplies BOTH products of its column tile, Y1 first.  k steps outermost: when
+        // the row tiles of a k step are done, its three weight registers are free and the same k step of the SECOND
+        // weight is requested into them -- it lands under the remaining MFMAs of the first product.  Per tile the
+        // accumulation order (k steps ascending, six terms each) is the 16-wave form's: bit-identical results.
+        constexpr int kMaxT = G::kMaxT;
+        const size_t plane = (size_t)rows_cap * G::kPlaneStride;
+        frag_cd acc[2][kMaxT];
+        if ((unsigned)T1 > (unsigned)(kMaxT * G::kWPC) || (unsigned)T2 > (unsigned)(kMaxT * G::kWPC)) {   // table / kernel mismatch
+            if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rt0 = h == 0 ? 0 : R1 / 16, rt1 = rt0 + (h == 0 ? T1 : T2);
+            const int first = rt0 + ((rt_par - rt0) % G::kWPC + G::kWPC) % G::kWPC;
+#pragma unroll
+            for (int j = 0; j < kMaxT; ++j) acc[h][j] = frag_cd{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < G::kKS; ++ks) {
+#pragma unroll
+                for (int j = 0; j < kMaxT; ++j) {
+                    const int rt = first + j * G::kWPC;
+                    if (rt < rt1) {                  // uniform over the wave
+                        const uint16_t* p0 = planes + (size_t)(rt * 16 + l15) * G::kPlaneStride + kq * 8 + ks * 32;
+                        const uint4 xh0 = *reinterpret_cast<const uint4*>(p0);
+                        const uint4 xm0 = *reinterpret_cast<const uint4*>(p0 + plane);
+                        const uint4 xl0 = *reinterpret_cast<const uint4*>(p0 + 2 * plane);
+                        acc[h][j] = cwn::mfma_split6(wsp[0][ks][0], wsp[0][ks][1], wsp[0][ks][2], xh0, xm0, xl0, acc[h][j]);
+                    }
+                }
+                if (h == 0) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wsp[0][ks][pl] = wload(1, ks, pl);
+                }
+            }
+        }
+        __syncthreads();                     // every wave has read its fragments: Y may overwrite the planes
+        CWN_STAMP(6);
+        if (gq == 0) *reinterpret_cast<float4*>(Y + (size_t)rows_cap * G::kYStride + f) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rt0 = h == 0 ? 0 : R1 / 16, rt1 = rt0 + (h == 0 ? T1 : T2);
+            const int first = rt0 + ((rt_par - rt0) % G::kWPC + G::kWPC) % G::kWPC;
+#pragma unroll
+            for (int j = 0; j < kMaxT; ++j) {
+                const int rt = first + j * G::kWPC;
+                if (rt < rt1) {
+                    frag_cd c = acc[h][j];
+                    if (h == 0 && has_bias) {
+                        c[0] += b4.x; c[1] += b4.y; c[2] += b4.z; c[3] += b4.w;
+                    }
+                    float* y0 = Y + (size_t)(rt * 16 + l15) * G::kYStride + ct * 16 + kq * 4;
+                    *reinterpret_cast<float4*>(y0) = make_float4(c[0], c[1], c[2], c[3]);
+                }
+            }
+        }
+    } else {
         const size_t plane = (size_t)rows_cap * G::kPlaneStride;
         // this wave's row tiles: at most kMaxT per half (six 16-row tiles in all at the row cap); the
         // accumulators wait in registers until every wave has read its fragments, because Y
         // overwrites the planes.  Tiles go in PAIRS (two independent MFMA chains in flight).
-        constexpr int kMaxT = CWN_LAYER_GEMM_ROWS(F) / 16 / G::kWPC;
+        constexpr int kMaxT = G::kMaxT;
         static_assert(kMaxT % 2 == 0, "tiles are processed in pairs");
         static_assert(offsetof(LayerArgs, set) == 0, "read through the kernarg segment pointer");
         static_assert(kSetFields <= 64 && CWN_LAYER_ITEM_INTS <= 64, "one lane per field");
-        frag_cd acc[2 / kHS][kMaxT];
+        frag_cd acc[kWSets][kMaxT];
 #pragma unroll
-        for (int hh = 0; hh < 2 / kHS; ++hh) {
+        for (int hh = 0; hh < kWSets; ++hh) {
             const int h = kHS == 2 ? my_h : hh;
             const uint4 (&wf)[G::kKS][3] = wsp[hh];
             const int rt0 = h == 0 ? 0 : R1 / 16, rt1 = rt0 + (h == 0 ? T1 : T2);
@@ -801,7 +946,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
         if (gq == 0) *reinterpret_cast<float4*>(Y + (size_t)rows_cap * G::kYStride + f) = make_float4(0.f, 0.f, 0.f, 0.f);
         // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = x row (lane & 15); Y1 carries the bias
 #pragma unroll
-        for (int hh = 0; hh < 2 / kHS; ++hh) {
+        for (int hh = 0; hh < kWSets; ++hh) {
             const int h = kHS == 2 ? my_h : hh;
             const int rt0 = h == 0 ? 0 : R1 / 16, rt1 = rt0 + (h == 0 ? T1 : T2);
             const int first = rt0 + ((rt_par - rt0) % G::kWPC + G::kWPC) % G::kWPC;
@@ -831,8 +976,17 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
             RowSet<kNR> R;
             float4 acc[kNR], xi[kNR];
             const int steps = row_ranges<kNR, G::kNG>(R, rowptr, gq + k * G::kNG, g_n);
+            if constexpr (kW8) {
+                // the rows this lane group loaded in phase 2 are not held across the matrix-core phase (128 registers):
+                // requested again here (L2), they land under the reduce's LDS chain
+                const gcb_p xg = (gcb_p)sfld(S_XG) + (size_t)t_r0[0] * kRowB;
 #pragma unroll
-            for (int u = 0; u < kNR; ++u) xi[u] = pick(xv, k + u);
+                for (int u = 0; u < kNR; ++u)
+                    xi[u] = ldg4o(xg, (uint32_t)min(gq + (k + u) * G::kNG, g_n - 1) * kRowB + fB);
+            } else {
+#pragma unroll
+                for (int u = 0; u < kNR; ++u) xi[u] = pick(xv, k + u);
+            }
             gather_relu_sum<kNR, G::kNG, G::kYStride>(acc, R, steps, scol, saux, Y, Y2, rows_cap, rows_cap - R1, f);
 #pragma unroll
             for (int u = 0; u < kNR; ++u)
@@ -843,6 +997,7 @@ __global__ __launch_bounds__(kThreads) void layer_kernel(LayerArgs A) {
     CWN_STAMP(8);
 }
 
+#if !CWN_W8
 // fp32 [F, 2F] weight of the message Linear -> bf16 hi / mid / lo planes in MFMA-fragment order: the 1-KiB
 // chunk number ((ks * 3 + plane) * 2 + h) * NCT + ct holds, for lane l = kq * 16 + n, the eight k-values
 // W[ct * 16 + n][h * F + ks * 32 + kq * 8 ..] of that plane (16 bytes per lane).
@@ -864,6 +1019,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     *reinterpret_cast<uint4*>(dst + kPlane) = pm;
     *reinterpret_cast<uint4*>(dst + 2 * kPlane) = pl;
 }
+#endif
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
@@ -877,45 +1033,55 @@ int launch(LayerArgs& A, int64_t n_items, hipStream_t stream) {
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
         attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel<F, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     });
     if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
 #ifdef CWN_LAYER_TIMING
     A.stamps = g_stamps;
 #endif
-    const size_t lds = lds_bytes<F>(A.rows_cap, A.xrows_cap);
+    const size_t lds = kW8 ? (size_t)A.lds_limit : lds_bytes<F>(A.rows_cap, A.xrows_cap);
     layer_kernel<F, MODE><<<dim3((unsigned)n_items), dim3(kThreads), lds, stream>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
 }  // namespace
 
-#ifdef CWN_LAYER_TIMING
+// The entry points of THIS compilation of the file: the public names (16-wave form, include/cwn_hip.h), or -- in the
+// second compilation (CWN_LAYER_W8) -- the same four functions of the two-per-CU form under internal names, which
+// the public ones dispatch to on cwn_layer_plan.variant.
+#if CWN_W8
+#define CWN_FN(name) cwn_layer_w8_##name
+#else
+#define CWN_FN(name) cwn_layer_v0_##name
+extern "C" int32_t cwn_layer_w8_round_rows(int32_t F);
+extern "C" size_t cwn_layer_w8_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows);
+extern "C" int cwn_layer_w8_items_check(const int32_t* items, int64_t n_items, int32_t F, const cwn_layer_plan* plan);
+extern "C" int cwn_layer_w8_launch(const cwn_layer_dim* dims, int n_dims, int32_t F, const cwn_layer_plan* plan,
+                                   int32_t flags, int32_t* err_flag, cwn_stream_t stream_);
+#endif
+
+#if defined(CWN_LAYER_TIMING) && !CWN_W8
 extern "C" void cwn_layer_debug_stamps(unsigned long long* buf) { g_stamps = buf; }
 #endif
 
-extern "C" size_t cwn_layer_packed_weight_bytes(int32_t F) {
-    return (F == 64 || F == 128) ? (size_t)F * 2 * F * 6 : 0;
-}
-
-extern "C" int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream_) {
-    if ((F != 64 && F != 128) || W == nullptr || out == nullptr || ldw < 2 * F) return CWN_ERR_BAD_ARG;
-    if (((uintptr_t)W & 3u) || !al16(out)) return CWN_ERR_ALIGN;
-    const int threads = (F / 16) * 2 * (F / 32) * 64;
-    hipStream_t stream = (hipStream_t)stream_;
-    if (F == 128) pack_weights_kernel<128><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
-    else pack_weights_kernel<64><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
-    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
-}
-
-extern "C" int32_t cwn_layer_round_rows(int32_t F) {
+extern "C" int32_t CWN_FN(round_rows)(int32_t F) {
     return (F == 64 || F == 128) ? kThreads / (F / 4) : 0;
+}
+
+extern "C" size_t CWN_FN(lds_bytes)(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows) {
+    if (max_gemm_rows < 0 || max_gemm_rows % 16 != 0 || max_source_rows < 0) return 0;
+    size_t b = 0;
+    if (F == 128 && max_gemm_rows <= gemm_rows_cap(128) && max_source_rows <= 2 * source_rows_cap(128))
+        b = lds_bytes<128>(max_gemm_rows, max_source_rows);
+    if (F == 64 && max_gemm_rows <= gemm_rows_cap(64) && max_source_rows <= 2 * source_rows_cap(64))
+        b = lds_bytes<64>(max_gemm_rows, max_source_rows);
+    return b <= kLdsBudget ? b : 0;      // (two-per-CU form: of ONE item with these rows; a launch takes the largest)
 }
 
 // Host-side check of a HOST copy of the item table against its plan: every derived field is what
 // include/cwn_hip.h defines, every range lies inside the plan's summary, every item fits the caps.  The
 // kernel itself re-checks only what keeps a workgroup inside its LDS.
-extern "C" int cwn_layer_items_check(const int32_t* items, int64_t n_items, int32_t F, const cwn_layer_plan* plan) {
+extern "C" int CWN_FN(items_check)(const int32_t* items, int64_t n_items, int32_t F, const cwn_layer_plan* plan) {
     if (plan == nullptr || n_items < 0 || (n_items > 0 && items == nullptr) || (F != 64 && F != 128)) return CWN_ERR_BAD_ARG;
     if (plan->n_items != n_items) return CWN_ERR_BAD_ARG;
     const int ng = kThreads / (F / 4);
@@ -958,6 +1124,8 @@ extern "C" int cwn_layer_items_check(const int32_t* items, int64_t n_items, int3
             if (nt > 1 && (T1r[T_DIM] != g + 1 || T1r[T_R0] != r[I_CR0] || T1r[T_N] != nc ||
                            (T1r[T_BNE] > 0 && (T1r[T_SR0] != T0[T_R0] || T1r[T_SN] != T0[T_N]))))
                 return CWN_ERR_BAD_ARG;
+            // two-per-CU form: the rows of EACH product are bounded (a wave holds the accumulators of both)
+            if (kW8 && (pad16(n0) > CWN_LAYER_W8_HALF_ROWS(F) || pad16(nc) > CWN_LAYER_W8_HALF_ROWS(F))) return CWN_ERR_BAD_ARG;
         } else {
             if (r[I_CN] != 0 || r[I_UNE] != 0 || nt > 1) return CWN_ERR_BAD_ARG;
         }
@@ -967,23 +1135,21 @@ extern "C" int cwn_layer_items_check(const int32_t* items, int64_t n_items, int3
         if (r[I_R1] != r1 || r[I_ROWS] != rows || r[I_B1] != b1 || r[I_B2] != b2 || r[I_TOTAL] != total) return CWN_ERR_BAD_ARG;
         for (int k = I_TOTAL + 1; k < CWN_LAYER_ITEM_INTS; ++k)
             if (r[k] != 0) return CWN_ERR_BAD_ARG;
-        if (rows > plan->max_gemm_rows || sn > plan->max_source_rows || total > CWN_LAYER_MAX_ENTRIES) return CWN_ERR_BAD_ARG;
+        // sources that take LDS: both tasks' in the 16-wave form, task 0's in the two-per-CU form
+        const int64_t sn_lds = kW8 ? (nt > 0 ? (int64_t)T0[T_SN] : 0) : sn;
+        if (rows > plan->max_gemm_rows || sn_lds > plan->max_source_rows || total > CWN_LAYER_MAX_ENTRIES) return CWN_ERR_BAD_ARG;
+        if (kW8) {       // every item lays out its own rows: staged rows + the LOADED sources (task 0's) within the launch's LDS
+            const int64_t src0 = nt > 0 ? T0[T_SN] : 0;
+            const size_t need = CWN_FN(lds_bytes)(F, (int32_t)rows, (int32_t)src0);
+            if (need == 0 || (int64_t)need > plan->lds_bytes) return CWN_ERR_BAD_ARG;
+        }
     }
-    return cwn_layer_fused_lds_bytes(F, plan->max_gemm_rows, plan->max_source_rows) != 0 ? CWN_OK : CWN_ERR_BAD_ARG;
+    if (kW8) return plan->lds_bytes <= (int64_t)kLdsBudget ? CWN_OK : CWN_ERR_BAD_ARG;
+    return CWN_FN(lds_bytes)(F, plan->max_gemm_rows, plan->max_source_rows) != 0 ? CWN_OK : CWN_ERR_BAD_ARG;
 }
 
-extern "C" size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows) {
-    if (max_gemm_rows < 0 || max_gemm_rows % 16 != 0 || max_source_rows < 0) return 0;
-    size_t b = 0;
-    if (F == 128 && max_gemm_rows <= CWN_LAYER_GEMM_ROWS(128) && max_source_rows <= 2 * CWN_LAYER_SOURCE_ROWS(128))
-        b = lds_bytes<128>(max_gemm_rows, max_source_rows);
-    if (F == 64 && max_gemm_rows <= CWN_LAYER_GEMM_ROWS(64) && max_source_rows <= 2 * CWN_LAYER_SOURCE_ROWS(64))
-        b = lds_bytes<64>(max_gemm_rows, max_source_rows);
-    return b <= 160 * 1024 ? b : 0;
-}
-
-extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_t F, const cwn_layer_plan* plan,
-                                   int32_t flags, int32_t* err_flag, cwn_stream_t stream_) {
+extern "C" int CWN_FN(launch)(const cwn_layer_dim* dims, int n_dims, int32_t F, const cwn_layer_plan* plan,
+                              int32_t flags, int32_t* err_flag, cwn_stream_t stream_) {
     if (dims == nullptr || plan == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS || plan->n_items < 0)
         return CWN_ERR_BAD_ARG;
     if ((flags & ~(CWN_LAYER_CSR_STORE | CWN_LAYER_CSR_LOAD)) != 0 ||
@@ -995,7 +1161,8 @@ extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_
     if (plan->items == nullptr || err_flag == nullptr) return CWN_ERR_BAD_ARG;
     if (flags != 0 && plan->csr_cache == nullptr) return CWN_ERR_BAD_ARG;
     if (n_items >= INT32_MAX) return CWN_ERR_TOO_LARGE;
-    if (cwn_layer_fused_lds_bytes(F, plan->max_gemm_rows, plan->max_source_rows) == 0) return CWN_ERR_BAD_ARG;
+    if (!kW8 && CWN_FN(lds_bytes)(F, plan->max_gemm_rows, plan->max_source_rows) == 0) return CWN_ERR_BAD_ARG;
+    if (kW8 && (plan->max_gemm_rows > gemm_rows_cap(F) || plan->max_source_rows > 2 * source_rows_cap(F))) return CWN_ERR_BAD_ARG;
     if (!al16(plan->items) || !al16(plan->csr_cache)) return CWN_ERR_ALIGN;
     LayerArgs A{};
     bool has_up[CWN_LAYER_MAX_DIMS] = {false, false, false};
@@ -1062,6 +1229,8 @@ extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_
     A.csr_cache = static_cast<unsigned char*>(plan->csr_cache);
     A.rows_cap = plan->max_gemm_rows;
     A.xrows_cap = plan->max_source_rows;
+    A.lds_limit = (int32_t)plan->lds_bytes;
+    if (kW8 && (plan->lds_bytes < (int64_t)lds_bytes<128>(16, 0) || plan->lds_bytes > (int64_t)kLdsBudget)) return CWN_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     const int mode = (flags & CWN_LAYER_CSR_LOAD) ? kLoad : (flags & CWN_LAYER_CSR_STORE) ? kSortStore : kSort;
     if (F == 128) {
@@ -1073,3 +1242,47 @@ extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_
     if (mode == kSortStore) return launch<64, kSortStore>(A, n_items, stream);
     return launch<64, kSort>(A, n_items, stream);
 }
+
+#if !CWN_W8
+// ---- the public entry points (include/cwn_hip.h): variant 0 = the 16-wave form above, variant 1 = the two-per-CU form
+extern "C" size_t cwn_layer_packed_weight_bytes(int32_t F) {
+    return (F == 64 || F == 128) ? (size_t)F * 2 * F * 6 : 0;
+}
+
+extern "C" int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream_) {
+    if ((F != 64 && F != 128) || W == nullptr || out == nullptr || ldw < 2 * F) return CWN_ERR_BAD_ARG;
+    if (((uintptr_t)W & 3u) || !al16(out)) return CWN_ERR_ALIGN;
+    const int threads = (F / 16) * 2 * (F / 32) * 64;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (F == 128) pack_weights_kernel<128><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
+    else pack_weights_kernel<64><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int32_t cwn_layer_variant_round_rows(int32_t F, int32_t variant) {
+    return variant == 0 ? cwn_layer_v0_round_rows(F) : variant == 1 ? cwn_layer_w8_round_rows(F) : 0;
+}
+extern "C" int32_t cwn_layer_round_rows(int32_t F) { return cwn_layer_v0_round_rows(F); }
+
+extern "C" size_t cwn_layer_variant_lds_bytes(int32_t F, int32_t variant, int32_t max_gemm_rows, int32_t max_source_rows) {
+    return variant == 0 ? cwn_layer_v0_lds_bytes(F, max_gemm_rows, max_source_rows)
+                        : variant == 1 ? cwn_layer_w8_lds_bytes(F, max_gemm_rows, max_source_rows) : 0;
+}
+extern "C" size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows) {
+    return cwn_layer_v0_lds_bytes(F, max_gemm_rows, max_source_rows);
+}
+
+extern "C" int cwn_layer_items_check(const int32_t* items, int64_t n_items, int32_t F, const cwn_layer_plan* plan) {
+    if (plan == nullptr) return CWN_ERR_BAD_ARG;
+    return plan->variant == 0 ? cwn_layer_v0_items_check(items, n_items, F, plan)
+                              : plan->variant == 1 ? cwn_layer_w8_items_check(items, n_items, F, plan) : CWN_ERR_BAD_ARG;
+}
+
+extern "C" int cwn_layer_fused_f32(const cwn_layer_dim* dims, int n_dims, int32_t F, const cwn_layer_plan* plan,
+                                   int32_t flags, int32_t* err_flag, cwn_stream_t stream_) {
+    if (plan == nullptr) return CWN_ERR_BAD_ARG;
+    return plan->variant == 0 ? cwn_layer_v0_launch(dims, n_dims, F, plan, flags, err_flag, stream_)
+                              : plan->variant == 1 ? cwn_layer_w8_launch(dims, n_dims, F, plan, flags, err_flag, stream_)
+                                                   : CWN_ERR_BAD_ARG;
+}
+#endif

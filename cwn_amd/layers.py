@@ -89,6 +89,11 @@ CSR_REUSE = True              # blocked layer kernel: sort a batch's adjacencies
 # complexes 646 vs 428, 512: 761 vs 588, 1024: 788 vs 759, 2048: 836 vs 900, 8192: 863 vs 981); beyond
 # ~2600 items (two per complex) the two-kernel path's streaming wins.
 BLOCKED_MAX_ITEMS = int(os.environ.get('CWN_BLOCKED_MAX_ITEMS', '2600'))
+# Which form of the blocked kernel a launch takes (include/cwn_hip.h, cwn_layer_plan.variant): 'auto' = the 16-wave
+# one-per-CU form while the items fit the chip once (TWO_PER_CU_MIN_ITEMS), the 8-wave two-per-CU form beyond that
+# when every complex fits its smaller caps; '0' / '1' force one (A/B measurements, tests).
+LAYER_VARIANT = os.environ.get('CWN_LAYER_VARIANT', 'auto')
+TWO_PER_CU_MIN_ITEMS = int(os.environ.get('CWN_TWO_PER_CU_MIN_ITEMS', '256'))
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
 _BLOCKED_CACHE = weakref.WeakKeyDictionary()
 
@@ -730,12 +735,25 @@ class SparseCINConv(torch.nn.Module):
             dims.append(D)
             has_up.append(bool(up))
         has_b = [D.b_index is not None for D in dims]
-        if plan.at_least(F, has_up, has_b) > BLOCKED_MAX_ITEMS:
-            return f'more than {BLOCKED_MAX_ITEMS} items: beyond the range where one workgroup per item beats the streaming CSR path'
-        table = plan.items(F, has_up, has_b)     # keyed on the streams THIS layer runs (a layer without
-        if table is None:                        # the boundary stream must not get records that carry boundary entries)
+        # Tables are keyed on the streams THIS layer runs (a layer without the boundary stream must not get
+        # records that carry boundary entries) and on the form of the kernel.  Beyond one item per CU the two-per-CU
+        # form is taken when every complex fits its smaller caps: it beats the 16-wave form AND the streaming CSR path
+        # at every size measured (tools/ab_variant.sh, M cells/s, two-per-CU / 16-wave / CSR: 512 complexes 1090 / 874 /
+        # 582, 2048: 1273 / 994 / 837, 8192: 1207 / 960 / 905; at 128 complexes = 256 items 633 / 711 / 322).
+        lower = plan.at_least(F, has_up, has_b)
+        table = None
+        if LAYER_VARIANT == '1' or (LAYER_VARIANT == 'auto' and lower > TWO_PER_CU_MIN_ITEMS):
+            table = plan.items(F, has_up, has_b, variant=1)
+        if table is None and LAYER_VARIANT != '1':
+            if lower > BLOCKED_MAX_ITEMS:
+                return f'more than {BLOCKED_MAX_ITEMS} items: beyond the range where one workgroup per item beats the streaming CSR path'
+            table = plan.items(F, has_up, has_b)
+            if table is not None and LAYER_VARIANT == 'auto' and table.n_items > TWO_PER_CU_MIN_ITEMS:
+                t1 = plan.items(F, has_up, has_b, variant=1)
+                table = t1 if t1 is not None else table
+        if table is None:
             return 'a complex does not fit one workgroup (row / entry caps)'
-        if table.n_items > BLOCKED_MAX_ITEMS:
+        if table.variant == 0 and table.n_items > BLOCKED_MAX_ITEMS:
             return f'{table.n_items} items: beyond the range where one workgroup per item beats the streaming CSR path'
         key = tuple((id(t), t._version) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
         return dims, plan, table, key

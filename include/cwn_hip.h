@@ -238,6 +238,15 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
 #define CWN_LAYER_TASK_ROWS 192
 #define CWN_LAYER_MAX_ENTRIES 1024
 #define CWN_ERR_BIT_BLOCK 8                    /* *err_flag bit: index outside its item */
+/* VARIANT 1 of the launch, the two-per-CU form (cwn_layer_plan.variant = 1): workgroups of 8 waves within 128 VGPRs
+ * and CWN_LAYER_W8_LDS_BYTES of LDS, so that two are resident on a CU and one item's load / sort phases run under
+ * the other's matrix-core / reduce phases -- for launches with more items than the chip has CUs.  Same record
+ * layout, same arithmetic, bit-identical outputs; smaller caps, and the rows of EACH product (cells of g, cells of
+ * g+1, each padded to 16) are bounded by CWN_LAYER_W8_HALF_ROWS.  Rows per round: cwn_layer_variant_round_rows. */
+#define CWN_LAYER_W8_LDS_BYTES (80 * 1024)
+#define CWN_LAYER_W8_GEMM_ROWS(F) ((F) == 64 ? 128 : 80)
+#define CWN_LAYER_W8_SOURCE_ROWS(F) ((F) == 64 ? 128 : 48)
+#define CWN_LAYER_W8_HALF_ROWS(F) ((F) == 64 ? 128 : 64)
 
 typedef struct cwn_layer_dim {
     const float* x;            /* [n_cells, F] */
@@ -284,10 +293,13 @@ typedef struct cwn_layer_plan {
     int32_t set_start[CWN_LAYER_MAX_DIMS + 1];  /* first item of set s (set_start[0] = 0) */
     int32_t max_gemm_rows;                      /* bound (multiple of 16) of the staged rows of any item */
     int32_t max_source_rows;                    /* bound of the boundary-source cells of any item */
-    int32_t pad_;
+    int32_t variant;                            /* 0: one 16-wave workgroup per CU; 1: the two-per-CU form (caps above) */
     int64_t cells_end[CWN_LAYER_MAX_DIMS];      /* max (first cell + count) the table names, per dimension */
     int64_t up_end[CWN_LAYER_MAX_DIMS];         /* max (first entry + count) of up_index_d */
     int64_t b_end[CWN_LAYER_MAX_DIMS];          /* max (first entry + count) of b_index_d */
+    int64_t lds_bytes;                          /* variant 1: dynamic LDS of the launch = the largest per-item need
+                                                   (cwn_layer_variant_lds_bytes of its staged rows and task-0 sources);
+                                                   variant 0: unused (one layout per launch from the two maxima) */
 } cwn_layer_plan;
 
 int cwn_layer_fused_f32(const cwn_layer_dim* dims_host, int n_dims, int32_t F, const cwn_layer_plan* plan_host,
@@ -310,15 +322,17 @@ typedef struct cwn_layer_sizes {
 #define CWN_LAYER_ITEMS_TOO_LARGE (-1)
 #define CWN_LAYER_ITEMS_BAD_ARG (-2)
 int64_t cwn_layer_items_build(const cwn_layer_sizes* sizes_host, int32_t F, int32_t* items_host, int64_t cap_items,
-                              cwn_layer_plan* plan_host);
+                              cwn_layer_plan* plan_host);     /* plan_host->variant (in): which form's caps to cut under */
 
 /* HOST check of a host copy of the item table against its plan (record layout above): CWN_OK or
  * CWN_ERR_BAD_ARG.  The kernel re-checks only what keeps a workgroup inside its LDS. */
 int cwn_layer_items_check(const int32_t* items_host, int64_t n_items, int32_t F, const cwn_layer_plan* plan_host);
 /* rows a workgroup stages per round (threads / (F / 4)): the coface block of an item starts at a multiple of it */
-int32_t cwn_layer_round_rows(int32_t F);
-/* dynamic LDS bytes such a launch uses, 0 for unsupported arguments or more than 160 KiB */
-size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows);
+int32_t cwn_layer_round_rows(int32_t F);                               /* variant 0 */
+int32_t cwn_layer_variant_round_rows(int32_t F, int32_t variant);
+/* dynamic LDS bytes such a launch uses, 0 for unsupported arguments or more than the variant's budget */
+size_t cwn_layer_fused_lds_bytes(int32_t F, int32_t max_gemm_rows, int32_t max_source_rows);     /* variant 0: 160 KiB */
+size_t cwn_layer_variant_lds_bytes(int32_t F, int32_t variant, int32_t max_gemm_rows, int32_t max_source_rows);
 
 /* ------------------------------------------------------------------------------------------
  * The update / combine networks of a SparseCIN layer, all dimensions, in ONE launch (inference):

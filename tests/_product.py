@@ -38,9 +38,18 @@ def gate(got, ref, what: str = '', tol: float = 1e-5) -> float:
     assert g.shape == r.shape, (what, tuple(g.shape), tuple(r.shape))
     err = float((g - r).abs().max()) if r.numel() else 0.0
     scale = max(1.0, float(r.abs().max())) if r.numel() else 1.0
-    print(f'[gate] {what}: max|delta| = {err:.3e}  |ref|_inf = {scale:.3g}  bound = {tol * scale:.3e}')
+    # stated precisely: the bound is RELATIVE to |ref|_inf once that exceeds 1; whether the
+    # north star's absolute 1e-5 holds as well is printed with every line
+    print(f'[gate] {what}: max|delta| = {err:.3e} absolute  |ref|_inf = {scale:.3g}  bound = {tol * scale:.3e} '
+          f'({"also within" if err <= tol else "ABOVE"} the absolute {tol:g})')
     assert err <= tol * scale, f'{what}: max|delta| {err:.3e} > {tol * scale:.3e}'
     return err
+
+
+def deviation(t, ref64) -> float:
+    """max |t - ref64| in float64 (0 for empty tensors)."""
+    r = ref64.detach().cpu().double()
+    return float((t.detach().cpu().double() - r).abs().max()) if r.numel() else 0.0
 
 
 def to_double(state: dict) -> dict:

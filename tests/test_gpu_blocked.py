@@ -478,3 +478,51 @@ def test_static_graph_at_width_64():
         want = _run(conv, b, blocked=True)
         for i, (g, w) in enumerate(zip(got, want)):
             assert torch.equal(g, w), (i, (g - w).abs().max().item())
+
+
+@pytest.mark.parametrize('kind,n,F', [('zinc', 128, 128), ('zinc', 300, 128), ('zinc', 1, 128), ('zinc', 64, 64), ('zinc', 700, 64)])
+def test_two_per_cu_form_bit_identical_to_the_16_wave_form(kind, n, F):
+    """cwn_layer_plan.variant = 1 (8 waves, <= 128 VGPRs, <= 80 KiB LDS: two workgroups per CU; a wave multiplies both
+    products one after the other through one register set, the rings' boundary sources are read out of the bf16
+    planes, every item lays out its own rows) against variant 0: same split, same MFMA order per tile, same entry
+    order -> every output bit agrees; sort, sort + store and load modes."""
+    from cwn_amd import layers
+    b = _batch(kind, n, F, seed=31)
+    conv = _conv(F, seed=32, eps=0.375)
+    outs = {}
+    prev = layers.LAYER_VARIANT
+    try:
+        for v in ('0', '1'):
+            layers.LAYER_VARIANT = v
+            layers._BLOCKED_CACHE.clear()
+            b.block_plan().forget_csr()
+            first = _run(conv, b, blocked=True)          # sorts (and stores the per-item CSR)
+            second = _run(conv, b, blocked=True)         # loads it back
+            with torch.no_grad():
+                prm = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+                table = conv._blocked_args(prm, 0)[2]
+            assert table.variant == int(v), (v, table.variant)
+            outs[v] = (first, second)
+    finally:
+        layers.LAYER_VARIANT = prev
+        layers._BLOCKED_CACHE.clear()
+    for i in range(6):
+        assert torch.equal(outs['0'][0][i], outs['1'][0][i]), (i, (outs['0'][0][i] - outs['1'][0][i]).abs().max().item())
+        assert torch.equal(outs['1'][0][i], outs['1'][1][i]), i
+
+
+def test_auto_variant_takes_the_two_per_cu_form_beyond_one_item_per_cu():
+    from cwn_amd import layers
+    conv = _conv(128, seed=33)
+    assert layers.LAYER_VARIANT == 'auto'
+    small, big = _batch('zinc', 100, 128, seed=34), _batch('zinc', 400, 128, seed=35)
+    with torch.no_grad():
+        t_small = conv._blocked_args(small.get_all_cochain_params(max_dim=2, include_down_features=False), 0)[2]
+        t_big = conv._blocked_args(big.get_all_cochain_params(max_dim=2, include_down_features=False), 0)[2]
+    assert t_small.variant == 0 and t_small.n_items <= layers.TWO_PER_CU_MIN_ITEMS
+    assert t_big.variant == 1 and t_big.n_items > layers.TWO_PER_CU_MIN_ITEMS
+    ref = _oracle_scope(conv, big)
+    outs = _run(conv, big, blocked=True)
+    for d in range(3):
+        _gate(outs[2 * d], ref[d][0], f'two-per-CU out_up[{d}]')
+        _gate(outs[2 * d + 1], ref[d][1], f'two-per-CU out_b[{d}]')

@@ -30,10 +30,12 @@ def table():
 
 def test_headline_kernels_keep_their_registers(table):
     layer = {n: v for n, v in table.items() if n.startswith('layer_kernel<')}
-    assert len(layer) == 6                            # F in {64, 128} x {sort, sort + store, load}
+    # F in {64, 128} x {sort, sort + store, load}, in two forms (cwn_layer.hip compiled twice): 16 waves, one workgroup
+    # per CU; 8 waves within 128 registers, two per CU
+    assert len(layer) == 12 and sorted(v['max_flat_workgroup_size'] for v in layer.values()) == [512] * 6 + [1024] * 6
     for n, v in layer.items():
-        # 1024 threads = 16 waves = four per SIMD: 512 / 4 = 128 registers a lane, none of them in scratch
-        assert v['max_flat_workgroup_size'] == 1024 and v['vgpr_count'] <= 128, (n, v)
+        # 1024 threads = 16 waves = four per SIMD: 512 / 4 = 128 registers a lane; 2 x 512 threads: the same; none in scratch
+        assert v['vgpr_count'] <= 128, (n, v)
         assert v['vgpr_spill_count'] == v['sgpr_spill_count'] == v['private_segment_fixed_size'] == 0, (n, v)
     mlp = {n: v for n, v in table.items() if n.startswith('update_mlp_kernel<')}
     assert len(mlp) == 2

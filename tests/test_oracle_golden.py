@@ -223,6 +223,38 @@ def test_cin_conv_and_orient_golden():
     torch.testing.assert_close(down, T(g['orient/down']), rtol=0, atol=1e-6)
 
 
+def _bn_eval(p, pre):
+    return lambda h: (h - p[pre + '.running_mean']) / torch.sqrt(p[pre + '.running_var'] + 1e-5) * p[pre + '.weight'] + p[pre + '.bias']
+
+
+def test_edge_cin_conv_and_full_oriented_conv_golden():
+    """Round 3: EdgeCINConv as EdgeCIN0 calls it (mp/layers.py:127-150, mp/models.py:388-390:
+    max_dim 1, top features as up_attr of the edges, no lower adjacency on the vertices) and a full
+    OrientedConv.forward (mp/layers.py:441-452), oracle vs the reference's outputs."""
+    g = load('edge_oriented.npz')
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/testing']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    for d in range(3):
+        cx['cochains'][d]['x'] = T(g[f'edge_cin/x/{d}'])
+    st = state_dict(g, 'edge_cin/state')
+    prms = O.all_cochain_params(cx, 1, include_top_features=True)
+    assert len(prms) == 2
+    for d in range(2):
+        p = {k[len(f'mp_levels.{d}.'):]: v for k, v in st.items() if k.startswith(f'mp_levels.{d}.')}
+        lin = lambda pre, p=p: (lambda h: h @ p[pre + '.weight'].t() + p[pre + '.bias'])
+        msg = lambda pre, p=p: (lambda h: _bn_eval(p, pre + '.2')(torch.relu(lin(pre + '.0', p)(h))))
+        upd = lambda h, p=p: _bn_eval(p, 'update_nn.4')(torch.relu(lin('update_nn.2', p)(torch.relu(lin('update_nn.0', p)(h)))))
+        out = O.cin_cochain_conv(prms[d], msg('msg_up_nn'), msg('msg_down_nn') if d == 1 else (lambda h: None), upd, p['eps'])
+        torch.testing.assert_close(out, T(g[f'edge_cin/out/{d}']), rtol=1e-5, atol=1e-5)
+    so = state_dict(g, 'oriented/state')
+    x = T(g['oriented/x'])
+    up, down = O.oriented_conv_messages(x, T(g['oriented/upper_index']), T(g['oriented/lower_index']),
+                                        T(g['oriented/upper_orient']), T(g['oriented/lower_orient']))
+    aff = lambda pre, h: h @ so[pre + '.weight'].t() + so[pre + '.bias']
+    y = torch.tanh(aff('update_nn', x) + aff('update_up_nn', up) + aff('update_down_nn', down))
+    torch.testing.assert_close(y, T(g['oriented/out']), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('tag', ['h16_l2', 'h32_l4'])
 def test_embed_sparse_cin_golden(tag):
     g = load('embed_sparse_cin.npz')

@@ -38,12 +38,18 @@ def kernels(lib_path: str) -> dict:
         for blk in re.split(r'\n\s+- \.agpr_count', notes)[1:]:
             blk = '.agpr_count' + blk
             name = re.search(r'\.name:\s+(\S+)', blk).group(1)
-            out[name] = {k: int(re.search(r'\.' + k + r':\s+(\d+)', blk).group(1)) for k in FIELDS}
+            v = {k: int(re.search(r'\.' + k + r':\s+(\d+)', blk).group(1)) for k in FIELDS}
+            # the same source compiled twice (cwn_layer.hip: the 16-wave and the two-per-CU form) gives two code objects
+            # with the same kernel names: keep both, the second one under name@<threads>
+            if name in out and out[name] != v:
+                name = f'{name}@{v["max_flat_workgroup_size"]}'
+            out[name] = v
 
 
 def short(name: str) -> str:
+    name, _, tag = name.partition('@')
     m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I(.*)EEv', name)
-    return f'{m.group(1)}<{m.group(2)}>' if m else name
+    return (f'{m.group(1)}<{m.group(2)}>' if m else name) + (f'@{tag}' if tag else '')
 
 
 if __name__ == '__main__':
