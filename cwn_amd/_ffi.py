@@ -21,7 +21,7 @@ ABI_VERSION = 12
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
-           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
+           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
 
 
@@ -219,6 +219,8 @@ def lib():
     L.cwn_adam_f32.restype = C.c_int
     L.cwn_adam_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.cwn_loss_f32.restype = C.c_int
+    L.cwn_loss_f32.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cwn_embedding_fwd_f32.restype = C.c_int
     L.cwn_embedding_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
@@ -348,11 +350,56 @@ def norm_bwd_apply(descs: Sequence[NormDesc], device) -> None:
 DETERMINISTIC_TN = False
 
 
-def gemm_tn(descs: Sequence[GemmTnDesc], device) -> None:
+MAX_TN_DESCS = 24          # = CWN_GEMM_TN_MAX_DESCS
+# Deferred weight gradients.  Nothing reads a weight gradient before the optimizer step (or the gradient all-reduce of
+# its chunk), so a caller that accumulates into buffers it owns (ops.accumulate_into_grad: cwn_amd.train.TrainStep) lets
+# the launches queue up and runs them together -- `flush_tn` -- in launches of MAX_TN_DESCS: ~100 small GEMMs of a
+# 4-layer model in 5 launches that fill the chip instead of 17 that each pay their own latency chain (0.31 of a
+# 1.45 ms step).  The queue keeps the operand tensors alive (under stream capture a freed block would be handed out
+# again before the deferred kernel has read it).
+_tn_queue = None
+
+
+def defer_tn(on: bool) -> None:
+    """Start (True) or stop (False) queueing deferrable weight-gradient launches; stopping does NOT flush."""
+    global _tn_queue
+    if on and _tn_queue is None:
+        _tn_queue = []
+    elif not on:
+        if _tn_queue:
+            raise CwnError('defer_tn(False) with queued weight gradients: call flush_tn first')
+        _tn_queue = None
+
+
+def flush_tn(device) -> None:
+    """Launch every queued weight gradient (queue order), MAX_TN_DESCS per launch."""
+    global _tn_queue
+    if not _tn_queue:
+        return
+    q, _tn_queue = _tn_queue, []
+    descs = [d for ds, _ in q for d in ds]
+    # one launch runs ONE form of the kernel: descriptors that need the element-wise loads (a width that is not a
+    # multiple of 4: the head's lin2) go into launches of their own instead of slowing the 16-byte form of the rest
+    def vec(d):
+        ok = lambda p: p is None or p % 16 == 0
+        return (ok(d.dZ) and ok(d.X) and ok(d.X2) and d.lddz % 4 == 0 and d.ldx % 4 == 0 and (d.K2 == 0 or d.ldx2 % 4 == 0)
+                and d.N % 4 == 0 and d.K % 4 == 0 and d.K2 % 4 == 0)
+    fast, slow = [d for d in descs if vec(d)], [d for d in descs if not vec(d)]
+    for part in (fast, slow):
+        if part:
+            gemm_tn(part, device)               # (the operands stay referenced by `q` until here)
+
+
+def gemm_tn(descs: Sequence[GemmTnDesc], device, keep=None, deferrable: bool = False) -> None:
+    """dW += dZ^T [X | X2] for every descriptor.  `deferrable`: the targets are buffers the caller owns until
+    flush_tn (never tensors handed back to autograd); `keep`: every tensor a descriptor points at."""
+    if deferrable and _tn_queue is not None and not DETERMINISTIC_TN:
+        _tn_queue.append((list(descs), keep))
+        return
     L = lib()
     s = stream_ptr(device)
-    for i in range(0, len(descs), MAX_DESCS):
-        chunk = descs[i:i + MAX_DESCS]
+    for i in range(0, len(descs), MAX_TN_DESCS):
+        chunk = descs[i:i + MAX_TN_DESCS]
         arr = (GemmTnDesc * len(chunk))(*chunk)
         ws, nbytes = None, 0
         if DETERMINISTIC_TN:

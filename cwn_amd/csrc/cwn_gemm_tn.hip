@@ -17,7 +17,9 @@
 //     straight into dW (no workspace; ~27 same-address adds per element at M ~3 k);
 //   * the normalisation + ReLU of the producing layer is applied to X on the way into LDS (the
 //     activation itself is never materialised in the forward pass);
-//   * up to CWN_MAX_DESCS weight gradients per launch.
+//   * up to CWN_GEMM_TN_MAX_DESCS (24) weight gradients per launch: a training step defers them to the end of its backward
+//     (nothing reads a weight gradient before the optimizer) and runs the ~100 of a 4-layer model in 5 launches that
+//     fill the chip, where 17 launches of ~440 workgroups each spent 18 us apiece on their own latency chain.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "../../include/cwn_hip.h"
@@ -29,20 +31,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
 constexpr int kTile = 64;        // rows of dW (n) and columns of dW (k) per workgroup
 constexpr int kChunk = 64;       // rows of M per LDS stage
-constexpr int kBandRows = 128;   // rows of M per workgroup
+constexpr int kBandRows = 128;   // rows of M per workgroup at least (the launcher doubles it while a launch has more workgroups than
+                                 // fit the chip at once: a band more is 4096 more fp32 atomics, 4.9 us of the 15 us launch at the ZINC batch)
+constexpr int kMaxBandRows = 1024;
+constexpr int64_t kTargetBlocks = 2048;   // (320 = one round was measured at the ZINC batch: 15.1 -> 15.9 us, the per-workgroup chain got longer)
 constexpr int kLd = 80;          // LDS row stride in floats
 constexpr int kU = kChunk * (kTile / 4) / kThreads;   // 16-B loads per thread per tile (= 4)
 
-struct TnBatch {
-    cwn_gemm_tn_desc d[CWN_MAX_DESCS];
-    int32_t blk_start[CWN_MAX_DESCS + 1];
-    int32_t tiles_n[CWN_MAX_DESCS], tiles_k[CWN_MAX_DESCS];
-    int32_t vec[CWN_MAX_DESCS];
+struct TnBatch {       // a kernel argument: must stay under 4 KiB (static_assert below)
+    cwn_gemm_tn_desc d[CWN_GEMM_TN_MAX_DESCS];
+    int32_t blk_start[CWN_GEMM_TN_MAX_DESCS + 1];
+    int32_t tiles_n[CWN_GEMM_TN_MAX_DESCS], tiles_k[CWN_GEMM_TN_MAX_DESCS];
+    int32_t vec[CWN_GEMM_TN_MAX_DESCS];
     int32_t n;
-    float* ws[CWN_MAX_DESCS];      // per-band partials [bands][N][K + K2] then [bands][N] (db), or NULL
-    int32_t bands[CWN_MAX_DESCS];
+    float* ws[CWN_GEMM_TN_MAX_DESCS];      // per-band partials [bands][N][K + K2] then [bands][N] (db), or NULL
+    int32_t bands[CWN_GEMM_TN_MAX_DESCS];
+    int32_t band_rows; // rows of M per workgroup in THIS launch (multiple of kChunk)
     int32_t dbg;       // timing experiments (CWN_TN_DBG): 1 no output, 2 no MFMA, 4 no bias sum
 };
+
+static_assert(sizeof(TnBatch) <= 4096, "kernel-argument segment");
 
 struct Src {                 // one logical [M, C1 + C2] operand made of up to two matrices
     const float* p1;
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TnBatch B) {
     __shared__ __attribute__((aligned(16))) float xt[kChunk * kLd];
     int di = 0;
 #pragma unroll
-    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+    for (int i = 1; i < CWN_GEMM_TN_MAX_DESCS; ++i)
         if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
     const cwn_gemm_tn_desc& D = B.d[di];
     const int tn = B.tiles_n[di], tk = B.tiles_k[di];
@@ -122,8 +130,8 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TnBatch B) {
     const int tile_n = b % tn;
     const int band = b / tn;
     const int64_t M = D.M;
-    const int64_t row_lo = (int64_t)band * kBandRows;
-    const int64_t row_hi = row_lo + kBandRows < M ? row_lo + kBandRows : M;
+    const int64_t row_lo = (int64_t)band * B.band_rows;
+    const int64_t row_hi = row_lo + B.band_rows < M ? row_lo + B.band_rows : M;
     const int n0 = tile_n * kTile, k0 = tile_k * kTile;
     const int N = D.N, Ktot = D.K + D.K2;
     const Src SZ{D.dZ, nullptr, D.lddz, 0, N, 0, nullptr, nullptr, nullptr, nullptr, 0};
@@ -236,7 +244,7 @@ inline size_t tn_ws_floats(const cwn_gemm_tn_desc& D) {
 }  // namespace
 
 extern "C" size_t cwn_gemm_tn_workspace_bytes(const cwn_gemm_tn_desc* descs, int n) {
-    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return 0;
+    if (descs == nullptr || n <= 0 || n > CWN_GEMM_TN_MAX_DESCS) return 0;
     size_t total = 0;
     for (int i = 0; i < n; ++i) total += (tn_ws_floats(descs[i]) * 4 + 255) / 256 * 256;
     return total;
@@ -244,7 +252,7 @@ extern "C" size_t cwn_gemm_tn_workspace_bytes(const cwn_gemm_tn_desc* descs, int
 
 extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* workspace, size_t ws_bytes,
                                cwn_stream_t stream_) {
-    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return CWN_ERR_BAD_ARG;
+    if (descs == nullptr || n <= 0 || n > CWN_GEMM_TN_MAX_DESCS) return CWN_ERR_BAD_ARG;
     if (workspace != nullptr && ws_bytes < cwn_gemm_tn_workspace_bytes(descs, n)) return CWN_ERR_WORKSPACE;
     TnBatch B{};
     B.n = n;
@@ -266,13 +274,22 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
         B.d[i] = D;
         B.tiles_n[i] = (D.N + kTile - 1) / kTile;
         B.tiles_k[i] = (D.K + D.K2 + kTile - 1) / kTile;
-        const int64_t bands = (D.M + kBandRows - 1) / kBandRows;
-        B.bands[i] = (int32_t)bands;
-        B.blk_start[i] = (int32_t)blocks;
-        blocks += bands * B.tiles_n[i] * B.tiles_k[i];
-        if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     }
-    for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
+    // rows of M per workgroup: as few bands as keep the chip busy (workspace layouts are sized for kBandRows: an upper bound)
+    int band_rows = kBandRows;
+    for (;; band_rows *= 2) {
+        blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const int64_t bands = (descs[i].M + band_rows - 1) / band_rows;
+            B.bands[i] = (int32_t)bands;
+            B.blk_start[i] = (int32_t)blocks;
+            blocks += bands * B.tiles_n[i] * B.tiles_k[i];
+            if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+        }
+        if (blocks <= kTargetBlocks || band_rows >= kMaxBandRows) break;
+    }
+    B.band_rows = band_rows;
+    for (int i = n; i <= CWN_GEMM_TN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
     if (blocks == 0) return CWN_OK;
     static const int dbg = getenv("CWN_TN_DBG") ? atoi(getenv("CWN_TN_DBG")) : 0;
     B.dbg = dbg;

@@ -371,6 +371,53 @@ extern "C" int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
+// ---- the loss of a training step and its gradient in ONE launch ------------------------------------------
+// exp/train_utils.py:62-73: loss = criterion(pred, targets); loss.backward().  For the elementwise-mean criteria
+// (L1Loss 'regression', MSELoss 'mse_regression', BCEWithLogitsLoss 'bin_classification': exp/train_utils.py:20-31)
+// the framework runs ~9 launches of a few hundred elements each (sub, abs, mean, fill, sign, div, mul ...: 45 us of a
+// step); here one workgroup computes  loss = mean_i l(pred_i, y_i)  and  grad_i = dl/dpred_i / n  together.
+namespace {
+
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pred, const float* __restrict__ y, int64_t n,
+                                                   int kind, float* __restrict__ loss, float* __restrict__ grad) {
+    __shared__ float part[256];
+    const float inv = 1.0f / (float)n;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float p = pred[i], t = y[i], d = p - t;
+        float l, gr;
+        if (kind == CWN_LOSS_L1) {
+            l = fabsf(d);
+            gr = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);             // torch: sign(0) = 0
+        } else if (kind == CWN_LOSS_MSE) {
+            l = d * d;
+            gr = 2.f * d;
+        } else {                                                      // BCE with logits, the stable form torch uses
+            l = fmaxf(p, 0.f) - p * t + log1pf(expf(-fabsf(p)));
+            gr = 1.f / (1.f + expf(-p)) - t;
+        }
+        s += l;
+        grad[i] = gr * inv;
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {                         // fixed tree: deterministic
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = part[0] * inv;
+}
+
+}  // namespace
+
+extern "C" int cwn_loss_f32(int32_t kind, const float* pred, const float* y, int64_t n, float* loss, float* grad,
+                            cwn_stream_t stream_) {
+    if (kind < 0 || kind > CWN_LOSS_BCE_LOGITS || n <= 0 || pred == nullptr || y == nullptr || loss == nullptr || grad == nullptr)
+        return CWN_ERR_BAD_ARG;
+    loss_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)stream_>>>(pred, y, n, kind, loss, grad);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
 // ---- embedding backward: dW[v, :] += sum over the cells that looked row v up of g[cell, :] ----------
 // (torch.nn.Embedding / OGB Atom-BondEncoder tables: v_embed_init, e_embed_init of
 // mp/molec_models.py:44-52, 237-245.)  The tables are tiny (28 x 128, 173 x 64) and a few rows take
@@ -381,7 +428,10 @@ extern "C" int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_
 // layers).
 namespace {
 
-constexpr int kEmbBand = 128;    // cells per workgroup (ZINC-128: 25 + 26 workgroups; 512 left most CUs idle)
+// cells per workgroup.  Round 2 took 128 with one float per lane: 26 workgroups of 64 dependent passes (index -> gradient
+// row -> LDS add), 33 us per table at the ZINC batch of 128 -- the two calls were 4.5 % of the training step.  Four
+// features per lane put eight cells of a 128-wide table in flight per pass, and 64-cell bands fill a hundred CUs.
+constexpr int kEmbBand = 64;
 
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ g,
                                                             const int64_t* __restrict__ src,
@@ -395,16 +445,34 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * kEmbBand;
     const int64_t r1 = r0 + kEmbBand < n_rows ? r0 + kEmbBand : n_rows;
-    const int lanes = H < 256 ? H : 256;      // threads walking one cell's features
-    const int per = 256 / lanes;              // cells in flight
-    const int h0 = threadIdx.x % lanes, sub = threadIdx.x / lanes;
-    if (sub < per) {
-        for (int64_t r = r0 + sub; r < r1; r += per) {
-            for (int c = 0; c < cols; ++c) {
-                int64_t v = src[r * cols + c];
-                if (v < 0 || v >= (col_size != nullptr ? col_size[c] : V)) continue;   // flagged by the forward
-                if (col_off != nullptr) v += col_off[c];
-                for (int h = h0; h < H; h += lanes) atomicAdd(&table[v * H + h], g[r * H + h]);
+    if ((H & 3) == 0 && H <= 1024) {
+        const int lanes = H / 4;                  // threads walking one cell's features, four each
+        const int per = 256 / lanes;              // cells in flight
+        const int h0 = 4 * (threadIdx.x % lanes), sub = threadIdx.x / lanes;
+        if (sub < per) {
+            for (int64_t r = r0 + sub; r < r1; r += per) {
+                const float4 gv = *reinterpret_cast<const float4*>(g + r * H + h0);
+                for (int c = 0; c < cols; ++c) {
+                    int64_t v = src[r * cols + c];
+                    if (v < 0 || v >= (col_size != nullptr ? col_size[c] : V)) continue;   // flagged by the forward
+                    if (col_off != nullptr) v += col_off[c];
+                    float* t = table + v * H + h0;
+                    atomicAdd(t, gv.x); atomicAdd(t + 1, gv.y); atomicAdd(t + 2, gv.z); atomicAdd(t + 3, gv.w);
+                }
+            }
+        }
+    } else {
+        const int lanes = H < 256 ? H : 256;      // threads walking one cell's features
+        const int per = 256 / lanes;              // cells in flight
+        const int h0 = threadIdx.x % lanes, sub = threadIdx.x / lanes;
+        if (sub < per) {
+            for (int64_t r = r0 + sub; r < r1; r += per) {
+                for (int c = 0; c < cols; ++c) {
+                    int64_t v = src[r * cols + c];
+                    if (v < 0 || v >= (col_size != nullptr ? col_size[c] : V)) continue;   // flagged by the forward
+                    if (col_off != nullptr) v += col_off[c];
+                    for (int h = h0; h < H; h += lanes) atomicAdd(&table[v * H + h], g[r * H + h]);
+                }
             }
         }
     }
@@ -473,6 +541,7 @@ extern "C" int cwn_embedding_bwd_f32(const float* g, const int64_t* src, const i
     if (n_rows < 0 || cols <= 0 || H <= 0 || V <= 0) return CWN_ERR_BAD_ARG;
     if (n_rows == 0) return CWN_OK;
     if (g == nullptr || src == nullptr || dW == nullptr) return CWN_ERR_BAD_ARG;
+    if ((H & 3) == 0 && ((uintptr_t)g & 15u)) return CWN_ERR_ALIGN;       // gradient rows are read 16 bytes a lane
     const int64_t bytes = V * H * 4;
     if (bytes > 60 * 1024) return CWN_ERR_TOO_LARGE;       // the table must fit one workgroup's LDS
     const int64_t blocks = (n_rows + kEmbBand - 1) / kEmbBand;

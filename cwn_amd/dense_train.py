@@ -289,8 +289,12 @@ class _DenseTrain(torch.autograd.Function):
                     dW=dW.data_ptr(), db=_ffi.ptr(db), M=dZ3[i].size(0), lddz=ld(dZ3[i]), ldx=ld(Xu),
                     ldx2=ld(Xb), lddw=dW.stride(0), N=W.size(0), K=Xu.size(1), K2=Xb.size(1), in_relu=3))
             nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
+        # weight gradients whose targets are all the parameters' own .grad buffers may wait for the end of the backward
+        can_defer = ops.ACCUMULATE_INTO_GRAD and all(tw is not None and (st.lin.bias is None or tb is not None)
+                                                     for st, (tw, tb) in zip(stages, targets))
+        keep_all = [dZ3, Z, A0, aff_of]
         if tn:
-            _ffi.gemm_tn(tn, dev)
+            _ffi.gemm_tn(tn, dev, keep=keep_all, deferrable=can_defer)
         dA = ops.run_gemm(nn, dev)                      # [M, H_up + H_bd] per dimension
         dy = []
         for i in range(nd):
@@ -321,7 +325,7 @@ class _DenseTrain(torch.autograd.Function):
                             lddw=dW.stride(0), N=W.size(0), K=X.size(1), K2=0, in_relu=1 if s > 0 else 0))
                     nn.append(ops.Gemm(X=dz, W=W, w_trans=True))
             if tn:
-                _ffi.gemm_tn(tn, dev)
+                _ffi.gemm_tn(tn, dev, keep=[dZ, Z, A0, aff_of], deferrable=can_defer)
             res = ops.run_gemm(nn, dev)
             k = 0
             for i in range(nd):

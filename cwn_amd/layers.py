@@ -94,6 +94,19 @@ BLOCKED_MAX_ITEMS = int(os.environ.get('CWN_BLOCKED_MAX_ITEMS', '2600'))
 # when every complex fits its smaller caps; '0' / '1' force one (A/B measurements, tests).
 LAYER_VARIANT = os.environ.get('CWN_LAYER_VARIANT', 'auto')
 TWO_PER_CU_MIN_ITEMS = int(os.environ.get('CWN_TWO_PER_CU_MIN_ITEMS', '256'))
+def _two_per_cu_wins(n0: int, n1: int) -> bool:
+    """A launch of n0 items in the 16-wave form (256 at a time) against n1 items in the two-per-CU form (512 at a
+    time, each ~1.3 x as long: 8 waves, a neighbour on the CU): whole rounds while a launch is a few rounds (the last
+    round costs as much as a full one), the ratio beyond.  Calibrated on tools/ab_variant.sh (M cells/s, 16-wave /
+    two-per-CU): ZINC 160 complexes 555 / 639, 192: 649 / 744, 256: 756 / 905, 384: 844 / 1009; molhiv 256: 1351 /
+    1575, 512: 2143 / 1974 (445 items in two rounds against 677 in two longer ones: the one case the 16-wave form
+    keeps), 1024: 2354 / 2550, 2048: 2603 / 2905."""
+    slots = TWO_PER_CU_MIN_ITEMS                       # = CUs
+    r0 = -(-n0 // slots) if n0 <= 4 * slots else n0 / slots
+    r1 = -(-n1 // (2 * slots)) if n1 <= 8 * slots else n1 / (2 * slots)
+    return 1.3 * r1 < r0
+
+
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
 _BLOCKED_CACHE = weakref.WeakKeyDictionary()
 
@@ -742,15 +755,18 @@ class SparseCINConv(torch.nn.Module):
         # 582, 2048: 1273 / 994 / 837, 8192: 1207 / 960 / 905; at 128 complexes = 256 items 633 / 711 / 322).
         lower = plan.at_least(F, has_up, has_b)
         table = None
-        if LAYER_VARIANT == '1' or (LAYER_VARIANT == 'auto' and lower > TWO_PER_CU_MIN_ITEMS):
+        if LAYER_VARIANT == '1':
             table = plan.items(F, has_up, has_b, variant=1)
+        elif LAYER_VARIANT == 'auto' and lower > 4 * TWO_PER_CU_MIN_ITEMS:
+            table = plan.items(F, has_up, has_b, variant=1)          # many rounds either way: two per CU (if every complex fits)
         if table is None and LAYER_VARIANT != '1':
             if lower > BLOCKED_MAX_ITEMS:
                 return f'more than {BLOCKED_MAX_ITEMS} items: beyond the range where one workgroup per item beats the streaming CSR path'
             table = plan.items(F, has_up, has_b)
             if table is not None and LAYER_VARIANT == 'auto' and table.n_items > TWO_PER_CU_MIN_ITEMS:
                 t1 = plan.items(F, has_up, has_b, variant=1)
-                table = t1 if t1 is not None else table
+                if t1 is not None and _two_per_cu_wins(table.n_items, t1.n_items):
+                    table = t1
         if table is None:
             return 'a complex does not fit one workgroup (row / entry caps)'
         if table.variant == 0 and table.n_items > BLOCKED_MAX_ITEMS:

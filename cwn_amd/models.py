@@ -40,13 +40,13 @@ def get_graph_norm(norm):
     raise ValueError(f'Graph Normalisation {norm} not currently supported')
 
 
-def _batch_adjacency(batch: torch.Tensor, size: int, n_rows: int):
+def _batch_adjacency(batch: torch.Tensor, size: int, n_rows: int, build: bool = True):
     """CSR keyed on the batch vector (cells of complex b = segment b), cached on the tensor."""
     ids = getattr(batch, '_cwn_ids', None)
     if ids is None or ids.numel() != batch.numel():
         ids = torch.arange(batch.numel(), device=batch.device)
         batch._cwn_ids, batch._cwn_index = ids, torch.stack([ids, batch])
-    return cached_adjacency(batch._cwn_index, size, n_rows)
+    return cached_adjacency(batch._cwn_index, size, n_rows, build=build)
 
 
 def global_pool(x: torch.Tensor, batch: torch.Tensor, size: int, mean: bool = False) -> torch.Tensor:
@@ -64,8 +64,18 @@ def pool_complex_list(xs: List[torch.Tensor], data: ComplexBatch, max_dim: int, 
     if batch_size is None:
         batch_size = int(data.cochains[0].batch.max()) + 1
     red = 'mean' if readout_type == 'mean' else 'add'
-    streams = [ops.Stream(adj=_batch_adjacency(data.cochains[i].batch, batch_size, xs[i].size(0)),
-                          n_dst=batch_size, width=int(xs[i].size(1)), A=xs[i], reduce=red)
+    # the plans of all dimensions -- and, when a backward will follow, their transposes -- in ONE batched build (they
+    # were four separate launches of ~10 us in every training step)
+    adjs = [_batch_adjacency(data.cochains[i].batch, batch_size, xs[i].size(0), build=False) for i in range(len(xs))]
+    todo = [a for a in adjs if not a.built]
+    if torch.is_grad_enabled() and any(x.requires_grad for x in xs):
+        for a in adjs:
+            a.transposes()
+            todo += [t for t in (a._t_src, a._t_aux) if t is not None and not t.built]
+    if todo:
+        from .csr import build_many
+        build_many(todo)
+    streams = [ops.Stream(adj=adjs[i], n_dst=batch_size, width=int(xs[i].size(1)), A=xs[i], reduce=red)
                for i in range(len(xs))]
     pooled = ops.aggregate_many(streams)
     for _ in range(len(xs), max_dim + 1):

@@ -719,6 +719,7 @@ def gemm_uses_split(gemms: Sequence[Gemm], device) -> bool:
 # cwn_amd.train.TrainStep -- which owns the flat gradient bucket and the all-reduce -- turns it on
 # around its own backward with `accumulate_into_grad()`.
 ACCUMULATE_INTO_GRAD = False
+DEFER_WEIGHT_GRADS = os.environ.get('CWN_DEFER_WEIGHT_GRADS') != '0'     # A/B: '0' launches every weight gradient where it arises
 
 
 class accumulate_into_grad:
@@ -730,11 +731,22 @@ class accumulate_into_grad:
     def __enter__(self):
         global ACCUMULATE_INTO_GRAD
         self.prev, ACCUMULATE_INTO_GRAD = ACCUMULATE_INTO_GRAD, self.on
+        # ... and, since nothing reads those buffers before the caller's optimizer step, the weight-gradient launches
+        # are collected and run together when the block ends (_ffi.gemm_tn / flush_tn)
+        self.defer = self.on and DEFER_WEIGHT_GRADS and _ffi._tn_queue is None
+        if self.defer:
+            _ffi.defer_tn(True)
         return self
 
     def __exit__(self, *exc):
         global ACCUMULATE_INTO_GRAD
         ACCUMULATE_INTO_GRAD = self.prev
+        if self.defer:
+            if exc[0] is None:
+                _ffi.flush_tn(torch.device('cuda', torch.cuda.current_device()))
+            else:
+                _ffi._tn_queue.clear()
+            _ffi.defer_tn(False)
         return False
 
 
@@ -843,7 +855,8 @@ class _GemmMany(torch.autograd.Function):
                         lddz=ld(g), ldx=ld(Xc), ldx2=0 if X2c is None else ld(X2c), lddw=dW.stride(0),
                         N=W.size(0), K=Xc.size(1), K2=0 if X2c is None else X2c.size(1), in_relu=0))
             if descs:
-                _ffi.gemm_tn(descs, dev)
+                # in-place targets only (no scratch handed back to autograd): the launch may wait for the end of the backward
+                _ffi.gemm_tn(descs, dev, keep=live + [flat], deferrable=ACCUMULATE_INTO_GRAD and flat is None)
         return (None, None) + tuple(grads)
 
 

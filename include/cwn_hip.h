@@ -504,6 +504,7 @@ int cwn_norm_bwd_apply_f32(const cwn_norm_desc* descs_host, int n, cwn_stream_t 
  * dW is [N, K + K2] (row stride lddw, torch Linear layout) and is ADDED to (the M rows are split
  * over workgroups whose partial tiles are then summed), so it can be the .grad buffer itself.
  * The prologue is the one of cwn_gemm_f32 (normalisation + ReLU of the producing layer). */
+#define CWN_GEMM_TN_MAX_DESCS 24   /* weight gradients per launch (the other batched calls take CWN_MAX_DESCS) */
 typedef struct cwn_gemm_tn_desc {
     const float* dZ;         /* [M, N] row stride lddz */
     const float* X;          /* [M, K] row stride ldx */
@@ -632,6 +633,14 @@ typedef struct cwn_head_dim {
 
 int cwn_head_f32(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
                  int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, cwn_stream_t stream);
+
+/* The loss of a training step and its gradient in one launch (exp/train_utils.py:62-73 with the elementwise-mean
+ * criteria of :20-31): loss[0] = mean_i l(pred_i, y_i), grad_i = dl/dpred_i / n over n contiguous fp32 elements.
+ * kinds: L1Loss, MSELoss, BCEWithLogitsLoss (torch's definitions, incl. sign(0) = 0 and the stable BCE form).
+ * One workgroup, fixed reduction tree (deterministic); meant for the few hundred predictions of a batch. */
+enum { CWN_LOSS_L1 = 0, CWN_LOSS_MSE = 1, CWN_LOSS_BCE_LOGITS = 2 };
+int cwn_loss_f32(int32_t kind, const float* pred, const float* y, int64_t n, float* loss, float* grad,
+                 cwn_stream_t stream);
 
 /* torch.optim.Adam's update (no amsgrad; weight_decay is the L2 form) for a whole model in one
  * launch: parameters p, gradients g and the moments m, v are each ONE contiguous fp32 buffer of n

@@ -112,6 +112,7 @@ def test_argument_errors_without_gpu():
     err = ctypes.c_int32(0)
     assert lib.cwn_embed_front_f32(tv, 0, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, ctypes.byref(err), None) == 0  # nothing to do
     assert lib.cwn_embed_front_f32(tv, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, ctypes.byref(err), None) == 1  # rows, no table
+    assert lib.cwn_loss_f32(0, None, None, 4, None, None, None) == 1 and lib.cwn_loss_f32(7, None, None, 4, None, None, None) == 1
     hd = (_ffi.HeadDim * 1)(_ffi.HeadDim())
     assert lib.cwn_head_f32(None, 1, 4, 128, 256, 0, 0, None, None, 1, None, None) == 1
     assert lib.cwn_head_f32(hd, 1, 0, 128, 256, 0, 0, None, None, 1, None, None) == 0          # no complexes

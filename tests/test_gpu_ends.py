@@ -173,3 +173,26 @@ def test_head_absent_dimension_and_batch_independence():
         out2 = model._head_fused(xs[:2], b, False, {})
     _, want2 = _head_reference(model, xs[:2], b, 'sum', 'sum')
     gate(out2, want2, 'head without dimension 2')
+
+
+@pytest.mark.parametrize('task', ['regression', 'mse_regression', 'bin_classification'])
+def test_fused_loss_matches_the_torch_criterion(task):
+    """cwn_loss_f32 (value and gradient in one launch) against the criteria of exp/train_utils.py:20-31, incl. the
+    sign(0) = 0 of L1Loss and large logits for the BCE."""
+    from cwn_amd.train import _LOSSES, fused_loss
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 128, 1000):
+        pred = (torch.randn(n, 1, generator=g) * 4).to(DEV)
+        y = (torch.rand(n, 1, generator=g) > 0.5).float().to(DEV) if task == 'bin_classification' else torch.randn(n, 1, generator=g).to(DEV)
+        if n > 1:
+            pred[0, 0] = y[0, 0]                                   # an exact hit: sign(0) = 0
+            pred[1, 0] = 60.0 if task == 'bin_classification' else pred[1, 0]
+        p1, p2 = pred.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+        l1 = fused_loss(task, p1, y)
+        assert l1 is not None
+        (l1 * 3.0).backward()
+        l2 = _LOSSES[task](p2, y)
+        (l2 * 3.0).backward()
+        torch.testing.assert_close(l1, l2, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(p1.grad, p2.grad, rtol=1e-6, atol=1e-8)
+    assert fused_loss('classification', pred, y) is None

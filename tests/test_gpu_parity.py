@@ -1520,11 +1520,13 @@ def test_training_accumulates_into_existing_grads():
 
     bucket = FlatGradBucket(fused.parameters())
     state = {k: v.clone() for k, v in fused.state_dict().items()}
+    # (the weight-gradient launches of a block run when it ENDS -- _ffi.flush_tn: the buffers are complete behind it)
     with ops.accumulate_into_grad():
         backward_once(fused)
-        once = bucket.flat.clone()
-        assert float(once.abs().max()) > 0
-        fused.load_state_dict(state)          # same running statistics / parameters for the second pass
+    once = bucket.flat.clone()
+    assert float(once.abs().max()) > 0
+    fused.load_state_dict(state)          # same running statistics / parameters for the second pass
+    with ops.accumulate_into_grad():
         backward_once(fused)
     torch.testing.assert_close(bucket.flat, 2 * once, rtol=1e-5, atol=1e-5 * float(once.abs().max()))
     # autograd's own accumulation (the default: grad hooks fire, torch.autograd.grad works)

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 ROOT=$PWD
 N=${1:-128}
-K=${2:-200}
+K=${2:-330}
 mkdir -p gpurun_out
 cd /tmp && rm -rf /tmp/prof_train
 rocprofv3 --kernel-trace --stats -d /tmp/prof_train -- python $ROOT/tools/train_graph.py $N 30 > /tmp/prof_train.log 2>&1
