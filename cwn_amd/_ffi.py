@@ -21,7 +21,7 @@ ABI_VERSION = 12
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
-           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
+           'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
 
 
@@ -100,7 +100,13 @@ class EmbedTable(C.Structure):
 class HeadDim(C.Structure):
     """cwn_head_dim (include/cwn_hip.h)."""
     _fields_ = [('x', C.c_void_p), ('cell_ptr', C.c_void_p), ('w1t', C.c_void_p), ('b1', C.c_void_p),
-                ('pooled_out', C.c_void_p), ('n_cells', C.c_int64), ('ldx', C.c_int64)]
+                ('pooled_out', C.c_void_p), ('h_out', C.c_void_p), ('n_cells', C.c_int64), ('ldx', C.c_int64)]
+
+
+class HeadBwdDim(C.Structure):
+    """cwn_head_bwd_dim (include/cwn_hip.h)."""
+    _fields_ = [('h', C.c_void_p), ('w1', C.c_void_p), ('cell_ptr', C.c_void_p), ('dx', C.c_void_p),
+                ('dh_out', C.c_void_p), ('n_cells', C.c_int64), ('lddx', C.c_int64)]
 
 
 ERR_BIT_BLOCK = 8         # = CWN_ERR_BIT_BLOCK
@@ -233,7 +239,10 @@ def lib():
                                       C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_head_f32.restype = C.c_int
     L.cwn_head_f32.argtypes = [C.POINTER(HeadDim), C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                               C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+                               C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cwn_head_bwd_f32.restype = C.c_int
+    L.cwn_head_bwd_f32.argtypes = [C.POINTER(HeadBwdDim), C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_lift_create.restype = C.c_void_p
     L.cwn_lift_create.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
     L.cwn_lift_size.restype = C.c_int64

@@ -358,7 +358,12 @@ class Complex(object):
         # the per-complex tables are cut from THESE index tensors (`__slices__` / `ptr`): a refilled batch
         # gets a fresh plan, re-validated against its entries on the next launch (a stale table
         # would have the kernel drop entries outside their complex without any host-side error)
-        if getattr(self, '_block_plan', None) is not None:
+        old = getattr(self, '_block_plan', None)
+        if old is not None:
+            # (the device copies of `ptr` survive when the next plan has the same cells per complex: an upload is not
+            # something a stream capture can hold, and a training step calls this inside its captured graph)
+            if old[1] is not None and old[1].__dict__.get('_cell_ptr_dev'):
+                self._cell_ptr_keep = (old[1].cell_ptr, old[1].__dict__['_cell_ptr_dev'])
             self._block_plan = None
         for c in self.cochains.values():
             for index in (c.upper_index, c.lower_index, c.boundary_index):
@@ -433,6 +438,12 @@ class Complex(object):
         if cached is None or cached[0] != x0.device:
             from .blockplan import BlockPlan
             cached = (x0.device, BlockPlan.from_batch(self))
+            keep = getattr(self, '_cell_ptr_keep', None)
+            if keep is not None and cached[1] is not None:
+                import numpy as np
+                if len(keep[0]) == len(cached[1].cell_ptr) and all(np.array_equal(a, b) for a, b in zip(keep[0], cached[1].cell_ptr)):
+                    cached[1].__dict__['_cell_ptr_dev'] = keep[1]
+                self._cell_ptr_keep = None
             self._block_plan = cached
         return cached[1]
 

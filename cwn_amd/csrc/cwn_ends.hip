@@ -181,6 +181,7 @@ constexpr int kPartFloats = 4 * kHeadThreads;          // partial row sums of on
 struct HeadArgs {
     cwn_head_dim d[CWN_HEAD_MAX_DIMS];
     const float* w2; const float* b2; float* out;
+    float* s_out;                                  // [C, H2] the summed hidden vector (training), or NULL
     int64_t C;
     int32_t n_dims, K, H2, O, mean_readout, mean_final;
 };
@@ -299,10 +300,12 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
             float h = 0.f;
             for (int q = 0; q < S; ++q) h += hpart[(size_t)d * 4 * kHeadThreads + q * H2 + tid];
             if (A.d[d].b1 != nullptr) h += A.d[d].b1[tid];
+            if (A.d[d].h_out != nullptr) A.d[d].h_out[c * H2 + tid] = h;      // pre-activation: the backward's ReLU mask
             s += fmaxf(h, 0.f);
         }
         if (A.mean_final) s = s / (float)nd;
         sbuf[tid] = s;
+        if (A.s_out != nullptr) A.s_out[c * H2 + tid] = s;
     }
     __syncthreads();
 
@@ -317,7 +320,119 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// head, backward (training): per complex  ds = W2^T g_out  ->  dh_d = ds . [h_d > 0]  ->  dpooled_d = W1_d^T dh_d  ->  every
+// row of the complex in x_d gets dpooled_d (/ count for a mean readout).  The weight gradients are sums over the
+// complexes -- dW1_d = dh_d^T pooled_d, dW2 = g_out^T s -- and are left to cwn_gemm_tn_f32 on the [C, .] matrices this
+// kernel writes (dh_out); here nothing is reduced across workgroups.  16 framework / GEMM launches of a training step
+// before (readout backward, two GEMMs and their weight gradients, six mask / multiply kernels).
+// ---------------------------------------------------------------------------------------------------------------
+struct HeadBwdArgs {
+    cwn_head_bwd_dim d[CWN_HEAD_MAX_DIMS];
+    const float* w2; const float* g_out;
+    int64_t C;
+    int32_t n_dims, K, H2, O, mean_readout, mean_final;
+};
+
+__global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int K = A.K, H2 = A.H2, nd = A.n_dims;
+    float* const dh = sm;                                          // [3][H2]
+    float* const part = dh + CWN_HEAD_MAX_DIMS * H2;               // [slices][K] partial dpooled of ONE dimension (<= 4 * 512)
+    float* const dp = part + 4 * kHeadThreads;                     // [K]
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    // 1. + 2.  ds and the masked dh of every dimension
+    if (tid < H2) {
+        float ds = 0.f;
+        for (int o = 0; o < A.O; ++o) ds = __builtin_fmaf(A.w2[(size_t)o * H2 + tid], A.g_out[c * A.O + o], ds);
+        if (A.mean_final) ds = ds / (float)nd;
+        for (int d = 0; d < nd; ++d) {
+            const float v = A.d[d].h[c * H2 + tid] > 0.f ? ds : 0.f;
+            dh[d * H2 + tid] = v;
+            if (A.d[d].dh_out != nullptr) A.d[d].dh_out[c * H2 + tid] = v;
+        }
+    }
+    __syncthreads();
+    const int KQ = K / 4, S = kHeadThreads / KQ;                    // a thread: four consecutive k, one slice of the j range
+    const int kq = tid % KQ, sl = tid / KQ;
+    const int G = KQ, NG = kHeadThreads / G, g = tid / G, l = tid - g * G;
+    for (int d = 0; d < nd; ++d) {
+        if (A.d[d].dx == nullptr || A.d[d].n_cells == 0) continue;   // uniform
+        // 3. dpooled_d[k] = sum_j W1_d[j][k] dh_d[j]   (W1 in its own [H2, K] layout: coalesced over k)
+        if (sl < S) {
+            const int jb = (H2 + S - 1) / S, j0 = min(H2, sl * jb), j1 = min(H2, j0 + jb);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* w = A.d[d].w1 + (size_t)j0 * K + 4 * kq;
+            int j = 0;
+            for (; j + 8 <= j1 - j0; j += 8) {
+                float4 wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const float4*>(w + (size_t)(j + u) * K);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float t = dh[d * H2 + j0 + j + u];
+                    a.x = __builtin_fmaf(wv[u].x, t, a.x); a.y = __builtin_fmaf(wv[u].y, t, a.y);
+                    a.z = __builtin_fmaf(wv[u].z, t, a.z); a.w = __builtin_fmaf(wv[u].w, t, a.w);
+                }
+            }
+            for (; j < j1 - j0; ++j) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)j * K);
+                const float t = dh[d * H2 + j0 + j];
+                a.x = __builtin_fmaf(wv.x, t, a.x); a.y = __builtin_fmaf(wv.y, t, a.y);
+                a.z = __builtin_fmaf(wv.z, t, a.z); a.w = __builtin_fmaf(wv.w, t, a.w);
+            }
+            *reinterpret_cast<float4*>(part + (size_t)sl * K + 4 * kq) = a;
+        }
+        __syncthreads();
+        int64_t r0 = A.d[d].cell_ptr[c], r1 = A.d[d].cell_ptr[c + 1];
+        r0 = r0 < 0 ? 0 : (r0 > A.d[d].n_cells ? A.d[d].n_cells : r0);
+        r1 = r1 < r0 ? r0 : (r1 > A.d[d].n_cells ? A.d[d].n_cells : r1);
+        if (tid < K) {
+            float v = 0.f;
+            for (int q = 0; q < S; ++q) v += part[(size_t)q * K + tid];       // fixed order
+            if (A.mean_readout) v = v / (float)(r1 - r0 > 0 ? r1 - r0 : 1);
+            dp[tid] = v;
+        }
+        __syncthreads();
+        // 4. every row of the complex gets it
+        if (g < NG) {
+            const float4 v = *reinterpret_cast<const float4*>(dp + 4 * l);
+            for (int64_t r = r0 + g; r < r1; r += NG)
+                cwn::store_result4(A.d[d].dx + r * A.d[d].lddx + 4 * l, v.x, v.y, v.z, v.w);
+        }
+        __syncthreads();                       // `part` / `dp` are reused by the next dimension
+    }
+}
+
 }  // namespace
+
+extern "C" int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims, int n_dims, int64_t C, int32_t K, int32_t H2,
+                                int32_t mean_readout, int32_t mean_final, const float* w2, int32_t O, const float* g_out,
+                                cwn_stream_t stream_) {
+    if (dims == nullptr || n_dims < 1 || n_dims > CWN_HEAD_MAX_DIMS || C < 0 || O < 1) return CWN_ERR_BAD_ARG;
+    if (K < 4 || (K & 3) != 0 || K > 4 * kHeadThreads || H2 < 4 || (H2 & 3) != 0 || H2 > kHeadThreads) return CWN_ERR_BAD_ARG;
+    if (C == 0) return CWN_OK;
+    if (C >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    if (w2 == nullptr || g_out == nullptr) return CWN_ERR_BAD_ARG;
+    HeadBwdArgs A{};
+    for (int d = 0; d < n_dims; ++d) {
+        const cwn_head_bwd_dim& D = dims[d];
+        if (D.h == nullptr || D.n_cells < 0) return CWN_ERR_BAD_ARG;
+        if (D.dx != nullptr && D.n_cells > 0 && (D.cell_ptr == nullptr || D.w1 == nullptr || D.lddx < K || (D.lddx & 3) != 0))
+            return CWN_ERR_BAD_ARG;
+        if (!al16(D.dx) || !al16(D.w1)) return CWN_ERR_ALIGN;
+        A.d[d] = D;
+    }
+    A.w2 = w2; A.g_out = g_out;
+    A.C = C;
+    A.n_dims = n_dims; A.K = K; A.H2 = H2; A.O = O;
+    A.mean_readout = mean_readout ? 1 : 0;
+    A.mean_final = mean_final ? 1 : 0;
+    const size_t lds = ((size_t)CWN_HEAD_MAX_DIMS * H2 + 4 * kHeadThreads + K) * sizeof(float);
+    head_bwd_kernel<<<dim3((unsigned)C), dim3(kHeadThreads), lds, (hipStream_t)stream_>>>(A);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
 
 extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, float* x0, const cwn_embed_table* e_tab,
                                    int64_t n1, float* x1, const int32_t* rowptr1, const int32_t* col1, int64_t nb1, int64_t n2,
@@ -355,7 +470,7 @@ extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, flo
 }
 
 extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
-                            int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out,
+                            int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, float* s_out,
                             cwn_stream_t stream_) {
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_HEAD_MAX_DIMS || C < 0 || O < 1) return CWN_ERR_BAD_ARG;
     // K / 4 lanes a row inside 512 threads; output j by thread j
@@ -372,6 +487,7 @@ extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int
         A.d[d] = D;
     }
     A.w2 = w2; A.b2 = b2; A.out = out;
+    A.s_out = s_out;
     A.C = C;
     A.n_dims = n_dims; A.K = K; A.H2 = H2; A.O = O;
     A.mean_readout = mean_readout ? 1 : 0;

@@ -244,9 +244,11 @@ class _SparseCINStack(torch.nn.Module):
         if not rd or len(rd) > 3:
             return None
         lins = [self.lin1s[d] for d in rd]
-        if torch.is_grad_enabled() and (any(p.requires_grad for l in lins + [self.lin2] for p in l.parameters())
-                                        or any(x.requires_grad for x in xs)):
-            return None
+        train = torch.is_grad_enabled() and (any(p.requires_grad for l in lins + [self.lin2] for p in l.parameters())
+                                             or any(x.requires_grad for x in xs))
+        if train and (not ops.FUSED_HEAD_TRAINING or any(d >= len(xs) for d in rd) or any(l.bias is None for l in lins)
+                      or self.lin2.bias is None):
+            return None              # (absent dimensions / bias-free lin1s: the unfused autograd path)
         plan = data.block_plan()
         if plan is None or data.num_complexes is None or plan.C != data.num_complexes:
             return None
@@ -260,6 +262,14 @@ class _SparseCINStack(torch.nn.Module):
         if any(d < len(xs) and h is None for d, h in zip(rd, hx)):
             return None                    # a feature matrix that is not the batch's own rows
         ptrs = [plan.cell_ptr_device(d, dev) if h is not None else None for d, h in zip(rd, hx)]
+        if train:
+            out, pooled = ops.head_train(hx, ptrs, plan.C, [l.weight for l in lins], [l.bias for l in lins],
+                                         self.lin2.weight, self.lin2.bias, mean_readout=self.readout == 'mean',
+                                         mean_final=self.final_readout == 'mean')
+            if include_partial:
+                for k in range(len(rd)):
+                    res[f'pool_{k}'] = pooled[k]
+            return out
         got = ops.head(hx, ptrs, plan.C, [l.weight for l in lins], [l.bias for l in lins], self.lin2.weight, self.lin2.bias,
                        mean_readout=self.readout == 'mean', mean_final=self.final_readout == 'mean',
                        want_pooled=include_partial)

@@ -173,7 +173,8 @@ class _AggregateMany(torch.autograd.Function):
         """Gradient of out[i] = max_p A[ia[p]] w.r.t. A: g[i, f] goes to ONE entry of the row, the first
         (in entry order) that attains the maximum -- torch-scatter's arg-max rule, the library behind
         mp/cell_mp.py:104-105, 439; torch's own amax spreads it over ties, identical without ties.
-        Plain tensor ops: the mode is exercised by no reference test (parity unpinned), not a hot path."""
+        Tensor ops for the selection, the library's own transposed aggregation for the sum: the mode is exercised by no
+        reference test (parity unpinned), not a hot path."""
         adj = st.adj
         E = adj.n_entries
         src = (adj.col if st.ia_mode == 'col' else adj.perm).long()
@@ -184,7 +185,15 @@ class _AggregateMany(torch.autograd.Function):
         start = adj.rowptr[:-1].long()[rowid]
         base = torch.where((start > 0).unsqueeze(1), c[(start - 1).clamp(min=0)], torch.zeros_like(c))
         first = eq & ((c - base) == 1)
-        return torch.zeros_like(A).index_add_(0, src, g[rowid] * first)
+        # the selected gradients go back to their SOURCE rows through the transposed plan (a segmented sum keyed on the
+        # source cell, in entry order: deterministic) -- round 2 used index_add_, i.e. fp32 atomics in arrival order
+        vals = g[rowid] * first                                   # [E, F] by CSR position
+        by_entry = torch.empty_like(vals)
+        by_entry[adj.perm.long()] = vals                          # ... by original entry number (a permutation)
+        t = adj.t_src
+        if st.ia_mode != 'col':                                   # per-entry operand: its "source rows" are the entries
+            return by_entry
+        return aggregate(t, t.n_dst, by_entry, ia_mode='perm')
 
     @staticmethod
     def backward(ctx, *gs):
@@ -472,6 +481,7 @@ class _EmbeddingSum(torch.autograd.Function):
 # the two ends of a model forward, one launch each (csrc/cwn_ends.hip; inference)
 # ------------------------------------------------------------------------------------------------
 FUSED_ENDS = True            # False: the front / head run as the separate launches they replace (A/B, tests)
+FUSED_HEAD_TRAINING = os.environ.get('CWN_FUSED_HEAD_TRAINING') != '0'    # the head with autograd as two launches (+ weight-gradient GEMMs)
 
 _table_cache = {}            # concatenated embedding tables, keyed on the weights' identities and versions
 
@@ -553,7 +563,7 @@ def _transposed(weight: Tensor) -> Tensor:
 
 def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexes: int, lin1_weights: Sequence[Tensor],
          lin1_biases: Sequence[Optional[Tensor]], lin2_weight: Tensor, lin2_bias: Optional[Tensor],
-         mean_readout: bool = False, mean_final: bool = False, want_pooled: bool = False):
+         mean_readout: bool = False, mean_final: bool = False, want_pooled: bool = False, want_hidden: bool = False):
     """pool_complex + lin1s (+ReLU) + final readout + lin2 in ONE launch (cwn_head_f32), one workgroup per complex.
     xs[d]: [N_d, K] or None (dimension absent from the batch: pooled zeros, mp/nn.py:55-56); cell_ptrs[d]: device
     int64 [C + 1], the collate's `ptr`.  Returns out [C, O] (and the pooled [C, K] per dimension)."""
@@ -561,7 +571,7 @@ def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexe
     _ffi.require_gpu(x0, 'x')
     dev = x0.device
     K, H2, O = int(lin1_weights[0].size(1)), int(lin1_weights[0].size(0)), int(lin2_weight.size(0))
-    keep, dims, pooled = [], [], []
+    keep, dims, pooled, hidden = [], [], [], []
     for d, x in enumerate(xs):
         D = _ffi.HeadDim()
         if x is not None:
@@ -572,20 +582,108 @@ def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexe
         w1t = _transposed(lin1_weights[d])
         b1 = None if lin1_biases[d] is None else _f32c(lin1_biases[d].detach(), 'lin1 bias')
         D.w1t, D.b1 = w1t.data_ptr(), _ffi.ptr(b1)
-        if want_pooled:
+        if want_pooled or want_hidden:
             po = torch.empty(n_complexes, K, dtype=torch.float32, device=dev)
             pooled.append(po)
             D.pooled_out = po.data_ptr()
+        if want_hidden:
+            ho = torch.empty(n_complexes, H2, dtype=torch.float32, device=dev)
+            hidden.append(ho)
+            D.h_out = ho.data_ptr()
         keep += [x, w1t, b1]
         dims.append(D)
     w2 = _f32c(lin2_weight.detach(), 'lin2 weight')
     b2 = None if lin2_bias is None else _f32c(lin2_bias.detach(), 'lin2 bias')
     out = torch.empty(n_complexes, O, dtype=torch.float32, device=dev)
+    s_out = torch.empty(n_complexes, H2, dtype=torch.float32, device=dev) if want_hidden else None
     arr = (_ffi.HeadDim * len(dims))(*dims)
     _ffi.check(_ffi.lib().cwn_head_f32(arr, len(dims), n_complexes, K, H2, 1 if mean_readout else 0,
                                        1 if mean_final else 0, w2.data_ptr(), _ffi.ptr(b2), O, out.data_ptr(),
-                                       _ffi.stream_ptr(dev)), 'cwn_head_f32')
+                                       _ffi.ptr(s_out), _ffi.stream_ptr(dev)), 'cwn_head_f32')
+    if want_hidden:
+        return out, pooled, hidden, s_out
     return (out, pooled) if want_pooled else out
+
+
+class _HeadTrain(torch.autograd.Function):
+    """The same head with autograd (the training step, exp/train_utils.py:57-75): forward = cwn_head_f32 leaving the
+    pooled vectors, the pre-activations and the hidden vector; backward = ONE launch per complex (cwn_head_bwd_f32:
+    dL/dx of every dimension) + the weight gradients as [C, .]^T [C, .] products through cwn_gemm_tn_f32 (deferred and
+    merged with the step's other weight gradients inside accumulate_into_grad).  Replaces 5 forward and 16 backward
+    launches of the unfused path (readout, two grouped GEMMs, ReLU masks, adds)."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        n_dims, cell_ptrs, C, mean_readout, mean_final = meta
+        xs = tensors[:n_dims]
+        w1s = tensors[n_dims:2 * n_dims]
+        b1s = tensors[2 * n_dims:3 * n_dims]
+        w2, b2 = tensors[3 * n_dims], tensors[3 * n_dims + 1]
+        out, pooled, hidden, s_out = head(xs, cell_ptrs, C, w1s, b1s, w2, b2, mean_readout, mean_final, want_hidden=True)
+        ctx.meta = meta
+        ctx.shapes = [None if x is None else (int(x.size(0)), int(x.size(1))) for x in xs]
+        ctx.params = (w1s, b1s, w2, b2)
+        ctx.save_for_backward(*pooled, *hidden, s_out)
+        ctx.mark_non_differentiable(*pooled)
+        return (out,) + tuple(pooled)
+
+    @staticmethod
+    def backward(ctx, g_out, *_):
+        n_dims, cell_ptrs, C, mean_readout, mean_final = ctx.meta
+        saved = ctx.saved_tensors
+        pooled, hidden, s_out = saved[:n_dims], saved[n_dims:2 * n_dims], saved[2 * n_dims]
+        w1s, b1s, w2, b2 = ctx.params
+        dev = g_out.device
+        g_out = _f32c(g_out, 'grad')
+        K, H2, O = int(w1s[0].size(1)), int(w1s[0].size(0)), int(w2.size(0))
+        dims, dxs, dhs, keep = [], [], [], []
+        for d in range(n_dims):
+            D = _ffi.HeadBwdDim(h=hidden[d].data_ptr())
+            dh = torch.empty(C, H2, dtype=torch.float32, device=dev)
+            dhs.append(dh)
+            D.dh_out = dh.data_ptr()
+            dx = None
+            if ctx.shapes[d] is not None and ctx.needs_input_grad[1 + d]:
+                w1 = _f32c(w1s[d].detach(), 'lin1 weight')
+                dx = torch.empty(ctx.shapes[d][0], K, dtype=torch.float32, device=dev)
+                D.w1, D.cell_ptr, D.dx, D.n_cells, D.lddx = w1.data_ptr(), cell_ptrs[d].data_ptr(), dx.data_ptr(), dx.size(0), K
+                keep.append(w1)
+            dxs.append(dx)
+            dims.append(D)
+        w2c = _f32c(w2.detach(), 'lin2 weight')
+        arr = (_ffi.HeadBwdDim * n_dims)(*dims)
+        _ffi.check(_ffi.lib().cwn_head_bwd_f32(arr, n_dims, C, K, H2, 1 if mean_readout else 0, 1 if mean_final else 0,
+                                               w2c.data_ptr(), O, g_out.data_ptr(), _ffi.stream_ptr(dev)), 'cwn_head_bwd_f32')
+        # weight gradients: sums over the complexes = dZ^T X on [C, .] matrices; in-place targets when the caller owns them
+        jobs = [(dhs[d], pooled[d], w1s[d], b1s[d]) for d in range(n_dims)] + [(g_out, s_out, w2, b2)]
+        grads_w, grads_b, descs, scratch = [], [], [], []
+        in_place = True
+        for k, (dZ, X, W, b) in enumerate(jobs):
+            nW = ctx.needs_input_grad[1 + n_dims + k] if k < n_dims else ctx.needs_input_grad[1 + 3 * n_dims]
+            nb = b is not None and (ctx.needs_input_grad[1 + 2 * n_dims + k] if k < n_dims else ctx.needs_input_grad[2 + 3 * n_dims])
+            tw = _grad_target(W) if nW else None
+            tb = _grad_target(b) if nb else None
+            dW = tw if tw is not None else torch.zeros(W.shape, dtype=torch.float32, device=dev)
+            db = (tb if tb is not None else torch.zeros(W.size(0), dtype=torch.float32, device=dev)) if nb else None
+            in_place = in_place and (tw is not None or not nW) and (tb is not None or not nb)
+            grads_w.append(None if (tw is not None or not nW) else dW)
+            grads_b.append(None if (tb is not None or not nb) else db)
+            scratch += [dW, db]
+            descs.append(_ffi.GemmTnDesc(dZ=dZ.data_ptr(), X=X.data_ptr(), X2=None, in_scale=None, in_shift=None,
+                                         in_scale2=None, in_shift2=None, dW=dW.data_ptr(), db=_ffi.ptr(db), M=C,
+                                         lddz=dZ.size(1), ldx=X.size(1), ldx2=0, lddw=dW.stride(0), N=W.size(0), K=X.size(1),
+                                         K2=0, in_relu=0))
+        _ffi.gemm_tn(descs, dev, keep=[dhs, list(pooled), s_out, g_out, scratch], deferrable=ACCUMULATE_INTO_GRAD and in_place)
+        return (None,) + tuple(dxs) + tuple(grads_w[:n_dims]) + tuple(grads_b[:n_dims]) + (grads_w[n_dims], grads_b[n_dims])
+
+
+def head_train(xs, cell_ptrs, n_complexes, lin1_weights, lin1_biases, lin2_weight, lin2_bias, mean_readout=False,
+               mean_final=False):
+    """(out, pooled list) with autograd: see _HeadTrain."""
+    n = len(xs)
+    meta = (n, list(cell_ptrs), int(n_complexes), bool(mean_readout), bool(mean_final))
+    res = _HeadTrain.apply(meta, *xs, *lin1_weights, *lin1_biases, lin2_weight, lin2_bias)
+    return res[0], list(res[1:])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -628,11 +628,33 @@ typedef struct cwn_head_dim {
     const float* w1t;           /* [K, H2] */
     const float* b1;            /* [H2] or NULL */
     float* pooled_out;          /* [C, K] or NULL */
+    float* h_out;               /* [C, H2] or NULL: W1_d pooled_d + b1_d BEFORE the ReLU (training: the backward's mask) */
     int64_t n_cells, ldx;
 } cwn_head_dim;
 
+/* s_out (optional, training): [C, H2] the hidden vector lin2 multiplies (sum / mean over the dimensions). */
 int cwn_head_f32(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
-                 int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, cwn_stream_t stream);
+                 int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, float* s_out,
+                 cwn_stream_t stream);
+
+/* Backward of the same head for the training step (exp/train_utils.py:62-73), one workgroup per complex, given
+ * g_out = dL/dout [C, O] and what the forward left (h_out per dimension):
+ *     ds = W2^T g_out [/ n_dims];  dh_d = ds . [h_d > 0]  (written to dh_out [C, H2]);
+ *     dx_d[r] = W1_d^T dh_d  [/ cells of the complex]   for every row r of the complex   (dx == NULL: not wanted)
+ * The weight gradients are sums over the complexes and go through cwn_gemm_tn_f32 on the [C, .] matrices:
+ * dW1_d = dh_d^T pooled_d, db1_d = column sums of dh_d, dW2 = g_out^T s, db2 = column sums of g_out.
+ * w1 is lin1s[d].weight in its own [H2, K] layout (16-B aligned); same size limits as the forward. */
+typedef struct cwn_head_bwd_dim {
+    const float* h;             /* [C, H2] pre-activation saved by the forward */
+    const float* w1;            /* [H2, K] */
+    const int64_t* cell_ptr;    /* device [C + 1] */
+    float* dx;                  /* [n_cells, K], row stride lddx, or NULL */
+    float* dh_out;              /* [C, H2] or NULL */
+    int64_t n_cells, lddx;
+} cwn_head_bwd_dim;
+
+int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
+                     int32_t mean_final, const float* w2, int32_t O, const float* g_out, cwn_stream_t stream);
 
 /* The loss of a training step and its gradient in one launch (exp/train_utils.py:62-73 with the elementwise-mean
  * criteria of :20-31): loss[0] = mean_i l(pred_i, y_i), grad_i = dl/dpred_i / n over n contiguous fp32 elements.

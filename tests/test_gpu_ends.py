@@ -196,3 +196,67 @@ def test_fused_loss_matches_the_torch_criterion(task):
         torch.testing.assert_close(l1, l2, rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(p1.grad, p2.grad, rtol=1e-6, atol=1e-8)
     assert fused_loss('classification', pred, y) is None
+
+
+@pytest.mark.parametrize('hidden,readout,final_readout', [(128, 'sum', 'sum'), (64, 'mean', 'mean')])
+def test_training_head_matches_the_unfused_autograd_path(hidden, readout, final_readout):
+    """The head with autograd as two launches (cwn_head_f32 leaving pooled / pre-activations / hidden vector,
+    cwn_head_bwd_f32) + the weight gradients through cwn_gemm_tn_f32, against the unfused path (segmented reduce,
+    grouped GEMMs, torch adds -- each with its own backward): output, dL/dx of every dimension, every parameter
+    gradient; and against float64 CPU autograd of the same formulas."""
+    from cwn_amd import ops
+    from cwn_amd.synthetic import zinc_like_batch
+    model = _zinc_model(hidden, layers=1, readout=readout, final_readout=final_readout, seed=21).train()
+    b = zinc_like_batch(29, seed=22, device=DEV)
+    K = model.lin1s[0].in_features
+    g = torch.Generator().manual_seed(23)
+    x0 = [torch.randn(b.cochains[d].num_cells, K, generator=g) for d in range(3)]
+    w = torch.randn(b.num_complexes, 1, generator=g).to(DEV)
+    grads = {}
+    for fused in (True, False):
+        prev, ops.FUSED_HEAD_TRAINING = ops.FUSED_HEAD_TRAINING, fused
+        try:
+            model.zero_grad(set_to_none=True)
+            xs = [x.clone().to(DEV).requires_grad_(True) for x in x0]
+            res = {}
+            out = model._head_fused(xs, b, True, res)
+            if not fused:
+                assert out is None
+                with _ends(False):
+                    from cwn_amd.models import pool_complex_list
+                    pooled = pool_complex_list(xs, b, 2, readout)
+                    hs = [torch.relu(model.lin1s[d](pooled[d])) for d in range(3)]
+                    sv = hs[0] + hs[1] + hs[2]
+                    out = model.lin2(sv / 3 if final_readout == 'mean' else sv)
+            (out * w).sum().backward()
+            grads[fused] = (out.detach(), [x.grad for x in xs], {n: p.grad.clone() for n, p in model.named_parameters()
+                                                                 if p.grad is not None and ('lin1s' in n or 'lin2' in n)})
+        finally:
+            ops.FUSED_HEAD_TRAINING = prev
+    gate(grads[True][0], grads[False][0].double(), 'training head out')
+    for d in range(3):
+        gate(grads[True][1][d], grads[False][1][d].double(), f'training head dL/dx[{d}]')
+    assert set(grads[True][2]) == set(grads[False][2]) and len(grads[True][2]) == 8
+    for n in grads[True][2]:
+        gate(grads[True][2][n], grads[False][2][n].double(), f'training head dL/d{n}', tol=2e-5)
+    # float64 reference of the whole thing
+    lin = [(model.lin1s[d].weight.detach().double().cpu().requires_grad_(True), model.lin1s[d].bias.detach().double().cpu().requires_grad_(True)) for d in range(3)]
+    w2, b2 = model.lin2.weight.detach().double().cpu().requires_grad_(True), model.lin2.bias.detach().double().cpu().requires_grad_(True)
+    xr = [x.double().requires_grad_(True) for x in x0]
+    C = b.num_complexes
+    hs = []
+    for d in range(3):
+        bv = b.cochains[d].batch.cpu()
+        p = torch.zeros(C, K, dtype=torch.float64).index_add(0, bv, xr[d])
+        if readout == 'mean':
+            p = p / torch.bincount(bv, minlength=C).clamp(min=1).double().unsqueeze(1)
+        hs.append(torch.relu(p @ lin[d][0].t() + lin[d][1]))
+    sv = hs[0] + hs[1] + hs[2]
+    ref = (sv / 3 if final_readout == 'mean' else sv) @ w2.t() + b2
+    (ref * w.double().cpu()).sum().backward()
+    gate(grads[True][0], ref.detach(), 'training head out vs float64')
+    for d in range(3):
+        gate(grads[True][1][d], xr[d].grad, f'training head dL/dx[{d}] vs float64')
+        gate(grads[True][2][f'lin1s.{d}.weight'], lin[d][0].grad, f'dL/dlin1s.{d}.weight vs float64', tol=2e-5)
+    gate(grads[True][2]['lin2.weight'], w2.grad, 'dL/dlin2.weight vs float64', tol=2e-5)
+    gate(grads[True][2]['lin2.bias'], b2.grad, 'dL/dlin2.bias vs float64', tol=2e-5)
