@@ -75,6 +75,16 @@ MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA, dense
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (never the 2:1-sparsity figure)
 
 
+def load_profile_json(stem):
+    """profiles/r<N>_<stem>.json of the latest round that has one (PMC traffic of the kernels, tools/collect_traffic.py)."""
+    for r in (3, 2):
+        path = os.path.join(ROOT, 'profiles', f'r{r}_{stem}.json')
+        if os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh)
+    raise OSError(stem)
+
+
 def gemm_roofline(flops, us, split, io_bytes, narrow, traffic):
     """Roofline entry of the grouped message GEMM.  The exact kernel is priced against the fp32-MFMA
     peak.  The split kernel (cwn_gemm_split.hip) issues SIX bf16 MFMAs per fp32-accurate product
@@ -461,8 +471,7 @@ def main():
                           + 16 * (s0_['B1'] + s0_['B2']) + 2 * 4 * H * s0_['cells'])
             traffic = None
             try:
-                with open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as fh:
-                    tj = json.load(fh)
+                tj = load_profile_json('traffic')
                 ent = tj['entries'].get(str(args.batch))
                 if WL == 'zinc' and tj.get('hidden') == H and ent and ent.get('kernel', '').startswith('layer_kernel'):
                     traffic = ent['traffic_bytes']
@@ -573,8 +582,7 @@ def main():
             # workload shape); None when no pass exists for this configuration
             traffic = None
             try:
-                with open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as fh:
-                    tj = json.load(fh)
+                tj = load_profile_json('traffic')
                 ent = tj['entries'].get(str(args.batch))
                 if WL == 'zinc' and tj.get('hidden') == H and ent and ent.get('kernel', '').startswith('aggregate_kernel'):
                     traffic = ent['traffic_bytes']
@@ -591,8 +599,7 @@ def main():
             # streams as MI355X_MICROARCH.md prescribes, WRITE_SIZE as is), K <= 128 wide-tile kernel
             gemm_traffic = None
             try:
-                with open(os.path.join(ROOT, 'profiles', 'r2_pmc_fetch_write_raw.json')) as fh:
-                    raw = json.load(fh).get(str(args.batch), {})
+                raw = load_profile_json('pmc_fetch_write_raw').get(str(args.batch), {})
                 if WL == 'zinc' and H == 128:
                     for kname, v in raw.items():
                         if kname.startswith('gemm_split_kernel') or (gemm_traffic is None and kname.startswith('gemm_kernel<true, false, 128, 4')):

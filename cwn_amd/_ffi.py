@@ -64,7 +64,9 @@ class LayerDim(C.Structure):
     _fields_ = [('x', C.c_void_p), ('up_index', C.c_void_p), ('up_shared', C.c_void_p),
                 ('b_index', C.c_void_p), ('msg_w_packed', C.c_void_p), ('msg_bias', C.c_void_p),
                 ('eps1', C.c_void_p), ('eps2', C.c_void_p), ('out_up', C.c_void_p),
-                ('out_b', C.c_void_p), ('n_cells', C.c_int64), ('e_up', C.c_int64), ('n_b', C.c_int64)]
+                ('out_b', C.c_void_p), ('n_cells', C.c_int64), ('e_up', C.c_int64), ('n_b', C.c_int64),
+                ('big_up_rowptr', C.c_void_p), ('big_up_col', C.c_void_p), ('big_up_aux', C.c_void_p),
+                ('big_b_rowptr', C.c_void_p), ('big_b_col', C.c_void_p), ('big_y1', C.c_void_p), ('big_y2', C.c_void_p)]
 
 
 class LayerPlan(C.Structure):
@@ -72,12 +74,13 @@ class LayerPlan(C.Structure):
     _fields_ = [('items', C.c_void_p), ('csr_cache', C.c_void_p), ('n_items', C.c_int64),
                 ('set_start', C.c_int32 * 4), ('max_gemm_rows', C.c_int32), ('max_source_rows', C.c_int32),
                 ('variant', C.c_int32), ('cells_end', C.c_int64 * 3), ('up_end', C.c_int64 * 3),
-                ('b_end', C.c_int64 * 3), ('lds_bytes', C.c_int64)]
+                ('b_end', C.c_int64 * 3), ('n_big', C.c_int64), ('lds_bytes', C.c_int64)]
 
 
 class LayerSizes(C.Structure):
     """cwn_layer_sizes (include/cwn_hip.h)."""
     _fields_ = [('n_complexes', C.c_int64), ('n_dims', C.c_int32), ('has_up', C.c_int32 * 3),
+                ('allow_big', C.c_int32), ('pad_', C.c_int32),
                 ('cell_ptr', C.c_void_p * 3), ('up_ptr', C.c_void_p * 3), ('b_ptr', C.c_void_p * 3)]
 
 

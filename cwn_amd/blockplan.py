@@ -51,9 +51,13 @@ class ItemTable:
     needs to know about it (cwn_layer_plan) + the per-item CSR cache and its validity."""
 
     def __init__(self, table: np.ndarray, set_start: List[int], max_rows: int, max_src: int,
-                 cells_end, up_end, b_end, device, variant: int = 0, lds_bytes: int = 0):
+                 cells_end, up_end, b_end, device, variant: int = 0, lds_bytes: int = 0, n_big: int = 0):
         self.variant = int(variant)        # 0: one 16-wave workgroup per CU; 1: the two-per-CU form (include/cwn_hip.h)
         self.lds_bytes = int(lds_bytes)    # variant 1: dynamic LDS of the launch (the largest per-item need)
+        self.n_big = int(n_big)            # BIG records: complexes a workgroup streams (include/cwn_hip.h)
+        # (set, complex) of every BIG record and what the launch needs for them (ops.LayerLaunch fills it in)
+        self.big_records = table[(table[:, 0] & 2) != 0].copy() if n_big else None
+        self.big_ctx = None
         self.n_items = int(table.shape[0])
         self.items = torch.from_numpy(table)
         if device is not None:
@@ -70,7 +74,7 @@ class ItemTable:
             self.csr_cache = torch.empty(self.n_items * CSR_SLOT_BYTES, dtype=torch.uint8, device=self.device)
         p = _ffi.LayerPlan(items=self.items.data_ptr(), csr_cache=_ffi.ptr(self.csr_cache) if with_cache else None,
                            n_items=self.n_items, max_gemm_rows=self.max_rows, max_source_rows=self.max_src,
-                           variant=self.variant, lds_bytes=self.lds_bytes)
+                           variant=self.variant, lds_bytes=self.lds_bytes, n_big=self.n_big)
         for i, v in enumerate(self.set_start[:4]):
             p.set_start[i] = int(v)
         for d in range(len(self.cells_end)):
@@ -164,7 +168,7 @@ class BlockPlan:
         return n
 
     def items(self, F: int, has_up: Sequence[bool], has_b: Optional[Sequence[bool]] = None,
-              variant: int = 0) -> Optional[ItemTable]:
+              variant: int = 0, allow_big: bool = False) -> Optional[ItemTable]:
         """The item table for feature width F, or None when some complex does not fit one
         workgroup's LDS (hub complexes: the caller then runs the CSR path).  `has_up[d]`: dimension d
         reduces an upper adjacency with coboundary features (needs d + 1 < n_dims).  `has_b[d]`: the
@@ -175,12 +179,12 @@ class BlockPlan:
         if has_b is None:
             has_b = [p is not None for p in self.b_ptr]
         key = (F, tuple(bool(h) for h in has_up), tuple(bool(h) and self.b_ptr[d] is not None for d, h in enumerate(has_b)),
-               int(variant))
+               int(variant), bool(allow_big))
         if key not in self._tables:
-            self._tables[key] = self._build(F, key[1], key[2], key[3])
+            self._tables[key] = self._build(F, key[1], key[2], key[3], key[4])
         return self._tables[key]
 
-    def _build(self, F: int, has_up, has_b, variant: int = 0) -> Optional[ItemTable]:
+    def _build(self, F: int, has_up, has_b, variant: int = 0, allow_big: bool = False) -> Optional[ItemTable]:
         """cwn_layer_items_build (csrc/cwn_blockplan.cpp, host C++): the greedy cut under the kernel's caps and
         the split of one launch's LDS between staged rows and boundary sources that gives the fewest items.  (A
         Python version of the same took 11 ms for a ZINC-like batch of 128 -- tests/_blockplan_ref.py keeps it as
@@ -192,7 +196,7 @@ class BlockPlan:
         for d in range(self.n_dims):
             if has_up[d] and (d + 1 >= self.n_dims or self.up_ptr[d] is None):
                 return None
-        sizes = _ffi.LayerSizes(n_complexes=C, n_dims=self.n_dims)
+        sizes = _ffi.LayerSizes(n_complexes=C, n_dims=self.n_dims, allow_big=1 if (allow_big and variant == 0) else 0)
         keep = []
         for d in range(self.n_dims):
             sizes.has_up[d] = 1 if has_up[d] else 0
@@ -215,7 +219,7 @@ class BlockPlan:
         out = ItemTable(table, [int(plan.set_start[i]) for i in range(n_sets)], int(plan.max_gemm_rows),
                         int(plan.max_source_rows), [int(plan.cells_end[d]) for d in range(self.n_dims)],
                         [int(plan.up_end[d]) for d in range(self.n_dims)], [int(plan.b_end[d]) for d in range(self.n_dims)],
-                        self.device, variant=variant, lds_bytes=int(plan.lds_bytes))
+                        self.device, variant=variant, lds_bytes=int(plan.lds_bytes), n_big=int(plan.n_big))
         rc = _ffi.lib().cwn_layer_items_check(table.ctypes.data, n, F, out.c_plan(False))
         if rc != 0:
             raise _ffi.CwnError(f'item table failed cwn_layer_items_check ({rc})')

@@ -66,7 +66,7 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
     Set sets[CWN_LAYER_MAX_DIMS];
     const int n_sets = make_sets(in, sets);
     const int64_t gmax = std::max<int64_t>(1, C / (sh.variant == 1 ? 2 * kTargetItems : kTargetItems));   // two workgroups a CU
-    int64_t max_rows = 0, max_src = 0, max_item_lds = 0;
+    int64_t max_rows = 0, max_src = 0, max_item_lds = 0, n_big = 0;
     std::vector<int32_t> recs;
     std::vector<int64_t> weight;
     std::vector<int64_t> order;
@@ -101,9 +101,14 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
                 if (!ok) break;
                 c1 = nxt;
             }
-            if (c1 == c0) return -1;
+            const bool big = c1 == c0;          // not even this one complex fits a workgroup
+            if (big) {
+                if (!in.allow_big || sh.variant != 0) return -1;
+                c1 = c0 + 1;                    // a BIG record of its own: the workgroup streams it (include/cwn_hip.h)
+                ++n_big;
+            }
             int32_t r[kInts] = {0};
-            r[0] = s_ << 8;
+            r[0] = (s_ << 8) | (big ? CWN_LAYER_ITEM_BIG : 0);
             const int64_t n0 = cells(d0, c0, c1);
             int64_t nc = 0, une = 0;
             int live = S.n_tasks;
@@ -125,7 +130,7 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
                     live = 1;
                 }
             }
-            max_rows = std::max(max_rows, sh.staged(n0, nc));
+            if (!big) max_rows = std::max(max_rows, sh.staged(n0, nc));
             r[8] = live;
             int64_t src = 0, src_lds = 0, bne[2] = {0, 0};
             for (int t = 0; t < live; ++t) {
@@ -143,16 +148,18 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
                     if (sh.variant == 0 || t == 0) src_lds += r[o + 6];
                 }
             }
-            max_src = std::max(max_src, sh.variant == 0 ? src : src_lds);
-            max_item_lds = std::max(max_item_lds, sh.lds(sh.staged(n0, nc), src_lds));
-            const int64_t b1 = pad4(une), b2 = pad4(b1 + bne[0]);
-            r[23] = (int32_t)sh.first_coface_row(n0, nc);
-            r[24] = (int32_t)sh.staged(n0, nc);
-            r[25] = (int32_t)b1;
-            r[26] = (int32_t)b2;
-            r[27] = (int32_t)pad4(b2 + bne[1]);
+            if (!big) {
+                max_src = std::max(max_src, sh.variant == 0 ? src : src_lds);
+                max_item_lds = std::max(max_item_lds, sh.lds(sh.staged(n0, nc), src_lds));
+                const int64_t b1 = pad4(une), b2 = pad4(b1 + bne[0]);
+                r[23] = (int32_t)sh.first_coface_row(n0, nc);
+                r[24] = (int32_t)sh.staged(n0, nc);
+                r[25] = (int32_t)b1;
+                r[26] = (int32_t)b2;
+                r[27] = (int32_t)pad4(b2 + bne[1]);
+            }
             recs.insert(recs.end(), r, r + kInts);
-            weight.push_back((int64_t)r[11] + r[5]);
+            weight.push_back((int64_t)r[11] + r[5]);       // (a big item is the heaviest of its set: it starts first)
             c0 = c1;
         }
         // heavy items first within the set: a workgroup with five row tiles should not start last
@@ -169,6 +176,7 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
     plan.max_source_rows = (int32_t)max_src;
     plan.variant = sh.variant;
     plan.lds_bytes = sh.variant == 1 ? max_item_lds : 0;
+    plan.n_big = n_big;
     for (int d = 0; d < CWN_LAYER_MAX_DIMS; ++d) {
         const bool on = d < in.n_dims;
         plan.cells_end[d] = on ? in.cell_ptr[d][C] : 0;
@@ -222,7 +230,7 @@ extern "C" int64_t cwn_layer_items_build(const cwn_layer_sizes* in, int32_t F, i
         if (n < 0) { too_big = true; if (variant == 1) break; continue; }
         if (n == 0 || (variant == 0 && sh.lds(pc.max_gemm_rows, pc.max_source_rows) > kLds)) continue;
         if (variant == 1) { best.swap(cur); pb = pc; have = true; break; }
-        if (!have || n < pb.n_items) {
+        if (!have || pc.n_big < pb.n_big || (pc.n_big == pb.n_big && n < pb.n_items)) {      // fewest streamed complexes first
             best.swap(cur);
             pb = pc;
             have = true;

@@ -126,6 +126,14 @@ enum { ST_X = 0, ST_XS, ST_OUT_UP, ST_OUT_B, ST_B_INDEX, ST_B_E, ST_EPS1, ST_EPS
 constexpr int kSetFields = S_TASK0 + 2 * ST_FIELDS;         // 24 fields of 8 bytes
 constexpr int kMaxSets = CWN_LAYER_MAX_DIMS;
 
+// what a BIG item (include/cwn_hip.h) reads besides its set record: the caller's CSR of the big complexes' entries
+// (global cell numbers) and the scratch matrices for Y1 / Y2
+struct BigSet {
+    const int32_t* up_rowptr; const int32_t* up_col; const int32_t* up_aux;
+    const int32_t* b_rowptr[2]; const int32_t* b_col[2];
+    float* y1; float* y2;
+};
+
 struct LayerArgs {
     uint64_t set[kMaxSets][kSetFields];      // MUST stay first: read through the kernarg segment pointer
     const int32_t* items;
@@ -135,6 +143,7 @@ struct LayerArgs {
     int32_t xrows_cap;                       // boundary-source rows it holds
     int32_t set_start1, set_start2;          // first workgroup of set 1 / set 2 (items are ordered by set)
     int32_t lds_limit;                       // dynamic LDS bytes of this launch (kW8: every item lays out its own rows inside it)
+    BigSet big[kMaxSets];                    // big items only
 #ifdef CWN_LAYER_TIMING
     unsigned long long* stamps;              // [n_items][64]: [0, 16) phase ends seen by wave 0, [16 + 16 k + w] point k of wave w
 #endif
@@ -498,6 +507,203 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
     constexpr uint32_t kRowB = F * 4;                          // bytes per row
     const uint32_t fB = (uint32_t)f * 4;
     CWN_STAMP(10);
+    // ---- BIG item: a complex that no workgroup's LDS holds is STREAMED by this workgroup (include/cwn_hip.h) ---------
+    // Uniform over the workgroup.  Y1 / Y2 of the complex go row tile by row tile through the matrix cores straight
+    // from the fp32 rows (fragment-shaped loads, split on the fly: this wave's weight slice is the stationary operand
+    // as ever) into the scratch matrices in global memory; then every lane group walks the rows of the complex through
+    // the caller's CSR of its entries (global cell numbers) like the streaming path's aggregation does.  Same split,
+    // same MFMA order per tile, same entry order, same epilogue arithmetic: bit-identical to every other path.  It
+    // is the slow way to do a complex (~2.5 x the matrix-pipe time for the redundant splits, L2 round trips instead
+    // of LDS) -- and it keeps ONE oversized molecule from sending its whole batch to the two-kernel path.
+    if ((fld(I_FLAGS) & CWN_LAYER_ITEM_BIG) != 0) {
+        if constexpr (kW8) {
+            if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);      // big items ride in the 16-wave form only
+            return;
+        } else {
+            const BigSet& Bg = A.big[set];
+            if (Bg.y1 == nullptr && has_gemm) {                    // the caller gave no scratch / CSR: refuse, do not fault
+                if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
+                return;
+            }
+#pragma unroll
+            for (int hh = 0; hh < kWSets; ++hh) {                  // the rest of this wave's weight slice
+                const int h = kHS == 2 ? my_h : hh;
+#pragma unroll
+                for (int ks = kWEarly; ks < G::kKS; ++ks)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wsp[hh][ks][pl] = wload(h, ks, pl);
+            }
+            const int c_r0 = fld(I_CR0);
+            constexpr int kCH = 32;                                   // rows of EACH product per chunk
+            uint16_t* const bplanes = reinterpret_cast<uint16_t*>(smem);      // [3][2 * kCH][F + 8]
+            constexpr size_t bplane = (size_t)2 * kCH * G::kPlaneStride;
+            if (has_gemm) {
+                // Y1 | Y2 in chunks of 32 + 32 rows: coalesced row loads (the next chunk's are in flight during this
+                // chunk's MFMAs), ONE split per element into bf16 planes in LDS, fragments out of LDS -- the normal
+                // path's phases 2 / 4 / 6 in a loop, the results to the scratch matrices instead of LDS
+                const gcf_p bias_p = (gcf_p)sfld(S_MSG_BIAS);
+                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias_p != (gcf_p)0) bb = ldg4(bias_p + ct * 16 + kq * 4);
+                const gcb_p xg_b = (gcb_p)sfld(S_XG) + (size_t)t_r0[0] * kRowB, xc_b = (gcb_p)sfld(S_XC) + (size_t)c_r0 * kRowB;
+                constexpr int kPer = 2 * kCH / G::kNG;                // float4 per thread per chunk (2 at F = 128, 1 at F = 64)
+                // chunk-local row of this thread's load i: rows [0, 32) belong to product 0, [32, 64) to product 1
+                auto request = [&](float4 (&v)[kPer], int c0) {
+#pragma unroll
+                    for (int i = 0; i < kPer; ++i) {
+                        const int lr = gq + i * G::kNG, hh_ = lr / kCH, rr = c0 + (lr - hh_ * kCH);
+                        const int n_h = hh_ == 0 ? g_n : c_n;
+                        v[i] = ldg4o(hh_ == 0 ? xg_b : xc_b, (uint32_t)min(rr, max(n_h - 1, 0)) * kRowB + fB);
+                    }
+                };
+                float4 cur[kPer], nxt[kPer];
+                const int n_max = max(g_n, c_n);
+                request(cur, 0);
+                for (int c0 = 0; c0 < n_max; c0 += kCH) {
+                    __syncthreads();                                  // the fragments of the previous chunk have been read
+#pragma unroll
+                    for (int i = 0; i < kPer; ++i) {
+                        const int lr = gq + i * G::kNG;
+                        uint2 ph, pm, pl;
+                        cwn::split4(cur[i], ph, pm, pl);
+                        uint16_t* dst = bplanes + (size_t)lr * G::kPlaneStride + f;
+                        *reinterpret_cast<uint2*>(dst) = ph;
+                        *reinterpret_cast<uint2*>(dst + bplane) = pm;
+                        *reinterpret_cast<uint2*>(dst + 2 * bplane) = pl;
+                    }
+                    if (c0 + kCH < n_max) request(nxt, c0 + kCH);
+                    __syncthreads();
+#pragma unroll
+                    for (int hh = 0; hh < kWSets; ++hh) {
+                        const int h = kHS == 2 ? my_h : hh;
+                        const int rows_h = h == 0 ? g_n : c_n;
+                        float* const yb = h == 0 ? Bg.y1 + (size_t)t_r0[0] * F : Bg.y2 + (size_t)c_r0 * F;
+                        for (int tl = rt_par; tl < kCH / 16; tl += G::kWPC) {
+                            if (c0 + tl * 16 >= rows_h) break;
+                            const uint16_t* p0 = bplanes + (size_t)(h * kCH + tl * 16 + l15) * G::kPlaneStride + kq * 8;
+                            frag_cd c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int ks = 0; ks < G::kKS; ++ks) {
+                                const uint4 xh = *reinterpret_cast<const uint4*>(p0 + ks * 32);
+                                const uint4 xm = *reinterpret_cast<const uint4*>(p0 + bplane + ks * 32);
+                                const uint4 xl = *reinterpret_cast<const uint4*>(p0 + 2 * bplane + ks * 32);
+                                c = cwn::mfma_split6(wsp[hh][ks][0], wsp[hh][ks][1], wsp[hh][ks][2], xh, xm, xl, c);
+                            }
+                            if (h == 0) { c[0] += bb.x; c[1] += bb.y; c[2] += bb.z; c[3] += bb.w; }
+                            const int row = c0 + tl * 16 + l15;
+                            if (row < rows_h)
+                                *reinterpret_cast<float4*>(yb + (size_t)row * F + ct * 16 + kq * 4) = make_float4(c[0], c[1], c[2], c[3]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < kPer; ++i) cur[i] = nxt[i];
+                }
+            }
+            // the Y rows of this workgroup's other waves: written to global memory, read back below
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // the complex's slices of the caller's CSR (its rows are contiguous, so are their segments) come into LDS in
+            // one coalesced pass when they fit; the row loops below then chase LDS instead of global memory
+            int32_t* const lidx = reinterpret_cast<int32_t*>(smem);
+            const int lcap = A.lds_limit / 4;
+            int lused = 0;
+            // (positions are the caller's CSR positions; an LDS copy starts at position `off` -- subtracted at every access: a
+            // pointer moved BELOW its LDS array is a 32-bit wrap that the cast to a generic pointer does not undo)
+            struct Seg { const int32_t* rp; const int32_t* cl; const int32_t* ax; int off; };
+            auto stage = [&](const int32_t* rp_g, const int32_t* cl_g, const int32_t* ax_g, int first, int n_rows) {
+                if (rp_g == nullptr || n_rows <= 0) return Seg{nullptr, nullptr, nullptr, 0};
+                Seg sg{rp_g + first, cl_g, ax_g, 0};
+                const int s0 = rp_g[first], e0 = rp_g[first + n_rows], ne = e0 - s0;
+                const int need = (n_rows + 1) + ne * (ax_g != nullptr ? 2 : 1);
+#ifdef CWN_BIG_NO_STAGE
+                if (true) return sg;
+#endif
+                if (ne < 0 || lused + need > lcap) return sg;          // does not fit: chase global memory (correct, slower)
+                int32_t* lrp = lidx + lused;
+                int32_t* lcl = lrp + n_rows + 1;
+                int32_t* lax = lcl + ne;
+                for (int i = tid; i <= n_rows; i += kThreads) lrp[i] = rp_g[first + i];
+                for (int i = tid; i < ne; i += kThreads) {
+                    lcl[i] = cl_g[s0 + i];
+                    if (ax_g != nullptr) lax[i] = ax_g[s0 + i];
+                }
+                lused += need;
+                return Seg{lrp, lcl, ax_g != nullptr ? lax : nullptr, s0};
+            };
+            const Seg su = (has_gemm) ? stage(Bg.up_rowptr, Bg.up_col, Bg.up_aux, t_r0[0], g_n) : Seg{nullptr, nullptr, nullptr, 0};
+            Seg sb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                sb[t] = t_bne[t] > 0 ? stage(Bg.b_rowptr[t], Bg.b_col[t], nullptr, t_r0[t], t_n[t]) : Seg{nullptr, nullptr, nullptr, 0};
+            __syncthreads();
+            bool bad_big = false;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t_n[t] == 0) continue;                        // uniform
+                const gcf_p e1p = (gcf_p)sfld(S_TASK0 + t * ST_FIELDS + ST_EPS1), e2p = (gcf_p)sfld(S_TASK0 + t * ST_FIELDS + ST_EPS2);
+                const float eps1 = e1p != (gcf_p)0 ? *e1p : 0.f, eps2 = e2p != (gcf_p)0 ? *e2p : 0.f;
+                const gcb_p xt = (gcb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_X), xs = (gcb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_XS);
+                const gb_p o_up = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_UP), o_b = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_B);
+                const Seg B_ = sb[t];
+                const bool upper = t == 0 && has_gemm && su.rp != nullptr;
+                const int s_lo = fld(I_TASK0 + t * T_INTS + T_SR0), s_n = t_sn[t];
+                for (int r = gq; r < t_n[t]; r += G::kNG) {
+                    const int64_t row = (int64_t)t_r0[t] + r;
+                    const float4 xi = ldg4o(xt, (uint32_t)row * kRowB + fB);
+                    float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (B_.rp != nullptr) {
+                        const int s_ = B_.rp[r], e_ = B_.rp[r + 1];
+                        for (int p = s_; p < e_; p += 4) {              // four source rows in flight, added in entry order
+                            int v[4];
+                            float4 a[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                v[u] = B_.cl[min(p + u, e_ - 1) - B_.off];
+                                if ((unsigned)(v[u] - s_lo) >= (unsigned)s_n) { bad_big = true; v[u] = s_lo; }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) a[u] = ldg4o(xs, (uint32_t)v[u] * kRowB + fB);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (p + u < e_) { ab.x += a[u].x; ab.y += a[u].y; ab.z += a[u].z; ab.w += a[u].w; }
+                        }
+                    }
+                    stg4o(o_b, (uint32_t)row * kRowB + fB, axpy4(ab, 1.0f + eps2, xi));
+                    float4 au = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (upper) {
+                        const int s_ = su.rp[r], e_ = su.rp[r + 1];
+                        for (int p = s_; p < e_; p += 4) {
+                            int j[4], ci[4];
+                            float4 y[4], z[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                j[u] = su.cl[min(p + u, e_ - 1) - su.off];
+                                ci[u] = su.ax[min(p + u, e_ - 1) - su.off];
+                                if ((unsigned)(j[u] - t_r0[0]) >= (unsigned)g_n || (unsigned)(ci[u] - c_r0) >= (unsigned)c_n) {
+                                    bad_big = true;
+                                    j[u] = t_r0[0]; ci[u] = c_r0;
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                y[u] = *reinterpret_cast<const float4*>(Bg.y1 + (size_t)j[u] * F + f);
+                                z[u] = *reinterpret_cast<const float4*>(Bg.y2 + (size_t)ci[u] * F + f);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (p + u < e_) {
+                                    au.x += fmaxf(y[u].x + z[u].x, 0.0f); au.y += fmaxf(y[u].y + z[u].y, 0.0f);
+                                    au.z += fmaxf(y[u].z + z[u].z, 0.0f); au.w += fmaxf(y[u].w + z[u].w, 0.0f);
+                                }
+                        }
+                    }
+                    stg4o(o_up, (uint32_t)row * kRowB + fB, axpy4(au, 1.0f + eps1, xi));
+                }
+            }
+            if (bad_big) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
+            return;
+        }
+    }
     // What stays checked here: that the record fits the LDS of this launch (memory safety inside the
     // workgroup).  Uniform over the workgroup; unsigned compares also catch negative fields.
     const bool fits = kW8 ? ((unsigned)rows_pad <= (unsigned)gemm_rows_cap(F) && (unsigned)x_rows <= (unsigned)source_rows_cap(F) &&
@@ -1039,7 +1245,12 @@ int launch(LayerArgs& A, int64_t n_items, hipStream_t stream) {
 #ifdef CWN_LAYER_TIMING
     A.stamps = g_stamps;
 #endif
-    const size_t lds = kW8 ? (size_t)A.lds_limit : lds_bytes<F>(A.rows_cap, A.xrows_cap);
+    size_t lds = kW8 ? (size_t)A.lds_limit : lds_bytes<F>(A.rows_cap, A.xrows_cap);
+    if (!kW8) {
+        // BIG items stage 64-row chunks as planes and then the complex's CSR slices in the same LDS: at least 96 KiB
+        if (A.big[0].y1 != nullptr || A.big[1].y1 != nullptr || A.big[2].y1 != nullptr) lds = lds > 96 * 1024 ? lds : 96 * 1024;
+        A.lds_limit = (int32_t)lds;
+    }
     layer_kernel<F, MODE><<<dim3((unsigned)n_items), dim3(kThreads), lds, stream>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
@@ -1087,6 +1298,7 @@ extern "C" int CWN_FN(items_check)(const int32_t* items, int64_t n_items, int32_
     const int ng = kThreads / (F / 4);
     auto pad16 = [](int64_t n) { return (n + 15) / 16 * 16; };
     auto pad4 = [](int64_t n) { return (n + 3) / 4 * 4; };
+    int64_t n_big = 0;
     for (int64_t it = 0; it < n_items; ++it) {
         const int32_t* r = items + it * CWN_LAYER_ITEM_INTS;
         const bool has_gemm = (r[I_FLAGS] & 1) != 0;
@@ -1101,7 +1313,8 @@ extern "C" int CWN_FN(items_check)(const int32_t* items, int64_t n_items, int32_
                 continue;
             }
             const int d = T[T_DIM];
-            if (d < 0 || d >= CWN_LAYER_MAX_DIMS || T[T_R0] < 0 || T[T_N] < 0 || T[T_N] > CWN_LAYER_TASK_ROWS ||
+            const bool is_big = (r[I_FLAGS] & CWN_LAYER_ITEM_BIG) != 0;        // a streamed complex is not bound by the LDS caps
+            if (d < 0 || d >= CWN_LAYER_MAX_DIMS || T[T_R0] < 0 || T[T_N] < 0 || (!is_big && T[T_N] > CWN_LAYER_TASK_ROWS) ||
                 T[T_BE0] < 0 || T[T_BNE] < 0 || T[T_SR0] < 0 || T[T_SN] < 0)
                 return CWN_ERR_BAD_ARG;
             if ((int64_t)T[T_R0] + T[T_N] > plan->cells_end[d] || (int64_t)T[T_BE0] + T[T_BNE] > plan->b_end[d]) return CWN_ERR_BAD_ARG;
@@ -1129,6 +1342,13 @@ extern "C" int CWN_FN(items_check)(const int32_t* items, int64_t n_items, int32_
         } else {
             if (r[I_CN] != 0 || r[I_UNE] != 0 || nt > 1) return CWN_ERR_BAD_ARG;
         }
+        if ((r[I_FLAGS] & CWN_LAYER_ITEM_BIG) != 0) {      // a streamed complex: ranges only (checked above), no derived fields
+            if (kW8) return CWN_ERR_BAD_ARG;
+            for (int k = I_R1; k < CWN_LAYER_ITEM_INTS; ++k)
+                if (r[k] != 0) return CWN_ERR_BAD_ARG;
+            ++n_big;
+            continue;
+        }
         const int64_t r1 = nc > 0 ? (pad16(n0) + ng - 1) / ng * ng : pad16(n0);
         const int64_t rows = nc > 0 ? r1 + pad16(nc) : pad16(n0);
         const int64_t b1 = pad4(une), b2 = pad4(b1 + bne[0]), total = pad4(b2 + bne[1]);
@@ -1144,6 +1364,7 @@ extern "C" int CWN_FN(items_check)(const int32_t* items, int64_t n_items, int32_
             if (need == 0 || (int64_t)need > plan->lds_bytes) return CWN_ERR_BAD_ARG;
         }
     }
+    if (n_big != plan->n_big) return CWN_ERR_BAD_ARG;
     if (kW8) return plan->lds_bytes <= (int64_t)kLdsBudget ? CWN_OK : CWN_ERR_BAD_ARG;
     return CWN_FN(lds_bytes)(F, plan->max_gemm_rows, plan->max_source_rows) != 0 ? CWN_OK : CWN_ERR_BAD_ARG;
 }
@@ -1182,6 +1403,15 @@ extern "C" int CWN_FN(launch)(const cwn_layer_dim* dims, int n_dims, int32_t F, 
             plan->up_end[d] > D.e_up || plan->b_end[d] < 0 || plan->b_end[d] > D.n_b)
             return CWN_ERR_BAD_ARG;
         has_up[d] = D.e_up > 0;
+        // BIG records: the streamed complexes need their CSR and the scratch matrices (include/cwn_hip.h)
+        if (plan->n_big > 0) {
+            if (kW8) return CWN_ERR_BAD_ARG;
+            if (D.e_up > 0 && (D.big_up_rowptr == nullptr || D.big_up_col == nullptr || D.big_up_aux == nullptr ||
+                               D.big_y1 == nullptr || dims[d + 1].big_y2 == nullptr))
+                return CWN_ERR_BAD_ARG;
+            if (D.n_b > 0 && (D.big_b_rowptr == nullptr || D.big_b_col == nullptr)) return CWN_ERR_BAD_ARG;
+            if (!(al16(D.big_y1) && al16(D.big_y2))) return CWN_ERR_ALIGN;
+        }
     }
     // the sets, in the order the item table numbers them (include/cwn_hip.h): every dimension with an
     // upper adjacency is the GEMM dimension of a set; the top dimension without one rides as its
@@ -1201,9 +1431,17 @@ extern "C" int CWN_FN(launch)(const cwn_layer_dim* dims, int n_dims, int32_t F, 
             S[S_MSG_BIAS] = (uint64_t)(uintptr_t)D.msg_bias;
             if (d + 1 < n_dims && !has_up[d + 1] && d + 2 >= n_dims) tasks[1] = d + 1;
         }
+        BigSet& Bg = A.big[n_sets - 1];
+        if (has_up[d]) {
+            Bg.up_rowptr = dims[d].big_up_rowptr; Bg.up_col = dims[d].big_up_col; Bg.up_aux = dims[d].big_up_aux;
+            Bg.y1 = dims[d].big_y1;
+            Bg.y2 = dims[d + 1].big_y2;
+        }
         for (int t = 0; t < 2; ++t) {
             if (tasks[t] < 0) continue;
             const cwn_layer_dim& D = dims[tasks[t]];
+            Bg.b_rowptr[t] = D.big_b_rowptr;
+            Bg.b_col[t] = D.big_b_col;
             uint64_t* T = S + S_TASK0 + t * ST_FIELDS;
             T[ST_X] = (uint64_t)(uintptr_t)D.x;
             T[ST_XS] = tasks[t] > 0 ? (uint64_t)(uintptr_t)dims[tasks[t] - 1].x : 0;

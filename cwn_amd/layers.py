@@ -93,7 +93,26 @@ BLOCKED_MAX_ITEMS = int(os.environ.get('CWN_BLOCKED_MAX_ITEMS', '2600'))
 # one-per-CU form while the items fit the chip once (TWO_PER_CU_MIN_ITEMS), the 8-wave two-per-CU form beyond that
 # when every complex fits its smaller caps; '0' / '1' force one (A/B measurements, tests).
 LAYER_VARIANT = os.environ.get('CWN_LAYER_VARIANT', 'auto')
+# A complex beyond a workgroup's LDS (a molecule of more than ~45 atoms at width 128, ~115 at 64) is streamed by its own
+# workgroup inside the blocked launch (BIG records) instead of sending the whole batch to the two-kernel path -- while
+# such complexes are the exception (at most BIG_MAX_SHARE of the items: a batch of hub complexes IS the streaming case).
+BIG_ITEMS = {'0': False, 'always': 'always'}.get(os.environ.get('CWN_BIG_ITEMS', '1'), True)   # 'always': skip the cost model below (tests, A/B)
+BIG_MAX_SHARE = 0.25
 TWO_PER_CU_MIN_ITEMS = int(os.environ.get('CWN_TWO_PER_CU_MIN_ITEMS', '256'))
+def _streaming_pays(table, F: int) -> bool:
+    """BIG records against sending the whole batch to the two-kernel path.  The launch lasts as long as its longest
+    workgroup: a streamed complex takes ~0.07 us per staged row at width 128 (~0.035 at 64; a 200-atom molecule = 415
+    rows ~ 30 us), the rest of the batch ~8.7 us per round of 256 items, and the two-kernel path ~1.9 x the blocked time
+    of the same batch without its giants.  Calibrated on tools/big_items_bench.py (share of the all-small rate, streamed
+    / two-kernel path): molhiv-512 with 5 % giants of 60 - 200 atoms 0.87 / 0.43, ZINC-512 0.77 / 0.67, ZINC-128 0.38 /
+    0.54 -- the one case that keeps the two-kernel path: a launch of 9 us cannot hide a 30-us workgroup."""
+    recs = table.big_records
+    rows = max(int(r[11]) + int(r[5]) for r in recs)
+    t_big = (0.07 if F == 128 else 0.035) * rows
+    rounds = max(1, -(-(table.n_items - table.n_big) // TWO_PER_CU_MIN_ITEMS))
+    return t_big < 1.9 * 8.7 * rounds
+
+
 def _two_per_cu_wins(n0: int, n1: int) -> bool:
     """A launch of n0 items in the 16-wave form (256 at a time) against n1 items in the two-per-CU form (512 at a
     time, each ~1.3 x as long: 8 waves, a neighbour on the CU): whole rounds while a launch is a few rounds (the last
@@ -767,6 +786,12 @@ class SparseCINConv(torch.nn.Module):
                 t1 = plan.items(F, has_up, has_b, variant=1)
                 if t1 is not None and _two_per_cu_wins(table.n_items, t1.n_items):
                     table = t1
+        if table is None and LAYER_VARIANT != '1' and BIG_ITEMS and lower <= BLOCKED_MAX_ITEMS:
+            # some complex does not fit a workgroup's LDS: ITS workgroup streams it (BIG records, include/cwn_hip.h), the
+            # rest of the batch stays blocked -- unless most of the batch is like that (REDDIT-like hub complexes)
+            t = plan.items(F, has_up, has_b, variant=0, allow_big=True)
+            if t is not None and (BIG_ITEMS == 'always' or (t.n_big <= max(2, BIG_MAX_SHARE * t.n_items) and _streaming_pays(t, F))):
+                table = t
         if table is None:
             return 'a complex does not fit one workgroup (row / entry caps)'
         if table.variant == 0 and table.n_items > BLOCKED_MAX_ITEMS:

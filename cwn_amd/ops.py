@@ -1203,6 +1203,8 @@ class LayerLaunch:
                                         eps2=_ffi.ptr(e2), n_cells=int(D.x.size(0)), e_up=e_up,
                                         n_b=0 if bi is None else int(bi.size(1)))
             self.rows.append(int(D.x.size(0)))
+        if getattr(table, 'n_big', 0):
+            self._attach_big(dims, table)
         self.total_rows = sum(self.rows)
         self._sizes = [r for r in self.rows for _ in range(2)]          # rows of out_up_d, out_b_d, in output order
         self._off = [sum(self._sizes[:i]) for i in range(len(self._sizes))]
@@ -1212,6 +1214,77 @@ class LayerLaunch:
         self.err = _err_flag(self.dev)
         self._err_ptr = self.err.data_ptr()
         self.fn = _ffi.lib().cwn_layer_fused_f32
+
+    def _attach_big(self, dims: Sequence[LayerDim], table) -> None:
+        """BIG records (include/cwn_hip.h): complexes no workgroup's LDS holds are streamed by their workgroup, which
+        needs (a) the destination-sorted CSR of THEIR entries of every adjacency, in global cell numbers -- built here
+        once per batch from slices of the batch's own index tensors (the table records where each complex's entries
+        lie), cached on the table for all layers -- and (b) scratch matrices for Y1 / Y2."""
+        from .csr import Adjacency, build_many
+        key = tuple((id(t), t._version) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
+        ctx = table.big_ctx
+        if ctx is None or ctx['key'] != key or ctx['F'] != self.F:
+            recs = table.big_records
+            dev, n, F = dims[0].x.device, len(dims), self.F
+            ctx = {'key': key, 'F': F, 'dims': [dict() for _ in range(n)], 'keep': []}
+            todo = []
+            dummy_i = torch.zeros(4, dtype=torch.int32, device=dev)
+            for d, D in enumerate(dims):
+                N = int(D.x.size(0))
+                c = ctx['dims'][d]
+                if D.up_index is not None and D.up_index.size(1) > 0:
+                    sl = [(int(r[6]), int(r[7])) for r in recs if (r[0] & 1) and int(r[1]) == d and r[7] > 0]
+                    if sl:
+                        idx = torch.cat([D.up_index[:, a:a + m] for a, m in sl], 1).contiguous()
+                        sh = torch.cat([D.up_shared[a:a + m] for a, m in sl]).contiguous()
+                        adj = Adjacency.from_index(idx, N, N, sh, int(dims[d + 1].x.size(0)), build=False)
+                        todo.append(adj)
+                        c['up'] = adj
+                        ctx['keep'] += [idx, sh]
+                    # scratch: Y1 of this dimension, Y2 of the next one (only complexes with BIG records write / read them)
+                    c['y1'] = torch.empty(N if sl else 4, F, dtype=torch.float32, device=dev)
+                    ctx['dims'][d + 1]['y2'] = torch.empty(int(dims[d + 1].x.size(0)) if sl else 4, F, dtype=torch.float32, device=dev)
+                if D.b_index is not None and D.b_index.size(1) > 0 and d > 0:
+                    sl = []
+                    for r in recs:
+                        for t in range(int(r[8])):
+                            o = 9 + 7 * t
+                            if int(r[o]) == d and r[o + 4] > 0:
+                                sl.append((int(r[o + 3]), int(r[o + 4])))
+                    if sl:
+                        idx = torch.cat([D.b_index[:, a:a + m] for a, m in sl], 1).contiguous()
+                        adj = Adjacency.from_index(idx, N, int(dims[d - 1].x.size(0)), build=False)
+                        todo.append(adj)
+                        c['b'] = adj
+                        ctx['keep'].append(idx)
+            build_many(todo)
+            ctx['dummy'] = dummy_i
+            table.big_ctx = ctx
+        self.keep.append(ctx)
+        dummy = ctx['dummy']
+        for d, D in enumerate(dims):
+            c, a = ctx['dims'][d], self.arr[d]
+            if a.e_up > 0:
+                up = c.get('up')
+                rowptr = up.rowptr if up is not None else self._zero_rowptr(ctx, int(D.x.size(0)), dummy.device)
+                a.big_up_rowptr = rowptr.data_ptr()
+                a.big_up_col = (up.col if up is not None else dummy).data_ptr()
+                a.big_up_aux = (up.aux if up is not None else dummy).data_ptr()
+                a.big_y1 = c['y1'].data_ptr()
+            if 'y2' in c:
+                a.big_y2 = c['y2'].data_ptr()
+            if a.n_b > 0:
+                b = c.get('b')
+                rowptr = b.rowptr if b is not None else self._zero_rowptr(ctx, int(D.x.size(0)), dummy.device)
+                a.big_b_rowptr = rowptr.data_ptr()
+                a.big_b_col = (b.col if b is not None else dummy).data_ptr()
+
+    @staticmethod
+    def _zero_rowptr(ctx, n, dev):
+        z = ctx.setdefault('zeros', {})
+        if n not in z:
+            z[n] = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        return z[n]
 
     def run(self, xs: Sequence[Tensor], csr_mode: int = 0) -> List[Tensor]:
         F = self.F

@@ -243,6 +243,17 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  * the other's matrix-core / reduce phases -- for launches with more items than the chip has CUs.  Same record
  * layout, same arithmetic, bit-identical outputs; smaller caps, and the rows of EACH product (cells of g, cells of
  * g+1, each padded to 16) are bounded by CWN_LAYER_W8_HALF_ROWS.  Rows per round: cwn_layer_variant_round_rows. */
+/* BIG ITEMS (record flag bit 1; variant 0 only; cwn_layer_sizes.allow_big).  A complex whose rows or entries exceed
+ * what a workgroup's LDS holds (a molecule of more than ~45 atoms at F = 128, ~115 at F = 64) used to send its WHOLE
+ * batch to the streaming path (cwn_gemm_f32 + cwn_aggregate_f32).  With allow_big the table builder gives such a
+ * complex one BIG record per set instead: its workgroup runs the streaming algorithm by itself inside the same launch --
+ * Y1 / Y2 of the complex row tile by row tile on the matrix cores straight from the fp32 rows into the scratch matrices
+ * cwn_layer_dim.big_y1 / big_y2 (global memory, L2-resident), then the segmented reductions over the caller's CSR of the
+ * big complexes' entries (big_up_* / big_b_*: built once per batch) -- same split, same MFMA order per tile, same entry
+ * order: bit-identical to the other paths.  A BIG record uses the fields [0..22] as above (all ranges of the complex);
+ * the derived fields [23..27] are 0.  An upper / boundary entry of a big complex whose source, coface or boundary cell
+ * lies outside the complex sets CWN_ERR_BIT_BLOCK. */
+#define CWN_LAYER_ITEM_BIG 2
 #define CWN_LAYER_W8_LDS_BYTES (80 * 1024)
 #define CWN_LAYER_W8_GEMM_ROWS(F) ((F) == 64 ? 128 : 80)
 #define CWN_LAYER_W8_SOURCE_ROWS(F) ((F) == 64 ? 128 : 48)
@@ -260,6 +271,16 @@ typedef struct cwn_layer_dim {
     float* out_up;             /* [n_cells, F] */
     float* out_b;              /* [n_cells, F] */
     int64_t n_cells, e_up, n_b;
+    /* BIG items only (all NULL otherwise; see "Big items" below): the destination-sorted int32 CSR (cwn_csr_build, GLOBAL
+     * cell numbers) of the big complexes' entries of up_index / b_index of this dimension, and two [n_cells, F] scratch
+     * matrices the launch may write (Y1 of this dimension as a GEMM dimension, Y2 of it as the coface dimension) */
+    const int32_t* big_up_rowptr;   /* [n_cells + 1] */
+    const int32_t* big_up_col;      /* source cell (dim d) */
+    const int32_t* big_up_aux;      /* shared coface (dim d + 1) */
+    const int32_t* big_b_rowptr;    /* [n_cells + 1] */
+    const int32_t* big_b_col;       /* boundary cell (dim d - 1) */
+    float* big_y1;
+    float* big_y2;
 } cwn_layer_dim;
 
 /* The weight of the message Linear in the form the kernel's matrix-core loop reads it: the exact
@@ -297,6 +318,7 @@ typedef struct cwn_layer_plan {
     int64_t cells_end[CWN_LAYER_MAX_DIMS];      /* max (first cell + count) the table names, per dimension */
     int64_t up_end[CWN_LAYER_MAX_DIMS];         /* max (first entry + count) of up_index_d */
     int64_t b_end[CWN_LAYER_MAX_DIMS];          /* max (first entry + count) of b_index_d */
+    int64_t n_big;                              /* BIG records in the table (0: none; the launcher then ignores big_*) */
     int64_t lds_bytes;                          /* variant 1: dynamic LDS of the launch = the largest per-item need
                                                    (cwn_layer_variant_lds_bytes of its staged rows and task-0 sources);
                                                    variant 0: unused (one layout per launch from the two maxima) */
@@ -315,6 +337,9 @@ typedef struct cwn_layer_sizes {
     int64_t n_complexes;
     int32_t n_dims;
     int32_t has_up[CWN_LAYER_MAX_DIMS];             /* dimension d reduces an upper adjacency with coboundary features */
+    int32_t allow_big;                              /* 1: a complex beyond the caps becomes BIG records (variant 0) instead of
+                                                       CWN_LAYER_ITEMS_TOO_LARGE */
+    int32_t pad_;
     const int64_t* cell_ptr[CWN_LAYER_MAX_DIMS];    /* [n_complexes + 1] prefix sums of the cells per complex */
     const int64_t* up_ptr[CWN_LAYER_MAX_DIMS];      /* the same for the entries of upper_index_d, or NULL */
     const int64_t* b_ptr[CWN_LAYER_MAX_DIMS];       /* the same for the entries of boundary_index_d, or NULL */

@@ -526,3 +526,53 @@ def test_auto_variant_takes_the_two_per_cu_form_beyond_one_item_per_cu():
     for d in range(3):
         _gate(outs[2 * d], ref[d][0], f'two-per-CU out_up[{d}]')
         _gate(outs[2 * d + 1], ref[d][1], f'two-per-CU out_b[{d}]')
+
+
+@pytest.mark.parametrize('F,n_small,big_sizes', [(128, 30, [(70, 90)]), (128, 100, [(50, 60), (150, 200)]), (64, 40, [(130, 200)])])
+def test_big_complexes_are_streamed_inside_the_blocked_launch(F, n_small, big_sizes):
+    """a complex beyond a workgroup's LDS no longer sends its whole batch to the two-kernel path --
+    its workgroup streams it (BIG records, include/cwn_hip.h) while the rest stays blocked, in the same launch:
+    bit-identical to the two-kernel path on every row of the mixed batch, and inside the gate against the oracle."""
+    from cwn_amd import csr, layers
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    cxs = zinc_like_complexes(n_small, 41, 6)
+    for k, (lo, hi) in enumerate(big_sizes):
+        giants = zinc_like_complexes(2, 42 + k, 6, n_lo=lo, n_hi=hi)
+        cxs = cxs[:7 * (k + 1)] + giants[:1] + cxs[7 * (k + 1):] + giants[1:]        # in the middle and at the end
+    b = ComplexBatch.from_complex_list(cxs, max_dim=2).to(DEV)
+    g = torch.Generator().manual_seed(43)
+    for d in range(3):
+        b.cochains[d].x = torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV)
+    conv = _conv(F, seed=44, eps=0.3)
+    keep_policy, layers.BIG_ITEMS = layers.BIG_ITEMS, 'always'      # (the cost model would send the largest ones of these
+    try:                                                            # small batches to the two-kernel path: _streaming_pays)
+        with torch.no_grad():
+            table = conv._blocked_args(b.get_all_cochain_params(max_dim=2, include_down_features=False), 0)[2]
+        assert table.variant == 0 and 2 <= table.n_big <= 4 * len(big_sizes), (table.n_big, table.n_items)
+        first = _run(conv, b, blocked=True)
+        second = _run(conv, b, blocked=True)                  # the layers after the first load the cached per-item CSR
+    finally:
+        layers.BIG_ITEMS = keep_policy
+    csr._cache.clear()
+    plain = _run(conv, b, blocked=False)
+    for i, (f, s2, p) in enumerate(zip(first, second, plain)):
+        assert torch.equal(s2, f), i
+        if F == 128:      # (at width 64 the two-kernel path multiplies on fp32 MFMA, not through the bf16 split: not bit-comparable)
+            assert torch.equal(f, p), (i, (f - p).abs().max().item())
+    ref = _oracle_scope(conv, b)
+    for d in range(3):
+        _gate(first[2 * d], ref[d][0], f'big items F={F} out_up[{d}]')
+        _gate(first[2 * d + 1], ref[d][1], f'big items F={F} out_b[{d}]')
+    # the policy: a giant of 30 us in a one-round launch of 9 us does not pay, the same giant in a larger batch does
+    big_rows = max(int(r[11]) + int(r[5]) for r in table.big_records)
+    assert layers._streaming_pays(table, F) == ((0.07 if F == 128 else 0.035) * big_rows < 1.9 * 8.7 * max(1, -(-(table.n_items - table.n_big) // 256)))
+    # switched off: the whole batch takes the two-kernel path, as before
+    prev, layers.BIG_ITEMS = layers.BIG_ITEMS, False
+    try:
+        layers._BLOCKED_CACHE.clear()
+        with torch.no_grad():
+            assert isinstance(conv._blocked_args(b.get_all_cochain_params(max_dim=2, include_down_features=False), 0), str)
+    finally:
+        layers.BIG_ITEMS = prev
+        layers._BLOCKED_CACHE.clear()
