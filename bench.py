@@ -151,7 +151,10 @@ def main():
                                nonlinearity='relu', readout='sum', train_eps=False,
                                final_hidden_multiplier=2, final_readout='sum', init_reduce='sum',
                                embed_edge=True, use_coboundaries=True, graph_norm='bn')
-        gen = lambda seed: zinc_like_complexes(args.batch, seed, 6)
+        # CWN_BENCH_ATOMS=lo,hi (exploration, never the headline): molecule sizes other than the generator's 18 - 30 atoms,
+        # e.g. 9,38 for the spread of the real ZINC subset (mixed launches / big items)
+        atoms = tuple(int(v) for v in os.environ.get('CWN_BENCH_ATOMS', '18,30').split(','))
+        gen = lambda seed: zinc_like_complexes(args.batch, seed, 6, n_lo=atoms[0], n_hi=atoms[1])
         coboundary = True
     elif WL == 'molhiv':  # exp/scripts/cwn-molhiv.sh:9-32, batch per BASELINE.json
         model = OGBEmbedSparseCIN(1, L, H, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum',
@@ -216,8 +219,9 @@ def main():
         FORM = None
         if BLOCKED:
             t_ = model.convs[0]._blocked_args(b0.get_all_cochain_params(max_dim=2, include_down_features=False), 0)[2]
-            FORM = {'variant': t_.variant, 'items_per_launch': t_.n_items,
-                    'form': '16 waves, one workgroup per CU' if t_.variant == 0 else '8 waves <= 128 VGPRs <= 80 KiB LDS, two workgroups per CU'}
+            FORM = {'variant': t_.variant, 'items_per_launch': t_.n_items, 'big_items': int(getattr(t_, 'n_big', 0)),
+                    'form': {0: '16 waves, one workgroup per CU', 1: '8 waves <= 128 VGPRs <= 80 KiB LDS, two workgroups per CU',
+                             'mixed': 'two launches: two-per-CU form for the complexes that fit it + 16-wave form for the rest'}[t_.variant]}
         if rank == 0:
             print(f'[bench] complex-blocked layer kernel: {BLOCKED}'
                   + ('' if BLOCKED else f' ({model.convs[0].blocked_reason})'), file=sys.stderr)

@@ -81,7 +81,8 @@ class LayerSizes(C.Structure):
     """cwn_layer_sizes (include/cwn_hip.h)."""
     _fields_ = [('n_complexes', C.c_int64), ('n_dims', C.c_int32), ('has_up', C.c_int32 * 3),
                 ('allow_big', C.c_int32), ('pad_', C.c_int32),
-                ('cell_ptr', C.c_void_p * 3), ('up_ptr', C.c_void_p * 3), ('b_ptr', C.c_void_p * 3)]
+                ('cell_ptr', C.c_void_p * 3), ('up_ptr', C.c_void_p * 3), ('b_ptr', C.c_void_p * 3),
+                ('skip', C.c_void_p), ('unfit', C.c_void_p)]
 
 
 LAYER_ITEMS_TOO_LARGE, LAYER_ITEMS_BAD_ARG = -1, -2

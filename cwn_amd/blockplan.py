@@ -82,6 +82,31 @@ class ItemTable:
         return p
 
 
+class MixedTable:
+    """Two item tables over complementary subsets of a batch's complexes -- `parts[0]` in the two-per-CU form (the
+    complexes that fit its caps), `parts[1]` in the 16-wave form (the rest, BIG records included) -- served by two
+    launches into the same outputs (ops.LayerLaunch).  Quacks like an ItemTable where the layer code looks at one."""
+    variant = 'mixed'
+
+    def __init__(self, parts: List[ItemTable], n_rest: int):
+        self.parts = parts
+        self.n_rest = int(n_rest)              # complexes in the 16-wave part
+        self.n_items = sum(t.n_items for t in parts)
+        self.n_big = sum(t.n_big for t in parts)
+        self.big_records = parts[1].big_records
+        self.device = parts[0].device
+
+    @property
+    def csr_key(self):
+        keys = {t.csr_key for t in self.parts}
+        return keys.pop() if len(keys) == 1 else None
+
+    @csr_key.setter
+    def csr_key(self, v):
+        for t in self.parts:
+            t.csr_key = v
+
+
 class BlockPlan:
     """Host-side description of a batch + the item tables cut from it (one per feature width)."""
 
@@ -137,7 +162,7 @@ class BlockPlan:
         starts from the COO entries again)."""
         for t in self._tables.values():
             if t is not None:
-                t.csr_key = None
+                t.csr_key = None           # (a MixedTable passes it on to its parts)
 
     # ---- items ------------------------------------------------------------------------------------
     def _sets(self, has_up: Sequence[bool]):
@@ -184,7 +209,27 @@ class BlockPlan:
             self._tables[key] = self._build(F, key[1], key[2], key[3], key[4])
         return self._tables[key]
 
-    def _build(self, F: int, has_up, has_b, variant: int = 0, allow_big: bool = False) -> Optional[ItemTable]:
+    def items_mixed(self, F: int, has_up: Sequence[bool], has_b: Optional[Sequence[bool]] = None) -> Optional['MixedTable']:
+        """A batch whose complexes do not ALL fit the two-per-CU form (its LDS holds ~30 atoms at width 128): the ones
+        that fit are cut into a table of that form, the rest into a table of the 16-wave form (BIG records where even
+        that is too small) -- two launches into the same outputs.  None when nothing fits the two-per-CU form or the rest
+        has no table."""
+        if has_b is None:
+            has_b = [p is not None for p in self.b_ptr]
+        key = ('mixed', F, tuple(bool(h) for h in has_up), tuple(bool(h) and self.b_ptr[d] is not None for d, h in enumerate(has_b)))
+        if key not in self._tables:
+            unfit = np.zeros(self.C, dtype=np.uint8)
+            self._build(F, key[2], key[3], 1, False, unfit_out=unfit)                # which complexes do not fit (any set)
+            res = None
+            if unfit.any() and not unfit.all():
+                t1 = self._build(F, key[2], key[3], 1, False, skip=unfit)
+                t0 = self._build(F, key[2], key[3], 0, True, skip=(1 - unfit).astype(np.uint8))
+                if t1 is not None and t0 is not None:
+                    res = MixedTable([t1, t0], int(unfit.sum()))
+            self._tables[key] = res
+        return self._tables[key]
+
+    def _build(self, F: int, has_up, has_b, variant: int = 0, allow_big: bool = False, skip=None, unfit_out=None) -> Optional[ItemTable]:
         """cwn_layer_items_build (csrc/cwn_blockplan.cpp, host C++): the greedy cut under the kernel's caps and
         the split of one launch's LDS between staged rows and boundary sources that gives the fewest items.  (A
         Python version of the same took 11 ms for a ZINC-like batch of 128 -- tests/_blockplan_ref.py keeps it as
@@ -198,6 +243,13 @@ class BlockPlan:
                 return None
         sizes = _ffi.LayerSizes(n_complexes=C, n_dims=self.n_dims, allow_big=1 if (allow_big and variant == 0) else 0)
         keep = []
+        if skip is not None:
+            skip = np.ascontiguousarray(skip, dtype=np.uint8)
+            keep.append(skip)
+            sizes.skip = skip.ctypes.data
+        if unfit_out is not None:
+            assert unfit_out.dtype == np.uint8 and unfit_out.flags.c_contiguous and unfit_out.size == C
+            sizes.unfit = unfit_out.ctypes.data
         for d in range(self.n_dims):
             sizes.has_up[d] = 1 if has_up[d] else 0
             for name, arr in (('cell_ptr', self.cell_ptr[d]), ('up_ptr', self.up_ptr[d]),

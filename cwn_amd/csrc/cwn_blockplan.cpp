@@ -82,8 +82,9 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
         recs.clear();
         weight.clear();
         for (int64_t c0 = 0; c0 < C;) {
+            if (in.skip != nullptr && in.skip[c0]) { ++c0; continue; }      // not in this table (ranges break at it)
             int64_t c1 = c0;
-            while (c1 < C && c1 - c0 < gmax) {
+            while (c1 < C && c1 - c0 < gmax && !(in.skip != nullptr && in.skip[c1])) {
                 const int64_t nxt = c1 + 1;
                 const int64_t rows = sh.staged(cells(d0, c0, nxt), g >= 0 ? cells(g + 1, c0, nxt) : 0);
                 int64_t src = 0, ents = pad4(span(up, c0, nxt));
@@ -101,7 +102,12 @@ int64_t build_with(const cwn_layer_sizes& in, const Shape& sh, int64_t row_cap, 
                 if (!ok) break;
                 c1 = nxt;
             }
-            const bool big = c1 == c0;          // not even this one complex fits a workgroup
+            bool big = c1 == c0;                // not even this one complex fits a workgroup
+            if (big && in.unfit != nullptr) {   // the caller serves it with another launch: marked, left out
+                in.unfit[c0] = 1;
+                ++c0;
+                continue;
+            }
             if (big) {
                 if (!in.allow_big || sh.variant != 0) return -1;
                 c1 = c0 + 1;                    // a BIG record of its own: the workgroup streams it (include/cwn_hip.h)

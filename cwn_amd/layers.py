@@ -93,7 +93,7 @@ BLOCKED_MAX_ITEMS = int(os.environ.get('CWN_BLOCKED_MAX_ITEMS', '2600'))
 # one-per-CU form while the items fit the chip once (TWO_PER_CU_MIN_ITEMS), the 8-wave two-per-CU form beyond that
 # when every complex fits its smaller caps; '0' / '1' force one (A/B measurements, tests).
 LAYER_VARIANT = os.environ.get('CWN_LAYER_VARIANT', 'auto')
-# A complex beyond a workgroup's LDS (a molecule of more than ~45 atoms at width 128, ~115 at 64) is streamed by its own
+# A complex beyond a workgroup's LDS (a molecule of more than 32 atoms at width 128, ~115 at 64) is streamed by its own
 # workgroup inside the blocked launch (BIG records) instead of sending the whole batch to the two-kernel path -- while
 # such complexes are the exception (at most BIG_MAX_SHARE of the items: a batch of hub complexes IS the streaming case).
 BIG_ITEMS = {'0': False, 'always': 'always'}.get(os.environ.get('CWN_BIG_ITEMS', '1'), True)   # 'always': skip the cost model below (tests, A/B)
@@ -111,6 +111,22 @@ def _streaming_pays(table, F: int) -> bool:
     t_big = (0.07 if F == 128 else 0.035) * rows
     rounds = max(1, -(-(table.n_items - table.n_big) // TWO_PER_CU_MIN_ITEMS))
     return t_big < 1.9 * 8.7 * rounds
+
+
+def _mixed_wins(tm, table0, lower: int) -> bool:
+    """Two launches (two-per-CU form for the complexes that fit + 16-wave form for the rest) against one launch of the
+    16-wave form for all: rounds as in _two_per_cu_wins, plus one launch boundary.  Measured on batches with the size
+    spread of the real ZINC subset (9 - 38 atoms, tools/ab_mixed.sh; M cells/s mixed / 16-wave form with big items /
+    two-kernel path): batch 512: 798 / 849 / 577 (the one-round second launch costs more than it saves), batch 2048:
+    1054 / 954 / 851; batch 128 has one round either way: 558 / 558 / 325."""
+    slots = TWO_PER_CU_MIN_ITEMS
+    rounds = lambda n, per: -(-n // per) if n <= 2 * per else n / per      # (a partial LAST round of many costs its share)
+    t1, t0 = tm.parts
+    if t0.n_big and not _streaming_pays(t0, 128 if t1.max_rows <= 80 else 64):
+        return False
+    mixed = 1.3 * rounds(t1.n_items, 2 * slots) + rounds(t0.n_items, slots) + 0.2
+    alone = rounds(table0.n_items if table0 is not None else lower, slots) if table0 is not None else 2.0 * rounds(lower, slots)
+    return mixed < alone
 
 
 def _two_per_cu_wins(n0: int, n1: int) -> bool:
@@ -786,6 +802,13 @@ class SparseCINConv(torch.nn.Module):
                 t1 = plan.items(F, has_up, has_b, variant=1)
                 if t1 is not None and _two_per_cu_wins(table.n_items, t1.n_items):
                     table = t1
+        if LAYER_VARIANT in ('auto', 'mixed') and lower > TWO_PER_CU_MIN_ITEMS and (table is None or table.variant == 0):
+            # more items than CUs, but some complex is too large for the two-per-CU form (its 80 KiB hold ~30 atoms at
+            # width 128): that form for the complexes that fit, the 16-wave form (BIG records where needed) for the
+            # rest -- two launches into the same outputs (blockplan.MixedTable)
+            tm = plan.items_mixed(F, has_up, has_b)
+            if tm is not None and (LAYER_VARIANT == 'mixed' or _mixed_wins(tm, table, lower)):
+                table = tm
         if table is None and LAYER_VARIANT != '1' and BIG_ITEMS and lower <= BLOCKED_MAX_ITEMS:
             # some complex does not fit a workgroup's LDS: ITS workgroup streams it (BIG records, include/cwn_hip.h), the
             # rest of the batch stays blocked -- unless most of the batch is like that (REDDIT-like hub complexes)
@@ -794,7 +817,7 @@ class SparseCINConv(torch.nn.Module):
                 table = t
         if table is None:
             return 'a complex does not fit one workgroup (row / entry caps)'
-        if table.variant == 0 and table.n_items > BLOCKED_MAX_ITEMS:
+        if table.variant == 0 and table.n_items > BLOCKED_MAX_ITEMS:     # (a MixedTable's variant is 'mixed')
             return f'{table.n_items} items: beyond the range where one workgroup per item beats the streaming CSR path'
         key = tuple((id(t), t._version) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
         return dims, plan, table, key

@@ -1183,6 +1183,9 @@ class LayerLaunch:
 
     def __init__(self, dims: Sequence[LayerDim], table):
         self.table = table
+        # one launch per item table: a MixedTable (blockplan.py) is two -- the two-per-CU form for the complexes that
+        # fit it, the 16-wave form for the rest -- over complementary complexes, into the same outputs
+        self.parts = list(getattr(table, 'parts', [table]))
         self.n = len(dims)
         self.F = int(dims[0].x.size(1))
         self.arr = (_ffi.LayerDim * self.n)()
@@ -1203,8 +1206,9 @@ class LayerLaunch:
                                         eps2=_ffi.ptr(e2), n_cells=int(D.x.size(0)), e_up=e_up,
                                         n_b=0 if bi is None else int(bi.size(1)))
             self.rows.append(int(D.x.size(0)))
-        if getattr(table, 'n_big', 0):
-            self._attach_big(dims, table)
+        for part in self.parts:
+            if getattr(part, 'n_big', 0):
+                self._attach_big(dims, part)
         self.total_rows = sum(self.rows)
         self._sizes = [r for r in self.rows for _ in range(2)]          # rows of out_up_d, out_b_d, in output order
         self._off = [sum(self._sizes[:i]) for i in range(len(self._sizes))]
@@ -1303,10 +1307,12 @@ class LayerLaunch:
             a.x = x.data_ptr()
             a.out_up = base + self._off[2 * d] * row_b
             a.out_b = base + self._off[2 * d + 1] * row_b
-        plan = self._plans.get(csr_mode != 0)
-        if plan is None:
-            plan = self._plans[csr_mode != 0] = self.table.c_plan(with_cache=csr_mode != 0)
-        rc = self.fn(self.arr, self.n, F, plan, int(csr_mode), self._err_ptr, _ffi.stream_ptr(self.dev))
-        if rc != 0:
-            _ffi.check(rc, 'cwn_layer_fused_f32')
+        plans = self._plans.get(csr_mode != 0)
+        if plans is None:
+            plans = self._plans[csr_mode != 0] = [t.c_plan(with_cache=csr_mode != 0) for t in self.parts]
+        stream = _ffi.stream_ptr(self.dev)
+        for plan in plans:
+            rc = self.fn(self.arr, self.n, F, plan, int(csr_mode), self._err_ptr, stream)
+            if rc != 0:
+                _ffi.check(rc, 'cwn_layer_fused_f32')
         return list(outs)

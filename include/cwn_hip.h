@@ -244,7 +244,7 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  * layout, same arithmetic, bit-identical outputs; smaller caps, and the rows of EACH product (cells of g, cells of
  * g+1, each padded to 16) are bounded by CWN_LAYER_W8_HALF_ROWS.  Rows per round: cwn_layer_variant_round_rows. */
 /* BIG ITEMS (record flag bit 1; variant 0 only; cwn_layer_sizes.allow_big).  A complex whose rows or entries exceed
- * what a workgroup's LDS holds (a molecule of more than ~45 atoms at F = 128, ~115 at F = 64) used to send its WHOLE
+ * what a workgroup's LDS holds (a molecule of more than 32 atoms at F = 128 -- 33 atoms pad to 64 staged rows and their bonds to 48 more, beyond the 96 -- or of more than ~115 at F = 64) used to send its WHOLE
  * batch to the streaming path (cwn_gemm_f32 + cwn_aggregate_f32).  With allow_big the table builder gives such a
  * complex one BIG record per set instead: its workgroup runs the streaming algorithm by itself inside the same launch --
  * Y1 / Y2 of the complex row tile by row tile on the matrix cores straight from the fp32 rows into the scratch matrices
@@ -343,6 +343,14 @@ typedef struct cwn_layer_sizes {
     const int64_t* cell_ptr[CWN_LAYER_MAX_DIMS];    /* [n_complexes + 1] prefix sums of the cells per complex */
     const int64_t* up_ptr[CWN_LAYER_MAX_DIMS];      /* the same for the entries of upper_index_d, or NULL */
     const int64_t* b_ptr[CWN_LAYER_MAX_DIMS];       /* the same for the entries of boundary_index_d, or NULL */
+    /* A batch served by TWO launches -- the two-per-CU form for the complexes that fit its (smaller) caps, the 16-wave
+     * form for the rest -- is cut in two calls over complementary subsets of the complexes:
+     * skip (in, [n_complexes] or NULL): complexes with a non-zero byte are left out of this table;
+     * unfit (out, [n_complexes] or NULL): when given, a complex that does not fit the caps in some set is marked 1 and
+     * left out of that set's items instead of failing the table (the caller then builds again with skip = unfit, so
+     * that a complex is in every set of a table or in none). */
+    const uint8_t* skip;
+    uint8_t* unfit;
 } cwn_layer_sizes;
 #define CWN_LAYER_ITEMS_TOO_LARGE (-1)
 #define CWN_LAYER_ITEMS_BAD_ARG (-2)

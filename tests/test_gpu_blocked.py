@@ -576,3 +576,44 @@ def test_big_complexes_are_streamed_inside_the_blocked_launch(F, n_small, big_si
     finally:
         layers.BIG_ITEMS = prev
         layers._BLOCKED_CACHE.clear()
+
+
+def test_mixed_launch_two_per_cu_form_plus_16_wave_form():
+    """A batch with more items than CUs in which some molecules are too large for the two-per-CU form (its 80 KiB hold
+    ~30 atoms at width 128): that form serves the complexes that fit, the 16-wave form (BIG records for the ones beyond
+    ITS caps) the rest -- two launches over complementary complexes into the same outputs (blockplan.MixedTable),
+    bit-identical to the two-kernel path."""
+    from cwn_amd import csr, layers
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    F = 128
+    small, large = zinc_like_complexes(300, 51, 6), zinc_like_complexes(24, 52, 6, n_lo=28, n_hi=44)
+    cxs = []
+    for i, c in enumerate(small):
+        cxs.append(c)
+        if i % 13 == 5 and large:
+            cxs.append(large.pop())
+    cxs += large
+    b = ComplexBatch.from_complex_list(cxs, max_dim=2).to(DEV)
+    g = torch.Generator().manual_seed(53)
+    for d in range(3):
+        b.cochains[d].x = torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV)
+    conv = _conv(F, seed=54, eps=0.2)
+    prev_v, prev_b = layers.LAYER_VARIANT, layers.BIG_ITEMS
+    layers.LAYER_VARIANT, layers.BIG_ITEMS = 'mixed', 'always'
+    try:
+        layers._BLOCKED_CACHE.clear()
+        with torch.no_grad():
+            table = conv._blocked_args(b.get_all_cochain_params(max_dim=2, include_down_features=False), 0)[2]
+        assert table.variant == 'mixed' and [t.variant for t in table.parts] == [1, 0]
+        assert table.parts[0].n_items > 256 and 0 < table.n_rest < 24 + 10 and table.parts[1].n_items == 2 * table.n_rest
+        first = _run(conv, b, blocked=True)
+        second = _run(conv, b, blocked=True)
+    finally:
+        layers.LAYER_VARIANT, layers.BIG_ITEMS = prev_v, prev_b
+        layers._BLOCKED_CACHE.clear()
+    csr._cache.clear()
+    plain = _run(conv, b, blocked=False)
+    for i, (f, s2, p) in enumerate(zip(first, second, plain)):
+        assert torch.equal(f, p), (i, (f - p).abs().max().item())
+        assert torch.equal(s2, p), i
