@@ -1011,9 +1011,12 @@ def main():
             and args.batch == 128 and H == 128):
         import subprocess
         workloads = {}
-        for wl in ('molhiv', 'reddit'):
+        # (+ the headline's own workload at batch 2048: the range where a launch has many items per CU and takes the
+        # two-per-CU form of the layer kernel -- DESIGN.md 4.0b)
+        for wl in ('molhiv', 'reddit', 'zinc_batch2048'):
             try:
-                cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--brief', '--steps', str(max(args.steps, 20)),
+                extra = ['--workload', wl] if wl != 'zinc_batch2048' else ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1']
+                cmd = [sys.executable, os.path.abspath(__file__)] + extra + ['--brief', '--steps', str(max(args.steps, 20)),
                        '--warmup', str(max(args.warmup, 5)), '--kernel-reps', str(min(args.kernel_reps, 50))]
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
                 line = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
@@ -1022,6 +1025,7 @@ def main():
                 d_ = json.loads(line[-1])
                 workloads[wl] = {'value': d_['value'], 'unit': d_['unit'], 'ms_per_step': d_['ms_per_step'],
                                  'workload': d_['config']['workload'], 'layer_kernel': d_['config']['layer_kernel'],
+                                 'layer_kernel_form': d_['config'].get('layer_kernel_form'),
                                  'cells_per_batch': d_['config']['cells_per_batch'], 'timing': d_.get('timing'),
                                  'roofline': {k: (d_['roofline'] or {}).get(k) for k in
                                               ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us',

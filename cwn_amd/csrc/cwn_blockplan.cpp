@@ -225,6 +225,13 @@ extern "C" int64_t cwn_layer_items_build(const cwn_layer_sizes* in, int32_t F, i
     const int64_t cap = variant == 1 ? CWN_LAYER_W8_GEMM_ROWS(F) : CWN_LAYER_GEMM_ROWS(F);
     const int64_t src_max = variant == 1 ? CWN_LAYER_W8_SOURCE_ROWS(F) : CWN_LAYER_SOURCE_ROWS(F), step = std::max<int64_t>(16, cap / 8);
     std::vector<int32_t> cur, best;
+    int64_t floor_items = 0;
+    {
+        Set sets_[CWN_LAYER_MAX_DIMS];
+        const int n_sets_ = make_sets(*in, sets_);
+        const int64_t gmax_ = std::max<int64_t>(1, in->n_complexes / (variant == 1 ? 2 * kTargetItems : kTargetItems));
+        floor_items = (in->skip == nullptr) ? n_sets_ * ((in->n_complexes + gmax_ - 1) / gmax_) : -1;
+    }
     cwn_layer_plan pc = *plan, pb = *plan;
     bool have = false, too_big = false;
     for (int64_t row_cap = cap; row_cap >= step; row_cap -= step) {
@@ -243,6 +250,9 @@ extern "C" int64_t cwn_layer_items_build(const cwn_layer_sizes* in, int32_t F, i
         } else if (n > pb.n_items + pb.n_items / 8) {
             break;                               // getting worse: smaller row caps only split more
         }
+        // no table has fewer items than one per gmax complexes and set: the search is over (the usual case at small
+        // batches: one complex per item whatever the split -- six more greedy passes were half of the 88 us a table cost)
+        if (have && pb.n_big == 0 && pb.n_items == floor_items) break;
     }
     if (!have) return too_big ? CWN_LAYER_ITEMS_TOO_LARGE : 0;
     if (pb.n_items > cap_items) return CWN_LAYER_ITEMS_BAD_ARG;

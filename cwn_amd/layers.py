@@ -113,7 +113,7 @@ def _streaming_pays(table, F: int) -> bool:
     return t_big < 1.9 * 8.7 * rounds
 
 
-def _mixed_wins(tm, table0, lower: int) -> bool:
+def _mixed_wins(tm, table0, lower: int, F: int = 128) -> bool:
     """Two launches (two-per-CU form for the complexes that fit + 16-wave form for the rest) against one launch of the
     16-wave form for all: rounds as in _two_per_cu_wins, plus one launch boundary.  Measured on batches with the size
     spread of the real ZINC subset (9 - 38 atoms, tools/ab_mixed.sh; M cells/s mixed / 16-wave form with big items /
@@ -122,7 +122,7 @@ def _mixed_wins(tm, table0, lower: int) -> bool:
     slots = TWO_PER_CU_MIN_ITEMS
     rounds = lambda n, per: -(-n // per) if n <= 2 * per else n / per      # (a partial LAST round of many costs its share)
     t1, t0 = tm.parts
-    if t0.n_big and not _streaming_pays(t0, 128 if t1.max_rows <= 80 else 64):
+    if t0.n_big and BIG_ITEMS != 'always' and not (BIG_ITEMS and _streaming_pays(t0, F)):
         return False
     mixed = 1.3 * rounds(t1.n_items, 2 * slots) + rounds(t0.n_items, slots) + 0.2
     alone = rounds(table0.n_items if table0 is not None else lower, slots) if table0 is not None else 2.0 * rounds(lower, slots)
@@ -794,20 +794,27 @@ class SparseCINConv(torch.nn.Module):
             table = plan.items(F, has_up, has_b, variant=1)
         elif LAYER_VARIANT == 'auto' and lower > 4 * TWO_PER_CU_MIN_ITEMS:
             table = plan.items(F, has_up, has_b, variant=1)          # many rounds either way: two per CU (if every complex fits)
-        if table is None and LAYER_VARIANT != '1':
-            if lower > BLOCKED_MAX_ITEMS:
+        if table is None and LAYER_VARIANT != '1' and lower > BLOCKED_MAX_ITEMS:
+            # too many items for the 16-wave form alone: the two-per-CU form for whatever fits it + the rest (mixed), or
+            # the streaming path
+            tm = plan.items_mixed(F, has_up, has_b) if LAYER_VARIANT in ('auto', 'mixed') else None
+            if tm is None or tm.parts[1].n_items > BLOCKED_MAX_ITEMS or (tm.parts[1].n_big and BIG_ITEMS != 'always' and not (
+                    BIG_ITEMS and _streaming_pays(tm.parts[1], F))):
                 return f'more than {BLOCKED_MAX_ITEMS} items: beyond the range where one workgroup per item beats the streaming CSR path'
+            table = tm
+        if table is None and LAYER_VARIANT != '1':
             table = plan.items(F, has_up, has_b)
             if table is not None and LAYER_VARIANT == 'auto' and table.n_items > TWO_PER_CU_MIN_ITEMS:
                 t1 = plan.items(F, has_up, has_b, variant=1)
                 if t1 is not None and _two_per_cu_wins(table.n_items, t1.n_items):
                     table = t1
-        if LAYER_VARIANT in ('auto', 'mixed') and lower > TWO_PER_CU_MIN_ITEMS and (table is None or table.variant == 0):
+        if LAYER_VARIANT in ('auto', 'mixed') and lower > TWO_PER_CU_MIN_ITEMS and (table is None or table.variant == 0) \
+                and lower <= BLOCKED_MAX_ITEMS:
             # more items than CUs, but some complex is too large for the two-per-CU form (its 80 KiB hold ~30 atoms at
             # width 128): that form for the complexes that fit, the 16-wave form (BIG records where needed) for the
             # rest -- two launches into the same outputs (blockplan.MixedTable)
             tm = plan.items_mixed(F, has_up, has_b)
-            if tm is not None and (LAYER_VARIANT == 'mixed' or _mixed_wins(tm, table, lower)):
+            if tm is not None and (LAYER_VARIANT == 'mixed' or _mixed_wins(tm, table, lower, F)):
                 table = tm
         if table is None and LAYER_VARIANT != '1' and BIG_ITEMS and lower <= BLOCKED_MAX_ITEMS:
             # some complex does not fit a workgroup's LDS: ITS workgroup streams it (BIG records, include/cwn_hip.h), the

@@ -29,6 +29,9 @@ def build(self, F: int, has_up):
             best = t
         elif t.n_items > best.n_items + best.n_items // 8:
             break                               # getting worse: smaller row caps only split more
+        gmax = max(1, self.C // 128)
+        if best is not None and best.n_items == len(self._sets(has_up)) * -(-self.C // gmax):
+            break                               # one item per gmax complexes and set: nothing can have fewer
     return best
 
 def _build_with(self, F: int, has_up, row_cap: int, src_cap: int):
