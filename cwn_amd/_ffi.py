@@ -384,9 +384,30 @@ def defer_tn(on: bool) -> None:
         _tn_queue = None
 
 
+# ... or, TN_SIDE_STREAM, launched where they arise but on a SIDE stream that forks off the caller's stream there and
+# joins it again in flush_tn: the weight gradients leave the critical path of the backward (a chain of small
+# latency-bound launches that leaves most of the chip idle) instead of waiting for its end -- under stream capture
+# the fork / join become parallel branches of the graph.  OFF by default: measured on the graph-captured ZINC-128 step the
+# forked graph replays SLOWER (1.17 -> 1.46 - 1.61 ms; every cross-branch edge of a hipGraph costs more than the overlap
+# wins); kept as a switch for eager multi-stream runs (CWN_TN_SIDE=1).
+TN_SIDE_STREAM = os.environ.get('CWN_TN_SIDE', '0') == '1'
+_tn_side = {}
+_tn_side_used = False
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _tn_side:
+        _tn_side[key] = torch.cuda.Stream(device=key)
+    return _tn_side[key]
+
+
 def flush_tn(device) -> None:
-    """Launch every queued weight gradient (queue order), MAX_TN_DESCS per launch."""
-    global _tn_queue
+    """Launch every queued weight gradient (queue order), MAX_TN_DESCS per launch; join the side stream."""
+    global _tn_queue, _tn_side_used
+    if _tn_side_used:
+        torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+        _tn_side_used = False
     if not _tn_queue:
         return
     q, _tn_queue = _tn_queue, []
@@ -407,7 +428,16 @@ def gemm_tn(descs: Sequence[GemmTnDesc], device, keep=None, deferrable: bool = F
     """dW += dZ^T [X | X2] for every descriptor.  `deferrable`: the targets are buffers the caller owns until
     flush_tn (never tensors handed back to autograd); `keep`: every tensor a descriptor points at."""
     if deferrable and _tn_queue is not None and not DETERMINISTIC_TN:
-        _tn_queue.append((list(descs), keep))
+        if not TN_SIDE_STREAM:
+            _tn_queue.append((list(descs), keep))
+            return
+        global _tn_side_used
+        main, side = torch.cuda.current_stream(device), _side_stream(device)
+        side.wait_stream(main)                  # everything the descriptors read has been issued on `main`
+        _tn_queue.append(([], keep))            # the operands stay referenced until the join
+        _tn_side_used = True
+        with torch.cuda.stream(side):
+            gemm_tn(descs, device)
         return
     L = lib()
     s = stream_ptr(device)

@@ -87,27 +87,53 @@ __device__ __forceinline__ void tile_load(f32x4 (&v)[kU], const Src& S, int col0
     }
 }
 
-__device__ __forceinline__ void tile_store(float* lds, const f32x4 (&v)[kU], const Src& S, int col0,
-                                           int64_t row0, int64_t row_hi) {
+// The prologue constants of a thread: q = u * kThreads + tid walks rows only (kThreads is a multiple of kTile / 4), so its
+// four columns are the same in every tile of the band -- loaded ONCE per workgroup (inside tile_store they were global loads
+// in front of every LDS store: 23 of the 71 us of the merged ZINC-128 launch, tools/ubench_tn24.py).
+struct Pro {
+    f32x4 sc, sh;
+    bool affine, relu;
+    int cc, cmax;
+};
+
+__device__ __forceinline__ Pro make_pro(const Src& S, int col0) {
+    static_assert(kThreads % (kTile / 4) == 0, "a thread keeps its columns");
+    const int c = threadIdx.x % (kTile / 4);
+    const int col = col0 + 4 * c;
+    const bool second = S.c2 > 0 && col >= S.c1;
+    Pro P;
+    P.cc = second ? col - S.c1 : col;
+    P.cmax = second ? S.c2 : S.c1;
+    const float* sc = second ? S.scale2 : S.scale1;
+    const float* sh = second ? S.shift2 : S.shift1;
+    P.relu = (S.relu & (second ? 2 : 1)) != 0;
+    P.affine = sc != nullptr;
+    P.sc = (f32x4){1.f, 1.f, 1.f, 1.f};
+    P.sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (P.affine) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (P.cc + t < P.cmax) {
+                P.sc[t] = sc[P.cc + t];
+                P.sh[t] = sh[P.cc + t];
+            }
+    }
+    return P;
+}
+
+__device__ __forceinline__ void tile_store(float* lds, const f32x4 (&v)[kU], const Pro& P, int64_t row0, int64_t row_hi) {
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
         const int q = u * kThreads + threadIdx.x;
         const int r = q / (kTile / 4), c = q % (kTile / 4);
         const bool row_ok = row0 + r < row_hi;
-        const int col = col0 + 4 * c;
-        const bool second = S.c2 > 0 && col >= S.c1;
-        const int cc = second ? col - S.c1 : col;
-        const int cmax = second ? S.c2 : S.c1;
-        const float* sc = second ? S.scale2 : S.scale1;
-        const float* sh = second ? S.shift2 : S.shift1;
-        const bool relu = (S.relu & (second ? 2 : 1)) != 0;
         f32x4 x = v[u];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float y = x[t];
-            const bool ok = row_ok && cc + t < cmax;
-            if (ok && sc != nullptr) y = y * sc[cc + t] + sh[cc + t];
-            if (relu) y = fmaxf(y, 0.f);
+            const bool ok = row_ok && P.cc + t < P.cmax;
+            if (P.affine) y = y * P.sc[t] + P.sh[t];
+            if (P.relu) y = fmaxf(y, 0.f);
             x[t] = ok ? y : 0.f;      // rows past the band and columns past the matrix add nothing
         }
         *reinterpret_cast<f32x4*>(lds + r * kLd + 4 * c) = x;
@@ -115,7 +141,7 @@ __device__ __forceinline__ void tile_store(float* lds, const f32x4 (&v)[kU], con
 }
 
 template <bool FAST>
-__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TnBatch B) {
+__global__ __launch_bounds__(kThreads, 4) void gemm_tn_kernel(TnBatch B) {
     __shared__ __attribute__((aligned(16))) float zt[kChunk * kLd];
     __shared__ __attribute__((aligned(16))) float xt[kChunk * kLd];
     int di = 0;
@@ -152,10 +178,11 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TnBatch B) {
     f32x4 vz[kU], vx[kU];
     tile_load<FAST>(vz, SZ, n0, row_lo, row_hi);
     tile_load<FAST>(vx, SX, k0, row_lo, row_hi);
+    const Pro PZ = make_pro(SZ, n0), PX = make_pro(SX, k0);
     for (int64_t row0 = row_lo; row0 < row_hi; row0 += kChunk) {
         __syncthreads();                          // everyone is done reading the previous chunk
-        tile_store(zt, vz, SZ, n0, row0, row_hi);
-        tile_store(xt, vx, SX, k0, row0, row_hi);
+        tile_store(zt, vz, PZ, row0, row_hi);
+        tile_store(xt, vx, PX, row0, row_hi);
         __syncthreads();
         if (row0 + kChunk < row_hi) {             // next chunk in flight during the MFMAs
             tile_load<FAST>(vz, SZ, n0, row0 + kChunk, row_hi);
