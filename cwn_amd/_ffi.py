@@ -20,7 +20,7 @@ ABI_VERSION = 12
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
-           'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32',
+           'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
 
@@ -222,6 +222,8 @@ def lib():
     for name in ('cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32'):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [C.POINTER(NormDesc), C.c_int, C.c_void_p]
+    L.cwn_norm_bwd_f32.restype = C.c_int
+    L.cwn_norm_bwd_f32.argtypes = [C.POINTER(NormDesc), C.c_int, C.c_int, C.c_void_p]
     L.cwn_gemm_tn_f32.restype = C.c_int
     L.cwn_gemm_tn_f32.argtypes = [C.POINTER(GemmTnDesc), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     L.cwn_gemm_tn_workspace_bytes.restype = C.c_size_t
@@ -355,6 +357,19 @@ def norm_bwd_reduce(descs: Sequence[NormDesc], device) -> None:
 
 def norm_bwd_apply(descs: Sequence[NormDesc], device) -> None:
     _chunked('cwn_norm_bwd_apply_f32', NormDesc, descs, device, MAX_NORM_DESCS)
+
+
+NORM_BWD_FUSED_MAX_ROWS = 4096     # = CWN_NORM_BWD_FUSED_MAX_ROWS
+
+
+def norm_bwd(descs: Sequence[NormDesc], device, accumulate: bool) -> None:
+    """Reduce + apply in one launch (matrices of at most NORM_BWD_FUSED_MAX_ROWS rows, 16-byte aligned)."""
+    L = lib()
+    s = stream_ptr(device)
+    for i in range(0, len(descs), MAX_NORM_DESCS):
+        chunk = descs[i:i + MAX_NORM_DESCS]
+        arr = (NormDesc * len(chunk))(*chunk)
+        check(L.cwn_norm_bwd_f32(arr, len(chunk), int(bool(accumulate)), s), 'cwn_norm_bwd_f32')
 
 
 # False: the row bands of a weight gradient are added with fp32 atomics (fastest: 1.48 ms ZINC training

@@ -33,6 +33,13 @@ from torch.nn import BatchNorm1d, Identity, Linear
 
 from . import _ffi, ops
 
+# True: BatchNorm backward as ONE launch per stage (cwn_norm_bwd_f32: column-owning workgroups, sums bit-reproducible and added
+# straight into gamma.grad / beta.grad).  OFF: measured on the ZINC-128 step the launch takes 28 us against 6.3 + 5.9 us
+# for reduce + apply -- a workgroup that owns 4 columns reads and writes 16 B of every 128-B line, and the partial-line
+# traffic of 32 workgroups per matrix costs far more than the launch it saves (step 1.17 -> 1.34 ms).  Kept for runs that
+# want reproducible BatchNorm gradients (with _ffi.DETERMINISTIC_TN for the weights).
+FUSED_NORM_BACKWARD = False
+
 
 @dataclass
 class Stage:
@@ -223,15 +230,27 @@ class _DenseTrain(torch.autograd.Function):
         # into it and autograd gets None -- else a slice of one zeroed scratch buffer.  The
         # BatchNorm sums s1 / s2 always go to scratch (the apply kernel needs THIS pass's sums) and
         # are added to gamma.grad / beta.grad with one multi-tensor add at the end.
-        sizes, targets = [], []
+        # With the one-launch BatchNorm backward (every matrix of the layer within its row cap, 16-byte aligned) the sums go
+        # straight INTO gamma.grad / beta.grad when those exist: no scratch to zero, no multi-tensor add at the end.
+        fused_norm = FUSED_NORM_BACKWARD and all(
+            z.size(0) <= _ffi.NORM_BWD_FUSED_MAX_ROWS and z.size(1) % 4 == 0 and z.stride(0) % 4 == 0 and z.data_ptr() % 16 == 0
+            for z in [zz for i in range(nd) for br in (0, 1) for zz in Z[i][br]] + Z3)
+        sizes, targets, norm_targets = [], [], {}
         for st in stages:
             W, b, gamma, beta = P[id(st)]
             tw, tb = ops._grad_target(st.lin.weight), ops._grad_target(st.lin.bias)
             targets.append((tw, tb))
+            direct = None
+            if st.is_bn and fused_norm:
+                tg, tbeta = ops._grad_target(st.norm.weight), ops._grad_target(st.norm.bias)
+                if tg is not None and tbeta is not None and tg.data_ptr() % 16 == 0 and tbeta.data_ptr() % 16 == 0:
+                    direct = (tbeta, tg)                      # (s1 = d beta, s2 = d gamma)
+            norm_targets[id(st)] = direct
             sizes.append((0 if tw is not None else W.numel(),
                           0 if (b is None or tb is not None) else b.numel(),
-                          2 * W.size(0) if st.is_bn else 0))
-        flat = torch.zeros(sum(a + b + c for a, b, c in sizes), dtype=torch.float32, device=dev)
+                          2 * W.size(0) if st.is_bn and direct is None else 0))
+        n_flat = sum(a + b + c for a, b, c in sizes)
+        flat = torch.zeros(n_flat, dtype=torch.float32, device=dev) if n_flat else None
         G, q = {}, 0
         for st, (nw, nb, ns), (tw, tb) in zip(stages, sizes, targets):
             W, b = P[id(st)][0], P[id(st)][1]
@@ -246,6 +265,7 @@ class _DenseTrain(torch.autograd.Function):
         def norm_backward(items):
             """items: (stage, dy, z) -> dz list; BatchNorm stages reduce first."""
             red, app, outs = [], [], []
+            direct, scratch, late = [], [], []
             for st, dy, z in items:
                 dz = torch.empty(z.shape, dtype=torch.float32, device=dev)
                 outs.append(dz)
@@ -253,13 +273,29 @@ class _DenseTrain(torch.autograd.Function):
                     continue
                 aff = aff_of.get(id(st))
                 s12 = G[id(st)][2]
+                tgt = norm_targets[id(st)]
+                sums = tgt if tgt is not None else s12
+                if (fused_norm and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0
+                        and (sums is None or sums[0].data_ptr() % 16 == 0)):
+                    (direct if tgt is not None else scratch).append(_norm_desc(z, dy=dy, out=dz, aff=aff, s12=sums))
+                    continue
+                if st.is_bn and tgt is not None:       # (an unaligned dy handed in by autograd) sums through a scratch pair
+                    s12 = torch.zeros(2, z.size(1), dtype=torch.float32, device=dev)
+                    late.append((tgt, s12))
                 if st.is_bn:
                     red.append(_norm_desc(z, dy=dy, aff=aff, s12=s12))
                 app.append(_norm_desc(z, dy=dy, out=dz, aff=aff, s12=s12))
+            if direct:
+                _ffi.norm_bwd(direct, dev, accumulate=True)
+            if scratch:
+                _ffi.norm_bwd(scratch, dev, accumulate=False)
             if red:
                 _ffi.norm_bwd_reduce(red, dev)
             if app:
                 _ffi.norm_bwd_apply(app, dev)
+            for tgt, s12 in late:
+                tgt[0].add_(s12[0])
+                tgt[1].add_(s12[1])
             return outs
 
         def prologue(st: Optional[Stage]):
@@ -340,7 +376,7 @@ class _DenseTrain(torch.autograd.Function):
             dW, db, s12 = G[id(st)]
             W, b, gamma, beta = P[id(st)]
             gg = gb = None
-            if st.is_bn:
+            if st.is_bn and norm_targets[id(st)] is None:
                 tg, tbeta = ops._grad_target(st.norm.weight), ops._grad_target(st.norm.bias)
                 if gamma is not None:
                     if tg is None:

@@ -531,6 +531,15 @@ int cwn_norm_act_f32(const cwn_norm_desc* descs_host, int n, cwn_stream_t stream
 int cwn_norm_bwd_reduce_f32(const cwn_norm_desc* descs_host, int n, cwn_stream_t stream);
 /* out = scale * (dyh - s1 / M - xhat * s2 / M)      (out = dyh when scale == NULL) */
 int cwn_norm_bwd_apply_f32(const cwn_norm_desc* descs_host, int n, cwn_stream_t stream);
+/* Both in ONE launch for matrices of at most CWN_NORM_BWD_FUSED_MAX_ROWS rows (the ZINC / MOLHIV batches): a workgroup
+ * owns four columns of one matrix over ALL its rows, so the column sums never leave it -- no atomics (the sums are
+ * bit-reproducible), no zeroed s1 / s2, nothing between the reduction and the apply but a workgroup barrier.
+ * s1 / s2 are WRITTEN (accumulate == 0) or ADDED TO (accumulate != 0: they may be the .grad of beta / gamma);
+ * when scale == NULL they are not touched.  Needs 16-byte aligned operands and strides (CWN_ERR_ALIGN otherwise).
+ * SLOWER than reduce + apply at the ZINC batch (28 us against 12: every workgroup touches 16 B of every line); the
+ * form for bit-reproducible BatchNorm gradients, not the default. */
+#define CWN_NORM_BWD_FUSED_MAX_ROWS 4096
+int cwn_norm_bwd_f32(const cwn_norm_desc* descs_host, int n, int accumulate, cwn_stream_t stream);
 
 /* Weight gradient of a Linear layer on the matrix cores, accumulated:
  *     dW[n, k] += sum_m dZ[m, n] * prologue([X | X2])[m, k]          db[n] += sum_m dZ[m, n]

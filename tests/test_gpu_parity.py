@@ -1411,6 +1411,24 @@ def test_batchnorm_relu_pieces_match_torch(M, N):
     torch.testing.assert_close(cpu(dZ).double(), z_ref.grad, rtol=1e-4, atol=2e-5 * max(scale, 1.0))
     torch.testing.assert_close(cpu(s12[1]).double(), bn64.weight.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(cpu(s12[0]).double(), bn64.bias.grad, rtol=1e-4, atol=1e-4)
+    # the same in ONE launch (cwn_norm_bwd_f32), sums written / added to what the targets hold; twice: bit-reproducible
+    if M <= _ffi.NORM_BWD_FUSED_MAX_ROWS and N % 4 == 0:
+        t12 = torch.full((2, N), 3.0, device=DEV)
+        dZ2 = torch.empty(M, N, device=DEV)
+        _ffi.norm_bwd([_norm_desc(Z, dy=dHd, out=dZ2, aff=aff, s12=t12)], DEV, accumulate=False)
+        torch.testing.assert_close(cpu(dZ2).double(), z_ref.grad, rtol=1e-4, atol=2e-5 * max(scale, 1.0))
+        torch.testing.assert_close(cpu(t12[1]).double(), bn64.weight.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(cpu(t12[0]).double(), bn64.bias.grad, rtol=1e-4, atol=1e-4)
+        first, dZ3 = t12.clone(), torch.empty(M, N, device=DEV)
+        _ffi.norm_bwd([_norm_desc(Z, dy=dHd, out=dZ3, aff=aff, s12=t12)], DEV, accumulate=True)
+        assert torch.equal(t12, 2 * first) and torch.equal(dZ3, dZ2)
+        # identity normalisation: the ReLU mask only, sums untouched
+        dZ4 = torch.empty(M, N, device=DEV)
+        _ffi.norm_bwd([_norm_desc(Z, dy=dHd, out=dZ4, aff=None)], DEV, accumulate=False)
+        assert torch.equal(dZ4, dHd * (Z > 0))
+    else:
+        with pytest.raises(_ffi.CwnError):
+            _ffi.norm_bwd([_norm_desc(Z, dy=dHd, out=torch.empty(M, N, device=DEV), aff=aff, s12=s12)], DEV, accumulate=False)
 
 
 def _train_layer_pair(graph_norm, hidden, use_cob, seed=0):
@@ -1425,6 +1443,43 @@ def _train_layer_pair(graph_norm, hidden, use_cob, seed=0):
     b = layers.SparseCINConv(hidden, hidden, hidden, **kw).to(DEV).train()
     b.load_state_dict(a.state_dict())
     return a, b
+
+
+@pytest.mark.parametrize('into_grad', [False, True])
+def test_one_launch_batchnorm_backward_gives_the_same_gradients(into_grad):
+    """dense_train.FUSED_NORM_BACKWARD (cwn_norm_bwd_f32, the bit-reproducible form) against reduce + apply: same layer,
+    same inputs; with `into_grad` the sums are added straight into gamma.grad / beta.grad (pre-filled with ones)."""
+    from cwn_amd import dense_train as DT, ops
+    from cwn_amd.synthetic import zinc_like_batch
+    a, bl = _train_layer_pair(torch.nn.BatchNorm1d, 128, True, seed=3)
+    b = zinc_like_batch(8, seed=2, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(b.cochains[d].num_cells, 128, generator=g).to(DEV) for d in range(3)]
+    ws = [torch.randn(b.cochains[d].num_cells, 128, generator=g).to(DEV) for d in range(3)]
+
+    def run(conv, fused):
+        DT.FUSED_NORM_BACKWARD = fused
+        try:
+            if into_grad:
+                for p in conv.parameters():
+                    p.grad = torch.ones_like(p)
+            xin = [x.clone().requires_grad_() for x in xs]
+            b.set_xs(xin)
+            out = conv(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+            with ops.accumulate_into_grad(into_grad):
+                sum((o * w).sum() for o, w in zip(out, ws)).backward()
+        finally:
+            DT.FUSED_NORM_BACKWARD = False
+        return xin
+
+    xa, xb = run(a, True), run(bl, False)
+    for u, v in zip(xa, xb):
+        torch.testing.assert_close(u.grad, v.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(v.grad.abs().max())))
+    for (n, p), q in zip(a.named_parameters(), bl.parameters()):
+        if q.grad is None:
+            assert p.grad is None, n
+            continue
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(q.grad.abs().max())), msg=n)
 
 
 @pytest.mark.parametrize('norm,hidden,use_cob', [('bn', 128, True), ('bn', 64, False), ('id', 32, True)])
