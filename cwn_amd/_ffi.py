@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
@@ -56,7 +56,8 @@ class GemmDesc(C.Structure):
 
 
 GEMM_EXACT = 1
-GEMM_W_PACKED = 2         # = CWN_GEMM_W_PACKED            # = CWN_GEMM_EXACT (cwn_gemm_desc.flags)
+GEMM_W_PACKED = 2         # = CWN_GEMM_W_PACKED
+GEMM_ADD_OUT = 4          # = CWN_GEMM_ADD_OUT            # = CWN_GEMM_EXACT (cwn_gemm_desc.flags)
 
 
 class LayerDim(C.Structure):
@@ -129,14 +130,14 @@ class BnDesc(C.Structure):
                 ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
                 ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p),
                 ('M', C.c_int64), ('N', C.c_int32), ('eps', C.c_float), ('momentum', C.c_float),
-                ('pad_', C.c_int32)]
+                ('pad_', C.c_int32), ('num_batches_tracked', C.c_void_p), ('bwd_sums', C.c_void_p)]
 
 
 class NormDesc(C.Structure):
     _fields_ = [('dy', C.c_void_p), ('z', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
                 ('mean', C.c_void_p), ('rstd', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p),
                 ('out', C.c_void_p), ('M', C.c_int64), ('lddy', C.c_int64), ('ldz', C.c_int64),
-                ('ldout', C.c_int64), ('N', C.c_int32), ('relu', C.c_int32)]
+                ('ldout', C.c_int64), ('N', C.c_int32), ('relu', C.c_int32), ('acc1', C.c_void_p), ('acc2', C.c_void_p)]
 
 
 class GemmTnDesc(C.Structure):

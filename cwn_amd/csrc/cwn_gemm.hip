@@ -104,31 +104,67 @@ struct Prologue {
     int relu;              // bit 0: ReLU on X, bit 1: ReLU on X2
 };
 
+// A thread's part of the prologue: q = u * kThreads + tid walks ROWS only (kThreads is a multiple of KP / 4), so its four
+// input columns -- and their scale / shift -- are the same for every row of every tile: loaded once per workgroup.  (Round 2
+// read them from global memory in front of every LDS store: 3 of the 16.5 us of a ZINC-128 stage-2 launch,
+// tools/ubench_gemm_train.py.)
+// v of the lane CTRL's rotation away within its 16-lane row (DPP row_ror:n = 0x120 + n), for a double
+template <int CTRL>
+__device__ __forceinline__ double row_ror_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+
+struct ProConst {
+    f32x4 sc, sh;
+    bool affine, relu;
+    int kk, kmax;
+};
+
+template <int KP>
+__device__ __forceinline__ ProConst make_pro(int K1, int K2, const Prologue& P) {
+    constexpr int CPR = KP / 4;
+    static_assert(kThreads % CPR == 0, "a thread keeps its columns");
+    const int k = 4 * (threadIdx.x % CPR);
+    const bool second = K2 > 0 && k >= K1;
+    ProConst C;
+    C.kk = second ? k - K1 : k;
+    C.kmax = second ? K2 : K1;
+    const float* sc = second ? P.scale2 : P.scale;
+    const float* sh = second ? P.shift2 : P.shift;
+    C.affine = sc != nullptr;
+    C.relu = (P.relu & (second ? 2 : 1)) != 0;
+    C.sc = (f32x4){1.f, 1.f, 1.f, 1.f};
+    C.sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (C.affine) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (C.kk + t < C.kmax) {
+                C.sc[t] = sc[C.kk + t];
+                C.sh[t] = sh[C.kk + t];
+            }
+    }
+    return C;
+}
+
 template <bool PRO, int ROWS, int KP, int U0, int U1>
-__device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, int K1, int K2,
-                                            const Prologue& P) {
+__device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, const ProConst& C) {
     constexpr int CPR = KP / 4;
 #pragma unroll
     for (int u = U0; u < U1; ++u) {
         const int q = u * kThreads + threadIdx.x;
         const int r = q / CPR, c = q % CPR;
-        const int k = 4 * c;
-        const bool second = K2 > 0 && k >= K1;
-        const int kk = second ? k - K1 : k;
-        const int kmax = second ? K2 : K1;
         f32x4 v = st.v[u];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float x = v[t];
             if constexpr (PRO) {
-                const float* sc = second ? P.scale2 : P.scale;
-                const float* sh = second ? P.shift2 : P.shift;
-                if (kk + t < kmax) {
-                    if (sc != nullptr) x = x * sc[kk + t] + sh[kk + t];
-                    if (P.relu & (second ? 2 : 1)) x = fmaxf(x, 0.f);
-                }
+                if (C.affine) x = x * C.sc[t] + C.sh[t];
+                if (C.relu) x = fmaxf(x, 0.f);
             }
-            v[t] = kk + t < kmax ? x : 0.f;
+            v[t] = C.kk + t < C.kmax ? x : 0.f;
         }
         *reinterpret_cast<f32x4*>(lds + lds_off<KP>(r, c)) = v;
     }
@@ -166,7 +202,8 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
     const float* const Wp = D.W;
     const int64_t ldx = D.ldx, ldx2 = D.ldx2, ldw = D.ldw, ldy = D.ldy, M = D.M;
     const int N = D.N, K1 = D.K, K2 = D.K2, Ktot = D.K + D.K2;
-    const Prologue pro{D.in_scale, D.in_shift, D.in_scale2, D.in_shift2, D.in_relu};
+    const ProConst pro = make_pro<KP>(K1, K2, Prologue{D.in_scale, D.in_shift, D.in_scale2, D.in_shift2, D.in_relu});
+    const bool add_out = (D.flags & CWN_GEMM_ADD_OUT) != 0;
     const int dbg = D.flags >> 8;   // timing experiments (tools/ubench_gemm.py): 1 no MFMA, 2 no W staging, 4 no store
     constexpr int SLABS = KP / 16;
     using SX = Staged<BM, KP>;                 // a 32-row tile in flight: KP/32 x 16 B per thread
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             it = 0;
         }
         float* ldsX = smem + (it & 1) * (BM * KP);
-        stage_store<PRO, BM, KP, 0, SX::U>(ldsX, sx, K1, K2, pro);
+        stage_store<PRO, BM, KP, 0, SX::U>(ldsX, sx, pro);
         __syncthreads();                     // tile visible; everyone is done with the other buffer
         if constexpr (DEEP) {
             sx = sx2;                        // tile + nblk is already on its way
@@ -400,12 +437,13 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
                 const int64_t slot = m_base / 32 + wm;   // RT == 2 only (host-checked): tiles align to bands
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // (DPP rotations within the 16-lane row, two 32-bit halves per double: __shfl_xor on a double is two
+                    // ds_bpermute round trips per step, 3 us of a 13.5-us stage launch, tools/ubench_gemm_train.py)
                     double a = csum[r], b = csq[r];
-#pragma unroll
-                    for (int o = 8; o >= 1; o >>= 1) {
-                        a += __shfl_xor(a, o, 16);
-                        b += __shfl_xor(b, o, 16);
-                    }
+                    a += row_ror_f64<0x128>(a); b += row_ror_f64<0x128>(b);
+                    a += row_ror_f64<0x124>(a); b += row_ror_f64<0x124>(b);
+                    a += row_ror_f64<0x122>(a); b += row_ror_f64<0x122>(b);
+                    a += row_ror_f64<0x121>(a); b += row_ror_f64<0x121>(b);
                     if (j == 0 && n0 + r < N && slot < CWN_STAT_ROWS(M)) {
                         D.col_sum[slot * N + n0 + r] = a;
                         D.col_sumsq[slot * N + n0 + r] = b;
@@ -442,7 +480,16 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             const bool full = n0 + 3 < N;
             if (ra < M && n0 < N) {
                 float* yp = D.Y + ra * ldy + n0;
-                if (full && vec) cwn::store_result4(yp, va[0], va[1], va[2], va[3]);
+                if (add_out) {      // Y += : this launch is the only writer of Y (host contract), a plain read-modify-write
+if (full && vec) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(yp);
+                        cwn::store_result4(yp, o[0] + va[0], o[1] + va[1], o[2] + va[2], o[3] + va[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n0 + r < N) yp[r] += va[r];
+                    }
+                } else if (full && vec) cwn::store_result4(yp, va[0], va[1], va[2], va[3]);
                 else
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -450,7 +497,16 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             }
             if (rb < M && n0 < N) {
                 float* yp = D.Y + rb * ldy + n0;
-                if (full && vec) cwn::store_result4(yp, vb[0], vb[1], vb[2], vb[3]);
+                if (add_out) {
+if (full && vec) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(yp);
+                        cwn::store_result4(yp, o[0] + vb[0], o[1] + vb[1], o[2] + vb[2], o[3] + vb[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n0 + r < N) yp[r] += vb[r];
+                    }
+                } else if (full && vec) cwn::store_result4(yp, vb[0], vb[1], vb[2], vb[3]);
                 else
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -471,7 +527,7 @@ int cwn_gemm_split_launch(const cwn_gemm_desc* descs, int n, hipStream_t stream)
 extern "C" int cwn_gemm_would_split(const cwn_gemm_desc* descs, int n) {
     if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return 0;
     for (int i = 0; i < n; ++i)
-        if (descs[i].flags & CWN_GEMM_EXACT) return 0;
+        if (descs[i].flags & (CWN_GEMM_EXACT | CWN_GEMM_ADD_OUT)) return 0;
     return cwn_gemm_split_eligible(descs, n) ? 1 : 0;
 }
 

@@ -44,11 +44,15 @@ __device__ __forceinline__ int find_desc(const int32_t* start, int n, int b) {
 }
 
 // grid (column chunk of 64, descriptor).  The GEMM epilogue left one fp64 partial per 32-row band
-// and column; lanes read consecutive columns (coalesced), the four waves take every fourth band
-// with eight loads in flight each (a dependent round trip is ~1 us, and one thread walking 105
-// bands four at a time made this a 12-us kernel), and the four partials meet in LDS.
-__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(BnBatch B) {
-    __shared__ double part[2][4][64];
+// and column; lanes read consecutive columns (coalesced), the SIXTEEN waves take every sixteenth band
+// with eight loads in flight each: the 105 bands of a ZINC-128 dimension are one round trip (a dependent
+// round trip is ~1 us; four waves walking them in four rounds made this a 6.6-us kernel -- 9 us start to
+// start, twelve times per training step -- and one thread walking them a 12-us one), and the
+// sixteen partials meet in LDS.
+constexpr int kFinThreads = 1024, kFinSlices = kFinThreads / 64;
+
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(BnBatch B) {
+    __shared__ double part[2][kFinSlices][64];
     const cwn_bn_desc& D = B.d[blockIdx.y];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int slice = threadIdx.x >> 6;
@@ -56,18 +60,18 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(BnBatch B) {
     const bool ok = n < D.N;
     const int nc = ok ? n : D.N - 1;
     double s = 0.0, sq = 0.0;
-    for (int64_t b0 = slice; b0 < bands; b0 += 4 * 8) {
+    for (int64_t b0 = slice; b0 < bands; b0 += kFinSlices * 8) {
         double t[8], u[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int64_t b = b0 + 4 * q;
+            const int64_t b = b0 + kFinSlices * q;
             const int64_t bc = b < bands ? b : bands - 1;
             t[q] = D.col_sum[bc * D.N + nc];
             u[q] = D.col_sumsq[bc * D.N + nc];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (b0 + 4 * q < bands) {
+            if (b0 + kFinSlices * q < bands) {
                 s += t[q];
                 sq += u[q];
             }
@@ -77,8 +81,12 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(BnBatch B) {
     part[1][slice][threadIdx.x & 63] = sq;
     __syncthreads();
     if (slice != 0 || !ok) return;
-    s = part[0][0][threadIdx.x] + part[0][1][threadIdx.x] + part[0][2][threadIdx.x] + part[0][3][threadIdx.x];
-    sq = part[1][0][threadIdx.x] + part[1][1][threadIdx.x] + part[1][2][threadIdx.x] + part[1][3][threadIdx.x];
+    s = sq = 0.0;
+#pragma unroll
+    for (int q = 0; q < kFinSlices; ++q) {
+        s += part[0][q][threadIdx.x];
+        sq += part[1][q][threadIdx.x];
+    }
     const double invM = 1.0 / (double)D.M;
     const double mean = s * invM;
     double var = sq * invM - mean * mean;     // biased, as BatchNorm normalises
@@ -91,6 +99,11 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(BnBatch B) {
     D.shift[n] = beta - (float)mean * scale;
     D.mean[n] = (float)mean;
     D.rstd[n] = rstd;
+    if (D.bwd_sums != nullptr) {
+        D.bwd_sums[n] = 0.f;
+        D.bwd_sums[D.N + n] = 0.f;
+    }
+    if (D.num_batches_tracked != nullptr && n == 0) *D.num_batches_tracked += 1;
     if (D.running_mean != nullptr) {
         const float mom = D.momentum;
         const double unbiased = D.M > 1 ? var * ((double)D.M / (double)(D.M - 1)) : var;
@@ -151,6 +164,13 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
             if constexpr (MODE == 2) {
                 ld_vec<VEC>(k1, D.s1 + c);
                 ld_vec<VEC>(k2, D.s2 + c);
+                if (row0 == 0 && tr == 0) {          // the first band's first row group hands the sums on: one writer per column
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        if (D.acc1 != nullptr) D.acc1[c + v] += k1[v];
+                        if (D.acc2 != nullptr) D.acc2[c + v] += k2[v];
+                    }
+                }
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     k1[v] *= invM;
@@ -380,7 +400,7 @@ extern "C" int cwn_bn_finalize_f32(const cwn_bn_desc* descs, int n, cwn_stream_t
     }
     int nmax = 0;
     for (int i = 0; i < n; ++i) nmax = descs[i].N > nmax ? descs[i].N : nmax;
-    bn_finalize_kernel<<<dim3((nmax + 63) / 64, n), dim3(kThreads), 0, (hipStream_t)stream_>>>(B);
+    bn_finalize_kernel<<<dim3((nmax + 63) / 64, n), dim3(kFinThreads), 0, (hipStream_t)stream_>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 

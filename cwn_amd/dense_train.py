@@ -129,12 +129,16 @@ class _DenseTrain(torch.autograd.Function):
         stats = torch.empty(2 * sum(rows_of[id(st)] * w for st, w in zip(bns, widths)),
                             dtype=torch.float64, device=dev)
         affs = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
-        stat_of, aff_of, o, so = {}, {}, 0, 0
+        # the backward pass' column sums (s1, s2 per BatchNorm stage): allocated here and CLEARED by cwn_bn_finalize_f32,
+        # so that the backward launches no fill for them
+        sums = torch.empty(2 * sum(widths), dtype=torch.float32, device=dev)
+        stat_of, aff_of, sum_of, o, so = {}, {}, {}, 0, 0
         for st, w in zip(bns, widths):
             r = rows_of[id(st)]
             stat_of[id(st)] = stats[so: so + 2 * r * w].view(2, r, w)
             so += 2 * r * w
             aff_of[id(st)] = affs[4 * o: 4 * o + 4 * w].view(4, w)
+            sum_of[id(st)] = sums[2 * o: 2 * o + 2 * w].view(2, w)
             o += w
 
         def finalize(group: Sequence[Tuple[Stage, int]]):
@@ -149,7 +153,8 @@ class _DenseTrain(torch.autograd.Function):
                     beta=_ffi.ptr(beta), running_mean=n.running_mean.data_ptr(),
                     running_var=n.running_var.data_ptr(), scale=a[0].data_ptr(), shift=a[1].data_ptr(),
                     mean=a[2].data_ptr(), rstd=a[3].data_ptr(), M=M, N=s.size(2), eps=float(n.eps),
-                    momentum=float(n.momentum)))
+                    momentum=float(n.momentum), num_batches_tracked=n.num_batches_tracked.data_ptr(),
+                    bwd_sums=sum_of[id(st)].data_ptr()))
             if descs:
                 _ffi.bn_finalize(descs, dev)
 
@@ -195,10 +200,10 @@ class _DenseTrain(torch.autograd.Function):
         _ffi.norm_act([_norm_desc(z, out=h, aff=aff_of.get(id(plan.cb[i])))
                        for i, (z, h) in enumerate(zip(Z3, H)) if z.numel()], dev)
         if bns:
-            torch._foreach_add_([st.norm.num_batches_tracked for st in bns], 1)
-            ops.state_changed()      # bn_finalize wrote the running statistics through raw pointers
+            ops.state_changed()      # bn_finalize wrote the running statistics (and the batch counters) through raw pointers
         ctx.plan = plan
         ctx.aff_of = {k: v for k, v in aff_of.items()}
+        ctx.sum_of, ctx.sums, ctx.sums_clean = sum_of, sums, True
         flatZ = [Z[i][br][s] for i in range(nd) for br in (0, 1) for s in range(depth)]
         ctx.save_for_backward(*[a for pair in A0 for a in pair], *flatZ, *Z3, affs,
                               *[t for t in par])
@@ -228,10 +233,11 @@ class _DenseTrain(torch.autograd.Function):
         # gradient targets.  Weights / biases: the parameter's own .grad when it is allocated
         # (ops._grad_target: a FlatGradBucket or zero_grad(set_to_none=False)) -- the TN kernel adds
         # into it and autograd gets None -- else a slice of one zeroed scratch buffer.  The
-        # BatchNorm sums s1 / s2 always go to scratch (the apply kernel needs THIS pass's sums) and
-        # are added to gamma.grad / beta.grad with one multi-tensor add at the end.
-        # With the one-launch BatchNorm backward (every matrix of the layer within its row cap, 16-byte aligned) the sums go
-        # straight INTO gamma.grad / beta.grad when those exist: no scratch to zero, no multi-tensor add at the end.
+        # BatchNorm sums s1 / s2 always go to scratch (the apply kernel needs THIS pass's sums): the buffer the forward
+        # allocated and cwn_bn_finalize_f32 cleared; the apply launch adds them to gamma.grad / beta.grad where those
+        # exist (round 2: a fill per layer before, a multi-tensor add after).
+        # With the one-launch BatchNorm backward (opt-in; every matrix within its row cap, 16-byte aligned) the sums go
+        # straight INTO gamma.grad / beta.grad.
         fused_norm = FUSED_NORM_BACKWARD and all(
             z.size(0) <= _ffi.NORM_BWD_FUSED_MAX_ROWS and z.size(1) % 4 == 0 and z.stride(0) % 4 == 0 and z.data_ptr() % 16 == 0
             for z in [zz for i in range(nd) for br in (0, 1) for zz in Z[i][br]] + Z3)
@@ -241,31 +247,31 @@ class _DenseTrain(torch.autograd.Function):
             tw, tb = ops._grad_target(st.lin.weight), ops._grad_target(st.lin.bias)
             targets.append((tw, tb))
             direct = None
-            if st.is_bn and fused_norm:
+            if st.is_bn:
                 tg, tbeta = ops._grad_target(st.norm.weight), ops._grad_target(st.norm.bias)
-                if tg is not None and tbeta is not None and tg.data_ptr() % 16 == 0 and tbeta.data_ptr() % 16 == 0:
+                if tg is not None and tbeta is not None and (not fused_norm or (tg.data_ptr() % 16 == 0 and tbeta.data_ptr() % 16 == 0)):
                     direct = (tbeta, tg)                      # (s1 = d beta, s2 = d gamma)
             norm_targets[id(st)] = direct
-            sizes.append((0 if tw is not None else W.numel(),
-                          0 if (b is None or tb is not None) else b.numel(),
-                          2 * W.size(0) if st.is_bn and direct is None else 0))
-        n_flat = sum(a + b + c for a, b, c in sizes)
+            sizes.append((0 if tw is not None else W.numel(), 0 if (b is None or tb is not None) else b.numel()))
+        n_flat = sum(a + b for a, b in sizes)
         flat = torch.zeros(n_flat, dtype=torch.float32, device=dev) if n_flat else None
+        if not ctx.sums_clean:            # a second backward over the same forward (retain_graph): the scratch holds the first's sums
+            ctx.sums.zero_()
+        ctx.sums_clean = False
         G, q = {}, 0
-        for st, (nw, nb, ns), (tw, tb) in zip(stages, sizes, targets):
+        for st, (nw, nb), (tw, tb) in zip(stages, sizes, targets):
             W, b = P[id(st)][0], P[id(st)][1]
             dW = flat[q: q + nw].view_as(W) if tw is None else tw
             q += nw
             db = (flat[q: q + nb] if nb else None) if tb is None else tb
             q += nb
-            s12 = flat[q: q + ns].view(2, -1) if ns else None
-            q += ns
-            G[id(st)] = (dW, db, s12)
+            G[id(st)] = (dW, db, ctx.sum_of.get(id(st)))
 
         def norm_backward(items):
-            """items: (stage, dy, z) -> dz list; BatchNorm stages reduce first."""
+            """items: (stage, dy, z) -> dz list; BatchNorm stages reduce first.  The sums are handed on to gamma.grad /
+            beta.grad by the apply launch itself where those buffers exist (`norm_targets`)."""
             red, app, outs = [], [], []
-            direct, scratch, late = [], [], []
+            direct, scratch = [], []
             for st, dy, z in items:
                 dz = torch.empty(z.shape, dtype=torch.float32, device=dev)
                 outs.append(dz)
@@ -274,17 +280,16 @@ class _DenseTrain(torch.autograd.Function):
                 aff = aff_of.get(id(st))
                 s12 = G[id(st)][2]
                 tgt = norm_targets[id(st)]
-                sums = tgt if tgt is not None else s12
-                if (fused_norm and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0
-                        and (sums is None or sums[0].data_ptr() % 16 == 0)):
-                    (direct if tgt is not None else scratch).append(_norm_desc(z, dy=dy, out=dz, aff=aff, s12=sums))
+                if fused_norm and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and (s12 is None or s12.data_ptr() % 16 == 0):
+                    (direct if tgt is not None else scratch).append(
+                        _norm_desc(z, dy=dy, out=dz, aff=aff, s12=tgt if tgt is not None else s12))
                     continue
-                if st.is_bn and tgt is not None:       # (an unaligned dy handed in by autograd) sums through a scratch pair
-                    s12 = torch.zeros(2, z.size(1), dtype=torch.float32, device=dev)
-                    late.append((tgt, s12))
                 if st.is_bn:
                     red.append(_norm_desc(z, dy=dy, aff=aff, s12=s12))
-                app.append(_norm_desc(z, dy=dy, out=dz, aff=aff, s12=s12))
+                d = _norm_desc(z, dy=dy, out=dz, aff=aff, s12=s12)
+                if st.is_bn and tgt is not None:
+                    d.acc1, d.acc2 = tgt[0].data_ptr(), tgt[1].data_ptr()
+                app.append(d)
             if direct:
                 _ffi.norm_bwd(direct, dev, accumulate=True)
             if scratch:
@@ -293,9 +298,6 @@ class _DenseTrain(torch.autograd.Function):
                 _ffi.norm_bwd_reduce(red, dev)
             if app:
                 _ffi.norm_bwd_apply(app, dev)
-            for tgt, s12 in late:
-                tgt[0].add_(s12[0])
-                tgt[1].add_(s12[1])
             return outs
 
         def prologue(st: Optional[Stage]):
@@ -371,29 +373,15 @@ class _DenseTrain(torch.autograd.Function):
         grads: List[Optional[Tensor]] = [None]
         for i in range(nd):
             grads += [dy[i][0], dy[i][1]]
-        acc_dst, acc_src = [], []
         for st, (tw, tb) in zip(stages, targets):
             dW, db, s12 = G[id(st)]
             W, b, gamma, beta = P[id(st)]
             gg = gb = None
-            if st.is_bn and norm_targets[id(st)] is None:
-                tg, tbeta = ops._grad_target(st.norm.weight), ops._grad_target(st.norm.bias)
-                if gamma is not None:
-                    if tg is None:
-                        gg = s12[1]
-                    else:
-                        acc_dst.append(tg)
-                        acc_src.append(s12[1])
-                if beta is not None:
-                    if tbeta is None:
-                        gb = s12[0]
-                    else:
-                        acc_dst.append(tbeta)
-                        acc_src.append(s12[0])
+            if st.is_bn and norm_targets[id(st)] is None:     # (else the launches above have added the sums to the .grad buffers)
+                gg = s12[1] if gamma is not None else None
+                gb = s12[0] if beta is not None else None
             grads += [dW if tw is None else None,
                       (db if tb is None else None) if b is not None else None, gg, gb]
-        if acc_dst:
-            torch._foreach_add_(acc_dst, acc_src)
         return tuple(grads)
 
 

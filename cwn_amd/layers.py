@@ -643,13 +643,19 @@ class SparseCINConv(torch.nn.Module):
             sp = self.mp_levels[dim].gemm_specs(cochain_params[dim])
             specs += sp
             owner += [dim] * len(sp)
-        ys = ops.gemm_many(specs) if specs else []
         plans = [None] * n
-        for dim in range(start_to_process, n):
-            mine = [y for y, o in zip(ys, owner) if o == dim]
-            plans[dim] = self.mp_levels[dim].streams(cochain_params[dim], mine or None)
-        fused = [st for p in plans if p is not None for st in p]
-        outs = ops.aggregate_many(fused) if fused else []
+
+        def make_streams(ys):
+            for dim in range(start_to_process, n):
+                mine = [y for y, o in zip(ys, owner) if o == dim]
+                plans[dim] = self.mp_levels[dim].streams(cochain_params[dim], mine or None)
+            return [st for p in plans if p is not None for st in p]
+
+        if specs:       # (training: ONE autograd node around the products and the aggregation, ops._GemmAggregate)
+            _, outs = ops.gemm_aggregate(specs, make_streams)
+        else:
+            fused = make_streams([])
+            outs = ops.aggregate_many(fused) if fused else []
         return plans, outs
 
     def _propagate_blocked(self, cochain_params, start_to_process) -> Optional[List[Tensor]]:

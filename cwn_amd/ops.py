@@ -139,6 +139,108 @@ class Stream:
             raise ValueError('self term must be [n_dst, width]')
 
 
+def _ident(t: Tensor):
+    """Identity of a tensor as a view of device memory (saved tensors come back re-wrapped)."""
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+
+
+def _aggregate_backward(streams, tensors, needs, gs, max_outs, device) -> List[Optional[Tensor]]:
+    """Gradients of aggregate_many's tensor inputs (four per stream: A, B, self_x, eps; `needs` likewise).
+    One launch.  A cell-feature matrix x usually enters several slots of the same call (the
+    self term of the upper stream, the self term of the boundary stream, the gathered operand
+    of the next dimension's boundary stream: mp/layers.py:185-192), and its gradient is the sum
+    of a transposed aggregation and the scaled self terms.  Those are folded into ONE
+    descriptor (gathered part + up to two self terms) whose result is returned in one slot,
+    None in the others -- instead of one `g * (1 + eps)` kernel per self term plus autograd's
+    add kernels (48 of the ~100 framework launches of a ZINC training step)."""
+    grads: List[Optional[Tensor]] = [None] * len(tensors)
+    specs, slots = [], []
+    ident = lambda t: (t.data_ptr(), tuple(t.shape), tuple(t.stride()))   # saved tensors are re-wrapped
+    selfs = {}       # ident(x) -> [(slot, g, eps)] self-term contributions waiting for a host spec
+    gathered = {}    # ident(x) -> index into specs of a gathered contribution to the same tensor
+    for k, st in enumerate(streams):
+        g = gs[k]
+        if g is None:
+            continue
+        A, B, self_x, eps = tensors[4 * k: 4 * k + 4]
+        need_A, need_B, need_self, need_eps = needs[4 * k: 4 * k + 4]
+        g = g.contiguous()
+        if self_x is not None:
+            if need_self:
+                selfs.setdefault(ident(self_x), []).append((4 * k + 2, g, eps))
+            if need_eps and eps is not None:
+                grads[4 * k + 3] = (g * self_x).sum().reshape(eps.shape)
+        adj, op = st.adj, st.msg_op
+        if adj is None or not (need_A or need_B):
+            continue
+        if st.reduce == 'max':
+            out_k = max_outs[sum(1 for s_ in streams[:k] if s_.reduce == 'max')]
+            if op != MSG_A:
+                raise NotImplementedError("gradient of reduce='max' with a two-operand fused message: "
+                                          'route the message through the generic (hook) path')
+            if need_A:
+                grads[4 * k] = _AggregateMany._max_backward(st, A, out_k, g)
+            continue
+        if st.reduce == 'mean':
+            g = g / adj.counts
+        F = g.size(1)
+        if need_A:
+            if st.ia_mode == 'perm':   # A holds one row per ENTRY: dA[e] = g[dst[e]]
+                grads[4 * k] = _ffi.gather_rows(g, adj.key)
+            else:
+                t = adj.t_src          # rows of A collect from the destinations they fed
+                s = AggSpec(adj=t, n_dst=t.n_dst, F=F, A=g, ia=t.col)
+                if op == MSG_A_TIMES_B:
+                    s.msg_op, s.B = MSG_A_TIMES_B, B
+                    s.ib = t.aux if st.ib_mode == 'aux' else t.perm
+                elif op == MSG_RELU_A_PLUS_B:
+                    # B per shared cell (lazy up_attr) or per ENTRY (a materialised up_attr): the
+                    # transposed plan's perm is the entry id of each of its positions
+                    s.msg_op, s.B, s.self_pre = MSG_A_MASK_RELU, B, A
+                    s.ib = t.aux if st.ib_mode == 'aux' else t.perm
+                gathered.setdefault(ident(A), len(specs))
+                specs.append(s)
+                slots.append(4 * k)
+        if need_B:
+            if op == MSG_A_TIMES_B:
+                raise NotImplementedError(
+                    'no gradient for the multiplicative attribute; route it through the '
+                    'generic (hook) path if it is trainable')
+            if st.ib_mode == 'perm':
+                gB = _ffi.gather_rows(g, adj.key)          # dB[e] = g[dst[e]] ...
+                if op == MSG_RELU_A_PLUS_B:                # ... where the entry's pre-activation is positive
+                    gB = gB * ((_ffi.gather_rows(A, adj.val) + B) > 0)
+                grads[4 * k + 1] = gB
+            else:
+                t = adj.t_aux          # keyed on the aux cell: col = destination, aux = source
+                s = AggSpec(adj=t, n_dst=t.n_dst, F=F, A=g, ia=t.col)
+                if op == MSG_RELU_A_PLUS_B:
+                    s.msg_op, s.B, s.ib, s.self_pre = MSG_A_MASK_RELU, A, t.aux, B
+                gathered.setdefault(ident(B), len(specs))
+                specs.append(s)
+                slots.append(4 * k + 1)
+    # fold the self terms: two per descriptor, onto a gathered contribution to the same tensor
+    # when there is one, else onto a descriptor without adjacency (zeros + self terms)
+    for key, terms in selfs.items():
+        host = gathered.get(key)
+        while terms:
+            take, terms = terms[:2], terms[2:]
+            if host is None:
+                _, g0, _ = take[0]
+                s = AggSpec(adj=None, n_dst=g0.size(0), F=g0.size(1))
+                specs.append(s)
+                slots.append(take[0][0])
+            else:
+                s, host = specs[host], None
+            s.self_x, s.eps = take[0][1], take[0][2]
+            if len(take) == 2:
+                s.self_x2, s.eps2 = take[1][1], take[1][2]
+    if specs:
+        for slot, o in zip(slots, run_aggregate(specs, device)):
+            grads[slot] = o
+    return grads
+
+
 class _AggregateMany(torch.autograd.Function):
     """N streams, one launch forward, one launch backward.  Tensor inputs are flattened four per
     stream: (A, B, self_x, eps)."""
@@ -197,100 +299,9 @@ class _AggregateMany(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        """One launch.  A cell-feature matrix x usually enters several slots of the same call (the
-        self term of the upper stream, the self term of the boundary stream, the gathered operand
-        of the next dimension's boundary stream: mp/layers.py:185-192), and its gradient is the sum
-        of a transposed aggregation and the scaled self terms.  Those are folded into ONE
-        descriptor (gathered part + up to two self terms) whose result is returned in one slot,
-        None in the others -- instead of one `g * (1 + eps)` kernel per self term plus autograd's
-        add kernels (48 of the ~100 framework launches of a ZINC training step)."""
         saved = ctx.saved_tensors
         tensors, max_outs = saved[:ctx.n_in], list(saved[ctx.n_in:])
-        grads: List[Optional[Tensor]] = [None] * len(tensors)
-        specs, slots = [], []
-        ident = lambda t: (t.data_ptr(), tuple(t.shape), tuple(t.stride()))   # saved tensors are re-wrapped
-        selfs = {}       # ident(x) -> [(slot, g, eps)] self-term contributions waiting for a host spec
-        gathered = {}    # ident(x) -> index into specs of a gathered contribution to the same tensor
-        for k, st in enumerate(ctx.streams):
-            g = gs[k]
-            if g is None:
-                continue
-            A, B, self_x, eps = tensors[4 * k: 4 * k + 4]
-            need_A, need_B, need_self, need_eps = ctx.needs_input_grad[2 + 4 * k: 6 + 4 * k]
-            g = g.contiguous()
-            if self_x is not None:
-                if need_self:
-                    selfs.setdefault(ident(self_x), []).append((4 * k + 2, g, eps))
-                if need_eps and eps is not None:
-                    grads[4 * k + 3] = (g * self_x).sum().reshape(eps.shape)
-            adj, op = st.adj, st.msg_op
-            if adj is None or not (need_A or need_B):
-                continue
-            if st.reduce == 'max':
-                out_k = max_outs[sum(1 for s_ in ctx.streams[:k] if s_.reduce == 'max')]
-                if op != MSG_A:
-                    raise NotImplementedError("gradient of reduce='max' with a two-operand fused message: "
-                                              'route the message through the generic (hook) path')
-                if need_A:
-                    grads[4 * k] = _AggregateMany._max_backward(st, A, out_k, g)
-                continue
-            if st.reduce == 'mean':
-                g = g / adj.counts
-            F = g.size(1)
-            if need_A:
-                if st.ia_mode == 'perm':   # A holds one row per ENTRY: dA[e] = g[dst[e]]
-                    grads[4 * k] = _ffi.gather_rows(g, adj.key)
-                else:
-                    t = adj.t_src          # rows of A collect from the destinations they fed
-                    s = AggSpec(adj=t, n_dst=t.n_dst, F=F, A=g, ia=t.col)
-                    if op == MSG_A_TIMES_B:
-                        s.msg_op, s.B = MSG_A_TIMES_B, B
-                        s.ib = t.aux if st.ib_mode == 'aux' else t.perm
-                    elif op == MSG_RELU_A_PLUS_B:
-                        # B per shared cell (lazy up_attr) or per ENTRY (a materialised up_attr): the
-                        # transposed plan's perm is the entry id of each of its positions
-                        s.msg_op, s.B, s.self_pre = MSG_A_MASK_RELU, B, A
-                        s.ib = t.aux if st.ib_mode == 'aux' else t.perm
-                    gathered.setdefault(ident(A), len(specs))
-                    specs.append(s)
-                    slots.append(4 * k)
-            if need_B:
-                if op == MSG_A_TIMES_B:
-                    raise NotImplementedError(
-                        'no gradient for the multiplicative attribute; route it through the '
-                        'generic (hook) path if it is trainable')
-                if st.ib_mode == 'perm':
-                    gB = _ffi.gather_rows(g, adj.key)          # dB[e] = g[dst[e]] ...
-                    if op == MSG_RELU_A_PLUS_B:                # ... where the entry's pre-activation is positive
-                        gB = gB * ((_ffi.gather_rows(A, adj.val) + B) > 0)
-                    grads[4 * k + 1] = gB
-                else:
-                    t = adj.t_aux          # keyed on the aux cell: col = destination, aux = source
-                    s = AggSpec(adj=t, n_dst=t.n_dst, F=F, A=g, ia=t.col)
-                    if op == MSG_RELU_A_PLUS_B:
-                        s.msg_op, s.B, s.ib, s.self_pre = MSG_A_MASK_RELU, A, t.aux, B
-                    gathered.setdefault(ident(B), len(specs))
-                    specs.append(s)
-                    slots.append(4 * k + 1)
-        # fold the self terms: two per descriptor, onto a gathered contribution to the same tensor
-        # when there is one, else onto a descriptor without adjacency (zeros + self terms)
-        for key, terms in selfs.items():
-            host = gathered.get(key)
-            while terms:
-                take, terms = terms[:2], terms[2:]
-                if host is None:
-                    _, g0, _ = take[0]
-                    s = AggSpec(adj=None, n_dst=g0.size(0), F=g0.size(1))
-                    specs.append(s)
-                    slots.append(take[0][0])
-                else:
-                    s, host = specs[host], None
-                s.self_x, s.eps = take[0][1], take[0][2]
-                if len(take) == 2:
-                    s.self_x2, s.eps2 = take[1][1], take[1][2]
-        if specs:
-            for slot, o in zip(slots, run_aggregate(specs, ctx.device)):
-                grads[slot] = o
+        grads = _aggregate_backward(ctx.streams, tensors, ctx.needs_input_grad[2:], gs, max_outs, ctx.device)
         return (None, None) + tuple(grads)
 
 
@@ -625,6 +636,7 @@ class _HeadTrain(torch.autograd.Function):
         ctx.params = (w1s, b1s, w2, b2)
         ctx.save_for_backward(*pooled, *hidden, s_out)
         ctx.mark_non_differentiable(*pooled)
+        ctx.set_materialize_grads(False)            # (else autograd fills a [C, K] zero gradient per pooled output)
         return (out,) + tuple(pooled)
 
     @staticmethod
@@ -633,6 +645,8 @@ class _HeadTrain(torch.autograd.Function):
         saved = ctx.saved_tensors
         pooled, hidden, s_out = saved[:n_dims], saved[n_dims:2 * n_dims], saved[2 * n_dims]
         w1s, b1s, w2, b2 = ctx.params
+        if g_out is None:
+            return (None,) * (1 + 3 * n_dims + 2)
         dev = g_out.device
         g_out = _f32c(g_out, 'grad')
         K, H2, O = int(w1s[0].size(1)), int(w1s[0].size(0)), int(w2.size(0))
@@ -725,6 +739,7 @@ class Gemm:
                                          # lets autograd see the whole Parameter instead of a slice
     w_packed: Optional[Tensor] = None    # pack_gemm_weight(W): used when the launch runs on the bf16-split path
                                          # (inference: one split per weight version, not per workgroup)
+    add_out: bool = False                # `out` += the product instead of `out` = the product (no other writer of `out`)
 
     def desc(self, Y: Tensor, packed: bool = False) -> _ffi.GemmDesc:
         X, W, X2 = self.X, self.W, self.X2
@@ -754,7 +769,7 @@ class Gemm:
             N=W.size(1 if self.w_trans else 0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu),
             w_trans=int(self.w_trans),
             flags=(_ffi.GEMM_EXACT if (self.exact or GEMM_EXACT) else 0) | (_ffi.GEMM_W_PACKED if packed else 0)
-            | (int(self.debug) << 8))
+            | (_ffi.GEMM_ADD_OUT if self.add_out else 0) | (int(self.debug) << 8))
 
 
 def stat_rows(M: int) -> int:
@@ -864,6 +879,92 @@ def _grad_target(p: Optional[Tensor]) -> Optional[Tensor]:
     return g
 
 
+def _gemm_backward(gemms, tensors, outs, needs, gs, acc=None) -> List[Optional[Tensor]]:
+    """Gradients of gemm_many's tensor inputs (four per GEMM: X, X2, W, bias; `needs` likewise).
+    Grouped launches again: every dX (and dX2) of the group is one transposed-weight
+    cwn_gemm_f32, every dW / db one cwn_gemm_tn_f32 (accumulating into one zeroed buffer).
+    `acc` (identity of an input tensor -> buffer): the FIRST product into that input is added onto the buffer in the GEMM's
+    epilogue (CWN_GEMM_ADD_OUT) instead of written to a new matrix, and its slot gets None -- the caller hands the buffer on."""
+    n = len(gemms)
+    grads: List[Optional[Tensor]] = [None] * (4 * n)
+    ld = lambda t: t.stride(0) if t.size(0) > 1 else t.size(1)
+    live = []
+    nn_specs, nn_slot, tn_jobs, total = [], [], [], 0
+    for k, gm in enumerate(gemms):
+        g = gs[k]
+        if g is None:
+            continue
+        X, X2, W, bias = tensors[4 * k: 4 * k + 4]
+        nX, nX2, nW, nb = needs[4 * k: 4 * k + 4]
+        if gm.relu:
+            g = g * (outs[k] > 0)
+        if gm.out_scale is not None:
+            g = g * gm.out_scale
+        g = _rowmajor(g, 'grad')
+        live.append(g)
+        K = X.size(1)
+        c0 = gm.w_col0 or 0
+        if nX:
+            into = None if acc is None else acc.pop(_ident(X), None)        # (one product per buffer: the kernel's contract)
+            nn_specs.append(Gemm(X=g, W=W[:, c0:c0 + K], w_trans=True, out=into, add_out=into is not None))
+            nn_slot.append(None if into is not None else 4 * k)
+        if nX2 and X2 is not None:
+            into = None if acc is None else acc.pop(_ident(X2), None)
+            nn_specs.append(Gemm(X=g, W=W[:, c0 + K:c0 + K + X2.size(1)], w_trans=True, out=into, add_out=into is not None))
+            nn_slot.append(None if into is not None else 4 * k + 1)
+        want_b = nb and bias is not None
+        if nW or want_b:
+            tn_jobs.append((k, g, X, X2, W, bias, nW, want_b, c0))
+    dev = live[0].device if live else None
+    if nn_specs:
+        for slot, y in zip(nn_slot, run_gemm(nn_specs, dev)):
+            if slot is not None:
+                grads[slot] = y
+    if tn_jobs:
+        # gradient targets: the parameter's own .grad when it is allocated (a FlatGradBucket /
+        # zero_grad(set_to_none=False)) and ACCUMULATE_INTO_GRAD is on -- the kernel adds into it
+        # and autograd gets None -- else one zeroed scratch buffer handed back to autograd
+        targets, scratch = [], 0
+        for k, g, X, X2, W, bias, nW, want_b, c0 in tn_jobs:
+            tw = _grad_target(W) if nW else None
+            tb = _grad_target(bias) if want_b else None
+            targets.append((tw, tb))
+            scratch += (W.numel() if nW and tw is None else 0) + (W.size(0) if want_b and tb is None else 0)
+        flat = torch.zeros(scratch, dtype=torch.float32, device=dev) if scratch else None
+        off, descs = 0, []
+        for (k, g, X, X2, W, bias, nW, want_b, c0), (tw, tb) in zip(tn_jobs, targets):
+            Xc = _rowmajor(X, 'X')
+            X2c = None if X2 is None else _rowmajor(X2, 'X2')
+            live += [Xc, X2c]
+            dW = db = None
+            if nW:
+                if tw is None:
+                    dW = flat[off: off + W.numel()].view(W.size(0), W.size(1))
+                    off += W.numel()
+                    grads[4 * k + 2] = dW
+                else:
+                    dW = tw
+            if want_b:
+                if tb is None:
+                    db = flat[off: off + W.size(0)]
+                    off += W.size(0)
+                    grads[4 * k + 3] = db
+                else:
+                    db = tb
+            if g.size(0):
+                if dW is None:      # only the bias gradient is wanted: a throw-away dW
+                    dW = torch.zeros(W.size(0), W.size(1), dtype=torch.float32, device=dev)
+                descs.append(_ffi.GemmTnDesc(
+                    dZ=g.data_ptr(), X=Xc.data_ptr(), X2=_ffi.ptr(X2c), in_scale=None, in_shift=None,
+                    in_scale2=None, in_shift2=None, dW=dW.data_ptr() + 4 * c0, db=_ffi.ptr(db), M=g.size(0),
+                    lddz=ld(g), ldx=ld(Xc), ldx2=0 if X2c is None else ld(X2c), lddw=dW.stride(0),
+                    N=W.size(0), K=Xc.size(1), K2=0 if X2c is None else X2c.size(1), in_relu=0))
+        if descs:
+            # in-place targets only (no scratch handed back to autograd): the launch may wait for the end of the backward
+            _ffi.gemm_tn(descs, dev, keep=live + [flat], deferrable=ACCUMULATE_INTO_GRAD and flat is None)
+    return grads
+
+
 class _GemmMany(torch.autograd.Function):
     """Grouped GEMM forward on the MFMA kernel; tensor inputs flattened (X, X2, W, bias) per GEMM.
     Backward: dX = g W, dW = g^T [X|X2], db = sum g on the same kernels (see backward)."""
@@ -877,84 +978,9 @@ class _GemmMany(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        """Grouped launches again: every dX (and dX2) of the group is one transposed-weight
-        cwn_gemm_f32, every dW / db one cwn_gemm_tn_f32 (accumulating into one zeroed buffer)."""
         n = len(ctx.gemms)
         saved = ctx.saved_tensors
-        tensors, outs = saved[:4 * n], saved[4 * n:]
-        grads: List[Optional[Tensor]] = [None] * (4 * n)
-        ld = lambda t: t.stride(0) if t.size(0) > 1 else t.size(1)
-        live = []
-        nn_specs, nn_slot, tn_jobs, total = [], [], [], 0
-        for k, gm in enumerate(ctx.gemms):
-            g = gs[k]
-            if g is None:
-                continue
-            X, X2, W, bias = tensors[4 * k: 4 * k + 4]
-            nX, nX2, nW, nb = ctx.needs_input_grad[2 + 4 * k: 6 + 4 * k]
-            if gm.relu:
-                g = g * (outs[k] > 0)
-            if gm.out_scale is not None:
-                g = g * gm.out_scale
-            g = _rowmajor(g, 'grad')
-            live.append(g)
-            K = X.size(1)
-            c0 = gm.w_col0 or 0
-            if nX:
-                nn_specs.append(Gemm(X=g, W=W[:, c0:c0 + K], w_trans=True))
-                nn_slot.append(4 * k)
-            if nX2 and X2 is not None:
-                nn_specs.append(Gemm(X=g, W=W[:, c0 + K:c0 + K + X2.size(1)], w_trans=True))
-                nn_slot.append(4 * k + 1)
-            want_b = nb and bias is not None
-            if nW or want_b:
-                tn_jobs.append((k, g, X, X2, W, bias, nW, want_b, c0))
-        dev = live[0].device if live else None
-        if nn_specs:
-            for slot, y in zip(nn_slot, run_gemm(nn_specs, dev)):
-                grads[slot] = y
-        if tn_jobs:
-            # gradient targets: the parameter's own .grad when it is allocated (a FlatGradBucket /
-            # zero_grad(set_to_none=False)) and ACCUMULATE_INTO_GRAD is on -- the kernel adds into it
-            # and autograd gets None -- else one zeroed scratch buffer handed back to autograd
-            targets, scratch = [], 0
-            for k, g, X, X2, W, bias, nW, want_b, c0 in tn_jobs:
-                tw = _grad_target(W) if nW else None
-                tb = _grad_target(bias) if want_b else None
-                targets.append((tw, tb))
-                scratch += (W.numel() if nW and tw is None else 0) + (W.size(0) if want_b and tb is None else 0)
-            flat = torch.zeros(scratch, dtype=torch.float32, device=dev) if scratch else None
-            off, descs = 0, []
-            for (k, g, X, X2, W, bias, nW, want_b, c0), (tw, tb) in zip(tn_jobs, targets):
-                Xc = _rowmajor(X, 'X')
-                X2c = None if X2 is None else _rowmajor(X2, 'X2')
-                live += [Xc, X2c]
-                dW = db = None
-                if nW:
-                    if tw is None:
-                        dW = flat[off: off + W.numel()].view(W.size(0), W.size(1))
-                        off += W.numel()
-                        grads[4 * k + 2] = dW
-                    else:
-                        dW = tw
-                if want_b:
-                    if tb is None:
-                        db = flat[off: off + W.size(0)]
-                        off += W.size(0)
-                        grads[4 * k + 3] = db
-                    else:
-                        db = tb
-                if g.size(0):
-                    if dW is None:      # only the bias gradient is wanted: a throw-away dW
-                        dW = torch.zeros(W.size(0), W.size(1), dtype=torch.float32, device=dev)
-                    descs.append(_ffi.GemmTnDesc(
-                        dZ=g.data_ptr(), X=Xc.data_ptr(), X2=_ffi.ptr(X2c), in_scale=None, in_shift=None,
-                        in_scale2=None, in_shift2=None, dW=dW.data_ptr() + 4 * c0, db=_ffi.ptr(db), M=g.size(0),
-                        lddz=ld(g), ldx=ld(Xc), ldx2=0 if X2c is None else ld(X2c), lddw=dW.stride(0),
-                        N=W.size(0), K=Xc.size(1), K2=0 if X2c is None else X2c.size(1), in_relu=0))
-            if descs:
-                # in-place targets only (no scratch handed back to autograd): the launch may wait for the end of the backward
-                _ffi.gemm_tn(descs, dev, keep=live + [flat], deferrable=ACCUMULATE_INTO_GRAD and flat is None)
+        grads = _gemm_backward(ctx.gemms, saved[:4 * n], saved[4 * n:], ctx.needs_input_grad[2:], gs)
         return (None, None) + tuple(grads)
 
 
@@ -969,6 +995,108 @@ def gemm_many(gemms: Sequence[Gemm]) -> List[Tensor]:
     if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in flat)):
         return run_gemm(gemms, device)
     return list(_GemmMany.apply(tuple(gemms), device, *flat))
+
+
+# ------------------------------------------------------------------------------------------------
+# gemm_many + aggregate_many of one propagate step as ONE autograd node
+# ------------------------------------------------------------------------------------------------
+FUSED_PROPAGATE_NODE = os.environ.get('CWN_FUSED_PROPAGATE_NODE') != '0'     # A/B: '0' keeps the two nodes
+
+
+class _GemmAggregate(torch.autograd.Function):
+    """The message products and the aggregation of a SparseCINConv layer (SparseCINConv.propagate_all, training) behind one
+    node.  As two nodes (_GemmMany, _AggregateMany) every cell-feature matrix received its gradient in pieces -- from the
+    aggregation (self terms, boundary gather) and from each product it entered -- and the autograd engine added the
+    pieces with one framework kernel per piece: 16 add kernels per ZINC training step.  Here the aggregation's backward
+    writes its piece first and a transposed-weight GEMM adds its piece onto it (CWN_GEMM_ADD_OUT, one product per
+    matrix; x_1, which enters two products, still gets one framework add): 4 add kernels per step instead of 16.  tensors = 4 per GEMM (X, X2, W, bias) then 4 per stream (A, B, self_x, eps); `links[(k, slot)]` = the
+    GEMM whose output is stream k's A (slot 0) or B (slot 1) -- those tensor slots hold None."""
+
+    @staticmethod
+    def forward(ctx, gemms, streams, links, ys, device, *tensors):
+        ng = len(gemms)
+        st_tensors = list(tensors[4 * ng:])
+        for (k, slot), gi in links.items():
+            st_tensors[4 * k + slot] = ys[gi]
+        outs = run_aggregate(_AggregateMany.specs_of(streams, st_tensors), device)
+        ctx.gemms, ctx.streams, ctx.links, ctx.device, ctx.ng = gemms, streams, links, device, ng
+        keep = [o for o, st in zip(outs, streams) if st.reduce == 'max']
+        ctx.n_in = len(tensors)
+        ctx.save_for_backward(*tensors, *ys, *keep)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ng, links = ctx.ng, ctx.links
+        saved = ctx.saved_tensors
+        tensors = saved[:ctx.n_in]
+        ys = saved[ctx.n_in: ctx.n_in + ng]
+        max_outs = list(saved[ctx.n_in + ng:])
+        g_tensors, s_tensors = tensors[:4 * ng], list(tensors[4 * ng:])
+        needs = list(ctx.needs_input_grad[5:])
+        g_needs, s_needs = needs[:4 * ng], needs[4 * ng:]
+        g_of = [None] * ng          # gradient of every GEMM output, from the streams it feeds
+        for (k, slot), gi in links.items():
+            s_tensors[4 * k + slot] = ys[gi]
+            s_needs[4 * k + slot] = any(g_needs[4 * gi: 4 * gi + 4])
+        s_grads = _aggregate_backward(ctx.streams, s_tensors, s_needs, gs, max_outs, ctx.device)
+        for (k, slot), gi in links.items():
+            g = s_grads[4 * k + slot]
+            s_grads[4 * k + slot] = None
+            if g is not None:
+                g_of[gi] = g if g_of[gi] is None else g_of[gi] + g
+        # the matrices that already hold a gradient piece take the GEMMs' pieces on top of it
+        acc = {}
+        for q, t in enumerate(s_tensors):
+            if s_grads[q] is not None and t is not None and q % 4 in (0, 2) and (q // 4, q % 4) not in links:
+                if s_grads[q].dim() == 2 and s_grads[q].is_contiguous():
+                    acc.setdefault(_ident(t), s_grads[q])
+        # (two products may enter the same matrix -- x_1 is the first operand of its own dimension's message and the second of
+        # the dimension below: the first takes the buffer, the second returns its own matrix and the engine adds it)
+        g_grads = _gemm_backward(ctx.gemms, g_tensors, ys, g_needs, g_of, acc=acc)
+        return (None, None, None, None, None) + tuple(g_grads) + tuple(s_grads)
+
+
+def gemm_aggregate(gemms: Sequence[Gemm], make_streams) -> Tuple[List[Stream], List[Tensor]]:
+    """ys = gemm_many(gemms); streams = make_streams(ys); outs = aggregate_many(streams) -- with ONE autograd node around
+    both when a gradient is wanted (see _GemmAggregate).  Returns (streams, outs)."""
+    flat_g: List[Optional[Tensor]] = []
+    for gm in gemms:
+        flat_g += [gm.X, gm.X2, gm.W, gm.bias]
+    device = gemms[0].X.device
+    grad = torch.is_grad_enabled()
+    if not (grad and FUSED_PROPAGATE_NODE) or any(gm.in_scale is not None or gm.relu or gm.out_scale is not None for gm in gemms):
+        ys = gemm_many(gemms)
+        streams = make_streams(ys)
+        return streams, (aggregate_many(streams) if streams else [])
+    ys = run_gemm(gemms, device)
+    streams = make_streams(ys)
+    if not streams:
+        return streams, []
+    links, flat_s = {}, []
+    for k, st in enumerate(streams):
+        st.validate()
+        row = [st.A, st.B, st.self_x, st.eps]
+        for slot in (0, 1):
+            for gi, y in enumerate(ys):
+                if row[slot] is y:
+                    links[(k, slot)] = gi
+                    row[slot] = None
+        flat_s += row
+    if not any(t is not None and t.requires_grad for t in flat_g + flat_s):
+        for (k, slot), gi in links.items():
+            flat_s[4 * k + slot] = ys[gi]
+        return streams, run_aggregate(_AggregateMany.specs_of(streams, flat_s), device)
+    from .csr import build_many
+    todo = [st.adj for st in streams if st.adj is not None and not st.adj.built]
+    for st in streams:
+        if st.adj is not None and st.ia_mode == 'col':
+            st.adj.transposes()
+            todo += [a for a in (st.adj._t_src, st.adj._t_aux) if a is not None and not a.built]
+    if todo:
+        build_many(todo)
+    outs = _GemmAggregate.apply(tuple(gemms), tuple(streams), links, tuple(ys), device, *flat_g, *flat_s)
+    return streams, list(outs)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 12
+#define CWN_ABI_VERSION 13
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -463,6 +463,11 @@ typedef struct cwn_gemm_desc {
  * Weight preparation for inference: one small launch per weight VERSION instead of a split of the same
  * numbers in every workgroup of every launch. */
 #define CWN_GEMM_W_PACKED 2
+/* ADD_OUT: Y += the product (Y initialised by the caller; THIS descriptor is the only writer of Y while the launch
+ * runs) instead of Y = the product -- the backward of a propagate step adds dX = dY W onto the gradient its aggregation
+ * kernel has already written for the same cells, where the framework launched an add kernel per matrix.  A plain
+ * read-modify-write: fp32 atomics here cost 11 us per launch at the ZINC batch.  Exact-kernel only. */
+#define CWN_GEMM_ADD_OUT 4
 size_t cwn_gemm_packed_weight_bytes(void);
 int cwn_gemm_pack_weights_f32(const float* W, int64_t ldw, void* out, cwn_stream_t stream);
 
@@ -504,6 +509,9 @@ typedef struct cwn_bn_desc {
     float eps;
     float momentum;
     int32_t pad_;
+    int64_t* num_batches_tracked; /* or NULL: += 1 (BatchNorm1d's counter; one launch less per layer than a framework add) */
+    float* bwd_sums;          /* or NULL: [2, N] set to 0 -- the s1 / s2 scratch of this stage's backward reduce, cleared
+                                 here so that the backward pass launches no fill */
 } cwn_bn_desc;
 
 /* One launch for up to CWN_MAX_NORM_DESCS normalisations. */
@@ -523,6 +531,8 @@ typedef struct cwn_norm_desc {
     int64_t lddy, ldz, ldout;
     int32_t N;
     int32_t relu;        /* activation: ReLU (1) or identity (0) */
+    float* acc1;         /* backward apply only, or NULL: acc1[n] += s1[n]  (beta.grad: d beta = s1) */
+    float* acc2;         /* backward apply only, or NULL: acc2[n] += s2[n]  (gamma.grad: d gamma = s2); one writer per column */
 } cwn_norm_desc;
 
 /* out = act(z * scale + shift)                                    (the last stage's output) */
