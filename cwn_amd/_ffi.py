@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
@@ -44,6 +44,13 @@ class AggDesc(C.Structure):
                 ('self_x2', C.c_void_p), ('eps2', C.c_void_p)]
 
 
+class GemmBnb(C.Structure):
+    """cwn_gemm_bnb (include/cwn_hip.h)."""
+    _fields_ = [('z', C.c_void_p), ('dz', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p),
+                ('rstd', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p), ('acc1', C.c_void_p), ('acc2', C.c_void_p),
+                ('ldz', C.c_int64), ('lddz', C.c_int64), ('relu', C.c_int32), ('pad_', C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [('X', C.c_void_p), ('X2', C.c_void_p), ('W', C.c_void_p), ('bias', C.c_void_p),
                 ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('in_scale2', C.c_void_p),
@@ -52,7 +59,7 @@ class GemmDesc(C.Structure):
                 ('Y', C.c_void_p), ('M', C.c_int64), ('ldx', C.c_int64), ('ldx2', C.c_int64),
                 ('ldw', C.c_int64), ('ldy', C.c_int64), ('N', C.c_int32), ('K', C.c_int32),
                 ('K2', C.c_int32), ('relu', C.c_int32), ('in_relu', C.c_int32),
-                ('w_trans', C.c_int32), ('flags', C.c_int32), ('pad_', C.c_int32)]
+                ('w_trans', C.c_int32), ('flags', C.c_int32), ('pad_', C.c_int32), ('bnb', C.POINTER(GemmBnb))]
 
 
 GEMM_EXACT = 1

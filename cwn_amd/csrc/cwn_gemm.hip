@@ -30,6 +30,7 @@
 //   (BatchNorm batch statistics in training mode).
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <type_traits>
 #include <stdlib.h>
 #include "../../include/cwn_hip.h"
 #include "cwn_mem.h"
@@ -170,7 +171,87 @@ __device__ __forceinline__ void stage_store(float* lds, Staged<ROWS, KP>& st, co
     }
 }
 
-template <bool FAST, bool PRO, int KP, int WN, bool WT, int RT>
+// ---- BatchNorm + ReLU backward as the prologue of the input-gradient GEMM (cwn_gemm_bnb) -------------------------------
+// The tile staged for the MFMAs is dz = scale * (dyh - s1 / M - xhat * s2 / M), formed from the dy tile and the z tile
+// on their way into LDS; it also goes to global memory for the weight-gradient GEMM.  Round 2 ran this as a launch of
+// its own (cwn_norm_bwd_apply_f32: 6.5 us start to start, twelve times per ZINC training step) that wrote dz and the
+// GEMM read it back.
+struct BnbBatch {
+    cwn_gemm_bnb x[CWN_MAX_DESCS];
+};
+
+struct NoBnb {
+    cwn_gemm_bnb x[1];       // never read
+};
+template <bool BNB>
+using BnbArg = typename std::conditional<BNB, BnbBatch, NoBnb>::type;
+
+// Per input column:  dz = scale * dyh + c0 + c1 * (z - mean),  dyh = dy * [z * scale + shift > 0].  Five constants a column;
+// they live in LDS (written once per workgroup, read back 16 B at a time when a tile is staged): as 20 registers per thread
+// next to the stationary weight fragments and two staged tiles they pushed 26 registers into scratch (21 us per launch
+// against 12 + 6.5 for GEMM + apply).
+struct BnbFlags {
+    bool on, relu;
+};
+
+template <int KP>
+__device__ __forceinline__ BnbFlags make_bnb(const cwn_gemm_bnb& E, int K, int64_t M, bool first_block, float* cst) {
+    BnbFlags F;
+    F.on = E.z != nullptr;
+    F.relu = E.relu != 0;
+    if (F.on && threadIdx.x < KP) {
+        const int k = threadIdx.x;
+        float sc = 1.f, sh = 0.f, mu = 0.f, c0 = 0.f, c1 = 0.f;
+        if (E.scale != nullptr && k < K) {
+            const float invM = 1.0f / (float)M;
+            const float rs = E.rstd[k], s1 = E.s1[k], s2 = E.s2[k];
+            sc = E.scale[k];
+            sh = E.shift[k];
+            mu = E.mean[k];
+            c0 = -sc * (s1 * invM);
+            c1 = -sc * (rs * (s2 * invM));
+            if (first_block) {                  // the sums go on to beta.grad / gamma.grad: one writer per column
+                if (E.acc1 != nullptr) E.acc1[k] += s1;
+                if (E.acc2 != nullptr) E.acc2[k] += s2;
+            }
+        }
+        cst[k] = sc;
+        cst[KP + k] = sh;
+        cst[2 * KP + k] = mu;
+        cst[3 * KP + k] = c0;
+        cst[4 * KP + k] = c1;
+    }
+    return F;                                   // (the caller's first __syncthreads() publishes cst)
+}
+
+template <int ROWS, int KP, int U0, int U1>
+__device__ __forceinline__ void stage_store_bnb(float* lds, const Staged<ROWS, KP>& sy, const Staged<ROWS, KP>& sz,
+                                                const BnbFlags& F, const float* cst, int K, int64_t row0, int64_t M,
+                                                float* dz, int64_t lddz) {
+    constexpr int CPR = KP / 4;
+    const int c = threadIdx.x % CPR;             // a thread's columns are the same in every row
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(cst + 4 * c), shift = *reinterpret_cast<const f32x4*>(cst + KP + 4 * c);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(cst + 2 * KP + 4 * c), c0 = *reinterpret_cast<const f32x4*>(cst + 3 * KP + 4 * c);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(cst + 4 * KP + 4 * c);
+#pragma unroll
+    for (int u = U0; u < U1; ++u) {
+        const int q = u * kThreads + threadIdx.x;
+        const int r = q / CPR;
+        const f32x4 dy = sy.v[u], z = sz.v[u];
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float y = z[t] * scale[t] + shift[t];
+            const float dyh = (!F.relu || y > 0.f) ? dy[t] : 0.f;
+            const float d = scale[t] * dyh + c0[t] + c1[t] * (z[t] - mean[t]);
+            v[t] = 4 * c + t < K ? d : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(lds + lds_off<KP>(r, c)) = v;
+        if (dz != nullptr && row0 + r < M && 4 * c < K) cwn::store_result4(dz + (row0 + r) * lddz + 4 * c, v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <bool FAST, bool PRO, int KP, int WN, bool WT, int RT, bool BNB>
 #ifndef CWN_GEMM_LB
 #define CWN_GEMM_LB 2
 #endif
@@ -180,7 +261,7 @@ template <bool FAST, bool PRO, int KP, int WN, bool WT, int RT>
 #ifndef CWN_GEMM_FRAGPF
 #define CWN_GEMM_FRAGPF 0
 #endif
-__global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B) {
+__global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B, BnbArg<BNB> E) {
     // RT = 16-row MFMA tiles per wave (2; 3 for the one-round small-M case, see the host side)
     constexpr int BM = 16 * RT * (4 / WN);   // rows per tile: WN waves side by side along N, 4/WN along M
     constexpr int BN = 32 * WN;         // columns per tile
@@ -204,6 +285,19 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
     const int N = D.N, K1 = D.K, K2 = D.K2, Ktot = D.K + D.K2;
     const ProConst pro = make_pro<KP>(K1, K2, Prologue{D.in_scale, D.in_shift, D.in_scale2, D.in_shift2, D.in_relu});
     const bool add_out = (D.flags & CWN_GEMM_ADD_OUT) != 0;
+    BnbFlags bnb{};
+    __shared__ __attribute__((aligned(16))) float bnb_cst[BNB ? 5 * KP : 4];
+    const float* Zp = nullptr;
+    float* dzp = nullptr;
+    int64_t ldz = 0, lddz = 0;
+    if constexpr (BNB) {
+        const cwn_gemm_bnb& X = E.x[di];
+        bnb = make_bnb<KP>(X, D.K, D.M, (int)blockIdx.x == B.blk_start[di], bnb_cst);
+        Zp = X.z;
+        dzp = X.dz;
+        ldz = X.ldz;
+        lddz = X.lddz;
+    }
     const int dbg = D.flags >> 8;   // timing experiments (tools/ubench_gemm.py): 1 no MFMA, 2 no W staging, 4 no store
     constexpr int SLABS = KP / 16;
     using SX = Staged<BM, KP>;                 // a 32-row tile in flight: KP/32 x 16 B per thread
@@ -222,8 +316,13 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
     // whose tiles are twice as large)
     constexpr bool DEEP = KP <= 128 && CWN_GEMM_DEEP && !WT;   // (the WT variants have no registers to spare)
     SX sx, sx2;
-    if (tile < tiles)
+    SX sz;                                   // BNB: the z tile that goes with sx
+    static_assert(!BNB || (WT && !DEEP), "the backward prologue belongs to the transposed-weight variants");
+    if (tile < tiles) {
         stage_load<FAST, BM, KP, 0, SX::U>(sx, (int64_t)(tile / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
+        if constexpr (BNB)
+            if (bnb.on) stage_load<FAST, BM, KP, 0, SX::U>(sz, (int64_t)(tile / tiles_n) * BM, M, Zp, ldz, K1, nullptr, 0, 0);
+    }
     if (DEEP && tile + nblk < tiles)
         stage_load<FAST, BM, KP, 0, SX::U>(sx2, (int64_t)((tile + nblk) / tiles_n) * BM, M, Xp, ldx, K1, X2p, ldx2, K2);
     for (; tile < tiles; tile += nblk, ++it) {
@@ -326,7 +425,8 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_
             it = 0;
         }
         float* ldsX = smem + (it & 1) * (BM * KP);
-        stage_store<PRO, BM, KP, 0, SX::U>(ldsX, sx, pro);
+        if (BNB && bnb.on) stage_store_bnb<BM, KP, 0, SX::U>(ldsX, sx, sz, bnb, bnb_cst, K1, m_base, M, tile_n == 0 ? dzp : nullptr, lddz);
+        else stage_store<PRO, BM, KP, 0, SX::U>(ldsX, sx, pro);
         __syncthreads();                     // tile visible; everyone is done with the other buffer
         if constexpr (DEEP) {
             sx = sx2;                        // tile + nblk is already on its way
@@ -513,6 +613,13 @@ if (full && vec) {
                         if (n0 + r < N) yp[r] = vb[r];
             }
         }
+        if constexpr (BNB) {
+            // the next tile's z only now: across the MFMAs it would be 16 more live registers (-> scratch); its latency
+            // hides behind the stores above
+            const int next = tile + nblk;
+            if (bnb.on && next < tiles)
+                stage_load<FAST, BM, KP, 0, SX::U>(sz, (int64_t)(next / tiles_n) * BM, M, Zp, ldz, K1, nullptr, 0, 0);
+        }
     }
 }
 
@@ -534,6 +641,8 @@ extern "C" int cwn_gemm_would_split(const cwn_gemm_desc* descs, int n) {
 extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stream_) {
     if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return CWN_ERR_BAD_ARG;
     GemmBatch B{};
+    BnbBatch E{};
+    bool any_bnb = false;
     B.n = n;
     int64_t total_tiles = 0;
     for (int i = 0; i < n; ++i) {
@@ -557,6 +666,21 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
                     D.ldw % 4 == 0 && D.ldy % 4 == 0 && (D.K2 == 0 || D.ldx2 % 4 == 0) &&
                     D.K % 4 == 0 && D.K2 % 4 == 0) ? 1 : 0;
         B.d[i] = D;
+        B.d[i].bnb = nullptr;              // (a host pointer: the extension travels in its own argument)
+        if (D.bnb != nullptr) {
+            const cwn_gemm_bnb& X = *D.bnb;
+            if (!D.w_trans || D.K2 != 0 || D.K > 128 || X.z == nullptr || X.ldz < D.K || (X.dz != nullptr && X.lddz < D.K))
+                return CWN_ERR_BAD_ARG;
+            if ((X.scale == nullptr) != (X.shift == nullptr)) return CWN_ERR_BAD_ARG;
+            if (X.scale != nullptr && (X.mean == nullptr || X.rstd == nullptr || X.s1 == nullptr || X.s2 == nullptr))
+                return CWN_ERR_BAD_ARG;
+            if (!al16(X.z) || !al16(X.dz) || X.ldz % 4 != 0 || X.lddz % 4 != 0) return CWN_ERR_ALIGN;
+            const void* ps[] = {X.scale, X.shift, X.mean, X.rstd, X.s1, X.s2, X.acc1, X.acc2};
+            for (const void* q : ps)
+                if (q != nullptr && ((uintptr_t)q & 3u)) return CWN_ERR_ALIGN;
+            E.x[i] = X;
+            any_bnb = true;
+        }
     }
     // precision policy is PER CALL (no process-wide state): CWN_GEMM_EXACT on any descriptor keeps the
     // launch on the exact fp32-MFMA kernel below
@@ -588,7 +712,7 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
             t48 += ((descs[i].M + 47) / 48) * tn_;
             stats = stats || descs[i].col_sum != nullptr;
         }
-        rt3 = !stats && t32 > kCUs && t48 <= kCUs;
+        rt3 = !stats && !any_bnb && t32 > kCUs && t48 <= kCUs;
         if (rt3) BM = 48;
     }
     for (int i = 0; i < n; ++i) {
@@ -630,12 +754,12 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         fast = fast && B.vec[i] != 0;
         pro = pro || B.d[i].in_scale != nullptr || B.d[i].in_scale2 != nullptr || B.d[i].in_relu != 0;
     }
-    using Kern = void (*)(GemmBatch);
+    using Kern = void (*)(GemmBatch, NoBnb);
     // shape index: 0 = 32x128 tile, K <= 128;  1 = 32x128, K <= 256;  2 = 64x64, K <= 64;
     //              3 = 64x64, K <= 128;        4 = 64x64, K <= 256;   5 = 48x128, K <= 128
 #define CWN_SHAPES(F, P, T)                                                                           \
-    {gemm_kernel<F, P, 128, 4, T, 2>, gemm_kernel<F, P, 256, 4, T, 2>, gemm_kernel<F, P, 64, 2, T, 2>,   \
-     gemm_kernel<F, P, 128, 2, T, 2>, gemm_kernel<F, P, 256, 2, T, 2>, gemm_kernel<F, P, 128, 4, T, 3>}
+    {gemm_kernel<F, P, 128, 4, T, 2, false>, gemm_kernel<F, P, 256, 4, T, 2, false>, gemm_kernel<F, P, 64, 2, T, 2, false>,   \
+     gemm_kernel<F, P, 128, 2, T, 2, false>, gemm_kernel<F, P, 256, 2, T, 2, false>, gemm_kernel<F, P, 128, 4, T, 3, false>}
     static const Kern kerns[2][2][6] = {{CWN_SHAPES(false, false, false), CWN_SHAPES(false, true, false)},
                                         {CWN_SHAPES(true, false, false), CWN_SHAPES(true, true, false)}};
     // transposed-weight variants (the input-gradient GEMM): no prologue
@@ -660,7 +784,23 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
     if (!attr_ok) return CWN_ERR_LAUNCH;
     if (wt && pro) return CWN_ERR_BAD_ARG;
     const int shape = narrow ? (KP == 64 ? 2 : (KP == 128 ? 3 : 4)) : (rt3 ? 5 : (KP == 128 ? 0 : 1));
+    if (any_bnb) {
+        // the backward prologue: transposed weight, 16-byte operands, the two shapes of the hidden-128 / hidden-64 models
+        if (!wt || !fast || (shape != 0 && shape != 2)) return CWN_ERR_BAD_ARG;
+        static std::once_flag bnb_once;
+        static bool bnb_ok = true;
+        std::call_once(bnb_once, [&] {
+            bnb_ok = hipFuncSetAttribute((const void*)gemm_kernel<true, false, 128, 4, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kShapeLds[0]) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)gemm_kernel<true, false, 64, 2, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kShapeLds[2]) == hipSuccess;
+        });
+        if (!bnb_ok) return CWN_ERR_LAUNCH;
+        if (shape == 0) hipLaunchKernelGGL((gemm_kernel<true, false, 128, 4, true, 2, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B, E);
+        else hipLaunchKernelGGL((gemm_kernel<true, false, 64, 2, true, 2, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B, E);
+        return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+    }
     const Kern k = wt ? kerns_wt[fast ? 1 : 0][shape] : kerns[fast ? 1 : 0][pro ? 1 : 0][shape];
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B, NoBnb{});
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

@@ -24,6 +24,7 @@ Backward, per stage from the last to the first:
 Semantics are those of torch.nn.Linear / BatchNorm1d(train) / ReLU; tests/test_gpu_parity.py checks
 outputs, every gradient and the running statistics against the torch modules.
 """
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -39,6 +40,9 @@ from . import _ffi, ops
 # traffic of 32 workgroups per matrix costs far more than the launch it saves (step 1.17 -> 1.34 ms).  Kept for runs that
 # want reproducible BatchNorm gradients (with _ffi.DETERMINISTIC_TN for the weights).
 FUSED_NORM_BACKWARD = False
+# The apply half of the BatchNorm backward as the PROLOGUE of the input-gradient GEMM that consumes it (cwn_gemm_bnb): no
+# apply launch, dz written once on the way.  False: cwn_norm_bwd_apply_f32 + a plain transposed-weight GEMM (A/B, tests).
+FUSED_NORM_APPLY = os.environ.get('CWN_FUSED_NORM_APPLY') != '0'
 
 
 @dataclass
@@ -267,15 +271,22 @@ class _DenseTrain(torch.autograd.Function):
             q += nb
             G[id(st)] = (dW, db, ctx.sum_of.get(id(st)))
 
-        def norm_backward(items):
+        def bnb_ok(dy, z):
+            return (FUSED_NORM_APPLY and not fused_norm and z.size(1) in (64, 128) and z.numel() > 0
+                    and all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in (dy, z)))
+
+        def norm_backward(items, lazy=False):
             """items: (stage, dy, z) -> dz list; BatchNorm stages reduce first.  The sums are handed on to gamma.grad /
-            beta.grad by the apply launch itself where those buffers exist (`norm_targets`)."""
+            beta.grad by the apply launch itself where those buffers exist (`norm_targets`).  `lazy`: only the reduce is
+            launched and every entry comes back as (dz, bnb) -- dz still EMPTY, bnb the cwn_gemm_bnb extension with which
+            the consuming transposed-weight GEMM forms (and writes) it in its prologue; bnb None = dz is complete."""
             red, app, outs = [], [], []
             direct, scratch = [], []
+            lazy = lazy and all(bnb_ok(dy, z) for _, dy, z in items if z.numel())
             for st, dy, z in items:
                 dz = torch.empty(z.shape, dtype=torch.float32, device=dev)
-                outs.append(dz)
                 if not z.numel():
+                    outs.append((dz, None) if lazy else dz)
                     continue
                 aff = aff_of.get(id(st))
                 s12 = G[id(st)][2]
@@ -283,13 +294,24 @@ class _DenseTrain(torch.autograd.Function):
                 if fused_norm and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and (s12 is None or s12.data_ptr() % 16 == 0):
                     (direct if tgt is not None else scratch).append(
                         _norm_desc(z, dy=dy, out=dz, aff=aff, s12=tgt if tgt is not None else s12))
+                    outs.append(dz)
                     continue
                 if st.is_bn:
                     red.append(_norm_desc(z, dy=dy, aff=aff, s12=s12))
+                if lazy:
+                    b = _ffi.GemmBnb(z=z.data_ptr(), dz=dz.data_ptr(), ldz=z.stride(0), lddz=dz.stride(0), relu=1)
+                    if aff is not None:
+                        b.scale, b.shift, b.mean, b.rstd = (aff[r].data_ptr() for r in range(4))
+                        b.s1, b.s2 = s12[0].data_ptr(), s12[1].data_ptr()
+                        if tgt is not None:
+                            b.acc1, b.acc2 = tgt[0].data_ptr(), tgt[1].data_ptr()
+                    outs.append((dz, b))
+                    continue
                 d = _norm_desc(z, dy=dy, out=dz, aff=aff, s12=s12)
                 if st.is_bn and tgt is not None:
                     d.acc1, d.acc2 = tgt[0].data_ptr(), tgt[1].data_ptr()
                 app.append(d)
+                outs.append(dz)
             if direct:
                 _ffi.norm_bwd(direct, dev, accumulate=True)
             if scratch:
@@ -299,6 +321,12 @@ class _DenseTrain(torch.autograd.Function):
             if app:
                 _ffi.norm_bwd_apply(app, dev)
             return outs
+
+        def second_view(b):
+            """The extension for a second GEMM over the same input: same dz, nothing written twice."""
+            c = _ffi.GemmBnb.from_buffer_copy(b)
+            c.dz, c.acc1, c.acc2 = None, None, None
+            return c
 
         def prologue(st: Optional[Stage]):
             if st is None or not st.is_bn:
@@ -311,8 +339,11 @@ class _DenseTrain(torch.autograd.Function):
         # ---- combine stage -------------------------------------------------------------------
         dH = [g if g is not None else torch.zeros_like(z) for g, z in zip(dH, Z3)]
         dH = [ops._rowmajor(g, 'grad') for g in dH]
-        dZ3 = norm_backward([(plan.cb[i], dH[i], Z3[i]) for i in range(nd)])
+        pend3 = norm_backward([(plan.cb[i], dH[i], Z3[i]) for i in range(nd)], lazy=True)
+        lazy3 = bool(pend3) and isinstance(pend3[0], tuple)
+        dZ3 = [p[0] for p in pend3] if lazy3 else pend3
         tn, nn = [], []
+        dA = []
         for i in range(nd):
             st = plan.cb[i]
             W = P[id(st)][0]
@@ -326,14 +357,31 @@ class _DenseTrain(torch.autograd.Function):
                     in_shift=_ffi.ptr(sh), in_scale2=_ffi.ptr(sc2), in_shift2=_ffi.ptr(sh2),
                     dW=dW.data_ptr(), db=_ffi.ptr(db), M=dZ3[i].size(0), lddz=ld(dZ3[i]), ldx=ld(Xu),
                     ldx2=ld(Xb), lddw=dW.stride(0), N=W.size(0), K=Xu.size(1), K2=Xb.size(1), in_relu=3))
-            nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
+            hu = plan.up[i][-1].lin.out_features
+            if lazy3 and pend3[i][1] is not None:
+                # the two halves of dA as two products over the same dz (each 128 or 64 columns wide: the kernel's shapes)
+                out = torch.empty(dZ3[i].size(0), W.size(1), dtype=torch.float32, device=dev)
+                b = pend3[i][1]
+                nn.append(ops.Gemm(X=dH[i], W=W[:, :hu], w_trans=True, out=out[:, :hu], bnb=b))
+                nn.append(ops.Gemm(X=dH[i], W=W[:, hu:], w_trans=True, out=out[:, hu:], bnb=second_view(b)))
+                dA.append(out)
+            else:
+                nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
+                dA.append(None)
         # weight gradients whose targets are all the parameters' own .grad buffers may wait for the end of the backward
         can_defer = ops.ACCUMULATE_INTO_GRAD and all(tw is not None and (st.lin.bias is None or tb is not None)
                                                      for st, (tw, tb) in zip(stages, targets))
-        keep_all = [dZ3, Z, A0, aff_of]
+        keep_all = [dZ3, Z, A0, aff_of, dH]
+        res = ops.run_gemm(nn, dev)                     # [M, H_up + H_bd] per dimension (first: with the lazy form it WRITES dZ3)
+        k = 0
+        for i in range(nd):
+            if dA[i] is None:
+                dA[i] = res[k]
+                k += 1
+            else:
+                k += 2
         if tn:
             _ffi.gemm_tn(tn, dev, keep=keep_all, deferrable=can_defer)
-        dA = ops.run_gemm(nn, dev)                      # [M, H_up + H_bd] per dimension
         dy = []
         for i in range(nd):
             hu = plan.up[i][-1].lin.out_features
@@ -344,7 +392,9 @@ class _DenseTrain(torch.autograd.Function):
             for i in range(nd):
                 for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
                     items.append((chain[s], dy[i][br], Z[i][br][s]))
-            dZ = norm_backward(items)
+            pend = norm_backward(items, lazy=True)
+            lazy_s = bool(pend) and isinstance(pend[0], tuple)
+            dZ = [p[0] for p in pend] if lazy_s else pend
             tn, nn, k = [], [], 0
             for i in range(nd):
                 for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
@@ -354,17 +404,20 @@ class _DenseTrain(torch.autograd.Function):
                     X = A0[i][br] if s == 0 else Z[i][br][s - 1]
                     sc, sh = prologue(chain[s - 1] if s > 0 else None)
                     dz = dZ[k]
-                    k += 1
                     if dz.numel():
                         tn.append(_ffi.GemmTnDesc(
                             dZ=dz.data_ptr(), X=X.data_ptr(), X2=None, in_scale=_ffi.ptr(sc),
                             in_shift=_ffi.ptr(sh), in_scale2=None, in_shift2=None, dW=dW.data_ptr(),
                             db=_ffi.ptr(db), M=dz.size(0), lddz=ld(dz), ldx=ld(X), ldx2=0,
                             lddw=dW.stride(0), N=W.size(0), K=X.size(1), K2=0, in_relu=1 if s > 0 else 0))
-                    nn.append(ops.Gemm(X=dz, W=W, w_trans=True))
+                    if lazy_s and pend[k][1] is not None:
+                        nn.append(ops.Gemm(X=dy[i][br], W=W, w_trans=True, bnb=pend[k][1]))
+                    else:
+                        nn.append(ops.Gemm(X=dz, W=W, w_trans=True))
+                    k += 1
+            res = ops.run_gemm(nn, dev)                  # (before the weight gradients: with the lazy form it writes dZ)
             if tn:
-                _ffi.gemm_tn(tn, dev, keep=[dZ, Z, A0, aff_of], deferrable=can_defer)
-            res = ops.run_gemm(nn, dev)
+                _ffi.gemm_tn(tn, dev, keep=[dZ, Z, A0, aff_of, dy], deferrable=can_defer)
             k = 0
             for i in range(nd):
                 for br in (0, 1):

@@ -9,6 +9,7 @@ form.  There is no CPU path here by design; `oracle/` is the CPU checker.
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import ctypes as C
 import os
 import weakref
 
@@ -740,6 +741,7 @@ class Gemm:
     w_packed: Optional[Tensor] = None    # pack_gemm_weight(W): used when the launch runs on the bf16-split path
                                          # (inference: one split per weight version, not per workgroup)
     add_out: bool = False                # `out` += the product instead of `out` = the product (no other writer of `out`)
+    bnb: Optional[object] = None         # _ffi.GemmBnb: X is dy of a BatchNorm / ReLU stage, the GEMM multiplies its dz (w_trans only)
 
     def desc(self, Y: Tensor, packed: bool = False) -> _ffi.GemmDesc:
         X, W, X2 = self.X, self.W, self.X2
@@ -767,7 +769,7 @@ class Gemm:
             ldx2=(X2.stride(0) if X2.size(0) > 1 else max(K2, 1)) if X2 is not None else 0,
             ldw=W.stride(0) if W.size(0) > 1 else W.size(1), ldy=Y.stride(0) if Y.size(0) > 1 else Y.size(1),
             N=W.size(1 if self.w_trans else 0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu),
-            w_trans=int(self.w_trans),
+            w_trans=int(self.w_trans), bnb=None if self.bnb is None else C.pointer(self.bnb),
             flags=(_ffi.GEMM_EXACT if (self.exact or GEMM_EXACT) else 0) | (_ffi.GEMM_W_PACKED if packed else 0)
             | (_ffi.GEMM_ADD_OUT if self.add_out else 0) | (int(self.debug) << 8))
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 13
+#define CWN_ABI_VERSION 14
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -430,6 +430,29 @@ int cwn_update_mlp_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void
 /* bands of 32 rows the statistics epilogue writes one partial sum for */
 #define CWN_STAT_ROWS(M) (((M) + 31) / 32)
 
+/* Optional extension of a TRANSPOSED-weight descriptor (the input-gradient GEMM of the training step): the GEMM's input
+ * is not X itself but the BatchNorm + ReLU backward of it,
+ *     dyh = X * [act'(z * scale + shift)],   dz = scale * (dyh - s1 / M - xhat * s2 / M),   xhat = (z - mean) * rstd
+ * (dz = dyh when scale == NULL), formed while the tile is staged -- what cwn_norm_bwd_apply_f32 computes, without its
+ * launch and without reading dz back.  dz is also written to `dz` (the weight-gradient GEMM needs it), and the sums are
+ * handed on to acc1 / acc2 (beta.grad / gamma.grad) by the descriptor's first workgroup.  s1 / s2 are complete when the
+ * launch starts (cwn_norm_bwd_reduce_f32, or the epilogue of the previous launch). */
+typedef struct cwn_gemm_bnb {
+    const float* z;      /* [M, K] pre-normalisation values of the stage, row stride ldz (16-byte aligned) */
+    float* dz;           /* [M, K] out, row stride lddz, or NULL (a second descriptor over the same input) */
+    const float* scale;  /* [K] or NULL: identity normalisation */
+    const float* shift;
+    const float* mean;
+    const float* rstd;
+    const float* s1;     /* [K] sum_m dyh */
+    const float* s2;     /* [K] sum_m dyh * xhat */
+    float* acc1;         /* or NULL: acc1[k] += s1[k] */
+    float* acc2;         /* or NULL: acc2[k] += s2[k] */
+    int64_t ldz, lddz;
+    int32_t relu;        /* activation of the stage: ReLU (1) or identity (0) */
+    int32_t pad_;
+} cwn_gemm_bnb;
+
 typedef struct cwn_gemm_desc {
     const float* X;
     const float* X2;        /* or NULL */
@@ -451,6 +474,8 @@ typedef struct cwn_gemm_desc {
     int32_t w_trans;
     int32_t flags;          /* CWN_GEMM_* bits, 0: none */
     int32_t pad_;
+    const cwn_gemm_bnb* bnb;  /* HOST pointer or NULL, see the struct above: w_trans launches with 16-byte aligned operands, K <= 128,
+                               N <= 128 per descriptor or all N <= 64; CWN_ERR_BAD_ARG otherwise */
 } cwn_gemm_desc;
 
 /* cwn_gemm_desc.flags.  EXACT: keep this launch on the exact fp32-MFMA kernel (bitwise an fmaf chain

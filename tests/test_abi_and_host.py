@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 13
+    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 14
     assert lib.cwn_target_arch() == b'gfx950'
     assert lib.cwn_error_string(0) == b'ok'
 
@@ -36,7 +36,7 @@ def test_struct_layout_matches_header(tmp_path):
     field offset and struct size with the ctypes mirror in cwn_amd/_ffi.py."""
     import subprocess
     structs = {'cwn_csr_desc': _ffi.CsrDesc, 'cwn_agg_desc': _ffi.AggDesc,
-               'cwn_gemm_desc': _ffi.GemmDesc, 'cwn_collate_desc': _ffi.CollateDesc,
+               'cwn_gemm_desc': _ffi.GemmDesc, 'cwn_gemm_bnb': _ffi.GemmBnb, 'cwn_collate_desc': _ffi.CollateDesc,
                'cwn_bn_desc': _ffi.BnDesc, 'cwn_norm_desc': _ffi.NormDesc,
                'cwn_gemm_tn_desc': _ffi.GemmTnDesc, 'cwn_layer_dim': _ffi.LayerDim,
                'cwn_layer_plan': _ffi.LayerPlan, 'cwn_mlp_dim': _ffi.MlpDim, 'cwn_layer_sizes': _ffi.LayerSizes,
