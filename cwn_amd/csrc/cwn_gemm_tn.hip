@@ -31,10 +31,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
 constexpr int kTile = 64;        // rows of dW (n) and columns of dW (k) per workgroup
 constexpr int kChunk = 64;       // rows of M per LDS stage
-constexpr int kBandRows = 128;   // rows of M per workgroup at least (the launcher doubles it while a launch has more workgroups than
-                                 // fit the chip at once: a band more is 4096 more fp32 atomics, 4.9 us of the 15 us launch at the ZINC batch)
+constexpr int kBandRows = 128;   // rows of M per workgroup at least; the launcher picks a multiple of kChunk from here up (see there)
 constexpr int kMaxBandRows = 1024;
-constexpr int64_t kTargetBlocks = 2048;   // (320 = one round was measured at the ZINC batch: 15.1 -> 15.9 us, the per-workgroup chain got longer)
 constexpr int kLd = 80;          // LDS row stride in floats
 constexpr int kU = kChunk * (kTile / 4) / kThreads;   // 16-B loads per thread per tile (= 4)
 
@@ -302,18 +300,35 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
         B.tiles_n[i] = (D.N + kTile - 1) / kTile;
         B.tiles_k[i] = (D.K + D.K2 + kTile - 1) / kTile;
     }
-    // rows of M per workgroup: as few bands as keep the chip busy (workspace layouts are sized for kBandRows: an upper bound)
+    // Rows of M per workgroup (workspace layouts are sized for kBandRows: an upper bound on the bands).  The chip holds
+    // kResident workgroups of this kernel at once (4 per CU: 40 KB of LDS, 100 registers); a launch costs about
+    // rounds x (a fixed ~6 chunk-times of prologue / atomics + its chunks), and a second round that is mostly empty is
+    // the expensive case: the merged ZINC-128 launch (24 descriptors) measured 48.7 / 44.7 / 47.9 / 41.9 / 40.0 / 44.4 /
+    // 48.8 us at 128 / 192 / 256 / 320 / 384 / 448 / 512 rows (2200 ... 600 workgroups; tools/ubench_tn24.py with
+    // CWN_TN_BAND), where doubling from 128 until <= 2048 workgroups had picked 256.
+    static const int band_env = getenv("CWN_TN_BAND") ? atoi(getenv("CWN_TN_BAND")) : 0;     // tuning: fixed rows per workgroup
+    constexpr int64_t kResident = 1024;
     int band_rows = kBandRows;
-    for (;; band_rows *= 2) {
-        blocks = 0;
-        for (int i = 0; i < n; ++i) {
-            const int64_t bands = (descs[i].M + band_rows - 1) / band_rows;
-            B.bands[i] = (int32_t)bands;
-            B.blk_start[i] = (int32_t)blocks;
-            blocks += bands * B.tiles_n[i] * B.tiles_k[i];
-            if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    {
+        double best = 0.0;
+        for (int cand = kBandRows; cand <= kMaxBandRows; cand += kChunk) {
+            if (band_env >= kBandRows && band_env % kChunk == 0 && cand != band_env) continue;
+            int64_t nb = 0;
+            for (int i = 0; i < n; ++i) nb += ((descs[i].M + cand - 1) / cand) * B.tiles_n[i] * B.tiles_k[i];
+            const double cost = (double)((nb + kResident - 1) / kResident) * (6.0 + cand / (double)kChunk);
+            if (cand == kBandRows || cost < best || (band_env == cand)) {
+                best = cost;
+                band_rows = cand;
+            }
         }
-        if (blocks <= kTargetBlocks || band_rows >= kMaxBandRows) break;
+    }
+    blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t bands = (descs[i].M + band_rows - 1) / band_rows;
+        B.bands[i] = (int32_t)bands;
+        B.blk_start[i] = (int32_t)blocks;
+        blocks += bands * B.tiles_n[i] * B.tiles_k[i];
+        if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     }
     B.band_rows = band_rows;
     for (int i = n; i <= CWN_GEMM_TN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
