@@ -71,6 +71,7 @@ def layer_algorithmic_bytes(stats, F, coboundary=True):
 CAPTURE_MODE = 'thread_local'
 
 
+L2_TO_CU_BYTES_PER_US = 77.5e3  # measured, per CU, independent of how many CUs stream: (2304 - 576) KB in 31.7 - 9.4 us (profiles/r3_l2_stream.txt)
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA, dense
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (never the 2:1-sparsity figure)
 
@@ -520,6 +521,15 @@ def main():
                             'weight_stream_bytes_per_launch': int(-(-s0_['N0'] // (4096 // H)) + -(-s0_['N1'] // (4096 // H)) + -(-s0_['N2'] // (4096 // H))) * 6 * H * H * 6,
                             'note': 'fp32-equivalent FLOPs (2 M N K per Linear) / launch time; every workgroup streams the six packed '
                                     'weights out of L2 (weight_stream_bytes_per_launch), which is what bounds it at this batch size'}
+                        # what actually bounds it: a CU receives ~77.5 GB/s (~35 B per clock) from L2 whatever the other CUs do
+                        # (profiles/r3_l2_stream.txt: 32 ... 256 workgroups streaming one 576-KB buffer, same or spread
+                        # addresses, tools/proto/l2_stream.hip), and a workgroup needs its 6 weights + its two input tiles
+                        wg_bytes = 6 * H * H * 6 + 2 * (4096 // H) * H * 4
+                        floor_us = wg_bytes / L2_TO_CU_BYTES_PER_US
+                        roofline_mlp['l2_to_cu_stream'] = {
+                            'bytes_per_workgroup': wg_bytes, 'measured_cap_GB_per_s_per_CU': round(L2_TO_CU_BYTES_PER_US / 1e3, 1),
+                            'floor_us': round(floor_us, 2), 'frac_of_floor': round(floor_us / mlp_us, 3),
+                            'note': 'one workgroup per CU, one round: the launch cannot be faster than one workgroup\'s stream'}
             except Exception as e:
                 print(f'[bench] update-mlp roofline failed: {type(e).__name__}: {e}', file=sys.stderr)
             # where a full forward goes, launch by launch (the same back-to-back replay measurement)
