@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 14
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
@@ -123,6 +123,7 @@ class HeadBwdDim(C.Structure):
 
 ERR_BIT_BLOCK = 8         # = CWN_ERR_BIT_BLOCK
 LAYER_CSR_STORE, LAYER_CSR_LOAD = 1, 2
+LAYER_STORE_Y = 4          # = CWN_LAYER_STORE_Y
 LAYER_CSR_SLOT_BYTES = 5264
 
 
@@ -196,6 +197,8 @@ def lib():
     L.cwn_layer_fused_f32.restype = C.c_int
     L.cwn_layer_fused_f32.argtypes = [C.POINTER(LayerDim), C.c_int, C.c_int32, C.POINTER(LayerPlan), C.c_int32,
                                       C.c_void_p, C.c_void_p]
+    L.cwn_layer_pack_weights_many_f32.restype = C.c_int
+    L.cwn_layer_pack_weights_many_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.cwn_layer_packed_weight_bytes.restype = C.c_size_t
     L.cwn_layer_packed_weight_bytes.argtypes = [C.c_int32]
     L.cwn_layer_pack_weights_f32.restype = C.c_int

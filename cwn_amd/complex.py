@@ -362,8 +362,11 @@ class Complex(object):
         if old is not None:
             # (the device copies of `ptr` survive when the next plan has the same cells per complex: an upload is not
             # something a stream capture can hold, and a training step calls this inside its captured graph)
-            if old[1] is not None and old[1].__dict__.get('_cell_ptr_dev'):
-                self._cell_ptr_keep = (old[1].cell_ptr, old[1].__dict__['_cell_ptr_dev'])
+            # ... and so do the item tables (ranges per complex, cut from the SAME prefix sums: entry VALUES are checked by
+            # the kernel on every launch) -- the training forward runs the blocked kernel inside its captured graph too
+            if old[1] is not None and (old[1].__dict__.get('_cell_ptr_dev') or old[1]._tables):
+                self._cell_ptr_keep = (old[1].cell_ptr, old[1].__dict__.get('_cell_ptr_dev'), old[1].up_ptr, old[1].b_ptr,
+                                       old[1]._tables)
             self._block_plan = None
         for c in self.cochains.values():
             for index in (c.upper_index, c.lower_index, c.boundary_index):
@@ -441,8 +444,16 @@ class Complex(object):
             keep = getattr(self, '_cell_ptr_keep', None)
             if keep is not None and cached[1] is not None:
                 import numpy as np
-                if len(keep[0]) == len(cached[1].cell_ptr) and all(np.array_equal(a, b) for a, b in zip(keep[0], cached[1].cell_ptr)):
-                    cached[1].__dict__['_cell_ptr_dev'] = keep[1]
+                same = lambda xs, ys: len(xs) == len(ys) and all((a is None and b is None) or (
+                    a is not None and b is not None and np.array_equal(a, b)) for a, b in zip(xs, ys))
+                if same(keep[0], cached[1].cell_ptr):
+                    if keep[1]:
+                        cached[1].__dict__['_cell_ptr_dev'] = keep[1]
+                    if same(keep[2], cached[1].up_ptr) and same(keep[3], cached[1].b_ptr):
+                        cached[1]._tables = keep[4]
+                        for t in keep[4].values():          # (their per-item CSR caches belong to the old index tensors' values)
+                            if t is not None:
+                                t.csr_key = None            # (a MixedTable passes it on to its parts)
                 self._cell_ptr_keep = None
             self._block_plan = cached
         return cached[1]

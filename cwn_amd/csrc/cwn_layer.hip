@@ -143,6 +143,7 @@ struct LayerArgs {
     int32_t xrows_cap;                       // boundary-source rows it holds
     int32_t set_start1, set_start2;          // first workgroup of set 1 / set 2 (items are ordered by set)
     int32_t lds_limit;                       // dynamic LDS bytes of this launch (kW8: every item lays out its own rows inside it)
+    int32_t store_y;                         // CWN_LAYER_STORE_Y: Y1 / Y2 of every item also go to big[set].y1 / y2
     BigSet big[kMaxSets];                    // big items only
 #ifdef CWN_LAYER_TIMING
     unsigned long long* stamps;              // [n_items][64]: [0, 16) phase ends seen by wave 0, [16 + 16 k + w] point k of wave w
@@ -1172,6 +1173,18 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
     }
     __syncthreads();
     CWN_STAMP(7);
+    if (A.store_y) {
+        // training forward (CWN_LAYER_STORE_Y): the backward pass needs Y1 / Y2 (ReLU mask of the message); they are
+        // complete in LDS here -- every lane group copies the rows it is about to reduce anyway
+        const BigSet& Bs = A.big[set];
+        float* const y1g = Bs.y1 + (size_t)t_r0[0] * F;
+        float* const y2g = Bs.y2 + (size_t)fld(I_CR0) * F;
+        const float* const Y2l = Y + (size_t)R1 * G::kYStride;
+        for (int r = gq; r < g_n; r += G::kNG)
+            *reinterpret_cast<float4*>(y1g + (size_t)r * F + f) = *reinterpret_cast<const float4*>(Y + (size_t)r * G::kYStride + f);
+        for (int r = gq; r < c_n; r += G::kNG)
+            *reinterpret_cast<float4*>(y2g + (size_t)r * F + f) = *reinterpret_cast<const float4*>(Y2l + (size_t)r * G::kYStride + f);
+    }
 
     // ---- 7. upper stream out of LDS: out_up[i] = sum_p relu(Y1[col[p]] + Y2[aux[p]]) + (1 + eps1) x_i -
     {
@@ -1207,10 +1220,18 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
 // fp32 [F, 2F] weight of the message Linear -> bf16 hi / mid / lo planes in MFMA-fragment order: the 1-KiB
 // chunk number ((ks * 3 + plane) * 2 + h) * NCT + ct holds, for lane l = kq * 16 + n, the eight k-values
 // W[ct * 16 + n][h * F + ks * 32 + kq * 8 ..] of that plane (16 bytes per lane).
+struct PackMany {            // up to CWN_LAYER_PACK_MAX weights of one width in one launch (blockIdx.y = the weight)
+    const float* W[CWN_LAYER_PACK_MAX];
+    unsigned char* out[CWN_LAYER_PACK_MAX];
+    int64_t ldw[CWN_LAYER_PACK_MAX];
+};
+
 template <int F>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ W, int64_t ldw,
-                                                           unsigned char* __restrict__ out) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackMany P) {
     constexpr int KS = F / 32, NCT = F / 16;
+    const float* __restrict__ W = P.W[blockIdx.y];
+    unsigned char* __restrict__ out = P.out[blockIdx.y];
+    const int64_t ldw = P.ldw[blockIdx.y];
     const int g = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (ct, h, ks, lane)
     if (g >= NCT * 2 * KS * 64) return;
     const int lane = g & 63, chunk3 = g >> 6;                     // chunk3 = (ct * 2 + h) * KS + ks
@@ -1373,14 +1394,15 @@ extern "C" int CWN_FN(launch)(const cwn_layer_dim* dims, int n_dims, int32_t F, 
                               int32_t flags, int32_t* err_flag, cwn_stream_t stream_) {
     if (dims == nullptr || plan == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS || plan->n_items < 0)
         return CWN_ERR_BAD_ARG;
-    if ((flags & ~(CWN_LAYER_CSR_STORE | CWN_LAYER_CSR_LOAD)) != 0 ||
+    if ((flags & ~(CWN_LAYER_CSR_STORE | CWN_LAYER_CSR_LOAD | CWN_LAYER_STORE_Y)) != 0 ||
         (flags & (CWN_LAYER_CSR_STORE | CWN_LAYER_CSR_LOAD)) == (CWN_LAYER_CSR_STORE | CWN_LAYER_CSR_LOAD))
         return CWN_ERR_BAD_ARG;
+    const bool store_y = (flags & CWN_LAYER_STORE_Y) != 0;
     if (F != 64 && F != 128) return CWN_ERR_BAD_ARG;
     const int64_t n_items = plan->n_items;
     if (n_items == 0) return CWN_OK;
     if (plan->items == nullptr || err_flag == nullptr) return CWN_ERR_BAD_ARG;
-    if (flags != 0 && plan->csr_cache == nullptr) return CWN_ERR_BAD_ARG;
+    if ((flags & (CWN_LAYER_CSR_STORE | CWN_LAYER_CSR_LOAD)) != 0 && plan->csr_cache == nullptr) return CWN_ERR_BAD_ARG;
     if (n_items >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     if (!kW8 && CWN_FN(lds_bytes)(F, plan->max_gemm_rows, plan->max_source_rows) == 0) return CWN_ERR_BAD_ARG;
     if (kW8 && (plan->max_gemm_rows > gemm_rows_cap(F) || plan->max_source_rows > 2 * source_rows_cap(F))) return CWN_ERR_BAD_ARG;
@@ -1403,6 +1425,10 @@ extern "C" int CWN_FN(launch)(const cwn_layer_dim* dims, int n_dims, int32_t F, 
             plan->up_end[d] > D.e_up || plan->b_end[d] < 0 || plan->b_end[d] > D.n_b)
             return CWN_ERR_BAD_ARG;
         has_up[d] = D.e_up > 0;
+        if (store_y && D.e_up > 0) {
+            if (D.big_y1 == nullptr || dims[d + 1].big_y2 == nullptr) return CWN_ERR_BAD_ARG;
+            if (!(al16(D.big_y1) && al16(dims[d + 1].big_y2))) return CWN_ERR_ALIGN;
+        }
         // BIG records: the streamed complexes need their CSR and the scratch matrices (include/cwn_hip.h)
         if (plan->n_big > 0) {
             if (kW8) return CWN_ERR_BAD_ARG;
@@ -1468,6 +1494,7 @@ extern "C" int CWN_FN(launch)(const cwn_layer_dim* dims, int n_dims, int32_t F, 
     A.rows_cap = plan->max_gemm_rows;
     A.xrows_cap = plan->max_source_rows;
     A.lds_limit = (int32_t)plan->lds_bytes;
+    A.store_y = store_y ? 1 : 0;
     if (kW8 && (plan->lds_bytes < (int64_t)lds_bytes<128>(16, 0) || plan->lds_bytes > (int64_t)kLdsBudget)) return CWN_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     const int mode = (flags & CWN_LAYER_CSR_LOAD) ? kLoad : (flags & CWN_LAYER_CSR_STORE) ? kSortStore : kSort;
@@ -1487,14 +1514,29 @@ extern "C" size_t cwn_layer_packed_weight_bytes(int32_t F) {
     return (F == 64 || F == 128) ? (size_t)F * 2 * F * 6 : 0;
 }
 
-extern "C" int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream_) {
-    if ((F != 64 && F != 128) || W == nullptr || out == nullptr || ldw < 2 * F) return CWN_ERR_BAD_ARG;
-    if (((uintptr_t)W & 3u) || !al16(out)) return CWN_ERR_ALIGN;
+extern "C" int cwn_layer_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
+                                               cwn_stream_t stream_) {
+    if ((F != 64 && F != 128) || W == nullptr || out == nullptr || ldw == nullptr || n < 0) return CWN_ERR_BAD_ARG;
     const int threads = (F / 16) * 2 * (F / 32) * 64;
     hipStream_t stream = (hipStream_t)stream_;
-    if (F == 128) pack_weights_kernel<128><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
-    else pack_weights_kernel<64><<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(W, ldw, (unsigned char*)out);
+    for (int i0 = 0; i0 < n; i0 += CWN_LAYER_PACK_MAX) {
+        const int m = n - i0 < CWN_LAYER_PACK_MAX ? n - i0 : CWN_LAYER_PACK_MAX;
+        PackMany P{};
+        for (int i = 0; i < m; ++i) {
+            if (W[i0 + i] == nullptr || out[i0 + i] == nullptr || ldw[i0 + i] < 2 * F) return CWN_ERR_BAD_ARG;
+            if (((uintptr_t)W[i0 + i] & 3u) || !al16(out[i0 + i])) return CWN_ERR_ALIGN;
+            P.W[i] = W[i0 + i];
+            P.out[i] = (unsigned char*)out[i0 + i];
+            P.ldw[i] = ldw[i0 + i];
+        }
+        if (F == 128) pack_weights_kernel<128><<<dim3((threads + 255) / 256, m), dim3(256), 0, stream>>>(P);
+        else pack_weights_kernel<64><<<dim3((threads + 255) / 256, m), dim3(256), 0, stream>>>(P);
+    }
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream_) {
+    return cwn_layer_pack_weights_many_f32(&W, &ldw, F, &out, 1, stream_);
 }
 
 extern "C" int32_t cwn_layer_variant_round_rows(int32_t F, int32_t variant) {

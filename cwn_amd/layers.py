@@ -82,6 +82,7 @@ def _is_cat_linear_relu(nn) -> bool:
 
 FUSED_DENSE_TRAINING = True   # set False to run the update / combine networks as torch modules
 FUSED_UPDATE_MLP = os.environ.get('CWN_FUSED_UPDATE_MLP') != '0'   # False: the update / combine networks as three grouped GEMM launches
+BLOCKED_TRAIN_FORWARD = os.environ.get('CWN_BLOCKED_TRAIN_FORWARD') != '0'    # the training forward through the blocked kernel too
 BLOCKED_LAYER = os.environ.get('CWN_BLOCKED_LAYER') != '0'   # False: propagate scope as grouped GEMM + CSR aggregation
 CSR_REUSE = True              # blocked layer kernel: sort a batch's adjacencies once, later layers load the result
 # One workgroup per item and one item per CU at a time: the blocked kernel wins while the items fit the chip
@@ -644,6 +645,7 @@ class SparseCINConv(torch.nn.Module):
             specs += sp
             owner += [dim] * len(sp)
         plans = [None] * n
+        pre = self._propagate_blocked_train(cochain_params, start_to_process, specs, owner) if specs else None
 
         def make_streams(ys):
             for dim in range(start_to_process, n):
@@ -652,7 +654,7 @@ class SparseCINConv(torch.nn.Module):
             return [st for p in plans if p is not None for st in p]
 
         if specs:       # (training: ONE autograd node around the products and the aggregation, ops._GemmAggregate)
-            _, outs = ops.gemm_aggregate(specs, make_streams)
+            _, outs = ops.gemm_aggregate(specs, make_streams, precomputed=pre)
         else:
             fused = make_streams([])
             outs = ops.aggregate_many(fused) if fused else []
@@ -711,6 +713,49 @@ class SparseCINConv(torch.nn.Module):
             plan.validated = True
         return outs
 
+    def _propagate_blocked_train(self, cochain_params, start_to_process, specs, owner):
+        """The TRAINING forward of the propagate step through the blocked layer kernel (CWN_LAYER_STORE_Y): one launch
+        (+ one small launch per message weight to pack it) instead of the grouped GEMM + the aggregation, with Y1 / Y2
+        written out for the backward pass, which stays on the CSR path (ops._GemmAggregate).  Returns (ys, outs) in the
+        order of `specs` / of the streams, or None when the blocked form does not apply to (this layer, this batch)."""
+        if not (BLOCKED_TRAIN_FORWARD and torch.is_grad_enabled() and ops.FUSED_PROPAGATE_NODE):
+            return None
+        n = len(cochain_params)
+        if len(specs) != 2 * sum(1 for d in range(n) if owner.count(d) == 2) or any(owner.count(d) not in (0, 2) for d in range(n)):
+            return None
+        args = self._blocked_args(cochain_params, start_to_process, training=True)
+        if isinstance(args, str):
+            self.blocked_reason = args
+            return None
+        dims, plan, table, key = args
+        if getattr(table, 'variant', 0) == 'mixed' or getattr(table, 'n_big', 0):
+            return None                  # (two launches into the same outputs / streamed complexes: inference only)
+        dev, F = dims[0].x.device, int(dims[0].x.size(1))
+        ys_of = [[None, None] for _ in range(n)]
+        ys = []
+        for d in range(n):
+            if owner.count(d) == 2:
+                if d + 1 >= n:
+                    return None
+                y1 = torch.empty(dims[d].x.size(0), F, dtype=torch.float32, device=dev)
+                y2 = torch.empty(dims[d + 1].x.size(0), F, dtype=torch.float32, device=dev)
+                ys_of[d][0], ys_of[d + 1][1] = y1, y2
+                ys += [y1, y2]
+        from . import _ffi
+        launch = ops.LayerLaunch(dims, table)
+        # (the layers of one forward share their index tensors: the first launch stores every item's sorted adjacency,
+        # the following ones load it back -- as in the inference path)
+        mode = _ffi.LAYER_CSR_LOAD if (CSR_REUSE and table.csr_key == key) else (_ffi.LAYER_CSR_STORE if CSR_REUSE else 0)
+        outs = launch.run([c.x.detach() for c in cochain_params], mode, ys=[tuple(p) for p in ys_of])
+        if mode == _ffi.LAYER_CSR_STORE:
+            table.csr_key = key
+        if not plan.validated and not torch.cuda.is_current_stream_capturing():
+            from . import csr
+            csr.check_errors(dev)
+            plan.validated = True
+        self.blocked_reason = None
+        return ys, outs
+
     def _blocked_still_valid(self, ent, cochain_params) -> bool:
         """The per-call part of `_blocked_args`: autograd state, feature tensors, lazy attributes, and the
         packed weights (re-packed when an optimizer step has bumped the weight's version)."""
@@ -741,7 +786,7 @@ class SparseCINConv(torch.nn.Module):
                 return False          # weights changed: rebuild (re-pack) through _blocked_args
         return True
 
-    def _blocked_args(self, cochain_params, start_to_process):
+    def _blocked_args(self, cochain_params, start_to_process, training=False):
         if not BLOCKED_LAYER:
             return 'layers.BLOCKED_LAYER is off'
         if ops.GEMM_EXACT:
@@ -754,8 +799,8 @@ class SparseCINConv(torch.nn.Module):
             return 'the batch carries no per-complex tables (ptr / __slices__)'
         if n > 3 or n != plan.n_dims:
             return 'dimension count'
-        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
-                                        or any(c.x.requires_grad for c in cochain_params)):
+        if not training and torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                                         or any(c.x.requires_grad for c in cochain_params)):
             return 'autograd is recording (inference path only)'
         F = int(cochain_params[0].x.size(1))
         if F not in (64, 128):
@@ -780,7 +825,7 @@ class SparseCINConv(torch.nn.Module):
                 if not isinstance(attr, IndexedRows) or d + 1 >= n or attr.src is not cochain_params[d + 1].x:
                     return f'dim {d}: up_attr is not the lazy gather of the next dimension\'s features'
                 D.up_index, D.up_shared = c.up_index, attr.index
-                D.msg_w_packed, D.msg_bias = ops.pack_layer_weight(lin.weight), lin.bias
+                D.msg_w_packed, D.msg_bias = ops.pack_layer_weight(lin.weight, fresh=training), lin.bias
             b_index, b_attr = c.boundary_index, c.kwargs.get('boundary_attr')
             if lvl.use_boundary_msg and b_attr is not None:
                 if b_index is None or d == 0 or b_attr is not cochain_params[d - 1].x:

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn import BatchNorm1d as BN, Embedding, Identity, LayerNorm as LN, Linear
 
-from . import ops
+from . import layers, ops
 from .complex import ComplexBatch
 from .csr import cached_adjacency
 from .layers import EmbedVEWithReduce, InitReduceConv, SparseCINConv
@@ -171,6 +171,12 @@ class _SparseCINStack(torch.nn.Module):
     def _convs_and_head(self, data: ComplexBatch, include_partial: bool, res: dict):
         act = get_nonlinearity(self.nonlinearity, return_module=False)
         jump_xs, xs = None, None
+        if torch.is_grad_enabled() and layers.BLOCKED_TRAIN_FORWARD and layers.BLOCKED_LAYER:
+            # training forward through the blocked layer kernel: the message weights of all layers packed in one launch
+            ws = [lvl.msg_up_nn[1].weight for conv in self.convs for lvl in getattr(conv, 'mp_levels', [])
+                  if getattr(lvl, '_up_kind', lambda: None)() == 'cat_linear_relu' and lvl.msg_up_nn[1].weight.is_cuda]
+            if ws:
+                ops.pack_layer_weights_many(ws)
         for c, conv in enumerate(self.convs):
             params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
             xs = conv(*params, start_to_process=0)

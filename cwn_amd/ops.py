@@ -1016,11 +1016,13 @@ class _GemmAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gemms, streams, links, ys, device, *tensors):
+        links = dict(links)           # ((stream, slot), gemm) pairs: a tuple, not a dict (the profiler's argument recorder)
         ng = len(gemms)
         st_tensors = list(tensors[4 * ng:])
         for (k, slot), gi in links.items():
             st_tensors[4 * k + slot] = ys[gi]
-        outs = run_aggregate(_AggregateMany.specs_of(streams, st_tensors), device)
+        pre = getattr(ys, 'outs', None)          # the blocked layer kernel has already produced the outputs (and ys)
+        outs = list(pre) if pre is not None else run_aggregate(_AggregateMany.specs_of(streams, st_tensors), device)
         ctx.gemms, ctx.streams, ctx.links, ctx.device, ctx.ng = gemms, streams, links, device, ng
         keep = [o for o, st in zip(outs, streams) if st.reduce == 'max']
         ctx.n_in = len(tensors)
@@ -1059,19 +1061,33 @@ class _GemmAggregate(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(g_grads) + tuple(s_grads)
 
 
-def gemm_aggregate(gemms: Sequence[Gemm], make_streams) -> Tuple[List[Stream], List[Tensor]]:
+class _Precomputed(tuple):
+    """The GEMM outputs of a propagate step together with the step's OUTPUTS, both already produced (by the blocked layer
+    kernel with CWN_LAYER_STORE_Y): what _GemmAggregate's forward then has left to do is remember them."""
+    outs = None
+
+
+def gemm_aggregate(gemms: Sequence[Gemm], make_streams, precomputed=None) -> Tuple[List[Stream], List[Tensor]]:
     """ys = gemm_many(gemms); streams = make_streams(ys); outs = aggregate_many(streams) -- with ONE autograd node around
-    both when a gradient is wanted (see _GemmAggregate).  Returns (streams, outs)."""
+    both when a gradient is wanted (see _GemmAggregate).  Returns (streams, outs).  `precomputed` = (ys, outs): forward
+    results that already exist (the training forward through the blocked layer kernel); the node then only records."""
     flat_g: List[Optional[Tensor]] = []
     for gm in gemms:
         flat_g += [gm.X, gm.X2, gm.W, gm.bias]
     device = gemms[0].X.device
     grad = torch.is_grad_enabled()
-    if not (grad and FUSED_PROPAGATE_NODE) or any(gm.in_scale is not None or gm.relu or gm.out_scale is not None for gm in gemms):
+    if precomputed is None and (not (grad and FUSED_PROPAGATE_NODE) or any(
+            gm.in_scale is not None or gm.relu or gm.out_scale is not None for gm in gemms)):
         ys = gemm_many(gemms)
         streams = make_streams(ys)
         return streams, (aggregate_many(streams) if streams else [])
-    ys = run_gemm(gemms, device)
+    if precomputed is not None:
+        ys = _Precomputed(precomputed[0])
+        ys.outs = tuple(precomputed[1])
+        for gm in gemms:
+            gm.X, gm.W = _rowmajor(gm.X, 'X'), _rowmajor(gm.W, 'W')
+    else:
+        ys = run_gemm(gemms, device)
     streams = make_streams(ys)
     if not streams:
         return streams, []
@@ -1086,6 +1102,8 @@ def gemm_aggregate(gemms: Sequence[Gemm], make_streams) -> Tuple[List[Stream], L
                     row[slot] = None
         flat_s += row
     if not any(t is not None and t.requires_grad for t in flat_g + flat_s):
+        if precomputed is not None:
+            return streams, list(precomputed[1])
         for (k, slot), gi in links.items():
             flat_s[4 * k + slot] = ys[gi]
         return streams, run_aggregate(_AggregateMany.specs_of(streams, flat_s), device)
@@ -1097,7 +1115,8 @@ def gemm_aggregate(gemms: Sequence[Gemm], make_streams) -> Tuple[List[Stream], L
             todo += [a for a in (st.adj._t_src, st.adj._t_aux) if a is not None and not a.built]
     if todo:
         build_many(todo)
-    outs = _GemmAggregate.apply(tuple(gemms), tuple(streams), links, tuple(ys), device, *flat_g, *flat_s)
+    outs = _GemmAggregate.apply(tuple(gemms), tuple(streams), tuple(links.items()), ys if isinstance(ys, _Precomputed) else tuple(ys), device,
+                                *flat_g, *flat_s)
     return streams, list(outs)
 
 
@@ -1134,17 +1153,22 @@ def state_changed() -> None:
 _packed_weights = {}
 
 
-def pack_layer_weight(weight: Tensor) -> Tensor:
+_pack_token = 0          # bumped by every pack_layer_weights_many call: entries it wrote are "fresh" until the next one
+
+
+def pack_layer_weight(weight: Tensor, fresh: bool = False) -> Tensor:
     """The message Linear's weight [F, 2F] in the form cwn_layer_fused_f32 reads (bf16 hi / mid / lo
     planes in MFMA-fragment order, include/cwn_hip.h: cwn_layer_pack_weights_f32): one small launch
     per weight VERSION, cached on (storage, version) -- an optimizer step bumps the version and the
-    next forward re-packs.  Weight preparation (like folding BatchNorm into an affine), not per step."""
+    next forward re-packs.  Weight preparation (like folding BatchNorm into an affine), not per step.
+    `fresh` (the training forward, whose weights change between any two calls -- also inside a replayed graph, where
+    no version counter moves): only an entry written by the LATEST pack_layer_weights_many call counts as a hit."""
     import weakref
     w = weight.detach()
     key = id(weight)
     ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
     hit = _packed_weights.get(key)
-    if hit is not None and hit[0] == ver and hit[1]() is weight:
+    if hit is not None and hit[0] == ver and hit[1]() is weight and (not fresh or hit[3] == _pack_token):
         return hit[2]
     w = _f32c(w, 'weight')
     F = int(w.size(0))
@@ -1154,8 +1178,38 @@ def pack_layer_weight(weight: Tensor) -> Tensor:
     out = torch.empty(int(L.cwn_layer_packed_weight_bytes(F)), dtype=torch.uint8, device=w.device)
     _ffi.check(L.cwn_layer_pack_weights_f32(w.data_ptr(), w.stride(0), F, out.data_ptr(), _ffi.stream_ptr(w.device)),
                'cwn_layer_pack_weights_f32')
-    _packed_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_weights.pop(k, None)), out)
+    _packed_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_weights.pop(k, None)), out, -1)
     return out
+
+
+def pack_layer_weights_many(weights: Sequence[Tensor]) -> None:
+    """Pack the message weights of ALL layers of a model in one launch per width (cwn_layer_pack_weights_many_f32) and
+    leave them in pack_layer_weight's cache as fresh entries: a training forward calls this once, its layers then find
+    their weight packed (8 launches per ZINC step otherwise)."""
+    import weakref
+    global _pack_token
+    _pack_token += 1
+    L = _ffi.lib()
+    by_F = {}
+    for weight in weights:
+        w = weight.detach()
+        if w.dim() != 2 or w.size(1) != 2 * w.size(0) or w.size(0) not in (64, 128) or not w.is_cuda or w.dtype != torch.float32 \
+                or w.stride(1) != 1:
+            continue
+        by_F.setdefault(int(w.size(0)), []).append((weight, w))
+    for F, ws in by_F.items():
+        n = len(ws)
+        nbytes = int(L.cwn_layer_packed_weight_bytes(F))
+        outs = [torch.empty(nbytes, dtype=torch.uint8, device=w.device) for _, w in ws]
+        Wp = (C.c_void_p * n)(*[w.data_ptr() for _, w in ws])
+        ld = (C.c_int64 * n)(*[w.stride(0) for _, w in ws])
+        Op = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        _ffi.check(L.cwn_layer_pack_weights_many_f32(Wp, ld, F, Op, n, _ffi.stream_ptr(ws[0][1].device)),
+                   'cwn_layer_pack_weights_many_f32')
+        for (weight, w), out in zip(ws, outs):
+            key = id(weight)
+            ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
+            _packed_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_weights.pop(k, None)), out, _pack_token)
 
 
 _packed_gemm_weights = {}
@@ -1339,6 +1393,7 @@ class LayerLaunch:
         for part in self.parts:
             if getattr(part, 'n_big', 0):
                 self._attach_big(dims, part)
+        self._big_y = [(self.arr[d].big_y1, self.arr[d].big_y2) for d in range(self.n)]     # the BIG records' scratch
         self.total_rows = sum(self.rows)
         self._sizes = [r for r in self.rows for _ in range(2)]          # rows of out_up_d, out_b_d, in output order
         self._off = [sum(self._sizes[:i]) for i in range(len(self._sizes))]
@@ -1420,8 +1475,17 @@ class LayerLaunch:
             z[n] = torch.zeros(n + 1, dtype=torch.int32, device=dev)
         return z[n]
 
-    def run(self, xs: Sequence[Tensor], csr_mode: int = 0) -> List[Tensor]:
+    def run(self, xs: Sequence[Tensor], csr_mode: int = 0, ys: Optional[Sequence] = None) -> List[Tensor]:
+        """`ys` (training forward): per dimension (Y1 matrix or None, Y2 matrix or None), [n_cells, F] fp32 -- every item
+        also writes its rows of the message products there (CWN_LAYER_STORE_Y)."""
         F = self.F
+        for d in range(self.n):
+            y1, y2 = ys[d] if ys is not None else (None, None)
+            a = self.arr[d]
+            a.big_y1 = y1.data_ptr() if y1 is not None else self._big_y[d][0]
+            a.big_y2 = y2.data_ptr() if y2 is not None else self._big_y[d][1]
+        if ys is not None:
+            csr_mode = int(csr_mode) | _ffi.LAYER_STORE_Y
         buf = torch.empty(2 * self.total_rows, F, dtype=torch.float32, device=self.dev)   # all six outputs
         outs = buf.split(self._sizes)                       # one call: [out_up_0, out_b_0, out_up_1, ...]
         base, row_b = buf.data_ptr(), 4 * F
@@ -1437,9 +1501,10 @@ class LayerLaunch:
             a.x = x.data_ptr()
             a.out_up = base + self._off[2 * d] * row_b
             a.out_b = base + self._off[2 * d + 1] * row_b
-        plans = self._plans.get(csr_mode != 0)
+        cached = (int(csr_mode) & (_ffi.LAYER_CSR_STORE | _ffi.LAYER_CSR_LOAD)) != 0
+        plans = self._plans.get(cached)
         if plans is None:
-            plans = self._plans[csr_mode != 0] = [t.c_plan(with_cache=csr_mode != 0) for t in self.parts]
+            plans = self._plans[cached] = [t.c_plan(with_cache=cached) for t in self.parts]
         stream = _ffi.stream_ptr(self.dev)
         for plan in plans:
             rc = self.fn(self.arr, self.n, F, plan, int(csr_mode), self._err_ptr, stream)

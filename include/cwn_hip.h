@@ -292,6 +292,11 @@ typedef struct cwn_layer_dim {
  * 16-B aligned.  Weight preparation, like folding BatchNorm into an affine: not part of a step. */
 size_t cwn_layer_packed_weight_bytes(int32_t F);
 int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream);
+/* the same for n weights of one width in ONE launch (a training step packs the message weights of all its layers once,
+ * after the optimizer has written them): host arrays of n device pointers / row strides */
+#define CWN_LAYER_PACK_MAX 16
+int cwn_layer_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
+                                    cwn_stream_t stream);
 
 /* The item table and what the launcher needs to know about it (HOST struct; built by
  * cwn_layer_items_build).  Items are ordered by set.  The *_end fields summarise what the table
@@ -306,6 +311,13 @@ int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out
 #define CWN_LAYER_CSR_SLOT_BYTES 5264          /* 2 * 2 * MAX_ENTRIES + 3 * 2 * (TASK_ROWS + 2), 16-B multiple */
 #define CWN_LAYER_CSR_STORE 1
 #define CWN_LAYER_CSR_LOAD 2
+/* STORE_Y (any form, with or without the CSR flags): every item also writes its rows of the message products to the
+ * matrices cwn_layer_dim.big_y1 (Y1 = x_d W[:, :F]^T + b of this dimension's cells) and the NEXT dimension's big_y2
+ * (Y2 = x_{d+1} W[:, F:]^T) -- each row exactly once, by the item that owns its complex.  The training step runs its
+ * forward through this launch and keeps Y1 / Y2 for the backward pass (the ReLU mask of the coboundary message needs
+ * them), where the inference path never lets them leave LDS.  Both matrices are required for every dimension with an
+ * upper adjacency (CWN_ERR_BAD_ARG otherwise). */
+#define CWN_LAYER_STORE_Y 4
 
 typedef struct cwn_layer_plan {
     const int32_t* items;                       /* device int32 [n_items][CWN_LAYER_ITEM_INTS] */
