@@ -91,6 +91,8 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_lift_create(7, 3, None, 0, 6, 0) is None        # unknown lift kind
     assert lib.cwn_layer_fused_f32(None, 1, 128, None, 0, None, None) == 1
     assert lib.cwn_layer_pack_weights_f32(None, 256, 128, None, None) == 1
+    assert lib.cwn_layer_pack_weights_many_f32(None, None, 128, None, 1, None) == 1
+    assert lib.cwn_layer_fused_f32(None, 1, 128, None, _ffi.LAYER_STORE_Y, None, None) == 1
     assert lib.cwn_layer_packed_weight_bytes(128) == 128 * 256 * 6 and lib.cwn_layer_packed_weight_bytes(96) == 0
     assert lib.cwn_layer_fused_lds_bytes(128, 96, 64) == 3 * 96 * 136 * 2 + 65 * 128 * 4 + 9648
     # round-2 additions

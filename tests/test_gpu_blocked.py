@@ -617,3 +617,87 @@ def test_mixed_launch_two_per_cu_form_plus_16_wave_form():
     for i, (f, s2, p) in enumerate(zip(first, second, plain)):
         assert torch.equal(f, p), (i, (f - p).abs().max().item())
         assert torch.equal(s2, p), i
+
+
+@pytest.mark.parametrize('kind,n,F', [('zinc', 64, 128), ('zinc', 300, 128), ('molhiv', 96, 64)])
+def test_training_forward_through_the_blocked_kernel(kind, n, F):
+    """CWN_LAYER_STORE_Y: with autograd on, the propagate step runs as the blocked launch, leaves Y1 / Y2 for the backward
+    pass (ops._GemmAggregate) and gives the gradients of the two-kernel path.  At F = 128 outputs and the stored products
+    are bit-identical to that path (same split, same MFMA order); at F = 64 the two-kernel path multiplies on fp32 MFMA."""
+    from cwn_amd import layers, ops
+    b = _batch(kind, n, F, seed=5)
+    conv = _conv(F, seed=6, eps=0.5).train()
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV) for d in range(3)]
+    captured = {}
+    orig = ops.gemm_aggregate
+
+    def spy(specs, make_streams, precomputed=None):
+        captured['pre'] = precomputed
+        return orig(specs, make_streams, precomputed=precomputed)
+
+    def run(flag):
+        layers.BLOCKED_TRAIN_FORWARD = flag
+        ops.gemm_aggregate = spy
+        try:
+            conv.zero_grad(set_to_none=True)
+            xin = [b.cochains[d].x.detach().clone().requires_grad_() for d in range(3)]
+            b.set_xs(xin)
+            plans, outs = conv.propagate_all(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+            sum((o * torch.cat([w, w])[:o.size(0)]).sum() for o, w in zip(outs, [w for w in ws for _ in range(2)])).backward()
+            return outs, xin, {k: v.grad.clone() for k, v in conv.named_parameters() if v.grad is not None}, captured.get('pre')
+        finally:
+            layers.BLOCKED_TRAIN_FORWARD = True
+            ops.gemm_aggregate = orig
+
+    outs1, x1, g1, pre1 = run(True)
+    outs0, x0, g0, pre0 = run(False)
+    assert pre1 is not None and pre0 is None, 'the training forward did not take the blocked kernel'
+    for a, c in zip(outs1, outs0):
+        if F == 128:
+            assert torch.equal(a, c)
+        else:
+            torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5 * max(1.0, float(c.abs().max())))
+    for a, c in zip(x1, x0):
+        torch.testing.assert_close(a.grad, c.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(c.grad.abs().max())))
+    assert g1.keys() == g0.keys() and g1
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=1e-4, atol=1e-4 * max(1.0, float(g0[k].abs().max())), msg=k)
+    if F == 128:      # the stored products are the grouped GEMM's, bit for bit
+        ys = pre1[0]
+        lin0 = conv.mp_levels[0].msg_up_nn[1]
+        ref, = ops.run_gemm([ops.Gemm(X=b.cochains[0].x.detach(), W=lin0.weight.detach(), w_col0=0, bias=lin0.bias.detach())], DEV)
+        assert torch.equal(ys[0], ref)
+
+
+def test_item_tables_survive_forget_plans_when_the_structure_is_the_same():
+    """A training step calls forget_plans() inside its captured graph and then runs the blocked forward: the item tables
+    (ranges per complex) are carried over to the fresh plan, their per-item CSR caches are not."""
+    b = _batch('zinc', 16, 128, seed=21)
+    conv = _conv(128, seed=1)
+    _run(conv, b, blocked=True)
+    p0 = b.block_plan()
+    t0 = dict(p0._tables)
+    assert t0 and all(t is None or t.csr_key is not None for t in t0.values())
+    b.forget_plans()
+    p1 = b.block_plan()
+    assert p1 is not p0 and p1._tables.keys() == t0.keys() and all(p1._tables[k] is t0[k] for k in t0)
+    assert all(t is None or t.csr_key is None for t in p1._tables.values()) and not p1.validated
+    out1 = _run(conv, b, blocked=True)
+    ref = _oracle_scope(conv, b)
+    for d in range(3):
+        _gate(out1[2 * d], ref[d][0], f'out_up[{d}]')
+
+
+def test_packing_many_layer_weights_at_once_equals_one_by_one():
+    from cwn_amd import ops
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(F, 2 * F, device=DEV)) for F in (128, 64, 128, 128, 64)]
+    ops.pack_layer_weights_many(ws)
+    many = [ops.pack_layer_weight(w, fresh=True).clone() for w in ws]           # fresh entries of the latest batch: cache hits
+    one = [ops.pack_layer_weight(torch.nn.Parameter(w.detach().clone())) for w in ws]
+    for a, c in zip(many, one):
+        assert torch.equal(a, c)
+    ops.pack_layer_weights_many(ws[:1])                                         # a later batch: the other entries are stale
+    again = ops.pack_layer_weight(ws[1], fresh=True)
+    assert torch.equal(again, one[1])
