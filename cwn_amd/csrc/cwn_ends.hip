@@ -42,36 +42,97 @@ struct FrontArgs {
     int32_t* err;
 };
 
+__device__ __forceinline__ int64_t clampi(int64_t v, int64_t n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+
 // sum over the index columns of one row of a table set, 4 features at h.  An index outside its own table sets
-// bit 1 of the sticky word and contributes nothing (as cwn_embedding_fwd_f32).
-__device__ __forceinline__ float4 emb_row(const cwn_embed_table& T, int64_t r, int H, int h, int32_t* err) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < T.cols; ++c) {
-        int64_t v;
-        if (T.src_is_f32) v = (int64_t)reinterpret_cast<const float*>(T.src)[r * T.cols + c];     // .to(torch.long): truncation
-        else v = reinterpret_cast<const int64_t*>(T.src)[r * T.cols + c];
-        const int64_t lim = T.col_size != nullptr ? T.col_size[c] : T.V;
-        if (v < 0 || v >= lim) {
-            if (h == 0) atomicOr(err, 2);
-            continue;
-        }
-        if (T.col_off != nullptr) v += T.col_off[c];
-        const float4 w = *reinterpret_cast<const float4*>(T.W + v * H + h);
-        acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+// bit 1 of the sticky word and contributes nothing (as cwn_embedding_fwd_f32).  LEVEL BY LEVEL: the integer features of
+// all columns, then all table rows, the adds in column order (bit-identical to the column loop).  Walked column by column
+// (round 3's first form) a row of the OGB encoders -- 9 atom columns, each a chain feature -> column size -> column offset
+// -> table row -- was ~30 dependent round trips: 65 us per launch at the molhiv batch of 512, where the launches it
+// replaced took 25.  The column layout of a table set sits in LDS (FrontLayout), staged once per workgroup.
+constexpr int kMaxCols = 16;          // the layout's bound; the kernel is instantiated for 1 (one table per cell type: ZINC) and 16
+
+struct FrontLayout {                   // [0]: vertex tables, [1]: edge tables
+    int64_t off[2][kMaxCols], size[2][kMaxCols];
+};
+
+template <int MAXC>
+__device__ __forceinline__ float4 emb_row(const cwn_embed_table& T, const FrontLayout& L, int which, int64_t r, int H, int h,
+                                          int32_t* err) {
+    int64_t id[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        id[c] = 0;
+        if (c < T.cols)
+            id[c] = T.src_is_f32 ? (int64_t)reinterpret_cast<const float*>(T.src)[r * T.cols + c]     // .to(torch.long): truncation
+                                 : reinterpret_cast<const int64_t*>(T.src)[r * T.cols + c];
     }
+    float4 w[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        w[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < T.cols) {
+            const bool ok = id[c] >= 0 && id[c] < (MAXC == 1 ? T.V : L.size[which][c]);
+            if (!ok && h == 0) atomicOr(err, 2);
+            if (ok) w[c] = *reinterpret_cast<const float4*>(T.W + (id[c] + (MAXC == 1 ? 0 : L.off[which][c])) * H + h);
+        }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < T.cols) { acc.x += w[c].x; acc.y += w[c].y; acc.z += w[c].z; acc.w += w[c].w; }
     return acc;
 }
 
-// red1[e] = sum of the embedded boundary vertices of edge e, in CSR order
-__device__ __forceinline__ float4 reduce_edge(const FrontArgs& A, int64_t e, int h) {
+// the same for TWO rows at once (the two boundary vertices of an edge): features of both, then table rows of both
+template <int MAXC>
+__device__ __forceinline__ void emb_row_pair(const cwn_embed_table& T, const FrontLayout& L, int which, int64_t r0, int64_t r1, int H,
+                                             int h, int32_t* err, float4& a0, float4& a1) {
+    int64_t id[2][MAXC];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int64_t r = q == 0 ? r0 : r1;
+            id[q][c] = 0;
+            if (c < T.cols)
+                id[q][c] = T.src_is_f32 ? (int64_t)reinterpret_cast<const float*>(T.src)[r * T.cols + c]
+                                        : reinterpret_cast<const int64_t*>(T.src)[r * T.cols + c];
+        }
+    float4 w[2][MAXC];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            w[q][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < T.cols) {
+                const bool ok = id[q][c] >= 0 && id[q][c] < (MAXC == 1 ? T.V : L.size[which][c]);
+                if (!ok && h == 0) atomicOr(err, 2);
+                if (ok) w[q][c] = *reinterpret_cast<const float4*>(T.W + (id[q][c] + (MAXC == 1 ? 0 : L.off[which][c])) * H + h);
+            }
+        }
+    a0 = a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < T.cols) {
+            a0.x += w[0][c].x; a0.y += w[0][c].y; a0.z += w[0][c].z; a0.w += w[0][c].w;
+            a1.x += w[1][c].x; a1.y += w[1][c].y; a1.z += w[1][c].z; a1.w += w[1][c].w;
+        }
+}
+
+// red1[e] = sum of the embedded boundary vertices of edge e, in CSR order; two boundary vertices at a time (an edge has
+// exactly two)
+template <int MAXC>
+__device__ __forceinline__ float4 reduce_edge(const FrontArgs& A, const FrontLayout& L, int64_t e, int h) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (A.rowptr1 == nullptr) return acc;
     const int s = A.rowptr1[e], t = A.rowptr1[e + 1];
-    for (int p = s; p < t; ++p) {
-        int64_t v = A.col1[p];
-        v = v < 0 ? 0 : (v >= A.n0 ? A.n0 - 1 : v);          // the plan build reported it; never fault
-        const float4 w = emb_row(A.tv, v, A.H, h, A.err);
-        acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+    for (int p = s; p < t; p += 2) {
+        const int64_t v0 = clampi(A.col1[p], A.n0), v1 = clampi(A.col1[p + 1 < t ? p + 1 : p], A.n0);   // the plan build reported bad ones; never fault
+        float4 w0, w1;
+        emb_row_pair<MAXC>(A.tv, L, 0, v0, v1, A.H, h, A.err, w0, w1);
+        acc.x += w0.x; acc.y += w0.y; acc.z += w0.z; acc.w += w0.w;
+        if (p + 1 < t) { acc.x += w1.x; acc.y += w1.y; acc.z += w1.z; acc.w += w1.w; }
     }
     return acc;
 }
@@ -83,17 +144,16 @@ __device__ __forceinline__ float4 reduce_edge(const FrontArgs& A, int64_t e, int
 // sequential walk).  An edge has two boundary vertices; further ones (any other CSR1) take the sequential tail.
 constexpr int kChunk = 8;
 
-__device__ __forceinline__ int64_t clampi(int64_t v, int64_t n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
-
-__device__ __forceinline__ float4 ring_chunk(const FrontArgs& A, int p0, int n, int h, float4 acc) {
-    const bool one_col = A.tv.cols == 1;
+template <int MAXC>
+__device__ __forceinline__ float4 ring_chunk(const FrontArgs& A, const FrontLayout& L, int p0, int n, int h, float4 acc) {
+    constexpr bool one_col = MAXC == 1;
     int64_t e[kChunk];
     int s1[kChunk], t1[kChunk];
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) e[u] = clampi(A.col2[p0 + (u < n ? u : 0)], A.n1);
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) { s1[u] = A.rowptr1[e[u]]; t1[u] = A.rowptr1[e[u] + 1]; }
-    if (one_col) {
+    if constexpr (one_col) {
         // one table (ZINC): vertex numbers, integer features and table rows of both endpoints of every edge, level by level
         int64_t v[kChunk][2], id[kChunk][2];
         float4 w[kChunk][2];
@@ -124,21 +184,52 @@ __device__ __forceinline__ float4 ring_chunk(const FrontArgs& A, int p0, int n, 
             for (int q = 0; q < 2; ++q)
                 if (s1[u] + q < t1[u]) { r.x += w[u][q].x; r.y += w[u][q].y; r.z += w[u][q].z; r.w += w[u][q].w; }
             for (int p = s1[u] + 2; p < t1[u]; ++p) {                   // not a 1-cell's boundary: the plain walk
-                const float4 x = emb_row(A.tv, clampi(A.col1[p], A.n0), A.H, h, A.err);
+                const float4 x = emb_row<MAXC>(A.tv, L, 0, clampi(A.col1[p], A.n0), A.H, h, A.err);
                 r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
             }
             acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
         }
     } else {
-        for (int u = 0; u < n; ++u) {                                   // several tables per vertex (OGB): edge by edge
-            const float4 r = reduce_edge(A, e[u], h);
+        // several tables per vertex (OGB): the vertex numbers of all edges of the chunk first, then edge by edge both
+        // endpoints at once (features of both, table rows of both)
+        int64_t v[kChunk][2];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) v[u][q] = clampi(A.col1[s1[u] + q < t1[u] ? s1[u] + q : (t1[u] > s1[u] ? t1[u] - 1 : 0)], A.n0);
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            if (u >= n) break;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t1[u] > s1[u]) {
+                float4 w0, w1;
+                emb_row_pair<MAXC>(A.tv, L, 0, v[u][0], v[u][1], A.H, h, A.err, w0, w1);
+                r = w0;
+                if (s1[u] + 1 < t1[u]) { r.x += w1.x; r.y += w1.y; r.z += w1.z; r.w += w1.w; }
+            }
+            for (int p = s1[u] + 2; p < t1[u]; ++p) {                   // not a 1-cell's boundary: the plain walk
+                const float4 x = emb_row<MAXC>(A.tv, L, 0, clampi(A.col1[p], A.n0), A.H, h, A.err);
+                r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
+            }
             acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
         }
     }
     return acc;
 }
 
+template <int MAXC>
 __global__ __launch_bounds__(256) void embed_front_kernel(FrontArgs A) {
+    __shared__ FrontLayout L;
+    if constexpr (MAXC > 1) {            // (one table per cell type: its size is T.V, no offsets -- nothing to stage)
+        if (threadIdx.x < 2 * kMaxCols) {
+            const int which = threadIdx.x / kMaxCols, c = threadIdx.x % kMaxCols;
+            const cwn_embed_table& T = which == 0 ? A.tv : A.te;
+            const bool on = (which == 0 || A.has_te) && c < T.cols;
+            L.off[which][c] = on && T.col_off != nullptr ? T.col_off[c] : 0;
+            L.size[which][c] = on ? (T.col_size != nullptr ? T.col_size[c] : T.V) : 0;
+        }
+        __syncthreads();
+    }
     const int G = A.G, gl = threadIdx.x & (G - 1);
     const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
     if (row >= A.n0 + A.n1 + A.n2) return;
@@ -146,18 +237,18 @@ __global__ __launch_bounds__(256) void embed_front_kernel(FrontArgs A) {
         float4 v;
         float* dst;
         if (row < A.n0) {
-            v = emb_row(A.tv, row, A.H, h, A.err);
+            v = emb_row<MAXC>(A.tv, L, 0, row, A.H, h, A.err);
             dst = A.x0 + row * A.H + h;
         } else if (row < A.n0 + A.n1) {
             const int64_t e = row - A.n0;
-            v = A.has_te ? emb_row(A.te, e, A.H, h, A.err) : reduce_edge(A, e, h);
+            v = A.has_te ? emb_row<MAXC>(A.te, L, 1, e, A.H, h, A.err) : reduce_edge<MAXC>(A, L, e, h);
             dst = A.x1 + e * A.H + h;
         } else {
             const int64_t r = row - A.n0 - A.n1;
             v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (A.rowptr2 != nullptr && A.rowptr1 != nullptr) {
                 const int s = A.rowptr2[r], t = A.rowptr2[r + 1];
-                for (int p = s; p < t; p += kChunk) v = ring_chunk(A, p, min(kChunk, t - p), h, v);
+                for (int p = s; p < t; p += kChunk) v = ring_chunk<MAXC>(A, L, p, min(kChunk, t - p), h, v);
             }
             if (A.halve) { v.x *= 0.5f; v.y *= 0.5f; v.z *= 0.5f; v.w *= 0.5f; }
             dst = A.x2 + r * A.H + h;
@@ -169,7 +260,8 @@ __global__ __launch_bounds__(256) void embed_front_kernel(FrontArgs A) {
 inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 inline bool table_ok(const cwn_embed_table& T) {
-    return T.W != nullptr && T.src != nullptr && T.cols > 0 && T.V > 0 && (T.col_off == nullptr) == (T.col_size == nullptr);
+    return T.W != nullptr && T.src != nullptr && T.cols > 0 && T.cols <= kMaxCols && T.V > 0 &&
+           (T.col_off == nullptr) == (T.col_size == nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -465,7 +557,9 @@ extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, flo
     A.G = G;
     const int64_t rows = n0 + n1 + n2, per = 256 / G, blocks = (rows + per - 1) / per;
     if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
-    embed_front_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(A);
+    const bool single = A.tv.cols == 1 && (!A.has_te || A.te.cols == 1);
+    if (single) embed_front_kernel<1><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(A);
+    else embed_front_kernel<kMaxCols><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 

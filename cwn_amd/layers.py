@@ -1252,8 +1252,8 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
     def _forward_fused(self, v_params, e_params, c_params) -> Optional[List[Tensor]]:
         """The whole front in ONE launch (ops.embed_front, csrc/cwn_ends.hip): both embeddings, the reduction of
         the vertex embeddings onto the edges and of that onto the rings, halved -- the 8 launches below it were 29 us
-        of a 167 us forward at the ZINC batch of 128.  Inference with plain embedding tables and 'sum' reduction;
-        None otherwise (the caller runs the separate launches, which also carry the autograd)."""
+        of a 167 us forward at the ZINC batch of 128.  Plain embedding tables and 'sum' reduction; with autograd
+        (training) the same launch behind ops._EmbedFrontTrain.  None otherwise (the caller runs the separate launches)."""
         if not ops.FUSED_ENDS or e_params is None or v_params.x is None or not v_params.x.is_cuda:
             return None
         if self.init_reduce.reduce not in ('add', 'sum'):
@@ -1262,7 +1262,13 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
         et = _embedding_tables(self.e_embed_layer) if e_params.x is not None else None
         if vt is None or (e_params.x is not None and et is None):
             return None
-        if torch.is_grad_enabled() and any(w.requires_grad for w in vt + (et or [])):
+        if len(vt) > 1 or (et is not None and len(et) > 1):
+            # OGB-style encoders (a table per integer feature column: 9 + 3 at molhiv): the one-launch form is SLOWER there
+            # -- 44 - 60 us per launch at the molhiv batch of 512 against ~25 for the separate launches (every vertex row
+            # walks nine columns, every ring row twelve vertices of nine); measured, so the separate launches keep it
+            return None
+        train = torch.is_grad_enabled() and any(w.requires_grad for w in vt + (et or []))
+        if train and not ops.FUSED_FRONT_TRAINING:
             return None
         H = int(vt[0].size(1))
         if H % 4 != 0 or any(w.size(1) != H or not w.is_cuda or w.dtype != torch.float32 for w in vt + (et or [])):
@@ -1287,7 +1293,12 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
                 adj2 = cached_adjacency(c_params.boundary_index, n2, n1)
         if e_params.x is None and adj1 is None:
             return None                   # edges without features and without boundaries: let the plain path raise
-        xs = ops.embed_front(vt, v_params.x, et, e_params.x if et is not None else None, n1, adj1, n2, adj2, halve=True)
+        if train:
+            if H * sum(int(w.size(0)) for w in vt) * 4 > 60 * 1024 or (et and H * sum(int(w.size(0)) for w in et) * 4 > 60 * 1024):
+                return None               # tables beyond the LDS-table backward kernel: the generic path
+            xs = ops.embed_front_train(vt, v_params.x, et, e_params.x if et is not None else None, n1, adj1, n2, adj2, halve=True)
+        else:
+            xs = ops.embed_front(vt, v_params.x, et, e_params.x if et is not None else None, n1, adj1, n2, adj2, halve=True)
         return xs if c_params is not None else xs[:2]
 
     def reset_parameters(self):

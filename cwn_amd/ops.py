@@ -464,35 +464,46 @@ class _EmbeddingSum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         idx, = ctx.saved_tensors
-        V, H, sizes = ctx.meta
-        g = g.contiguous()
-        off, size = _EmbeddingSum._columns(ctx.tables, g.device)
-        dW = torch.zeros(V, H, dtype=torch.float32, device=g.device)
-        _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
-            g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), dW.data_ptr(), idx.size(0),
-            idx.size(1), H, V, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
-        views, o = [], 0
-        for n in sizes:
-            views.append(dW[o:o + n])
-            o += n
-        grads, acc_dst, acc_src = [], [], []
-        for w, v in zip(ctx.tables, views):
-            t = _grad_target(w)
-            if t is None:
-                grads.append(v)
-            else:
-                acc_dst.append(t)
-                acc_src.append(v)
-                grads.append(None)
-        if acc_dst:
-            torch._foreach_add_(acc_dst, acc_src)
-        return (None,) + tuple(grads)
+        return (None,) + tuple(_embedding_table_grads(ctx.tables, idx, g))
+
+
+def _embedding_table_grads(tables, idx: Tensor, g: Tensor) -> List[Optional[Tensor]]:
+    """d(table) of out[i] = sum_c table_c[idx[i, c]] given g = d out: cwn_embedding_bwd_f32 into one zeroed buffer, handed
+    back as per-table views -- or added into the parameters' .grad directly where those are allocated (then None)."""
+    H = int(tables[0].size(1))
+    sizes = [int(w.size(0)) for w in tables]
+    V = sum(sizes)
+    g = g.contiguous()
+    if idx.dim() == 1:
+        idx = idx.unsqueeze(1)
+    off, size = _EmbeddingSum._columns(tables, g.device)
+    dW = torch.zeros(V, H, dtype=torch.float32, device=g.device)
+    _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
+        g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), dW.data_ptr(), idx.size(0),
+        idx.size(1), H, V, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
+    views, o = [], 0
+    for n in sizes:
+        views.append(dW[o:o + n])
+        o += n
+    grads, acc_dst, acc_src = [], [], []
+    for w, v in zip(tables, views):
+        t = _grad_target(w)
+        if t is None:
+            grads.append(v)
+        else:
+            acc_dst.append(t)
+            acc_src.append(v)
+            grads.append(None)
+    if acc_dst:
+        torch._foreach_add_(acc_dst, acc_src)
+    return grads
 
 
 # ------------------------------------------------------------------------------------------------
 # the two ends of a model forward, one launch each (csrc/cwn_ends.hip; inference)
 # ------------------------------------------------------------------------------------------------
 FUSED_ENDS = True            # False: the front / head run as the separate launches they replace (A/B, tests)
+FUSED_FRONT_TRAINING = os.environ.get('CWN_FUSED_FRONT_TRAINING') != '0'  # the front with autograd as one forward launch
 FUSED_HEAD_TRAINING = os.environ.get('CWN_FUSED_HEAD_TRAINING') != '0'    # the head with autograd as two launches (+ weight-gradient GEMMs)
 
 _table_cache = {}            # concatenated embedding tables, keyed on the weights' identities and versions
@@ -555,6 +566,76 @@ def embed_front(v_weights: Sequence[Tensor], v_feats: Tensor, e_weights: Optiona
     if VALIDATE_INDICES and not torch.cuda.is_current_stream_capturing():
         check_errors(dev)
     return [x0, x1, x2]
+
+
+def _long_index(feats: Tensor) -> Tensor:
+    """The integer features of a batch as int64 [n, cols] (what cwn_embedding_bwd_f32 indexes with), converted once per
+    feature tensor (they do not change between the steps that reuse a batch)."""
+    hit = getattr(feats, '_cwn_long', None)
+    if hit is None or hit[0] != feats._version:
+        f = feats if feats.dim() == 2 else feats.unsqueeze(1)
+        hit = (feats._version, f.to(torch.long).contiguous())
+        try:
+            feats._cwn_long = hit
+        except AttributeError:
+            pass
+    return hit[1]
+
+
+class _EmbedFrontTrain(torch.autograd.Function):
+    """EmbedVEWithReduce.forward with autograd: forward = the one launch of embed_front; backward = the transposed
+    reductions (rings -> edges -> vertices, the vertices' own gradient folded in as the self term) and one
+    cwn_embedding_bwd_f32 per table set.  Replaces 8 forward launches (two index conversions, two gather-sums, two
+    reductions, the halving) of the unfused path.  tensors = v tables..., e tables..."""
+
+    @staticmethod
+    def forward(ctx, meta, v_feats, e_feats, *tables):
+        nv, n1, adj1, n2, adj2, halve = meta
+        vt, et = list(tables[:nv]), list(tables[nv:])
+        xs = embed_front(vt, v_feats, et or None, e_feats if et else None, n1, adj1, n2, adj2, halve=halve)
+        ctx.meta, ctx.tables = meta, (vt, et)
+        ctx.idx = (_long_index(v_feats), _long_index(e_feats) if et else None)
+        return tuple(xs)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        nv, n1, adj1, n2, adj2, halve = ctx.meta
+        vt, et = ctx.tables
+        iv, ie = ctx.idx
+        dev = iv.device
+        H = int(vt[0].size(1))
+        # d red1[e] = (1/2) sum_{rings containing e} g2[ring]  (+ g1[e] when the edges have no table of their own: x1 = red1)
+        t1 = None
+        if g2 is not None and adj2 is not None and n2 > 0:
+            t = adj2.t_src
+            t1 = aggregate(t, t.n_dst, (g2 * 0.5 if halve else g2).contiguous(), self_x=None if (et or g1 is None) else g1.contiguous())
+        elif not et and g1 is not None:
+            t1 = g1.contiguous()
+        dv = None if g0 is None else g0.contiguous()
+        if t1 is not None and adj1 is not None:
+            t = adj1.t_src
+            dv = aggregate(t, t.n_dst, t1, self_x=dv)
+        grads = [None] * (len(vt) + len(et))
+        if dv is not None and any(ctx.needs_input_grad[3:3 + len(vt)]):
+            grads[:len(vt)] = _embedding_table_grads(vt, iv, dv)
+        if et and g1 is not None and any(ctx.needs_input_grad[3 + len(vt):]):
+            grads[len(vt):] = _embedding_table_grads(et, ie, g1)
+        return (None, None, None) + tuple(grads)
+
+
+def embed_front_train(v_weights, v_feats, e_weights, e_feats, n1, adj1, n2, adj2, halve=True) -> List[Tensor]:
+    """embed_front with autograd w.r.t. the tables (see _EmbedFrontTrain); the transposed plans of the two boundary
+    adjacencies are built here, in one batched call, so that the backward pass launches no index kernels."""
+    from .csr import build_many
+    todo = []
+    for adj in (adj1, adj2):
+        if adj is not None:
+            adj.transposes()
+            todo += [a for a in (adj, adj._t_src) if a is not None and not a.built]
+    if todo:
+        build_many(todo)
+    meta = (len(v_weights), int(n1), adj1, int(n2), adj2, bool(halve))
+    return list(_EmbedFrontTrain.apply(meta, v_feats, e_feats, *v_weights, *(e_weights or [])))
 
 
 _w1t_cache = {}
