@@ -1249,8 +1249,13 @@ def pack_layer_weight(weight: Tensor, fresh: bool = False) -> Tensor:
     key = id(weight)
     ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
     hit = _packed_weights.get(key)
-    if hit is not None and hit[0] == ver and hit[1]() is weight and (not fresh or hit[3] == _pack_token):
-        return hit[2]
+    if hit is not None and hit[1]() is weight:
+        if not fresh and hit[0] == ver:
+            return hit[2]
+        # (the latest batch's entries: the state epoch moves INSIDE a training forward -- every layer's BatchNorm statistics
+        # bump it -- without touching the message weights, which only the optimizer writes)
+        if fresh and hit[3] == _pack_token and hit[0][:2] == ver[:2] and hit[0][3:] == ver[3:]:
+            return hit[2]
     w = _f32c(w, 'weight')
     F = int(w.size(0))
     if w.dim() != 2 or w.size(1) != 2 * F:
