@@ -2339,3 +2339,80 @@ def test_both_csr_build_paths_treat_bad_indices_alike(E, n_dst, n_src):
     assert torch.equal(cpu(adj.perm)[:n_ok].long(), order)
     assert torch.equal(cpu(adj.col)[:n_ok].long(), val[order].clamp(0, n_src - 1))
     assert torch.equal(cpu(adj.aux)[:n_ok].long(), aux[order].clamp(0, 12))
+
+
+@pytest.mark.parametrize('M,K,N,affine,relu', [(1, 128, 128, True, 1), (33, 128, 128, True, 1), (3341, 128, 128, True, 1),
+                                               (500, 128, 128, False, 1), (777, 64, 64, True, 1), (65, 64, 64, True, 0),
+                                               (2000, 128, 128, True, 0)])
+def test_gemm_with_batchnorm_backward_prologue(M, K, N, affine, relu):
+    """cwn_gemm_bnb: the transposed-weight GEMM whose input is the BatchNorm / ReLU backward of dy, formed in the prologue,
+    against cwn_norm_bwd_apply_f32 + the plain GEMM (same arithmetic up to the grouping of the per-column constants) and
+    against float64; dz written once, the sums handed on to acc1 / acc2 by exactly one workgroup; a second descriptor over
+    the same input (dz = NULL) multiplies the same dz."""
+    from cwn_amd import _ffi, ops
+    from cwn_amd.dense_train import _norm_desc
+    g = torch.Generator().manual_seed(M + 3 * K + 7 * N + affine + 2 * relu)
+    dy = torch.randn(M, K, generator=g).to(DEV)
+    z = (torch.randn(M, K, generator=g) * 2 + 0.5).to(DEV)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)          # w_trans layout: [K, N]
+    aff = None
+    s12 = torch.zeros(2, K, device=DEV)
+    if affine:
+        aff = torch.stack([torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g), torch.randn(K, generator=g) * 0.3 + 0.5,
+                           torch.rand(K, generator=g) + 0.5]).to(DEV)      # scale, shift, mean, rstd
+        _ffi.norm_bwd_reduce([_norm_desc(z, dy=dy, aff=aff, s12=s12, relu=bool(relu))], DEV)
+    # reference: apply launch + plain GEMM, and float64
+    dz_ref = torch.empty(M, K, device=DEV)
+    _ffi.norm_bwd_apply([_norm_desc(z, dy=dy, out=dz_ref, aff=aff, s12=s12 if affine else None, relu=bool(relu))], DEV)
+    y_ref, = ops.run_gemm([ops.Gemm(X=dz_ref, W=W, w_trans=True)], DEV)
+    z64, dy64 = cpu(z).double(), cpu(dy).double()
+    if affine:
+        sc, sh, mu, rs = (cpu(aff[r]).double() for r in range(4))
+        yv = z64 * sc + sh
+        dyh = dy64 * (yv > 0) if relu else dy64
+        xhat = (z64 - mu) * rs
+        dz64 = sc * (dyh - cpu(s12[0]).double() / M - xhat * cpu(s12[1]).double() / M)
+    else:
+        dz64 = dy64 * (z64 > 0) if relu else dy64
+    y64 = dz64 @ cpu(W).double()
+    # the fused form, two descriptors over the same input (the halves of a combine weight in the training step)
+    W = torch.cat([W, W.flip(1)], 1).contiguous()                     # [K, 2N]: the second product uses another weight
+    y64 = torch.cat([y64, y64.flip(1)], 1)
+    y_ref = torch.cat([y_ref, y_ref.flip(1)], 1)
+    h = N
+    dz = torch.full((M, K), float('nan'), device=DEV)
+    acc = torch.ones(2, K, device=DEV)
+    out = torch.empty(M, 2 * N, device=DEV)
+    b = _ffi.GemmBnb(z=z.data_ptr(), dz=dz.data_ptr(), ldz=z.stride(0), lddz=dz.stride(0), relu=relu)
+    if affine:
+        b.scale, b.shift, b.mean, b.rstd = (aff[r].data_ptr() for r in range(4))
+        b.s1, b.s2, b.acc1, b.acc2 = s12[0].data_ptr(), s12[1].data_ptr(), acc[0].data_ptr(), acc[1].data_ptr()
+    b2 = _ffi.GemmBnb.from_buffer_copy(b)
+    b2.dz, b2.acc1, b2.acc2 = None, None, None
+    ops.run_gemm([ops.Gemm(X=dy, W=W[:, :h], w_trans=True, out=out[:, :h], bnb=b),
+                  ops.Gemm(X=dy, W=W[:, h:], w_trans=True, out=out[:, h:], bnb=b2)], DEV)
+    scale = max(1.0, float(dz64.abs().max()))
+    torch.testing.assert_close(cpu(dz).double(), dz64, rtol=1e-5, atol=2e-5 * scale)
+    torch.testing.assert_close(cpu(dz), cpu(dz_ref), rtol=1e-5, atol=1e-5 * scale)
+    torch.testing.assert_close(cpu(out).double(), y64, rtol=1e-5, atol=3e-5 * max(1.0, float(y64.abs().max())))
+    torch.testing.assert_close(cpu(out), cpu(y_ref), rtol=1e-5, atol=2e-5 * max(1.0, float(y64.abs().max())))
+    if affine:
+        assert torch.equal(acc, 1.0 + s12)          # added once (the first workgroup of the FIRST descriptor), exactly
+    else:
+        assert torch.equal(acc, torch.ones_like(acc))
+    # misuse is refused before anything is launched
+    with pytest.raises(_ffi.CwnError):
+        ops.run_gemm([ops.Gemm(X=dy, W=W.t().contiguous(), bnb=b)], DEV)           # not a transposed-weight launch
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 128, 128), (3341, 128, 128), (515, 64, 64), (100, 40, 24), (48 * 7 + 5, 128, 128)])
+def test_gemm_add_out_adds_onto_what_the_output_holds(M, N, K):
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    X = torch.randn(M, K, generator=g).to(DEV)
+    Wt = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+    base = torch.randn(M, N, generator=g).to(DEV)
+    plain, = ops.run_gemm([ops.Gemm(X=X, W=Wt, w_trans=True)], DEV)
+    out = base.clone()
+    ops.run_gemm([ops.Gemm(X=X, W=Wt, w_trans=True, out=out, add_out=True)], DEV)
+    assert torch.equal(out, base + plain)
