@@ -786,18 +786,21 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
     const int shape = narrow ? (KP == 64 ? 2 : (KP == 128 ? 3 : 4)) : (rt3 ? 5 : (KP == 128 ? 0 : 1));
     if (any_bnb) {
         // the backward prologue: transposed weight, 16-byte operands, the two shapes of the hidden-128 / hidden-64 models
-        if (!wt || !fast || (shape != 0 && shape != 2)) return CWN_ERR_BAD_ARG;
+        if (!wt || !fast || (shape != 0 && shape != 2 && shape != 3)) return CWN_ERR_BAD_ARG;
         static std::once_flag bnb_once;
         static bool bnb_ok = true;
         std::call_once(bnb_once, [&] {
             bnb_ok = hipFuncSetAttribute((const void*)gemm_kernel<true, false, 128, 4, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kShapeLds[0]) == hipSuccess &&
                      hipFuncSetAttribute((const void*)gemm_kernel<true, false, 64, 2, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         kShapeLds[2]) == hipSuccess;
+                                         kShapeLds[2]) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)gemm_kernel<true, false, 128, 2, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kShapeLds[3]) == hipSuccess;
         });
         if (!bnb_ok) return CWN_ERR_LAUNCH;
         if (shape == 0) hipLaunchKernelGGL((gemm_kernel<true, false, 128, 4, true, 2, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B, E);
-        else hipLaunchKernelGGL((gemm_kernel<true, false, 64, 2, true, 2, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B, E);
+        else if (shape == 2) hipLaunchKernelGGL((gemm_kernel<true, false, 64, 2, true, 2, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B, E);
+        else hipLaunchKernelGGL((gemm_kernel<true, false, 128, 2, true, 2, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, (hipStream_t)stream_, B, E);
         return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
     }
     const Kern k = wt ? kerns_wt[fast ? 1 : 0][shape] : kerns[fast ? 1 : 0][pro ? 1 : 0][shape];

@@ -486,8 +486,8 @@ typedef struct cwn_gemm_desc {
     int32_t w_trans;
     int32_t flags;          /* CWN_GEMM_* bits, 0: none */
     int32_t pad_;
-    const cwn_gemm_bnb* bnb;  /* HOST pointer or NULL, see the struct above: w_trans launches with 16-byte aligned operands, K <= 128,
-                               N <= 128 per descriptor or all N <= 64; CWN_ERR_BAD_ARG otherwise */
+    const cwn_gemm_bnb* bnb;  /* HOST pointer or NULL, see the struct above: w_trans launches with 16-byte aligned operands and
+                               K <= 128 (the launch's tile shapes for K <= 128: any N); CWN_ERR_BAD_ARG otherwise */
 } cwn_gemm_desc;
 
 /* cwn_gemm_desc.flags.  EXACT: keep this launch on the exact fp32-MFMA kernel (bitwise an fmaf chain

@@ -2343,7 +2343,7 @@ def test_both_csr_build_paths_treat_bad_indices_alike(E, n_dst, n_src):
 
 @pytest.mark.parametrize('M,K,N,affine,relu', [(1, 128, 128, True, 1), (33, 128, 128, True, 1), (3341, 128, 128, True, 1),
                                                (500, 128, 128, False, 1), (777, 64, 64, True, 1), (65, 64, 64, True, 0),
-                                               (2000, 128, 128, True, 0)])
+                                               (2000, 128, 128, True, 0), (500, 128, 64, True, 1), (300, 64, 128, True, 1)])
 def test_gemm_with_batchnorm_backward_prologue(M, K, N, affine, relu):
     """cwn_gemm_bnb: the transposed-weight GEMM whose input is the BatchNorm / ReLU backward of dy, formed in the prologue,
     against cwn_norm_bwd_apply_f32 + the plain GEMM (same arithmetic up to the grouping of the per-column constants) and
