@@ -915,6 +915,18 @@ def main():
                 ts.step(i % len(tb))
             barrier()
             dtt = time.perf_counter() - t0
+            # the same steps, four behind one graph replay (TrainStep.steps): what a loop over a fixed epoch order pays
+            dt4 = None
+            if train_graph and world == 1:
+                seq4 = [i % len(tb) for i in range(4)]
+                ts.steps(seq4)
+                ts.steps(seq4)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(max(tsteps // 4, 3)):
+                    ts.steps(seq4)
+                torch.cuda.synchronize()
+                dt4 = (time.perf_counter() - t1) / (max(tsteps // 4, 3) * 4)
             if dist is not None:
                 t = torch.tensor([dtt], device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -927,6 +939,7 @@ def main():
                      'cells_per_s': round(float(tcells.item()) / dtt, 1), 'steps': tsteps,
                      'params': int(sum(p.numel() for p in ts.bucket.params)),
                      'backward_pieces': int(ts.n_stages),
+                     'ms_per_step_four_per_graph': None if dt4 is None else round(dt4 * 1e3, 4),
                      'scope': 'adjacency plans (forward + transposed), forward, L1 loss, backward, Adam on one flat buffer (cwn_adam_f32)'
                               + (f', {ts.bucket.flat.numel() * 4 / 1e6:.1f} MB flat gradient bucket all-reduced over RCCL in '
                                  f'{ts.n_stages} chunk(s), each issued as soon as the backward has left its layers'
