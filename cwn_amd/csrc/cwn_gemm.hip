@@ -261,7 +261,7 @@ template <bool FAST, bool PRO, int KP, int WN, bool WT, int RT, bool BNB>
 #ifndef CWN_GEMM_FRAGPF
 #define CWN_GEMM_FRAGPF 0
 #endif
-__global__ __launch_bounds__(kThreads, (KP <= 128 ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B, BnbArg<BNB> E) {
+__global__ __launch_bounds__(kThreads, (KP <= 128 && RT == 2 ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B, BnbArg<BNB> E) {
     // RT = 16-row MFMA tiles per wave (2; 3 for the one-round small-M case, see the host side)
     constexpr int BM = 16 * RT * (4 / WN);   // rows per tile: WN waves side by side along N, 4/WN along M
     constexpr int BN = 32 * WN;         // columns per tile
