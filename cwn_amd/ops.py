@@ -1092,8 +1092,10 @@ class _GemmAggregate(torch.autograd.Function):
     aggregation (self terms, boundary gather) and from each product it entered -- and the autograd engine added the
     pieces with one framework kernel per piece: 16 add kernels per ZINC training step.  Here the aggregation's backward
     writes its piece first and a transposed-weight GEMM adds its piece onto it (CWN_GEMM_ADD_OUT, one product per
-    matrix; x_1, which enters two products, still gets one framework add): 4 add kernels per step instead of 16.  tensors = 4 per GEMM (X, X2, W, bias) then 4 per stream (A, B, self_x, eps); `links[(k, slot)]` = the
-    GEMM whose output is stream k's A (slot 0) or B (slot 1) -- those tensor slots hold None."""
+    matrix; x_1, which enters two products, still gets one framework add): 4 add kernels per step instead of 16.
+    tensors = 4 per GEMM (X, X2, W, bias) then 4 per stream (A, B, self_x, eps); `links[(k, slot)]` = the GEMM whose
+    output is stream k's A (slot 0) or B (slot 1) -- those tensor slots hold None.  `ys` may be a _Precomputed: the
+    products AND the outputs already exist (the training forward through the blocked layer kernel)."""
 
     @staticmethod
     def forward(ctx, gemms, streams, links, ys, device, *tensors):
