@@ -16,10 +16,10 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
@@ -75,6 +75,14 @@ class LayerDim(C.Structure):
                 ('out_b', C.c_void_p), ('n_cells', C.c_int64), ('e_up', C.c_int64), ('n_b', C.c_int64),
                 ('big_up_rowptr', C.c_void_p), ('big_up_col', C.c_void_p), ('big_up_aux', C.c_void_p),
                 ('big_b_rowptr', C.c_void_p), ('big_b_col', C.c_void_p), ('big_y1', C.c_void_p), ('big_y2', C.c_void_p)]
+
+
+class LayerBwdDim(C.Structure):
+    """cwn_layer_bwd_dim (include/cwn_hip.h)."""
+    _fields_ = [('g_up', C.c_void_p), ('g_b', C.c_void_p), ('y1', C.c_void_p), ('y2', C.c_void_p), ('up_index', C.c_void_p),
+                ('up_shared', C.c_void_p), ('b_index', C.c_void_p), ('wt_packed', C.c_void_p), ('eps1', C.c_void_p),
+                ('eps2', C.c_void_p), ('dx', C.c_void_p), ('gy1', C.c_void_p), ('gy2', C.c_void_p),
+                ('n_cells', C.c_int64), ('e_up', C.c_int64), ('n_b', C.c_int64)]
 
 
 class LayerPlan(C.Structure):
@@ -197,8 +205,13 @@ def lib():
     L.cwn_layer_fused_f32.restype = C.c_int
     L.cwn_layer_fused_f32.argtypes = [C.POINTER(LayerDim), C.c_int, C.c_int32, C.POINTER(LayerPlan), C.c_int32,
                                       C.c_void_p, C.c_void_p]
-    L.cwn_layer_pack_weights_many_f32.restype = C.c_int
-    L.cwn_layer_pack_weights_many_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    for name in ('cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32'):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    L.cwn_layer_bwd_f32.restype = C.c_int
+    L.cwn_layer_bwd_f32.argtypes = [C.POINTER(LayerBwdDim), C.c_int, C.c_int32, C.POINTER(LayerPlan), C.c_void_p, C.c_void_p]
+    L.cwn_layer_bwd_lds_bytes.restype = C.c_size_t
+    L.cwn_layer_bwd_lds_bytes.argtypes = [C.c_int32, C.c_int32]
     L.cwn_layer_packed_weight_bytes.restype = C.c_size_t
     L.cwn_layer_packed_weight_bytes.argtypes = [C.c_int32]
     L.cwn_layer_pack_weights_f32.restype = C.c_int

@@ -1224,6 +1224,7 @@ struct PackMany {            // up to CWN_LAYER_PACK_MAX weights of one width in
     const float* W[CWN_LAYER_PACK_MAX];
     unsigned char* out[CWN_LAYER_PACK_MAX];
     int64_t ldw[CWN_LAYER_PACK_MAX];
+    int32_t trans;           // 1: the transposed halves (the backward launch's operand: cwn_layer_bwd.hip)
 };
 
 template <int F>
@@ -1236,8 +1237,17 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackMany P) {
     if (g >= NCT * 2 * KS * 64) return;
     const int lane = g & 63, chunk3 = g >> 6;                     // chunk3 = (ct * 2 + h) * KS + ks
     const int ks = chunk3 % KS, h = (chunk3 / KS) & 1, ct = chunk3 / (2 * KS);
-    const float* src = W + (int64_t)(ct * 16 + (lane & 15)) * ldw + h * F + ks * 32 + (lane >> 4) * 8;
-    const float4 a = make_float4(src[0], src[1], src[2], src[3]), b = make_float4(src[4], src[5], src[6], src[7]);
+    float e[8];
+    if (P.trans) {           // element k of lane (kq, n): W[ks * 32 + kq * 8 + k][h * F + ct * 16 + n]
+        const float* src = W + (int64_t)(ks * 32 + (lane >> 4) * 8) * ldw + h * F + ct * 16 + (lane & 15);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = src[(int64_t)k * ldw];
+    } else {
+        const float* src = W + (int64_t)(ct * 16 + (lane & 15)) * ldw + h * F + ks * 32 + (lane >> 4) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = src[k];
+    }
+    const float4 a = make_float4(e[0], e[1], e[2], e[3]), b = make_float4(e[4], e[5], e[6], e[7]);
     uint4 ph, pm, pl;
     cwn::split8(a, b, ph, pm, pl);
     unsigned char* dst = out + ((size_t)(ks * 3 * 2 + h) * NCT + ct) * 1024 + lane * 16;
@@ -1514,14 +1524,15 @@ extern "C" size_t cwn_layer_packed_weight_bytes(int32_t F) {
     return (F == 64 || F == 128) ? (size_t)F * 2 * F * 6 : 0;
 }
 
-extern "C" int cwn_layer_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
-                                               cwn_stream_t stream_) {
+static int pack_many(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n, int trans,
+                     cwn_stream_t stream_) {
     if ((F != 64 && F != 128) || W == nullptr || out == nullptr || ldw == nullptr || n < 0) return CWN_ERR_BAD_ARG;
     const int threads = (F / 16) * 2 * (F / 32) * 64;
     hipStream_t stream = (hipStream_t)stream_;
     for (int i0 = 0; i0 < n; i0 += CWN_LAYER_PACK_MAX) {
         const int m = n - i0 < CWN_LAYER_PACK_MAX ? n - i0 : CWN_LAYER_PACK_MAX;
         PackMany P{};
+        P.trans = trans;
         for (int i = 0; i < m; ++i) {
             if (W[i0 + i] == nullptr || out[i0 + i] == nullptr || ldw[i0 + i] < 2 * F) return CWN_ERR_BAD_ARG;
             if (((uintptr_t)W[i0 + i] & 3u) || !al16(out[i0 + i])) return CWN_ERR_ALIGN;
@@ -1533,6 +1544,16 @@ extern "C" int cwn_layer_pack_weights_many_f32(const float* const* W, const int6
         else pack_weights_kernel<64><<<dim3((threads + 255) / 256, m), dim3(256), 0, stream>>>(P);
     }
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int cwn_layer_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
+                                               cwn_stream_t stream_) {
+    return pack_many(W, ldw, F, out, n, 0, stream_);
+}
+
+extern "C" int cwn_layer_pack_weights_t_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
+                                                 cwn_stream_t stream_) {
+    return pack_many(W, ldw, F, out, n, 1, stream_);
 }
 
 extern "C" int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream_) {

@@ -732,7 +732,7 @@ class SparseCINConv(torch.nn.Module):
             return None                  # (two launches into the same outputs / streamed complexes: inference only)
         dev, F = dims[0].x.device, int(dims[0].x.size(1))
         ys_of = [[None, None] for _ in range(n)]
-        ys = []
+        ys, ydims = [], []
         for d in range(n):
             if owner.count(d) == 2:
                 if d + 1 >= n:
@@ -741,6 +741,7 @@ class SparseCINConv(torch.nn.Module):
                 y2 = torch.empty(dims[d + 1].x.size(0), F, dtype=torch.float32, device=dev)
                 ys_of[d][0], ys_of[d + 1][1] = y1, y2
                 ys += [y1, y2]
+                ydims += [(d, 'y1'), (d + 1, 'y2')]
         from . import _ffi
         launch = ops.LayerLaunch(dims, table)
         # (the layers of one forward share their index tensors: the first launch stores every item's sorted adjacency,
@@ -754,7 +755,7 @@ class SparseCINConv(torch.nn.Module):
             csr.check_errors(dev)
             plan.validated = True
         self.blocked_reason = None
-        return ys, outs
+        return ys, outs, (dims, table, ydims)       # (the last: what the blocked BACKWARD launch needs, ops._GemmAggregate)
 
     def _blocked_still_valid(self, ent, cochain_params) -> bool:
         """The per-call part of `_blocked_args`: autograd state, feature tensors, lazy attributes, and the

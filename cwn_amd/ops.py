@@ -1107,10 +1107,13 @@ class _GemmAggregate(torch.autograd.Function):
         pre = getattr(ys, 'outs', None)          # the blocked layer kernel has already produced the outputs (and ys)
         outs = list(pre) if pre is not None else run_aggregate(_AggregateMany.specs_of(streams, st_tensors), device)
         ctx.gemms, ctx.streams, ctx.links, ctx.device, ctx.ng = gemms, streams, links, device, ng
+        ctx.blocked = getattr(ys, 'blocked', None)       # (dims, table, where each stored product lives): the forward ran blocked
         keep = [o for o, st in zip(outs, streams) if st.reduce == 'max']
         ctx.n_in = len(tensors)
         ctx.save_for_backward(*tensors, *ys, *keep)
         return tuple(outs)
+
+    _blocked_backward = staticmethod(lambda *a: _blocked_backward_impl(*a))
 
     @staticmethod
     def backward(ctx, *gs):
@@ -1126,6 +1129,9 @@ class _GemmAggregate(torch.autograd.Function):
         for (k, slot), gi in links.items():
             s_tensors[4 * k + slot] = ys[gi]
             s_needs[4 * k + slot] = any(g_needs[4 * gi: 4 * gi + 4])
+        blocked = _GemmAggregate._blocked_backward(ctx, gs, ys, g_tensors, g_needs, s_tensors, s_needs)
+        if blocked is not None:
+            return (None, None, None, None, None) + blocked
         s_grads = _aggregate_backward(ctx.streams, s_tensors, s_needs, gs, max_outs, ctx.device)
         for (k, slot), gi in links.items():
             g = s_grads[4 * k + slot]
@@ -1144,10 +1150,53 @@ class _GemmAggregate(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(g_grads) + tuple(s_grads)
 
 
+def _blocked_backward_impl(ctx, gs, ys, g_tensors, g_needs, s_tensors, s_needs):
+    """The backward of a propagate step whose forward ran as the blocked launch, as ONE launch over the same item table
+    (layer_backward) + the weight-gradient GEMMs; None = does not apply (the streaming backward runs)."""
+    info = ctx.blocked
+    if info is None or not BLOCKED_BACKWARD:
+        return None
+    dims, table, ydims = info
+    n, ng = len(dims), ctx.ng
+    if len(ctx.streams) != 2 * n or len(gs) != 2 * n:
+        return None
+    if any(s_needs[4 * k + 3] and s_tensors[4 * k + 3] is not None for k in range(2 * n)):
+        return None                        # trainable eps: its gradient is a reduction the launch does not take
+    # transposed packed weight of every dimension with an upper adjacency (packed with the forward's weights)
+    wt_of = [None] * n
+    for gi, (d, which) in enumerate(ydims):
+        if which == 'y1':
+            W = ctx.gemms[gi].W
+            wt_of[d] = packed_layer_weight_t(W)
+            if wt_of[d] is None:
+                return None
+    ys_of = [[None, None] for _ in range(n)]
+    for gi, (d, which) in enumerate(ydims):
+        ys_of[d][0 if which == 'y1' else 1] = ys[gi]
+    res = layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[2 * d], gs[2 * d + 1]) for d in range(n)], wt_of)
+    if res is None:
+        return None
+    dxs, gys = res
+    g_of = [gys[d][0 if which == 'y1' else 1] for (d, which) in ydims]
+    # weight (and bias) gradients of the message Linear: gY^T x through the merged weight-gradient launches; dX is done
+    needs_w = list(g_needs)
+    for k in range(ng):
+        needs_w[4 * k] = needs_w[4 * k + 1] = False
+    g_grads = _gemm_backward(ctx.gemms, g_tensors, ys, needs_w, g_of)
+    s_grads: List[Optional[Tensor]] = [None] * len(s_tensors)
+    for d in range(n):
+        want = _ident(dims[d].x)
+        slots = [q for q, t in enumerate(s_tensors) if t is not None and q % 4 in (0, 2) and s_needs[q] and _ident(t) == want]
+        if slots:
+            s_grads[slots[0]] = dxs[d]
+    return tuple(g_grads) + tuple(s_grads)
+
+
 class _Precomputed(tuple):
     """The GEMM outputs of a propagate step together with the step's OUTPUTS, both already produced (by the blocked layer
     kernel with CWN_LAYER_STORE_Y): what _GemmAggregate's forward then has left to do is remember them."""
     outs = None
+    blocked = None
 
 
 def gemm_aggregate(gemms: Sequence[Gemm], make_streams, precomputed=None) -> Tuple[List[Stream], List[Tensor]]:
@@ -1167,6 +1216,7 @@ def gemm_aggregate(gemms: Sequence[Gemm], make_streams, precomputed=None) -> Tup
     if precomputed is not None:
         ys = _Precomputed(precomputed[0])
         ys.outs = tuple(precomputed[1])
+        ys.blocked = precomputed[2] if len(precomputed) > 2 else None
         for gm in gemms:
             gm.X, gm.W = _rowmajor(gm.X, 'X'), _rowmajor(gm.W, 'W')
     else:
@@ -1237,6 +1287,7 @@ _packed_weights = {}
 
 
 _pack_token = 0          # bumped by every pack_layer_weights_many call: entries it wrote are "fresh" until the next one
+_packed_weights_t = {}   # id(weight) -> (token, weakref, buffer): the TRANSPOSED packs of the latest batch (backward launch)
 
 
 def pack_layer_weight(weight: Tensor, fresh: bool = False) -> Tensor:
@@ -1270,10 +1321,19 @@ def pack_layer_weight(weight: Tensor, fresh: bool = False) -> Tensor:
     return out
 
 
-def pack_layer_weights_many(weights: Sequence[Tensor]) -> None:
+def packed_layer_weight_t(weight: Tensor) -> Optional[Tensor]:
+    """The transposed pack of `weight` written by the LATEST pack_layer_weights_many(..., transposed=True), or None."""
+    hit = _packed_weights_t.get(id(weight))
+    if hit is not None and hit[0] == _pack_token and hit[1]() is weight:
+        return hit[2]
+    return None
+
+
+def pack_layer_weights_many(weights: Sequence[Tensor], transposed: bool = False) -> None:
     """Pack the message weights of ALL layers of a model in one launch per width (cwn_layer_pack_weights_many_f32) and
     leave them in pack_layer_weight's cache as fresh entries: a training forward calls this once, its layers then find
-    their weight packed (8 launches per ZINC step otherwise)."""
+    their weight packed (8 launches per ZINC step otherwise).  `transposed`: also the form the backward launch multiplies
+    with (cwn_layer_pack_weights_t_many_f32; packed_layer_weight_t hands it out)."""
     import weakref
     global _pack_token
     _pack_token += 1
@@ -1298,6 +1358,14 @@ def pack_layer_weights_many(weights: Sequence[Tensor]) -> None:
             key = id(weight)
             ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
             _packed_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_weights.pop(k, None)), out, _pack_token)
+        if transposed:
+            outs_t = [torch.empty(nbytes, dtype=torch.uint8, device=w.device) for _, w in ws]
+            Ot = (C.c_void_p * n)(*[o.data_ptr() for o in outs_t])
+            _ffi.check(L.cwn_layer_pack_weights_t_many_f32(Wp, ld, F, Ot, n, _ffi.stream_ptr(ws[0][1].device)),
+                       'cwn_layer_pack_weights_t_many_f32')
+            for (weight, w), out in zip(ws, outs_t):
+                key = id(weight)
+                _packed_weights_t[key] = (_pack_token, weakref.ref(weight, lambda _r, k=key: _packed_weights_t.pop(k, None)), out)
 
 
 _packed_gemm_weights = {}
@@ -1445,6 +1513,58 @@ def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tens
     _ffi.check(_ffi.lib().cwn_layer_fused_f32(arr, len(dims), F, plan, int(csr_mode), _err_flag(dev).data_ptr(),
                                                _ffi.stream_ptr(dev)), 'cwn_layer_fused_f32')
     return outs
+
+
+# The backward of the propagate step as ONE launch over the forward's item table (cwn_layer_bwd_f32).  OFF: correct (tested
+# against float64 autograd), but 56 us per launch at the ZINC batch of 128 against ~34 us for the streaming backward it
+# replaces (transposed aggregation 13 + transposed-weight GEMM 16 + an add): 31 of the 56 are the fp32 LDS atomics that
+# scatter the masked gradients into gY1 | gY2 (~100 cycles per wave instruction, tools/ubench_layer_bwd.py), 8 the fp32
+# global atomics that collect dx from up to three workgroups.  What it needs to win: the item's entries bucket-sorted by
+# source and by coface in LDS (integer atomics, as the forward sorts by destination) instead of float atomics, and one
+# item per complex across all dimensions so that dx rows have ONE owner.  CWN_BLOCKED_BACKWARD=1 switches it on.
+BLOCKED_BACKWARD = os.environ.get('CWN_BLOCKED_BACKWARD') == '1'
+
+
+def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of) -> Optional[Tuple[List[Tensor], List]]:
+    """cwn_layer_bwd_f32: the backward of one propagate step over the item table of its forward launch.  dims: the
+    LayerDim list of the forward; ys_of[d] = (Y1_d or None, Y2 stored at dimension d or None); gs_of[d] = (dL/d out_up_d,
+    dL/d out_b_d), None = zero; wt_of[d] = transposed packed weight or None.  Returns ([dx_d], [(gY1_d, gY2 at d)]) or
+    None when the launch does not apply (a table in another form, an item beyond the backward's LDS)."""
+    if getattr(table, 'variant', 0) != 0 or getattr(table, 'n_big', 0):
+        return None
+    n, F = len(dims), int(dims[0].x.size(1))
+    L = _ffi.lib()
+    if int(L.cwn_layer_bwd_lds_bytes(F, int(table.max_rows))) == 0:
+        return None
+    dev = dims[0].x.device
+    rows = [int(D.x.size(0)) for D in dims]
+    dx_buf = torch.zeros(sum(rows), F, dtype=torch.float32, device=dev)          # every piece is ADDED: one fill for the layer
+    dxs = list(dx_buf.split(rows))
+    arr = (_ffi.LayerBwdDim * n)()
+    gys, keep = [], []
+    for d, D in enumerate(dims):
+        e_up = 0 if D.up_index is None else int(D.up_index.size(1))
+        n_b = 0 if D.b_index is None else int(D.b_index.size(1))
+        y1, y2 = ys_of[d]
+        gy1 = torch.empty(rows[d], F, dtype=torch.float32, device=dev) if y1 is not None else None
+        gy2 = torch.empty(rows[d], F, dtype=torch.float32, device=dev) if y2 is not None else None
+        gys.append((gy1, gy2))
+        gu, gb = gs_of[d]
+        gu = None if gu is None else _f32c(gu, 'grad')
+        gb = None if gb is None else _f32c(gb, 'grad')
+        e1, e2 = _f32c(D.eps1, 'eps1'), _f32c(D.eps2, 'eps2')
+        keep += [gu, gb, e1, e2]
+        if e_up and wt_of[d] is None:
+            return None
+        arr[d] = _ffi.LayerBwdDim(g_up=_ffi.ptr(gu), g_b=_ffi.ptr(gb), y1=_ffi.ptr(y1), y2=_ffi.ptr(y2),
+                                  up_index=_ffi.ptr(D.up_index) if e_up else None, up_shared=_ffi.ptr(D.up_shared) if e_up else None,
+                                  b_index=_ffi.ptr(D.b_index) if n_b else None, wt_packed=_ffi.ptr(wt_of[d]) if e_up else None,
+                                  eps1=_ffi.ptr(e1), eps2=_ffi.ptr(e2), dx=dxs[d].data_ptr(), gy1=_ffi.ptr(gy1), gy2=_ffi.ptr(gy2),
+                                  n_cells=rows[d], e_up=e_up, n_b=n_b)
+    from .csr import _err_flag
+    plan = table.c_plan(with_cache=False)
+    _ffi.check(L.cwn_layer_bwd_f32(arr, n, F, plan, _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)), 'cwn_layer_bwd_f32')
+    return dxs, gys
 
 
 class LayerLaunch:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 14
+#define CWN_ABI_VERSION 15
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -297,6 +297,11 @@ int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out
 #define CWN_LAYER_PACK_MAX 16
 int cwn_layer_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
                                     cwn_stream_t stream);
+/* ... and in the form the BACKWARD launch (cwn_layer_bwd_f32) multiplies with: the same planes and chunk order of the
+ * TRANSPOSED halves, chunk (ks, plane, h, ct) holding W[ks * 32 + kq * 8 .., h * F + ct * 16 + n] for lane kq * 16 + n
+ * (output column = input feature of the Linear, reduction over its outputs: dX = gY W). */
+int cwn_layer_pack_weights_t_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
+                                      cwn_stream_t stream);
 
 /* The item table and what the launcher needs to know about it (HOST struct; built by
  * cwn_layer_items_build).  Items are ordered by set.  The *_end fields summarise what the table
@@ -338,6 +343,36 @@ typedef struct cwn_layer_plan {
 
 int cwn_layer_fused_f32(const cwn_layer_dim* dims_host, int n_dims, int32_t F, const cwn_layer_plan* plan_host,
                         int32_t flags, int32_t* err_flag, cwn_stream_t stream);
+
+/* The BACKWARD of the same step in one launch over the SAME item table (variant 0, no BIG records): see
+ * csrc/cwn_layer_bwd.hip for the formulas.  Per dimension: the gradients of the two outputs (NULL = zero), the products
+ * the forward launch stored (CWN_LAYER_STORE_Y: y1 = Y1 of this dimension, y2 = Y2 of the dimension BELOW, both
+ * [n_cells, F]), the index tensors as in cwn_layer_dim, the transposed packed message weight of this dimension
+ * (cwn_layer_pack_weights_t_many_f32; NULL without upper adjacency), eps.  Outputs: dx [n_cells, F] -- ZEROED by the
+ * caller, every piece is added with fp32 atomics -- and gy1 / gy2 [n_cells, F] (written; NULL = not wanted): the
+ * gradients of Y1 of this dimension / of Y2 of the dimension below, what the weight-gradient GEMM multiplies.
+ * An index that leaves its item sets bit 3 of *err_flag.  cwn_layer_bwd_lds_bytes: the launch's LDS for a table whose
+ * largest item stages max_gemm_rows rows, 0 = beyond a CU (CWN_ERR_TOO_LARGE from the launch: the caller keeps the
+ * streaming backward). */
+typedef struct cwn_layer_bwd_dim {
+    const float* g_up;
+    const float* g_b;
+    const float* y1;
+    const float* y2;
+    const int64_t* up_index;
+    const int64_t* up_shared;
+    const int64_t* b_index;
+    const void* wt_packed;
+    const float* eps1;
+    const float* eps2;
+    float* dx;
+    float* gy1;
+    float* gy2;
+    int64_t n_cells, e_up, n_b;
+} cwn_layer_bwd_dim;
+size_t cwn_layer_bwd_lds_bytes(int32_t F, int32_t max_gemm_rows);
+int cwn_layer_bwd_f32(const cwn_layer_bwd_dim* dims_host, int n_dims, int32_t F, const cwn_layer_plan* plan_host,
+                      int32_t* err_flag, cwn_stream_t stream);
 /* The item table, built on the HOST from the per-complex prefix sums the reference's collate keeps (`ptr`:
  * data/complex.py:344, 432; `__slices__`: :349-394): contiguous ranges of complexes per set, greedily under the
  * limits above, with ONE launch's LDS split between staged rows and boundary sources so that the items are as

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 14
+    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 15
     assert lib.cwn_target_arch() == b'gfx950'
     assert lib.cwn_error_string(0) == b'ok'
 
@@ -39,7 +39,7 @@ def test_struct_layout_matches_header(tmp_path):
                'cwn_gemm_desc': _ffi.GemmDesc, 'cwn_gemm_bnb': _ffi.GemmBnb, 'cwn_collate_desc': _ffi.CollateDesc,
                'cwn_bn_desc': _ffi.BnDesc, 'cwn_norm_desc': _ffi.NormDesc,
                'cwn_gemm_tn_desc': _ffi.GemmTnDesc, 'cwn_layer_dim': _ffi.LayerDim,
-               'cwn_layer_plan': _ffi.LayerPlan, 'cwn_mlp_dim': _ffi.MlpDim, 'cwn_layer_sizes': _ffi.LayerSizes,
+               'cwn_layer_plan': _ffi.LayerPlan, 'cwn_layer_bwd_dim': _ffi.LayerBwdDim, 'cwn_mlp_dim': _ffi.MlpDim, 'cwn_layer_sizes': _ffi.LayerSizes,
                'cwn_embed_table': _ffi.EmbedTable, 'cwn_head_dim': _ffi.HeadDim, 'cwn_head_bwd_dim': _ffi.HeadBwdDim}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cwn_hip.h"', 'int main(void) {']
     for cname, st in structs.items():
@@ -92,6 +92,9 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_layer_fused_f32(None, 1, 128, None, 0, None, None) == 1
     assert lib.cwn_layer_pack_weights_f32(None, 256, 128, None, None) == 1
     assert lib.cwn_layer_pack_weights_many_f32(None, None, 128, None, 1, None) == 1
+    assert lib.cwn_layer_pack_weights_t_many_f32(None, None, 128, None, 1, None) == 1
+    assert lib.cwn_layer_bwd_f32(None, 1, 128, None, None, None) == 1
+    assert lib.cwn_layer_bwd_lds_bytes(128, 96) == 96 * 132 * 4 + 3 * 96 * 136 * 2 and lib.cwn_layer_bwd_lds_bytes(64, 256) == 0
     assert lib.cwn_layer_fused_f32(None, 1, 128, None, _ffi.LAYER_STORE_Y, None, None) == 1
     assert lib.cwn_layer_packed_weight_bytes(128) == 128 * 256 * 6 and lib.cwn_layer_packed_weight_bytes(96) == 0
     assert lib.cwn_layer_fused_lds_bytes(128, 96, 64) == 3 * 96 * 136 * 2 + 65 * 128 * 4 + 9648

@@ -619,8 +619,9 @@ def test_mixed_launch_two_per_cu_form_plus_16_wave_form():
         assert torch.equal(s2, p), i
 
 
-@pytest.mark.parametrize('kind,n,F', [('zinc', 64, 128), ('zinc', 300, 128), ('molhiv', 96, 64)])
-def test_training_forward_through_the_blocked_kernel(kind, n, F):
+@pytest.mark.parametrize('kind,n,F,blocked_bwd', [('zinc', 64, 128, False), ('zinc', 300, 128, False), ('molhiv', 96, 64, False),
+                                                  ('zinc', 64, 128, True), ('zinc', 20, 64, True)])
+def test_training_forward_through_the_blocked_kernel(kind, n, F, blocked_bwd):
     """CWN_LAYER_STORE_Y: with autograd on, the propagate step runs as the blocked launch, leaves Y1 / Y2 for the backward
     pass (ops._GemmAggregate) and gives the gradients of the two-kernel path.  At F = 128 outputs and the stored products
     are bit-identical to that path (same split, same MFMA order); at F = 64 the two-kernel path multiplies on fp32 MFMA."""
@@ -638,7 +639,10 @@ def test_training_forward_through_the_blocked_kernel(kind, n, F):
 
     def run(flag):
         layers.BLOCKED_TRAIN_FORWARD = flag
+        ops.BLOCKED_BACKWARD = blocked_bwd and flag      # (the one-launch backward prototype, csrc/cwn_layer_bwd.hip: off by default)
         ops.gemm_aggregate = spy
+        if blocked_bwd and flag:
+            ops.pack_layer_weights_many([conv.mp_levels[d].msg_up_nn[1].weight for d in range(2)], transposed=True)
         try:
             conv.zero_grad(set_to_none=True)
             xin = [b.cochains[d].x.detach().clone().requires_grad_() for d in range(3)]
@@ -648,6 +652,7 @@ def test_training_forward_through_the_blocked_kernel(kind, n, F):
             return outs, xin, {k: v.grad.clone() for k, v in conv.named_parameters() if v.grad is not None}, captured.get('pre')
         finally:
             layers.BLOCKED_TRAIN_FORWARD = True
+            ops.BLOCKED_BACKWARD = False
             ops.gemm_aggregate = orig
 
     outs1, x1, g1, pre1 = run(True)
@@ -701,3 +706,73 @@ def test_packing_many_layer_weights_at_once_equals_one_by_one():
     ops.pack_layer_weights_many(ws[:1])                                         # a later batch: the other entries are stale
     again = ops.pack_layer_weight(ws[1], fresh=True)
     assert torch.equal(again, one[1])
+
+
+def _propagate_reference_backward(conv, b, gs, F):
+    """float64 autograd through a plain restatement of the propagate step (mp/layers.py:184-192, 290-295): per dimension
+    the gradients of x, Y1, Y2 for output gradients gs = [gU_0, gB_0, gU_1, ...]."""
+    xs = [cpu(b.cochains[d].x).double().requires_grad_() for d in range(3)]
+    Y1, Y2, loss = [None] * 3, [None] * 3, 0.0
+    for d in range(3):
+        c = b.cochains[d]
+        lvl = conv.mp_levels[d]
+        n = xs[d].size(0)
+        e1, e2 = float(lvl.eps1), float(lvl.eps2)
+        out_up = (1 + e1) * xs[d]
+        if d + 1 < 3 and c.upper_index is not None and c.upper_index.size(1):
+            W = cpu(lvl.msg_up_nn[1].weight).double()
+            bias = cpu(lvl.msg_up_nn[1].bias).double()
+            Y1[d] = xs[d] @ W[:, :F].t() + bias
+            Y2[d + 1] = xs[d + 1] @ W[:, F:].t()
+            Y1[d].retain_grad()
+            Y2[d + 1].retain_grad()
+            ui, sh = cpu(c.upper_index), cpu(c.shared_coboundaries)
+            msg = torch.relu(Y1[d][ui[0]] + Y2[d + 1][sh])
+            out_up = out_up + torch.zeros(n, F, dtype=torch.float64).index_add(0, ui[1], msg)
+        out_b = (1 + e2) * xs[d]
+        if d > 0 and c.boundary_index is not None and c.boundary_index.size(1):
+            bi = cpu(c.boundary_index)
+            out_b = out_b + torch.zeros(n, F, dtype=torch.float64).index_add(0, bi[1], xs[d - 1][bi[0]])
+        loss = loss + (out_up * cpu(gs[2 * d]).double()).sum() + (out_b * cpu(gs[2 * d + 1]).double()).sum()
+    loss.backward()
+    return [x.grad for x in xs], [None if y is None else y.grad for y in Y1], [None if y is None else y.grad for y in Y2]
+
+
+@pytest.mark.parametrize('kind,n,F,eps', [('zinc', 64, 128, 0.0), ('zinc', 128, 128, 0.3), ('zinc', 9, 128, 0.0), ('zinc', 40, 64, 0.2)])
+def test_blocked_backward_launch_vs_float64_autograd(kind, n, F, eps):
+    """cwn_layer_bwd_f32 (ops.layer_backward) over the item table of the forward launch: dx of every dimension and the
+    gradients of the stored products against float64 autograd of the plain restatement."""
+    from cwn_amd import layers, ops, _ffi
+    b = _batch(kind, n, F, seed=31)
+    conv = _conv(F, seed=32, eps=eps).train()
+    params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+    args = conv._blocked_args(params, 0, training=True)
+    assert not isinstance(args, str), args
+    dims, plan, table, key = args
+    assert table.variant == 0 and not table.n_big
+    rows = [int(D.x.size(0)) for D in dims]
+    ys_of = [[None, None] for _ in range(3)]
+    for d in range(2):
+        if dims[d].up_index is not None and dims[d].up_index.size(1):
+            ys_of[d][0] = torch.empty(rows[d], F, device=DEV)
+            ys_of[d + 1][1] = torch.empty(rows[d + 1], F, device=DEV)
+    outs = ops.LayerLaunch(dims, table).run([D.x for D in dims], 0, ys=[tuple(p) for p in ys_of])
+    g = torch.Generator().manual_seed(5)
+    gs = [torch.randn(o.shape, generator=g).to(DEV) for o in outs]
+    gs[3] = None if n == 9 else gs[3]                                   # an output nobody differentiates: a NULL gradient
+    ws = [conv.mp_levels[d].msg_up_nn[1].weight for d in range(2)]
+    ops.pack_layer_weights_many(ws, transposed=True)
+    wt_of = [ops.packed_layer_weight_t(ws[0]), ops.packed_layer_weight_t(ws[1]), None]
+    got = ops.layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[2 * d], gs[2 * d + 1]) for d in range(3)], wt_of)
+    assert got is not None
+    from cwn_amd import csr
+    csr.check_errors(DEV)
+    dxs, gys = got
+    ref_gs = [torch.zeros_like(outs[k]) if x is None else x for k, x in enumerate(gs)]
+    dx_ref, gy1_ref, gy2_ref = _propagate_reference_backward(conv, b, ref_gs, F)
+    for d in range(3):
+        _gate(dxs[d], dx_ref[d], f'dx[{d}]')
+        if gy1_ref[d] is not None:
+            _gate(gys[d][0], gy1_ref[d], f'gY1[{d}]')
+        if gy2_ref[d] is not None:
+            _gate(gys[d][1], gy2_ref[d], f'gY2[{d}]')
