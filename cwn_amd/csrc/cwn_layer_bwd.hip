@@ -12,22 +12,22 @@
 // The training step ran this as a transposed CSR aggregation (gY1, gY2, boundary transposes, self terms: one launch
 // over plans that had to be built per batch), a transposed-weight GEMM that added gY W onto it, and framework adds.
 // Here the workgroup that owns a range of complexes for a GEMM dimension g (the SAME item table as the forward launch)
-// scatters the masked gradients of its upper entries into gY1 | gY2 in LDS (fp32 LDS atomics: no sort, no transposed
-// plan), writes them out for the weight-gradient GEMM, multiplies them by the transposed message weight on the matrix
+// gathers, for every row of gY1 | gY2 it owns, the masked gradients of the upper entries that name the row as source or
+// coface (out of LDS, in entry order: no float atomics, no sort, no transposed plan), writes them out for the weight-gradient GEMM, multiplies them by the transposed message weight on the matrix
 // cores (the forward's exact three-way bf16 split, cwn_split.h) and adds every piece of dx -- products, self terms,
 // boundary transposes -- to the caller's ZEROED dx matrices with fp32 atomics: a cell receives pieces from up to three
 // workgroups (its own set's, the set below's second product, the set above's boundary entries).  Sums therefore run in
 // arrival order: results agree with the streaming path to rounding, not bit for bit (as the weight gradients already do).
 //
 // STATE (round 3): correct -- dx, gY1, gY2 against float64 autograd, and whole training steps through it -- and NOT the
-// default: 56 us per launch at the ZINC batch of 128 (256 items) against ~34 us for the three launches it replaces.
-// tools/ubench_layer_bwd.py with CWN_LBWD_DBG: the entry scatter of phase 2 is 31 us (ds_add_f32 runs at ~100 cycles per
-// wave instruction; 64 entries x 2 targets x 4 instructions per item), the global atomics of phases 4 / 5 ~10 us, the rest
-// (fill of dx, loads, split, MFMA) ~14 us.  Two things measured on the way: written with a branch per entry the compiler
-// waited for each entry's indices before requesting the next one's (the loads are branch-free now), and atomics for
-// ABSENT entries -- zeros onto row 0 -- serialised on that one address (95 us): only live entries add.  Next: sort the
-// entries by source and by coface in LDS with integer atomics (as the forward sorts by destination) and reduce without
-// float atomics; one item per complex over all dimensions gives every dx row a single owner (plain stores).
+// default: 25 us per launch (+ the fill of dx) at the ZINC batch of 128 (256 items) against ~34 us for the three launches it
+// replaces; the training step reads the same with and without it.  What was measured on the way (tools/ubench_layer_bwd.py
+// with CWN_LBWD_DBG): the first form scattered the masked gradients with fp32 LDS atomics -- ds_add_f32 runs at ~100 cycles
+// per wave instruction: 31 us of a 56-us launch; written with a branch per entry the compiler waited for each entry's
+// indices before requesting the next one's; atomics for ABSENT entries (zeros onto row 0) serialised on that one address
+// (95 us); walking the entries four keys per LDS read and a branch per key cost 15 us where one key per lane and a ballot
+// costs 6.  Left: ~10 us of staging and launch, 6 of walk, 6 of global fp32 atomics into dx, 2 of MFMA.  Next: one item per
+// complex over all dimensions gives every dx row a single owner (plain stores, no fill).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -65,7 +65,8 @@ template <int F> struct Geo {
     static constexpr int kNG = kThreads / kG;           // rows / entries per round
     __host__ __device__ static constexpr size_t gy_bytes(int rows) { return (size_t)rows * kYStride * 4; }
     __host__ __device__ static constexpr size_t planes_bytes(int rows) { return (size_t)3 * rows * kPlaneStride * 2; }
-    __host__ __device__ static constexpr size_t lds_bytes(int rows) { return gy_bytes(rows) + planes_bytes(rows); }
+    // + the item's upper entries as three int arrays (source, destination, coface; padded to 4)
+    __host__ __device__ static constexpr size_t lds_bytes(int rows) { return gy_bytes(rows) + planes_bytes(rows) + (size_t)3 * CWN_LAYER_MAX_ENTRIES * 4; }
 };
 
 __device__ __forceinline__ void atomic_add4(float* p, const float4& v) {
@@ -119,85 +120,97 @@ __global__ __launch_bounds__(kThreads) void layer_bwd_kernel(BwdArgs A) {
                 for (int pl = 0; pl < 3; ++pl)
                     wsp[ks][pl] = *reinterpret_cast<const uint4*>(wp + (size_t)(((ks * 3 + pl) * 2 + my_h) * G::kNCT) * 1024);
         }
-        // ---- 1. gY1 | gY2 = 0 in LDS -------------------------------------------------------------------------------
-        for (int r = gq; r < rows_pad; r += G::kNG)
-            *reinterpret_cast<float4*>(gY + (size_t)r * G::kYStride + f) = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        // ---- 2. the item's upper entries, four per lane group in flight: masked gradient into both targets ------------
-        // BRANCH-FREE: every level of loads (the three indices of four entries, then the three rows of each) is issued in
-        // one run and an entry that is out of range or past the end adds zeros -- written with a branch per entry the
-        // compiler waited for each entry's indices before it requested the next one's (eight dependent round trips,
-        // 17 us of the launch, tools/ubench_layer_bwd.py).
+        // ---- 1. stage: Y1 | Y2 rows (fp32) into S, the rows of gU into the plane region (free until phase 3), the item's
+        //         upper entries as LOCAL row numbers (structure of arrays: source, destination, coface) --------------------------
+        float* const S = gY;                                                      // [rows_cap][F + 4]: Y1 rows, from R1 the Y2 rows
+        float* const T = reinterpret_cast<float*>(planes);                        // [g_n][F + 4]: gU rows
+        int* const ej = reinterpret_cast<int*>(smem + G::gy_bytes(rows_cap) + G::planes_bytes(rows_cap));
+        const int une4 = (une + 3) & ~3;
+        int* const ei = ej + une4;
+        int* const ec = ei + une4;
+        const bool have_gu = Dg.g_up != nullptr && !(A.dbg & 1);
         {
             const int64_t E = Dg.e_up;
-            const int64_t* const src_p = Dg.up_index + ue0;
-            const int64_t* const dst_p = Dg.up_index + E + ue0;
-            const int64_t* const cof_p = Dg.up_shared + ue0;
-            const float* const y1 = Dg.y1 + (size_t)g_r0 * F + f;
-            const float* const y2 = Dc.y2 + (size_t)c_r0 * F + f;
-            const float* const gu = (Dg.g_up != nullptr ? Dg.g_up : Dg.y1) + (size_t)g_r0 * F + f;    // (never NULL: a masked read)
-            const float gon = Dg.g_up != nullptr && !(A.dbg & 1) ? 1.0f : 0.0f;
             int bad = 0;
-            for (int p0 = gq; p0 < une; p0 += 4 * G::kNG) {
-                int64_t sj[4], si[4], sc[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int q = min(p0 + u * G::kNG, une - 1);
-                    sj[u] = src_p[q];
-                    si[u] = dst_p[q];
-                    sc[u] = cof_p[q];
-                }
-                int j[4], i[4], c[4];
-                float on[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t jj = sj[u] - g_r0, ii = si[u] - g_r0, cc = sc[u] - c_r0;
-                    const int ok = (int)((uint64_t)jj < (uint64_t)g_n) & (int)((uint64_t)ii < (uint64_t)g_n) &
-                                   (int)((uint64_t)cc < (uint64_t)c_n);
-                    const int live = (int)(p0 + u * G::kNG < une);
-                    bad |= live & (ok ^ 1);
-                    on[u] = (live & ok) ? gon : 0.0f;
-                    j[u] = ok ? (int)jj : 0;
-                    i[u] = ok ? (int)ii : 0;
-                    c[u] = ok ? (int)cc : 0;
-                }
-                float4 a[4], b[4], m[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    a[u] = *reinterpret_cast<const float4*>(y1 + (size_t)j[u] * F);
-                    b[u] = *reinterpret_cast<const float4*>(y2 + (size_t)c[u] * F);
-                    m[u] = *reinterpret_cast<const float4*>(gu + (size_t)i[u] * F);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float4 v;
-                    v.x = a[u].x + b[u].x > 0.f ? m[u].x * on[u] : 0.f;
-                    v.y = a[u].y + b[u].y > 0.f ? m[u].y * on[u] : 0.f;
-                    v.z = a[u].z + b[u].z > 0.f ? m[u].z * on[u] : 0.f;
-                    v.w = a[u].w + b[u].w > 0.f ? m[u].w * on[u] : 0.f;
-                    if (on[u] != 0.f) {          // (no atomics for absent entries: they would all meet on row 0)
-                        atomic_add4(gY + (size_t)j[u] * G::kYStride + f, v);
-                        atomic_add4(gY + (size_t)(R1 + c[u]) * G::kYStride + f, v);
-                    }
-                }
+            for (int p = tid; p < une4; p += kThreads) {
+                const int q = min(p, une - 1);
+                const int64_t jj = Dg.up_index[ue0 + q] - g_r0, ii = Dg.up_index[E + ue0 + q] - g_r0, cc = Dg.up_shared[ue0 + q] - c_r0;
+                const int ok = (int)((uint64_t)jj < (uint64_t)g_n) & (int)((uint64_t)ii < (uint64_t)g_n) & (int)((uint64_t)cc < (uint64_t)c_n);
+                const int live = (int)(p < une);
+                bad |= live & (ok ^ 1);
+                ej[p] = (live & ok) ? (int)jj : -1;                               // -1: matches no row
+                ei[p] = (live & ok) ? (int)ii : 0;
+                ec[p] = (live & ok) ? (int)cc : -1;
             }
             if (bad) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
+            for (int r = gq; r < g_n; r += G::kNG) {
+                *reinterpret_cast<float4*>(S + (size_t)r * G::kYStride + f) = *reinterpret_cast<const float4*>(Dg.y1 + (size_t)(g_r0 + r) * F + f);
+                if (have_gu)
+                    *reinterpret_cast<float4*>(T + (size_t)r * G::kYStride + f) = *reinterpret_cast<const float4*>(Dg.g_up + (size_t)(g_r0 + r) * F + f);
+            }
+            for (int r = gq; r < c_n; r += G::kNG)
+                *reinterpret_cast<float4*>(S + (size_t)(R1 + r) * G::kYStride + f) = *reinterpret_cast<const float4*>(Dc.y2 + (size_t)(c_r0 + r) * F + f);
         }
         __syncthreads();
-        // ---- 3. gY out (the weight-gradient GEMM reads it) and into the bf16 planes ------------------------------------
-        for (int r = gq; r < rows_pad; r += G::kNG) {
-            const float4 v = *reinterpret_cast<const float4*>(gY + (size_t)r * G::kYStride + f);
-            if (r < g_n) {
-                if (Dg.gy1 != nullptr && !(A.dbg & 8)) *reinterpret_cast<float4*>(Dg.gy1 + (size_t)(g_r0 + r) * F + f) = v;
-            } else if (r >= R1 && r - R1 < c_n) {
-                if (Dc.gy2 != nullptr && !(A.dbg & 8)) *reinterpret_cast<float4*>(Dc.gy2 + (size_t)(c_r0 + r - R1) * F + f) = v;
+        // ---- 2. every lane group OWNS the rows gq, gq + kNG, ... of gY1 | gY2 and walks the item's entries for each: those
+        //         whose source (gY1) or coface (gY2) is the row add their masked gradient, out of LDS, in entry order.  No
+        //         float atomics (the first form scattered with ds_add_f32: ~100 cycles per wave instruction, 31 us of a
+        //         56-us launch), no sort, deterministic; the walk is rows x entries compares -- a few hundred per lane group.
+        constexpr int kMaxOwn = (CWN_LAYER_GEMM_ROWS(F) + G::kNG - 1) / G::kNG;
+        float4 own[kMaxOwn];
+#pragma unroll
+        for (int k = 0; k < kMaxOwn; ++k) {
+            own[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int r = gq + k * G::kNG;
+            const bool is1 = r < g_n, is2 = r >= R1 && r - R1 < c_n;
+            if (have_gu && (is1 || is2) && !(A.dbg & 16)) {
+                const int* const key = is1 ? ej : ec;
+                const int want = is1 ? r : r - R1;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                // the lanes of the group test kG entries AT ONCE (one key each, a ballot gives the group its matches); only
+                // the matches -- a cell's degree, two or three -- are then walked, in entry order.  (Walked entry by entry
+                // the group paid an LDS round trip per four keys and a branch per key: 15 us of the launch.)
+                const int gsh = (lane / G::kG) * G::kG;                      // this group's bits of the wave's ballot
+                for (int e0 = 0; e0 < une4; e0 += G::kG) {
+                    const int e = e0 + gl;
+                    const int kv = e < une4 ? key[e] : -2;
+                    unsigned long long bal = __ballot(kv == want);
+                    unsigned m = (unsigned)((bal >> gsh) & (G::kG == 32 ? 0xffffffffull : 0xffffull));
+                    while (m != 0u) {
+                        const int q = e0 + __builtin_ctz(m);
+                        m &= m - 1u;
+                        const int j = ej[q], i = ei[q], c = ec[q];
+                        const float4 a = *reinterpret_cast<const float4*>(S + (size_t)j * G::kYStride + f);
+                        const float4 b = *reinterpret_cast<const float4*>(S + (size_t)(R1 + c) * G::kYStride + f);
+                        const float4 mm = *reinterpret_cast<const float4*>(T + (size_t)i * G::kYStride + f);
+                        acc.x += a.x + b.x > 0.f ? mm.x : 0.f;
+                        acc.y += a.y + b.y > 0.f ? mm.y : 0.f;
+                        acc.z += a.z + b.z > 0.f ? mm.z : 0.f;
+                        acc.w += a.w + b.w > 0.f ? mm.w : 0.f;
+                    }
+                }
+                own[k] = acc;
             }
-            uint2 ph, pm, pl;
-            cwn::split4(v, ph, pm, pl);
-            uint16_t* dst = planes + (size_t)r * G::kPlaneStride + f;
-            *reinterpret_cast<uint2*>(dst) = ph;
-            *reinterpret_cast<uint2*>(dst + plane) = pm;
-            *reinterpret_cast<uint2*>(dst + 2 * plane) = pl;
+        }
+        __syncthreads();                     // every group is done with S and T: the planes may overwrite T
+        // ---- 3. gY out (the weight-gradient GEMM reads it) and into the bf16 planes ------------------------------------
+#pragma unroll
+        for (int k = 0; k < kMaxOwn; ++k) {
+            const int r = gq + k * G::kNG;
+            if (r < rows_pad) {
+                const float4 v = own[k];
+                if (r < g_n) {
+                    if (Dg.gy1 != nullptr && !(A.dbg & 8)) *reinterpret_cast<float4*>(Dg.gy1 + (size_t)(g_r0 + r) * F + f) = v;
+                } else if (r >= R1 && r - R1 < c_n) {
+                    if (Dc.gy2 != nullptr && !(A.dbg & 8)) *reinterpret_cast<float4*>(Dc.gy2 + (size_t)(c_r0 + r - R1) * F + f) = v;
+                }
+                uint2 ph, pm, pl;
+                cwn::split4(v, ph, pm, pl);
+                uint16_t* dst = planes + (size_t)r * G::kPlaneStride + f;
+                *reinterpret_cast<uint2*>(dst) = ph;
+                *reinterpret_cast<uint2*>(dst + plane) = pm;
+                *reinterpret_cast<uint2*>(dst + 2 * plane) = pl;
+            }
         }
         __syncthreads();
         // ---- 4. dx_g += gY1 W[:, :F],  dx_{g+1} += gY2 W[:, F:] on the matrix cores ---------------------------------------

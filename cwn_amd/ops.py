@@ -1516,12 +1516,12 @@ def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tens
 
 
 # The backward of the propagate step as ONE launch over the forward's item table (cwn_layer_bwd_f32).  OFF: correct (tested
-# against float64 autograd), but 56 us per launch at the ZINC batch of 128 against ~34 us for the streaming backward it
-# replaces (transposed aggregation 13 + transposed-weight GEMM 16 + an add): 31 of the 56 are the fp32 LDS atomics that
-# scatter the masked gradients into gY1 | gY2 (~100 cycles per wave instruction, tools/ubench_layer_bwd.py), 8 the fp32
-# global atomics that collect dx from up to three workgroups.  What it needs to win: the item's entries bucket-sorted by
-# source and by coface in LDS (integer atomics, as the forward sorts by destination) instead of float atomics, and one
-# item per complex across all dimensions so that dx rows have ONE owner.  CWN_BLOCKED_BACKWARD=1 switches it on.
+# against float64 autograd and through whole training steps), and at the ZINC batch of 128 no faster than what it replaces:
+# 25 us per launch + the fill of dx against 13 (transposed aggregation) + 16 (transposed-weight GEMM) + an add; the
+# training step reads 0.997 ms with it and 1.001 without.  Of the 25: ~10 staging and launch, 6 the walk that gathers every
+# gY row's entries, 6 the fp32 global atomics that collect dx from up to three workgroups per row, 2 the matrix cores
+# (tools/ubench_layer_bwd.py).  To win it needs one item per complex over all dimensions, so that every dx row has a single
+# owner and is stored instead of added into a zeroed matrix.  CWN_BLOCKED_BACKWARD=1 switches it on.
 BLOCKED_BACKWARD = os.environ.get('CWN_BLOCKED_BACKWARD') == '1'
 
 

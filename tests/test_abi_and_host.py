@@ -94,7 +94,7 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_layer_pack_weights_many_f32(None, None, 128, None, 1, None) == 1
     assert lib.cwn_layer_pack_weights_t_many_f32(None, None, 128, None, 1, None) == 1
     assert lib.cwn_layer_bwd_f32(None, 1, 128, None, None, None) == 1
-    assert lib.cwn_layer_bwd_lds_bytes(128, 96) == 96 * 132 * 4 + 3 * 96 * 136 * 2 and lib.cwn_layer_bwd_lds_bytes(64, 256) == 0
+    assert lib.cwn_layer_bwd_lds_bytes(128, 96) == 96 * 132 * 4 + 3 * 96 * 136 * 2 + 3 * 1024 * 4 and lib.cwn_layer_bwd_lds_bytes(64, 256) == 0
     assert lib.cwn_layer_fused_f32(None, 1, 128, None, _ffi.LAYER_STORE_Y, None, None) == 1
     assert lib.cwn_layer_packed_weight_bytes(128) == 128 * 256 * 6 and lib.cwn_layer_packed_weight_bytes(96) == 0
     assert lib.cwn_layer_fused_lds_bytes(128, 96, 64) == 3 * 96 * 136 * 2 + 65 * 128 * 4 + 9648

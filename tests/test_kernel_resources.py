@@ -20,8 +20,7 @@ KNOWN_SPILLS = {'gemm_kernel<Lb0ELb0ELi128ELi2ELb0ELi2ELb0E>', 'gemm_kernel<Lb0E
                 # constants on top of the stationary weight fragments (26 registers in scratch, outside the MFMA loop)
                 'gemm_kernel<Lb1ELb0ELi128ELi4ELb1ELi2ELb1E>',
                 'gemm_kernel<Lb1ELb0ELi128ELi2ELb1ELi2ELb1E>',        # the same at 64 x 64 tiles (K = 128, N <= 64: no model of the reference has it)
-                'aggregate_kernel<Li4ELb0ELb1E>', 'aggregate_kernel<Li4ELb1ELb1E>',
-                'layer_bwd_kernel<Li128E>'}       # the blocked backward prototype (off by default, csrc/cwn_layer_bwd.hip): 8 registers
+                'aggregate_kernel<Li4ELb0ELb1E>', 'aggregate_kernel<Li4ELb1ELb1E>'}
 
 
 @pytest.fixture(scope='module')
