@@ -1953,13 +1953,15 @@ def test_narrow_feature_medium_rows_entry_parallel(F, op):
         torch.testing.assert_close(cpu(gr), O.scatter_rows(xi[src], dst, n_dst, red), rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize('dims', [(28,), (4,), (119, 5, 12, 12, 10, 6, 6, 2, 2), (5, 6, 2)])
-def test_embedding_sum_matches_torch_embedding(dims):
+@pytest.mark.parametrize('dims,N,H', [((28,), 3165, 64), ((4,), 3165, 64), ((119, 5, 12, 12, 10, 6, 6, 2, 2), 3165, 64),
+                                      ((5, 6, 2), 3165, 64), ((28,), 3341, 128), ((4,), 70, 128), ((60,), 1000, 256),
+                                      ((70,), 500, 128), ((28,), 333, 96)])
+def test_embedding_sum_matches_torch_embedding(dims, N, H):
     """Forward bit-identical to the sum of torch.nn.Embedding outputs (same order); backward equal
-    to embedding_backward up to fp32 re-association of the very long table rows."""
+    to embedding_backward up to fp32 re-association of the very long table rows (one small table at width 64 / 128 / 256:
+    the ballot kernel; everything else: the table-in-LDS kernel)."""
     from cwn_amd import ops
-    g = torch.Generator().manual_seed(sum(dims))
-    N, H = 3165, 64
+    g = torch.Generator().manual_seed(sum(dims) + N + H)
     tables = [torch.randn(d, H, generator=g).to(DEV).requires_grad_() for d in dims]
     ref_tables = [t.detach().clone().requires_grad_() for t in tables]
     idx = torch.stack([torch.randint(0, d, (N,), generator=g) for d in dims], 1).to(DEV)
