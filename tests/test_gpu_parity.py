@@ -1879,11 +1879,11 @@ def test_several_steps_behind_one_replay_take_the_same_steps():
     lb, sb, yb = run(False)
     assert len(la) == len(lb) == 4
     for a, b in zip(la, lb):
-        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (la, lb)
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (la, lb)
     # (parameter by parameter the two runs may differ by 2 lr after any step: a Linear bias in front of a BatchNorm has a
     # zero gradient up to rounding, and Adam normalises that noise to full-size steps -- which the network's output does
     # not see, nor do the normalised activations, while running_mean follows the bias; compared are the integer state and
-    # the per-step training losses, which agree to 2e-4)
+    # the per-step training losses, which agree to 1e-3: observed 1e-6 ... 1e-4, growing with the step)
     for k in sb:
         if not sb[k].dtype.is_floating_point:
             assert torch.equal(sa[k], sb[k]), k
