@@ -82,6 +82,28 @@ class ItemTable:
         return p
 
 
+class BwdItemTable:
+    """Item table of the OWNER form of the backward launch (`cwn_layer_bwd_own_f32`, include/cwn_hip.h): one record per
+    (range of complexes, dimension whose rows the workgroup owns), built by `cwn_layer_bwd_items_build`."""
+
+    def __init__(self, table: np.ndarray, lds_bytes: int, cells_end, up_end, b_end, device):
+        self.host = table
+        self.n_items = int(table.shape[0])
+        self.items = torch.from_numpy(table)
+        if device is not None:
+            self.items = self.items.to(device)
+        self.lds_bytes = int(lds_bytes)
+        self.cells_end, self.up_end, self.b_end = cells_end, up_end, b_end
+        self.device = device
+
+    def c_plan(self):
+        from . import _ffi
+        p = _ffi.LayerBwdPlan(items=self.items.data_ptr(), n_items=self.n_items, lds_bytes=self.lds_bytes)
+        for d in range(len(self.cells_end)):
+            p.cells_end[d], p.up_end[d], p.b_end[d] = int(self.cells_end[d]), int(self.up_end[d]), int(self.b_end[d])
+        return p
+
+
 class MixedTable:
     """Two item tables over complementary subsets of a batch's complexes -- `parts[0]` in the two-per-CU form (the
     complexes that fit its caps), `parts[1]` in the 16-wave form (the rest, BIG records included) -- served by two
@@ -228,6 +250,43 @@ class BlockPlan:
                     res = MixedTable([t1, t0], int(unfit.sum()))
             self._tables[key] = res
         return self._tables[key]
+
+    def bwd_items(self, F: int, has_up: Sequence[bool], has_b: Optional[Sequence[bool]] = None) -> Optional[BwdItemTable]:
+        """The item table of the owner form of the backward launch for feature width F (same meaning of `has_up` /
+        `has_b` as `items`), or None when some complex is beyond a workgroup (the caller keeps the streaming backward)."""
+        from . import _ffi
+        if has_b is None:
+            has_b = [p is not None for p in self.b_ptr]
+        key = ('bwd', F, tuple(bool(h) for h in has_up), tuple(bool(h) and self.b_ptr[d] is not None for d, h in enumerate(has_b)))
+        if key in self._tables:
+            return self._tables[key]
+        res = None
+        C = self.C
+        ok = C > 0 and all(not key[2][d] or (d + 1 < self.n_dims and self.up_ptr[d] is not None) for d in range(self.n_dims))
+        if ok:
+            sizes = _ffi.LayerSizes(n_complexes=C, n_dims=self.n_dims)
+            keep = []
+            for d in range(self.n_dims):
+                sizes.has_up[d] = 1 if key[2][d] else 0
+                for name, arr in (('cell_ptr', self.cell_ptr[d]), ('up_ptr', self.up_ptr[d]),
+                                  ('b_ptr', self.b_ptr[d] if key[3][d] else None)):
+                    if arr is not None:
+                        a = np.ascontiguousarray(arr, dtype=np.int64)
+                        keep.append(a)
+                        getattr(sizes, name)[d] = a.ctypes.data
+            cap_items = self.n_dims * C
+            table = np.zeros((cap_items, _ffi.LAYER_BWD_ITEM_INTS), dtype=np.int32)
+            plan = _ffi.LayerBwdPlan()
+            n = int(_ffi.lib().cwn_layer_bwd_items_build(sizes, F, table.ctypes.data, cap_items, plan))
+            if n < 0 and n != _ffi.LAYER_ITEMS_TOO_LARGE:
+                raise _ffi.CwnError(f'cwn_layer_bwd_items_build failed ({n})')
+            if n > 0:
+                res = BwdItemTable(np.ascontiguousarray(table[:n]), int(plan.lds_bytes),
+                                   [int(plan.cells_end[d]) for d in range(self.n_dims)],
+                                   [int(plan.up_end[d]) for d in range(self.n_dims)],
+                                   [int(plan.b_end[d]) for d in range(self.n_dims)], self.device)
+        self._tables[key] = res
+        return res
 
     def _build(self, F: int, has_up, has_b, variant: int = 0, allow_big: bool = False, skip=None, unfit_out=None) -> Optional[ItemTable]:
         """cwn_layer_items_build (csrc/cwn_blockplan.cpp, host C++): the greedy cut under the kernel's caps and

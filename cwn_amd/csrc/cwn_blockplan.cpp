@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <vector>
 #include "../../include/cwn_hip.h"
+#include "cwn_layer_bwd_own.h"
 
 namespace {
 
@@ -263,4 +264,122 @@ extern "C" int64_t cwn_layer_items_build(const cwn_layer_sizes* in, int32_t F, i
     plan->items = keep_items;
     plan->csr_cache = keep_cache;
     return pb.n_items;
+}
+
+// ---- the OWNER form of the backward launch (include/cwn_hip.h: cwn_layer_bwd_own_f32) ------------------------------------
+// Same sets as the forward (a top dimension without upper adjacency rides with the one below), one greedy cut per set
+// under the limits of the kernel; the LDS of an item follows from its record (cwn_layer_bwd_own.h).
+extern "C" int64_t cwn_layer_bwd_items_build(const cwn_layer_sizes* in, int32_t F, int32_t* items, int64_t cap_items,
+                                             cwn_layer_bwd_plan* plan) {
+    namespace bo = cwn_bwd_own;
+    if (in == nullptr || plan == nullptr || (F != 64 && F != 128) || in->n_dims < 1 || in->n_dims > CWN_LAYER_MAX_DIMS ||
+        in->n_complexes < 0 || (cap_items > 0 && items == nullptr))
+        return CWN_LAYER_ITEMS_BAD_ARG;
+    const int64_t C = in->n_complexes;
+    if (C == 0) return 0;
+    auto prefix_sum = [C](const int64_t* p) {
+        if (p[0] != 0) return false;
+        for (int64_t c = 0; c < C; ++c)
+            if (p[c + 1] < p[c]) return false;
+        return p[C] <= INT32_MAX;
+    };
+    for (int d = 0; d < in->n_dims; ++d) {
+        if (in->cell_ptr[d] == nullptr || !prefix_sum(in->cell_ptr[d])) return CWN_LAYER_ITEMS_BAD_ARG;
+        if (in->has_up[d] && (d + 1 >= in->n_dims || in->up_ptr[d] == nullptr)) return CWN_LAYER_ITEMS_BAD_ARG;
+        if (in->up_ptr[d] != nullptr && !prefix_sum(in->up_ptr[d])) return CWN_LAYER_ITEMS_BAD_ARG;
+        if (in->b_ptr[d] != nullptr && !prefix_sum(in->b_ptr[d])) return CWN_LAYER_ITEMS_BAD_ARG;
+    }
+    Set sets[CWN_LAYER_MAX_DIMS];
+    const int n_sets = make_sets(*in, sets);
+    const int64_t gmax = std::max<int64_t>(1, C / kTargetItems);
+    constexpr int kI = CWN_LAYER_BWD_ITEM_INTS;
+    std::vector<int32_t> out, recs;
+    std::vector<int64_t> weight, order;
+    int64_t max_lds = 0;
+    auto span = [](const int64_t* p, int64_t a, int64_t b) { return p ? p[b] - p[a] : (int64_t)0; };
+    for (int s_ = 0; s_ < n_sets; ++s_) {
+        const int d = sets[s_].tasks[0];
+        const bool top = sets[s_].n_tasks == 2, pa = in->has_up[d] != 0, pb = d > 0 && in->has_up[d - 1] != 0;
+        const bool above = d + 1 < in->n_dims;
+        const int64_t* upa = pa ? in->up_ptr[d] : nullptr;
+        const int64_t* upb = pb ? in->up_ptr[d - 1] : nullptr;
+        const int64_t* bnd = above ? in->b_ptr[d + 1] : nullptr;
+        const int flags = (pa ? bo::F_PA : 0) | (pb ? bo::F_PB : 0) | (top ? bo::F_TOP : 0);
+        auto cells = [&](int dd, int64_t a, int64_t b) { return in->cell_ptr[dd][b] - in->cell_ptr[dd][a]; };
+        // what an item over complexes [a, b) needs; false: beyond a limit
+        auto fits = [&](int64_t a, int64_t b, bo::Layout* Lout) {
+            const int64_t n_o = cells(d, a, b), n_a = above ? cells(d + 1, a, b) : 0, n_b = pb ? cells(d - 1, a, b) : 0;
+            const int64_t ea = span(upa, a, b), eb = span(upb, a, b), bd = span(bnd, a, b);
+            if (n_o > bo::own_rows_cap(F) || (top && n_a > bo::top_rows_cap(F))) return false;
+            if (ea > CWN_LAYER_MAX_ENTRIES || eb > CWN_LAYER_MAX_ENTRIES || bd > CWN_LAYER_MAX_ENTRIES) return false;
+            if (n_a > 4096 || n_b > 4096) return false;                       // (keeps the layout arithmetic far inside int32)
+            const bool need_a = pa || top || bd > 0;
+            const bo::Layout L = bo::layout(F, flags, (int)n_o, need_a ? (int)n_a : 0, (int)n_b, (int)ea, (int)eb, (int)bd);
+            if (Lout != nullptr) *Lout = L;
+            return L.total <= 160 * 1024;
+        };
+        recs.clear();
+        weight.clear();
+        for (int64_t c0 = 0; c0 < C;) {
+            int64_t c1 = c0;
+            while (c1 < C && c1 - c0 < gmax && fits(c0, c1 + 1, nullptr)) ++c1;
+            if (c1 == c0) return CWN_LAYER_ITEMS_TOO_LARGE;                   // not even this one complex fits a workgroup
+            bo::Layout L;
+            fits(c0, c1, &L);
+            const int64_t n_o = cells(d, c0, c1), n_a = above ? cells(d + 1, c0, c1) : 0;
+            const int64_t ea = span(upa, c0, c1), eb = span(upb, c0, c1), bd = span(bnd, c0, c1);
+            if (n_o == 0) {
+                // cells of d+1 (or entries) without cells of d: not a cell complex
+                if ((top && n_a > 0) || ea > 0 || eb > 0 || bd > 0) return CWN_LAYER_ITEMS_TOO_LARGE;
+                c0 = c1;
+                continue;                                                     // nothing to write
+            }
+            const bool need_a = pa || top || bd > 0;
+            int32_t r[kI] = {0};
+            r[bo::R_FLAGS] = flags | (s_ << 8);
+            r[bo::R_DIM] = d;
+            r[bo::R_OWN_R0] = (int32_t)in->cell_ptr[d][c0];
+            r[bo::R_OWN_N] = (int32_t)n_o;
+            if (need_a) {
+                r[bo::R_ABOVE_R0] = (int32_t)in->cell_ptr[d + 1][c0];
+                r[bo::R_ABOVE_N] = (int32_t)n_a;
+            }
+            if (pb) {
+                r[bo::R_BELOW_R0] = (int32_t)in->cell_ptr[d - 1][c0];
+                r[bo::R_BELOW_N] = (int32_t)cells(d - 1, c0, c1);
+                r[bo::R_UPB_E0] = (int32_t)upb[c0];
+                r[bo::R_UPB_NE] = (int32_t)eb;
+            }
+            if (pa) {
+                r[bo::R_UPA_E0] = (int32_t)upa[c0];
+                r[bo::R_UPA_NE] = (int32_t)ea;
+            }
+            if (bd > 0) {
+                r[bo::R_BND_E0] = (int32_t)bnd[c0];
+                r[bo::R_BND_NE] = (int32_t)bd;
+            }
+            r[bo::R_LDS_BYTES] = L.total;
+            max_lds = std::max<int64_t>(max_lds, L.total);
+            recs.insert(recs.end(), r, r + kI);
+            weight.push_back(n_o + n_a + ea + eb);
+            c0 = c1;
+        }
+        const int64_t n = (int64_t)weight.size();
+        order.resize(n);
+        for (int64_t i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return weight[a] > weight[b]; });
+        for (int64_t i = 0; i < n; ++i) out.insert(out.end(), recs.begin() + order[i] * kI, recs.begin() + (order[i] + 1) * kI);
+    }
+    const int64_t n_items = (int64_t)(out.size() / kI);
+    if (n_items > cap_items) return CWN_LAYER_ITEMS_BAD_ARG;
+    std::copy(out.begin(), out.end(), items);
+    plan->n_items = n_items;
+    plan->lds_bytes = max_lds;
+    for (int d = 0; d < CWN_LAYER_MAX_DIMS; ++d) {
+        const bool on = d < in->n_dims;
+        plan->cells_end[d] = on ? in->cell_ptr[d][C] : 0;
+        plan->up_end[d] = on && in->has_up[d] && in->up_ptr[d] ? in->up_ptr[d][C] : 0;
+        plan->b_end[d] = on && d > 0 && in->b_ptr[d] ? in->b_ptr[d][C] : 0;
+    }
+    return n_items;
 }

@@ -755,7 +755,11 @@ class SparseCINConv(torch.nn.Module):
             csr.check_errors(dev)
             plan.validated = True
         self.blocked_reason = None
-        return ys, outs, (dims, table, ydims)       # (the last: what the blocked BACKWARD launch needs, ops._GemmAggregate)
+        bwd_table = None
+        if ops.BLOCKED_BACKWARD == 2:               # the owner form of the backward launch cuts a table of its own
+            bwd_table = plan.bwd_items(F, [D.up_index is not None and D.up_index.size(1) > 0 for D in dims],
+                                       [D.b_index is not None for D in dims])
+        return ys, outs, (dims, table, ydims, bwd_table)    # (the last: what the blocked BACKWARD launch needs, ops._GemmAggregate)
 
     def _blocked_still_valid(self, ent, cochain_params) -> bool:
         """The per-call part of `_blocked_args`: autograd state, feature tensors, lazy attributes, and the

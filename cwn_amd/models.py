@@ -176,7 +176,7 @@ class _SparseCINStack(torch.nn.Module):
             ws = [lvl.msg_up_nn[1].weight for conv in self.convs for lvl in getattr(conv, 'mp_levels', [])
                   if getattr(lvl, '_up_kind', lambda: None)() == 'cat_linear_relu' and lvl.msg_up_nn[1].weight.is_cuda]
             if ws:
-                ops.pack_layer_weights_many(ws, transposed=ops.BLOCKED_BACKWARD)
+                ops.pack_layer_weights_many(ws, transposed=bool(ops.BLOCKED_BACKWARD))
         for c, conv in enumerate(self.convs):
             params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
             xs = conv(*params, start_to_process=0)

@@ -1156,7 +1156,10 @@ def _blocked_backward_impl(ctx, gs, ys, g_tensors, g_needs, s_tensors, s_needs):
     info = ctx.blocked
     if info is None or not BLOCKED_BACKWARD:
         return None
-    dims, table, ydims = info
+    dims, table, ydims = info[:3]
+    bwd_table = info[3] if len(info) > 3 else None
+    if BLOCKED_BACKWARD == 2 and bwd_table is None:
+        return None                        # some complex is beyond the owner form's workgroup: the streaming backward
     n, ng = len(dims), ctx.ng
     if len(ctx.streams) != 2 * n or len(gs) != 2 * n:
         return None
@@ -1173,7 +1176,8 @@ def _blocked_backward_impl(ctx, gs, ys, g_tensors, g_needs, s_tensors, s_needs):
     ys_of = [[None, None] for _ in range(n)]
     for gi, (d, which) in enumerate(ydims):
         ys_of[d][0 if which == 'y1' else 1] = ys[gi]
-    res = layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[2 * d], gs[2 * d + 1]) for d in range(n)], wt_of)
+    res = layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[2 * d], gs[2 * d + 1]) for d in range(n)], wt_of,
+                         bwd_table=bwd_table if BLOCKED_BACKWARD == 2 else None)
     if res is None:
         return None
     dxs, gys = res
@@ -1515,30 +1519,36 @@ def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tens
     return outs
 
 
-# The backward of the propagate step as ONE launch over the forward's item table (cwn_layer_bwd_f32).  OFF: correct (tested
-# against float64 autograd and through whole training steps), and at the ZINC batch of 128 no faster than what it replaces:
-# 25 us per launch + the fill of dx against 13 (transposed aggregation) + 16 (transposed-weight GEMM) + an add; the
-# training step reads 0.997 ms with it and 1.001 without.  Of the 25: ~10 staging and launch, 6 the walk that gathers every
-# gY row's entries, 6 the fp32 global atomics that collect dx from up to three workgroups per row, 2 the matrix cores
-# (tools/ubench_layer_bwd.py).  To win it needs one item per complex over all dimensions, so that every dx row has a single
-# owner and is stored instead of added into a zeroed matrix.  CWN_BLOCKED_BACKWARD=1 switches it on.
-BLOCKED_BACKWARD = os.environ.get('CWN_BLOCKED_BACKWARD') == '1'
+# The backward of the propagate step as ONE launch.  Two forms:
+#   2 (default) the OWNER form (cwn_layer_bwd_own_f32, csrc/cwn_layer_bwd_own.hip) over a table of its own
+#     (blockplan.BlockPlan.bwd_items): an item owns the rows of one dimension for a range of complexes and gathers
+#     everything they receive -- one writer per dx row, plain stores, no fill, deterministic.  18.6 us per launch at the
+#     ZINC batch of 128 against ~30 for what it replaces (transposed aggregation + transposed-weight GEMM + an add); the
+#     training step 0.993 -> 0.948 ms.  A batch with a complex beyond a workgroup keeps the streaming backward.
+#   1 the first, ATOMIC form (cwn_layer_bwd_f32) over the forward's item table: a dx row receives pieces from up to three
+#     workgroups through fp32 atomics onto a zeroed matrix -- 25 us + the fill, no gain over the streaming path; kept for
+#     the comparison (tools/ubench_layer_bwd.py).
+#   0 the streaming backward (transposed CSR aggregation + GEMM).
+BLOCKED_BACKWARD = int(os.environ.get('CWN_BLOCKED_BACKWARD', '2') or 0)
+BLOCKED_BACKWARD_LAUNCHES = [0, 0]         # launches of the atomic / owner form so far (tests: the path that ran)
 
 
-def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of) -> Optional[Tuple[List[Tensor], List]]:
+def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of, bwd_table=None) -> Optional[Tuple[List[Tensor], List]]:
     """cwn_layer_bwd_f32: the backward of one propagate step over the item table of its forward launch.  dims: the
     LayerDim list of the forward; ys_of[d] = (Y1_d or None, Y2 stored at dimension d or None); gs_of[d] = (dL/d out_up_d,
     dL/d out_b_d), None = zero; wt_of[d] = transposed packed weight or None.  Returns ([dx_d], [(gY1_d, gY2 at d)]) or
     None when the launch does not apply (a table in another form, an item beyond the backward's LDS)."""
-    if getattr(table, 'variant', 0) != 0 or getattr(table, 'n_big', 0):
+    own = bwd_table is not None            # the owner form (cwn_layer_bwd_own_f32): its own table, dx stored once
+    if not own and (getattr(table, 'variant', 0) != 0 or getattr(table, 'n_big', 0)):
         return None
     n, F = len(dims), int(dims[0].x.size(1))
     L = _ffi.lib()
-    if int(L.cwn_layer_bwd_lds_bytes(F, int(table.max_rows))) == 0:
+    if not own and int(L.cwn_layer_bwd_lds_bytes(F, int(table.max_rows))) == 0:
         return None
     dev = dims[0].x.device
     rows = [int(D.x.size(0)) for D in dims]
-    dx_buf = torch.zeros(sum(rows), F, dtype=torch.float32, device=dev)          # every piece is ADDED: one fill for the layer
+    # atomic form: every piece is ADDED (one fill for the layer); owner form: every row is written once
+    dx_buf = (torch.empty if own else torch.zeros)(sum(rows), F, dtype=torch.float32, device=dev)
     dxs = list(dx_buf.split(rows))
     arr = (_ffi.LayerBwdDim * n)()
     gys, keep = [], []
@@ -1562,8 +1572,14 @@ def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of) -> Opti
                                   eps1=_ffi.ptr(e1), eps2=_ffi.ptr(e2), dx=dxs[d].data_ptr(), gy1=_ffi.ptr(gy1), gy2=_ffi.ptr(gy2),
                                   n_cells=rows[d], e_up=e_up, n_b=n_b)
     from .csr import _err_flag
+    if own:
+        _ffi.check(L.cwn_layer_bwd_own_f32(arr, n, F, bwd_table.c_plan(), _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)),
+                   'cwn_layer_bwd_own_f32')
+        BLOCKED_BACKWARD_LAUNCHES[1] += 1
+        return dxs, gys
     plan = table.c_plan(with_cache=False)
     _ffi.check(L.cwn_layer_bwd_f32(arr, n, F, plan, _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)), 'cwn_layer_bwd_f32')
+    BLOCKED_BACKWARD_LAUNCHES[0] += 1
     return dxs, gys
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 15
+#define CWN_ABI_VERSION 16
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -373,6 +373,42 @@ typedef struct cwn_layer_bwd_dim {
 size_t cwn_layer_bwd_lds_bytes(int32_t F, int32_t max_gemm_rows);
 int cwn_layer_bwd_f32(const cwn_layer_bwd_dim* dims_host, int n_dims, int32_t F, const cwn_layer_plan* plan_host,
                       int32_t* err_flag, cwn_stream_t stream);
+/* The OWNER form of the same backward (csrc/cwn_layer_bwd_own.hip): every row of dx has ONE writer.  An item is a
+ * contiguous range of complexes for one dimension d whose cells it OWNS; its workgroup gathers everything those rows
+ * receive -- gY1_d over the entries of up_index_d that name the row as source, the gradient of Y2 at d over the entries of
+ * up_index_{d-1} that name it as coface, the boundary transposes over the entries of b_index_{d+1} that name it as
+ * boundary cell -- multiplies [gY1_d | gY2] by the transposed message weights of d and d-1 on the matrix cores and
+ * stores dx_d = products + self terms + transposes ONCE: no atomics, no zeroed output, sums in entry order
+ * (deterministic).  A top dimension without upper adjacency rides with the dimension below it (its rows are owned by
+ * the same item: third product + self terms), exactly as in the forward's sets.  Record (int32 x 16):
+ *   [0] flags   bit 0 (A): dimension d reduces an upper adjacency (entries [8], [9] of up_index_d; product gY1_d W_d[:, :F])
+ *               bit 1 (B): dimension d-1 does (entries [10], [11] of up_index_{d-1}; product gY2 W_{d-1}[:, F:])
+ *               bit 2 (TOP): the item also owns the cells of d+1 (product gY2_{d+1} W_d[:, F:], self terms); bits 8-9: set
+ *   [1] d       [2] first owned cell  [3] owned cells
+ *   [4] first cell of d+1  [5] cells of d+1 (coface rows of A, sources of the transposes, the TOP rows; 0: none needed)
+ *   [6] first cell of d-1  [7] cells of d-1 (0 unless B)
+ *   [8] first entry of up_index_d      [9] entries (0 unless A)
+ *   [10] first entry of up_index_{d-1} [11] entries (0 unless B)
+ *   [12] first entry of b_index_{d+1}  [13] entries (0: no transposes)
+ *   [14] LDS bytes of the item (csrc/cwn_layer_bwd_own.h: the layout follows from the record)   [15] 0
+ * Limits per item: owned cells <= CWN_LAYER_GEMM_ROWS(F), TOP cells <= 1024 / (F / 4), each entry list <=
+ * CWN_LAYER_MAX_ENTRIES, LDS <= 160 KiB.  The table is built on the host from the same prefix sums as the forward's
+ * (cwn_layer_sizes; allow_big / skip / unfit are ignored: a complex beyond the limits gives CWN_LAYER_ITEMS_TOO_LARGE
+ * and the caller keeps the streaming backward).  dims: as for cwn_layer_bwd_f32, except that dx needs no zeroing. */
+#define CWN_LAYER_BWD_ITEM_INTS 16
+typedef struct cwn_layer_bwd_plan {
+    const int32_t* items;                       /* device int32 [n_items][CWN_LAYER_BWD_ITEM_INTS] */
+    int64_t n_items;
+    int64_t lds_bytes;                          /* dynamic LDS of the launch = the largest item */
+    int64_t cells_end[CWN_LAYER_MAX_DIMS];      /* as in cwn_layer_plan: what the table addresses */
+    int64_t up_end[CWN_LAYER_MAX_DIMS];
+    int64_t b_end[CWN_LAYER_MAX_DIMS];
+} cwn_layer_bwd_plan;
+struct cwn_layer_sizes;
+int64_t cwn_layer_bwd_items_build(const struct cwn_layer_sizes* sizes_host, int32_t F, int32_t* items_host, int64_t cap_items,
+                                  cwn_layer_bwd_plan* plan_host);
+int cwn_layer_bwd_own_f32(const cwn_layer_bwd_dim* dims_host, int n_dims, int32_t F, const cwn_layer_bwd_plan* plan_host,
+                          int32_t* err_flag, cwn_stream_t stream);
 /* The item table, built on the HOST from the per-complex prefix sums the reference's collate keeps (`ptr`:
  * data/complex.py:344, 432; `__slices__`: :349-394): contiguous ranges of complexes per set, greedily under the
  * limits above, with ONE launch's LDS split between staged rows and boundary sources so that the items are as

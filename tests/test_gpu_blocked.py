@@ -619,8 +619,9 @@ def test_mixed_launch_two_per_cu_form_plus_16_wave_form():
         assert torch.equal(s2, p), i
 
 
-@pytest.mark.parametrize('kind,n,F,blocked_bwd', [('zinc', 64, 128, False), ('zinc', 300, 128, False), ('molhiv', 96, 64, False),
-                                                  ('zinc', 64, 128, True), ('zinc', 20, 64, True)])
+@pytest.mark.parametrize('kind,n,F,blocked_bwd', [('zinc', 64, 128, 0), ('zinc', 300, 128, 0), ('molhiv', 96, 64, 0),
+                                                  ('zinc', 64, 128, 1), ('zinc', 20, 64, 1),
+                                                  ('zinc', 64, 128, 2), ('zinc', 300, 128, 2), ('molhiv', 96, 64, 2)])
 def test_training_forward_through_the_blocked_kernel(kind, n, F, blocked_bwd):
     """CWN_LAYER_STORE_Y: with autograd on, the propagate step runs as the blocked launch, leaves Y1 / Y2 for the backward
     pass (ops._GemmAggregate) and gives the gradients of the two-kernel path.  At F = 128 outputs and the stored products
@@ -637,9 +638,11 @@ def test_training_forward_through_the_blocked_kernel(kind, n, F, blocked_bwd):
         captured['pre'] = precomputed
         return orig(specs, make_streams, precomputed=precomputed)
 
+    prev_bwd = ops.BLOCKED_BACKWARD
+
     def run(flag):
         layers.BLOCKED_TRAIN_FORWARD = flag
-        ops.BLOCKED_BACKWARD = blocked_bwd and flag      # (the one-launch backward prototype, csrc/cwn_layer_bwd.hip: off by default)
+        ops.BLOCKED_BACKWARD = blocked_bwd if flag else 0      # (the one-launch backward: 1 atomic form, 2 owner form)
         ops.gemm_aggregate = spy
         if blocked_bwd and flag:
             ops.pack_layer_weights_many([conv.mp_levels[d].msg_up_nn[1].weight for d in range(2)], transposed=True)
@@ -652,10 +655,13 @@ def test_training_forward_through_the_blocked_kernel(kind, n, F, blocked_bwd):
             return outs, xin, {k: v.grad.clone() for k, v in conv.named_parameters() if v.grad is not None}, captured.get('pre')
         finally:
             layers.BLOCKED_TRAIN_FORWARD = True
-            ops.BLOCKED_BACKWARD = False
+            ops.BLOCKED_BACKWARD = prev_bwd
             ops.gemm_aggregate = orig
 
+    before = list(ops.BLOCKED_BACKWARD_LAUNCHES)
     outs1, x1, g1, pre1 = run(True)
+    if blocked_bwd:
+        assert ops.BLOCKED_BACKWARD_LAUNCHES[blocked_bwd - 1] == before[blocked_bwd - 1] + 1, 'the blocked backward did not run'
     outs0, x0, g0, pre0 = run(False)
     assert pre1 is not None and pre0 is None, 'the training forward did not take the blocked kernel'
     for a, c in zip(outs1, outs0):
@@ -738,10 +744,13 @@ def _propagate_reference_backward(conv, b, gs, F):
     return [x.grad for x in xs], [None if y is None else y.grad for y in Y1], [None if y is None else y.grad for y in Y2]
 
 
-@pytest.mark.parametrize('kind,n,F,eps', [('zinc', 64, 128, 0.0), ('zinc', 128, 128, 0.3), ('zinc', 9, 128, 0.0), ('zinc', 40, 64, 0.2)])
-def test_blocked_backward_launch_vs_float64_autograd(kind, n, F, eps):
-    """cwn_layer_bwd_f32 (ops.layer_backward) over the item table of the forward launch: dx of every dimension and the
-    gradients of the stored products against float64 autograd of the plain restatement."""
+@pytest.mark.parametrize('form', ['atomic', 'own'])
+@pytest.mark.parametrize('kind,n,F,eps', [('zinc', 64, 128, 0.0), ('zinc', 128, 128, 0.3), ('zinc', 9, 128, 0.0), ('zinc', 40, 64, 0.2),
+                                          ('zinc', 300, 128, 0.1), ('molhiv', 200, 64, 0.0)])
+def test_blocked_backward_launch_vs_float64_autograd(kind, n, F, eps, form):
+    """cwn_layer_bwd_f32 (ops.layer_backward) over the item table of the forward launch, and cwn_layer_bwd_own_f32 over
+    the owner table (one writer per row; dx is handed over UNINITIALISED -- filled with NaN here): dx of every dimension
+    and the gradients of the stored products against float64 autograd of the plain restatement."""
     from cwn_amd import layers, ops, _ffi
     b = _batch(kind, n, F, seed=31)
     conv = _conv(F, seed=32, eps=eps).train()
@@ -749,7 +758,14 @@ def test_blocked_backward_launch_vs_float64_autograd(kind, n, F, eps):
     args = conv._blocked_args(params, 0, training=True)
     assert not isinstance(args, str), args
     dims, plan, table, key = args
-    assert table.variant == 0 and not table.n_big
+    if table.variant == 'mixed' or table.n_big:
+        pytest.skip('the forward of this batch is not one plain launch')
+    if form == 'atomic' and table.variant != 0:
+        pytest.skip('the atomic form runs over the 16-wave table only')
+    bwd_table = None
+    if form == 'own':
+        bwd_table = plan.bwd_items(F, [D.up_index is not None and D.up_index.size(1) > 0 for D in dims], [D.b_index is not None for D in dims])
+        assert bwd_table is not None
     rows = [int(D.x.size(0)) for D in dims]
     ys_of = [[None, None] for _ in range(3)]
     for d in range(2):
@@ -763,7 +779,11 @@ def test_blocked_backward_launch_vs_float64_autograd(kind, n, F, eps):
     ws = [conv.mp_levels[d].msg_up_nn[1].weight for d in range(2)]
     ops.pack_layer_weights_many(ws, transposed=True)
     wt_of = [ops.packed_layer_weight_t(ws[0]), ops.packed_layer_weight_t(ws[1]), None]
-    got = ops.layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[2 * d], gs[2 * d + 1]) for d in range(3)], wt_of)
+    if form == 'own':                  # whatever the allocator hands out next: NaN (the launch must write every row)
+        junk = torch.full((sum(rows) * 3, F), float('nan'), device=DEV)
+        del junk
+    got = ops.layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[2 * d], gs[2 * d + 1]) for d in range(3)], wt_of,
+                             bwd_table=bwd_table)
     assert got is not None
     from cwn_amd import csr
     csr.check_errors(DEV)

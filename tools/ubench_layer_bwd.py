@@ -1,6 +1,8 @@
-"""The blocked backward launch (cwn_layer_bwd_f32) alone on the ZINC batch, graph-replayed, under its debug knobs
-(CWN_LBWD_DBG: 1 no entry scatter, 2 no MFMA / product atomics, 4 no self terms / boundary transposes, 8 no gY store).
-usage: ubench_layer_bwd.py [batch] [F]"""
+"""The blocked backward launch alone on the ZINC batch, graph-replayed, under its debug knobs: the atomic form
+(cwn_layer_bwd_f32; CWN_LBWD_DBG: 1 no entry scatter, 2 no MFMA / product atomics, 4 no self terms / boundary transposes,
+8 no gY store) or, with a third argument `own`, the owner form (cwn_layer_bwd_own_f32; CWN_LBWD_DBG: 1 no entry walk,
+2 no matrix cores, 4 no gY store).
+usage: ubench_layer_bwd.py [batch] [F] [own]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +13,7 @@ from cwn_amd.synthetic import zinc_like_complexes
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+OWN = len(sys.argv) > 3 and sys.argv[3] == 'own'
 torch.manual_seed(0)
 conv = SparseCINConv(F, F, F, None, None, None, None, max_dim=2, hidden=F, act_module=torch.nn.ReLU, layer_dim=F,
                      use_coboundaries=True).to(dev).train()
@@ -29,7 +32,9 @@ gs = [torch.randn_like(o) for o in outs]
 ws = [conv.mp_levels[d].msg_up_nn[1].weight for d in range(2)]
 ops.pack_layer_weights_many(ws, transposed=True)
 wt_of = [ops.packed_layer_weight_t(ws[0]), ops.packed_layer_weight_t(ws[1]), None]
-go = lambda: ops.layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[2 * d], gs[2 * d + 1]) for d in range(3)], wt_of)
+bwd_table = plan.bwd_items(F, [True, True, False], [D.b_index is not None for D in dims]) if OWN else None
+assert not OWN or bwd_table is not None
+go = lambda: ops.layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[2 * d], gs[2 * d + 1]) for d in range(3)], wt_of, bwd_table=bwd_table)
 go(); torch.cuda.synchronize()
 s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
@@ -45,4 +50,5 @@ e0.record()
 for _ in range(3):
     g.replay()
 e1.record(); torch.cuda.synchronize()
-print(f'dbg={os.environ.get("CWN_LBWD_DBG", "0")}: {1e3 * e0.elapsed_time(e1) / 60:.2f} us per (fill + launch), {table.n_items} items')
+print(f'{"own" if OWN else "atomic"} dbg={os.environ.get("CWN_LBWD_DBG", "0")}: {1e3 * e0.elapsed_time(e1) / 60:.2f} us per ({"alloc" if OWN else "fill"} + launch), '
+      f'{bwd_table.n_items if OWN else table.n_items} items' + (f', {bwd_table.lds_bytes} B of LDS' if OWN else ''))
