@@ -1,0 +1,306 @@
+// cwn_stage.hip -- ONE stage of the update / combine networks of a SparseCIN layer in TRAINING mode, all dimensions and
+// both branches in one launch:
+//
+//     Z = prologue([X | X2]) W^T + b,     per-column sum / sum of squares of Z per 32-row band (fp64)
+//
+// (mp/layers.py:193-199, 303-325: Linear -> BatchNorm(train) -> ReLU; the prologue is the BatchNorm apply + ReLU of the
+// stage before, cwn_bn_finalize_f32 turns the band sums into the next prologue's affine.)  Training cannot chain the
+// stages inside a workgroup the way cwn_update_mlp_f32 does -- batch statistics are a reduction over ALL rows between any
+// two of them -- so a stage stays a launch; this is the launch with the inference kernel's arithmetic: 32 (F = 128) or
+// 64 (F = 64) rows per workgroup, the tile split ONCE per element into bf16 planes in LDS (cwn_split.h: exact three-way
+// split, six MFMAs per product term, fp32 accuracy), the weight pre-split and packed in fragment order once per optimizer
+// step (cwn_update_mlp_pack_weights_many_f32) and streamed 1 KiB per load instruction into registers, eight waves = eight
+// column tiles.  The grouped fp32-MFMA launch it replaces (cwn_gemm_f32: weights stationary per workgroup, staged through
+// LDS; 157 TF peak) took 13 - 14.4 us per stage at the ZINC batch of 128 -- with 1.7 tiles per workgroup it never reaches
+// a steady state: weight staging, tile load, 128 dependent MFMAs and the epilogue run back to back.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <mutex>
+#include "../../include/cwn_hip.h"
+#include "cwn_split.h"
+#include "cwn_mem.h"
+
+namespace {
+
+using cwn::frag_cd;
+
+constexpr int kThreads = 512;
+constexpr int kV = 2;                             // float4 of an input tile per thread
+constexpr int kRT = 2;                            // 16-row tiles per wave
+
+template <int F> struct Shape {
+    static constexpr int kTM = 4096 / F;
+    static constexpr int kNCT = F / 16;
+    static constexpr int kKS = F / 32;
+    static constexpr int kRowStride = F + 8;          // bf16 elements per LDS row (fragment reads conflict-free)
+    static constexpr int kChunksPerTile = kKS * 3;    // packed weight: 1-KiB chunks per 16-column tile (k steps x planes)
+    static constexpr size_t kPlaneElems = (size_t)kTM * kRowStride;
+    static constexpr size_t kBufBytes = 3 * kPlaneElems * 2;   // three planes
+    static constexpr size_t kLdsBytes = 2 * kBufBytes;         // the tile of X and of X2
+    static_assert(kTM * (F / 4) == kV * kThreads && (kTM / 16) * kNCT == 8 * kRT, "tile shape");
+    static_assert(kThreads % (F / 4) == 0, "a thread keeps its input columns");
+};
+
+struct StageBatch {
+    cwn_stage_desc d[CWN_MAX_DESCS];
+    int32_t blk_start[CWN_MAX_DESCS + 1];
+    int32_t n;
+};
+
+// v of the lane CTRL's rotation away within its 16-lane row (DPP row_ror:n = 0x120 + n), for a double
+template <int CTRL>
+__device__ __forceinline__ double row_ror_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+
+template <int F>
+__global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
+    using S = Shape<F>;
+    constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
+    constexpr size_t kPlaneElems = S::kPlaneElems, kBufBytes = S::kBufBytes;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* const buf0 = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* const buf1 = reinterpret_cast<uint16_t*>(smem + kBufBytes);
+    int di = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+        if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
+    const cwn_stage_desc& D = B.d[di];
+    const int64_t row0 = (int64_t)((int)blockIdx.x - B.blk_start[di]) * TM;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ct = wave % S::kNCT, rt0 = (wave / S::kNCT) * kRT;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const bool two = D.X2 != nullptr;
+
+    // an input tile: TM rows x F / 4 float4, two per thread, row-contiguous; rows past M are clamped, not guarded (their
+    // outputs are neither stored nor counted)
+    typedef float4 RowRegs[kV];
+    RowRegs v0, v1;
+    auto request_rows = [&](RowRegs& v, const float* X, int64_t ld) {
+#pragma unroll
+        for (int i = 0; i < kV; ++i) {
+            const int idx = threadIdx.x + i * kThreads, r = idx / (F / 4), c4 = idx % (F / 4);
+            const int64_t row = row0 + r < D.M ? row0 + r : D.M - 1;
+            v[i] = reinterpret_cast<const float4*>(X + row * ld)[c4];
+        }
+    };
+    // the prologue of an input: per-column affine (the producing stage's BatchNorm) and ReLU.  A thread's columns are the
+    // same for every row it stages (kThreads is a multiple of F / 4): its constants are loaded once.
+    struct Pro { float4 sc, sh; bool affine, relu; };
+    auto request_pro = [&](const float* scale, const float* shift, bool relu) {
+        Pro p;
+        p.sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        p.sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        p.affine = scale != nullptr;
+        p.relu = relu;
+        if (p.affine) {
+            const int c4 = threadIdx.x % (F / 4);
+            p.sc = reinterpret_cast<const float4*>(scale)[c4];
+            p.sh = reinterpret_cast<const float4*>(shift)[c4];
+        }
+        return p;
+    };
+    auto stage_rows = [&](const RowRegs& v, const Pro& p, uint16_t* buf) {   // prologue, then split ONCE per element
+#pragma unroll
+        for (int i = 0; i < kV; ++i) {
+            const int idx = threadIdx.x + i * kThreads, r = idx / (F / 4), c4 = idx % (F / 4);
+            float4 x = v[i];
+            if (p.affine) x = make_float4(x.x * p.sc.x + p.sh.x, x.y * p.sc.y + p.sh.y, x.z * p.sc.z + p.sh.z, x.w * p.sc.w + p.sh.w);
+            if (p.relu) x = make_float4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f));
+            uint2 ph, pm, pl;
+            cwn::split4(x, ph, pm, pl);
+            uint16_t* dst = buf + (size_t)r * kRowStride + c4 * 4;
+            *reinterpret_cast<uint2*>(dst) = ph;
+            *reinterpret_cast<uint2*>(dst + kPlaneElems) = pm;
+            *reinterpret_cast<uint2*>(dst + 2 * kPlaneElems) = pl;
+        }
+    };
+    // workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding global load: here
+    // the weight, which keeps streaming across the barrier)
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // the stationary operand: this wave's 16 output columns of one F x F block, [k step][plane]; two sets
+    typedef uint4 WeightRegs[kKS][3];
+    WeightRegs wfA, wfB;
+    auto request_kstep = [&](WeightRegs& wf, const void* packed, int ks) {
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(packed) + (size_t)ct * kChunksPerTile * 1024 + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wf[ks][pl] = *reinterpret_cast<const uint4*>(wp + (ks * 3 + pl) * 1024);
+    };
+    typedef frag_cd AccRegs[kRT];
+    AccRegs acc;
+    // acc += buf x W^T (k steps in order, six terms each: cwn_split.h).  `next` != NULL: the k steps of that block are
+    // requested into the OTHER register set one by one between this block's MFMAs.
+    auto multiply = [&](const uint16_t* buf, const WeightRegs& wf, WeightRegs& wnext, const void* next) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+#pragma unroll
+            for (int rt = 0; rt < kRT; ++rt) {
+                const uint16_t* p = buf + (size_t)((rt0 + rt) * 16 + l15) * kRowStride + ks * 32 + kq * 8;
+                const uint4 xh = *reinterpret_cast<const uint4*>(p);
+                const uint4 xm = *reinterpret_cast<const uint4*>(p + kPlaneElems);
+                const uint4 xl = *reinterpret_cast<const uint4*>(p + 2 * kPlaneElems);
+                acc[rt] = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh, xm, xl, acc[rt]);
+            }
+            if (next != nullptr) request_kstep(wnext, next, ks);
+        }
+    };
+
+    // requests: rows and the constants behind them first, then the weight (loads return in order: a constant behind 96 KB of
+    // weight is a wait for the weight)
+    request_rows(v0, D.X, D.ldx);
+    const Pro p0 = request_pro(D.in_scale, D.in_shift, (D.in_relu & 1) != 0);
+    Pro p1 = p0;
+    if (two) {
+        request_rows(v1, D.X2, D.ldx2);
+        p1 = request_pro(D.in_scale2, D.in_shift2, (D.in_relu & 2) != 0);
+    }
+    const int n0 = ct * 16 + kq * 4;                 // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = row (lane & 15)
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (D.bias != nullptr) b4 = *reinterpret_cast<const float4*>(D.bias + n0);
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) request_kstep(wfA, D.w_packed, ks);
+    stage_rows(v0, p0, buf0);
+    if (two) stage_rows(v1, p1, buf1);
+    lds_barrier();
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
+    multiply(buf0, wfA, wfB, two ? D.w2_packed : nullptr);
+    if (two) multiply(buf1, wfB, wfA, nullptr);
+
+    // epilogue: + bias; the band's column statistics of the pre-normalisation value (fp64, the 16 rows of a lane group
+    // through DPP, both row tiles summed in registers first, ONE plain store per column and band: no atomics, no zero
+    // fill, deterministic -- as cwn_gemm_f32's); the rows of Z
+    const bool stats = D.col_sum != nullptr;
+    double csum[4] = {0., 0., 0., 0.}, csq[4] = {0., 0., 0., 0.};
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) {
+        const int r = (rt0 + rt) * 16 + l15;
+        const bool ok = row0 + r < D.M;
+        const float y[4] = {acc[rt][0] + b4.x, acc[rt][1] + b4.y, acc[rt][2] + b4.z, acc[rt][3] + b4.w};
+        if (stats && ok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                csum[q] += (double)y[q];
+                csq[q] += (double)y[q] * (double)y[q];
+            }
+        }
+        if (ok) cwn::store_result4(D.Y + (row0 + r) * D.ldy + n0, y[0], y[1], y[2], y[3]);
+    }
+    if (stats) {
+        const int64_t slot = (row0 + rt0 * 16) / 32;          // this wave's two row tiles are one 32-row band
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double a = csum[q], b = csq[q];
+            a += row_ror_f64<0x128>(a); b += row_ror_f64<0x128>(b);
+            a += row_ror_f64<0x124>(a); b += row_ror_f64<0x124>(b);
+            a += row_ror_f64<0x122>(a); b += row_ror_f64<0x122>(b);
+            a += row_ror_f64<0x121>(a); b += row_ror_f64<0x121>(b);
+            if (l15 == 0 && slot < CWN_STAT_ROWS(D.M)) {
+                D.col_sum[slot * F + n0 + q] = a;
+                D.col_sumsq[slot * F + n0 + q] = b;
+            }
+        }
+    }
+}
+
+inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15u) == 0; }
+
+template <int F>
+int launch_stage(const StageBatch& B, int64_t blocks, hipStream_t stream) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_stage_kernel<F>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Shape<F>::kLdsBytes);
+    });
+    if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
+    dense_stage_kernel<F><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F>::kLdsBytes, stream>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+// n weights -> packed blocks in ONE launch: entry e is the F x F block W[e][:, col0[e] : col0[e] + F] (row stride ldw[e])
+struct PackTable {
+    const float* W[CWN_STAGE_PACK_MAX];
+    unsigned char* out[CWN_STAGE_PACK_MAX];
+    int64_t ldw[CWN_STAGE_PACK_MAX];
+};
+
+// (the layout of cwn_update_mlp_pack_weights_f32: chunk ((tile * KS + ks) * 3 + plane), lane l = kq * 16 + n holds
+// W[tile * 16 + n][ks * 32 + kq * 8 ..] of that plane)
+template <int F>
+__global__ __launch_bounds__(256) void pack_stage_weights_kernel(PackTable T) {
+    constexpr int KS = F / 32;
+    constexpr int kPerWeight = (F / 16) * KS * 64;                 // one thread per (tile, ks, lane)
+    const int e = blockIdx.y;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= kPerWeight) return;
+    const int lane = g & 63, ks = (g >> 6) % KS, tile = (g >> 6) / KS;
+    const float* src = T.W[e] + (int64_t)(tile * 16 + (lane & 15)) * T.ldw[e] + ks * 32 + (lane >> 4) * 8;
+    const float4 a = make_float4(src[0], src[1], src[2], src[3]), b = make_float4(src[4], src[5], src[6], src[7]);
+    uint4 ph, pm, pl;
+    cwn::split8(a, b, ph, pm, pl);
+    unsigned char* dst = T.out[e] + ((size_t)(tile * KS + ks) * 3) * 1024 + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = ph;
+    *reinterpret_cast<uint4*>(dst + 1024) = pm;
+    *reinterpret_cast<uint4*>(dst + 2048) = pl;
+}
+
+}  // namespace
+
+extern "C" int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
+                                                    int32_t n, cwn_stream_t stream_) {
+    if ((F != 64 && F != 128) || n < 0 || n > CWN_STAGE_PACK_MAX) return CWN_ERR_BAD_ARG;
+    if (n == 0) return CWN_OK;
+    if (W == nullptr || ldw == nullptr || out == nullptr) return CWN_ERR_BAD_ARG;
+    PackTable T{};
+    for (int e = 0; e < n; ++e) {
+        if (W[e] == nullptr || out[e] == nullptr || ldw[e] < F) return CWN_ERR_BAD_ARG;
+        if (((uintptr_t)W[e] & 3u) || ((uintptr_t)out[e] & 15u)) return CWN_ERR_ALIGN;
+        T.W[e] = W[e];
+        T.out[e] = (unsigned char*)out[e];
+        T.ldw[e] = ldw[e];
+    }
+    const int threads = (F / 16) * (F / 32) * 64;
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((threads + 255) / 256, n);
+    if (F == 128) pack_stage_weights_kernel<128><<<grid, dim3(256), 0, stream>>>(T);
+    else pack_stage_weights_kernel<64><<<grid, dim3(256), 0, stream>>>(T);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+extern "C" int cwn_dense_stage_f32(const cwn_stage_desc* descs, int n, int32_t F, cwn_stream_t stream_) {
+    if (descs == nullptr || n < 1 || n > CWN_MAX_DESCS || (F != 64 && F != 128)) return CWN_ERR_BAD_ARG;
+    const int TM = 4096 / F;
+    StageBatch B{};
+    B.n = n;
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const cwn_stage_desc& D = descs[i];
+        if (D.M < 0) return CWN_ERR_BAD_ARG;
+        B.blk_start[i] = (int32_t)blocks;
+        B.d[i] = D;
+        if (D.M == 0) continue;
+        if (D.X == nullptr || D.Y == nullptr || D.w_packed == nullptr) return CWN_ERR_BAD_ARG;
+        if ((D.X2 == nullptr) != (D.w2_packed == nullptr)) return CWN_ERR_BAD_ARG;
+        if ((D.in_scale == nullptr) != (D.in_shift == nullptr) || (D.in_scale2 == nullptr) != (D.in_shift2 == nullptr))
+            return CWN_ERR_BAD_ARG;
+        if ((D.col_sum == nullptr) != (D.col_sumsq == nullptr)) return CWN_ERR_BAD_ARG;
+        if (D.ldx < F || D.ldy < F || D.ldx % 4 || D.ldy % 4 || (D.X2 != nullptr && (D.ldx2 < F || D.ldx2 % 4)))
+            return CWN_ERR_BAD_ARG;
+        if (!(al16(D.X) && al16(D.X2) && al16(D.Y) && al16(D.w_packed) && al16(D.w2_packed) && al16(D.bias) && al16(D.in_scale) &&
+              al16(D.in_shift) && al16(D.in_scale2) && al16(D.in_shift2)))
+            return CWN_ERR_ALIGN;
+        if (((uintptr_t)D.col_sum & 7u) || ((uintptr_t)D.col_sumsq & 7u)) return CWN_ERR_ALIGN;
+        blocks += (D.M + TM - 1) / TM;
+        if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    }
+    for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
+    if (blocks == 0) return CWN_OK;
+    return F == 128 ? launch_stage<128>(B, blocks, (hipStream_t)stream_) : launch_stage<64>(B, blocks, (hipStream_t)stream_);
+}

@@ -182,7 +182,9 @@ class _DenseTrain(torch.autograd.Function):
                                           in_relu=1 if s > 0 else 0,
                                           col_stats=stat_of.get(id(st))))
                     group.append((st, X.size(0)))
-            res = ops.run_gemm(gemms, dev)
+            res = ops.run_stage(gemms, dev)          # cwn_dense_stage_f32 when the blocks are packed (ops.STAGE_KERNEL)
+            if res is None:
+                res = ops.run_gemm(gemms, dev)
             k = 0
             for i in range(nd):
                 for br in (0, 1):
@@ -198,7 +200,9 @@ class _DenseTrain(torch.autograd.Function):
             gemms.append(ops.Gemm(X=Z[i][0][-1], X2=Z[i][1][-1], W=W, bias=b, in_scale=sc, in_shift=sh,
                                   in_scale2=sc2, in_shift2=sh2, in_relu=3, col_stats=stat_of.get(id(st))))
             group.append((st, Z[i][0][-1].size(0)))
-        Z3 = ops.run_gemm(gemms, dev)
+        Z3 = ops.run_stage(gemms, dev)
+        if Z3 is None:
+            Z3 = ops.run_gemm(gemms, dev)
         finalize(group)
         H = [torch.empty_like(z) for z in Z3]
         _ffi.norm_act([_norm_desc(z, out=h, aff=aff_of.get(id(plan.cb[i])))

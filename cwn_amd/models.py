@@ -177,6 +177,19 @@ class _SparseCINStack(torch.nn.Module):
                   if getattr(lvl, '_up_kind', lambda: None)() == 'cat_linear_relu' and lvl.msg_up_nn[1].weight.is_cuda]
             if ws:
                 ops.pack_layer_weights_many(ws, transposed=bool(ops.BLOCKED_BACKWARD))
+        if torch.is_grad_enabled() and ops.STAGE_KERNEL and layers.FUSED_DENSE_TRAINING:
+            # ... and the blocks of the update / combine Linear layers (cwn_dense_stage_f32 streams them pre-split)
+            sw = []
+            for conv in self.convs:
+                for lvl in getattr(conv, 'mp_levels', []):
+                    for net in (getattr(lvl, 'update_up_nn', None), getattr(lvl, 'update_boundaries_nn', None),
+                                getattr(lvl, 'combine_nn', None)):
+                        st = layers._mlp_stages(net) if net is not None else None
+                        for lin, _ in (st or []):
+                            if lin.weight.is_cuda and lin.weight.requires_grad:
+                                sw.append(lin.weight)
+            if sw:
+                ops.pack_stage_weights_many(sw)
         for c, conv in enumerate(self.convs):
             params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
             xs = conv(*params, start_to_process=0)

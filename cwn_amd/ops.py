@@ -1481,6 +1481,106 @@ def pack_mlp_weight(weight: Tensor):
     return parts
 
 
+# ---- one stage of the update / combine networks in training mode on the inference kernels' arithmetic (cwn_dense_stage_f32) ----
+# The training forward of a layer's dense networks is three grouped launches (stage 1, stage 2, combine), each followed by
+# cwn_bn_finalize_f32: batch statistics are a reduction over all rows between any two stages.  STAGE_KERNEL routes them
+# to csrc/cwn_stage.hip -- pre-packed bf16-split weights streamed into registers, the tile split once into LDS planes --
+# when every product of the launch is F -> F or 2F -> F with F in (64, 128) and its weight block was packed by the
+# latest pack_stage_weights_many call (the training forward packs all of a model's blocks in one launch, after the
+# optimizer has written them); anything else stays on cwn_gemm_f32.
+STAGE_KERNEL = os.environ.get('CWN_STAGE_KERNEL') != '0'
+_stage_token = 0
+_packed_stage = {}       # (id(weight), col0) -> (token, weakref, buffer)
+
+
+def pack_stage_weights_many(weights: Sequence[Tensor]) -> None:
+    """Pack the [F, F] weights (and the two column halves of the [F, 2F] ones) of all given Linear layers in one launch per
+    width; `packed_stage_block` hands the blocks out until the next call."""
+    import weakref
+    global _stage_token
+    _stage_token += 1
+    L = _ffi.lib()
+    by_F = {}
+    for weight in weights:
+        w = weight.detach()
+        F = int(w.size(0)) if w.dim() == 2 else 0
+        if F not in (64, 128) or w.size(1) not in (F, 2 * F) or not w.is_cuda or w.dtype != torch.float32 or w.stride(1) != 1 \
+                or w.data_ptr() % 16 or w.stride(0) % 4:
+            continue
+        for c0 in range(0, int(w.size(1)), F):
+            by_F.setdefault(F, []).append((weight, w, c0))
+    for F, blocks in by_F.items():
+        nbytes = int(L.cwn_update_mlp_packed_weight_bytes(F))
+        for lo in range(0, len(blocks), _ffi.STAGE_PACK_MAX):
+            part = blocks[lo: lo + _ffi.STAGE_PACK_MAX]
+            n = len(part)
+            dev = part[0][1].device
+            buf = torch.empty(n * nbytes, dtype=torch.uint8, device=dev)
+            outs = [buf[k * nbytes: (k + 1) * nbytes] for k in range(n)]
+            Wp = (C.c_void_p * n)(*[w.data_ptr() + 4 * c0 for _, w, c0 in part])
+            ld = (C.c_int64 * n)(*[w.stride(0) for _, w, _ in part])
+            Op = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+            _ffi.check(L.cwn_update_mlp_pack_weights_many_f32(Wp, ld, F, Op, n, _ffi.stream_ptr(dev)),
+                       'cwn_update_mlp_pack_weights_many_f32')
+            for (weight, w, c0), o in zip(part, outs):
+                key = (id(weight), c0)
+                _packed_stage[key] = (_stage_token, weakref.ref(weight, lambda _r, k=key: _packed_stage.pop(k, None)), o,
+                                      (w.data_ptr(), tuple(w.shape)))
+
+
+def packed_stage_block(weight: Tensor, col0: int) -> Optional[Tensor]:
+    """The packed block weight[:, col0 : col0 + F] written by the LATEST pack_stage_weights_many call, or None."""
+    hit = _packed_stage.get((id(weight), col0))
+    if hit is not None and hit[0] == _stage_token and hit[1]() is weight and hit[3] == (weight.data_ptr(), tuple(weight.shape)):
+        return hit[2]
+    return None
+
+
+def run_stage(gemms: Sequence['Gemm'], device) -> Optional[List[Tensor]]:
+    """The grouped launch `gemms` on cwn_dense_stage_f32, or None when it does not apply (the caller runs cwn_gemm_f32)."""
+    if not STAGE_KERNEL or not gemms or len(gemms) > _ffi.MAX_DESCS:
+        return None
+    F = int(gemms[0].X.size(1))
+    if F not in (64, 128):
+        return None
+    arr = (_ffi.StageDesc * len(gemms))()
+    keep, outs = [], []
+    for k, g in enumerate(gemms):
+        X, X2, W = g.X, g.X2, g.W
+        if (g.relu or g.out_scale is not None or g.w_trans or g.bnb is not None or g.add_out or g.out is not None or g.exact
+                or g.w_col0 is not None or g.debug):
+            return None
+        if W.dim() != 2 or W.size(0) != F or W.size(1) != (2 * F if X2 is not None else F):
+            return None
+        for t in (X, X2):
+            if t is not None and (t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.size(1) != F or t.stride(1) != 1
+                                  or t.stride(0) % 4 or t.data_ptr() % 16 or t.size(0) != X.size(0)):
+                return None
+        w1 = packed_stage_block(W, 0)
+        w2 = packed_stage_block(W, F) if X2 is not None else None
+        if w1 is None or (X2 is not None and w2 is None):
+            return None
+        cons = [g.bias, g.in_scale, g.in_shift, g.in_scale2, g.in_shift2]
+        cons = [None if t is None else _f32c(t, 'constant') for t in cons]
+        if any(t is not None and (t.numel() != F or t.data_ptr() % 16) for t in cons):
+            return None
+        cs = g.col_stats
+        M = int(X.size(0))
+        if cs is not None and (cs.dtype != torch.float64 or tuple(cs.shape) != (2, stat_rows(M), F) or not cs.is_contiguous()):
+            return None
+        Y = torch.empty(M, F, dtype=torch.float32, device=X.device)
+        ld = lambda t: int(t.stride(0)) if t.size(0) > 1 else F
+        arr[k] = _ffi.StageDesc(X=X.data_ptr(), X2=_ffi.ptr(X2), w_packed=w1.data_ptr(), w2_packed=_ffi.ptr(w2),
+                                bias=_ffi.ptr(cons[0]), in_scale=_ffi.ptr(cons[1]), in_shift=_ffi.ptr(cons[2]),
+                                in_scale2=_ffi.ptr(cons[3]), in_shift2=_ffi.ptr(cons[4]), Y=Y.data_ptr(),
+                                col_sum=None if cs is None else cs[0].data_ptr(), col_sumsq=None if cs is None else cs[1].data_ptr(),
+                                M=M, ldx=ld(X), ldx2=0 if X2 is None else ld(X2), ldy=F, in_relu=int(g.in_relu))
+        keep += cons + [w1, w2]
+        outs.append(Y)
+    _ffi.check(_ffi.lib().cwn_dense_stage_f32(arr, len(gemms), F, _ffi.stream_ptr(device)), 'cwn_dense_stage_f32')
+    return outs
+
+
 def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tensor]:
     """[out_up_0, out_b_0, out_up_1, out_b_1, ...]; no autograd (inference path).  `table` is one of the
     batch's item tables (cwn_amd/blockplan.py: ItemTable); csr_mode 0 sorts the COO entries in the

@@ -486,6 +486,44 @@ int64_t cwn_update_mlp_max_rows(void);
  * bytes, 16-B aligned; one small launch per weight VERSION */
 size_t cwn_update_mlp_packed_weight_bytes(int32_t F);
 int cwn_update_mlp_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream);
+/* the same for n blocks in ONE launch (a training step packs the update / combine weights of all its layers once, after
+ * the optimizer has written them): host arrays of n device pointers (the first element of each F x F block: a column
+ * offset selects half of a combine weight) / row strides / outputs */
+#define CWN_STAGE_PACK_MAX 96
+int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
+                                         cwn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One STAGE of the same networks in TRAINING mode (csrc/cwn_stage.hip), up to CWN_MAX_DESCS products per launch:
+ *
+ *     Y = prologue([X | X2]) W^T + bias      col_sum / col_sumsq [CWN_STAT_ROWS(M), F]: per-32-row-band sums of Y, Y^2 (fp64)
+ *
+ * i.e. a Linear(F -> F) or, with X2, Linear(2F -> F) on the K-concatenation (combine_nn's torch.cat, mp/layers.py:199) whose
+ * BatchNorm(train) statistics are accumulated in the epilogue exactly as cwn_gemm_f32 does (plain stores per band:
+ * deterministic; cwn_bn_finalize_f32 reduces them), with the producing stage's BatchNorm apply + ReLU as the prologue
+ * (in_scale / in_shift per input column or NULL, in_relu bit 0: X, bit 1: X2).  Arithmetic: the exact three-way bf16
+ * split of csrc/cwn_split.h (fp32 in, fp32 accumulate, fp32 out; the inference kernels' path), weights pre-packed by
+ * cwn_update_mlp_pack_weights_f32 or its _many form: w_packed = the block that multiplies X, w2_packed the block that multiplies X2.
+ * F = 64 or 128 = the width of X, X2 and Y; pointers 16-B aligned, strides multiples of 4.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cwn_stage_desc {
+    const float* X;          /* [M, F] */
+    const float* X2;         /* [M, F] or NULL */
+    const void* w_packed;
+    const void* w2_packed;   /* NULL without X2 */
+    const float* bias;       /* [F] or NULL */
+    const float* in_scale;   /* [F] or NULL */
+    const float* in_shift;
+    const float* in_scale2;
+    const float* in_shift2;
+    float* Y;                /* [M, F] */
+    double* col_sum;         /* [CWN_STAT_ROWS(M), F] or NULL */
+    double* col_sumsq;
+    int64_t M, ldx, ldx2, ldy;
+    int32_t in_relu;
+    int32_t pad_;
+} cwn_stage_desc;
+int cwn_dense_stage_f32(const cwn_stage_desc* descs_host, int n, int32_t F, cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense parts of the path on the matrix cores (fp32 MFMA, exact fp32):

@@ -2457,3 +2457,81 @@ def test_gemm_add_out_adds_onto_what_the_output_holds(M, N, K):
     out = base.clone()
     ops.run_gemm([ops.Gemm(X=X, W=Wt, w_trans=True, out=out, add_out=True)], DEV)
     assert torch.equal(out, base + plain)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('F,Ms', [(128, (3165, 3341, 304)), (128, (1, 33)), (64, (700, 65, 2))])
+def test_dense_stage_kernel_vs_grouped_gemm(F, Ms):
+    """cwn_dense_stage_f32 (csrc/cwn_stage.hip: one stage of the update / combine networks in training mode on the bf16-split
+    path with pre-packed weights) against the grouped cwn_gemm_f32 launch it replaces and a float64 product: the rows of Z
+    within the gate, the per-band column statistics (fp64 partials of what each path wrote) to 1e-6 of the band's scale;
+    both forms (F -> F with one prologue, 2F -> F on the K-concatenation with two), a launch of several products, row
+    counts that end inside a band and inside a workgroup."""
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(F + len(Ms))
+    rn = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    lins = [torch.nn.Linear(F, F).to(DEV) for _ in Ms] + [torch.nn.Linear(2 * F, F).to(DEV) for _ in Ms]
+    ops.pack_stage_weights_many([l.weight for l in lins])
+
+    def make(form):
+        gemms = []
+        for k, M in enumerate(Ms):
+            X, X2 = rn(M, F), rn(M, F)
+            sc, sh, sc2, sh2 = rn(F).abs() + 0.5, rn(F), rn(F).abs() + 0.5, rn(F)
+            stats = torch.zeros(2, ops.stat_rows(M), F, dtype=torch.float64, device=DEV)
+            if form == 'single':
+                lin = lins[k]
+                gemms.append(ops.Gemm(X=X, W=lin.weight, bias=lin.bias.detach(), in_scale=sc if k % 2 == 0 else None,
+                                      in_shift=sh if k % 2 == 0 else None, in_relu=1 if k != 1 else 0, col_stats=stats))
+            else:
+                lin = lins[len(Ms) + k]
+                gemms.append(ops.Gemm(X=X, X2=X2, W=lin.weight, bias=lin.bias.detach() if k else None, in_scale=sc, in_shift=sh,
+                                      in_scale2=sc2, in_shift2=sh2, in_relu=3, col_stats=stats))
+        return gemms
+
+    for form in ('single', 'cat'):
+        gemms = make(form)
+        got = ops.run_stage(gemms, DEV)
+        assert got is not None, 'the stage kernel refused a launch it is written for'
+        got_stats = [gm.col_stats.clone() for gm in gemms]
+        for gm in gemms:
+            gm.col_stats.zero_()
+        with torch.no_grad():
+            ref = ops.run_gemm(gemms, DEV)
+        for k, gm in enumerate(gemms):
+            x = gm.X.double()
+            if gm.in_scale is not None:
+                x = x * gm.in_scale.double() + gm.in_shift.double()
+            if gm.in_relu & 1:
+                x = x.relu()
+            if gm.X2 is not None:
+                x2 = (gm.X2.double() * gm.in_scale2.double() + gm.in_shift2.double()).relu()
+                x = torch.cat([x, x2], 1)
+            z = x @ gm.W.detach().double().t() + (gm.bias.double() if gm.bias is not None else 0.0)
+            scale = float(z.abs().max())
+            assert (got[k].double() - z).abs().max() <= 1e-5 * max(1.0, scale), (form, k)
+            assert (ref[k].double() - z).abs().max() <= 1e-5 * max(1.0, scale), (form, k)
+            M = z.size(0)
+            pad = (-M) % 32
+            zp = torch.cat([z, z.new_zeros(pad, F)]).view(-1, 32, F)
+            want = torch.stack([zp.sum(1), (zp * zp).sum(1)])
+            tol = 1e-6 * max(1.0, float(want.abs().max()))
+            assert (got_stats[k] - want).abs().max() <= 32 * 1e-6 * max(1.0, scale * scale), (form, k)
+            assert (gm.col_stats - want).abs().max() <= 32 * 1e-6 * max(1.0, scale * scale), (form, k)
+            del tol
+    # a block that was not packed by the latest call: the launch is refused (the caller runs cwn_gemm_f32)
+    ops.pack_stage_weights_many([lins[0].weight])
+    assert ops.run_stage(make('cat'), DEV) is None
+
+
+@pytest.mark.gpu
+def test_packing_many_stage_blocks_equals_one_by_one():
+    from cwn_amd import ops
+    torch.manual_seed(3)
+    ws = [torch.nn.Parameter(torch.randn(F, c * F, device=DEV)) for F, c in ((128, 1), (64, 2), (128, 2), (128, 1), (64, 1))]
+    ops.pack_stage_weights_many(ws)
+    for w in ws:
+        F = w.size(0)
+        one = ops.pack_mlp_weight(torch.nn.Parameter(w.detach().clone()))
+        for h, c0 in enumerate(range(0, w.size(1), F)):
+            assert torch.equal(ops.packed_stage_block(w, c0), one[h]), (tuple(w.shape), c0)
