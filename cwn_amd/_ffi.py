@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 16
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_dense_stage_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
@@ -125,6 +125,15 @@ class StageDesc(C.Structure):
                 ('in_shift2', C.c_void_p), ('Y', C.c_void_p), ('col_sum', C.c_void_p), ('col_sumsq', C.c_void_p),
                 ('M', C.c_int64), ('ldx', C.c_int64), ('ldx2', C.c_int64), ('ldy', C.c_int64),
                 ('in_relu', C.c_int32), ('pad_', C.c_int32)]
+
+
+class StageBwdDesc(C.Structure):
+    """cwn_stage_bwd_desc (include/cwn_hip.h)."""
+    _fields_ = [('dy', C.c_void_p), ('z', C.c_void_p), ('dz', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('mean', C.c_void_p), ('rstd', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p), ('acc1', C.c_void_p),
+                ('acc2', C.c_void_p), ('wt_packed', C.c_void_p), ('wt2_packed', C.c_void_p), ('dx', C.c_void_p), ('dx2', C.c_void_p),
+                ('M', C.c_int64), ('lddy', C.c_int64), ('ldz', C.c_int64), ('lddz', C.c_int64), ('lddx', C.c_int64),
+                ('lddx2', C.c_int64), ('relu', C.c_int32), ('pad_', C.c_int32)]
 
 
 STAGE_PACK_MAX = 96            # = CWN_STAGE_PACK_MAX
@@ -248,6 +257,10 @@ def lib():
     L.cwn_update_mlp_pack_weights_many_f32.restype = C.c_int
     L.cwn_update_mlp_pack_weights_many_f32.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_void_p),
                                                        C.c_int32, C.c_void_p]
+    L.cwn_update_mlp_pack_weights_t_many_f32.restype = C.c_int
+    L.cwn_update_mlp_pack_weights_t_many_f32.argtypes = L.cwn_update_mlp_pack_weights_many_f32.argtypes
+    L.cwn_dense_stage_bwd_f32.restype = C.c_int
+    L.cwn_dense_stage_bwd_f32.argtypes = [C.POINTER(StageBwdDesc), C.c_int, C.c_int32, C.c_void_p]
     L.cwn_dense_stage_f32.restype = C.c_int
     L.cwn_dense_stage_f32.argtypes = [C.POINTER(StageDesc), C.c_int, C.c_int32, C.c_void_p]
     L.cwn_update_mlp_max_rows.restype = C.c_int64

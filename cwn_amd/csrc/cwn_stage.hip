@@ -209,6 +209,159 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     }
 }
 
+// ---- the same stage BACKWARD: dX = dz W, with dz formed on the way in ---------------------------------------------------------
+//     dz = scale * (dyh - s1 / M - xhat * s2 / M),   dyh = dy * [z * scale + shift > 0],   xhat = (z - mean) * rstd
+// (BatchNorm(train) + ReLU backward given the column sums s1 = sum dyh, s2 = sum dyh * xhat of cwn_norm_bwd_reduce_f32;
+// without a norm: dz = dy * [z > 0]).  The tile of dz goes to global memory (the weight-gradient GEMM reads it) and,
+// split once, into the LDS planes; one or two products leave from the SAME planes: dX = dz W for a Linear(F -> F), the two
+// halves dz W[:, :F] and dz W[:, F:] for combine_nn's Linear(2F -> F).  Weights: the transposed blocks
+// (cwn_update_mlp_pack_weights_t_many_f32).  Replaces the transposed-weight launch of cwn_gemm_f32 with the cwn_gemm_bnb
+// prologue (fp32 MFMA, weights staged through LDS per workgroup: 16.2 us per launch at the ZINC batch of 128, twelve per
+// training step).
+struct StageBwdBatch {
+    cwn_stage_bwd_desc d[CWN_MAX_DESCS];
+    int32_t blk_start[CWN_MAX_DESCS + 1];
+    int32_t n;
+};
+
+template <int F>
+__global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBatch B) {
+    using S = Shape<F>;
+    constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
+    constexpr size_t kPlaneElems = S::kPlaneElems;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* const buf0 = reinterpret_cast<uint16_t*>(smem);
+    int di = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+        if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
+    const cwn_stage_bwd_desc& D = B.d[di];
+    const bool first_block = (int)blockIdx.x == B.blk_start[di];
+    const int64_t row0 = (int64_t)((int)blockIdx.x - B.blk_start[di]) * TM;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ct = wave % S::kNCT, rt0 = (wave / S::kNCT) * kRT;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const bool two = D.wt2_packed != nullptr;
+
+    typedef float4 RowRegs[kV];
+    RowRegs vy, vz;
+    auto request_rows = [&](RowRegs& v, const float* X, int64_t ld) {
+#pragma unroll
+        for (int i = 0; i < kV; ++i) {
+            const int idx = threadIdx.x + i * kThreads, r = idx / (F / 4), c4 = idx % (F / 4);
+            const int64_t row = row0 + r < D.M ? row0 + r : D.M - 1;
+            v[i] = reinterpret_cast<const float4*>(X + row * ld)[c4];
+        }
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // ONE set of weight registers; the second block of a two-output stage is requested when the first product is done (its
+    // latency is covered by the CU's other workgroup).  Two sets, two accumulator sets and the fragments of both row tiles
+    // were 164 registers -- one workgroup per CU where two overlap each other's loads -- and bounded to 128 the compiler
+    // put 56 of them in scratch; requesting the second block k step by k step into the registers the first had just
+    // finished with was allocated as a second set all the same (44 in scratch).
+    typedef uint4 WeightRegs[kKS][3];
+    WeightRegs wf;
+    auto request_kstep = [&](const void* packed, int ks) {
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(packed) + (size_t)ct * kChunksPerTile * 1024 + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wf[ks][pl] = *reinterpret_cast<const uint4*>(wp + (ks * 3 + pl) * 1024);
+    };
+    typedef frag_cd AccRegs[kRT];
+    auto multiply = [&](AccRegs& acc) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+#pragma unroll
+            for (int rt = 0; rt < kRT; ++rt) {
+                const uint16_t* p = buf0 + (size_t)((rt0 + rt) * 16 + l15) * kRowStride + ks * 32 + kq * 8;
+                const uint4 xh = *reinterpret_cast<const uint4*>(p);
+                const uint4 xm = *reinterpret_cast<const uint4*>(p + kPlaneElems);
+                const uint4 xl = *reinterpret_cast<const uint4*>(p + 2 * kPlaneElems);
+                acc[rt] = cwn::mfma_split6(wf[ks][0], wf[ks][1], wf[ks][2], xh, xm, xl, acc[rt]);
+            }
+        }
+    };
+
+    // requests: the two tiles, the constants of this thread's four columns (the same in every row it stages), the weight
+    request_rows(vy, D.dy, D.lddy);
+    request_rows(vz, D.z, D.ldz);
+    const int c4 = threadIdx.x % (F / 4);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), mu = sh, c0 = sh, c1 = sh;
+    const bool norm = D.scale != nullptr;
+    if (norm) {
+        sc = reinterpret_cast<const float4*>(D.scale)[c4];
+        sh = reinterpret_cast<const float4*>(D.shift)[c4];
+        mu = reinterpret_cast<const float4*>(D.mean)[c4];
+        const float4 rs = reinterpret_cast<const float4*>(D.rstd)[c4];
+        const float4 s1 = reinterpret_cast<const float4*>(D.s1)[c4], s2 = reinterpret_cast<const float4*>(D.s2)[c4];
+        const float invM = 1.0f / (float)D.M;
+        c0 = make_float4(-sc.x * (s1.x * invM), -sc.y * (s1.y * invM), -sc.z * (s1.z * invM), -sc.w * (s1.w * invM));
+        c1 = make_float4(-sc.x * (rs.x * (s2.x * invM)), -sc.y * (rs.y * (s2.y * invM)), -sc.z * (rs.z * (s2.z * invM)),
+                         -sc.w * (rs.w * (s2.w * invM)));
+        if (first_block && threadIdx.x < F / 4) {       // the sums go on to beta.grad / gamma.grad: one writer per column
+            if (D.acc1 != nullptr) {
+                float4* a = reinterpret_cast<float4*>(D.acc1) + c4;
+                const float4 o = *a;
+                *a = make_float4(o.x + s1.x, o.y + s1.y, o.z + s1.z, o.w + s1.w);
+            }
+            if (D.acc2 != nullptr) {
+                float4* a = reinterpret_cast<float4*>(D.acc2) + c4;
+                const float4 o = *a;
+                *a = make_float4(o.x + s2.x, o.y + s2.y, o.z + s2.z, o.w + s2.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) request_kstep(D.wt_packed, ks);
+    const bool relu = D.relu != 0;
+#pragma unroll
+    for (int i = 0; i < kV; ++i) {
+        const int idx = threadIdx.x + i * kThreads, r = idx / (F / 4);
+        const float4 dy = vy[i], z = vz[i];
+        auto one = [&](float dyv, float zv, float s, float h, float m, float a0, float a1) {
+            const float y = zv * s + h;
+            const float dyh = (!relu || y > 0.f) ? dyv : 0.f;
+            return s * dyh + a0 + a1 * (zv - m);
+        };
+        const float4 d = make_float4(one(dy.x, z.x, sc.x, sh.x, mu.x, c0.x, c1.x), one(dy.y, z.y, sc.y, sh.y, mu.y, c0.y, c1.y),
+                                     one(dy.z, z.z, sc.z, sh.z, mu.z, c0.z, c1.z), one(dy.w, z.w, sc.w, sh.w, mu.w, c0.w, c1.w));
+        if (D.dz != nullptr && row0 + r < D.M) cwn::store_result4(D.dz + (row0 + r) * D.lddz + c4 * 4, d.x, d.y, d.z, d.w);
+        uint2 ph, pm, pl;
+        cwn::split4(d, ph, pm, pl);
+        uint16_t* dst = buf0 + (size_t)r * kRowStride + c4 * 4;
+        *reinterpret_cast<uint2*>(dst) = ph;
+        *reinterpret_cast<uint2*>(dst + kPlaneElems) = pm;
+        *reinterpret_cast<uint2*>(dst + 2 * kPlaneElems) = pl;
+    }
+    lds_barrier();
+    const int n0 = ct * 16 + kq * 4;                 // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = row (lane & 15)
+    AccRegs acc;
+    auto store = [&](float* out, int64_t ld) {
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) {
+            const int r = (rt0 + rt) * 16 + l15;
+            if (row0 + r < D.M) cwn::store_result4(out + (row0 + r) * ld + n0, acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+        }
+    };
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
+    multiply(acc);
+    if (two) {
+        __builtin_amdgcn_sched_barrier(0);               // (the requests below not hoisted into the product above)
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) request_kstep(D.wt2_packed, ks);
+    }
+    store(D.dx, D.lddx);
+    if (two) {
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
+        multiply(acc);
+        store(D.dx2, D.lddx2);
+    }
+}
+
 inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15u) == 0; }
 
 template <int F>
@@ -224,6 +377,12 @@ int launch_stage(const StageBatch& B, int64_t blocks, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
+template <int F>
+int launch_stage_bwd(const StageBwdBatch& B, int64_t blocks, hipStream_t stream) {
+    dense_stage_bwd_kernel<F><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F>::kBufBytes, stream>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
 // n weights -> packed blocks in ONE launch: entry e is the F x F block W[e][:, col0[e] : col0[e] + F] (row stride ldw[e])
 struct PackTable {
     const float* W[CWN_STAGE_PACK_MAX];
@@ -233,7 +392,9 @@ struct PackTable {
 
 // (the layout of cwn_update_mlp_pack_weights_f32: chunk ((tile * KS + ks) * 3 + plane), lane l = kq * 16 + n holds
 // W[tile * 16 + n][ks * 32 + kq * 8 ..] of that plane)
-template <int F>
+// TRANS: the block of the TRANSPOSED weight (dX = dz W: output column = input feature of the Linear, reduction over its
+// outputs): lane l = kq * 16 + n of chunk (tile, ks) holds W[ks * 32 + kq * 8 ..][tile * 16 + n]
+template <int F, bool TRANS>
 __global__ __launch_bounds__(256) void pack_stage_weights_kernel(PackTable T) {
     constexpr int KS = F / 32;
     constexpr int kPerWeight = (F / 16) * KS * 64;                 // one thread per (tile, ks, lane)
@@ -241,8 +402,17 @@ __global__ __launch_bounds__(256) void pack_stage_weights_kernel(PackTable T) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= kPerWeight) return;
     const int lane = g & 63, ks = (g >> 6) % KS, tile = (g >> 6) / KS;
-    const float* src = T.W[e] + (int64_t)(tile * 16 + (lane & 15)) * T.ldw[e] + ks * 32 + (lane >> 4) * 8;
-    const float4 a = make_float4(src[0], src[1], src[2], src[3]), b = make_float4(src[4], src[5], src[6], src[7]);
+    float4 a, b;
+    if constexpr (TRANS) {
+        const float* src = T.W[e] + (int64_t)(ks * 32 + (lane >> 4) * 8) * T.ldw[e] + tile * 16 + (lane & 15);
+        const int64_t ld = T.ldw[e];
+        a = make_float4(src[0], src[ld], src[2 * ld], src[3 * ld]);
+        b = make_float4(src[4 * ld], src[5 * ld], src[6 * ld], src[7 * ld]);
+    } else {
+        const float* src = T.W[e] + (int64_t)(tile * 16 + (lane & 15)) * T.ldw[e] + ks * 32 + (lane >> 4) * 8;
+        a = make_float4(src[0], src[1], src[2], src[3]);
+        b = make_float4(src[4], src[5], src[6], src[7]);
+    }
     uint4 ph, pm, pl;
     cwn::split8(a, b, ph, pm, pl);
     unsigned char* dst = T.out[e] + ((size_t)(tile * KS + ks) * 3) * 1024 + lane * 16;
@@ -253,8 +423,8 @@ __global__ __launch_bounds__(256) void pack_stage_weights_kernel(PackTable T) {
 
 }  // namespace
 
-extern "C" int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
-                                                    int32_t n, cwn_stream_t stream_) {
+namespace {
+int pack_stage_many(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n, bool trans, cwn_stream_t stream_) {
     if ((F != 64 && F != 128) || n < 0 || n > CWN_STAGE_PACK_MAX) return CWN_ERR_BAD_ARG;
     if (n == 0) return CWN_OK;
     if (W == nullptr || ldw == nullptr || out == nullptr) return CWN_ERR_BAD_ARG;
@@ -269,9 +439,22 @@ extern "C" int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const
     const int threads = (F / 16) * (F / 32) * 64;
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((threads + 255) / 256, n);
-    if (F == 128) pack_stage_weights_kernel<128><<<grid, dim3(256), 0, stream>>>(T);
-    else pack_stage_weights_kernel<64><<<grid, dim3(256), 0, stream>>>(T);
+    if (F == 128 && !trans) pack_stage_weights_kernel<128, false><<<grid, dim3(256), 0, stream>>>(T);
+    else if (F == 128) pack_stage_weights_kernel<128, true><<<grid, dim3(256), 0, stream>>>(T);
+    else if (!trans) pack_stage_weights_kernel<64, false><<<grid, dim3(256), 0, stream>>>(T);
+    else pack_stage_weights_kernel<64, true><<<grid, dim3(256), 0, stream>>>(T);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+}  // namespace
+
+extern "C" int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
+                                                    int32_t n, cwn_stream_t stream) {
+    return pack_stage_many(W, ldw, F, out, n, false, stream);
+}
+
+extern "C" int cwn_update_mlp_pack_weights_t_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
+                                                      int32_t n, cwn_stream_t stream) {
+    return pack_stage_many(W, ldw, F, out, n, true, stream);
 }
 
 extern "C" int cwn_dense_stage_f32(const cwn_stage_desc* descs, int n, int32_t F, cwn_stream_t stream_) {
@@ -303,4 +486,34 @@ extern "C" int cwn_dense_stage_f32(const cwn_stage_desc* descs, int n, int32_t F
     for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
     if (blocks == 0) return CWN_OK;
     return F == 128 ? launch_stage<128>(B, blocks, (hipStream_t)stream_) : launch_stage<64>(B, blocks, (hipStream_t)stream_);
+}
+
+extern "C" int cwn_dense_stage_bwd_f32(const cwn_stage_bwd_desc* descs, int n, int32_t F, cwn_stream_t stream_) {
+    if (descs == nullptr || n < 1 || n > CWN_MAX_DESCS || (F != 64 && F != 128)) return CWN_ERR_BAD_ARG;
+    const int TM = 4096 / F;
+    StageBwdBatch B{};
+    B.n = n;
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const cwn_stage_bwd_desc& D = descs[i];
+        if (D.M < 0) return CWN_ERR_BAD_ARG;
+        B.blk_start[i] = (int32_t)blocks;
+        B.d[i] = D;
+        if (D.M == 0) continue;
+        if (D.dy == nullptr || D.z == nullptr || D.wt_packed == nullptr || D.dx == nullptr) return CWN_ERR_BAD_ARG;
+        if ((D.wt2_packed == nullptr) != (D.dx2 == nullptr)) return CWN_ERR_BAD_ARG;
+        if (D.scale != nullptr && (D.shift == nullptr || D.mean == nullptr || D.rstd == nullptr || D.s1 == nullptr || D.s2 == nullptr))
+            return CWN_ERR_BAD_ARG;
+        if (D.lddy < F || D.ldz < F || D.lddx < F || D.lddy % 4 || D.ldz % 4 || D.lddx % 4) return CWN_ERR_BAD_ARG;
+        if (D.dz != nullptr && (D.lddz < F || D.lddz % 4)) return CWN_ERR_BAD_ARG;
+        if (D.dx2 != nullptr && (D.lddx2 < F || D.lddx2 % 4)) return CWN_ERR_BAD_ARG;
+        if (!(al16(D.dy) && al16(D.z) && al16(D.dz) && al16(D.dx) && al16(D.dx2) && al16(D.wt_packed) && al16(D.wt2_packed) &&
+              al16(D.scale) && al16(D.shift) && al16(D.mean) && al16(D.rstd) && al16(D.s1) && al16(D.s2) && al16(D.acc1) && al16(D.acc2)))
+            return CWN_ERR_ALIGN;
+        blocks += (D.M + TM - 1) / TM;
+        if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    }
+    for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
+    if (blocks == 0) return CWN_OK;
+    return F == 128 ? launch_stage_bwd<128>(B, blocks, (hipStream_t)stream_) : launch_stage_bwd<64>(B, blocks, (hipStream_t)stream_);
 }

@@ -348,6 +348,7 @@ class _DenseTrain(torch.autograd.Function):
         dZ3 = [p[0] for p in pend3] if lazy3 else pend3
         tn, nn = [], []
         dA = []
+        stage_bwd = []          # the same products for cwn_dense_stage_bwd_f32 (ops.run_stage_bwd), when every one has the lazy form
         for i in range(nd):
             st = plan.cb[i]
             W = P[id(st)][0]
@@ -369,21 +370,25 @@ class _DenseTrain(torch.autograd.Function):
                 nn.append(ops.Gemm(X=dH[i], W=W[:, :hu], w_trans=True, out=out[:, :hu], bnb=b))
                 nn.append(ops.Gemm(X=dH[i], W=W[:, hu:], w_trans=True, out=out[:, hu:], bnb=second_view(b)))
                 dA.append(out)
+                stage_bwd.append((dH[i], b, W, out[:, :hu], out[:, hu:]) if W.size(1) == 2 * hu else None)
             else:
                 nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
                 dA.append(None)
+                stage_bwd.append(None)
         # weight gradients whose targets are all the parameters' own .grad buffers may wait for the end of the backward
         can_defer = ops.ACCUMULATE_INTO_GRAD and all(tw is not None and (st.lin.bias is None or tb is not None)
                                                      for st, (tw, tb) in zip(stages, targets))
         keep_all = [dZ3, Z, A0, aff_of, dH]
-        res = ops.run_gemm(nn, dev)                     # [M, H_up + H_bd] per dimension (first: with the lazy form it WRITES dZ3)
-        k = 0
-        for i in range(nd):
-            if dA[i] is None:
-                dA[i] = res[k]
-                k += 1
-            else:
-                k += 2
+        # [M, H_up + H_bd] per dimension (before the weight gradients: with the lazy form the launch WRITES dZ3)
+        if not (all(e is not None for e in stage_bwd) and ops.run_stage_bwd(stage_bwd, dev)):
+            res = ops.run_gemm(nn, dev)
+            k = 0
+            for i in range(nd):
+                if dA[i] is None:
+                    dA[i] = res[k]
+                    k += 1
+                else:
+                    k += 2
         if tn:
             _ffi.gemm_tn(tn, dev, keep=keep_all, deferrable=can_defer)
         dy = []
@@ -400,6 +405,7 @@ class _DenseTrain(torch.autograd.Function):
             lazy_s = bool(pend) and isinstance(pend[0], tuple)
             dZ = [p[0] for p in pend] if lazy_s else pend
             tn, nn, k = [], [], 0
+            stage_bwd = []
             for i in range(nd):
                 for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
                     st = chain[s]
@@ -416,10 +422,17 @@ class _DenseTrain(torch.autograd.Function):
                             lddw=dW.stride(0), N=W.size(0), K=X.size(1), K2=0, in_relu=1 if s > 0 else 0))
                     if lazy_s and pend[k][1] is not None:
                         nn.append(ops.Gemm(X=dy[i][br], W=W, w_trans=True, bnb=pend[k][1]))
+                        stage_bwd.append((dy[i][br], pend[k][1], W, torch.empty(dz.size(0), W.size(1), dtype=torch.float32, device=dev),
+                                          None))
                     else:
                         nn.append(ops.Gemm(X=dz, W=W, w_trans=True))
+                        stage_bwd.append(None)
                     k += 1
-            res = ops.run_gemm(nn, dev)                  # (before the weight gradients: with the lazy form it writes dZ)
+            # (before the weight gradients: with the lazy form the launch writes dZ)
+            if all(e is not None for e in stage_bwd) and ops.run_stage_bwd(stage_bwd, dev):
+                res = [e[3] for e in stage_bwd]
+            else:
+                res = ops.run_gemm(nn, dev)
             if tn:
                 _ffi.gemm_tn(tn, dev, keep=[dZ, Z, A0, aff_of, dy], deferrable=can_defer)
             k = 0

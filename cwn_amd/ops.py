@@ -1490,15 +1490,21 @@ def pack_mlp_weight(weight: Tensor):
 # optimizer has written them); anything else stays on cwn_gemm_f32.
 STAGE_KERNEL = os.environ.get('CWN_STAGE_KERNEL') != '0'
 _stage_token = 0
-_packed_stage = {}       # (id(weight), col0) -> (token, weakref, buffer)
+_packed_stage = {}       # (storage address, shape, row stride, col0) -> (token, block, transposed block)
 
 
-def pack_stage_weights_many(weights: Sequence[Tensor]) -> None:
+def _stage_key(w: Tensor, col0: int):
+    # (by storage, not by object: the backward sees its saved weights re-wrapped)
+    return (w.data_ptr(), tuple(w.shape), int(w.stride(0)), int(col0))
+
+
+def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True) -> None:
     """Pack the [F, F] weights (and the two column halves of the [F, 2F] ones) of all given Linear layers in one launch per
-    width; `packed_stage_block` hands the blocks out until the next call."""
-    import weakref
+    width (+ one for the transposed blocks the backward stage multiplies with); `packed_stage_block` hands the blocks out
+    until the next call."""
     global _stage_token
     _stage_token += 1
+    _packed_stage.clear()                   # (entries of earlier calls are stale by definition)
     L = _ffi.lib()
     by_F = {}
     for weight in weights:
@@ -1522,18 +1528,60 @@ def pack_stage_weights_many(weights: Sequence[Tensor]) -> None:
             Op = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
             _ffi.check(L.cwn_update_mlp_pack_weights_many_f32(Wp, ld, F, Op, n, _ffi.stream_ptr(dev)),
                        'cwn_update_mlp_pack_weights_many_f32')
-            for (weight, w, c0), o in zip(part, outs):
-                key = (id(weight), c0)
-                _packed_stage[key] = (_stage_token, weakref.ref(weight, lambda _r, k=key: _packed_stage.pop(k, None)), o,
-                                      (w.data_ptr(), tuple(w.shape)))
+            outs_t = [None] * n
+            if transposed:                      # ... and the blocks of the transposed weight (cwn_dense_stage_bwd_f32: dX = dz W)
+                buf_t = torch.empty(n * nbytes, dtype=torch.uint8, device=dev)
+                outs_t = [buf_t[k * nbytes: (k + 1) * nbytes] for k in range(n)]
+                Tp = (C.c_void_p * n)(*[o.data_ptr() for o in outs_t])
+                _ffi.check(L.cwn_update_mlp_pack_weights_t_many_f32(Wp, ld, F, Tp, n, _ffi.stream_ptr(dev)),
+                           'cwn_update_mlp_pack_weights_t_many_f32')
+            for (weight, w, c0), o, ot in zip(part, outs, outs_t):
+                _packed_stage[_stage_key(w, c0)] = (_stage_token, o, ot)
 
 
-def packed_stage_block(weight: Tensor, col0: int) -> Optional[Tensor]:
-    """The packed block weight[:, col0 : col0 + F] written by the LATEST pack_stage_weights_many call, or None."""
-    hit = _packed_stage.get((id(weight), col0))
-    if hit is not None and hit[0] == _stage_token and hit[1]() is weight and hit[3] == (weight.data_ptr(), tuple(weight.shape)):
-        return hit[2]
+def packed_stage_block(weight: Tensor, col0: int, transposed: bool = False) -> Optional[Tensor]:
+    """The packed block weight[:, col0 : col0 + F] (or the block of the transposed weight) written by the LATEST
+    pack_stage_weights_many call, or None."""
+    hit = _packed_stage.get(_stage_key(weight, col0)) if weight.dim() == 2 else None
+    if hit is not None and hit[0] == _stage_token:
+        return hit[2] if transposed else hit[1]
     return None
+
+
+def run_stage_bwd(entries, device) -> bool:
+    """cwn_dense_stage_bwd_f32 over `entries` = [(dy, bnb, W, dx, dx2)]: dy the gradient of a stage's output, bnb the
+    _ffi.GemmBnb extension dense_train prepared for the transposed-weight GEMM (z, dz, the norm's constants and sums), W the
+    Linear's weight Parameter, dx (and dx2 for an [F, 2F] weight) the outputs.  False: does not apply, nothing launched."""
+    if not STAGE_KERNEL or not entries or len(entries) > _ffi.MAX_DESCS:
+        return False
+    F = int(entries[0][0].size(1))
+    if F not in (64, 128):
+        return False
+    arr = (_ffi.StageBwdDesc * len(entries))()
+    keep = []
+    ok_t = lambda t, w: (t.dtype == torch.float32 and t.is_cuda and t.dim() == 2 and t.size(1) == w and t.stride(1) == 1
+                         and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0)
+    for k, (dy, b, W, dx, dx2) in enumerate(entries):
+        if b is None or W.dim() != 2 or W.size(0) != F or W.size(1) != (2 * F if dx2 is not None else F):
+            return False
+        M = int(dy.size(0))
+        if M == 0 or not ok_t(dy, F) or not ok_t(dx, F) or (dx2 is not None and not ok_t(dx2, F)) or dx.size(0) != M:
+            return False
+        w1 = packed_stage_block(W, 0, transposed=True)
+        w2 = packed_stage_block(W, F, transposed=True) if dx2 is not None else None
+        if w1 is None or (dx2 is not None and w2 is None):
+            return False
+        ptrs = [b.scale, b.shift, b.mean, b.rstd, b.s1, b.s2, b.acc1, b.acc2, b.z, b.dz]
+        if any(p is not None and p % 16 for p in ptrs) or b.ldz % 4 or (b.dz is not None and b.lddz % 4):
+            return False
+        ld = lambda t: int(t.stride(0)) if t.size(0) > 1 else int(t.size(1))
+        arr[k] = _ffi.StageBwdDesc(dy=dy.data_ptr(), z=b.z, dz=b.dz, scale=b.scale, shift=b.shift, mean=b.mean, rstd=b.rstd,
+                                   s1=b.s1, s2=b.s2, acc1=b.acc1, acc2=b.acc2, wt_packed=w1.data_ptr(), wt2_packed=_ffi.ptr(w2),
+                                   dx=dx.data_ptr(), dx2=_ffi.ptr(dx2), M=M, lddy=ld(dy), ldz=int(b.ldz), lddz=int(b.lddz),
+                                   lddx=ld(dx), lddx2=0 if dx2 is None else ld(dx2), relu=int(b.relu))
+        keep += [w1, w2]
+    _ffi.check(_ffi.lib().cwn_dense_stage_bwd_f32(arr, len(entries), F, _ffi.stream_ptr(device)), 'cwn_dense_stage_bwd_f32')
+    return True
 
 
 def run_stage(gemms: Sequence['Gemm'], device) -> Optional[List[Tensor]]:

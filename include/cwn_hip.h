@@ -524,6 +524,35 @@ typedef struct cwn_stage_desc {
     int32_t pad_;
 } cwn_stage_desc;
 int cwn_dense_stage_f32(const cwn_stage_desc* descs_host, int n, int32_t F, cwn_stream_t stream);
+/* ... and BACKWARD: dX = dz W (two halves dX, dX2 for a Linear(2F -> F)) with the BatchNorm(train) + ReLU backward as the
+ * prologue -- dz = scale * (dyh - s1 / M - xhat * s2 / M), dyh = dy * [z * scale + shift > 0]; scale NULL: dz = dy * [z > 0]
+ * when relu, dy otherwise -- given the column sums s1, s2 of cwn_norm_bwd_reduce_f32.  dz is also written (the
+ * weight-gradient GEMM reads it; NULL: not wanted); acc1 / acc2 (or NULL): beta.grad += s1, gamma.grad += s2, once.
+ * wt_packed / wt2_packed: cwn_update_mlp_pack_weights_t_many_f32 of the block W[:, :F] / W[:, F:] (torch Linear layout).
+ * Every acc1 / acc2 / s1 / s2 / constant pointer 16-B aligned. */
+int cwn_update_mlp_pack_weights_t_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
+                                           cwn_stream_t stream);
+typedef struct cwn_stage_bwd_desc {
+    const float* dy;         /* [M, F] */
+    const float* z;          /* [M, F] */
+    float* dz;               /* [M, F] or NULL */
+    const float* scale;      /* [F] each, or all NULL (no norm) */
+    const float* shift;
+    const float* mean;
+    const float* rstd;
+    const float* s1;
+    const float* s2;
+    float* acc1;
+    float* acc2;
+    const void* wt_packed;
+    const void* wt2_packed;  /* NULL: one product */
+    float* dx;               /* [M, F] */
+    float* dx2;              /* [M, F] or NULL */
+    int64_t M, lddy, ldz, lddz, lddx, lddx2;
+    int32_t relu;
+    int32_t pad_;
+} cwn_stage_bwd_desc;
+int cwn_dense_stage_bwd_f32(const cwn_stage_bwd_desc* descs_host, int n, int32_t F, cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense parts of the path on the matrix cores (fp32 MFMA, exact fp32):

@@ -2535,3 +2535,51 @@ def test_packing_many_stage_blocks_equals_one_by_one():
         one = ops.pack_mlp_weight(torch.nn.Parameter(w.detach().clone()))
         for h, c0 in enumerate(range(0, w.size(1), F)):
             assert torch.equal(ops.packed_stage_block(w, c0), one[h]), (tuple(w.shape), c0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('F,Ms', [(128, (3165, 3341, 304)), (128, (1, 33)), (64, (700, 65, 2))])
+def test_dense_stage_backward_kernel_vs_float64(F, Ms):
+    """cwn_dense_stage_bwd_f32: dz = BatchNorm(train) + ReLU backward of dy (given the column sums), written out, and dX = dz W
+    -- one output for a Linear(F -> F), the two halves for a Linear(2F -> F) -- against the formulas in float64; the sums
+    handed on to beta.grad / gamma.grad once; a stage without a norm (dz = dy where z > 0)."""
+    from cwn_amd import ops, _ffi
+    g = torch.Generator().manual_seed(7 * F + len(Ms))
+    rn = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    for wide in (False, True):
+        lins = [torch.nn.Linear(2 * F if wide else F, F).to(DEV) for _ in Ms]
+        ops.pack_stage_weights_many([l.weight for l in lins])
+        entries, refs, keep = [], [], []
+        for k, M in enumerate(Ms):
+            dy, z = rn(M, F), rn(M, F)
+            with_norm = k != 1
+            aff = torch.stack([rn(F).abs() + 0.5, rn(F), rn(F) * 0.1, rn(F).abs() + 0.5])      # scale, shift, mean, rstd
+            s12 = torch.stack([rn(F), rn(F)]) * M ** 0.5
+            acc = torch.stack([rn(F), rn(F)])
+            acc0 = acc.clone()
+            dz = torch.empty(M, F, device=DEV)
+            b = _ffi.GemmBnb(z=z.data_ptr(), dz=dz.data_ptr(), ldz=F, lddz=F, relu=1)
+            if with_norm:
+                b.scale, b.shift, b.mean, b.rstd = (aff[r].data_ptr() for r in range(4))
+                b.s1, b.s2 = s12[0].data_ptr(), s12[1].data_ptr()
+                b.acc1, b.acc2 = acc[0].data_ptr(), acc[1].data_ptr()
+            out = torch.full((M, 2 * F if wide else F), float('nan'), device=DEV)
+            W = lins[k].weight
+            entries.append((dy, b, W, out[:, :F], out[:, F:] if wide else None))
+            keep += [dy, z, aff, s12, acc, dz, out]
+            D = lambda t: t.double()
+            if with_norm:
+                sc, sh, mu, rs = (D(aff[r]) for r in range(4))
+                dyh = D(dy) * ((D(z) * sc + sh) > 0)
+                want_dz = sc * dyh - sc * D(s12[0]) / M - sc * rs * D(s12[1]) / M * (D(z) - mu)
+            else:
+                want_dz = D(dy) * (D(z) > 0)
+            refs.append((dz, want_dz, out, want_dz @ D(W.detach()), acc, acc0, s12 if with_norm else None))
+        assert ops.run_stage_bwd(entries, DEV), 'the backward stage kernel refused a launch it is written for'
+        for k, (dz, want_dz, out, want_dx, acc, acc0, s12) in enumerate(refs):
+            assert (dz.double() - want_dz).abs().max() <= 1e-5 * max(1.0, float(want_dz.abs().max())), (wide, k)
+            assert (out.double() - want_dx).abs().max() <= 1e-5 * max(1.0, float(want_dx.abs().max())), (wide, k)
+            if s12 is not None:
+                torch.testing.assert_close(acc, acc0 + s12, rtol=1e-6, atol=1e-6)
+            else:
+                assert torch.equal(acc, acc0)
