@@ -43,6 +43,11 @@ FUSED_NORM_BACKWARD = False
 # The apply half of the BatchNorm backward as the PROLOGUE of the input-gradient GEMM that consumes it (cwn_gemm_bnb): no
 # apply launch, dz written once on the way.  False: cwn_norm_bwd_apply_f32 + a plain transposed-weight GEMM (A/B, tests).
 FUSED_NORM_APPLY = os.environ.get('CWN_FUSED_NORM_APPLY') != '0'
+# (Measured and dropped: the REDUCE half of the next stage -- column sums of dyh, dyh * xhat -- taken in the epilogue of the
+# backward-stage launch that produces its dy, the tile still in registers, so that 8 of the 12 reduce launches of a ZINC step
+# go away.  A workgroup of cwn_dense_stage_bwd_f32 owns 32 rows: 428 workgroups x 256 column sums = 110 k fp32 atomics per
+# launch against the ~7 k of cwn_norm_bwd_reduce_f32's 128-row bands -- the launch went from 9.9 to 20.5 us, the step
+# from 0.811 to 0.884 ms.)
 
 
 @dataclass
