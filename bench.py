@@ -940,7 +940,8 @@ def main():
                      'params': int(sum(p.numel() for p in ts.bucket.params)),
                      'backward_pieces': int(ts.n_stages),
                      'ms_per_step_four_per_graph': None if dt4 is None else round(dt4 * 1e3, 4),
-                     'scope': 'adjacency plans (forward + transposed), forward, L1 loss, backward, Adam on one flat buffer (cwn_adam_f32)'
+                     'scope': 'adjacency plans, weight packing, forward, L1 loss, backward (propagate steps: cwn_layer_bwd_own_f32; dense stages: '
+                              'cwn_dense_stage_f32 / _bwd_f32), Adam on one flat buffer (cwn_adam_f32)'
                               + (f', {ts.bucket.flat.numel() * 4 / 1e6:.1f} MB flat gradient bucket all-reduced over RCCL in '
                                  f'{ts.n_stages} chunk(s), each issued as soon as the backward has left its layers'
                                  if world > 1 else '')

@@ -13,6 +13,9 @@
 // column tiles.  The grouped fp32-MFMA launch it replaces (cwn_gemm_f32: weights stationary per workgroup, staged through
 // LDS; 157 TF peak) took 13 - 14.4 us per stage at the ZINC batch of 128 -- with 1.7 tiles per workgroup it never reaches
 // a steady state: weight staging, tile load, 128 dependent MFMAs and the epilogue run back to back.
+// (Measured and dropped: 64 rows per workgroup at F = 128 -- four row tiles a wave, half the weight bytes per row, at most
+// one workgroup per CU at the ZINC batch (214 instead of 428): the training step read 0.829 ms against 0.822, MOLHIV-512
+// 0.965 against 0.931.  Two small workgroups on a CU overlap each other's load and multiply phases; one large one does not.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>

@@ -2460,7 +2460,8 @@ def test_gemm_add_out_adds_onto_what_the_output_holds(M, N, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('F,Ms', [(128, (3165, 3341, 304)), (128, (1, 33)), (64, (700, 65, 2))])
+@pytest.mark.parametrize('F,Ms', [(128, (3165, 3341, 304)), (128, (1, 33)), (64, (700, 65, 2)),
+                                  (128, (3165, 3341, 304, 3165, 3341, 299)), (64, (9000, 8999))])     # (the last two: the large row tile)
 def test_dense_stage_kernel_vs_grouped_gemm(F, Ms):
     """cwn_dense_stage_f32 (csrc/cwn_stage.hip: one stage of the update / combine networks in training mode on the bf16-split
     path with pre-packed weights) against the grouped cwn_gemm_f32 launch it replaces and a float64 product: the rows of Z
@@ -2538,7 +2539,8 @@ def test_packing_many_stage_blocks_equals_one_by_one():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('F,Ms', [(128, (3165, 3341, 304)), (128, (1, 33)), (64, (700, 65, 2))])
+@pytest.mark.parametrize('F,Ms', [(128, (3165, 3341, 304)), (128, (1, 33)), (64, (700, 65, 2)),
+                                  (128, (3165, 3341, 304, 3165, 3341, 299)), (64, (9000, 8999))])     # (the last two: the large row tile)
 def test_dense_stage_backward_kernel_vs_float64(F, Ms):
     """cwn_dense_stage_bwd_f32: dz = BatchNorm(train) + ReLU backward of dy (given the column sums), written out, and dX = dz W
     -- one output for a Linear(F -> F), the two halves for a Linear(2F -> F) -- against the formulas in float64; the sums
