@@ -20,10 +20,11 @@ def _batch(n, seed, kind='zinc', **kw):
 
 
 def _problem(b, F, seed):
-    """Random features / weights / output gradients for the batch's three dimensions (float64)."""
+    """Random features / weights / output gradients for the batch's dimensions (float64)."""
     g = torch.Generator().manual_seed(seed)
     P = {'x': [], 'W': [], 'bias': [], 'eps1': [], 'eps2': [], 'gU': [], 'gB': [], 'up': [], 'sh': [], 'bi': []}
-    for d in range(3):
+    nd = len(b.cochains)
+    for d in range(nd):
         c = b.cochains[d]
         n = c.num_cells
         P['x'].append(torch.randn(n, F, generator=g, dtype=torch.float64))
@@ -33,7 +34,7 @@ def _problem(b, F, seed):
         P['eps2'].append(-0.1 * (d + 1))
         P['gU'].append(torch.randn(n, F, generator=g, dtype=torch.float64))
         P['gB'].append(torch.randn(n, F, generator=g, dtype=torch.float64))
-        up = c.upper_index if (d < 2 and c.upper_index is not None and c.upper_index.size(1)) else None
+        up = c.upper_index if (d < nd - 1 and c.upper_index is not None and c.upper_index.size(1)) else None
         P['up'].append(up)
         P['sh'].append(c.shared_coboundaries if up is not None else None)
         bi = c.boundary_index if (d > 0 and c.boundary_index is not None and c.boundary_index.size(1)) else None
@@ -43,8 +44,9 @@ def _problem(b, F, seed):
 
 def _autograd(P, F):
     xs = [x.clone().requires_grad_() for x in P['x']]
-    Y1, Y2, loss = [None] * 3, [None] * 3, 0.0
-    for d in range(3):
+    nd = len(xs)
+    Y1, Y2, loss = [None] * nd, [None] * nd, 0.0
+    for d in range(nd):
         n = xs[d].size(0)
         out_up = (1 + P['eps1'][d]) * xs[d]
         if P['up'][d] is not None:
@@ -161,7 +163,7 @@ def test_owner_table_executed_on_the_cpu_reproduces_autograd(n, F, kind):
     P = _problem(b, F, seed=3)
     dx_ref, gy1_ref, gy2_ref, Y1, Y2 = _autograd(P, F)
     dx, gy1, gy2, cnt = _execute(tab, P, Y1, Y2, F)
-    for d in range(3):
+    for d in range(len(dx)):
         assert (cnt['dx'][d] == 1).all(), f'dx[{d}]: a row without exactly one owner'
         np.testing.assert_allclose(dx[d], dx_ref[d].numpy(), rtol=1e-10, atol=1e-10)
         if gy1_ref[d] is not None:
@@ -196,3 +198,40 @@ def test_owner_table_limits_and_bad_arguments():
     assert L.cwn_layer_bwd_own_f32(dims, 3, 128, p, None, None) == 1          # CWN_ERR_BAD_ARG
     assert L.cwn_layer_bwd_own_f32(dims, 3, 96, p, None, None) == 1          # CWN_ERR_BAD_ARG
     assert L.cwn_layer_bwd_own_f32(None, 3, 128, p, None, None) == 1          # CWN_ERR_BAD_ARG
+
+
+def test_owner_table_of_a_one_dimensional_batch_and_of_complexes_without_rings():
+    """Graphs lifted to 1-complexes (vertices own their rows, the edges ride as the TOP rows of the same items: first and
+    third product, no second) and a batch in which some molecules have no ring at all (items whose TOP block is empty)."""
+    from cwn_amd.blockplan import BlockPlan
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    F = 128
+    small = [c for c in zinc_like_complexes(60, 3, 6) if c.cochains[1].num_cells <= 32]      # (TOP rows: one round of lane groups)
+    b1 = ComplexBatch.from_complex_list(small, max_dim=1)
+    t1 = BlockPlan.from_batch(b1).bwd_items(F, [True, False])
+    assert t1 is not None and ((t1.host[:, R_FLAGS] & 7) == (PA | TOP)).all()
+    # ... and one molecule with more edges than that gives no table: the caller keeps the streaming backward
+    assert BlockPlan.from_batch(ComplexBatch.from_complex_list(zinc_like_complexes(60, 3, 6), max_dim=1)).bwd_items(F, [True, False]) is None
+    P = _problem(b1, F, seed=5)
+    dx_ref, gy1_ref, gy2_ref, Y1, Y2 = _autograd(P, F)
+    dx, gy1, gy2, cnt = _execute(t1.host, P, Y1, Y2, F)
+    for d in range(2):
+        assert (cnt['dx'][d] == 1).all()
+        np.testing.assert_allclose(dx[d], dx_ref[d].numpy(), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(gy1[0], gy1_ref[0].numpy(), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(gy2[1], gy2_ref[1].numpy(), rtol=1e-10, atol=1e-10)
+    # trees next to ring molecules: rings (and the edges' upper adjacency) absent for some complexes
+    cxs = zinc_like_complexes(30, 7, 6)
+    trees = [c for c in zinc_like_complexes(60, 11, 2) if 2 not in c.cochains or c.cochains[2].num_cells == 0][:6]
+    if trees:
+        mixed = cxs[:10] + trees + cxs[10:]
+        b2 = ComplexBatch.from_complex_list(mixed, max_dim=2)
+        t2 = BlockPlan.from_batch(b2).bwd_items(F, [True, True, False])
+        assert t2 is not None
+        P = _problem(b2, F, seed=6)
+        dx_ref, gy1_ref, gy2_ref, Y1, Y2 = _autograd(P, F)
+        dx, gy1, gy2, cnt = _execute(t2.host, P, Y1, Y2, F)
+        for d in range(3):
+            assert (cnt['dx'][d] == 1).all()
+            np.testing.assert_allclose(dx[d], dx_ref[d].numpy(), rtol=1e-10, atol=1e-10)

@@ -32,8 +32,12 @@ def _conv(F, seed=0, eps=0.0, train_eps=False):
 def _batch(kind, n, F, seed=0, integer=False):
     from cwn_amd.complex import ComplexBatch
     from cwn_amd.synthetic import zinc_like_complexes, molhiv_like_complexes
-    gen = zinc_like_complexes if kind == 'zinc' else molhiv_like_complexes
-    b = ComplexBatch.from_complex_list(gen(n, seed, 6), max_dim=2).to(DEV)
+    gen = zinc_like_complexes if kind in ('zinc', 'zinctrees') else molhiv_like_complexes
+    cxs = gen(n, seed, 6)
+    if kind == 'zinctrees':            # some molecules without a ring (no 2-cells, no upper adjacency of their edges)
+        trees = [c for c in zinc_like_complexes(3 * n, seed + 1, 2) if 2 not in c.cochains or c.cochains[2].num_cells == 0][:max(1, n // 4)]
+        cxs = cxs[: n // 2] + trees + cxs[n // 2:]
+    b = ComplexBatch.from_complex_list(cxs, max_dim=2).to(DEV)
     g = torch.Generator().manual_seed(seed + 17)
     for d in range(3):
         n_d = b.cochains[d].num_cells
@@ -746,7 +750,7 @@ def _propagate_reference_backward(conv, b, gs, F):
 
 @pytest.mark.parametrize('form', ['atomic', 'own'])
 @pytest.mark.parametrize('kind,n,F,eps', [('zinc', 64, 128, 0.0), ('zinc', 128, 128, 0.3), ('zinc', 9, 128, 0.0), ('zinc', 40, 64, 0.2),
-                                          ('zinc', 300, 128, 0.1), ('molhiv', 200, 64, 0.0)])
+                                          ('zinc', 300, 128, 0.1), ('molhiv', 200, 64, 0.0), ('zinctrees', 48, 128, 0.2)])
 def test_blocked_backward_launch_vs_float64_autograd(kind, n, F, eps, form):
     """cwn_layer_bwd_f32 (ops.layer_backward) over the item table of the forward launch, and cwn_layer_bwd_own_f32 over
     the owner table (one writer per row; dx is handed over UNINITIALISED -- filled with NaN here): dx of every dimension
