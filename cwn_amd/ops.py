@@ -477,6 +477,15 @@ def _embedding_table_grads(tables, idx: Tensor, g: Tensor) -> List[Optional[Tens
     if idx.dim() == 1:
         idx = idx.unsqueeze(1)
     off, size = _EmbeddingSum._columns(tables, g.device)
+    if len(tables) == 1:
+        # one table whose .grad is allocated: the kernel ADDS its band partials (fp32 atomics) -- straight into the gradient
+        # buffer, no zeroed scratch and no add behind it (two launches per table of a ZINC training step)
+        t = _grad_target(tables[0])
+        if t is not None and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (V, H):
+            _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
+                g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), t.data_ptr(), idx.size(0),
+                idx.size(1), H, V, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
+            return [None]
     dW = torch.zeros(V, H, dtype=torch.float32, device=g.device)
     _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
         g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), dW.data_ptr(), idx.size(0),
