@@ -663,6 +663,20 @@ def _transposed(weight: Tensor) -> Tensor:
     return t
 
 
+def _transpose_many(weights: Sequence[Tensor]) -> None:
+    """The transposes of all of a head's lin1 weights that `_transposed` would miss, in ONE launch (a training step changes
+    every weight: three copy launches per step otherwise)."""
+    stale = [w for w in weights if not ((h := _w1t_cache.get(id(w))) is not None and h[0]() is w and h[1] == (w._version, STATE_EPOCH))]
+    if len(stale) < 2 or len({(tuple(w.shape), w.dtype, w.device) for w in stale}) != 1 or stale[0].dtype != torch.float32:
+        return
+    if len(_w1t_cache) > 64:
+        _w1t_cache.clear()
+    K = int(stale[0].size(1))
+    both = torch.cat([w.detach().t() for w in stale], dim=0)          # [n K, H2], one kernel
+    for k, w in enumerate(stale):
+        _w1t_cache[id(w)] = (weakref.ref(w), (w._version, STATE_EPOCH), both[k * K: (k + 1) * K])
+
+
 def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexes: int, lin1_weights: Sequence[Tensor],
          lin1_biases: Sequence[Optional[Tensor]], lin2_weight: Tensor, lin2_bias: Optional[Tensor],
          mean_readout: bool = False, mean_final: bool = False, want_pooled: bool = False, want_hidden: bool = False):
@@ -673,6 +687,7 @@ def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexe
     _ffi.require_gpu(x0, 'x')
     dev = x0.device
     K, H2, O = int(lin1_weights[0].size(1)), int(lin1_weights[0].size(0)), int(lin2_weight.size(0))
+    _transpose_many(lin1_weights)
     keep, dims, pooled, hidden = [], [], [], []
     for d, x in enumerate(xs):
         D = _ffi.HeadDim()
