@@ -1268,14 +1268,21 @@ def gemm_aggregate(gemms: Sequence[Gemm], make_streams, precomputed=None) -> Tup
         for (k, slot), gi in links.items():
             flat_s[4 * k + slot] = ys[gi]
         return streams, run_aggregate(_AggregateMany.specs_of(streams, flat_s), device)
-    from .csr import build_many
-    todo = [st.adj for st in streams if st.adj is not None and not st.adj.built]
-    for st in streams:
-        if st.adj is not None and st.ia_mode == 'col':
-            st.adj.transposes()
-            todo += [a for a in (st.adj._t_src, st.adj._t_aux) if a is not None and not a.built]
-    if todo:
-        build_many(todo)
+    # the adjacency plans and their transposes in one batched build -- unless neither pass will read them: the forward is
+    # precomputed (the blocked launch) and the backward is the owner-form launch over its own item table (a backward that
+    # falls back to the streaming path after all builds them when it asks for them: csr.Adjacency.t_src / t_aux)
+    blocked = getattr(ys, 'blocked', None)
+    plans_unused = (precomputed is not None and BLOCKED_BACKWARD == 2 and blocked is not None and len(blocked) > 3
+                    and blocked[3] is not None)
+    if not plans_unused:
+        from .csr import build_many
+        todo = [st.adj for st in streams if st.adj is not None and not st.adj.built]
+        for st in streams:
+            if st.adj is not None and st.ia_mode == 'col':
+                st.adj.transposes()
+                todo += [a for a in (st.adj._t_src, st.adj._t_aux) if a is not None and not a.built]
+        if todo:
+            build_many(todo)
     outs = _GemmAggregate.apply(tuple(gemms), tuple(streams), tuple(links.items()), ys if isinstance(ys, _Precomputed) else tuple(ys), device,
                                 *flat_g, *flat_s)
     return streams, list(outs)
