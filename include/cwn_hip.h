@@ -373,7 +373,8 @@ typedef struct cwn_layer_bwd_dim {
 size_t cwn_layer_bwd_lds_bytes(int32_t F, int32_t max_gemm_rows);
 int cwn_layer_bwd_f32(const cwn_layer_bwd_dim* dims_host, int n_dims, int32_t F, const cwn_layer_plan* plan_host,
                       int32_t* err_flag, cwn_stream_t stream);
-/* The OWNER form of the same backward (csrc/cwn_layer_bwd_own.hip): every row of dx has ONE writer.  An item is a
+/* The OWNER form of the same backward (csrc/cwn_layer_bwd_own.hip; what autograd derives for mp/layers.py:184-192, 290-295,
+ * 333-342 -> mp/cell_mp.py:357-392): every row of dx has ONE writer.  An item is a
  * contiguous range of complexes for one dimension d whose cells it OWNS; its workgroup gathers everything those rows
  * receive -- gY1_d over the entries of up_index_d that name the row as source, the gradient of Y2 at d over the entries of
  * up_index_{d-1} that name it as coface, the boundary transposes over the entries of b_index_{d+1} that name it as
@@ -524,7 +525,8 @@ typedef struct cwn_stage_desc {
     int32_t pad_;
 } cwn_stage_desc;
 int cwn_dense_stage_f32(const cwn_stage_desc* descs_host, int n, int32_t F, cwn_stream_t stream);
-/* ... and BACKWARD: dX = dz W (two halves dX, dX2 for a Linear(2F -> F)) with the BatchNorm(train) + ReLU backward as the
+/* ... and BACKWARD (autograd of the Linear / BatchNorm1d(train) / ReLU modules of mp/layers.py:303-325): dX = dz W (two halves
+ * dX, dX2 for a Linear(2F -> F)) with the BatchNorm(train) + ReLU backward as the
  * prologue -- dz = scale * (dyh - s1 / M - xhat * s2 / M), dyh = dy * [z * scale + shift > 0]; scale NULL: dz = dy * [z > 0]
  * when relu, dy otherwise -- given the column sums s1, s2 of cwn_norm_bwd_reduce_f32.  dz is also written (the
  * weight-gradient GEMM reads it; NULL: not wanted); acc1 / acc2 (or NULL): beta.grad += s1, gamma.grad += s2, once.
