@@ -110,6 +110,137 @@ def gemm_roofline(flops, us, split, io_bytes, narrow, traffic):
             'frac_of_fp32_mfma_peak_157': round(tf / MFMA_F32_PEAK_TF, 4)}
 
 
+def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixed_forward_ms, fixed_train_ms):
+    """secondary.fresh_batches: propagate scope, full forward and full training step over >= 64 distinct shuffled batches per
+    epoch drawn by cwn_amd.packed.PackedLoader, each scope ONE captured graph over a StaticBatch (see the call site)."""
+    import copy
+    import numpy as np
+    from cwn_amd import csr
+    from cwn_amd.packed import PackedComplexes, PackedLoader
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    NB = int(os.environ.get('CWN_BENCH_FRESH_BATCHES', '64'))
+    S = int(os.environ.get('CWN_BENCH_FRESH_STEPS_PER_GRAPH', '8'))
+    EPOCHS = int(os.environ.get('CWN_BENCH_FRESH_EPOCHS', '6'))
+    B = args.batch
+    pool = [c for i in range(NB) for c in gen(9000 + 1000 * rank + i)]
+    packed = PackedComplexes(pool, dev, max_dim=2, with_csr=True)
+    loader = PackedLoader(packed, batch_size=B, shuffle=True, seed=17)
+
+    def epoch(e):
+        loader.set_epoch(e)
+        return loader.batches()
+
+    def cells(bs):
+        return float(sum(int(packed._meta[idx][:, 0:9:3].sum()) for idx in bs)) * L
+
+    sb = StaticBatch(packed, B)
+    sb.reserve_epoch(NB)
+    model = model.eval()
+    inputs = [sb.bufs.get((d, 'x')) for d in range(3)]
+
+    def restore():
+        for d in range(3):
+            sb.batch.cochains[d]._x = inputs[d]
+
+    g_ = torch.Generator().manual_seed(3)
+    feats = [[torch.randn(sb.cap_cells[d], H, generator=g_).to(dev) for d in range(3)] for _ in range(L)]
+
+    def prop_step():
+        sb.fill()
+        b = sb.batch
+        outs = None
+        with sb.dynamic():
+            for l, conv in enumerate(model.convs):
+                b.set_xs(feats[l])
+                _, outs = conv.propagate_all(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+        restore()
+        return outs
+
+    def fwd_step():
+        sb.fill()
+        restore()
+        with sb.dynamic():
+            out = model(sb.batch)
+        restore()
+        return out
+
+    def graph_of(fn, steps):
+        with torch.no_grad():
+            sb.set_epoch(epoch(0))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                keep = [fn() for _ in range(steps)]
+        return g, keep
+
+    def run_epochs(replay, steps_per_replay):
+        """EPOCHS epochs of NB fresh batches each (the per-epoch permutation upload is inside the timed region)"""
+        total = 0.0
+        sb.set_epoch(epoch(1))
+        for _ in range(NB // steps_per_replay):
+            replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for e in range(EPOCHS):
+            bs = epoch(2 + e)
+            sb.set_epoch(bs)
+            for _ in range(NB // steps_per_replay):
+                replay()
+            total += cells(bs[:NB // steps_per_replay * steps_per_replay])
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        n_steps = EPOCHS * (NB // steps_per_replay) * steps_per_replay
+        return total / dt_, dt_ / n_steps * 1e3
+
+    out = {'distinct_batches_per_epoch': NB, 'epochs_timed': EPOCHS, 'batch': B, 'dataset_complexes': len(pool),
+           'capacities': {'cells': list(sb.cap_cells), 'complexes': B},
+           'host_work_per_step': 'one hipGraph replay per %d steps (propagate, forward) / per step (train); the epoch\'s '
+                                 'permutation is uploaded once per epoch, inside the timed region' % S,
+           'scope': 'device-side collate from the HBM-resident packed dataset + segment tables + item tables + the scope itself, '
+                    'every step a batch of the shuffled epoch never seen before (PackedLoader, shuffle=True)'}
+    all_fit = all(bool(sb.fits(epoch(e)).all()) for e in range(2 + EPOCHS))
+    # --- propagate scope
+    g, keep = graph_of(prop_step, S)
+    cps, ms = run_epochs(g.replay, S)
+    out['propagate'] = {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5),
+                        'vs_fixed_batch_replay': round(cps / fixed_cells_per_s, 4) if fixed_cells_per_s else None}
+    del g, keep
+    # --- full forward; the first batch of an epoch against the per-batch launches, bit for bit
+    g, keep = graph_of(fwd_step, S)
+    with torch.no_grad():
+        bs = epoch(1)
+        sb.set_epoch(bs)
+        g.replay()
+        same = all(bool(torch.equal(keep[j][:len(bs[j])], model(packed.collate(bs[j])))) for j in range(min(S, 3)))
+    cps, ms = run_epochs(g.replay, S)
+    out['forward'] = {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'bit_identical_to_per_batch_launches': same,
+                      'vs_fixed_batch_replay': round(fixed_forward_ms / ms, 4) if fixed_forward_ms else None}
+    del g, keep
+    # --- full training step
+    tmodel = copy.deepcopy(model).train()
+    sb.set_epoch(epoch(0))
+    ts = StaticTrainStep(tmodel, sb, task_type='regression')
+    ts.step()
+    all_fit = all_fit and all(bool(sb.fits(epoch(e)).all()) for e in range(2 + EPOCHS))      # (now incl. the backward table)
+    cps, ms = run_epochs(ts.step, 1)
+    out['train'] = {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'loss_finite': bool(torch.isfinite(ts.step()).item()),
+                    'vs_fixed_batch_replay': round(fixed_train_ms / ms, 4) if fixed_train_ms else None}
+    out['every_batch_within_capacity'] = all_fit
+    try:
+        csr.check_errors(dev)
+        out['device_error_word'] = 0
+    except IndexError as e:
+        out['device_error_word'] = str(e)
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -1028,6 +1159,22 @@ def main():
         except Exception as e:
             print(f'[bench] collate leg failed: {type(e).__name__}: {e}', file=sys.stderr)
 
+    # secondary: the reference's loop as it really runs -- every step a batch it has never seen (data/data_loading.py:84-111
+    # shuffles, exp/train_utils.py:35-75 steps through).  ONE captured graph per scope serves every batch of an epoch: the
+    # collate, the segment tables, the item tables and every row count are device-side (cwn_amd/static_batch.py), the epoch's
+    # permutation is uploaded once, a step is a graph replay and nothing else.
+    fresh = None
+    if rank == 0 and world == 1 and not args.only_primary and 'fresh' not in SKIP and BLOCKED and use_graph and WL in ('zinc', 'molhiv'):
+        try:
+            fresh = fresh_batches_leg(args, model, gen, dev, H, L, rank, value / world, dt_full / full_steps * 1e3 if dt_full == dt_full else None,
+                                      None if train is None else train.get('ms_per_step'))
+        except Exception as e:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            print(f'[bench] fresh-batches leg failed: {type(e).__name__}: {e}', file=sys.stderr)
+            fresh = {'failed': f'{type(e).__name__}: {e}'}
+            torch.cuda.synchronize()
+
     # secondary: BASELINE configs[2] and configs[4] (molhiv-512, REDDIT-32) in the same default run -- value + roofline of
     # each from a `--brief` child process of this file (they existed only as builder-run files)
     workloads = None
@@ -1063,6 +1210,7 @@ def main():
         printed.set()
         line_ = result_line(train, collate)
         line_['secondary']['workloads'] = workloads
+        line_['secondary']['fresh_batches'] = fresh
         print(json.dumps(line_), flush=True)
     if dist is not None:
         dist.barrier()      # rank 0 runs the roofline / collate legs alone; leave together

@@ -16,10 +16,10 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
@@ -41,7 +41,7 @@ class AggDesc(C.Structure):
                 ('n_dst', C.c_int64), ('F', C.c_int32), ('b_width', C.c_int32),
                 ('msg_op', C.c_int32), ('reduce', C.c_int32),
                 ('long_cap', C.c_int32), ('flags', C.c_int32),
-                ('self_x2', C.c_void_p), ('eps2', C.c_void_p)]
+                ('self_x2', C.c_void_p), ('eps2', C.c_void_p), ('m_dev', C.c_void_p)]
 
 
 class GemmBnb(C.Structure):
@@ -101,6 +101,13 @@ class LayerSizes(C.Structure):
                 ('skip', C.c_void_p), ('unfit', C.c_void_p)]
 
 
+class LayerSizesDev(C.Structure):
+    """cwn_layer_sizes_dev (include/cwn_hip.h): the prefix sums of a batch as DEVICE arrays."""
+    _fields_ = [('n_complexes', C.c_void_p), ('cap_complexes', C.c_int64), ('n_dims', C.c_int32), ('has_up', C.c_int32 * 3),
+                ('cell_ptr', C.c_void_p * 3), ('up_ptr', C.c_void_p * 3), ('b_ptr', C.c_void_p * 3)]
+
+
+ERR_BIT_UNFIT = 16        # = CWN_ERR_BIT_UNFIT
 LAYER_ITEMS_TOO_LARGE, LAYER_ITEMS_BAD_ARG = -1, -2
 LAYER_BWD_ITEM_INTS = 16       # = CWN_LAYER_BWD_ITEM_INTS
 
@@ -115,7 +122,8 @@ class MlpDim(C.Structure):
     """cwn_mlp_dim (include/cwn_hip.h)."""
     _fields_ = [('x_up', C.c_void_p), ('x_b', C.c_void_p), ('w_packed', C.c_void_p * 6),
                 ('bias', C.c_void_p * 5), ('scale', C.c_void_p * 5), ('shift', C.c_void_p * 5),
-                ('y', C.c_void_p), ('M', C.c_int64), ('ldx_up', C.c_int64), ('ldx_b', C.c_int64), ('ldy', C.c_int64)]
+                ('y', C.c_void_p), ('M', C.c_int64), ('ldx_up', C.c_int64), ('ldx_b', C.c_int64), ('ldy', C.c_int64),
+                ('m_dev', C.c_void_p)]
 
 
 class StageDesc(C.Structure):
@@ -124,7 +132,7 @@ class StageDesc(C.Structure):
                 ('bias', C.c_void_p), ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('in_scale2', C.c_void_p),
                 ('in_shift2', C.c_void_p), ('Y', C.c_void_p), ('col_sum', C.c_void_p), ('col_sumsq', C.c_void_p),
                 ('M', C.c_int64), ('ldx', C.c_int64), ('ldx2', C.c_int64), ('ldy', C.c_int64),
-                ('in_relu', C.c_int32), ('pad_', C.c_int32)]
+                ('in_relu', C.c_int32), ('pad_', C.c_int32), ('m_dev', C.c_void_p)]
 
 
 class StageBwdDesc(C.Structure):
@@ -133,7 +141,7 @@ class StageBwdDesc(C.Structure):
                 ('mean', C.c_void_p), ('rstd', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p), ('acc1', C.c_void_p),
                 ('acc2', C.c_void_p), ('wt_packed', C.c_void_p), ('wt2_packed', C.c_void_p), ('dx', C.c_void_p), ('dx2', C.c_void_p),
                 ('M', C.c_int64), ('lddy', C.c_int64), ('ldz', C.c_int64), ('lddz', C.c_int64), ('lddx', C.c_int64),
-                ('lddx2', C.c_int64), ('relu', C.c_int32), ('pad_', C.c_int32)]
+                ('lddx2', C.c_int64), ('relu', C.c_int32), ('pad_', C.c_int32), ('m_dev', C.c_void_p)]
 
 
 STAGE_PACK_MAX = 96            # = CWN_STAGE_PACK_MAX
@@ -174,14 +182,15 @@ class BnDesc(C.Structure):
                 ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
                 ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p),
                 ('M', C.c_int64), ('N', C.c_int32), ('eps', C.c_float), ('momentum', C.c_float),
-                ('pad_', C.c_int32), ('num_batches_tracked', C.c_void_p), ('bwd_sums', C.c_void_p)]
+                ('pad_', C.c_int32), ('num_batches_tracked', C.c_void_p), ('bwd_sums', C.c_void_p), ('m_dev', C.c_void_p)]
 
 
 class NormDesc(C.Structure):
     _fields_ = [('dy', C.c_void_p), ('z', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
                 ('mean', C.c_void_p), ('rstd', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p),
                 ('out', C.c_void_p), ('M', C.c_int64), ('lddy', C.c_int64), ('ldz', C.c_int64),
-                ('ldout', C.c_int64), ('N', C.c_int32), ('relu', C.c_int32), ('acc1', C.c_void_p), ('acc2', C.c_void_p)]
+                ('ldout', C.c_int64), ('N', C.c_int32), ('relu', C.c_int32), ('acc1', C.c_void_p), ('acc2', C.c_void_p),
+                ('m_dev', C.c_void_p)]
 
 
 class GemmTnDesc(C.Structure):
@@ -189,11 +198,11 @@ class GemmTnDesc(C.Structure):
                 ('in_shift', C.c_void_p), ('in_scale2', C.c_void_p), ('in_shift2', C.c_void_p),
                 ('dW', C.c_void_p), ('db', C.c_void_p), ('M', C.c_int64), ('lddz', C.c_int64),
                 ('ldx', C.c_int64), ('ldx2', C.c_int64), ('lddw', C.c_int64), ('N', C.c_int32),
-                ('K', C.c_int32), ('K2', C.c_int32), ('in_relu', C.c_int32)]
+                ('K', C.c_int32), ('K2', C.c_int32), ('in_relu', C.c_int32), ('m_dev', C.c_void_p)]
 
 
 MAX_NORM_DESCS = 16
-COLLATE_COPY32, COLLATE_COPY64, COLLATE_ADD64, COLLATE_SEGID64 = range(4)
+COLLATE_COPY32, COLLATE_COPY64, COLLATE_ADD64, COLLATE_SEGID64, COLLATE_ADD32 = range(5)
 MAX_COLLATE_DESCS = 32
 
 
@@ -282,6 +291,16 @@ def lib():
     L.cwn_gemm_would_split.argtypes = [C.POINTER(GemmDesc), C.c_int]
     L.cwn_collate.restype = C.c_int
     L.cwn_collate.argtypes = [C.POINTER(CollateDesc), C.c_int, C.c_int64, C.c_void_p]
+    L.cwn_collate_tables_len.restype = C.c_size_t
+    L.cwn_collate_tables_len.argtypes = [C.c_int32, C.c_int32, C.c_int64]
+    L.cwn_collate_tables.restype = C.c_int
+    L.cwn_collate_tables.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+    L.cwn_layer_items_build_dev.restype = C.c_int
+    L.cwn_layer_items_build_dev.argtypes = [C.POINTER(LayerSizesDev), C.c_int32, C.POINTER(LayerPlan), C.c_int32, C.c_void_p, C.c_void_p]
+    L.cwn_layer_bwd_items_build_dev.restype = C.c_int
+    L.cwn_layer_bwd_items_build_dev.argtypes = [C.POINTER(LayerSizesDev), C.c_int32, C.POINTER(LayerBwdPlan), C.c_int32, C.c_void_p,
+                                                C.c_void_p]
     L.cwn_bn_finalize_f32.restype = C.c_int
     L.cwn_bn_finalize_f32.argtypes = [C.POINTER(BnDesc), C.c_int, C.c_void_p]
     for name in ('cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32'):
@@ -297,17 +316,17 @@ def lib():
     L.cwn_adam_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     L.cwn_loss_f32.restype = C.c_int
-    L.cwn_loss_f32.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cwn_loss_f32.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cwn_embedding_fwd_f32.restype = C.c_int
     L.cwn_embedding_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     L.cwn_embedding_bwd_f32.restype = C.c_int
     L.cwn_embedding_bwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                        C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+                                        C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_embed_front_f32.restype = C.c_int
     L.cwn_embed_front_f32.argtypes = [C.POINTER(EmbedTable), C.c_int64, C.c_void_p, C.POINTER(EmbedTable), C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+                                      C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cwn_head_f32.restype = C.c_int
     L.cwn_head_f32.argtypes = [C.POINTER(HeadDim), C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -343,6 +362,44 @@ def check(code: int, what: str):
         raise CwnError(f'{what}: {lib().cwn_error_string(code).decode()} (code {code})')
 
 
+# ---- device-side row counts (include/cwn_hip.h, "Conventions") ------------------------------------------------------------
+# A step captured ONCE over capacity-sized buffers serves batches of any shape (cwn_amd/static_graph.py): the tensors the
+# model code passes around then have the CAPACITY as their row count, and the number of rows that exist lives in device
+# memory.  DYN_ROWS maps a capacity to the address of that device int64; every launch wrapper below (and the few direct
+# calls in ops.py / train.py) looks its descriptors' row counts up here and fills `m_dev`.  Empty outside
+# `dynamic_rows(...)`: nothing changes for ordinary launches.  The capacities of a static batch are pairwise distinct
+# (static_graph.StaticBatch sees to it), so a row count identifies its dimension.
+DYN_ROWS = {}
+
+
+class dynamic_rows:
+    """Context manager: inside, a descriptor whose row count is a key of `mapping` gets m_dev = mapping[rows]."""
+
+    def __init__(self, mapping):
+        self.mapping = dict(mapping)
+
+    def __enter__(self):
+        self.prev = dict(DYN_ROWS)
+        DYN_ROWS.update(self.mapping)
+        return self
+
+    def __exit__(self, *exc):
+        DYN_ROWS.clear()
+        DYN_ROWS.update(self.prev)
+        return False
+
+
+def dyn(rows) -> Optional[int]:
+    """Device address of the actual row count behind the capacity `rows`, or None."""
+    return DYN_ROWS.get(int(rows)) if DYN_ROWS else None
+
+
+def _set_dyn(descs, field: str = 'M') -> None:
+    if DYN_ROWS:
+        for d in descs:
+            d.m_dev = DYN_ROWS.get(int(getattr(d, field)))
+
+
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
@@ -368,6 +425,7 @@ def aggregate(descs: Sequence[AggDesc], device) -> None:
     """One kernel launch for up to MAX_DESCS descriptors; more are split into several calls."""
     L = lib()
     s = stream_ptr(device)
+    _set_dyn(descs, 'n_dst')
     for i in range(0, len(descs), MAX_DESCS):
         chunk = descs[i:i + MAX_DESCS]
         arr = (AggDesc * len(chunk))(*chunk)
@@ -402,6 +460,7 @@ def _chunked(fn_name: str, struct, descs, device, limit: int) -> None:
     L = lib()
     s = stream_ptr(device)
     fn = getattr(L, fn_name)
+    _set_dyn(descs)
     for i in range(0, len(descs), limit):
         chunk = descs[i:i + limit]
         arr = (struct * len(chunk))(*chunk)
@@ -431,6 +490,7 @@ def norm_bwd(descs: Sequence[NormDesc], device, accumulate: bool) -> None:
     """Reduce + apply in one launch (matrices of at most NORM_BWD_FUSED_MAX_ROWS rows, 16-byte aligned)."""
     L = lib()
     s = stream_ptr(device)
+    _set_dyn(descs)
     for i in range(0, len(descs), MAX_NORM_DESCS):
         chunk = descs[i:i + MAX_NORM_DESCS]
         arr = (NormDesc * len(chunk))(*chunk)
@@ -521,6 +581,7 @@ def gemm_tn(descs: Sequence[GemmTnDesc], device, keep=None, deferrable: bool = F
         return
     L = lib()
     s = stream_ptr(device)
+    _set_dyn(descs)
     for i in range(0, len(descs), MAX_TN_DESCS):
         chunk = descs[i:i + MAX_TN_DESCS]
         arr = (GemmTnDesc * len(chunk))(*chunk)

@@ -335,3 +335,108 @@ class BlockPlan:
         if rc != 0:
             raise _ffi.CwnError(f'item table failed cwn_layer_items_check ({rc})')
         return out
+
+
+# ---- which single complexes a workgroup holds (numpy, vectorised over a dataset) ------------------------------------------
+# The device-side table builders (csrc/cwn_items_dev.hip) give a complex that does not fit alone no record and set an error
+# bit; a caller that feeds them fresh batches (cwn_amd/static_batch.py) checks BEFORE the launch, on the host, from the same
+# per-complex sizes -- these functions restate the builders' `fits(c, c + 1)` for every complex of a dataset at once.
+def _sets_of(n_dims: int, has_up: Sequence[bool]):
+    sets, d = [], 0
+    while d < n_dims:
+        if has_up[d]:
+            tasks = [d]
+            if d + 1 < n_dims and not has_up[d + 1] and d + 2 >= n_dims:
+                tasks.append(d + 1)
+            sets.append((d, tasks))
+            d += len(tasks)
+        else:
+            sets.append((None, [d]))
+            d += 1
+    return sets
+
+
+def single_fit_forward(cells: Sequence[np.ndarray], up_len: Sequence[Optional[np.ndarray]], b_len: Sequence[Optional[np.ndarray]],
+                       F: int, has_up: Sequence[bool], has_b: Sequence[bool], variant: int, row_cap: int, src_cap: int) -> np.ndarray:
+    """bool per complex: does it fit one workgroup of cwn_layer_fused_f32 in EVERY set (cells[d], up_len[d], b_len[d]: per-complex
+    counts; the caps: the launch's LDS split)?  = items_fwd_kernel's fits(c, c + 1)."""
+    n_dims = len(cells)
+    cells = [np.asarray(c, dtype=np.int64) for c in cells]
+    z = np.zeros_like(cells[0])
+    up = [np.asarray(u, dtype=np.int64) if (u is not None) else z for u in up_len]
+    bl = [np.asarray(b, dtype=np.int64) if (b is not None and has_b[d]) else z for d, b in enumerate(b_len)]
+    p16 = lambda n: (n + 15) // 16 * 16
+    p4 = lambda n: (n + 3) // 4 * 4
+    rr = (1024 if variant == 0 else 512) // (F // 4)                   # rows per round (cwn_layer_variant_round_rows)
+    budget = LDS_BYTES if variant == 0 else 80 * 1024
+    half = 0 if variant == 0 else (128 if F == 64 else 64)
+    ok = np.ones(cells[0].shape, dtype=bool)
+    for g, tasks in _sets_of(n_dims, has_up):
+        d0 = tasks[0]
+        n0 = cells[d0]
+        nc = cells[g + 1] if g is not None else z
+        first = np.where(nc > 0, (p16(n0) + rr - 1) // rr * rr, p16(n0))
+        rows = np.where(nc > 0, first + p16(nc), p16(n0))
+        src = np.zeros_like(n0)
+        ents = p4(up[g]) if g is not None else np.zeros_like(n0)
+        for t, d in enumerate(tasks):
+            be = bl[d] if d > 0 else z
+            if d > 0 and (variant == 0 or t == 0):
+                src = src + np.where(be > 0, cells[d - 1], 0)
+            ents = ents + p4(be)
+            ok &= cells[d] <= TASK_ROWS
+        lds = 3 * rows * (F + 8) * 2 + (src + 1) * F * 4 + _IDX_BYTES
+        ok &= (rows <= row_cap) & (src <= src_cap) & (lds <= budget) & (ents <= MAX_ENTRIES)
+        if half and g is not None:
+            ok &= (p16(n0) <= half) & (p16(nc) <= half)
+    return ok
+
+
+def bwd_layout_total(F: int, flags: int, n_o, n_a, n_b, ne_a, ne_b, ne_bd):
+    """cwn_bwd_own::layout(...).total (csrc/cwn_layer_bwd_own.h), vectorised."""
+    pa, pb, top = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+    p16 = lambda n: (n + 15) // 16 * 16
+    p4 = lambda n: (n + 3) // 4 * 4
+    s_rows = (2 * n_o + n_a if pa else 0) + (n_o + 2 * n_b if pb else 0) + np.where(ne_bd > 0, n_a, 0)
+    RO = p16(n_o)
+    RT = p16(n_a) if top else 0 * n_o
+    pl_rows = (RO if pa else 0) + (RO if pb else 0) + RT
+    s_bytes, p_bytes = s_rows * (F + 4) * 4, 3 * pl_rows * (F + 8) * 2
+    reg0 = (np.maximum(s_bytes, p_bytes) + 15) // 16 * 16
+    ent_off = reg0 + (RO + RT) * (F + 4) * 4
+    ea4 = p4(ne_a) if pa else 0 * n_o
+    eb4 = p4(ne_b) if pb else 0 * n_o
+    p_off = (ent_off + (6 * ea4 + 3 * eb4 + 2 * p4(ne_bd)) * 4 + 15) // 16 * 16
+    rounds = 1024 // (F // 4)
+    return p_off + (np.where(n_a > 0, rounds * (F + 4) * 4, 0) if top else 0)
+
+
+def single_fit_backward(cells: Sequence[np.ndarray], up_len: Sequence[Optional[np.ndarray]], b_len: Sequence[Optional[np.ndarray]],
+                        F: int, has_up: Sequence[bool], has_b: Sequence[bool], lds_cap: int = LDS_BYTES) -> np.ndarray:
+    """bool per complex: does it fit one workgroup of cwn_layer_bwd_own_f32 in every set?  = items_bwd_kernel's classify >= 0."""
+    n_dims = len(cells)
+    cells = [np.asarray(c, dtype=np.int64) for c in cells]
+    z = np.zeros_like(cells[0])
+    up = [np.asarray(u, dtype=np.int64) if u is not None else z for u in up_len]
+    bl = [np.asarray(b, dtype=np.int64) if (b is not None and has_b[d]) else z for d, b in enumerate(b_len)]
+    own_cap = 256 if F == 64 else 96
+    top_cap = 1024 // (F // 4)
+    ok = np.ones(cells[0].shape, dtype=bool)
+    for g, tasks in _sets_of(n_dims, has_up):
+        d = tasks[0]
+        top, pa, pb = len(tasks) == 2, bool(has_up[d]), d > 0 and bool(has_up[d - 1])
+        above = d + 1 < n_dims
+        n_o = cells[d]
+        n_a = cells[d + 1] if above else z
+        n_b = cells[d - 1] if pb else z
+        ea = up[d] if pa else z
+        eb = up[d - 1] if pb else z
+        bd = bl[d + 1] if above else z
+        flags = (1 if pa else 0) | (2 if pb else 0) | (4 if top else 0)
+        need_a = pa or top
+        na_eff = n_a if need_a else np.where(bd > 0, n_a, 0)
+        total = bwd_layout_total(F, flags, n_o, na_eff, n_b, ea, eb, bd)
+        ok &= (n_o <= own_cap) & ((n_a <= top_cap) if top else True) & (ea <= MAX_ENTRIES) & (eb <= MAX_ENTRIES) & (bd <= MAX_ENTRIES)
+        ok &= (n_a <= 4096) & (n_b <= 4096) & (total <= lds_cap)
+        ok &= ~((n_o == 0) & (((n_a > 0) if top else False) | (ea > 0) | (eb > 0) | (bd > 0)))
+    return ok

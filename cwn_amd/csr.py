@@ -207,7 +207,9 @@ def build_many(adjs: Sequence[Adjacency], overlap: bool = False, validate: bool 
 
 def _describe(flag: int) -> str:
     what = [n for b, n in ((1, 'destination index'), (2, 'source index'), (4, 'shared (co)boundary index'),
-                           (8, 'an index outside its complex (batch not block-diagonal, or a stale item table)'))
+                           (8, 'an index outside its complex (batch not block-diagonal, or a stale item table)'),
+                           (16, 'a complex beyond what one workgroup holds reached the device-side item-table build '
+                                '(static_batch.StaticBatch.fits() tells which batches a static batch takes)'))
             if flag & b]
     return 'index out of range in adjacency: ' + ', '.join(what)
 

@@ -301,8 +301,10 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
     const int gq = threadIdx.x / G;
     const bool has_long = D.long_rows != nullptr && D.n_long != nullptr && D.rowptr != nullptr;
     const int64_t row = (int64_t)blk * R + gq;
+    // destination rows that exist (include/cwn_hip.h, "device-side row counts"; D.n_dst is then the capacity)
+    const int64_t n_dst = D.m_dev != nullptr ? *D.m_dev : D.n_dst;
     int start = 0, end = 0;
-    if (row < D.n_dst && D.rowptr != nullptr) {
+    if (row < n_dst && D.rowptr != nullptr) {
         start = D.rowptr[row];
         end = D.rowptr[row + 1];
     }
@@ -315,7 +317,7 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
     int z = 0;
     asm volatile("" : "+v"(z));  // a zero the compiler cannot fold: keeps the eps loads in VMEM
     const float self_scale = 1.0f + (D.eps != nullptr ? D.eps[z] : 0.0f);
-    if (row < D.n_dst) {  // whole groups take the branch together (G divides 64)
+    if (row < n_dst) {  // whole groups take the branch together (G divides 64)
         if (has_long && end - start > CWN_LONG_ROW) {
             // left to the whole-workgroup pass below
         } else if (GF < G && end - start > kSplitRow) {

@@ -30,6 +30,11 @@ __global__ __launch_bounds__(kThreads) void collate_kernel(CollateBatch B, int64
             const int32_t* src = (const int32_t*)D.src + r * D.src_row_stride + s0;
             int32_t* dst = (int32_t*)D.dst + r * D.dst_row_stride + d0;
             for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = src[q];
+        } else if (D.op == CWN_COLLATE_ADD32) {
+            const int32_t* src = (const int32_t*)D.src + r * D.src_row_stride + s0;
+            int32_t* dst = (int32_t*)D.dst + r * D.dst_row_stride + d0;
+            const int32_t a = (int32_t)add;
+            for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = src[q] + a;
         } else if (D.op == CWN_COLLATE_SEGID64) {
             int64_t* dst = (int64_t*)D.dst + r * D.dst_row_stride + d0;
             for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = s;
@@ -42,7 +47,104 @@ __global__ __launch_bounds__(kThreads) void collate_kernel(CollateBatch B, int64
     }
 }
 
+// ---- the segment tables of a batch, on the device (include/cwn_hip.h: cwn_collate_tables) ------------------------------------
+// One workgroup of 16 waves; wave w takes the columns w, w + 16, ... of the 3 D + K scanned ones (cells / below / above of
+// every dimension, the length of every key): per column an inclusive scan over the B complexes of the batch, 64 at a time
+// (a gather of the complexes' metadata rows, a wave scan, a running carry), written out in the forms the collate launch
+// and the item-table launches read.  Integer work on a few kilobytes: its cost is two dependent memory round trips per 64
+// complexes and column, all columns in parallel.
+constexpr int kTabThreads = 1024;
+
+__global__ __launch_bounds__(kTabThreads) void collate_tables_kernel(const int64_t* __restrict__ meta, int64_t num, int D, int K,
+                                                                     const int64_t* __restrict__ idx_all, int64_t B,
+                                                                     int64_t* __restrict__ cursor, int64_t* __restrict__ tab,
+                                                                     int32_t* __restrict__ err) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = 3 * D + 3 * K, ncol = 3 * D + K;
+    int64_t cur = 0;
+    if (cursor != nullptr) cur = *cursor;
+    __syncthreads();                                    // every thread has read the cursor before it moves
+    if (cursor != nullptr && threadIdx.x == 0) *cursor = cur + 1;
+    const int64_t* idx = idx_all + cur * B;
+    const int64_t o_src = (int64_t)K * (B + 1), o_off = o_src + (int64_t)K * B, o_seg = o_off + (int64_t)D * 5 * B;
+    const int64_t o_sizes = o_seg + (int64_t)D * (B + 1);
+    bool bad = false;
+    for (int col = wave; col < ncol; col += kTabThreads / 64) {
+        int64_t carry = 0;
+        const bool is_key = col >= 3 * D;
+        const int k = col - 3 * D, d = col / 3, which = col % 3;
+        for (int64_t s0 = 0; s0 < B; s0 += 64) {
+            const int64_t s = s0 + lane;
+            int64_t c = s < B ? idx[s] : -1;
+            if (c >= num) { bad = true; c = -1; }
+            const int64_t v = c >= 0 ? meta[c * W + col] : 0;
+            const int64_t start = (is_key && c >= 0) ? meta[c * W + col + K] : 0;
+            int64_t x = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int64_t y = __shfl_up(x, o, 64);
+                if (lane >= o) x += y;
+            }
+            const int64_t incl = carry + x, excl = incl - v;
+            if (s < B) {
+                if (is_key) {
+                    tab[(int64_t)k * (B + 1) + s + 1] = incl;
+                    tab[o_src + (int64_t)k * B + s] = start;
+                } else {
+                    int64_t* off = tab + o_off + (int64_t)d * 5 * B;
+                    if (which == 0) {                   // (here, here, below, here, above)
+                        off[0 * B + s] = excl;
+                        off[1 * B + s] = excl;
+                        off[3 * B + s] = excl;
+                        tab[o_seg + (int64_t)d * (B + 1) + s] = excl;
+                    } else if (which == 1) {
+                        off[2 * B + s] = excl;
+                    } else {
+                        off[4 * B + s] = excl;
+                    }
+                }
+            }
+            carry += __shfl(x, 63, 64);
+        }
+        if (lane == 0) {
+            if (is_key) {
+                tab[(int64_t)k * (B + 1)] = 0;
+                tab[o_sizes + 8 + k] = carry;
+            } else if (which == 0) {
+                tab[o_seg + (int64_t)d * (B + 1) + B] = carry;
+                if (d < 3) tab[o_sizes + d] = carry;
+            }
+        }
+    }
+    if (wave == 0) {                                    // complexes in the batch; the unused size slots
+        int64_t n = 0;
+        for (int64_t s0 = 0; s0 < B; s0 += 64) {
+            const int64_t s = s0 + lane;
+            const int64_t c = s < B ? idx[s] : -1;
+            n += __popcll(__ballot(c >= 0 && c < num));
+        }
+        if (lane == 0) tab[o_sizes + 3] = n;
+        if (lane >= 4 && lane < 8) tab[o_sizes + lane] = 0;
+        if (lane < 3 && lane >= D) tab[o_sizes + lane] = 0;
+    }
+    if (bad) atomicOr(err, 2);
+}
+
 }  // namespace
+
+extern "C" size_t cwn_collate_tables_len(int32_t D, int32_t K, int64_t B) {
+    if (D < 1 || K < 0 || B < 1) return 0;
+    return (size_t)((int64_t)K * (B + 1) + (int64_t)K * B + (int64_t)D * 5 * B + (int64_t)D * (B + 1) + 8 + K);
+}
+
+extern "C" int cwn_collate_tables(const int64_t* meta, int64_t num, int32_t D, int32_t K, const int64_t* idx, int64_t B,
+                                  int64_t* cursor, int64_t* tables, int32_t* err_flag, cwn_stream_t stream_) {
+    if (meta == nullptr || idx == nullptr || tables == nullptr || err_flag == nullptr || num < 0 || D < 1 || D > 8 || K < 0 || B < 1)
+        return CWN_ERR_BAD_ARG;
+    if (B >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    collate_tables_kernel<<<dim3(1), dim3(kTabThreads), 0, (hipStream_t)stream_>>>(meta, num, D, K, idx, B, cursor, tables, err_flag);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
 
 extern "C" int cwn_collate(const cwn_collate_desc* descs, int n, int64_t n_seg, cwn_stream_t stream_) {
     if (descs == nullptr || n <= 0 || n > CWN_MAX_COLLATE_DESCS || n_seg < 0) return CWN_ERR_BAD_ARG;
@@ -53,9 +155,9 @@ extern "C" int cwn_collate(const cwn_collate_desc* descs, int n, int64_t n_seg, 
     for (int i = 0; i < n; ++i) {
         const cwn_collate_desc& D = descs[i];
         if (D.dst == nullptr || D.dst_start == nullptr || D.n_rows < 1 || D.n_rows > 2) return CWN_ERR_BAD_ARG;
-        if (D.op < CWN_COLLATE_COPY32 || D.op > CWN_COLLATE_SEGID64) return CWN_ERR_BAD_ARG;
+        if (D.op < CWN_COLLATE_COPY32 || D.op > CWN_COLLATE_ADD32) return CWN_ERR_BAD_ARG;
         if (D.op != CWN_COLLATE_SEGID64 && (D.src == nullptr || D.src_start == nullptr)) return CWN_ERR_BAD_ARG;
-        if (D.op == CWN_COLLATE_ADD64 && D.add == nullptr) return CWN_ERR_BAD_ARG;
+        if ((D.op == CWN_COLLATE_ADD64 || D.op == CWN_COLLATE_ADD32) && D.add == nullptr) return CWN_ERR_BAD_ARG;
         B.d[i] = D;
     }
     collate_kernel<<<dim3((unsigned)n_seg, (unsigned)n), dim3(kThreads), 0, (hipStream_t)stream_>>>(B, n_seg);

@@ -40,6 +40,7 @@ struct FrontArgs {
     int64_t n0, n1, n2;
     int32_t H, G, has_te, halve;
     int32_t* err;
+    const int64_t* n_dev;        // [3] the actual n0, n1, n2 (the fields above are then capacities: grid, output blocks), or NULL
 };
 
 __device__ __forceinline__ int64_t clampi(int64_t v, int64_t n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
@@ -220,6 +221,17 @@ __device__ __forceinline__ float4 ring_chunk(const FrontArgs& A, const FrontLayo
 template <int MAXC>
 __global__ __launch_bounds__(256) void embed_front_kernel(FrontArgs A) {
     __shared__ FrontLayout L;
+    // device-side row counts: the ROW -> (dimension, cell) mapping below follows the capacities (the grid was sized with
+    // them); a cell past its dimension's actual count leaves
+    // (the index clamps of the reductions keep the capacities: they are there so that no address leaves the buffers)
+    const int64_t cap0 = A.n0, cap1 = A.n1;
+    int64_t live0 = A.n0, live1 = A.n1, live2 = A.n2;
+    if (A.n_dev != nullptr) {
+        const int64_t d0 = A.n_dev[0], d1 = A.n_dev[1], d2 = A.n_dev[2];
+        live0 = d0 < live0 ? d0 : live0;
+        live1 = d1 < live1 ? d1 : live1;
+        live2 = d2 < live2 ? d2 : live2;
+    }
     if constexpr (MAXC > 1) {            // (one table per cell type: its size is T.V, no offsets -- nothing to stage)
         if (threadIdx.x < 2 * kMaxCols) {
             const int which = threadIdx.x / kMaxCols, c = threadIdx.x % kMaxCols;
@@ -232,19 +244,20 @@ __global__ __launch_bounds__(256) void embed_front_kernel(FrontArgs A) {
     }
     const int G = A.G, gl = threadIdx.x & (G - 1);
     const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
-    if (row >= A.n0 + A.n1 + A.n2) return;
+    if (row >= cap0 + cap1 + A.n2) return;
+    if (row < cap0 ? row >= live0 : (row < cap0 + cap1 ? row - cap0 >= live1 : row - cap0 - cap1 >= live2)) return;
     for (int h = 4 * gl; h < A.H; h += 4 * G) {
         float4 v;
         float* dst;
-        if (row < A.n0) {
+        if (row < cap0) {
             v = emb_row<MAXC>(A.tv, L, 0, row, A.H, h, A.err);
             dst = A.x0 + row * A.H + h;
-        } else if (row < A.n0 + A.n1) {
-            const int64_t e = row - A.n0;
+        } else if (row < cap0 + cap1) {
+            const int64_t e = row - cap0;
             v = A.has_te ? emb_row<MAXC>(A.te, L, 1, e, A.H, h, A.err) : reduce_edge<MAXC>(A, L, e, h);
             dst = A.x1 + e * A.H + h;
         } else {
-            const int64_t r = row - A.n0 - A.n1;
+            const int64_t r = row - cap0 - cap1;
             v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (A.rowptr2 != nullptr && A.rowptr1 != nullptr) {
                 const int s = A.rowptr2[r], t = A.rowptr2[r + 1];
@@ -529,7 +542,7 @@ extern "C" int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims, int n_dims, int64_
 extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, float* x0, const cwn_embed_table* e_tab,
                                    int64_t n1, float* x1, const int32_t* rowptr1, const int32_t* col1, int64_t nb1, int64_t n2,
                                    float* x2, const int32_t* rowptr2, const int32_t* col2, int64_t nb2, int32_t H,
-                                   int32_t halve, int32_t* err_flag, cwn_stream_t stream_) {
+                                   int32_t halve, int32_t* err_flag, const int64_t* n_dev, cwn_stream_t stream_) {
     if (v_tab == nullptr || n0 < 0 || n1 < 0 || n2 < 0 || H <= 0 || (H & 3) != 0 || err_flag == nullptr) return CWN_ERR_BAD_ARG;
     if (n0 + n1 + n2 == 0) return CWN_OK;
     if (nb1 < 0 || nb2 < 0) return CWN_ERR_BAD_ARG;
@@ -552,6 +565,7 @@ extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, flo
     A.H = H;
     A.halve = halve ? 1 : 0;
     A.err = err_flag;
+    A.n_dev = n_dev;
     int G = 1;
     while (G < H / 4 && G < 64) G <<= 1;
     A.G = G;

@@ -40,7 +40,6 @@ struct TnBatch {       // a kernel argument: must stay under 4 KiB (static_asser
     cwn_gemm_tn_desc d[CWN_GEMM_TN_MAX_DESCS];
     int32_t blk_start[CWN_GEMM_TN_MAX_DESCS + 1];
     int32_t tiles_n[CWN_GEMM_TN_MAX_DESCS], tiles_k[CWN_GEMM_TN_MAX_DESCS];
-    int32_t vec[CWN_GEMM_TN_MAX_DESCS];
     int32_t n;
     float* ws[CWN_GEMM_TN_MAX_DESCS];      // per-band partials [bands][N][K + K2] then [bands][N] (db), or NULL
     int32_t bands[CWN_GEMM_TN_MAX_DESCS];
@@ -153,8 +152,12 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_tn_kernel(TnBatch B) {
     b /= tk;
     const int tile_n = b % tn;
     const int band = b / tn;
-    const int64_t M = D.M;
+    // rows of the reduction that exist (include/cwn_hip.h, "device-side row counts"): D.M is then the capacity -- it shaped the
+    // grid and bounds the addresses of the loads, which do not wait for this one
+    const int64_t Mcap = D.M;
+    const int64_t M = D.m_dev != nullptr ? (*D.m_dev < Mcap ? *D.m_dev : Mcap) : Mcap;
     const int64_t row_lo = (int64_t)band * B.band_rows;
+    const int64_t cap_hi = row_lo + B.band_rows < Mcap ? row_lo + B.band_rows : Mcap;
     const int64_t row_hi = row_lo + B.band_rows < M ? row_lo + B.band_rows : M;
     const int n0 = tile_n * kTile, k0 = tile_k * kTile;
     const int N = D.N, Ktot = D.K + D.K2;
@@ -174,8 +177,10 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_tn_kernel(TnBatch B) {
     const bool do_bias = D.db != nullptr && tile_k == 0;
 
     f32x4 vz[kU], vx[kU];
-    tile_load<FAST>(vz, SZ, n0, row_lo, row_hi);
-    tile_load<FAST>(vx, SX, k0, row_lo, row_hi);
+    tile_load<FAST>(vz, SZ, n0, row_lo, cap_hi);
+    tile_load<FAST>(vx, SX, k0, row_lo, cap_hi);
+    // a band past the batch's own rows adds nothing (the deterministic form still writes its partial tile: zeros)
+    if (row_lo >= row_hi && B.ws[di] == nullptr) return;
     const Pro PZ = make_pro(SZ, n0), PX = make_pro(SX, k0);
     for (int64_t row0 = row_lo; row0 < row_hi; row0 += kChunk) {
         __syncthreads();                          // everyone is done reading the previous chunk
@@ -183,8 +188,8 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_tn_kernel(TnBatch B) {
         tile_store(xt, vx, PX, row0, row_hi);
         __syncthreads();
         if (row0 + kChunk < row_hi) {             // next chunk in flight during the MFMAs
-            tile_load<FAST>(vz, SZ, n0, row0 + kChunk, row_hi);
-            tile_load<FAST>(vx, SX, k0, row0 + kChunk, row_hi);
+            tile_load<FAST>(vz, SZ, n0, row0 + kChunk, cap_hi);
+            tile_load<FAST>(vx, SX, k0, row0 + kChunk, cap_hi);
         }
         if (do_bias && threadIdx.x < kTile && !(B.dbg & 4)) {
             float s = 0.f;

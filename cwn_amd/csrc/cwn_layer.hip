@@ -468,6 +468,9 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
     // four waves per SIMD an instruction costs an issue slot in each of them, and 16 waves deriving the
     // same scalars took longer than the loads they lead to.  Absent tasks / products are all-zero fields.
     const bool has_gemm = (fld(I_FLAGS) & 1) != 0;
+    // an EMPTY record (no task): a table of fixed capacity that this batch does not fill (cwn_amd/static_graph.py,
+    // cwn_layer_items_build_dev) -- uniform over the workgroup, before any barrier; the early weight requests are dropped
+    if (fld(I_NT) == 0) return;
     CWN_STAMP(9);
     int t_r0[2], t_n[2], t_bne[2], t_sn[2];
 #pragma unroll

@@ -123,6 +123,8 @@ __global__ __launch_bounds__(kThreads) void layer_bwd_own_kernel(OwnArgs A) {
     const int ea0 = it[bo::R_UPA_E0], ne_a = it[bo::R_UPA_NE], eb0 = it[bo::R_UPB_E0], ne_b = it[bo::R_UPB_NE];
     const int bd0 = it[bo::R_BND_E0], ne_bd = it[bo::R_BND_NE];
     const bool PA = (flags & bo::F_PA) != 0, PB = (flags & bo::F_PB) != 0, TOP = (flags & bo::F_TOP) != 0;
+    // an EMPTY record (all zero: a table of fixed capacity that this batch does not fill, cwn_layer_bwd_items_build_dev): nothing to do
+    if (flags == 0 && n_o == 0 && n_a == 0 && n_b == 0 && ne_a == 0 && ne_b == 0 && ne_bd == 0) return;
     // table / launch mismatch (uniform over the workgroup, before any barrier)
     bool bad_rec = d < 0 || d >= A.n_dims || n_o <= 0 || n_o > bo::own_rows_cap(F) || n_a < 0 || n_b < 0 || n_a > 4096 || n_b > 4096 ||
                    ne_a < 0 || ne_b < 0 || ne_bd < 0 || ne_a > CWN_LAYER_MAX_ENTRIES || ne_b > CWN_LAYER_MAX_ENTRIES ||

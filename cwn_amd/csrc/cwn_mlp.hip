@@ -100,6 +100,9 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
         if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
     const cwn_mlp_dim& D = B.d[di];
     const int64_t row0 = (int64_t)((int)blockIdx.x - B.blk_start[di]) * TM;
+    // rows that exist (include/cwn_hip.h, "device-side row counts"; D.M is then the capacity: it bounds the addresses)
+    const int64_t Mv = D.m_dev != nullptr ? *D.m_dev : D.M;
+    if (row0 >= Mv) return;                         // (uniform) a tile past the batch's own rows
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ct = wave % S::kNCT, rt0 = (wave / S::kNCT) * kRT;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
                 *reinterpret_cast<uint2*>(dst) = ph;
                 *reinterpret_cast<uint2*>(dst + kPlaneElems) = pm;
                 *reinterpret_cast<uint2*>(dst + 2 * kPlaneElems) = pl;
-            } else if (row0 + r < D.M) {
+            } else if (row0 + r < Mv) {
                 cwn::store_result4(D.y + (row0 + r) * D.ldy + n0, y[0], y[1], y[2], y[3]);
             }
         }

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(BnBatch B) {
     const cwn_bn_desc& D = B.d[blockIdx.y];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int slice = threadIdx.x >> 6;
-    const int64_t bands = CWN_STAT_ROWS(D.M);
+    const int64_t Mv = D.m_dev != nullptr ? *D.m_dev : D.M;       // rows the statistics were taken over (D.M: capacity)
+    const int64_t bands = CWN_STAT_ROWS(Mv);
     const bool ok = n < D.N;
     const int nc = ok ? n : D.N - 1;
     double s = 0.0, sq = 0.0;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(BnBatch B) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int64_t b = b0 + kFinSlices * q;
-            const int64_t bc = b < bands ? b : bands - 1;
+            const int64_t bc = b < bands ? b : (bands > 0 ? bands - 1 : 0);
             t[q] = D.col_sum[bc * D.N + nc];
             u[q] = D.col_sumsq[bc * D.N + nc];
         }
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(BnBatch B) {
         s += part[0][q][threadIdx.x];
         sq += part[1][q][threadIdx.x];
     }
-    const double invM = 1.0 / (double)D.M;
+    const double invM = 1.0 / (double)(Mv > 0 ? Mv : 1);
     const double mean = s * invM;
     double var = sq * invM - mean * mean;     // biased, as BatchNorm normalises
     var = var > 0.0 ? var : 0.0;
@@ -103,10 +104,11 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(BnBatch B) {
         D.bwd_sums[n] = 0.f;
         D.bwd_sums[D.N + n] = 0.f;
     }
+    if (Mv < 1) return;        // (device-side count: a batch without cells of this dimension leaves the module's state alone)
     if (D.num_batches_tracked != nullptr && n == 0) *D.num_batches_tracked += 1;
     if (D.running_mean != nullptr) {
         const float mom = D.momentum;
-        const double unbiased = D.M > 1 ? var * ((double)D.M / (double)(D.M - 1)) : var;
+        const double unbiased = Mv > 1 ? var * ((double)Mv / (double)(Mv - 1)) : var;
         D.running_mean[n] = (1.0f - mom) * D.running_mean[n] + mom * (float)mean;
         D.running_var[n] = (1.0f - mom) * D.running_var[n] + mom * (float)unbiased;
     }
@@ -141,11 +143,14 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
     const int di = find_desc(B.blk_start, B.n, blockIdx.x);
     const cwn_norm_desc& D = B.d[di];
     const int64_t row0 = (int64_t)(blockIdx.x - B.blk_start[di]) * kBand;
+    const int64_t Mv = D.m_dev != nullptr ? *D.m_dev : D.M;      // rows that exist (D.M: the capacity, bounds the addresses)
     const int tc = threadIdx.x % kTPR, tr = threadIdx.x / kTPR;
     const int N = D.N;
     const bool has_norm = D.scale != nullptr;
     const bool relu = D.relu != 0;
-    const float invM = 1.0f / (float)D.M;
+    const float invM = 1.0f / (float)(Mv > 0 ? Mv : 1);
+    // (a band past the batch's own rows has nothing to do -- except the apply form's first band, which hands the sums on)
+    if (row0 >= Mv && !(MODE == 2 && row0 == 0)) return;
     for (int c0 = 0; c0 < N; c0 += kTPR * VEC) {     // column chunks of 128 (VEC = 4) or 32
         const int c = c0 + tc * VEC;
         const bool cok = c < N;                       // N % VEC == 0 (host-checked)
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
 #pragma unroll
         for (int i = 0; i < kBand / kRowsPerPass; ++i) {
             const int64_t r = row0 + tr + i * kRowsPerPass;
-            const bool ok = cok && r < D.M;
+            const bool ok = cok && r < Mv;
             float o[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
@@ -261,7 +266,8 @@ __global__ __launch_bounds__(kFT) void norm_bwd_fused_kernel(NormBatch B, int ac
     const cwn_norm_desc& D = B.d[di];
     const int c = ((int)blockIdx.x - B.blk_start[di]) * 4;
     const bool has_norm = D.scale != nullptr, relu = D.relu != 0;
-    const int64_t M = D.M;
+    const int64_t Mcap = D.M;
+    const int64_t M = D.m_dev != nullptr ? *D.m_dev : D.M;
     float scale[4] = {1.f, 1.f, 1.f, 1.f}, shift[4] = {0.f, 0.f, 0.f, 0.f}, mean[4] = {0.f, 0.f, 0.f, 0.f},
           rstd[4] = {0.f, 0.f, 0.f, 0.f};
     if (has_norm) {
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(kFT) void norm_bwd_fused_kernel(NormBatch B, int ac
 #pragma unroll
     for (int i = 0; i < kFR; ++i) {
         const int64_t r = threadIdx.x + (int64_t)i * kFT;
-        const int64_t rc = r < M ? r : M - 1;
+        const int64_t rc = r < Mcap ? r : Mcap - 1;
         ld_vec<4>(z[i], D.z + rc * D.ldz + c);
         ld_vec<4>(g[i], D.dy + rc * D.lddy + c);
     }
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(kFT) void norm_bwd_fused_kernel(NormBatch B, int ac
             }
         }
         __syncthreads();
-        const float invM = 1.0f / (float)M;
+        const float invM = 1.0f / (float)(M > 0 ? M : 1);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             float t1 = 0.f, t2 = 0.f;
@@ -521,13 +527,27 @@ extern "C" int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_
 // step); here one workgroup computes  loss = mean_i l(pred_i, y_i)  and  grad_i = dl/dpred_i / n  together.
 namespace {
 
-__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pred, const float* __restrict__ y, int64_t n,
-                                                   int kind, float* __restrict__ loss, float* __restrict__ grad) {
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pred, const float* __restrict__ y, int64_t n_cap,
+                                                   int kind, float* __restrict__ loss, float* __restrict__ grad,
+                                                   const int64_t* __restrict__ n_dev) {
     __shared__ float part[256];
-    const float inv = 1.0f / (float)n;
+    __shared__ int cnt[256];
+    const int64_t n = n_dev != nullptr ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap;
+    // null labels (exp/train_utils.py:64-66: `mask = ~torch.isnan(targets)`; ogbg-mol* tasks): not in the mean, no gradient
+    int valid = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) valid += (y[i] == y[i]) ? 1 : 0;
+    cnt[threadIdx.x] = valid;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) cnt[threadIdx.x] += cnt[threadIdx.x + off];
+        __syncthreads();
+    }
+    const float inv = 1.0f / (float)cnt[0];           // (no valid target: the mean of nothing is NaN, as torch's)
     float s = 0.f;
+    for (int64_t i = n + threadIdx.x; i < n_cap; i += 256) grad[i] = 0.f;       // rows past the batch's own
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const float p = pred[i], t = y[i], d = p - t;
+        if (!(t == t)) { grad[i] = 0.f; continue; }
         float l, gr;
         if (kind == CWN_LOSS_L1) {
             l = fabsf(d);
@@ -548,16 +568,16 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pre
         if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss = part[0] * inv;
+    if (threadIdx.x == 0) *loss = cnt[0] > 0 ? part[0] * inv : __int_as_float(0x7fc00000);
 }
 
 }  // namespace
 
 extern "C" int cwn_loss_f32(int32_t kind, const float* pred, const float* y, int64_t n, float* loss, float* grad,
-                            cwn_stream_t stream_) {
+                            const int64_t* n_dev, cwn_stream_t stream_) {
     if (kind < 0 || kind > CWN_LOSS_BCE_LOGITS || n <= 0 || pred == nullptr || y == nullptr || loss == nullptr || grad == nullptr)
         return CWN_ERR_BAD_ARG;
-    loss_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)stream_>>>(pred, y, n, kind, loss, grad);
+    loss_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)stream_>>>(pred, y, n, kind, loss, grad, n_dev);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
@@ -576,17 +596,24 @@ namespace {
 // features per lane put eight cells of a 128-wide table in flight per pass, and 64-cell bands fill a hundred CUs.
 constexpr int kEmbBand = 64;
 
+// the integer features as the containers deliver them: int64, or float32 (truncated, as `.to(torch.long)` does)
+__device__ __forceinline__ int64_t emb_index(const void* src, int f32, int64_t i) {
+    return f32 ? (int64_t)reinterpret_cast<const float*>(src)[i] : reinterpret_cast<const int64_t*>(src)[i];
+}
+
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ g,
-                                                            const int64_t* __restrict__ src,
+                                                            const void* __restrict__ src,
                                                             const int64_t* __restrict__ col_off,
                                                             const int64_t* __restrict__ col_size,
-                                                            float* __restrict__ dW, int64_t n_rows, int cols,
-                                                            int H, int64_t V) {
+                                                            float* __restrict__ dW, int64_t n_cap, int cols,
+                                                            int H, int64_t V, int src_f32, const int64_t* __restrict__ n_dev) {
     extern __shared__ float table[];          // [V][H]
+    const int64_t n_rows = n_dev != nullptr ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap;
+    const int64_t r0 = (int64_t)blockIdx.x * kEmbBand;
+    if (r0 >= n_rows) return;                 // (uniform) a band past the batch's own rows
     const int64_t total = V * H;
     for (int64_t i = threadIdx.x; i < total; i += 256) table[i] = 0.f;
     __syncthreads();
-    const int64_t r0 = (int64_t)blockIdx.x * kEmbBand;
     const int64_t r1 = r0 + kEmbBand < n_rows ? r0 + kEmbBand : n_rows;
     if ((H & 3) == 0 && H <= 1024) {
         const int lanes = H / 4;                  // threads walking one cell's features, four each
@@ -596,7 +623,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
             for (int64_t r = r0 + sub; r < r1; r += per) {
                 const float4 gv = *reinterpret_cast<const float4*>(g + r * H + h0);
                 for (int c = 0; c < cols; ++c) {
-                    int64_t v = src[r * cols + c];
+                    int64_t v = emb_index(src, src_f32, r * cols + c);
                     if (v < 0 || v >= (col_size != nullptr ? col_size[c] : V)) continue;   // flagged by the forward
                     if (col_off != nullptr) v += col_off[c];
                     float* t = table + v * H + h0;
@@ -611,7 +638,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
         if (sub < per) {
             for (int64_t r = r0 + sub; r < r1; r += per) {
                 for (int c = 0; c < cols; ++c) {
-                    int64_t v = src[r * cols + c];
+                    int64_t v = emb_index(src, src_f32, r * cols + c);
                     if (v < 0 || v >= (col_size != nullptr ? col_size[c] : V)) continue;   // flagged by the forward
                     if (col_off != nullptr) v += col_off[c];
                     for (int h = h0; h < H; h += lanes) atomicAdd(&table[v * H + h], g[r * H + h]);
@@ -632,11 +659,14 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
 // memory.  No float atomics in LDS: ds_add_f32 runs at ~100 cycles per wave instruction (measured in cwn_layer_bwd.hip),
 // which is what made the table-in-LDS form above 14 us per ZINC table.
 template <int H>
-__global__ __launch_bounds__(256) void embedding_bwd_one_table_kernel(const float* __restrict__ g, const int64_t* __restrict__ src,
-                                                                     float* __restrict__ dW, int64_t n_rows, int V) {
+__global__ __launch_bounds__(256) void embedding_bwd_one_table_kernel(const float* __restrict__ g, const void* __restrict__ src,
+                                                                     float* __restrict__ dW, int64_t n_cap, int V, int src_f32,
+                                                                     const int64_t* __restrict__ n_dev) {
     __shared__ __attribute__((aligned(16))) float rows[kEmbBand][H];
     const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t n_rows = n_dev != nullptr ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap;
     const int64_t r0 = (int64_t)blockIdx.x * kEmbBand;
+    if (r0 >= n_rows) return;                 // (uniform) a band past the batch's own rows
     const int n = (int)((n_rows - r0) < kEmbBand ? (n_rows - r0) : kEmbBand);
     // stage: kEmbBand x H floats, 16 bytes a thread and pass, row-contiguous
     for (int i = tid; i < kEmbBand * (H / 4); i += 256) {
@@ -645,7 +675,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_one_table_kernel(const floa
         if (r < n) v = *reinterpret_cast<const float4*>(g + (r0 + r) * H + 4 * c4);
         *reinterpret_cast<float4*>(&rows[r][4 * c4]) = v;
     }
-    const int64_t id = lane < n ? src[r0 + lane] : -1;                 // lane = cell of the band (every wave holds all 64)
+    const int64_t id = lane < n ? emb_index(src, src_f32, r0 + lane) : -1;   // lane = cell of the band (every wave holds all 64)
     __syncthreads();
     constexpr int kSlices = 256 / H > 0 ? 256 / H : 1;               // threads per feature (H = 256: 1, 128: 2, 64: 4)
     constexpr int kPer = kEmbBand / kSlices;                          // cells of a slice
@@ -716,9 +746,9 @@ extern "C" int cwn_embedding_fwd_f32(const float* W, const int64_t* src, const i
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
-extern "C" int cwn_embedding_bwd_f32(const float* g, const int64_t* src, const int64_t* col_off,
+extern "C" int cwn_embedding_bwd_f32(const float* g, const void* src, const int64_t* col_off,
                                      const int64_t* col_size, float* dW, int64_t n_rows, int32_t cols,
-                                     int32_t H, int64_t V, cwn_stream_t stream_) {
+                                     int32_t H, int64_t V, int32_t src_f32, const int64_t* n_dev, cwn_stream_t stream_) {
     if (n_rows < 0 || cols <= 0 || H <= 0 || V <= 0) return CWN_ERR_BAD_ARG;
     if (n_rows == 0) return CWN_OK;
     if (g == nullptr || src == nullptr || dW == nullptr) return CWN_ERR_BAD_ARG;
@@ -730,12 +760,13 @@ extern "C" int cwn_embedding_bwd_f32(const float* g, const int64_t* src, const i
     if (cols == 1 && col_off == nullptr && V <= 64 && (H == 64 || H == 128 || H == 256)) {
         // one small table: the ballot form (no float atomics in LDS)
         hipStream_t st = (hipStream_t)stream_;
-        if (H == 64) embedding_bwd_one_table_kernel<64><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, dW, n_rows, (int)V);
-        else if (H == 128) embedding_bwd_one_table_kernel<128><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, dW, n_rows, (int)V);
-        else embedding_bwd_one_table_kernel<256><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, dW, n_rows, (int)V);
+        const int sf = src_f32 ? 1 : 0;
+        if (H == 64) embedding_bwd_one_table_kernel<64><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, dW, n_rows, (int)V, sf, n_dev);
+        else if (H == 128) embedding_bwd_one_table_kernel<128><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, dW, n_rows, (int)V, sf, n_dev);
+        else embedding_bwd_one_table_kernel<256><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, dW, n_rows, (int)V, sf, n_dev);
         return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
     }
     embedding_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), (size_t)bytes, (hipStream_t)stream_>>>(
-        g, src, col_off, col_size, dW, n_rows, cols, H, V);
+        g, src, col_off, col_size, dW, n_rows, cols, H, V, src_f32 ? 1 : 0, n_dev);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

@@ -73,6 +73,9 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
         if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
     const cwn_stage_desc& D = B.d[di];
     const int64_t row0 = (int64_t)((int)blockIdx.x - B.blk_start[di]) * TM;
+    // rows that exist (include/cwn_hip.h, "device-side row counts"): D.M is then the capacity of the buffers -- it bounds the
+    // addresses below, so that no load waits for this one -- and Mv what is stored and counted
+    const int64_t Mv = D.m_dev != nullptr ? *D.m_dev : D.M;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ct = wave % S::kNCT, rt0 = (wave / S::kNCT) * kRT;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     // requests: rows and the constants behind them first, then the weight (loads return in order: a constant behind 96 KB of
     // weight is a wait for the weight)
     request_rows(v0, D.X, D.ldx);
+    if (row0 >= Mv) return;                         // (uniform) a tile past the batch's own rows: nothing to store or count
     const Pro p0 = request_pro(D.in_scale, D.in_shift, (D.in_relu & 1) != 0);
     Pro p1 = p0;
     if (two) {
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) {
         const int r = (rt0 + rt) * 16 + l15;
-        const bool ok = row0 + r < D.M;
+        const bool ok = row0 + r < Mv;
         const float y[4] = {acc[rt][0] + b4.x, acc[rt][1] + b4.y, acc[rt][2] + b4.z, acc[rt][3] + b4.w};
         if (stats && ok) {
 #pragma unroll
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
             a += row_ror_f64<0x124>(a); b += row_ror_f64<0x124>(b);
             a += row_ror_f64<0x122>(a); b += row_ror_f64<0x122>(b);
             a += row_ror_f64<0x121>(a); b += row_ror_f64<0x121>(b);
-            if (l15 == 0 && slot < CWN_STAT_ROWS(D.M)) {
+            if (l15 == 0 && slot < CWN_STAT_ROWS(Mv)) {
                 D.col_sum[slot * F + n0 + q] = a;
                 D.col_sumsq[slot * F + n0 + q] = b;
             }
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
     const cwn_stage_bwd_desc& D = B.d[di];
     const bool first_block = (int)blockIdx.x == B.blk_start[di];
     const int64_t row0 = (int64_t)((int)blockIdx.x - B.blk_start[di]) * TM;
+    const int64_t Mv = D.m_dev != nullptr ? *D.m_dev : D.M;      // rows that exist (D.M: the capacity, bounds the addresses)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ct = wave % S::kNCT, rt0 = (wave / S::kNCT) * kRT;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
         mu = reinterpret_cast<const float4*>(D.mean)[c4];
         const float4 rs = reinterpret_cast<const float4*>(D.rstd)[c4];
         const float4 s1 = reinterpret_cast<const float4*>(D.s1)[c4], s2 = reinterpret_cast<const float4*>(D.s2)[c4];
-        const float invM = 1.0f / (float)D.M;
+        const float invM = 1.0f / (float)(Mv > 0 ? Mv : 1);
         c0 = make_float4(-sc.x * (s1.x * invM), -sc.y * (s1.y * invM), -sc.z * (s1.z * invM), -sc.w * (s1.w * invM));
         c1 = make_float4(-sc.x * (rs.x * (s2.x * invM)), -sc.y * (rs.y * (s2.y * invM)), -sc.z * (rs.z * (s2.z * invM)),
                          -sc.w * (rs.w * (s2.w * invM)));
@@ -316,6 +321,9 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
             }
         }
     }
+    // (a tile past the batch's own rows leaves here -- behind the hand-over of the sums above, which the FIRST workgroup of a
+    // descriptor does whatever the batch holds)
+    if (row0 >= Mv) return;
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) request_kstep(D.wt_packed, ks);
     const bool relu = D.relu != 0;
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
         };
         const float4 d = make_float4(one(dy.x, z.x, sc.x, sh.x, mu.x, c0.x, c1.x), one(dy.y, z.y, sc.y, sh.y, mu.y, c0.y, c1.y),
                                      one(dy.z, z.z, sc.z, sh.z, mu.z, c0.z, c1.z), one(dy.w, z.w, sc.w, sh.w, mu.w, c0.w, c1.w));
-        if (D.dz != nullptr && row0 + r < D.M) cwn::store_result4(D.dz + (row0 + r) * D.lddz + c4 * 4, d.x, d.y, d.z, d.w);
+        if (D.dz != nullptr && row0 + r < Mv) cwn::store_result4(D.dz + (row0 + r) * D.lddz + c4 * 4, d.x, d.y, d.z, d.w);
         uint2 ph, pm, pl;
         cwn::split4(d, ph, pm, pl);
         uint16_t* dst = buf0 + (size_t)r * kRowStride + c4 * 4;
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
 #pragma unroll
         for (int rt = 0; rt < kRT; ++rt) {
             const int r = (rt0 + rt) * 16 + l15;
-            if (row0 + r < D.M) cwn::store_result4(out + (row0 + r) * ld + n0, acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+            if (row0 + r < Mv) cwn::store_result4(out + (row0 + r) * ld + n0, acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
         }
     };
 #pragma unroll

@@ -476,6 +476,12 @@ def _embedding_table_grads(tables, idx: Tensor, g: Tensor) -> List[Optional[Tens
     g = g.contiguous()
     if idx.dim() == 1:
         idx = idx.unsqueeze(1)
+    # the integer features as the containers deliver them: int64, or float32 (truncated by the kernel as `.to(torch.long)`
+    # does) -- no converted copy, which a step captured over static buffers could not keep current
+    if idx.dtype not in (torch.long, torch.float32):
+        idx = idx.to(torch.long)
+    idx = idx.contiguous()
+    f32, n_dev = (1 if idx.dtype == torch.float32 else 0), _ffi.dyn(idx.size(0))
     off, size = _EmbeddingSum._columns(tables, g.device)
     if len(tables) == 1:
         # one table whose .grad is allocated: the kernel ADDS its band partials (fp32 atomics) -- straight into the gradient
@@ -484,12 +490,12 @@ def _embedding_table_grads(tables, idx: Tensor, g: Tensor) -> List[Optional[Tens
         if t is not None and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (V, H):
             _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
                 g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), t.data_ptr(), idx.size(0),
-                idx.size(1), H, V, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
+                idx.size(1), H, V, f32, n_dev, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
             return [None]
     dW = torch.zeros(V, H, dtype=torch.float32, device=g.device)
     _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
         g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), dW.data_ptr(), idx.size(0),
-        idx.size(1), H, V, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
+        idx.size(1), H, V, f32, n_dev, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
     views, o = [], 0
     for n in sizes:
         views.append(dW[o:o + n])
@@ -571,10 +577,22 @@ def embed_front(v_weights: Sequence[Tensor], v_feats: Tensor, e_weights: Optiona
         _ffi.ptr(adj1.rowptr) if adj1 is not None else None, _ffi.ptr(adj1.col) if adj1 is not None else None,
         adj1.n_entries if adj1 is not None else 0, n2, x2.data_ptr(),
         _ffi.ptr(adj2.rowptr) if adj2 is not None else None, _ffi.ptr(adj2.col) if adj2 is not None else None,
-        adj2.n_entries if adj2 is not None else 0, H, 1 if halve else 0, _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)), 'cwn_embed_front_f32')
+        adj2.n_entries if adj2 is not None else 0, H, 1 if halve else 0, _err_flag(dev).data_ptr(), _front_counts(n0, n1, n2),
+        _ffi.stream_ptr(dev)), 'cwn_embed_front_f32')
     if VALIDATE_INDICES and not torch.cuda.is_current_stream_capturing():
         check_errors(dev)
     return [x0, x1, x2]
+
+
+def _front_counts(n0: int, n1: int, n2: int) -> Optional[int]:
+    """Device address of the int64 triple (actual n0, n1, n2) when the three row counts are the capacities of a static batch
+    (_ffi.dynamic_rows: static_graph.StaticBatch keeps the three counts consecutive in memory), else None."""
+    p0, p1, p2 = _ffi.dyn(n0), _ffi.dyn(n1), (_ffi.dyn(n2) if n2 else None)
+    if p0 is None:
+        return None
+    if p1 != p0 + 8 or (n2 and p2 != p0 + 16):
+        raise _ffi.CwnError('embed_front: the device-side row counts of the three dimensions are not consecutive')
+    return p0
 
 
 def _long_index(feats: Tensor) -> Tensor:
@@ -603,7 +621,7 @@ class _EmbedFrontTrain(torch.autograd.Function):
         vt, et = list(tables[:nv]), list(tables[nv:])
         xs = embed_front(vt, v_feats, et or None, e_feats if et else None, n1, adj1, n2, adj2, halve=halve)
         ctx.meta, ctx.tables = meta, (vt, et)
-        ctx.idx = (_long_index(v_feats), _long_index(e_feats) if et else None)
+        ctx.idx = (v_feats, e_feats if et else None)          # (as delivered: float32 or int64; _embedding_table_grads)
         return tuple(xs)
 
     @staticmethod
@@ -1467,6 +1485,7 @@ def update_mlp(dims: Sequence[MlpDim]) -> List[Tensor]:
         a.ldx_up = xu.stride(0) if xu.size(0) > 1 else F
         a.ldx_b = xb.stride(0) if xb.size(0) > 1 else F
         a.ldy = F
+        a.m_dev = _ffi.dyn(xu.size(0))
         packed = []
         for l in D.linears[:4]:
             packed += list(pack_mlp_weight(l.weight))
@@ -1609,7 +1628,7 @@ def run_stage_bwd(entries, device) -> bool:
         arr[k] = _ffi.StageBwdDesc(dy=dy.data_ptr(), z=b.z, dz=b.dz, scale=b.scale, shift=b.shift, mean=b.mean, rstd=b.rstd,
                                    s1=b.s1, s2=b.s2, acc1=b.acc1, acc2=b.acc2, wt_packed=w1.data_ptr(), wt2_packed=_ffi.ptr(w2),
                                    dx=dx.data_ptr(), dx2=_ffi.ptr(dx2), M=M, lddy=ld(dy), ldz=int(b.ldz), lddz=int(b.lddz),
-                                   lddx=ld(dx), lddx2=0 if dx2 is None else ld(dx2), relu=int(b.relu))
+                                   lddx=ld(dx), lddx2=0 if dx2 is None else ld(dx2), relu=int(b.relu), m_dev=_ffi.dyn(M))
         keep += [w1, w2]
     _ffi.check(_ffi.lib().cwn_dense_stage_bwd_f32(arr, len(entries), F, _ffi.stream_ptr(device)), 'cwn_dense_stage_bwd_f32')
     return True
@@ -1653,7 +1672,7 @@ def run_stage(gemms: Sequence['Gemm'], device) -> Optional[List[Tensor]]:
                                 bias=_ffi.ptr(cons[0]), in_scale=_ffi.ptr(cons[1]), in_shift=_ffi.ptr(cons[2]),
                                 in_scale2=_ffi.ptr(cons[3]), in_shift2=_ffi.ptr(cons[4]), Y=Y.data_ptr(),
                                 col_sum=None if cs is None else cs[0].data_ptr(), col_sumsq=None if cs is None else cs[1].data_ptr(),
-                                M=M, ldx=ld(X), ldx2=0 if X2 is None else ld(X2), ldy=F, in_relu=int(g.in_relu))
+                                M=M, ldx=ld(X), ldx2=0 if X2 is None else ld(X2), ldy=F, in_relu=int(g.in_relu), m_dev=_ffi.dyn(M))
         keep += cons + [w1, w2]
         outs.append(Y)
     _ffi.check(_ffi.lib().cwn_dense_stage_f32(arr, len(gemms), F, _ffi.stream_ptr(device)), 'cwn_dense_stage_f32')

@@ -21,6 +21,13 @@ from .complex import CochainBatch, Complex, ComplexBatch
 
 _INDEX_KEYS = ('upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries', 'boundary_index')
 _ALL_KEYS = ('x', 'y') + _INDEX_KEYS
+# The destination-sorted CSR of a complex's boundary adjacency and of its transpose, kept per complex in LOCAL numbers
+# (`with_csr=True`).  A batch is block-diagonal and per-complex contiguous (data/complex.py:148-169), so the batch's CSR is
+# the concatenation of its complexes' CSRs: the `col` arrays collate like an index row (+ the cell offset of the source
+# dimension), the row pointers -- stored WITHOUT their leading zero, one number per cell -- collate to rowptr[1:] + the
+# running entry count.  What cwn_csr_build does per batch (two launches per step for the front's plans and their transposes)
+# is then part of the one collate launch.
+_CSR_KEYS = ('b_rowptr', 'b_col', 'bt_rowptr', 'bt_col')
 
 
 class _Packed:
@@ -35,9 +42,10 @@ class _Packed:
 class PackedComplexes:
     """`complexes` (cwn_amd Complex objects with CPU tensors) packed on `device`."""
 
-    def __init__(self, complexes: Sequence[Complex], device, max_dim: int = 2):
+    def __init__(self, complexes: Sequence[Complex], device, max_dim: int = 2, with_csr: bool = False):
         self.device = torch.device(device)
         self.max_dim = max_dim
+        self.with_csr = bool(with_csr)
         self.num = len(complexes)
         self.dims = np.array([min(c.dimension, max_dim) for c in complexes], dtype=np.int64)
         C = self.num
@@ -74,7 +82,8 @@ class PackedComplexes:
         self._finalise()
 
     @classmethod
-    def from_arrays(cls, device, max_dim: int, dims, n_cells, has_cells, n_up, n_down, keys, y=None) -> 'PackedComplexes':
+    def from_arrays(cls, device, max_dim: int, dims, n_cells, has_cells, n_up, n_down, keys, y=None,
+                    with_csr: bool = False) -> 'PackedComplexes':
         """A packed dataset from arrays that are ALREADY concatenated per key (cwn_amd.lifting.pack_graph_dataset_*:
         a dataset lifted by cwn_lift_many goes from graphs to HBM without per-complex Python objects).
         keys[d][name] = (data, lengths, has): `data` as the constructor would concatenate it (x: [rows, width] or flat;
@@ -83,6 +92,7 @@ class PackedComplexes:
         self = cls.__new__(cls)
         self.device = torch.device(device)
         self.max_dim = max_dim
+        self.with_csr = bool(with_csr)
         self.dims = np.minimum(np.asarray(dims, dtype=np.int64), max_dim)
         self.num = int(self.dims.size)
         D = max_dim + 1
@@ -138,11 +148,45 @@ class PackedComplexes:
                        self._op(data, key))
 
     # --------------------------------------------------------------------------------------------
+    def _add_csr_keys(self) -> None:
+        """Per complex, in local numbers: the destination-sorted CSR of boundary_index_d (rows = cells of d, col = boundary
+        cell) and of its transpose (rows = cells of d - 1, col = cell), stable in entry order -- what cwn_csr_build
+        produces for the batched index, cut at the complexes (module comment at _CSR_KEYS)."""
+        D = self.max_dim + 1
+        for d in range(1, D):
+            pk = self.keys[d].get('boundary_index')
+            if pk is None:
+                continue
+            idx = pk.data.detach().cpu().numpy()                       # [2, E]: row 0 boundary cell, row 1 cell (local)
+            E = int(idx.shape[1])
+            lengths = np.asarray(pk.length, dtype=np.int64)
+            C = self.num
+            cid = np.repeat(np.arange(C, dtype=np.int64), lengths)
+            ent0 = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+            for name, rows_of, key_row, val_row in (('b', self.n_cells[d], 1, 0), ('bt', self.n_down[d], 0, 1)):
+                rows_of = np.asarray(rows_of, dtype=np.int64)
+                row0 = np.concatenate([[0], np.cumsum(rows_of)[:-1]]).astype(np.int64)
+                key, val = idx[key_row].astype(np.int64), idx[val_row].astype(np.int64)
+                if E and (key.min() < 0 or (key >= rows_of[cid]).any()):
+                    raise IndexError(f'boundary_index of dimension {d}: a local index outside its complex')
+                g = row0[cid] + key                                    # row number in packed order: sorted by complex already
+                order = np.argsort(g, kind='stable')
+                col = val[order].astype(np.int32)
+                counts = np.bincount(g, minlength=int(rows_of.sum())).astype(np.int64)
+                incl = np.cumsum(counts) - np.repeat(ent0, rows_of)    # local inclusive row pointers: rowptr[1:] of each complex
+                dev = self.device
+                self.keys[d][name + '_rowptr'] = _Packed(torch.from_numpy(incl.astype(np.int32)).to(dev), row0, rows_of,
+                                                         rows_of > 0, 1, 1, _ffi.COLLATE_ADD32)
+                self.keys[d][name + '_col'] = _Packed(torch.from_numpy(col).to(dev), ent0, lengths, lengths > 0, 1, 1,
+                                                      _ffi.COLLATE_ADD32)
+
     def _finalise(self) -> None:
         """Per-complex metadata of every key stacked into matrices: a batch's tables are then a dozen numpy calls
         in all (the first form made ~100 small ones, 150 us of host time per batch of 128 -- four propagate
         steps)."""
         D = self.max_dim + 1
+        if self.with_csr:
+            self._add_csr_keys()
         self._klist = [(d, key, pk) for d in range(D) for key, pk in self.keys[d].items()]
         if self.y is not None:
             self._klist.append((-1, 'y', self.y))
@@ -152,6 +196,19 @@ class PackedComplexes:
         for f in ('length', 'start', 'has'):
             cols += [np.asarray(getattr(pk, f), dtype=np.int64)[None] for _, _, pk in self._klist]
         self._meta = np.ascontiguousarray(np.concatenate(cols, axis=0).T)                  # [num, 3D + 3K]
+        self._meta_dev = None          # the same matrix in HBM (cwn_collate_tables: the tables of a batch built on the device)
+
+    def meta_device(self) -> torch.Tensor:
+        if self._meta_dev is None:
+            self._meta_dev = torch.from_numpy(self._meta).to(self.device)
+        return self._meta_dev
+
+    def key_index(self, d: int, key: str) -> int:
+        """Position of (dimension, key) in the table layout (the `k` of cwn_collate_tables), -1 when the dataset has no such array."""
+        for k, (dd, kk, _) in enumerate(self._klist):
+            if dd == d and kk == key:
+                return k
+        return -1
 
     # add-table of a key inside a dimension's block of five offset rows (here, here, down, here, up), in rows
     _ADD_ROW = {'upper_index': 0, 'lower_index': 0, 'shared_boundaries': 2, 'shared_coboundaries': 4, 'boundary_index': 2}
@@ -197,8 +254,8 @@ class PackedComplexes:
                 y = torch.empty(total, dtype=pk.data.dtype, device=dev)
                 plan.append((pk, y, k * (B + 1), o_src + k * B, None, total))
                 continue
-            if not present[k]:
-                continue
+            if not present[k] or key in _CSR_KEYS:
+                continue                    # (the per-complex CSRs serve the static path: cwn_amd/static_graph.py)
             if key == 'x':
                 out = torch.empty(total // pk.width, pk.width, dtype=pk.data.dtype, device=dev)
             elif pk.rows == 2:

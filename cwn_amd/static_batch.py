@@ -1,0 +1,557 @@
+"""A batch of FIXED CAPACITY that a captured hipGraph refills on the device: the reference's shuffled epoch
+(data/data_loading.py:84-111 -> exp/train_utils.py:35-75: every step sees a batch it has never seen) on the graph path.
+
+A hipGraph bakes pointers, grid sizes and kernel arguments in, and round 3's fast paths therefore needed the batch known
+in advance (one graph per distinct batch).  Here everything a batch changes lives in DEVICE memory:
+
+  * the arrays of the batch are capacity-sized buffers (features `[cap_d, width]`, indices `[2, cap]` with the second row
+    at a fixed offset, `[cap]` vectors), filled by the collate launch from the HBM-resident packed dataset;
+  * the segment tables of the collate -- and with them `ptr` / `__slices__`, the number of cells per dimension and the
+    number of complexes -- are computed ON THE DEVICE from the dataset's per-complex metadata and the batch's complex
+    numbers (cwn_collate_tables); with the `cursor` the complex numbers are read from a permutation uploaded once per epoch,
+    so that a step needs NOTHING from the host but the replay;
+  * the item tables of the complex-blocked launches are cut on the device from those tables (cwn_layer_items_build_dev,
+    cwn_layer_bwd_items_build_dev) into fixed regions, empty records behind the batch's own;
+  * the CSR plans the model's front needs (boundary adjacencies and their transposes) are the concatenation of
+    per-complex CSRs kept in the packed dataset: part of the collate launch, no cwn_csr_build;
+  * every row-count-carrying kernel argument of the dense / norm / weight-gradient / readout launches becomes a
+    capacity, the actual count being read from the tables (`m_dev`, include/cwn_hip.h "device-side row counts").
+
+`StaticBatch.batch` is a ComplexBatch over those buffers: the model code runs on it unchanged (it sees the capacities as
+its sizes) inside `StaticBatch.dynamic()`, which maps each capacity to the device address of the actual count.
+cwn_amd/static_graph.py captures a forward / a training step over it once.
+"""
+from typing import Dict, List, Optional, Sequence
+
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _ffi, csr
+from .blockplan import BwdItemTable, ITEM_INTS, ItemTable, LDS_BYTES, gemm_rows_cap, lds_bytes
+from .complex import CochainBatch, ComplexBatch
+from .packed import _CSR_KEYS, PackedComplexes
+
+_TWO_ROW = ('upper_index', 'lower_index', 'boundary_index')
+_ADD_ROW = dict(PackedComplexes._ADD_ROW, b_col=2, bt_col=0)
+
+
+class _PlanOnlyAdjacency:
+    """What the layer code receives for an UPPER adjacency of a static batch: sizes only.  The blocked launches read the
+    int64 index tensors through the item tables; a code path that wants this adjacency's CSR (the streaming backward, a
+    generic message hook) is not available on a static batch and fails here, loudly."""
+    built = True
+    ready = None
+    long_rows = n_long = None
+    long_cap = 1
+
+    def __init__(self, index: torch.Tensor, n_dst: int, n_val: int, aux_index: Optional[torch.Tensor], n_aux: int):
+        self.key, self.val, self.aux_index = index[1], index[0], aux_index
+        self.n_entries = int(index.size(1))
+        self.n_dst, self.n_val, self.n_aux = int(n_dst), int(n_val), int(n_aux)
+        self.device = index.device
+        self._t_src = self._t_aux = None
+
+    def _no(self, what):
+        raise _ffi.CwnError(f'a static batch has no CSR of its upper adjacencies ({what}): the complex-blocked launches are the '
+                            'only path (cwn_amd/static_batch.py); use PackedComplexes.collate for this model / configuration')
+
+    rowptr = property(lambda self: self._no('rowptr'))
+    col = property(lambda self: self._no('col'))
+    perm = property(lambda self: self._no('perm'))
+    aux = property(lambda self: self._no('aux'))
+    t_src = property(lambda self: self._no('t_src'))
+    t_aux = property(lambda self: self._no('t_aux'))
+
+    def transposes(self):
+        return []
+
+
+class _CollatedAdjacency(csr.Adjacency):
+    """The destination-sorted CSR of a boundary adjacency of a static batch: arrays written by the collate launch (the
+    concatenation of the complexes' own CSRs), not by cwn_csr_build.  No `perm` (nothing on these paths reads one)."""
+
+    def __init__(self, index: torch.Tensor, key_row: int, n_dst: int, n_val: int, rowptr: torch.Tensor, col: torch.Tensor):
+        self.key, self.val, self.aux_index = index[key_row], index[1 - key_row], None
+        self.n_entries = int(index.size(1))
+        self.n_dst, self.n_val, self.n_aux = int(n_dst), int(n_val), 0
+        self.device = index.device
+        self.rowptr, self.col, self.perm, self.aux = rowptr, col, None, None
+        self.long_cap = self.n_entries // csr.LONG_ROW + 1
+        self.long_rows = self.n_long = None          # (a cell's boundary is a handful of entries: no long rows)
+        self.built, self.ready = True, None
+        self._t_src = self._t_aux = None
+        self._counts = None
+
+    def transposes(self):
+        return []
+
+
+class StaticBlockPlan:
+    """The BlockPlan (cwn_amd/blockplan.py) of a static batch: item tables in fixed device buffers, rebuilt by the device
+    builders after every fill.  Duck-types what the layer / model code asks a BlockPlan."""
+
+    def __init__(self, owner: 'StaticBatch', variant: int, group: int):
+        self.owner = owner
+        self.n_dims = owner.D
+        self.C = owner.B
+        self.device = owner.device
+        self.variant, self.group = int(variant), int(group)
+        self.cell_ptr = [np.array([0, owner.cap_cells[d]], dtype=np.int64) for d in range(owner.D)]
+        self.up_ptr = [(np.array([0, owner.cap_key(d, 'upper_index')]) if owner.k_of(d, 'upper_index') >= 0 else None)
+                       for d in range(owner.D)]
+        self.b_ptr = [(np.array([0, owner.cap_key(d, 'boundary_index')]) if owner.k_of(d, 'boundary_index') >= 0 else None)
+                      for d in range(owner.D)]
+        self._tables: Dict = {}
+        self.validated = False
+
+    # ---- what the model code asks -------------------------------------------------------------------------------
+    def cell_ptr_device(self, d: int, device) -> torch.Tensor:
+        return self.owner.seg_view(d)
+
+    def forget_csr(self) -> None:
+        for t in self._tables.values():
+            if t is not None and hasattr(t, 'csr_key'):
+                t.csr_key = None
+
+    def _n_sets(self, has_up) -> int:
+        n, d = 0, 0
+        while d < self.n_dims:
+            step = 1
+            if has_up[d] and d + 1 < self.n_dims and not has_up[d + 1] and d + 2 >= self.n_dims:
+                step = 2
+            n += 1
+            d += step
+        return n
+
+    def at_least(self, F: int, has_up, has_b=None) -> int:
+        return self._n_sets(has_up) * -(-self.C // self.group)
+
+    def items_mixed(self, F, has_up, has_b=None):
+        return None
+
+    def _norm_key(self, has_up, has_b):
+        if has_b is None:
+            has_b = [p is not None for p in self.b_ptr]
+        return (tuple(bool(h) for h in has_up),
+                tuple(bool(h) and self.b_ptr[d] is not None for d, h in enumerate(has_b)))
+
+    def items(self, F: int, has_up, has_b=None, variant: int = 0, allow_big: bool = False) -> Optional[ItemTable]:
+        if allow_big:
+            return None                        # no BIG records
+        # (one form per static batch, chosen when it was built: whatever form the caller's heuristics ask for gets this table)
+        hu, hb = self._norm_key(has_up, has_b)
+        key = ('fwd', int(F), hu, hb)
+        t = self._tables.get(key)
+        if t is None:
+            t = self._tables[key] = self._make_fwd(int(F), hu, hb)
+        if t is not None and t.filled != self.owner.fill_id:
+            self._launch_fwd(t)
+        return t
+
+    def bwd_items(self, F: int, has_up, has_b=None) -> Optional[BwdItemTable]:
+        hu, hb = self._norm_key(has_up, has_b)
+        key = ('bwd', int(F), hu, hb)
+        t = self._tables.get(key)
+        if t is None:
+            t = self._tables[key] = self._make_bwd(int(F), hu, hb)
+        if t is not None and t.filled != self.owner.fill_id:
+            self._launch_bwd(t)
+        return t
+
+    def refill(self) -> None:
+        """The item tables cut so far, for the batch the buffers now hold (StaticBatch.fill calls this: the layers keep
+        prepared launches per plan and do not ask again)."""
+        for key, t in self._tables.items():
+            if t is None:
+                continue
+            if key[0] == 'fwd':
+                self._launch_fwd(t)
+            else:
+                self._launch_bwd(t)
+
+    def fit_mask(self) -> np.ndarray:
+        """bool per complex of the dataset: every table cut so far takes it as one item (numpy restatement of the device
+        builders' test: blockplan.single_fit_forward / _backward)."""
+        from .blockplan import single_fit_backward, single_fit_forward
+        o = self.owner
+        meta, D = o.packed._meta, o.D
+        cells = [meta[:, 3 * d] for d in range(D)]
+        col = lambda d, key: (meta[:, 3 * D + o.k_of(d, key)] if o.k_of(d, key) >= 0 else None)
+        up_len = [col(d, 'upper_index') for d in range(D)]
+        b_len = [col(d, 'boundary_index') for d in range(D)]
+        ok = np.ones(meta.shape[0], dtype=bool)
+        for key, t in self._tables.items():
+            if t is None:
+                continue
+            _, F, hu, hb = key
+            if key[0] == 'fwd':
+                ok &= single_fit_forward(cells, up_len, b_len, F, hu, hb, self.variant, t.max_rows, t.max_src)
+            else:
+                ok &= single_fit_backward(cells, up_len, b_len, F, hu, hb)
+        return ok
+
+    # ---- tables ---------------------------------------------------------------------------------------------------
+    def _sizes_dev(self, has_up, has_b) -> _ffi.LayerSizesDev:
+        o = self.owner
+        s = _ffi.LayerSizesDev(n_complexes=o.size_ptr(3), cap_complexes=o.B, n_dims=o.D)
+        for d in range(o.D):
+            s.has_up[d] = 1 if has_up[d] else 0
+            s.cell_ptr[d] = o.seg_view(d).data_ptr()
+            k = o.k_of(d, 'upper_index')
+            if k >= 0:
+                s.up_ptr[d] = o.dst_view(k).data_ptr()
+            k = o.k_of(d, 'boundary_index')
+            if k >= 0 and has_b[d]:
+                s.b_ptr[d] = o.dst_view(k).data_ptr()
+        return s
+
+    def _make_fwd(self, F: int, has_up, has_b) -> Optional[ItemTable]:
+        o = self.owner
+        if F not in (64, 128) or any(has_up[d] and (d + 1 >= o.D or o.k_of(d, 'upper_index') < 0) for d in range(o.D)):
+            return None
+        L = _ffi.lib()
+        n_sets = self._n_sets(has_up)
+        n_items = n_sets * o.B                                   # a region of B records per set always suffices
+        set_start = [s * o.B for s in range(n_sets)]
+        if self.variant == 0:
+            # one launch = one LDS layout: the full row cap, the boundary sources take what is left of the 160 KiB
+            cap = gemm_rows_cap(F)
+            src_cap = min(cap, (LDS_BYTES - lds_bytes(F, cap, 0)) // (F * 4))
+            if src_cap < 16 or L.cwn_layer_fused_lds_bytes(F, cap, src_cap) == 0:
+                return None
+            dyn_lds = 0
+        else:
+            cap = 128 if F == 64 else 80                         # = CWN_LAYER_W8_GEMM_ROWS / _SOURCE_ROWS / _LDS_BYTES
+            src_cap = 128 if F == 64 else 48
+            dyn_lds = 80 * 1024
+        cap_up = [o.cap_key(d, 'upper_index') if has_up[d] else 0 for d in range(o.D)]
+        cap_b = [o.cap_key(d, 'boundary_index') if (d > 0 and has_b[d]) else 0 for d in range(o.D)]
+        t = ItemTable(np.zeros((n_items, ITEM_INTS), dtype=np.int32), set_start, cap, src_cap, list(o.cap_cells), cap_up, cap_b,
+                      o.device, variant=self.variant, lds_bytes=dyn_lds)
+        t.filled = -1
+        t.sizes = self._sizes_dev(has_up, has_b)
+        t.F = F
+        return t
+
+    def _launch_fwd(self, t: ItemTable) -> None:
+        plan = t.c_plan(with_cache=False)
+        _ffi.check(_ffi.lib().cwn_layer_items_build_dev(t.sizes, t.F, plan, self.group, csr._err_flag(self.device).data_ptr(),
+                                                        _ffi.stream_ptr(self.device)), 'cwn_layer_items_build_dev')
+        t.filled = self.owner.fill_id
+        t.csr_key = None                     # (the per-item CSR cache belongs to the previous batch's entries)
+
+    def _make_bwd(self, F: int, has_up, has_b) -> Optional[BwdItemTable]:
+        o = self.owner
+        if F not in (64, 128):
+            return None
+        if not all(not has_b[d] or (d + 1 <= o.D and o.k_of(d, 'boundary_index') >= 0) for d in range(o.D)):
+            return None
+        n_sets = self._n_sets(has_up)
+        n_items = n_sets * o.B
+        cap_up = [o.cap_key(d, 'upper_index') if has_up[d] else 0 for d in range(o.D)]
+        cap_b = [o.cap_key(d, 'boundary_index') if (d > 0 and has_b[d]) else 0 for d in range(o.D)]
+        t = BwdItemTable(np.zeros((n_items, _ffi.LAYER_BWD_ITEM_INTS), dtype=np.int32), LDS_BYTES, list(o.cap_cells), cap_up, cap_b,
+                         o.device)
+        t.filled = -1
+        t.sizes = self._sizes_dev(has_up, has_b)
+        t.F = F
+        return t
+
+    def _launch_bwd(self, t: BwdItemTable) -> None:
+        plan = t.c_plan()
+        _ffi.check(_ffi.lib().cwn_layer_bwd_items_build_dev(t.sizes, t.F, plan, self.group, csr._err_flag(self.device).data_ptr(),
+                                                            _ffi.stream_ptr(self.device)), 'cwn_layer_bwd_items_build_dev')
+        t.filled = self.owner.fill_id
+
+
+class StaticComplexBatch(ComplexBatch):
+    """The ComplexBatch over a StaticBatch's buffers: its plans are not built per batch (the collate launch writes them)."""
+
+    def prepare(self, *args, **kwargs):
+        return self
+
+    def forget_plans(self):
+        return self
+
+
+class StaticBatch:
+    """Capacity-sized device buffers for batches of `batch_size` complexes of `packed` (a PackedComplexes built with
+    with_csr=True), and the two launches that fill them (`fill`).
+
+    caps: {'cells': [per dimension], (d, key): elements} overrides; by default every capacity is what a batch of the
+    dataset's sizes needs with a wide margin (mean x B + 6 sigma sqrt(B), at most the sum of the B largest), and
+    `fits(idx)` tells the caller which batches the buffers hold."""
+
+    def __init__(self, packed: PackedComplexes, batch_size: int, caps: Optional[dict] = None, variant: int = 0,
+                 group: Optional[int] = None, indices: Optional[Sequence[int]] = None):
+        if not packed.with_csr:
+            raise ValueError('StaticBatch needs a PackedComplexes built with with_csr=True')
+        if packed.device.type != 'cuda':
+            raise _ffi.CwnError('StaticBatch needs the packed dataset on the GPU')
+        self.packed, self.B = packed, int(batch_size)
+        self.device = packed.device
+        self.D = packed.max_dim + 1
+        self.K = len(packed._klist)
+        B, D, K = self.B, self.D, self.K
+        dev = self.device
+        meta = packed._meta if indices is None else packed._meta[np.asarray(indices, dtype=np.int64)]
+        # ---- capacities ---------------------------------------------------------------------------------------------
+        def cap_of(col: np.ndarray) -> int:
+            col = np.asarray(col, dtype=np.float64)
+            top = float(np.sort(col)[-min(B, col.size):].sum()) + (B - min(B, col.size)) * float(col.max(initial=0))
+            stat = B * float(col.mean()) + 6.0 * float(col.std()) * np.sqrt(B) + 8
+            return int(max(1, np.ceil(min(top, stat))))
+        caps = dict(caps or {})
+        self.cap_cells = list(caps.get('cells', [cap_of(meta[:, 3 * d]) for d in range(D)]))
+        # pairwise distinct, and distinct from the number of complexes: a row count then identifies what it counts
+        # (_ffi.dynamic_rows)
+        used = {B}
+        for d in range(D):
+            while self.cap_cells[d] in used:
+                self.cap_cells[d] += 1
+            used.add(self.cap_cells[d])
+        self._caps: List[int] = []
+        for k, (d, key, pk) in enumerate(packed._klist):
+            if key == 'x':
+                c = self.cap_cells[d] * pk.width
+            elif key == 'b_rowptr':
+                c = self.cap_cells[d]
+            elif key == 'bt_rowptr':
+                c = self.cap_cells[d - 1]
+            elif d < 0:
+                c = B * max(1, int(np.max(meta[:, 3 * D + k], initial=1)))
+            else:
+                c = int(caps.get((d, key), cap_of(meta[:, 3 * D + k])))
+            self._caps.append(int(c))
+        for d in range(1, D):            # the CSR columns cover the boundary entries one to one
+            kb = self.k_of(d, 'boundary_index')
+            if kb >= 0:
+                for name in ('b_col', 'bt_col'):
+                    self._caps[self.k_of(d, name)] = self._caps[kb]
+        # ---- tables -------------------------------------------------------------------------------------------------
+        L = _ffi.lib()
+        self.n_tab = int(L.cwn_collate_tables_len(D, K, B))
+        self.tables = torch.zeros(self.n_tab, dtype=torch.int64, device=dev)
+        self.o_src = K * (B + 1)
+        self.o_off = self.o_src + K * B
+        self.o_seg = self.o_off + D * 5 * B
+        self.o_sizes = self.o_seg + D * (B + 1)
+        self.meta = packed.meta_device()
+        self.idx = torch.full((B,), -1, dtype=torch.int64, device=dev)       # one batch, or an epoch's permutation (set_epoch)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.use_cursor = False
+        self.fill_id = 0
+        # ---- buffers + the collate launch's descriptors ---------------------------------------------------------------
+        base = self.tables.data_ptr()
+        cochains = [CochainBatch(d) for d in range(D)]
+        self.bufs: Dict = {}
+        descs = []
+        y = None
+        for k, (d, key, pk) in enumerate(packed._klist):
+            cap = self._caps[k]
+            add_ptr, dst_off = None, 0
+            if key == 'x':
+                out = torch.zeros(self.cap_cells[d], pk.width, dtype=pk.data.dtype, device=dev)
+            elif key in _TWO_ROW:
+                out = torch.zeros(2, cap, dtype=pk.data.dtype, device=dev)
+            elif key in ('b_rowptr', 'bt_rowptr'):
+                out = torch.zeros(cap + 1, dtype=torch.int32, device=dev)      # rowptr[0] = 0 is never rewritten
+                dst_off = 4
+                add_ptr = base + 8 * (self.k_of(d, 'b_col' if key == 'b_rowptr' else 'bt_col') * (B + 1))
+            else:
+                out = torch.zeros(cap, dtype=pk.data.dtype, device=dev)
+            row = _ADD_ROW.get(key)
+            if row is not None:
+                add_ptr = base + 8 * (self.o_off + (d * 5 + row) * B)
+            self.bufs[(d, key)] = out
+            if d < 0:
+                y = out
+            elif key == 'x':
+                cochains[d]._x = out
+            elif key not in _CSR_KEYS:
+                setattr(cochains[d], key, out)
+            two = pk.rows == 2
+            descs.append(_ffi.CollateDesc(
+                src=pk.data.data_ptr(), dst=out.data_ptr() + dst_off, dst_start=base + 8 * (k * (B + 1)),
+                src_start=base + 8 * (self.o_src + k * B), add=add_ptr,
+                src_row_stride=pk.data.size(-1) if two else 0, dst_row_stride=cap if two else 0,
+                n_rows=pk.rows, op=pk.op))
+        for d, cb in enumerate(cochains):
+            cb.batch = torch.zeros(self.cap_cells[d], dtype=torch.int64, device=dev)
+            descs.append(_ffi.CollateDesc(src=None, dst=cb.batch.data_ptr(), dst_start=base + 8 * (self.o_seg + d * (B + 1)),
+                                          src_start=None, add=None, src_row_stride=0, dst_row_stride=0, n_rows=1,
+                                          op=_ffi.COLLATE_SEGID64))
+            cb.ptr = None
+            cb.__num_cells__ = self.cap_cells[d]
+            cb.__num_cells_up__ = self.cap_cells[d + 1] if d + 1 < D else 0
+            if d > 0:
+                cb.__num_cells_down__ = self.cap_cells[d - 1]
+            cb.__num_cochains__ = B
+            cb.__slices__ = {}
+        self._descs = [(_ffi.CollateDesc * len(part))(*part)
+                       for part in (descs[i:i + _ffi.MAX_COLLATE_DESCS] for i in range(0, len(descs), _ffi.MAX_COLLATE_DESCS))]
+        self.batch = StaticComplexBatch(*cochains, y=y, num_complexes=B, dimension=D - 1)
+        # ---- plans: CSR of the boundary adjacencies (collated), sizes-only stand-ins for the upper ones -----------------
+        self._adjs = []
+        for d in range(D):
+            cb = cochains[d]
+            if d > 0 and cb.boundary_index is not None and self.k_of(d, 'b_col') >= 0:
+                bi = cb.boundary_index
+                adj = _CollatedAdjacency(bi, 1, self.cap_cells[d], self.cap_cells[d - 1], self.bufs[(d, 'b_rowptr')],
+                                         self.bufs[(d, 'b_col')])
+                adj._t_src = _CollatedAdjacency(bi, 0, self.cap_cells[d - 1], self.cap_cells[d], self.bufs[(d, 'bt_rowptr')],
+                                                self.bufs[(d, 'bt_col')])
+                self._register(bi, adj)
+            if cb.upper_index is not None and d + 1 < D:
+                ui = cb.upper_index
+                self._register(ui, _PlanOnlyAdjacency(ui, self.cap_cells[d], self.cap_cells[d], cb.shared_coboundaries,
+                                                      self.cap_cells[d + 1]))
+        if variant not in (0, 1):
+            raise ValueError('variant 0 (one 16-wave workgroup per CU) or 1 (the two-per-CU form)')
+        if group is None:
+            group = max(1, B // (256 if variant == 1 else 128))
+        self.plan = StaticBlockPlan(self, variant, group)
+        some = next(t for t in self.bufs.values())
+        self.batch._block_plan = (some.device, self.plan)          # (the device as the tensors spell it: Complex.block_plan compares)
+
+    # ---- layout helpers --------------------------------------------------------------------------------------------
+    def k_of(self, d: int, key: str) -> int:
+        return self.packed.key_index(d, key)
+
+    def cap_key(self, d: int, key: str) -> int:
+        k = self.k_of(d, key)
+        return self._caps[k] if k >= 0 else 0
+
+    def seg_view(self, d: int) -> torch.Tensor:
+        """`ptr` of dimension d: int64 [B + 1], the cells of complex c are rows seg[c] .. seg[c + 1]."""
+        o = self.o_seg + d * (self.B + 1)
+        return self.tables[o: o + self.B + 1]
+
+    def dst_view(self, k: int) -> torch.Tensor:
+        """`__slices__` of key k: int64 [B + 1]."""
+        return self.tables[k * (self.B + 1): (k + 1) * (self.B + 1)]
+
+    def size_ptr(self, j: int) -> int:
+        return self.tables.data_ptr() + 8 * (self.o_sizes + j)
+
+    def sizes(self) -> List[int]:
+        """[cells of dims 0..2, complexes] of the batch in the buffers (host sync: tests, diagnostics)."""
+        return self.tables[self.o_sizes: self.o_sizes + 4].tolist()
+
+    def _register(self, index: torch.Tensor, adj) -> None:
+        import weakref
+        key = id(index)
+        csr._cache[key] = ((index._version, adj.n_dst, adj.n_val), weakref.ref(index, lambda _r, k=key: csr._cache.pop(k, None)), adj)
+        self._adjs.append(adj)
+
+    def dynamic(self) -> _ffi.dynamic_rows:
+        """Context manager: inside, every launch whose row count is one of this batch's capacities reads the actual count
+        from the tables (the three cell counts are consecutive int64: cwn_embed_front_f32's n_dev)."""
+        m = {self.cap_cells[d]: self.size_ptr(d) for d in range(min(self.D, 3))}
+        m[self.B] = self.size_ptr(3)
+        return _ffi.dynamic_rows(m)
+
+    # ---- which batches fit ------------------------------------------------------------------------------------------
+    def fits(self, batches: Sequence[np.ndarray]) -> np.ndarray:
+        """bool per batch (index arrays): every array of the batch within its capacity and at least two cells of every
+        dimension the dataset has (BatchNorm in training mode needs them; the reference raises below two)."""
+        meta, D, K = self.packed._meta, self.D, self.K
+        ok = np.ones(len(batches), dtype=bool)
+        caps_cells = np.asarray(self.cap_cells, dtype=np.int64)
+        caps_keys = np.asarray(self._caps, dtype=np.int64)
+        single = self.plan.fit_mask()              # complexes every item table cut so far takes
+        for i, idx in enumerate(batches):
+            idx = np.asarray(idx, dtype=np.int64)
+            if idx.size == 0 or idx.size > self.B:
+                ok[i] = False
+                continue
+            m = meta[idx]
+            cells = m[:, 0:3 * D:3].sum(axis=0)
+            lens = m[:, 3 * D:3 * D + K].sum(axis=0)
+            ok[i] = bool((cells <= caps_cells).all() and (lens <= caps_keys).all() and (cells >= 2).all() and single[idx].all())
+        return ok
+
+    # ---- filling ------------------------------------------------------------------------------------------------------
+    def set_batch(self, idx: Sequence[int]) -> None:
+        """The complexes of the next fill (host -> device copy of <= B numbers; pads with -1)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size > self.B or idx.size == 0:
+            raise ValueError(f'a batch of 1 .. {self.B} complexes')
+        host = np.full(self.B, -1, dtype=np.int64)
+        host[:idx.size] = idx
+        if self.use_cursor:
+            raise RuntimeError('set_batch after set_epoch: the fills read the epoch permutation (call clear_epoch first)')
+        self.idx.copy_(torch.from_numpy(host), non_blocking=False)
+
+    def set_epoch(self, batches: Sequence[np.ndarray]) -> None:
+        """Upload the complex numbers of a whole epoch's batches; fill number j after this call takes batch j (the device
+        cursor advances by itself: a replayed step needs nothing from the host).  Re-uses the permutation buffer when the
+        number of batches did not grow (a captured fill holds its address)."""
+        n = len(batches)
+        host = np.full((max(n, 1), self.B), -1, dtype=np.int64)
+        for j, idx in enumerate(batches):
+            idx = np.asarray(idx, dtype=np.int64)
+            if idx.size > self.B or idx.size == 0:
+                raise ValueError(f'batch {j}: 1 .. {self.B} complexes')
+            host[j, :idx.size] = idx
+        if not self.use_cursor or self.idx.numel() < host.size:
+            if self.fill_id > 0 and self.use_cursor:
+                raise RuntimeError('set_epoch: more batches than the permutation buffer a captured step reads; reserve with '
+                                   'reserve_epoch(n) before the first fill')
+            self.idx = torch.full((host.size,), -1, dtype=torch.int64, device=self.device)
+        self.use_cursor = True
+        self.idx[:host.size].copy_(torch.from_numpy(host.reshape(-1)))
+        self.cursor.zero_()
+
+    def reserve_epoch(self, n_batches: int) -> None:
+        """Size the permutation buffer for epochs of up to n_batches batches (before the first fill / capture)."""
+        self.idx = torch.full((max(1, int(n_batches)) * self.B,), -1, dtype=torch.int64, device=self.device)
+        self.use_cursor = True
+        self.cursor.zero_()
+
+    def rewind(self, j: int = 0) -> None:
+        self.cursor.fill_(int(j))
+
+    def fill(self) -> None:
+        """Two launches: the batch's tables (cwn_collate_tables) and its arrays (cwn_collate).  Graph-capturable; the item
+        tables follow lazily, at the first launch that asks the plan for them."""
+        L = _ffi.lib()
+        s = _ffi.stream_ptr(self.device)
+        err = csr._err_flag(self.device).data_ptr()
+        _ffi.check(L.cwn_collate_tables(self.meta.data_ptr(), self.packed.num, self.D, self.K, self.idx.data_ptr(), self.B,
+                                        self.cursor.data_ptr() if self.use_cursor else None, self.tables.data_ptr(), err, s),
+                   'cwn_collate_tables')
+        for arr in self._descs:
+            _ffi.check(L.cwn_collate(arr, len(arr), self.B, s), 'cwn_collate')
+        self.fill_id += 1
+        self.plan.forget_csr()
+        self.plan.validated = True          # (index VALUES are checked by every blocked launch; the sticky word is read by the caller)
+        # ... and the item tables the model has asked for so far (a table asked for later is cut at that moment: StaticBlockPlan)
+        self.plan.refill()
+
+    # ---- the reference tables (tests) -----------------------------------------------------------------------------------
+    def host_tables(self, idx: Sequence[int]) -> np.ndarray:
+        """What cwn_collate_tables must write for the complexes `idx` (numpy restatement: the test's checker)."""
+        B, D, K = self.B, self.D, self.K
+        meta = self.packed._meta
+        idx = np.asarray(idx, dtype=np.int64)
+        m = np.zeros((B, meta.shape[1]), dtype=np.int64)
+        m[:idx.size] = meta[idx]
+        out = np.zeros(self.n_tab, dtype=np.int64)
+        cs = np.cumsum(m[:, :3 * D + K], axis=0)
+        dst = np.zeros((K, B + 1), dtype=np.int64)
+        dst[:, 1:] = cs[:, 3 * D:].T
+        out[:K * (B + 1)] = dst.reshape(-1)
+        out[self.o_src: self.o_src + K * B] = m[:, 3 * D + K: 3 * D + 2 * K].T.reshape(-1)
+        cnt = m[:, :3 * D].T.reshape(D, 3, B)
+        end = cs[:, :3 * D].T.reshape(D, 3, B)
+        off = end - cnt
+        out[self.o_off: self.o_off + D * 5 * B] = off[:, (0, 0, 1, 0, 2), :].reshape(-1)
+        seg = np.concatenate([off[:, 0, :], end[:, 0, -1:]], axis=1)
+        out[self.o_seg: self.o_seg + D * (B + 1)] = seg.reshape(-1)
+        for d in range(min(D, 3)):
+            out[self.o_sizes + d] = end[d, 0, -1]
+        out[self.o_sizes + 3] = idx.size
+        out[self.o_sizes + 8: self.o_sizes + 8 + K] = dst[:, -1]
+        return out

@@ -139,3 +139,131 @@ class StaticPropagate:
                     self.outs = self._run()
             self.graph.replay()
         return [[o[:self.n_cells[i // 2]] for i, o in enumerate(lo)] for lo in self.outs]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 4: whole forwards and whole training steps over batches never seen before
+# ------------------------------------------------------------------------------------------------------------------------------
+# StaticPropagate above replays the propagate scope for a new batch after the HOST has cut and uploaded its item table.
+# The classes below capture a model's full forward / a full optimisation step ONCE over a cwn_amd.static_batch.StaticBatch:
+# the collate, the per-batch tables, the item tables and every row count are device-side (static_batch.py), so a step on a
+# batch of the reference's shuffled epoch (data/data_loading.py:84-111, exp/train_utils.py:35-75) is ONE graph replay and
+# nothing else -- with StaticBatch.set_epoch not even the batch's complex numbers cross the bus per step.
+from .static_batch import StaticBatch            # noqa: E402
+from .train import TrainStep                     # noqa: E402
+
+
+def _cochains(b):
+    return [b.cochains[d] for d in range(b.dimension + 1)]
+
+
+class StaticForward:
+    """`model(batch)` (eval, no autograd) for every batch a StaticBatch holds, as one captured graph:
+        fill (tables + collate + item tables) -> front -> L x (layer launch + update launch) -> head.
+    `run(idx)` = set_batch + replay -> predictions of those complexes; after `static.set_epoch(batches)` every `replay()`
+    takes the next batch of the epoch.  The graph holds the packed forms of the model's weights: it is re-captured when
+    a parameter (or, through ops.STATE_EPOCH, a raw-pointer writer such as a TrainStep) has changed them."""
+
+    def __init__(self, model: torch.nn.Module, static: StaticBatch, include_partial: bool = False):
+        self.model, self.sb = model, static
+        self.include_partial = include_partial
+        self.inputs = [static.bufs.get((d, 'x')) for d in range(static.D)]
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.out = None
+        self._stamp = None
+
+    def _restore(self):
+        for c, x in zip(_cochains(self.sb.batch), self.inputs):
+            c._x = x
+
+    def _state(self):
+        return (ops.STATE_EPOCH,) + tuple(p._version for p in self.model.parameters()) + \
+            tuple(b._version for b in self.model.buffers())
+
+    def _run(self):
+        self.sb.fill()
+        self._restore()
+        with self.sb.dynamic():
+            out = self.model(self.sb.batch, include_partial=True) if self.include_partial else self.model(self.sb.batch)
+        self._restore()
+        return out
+
+    def eager(self):
+        """The same forward as ordinary launches (tests: what the replay must reproduce bit for bit)."""
+        with torch.no_grad():
+            return self._run()
+
+    def replay(self):
+        """Predictions [capacity, out]: rows past the batch's complexes are not meaningful."""
+        if self.model.training:
+            raise RuntimeError('StaticForward: model.eval() first (training-mode layers have no static inference form)')
+        if self.graph is None or self._stamp != self._state():
+            with torch.no_grad():
+                cur = self.sb.cursor.clone() if self.sb.use_cursor else None
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._run()                   # warm-up outside the capture: packed weights, prepared launches, item tables
+                    if cur is not None:
+                        self.sb.cursor.copy_(cur)
+                    self._run()
+                    if cur is not None:
+                        self.sb.cursor.copy_(cur)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
+                    self.out = self._run()
+            self._stamp = self._state()
+        self.graph.replay()
+        return self.out
+
+    def run(self, idx: Sequence[int]) -> torch.Tensor:
+        self.sb.set_batch(idx)
+        out = self.replay()
+        pred = out[0] if isinstance(out, tuple) else out
+        return pred[:len(idx)]
+
+
+class StaticTrainStep(TrainStep):
+    """One optimisation step (exp/train_utils.py:57-75: zero_grad, forward, loss, backward, Adam) on whatever batch the
+    StaticBatch holds next, captured ONCE: `step()` is a graph replay for every batch of an epoch.  World size 1 (the
+    data-parallel form replays the same pieces with the collectives in between, as TrainStep does)."""
+
+    def __init__(self, model: torch.nn.Module, static: StaticBatch, task_type: str = 'regression', lr: float = 1e-3,
+                 use_graph: bool = True, optimizer=None, stages: Optional[int] = None):
+        self.sb = static
+        static.fill()                                 # the buffers hold a real batch from here on (probe forwards, warm-up)
+        with static.dynamic():
+            super().__init__(model, [static.batch], task_type=task_type, lr=lr, use_graph=use_graph, optimizer=optimizer,
+                             rebuild_plans=False, stages=stages)
+        # the inputs ARE the static buffers (TrainStep keeps clones: the collate writes through raw pointers)
+        self.inputs = [[static.bufs.get((d, 'x')) for d in range(static.D)]]
+
+    def _forward_backward(self, i: int, pieces=None):
+        if pieces is None or 0 in pieces:
+            self.sb.fill()
+        with self.sb.dynamic():
+            return super()._forward_backward(i, pieces)
+
+    def _probe_stages(self, convs, ks):
+        with self.sb.dynamic():
+            return super()._probe_stages(convs, ks)
+
+    def _capture(self, i: int):
+        # the warm-up steps of the capture consume batches: put the cursor back so that the first replay takes the batch
+        # the caller expects
+        cur = self.sb.cursor.clone() if self.sb.use_cursor else None
+        res = super()._capture(i)
+        if cur is not None:
+            self.sb.cursor.copy_(cur)
+        return res
+
+    def step(self, i: int = 0) -> torch.Tensor:
+        """One step on the next batch (set_epoch) / the batch of set_batch.  Returns the loss tensor of the captured
+        step (overwritten by the next replay)."""
+        return super().step(0)
+
+    def step_on(self, idx: Sequence[int]) -> torch.Tensor:
+        self.sb.set_batch(idx)
+        return self.step()

@@ -48,8 +48,11 @@ class _FusedMeanLoss(torch.autograd.Function):
         p = pred.contiguous()
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         grad = torch.empty_like(p)
+        n_dev = _ffi.dyn(p.size(0)) if p.dim() >= 1 else None          # a static batch: the complexes that exist (device int64)
+        if n_dev is not None and p.numel() != p.size(0):
+            raise NotImplementedError('fused loss over a static batch: one prediction per complex')
         _ffi.check(_ffi.lib().cwn_loss_f32(kind, p.data_ptr(), y.contiguous().data_ptr(), p.numel(), loss.data_ptr(),
-                                           grad.data_ptr(), _ffi.stream_ptr(p.device)), 'cwn_loss_f32')
+                                           grad.data_ptr(), n_dev, _ffi.stream_ptr(p.device)), 'cwn_loss_f32')
         ctx.save_for_backward(grad)
         return loss
 
@@ -68,7 +71,7 @@ def fused_loss(task_type: str, pred: torch.Tensor, y: torch.Tensor) -> Optional[
     CrossEntropy)."""
     kind = _FUSED_KIND.get(task_type)
     if (not FUSED_LOSS or kind is None or not pred.is_cuda or pred.dtype != torch.float32 or y.dtype != torch.float32
-            or pred.shape != y.shape or pred.numel() == 0):
+            or pred.shape != y.shape or pred.numel() == 0 or not y.is_cuda or y.device != pred.device):
         return None
     return _FusedMeanLoss.apply(pred, y, kind)
 
@@ -261,7 +264,14 @@ class TrainStep:
         pred = self.model(b)
         y = b.y.view(-1,) if self.task_type == 'classification' else b.y.view(pred.shape).to(pred.dtype)
         loss = fused_loss(self.task_type, pred, y)
-        return loss if loss is not None else self.loss_fn(pred, y)
+        if loss is not None:
+            return loss
+        if self.task_type != 'classification' and not (pred.is_cuda and torch.cuda.is_current_stream_capturing()):
+            # null labels (exp/train_utils.py:64-68): `mask = ~torch.isnan(targets)`; the fused kernel does the same in place
+            # (boolean indexing is a host sync: not inside a capture, where only the fused form masks)
+            mask = ~torch.isnan(y)
+            return self.loss_fn(pred[mask], y[mask])
+        return self.loss_fn(pred, y)
 
     def _forward_backward(self, i: int, pieces: Optional[Sequence[int]] = None):
         """zero the gradients, forward, backward.  With a staged backward `pieces` selects what runs now:

@@ -16,6 +16,16 @@
  *     reported through a caller-provided int32 error word (see cwn_csr_build);
  *   - features are fp32 row-major [rows, F]; indices arrive as int64 (the reference asserts
  *     torch.long, mp/cell_mp.py:158) and are narrowed ONCE to int32 CSR by cwn_csr_build.
+ *   - DEVICE-SIDE ROW COUNTS (ABI 17).  The reference's training loop draws a new shuffled batch every step
+ *     (data/data_loading.py:84-111, exp/train_utils.py:35-75): every batch has its own cell and entry counts, and a
+ *     captured hipGraph bakes kernel arguments in.  Descriptors whose row count is a host integer therefore carry an
+ *     optional `m_dev` (device int64, or NULL): when given, the host count (M, n_dst, n_rows ...) is the CAPACITY of the
+ *     buffers -- it sizes the grid and bounds every address -- and the kernel reads the ACTUAL count from *m_dev
+ *     (0 <= *m_dev <= capacity; the caller vouches) for everything that is stored, counted or divided by.  Rows in
+ *     [*m_dev, capacity) are never written and never enter a reduction.  One captured launch then serves batches of
+ *     any shape up to the capacity; the item-table kernels (cwn_layer_fused_f32, cwn_layer_bwd_own_f32) have always
+ *     worked this way (their sizes live in the item table).  cwn_collate_tables / cwn_layer_items_build_dev /
+ *     cwn_layer_bwd_items_build_dev produce the per-batch tables on the device.
  */
 #ifndef CWN_HIP_H
 #define CWN_HIP_H
@@ -27,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 16
+#define CWN_ABI_VERSION 17
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -167,6 +177,7 @@ typedef struct cwn_agg_desc {
     int32_t flags;         /* CWN_AGG_* bits (0: none) */
     const float* self_x2;  /* [n_dst, F] or NULL: a second self term, out += (1 + *eps2) * self_x2 */
     const float* eps2;     /* device scalar or NULL (= 0) */
+    const int64_t* m_dev;  /* or NULL: the ACTUAL number of destination rows (n_dst is then the capacity), see "Conventions" */
 } cwn_agg_desc;
 
 int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream);
@@ -441,6 +452,32 @@ typedef struct cwn_layer_sizes {
 int64_t cwn_layer_items_build(const cwn_layer_sizes* sizes_host, int32_t F, int32_t* items_host, int64_t cap_items,
                               cwn_layer_plan* plan_host);     /* plan_host->variant (in): which form's caps to cut under */
 
+/* The same tables built ON THE DEVICE (one workgroup per set, a few microseconds), for launches captured once over
+ * capacity-sized buffers: the prefix sums are device arrays (the `seg` / `dst` rows cwn_collate_tables writes) and so is
+ * the number of complexes.  Set s owns the FIXED region [set_start[s], set_start[s + 1]) of the table (set_start[n_sets] =
+ * n_items = the capacity of the table; a region of `cap_complexes` records always suffices); records past a set's own
+ * are zeroed (empty: their workgroups leave at once).  The cut is simpler than the host's: complexes are taken in
+ * groups of `group` consecutive ones; a group that fits the caps is one item, one that does not is cut into its single
+ * complexes, and a complex that does not fit alone sets bit 4 (16) of *err_flag and gets no record (the caller checks
+ * that before it trusts a batch to this path -- the per-complex sizes are host metadata too).  No BIG records, no
+ * heavy-first order.  Forward: plan_host gives `items` (device, written), n_items, set_start, variant, and the LDS
+ * split of the captured launch (max_gemm_rows / max_source_rows; variant 1: lds_bytes).  Backward: plan_host gives
+ * `items`, n_items, lds_bytes (the launch's dynamic LDS); set s owns records [s * cap_complexes, (s + 1) * cap_complexes). */
+typedef struct cwn_layer_sizes_dev {
+    const int64_t* n_complexes;                     /* DEVICE int64: complexes in this batch, <= cap_complexes */
+    int64_t cap_complexes;
+    int32_t n_dims;
+    int32_t has_up[CWN_LAYER_MAX_DIMS];
+    const int64_t* cell_ptr[CWN_LAYER_MAX_DIMS];    /* DEVICE [cap_complexes + 1]; entries past the batch's own = the total */
+    const int64_t* up_ptr[CWN_LAYER_MAX_DIMS];      /* or NULL */
+    const int64_t* b_ptr[CWN_LAYER_MAX_DIMS];       /* or NULL */
+} cwn_layer_sizes_dev;
+#define CWN_ERR_BIT_UNFIT 16                   /* *err_flag bit: a complex beyond what one workgroup holds (device table build) */
+int cwn_layer_items_build_dev(const cwn_layer_sizes_dev* sizes_host, int32_t F, const cwn_layer_plan* plan_host, int32_t group,
+                              int32_t* err_flag, cwn_stream_t stream);
+int cwn_layer_bwd_items_build_dev(const cwn_layer_sizes_dev* sizes_host, int32_t F, const cwn_layer_bwd_plan* plan_host,
+                                  int32_t group, int32_t* err_flag, cwn_stream_t stream);
+
 /* HOST check of a host copy of the item table against its plan (record layout above): CWN_OK or
  * CWN_ERR_BAD_ARG.  The kernel re-checks only what keeps a workgroup inside its LDS. */
 int cwn_layer_items_check(const int32_t* items_host, int64_t n_items, int32_t F, const cwn_layer_plan* plan_host);
@@ -479,6 +516,7 @@ typedef struct cwn_mlp_dim {
     const float* shift[5];
     float* y;                   /* [M, F], row stride ldy */
     int64_t M, ldx_up, ldx_b, ldy;
+    const int64_t* m_dev;       /* or NULL: actual rows (M = capacity) */
 } cwn_mlp_dim;
 
 int cwn_update_mlp_f32(const cwn_mlp_dim* dims_host, int n_dims, int32_t F, cwn_stream_t stream);
@@ -523,6 +561,8 @@ typedef struct cwn_stage_desc {
     int64_t M, ldx, ldx2, ldy;
     int32_t in_relu;
     int32_t pad_;
+    const int64_t* m_dev;    /* or NULL: actual rows (M = capacity; col_sum / col_sumsq hold CWN_STAT_ROWS(M) bands, the first
+                                CWN_STAT_ROWS(*m_dev) are written) */
 } cwn_stage_desc;
 int cwn_dense_stage_f32(const cwn_stage_desc* descs_host, int n, int32_t F, cwn_stream_t stream);
 /* ... and BACKWARD (autograd of the Linear / BatchNorm1d(train) / ReLU modules of mp/layers.py:303-325): dX = dz W (two halves
@@ -553,6 +593,7 @@ typedef struct cwn_stage_bwd_desc {
     int64_t M, lddy, ldz, lddz, lddx, lddx2;
     int32_t relu;
     int32_t pad_;
+    const int64_t* m_dev;    /* or NULL: actual rows (M = capacity) */
 } cwn_stage_bwd_desc;
 int cwn_dense_stage_bwd_f32(const cwn_stage_bwd_desc* descs_host, int n, int32_t F, cwn_stream_t stream);
 
@@ -689,6 +730,9 @@ typedef struct cwn_bn_desc {
     int64_t* num_batches_tracked; /* or NULL: += 1 (BatchNorm1d's counter; one launch less per layer than a framework add) */
     float* bwd_sums;          /* or NULL: [2, N] set to 0 -- the s1 / s2 scratch of this stage's backward reduce, cleared
                                  here so that the backward pass launches no fill */
+    const int64_t* m_dev;     /* or NULL: actual rows the statistics were taken over (M = capacity: the band buffers hold
+                                 CWN_STAT_ROWS(M) bands, the first CWN_STAT_ROWS(*m_dev) are summed).  *m_dev < 1: the affine
+                                 is the identity-statistics one (mean 0, var 0) and the running statistics are left alone */
 } cwn_bn_desc;
 
 /* One launch for up to CWN_MAX_NORM_DESCS normalisations. */
@@ -710,6 +754,7 @@ typedef struct cwn_norm_desc {
     int32_t relu;        /* activation: ReLU (1) or identity (0) */
     float* acc1;         /* backward apply only, or NULL: acc1[n] += s1[n]  (beta.grad: d beta = s1) */
     float* acc2;         /* backward apply only, or NULL: acc2[n] += s2[n]  (gamma.grad: d gamma = s2); one writer per column */
+    const int64_t* m_dev; /* or NULL: actual rows (M = capacity) */
 } cwn_norm_desc;
 
 /* out = act(z * scale + shift)                                    (the last stage's output) */
@@ -748,6 +793,7 @@ typedef struct cwn_gemm_tn_desc {
     int64_t lddz, ldx, ldx2, lddw;
     int32_t N, K, K2;
     int32_t in_relu;         /* bit 0: X, bit 1: X2 */
+    const int64_t* m_dev;    /* or NULL: actual rows of the reduction (M = capacity: grid, workspace layout) */
 } cwn_gemm_tn_desc;
 
 /* With a workspace of cwn_gemm_tn_workspace_bytes() the row bands are combined in a fixed order by
@@ -769,9 +815,17 @@ int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs_host, int n, void* workspace, 
  *   CWN_COLLATE_COPY32 / COPY64  plain copy of 4- / 8-byte elements (features, labels)
  *   CWN_COLLATE_ADD64            int64 element + add[r][s]            (index tensors)
  *   CWN_COLLATE_SEGID64          int64 segment number s               (the `batch` vector)
+ *   CWN_COLLATE_ADD32            int32 element + (int32) add[r][s]    (CSR arrays, below)
  * Tables (dst_start [n_seg+1], src_start [n_seg], add [n_rows][n_seg]) are int64 device arrays.
+ *
+ * The CSR of a batch is the concatenation of its complexes' CSRs (the adjacency is block-diagonal and the cells of a
+ * complex are contiguous, data/complex.py:148-169): `col` arrays collate like an index row (ADD32 with the source
+ * dimension's cell offset), and a complex's row pointers WITHOUT their leading zero (n_c numbers) collate to
+ * rowptr + 1 with the running entry count as `add` -- rowptr[0] = 0 is written once.  A packed dataset that keeps the
+ * per-complex CSRs of its boundary adjacencies needs no cwn_csr_build per batch (cwn_amd/packed.py).
  * ------------------------------------------------------------------------------------------ */
-enum { CWN_COLLATE_COPY32 = 0, CWN_COLLATE_COPY64 = 1, CWN_COLLATE_ADD64 = 2, CWN_COLLATE_SEGID64 = 3 };
+enum { CWN_COLLATE_COPY32 = 0, CWN_COLLATE_COPY64 = 1, CWN_COLLATE_ADD64 = 2, CWN_COLLATE_SEGID64 = 3,
+       CWN_COLLATE_ADD32 = 4   /* int32 element + (int32) add[r][s]: the CSR arrays of a block-diagonal adjacency */ };
 #define CWN_MAX_COLLATE_DESCS 32
 
 typedef struct cwn_collate_desc {
@@ -788,6 +842,30 @@ typedef struct cwn_collate_desc {
 
 int cwn_collate(const cwn_collate_desc* descs_host, int n, int64_t n_seg, cwn_stream_t stream);
 
+/* The segment tables of a batch, built ON THE DEVICE from the per-complex metadata of a packed dataset (what
+ * cwn_amd/packed.py's host path computes with numpy and uploads: the reference does it in CochainBatch.from_cochain_list,
+ * data/complex.py:323-458).  With it a step needs nothing from the host but the batch's complex numbers -- or, with
+ * `cursor`, nothing at all: an epoch's permutation is uploaded once and every replay of a captured step takes the next
+ * batch (exp/train_utils.py:35: `for batch in train_loader`).
+ *   meta   device int64 [num][W], W = 3 D + 3 K, one row per complex of the dataset:
+ *            [3 d + 0 / 1 / 2]  cells of dimension d / cells below / cells above (the three running offsets of
+ *                               data/complex.py:148-169)
+ *            [3 D + k] length, [3 D + K + k] start, [3 D + 2 K + k] has      of key k (one array of the packed dataset)
+ *   idx    device int64: the complexes of a batch in order, B per batch; a negative entry = no complex (a short last
+ *          batch; such entries form a suffix); an entry >= num sets bit 1 of *err_flag and counts as absent
+ *   cursor device int64 or NULL: when given, the batch is idx[*cursor * B .. (*cursor + 1) * B) and the launch adds 1
+ *   tables (out) device int64 [cwn_collate_tables_len(D, K, B)]:
+ *            dst   [K][B + 1]  at 0               dst[k][s] = sum_{s' < s} length_k(idx[s'])   (`__slices__`, :349-394)
+ *            src   [K][B]      at K (B + 1)       start_k(idx[s])
+ *            off   [D][5][B]   then               exclusive sums of (cells, cells, below, cells, above) of dimension d
+ *            seg   [D][B + 1]  then               exclusive sums of the cells of dimension d, the total last (`ptr`, :344, 432)
+ *            sizes [8 + K]     then               [d] cells of dimension d (0 beyond D; d < 3), [3] complexes in the batch,
+ *                                                 [4..7] 0, [8 + k] total length of key k  -- what `m_dev` fields point at
+ * One workgroup; a few microseconds. */
+size_t cwn_collate_tables_len(int32_t D, int32_t K, int64_t B);      /* int64 elements */
+int cwn_collate_tables(const int64_t* meta, int64_t num, int32_t D, int32_t K, const int64_t* idx, int64_t B,
+                       int64_t* cursor, int64_t* tables, int32_t* err_flag, cwn_stream_t stream);
+
 /* Embedding lookup with a sum over index columns (torch.nn.Embedding for cols = 1; the OGB
  * Atom/BondEncoder sum over one table per integer feature column, mp/molec_models.py:44-52, 237-245):
  *     out[r, :] = sum_c W[col_off[c] + src[r, c], :]
@@ -803,9 +881,11 @@ int cwn_embedding_fwd_f32(const float* W, const int64_t* src, const int64_t* col
  * zeroes it) must fit one workgroup's LDS (V * H * 4 <= 60 KiB): every workgroup accumulates its
  * band of cells into a private copy of the whole table and adds it to dW once;
  * CWN_ERR_TOO_LARGE otherwise (callers then use the transposed aggregation). */
-int cwn_embedding_bwd_f32(const float* g, const int64_t* src, const int64_t* col_off,
+/* src_f32 != 0: `src` holds the integer features as float32 (as the containers deliver them; truncated like the front's);
+ * n_dev (or NULL): device int64 = the actual number of rows (n_rows = capacity). */
+int cwn_embedding_bwd_f32(const float* g, const void* src, const int64_t* col_off,
                           const int64_t* col_size, float* dW, int64_t n_rows, int32_t cols, int32_t H,
-                          int64_t V, cwn_stream_t stream);
+                          int64_t V, int32_t src_f32, const int64_t* n_dev, cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * The two ends of a model forward, one launch each (inference; csrc/cwn_ends.hip).
@@ -834,10 +914,11 @@ typedef struct cwn_embed_table {
     int32_t src_is_f32;
 } cwn_embed_table;
 
+/* n_dev (or NULL): device int64 [3] = the ACTUAL n0, n1, n2 (the arguments are then capacities, see "Conventions"). */
 int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, float* x0, const cwn_embed_table* e_tab,
                         int64_t n1, float* x1, const int32_t* rowptr1, const int32_t* col1, int64_t nb1, int64_t n2,
                         float* x2, const int32_t* rowptr2, const int32_t* col2, int64_t nb2, int32_t H, int32_t halve,
-                        int32_t* err_flag, cwn_stream_t stream);
+                        int32_t* err_flag, const int64_t* n_dev, cwn_stream_t stream);
 
 /* HEAD -- pool_complex (mp/nn.py:50-60) + lin1s + final readout + lin2 (mp/molec_models.py:129-156,
  * mp/models.py:222-253), one workgroup per complex:
@@ -890,8 +971,11 @@ int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims_host, int n_dims, int64_t C, i
  * kinds: L1Loss, MSELoss, BCEWithLogitsLoss (torch's definitions, incl. sign(0) = 0 and the stable BCE form).
  * One workgroup, fixed reduction tree (deterministic); meant for the few hundred predictions of a batch. */
 enum { CWN_LOSS_L1 = 0, CWN_LOSS_MSE = 1, CWN_LOSS_BCE_LOGITS = 2 };
+/* n_dev (or NULL): device int64 = the ACTUAL number of elements (n is then the capacity: grad[i] = 0 for i >= *n_dev).
+ * A target that is NaN is a NULL label (exp/train_utils.py:64-66: `mask = ~torch.isnan(targets)`): it contributes no loss and
+ * no gradient and does not count in the mean. */
 int cwn_loss_f32(int32_t kind, const float* pred, const float* y, int64_t n, float* loss, float* grad,
-                 cwn_stream_t stream);
+                 const int64_t* n_dev, cwn_stream_t stream);
 
 /* torch.optim.Adam's update (no amsgrad; weight_decay is the L2 form) for a whole model in one
  * launch: parameters p, gradients g and the moments m, v are each ONE contiguous fp32 buffer of n

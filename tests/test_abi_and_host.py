@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 16
+    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 17
     assert lib.cwn_target_arch() == b'gfx950'
     assert lib.cwn_error_string(0) == b'ok'
 
@@ -82,8 +82,8 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_norm_bwd_f32(nd, 1, 0, None) == 0                # nothing to do
     assert _ffi.NORM_BWD_FUSED_MAX_ROWS == int(re.search(r'#define CWN_NORM_BWD_FUSED_MAX_ROWS (\d+)', open(os.path.join(ROOT, 'include', 'cwn_hip.h')).read()).group(1))
     assert lib.cwn_adam_f32(None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, None, None) == 1
-    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 8, 1, 64, 28, None) == 1
-    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 0, 1, 64, 28, None) == 0   # nothing to do
+    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 8, 1, 64, 28, 0, None, None) == 1
+    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 0, 1, 64, 28, 0, None, None) == 0   # nothing to do
     assert lib.cwn_embedding_fwd_f32(None, None, None, None, None, 8, 1, 64, 28, None, None) == 1
     g = (_ffi.GemmDesc * 1)(_ffi.GemmDesc(M=4, N=8, K=300, K2=0, ldx=300, ldw=300, ldy=8))
     assert lib.cwn_gemm_f32(g, 1, None) == 2                       # CWN_ERR_TOO_LARGE: K beyond the kernel
@@ -119,12 +119,12 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_gemm_would_split(g, 1) == 0                       # not the split kernel's shape ...
     # round-3 additions: the fused ends (csrc/cwn_ends.hip)
     tv = _ffi.EmbedTable(V=28, cols=1)
-    assert lib.cwn_embed_front_f32(None, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, None, None) == 1
-    assert lib.cwn_embed_front_f32(tv, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 66, 1, None, None) == 1   # H % 4
+    assert lib.cwn_embed_front_f32(None, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, None, None, None) == 1
+    assert lib.cwn_embed_front_f32(tv, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 66, 1, None, None, None) == 1   # H % 4
     err = ctypes.c_int32(0)
-    assert lib.cwn_embed_front_f32(tv, 0, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, ctypes.byref(err), None) == 0  # nothing to do
-    assert lib.cwn_embed_front_f32(tv, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, ctypes.byref(err), None) == 1  # rows, no table
-    assert lib.cwn_loss_f32(0, None, None, 4, None, None, None) == 1 and lib.cwn_loss_f32(7, None, None, 4, None, None, None) == 1
+    assert lib.cwn_embed_front_f32(tv, 0, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, ctypes.byref(err), None, None) == 0  # nothing to do
+    assert lib.cwn_embed_front_f32(tv, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, ctypes.byref(err), None, None) == 1  # rows, no table
+    assert lib.cwn_loss_f32(0, None, None, 4, None, None, None, None) == 1 and lib.cwn_loss_f32(7, None, None, 4, None, None, None, None) == 1
     hd = (_ffi.HeadDim * 1)(_ffi.HeadDim())
     assert lib.cwn_head_f32(None, 1, 4, 128, 256, 0, 0, None, None, 1, None, None, None) == 1
     assert lib.cwn_head_f32(hd, 1, 0, 128, 256, 0, 0, None, None, 1, None, None, None) == 0          # no complexes

@@ -1,0 +1,245 @@
+"""GPU tests of the static-batch path (round 4): one captured graph per model serves batches it has never seen, the way the
+reference's training loop meets them (data/data_loading.py:84-111 shuffles, exp/train_utils.py:35-75 steps through).
+Everything a batch changes is computed on the device (cwn_amd/static_batch.py); these tests pin each device-side piece on
+its host / per-batch counterpart and the captured forward / training step on the ordinary per-batch launches."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+
+
+def _packed(n=220, seed=3, n_lo=9, n_hi=30, with_csr=True):
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.synthetic import zinc_like_complexes
+    pool = zinc_like_complexes(n, seed=seed, max_ring=6, n_lo=n_lo, n_hi=n_hi)
+    return pool, PackedComplexes(pool, DEV, max_dim=2, with_csr=with_csr)
+
+
+def _batches(n, B, seed, sizes=None):
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(n)
+    out, lo = [], 0
+    for b in (sizes or [B] * (n // B)):
+        out.append(perm[lo:lo + b])
+        lo += b
+    return out
+
+
+def test_device_tables_equal_the_host_tables_and_the_collate_its_per_batch_form():
+    """cwn_collate_tables against the numpy restatement (every table, the sizes, bit for bit: full batches, a short last
+    batch, one complex), then the arrays the static collate writes against PackedComplexes.collate of the same complexes
+    (features, index rows with the second row at the capacity offset, shared cells, batch vectors, labels) and the
+    collated CSR of the boundary adjacencies and their transposes against cwn_csr_build on the per-batch index."""
+    from cwn_amd import csr
+    from cwn_amd.static_batch import StaticBatch
+    pool, p = _packed()
+    B = 48
+    sb = StaticBatch(p, B)
+    for idx in _batches(len(pool), B, 1, sizes=[B, B, 17, 1, B]):
+        sb.set_batch(idx)
+        sb.fill()
+        torch.cuda.synchronize()
+        assert np.array_equal(sb.tables.cpu().numpy(), sb.host_tables(idx)), len(idx)
+        ref = p.collate(idx)
+        n = [ref.cochains[d].num_cells for d in range(3)]
+        assert sb.sizes() == n + [len(idx)]
+        for d in range(3):
+            rc, sc = ref.cochains[d], sb.batch.cochains[d]
+            if rc.x is not None:
+                assert torch.equal(sc._x[:n[d]], rc.x)
+            assert torch.equal(sc.batch[:n[d]], rc.batch)
+            for key in ('upper_index', 'boundary_index'):
+                a = getattr(rc, key)
+                if a is not None:
+                    e = a.size(1)
+                    assert torch.equal(getattr(sc, key)[:, :e], a), (d, key)       # row 1 lives at offset `capacity`
+            if rc.shared_coboundaries is not None:
+                e = rc.shared_coboundaries.numel()
+                assert torch.equal(sc.shared_coboundaries[:e], rc.shared_coboundaries)
+            if d > 0 and rc.boundary_index is not None:
+                adj = csr.cached_adjacency(rc.boundary_index, n[d], n[d - 1])
+                t = adj.t_src
+                e = rc.boundary_index.size(1)
+                assert torch.equal(sb.bufs[(d, 'b_rowptr')][:n[d] + 1], adj.rowptr)
+                assert torch.equal(sb.bufs[(d, 'b_col')][:e], adj.col)
+                assert torch.equal(sb.bufs[(d, 'bt_rowptr')][:n[d - 1] + 1], t.rowptr)
+                assert torch.equal(sb.bufs[(d, 'bt_col')][:e], t.col)
+        assert torch.equal(sb.batch.y[:len(idx)], ref.y.view(-1))
+    csr.check_errors(DEV)
+
+
+def test_epoch_cursor_takes_the_batches_in_order():
+    """set_epoch uploads the complex numbers of a whole epoch once; every fill then takes the next batch by itself (the
+    device-side cursor): the tables after fill j are those of batch j."""
+    from cwn_amd.static_batch import StaticBatch
+    pool, p = _packed(n=150)
+    B = 32
+    sb = StaticBatch(p, B)
+    batches = _batches(len(pool), B, 7, sizes=[B, B, B, 20])
+    sb.set_epoch(batches)
+    for j, idx in enumerate(batches):
+        sb.fill()
+        torch.cuda.synchronize()
+        assert np.array_equal(sb.tables.cpu().numpy(), sb.host_tables(idx)), j
+    sb.rewind(1)
+    sb.fill()
+    assert np.array_equal(sb.tables.cpu().numpy(), sb.host_tables(batches[1]))
+
+
+@pytest.mark.parametrize('F,group', [(128, 1), (128, 3), (64, 4)])
+def test_device_item_tables_pass_the_host_check_and_cover_every_cell_once(F, group):
+    """cwn_layer_items_build_dev / cwn_layer_bwd_items_build_dev: the forward table passes the host-side validator
+    (cwn_layer_items_check: derived fields, ranges, caps), its records and the backward table's own every cell of the batch
+    exactly once per set, and empty records sit behind a set's own."""
+    from cwn_amd import _ffi, csr
+    from cwn_amd.static_batch import StaticBatch
+    pool, p = _packed(n_lo=9, n_hi=28 if F == 128 else 45)
+    B = 40
+    sb = StaticBatch(p, B, group=group)
+    has_up, has_b = [True, True, False], [False, True, True]
+    for idx in _batches(len(pool), B, 5, sizes=[B, 13, B]):
+        sb.set_batch(idx)
+        sb.fill()
+        t = sb.plan.items(F, has_up, has_b)
+        tb = sb.plan.bwd_items(F, has_up, has_b)
+        torch.cuda.synchronize()
+        csr.check_errors(DEV)
+        items = t.items.cpu().numpy()
+        rc = _ffi.lib().cwn_layer_items_check(items.ctypes.data, t.n_items, F, t.c_plan(False))
+        assert rc == 0, rc
+        n = sb.sizes()
+        for s, (dims_of_set) in enumerate(([0], [1, 2])):
+            rec = items[s * B:(s + 1) * B]
+            live = rec[:, 8] > 0
+            assert not live[np.argmin(live):].any() if not live.all() else True          # empties behind the set's own
+            for k, d in enumerate(dims_of_set):
+                r0, cnt = rec[live, 10 + 7 * k], rec[live, 11 + 7 * k]
+                order = np.argsort(r0, kind='stable')
+                assert (np.cumsum(cnt[order]) - cnt[order] == r0[order]).all() and cnt.sum() == n[d], (s, d)
+        bw = tb.items.cpu().numpy()
+        for s, d in enumerate((0, 1)):
+            rec = bw[s * B:(s + 1) * B]
+            live = rec[:, 3] > 0
+            r0, cnt = rec[live, 2], rec[live, 3]
+            order = np.argsort(r0, kind='stable')
+            assert (rec[live, 1] == d).all() and (np.cumsum(cnt[order]) - cnt[order] == r0[order]).all() and cnt.sum() == n[d]
+            if d == 1:                                                    # the rings ride with the edges (TOP)
+                assert rec[live, 5].sum() == n[2]
+
+
+def _model(hidden=128, layers=2, seed=0):
+    from cwn_amd.models import EmbedSparseCIN
+    torch.manual_seed(seed)
+    return EmbedSparseCIN(28, 4, 1, layers, hidden, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu',
+                          readout='sum', train_eps=False, final_hidden_multiplier=2, final_readout='sum', init_reduce='sum',
+                          embed_edge=True, use_coboundaries=True, graph_norm='bn').to(DEV)
+
+
+@pytest.mark.parametrize('hidden', [128, 64])
+def test_static_forward_replays_one_graph_for_unseen_batches_bit_identically(hidden):
+    """StaticForward: the whole eval forward (front, layers, update networks, head) captured ONCE; batches of 48, 48, 17, 1
+    and 48 complexes it has never seen give predictions bit-identical to model(collate(batch)) -- the per-batch launches
+    with host-built tables -- and inside the gate of ... nothing else: equality is the bar (every kernel's result per row /
+    per complex is independent of how the batch was cut)."""
+    from cwn_amd import csr
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward
+    pool, p = _packed(n_hi=28)
+    model = _model(hidden).eval()
+    B = 48
+    sb = StaticBatch(p, B)
+    sf = StaticForward(model, sb)
+    graphs = set()
+    with torch.no_grad():
+        for idx in _batches(len(pool), B, 11, sizes=[B, B, 17, 1, B]):
+            got = sf.run(idx).clone()
+            graphs.add(id(sf.graph))
+            want = model(p.collate(idx))
+            assert torch.equal(got, want), float((got - want).abs().max())
+    assert len(graphs) == 1
+    csr.check_errors(DEV)
+    assert sb.fits(_batches(len(pool), B, 11, sizes=[B, 17])).all()
+
+
+def test_static_forward_over_an_epoch_needs_nothing_from_the_host_per_step():
+    """set_epoch + replay, replay, ...: the predictions of step j are those of the epoch's j-th batch."""
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward
+    pool, p = _packed(n=200, n_hi=28)
+    model = _model(128).eval()
+    B = 32
+    sb = StaticBatch(p, B)
+    sb.reserve_epoch(8)
+    sf = StaticForward(model, sb)
+    batches = _batches(len(pool), B, 2, sizes=[B] * 5 + [9])
+    with torch.no_grad():
+        for epoch in range(2):
+            order = batches if epoch == 0 else batches[::-1]
+            sb.set_epoch(order)
+            for idx in order:
+                got = sf.replay()[:len(idx)].clone()
+                assert torch.equal(got, model(p.collate(idx)))
+
+
+def test_static_train_step_matches_the_per_batch_step():
+    """StaticTrainStep: zero_grad, forward, loss, backward and Adam of exp/train_utils.py:57-75 captured ONCE and replayed on
+    three batches it has never seen (48, 48, 20 complexes) against TrainStep's eager per-batch step from the same state:
+    loss, the flat gradient after every step and the parameters after the last (the weight-gradient / BatchNorm-backward
+    sums are fp32 atomics in both: summation order is the only difference)."""
+    from cwn_amd import csr
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    from cwn_amd.train import TrainStep
+    pool, p = _packed(n_hi=28)
+    B = 48
+    m1, m2 = _model(128, 2, seed=4), _model(128, 2, seed=4)
+    m2.load_state_dict(m1.state_dict())
+    batches = _batches(len(pool), B, 13, sizes=[B, B, 20])
+    sb = StaticBatch(p, B)
+    sb.set_batch(batches[0])
+    st = StaticTrainStep(m1, sb, lr=1e-3)
+    ref = TrainStep(m2, [p.collate(idx) for idx in batches], lr=1e-3, use_graph=False)
+    for j, idx in enumerate(batches):
+        l1 = st.step_on(idx).clone()
+        l2 = ref.step(j)
+        torch.cuda.synchronize()
+        assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l2))), (j, float(l1), float(l2))
+        g1, g2 = st.bucket.flat, ref.bucket.flat
+        rel = float((g1 - g2).norm() / g2.norm())
+        print(f'[static train] step {j}: loss {float(l1):.6f} vs {float(l2):.6f}, relative L2 distance of the gradient {rel:.2e}')
+        assert rel < 2e-5, (j, rel)
+    csr.check_errors(DEV)
+    assert len(st._graphs) == 1
+    worst = 0.0
+    for (n_, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        if a.dtype.is_floating_point:
+            worst = max(worst, float((a - b).abs().max()) / max(1.0, float(b.abs().max())))
+    assert worst < 2 * 1e-3 * 3 * 1.1, worst         # (Adam's first steps: sign flips of noise-level gradients, test_gpu_parity)
+    for (n_, a), (_, b) in zip(m1.named_buffers(), m2.named_buffers()):
+        if a.dtype.is_floating_point:                # BatchNorm running statistics: the batch's own rows only
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), n_
+
+
+def test_a_complex_beyond_a_workgroup_is_refused_by_fits_and_flagged_by_the_device():
+    """A 44-atom molecule does not fit one workgroup at width 128: fits() says so for the batches that hold it (the caller
+    routes them to PackedComplexes.collate), and pushing such a batch through anyway sets the sticky UNFIT bit."""
+    from cwn_amd import csr
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward
+    from cwn_amd.synthetic import zinc_like_complexes
+    pool = zinc_like_complexes(60, seed=1, max_ring=6, n_lo=12, n_hi=26) + zinc_like_complexes(1, seed=2, max_ring=6, n_lo=44, n_hi=44)
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+    sb = StaticBatch(p, 16, caps={'cells': [600, 700, 90]})
+    sf = StaticForward(_model(128).eval(), sb)
+    with torch.no_grad():
+        sf.run(list(range(16)))
+    good, bad = np.arange(16), np.concatenate([np.arange(15), [60]])
+    assert sb.fits([good, bad]).tolist() == [True, False]
+    csr.check_errors(DEV)
+    with torch.no_grad():
+        sf.run(bad)
+    with pytest.raises(IndexError, match='beyond what one workgroup holds'):
+        csr.check_errors(DEV)
