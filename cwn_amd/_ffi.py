@@ -542,16 +542,25 @@ def _side_stream(device):
     return _tn_side[key]
 
 
-def flush_tn(device) -> None:
-    """Launch every queued weight gradient (queue order), MAX_TN_DESCS per launch; join the side stream."""
+def flush_tn(device=None) -> None:
+    """Launch every queued weight gradient (queue order), MAX_TN_DESCS per launch, on the device (and its current stream)
+    the operands live on -- recorded when they were queued (not the process' current device); join the side stream."""
     global _tn_queue, _tn_side_used
     if _tn_side_used:
-        torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+        dev_ = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        torch.cuda.current_stream(dev_).wait_stream(_side_stream(dev_))
         _tn_side_used = False
     if not _tn_queue:
         return
     q, _tn_queue = _tn_queue, []
-    descs = [d for ds, _ in q for d in ds]
+    by_dev = {}
+    for ds, _, dv in q:
+        by_dev.setdefault(dv, []).extend(ds)
+    for dv, descs in by_dev.items():
+        _flush_descs(descs, dv if dv is not None else device)
+
+
+def _flush_descs(descs, device) -> None:
     # one launch runs ONE form of the kernel: descriptors that need the element-wise loads (a width that is not a
     # multiple of 4: the head's lin2) go into launches of their own instead of slowing the 16-byte form of the rest
     def vec(d):
@@ -569,12 +578,12 @@ def gemm_tn(descs: Sequence[GemmTnDesc], device, keep=None, deferrable: bool = F
     flush_tn (never tensors handed back to autograd); `keep`: every tensor a descriptor points at."""
     if deferrable and _tn_queue is not None and not DETERMINISTIC_TN:
         if not TN_SIDE_STREAM:
-            _tn_queue.append((list(descs), keep))
+            _tn_queue.append((list(descs), keep, torch.device(device)))
             return
         global _tn_side_used
         main, side = torch.cuda.current_stream(device), _side_stream(device)
         side.wait_stream(main)                  # everything the descriptors read has been issued on `main`
-        _tn_queue.append(([], keep))            # the operands stay referenced until the join
+        _tn_queue.append(([], keep, torch.device(device)))            # the operands stay referenced until the join
         _tn_side_used = True
         with torch.cuda.stream(side):
             gemm_tn(descs, device)

@@ -981,7 +981,7 @@ class accumulate_into_grad:
         ACCUMULATE_INTO_GRAD = self.prev
         if self.defer:
             if exc[0] is None:
-                _ffi.flush_tn(torch.device('cuda', torch.cuda.current_device()))
+                _ffi.flush_tn()
             else:
                 _ffi._tn_queue.clear()
             _ffi.defer_tn(False)
@@ -1329,11 +1329,22 @@ class LayerDim:
 # state_changed(); the epoch is part of every cache key.  (A caller who replays its own graph of training kernels
 # calls it too.)
 STATE_EPOCH = 0
+# ... and the subset of those writes that touch PARAMETERS (the optimizer: cwn_adam_f32, a replayed training step) -- the
+# BatchNorm-statistics epilogue moves STATE_EPOCH inside every training forward, between the packing of a step's weight
+# blocks and their use, without touching a weight; the packed blocks of the stage kernels are validated against this one.
+WEIGHT_EPOCH = 0
 
 
 def state_changed() -> None:
     global STATE_EPOCH
     STATE_EPOCH += 1
+
+
+def weights_changed() -> None:
+    """A raw-pointer writer has changed parameters (FlatAdam.step, every replay of a captured training step)."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+    state_changed()
 
 
 _packed_weights = {}
@@ -1586,14 +1597,17 @@ def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True) 
                 _ffi.check(L.cwn_update_mlp_pack_weights_t_many_f32(Wp, ld, F, Tp, n, _ffi.stream_ptr(dev)),
                            'cwn_update_mlp_pack_weights_t_many_f32')
             for (weight, w, c0), o, ot in zip(part, outs, outs_t):
-                _packed_stage[_stage_key(w, c0)] = (_stage_token, o, ot)
+                _packed_stage[_stage_key(w, c0)] = (_stage_token, o, ot, weight._version, WEIGHT_EPOCH)
 
 
 def packed_stage_block(weight: Tensor, col0: int, transposed: bool = False) -> Optional[Tensor]:
     """The packed block weight[:, col0 : col0 + F] (or the block of the transposed weight) written by the LATEST
     pack_stage_weights_many call, or None."""
     hit = _packed_stage.get(_stage_key(weight, col0)) if weight.dim() == 2 else None
-    if hit is not None and hit[0] == _stage_token:
+    # (ADVICE r3: an entry is keyed on the weight's STORAGE -- the backward sees its saved weights re-wrapped -- so it must
+    # also prove that nothing has written that storage since: the tensor version (torch optimizers, in-place ops) and the
+    # parameter epoch (FlatAdam / a replayed step write through raw pointers).  A miss sends the caller to cwn_gemm_f32.)
+    if hit is not None and hit[0] == _stage_token and hit[3] == weight._version and hit[4] == WEIGHT_EPOCH:
         return hit[2] if transposed else hit[1]
     return None
 
@@ -1746,7 +1760,10 @@ def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of, bwd_tab
     dev = dims[0].x.device
     rows = [int(D.x.size(0)) for D in dims]
     # atomic form: every piece is ADDED (one fill for the layer); owner form: every row is written once
-    dx_buf = (torch.empty if own else torch.zeros)(sum(rows), F, dtype=torch.float32, device=dev)
+    # (the owner form writes the rows its table owns -- a table that ends before a matrix does leaves the rest
+    # unwritten: zero-filled then, unless the rows are a static batch's capacity padding, which nothing ever reads)
+    covered = own and all(int(bwd_table.cells_end[d]) == rows[d] for d in range(n))
+    dx_buf = (torch.empty if covered else torch.zeros)(sum(rows), F, dtype=torch.float32, device=dev)
     dxs = list(dx_buf.split(rows))
     arr = (_ffi.LayerBwdDim * n)()
     gys, keep = [], []

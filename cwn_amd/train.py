@@ -115,7 +115,7 @@ class FlatAdam:
             self.flat_p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
             g.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
             self.t.data_ptr(), _ffi.stream_ptr(g.device)), 'cwn_adam_f32')
-        ops.state_changed()          # the parameters were written through a raw pointer: tensor versions did not move
+        ops.weights_changed()        # the parameters were written through a raw pointer: tensor versions did not move
 
 
 class TrainStep:
@@ -357,6 +357,8 @@ class TrainStep:
             self.opt.step()
         return (pieces, g2, loss)
 
+    MAX_SEQ_GRAPHS = 8
+
     # ---- several steps behind one replay -------------------------------------------------------
     def steps(self, seq: Sequence[int]) -> List[torch.Tensor]:
         """The steps on batches[seq[0]], batches[seq[1]], ... in this order; returns their losses.  With `use_graph` on one
@@ -368,6 +370,11 @@ class TrainStep:
             return [self.step(i) for i in seq]
         key = ('seq',) + seq
         if key not in self._graphs:
+            # (a loop that reshuffles its batch order every epoch asks for a new sequence each time; every captured
+            # graph holds device memory of its own -- keep the most recent MAX_SEQ_GRAPHS of them)
+            seqs = [k for k in self._graphs if isinstance(k, tuple)]
+            while len(seqs) >= self.MAX_SEQ_GRAPHS:
+                del self._graphs[seqs.pop(0)]
             for i in dict.fromkeys(seq):                       # warm-up and the one-step graphs (they own the warm-up logic)
                 if i not in self._graphs:
                     self._graphs[i] = self._capture(i)
@@ -376,7 +383,7 @@ class TrainStep:
                 losses = [self._eager(i) for i in seq]
             self._graphs[key] = (g, losses)
         g, losses = self._graphs[key]
-        ops.state_changed()
+        ops.weights_changed()
         g.replay()
         return losses
 
@@ -387,7 +394,7 @@ class TrainStep:
         if i not in self._graphs:
             self._graphs[i] = self._capture(i)
         pieces, g2, loss = self._graphs[i]
-        ops.state_changed()          # a replay runs no Python: caches of packed weights / folded BatchNorm must not survive it
+        ops.weights_changed()        # a replay runs no Python: caches of packed weights / folded BatchNorm must not survive it
         if g2 is None:
             pieces[0].replay()
             return loss

@@ -1,0 +1,97 @@
+"""The training step pinned AT THE SIZE THAT IS TIMED (VERDICT r3 "what's weak" #1): BASELINE configs[1] exactly -- EmbedSparseCIN,
+hidden 128, 4 layers, batch 128, BatchNorm in training mode, L1 loss -- and configs[2] (molhiv-like, batch 512, hidden 64,
+2 layers, mean readout), one `TrainStep.step` through the captured graph against torch autograd over the ORACLE's forward in
+float64 on the CPU (exp/train_utils.py:57-75 is the loop, mp/test_layers.py:72-112 the reference's own gradient test):
+the loss, every parameter gradient, and the parameters after the Adam step.  These are the kernels `secondary.train_step`
+times: cwn_layer_fused_f32 (STORE_Y), cwn_dense_stage_f32 / _bwd_f32 on the packed bf16-split blocks,
+cwn_layer_bwd_own_f32, the merged cwn_gemm_tn_f32 launches, cwn_head_f32 / _bwd_f32, cwn_adam_f32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cwn_oracle as O
+from tests._product import gate, to_double
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+
+
+def _oracle_cx(b):
+    cpu = lambda t: None if t is None else t.detach().cpu()
+    return {'dimension': b.dimension, 'y': None, 'num_complexes': b.num_complexes, 'cochains': [
+        {k: cpu(b.cochains[d][k]) for k in ('x', 'upper_index', 'lower_index', 'shared_boundaries',
+                                            'shared_coboundaries', 'boundary_index', 'y', 'batch')}
+        for d in range(b.dimension + 1)]}
+
+
+@pytest.mark.parametrize('cfg', ['zinc128', 'molhiv512'])
+def test_training_step_at_the_timed_size_vs_float64_oracle(cfg):
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import EmbedSparseCIN, OGBEmbedSparseCIN
+    from cwn_amd.synthetic import molhiv_like_complexes, zinc_like_complexes
+    from cwn_amd.train import TrainStep
+    torch.manual_seed(0)
+    if cfg == 'zinc128':          # bench.py's model, exp/scripts/cwn-zinc.sh:14-30
+        L = 4
+        model = EmbedSparseCIN(28, 4, 1, L, 128, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu', readout='sum',
+                               train_eps=False, final_hidden_multiplier=2, final_readout='sum', init_reduce='sum', embed_edge=True,
+                               use_coboundaries=True, graph_norm='bn')
+        b = ComplexBatch.from_complex_list(zinc_like_complexes(128, 41, 6), max_dim=2)
+        okw = dict(embed='zinc')
+    else:                         # exp/scripts/cwn-molhiv.sh:9-32 at BASELINE's batch of 512
+        L = 2
+        model = OGBEmbedSparseCIN(1, L, 64, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum', init_reduce='sum',
+                                  embed_edge=True, use_coboundaries=True, graph_norm='bn')
+        b = ComplexBatch.from_complex_list(molhiv_like_complexes(512, 43, 6), max_dim=2)
+        b.y = torch.randn(512, 1, generator=torch.Generator().manual_seed(1))
+        okw = dict(embed='ogb', readout='mean')
+    model = model.to(DEV).train()
+    b = b.to(DEV)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    # ---- the oracle in float64: forward in training mode, L1 loss, autograd
+    ocx = _oracle_cx(b)
+    leaves = {k: v.double().requires_grad_(True) for k, v in state.items() if v.is_floating_point() and 'running' not in k}
+    ostate = dict(to_double(state))
+    ostate.update(leaves)
+    ref_out, _ = O.sparse_cin_model_forward(ostate, ocx, L, use_coboundaries=True, training=True, norm='bn', **okw)
+    y = b.y.detach().cpu().double().view(ref_out.shape)
+    ref_loss = (ref_out - y).abs().mean()
+    ref_loss.backward()
+    # ---- the product: ONE step of the captured training graph
+    lr = 1e-3
+    ts = TrainStep(model, [b], task_type='regression', lr=lr, use_graph=True)
+    p0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    loss = ts.step(0)
+    torch.cuda.synchronize()
+    gate(loss.detach().view(1), ref_loss.detach().view(1), f'{cfg}: training loss (BatchNorm batch statistics) vs float64 oracle')
+    worst, above, n_par = 0.0, [], 0
+    for name, p in model.named_parameters():
+        r = leaves[name].grad
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        n_par += 1
+        g, r = p.grad.detach().cpu().double(), r.double()
+        err = float((g - r).abs().max())
+        scale = max(1.0, float(r.abs().max()))
+        worst = max(worst, err / scale)
+        if err > 1e-5 * scale:
+            above.append((name, err, scale))
+    print(f'[gate] {cfg}: {n_par} parameter gradients of one training step vs float64 oracle autograd: worst max|delta| / max(1, |ref|_inf) '
+          f'= {worst:.3e}; above the 1e-5 bar: {len(above)} ' + ', '.join(f'{n} ({e:.2e} / {s:.3g})' for n, e, s in above[:8]))
+    # the bar: 1e-5 . max(1, |ref|_inf) as for the forward; what may sit above it is listed (a ReLU pre-activation within
+    # rounding distance of zero takes either side: one cell's contribution moves by its whole value)
+    assert worst <= 5e-5, worst
+    assert len(above) <= max(2, n_par // 20), above
+    # ---- the Adam step (torch.optim.Adam, first step: m = (1 - b1) g, v = (1 - b2) g^2) from the product's own gradient, in float64
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    worst_p = 0.0
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().cpu().double()
+        m, v = (1 - b1) * g, (1 - b2) * g * g
+        want = p0[name].cpu().double() - (lr / (1 - b1)) * (m / (v.sqrt() / np.sqrt(1 - b2) + eps))
+        worst_p = max(worst_p, float((p.detach().cpu().double() - want).abs().max()))
+    print(f'[gate] {cfg}: parameters after the Adam step vs float64 Adam on the same gradient: max|delta| = {worst_p:.3e} (lr {lr})')
+    assert worst_p <= 2e-3 * lr, worst_p
