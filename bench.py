@@ -120,7 +120,7 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
     from cwn_amd.static_batch import StaticBatch
     from cwn_amd.static_graph import StaticTrainStep
     NB = int(os.environ.get('CWN_BENCH_FRESH_BATCHES', '64'))
-    S = int(os.environ.get('CWN_BENCH_FRESH_STEPS_PER_GRAPH', '8'))
+    S = int(os.environ.get('CWN_BENCH_FRESH_SLOTS', '8'))
     EPOCHS = int(os.environ.get('CWN_BENCH_FRESH_EPOCHS', '6'))
     B = args.batch
     pool = [c for i in range(NB) for c in gen(9000 + 1000 * rank + i)]
@@ -134,38 +134,26 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
     def cells(bs):
         return float(sum(int(packed._meta[idx][:, 0:9:3].sum()) for idx in bs)) * L
 
-    sb = StaticBatch(packed, B)
+    sb = StaticBatch(packed, B, slots=S)
     sb.reserve_epoch(NB)
     model = model.eval()
-    inputs = [sb.bufs.get((d, 'x')) for d in range(3)]
-
-    def restore():
-        for d in range(3):
-            sb.batch.cochains[d]._x = inputs[d]
-
     g_ = torch.Generator().manual_seed(3)
     feats = [[torch.randn(sb.cap_cells[d], H, generator=g_).to(dev) for d in range(3)] for _ in range(L)]
 
-    def prop_step():
+    def prop_steps():
         sb.fill()
-        b = sb.batch
-        outs = None
-        with sb.dynamic():
-            for l, conv in enumerate(model.convs):
-                b.set_xs(feats[l])
-                _, outs = conv.propagate_all(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
-        restore()
-        return outs
+        keep = []
+        for slot in sb.slots:
+            b, outs = slot.batch, None
+            with slot.dynamic():
+                for l, conv in enumerate(model.convs):
+                    b.set_xs(feats[l])
+                    _, outs = conv.propagate_all(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+            slot.restore()
+            keep.append(outs)
+        return keep
 
-    def fwd_step():
-        sb.fill()
-        restore()
-        with sb.dynamic():
-            out = model(sb.batch)
-        restore()
-        return out
-
-    def graph_of(fn, steps):
+    def graph_of(fn):
         with torch.no_grad():
             sb.set_epoch(epoch(0))
             side = torch.cuda.Stream()
@@ -177,61 +165,79 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
-                keep = [fn() for _ in range(steps)]
+                keep = fn()
         return g, keep
 
-    def run_epochs(replay, steps_per_replay):
+    def run_epochs(replay):
         """EPOCHS epochs of NB fresh batches each (the per-epoch permutation upload is inside the timed region)"""
         total = 0.0
-        sb.set_epoch(epoch(1))
-        for _ in range(NB // steps_per_replay):
+        n_rep = sb.set_epoch(epoch(1))
+        for _ in range(n_rep):
             replay()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for e in range(EPOCHS):
             bs = epoch(2 + e)
-            sb.set_epoch(bs)
-            for _ in range(NB // steps_per_replay):
+            n_rep = sb.set_epoch(bs)
+            for _ in range(n_rep):
                 replay()
-            total += cells(bs[:NB // steps_per_replay * steps_per_replay])
+            total += cells(bs)
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
-        n_steps = EPOCHS * (NB // steps_per_replay) * steps_per_replay
-        return total / dt_, dt_ / n_steps * 1e3
+        return total / dt_, dt_ / (EPOCHS * NB) * 1e3
 
     out = {'distinct_batches_per_epoch': NB, 'epochs_timed': EPOCHS, 'batch': B, 'dataset_complexes': len(pool),
-           'capacities': {'cells': list(sb.cap_cells), 'complexes': B},
-           'host_work_per_step': 'one hipGraph replay per %d steps (propagate, forward) / per step (train); the epoch\'s '
-                                 'permutation is uploaded once per epoch, inside the timed region' % S,
+           'steps_per_replay': S, 'capacities': {'cells': list(sb.cap_cells), 'complexes': B},
+           'host_work_per_step': 'one hipGraph replay per %d steps (a StaticBatch of %d slots: the fill launches cut the tables, '
+                                 'arrays and item tables of %d batches at once); the epoch\'s permutation is uploaded once per '
+                                 'epoch, inside the timed region' % (S, S, S),
            'scope': 'device-side collate from the HBM-resident packed dataset + segment tables + item tables + the scope itself, '
                     'every step a batch of the shuffled epoch never seen before (PackedLoader, shuffle=True)'}
     all_fit = all(bool(sb.fits(epoch(e)).all()) for e in range(2 + EPOCHS))
-    # --- propagate scope
-    g, keep = graph_of(prop_step, S)
-    cps, ms = run_epochs(g.replay, S)
-    out['propagate'] = {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5),
-                        'vs_fixed_batch_replay': round(cps / fixed_cells_per_s, 4) if fixed_cells_per_s else None}
-    del g, keep
-    # --- full forward; the first batch of an epoch against the per-batch launches, bit for bit
-    g, keep = graph_of(fwd_step, S)
-    with torch.no_grad():
-        bs = epoch(1)
-        sb.set_epoch(bs)
-        g.replay()
-        same = all(bool(torch.equal(keep[j][:len(bs[j])], model(packed.collate(bs[j])))) for j in range(min(S, 3)))
-    cps, ms = run_epochs(g.replay, S)
-    out['forward'] = {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'bit_identical_to_per_batch_launches': same,
-                      'vs_fixed_batch_replay': round(fixed_forward_ms / ms, 4) if fixed_forward_ms else None}
-    del g, keep
-    # --- full training step
-    tmodel = copy.deepcopy(model).train()
-    sb.set_epoch(epoch(0))
-    ts = StaticTrainStep(tmodel, sb, task_type='regression')
-    ts.step()
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            out[name] = {'failed': f'{type(e).__name__}: {e}'}
+            torch.cuda.synchronize()
+
+    def leg_propagate():
+        g, keep = graph_of(prop_steps)
+        cps, ms = run_epochs(g.replay)
+        return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5),
+                'vs_fixed_batch_replay': round(cps / fixed_cells_per_s, 4) if fixed_cells_per_s else None}
+
+    def leg_forward():
+        from cwn_amd.static_graph import StaticForward
+        sf = StaticForward(model, sb)
+        with torch.no_grad():
+            bs = epoch(1)
+            sb.set_epoch(bs)
+            outs = sf.replay()
+            # the first batches of an epoch against the per-batch launches, bit for bit
+            same = all(bool(torch.equal(outs[j][:len(bs[j])], model(packed.collate(bs[j])))) for j in range(min(S, 3)))
+            cps, ms = run_epochs(sf.replay)
+        return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'bit_identical_to_per_batch_launches': same,
+                'vs_fixed_batch_replay': round(fixed_forward_ms / ms, 4) if fixed_forward_ms else None}
+
+    def leg_train():
+        tmodel = copy.deepcopy(model).train()
+        sb.set_epoch(epoch(0))
+        ts = StaticTrainStep(tmodel, sb, task_type='regression')
+        ts.step()
+        cps, ms = run_epochs(ts.step)
+        sb.set_epoch(epoch(1))
+        finite = all(bool(torch.isfinite(l).item()) for l in ts.step())
+        return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'loss_finite': finite,
+                'vs_fixed_batch_replay': round(fixed_train_ms / ms, 4) if fixed_train_ms else None}
+
+    leg('propagate', leg_propagate)
+    leg('forward', leg_forward)
+    leg('train', leg_train)
     all_fit = all_fit and all(bool(sb.fits(epoch(e)).all()) for e in range(2 + EPOCHS))      # (now incl. the backward table)
-    cps, ms = run_epochs(ts.step, 1)
-    out['train'] = {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'loss_finite': bool(torch.isfinite(ts.step()).item()),
-                    'vs_fixed_batch_replay': round(fixed_train_ms / ms, 4) if fixed_train_ms else None}
     out['every_batch_within_capacity'] = all_fit
     try:
         csr.check_errors(dev)

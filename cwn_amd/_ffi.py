@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 17
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_slots', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
            'cwn_bn_finalize_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
@@ -104,7 +104,8 @@ class LayerSizes(C.Structure):
 class LayerSizesDev(C.Structure):
     """cwn_layer_sizes_dev (include/cwn_hip.h): the prefix sums of a batch as DEVICE arrays."""
     _fields_ = [('n_complexes', C.c_void_p), ('cap_complexes', C.c_int64), ('n_dims', C.c_int32), ('has_up', C.c_int32 * 3),
-                ('cell_ptr', C.c_void_p * 3), ('up_ptr', C.c_void_p * 3), ('b_ptr', C.c_void_p * 3)]
+                ('cell_ptr', C.c_void_p * 3), ('up_ptr', C.c_void_p * 3), ('b_ptr', C.c_void_p * 3),
+                ('n_slots', C.c_int32), ('pad_', C.c_int32), ('table_slot_stride', C.c_int64)]
 
 
 ERR_BIT_UNFIT = 16        # = CWN_ERR_BIT_UNFIT
@@ -294,8 +295,11 @@ def lib():
     L.cwn_collate_tables_len.restype = C.c_size_t
     L.cwn_collate_tables_len.argtypes = [C.c_int32, C.c_int32, C.c_int64]
     L.cwn_collate_tables.restype = C.c_int
-    L.cwn_collate_tables.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_void_p]
+    L.cwn_collate_tables.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                     C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cwn_collate_slots.restype = C.c_int
+    L.cwn_collate_slots.argtypes = [C.POINTER(CollateDesc), C.c_int, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.c_void_p,
+                                    C.c_void_p]
     L.cwn_layer_items_build_dev.restype = C.c_int
     L.cwn_layer_items_build_dev.argtypes = [C.POINTER(LayerSizesDev), C.c_int32, C.POINTER(LayerPlan), C.c_int32, C.c_void_p, C.c_void_p]
     L.cwn_layer_bwd_items_build_dev.restype = C.c_int
@@ -314,7 +318,7 @@ def lib():
     L.cwn_gemm_tn_workspace_bytes.argtypes = [C.POINTER(GemmTnDesc), C.c_int]
     L.cwn_adam_f32.restype = C.c_int
     L.cwn_adam_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
-                               C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+                               C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cwn_loss_f32.restype = C.c_int
     L.cwn_loss_f32.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cwn_embedding_fwd_f32.restype = C.c_int

@@ -14,33 +14,41 @@ constexpr int kThreads = 64;
 
 struct CollateBatch {
     cwn_collate_desc d[CWN_MAX_COLLATE_DESCS];
+    int64_t dst_slot_bytes[CWN_MAX_COLLATE_DESCS];   // cwn_collate_slots: bytes between the output arrays of consecutive slots
+    int64_t table_slot_stride;                       // ... and int64 elements between their tables
+    int64_t* cursor;                                 // or NULL: advanced by the number of slots (one thread of the launch)
     int32_t n;
 };
 
 __global__ __launch_bounds__(kThreads) void collate_kernel(CollateBatch B, int64_t n_seg) {
     const int di = blockIdx.y;
     const int64_t s = blockIdx.x;
+    const int64_t slot = blockIdx.z;
+    if (B.cursor != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        *B.cursor += (int64_t)gridDim.z;             // (the tables of this launch were cut by an EARLIER launch: no reader left)
     const cwn_collate_desc& D = B.d[di];
-    const int64_t d0 = D.dst_start[s], len = D.dst_start[s + 1] - d0;
+    const int64_t tab_off = slot * B.table_slot_stride;
+    const int64_t d0 = D.dst_start[tab_off + s], len = D.dst_start[tab_off + s + 1] - d0;
     if (len <= 0) return;
-    const int64_t s0 = D.op == CWN_COLLATE_SEGID64 ? 0 : D.src_start[s];
+    const int64_t s0 = D.op == CWN_COLLATE_SEGID64 ? 0 : D.src_start[tab_off + s];
+    char* const dst_base = (char*)D.dst + slot * B.dst_slot_bytes[di];
     for (int r = 0; r < D.n_rows; ++r) {
-        const int64_t add = D.add != nullptr ? D.add[(int64_t)r * n_seg + s] : 0;
+        const int64_t add = D.add != nullptr ? D.add[tab_off + (int64_t)r * n_seg + s] : 0;
         if (D.op == CWN_COLLATE_COPY32) {
             const int32_t* src = (const int32_t*)D.src + r * D.src_row_stride + s0;
-            int32_t* dst = (int32_t*)D.dst + r * D.dst_row_stride + d0;
+            int32_t* dst = (int32_t*)dst_base + r * D.dst_row_stride + d0;
             for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = src[q];
         } else if (D.op == CWN_COLLATE_ADD32) {
             const int32_t* src = (const int32_t*)D.src + r * D.src_row_stride + s0;
-            int32_t* dst = (int32_t*)D.dst + r * D.dst_row_stride + d0;
+            int32_t* dst = (int32_t*)dst_base + r * D.dst_row_stride + d0;
             const int32_t a = (int32_t)add;
             for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = src[q] + a;
         } else if (D.op == CWN_COLLATE_SEGID64) {
-            int64_t* dst = (int64_t*)D.dst + r * D.dst_row_stride + d0;
+            int64_t* dst = (int64_t*)dst_base + r * D.dst_row_stride + d0;
             for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = s;
         } else {
             const int64_t* src = (const int64_t*)D.src + r * D.src_row_stride + s0;
-            int64_t* dst = (int64_t*)D.dst + r * D.dst_row_stride + d0;
+            int64_t* dst = (int64_t*)dst_base + r * D.dst_row_stride + d0;
             const int64_t a = D.op == CWN_COLLATE_ADD64 ? add : 0;
             for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = src[q] + a;
         }
@@ -56,19 +64,21 @@ __global__ __launch_bounds__(kThreads) void collate_kernel(CollateBatch B, int64
 constexpr int kTabThreads = 1024;
 
 __global__ __launch_bounds__(kTabThreads) void collate_tables_kernel(const int64_t* __restrict__ meta, int64_t num, int D, int K,
-                                                                     const int64_t* __restrict__ idx_all, int64_t B,
-                                                                     int64_t* __restrict__ cursor, int64_t* __restrict__ tab,
-                                                                     int32_t* __restrict__ err) {
+                                                                     const int64_t* __restrict__ idx_all, int64_t B, int64_t n_batches,
+                                                                     const int64_t* __restrict__ cursor, int64_t slot_stride,
+                                                                     int64_t* __restrict__ tab_all, int32_t* __restrict__ err) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int W = 3 * D + 3 * K, ncol = 3 * D + K;
-    int64_t cur = 0;
-    if (cursor != nullptr) cur = *cursor;
-    __syncthreads();                                    // every thread has read the cursor before it moves
-    if (cursor != nullptr && threadIdx.x == 0) *cursor = cur + 1;
-    const int64_t* idx = idx_all + cur * B;
+    // workgroup j of the launch cuts the tables of slot j = batch (*cursor + j) of the buffer; past the buffer: an empty batch
+    // (and the sticky bit: a replay too many)
+    const int64_t cur = (cursor != nullptr ? *cursor : 0) + (int64_t)blockIdx.x;
+    const bool past = cur < 0 || cur >= n_batches;
+    const int64_t* idx = idx_all + (past ? 0 : cur) * B;
+    int64_t* const tab = tab_all + (int64_t)blockIdx.x * slot_stride;
+    if (past) num = 0;                                  // every entry counts as absent ...
     const int64_t o_src = (int64_t)K * (B + 1), o_off = o_src + (int64_t)K * B, o_seg = o_off + (int64_t)D * 5 * B;
     const int64_t o_sizes = o_seg + (int64_t)D * (B + 1);
-    bool bad = false;
+    bool bad = past;                                    // ... and is reported
     for (int col = wave; col < ncol; col += kTabThreads / 64) {
         int64_t carry = 0;
         const bool is_key = col >= 3 * D;
@@ -76,7 +86,7 @@ __global__ __launch_bounds__(kTabThreads) void collate_tables_kernel(const int64
         for (int64_t s0 = 0; s0 < B; s0 += 64) {
             const int64_t s = s0 + lane;
             int64_t c = s < B ? idx[s] : -1;
-            if (c >= num) { bad = true; c = -1; }
+            if (c >= num) { bad = bad || num > 0; c = -1; }
             const int64_t v = c >= 0 ? meta[c * W + col] : 0;
             const int64_t start = (is_key && c >= 0) ? meta[c * W + col + K] : 0;
             int64_t x = v;
@@ -138,20 +148,33 @@ extern "C" size_t cwn_collate_tables_len(int32_t D, int32_t K, int64_t B) {
 }
 
 extern "C" int cwn_collate_tables(const int64_t* meta, int64_t num, int32_t D, int32_t K, const int64_t* idx, int64_t B,
-                                  int64_t* cursor, int64_t* tables, int32_t* err_flag, cwn_stream_t stream_) {
-    if (meta == nullptr || idx == nullptr || tables == nullptr || err_flag == nullptr || num < 0 || D < 1 || D > 8 || K < 0 || B < 1)
+                                  int64_t n_batches, const int64_t* cursor, int32_t n_slots, int64_t slot_stride, int64_t* tables,
+                                  int32_t* err_flag, cwn_stream_t stream_) {
+    if (meta == nullptr || idx == nullptr || tables == nullptr || err_flag == nullptr || num < 0 || D < 1 || D > 8 || K < 0 || B < 1 ||
+        n_batches < 1 || n_slots < 1 || n_slots > 1024)
         return CWN_ERR_BAD_ARG;
+    if (n_slots > 1 && slot_stride < (int64_t)cwn_collate_tables_len(D, K, B)) return CWN_ERR_BAD_ARG;
     if (B >= INT32_MAX) return CWN_ERR_TOO_LARGE;
-    collate_tables_kernel<<<dim3(1), dim3(kTabThreads), 0, (hipStream_t)stream_>>>(meta, num, D, K, idx, B, cursor, tables, err_flag);
+    collate_tables_kernel<<<dim3(n_slots), dim3(kTabThreads), 0, (hipStream_t)stream_>>>(meta, num, D, K, idx, B, n_batches, cursor,
+                                                                                        slot_stride, tables, err_flag);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
 extern "C" int cwn_collate(const cwn_collate_desc* descs, int n, int64_t n_seg, cwn_stream_t stream_) {
-    if (descs == nullptr || n <= 0 || n > CWN_MAX_COLLATE_DESCS || n_seg < 0) return CWN_ERR_BAD_ARG;
+    return cwn_collate_slots(descs, n, n_seg, 1, 0, nullptr, nullptr, stream_);
+}
+
+extern "C" int cwn_collate_slots(const cwn_collate_desc* descs, int n, int64_t n_seg, int32_t n_slots, int64_t table_slot_stride,
+                                 const int64_t* dst_slot_bytes, int64_t* cursor, cwn_stream_t stream_) {
+    if (descs == nullptr || n <= 0 || n > CWN_MAX_COLLATE_DESCS || n_seg < 0 || n_slots < 1 || n_slots > 1024) return CWN_ERR_BAD_ARG;
+    if (n_slots > 1 && (dst_slot_bytes == nullptr || table_slot_stride <= 0)) return CWN_ERR_BAD_ARG;
     if (n_seg == 0) return CWN_OK;
     if (n_seg >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     CollateBatch B{};
     B.n = n;
+    B.table_slot_stride = n_slots > 1 ? table_slot_stride : 0;
+    B.cursor = cursor;
+    for (int i = 0; i < n; ++i) B.dst_slot_bytes[i] = (n_slots > 1 && dst_slot_bytes != nullptr) ? dst_slot_bytes[i] : 0;
     for (int i = 0; i < n; ++i) {
         const cwn_collate_desc& D = descs[i];
         if (D.dst == nullptr || D.dst_start == nullptr || D.n_rows < 1 || D.n_rows > 2) return CWN_ERR_BAD_ARG;
@@ -160,6 +183,6 @@ extern "C" int cwn_collate(const cwn_collate_desc* descs, int n, int64_t n_seg, 
         if ((D.op == CWN_COLLATE_ADD64 || D.op == CWN_COLLATE_ADD32) && D.add == nullptr) return CWN_ERR_BAD_ARG;
         B.d[i] = D;
     }
-    collate_kernel<<<dim3((unsigned)n_seg, (unsigned)n), dim3(kThreads), 0, (hipStream_t)stream_>>>(B, n_seg);
+    collate_kernel<<<dim3((unsigned)n_seg, (unsigned)n, (unsigned)n_slots), dim3(kThreads), 0, (hipStream_t)stream_>>>(B, n_seg);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

@@ -44,7 +44,22 @@ struct ItemsArgs {
     int32_t has_up[CWN_LAYER_MAX_DIMS];
     int64_t row_cap, src_cap, lds_budget, half_cap, idx_bytes;
     int64_t bwd_lds;                 // backward table: the launch's dynamic LDS
+    int64_t table_slot_stride;       // slots (blockIdx.y): int64 elements between the tables of consecutive slots ...
+    int64_t items_slot_ints;         // ... and int32 elements between their item tables
 };
+
+// the arguments as slot `slot` sees them
+__device__ __forceinline__ void to_slot(ItemsArgs& A, int slot) {
+    const int64_t o = (int64_t)slot * A.table_slot_stride;
+    A.n_complexes += o;
+#pragma unroll
+    for (int d = 0; d < CWN_LAYER_MAX_DIMS; ++d) {
+        A.cell_ptr[d] += o;
+        if (A.up_ptr[d] != nullptr) A.up_ptr[d] += o;
+        if (A.b_ptr[d] != nullptr) A.b_ptr[d] += o;
+    }
+    A.items += (int64_t)slot * A.items_slot_ints;
+}
 
 // workgroup-wide exclusive scan of one small integer per thread; returns the thread's offset, *total = the sum
 __device__ __forceinline__ int block_scan(int v, int* total, int* lds /* [2 * 16] */) {
@@ -162,8 +177,10 @@ struct FwdGeom {
     }
 };
 
-__global__ __launch_bounds__(kThreads) void items_fwd_kernel(ItemsArgs A) {
+__global__ __launch_bounds__(kThreads) void items_fwd_kernel(ItemsArgs A_) {
     __shared__ int scan_lds[32];
+    ItemsArgs A = A_;
+    to_slot(A, blockIdx.y);
     const int set = blockIdx.x;
     const DevSet S = A.sets[set];
     const FwdGeom G{A, S};
@@ -282,8 +299,10 @@ struct BwdGeom {
     }
 };
 
-__global__ __launch_bounds__(kThreads) void items_bwd_kernel(ItemsArgs A) {
+__global__ __launch_bounds__(kThreads) void items_bwd_kernel(ItemsArgs A_) {
     __shared__ int scan_lds[32];
+    ItemsArgs A = A_;
+    to_slot(A, blockIdx.y);
     const int set = blockIdx.x;
     const DevSet S = A.sets[set];
     const int d = S.tasks[0];
@@ -383,6 +402,8 @@ int fill_common(const cwn_layer_sizes_dev* in, int32_t F, int32_t group, int32_t
     A.group = group;
     A.err = err_flag;
     A.n_sets = make_sets(*in, A.sets);
+    if (in->n_slots < 1 || in->n_slots > 1024 || (in->n_slots > 1 && in->table_slot_stride <= 0)) return CWN_ERR_BAD_ARG;
+    A.table_slot_stride = in->n_slots > 1 ? in->table_slot_stride : 0;
     return CWN_OK;
 }
 
@@ -418,7 +439,8 @@ extern "C" int cwn_layer_items_build_dev(const cwn_layer_sizes_dev* in, int32_t 
         if ((s == 0 && v != 0) || v < lo || v > plan->n_items || v >= INT32_MAX) return CWN_ERR_BAD_ARG;
         A.set_start[s] = (int32_t)v;
     }
-    items_fwd_kernel<<<dim3(A.n_sets), dim3(kThreads), 0, (hipStream_t)stream_>>>(A);
+    A.items_slot_ints = plan->n_items * kInts;
+    items_fwd_kernel<<<dim3(A.n_sets, in->n_slots), dim3(kThreads), 0, (hipStream_t)stream_>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
@@ -433,6 +455,7 @@ extern "C" int cwn_layer_bwd_items_build_dev(const cwn_layer_sizes_dev* in, int3
     A.items = const_cast<int32_t*>(plan->items);
     A.bwd_lds = plan->lds_bytes;
     for (int s = 0; s <= A.n_sets; ++s) A.set_start[s] = (int32_t)(s * in->cap_complexes);
-    items_bwd_kernel<<<dim3(A.n_sets), dim3(kThreads), 0, (hipStream_t)stream_>>>(A);
+    A.items_slot_ints = plan->n_items * kBInts;
+    items_bwd_kernel<<<dim3(A.n_sets, in->n_slots), dim3(kThreads), 0, (hipStream_t)stream_>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

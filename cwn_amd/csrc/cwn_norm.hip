@@ -463,7 +463,8 @@ namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float lr, float b1, float b2, float eps, float wd,
-                                                   const int32_t* __restrict__ step) {
+                                                   const int32_t* __restrict__ step, const int64_t* __restrict__ active) {
+    if (active != nullptr && *active <= 0) return;       // (uniform) an empty batch of a static epoch: the step changes nothing
     const float t = (float)*step;
     const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
     const float step_size = lr / bc1;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }  // namespace
 
 extern "C" int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                            float beta2, float eps, float weight_decay, const int32_t* step,
+                            float beta2, float eps, float weight_decay, const int32_t* step, const int64_t* active,
                             cwn_stream_t stream_) {
     if (n < 0) return CWN_ERR_BAD_ARG;
     if (n == 0) return CWN_OK;
@@ -516,7 +517,7 @@ extern "C" int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_
     const int64_t threads = (n + 3) / 4, blocks = (threads + 255) / 256;
     if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(p, g, m, v, n, lr, beta1, beta2,
-                                                                                 eps, weight_decay, step);
+                                                                                 eps, weight_decay, step, active);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 

@@ -36,6 +36,14 @@ _TWO_ROW = ('upper_index', 'lower_index', 'boundary_index')
 _ADD_ROW = dict(PackedComplexes._ADD_ROW, b_col=2, bt_col=0)
 
 
+class _NoArray:
+    """Stands where a CSR array of an upper adjacency would be: present (the layer code only asks `is None`), unusable."""
+
+    def __getattr__(self, name):
+        raise _ffi.CwnError('a static batch has no CSR of its upper adjacencies: the complex-blocked launches are the only path '
+                            '(cwn_amd/static_batch.py); use PackedComplexes.collate for this model / configuration')
+
+
 class _PlanOnlyAdjacency:
     """What the layer code receives for an UPPER adjacency of a static batch: sizes only.  The blocked launches read the
     int64 index tensors through the item tables; a code path that wants this adjacency's CSR (the streaming backward, a
@@ -59,7 +67,7 @@ class _PlanOnlyAdjacency:
     rowptr = property(lambda self: self._no('rowptr'))
     col = property(lambda self: self._no('col'))
     perm = property(lambda self: self._no('perm'))
-    aux = property(lambda self: self._no('aux'))
+    aux = _NoArray()                  # (`Stream.validate` asks whether the plan was built with a shared-cell index: it was)
     t_src = property(lambda self: self._no('t_src'))
     t_aux = property(lambda self: self._no('t_aux'))
 
@@ -88,44 +96,34 @@ class _CollatedAdjacency(csr.Adjacency):
 
 
 class StaticBlockPlan:
-    """The BlockPlan (cwn_amd/blockplan.py) of a static batch: item tables in fixed device buffers, rebuilt by the device
-    builders after every fill.  Duck-types what the layer / model code asks a BlockPlan."""
+    """The BlockPlan (cwn_amd/blockplan.py) of one slot of a static batch: item tables in fixed device buffers, rebuilt by the
+    device builders after every fill.  Duck-types what the layer / model code asks a BlockPlan."""
 
-    def __init__(self, owner: 'StaticBatch', variant: int, group: int):
-        self.owner = owner
+    def __init__(self, owner: 'StaticBatch', slot: int):
+        self.owner, self.slot = owner, int(slot)
         self.n_dims = owner.D
         self.C = owner.B
         self.device = owner.device
-        self.variant, self.group = int(variant), int(group)
+        self.variant, self.group = owner.variant, owner.group
         self.cell_ptr = [np.array([0, owner.cap_cells[d]], dtype=np.int64) for d in range(owner.D)]
         self.up_ptr = [(np.array([0, owner.cap_key(d, 'upper_index')]) if owner.k_of(d, 'upper_index') >= 0 else None)
                        for d in range(owner.D)]
         self.b_ptr = [(np.array([0, owner.cap_key(d, 'boundary_index')]) if owner.k_of(d, 'boundary_index') >= 0 else None)
                       for d in range(owner.D)]
-        self._tables: Dict = {}
-        self.validated = False
+        self.validated = True           # (index VALUES are checked by every blocked launch; the sticky word is read by the caller)
 
     # ---- what the model code asks -------------------------------------------------------------------------------
     def cell_ptr_device(self, d: int, device) -> torch.Tensor:
-        return self.owner.seg_view(d)
+        return self.owner.seg_view(d, self.slot)
 
     def forget_csr(self) -> None:
-        for t in self._tables.values():
-            if t is not None and hasattr(t, 'csr_key'):
+        for fam in self.owner._families.values():
+            t = fam[self.slot]
+            if hasattr(t, 'csr_key'):
                 t.csr_key = None
 
-    def _n_sets(self, has_up) -> int:
-        n, d = 0, 0
-        while d < self.n_dims:
-            step = 1
-            if has_up[d] and d + 1 < self.n_dims and not has_up[d + 1] and d + 2 >= self.n_dims:
-                step = 2
-            n += 1
-            d += step
-        return n
-
     def at_least(self, F: int, has_up, has_b=None) -> int:
-        return self._n_sets(has_up) * -(-self.C // self.group)
+        return self.owner._n_sets(has_up) * -(-self.C // self.group)
 
     def items_mixed(self, F, has_up, has_b=None):
         return None
@@ -141,132 +139,17 @@ class StaticBlockPlan:
             return None                        # no BIG records
         # (one form per static batch, chosen when it was built: whatever form the caller's heuristics ask for gets this table)
         hu, hb = self._norm_key(has_up, has_b)
-        key = ('fwd', int(F), hu, hb)
-        t = self._tables.get(key)
-        if t is None:
-            t = self._tables[key] = self._make_fwd(int(F), hu, hb)
-        if t is not None and t.filled != self.owner.fill_id:
-            self._launch_fwd(t)
-        return t
+        fam = self.owner.family('fwd', int(F), hu, hb)
+        return None if fam is None else fam[self.slot]
 
     def bwd_items(self, F: int, has_up, has_b=None) -> Optional[BwdItemTable]:
         hu, hb = self._norm_key(has_up, has_b)
-        key = ('bwd', int(F), hu, hb)
-        t = self._tables.get(key)
-        if t is None:
-            t = self._tables[key] = self._make_bwd(int(F), hu, hb)
-        if t is not None and t.filled != self.owner.fill_id:
-            self._launch_bwd(t)
-        return t
-
-    def refill(self) -> None:
-        """The item tables cut so far, for the batch the buffers now hold (StaticBatch.fill calls this: the layers keep
-        prepared launches per plan and do not ask again)."""
-        for key, t in self._tables.items():
-            if t is None:
-                continue
-            if key[0] == 'fwd':
-                self._launch_fwd(t)
-            else:
-                self._launch_bwd(t)
-
-    def fit_mask(self) -> np.ndarray:
-        """bool per complex of the dataset: every table cut so far takes it as one item (numpy restatement of the device
-        builders' test: blockplan.single_fit_forward / _backward)."""
-        from .blockplan import single_fit_backward, single_fit_forward
-        o = self.owner
-        meta, D = o.packed._meta, o.D
-        cells = [meta[:, 3 * d] for d in range(D)]
-        col = lambda d, key: (meta[:, 3 * D + o.k_of(d, key)] if o.k_of(d, key) >= 0 else None)
-        up_len = [col(d, 'upper_index') for d in range(D)]
-        b_len = [col(d, 'boundary_index') for d in range(D)]
-        ok = np.ones(meta.shape[0], dtype=bool)
-        for key, t in self._tables.items():
-            if t is None:
-                continue
-            _, F, hu, hb = key
-            if key[0] == 'fwd':
-                ok &= single_fit_forward(cells, up_len, b_len, F, hu, hb, self.variant, t.max_rows, t.max_src)
-            else:
-                ok &= single_fit_backward(cells, up_len, b_len, F, hu, hb)
-        return ok
-
-    # ---- tables ---------------------------------------------------------------------------------------------------
-    def _sizes_dev(self, has_up, has_b) -> _ffi.LayerSizesDev:
-        o = self.owner
-        s = _ffi.LayerSizesDev(n_complexes=o.size_ptr(3), cap_complexes=o.B, n_dims=o.D)
-        for d in range(o.D):
-            s.has_up[d] = 1 if has_up[d] else 0
-            s.cell_ptr[d] = o.seg_view(d).data_ptr()
-            k = o.k_of(d, 'upper_index')
-            if k >= 0:
-                s.up_ptr[d] = o.dst_view(k).data_ptr()
-            k = o.k_of(d, 'boundary_index')
-            if k >= 0 and has_b[d]:
-                s.b_ptr[d] = o.dst_view(k).data_ptr()
-        return s
-
-    def _make_fwd(self, F: int, has_up, has_b) -> Optional[ItemTable]:
-        o = self.owner
-        if F not in (64, 128) or any(has_up[d] and (d + 1 >= o.D or o.k_of(d, 'upper_index') < 0) for d in range(o.D)):
-            return None
-        L = _ffi.lib()
-        n_sets = self._n_sets(has_up)
-        n_items = n_sets * o.B                                   # a region of B records per set always suffices
-        set_start = [s * o.B for s in range(n_sets)]
-        if self.variant == 0:
-            # one launch = one LDS layout: the full row cap, the boundary sources take what is left of the 160 KiB
-            cap = gemm_rows_cap(F)
-            src_cap = min(cap, (LDS_BYTES - lds_bytes(F, cap, 0)) // (F * 4))
-            if src_cap < 16 or L.cwn_layer_fused_lds_bytes(F, cap, src_cap) == 0:
-                return None
-            dyn_lds = 0
-        else:
-            cap = 128 if F == 64 else 80                         # = CWN_LAYER_W8_GEMM_ROWS / _SOURCE_ROWS / _LDS_BYTES
-            src_cap = 128 if F == 64 else 48
-            dyn_lds = 80 * 1024
-        cap_up = [o.cap_key(d, 'upper_index') if has_up[d] else 0 for d in range(o.D)]
-        cap_b = [o.cap_key(d, 'boundary_index') if (d > 0 and has_b[d]) else 0 for d in range(o.D)]
-        t = ItemTable(np.zeros((n_items, ITEM_INTS), dtype=np.int32), set_start, cap, src_cap, list(o.cap_cells), cap_up, cap_b,
-                      o.device, variant=self.variant, lds_bytes=dyn_lds)
-        t.filled = -1
-        t.sizes = self._sizes_dev(has_up, has_b)
-        t.F = F
-        return t
-
-    def _launch_fwd(self, t: ItemTable) -> None:
-        plan = t.c_plan(with_cache=False)
-        _ffi.check(_ffi.lib().cwn_layer_items_build_dev(t.sizes, t.F, plan, self.group, csr._err_flag(self.device).data_ptr(),
-                                                        _ffi.stream_ptr(self.device)), 'cwn_layer_items_build_dev')
-        t.filled = self.owner.fill_id
-        t.csr_key = None                     # (the per-item CSR cache belongs to the previous batch's entries)
-
-    def _make_bwd(self, F: int, has_up, has_b) -> Optional[BwdItemTable]:
-        o = self.owner
-        if F not in (64, 128):
-            return None
-        if not all(not has_b[d] or (d + 1 <= o.D and o.k_of(d, 'boundary_index') >= 0) for d in range(o.D)):
-            return None
-        n_sets = self._n_sets(has_up)
-        n_items = n_sets * o.B
-        cap_up = [o.cap_key(d, 'upper_index') if has_up[d] else 0 for d in range(o.D)]
-        cap_b = [o.cap_key(d, 'boundary_index') if (d > 0 and has_b[d]) else 0 for d in range(o.D)]
-        t = BwdItemTable(np.zeros((n_items, _ffi.LAYER_BWD_ITEM_INTS), dtype=np.int32), LDS_BYTES, list(o.cap_cells), cap_up, cap_b,
-                         o.device)
-        t.filled = -1
-        t.sizes = self._sizes_dev(has_up, has_b)
-        t.F = F
-        return t
-
-    def _launch_bwd(self, t: BwdItemTable) -> None:
-        plan = t.c_plan()
-        _ffi.check(_ffi.lib().cwn_layer_bwd_items_build_dev(t.sizes, t.F, plan, self.group, csr._err_flag(self.device).data_ptr(),
-                                                            _ffi.stream_ptr(self.device)), 'cwn_layer_bwd_items_build_dev')
-        t.filled = self.owner.fill_id
+        fam = self.owner.family('bwd', int(F), hu, hb)
+        return None if fam is None else fam[self.slot]
 
 
 class StaticComplexBatch(ComplexBatch):
-    """The ComplexBatch over a StaticBatch's buffers: its plans are not built per batch (the collate launch writes them)."""
+    """The ComplexBatch over one slot of a StaticBatch: its plans are not built per batch (the collate launch writes them)."""
 
     def prepare(self, *args, **kwargs):
         return self
@@ -275,25 +158,61 @@ class StaticComplexBatch(ComplexBatch):
         return self
 
 
+class StaticSlot:
+    """One batch of a StaticBatch: the ComplexBatch the model code runs on, its plan, its views of the buffers."""
+
+    def __init__(self, owner: 'StaticBatch', j: int, batch: StaticComplexBatch, bufs: Dict, plan: StaticBlockPlan):
+        self.owner, self.j, self.batch, self.bufs, self.plan = owner, j, batch, bufs, plan
+        self.inputs = [bufs.get((d, 'x')) for d in range(owner.D)]
+
+    def restore(self) -> None:
+        """The raw input features back into the container (the models overwrite them layer by layer: set_xs)."""
+        for d in range(self.owner.D):
+            self.batch.cochains[d]._x = self.inputs[d]
+
+    def size_ptr(self, k: int) -> int:
+        return self.owner.size_ptr(k, self.j)
+
+    def sizes(self) -> List[int]:
+        """[cells of dims 0..2, complexes] of the batch in this slot (host sync: tests, diagnostics)."""
+        o = self.owner
+        return o.tables[self.j, o.o_sizes: o.o_sizes + 4].tolist()
+
+    def dynamic(self) -> _ffi.dynamic_rows:
+        """Context manager: inside, every launch whose row count is one of the capacities reads this slot's actual count
+        from its tables (the three cell counts are consecutive int64: cwn_embed_front_f32's n_dev)."""
+        o = self.owner
+        m = {o.cap_cells[d]: self.size_ptr(d) for d in range(min(o.D, 3))}
+        m[o.B] = self.size_ptr(3)
+        return _ffi.dynamic_rows(m)
+
+
 class StaticBatch:
-    """Capacity-sized device buffers for batches of `batch_size` complexes of `packed` (a PackedComplexes built with
-    with_csr=True), and the two launches that fill them (`fill`).
+    """Capacity-sized device buffers for `slots` batches of `batch_size` complexes of `packed` (a PackedComplexes built with
+    with_csr=True), and the launches that fill them (`fill`): the batch's tables, its arrays, its item tables -- for ALL
+    slots at once, so that a graph holding S steps pays for three small launches per S steps, not per step.
 
     caps: {'cells': [per dimension], (d, key): elements} overrides; by default every capacity is what a batch of the
     dataset's sizes needs with a wide margin (mean x B + 6 sigma sqrt(B), at most the sum of the B largest), and
-    `fits(idx)` tells the caller which batches the buffers hold."""
+    `fits(batches)` tells the caller which batches the buffers hold."""
 
     def __init__(self, packed: PackedComplexes, batch_size: int, caps: Optional[dict] = None, variant: int = 0,
-                 group: Optional[int] = None, indices: Optional[Sequence[int]] = None):
+                 group: Optional[int] = None, indices: Optional[Sequence[int]] = None, slots: int = 1):
         if not packed.with_csr:
             raise ValueError('StaticBatch needs a PackedComplexes built with with_csr=True')
         if packed.device.type != 'cuda':
             raise _ffi.CwnError('StaticBatch needs the packed dataset on the GPU')
-        self.packed, self.B = packed, int(batch_size)
+        if variant not in (0, 1):
+            raise ValueError('variant 0 (one 16-wave workgroup per CU) or 1 (the two-per-CU form)')
+        self.packed, self.B, self.S = packed, int(batch_size), int(slots)
+        if self.S < 1 or self.S > 64:
+            raise ValueError('1 .. 64 slots')
         self.device = packed.device
         self.D = packed.max_dim + 1
         self.K = len(packed._klist)
-        B, D, K = self.B, self.D, self.K
+        self.variant = int(variant)
+        self.group = int(group) if group is not None else max(1, self.B // (256 if variant == 1 else 128))
+        B, D, K, S = self.B, self.D, self.K, self.S
         dev = self.device
         meta = packed._meta if indices is None else packed._meta[np.asarray(indices, dtype=np.int64)]
         # ---- capacities ---------------------------------------------------------------------------------------------
@@ -332,56 +251,76 @@ class StaticBatch:
         # ---- tables -------------------------------------------------------------------------------------------------
         L = _ffi.lib()
         self.n_tab = int(L.cwn_collate_tables_len(D, K, B))
-        self.tables = torch.zeros(self.n_tab, dtype=torch.int64, device=dev)
+        self.tables = torch.zeros(S, self.n_tab, dtype=torch.int64, device=dev)
         self.o_src = K * (B + 1)
         self.o_off = self.o_src + K * B
         self.o_seg = self.o_off + D * 5 * B
         self.o_sizes = self.o_seg + D * (B + 1)
         self.meta = packed.meta_device()
-        self.idx = torch.full((B,), -1, dtype=torch.int64, device=dev)       # one batch, or an epoch's permutation (set_epoch)
+        self.n_batches = S                                                       # batches the index buffer holds
+        self.idx = torch.full((S * B,), -1, dtype=torch.int64, device=dev)       # S batches, or an epoch's permutation (set_epoch)
         self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
         self.use_cursor = False
         self.fill_id = 0
-        # ---- buffers + the collate launch's descriptors ---------------------------------------------------------------
+        # ---- buffers ([S, ...]) + the collate launch's descriptors (slot 0's pointers + the slot strides) --------------
         base = self.tables.data_ptr()
-        cochains = [CochainBatch(d) for d in range(D)]
         self.bufs: Dict = {}
-        descs = []
-        y = None
+        descs, slot_bytes = [], []
         for k, (d, key, pk) in enumerate(packed._klist):
             cap = self._caps[k]
             add_ptr, dst_off = None, 0
             if key == 'x':
-                out = torch.zeros(self.cap_cells[d], pk.width, dtype=pk.data.dtype, device=dev)
+                out = torch.zeros(S, self.cap_cells[d], pk.width, dtype=pk.data.dtype, device=dev)
             elif key in _TWO_ROW:
-                out = torch.zeros(2, cap, dtype=pk.data.dtype, device=dev)
+                out = torch.zeros(S, 2, cap, dtype=pk.data.dtype, device=dev)
             elif key in ('b_rowptr', 'bt_rowptr'):
-                out = torch.zeros(cap + 1, dtype=torch.int32, device=dev)      # rowptr[0] = 0 is never rewritten
+                out = torch.zeros(S, cap + 1, dtype=torch.int32, device=dev)      # rowptr[0] = 0 is never rewritten
                 dst_off = 4
                 add_ptr = base + 8 * (self.k_of(d, 'b_col' if key == 'b_rowptr' else 'bt_col') * (B + 1))
             else:
-                out = torch.zeros(cap, dtype=pk.data.dtype, device=dev)
+                out = torch.zeros(S, cap, dtype=pk.data.dtype, device=dev)
             row = _ADD_ROW.get(key)
             if row is not None:
                 add_ptr = base + 8 * (self.o_off + (d * 5 + row) * B)
             self.bufs[(d, key)] = out
-            if d < 0:
-                y = out
-            elif key == 'x':
-                cochains[d]._x = out
-            elif key not in _CSR_KEYS:
-                setattr(cochains[d], key, out)
             two = pk.rows == 2
             descs.append(_ffi.CollateDesc(
                 src=pk.data.data_ptr(), dst=out.data_ptr() + dst_off, dst_start=base + 8 * (k * (B + 1)),
                 src_start=base + 8 * (self.o_src + k * B), add=add_ptr,
                 src_row_stride=pk.data.size(-1) if two else 0, dst_row_stride=cap if two else 0,
                 n_rows=pk.rows, op=pk.op))
-        for d, cb in enumerate(cochains):
-            cb.batch = torch.zeros(self.cap_cells[d], dtype=torch.int64, device=dev)
-            descs.append(_ffi.CollateDesc(src=None, dst=cb.batch.data_ptr(), dst_start=base + 8 * (self.o_seg + d * (B + 1)),
+            slot_bytes.append(out[0].numel() * out.element_size())
+        for d in range(D):
+            out = torch.zeros(S, self.cap_cells[d], dtype=torch.int64, device=dev)
+            self.bufs[(d, 'batch')] = out
+            descs.append(_ffi.CollateDesc(src=None, dst=out.data_ptr(), dst_start=base + 8 * (self.o_seg + d * (B + 1)),
                                           src_start=None, add=None, src_row_stride=0, dst_row_stride=0, n_rows=1,
                                           op=_ffi.COLLATE_SEGID64))
+            slot_bytes.append(out[0].numel() * 8)
+        self._descs = []
+        for i in range(0, len(descs), _ffi.MAX_COLLATE_DESCS):
+            part = descs[i:i + _ffi.MAX_COLLATE_DESCS]
+            self._descs.append(((_ffi.CollateDesc * len(part))(*part), (C.c_int64 * len(part))(*slot_bytes[i:i + len(part)])))
+        # ---- the slots: a ComplexBatch over slot j's views, its plans ---------------------------------------------------
+        self._families: Dict = {}
+        self._adjs = []
+        self.slots: List[StaticSlot] = [self._make_slot(j) for j in range(S)]
+        # (slot 0 under the names a one-slot caller uses)
+        self.batch, self.plan = self.slots[0].batch, self.slots[0].plan
+
+    def _make_slot(self, j: int) -> StaticSlot:
+        D, B = self.D, self.B
+        bufs = {k: v[j] for k, v in self.bufs.items()}
+        cochains = [CochainBatch(d) for d in range(D)]
+        y = None
+        for (d, key), out in bufs.items():
+            if d < 0:
+                y = out
+            elif key == 'x':
+                cochains[d]._x = out
+            elif key not in _CSR_KEYS:
+                setattr(cochains[d], key, out)
+        for d, cb in enumerate(cochains):
             cb.ptr = None
             cb.__num_cells__ = self.cap_cells[d]
             cb.__num_cells_up__ = self.cap_cells[d + 1] if d + 1 < D else 0
@@ -389,31 +328,24 @@ class StaticBatch:
                 cb.__num_cells_down__ = self.cap_cells[d - 1]
             cb.__num_cochains__ = B
             cb.__slices__ = {}
-        self._descs = [(_ffi.CollateDesc * len(part))(*part)
-                       for part in (descs[i:i + _ffi.MAX_COLLATE_DESCS] for i in range(0, len(descs), _ffi.MAX_COLLATE_DESCS))]
-        self.batch = StaticComplexBatch(*cochains, y=y, num_complexes=B, dimension=D - 1)
-        # ---- plans: CSR of the boundary adjacencies (collated), sizes-only stand-ins for the upper ones -----------------
-        self._adjs = []
+        batch = StaticComplexBatch(*cochains, y=y, num_complexes=B, dimension=D - 1)
+        # plans: CSR of the boundary adjacencies (collated), sizes-only stand-ins for the upper ones
         for d in range(D):
             cb = cochains[d]
             if d > 0 and cb.boundary_index is not None and self.k_of(d, 'b_col') >= 0:
                 bi = cb.boundary_index
-                adj = _CollatedAdjacency(bi, 1, self.cap_cells[d], self.cap_cells[d - 1], self.bufs[(d, 'b_rowptr')],
-                                         self.bufs[(d, 'b_col')])
-                adj._t_src = _CollatedAdjacency(bi, 0, self.cap_cells[d - 1], self.cap_cells[d], self.bufs[(d, 'bt_rowptr')],
-                                                self.bufs[(d, 'bt_col')])
+                adj = _CollatedAdjacency(bi, 1, self.cap_cells[d], self.cap_cells[d - 1], bufs[(d, 'b_rowptr')], bufs[(d, 'b_col')])
+                adj._t_src = _CollatedAdjacency(bi, 0, self.cap_cells[d - 1], self.cap_cells[d], bufs[(d, 'bt_rowptr')],
+                                                bufs[(d, 'bt_col')])
                 self._register(bi, adj)
             if cb.upper_index is not None and d + 1 < D:
                 ui = cb.upper_index
                 self._register(ui, _PlanOnlyAdjacency(ui, self.cap_cells[d], self.cap_cells[d], cb.shared_coboundaries,
                                                       self.cap_cells[d + 1]))
-        if variant not in (0, 1):
-            raise ValueError('variant 0 (one 16-wave workgroup per CU) or 1 (the two-per-CU form)')
-        if group is None:
-            group = max(1, B // (256 if variant == 1 else 128))
-        self.plan = StaticBlockPlan(self, variant, group)
-        some = next(t for t in self.bufs.values())
-        self.batch._block_plan = (some.device, self.plan)          # (the device as the tensors spell it: Complex.block_plan compares)
+        plan = StaticBlockPlan(self, j)
+        some = next(iter(bufs.values()))
+        batch._block_plan = (some.device, plan)          # (the device as the tensors spell it: Complex.block_plan compares)
+        return StaticSlot(self, j, batch, bufs, plan)
 
     # ---- layout helpers --------------------------------------------------------------------------------------------
     def k_of(self, d: int, key: str) -> int:
@@ -423,44 +355,148 @@ class StaticBatch:
         k = self.k_of(d, key)
         return self._caps[k] if k >= 0 else 0
 
-    def seg_view(self, d: int) -> torch.Tensor:
+    def seg_view(self, d: int, slot: int = 0) -> torch.Tensor:
         """`ptr` of dimension d: int64 [B + 1], the cells of complex c are rows seg[c] .. seg[c + 1]."""
         o = self.o_seg + d * (self.B + 1)
-        return self.tables[o: o + self.B + 1]
+        return self.tables[slot, o: o + self.B + 1]
 
-    def dst_view(self, k: int) -> torch.Tensor:
+    def dst_view(self, k: int, slot: int = 0) -> torch.Tensor:
         """`__slices__` of key k: int64 [B + 1]."""
-        return self.tables[k * (self.B + 1): (k + 1) * (self.B + 1)]
+        return self.tables[slot, k * (self.B + 1): (k + 1) * (self.B + 1)]
 
-    def size_ptr(self, j: int) -> int:
-        return self.tables.data_ptr() + 8 * (self.o_sizes + j)
+    def size_ptr(self, j: int, slot: int = 0) -> int:
+        return self.tables.data_ptr() + 8 * (slot * self.n_tab + self.o_sizes + j)
 
-    def sizes(self) -> List[int]:
-        """[cells of dims 0..2, complexes] of the batch in the buffers (host sync: tests, diagnostics)."""
-        return self.tables[self.o_sizes: self.o_sizes + 4].tolist()
+    def sizes(self, slot: int = 0) -> List[int]:
+        return self.slots[slot].sizes()
+
+    def dynamic(self) -> _ffi.dynamic_rows:
+        return self.slots[0].dynamic()
 
     def _register(self, index: torch.Tensor, adj) -> None:
         import weakref
         key = id(index)
         csr._cache[key] = ((index._version, adj.n_dst, adj.n_val), weakref.ref(index, lambda _r, k=key: csr._cache.pop(k, None)), adj)
-        self._adjs.append(adj)
+        self._adjs.append((index, adj))          # (the view tensors the cache is keyed on stay alive with the batch)
 
-    def dynamic(self) -> _ffi.dynamic_rows:
-        """Context manager: inside, every launch whose row count is one of this batch's capacities reads the actual count
-        from the tables (the three cell counts are consecutive int64: cwn_embed_front_f32's n_dev)."""
-        m = {self.cap_cells[d]: self.size_ptr(d) for d in range(min(self.D, 3))}
-        m[self.B] = self.size_ptr(3)
-        return _ffi.dynamic_rows(m)
+    def _n_sets(self, has_up) -> int:
+        n, d = 0, 0
+        while d < self.D:
+            step = 1
+            if has_up[d] and d + 1 < self.D and not has_up[d + 1] and d + 2 >= self.D:
+                step = 2
+            n += 1
+            d += step
+        return n
+
+    # ---- item tables: one family = the tables of all slots for one (kind, width, streams), cut by ONE launch ------------
+    def _sizes_dev(self, has_up, has_b) -> _ffi.LayerSizesDev:
+        s = _ffi.LayerSizesDev(n_complexes=self.size_ptr(3), cap_complexes=self.B, n_dims=self.D, n_slots=self.S,
+                               table_slot_stride=self.n_tab)
+        for d in range(self.D):
+            s.has_up[d] = 1 if has_up[d] else 0
+            s.cell_ptr[d] = self.seg_view(d).data_ptr()
+            k = self.k_of(d, 'upper_index')
+            if k >= 0:
+                s.up_ptr[d] = self.dst_view(k).data_ptr()
+            k = self.k_of(d, 'boundary_index')
+            if k >= 0 and has_b[d]:
+                s.b_ptr[d] = self.dst_view(k).data_ptr()
+        return s
+
+    def family(self, kind: str, F: int, has_up, has_b):
+        key = (kind, F, has_up, has_b)
+        if key not in self._families:
+            fam = self._make_family(kind, F, has_up, has_b)
+            self._families[key] = fam
+            if fam is not None:
+                self._launch_family(key, self.S)       # cut for the batches the buffers hold now
+        return self._families[key]
+
+    def _make_family(self, kind: str, F: int, has_up, has_b):
+        if F not in (64, 128) or any(has_up[d] and (d + 1 >= self.D or self.k_of(d, 'upper_index') < 0) for d in range(self.D)):
+            return None
+        S, B, dev = self.S, self.B, self.device
+        n_sets = self._n_sets(has_up)
+        n_items = n_sets * B                                   # a region of B records per set always suffices
+        cap_up = [self.cap_key(d, 'upper_index') if has_up[d] else 0 for d in range(self.D)]
+        cap_b = [self.cap_key(d, 'boundary_index') if (d > 0 and has_b[d]) else 0 for d in range(self.D)]
+        if kind == 'fwd':
+            if self.variant == 0:
+                # one launch = one LDS layout: the full row cap, the boundary sources take what is left of the 160 KiB
+                cap = gemm_rows_cap(F)
+                src_cap = min(cap, (LDS_BYTES - lds_bytes(F, cap, 0)) // (F * 4))
+                if src_cap < 16 or _ffi.lib().cwn_layer_fused_lds_bytes(F, cap, src_cap) == 0:
+                    return None
+                dyn_lds = 0
+            else:
+                cap = 128 if F == 64 else 80                   # = CWN_LAYER_W8_GEMM_ROWS / _SOURCE_ROWS / _LDS_BYTES
+                src_cap = 128 if F == 64 else 48
+                dyn_lds = 80 * 1024
+            store = torch.zeros(S, n_items, ITEM_INTS, dtype=torch.int32, device=dev)
+            fam = []
+            for j in range(S):
+                t = ItemTable(np.zeros((0, ITEM_INTS), dtype=np.int32), [s_ * B for s_ in range(n_sets)], cap, src_cap,
+                              list(self.cap_cells), cap_up, cap_b, None, variant=self.variant, lds_bytes=dyn_lds)
+                t.items, t.n_items, t.device = store[j], n_items, dev
+                fam.append(t)
+        else:
+            store = torch.zeros(S, n_items, _ffi.LAYER_BWD_ITEM_INTS, dtype=torch.int32, device=dev)
+            fam = []
+            for j in range(S):
+                t = BwdItemTable(np.zeros((0, _ffi.LAYER_BWD_ITEM_INTS), dtype=np.int32), LDS_BYTES, list(self.cap_cells), cap_up,
+                                 cap_b, None)
+                t.items, t.n_items, t.device = store[j], n_items, dev
+                fam.append(t)
+        fam[0].store, fam[0].sizes, fam[0].F = store, self._sizes_dev(has_up, has_b), F
+        return fam
+
+    def _launch_family(self, key, n_slots: int) -> None:
+        fam = self._families.get(key)
+        if fam is None:
+            return
+        t0 = fam[0]
+        t0.sizes.n_slots = int(n_slots)
+        err, s = csr._err_flag(self.device).data_ptr(), _ffi.stream_ptr(self.device)
+        if key[0] == 'fwd':
+            _ffi.check(_ffi.lib().cwn_layer_items_build_dev(t0.sizes, t0.F, t0.c_plan(with_cache=False), self.group, err, s),
+                       'cwn_layer_items_build_dev')
+            for t in fam[:n_slots]:
+                t.csr_key = None                 # (the per-item CSR cache belongs to the previous batch's entries)
+        else:
+            _ffi.check(_ffi.lib().cwn_layer_bwd_items_build_dev(t0.sizes, t0.F, t0.c_plan(), self.group, err, s),
+                       'cwn_layer_bwd_items_build_dev')
+
+    def fit_mask(self) -> np.ndarray:
+        """bool per complex of the dataset: every item table cut so far takes it as one item (numpy restatement of the device
+        builders' test: blockplan.single_fit_forward / _backward)."""
+        from .blockplan import single_fit_backward, single_fit_forward
+        meta, D = self.packed._meta, self.D
+        cells = [meta[:, 3 * d] for d in range(D)]
+        col = lambda d, key: (meta[:, 3 * D + self.k_of(d, key)] if self.k_of(d, key) >= 0 else None)
+        up_len = [col(d, 'upper_index') for d in range(D)]
+        b_len = [col(d, 'boundary_index') for d in range(D)]
+        ok = np.ones(meta.shape[0], dtype=bool)
+        for key, fam in self._families.items():
+            if fam is None:
+                continue
+            kind, F, hu, hb = key
+            if kind == 'fwd':
+                ok &= single_fit_forward(cells, up_len, b_len, F, hu, hb, self.variant, fam[0].max_rows, fam[0].max_src)
+            else:
+                ok &= single_fit_backward(cells, up_len, b_len, F, hu, hb)
+        return ok
 
     # ---- which batches fit ------------------------------------------------------------------------------------------
     def fits(self, batches: Sequence[np.ndarray]) -> np.ndarray:
-        """bool per batch (index arrays): every array of the batch within its capacity and at least two cells of every
-        dimension the dataset has (BatchNorm in training mode needs them; the reference raises below two)."""
+        """bool per batch (index arrays): every array of the batch within its capacity, every complex within what one
+        workgroup of the item tables cut so far holds, and at least two cells of every dimension the dataset has
+        (BatchNorm in training mode needs them; the reference raises below two)."""
         meta, D, K = self.packed._meta, self.D, self.K
         ok = np.ones(len(batches), dtype=bool)
         caps_cells = np.asarray(self.cap_cells, dtype=np.int64)
         caps_keys = np.asarray(self._caps, dtype=np.int64)
-        single = self.plan.fit_mask()              # complexes every item table cut so far takes
+        single = self.fit_mask()
         for i, idx in enumerate(batches):
             idx = np.asarray(idx, dtype=np.int64)
             if idx.size == 0 or idx.size > self.B:
@@ -473,62 +509,72 @@ class StaticBatch:
         return ok
 
     # ---- filling ------------------------------------------------------------------------------------------------------
-    def set_batch(self, idx: Sequence[int]) -> None:
-        """The complexes of the next fill (host -> device copy of <= B numbers; pads with -1)."""
-        idx = np.asarray(idx, dtype=np.int64)
-        if idx.size > self.B or idx.size == 0:
-            raise ValueError(f'a batch of 1 .. {self.B} complexes')
-        host = np.full(self.B, -1, dtype=np.int64)
-        host[:idx.size] = idx
-        if self.use_cursor:
-            raise RuntimeError('set_batch after set_epoch: the fills read the epoch permutation (call clear_epoch first)')
-        self.idx.copy_(torch.from_numpy(host), non_blocking=False)
-
-    def set_epoch(self, batches: Sequence[np.ndarray]) -> None:
-        """Upload the complex numbers of a whole epoch's batches; fill number j after this call takes batch j (the device
-        cursor advances by itself: a replayed step needs nothing from the host).  Re-uses the permutation buffer when the
-        number of batches did not grow (a captured fill holds its address)."""
-        n = len(batches)
-        host = np.full((max(n, 1), self.B), -1, dtype=np.int64)
+    def _host_perm(self, batches: Sequence[np.ndarray], n: int) -> np.ndarray:
+        host = np.full((n, self.B), -1, dtype=np.int64)
         for j, idx in enumerate(batches):
             idx = np.asarray(idx, dtype=np.int64)
             if idx.size > self.B or idx.size == 0:
                 raise ValueError(f'batch {j}: 1 .. {self.B} complexes')
             host[j, :idx.size] = idx
-        if not self.use_cursor or self.idx.numel() < host.size:
-            if self.fill_id > 0 and self.use_cursor:
-                raise RuntimeError('set_epoch: more batches than the permutation buffer a captured step reads; reserve with '
-                                   'reserve_epoch(n) before the first fill')
-            self.idx = torch.full((host.size,), -1, dtype=torch.int64, device=self.device)
-        self.use_cursor = True
-        self.idx[:host.size].copy_(torch.from_numpy(host.reshape(-1)))
-        self.cursor.zero_()
+        return host
+
+    def set_batches(self, batches: Sequence[Sequence[int]]) -> None:
+        """The complexes of the next fill, one index list per slot (at most `slots`; the other slots get empty batches)."""
+        if self.use_cursor:
+            raise RuntimeError('set_batches after set_epoch / reserve_epoch: the fills read the epoch permutation')
+        if len(batches) > self.S or len(batches) == 0:
+            raise ValueError(f'1 .. {self.S} batches')
+        self.idx[:self.S * self.B].copy_(torch.from_numpy(self._host_perm(batches, self.S).reshape(-1)))
+
+    def set_batch(self, idx: Sequence[int]) -> None:
+        self.set_batches([idx])
 
     def reserve_epoch(self, n_batches: int) -> None:
-        """Size the permutation buffer for epochs of up to n_batches batches (before the first fill / capture)."""
-        self.idx = torch.full((max(1, int(n_batches)) * self.B,), -1, dtype=torch.int64, device=self.device)
+        """Size the permutation buffer for epochs of up to n_batches batches (before the first fill / capture: a captured
+        fill holds the buffer's address and its length)."""
+        if self.fill_id > 0:
+            raise RuntimeError('reserve_epoch after the first fill: a captured step reads the old buffer')
+        n = -(-max(1, int(n_batches)) // self.S) * self.S              # whole replays of S steps
+        self.n_batches = n
+        self.idx = torch.full((n * self.B,), -1, dtype=torch.int64, device=self.device)
         self.use_cursor = True
         self.cursor.zero_()
+
+    def set_epoch(self, batches: Sequence[np.ndarray]) -> int:
+        """Upload the complex numbers of a whole epoch's batches (one host -> device copy); fill number j after this call takes
+        batches j S .. j S + S - 1 (the device cursor advances by itself: a replayed step needs nothing from the host).  Batches
+        past the epoch's own are empty (their steps change nothing).  Returns the number of fills the epoch takes."""
+        if not self.use_cursor:
+            self.reserve_epoch(len(batches))
+        if len(batches) > self.n_batches:
+            raise RuntimeError(f'set_epoch: {len(batches)} batches, the permutation buffer a captured step reads holds '
+                               f'{self.n_batches}: reserve_epoch(n) before the first fill')
+        self.idx.copy_(torch.from_numpy(self._host_perm(batches, self.n_batches).reshape(-1)))
+        self.cursor.zero_()
+        return -(-len(batches) // self.S)
 
     def rewind(self, j: int = 0) -> None:
         self.cursor.fill_(int(j))
 
-    def fill(self) -> None:
-        """Two launches: the batch's tables (cwn_collate_tables) and its arrays (cwn_collate).  Graph-capturable; the item
-        tables follow lazily, at the first launch that asks the plan for them."""
+    def fill(self, n_slots: Optional[int] = None) -> None:
+        """The tables (cwn_collate_tables), the arrays (cwn_collate_slots) and the item tables asked for so far
+        (cwn_layer_items_build_dev / _bwd_) of the first n_slots slots (default: all) -- one launch each whatever the number
+        of slots.  Graph-capturable, no host sync; an item table asked for later is cut at that moment."""
+        n = self.S if n_slots is None else int(n_slots)
+        if not (1 <= n <= self.S):
+            raise ValueError(f'1 .. {self.S} slots')
         L = _ffi.lib()
         s = _ffi.stream_ptr(self.device)
         err = csr._err_flag(self.device).data_ptr()
+        cur = self.cursor.data_ptr() if self.use_cursor else None
         _ffi.check(L.cwn_collate_tables(self.meta.data_ptr(), self.packed.num, self.D, self.K, self.idx.data_ptr(), self.B,
-                                        self.cursor.data_ptr() if self.use_cursor else None, self.tables.data_ptr(), err, s),
-                   'cwn_collate_tables')
-        for arr in self._descs:
-            _ffi.check(L.cwn_collate(arr, len(arr), self.B, s), 'cwn_collate')
+                                        self.n_batches, cur, n, self.n_tab, self.tables.data_ptr(), err, s), 'cwn_collate_tables')
+        for i, (arr, strides) in enumerate(self._descs):
+            _ffi.check(L.cwn_collate_slots(arr, len(arr), self.B, n, self.n_tab, strides, cur if i == len(self._descs) - 1 else None, s),
+                       'cwn_collate_slots')
         self.fill_id += 1
-        self.plan.forget_csr()
-        self.plan.validated = True          # (index VALUES are checked by every blocked launch; the sticky word is read by the caller)
-        # ... and the item tables the model has asked for so far (a table asked for later is cut at that moment: StaticBlockPlan)
-        self.plan.refill()
+        for key in self._families:
+            self._launch_family(key, n)
 
     # ---- the reference tables (tests) -----------------------------------------------------------------------------------
     def host_tables(self, idx: Sequence[int]) -> np.ndarray:

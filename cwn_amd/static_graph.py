@@ -147,123 +147,142 @@ class StaticPropagate:
 # StaticPropagate above replays the propagate scope for a new batch after the HOST has cut and uploaded its item table.
 # The classes below capture a model's full forward / a full optimisation step ONCE over a cwn_amd.static_batch.StaticBatch:
 # the collate, the per-batch tables, the item tables and every row count are device-side (static_batch.py), so a step on a
-# batch of the reference's shuffled epoch (data/data_loading.py:84-111, exp/train_utils.py:35-75) is ONE graph replay and
-# nothing else -- with StaticBatch.set_epoch not even the batch's complex numbers cross the bus per step.
+# batch of the reference's shuffled epoch (data/data_loading.py:84-111, exp/train_utils.py:35-75) is a graph replay and
+# nothing else -- with StaticBatch.set_epoch not even the batch's complex numbers cross the bus per step.  A StaticBatch of
+# S slots puts S consecutive steps behind one replay: the three fill launches and the gap between two replays are paid
+# once per S steps.
 from .static_batch import StaticBatch            # noqa: E402
 from .train import TrainStep                     # noqa: E402
 
 
-def _cochains(b):
-    return [b.cochains[d] for d in range(b.dimension + 1)]
-
-
 class StaticForward:
     """`model(batch)` (eval, no autograd) for every batch a StaticBatch holds, as one captured graph:
-        fill (tables + collate + item tables) -> front -> L x (layer launch + update launch) -> head.
+        fill (tables + collate + item tables, all slots) -> per slot: front -> L x (layer launch + update launch) -> head.
     `run(idx)` = set_batch + replay -> predictions of those complexes; after `static.set_epoch(batches)` every `replay()`
-    takes the next batch of the epoch.  The graph holds the packed forms of the model's weights: it is re-captured when
+    takes the next S batches of the epoch.  The graph holds the packed forms of the model's weights: it is re-captured when
     a parameter (or, through ops.STATE_EPOCH, a raw-pointer writer such as a TrainStep) has changed them."""
 
-    def __init__(self, model: torch.nn.Module, static: StaticBatch, include_partial: bool = False):
+    def __init__(self, model: torch.nn.Module, static: StaticBatch):
         self.model, self.sb = model, static
-        self.include_partial = include_partial
-        self.inputs = [static.bufs.get((d, 'x')) for d in range(static.D)]
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.out = None
+        self.outs: Optional[List[torch.Tensor]] = None
         self._stamp = None
-
-    def _restore(self):
-        for c, x in zip(_cochains(self.sb.batch), self.inputs):
-            c._x = x
 
     def _state(self):
         return (ops.STATE_EPOCH,) + tuple(p._version for p in self.model.parameters()) + \
             tuple(b._version for b in self.model.buffers())
 
-    def _run(self):
+    def _run(self) -> List[torch.Tensor]:
         self.sb.fill()
-        self._restore()
-        with self.sb.dynamic():
-            out = self.model(self.sb.batch, include_partial=True) if self.include_partial else self.model(self.sb.batch)
-        self._restore()
-        return out
+        outs = []
+        for slot in self.sb.slots:
+            slot.restore()
+            with slot.dynamic():
+                outs.append(self.model(slot.batch))
+            slot.restore()
+        return outs
 
-    def eager(self):
-        """The same forward as ordinary launches (tests: what the replay must reproduce bit for bit)."""
+    def eager(self) -> List[torch.Tensor]:
+        """The same forwards as ordinary launches (what a replay must reproduce bit for bit)."""
         with torch.no_grad():
             return self._run()
 
-    def replay(self):
-        """Predictions [capacity, out]: rows past the batch's complexes are not meaningful."""
+    def replay(self) -> List[torch.Tensor]:
+        """Per slot the predictions [capacity, out]; rows past a batch's complexes are not meaningful."""
         if self.model.training:
             raise RuntimeError('StaticForward: model.eval() first (training-mode layers have no static inference form)')
         if self.graph is None or self._stamp != self._state():
             with torch.no_grad():
-                cur = self.sb.cursor.clone() if self.sb.use_cursor else None
+                cur = self.sb.cursor.clone()
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
-                    self._run()                   # warm-up outside the capture: packed weights, prepared launches, item tables
-                    if cur is not None:
-                        self.sb.cursor.copy_(cur)
-                    self._run()
-                    if cur is not None:
+                    for _ in range(2):            # warm-up outside the capture: packed weights, prepared launches, item tables
+                        self._run()
                         self.sb.cursor.copy_(cur)
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
-                    self.out = self._run()
+                    self.outs = self._run()
             self._stamp = self._state()
         self.graph.replay()
-        return self.out
+        return self.outs
 
     def run(self, idx: Sequence[int]) -> torch.Tensor:
+        """Predictions of the complexes `idx` (one batch, slot 0; the other slots run empty batches)."""
         self.sb.set_batch(idx)
-        out = self.replay()
-        pred = out[0] if isinstance(out, tuple) else out
-        return pred[:len(idx)]
+        return self.replay()[0][:len(idx)]
+
+    def run_many(self, batches: Sequence[Sequence[int]]) -> List[torch.Tensor]:
+        self.sb.set_batches(batches)
+        outs = self.replay()
+        return [outs[j][:len(idx)] for j, idx in enumerate(batches)]
 
 
 class StaticTrainStep(TrainStep):
-    """One optimisation step (exp/train_utils.py:57-75: zero_grad, forward, loss, backward, Adam) on whatever batch the
-    StaticBatch holds next, captured ONCE: `step()` is a graph replay for every batch of an epoch.  World size 1 (the
-    data-parallel form replays the same pieces with the collectives in between, as TrainStep does)."""
+    """Optimisation steps (exp/train_utils.py:57-75: zero_grad, forward, loss, backward, Adam) on whatever batches the
+    StaticBatch holds next, captured ONCE: `step()` replays S steps, one per slot, for every S batches of an epoch.  A slot
+    whose batch is empty (an epoch that is not a multiple of S) leaves the model and the optimizer untouched.  World size 1."""
 
     def __init__(self, model: torch.nn.Module, static: StaticBatch, task_type: str = 'regression', lr: float = 1e-3,
-                 use_graph: bool = True, optimizer=None, stages: Optional[int] = None):
+                 use_graph: bool = True, optimizer=None):
         self.sb = static
-        static.fill()                                 # the buffers hold a real batch from here on (probe forwards, warm-up)
-        with static.dynamic():
-            super().__init__(model, [static.batch], task_type=task_type, lr=lr, use_graph=use_graph, optimizer=optimizer,
-                             rebuild_plans=False, stages=stages)
+        static.fill()                                 # the buffers hold real batches from here on (warm-up)
+        super().__init__(model, [sl.batch for sl in static.slots], task_type=task_type, lr=lr, use_graph=use_graph,
+                         optimizer=optimizer, rebuild_plans=False, stages=1)
+        if self.world > 1:
+            raise NotImplementedError('StaticTrainStep: one rank (the data-parallel step is TrainStep)')
         # the inputs ARE the static buffers (TrainStep keeps clones: the collate writes through raw pointers)
-        self.inputs = [[static.bufs.get((d, 'x')) for d in range(static.D)]]
+        self.inputs = [list(sl.inputs) for sl in static.slots]
+        self._actives = [static.tables[j, static.o_sizes + 3: static.o_sizes + 4] for j in range(static.S)]
 
     def _forward_backward(self, i: int, pieces=None):
-        if pieces is None or 0 in pieces:
+        if i == 0:
             self.sb.fill()
-        with self.sb.dynamic():
+        with self.sb.slots[i].dynamic():
             return super()._forward_backward(i, pieces)
 
-    def _probe_stages(self, convs, ks):
-        with self.sb.dynamic():
-            return super()._probe_stages(convs, ks)
+    def _eager(self, i: int) -> torch.Tensor:
+        if hasattr(self.opt, 'active'):
+            self.opt.active = self._actives[i]        # (FlatAdam: an empty batch's step changes nothing)
+        try:
+            return super()._eager(i)
+        finally:
+            if hasattr(self.opt, 'active'):
+                self.opt.active = None
 
     def _capture(self, i: int):
-        # the warm-up steps of the capture consume batches: put the cursor back so that the first replay takes the batch
+        # the warm-up steps of the capture consume batches: put the cursor back so that the first replay takes the batches
         # the caller expects
-        cur = self.sb.cursor.clone() if self.sb.use_cursor else None
+        cur = self.sb.cursor.clone()
         res = super()._capture(i)
-        if cur is not None:
-            self.sb.cursor.copy_(cur)
+        self.sb.cursor.copy_(cur)
         return res
 
-    def step(self, i: int = 0) -> torch.Tensor:
-        """One step on the next batch (set_epoch) / the batch of set_batch.  Returns the loss tensor of the captured
-        step (overwritten by the next replay)."""
-        return super().step(0)
+    def step(self, i: int = 0) -> List[torch.Tensor]:
+        """S steps, one per slot, on the next S batches (set_epoch) / the batches of set_batches.  Returns the loss tensors of
+        the captured steps (overwritten by the next replay; NaN for an empty batch)."""
+        S = self.sb.S
+        if S == 1:
+            return [super().step(0)]
+        key = ('seq',) + tuple(range(S))
+        if key not in self._graphs:
+            cur = self.sb.cursor.clone()
+            for j in range(S):                        # warm-up + the one-step graphs TrainStep.steps builds on
+                if j not in self._graphs:
+                    self._graphs[j] = self._capture(j)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                losses = [self._eager(j) for j in range(S)]
+            self._graphs[key] = (g, losses)
+            self.sb.cursor.copy_(cur)
+        g, losses = self._graphs[key]
+        ops.weights_changed()
+        g.replay()
+        return losses
 
-    def step_on(self, idx: Sequence[int]) -> torch.Tensor:
-        self.sb.set_batch(idx)
-        return self.step()
+    def step_on(self, batches: Sequence[Sequence[int]]) -> List[torch.Tensor]:
+        """Steps on the given batches (<= S index lists; the remaining slots run empty)."""
+        self.sb.set_batches(batches)
+        return self.step()[:len(batches)]

@@ -97,6 +97,9 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(g)
         self.exp_avg_sq = torch.zeros_like(g)
         self.t = torch.zeros(1, dtype=torch.int32, device=g.device)
+        # a device int64 (or None): the complexes of the batch this step belongs to -- a step on an EMPTY batch of a static
+        # epoch changes nothing (static_graph.StaticTrainStep sets it per slot)
+        self.active: Optional[torch.Tensor] = None
         # what TrainStep snapshots around its warm-up
         self.param_groups = [{'params': list(bucket.params)}]
         self.state = {}
@@ -109,12 +112,15 @@ class FlatAdam:
 
     @torch.no_grad()
     def step(self):
-        self.t.add_(1)
+        if self.active is None:
+            self.t.add_(1)
+        else:
+            self.t.add_((self.active > 0).to(torch.int32).view(1))
         g = self.bucket.flat
         _ffi.check(_ffi.lib().cwn_adam_f32(
             self.flat_p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
             g.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-            self.t.data_ptr(), _ffi.stream_ptr(g.device)), 'cwn_adam_f32')
+            self.t.data_ptr(), _ffi.ptr(self.active), _ffi.stream_ptr(g.device)), 'cwn_adam_f32')
         ops.weights_changed()        # the parameters were written through a raw pointer: tensor versions did not move
 
 

@@ -471,6 +471,9 @@ typedef struct cwn_layer_sizes_dev {
     const int64_t* cell_ptr[CWN_LAYER_MAX_DIMS];    /* DEVICE [cap_complexes + 1]; entries past the batch's own = the total */
     const int64_t* up_ptr[CWN_LAYER_MAX_DIMS];      /* or NULL */
     const int64_t* b_ptr[CWN_LAYER_MAX_DIMS];       /* or NULL */
+    int32_t n_slots;                                /* >= 1: the batches of a multi-slot static batch, cut by one launch: slot j reads every */
+    int32_t pad_;                                   /* pointer above at + j * table_slot_stride (int64 elements) and writes the item table */
+    int64_t table_slot_stride;                      /* at items + j * n_items records */
 } cwn_layer_sizes_dev;
 #define CWN_ERR_BIT_UNFIT 16                   /* *err_flag bit: a complex beyond what one workgroup holds (device table build) */
 int cwn_layer_items_build_dev(const cwn_layer_sizes_dev* sizes_host, int32_t F, const cwn_layer_plan* plan_host, int32_t group,
@@ -841,6 +844,13 @@ typedef struct cwn_collate_desc {
 } cwn_collate_desc;
 
 int cwn_collate(const cwn_collate_desc* descs_host, int n, int64_t n_seg, cwn_stream_t stream);
+/* The same launch for n_slots batches at once (blockIdx.z = slot): slot j writes dst + j * dst_slot_bytes[i] (host array [n]) of
+ * every descriptor i and reads its tables at dst_start / src_start / add + j * table_slot_stride (int64 elements) -- the output
+ * arrays and the tables of a multi-slot static batch are [n_slots, ...] tensors (cwn_amd/static_batch.py: the fill of several
+ * steps of a captured graph in one launch).  cursor (device int64 or NULL): += n_slots, by one thread of the launch (the
+ * tables it used were cut by an earlier launch, cwn_collate_tables, which only reads the cursor). */
+int cwn_collate_slots(const cwn_collate_desc* descs_host, int n, int64_t n_seg, int32_t n_slots, int64_t table_slot_stride,
+                      const int64_t* dst_slot_bytes_host, int64_t* cursor, cwn_stream_t stream);
 
 /* The segment tables of a batch, built ON THE DEVICE from the per-complex metadata of a packed dataset (what
  * cwn_amd/packed.py's host path computes with numpy and uploads: the reference does it in CochainBatch.from_cochain_list,
@@ -851,9 +861,11 @@ int cwn_collate(const cwn_collate_desc* descs_host, int n, int64_t n_seg, cwn_st
  *            [3 d + 0 / 1 / 2]  cells of dimension d / cells below / cells above (the three running offsets of
  *                               data/complex.py:148-169)
  *            [3 D + k] length, [3 D + K + k] start, [3 D + 2 K + k] has      of key k (one array of the packed dataset)
- *   idx    device int64: the complexes of a batch in order, B per batch; a negative entry = no complex (a short last
- *          batch; such entries form a suffix); an entry >= num sets bit 1 of *err_flag and counts as absent
- *   cursor device int64 or NULL: when given, the batch is idx[*cursor * B .. (*cursor + 1) * B) and the launch adds 1
+ *   idx    device int64 [n_batches][B]: the complexes of the batches in order; a negative entry = no complex (a short last
+ *          batch); an entry >= num sets bit 1 of *err_flag and counts as absent
+ *   cursor device int64 or NULL (= 0), READ only: workgroup j of the launch cuts the tables of batch *cursor + j into
+ *          tables + j * slot_stride, j < n_slots (cwn_collate_slots advances the cursor); a batch past n_batches is an empty
+ *          batch and sets bit 1 of *err_flag
  *   tables (out) device int64 [cwn_collate_tables_len(D, K, B)]:
  *            dst   [K][B + 1]  at 0               dst[k][s] = sum_{s' < s} length_k(idx[s'])   (`__slices__`, :349-394)
  *            src   [K][B]      at K (B + 1)       start_k(idx[s])
@@ -861,10 +873,11 @@ int cwn_collate(const cwn_collate_desc* descs_host, int n, int64_t n_seg, cwn_st
  *            seg   [D][B + 1]  then               exclusive sums of the cells of dimension d, the total last (`ptr`, :344, 432)
  *            sizes [8 + K]     then               [d] cells of dimension d (0 beyond D; d < 3), [3] complexes in the batch,
  *                                                 [4..7] 0, [8 + k] total length of key k  -- what `m_dev` fields point at
- * One workgroup; a few microseconds. */
+ * One workgroup per slot; a few microseconds. */
 size_t cwn_collate_tables_len(int32_t D, int32_t K, int64_t B);      /* int64 elements */
-int cwn_collate_tables(const int64_t* meta, int64_t num, int32_t D, int32_t K, const int64_t* idx, int64_t B,
-                       int64_t* cursor, int64_t* tables, int32_t* err_flag, cwn_stream_t stream);
+int cwn_collate_tables(const int64_t* meta, int64_t num, int32_t D, int32_t K, const int64_t* idx, int64_t B, int64_t n_batches,
+                       const int64_t* cursor, int32_t n_slots, int64_t slot_stride, int64_t* tables, int32_t* err_flag,
+                       cwn_stream_t stream);
 
 /* Embedding lookup with a sum over index columns (torch.nn.Embedding for cols = 1; the OGB
  * Atom/BondEncoder sum over one table per integer feature column, mp/molec_models.py:44-52, 237-245):
@@ -982,8 +995,11 @@ int cwn_loss_f32(int32_t kind, const float* pred, const float* y, int64_t n, flo
  * elements (16-B aligned).  `step` is a device int32 holding the 1-based step number (the caller
  * increments it before the call), so the launch is graph-capturable.  Replaces optimizer.step() of
  * exp/train_utils.py:75 for the data-parallel training path. */
+/* active (device int64 or NULL): when given and *active <= 0 the launch changes nothing -- the step of an EMPTY batch of a
+ * static epoch (cwn_amd/static_batch.py: a replay holds a fixed number of steps, an epoch need not be a multiple of it); the
+ * caller then also leaves `step` alone. */
 int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, const int32_t* step, cwn_stream_t stream);
+                 float beta2, float eps, float weight_decay, const int32_t* step, const int64_t* active, cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Graph -> 2-complex lifting on the HOST (integer preprocessing that produces the path's inputs;

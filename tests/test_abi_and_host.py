@@ -81,7 +81,7 @@ def test_argument_errors_without_gpu():
     nd[0].M = 0
     assert lib.cwn_norm_bwd_f32(nd, 1, 0, None) == 0                # nothing to do
     assert _ffi.NORM_BWD_FUSED_MAX_ROWS == int(re.search(r'#define CWN_NORM_BWD_FUSED_MAX_ROWS (\d+)', open(os.path.join(ROOT, 'include', 'cwn_hip.h')).read()).group(1))
-    assert lib.cwn_adam_f32(None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, None, None) == 1
+    assert lib.cwn_adam_f32(None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, None, None, None) == 1
     assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 8, 1, 64, 28, 0, None, None) == 1
     assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 0, 1, 64, 28, 0, None, None) == 0   # nothing to do
     assert lib.cwn_embedding_fwd_f32(None, None, None, None, None, 8, 1, 64, 28, None, None) == 1

@@ -41,7 +41,7 @@ def test_device_tables_equal_the_host_tables_and_the_collate_its_per_batch_form(
         sb.set_batch(idx)
         sb.fill()
         torch.cuda.synchronize()
-        assert np.array_equal(sb.tables.cpu().numpy(), sb.host_tables(idx)), len(idx)
+        assert np.array_equal(sb.tables[0].cpu().numpy(), sb.host_tables(idx)), len(idx)
         ref = p.collate(idx)
         n = [ref.cochains[d].num_cells for d in range(3)]
         assert sb.sizes() == n + [len(idx)]
@@ -62,10 +62,10 @@ def test_device_tables_equal_the_host_tables_and_the_collate_its_per_batch_form(
                 adj = csr.cached_adjacency(rc.boundary_index, n[d], n[d - 1])
                 t = adj.t_src
                 e = rc.boundary_index.size(1)
-                assert torch.equal(sb.bufs[(d, 'b_rowptr')][:n[d] + 1], adj.rowptr)
-                assert torch.equal(sb.bufs[(d, 'b_col')][:e], adj.col)
-                assert torch.equal(sb.bufs[(d, 'bt_rowptr')][:n[d - 1] + 1], t.rowptr)
-                assert torch.equal(sb.bufs[(d, 'bt_col')][:e], t.col)
+                assert torch.equal(sb.slots[0].bufs[(d, 'b_rowptr')][:n[d] + 1], adj.rowptr)
+                assert torch.equal(sb.slots[0].bufs[(d, 'b_col')][:e], adj.col)
+                assert torch.equal(sb.slots[0].bufs[(d, 'bt_rowptr')][:n[d - 1] + 1], t.rowptr)
+                assert torch.equal(sb.slots[0].bufs[(d, 'bt_col')][:e], t.col)
         assert torch.equal(sb.batch.y[:len(idx)], ref.y.view(-1))
     csr.check_errors(DEV)
 
@@ -82,10 +82,10 @@ def test_epoch_cursor_takes_the_batches_in_order():
     for j, idx in enumerate(batches):
         sb.fill()
         torch.cuda.synchronize()
-        assert np.array_equal(sb.tables.cpu().numpy(), sb.host_tables(idx)), j
+        assert np.array_equal(sb.tables[0].cpu().numpy(), sb.host_tables(idx)), j
     sb.rewind(1)
     sb.fill()
-    assert np.array_equal(sb.tables.cpu().numpy(), sb.host_tables(batches[1]))
+    assert np.array_equal(sb.tables[0].cpu().numpy(), sb.host_tables(batches[1]))
 
 
 @pytest.mark.parametrize('F,group', [(128, 1), (128, 3), (64, 4)])
@@ -179,7 +179,7 @@ def test_static_forward_over_an_epoch_needs_nothing_from_the_host_per_step():
             order = batches if epoch == 0 else batches[::-1]
             sb.set_epoch(order)
             for idx in order:
-                got = sf.replay()[:len(idx)].clone()
+                got = sf.replay()[0][:len(idx)].clone()
                 assert torch.equal(got, model(p.collate(idx)))
 
 
@@ -202,14 +202,16 @@ def test_static_train_step_matches_the_per_batch_step():
     st = StaticTrainStep(m1, sb, lr=1e-3)
     ref = TrainStep(m2, [p.collate(idx) for idx in batches], lr=1e-3, use_graph=False)
     for j, idx in enumerate(batches):
-        l1 = st.step_on(idx).clone()
+        l1 = st.step_on([idx])[0].clone()
         l2 = ref.step(j)
         torch.cuda.synchronize()
         assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l2))), (j, float(l1), float(l2))
         g1, g2 = st.bucket.flat, ref.bucket.flat
         rel = float((g1 - g2).norm() / g2.norm())
         print(f'[static train] step {j}: loss {float(l1):.6f} vs {float(l2):.6f}, relative L2 distance of the gradient {rel:.2e}')
-        assert rel < 2e-5, (j, rel)
+        # step 0 starts from identical states; from step 1 on the two models differ where Adam turned summation noise of
+        # step 0 into a +-lr step (test_gpu_parity.py: test_train_step_graph_replay_matches_eager), and so do their gradients
+        assert rel < (2e-5 if j == 0 else 5e-3), (j, rel)
     csr.check_errors(DEV)
     assert len(st._graphs) == 1
     worst = 0.0
@@ -243,3 +245,73 @@ def test_a_complex_beyond_a_workgroup_is_refused_by_fits_and_flagged_by_the_devi
         sf.run(bad)
     with pytest.raises(IndexError, match='beyond what one workgroup holds'):
         csr.check_errors(DEV)
+
+
+def test_three_slots_put_three_steps_behind_one_replay():
+    """StaticBatch(slots=3): the fill launches cut the tables, arrays and item tables of three batches at once and a replay
+    runs three forwards; an epoch of seven batches takes three replays, the last with two empty slots.  Every prediction
+    bit-identical to model(collate(batch)); the device tables of every slot equal to the host restatement."""
+    from cwn_amd import csr
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward
+    pool, p = _packed(n=260, n_hi=28)
+    model = _model(128).eval()
+    B, S = 32, 3
+    sb = StaticBatch(p, B, slots=S)
+    sb.reserve_epoch(9)
+    sf = StaticForward(model, sb)
+    batches = _batches(len(pool), B, 4, sizes=[B] * 6 + [11])
+    with torch.no_grad():
+        n_replays = sb.set_epoch(batches)
+        assert n_replays == 3
+        for r in range(n_replays):
+            outs = [o.clone() for o in sf.replay()]
+            torch.cuda.synchronize()
+            for j in range(S):
+                k = r * S + j
+                if k < len(batches):
+                    assert np.array_equal(sb.tables[j].cpu().numpy(), sb.host_tables(batches[k])), (r, j)
+                    assert torch.equal(outs[j][:len(batches[k])], model(p.collate(batches[k]))), (r, j)
+                else:
+                    assert sb.slots[j].sizes() == [0, 0, 0, 0]
+    csr.check_errors(DEV)
+
+
+def test_static_train_two_slots_and_an_empty_slot_changes_nothing():
+    """StaticTrainStep over StaticBatch(slots=2): three batches = two replays, the last slot of the second empty.  Against the
+    per-batch eager steps from the same state: losses, and after the epoch parameters, BatchNorm statistics and the Adam
+    step counter (an empty batch's step must leave model and optimizer alone)."""
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    from cwn_amd.train import TrainStep
+    pool, p = _packed(n_hi=28)
+    B = 40
+    m1, m2 = _model(64, 2, seed=6), _model(64, 2, seed=6)
+    m2.load_state_dict(m1.state_dict())
+    batches = _batches(len(pool), B, 21, sizes=[B, B, 25])
+    sb = StaticBatch(p, B, slots=2)
+    sb.reserve_epoch(4)
+    sb.set_epoch(batches)
+    st = StaticTrainStep(m1, sb, lr=1e-3)
+    ref = TrainStep(m2, [p.collate(idx) for idx in batches], lr=1e-3, use_graph=False)
+    sb.set_epoch(batches)
+    got = []
+    for r in range(2):
+        got += [float(l) for l in st.step()]
+    want = [float(ref.step(j)) for j in range(3)]
+    torch.cuda.synchronize()
+    print('[static train, 2 slots] losses', got, 'vs', want)
+    for a, b in zip(got[:3], want):
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (got, want)
+    assert got[3] != got[3]                          # the empty batch: the mean of nothing
+    assert int(st.opt.t) == 3 == int(ref.opt.t)
+    for (n_, a), (_, b) in zip(m1.named_buffers(), m2.named_buffers()):
+        if a.dtype.is_floating_point:
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), n_
+        else:
+            assert torch.equal(a, b), n_             # num_batches_tracked: three, not four
+    worst = 0.0
+    for (n_, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        if a.dtype.is_floating_point:
+            worst = max(worst, float((a - b).abs().max()) / max(1.0, float(b.abs().max())))
+    assert worst < 2 * 1e-3 * 3 * 1.1, worst

