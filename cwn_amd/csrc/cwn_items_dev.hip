@@ -48,18 +48,11 @@ struct ItemsArgs {
     int64_t items_slot_ints;         // ... and int32 elements between their item tables
 };
 
-// the arguments as slot `slot` sees them
-__device__ __forceinline__ void to_slot(ItemsArgs& A, int slot) {
-    const int64_t o = (int64_t)slot * A.table_slot_stride;
-    A.n_complexes += o;
-#pragma unroll
-    for (int d = 0; d < CWN_LAYER_MAX_DIMS; ++d) {
-        A.cell_ptr[d] += o;
-        if (A.up_ptr[d] != nullptr) A.up_ptr[d] += o;
-        if (A.b_ptr[d] != nullptr) A.b_ptr[d] += o;
-    }
-    A.items += (int64_t)slot * A.items_slot_ints;
-}
+// Everything below reads the kernel arguments with COMPILE-TIME indices (sel3, unrolled loops): a run-time index into a
+// by-value argument array makes the compiler copy the whole structure to scratch (the first form of these kernels: 23 us for
+// eight slots, all of it scratch traffic).
+template <typename T>
+__device__ __forceinline__ T sel3(int i, T v0, T v1, T v2) { return i == 0 ? v0 : (i == 1 ? v1 : v2); }
 
 // workgroup-wide exclusive scan of one small integer per thread; returns the thread's offset, *total = the sum
 __device__ __forceinline__ int block_scan(int v, int* total, int* lds /* [2 * 16] */) {
@@ -88,65 +81,97 @@ __device__ __forceinline__ int block_scan(int v, int* total, int* lds /* [2 * 16
     return off;
 }
 
+// the prefix sums of a range of complexes [a, b): first cell / entry and count, per dimension (absent tables: zeros)
+struct Range {
+    int64_t c0[CWN_LAYER_MAX_DIMS], cn[CWN_LAYER_MAX_DIMS];     // cells
+    int64_t u0[CWN_LAYER_MAX_DIMS], un[CWN_LAYER_MAX_DIMS];     // entries of upper_index_d
+    int64_t b0[CWN_LAYER_MAX_DIMS], bn[CWN_LAYER_MAX_DIMS];     // entries of boundary_index_d
+    __device__ __forceinline__ int64_t cells(int d) const { return sel3(d, cn[0], cn[1], cn[2]); }
+    __device__ __forceinline__ int64_t cell0(int d) const { return sel3(d, c0[0], c0[1], c0[2]); }
+    __device__ __forceinline__ int64_t ups(int d) const { return sel3(d, un[0], un[1], un[2]); }
+    __device__ __forceinline__ int64_t up0(int d) const { return sel3(d, u0[0], u0[1], u0[2]); }
+    __device__ __forceinline__ int64_t bnds(int d) const { return sel3(d, bn[0], bn[1], bn[2]); }
+    __device__ __forceinline__ int64_t bnd0(int d) const { return sel3(d, b0[0], b0[1], b0[2]); }
+};
+
+__device__ __forceinline__ Range load_range(const ItemsArgs& A, int64_t o, int64_t a, int64_t b) {
+    Range R;
+#pragma unroll
+    for (int d = 0; d < CWN_LAYER_MAX_DIMS; ++d) {
+        R.c0[d] = R.cn[d] = R.u0[d] = R.un[d] = R.b0[d] = R.bn[d] = 0;
+        if (d < A.n_dims) {
+            const int64_t* cp = A.cell_ptr[d] + o;
+            R.c0[d] = cp[a];
+            R.cn[d] = cp[b] - R.c0[d];
+            if (A.up_ptr[d] != nullptr) {
+                const int64_t* up = A.up_ptr[d] + o;
+                R.u0[d] = up[a];
+                R.un[d] = up[b] - R.u0[d];
+            }
+            if (A.b_ptr[d] != nullptr) {
+                const int64_t* bp = A.b_ptr[d] + o;
+                R.b0[d] = bp[a];
+                R.bn[d] = bp[b] - R.b0[d];
+            }
+        }
+    }
+    return R;
+}
+
 __device__ __forceinline__ void store_record(int32_t* dst, const int32_t* r, int n_ints) {
     for (int k = 0; k < n_ints; k += 4) *reinterpret_cast<int4*>(dst + k) = make_int4(r[k], r[k + 1], r[k + 2], r[k + 3]);
 }
 
 // ---- forward table (record layout: include/cwn_hip.h; the arithmetic of cwn_blockplan.cpp: build_with) --------------------
 struct FwdGeom {
-    const ItemsArgs& A;
-    const DevSet& S;
-    __device__ int64_t cells(int d, int64_t a, int64_t b) const { return A.cell_ptr[d][b] - A.cell_ptr[d][a]; }
-    __device__ static int64_t span(const int64_t* p, int64_t a, int64_t b) { return p != nullptr ? p[b] - p[a] : 0; }
+    int F, variant, round_rows, g, n_tasks, t0, t1;
+    int64_t row_cap, src_cap, lds_budget, half_cap, idx_bytes;
+    __device__ __forceinline__ int task(int t) const { return t == 0 ? t0 : t1; }
     __device__ int64_t first_coface_row(int64_t n_g, int64_t n_c) const {
         const int64_t r1 = pad16(n_g);
-        return n_c > 0 ? (r1 + A.round_rows - 1) / A.round_rows * A.round_rows : r1;
+        return n_c > 0 ? (r1 + round_rows - 1) / round_rows * round_rows : r1;
     }
     __device__ int64_t staged(int64_t n_g, int64_t n_c) const { return n_c > 0 ? first_coface_row(n_g, n_c) + pad16(n_c) : pad16(n_g); }
-    __device__ int64_t lds(int64_t rows, int64_t src) const { return 3 * rows * (A.F + 8) * 2 + (src + 1) * A.F * 4 + A.idx_bytes; }
-    __device__ const int64_t* bp(int t) const { return S.tasks[t] > 0 ? A.b_ptr[S.tasks[t]] : nullptr; }
+    __device__ int64_t lds(int64_t rows, int64_t src) const { return 3 * rows * (F + 8) * 2 + (src + 1) * F * 4 + idx_bytes; }
 
-    // do the complexes [a, b) fit one workgroup?  (*bad: cells of a higher dimension without cells of the set's first one)
-    __device__ bool fits(int64_t a, int64_t b, bool* bad) const {
-        const int g = S.g, d0 = S.tasks[0];
-        const int64_t* up = g >= 0 ? A.up_ptr[g] : nullptr;
-        const int64_t n0 = cells(d0, a, b);
-        const int64_t rows = staged(n0, g >= 0 ? cells(g + 1, a, b) : 0);
-        int64_t src = 0, ents = pad4(span(up, a, b));
+    // does the range fit one workgroup?  (*bad: cells of a higher dimension without cells of the set's first one)
+    __device__ bool fits(const Range& R, bool* bad) const {
+        const int64_t n0 = R.cells(t0);
+        const int64_t ncf = g >= 0 ? R.cells(g + 1) : 0;
+        const int64_t rows = staged(n0, ncf);
+        int64_t src = 0, ents = pad4(g >= 0 ? R.ups(g) : 0);
         bool ok = true;
-        for (int t = 0; t < S.n_tasks; ++t) {
-            const int d = S.tasks[t];
-            const int64_t be = span(bp(t), a, b);
-            if (d > 0 && be > 0 && (A.variant == 0 || t == 0)) src += cells(d - 1, a, b);
+        for (int t = 0; t < n_tasks; ++t) {
+            const int d = task(t);
+            const int64_t be = d > 0 ? R.bnds(d) : 0;
+            if (d > 0 && be > 0 && (variant == 0 || t == 0)) src += R.cells(d - 1);
             ents += pad4(be);
-            ok = ok && cells(d, a, b) <= CWN_LAYER_TASK_ROWS;
-            if (g >= 0 && n0 == 0 && t > 0 && cells(d, a, b) > 0) *bad = true;
+            ok = ok && R.cells(d) <= CWN_LAYER_TASK_ROWS;
+            if (g >= 0 && n0 == 0 && t > 0 && R.cells(d) > 0) *bad = true;
         }
-        ok = ok && rows <= A.row_cap && src <= A.src_cap && lds(rows, src) <= A.lds_budget && ents <= CWN_LAYER_MAX_ENTRIES;
-        if (A.half_cap > 0 && g >= 0) ok = ok && pad16(n0) <= A.half_cap && pad16(cells(g + 1, a, b)) <= A.half_cap;
+        ok = ok && rows <= row_cap && src <= src_cap && lds(rows, src) <= lds_budget && ents <= CWN_LAYER_MAX_ENTRIES;
+        if (half_cap > 0 && g >= 0) ok = ok && pad16(n0) <= half_cap && pad16(ncf) <= half_cap;
         return ok;
     }
 
-    __device__ void record(int set, int64_t a, int64_t b, int32_t (&r)[kInts]) const {
+    __device__ void record(int set, const Range& R, int32_t (&r)[kInts]) const {
 #pragma unroll
         for (int k = 0; k < kInts; ++k) r[k] = 0;
-        const int g = S.g, d0 = S.tasks[0];
-        const int64_t* up = g >= 0 ? A.up_ptr[g] : nullptr;
         r[0] = set << 8;
-        const int64_t n0 = cells(d0, a, b);
+        const int64_t n0 = R.cells(t0);
         int64_t nc = 0, une = 0;
-        int live = S.n_tasks;
+        int live = n_tasks;
         if (g >= 0) {
             r[1] = g;
             if (n0 > 0) {
-                nc = cells(g + 1, a, b);
-                une = span(up, a, b);
+                nc = R.cells(g + 1);
+                une = R.ups(g);
                 r[0] |= 1;
-                r[2] = (int32_t)A.cell_ptr[g][a];
+                r[2] = (int32_t)R.cell0(g);
                 r[3] = (int32_t)n0;
-                r[4] = (int32_t)A.cell_ptr[g + 1][a];
+                r[4] = (int32_t)R.cell0(g + 1);
                 r[5] = (int32_t)nc;
-                r[6] = (int32_t)(up != nullptr ? up[a] : 0);
+                r[6] = (int32_t)R.up0(g);
                 r[7] = (int32_t)une;
             } else {
                 live = 1;
@@ -154,18 +179,20 @@ struct FwdGeom {
         }
         r[8] = live;
         int64_t bne[2] = {0, 0};
-        for (int t = 0; t < live; ++t) {
-            const int d = S.tasks[t], o = 9 + 7 * t;
-            const int64_t* p = bp(t);
-            bne[t] = span(p, a, b);
-            r[o] = d;
-            r[o + 1] = (int32_t)A.cell_ptr[d][a];
-            r[o + 2] = (int32_t)cells(d, a, b);
-            r[o + 3] = (int32_t)(p != nullptr ? p[a] : 0);
-            r[o + 4] = (int32_t)bne[t];
-            if (d > 0 && bne[t] > 0) {          // boundary sources are staged only when read
-                r[o + 5] = (int32_t)A.cell_ptr[d - 1][a];
-                r[o + 6] = (int32_t)cells(d - 1, a, b);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < live) {
+                const int d = task(t), o = 9 + 7 * t;
+                bne[t] = d > 0 ? R.bnds(d) : 0;
+                r[o] = d;
+                r[o + 1] = (int32_t)R.cell0(d);
+                r[o + 2] = (int32_t)R.cells(d);
+                r[o + 3] = (int32_t)(d > 0 ? R.bnd0(d) : 0);
+                r[o + 4] = (int32_t)bne[t];
+                if (d > 0 && bne[t] > 0) {          // boundary sources are staged only when read
+                    r[o + 5] = (int32_t)R.cell0(d - 1);
+                    r[o + 6] = (int32_t)R.cells(d - 1);
+                }
             }
         }
         const int64_t b1 = pad4(une), b2 = pad4(b1 + bne[0]);
@@ -177,16 +204,19 @@ struct FwdGeom {
     }
 };
 
-__global__ __launch_bounds__(kThreads) void items_fwd_kernel(ItemsArgs A_) {
+__global__ __launch_bounds__(kThreads) void items_fwd_kernel(ItemsArgs A) {
     __shared__ int scan_lds[32];
-    ItemsArgs A = A_;
-    to_slot(A, blockIdx.y);
     const int set = blockIdx.x;
-    const DevSet S = A.sets[set];
-    const FwdGeom G{A, S};
-    const int64_t nc_dev = *A.n_complexes;
+    const int64_t o = (int64_t)blockIdx.y * A.table_slot_stride;
+    int32_t* const items = A.items + (int64_t)blockIdx.y * A.items_slot_ints;
+    const DevSet S0 = A.sets[0], S1 = A.sets[1], S2 = A.sets[2];
+    const DevSet S = set == 0 ? S0 : (set == 1 ? S1 : S2);
+    const FwdGeom G{A.F, A.variant, A.round_rows, S.g, S.n_tasks, S.tasks[0], S.tasks[1], A.row_cap, A.src_cap, A.lds_budget,
+                    A.half_cap, A.idx_bytes};
+    const int64_t nc_dev = A.n_complexes[o];
     const int64_t C = nc_dev < A.cap_c ? (nc_dev < 0 ? 0 : nc_dev) : A.cap_c;
-    const int region0 = A.set_start[set], region1 = A.set_start[set + 1];
+    const int region0 = sel3(set, A.set_start[0], A.set_start[1], A.set_start[2]);
+    const int region1 = sel3(set, A.set_start[1], A.set_start[2], A.set_start[3]);
     const int64_t groups = (A.cap_c + A.group - 1) / A.group;
     int base = 0;
     bool unfit = false;
@@ -195,13 +225,15 @@ __global__ __launch_bounds__(kThreads) void items_fwd_kernel(ItemsArgs A_) {
         const int64_t b = a + A.group < C ? a + A.group : C;
         int cnt = 0;
         bool whole = false, bad = false;
+        Range R;
         if (a < C) {
-            whole = G.fits(a, b, &bad);
+            R = load_range(A, o, a, b);
+            whole = G.fits(R, &bad);
             if (whole) {
                 cnt = 1;
             } else {
                 for (int64_t c = a; c < b; ++c) {
-                    const bool one = G.fits(c, c + 1, &bad);
+                    const bool one = G.fits(load_range(A, o, c, c + 1), &bad);
                     cnt += one ? 1 : 0;
                     unfit = unfit || !one;
                 }
@@ -215,18 +247,19 @@ __global__ __launch_bounds__(kThreads) void items_fwd_kernel(ItemsArgs A_) {
             int slot = region0 + base + off;
             if (whole) {
                 if (slot < region1) {
-                    G.record(set, a, b, r);
-                    store_record(A.items + (size_t)slot * kInts, r, kInts);
+                    G.record(set, R, r);
+                    store_record(items + (size_t)slot * kInts, r, kInts);
                 } else {
                     unfit = true;
                 }
             } else {
                 for (int64_t c = a; c < b; ++c) {
                     bool dummy = false;
-                    if (!G.fits(c, c + 1, &dummy)) continue;
+                    const Range R1 = load_range(A, o, c, c + 1);
+                    if (!G.fits(R1, &dummy)) continue;
                     if (slot < region1) {
-                        G.record(set, c, c + 1, r);
-                        store_record(A.items + (size_t)slot * kInts, r, kInts);
+                        G.record(set, R1, r);
+                        store_record(items + (size_t)slot * kInts, r, kInts);
                     } else {
                         unfit = true;
                     }
@@ -238,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void items_fwd_kernel(ItemsArgs A_) {
     }
     // records past the set's own: empty
     for (int i = region0 + base + (int)threadIdx.x; i < region1; i += kThreads) {
-        int4* dst = reinterpret_cast<int4*>(A.items + (size_t)i * kInts);
+        int4* dst = reinterpret_cast<int4*>(items + (size_t)i * kInts);
 #pragma unroll
         for (int k = 0; k < kInts / 4; ++k) dst[k] = make_int4(0, 0, 0, 0);
     }
@@ -247,51 +280,45 @@ __global__ __launch_bounds__(kThreads) void items_fwd_kernel(ItemsArgs A_) {
 
 // ---- backward table, owner form (record layout: include/cwn_hip.h; cwn_blockplan.cpp: cwn_layer_bwd_items_build) ----------
 struct BwdGeom {
-    const ItemsArgs& A;
-    int d;
+    int F, d, set;
     bool top, pa, pb, above;
     int flags;
-    const int64_t* upa;
-    const int64_t* upb;
-    const int64_t* bnd;
-    __device__ int64_t cells(int dd, int64_t a, int64_t b) const { return A.cell_ptr[dd][b] - A.cell_ptr[dd][a]; }
-    __device__ static int64_t span(const int64_t* p, int64_t a, int64_t b) { return p != nullptr ? p[b] - p[a] : 0; }
+    int64_t bwd_lds;
 
     // 1: an item; 0: nothing to write (no owned cells); -1: beyond a limit; -2: entries without cells (not a cell complex)
-    __device__ int classify(int64_t a, int64_t b, int32_t (&r)[kBInts]) const {
+    __device__ int classify(const Range& R, int32_t (&r)[kBInts]) const {
         namespace bo = cwn_bwd_own;
-        const int F = A.F;
-        const int64_t n_o = cells(d, a, b), n_a = above ? cells(d + 1, a, b) : 0, n_b = pb ? cells(d - 1, a, b) : 0;
-        const int64_t ea = span(upa, a, b), eb = span(upb, a, b), bd = span(bnd, a, b);
+        const int64_t n_o = R.cells(d), n_a = above ? R.cells(d + 1) : 0, n_b = pb ? R.cells(d - 1) : 0;
+        const int64_t ea = pa ? R.ups(d) : 0, eb = pb ? R.ups(d - 1) : 0, bd = above ? R.bnds(d + 1) : 0;
         if (n_o > bo::own_rows_cap(F) || (top && n_a > bo::top_rows_cap(F))) return -1;
         if (ea > CWN_LAYER_MAX_ENTRIES || eb > CWN_LAYER_MAX_ENTRIES || bd > CWN_LAYER_MAX_ENTRIES) return -1;
         if (n_a > 4096 || n_b > 4096) return -1;
         const bool need_a = pa || top || bd > 0;
         const bo::Layout L = bo::layout(F, flags, (int)n_o, need_a ? (int)n_a : 0, (int)n_b, (int)ea, (int)eb, (int)bd);
-        if (L.total > A.bwd_lds) return -1;
+        if (L.total > bwd_lds) return -1;
         if (n_o == 0) return ((top && n_a > 0) || ea > 0 || eb > 0 || bd > 0) ? -2 : 0;
 #pragma unroll
         for (int k = 0; k < kBInts; ++k) r[k] = 0;
-        r[bo::R_FLAGS] = flags | ((int)blockIdx.x << 8);
+        r[bo::R_FLAGS] = flags | (set << 8);
         r[bo::R_DIM] = d;
-        r[bo::R_OWN_R0] = (int32_t)A.cell_ptr[d][a];
+        r[bo::R_OWN_R0] = (int32_t)R.cell0(d);
         r[bo::R_OWN_N] = (int32_t)n_o;
         if (need_a) {
-            r[bo::R_ABOVE_R0] = (int32_t)A.cell_ptr[d + 1][a];
+            r[bo::R_ABOVE_R0] = (int32_t)R.cell0(d + 1);
             r[bo::R_ABOVE_N] = (int32_t)n_a;
         }
         if (pb) {
-            r[bo::R_BELOW_R0] = (int32_t)A.cell_ptr[d - 1][a];
+            r[bo::R_BELOW_R0] = (int32_t)R.cell0(d - 1);
             r[bo::R_BELOW_N] = (int32_t)n_b;
-            r[bo::R_UPB_E0] = (int32_t)upb[a];
+            r[bo::R_UPB_E0] = (int32_t)R.up0(d - 1);
             r[bo::R_UPB_NE] = (int32_t)eb;
         }
         if (pa) {
-            r[bo::R_UPA_E0] = (int32_t)upa[a];
+            r[bo::R_UPA_E0] = (int32_t)R.up0(d);
             r[bo::R_UPA_NE] = (int32_t)ea;
         }
         if (bd > 0) {
-            r[bo::R_BND_E0] = (int32_t)bnd[a];
+            r[bo::R_BND_E0] = (int32_t)R.bnd0(d + 1);
             r[bo::R_BND_NE] = (int32_t)bd;
         }
         r[bo::R_LDS_BYTES] = L.total;
@@ -299,21 +326,22 @@ struct BwdGeom {
     }
 };
 
-__global__ __launch_bounds__(kThreads) void items_bwd_kernel(ItemsArgs A_) {
+__global__ __launch_bounds__(kThreads) void items_bwd_kernel(ItemsArgs A) {
     __shared__ int scan_lds[32];
-    ItemsArgs A = A_;
-    to_slot(A, blockIdx.y);
     const int set = blockIdx.x;
-    const DevSet S = A.sets[set];
+    const int64_t o = (int64_t)blockIdx.y * A.table_slot_stride;
+    int32_t* const items = A.items + (int64_t)blockIdx.y * A.items_slot_ints;
+    const DevSet S0 = A.sets[0], S1 = A.sets[1], S2 = A.sets[2];
+    const DevSet S = set == 0 ? S0 : (set == 1 ? S1 : S2);
     const int d = S.tasks[0];
-    BwdGeom G{A, d, S.n_tasks == 2, A.has_up[d] != 0, d > 0 && A.has_up[d - 1] != 0, d + 1 < A.n_dims, 0, nullptr, nullptr, nullptr};
+    const bool pa = sel3(d, A.has_up[0], A.has_up[1], A.has_up[2]) != 0;
+    const bool pb = d > 0 && sel3(d - 1, A.has_up[0], A.has_up[1], A.has_up[2]) != 0;
+    BwdGeom G{A.F, d, set, S.n_tasks == 2, pa, pb, d + 1 < A.n_dims, 0, A.bwd_lds};
     G.flags = (G.pa ? cwn_bwd_own::F_PA : 0) | (G.pb ? cwn_bwd_own::F_PB : 0) | (G.top ? cwn_bwd_own::F_TOP : 0);
-    G.upa = G.pa ? A.up_ptr[d] : nullptr;
-    G.upb = G.pb ? A.up_ptr[d - 1] : nullptr;
-    G.bnd = G.above ? A.b_ptr[d + 1] : nullptr;
-    const int64_t nc_dev = *A.n_complexes;
+    const int64_t nc_dev = A.n_complexes[o];
     const int64_t C = nc_dev < A.cap_c ? (nc_dev < 0 ? 0 : nc_dev) : A.cap_c;
-    const int region0 = A.set_start[set], region1 = A.set_start[set + 1];
+    const int region0 = sel3(set, A.set_start[0], A.set_start[1], A.set_start[2]);
+    const int region1 = sel3(set, A.set_start[1], A.set_start[2], A.set_start[3]);
     const int64_t groups = (A.cap_c + A.group - 1) / A.group;
     int base = 0;
     bool unfit = false;
@@ -323,13 +351,13 @@ __global__ __launch_bounds__(kThreads) void items_bwd_kernel(ItemsArgs A_) {
         int32_t r[kBInts];
         int cnt = 0, whole = 0;
         if (a < C) {
-            whole = G.classify(a, b, r);
+            whole = G.classify(load_range(A, o, a, b), r);
             if (whole == 1) {
                 cnt = 1;
             } else if (whole == -1) {
                 for (int64_t c = a; c < b; ++c) {
                     int32_t r1[kBInts];
-                    const int k = G.classify(c, c + 1, r1);
+                    const int k = G.classify(load_range(A, o, c, c + 1), r1);
                     cnt += k == 1 ? 1 : 0;
                     unfit = unfit || k < 0;
                 }
@@ -342,12 +370,12 @@ __global__ __launch_bounds__(kThreads) void items_bwd_kernel(ItemsArgs A_) {
         if (cnt > 0) {
             int slot = region0 + base + off;
             if (whole == 1) {
-                if (slot < region1) store_record(A.items + (size_t)slot * kBInts, r, kBInts);
+                if (slot < region1) store_record(items + (size_t)slot * kBInts, r, kBInts);
                 else unfit = true;
             } else {
                 for (int64_t c = a; c < b; ++c) {
-                    if (G.classify(c, c + 1, r) != 1) continue;
-                    if (slot < region1) store_record(A.items + (size_t)slot * kBInts, r, kBInts);
+                    if (G.classify(load_range(A, o, c, c + 1), r) != 1) continue;
+                    if (slot < region1) store_record(items + (size_t)slot * kBInts, r, kBInts);
                     else unfit = true;
                     ++slot;
                 }
@@ -356,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void items_bwd_kernel(ItemsArgs A_) {
         base += total;
     }
     for (int i = region0 + base + (int)threadIdx.x; i < region1; i += kThreads) {
-        int4* dst = reinterpret_cast<int4*>(A.items + (size_t)i * kBInts);
+        int4* dst = reinterpret_cast<int4*>(items + (size_t)i * kBInts);
 #pragma unroll
         for (int k = 0; k < kBInts / 4; ++k) dst[k] = make_int4(0, 0, 0, 0);
     }
