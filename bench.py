@@ -269,6 +269,23 @@ def main():
     else:
         dist = None
 
+    # what a first multi-GPU run needs to read off the line: how many ranks talk over what, which device each one holds
+    MULTI = {'rccl_ranks': world, 'backend': None if dist is None else dist.get_backend(),
+             'transport': None if dist is None else ('gloo over one shared GPU (CWN_BENCH_SHARE_GPU: control-flow test)' if share
+                                                     else 'RCCL (torch.distributed "nccl") over xGMI, one process per GPU')}
+    try:
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': torch.cuda.current_device(),
+                'name': torch.cuda.get_device_name(dev), 'pid': os.getpid(),
+                'hsa_ipc_legacy': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}
+        if dist is not None:
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            MULTI['ranks'] = allr
+        else:
+            MULTI['ranks'] = [mine]
+    except Exception as e:
+        MULTI['ranks_error'] = f'{type(e).__name__}: {e}'
+
     from cwn_amd import _ffi, csr, ops
     from cwn_amd import layers as layers_mod
     from cwn_amd.complex import ComplexBatch
@@ -291,8 +308,12 @@ def main():
                                embed_edge=True, use_coboundaries=True, graph_norm='bn')
         # CWN_BENCH_ATOMS=lo,hi (exploration, never the headline): molecule sizes other than the generator's 18 - 30 atoms,
         # e.g. 9,38 for the spread of the real ZINC subset (mixed launches / big items)
-        atoms = tuple(int(v) for v in os.environ.get('CWN_BENCH_ATOMS', '18,30').split(','))
-        gen = lambda seed: zinc_like_complexes(args.batch, seed, 6, n_lo=atoms[0], n_hi=atoms[1])
+        # ... or 'zinc': the size statistics of the real ZINC-12k subset (9 - 37 atoms, mean 23.2: cwn_amd/synthetic.py)
+        if os.environ.get('CWN_BENCH_ATOMS') == 'zinc':
+            gen = lambda seed: zinc_like_complexes(args.batch, seed, 6, size_dist='zinc')
+        else:
+            atoms = tuple(int(v) for v in os.environ.get('CWN_BENCH_ATOMS', '18,30').split(','))
+            gen = lambda seed: zinc_like_complexes(args.batch, seed, 6, n_lo=atoms[0], n_hi=atoms[1])
         coboundary = True
     elif WL == 'molhiv':  # exp/scripts/cwn-molhiv.sh:9-32, batch per BASELINE.json
         model = OGBEmbedSparseCIN(1, L, H, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum',
@@ -984,6 +1005,7 @@ def main():
             'roofline': roofline, 'roofline_other': roofline_other, 'roofline_mlp': roofline_mlp, 'roofline_plan_build': r_plan,
             'roofline_step': roofline_step,
             'cpu_baseline': cpu_baseline,
+            'multi_gpu': MULTI,
             'secondary': {'full_forward_cells_per_s': (round(full_cells_total / dt_full, 1)
                                                        if dt_full == dt_full else None),     # leg skipped: null, not NaN
                           'full_forward_ms': round(dt_full / full_steps * 1e3, 5) if dt_full == dt_full else None,
@@ -1068,6 +1090,36 @@ def main():
                 t = torch.tensor([dtt], device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dtt = float(t.item())
+                # what the collective costs the step: the SAME steps with the bucket's reduce calls turned into no-ops (every
+                # rank keeps its own gradient: numbers meaningless, kernels identical) -- exposed all-reduce time = the difference
+                try:
+                    bk = ts.bucket
+                    saved = (bk.reduce_chunk, bk.all_reduce_mean, bk.finish)
+                    bk.reduce_chunk = lambda *a, **k: None
+                    bk.all_reduce_mean = lambda *a, **k: None
+                    bk.finish = lambda *a, **k: None
+                    for i in range(3):
+                        ts.step(i % len(tb))
+                    barrier()
+                    t1 = time.perf_counter()
+                    for i in range(tsteps):
+                        ts.step(i % len(tb))
+                    barrier()
+                    dt_nc = time.perf_counter() - t1
+                    bk.reduce_chunk, bk.all_reduce_mean, bk.finish = saved
+                    t = torch.tensor([dt_nc], device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt_nc = float(t.item())
+                    MULTI.update({'bucket_bytes': int(bk.flat.numel() * 4), 'bucket_chunks': int(ts.n_stages),
+                                  'train_ms_per_step': round(dtt / tsteps * 1e3, 4),
+                                  'train_ms_per_step_without_collectives': round(dt_nc / tsteps * 1e3, 4),
+                                  'exposed_allreduce_ms_per_step': round((dtt - dt_nc) / tsteps * 1e3, 4),
+                                  'allreduce_wire_floor_ms': round(2 * (world - 1) / world * bk.flat.numel() * 4 / 153e9 * 1e3, 4),
+                                  'note': 'exposed = step with the chunked all-reduce issued inside the backward minus the same '
+                                          'kernels with the collectives turned off (max over ranks); wire floor = ring all-reduce of '
+                                          'the bucket at one xGMI link (~153 GB/s)'})
+                except Exception as e:
+                    MULTI['exposed_allreduce_error'] = f'{type(e).__name__}: {e}'
             tcells = torch.tensor([sum(batch_stats(tb[i % len(tb)])['cells'] for i in range(tsteps)) * L],
                                   device=dev, dtype=torch.float64)
             if dist is not None:
@@ -1190,12 +1242,19 @@ def main():
         workloads = {}
         # (+ the headline's own workload at batch 2048: the range where a launch has many items per CU and takes the
         # two-per-CU form of the layer kernel -- DESIGN.md 4.0b)
-        for wl in ('molhiv', 'reddit', 'zinc_batch2048'):
+        # (+ the headline's workload with the molecule sizes of the REAL ZINC subset -- 9 - 37 atoms, ~2 % beyond the 32 one
+        # workgroup holds at width 128: those become BIG records -- at batch 128 and 2048: VERDICT r3 item 5)
+        for wl in ('molhiv', 'reddit', 'zinc_batch2048', 'zinc_real_spread', 'zinc_real_spread_batch2048'):
             try:
-                extra = ['--workload', wl] if wl != 'zinc_batch2048' else ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1']
+                extra = {'zinc_batch2048': ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1'],
+                         'zinc_real_spread': ['--workload', 'zinc'],
+                         'zinc_real_spread_batch2048': ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1']}.get(wl, ['--workload', wl])
                 cmd = [sys.executable, os.path.abspath(__file__)] + extra + ['--brief', '--steps', str(max(args.steps, 20)),
                        '--warmup', str(max(args.warmup, 5)), '--kernel-reps', str(min(args.kernel_reps, 50))]
-                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                env_ = dict(os.environ)
+                if wl.startswith('zinc_real_spread'):
+                    env_['CWN_BENCH_ATOMS'] = 'zinc'
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env_)
                 line = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
                 if pr.returncode != 0 or not line:
                     raise RuntimeError(f'rc {pr.returncode}: {pr.stderr[-300:]}')

@@ -178,13 +178,20 @@ def ring_lift(n: int, bonds: Sequence[Tuple[int, int]], vx: torch.Tensor,
 # ------------------------------------------------------------------------------------------------
 def zinc_like_complexes(num: int, seed: int = 0, max_ring: int = 6, n_lo: int = 18, n_hi: int = 30,
                         atom_types: int = 28, bond_types: int = 4,
-                        include_down_adj: bool = False) -> List[Complex]:
+                        include_down_adj: bool = False, size_dist: str = 'uniform') -> List[Complex]:
     """`num` ZINC-shaped ring-lifted complexes with integer atom / bond types as [N,1] floats
-    (the form EmbedSparseCIN expects, mp/molec_models.py:95-99)."""
+    (the form EmbedSparseCIN expects, mp/molec_models.py:95-99).  size_dist: 'uniform' on [n_lo, n_hi] (SURVEY.md 8d's
+    generator: 18 - 30), or 'zinc': the published size statistics of the ZINC-12k subset the reference trains on (9 - 37 heavy
+    atoms, mean 23.2, standard deviation ~4.6: a clipped normal -- about 2 % of the molecules have more than 32 atoms, the
+    most one workgroup of the 16-wave layer kernel holds at width 128)."""
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(num):
-        n, bonds = random_molecule(rng, n_lo, n_hi)
+        if size_dist == 'zinc':
+            k = int(np.clip(np.rint(rng.normal(23.2, 4.6)), 9, 37))
+            n, bonds = random_molecule(rng, k, k)
+        else:
+            n, bonds = random_molecule(rng, n_lo, n_hi)
         vx = torch.from_numpy(rng.integers(0, atom_types, size=(n, 1))).float()
         ex = torch.from_numpy(rng.integers(0, bond_types, size=(len(bonds), 1))).float()
         y = torch.from_numpy(rng.standard_normal(1).astype(np.float32))

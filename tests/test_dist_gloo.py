@@ -322,3 +322,64 @@ def test_packed_loader_shards_every_global_batch_across_the_ranks():
     with pytest.raises(ValueError):
         PackedLoader(Fake(), 4, rank=2, world=2)
     assert len(PackedLoader(Fake(), 3, world=4)) == 0                       # a batch smaller than the world: nothing to shard
+
+
+# ---- world 8: the staged (chunk-by-chunk) reduce and the one-collective fallback of a jumping-knowledge model -----------------
+def _idx_of(rank):
+    return torch.tensor([(rank + k * (rank % 3 + 1)) % 5 for k in range(4)])
+
+
+def _staged_worker8(rank, world, port, ret, jk):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from cwn_amd.dist import FlatGradBucket, init_from_env
+    init_from_env('gloo')
+    n_local = 1 + (3 * rank) % 5                                     # unequal shards: the mean is weighted
+    if jk:
+        # the loss reads every layer's output (jump_mode: the REDDIT config): the backward cannot be cut -- recognised on the
+        # autograd graph -- and the step keeps ONE collective behind the whole backward
+        net, st, so, bucket, sp = _staged_setup()
+        st.begin()
+        assert st.stages(net(_idx_of(rank), jk=True), list(net.parameters())) is None
+        bucket = FlatGradBucket(net.parameters())
+        bucket.zero_()
+        net(_idx_of(rank), jk=True).backward()
+        bucket.all_reduce_mean(n_local=n_local)
+    else:
+        net, st, so, bucket, sp = _staged_setup()
+        bucket.zero_()
+        st.begin()
+        loss = net(_idx_of(rank))
+        for j in range(st.n_stages):
+            st.piece(j, loss, sp[j])
+            bucket.reduce_chunk(j, n_local)                          # in flight while the next piece runs
+        bucket.finish()
+    if rank in (0, world - 1):
+        ret[f'flat{rank}'] = bucket.flat.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('jk', [False, True])
+def test_eight_rank_staged_reduce_and_jumping_knowledge_fallback(jk):
+    """BASELINE configs[3] at the world size the node has (exp/scripts/cwn-zinc-full.sh:4-34 under DDP), without hardware:
+    eight gloo ranks with unequal shards run (a) the staged backward with the chunk-by-chunk reduce issued inside it and
+    (b) the one-collective step a jumping-knowledge model falls back to; first and last rank must hold the shard-weighted
+    mean of the eight per-rank gradients."""
+    from cwn_amd.dist import FlatGradBucket
+    world, port = 8, _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_staged_worker8, args=(world, port, ret, jk), nprocs=world, join=True)
+        first, last = ret['flat0'], ret[f'flat{world - 1}']
+    assert torch.equal(first, last)
+    ref, wsum = None, 0.0
+    for r in range(world):
+        net, st, so, bucket, sp = _staged_setup()
+        if jk:
+            bucket = FlatGradBucket(net.parameters())
+        bucket.zero_()
+        net(_idx_of(r), jk=jk).backward()
+        w = float(1 + (3 * r) % 5)
+        ref = w * bucket.flat if ref is None else ref + w * bucket.flat
+        wsum += w
+    torch.testing.assert_close(first, ref / wsum, rtol=1e-6, atol=1e-7)

@@ -800,3 +800,52 @@ def test_blocked_backward_launch_vs_float64_autograd(kind, n, F, eps, form):
             _gate(gys[d][0], gy1_ref[d], f'gY1[{d}]')
         if gy2_ref[d] is not None:
             _gate(gys[d][1], gy2_ref[d], f'gY2[{d}]')
+
+
+def _macrocycle_complexes(n, seed, max_ring):
+    """Molecules the ZINC generator does not make: a large ring of 9 .. 16 atoms with a few side chains and a fused hexagon,
+    ring-lifted with max_ring (exp/scripts/cwn-zinc.sh:24 lifts ZINC with max_ring_size 18; SURVEY 8d's generator stops at 6)."""
+    import numpy as np
+    from cwn_amd.synthetic import ring_lift
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.integers(9, 17))
+        bonds = [(i, (i + 1) % k) for i in range(k)]
+        m = k
+        a = int(rng.integers(0, k))                       # a hexagon fused on the bond (a, a + 1)
+        chain = [a] + list(range(m, m + 4)) + [(a + 1) % k]
+        bonds += [(chain[i], chain[i + 1]) for i in range(5)]
+        m += 4
+        for _ in range(int(rng.integers(0, 4))):          # side chains
+            bonds.append((int(rng.integers(0, m)), m))
+            m += 1
+        bonds = sorted({(min(u, v), max(u, v)) for u, v in bonds})
+        vx = torch.from_numpy(rng.integers(0, 28, size=(m, 1))).float()
+        ex = torch.from_numpy(rng.integers(0, 4, size=(len(bonds), 1))).float()
+        out.append(ring_lift(m, bonds, vx, ex, max_k=max_ring))
+    return out
+
+
+@pytest.mark.parametrize('F', [128, 64])
+def test_blocked_layer_on_rings_up_to_eighteen(F):
+    """exp/scripts/cwn-zinc.sh:24 lifts with max_ring_size 18: 2-cells with up to 16 boundary edges here (a ring of k edges
+    gives k (k - 1) upper-adjacency entries among them: 240 for one cell), through the blocked launch, the two-kernel path
+    and the float64 oracle -- untimed, parity only."""
+    from cwn_amd.complex import ComplexBatch
+    cxs = _macrocycle_complexes(24, 3, 18)
+    assert max(int(c.cochains[2].boundary_index[1].bincount().max()) for c in cxs) >= 12      # large rings really are cells
+    b = ComplexBatch.from_complex_list(cxs, max_dim=2).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    for d in range(3):
+        b.cochains[d].x = torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV)
+    conv = _conv(F, seed=8, eps=0.2)
+    ref = _oracle_scope(conv, b)
+    blocked, streamed = _run(conv, b, blocked=True), _run(conv, b, blocked=False)
+    for d in range(3):
+        _gate(blocked[2 * d], ref[d][0], f'max_ring 18, F = {F}: blocked out_up[{d}]')
+        _gate(blocked[2 * d + 1], ref[d][1], f'max_ring 18, F = {F}: blocked out_b[{d}]')
+        if F == 128:
+            assert torch.equal(blocked[2 * d], streamed[2 * d]) and torch.equal(blocked[2 * d + 1], streamed[2 * d + 1])
+        else:
+            _gate(streamed[2 * d], ref[d][0], f'max_ring 18, F = {F}: two-kernel out_up[{d}]')
