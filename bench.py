@@ -623,9 +623,11 @@ def main():
                 b.set_xs(feats[1])
                 params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
                 dims, plan_, table, _key = model.convs[1]._blocked_args(params, 0)
-                ops.layer_fused(dims, table, _ffi.LAYER_CSR_STORE)
-                load_us = replay_us(lambda: ops.layer_fused(dims, table, _ffi.LAYER_CSR_LOAD), args.kernel_reps)
-                store_us = replay_us(lambda: ops.layer_fused(dims, table, _ffi.LAYER_CSR_STORE), args.kernel_reps)
+                ll_ = ops.LayerLaunch(dims, table)         # (one launch per item table; BIG records get their scratch)
+                xs_ = [D_.x for D_ in dims]
+                ll_.run(xs_, _ffi.LAYER_CSR_STORE)
+                load_us = replay_us(lambda: ll_.run(xs_, _ffi.LAYER_CSR_LOAD), args.kernel_reps)
+                store_us = replay_us(lambda: ll_.run(xs_, _ffi.LAYER_CSR_STORE), args.kernel_reps)
             s0_ = stats[0]
             gemm_rows = (s0_['N0'] + s0_['N1']) + (s0_['N1'] + s0_['N2'])      # Y1 | Y2 rows of both GEMM dimensions
             flops = 2.0 * gemm_rows * H * H

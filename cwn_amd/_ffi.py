@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_slots', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
@@ -127,13 +127,25 @@ class MlpDim(C.Structure):
                 ('m_dev', C.c_void_p)]
 
 
+BN_SLOTS = 8                   # = CWN_BN_SLOTS
+
+
+class BnLive(C.Structure):
+    """cwn_bn_live (include/cwn_hip.h): a BatchNorm1d(train) whose statistics are summed by the producing launch and turned
+    into the affine by the consuming one."""
+    _fields_ = [('slots', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p),
+                ('running_var', C.c_void_p), ('num_batches_tracked', C.c_void_p), ('aff', C.c_void_p),
+                ('eps', C.c_float), ('momentum', C.c_float)]
+
+
 class StageDesc(C.Structure):
     """cwn_stage_desc (include/cwn_hip.h)."""
     _fields_ = [('X', C.c_void_p), ('X2', C.c_void_p), ('w_packed', C.c_void_p), ('w2_packed', C.c_void_p),
                 ('bias', C.c_void_p), ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('in_scale2', C.c_void_p),
                 ('in_shift2', C.c_void_p), ('Y', C.c_void_p), ('col_sum', C.c_void_p), ('col_sumsq', C.c_void_p),
                 ('M', C.c_int64), ('ldx', C.c_int64), ('ldx2', C.c_int64), ('ldy', C.c_int64),
-                ('in_relu', C.c_int32), ('pad_', C.c_int32), ('m_dev', C.c_void_p)]
+                ('in_relu', C.c_int32), ('pad_', C.c_int32), ('m_dev', C.c_void_p), ('stat_slots', C.c_void_p),
+                ('in_bn', BnLive), ('in_bn2', BnLive)]
 
 
 class StageBwdDesc(C.Structure):
@@ -191,7 +203,7 @@ class NormDesc(C.Structure):
                 ('mean', C.c_void_p), ('rstd', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p),
                 ('out', C.c_void_p), ('M', C.c_int64), ('lddy', C.c_int64), ('ldz', C.c_int64),
                 ('ldout', C.c_int64), ('N', C.c_int32), ('relu', C.c_int32), ('acc1', C.c_void_p), ('acc2', C.c_void_p),
-                ('m_dev', C.c_void_p)]
+                ('m_dev', C.c_void_p), ('bn', BnLive)]
 
 
 class GemmTnDesc(C.Structure):
@@ -504,7 +516,7 @@ def norm_bwd(descs: Sequence[NormDesc], device, accumulate: bool) -> None:
 # False: the row bands of a weight gradient are added with fp32 atomics (fastest: 1.48 ms ZINC training
 # step).  True: per-band partial tiles + a second launch that sums them in band order -- bit-reproducible
 # weight gradients for 0.14 ms more per step (17 extra launches).
-DETERMINISTIC_TN = False
+DETERMINISTIC_TN = os.environ.get('CWN_DETERMINISTIC_TN', '0') == '1'
 
 
 MAX_TN_DESCS = 24          # = CWN_GEMM_TN_MAX_DESCS
@@ -580,7 +592,7 @@ def _flush_descs(descs, device) -> None:
 def gemm_tn(descs: Sequence[GemmTnDesc], device, keep=None, deferrable: bool = False) -> None:
     """dW += dZ^T [X | X2] for every descriptor.  `deferrable`: the targets are buffers the caller owns until
     flush_tn (never tensors handed back to autograd); `keep`: every tensor a descriptor points at."""
-    if deferrable and _tn_queue is not None and not DETERMINISTIC_TN:
+    if deferrable and _tn_queue is not None:
         if not TN_SIDE_STREAM:
             _tn_queue.append((list(descs), keep, torch.device(device)))
             return

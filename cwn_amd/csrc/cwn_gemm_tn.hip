@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "../../include/cwn_hip.h"
+#include "cwn_split.h"
 
 namespace {
 
@@ -35,6 +36,7 @@ constexpr int kBandRows = 128;   // rows of M per workgroup at least; the launch
 constexpr int kMaxBandRows = 1024;
 constexpr int kLd = 80;          // LDS row stride in floats
 constexpr int kU = kChunk * (kTile / 4) / kThreads;   // 16-B loads per thread per tile (= 4)
+constexpr double kTnFixed2 = 4.0; // split kernel: prologue + epilogue of a workgroup in 64-row chunk-times (band choice below)
 
 struct TnBatch {       // a kernel argument: must stay under 4 KiB (static_assert below)
     cwn_gemm_tn_desc d[CWN_GEMM_TN_MAX_DESCS];
@@ -61,13 +63,13 @@ struct Src {                 // one logical [M, C1 + C2] operand made of up to t
     int relu;                // bit 0: first matrix, bit 1: second
 };
 
-template <bool FAST>
+template <bool FAST, int TW = kTile>
 __device__ __forceinline__ void tile_load(f32x4 (&v)[kU], const Src& S, int col0, int64_t row0,
                                           int64_t row_hi) {
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
         const int q = u * kThreads + threadIdx.x;
-        const int r = q / (kTile / 4), c = q % (kTile / 4);
+        const int r = q / (TW / 4), c = q % (TW / 4);
         const int64_t row = row0 + r < row_hi ? row0 + r : row_hi - 1;   // clamped, never faults
         const int col = col0 + 4 * c;
         const bool second = S.c2 > 0 && col >= S.c1;
@@ -93,9 +95,10 @@ struct Pro {
     int cc, cmax;
 };
 
+template <int TW = kTile>
 __device__ __forceinline__ Pro make_pro(const Src& S, int col0) {
-    static_assert(kThreads % (kTile / 4) == 0, "a thread keeps its columns");
-    const int c = threadIdx.x % (kTile / 4);
+    static_assert(kThreads % (TW / 4) == 0, "a thread keeps its columns");
+    const int c = threadIdx.x % (TW / 4);
     const int col = col0 + 4 * c;
     const bool second = S.c2 > 0 && col >= S.c1;
     Pro P;
@@ -237,6 +240,178 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_tn_kernel(TnBatch B) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe (round 4): both operands split three ways (cwn_split.h: x = hi + mid + lo, exact),
+// six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block instead of eight v_mfma_f32_16x16x4_f32 at twice their issue time each
+// -- 96 MFMA cycles where the fp32 pipe takes 256 -- with the dropped terms (<= 2^-26 |dz||x|) below the rounding of the fp32
+// accumulation, like the forward kernels.  What changes around the MFMAs:
+//   * a workgroup owns a 128 x 128 tile of dW (all of it at hidden 128: dZ and X are read ONCE per band, where 64 x 64
+//     tiles read each twice), its four waves 64 x 64 each (16 accumulator tiles);
+//   * a chunk is 32 rows of M.  A thread splits the float4s it loaded (prologue applied first) and stores 4 bf16 per plane
+//     ROW-MAJOR, [m][n] / [m][k] with a row stride of 144 bf16: a wave writes two full rows, every bank once;
+//   * an MFMA operand wants 8 CONSECUTIVE m for one n (or k): the column of a row-major tile.  gfx950's transposing LDS read
+//     does exactly that (ds_read_b64_tr_b16: a 16-lane group reads a 4 x 16 block, lane i supplying the address of
+//     [i / 4][4 (i % 4)] and receiving column i; semantics pinned by tools/proto/tr_read_probe.hip on the hardware): two of them
+//     per fragment.  The 8 reduction indices of lane group g are chunk rows {4g .. 4g+3} and {16+4g .. 16+4g+3} -- any
+//     bijection works as long as both operands use the same one, and this one makes the 32 lanes the LDS serves together read
+//     8 CONSECUTIVE rows, which at 72 dwords per row land on all 64 banks once (rows 8 apart would collide);
+//   * the bias gradient is summed from the registers of the load (a thread keeps its 4 columns for the whole band) and
+//     reduced once at the end of the band.
+// 55 KB of LDS, <= 256 VGPRs: two workgroups per CU.  Chosen when every operand is 16-B aligned (the FAST test below) unless
+// CWN_TN_SPLIT=0; the fp32-MFMA kernel above stays for the rest and for the comparison (tools/ubench_tn24.py).
+constexpr int kTile2 = 128;      // rows and columns of dW per workgroup
+constexpr int kChunk2 = 32;      // rows of M per LDS stage = the k of one MFMA
+constexpr int kLd2 = 144;        // LDS row stride in bf16 (72 dwords = 8 * 9)
+constexpr int kPlane = kChunk2 * kLd2;
+static_assert(kChunk2 * (kTile2 / 4) / kThreads == kU, "four 16-B loads per thread per operand");
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint2 lds_tr(const uint16_t* p) {
+    const v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+
+// one operand fragment (8 reduction indices of this lane group for column `col`) of the three planes at `base`
+__device__ __forceinline__ void frag3(const uint16_t* base, uint4& h, uint4& m, uint4& l) {
+    const uint2 h0 = lds_tr(base), h1 = lds_tr(base + 16 * kLd2);
+    const uint2 m0 = lds_tr(base + kPlane), m1 = lds_tr(base + kPlane + 16 * kLd2);
+    const uint2 l0 = lds_tr(base + 2 * kPlane), l1 = lds_tr(base + 2 * kPlane + 16 * kLd2);
+    h = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    m = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    l = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+// prologue + three-way split of the chunk a thread loaded, 4 bf16 per plane at [r][4c]; returns the column sums it saw
+__device__ __forceinline__ f32x4 tile_store_split(uint16_t* planes, const f32x4 (&v)[kU], const Pro& P, int64_t row0,
+                                                  int64_t row_hi) {
+    f32x4 colsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+        const int q = u * kThreads + threadIdx.x;
+        const int r = q / (kTile2 / 4), c = q % (kTile2 / 4);
+        const bool row_ok = row0 + r < row_hi;
+        f32x4 x = v[u];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float y = x[t];
+            const bool ok = row_ok && P.cc + t < P.cmax;
+            if (P.affine) y = y * P.sc[t] + P.sh[t];
+            if (P.relu) y = fmaxf(y, 0.f);
+            x[t] = ok ? y : 0.f;
+        }
+        colsum += x;
+        uint2 ph, pm, pl;
+        cwn::split4(make_float4(x[0], x[1], x[2], x[3]), ph, pm, pl);
+        uint16_t* dst = planes + r * kLd2 + 4 * c;
+        *reinterpret_cast<uint2*>(dst) = ph;
+        *reinterpret_cast<uint2*>(dst + kPlane) = pm;
+        *reinterpret_cast<uint2*>(dst + 2 * kPlane) = pl;
+    }
+    return colsum;
+}
+
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn_split_kernel(TnBatch B) {
+    __shared__ __attribute__((aligned(16))) uint16_t zp[3 * kPlane];
+    __shared__ __attribute__((aligned(16))) uint16_t xp[3 * kPlane];
+    int di = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_GEMM_TN_MAX_DESCS; ++i)
+        if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
+    const cwn_gemm_tn_desc& D = B.d[di];
+    const int tn = B.tiles_n[di], tk = B.tiles_k[di];
+    int b = blockIdx.x - B.blk_start[di];
+    const int tile_k = b % tk;
+    b /= tk;
+    const int tile_n = b % tn;
+    const int band = b / tn;
+    const int64_t Mcap = D.M;
+    const int64_t M = D.m_dev != nullptr ? (*D.m_dev < Mcap ? *D.m_dev : Mcap) : Mcap;
+    const int64_t row_lo = (int64_t)band * B.band_rows;
+    const int64_t cap_hi = row_lo + B.band_rows < Mcap ? row_lo + B.band_rows : Mcap;
+    const int64_t row_hi = row_lo + B.band_rows < M ? row_lo + B.band_rows : M;
+    const int n0 = tile_n * kTile2, k0 = tile_k * kTile2;
+    const int N = D.N, Ktot = D.K + D.K2;
+    const Src SZ{D.dZ, nullptr, D.lddz, 0, N, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    const Src SX{D.X, D.X2, D.ldx, D.ldx2, D.K, D.K2, D.in_scale, D.in_shift, D.in_scale2, D.in_shift2,
+                 D.in_relu};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+
+    cwn::frag_cd acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (cwn::frag_cd){0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = D.db != nullptr && tile_k == 0;
+
+    f32x4 vz[kU], vx[kU];
+    tile_load<true, kTile2>(vz, SZ, n0, row_lo, cap_hi);
+    tile_load<true, kTile2>(vx, SX, k0, row_lo, cap_hi);
+    if (row_lo >= row_hi && B.ws[di] == nullptr) return;
+    const Pro PZ = make_pro<kTile2>(SZ, n0), PX = make_pro<kTile2>(SX, k0);
+    // this lane's corner of a 4 x 16 block: row 4g + j / 4 (+ 16 for the second half), column 4 (j % 4)
+    const int frag_off = (4 * g + (j >> 2)) * kLd2 + 4 * (j & 3);
+    const uint16_t* const za = zp + frag_off + wn * 64;
+    const uint16_t* const xa = xp + frag_off + wk * 64;
+    for (int64_t row0 = row_lo; row0 < row_hi; row0 += kChunk2) {
+        __syncthreads();                          // everyone is done reading the previous chunk
+        const f32x4 cs = tile_store_split(zp, vz, PZ, row0, row_hi);
+        if (do_bias && !(B.dbg & 4)) bsum += cs;
+        tile_store_split(xp, vx, PX, row0, row_hi);
+        __syncthreads();
+        if (row0 + kChunk2 < row_hi) {            // next chunk in flight during the MFMAs
+            tile_load<true, kTile2>(vz, SZ, n0, row0 + kChunk2, cap_hi);
+            tile_load<true, kTile2>(vx, SX, k0, row0 + kChunk2, cap_hi);
+        }
+        if (B.dbg & 2) continue;
+        uint4 xh[4], xm[4], xl[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) frag3(xa + kt * 16, xh[kt], xm[kt], xl[kt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            uint4 zh, zm, zl;
+            frag3(za + nt * 16, zh, zm, zl);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = cwn::mfma_split6(zh, zm, zl, xh[kt], xm[kt], xl[kt], acc[nt][kt]);
+        }
+    }
+    // acc[nt][kt][r] = partial dW[n0 + wn*64 + nt*16 + 4g + r][k0 + wk*64 + kt*16 + j]
+    if (B.dbg & 1) return;
+    float* const ws = B.ws[di];
+    float* const wsW = ws != nullptr ? ws + (int64_t)band * N * Ktot : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
+                const int k = k0 + wk * 64 + kt * 16 + j;
+                if (n < N && k < Ktot) {
+                    if (wsW != nullptr) wsW[(int64_t)n * Ktot + k] = acc[nt][kt][r];
+                    else atomicAdd(D.dW + (int64_t)n * D.lddw + k, acc[nt][kt][r]);
+                }
+            }
+    if (do_bias) {
+        // thread t summed columns 4 (t % 32) .. +3 over the rows t / 32 + 8 u of every chunk: eight partial sums per column
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(zp);          // [8][128]
+        *reinterpret_cast<f32x4*>(red + (threadIdx.x / (kTile2 / 4)) * kTile2 + 4 * (threadIdx.x % (kTile2 / 4))) = bsum;
+        __syncthreads();
+        if (threadIdx.x < kTile2 && n0 + (int)threadIdx.x < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < kThreads / (kTile2 / 4); ++i) s += red[i * kTile2 + threadIdx.x];
+            if (ws != nullptr) ws[(int64_t)B.bands[di] * N * Ktot + (int64_t)band * N + n0 + threadIdx.x] = s;
+            else atomicAdd(D.db + n0 + threadIdx.x, s);
+        }
+    }
+}
+
 // second stage of the deterministic form: dW[n, k] += sum over the bands (in band order) of the
 // partial tiles; db likewise.  One thread per element, bands walked four at a time.
 __global__ __launch_bounds__(kThreads) void tn_reduce_kernel(TnBatch B) {
@@ -302,8 +477,13 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
         fast = fast && al16(D.dZ) && al16(D.X) && al16(D.X2) && D.lddz % 4 == 0 && D.ldx % 4 == 0 &&
                (D.K2 == 0 || D.ldx2 % 4 == 0) && D.N % 4 == 0 && D.K % 4 == 0 && D.K2 % 4 == 0;
         B.d[i] = D;
-        B.tiles_n[i] = (D.N + kTile - 1) / kTile;
-        B.tiles_k[i] = (D.K + D.K2 + kTile - 1) / kTile;
+    }
+    static const bool split_off = getenv("CWN_TN_SPLIT") != nullptr && atoi(getenv("CWN_TN_SPLIT")) == 0;
+    const bool split = fast && !split_off;           // the bf16-split kernel: 128 x 128 tiles, 32-row chunks, two per CU
+    const int tile = split ? kTile2 : kTile;
+    for (int i = 0; i < n; ++i) {
+        B.tiles_n[i] = (descs[i].N + tile - 1) / tile;
+        B.tiles_k[i] = (descs[i].K + descs[i].K2 + tile - 1) / tile;
     }
     // Rows of M per workgroup (workspace layouts are sized for kBandRows: an upper bound on the bands).  The chip holds
     // kResident workgroups of this kernel at once (4 per CU: 40 KB of LDS, 100 registers); a launch costs about
@@ -312,7 +492,8 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
     // 48.8 us at 128 / 192 / 256 / 320 / 384 / 448 / 512 rows (2200 ... 600 workgroups; tools/ubench_tn24.py with
     // CWN_TN_BAND), where doubling from 128 until <= 2048 workgroups had picked 256.
     static const int band_env = getenv("CWN_TN_BAND") ? atoi(getenv("CWN_TN_BAND")) : 0;     // tuning: fixed rows per workgroup
-    constexpr int64_t kResident = 1024;
+    const int64_t kResident = split ? 512 : 1024;
+    const double fixed = split ? kTnFixed2 : 6.0, per_chunk = split ? 0.5 : 1.0;    // (in 64-row chunk-times of the fp32 kernel)
     int band_rows = kBandRows;
     {
         double best = 0.0;
@@ -320,7 +501,7 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
             if (band_env >= kBandRows && band_env % kChunk == 0 && cand != band_env) continue;
             int64_t nb = 0;
             for (int i = 0; i < n; ++i) nb += ((descs[i].M + cand - 1) / cand) * B.tiles_n[i] * B.tiles_k[i];
-            const double cost = (double)((nb + kResident - 1) / kResident) * (6.0 + cand / (double)kChunk);
+            const double cost = (double)((nb + kResident - 1) / kResident) * (fixed + per_chunk * cand / (double)kChunk);
             if (cand == kBandRows || cost < best || (band_env == cand)) {
                 best = cost;
                 band_rows = cand;
@@ -348,7 +529,8 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
         }
     }
     hipStream_t stream = (hipStream_t)stream_;
-    if (fast) gemm_tn_kernel<true><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    if (split) gemm_tn_split_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    else if (fast) gemm_tn_kernel<true><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
     else gemm_tn_kernel<false><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
     if (workspace != nullptr) tn_reduce_kernel<<<dim3(64, n), dim3(kThreads), 0, stream>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/cwn_hip.h"
 #include "cwn_mem.h"
+#include "cwn_bn_live.h"
 
 namespace {
 
@@ -146,7 +147,9 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
     const int64_t Mv = D.m_dev != nullptr ? *D.m_dev : D.M;      // rows that exist (D.M: the capacity, bounds the addresses)
     const int tc = threadIdx.x % kTPR, tr = threadIdx.x / kTPR;
     const int N = D.N;
-    const bool has_norm = D.scale != nullptr;
+    // (activation only) a live BatchNorm (cwn_bn_live.h): the affine is derived here from the producing launch's slot sums
+    const bool live = MODE == 0 && D.bn.slots != nullptr;
+    const bool has_norm = D.scale != nullptr || live;
     const bool relu = D.relu != 0;
     const float invM = 1.0f / (float)(Mv > 0 ? Mv : 1);
     // (a band past the batch's own rows has nothing to do -- except the apply form's first band, which hands the sums on)
@@ -159,7 +162,26 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
         for (int v = 0; v < VEC; ++v) {
             scale[v] = 1.f; shift[v] = 0.f; mean[v] = 0.f; rstd[v] = 0.f; k1[v] = 0.f; k2[v] = 0.f;
         }
-        if (cok && has_norm) {
+        if constexpr (MODE == 0) {
+            if (live) {                               // (uniform) thread i < chunk width: column c0 + i; the first band writes
+                if ((int)threadIdx.x < kTPR * VEC && c0 + (int)threadIdx.x < N) {
+                    float sc, sh;
+                    cwn::bn_live_column(D.bn, N, Mv, c0 + threadIdx.x, row0 == 0, sc, sh);
+                    red[0][0][threadIdx.x] = sc;
+                    red[1][0][threadIdx.x] = sh;
+                }
+                __syncthreads();
+                if (cok) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        scale[v] = red[0][0][tc * VEC + v];
+                        shift[v] = red[1][0][tc * VEC + v];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (cok && has_norm && !live) {
             ld_vec<VEC>(scale, D.scale + c);
             ld_vec<VEC>(shift, D.shift + c);
             if constexpr (MODE != 0) {
@@ -360,6 +382,9 @@ int launch_norm(const cwn_norm_desc* descs, int n, cwn_stream_t stream_) {
         const cwn_norm_desc& D = descs[i];
         if (D.M < 0 || D.N <= 0) return CWN_ERR_BAD_ARG;
         if ((D.scale == nullptr) != (D.shift == nullptr)) return CWN_ERR_BAD_ARG;
+        if (D.bn.slots != nullptr && (MODE != 0 || D.scale != nullptr || D.bn.aff == nullptr || ((uintptr_t)D.bn.slots & 7u) ||
+                                      (D.bn.running_mean == nullptr) != (D.bn.running_var == nullptr)))
+            return CWN_ERR_BAD_ARG;
         if (D.M > 0) {
             if (D.z == nullptr || D.ldz < D.N) return CWN_ERR_BAD_ARG;
             if (MODE != 1 && (D.out == nullptr || D.ldout < D.N)) return CWN_ERR_BAD_ARG;

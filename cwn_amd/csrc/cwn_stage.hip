@@ -22,6 +22,7 @@
 #include "../../include/cwn_hip.h"
 #include "cwn_split.h"
 #include "cwn_mem.h"
+#include "cwn_bn_live.h"
 
 namespace {
 
@@ -65,6 +66,9 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
     constexpr size_t kPlaneElems = S::kPlaneElems, kBufBytes = S::kBufBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // 2 KiB next to the tiles: the affines a live BatchNorm prologue derives ([input][scale | shift][F] floats) and, behind the
+    // products, the workgroup's column statistics on their way to one coalesced atomic per column ([half][sum | sq][F] doubles)
+    __shared__ __attribute__((aligned(16))) double live_scratch[256];
     uint16_t* const buf0 = reinterpret_cast<uint16_t*>(smem);
     uint16_t* const buf1 = reinterpret_cast<uint16_t*>(smem + kBufBytes);
     int di = 0;
@@ -96,14 +100,18 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     // the prologue of an input: per-column affine (the producing stage's BatchNorm) and ReLU.  A thread's columns are the
     // same for every row it stages (kThreads is a multiple of F / 4): its constants are loaded once.
     struct Pro { float4 sc, sh; bool affine, relu; };
-    auto request_pro = [&](const float* scale, const float* shift, bool relu) {
+    auto request_pro = [&](const float* scale, const float* shift, bool relu, int live_slot) {
         Pro p;
         p.sc = make_float4(1.f, 1.f, 1.f, 1.f);
         p.sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        p.affine = scale != nullptr;
+        p.affine = scale != nullptr || live_slot >= 0;
         p.relu = relu;
-        if (p.affine) {
-            const int c4 = threadIdx.x % (F / 4);
+        const int c4 = threadIdx.x % (F / 4);
+        if (live_slot >= 0) {              // derived in this workgroup (below): [input][scale | shift][F] floats in LDS
+            const float4* aff = reinterpret_cast<const float4*>(live_scratch) + live_slot * 2 * (F / 4);
+            p.sc = aff[c4];
+            p.sh = aff[F / 4 + c4];
+        } else if (p.affine) {
             p.sc = reinterpret_cast<const float4*>(scale)[c4];
             p.sh = reinterpret_cast<const float4*>(shift)[c4];
         }
@@ -161,12 +169,28 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     // weight is a wait for the weight)
     request_rows(v0, D.X, D.ldx);
     if (row0 >= Mv) return;                         // (uniform) a tile past the batch's own rows: nothing to store or count
-    const Pro p0 = request_pro(D.in_scale, D.in_shift, (D.in_relu & 1) != 0);
-    Pro p1 = p0;
-    if (two) {
-        request_rows(v1, D.X2, D.ldx2);
-        p1 = request_pro(D.in_scale2, D.in_shift2, (D.in_relu & 2) != 0);
+    if (two) request_rows(v1, D.X2, D.ldx2);
+    const bool live0 = D.in_bn.slots != nullptr, live1 = D.in_bn2.slots != nullptr;
+    if (live0 || live1) {
+        // live BatchNorm prologue (cwn_bn_live.h): thread c < F the column c of X's record, thread F + c of X2's; the first
+        // workgroup of the descriptor writes what the backward reads and the running statistics
+        float* const aff = reinterpret_cast<float*>(live_scratch);
+        const bool writer = (int)blockIdx.x == B.blk_start[di];
+        const int which = threadIdx.x / F, col = threadIdx.x % F;
+        if (which < 2) {
+            const cwn_bn_live& L = which == 0 ? D.in_bn : D.in_bn2;
+            if (L.slots != nullptr) {
+                float sc, sh;
+                cwn::bn_live_column(L, F, Mv, col, writer, sc, sh);
+                aff[(which * 2) * F + col] = sc;
+                aff[(which * 2 + 1) * F + col] = sh;
+            }
+        }
+        __syncthreads();
     }
+    const Pro p0 = request_pro(D.in_scale, D.in_shift, (D.in_relu & 1) != 0, live0 ? 0 : -1);
+    Pro p1 = p0;
+    if (two) p1 = request_pro(D.in_scale2, D.in_shift2, (D.in_relu & 2) != 0, live1 ? 1 : -1);
     const int n0 = ct * 16 + kq * 4;                 // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = row (lane & 15)
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (D.bias != nullptr) b4 = *reinterpret_cast<const float4*>(D.bias + n0);
@@ -183,7 +207,8 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     // epilogue: + bias; the band's column statistics of the pre-normalisation value (fp64, the 16 rows of a lane group
     // through DPP, both row tiles summed in registers first, ONE plain store per column and band: no atomics, no zero
     // fill, deterministic -- as cwn_gemm_f32's); the rows of Z
-    const bool stats = D.col_sum != nullptr;
+    const bool slotted = D.stat_slots != nullptr;
+    const bool stats = D.col_sum != nullptr || slotted;
     double csum[4] = {0., 0., 0., 0.}, csq[4] = {0., 0., 0., 0.};
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) {
@@ -208,9 +233,25 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
             a += row_ror_f64<0x124>(a); b += row_ror_f64<0x124>(b);
             a += row_ror_f64<0x122>(a); b += row_ror_f64<0x122>(b);
             a += row_ror_f64<0x121>(a); b += row_ror_f64<0x121>(b);
-            if (l15 == 0 && slot < CWN_STAT_ROWS(Mv)) {
+            if (slotted) {
+                if (l15 == 0) {                       // (F = 64: two waves per column tile, one per 32-row half)
+                    const int half = wave / S::kNCT;
+                    live_scratch[(half * 2) * F + n0 + q] = a;
+                    live_scratch[(half * 2 + 1) * F + n0 + q] = b;
+                }
+            } else if (l15 == 0 && slot < CWN_STAT_ROWS(Mv)) {
                 D.col_sum[slot * F + n0 + q] = a;
                 D.col_sumsq[slot * F + n0 + q] = b;
+            }
+        }
+        if (slotted) {
+            // the workgroup's 2 F sums leave as 2 F / 64 fully coalesced fp64 atomic instructions
+            __syncthreads();
+            if (threadIdx.x < 2 * F) {
+                const int which = threadIdx.x / F, col = threadIdx.x % F;
+                double v = live_scratch[which * F + col];
+                if constexpr (TM > 32) v += live_scratch[(2 + which) * F + col];
+                unsafeAtomicAdd(D.stat_slots + (size_t)(((int)blockIdx.x % CWN_BN_SLOTS) * 2 + which) * F + col, v);
             }
         }
     }
@@ -485,6 +526,12 @@ extern "C" int cwn_dense_stage_f32(const cwn_stage_desc* descs, int n, int32_t F
         if ((D.in_scale == nullptr) != (D.in_shift == nullptr) || (D.in_scale2 == nullptr) != (D.in_shift2 == nullptr))
             return CWN_ERR_BAD_ARG;
         if ((D.col_sum == nullptr) != (D.col_sumsq == nullptr)) return CWN_ERR_BAD_ARG;
+        if (D.stat_slots != nullptr && (D.col_sum != nullptr || ((uintptr_t)D.stat_slots & 7u))) return CWN_ERR_BAD_ARG;
+        if (D.in_bn.slots != nullptr && (D.in_scale != nullptr || D.in_bn.aff == nullptr || !al16(D.in_bn.aff))) return CWN_ERR_BAD_ARG;
+        if (D.in_bn2.slots != nullptr && (D.X2 == nullptr || D.in_scale2 != nullptr || D.in_bn2.aff == nullptr || !al16(D.in_bn2.aff)))
+            return CWN_ERR_BAD_ARG;
+        if ((D.in_bn.running_mean == nullptr) != (D.in_bn.running_var == nullptr)) return CWN_ERR_BAD_ARG;
+        if ((D.in_bn2.running_mean == nullptr) != (D.in_bn2.running_var == nullptr)) return CWN_ERR_BAD_ARG;
         if (D.ldx < F || D.ldy < F || D.ldx % 4 || D.ldy % 4 || (D.X2 != nullptr && (D.ldx2 < F || D.ldx2 % 4)))
             return CWN_ERR_BAD_ARG;
         if (!(al16(D.X) && al16(D.X2) && al16(D.Y) && al16(D.w_packed) && al16(D.w2_packed) && al16(D.bias) && al16(D.in_scale) &&

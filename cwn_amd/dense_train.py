@@ -43,6 +43,13 @@ FUSED_NORM_BACKWARD = False
 # The apply half of the BatchNorm backward as the PROLOGUE of the input-gradient GEMM that consumes it (cwn_gemm_bnb): no
 # apply launch, dz written once on the way.  False: cwn_norm_bwd_apply_f32 + a plain transposed-weight GEMM (A/B, tests).
 FUSED_NORM_APPLY = os.environ.get('CWN_FUSED_NORM_APPLY') != '0'
+# A BatchNorm without a launch of its own (include/cwn_hip.h: cwn_bn_live; round 4): the stage launch adds its workgroups'
+# column sums into 8 fp64 slot rows, every workgroup of the NEXT launch (the following stage, or the activation of the
+# layer's last stage) derives the affine from them in its prologue and its first workgroup writes what the backward reads and
+# the running statistics -- the 12 cwn_bn_finalize_f32 launches of a ZINC training step (5.9 us each) are gone.  Needs every
+# stage on cwn_dense_stage_f32 (width 64 / 128, packed blocks); CWN_LIVE_BN=0 restores the finalize launches (whose per-band
+# partials summed in band order are the bit-reproducible form).
+LIVE_BN = os.environ.get('CWN_LIVE_BN', '1') != '0'
 # (Measured and dropped: the REDUCE half of the next stage -- column sums of dyh, dyh * xhat -- taken in the epilogue of the
 # backward-stage launch that produces its dy, the tile still in registers, so that 8 of the 12 reduce launches of a ZINC step
 # go away.  A workgroup of cwn_dense_stage_bwd_f32 owns 32 rows: 428 workgroups x 256 column sums = 110 k fp32 atomics per
@@ -135,22 +142,56 @@ class _DenseTrain(torch.autograd.Function):
             for st in plan.up[i] + plan.bd[i] + [plan.cb[i]]:
                 rows_of[id(st)] = ops.stat_rows(A0[i][0].size(0))
         widths = [st.lin.out_features for st in bns]
-        stats = torch.empty(2 * sum(rows_of[id(st)] * w for st, w in zip(bns, widths)),
-                            dtype=torch.float64, device=dev)
+        F0 = int(A0[0][0].size(1))
+        live = bool(LIVE_BN and ops.STAGE_KERNEL and bns and len(bns) == len(stages) and F0 in (64, 128) and 2 * nd <= _ffi.MAX_DESCS
+                    and all(a.size(1) == F0 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 for pair in A0 for a in pair)
+                    and all(tuple(P[id(st)][0].shape) == (F0, F0) and ops.packed_stage_block(P[id(st)][0], 0) is not None
+                            for i in range(nd) for st in plan.up[i] + plan.bd[i])
+                    and all(tuple(P[id(st)][0].shape) == (F0, 2 * F0) and ops.packed_stage_block(P[id(st)][0], 0) is not None
+                            and ops.packed_stage_block(P[id(st)][0], F0) is not None for st in plan.cb)
+                    and all(t is None or (t.numel() == F0 and t.data_ptr() % 16 == 0 and t.is_contiguous())
+                            for st in stages for t in P[id(st)][1:]))
         affs = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
-        # the backward pass' column sums (s1, s2 per BatchNorm stage): allocated here and CLEARED by cwn_bn_finalize_f32,
-        # so that the backward launches no fill for them
-        sums = torch.empty(2 * sum(widths), dtype=torch.float32, device=dev)
-        stat_of, aff_of, sum_of, o, so = {}, {}, {}, 0, 0
+        stat_of, aff_of, sum_of, slot_of, o, so = {}, {}, {}, {}, 0, 0
+        if live:
+            # slot sums (fp64) and the backward's s1 / s2 (fp32) of every BatchNorm: ONE zeroed region (the step arena's, when a
+            # step driver brackets the step: no fill of their own)
+            nb, nw = len(bns), sum(widths)
+            zero = ops.zeros_scratch(8 * _ffi.BN_SLOTS * 2 * nw + 4 * 2 * nw, dev)
+            slots = zero[:8 * _ffi.BN_SLOTS * 2 * nw].view(torch.float64)
+            sums = zero[8 * _ffi.BN_SLOTS * 2 * nw: 8 * _ffi.BN_SLOTS * 2 * nw + 4 * 2 * nw].view(torch.float32)
+            stats = None
+        else:
+            stats = torch.empty(2 * sum(rows_of[id(st)] * w for st, w in zip(bns, widths)),
+                                dtype=torch.float64, device=dev)
+            # the backward pass' column sums (s1, s2 per BatchNorm stage): allocated here and CLEARED by cwn_bn_finalize_f32,
+            # so that the backward launches no fill for them
+            sums = torch.empty(2 * sum(widths), dtype=torch.float32, device=dev)
         for st, w in zip(bns, widths):
             r = rows_of[id(st)]
-            stat_of[id(st)] = stats[so: so + 2 * r * w].view(2, r, w)
-            so += 2 * r * w
+            if live:
+                slot_of[id(st)] = slots[_ffi.BN_SLOTS * 2 * o: _ffi.BN_SLOTS * 2 * (o + w)].view(_ffi.BN_SLOTS, 2, w)
+            else:
+                stat_of[id(st)] = stats[so: so + 2 * r * w].view(2, r, w)
+                so += 2 * r * w
             aff_of[id(st)] = affs[4 * o: 4 * o + 4 * w].view(4, w)
             sum_of[id(st)] = sums[2 * o: 2 * o + 2 * w].view(2, w)
             o += w
 
+        def live_record(st: Optional[Stage]):
+            """The cwn_bn_live record with which a consumer of `st`'s output derives its BatchNorm."""
+            if not live or st is None:
+                return None
+            n = st.norm
+            _, _, gamma, beta = P[id(st)]
+            return _ffi.BnLive(slots=slot_of[id(st)].data_ptr(), gamma=_ffi.ptr(gamma), beta=_ffi.ptr(beta),
+                               running_mean=n.running_mean.data_ptr(), running_var=n.running_var.data_ptr(),
+                               num_batches_tracked=n.num_batches_tracked.data_ptr(), aff=aff_of[id(st)].data_ptr(),
+                               eps=float(n.eps), momentum=float(n.momentum))
+
         def finalize(group: Sequence[Tuple[Stage, int]]):
+            if live:
+                return
             descs = []
             for st, M in group:
                 if not st.is_bn:
@@ -169,10 +210,18 @@ class _DenseTrain(torch.autograd.Function):
 
         def prologue(st: Optional[Stage]):
             """(scale, shift) of the producing stage for the consumer's prologue."""
-            if st is None or not st.is_bn:
+            if st is None or not st.is_bn or live:
                 return None, None
             a = aff_of[id(st)]
             return a[0], a[1]
+
+        def run(gemms):
+            res = ops.run_stage(gemms, dev)          # cwn_dense_stage_f32 when the blocks are packed (ops.STAGE_KERNEL)
+            if res is None:
+                if live:
+                    raise RuntimeError('dense_train: a stage left cwn_dense_stage_f32 in live-BatchNorm mode (set CWN_LIVE_BN=0)')
+                res = ops.run_gemm(gemms, dev)
+            return res
 
         Z = [[[None] * depth, [None] * depth] for _ in range(nd)]   # Z[dim][branch][stage]
         for s in range(depth):
@@ -185,11 +234,10 @@ class _DenseTrain(torch.autograd.Function):
                     sc, sh = prologue(chain[s - 1] if s > 0 else None)
                     gemms.append(ops.Gemm(X=X, W=W, bias=b, in_scale=sc, in_shift=sh,
                                           in_relu=1 if s > 0 else 0,
-                                          col_stats=stat_of.get(id(st))))
+                                          col_stats=stat_of.get(id(st)), stat_slots=slot_of.get(id(st)),
+                                          in_bn=live_record(chain[s - 1] if s > 0 else None)))
                     group.append((st, X.size(0)))
-            res = ops.run_stage(gemms, dev)          # cwn_dense_stage_f32 when the blocks are packed (ops.STAGE_KERNEL)
-            if res is None:
-                res = ops.run_gemm(gemms, dev)
+            res = run(gemms)
             k = 0
             for i in range(nd):
                 for br in (0, 1):
@@ -203,15 +251,21 @@ class _DenseTrain(torch.autograd.Function):
             sc, sh = prologue(plan.up[i][-1])
             sc2, sh2 = prologue(plan.bd[i][-1])
             gemms.append(ops.Gemm(X=Z[i][0][-1], X2=Z[i][1][-1], W=W, bias=b, in_scale=sc, in_shift=sh,
-                                  in_scale2=sc2, in_shift2=sh2, in_relu=3, col_stats=stat_of.get(id(st))))
+                                  in_scale2=sc2, in_shift2=sh2, in_relu=3, col_stats=stat_of.get(id(st)),
+                                  stat_slots=slot_of.get(id(st)), in_bn=live_record(plan.up[i][-1]),
+                                  in_bn2=live_record(plan.bd[i][-1])))
             group.append((st, Z[i][0][-1].size(0)))
-        Z3 = ops.run_stage(gemms, dev)
-        if Z3 is None:
-            Z3 = ops.run_gemm(gemms, dev)
+        Z3 = run(gemms)
         finalize(group)
         H = [torch.empty_like(z) for z in Z3]
-        _ffi.norm_act([_norm_desc(z, out=h, aff=aff_of.get(id(plan.cb[i])))
-                       for i, (z, h) in enumerate(zip(Z3, H)) if z.numel()], dev)
+        acts = []
+        for i, (z, h) in enumerate(zip(Z3, H)):
+            if z.numel():
+                d = _norm_desc(z, out=h, aff=None if live else aff_of.get(id(plan.cb[i])))
+                if live:
+                    d.bn = live_record(plan.cb[i])
+                acts.append(d)
+        _ffi.norm_act(acts, dev)
         if bns:
             ops.state_changed()      # bn_finalize wrote the running statistics (and the batch counters) through raw pointers
         ctx.plan = plan

@@ -7,7 +7,7 @@ dimension) in ONE kernel launch forward and ONE launch backward; `aggregate` is 
 form.  There is no CPU path here by design; `oracle/` is the CPU checker.
 """
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import ctypes as C
 import os
@@ -865,6 +865,11 @@ class Gemm:
                                          # (inference: one split per weight version, not per workgroup)
     add_out: bool = False                # `out` += the product instead of `out` = the product (no other writer of `out`)
     bnb: Optional[object] = None         # _ffi.GemmBnb: X is dy of a BatchNorm / ReLU stage, the GEMM multiplies its dz (w_trans only)
+    # cwn_dense_stage_f32 only (include/cwn_hip.h: cwn_bn_live): the statistics of Y go to `stat_slots` ([BN_SLOTS, 2, F] fp64,
+    # zero on entry); the prologue of X / X2 is the BatchNorm record `in_bn` / `in_bn2` (_ffi.BnLive), derived in the kernel
+    stat_slots: Optional[Tensor] = None
+    in_bn: Optional[object] = None
+    in_bn2: Optional[object] = None
 
     def desc(self, Y: Tensor, packed: bool = False) -> _ffi.GemmDesc:
         X, W, X2 = self.X, self.W, self.X2
@@ -923,6 +928,8 @@ def run_gemm(gemms: Sequence[Gemm], device) -> List[Tensor]:
     """Raw grouped launch (no autograd)."""
     outs, descs = [], []
     for gm in gemms:
+        if gm.stat_slots is not None or gm.in_bn is not None or gm.in_bn2 is not None:
+            raise RuntimeError('a live BatchNorm record (cwn_bn_live) is served by cwn_dense_stage_f32 only')
         gm.X, gm.W = _rowmajor(gm.X, 'X'), _rowmajor(gm.W, 'W')
         if gm.X2 is not None:
             gm.X2 = _rowmajor(gm.X2, 'X2')
@@ -1600,6 +1607,71 @@ def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True) 
                 _packed_stage[_stage_key(w, c0)] = (_stage_token, o, ot, weight._version, WEIGHT_EPOCH)
 
 
+# ---- the step arena: the zeroed scratch of a training step ------------------------------------------------------------
+# What a step needs ZERO on entry -- the slot sums of every live BatchNorm (cwn_bn_live), the s1 / s2 sums of their backward --
+# used to be cleared by launches of their own (cwn_bn_finalize_f32 cleared the backward sums; a live BatchNorm has no such
+# launch).  A driver of whole steps (train.TrainStep) brackets each with step_arena(device): ONE fill over the bytes the
+# previous steps used, then zeros_scratch() hands out regions of it in call order; outside such a bracket zeros_scratch() is a
+# torch.zeros.  A region lives until the NEXT step begins: fine for everything a step's own forward + backward touch, not for a
+# graph kept beyond its step (retain_graph into the next step).
+_ARENA_MIN = 1 << 22
+
+
+class _Arena:
+    def __init__(self, device):
+        self.buf = torch.zeros(_ARENA_MIN, dtype=torch.uint8, device=device)
+        self.used = 0             # bytes handed out in the current step
+        self.high = 0             # bytes ever handed out: everything behind is still zero
+        self.want = 0             # bytes the last step asked for beyond the buffer
+        self.active = False
+        self.retired = []
+
+
+_arenas: Dict[torch.device, '_Arena'] = {}
+
+
+class step_arena:
+    """with ops.step_arena(device): ...one training step..."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        a = _arenas.get(self.device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if a is None or (a.want and not capturing):
+            size = _ARENA_MIN if a is None else max(2 * a.buf.numel(), 2 * (a.buf.numel() + a.want))
+            a = _arenas[self.device] = _Arena(self.device) if a is None else a
+            if a.buf.numel() < size:
+                a.retired.append(a.buf)          # (captured steps keep replaying into the buffer they were captured with)
+                a.buf = torch.zeros(size, dtype=torch.uint8, device=self.device)
+                a.high = 0
+            a.want = 0
+        if a.high:
+            a.buf[:a.high].zero_()
+        a.used, a.active = 0, True
+        return self
+
+    def __exit__(self, *exc):
+        a = _arenas[self.device]
+        a.active = False
+        return False
+
+
+def zeros_scratch(nbytes: int, device) -> Tensor:
+    """`nbytes` of zeroed device memory (uint8, 256-B aligned) -- a region of the step arena inside step_arena(), else fresh."""
+    a = _arenas.get(torch.device(device))
+    n = (int(nbytes) + 255) // 256 * 256
+    if a is not None and a.active:
+        if a.used + n <= a.buf.numel():
+            out = a.buf[a.used: a.used + n]
+            a.used += n
+            a.high = max(a.high, a.used)
+            return out
+        a.want += n               # (the next bracket outside a capture grows the buffer)
+    return torch.zeros(n, dtype=torch.uint8, device=device)
+
+
 def packed_stage_block(weight: Tensor, col0: int, transposed: bool = False) -> Optional[Tensor]:
     """The packed block weight[:, col0 : col0 + F] (or the block of the transposed weight) written by the LATEST
     pack_stage_weights_many call, or None."""
@@ -1680,13 +1752,22 @@ def run_stage(gemms: Sequence['Gemm'], device) -> Optional[List[Tensor]]:
         M = int(X.size(0))
         if cs is not None and (cs.dtype != torch.float64 or tuple(cs.shape) != (2, stat_rows(M), F) or not cs.is_contiguous()):
             return None
+        ss = g.stat_slots
+        if ss is not None and (cs is not None or ss.dtype != torch.float64 or tuple(ss.shape) != (_ffi.BN_SLOTS, 2, F)
+                               or not ss.is_contiguous()):
+            return None
         Y = torch.empty(M, F, dtype=torch.float32, device=X.device)
         ld = lambda t: int(t.stride(0)) if t.size(0) > 1 else F
         arr[k] = _ffi.StageDesc(X=X.data_ptr(), X2=_ffi.ptr(X2), w_packed=w1.data_ptr(), w2_packed=_ffi.ptr(w2),
                                 bias=_ffi.ptr(cons[0]), in_scale=_ffi.ptr(cons[1]), in_shift=_ffi.ptr(cons[2]),
                                 in_scale2=_ffi.ptr(cons[3]), in_shift2=_ffi.ptr(cons[4]), Y=Y.data_ptr(),
                                 col_sum=None if cs is None else cs[0].data_ptr(), col_sumsq=None if cs is None else cs[1].data_ptr(),
-                                M=M, ldx=ld(X), ldx2=0 if X2 is None else ld(X2), ldy=F, in_relu=int(g.in_relu), m_dev=_ffi.dyn(M))
+                                M=M, ldx=ld(X), ldx2=0 if X2 is None else ld(X2), ldy=F, in_relu=int(g.in_relu), m_dev=_ffi.dyn(M),
+                                stat_slots=_ffi.ptr(ss))
+        if g.in_bn is not None:
+            arr[k].in_bn = g.in_bn
+        if g.in_bn2 is not None:
+            arr[k].in_bn2 = g.in_bn2
         keep += cons + [w1, w2]
         outs.append(Y)
     _ffi.check(_ffi.lib().cwn_dense_stage_f32(arr, len(gemms), F, _ffi.stream_ptr(device)), 'cwn_dense_stage_f32')

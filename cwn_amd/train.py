@@ -287,9 +287,10 @@ class TrainStep:
             if self.rebuild_plans:
                 b.forget_plans().prepare(backward=True)
             self.bucket.zero_()
-            loss = self._loss(b)
-            with ops.accumulate_into_grad():        # gradients are views into self.bucket: kernels add in place
-                loss.backward()
+            with ops.step_arena(self.bucket.flat.device):   # (what the step needs zero on entry: one fill for all of it)
+                loss = self._loss(b)
+                with ops.accumulate_into_grad():        # gradients are views into self.bucket: kernels add in place
+                    loss.backward()
             self._restore(i)                          # drop the references to the autograd graph
             return loss.detach()
         S = self.n_stages
@@ -299,12 +300,15 @@ class TrainStep:
                 if self.rebuild_plans:
                     b.forget_plans().prepare(backward=True)
                 self.bucket.zero_()
+                self._arena = ops.step_arena(self.bucket.flat.device)
+                self._arena.__enter__()
                 self.staged.begin()
                 self._live_loss = self._loss(b)
             with ops.accumulate_into_grad():
                 self.staged.piece(j, self._live_loss, self.stage_params[j])
             if j == S - 1:
                 loss, self._live_loss = self._live_loss.detach(), None
+                self._arena.__exit__(None, None, None)
                 self._restore(i)
                 return loss
         return self._live_loss.detach()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 17
+#define CWN_ABI_VERSION 18
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -536,6 +536,31 @@ int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* l
                                          cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A BatchNorm1d(train) WITHOUT a launch of its own (round 4; torch.nn.BatchNorm1d inside update_up_nn / update_boundaries_nn /
+ * combine_nn, mp/layers.py:303-325, exp/train_utils.py:57-75 in training mode): the launch that PRODUCES the pre-normalisation
+ * values adds its workgroups' column sums into `slots` (fp64 atomics, one coalesced instruction per 64 columns and workgroup,
+ * workgroup b into slot b % CWN_BN_SLOTS so that an address sees M / (32 * CWN_BN_SLOTS) adds); every workgroup of the launch
+ * that CONSUMES them sums the slots in slot order and derives mean / rstd / scale / shift for its columns in its prologue
+ * (cwn_bn_finalize_f32's arithmetic), and the FIRST workgroup of the consuming descriptor also writes `aff` (what the backward
+ * reads) and updates the running statistics and the batch counter.  `slots` must be ZERO before the producing launch (the
+ * caller's per-step fill -- cwn_amd/ops.py: step arena); slots == NULL: the record is unused.  The order of the adds inside a
+ * slot is the order of arrival: the sums are fp64, so two runs differ by ~1e-16 relative before they are rounded to fp32 --
+ * reproducible in practice, not by construction; cwn_bn_finalize_f32 over per-band partials stays the deterministic form.
+ * ------------------------------------------------------------------------------------------ */
+#define CWN_BN_SLOTS 8
+typedef struct cwn_bn_live {
+    double* slots;                 /* [CWN_BN_SLOTS][2][N]: column sums, column sums of squares */
+    const float* gamma;            /* [N] or NULL (= 1) */
+    const float* beta;             /* [N] or NULL (= 0) */
+    float* running_mean;           /* [N] or NULL */
+    float* running_var;
+    int64_t* num_batches_tracked;  /* or NULL */
+    float* aff;                    /* [4][N] out: scale, shift, mean, rstd (16-B aligned) */
+    float eps;
+    float momentum;
+} cwn_bn_live;
+
+/* ------------------------------------------------------------------------------------------
  * One STAGE of the same networks in TRAINING mode (csrc/cwn_stage.hip), up to CWN_MAX_DESCS products per launch:
  *
  *     Y = prologue([X | X2]) W^T + bias      col_sum / col_sumsq [CWN_STAT_ROWS(M), F]: per-32-row-band sums of Y, Y^2 (fp64)
@@ -566,6 +591,10 @@ typedef struct cwn_stage_desc {
     int32_t pad_;
     const int64_t* m_dev;    /* or NULL: actual rows (M = capacity; col_sum / col_sumsq hold CWN_STAT_ROWS(M) bands, the first
                                 CWN_STAT_ROWS(*m_dev) are written) */
+    double* stat_slots;      /* or NULL: the statistics of Y go HERE ([CWN_BN_SLOTS][2][F], see cwn_bn_live) instead of col_sum */
+    cwn_bn_live in_bn;       /* .slots != NULL: the prologue of X is this BatchNorm, derived in the kernel (in_scale / in_shift
+                                must then be NULL) */
+    cwn_bn_live in_bn2;      /* the same for X2 */
 } cwn_stage_desc;
 int cwn_dense_stage_f32(const cwn_stage_desc* descs_host, int n, int32_t F, cwn_stream_t stream);
 /* ... and BACKWARD (autograd of the Linear / BatchNorm1d(train) / ReLU modules of mp/layers.py:303-325): dX = dz W (two halves
@@ -758,6 +787,7 @@ typedef struct cwn_norm_desc {
     float* acc1;         /* backward apply only, or NULL: acc1[n] += s1[n]  (beta.grad: d beta = s1) */
     float* acc2;         /* backward apply only, or NULL: acc2[n] += s2[n]  (gamma.grad: d gamma = s2); one writer per column */
     const int64_t* m_dev; /* or NULL: actual rows (M = capacity) */
+    cwn_bn_live bn;       /* cwn_norm_act_f32 only; .slots != NULL: scale / shift are derived in the kernel (both NULL here) */
 } cwn_norm_desc;
 
 /* out = act(z * scale + shift)                                    (the last stage's output) */

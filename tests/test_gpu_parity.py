@@ -1555,6 +1555,69 @@ def test_fused_training_layer_matches_torch_modules(norm, hidden, use_cob):
             assert torch.equal(bf[name], t), name
 
 
+@pytest.mark.parametrize('hidden', [128, 64])
+def test_live_batchnorm_matches_the_finalize_launches(hidden):
+    """cwn_bn_live (round 4): the stage launches sum the statistics into slots and the consuming launches derive the affine --
+    no cwn_bn_finalize_f32 launch -- against the same layer with CWN_LIVE_BN off (per-band partials + finalize): outputs,
+    input gradients, parameter gradients, running statistics and batch counters, inside a step arena and outside one; a
+    batch with an empty dimension (no 2-cells) included."""
+    from cwn_amd import _ffi, dense_train as DT, layers, ops
+    from cwn_amd.synthetic import zinc_like_batch
+    fused, _ = _train_layer_pair(torch.nn.BatchNorm1d, hidden, True)
+    state0 = {k: v.clone() for k, v in fused.state_dict().items()}
+    calls = []
+    orig = _ffi.bn_finalize
+    _ffi.bn_finalize = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+
+    def run(b, live, arena):
+        fused.load_state_dict(state0)
+        fused.zero_grad(set_to_none=True)
+        ops.weights_changed()
+        # (the model's forward packs the blocks of every update / combine Linear for cwn_dense_stage_f32: models.py)
+        ops.pack_stage_weights_many([lin.weight for lvl in fused.mp_levels
+                                     for net in (lvl.update_up_nn, lvl.update_boundaries_nn, lvl.combine_nn)
+                                     for lin, _ in layers._mlp_stages(net)])
+        DT.LIVE_BN = live
+        g = torch.Generator().manual_seed(3)
+        xin = [(torch.randn(b.cochains[d].num_cells, hidden, generator=g).to(DEV)).requires_grad_() for d in range(3)]
+        ws = [torch.randn(b.cochains[d].num_cells, hidden, generator=g).to(DEV) for d in range(3)]
+        b.set_xs(xin)
+        params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+        ctx = ops.step_arena(DEV) if arena else contextlib.nullcontext()
+        with ctx:
+            out = fused(*params)
+            sum((o * w).sum() for o, w in zip(out, ws)).backward()
+        torch.cuda.synchronize()
+        return ([o.detach().clone() for o in out], [x.grad.clone() for x in xin],
+                {n: p.grad.clone() for n, p in fused.named_parameters() if p.grad is not None},
+                {n: t.clone() for n, t in fused.named_buffers()})
+
+    import contextlib
+    try:
+        for b in (zinc_like_batch(24, seed=5, device=DEV), zinc_like_batch(3, seed=8, device=DEV)):
+            calls.clear()
+            ref = run(b, False, False)
+            assert calls, 'the finalize form did not launch cwn_bn_finalize_f32'
+            for arena in (False, True, True):           # (twice inside the arena: the second step starts from its fill)
+                calls.clear()
+                got = run(b, True, arena)
+                assert not calls, 'live BatchNorm still launched cwn_bn_finalize_f32'
+                for a, r in zip(got[0] + got[1], ref[0] + ref[1]):
+                    torch.testing.assert_close(a, r, rtol=2e-5, atol=2e-5 * max(1.0, float(r.abs().max())))
+                assert got[2].keys() == ref[2].keys()
+                for n in ref[2]:
+                    sc = 40.0 if n.endswith(('eps1', 'eps2')) else max(1.0, float(ref[2][n].abs().max()))   # (a scalar: the sum
+                    torch.testing.assert_close(got[2][n], ref[2][n], rtol=1e-4, atol=5e-5 * sc, msg=n)      #  of ~1e5 cancelling terms)
+                for n, t in ref[3].items():
+                    if t.dtype.is_floating_point:
+                        torch.testing.assert_close(got[3][n], t, rtol=1e-6, atol=1e-7, msg=n)
+                    else:
+                        assert torch.equal(got[3][n], t), n
+    finally:
+        _ffi.bn_finalize = orig
+        DT.LIVE_BN = True
+
+
 def test_training_accumulates_into_existing_grads():
     """With .grad buffers allocated (FlatGradBucket), the weight-gradient kernels add into them
     directly; two backward passes must equal twice one pass, and must match autograd's own

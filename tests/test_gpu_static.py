@@ -201,24 +201,31 @@ def test_static_train_step_matches_the_per_batch_step():
     sb.set_batch(batches[0])
     st = StaticTrainStep(m1, sb, lr=1e-3)
     ref = TrainStep(m2, [p.collate(idx) for idx in batches], lr=1e-3, use_graph=False)
+    worst = 0.0
     for j, idx in enumerate(batches):
         l1 = st.step_on([idx])[0].clone()
         l2 = ref.step(j)
         torch.cuda.synchronize()
-        assert abs(float(l1) - float(l2)) <= (1e-5 if j == 0 else 1e-3) * max(1.0, abs(float(l2))), (j, float(l1), float(l2))
+        assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l2))), (j, float(l1), float(l2))
         g1, g2 = st.bucket.flat, ref.bucket.flat
         rel = float((g1 - g2).norm() / g2.norm())
         print(f'[static train] step {j}: loss {float(l1):.6f} vs {float(l2):.6f}, relative L2 distance of the gradient {rel:.2e}')
-        # step 0 starts from identical states; from step 1 on the two models differ where Adam turned summation noise of
-        # step 0 into a +-lr step (test_gpu_parity.py: test_train_step_graph_replay_matches_eager), and so do their gradients
-        assert rel < (2e-5 if j == 0 else 5e-3), (j, rel)
+        assert rel < 2e-5, (j, rel)
+        if j + 1 < len(batches):
+            # every step starts from ONE state: Adam turns summation noise of noise-level gradients into +-lr steps
+            # (test_gpu_parity.py: test_train_step_graph_replay_matches_eager), after which two trajectories part for good
+            worst = max(worst, float((st.opt.flat_p - ref.opt.flat_p).abs().max()))
+            ref.opt.flat_p.copy_(st.opt.flat_p)
+            ref.opt.exp_avg.copy_(st.opt.exp_avg)
+            ref.opt.exp_avg_sq.copy_(st.opt.exp_avg_sq)
+            for (_, a), (_, b) in zip(m1.named_buffers(), m2.named_buffers()):
+                b.copy_(a)
     csr.check_errors(DEV)
     assert len(st._graphs) == 1
-    worst = 0.0
     for (n_, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         if a.dtype.is_floating_point:
             worst = max(worst, float((a - b).abs().max()) / max(1.0, float(b.abs().max())))
-    assert worst < 2 * 1e-3 * 3 * 1.1, worst         # (Adam's first steps: sign flips of noise-level gradients, test_gpu_parity)
+    assert worst < 2 * 1e-3 * 1.1, worst             # (ONE Adam step apart at most: sign flips of noise-level gradients, test_gpu_parity)
     for (n_, a), (_, b) in zip(m1.named_buffers(), m2.named_buffers()):
         if a.dtype.is_floating_point:                # BatchNorm running statistics: the batch's own rows only
             assert torch.allclose(a, b, rtol=5e-3, atol=2e-3), n_
