@@ -148,13 +148,19 @@ class StageDesc(C.Structure):
                 ('in_bn', BnLive), ('in_bn2', BnLive)]
 
 
+class BnBwdLive(C.Structure):
+    """cwn_bn_bwd_live (include/cwn_hip.h)."""
+    _fields_ = [('z', C.c_void_p), ('aff', C.c_void_p), ('slots', C.c_void_p), ('ldz', C.c_int64)]
+
+
 class StageBwdDesc(C.Structure):
     """cwn_stage_bwd_desc (include/cwn_hip.h)."""
     _fields_ = [('dy', C.c_void_p), ('z', C.c_void_p), ('dz', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
                 ('mean', C.c_void_p), ('rstd', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p), ('acc1', C.c_void_p),
                 ('acc2', C.c_void_p), ('wt_packed', C.c_void_p), ('wt2_packed', C.c_void_p), ('dx', C.c_void_p), ('dx2', C.c_void_p),
                 ('M', C.c_int64), ('lddy', C.c_int64), ('ldz', C.c_int64), ('lddz', C.c_int64), ('lddx', C.c_int64),
-                ('lddx2', C.c_int64), ('relu', C.c_int32), ('pad_', C.c_int32), ('m_dev', C.c_void_p)]
+                ('lddx2', C.c_int64), ('relu', C.c_int32), ('pad_', C.c_int32), ('m_dev', C.c_void_p), ('s_slots', C.c_void_p),
+                ('out_bn', BnBwdLive), ('out_bn2', BnBwdLive)]
 
 
 STAGE_PACK_MAX = 96            # = CWN_STAGE_PACK_MAX

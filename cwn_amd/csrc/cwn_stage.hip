@@ -60,6 +60,11 @@ __device__ __forceinline__ double row_ror_f64(double v) {
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
 }
 
+template <int CTRL>
+__device__ __forceinline__ float row_ror_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 template <int F>
 __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     using S = Shape<F>;
@@ -278,6 +283,9 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
     constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
     constexpr size_t kPlaneElems = S::kPlaneElems;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // 1 KiB next to the tile: the slot sums s1 | s2 a live consumer takes in its prologue, and the workgroup's column sums of
+    // a live producer on their way to one coalesced atomic per column ([half][s1 | s2][F])
+    __shared__ __attribute__((aligned(16))) float bn_scratch[256];
     uint16_t* const buf0 = reinterpret_cast<uint16_t*>(smem);
     int di = 0;
 #pragma unroll
@@ -344,7 +352,27 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
         sh = reinterpret_cast<const float4*>(D.shift)[c4];
         mu = reinterpret_cast<const float4*>(D.mean)[c4];
         const float4 rs = reinterpret_cast<const float4*>(D.rstd)[c4];
-        const float4 s1 = reinterpret_cast<const float4*>(D.s1)[c4], s2 = reinterpret_cast<const float4*>(D.s2)[c4];
+        float4 s1, s2;
+        if (D.s_slots != nullptr) {
+            // the sums the producing launch left in the slots: thread t < 2 F one column of s1 | s2, slot order
+            if ((int)threadIdx.x < 2 * F) {
+                float t[CWN_BN_SLOTS];
+#pragma unroll
+                for (int q = 0; q < CWN_BN_SLOTS; ++q) t[q] = D.s_slots[(size_t)q * 2 * F + threadIdx.x];
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < CWN_BN_SLOTS; ++q) a += t[q];
+                bn_scratch[threadIdx.x] = a;
+                if (first_block) ((int)threadIdx.x < F ? D.s1 : D.s2 - F)[threadIdx.x] = a;
+            }
+            __syncthreads();
+            s1 = reinterpret_cast<const float4*>(bn_scratch)[c4];
+            s2 = reinterpret_cast<const float4*>(bn_scratch + F)[c4];
+            __syncthreads();                     // (the scratch is the producer side's staging area below)
+        } else {
+            s1 = reinterpret_cast<const float4*>(D.s1)[c4];
+            s2 = reinterpret_cast<const float4*>(D.s2)[c4];
+        }
         const float invM = 1.0f / (float)(Mv > 0 ? Mv : 1);
         c0 = make_float4(-sc.x * (s1.x * invM), -sc.y * (s1.y * invM), -sc.z * (s1.z * invM), -sc.w * (s1.w * invM));
         c1 = make_float4(-sc.x * (rs.x * (s2.x * invM)), -sc.y * (rs.y * (s2.y * invM)), -sc.z * (rs.z * (s2.z * invM)),
@@ -390,12 +418,62 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
     lds_barrier();
     const int n0 = ct * 16 + kq * 4;                 // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = row (lane & 15)
     AccRegs acc;
-    auto store = [&](float* out, int64_t ld) {
+    auto store = [&](float* out, int64_t ld, const cwn_bn_bwd_live& L) {
+        const bool live = L.slots != nullptr;
+        float4 zz[kRT], lsc, lsh, lmu, lrs;
+        if (live) {              // requested before the stores: the receiving stage's z at this lane's rows / columns, its constants
+#pragma unroll
+            for (int rt = 0; rt < kRT; ++rt) {
+                const int64_t row = row0 + (rt0 + rt) * 16 + l15;
+                zz[rt] = *reinterpret_cast<const float4*>(L.z + (row < D.M ? row : D.M - 1) * L.ldz + n0);
+            }
+            lsc = *reinterpret_cast<const float4*>(L.aff + n0);
+            lsh = *reinterpret_cast<const float4*>(L.aff + F + n0);
+            lmu = *reinterpret_cast<const float4*>(L.aff + 2 * F + n0);
+            lrs = *reinterpret_cast<const float4*>(L.aff + 3 * F + n0);
+        }
 #pragma unroll
         for (int rt = 0; rt < kRT; ++rt) {
             const int r = (rt0 + rt) * 16 + l15;
             if (row0 + r < Mv) cwn::store_result4(out + (row0 + r) * ld + n0, acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
         }
+        if (!live) return;
+        // dyh = dx * [z * scale + shift > 0]; column sums of dyh and dyh * xhat over the workgroup's rows
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        const float sc[4] = {lsc.x, lsc.y, lsc.z, lsc.w}, sh[4] = {lsh.x, lsh.y, lsh.z, lsh.w};
+        const float mu[4] = {lmu.x, lmu.y, lmu.z, lmu.w}, rs[4] = {lrs.x, lrs.y, lrs.z, lrs.w};
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) {
+            const bool ok = row0 + (rt0 + rt) * 16 + l15 < Mv;
+            const float zv[4] = {zz[rt].x, zz[rt].y, zz[rt].z, zz[rt].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float y = zv[q] * sc[q] + sh[q];
+                const float dyh = (ok && y > 0.f) ? acc[rt][q] : 0.f;
+                a1[q] += dyh;
+                a2[q] += dyh * ((zv[q] - mu[q]) * rs[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = a1[q], b = a2[q];
+            a += row_ror_f32<0x128>(a); b += row_ror_f32<0x128>(b);
+            a += row_ror_f32<0x124>(a); b += row_ror_f32<0x124>(b);
+            a += row_ror_f32<0x122>(a); b += row_ror_f32<0x122>(b);
+            a += row_ror_f32<0x121>(a); b += row_ror_f32<0x121>(b);
+            if (l15 == 0) {                       // (F = 64: two waves per column tile, one per 32-row half)
+                const int half = wave / S::kNCT;
+                bn_scratch[(half * 2) * F + n0 + q] = a;
+                bn_scratch[(half * 2 + 1) * F + n0 + q] = b;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * F) {
+            float v = bn_scratch[threadIdx.x];
+            if constexpr (TM > 32) v += bn_scratch[2 * F + threadIdx.x];
+            unsafeAtomicAdd(L.slots + (size_t)((int)blockIdx.x % CWN_BN_SLOTS) * 2 * F + threadIdx.x, v);
+        }
+        __syncthreads();                          // (a second product of the workgroup stages through the same scratch)
     };
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
@@ -405,12 +483,12 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) request_kstep(D.wt2_packed, ks);
     }
-    store(D.dx, D.lddx);
+    store(D.dx, D.lddx, D.out_bn);
     if (two) {
 #pragma unroll
         for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
         multiply(acc);
-        store(D.dx2, D.lddx2);
+        store(D.dx2, D.lddx2, D.out_bn2);
     }
 }
 
@@ -563,6 +641,13 @@ extern "C" int cwn_dense_stage_bwd_f32(const cwn_stage_bwd_desc* descs, int n, i
         if (D.scale != nullptr && (D.shift == nullptr || D.mean == nullptr || D.rstd == nullptr || D.s1 == nullptr || D.s2 == nullptr))
             return CWN_ERR_BAD_ARG;
         if (D.lddy < F || D.ldz < F || D.lddx < F || D.lddy % 4 || D.ldz % 4 || D.lddx % 4) return CWN_ERR_BAD_ARG;
+        if (D.s_slots != nullptr && (D.scale == nullptr || !al16(D.s_slots))) return CWN_ERR_BAD_ARG;
+        for (const cwn_bn_bwd_live* L : {&D.out_bn, &D.out_bn2}) {
+            if (L->slots == nullptr) continue;
+            if (L == &D.out_bn2 && D.dx2 == nullptr) return CWN_ERR_BAD_ARG;
+            if (L->z == nullptr || L->aff == nullptr || L->ldz < F || L->ldz % 4) return CWN_ERR_BAD_ARG;
+            if (!(al16(L->z) && al16(L->aff) && al16(L->slots))) return CWN_ERR_ALIGN;
+        }
         if (D.dz != nullptr && (D.lddz < F || D.lddz % 4)) return CWN_ERR_BAD_ARG;
         if (D.dx2 != nullptr && (D.lddx2 < F || D.lddx2 % 4)) return CWN_ERR_BAD_ARG;
         if (!(al16(D.dy) && al16(D.z) && al16(D.dz) && al16(D.dx) && al16(D.dx2) && al16(D.wt_packed) && al16(D.wt2_packed) &&

@@ -50,6 +50,13 @@ FUSED_NORM_APPLY = os.environ.get('CWN_FUSED_NORM_APPLY') != '0'
 # stage on cwn_dense_stage_f32 (width 64 / 128, packed blocks); CWN_LIVE_BN=0 restores the finalize launches (whose per-band
 # partials summed in band order are the bit-reproducible form).
 LIVE_BN = os.environ.get('CWN_LIVE_BN', '1') != '0'
+# ... and the REDUCE half of its backward (cwn_bn_bwd_live): the backward-stage launch that produces a stage's dy adds the
+# column sums of dyh, dyh * xhat into 8 fp32 slot rows from its epilogue (the tile still in registers, one coalesced atomic
+# instruction per 64 columns and workgroup); the launch that consumes them sums the slots in its prologue.  8 of the 12
+# cwn_norm_bwd_reduce_f32 launches of a ZINC step go (the combine stages' dy comes from autograd: theirs stay).  Round 3
+# tried this with one atomic per column and lane group straight into s1 / s2 -- 110 k four-lane atomic instructions onto 256
+# addresses per launch, 9.9 -> 20.5 us; staged through LDS it is four 64-lane instructions per workgroup onto 8 x 256.
+LIVE_BN_BWD = os.environ.get('CWN_LIVE_BN_BWD', '1') != '0'
 # (Measured and dropped: the REDUCE half of the next stage -- column sums of dyh, dyh * xhat -- taken in the epilogue of the
 # backward-stage launch that produces its dy, the tile still in registers, so that 8 of the 12 reduce launches of a ZINC step
 # go away.  A workgroup of cwn_dense_stage_bwd_f32 owns 32 rows: 428 workgroups x 256 column sums = 110 k fp32 atomics per
@@ -334,6 +341,24 @@ class _DenseTrain(torch.autograd.Function):
             q += nb
             G[id(st)] = (dW, db, ctx.sum_of.get(id(st)))
 
+        # slot sums of the reduce halves the backward-stage launches take over (LIVE_BN_BWD): one zeroed region
+        upd = [st for i in range(nd) for st in plan.up[i] + plan.bd[i] if st.is_bn]
+        F0 = int(Z3[0].size(1))
+        live_bwd = bool(LIVE_BN_BWD and not fused_norm and ops.STAGE_KERNEL and upd and F0 in (64, 128)
+                        and all(st.lin.out_features == F0 for st in upd))
+        bslot_of, filled = {}, set()
+        if live_bwd:
+            zb = ops.zeros_scratch(4 * _ffi.BN_SLOTS * 2 * F0 * len(upd), dev).view(torch.float32)
+            for k, st in enumerate(upd):
+                bslot_of[id(st)] = zb[k * _ffi.BN_SLOTS * 2 * F0: (k + 1) * _ffi.BN_SLOTS * 2 * F0].view(_ffi.BN_SLOTS, 2, F0)
+
+        def out_record(st: Optional[Stage], z: Tensor):
+            """The cwn_bn_bwd_live record with which a launch whose dx is `st`'s dy takes over the reduce of its backward."""
+            if not live_bwd or st is None or not st.is_bn or not z.numel() or z.stride(1) != 1 or z.stride(0) % 4 or z.data_ptr() % 16:
+                return None
+            return _ffi.BnBwdLive(z=z.data_ptr(), aff=aff_of[id(st)].data_ptr(), slots=bslot_of[id(st)].data_ptr(),
+                                  ldz=z.stride(0))
+
         def bnb_ok(dy, z):
             return (FUSED_NORM_APPLY and not fused_norm and z.size(1) in (64, 128) and z.numel() > 0
                     and all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in (dy, z)))
@@ -359,10 +384,15 @@ class _DenseTrain(torch.autograd.Function):
                         _norm_desc(z, dy=dy, out=dz, aff=aff, s12=tgt if tgt is not None else s12))
                     outs.append(dz)
                     continue
-                if st.is_bn:
+                have_slots = id(st) in filled
+                if have_slots and not lazy:          # (the sums are needed as arrays: rare -- the lazy form is the stage launch's)
+                    s12.copy_(bslot_of[id(st)].sum(0))
+                    have_slots = False
+                elif st.is_bn and not have_slots:
                     red.append(_norm_desc(z, dy=dy, aff=aff, s12=s12))
                 if lazy:
                     b = _ffi.GemmBnb(z=z.data_ptr(), dz=dz.data_ptr(), ldz=z.stride(0), lddz=dz.stride(0), relu=1)
+                    b.s_slots = bslot_of[id(st)] if have_slots else None
                     if aff is not None:
                         b.scale, b.shift, b.mean, b.rstd = (aff[r].data_ptr() for r in range(4))
                         b.s1, b.s2 = s12[0].data_ptr(), s12[1].data_ptr()
@@ -408,6 +438,15 @@ class _DenseTrain(torch.autograd.Function):
         tn, nn = [], []
         dA = []
         stage_bwd = []          # the same products for cwn_dense_stage_bwd_f32 (ops.run_stage_bwd), when every one has the lazy form
+        live_recs, live_to = [], []   # per entry: the slot-sum forms (ops.run_stage_bwd) and the stages whose reduce they take over
+
+        def mark_filled(recs, to):
+            for (_, o1, o2), (t1, t2) in zip(recs, to):
+                if o1 is not None:
+                    filled.add(id(t1))
+                if o2 is not None:
+                    filled.add(id(t2))
+
         for i in range(nd):
             st = plan.cb[i]
             W = P[id(st)][0]
@@ -430,16 +469,24 @@ class _DenseTrain(torch.autograd.Function):
                 nn.append(ops.Gemm(X=dH[i], W=W[:, hu:], w_trans=True, out=out[:, hu:], bnb=second_view(b)))
                 dA.append(out)
                 stage_bwd.append((dH[i], b, W, out[:, :hu], out[:, hu:]) if W.size(1) == 2 * hu else None)
+                live_recs.append((getattr(b, 's_slots', None), out_record(plan.up[i][-1], Z[i][0][-1]),
+                                  out_record(plan.bd[i][-1], Z[i][1][-1])))
+                live_to.append((plan.up[i][-1], plan.bd[i][-1]))
             else:
                 nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
                 dA.append(None)
                 stage_bwd.append(None)
+                live_recs.append((None, None, None))
+                live_to.append((None, None))
         # weight gradients whose targets are all the parameters' own .grad buffers may wait for the end of the backward
         can_defer = ops.ACCUMULATE_INTO_GRAD and all(tw is not None and (st.lin.bias is None or tb is not None)
                                                      for st, (tw, tb) in zip(stages, targets))
         keep_all = [dZ3, Z, A0, aff_of, dH]
         # [M, H_up + H_bd] per dimension (before the weight gradients: with the lazy form the launch WRITES dZ3)
-        if not (all(e is not None for e in stage_bwd) and ops.run_stage_bwd(stage_bwd, dev)):
+        if all(e is not None for e in stage_bwd) and ops.run_stage_bwd(stage_bwd, dev, live_recs if live_bwd else None):
+            if live_bwd:
+                mark_filled(live_recs, live_to)
+        else:
             res = ops.run_gemm(nn, dev)
             k = 0
             for i in range(nd):
@@ -464,7 +511,7 @@ class _DenseTrain(torch.autograd.Function):
             lazy_s = bool(pend) and isinstance(pend[0], tuple)
             dZ = [p[0] for p in pend] if lazy_s else pend
             tn, nn, k = [], [], 0
-            stage_bwd = []
+            stage_bwd, live_recs, live_to = [], [], []
             for i in range(nd):
                 for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
                     st = chain[s]
@@ -483,14 +530,24 @@ class _DenseTrain(torch.autograd.Function):
                         nn.append(ops.Gemm(X=dy[i][br], W=W, w_trans=True, bnb=pend[k][1]))
                         stage_bwd.append((dy[i][br], pend[k][1], W, torch.empty(dz.size(0), W.size(1), dtype=torch.float32, device=dev),
                                           None))
+                        live_recs.append((getattr(pend[k][1], 's_slots', None),
+                                          out_record(chain[s - 1], Z[i][br][s - 1]) if s > 0 else None, None))
+                        live_to.append((chain[s - 1] if s > 0 else None, None))
                     else:
                         nn.append(ops.Gemm(X=dz, W=W, w_trans=True))
                         stage_bwd.append(None)
+                        live_recs.append((None, None, None))
+                        live_to.append((None, None))
                     k += 1
             # (before the weight gradients: with the lazy form the launch writes dZ)
-            if all(e is not None for e in stage_bwd) and ops.run_stage_bwd(stage_bwd, dev):
+            if all(e is not None for e in stage_bwd) and ops.run_stage_bwd(stage_bwd, dev, live_recs if live_bwd else None):
                 res = [e[3] for e in stage_bwd]
+                if live_bwd:
+                    mark_filled(live_recs, live_to)
             else:
+                for st_, _, _ in items:              # (cwn_gemm_bnb reads s1 / s2 as arrays)
+                    if id(st_) in filled:
+                        G[id(st_)][2].copy_(bslot_of[id(st_)].sum(0))
                 res = ops.run_gemm(nn, dev)
             if tn:
                 _ffi.gemm_tn(tn, dev, keep=[dZ, Z, A0, aff_of, dy], deferrable=can_defer)

@@ -1684,10 +1684,13 @@ def packed_stage_block(weight: Tensor, col0: int, transposed: bool = False) -> O
     return None
 
 
-def run_stage_bwd(entries, device) -> bool:
+def run_stage_bwd(entries, device, live=None) -> bool:
     """cwn_dense_stage_bwd_f32 over `entries` = [(dy, bnb, W, dx, dx2)]: dy the gradient of a stage's output, bnb the
     _ffi.GemmBnb extension dense_train prepared for the transposed-weight GEMM (z, dz, the norm's constants and sums), W the
-    Linear's weight Parameter, dx (and dx2 for an [F, 2F] weight) the outputs.  False: does not apply, nothing launched."""
+    Linear's weight Parameter, dx (and dx2 for an [F, 2F] weight) the outputs.  False: does not apply, nothing launched.
+    `live` (or None): per entry (s_slots, out_bn, out_bn2) -- the slot-sum forms of the BatchNorm backward's reduce
+    (include/cwn_hip.h: cwn_bn_bwd_live): a [BN_SLOTS, 2, F] fp32 tensor this stage takes its s1 / s2 from, and the
+    _ffi.BnBwdLive records of the stages that receive dx / dx2 as their dy; each may be None."""
     if not STAGE_KERNEL or not entries or len(entries) > _ffi.MAX_DESCS:
         return False
     F = int(entries[0][0].size(1))
@@ -1715,6 +1718,18 @@ def run_stage_bwd(entries, device) -> bool:
                                    s1=b.s1, s2=b.s2, acc1=b.acc1, acc2=b.acc2, wt_packed=w1.data_ptr(), wt2_packed=_ffi.ptr(w2),
                                    dx=dx.data_ptr(), dx2=_ffi.ptr(dx2), M=M, lddy=ld(dy), ldz=int(b.ldz), lddz=int(b.lddz),
                                    lddx=ld(dx), lddx2=0 if dx2 is None else ld(dx2), relu=int(b.relu), m_dev=_ffi.dyn(M))
+        if live is not None:
+            sl, o1, o2 = live[k]
+            if sl is not None:
+                if sl.dtype != torch.float32 or tuple(sl.shape) != (_ffi.BN_SLOTS, 2, F) or not sl.is_contiguous() or b.scale is None:
+                    return False
+                arr[k].s_slots = sl.data_ptr()
+            if o1 is not None:
+                arr[k].out_bn = o1
+            if o2 is not None:
+                if dx2 is None:
+                    return False
+                arr[k].out_bn2 = o2
         keep += [w1, w2]
     _ffi.check(_ffi.lib().cwn_dense_stage_bwd_f32(arr, len(entries), F, _ffi.stream_ptr(device)), 'cwn_dense_stage_bwd_f32')
     return True

@@ -606,6 +606,12 @@ int cwn_dense_stage_f32(const cwn_stage_desc* descs_host, int n, int32_t F, cwn_
  * Every acc1 / acc2 / s1 / s2 / constant pointer 16-B aligned. */
 int cwn_update_mlp_pack_weights_t_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
                                            cwn_stream_t stream);
+typedef struct cwn_bn_bwd_live {
+    const float* z;          /* [M, F] (row stride ldz) pre-normalisation values of the stage that receives dx as its dy */
+    const float* aff;        /* [4][F]: scale, shift, mean, rstd of its BatchNorm (cwn_bn_live.aff) */
+    float* slots;            /* [CWN_BN_SLOTS][2][F]; NULL: unused */
+    int64_t ldz;
+} cwn_bn_bwd_live;
 typedef struct cwn_stage_bwd_desc {
     const float* dy;         /* [M, F] */
     const float* z;          /* [M, F] */
@@ -614,8 +620,8 @@ typedef struct cwn_stage_bwd_desc {
     const float* shift;
     const float* mean;
     const float* rstd;
-    const float* s1;
-    const float* s2;
+    float* s1;               /* (read; written when s_slots != NULL) */
+    float* s2;
     float* acc1;
     float* acc2;
     const void* wt_packed;
@@ -626,6 +632,16 @@ typedef struct cwn_stage_bwd_desc {
     int32_t relu;
     int32_t pad_;
     const int64_t* m_dev;    /* or NULL: actual rows (M = capacity) */
+    /* The REDUCE half of the BatchNorm backward without a launch of its own (round 4; the backward twin of cwn_bn_live).
+     * Producer side: dx (dx2) of this launch is the dy of an earlier Linear -> BatchNorm -> ReLU stage whose pre-normalisation
+     * values are out_bn.z (out_bn2.z): the epilogue forms dyh = dx * [z * scale + shift > 0] and adds the workgroup's column
+     * sums of dyh and dyh * xhat into out_bn.slots ([CWN_BN_SLOTS][2][F] fp32, ZERO on entry; workgroup b into slot
+     * b % CWN_BN_SLOTS, one coalesced atomic instruction per 64 columns) -- what cwn_norm_bwd_reduce_f32 would have summed.
+     * Consumer side: s_slots != NULL: s1 / s2 of THIS stage are the sums over those slots (slot order), taken in the prologue;
+     * the first workgroup of the descriptor also stores them to s1 / s2 (then outputs: d beta, d gamma for the caller). */
+    const float* s_slots;
+    cwn_bn_bwd_live out_bn;
+    cwn_bn_bwd_live out_bn2;
 } cwn_stage_bwd_desc;
 int cwn_dense_stage_bwd_f32(const cwn_stage_bwd_desc* descs_host, int n, int32_t F, cwn_stream_t stream);
 

@@ -1557,17 +1557,19 @@ def test_fused_training_layer_matches_torch_modules(norm, hidden, use_cob):
 
 @pytest.mark.parametrize('hidden', [128, 64])
 def test_live_batchnorm_matches_the_finalize_launches(hidden):
-    """cwn_bn_live (round 4): the stage launches sum the statistics into slots and the consuming launches derive the affine --
-    no cwn_bn_finalize_f32 launch -- against the same layer with CWN_LIVE_BN off (per-band partials + finalize): outputs,
+    """cwn_bn_live / cwn_bn_bwd_live (round 4): the stage launches sum the statistics (forward) and the reduce half of the
+    BatchNorm backward into slots and the consuming launches take them in their prologue -- no cwn_bn_finalize_f32 launch, a
+    cwn_norm_bwd_reduce_f32 launch for the combine stages only -- against the same layer with CWN_LIVE_BN off (per-band partials + finalize): outputs,
     input gradients, parameter gradients, running statistics and batch counters, inside a step arena and outside one; a
     batch with an empty dimension (no 2-cells) included."""
     from cwn_amd import _ffi, dense_train as DT, layers, ops
     from cwn_amd.synthetic import zinc_like_batch
     fused, _ = _train_layer_pair(torch.nn.BatchNorm1d, hidden, True)
     state0 = {k: v.clone() for k, v in fused.state_dict().items()}
-    calls = []
-    orig = _ffi.bn_finalize
+    calls, reduced = [], []
+    orig, orig_red = _ffi.bn_finalize, _ffi.norm_bwd_reduce
     _ffi.bn_finalize = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    _ffi.norm_bwd_reduce = lambda descs, *a, **k: (reduced.append(len(descs)), orig_red(descs, *a, **k))[1]
 
     def run(b, live, arena):
         fused.load_state_dict(state0)
@@ -1577,7 +1579,7 @@ def test_live_batchnorm_matches_the_finalize_launches(hidden):
         ops.pack_stage_weights_many([lin.weight for lvl in fused.mp_levels
                                      for net in (lvl.update_up_nn, lvl.update_boundaries_nn, lvl.combine_nn)
                                      for lin, _ in layers._mlp_stages(net)])
-        DT.LIVE_BN = live
+        DT.LIVE_BN = DT.LIVE_BN_BWD = live
         g = torch.Generator().manual_seed(3)
         xin = [(torch.randn(b.cochains[d].num_cells, hidden, generator=g).to(DEV)).requires_grad_() for d in range(3)]
         ws = [torch.randn(b.cochains[d].num_cells, hidden, generator=g).to(DEV) for d in range(3)]
@@ -1596,12 +1598,16 @@ def test_live_batchnorm_matches_the_finalize_launches(hidden):
     try:
         for b in (zinc_like_batch(24, seed=5, device=DEV), zinc_like_batch(3, seed=8, device=DEV)):
             calls.clear()
+            reduced.clear()
             ref = run(b, False, False)
             assert calls, 'the finalize form did not launch cwn_bn_finalize_f32'
+            assert sum(reduced) == 15, reduced          # every BatchNorm of the layer: 5 per dimension
             for arena in (False, True, True):           # (twice inside the arena: the second step starts from its fill)
                 calls.clear()
+                reduced.clear()
                 got = run(b, True, arena)
                 assert not calls, 'live BatchNorm still launched cwn_bn_finalize_f32'
+                assert sum(reduced) == 3, reduced       # the combine stages only (their dy comes from autograd)
                 for a, r in zip(got[0] + got[1], ref[0] + ref[1]):
                     torch.testing.assert_close(a, r, rtol=2e-5, atol=2e-5 * max(1.0, float(r.abs().max())))
                 assert got[2].keys() == ref[2].keys()
@@ -1614,8 +1620,8 @@ def test_live_batchnorm_matches_the_finalize_launches(hidden):
                     else:
                         assert torch.equal(got[3][n], t), n
     finally:
-        _ffi.bn_finalize = orig
-        DT.LIVE_BN = True
+        _ffi.bn_finalize, _ffi.norm_bwd_reduce = orig, orig_red
+        DT.LIVE_BN = DT.LIVE_BN_BWD = True
 
 
 def test_training_accumulates_into_existing_grads():
