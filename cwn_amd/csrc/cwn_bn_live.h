@@ -9,29 +9,37 @@
 
 namespace cwn {
 
-__device__ __forceinline__ void bn_live_column(const cwn_bn_live& L, int N, int64_t Mv, int n, bool writer, float& scale,
-                                               float& shift) {
+// the loads of one column (requested early: ahead of the consumer's own tile loads, which return behind them)
+struct BnLiveRegs {
     double t[CWN_BN_SLOTS], u[CWN_BN_SLOTS];
+    float g, beta;
+};
+
+__device__ __forceinline__ void bn_live_request(const cwn_bn_live& L, int N, int n, BnLiveRegs& R) {
 #pragma unroll
     for (int q = 0; q < CWN_BN_SLOTS; ++q) {
-        t[q] = L.slots[(size_t)(2 * q) * N + n];
-        u[q] = L.slots[(size_t)(2 * q + 1) * N + n];
+        R.t[q] = L.slots[(size_t)(2 * q) * N + n];
+        R.u[q] = L.slots[(size_t)(2 * q + 1) * N + n];
     }
+    R.g = L.gamma != nullptr ? L.gamma[n] : 1.0f;
+    R.beta = L.beta != nullptr ? L.beta[n] : 0.0f;
+}
+
+__device__ __forceinline__ void bn_live_finish(const cwn_bn_live& L, const BnLiveRegs& R, int N, int64_t Mv, int n, bool writer,
+                                               float& scale, float& shift) {
     double s = 0.0, sq = 0.0;
 #pragma unroll
     for (int q = 0; q < CWN_BN_SLOTS; ++q) {
-        s += t[q];
-        sq += u[q];
+        s += R.t[q];
+        sq += R.u[q];
     }
     const double invM = 1.0 / (double)(Mv > 0 ? Mv : 1);
     const double mean = s * invM;
     double var = sq * invM - mean * mean;     // biased, as BatchNorm normalises
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)L.eps));
-    const float g = L.gamma != nullptr ? L.gamma[n] : 1.0f;
-    const float beta = L.beta != nullptr ? L.beta[n] : 0.0f;
-    scale = g * rstd;
-    shift = beta - (float)mean * scale;
+    scale = R.g * rstd;
+    shift = R.beta - (float)mean * scale;
     if (!writer) return;
     L.aff[n] = scale;
     L.aff[N + n] = shift;
@@ -45,6 +53,13 @@ __device__ __forceinline__ void bn_live_column(const cwn_bn_live& L, int N, int6
         L.running_mean[n] = (1.0f - mom) * L.running_mean[n] + mom * (float)mean;
         L.running_var[n] = (1.0f - mom) * L.running_var[n] + mom * (float)unbiased;
     }
+}
+
+__device__ __forceinline__ void bn_live_column(const cwn_bn_live& L, int N, int64_t Mv, int n, bool writer, float& scale,
+                                               float& shift) {
+    BnLiveRegs R;
+    bn_live_request(L, N, n, R);
+    bn_live_finish(L, R, N, Mv, n, writer, scale, shift);
 }
 
 }  // namespace cwn

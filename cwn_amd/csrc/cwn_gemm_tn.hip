@@ -41,11 +41,11 @@ constexpr double kTnFixed2 = 4.0; // split kernel: prologue + epilogue of a work
 struct TnBatch {       // a kernel argument: must stay under 4 KiB (static_assert below)
     cwn_gemm_tn_desc d[CWN_GEMM_TN_MAX_DESCS];
     int32_t blk_start[CWN_GEMM_TN_MAX_DESCS + 1];
-    int32_t tiles_n[CWN_GEMM_TN_MAX_DESCS], tiles_k[CWN_GEMM_TN_MAX_DESCS];
+    int16_t tiles_n[CWN_GEMM_TN_MAX_DESCS], tiles_k[CWN_GEMM_TN_MAX_DESCS];
+    int32_t band_rows_of[CWN_GEMM_TN_MAX_DESCS];   // rows of M per workgroup of descriptor i (multiple of the kernel's chunk)
     int32_t n;
     float* ws[CWN_GEMM_TN_MAX_DESCS];      // per-band partials [bands][N][K + K2] then [bands][N] (db), or NULL
     int32_t bands[CWN_GEMM_TN_MAX_DESCS];
-    int32_t band_rows; // rows of M per workgroup in THIS launch (multiple of kChunk)
     int32_t dbg;       // timing experiments (CWN_TN_DBG): 1 no output, 2 no MFMA, 4 no bias sum
 };
 
@@ -93,7 +93,26 @@ struct Pro {
     f32x4 sc, sh;
     bool affine, relu;
     int cc, cmax;
+    bool second;     // (the split kernel) the thread's columns lie in the second matrix of the operand
 };
+
+// the prologue constants of a thread whose columns (second, cc, cmax) are set
+__device__ __forceinline__ void fill_pro(Pro& P, const Src& S) {
+    const float* sc = P.second ? S.scale2 : S.scale1;
+    const float* sh = P.second ? S.shift2 : S.shift1;
+    P.relu = (S.relu & (P.second ? 2 : 1)) != 0;
+    P.affine = sc != nullptr;
+    P.sc = (f32x4){1.f, 1.f, 1.f, 1.f};
+    P.sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (P.affine) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (P.cc + t < P.cmax) {
+                P.sc[t] = sc[P.cc + t];
+                P.sh[t] = sh[P.cc + t];
+            }
+    }
+}
 
 template <int TW = kTile>
 __device__ __forceinline__ Pro make_pro(const Src& S, int col0) {
@@ -159,9 +178,10 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_tn_kernel(TnBatch B) {
     // grid and bounds the addresses of the loads, which do not wait for this one
     const int64_t Mcap = D.M;
     const int64_t M = D.m_dev != nullptr ? (*D.m_dev < Mcap ? *D.m_dev : Mcap) : Mcap;
-    const int64_t row_lo = (int64_t)band * B.band_rows;
-    const int64_t cap_hi = row_lo + B.band_rows < Mcap ? row_lo + B.band_rows : Mcap;
-    const int64_t row_hi = row_lo + B.band_rows < M ? row_lo + B.band_rows : M;
+    const int64_t band_rows = B.band_rows_of[di];
+    const int64_t row_lo = (int64_t)band * band_rows;
+    const int64_t cap_hi = row_lo + band_rows < Mcap ? row_lo + band_rows : Mcap;
+    const int64_t row_hi = row_lo + band_rows < M ? row_lo + band_rows : M;
     const int n0 = tile_n * kTile, k0 = tile_k * kTile;
     const int N = D.N, Ktot = D.K + D.K2;
     const Src SZ{D.dZ, nullptr, D.lddz, 0, N, 0, nullptr, nullptr, nullptr, nullptr, 0};
@@ -245,11 +265,17 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_tn_kernel(TnBatch B) {
 // The same product on the bf16 matrix pipe (round 4): both operands split three ways (cwn_split.h: x = hi + mid + lo, exact),
 // six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block instead of eight v_mfma_f32_16x16x4_f32 at twice their issue time each
 // -- 96 MFMA cycles where the fp32 pipe takes 256 -- with the dropped terms (<= 2^-26 |dz||x|) below the rounding of the fp32
-// accumulation, like the forward kernels.  What changes around the MFMAs:
+// accumulation, like the forward kernels.  With the multiply that cheap the launch is a memory pipeline, and shaped as one:
 //   * a workgroup owns a 128 x 128 tile of dW (all of it at hidden 128: dZ and X are read ONCE per band, where 64 x 64
-//     tiles read each twice), its four waves 64 x 64 each (16 accumulator tiles);
-//   * a chunk is 32 rows of M.  A thread splits the float4s it loaded (prologue applied first) and stores 4 bf16 per plane
-//     ROW-MAJOR, [m][n] / [m][k] with a row stride of 144 bf16: a wave writes two full rows, every bank once;
+//     tiles read each twice) and a band of rows; EIGHT waves, 64 (n) x 32 (k) each (8 accumulator tiles), one workgroup
+//     per CU;
+//   * a chunk is 32 rows of M = 32 KB of the two operands, two 16-B loads per thread and operand -- and THREE chunks are in
+//     flight in registers (a ring of three named buffers, the loop unrolled by three): a chunk's MFMAs take ~0.4 us, a load
+//     from HBM / MALL 2 us, and with one chunk in flight (the first form of this kernel: four waves, two workgroups per CU)
+//     every chunk waited ~1.5 us for its data: 45 us per merged ZINC-128 launch where the fp32 kernel, four workgroups deep
+//     per CU, took 38;
+//   * a thread splits the float4s it loaded (prologue applied first) and stores 4 bf16 per plane ROW-MAJOR, [m][n] / [m][k]
+//     with a row stride of 144 bf16: a wave writes two full rows, every bank once;
 //   * an MFMA operand wants 8 CONSECUTIVE m for one n (or k): the column of a row-major tile.  gfx950's transposing LDS read
 //     does exactly that (ds_read_b64_tr_b16: a 16-lane group reads a 4 x 16 block, lane i supplying the address of
 //     [i / 4][4 (i % 4)] and receiving column i; semantics pinned by tools/proto/tr_read_probe.hip on the hardware): two of them
@@ -258,13 +284,22 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_tn_kernel(TnBatch B) {
 //     8 CONSECUTIVE rows, which at 72 dwords per row land on all 64 banks once (rows 8 apart would collide);
 //   * the bias gradient is summed from the registers of the load (a thread keeps its 4 columns for the whole band) and
 //     reduced once at the end of the band.
-// 55 KB of LDS, <= 256 VGPRs: two workgroups per CU.  Chosen when every operand is 16-B aligned (the FAST test below) unless
-// CWN_TN_SPLIT=0; the fp32-MFMA kernel above stays for the rest and for the comparison (tools/ubench_tn24.py).
+// 110 KB of LDS (two sets of planes).  Chosen when every operand is 16-B aligned (the FAST test below) unless CWN_TN_SPLIT=0; the fp32-MFMA kernel
+// above stays for the rest and for the comparison (tools/ubench_tn24.py).
+constexpr int kThreads2 = 512;
 constexpr int kTile2 = 128;      // rows and columns of dW per workgroup
 constexpr int kChunk2 = 32;      // rows of M per LDS stage = the k of one MFMA
 constexpr int kLd2 = 144;        // LDS row stride in bf16 (72 dwords = 8 * 9)
 constexpr int kPlane = kChunk2 * kLd2;
-static_assert(kChunk2 * (kTile2 / 4) / kThreads == kU, "four 16-B loads per thread per operand");
+constexpr int kU2 = kChunk2 * (kTile2 / 4) / kThreads2;     // 16-B loads per thread, operand and chunk (= 2)
+#ifndef CWN_TN_RING
+#define CWN_TN_RING 3
+#endif
+#ifndef CWN_TN_WGS
+#define CWN_TN_WGS 1
+#endif
+constexpr int kRing = CWN_TN_RING;         // chunks in flight
+static_assert(kThreads2 % (kTile2 / 4) == 0, "a thread keeps its columns");
 
 typedef short v4s __attribute__((ext_vector_type(4)));
 
@@ -283,13 +318,28 @@ __device__ __forceinline__ void frag3(const uint16_t* base, uint4& h, uint4& m, 
     l = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
+struct Chunk { f32x4 z[kU2], x[kU2]; };      // one chunk of both operands as a thread holds it
+
+__device__ __forceinline__ void chunk_load_one(f32x4 (&v)[kU2], const Src& S, const Pro& P, int64_t row0, int64_t row_hi) {
+#pragma unroll
+    for (int u = 0; u < kU2; ++u) {
+        const int r = (u * kThreads2 + (int)threadIdx.x) / (kTile2 / 4);
+        const int64_t row = row0 + r < row_hi ? row0 + r : row_hi - 1;      // clamped, never faults
+        const bool second = P.second;
+        const float* base = second ? S.p2 : S.p1;
+        const int64_t ld = second ? S.ld2 : S.ld1;
+        v[u] = *reinterpret_cast<const f32x4*>(base + row * ld + (P.cc < P.cmax ? P.cc : 0));
+    }
+}
+
 // prologue + three-way split of the chunk a thread loaded, 4 bf16 per plane at [r][4c]; returns the column sums it saw
-__device__ __forceinline__ f32x4 tile_store_split(uint16_t* planes, const f32x4 (&v)[kU], const Pro& P, int64_t row0,
-                                                  int64_t row_hi) {
+template <bool PLAIN>
+__device__ __forceinline__ f32x4 chunk_store_one(uint16_t* planes, const f32x4 (&v)[kU2], const Pro& P, int64_t row0,
+                                                 int64_t row_hi) {
     f32x4 colsum = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-        const int q = u * kThreads + threadIdx.x;
+    for (int u = 0; u < kU2; ++u) {
+        const int q = u * kThreads2 + threadIdx.x;
         const int r = q / (kTile2 / 4), c = q % (kTile2 / 4);
         const bool row_ok = row0 + r < row_hi;
         f32x4 x = v[u];
@@ -297,8 +347,10 @@ __device__ __forceinline__ f32x4 tile_store_split(uint16_t* planes, const f32x4 
         for (int t = 0; t < 4; ++t) {
             float y = x[t];
             const bool ok = row_ok && P.cc + t < P.cmax;
-            if (P.affine) y = y * P.sc[t] + P.sh[t];
-            if (P.relu) y = fmaxf(y, 0.f);
+            if constexpr (!PLAIN) {
+                if (P.affine) y = y * P.sc[t] + P.sh[t];
+                if (P.relu) y = fmaxf(y, 0.f);
+            }
             x[t] = ok ? y : 0.f;
         }
         colsum += x;
@@ -312,9 +364,12 @@ __device__ __forceinline__ f32x4 tile_store_split(uint16_t* planes, const f32x4 
     return colsum;
 }
 
-__global__ __launch_bounds__(kThreads, 2) void gemm_tn_split_kernel(TnBatch B) {
-    __shared__ __attribute__((aligned(16))) uint16_t zp[3 * kPlane];
-    __shared__ __attribute__((aligned(16))) uint16_t xp[3 * kPlane];
+__global__ __launch_bounds__(kThreads2, CWN_TN_WGS) void gemm_tn_split_kernel(TnBatch B) {
+    // two sets of planes: chunk c is staged in set c & 1 while slower waves still multiply chunk c - 1 out of the other --
+    // ONE barrier per chunk (a wave that has passed the barrier of chunk c is done with the MFMAs of chunk c - 1, whose set
+    // chunk c + 1 overwrites)
+    __shared__ __attribute__((aligned(16))) uint16_t zp[2][3 * kPlane];
+    __shared__ __attribute__((aligned(16))) uint16_t xp[2][3 * kPlane];
     int di = 0;
 #pragma unroll
     for (int i = 1; i < CWN_GEMM_TN_MAX_DESCS; ++i)
@@ -327,85 +382,121 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_split_kernel(TnBatch B) {
     const int tile_n = b % tn;
     const int band = b / tn;
     const int64_t Mcap = D.M;
-    const int64_t M = D.m_dev != nullptr ? (*D.m_dev < Mcap ? *D.m_dev : Mcap) : Mcap;
-    const int64_t row_lo = (int64_t)band * B.band_rows;
-    const int64_t cap_hi = row_lo + B.band_rows < Mcap ? row_lo + B.band_rows : Mcap;
-    const int64_t row_hi = row_lo + B.band_rows < M ? row_lo + B.band_rows : M;
+    const int64_t band_rows = B.band_rows_of[di];
+    const int64_t row_lo = (int64_t)band * band_rows;
+    const int64_t cap_hi = row_lo + band_rows < Mcap ? row_lo + band_rows : Mcap;
     const int n0 = tile_n * kTile2, k0 = tile_k * kTile2;
     const int N = D.N, Ktot = D.K + D.K2;
     const Src SZ{D.dZ, nullptr, D.lddz, 0, N, 0, nullptr, nullptr, nullptr, nullptr, 0};
     const Src SX{D.X, D.X2, D.ldx, D.ldx2, D.K, D.K2, D.in_scale, D.in_shift, D.in_scale2, D.in_shift2,
                  D.in_relu};
+    // which matrix / columns this thread loads (the same for every chunk); the prologue's constants come after the first loads
+    Pro PZ, PX;
+    {
+        const int c = threadIdx.x % (kTile2 / 4);
+        PZ.second = false; PZ.cc = n0 + 4 * c; PZ.cmax = N;
+        const int col = k0 + 4 * c;
+        PX.second = SX.c2 > 0 && col >= SX.c1;
+        PX.cc = PX.second ? col - SX.c1 : col;
+        PX.cmax = PX.second ? SX.c2 : SX.c1;
+    }
+    // the ring: chunks 0 .. 2 of the band requested at once (bounded by the CAPACITY of the band: the row count on the device
+    // is not waited for)
+    Chunk ring0, ring1, ring2;
+    chunk_load_one(ring0.z, SZ, PZ, row_lo, cap_hi);
+    chunk_load_one(ring0.x, SX, PX, row_lo, cap_hi);
+    if (row_lo + kChunk2 < cap_hi) {
+        chunk_load_one(ring1.z, SZ, PZ, row_lo + kChunk2, cap_hi);
+        chunk_load_one(ring1.x, SX, PX, row_lo + kChunk2, cap_hi);
+    }
+    if (kRing > 2 && row_lo + 2 * kChunk2 < cap_hi) {
+        chunk_load_one(ring2.z, SZ, PZ, row_lo + 2 * kChunk2, cap_hi);
+        chunk_load_one(ring2.x, SX, PX, row_lo + 2 * kChunk2, cap_hi);
+    }
+    const int64_t M = D.m_dev != nullptr ? (*D.m_dev < Mcap ? *D.m_dev : Mcap) : Mcap;
+    const int64_t row_hi = row_lo + band_rows < M ? row_lo + band_rows : M;
+    if (row_lo >= row_hi && B.ws[di] == nullptr) return;
+    fill_pro(PX, SX);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave >> 2, wk = wave & 3;
 
-    cwn::frag_cd acc[4][4];
+    cwn::frag_cd acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = (cwn::frag_cd){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 2; ++c) acc[a][c] = (cwn::frag_cd){0.f, 0.f, 0.f, 0.f};
     f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = D.db != nullptr && tile_k == 0;
-
-    f32x4 vz[kU], vx[kU];
-    tile_load<true, kTile2>(vz, SZ, n0, row_lo, cap_hi);
-    tile_load<true, kTile2>(vx, SX, k0, row_lo, cap_hi);
-    if (row_lo >= row_hi && B.ws[di] == nullptr) return;
-    const Pro PZ = make_pro<kTile2>(SZ, n0), PX = make_pro<kTile2>(SX, k0);
     // this lane's corner of a 4 x 16 block: row 4g + j / 4 (+ 16 for the second half), column 4 (j % 4)
     const int frag_off = (4 * g + (j >> 2)) * kLd2 + 4 * (j & 3);
-    const uint16_t* const za = zp + frag_off + wn * 64;
-    const uint16_t* const xa = xp + frag_off + wk * 64;
-    for (int64_t row0 = row_lo; row0 < row_hi; row0 += kChunk2) {
-        __syncthreads();                          // everyone is done reading the previous chunk
-        const f32x4 cs = tile_store_split(zp, vz, PZ, row0, row_hi);
+    const int frag_z = frag_off + wn * 64, frag_x = frag_off + wk * 32;
+
+    // one chunk: planes <- the ring slot, the slot re-requested three chunks ahead, the MFMAs
+    int set = 0;
+    auto step = [&](Chunk& C, int64_t row0) {
+        const f32x4 cs = chunk_store_one<true>(zp[set], C.z, PZ, row0, row_hi);
         if (do_bias && !(B.dbg & 4)) bsum += cs;
-        tile_store_split(xp, vx, PX, row0, row_hi);
+        chunk_store_one<false>(xp[set], C.x, PX, row0, row_hi);
         __syncthreads();
-        if (row0 + kChunk2 < row_hi) {            // next chunk in flight during the MFMAs
-            tile_load<true, kTile2>(vz, SZ, n0, row0 + kChunk2, cap_hi);
-            tile_load<true, kTile2>(vx, SX, k0, row0 + kChunk2, cap_hi);
+        if (row0 + kRing * kChunk2 < row_hi) {
+            chunk_load_one(C.z, SZ, PZ, row0 + kRing * kChunk2, cap_hi);
+            chunk_load_one(C.x, SX, PX, row0 + kRing * kChunk2, cap_hi);
         }
-        if (B.dbg & 2) continue;
-        uint4 xh[4], xm[4], xl[4];
+        const uint16_t* const za = zp[set] + frag_z;
+        const uint16_t* const xa = xp[set] + frag_x;
+        set ^= 1;
+        if (B.dbg & 2) return;
+        // all six fragments of the wave, then the six terms of cwn::mfma_split6 (same terms, same order per tile) ACROSS the
+        // eight tiles: consecutive MFMAs never wait for each other's accumulator
+        uint4 xh[2], xm[2], xl[2], zh[4], zm[4], zl[4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) frag3(xa + kt * 16, xh[kt], xm[kt], xl[kt]);
+        for (int kt = 0; kt < 2; ++kt) frag3(xa + kt * 16, xh[kt], xm[kt], xl[kt]);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            uint4 zh, zm, zl;
-            frag3(za + nt * 16, zh, zm, zl);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = cwn::mfma_split6(zh, zm, zl, xh[kt], xm[kt], xl[kt], acc[nt][kt]);
-        }
+        for (int nt = 0; nt < 4; ++nt) frag3(za + nt * 16, zh[nt], zm[nt], zl[nt]);
+#define CWN_TN_TERM(ZP, XP)                                                                                              \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                   \
+        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cwn::as_frag(ZP[nt]), cwn::as_frag(XP[kt]), acc[nt][kt], 0, 0, 0);
+        CWN_TN_TERM(zl, xh)
+        CWN_TN_TERM(zh, xl)
+        CWN_TN_TERM(zm, xm)
+        CWN_TN_TERM(zm, xh)
+        CWN_TN_TERM(zh, xm)
+        CWN_TN_TERM(zh, xh)
+#undef CWN_TN_TERM
+    };
+    for (int64_t row0 = row_lo; row0 < row_hi; row0 += kRing * kChunk2) {
+        step(ring0, row0);
+        if (row0 + kChunk2 < row_hi) step(ring1, row0 + kChunk2);
+        if (kRing > 2 && row0 + 2 * kChunk2 < row_hi) step(ring2, row0 + 2 * kChunk2);
     }
-    // acc[nt][kt][r] = partial dW[n0 + wn*64 + nt*16 + 4g + r][k0 + wk*64 + kt*16 + j]
+    // acc[nt][kt][r] = partial dW[n0 + wn*64 + nt*16 + 4g + r][k0 + wk*32 + kt*16 + j]
     if (B.dbg & 1) return;
     float* const ws = B.ws[di];
     float* const wsW = ws != nullptr ? ws + (int64_t)band * N * Ktot : nullptr;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
-                const int k = k0 + wk * 64 + kt * 16 + j;
+                const int k = k0 + wk * 32 + kt * 16 + j;
                 if (n < N && k < Ktot) {
                     if (wsW != nullptr) wsW[(int64_t)n * Ktot + k] = acc[nt][kt][r];
                     else atomicAdd(D.dW + (int64_t)n * D.lddw + k, acc[nt][kt][r]);
                 }
             }
     if (do_bias) {
-        // thread t summed columns 4 (t % 32) .. +3 over the rows t / 32 + 8 u of every chunk: eight partial sums per column
+        // thread t summed columns 4 (t % 32) .. +3 over the rows t / 32 + 16 u of every chunk: sixteen partial sums per column
         __syncthreads();
-        float* red = reinterpret_cast<float*>(zp);          // [8][128]
+        float* red = reinterpret_cast<float*>(zp[0]);       // [16][128]
         *reinterpret_cast<f32x4*>(red + (threadIdx.x / (kTile2 / 4)) * kTile2 + 4 * (threadIdx.x % (kTile2 / 4))) = bsum;
         __syncthreads();
         if (threadIdx.x < kTile2 && n0 + (int)threadIdx.x < N) {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < kThreads / (kTile2 / 4); ++i) s += red[i * kTile2 + threadIdx.x];
+            for (int i = 0; i < kThreads2 / (kTile2 / 4); ++i) s += red[i * kTile2 + threadIdx.x];
             if (ws != nullptr) ws[(int64_t)B.bands[di] * N * Ktot + (int64_t)band * N + n0 + threadIdx.x] = s;
             else atomicAdd(D.db + n0 + threadIdx.x, s);
         }
@@ -482,8 +573,9 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
     const bool split = fast && !split_off;           // the bf16-split kernel: 128 x 128 tiles, 32-row chunks, two per CU
     const int tile = split ? kTile2 : kTile;
     for (int i = 0; i < n; ++i) {
-        B.tiles_n[i] = (descs[i].N + tile - 1) / tile;
-        B.tiles_k[i] = (descs[i].K + descs[i].K2 + tile - 1) / tile;
+        if ((descs[i].N + tile - 1) / tile > INT16_MAX || (descs[i].K + descs[i].K2 + tile - 1) / tile > INT16_MAX) return CWN_ERR_TOO_LARGE;
+        B.tiles_n[i] = (int16_t)((descs[i].N + tile - 1) / tile);
+        B.tiles_k[i] = (int16_t)((descs[i].K + descs[i].K2 + tile - 1) / tile);
     }
     // Rows of M per workgroup (workspace layouts are sized for kBandRows: an upper bound on the bands).  The chip holds
     // kResident workgroups of this kernel at once (4 per CU: 40 KB of LDS, 100 registers); a launch costs about
@@ -492,16 +584,28 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
     // 48.8 us at 128 / 192 / 256 / 320 / 384 / 448 / 512 rows (2200 ... 600 workgroups; tools/ubench_tn24.py with
     // CWN_TN_BAND), where doubling from 128 until <= 2048 workgroups had picked 256.
     static const int band_env = getenv("CWN_TN_BAND") ? atoi(getenv("CWN_TN_BAND")) : 0;     // tuning: fixed rows per workgroup
-    const int64_t kResident = split ? 512 : 1024;
-    const double fixed = split ? kTnFixed2 : 6.0, per_chunk = split ? 0.5 : 1.0;    // (in 64-row chunk-times of the fp32 kernel)
+    const int64_t kResident = split ? 256 : 1024;
+    const double fixed = split ? kTnFixed2 : 6.0, per_chunk = split ? 0.6 : 1.0;    // (in 64-row chunk-times of the fp32 kernel)
+    const int chunk = split ? kChunk2 : kChunk;
+    // a target of `cand` rows per workgroup; descriptor i is cut into ceil(M_i / cand) bands of EQUAL length (rounded up to the
+    // chunk): the workgroups of a launch end together instead of a short last band per descriptor idling its CU
+    auto bands_of = [&](int i, int cand) { return (descs[i].M + cand - 1) / cand; };
+    auto rows_of = [&](int i, int cand) {
+        const int64_t nb = bands_of(i, cand);
+        if (!split || nb == 0) return (int64_t)cand;
+        return ((descs[i].M + nb - 1) / nb + chunk - 1) / chunk * chunk;
+    };
     int band_rows = kBandRows;
     {
         double best = 0.0;
         for (int cand = kBandRows; cand <= kMaxBandRows; cand += kChunk) {
             if (band_env >= kBandRows && band_env % kChunk == 0 && cand != band_env) continue;
-            int64_t nb = 0;
-            for (int i = 0; i < n; ++i) nb += ((descs[i].M + cand - 1) / cand) * B.tiles_n[i] * B.tiles_k[i];
-            const double cost = (double)((nb + kResident - 1) / kResident) * (fixed + per_chunk * cand / (double)kChunk);
+            int64_t nb = 0, longest = 0;
+            for (int i = 0; i < n; ++i) {
+                nb += bands_of(i, cand) * B.tiles_n[i] * B.tiles_k[i];
+                longest = rows_of(i, cand) > longest ? rows_of(i, cand) : longest;
+            }
+            const double cost = (double)((nb + kResident - 1) / kResident) * (fixed + per_chunk * (double)longest / (double)kChunk);
             if (cand == kBandRows || cost < best || (band_env == cand)) {
                 best = cost;
                 band_rows = cand;
@@ -510,13 +614,13 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
     }
     blocks = 0;
     for (int i = 0; i < n; ++i) {
-        const int64_t bands = (descs[i].M + band_rows - 1) / band_rows;
+        const int64_t bands = bands_of(i, band_rows);
         B.bands[i] = (int32_t)bands;
+        B.band_rows_of[i] = (int32_t)rows_of(i, band_rows);
         B.blk_start[i] = (int32_t)blocks;
         blocks += bands * B.tiles_n[i] * B.tiles_k[i];
         if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     }
-    B.band_rows = band_rows;
     for (int i = n; i <= CWN_GEMM_TN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
     if (blocks == 0) return CWN_OK;
     static const int dbg = getenv("CWN_TN_DBG") ? atoi(getenv("CWN_TN_DBG")) : 0;
@@ -529,7 +633,7 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
         }
     }
     hipStream_t stream = (hipStream_t)stream_;
-    if (split) gemm_tn_split_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
+    if (split) gemm_tn_split_kernel<<<dim3((unsigned)blocks), dim3(kThreads2), 0, stream>>>(B);
     else if (fast) gemm_tn_kernel<true><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
     else gemm_tn_kernel<false><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B);
     if (workspace != nullptr) tn_reduce_kernel<<<dim3(64, n), dim3(kThreads), 0, stream>>>(B);

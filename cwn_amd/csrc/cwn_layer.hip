@@ -1227,7 +1227,7 @@ struct PackMany {            // up to CWN_LAYER_PACK_MAX weights of one width in
     const float* W[CWN_LAYER_PACK_MAX];
     unsigned char* out[CWN_LAYER_PACK_MAX];
     int64_t ldw[CWN_LAYER_PACK_MAX];
-    int32_t trans;           // 1: the transposed halves (the backward launch's operand: cwn_layer_bwd.hip)
+    uint8_t trans[CWN_LAYER_PACK_MAX];   // 1: the transposed halves (the backward launch's operand: cwn_layer_bwd.hip)
 };
 
 template <int F>
@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackMany P) {
     const int lane = g & 63, chunk3 = g >> 6;                     // chunk3 = (ct * 2 + h) * KS + ks
     const int ks = chunk3 % KS, h = (chunk3 / KS) & 1, ct = chunk3 / (2 * KS);
     float e[8];
-    if (P.trans) {           // element k of lane (kq, n): W[ks * 32 + kq * 8 + k][h * F + ct * 16 + n]
+    if (P.trans[blockIdx.y]) {           // element k of lane (kq, n): W[ks * 32 + kq * 8 + k][h * F + ct * 16 + n]
         const float* src = W + (int64_t)(ks * 32 + (lane >> 4) * 8) * ldw + h * F + ct * 16 + (lane & 15);
 #pragma unroll
         for (int k = 0; k < 8; ++k) e[k] = src[(int64_t)k * ldw];
@@ -1527,21 +1527,28 @@ extern "C" size_t cwn_layer_packed_weight_bytes(int32_t F) {
     return (F == 64 || F == 128) ? (size_t)F * 2 * F * 6 : 0;
 }
 
-static int pack_many(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n, int trans,
+static int pack_many(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, void* const* out_t, int32_t n,
                      cwn_stream_t stream_) {
-    if ((F != 64 && F != 128) || W == nullptr || out == nullptr || ldw == nullptr || n < 0) return CWN_ERR_BAD_ARG;
+    if ((F != 64 && F != 128) || W == nullptr || (out == nullptr && out_t == nullptr) || ldw == nullptr || n < 0) return CWN_ERR_BAD_ARG;
     const int threads = (F / 16) * 2 * (F / 32) * 64;
     hipStream_t stream = (hipStream_t)stream_;
-    for (int i0 = 0; i0 < n; i0 += CWN_LAYER_PACK_MAX) {
-        const int m = n - i0 < CWN_LAYER_PACK_MAX ? n - i0 : CWN_LAYER_PACK_MAX;
+    // entries: (weight, form); CWN_LAYER_PACK_MAX per launch
+    const int forms = (out != nullptr) + (out_t != nullptr);
+    const int64_t total = (int64_t)n * forms;
+    for (int64_t e0 = 0; e0 < total; e0 += CWN_LAYER_PACK_MAX) {
+        const int m = (int)(total - e0 < CWN_LAYER_PACK_MAX ? total - e0 : CWN_LAYER_PACK_MAX);
         PackMany P{};
-        P.trans = trans;
         for (int i = 0; i < m; ++i) {
-            if (W[i0 + i] == nullptr || out[i0 + i] == nullptr || ldw[i0 + i] < 2 * F) return CWN_ERR_BAD_ARG;
-            if (((uintptr_t)W[i0 + i] & 3u) || !al16(out[i0 + i])) return CWN_ERR_ALIGN;
-            P.W[i] = W[i0 + i];
-            P.out[i] = (unsigned char*)out[i0 + i];
-            P.ldw[i] = ldw[i0 + i];
+            const int64_t e = e0 + i;
+            const int form = forms == 2 ? (int)(e / n) : (out != nullptr ? 0 : 1);
+            const int w = (int)(e % n);
+            void* o = form == 0 ? out[w] : out_t[w];
+            if (W[w] == nullptr || o == nullptr || ldw[w] < 2 * F) return CWN_ERR_BAD_ARG;
+            if (((uintptr_t)W[w] & 3u) || !al16(o)) return CWN_ERR_ALIGN;
+            P.W[i] = W[w];
+            P.out[i] = (unsigned char*)o;
+            P.ldw[i] = ldw[w];
+            P.trans[i] = (uint8_t)form;
         }
         if (F == 128) pack_weights_kernel<128><<<dim3((threads + 255) / 256, m), dim3(256), 0, stream>>>(P);
         else pack_weights_kernel<64><<<dim3((threads + 255) / 256, m), dim3(256), 0, stream>>>(P);
@@ -1551,12 +1558,18 @@ static int pack_many(const float* const* W, const int64_t* ldw, int32_t F, void*
 
 extern "C" int cwn_layer_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
                                                cwn_stream_t stream_) {
-    return pack_many(W, ldw, F, out, n, 0, stream_);
+    return pack_many(W, ldw, F, out, nullptr, n, stream_);
 }
 
 extern "C" int cwn_layer_pack_weights_t_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
                                                  cwn_stream_t stream_) {
-    return pack_many(W, ldw, F, out, n, 1, stream_);
+    return pack_many(W, ldw, F, nullptr, out, n, stream_);
+}
+
+extern "C" int cwn_layer_pack_weights_both_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
+                                                    void* const* out_t, int32_t n, cwn_stream_t stream_) {
+    if (out == nullptr || out_t == nullptr) return CWN_ERR_BAD_ARG;
+    return pack_many(W, ldw, F, out, out_t, n, stream_);
 }
 
 extern "C" int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream_) {

@@ -546,6 +546,34 @@ extern "C" int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
+// ---- the start of a training step: zero the gradients, zero the step arena, count the step -----------------------------
+namespace {
+__global__ __launch_bounds__(256) void step_begin_kernel(uint4* __restrict__ a, int64_t na, uint4* __restrict__ b, int64_t nb,
+                                                         int32_t* __restrict__ step, const int64_t* __restrict__ active) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += stride) {
+        if (i < na) a[i] = z;
+        else b[i - na] = z;
+    }
+    if (step != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && (active == nullptr || *active > 0)) *step += 1;
+}
+}  // namespace
+
+extern "C" int cwn_step_begin(void* a, int64_t a_bytes, void* b, int64_t b_bytes, int32_t* step, const int64_t* active,
+                              cwn_stream_t stream_) {
+    if (a_bytes < 0 || b_bytes < 0 || (a_bytes & 15) || (b_bytes & 15)) return CWN_ERR_BAD_ARG;
+    if ((a_bytes > 0 && a == nullptr) || (b_bytes > 0 && b == nullptr)) return CWN_ERR_BAD_ARG;
+    if ((((uintptr_t)a) | ((uintptr_t)b)) & 15u) return CWN_ERR_ALIGN;
+    const int64_t n = (a_bytes + b_bytes) / 16;
+    if (n == 0 && step == nullptr) return CWN_OK;
+    int64_t blocks = (n + 4 * 256 - 1) / (4 * 256);        // four 16-B stores per thread
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    step_begin_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>((uint4*)a, a_bytes / 16, (uint4*)b,
+                                                                                       b_bytes / 16, step, active);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
 // ---- the loss of a training step and its gradient in ONE launch ------------------------------------------
 // exp/train_utils.py:62-73: loss = criterion(pred, targets); loss.backward().  For the elementwise-mean criteria
 // (L1Loss 'regression', MSELoss 'mse_regression', BCEWithLogitsLoss 'bin_classification': exp/train_utils.py:20-31)

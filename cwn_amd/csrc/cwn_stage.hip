@@ -90,6 +90,12 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     const int l15 = lane & 15, kq = lane >> 4;
     const bool two = D.X2 != nullptr;
 
+    // workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding global load: here
+    // the tiles and the weight, which keep streaming across the barrier)
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
     // an input tile: TM rows x F / 4 float4, two per thread, row-contiguous; rows past M are clamped, not guarded (their
     // outputs are neither stored nor counted)
     typedef float4 RowRegs[kV];
@@ -137,12 +143,6 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
             *reinterpret_cast<uint2*>(dst + 2 * kPlaneElems) = pl;
         }
     };
-    // workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding global load: here
-    // the weight, which keeps streaming across the barrier)
-    auto lds_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
     // the stationary operand: this wave's 16 output columns of one F x F block, [k step][plane]; two sets
     typedef uint4 WeightRegs[kKS][3];
     WeightRegs wfA, wfB;
@@ -172,26 +172,27 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
 
     // requests: rows and the constants behind them first, then the weight (loads return in order: a constant behind 96 KB of
     // weight is a wait for the weight)
+    // live BatchNorm prologue (cwn_bn_live.h): thread c < F the column c of X's record, thread F + c of X2's; their slot sums
+    // are requested AHEAD of the tiles (loads return in order: behind the tiles they would wait for them)
+    const bool live0 = D.in_bn.slots != nullptr, live1 = D.in_bn2.slots != nullptr;
+    const int live_which = threadIdx.x / F, live_col = threadIdx.x % F;
+    const bool live_mine = (live_which == 0 && live0) || (live_which == 1 && live1);
+    cwn::BnLiveRegs live_regs;
+    if (live_mine) cwn::bn_live_request(live_which == 0 ? D.in_bn : D.in_bn2, F, live_col, live_regs);
     request_rows(v0, D.X, D.ldx);
     if (row0 >= Mv) return;                         // (uniform) a tile past the batch's own rows: nothing to store or count
     if (two) request_rows(v1, D.X2, D.ldx2);
-    const bool live0 = D.in_bn.slots != nullptr, live1 = D.in_bn2.slots != nullptr;
     if (live0 || live1) {
-        // live BatchNorm prologue (cwn_bn_live.h): thread c < F the column c of X's record, thread F + c of X2's; the first
-        // workgroup of the descriptor writes what the backward reads and the running statistics
+        // ... the first workgroup of the descriptor writes what the backward reads and the running statistics
         float* const aff = reinterpret_cast<float*>(live_scratch);
-        const bool writer = (int)blockIdx.x == B.blk_start[di];
-        const int which = threadIdx.x / F, col = threadIdx.x % F;
-        if (which < 2) {
-            const cwn_bn_live& L = which == 0 ? D.in_bn : D.in_bn2;
-            if (L.slots != nullptr) {
-                float sc, sh;
-                cwn::bn_live_column(L, F, Mv, col, writer, sc, sh);
-                aff[(which * 2) * F + col] = sc;
-                aff[(which * 2 + 1) * F + col] = sh;
-            }
+        if (live_mine) {
+            float sc, sh;
+            cwn::bn_live_finish(live_which == 0 ? D.in_bn : D.in_bn2, live_regs, F, Mv, live_col,
+                                (int)blockIdx.x == B.blk_start[di], sc, sh);
+            aff[(live_which * 2) * F + live_col] = sc;
+            aff[(live_which * 2 + 1) * F + live_col] = sh;
         }
-        __syncthreads();
+        lds_barrier();                              // (LDS traffic only: the tiles stay in flight)
     }
     const Pro p0 = request_pro(D.in_scale, D.in_shift, (D.in_relu & 1) != 0, live0 ? 0 : -1);
     Pro p1 = p0;
@@ -341,7 +342,14 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
         }
     };
 
-    // requests: the two tiles, the constants of this thread's four columns (the same in every row it stages), the weight
+    // requests: (a live consumer: the slot sums of its s1 | s2, thread t < 2 F one column, AHEAD of the tiles,) the two tiles,
+    // the constants of this thread's four columns (the same in every row it stages), the weight
+    float slot_t[CWN_BN_SLOTS];
+    const bool slot_mine = D.s_slots != nullptr && (int)threadIdx.x < 2 * F;
+    if (slot_mine) {
+#pragma unroll
+        for (int q = 0; q < CWN_BN_SLOTS; ++q) slot_t[q] = D.s_slots[(size_t)q * 2 * F + threadIdx.x];
+    }
     request_rows(vy, D.dy, D.lddy);
     request_rows(vz, D.z, D.ldz);
     const int c4 = threadIdx.x % (F / 4);
@@ -354,21 +362,18 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
         const float4 rs = reinterpret_cast<const float4*>(D.rstd)[c4];
         float4 s1, s2;
         if (D.s_slots != nullptr) {
-            // the sums the producing launch left in the slots: thread t < 2 F one column of s1 | s2, slot order
-            if ((int)threadIdx.x < 2 * F) {
-                float t[CWN_BN_SLOTS];
-#pragma unroll
-                for (int q = 0; q < CWN_BN_SLOTS; ++q) t[q] = D.s_slots[(size_t)q * 2 * F + threadIdx.x];
+            // the sums the producing launch left in the slots, in slot order
+            if (slot_mine) {
                 float a = 0.f;
 #pragma unroll
-                for (int q = 0; q < CWN_BN_SLOTS; ++q) a += t[q];
+                for (int q = 0; q < CWN_BN_SLOTS; ++q) a += slot_t[q];
                 bn_scratch[threadIdx.x] = a;
                 if (first_block) ((int)threadIdx.x < F ? D.s1 : D.s2 - F)[threadIdx.x] = a;
             }
-            __syncthreads();
+            lds_barrier();                       // (LDS traffic only: the tiles stay in flight)
             s1 = reinterpret_cast<const float4*>(bn_scratch)[c4];
             s2 = reinterpret_cast<const float4*>(bn_scratch + F)[c4];
-            __syncthreads();                     // (the scratch is the producer side's staging area below)
+            // (the producer side stages through the same scratch -- behind the barrier in front of the product below)
         } else {
             s1 = reinterpret_cast<const float4*>(D.s1)[c4];
             s2 = reinterpret_cast<const float4*>(D.s2)[c4];
@@ -518,13 +523,15 @@ struct PackTable {
     const float* W[CWN_STAGE_PACK_MAX];
     unsigned char* out[CWN_STAGE_PACK_MAX];
     int64_t ldw[CWN_STAGE_PACK_MAX];
+    uint8_t trans[CWN_STAGE_PACK_MAX];        // per entry: the block of the transposed weight
 };
+static_assert(sizeof(PackTable) <= 4096, "kernel-argument segment");
 
 // (the layout of cwn_update_mlp_pack_weights_f32: chunk ((tile * KS + ks) * 3 + plane), lane l = kq * 16 + n holds
 // W[tile * 16 + n][ks * 32 + kq * 8 ..] of that plane)
 // TRANS: the block of the TRANSPOSED weight (dX = dz W: output column = input feature of the Linear, reduction over its
 // outputs): lane l = kq * 16 + n of chunk (tile, ks) holds W[ks * 32 + kq * 8 ..][tile * 16 + n]
-template <int F, bool TRANS>
+template <int F>
 __global__ __launch_bounds__(256) void pack_stage_weights_kernel(PackTable T) {
     constexpr int KS = F / 32;
     constexpr int kPerWeight = (F / 16) * KS * 64;                 // one thread per (tile, ks, lane)
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(256) void pack_stage_weights_kernel(PackTable T) {
     if (g >= kPerWeight) return;
     const int lane = g & 63, ks = (g >> 6) % KS, tile = (g >> 6) / KS;
     float4 a, b;
-    if constexpr (TRANS) {
+    if (T.trans[e]) {
         const float* src = T.W[e] + (int64_t)(ks * 32 + (lane >> 4) * 8) * T.ldw[e] + tile * 16 + (lane & 15);
         const int64_t ld = T.ldw[e];
         a = make_float4(src[0], src[ld], src[2 * ld], src[3 * ld]);
@@ -554,37 +561,49 @@ __global__ __launch_bounds__(256) void pack_stage_weights_kernel(PackTable T) {
 }  // namespace
 
 namespace {
-int pack_stage_many(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n, bool trans, cwn_stream_t stream_) {
-    if ((F != 64 && F != 128) || n < 0 || n > CWN_STAGE_PACK_MAX) return CWN_ERR_BAD_ARG;
+// entries: n blocks in the plain form into out[] (when given) and the same n in the transposed form into out_t[] (when given)
+int pack_stage_many(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, void* const* out_t, int32_t n,
+                    cwn_stream_t stream_) {
+    if ((F != 64 && F != 128) || n < 0) return CWN_ERR_BAD_ARG;
+    const int forms = (out != nullptr) + (out_t != nullptr);
     if (n == 0) return CWN_OK;
-    if (W == nullptr || ldw == nullptr || out == nullptr) return CWN_ERR_BAD_ARG;
+    if (W == nullptr || ldw == nullptr || forms == 0 || (int64_t)n * forms > CWN_STAGE_PACK_MAX) return CWN_ERR_BAD_ARG;
     PackTable T{};
-    for (int e = 0; e < n; ++e) {
-        if (W[e] == nullptr || out[e] == nullptr || ldw[e] < F) return CWN_ERR_BAD_ARG;
-        if (((uintptr_t)W[e] & 3u) || ((uintptr_t)out[e] & 15u)) return CWN_ERR_ALIGN;
-        T.W[e] = W[e];
-        T.out[e] = (unsigned char*)out[e];
-        T.ldw[e] = ldw[e];
+    int m = 0;
+    for (int form = 0; form < 2; ++form) {
+        void* const* o = form == 0 ? out : out_t;
+        if (o == nullptr) continue;
+        for (int e = 0; e < n; ++e, ++m) {
+            if (W[e] == nullptr || o[e] == nullptr || ldw[e] < F) return CWN_ERR_BAD_ARG;
+            if (((uintptr_t)W[e] & 3u) || ((uintptr_t)o[e] & 15u)) return CWN_ERR_ALIGN;
+            T.W[m] = W[e];
+            T.out[m] = (unsigned char*)o[e];
+            T.ldw[m] = ldw[e];
+            T.trans[m] = (uint8_t)form;
+        }
     }
     const int threads = (F / 16) * (F / 32) * 64;
     hipStream_t stream = (hipStream_t)stream_;
-    const dim3 grid((threads + 255) / 256, n);
-    if (F == 128 && !trans) pack_stage_weights_kernel<128, false><<<grid, dim3(256), 0, stream>>>(T);
-    else if (F == 128) pack_stage_weights_kernel<128, true><<<grid, dim3(256), 0, stream>>>(T);
-    else if (!trans) pack_stage_weights_kernel<64, false><<<grid, dim3(256), 0, stream>>>(T);
-    else pack_stage_weights_kernel<64, true><<<grid, dim3(256), 0, stream>>>(T);
+    const dim3 grid((threads + 255) / 256, m);
+    if (F == 128) pack_stage_weights_kernel<128><<<grid, dim3(256), 0, stream>>>(T);
+    else pack_stage_weights_kernel<64><<<grid, dim3(256), 0, stream>>>(T);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 }  // namespace
 
 extern "C" int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
                                                     int32_t n, cwn_stream_t stream) {
-    return pack_stage_many(W, ldw, F, out, n, false, stream);
+    return out == nullptr ? CWN_ERR_BAD_ARG : pack_stage_many(W, ldw, F, out, nullptr, n, stream);
 }
 
 extern "C" int cwn_update_mlp_pack_weights_t_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
                                                       int32_t n, cwn_stream_t stream) {
-    return pack_stage_many(W, ldw, F, out, n, true, stream);
+    return out == nullptr ? CWN_ERR_BAD_ARG : pack_stage_many(W, ldw, F, nullptr, out, n, stream);
+}
+
+extern "C" int cwn_update_mlp_pack_weights_both_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
+                                                         void* const* out_t, int32_t n, cwn_stream_t stream) {
+    return (out == nullptr || out_t == nullptr) ? CWN_ERR_BAD_ARG : pack_stage_many(W, ldw, F, out, out_t, n, stream);
 }
 
 extern "C" int cwn_dense_stage_f32(const cwn_stage_desc* descs, int n, int32_t F, cwn_stream_t stream_) {

@@ -1423,17 +1423,19 @@ def pack_layer_weights_many(weights: Sequence[Tensor], transposed: bool = False)
         Wp = (C.c_void_p * n)(*[w.data_ptr() for _, w in ws])
         ld = (C.c_int64 * n)(*[w.stride(0) for _, w in ws])
         Op = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
-        _ffi.check(L.cwn_layer_pack_weights_many_f32(Wp, ld, F, Op, n, _ffi.stream_ptr(ws[0][1].device)),
-                   'cwn_layer_pack_weights_many_f32')
+        outs_t = [torch.empty(nbytes, dtype=torch.uint8, device=w.device) for _, w in ws] if transposed else None
+        if transposed:
+            Ot = (C.c_void_p * n)(*[o.data_ptr() for o in outs_t])
+            _ffi.check(L.cwn_layer_pack_weights_both_many_f32(Wp, ld, F, Op, Ot, n, _ffi.stream_ptr(ws[0][1].device)),
+                       'cwn_layer_pack_weights_both_many_f32')
+        else:
+            _ffi.check(L.cwn_layer_pack_weights_many_f32(Wp, ld, F, Op, n, _ffi.stream_ptr(ws[0][1].device)),
+                       'cwn_layer_pack_weights_many_f32')
         for (weight, w), out in zip(ws, outs):
             key = id(weight)
             ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
             _packed_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_weights.pop(k, None)), out, _pack_token)
         if transposed:
-            outs_t = [torch.empty(nbytes, dtype=torch.uint8, device=w.device) for _, w in ws]
-            Ot = (C.c_void_p * n)(*[o.data_ptr() for o in outs_t])
-            _ffi.check(L.cwn_layer_pack_weights_t_many_f32(Wp, ld, F, Ot, n, _ffi.stream_ptr(ws[0][1].device)),
-                       'cwn_layer_pack_weights_t_many_f32')
             for (weight, w), out in zip(ws, outs_t):
                 key = id(weight)
                 _packed_weights_t[key] = (_pack_token, weakref.ref(weight, lambda _r, k=key: _packed_weights_t.pop(k, None)), out)
@@ -1585,8 +1587,9 @@ def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True) 
             by_F.setdefault(F, []).append((weight, w, c0))
     for F, blocks in by_F.items():
         nbytes = int(L.cwn_update_mlp_packed_weight_bytes(F))
-        for lo in range(0, len(blocks), _ffi.STAGE_PACK_MAX):
-            part = blocks[lo: lo + _ffi.STAGE_PACK_MAX]
+        per = _ffi.STAGE_PACK_MAX // 2 if transposed else _ffi.STAGE_PACK_MAX     # (both forms share a launch's table)
+        for lo in range(0, len(blocks), per):
+            part = blocks[lo: lo + per]
             n = len(part)
             dev = part[0][1].device
             buf = torch.empty(n * nbytes, dtype=torch.uint8, device=dev)
@@ -1594,15 +1597,16 @@ def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True) 
             Wp = (C.c_void_p * n)(*[w.data_ptr() + 4 * c0 for _, w, c0 in part])
             ld = (C.c_int64 * n)(*[w.stride(0) for _, w, _ in part])
             Op = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
-            _ffi.check(L.cwn_update_mlp_pack_weights_many_f32(Wp, ld, F, Op, n, _ffi.stream_ptr(dev)),
-                       'cwn_update_mlp_pack_weights_many_f32')
             outs_t = [None] * n
             if transposed:                      # ... and the blocks of the transposed weight (cwn_dense_stage_bwd_f32: dX = dz W)
                 buf_t = torch.empty(n * nbytes, dtype=torch.uint8, device=dev)
                 outs_t = [buf_t[k * nbytes: (k + 1) * nbytes] for k in range(n)]
                 Tp = (C.c_void_p * n)(*[o.data_ptr() for o in outs_t])
-                _ffi.check(L.cwn_update_mlp_pack_weights_t_many_f32(Wp, ld, F, Tp, n, _ffi.stream_ptr(dev)),
-                           'cwn_update_mlp_pack_weights_t_many_f32')
+                _ffi.check(L.cwn_update_mlp_pack_weights_both_many_f32(Wp, ld, F, Op, Tp, n, _ffi.stream_ptr(dev)),
+                           'cwn_update_mlp_pack_weights_both_many_f32')
+            else:
+                _ffi.check(L.cwn_update_mlp_pack_weights_many_f32(Wp, ld, F, Op, n, _ffi.stream_ptr(dev)),
+                           'cwn_update_mlp_pack_weights_many_f32')
             for (weight, w, c0), o, ot in zip(part, outs, outs_t):
                 _packed_stage[_stage_key(w, c0)] = (_stage_token, o, ot, weight._version, WEIGHT_EPOCH)
 
@@ -1631,10 +1635,13 @@ _arenas: Dict[torch.device, '_Arena'] = {}
 
 
 class step_arena:
-    """with ops.step_arena(device): ...one training step..."""
+    """with ops.step_arena(device): ...one training step...
+    `flat` (a float32 gradient buffer to zero), `counter` / `active` (an int32 step counter to advance unless *active <= 0):
+    done by the SAME launch as the arena's fill (cwn_step_begin)."""
 
-    def __init__(self, device):
+    def __init__(self, device, flat: Optional[Tensor] = None, counter: Optional[Tensor] = None, active: Optional[Tensor] = None):
         self.device = torch.device(device)
+        self.flat, self.counter, self.active = flat, counter, active
 
     def __enter__(self):
         a = _arenas.get(self.device)
@@ -1647,8 +1654,14 @@ class step_arena:
                 a.buf = torch.zeros(size, dtype=torch.uint8, device=self.device)
                 a.high = 0
             a.want = 0
-        if a.high:
-            a.buf[:a.high].zero_()
+        flat = self.flat
+        if flat is not None and (flat.dtype != torch.float32 or not flat.is_contiguous() or flat.data_ptr() % 16 or (4 * flat.numel()) % 16):
+            flat.zero_()
+            flat = None
+        if a.high or flat is not None or self.counter is not None:
+            _ffi.check(_ffi.lib().cwn_step_begin(_ffi.ptr(flat), 0 if flat is None else 4 * flat.numel(), a.buf.data_ptr(),
+                                                 (a.high + 15) // 16 * 16, _ffi.ptr(self.counter), _ffi.ptr(self.active),
+                                                 _ffi.stream_ptr(self.device)), 'cwn_step_begin')
         a.used, a.active = 0, True
         return self
 

@@ -59,7 +59,21 @@ class _FusedMeanLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         grad, = ctx.saved_tensors
+        one = _ONES.get(g.device)
+        if one is not None and g.data_ptr() == one.data_ptr():      # the seed of TrainStep's backward: exactly 1
+            return grad, None, None
         return grad * g, None, None
+
+
+_ONES = {}
+
+
+def _one(device) -> torch.Tensor:
+    """A cached scalar 1.0: the seed of loss.backward() without the framework's fill."""
+    t = _ONES.get(device)
+    if t is None:
+        t = _ONES[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
 
 
 _FUSED_KIND = {'regression': 0, 'mse_regression': 1, 'bin_classification': 2}      # = CWN_LOSS_*
@@ -100,6 +114,7 @@ class FlatAdam:
         # a device int64 (or None): the complexes of the batch this step belongs to -- a step on an EMPTY batch of a static
         # epoch changes nothing (static_graph.StaticTrainStep sets it per slot)
         self.active: Optional[torch.Tensor] = None
+        self.counted = False        # the next step()'s count has been taken by the step's opening launch (TrainStep._begin)
         # what TrainStep snapshots around its warm-up
         self.param_groups = [{'params': list(bucket.params)}]
         self.state = {}
@@ -112,7 +127,9 @@ class FlatAdam:
 
     @torch.no_grad()
     def step(self):
-        if self.active is None:
+        if self.counted:                 # (the step's opening launch has advanced the counter: cwn_step_begin)
+            self.counted = False
+        elif self.active is None:
             self.t.add_(1)
         else:
             self.t.add_((self.active > 0).to(torch.int32).view(1))
@@ -196,6 +213,14 @@ class TrainStep:
         # a new batch needs its adjacency plans (forward + transposed) built: part of the step
         # unless the caller trains on a fixed set of batches and says so
         self.rebuild_plans = rebuild_plans
+
+    def _begin(self):
+        """The bracket of one step (ops.step_arena): gradients zeroed, arena zeroed, FlatAdam's counter advanced."""
+        mine = isinstance(self.opt, FlatAdam)
+        if mine:
+            self.opt.counted = True
+        return ops.step_arena(self.bucket.flat.device, flat=self.bucket.flat, counter=self.opt.t if mine else None,
+                              active=self.opt.active if mine else None)
 
     # ---- pieces ------------------------------------------------------------------------------
     @staticmethod
@@ -286,11 +311,11 @@ class TrainStep:
             b = self._restore(i)
             if self.rebuild_plans:
                 b.forget_plans().prepare(backward=True)
-            self.bucket.zero_()
-            with ops.step_arena(self.bucket.flat.device):   # (what the step needs zero on entry: one fill for all of it)
+            # zero_grad + what the step's kernels need zero on entry + the optimizer's step counter: one launch
+            with self._begin():
                 loss = self._loss(b)
                 with ops.accumulate_into_grad():        # gradients are views into self.bucket: kernels add in place
-                    loss.backward()
+                    loss.backward(gradient=_one(loss.device))      # (no fill for the seed; _FusedMeanLoss hands its gradient on as is)
             self._restore(i)                          # drop the references to the autograd graph
             return loss.detach()
         S = self.n_stages
@@ -299,8 +324,7 @@ class TrainStep:
                 b = self._restore(i)
                 if self.rebuild_plans:
                     b.forget_plans().prepare(backward=True)
-                self.bucket.zero_()
-                self._arena = ops.step_arena(self.bucket.flat.device)
+                self._arena = self._begin()
                 self._arena.__enter__()
                 self.staged.begin()
                 self._live_loss = self._loss(b)

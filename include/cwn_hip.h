@@ -313,6 +313,9 @@ int cwn_layer_pack_weights_many_f32(const float* const* W, const int64_t* ldw, i
  * (output column = input feature of the Linear, reduction over its outputs: dX = gY W). */
 int cwn_layer_pack_weights_t_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
                                       cwn_stream_t stream);
+/* ... and both in ONE launch: out[e] the forward form, out_t[e] the transposed one. */
+int cwn_layer_pack_weights_both_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
+                                         void* const* out_t, int32_t n, cwn_stream_t stream);
 
 /* The item table and what the launcher needs to know about it (HOST struct; built by
  * cwn_layer_items_build).  Items are ordered by set.  The *_end fields summarise what the table
@@ -531,7 +534,7 @@ int cwn_update_mlp_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void
 /* the same for n blocks in ONE launch (a training step packs the update / combine weights of all its layers once, after
  * the optimizer has written them): host arrays of n device pointers (the first element of each F x F block: a column
  * offset selects half of a combine weight) / row strides / outputs */
-#define CWN_STAGE_PACK_MAX 96
+#define CWN_STAGE_PACK_MAX 160   /* blocks per launch (the table is a kernel argument: 160 x 25 B) */
 int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
                                          cwn_stream_t stream);
 
@@ -547,7 +550,7 @@ int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* l
  * slot is the order of arrival: the sums are fp64, so two runs differ by ~1e-16 relative before they are rounded to fp32 --
  * reproducible in practice, not by construction; cwn_bn_finalize_f32 over per-band partials stays the deterministic form.
  * ------------------------------------------------------------------------------------------ */
-#define CWN_BN_SLOTS 8
+#define CWN_BN_SLOTS 4
 typedef struct cwn_bn_live {
     double* slots;                 /* [CWN_BN_SLOTS][2][N]: column sums, column sums of squares */
     const float* gamma;            /* [N] or NULL (= 1) */
@@ -606,6 +609,10 @@ int cwn_dense_stage_f32(const cwn_stage_desc* descs_host, int n, int32_t F, cwn_
  * Every acc1 / acc2 / s1 / s2 / constant pointer 16-B aligned. */
 int cwn_update_mlp_pack_weights_t_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
                                            cwn_stream_t stream);
+/* Both forms of the same n blocks in ONE launch (a training step re-packs every weight after the optimizer: one launch
+ * instead of two): out[e] as cwn_update_mlp_pack_weights_many_f32, out_t[e] as cwn_update_mlp_pack_weights_t_many_f32. */
+int cwn_update_mlp_pack_weights_both_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
+                                              void* const* out_t, int32_t n, cwn_stream_t stream);
 typedef struct cwn_bn_bwd_live {
     const float* z;          /* [M, F] (row stride ldz) pre-normalisation values of the stage that receives dx as its dy */
     const float* aff;        /* [4][F]: scale, shift, mean, rstd of its BatchNorm (cwn_bn_live.aff) */
@@ -1035,6 +1042,13 @@ enum { CWN_LOSS_L1 = 0, CWN_LOSS_MSE = 1, CWN_LOSS_BCE_LOGITS = 2 };
  * no gradient and does not count in the mean. */
 int cwn_loss_f32(int32_t kind, const float* pred, const float* y, int64_t n, float* loss, float* grad,
                  const int64_t* n_dev, cwn_stream_t stream);
+
+/* The start of a training step in ONE launch (optimizer.zero_grad() of exp/train_utils.py:61 + what the step's own kernels
+ * need zero on entry + the optimizer's step counter): a[0 .. a_bytes) = 0 (the flat gradient buffer), b[0 .. b_bytes) = 0 (the
+ * step arena of cwn_amd/ops.py: slot sums of the live BatchNorms), and *step += 1 -- only when active == NULL or *active > 0
+ * (cwn_adam_f32's convention: an empty batch of a static epoch is no step).  Pointers 16-B aligned, byte counts multiples of
+ * 16; any of a / b / step may be NULL.  Replaces two fills and an add of the framework. */
+int cwn_step_begin(void* a, int64_t a_bytes, void* b, int64_t b_bytes, int32_t* step, const int64_t* active, cwn_stream_t stream);
 
 /* torch.optim.Adam's update (no amsgrad; weight_decay is the L2 form) for a whole model in one
  * launch: parameters p, gradients g and the moments m, v are each ONE contiguous fp32 buffer of n
