@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
         }
         if (slotted) {
             // the workgroup's 2 F sums leave as 2 F / 64 fully coalesced fp64 atomic instructions
-            __syncthreads();
+            lds_barrier();                        // (LDS traffic only: the stores of Y above are not waited for)
             if (threadIdx.x < 2 * F) {
                 const int which = threadIdx.x / F, col = threadIdx.x % F;
                 double v = live_scratch[which * F + col];
@@ -472,13 +472,13 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
                 bn_scratch[(half * 2 + 1) * F + n0 + q] = b;
             }
         }
-        __syncthreads();
+        lds_barrier();                            // (LDS traffic only: the stores of dx above are not waited for)
         if ((int)threadIdx.x < 2 * F) {
             float v = bn_scratch[threadIdx.x];
             if constexpr (TM > 32) v += bn_scratch[2 * F + threadIdx.x];
             unsafeAtomicAdd(L.slots + (size_t)((int)blockIdx.x % CWN_BN_SLOTS) * 2 * F + threadIdx.x, v);
         }
-        __syncthreads();                          // (a second product of the workgroup stages through the same scratch)
+        lds_barrier();                            // (a second product of the workgroup stages through the same scratch)
     };
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
