@@ -146,24 +146,33 @@ struct LayerArgs {
     int32_t store_y;                         // CWN_LAYER_STORE_Y: Y1 / Y2 of every item also go to big[set].y1 / y2
     BigSet big[kMaxSets];                    // big items only
 #ifdef CWN_LAYER_TIMING
-    unsigned long long* stamps;              // [n_items][64]: [0, 16) phase ends seen by wave 0, [16 + 16 k + w] point k of wave w
+    unsigned long long* stamps;              // [n_items][96]: [0, 16) phase ends seen by wave 0, [16 + 16 k + w] point k of wave w
+                                             // (shader clock: per XCD); [64 + w] / [80 + w]: wave w's first / last instruction on
+                                             // the chip-wide 100-MHz clock (s_memrealtime: comparable across workgroups and launches)
 #endif
 };
 
 #ifdef CWN_LAYER_TIMING
+#define CWN_STAMP_REC 96
 #define CWN_STAMP(k)                                                                   \
     do {                                                                               \
         if (threadIdx.x == 0 && A.stamps != nullptr)                                   \
-            A.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime();    \
+            A.stamps[(size_t)blockIdx.x * CWN_STAMP_REC + (k)] = __builtin_amdgcn_s_memtime();    \
     } while (0)
 #define CWN_WSTAMP(k)                                                                  \
     do {                                                                               \
         if ((threadIdx.x & 63) == 0 && A.stamps != nullptr)                            \
-            A.stamps[(size_t)blockIdx.x * 64 + 16 + 16 * (k) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); \
+            A.stamps[(size_t)blockIdx.x * CWN_STAMP_REC + 16 + 16 * (k) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define CWN_RSTAMP(k)                                                                  \
+    do {                                                                               \
+        if ((threadIdx.x & 63) == 0 && A.stamps != nullptr)                            \
+            A.stamps[(size_t)blockIdx.x * CWN_STAMP_REC + 64 + 16 * (k) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define CWN_STAMP(k) do { } while (0)
 #define CWN_WSTAMP(k) do { } while (0)
+#define CWN_RSTAMP(k) do { } while (0)
 #endif
 
 template <int F> struct Geo {
@@ -417,6 +426,7 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
 
     CWN_STAMP(0);
     CWN_WSTAMP(0);           // every wave: when it starts
+    CWN_RSTAMP(0);
     // ---- 1. item record and set record: ONE round trip ------------------------------------------------
     // lane l reads word l of the item and 8-byte field l of the set record (the kernel-argument segment
     // is ordinary global memory); fields are broadcast with v_readlane where they are used, so they
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
     const bool has_gemm = (fld(I_FLAGS) & 1) != 0;
     // an EMPTY record (no task): a table of fixed capacity that this batch does not fill (cwn_amd/static_graph.py,
     // cwn_layer_items_build_dev) -- uniform over the workgroup, before any barrier; the early weight requests are dropped
-    if (fld(I_NT) == 0) return;
+    if (fld(I_NT) == 0) { CWN_RSTAMP(1); return; }
     CWN_STAMP(9);
     int t_r0[2], t_n[2], t_bne[2], t_sn[2];
 #pragma unroll
@@ -705,6 +715,7 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
                 }
             }
             if (bad_big) atomicOr(A.err, CWN_ERR_BIT_BLOCK);
+            CWN_RSTAMP(1);
             return;
         }
     }
@@ -1033,7 +1044,7 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
         }
     }
     CWN_STAMP(5);
-    if (!has_gemm) return;
+    if (!has_gemm) { CWN_RSTAMP(1); return; }
 
     // ---- 6. Y1 | Y2 on the matrix cores ---------------------------------------------------------------
     // the bias of this wave's output columns: needed after the MFMAs, requested here (four registers that
@@ -1217,6 +1228,7 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
         }
     }
     CWN_STAMP(8);
+    CWN_RSTAMP(1);
 }
 
 #if !CWN_W8
@@ -1265,6 +1277,7 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 #ifdef CWN_LAYER_TIMING
 unsigned long long* g_stamps = nullptr;
+long long g_stamp_launch = 0, g_stamp_launches = 1;     // the next launch's slot / the slots the buffer holds (round robin)
 #endif
 
 template <int F, int MODE>
@@ -1277,7 +1290,7 @@ int launch(LayerArgs& A, int64_t n_items, hipStream_t stream) {
     });
     if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
 #ifdef CWN_LAYER_TIMING
-    A.stamps = g_stamps;
+    A.stamps = g_stamps == nullptr ? nullptr : g_stamps + (size_t)(g_stamp_launch++ % g_stamp_launches) * (size_t)n_items * CWN_STAMP_REC;
 #endif
     size_t lds = kW8 ? (size_t)A.lds_limit : lds_bytes<F>(A.rows_cap, A.xrows_cap);
     if (!kW8) {
@@ -1306,7 +1319,13 @@ extern "C" int cwn_layer_w8_launch(const cwn_layer_dim* dims, int n_dims, int32_
 #endif
 
 #if defined(CWN_LAYER_TIMING) && !CWN_W8
-extern "C" void cwn_layer_debug_stamps(unsigned long long* buf) { g_stamps = buf; }
+extern "C" void cwn_layer_debug_stamps(unsigned long long* buf) { g_stamps = buf; g_stamp_launch = 0; g_stamp_launches = 1; }
+// buf holds `launches` x n_items x CWN_STAMP_REC stamps: consecutive launches write consecutive slots (round robin)
+extern "C" void cwn_layer_debug_stamps_many(unsigned long long* buf, long long launches) {
+    g_stamps = buf;
+    g_stamp_launch = 0;
+    g_stamp_launches = launches > 0 ? launches : 1;
+}
 #endif
 
 extern "C" int32_t CWN_FN(round_rows)(int32_t F) {

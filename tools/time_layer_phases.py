@@ -36,7 +36,7 @@ dims, plan, table, key = args
 items, mr, ms = table.items, table.max_rows, table.max_src
 MODE = int(os.environ.get('MODE', '0'))   # 0 sort, 1 sort + store, 2 load (after one storing launch)
 REP = 1
-stamps = torch.zeros(items.size(0), 64, dtype=torch.int64, device=dev)
+stamps = torch.zeros(items.size(0), 96, dtype=torch.int64, device=dev)      # (= CWN_STAMP_REC)
 L.cwn_layer_debug_stamps(stamps.data_ptr())
 with torch.no_grad():
     if MODE == 2:
