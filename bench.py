@@ -17,8 +17,10 @@ One STEP = one pass of the hot path over one batch with the batch already reside
     plus the GIN self terms that are fused into the same kernel.
 Unit: cell-updates/s = sum_d N_d x layers x steps / wall time, summed over ranks
 (weak scaling: every rank owns its own batches, no data-path collective).
-The JSON line also carries `roofline` (dominant kernel = aggregate_kernel), `cpu_baseline`
-(oracle timed on the host cores, rank 0, N=1 only) and `secondary` (full model forward).
+The JSON line also carries `roofline` (dominant kernel: layer_kernel<F, load>, csrc/cwn_layer.hip, at the configurations the
+complex-blocked launch serves; aggregate_kernel on the CSR path), `cpu_baseline` (oracle timed on the host cores, rank 0,
+N=1 only) and `secondary` (full model forward, training step, the same three scopes on batches never seen before, other
+workloads).
 """
 import argparse
 import json
@@ -659,7 +661,10 @@ def main():
                 'note': 'algorithmic bytes = SURVEY.md 8(d), gather-counted (a row is counted once per entry that '
                         'reads it); the kernel reads each row once per workgroup, so its real traffic (`traffic`, PMC) '
                         'is the compulsory figure plus the packed weights; avg over back-to-back dependent launches '
-                        'replayed from a hipGraph between two HIP events'}
+                        'replayed from a hipGraph between two HIP events.  `achieved` is a BYTE RATE quoted against the HBM '
+                        'peak, not DRAM traffic: the cycled batches (~60 MB) and the weights live in L2 / MALL between '
+                        'launches -- `traffic` (PMC, when the committed pass covers this batch size) is what the memory '
+                        'side moved'}
             # the dense half of the layer: update_up_nn / update_boundaries_nn / combine_nn of all dimensions in one
             # launch (csrc/cwn_mlp.hip) -- the north star's MFMA target, priced against the matrix pipe
             try:
