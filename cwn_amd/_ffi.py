@@ -20,7 +20,7 @@ ABI_VERSION = 18
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_update_mlp_pack_weights_both_many_f32', 'cwn_layer_pack_weights_both_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_slots', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
-           'cwn_bn_finalize_f32', 'cwn_step_begin', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
+           'cwn_bn_finalize_f32', 'cwn_step_begin', 'cwn_embed_front_bwd_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
 
@@ -151,6 +151,15 @@ class StageDesc(C.Structure):
 class BnBwdLive(C.Structure):
     """cwn_bn_bwd_live (include/cwn_hip.h)."""
     _fields_ = [('z', C.c_void_p), ('aff', C.c_void_p), ('slots', C.c_void_p), ('ldz', C.c_int64)]
+
+
+class FrontBwd(C.Structure):
+    """cwn_front_bwd (include/cwn_hip.h)."""
+    _fields_ = [('g0', C.c_void_p), ('g1', C.c_void_p), ('g2', C.c_void_p), ('rowptr1', C.c_void_p), ('col1', C.c_void_p),
+                ('rowptr2', C.c_void_p), ('col2', C.c_void_p), ('v_src', C.c_void_p), ('e_src', C.c_void_p), ('dWv', C.c_void_p),
+                ('dWe', C.c_void_p), ('n0', C.c_int64), ('n1', C.c_int64), ('n0_dev', C.c_void_p), ('n1_dev', C.c_void_p),
+                ('H', C.c_int32), ('Vv', C.c_int32), ('Ve', C.c_int32), ('src_f32', C.c_int32), ('halve', C.c_int32),
+                ('pad_', C.c_int32)]
 
 
 class StageBwdDesc(C.Structure):
@@ -327,6 +336,8 @@ def lib():
     L.cwn_layer_bwd_items_build_dev.restype = C.c_int
     L.cwn_layer_bwd_items_build_dev.argtypes = [C.POINTER(LayerSizesDev), C.c_int32, C.POINTER(LayerBwdPlan), C.c_int32, C.c_void_p,
                                                 C.c_void_p]
+    L.cwn_embed_front_bwd_f32.restype = C.c_int
+    L.cwn_embed_front_bwd_f32.argtypes = [C.POINTER(FrontBwd), C.c_void_p]
     L.cwn_step_begin.restype = C.c_int
     L.cwn_step_begin.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cwn_bn_finalize_f32.restype = C.c_int

@@ -800,6 +800,96 @@ extern "C" int cwn_embedding_fwd_f32(const float* W, const int64_t* src, const i
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
+// ---- the backward of the model's front in one launch (include/cwn_hip.h: cwn_front_bwd) ---------------------------------
+namespace {
+template <int H>
+__global__ __launch_bounds__(256) void front_bwd_kernel(cwn_front_bwd A, int nb0) {
+    __shared__ __attribute__((aligned(16))) float rows[kEmbBand][H];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool vert = (int)blockIdx.x < nb0;
+    const int64_t cap = vert ? A.n0 : A.n1;
+    const int64_t* nd = vert ? A.n0_dev : A.n1_dev;
+    const int64_t n_rows = nd != nullptr ? (*nd < cap ? *nd : cap) : cap;
+    const int64_t r0 = (int64_t)((int)blockIdx.x - (vert ? 0 : nb0)) * kEmbBand;
+    if (r0 >= n_rows) return;                 // (uniform) a band past the batch's own rows
+    const int n = (int)((n_rows - r0) < kEmbBand ? (n_rows - r0) : kEmbBand);
+    const float scale = A.halve ? 0.5f : 1.0f;
+    const bool g1_to_v = A.e_src == nullptr && A.g1 != nullptr;
+    for (int i = tid; i < kEmbBand * (H / 4); i += 256) {
+        const int r = i / (H / 4), c4 = i % (H / 4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) {
+            const int64_t row = r0 + r;
+            if (!vert) {
+                acc = *reinterpret_cast<const float4*>(A.g1 + row * H + 4 * c4);
+            } else {
+                if (A.g0 != nullptr) acc = *reinterpret_cast<const float4*>(A.g0 + row * H + 4 * c4);
+                if (A.rowptr1 != nullptr) {
+                    const int k1 = A.rowptr1[row + 1];
+                    for (int k = A.rowptr1[row]; k < k1; ++k) {
+                        const int64_t e = A.col1[k];
+                        if (g1_to_v) {
+                            const float4 t = *reinterpret_cast<const float4*>(A.g1 + e * H + 4 * c4);
+                            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                        }
+                        if (A.rowptr2 != nullptr && A.g2 != nullptr) {
+                            const int q1 = A.rowptr2[e + 1];
+                            for (int q = A.rowptr2[e]; q < q1; ++q) {
+                                const float4 t = *reinterpret_cast<const float4*>(A.g2 + (int64_t)A.col2[q] * H + 4 * c4);
+                                acc.x += scale * t.x; acc.y += scale * t.y; acc.z += scale * t.z; acc.w += scale * t.w;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(&rows[r][4 * c4]) = acc;
+    }
+    const void* src = vert ? A.v_src : A.e_src;
+    const int f32 = vert ? (A.src_f32 & 1) : ((A.src_f32 >> 1) & 1);
+    const int V = vert ? A.Vv : A.Ve;
+    float* const dW = vert ? A.dWv : A.dWe;
+    const int64_t id = lane < n ? emb_index(src, f32, r0 + lane) : -1;       // lane = cell of the band (every wave holds all 64)
+    __syncthreads();
+    constexpr int kSlices = 256 / H > 0 ? 256 / H : 1;
+    constexpr int kPer = kEmbBand / kSlices;
+    const int h = tid % H, sl = tid / H;
+    for (int v = 0; v < V; ++v) {
+        const unsigned long long bal = __ballot(id == (int64_t)v);
+        if (bal == 0ull) continue;                                     // uniform
+        unsigned long long m = kPer == 64 ? bal : (bal >> (sl * kPer)) & ((1ull << kPer) - 1ull);
+        float acc = 0.f;
+        while (m != 0ull) {
+            const int r = sl * kPer + __builtin_ctzll(m);
+            m &= m - 1ull;
+            acc += rows[r][h];
+        }
+        if (acc != 0.f) atomicAdd(dW + (size_t)v * H + h, acc);
+    }
+}
+}  // namespace
+
+extern "C" int cwn_embed_front_bwd_f32(const cwn_front_bwd* a, cwn_stream_t stream_) {
+    if (a == nullptr || a->n0 < 0 || a->n1 < 0) return CWN_ERR_BAD_ARG;
+    if ((a->H != 64 && a->H != 128 && a->H != 256) || a->Vv <= 0 || a->Vv > 64 || a->Ve < 0 || a->Ve > 64) return CWN_ERR_BAD_ARG;
+    const bool edges = a->e_src != nullptr && a->n1 > 0;
+    if (a->n0 > 0 && (a->v_src == nullptr || a->dWv == nullptr)) return CWN_ERR_BAD_ARG;
+    if (edges && (a->dWe == nullptr || a->g1 == nullptr || a->Ve <= 0)) return CWN_ERR_BAD_ARG;
+    if ((a->rowptr1 == nullptr) != (a->col1 == nullptr) || (a->rowptr2 == nullptr) != (a->col2 == nullptr)) return CWN_ERR_BAD_ARG;
+    const void* ptrs[] = {a->g0, a->g1, a->g2};
+    for (const void* p : ptrs)
+        if ((uintptr_t)p & 15u) return CWN_ERR_ALIGN;
+    const int64_t nb0 = (a->n0 + kEmbBand - 1) / kEmbBand, nb1 = edges ? (a->n1 + kEmbBand - 1) / kEmbBand : 0;
+    if (nb0 + nb1 == 0) return CWN_OK;
+    if (nb0 + nb1 >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream_;
+    const dim3 grid((unsigned)(nb0 + nb1));
+    if (a->H == 64) front_bwd_kernel<64><<<grid, dim3(256), 0, st>>>(*a, (int)nb0);
+    else if (a->H == 128) front_bwd_kernel<128><<<grid, dim3(256), 0, st>>>(*a, (int)nb0);
+    else front_bwd_kernel<256><<<grid, dim3(256), 0, st>>>(*a, (int)nb0);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
 extern "C" int cwn_embedding_bwd_f32(const float* g, const void* src, const int64_t* col_off,
                                      const int64_t* col_size, float* dW, int64_t n_rows, int32_t cols,
                                      int32_t H, int64_t V, int32_t src_f32, const int64_t* n_dev, cwn_stream_t stream_) {

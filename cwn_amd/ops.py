@@ -631,6 +631,9 @@ class _EmbedFrontTrain(torch.autograd.Function):
         iv, ie = ctx.idx
         dev = iv.device
         H = int(vt[0].size(1))
+        fused = _front_backward_fused(ctx, g0, g1, g2)
+        if fused is not None:
+            return (None, None, None) + tuple(fused)
         # d red1[e] = (1/2) sum_{rings containing e} g2[ring]  (+ g1[e] when the edges have no table of their own: x1 = red1)
         t1 = None
         if g2 is not None and adj2 is not None and n2 > 0:
@@ -648,6 +651,56 @@ class _EmbedFrontTrain(torch.autograd.Function):
         if et and g1 is not None and any(ctx.needs_input_grad[3 + len(vt):]):
             grads[len(vt):] = _embedding_table_grads(et, ie, g1)
         return (None, None, None) + tuple(grads)
+
+
+FUSED_FRONT_BACKWARD = os.environ.get('CWN_FUSED_FRONT_BACKWARD', '1') != '0'
+
+
+def _front_backward_fused(ctx, g0, g1, g2) -> Optional[List[Optional[Tensor]]]:
+    """cwn_embed_front_bwd_f32: the whole backward of the front in one launch (one vertex table, at most one edge table, one
+    integer feature each, width 64 / 128 / 256: the ZINC models) -- or None (the caller runs the launches it replaces: the
+    halving, two transposed aggregations, two table gradients)."""
+    nv, n1, adj1, n2, adj2, halve = ctx.meta
+    vt, et = ctx.tables
+    iv, ie = ctx.idx
+    if not FUSED_FRONT_BACKWARD or nv != 1 or len(et) > 1:
+        return None
+    H, Vv = int(vt[0].size(1)), int(vt[0].size(0))
+    Ve = int(et[0].size(0)) if et else 0
+    if H not in (64, 128, 256) or Vv > 64 or Ve > 64 or (et and int(et[0].size(1)) != H):
+        return None
+    feats = [iv] + ([ie] if et else [])
+    for f in feats:
+        if f is None or f.dtype not in (torch.long, torch.float32) or (f.dim() == 2 and f.size(1) != 1) or f.dim() > 2:
+            return None
+    if (et and g1 is None) or not any(ctx.needs_input_grad[3:]):
+        return None
+    dev = iv.device
+    n0 = int(iv.size(0))
+    gs = [None if g is None else _f32c(g, 'grad') for g in (g0, g1, g2)]
+    if any(g is not None and g.data_ptr() % 16 for g in gs):
+        return None
+    t1 = adj1.t_src if (adj1 is not None and n1 > 0) else None      # per vertex its edges
+    t2 = adj2.t_src if (adj2 is not None and n2 > 0 and gs[2] is not None) else None      # per edge its rings
+    outs, targets = [], []
+    for w in [vt[0]] + list(et):
+        t = _grad_target(w)
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape != w.shape):
+            t = None
+        targets.append(t if t is not None else torch.zeros_like(w, dtype=torch.float32))
+        outs.append(None if t is not None else targets[-1])
+    fv = iv.contiguous()
+    fe = ie.contiguous() if et else None
+    a = _ffi.FrontBwd(g0=_ffi.ptr(gs[0]), g1=_ffi.ptr(gs[1]), g2=_ffi.ptr(gs[2]),
+                      rowptr1=None if t1 is None else t1.rowptr.data_ptr(), col1=None if t1 is None else t1.col.data_ptr(),
+                      rowptr2=None if t2 is None else t2.rowptr.data_ptr(), col2=None if t2 is None else t2.col.data_ptr(),
+                      v_src=fv.data_ptr(), e_src=_ffi.ptr(fe), dWv=targets[0].data_ptr(),
+                      dWe=targets[1].data_ptr() if et else None, n0=n0, n1=int(n1) if (et or t1 is not None) else 0,
+                      n0_dev=_ffi.dyn(n0), n1_dev=_ffi.dyn(int(n1)) if n1 else None, H=H, Vv=Vv, Ve=Ve,
+                      src_f32=(1 if fv.dtype == torch.float32 else 0) | (2 if (fe is not None and fe.dtype == torch.float32) else 0),
+                      halve=int(bool(halve)))
+    _ffi.check(_ffi.lib().cwn_embed_front_bwd_f32(C.byref(a), _ffi.stream_ptr(dev)), 'cwn_embed_front_bwd_f32')
+    return outs
 
 
 def embed_front_train(v_weights, v_feats, e_weights, e_feats, n1, adj1, n2, adj2, halve=True) -> List[Tensor]:

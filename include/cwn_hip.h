@@ -953,6 +953,40 @@ int cwn_embedding_bwd_f32(const float* g, const void* src, const int64_t* col_of
                           const int64_t* col_size, float* dW, int64_t n_rows, int32_t cols, int32_t H,
                           int64_t V, int32_t src_f32, const int64_t* n_dev, cwn_stream_t stream);
 
+/* The backward of cwn_embed_front_f32 (EmbedVEWithReduce, mp/layers.py:490-593: vertex / edge embeddings + InitReduceConv
+ * twice) in ONE launch, for one vertex table and at most one edge table with one integer feature each (the ZINC models):
+ *     dv[v]    = g0[v] + sum_{edges e of v} t1[e],   t1[e] = (g1[e] when the edges have no table: x1 = red1)
+ *                                                            + (halve ? 1/2 : 1) sum_{rings r of e} g2[r]
+ *     dWv[type(v)] += dv[v]         dWe[type(e)] += g1[e]
+ * A workgroup owns a band of 64 vertices (it gathers their dv into LDS: every incident edge, every ring of that edge) or of
+ * 64 edges, then adds the band to the table rows by ballot, as cwn_embedding_bwd_f32's one-table form.  Replaces the
+ * halving multiply, two transposed aggregations and two table-gradient launches of a training step.
+ * rowptr1 / col1: CSR of the TRANSPOSED boundary adjacency of dimension 1 (per vertex its edges), rowptr2 / col2 of
+ * dimension 2 (per edge its rings) -- int32, from cwn_csr_build or the collate; either may be NULL (no such cells).
+ * H = 64 / 128 / 256; Vv, Ve <= 64; pointers 16-B aligned; dWv / dWe are ADDED to (fp32 atomics, one per band and
+ * touched element). */
+typedef struct cwn_front_bwd {
+    const float* g0;         /* [n0, H] or NULL (= 0) */
+    const float* g1;         /* [n1, H] or NULL */
+    const float* g2;         /* [n2, H] or NULL */
+    const int32_t* rowptr1;  /* [n0 + 1] */
+    const int32_t* col1;
+    const int32_t* rowptr2;  /* [n1 + 1] */
+    const int32_t* col2;
+    const void* v_src;       /* [n0] int64 or float32 */
+    const void* e_src;       /* [n1], or NULL: no edge table (g1 then flows into the vertices) */
+    float* dWv;              /* [Vv, H] */
+    float* dWe;              /* [Ve, H] or NULL */
+    int64_t n0, n1;          /* capacities */
+    const int64_t* n0_dev;   /* or NULL: actual rows */
+    const int64_t* n1_dev;
+    int32_t H, Vv, Ve;
+    int32_t src_f32;         /* bit 0: v_src is float32, bit 1: e_src is */
+    int32_t halve;
+    int32_t pad_;
+} cwn_front_bwd;
+int cwn_embed_front_bwd_f32(const cwn_front_bwd* args_host, cwn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * The two ends of a model forward, one launch each (inference; csrc/cwn_ends.hip).
  *

@@ -74,6 +74,58 @@ def test_front_bit_identical_to_the_launches_it_replaces(kind):
         gate(got[1], red1, f'{kind} x1 = reduced')
 
 
+@pytest.mark.parametrize('kind', ['zinc', 'zinc_no_edge_table'])
+def test_front_backward_in_one_launch(kind):
+    """cwn_embed_front_bwd_f32 (round 4): the table gradients of EmbedVEWithReduce (mp/layers.py:490-593) from ONE launch --
+    against the launches it replaces (halving, two transposed aggregations, two table gradients) and against autograd over a
+    float64 restatement of the forward."""
+    from cwn_amd import ops
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.layers import EmbedVEWithReduce, InitReduceConv
+    from cwn_amd.synthetic import zinc_like_complexes
+    torch.manual_seed(5)
+    H = 128
+    e = torch.nn.Embedding(4, H) if kind == 'zinc' else None
+    front = EmbedVEWithReduce(torch.nn.Embedding(28, H), e, InitReduceConv('sum')).to(DEV)
+    b = ComplexBatch.from_complex_list(zinc_like_complexes(37, 6, 6), max_dim=2).to(DEV)
+    if kind == 'zinc_no_edge_table':
+        b.cochains[1]._x = None
+    g = torch.Generator().manual_seed(1)
+    ws = [torch.randn(b.cochains[d].num_cells, H, generator=g).to(DEV) for d in range(3)]
+    calls = []
+    orig = ops._front_backward_fused
+    ops._front_backward_fused = lambda *a: (lambda r: (calls.append(r is not None), r)[1])(orig(*a))
+
+    def run(fused):
+        ops.FUSED_FRONT_BACKWARD = fused
+        front.zero_grad(set_to_none=True)
+        with _ends(True):
+            out = front(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+        sum((o * w).sum() for o, w in zip(out, ws)).backward()
+        return [p.grad.detach().clone() for p in front.parameters()]
+
+    try:
+        got = run(True)
+        assert calls and calls[-1], 'the one-launch backward was not taken'
+        want = run(False)
+    finally:
+        ops.FUSED_FRONT_BACKWARD, ops._front_backward_fused = True, orig
+    for a, r in zip(got, want):
+        torch.testing.assert_close(a, r, rtol=1e-5, atol=1e-5 * max(1.0, float(r.abs().max())))
+    # float64 autograd of mp/layers.py:509-547
+    vt = front.v_embed_layer.weight.detach().double().cpu().requires_grad_(True)
+    et = None if e is None else front.e_embed_layer.weight.detach().double().cpu().requires_grad_(True)
+    x0 = vt[b.cochains[0].x.long().cpu().view(-1)]
+    bi1, bi2 = b.cochains[1].boundary_index.cpu(), b.cochains[2].boundary_index.cpu()
+    red1 = torch.zeros(b.cochains[1].num_cells, H, dtype=torch.float64).index_add(0, bi1[1], x0[bi1[0]])
+    x1 = red1 if et is None else et[b.cochains[1].x.long().cpu().view(-1)]
+    x2 = torch.zeros(b.cochains[2].num_cells, H, dtype=torch.float64).index_add(0, bi2[1], red1[bi2[0]]) / 2
+    sum((o * w.double().cpu()).sum() for o, w in zip((x0, x1, x2), ws)).backward()
+    gate(got[0], vt.grad, f'{kind}: d vertex table, one-launch front backward')
+    if et is not None:
+        gate(got[1], et.grad, f'{kind}: d edge table, one-launch front backward')
+
+
 def test_front_reports_an_index_outside_its_table():
     from cwn_amd import csr
     from cwn_amd.complex import ComplexBatch
