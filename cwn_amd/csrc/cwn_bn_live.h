@@ -13,9 +13,13 @@ namespace cwn {
 struct BnLiveRegs {
     double t[CWN_BN_SLOTS], u[CWN_BN_SLOTS];
     float g, beta;
+    float rm, rv;       // (the writer) the running statistics it is about to update
+    int64_t nbt;        // ... and the batch counter (column 0)
 };
 
-__device__ __forceinline__ void bn_live_request(const cwn_bn_live& L, int N, int n, BnLiveRegs& R) {
+// `writer`: also the module's running statistics -- requested HERE, with everything else: behind the derive they were a
+// second dependent round trip in the one workgroup that every launch then waited for (+1 us per consuming launch, measured)
+__device__ __forceinline__ void bn_live_request(const cwn_bn_live& L, int N, int n, bool writer, BnLiveRegs& R) {
 #pragma unroll
     for (int q = 0; q < CWN_BN_SLOTS; ++q) {
         R.t[q] = L.slots[(size_t)(2 * q) * N + n];
@@ -23,6 +27,13 @@ __device__ __forceinline__ void bn_live_request(const cwn_bn_live& L, int N, int
     }
     R.g = L.gamma != nullptr ? L.gamma[n] : 1.0f;
     R.beta = L.beta != nullptr ? L.beta[n] : 0.0f;
+    R.rm = R.rv = 0.f;
+    R.nbt = 0;
+    if (writer && L.running_mean != nullptr) {
+        R.rm = L.running_mean[n];
+        R.rv = L.running_var[n];
+    }
+    if (writer && n == 0 && L.num_batches_tracked != nullptr) R.nbt = *L.num_batches_tracked;
 }
 
 __device__ __forceinline__ void bn_live_finish(const cwn_bn_live& L, const BnLiveRegs& R, int N, int64_t Mv, int n, bool writer,
@@ -33,11 +44,21 @@ __device__ __forceinline__ void bn_live_finish(const cwn_bn_live& L, const BnLiv
         s += R.t[q];
         sq += R.u[q];
     }
-    const double invM = 1.0 / (double)(Mv > 0 ? Mv : 1);
+    // 1 / M and 1 / sqrt(var + eps) in fp64 from fp32 seeds and two Newton steps each (relative error ~1e-7 -> 1e-14 -> 1e-28:
+    // the last bit of a double) -- the library's fp64 division and square root are ~150 dependent instructions, 1.3 us of every
+    // consuming launch (measured: CWN_STAGE_DBG); these are ~25
+    const double Md = (double)(Mv > 0 ? Mv : 1);
+    double invM = (double)(1.0f / (float)Md);
+    invM = invM * (2.0 - Md * invM);
+    invM = invM * (2.0 - Md * invM);
     const double mean = s * invM;
     double var = sq * invM - mean * mean;     // biased, as BatchNorm normalises
     var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)L.eps));
+    const double x = var + (double)L.eps;
+    double y = (double)rsqrtf((float)x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    const float rstd = (float)y;
     scale = R.g * rstd;
     shift = R.beta - (float)mean * scale;
     if (!writer) return;
@@ -46,19 +67,19 @@ __device__ __forceinline__ void bn_live_finish(const cwn_bn_live& L, const BnLiv
     L.aff[2 * N + n] = (float)mean;
     L.aff[3 * N + n] = rstd;
     if (Mv < 1) return;
-    if (L.num_batches_tracked != nullptr && n == 0) *L.num_batches_tracked += 1;
+    if (L.num_batches_tracked != nullptr && n == 0) *L.num_batches_tracked = R.nbt + 1;
     if (L.running_mean != nullptr) {
         const float mom = L.momentum;
-        const double unbiased = Mv > 1 ? var * ((double)Mv / (double)(Mv - 1)) : var;
-        L.running_mean[n] = (1.0f - mom) * L.running_mean[n] + mom * (float)mean;
-        L.running_var[n] = (1.0f - mom) * L.running_var[n] + mom * (float)unbiased;
+        const float unbiased = Mv > 1 ? (float)var * ((float)Mv / (float)(Mv - 1)) : (float)var;
+        L.running_mean[n] = (1.0f - mom) * R.rm + mom * (float)mean;
+        L.running_var[n] = (1.0f - mom) * R.rv + mom * unbiased;
     }
 }
 
 __device__ __forceinline__ void bn_live_column(const cwn_bn_live& L, int N, int64_t Mv, int n, bool writer, float& scale,
                                                float& shift) {
     BnLiveRegs R;
-    bn_live_request(L, N, n, R);
+    bn_live_request(L, N, n, writer, R);
     bn_live_finish(L, R, N, Mv, n, writer, scale, shift);
 }
 

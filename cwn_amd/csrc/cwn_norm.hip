@@ -162,25 +162,6 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
         for (int v = 0; v < VEC; ++v) {
             scale[v] = 1.f; shift[v] = 0.f; mean[v] = 0.f; rstd[v] = 0.f; k1[v] = 0.f; k2[v] = 0.f;
         }
-        if constexpr (MODE == 0) {
-            if (live) {                               // (uniform) thread i < chunk width: column c0 + i; the first band writes
-                if ((int)threadIdx.x < kTPR * VEC && c0 + (int)threadIdx.x < N) {
-                    float sc, sh;
-                    cwn::bn_live_column(D.bn, N, Mv, c0 + threadIdx.x, row0 == 0, sc, sh);
-                    red[0][0][threadIdx.x] = sc;
-                    red[1][0][threadIdx.x] = sh;
-                }
-                __syncthreads();
-                if (cok) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        scale[v] = red[0][0][tc * VEC + v];
-                        shift[v] = red[1][0][tc * VEC + v];
-                    }
-                }
-                __syncthreads();
-            }
-        }
         if (cok && has_norm && !live) {
             ld_vec<VEC>(scale, D.scale + c);
             ld_vec<VEC>(shift, D.shift + c);
@@ -219,6 +200,26 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
             if (cok) {
                 ld_vec<VEC>(z[i], D.z + rc * D.ldz + c);
                 if constexpr (MODE != 0) ld_vec<VEC>(g[i], D.dy + rc * D.lddy + c);
+            }
+        }
+        if constexpr (MODE == 0) {
+            if (live) {                               // (uniform) thread i < chunk width: column c0 + i; the first band writes.  BEHIND the row
+                                                      // requests above: the derive runs while they travel
+                if ((int)threadIdx.x < kTPR * VEC && c0 + (int)threadIdx.x < N) {
+                    float sc, sh;
+                    cwn::bn_live_column(D.bn, N, Mv, c0 + threadIdx.x, row0 == 0, sc, sh);
+                    red[0][0][threadIdx.x] = sc;
+                    red[1][0][threadIdx.x] = sh;
+                }
+                __syncthreads();
+                if (cok) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        scale[v] = red[0][0][tc * VEC + v];
+                        shift[v] = red[1][0][tc * VEC + v];
+                    }
+                }
+                __syncthreads();
             }
         }
 #pragma unroll
@@ -802,20 +803,24 @@ extern "C" int cwn_embedding_fwd_f32(const float* W, const int64_t* src, const i
 
 // ---- the backward of the model's front in one launch (include/cwn_hip.h: cwn_front_bwd) ---------------------------------
 namespace {
+// (bands of 32 cells, not cwn_embedding_bwd_f32's 64: a thread walks its items' edges and rings one dependent load after
+// another -- four items per thread instead of eight, twice the workgroups: 21 -> ~12 us at the ZINC batch)
+constexpr int kFrontBand = 32;
+
 template <int H>
 __global__ __launch_bounds__(256) void front_bwd_kernel(cwn_front_bwd A, int nb0) {
-    __shared__ __attribute__((aligned(16))) float rows[kEmbBand][H];
+    __shared__ __attribute__((aligned(16))) float rows[kFrontBand][H];
     const int tid = threadIdx.x, lane = tid & 63;
     const bool vert = (int)blockIdx.x < nb0;
     const int64_t cap = vert ? A.n0 : A.n1;
     const int64_t* nd = vert ? A.n0_dev : A.n1_dev;
     const int64_t n_rows = nd != nullptr ? (*nd < cap ? *nd : cap) : cap;
-    const int64_t r0 = (int64_t)((int)blockIdx.x - (vert ? 0 : nb0)) * kEmbBand;
+    const int64_t r0 = (int64_t)((int)blockIdx.x - (vert ? 0 : nb0)) * kFrontBand;
     if (r0 >= n_rows) return;                 // (uniform) a band past the batch's own rows
-    const int n = (int)((n_rows - r0) < kEmbBand ? (n_rows - r0) : kEmbBand);
+    const int n = (int)((n_rows - r0) < kFrontBand ? (n_rows - r0) : kFrontBand);
     const float scale = A.halve ? 0.5f : 1.0f;
     const bool g1_to_v = A.e_src == nullptr && A.g1 != nullptr;
-    for (int i = tid; i < kEmbBand * (H / 4); i += 256) {
+    for (int i = tid; i < kFrontBand * (H / 4); i += 256) {
         const int r = i / (H / 4), c4 = i % (H / 4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < n) {
@@ -852,12 +857,13 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(cwn_front_bwd A, int nb0
     const int64_t id = lane < n ? emb_index(src, f32, r0 + lane) : -1;       // lane = cell of the band (every wave holds all 64)
     __syncthreads();
     constexpr int kSlices = 256 / H > 0 ? 256 / H : 1;
-    constexpr int kPer = kEmbBand / kSlices;
+    constexpr int kPer = kFrontBand / kSlices;
+    static_assert(kPer >= 1 && kFrontBand <= 64, "a wave's ballot covers the band");
     const int h = tid % H, sl = tid / H;
     for (int v = 0; v < V; ++v) {
         const unsigned long long bal = __ballot(id == (int64_t)v);
         if (bal == 0ull) continue;                                     // uniform
-        unsigned long long m = kPer == 64 ? bal : (bal >> (sl * kPer)) & ((1ull << kPer) - 1ull);
+        unsigned long long m = (bal >> (sl * kPer)) & ((1ull << kPer) - 1ull);
         float acc = 0.f;
         while (m != 0ull) {
             const int r = sl * kPer + __builtin_ctzll(m);
@@ -879,7 +885,7 @@ extern "C" int cwn_embed_front_bwd_f32(const cwn_front_bwd* a, cwn_stream_t stre
     const void* ptrs[] = {a->g0, a->g1, a->g2};
     for (const void* p : ptrs)
         if ((uintptr_t)p & 15u) return CWN_ERR_ALIGN;
-    const int64_t nb0 = (a->n0 + kEmbBand - 1) / kEmbBand, nb1 = edges ? (a->n1 + kEmbBand - 1) / kEmbBand : 0;
+    const int64_t nb0 = (a->n0 + kFrontBand - 1) / kFrontBand, nb1 = edges ? (a->n1 + kFrontBand - 1) / kFrontBand : 0;
     if (nb0 + nb1 == 0) return CWN_OK;
     if (nb0 + nb1 >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     hipStream_t st = (hipStream_t)stream_;

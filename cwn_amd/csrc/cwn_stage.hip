@@ -18,6 +18,7 @@
 // 0.965 against 0.931.  Two small workgroups on a CU overlap each other's load and multiply phases; one large one does not.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <mutex>
 #include "../../include/cwn_hip.h"
 #include "cwn_split.h"
@@ -49,6 +50,7 @@ struct StageBatch {
     cwn_stage_desc d[CWN_MAX_DESCS];
     int32_t blk_start[CWN_MAX_DESCS + 1];
     int32_t n;
+    int32_t dbg;      // timing experiments (CWN_STAGE_DBG): 1 live prologue without its arithmetic, 2 without its loads, 4 no statistics atomics
 };
 
 // v of the lane CTRL's rotation away within its 16-lane row (DPP row_ror:n = 0x120 + n), for a double
@@ -178,7 +180,9 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     const int live_which = threadIdx.x / F, live_col = threadIdx.x % F;
     const bool live_mine = (live_which == 0 && live0) || (live_which == 1 && live1);
     cwn::BnLiveRegs live_regs;
-    if (live_mine) cwn::bn_live_request(live_which == 0 ? D.in_bn : D.in_bn2, F, live_col, live_regs);
+    if (live_mine && !(B.dbg & 2))
+        cwn::bn_live_request(live_which == 0 ? D.in_bn : D.in_bn2, F, live_col, (int)blockIdx.x == B.blk_start[di], live_regs);
+    __builtin_amdgcn_sched_barrier(0);              // (the slot requests leave FIRST: the compiler would hoist the tile loads)
     request_rows(v0, D.X, D.ldx);
     if (row0 >= Mv) return;                         // (uniform) a tile past the batch's own rows: nothing to store or count
     if (two) request_rows(v1, D.X2, D.ldx2);
@@ -186,9 +190,16 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
         // ... the first workgroup of the descriptor writes what the backward reads and the running statistics
         float* const aff = reinterpret_cast<float*>(live_scratch);
         if (live_mine) {
-            float sc, sh;
-            cwn::bn_live_finish(live_which == 0 ? D.in_bn : D.in_bn2, live_regs, F, Mv, live_col,
-                                (int)blockIdx.x == B.blk_start[di], sc, sh);
+            float sc = 1.f, sh = 0.f;
+            if (!(B.dbg & 3)) {
+                cwn::bn_live_finish(live_which == 0 ? D.in_bn : D.in_bn2, live_regs, F, Mv, live_col,
+                                    (int)blockIdx.x == B.blk_start[di] && !(B.dbg & 8), sc, sh);
+            } else if (!(B.dbg & 2)) {               // every load consumed, none of the arithmetic
+                double a = 0.0;
+#pragma unroll
+                for (int q = 0; q < CWN_BN_SLOTS; ++q) a += live_regs.t[q] + live_regs.u[q];
+                sc = (float)a + live_regs.g + live_regs.beta;
+            }
             aff[(live_which * 2) * F + live_col] = sc;
             aff[(live_which * 2 + 1) * F + live_col] = sh;
         }
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
         if (slotted) {
             // the workgroup's 2 F sums leave as 2 F / 64 fully coalesced fp64 atomic instructions
             lds_barrier();                        // (LDS traffic only: the stores of Y above are not waited for)
-            if (threadIdx.x < 2 * F) {
+            if (threadIdx.x < 2 * F && !(B.dbg & 4)) {
                 const int which = threadIdx.x / F, col = threadIdx.x % F;
                 double v = live_scratch[which * F + col];
                 if constexpr (TM > 32) v += live_scratch[(2 + which) * F + col];
@@ -640,6 +651,8 @@ extern "C" int cwn_dense_stage_f32(const cwn_stage_desc* descs, int n, int32_t F
     }
     for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
     if (blocks == 0) return CWN_OK;
+    static const int dbg = getenv("CWN_STAGE_DBG") ? atoi(getenv("CWN_STAGE_DBG")) : 0;
+    B.dbg = dbg;
     return F == 128 ? launch_stage<128>(B, blocks, (hipStream_t)stream_) : launch_stage<64>(B, blocks, (hipStream_t)stream_);
 }
 

@@ -958,8 +958,8 @@ int cwn_embedding_bwd_f32(const float* g, const void* src, const int64_t* col_of
  *     dv[v]    = g0[v] + sum_{edges e of v} t1[e],   t1[e] = (g1[e] when the edges have no table: x1 = red1)
  *                                                            + (halve ? 1/2 : 1) sum_{rings r of e} g2[r]
  *     dWv[type(v)] += dv[v]         dWe[type(e)] += g1[e]
- * A workgroup owns a band of 64 vertices (it gathers their dv into LDS: every incident edge, every ring of that edge) or of
- * 64 edges, then adds the band to the table rows by ballot, as cwn_embedding_bwd_f32's one-table form.  Replaces the
+ * A workgroup owns a band of 32 vertices (it gathers their dv into LDS: every incident edge, every ring of that edge) or of
+ * 32 edges, then adds the band to the table rows by ballot, as cwn_embedding_bwd_f32's one-table form.  Replaces the
  * halving multiply, two transposed aggregations and two table-gradient launches of a training step.
  * rowptr1 / col1: CSR of the TRANSPOSED boundary adjacency of dimension 1 (per vertex its edges), rowptr2 / col2 of
  * dimension 2 (per edge its rings) -- int32, from cwn_csr_build or the collate; either may be NULL (no such cells).
