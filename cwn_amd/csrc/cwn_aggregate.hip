@@ -104,6 +104,10 @@ __device__ __forceinline__ Acc<VEC> message(const Acc<VEC>& a, const Acc<VEC>& b
         else if constexpr (OP == CWN_MSG_A_PLUS_B) m.v[k] = a.v[k] + b.v[k];
         else if constexpr (OP == CWN_MSG_A_TIMES_B) m.v[k] = a.v[k] * b.v[k];
         else if constexpr (OP == CWN_MSG_RELU_A_PLUS_B) m.v[k] = fmaxf(a.v[k] + b.v[k], 0.0f);
+        else if constexpr (OP == CWN_MSG_RELU_A_PLUS_B_SQ) {
+            const float r = fmaxf(a.v[k] + b.v[k], 0.0f);
+            m.v[k] = r * r;
+        } else if constexpr (OP == CWN_MSG_A_TIMES_2RELU) m.v[k] = 2.0f * a.v[k] * fmaxf(pre.v[k] + b.v[k], 0.0f);
         else m.v[k] = (pre.v[k] + b.v[k] > 0.0f) ? a.v[k] : 0.0f;
     }
     return m;
@@ -324,7 +328,7 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
             const int f = (gl % GF) * VEC;
             const bool active = f < F;
             Acc<VEC> pre = splat<VEC>(0.0f);
-            if constexpr (OP == CWN_MSG_A_MASK_RELU) {
+            if constexpr (OP == CWN_MSG_A_MASK_RELU || OP == CWN_MSG_A_TIMES_2RELU) {
                 if (active) pre = ld<VEC>(row_at<SMALL>(D.self_pre, row, F, f));
             }
             const SelfTerms<VEC> self = load_self_early<VEC, OP, SMALL>(D, row, f, active && gl < GF);
@@ -338,7 +342,7 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
                 const int f = f0 + gl * VEC;
                 const bool active = f < F;
                 Acc<VEC> pre = splat<VEC>(0.0f);
-                if constexpr (OP == CWN_MSG_A_MASK_RELU) {
+                if constexpr (OP == CWN_MSG_A_MASK_RELU || OP == CWN_MSG_A_TIMES_2RELU) {
                     if (active) pre = ld<VEC>(row_at<SMALL>(D.self_pre, row, F, f));
                 }
                 const SelfTerms<VEC> self = load_self_early<VEC, OP, SMALL>(D, row, f, active);
@@ -366,7 +370,7 @@ __device__ __forceinline__ void run_desc(const cwn_agg_desc& D, int blk, int nbl
             const int f = f0 + gl * VEC;
             const bool active = f < F;
             Acc<VEC> pre = splat<VEC>(0.0f);
-            if constexpr (OP == CWN_MSG_A_MASK_RELU) {
+            if constexpr (OP == CWN_MSG_A_MASK_RELU || OP == CWN_MSG_A_TIMES_2RELU) {
                 if (active) pre = ld<VEC>(row_at<SMALL>(D.self_pre, lrow, F, f));
             }
             Acc<VEC> acc = fold_range<VEC, OP, RED, SMALL>(D, s, e, G, gl, f, active, pre);
@@ -431,6 +435,10 @@ void aggregate_kernel(AggBatch B) {
             run_desc<VEC, CWN_MSG_RELU_A_PLUS_B, CWN_REDUCE_ADD, SMALL>(D, blk, nblk, G, GF, part); break;
         case CWN_MSG_A_MASK_RELU:
             run_desc<VEC, CWN_MSG_A_MASK_RELU, CWN_REDUCE_ADD, SMALL>(D, blk, nblk, G, GF, part); break;
+        case CWN_MSG_RELU_A_PLUS_B_SQ:
+            run_desc<VEC, CWN_MSG_RELU_A_PLUS_B_SQ, CWN_REDUCE_ADD, SMALL>(D, blk, nblk, G, GF, part); break;
+        case CWN_MSG_A_TIMES_2RELU:
+            run_desc<VEC, CWN_MSG_A_TIMES_2RELU, CWN_REDUCE_ADD, SMALL>(D, blk, nblk, G, GF, part); break;
         default: run_desc_red<VEC, CWN_MSG_A, SMALL>(D, blk, nblk, G, GF, part); break;
     }
 }
@@ -472,14 +480,14 @@ extern "C" int cwn_aggregate_f32(const cwn_agg_desc* descs, int n, cwn_stream_t 
     for (int i = 0; i < n; ++i) {
         const cwn_agg_desc& D = descs[i];
         if (D.F <= 0 || D.n_dst < 0 || (D.n_dst > 0 && D.out == nullptr)) return CWN_ERR_BAD_ARG;
-        if (D.msg_op < CWN_MSG_A || D.msg_op > CWN_MSG_A_MASK_RELU) return CWN_ERR_BAD_ARG;
+        if (D.msg_op < CWN_MSG_A || D.msg_op > CWN_MSG_A_TIMES_2RELU) return CWN_ERR_BAD_ARG;
         if (D.reduce < CWN_REDUCE_ADD || D.reduce > CWN_REDUCE_MAX) return CWN_ERR_BAD_ARG;
         if (D.msg_op >= CWN_MSG_RELU_A_PLUS_B && D.reduce != CWN_REDUCE_ADD) return CWN_ERR_BAD_ARG;
         if (D.rowptr != nullptr) {
             if (D.ia == nullptr || D.A == nullptr) return CWN_ERR_BAD_ARG;
             if (D.msg_op != CWN_MSG_A && (D.ib == nullptr || D.B == nullptr)) return CWN_ERR_BAD_ARG;
             if (D.msg_op != CWN_MSG_A && D.b_width != D.F && D.b_width != 1) return CWN_ERR_BAD_ARG;
-            if (D.msg_op == CWN_MSG_A_MASK_RELU && D.self_pre == nullptr) return CWN_ERR_BAD_ARG;
+            if ((D.msg_op == CWN_MSG_A_MASK_RELU || D.msg_op == CWN_MSG_A_TIMES_2RELU) && D.self_pre == nullptr) return CWN_ERR_BAD_ARG;
         }
         if (D.n_dst >= INT32_MAX) return CWN_ERR_TOO_LARGE;
         // widest vector every pointer and the row stride allow

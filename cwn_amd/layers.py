@@ -81,6 +81,7 @@ def _is_cat_linear_relu(nn) -> bool:
 
 
 FUSED_DENSE_TRAINING = True   # set False to run the update / combine networks as torch modules
+FUSED_CIN_TRAINING = os.environ.get('CWN_FUSED_CIN_TRAINING') != '0'      # False: CINCochainConv's training forward on the generic path
 FUSED_UPDATE_MLP = os.environ.get('CWN_FUSED_UPDATE_MLP') != '0'   # False: the update / combine networks as three grouped GEMM launches
 BLOCKED_TRAIN_FORWARD = os.environ.get('CWN_BLOCKED_TRAIN_FORWARD') != '0'    # the training forward through the blocked kernel too
 BLOCKED_LAYER = os.environ.get('CWN_BLOCKED_LAYER') != '0'   # False: propagate scope as grouped GEMM + CSR aggregation
@@ -263,6 +264,8 @@ class CINCochainConv(CochainMessagePassing):
 
     def forward(self, cochain: CochainMessagePassingParams):
         fused = self._fused_inference(cochain)
+        if fused is None:
+            fused = self._fused_training(cochain)
         if fused is not None:
             return self.update_nn(fused)
         out_up, out_down, _ = self.propagate(cochain.up_index, cochain.down_index, None, x=cochain.x,
@@ -352,6 +355,111 @@ class CINCochainConv(CochainMessagePassing):
         streams = self._fused_streams(plan, ys)
         outs = ops.aggregate_many(streams) if streams else []
         return self._fused_finish(plan, outs)
+
+    # ---- fused training (round 4) ----------------------------------------------------------------
+    @staticmethod
+    def _message_form_train(nn):
+        """(Linear, norm | None) when `nn` is Linear -> ReLU [-> BatchNorm1d | Identity] in a state the fused training path
+        reproduces, else None."""
+        if not isinstance(nn, Sequential) or len(nn) not in (2, 3):
+            return None
+        if not (isinstance(nn[0], Linear) and isinstance(nn[1], ReLU)):
+            return None
+        norm = nn[2] if len(nn) == 3 else None
+        if norm is None or isinstance(norm, torch.nn.Identity):
+            return nn[0], None
+        if not isinstance(norm, BN) or norm.num_features != nn[0].out_features:
+            return None
+        if norm.training and norm.track_running_stats and norm.momentum is None:
+            return None                  # (cumulative moving average: not restated)
+        if not norm.training and norm.running_mean is None:
+            return None
+        return nn[0], norm
+
+    def _fused_training(self, cochain: CochainMessagePassingParams) -> Optional[Tensor]:
+        """out_up + out_down of forward() WITH autograd and without a message ever materialised, for the
+        message networks the reference's models build (mp/models.py:40-47: Linear -> ReLU -> BatchNorm).  The split of
+        _fused_inference holds in training too -- relu(W [x_j | a_e] + b) = relu(Y1[j] + Y2[c]), Y1 / Y2 once per CELL on
+        the MFMA kernel (ops.gemm_many: differentiable) -- and BatchNorm in TRAINING mode normalises over the ENTRIES of
+        the adjacency, whose batch statistics are column sums of two aggregations:
+            S_i = sum_{e -> i} r_e (CWN_MSG_RELU_A_PLUS_B),   Q_i = sum_{e -> i} r_e^2 (CWN_MSG_RELU_A_PLUS_B_SQ)
+            mean = sum_i S_i / E,  var = sum_i Q_i / E - mean^2 (float64),   sum_e BN(r_e) = scale S_i + deg_i shift
+        with the running statistics updated as torch does (momentum, unbiased variance).  Gradients: autograd over these
+        few [n, F] tensor ops + the aggregations' own transposed launches (the squared form's is CWN_MSG_A_TIMES_2RELU).
+        Per adjacency: 1 grouped GEMM + 1 aggregation launch (both sums) forward, against gather -> per-entry Linear ->
+        ReLU -> BatchNorm -> scatter over E x 2F / E x F matrices.  None when it does not apply."""
+        x = cochain.x
+        if (not FUSED_CIN_TRAINING or not torch.is_grad_enabled() or x is None or not x.is_cuda or x.dtype != torch.float32
+                or x.dim() != 2):
+            return None
+        if (self.aggr_up or 'add') != 'add' or (self.aggr_down or 'add') != 'add':
+            return None
+        n, F = x.size(0), x.size(1)
+        jobs = []
+        for index, name, attr, nn in ((cochain.up_index, 'up', cochain.kwargs.get('up_attr'), self.msg_up_nn),
+                                      (cochain.down_index, 'down', cochain.kwargs.get('down_attr'), self.msg_down_nn)):
+            if index is None or (name == 'down' and not self.use_down_msg):
+                continue
+            form = self._message_form_train(nn)
+            if form is None or attr is None:
+                return None
+            lin, norm = form
+            attr_src, mode = _attr_operand(attr)
+            if lin.in_features != F + attr_src.size(1) or lin.out_features != F or max(F, attr_src.size(1)) > ops.GEMM_MAX_K:
+                return None
+            E = int(index.size(1))
+            if isinstance(norm, BN) and norm.training and E < 2:
+                return None              # (torch refuses BatchNorm over fewer than two values per channel: let it)
+            jobs.append((index, name, attr_src, mode, lin, norm, E))
+        kw = dict(x=x, up_attr=cochain.kwargs.get('up_attr'), down_attr=cochain.kwargs.get('down_attr'))
+        total = (2 * (1 + self.eps)) * x
+        if not jobs:
+            return total
+        gemms = []
+        for index, name, attr_src, mode, lin, norm, E in jobs:
+            gemms += [ops.Gemm(X=x, W=lin.weight, w_col0=0, bias=lin.bias), ops.Gemm(X=attr_src, W=lin.weight, w_col0=F)]
+        ys = ops.gemm_many(gemms)
+        streams, adjs = [], []
+        for k, (index, name, attr_src, mode, lin, norm, E) in enumerate(jobs):
+            size = self.__check_input_separately__(index, None)
+            adj = self._adjacency(index, name, size, kw)
+            adjs.append(adj)
+            streams.append(ops.Stream(adj=adj, n_dst=n, width=F, A=ys[2 * k], B=ys[2 * k + 1], msg_op=ops.MSG_RELU_A_PLUS_B,
+                                      ib_mode=mode))
+            if isinstance(norm, BN) and norm.training:
+                streams.append(ops.Stream(adj=adj, n_dst=n, width=F, A=ys[2 * k], B=ys[2 * k + 1],
+                                          msg_op=ops.MSG_RELU_A_PLUS_B_SQ, ib_mode=mode))
+        outs = ops.aggregate_many(streams)
+        o = 0
+        for (index, name, attr_src, mode, lin, norm, E), adj in zip(jobs, adjs):
+            S = outs[o]
+            o += 1
+            if norm is None:
+                total = total + S
+                continue
+            deg = (adj.rowptr[1:] - adj.rowptr[:-1]).to(torch.float32).unsqueeze(1)
+            w = norm.weight.double() if norm.weight is not None else None
+            if norm.training:
+                Q = outs[o]
+                o += 1
+                mean = S.sum(0, dtype=torch.float64) / E
+                var = (Q.sum(0, dtype=torch.float64) / E - mean * mean).clamp_min(0.0)      # biased, as BatchNorm normalises
+                if norm.track_running_stats and norm.running_mean is not None:
+                    with torch.no_grad():
+                        m = float(norm.momentum)
+                        norm.running_mean.mul_(1 - m).add_(mean.to(norm.running_mean.dtype), alpha=m)
+                        norm.running_var.mul_(1 - m).add_((var * (E / (E - 1))).to(norm.running_var.dtype), alpha=m)
+                        norm.num_batches_tracked += 1
+            else:
+                mean, var = norm.running_mean.double(), norm.running_var.double()
+            scale = torch.rsqrt(var + norm.eps)
+            if w is not None:
+                scale = scale * w
+            shift = -mean * scale
+            if norm.bias is not None:
+                shift = shift + norm.bias.double()
+            total = total + S * scale.float() + deg * shift.float()
+        return total
 
     def reset_parameters(self):
         reset(self.msg_up_nn)

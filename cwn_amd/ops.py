@@ -19,7 +19,7 @@ from torch import Tensor
 from . import _ffi
 from .csr import Adjacency, wait_ready
 
-MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
+MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU, MSG_RELU_A_PLUS_B_SQ, MSG_A_TIMES_2RELU = range(7)
 
 
 def _f32c(t: Optional[Tensor], name: str) -> Optional[Tensor]:
@@ -194,10 +194,11 @@ def _aggregate_backward(streams, tensors, needs, gs, max_outs, device) -> List[O
                 if op == MSG_A_TIMES_B:
                     s.msg_op, s.B = MSG_A_TIMES_B, B
                     s.ib = t.aux if st.ib_mode == 'aux' else t.perm
-                elif op == MSG_RELU_A_PLUS_B:
+                elif op in (MSG_RELU_A_PLUS_B, MSG_RELU_A_PLUS_B_SQ):
                     # B per shared cell (lazy up_attr) or per ENTRY (a materialised up_attr): the
                     # transposed plan's perm is the entry id of each of its positions
-                    s.msg_op, s.B, s.self_pre = MSG_A_MASK_RELU, B, A
+                    # (the squared form: d relu(a + b)^2 / da = 2 relu(a + b))
+                    s.msg_op, s.B, s.self_pre = (MSG_A_MASK_RELU if op == MSG_RELU_A_PLUS_B else MSG_A_TIMES_2RELU), B, A
                     s.ib = t.aux if st.ib_mode == 'aux' else t.perm
                 gathered.setdefault(ident(A), len(specs))
                 specs.append(s)
@@ -211,12 +212,14 @@ def _aggregate_backward(streams, tensors, needs, gs, max_outs, device) -> List[O
                 gB = _ffi.gather_rows(g, adj.key)          # dB[e] = g[dst[e]] ...
                 if op == MSG_RELU_A_PLUS_B:                # ... where the entry's pre-activation is positive
                     gB = gB * ((_ffi.gather_rows(A, adj.val) + B) > 0)
+                elif op == MSG_RELU_A_PLUS_B_SQ:
+                    gB = gB * (2 * torch.relu(_ffi.gather_rows(A, adj.val) + B))
                 grads[4 * k + 1] = gB
             else:
                 t = adj.t_aux          # keyed on the aux cell: col = destination, aux = source
                 s = AggSpec(adj=t, n_dst=t.n_dst, F=F, A=g, ia=t.col)
-                if op == MSG_RELU_A_PLUS_B:
-                    s.msg_op, s.B, s.ib, s.self_pre = MSG_A_MASK_RELU, A, t.aux, B
+                if op in (MSG_RELU_A_PLUS_B, MSG_RELU_A_PLUS_B_SQ):
+                    s.msg_op, s.B, s.ib, s.self_pre = (MSG_A_MASK_RELU if op == MSG_RELU_A_PLUS_B else MSG_A_TIMES_2RELU), A, t.aux, B
                 gathered.setdefault(ident(B), len(specs))
                 specs.append(s)
                 slots.append(4 * k + 1)

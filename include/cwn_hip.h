@@ -137,6 +137,10 @@ int cwn_gather_rows_f32(const float* src, int64_t n_src, int64_t F, const int64_
  *                                                            mp/layers.py:290-293, restructured as
  *                                                            A = X_d W1^T + b, B = X_{d+1} W2^T
  *     CWN_MSG_A_MASK_RELU  A[ia[p], :] * step(self_pre[i,:] + B[ib[p], :] > 0)
+ *     CWN_MSG_RELU_A_PLUS_B_SQ  relu(A[ia[p], :] + B[ib[p], :])^2   the second moment of the CIN messages: BatchNorm(train) over
+ *                               the ENTRIES of an adjacency (mp/models.py:40-47 conv_up / conv_down in training mode) needs
+ *                               sum_e r_e and sum_e r_e^2 per column -- the column sums of two aggregations
+ *     CWN_MSG_A_TIMES_2RELU     2 A[ia[p], :] * relu(self_pre[i, :] + B[ib[p], :])   its transposed (backward) form
  *                                                            backward of the previous form
  * and `reduce` one of add / mean / max (mp/cell_mp.py:104-105 -> torch_scatter.scatter, :439):
  * rows with no entry are 0 for every reduce; mean divides by max(count, 1).
@@ -147,7 +151,7 @@ int cwn_gather_rows_f32(const float* src, int64_t n_src, int64_t F, const int64_
  * All descriptors of one call run in ONE kernel launch.
  * ------------------------------------------------------------------------------------------ */
 enum { CWN_MSG_A = 0, CWN_MSG_A_PLUS_B = 1, CWN_MSG_A_TIMES_B = 2, CWN_MSG_RELU_A_PLUS_B = 3,
-       CWN_MSG_A_MASK_RELU = 4 };
+       CWN_MSG_A_MASK_RELU = 4, CWN_MSG_RELU_A_PLUS_B_SQ = 5, CWN_MSG_A_TIMES_2RELU = 6 };
 enum { CWN_REDUCE_ADD = 0, CWN_REDUCE_MEAN = 1, CWN_REDUCE_MAX = 2 };
 
 /* cwn_agg_desc.flags.  SMALL_OPERANDS: the caller vouches that every element of A and of B that an

@@ -456,6 +456,83 @@ def test_cin_conv_and_oriented_messages_golden():
     torch.testing.assert_close(cpu(down), T(g['orient/down']), rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize('norm,lazy', [('bn', True), ('bn', False), ('none', True), ('bn_eval', True)])
+def test_cin_conv_fused_training_matches_the_per_entry_path(norm, lazy):
+    """CINCochainConv._fused_training (round 4; mp/layers.py:62-124 with the message networks of
+    mp/models.py:40-47, Linear -> ReLU -> BatchNorm in TRAINING mode: statistics over the ENTRIES of each adjacency) against
+    the generic path -- gather, the torch network per entry, segmented reduce -- on a ZINC-like batch with upper AND lower
+    adjacencies: outputs, input gradients, every parameter gradient, the running statistics and batch counters.  `lazy`:
+    the attributes as IndexedRows (gathered through the shared-cell index) or materialised per entry."""
+    from cwn_amd import layers
+    from cwn_amd.layers import CINConv
+    from cwn_amd.synthetic import zinc_like_batch
+    F = 64
+    torch.manual_seed(7)
+
+    def msg():
+        mods = [torch.nn.Linear(2 * F, F), torch.nn.ReLU()]
+        if norm != 'none':
+            mods.append(torch.nn.BatchNorm1d(F))
+        return torch.nn.Sequential(*mods)
+    upd = torch.nn.Sequential(torch.nn.Linear(F, F), torch.nn.ReLU(), torch.nn.BatchNorm1d(F))
+    conv = CINConv(F, F, msg(), msg(), upd, eps=0.1, train_eps=True, max_dim=2).to(DEV).train()
+    if norm == 'bn_eval':
+        for lvl in conv.mp_levels:
+            for net in (lvl.msg_up_nn, lvl.msg_down_nn):
+                net[2].eval()
+                net[2].running_mean.uniform_(-0.2, 0.2)
+                net[2].running_var.uniform_(0.5, 1.5)
+    state0 = {k: v.clone() for k, v in conv.state_dict().items()}
+    b = zinc_like_batch(12, seed=4, device=DEV)
+    g = torch.Generator().manual_seed(2)
+    xs0 = [torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV) for d in range(3)]
+    ws = [torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV) for d in range(3)]
+    taken = []
+    orig = layers.CINCochainConv._fused_training
+    layers.CINCochainConv._fused_training = lambda self, c: (lambda r: (taken.append(r is not None), r)[1])(orig(self, c))
+
+    def run(fused):
+        layers.FUSED_CIN_TRAINING = fused
+        conv.load_state_dict(state0)
+        conv.zero_grad(set_to_none=True)
+        xin = [x.clone().requires_grad_() for x in xs0]
+        b.set_xs(xin)
+        params = b.get_all_cochain_params(max_dim=2, include_down_features=True)
+        if not lazy:
+            for prm in params:
+                for key in ('up_attr', 'down_attr'):
+                    a = prm.kwargs.get(key)
+                    if a is not None and hasattr(a, 'tensor'):        # cell_mp.IndexedRows -> one row per entry
+                        prm.kwargs[key] = a.tensor()
+        out = conv(*params)
+        sum((o * w).sum() for o, w in zip(out, ws)).backward()
+        return ([o.detach().clone() for o in out], [x.grad.clone() for x in xin],
+                {n: p.grad.clone() for n, p in conv.named_parameters() if p.grad is not None},
+                {n: t.clone() for n, t in conv.named_buffers()})
+
+    try:
+        taken.clear()
+        got = run(True)
+        assert taken and all(taken), f'the fused training path was not taken: {taken}'
+        want = run(False)
+    finally:
+        layers.FUSED_CIN_TRAINING = True
+        layers.CINCochainConv._fused_training = orig
+    for d, (a, r) in enumerate(zip(got[0], want[0])):
+        torch.testing.assert_close(a, r, rtol=1e-4, atol=2e-5 * max(1.0, float(r.abs().max())), msg=lambda m, d=d: f'out[{d}]: {m}')
+    for d, (a, r) in enumerate(zip(got[1], want[1])):
+        torch.testing.assert_close(a, r, rtol=1e-4, atol=5e-5 * max(1.0, float(r.abs().max())), msg=lambda m, d=d: f'dx[{d}]: {m}')
+    assert got[2].keys() == want[2].keys()
+    for n_, r in want[2].items():
+        sc = 40.0 if n_.endswith('eps') else max(1.0, float(r.abs().max()))
+        torch.testing.assert_close(got[2][n_], r, rtol=1e-4, atol=5e-5 * sc, msg=lambda m, n_=n_: f'{n_}: {m}')
+    for n_, t in want[3].items():
+        if t.dtype.is_floating_point:
+            torch.testing.assert_close(got[3][n_], t, rtol=1e-5, atol=1e-6, msg=lambda m, n_=n_: f'{n_}: {m}')
+        else:
+            assert torch.equal(got[3][n_], t), n_
+
+
 def test_edge_cin_conv_and_full_oriented_conv_golden_gpu():
     """Round 3: `EdgeCINConv` with EdgeCIN0's networks and call (mp/layers.py:127-150,
     mp/models.py:311-341, 388-390) and a FULL `OrientedConv.forward` (mp/layers.py:441-452: propagate with the
