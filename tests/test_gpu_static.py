@@ -324,3 +324,62 @@ def test_static_train_two_slots_and_an_empty_slot_changes_nothing():
         if a.dtype.is_floating_point:
             worst = max(worst, float((a - b).abs().max()) / max(1.0, float(b.abs().max())))
     assert worst < 2 * 1e-3 * 3 * 1.1, worst
+
+
+def test_static_forward_and_train_step_on_the_molhiv_like_configuration():
+    """BASELINE configs[2] through the static path: OGBEmbedSparseCIN (nine atom-feature tables, three bond-feature tables,
+    hidden 64, mean readout; exp/scripts/cwn-molhiv.sh:9-32) -- the eval forward of unseen batches bit-identical to the
+    per-batch launches, and a captured training step (regression loss on synthetic targets) against TrainStep's eager
+    per-batch step from the same state."""
+    from cwn_amd import csr
+    from cwn_amd.models import OGBEmbedSparseCIN
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward, StaticTrainStep
+    from cwn_amd.synthetic import molhiv_like_complexes
+    from cwn_amd.train import TrainStep
+    pool = molhiv_like_complexes(150, 7, 6)
+    g = torch.Generator().manual_seed(0)
+    for c in pool:
+        c.y = torch.randn(1, 1, generator=g)
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+
+    def make(seed=1):
+        torch.manual_seed(seed)
+        return OGBEmbedSparseCIN(1, 2, 64, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum', init_reduce='sum',
+                                 embed_edge=True, use_coboundaries=True, graph_norm='bn').to(DEV)
+    B = 40
+    batches = _batches(len(pool), B, 5, sizes=[B, B, 23])
+    model = make().eval()
+    sb = StaticBatch(p, B)
+    assert sb.fits(batches).all()
+    sf = StaticForward(model, sb)
+    with torch.no_grad():
+        for idx in batches:
+            got = sf.run(idx).clone()
+            want = model(p.collate(idx))
+            assert torch.equal(got, want), float((got - want).abs().max())
+    csr.check_errors(DEV)
+    # training
+    m1, m2 = make(2), make(2)
+    m2.load_state_dict(m1.state_dict())
+    sb2 = StaticBatch(p, B)
+    sb2.set_batch(batches[0])
+    st = StaticTrainStep(m1, sb2, lr=1e-3)
+    ref = TrainStep(m2, [p.collate(idx) for idx in batches], lr=1e-3, use_graph=False)
+    for j, idx in enumerate(batches):
+        l1 = st.step_on([idx])[0].clone()
+        l2 = ref.step(j)
+        torch.cuda.synchronize()
+        assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l2))), (j, float(l1), float(l2))
+        rel = float((st.bucket.flat - ref.bucket.flat).norm() / ref.bucket.flat.norm())
+        print(f'[static train, molhiv-like] step {j}: loss {float(l1):.6f} vs {float(l2):.6f}, relative L2 distance of the gradient {rel:.2e}')
+        assert rel < 2e-5, (j, rel)
+        if j + 1 < len(batches):                     # (every step from ONE state: test_static_train_step_matches_the_per_batch_step)
+            ref.opt.flat_p.copy_(st.opt.flat_p)
+            ref.opt.exp_avg.copy_(st.opt.exp_avg)
+            ref.opt.exp_avg_sq.copy_(st.opt.exp_avg_sq)
+            for (_, a), (_, b_) in zip(m1.named_buffers(), m2.named_buffers()):
+                b_.copy_(a)
+    csr.check_errors(DEV)
+    assert len(st._graphs) == 1
