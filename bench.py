@@ -1256,9 +1256,14 @@ def main():
                 extra = {'zinc_batch2048': ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1'],
                          'zinc_real_spread': ['--workload', 'zinc'],
                          'zinc_real_spread_batch2048': ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1']}.get(wl, ['--workload', wl])
-                cmd = [sys.executable, os.path.abspath(__file__)] + extra + ['--brief', '--steps', str(max(args.steps, 20)),
+                # (molhiv-512 = BASELINE configs[2] also runs its full forward, training step and the never-seen-batch legs)
+                whole = wl == 'molhiv'
+                cmd = [sys.executable, os.path.abspath(__file__)] + extra + (['--no-cpu'] if whole else ['--brief']) + [
+                       '--steps', str(max(args.steps, 20)),
                        '--warmup', str(max(args.warmup, 5)), '--kernel-reps', str(min(args.kernel_reps, 50))]
                 env_ = dict(os.environ)
+                if whole:
+                    env_['CWN_BENCH_SKIP'] = 'eager,concurrent,collate,workloads'
                 if wl.startswith('zinc_real_spread'):
                     env_['CWN_BENCH_ATOMS'] = 'zinc'
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env_)
@@ -1274,6 +1279,14 @@ def main():
                                               ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us',
                                                'algorithmic_bytes_per_launch')},
                                  'roofline_step': {k: (d_['roofline_step'] or {}).get(k) for k in ('achieved', 'unit', 'frac')}}
+                if whole:
+                    sec_ = d_.get('secondary') or {}
+                    fb_ = sec_.get('fresh_batches') or {}
+                    workloads[wl].update({
+                        'full_forward_ms': sec_.get('full_forward_ms'),
+                        'train_step_ms': (sec_.get('train_step') or {}).get('ms_per_step'),
+                        'fresh_batches': {k: fb_.get(k) for k in ('propagate', 'forward', 'train', 'every_batch_within_capacity',
+                                                                   'device_error_word', 'steps_per_replay', 'batch', 'failed')}})
             except Exception as e:
                 workloads[wl] = {'failed': f'{type(e).__name__}: {e}'}
                 print(f'[bench] workload {wl} failed: {type(e).__name__}: {e}', file=sys.stderr)

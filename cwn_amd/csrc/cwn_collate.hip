@@ -3,14 +3,16 @@
 // One launch fills every array of a ComplexBatch: workgroup (descriptor d, segment s) copies the
 // s-th selected complex's slice of array d to its place in the batched array, adding that
 // complex's running cell offset to index values.  Byte / integer work, HBM-bound; segments are
-// tens to hundreds of elements, so a 64-thread workgroup per (array, complex) with coalesced
-// element-wise accesses is the natural grain (B = 128 complexes x ~14 arrays = ~1.8 k workgroups).
+// tens to hundreds of elements, so a WAVE per (array, complex) with coalesced element-wise accesses is the
+// natural grain -- four to a workgroup: a static batch of 8 slots x 512 complexes x ~30 arrays was 123 k
+// one-wave workgroups, 38 us of workgroup launches.
 #include <hip/hip_runtime.h>
 #include "../../include/cwn_hip.h"
 
 namespace {
 
-constexpr int kThreads = 64;
+constexpr int kThreads = 256;        // four segments per workgroup, a wave each
+constexpr int kSegPerWg = kThreads / 64;
 
 struct CollateBatch {
     cwn_collate_desc d[CWN_MAX_COLLATE_DESCS];
@@ -22,10 +24,12 @@ struct CollateBatch {
 
 __global__ __launch_bounds__(kThreads) void collate_kernel(CollateBatch B, int64_t n_seg) {
     const int di = blockIdx.y;
-    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * kSegPerWg + (threadIdx.x >> 6);
     const int64_t slot = blockIdx.z;
     if (B.cursor != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
         *B.cursor += (int64_t)gridDim.z;             // (the tables of this launch were cut by an EARLIER launch: no reader left)
+    if (s >= n_seg) return;                          // (a whole wave)
     const cwn_collate_desc& D = B.d[di];
     const int64_t tab_off = slot * B.table_slot_stride;
     const int64_t d0 = D.dst_start[tab_off + s], len = D.dst_start[tab_off + s + 1] - d0;
@@ -37,20 +41,20 @@ __global__ __launch_bounds__(kThreads) void collate_kernel(CollateBatch B, int64
         if (D.op == CWN_COLLATE_COPY32) {
             const int32_t* src = (const int32_t*)D.src + r * D.src_row_stride + s0;
             int32_t* dst = (int32_t*)dst_base + r * D.dst_row_stride + d0;
-            for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = src[q];
+            for (int64_t q = lane; q < len; q += 64) dst[q] = src[q];
         } else if (D.op == CWN_COLLATE_ADD32) {
             const int32_t* src = (const int32_t*)D.src + r * D.src_row_stride + s0;
             int32_t* dst = (int32_t*)dst_base + r * D.dst_row_stride + d0;
             const int32_t a = (int32_t)add;
-            for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = src[q] + a;
+            for (int64_t q = lane; q < len; q += 64) dst[q] = src[q] + a;
         } else if (D.op == CWN_COLLATE_SEGID64) {
             int64_t* dst = (int64_t*)dst_base + r * D.dst_row_stride + d0;
-            for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = s;
+            for (int64_t q = lane; q < len; q += 64) dst[q] = s;
         } else {
             const int64_t* src = (const int64_t*)D.src + r * D.src_row_stride + s0;
             int64_t* dst = (int64_t*)dst_base + r * D.dst_row_stride + d0;
             const int64_t a = D.op == CWN_COLLATE_ADD64 ? add : 0;
-            for (int64_t q = threadIdx.x; q < len; q += kThreads) dst[q] = src[q] + a;
+            for (int64_t q = lane; q < len; q += 64) dst[q] = src[q] + a;
         }
     }
 }
@@ -79,16 +83,33 @@ __global__ __launch_bounds__(kTabThreads) void collate_tables_kernel(const int64
     const int64_t o_src = (int64_t)K * (B + 1), o_off = o_src + (int64_t)K * B, o_seg = o_off + (int64_t)D * 5 * B;
     const int64_t o_sizes = o_seg + (int64_t)D * (B + 1);
     bool bad = past;                                    // ... and is reported
-    for (int col = wave; col < ncol; col += kTabThreads / 64) {
+    // columns: wave w of workgroup (slot, y) takes w + 16 y, + 16 gridDim.y, ...; the chunks of a column (64 complexes each) are
+    // REQUESTED kTabChunks at a time -- index, then both metadata words -- before the first scan: two dependent round trips per
+    // 512 complexes instead of two per 64
+    constexpr int kTabChunks = 8;
+    for (int col = wave + (kTabThreads / 64) * (int)blockIdx.y; col < ncol; col += (kTabThreads / 64) * (int)gridDim.y) {
         int64_t carry = 0;
         const bool is_key = col >= 3 * D;
         const int k = col - 3 * D, d = col / 3, which = col % 3;
-        for (int64_t s0 = 0; s0 < B; s0 += 64) {
+        for (int64_t sb0 = 0; sb0 < B; sb0 += 64 * kTabChunks) {
+        int64_t cc[kTabChunks], vv[kTabChunks], st[kTabChunks];
+#pragma unroll
+        for (int u = 0; u < kTabChunks; ++u) {
+            const int64_t s = sb0 + 64 * u + lane;
+            cc[u] = s < B ? idx[s] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kTabChunks; ++u) {
+            if (cc[u] >= num) { bad = bad || num > 0; cc[u] = -1; }
+            vv[u] = cc[u] >= 0 ? meta[cc[u] * W + col] : 0;
+            st[u] = (is_key && cc[u] >= 0) ? meta[cc[u] * W + col + K] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kTabChunks; ++u) {
+            const int64_t s0 = sb0 + 64 * u;
+            if (s0 >= B) break;
             const int64_t s = s0 + lane;
-            int64_t c = s < B ? idx[s] : -1;
-            if (c >= num) { bad = bad || num > 0; c = -1; }
-            const int64_t v = c >= 0 ? meta[c * W + col] : 0;
-            const int64_t start = (is_key && c >= 0) ? meta[c * W + col + K] : 0;
+            const int64_t v = vv[u], start = st[u];
             int64_t x = v;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -116,6 +137,7 @@ __global__ __launch_bounds__(kTabThreads) void collate_tables_kernel(const int64
             }
             carry += __shfl(x, 63, 64);
         }
+        }
         if (lane == 0) {
             if (is_key) {
                 tab[(int64_t)k * (B + 1)] = 0;
@@ -126,7 +148,7 @@ __global__ __launch_bounds__(kTabThreads) void collate_tables_kernel(const int64
             }
         }
     }
-    if (wave == 0) {                                    // complexes in the batch; the unused size slots
+    if (wave == 0 && blockIdx.y == 0) {                 // complexes in the batch; the unused size slots
         int64_t n = 0;
         for (int64_t s0 = 0; s0 < B; s0 += 64) {
             const int64_t s = s0 + lane;
@@ -155,8 +177,9 @@ extern "C" int cwn_collate_tables(const int64_t* meta, int64_t num, int32_t D, i
         return CWN_ERR_BAD_ARG;
     if (n_slots > 1 && slot_stride < (int64_t)cwn_collate_tables_len(D, K, B)) return CWN_ERR_BAD_ARG;
     if (B >= INT32_MAX) return CWN_ERR_TOO_LARGE;
-    collate_tables_kernel<<<dim3(n_slots), dim3(kTabThreads), 0, (hipStream_t)stream_>>>(meta, num, D, K, idx, B, n_batches, cursor,
-                                                                                        slot_stride, tables, err_flag);
+    const int ncol = 3 * D + K, per = kTabThreads / 64;
+    collate_tables_kernel<<<dim3(n_slots, (unsigned)((ncol + per - 1) / per)), dim3(kTabThreads), 0, (hipStream_t)stream_>>>(
+        meta, num, D, K, idx, B, n_batches, cursor, slot_stride, tables, err_flag);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
@@ -183,6 +206,7 @@ extern "C" int cwn_collate_slots(const cwn_collate_desc* descs, int n, int64_t n
         if ((D.op == CWN_COLLATE_ADD64 || D.op == CWN_COLLATE_ADD32) && D.add == nullptr) return CWN_ERR_BAD_ARG;
         B.d[i] = D;
     }
-    collate_kernel<<<dim3((unsigned)n_seg, (unsigned)n, (unsigned)n_slots), dim3(kThreads), 0, (hipStream_t)stream_>>>(B, n_seg);
+    collate_kernel<<<dim3((unsigned)((n_seg + kSegPerWg - 1) / kSegPerWg), (unsigned)n, (unsigned)n_slots), dim3(kThreads), 0,
+                     (hipStream_t)stream_>>>(B, n_seg);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

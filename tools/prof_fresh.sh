@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 ROOT=$PWD
 mkdir -p gpurun_out
 cd /tmp && rm -rf /tmp/prof_fresh
-CWN_BENCH_SKIP=full,eager,concurrent,train,collate,workloads,roofline CWN_BENCH_FRESH_EPOCHS=2 rocprofv3 --kernel-trace --stats -d /tmp/prof_fresh -- python $ROOT/bench.py --no-cpu > /tmp/prof_fresh.log 2>&1
+CWN_BENCH_SKIP=full,eager,concurrent,train,collate,workloads,roofline CWN_BENCH_FRESH_EPOCHS=2 rocprofv3 --kernel-trace --stats -d /tmp/prof_fresh -- python $ROOT/bench.py --no-cpu "$@" > /tmp/prof_fresh.log 2>&1
 cd $ROOT
 python profiles/summarize_rocprof.py "$(ls /tmp/prof_fresh/*/*results.db | head -1)" 60 > gpurun_out/prof_fresh.md
-grep -E "collate|items_|tables" gpurun_out/prof_fresh.md | head -8 | cut -c1-150
+head -14 gpurun_out/prof_fresh.md | cut -c1-150
