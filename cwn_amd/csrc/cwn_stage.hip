@@ -434,15 +434,23 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
     lds_barrier();
     const int n0 = ct * 16 + kq * 4;                 // D[i][j]: i = output column (lane >> 4) * 4 + reg, j = row (lane & 15)
     AccRegs acc;
-    auto store = [&](float* out, int64_t ld, const cwn_bn_bwd_live& L) {
-        const bool live = L.slots != nullptr;
-        float4 zz[kRT], lsc, lsh, lmu, lrs;
-        if (live) {              // requested before the stores: the receiving stage's z at this lane's rows / columns, its constants
+    // what a live producer needs of the stage that receives its dx: that stage's z at this lane's rows / columns -- requested
+    // BEFORE the product whose result it meets (behind it: an exposed round trip to HBM at the end of every workgroup)
+    struct LiveIn { float4 zz[kRT]; };
+    auto request_live = [&](const cwn_bn_bwd_live& L, LiveIn& R) {
+        if (L.slots == nullptr) return;
 #pragma unroll
-            for (int rt = 0; rt < kRT; ++rt) {
-                const int64_t row = row0 + (rt0 + rt) * 16 + l15;
-                zz[rt] = *reinterpret_cast<const float4*>(L.z + (row < D.M ? row : D.M - 1) * L.ldz + n0);
-            }
+        for (int rt = 0; rt < kRT; ++rt) {
+            const int64_t row = row0 + (rt0 + rt) * 16 + l15;
+            R.zz[rt] = *reinterpret_cast<const float4*>(L.z + (row < D.M ? row : D.M - 1) * L.ldz + n0);
+        }
+    };
+    auto store = [&](float* out, int64_t ld, const cwn_bn_bwd_live& L, const LiveIn& R) {
+        const bool live = L.slots != nullptr;
+        const float4 (&zz)[kRT] = R.zz;
+        // (the constants behind the product: with them in flight across it the F = 128 kernel spills past its 128 registers)
+        float4 lsc, lsh, lmu, lrs;
+        if (live) {
             lsc = *reinterpret_cast<const float4*>(L.aff + n0);
             lsh = *reinterpret_cast<const float4*>(L.aff + F + n0);
             lmu = *reinterpret_cast<const float4*>(L.aff + 2 * F + n0);
@@ -493,18 +501,21 @@ __global__ __launch_bounds__(kThreads, 4) void dense_stage_bwd_kernel(StageBwdBa
     };
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
+    LiveIn live_in;
+    request_live(D.out_bn, live_in);
     multiply(acc);
     if (two) {
         __builtin_amdgcn_sched_barrier(0);               // (the requests below not hoisted into the product above)
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) request_kstep(D.wt2_packed, ks);
     }
-    store(D.dx, D.lddx, D.out_bn);
+    store(D.dx, D.lddx, D.out_bn, live_in);
     if (two) {
 #pragma unroll
         for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
+        request_live(D.out_bn2, live_in);
         multiply(acc);
-        store(D.dx2, D.lddx2, D.out_bn2);
+        store(D.dx2, D.lddx2, D.out_bn2, live_in);
     }
 }
 

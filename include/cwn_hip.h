@@ -309,7 +309,7 @@ size_t cwn_layer_packed_weight_bytes(int32_t F);
 int cwn_layer_pack_weights_f32(const float* W, int64_t ldw, int32_t F, void* out, cwn_stream_t stream);
 /* the same for n weights of one width in ONE launch (a training step packs the message weights of all its layers once,
  * after the optimizer has written them): host arrays of n device pointers / row strides */
-#define CWN_LAYER_PACK_MAX 16
+#define CWN_LAYER_PACK_MAX 32
 int cwn_layer_pack_weights_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out, int32_t n,
                                     cwn_stream_t stream);
 /* ... and in the form the BACKWARD launch (cwn_layer_bwd_f32) multiplies with: the same planes and chunk order of the
