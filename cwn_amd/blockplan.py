@@ -375,7 +375,7 @@ def single_fit_forward(cells: Sequence[np.ndarray], up_len: Sequence[Optional[np
         d0 = tasks[0]
         n0 = cells[d0]
         nc = cells[g + 1] if g is not None else z
-        first = np.where(nc > 0, (p16(n0) + rr - 1) // rr * rr, p16(n0))
+        first = p16(n0)                                                   # (round 4: a multiple of 16, not of `rr`)
         rows = np.where(nc > 0, first + p16(nc), p16(n0))
         src = np.zeros_like(n0)
         ents = p4(up[g]) if g is not None else np.zeros_like(n0)

@@ -26,10 +26,8 @@ struct Shape {
     int F, round_rows, variant;
     int64_t kLds;                      // LDS budget of a workgroup of this variant
     int64_t half_cap;                  // bound of the (padded) rows of ONE product, or 0: only the sum is bounded
-    int64_t first_coface_row(int64_t n_g, int64_t n_c) const {
-        const int64_t r1 = pad16(n_g);
-        return n_c > 0 ? (r1 + round_rows - 1) / round_rows * round_rows : r1;
-    }
+    // (round 4: a multiple of 16, no longer of the kernel's rows per round -- cwn_layer.hip, the load rounds decide per wave)
+    int64_t first_coface_row(int64_t n_g, int64_t /*n_c*/) const { return pad16(n_g); }
     int64_t staged(int64_t n_g, int64_t n_c) const { return n_c > 0 ? first_coface_row(n_g, n_c) + pad16(n_c) : pad16(n_g); }
     // = cwn_layer_fused_lds_bytes without its argument checks
     int64_t lds(int64_t rows, int64_t src) const {

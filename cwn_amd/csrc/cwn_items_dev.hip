@@ -127,10 +127,7 @@ struct FwdGeom {
     int F, variant, round_rows, g, n_tasks, t0, t1;
     int64_t row_cap, src_cap, lds_budget, half_cap, idx_bytes;
     __device__ __forceinline__ int task(int t) const { return t == 0 ? t0 : t1; }
-    __device__ int64_t first_coface_row(int64_t n_g, int64_t n_c) const {
-        const int64_t r1 = pad16(n_g);
-        return n_c > 0 ? (r1 + round_rows - 1) / round_rows * round_rows : r1;
-    }
+    __device__ int64_t first_coface_row(int64_t n_g, int64_t /*n_c*/) const { return pad16(n_g); }   // (= cwn_blockplan.cpp)
     __device__ int64_t staged(int64_t n_g, int64_t n_c) const { return n_c > 0 ? first_coface_row(n_g, n_c) + pad16(n_c) : pad16(n_g); }
     __device__ int64_t lds(int64_t rows, int64_t src) const { return 3 * rows * (F + 8) * 2 + (src + 1) * F * 4 + idx_bytes; }
 

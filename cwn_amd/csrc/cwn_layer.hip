@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
         t_sn[t] = fld(o + T_SN);                 // 0 unless the task has boundary entries (sources are staged)
     }
     // staged rows: [0, g_n) the cells of task 0 (the GEMM dimension g when the item has one), then, from
-    // row R1 (a multiple of the rows-per-round, so that lane groups line up), the c_n cells of g + 1
+    // row R1 (a multiple of 16: whole MFMA tiles, whole waves of the load rounds), the c_n cells of g + 1
     const int g_n = t_n[0], c_n = fld(I_CN);
     const int R1 = fld(I_R1), rows_pad = fld(I_ROWS);
     // segments of the item's combined entry list, each starting at a multiple of 4 (ds_read_b128 of
@@ -794,17 +794,21 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
         const gcb_p xg = (gcb_p)sfld(S_XG) + (size_t)t_r0[0] * kRowB, xc = (gcb_p)sfld(S_XC) + (size_t)fld(I_CR0) * kRowB;
         const gcb_p xs = (gcb_p)sfld(S_TASK0 + ST_XS) + (size_t)fld(I_TASK0 + T_SR0) * kRowB;
         const int nxr = (rows_pad + G::kNG - 1) / G::kNG, ner = (t_sn[0] + G::kNG - 1) / G::kNG;
-        // Round i belongs to the coface block iff i >= k0 (= R1 / kNG; no coface block: never): base, row
-        // count and first row of the round are chosen by scalar selects, one compare per round
-        const int k0 = c_n > 0 ? R1 / G::kNG : kNX;
+        // The staged rows of a WAVE in round i (64 / kG consecutive ones from i * kNG + wave_row0) lie in the coface block
+        // iff the first of them is >= R1 -- R1 is a multiple of 16, a wave's rows never straddle it: base, row count and
+        // first row of the round are chosen by scalar selects, one compare per round.  (Round 4: R1 used to be a multiple
+        // of kNG, the decision one per WORKGROUP and round; 33 vertices then padded to 64 staged rows and a molecule of
+        // more than 32 atoms did not fit the 96 rows of F = 128 -- the real ZINC subset has ~2 % of them.)
+        const int wave_row0 = wave_u * (64 / G::kG);
         const uint64_t xg_b = (uint64_t)(uintptr_t)xg, xc_b = (uint64_t)(uintptr_t)xc;
 #pragma unroll
         for (int i = 0; i < kNX; ++i) {
             if (i < nxr) {           // a skipped round leaves xv[i] unset: it is never read (rows >= rows_pad)
-                const bool second = i >= k0;
+                // (16 rows per round -- the two-per-CU form at F = 128: R1 is whole rounds, nothing per wave)
+                const bool second = c_n > 0 && i * G::kNG + (G::kNG > 16 ? wave_row0 : 0) >= R1;
                 const gcb_p base = (gcb_p)(second ? xc_b : xg_b);
-                const int last = (second ? c_n : g_n) - 1, first = (second ? i - k0 : i) * G::kNG;
-                xv[i] = ldg4o(base, (uint32_t)min(gq + first, last) * kRowB + fB);
+                const int last = (second ? c_n : g_n) - 1, first = second ? i * G::kNG - R1 : i * G::kNG;
+                xv[i] = ldg4o(base, (uint32_t)max(min(gq + first, last), 0) * kRowB + fB);
             }
         }
 #pragma unroll
@@ -1006,20 +1010,26 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
             out_b[t] = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_B) + (size_t)t_r0[t] * kRowB;
         }
         const uint16_t* const cols[2] = {scol + b1, scol + b2};
-        const int k0 = R1 / G::kNG;                 // first staged round of task 1's cells
+        // Task 1's cells are the staged rows from R1 on, and a lane group finishes the rows IT loaded (their self terms wait in
+        // its registers): cell r of task 1 is staged row R1 + r, loaded by lane group (R1 + r) % kNG in round (R1 + r) / kNG.
+        // So lane group gq takes the cells r = (gq - R1) mod kNG + k kNG of task 1 -- the cells gq + k kNG when R1 is a whole
+        // number of rounds (every item before round 4).
+        const int sh = G::kNG > 16 ? R1 % G::kNG : 0, k0 = R1 / G::kNG;
+        const int gq1 = gq >= sh ? gq - sh : gq - sh + G::kNG, carry1 = gq >= sh ? 0 : 1;
         const bool any_b = t_bne[0] + t_bne[1] > 0; // no boundary entries at all (vertices): self terms only
         const int rounds = (max(t_n[0], t_n[1]) + G::kNG - 1) / G::kNG;
         for (int k = 0; k < rounds; ++k) {
             const int r = gq + k * G::kNG;
+            const int rt_[2] = {r, gq1 + k * G::kNG};
             RowSet<2> R;
             int steps = 0;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                R.on[t] = r < t_n[t];
+                R.on[t] = rt_[t] < t_n[t];
                 R.s[t] = R.e[t] = 0;
                 if (any_b) {
                     const uint16_t* rp = rowptr + (t + 1) * kRpStride;
-                    const int rr = R.on[t] ? r : 0;
+                    const int rr = R.on[t] ? rt_[t] : 0;
                     const int s_ = rp[rr], e_ = rp[rr + 1];
                     R.s[t] = R.on[t] ? s_ : 0;
                     R.e[t] = R.on[t] ? e_ : 0;
@@ -1027,14 +1037,14 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
                 }
             }
             float4 acc[2];
-            const float4 xi[2] = {pick(xv, k), pick(xv, k0 + k)};     // self terms: this group loaded them
+            const float4 xi[2] = {pick(xv, k), pick(xv, k0 + k + carry1)};     // self terms: this group loaded them
             if constexpr (kW8)
                 gather_sum_planes<F>(acc, R, steps, cols, xsrc, x_rows, planes, (size_t)rows_cap * G::kPlaneStride, t_sn[0], f);
             else
                 gather_sum<2, F>(acc, R, steps, cols, xsrc, x_rows, f);
-            const uint32_t off = (uint32_t)r * kRowB + fB;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+                const uint32_t off = (uint32_t)rt_[t] * kRowB + fB;
                 if (R.on[t]) {
                     stg4o(out_b[t], off, axpy4(acc[t], 1.0f + eps2[t], xi[t]));
                     if (!(has_gemm && t == 0))   // no upper adjacency in this dimension: zeros + self term
@@ -1402,7 +1412,8 @@ extern "C" int CWN_FN(items_check)(const int32_t* items, int64_t n_items, int32_
             ++n_big;
             continue;
         }
-        const int64_t r1 = nc > 0 ? (pad16(n0) + ng - 1) / ng * ng : pad16(n0);
+        const int64_t r1 = pad16(n0);                      // (round 4: no longer a whole number of rounds of `ng` rows)
+        (void)ng;
         const int64_t rows = nc > 0 ? r1 + pad16(nc) : pad16(n0);
         const int64_t b1 = pad4(une), b2 = pad4(b1 + bne[0]), total = pad4(b2 + bne[1]);
         if (r[I_R1] != r1 || r[I_ROWS] != rows || r[I_B1] != b1 || r[I_B2] != b2 || r[I_TOTAL] != total) return CWN_ERR_BAD_ARG;

@@ -95,7 +95,7 @@ BLOCKED_MAX_ITEMS = int(os.environ.get('CWN_BLOCKED_MAX_ITEMS', '2600'))
 # one-per-CU form while the items fit the chip once (TWO_PER_CU_MIN_ITEMS), the 8-wave two-per-CU form beyond that
 # when every complex fits its smaller caps; '0' / '1' force one (A/B measurements, tests).
 LAYER_VARIANT = os.environ.get('CWN_LAYER_VARIANT', 'auto')
-# A complex beyond a workgroup's LDS (a molecule of more than 32 atoms at width 128, ~115 at 64) is streamed by its own
+# A complex beyond a workgroup's LDS (a molecule of more than ~44 atoms at width 128, ~115 at 64) is streamed by its own
 # workgroup inside the blocked launch (BIG records) instead of sending the whole batch to the two-kernel path -- while
 # such complexes are the exception (at most BIG_MAX_SHARE of the items: a batch of hub complexes IS the streaming case).
 BIG_ITEMS = {'0': False, 'always': 'always'}.get(os.environ.get('CWN_BIG_ITEMS', '1'), True)   # 'always': skip the cost model below (tests, A/B)

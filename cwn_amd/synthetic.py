@@ -182,7 +182,7 @@ def zinc_like_complexes(num: int, seed: int = 0, max_ring: int = 6, n_lo: int = 
     """`num` ZINC-shaped ring-lifted complexes with integer atom / bond types as [N,1] floats
     (the form EmbedSparseCIN expects, mp/molec_models.py:95-99).  size_dist: 'uniform' on [n_lo, n_hi] (SURVEY.md 8d's
     generator: 18 - 30), or 'zinc': the published size statistics of the ZINC-12k subset the reference trains on (9 - 37 heavy
-    atoms, mean 23.2, standard deviation ~4.6: a clipped normal -- about 2 % of the molecules have more than 32 atoms, the
+    atoms, mean 23.2, standard deviation ~4.6: a clipped normal -- about 2 % of the molecules have more than 32 atoms (what a workgroup of the layer kernel held at width 128 until round 4), the
     most one workgroup of the 16-wave layer kernel holds at width 128)."""
     rng = np.random.default_rng(seed)
     out = []

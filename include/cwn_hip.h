@@ -259,7 +259,7 @@ int cwn_aggregate_f32(const cwn_agg_desc* descs_host, int n, cwn_stream_t stream
  * layout, same arithmetic, bit-identical outputs; smaller caps, and the rows of EACH product (cells of g, cells of
  * g+1, each padded to 16) are bounded by CWN_LAYER_W8_HALF_ROWS.  Rows per round: cwn_layer_variant_round_rows. */
 /* BIG ITEMS (record flag bit 1; variant 0 only; cwn_layer_sizes.allow_big).  A complex whose rows or entries exceed
- * what a workgroup's LDS holds (a molecule of more than 32 atoms at F = 128 -- 33 atoms pad to 64 staged rows and their bonds to 48 more, beyond the 96 -- or of more than ~115 at F = 64) used to send its WHOLE
+ * what a workgroup's LDS holds (at F = 128: the atoms and the bonds of a molecule, each padded to 16, beyond 96 staged rows -- 48 atoms + 48 bonds at most, i.e. molecules of more than ~44 atoms; round 3 padded the first block to whole load rounds of 32 and stopped at 32 atoms -- or of more than ~115 atoms at F = 64) used to send its WHOLE
  * batch to the streaming path (cwn_gemm_f32 + cwn_aggregate_f32).  With allow_big the table builder gives such a
  * complex one BIG record per set instead: its workgroup runs the streaming algorithm by itself inside the same launch --
  * Y1 / Y2 of the complex row tile by row tile on the matrix cores straight from the fp32 rows into the scratch matrices

@@ -42,7 +42,7 @@ def _build_with(self, F: int, has_up, row_cap: int, src_cap: int):
 
     def first_coface_row(n_g: int, n_c: int) -> int:
         r1 = _pad16(n_g)
-        return (r1 + ng_round - 1) // ng_round * ng_round if n_c > 0 else r1
+        return r1                               # (round 4: a multiple of 16, no longer of the rows per round)
 
     def staged(n_g: int, n_c: int) -> int:
         return first_coface_row(n_g, n_c) + _pad16(n_c) if n_c > 0 else _pad16(n_g)

@@ -447,7 +447,7 @@ def test_item_table_derived_fields_and_host_check():
         pad4 = lambda n: (n + 3) // 4 * 4
         for r in tab:
             n0, nc, une = int(r[11]), int(r[5]), int(r[7])
-            r1 = (pad16(n0) + ng - 1) // ng * ng if nc > 0 else pad16(n0)
+            r1 = pad16(n0)                         # (round 4: whole 16-row tiles, no longer whole load rounds of `ng` rows)
             assert r[23] == r1 and r[24] == (r1 + pad16(nc) if nc > 0 else pad16(n0))
             assert r[25] == pad4(une) and r[26] == pad4(r[25] + r[13]) and r[27] == pad4(r[26] + r[20])
             assert not r[28:].any()

@@ -234,16 +234,16 @@ def test_static_train_step_matches_the_per_batch_step():
 
 
 def test_a_complex_beyond_a_workgroup_is_refused_by_fits_and_flagged_by_the_device():
-    """A 44-atom molecule does not fit one workgroup at width 128: fits() says so for the batches that hold it (the caller
+    """A 60-atom molecule does not fit one workgroup at width 128 (48 atoms + 48 bonds are the 96 staged rows): fits() says so for the batches that hold it (the caller
     routes them to PackedComplexes.collate), and pushing such a batch through anyway sets the sticky UNFIT bit."""
     from cwn_amd import csr
     from cwn_amd.packed import PackedComplexes
     from cwn_amd.static_batch import StaticBatch
     from cwn_amd.static_graph import StaticForward
     from cwn_amd.synthetic import zinc_like_complexes
-    pool = zinc_like_complexes(60, seed=1, max_ring=6, n_lo=12, n_hi=26) + zinc_like_complexes(1, seed=2, max_ring=6, n_lo=44, n_hi=44)
+    pool = zinc_like_complexes(60, seed=1, max_ring=6, n_lo=12, n_hi=26) + zinc_like_complexes(1, seed=2, max_ring=6, n_lo=60, n_hi=60)
     p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
-    sb = StaticBatch(p, 16, caps={'cells': [600, 700, 90]})
+    sb = StaticBatch(p, 16, caps={'cells': [640, 740, 90]})
     sf = StaticForward(_model(128).eval(), sb)
     with torch.no_grad():
         sf.run(list(range(16)))
