@@ -1250,7 +1250,7 @@ def main():
         # (+ the headline's own workload at batch 2048: the range where a launch has many items per CU and takes the
         # two-per-CU form of the layer kernel -- DESIGN.md 4.0b)
         # (+ the headline's workload with the molecule sizes of the REAL ZINC subset -- 9 - 37 atoms, ~2 % beyond the 32 one
-        # workgroup holds at width 128: those become BIG records -- at batch 128 and 2048: VERDICT r3 item 5)
+        # workgroup held at width 128 until round 4 (BIG records then; they fit since) -- at batch 128 and 2048: VERDICT r3 item 5)
         for wl in ('molhiv', 'reddit', 'zinc_batch2048', 'zinc_real_spread', 'zinc_real_spread_batch2048'):
             try:
                 extra = {'zinc_batch2048': ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1'],
