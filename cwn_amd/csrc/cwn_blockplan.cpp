@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include "../../include/cwn_hip.h"
 #include "cwn_layer_bwd_own.h"
@@ -17,7 +18,13 @@
 namespace {
 
 constexpr int kInts = CWN_LAYER_ITEM_INTS;
-constexpr int kTargetItems = 128;      // per GEMM dimension: ~one workgroup per CU over the two sets of a 2-complex
+constexpr int kTargetItemsDefault = 128;      // per GEMM dimension: ~one workgroup per CU over the two sets of a 2-complex
+// (CWN_LAYER_TARGET_ITEMS: tuning experiments -- how many complexes an item may hold at most = C / target)
+static const int kTargetItems = [] {
+    const char* e = getenv("CWN_LAYER_TARGET_ITEMS");
+    const int v = e != nullptr ? atoi(e) : 0;
+    return v > 0 ? v : kTargetItemsDefault;
+}();
 
 inline int64_t pad16(int64_t n) { return (n + 15) / 16 * 16; }
 inline int64_t pad4(int64_t n) { return (n + 3) / 4 * 4; }
