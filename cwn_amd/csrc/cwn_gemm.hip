@@ -261,7 +261,16 @@ template <bool FAST, bool PRO, int KP, int WN, bool WT, int RT, bool BNB>
 #ifndef CWN_GEMM_FRAGPF
 #define CWN_GEMM_FRAGPF 0
 #endif
-__global__ __launch_bounds__(kThreads, (KP <= 128 && RT == 2 ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B, BnbArg<BNB> E) {
+// (Round 4, VERDICT r3 item 8: the instantiations that do not fit 256 registers -- the 64 x 64 tile with a prologue or a transposed
+// weight at K <= 128, the BatchNorm-backward prologue: 6 - 51 VGPRs in scratch -- compiled for ONE workgroup per SIMD pair
+// (-DCWN_GEMM_NOSPILL=1: no spill left in this file) are SLOWER where they run: training steps with CWN_STAGE_KERNEL=0, molhiv-512
+// 1.075 vs 1.061 ms, ZINC-128 0.952 vs 0.900 ms (profiles/r4_gemm_spills.txt).  Two co-resident workgroups that spill a few
+// registers beat one that does not: the bound stays.)
+#ifndef CWN_GEMM_NOSPILL
+#define CWN_GEMM_NOSPILL 0
+#endif
+__global__ __launch_bounds__(kThreads, (KP <= 128 && RT == 2 && !(CWN_GEMM_NOSPILL && KP == 128 && ((WN == 2 && (PRO || WT)) || BNB))
+                                        ? CWN_GEMM_LB : 1)) void gemm_kernel(GemmBatch B, BnbArg<BNB> E) {
     // RT = 16-row MFMA tiles per wave (2; 3 for the one-round small-M case, see the host side)
     constexpr int BM = 16 * RT * (4 / WN);   // rows per tile: WN waves side by side along N, 4/WN along M
     constexpr int BN = 32 * WN;         // columns per tile
