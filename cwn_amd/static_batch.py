@@ -257,10 +257,14 @@ class StaticBatch:
         self.o_seg = self.o_off + D * 5 * B
         self.o_sizes = self.o_seg + D * (B + 1)
         self.meta = packed.meta_device()
-        self.n_batches = S                                                       # batches the index buffer holds
-        self.idx = torch.full((S * B,), -1, dtype=torch.int64, device=dev)       # S batches, or an epoch's permutation (set_epoch)
+        # the batch numbers the fills read: room for an epoch over the whole dataset (+ a replay's worth of spare slots) from the
+        # start -- a captured fill holds this buffer's address and length, so it must not move once a step has been captured
+        # (reserve_epoch asks for more BEFORE the first fill).  Fill number j takes the batches at the device cursor, which it
+        # advances by S: set_batches / set_epoch upload and rewind.
+        self.n_batches = -(-(max(S, -(-packed.num // B)) + S) // S) * S
+        self.idx = torch.full((self.n_batches * B,), -1, dtype=torch.int64, device=dev)
         self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.use_cursor = False
+        self.use_cursor = True
         self.fill_id = 0
         # ---- buffers ([S, ...]) + the collate launch's descriptors (slot 0's pointers + the slot strides) --------------
         base = self.tables.data_ptr()
@@ -519,12 +523,12 @@ class StaticBatch:
         return host
 
     def set_batches(self, batches: Sequence[Sequence[int]]) -> None:
-        """The complexes of the next fill, one index list per slot (at most `slots`; the other slots get empty batches)."""
-        if self.use_cursor:
-            raise RuntimeError('set_batches after set_epoch / reserve_epoch: the fills read the epoch permutation')
+        """The complexes of the NEXT fill, one index list per slot (at most `slots`; the other slots get empty batches): an
+        epoch of one replay."""
         if len(batches) > self.S or len(batches) == 0:
             raise ValueError(f'1 .. {self.S} batches')
         self.idx[:self.S * self.B].copy_(torch.from_numpy(self._host_perm(batches, self.S).reshape(-1)))
+        self.cursor.zero_()
 
     def set_batch(self, idx: Sequence[int]) -> None:
         self.set_batches([idx])
@@ -532,20 +536,21 @@ class StaticBatch:
     def reserve_epoch(self, n_batches: int) -> None:
         """Size the permutation buffer for epochs of up to n_batches batches (before the first fill / capture: a captured
         fill holds the buffer's address and its length)."""
-        if self.fill_id > 0:
-            raise RuntimeError('reserve_epoch after the first fill: a captured step reads the old buffer')
         n = -(-max(1, int(n_batches)) // self.S) * self.S              # whole replays of S steps
+        if n <= self.n_batches:
+            return
+        if self.fill_id > 0:
+            raise RuntimeError(f'reserve_epoch({n_batches}) after the first fill: a captured step reads the buffer of {self.n_batches} '
+                               'batches it was captured with -- ask before building StaticForward / StaticTrainStep')
         self.n_batches = n
         self.idx = torch.full((n * self.B,), -1, dtype=torch.int64, device=self.device)
-        self.use_cursor = True
         self.cursor.zero_()
 
     def set_epoch(self, batches: Sequence[np.ndarray]) -> int:
         """Upload the complex numbers of a whole epoch's batches (one host -> device copy); fill number j after this call takes
         batches j S .. j S + S - 1 (the device cursor advances by itself: a replayed step needs nothing from the host).  Batches
         past the epoch's own are empty (their steps change nothing).  Returns the number of fills the epoch takes."""
-        if not self.use_cursor:
-            self.reserve_epoch(len(batches))
+        self.reserve_epoch(len(batches))
         if len(batches) > self.n_batches:
             raise RuntimeError(f'set_epoch: {len(batches)} batches, the permutation buffer a captured step reads holds '
                                f'{self.n_batches}: reserve_epoch(n) before the first fill')
@@ -566,7 +571,7 @@ class StaticBatch:
         L = _ffi.lib()
         s = _ffi.stream_ptr(self.device)
         err = csr._err_flag(self.device).data_ptr()
-        cur = self.cursor.data_ptr() if self.use_cursor else None
+        cur = self.cursor.data_ptr()
         _ffi.check(L.cwn_collate_tables(self.meta.data_ptr(), self.packed.num, self.D, self.K, self.idx.data_ptr(), self.B,
                                         self.n_batches, cur, n, self.n_tab, self.tables.data_ptr(), err, s), 'cwn_collate_tables')
         for i, (arr, strides) in enumerate(self._descs):

@@ -383,3 +383,35 @@ def test_static_forward_and_train_step_on_the_molhiv_like_configuration():
                 b_.copy_(a)
     csr.check_errors(DEV)
     assert len(st._graphs) == 1
+
+
+def test_the_readme_training_loop():
+    """README.md's eight-line loop as written: a packed dataset, StaticBatch(slots=4), StaticTrainStep, two shuffled epochs of
+    batches of 32 (the last one short, the last replay's spare slots empty): every real batch gives a finite loss, an empty slot
+    NaN and no step; the step counter equals the number of real batches; the parameters move."""
+    from cwn_amd import csr
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    pool, packed = _packed(n=150, n_hi=28)
+    model = _model(64, 2, seed=3)
+    before = [p.detach().clone() for p in model.parameters()]
+    sb = StaticBatch(packed, batch_size=32, slots=4)
+    step = StaticTrainStep(model, sb, lr=1e-3)
+    rng = np.random.default_rng(0)
+    real = 0
+    for epoch in range(2):
+        perm = rng.permutation(len(pool))
+        order = [perm[i:i + 32] for i in range(0, len(perm), 32)]             # 5 batches: 32, 32, 32, 32, 22
+        n_rep = sb.set_epoch(order)
+        assert n_rep == 2                                                     # 4 + 1 (+ 3 empty slots)
+        losses = []
+        for _ in range(n_rep):
+            losses += [float(l) for l in step.step()]
+        assert len(losses) == 8
+        assert all(np.isfinite(l) for l in losses[:5]) and all(np.isnan(l) for l in losses[5:]), losses
+        real += 5
+    torch.cuda.synchronize()
+    csr.check_errors(DEV)
+    assert int(step.opt.t) == real, (int(step.opt.t), real)
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    assert sum(isinstance(k, tuple) for k in step._graphs) == 1          # ONE graph of four steps (+ the one-step graphs of its warm-up)
