@@ -114,14 +114,30 @@ class FlatGradBucket:
         world = self._world(group)
         if world == 1:
             return None
-        w = float(1 if n_local is None else n_local)
+        w = self._weight(n_local)
         self.flat.mul_(w)
-        self._buf[-1] = w
+        self._buf[-1:] = w
         work = dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if async_op:
             return work, world
-        self.flat.div_(self._buf[-1])
+        self._divide()
         return None
+
+    def _weight(self, n_local):
+        """The rank's weight as something `mul_` takes: a float, or -- a static batch, whose sample count lives on the device
+        (cwn_amd/static_graph.py) -- a one-element tensor of the bucket's dtype (no host sync)."""
+        if torch.is_tensor(n_local):
+            return n_local.reshape(1).to(dtype=self._buf.dtype, device=self._buf.device)
+        return float(1 if n_local is None else n_local)
+
+    def _divide(self) -> None:
+        """flat /= the summed weights.  A step in which NO rank held a sample (tensor weights may be 0: the empty tail of a
+        static epoch) leaves the zeros it summed: the divisor is clamped, the optimizer skips that step (global_count())."""
+        self.flat.div_(self._buf[-1].clamp(min=torch.finfo(self._buf.dtype).tiny))
+
+    def global_count(self) -> torch.Tensor:
+        """The summed weights of the last reduction (one element, on the device): the samples of the GLOBAL batch."""
+        return self._buf[-1:]
 
     def finish(self, handle=None):
         """Complete an async all-reduce started with all_reduce_mean(async_op=True), or every chunk
@@ -129,13 +145,13 @@ class FlatGradBucket:
         if handle is not None:
             work, world = handle
             work.wait()
-            self.flat.div_(self._buf[-1])
+            self._divide()
             return
         if self._pending:
             for work in self._pending:
                 work.wait()
             self._pending = []
-            self.flat.div_(self._buf[-1])
+            self._divide()
 
     def reduce_chunk(self, c: int, n_local: Optional[int] = None, group=None) -> None:
         """Start the (asynchronous) weighted all-reduce of chunk c; every rank calls it for c = 0 .. S-1 in
@@ -144,11 +160,11 @@ class FlatGradBucket:
         launched afterwards (the backward of the earlier stages) overlap with it."""
         if self._world(group) == 1:
             return
-        w = float(1 if n_local is None else n_local)
+        w = self._weight(n_local)
         lo, hi = self.chunks[c]
         last = c == len(self.chunks) - 1
         if last:
-            self._buf[-1] = w
+            self._buf[-1:] = w
             # the tail chunk goes with the count element even when it holds no gradient
             t = self._buf[lo:]
             t[:-1].mul_(w)

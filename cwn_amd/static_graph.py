@@ -231,11 +231,12 @@ class StaticTrainStep(TrainStep):
         static.fill()                                 # the buffers hold real batches from here on (warm-up)
         super().__init__(model, [sl.batch for sl in static.slots], task_type=task_type, lr=lr, use_graph=use_graph,
                          optimizer=optimizer, rebuild_plans=False, stages=1)
-        if self.world > 1:
-            raise NotImplementedError('StaticTrainStep: one rank (the data-parallel step is TrainStep)')
+        # (world > 1: step() runs the slots of a fill as TrainStep's per-step graph(forward + backward) -> all-reduce -> graph(Adam);
+        #  the backward is not cut into pieces here -- stages = 1: one collective per step behind the backward)
         # the inputs ARE the static buffers (TrainStep keeps clones: the collate writes through raw pointers)
         self.inputs = [list(sl.inputs) for sl in static.slots]
         self._actives = [static.tables[j, static.o_sizes + 3: static.o_sizes + 4] for j in range(static.S)]
+        self._global_active = torch.ones(1, dtype=torch.int64, device=static.device)
 
     def _forward_backward(self, i: int, pieces=None):
         if i == 0:
@@ -243,9 +244,24 @@ class StaticTrainStep(TrainStep):
         with self.sb.slots[i].dynamic():
             return super()._forward_backward(i, pieces)
 
+    # ---- data parallel: the sample counts live on the device --------------------------------------------------------------------
+    def _n_local(self, i: int):
+        return self._actives[i] if self.world > 1 else self.batches[i].num_complexes
+
+    def _count_at_begin(self) -> bool:
+        return self.world == 1                        # (under data parallelism a step is real iff ANY rank holds a sample)
+
+    def _before_optimizer(self, i: int) -> None:
+        if self.world > 1 and hasattr(self.opt, 'active') and self.opt.active is not None:
+            # the samples of the GLOBAL batch, summed by the all-reduce (no process group -- a forced data-parallel form on
+            # one rank: its own)
+            self._global_active.copy_(self.bucket.global_count() if self.bucket._world(None) > 1 else self._actives[i])
+
     def _eager(self, i: int) -> torch.Tensor:
         if hasattr(self.opt, 'active'):
-            self.opt.active = self._actives[i]        # (FlatAdam: an empty batch's step changes nothing)
+            # FlatAdam: an empty batch's step changes nothing -- empty on EVERY rank under data parallelism (one that holds no
+            # sample itself still takes the step the others take: the parameters stay in step)
+            self.opt.active = self._global_active if self.world > 1 else self._actives[i]
         try:
             return super()._eager(i)
         finally:
@@ -266,6 +282,10 @@ class StaticTrainStep(TrainStep):
         S = self.sb.S
         if S == 1:
             return [super().step(0)]
+        if self.world > 1 or self.staged is not None:
+            # data parallel: no collective is captured (train.TrainStep: graph(forward + backward [pieces]) -> all-reduce ->
+            # graph(Adam) per step), so the S steps of a fill are S replays of those graphs; slot 0's first piece holds the fill
+            return [TrainStep.step(self, j) for j in range(S)]
         key = ('seq',) + tuple(range(S))
         if key not in self._graphs:
             cur = self.sb.cursor.clone()

@@ -214,9 +214,13 @@ class TrainStep:
         # unless the caller trains on a fixed set of batches and says so
         self.rebuild_plans = rebuild_plans
 
+    def _count_at_begin(self) -> bool:
+        """May the step's opening launch advance FlatAdam's counter (it knows whether the step is real)?"""
+        return True
+
     def _begin(self):
         """The bracket of one step (ops.step_arena): gradients zeroed, arena zeroed, FlatAdam's counter advanced."""
-        mine = isinstance(self.opt, FlatAdam)
+        mine = isinstance(self.opt, FlatAdam) and self._count_at_begin()
         if mine:
             self.opt.counted = True
         return ops.step_arena(self.bucket.flat.device, flat=self.bucket.flat, counter=self.opt.t if mine else None,
@@ -337,8 +341,16 @@ class TrainStep:
                 return loss
         return self._live_loss.detach()
 
+    def _n_local(self, i: int):
+        """The samples this rank's loss of step i averages over: its weight in the gradient all-reduce (a static batch hands a
+        device tensor)."""
+        return self.batches[i].num_complexes
+
+    def _before_optimizer(self, i: int) -> None:
+        """Between the (reduced) gradient and the optimizer's step (static_graph.StaticTrainStep: the global sample count)."""
+
     def _eager(self, i: int) -> torch.Tensor:
-        n_local = self.batches[i].num_complexes
+        n_local = self._n_local(i)
         if self.staged is None:
             loss = self._forward_backward(i)
             if self.world > 1:
@@ -348,6 +360,7 @@ class TrainStep:
                 loss = self._forward_backward(i, [j])
                 self.bucket.reduce_chunk(j, n_local)      # overlaps with piece j + 1
             self.bucket.finish()
+        self._before_optimizer(i)
         self.opt.step()
         return loss
 
@@ -388,6 +401,7 @@ class TrainStep:
             pieces.append(g)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
+            self._before_optimizer(i)
             self.opt.step()
         return (pieces, g2, loss)
 
@@ -432,7 +446,7 @@ class TrainStep:
         if g2 is None:
             pieces[0].replay()
             return loss
-        n_local = self.batches[i].num_complexes
+        n_local = self._n_local(i)
         if self.staged is None:
             pieces[0].replay()
             self.bucket.all_reduce_mean(n_local=n_local)   # the ONE collective of the step (RCCL over xGMI)

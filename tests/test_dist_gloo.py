@@ -284,6 +284,56 @@ def test_two_rank_chunked_reduce_inside_the_backward():
     torch.testing.assert_close(flat, ref / wsum, rtol=1e-6, atol=1e-7)
 
 
+def _tensor_count_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from cwn_amd.dist import init_from_env
+    init_from_env('gloo')
+    out = {}
+    for name, counts in (('mixed', [5, 0]), ('none', [0, 0])):
+        net, st, so, bucket, sp = _staged_setup()
+        bucket.zero_()
+        net(torch.tensor([[0, 1, 1, 4], [2, 2, 3, 0]][rank])).backward()
+        n_local = torch.tensor([counts[rank]], dtype=torch.int64)            # a static batch: the count is a (device) tensor
+        bucket.all_reduce_mean(n_local=n_local)
+        out[name] = (bucket.flat.clone(), float(bucket.global_count()))
+        # ... and the chunked form of the staged backward
+        net, st, so, bucket, sp = _staged_setup()
+        bucket.zero_()
+        st.begin()
+        loss = net(torch.tensor([[0, 1, 1, 4], [2, 2, 3, 0]][rank]))
+        for j in range(st.n_stages):
+            st.piece(j, loss, sp[j])
+            bucket.reduce_chunk(j, n_local)
+        bucket.finish()
+        out[name + '_chunked'] = (bucket.flat.clone(), float(bucket.global_count()))
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_reduce_with_device_side_sample_counts():
+    """The sample count of a static batch is a tensor (cwn_amd/static_graph.py: no host sync): all_reduce_mean / reduce_chunk
+    take it as the rank's weight.  A rank WITHOUT samples (the empty tail of its epoch) contributes nothing and receives the
+    other's gradient; a step in which no rank holds a sample leaves zeros (and a global count of 0: the optimizer skips it)."""
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_tensor_count_worker, args=(world, port, ret), nprocs=world, join=True)
+        got = {r: ret[r] for r in range(world)}
+    net, st, so, bucket, sp = _staged_setup()
+    bucket.zero_()
+    net(torch.tensor([0, 1, 1, 4])).backward()                                # rank 0's own gradient
+    want = bucket.flat.clone()
+    for r in range(world):
+        for name in ('mixed', 'mixed_chunked'):
+            flat, cnt = got[r][name]
+            assert cnt == 5.0
+            torch.testing.assert_close(flat, want, rtol=1e-6, atol=1e-7, msg=f'rank {r} {name}')
+        for name in ('none', 'none_chunked'):
+            flat, cnt = got[r][name]
+            assert cnt == 0.0 and float(flat.abs().max()) == 0.0 and bool(torch.isfinite(flat).all()), (r, name)
+
+
 def test_packed_loader_shards_every_global_batch_across_the_ranks():
     """cwn_amd.packed.PackedLoader (the DataLoader of data/data_loading.py:84-111 over the packed dataset): the ranks
     split each global batch, see the same number of batches, cover a split exactly once per epoch, and reshuffle

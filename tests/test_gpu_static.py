@@ -415,3 +415,31 @@ def test_the_readme_training_loop():
     assert int(step.opt.t) == real, (int(step.opt.t), real)
     assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
     assert sum(isinstance(k, tuple) for k in step._graphs) == 1          # ONE graph of four steps (+ the one-step graphs of its warm-up)
+
+
+def test_static_train_step_in_the_data_parallel_form():
+    """world > 1 (forced here on one GPU: the collectives are no-ops without a process group) runs the S steps of a fill as S
+    replays of TrainStep's graph(forward + backward) -> all-reduce -> graph(Adam) form -- nothing is captured around a
+    collective -- and must equal the one-graph form step for step."""
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    pool, p = _packed(n_hi=28)
+    B = 40
+    m1, m2 = _model(128, 2, seed=6), _model(128, 2, seed=6)
+    m2.load_state_dict(m1.state_dict())
+    batches = _batches(len(pool), B, 21, sizes=[B, B, B, 17])
+    sa, sb_ = StaticBatch(p, B, slots=2), StaticBatch(p, B, slots=2)
+    one = StaticTrainStep(m1, sa, lr=1e-3)
+    two = StaticTrainStep(m2, sb_, lr=1e-3)
+    two.world = 2
+    for sb in (sa, sb_):
+        assert sb.set_epoch(batches) == 2
+    for rep in range(2):
+        la, lb = one.step(), two.step()
+        torch.cuda.synchronize()
+        for a, b in zip(la, lb):
+            assert abs(float(a) - float(b)) <= 2e-3 * max(1.0, abs(float(a))), (rep, float(a), float(b))
+    assert two._graphs[0][1] is not None                # the Adam graph of the two-graph form
+    worst = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(m1.parameters(), m2.parameters()))
+    print(f'[static train, data-parallel form] parameters after four steps: max|delta| = {worst:.3e}')
+    assert worst < 2 * 1e-3 * 4 * 1.1, worst           # (four Adam steps: sign flips of noise-level gradients at most)
