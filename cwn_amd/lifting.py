@@ -159,7 +159,7 @@ def _reduce_rows(vx: torch.Tensor, members: torch.Tensor, seg: torch.Tensor, n_s
 
 
 def _pack_dataset(kind: int, graphs, max_k: int, include_down_adj: bool, init_method: str, init_edges: bool,
-                  init_cells2: bool, n_threads: int, device):
+                  init_cells2: bool, n_threads: int, device, with_csr: bool = False):
     """Per-graph objects -> the collated form (one pass over the graphs, the only per-graph Python of the path)."""
     G = len(graphs)
     if G == 0:
@@ -185,13 +185,13 @@ def _pack_dataset(kind: int, graphs, max_k: int, include_down_adj: bool, init_me
                 raise ValueError('y must label the graph (first dimension 1) or every vertex, for every graph alike')
         y_vertex = torch.cat(ys, dim=0)
     return _pack_collated(kind, n, m, torch.cat(eis, dim=1), torch.cat(xs, dim=0), ea, y_graph, y_vertex, max_k,
-                          include_down_adj, init_method, init_edges, init_cells2, n_threads, device)
+                          include_down_adj, init_method, init_edges, init_cells2, n_threads, device, with_csr=with_csr)
 
 
 def _pack_collated(kind: int, n: np.ndarray, m: np.ndarray, edge_index: torch.Tensor, vx: torch.Tensor,
                    ea: Optional[torch.Tensor], y_graph: Optional[torch.Tensor], y_vertex: Optional[torch.Tensor],
                    max_k: int, include_down_adj: bool, init_method: str, init_edges: bool, init_cells2: bool,
-                   n_threads: int, device):
+                   n_threads: int, device, with_csr: bool = False):
     """The dataset in collated form -- vertices per graph `n`, directed edge entries per graph `m`, edge_index
     [2, sum m] with vertex ids LOCAL to each graph (how a PyG InMemoryDataset stores itself), vx [sum n, F],
     ea [sum m, Fe] or None -- lifted by host threads and packed.  No per-graph Python."""
@@ -293,7 +293,7 @@ def _pack_collated(kind: int, n: np.ndarray, m: np.ndarray, edge_index: torch.Te
         if y_graph.size(0) != G:
             raise ValueError('graph labels: one row per graph')
         gy = labels(y_graph, np.ones(G, dtype=np.int64))
-    packed = PackedComplexes.from_arrays(device, 2, dims, n_cells, has_cells, n_up, n_down, keys, gy)
+    packed = PackedComplexes.from_arrays(device, 2, dims, n_cells, has_cells, n_up, n_down, keys, gy, with_csr=with_csr)
     dimension = int(dims.max())
     feats = [w(vx), None if ex is None else w(ex), None if cx2 is None else w(cx2)][:dimension + 1]
     return packed, dimension, feats
@@ -328,23 +328,24 @@ def pack_collated_dataset_with_rings(x: torch.Tensor, edge_index: torch.Tensor, 
 
 def pack_graph_dataset_with_rings(graphs, max_ring_size: int = 7, include_down_adj: bool = False,
                                   init_method: str = 'sum', init_edges: bool = True, init_rings: bool = False,
-                                  n_threads: int = 0, device='cuda'):
+                                  n_threads: int = 0, device='cuda', with_csr: bool = False):
     """The dataset-level counterpart of convert_graph_dataset_with_rings (data/utils.py:501-544; same arguments,
     n_jobs -> n_threads): `graphs` are PyG-Data-like objects or dicts with x [n, F], edge_index [2, M] (both
     directions, as PyG stores them, or one), edge_attr [M, Fe] or None, y, num_nodes.  Returns
     (PackedComplexes on `device`, dimension, num_features): the lifted dataset resident in HBM, ready for
     `collate(indices)`, instead of a Python list of Complex objects -- the graphs are lifted by host threads
     (cwn_lift_many) and every tensor of the dataset is built once, concatenated.  Complex c of the result equals
-    `ring_lift` of graph c (tests/test_lifting.py)."""
+    `ring_lift` of graph c (tests/test_lifting.py).  `with_csr`: also the per-complex CSRs of the boundary adjacencies a
+    static batch collates (cwn_amd/static_batch.py)."""
     return _pack_dataset(RING, graphs, max_ring_size, include_down_adj, init_method, init_edges, init_rings,
-                         n_threads, device)
+                         n_threads, device, with_csr=with_csr)
 
 
 def pack_graph_dataset_with_cliques(graphs, expansion_dim: int = 2, include_down_adj: bool = True,
-                                    init_method: str = 'sum', n_threads: int = 0, device='cuda'):
+                                    init_method: str = 'sum', n_threads: int = 0, device='cuda', with_csr: bool = False):
     """convert_graph_dataset_with_gudhi (data/utils.py:275-297) for expansion_dim <= 2, packed like
     pack_graph_dataset_with_rings; higher cells take the reduce of their vertices' features (:141-155)."""
     if expansion_dim > 2:
         raise NotImplementedError('clique lift up to dimension 2')
     kind = CLIQUE if expansion_dim >= 2 else RING
-    return _pack_dataset(kind, graphs, 0, include_down_adj, init_method, True, True, n_threads, device)
+    return _pack_dataset(kind, graphs, 0, include_down_adj, init_method, True, True, n_threads, device, with_csr=with_csr)

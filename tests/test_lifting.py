@@ -275,6 +275,11 @@ def test_dataset_ring_lift_packs_what_the_per_graph_lift_packs():
                 init_rings=init_rings, n_threads=threads, device='cpu')
             _same_packed(got, want)
             assert dimension == 2 and feats[0] == 1
+        # ... and with the per-complex CSRs of the boundary adjacencies a static batch collates (round 4)
+        got_csr, _, _ = lifting.pack_graph_dataset_with_rings(
+            graphs, max_ring_size=6, include_down_adj=down, init_method='sum', init_edges=True, init_rings=init_rings,
+            n_threads=2, device='cpu', with_csr=True)
+        _same_packed(got_csr, PackedComplexes(ref, 'cpu', max_dim=2, with_csr=True))
         # the same dataset handed over the way a PyG InMemoryDataset stores itself (data + slices)
         sl = dict(x=np.concatenate([[0], np.cumsum([g['num_nodes'] for g in graphs])]),
                   edge_index=np.concatenate([[0], np.cumsum([g['edge_index'].size(1) for g in graphs])]),
