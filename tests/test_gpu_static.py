@@ -443,3 +443,51 @@ def test_static_train_step_in_the_data_parallel_form():
     worst = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(m1.parameters(), m2.parameters()))
     print(f'[static train, data-parallel form] parameters after four steps: max|delta| = {worst:.3e}')
     assert worst < 2 * 1e-3 * 4 * 1.1, worst           # (four Adam steps: sign flips of noise-level gradients at most)
+
+
+def test_from_graphs_to_static_training_steps_without_per_complex_objects():
+    """data/utils.py:501-544 + data/data_loading.py:84-111 + exp/train_utils.py:57-75 end to end on the device path: PyG-like
+    graphs are ring-lifted by host threads straight into the packed dataset (with the per-complex CSRs), PackedLoader shuffles
+    index lists, StaticTrainStep cuts the batches and steps -- against TrainStep on the collated batches of the same lists."""
+    from cwn_amd import csr, lifting
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.packed import PackedLoader
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    from cwn_amd.train import TrainStep
+    from tests.test_lifting import _pyg_like, random_molecule
+    rng = np.random.default_rng(4)
+    graphs = []
+    for i in range(96):
+        n, bonds = random_molecule(rng, 8, 26)
+        g, _ = _pyg_like(rng, n, bonds, with_attr=True, long_x=False)
+        g['x'] = torch.from_numpy(rng.integers(0, 28, size=(n, 1))).float()               # atom types
+        g['y'] = torch.randn(1, 1, generator=torch.Generator().manual_seed(i))           # (edge_attr: bond types 0 .. 3)
+        graphs.append(g)
+    packed, dimension, feats = lifting.pack_graph_dataset_with_rings(graphs, max_ring_size=6, init_edges=True, init_rings=False,
+                                                                     n_threads=2, device=DEV, with_csr=True)
+    assert dimension == 2
+
+    def make():
+        torch.manual_seed(9)
+        return EmbedSparseCIN(28, 4, 1, 2, 64, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu', readout='sum',
+                              train_eps=False, final_hidden_multiplier=2, final_readout='sum', init_reduce='sum',
+                              embed_edge=True, use_coboundaries=True, graph_norm='bn').to(DEV)
+    loader = PackedLoader(packed, batch_size=24, shuffle=True, seed=5)
+    loader.set_epoch(0)
+    batches = loader.batches()
+    assert len(batches) == 4
+    sb = StaticBatch(packed, 24, slots=2)
+    assert sb.fits(batches).all()
+    m1, m2 = make(), make()
+    st = StaticTrainStep(m1, sb, lr=1e-3)
+    ref = TrainStep(m2, [packed.collate(idx) for idx in batches[:2]], lr=1e-3, use_graph=False)
+    assert sb.set_epoch(batches) == 2
+    losses = [float(l) for l in st.step()]
+    want = [float(ref.step(0)), float(ref.step(1))]
+    torch.cuda.synchronize()
+    assert abs(losses[0] - want[0]) <= 1e-5 * max(1.0, abs(want[0])), (losses, want)
+    assert abs(losses[1] - want[1]) <= 2e-3 * max(1.0, abs(want[1])), (losses, want)       # (one Adam step apart already)
+    more = [float(l) for l in st.step()]
+    assert all(np.isfinite(l) for l in more)
+    csr.check_errors(DEV)
