@@ -584,10 +584,11 @@ namespace {
 
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pred, const float* __restrict__ y, int64_t n_cap,
                                                    int kind, float* __restrict__ loss, float* __restrict__ grad,
-                                                   const int64_t* __restrict__ n_dev) {
+                                                   const int64_t* __restrict__ n_dev, int64_t cols) {
     __shared__ float part[256];
     __shared__ int cnt[256];
-    const int64_t n = n_dev != nullptr ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap;
+    // (a static batch: *n_dev complexes with `cols` predictions each are real, the rest of the n_cap elements is capacity)
+    const int64_t n = n_dev != nullptr ? (*n_dev * cols < n_cap ? *n_dev * cols : n_cap) : n_cap;
     // null labels (exp/train_utils.py:64-66: `mask = ~torch.isnan(targets)`; ogbg-mol* tasks): not in the mean, no gradient
     int valid = 0;
     for (int64_t i = threadIdx.x; i < n; i += 256) valid += (y[i] == y[i]) ? 1 : 0;
@@ -628,12 +629,18 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pre
 
 }  // namespace
 
+extern "C" int cwn_loss_cols_f32(int32_t kind, const float* pred, const float* y, int64_t n, int64_t cols, float* loss, float* grad,
+                                 const int64_t* n_dev, cwn_stream_t stream_) {
+    if (kind < 0 || kind > CWN_LOSS_BCE_LOGITS || n <= 0 || cols <= 0 || n % cols != 0 || pred == nullptr || y == nullptr ||
+        loss == nullptr || grad == nullptr)
+        return CWN_ERR_BAD_ARG;
+    loss_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)stream_>>>(pred, y, n, kind, loss, grad, n_dev, cols);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
 extern "C" int cwn_loss_f32(int32_t kind, const float* pred, const float* y, int64_t n, float* loss, float* grad,
                             const int64_t* n_dev, cwn_stream_t stream_) {
-    if (kind < 0 || kind > CWN_LOSS_BCE_LOGITS || n <= 0 || pred == nullptr || y == nullptr || loss == nullptr || grad == nullptr)
-        return CWN_ERR_BAD_ARG;
-    loss_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)stream_>>>(pred, y, n, kind, loss, grad, n_dev);
-    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+    return cwn_loss_cols_f32(kind, pred, y, n, 1, loss, grad, n_dev, stream_);
 }
 
 // ---- embedding backward: dW[v, :] += sum over the cells that looked row v up of g[cell, :] ----------

@@ -49,10 +49,9 @@ class _FusedMeanLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         grad = torch.empty_like(p)
         n_dev = _ffi.dyn(p.size(0)) if p.dim() >= 1 else None          # a static batch: the complexes that exist (device int64)
-        if n_dev is not None and p.numel() != p.size(0):
-            raise NotImplementedError('fused loss over a static batch: one prediction per complex')
-        _ffi.check(_ffi.lib().cwn_loss_f32(kind, p.data_ptr(), y.contiguous().data_ptr(), p.numel(), loss.data_ptr(),
-                                           grad.data_ptr(), n_dev, _ffi.stream_ptr(p.device)), 'cwn_loss_f32')
+        cols = p.numel() // p.size(0) if (p.dim() >= 1 and p.size(0) > 0) else 1         # (multi-task heads: [complexes, tasks])
+        _ffi.check(_ffi.lib().cwn_loss_cols_f32(kind, p.data_ptr(), y.contiguous().data_ptr(), p.numel(), cols, loss.data_ptr(),
+                                                grad.data_ptr(), n_dev, _ffi.stream_ptr(p.device)), 'cwn_loss_cols_f32')
         ctx.save_for_backward(grad)
         return loss
 

@@ -1080,6 +1080,10 @@ enum { CWN_LOSS_L1 = 0, CWN_LOSS_MSE = 1, CWN_LOSS_BCE_LOGITS = 2 };
  * no gradient and does not count in the mean. */
 int cwn_loss_f32(int32_t kind, const float* pred, const float* y, int64_t n, float* loss, float* grad,
                  const int64_t* n_dev, cwn_stream_t stream);
+/* ... with `cols` predictions per complex (the multi-task ogbg-mol* heads: [complexes, tasks] row-major, n = capacity x cols):
+ * *n_dev counts COMPLEXES, so the first *n_dev * cols elements are real. */
+int cwn_loss_cols_f32(int32_t kind, const float* pred, const float* y, int64_t n, int64_t cols, float* loss, float* grad,
+                      const int64_t* n_dev, cwn_stream_t stream);
 
 /* The start of a training step in ONE launch (optimizer.zero_grad() of exp/train_utils.py:61 + what the step's own kernels
  * need zero on entry + the optimizer's step counter): a[0 .. a_bytes) = 0 (the flat gradient buffer), b[0 .. b_bytes) = 0 (the

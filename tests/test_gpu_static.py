@@ -491,3 +491,50 @@ def test_from_graphs_to_static_training_steps_without_per_complex_objects():
     more = [float(l) for l in st.step()]
     assert all(np.isfinite(l) for l in more)
     csr.check_errors(DEV)
+
+
+def test_static_train_step_on_a_multi_task_head_with_null_labels():
+    """ogbg-mol* style: 12 binary tasks per molecule, ~30 % of the labels missing (NaN) -- exp/train_utils.py:62-73 masks them
+    out of BCEWithLogits.  The captured static step (cwn_loss_cols_f32: *n_dev complexes x 12 columns are real) against the
+    per-batch eager step on two unseen batches, one of them short."""
+    from cwn_amd import csr
+    from cwn_amd.models import OGBEmbedSparseCIN
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    from cwn_amd.synthetic import molhiv_like_complexes
+    from cwn_amd.train import TrainStep
+    T = 12
+    pool = molhiv_like_complexes(90, 11, 6, n_hi=40)
+    g = torch.Generator().manual_seed(2)
+    for c in pool:
+        y = (torch.rand(1, T, generator=g) > 0.5).float()
+        y[torch.rand(1, T, generator=g) < 0.3] = float('nan')
+        c.y = y
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+
+    def make():
+        torch.manual_seed(5)
+        return OGBEmbedSparseCIN(T, 2, 64, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum', init_reduce='sum',
+                                 embed_edge=True, use_coboundaries=True, graph_norm='bn').to(DEV)
+    B = 32
+    batches = _batches(len(pool), B, 8, sizes=[B, 19])
+    m1, m2 = make(), make()
+    m2.load_state_dict(m1.state_dict())
+    sb = StaticBatch(p, B)
+    sb.set_batch(batches[0])
+    st = StaticTrainStep(m1, sb, task_type='bin_classification', lr=1e-3)
+    ref = TrainStep(m2, [p.collate(idx) for idx in batches], task_type='bin_classification', lr=1e-3, use_graph=False)
+    for j, idx in enumerate(batches):
+        l1 = st.step_on([idx])[0].clone()
+        l2 = ref.step(j)
+        torch.cuda.synchronize()
+        assert np.isfinite(float(l2)) and abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l2))), (j, float(l1), float(l2))
+        rel = float((st.bucket.flat - ref.bucket.flat).norm() / ref.bucket.flat.norm())
+        assert rel < 2e-5, (j, rel)
+        ref.opt.flat_p.copy_(st.opt.flat_p)
+        ref.opt.exp_avg.copy_(st.opt.exp_avg)
+        ref.opt.exp_avg_sq.copy_(st.opt.exp_avg_sq)
+        for (_, a), (_, b_) in zip(m1.named_buffers(), m2.named_buffers()):
+            b_.copy_(a)
+    csr.check_errors(DEV)
