@@ -244,6 +244,20 @@ class StaticTrainStep(TrainStep):
         with self.sb.slots[i].dynamic():
             return super()._forward_backward(i, pieces)
 
+    def _loss(self, b) -> torch.Tensor:
+        """The criterion over the complexes that EXIST: only the fused form knows the device-side count (a framework criterion
+        would average over the capacity rows of a short batch) -- anything else is refused, loudly."""
+        from .train import fused_loss
+        pred = self.model(b)
+        if self.task_type == 'classification':
+            raise NotImplementedError('StaticTrainStep: the cross-entropy criterion is not restated for static batches '
+                                      '(regression / mse_regression / bin_classification are): use TrainStep on collated batches')
+        loss = fused_loss(self.task_type, pred, b.y.view(pred.shape).to(pred.dtype))
+        if loss is None:
+            raise NotImplementedError('StaticTrainStep: predictions / targets the fused criterion does not take (float32 CUDA '
+                                      'tensors of one shape)')
+        return loss
+
     # ---- data parallel: the sample counts live on the device --------------------------------------------------------------------
     def _n_local(self, i: int):
         return self._actives[i] if self.world > 1 else self.batches[i].num_complexes
