@@ -538,3 +538,15 @@ def test_static_train_step_on_a_multi_task_head_with_null_labels():
         for (_, a), (_, b_) in zip(m1.named_buffers(), m2.named_buffers()):
             b_.copy_(a)
     csr.check_errors(DEV)
+
+
+def test_the_example_script_runs():
+    """examples/train_shuffled_epochs.py (the reference's loop end to end on the device path) at a small size."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pr = subprocess.run([sys.executable, os.path.join(root, 'examples', 'train_shuffled_epochs.py'), '384', '2'],
+                        capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    assert 'held-out MAE' in pr.stdout and 'epoch 1:' in pr.stdout, pr.stdout[-2000:]
