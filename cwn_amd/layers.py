@@ -29,7 +29,7 @@ from torch.nn import BatchNorm1d as BN, Linear, ReLU, Sequential
 
 from . import ops
 from .cell_mp import CochainMessagePassing, CochainMessagePassingParams, IndexedRows, dense
-from .csr import Adjacency
+from .csr import Adjacency, cached_adjacency
 
 
 def reset(nn):
@@ -609,7 +609,7 @@ class SparseCINCochainConv(CochainMessagePassing):
                               eps=eps, reduce=self.aggr_up or 'add')
         if kind == 'cat_linear_relu' and up_attr is not None and (self.aggr_up or 'add') == 'add':
             if ys is None:
-                specs = self.gemm_specs(CochainMessagePassingParams(x, adj, up_attr=up_attr))
+                specs = SparseCINCochainConv.gemm_specs(self, CochainMessagePassingParams(x, adj, up_attr=up_attr))
                 if not specs:
                     return None
                 ys = ops.gemm_many(specs)
@@ -620,6 +620,9 @@ class SparseCINCochainConv(CochainMessagePassing):
 
     def _boundary_fusable(self) -> bool:
         return isinstance(self.msg_boundaries_nn, Passthrough)
+
+    def _boundary_eps(self):
+        return self.eps2          # mp/layers.py:192 (CIN++ numbers its three eps differently, :252-254)
 
     def message_and_aggregate_up(self, up_adj_t: Adjacency, x, up_attr) -> Tensor:
         st = self._up_stream(up_adj_t, x, up_attr)
@@ -661,9 +664,9 @@ class SparseCINCochainConv(CochainMessagePassing):
             size = self.__check_input_separately__(cochain.boundary_index, None)
             adj = self._adjacency(cochain.boundary_index, 'boundary', size, kw)
             bnd = ops.Stream(adj=adj, n_dst=n, width=int(b_attr.size(1)), A=b_attr, self_x=x,
-                             eps=self.eps2, reduce=self.aggr_boundary or 'add')
+                             eps=self._boundary_eps(), reduce=self.aggr_boundary or 'add')
         else:
-            bnd = ops.Stream(adj=None, n_dst=n, width=int(x.size(1)), self_x=x, eps=self.eps2)
+            bnd = ops.Stream(adj=None, n_dst=n, width=int(x.size(1)), self_x=x, eps=self._boundary_eps())
         if up.width != x.size(1) or bnd.width != x.size(1):
             return None   # self term needs message width == feature width
         return [up, bnd]
@@ -1156,13 +1159,97 @@ class CINppCochainConv(SparseCINCochainConv):
     def message_down(self, down_x_j: Tensor, down_attr: Tensor) -> Tensor:
         return self.msg_down_nn((down_x_j, down_attr))
 
+    # ---- fused forms (round 4): every stream of the level in the layer's ONE aggregation launch --
+    def _boundary_eps(self):
+        return self.eps3          # mp/layers.py:254
+
+    def _down_kind(self) -> str:
+        if isinstance(self.msg_down_nn, FirstOf):
+            return 'first'
+        return 'cat_linear_relu' if _is_cat_linear_relu(self.msg_down_nn) else 'custom'
+
+    def _down_active(self, cochain) -> bool:
+        return bool(self.use_down_msg) and cochain.down_index is not None
+
+    def _down_specs(self, cochain) -> List[ops.Gemm]:
+        """The lower-adjacency message ReLU(Linear(cat(x_j, down_attr))) as Y1[j] + Y2[shared boundary] (the form of the
+        coboundary message, SparseCINCochainConv.gemm_specs); [] when the lower stream is off (the reference's quirk, the
+        default) or its network is another form."""
+        x, attr = cochain.x, cochain.kwargs.get('down_attr')
+        if (not self._down_active(cochain) or attr is None or self._down_kind() != 'cat_linear_relu'
+                or (self.aggr_down or 'add') != 'add'):
+            return []
+        lin, F = self.msg_down_nn[1], x.size(1)
+        src, _ = _attr_operand(attr)
+        if lin.in_features != F + src.size(1) or max(F, src.size(1)) > ops.GEMM_MAX_K:
+            return []
+        return [ops.Gemm(X=x, W=lin.weight, w_col0=0, bias=lin.bias), ops.Gemm(X=src, W=lin.weight, w_col0=F)]
+
     def gemm_specs(self, cochain):
-        return []            # three streams: runs through propagate() (fused hooks + generic lower)
+        return SparseCINCochainConv.gemm_specs(self, cochain) + self._down_specs(cochain)
 
     def streams(self, cochain, ys=None):
-        return None
+        """[upper, lower, boundary (, co-boundary)] with the self terms folded in -- (1 + eps1 / eps2 / eps3 / eps4) x,
+        mp/layers.py:252-254 -- or None when a message network is not a recognised form (the caller then runs
+        `forward_unfused`).  The lower stream of the default layer is its self term alone (the quirk: zeros + (1+eps2) x)."""
+        n_up = len(SparseCINCochainConv.gemm_specs(self, cochain)) if ys else 0
+        base = SparseCINCochainConv.streams(self, cochain, (list(ys[:n_up]) or None) if ys else None)
+        if base is None:
+            return None
+        up, bnd = base
+        x = cochain.x
+        n, F = x.size(0), int(x.size(1))
+        if self._down_active(cochain):
+            attr = cochain.kwargs.get('down_attr') if self.feed_down_attr else None
+            size = self.__check_input_separately__(cochain.down_index, None)
+            adj = self._adjacency(cochain.down_index, 'down', size, dict(x=x, down_attr=attr))
+            kind = self._down_kind()
+            if kind == 'first':
+                down = ops.Stream(adj=adj, n_dst=adj.n_dst, width=F, A=x, self_x=x, eps=self.eps2,
+                                  reduce=self.aggr_down or 'add')
+            elif kind == 'cat_linear_relu' and attr is not None and (self.aggr_down or 'add') == 'add':
+                yd = list(ys[n_up:]) if ys else []
+                if not yd:
+                    specs = self._down_specs(cochain)
+                    if not specs:
+                        return None
+                    yd = ops.gemm_many(specs)
+                _, mode = _attr_operand(attr)
+                down = ops.Stream(adj=adj, n_dst=adj.n_dst, width=int(yd[0].size(1)), A=yd[0], B=yd[1],
+                                  msg_op=ops.MSG_RELU_A_PLUS_B, ib_mode=mode, self_x=x, eps=self.eps2)
+            else:
+                return None
+        else:
+            down = ops.Stream(adj=None, n_dst=n, width=F, self_x=x, eps=self.eps2)
+        out = [up, down, bnd]
+        if self.update_coboundaries_nn is not None:
+            cob_index, cob_attr = getattr(cochain, 'coboundary_index', None), getattr(cochain, 'coboundary_attr', None)
+            if cob_index is not None and cob_attr is not None:
+                if cob_attr.dim() != 2 or cob_index.dim() != 2 or cob_index.size(0) != 2:
+                    return None          # (propagate_coboundary raises the errors)
+                t = cached_adjacency(cob_index, int(cob_attr.size(0)), int(n)).t_src     # keyed on this dimension's cell
+                out.append(ops.Stream(adj=t, n_dst=n, width=int(cob_attr.size(1)), A=cob_attr, self_x=x, eps=self.eps4))
+            else:
+                out.append(ops.Stream(adj=None, n_dst=n, width=F, self_x=x, eps=self.eps4))
+        if any(st.width != F for st in out):
+            return None
+        return out
+
+    def finish(self, out_up: Tensor, out_down: Tensor, out_boundaries: Tensor, out_cob: Optional[Tensor] = None) -> Tensor:
+        """mp/layers.py:255-260 (+ the fourth stream)."""
+        parts = [self.update_up_nn(out_up), self.update_down_nn(out_down), self.update_boundaries_nn(out_boundaries)]
+        if self.update_coboundaries_nn is not None:
+            parts.append(self.update_coboundaries_nn(out_cob))
+        return self.combine_nn(torch.cat(parts, dim=-1))
 
     def forward(self, cochain: CochainMessagePassingParams):
+        sts = self.streams(cochain)
+        if sts is None:
+            return self.forward_unfused(cochain)
+        return self.finish(*ops.aggregate_many(sts))
+
+    def forward_unfused(self, cochain: CochainMessagePassingParams):
+        """The reference's own sequence (mp/layers.py:243-260) through propagate() and the hooks."""
         kw = dict(x=cochain.x, up_attr=cochain.kwargs['up_attr'], boundary_attr=cochain.kwargs['boundary_attr'])
         down_index = cochain.down_index
         if self.feed_down_attr:
@@ -1181,8 +1268,6 @@ class CINppCochainConv(SparseCINCochainConv):
                 out_cob = ops.zeros_rows(cochain.x.size(0), cochain.x.size(1), cochain.x.device)
             parts.append(self.update_coboundaries_nn(out_cob + (1 + self.eps4) * cochain.x))
         return self.combine_nn(torch.cat(parts, dim=-1))
-
-    forward_unfused = forward
 
 
 class CINppConv(SparseCINConv):
@@ -1216,6 +1301,39 @@ class CINppConv(SparseCINConv):
                 combine_nn=Sequential(Linear(hid * n_streams, hid), graph_norm(hid), act()),
                 eps=eps, train_eps=train_eps, feed_down_attr=feed_down_attr,
                 update_coboundaries_nn=_update_mlp(ld, hid, graph_norm, act) if coboundary_stream else None))
+
+    # The blocked layer kernel and the grouped update / combine launches are built for SparseCINConv's two streams
+    # (upper + boundary, a 2F-wide combine): CIN++ takes the grouped message GEMM + ONE aggregation launch for the
+    # three (four) streams of all dimensions -- one autograd node in training (ops.gemm_aggregate) -- and its update /
+    # combine networks as torch modules.
+    def _propagate_blocked(self, cochain_params, start_to_process):
+        self.blocked_reason = 'CIN++: three streams per dimension (the blocked kernel has two)'
+        return None
+
+    def _propagate_blocked_train(self, cochain_params, start_to_process, specs, owner):
+        return None
+
+    def _dense_eval(self, plans, outs, start: int = 0):
+        return None
+
+    def _dense_train(self, plans, outs, start: int = 0):
+        return None
+
+    def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0):
+        """mp/layers.py:418-427."""
+        assert len(cochain_params) <= self.max_dim + 1
+        plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
+        out, k = [], 0
+        for dim, cochain in enumerate(cochain_params):
+            if dim < start_to_process:
+                out.append(cochain.x)
+            elif plans[dim] is None:
+                out.append(self.mp_levels[dim].forward_unfused(cochain))
+            else:
+                m = len(plans[dim])
+                out.append(self.mp_levels[dim].finish(*outs[k:k + m]))
+                k += m
+        return out
 
 
 # ------------------------------------------------------------------------------------------------

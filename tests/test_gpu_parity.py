@@ -2459,6 +2459,72 @@ def test_cinpp_with_a_real_lower_stream_and_coboundary_stream():
     assert params[2].coboundary_index is None        # nothing above the top dimension
 
 
+@pytest.mark.parametrize('proper', [False, True])
+@pytest.mark.parametrize('F', [8, 64])
+def test_cinpp_fused_streams_match_the_hook_path(F, proper):
+    """CINppConv's three streams (four with coboundary_stream) of ALL dimensions -- the coboundary and
+    the lower message as ReLU(Y1[j] + Y2[shared cell]), the self terms (1 + eps1 / eps2 / eps3 / eps4) x folded in -- in
+    one grouped GEMM + ONE aggregation launch, one autograd node in training, against the reference's own sequence
+    (`forward_unfused`: propagate() + the message hooks, mp/layers.py:243-260): outputs, input and parameter gradients,
+    eval and training mode.  Width 64 on a batch that carries its per-complex tables is the case SparseCINConv's blocked
+    two-stream kernel would otherwise claim."""
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.layers import CINppConv
+    from cwn_amd.synthetic import zinc_like_complexes
+    torch.manual_seed(3)
+    if proper:           # the reference's test complexes: they carry lower adjacencies and shared boundaries
+        b = dummy_batch(list_names('mol') + list_names('mol'), max_dim=2, device=DEV)
+    else:
+        b = ComplexBatch.from_complex_list(zinc_like_complexes(12, 5, 6), max_dim=2).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    conv = CINppConv(F, F, F, None, None, None, None, None, None, max_dim=2, hidden=F, act_module=torch.nn.ReLU,
+                     layer_dim=F, use_coboundaries=True, train_eps=True, feed_down_attr=proper,
+                     coboundary_stream=proper).to(DEV)
+    with torch.no_grad():
+        for k, lvl in enumerate(conv.mp_levels):             # distinct eps per stream: a mix-up shows
+            for j, name in enumerate(('eps1', 'eps2', 'eps3') + (('eps4',) if proper else ())):
+                getattr(lvl, name).fill_(0.1 * (j + 1) + 0.01 * k)
+    xs = [torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV) for d in range(3)]
+    ws = [torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV) for d in range(3)]
+
+    def run(fused, train):
+        conv.train(train)
+        conv.zero_grad(set_to_none=True)
+        for d in range(3):
+            b.cochains[d].x = xs[d].clone().requires_grad_(True)
+        params = b.get_all_cochain_params(max_dim=2, include_down_features=proper)
+        outs = conv(*params) if fused else [conv.mp_levels[d].forward_unfused(params[d]) for d in range(3)]
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        return ([o.detach() for o in outs], [b.cochains[d].x.grad for d in range(3)],
+                {n: p.grad.clone() for n, p in conv.named_parameters() if p.grad is not None})
+
+    def close(a, r, what):
+        tol = 2e-5 * max(1.0, float(r.abs().max()))
+        assert float((a - r).abs().max()) <= tol, (what, float((a - r).abs().max()), tol)
+
+    for train in (False, True):
+        if train:
+            for m in conv.modules():                          # both runs start from the same running statistics
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.reset_running_stats()
+        o1, gx1, gp1 = run(True, train)
+        assert conv.blocked_reason is None or 'CIN++' in conv.blocked_reason
+        o0, gx0, gp0 = run(False, train)
+        for d in range(3):
+            close(o1[d], o0[d], f'output dim {d} train={train}')
+            close(gx1[d], gx0[d], f'input gradient dim {d} train={train}')
+        assert set(gp1) == set(gp0)
+        for n in gp0:
+            close(gp1[n], gp0[n], f'gradient of {n} train={train}')
+    # the lower stream of the proper form is live; the quirk's is the self term alone
+    lvl = conv.mp_levels[1]
+    params = b.get_all_cochain_params(max_dim=2, include_down_features=proper)
+    with torch.no_grad():
+        sts = lvl.streams(params[1])
+    assert sts is not None and len(sts) == (4 if proper else 3)
+    assert (sts[1].adj is not None) == proper
+
+
 @pytest.mark.parametrize('world,with_train', [(2, False), (8, True)])
 def test_bench_multi_rank_control_flow_on_one_gpu(tmp_path, world, with_train):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per
