@@ -106,21 +106,27 @@ def _norm_desc(z: Tensor, *, dy: Optional[Tensor] = None, out: Optional[Tensor] 
 
 class _Plan:
     """Static description of one layer's dense networks: per dimension, `depth` update stages for
-    each of the two branches and one combine stage."""
+    each of the branches (SparseCINConv: two, upper and boundary) and one combine stage over the K-concatenation of the
+    two.  `chains` (round 4, CINppConv): any number of branches per dimension and NO combine stage -- the Function then
+    returns every branch's activated output and the caller concatenates and combines them."""
 
-    def __init__(self, up: List[List[Stage]], bd: List[List[Stage]], cb: List[Stage]):
-        self.up, self.bd, self.cb = up, bd, cb
-        self.nd = len(cb)
-        self.depth = len(up[0])
+    def __init__(self, up: Optional[List[List[Stage]]], bd: Optional[List[List[Stage]]], cb: Optional[List[Stage]],
+                 chains: Optional[List[List[List[Stage]]]] = None):
+        self.chains = chains if chains is not None else [[u, b] for u, b in zip(up, bd)]     # [dim][branch] -> stages
+        self.cb = cb
+        assert cb is None or all(len(c) == 2 for c in self.chains)
+        self.nd = len(self.chains)
+        self.nb = len(self.chains[0])
+        self.depth = len(self.chains[0][0])
 
     def stages(self):
         """Every stage in the flattening order of the Function's tensor arguments."""
         for i in range(self.nd):
-            for st in self.up[i]:
-                yield st
-            for st in self.bd[i]:
-                yield st
-            yield self.cb[i]
+            for chain in self.chains[i]:
+                for st in chain:
+                    yield st
+            if self.cb is not None:
+                yield self.cb[i]
 
 
 def _stage_tensors(st: Stage) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
@@ -130,32 +136,32 @@ def _stage_tensors(st: Stage) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor
 
 class _DenseTrain(torch.autograd.Function):
     """tensors = [out_up_0, out_bd_0, ..., out_up_{nd-1}, out_bd_{nd-1}] + 4 per stage (W, b, gamma,
-    beta) in _Plan.stages() order.  Returns H_0 .. H_{nd-1}."""
+    beta) in _Plan.stages() order.  Returns H_0 .. H_{nd-1} (a plan without combine stages: the activated output of
+    every branch, [dim][branch] flattened)."""
 
     @staticmethod
     def forward(ctx, plan: _Plan, *tensors):
-        nd, depth = plan.nd, plan.depth
+        nd, depth, nb = plan.nd, plan.depth, plan.nb
         dev = tensors[0].device
-        A0 = [[ops._rowmajor(tensors[2 * i], 'out_up'), ops._rowmajor(tensors[2 * i + 1], 'out_boundaries')]
-              for i in range(nd)]
+        A0 = [[ops._rowmajor(tensors[nb * i + br], 'stream output') for br in range(nb)] for i in range(nd)]
         stages = list(plan.stages())
-        par = tensors[2 * nd:]
+        par = tensors[nb * nd:]
         P = {id(st): par[4 * k: 4 * k + 4] for k, st in enumerate(stages)}
         bns = [st for st in stages if st.is_bn]
         # one fp64 buffer for all batch statistics (per-band partials written by the GEMM
         # epilogue: nothing to zero), one fp32 buffer for all affines
         rows_of = {}
         for i in range(nd):
-            for st in plan.up[i] + plan.bd[i] + [plan.cb[i]]:
+            for st in [t for chain in plan.chains[i] for t in chain] + ([plan.cb[i]] if plan.cb is not None else []):
                 rows_of[id(st)] = ops.stat_rows(A0[i][0].size(0))
         widths = [st.lin.out_features for st in bns]
         F0 = int(A0[0][0].size(1))
-        live = bool(LIVE_BN and ops.STAGE_KERNEL and bns and len(bns) == len(stages) and F0 in (64, 128) and 2 * nd <= _ffi.MAX_DESCS
+        live = bool(LIVE_BN and ops.STAGE_KERNEL and bns and len(bns) == len(stages) and F0 in (64, 128) and nb * nd <= _ffi.MAX_DESCS
                     and all(a.size(1) == F0 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 for pair in A0 for a in pair)
                     and all(tuple(P[id(st)][0].shape) == (F0, F0) and ops.packed_stage_block(P[id(st)][0], 0) is not None
-                            for i in range(nd) for st in plan.up[i] + plan.bd[i])
+                            for i in range(nd) for chain in plan.chains[i] for st in chain)
                     and all(tuple(P[id(st)][0].shape) == (F0, 2 * F0) and ops.packed_stage_block(P[id(st)][0], 0) is not None
-                            and ops.packed_stage_block(P[id(st)][0], F0) is not None for st in plan.cb)
+                            and ops.packed_stage_block(P[id(st)][0], F0) is not None for st in (plan.cb or []))
                     and all(t is None or (t.numel() == F0 and t.data_ptr() % 16 == 0 and t.is_contiguous())
                             for st in stages for t in P[id(st)][1:]))
         affs = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
@@ -163,7 +169,7 @@ class _DenseTrain(torch.autograd.Function):
         if live:
             # slot sums (fp64) and the backward's s1 / s2 (fp32) of every BatchNorm: ONE zeroed region (the step arena's, when a
             # step driver brackets the step: no fill of their own)
-            nb, nw = len(bns), sum(widths)
+            nw = sum(widths)
             zero = ops.zeros_scratch(8 * _ffi.BN_SLOTS * 2 * nw + 4 * 2 * nw, dev)
             slots = zero[:8 * _ffi.BN_SLOTS * 2 * nw].view(torch.float64)
             sums = zero[8 * _ffi.BN_SLOTS * 2 * nw: 8 * _ffi.BN_SLOTS * 2 * nw + 4 * 2 * nw].view(torch.float32)
@@ -230,11 +236,11 @@ class _DenseTrain(torch.autograd.Function):
                 res = ops.run_gemm(gemms, dev)
             return res
 
-        Z = [[[None] * depth, [None] * depth] for _ in range(nd)]   # Z[dim][branch][stage]
+        Z = [[[None] * depth for _ in range(nb)] for _ in range(nd)]   # Z[dim][branch][stage]
         for s in range(depth):
             gemms, group = [], []
             for i in range(nd):
-                for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
+                for br, chain in enumerate(plan.chains[i]):
                     st = chain[s]
                     W, b, _, _ = P[id(st)]
                     X = A0[i][br] if s == 0 else Z[i][br][s - 1]
@@ -247,38 +253,45 @@ class _DenseTrain(torch.autograd.Function):
             res = run(gemms)
             k = 0
             for i in range(nd):
-                for br in (0, 1):
+                for br in range(nb):
                     Z[i][br][s] = res[k]
                     k += 1
             finalize(group)
-        gemms, group = [], []
-        for i in range(nd):
-            st = plan.cb[i]
-            W, b, _, _ = P[id(st)]
-            sc, sh = prologue(plan.up[i][-1])
-            sc2, sh2 = prologue(plan.bd[i][-1])
-            gemms.append(ops.Gemm(X=Z[i][0][-1], X2=Z[i][1][-1], W=W, bias=b, in_scale=sc, in_shift=sh,
-                                  in_scale2=sc2, in_shift2=sh2, in_relu=3, col_stats=stat_of.get(id(st)),
-                                  stat_slots=slot_of.get(id(st)), in_bn=live_record(plan.up[i][-1]),
-                                  in_bn2=live_record(plan.bd[i][-1])))
-            group.append((st, Z[i][0][-1].size(0)))
-        Z3 = run(gemms)
-        finalize(group)
-        H = [torch.empty_like(z) for z in Z3]
+        if plan.cb is not None:
+            gemms, group = [], []
+            for i in range(nd):
+                st = plan.cb[i]
+                W, b, _, _ = P[id(st)]
+                last_up, last_bd = plan.chains[i][0][-1], plan.chains[i][1][-1]
+                sc, sh = prologue(last_up)
+                sc2, sh2 = prologue(last_bd)
+                gemms.append(ops.Gemm(X=Z[i][0][-1], X2=Z[i][1][-1], W=W, bias=b, in_scale=sc, in_shift=sh,
+                                      in_scale2=sc2, in_shift2=sh2, in_relu=3, col_stats=stat_of.get(id(st)),
+                                      stat_slots=slot_of.get(id(st)), in_bn=live_record(last_up),
+                                      in_bn2=live_record(last_bd)))
+                group.append((st, Z[i][0][-1].size(0)))
+            Z3 = run(gemms)
+            finalize(group)
+            last = [(z, plan.cb[i]) for i, z in enumerate(Z3)]
+        else:               # no combine stage here: every branch's last stage is activated and handed back
+            Z3 = []
+            last = [(Z[i][br][-1], plan.chains[i][br][-1]) for i in range(nd) for br in range(nb)]
+        H = [torch.empty_like(z) for z, _ in last]
         acts = []
-        for i, (z, h) in enumerate(zip(Z3, H)):
+        for (z, st), h in zip(last, H):
             if z.numel():
-                d = _norm_desc(z, out=h, aff=None if live else aff_of.get(id(plan.cb[i])))
+                d = _norm_desc(z, out=h, aff=None if live else aff_of.get(id(st)))
                 if live:
-                    d.bn = live_record(plan.cb[i])
+                    d.bn = live_record(st)
                 acts.append(d)
-        _ffi.norm_act(acts, dev)
+        if acts:
+            _ffi.norm_act(acts, dev)
         if bns:
             ops.state_changed()      # bn_finalize wrote the running statistics (and the batch counters) through raw pointers
         ctx.plan = plan
         ctx.aff_of = {k: v for k, v in aff_of.items()}
         ctx.sum_of, ctx.sums, ctx.sums_clean = sum_of, sums, True
-        flatZ = [Z[i][br][s] for i in range(nd) for br in (0, 1) for s in range(depth)]
+        flatZ = [Z[i][br][s] for i in range(nd) for br in range(nb) for s in range(depth)]
         ctx.save_for_backward(*[a for pair in A0 for a in pair], *flatZ, *Z3, affs,
                               *[t for t in par])
         ctx.n_par = len(par)
@@ -287,23 +300,24 @@ class _DenseTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dH):
         plan: _Plan = ctx.plan
-        nd, depth = plan.nd, plan.depth
+        nd, depth, nb = plan.nd, plan.depth, plan.nb
         saved = ctx.saved_tensors
-        A0 = [[saved[2 * i], saved[2 * i + 1]] for i in range(nd)]
-        o = 2 * nd
-        Z = [[[None] * depth, [None] * depth] for _ in range(nd)]
+        A0 = [[saved[nb * i + br] for br in range(nb)] for i in range(nd)]
+        o = nb * nd
+        Z = [[[None] * depth for _ in range(nb)] for _ in range(nd)]
         for i in range(nd):
-            for br in (0, 1):
+            for br in range(nb):
                 for s in range(depth):
                     Z[i][br][s] = saved[o]
                     o += 1
-        Z3 = list(saved[o: o + nd])
-        o += nd + 1                                   # + the flat affine buffer (kept alive)
+        n3 = nd if plan.cb is not None else 0
+        Z3 = list(saved[o: o + n3])
+        o += n3 + 1                                   # + the flat affine buffer (kept alive)
         par = saved[o: o + ctx.n_par]
         stages = list(plan.stages())
         P = {id(st): par[4 * k: 4 * k + 4] for k, st in enumerate(stages)}
         aff_of = ctx.aff_of
-        dev = Z3[0].device
+        dev = A0[0][0].device
         # gradient targets.  Weights / biases: the parameter's own .grad when it is allocated
         # (ops._grad_target: a FlatGradBucket or zero_grad(set_to_none=False)) -- the TN kernel adds
         # into it and autograd gets None -- else a slice of one zeroed scratch buffer.  The
@@ -314,7 +328,7 @@ class _DenseTrain(torch.autograd.Function):
         # straight INTO gamma.grad / beta.grad.
         fused_norm = FUSED_NORM_BACKWARD and all(
             z.size(0) <= _ffi.NORM_BWD_FUSED_MAX_ROWS and z.size(1) % 4 == 0 and z.stride(0) % 4 == 0 and z.data_ptr() % 16 == 0
-            for z in [zz for i in range(nd) for br in (0, 1) for zz in Z[i][br]] + Z3)
+            for z in [zz for i in range(nd) for br in range(nb) for zz in Z[i][br]] + Z3)
         sizes, targets, norm_targets = [], [], {}
         for st in stages:
             W, b, gamma, beta = P[id(st)]
@@ -333,17 +347,17 @@ class _DenseTrain(torch.autograd.Function):
             ctx.sums.zero_()
         ctx.sums_clean = False
         G, q = {}, 0
-        for st, (nw, nb), (tw, tb) in zip(stages, sizes, targets):
+        for st, (nw, nbias), (tw, tb) in zip(stages, sizes, targets):
             W, b = P[id(st)][0], P[id(st)][1]
             dW = flat[q: q + nw].view_as(W) if tw is None else tw
             q += nw
-            db = (flat[q: q + nb] if nb else None) if tb is None else tb
-            q += nb
+            db = (flat[q: q + nbias] if nbias else None) if tb is None else tb
+            q += nbias
             G[id(st)] = (dW, db, ctx.sum_of.get(id(st)))
 
         # slot sums of the reduce halves the backward-stage launches take over (LIVE_BN_BWD): one zeroed region
-        upd = [st for i in range(nd) for st in plan.up[i] + plan.bd[i] if st.is_bn]
-        F0 = int(Z3[0].size(1))
+        upd = [st for i in range(nd) for chain in plan.chains[i] for st in chain if st.is_bn]
+        F0 = int(Z[0][0][-1].size(1))
         live_bwd = bool(LIVE_BN_BWD and not fused_norm and ops.STAGE_KERNEL and upd and F0 in (64, 128)
                         and all(st.lin.out_features == F0 for st in upd))
         bslot_of, filled = {}, set()
@@ -429,17 +443,9 @@ class _DenseTrain(torch.autograd.Function):
 
         ld = lambda t: t.stride(0) if t.size(0) > 1 else t.size(1)
 
-        # ---- combine stage -------------------------------------------------------------------
-        dH = [g if g is not None else torch.zeros_like(z) for g, z in zip(dH, Z3)]
-        dH = [ops._rowmajor(g, 'grad') for g in dH]
-        pend3 = norm_backward([(plan.cb[i], dH[i], Z3[i]) for i in range(nd)], lazy=True)
-        lazy3 = bool(pend3) and isinstance(pend3[0], tuple)
-        dZ3 = [p[0] for p in pend3] if lazy3 else pend3
-        tn, nn = [], []
-        dA = []
-        stage_bwd = []          # the same products for cwn_dense_stage_bwd_f32 (ops.run_stage_bwd), when every one has the lazy form
-        live_recs, live_to = [], []   # per entry: the slot-sum forms (ops.run_stage_bwd) and the stages whose reduce they take over
-
+        # weight gradients whose targets are all the parameters' own .grad buffers may wait for the end of the backward
+        can_defer = ops.ACCUMULATE_INTO_GRAD and all(tw is not None and (st.lin.bias is None or tb is not None)
+                                                     for st, (tw, tb) in zip(stages, targets))
         def mark_filled(recs, to):
             for (_, o1, o2), (t1, t2) in zip(recs, to):
                 if o1 is not None:
@@ -447,65 +453,77 @@ class _DenseTrain(torch.autograd.Function):
                 if o2 is not None:
                     filled.add(id(t2))
 
-        for i in range(nd):
-            st = plan.cb[i]
-            W = P[id(st)][0]
-            dW, db, _ = G[id(st)]
-            Xu, Xb = Z[i][0][-1], Z[i][1][-1]
-            sc, sh = prologue(plan.up[i][-1])
-            sc2, sh2 = prologue(plan.bd[i][-1])
-            if dZ3[i].numel():
-                tn.append(_ffi.GemmTnDesc(
-                    dZ=dZ3[i].data_ptr(), X=Xu.data_ptr(), X2=Xb.data_ptr(), in_scale=_ffi.ptr(sc),
-                    in_shift=_ffi.ptr(sh), in_scale2=_ffi.ptr(sc2), in_shift2=_ffi.ptr(sh2),
-                    dW=dW.data_ptr(), db=_ffi.ptr(db), M=dZ3[i].size(0), lddz=ld(dZ3[i]), ldx=ld(Xu),
-                    ldx2=ld(Xb), lddw=dW.stride(0), N=W.size(0), K=Xu.size(1), K2=Xb.size(1), in_relu=3))
-            hu = plan.up[i][-1].lin.out_features
-            if lazy3 and pend3[i][1] is not None:
-                # the two halves of dA as two products over the same dz (each 128 or 64 columns wide: the kernel's shapes)
-                out = torch.empty(dZ3[i].size(0), W.size(1), dtype=torch.float32, device=dev)
-                b = pend3[i][1]
-                nn.append(ops.Gemm(X=dH[i], W=W[:, :hu], w_trans=True, out=out[:, :hu], bnb=b))
-                nn.append(ops.Gemm(X=dH[i], W=W[:, hu:], w_trans=True, out=out[:, hu:], bnb=second_view(b)))
-                dA.append(out)
-                stage_bwd.append((dH[i], b, W, out[:, :hu], out[:, hu:]) if W.size(1) == 2 * hu else None)
-                live_recs.append((getattr(b, 's_slots', None), out_record(plan.up[i][-1], Z[i][0][-1]),
-                                  out_record(plan.bd[i][-1], Z[i][1][-1])))
-                live_to.append((plan.up[i][-1], plan.bd[i][-1]))
-            else:
-                nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
-                dA.append(None)
-                stage_bwd.append(None)
-                live_recs.append((None, None, None))
-                live_to.append((None, None))
-        # weight gradients whose targets are all the parameters' own .grad buffers may wait for the end of the backward
-        can_defer = ops.ACCUMULATE_INTO_GRAD and all(tw is not None and (st.lin.bias is None or tb is not None)
-                                                     for st, (tw, tb) in zip(stages, targets))
-        keep_all = [dZ3, Z, A0, aff_of, dH]
-        # [M, H_up + H_bd] per dimension (before the weight gradients: with the lazy form the launch WRITES dZ3)
-        if all(e is not None for e in stage_bwd) and ops.run_stage_bwd(stage_bwd, dev, live_recs if live_bwd else None):
-            if live_bwd:
-                mark_filled(live_recs, live_to)
+        # ---- combine stage -------------------------------------------------------------------
+        if plan.cb is None:          # (the caller's combine network runs on torch: dH is the gradient of every branch's activated output)
+            flat_dH = [g if g is not None else torch.zeros_like(Z[k // nb][k % nb][-1]) for k, g in enumerate(dH)]
+            dy = [[ops._rowmajor(flat_dH[nb * i + br], 'grad') for br in range(nb)] for i in range(nd)]
         else:
-            res = ops.run_gemm(nn, dev)
-            k = 0
+            dH = [g if g is not None else torch.zeros_like(z) for g, z in zip(dH, Z3)]
+            dH = [ops._rowmajor(g, 'grad') for g in dH]
+            pend3 = norm_backward([(plan.cb[i], dH[i], Z3[i]) for i in range(nd)], lazy=True)
+            lazy3 = bool(pend3) and isinstance(pend3[0], tuple)
+            dZ3 = [p[0] for p in pend3] if lazy3 else pend3
+            tn, nn = [], []
+            dA = []
+            stage_bwd = []          # the same products for cwn_dense_stage_bwd_f32 (ops.run_stage_bwd), when every one has the lazy form
+            live_recs, live_to = [], []   # per entry: the slot-sum forms (ops.run_stage_bwd) and the stages whose reduce they take over
+
             for i in range(nd):
-                if dA[i] is None:
-                    dA[i] = res[k]
-                    k += 1
+                st = plan.cb[i]
+                W = P[id(st)][0]
+                dW, db, _ = G[id(st)]
+                Xu, Xb = Z[i][0][-1], Z[i][1][-1]
+                sc, sh = prologue(plan.chains[i][0][-1])
+                sc2, sh2 = prologue(plan.chains[i][1][-1])
+                if dZ3[i].numel():
+                    tn.append(_ffi.GemmTnDesc(
+                        dZ=dZ3[i].data_ptr(), X=Xu.data_ptr(), X2=Xb.data_ptr(), in_scale=_ffi.ptr(sc),
+                        in_shift=_ffi.ptr(sh), in_scale2=_ffi.ptr(sc2), in_shift2=_ffi.ptr(sh2),
+                        dW=dW.data_ptr(), db=_ffi.ptr(db), M=dZ3[i].size(0), lddz=ld(dZ3[i]), ldx=ld(Xu),
+                        ldx2=ld(Xb), lddw=dW.stride(0), N=W.size(0), K=Xu.size(1), K2=Xb.size(1), in_relu=3))
+                hu = plan.chains[i][0][-1].lin.out_features
+                if lazy3 and pend3[i][1] is not None:
+                    # the two halves of dA as two products over the same dz (each 128 or 64 columns wide: the kernel's shapes)
+                    out = torch.empty(dZ3[i].size(0), W.size(1), dtype=torch.float32, device=dev)
+                    b = pend3[i][1]
+                    nn.append(ops.Gemm(X=dH[i], W=W[:, :hu], w_trans=True, out=out[:, :hu], bnb=b))
+                    nn.append(ops.Gemm(X=dH[i], W=W[:, hu:], w_trans=True, out=out[:, hu:], bnb=second_view(b)))
+                    dA.append(out)
+                    stage_bwd.append((dH[i], b, W, out[:, :hu], out[:, hu:]) if W.size(1) == 2 * hu else None)
+                    live_recs.append((getattr(b, 's_slots', None), out_record(plan.chains[i][0][-1], Z[i][0][-1]),
+                                      out_record(plan.chains[i][1][-1], Z[i][1][-1])))
+                    live_to.append((plan.chains[i][0][-1], plan.chains[i][1][-1]))
                 else:
-                    k += 2
-        if tn:
-            _ffi.gemm_tn(tn, dev, keep=keep_all, deferrable=can_defer)
-        dy = []
-        for i in range(nd):
-            hu = plan.up[i][-1].lin.out_features
-            dy.append([dA[i][:, :hu], dA[i][:, hu:]])
+                    nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
+                    dA.append(None)
+                    stage_bwd.append(None)
+                    live_recs.append((None, None, None))
+                    live_to.append((None, None))
+            keep_all = [dZ3, Z, A0, aff_of, dH]
+            # [M, H_up + H_bd] per dimension (before the weight gradients: with the lazy form the launch WRITES dZ3)
+            if all(e is not None for e in stage_bwd) and ops.run_stage_bwd(stage_bwd, dev, live_recs if live_bwd else None):
+                if live_bwd:
+                    mark_filled(live_recs, live_to)
+            else:
+                res = ops.run_gemm(nn, dev)
+                k = 0
+                for i in range(nd):
+                    if dA[i] is None:
+                        dA[i] = res[k]
+                        k += 1
+                    else:
+                        k += 2
+            if tn:
+                _ffi.gemm_tn(tn, dev, keep=keep_all, deferrable=can_defer)
+            dy = []
+            for i in range(nd):
+                hu = plan.chains[i][0][-1].lin.out_features
+                dy.append([dA[i][:, :hu], dA[i][:, hu:]])
         # ---- update stages, last to first ------------------------------------------------------
         for s in range(depth - 1, -1, -1):
             items = []
             for i in range(nd):
-                for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
+                for br, chain in enumerate(plan.chains[i]):
                     items.append((chain[s], dy[i][br], Z[i][br][s]))
             pend = norm_backward(items, lazy=True)
             lazy_s = bool(pend) and isinstance(pend[0], tuple)
@@ -513,7 +531,7 @@ class _DenseTrain(torch.autograd.Function):
             tn, nn, k = [], [], 0
             stage_bwd, live_recs, live_to = [], [], []
             for i in range(nd):
-                for br, chain in ((0, plan.up[i]), (1, plan.bd[i])):
+                for br, chain in enumerate(plan.chains[i]):
                     st = chain[s]
                     W = P[id(st)][0]
                     dW, db, _ = G[id(st)]
@@ -553,12 +571,12 @@ class _DenseTrain(torch.autograd.Function):
                 _ffi.gemm_tn(tn, dev, keep=[dZ, Z, A0, aff_of, dy], deferrable=can_defer)
             k = 0
             for i in range(nd):
-                for br in (0, 1):
+                for br in range(nb):
                     dy[i][br] = res[k]
                     k += 1
         grads: List[Optional[Tensor]] = [None]
         for i in range(nd):
-            grads += [dy[i][0], dy[i][1]]
+            grads += list(dy[i])
         for st, (tw, tb) in zip(stages, targets):
             dW, db, s12 = G[id(st)]
             W, b, gamma, beta = P[id(st)]

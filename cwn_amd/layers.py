@@ -1316,13 +1316,58 @@ class CINppConv(SparseCINConv):
     def _dense_eval(self, plans, outs, start: int = 0):
         return None
 
-    def _dense_train(self, plans, outs, start: int = 0):
-        return None
+    def _dense_train(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
+        """Training mode: the update networks of EVERY stream and dimension (three or four chains of Linear ->
+        BatchNorm(train) -> ReLU stages per dimension) through dense_train's stage launches, forward and backward -- a plan
+        without combine stages, at most _ffi.MAX_DESCS chains per autograd node -- then torch.cat + combine_nn as torch
+        modules (mp/layers.py:255-260).  None when it does not apply (LayerNorm, custom networks, fewer than two cells)."""
+        from . import _ffi, dense_train as DT
+        if not torch.is_grad_enabled() or not FUSED_DENSE_TRAINING:
+            return None
+        active = list(range(start, len(plans)))
+        if not active or any(plans[d] is None for d in active):
+            return None
+        nb = len(plans[active[0]])
+        if any(len(plans[d]) != nb for d in active) or len(outs) != nb * len(active) or any(o.size(0) < 2 for o in outs):
+            return None
+        chains = []
+        for d in active:
+            lvl = self.mp_levels[d]
+            nets = [lvl.update_up_nn, lvl.update_down_nn, lvl.update_boundaries_nn]
+            if nb == 4:
+                nets.append(lvl.update_coboundaries_nn)
+            sts = [_mlp_stages(net) for net in nets]
+            if any(s is None for s in sts) or len({len(s) for s in sts}) != 1:
+                return None
+            cs = [[DT.Stage(lin, norm) for lin, norm in s] for s in sts]
+            if not all(DT.supported(c) for c in cs) or any(isinstance(s.norm, BN) and not s.norm.training for c in cs for s in c):
+                return None
+            chains.append(cs)
+        if len({len(cs[0]) for cs in chains}) != 1:
+            return None
+        if ops.STAGE_KERNEL:
+            # This layer packs its own blocks on every training forward, next to whatever a model packed (fresh=False).  ALWAYS:
+            # a block is keyed on its weight's storage address, and a look-up that trusted an earlier entry could be handed
+            # the block of a dead layer whose parameters lived at the same address (seen in the tests: two layers built one
+            # after the other).
+            ws = [st.lin.weight for cs in chains for c in cs for st in c if st.lin.weight.is_cuda]
+            if ws:
+                ops.pack_stage_weights_many(ws, fresh=False)
+        per = max(1, _ffi.MAX_DESCS // nb)                    # dimensions per autograd node
+        hs: List[Tensor] = []
+        for lo in range(0, len(active), per):
+            grp = chains[lo: lo + per]
+            hs += DT.dense_train(DT._Plan(None, None, None, chains=grp), outs[nb * lo: nb * (lo + len(grp))])
+        return [self.mp_levels[d].combine_nn(torch.cat(hs[nb * k: nb * (k + 1)], dim=-1)) for k, d in enumerate(active)]
 
     def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0):
         """mp/layers.py:418-427."""
         assert len(cochain_params) <= self.max_dim + 1
         plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
+        dense = self._dense_train(plans, outs, start_to_process)
+        if dense is not None:
+            it = iter(dense)
+            return [c.x if dim < start_to_process else next(it) for dim, c in enumerate(cochain_params)]
         out, k = [], 0
         for dim, cochain in enumerate(cochain_params):
             if dim < start_to_process:

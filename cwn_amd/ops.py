@@ -1624,13 +1624,15 @@ def _stage_key(w: Tensor, col0: int):
     return (w.data_ptr(), tuple(w.shape), int(w.stride(0)), int(col0))
 
 
-def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True) -> None:
+def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True, fresh: bool = True) -> None:
     """Pack the [F, F] weights (and the two column halves of the [F, 2F] ones) of all given Linear layers in one launch per
     width (+ one for the transposed blocks the backward stage multiplies with); `packed_stage_block` hands the blocks out
-    until the next call."""
+    until the next call.  `fresh=False` (a single layer packing its own blocks next to a model's): the blocks of earlier
+    calls stay valid -- each is still guarded by its weight's version and the parameter epoch."""
     global _stage_token
-    _stage_token += 1
-    _packed_stage.clear()                   # (entries of earlier calls are stale by definition)
+    if fresh:
+        _stage_token += 1
+        _packed_stage.clear()               # (entries of earlier calls are stale by definition)
     L = _ffi.lib()
     by_F = {}
     for weight in weights:
