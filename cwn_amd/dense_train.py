@@ -23,6 +23,10 @@ Backward, per stage from the last to the first:
 
 Semantics are those of torch.nn.Linear / BatchNorm1d(train) / ReLU; tests/test_gpu_parity.py checks
 outputs, every gradient and the running statistics against the torch modules.
+
+CINppConv (mp/layers.py:216-260: three update networks per dimension, four with the co-boundary stream, and a 3F / 4F-wide
+combine) uses the same Function with a plan of N branches and NO combine stage: the update stages run as above, the last
+stage of every branch is activated by cwn_norm_act and handed back, torch.cat + combine_nn run as torch modules.
 """
 import os
 from dataclasses import dataclass
