@@ -1313,22 +1313,13 @@ class CINppConv(SparseCINConv):
     def _propagate_blocked_train(self, cochain_params, start_to_process, specs, owner):
         return None
 
-    def _dense_eval(self, plans, outs, start: int = 0):
-        return None
-
-    def _dense_train(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
-        """Training mode: the update networks of EVERY stream and dimension (three or four chains of Linear ->
-        BatchNorm(train) -> ReLU stages per dimension) through dense_train's stage launches, forward and backward -- a plan
-        without combine stages, at most _ffi.MAX_DESCS chains per autograd node -- then torch.cat + combine_nn as torch
-        modules (mp/layers.py:255-260).  None when it does not apply (LayerNorm, custom networks, fewer than two cells)."""
-        from . import _ffi, dense_train as DT
-        if not torch.is_grad_enabled() or not FUSED_DENSE_TRAINING:
-            return None
+    def _update_chains(self, plans, outs, start: int):
+        """(active dimensions, streams per dimension, [dim][stream] -> [(Linear, norm), ...]) or None."""
         active = list(range(start, len(plans)))
         if not active or any(plans[d] is None for d in active):
             return None
         nb = len(plans[active[0]])
-        if any(len(plans[d]) != nb for d in active) or len(outs) != nb * len(active) or any(o.size(0) < 2 for o in outs):
+        if any(len(plans[d]) != nb for d in active) or len(outs) != nb * len(active):
             return None
         chains = []
         for d in active:
@@ -1337,14 +1328,55 @@ class CINppConv(SparseCINConv):
             if nb == 4:
                 nets.append(lvl.update_coboundaries_nn)
             sts = [_mlp_stages(net) for net in nets]
-            if any(s is None for s in sts) or len({len(s) for s in sts}) != 1:
+            if any(st is None for st in sts):
                 return None
-            cs = [[DT.Stage(lin, norm) for lin, norm in s] for s in sts]
+            chains.append(sts)
+        if len({len(st) for sts in chains for st in sts}) != 1:
+            return None
+        return active, nb, chains
+
+    def _dense_eval(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
+        """Inference: the update networks of every stream and dimension as grouped MFMA launches, one per stage, with
+        eval-mode BatchNorm and the ReLU folded into the epilogue (SparseCINConv._dense_eval's form); torch.cat + combine_nn
+        as torch modules."""
+        from . import _ffi
+        if torch.is_grad_enabled():
+            return None
+        got = self._update_chains(plans, outs, start)
+        if got is None:
+            return None
+        active, nb, chains = got
+        flat = [st for sts in chains for st in sts]                      # [dim][stream] flattened, as `outs`
+        folds = [[_fold_norm(norm, lin.out_features) for lin, norm in st] for st in flat]
+        if any(f is None for fs in folds for f in fs) or any(lin.in_features > ops.GEMM_MAX_K for st in flat for lin, _ in st):
+            return None
+        hs, dev = list(outs), outs[0].device
+        for s in range(len(flat[0])):
+            gemms = [ops.Gemm(X=h, W=st[s][0].weight, bias=st[s][0].bias, relu=True, out_scale=fs[s][0], out_shift=fs[s][1],
+                              w_packed=ops.pack_gemm_weight(st[s][0].weight)) for h, st, fs in zip(hs, flat, folds)]
+            hs = []
+            for lo in range(0, len(gemms), _ffi.MAX_DESCS):
+                hs += ops.run_gemm(gemms[lo: lo + _ffi.MAX_DESCS], dev)
+        return [self.mp_levels[d].combine_nn(torch.cat(hs[nb * k: nb * (k + 1)], dim=-1)) for k, d in enumerate(active)]
+
+    def _dense_train(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
+        """Training mode: the update networks of EVERY stream and dimension (three or four chains of Linear ->
+        BatchNorm(train) -> ReLU stages per dimension) through dense_train's stage launches, forward and backward -- a plan
+        without combine stages, at most _ffi.MAX_DESCS chains per autograd node -- then torch.cat + combine_nn as torch
+        modules (mp/layers.py:255-260).  None when it does not apply (LayerNorm, custom networks, fewer than two cells)."""
+        from . import _ffi, dense_train as DT
+        if not torch.is_grad_enabled() or not FUSED_DENSE_TRAINING or any(o.size(0) < 2 for o in outs):
+            return None
+        got = self._update_chains(plans, outs, start)
+        if got is None:
+            return None
+        active, nb, raw = got
+        chains = []
+        for sts in raw:
+            cs = [[DT.Stage(lin, norm) for lin, norm in st] for st in sts]
             if not all(DT.supported(c) for c in cs) or any(isinstance(s.norm, BN) and not s.norm.training for c in cs for s in c):
                 return None
             chains.append(cs)
-        if len({len(cs[0]) for cs in chains}) != 1:
-            return None
         if ops.STAGE_KERNEL:
             # This layer packs its own blocks on every training forward, next to whatever a model packed (fresh=False).  ALWAYS:
             # a block is keyed on its weight's storage address, and a look-up that trusted an earlier entry could be handed
@@ -1364,7 +1396,9 @@ class CINppConv(SparseCINConv):
         """mp/layers.py:418-427."""
         assert len(cochain_params) <= self.max_dim + 1
         plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
-        dense = self._dense_train(plans, outs, start_to_process)
+        dense = self._dense_eval(plans, outs, start_to_process)
+        if dense is None:
+            dense = self._dense_train(plans, outs, start_to_process)
         if dense is not None:
             it = iter(dense)
             return [c.x if dim < start_to_process else next(it) for dim, c in enumerate(cochain_params)]

@@ -2535,6 +2535,20 @@ def test_cinpp_fused_streams_match_the_hook_path(F, proper):
         assert set(gp1) == set(gp0)
         for n in gp0:
             close(gp1[n], gp0[n], f'gradient of {n} train={train}', mult=2.5 * _grad_scale(n, gp0[n]) / max(1.0, float(gp0[n].abs().max())))
+    # inference (no autograd): the update networks as grouped launches with the eval-mode BatchNorm folded in
+    conv.eval()
+    for d in range(3):
+        b.cochains[d].x = xs[d]
+    params = b.get_all_cochain_params(max_dim=2, include_down_features=proper)
+    taken, orig = [], conv._dense_eval
+    conv._dense_eval = lambda *a, **k: (taken.append(orig(*a, **k)) or taken[-1])
+    with torch.no_grad():
+        got = conv(*params)
+        want = [conv.mp_levels[d].forward_unfused(params[d]) for d in range(3)]
+    conv._dense_eval = orig
+    assert taken and taken[0] is not None, 'the grouped inference path of the update networks was not taken'
+    for d in range(3):
+        close(got[d], want[d], f'inference output dim {d}')
     # the lower stream of the proper form is live; the quirk's is the self term alone
     lvl = conv.mp_levels[1]
     params = b.get_all_cochain_params(max_dim=2, include_down_features=proper)
