@@ -1433,12 +1433,41 @@ class OrientedConv(CochainMessagePassing):
         self.act_fn = act_fn
         self.orient = orient
 
+    def _stream(self, adj: Adjacency, x: Tensor, attr: Tensor, aggr) -> ops.Stream:
+        if not self.orient:
+            return ops.Stream(adj=adj, n_dst=adj.n_dst, width=int(x.size(1)), A=x, reduce=aggr or 'add')
+        return ops.Stream(adj=adj, n_dst=adj.n_dst, width=int(x.size(1)), A=x, B=dense(attr).to(torch.float32),
+                          msg_op=ops.MSG_A_TIMES_B, ib_mode='perm', reduce=aggr or 'add')
+
+    def propagate_both(self, cochain) -> Optional[List[Tensor]]:
+        """(out_up, out_down) of mp/layers.py:441-446 in ONE aggregation launch (one autograd node in training) instead of
+        one per adjacency; None when a subclass has replaced the hooks (forward then runs propagate())."""
+        x = cochain.x
+        if (not isinstance(x, Tensor) or not x.is_cuda or type(self).message_up is not OrientedConv.message_up
+                or type(self).message_down is not OrientedConv.message_down
+                or type(self).message_and_aggregate_up is not OrientedConv.message_and_aggregate_up
+                or type(self).message_and_aggregate_down is not OrientedConv.message_and_aggregate_down
+                or self._overrides['aggregate_up'] or self._overrides['aggregate_down'] or self._overrides['update']):
+            return None
+        up_attr, down_attr = cochain.upper_orient.view(-1, 1), cochain.lower_orient.view(-1, 1)
+        kw = dict(x=x, up_attr=up_attr, down_attr=down_attr)
+        up_size = self.__check_input_separately__(cochain.upper_index, None)
+        down_size = self.__check_input_separately__(cochain.lower_index, None)
+        self.__check_input_together__(cochain.upper_index, cochain.lower_index, up_size, down_size)
+        sts = [self._stream(self._adjacency(cochain.upper_index, 'up', up_size, kw), x, up_attr, self.aggr_up),
+               self._stream(self._adjacency(cochain.lower_index, 'down', down_size, kw), x, down_attr, self.aggr_down)]
+        return ops.aggregate_many(sts)
+
     def forward(self, cochain):
         assert len(cochain.upper_orient) == cochain.upper_index.size(1)
         assert len(cochain.lower_orient) == cochain.lower_index.size(1)
-        out_up, out_down, _ = self.propagate(
-            cochain.upper_index, cochain.lower_index, None, x=cochain.x,
-            up_attr=cochain.upper_orient.view(-1, 1), down_attr=cochain.lower_orient.view(-1, 1))
+        both = self.propagate_both(cochain)
+        if both is not None:
+            out_up, out_down = both
+        else:
+            out_up, out_down, _ = self.propagate(
+                cochain.upper_index, cochain.lower_index, None, x=cochain.x,
+                up_attr=cochain.upper_orient.view(-1, 1), down_attr=cochain.lower_orient.view(-1, 1))
         out_up = self.update_up_nn(out_up)
         out_down = self.update_down_nn(out_down)
         x = self.update_nn(cochain.x)

@@ -585,6 +585,29 @@ def test_edge_cin_conv_and_full_oriented_conv_golden_gpu():
     with torch.no_grad():
         y = oc(c)
     gate(y, T(g['oriented/out']), 'OrientedConv.forward')
+    # both adjacencies in ONE aggregation launch / one autograd node (OrientedConv.propagate_both, round 4) against
+    # propagate() -- a launch per adjacency: outputs, input and parameter gradients, with and without orientations
+    x0, w = c.x.detach().clone(), torch.randn(c.x.size(0), Hd, generator=torch.Generator().manual_seed(2)).to(DEV)
+    for orient in (True, False):
+        oc.orient = orient
+        res = []
+        for one_launch in (True, False):
+            oc.zero_grad(set_to_none=True)
+            c.x = x0.clone().requires_grad_(True)
+            if not one_launch:
+                oc.propagate_both = lambda cochain: None
+            try:
+                y = oc(c)
+            finally:
+                oc.__dict__.pop('propagate_both', None)
+            (y * w).sum().backward()
+            res.append((y.detach(), c.x.grad.clone(), {n: p.grad.clone() for n, p in oc.named_parameters()}))
+        assert oc.propagate_both(c) is not None
+        torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
+        for n in res[1][2]:
+            torch.testing.assert_close(res[0][2][n], res[1][2][n], rtol=1e-5, atol=1e-5, msg=n)
+    oc.orient = True
 
 
 def test_init_reduce_known_answer_gpu():
