@@ -152,12 +152,7 @@ class _SparseCINStack(torch.nn.Module):
         self.convs = torch.nn.ModuleList()
         for i in range(num_layers):
             layer_dim = first_dim if i == 0 else hidden
-            self.convs.append(SparseCINConv(
-                up_msg_size=layer_dim, down_msg_size=layer_dim, boundary_msg_size=layer_dim,
-                passed_msg_boundaries_nn=None, passed_msg_up_nn=None, passed_update_up_nn=None,
-                passed_update_boundaries_nn=None, train_eps=train_eps, max_dim=self.max_dim,
-                hidden=hidden, act_module=act_module, layer_dim=layer_dim,
-                graph_norm=self.graph_norm, use_coboundaries=use_coboundaries))
+            self.convs.append(self._make_conv(layer_dim, hidden, act_module, train_eps, use_coboundaries))
         self.lin1s = torch.nn.ModuleList()
         for _ in range(max_dim + 1):
             if jump_mode == 'cat':   # no bias: an absent level contributes exactly zero
@@ -168,12 +163,21 @@ class _SparseCINStack(torch.nn.Module):
 
     conv_dropout = False       # OGBEmbedSparseCIN drops out after every conv (:298-300)
 
+    def _make_conv(self, layer_dim, hidden, act_module, train_eps, use_coboundaries):
+        return SparseCINConv(
+            up_msg_size=layer_dim, down_msg_size=layer_dim, boundary_msg_size=layer_dim,
+            passed_msg_boundaries_nn=None, passed_msg_up_nn=None, passed_update_up_nn=None,
+            passed_update_boundaries_nn=None, train_eps=train_eps, max_dim=self.max_dim,
+            hidden=hidden, act_module=act_module, layer_dim=layer_dim,
+            graph_norm=self.graph_norm, use_coboundaries=use_coboundaries)
+
     def _convs_and_head(self, data: ComplexBatch, include_partial: bool, res: dict):
         act = get_nonlinearity(self.nonlinearity, return_module=False)
         jump_xs, xs = None, None
         if torch.is_grad_enabled() and layers.BLOCKED_TRAIN_FORWARD and layers.BLOCKED_LAYER:
             # training forward through the blocked layer kernel: the message weights of all layers packed in one launch
-            ws = [lvl.msg_up_nn[1].weight for conv in self.convs for lvl in getattr(conv, 'mp_levels', [])
+            ws = [lvl.msg_up_nn[1].weight for conv in self.convs if not isinstance(conv, layers.CINppConv)
+                  for lvl in getattr(conv, 'mp_levels', [])
                   if getattr(lvl, '_up_kind', lambda: None)() == 'cat_linear_relu' and lvl.msg_up_nn[1].weight.is_cuda]
             if ws:
                 ops.pack_layer_weights_many(ws, transposed=bool(ops.BLOCKED_BACKWARD))
@@ -380,3 +384,25 @@ class OGBEmbedSparseCIN(_SparseCINStack):
         xs = [F.dropout(x, p=self.in_dropout_rate, training=self.training) for x in xs]
         data.set_xs(xs)
         return self._convs_and_head(data, include_partial, {})
+
+
+class _CINppLayers:
+    """The one difference of the CIN++ models (mp/molec_models.py:185-199, 370-384): every layer is a CINppConv."""
+
+    def _make_conv(self, layer_dim, hidden, act_module, train_eps, use_coboundaries):
+        return layers.CINppConv(
+            up_msg_size=layer_dim, down_msg_size=layer_dim, boundary_msg_size=layer_dim,
+            passed_msg_boundaries_nn=None, passed_msg_up_nn=None, passed_msg_down_nn=None, passed_update_up_nn=None,
+            passed_update_down_nn=None, passed_update_boundaries_nn=None, train_eps=train_eps, max_dim=self.max_dim,
+            hidden=hidden, act_module=act_module, layer_dim=layer_dim, graph_norm=self.graph_norm,
+            use_coboundaries=use_coboundaries)
+
+
+class EmbedCINpp(_CINppLayers, EmbedSparseCIN):
+    """mp/molec_models.py:167-199: EmbedSparseCIN with CINppConv layers.  As in the reference the lower stream stays off
+    (the forward asks for include_down_features=False and CINppCochainConv.forward passes no down_attr); the
+    state_dict is interchangeable (tests/golden/embed_cinpp.npz holds the reference's)."""
+
+
+class OGBEmbedCINpp(_CINppLayers, OGBEmbedSparseCIN):
+    """mp/molec_models.py:355-384."""

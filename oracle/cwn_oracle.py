@@ -333,21 +333,51 @@ def sparse_cin_cochain_conv(p: Dict, prm: Dict, use_coboundaries: bool, training
     return torch.relu(h)
 
 
+def cinpp_cochain_conv(p: Dict, prm: Dict, use_coboundaries: bool, training: bool = False,
+                       norm: str = 'bn') -> Tensor:
+    """CINppCochainConv.forward, mp/layers.py:243-260, with the default sub-networks of CINppConv (:366-416).  The
+    class inherits use_down_msg=False (:167-168) and its forward passes no down_attr (:244-247): the lower stream is
+    zeros, so out_down is the self term (1 + eps2) x alone; the boundary stream takes eps3."""
+    x = prm['x']
+    width = x.size(1)
+
+    def msg_up(x_j, attr):
+        if not use_coboundaries:
+            return x_j
+        return torch.relu(_lin(torch.cat([x_j, attr], dim=-1), p, 'msg_up_nn.1'))
+
+    out_up, out_down, out_b = propagate(
+        x, prm['up_index'], prm['down_index'], prm['boundary_index'],
+        up_attr=prm['up_attr'], boundary_attr=prm['boundary_attr'],
+        message_up=msg_up, use_down_msg=False,
+        up_msg_size=width, down_msg_size=width, boundary_msg_size=width)
+    out_up = out_up + (1 + p['eps1']) * x
+    out_down = out_down + (1 + p['eps2']) * x
+    out_b = out_b + (1 + p['eps3']) * x
+    out_up = _mlp2(out_up, p, 'update_up_nn', training, norm)
+    out_down = _mlp2(out_down, p, 'update_down_nn', training, norm)
+    out_b = _mlp2(out_b, p, 'update_boundaries_nn', training, norm)
+    h = _lin(torch.cat([out_up, out_down, out_b], dim=-1), p, 'combine_nn.0')
+    if norm == 'bn':
+        h = _bn(h, p, 'combine_nn.1', training)
+    return torch.relu(h)
+
+
 def _level_state(state: Dict, level: int) -> Dict:
     pre = f'mp_levels.{level}.'
     return {k[len(pre):]: v for k, v in state.items() if k.startswith(pre)}
 
 
 def sparse_cin_conv(state: Dict, params: List[Dict], use_coboundaries: bool,
-                    training: bool = False, norm: str = 'bn', start_to_process: int = 0):
-    """SparseCINConv.forward, mp/layers.py:333-342."""
+                    training: bool = False, norm: str = 'bn', start_to_process: int = 0, conv: str = 'sparse_cin'):
+    """SparseCINConv.forward, mp/layers.py:333-342 (`conv='cinpp'`: CINppConv.forward, :418-427)."""
+    level = cinpp_cochain_conv if conv == 'cinpp' else sparse_cin_cochain_conv
     outs = []
     for d, prm in enumerate(params):
         if d < start_to_process:
             outs.append(prm['x'])
         else:
-            outs.append(sparse_cin_cochain_conv(_level_state(state, d), prm, use_coboundaries,
-                                                training, norm))
+            outs.append(level(_level_state(state, d), prm, use_coboundaries, training, norm))
     return outs
 
 
@@ -443,11 +473,12 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
                              use_coboundaries: bool = True, readout: str = 'sum',
                              final_readout: str = 'sum', training: bool = False, norm: str = 'bn',
                              jump_mode: Optional[str] = None, embed: Optional[str] = 'zinc',
-                             init_reduce_mode: str = 'add', readout_dims=(0, 1, 2)):
+                             init_reduce_mode: str = 'add', readout_dims=(0, 1, 2), conv: str = 'sparse_cin'):
     """SparseCIN.forward (mp/models.py:195-260), EmbedSparseCIN.forward (mp/molec_models.py:90-160)
     and OGBEmbedSparseCIN.forward (mp/molec_models.py:281-350) with dropout off and jump_mode in
     {None, 'cat', 'max'}.  `embed`: None (features used as they are), 'zinc' (one Embedding per dimension
-    0/1) or 'ogb' (sum of per-column embeddings).  Returns (out, per-layer / pooled tensors)."""
+    0/1) or 'ogb' (sum of per-column embeddings).  `conv='cinpp'`: EmbedCINpp / OGBEmbedCINpp (mp/molec_models.py:167-199,
+    355-384: the same forward over CINppConv layers).  Returns (out, per-layer / pooled tensors)."""
     cx = {'dimension': cx['dimension'], 'y': cx.get('y'), 'num_complexes': cx.get('num_complexes'),
           'cochains': [dict(c) for c in cx['cochains']]}
     partial = {}
@@ -474,7 +505,7 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
         params = all_cochain_params(cx, max_dim=max_dim, include_down_features=False)
         pre = f'convs.{l}.'
         lstate = {k[len(pre):]: v for k, v in state.items() if k.startswith(pre)}
-        xs = sparse_cin_conv(lstate, params, use_coboundaries, training, norm)
+        xs = sparse_cin_conv(lstate, params, use_coboundaries, training, norm, conv=conv)
         for d, x in enumerate(xs):
             cx['cochains'][d]['x'] = x
             partial[f'layer{l}_{d}'] = x

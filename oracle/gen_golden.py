@@ -378,6 +378,8 @@ def edge_and_oriented():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'edge_oriented':
         edge_and_oriented()         # the round-3 fixture alone (the others stay byte-identical)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'cinpp':
+        pass                        # the round-4 fixture alone (written at the end of this file)
     else:
         main()
         edge_and_oriented()
@@ -436,5 +438,84 @@ def extra_models():
     save('sparse_cin_models.npz', out)
 
 
-if __name__ == '__main__' and os.environ.get('CWN_GOLDEN_EXTRA', '1') == '1':
-    extra_models()
+def cinpp_models():
+    """Round 4: CINppConv as the reference's EmbedCINpp / OGBEmbedCINpp build and call it (mp/molec_models.py:167-199,
+    355-384; mp/layers.py:216-260, 344-427: the lower stream stays off -- the forward passes no down_attr and the models ask
+    for include_down_features=False) -> embed_cinpp.npz: state, inputs, every layer's outputs and the prediction, eval and
+    training mode."""
+    from mp.molec_models import EmbedCINpp, OGBEmbedCINpp
+    from ogb.graphproppred.mol_encoder import ATOM_DIMS, BOND_DIMS
+    out = {}
+    gen = torch.Generator().manual_seed(17)
+    for tag, H, L in (('h16_l2', 16, 2), ('h64_l2', 64, 2)):
+        torch.manual_seed(41)
+        cxs = [get(n) for n in MOL_LIST]
+        for cx in cxs:
+            cx.cochains[0]._Cochain__x = torch.randint(0, 28, (cx.cochains[0].num_cells, 1), generator=gen).float()
+            if cx.dimension >= 1:
+                cx.cochains[1]._Cochain__x = torch.randint(0, 4, (cx.cochains[1].num_cells, 1), generator=gen).float()
+            if cx.dimension >= 2:
+                cx.cochains[2]._Cochain__x = None
+        b = ComplexBatch.from_complex_list(cxs, max_dim=2)
+        model = EmbedCINpp(28, 4, 1, L, H, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu', readout='sum',
+                           train_eps=True, final_hidden_multiplier=2, final_readout='sum', apply_dropout_before='lin2',
+                           init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn')
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.normal_(generator=gen)
+                    m.running_var.uniform_(0.5, 1.5, generator=gen)
+            for n, p in model.named_parameters():
+                if '.eps' in n:                       # distinct eps1 / eps2 / eps3: a mix-up of the three shows
+                    p.copy_(torch.rand(1, generator=gen) * 0.5)
+        out[f'{tag}/meta'] = np.array([H, L])
+        out.update(state_np(model, f'{tag}/state'))
+        out[f'{tag}/v_types'] = np_(b.cochains[0].x)
+        out[f'{tag}/e_types'] = np_(b.cochains[1].x)
+        for mode in ('eval', 'train'):
+            model.train(mode == 'train')
+            bb = ComplexBatch.from_complex_list(cxs, max_dim=2)
+            with torch.no_grad():
+                y, res = model(bb, include_partial=True)
+            out[f'{tag}/{mode}/out'] = np_(y)
+            for k, v in res.items():
+                out[f'{tag}/{mode}/{k}'] = np_(v)
+    # the OGB front on the same layers
+    torch.manual_seed(42)
+    cxs = [get(n) for n in MOL_LIST]
+    for cx in cxs:
+        n0 = cx.cochains[0].num_cells
+        cx.cochains[0]._Cochain__x = torch.stack([torch.randint(0, d, (n0,), generator=gen) for d in ATOM_DIMS], 1)
+        if cx.dimension >= 1:
+            n1 = cx.cochains[1].num_cells
+            cx.cochains[1]._Cochain__x = torch.stack([torch.randint(0, d, (n1,), generator=gen) for d in BOND_DIMS], 1)
+        if cx.dimension >= 2:
+            cx.cochains[2]._Cochain__x = None
+    b = ComplexBatch.from_complex_list(cxs, max_dim=2)
+    model = OGBEmbedCINpp(1, 2, 16, dropout_rate=0.0, indropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu',
+                          readout='mean', final_readout='sum', init_reduce='sum', embed_edge=True, use_coboundaries=True,
+                          graph_norm='bn')
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(generator=gen)
+                m.running_var.uniform_(0.5, 1.5, generator=gen)
+    model.eval()
+    out.update(state_np(model, 'ogb/state'))
+    out['ogb/v_feats'] = np_(b.cochains[0].x)
+    out['ogb/e_feats'] = np_(b.cochains[1].x)
+    with torch.no_grad():
+        y, res = model(b, include_partial=True)
+    out['ogb/out'] = np_(y)
+    for k, v in res.items():
+        out[f'ogb/{k}'] = np_(v)
+    save('embed_cinpp.npz', out)
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'cinpp':
+        cinpp_models()
+    elif os.environ.get('CWN_GOLDEN_EXTRA', '1') == '1':
+        extra_models()
+        if len(sys.argv) == 1:
+            cinpp_models()

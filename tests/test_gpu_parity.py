@@ -646,6 +646,64 @@ def test_embed_sparse_cin_whole_stack_golden(tag):
         gate(y, T(g[f'{tag}/{mode}/out']), f'{tag} {mode} out')
 
 
+@pytest.mark.parametrize('tag', ['h16_l2', 'h64_l2'])
+def test_embed_cinpp_whole_stack_golden(tag):
+    """EmbedCINpp (mp/molec_models.py:167-199: EmbedSparseCIN with CINppConv layers, mp/layers.py:216-260, 344-427) with the
+    REFERENCE's state_dict against the reference's own outputs (oracle/gen_golden.py cinpp): every layer output and the
+    prediction, eval and training mode -- and in training mode once more with autograd recording, where at hidden 64 the
+    update networks of all three streams run on the stage kernels (dense_train, a plan without combine stages)."""
+    from cwn_amd.models import EmbedCINpp
+    g = load('embed_cinpp.npz')
+    H, L = g[f'{tag}/meta'].tolist()
+    model = EmbedCINpp(28, 4, 1, L, H, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu', readout='sum',
+                       train_eps=True, final_hidden_multiplier=2, final_readout='sum', apply_dropout_before='lin2',
+                       init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn')
+    names = list_names('mol')
+    for mode, grad in (('eval', False), ('train', False), ('train', True)):
+        model.load_state_dict(state_dict(g, f'{tag}/state'))
+        model = model.to(DEV).train(mode == 'train')
+        b = dummy_batch(names, max_dim=2)
+        b.cochains[0].x = T(g[f'{tag}/v_types'])
+        b.cochains[1].x = T(g[f'{tag}/e_types'])
+        b.cochains[2]._x = None
+        b = b.to(DEV)
+        taken = []
+        if grad:
+            from cwn_amd import dense_train as DT
+            orig = DT.dense_train
+            DT.dense_train = lambda plan, outs: (taken.append(plan.nb), orig(plan, outs))[1]
+        try:
+            with torch.set_grad_enabled(grad):
+                y, res = model(b, include_partial=True)
+        finally:
+            if grad:
+                DT.dense_train = orig
+        if grad:
+            assert taken == [3, 3] * L, taken          # per layer: dimensions 0 - 1 and dimension 2, three chains each
+        for k, v in res.items():
+            gate(v, T(g[f'{tag}/{mode}/{k}']), f'{tag} {mode} grad={grad} {k}')
+        gate(y, T(g[f'{tag}/{mode}/out']), f'{tag} {mode} grad={grad} out')
+
+
+def test_ogb_embed_cinpp_golden():
+    """OGBEmbedCINpp (mp/molec_models.py:355-384) with the reference's state_dict against the reference's outputs."""
+    from cwn_amd.models import OGBEmbedCINpp
+    g = load('embed_cinpp.npz')
+    model = OGBEmbedCINpp(1, 2, 16, dropout_rate=0.0, indropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu',
+                          readout='mean', final_readout='sum', init_reduce='sum', embed_edge=True, use_coboundaries=True,
+                          graph_norm='bn')
+    model.load_state_dict(state_dict(g, 'ogb/state'))
+    model = model.to(DEV).eval()
+    b = dummy_batch(list_names('mol'), max_dim=2)
+    b.cochains[0].x, b.cochains[1].x = T(g['ogb/v_feats']), T(g['ogb/e_feats'])
+    b.cochains[2]._x = None
+    with torch.no_grad():
+        y, res = model(b.to(DEV), include_partial=True)
+    for k, v in res.items():
+        gate(v, T(g[f'ogb/{k}']), f'OGBEmbedCINpp {k}')
+    gate(y, T(g['ogb/out']), 'OGBEmbedCINpp out')
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE-size properties (ZINC-like batch of 128, F = 128): size-independent checks
 # ------------------------------------------------------------------------------------------------

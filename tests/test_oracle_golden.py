@@ -309,3 +309,34 @@ def test_extra_models_golden():
     for k, v in partial.items():
         torch.testing.assert_close(v, T(g[f'molhiv/{k}']), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(y, T(g['molhiv/out']), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('tag', ['h16_l2', 'h64_l2'])
+def test_embed_cinpp_golden(tag):
+    """The oracle's CIN++ layer (cinpp_cochain_conv: mp/layers.py:243-260 -- three eps, the lower stream off) inside the
+    EmbedCINpp forward (mp/molec_models.py:167-199) against the reference's own outputs, eval and training mode."""
+    g = load('embed_cinpp.npz')
+    H, L = g[f'{tag}/meta'].tolist()
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/mol']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    cx['cochains'][0]['x'], cx['cochains'][1]['x'] = T(g[f'{tag}/v_types']), T(g[f'{tag}/e_types'])
+    cx['cochains'][2]['x'] = None
+    state = state_dict(g, f'{tag}/state')
+    assert len({float(state[f'convs.0.mp_levels.1.eps{k}']) for k in (1, 2, 3)}) == 3      # a mix-up of the three would show
+    for mode in ('eval', 'train'):
+        y, partial = O.sparse_cin_model_forward(state, cx, L, training=(mode == 'train'), conv='cinpp')
+        for k, v in partial.items():
+            torch.testing.assert_close(v, T(g[f'{tag}/{mode}/{k}']), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(y, T(g[f'{tag}/{mode}/out']), rtol=1e-4, atol=1e-4)
+
+
+def test_ogb_embed_cinpp_golden():
+    g = load('embed_cinpp.npz')
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/mol']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    cx['cochains'][0]['x'], cx['cochains'][1]['x'] = T(g['ogb/v_feats']), T(g['ogb/e_feats'])
+    cx['cochains'][2]['x'] = None
+    y, partial = O.sparse_cin_model_forward(state_dict(g, 'ogb/state'), cx, 2, readout='mean', embed='ogb', conv='cinpp')
+    for k, v in partial.items():
+        torch.testing.assert_close(v, T(g[f'ogb/{k}']), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y, T(g['ogb/out']), rtol=1e-4, atol=1e-4)
