@@ -24,10 +24,10 @@ def _oracle_cx(b):
         for d in range(b.dimension + 1)]}
 
 
-@pytest.mark.parametrize('cfg', ['zinc128', 'molhiv512'])
+@pytest.mark.parametrize('cfg', ['zinc128', 'molhiv512', 'cinpp64'])
 def test_training_step_at_the_timed_size_vs_float64_oracle(cfg):
     from cwn_amd.complex import ComplexBatch
-    from cwn_amd.models import EmbedSparseCIN, OGBEmbedSparseCIN
+    from cwn_amd.models import EmbedCINpp, EmbedSparseCIN, OGBEmbedSparseCIN
     from cwn_amd.synthetic import molhiv_like_complexes, zinc_like_complexes
     from cwn_amd.train import TrainStep
     torch.manual_seed(0)
@@ -38,6 +38,13 @@ def test_training_step_at_the_timed_size_vs_float64_oracle(cfg):
                                use_coboundaries=True, graph_norm='bn')
         b = ComplexBatch.from_complex_list(zinc_like_complexes(128, 41, 6), max_dim=2)
         okw = dict(embed='zinc')
+    elif cfg == 'cinpp64':        # round 4: the CIN++ stack (mp/molec_models.py:167-199), three update networks per dimension on the
+        L = 2                     # stage kernels (a plan without combine stages), the 3F-wide combine on torch; trained eps
+        model = EmbedCINpp(28, 4, 1, L, 64, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu', readout='sum',
+                           train_eps=True, final_hidden_multiplier=2, final_readout='sum', init_reduce='sum', embed_edge=True,
+                           use_coboundaries=True, graph_norm='bn')
+        b = ComplexBatch.from_complex_list(zinc_like_complexes(64, 47, 6), max_dim=2)
+        okw = dict(embed='zinc', conv='cinpp')
     else:                         # exp/scripts/cwn-molhiv.sh:9-32 at BASELINE's batch of 512
         L = 2
         model = OGBEmbedSparseCIN(1, L, 64, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum', init_reduce='sum',
