@@ -155,6 +155,18 @@ from .static_batch import StaticBatch            # noqa: E402
 from .train import TrainStep                     # noqa: E402
 
 
+def refuse_unsupported_layers(model: torch.nn.Module, who: str) -> None:
+    """A static batch carries, per slot, what SparseCINConv's blocked kernels read (item tables, the collated CSR of the
+    boundary adjacencies for the backward) -- not a CSR plan of the UPPER / LOWER adjacencies, which the streaming aggregation
+    of other layers (CINppConv, CINConv, OrientedConv) builds per batch on the host's sizes.  Those layers take collated
+    batches (`model(batch)`, TrainStep); here they are refused instead of being handed capacity-sized index buffers."""
+    from .layers import CINConv, CINppConv, EdgeCINConv, OrientedConv
+    bad = sorted({type(m).__name__ for m in model.modules() if isinstance(m, (CINppConv, CINConv, EdgeCINConv, OrientedConv))})
+    if bad:
+        raise NotImplementedError(f'{who}: {", ".join(bad)} layers are not served by static batches (their aggregation needs a '
+                                  f'per-batch CSR plan of the upper / lower adjacency); use collated batches with model(batch) / TrainStep')
+
+
 class StaticForward:
     """`model(batch)` (eval, no autograd) for every batch a StaticBatch holds, as one captured graph:
         fill (tables + collate + item tables, all slots) -> per slot: front -> L x (layer launch + update launch) -> head.
@@ -163,6 +175,7 @@ class StaticForward:
     a parameter (or, through ops.STATE_EPOCH, a raw-pointer writer such as a TrainStep) has changed them."""
 
     def __init__(self, model: torch.nn.Module, static: StaticBatch):
+        refuse_unsupported_layers(model, 'StaticForward')
         self.model, self.sb = model, static
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.outs: Optional[List[torch.Tensor]] = None
@@ -227,6 +240,7 @@ class StaticTrainStep(TrainStep):
 
     def __init__(self, model: torch.nn.Module, static: StaticBatch, task_type: str = 'regression', lr: float = 1e-3,
                  use_graph: bool = True, optimizer=None):
+        refuse_unsupported_layers(model, 'StaticTrainStep')
         self.sb = static
         static.fill()                                 # the buffers hold real batches from here on (warm-up)
         super().__init__(model, [sl.batch for sl in static.slots], task_type=task_type, lr=lr, use_graph=use_graph,

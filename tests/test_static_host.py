@@ -100,3 +100,14 @@ def test_device_table_layout_is_the_host_collate_layout():
     assert t2[sb.o_sizes + 3] == 5
     seg0 = t2[sb.o_seg: sb.o_seg + B + 1]
     assert (seg0[5:] == seg0[5]).all() and seg0[5] == sum(pool[i].cochains[0].num_cells for i in idx[:5])
+
+
+def test_static_drivers_refuse_layers_that_need_a_per_batch_csr_plan():
+    """StaticForward / StaticTrainStep serve SparseCINConv stacks; a CIN++ model (streaming aggregation over a CSR plan of the
+    upper adjacency, built per batch on the host's sizes) is refused at construction, not handed capacity-sized buffers."""
+    from cwn_amd.models import EmbedCINpp, EmbedSparseCIN
+    from cwn_amd.static_graph import refuse_unsupported_layers
+    kw = dict(dropout_rate=0.0, max_dim=2, embed_edge=True, use_coboundaries=True)
+    refuse_unsupported_layers(EmbedSparseCIN(28, 4, 1, 2, 16, **kw), 'StaticForward')
+    with pytest.raises(NotImplementedError, match='CINppConv'):
+        refuse_unsupported_layers(EmbedCINpp(28, 4, 1, 2, 16, **kw), 'StaticForward')
