@@ -52,6 +52,12 @@ struct StageBatch {
     int32_t n;
     int32_t dbg;      // timing experiments (CWN_STAGE_DBG): 1 live prologue without its arithmetic, 2 without its loads, 4 no statistics atomics
 };
+// ... with a third / fourth K-block per product (cwn_dense_stage_ex_f32: CIN++'s 3F / 4F-wide combine): its own kernel, so
+// that the two-input launches of a SparseCIN step keep their argument block and their code
+struct StageBatchEx : StageBatch {
+    cwn_stage_extra more[CWN_MAX_DESCS][2];
+};
+static_assert(sizeof(StageBatchEx) <= 4096 - 256, "kernel-argument segment (with the hidden arguments)");
 
 // v of the lane CTRL's rotation away within its 16-lane row (DPP row_ror:n = 0x120 + n), for a double
 template <int CTRL>
@@ -67,15 +73,16 @@ __device__ __forceinline__ float row_ror_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <int F>
-__global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
+template <int F, bool EX, typename BatchT>
+__device__ __forceinline__ void dense_stage_body(const BatchT& B) {
     using S = Shape<F>;
     constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
     constexpr size_t kPlaneElems = S::kPlaneElems, kBufBytes = S::kBufBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // 2 KiB next to the tiles: the affines a live BatchNorm prologue derives ([input][scale | shift][F] floats) and, behind the
     // products, the workgroup's column statistics on their way to one coalesced atomic per column ([half][sum | sq][F] doubles)
-    __shared__ __attribute__((aligned(16))) double live_scratch[256];
+    // (EX: up to four inputs -> 4 KiB)
+    __shared__ __attribute__((aligned(16))) double live_scratch[EX ? 512 : 256];
     uint16_t* const buf0 = reinterpret_cast<uint16_t*>(smem);
     uint16_t* const buf1 = reinterpret_cast<uint16_t*>(smem + kBufBytes);
     int di = 0;
@@ -91,6 +98,15 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     const int ct = wave % S::kNCT, rt0 = (wave / S::kNCT) * kRT;
     const int l15 = lane & 15, kq = lane >> 4;
     const bool two = D.X2 != nullptr;
+    // (EX) the third / fourth K-block: tiles requested with the others, staged into the SAME two LDS buffers once the first
+    // two products have left them
+    const cwn_stage_extra* E = nullptr;
+    bool three = false, four = false;
+    if constexpr (EX) {
+        E = B.more[di];
+        three = E[0].X != nullptr;
+        four = three && E[1].X != nullptr;
+    }
 
     // workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding global load: here
     // the tiles and the weight, which keep streaming across the barrier)
@@ -177,22 +193,39 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
     // live BatchNorm prologue (cwn_bn_live.h): thread c < F the column c of X's record, thread F + c of X2's; their slot sums
     // are requested AHEAD of the tiles (loads return in order: behind the tiles they would wait for them)
     const bool live0 = D.in_bn.slots != nullptr, live1 = D.in_bn2.slots != nullptr;
+    bool live2 = false, live3 = false;
+    if constexpr (EX) {
+        live2 = three && E[0].bn.slots != nullptr;
+        live3 = four && E[1].bn.slots != nullptr;
+    }
     const int live_which = threadIdx.x / F, live_col = threadIdx.x % F;
-    const bool live_mine = (live_which == 0 && live0) || (live_which == 1 && live1);
+    bool live_mine = (live_which == 0 && live0) || (live_which == 1 && live1);
+    if constexpr (EX) live_mine = live_mine || (live_which == 2 && live2) || (live_which == 3 && live3);
+    auto live_rec = [&]() -> const cwn_bn_live& {
+        if constexpr (EX) {
+            if (live_which >= 2) return E[live_which == 2 ? 0 : 1].bn;
+        }
+        return live_which == 0 ? D.in_bn : D.in_bn2;
+    };
     cwn::BnLiveRegs live_regs;
     if (live_mine && !(B.dbg & 2))
-        cwn::bn_live_request(live_which == 0 ? D.in_bn : D.in_bn2, F, live_col, (int)blockIdx.x == B.blk_start[di], live_regs);
+        cwn::bn_live_request(live_rec(), F, live_col, (int)blockIdx.x == B.blk_start[di], live_regs);
     __builtin_amdgcn_sched_barrier(0);              // (the slot requests leave FIRST: the compiler would hoist the tile loads)
     request_rows(v0, D.X, D.ldx);
     if (row0 >= Mv) return;                         // (uniform) a tile past the batch's own rows: nothing to store or count
     if (two) request_rows(v1, D.X2, D.ldx2);
-    if (live0 || live1) {
+    RowRegs v2, v3;
+    if constexpr (EX) {
+        if (three) request_rows(v2, E[0].X, E[0].ldx);
+        if (four) request_rows(v3, E[1].X, E[1].ldx);
+    }
+    if (live0 || live1 || live2 || live3) {
         // ... the first workgroup of the descriptor writes what the backward reads and the running statistics
         float* const aff = reinterpret_cast<float*>(live_scratch);
         if (live_mine) {
             float sc = 1.f, sh = 0.f;
             if (!(B.dbg & 3)) {
-                cwn::bn_live_finish(live_which == 0 ? D.in_bn : D.in_bn2, live_regs, F, Mv, live_col,
+                cwn::bn_live_finish(live_rec(), live_regs, F, Mv, live_col,
                                     (int)blockIdx.x == B.blk_start[di] && !(B.dbg & 8), sc, sh);
             } else if (!(B.dbg & 2)) {               // every load consumed, none of the arithmetic
                 double a = 0.0;
@@ -219,7 +252,23 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) acc[rt] = frag_cd{0.f, 0.f, 0.f, 0.f};
     multiply(buf0, wfA, wfB, two ? D.w2_packed : nullptr);
-    if (two) multiply(buf1, wfB, wfA, nullptr);
+    if constexpr (!EX) {
+        if (two) multiply(buf1, wfB, wfA, nullptr);
+    } else {
+        if (two) multiply(buf1, wfB, wfA, three ? E[0].w_packed : nullptr);
+        if (three) {
+            const Pro p2 = request_pro(nullptr, nullptr, E[0].relu != 0, live2 ? 2 : -1);
+            lds_barrier();                          // every wave has read the first two tiles
+            stage_rows(v2, p2, buf0);
+            if (four) {
+                const Pro p3 = request_pro(nullptr, nullptr, E[1].relu != 0, live3 ? 3 : -1);
+                stage_rows(v3, p3, buf1);
+            }
+            lds_barrier();
+            multiply(buf0, wfA, wfB, four ? E[1].w_packed : nullptr);
+            if (four) multiply(buf1, wfB, wfA, nullptr);
+        }
+    }
 
     // epilogue: + bias; the band's column statistics of the pre-normalisation value (fp64, the 16 rows of a lane group
     // through DPP, both row tiles summed in registers first, ONE plain store per column and band: no atomics, no zero
@@ -272,6 +321,16 @@ __global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
             }
         }
     }
+}
+
+template <int F>
+__global__ __launch_bounds__(kThreads) void dense_stage_kernel(StageBatch B) {
+    dense_stage_body<F, false>(B);
+}
+
+template <int F>
+__global__ __launch_bounds__(kThreads) void dense_stage_ex_kernel(StageBatchEx B) {
+    dense_stage_body<F, true>(B);
 }
 
 // ---- the same stage BACKWARD: dX = dz W, with dz formed on the way in ---------------------------------------------------------
@@ -535,6 +594,19 @@ int launch_stage(const StageBatch& B, int64_t blocks, hipStream_t stream) {
 }
 
 template <int F>
+int launch_stage_ex(const StageBatchEx& B, int64_t blocks, hipStream_t stream) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_stage_ex_kernel<F>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Shape<F>::kLdsBytes);
+    });
+    if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
+    dense_stage_ex_kernel<F><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F>::kLdsBytes, stream>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+template <int F>
 int launch_stage_bwd(const StageBwdBatch& B, int64_t blocks, hipStream_t stream) {
     dense_stage_bwd_kernel<F><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F>::kBufBytes, stream>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
@@ -628,12 +700,11 @@ extern "C" int cwn_update_mlp_pack_weights_both_many_f32(const float* const* W, 
     return (out == nullptr || out_t == nullptr) ? CWN_ERR_BAD_ARG : pack_stage_many(W, ldw, F, out, out_t, n, stream);
 }
 
-extern "C" int cwn_dense_stage_f32(const cwn_stage_desc* descs, int n, int32_t F, cwn_stream_t stream_) {
+static int fill_stage_batch(StageBatch& B, const cwn_stage_desc* descs, int n, int32_t F, int64_t& blocks) {
     if (descs == nullptr || n < 1 || n > CWN_MAX_DESCS || (F != 64 && F != 128)) return CWN_ERR_BAD_ARG;
     const int TM = 4096 / F;
-    StageBatch B{};
     B.n = n;
-    int64_t blocks = 0;
+    blocks = 0;
     for (int i = 0; i < n; ++i) {
         const cwn_stage_desc& D = descs[i];
         if (D.M < 0) return CWN_ERR_BAD_ARG;
@@ -661,10 +732,43 @@ extern "C" int cwn_dense_stage_f32(const cwn_stage_desc* descs, int n, int32_t F
         if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     }
     for (int i = n; i <= CWN_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
-    if (blocks == 0) return CWN_OK;
     static const int dbg = getenv("CWN_STAGE_DBG") ? atoi(getenv("CWN_STAGE_DBG")) : 0;
     B.dbg = dbg;
+    return CWN_OK;
+}
+
+extern "C" int cwn_dense_stage_f32(const cwn_stage_desc* descs, int n, int32_t F, cwn_stream_t stream_) {
+    StageBatch B{};
+    int64_t blocks = 0;
+    const int rc = fill_stage_batch(B, descs, n, F, blocks);
+    if (rc != CWN_OK || blocks == 0) return rc;
     return F == 128 ? launch_stage<128>(B, blocks, (hipStream_t)stream_) : launch_stage<64>(B, blocks, (hipStream_t)stream_);
+}
+
+extern "C" int cwn_dense_stage_ex_f32(const cwn_stage_desc* descs, const cwn_stage_extra* extras, int n, int32_t F,
+                                      cwn_stream_t stream_) {
+    if (extras == nullptr) return cwn_dense_stage_f32(descs, n, F, stream_);
+    StageBatchEx B{};
+    int64_t blocks = 0;
+    const int rc = fill_stage_batch(B, descs, n, F, blocks);
+    if (rc != CWN_OK) return rc;
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < 2; ++k) {
+            const cwn_stage_extra& E = extras[2 * i + k];
+            B.more[i][k] = E;
+            if (descs[i].M == 0 || E.X == nullptr) continue;
+            if (k == 1 && extras[2 * i].X == nullptr) return CWN_ERR_BAD_ARG;        // a fourth block needs the third
+            if (descs[i].X2 == nullptr || E.w_packed == nullptr || E.ldx < F || E.ldx % 4) return CWN_ERR_BAD_ARG;
+            if (E.bn.slots != nullptr && (E.bn.aff == nullptr || !al16(E.bn.aff))) return CWN_ERR_BAD_ARG;
+            if ((E.bn.running_mean == nullptr) != (E.bn.running_var == nullptr)) return CWN_ERR_BAD_ARG;
+            if (!(al16(E.X) && al16(E.w_packed))) return CWN_ERR_ALIGN;
+            any = true;
+        }
+    }
+    if (blocks == 0) return CWN_OK;
+    if (!any) return F == 128 ? launch_stage<128>(B, blocks, (hipStream_t)stream_) : launch_stage<64>(B, blocks, (hipStream_t)stream_);
+    return F == 128 ? launch_stage_ex<128>(B, blocks, (hipStream_t)stream_) : launch_stage_ex<64>(B, blocks, (hipStream_t)stream_);
 }
 
 extern "C" int cwn_dense_stage_bwd_f32(const cwn_stage_bwd_desc* descs, int n, int32_t F, cwn_stream_t stream_) {

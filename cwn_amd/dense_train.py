@@ -25,8 +25,11 @@ Semantics are those of torch.nn.Linear / BatchNorm1d(train) / ReLU; tests/test_g
 outputs, every gradient and the running statistics against the torch modules.
 
 CINppConv (mp/layers.py:216-260: three update networks per dimension, four with the co-boundary stream, and a 3F / 4F-wide
-combine) uses the same Function with a plan of N branches and NO combine stage: the update stages run as above, the last
-stage of every branch is activated by cwn_norm_act and handed back, torch.cat + combine_nn run as torch modules.
+combine) uses the same Function with a plan of N branches: the combine stage takes the third / fourth branch as extra
+K-blocks of the same launch (cwn_dense_stage_ex_f32), its backward is two entries of the backward-stage launch and two K-pairs
+of the weight-gradient launch per dimension.  Where that form does not apply (widths other than 64 / 128, CWN_LIVE_BN=0) the
+plan comes WITHOUT a combine stage: the last stage of every branch is activated by cwn_norm_act and handed back, torch.cat +
+combine_nn run as torch modules.
 """
 import os
 from dataclasses import dataclass
@@ -68,6 +71,11 @@ LIVE_BN_BWD = os.environ.get('CWN_LIVE_BN_BWD', '1') != '0'
 # from 0.811 to 0.884 ms.)
 
 
+class CombineNeedsStageKernel(RuntimeError):
+    """A plan with a combine stage over three / four branches met conditions under which only the two-branch form exists (the
+    caller -- CINppConv -- then runs the branches here and the combine network as torch modules).  Raised before any launch."""
+
+
 @dataclass
 class Stage:
     """One Linear -> norm -> ReLU group.  `norm` is a BatchNorm1d in training mode or Identity."""
@@ -79,9 +87,9 @@ class Stage:
         return isinstance(self.norm, BatchNorm1d)
 
 
-def supported(stages: Sequence[Stage]) -> bool:
+def supported(stages: Sequence[Stage], max_k: Optional[int] = None) -> bool:
     for st in stages:
-        if not isinstance(st.lin, Linear) or st.lin.in_features > ops.GEMM_MAX_K:
+        if not isinstance(st.lin, Linear) or st.lin.in_features > (ops.GEMM_MAX_K if max_k is None else max_k):
             return False
         n = st.norm
         if isinstance(n, Identity):
@@ -111,14 +119,15 @@ def _norm_desc(z: Tensor, *, dy: Optional[Tensor] = None, out: Optional[Tensor] 
 class _Plan:
     """Static description of one layer's dense networks: per dimension, `depth` update stages for
     each of the branches (SparseCINConv: two, upper and boundary) and one combine stage over the K-concatenation of the
-    two.  `chains` (round 4, CINppConv): any number of branches per dimension and NO combine stage -- the Function then
-    returns every branch's activated output and the caller concatenates and combines them."""
+    two.  `chains` (round 4, CINppConv): two to four branches per dimension; with `cb` the combine stage takes the third /
+    fourth branch as extra K-blocks (cwn_dense_stage_ex_f32; live BatchNorm mode only -- CombineNeedsStageKernel otherwise),
+    without it the Function returns every branch's activated output and the caller concatenates and combines them."""
 
     def __init__(self, up: Optional[List[List[Stage]]], bd: Optional[List[List[Stage]]], cb: Optional[List[Stage]],
                  chains: Optional[List[List[List[Stage]]]] = None):
         self.chains = chains if chains is not None else [[u, b] for u, b in zip(up, bd)]     # [dim][branch] -> stages
         self.cb = cb
-        assert cb is None or all(len(c) == 2 for c in self.chains)
+        assert cb is None or all(2 <= len(c) <= 4 for c in self.chains)
         self.nd = len(self.chains)
         self.nb = len(self.chains[0])
         self.depth = len(self.chains[0][0])
@@ -164,10 +173,13 @@ class _DenseTrain(torch.autograd.Function):
                     and all(a.size(1) == F0 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 for pair in A0 for a in pair)
                     and all(tuple(P[id(st)][0].shape) == (F0, F0) and ops.packed_stage_block(P[id(st)][0], 0) is not None
                             for i in range(nd) for chain in plan.chains[i] for st in chain)
-                    and all(tuple(P[id(st)][0].shape) == (F0, 2 * F0) and ops.packed_stage_block(P[id(st)][0], 0) is not None
-                            and ops.packed_stage_block(P[id(st)][0], F0) is not None for st in (plan.cb or []))
+                    and all(tuple(P[id(st)][0].shape) == (F0, nb * F0)
+                            and all(ops.packed_stage_block(P[id(st)][0], c * F0) is not None for c in range(nb)) for st in (plan.cb or []))
                     and all(t is None or (t.numel() == F0 and t.data_ptr() % 16 == 0 and t.is_contiguous())
                             for st in stages for t in P[id(st)][1:]))
+        if plan.cb is not None and nb > 2 and not live:
+            raise CombineNeedsStageKernel('a combine stage over more than two branches runs on cwn_dense_stage_ex_f32 with live '
+                                          'BatchNorm records only')
         affs = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
         stat_of, aff_of, sum_of, slot_of, o, so = {}, {}, {}, {}, 0, 0
         if live:
@@ -269,10 +281,12 @@ class _DenseTrain(torch.autograd.Function):
                 last_up, last_bd = plan.chains[i][0][-1], plan.chains[i][1][-1]
                 sc, sh = prologue(last_up)
                 sc2, sh2 = prologue(last_bd)
+                # (a third / fourth branch -- CIN++: live mode only, checked above -- rides as an extra K-block each)
+                more = tuple((Z[i][br][-1], True, live_record(plan.chains[i][br][-1])) for br in range(2, nb))
                 gemms.append(ops.Gemm(X=Z[i][0][-1], X2=Z[i][1][-1], W=W, bias=b, in_scale=sc, in_shift=sh,
                                       in_scale2=sc2, in_shift2=sh2, in_relu=3, col_stats=stat_of.get(id(st)),
                                       stat_slots=slot_of.get(id(st)), in_bn=live_record(last_up),
-                                      in_bn2=live_record(last_bd)))
+                                      in_bn2=live_record(last_bd), more=more))
                 group.append((st, Z[i][0][-1].size(0)))
             Z3 = run(gemms)
             finalize(group)
@@ -472,31 +486,47 @@ class _DenseTrain(torch.autograd.Function):
             stage_bwd = []          # the same products for cwn_dense_stage_bwd_f32 (ops.run_stage_bwd), when every one has the lazy form
             live_recs, live_to = [], []   # per entry: the slot-sum forms (ops.run_stage_bwd) and the stages whose reduce they take over
 
+            # branch pairs of a dimension: one K-pair of the weight gradient and one backward-stage entry each (nb = 2: the pair)
+            pairs = [tuple(range(lo, min(lo + 2, nb))) for lo in range(0, nb, 2)]
             for i in range(nd):
                 st = plan.cb[i]
                 W = P[id(st)][0]
                 dW, db, _ = G[id(st)]
-                Xu, Xb = Z[i][0][-1], Z[i][1][-1]
-                sc, sh = prologue(plan.chains[i][0][-1])
-                sc2, sh2 = prologue(plan.chains[i][1][-1])
+                lasts = [plan.chains[i][br][-1] for br in range(nb)]
+                hu = lasts[0].lin.out_features
+                same_width = all(l.lin.out_features == hu for l in lasts) and W.size(1) == nb * hu
                 if dZ3[i].numel():
-                    tn.append(_ffi.GemmTnDesc(
-                        dZ=dZ3[i].data_ptr(), X=Xu.data_ptr(), X2=Xb.data_ptr(), in_scale=_ffi.ptr(sc),
-                        in_shift=_ffi.ptr(sh), in_scale2=_ffi.ptr(sc2), in_shift2=_ffi.ptr(sh2),
-                        dW=dW.data_ptr(), db=_ffi.ptr(db), M=dZ3[i].size(0), lddz=ld(dZ3[i]), ldx=ld(Xu),
-                        ldx2=ld(Xb), lddw=dW.stride(0), N=W.size(0), K=Xu.size(1), K2=Xb.size(1), in_relu=3))
-                hu = plan.chains[i][0][-1].lin.out_features
+                    for pr in pairs:
+                        Xa, Xb = Z[i][pr[0]][-1], (Z[i][pr[1]][-1] if len(pr) > 1 else None)
+                        sc, sh = prologue(lasts[pr[0]])
+                        sc2, sh2 = prologue(lasts[pr[1]]) if len(pr) > 1 else (None, None)
+                        c0 = sum(l.lin.out_features for l in lasts[:pr[0]])
+                        tn.append(_ffi.GemmTnDesc(
+                            dZ=dZ3[i].data_ptr(), X=Xa.data_ptr(), X2=_ffi.ptr(Xb), in_scale=_ffi.ptr(sc),
+                            in_shift=_ffi.ptr(sh), in_scale2=_ffi.ptr(sc2), in_shift2=_ffi.ptr(sh2),
+                            dW=dW.data_ptr() + 4 * c0, db=_ffi.ptr(db) if pr[0] == 0 else None, M=dZ3[i].size(0), lddz=ld(dZ3[i]),
+                            ldx=ld(Xa), ldx2=0 if Xb is None else ld(Xb), lddw=dW.stride(0), N=W.size(0), K=Xa.size(1),
+                            K2=0 if Xb is None else Xb.size(1), in_relu=3 if Xb is not None else 1))
                 if lazy3 and pend3[i][1] is not None:
-                    # the two halves of dA as two products over the same dz (each 128 or 64 columns wide: the kernel's shapes)
+                    # the pieces of dA as products over the same dz (each 128 or 64 columns wide: the kernel's shapes)
                     out = torch.empty(dZ3[i].size(0), W.size(1), dtype=torch.float32, device=dev)
                     b = pend3[i][1]
-                    nn.append(ops.Gemm(X=dH[i], W=W[:, :hu], w_trans=True, out=out[:, :hu], bnb=b))
-                    nn.append(ops.Gemm(X=dH[i], W=W[:, hu:], w_trans=True, out=out[:, hu:], bnb=second_view(b)))
+                    c0 = 0
+                    for br in range(nb):
+                        h = lasts[br].lin.out_features
+                        nn.append(ops.Gemm(X=dH[i], W=W[:, c0:c0 + h], w_trans=True, out=out[:, c0:c0 + h],
+                                           bnb=b if br == 0 else second_view(b)))
+                        c0 += h
                     dA.append(out)
-                    stage_bwd.append((dH[i], b, W, out[:, :hu], out[:, hu:]) if W.size(1) == 2 * hu else None)
-                    live_recs.append((getattr(b, 's_slots', None), out_record(plan.chains[i][0][-1], Z[i][0][-1]),
-                                      out_record(plan.chains[i][1][-1], Z[i][1][-1])))
-                    live_to.append((plan.chains[i][0][-1], plan.chains[i][1][-1]))
+                    for pr in pairs:
+                        c0 = pr[0] * hu
+                        ent = (dH[i], b if pr[0] == 0 else second_view(b), W, out[:, c0:c0 + hu],
+                               out[:, c0 + hu:c0 + 2 * hu] if len(pr) > 1 else None)
+                        stage_bwd.append((ent if nb == 2 else ent + (c0,)) if same_width else None)
+                        live_recs.append((getattr(b, 's_slots', None) if pr[0] == 0 else None,
+                                          out_record(lasts[pr[0]], Z[i][pr[0]][-1]),
+                                          out_record(lasts[pr[1]], Z[i][pr[1]][-1]) if len(pr) > 1 else None))
+                        live_to.append((lasts[pr[0]], lasts[pr[1]] if len(pr) > 1 else None))
                 else:
                     nn.append(ops.Gemm(X=dZ3[i], W=W, w_trans=True))
                     dA.append(None)
@@ -504,7 +534,7 @@ class _DenseTrain(torch.autograd.Function):
                     live_recs.append((None, None, None))
                     live_to.append((None, None))
             keep_all = [dZ3, Z, A0, aff_of, dH]
-            # [M, H_up + H_bd] per dimension (before the weight gradients: with the lazy form the launch WRITES dZ3)
+            # [M, sum of the branch widths] per dimension (before the weight gradients: with the lazy form the launch WRITES dZ3)
             if all(e is not None for e in stage_bwd) and ops.run_stage_bwd(stage_bwd, dev, live_recs if live_bwd else None):
                 if live_bwd:
                     mark_filled(live_recs, live_to)
@@ -516,13 +546,17 @@ class _DenseTrain(torch.autograd.Function):
                         dA[i] = res[k]
                         k += 1
                     else:
-                        k += 2
+                        k += nb
             if tn:
                 _ffi.gemm_tn(tn, dev, keep=keep_all, deferrable=can_defer)
             dy = []
             for i in range(nd):
-                hu = plan.chains[i][0][-1].lin.out_features
-                dy.append([dA[i][:, :hu], dA[i][:, hu:]])
+                cols, c0 = [], 0
+                for br in range(nb):
+                    h = plan.chains[i][br][-1].lin.out_features
+                    cols.append(dA[i][:, c0:c0 + h])
+                    c0 += h
+                dy.append(cols)
         # ---- update stages, last to first ------------------------------------------------------
         for s in range(depth - 1, -1, -1):
             items = []

@@ -81,6 +81,7 @@ def _is_cat_linear_relu(nn) -> bool:
 
 
 FUSED_DENSE_TRAINING = True   # set False to run the update / combine networks as torch modules
+FUSED_CINPP_COMBINE = os.environ.get('CWN_FUSED_CINPP_COMBINE') != '0'    # False: CINppConv's combine network as torch modules behind the fused branches
 FUSED_CIN_TRAINING = os.environ.get('CWN_FUSED_CIN_TRAINING') != '0'      # False: CINCochainConv's training forward on the generic path
 FUSED_UPDATE_MLP = os.environ.get('CWN_FUSED_UPDATE_MLP') != '0'   # False: the update / combine networks as three grouped GEMM launches
 BLOCKED_TRAIN_FORWARD = os.environ.get('CWN_BLOCKED_TRAIN_FORWARD') != '0'    # the training forward through the blocked kernel too
@@ -1386,6 +1387,28 @@ class CINppConv(SparseCINConv):
             if ws:
                 ops.pack_stage_weights_many(ws, fresh=False)
         per = max(1, _ffi.MAX_DESCS // nb)                    # dimensions per autograd node
+        # the combine stage in the same node (its third / fourth branch as extra K-blocks of cwn_dense_stage_ex_f32) ...
+        cbs = []
+        for d in active:
+            cb = _mlp_stages(self.mp_levels[d].combine_nn)
+            cbs.append(DT.Stage(*cb[0]) if cb is not None and len(cb) == 1 else None)
+        full = (FUSED_CINPP_COMBINE and ops.STAGE_KERNEL and all(c is not None and DT.supported([c], max_k=4 * 128) and c.is_bn and c.norm.training
+                                                                for c in cbs))
+        if full:
+            ws = [c.lin.weight for c in cbs if c.lin.weight.is_cuda]
+            if ws:
+                ops.pack_stage_weights_many(ws, fresh=False)
+            res: List[Tensor] = []
+            try:
+                for lo in range(0, len(active), per):
+                    grp = chains[lo: lo + per]
+                    res += DT.dense_train(DT._Plan(None, None, cbs[lo: lo + per], chains=grp), outs[nb * lo: nb * (lo + len(grp))])
+                return res
+            except DT.CombineNeedsStageKernel:
+                if res:         # (a later group refused after an earlier one has run: running it again would count its batch twice)
+                    raise
+                # (raised before any launch of the first group: the whole layer takes the other form)
+        # ... or on torch, behind the branches
         hs: List[Tensor] = []
         for lo in range(0, len(active), per):
             grp = chains[lo: lo + per]

@@ -926,8 +926,13 @@ class Gemm:
     stat_slots: Optional[Tensor] = None
     in_bn: Optional[object] = None
     in_bn2: Optional[object] = None
+    # cwn_dense_stage_ex_f32 only: a third / fourth K-block (CIN++'s 3F / 4F-wide combine) -- (X, relu, _ffi.BnLive or None)
+    # each; W is then [F, 3F] / [F, 4F]
+    more: Sequence = ()
 
     def desc(self, Y: Tensor, packed: bool = False) -> _ffi.GemmDesc:
+        if self.more:
+            raise RuntimeError('a product of more than two K-blocks is served by cwn_dense_stage_ex_f32 only')
         X, W, X2 = self.X, self.W, self.X2
         packed = packed and self.w_packed is not None
         K = X.size(1)
@@ -1638,8 +1643,8 @@ def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True, 
     for weight in weights:
         w = weight.detach()
         F = int(w.size(0)) if w.dim() == 2 else 0
-        if F not in (64, 128) or w.size(1) not in (F, 2 * F) or not w.is_cuda or w.dtype != torch.float32 or w.stride(1) != 1 \
-                or w.data_ptr() % 16 or w.stride(0) % 4:
+        if F not in (64, 128) or w.size(1) not in (F, 2 * F, 3 * F, 4 * F) or not w.is_cuda or w.dtype != torch.float32 \
+                or w.stride(1) != 1 or w.data_ptr() % 16 or w.stride(0) % 4:
             continue
         for c0 in range(0, int(w.size(1)), F):
             by_F.setdefault(F, []).append((weight, w, c0))
@@ -1771,14 +1776,17 @@ def run_stage_bwd(entries, device, live=None) -> bool:
     keep = []
     ok_t = lambda t, w: (t.dtype == torch.float32 and t.is_cuda and t.dim() == 2 and t.size(1) == w and t.stride(1) == 1
                          and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0)
-    for k, (dy, b, W, dx, dx2) in enumerate(entries):
-        if b is None or W.dim() != 2 or W.size(0) != F or W.size(1) != (2 * F if dx2 is not None else F):
+    for k, ent in enumerate(entries):
+        dy, b, W, dx, dx2 = ent[:5]
+        c0 = int(ent[5]) if len(ent) > 5 else 0          # (a wider weight: the blocks W[:, c0 : c0 + F (+ F)])
+        if b is None or W.dim() != 2 or W.size(0) != F or (W.size(1) != (2 * F if dx2 is not None else F) if len(ent) <= 5
+                                                           else W.size(1) < c0 + (2 * F if dx2 is not None else F)):
             return False
         M = int(dy.size(0))
         if M == 0 or not ok_t(dy, F) or not ok_t(dx, F) or (dx2 is not None and not ok_t(dx2, F)) or dx.size(0) != M:
             return False
-        w1 = packed_stage_block(W, 0, transposed=True)
-        w2 = packed_stage_block(W, F, transposed=True) if dx2 is not None else None
+        w1 = packed_stage_block(W, c0, transposed=True)
+        w2 = packed_stage_block(W, c0 + F, transposed=True) if dx2 is not None else None
         if w1 is None or (dx2 is not None and w2 is None):
             return False
         ptrs = [b.scale, b.shift, b.mean, b.rstd, b.s1, b.s2, b.acc1, b.acc2, b.z, b.dz]
@@ -1814,21 +1822,26 @@ def run_stage(gemms: Sequence['Gemm'], device) -> Optional[List[Tensor]]:
     if F not in (64, 128):
         return None
     arr = (_ffi.StageDesc * len(gemms))()
+    extras = None
     keep, outs = [], []
     for k, g in enumerate(gemms):
         X, X2, W = g.X, g.X2, g.W
         if (g.relu or g.out_scale is not None or g.w_trans or g.bnb is not None or g.add_out or g.out is not None or g.exact
                 or g.w_col0 is not None or g.debug):
             return None
-        if W.dim() != 2 or W.size(0) != F or W.size(1) != (2 * F if X2 is not None else F):
+        more = list(g.more)
+        if more and (X2 is None or len(more) > 2):
             return None
-        for t in (X, X2):
+        if W.dim() != 2 or W.size(0) != F or W.size(1) != ((2 + len(more)) * F if X2 is not None else F):
+            return None
+        for t in [X, X2] + [m[0] for m in more]:
             if t is not None and (t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.size(1) != F or t.stride(1) != 1
                                   or t.stride(0) % 4 or t.data_ptr() % 16 or t.size(0) != X.size(0)):
                 return None
         w1 = packed_stage_block(W, 0)
         w2 = packed_stage_block(W, F) if X2 is not None else None
-        if w1 is None or (X2 is not None and w2 is None):
+        wm = [packed_stage_block(W, (2 + j) * F) for j in range(len(more))]
+        if w1 is None or (X2 is not None and w2 is None) or any(w is None for w in wm):
             return None
         cons = [g.bias, g.in_scale, g.in_shift, g.in_scale2, g.in_shift2]
         cons = [None if t is None else _f32c(t, 'constant') for t in cons]
@@ -1854,9 +1867,19 @@ def run_stage(gemms: Sequence['Gemm'], device) -> Optional[List[Tensor]]:
             arr[k].in_bn = g.in_bn
         if g.in_bn2 is not None:
             arr[k].in_bn2 = g.in_bn2
-        keep += cons + [w1, w2]
+        for j, (xm, relu_m, bn_m) in enumerate(more):
+            if extras is None:
+                extras = (_ffi.StageExtra * (2 * len(gemms)))()
+            e = extras[2 * k + j]
+            e.X, e.w_packed, e.ldx, e.relu = xm.data_ptr(), wm[j].data_ptr(), ld(xm), int(bool(relu_m))
+            if bn_m is not None:
+                e.bn = bn_m
+        keep += cons + [w1, w2] + wm
         outs.append(Y)
-    _ffi.check(_ffi.lib().cwn_dense_stage_f32(arr, len(gemms), F, _ffi.stream_ptr(device)), 'cwn_dense_stage_f32')
+    if extras is not None:
+        _ffi.check(_ffi.lib().cwn_dense_stage_ex_f32(arr, extras, len(gemms), F, _ffi.stream_ptr(device)), 'cwn_dense_stage_ex_f32')
+    else:
+        _ffi.check(_ffi.lib().cwn_dense_stage_f32(arr, len(gemms), F, _ffi.stream_ptr(device)), 'cwn_dense_stage_f32')
     return outs
 
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 18
+#define CWN_ABI_VERSION 19
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -604,6 +604,22 @@ typedef struct cwn_stage_desc {
     cwn_bn_live in_bn2;      /* the same for X2 */
 } cwn_stage_desc;
 int cwn_dense_stage_f32(const cwn_stage_desc* descs_host, int n, int32_t F, cwn_stream_t stream);
+/* ... with a THIRD and FOURTH K-block per product (ABI 19): Z = prologue([X | X2 | X3 | X4]) W^T + b -- the combine network of a
+ * CIN++ layer, Linear(3F -> F) over cat(up, down, boundaries) (mp/layers.py:260, 408-410), 4F with the co-boundary stream.
+ * extras_host[2 i], extras_host[2 i + 1] belong to descs_host[i] (X NULL: block absent; the fourth needs the third, both
+ * need X2); a block's prologue is ReLU (`relu`) behind either nothing or a live BatchNorm (`bn.slots` != NULL, as
+ * cwn_stage_desc.in_bn).  w_packed: cwn_update_mlp_pack_weights_many_f32 of W[:, 2F:3F] / W[:, 3F:4F].  extras_host NULL =
+ * cwn_dense_stage_f32.  (A kernel of its own: the two-block launches keep their argument block and their code.) */
+typedef struct cwn_stage_extra {
+    const float* X;          /* [M, F] or NULL */
+    const void* w_packed;
+    int64_t ldx;
+    int32_t relu;
+    int32_t pad_;
+    cwn_bn_live bn;
+} cwn_stage_extra;
+int cwn_dense_stage_ex_f32(const cwn_stage_desc* descs_host, const cwn_stage_extra* extras_host, int n, int32_t F,
+                           cwn_stream_t stream);
 /* ... and BACKWARD (autograd of the Linear / BatchNorm1d(train) / ReLU modules of mp/layers.py:303-325): dX = dz W (two halves
  * dX, dX2 for a Linear(2F -> F)) with the BatchNorm(train) + ReLU backward as the
  * prologue -- dz = scale * (dyh - s1 / M - xhat * s2 / M), dyh = dy * [z * scale + shift > 0]; scale NULL: dz = dy * [z > 0]

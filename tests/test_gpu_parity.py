@@ -671,7 +671,11 @@ def test_embed_cinpp_whole_stack_golden(tag):
         if grad:
             from cwn_amd import dense_train as DT
             orig = DT.dense_train
-            DT.dense_train = lambda plan, outs: (taken.append(plan.nb), orig(plan, outs))[1]
+            def record(plan, outs):
+                res = orig(plan, outs)                      # (a refused plan raises: not recorded)
+                taken.append((plan.nb, plan.cb is not None))
+                return res
+            DT.dense_train = record
         try:
             with torch.set_grad_enabled(grad):
                 y, res = model(b, include_partial=True)
@@ -679,7 +683,9 @@ def test_embed_cinpp_whole_stack_golden(tag):
             if grad:
                 DT.dense_train = orig
         if grad:
-            assert taken == [3, 3] * L, taken          # per layer: dimensions 0 - 1 and dimension 2, three chains each
+            # per layer: dimensions 0 - 1 and dimension 2, three chains each; at 64 the combine stage rides in the same node
+            # (cwn_dense_stage_ex_f32), at 16 it stays a torch module
+            assert taken == [(3, H == 64)] * (2 * L), taken
         for k, v in res.items():
             gate(v, T(g[f'{tag}/{mode}/{k}']), f'{tag} {mode} grad={grad} {k}')
         gate(y, T(g[f'{tag}/{mode}/out']), f'{tag} {mode} grad={grad} out')
