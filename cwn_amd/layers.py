@@ -1378,14 +1378,6 @@ class CINppConv(SparseCINConv):
             if not all(DT.supported(c) for c in cs) or any(isinstance(s.norm, BN) and not s.norm.training for c in cs for s in c):
                 return None
             chains.append(cs)
-        if ops.STAGE_KERNEL:
-            # This layer packs its own blocks on every training forward, next to whatever a model packed (fresh=False).  ALWAYS:
-            # a block is keyed on its weight's storage address, and a look-up that trusted an earlier entry could be handed
-            # the block of a dead layer whose parameters lived at the same address (seen in the tests: two layers built one
-            # after the other).
-            ws = [st.lin.weight for cs in chains for c in cs for st in c if st.lin.weight.is_cuda]
-            if ws:
-                ops.pack_stage_weights_many(ws, fresh=False)
         per = max(1, _ffi.MAX_DESCS // nb)                    # dimensions per autograd node
         # the combine stage in the same node (its third / fourth branch as extra K-blocks of cwn_dense_stage_ex_f32) ...
         cbs = []
@@ -1394,10 +1386,17 @@ class CINppConv(SparseCINConv):
             cbs.append(DT.Stage(*cb[0]) if cb is not None and len(cb) == 1 else None)
         full = (FUSED_CINPP_COMBINE and ops.STAGE_KERNEL and all(c is not None and DT.supported([c], max_k=4 * 128) and c.is_bn and c.norm.training
                                                                 for c in cbs))
-        if full:
-            ws = [c.lin.weight for c in cbs if c.lin.weight.is_cuda]
+        if ops.STAGE_KERNEL:
+            # This layer packs its own blocks on every training forward (one launch: update and combine networks), next to
+            # whatever a model packed (fresh=False).  ALWAYS: a block is keyed on its weight's storage address, and a look-up
+            # that trusted an earlier entry could be handed the block of a dead layer whose parameters lived at the same
+            # address (seen in the tests: two layers built one after the other).
+            ws = [st.lin.weight for cs in chains for c in cs for st in c if st.lin.weight.is_cuda]
+            if full:
+                ws += [c.lin.weight for c in cbs if c.lin.weight.is_cuda]
             if ws:
                 ops.pack_stage_weights_many(ws, fresh=False)
+        if full:
             res: List[Tensor] = []
             try:
                 for lo in range(0, len(active), per):

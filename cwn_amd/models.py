@@ -185,6 +185,8 @@ class _SparseCINStack(torch.nn.Module):
             # ... and the blocks of the update / combine Linear layers (cwn_dense_stage_f32 streams them pre-split)
             sw = []
             for conv in self.convs:
+                if isinstance(conv, layers.CINppConv):
+                    continue                  # (packs its own blocks per forward, layers.CINppConv._dense_train)
                 for lvl in getattr(conv, 'mp_levels', []):
                     for net in (getattr(lvl, 'update_up_nn', None), getattr(lvl, 'update_boundaries_nn', None),
                                 getattr(lvl, 'combine_nn', None)):
