@@ -2858,6 +2858,92 @@ def test_dense_stage_kernel_vs_grouped_gemm(F, Ms):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('F,Ms,blocks', [(128, (3165, 3341, 304), 3), (128, (1, 33, 700), 4), (64, (700, 65, 2, 129), 3),
+                                         (64, (9000, 63), 4), (128, (2968, 6381, 612, 40), 4)])
+def test_dense_stage_ex_kernel_vs_float64(F, Ms, blocks):
+    """cwn_dense_stage_ex_f32 (round 4, ABI 19): Z = prologue([X | X2 | X3 (| X4)]) W^T + b with W [F, 3F] / [F, 4F] -- the
+    combine network of a CIN++ layer (mp/layers.py:260, 408-410) -- against the float64 product: the first two blocks with the
+    scale / shift prologues of cwn_dense_stage_f32, the extra blocks with ReLU or nothing in front, a LIVE BatchNorm record on
+    an extra block (its affine derived in the kernel from slot sums, written to `aff`; running statistics updated once), the
+    per-band column statistics, several products per launch, row counts that end inside a band and inside a workgroup; a launch
+    without extras falls through to the two-block kernel."""
+    from cwn_amd import ops, _ffi
+    g = torch.Generator().manual_seed(31 * F + sum(Ms) + blocks)
+    rn = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    lins = [torch.nn.Linear(blocks * F, F).to(DEV) for _ in Ms]
+    ops.pack_stage_weights_many([l.weight for l in lins])
+    gemms, refs, keep = [], [], []
+    for k, M in enumerate(Ms):
+        Xs = [rn(M, F) for _ in range(blocks)]
+        sc, sh, sc2, sh2 = rn(F).abs() + 0.5, rn(F), rn(F).abs() + 0.5, rn(F)
+        stats = torch.zeros(2, ops.stat_rows(M), F, dtype=torch.float64, device=DEV)
+        more, pro = [], []
+        for j in range(2, blocks):
+            relu = (j + k) % 2 == 0
+            live = (j == 2 and k % 2 == 0)
+            if live:
+                # a BatchNorm(train) in front of this block: slot sums of the block's own values (as the producing launch leaves them)
+                x64 = Xs[j].double()
+                slots = torch.zeros(_ffi.BN_SLOTS, 2, F, dtype=torch.float64, device=DEV)
+                parts = x64.chunk(_ffi.BN_SLOTS) if M >= _ffi.BN_SLOTS else [x64]
+                for q, part in enumerate(parts):
+                    slots[q, 0], slots[q, 1] = part.sum(0), (part * part).sum(0)
+                gamma, beta = rn(F).abs() + 0.5, rn(F)
+                rm, rv, nbt = torch.zeros(F, device=DEV), torch.ones(F, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+                aff = torch.full((4, F), float('nan'), device=DEV)
+                rec = _ffi.BnLive(slots=slots.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(), running_mean=rm.data_ptr(),
+                                  running_var=rv.data_ptr(), num_batches_tracked=nbt.data_ptr(), aff=aff.data_ptr(), eps=1e-5,
+                                  momentum=0.1)
+                mean, var = x64.mean(0), x64.var(0, unbiased=False)
+                scale = gamma.double() / torch.sqrt(var + 1e-5)
+                pro.append((scale, beta.double() - mean * scale, relu))
+                keep += [slots, gamma, beta, rm, rv, nbt, aff]
+                refs.append((k, aff, scale, mean, var, rm, rv, nbt, M))
+                more.append((Xs[j], relu, rec))
+            else:
+                pro.append((None, None, relu))
+                more.append((Xs[j], relu, None))
+        lin = lins[k]
+        gemms.append(ops.Gemm(X=Xs[0], X2=Xs[1], W=lin.weight, bias=lin.bias.detach() if k != 1 else None, in_scale=sc, in_shift=sh,
+                              in_scale2=sc2, in_shift2=sh2, in_relu=3 if k != 2 else 1, col_stats=stats, more=tuple(more)))
+        x = [(Xs[0].double() * sc.double() + sh.double()).relu()]
+        x2 = Xs[1].double() * sc2.double() + sh2.double()
+        x.append(x2.relu() if k != 2 else x2)
+        for j in range(2, blocks):
+            a, b_, relu = pro[j - 2]
+            xe = Xs[j].double() if a is None else Xs[j].double() * a + b_
+            x.append(xe.relu() if relu else xe)
+        z = torch.cat(x, 1) @ lin.weight.detach().double().t() + (lin.bias.detach().double() if k != 1 else 0.0)
+        keep.append((Xs, z, stats))
+    got = ops.run_stage(gemms, DEV)
+    assert got is not None, 'the stage kernel refused a launch it is written for'
+    torch.cuda.synchronize()
+    zs = [t[1] for t in keep if isinstance(t, tuple)]
+    for k, (gm, z) in enumerate(zip(gemms, zs)):
+        scale = max(1.0, float(z.abs().max()))
+        assert (got[k].double() - z).abs().max() <= 1e-5 * scale, (k, float((got[k].double() - z).abs().max()), scale)
+        M = z.size(0)
+        zp = torch.cat([z, z.new_zeros((-M) % 32, F)]).view(-1, 32, F)
+        want = torch.stack([zp.sum(1), (zp * zp).sum(1)])
+        assert (gm.col_stats - want).abs().max() <= 32 * 1e-6 * scale * scale, k
+    for k, aff, scale, mean, var, rm, rv, nbt, M in refs:
+        torch.testing.assert_close(aff[0].double(), scale, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(aff[2].double(), mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rm.double(), 0.1 * mean, rtol=1e-5, atol=1e-6)
+        unb = var * (M / max(M - 1, 1))
+        torch.testing.assert_close(rv.double(), 0.9 + 0.1 * unb, rtol=1e-5, atol=1e-6)
+        assert int(nbt) == 1
+    # without extra blocks the same call runs the two-block kernel
+    two = [ops.Gemm(X=gm.X, X2=gm.X2, W=torch.nn.Parameter(gm.W.detach()[:, :2 * F].contiguous()), in_relu=3) for gm in gemms]
+    ops.pack_stage_weights_many([t.W for t in two])
+    res = ops.run_stage(two, DEV)
+    assert res is not None
+    for t, r in zip(two, res):
+        z = torch.cat([t.X.double().relu(), t.X2.double().relu()], 1) @ t.W.detach().double().t()
+        assert (r.double() - z).abs().max() <= 1e-5 * max(1.0, float(z.abs().max()))
+
+
+@pytest.mark.gpu
 def test_packing_many_stage_blocks_equals_one_by_one():
     from cwn_amd import ops
     torch.manual_seed(3)
