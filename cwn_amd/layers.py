@@ -1303,10 +1303,9 @@ class CINppConv(SparseCINConv):
                 eps=eps, train_eps=train_eps, feed_down_attr=feed_down_attr,
                 update_coboundaries_nn=_update_mlp(ld, hid, graph_norm, act) if coboundary_stream else None))
 
-    # The blocked layer kernel and the grouped update / combine launches are built for SparseCINConv's two streams
-    # (upper + boundary, a 2F-wide combine): CIN++ takes the grouped message GEMM + ONE aggregation launch for the
-    # three (four) streams of all dimensions -- one autograd node in training (ops.gemm_aggregate) -- and its update /
-    # combine networks as torch modules.
+    # The blocked layer kernel and cwn_update_mlp_f32 are built for SparseCINConv's two streams (upper + boundary, a 2F-wide
+    # combine): CIN++ takes the grouped message GEMM + ONE aggregation launch for the three (four) streams of all dimensions
+    # -- one autograd node in training (ops.gemm_aggregate) -- and its dense networks through _dense_eval / _dense_train.
     def _propagate_blocked(self, cochain_params, start_to_process):
         self.blocked_reason = 'CIN++: three streams per dimension (the blocked kernel has two)'
         return None
