@@ -400,6 +400,10 @@ class _CINppLayers:
             use_coboundaries=use_coboundaries)
 
 
+class CINpp(_CINppLayers, SparseCIN):
+    """mp/models.py:259-284: the SparseCIN stack over CINppConv layers (features used as given)."""
+
+
 class EmbedCINpp(_CINppLayers, EmbedSparseCIN):
     """mp/molec_models.py:167-199: EmbedSparseCIN with CINppConv layers.  As in the reference the lower stream stays off
     (the forward asks for include_down_features=False and CINppCochainConv.forward passes no down_attr); the

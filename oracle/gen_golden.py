@@ -509,6 +509,32 @@ def cinpp_models():
     out['ogb/out'] = np_(y)
     for k, v in res.items():
         out[f'ogb/{k}'] = np_(v)
+    # mp/models.py:259-284: CINpp, the SparseCIN stack (features as given, JK cat) over CINppConv layers; no coboundary
+    # features in the messages (msg networks = first operand), eval and training mode
+    from mp.models import CINpp
+    torch.manual_seed(43)
+    b = ComplexBatch.from_complex_list([get(n) for n in TESTING_LIST], max_dim=2)
+    model = CINpp(1, 2, 2, 16, dropout_rate=0.0, max_dim=2, jump_mode='cat', nonlinearity='relu', readout='sum',
+                  train_eps=True, use_coboundaries=False, graph_norm='bn', final_readout='sum')
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(generator=gen)
+                m.running_var.uniform_(0.5, 1.5, generator=gen)
+        for n, p in model.named_parameters():
+            if '.eps' in n:
+                p.copy_(torch.rand(1, generator=gen) * 0.5)
+    out.update(state_np(model, 'plain/state'))
+    for d in range(3):
+        out[f'plain/x/{d}'] = np_(b.cochains[d].x)
+    for mode in ('eval', 'train'):
+        model.train(mode == 'train')
+        bb = ComplexBatch.from_complex_list([get(n) for n in TESTING_LIST], max_dim=2)
+        with torch.no_grad():
+            y, res = model(bb, include_partial=True)
+        out[f'plain/{mode}/out'] = np_(y)
+        for k, v in res.items():
+            out[f'plain/{mode}/{k}'] = np_(v)
     save('embed_cinpp.npz', out)
 
 

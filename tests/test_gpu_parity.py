@@ -691,6 +691,27 @@ def test_embed_cinpp_whole_stack_golden(tag):
         gate(y, T(g[f'{tag}/{mode}/out']), f'{tag} {mode} grad={grad} out')
 
 
+def test_plain_cinpp_golden():
+    """CINpp (mp/models.py:259-284: the SparseCIN stack over CINppConv layers, features as given, messages = the first
+    operand, JK cat) with the reference's state_dict against the reference's outputs, eval and training mode (with and without
+    autograd recording)."""
+    from cwn_amd.models import CINpp
+    g = load('embed_cinpp.npz')
+    model = CINpp(1, 2, 2, 16, dropout_rate=0.0, max_dim=2, jump_mode='cat', nonlinearity='relu', readout='sum', train_eps=True,
+                  use_coboundaries=False, graph_norm='bn', final_readout='sum')
+    for mode, grad in (('eval', False), ('train', False), ('train', True)):
+        model.load_state_dict(state_dict(g, 'plain/state'))
+        model = model.to(DEV).train(mode == 'train')
+        b = dummy_batch(list_names('testing'), max_dim=2)
+        for d in range(3):
+            b.cochains[d].x = T(g[f'plain/x/{d}'])
+        with torch.set_grad_enabled(grad):
+            y, res = model(b.to(DEV), include_partial=True)
+        for k, v in res.items():
+            gate(v, T(g[f'plain/{mode}/{k}']), f'CINpp {mode} grad={grad} {k}')
+        gate(y, T(g[f'plain/{mode}/out']), f'CINpp {mode} grad={grad} out')
+
+
 def test_ogb_embed_cinpp_golden():
     """OGBEmbedCINpp (mp/molec_models.py:355-384) with the reference's state_dict against the reference's outputs."""
     from cwn_amd.models import OGBEmbedCINpp

@@ -340,3 +340,18 @@ def test_ogb_embed_cinpp_golden():
     for k, v in partial.items():
         torch.testing.assert_close(v, T(g[f'ogb/{k}']), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(y, T(g['ogb/out']), rtol=1e-4, atol=1e-4)
+
+
+def test_plain_cinpp_golden():
+    """CINpp (mp/models.py:259-284: features as given, messages without coboundary features, JK cat) -- oracle vs the reference."""
+    g = load('embed_cinpp.npz')
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/testing']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    for d in range(3):
+        cx['cochains'][d]['x'] = T(g[f'plain/x/{d}'])
+    for mode in ('eval', 'train'):
+        y, partial = O.sparse_cin_model_forward(state_dict(g, 'plain/state'), cx, 2, use_coboundaries=False, norm='bn',
+                                                jump_mode='cat', embed=None, training=(mode == 'train'), conv='cinpp')
+        for k, v in partial.items():
+            torch.testing.assert_close(v, T(g[f'plain/{mode}/{k}']), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(y, T(g[f'plain/{mode}/out']), rtol=1e-4, atol=1e-4)
