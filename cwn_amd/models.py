@@ -14,9 +14,10 @@ import torch.nn.functional as F
 from torch.nn import BatchNorm1d as BN, Embedding, Identity, LayerNorm as LN, Linear
 
 from . import layers, ops
+from .layers import reset as reset_net
 from .complex import ComplexBatch
 from .csr import cached_adjacency
-from .layers import EmbedVEWithReduce, InitReduceConv, SparseCINConv
+from .layers import CINConv, EdgeCINConv, EmbedVEWithReduce, InitReduceConv, SparseCINConv
 
 
 def get_nonlinearity(nonlinearity, return_module=True):
@@ -412,3 +413,119 @@ class EmbedCINpp(_CINppLayers, EmbedSparseCIN):
 
 class OGBEmbedCINpp(_CINppLayers, OGBEmbedSparseCIN):
     """mp/molec_models.py:355-384."""
+
+
+# ------------------------------------------------------------------------------------------------
+# CIN0 / EdgeCIN0 (mp/models.py:12-109, 286-420): the dense-CIN stacks -- every adjacency entry carries a message network
+# Linear(2F -> F) -> act -> BatchNorm (layers.CINConv / EdgeCINConv: the fused per-entry form, training included), one update
+# network per dimension, the per-dimension readouts summed, lin1 -> act -> dropout -> lin2
+# ------------------------------------------------------------------------------------------------
+class _CIN0Stack(torch.nn.Module):
+    max_dim: int
+
+    @staticmethod
+    def _entry_net(k_in, width, act):
+        return torch.nn.Sequential(Linear(k_in, width), act(), BN(width))
+
+    @staticmethod
+    def _update_net(k_in, hidden, act):
+        return torch.nn.Sequential(Linear(k_in, hidden), act(), Linear(hidden, hidden), act(), BN(hidden))
+
+    def _finish_init(self, num_classes, num_layers, hidden, dropout_rate, jump_mode, nonlinearity, readout):
+        if jump_mode not in (None, 'cat', 'max'):
+            raise NotImplementedError("jump_mode must be None, 'cat' or 'max'")
+        self.dropout_rate, self.jump_mode, self.nonlinearity, self.readout = dropout_rate, jump_mode, nonlinearity, readout
+        self.lin1 = Linear(num_layers * hidden if jump_mode == 'cat' else hidden, hidden)
+        self.lin2 = Linear(hidden, num_classes)
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+        self.lin1.reset_parameters()
+        self.lin2.reset_parameters()
+
+    def _after_conv(self, data: ComplexBatch, c: int, xs):
+        data.set_xs(xs)
+
+    def _params(self, data: ComplexBatch):
+        return data.get_all_cochain_params(max_dim=self.max_dim)
+
+    def forward(self, data: ComplexBatch):
+        act = get_nonlinearity(self.nonlinearity, return_module=False)
+        xs, kept = None, None
+        for c, conv in enumerate(self.convs):
+            xs = conv(*self._params(data))
+            self._after_conv(data, c, xs)
+            if self.jump_mode is not None:
+                kept = [[] for _ in xs] if kept is None else kept
+                for i, x in enumerate(xs):
+                    kept[i].append(x)
+        if self.jump_mode == 'cat':
+            xs = [torch.cat(k, dim=-1) for k in kept]
+        elif self.jump_mode == 'max':
+            xs = [torch.stack(k, dim=-1).max(dim=-1)[0] for k in kept]
+        pooled = pool_complex_list(xs, data, self.max_dim, self.readout)     # absent dimensions: zero rows (mp/models.py:71-74)
+        x = pooled[0]
+        for t in pooled[1:]:
+            x = x + t
+        x = act(self.lin1(x))
+        x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        return self.lin2(x)
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+class CIN0(_CIN0Stack):
+    """mp/models.py:12-109: a cellular GIN over upper AND lower adjacencies (CINConv), all dimensions."""
+
+    def __init__(self, num_input_features, num_classes, num_layers, hidden, dropout_rate: float = 0.5, max_dim: int = 2,
+                 jump_mode=None, nonlinearity='relu', readout='sum'):
+        super().__init__()
+        self.max_dim = max_dim
+        act = get_nonlinearity(nonlinearity, return_module=True)
+        self.convs = torch.nn.ModuleList()
+        for i in range(num_layers):
+            w = num_input_features if i == 0 else hidden
+            update, up, down = self._update_net(w, hidden, act), self._entry_net(2 * w, w, act), self._entry_net(2 * w, w, act)
+            self.convs.append(CINConv(w, w, up, down, update, train_eps=False, max_dim=max_dim))
+        self._finish_init(num_classes, num_layers, hidden, dropout_rate, jump_mode, nonlinearity, readout)
+
+
+class EdgeCIN0(_CIN0Stack):
+    """mp/models.py:286-420: CIN0 up to the edges; the two-cell features ride along as the edges' upper attributes
+    (`include_top_features`) and are updated by a network of their own between layers (`update_top_features`)."""
+
+    def __init__(self, num_input_features, num_classes, num_layers, hidden, dropout_rate: float = 0.5, jump_mode=None,
+                 nonlinearity='relu', include_top_features=True, update_top_features=True, readout='sum'):
+        super().__init__()
+        self.max_dim = 1
+        self.include_top_features = include_top_features
+        self.update_top_features = include_top_features and update_top_features
+        act = get_nonlinearity(nonlinearity, return_module=True)
+        self.convs = torch.nn.ModuleList()
+        self.update_top_nns = torch.nn.ModuleList()
+        for i in range(num_layers):
+            w = num_input_features if i == 0 else hidden
+            v_update, e_update = self._update_net(w, hidden, act), self._update_net(w, hidden, act)
+            v_up, e_down = self._entry_net(2 * w, w, act), self._entry_net(2 * w, w, act)
+            e_up = self._entry_net(2 * w if include_top_features else w, w, act)
+            self.convs.append(EdgeCINConv(w, w, v_up, e_down, e_up, v_update, e_update, train_eps=False))
+            if self.update_top_features and i < num_layers - 1:
+                self.update_top_nns.append(self._update_net(w, hidden, act))
+        self._finish_init(num_classes, num_layers, hidden, dropout_rate, jump_mode, nonlinearity, readout)
+
+    def reset_parameters(self):
+        super().reset_parameters()
+        for net in self.update_top_nns:
+            reset_net(net)
+
+    def _params(self, data: ComplexBatch):
+        return data.get_all_cochain_params(max_dim=self.max_dim, include_top_features=self.include_top_features)
+
+    def _after_conv(self, data: ComplexBatch, c: int, xs):
+        # (not behind the last layer; only where the batch has two-cells: mp/models.py:388-394)
+        if self.update_top_features and c < len(self.convs) - 1 and 2 in data.cochains:
+            data.set_xs(list(xs) + [self.update_top_nns[c](data.cochains[2].x)])
+        else:
+            data.set_xs(xs)

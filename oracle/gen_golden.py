@@ -378,8 +378,8 @@ def edge_and_oriented():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'edge_oriented':
         edge_and_oriented()         # the round-3 fixture alone (the others stay byte-identical)
-    elif len(sys.argv) > 1 and sys.argv[1] == 'cinpp':
-        pass                        # the round-4 fixture alone (written at the end of this file)
+    elif len(sys.argv) > 1 and sys.argv[1] in ('cinpp', 'cin0'):
+        pass                        # a round-4 fixture alone (written at the end of this file)
     else:
         main()
         edge_and_oriented()
@@ -538,10 +538,50 @@ def cinpp_models():
     save('embed_cinpp.npz', out)
 
 
+def cin0_models():
+    """Round 4: CIN0 and EdgeCIN0 (mp/models.py:12-109, 286-420) on the testing batch -> cin0_models.npz: state, inputs, the
+    prediction in eval and training mode (BatchNorm over the adjacency ENTRIES in the message networks)."""
+    from mp.models import CIN0, EdgeCIN0
+    out = {}
+    gen = torch.Generator().manual_seed(23)
+    F = 8
+
+    def run(tag, model, max_dim):
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.normal_(generator=gen)
+                    m.running_var.uniform_(0.5, 1.5, generator=gen)
+        out.update(state_np(model, f'{tag}/state'))
+        b = ComplexBatch.from_complex_list([get(n) for n in TESTING_LIST], max_dim=2)
+        randomize_features(b, F, torch.Generator().manual_seed(5))
+        for d in range(3):
+            out[f'{tag}/x/{d}'] = np_(b.cochains[d].x)
+        for mode in ('eval', 'train'):
+            model.train(mode == 'train')
+            bb = ComplexBatch.from_complex_list([get(n) for n in TESTING_LIST], max_dim=2)
+            randomize_features(bb, F, torch.Generator().manual_seed(5))
+            with torch.no_grad():
+                out[f'{tag}/{mode}/out'] = np_(model(bb))
+
+    torch.manual_seed(51)
+    run('cin0', CIN0(F, 3, 2, 12, dropout_rate=0.0, max_dim=2, jump_mode='cat', nonlinearity='relu', readout='sum'), 2)
+    torch.manual_seed(52)
+    run('edge', EdgeCIN0(F, 3, 3, 12, dropout_rate=0.0, jump_mode=None, nonlinearity='relu', include_top_features=True,
+                         update_top_features=True, readout='mean'), 1)
+    torch.manual_seed(53)
+    run('edge_notop', EdgeCIN0(F, 3, 2, 12, dropout_rate=0.0, jump_mode=None, nonlinearity='relu', include_top_features=False,
+                               readout='sum'), 1)
+    save('cin0_models.npz', out)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'cinpp':
+    if len(sys.argv) > 1 and sys.argv[1] == 'cin0':
+        cin0_models()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'cinpp':
         cinpp_models()
     elif os.environ.get('CWN_GOLDEN_EXTRA', '1') == '1':
         extra_models()
         if len(sys.argv) == 1:
             cinpp_models()
+            cin0_models()

@@ -712,6 +712,33 @@ def test_plain_cinpp_golden():
         gate(y, T(g[f'plain/{mode}/out']), f'CINpp {mode} grad={grad} out')
 
 
+@pytest.mark.parametrize('tag', ['cin0', 'edge', 'edge_notop'])
+def test_cin0_and_edge_cin0_golden(tag):
+    """CIN0 / EdgeCIN0 (mp/models.py:12-109, 286-420: the dense-CIN stacks over CINConv / EdgeCINConv) with the REFERENCE's
+    state_dict against the reference's own predictions (oracle/gen_golden.py cin0): eval, training mode (BatchNorm over the
+    adjacency entries), and training mode with autograd recording -- the fused per-entry training form of the layers."""
+    from cwn_amd.models import CIN0, EdgeCIN0
+    g = load('cin0_models.npz')
+    F = 8
+    if tag == 'cin0':
+        model = CIN0(F, 3, 2, 12, dropout_rate=0.0, max_dim=2, jump_mode='cat', nonlinearity='relu', readout='sum')
+    elif tag == 'edge':
+        model = EdgeCIN0(F, 3, 3, 12, dropout_rate=0.0, jump_mode=None, nonlinearity='relu', include_top_features=True,
+                         update_top_features=True, readout='mean')
+    else:
+        model = EdgeCIN0(F, 3, 2, 12, dropout_rate=0.0, jump_mode=None, nonlinearity='relu', include_top_features=False,
+                         readout='sum')
+    for mode, grad in (('eval', False), ('train', False), ('train', True)):
+        model.load_state_dict(state_dict(g, f'{tag}/state'))
+        model = model.to(DEV).train(mode == 'train')
+        b = dummy_batch(list_names('testing'), max_dim=2)
+        for d in range(3):
+            b.cochains[d].x = T(g[f'{tag}/x/{d}'])
+        with torch.set_grad_enabled(grad):
+            y = model(b.to(DEV))
+        gate(y, T(g[f'{tag}/{mode}/out']), f'{tag} {mode} grad={grad}')
+
+
 def test_ogb_embed_cinpp_golden():
     """OGBEmbedCINpp (mp/molec_models.py:355-384) with the reference's state_dict against the reference's outputs."""
     from cwn_amd.models import OGBEmbedCINpp
