@@ -219,8 +219,21 @@ class CochainBatch(Cochain):
         dim = data_list[0].dim
         n_here = [c.num_cells for c in data_list]
         inc_here = [n or 0 for n in n_here]
-        inc_down = [(c.num_cells_down or 0) if dim > 0 else 0 for c in data_list]
-        inc_up = [c.num_cells_up or 0 for c in data_list]
+        # (the reference asks for an increment only when the key it offsets is present, data/complex.py:344-369: a cochain of
+        #  edges with adjacencies but no shared cells / boundaries -- mp/models.py EdgeOrient's input -- batches without them)
+        def below(c):
+            if dim == 0:
+                return 0
+            if c.shared_boundaries is None and c.boundary_index is None and c.__num_cells_down__ is None:
+                return 0
+            return c.num_cells_down or 0
+
+        def above(c):
+            if c.shared_coboundaries is None and c.__num_cells_up__ is None:
+                return 0
+            return c.num_cells_up or 0
+        inc_down = [below(c) for c in data_list]
+        inc_up = [above(c) for c in data_list]
         off_here, off_down, off_up = _offsets(inc_here), _offsets(inc_down), _offsets(inc_up)
 
         out = cls(dim)

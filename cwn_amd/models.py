@@ -529,3 +529,82 @@ class EdgeCIN0(_CIN0Stack):
             data.set_xs(list(xs) + [self.update_top_nns[c](data.cochains[2].x)])
         else:
             data.set_xs(xs)
+
+
+class Dummy(torch.nn.Module):
+    """mp/models.py:422-473: parameter-free layers (DummyCellularMessagePassing), the per-dimension readouts summed, one Linear."""
+
+    def __init__(self, num_input_features, num_classes, num_layers, max_dim: int = 2, readout='sum'):
+        super().__init__()
+        self.max_dim, self.readout = max_dim, readout
+        self.convs = torch.nn.ModuleList(layers.DummyCellularMessagePassing(max_dim=max_dim) for _ in range(num_layers))
+        self.lin = Linear(num_input_features, num_classes)
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+
+    def forward(self, data: ComplexBatch):
+        xs = None
+        for conv in self.convs:
+            xs = conv(*data.get_all_cochain_params())
+            data.set_xs(xs)
+        pooled = pool_complex_list(xs, data, self.max_dim, self.readout)
+        x = pooled[0]
+        for t in pooled[1:]:
+            x = x + t
+        return self.lin(x)
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+class EdgeOrient(torch.nn.Module):
+    """mp/models.py:476-546: edge signals under a choice of edge orientations -- L x OrientedConv (bias-free update maps: the
+    layers stay equivariant), |.| for invariance, readout over the edges of each complex, lin1 -> ReLU -> dropout -> lin2.
+    `data` is a CochainBatch of edges with `upper_orient` / `lower_orient`."""
+
+    def __init__(self, num_input_features, num_classes, num_layers, hidden, dropout_rate: float = 0.0, jump_mode=None,
+                 nonlinearity='id', readout='sum', fully_invar=False):
+        super().__init__()
+        self.max_dim = 1
+        self.fully_invar, self.dropout_rate, self.jump_mode = fully_invar, dropout_rate, jump_mode
+        self.nonlinearity, self.readout = nonlinearity, readout
+        if readout not in ('sum', 'mean'):
+            raise NotImplementedError(f'Readout {readout} is not currently supported.')
+        self.convs = torch.nn.ModuleList()
+        for i in range(num_layers):
+            w = num_input_features if i == 0 else hidden
+            self.convs.append(layers.OrientedConv(
+                dim=1, up_msg_size=w, down_msg_size=w, update_up_nn=Linear(w, hidden, bias=False),
+                update_down_nn=Linear(w, hidden, bias=False), update_nn=Linear(w, hidden, bias=False),
+                act_fn=get_nonlinearity(nonlinearity, return_module=False), orient=not fully_invar))
+        self.lin1 = Linear(hidden, hidden)
+        self.lin2 = Linear(hidden, num_classes)
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+        self.lin1.reset_parameters()
+        self.lin2.reset_parameters()
+
+    def forward(self, data, include_partial=False):
+        if self.fully_invar:
+            data.x = torch.abs(data.x)
+        x = data.x
+        for conv in self.convs:
+            x = conv(data)
+            data.x = x
+        cell_pred = x
+        if not self.fully_invar:
+            x = torch.abs(x)
+        n = getattr(data, 'num_cochains', None)
+        if n is None:
+            n = int(data.batch.max()) + 1
+        x = global_pool(x, data.batch, int(n), mean=self.readout == 'mean')
+        x = torch.relu(self.lin1(x))
+        x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        x = self.lin2(x)
+        return (x, cell_pred) if include_partial else x
+
+    def __repr__(self):
+        return self.__class__.__name__

@@ -572,6 +572,42 @@ def cin0_models():
     torch.manual_seed(53)
     run('edge_notop', EdgeCIN0(F, 3, 2, 12, dropout_rate=0.0, jump_mode=None, nonlinearity='relu', include_top_features=False,
                                readout='sum'), 1)
+    # Dummy (mp/models.py:422-473) on the testing batch, features as the dummy complexes carry them
+    from mp.models import Dummy, EdgeOrient
+    from data.complex import Cochain, CochainBatch
+    torch.manual_seed(54)
+    model = Dummy(1, 3, 2, max_dim=2, readout='sum')
+    out.update(state_np(model, 'dummy/state'))
+    b = ComplexBatch.from_complex_list([get(n) for n in TESTING_LIST], max_dim=2)
+    for d in range(3):
+        out[f'dummy/x/{d}'] = np_(b.cochains[d].x)
+    with torch.no_grad():
+        out['dummy/out'] = np_(model(b))
+    # EdgeOrient (mp/models.py:476-546) on a CochainBatch of edges with random orientations: both forms
+    edges = []
+    for name in ('house', 'kite', 'pyramid', 'bridged', 'square_dot'):
+        e = get(name).cochains[1]
+        n_up = 0 if e.upper_index is None else e.upper_index.size(1)
+        n_dn = 0 if e.lower_index is None else e.lower_index.size(1)
+        c = Cochain(dim=1, x=torch.randn(e.num_cells, F, generator=gen),
+                    upper_index=e.upper_index if e.upper_index is not None else torch.zeros(2, 0, dtype=torch.long),
+                    lower_index=e.lower_index if e.lower_index is not None else torch.zeros(2, 0, dtype=torch.long),
+                    upper_orient=torch.where(torch.rand(n_up, generator=gen) > 0.5, 1.0, -1.0),
+                    lower_orient=torch.where(torch.rand(n_dn, generator=gen) > 0.5, 1.0, -1.0))
+        edges.append(c)
+    for k, c in enumerate(edges):
+        for key in ('x', 'upper_index', 'lower_index', 'upper_orient', 'lower_orient'):
+            out[f'orient/edges/{k}/{key}'] = np_(getattr(c, key))
+    out['orient/n'] = np.int64(len(edges))
+    for tag, invar, act in (('orient', False, 'id'), ('orient_invar', True, 'relu')):
+        torch.manual_seed(55)
+        model = EdgeOrient(F, 2, 2, 12, dropout_rate=0.0, nonlinearity=act, readout='sum', fully_invar=invar)
+        out.update(state_np(model, f'{tag}/state'))
+        data = CochainBatch.from_cochain_list([Cochain(dim=1, **{key: getattr(c, key).clone() for key in
+                                               ('x', 'upper_index', 'lower_index', 'upper_orient', 'lower_orient')}) for c in edges])
+        with torch.no_grad():
+            y, cells = model(data, include_partial=True)
+        out[f'{tag}/out'], out[f'{tag}/cells'] = np_(y), np_(cells)
     save('cin0_models.npz', out)
 
 

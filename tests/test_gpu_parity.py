@@ -739,6 +739,37 @@ def test_cin0_and_edge_cin0_golden(tag):
         gate(y, T(g[f'{tag}/{mode}/out']), f'{tag} {mode} grad={grad}')
 
 
+def test_dummy_and_edge_orient_models_golden():
+    """Dummy (mp/models.py:422-473) and EdgeOrient (:476-546: OrientedConv layers on a CochainBatch of edges with random
+    orientations; the equivariant form with |.| behind the layers and the fully invariant form with |.| in front) with the
+    reference's state_dict against the reference's outputs -- predictions and the per-edge values."""
+    from cwn_amd.complex import Cochain, CochainBatch
+    from cwn_amd.models import Dummy, EdgeOrient
+    g = load('cin0_models.npz')
+    model = Dummy(1, 3, 2, max_dim=2, readout='sum')
+    model.load_state_dict(state_dict(g, 'dummy/state'))
+    b = dummy_batch(list_names('testing'), max_dim=2)
+    for d in range(3):
+        b.cochains[d].x = T(g[f'dummy/x/{d}'])
+    with torch.no_grad():
+        gate(model.to(DEV)(b.to(DEV)), T(g['dummy/out']), 'Dummy')
+    keys = ('x', 'upper_index', 'lower_index', 'upper_orient', 'lower_orient')
+    for tag, invar, act in (('orient', False, 'id'), ('orient_invar', True, 'relu')):
+        model = EdgeOrient(8, 2, 2, 12, dropout_rate=0.0, nonlinearity=act, readout='sum', fully_invar=invar)
+        model.load_state_dict(state_dict(g, f'{tag}/state'))
+        model = model.to(DEV).eval()
+        edges = [Cochain(dim=1, **{k: T(g[f'orient/edges/{i}/{k}']) for k in keys}) for i in range(int(g['orient/n']))]
+        data = CochainBatch.from_cochain_list(edges)
+        for k in keys + ('batch',):
+            setattr(data, k, getattr(data, k).to(DEV))
+        for grad in (False, True):
+            data.x = torch.cat([e.x for e in edges]).to(DEV)
+            with torch.set_grad_enabled(grad):
+                y, cells = model(data, include_partial=True)
+            gate(cells, T(g[f'{tag}/cells']), f'EdgeOrient[{tag}] per-edge values (grad={grad})')
+            gate(y, T(g[f'{tag}/out']), f'EdgeOrient[{tag}] prediction (grad={grad})')
+
+
 def test_ogb_embed_cinpp_golden():
     """OGBEmbedCINpp (mp/molec_models.py:355-384) with the reference's state_dict against the reference's outputs."""
     from cwn_amd.models import OGBEmbedCINpp
