@@ -164,6 +164,9 @@ class _SparseCINStack(torch.nn.Module):
 
     conv_dropout = False       # OGBEmbedSparseCIN drops out after every conv (:298-300)
 
+    def _edit_params(self, params):
+        return params              # (EmbedSparseCINNoRings drops the edges' upper adjacency)
+
     def _make_conv(self, layer_dim, hidden, act_module, train_eps, use_coboundaries):
         return SparseCINConv(
             up_msg_size=layer_dim, down_msg_size=layer_dim, boundary_msg_size=layer_dim,
@@ -198,7 +201,7 @@ class _SparseCINStack(torch.nn.Module):
             if sw:
                 ops.pack_stage_weights_many(sw)
         for c, conv in enumerate(self.convs):
-            params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
+            params = self._edit_params(data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False))
             xs = conv(*params, start_to_process=0)
             if self.conv_dropout:
                 xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
@@ -351,11 +354,31 @@ class EmbedSparseCIN(_SparseCINStack):
         assert data.cochains[0].x.size(-1) == 1
         if 1 in data.cochains and data.cochains[1].x is not None:
             assert data.cochains[1].x.size(-1) == 1
-        params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
+        params = self._edit_params(data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False))
         xs = list(self.init_conv(*params))
         xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
         data.set_xs(xs)
         return self._convs_and_head(data, include_partial, {})
+
+
+class EmbedSparseCINNoRings(EmbedSparseCIN):
+    """mp/molec_models.py:386-503: the same stack on vertices and edges only -- max_dim 1, and the edges' upper adjacency (the
+    rings they bound) dropped from every layer's parameters (:456-457, 471-472)."""
+
+    def __init__(self, atom_types, bond_types, out_size, num_layers, hidden, dropout_rate: float = 0.5, nonlinearity='relu',
+                 readout='sum', train_eps=False, final_hidden_multiplier: int = 2, final_readout='sum',
+                 apply_dropout_before='lin2', init_reduce='sum', embed_edge=False, embed_dim=None, use_coboundaries=False,
+                 graph_norm='bn'):
+        super().__init__(atom_types, bond_types, out_size, num_layers, hidden, dropout_rate=dropout_rate, max_dim=1,
+                         jump_mode=None, nonlinearity=nonlinearity, readout=readout, train_eps=train_eps,
+                         final_hidden_multiplier=final_hidden_multiplier, readout_dims=(0, 1), final_readout=final_readout,
+                         apply_dropout_before=apply_dropout_before, init_reduce=init_reduce, embed_edge=embed_edge,
+                         embed_dim=embed_dim, use_coboundaries=use_coboundaries, graph_norm=graph_norm)
+
+    def _edit_params(self, params):
+        if len(params) > 1:
+            params[1].up_index = None
+        return params
 
 
 class OGBEmbedSparseCIN(_SparseCINStack):

@@ -473,17 +473,26 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
                              use_coboundaries: bool = True, readout: str = 'sum',
                              final_readout: str = 'sum', training: bool = False, norm: str = 'bn',
                              jump_mode: Optional[str] = None, embed: Optional[str] = 'zinc',
-                             init_reduce_mode: str = 'add', readout_dims=(0, 1, 2), conv: str = 'sparse_cin'):
+                             init_reduce_mode: str = 'add', readout_dims=(0, 1, 2), conv: str = 'sparse_cin',
+                             drop_edge_up: bool = False):
     """SparseCIN.forward (mp/models.py:195-260), EmbedSparseCIN.forward (mp/molec_models.py:90-160)
     and OGBEmbedSparseCIN.forward (mp/molec_models.py:281-350) with dropout off and jump_mode in
     {None, 'cat', 'max'}.  `embed`: None (features used as they are), 'zinc' (one Embedding per dimension
     0/1) or 'ogb' (sum of per-column embeddings).  `conv='cinpp'`: EmbedCINpp / OGBEmbedCINpp (mp/molec_models.py:167-199,
-    355-384: the same forward over CINppConv layers).  Returns (out, per-layer / pooled tensors)."""
+    355-384: the same forward over CINppConv layers).  `drop_edge_up` (with max_dim 1): EmbedSparseCINNoRings
+    (mp/molec_models.py:386-503: the edges' upper adjacency is removed from every layer's parameters, :456-457, 471-472).
+    Returns (out, per-layer / pooled tensors)."""
     cx = {'dimension': cx['dimension'], 'y': cx.get('y'), 'num_complexes': cx.get('num_complexes'),
           'cochains': [dict(c) for c in cx['cochains']]}
     partial = {}
-    if embed is not None:
+    def layer_params():
         params = all_cochain_params(cx, max_dim=max_dim, include_down_features=False)
+        if drop_edge_up and len(params) > 1:
+            params[1]['up_index'] = None
+        return params
+
+    if embed is not None:
+        params = layer_params()
         if embed == 'zinc':
             xs = embed_ve_with_reduce(state['v_embed_init.weight'], state.get('e_embed_init.weight'),
                                       params, init_reduce_mode)
@@ -502,7 +511,7 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
             cx['cochains'][d]['x'] = x
     jump = None
     for l in range(num_layers):
-        params = all_cochain_params(cx, max_dim=max_dim, include_down_features=False)
+        params = layer_params()
         pre = f'convs.{l}.'
         lstate = {k[len(pre):]: v for k, v in state.items() if k.startswith(pre)}
         xs = sparse_cin_conv(lstate, params, use_coboundaries, training, norm, conv=conv)

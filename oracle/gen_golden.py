@@ -378,7 +378,7 @@ def edge_and_oriented():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'edge_oriented':
         edge_and_oriented()         # the round-3 fixture alone (the others stay byte-identical)
-    elif len(sys.argv) > 1 and sys.argv[1] in ('cinpp', 'cin0'):
+    elif len(sys.argv) > 1 and sys.argv[1] in ('cinpp', 'cin0', 'no_rings'):
         pass                        # a round-4 fixture alone (written at the end of this file)
     else:
         main()
@@ -538,6 +538,37 @@ def cinpp_models():
     save('embed_cinpp.npz', out)
 
 
+def no_rings_model():
+    """Round 4: EmbedSparseCINNoRings (mp/molec_models.py:386-503) on the molecule list -> no_rings.npz."""
+    from mp.molec_models import EmbedSparseCINNoRings
+    out = {}
+    gen = torch.Generator().manual_seed(29)
+    torch.manual_seed(61)
+    cxs = [get(n) for n in MOL_LIST]
+    for cx in cxs:
+        cx.cochains[0]._Cochain__x = torch.randint(0, 28, (cx.cochains[0].num_cells, 1), generator=gen).float()
+        if cx.dimension >= 1:
+            cx.cochains[1]._Cochain__x = torch.randint(0, 4, (cx.cochains[1].num_cells, 1), generator=gen).float()
+        if cx.dimension >= 2:
+            cx.cochains[2]._Cochain__x = None
+    model = EmbedSparseCINNoRings(28, 4, 1, 2, 16, dropout_rate=0.0, nonlinearity='relu', readout='sum', train_eps=False,
+                                  final_hidden_multiplier=2, final_readout='sum', init_reduce='sum', embed_edge=True,
+                                  use_coboundaries=True, graph_norm='bn')
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(generator=gen)
+                m.running_var.uniform_(0.5, 1.5, generator=gen)
+    out.update(state_np(model, 'state'))
+    b = ComplexBatch.from_complex_list(cxs, max_dim=2)
+    out['v_types'], out['e_types'] = np_(b.cochains[0].x), np_(b.cochains[1].x)
+    for mode in ('eval', 'train'):
+        model.train(mode == 'train')
+        with torch.no_grad():
+            out[f'{mode}/out'] = np_(model(ComplexBatch.from_complex_list(cxs, max_dim=2)))
+    save('no_rings.npz', out)
+
+
 def cin0_models():
     """Round 4: CIN0 and EdgeCIN0 (mp/models.py:12-109, 286-420) on the testing batch -> cin0_models.npz: state, inputs, the
     prediction in eval and training mode (BatchNorm over the adjacency ENTRIES in the message networks)."""
@@ -612,7 +643,9 @@ def cin0_models():
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'cin0':
+    if len(sys.argv) > 1 and sys.argv[1] == 'no_rings':
+        no_rings_model()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'cin0':
         cin0_models()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cinpp':
         cinpp_models()
@@ -621,3 +654,4 @@ if __name__ == '__main__':
         if len(sys.argv) == 1:
             cinpp_models()
             cin0_models()
+            no_rings_model()

@@ -770,6 +770,25 @@ def test_dummy_and_edge_orient_models_golden():
             gate(y, T(g[f'{tag}/out']), f'EdgeOrient[{tag}] prediction (grad={grad})')
 
 
+def test_embed_sparse_cin_no_rings_golden():
+    """EmbedSparseCINNoRings (mp/molec_models.py:386-503) with the reference's state_dict against the reference's predictions:
+    eval, training mode, training mode with autograd recording."""
+    from cwn_amd.models import EmbedSparseCINNoRings
+    g = load('no_rings.npz')
+    model = EmbedSparseCINNoRings(28, 4, 1, 2, 16, dropout_rate=0.0, nonlinearity='relu', readout='sum', train_eps=False,
+                                  final_hidden_multiplier=2, final_readout='sum', init_reduce='sum', embed_edge=True,
+                                  use_coboundaries=True, graph_norm='bn')
+    for mode, grad in (('eval', False), ('train', False), ('train', True)):
+        model.load_state_dict(state_dict(g, 'state'))
+        model = model.to(DEV).train(mode == 'train')
+        b = dummy_batch(list_names('mol'), max_dim=2)
+        b.cochains[0].x, b.cochains[1].x = T(g['v_types']), T(g['e_types'])
+        b.cochains[2]._x = None
+        with torch.set_grad_enabled(grad):
+            y = model(b.to(DEV))
+        gate(y, T(g[f'{mode}/out']), f'EmbedSparseCINNoRings {mode} grad={grad}')
+
+
 def test_ogb_embed_cinpp_golden():
     """OGBEmbedCINpp (mp/molec_models.py:355-384) with the reference's state_dict against the reference's outputs."""
     from cwn_amd.models import OGBEmbedCINpp

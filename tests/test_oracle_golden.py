@@ -355,3 +355,17 @@ def test_plain_cinpp_golden():
         for k, v in partial.items():
             torch.testing.assert_close(v, T(g[f'plain/{mode}/{k}']), rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(y, T(g[f'plain/{mode}/out']), rtol=1e-4, atol=1e-4)
+
+
+def test_embed_sparse_cin_no_rings_golden():
+    """EmbedSparseCINNoRings (mp/molec_models.py:386-503: vertices and edges only, the edges' upper adjacency dropped) -- the
+    oracle's forward with max_dim 1 / drop_edge_up against the reference's outputs, eval and training mode."""
+    g = load('no_rings.npz')
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/mol']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    cx['cochains'][0]['x'], cx['cochains'][1]['x'] = T(g['v_types']), T(g['e_types'])
+    cx['cochains'][2]['x'] = None
+    for mode in ('eval', 'train'):
+        y, _ = O.sparse_cin_model_forward(state_dict(g, 'state'), cx, 2, max_dim=1, training=(mode == 'train'), embed='zinc',
+                                          readout_dims=(0, 1), drop_edge_up=True)
+        torch.testing.assert_close(y, T(g[f'{mode}/out']), rtol=1e-4, atol=1e-4)
