@@ -1671,7 +1671,9 @@ def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True, 
                 _ffi.check(L.cwn_update_mlp_pack_weights_many_f32(Wp, ld, F, Op, n, _ffi.stream_ptr(dev)),
                            'cwn_update_mlp_pack_weights_many_f32')
             for (weight, w, c0), o, ot in zip(part, outs, outs_t):
-                _packed_stage[_stage_key(w, c0)] = (_stage_token, o, ot, weight._version, WEIGHT_EPOCH)
+                # (a weak reference to the tensor that was packed: an entry whose weight has died -- a layer that is gone, its
+                #  storage address handed to a NEW parameter of the same shape -- is not served, ADVICE r3 / round 4's CIN++ tests)
+                _packed_stage[_stage_key(w, c0)] = (_stage_token, o, ot, weight._version, WEIGHT_EPOCH, weakref.ref(weight))
 
 
 # ---- the step arena: the zeroed scratch of a training step ------------------------------------------------------------
@@ -1755,7 +1757,7 @@ def packed_stage_block(weight: Tensor, col0: int, transposed: bool = False) -> O
     # (an entry is keyed on the weight's STORAGE -- the backward sees its saved weights re-wrapped -- so it must
     # also prove that nothing has written that storage since: the tensor version (torch optimizers, in-place ops) and the
     # parameter epoch (FlatAdam / a replayed step write through raw pointers).  A miss sends the caller to cwn_gemm_f32.)
-    if hit is not None and hit[0] == _stage_token and hit[3] == weight._version and hit[4] == WEIGHT_EPOCH:
+    if hit is not None and hit[0] == _stage_token and hit[3] == weight._version and hit[4] == WEIGHT_EPOCH and hit[5]() is not None:
         return hit[2] if transposed else hit[1]
     return None
 
