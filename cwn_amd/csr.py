@@ -209,7 +209,9 @@ def _describe(flag: int) -> str:
     what = [n for b, n in ((1, 'destination index'), (2, 'source index'), (4, 'shared (co)boundary index'),
                            (8, 'an index outside its complex (batch not block-diagonal, or a stale item table)'),
                            (16, 'a complex beyond what one workgroup holds reached the device-side item-table build '
-                                '(static_batch.StaticBatch.fits() tells which batches a static batch takes)'))
+                                '(static_batch.StaticBatch.fits() tells which batches a static batch takes)'),
+                           (32, 'a batch beyond the capacity of its static buffers was dropped (its slot ran as an empty batch; '
+                                'static_batch.StaticBatch.fits() / larger `caps`)'))
             if flag & b]
     return 'index out of range in adjacency: ' + ', '.join(what)
 

@@ -162,7 +162,38 @@ __global__ __launch_bounds__(kTabThreads) void collate_tables_kernel(const int64
     if (bad) atomicOr(err, 2);
 }
 
+// ---- a batch beyond the capacity of its buffers becomes an EMPTY batch (include/cwn_hip.h: cwn_collate_guard) ---------------------
+// One workgroup per slot: the totals cwn_collate_tables scanned (cells per dimension = seg[d][B], length per key = sizes[8 + k])
+// against the capacities of the arrays the collate launch is about to write.  Over any of them: the slot's whole table is zeroed
+// (= the tables of a batch without complexes: every segment empty, every row count 0 -- its step changes nothing) and the sticky
+// bit is set.  Without this a batch heavier than the statistical capacity of a static batch wrote past its buffers inside a
+// replayed graph.
+__global__ __launch_bounds__(256) void collate_guard_kernel(int64_t* __restrict__ tab_all, int64_t slot_stride, int D, int K, int64_t B,
+                                                            int64_t n_tab, const int64_t* __restrict__ caps, int32_t* __restrict__ err) {
+    int64_t* const tab = tab_all + (int64_t)blockIdx.x * slot_stride;
+    const int64_t o_src = (int64_t)K * (B + 1), o_off = o_src + (int64_t)K * B, o_seg = o_off + (int64_t)D * 5 * B;
+    const int64_t o_sizes = o_seg + (int64_t)D * (B + 1);
+    int over = 0;
+    for (int c = threadIdx.x; c < D + K; c += blockDim.x) {
+        const int64_t total = c < D ? tab[o_seg + (int64_t)c * (B + 1) + B] : tab[o_sizes + 8 + (c - D)];
+        over |= total > caps[c];
+    }
+    if (!__syncthreads_or(over)) return;
+    for (int64_t q = threadIdx.x; q < n_tab; q += blockDim.x) tab[q] = 0;
+    if (threadIdx.x == 0) atomicOr(err, CWN_ERR_BIT_CAPACITY);
+}
+
 }  // namespace
+
+extern "C" int cwn_collate_guard(int64_t* tables, int32_t D, int32_t K, int64_t B, int32_t n_slots, int64_t slot_stride,
+                                 const int64_t* caps, int32_t* err_flag, cwn_stream_t stream_) {
+    if (tables == nullptr || caps == nullptr || err_flag == nullptr || D < 1 || D > 8 || K < 0 || B < 1 || n_slots < 1 || n_slots > 1024)
+        return CWN_ERR_BAD_ARG;
+    const int64_t n_tab = (int64_t)cwn_collate_tables_len(D, K, B);
+    if (n_slots > 1 && slot_stride < n_tab) return CWN_ERR_BAD_ARG;
+    collate_guard_kernel<<<dim3(n_slots), dim3(256), 0, (hipStream_t)stream_>>>(tables, slot_stride, D, K, B, n_tab, caps, err_flag);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
 
 extern "C" size_t cwn_collate_tables_len(int32_t D, int32_t K, int64_t B) {
     if (D < 1 || K < 0 || B < 1) return 0;

@@ -257,6 +257,8 @@ class StaticBatch:
         self.o_seg = self.o_off + D * 5 * B
         self.o_sizes = self.o_seg + D * (B + 1)
         self.meta = packed.meta_device()
+        # what cwn_collate_guard compares a slot's scanned totals with: a batch beyond them runs as an EMPTY batch
+        self.caps_dev = torch.tensor(list(self.cap_cells) + list(self._caps), dtype=torch.int64, device=dev)
         # the batch numbers the fills read: room for an epoch over the whole dataset (+ a replay's worth of spare slots) from the
         # start -- a captured fill holds this buffer's address and length, so it must not move once a step has been captured
         # (reserve_epoch asks for more BEFORE the first fill).  Fill number j takes the batches at the device cursor, which it
@@ -519,8 +521,32 @@ class StaticBatch:
             idx = np.asarray(idx, dtype=np.int64)
             if idx.size > self.B or idx.size == 0:
                 raise ValueError(f'batch {j}: 1 .. {self.B} complexes')
+            if idx.min() < 0 or idx.max() >= self.packed.num:
+                raise IndexError(f'batch {j}: complex numbers outside 0 .. {self.packed.num - 1}')
             host[j, :idx.size] = idx
+        self._check_capacity(host[:len(batches)])
         return host
+
+    def _check_capacity(self, host: np.ndarray) -> None:
+        """Every batch within the capacity of every buffer (the default capacities are a statistical bound, mean x B + 6 sigma
+        sqrt(B): a size-sorted or bucketed batch order can exceed them).  A few numpy operations per epoch; the device repeats
+        the test per fill (cwn_collate_guard: an oversize batch runs as an empty one and sets a sticky bit) for callers that
+        write `idx` themselves."""
+        D, K = self.D, self.K
+        meta = self.packed._meta
+        take = np.concatenate([meta[:, 0:3 * D:3], meta[:, 3 * D:3 * D + K]], axis=1)          # [num, D + K]
+        take = np.concatenate([take, np.zeros((1, D + K), dtype=take.dtype)], axis=0)            # row -1: no complex
+        caps = np.asarray(list(self.cap_cells) + list(self._caps), dtype=np.int64)
+        for lo in range(0, host.shape[0], 4096):
+            tot = take[host[lo:lo + 4096]].sum(axis=1)                                            # [n, D + K]
+            bad = np.nonzero((tot > caps).any(axis=1))[0]
+            if bad.size:
+                j = int(bad[0])
+                c = int(np.nonzero(tot[j] > caps)[0][0])
+                what = f'cells of dimension {c}' if c < D else 'elements of {1!r} (dimension {0})'.format(*self.packed._klist[c - D][:2])
+                raise ValueError(f'batch {lo + j}: {int(tot[j, c])} {what} exceed the capacity {int(caps[c])} of this StaticBatch '
+                                 f'({bad.size} such batch(es)); build it with larger `caps`, or route these batches through '
+                                 'PackedComplexes.collate (StaticBatch.fits() tells which)')
 
     def set_batches(self, batches: Sequence[Sequence[int]]) -> None:
         """The complexes of the NEXT fill, one index list per slot (at most `slots`; the other slots get empty batches): an
@@ -574,6 +600,8 @@ class StaticBatch:
         cur = self.cursor.data_ptr()
         _ffi.check(L.cwn_collate_tables(self.meta.data_ptr(), self.packed.num, self.D, self.K, self.idx.data_ptr(), self.B,
                                         self.n_batches, cur, n, self.n_tab, self.tables.data_ptr(), err, s), 'cwn_collate_tables')
+        _ffi.check(L.cwn_collate_guard(self.tables.data_ptr(), self.D, self.K, self.B, n, self.n_tab, self.caps_dev.data_ptr(), err, s),
+                   'cwn_collate_guard')
         for i, (arr, strides) in enumerate(self._descs):
             _ffi.check(L.cwn_collate_slots(arr, len(arr), self.B, n, self.n_tab, strides, cur if i == len(self._descs) - 1 else None, s),
                        'cwn_collate_slots')

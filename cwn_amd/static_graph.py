@@ -296,6 +296,18 @@ class StaticTrainStep(TrainStep):
             if hasattr(self.opt, 'active'):
                 self.opt.active = None
 
+    def _optimizer_step(self, i: int) -> None:
+        # (also the data-parallel form's captured graph(Adam), which does not come through _eager: without `active` set
+        #  while it is recorded, an empty tail slot would take an unconditional Adam step on a zero gradient -- ADVICE r4)
+        had = getattr(self.opt, 'active', None)
+        if hasattr(self.opt, 'active') and had is None:
+            self.opt.active = self._global_active if self.world > 1 else self._actives[i]
+        try:
+            super()._optimizer_step(i)
+        finally:
+            if hasattr(self.opt, 'active'):
+                self.opt.active = had
+
     def _capture(self, i: int):
         # the warm-up steps of the capture consume batches: put the cursor back so that the first replay takes the batches
         # the caller expects

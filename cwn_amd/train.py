@@ -225,6 +225,16 @@ class TrainStep:
         return ops.step_arena(self.bucket.flat.device, flat=self.bucket.flat, counter=self.opt.t if mine else None,
                               active=self.opt.active if mine else None)
 
+    def _abort_step(self) -> None:
+        """A step that raised between its opening launch and the optimizer: the count _begin took is given back."""
+        if isinstance(self.opt, FlatAdam) and self.opt.counted:
+            self.opt.counted = False
+            with torch.no_grad():
+                if self.opt.active is None:
+                    self.opt.t.sub_(1)
+                else:
+                    self.opt.t.sub_((self.opt.active > 0).to(torch.int32).view(1))
+
     # ---- pieces ------------------------------------------------------------------------------
     @staticmethod
     def _cochains(b):
@@ -315,29 +325,46 @@ class TrainStep:
             if self.rebuild_plans:
                 b.forget_plans().prepare(backward=True)
             # zero_grad + what the step's kernels need zero on entry + the optimizer's step counter: one launch
-            with self._begin():
-                loss = self._loss(b)
-                with ops.accumulate_into_grad():        # gradients are views into self.bucket: kernels add in place
-                    loss.backward(gradient=_one(loss.device))      # (no fill for the seed; _FusedMeanLoss hands its gradient on as is)
-            self._restore(i)                          # drop the references to the autograd graph
+            try:
+                with self._begin():
+                    loss = self._loss(b)
+                    with ops.accumulate_into_grad():        # gradients are views into self.bucket: kernels add in place
+                        loss.backward(gradient=_one(loss.device))      # (no fill for the seed; _FusedMeanLoss hands its gradient on as is)
+            except BaseException:
+                self._abort_step()
+                raise
+            finally:
+                self._restore(i)                      # drop the references to the autograd graph
             return loss.detach()
         S = self.n_stages
-        for j in (range(S) if pieces is None else pieces):
-            if j == 0:
-                b = self._restore(i)
-                if self.rebuild_plans:
-                    b.forget_plans().prepare(backward=True)
-                self._arena = self._begin()
-                self._arena.__enter__()
-                self.staged.begin()
-                self._live_loss = self._loss(b)
-            with ops.accumulate_into_grad():
-                self.staged.piece(j, self._live_loss, self.stage_params[j])
-            if j == S - 1:
-                loss, self._live_loss = self._live_loss.detach(), None
-                self._arena.__exit__(None, None, None)
-                self._restore(i)
-                return loss
+        try:
+            for j in (range(S) if pieces is None else pieces):
+                if j == 0:
+                    b = self._restore(i)
+                    if self.rebuild_plans:
+                        b.forget_plans().prepare(backward=True)
+                    self._arena = self._begin()
+                    self._arena.__enter__()
+                    self.staged.begin()
+                    self._live_loss = self._loss(b)
+                with ops.accumulate_into_grad():
+                    self.staged.piece(j, self._live_loss, self.stage_params[j])
+                if j == S - 1:
+                    loss, self._live_loss = self._live_loss.detach(), None
+                    arena, self._arena = self._arena, None
+                    arena.__exit__(None, None, None)
+                    self._restore(i)
+                    return loss
+        except BaseException as e:
+            # a forward / backward that raised (out of memory, a refused layer): close the step's bracket and hand the
+            # optimizer's count back, or the NEXT step would skip its increment against a stale count
+            arena, self._arena = getattr(self, '_arena', None), None
+            if arena is not None:
+                arena.__exit__(type(e), e, e.__traceback__)
+            self._live_loss = None
+            self._abort_step()
+            self._restore(i)
+            raise
         return self._live_loss.detach()
 
     def _n_local(self, i: int):
@@ -359,9 +386,13 @@ class TrainStep:
                 loss = self._forward_backward(i, [j])
                 self.bucket.reduce_chunk(j, n_local)      # overlaps with piece j + 1
             self.bucket.finish()
+        self._optimizer_step(i)
+        return loss
+
+    def _optimizer_step(self, i: int) -> None:
+        """What follows the (reduced) gradient: eagerly, and as the data-parallel form's last captured graph."""
         self._before_optimizer(i)
         self.opt.step()
-        return loss
 
     def _capture(self, i: int):
         if not self._warm:
@@ -400,8 +431,7 @@ class TrainStep:
             pieces.append(g)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
-            self._before_optimizer(i)
-            self.opt.step()
+            self._optimizer_step(i)
         return (pieces, g2, loss)
 
     MAX_SEQ_GRAPHS = 8

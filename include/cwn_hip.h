@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 19
+#define CWN_ABI_VERSION 20
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -951,6 +951,16 @@ size_t cwn_collate_tables_len(int32_t D, int32_t K, int64_t B);      /* int64 el
 int cwn_collate_tables(const int64_t* meta, int64_t num, int32_t D, int32_t K, const int64_t* idx, int64_t B, int64_t n_batches,
                        const int64_t* cursor, int32_t n_slots, int64_t slot_stride, int64_t* tables, int32_t* err_flag,
                        cwn_stream_t stream);
+
+/* The capacity guard of a static batch, between cwn_collate_tables and cwn_collate_slots: caps = device int64 [D + K], the
+ * cells the feature / batch arrays of dimension d hold, then the elements the array of key k holds.  A slot whose scanned
+ * totals exceed any of them has its tables zeroed -- it becomes a batch WITHOUT complexes: the collate launch writes nothing
+ * for it, every m_dev row count reads 0, its training step changes nothing -- and CWN_ERR_BIT_CAPACITY is set in the sticky
+ * word.  (The reference's collate allocates per batch, data/complex.py:323-458: there is no such failure there; a fixed-capacity
+ * buffer must refuse instead of overrunning.) */
+#define CWN_ERR_BIT_CAPACITY 32               /* *err_flag bit: a batch beyond the capacity of its static buffers was dropped */
+int cwn_collate_guard(int64_t* tables, int32_t D, int32_t K, int64_t B, int32_t n_slots, int64_t slot_stride, const int64_t* caps,
+                      int32_t* err_flag, cwn_stream_t stream);
 
 /* Embedding lookup with a sum over index columns (torch.nn.Embedding for cols = 1; the OGB
  * Atom/BondEncoder sum over one table per integer feature column, mp/molec_models.py:44-52, 237-245):

@@ -552,3 +552,76 @@ def test_the_example_script_runs():
                         capture_output=True, text=True, timeout=600)
     assert pr.returncode == 0, pr.stderr[-2000:]
     assert 'held-out MAE' in pr.stdout and 'epoch 1:' in pr.stdout, pr.stdout[-2000:]
+
+
+def test_a_batch_beyond_the_capacity_is_refused_on_the_host_and_dropped_on_the_device():
+    """the default capacities are a statistical bound and nothing compared a batch with them -- a size-sorted batch
+    wrote past the buffers inside a replayed graph.  Now (a) set_batches / set_epoch raise for such a batch, and (b) a caller
+    that writes the complex numbers itself gets the device-side guard: the slot runs as an EMPTY batch (every size word 0,
+    nothing written past -- or into -- the arrays) and the sticky word reports it."""
+    from cwn_amd import csr
+    from cwn_amd.static_batch import StaticBatch
+    pool, p = _packed(n=200, n_lo=9, n_hi=40)
+    B = 32
+    sb = StaticBatch(p, B, slots=2)
+    heavy = np.argsort(-p._meta[:, 0])[:B]                  # the B largest molecules: beyond mean x B + 6 sigma sqrt(B)?
+    tot = p._meta[heavy, 0].sum()
+    if tot <= sb.cap_cells[0]:                              # (make sure the case is the one under test)
+        sb = StaticBatch(p, B, slots=2, caps={'cells': [int(tot) - 5, sb.cap_cells[1], sb.cap_cells[2]]})
+    light = np.argsort(p._meta[:, 0])[:B]
+    assert not sb.fits([heavy])[0] and sb.fits([light])[0]
+    with pytest.raises(ValueError, match='exceed the capacity'):
+        sb.set_batches([light, heavy])
+    with pytest.raises(ValueError, match='exceed the capacity'):
+        sb.set_epoch([light, light, heavy])
+    # (b) behind the host's back
+    sb.set_batches([light, light])
+    sb.fill()
+    torch.cuda.synchronize()
+    before = {k: v[1].clone() for k, v in sb.bufs.items()}
+    sb.idx[B:2 * B].copy_(torch.from_numpy(heavy).to(DEV))
+    sb.cursor.zero_()
+    sb.fill()
+    torch.cuda.synchronize()
+    assert sb.sizes(0) == [int(p._meta[light, 3 * d].sum()) for d in range(3)] + [B]      # slot 0 is served as ever
+    assert sb.sizes(1) == [0, 0, 0, 0]                                                   # slot 1: an empty batch
+    assert not sb.tables[1].any()
+    for k, v in sb.bufs.items():
+        assert torch.equal(v[1], before[k]), k                                           # ... and nothing was written for it
+    with pytest.raises(IndexError, match='capacity'):
+        csr.check_errors(DEV)
+    csr.check_errors(DEV)                                                                # (reported once)
+
+
+def test_data_parallel_form_leaves_an_empty_tail_slot_alone():
+    """in the data-parallel form (graph(forward + backward) -> all-reduce -> graph(Adam)) the Adam graph was recorded
+    with `active` unset, so an empty tail slot took an Adam step on a zero gradient (momentum moved the parameters, t
+    advanced).  Three batches over two slots, forced world 2 on one GPU: t == 3 and the second replay's empty slot changes
+    no parameter."""
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    pool, p = _packed(n_hi=28)
+    B = 40
+    m = _model(64, 2, seed=6)
+    batches = _batches(len(pool), B, 21, sizes=[B, B, 25])
+    sb = StaticBatch(p, B, slots=2)
+    st = StaticTrainStep(m, sb, lr=1e-3)
+    st.world = 2
+    sb.set_epoch(batches)
+    st.step()
+    torch.cuda.synchronize()
+    assert int(st.opt.t) == 2
+    # the second replay by hand: slot 0 real, slot 1 empty
+    from cwn_amd.train import TrainStep
+    TrainStep.step(st, 0)
+    torch.cuda.synchronize()
+    keep = [q.detach().clone() for q in m.parameters()]
+    mom = st.opt.exp_avg.clone()
+    assert int(st.opt.t) == 3
+    loss = TrainStep.step(st, 1)
+    torch.cuda.synchronize()
+    assert float(loss) != float(loss)                        # the mean of nothing
+    assert int(st.opt.t) == 3
+    assert torch.equal(st.opt.exp_avg, mom)
+    for a, b in zip(m.parameters(), keep):
+        assert torch.equal(a.detach(), b)
