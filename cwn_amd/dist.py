@@ -18,6 +18,16 @@ import torch.distributed as dist
 
 T = TypeVar('T')
 
+# The data-parallel form on ONE rank (CWN_FORCE_DP=1, or set by a test): TrainStep cuts its backward and brackets the
+# collectives with graphs as it does for world > 1, and the bucket issues its all-reduces to a process group of one rank --
+# RCCL reduces the buffer with itself.  Everything a first multi-GPU run exercises except the xGMI wire: the library load,
+# the communicator, RCCL's stream ordering against the graph replays, "no collective inside a capture".
+FORCE_DP = os.environ.get('CWN_FORCE_DP') == '1'
+
+
+def force_dp() -> bool:
+    return FORCE_DP
+
 
 def init_from_env(backend: Optional[str] = None) -> (int, int):
     """(rank, world) from the torchrun environment; initialises the process group when world > 1."""
@@ -103,9 +113,12 @@ class FlatGradBucket:
 
     @staticmethod
     def _world(group) -> int:
+        """Ranks the collectives run over: 1 = none is issued.  A group of ONE rank counts as two under FORCE_DP (the
+        all-reduce of the buffer with itself is issued)."""
         if not (dist.is_available() and dist.is_initialized()):
             return 1
-        return dist.get_world_size(group)
+        w = dist.get_world_size(group)
+        return max(w, 2) if FORCE_DP else w
 
     def all_reduce_mean(self, group=None, async_op: bool = False, n_local: Optional[int] = None):
         """Mean of the per-rank gradients, weighted by `n_local` (the number of samples the rank's loss

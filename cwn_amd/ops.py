@@ -1638,6 +1638,11 @@ def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True, 
     if fresh:
         _stage_token += 1
         _packed_stage.clear()               # (entries of earlier calls are stale by definition)
+    else:
+        # (a model made of layers that pack their own blocks never comes through `fresh`: entries -- and the
+        #  device buffers they hold -- of layers that have died would pile up)
+        for k in [k for k, v in _packed_stage.items() if v[5]() is None]:
+            del _packed_stage[k]
     L = _ffi.lib()
     by_F = {}
     for weight in weights:
@@ -1757,8 +1762,13 @@ def packed_stage_block(weight: Tensor, col0: int, transposed: bool = False) -> O
     # (an entry is keyed on the weight's STORAGE -- the backward sees its saved weights re-wrapped -- so it must
     # also prove that nothing has written that storage since: the tensor version (torch optimizers, in-place ops) and the
     # parameter epoch (FlatAdam / a replayed step write through raw pointers).  A miss sends the caller to cwn_gemm_f32.)
-    if hit is not None and hit[0] == _stage_token and hit[3] == weight._version and hit[4] == WEIGHT_EPOCH and hit[5]() is not None:
-        return hit[2] if transposed else hit[1]
+    if hit is not None and hit[0] == _stage_token and hit[3] == weight._version and hit[4] == WEIGHT_EPOCH:
+        # ... and that the tensor that was packed is alive AND still owns that storage (a Parameter re-pointed by
+        # `.data =` / load_state_dict(assign=True) stays alive while its old storage is recycled for another weight of the
+        # same shape and version)
+        owner = hit[5]()
+        if owner is not None and owner.data_ptr() == weight.data_ptr():
+            return hit[2] if transposed else hit[1]
     return None
 
 

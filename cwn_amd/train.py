@@ -159,8 +159,12 @@ class TrainStep:
         self.model, self.batches = model.train(), list(batches)
         self.loss_fn = _LOSSES[task_type]
         self.task_type = task_type
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if self.world > 1:
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if live else 1
+        from . import dist as _cd
+        if _cd.force_dp():                 # the data-parallel form on one rank (cwn_amd/dist.py: FORCE_DP)
+            self.world = max(self.world, 2)
+        if self.world > 1 and live:
             # a rank with fewer batches would leave the others waiting in a collective
             n = torch.tensor([len(self.batches), -len(self.batches)], dtype=torch.int64,
                              device=next(model.parameters()).device)
@@ -194,7 +198,7 @@ class TrainStep:
                 self.staged = None
         self.n_stages = self.staged.n_stages if self.staged is not None else 1
         self.bucket = FlatGradBucket(model.parameters(), stage_of, self.n_stages)
-        if self.world > 1:
+        if self.world > 1 and live:
             # the ranks reduce the bucket chunk by chunk: its layout must be the same everywhere
             lay = torch.tensor([hi for _, hi in self.bucket.chunks], dtype=torch.int64, device=self.bucket.flat.device)
             lay = torch.cat([lay, -lay])
@@ -292,7 +296,7 @@ class TrainStep:
             ok = ok and all(reached.setdefault(id(p), st) == st for p in conv.parameters() if p.requires_grad)
         mine = torch.tensor([reached.get(id(p), -1) for p in params] + [0 if ok else 1], dtype=torch.int64,
                             device=params[0].device)
-        if self.world > 1:
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
             both = mine.clone()
             dist.all_reduce(both, op=dist.ReduceOp.MAX)
             clash = ((mine >= 0) & (mine != both)).any().to(torch.int64).view(1)
