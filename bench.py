@@ -9,12 +9,14 @@ Workload (BASELINE.json configs[1]): ZINC-like ring-lifted batch (max_ring 6), 1
 GPU, 4-layer EmbedSparseCIN (hidden 128, coboundary messages, edge embedding, BatchNorm;
 exp/scripts/cwn-zinc.sh:14-30), synthetic inputs and random-init weights.
 
-One STEP = one pass of the hot path over one batch with the batch already resident in HBM:
-    per-batch CSR plan build (int64 COO as delivered -> int32 CSR, all adjacencies), then for each
+One STEP = one pass of the hot path over one batch with the batch already resident in HBM: for each
     of the 4 layers everything CochainMessagePassing.propagate does for the 3 cochain dimensions
-    (12 propagate calls in the reference): the message function (coboundary Linear + ReLU), the
+    (12 propagate calls in the reference) as ONE complex-blocked launch (cwn_layer_fused_f32) straight
+    from the int64 COO entries as delivered: the message function (coboundary Linear + ReLU), the
     gathers incl. the up_attr gather of data/complex.py:579-580, the scatter-adds, the zero fills,
-    plus the GIN self terms that are fused into the same kernel.
+    plus the GIN self terms.  The first layer's launch sorts the entries of each item into a per-item
+    CSR and stores it; the other layers load it.  (Workloads the blocked launch does not serve --
+    REDDIT hubs -- run a per-batch cwn_csr_build + grouped GEMM + cwn_aggregate_f32 instead.)
 Unit: cell-updates/s = sum_d N_d x layers x steps / wall time, summed over ranks
 (weak scaling: every rank owns its own batches, no data-path collective).
 The JSON line also carries `roofline` (dominant kernel: layer_kernel<F, load>, csrc/cwn_layer.hip, at the configurations the
@@ -268,11 +270,25 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
+    elif os.environ.get('CWN_BENCH_FORCE_DP') == '1':
+        # the data-parallel form on the ONE GPU of a test box: a process group of one rank over RCCL, the training leg's
+        # backward cut into chunks with an all-reduce each (cwn_amd/dist.py: FORCE_DP) -- `multi_gpu.exposed_allreduce_ms_per_step`
+        # is then a real RCCL number (the buffer reduced with itself), everything but the xGMI wire
+        import socket
+        import torch.distributed as dist
+        s_ = socket.socket()
+        s_.bind(('127.0.0.1', 0))
+        port_ = s_.getsockname()[1]
+        s_.close()
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port_}', rank=0, world_size=1, device_id=dev)
+        from cwn_amd import dist as _cd
+        _cd.FORCE_DP = True
     else:
         dist = None
 
     # what a first multi-GPU run needs to read off the line: how many ranks talk over what, which device each one holds
     MULTI = {'rccl_ranks': world, 'backend': None if dist is None else dist.get_backend(),
+             'forced_data_parallel_form_on_one_rank': bool(world == 1 and dist is not None),
              'transport': None if dist is None else ('gloo over one shared GPU (CWN_BENCH_SHARE_GPU: control-flow test)' if share
                                                      else 'RCCL (torch.distributed "nccl") over xGMI, one process per GPU')}
     try:
@@ -653,6 +669,8 @@ def main():
                           'bf16 matrix pipe into LDS, per-complex CSR, both reductions + self terms out of LDS)',
                 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                 'traffic': traffic,
+                'residency': 'L2/MALL' if args.batch * H <= 512 * 128 else 'HBM',
+                'traffic_source': 'profiles/*_traffic.json (committed PMC pass of the same kernel and batch size; not re-measured in this run)',
                 'frac_vs_pmc_traffic': None if traffic is None else round(traffic / (load_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 'algorithmic_bytes_per_launch': alg, 'compulsory_bytes_per_launch': int(compulsory),
                 'avg_launch_us': round(load_us, 3), 'avg_launch_us_store_variant': round(store_us, 3),
