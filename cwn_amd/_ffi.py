@@ -20,7 +20,7 @@ ABI_VERSION = 20
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_update_mlp_pack_weights_both_many_f32', 'cwn_layer_pack_weights_both_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_ex_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_slots', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_collate_guard', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
-           'cwn_bn_finalize_f32', 'cwn_step_begin', 'cwn_embed_front_bwd_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
+           'cwn_bn_finalize_f32', 'cwn_step_begin', 'cwn_dropout_f32', 'cwn_embed_front_bwd_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_loss_cols_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
 
@@ -220,12 +220,20 @@ class BnDesc(C.Structure):
                 ('pad_', C.c_int32), ('num_batches_tracked', C.c_void_p), ('bwd_sums', C.c_void_p), ('m_dev', C.c_void_p)]
 
 
+class Dropout(C.Structure):
+    """cwn_dropout: state = device int64 [2] {seed, step} (NULL: off), p, site."""
+    _fields_ = [('state', C.c_void_p), ('p', C.c_float), ('site', C.c_uint32)]
+
+
+HEAD_DROP_NONE, HEAD_DROP_LIN1, HEAD_DROP_FINAL, HEAD_DROP_LIN2 = range(4)      # = CWN_HEAD_DROP_*
+
+
 class NormDesc(C.Structure):
     _fields_ = [('dy', C.c_void_p), ('z', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
                 ('mean', C.c_void_p), ('rstd', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p),
                 ('out', C.c_void_p), ('M', C.c_int64), ('lddy', C.c_int64), ('ldz', C.c_int64),
                 ('ldout', C.c_int64), ('N', C.c_int32), ('relu', C.c_int32), ('acc1', C.c_void_p), ('acc2', C.c_void_p),
-                ('m_dev', C.c_void_p), ('bn', BnLive)]
+                ('m_dev', C.c_void_p), ('bn', BnLive), ('drop', Dropout), ('dy_out', C.c_void_p), ('lddy_out', C.c_int64)]
 
 
 class GemmTnDesc(C.Structure):
@@ -350,7 +358,10 @@ def lib():
     L.cwn_embed_front_bwd_f32.restype = C.c_int
     L.cwn_embed_front_bwd_f32.argtypes = [C.POINTER(FrontBwd), C.c_void_p]
     L.cwn_step_begin.restype = C.c_int
-    L.cwn_step_begin.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cwn_step_begin.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cwn_dropout_f32.restype = C.c_int
+    L.cwn_dropout_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Dropout), C.c_void_p,
+                                  C.c_void_p]
     L.cwn_bn_finalize_f32.restype = C.c_int
     L.cwn_bn_finalize_f32.argtypes = [C.POINTER(BnDesc), C.c_int, C.c_void_p]
     for name in ('cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32'):
@@ -381,10 +392,10 @@ def lib():
                                       C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cwn_head_f32.restype = C.c_int
     L.cwn_head_f32.argtypes = [C.POINTER(HeadDim), C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                               C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+                               C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Dropout), C.c_int32, C.c_void_p]
     L.cwn_head_bwd_f32.restype = C.c_int
     L.cwn_head_bwd_f32.argtypes = [C.POINTER(HeadBwdDim), C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                   C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+                                   C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Dropout), C.c_int32, C.c_void_p]
     L.cwn_lift_create.restype = C.c_void_p
     L.cwn_lift_create.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
     L.cwn_lift_size.restype = C.c_int64

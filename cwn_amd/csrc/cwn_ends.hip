@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include "../../include/cwn_hip.h"
 #include "cwn_mem.h"
+#include "cwn_dropout.h"
 
 namespace {
 
@@ -289,6 +290,8 @@ struct HeadArgs {
     float* s_out;                                  // [C, H2] the summed hidden vector (training), or NULL
     int64_t C;
     int32_t n_dims, K, H2, O, mean_readout, mean_final;
+    cwn_dropout drop;                              // the head's dropout (cwn_dropout.h) at position drop_pos (CWN_HEAD_DROP_*)
+    int32_t drop_pos;
 };
 
 __host__ __device__ constexpr size_t head_lds_floats(int K, int H2) {
@@ -304,6 +307,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
     float* const sbuf = hpart + CWN_HEAD_MAX_DIMS * 4 * kHeadThreads;          // [H2]
     const int tid = threadIdx.x;
     const int64_t c = blockIdx.x;
+    cwn::Dropout drop;
+    drop.init(A.drop);
+    const int dpos = drop.on ? A.drop_pos : CWN_HEAD_DROP_NONE;
 
     // ---- 1. pooled_d = sum of this complex's rows of x_d: K / 4 lanes a row, row groups side by side ------------
     const int G = K / 4, NG = kHeadThreads / G;
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
             const int64_t n = r1[d] - r0[d];
             s = s / (float)(n > 0 ? n : 1);
         }
+        if (dpos == CWN_HEAD_DROP_LIN1) s *= drop.mul1(((uint64_t)d * (uint64_t)A.C + (uint64_t)c) * (uint64_t)K + (uint64_t)k);
         pooled[i] = s;
         if (d < nd && A.d[d].pooled_out != nullptr) A.d[d].pooled_out[c * K + k] = s;
     }
@@ -406,9 +413,12 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
             for (int q = 0; q < S; ++q) h += hpart[(size_t)d * 4 * kHeadThreads + q * H2 + tid];
             if (A.d[d].b1 != nullptr) h += A.d[d].b1[tid];
             if (A.d[d].h_out != nullptr) A.d[d].h_out[c * H2 + tid] = h;      // pre-activation: the backward's ReLU mask
-            s += fmaxf(h, 0.f);
+            float a = fmaxf(h, 0.f);
+            if (dpos == CWN_HEAD_DROP_FINAL) a *= drop.mul1(((uint64_t)d * (uint64_t)A.C + (uint64_t)c) * (uint64_t)H2 + (uint64_t)tid);
+            s += a;
         }
         if (A.mean_final) s = s / (float)nd;
+        if (dpos == CWN_HEAD_DROP_LIN2) s *= drop.mul1((uint64_t)c * (uint64_t)H2 + (uint64_t)tid);
         sbuf[tid] = s;
         if (A.s_out != nullptr) A.s_out[c * H2 + tid] = s;
     }
@@ -437,6 +447,8 @@ struct HeadBwdArgs {
     const float* w2; const float* g_out;
     int64_t C;
     int32_t n_dims, K, H2, O, mean_readout, mean_final;
+    cwn_dropout drop;
+    int32_t drop_pos;
 };
 
 __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs A) {
@@ -447,13 +459,18 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs A) {
     float* const dp = part + 4 * kHeadThreads;                     // [K]
     const int tid = threadIdx.x;
     const int64_t c = blockIdx.x;
+    cwn::Dropout drop;
+    drop.init(A.drop);
+    const int dpos = drop.on ? A.drop_pos : CWN_HEAD_DROP_NONE;
     // 1. + 2.  ds and the masked dh of every dimension
     if (tid < H2) {
         float ds = 0.f;
         for (int o = 0; o < A.O; ++o) ds = __builtin_fmaf(A.w2[(size_t)o * H2 + tid], A.g_out[c * A.O + o], ds);
+        if (dpos == CWN_HEAD_DROP_LIN2) ds *= drop.mul1((uint64_t)c * (uint64_t)H2 + (uint64_t)tid);
         if (A.mean_final) ds = ds / (float)nd;
         for (int d = 0; d < nd; ++d) {
-            const float v = A.d[d].h[c * H2 + tid] > 0.f ? ds : 0.f;
+            float v = A.d[d].h[c * H2 + tid] > 0.f ? ds : 0.f;
+            if (dpos == CWN_HEAD_DROP_FINAL) v *= drop.mul1(((uint64_t)d * (uint64_t)A.C + (uint64_t)c) * (uint64_t)H2 + (uint64_t)tid);
             dh[d * H2 + tid] = v;
             if (A.d[d].dh_out != nullptr) A.d[d].dh_out[c * H2 + tid] = v;
         }
@@ -496,6 +513,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs A) {
         if (tid < K) {
             float v = 0.f;
             for (int q = 0; q < S; ++q) v += part[(size_t)q * K + tid];       // fixed order
+            if (dpos == CWN_HEAD_DROP_LIN1) v *= drop.mul1(((uint64_t)d * (uint64_t)A.C + (uint64_t)c) * (uint64_t)K + (uint64_t)tid);
             if (A.mean_readout) v = v / (float)(r1 - r0 > 0 ? r1 - r0 : 1);
             dp[tid] = v;
         }
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs A) {
 
 extern "C" int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims, int n_dims, int64_t C, int32_t K, int32_t H2,
                                 int32_t mean_readout, int32_t mean_final, const float* w2, int32_t O, const float* g_out,
-                                cwn_stream_t stream_) {
+                                const cwn_dropout* drop, int32_t drop_pos, cwn_stream_t stream_) {
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_HEAD_MAX_DIMS || C < 0 || O < 1) return CWN_ERR_BAD_ARG;
     if (K < 4 || (K & 3) != 0 || K > 4 * kHeadThreads || H2 < 4 || (H2 & 3) != 0 || H2 > kHeadThreads) return CWN_ERR_BAD_ARG;
     if (C == 0) return CWN_OK;
@@ -530,6 +548,11 @@ extern "C" int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims, int n_dims, int64_
         A.d[d] = D;
     }
     A.w2 = w2; A.g_out = g_out;
+    if (drop != nullptr && drop->state != nullptr && drop->p > 0.f) {
+        if (!(drop->p < 1.f) || drop_pos < CWN_HEAD_DROP_LIN1 || drop_pos > CWN_HEAD_DROP_LIN2) return CWN_ERR_BAD_ARG;
+        A.drop = *drop;
+        A.drop_pos = drop_pos;
+    }
     A.C = C;
     A.n_dims = n_dims; A.K = K; A.H2 = H2; A.O = O;
     A.mean_readout = mean_readout ? 1 : 0;
@@ -579,7 +602,7 @@ extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, flo
 
 extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
                             int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, float* s_out,
-                            cwn_stream_t stream_) {
+                            const cwn_dropout* drop, int32_t drop_pos, cwn_stream_t stream_) {
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_HEAD_MAX_DIMS || C < 0 || O < 1) return CWN_ERR_BAD_ARG;
     // K / 4 lanes a row inside 512 threads; output j by thread j
     if (K < 4 || (K & 3) != 0 || K > 4 * kHeadThreads || H2 < 4 || (H2 & 3) != 0 || H2 > kHeadThreads) return CWN_ERR_BAD_ARG;
@@ -596,6 +619,11 @@ extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int
     }
     A.w2 = w2; A.b2 = b2; A.out = out;
     A.s_out = s_out;
+    if (drop != nullptr && drop->state != nullptr && drop->p > 0.f) {
+        if (!(drop->p < 1.f) || drop_pos < CWN_HEAD_DROP_LIN1 || drop_pos > CWN_HEAD_DROP_LIN2) return CWN_ERR_BAD_ARG;
+        A.drop = *drop;
+        A.drop_pos = drop_pos;
+    }
     A.C = C;
     A.n_dims = n_dims; A.K = K; A.H2 = H2; A.O = O;
     A.mean_readout = mean_readout ? 1 : 0;

@@ -17,6 +17,7 @@
 #include "../../include/cwn_hip.h"
 #include "cwn_mem.h"
 #include "cwn_bn_live.h"
+#include "cwn_dropout.h"
 
 namespace {
 
@@ -152,6 +153,10 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
     const bool has_norm = D.scale != nullptr || live;
     const bool relu = D.relu != 0;
     const float invM = 1.0f / (float)(Mv > 0 ? Mv : 1);
+    // dropout of the activation (MODE 0: the epilogue) / of the incoming gradient (MODE 1: the prologue; cwn_dropout.h)
+    cwn::Dropout drop;
+    drop.on = false;
+    if constexpr (MODE != 2) drop.init(D.drop);
     // (a band past the batch's own rows has nothing to do -- except the apply form's first band, which hands the sums on)
     if (row0 >= Mv && !(MODE == 2 && row0 == 0)) return;
     for (int c0 = 0; c0 < N; c0 += kTPR * VEC) {     // column chunks of 128 (VEC = 4) or 32
@@ -202,6 +207,22 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
                 if constexpr (MODE != 0) ld_vec<VEC>(g[i], D.dy + rc * D.lddy + c);
             }
         }
+        if constexpr (MODE == 1) {
+            if (drop.on) {                            // (uniform) dy arrives w.r.t. the dropped activation
+#pragma unroll
+                for (int i = 0; i < kBand / kRowsPerPass; ++i) {
+                    const int64_t r = row0 + tr + i * kRowsPerPass;
+                    if (!(cok && r < Mv)) continue;
+                    if constexpr (VEC == 4) {
+                        const float4 m = drop.mul4((uint32_t)(((uint64_t)r * (uint64_t)N + (uint64_t)c) >> 2));
+                        g[i][0] *= m.x; g[i][1] *= m.y; g[i][2] *= m.z; g[i][3] *= m.w;
+                    } else {
+                        g[i][0] *= drop.mul1((uint64_t)r * (uint64_t)N + (uint64_t)c);
+                    }
+                    if (D.dy_out != nullptr) st_vec<VEC>(D.dy_out + r * D.lddy_out + c, g[i]);
+                }
+            }
+        }
         if constexpr (MODE == 0) {
             if (live) {                               // (uniform) thread i < chunk width: column c0 + i; the first band writes.  BEHIND the row
                                                       // requests above: the derive runs while they travel
@@ -242,6 +263,16 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(NormBatch B) {
                         }
                     } else {
                         o[v] = has_norm ? scale[v] * (dyh - k1[v] - xhat * k2[v]) : dyh;
+                    }
+                }
+            }
+            if constexpr (MODE == 0) {
+                if (drop.on && ok) {
+                    if constexpr (VEC == 4) {
+                        const float4 m = drop.mul4((uint32_t)(((uint64_t)r * (uint64_t)N + (uint64_t)c) >> 2));
+                        o[0] *= m.x; o[1] *= m.y; o[2] *= m.z; o[3] *= m.w;
+                    } else {
+                        o[0] *= drop.mul1((uint64_t)r * (uint64_t)N + (uint64_t)c);
                     }
                 }
             }
@@ -394,14 +425,16 @@ int launch_norm(const cwn_norm_desc* descs, int n, cwn_stream_t stream_) {
                 (D.mean == nullptr || D.rstd == nullptr || D.s1 == nullptr || D.s2 == nullptr))
                 return CWN_ERR_BAD_ARG;
             if (MODE == 1 && (D.s1 == nullptr || D.s2 == nullptr)) return CWN_ERR_BAD_ARG;
+            if (D.drop.state != nullptr && (MODE == 2 || !(D.drop.p >= 0.f && D.drop.p < 1.f))) return CWN_ERR_BAD_ARG;
+            if (D.dy_out != nullptr && (MODE != 1 || D.lddy_out < D.N)) return CWN_ERR_BAD_ARG;
         }
-        const void* ptrs[] = {D.dy, D.z, D.scale, D.shift, D.mean, D.rstd, D.s1, D.s2, D.out};
+        const void* ptrs[] = {D.dy, D.z, D.scale, D.shift, D.mean, D.rstd, D.s1, D.s2, D.out, D.dy_out};
         for (const void* p : ptrs) {
             if (p != nullptr && ((uintptr_t)p & 3u)) return CWN_ERR_ALIGN;
             vec = vec && al16(p);
         }
         vec = vec && D.N % 4 == 0 && D.ldz % 4 == 0 && (MODE == 0 || D.lddy % 4 == 0) &&
-              (MODE == 1 || D.ldout % 4 == 0);
+              (MODE == 1 || D.ldout % 4 == 0) && (D.dy_out == nullptr || D.lddy_out % 4 == 0);
         B.d[i] = D;
         B.blk_start[i] = (int32_t)blocks;
         blocks += (D.M + kBand - 1) / kBand;
@@ -550,7 +583,8 @@ extern "C" int cwn_adam_f32(float* p, const float* g, float* m, float* v, int64_
 // ---- the start of a training step: zero the gradients, zero the step arena, count the step -----------------------------
 namespace {
 __global__ __launch_bounds__(256) void step_begin_kernel(uint4* __restrict__ a, int64_t na, uint4* __restrict__ b, int64_t nb,
-                                                         int32_t* __restrict__ step, const int64_t* __restrict__ active) {
+                                                         int32_t* __restrict__ step, const int64_t* __restrict__ active,
+                                                         int64_t* __restrict__ dropout_state) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += stride) {
@@ -558,20 +592,62 @@ __global__ __launch_bounds__(256) void step_begin_kernel(uint4* __restrict__ a, 
         else b[i - na] = z;
     }
     if (step != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && (active == nullptr || *active > 0)) *step += 1;
+    if (dropout_state != nullptr && blockIdx.x == 0 && threadIdx.x == 1) dropout_state[1] += 1;      // (cwn_dropout.h: fresh masks per step)
 }
 }  // namespace
 
 extern "C" int cwn_step_begin(void* a, int64_t a_bytes, void* b, int64_t b_bytes, int32_t* step, const int64_t* active,
-                              cwn_stream_t stream_) {
+                              int64_t* dropout_state, cwn_stream_t stream_) {
     if (a_bytes < 0 || b_bytes < 0 || (a_bytes & 15) || (b_bytes & 15)) return CWN_ERR_BAD_ARG;
     if ((a_bytes > 0 && a == nullptr) || (b_bytes > 0 && b == nullptr)) return CWN_ERR_BAD_ARG;
     if ((((uintptr_t)a) | ((uintptr_t)b)) & 15u) return CWN_ERR_ALIGN;
     const int64_t n = (a_bytes + b_bytes) / 16;
-    if (n == 0 && step == nullptr) return CWN_OK;
+    if (n == 0 && step == nullptr && dropout_state == nullptr) return CWN_OK;
     int64_t blocks = (n + 4 * 256 - 1) / (4 * 256);        // four 16-B stores per thread
     blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
     step_begin_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>((uint4*)a, a_bytes / 16, (uint4*)b,
-                                                                                       b_bytes / 16, step, active);
+                                                                                       b_bytes / 16, step, active, dropout_state);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+// ---- dropout as a launch of its own: the applications no producing / consuming kernel takes (cwn_dropout.h) ------------------
+namespace {
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M, int N, int64_t ldx,
+                                                      int64_t ldout, cwn_dropout d, const int64_t* __restrict__ m_dev, int vec) {
+    cwn::Dropout drop;
+    drop.init(d);
+    const int64_t Mv = m_dev != nullptr ? (*m_dev < M ? *m_dev : M) : M;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t nq = Mv * (N / 4);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
+            const int64_t r = i / (N / 4), c = (i - r * (N / 4)) * 4;
+            float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            const float4 m = drop.mul4((uint32_t)(((uint64_t)r * (uint64_t)N + (uint64_t)c) >> 2));
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+            *reinterpret_cast<float4*>(out + r * ldout + c) = v;
+        }
+    } else {
+        const int64_t n = Mv * N;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const int64_t r = i / N, c = i - r * N;
+            out[r * ldout + c] = x[r * ldx + c] * drop.mul1((uint64_t)i);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int cwn_dropout_f32(const float* x, float* out, int64_t M, int32_t N, int64_t ldx, int64_t ldout, const cwn_dropout* drop,
+                               const int64_t* m_dev, cwn_stream_t stream_) {
+    if (M < 0 || N <= 0 || drop == nullptr || !(drop->p >= 0.f && drop->p < 1.f)) return CWN_ERR_BAD_ARG;
+    if (M == 0) return CWN_OK;
+    if (x == nullptr || out == nullptr || ldx < N || ldout < N) return CWN_ERR_BAD_ARG;
+    if ((((uintptr_t)x) | ((uintptr_t)out)) & 3u) return CWN_ERR_ALIGN;
+    const int vec = (al16(x) && al16(out) && N % 4 == 0 && ldx % 4 == 0 && ldout % 4 == 0) ? 1 : 0;
+    const int64_t work = vec ? M * (N / 4) : M * N;
+    int64_t blocks = (work + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+    dropout_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(x, out, M, N, ldx, ldout, *drop, m_dev, vec);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 

@@ -124,7 +124,11 @@ class _Plan:
     without it the Function returns every branch's activated output and the caller concatenates and combines them."""
 
     def __init__(self, up: Optional[List[List[Stage]]], bd: Optional[List[List[Stage]]], cb: Optional[List[Stage]],
-                 chains: Optional[List[List[List[Stage]]]] = None):
+                 chains: Optional[List[List[List[Stage]]]] = None, out_drop: float = 0.0):
+        # out_drop: dropout probability of the layer's OUTPUT (OGBEmbedSparseCIN drops out after every conv layer,
+        # mp/molec_models.py:298-300): applied by the activation launch of the combine stage, re-derived by the reduce launch of
+        # its backward (ops: "dropout without a mask tensor"); plans with a combine stage only
+        self.out_drop = float(out_drop) if cb is not None else 0.0
         self.chains = chains if chains is not None else [[u, b] for u, b in zip(up, bd)]     # [dim][branch] -> stages
         self.cb = cb
         assert cb is None or all(2 <= len(c) <= 4 for c in self.chains)
@@ -295,13 +299,19 @@ class _DenseTrain(torch.autograd.Function):
             Z3 = []
             last = [(Z[i][br][-1], plan.chains[i][br][-1]) for i in range(nd) for br in range(nb)]
         H = [torch.empty_like(z) for z, _ in last]
-        acts = []
+        acts, drop_sites = [], []
         for (z, st), h in zip(last, H):
+            site = None
             if z.numel():
                 d = _norm_desc(z, out=h, aff=None if live else aff_of.get(id(st)))
                 if live:
                     d.bn = live_record(st)
+                if plan.out_drop > 0.0:
+                    d.drop = ops.dropout_record(dev, plan.out_drop, tag=('conv', len(drop_sites)))
+                    site = int(d.drop.site)
                 acts.append(d)
+            drop_sites.append(site)
+        ctx.drop_sites = drop_sites
         if acts:
             _ffi.norm_act(acts, dev)
         if bns:
@@ -391,6 +401,9 @@ class _DenseTrain(torch.autograd.Function):
             return _ffi.BnBwdLive(z=z.data_ptr(), aff=aff_of[id(st)].data_ptr(), slots=bslot_of[id(st)].data_ptr(),
                                   ldz=z.stride(0))
 
+        drop_of = {}          # id(combine stage) -> (cwn_dropout record, the multiplied gradient the reduce launch writes)
+        ld = lambda t: t.stride(0) if t.size(0) > 1 else t.size(1)
+
         def bnb_ok(dy, z):
             return (FUSED_NORM_APPLY and not fused_norm and z.size(1) in (64, 128) and z.numel() > 0
                     and all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in (dy, z)))
@@ -408,6 +421,11 @@ class _DenseTrain(torch.autograd.Function):
                 if not z.numel():
                     outs.append((dz, None) if lazy else dz)
                     continue
+                # (the layer's output dropout: `dy` arrives w.r.t. the dropped activation; the reduce launch multiplies it on
+                #  the way in and writes the product, which everything behind it reads)
+                dy_in, drop = dy, drop_of.get(id(st))
+                if drop is not None:
+                    dy = drop[1]
                 aff = aff_of.get(id(st))
                 s12 = G[id(st)][2]
                 tgt = norm_targets[id(st)]
@@ -421,7 +439,10 @@ class _DenseTrain(torch.autograd.Function):
                     s12.copy_(bslot_of[id(st)].sum(0))
                     have_slots = False
                 elif st.is_bn and not have_slots:
-                    red.append(_norm_desc(z, dy=dy, aff=aff, s12=s12))
+                    rd = _norm_desc(z, dy=dy_in, aff=aff, s12=s12)
+                    if drop is not None:
+                        rd.drop, rd.dy_out, rd.lddy_out = drop[0], dy.data_ptr(), ld(dy)
+                    red.append(rd)
                 if lazy:
                     b = _ffi.GemmBnb(z=z.data_ptr(), dz=dz.data_ptr(), ldz=z.stride(0), lddz=dz.stride(0), relu=1)
                     b.s_slots = bslot_of[id(st)] if have_slots else None
@@ -478,7 +499,17 @@ class _DenseTrain(torch.autograd.Function):
         else:
             dH = [g if g is not None else torch.zeros_like(z) for g, z in zip(dH, Z3)]
             dH = [ops._rowmajor(g, 'grad') for g in dH]
-            pend3 = norm_backward([(plan.cb[i], dH[i], Z3[i]) for i in range(nd)], lazy=True)
+            dH_in = list(dH)
+            for i, site in enumerate(ctx.drop_sites):
+                if site is None or not dH[i].numel():
+                    continue
+                rec = ops.dropout_record(dev, plan.out_drop, site)
+                if plan.cb[i].is_bn and not fused_norm:           # the reduce launch of this stage takes it
+                    dH[i] = torch.empty_like(dH[i])
+                    drop_of[id(plan.cb[i])] = (rec, dH[i])
+                else:                                             # no reduce launch (an identity norm): a launch of its own
+                    dH[i] = dH_in[i] = ops.dropout_apply(dH[i], rec)
+            pend3 = norm_backward([(plan.cb[i], dH_in[i], Z3[i]) for i in range(nd)], lazy=True)
             lazy3 = bool(pend3) and isinstance(pend3[0], tuple)
             dZ3 = [p[0] for p in pend3] if lazy3 else pend3
             tn, nn = [], []

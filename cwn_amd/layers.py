@@ -1086,18 +1086,35 @@ class SparseCINConv(torch.nn.Module):
             cbs.append(chains[2][0])
         if len({len(u) for u in ups}) != 1:
             return None
-        return DT.dense_train(DT._Plan(ups, bds, cbs), outs)
+        p = self._out_drop
+        self._out_dropped = p > 0.0              # (the combine stage's activation launch applies it: dense_train._Plan.out_drop)
+        return DT.dense_train(DT._Plan(ups, bds, cbs, out_drop=p), outs)
 
-    def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0):
+    # the caller's dropout of this layer's OUTPUT (OGBEmbedSparseCIN: after every conv, mp/molec_models.py:298-300), handed in
+    # so that the fused training path applies it inside its last launch: forward(..., out_dropout=p).  _dense_train sets
+    # _out_dropped when it has; every other path gets ops.dropout (one launch per dimension, no mask tensor).
+    _out_drop = 0.0
+    _out_dropped = False
+
+    def _finish_dropout(self, out: List[Tensor], start: int) -> List[Tensor]:
+        p, done = self._out_drop, self._out_dropped
+        self._out_drop, self._out_dropped = 0.0, False
+        if p <= 0.0 or done:
+            return out
+        return [x if dim < start or x is None else ops.dropout(x, p, True) for dim, x in enumerate(out)]
+
+    def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0, out_dropout: float = 0.0):
         assert len(cochain_params) <= self.max_dim + 1
         n = len(cochain_params)
+        self._out_drop, self._out_dropped = (float(out_dropout) if self.training else 0.0), False
         plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
         dense = self._dense_eval(plans, outs, start_to_process)
         if dense is None:
             dense = self._dense_train(plans, outs, start_to_process)
         if dense is not None:
             it = iter(dense)
-            return [cochain_params[dim].x if dim < start_to_process else next(it) for dim in range(n)]
+            return self._finish_dropout([cochain_params[dim].x if dim < start_to_process else next(it) for dim in range(n)],
+                                        start_to_process)
         # update / combine networks per dimension
         out, k = [], 0
         for dim in range(n):
@@ -1108,7 +1125,7 @@ class SparseCINConv(torch.nn.Module):
             else:
                 out.append(self.mp_levels[dim].finish(outs[k], outs[k + 1]))
                 k += 2
-        return out
+        return self._finish_dropout(out, start_to_process)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1400,7 +1417,9 @@ class CINppConv(SparseCINConv):
             try:
                 for lo in range(0, len(active), per):
                     grp = chains[lo: lo + per]
-                    res += DT.dense_train(DT._Plan(None, None, cbs[lo: lo + per], chains=grp), outs[nb * lo: nb * (lo + len(grp))])
+                    res += DT.dense_train(DT._Plan(None, None, cbs[lo: lo + per], chains=grp, out_drop=self._out_drop),
+                                          outs[nb * lo: nb * (lo + len(grp))])
+                self._out_dropped = self._out_drop > 0.0
                 return res
             except DT.CombineNeedsStageKernel:
                 if res:         # (a later group refused after an earlier one has run: running it again would count its batch twice)
@@ -1413,16 +1432,18 @@ class CINppConv(SparseCINConv):
             hs += DT.dense_train(DT._Plan(None, None, None, chains=grp), outs[nb * lo: nb * (lo + len(grp))])
         return [self.mp_levels[d].combine_nn(torch.cat(hs[nb * k: nb * (k + 1)], dim=-1)) for k, d in enumerate(active)]
 
-    def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0):
+    def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0, out_dropout: float = 0.0):
         """mp/layers.py:418-427."""
         assert len(cochain_params) <= self.max_dim + 1
+        self._out_drop, self._out_dropped = (float(out_dropout) if self.training else 0.0), False
         plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
         dense = self._dense_eval(plans, outs, start_to_process)
         if dense is None:
             dense = self._dense_train(plans, outs, start_to_process)
         if dense is not None:
             it = iter(dense)
-            return [c.x if dim < start_to_process else next(it) for dim, c in enumerate(cochain_params)]
+            return self._finish_dropout([c.x if dim < start_to_process else next(it) for dim, c in enumerate(cochain_params)],
+                                        start_to_process)
         out, k = [], 0
         for dim, cochain in enumerate(cochain_params):
             if dim < start_to_process:
@@ -1433,7 +1454,7 @@ class CINppConv(SparseCINConv):
                 m = len(plans[dim])
                 out.append(self.mp_levels[dim].finish(*outs[k:k + m]))
                 k += m
-        return out
+        return self._finish_dropout(out, start_to_process)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn import BatchNorm1d as BN, Embedding, Identity, LayerNorm as LN, Linear
 
-from . import layers, ops
+from . import _ffi, layers, ops
 from .layers import reset as reset_net
 from .complex import ComplexBatch
 from .csr import cached_adjacency
@@ -202,9 +202,13 @@ class _SparseCINStack(torch.nn.Module):
                 ops.pack_stage_weights_many(sw)
         for c, conv in enumerate(self.convs):
             params = self._edit_params(data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False))
-            xs = conv(*params, start_to_process=0)
-            if self.conv_dropout:
-                xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
+            if self.conv_dropout and self.training and self.dropout_rate > 0 and isinstance(conv, SparseCINConv):
+                # (the layer's own last launch applies it: layers.SparseCINConv.forward(out_dropout=))
+                xs = conv(*params, start_to_process=0, out_dropout=self.dropout_rate)
+            else:
+                xs = conv(*params, start_to_process=0)
+                if self.conv_dropout:
+                    xs = [ops.dropout(x, self.dropout_rate, self.training) for x in xs]
             data.set_xs(xs)
             if include_partial:
                 for k in range(len(xs)):
@@ -235,21 +239,21 @@ class _SparseCINStack(torch.nn.Module):
         dense_head = (self.nonlinearity == 'relu' and xs[0].is_cuda
                       and max(l.in_features for l in lins + [self.lin2]) <= ops.GEMM_MAX_K)
         if self.apply_dropout_before == 'lin1':
-            xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
+            xs = [ops.dropout(x, self.dropout_rate, self.training) for x in xs]
         if dense_head:     # lin1s of all dimensions (+ReLU) in ONE grouped MFMA launch
             new_xs = ops.gemm_many([ops.Gemm(X=x, W=l.weight, bias=l.bias, relu=True)
                                     for x, l in zip(xs, lins)])
         else:
             new_xs = [act(l(x)) for x, l in zip(xs, lins)]
         if self.apply_dropout_before == 'final_readout':
-            new_xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in new_xs]
+            new_xs = [ops.dropout(x, self.dropout_rate, self.training) for x in new_xs]
         x = new_xs[0]
         for t in new_xs[1:]:
             x = x + t
         if self.final_readout == 'mean':
             x = x / len(new_xs)
         if self.apply_dropout_before not in ['lin1', 'final_readout']:
-            x = F.dropout(x, p=self.dropout_rate, training=self.training)
+            x = ops.dropout(x, self.dropout_rate, self.training)
         if dense_head:
             x, = ops.gemm_many([ops.Gemm(X=x, W=self.lin2.weight, bias=self.lin2.bias)])
         else:
@@ -267,8 +271,11 @@ class _SparseCINStack(torch.nn.Module):
             return None
         if self.readout not in ('sum', 'mean') or self.final_readout not in ('sum', 'mean'):
             return None
-        if self.training and self.dropout_rate > 0:
+        # the head's dropout (`apply_dropout_before`, mp/molec_models.py:129-146) rides inside the launch (cwn_dropout)
+        drop_p = float(self.dropout_rate) if (self.training and self.dropout_rate > 0) else 0.0
+        if drop_p >= 1.0:
             return None
+        drop_pos = {'lin1': _ffi.HEAD_DROP_LIN1, 'final_readout': _ffi.HEAD_DROP_FINAL}.get(self.apply_dropout_before, _ffi.HEAD_DROP_LIN2)
         rd = list(self.readout_dims)
         if not rd or len(rd) > 3:
             return None
@@ -294,14 +301,14 @@ class _SparseCINStack(torch.nn.Module):
         if train:
             out, pooled = ops.head_train(hx, ptrs, plan.C, [l.weight for l in lins], [l.bias for l in lins],
                                          self.lin2.weight, self.lin2.bias, mean_readout=self.readout == 'mean',
-                                         mean_final=self.final_readout == 'mean')
+                                         mean_final=self.final_readout == 'mean', drop_p=drop_p, drop_pos=drop_pos)
             if include_partial:
                 for k in range(len(rd)):
                     res[f'pool_{k}'] = pooled[k]
             return out
         got = ops.head(hx, ptrs, plan.C, [l.weight for l in lins], [l.bias for l in lins], self.lin2.weight, self.lin2.bias,
                        mean_readout=self.readout == 'mean', mean_final=self.final_readout == 'mean',
-                       want_pooled=include_partial)
+                       want_pooled=include_partial, drop=ops.dropout_record(dev, drop_p, tag=('head', drop_pos)) if drop_p > 0 else None, drop_pos=drop_pos)
         if include_partial:
             out, pooled = got
             for k in range(len(rd)):
@@ -356,7 +363,7 @@ class EmbedSparseCIN(_SparseCINStack):
             assert data.cochains[1].x.size(-1) == 1
         params = self._edit_params(data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False))
         xs = list(self.init_conv(*params))
-        xs = [F.dropout(x, p=self.dropout_rate, training=self.training) for x in xs]
+        xs = [ops.dropout(x, self.dropout_rate, self.training) for x in xs]
         data.set_xs(xs)
         return self._convs_and_head(data, include_partial, {})
 
@@ -407,7 +414,7 @@ class OGBEmbedSparseCIN(_SparseCINStack):
     def forward(self, data: ComplexBatch, include_partial=False):
         params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
         xs = list(self.init_conv(*params))
-        xs = [F.dropout(x, p=self.in_dropout_rate, training=self.training) for x in xs]
+        xs = [ops.dropout(x, self.in_dropout_rate, self.training) for x in xs]
         data.set_xs(xs)
         return self._convs_and_head(data, include_partial, {})
 
@@ -492,7 +499,7 @@ class _CIN0Stack(torch.nn.Module):
         for t in pooled[1:]:
             x = x + t
         x = act(self.lin1(x))
-        x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        x = ops.dropout(x, self.dropout_rate, self.training)
         return self.lin2(x)
 
     def __repr__(self):
@@ -625,7 +632,7 @@ class EdgeOrient(torch.nn.Module):
             n = int(data.batch.max()) + 1
         x = global_pool(x, data.batch, int(n), mean=self.readout == 'mean')
         x = torch.relu(self.lin1(x))
-        x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        x = ops.dropout(x, self.dropout_rate, self.training)
         x = self.lin2(x)
         return (x, cell_pred) if include_partial else x
 

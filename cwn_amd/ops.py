@@ -753,7 +753,8 @@ def _transpose_many(weights: Sequence[Tensor]) -> None:
 
 def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexes: int, lin1_weights: Sequence[Tensor],
          lin1_biases: Sequence[Optional[Tensor]], lin2_weight: Tensor, lin2_bias: Optional[Tensor],
-         mean_readout: bool = False, mean_final: bool = False, want_pooled: bool = False, want_hidden: bool = False):
+         mean_readout: bool = False, mean_final: bool = False, want_pooled: bool = False, want_hidden: bool = False,
+         drop: Optional['_ffi.Dropout'] = None, drop_pos: int = 0):
     """pool_complex + lin1s (+ReLU) + final readout + lin2 in ONE launch (cwn_head_f32), one workgroup per complex.
     xs[d]: [N_d, K] or None (dimension absent from the batch: pooled zeros, mp/nn.py:55-56); cell_ptrs[d]: device
     int64 [C + 1], the collate's `ptr`.  Returns out [C, O] (and the pooled [C, K] per dimension)."""
@@ -790,7 +791,8 @@ def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexe
     arr = (_ffi.HeadDim * len(dims))(*dims)
     _ffi.check(_ffi.lib().cwn_head_f32(arr, len(dims), n_complexes, K, H2, 1 if mean_readout else 0,
                                        1 if mean_final else 0, w2.data_ptr(), _ffi.ptr(b2), O, out.data_ptr(),
-                                       _ffi.ptr(s_out), _ffi.stream_ptr(dev)), 'cwn_head_f32')
+                                       _ffi.ptr(s_out), drop, int(drop_pos) if drop is not None else 0, _ffi.stream_ptr(dev)),
+               'cwn_head_f32')
     if want_hidden:
         return out, pooled, hidden, s_out
     return (out, pooled) if want_pooled else out
@@ -805,12 +807,17 @@ class _HeadTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, *tensors):
-        n_dims, cell_ptrs, C, mean_readout, mean_final = meta
+        n_dims, cell_ptrs, C, mean_readout, mean_final = meta[:5]
+        drop_p, drop_pos = meta[5:7] if len(meta) > 5 else (0.0, 0)
         xs = tensors[:n_dims]
         w1s = tensors[n_dims:2 * n_dims]
         b1s = tensors[2 * n_dims:3 * n_dims]
         w2, b2 = tensors[3 * n_dims], tensors[3 * n_dims + 1]
-        out, pooled, hidden, s_out = head(xs, cell_ptrs, C, w1s, b1s, w2, b2, mean_readout, mean_final, want_hidden=True)
+        # the head's dropout (`apply_dropout_before`): multipliers derived in the kernel, re-derived by the backward
+        ctx.drop = dropout_record(next(x for x in xs if x is not None).device, drop_p, tag=('head', int(drop_pos))) if drop_p > 0 and drop_pos else None
+        ctx.drop_pos = int(drop_pos)
+        out, pooled, hidden, s_out = head(xs, cell_ptrs, C, w1s, b1s, w2, b2, mean_readout, mean_final, want_hidden=True,
+                                          drop=ctx.drop, drop_pos=ctx.drop_pos)
         ctx.meta = meta
         ctx.shapes = [None if x is None else (int(x.size(0)), int(x.size(1))) for x in xs]
         ctx.params = (w1s, b1s, w2, b2)
@@ -821,7 +828,7 @@ class _HeadTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, *_):
-        n_dims, cell_ptrs, C, mean_readout, mean_final = ctx.meta
+        n_dims, cell_ptrs, C, mean_readout, mean_final = ctx.meta[:5]
         saved = ctx.saved_tensors
         pooled, hidden, s_out = saved[:n_dims], saved[n_dims:2 * n_dims], saved[2 * n_dims]
         w1s, b1s, w2, b2 = ctx.params
@@ -847,7 +854,8 @@ class _HeadTrain(torch.autograd.Function):
         w2c = _f32c(w2.detach(), 'lin2 weight')
         arr = (_ffi.HeadBwdDim * n_dims)(*dims)
         _ffi.check(_ffi.lib().cwn_head_bwd_f32(arr, n_dims, C, K, H2, 1 if mean_readout else 0, 1 if mean_final else 0,
-                                               w2c.data_ptr(), O, g_out.data_ptr(), _ffi.stream_ptr(dev)), 'cwn_head_bwd_f32')
+                                               w2c.data_ptr(), O, g_out.data_ptr(), ctx.drop, ctx.drop_pos if ctx.drop is not None else 0,
+                                               _ffi.stream_ptr(dev)), 'cwn_head_bwd_f32')
         # weight gradients: sums over the complexes = dZ^T X on [C, .] matrices; in-place targets when the caller owns them
         jobs = [(dhs[d], pooled[d], w1s[d], b1s[d]) for d in range(n_dims)] + [(g_out, s_out, w2, b2)]
         grads_w, grads_b, descs, scratch = [], [], [], []
@@ -872,12 +880,105 @@ class _HeadTrain(torch.autograd.Function):
 
 
 def head_train(xs, cell_ptrs, n_complexes, lin1_weights, lin1_biases, lin2_weight, lin2_bias, mean_readout=False,
-               mean_final=False):
-    """(out, pooled list) with autograd: see _HeadTrain."""
+               mean_final=False, drop_p: float = 0.0, drop_pos: int = 0):
+    """(out, pooled list) with autograd: see _HeadTrain.  drop_p / drop_pos (_ffi.HEAD_DROP_*): the head's dropout, in-kernel."""
     n = len(xs)
-    meta = (n, list(cell_ptrs), int(n_complexes), bool(mean_readout), bool(mean_final))
+    meta = (n, list(cell_ptrs), int(n_complexes), bool(mean_readout), bool(mean_final), float(drop_p), int(drop_pos))
     res = _HeadTrain.apply(meta, *xs, *lin1_weights, *lin1_biases, lin2_weight, lin2_bias)
     return res[0], list(res[1:])
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout without a mask tensor (csrc/cwn_dropout.h; include/cwn_hip.h: cwn_dropout)
+# ------------------------------------------------------------------------------------------------
+# F.dropout of the callers (mp/molec_models.py:104-106, 298-300, 338-346): the keep decision of an element is a pure function of
+# (seed, step, site, element), so the launch that produces a value applies it in its epilogue and the launch that consumes the
+# gradient re-derives it -- cwn_norm_act_f32 / cwn_norm_bwd_reduce_f32 for a conv layer's output, cwn_head_f32 / _bwd for the
+# head's positions, cwn_dropout_f32 (a launch of its own, the same multipliers) everywhere else.  {seed, step} live in device
+# memory: a TrainStep's opening launch (cwn_step_begin) advances `step`, so a replayed graph never repeats a mask; `site` is a
+# host counter, new for every application (baked into a captured launch).
+_drop_states: Dict[torch.device, Tensor] = {}
+_drop_site = 0
+DROPOUT_TRACE: Optional[list] = None          # tests: a list that receives (site, p, tag) of every application
+
+
+def dropout_state(device) -> Tensor:
+    """device int64 [2] {seed, step}; the seed is torch's (torch.initial_seed()) when the state is first needed."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    t = _drop_states.get(device)
+    if t is None:
+        seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        t = _drop_states[device] = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+    return t
+
+
+def dropout_seed(seed: int, device=None) -> None:
+    """Re-seed (and rewind) the dropout stream of `device` (default: every device that has one, and the current one)."""
+    devs = [torch.device(device)] if device is not None else (list(_drop_states) or [torch.device('cuda', torch.cuda.current_device())])
+    for d in devs:
+        dropout_state(d).copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+
+
+def dropout_record(device, p: float, site: Optional[int] = None, tag=None) -> '_ffi.Dropout':
+    """The cwn_dropout record of a NEW application (or of `site`: the backward's)."""
+    global _drop_site
+    if site is None:
+        _drop_site = (_drop_site + 1) & 0xFFFFFFFF
+        site = _drop_site
+        if DROPOUT_TRACE is not None:
+            DROPOUT_TRACE.append((site, float(p), tag))
+    return _ffi.Dropout(state=dropout_state(device).data_ptr(), p=float(p), site=int(site))
+
+
+def dropout_apply(x: Tensor, rec: '_ffi.Dropout', out: Optional[Tensor] = None) -> Tensor:
+    """out = x * multipliers(rec) over the last dimension's rows (cwn_dropout_f32)."""
+    x2 = x if x.dim() == 2 else x.reshape(-1, x.size(-1) if x.dim() else 1)
+    x2 = _rowmajor(x2, 'x')
+    if out is None:
+        out = torch.empty(x2.shape, dtype=torch.float32, device=x2.device)
+    M, N = int(x2.size(0)), int(x2.size(1))
+    ld = lambda t: int(t.stride(0)) if t.size(0) > 1 else int(t.size(1))
+    if M and N:
+        _ffi.check(_ffi.lib().cwn_dropout_f32(x2.data_ptr(), out.data_ptr(), M, N, ld(x2), ld(out), rec, _ffi.dyn(M),
+                                              _ffi.stream_ptr(x2.device)), 'cwn_dropout_f32')
+    return out.view(x.shape) if out.shape != x.shape else out
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        rec = dropout_record(x.device, p, tag=('tensor', tuple(x.shape)))
+        ctx.p, ctx.site = float(p), int(rec.site)
+        return dropout_apply(x, rec)
+
+    @staticmethod
+    def backward(ctx, g):
+        return dropout_apply(g, dropout_record(g.device, ctx.p, ctx.site)), None
+
+
+def dropout(x: Tensor, p: float, training: bool = True) -> Tensor:
+    """F.dropout(x, p, training) on the device path: one launch forward, one backward, no mask tensor (the framework's form
+    is a fused dropout launch + a mask tensor + a masked multiply in the backward).  CPU tensors / other dtypes: F.dropout."""
+    if not training or p <= 0.0:
+        return x
+    if not x.is_cuda or x.dtype != torch.float32 or p >= 1.0 or x.numel() == 0:
+        return torch.nn.functional.dropout(x, p=p, training=True)
+    return _Dropout.apply(x, float(p))
+
+
+def dropout_multipliers(shape, p: float, site: int, device, step: Optional[int] = None) -> Tensor:
+    """The multipliers (0 or 1 / (1 - p)) application `site` uses over a matrix of `shape` at `step` (default: the current
+    one) -- what a checker applies in its own arithmetic."""
+    st = dropout_state(device)
+    if step is not None:
+        st = torch.stack([st[0], torch.tensor(int(step), dtype=torch.int64, device=st.device)])
+    rec = _ffi.Dropout(state=st.data_ptr(), p=float(p), site=int(site))
+    ones = torch.ones(shape, dtype=torch.float32, device=st.device)
+    out = dropout_apply(ones, rec)
+    torch.cuda.synchronize(st.device)           # (`st` may be a temporary)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1728,10 +1829,11 @@ class step_arena:
         if flat is not None and (flat.dtype != torch.float32 or not flat.is_contiguous() or flat.data_ptr() % 16 or (4 * flat.numel()) % 16):
             flat.zero_()
             flat = None
-        if a.high or flat is not None or self.counter is not None:
+        ds = _drop_states.get(self.device)       # (exists once a dropout has been applied on this device: fresh masks per step)
+        if a.high or flat is not None or self.counter is not None or ds is not None:
             _ffi.check(_ffi.lib().cwn_step_begin(_ffi.ptr(flat), 0 if flat is None else 4 * flat.numel(), a.buf.data_ptr(),
                                                  (a.high + 15) // 16 * 16, _ffi.ptr(self.counter), _ffi.ptr(self.active),
-                                                 _ffi.stream_ptr(self.device)), 'cwn_step_begin')
+                                                 _ffi.ptr(ds), _ffi.stream_ptr(self.device)), 'cwn_step_begin')
         a.used, a.active = 0, True
         return self
 

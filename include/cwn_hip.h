@@ -555,6 +555,32 @@ int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* l
  * reproducible in practice, not by construction; cwn_bn_finalize_f32 over per-band partials stays the deterministic form.
  * ------------------------------------------------------------------------------------------ */
 #define CWN_BN_SLOTS 4
+
+/* ------------------------------------------------------------------------------------------
+ * DROPOUT without a mask tensor (F.dropout of the callers: mp/molec_models.py:104-106 input features, :298-300 after every
+ * conv layer of OGBEmbedSparseCIN, :129-146 / :338-346 before lin1 / the final readout / lin2 -- exp/scripts/cwn-molhiv.sh
+ * trains with --drop_rate 0.5).  The keep decision of element e of one application is a pure function of (seed, step, site, e):
+ *     r = Philox4x32-10(counter = (e / 4, site, step_lo, step_hi), key = (seed_lo, seed_hi))[e % 4]
+ *     keep <=> r >= floor(p * 2^32);   y = keep ? x / (1 - p) : 0
+ * so the forward applies it in the epilogue of the launch that produces x and the backward re-derives it in the prologue of
+ * the launch that consumes the gradient -- no mask is written or read.  `state` = device int64 [2] {seed, step}: READ by the
+ * kernels; cwn_step_begin advances step, so every replay of a captured training step draws fresh masks.  `site` tells the
+ * applications of one step apart (a host-side counter baked into the launch).  e = row * N + column of the [M, N] matrix the
+ * application covers (row stride irrelevant).  state == NULL or p == 0: no dropout.  The stream is Philox as torch uses it but
+ * NOT torch's sequence (nothing in the reference pins a mask); cwn_dropout_f32 on a matrix of ones exports the mask for a
+ * checker.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cwn_dropout {
+    const int64_t* state;          /* device [2]: seed, step; NULL = off */
+    float p;                       /* drop probability, 0 <= p < 1 */
+    uint32_t site;
+} cwn_dropout;
+
+/* out[m, n] = x[m, n] * multiplier(m * N + n)  over an [M, N] matrix (the backward is the same call on the gradient).  x == out
+ * is allowed.  m_dev (or NULL): the rows that exist (M = capacity). */
+int cwn_dropout_f32(const float* x, float* out, int64_t M, int32_t N, int64_t ldx, int64_t ldout, const cwn_dropout* drop,
+                    const int64_t* m_dev, cwn_stream_t stream);
+
 typedef struct cwn_bn_live {
     double* slots;                 /* [CWN_BN_SLOTS][2][N]: column sums, column sums of squares */
     const float* gamma;            /* [N] or NULL (= 1) */
@@ -831,6 +857,12 @@ typedef struct cwn_norm_desc {
     float* acc2;         /* backward apply only, or NULL: acc2[n] += s2[n]  (gamma.grad: d gamma = s2); one writer per column */
     const int64_t* m_dev; /* or NULL: actual rows (M = capacity) */
     cwn_bn_live bn;       /* cwn_norm_act_f32 only; .slots != NULL: scale / shift are derived in the kernel (both NULL here) */
+    cwn_dropout drop;     /* cwn_norm_act_f32: out = dropout(act(..)) (the conv layer's output dropout, mp/molec_models.py:298-300);
+                           * cwn_norm_bwd_reduce_f32: dy is the gradient w.r.t. the DROPPED activation -- it is multiplied by the
+                           * same multipliers on the way in, and ...  (.state == NULL: unused) */
+    float* dy_out;        /* ... cwn_norm_bwd_reduce_f32 only, or NULL: the multiplied dy written here, row stride lddy_out (what
+                           * the launches behind the reduce read instead of dy) */
+    int64_t lddy_out;
 } cwn_norm_desc;
 
 /* out = act(z * scale + shift)                                    (the last stage's output) */
@@ -1072,10 +1104,15 @@ typedef struct cwn_head_dim {
     int64_t n_cells, ldx;
 } cwn_head_dim;
 
-/* s_out (optional, training): [C, H2] the hidden vector lin2 multiplies (sum / mean over the dimensions). */
+/* s_out (optional, training): [C, H2] the hidden vector lin2 multiplies (sum / mean over the dimensions).
+ * drop (or NULL) + drop_pos: the head's dropout (`apply_dropout_before`, mp/molec_models.py:129-146): CWN_HEAD_DROP_LIN1 on
+ * pooled_d (element (d C + c) K + k; pooled_out then holds the dropped vector -- what lin1 multiplies), CWN_HEAD_DROP_FINAL on
+ * relu(h_d) before the sum over the dimensions (element (d C + c) H2 + j), CWN_HEAD_DROP_LIN2 on the summed hidden vector
+ * (element c H2 + j; s_out holds the dropped vector). */
+enum { CWN_HEAD_DROP_NONE = 0, CWN_HEAD_DROP_LIN1 = 1, CWN_HEAD_DROP_FINAL = 2, CWN_HEAD_DROP_LIN2 = 3 };
 int cwn_head_f32(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
                  int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, float* s_out,
-                 cwn_stream_t stream);
+                 const cwn_dropout* drop, int32_t drop_pos, cwn_stream_t stream);
 
 /* Backward of the same head for the training step (exp/train_utils.py:62-73), one workgroup per complex, given
  * g_out = dL/dout [C, O] and what the forward left (h_out per dimension):
@@ -1093,8 +1130,11 @@ typedef struct cwn_head_bwd_dim {
     int64_t n_cells, lddx;
 } cwn_head_bwd_dim;
 
+/* drop / drop_pos: the forward's (the same multipliers are re-derived: ds, dh_d or dpooled_d is multiplied where the forward
+ * multiplied the value). */
 int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
-                     int32_t mean_final, const float* w2, int32_t O, const float* g_out, cwn_stream_t stream);
+                     int32_t mean_final, const float* w2, int32_t O, const float* g_out, const cwn_dropout* drop,
+                     int32_t drop_pos, cwn_stream_t stream);
 
 /* The loss of a training step and its gradient in one launch (exp/train_utils.py:62-73 with the elementwise-mean
  * criteria of :20-31): loss[0] = mean_i l(pred_i, y_i), grad_i = dl/dpred_i / n over n contiguous fp32 elements.
@@ -1115,8 +1155,10 @@ int cwn_loss_cols_f32(int32_t kind, const float* pred, const float* y, int64_t n
  * need zero on entry + the optimizer's step counter): a[0 .. a_bytes) = 0 (the flat gradient buffer), b[0 .. b_bytes) = 0 (the
  * step arena of cwn_amd/ops.py: slot sums of the live BatchNorms), and *step += 1 -- only when active == NULL or *active > 0
  * (cwn_adam_f32's convention: an empty batch of a static epoch is no step).  Pointers 16-B aligned, byte counts multiples of
- * 16; any of a / b / step may be NULL.  Replaces two fills and an add of the framework. */
-int cwn_step_begin(void* a, int64_t a_bytes, void* b, int64_t b_bytes, int32_t* step, const int64_t* active, cwn_stream_t stream);
+ * 16; any of a / b / step may be NULL.  Replaces two fills and an add of the framework.  dropout_state (or NULL): the
+ * {seed, step} record of cwn_dropout -- its step is advanced by one, unconditionally (a replayed step never repeats a mask). */
+int cwn_step_begin(void* a, int64_t a_bytes, void* b, int64_t b_bytes, int32_t* step, const int64_t* active,
+                   int64_t* dropout_state, cwn_stream_t stream);
 
 /* torch.optim.Adam's update (no amsgrad; weight_decay is the L2 form) for a whole model in one
  * launch: parameters p, gradients g and the moments m, v are each ONE contiguous fp32 buffer of n

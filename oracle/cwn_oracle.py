@@ -474,14 +474,20 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
                              final_readout: str = 'sum', training: bool = False, norm: str = 'bn',
                              jump_mode: Optional[str] = None, embed: Optional[str] = 'zinc',
                              init_reduce_mode: str = 'add', readout_dims=(0, 1, 2), conv: str = 'sparse_cin',
-                             drop_edge_up: bool = False):
+                             drop_edge_up: bool = False, dropout: Optional[Dict] = None, drop_position: str = 'lin2'):
     """SparseCIN.forward (mp/models.py:195-260), EmbedSparseCIN.forward (mp/molec_models.py:90-160)
     and OGBEmbedSparseCIN.forward (mp/molec_models.py:281-350) with dropout off and jump_mode in
     {None, 'cat', 'max'}.  `embed`: None (features used as they are), 'zinc' (one Embedding per dimension
     0/1) or 'ogb' (sum of per-column embeddings).  `conv='cinpp'`: EmbedCINpp / OGBEmbedCINpp (mp/molec_models.py:167-199,
     355-384: the same forward over CINppConv layers).  `drop_edge_up` (with max_dim 1): EmbedSparseCINNoRings
     (mp/molec_models.py:386-503: the edges' upper adjacency is removed from every layer's parameters, :456-457, 471-472).
+    `dropout`: the MULTIPLIERS (0 or 1 / (1 - p), a tensor per application) F.dropout would have drawn, handed in by the caller so
+    that a training forward with active dropout can be checked: keys ('in', d) -- the input features of dimension d
+    (mp/molec_models.py:104-106, 290-292), ('conv', l, d) -- the output of conv layer l, OGBEmbedSparseCIN only (:297-300),
+    ('head', k) -- the head's single application at `drop_position` (:129-146 / :334-346): before lin1 of readout dimension k
+    ('lin1'), on relu(lin1) of readout dimension k ('final_readout'), or ('head',) on the summed hidden vector (else).
     Returns (out, per-layer / pooled tensors)."""
+    dropout = dropout or {}
     cx = {'dimension': cx['dimension'], 'y': cx.get('y'), 'num_complexes': cx.get('num_complexes'),
           'cochains': [dict(c) for c in cx['cochains']]}
     partial = {}
@@ -507,6 +513,7 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
                 xs.append(ex)
                 if len(params) == 3:
                     xs.append(init_reduce(reduced, params[2]['boundary_index'], init_reduce_mode) / 2.)
+        xs = [x * dropout[('in', d)] if ('in', d) in dropout else x for d, x in enumerate(xs)]
         for d, x in enumerate(xs):
             cx['cochains'][d]['x'] = x
     jump = None
@@ -515,6 +522,7 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
         pre = f'convs.{l}.'
         lstate = {k[len(pre):]: v for k, v in state.items() if k.startswith(pre)}
         xs = sparse_cin_conv(lstate, params, use_coboundaries, training, norm, conv=conv)
+        xs = [x * dropout[('conv', l, d)] if ('conv', l, d) in dropout else x for d, x in enumerate(xs)]
         for d, x in enumerate(xs):
             cx['cochains'][d]['x'] = x
             partial[f'layer{l}_{d}'] = x
@@ -536,13 +544,21 @@ def sparse_cin_model_forward(state: Dict, cx: Dict, num_layers: int, max_dim: in
     for k, d in enumerate(dims):
         partial[f'pool_{k}'] = pooled[d]
     hs = []
-    for d in dims:
-        h = pooled[d] @ state[f'lin1s.{d}.weight'].t()
+    for k, d in enumerate(dims):
+        pin = pooled[d]
+        if drop_position == 'lin1' and ('head', k) in dropout:
+            pin = pin * dropout[('head', k)]
+        h = pin @ state[f'lin1s.{d}.weight'].t()
         if f'lin1s.{d}.bias' in state:
             h = h + state[f'lin1s.{d}.bias']
-        hs.append(torch.relu(h))
+        h = torch.relu(h)
+        if drop_position == 'final_readout' and ('head', k) in dropout:
+            h = h * dropout[('head', k)]
+        hs.append(h)
     h = torch.stack(hs, 0)
     h = h.sum(0) if final_readout == 'sum' else h.mean(0)
+    if drop_position not in ('lin1', 'final_readout') and ('head',) in dropout:
+        h = h * dropout[('head',)]
     return _lin(h, state, 'lin2'), partial
 
 

@@ -378,8 +378,8 @@ def edge_and_oriented():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'edge_oriented':
         edge_and_oriented()         # the round-3 fixture alone (the others stay byte-identical)
-    elif len(sys.argv) > 1 and sys.argv[1] in ('cinpp', 'cin0', 'no_rings'):
-        pass                        # a round-4 fixture alone (written at the end of this file)
+    elif len(sys.argv) > 1 and sys.argv[1] in ('cinpp', 'cin0', 'no_rings', 'dropout'):
+        pass                        # a round-4 / round-5 fixture alone (written at the end of this file)
     else:
         main()
         edge_and_oriented()
@@ -642,9 +642,69 @@ def cin0_models():
     save('cin0_models.npz', out)
 
 
+def dropout_models():
+    """Round 5: WHERE the reference drops out (mp/molec_models.py:104-106 input features, :298-300 after every conv layer of
+    OGBEmbedSparseCIN, :129-146 / :334-346 the head's `apply_dropout_before` position) -> dropout.npz.  The reference's models
+    run in TRAINING mode with dropout 0.5 (exp/scripts/cwn-molhiv.sh:11-14) while `F.dropout` in mp.molec_models is replaced by
+    a function that draws a Bernoulli keep-mask from a seeded generator, RECORDS the multipliers (0 or 1 / (1 - p)) and applies
+    them -- F.dropout's own arithmetic with the randomness handed in.  The fixture holds the state, the inputs, the recorded
+    multipliers in call order and the training-mode outputs (BatchNorm batch statistics); a checker that applies the same
+    multipliers at the same places must reproduce the outputs."""
+    import mp.molec_models as MM
+    from mp.molec_models import OGBEmbedSparseCIN
+    from ogb.graphproppred.mol_encoder import ATOM_DIMS, BOND_DIMS
+    out = {}
+    real = MM.F.dropout
+    for tag, pos, indrop in (('ogb_lin2', 'lin2', 0.0), ('ogb_lin1', 'lin1', 0.25), ('ogb_final', 'final_readout', 0.0)):
+        gen = torch.Generator().manual_seed(77)
+        torch.manual_seed(83)
+        cxs = [get(n) for n in MOL_LIST]
+        for cx in cxs:
+            n0 = cx.cochains[0].num_cells
+            cx.cochains[0]._Cochain__x = torch.stack([torch.randint(0, d, (n0,), generator=gen) for d in ATOM_DIMS], 1)
+            if cx.dimension >= 1:
+                n1 = cx.cochains[1].num_cells
+                cx.cochains[1]._Cochain__x = torch.stack([torch.randint(0, d, (n1,), generator=gen) for d in BOND_DIMS], 1)
+            if cx.dimension >= 2:
+                cx.cochains[2]._Cochain__x = None
+        b = ComplexBatch.from_complex_list(cxs, max_dim=2)
+        model = OGBEmbedSparseCIN(1, 2, 16, dropout_rate=0.5, indropout_rate=indrop, max_dim=2, jump_mode=None,
+                                  nonlinearity='relu', readout='mean', final_readout='sum', apply_dropout_before=pos,
+                                  init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn')
+        model.train()
+        out.update(state_np(model, f'{tag}/state'))
+        out[f'{tag}/v_feats'] = np_(b.cochains[0].x)
+        out[f'{tag}/e_feats'] = np_(b.cochains[1].x)
+        calls = []
+
+        def recorded(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                calls.append(None)
+                return x
+            m = (torch.rand(x.shape, generator=gen) >= p).to(x.dtype) / (1.0 - p)
+            calls.append(m)
+            return x * m
+        MM.F.dropout = recorded
+        try:
+            with torch.no_grad():
+                y, res = model(b, include_partial=True)
+        finally:
+            MM.F.dropout = real
+        out[f'{tag}/n_calls'] = np.int64(len(calls))
+        for k, m in enumerate(calls):
+            if m is not None:
+                out[f'{tag}/mult/{k}'] = np_(m)
+        out[f'{tag}/out'] = np_(y)
+        for k, v in res.items():
+            out[f'{tag}/{k}'] = np_(v)
+    save('dropout.npz', out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'no_rings':
         no_rings_model()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'dropout':
+        dropout_models()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cin0':
         cin0_models()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cinpp':
@@ -655,3 +715,4 @@ if __name__ == '__main__':
             cinpp_models()
             cin0_models()
             no_rings_model()
+            dropout_models()

@@ -369,3 +369,46 @@ def test_embed_sparse_cin_no_rings_golden():
         y, _ = O.sparse_cin_model_forward(state_dict(g, 'state'), cx, 2, max_dim=1, training=(mode == 'train'), embed='zinc',
                                           readout_dims=(0, 1), drop_edge_up=True)
         torch.testing.assert_close(y, T(g[f'{mode}/out']), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('tag,pos', [('ogb_lin2', 'lin2'), ('ogb_lin1', 'lin1'), ('ogb_final', 'final_readout')])
+def test_dropout_placement_golden(tag, pos):
+    """WHERE the reference drops out (round 5): OGBEmbedSparseCIN in TRAINING mode with dropout 0.5 (exp/scripts/cwn-molhiv.sh),
+    F.dropout's randomness recorded by the generating script (oracle/gen_golden.py dropout) -- call 0..2 the input features
+    (mp/molec_models.py:290-292), 3..8 the outputs of the two conv layers (:297-300), then the head's position (:334-346).
+    The oracle with the same multipliers at the same places reproduces every layer output, the pooled vectors and the
+    prediction."""
+    g = load('dropout.npz')
+    names = [str(n) for n in load('dummy_complexes.npz')['lists/mol']]
+    cx = O.batch_complexes([dummy_complex(n) for n in names], max_dim=2)
+    cx['cochains'][0]['x'], cx['cochains'][1]['x'] = T(g[f'{tag}/v_feats']), T(g[f'{tag}/e_feats'])
+    cx['cochains'][2]['x'] = None
+    mult = lambda k: T(g[f'{tag}/mult/{k}']) if f'{tag}/mult/{k}' in g else None
+    drop = {}
+    for d in range(3):
+        if mult(d) is not None:
+            drop[('in', d)] = mult(d)
+    for l in range(2):
+        for d in range(3):
+            drop[('conv', l, d)] = mult(3 + 3 * l + d)
+    n = int(g[f'{tag}/n_calls'])
+    if pos == 'lin1':
+        assert n == 12
+        for k in range(3):
+            drop[('head', k)] = mult(9 + k)
+    elif pos == 'final_readout':
+        assert n == 10
+        for k in range(3):
+            drop[('head', k)] = mult(9)[k]
+    else:
+        assert n == 10
+        drop[('head',)] = mult(9)
+    assert (pos == 'lin1') == (('in', 0) in drop)          # (only that variant has an input dropout rate)
+    y, partial = O.sparse_cin_model_forward(state_dict(g, f'{tag}/state'), cx, 2, readout='mean', embed='ogb', training=True,
+                                            dropout=drop, drop_position=pos)
+    for k, v in partial.items():
+        torch.testing.assert_close(v, T(g[f'{tag}/{k}']), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y, T(g[f'{tag}/out']), rtol=1e-4, atol=1e-4)
+    # ... and the multipliers matter: without them the prediction differs
+    y0, _ = O.sparse_cin_model_forward(state_dict(g, f'{tag}/state'), cx, 2, readout='mean', embed='ogb', training=True)
+    assert float((y0 - y).abs().max()) > 1e-3
