@@ -127,9 +127,12 @@ def test_conv_output_dropout_fused_into_the_activation_and_the_reduce_launches(F
     sum((o * m * wi).sum() for o, m, wi in zip(outs_b, ms, w)).backward()
     for d in range(3):
         gate(ga[d], xs_b[d].grad.double(), f'F={F}: dL/dx_{d} through the fused output dropout vs an explicit multiplication')
-    for n, q in conv.named_parameters():
-        if q.grad is not None:
-            gate(pa[n], q.grad.double(), f'F={F}: dL/d{n} through the fused output dropout')
+    refs = {n: q.grad.double() for n, q in conv.named_parameters() if q.grad is not None}
+    for n, r in refs.items():
+        # (the bias of a Linear in front of a BatchNorm has gradient ZERO in exact arithmetic -- the norm removes the column
+        #  mean; both sides hold the rounding residue of a sum of ~1e3 terms of size |dW|: gated at the scale of that sum)
+        tol = 1e-5 * max(1.0, float(refs[n[:-4] + 'weight'].abs().max())) if n.endswith('.bias') and n[:-4] + 'weight' in refs else 1e-5
+        gate(pa[n], r, f'F={F}: dL/d{n} through the fused output dropout', tol=tol)
     # eval mode: the argument is ignored
     conv.eval()
     with torch.no_grad():
@@ -287,8 +290,15 @@ def test_config3_training_step_with_dropout_vs_float64_oracle():
     rel, rel32 = (d2 / n2) ** 0.5, (d2_32 / n2) ** 0.5
     print(f'[gate] molhiv-512 with dropout 0.5: {n_par} parameter gradients vs float64 oracle autograd: worst max|delta| / max(1, |ref|_inf) = '
           f'{worst:.3e} (fp32 oracle: {worst32:.3e}); relative L2 {rel:.3e} (fp32 oracle: {rel32:.3e})')
-    assert worst <= 2.0 * max(worst32, 1e-5), (worst, worst32)
-    assert rel <= 2.0 * max(rel32, 1e-6), (rel, rel32)
+    # The bar.  A WRONG multiplier anywhere in the backward moves the gradient by O(1) relative (half the entries of a stream
+    # dropped or not); rounding moves it by what the reference's own fp32 arithmetic moves it -- and at p = 0.5 that depends on
+    # the masks drawn: measured over mask realisations (tools/diag_dropout_grads.py) the whole-gradient relative L2 distance is
+    # 1.3e-4 .. 4.0e-4 for the product and 0.9e-4 .. 1.7e-4 for the fp32 oracle, the worst entry 1.6e-5 .. 7.7e-5 vs 1.0e-5 ..
+    # 1.6e-5 (single ReLU / BatchNorm-sensitive entries: the first-layer edge networks).  So: no further from float64 than
+    # twice the fp32 oracle OR the absolute floors below, which sit three orders of magnitude under a mask error.  (The
+    # dropout-free step keeps its tight bar: tests/test_gpu_train_full.py.)
+    assert worst <= max(2.0 * worst32, 2e-4), (worst, worst32)
+    assert rel <= max(2.0 * rel32, 1e-3), (rel, rel32)
     # a second replay: the step counter moved, the masks with it (the loss of the same batch differs beyond one Adam step's reach)
     l2 = float(ts.step(0))
     torch.cuda.synchronize()
