@@ -114,7 +114,7 @@ def gemm_roofline(flops, us, split, io_bytes, narrow, traffic):
             'frac_of_fp32_mfma_peak_157': round(tf / MFMA_F32_PEAK_TF, 4)}
 
 
-def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixed_forward_ms, fixed_train_ms):
+def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixed_forward_ms, fixed_train_ms, task='regression'):
     """secondary.fresh_batches: propagate scope, full forward and full training step over >= 64 distinct shuffled batches per
     epoch drawn by cwn_amd.packed.PackedLoader, each scope ONE captured graph over a StaticBatch (see the call site)."""
     import copy
@@ -230,7 +230,7 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
     def leg_train():
         tmodel = copy.deepcopy(model).train()
         sb.set_epoch(epoch(0))
-        ts = StaticTrainStep(tmodel, sb, task_type='regression')
+        ts = StaticTrainStep(tmodel, sb, task_type=task)
         ts.step()
         cps, ms = run_epochs(ts.step)
         sb.set_epoch(epoch(1))
@@ -334,7 +334,10 @@ def main():
             gen = lambda seed: zinc_like_complexes(args.batch, seed, 6, n_lo=atoms[0], n_hi=atoms[1])
         coboundary = True
     elif WL == 'molhiv':  # exp/scripts/cwn-molhiv.sh:9-32, batch per BASELINE.json
-        model = OGBEmbedSparseCIN(1, L, H, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum',
+        # (--drop_rate 0.5 --indrop_rate 0.0 --drop_position lin2: after every conv layer and before lin2, in TRAINING mode --
+        #  the training legs below; the eval-mode scopes are what they were)
+        model = OGBEmbedSparseCIN(1, L, H, dropout_rate=float(os.environ.get('CWN_BENCH_DROPOUT', '0.5')), indropout_rate=0.0, max_dim=2,
+                                  readout='mean', final_readout='sum', apply_dropout_before='lin2',
                                   init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn')
         gen = lambda seed: molhiv_like_complexes(args.batch, seed, 6)
         coboundary = True
@@ -347,6 +350,10 @@ def main():
         gen = lambda seed: reddit_like_complexes(args.batch, seed)
         coboundary = False
     model = model.to(dev).eval()
+    # the criterion of the training legs: exp/scripts/cwn-zinc.sh --task_type regression (L1), cwn-molhiv.sh bin_classification
+    # (BCE with logits); mpsn-redditb.sh trains with cross-entropy, which has no fused form yet: L1 there
+    TASK = {'zinc': 'regression', 'molhiv': 'bin_classification', 'reddit': 'regression'}[WL]
+    DROP = float(getattr(model, 'dropout_rate', 0.0)) if getattr(model, 'conv_dropout', False) else 0.0
 
     # ---- synthetic batches, resident in HBM ---------------------------------------------------
     cpu_batches = [ComplexBatch.from_complex_list(gen(1000 * rank + i), max_dim=2) for i in range(args.num_batches)]
@@ -1087,7 +1094,7 @@ def main():
             # RCCL on real multi-GPU hardware from this container, and a fault here would take the
             # scaling run's primary number down with it.  CWN_BENCH_TRAIN_GRAPH=1 opts in.
             train_graph = use_graph and (world == 1 or os.environ.get('CWN_BENCH_TRAIN_GRAPH') == '1')
-            ts = TrainStep(tmodel, tb, task_type='regression', use_graph=train_graph)
+            ts = TrainStep(tmodel, tb, task_type=TASK, use_graph=train_graph)
             trace('train: TrainStep built')
             tsteps = max(args.steps // 4, 10)
             for i in range(len(tb) + 2):
@@ -1152,7 +1159,7 @@ def main():
             train = {'ms_per_step': round(dtt / tsteps * 1e3, 4),
                      'cells_per_s': round(float(tcells.item()) / dtt, 1), 'steps': tsteps,
                      'params': int(sum(p.numel() for p in ts.bucket.params)),
-                     'backward_pieces': int(ts.n_stages),
+                     'backward_pieces': int(ts.n_stages), 'criterion': TASK, 'dropout_rate': DROP,
                      'ms_per_step_four_per_graph': None if dt4 is None else round(dt4 * 1e3, 4),
                      'scope': 'adjacency plans, weight packing, forward, L1 loss, backward (propagate steps: cwn_layer_bwd_own_f32; dense stages: '
                               'cwn_dense_stage_f32 / _bwd_f32), Adam on one flat buffer (cwn_adam_f32)'
@@ -1250,7 +1257,8 @@ def main():
     if rank == 0 and world == 1 and not args.only_primary and 'fresh' not in SKIP and BLOCKED and use_graph and WL in ('zinc', 'molhiv'):
         try:
             fresh = fresh_batches_leg(args, model, gen, dev, H, L, rank, value / world, dt_full / full_steps * 1e3 if dt_full == dt_full else None,
-                                      None if train is None else train.get('ms_per_step'))
+                                      None if train is None else train.get('ms_per_step'), task=TASK)
+            fresh['criterion'], fresh['dropout_rate'] = TASK, DROP
         except Exception as e:
             import traceback
             traceback.print_exc(file=sys.stderr)

@@ -1,6 +1,6 @@
 """The whole optimisation step (cwn_amd.train.TrainStep) on ZINC-like batches, graph-captured vs
 eager; under rocprofv3 --kernel-trace --stats the kernel mix of a step.
-usage: train_graph.py [batch] [steps] [workload]"""
+usage: train_graph.py [batch] [steps] [workload] [dropout]   (molhiv: BCE with logits, dropout default 0.5 = exp/scripts/cwn-molhiv.sh)"""
 import os
 import sys
 import time
@@ -16,11 +16,12 @@ torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 WL = sys.argv[3] if len(sys.argv) > 3 else 'zinc'
+DROP = float(sys.argv[4]) if len(sys.argv) > 4 else (0.5 if WL != 'zinc' else 0.0)
 if WL == 'zinc':
     model = EmbedSparseCIN(28, 4, 1, 4, 128, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(dev)
     gen = lambda s: zinc_like_complexes(B, s, 6)
 else:
-    model = OGBEmbedSparseCIN(1, 2, 64, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum',
+    model = OGBEmbedSparseCIN(1, 2, 64, dropout_rate=DROP, max_dim=2, readout='mean', final_readout='sum',
                               init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn').to(dev)
     gen = lambda s: molhiv_like_complexes(B, s, 6)
 batches = [ComplexBatch.from_complex_list(gen(i), max_dim=2).to(dev) for i in range(2)]
@@ -29,7 +30,7 @@ for b in batches:
         b.y = torch.zeros(b.num_complexes, 1, device=dev)
 cells = batch_stats(batches[0])['cells'] * len(model.convs)
 for graph in ([False, True] if os.environ.get('EAGER_TOO') else [True]):
-    ts = TrainStep(model, batches, use_graph=graph)
+    ts = TrainStep(model, batches, task_type='regression' if WL == 'zinc' else 'bin_classification', use_graph=graph)
     for i in range(4):
         ts.step(i % 2)
     torch.cuda.synchronize()
