@@ -300,17 +300,13 @@ def test_config3_training_step_with_dropout_vs_float64_oracle():
     assert worst <= max(2.0 * worst32, 2e-4), (worst, worst32)
     assert rel <= max(2.0 * rel32, 1e-3), (rel, rel32)
     # a second replay: the step counter moved, the masks with it (the loss of the same batch differs beyond one Adam step's reach)
+    l1 = float(loss)                         # (the graph's loss tensor: the next replay overwrites it)
     l2 = float(ts.step(0))
     torch.cuda.synchronize()
     assert _state()[1] == step + 1
-    _, g_same = None, None
-    ref2, _ = _oracle_step({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, ocx, b.y.detach().cpu(), sites, step + 1,
-                           seed, sizes, 512, 128)
-    # (the oracle evaluated at the parameters AFTER the second step cannot reproduce l2 exactly; what must hold: masks of step
-    #  and step + 1 differ)
     m_a, m_b = multipliers((sizes[0], 64), 0.5, seed, step, sites[0]), multipliers((sizes[0], 64), 0.5, seed, step + 1, sites[0])
     assert 0.4 < float((m_a != m_b).mean()) < 0.6
-    assert abs(l2 - float(loss)) > 1e-6
+    assert abs(l2 - l1) > 1e-6
     # eval: identity, no site is drawn
     model.eval()
     ops.DROPOUT_TRACE = []
