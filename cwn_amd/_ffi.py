@@ -30,7 +30,7 @@ class CsrDesc(C.Structure):
                 ('n_entries', C.c_int64), ('n_dst', C.c_int64), ('n_val', C.c_int64),
                 ('n_aux', C.c_int64), ('rowptr', C.c_void_p), ('col', C.c_void_p),
                 ('perm', C.c_void_p), ('aux_out', C.c_void_p),
-                ('long_rows', C.c_void_p), ('n_long', C.c_void_p)]
+                ('long_rows', C.c_void_p), ('n_long', C.c_void_p), ('e_dev', C.c_void_p)]
 
 
 class AggDesc(C.Structure):

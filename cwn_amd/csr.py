@@ -78,7 +78,10 @@ class Adjacency:
             n_entries=self.n_entries, n_dst=self.n_dst, n_val=self.n_val, n_aux=self.n_aux,
             rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(), perm=self.perm.data_ptr(),
             aux_out=_ffi.ptr(self.aux), long_rows=_ffi.ptr(self.long_rows),
-            n_long=_ffi.ptr(self.n_long))
+            n_long=_ffi.ptr(self.n_long),
+            # a static buffer (cwn_amd/static_batch.py, mode 'csr'): n_entries is its capacity, the batch's own count is in
+            # device memory -- looked up like every other dynamic row count (_ffi.dynamic_rows)
+            e_dev=_ffi.dyn(self.n_entries))
 
     # ---- transposes for the backward pass ----------------------------------------------
     def transposes(self) -> List['Adjacency']:

@@ -40,6 +40,13 @@ struct CsrBatch {
     int dbg;   // timing experiments (CWN_CSR_DBG): 1 no rowptr stores, 2 no long-row notes, 4 no loads
 };
 
+// entries that exist: the host count, or -- a static buffer -- what the device says, never more than the capacity
+__device__ __forceinline__ int64_t live_entries(const cwn_csr_desc& D) {
+    if (D.e_dev == nullptr) return D.n_entries;
+    const int64_t e = *D.e_dev;
+    return e < 0 ? 0 : (e < D.n_entries ? e : D.n_entries);
+}
+
 __device__ __forceinline__ int find_desc(const int64_t* start, int n, int64_t b) {
     int d = 0;
 #pragma unroll
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CsrBatch B, int32_t* er
     const int di = find_desc(B.blk_start, B.n, blockIdx.x);
     const cwn_csr_desc& D = B.d[di];
     const int64_t e = (int64_t)(blockIdx.x - B.blk_start[di]) * kThreads + threadIdx.x;
-    const bool in = e < D.n_entries;
+    const bool in = e < live_entries(D);
     int64_t k = -1;
     int bad = 0;
     if (in) {
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void place_kernel(CsrBatch B) {
     const int di = find_desc(B.blk_start, B.n, blockIdx.x);
     const cwn_csr_desc& D = B.d[di];
     const int64_t e = (int64_t)(blockIdx.x - B.blk_start[di]) * kThreads + threadIdx.x;
-    if (e >= D.n_entries) return;
+    if (e >= live_entries(D)) return;
     const int s = B.slot[di][e];
     if (s < 0) return;
     const int64_t r = D.key[e];
@@ -374,16 +381,16 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
     const cwn_csr_desc& D = B.d[di];
     const int parts = B.part_start[di + 1] - B.part_start[di];
     const int part = blockIdx.x - B.part_start[di];
-    const int n = (int)D.n_dst, E = (int)D.n_entries;
+    const int n = (int)D.n_dst, Ecap = (int)D.n_entries, E = (int)live_entries(D);      // (LDS is laid out for the capacity)
     const int rows_per = (n + parts - 1) / parts;
     const int lo = min(part * rows_per, n), hi = min(lo + rows_per, n);
     const int rows = hi - lo;
     int32_t* cnt = lds;                     // [rows + 1] counters, then exclusive row starts
     int32_t* ent = cnt + (rows_per + 1);    // [E] original id of the part's j-th entry
-    int32_t* slot = ent + E;                // [E] arrival slot of that entry inside its row
-    int32_t* byrow = slot + E;              // [E] local entry ids grouped by row
-    int32_t* lrow = byrow + E;              // [E] local row (key - lo) of that entry
-    int32_t* misc = lrow + E;               // [0] entries of smaller rows, [1] entries of this part,
+    int32_t* slot = ent + Ecap;             // [E] arrival slot of that entry inside its row
+    int32_t* byrow = slot + Ecap;           // [E] local entry ids grouped by row
+    int32_t* lrow = byrow + Ecap;           // [E] local row (key - lo) of that entry
+    int32_t* misc = lrow + Ecap;            // [0] entries of smaller rows, [1] entries of this part,
                                             // [2] long rows of this part
     const bool has_aux = D.aux != nullptr;
     const int lane = threadIdx.x & 63;
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e = base + u * kSmallThreads + threadIdx.x;
-            k[u] = D.key[e < E ? e : E - 1];          // clamped: unconditional loads
+            k[u] = D.key[e < E ? e : (E > 0 ? E - 1 : 0)];          // clamped: unconditional loads
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
             cnt[i] = running + ex;
             D.rowptr[lo + i] = gbase + running + ex;
             if (c > CWN_LONG_ROW && D.long_rows != nullptr)   // this part's own sub-list
-                D.long_rows[(int64_t)part * (E / CWN_LONG_ROW + 1) + atomicAdd(&misc[2], 1)] = lo + i;
+                D.long_rows[(int64_t)part * (Ecap / CWN_LONG_ROW + 1) + atomicAdd(&misc[2], 1)] = lo + i;
         }
         running += total;
     }

@@ -90,6 +90,10 @@ typedef struct cwn_csr_desc {
     int32_t* aux_out;    /* [E] out or NULL */
     int32_t* long_rows;  /* [CWN_LONG_PARTS][E / CWN_LONG_ROW + 1] out or NULL: long-row lists */
     int32_t* n_long;     /* [CWN_LONG_PARTS] out or NULL: length of each list (all eight written) */
+    const int64_t* e_dev; /* or NULL: device int64, the ACTUAL number of entries (n_entries is then the CAPACITY of key / val / aux and
+                           * of the outputs: it sizes the grid, the workspace and the long-row lists; entries in [*e_dev, n_entries) are
+                           * not read).  With it a plan is (re)built inside a captured graph for whatever batch a static buffer holds
+                           * (cwn_amd/static_batch.py, mode 'csr'): rows past the batch's own cells simply have no entries. */
 } cwn_csr_desc;
 
 /* Rows with more entries than CWN_LONG_ROW are "long" (REDDIT-like hubs): cwn_csr_build lists

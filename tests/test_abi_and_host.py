@@ -41,7 +41,8 @@ def test_struct_layout_matches_header(tmp_path):
                'cwn_gemm_tn_desc': _ffi.GemmTnDesc, 'cwn_layer_dim': _ffi.LayerDim,
                'cwn_layer_plan': _ffi.LayerPlan, 'cwn_layer_bwd_dim': _ffi.LayerBwdDim, 'cwn_mlp_dim': _ffi.MlpDim, 'cwn_layer_sizes': _ffi.LayerSizes,
                'cwn_embed_table': _ffi.EmbedTable, 'cwn_head_dim': _ffi.HeadDim, 'cwn_head_bwd_dim': _ffi.HeadBwdDim,
-               'cwn_layer_bwd_plan': _ffi.LayerBwdPlan, 'cwn_stage_desc': _ffi.StageDesc, 'cwn_stage_bwd_desc': _ffi.StageBwdDesc}
+               'cwn_layer_bwd_plan': _ffi.LayerBwdPlan, 'cwn_stage_desc': _ffi.StageDesc, 'cwn_stage_bwd_desc': _ffi.StageBwdDesc,
+               'cwn_dropout': _ffi.Dropout}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cwn_hip.h"', 'int main(void) {']
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
