@@ -166,13 +166,14 @@ def wait_ready(adjs) -> None:
             a.ready = None
 
 
-def build_many(adjs: Sequence[Adjacency], overlap: bool = False, validate: bool = True) -> None:
+def build_many(adjs: Sequence[Adjacency], overlap: bool = False, validate: bool = True, force: bool = False) -> None:
     """Build any number of adjacencies with batched C-ABI calls (<= MAX_DESCS per call; each call is
     one launch for small inputs, a fixed sequence of 5-7 launches otherwise, whatever the number of
     index tensors).  `overlap=True` enqueues the build on a side stream and tags every plan with
     an event that the first aggregation using it waits on, so the integer work runs underneath
-    whatever dense work the caller issues next (the layer-0 message GEMMs)."""
-    adjs = [a for a in adjs if not a.built]
+    whatever dense work the caller issues next (the layer-0 message GEMMs).  `force`: plans that are built already are
+    built AGAIN (a static batch's buffers hold another batch now: cwn_amd/static_batch.py, mode 'csr')."""
+    adjs = [a for a in adjs if force or not a.built]
     if not adjs:
         return
     dev = adjs[0].device

@@ -665,6 +665,48 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pre
     __shared__ int cnt[256];
     // (a static batch: *n_dev complexes with `cols` predictions each are real, the rest of the n_cap elements is capacity)
     const int64_t n = n_dev != nullptr ? (*n_dev * cols < n_cap ? *n_dev * cols : n_cap) : n_cap;
+    if (kind == CWN_LOSS_CE) {
+        // torch.nn.CrossEntropyLoss() (exp/train_utils.py:21-22, REDDIT-BINARY / the TU datasets): pred [rows, cols] logits, y the
+        // class of every row as int64; loss = mean over the rows with a class >= 0 of logsumexp(row) - row[class] (a negative
+        // class = torch's ignore_index), grad = (softmax(row) - onehot) / rows counted.  A thread per row, fixed reduction tree.
+        const int64_t* cls = reinterpret_cast<const int64_t*>(y);
+        const int64_t rows = n / cols, rows_cap = n_cap / cols;
+        int valid = 0;
+        for (int64_t r = threadIdx.x; r < rows; r += 256) valid += (cls[r] >= 0 && cls[r] < cols) ? 1 : 0;
+        cnt[threadIdx.x] = valid;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) cnt[threadIdx.x] += cnt[threadIdx.x + off];
+            __syncthreads();
+        }
+        const float inv = 1.0f / (float)cnt[0];
+        float s = 0.f;
+        for (int64_t i = rows * cols + threadIdx.x; i < rows_cap * cols; i += 256) grad[i] = 0.f;
+        for (int64_t r = threadIdx.x; r < rows; r += 256) {
+            const float* p = pred + r * cols;
+            float* g = grad + r * cols;
+            const int64_t c = cls[r];
+            if (!(c >= 0 && c < cols)) {
+                for (int64_t j = 0; j < cols; ++j) g[j] = 0.f;
+                continue;
+            }
+            float m = p[0];
+            for (int64_t j = 1; j < cols; ++j) m = fmaxf(m, p[j]);
+            float z = 0.f;
+            for (int64_t j = 0; j < cols; ++j) z += expf(p[j] - m);
+            const float lse = m + logf(z);
+            s += lse - p[c];
+            for (int64_t j = 0; j < cols; ++j) g[j] = (expf(p[j] - lse) - (j == c ? 1.f : 0.f)) * inv;
+        }
+        part[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *loss = cnt[0] > 0 ? part[0] * inv : __int_as_float(0x7fc00000);
+        return;
+    }
     // null labels (exp/train_utils.py:64-66: `mask = ~torch.isnan(targets)`; ogbg-mol* tasks): not in the mean, no gradient
     int valid = 0;
     for (int64_t i = threadIdx.x; i < n; i += 256) valid += (y[i] == y[i]) ? 1 : 0;
@@ -707,7 +749,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pre
 
 extern "C" int cwn_loss_cols_f32(int32_t kind, const float* pred, const float* y, int64_t n, int64_t cols, float* loss, float* grad,
                                  const int64_t* n_dev, cwn_stream_t stream_) {
-    if (kind < 0 || kind > CWN_LOSS_BCE_LOGITS || n <= 0 || cols <= 0 || n % cols != 0 || pred == nullptr || y == nullptr ||
+    if (kind < 0 || kind > CWN_LOSS_CE || n <= 0 || cols <= 0 || n % cols != 0 || pred == nullptr || y == nullptr ||
         loss == nullptr || grad == nullptr)
         return CWN_ERR_BAD_ARG;
     loss_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)stream_>>>(pred, y, n, kind, loss, grad, n_dev, cols);
@@ -716,6 +758,7 @@ extern "C" int cwn_loss_cols_f32(int32_t kind, const float* pred, const float* y
 
 extern "C" int cwn_loss_f32(int32_t kind, const float* pred, const float* y, int64_t n, float* loss, float* grad,
                             const int64_t* n_dev, cwn_stream_t stream_) {
+    if (kind == CWN_LOSS_CE) return CWN_ERR_BAD_ARG;          // (needs the number of classes: cwn_loss_cols_f32)
     return cwn_loss_cols_f32(kind, pred, y, n, 1, loss, grad, n_dev, stream_);
 }
 

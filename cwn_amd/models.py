@@ -282,9 +282,9 @@ class _SparseCINStack(torch.nn.Module):
         lins = [self.lin1s[d] for d in rd]
         train = torch.is_grad_enabled() and (any(p.requires_grad for l in lins + [self.lin2] for p in l.parameters())
                                              or any(x.requires_grad for x in xs))
-        if train and (not ops.FUSED_HEAD_TRAINING or any(d >= len(xs) for d in rd) or any(l.bias is None for l in lins)
-                      or self.lin2.bias is None):
-            return None              # (absent dimensions / bias-free lin1s: the unfused autograd path)
+        if train and (not ops.FUSED_HEAD_TRAINING or any(d >= len(xs) for d in rd) or self.lin2.bias is None
+                      or len({l.bias is None for l in lins}) != 1):
+            return None              # (absent dimensions: the unfused autograd path; bias-free lin1s -- jump_mode 'cat' -- ride along)
         plan = data.block_plan()
         if plan is None or data.num_complexes is None or plan.C != data.num_complexes:
             return None

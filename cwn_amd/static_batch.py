@@ -184,6 +184,10 @@ class StaticSlot:
         o = self.owner
         m = {o.cap_cells[d]: self.size_ptr(d) for d in range(min(o.D, 3))}
         m[o.B] = self.size_ptr(3)
+        # entry counts of the index keys (cwn_csr_desc.e_dev of a plan built over this slot's buffers)
+        for k, (d, key, pk) in enumerate(o.packed._klist):
+            if key in _TWO_ROW:
+                m[o._caps[k]] = self.size_ptr(8 + k)
         return _ffi.dynamic_rows(m)
 
 
@@ -197,7 +201,17 @@ class StaticBatch:
     `fits(batches)` tells the caller which batches the buffers hold."""
 
     def __init__(self, packed: PackedComplexes, batch_size: int, caps: Optional[dict] = None, variant: int = 0,
-                 group: Optional[int] = None, indices: Optional[Sequence[int]] = None, slots: int = 1):
+                 group: Optional[int] = None, indices: Optional[Sequence[int]] = None, slots: int = 1, mode: str = 'blocked'):
+        """mode 'blocked' (default): the complex-blocked launches of SparseCINConv are the only path -- item tables cut on the
+        device, no CSR of the upper adjacencies; a complex beyond one workgroup does not fit.  mode 'csr' (round 5): every
+        adjacency of a slot gets a REAL destination-sorted CSR plan, rebuilt by the fill from the slot's int64 entries with
+        the entry count read from the tables (cwn_csr_desc.e_dev) -- the streaming path (grouped GEMM + cwn_aggregate_f32)
+        then runs inside the captured graph: hub complexes (REDDIT-like clique lifts), CINppConv / OrientedConv layers,
+        molecules beyond a workgroup.  No item tables in this mode (the layers take their CSR path)."""
+        if mode not in ('blocked', 'csr'):
+            raise ValueError("mode 'blocked' or 'csr'")
+        self.mode = mode
+        self.build_backward = False          # (StaticTrainStep: the fill also builds the transposed plans)
         if not packed.with_csr:
             raise ValueError('StaticBatch needs a PackedComplexes built with with_csr=True')
         if packed.device.type != 'cuda':
@@ -243,6 +257,13 @@ class StaticBatch:
             else:
                 c = int(caps.get((d, key), cap_of(meta[:, 3 * D + k])))
             self._caps.append(int(c))
+        # the entry capacities of the index keys: pairwise distinct and distinct from the cell capacities -- an Adjacency's
+        # capacity then identifies the size word its actual count lives in (dynamic(): _ffi.dynamic_rows)
+        for k, (d, key, pk) in enumerate(packed._klist):
+            if key in _TWO_ROW:
+                while self._caps[k] in used:
+                    self._caps[k] += 1
+                used.add(self._caps[k])
         for d in range(1, D):            # the CSR columns cover the boundary entries one to one
             kb = self.k_of(d, 'boundary_index')
             if kb >= 0:
@@ -310,6 +331,7 @@ class StaticBatch:
         # ---- the slots: a ComplexBatch over slot j's views, its plans ---------------------------------------------------
         self._families: Dict = {}
         self._adjs = []
+        self._slot_adjs: Dict[int, list] = {}      # mode 'csr': the upper / lower adjacencies of every slot (rebuilt by every fill)
         self.slots: List[StaticSlot] = [self._make_slot(j) for j in range(S)]
         # (slot 0 under the names a one-slot caller uses)
         self.batch, self.plan = self.slots[0].batch, self.slots[0].plan
@@ -346,8 +368,18 @@ class StaticBatch:
                 self._register(bi, adj)
             if cb.upper_index is not None and d + 1 < D:
                 ui = cb.upper_index
-                self._register(ui, _PlanOnlyAdjacency(ui, self.cap_cells[d], self.cap_cells[d], cb.shared_coboundaries,
-                                                      self.cap_cells[d + 1]))
+                if self.mode == 'csr':
+                    adj = csr.Adjacency(ui[1], ui[0], self.cap_cells[d], self.cap_cells[d], cb.shared_coboundaries, self.cap_cells[d + 1])
+                    self._slot_adjs.setdefault(j, []).append(adj)
+                    self._register(ui, adj)
+                else:
+                    self._register(ui, _PlanOnlyAdjacency(ui, self.cap_cells[d], self.cap_cells[d], cb.shared_coboundaries,
+                                                          self.cap_cells[d + 1]))
+            if self.mode == 'csr' and d > 0 and getattr(cb, 'lower_index', None) is not None:
+                li = cb.lower_index
+                adj = csr.Adjacency(li[1], li[0], self.cap_cells[d], self.cap_cells[d], cb.shared_boundaries, self.cap_cells[d - 1])
+                self._slot_adjs.setdefault(j, []).append(adj)
+                self._register(li, adj)
         plan = StaticBlockPlan(self, j)
         some = next(iter(bufs.values()))
         batch._block_plan = (some.device, plan)          # (the device as the tensors spell it: Complex.block_plan compares)
@@ -420,6 +452,8 @@ class StaticBatch:
         return self._families[key]
 
     def _make_family(self, kind: str, F: int, has_up, has_b):
+        if self.mode == 'csr':
+            return None                        # (no item tables: the layers take their CSR path)
         if F not in (64, 128) or any(has_up[d] and (d + 1 >= self.D or self.k_of(d, 'upper_index') < 0) for d in range(self.D)):
             return None
         S, B, dev = self.S, self.B, self.device
@@ -608,6 +642,19 @@ class StaticBatch:
         self.fill_id += 1
         for key in self._families:
             self._launch_family(key, n)
+        if self.mode == 'csr':
+            # the CSR plans of the upper / lower adjacencies (and, for a training step, their transposes) of every slot:
+            # cwn_csr_build over the capacity-sized entries with the count in device memory -- one batched call per slot
+            for j in range(n):
+                todo = []
+                for adj in self._slot_adjs.get(j, []):
+                    todo.append(adj)
+                    if self.build_backward:
+                        adj.transposes()
+                        todo += [t for t in (adj._t_src, adj._t_aux) if t is not None]
+                if todo:
+                    with self.slots[j].dynamic():
+                        csr.build_many(todo, validate=False, force=True)
 
     # ---- the reference tables (tests) -----------------------------------------------------------------------------------
     def host_tables(self, idx: Sequence[int]) -> np.ndarray:

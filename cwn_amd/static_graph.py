@@ -155,16 +155,24 @@ from .static_batch import StaticBatch            # noqa: E402
 from .train import TrainStep                     # noqa: E402
 
 
-def refuse_unsupported_layers(model: torch.nn.Module, who: str) -> None:
-    """A static batch carries, per slot, what SparseCINConv's blocked kernels read (item tables, the collated CSR of the
-    boundary adjacencies for the backward) -- not a CSR plan of the UPPER / LOWER adjacencies, which the streaming aggregation
-    of other layers (CINppConv, CINConv, OrientedConv) builds per batch on the host's sizes.  Those layers take collated
-    batches (`model(batch)`, TrainStep); here they are refused instead of being handed capacity-sized index buffers."""
+def refuse_unsupported_layers(model: torch.nn.Module, who: str, static: Optional['StaticBatch'] = None, training: bool = False) -> None:
+    """A static batch in mode 'blocked' carries, per slot, what SparseCINConv's blocked kernels read (item tables, the collated
+    CSR of the boundary adjacencies for the backward) -- not a CSR plan of the UPPER / LOWER adjacencies, which the streaming
+    aggregation of other layers (CINppConv, CINConv, OrientedConv) reads: those layers are refused there.  In mode 'csr'
+    (round 5) the fill rebuilds those plans on the device (cwn_csr_desc.e_dev) and every layer's streaming path runs inside the
+    captured graph -- except, in TRAINING, CINConv / EdgeCINConv: their per-entry BatchNorm takes its statistics with framework
+    reductions over the capacity rows of a slot, which would count rows the batch does not have."""
     from .layers import CINConv, CINppConv, EdgeCINConv, OrientedConv
-    bad = sorted({type(m).__name__ for m in model.modules() if isinstance(m, (CINppConv, CINConv, EdgeCINConv, OrientedConv))})
+    if static is not None and static.mode == 'csr':
+        kinds = (CINConv, EdgeCINConv) if training else ()
+        why = 'their per-entry BatchNorm(train) statistics are framework reductions over the capacity rows of a slot'
+    else:
+        kinds = (CINppConv, CINConv, EdgeCINConv, OrientedConv)
+        why = "their aggregation needs a CSR plan of the upper / lower adjacency: build the StaticBatch with mode='csr'"
+    bad = sorted({type(m).__name__ for m in model.modules() if kinds and isinstance(m, kinds)})
     if bad:
-        raise NotImplementedError(f'{who}: {", ".join(bad)} layers are not served by static batches (their aggregation needs a '
-                                  f'per-batch CSR plan of the upper / lower adjacency); use collated batches with model(batch) / TrainStep')
+        raise NotImplementedError(f'{who}: {", ".join(bad)} layers are not served by this static batch ({why}); or use collated '
+                                  'batches with model(batch) / TrainStep')
 
 
 class StaticForward:
@@ -175,7 +183,7 @@ class StaticForward:
     a parameter (or, through ops.STATE_EPOCH, a raw-pointer writer such as a TrainStep) has changed them."""
 
     def __init__(self, model: torch.nn.Module, static: StaticBatch):
-        refuse_unsupported_layers(model, 'StaticForward')
+        refuse_unsupported_layers(model, 'StaticForward', static)
         self.model, self.sb = model, static
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.outs: Optional[List[torch.Tensor]] = None
@@ -240,8 +248,9 @@ class StaticTrainStep(TrainStep):
 
     def __init__(self, model: torch.nn.Module, static: StaticBatch, task_type: str = 'regression', lr: float = 1e-3,
                  use_graph: bool = True, optimizer=None):
-        refuse_unsupported_layers(model, 'StaticTrainStep')
+        refuse_unsupported_layers(model, 'StaticTrainStep', static, training=True)
         self.sb = static
+        static.build_backward = True                  # (mode 'csr': the fill also builds the transposed plans)
         static.fill()                                 # the buffers hold real batches from here on (warm-up)
         super().__init__(model, [sl.batch for sl in static.slots], task_type=task_type, lr=lr, use_graph=use_graph,
                          optimizer=optimizer, rebuild_plans=False, stages=1)
@@ -264,9 +273,9 @@ class StaticTrainStep(TrainStep):
         from .train import fused_loss
         pred = self.model(b)
         if self.task_type == 'classification':
-            raise NotImplementedError('StaticTrainStep: the cross-entropy criterion is not restated for static batches '
-                                      '(regression / mse_regression / bin_classification are): use TrainStep on collated batches')
-        loss = fused_loss(self.task_type, pred, b.y.view(pred.shape).to(pred.dtype))
+            loss = fused_loss(self.task_type, pred, b.y.view(-1))         # (cross-entropy over the complexes that exist: CWN_LOSS_CE)
+        else:
+            loss = fused_loss(self.task_type, pred, b.y.view(pred.shape).to(pred.dtype))
         if loss is None:
             raise NotImplementedError('StaticTrainStep: predictions / targets the fused criterion does not take (float32 CUDA '
                                       'tensors of one shape)')

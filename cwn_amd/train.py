@@ -50,6 +50,7 @@ class _FusedMeanLoss(torch.autograd.Function):
         grad = torch.empty_like(p)
         n_dev = _ffi.dyn(p.size(0)) if p.dim() >= 1 else None          # a static batch: the complexes that exist (device int64)
         cols = p.numel() // p.size(0) if (p.dim() >= 1 and p.size(0) > 0) else 1         # (multi-task heads: [complexes, tasks])
+        # (cross-entropy: `y` holds one int64 class per row -- CWN_LOSS_CE reads it as such)
         _ffi.check(_ffi.lib().cwn_loss_cols_f32(kind, p.data_ptr(), y.contiguous().data_ptr(), p.numel(), cols, loss.data_ptr(),
                                                 grad.data_ptr(), n_dev, _ffi.stream_ptr(p.device)), 'cwn_loss_cols_f32')
         ctx.save_for_backward(grad)
@@ -75,7 +76,7 @@ def _one(device) -> torch.Tensor:
     return t
 
 
-_FUSED_KIND = {'regression': 0, 'mse_regression': 1, 'bin_classification': 2}      # = CWN_LOSS_*
+_FUSED_KIND = {'regression': 0, 'mse_regression': 1, 'bin_classification': 2, 'classification': 3}      # = CWN_LOSS_*
 FUSED_LOSS = True
 
 
@@ -83,8 +84,14 @@ def fused_loss(task_type: str, pred: torch.Tensor, y: torch.Tensor) -> Optional[
     """The task's criterion through cwn_loss_f32, or None when it does not apply (CPU tensors, other dtypes / shapes,
     CrossEntropy)."""
     kind = _FUSED_KIND.get(task_type)
-    if (not FUSED_LOSS or kind is None or not pred.is_cuda or pred.dtype != torch.float32 or y.dtype != torch.float32
-            or pred.shape != y.shape or pred.numel() == 0 or not y.is_cuda or y.device != pred.device):
+    if not FUSED_LOSS or kind is None or not pred.is_cuda or pred.dtype != torch.float32 or pred.numel() == 0 or not y.is_cuda \
+            or y.device != pred.device:
+        return None
+    if task_type == 'classification':
+        # torch.nn.CrossEntropyLoss() (exp/train_utils.py:21-22): logits [complexes, classes], one int64 class per complex
+        if pred.dim() != 2 or y.dtype != torch.long or y.dim() != 1 or y.numel() != pred.size(0):
+            return None
+    elif y.dtype != torch.float32 or pred.shape != y.shape:
         return None
     return _FusedMeanLoss.apply(pred, y, kind)
 

@@ -1144,7 +1144,9 @@ int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims_host, int n_dims, int64_t C, i
  * criteria of :20-31): loss[0] = mean_i l(pred_i, y_i), grad_i = dl/dpred_i / n over n contiguous fp32 elements.
  * kinds: L1Loss, MSELoss, BCEWithLogitsLoss (torch's definitions, incl. sign(0) = 0 and the stable BCE form).
  * One workgroup, fixed reduction tree (deterministic); meant for the few hundred predictions of a batch. */
-enum { CWN_LOSS_L1 = 0, CWN_LOSS_MSE = 1, CWN_LOSS_BCE_LOGITS = 2 };
+enum { CWN_LOSS_L1 = 0, CWN_LOSS_MSE = 1, CWN_LOSS_BCE_LOGITS = 2, CWN_LOSS_CE = 3 };
+/* CWN_LOSS_CE (cwn_loss_cols_f32 only): torch.nn.CrossEntropyLoss() of exp/train_utils.py:21-22 -- pred = [rows, cols] logits and
+ * `y` points at the rows' classes as int64 (not float); a class outside [0, cols) is ignored like torch's ignore_index. */
 /* n_dev (or NULL): device int64 = the ACTUAL number of elements (n is then the capacity: grad[i] = 0 for i >= *n_dev).
  * A target that is NaN is a NULL label (exp/train_utils.py:64-66: `mask = ~torch.isnan(targets)`): it contributes no loss and
  * no gradient and does not count in the mean. */

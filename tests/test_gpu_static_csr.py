@@ -1,0 +1,226 @@
+"""Static batches in mode 'csr' (round 5; VERDICT r4 "what's missing" #2): the never-seen-batch fast path for what the
+complex-blocked launches do not serve -- REDDIT-like clique lifts with hub complexes (BASELINE configs[4],
+exp/scripts/mpsn-redditb.sh, trained with cross-entropy: exp/train_utils.py:21-22), CINppConv / OrientedConv layers, molecules
+beyond one workgroup.  The fill rebuilds every slot's CSR plans on the device from the capacity-sized int64 entries
+(cwn_csr_desc.e_dev); the streaming path then runs inside ONE captured graph for every batch of the shuffled epoch
+(data/data_loading.py:84-111).  Pinned on the per-batch launches over PackedComplexes.collate of the same complexes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+
+
+def _reddit_pool(n=40, seed=2, n_lo=60, n_hi=260):
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.synthetic import reddit_like_complexes
+    pool = reddit_like_complexes(n, seed=seed, n_lo=n_lo, n_hi=n_hi)
+    return pool, PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+
+
+def _batches(n, B, seed, sizes=None):
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(n)
+    out, lo = [], 0
+    for b in (sizes or [B] * (n // B)):
+        out.append(perm[lo:lo + b])
+        lo += b
+    return out
+
+
+def _reddit_model(hidden=64, layers=4, seed=0):
+    from cwn_amd.models import SparseCIN
+    torch.manual_seed(seed)
+    m = SparseCIN(1, 2, layers, hidden, dropout_rate=0.0, max_dim=2, jump_mode='cat', readout='sum', use_coboundaries=False,
+                  graph_norm='id').to(DEV)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.mul_(0.3)          # (no norm layer and degrees in the hundreds: keep activations finite, as bench.py does)
+    return m
+
+
+def test_device_built_plans_equal_the_per_batch_plans():
+    """After a fill the plan of every upper adjacency of every slot -- rowptr, col, perm, the shared-cell index, the hub-row
+    lists -- equals cwn_csr_build on the collated batch of the same complexes (rows past the batch's cells: no entries), and so
+    do the transposed plans a training step needs; a short batch and an empty slot included."""
+    from cwn_amd import csr
+    from cwn_amd.static_batch import StaticBatch
+    pool, p = _reddit_pool()
+    B, S = 6, 3
+    sb = StaticBatch(p, B, slots=S, mode='csr')
+    sb.build_backward = True
+    batches = _batches(len(pool), B, 4, sizes=[B, 3])
+    assert sb.fits(batches).all()
+    sb.set_batches(batches)
+    sb.fill()
+    torch.cuda.synchronize()
+    csr.check_errors(DEV)
+    saw_long = False
+    for j in range(S):
+        if j >= len(batches):
+            assert sb.sizes(j) == [0, 0, 0, 0]
+            for adj in sb._slot_adjs[j]:
+                assert int(adj.rowptr[-1]) == 0 and not adj.rowptr.any()
+            continue
+        ref = p.collate(batches[j]).prepare(backward=True)
+        n = [ref.cochains[d].num_cells for d in range(3)]
+        assert sb.sizes(j) == n + [len(batches[j])]
+        for d in range(2):
+            rc = ref.cochains[d]
+            want = csr.cached_adjacency(rc.upper_index, n[d], n[d], rc.shared_coboundaries, n[d + 1])
+            got = csr.cached_adjacency(sb.slots[j].batch.cochains[d].upper_index, sb.cap_cells[d], sb.cap_cells[d],
+                                       sb.slots[j].batch.cochains[d].shared_coboundaries, sb.cap_cells[d + 1], build=False)
+            assert got in sb._slot_adjs[j] and got.built
+            E = want.n_entries
+            for a, b, name in ((got, want, 'plan'), (got._t_src, want.t_src, 't_src'), (got._t_aux, want.t_aux, 't_aux')):
+                nd = b.n_dst
+                assert torch.equal(a.rowptr[:nd + 1], b.rowptr), (j, d, name)
+                assert bool((a.rowptr[nd:] == E).all()), (j, d, name)                  # rows the batch does not have: empty
+                assert torch.equal(a.col[:E], b.col) and torch.equal(a.perm[:E], b.perm), (j, d, name)
+                assert torch.equal(a.aux[:E], b.aux), (j, d, name)
+                assert sorted(a.long_row_list().tolist()) == sorted(b.long_row_list().tolist()), (j, d, name)
+                saw_long = saw_long or b.long_row_list().numel() > 0
+    assert saw_long                                                                      # the hubs are there
+
+
+def test_static_forward_on_reddit_like_batches_is_bit_identical_to_per_batch_launches():
+    from cwn_amd import csr
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward
+    pool, p = _reddit_pool()
+    B, S = 6, 2
+    model = _reddit_model().eval()
+    sb = StaticBatch(p, B, slots=S, mode='csr')
+    sf = StaticForward(model, sb)
+    epoch = _batches(len(pool), B, 9, sizes=[B, B, B, 4])
+    assert sb.fits(epoch).all()
+    sb.set_epoch(epoch)
+    with torch.no_grad():
+        for r in range(2):
+            outs = [o.clone() for o in sf.replay()]
+            for j in range(S):
+                idx = epoch[r * S + j]
+                want = model(p.collate(idx))
+                assert torch.equal(outs[j][:len(idx)], want), (r, j, float((outs[j][:len(idx)] - want).abs().max()))
+    torch.cuda.synchronize()
+    csr.check_errors(DEV)
+
+
+def test_static_train_step_on_reddit_like_batches_with_cross_entropy():
+    """BASELINE configs[4] as the reference trains it: SparseCIN 64 x 4, no coboundaries, identity norm, JK cat, sum readout,
+    CrossEntropyLoss -- StaticTrainStep (mode 'csr', two slots, a short batch) against TrainStep on the collated batches of
+    the same index lists, from the same state."""
+    from cwn_amd import csr
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    from cwn_amd.train import TrainStep
+    pool, p = _reddit_pool()
+    B, S = 6, 2
+    m1, m2 = _reddit_model(seed=3), _reddit_model(seed=3)
+    m2.load_state_dict(m1.state_dict())
+    epoch = _batches(len(pool), B, 11, sizes=[B, B, B, 5])
+    sb = StaticBatch(p, B, slots=S, mode='csr')
+    st = StaticTrainStep(m1, sb, task_type='classification', lr=1e-3)
+    ref = TrainStep(m2, [p.collate(idx) for idx in epoch], task_type='classification', lr=1e-3, use_graph=False)
+    sb.set_epoch(epoch)
+    got = []
+    for r in range(2):
+        got += [float(l) for l in st.step()]
+    want = [float(ref.step(j)) for j in range(4)]
+    torch.cuda.synchronize()
+    csr.check_errors(DEV)
+    print('[static csr train] losses', got, 'vs', want)
+    for k, (a, b) in enumerate(zip(got, want)):
+        tol = 1e-5 if k == 0 else 2e-2            # (later steps: one Adam sign flip of a noise-level gradient apart at most)
+        assert abs(a - b) <= tol * max(1.0, abs(b)), (k, got, want)
+    assert int(st.opt.t) == 4 == int(ref.opt.t)
+
+
+def test_cross_entropy_criterion_value_and_gradient():
+    """cwn_loss_cols_f32(CWN_LOSS_CE) against torch.nn.CrossEntropyLoss in float64: loss, gradient, ignored rows (a negative
+    class), a device-side row count."""
+    from cwn_amd import _ffi
+    from cwn_amd.train import fused_loss
+    g = torch.Generator().manual_seed(0)
+    pred = (3 * torch.randn(37, 5, generator=g)).to(DEV).requires_grad_(True)
+    y = torch.randint(0, 5, (37,), generator=g).to(DEV)
+    y[3] = -100
+    loss = fused_loss('classification', pred, y)
+    loss.backward()
+    p64 = pred.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(p64, y)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    assert float((pred.grad.double() - p64.grad).abs().max()) <= 1e-7
+    # capacity 37, 20 rows exist
+    n = torch.tensor([20], dtype=torch.int64, device=DEV)
+    with _ffi.dynamic_rows({37: n.data_ptr()}):
+        pred.grad = None
+        l2 = fused_loss('classification', pred, y)
+        l2.backward()
+    p64 = pred.detach().double().requires_grad_(True)
+    ref2 = torch.nn.functional.cross_entropy(p64[:20], y[:20])
+    ref2.backward()
+    assert abs(float(l2) - float(ref2)) <= 1e-6 * max(1.0, abs(float(ref2)))
+    assert float((pred.grad.double() - p64.grad).abs().max()) <= 1e-7 and not pred.grad[20:].any()
+
+
+def test_static_csr_mode_serves_cinpp_layers_and_molecules_beyond_a_workgroup():
+    """(a) EmbedCINpp (CINppConv layers: refused by a 'blocked' static batch) through StaticForward and StaticTrainStep in mode
+    'csr'; (b) a ZINC-like pool with molecules of 120 - 200 atoms (what ogbg-molhiv's tail looks like): 'blocked' refuses the
+    batches that hold one, 'csr' serves them, outputs equal to the per-batch launches."""
+    from cwn_amd import csr
+    from cwn_amd.models import EmbedCINpp, EmbedSparseCIN
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward, StaticTrainStep
+    from cwn_amd.synthetic import zinc_like_complexes
+    from cwn_amd.train import TrainStep
+    pool = zinc_like_complexes(90, seed=5, max_ring=6, n_lo=9, n_hi=30) + zinc_like_complexes(6, seed=6, max_ring=6, n_lo=120, n_hi=200)
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+    B = 24
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(len(pool))
+    epoch = [perm[k * B:(k + 1) * B] for k in range(4)]
+    # (b)
+    torch.manual_seed(2)
+    mk = lambda: EmbedSparseCIN(28, 4, 1, 2, 64, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu', readout='sum',
+                                train_eps=False, final_hidden_multiplier=2, final_readout='sum', init_reduce='sum', embed_edge=True,
+                                use_coboundaries=True, graph_norm='bn').to(DEV)
+    model = mk().eval()
+    blocked = StaticBatch(p, B, slots=1)
+    StaticForward(model, blocked).run(epoch[0][:4])           # (cuts the item tables fits() consults)
+    assert not blocked.fits(epoch).all()                       # some batch holds a molecule beyond a workgroup
+    sb = StaticBatch(p, B, slots=2, mode='csr')
+    assert sb.fits(epoch).all()
+    sf = StaticForward(model, sb)
+    sb.set_epoch(epoch)
+    with torch.no_grad():
+        for r in range(2):
+            outs = [o.clone() for o in sf.replay()]
+            for j in range(2):
+                idx = epoch[2 * r + j]
+                want = model(p.collate(idx))
+                err = float((outs[j][:len(idx)] - want).abs().max())
+                assert err <= 1e-5 * max(1.0, float(want.abs().max())), (r, j, err)
+    # (a)
+    torch.manual_seed(3)
+    mkpp = lambda: EmbedCINpp(28, 4, 1, 2, 64, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu', readout='sum',
+                              train_eps=False, final_hidden_multiplier=2, final_readout='sum', init_reduce='sum', embed_edge=True,
+                              use_coboundaries=True, graph_norm='bn').to(DEV)
+    m1, m2 = mkpp(), mkpp()
+    m2.load_state_dict(m1.state_dict())
+    with pytest.raises(NotImplementedError):
+        StaticForward(m1, blocked)
+    sb2 = StaticBatch(p, B, slots=2, mode='csr')
+    st = StaticTrainStep(m1, sb2, lr=1e-3)
+    ref = TrainStep(m2, [p.collate(idx) for idx in epoch[:2]], lr=1e-3, use_graph=False)
+    sb2.set_epoch(epoch[:2])
+    got = [float(l) for l in st.step()]
+    want = [float(ref.step(j)) for j in range(2)]
+    torch.cuda.synchronize()
+    csr.check_errors(DEV)
+    print('[static csr, CIN++] losses', got, 'vs', want)
+    assert abs(got[0] - want[0]) <= 1e-5 * max(1.0, abs(want[0])), (got, want)
+    assert abs(got[1] - want[1]) <= 2e-2 * max(1.0, abs(want[1])), (got, want)
