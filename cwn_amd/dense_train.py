@@ -594,7 +594,11 @@ class _DenseTrain(torch.autograd.Function):
             for i in range(nd):
                 for br, chain in enumerate(plan.chains[i]):
                     items.append((chain[s], dy[i][br], Z[i][br][s]))
-            pend = norm_backward(items, lazy=True)
+            # (the lazy form hands dz to the input-gradient GEMM's prologue, which exists for 16-byte rows only: a first layer
+            #  over 1-wide features -- REDDIT-BINARY's constant vertex feature, mp/models.py:112-260 -- takes the apply launch)
+            wide = all(P[id(chain[s])][0].size(1) % 4 == 0 and P[id(chain[s])][0].stride(0) % 4 == 0
+                       for i in range(nd) for chain in plan.chains[i])
+            pend = norm_backward(items, lazy=wide)
             lazy_s = bool(pend) and isinstance(pend[0], tuple)
             dZ = [p[0] for p in pend] if lazy_s else pend
             tn, nn, k = [], [], 0
