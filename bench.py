@@ -114,7 +114,7 @@ def gemm_roofline(flops, us, split, io_bytes, narrow, traffic):
             'frac_of_fp32_mfma_peak_157': round(tf / MFMA_F32_PEAK_TF, 4)}
 
 
-def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixed_forward_ms, fixed_train_ms, task='regression'):
+def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixed_forward_ms, fixed_train_ms, task='regression', mode='blocked'):
     """secondary.fresh_batches: propagate scope, full forward and full training step over >= 64 distinct shuffled batches per
     epoch drawn by cwn_amd.packed.PackedLoader, each scope ONE captured graph over a StaticBatch (see the call site)."""
     import copy
@@ -123,8 +123,9 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
     from cwn_amd.packed import PackedComplexes, PackedLoader
     from cwn_amd.static_batch import StaticBatch
     from cwn_amd.static_graph import StaticTrainStep
-    NB = int(os.environ.get('CWN_BENCH_FRESH_BATCHES', '64'))
-    S = int(os.environ.get('CWN_BENCH_FRESH_SLOTS', '16'))      # (8: 634 M cells/s on the propagate scope, 16: 659 M, 32: 668 M)
+    # (mode 'csr' -- REDDIT-like hub complexes, CIN++ layers: large batches, a smaller pool and fewer steps per replay)
+    NB = int(os.environ.get('CWN_BENCH_FRESH_BATCHES', '64' if mode == 'blocked' else '16'))
+    S = int(os.environ.get('CWN_BENCH_FRESH_SLOTS', '16' if mode == 'blocked' else '4'))      # (8: 634 M cells/s on the propagate scope, 16: 659 M, 32: 668 M)
     EPOCHS = int(os.environ.get('CWN_BENCH_FRESH_EPOCHS', '6'))
     B = args.batch
     pool = [c for i in range(NB) for c in gen(9000 + 1000 * rank + i)]
@@ -138,11 +139,13 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
     def cells(bs):
         return float(sum(int(packed._meta[idx][:, 0:9:3].sum()) for idx in bs)) * L
 
-    sb = StaticBatch(packed, B, slots=S)
+    sb = StaticBatch(packed, B, slots=S, mode=mode)
     sb.reserve_epoch(NB)
     model = model.eval()
     g_ = torch.Generator().manual_seed(3)
-    feats = [[torch.randn(sb.cap_cells[d], H, generator=g_).to(dev) for d in range(3)] for _ in range(L)]
+    # (a layer's input width: the first layer of a model without an embedding front takes the dataset's own features)
+    w_in = [int(getattr(conv.mp_levels[0].update_up_nn[0], 'in_features', H)) for conv in model.convs]
+    feats = [[torch.randn(sb.cap_cells[d], w_in[l], generator=g_).to(dev) for d in range(3)] for l in range(L)]
 
     def prop_steps():
         sb.fill()
@@ -191,7 +194,7 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
         return total / dt_, dt_ / (EPOCHS * NB) * 1e3
 
     out = {'distinct_batches_per_epoch': NB, 'epochs_timed': EPOCHS, 'batch': B, 'dataset_complexes': len(pool),
-           'steps_per_replay': S, 'capacities': {'cells': list(sb.cap_cells), 'complexes': B},
+           'steps_per_replay': S, 'capacities': {'cells': list(sb.cap_cells), 'complexes': B}, 'static_batch_mode': mode,
            'host_work_per_step': 'one hipGraph replay per %d steps (a StaticBatch of %d slots: the fill launches cut the tables, '
                                  'arrays and item tables of %d batches at once); the epoch\'s permutation is uploaded once per '
                                  'epoch, inside the timed region' % (S, S, S),
@@ -307,7 +310,8 @@ def main():
     from cwn_amd import _ffi, csr, ops
     from cwn_amd import layers as layers_mod
     from cwn_amd.complex import ComplexBatch
-    from cwn_amd.models import EmbedSparseCIN, OGBEmbedSparseCIN, SparseCIN
+    from cwn_amd.models import EmbedCINpp, EmbedSparseCIN, OGBEmbedSparseCIN, SparseCIN
+    CINPP = os.environ.get('CWN_BENCH_MODEL') == 'cinpp' and args.workload == 'zinc'
     from cwn_amd.synthetic import (batch_stats, zinc_like_complexes, molhiv_like_complexes,
                                    reddit_like_complexes)
     _ffi.lib()
@@ -320,10 +324,13 @@ def main():
     args.hidden, args.layers = H, L
     torch.manual_seed(0)
     if WL == 'zinc':      # exp/scripts/cwn-zinc.sh:14-30
-        model = EmbedSparseCIN(28, 4, 1, L, H, dropout_rate=0.0, max_dim=2, jump_mode=None,
-                               nonlinearity='relu', readout='sum', train_eps=False,
-                               final_hidden_multiplier=2, final_readout='sum', init_reduce='sum',
-                               embed_edge=True, use_coboundaries=True, graph_norm='bn')
+        # CWN_BENCH_MODEL=cinpp: the same stack over CINppConv layers (EmbedCINpp, mp/molec_models.py:167-199: three streams
+        # per dimension, streaming path) -- the `zinc_cinpp` entry of secondary.workloads
+        Model_ = EmbedCINpp if CINPP else EmbedSparseCIN
+        model = Model_(28, 4, 1, L, H, dropout_rate=0.0, max_dim=2, jump_mode=None,
+                       nonlinearity='relu', readout='sum', train_eps=False,
+                       final_hidden_multiplier=2, final_readout='sum', init_reduce='sum',
+                       embed_edge=True, use_coboundaries=True, graph_norm='bn')
         # CWN_BENCH_ATOMS=lo,hi (exploration, never the headline): molecule sizes other than the generator's 18 - 30 atoms,
         # e.g. 9,38 for the spread of the real ZINC subset (mixed launches / big items)
         # ... or 'zinc': the size statistics of the real ZINC-12k subset (9 - 37 atoms, mean 23.2: cwn_amd/synthetic.py)
@@ -351,8 +358,8 @@ def main():
         coboundary = False
     model = model.to(dev).eval()
     # the criterion of the training legs: exp/scripts/cwn-zinc.sh --task_type regression (L1), cwn-molhiv.sh bin_classification
-    # (BCE with logits); mpsn-redditb.sh trains with cross-entropy, which has no fused form yet: L1 there
-    TASK = {'zinc': 'regression', 'molhiv': 'bin_classification', 'reddit': 'regression'}[WL]
+    # (BCE with logits), mpsn-redditb.sh classification (CrossEntropyLoss, exp/train_utils.py:21-22)
+    TASK = {'zinc': 'regression', 'molhiv': 'bin_classification', 'reddit': 'classification'}[WL]
     DROP = float(getattr(model, 'dropout_rate', 0.0)) if getattr(model, 'conv_dropout', False) else 0.0
 
     # ---- synthetic batches, resident in HBM ---------------------------------------------------
@@ -1079,7 +1086,9 @@ def main():
             tb = [ComplexBatch.from_complex_list(gen(5000 + 1000 * rank + i), max_dim=2).to(dev)
                   for i in range(min(2, args.num_batches))]
             for b_ in tb:                       # targets of the prediction's shape where the
-                if b_.y is None or WL != 'zinc':    # synthetic generator has none
+                if TASK == 'classification':        # synthetic generator has none
+                    b_.y = torch.zeros(b_.num_complexes, dtype=torch.long, device=dev) if b_.y is None else b_.y.view(-1).long()
+                elif b_.y is None or WL != 'zinc':
                     with torch.no_grad():
                         cs_ = [b_.cochains[d] for d in range(b_.dimension + 1)]
                         xs_keep = [c._x for c in cs_]
@@ -1254,10 +1263,11 @@ def main():
     # collate, the segment tables, the item tables and every row count are device-side (cwn_amd/static_batch.py), the epoch's
     # permutation is uploaded once, a step is a graph replay and nothing else.
     fresh = None
-    if rank == 0 and world == 1 and not args.only_primary and 'fresh' not in SKIP and BLOCKED and use_graph and WL in ('zinc', 'molhiv'):
+    if rank == 0 and world == 1 and not args.only_primary and 'fresh' not in SKIP and use_graph and (BLOCKED or WL == 'reddit' or CINPP):
         try:
             fresh = fresh_batches_leg(args, model, gen, dev, H, L, rank, value / world, dt_full / full_steps * 1e3 if dt_full == dt_full else None,
-                                      None if train is None else train.get('ms_per_step'), task=TASK)
+                                      None if train is None else train.get('ms_per_step'), task=TASK,
+                                      mode='blocked' if BLOCKED else 'csr')
             fresh['criterion'], fresh['dropout_rate'] = TASK, DROP
         except Exception as e:
             import traceback
@@ -1277,13 +1287,13 @@ def main():
         # two-per-CU form of the layer kernel -- DESIGN.md 4.0b)
         # (+ the headline's workload with the molecule sizes of the REAL ZINC subset -- 9 - 37 atoms, ~2 % beyond the 32 one
         # workgroup held at width 128 until round 4 (BIG records then; they fit since) -- at batch 128 and 2048: VERDICT r3 item 5)
-        for wl in ('molhiv', 'reddit', 'zinc_batch2048', 'zinc_real_spread', 'zinc_real_spread_batch2048'):
+        for wl in ('molhiv', 'reddit', 'zinc_cinpp', 'zinc_batch2048', 'zinc_real_spread', 'zinc_real_spread_batch2048'):
             try:
                 extra = {'zinc_batch2048': ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1'],
-                         'zinc_real_spread': ['--workload', 'zinc'],
+                         'zinc_real_spread': ['--workload', 'zinc'], 'zinc_cinpp': ['--workload', 'zinc'],
                          'zinc_real_spread_batch2048': ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1']}.get(wl, ['--workload', wl])
                 # (molhiv-512 = BASELINE configs[2] also runs its full forward, training step and the never-seen-batch legs)
-                whole = wl == 'molhiv'
+                whole = wl in ('molhiv', 'reddit', 'zinc_cinpp')      # (reddit-32 = BASELINE configs[4]; zinc_cinpp: CIN++ layers)
                 cmd = [sys.executable, os.path.abspath(__file__)] + extra + (['--no-cpu'] if whole else ['--brief']) + [
                        '--steps', str(max(args.steps, 20)),
                        '--warmup', str(max(args.warmup, 5)), '--kernel-reps', str(min(args.kernel_reps, 50))]
@@ -1292,6 +1302,9 @@ def main():
                     env_['CWN_BENCH_SKIP'] = 'eager,concurrent,collate,workloads'
                 if wl.startswith('zinc_real_spread'):
                     env_['CWN_BENCH_ATOMS'] = 'zinc'
+                if wl == 'zinc_cinpp':
+                    env_['CWN_BENCH_MODEL'] = 'cinpp'
+                    env_['CWN_BENCH_SKIP'] = 'eager,concurrent,collate,workloads,roofline'
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env_)
                 line = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
                 if pr.returncode != 0 or not line:
@@ -1312,7 +1325,8 @@ def main():
                         'full_forward_ms': sec_.get('full_forward_ms'),
                         'train_step_ms': (sec_.get('train_step') or {}).get('ms_per_step'),
                         'fresh_batches': {k: fb_.get(k) for k in ('propagate', 'forward', 'train', 'every_batch_within_capacity',
-                                                                   'device_error_word', 'steps_per_replay', 'batch', 'failed')}})
+                                                                   'device_error_word', 'steps_per_replay', 'batch', 'failed',
+                                                                   'static_batch_mode')}})
             except Exception as e:
                 workloads[wl] = {'failed': f'{type(e).__name__}: {e}'}
                 print(f'[bench] workload {wl} failed: {type(e).__name__}: {e}', file=sys.stderr)

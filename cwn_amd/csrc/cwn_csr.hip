@@ -501,6 +501,14 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
     }
 }
 
+// the counters of a build, zeroed by a kernel: a memset node inside a captured graph did not reliably run again on replay
+// (ROCm 7.2: the second replay of a graph holding this build counted on top of the first's counters and wrote past the arrays)
+__global__ __launch_bounds__(256) void zero_words_kernel(uint4* __restrict__ p, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = z;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
@@ -612,7 +620,13 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
     }
     if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
 
-    if (hipMemsetAsync(ws, 0, L.cnt_total, stream) != hipSuccess) return CWN_ERR_LAUNCH;
+    if (((uintptr_t)ws & 15u) != 0) return CWN_ERR_ALIGN;
+    {
+        const int64_t n16 = (int64_t)(L.cnt_total / 16);                  // (cnt_total is a multiple of 256)
+        int64_t zb = (n16 + 255) / 256;
+        zb = zb < 1 ? 1 : (zb > 1024 ? 1024 : zb);
+        zero_words_kernel<<<dim3((unsigned)zb), dim3(256), 0, stream>>>((uint4*)ws, n16);
+    }
     if (blocks > 0) count_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(B, err_flag);
     static const char* force = getenv("CWN_CSR_SCAN");   // timing experiments: "tiled" / "single"
     const bool single = force != nullptr ? force[0] == 's' : max_dst <= kSingleScanMax;
