@@ -3,7 +3,7 @@
 // One fixed launch sequence builds up to CWN_MAX_DESCS structures at once (all adjacencies of a
 // batched complex), so the cost per batch is 5-6 launches regardless of how many index tensors
 // there are (inputs that fit LDS take the ONE-launch path further down instead):
-//   1. hipMemsetAsync          zero the per-destination counters of every descriptor
+//   1. zero_words_kernel       zero the per-destination counters of every descriptor (a kernel, not a memset node: see there)
 //   2. count_kernel            cnt[key[e]] += ... (one atomic per distinct key per wavefront;
 //                              returned value = arrival slot inside the row)
 //   3. scan (1 or 2 kernels)   rowptr = exclusive scan of cnt; rows longer than CWN_LONG_ROW
