@@ -125,7 +125,7 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
     from cwn_amd.static_graph import StaticTrainStep
     # (mode 'csr' -- REDDIT-like hub complexes, CIN++ layers: large batches, a smaller pool and fewer steps per replay)
     NB = int(os.environ.get('CWN_BENCH_FRESH_BATCHES', '64' if mode == 'blocked' else '16'))
-    S = int(os.environ.get('CWN_BENCH_FRESH_SLOTS', '16' if mode == 'blocked' else '4'))      # (8: 634 M cells/s on the propagate scope, 16: 659 M, 32: 668 M)
+    S = int(os.environ.get('CWN_BENCH_FRESH_SLOTS', '16' if mode == 'blocked' else '8'))      # (8: 634 M cells/s on the propagate scope, 16: 659 M, 32: 668 M)
     EPOCHS = int(os.environ.get('CWN_BENCH_FRESH_EPOCHS', '6'))
     B = args.batch
     pool = [c for i in range(NB) for c in gen(9000 + 1000 * rank + i)]
@@ -241,9 +241,35 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
         return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'loss_finite': finite,
                 'vs_fixed_batch_replay': round(fixed_train_ms / ms, 4) if fixed_train_ms else None}
 
+    def leg_fill():
+        # what a never-seen batch costs BEFORE the scope runs: tables + capacity guard + collate (+ item tables, or -- mode 'csr' --
+        # the CSR plans of every adjacency, which the fixed-batch forward / training legs find cached on their batch objects)
+        g, keep = graph_of(lambda: sb.fill())
+        sb.set_epoch(epoch(1))
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = max(4, 64 // S)
+        for _ in range(n):
+            sb.rewind(0)
+            g.replay()
+        torch.cuda.synchronize()
+        return {'ms_per_step': round((time.perf_counter() - t0) / (n * S) * 1e3, 5),
+                'launches': 'cwn_collate_tables + cwn_collate_guard + cwn_collate_slots + ' +
+                            ('cwn_csr_build per slot' if mode == 'csr' else 'cwn_layer_items_build_dev (forward [+ backward] tables)')}
+
     leg('propagate', leg_propagate)
     leg('forward', leg_forward)
     leg('train', leg_train)
+    leg('fill', leg_fill)
+    try:
+        f_ms = out['fill']['ms_per_step']
+        for k, fixed in (('forward', fixed_forward_ms), ('train', fixed_train_ms)):
+            if fixed and 'ms_per_step' in out.get(k, {}):
+                out[k]['vs_fixed_batch_replay_plus_fill'] = round((fixed + f_ms) / out[k]['ms_per_step'], 4)
+    except (KeyError, TypeError):
+        pass
     all_fit = all_fit and all(bool(sb.fits(epoch(e)).all()) for e in range(2 + EPOCHS))      # (now incl. the backward table)
     out['every_batch_within_capacity'] = all_fit
     try:
@@ -1326,7 +1352,7 @@ def main():
                         'train_step_ms': (sec_.get('train_step') or {}).get('ms_per_step'),
                         'fresh_batches': {k: fb_.get(k) for k in ('propagate', 'forward', 'train', 'every_batch_within_capacity',
                                                                    'device_error_word', 'steps_per_replay', 'batch', 'failed',
-                                                                   'static_batch_mode')}})
+                                                                   'static_batch_mode', 'fill')}})
             except Exception as e:
                 workloads[wl] = {'failed': f'{type(e).__name__}: {e}'}
                 print(f'[bench] workload {wl} failed: {type(e).__name__}: {e}', file=sys.stderr)
