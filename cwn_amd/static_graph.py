@@ -247,13 +247,13 @@ class StaticTrainStep(TrainStep):
     whose batch is empty (an epoch that is not a multiple of S) leaves the model and the optimizer untouched.  World size 1."""
 
     def __init__(self, model: torch.nn.Module, static: StaticBatch, task_type: str = 'regression', lr: float = 1e-3,
-                 use_graph: bool = True, optimizer=None):
+                 use_graph: bool = True, optimizer=None, share: Optional[TrainStep] = None):
         refuse_unsupported_layers(model, 'StaticTrainStep', static, training=True)
         self.sb = static
         static.build_backward = True                  # (mode 'csr': the fill also builds the transposed plans)
         static.fill()                                 # the buffers hold real batches from here on (warm-up)
         super().__init__(model, [sl.batch for sl in static.slots], task_type=task_type, lr=lr, use_graph=use_graph,
-                         optimizer=optimizer, rebuild_plans=False, stages=1)
+                         optimizer=optimizer, rebuild_plans=False, stages=1, share=share)
         # (world > 1: step() runs the slots of a fill as TrainStep's per-step graph(forward + backward) -> all-reduce -> graph(Adam);
         #  the backward is not cut into pieces here -- stages = 1: one collective per step behind the backward)
         # the inputs ARE the static buffers (TrainStep keeps clones: the collate writes through raw pointers)
@@ -355,3 +355,91 @@ class StaticTrainStep(TrainStep):
         """Steps on the given batches (<= S index lists; the remaining slots run empty)."""
         self.sb.set_batches(batches)
         return self.step()[:len(batches)]
+
+
+class StaticRouter:
+    """Two static batches over one packed dataset -- mode 'blocked' (the complex-blocked launches: the fast path, a complex
+    must fit one workgroup) and mode 'csr' (device-built CSR plans: everything fits) -- and the split of an epoch's batches
+    between them: a batch every complex of which fits the blocked tables goes there, the others (ogbg-molhiv draws one of its
+    120 - 220-atom molecules into ~one batch in seven at batch 512) to the streaming path.  Both run captured graphs; the
+    host's work per epoch is this split (numpy over the per-complex sizes) and two permutation uploads."""
+
+    def __init__(self, packed, batch_size: int, slots: int = 8, caps: Optional[dict] = None, variant: int = 0):
+        self.blocked = StaticBatch(packed, batch_size, caps=caps, variant=variant, slots=slots, mode='blocked')
+        self.csr = StaticBatch(packed, batch_size, caps=caps, slots=slots, mode='csr')
+        self.S = int(slots)
+
+    def split(self, batches: Sequence[np.ndarray]):
+        """(indices of the batches the blocked path takes, indices of the others); raises for a batch neither takes."""
+        fit = self.blocked.fits(batches)
+        rest = [i for i, f in enumerate(fit) if not f]
+        if rest:
+            ok = self.csr.fits([batches[i] for i in rest])
+            if not ok.all():
+                bad = [rest[k] for k, f in enumerate(ok) if not f]
+                raise ValueError(f'batches {bad[:8]} exceed the capacities of the static buffers (or hold fewer than two cells of a '
+                                 'dimension): build the router with larger `caps`')
+        return [i for i, f in enumerate(fit) if f], rest
+
+    def set_epoch(self, batches: Sequence[np.ndarray]):
+        a, b = self.split(batches)
+        na = self.blocked.set_epoch([batches[i] for i in a]) if a else 0
+        nb = self.csr.set_epoch([batches[i] for i in b]) if b else 0
+        return a, b, na, nb
+
+
+class RoutedForward:
+    """model(batch) in eval mode for every batch of an epoch through a StaticRouter: run_epoch(batches) -> predictions in the
+    order of `batches`."""
+
+    def __init__(self, model: torch.nn.Module, router: StaticRouter):
+        self.router = router
+        self.fa, self.fb = StaticForward(model, router.blocked), StaticForward(model, router.csr)
+        # capture now, over the EMPTY batches the buffers hold: the item tables the model asks for are cut, and
+        # StaticBatch.fits() -- the router's test -- knows what one workgroup holds for this model
+        self.fa.replay()
+        self.fb.replay()
+
+    def run_epoch(self, batches: Sequence[np.ndarray]) -> List[torch.Tensor]:
+        a, b, na, nb = self.router.set_epoch(batches)
+        out: List[Optional[torch.Tensor]] = [None] * len(batches)
+        S = self.router.S
+        for order, n_rep, sf in ((a, na, self.fa), (b, nb, self.fb)):
+            for r in range(n_rep):
+                outs = sf.replay()
+                for j in range(S):
+                    k = r * S + j
+                    if k < len(order):
+                        out[order[k]] = outs[j][:len(batches[order[k]])].clone()
+        return out
+
+
+class RoutedTrainStep:
+    """The optimisation steps of an epoch (exp/train_utils.py:35-75) through a StaticRouter: one StaticTrainStep per static
+    batch over ONE model, one flat gradient and one Adam state (TrainStep(share=)).  run_epoch(batches) -> the losses in the
+    order of `batches`.  The ORDER of the steps inside an epoch is the router's (the blocked path's batches S at a time,
+    then the streaming path's), not the loader's: every batch is visited exactly once, as in the reference's shuffled epoch."""
+
+    def __init__(self, model: torch.nn.Module, router: StaticRouter, task_type: str = 'regression', lr: float = 1e-3):
+        self.router = router
+        self.ta = StaticTrainStep(model, router.blocked, task_type=task_type, lr=lr)
+        self.tb = StaticTrainStep(model, router.csr, task_type=task_type, lr=lr, share=self.ta)
+        self.opt = self.ta.opt
+        # capture now, over the EMPTY batches the buffers hold (an empty batch's step changes nothing): the forward and
+        # backward item tables are cut, and StaticBatch.fits() -- the router's test -- knows what one workgroup holds
+        self.ta.step()
+        self.tb.step()
+
+    def run_epoch(self, batches: Sequence[np.ndarray], keep_losses: bool = True) -> List[Optional[torch.Tensor]]:
+        a, b, na, nb = self.router.set_epoch(batches)
+        out: List[Optional[torch.Tensor]] = [None] * len(batches)
+        S = self.router.S
+        for order, n_rep, ts in ((a, na, self.ta), (b, nb, self.tb)):
+            for r in range(n_rep):
+                losses = ts.step()
+                if keep_losses:
+                    for j in range(S):
+                        k = r * S + j
+                        if k < len(order):
+                            out[order[k]] = losses[j].clone()
+        return out

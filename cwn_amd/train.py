@@ -156,7 +156,7 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, batches: Sequence, task_type: str = 'regression',
                  lr: float = 1e-3, use_graph: bool = True, optimizer: Optional[torch.optim.Optimizer] = None,
-                 rebuild_plans: bool = True, stages: Optional[int] = None):
+                 rebuild_plans: bool = True, stages: Optional[int] = None, share: Optional['TrainStep'] = None):
         """`stages`: number of pieces the backward is cut into so that the gradient all-reduce overlaps with it
         (None: one per message-passing layer, at most 4, when the process group has more than one rank, else 1;
         env CWN_TRAIN_STAGES overrides).  Needs `model.convs`; a network whose layers cannot be cut (see
@@ -204,7 +204,15 @@ class TrainStep:
                 self.staged.remove()
                 self.staged = None
         self.n_stages = self.staged.n_stages if self.staged is not None else 1
-        self.bucket = FlatGradBucket(model.parameters(), stage_of, self.n_stages)
+        # `share`: a second step driver over the SAME model (static_graph.RoutedTrainStep: one per static batch) takes the
+        # first one's gradient bucket and optimizer -- the parameters have one flat gradient and one Adam state
+        if share is not None:
+            if share.model is not model or share.n_stages != self.n_stages:
+                raise ValueError('TrainStep(share=...): the same model and the same number of backward pieces')
+            self.bucket = share.bucket
+            optimizer = optimizer or share.opt
+        else:
+            self.bucket = FlatGradBucket(model.parameters(), stage_of, self.n_stages)
         if self.world > 1 and live:
             # the ranks reduce the bucket chunk by chunk: its layout must be the same everywhere
             lay = torch.tensor([hi for _, hi in self.bucket.chunks], dtype=torch.int64, device=self.bucket.flat.device)

@@ -224,3 +224,57 @@ def test_static_csr_mode_serves_cinpp_layers_and_molecules_beyond_a_workgroup():
     print('[static csr, CIN++] losses', got, 'vs', want)
     assert abs(got[0] - want[0]) <= 1e-5 * max(1.0, abs(want[0])), (got, want)
     assert abs(got[1] - want[1]) <= 2e-2 * max(1.0, abs(want[1])), (got, want)
+
+
+def test_routed_epoch_over_a_dataset_with_a_heavy_tail():
+    """A molhiv-like pool with molecules of 120 - 220 atoms: StaticRouter sends the batches that hold one to the csr-mode static
+    batch and the others to the blocked one; RoutedForward returns the per-batch predictions (vs model(collate), every batch),
+    RoutedTrainStep takes one step per batch of the epoch over ONE optimizer state (Adam's counter = number of batches; losses
+    finite; the first step of each path equal to TrainStep on the collated batch from the same state)."""
+    from cwn_amd import csr
+    from cwn_amd.models import OGBEmbedSparseCIN
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_graph import RoutedForward, RoutedTrainStep, StaticRouter
+    from cwn_amd.synthetic import molhiv_like_complexes
+    from cwn_amd.train import TrainStep
+    pool = molhiv_like_complexes(300, seed=7, max_ring=6, tail=0.02)
+    assert 2 <= sum(c.cochains[0].num_cells > 100 for c in pool) <= 20
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+    B, S = 32, 2
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(pool))
+    epoch = [perm[k * B:(k + 1) * B] for k in range(9)]
+
+    def mk():
+        torch.manual_seed(4)
+        return OGBEmbedSparseCIN(1, 2, 64, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum', init_reduce='sum',
+                                 embed_edge=True, use_coboundaries=True, graph_norm='bn').to(DEV)
+    model = mk().eval()
+    router = StaticRouter(p, B, slots=S)
+    rf = RoutedForward(model, router)
+    a, b = router.split(epoch)
+    print(f'[router] {len(a)} batches on the blocked path, {len(b)} on the streaming path')
+    assert a and b and sorted(a + b) == list(range(len(epoch)))
+    with torch.no_grad():
+        preds = rf.run_epoch(epoch)
+        for k, idx in enumerate(epoch):
+            want = model(p.collate(idx))
+            err = float((preds[k] - want).abs().max())
+            assert err <= 1e-5 * max(1.0, float(want.abs().max())), (k, k in b, err)
+    # training
+    m1, m2, m3 = mk(), mk(), mk()
+    router2 = StaticRouter(p, B, slots=S)
+    rt = RoutedTrainStep(m1, router2, task_type='bin_classification', lr=1e-3)
+    assert int(rt.opt.t) == 0                                           # the warm-up replays ran on empty batches: no step
+    for x, y in zip(m1.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(x, y)
+    losses = rt.run_epoch(epoch)
+    torch.cuda.synchronize()
+    csr.check_errors(DEV)
+    assert int(rt.opt.t) == len(epoch)
+    assert all(l is not None and bool(torch.isfinite(l)) for l in losses)
+    a2, b2 = router2.split(epoch)
+    # the first step of the epoch (blocked path, batch a2[0]) from the initial state
+    ref = TrainStep(m2, [p.collate(epoch[a2[0]])], task_type='bin_classification', lr=1e-3, use_graph=False)
+    want = float(ref.step(0))
+    assert abs(float(losses[a2[0]]) - want) <= 1e-5 * max(1.0, abs(want)), (float(losses[a2[0]]), want)
