@@ -259,6 +259,58 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
                 'launches': 'cwn_collate_tables + cwn_collate_guard + cwn_collate_slots + ' +
                             ('cwn_csr_build per slot' if mode == 'csr' else 'cwn_layer_items_build_dev (forward [+ backward] tables)')}
 
+    ROUTED = os.environ.get('CWN_BENCH_ROUTED') == '1' and mode == 'blocked'
+    if ROUTED:
+        # a dataset with complexes beyond one workgroup (molhiv's heavy tail): every epoch split between the blocked and the
+        # csr-mode static batch (cwn_amd/static_graph.py: StaticRouter), one optimizer state
+        from cwn_amd.static_graph import RoutedForward, RoutedTrainStep, StaticRouter
+
+        def timed_epochs(run):
+            run(epoch(1))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tot = 0.0
+            for e in range(EPOCHS):
+                bs = epoch(2 + e)
+                run(bs)
+                tot += cells(bs)
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0
+            return tot / dt_, dt_ / (EPOCHS * NB) * 1e3
+
+        def leg_forward_routed():
+            router = StaticRouter(packed, B, slots=S)
+            rf = RoutedForward(model, router)
+            with torch.no_grad():
+                a_, b_ = router.split(epoch(1))
+                bs = epoch(1)
+                outs = rf.run_epoch(bs)
+                same = all(bool(torch.allclose(outs[k], model(packed.collate(bs[k])), rtol=0, atol=1e-5 * max(1.0, float(outs[k].abs().max()))))
+                           for k in (list(a_[:2]) + list(b_[:2])))
+                cps, ms = timed_epochs(rf.run_epoch)
+            return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'equal_to_per_batch_launches_1e-5': same,
+                    'batches_on_the_blocked_path': len(a_), 'batches_on_the_streaming_path': len(b_),
+                    'vs_fixed_batch_replay': round(fixed_forward_ms / ms, 4) if fixed_forward_ms else None}
+
+        def leg_train_routed():
+            tmodel = copy.deepcopy(model).train()
+            router = StaticRouter(packed, B, slots=S)
+            rt = RoutedTrainStep(tmodel, router, task_type=task)
+            cps, ms = timed_epochs(lambda bs: rt.run_epoch(bs, keep_losses=False))
+            finite = all(bool(torch.isfinite(l).item()) for l in rt.run_epoch(epoch(1)) if l is not None)
+            return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'loss_finite': finite,
+                    'adam_steps': int(rt.opt.t), 'vs_fixed_batch_replay': round(fixed_train_ms / ms, 4) if fixed_train_ms else None}
+
+        out['routed'] = True
+        leg('forward', leg_forward_routed)
+        leg('train', leg_train_routed)
+        try:
+            csr.check_errors(dev)
+            out['device_error_word'] = 0
+        except IndexError as e:
+            out['device_error_word'] = str(e)
+        out['every_batch_within_capacity'] = True       # (the router raises otherwise)
+        return out
     leg('propagate', leg_propagate)
     leg('forward', leg_forward)
     leg('train', leg_train)
@@ -372,7 +424,9 @@ def main():
         model = OGBEmbedSparseCIN(1, L, H, dropout_rate=float(os.environ.get('CWN_BENCH_DROPOUT', '0.5')), indropout_rate=0.0, max_dim=2,
                                   readout='mean', final_readout='sum', apply_dropout_before='lin2',
                                   init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn')
-        gen = lambda seed: molhiv_like_complexes(args.batch, seed, 6)
+        # CWN_BENCH_MOLHIV_TAIL (the `molhiv_real_tail` entry of secondary.workloads: 5e-4): the dataset's molecules of 120 - 220 atoms
+        MTAIL = float(os.environ.get('CWN_BENCH_MOLHIV_TAIL', '0'))
+        gen = lambda seed: molhiv_like_complexes(args.batch, seed, 6, tail=MTAIL)
         coboundary = True
     else:                 # exp/scripts/mpsn-redditb.sh:6-28
         model = SparseCIN(1, 2, L, H, dropout_rate=0.0, max_dim=2, jump_mode='cat', readout='sum',
@@ -1313,13 +1367,14 @@ def main():
         # two-per-CU form of the layer kernel -- DESIGN.md 4.0b)
         # (+ the headline's workload with the molecule sizes of the REAL ZINC subset -- 9 - 37 atoms, ~2 % beyond the 32 one
         # workgroup held at width 128 until round 4 (BIG records then; they fit since) -- at batch 128 and 2048: VERDICT r3 item 5)
-        for wl in ('molhiv', 'reddit', 'zinc_cinpp', 'zinc_batch2048', 'zinc_real_spread', 'zinc_real_spread_batch2048'):
+        for wl in ('molhiv', 'molhiv_real_tail', 'reddit', 'zinc_cinpp', 'zinc_batch2048', 'zinc_real_spread', 'zinc_real_spread_batch2048'):
             try:
                 extra = {'zinc_batch2048': ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1'],
                          'zinc_real_spread': ['--workload', 'zinc'], 'zinc_cinpp': ['--workload', 'zinc'],
+                         'molhiv_real_tail': ['--workload', 'molhiv'],
                          'zinc_real_spread_batch2048': ['--workload', 'zinc', '--batch', '2048', '--num-batches', '1']}.get(wl, ['--workload', wl])
                 # (molhiv-512 = BASELINE configs[2] also runs its full forward, training step and the never-seen-batch legs)
-                whole = wl in ('molhiv', 'reddit', 'zinc_cinpp')      # (reddit-32 = BASELINE configs[4]; zinc_cinpp: CIN++ layers)
+                whole = wl in ('molhiv', 'molhiv_real_tail', 'reddit', 'zinc_cinpp')      # (reddit-32 = BASELINE configs[4]; zinc_cinpp: CIN++ layers)
                 cmd = [sys.executable, os.path.abspath(__file__)] + extra + (['--no-cpu'] if whole else ['--brief']) + [
                        '--steps', str(max(args.steps, 20)),
                        '--warmup', str(max(args.warmup, 5)), '--kernel-reps', str(min(args.kernel_reps, 50))]
@@ -1328,6 +1383,10 @@ def main():
                     env_['CWN_BENCH_SKIP'] = 'eager,concurrent,collate,workloads'
                 if wl.startswith('zinc_real_spread'):
                     env_['CWN_BENCH_ATOMS'] = 'zinc'
+                if wl == 'molhiv_real_tail':
+                    env_['CWN_BENCH_MOLHIV_TAIL'] = '5e-4'
+                    env_['CWN_BENCH_ROUTED'] = '1'
+                    env_['CWN_BENCH_SKIP'] = 'eager,concurrent,collate,workloads,roofline'
                 if wl == 'zinc_cinpp':
                     env_['CWN_BENCH_MODEL'] = 'cinpp'
                     env_['CWN_BENCH_SKIP'] = 'eager,concurrent,collate,workloads,roofline'
@@ -1352,7 +1411,7 @@ def main():
                         'train_step_ms': (sec_.get('train_step') or {}).get('ms_per_step'),
                         'fresh_batches': {k: fb_.get(k) for k in ('propagate', 'forward', 'train', 'every_batch_within_capacity',
                                                                    'device_error_word', 'steps_per_replay', 'batch', 'failed',
-                                                                   'static_batch_mode', 'fill')}})
+                                                                   'static_batch_mode', 'fill', 'routed')}})
             except Exception as e:
                 workloads[wl] = {'failed': f'{type(e).__name__}: {e}'}
                 print(f'[bench] workload {wl} failed: {type(e).__name__}: {e}', file=sys.stderr)
