@@ -212,6 +212,7 @@ class StaticBatch:
             raise ValueError("mode 'blocked' or 'csr'")
         self.mode = mode
         self.build_backward = False          # (StaticTrainStep: the fill also builds the transposed plans)
+        self._cap_cols = None                # (_check_capacity: the distinct size columns a batch can exceed)
         if not packed.with_csr:
             raise ValueError('StaticBatch needs a PackedComplexes built with with_csr=True')
         if packed.device.type != 'cuda':
@@ -563,22 +564,34 @@ class StaticBatch:
 
     def _check_capacity(self, host: np.ndarray) -> None:
         """Every batch within the capacity of every buffer (the default capacities are a statistical bound, mean x B + 6 sigma
-        sqrt(B): a size-sorted or bucketed batch order can exceed them).  A few numpy operations per epoch; the device repeats
-        the test per fill (cwn_collate_guard: an oversize batch runs as an empty one and sets a sticky bit) for callers that
-        write `idx` themselves."""
-        D, K = self.D, self.K
-        meta = self.packed._meta
-        take = np.concatenate([meta[:, 0:3 * D:3], meta[:, 3 * D:3 * D + K]], axis=1)          # [num, D + K]
-        take = np.concatenate([take, np.zeros((1, D + K), dtype=take.dtype)], axis=0)            # row -1: no complex
-        caps = np.asarray(list(self.cap_cells) + list(self._caps), dtype=np.int64)
-        for lo in range(0, host.shape[0], 4096):
-            tot = take[host[lo:lo + 4096]].sum(axis=1)                                            # [n, D + K]
-            bad = np.nonzero((tot > caps).any(axis=1))[0]
+        sqrt(B): a size-sorted or bucketed batch order can exceed them).  Host work per epoch, inside a training loop's critical
+        path: the size columns that are copies of one another (an index and its shared-cell vector, the boundary entries and
+        their CSR columns ...) are checked once, against the smallest of their capacities -- ~7 gathers over the epoch's
+        complex numbers.  The device repeats the test per fill (cwn_collate_guard: an oversize batch runs as an empty one and
+        sets a sticky bit) for callers that write `idx` themselves."""
+        if self._cap_cols is None:
+            D, K = self.D, self.K
+            meta = self.packed._meta
+            take = np.concatenate([meta[:, 0:3 * D:3], meta[:, 3 * D:3 * D + K]], axis=1)          # [num, D + K]
+            caps = np.asarray(list(self.cap_cells) + list(self._caps), dtype=np.int64)
+            groups = {}
+            for c in range(D + K):
+                groups.setdefault(take[:, c].tobytes(), []).append(c)
+            cols = []
+            for members in groups.values():
+                col = np.concatenate([take[:, members[0]], [0]]).astype(np.int64)                  # (row -1: no complex)
+                if int(np.sort(col)[-min(self.B, col.size):].sum()) <= int(caps[members].min()):
+                    continue                                                                       # no batch can exceed it
+                cols.append((np.ascontiguousarray(col), int(caps[members].min()), members[int(np.argmin(caps[members]))]))
+            self._cap_cols = cols
+        D = self.D
+        for col, cap, c in self._cap_cols:
+            tot = col[host].sum(axis=1)
+            bad = np.nonzero(tot > cap)[0]
             if bad.size:
                 j = int(bad[0])
-                c = int(np.nonzero(tot[j] > caps)[0][0])
                 what = f'cells of dimension {c}' if c < D else 'elements of {1!r} (dimension {0})'.format(*self.packed._klist[c - D][:2])
-                raise ValueError(f'batch {lo + j}: {int(tot[j, c])} {what} exceed the capacity {int(caps[c])} of this StaticBatch '
+                raise ValueError(f'batch {j}: {int(tot[j])} {what} exceed the capacity {cap} of this StaticBatch '
                                  f'({bad.size} such batch(es)); build it with larger `caps`, or route these batches through '
                                  'PackedComplexes.collate (StaticBatch.fits() tells which)')
 
