@@ -787,8 +787,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
                                                             const int64_t* __restrict__ col_off,
                                                             const int64_t* __restrict__ col_size,
                                                             float* __restrict__ dW, int64_t n_cap, int cols,
-                                                            int H, int64_t V, int src_f32, const int64_t* __restrict__ n_dev,
-                                                            float* __restrict__ ws) {
+                                                            int H, int64_t V, int src_f32, const int64_t* __restrict__ n_dev) {
     extern __shared__ float table[];          // [V][H]
     const int64_t n_rows = n_dev != nullptr ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap;
     const int64_t r0 = (int64_t)blockIdx.x * kEmbBand;
@@ -829,34 +828,10 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
         }
     }
     __syncthreads();
-    if (ws != nullptr) {
-        // the band's partial table with plain coalesced stores; embedding_reduce_kernel sums the bands in band order.  (With
-        // atomics straight into dW the 202 bands of a molhiv batch of 512 put 2.2 M device-scope adds on 11 k addresses:
-        // 67 us per table set, twice per training step -- 14 % of it.)
-        float* mine = ws + (int64_t)blockIdx.x * total;
-        for (int64_t i = threadIdx.x; i < total; i += 256) mine[i] = table[i];
-        return;
-    }
     for (int64_t i = threadIdx.x; i < total; i += 256) {
         const float t = table[i];
         if (t != 0.f) atomicAdd(dW + i, t);
     }
-}
-
-__global__ __launch_bounds__(256) void embedding_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int64_t total,
-                                                               int64_t n_cap, const int64_t* __restrict__ n_dev) {
-    const int64_t n_rows = n_dev != nullptr ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap;
-    const int64_t bands = (n_rows + kEmbBand - 1) / kEmbBand;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int64_t b = 0;
-    for (; b + 4 <= bands; b += 4) {                    // four loads in flight; a fixed order of additions
-        const float v0 = ws[b * total + i], v1 = ws[(b + 1) * total + i], v2 = ws[(b + 2) * total + i], v3 = ws[(b + 3) * total + i];
-        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-    }
-    for (; b < bands; ++b) a0 += ws[b * total + i];
-    dW[i] += (a0 + a1) + (a2 + a3);
 }
 
 // One table, few rows (ZINC: 28 atom types, 4 bond types), H = 64 / 128 / 256: the band's 64 gradient rows go to LDS in one
@@ -1047,15 +1022,9 @@ extern "C" int cwn_embed_front_bwd_f32(const cwn_front_bwd* a, cwn_stream_t stre
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
-extern "C" int64_t cwn_embedding_bwd_workspace_floats(int64_t n_rows, int64_t V, int32_t H) {
-    if (n_rows <= 0 || V <= 0 || H <= 0) return 0;
-    return (n_rows + kEmbBand - 1) / kEmbBand * V * H;
-}
-
 extern "C" int cwn_embedding_bwd_f32(const float* g, const void* src, const int64_t* col_off,
                                      const int64_t* col_size, float* dW, int64_t n_rows, int32_t cols,
-                                     int32_t H, int64_t V, int32_t src_f32, const int64_t* n_dev, float* workspace,
-                                     int64_t workspace_floats, cwn_stream_t stream_) {
+                                     int32_t H, int64_t V, int32_t src_f32, const int64_t* n_dev, cwn_stream_t stream_) {
     if (n_rows < 0 || cols <= 0 || H <= 0 || V <= 0) return CWN_ERR_BAD_ARG;
     if (n_rows == 0) return CWN_OK;
     if (g == nullptr || src == nullptr || dW == nullptr) return CWN_ERR_BAD_ARG;
@@ -1073,11 +1042,7 @@ extern "C" int cwn_embedding_bwd_f32(const float* g, const void* src, const int6
         else embedding_bwd_one_table_kernel<256><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, dW, n_rows, (int)V, sf, n_dev);
         return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
     }
-    // (a workspace of blocks x V x H floats: per-band partial tables + an ordered reduce instead of atomics into dW)
-    float* ws = (workspace != nullptr && workspace_floats >= blocks * V * H) ? workspace : nullptr;
     embedding_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), (size_t)bytes, (hipStream_t)stream_>>>(
-        g, src, col_off, col_size, dW, n_rows, cols, H, V, src_f32 ? 1 : 0, n_dev, ws);
-    if (ws != nullptr)
-        embedding_reduce_kernel<<<dim3((unsigned)((V * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(ws, dW, V * H, n_rows, n_dev);
+        g, src, col_off, col_size, dW, n_rows, cols, H, V, src_f32 ? 1 : 0, n_dev);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

@@ -470,9 +470,6 @@ class _EmbeddingSum(torch.autograd.Function):
         return (None,) + tuple(_embedding_table_grads(ctx.tables, idx, g))
 
 
-EMBEDDING_BWD_WORKSPACE = os.environ.get('CWN_EMB_BWD_WS', '1') != '0'
-
-
 def _embedding_table_grads(tables, idx: Tensor, g: Tensor) -> List[Optional[Tensor]]:
     """d(table) of out[i] = sum_c table_c[idx[i, c]] given g = d out: cwn_embedding_bwd_f32 into one zeroed buffer, handed
     back as per-table views -- or added into the parameters' .grad directly where those are allocated (then None)."""
@@ -496,18 +493,12 @@ def _embedding_table_grads(tables, idx: Tensor, g: Tensor) -> List[Optional[Tens
         if t is not None and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (V, H):
             _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
                 g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), t.data_ptr(), idx.size(0),
-                idx.size(1), H, V, f32, n_dev, None, 0, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
+                idx.size(1), H, V, f32, n_dev, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
             return [None]
     dW = torch.zeros(V, H, dtype=torch.float32, device=g.device)
-    # several tables (the OGB encoders): every band of cells touches every table row -- per-band partial tables + an ordered
-    # reduce instead of 2 M device-scope atomics (include/cwn_hip.h); capped at 64 MiB of workspace
-    ws, nws = None, int(_ffi.lib().cwn_embedding_bwd_workspace_floats(idx.size(0), V, H))
-    if EMBEDDING_BWD_WORKSPACE and len(tables) > 1 and 0 < nws <= (16 << 20):
-        ws = torch.empty(nws, dtype=torch.float32, device=g.device)
     _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
         g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), dW.data_ptr(), idx.size(0),
-        idx.size(1), H, V, f32, n_dev, _ffi.ptr(ws), nws if ws is not None else 0, _ffi.stream_ptr(g.device)),
-        'cwn_embedding_bwd_f32')
+        idx.size(1), H, V, f32, n_dev, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
     views, o = [], 0
     for n in sizes:
         views.append(dW[o:o + n])

@@ -1015,14 +1015,9 @@ int cwn_embedding_fwd_f32(const float* W, const int64_t* src, const int64_t* col
  * CWN_ERR_TOO_LARGE otherwise (callers then use the transposed aggregation). */
 /* src_f32 != 0: `src` holds the integer features as float32 (as the containers deliver them; truncated like the front's);
  * n_dev (or NULL): device int64 = the actual number of rows (n_rows = capacity). */
-/* workspace (or NULL) of at least cwn_embedding_bwd_workspace_floats(n_rows, V, H) floats: the bands write their partial tables
- * with plain stores and a second small launch adds them to dW in band order -- no atomics into dW (the form for tables of several
- * columns, where every band touches every row: ogbg-mol*'s nine atom-feature tables).  Without it: fp32 atomics into dW. */
-int64_t cwn_embedding_bwd_workspace_floats(int64_t n_rows, int64_t V, int32_t H);
 int cwn_embedding_bwd_f32(const float* g, const void* src, const int64_t* col_off,
                           const int64_t* col_size, float* dW, int64_t n_rows, int32_t cols, int32_t H,
-                          int64_t V, int32_t src_f32, const int64_t* n_dev, float* workspace, int64_t workspace_floats,
-                          cwn_stream_t stream);
+                          int64_t V, int32_t src_f32, const int64_t* n_dev, cwn_stream_t stream);
 
 /* The backward of cwn_embed_front_f32 (EmbedVEWithReduce, mp/layers.py:490-593: vertex / edge embeddings + InitReduceConv
  * twice) in ONE launch, for one vertex table and at most one edge table with one integer feature each (the ZINC models):

@@ -83,8 +83,8 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_norm_bwd_f32(nd, 1, 0, None) == 0                # nothing to do
     assert _ffi.NORM_BWD_FUSED_MAX_ROWS == int(re.search(r'#define CWN_NORM_BWD_FUSED_MAX_ROWS (\d+)', open(os.path.join(ROOT, 'include', 'cwn_hip.h')).read()).group(1))
     assert lib.cwn_adam_f32(None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, None, None, None) == 1
-    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 8, 1, 64, 28, 0, None, None, 0, None) == 1
-    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 0, 1, 64, 28, 0, None, None, 0, None) == 0   # nothing to do
+    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 8, 1, 64, 28, 0, None, None) == 1
+    assert lib.cwn_embedding_bwd_f32(None, None, None, None, None, 0, 1, 64, 28, 0, None, None) == 0   # nothing to do
     assert lib.cwn_embedding_fwd_f32(None, None, None, None, None, 8, 1, 64, 28, None, None) == 1
     g = (_ffi.GemmDesc * 1)(_ffi.GemmDesc(M=4, N=8, K=300, K2=0, ldx=300, ldw=300, ldy=8))
     assert lib.cwn_gemm_f32(g, 1, None) == 2                       # CWN_ERR_TOO_LARGE: K beyond the kernel
