@@ -834,6 +834,57 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
     }
 }
 
+// SEVERAL tables summed per cell (the OGB Atom / BondEncoder: nine / three integer feature columns, mp/molec_models.py:237-245),
+// H = 64 / 128 / 256, without float atomics in LDS: the table-in-LDS form above spent 97 us on the atom tables of a molhiv batch
+// of 512 (twice per training step: 13 % of it) -- a column has 2 .. 12 distinct values, so the 16 cells a pass has in flight
+// hit the same few LDS rows and every ds_add_f32 serialises.  Here the band's 64 gradient rows are staged once, lane = cell
+// holds the cell's index of the current column, and the DISTINCT values present in the band are walked with ballots: for value
+// v one thread per feature adds ITS feature of the cells that hold v out of LDS (conflict-free reads, ascending cell order)
+// and hands one partial per (v, feature) to dW.  The 256 / H feature groups take the distinct values in turn.
+template <int H>
+__global__ __launch_bounds__(256) void embedding_bwd_cols_kernel(const float* __restrict__ g, const void* __restrict__ src,
+                                                                 const int64_t* __restrict__ col_off, const int64_t* __restrict__ col_size,
+                                                                 float* __restrict__ dW, int64_t n_cap, int cols, int64_t V, int src_f32,
+                                                                 const int64_t* __restrict__ n_dev) {
+    __shared__ __attribute__((aligned(16))) float rows[kEmbBand][H];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t n_rows = n_dev != nullptr ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap;
+    const int64_t r0 = (int64_t)blockIdx.x * kEmbBand;
+    if (r0 >= n_rows) return;                 // (uniform) a band past the batch's own rows
+    const int n = (int)((n_rows - r0) < kEmbBand ? (n_rows - r0) : kEmbBand);
+    for (int i = tid; i < kEmbBand * (H / 4); i += 256) {
+        const int r = i / (H / 4), c4 = i % (H / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) v = *reinterpret_cast<const float4*>(g + (r0 + r) * H + 4 * c4);
+        *reinterpret_cast<float4*>(&rows[r][4 * c4]) = v;
+    }
+    __syncthreads();
+    constexpr int kG = 256 / H > 0 ? 256 / H : 1;                   // feature groups (H = 64: 4, 128: 2, 256: 1)
+    const int h = tid % H, q = tid / H;
+    for (int c = 0; c < cols; ++c) {
+        const int64_t lim = col_size != nullptr ? col_size[c] : V, off = col_off != nullptr ? col_off[c] : 0;
+        int64_t id = lane < n ? emb_index(src, src_f32, (r0 + lane) * cols + c) : -1;     // every wave holds all 64 cells
+        if (id < 0 || id >= lim) id = -1;                                                  // (flagged by the forward)
+        unsigned long long todo = __ballot(id >= 0);
+        int it = 0;
+        while (todo != 0ull) {                                                             // (uniform across the workgroup)
+            const int leader = __builtin_ctzll(todo);
+            const int64_t v = __shfl(id, leader, 64);
+            const unsigned long long bal = __ballot(id == v);
+            todo &= ~bal;
+            if ((it++ % kG) != q) continue;
+            unsigned long long m = bal;
+            float acc = 0.f;
+            while (m != 0ull) {
+                const int r = __builtin_ctzll(m);
+                m &= m - 1ull;
+                acc += rows[r][h];
+            }
+            if (acc != 0.f) atomicAdd(dW + (size_t)(off + v) * H + h, acc);
+        }
+    }
+}
+
 // One table, few rows (ZINC: 28 atom types, 4 bond types), H = 64 / 128 / 256: the band's 64 gradient rows go to LDS in one
 // coalesced pass, every wave knows each cell's table row (lane = cell), and for table row v a BALLOT gives the cells that
 // hit it -- a thread then adds ITS feature of those cells out of LDS and hands one partial per (v, feature) to global
@@ -1029,8 +1080,6 @@ extern "C" int cwn_embedding_bwd_f32(const float* g, const void* src, const int6
     if (n_rows == 0) return CWN_OK;
     if (g == nullptr || src == nullptr || dW == nullptr) return CWN_ERR_BAD_ARG;
     if ((H & 3) == 0 && ((uintptr_t)g & 15u)) return CWN_ERR_ALIGN;       // gradient rows are read 16 bytes a lane
-    const int64_t bytes = V * H * 4;
-    if (bytes > 60 * 1024) return CWN_ERR_TOO_LARGE;       // the table must fit one workgroup's LDS
     const int64_t blocks = (n_rows + kEmbBand - 1) / kEmbBand;
     if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     if (cols == 1 && col_off == nullptr && V <= 64 && (H == 64 || H == 128 || H == 256)) {
@@ -1042,6 +1091,17 @@ extern "C" int cwn_embedding_bwd_f32(const float* g, const void* src, const int6
         else embedding_bwd_one_table_kernel<256><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, dW, n_rows, (int)V, sf, n_dev);
         return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
     }
+    if ((H == 64 || H == 128 || H == 256) && !((uintptr_t)g & 15u)) {
+        // several tables, or one table of many rows: the ballot form over the distinct values of every column
+        hipStream_t st = (hipStream_t)stream_;
+        const int sf = src_f32 ? 1 : 0;
+        if (H == 64) embedding_bwd_cols_kernel<64><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, col_off, col_size, dW, n_rows, cols, V, sf, n_dev);
+        else if (H == 128) embedding_bwd_cols_kernel<128><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, col_off, col_size, dW, n_rows, cols, V, sf, n_dev);
+        else embedding_bwd_cols_kernel<256><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(g, src, col_off, col_size, dW, n_rows, cols, V, sf, n_dev);
+        return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+    }
+    const int64_t bytes = V * H * 4;
+    if (bytes > 60 * 1024) return CWN_ERR_TOO_LARGE;       // (other widths: the table-in-LDS form; the table must fit one workgroup's LDS)
     embedding_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), (size_t)bytes, (hipStream_t)stream_>>>(
         g, src, col_off, col_size, dW, n_rows, cols, H, V, src_f32 ? 1 : 0, n_dev);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;

@@ -1009,10 +1009,11 @@ int cwn_embedding_fwd_f32(const float* W, const int64_t* src, const int64_t* col
                           const int64_t* col_size, float* out, int64_t n_rows, int32_t cols, int32_t H,
                           int64_t V, int32_t* err_flag, cwn_stream_t stream);
 
-/* Its backward: dW[col_off[c] + src[r, c], :] += g[r, :].  dW ([V, H], accumulated; the caller
- * zeroes it) must fit one workgroup's LDS (V * H * 4 <= 60 KiB): every workgroup accumulates its
- * band of cells into a private copy of the whole table and adds it to dW once;
- * CWN_ERR_TOO_LARGE otherwise (callers then use the transposed aggregation). */
+/* Its backward: dW[col_off[c] + src[r, c], :] += g[r, :].  dW is [V, H], accumulated (the caller zeroes it).  H = 64 / 128 /
+ * 256: a band of 64 cells is staged in LDS and the distinct values of every column are walked with ballots -- one partial per
+ * (table row, feature) and band goes to dW with an fp32 atomic, no float atomics in LDS.  Other widths: every workgroup
+ * accumulates its band into a private copy of the whole table in LDS, which must fit (V * H * 4 <= 60 KiB; CWN_ERR_TOO_LARGE
+ * otherwise: callers then use the transposed aggregation). */
 /* src_f32 != 0: `src` holds the integer features as float32 (as the containers deliver them; truncated like the front's);
  * n_dev (or NULL): device int64 = the actual number of rows (n_rows = capacity). */
 int cwn_embedding_bwd_f32(const float* g, const void* src, const int64_t* col_off,
