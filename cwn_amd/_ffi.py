@@ -594,6 +594,9 @@ def defer_tn(on: bool) -> None:
 # forked graph replays SLOWER (1.17 -> 1.46 - 1.61 ms; every cross-branch edge of a hipGraph costs more than the overlap
 # wins); kept as a switch for eager multi-stream runs (CWN_TN_SIDE=1).
 TN_SIDE_STREAM = os.environ.get('CWN_TN_SIDE', '0') == '1'
+# ... or (round 5, CWN_TN_SIDE=2): queued as above, but every time a whole launch's worth (MAX_TN_DESCS) has queued up it is
+# issued on the side stream -- four forks and one join per ZINC step instead of one fork per stage.
+TN_SIDE_CHUNKS = os.environ.get('CWN_TN_SIDE', '0') == '2'
 _tn_side = {}
 _tn_side_used = False
 
@@ -603,6 +606,20 @@ def _side_stream(device):
     if key not in _tn_side:
         _tn_side[key] = torch.cuda.Stream(device=key)
     return _tn_side[key]
+
+
+def _side_flush(device) -> None:
+    """The queued descriptors as launches on the side stream, forked off the current one here (TN_SIDE_CHUNKS)."""
+    global _tn_queue, _tn_side_used
+    pend = [q for q in _tn_queue if not q[3:]]
+    descs = [d for q in pend for d in q[0]]
+    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    side.wait_stream(main)
+    _tn_side_used = True
+    with torch.cuda.stream(side):
+        _flush_descs(descs, device)
+    # (the operands stay referenced until the join; the entries are marked as issued)
+    _tn_queue = [q if q[3:] else ([], q[1], q[2], True) for q in _tn_queue]
 
 
 def flush_tn(device=None) -> None:
@@ -617,7 +634,8 @@ def flush_tn(device=None) -> None:
         return
     q, _tn_queue = _tn_queue, []
     by_dev = {}
-    for ds, _, dv in q:
+    for ent in q:
+        ds, dv = ent[0], ent[2]
         by_dev.setdefault(dv, []).extend(ds)
     for dv, descs in by_dev.items():
         _flush_descs(descs, dv if dv is not None else device)
@@ -642,6 +660,8 @@ def gemm_tn(descs: Sequence[GemmTnDesc], device, keep=None, deferrable: bool = F
     if deferrable and _tn_queue is not None:
         if not TN_SIDE_STREAM:
             _tn_queue.append((list(descs), keep, torch.device(device)))
+            if TN_SIDE_CHUNKS and sum(len(q[0]) for q in _tn_queue if not q[3:]) >= MAX_TN_DESCS:
+                _side_flush(torch.device(device))
             return
         global _tn_side_used
         main, side = torch.cuda.current_stream(device), _side_stream(device)

@@ -82,6 +82,7 @@ def test_training_step_at_the_timed_size_vs_float64_oracle(cfg):
     gate(loss.detach().view(1), ref_loss.detach().view(1), f'{cfg}: training loss (BatchNorm batch statistics) vs float64 oracle')
     worst, above, n_par = 0.0, [], 0
     worst32, above32 = 0.0, 0
+    per_tensor = []
     d2, d2_32, n2 = 0.0, 0.0, 0.0
     for name, p in model.named_parameters():
         r = leaves[name].grad
@@ -96,11 +97,21 @@ def test_training_step_at_the_timed_size_vs_float64_oracle(cfg):
         above32 += err32 > 1e-5 * scale
         if err > 1e-5 * scale:
             above.append((name, err, scale))
+            per_tensor.append((err / scale, err32 / scale, name))
         d2, d2_32, n2 = d2 + float(((g - r) ** 2).sum()), d2_32 + float(((r32 - r) ** 2).sum()), n2 + float((r ** 2).sum())
     rel, rel32 = (d2 / n2) ** 0.5, (d2_32 / n2) ** 0.5
     print(f'[gate] {cfg}: {n_par} parameter gradients of one training step vs float64 oracle autograd: worst max|delta| / max(1, |ref|_inf) '
           f'= {worst:.3e} (the fp32 oracle itself: {worst32:.3e}); above 1e-5: {len(above)} (fp32 oracle: {above32}); relative L2 distance '
           f'of the whole gradient {rel:.3e} (fp32 oracle: {rel32:.3e})')
+    # per tensor: every gradient the product has above 1e-5, with the fp32 oracle's own distance on the same
+    # tensor -- a tensor where the product is clearly above the bar (> 2e-5) while the reference's arithmetic is clearly
+    # not there (product > 4 x fp32 oracle) fails; where both are above, the product may not be further than 2 x (below)
+    per_tensor.sort(reverse=True)
+    lone = [(e, e32, n_) for e, e32, n_ in per_tensor if e32 <= 1e-5]
+    print(f'[gate] {cfg}: {len(per_tensor)} tensors above 1e-5, {len(lone)} of them where the fp32 oracle is not; the worst ten '
+          f'(product / fp32 oracle / name): ' + '; '.join(f'{e:.2e} / {e32:.2e} / {n_}' for e, e32, n_ in per_tensor[:10]))
+    bad = [(e, e32, n_) for e, e32, n_ in per_tensor if e > 2e-5 and e > 4.0 * e32]
+    assert not bad, bad[:5]
     # the bar: the north star's 1e-5 . max(1, |ref|_inf) where the reference's own fp32 arithmetic meets it, else no further
     # from the float64 gradient than twice what that arithmetic is
     assert worst <= 2.0 * max(worst32, 1e-5), (worst, worst32)
