@@ -2,7 +2,7 @@
 section prescribes: separate rocprofv3 passes for FETCH_SIZE and WRITE_SIZE (with --kernel-trace
 only), counters in KiB, gfx950 FETCH_SIZE doubled for wide coalesced streams, WRITE_SIZE as is.
 Run ON the GPU box from the repo root:   python tools/collect_traffic.py [batch ...]
-Writes profiles/r4_pmc_fetch_write_raw.json and profiles/r4_traffic.json (the dominant kernel of the
+Writes profiles/r5_pmc_fetch_write_raw.json and profiles/r5_traffic.json (the dominant kernel of the
 propagate scope: layer_kernel<F, 2>, the variant that loads the per-item CSR; the first launch of a
 step is layer_kernel<F, 1>)."""
 import csv
@@ -62,9 +62,9 @@ def main():
     # profiles/ is what bench.py reads; gpurun_out/ is what travels back from the GPU box
     for d in ('profiles', 'gpurun_out'):
         os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-        with open(os.path.join(ROOT, d, 'r4_pmc_fetch_write_raw.json'), 'w') as fh:
+        with open(os.path.join(ROOT, d, 'r5_pmc_fetch_write_raw.json'), 'w') as fh:
             json.dump(raw, fh, indent=1)
-        with open(os.path.join(ROOT, d, 'r4_traffic.json'), 'w') as fh:
+        with open(os.path.join(ROOT, d, 'r5_traffic.json'), 'w') as fh:
             json.dump(traffic, fh, indent=1)
     print(json.dumps(traffic['entries']))
 
