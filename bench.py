@@ -1418,6 +1418,14 @@ def main():
 
     if rank == 0:
         printed.set()
+        if dist is not None:
+            # RCCL writes its version banner to the C stdout of rank 0, buffered until exit when stdout is a file: flush it NOW so
+            # that the JSON line is the LAST line of stdout (the driver reads one line)
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
         line_ = result_line(train, collate)
         line_['secondary']['workloads'] = workloads
         line_['secondary']['fresh_batches'] = fresh

@@ -27,7 +27,7 @@ CWN_BENCH_FORCE_DP=1 CWN_BENCH_TRAIN_GRAPH=1 CWN_BENCH_SKIP=eager,concurrent,col
 python - <<PY
 import json
 try:
-    d = json.loads(open('$OUT/r5_${TAG}_bench_forced_dp.json').read().strip().splitlines()[-1])
+    d = json.loads([l for l in open('$OUT/r5_${TAG}_bench_forced_dp.json').read().strip().splitlines() if l.startswith('{')][-1])
     print('multi_gpu', json.dumps(d['multi_gpu'])[:900])
 except Exception as e:
     print('forced dp: no line', e)
