@@ -749,8 +749,8 @@ def main():
             traffic = None
             try:
                 tj = load_profile_json('traffic')
-                ent = tj['entries'].get(str(args.batch))
-                if WL == 'zinc' and tj.get('hidden') == H and ent and ent.get('kernel', '').startswith('layer_kernel'):
+                ent = tj['entries'].get(str(args.batch) if WL == 'zinc' else f'{WL}:{args.batch}')
+                if (WL != 'zinc' or tj.get('hidden') == H) and ent and ent.get('kernel', '').startswith(f'layer_kernel<{H}'):
                     traffic = ent['traffic_bytes']
             except (OSError, ValueError, KeyError):
                 traffic = None
@@ -874,8 +874,8 @@ def main():
             traffic = None
             try:
                 tj = load_profile_json('traffic')
-                ent = tj['entries'].get(str(args.batch))
-                if WL == 'zinc' and tj.get('hidden') == H and ent and ent.get('kernel', '').startswith('aggregate_kernel'):
+                ent = tj['entries'].get(str(args.batch) if WL == 'zinc' else f'{WL}:{args.batch}')
+                if (WL != 'zinc' or tj.get('hidden') == H) and ent and ent.get('kernel', '').startswith('aggregate_kernel'):
                     traffic = ent['traffic_bytes']
             except (OSError, ValueError, KeyError):
                 traffic = None
@@ -1401,7 +1401,7 @@ def main():
                                  'cells_per_batch': d_['config']['cells_per_batch'], 'timing': d_.get('timing'),
                                  'roofline': {k: (d_['roofline'] or {}).get(k) for k in
                                               ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us',
-                                               'algorithmic_bytes_per_launch')},
+                                               'algorithmic_bytes_per_launch', 'traffic', 'frac_vs_pmc_traffic')},
                                  'roofline_step': {k: (d_['roofline_step'] or {}).get(k) for k in ('achieved', 'unit', 'frac')}}
                 if whole:
                     sec_ = d_.get('secondary') or {}

@@ -265,6 +265,12 @@ class StaticBatch:
                 while self._caps[k] in used:
                     self._caps[k] += 1
                 used.add(self._caps[k])
+        # (an index and its shared-cell vector have one entry each per adjacency entry: one capacity)
+        for d in range(D):
+            for key, aux in (('upper_index', 'shared_coboundaries'), ('lower_index', 'shared_boundaries')):
+                ki, ka = self.k_of(d, key), self.k_of(d, aux)
+                if ki >= 0 and ka >= 0:
+                    self._caps[ka] = self._caps[ki]
         for d in range(1, D):            # the CSR columns cover the boundary entries one to one
             kb = self.k_of(d, 'boundary_index')
             if kb >= 0:
