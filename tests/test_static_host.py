@@ -111,3 +111,42 @@ def test_static_drivers_refuse_layers_that_need_a_per_batch_csr_plan():
     refuse_unsupported_layers(EmbedSparseCIN(28, 4, 1, 2, 16, **kw), 'StaticForward')
     with pytest.raises(NotImplementedError, match='CINppConv'):
         refuse_unsupported_layers(EmbedCINpp(28, 4, 1, 2, 16, **kw), 'StaticForward')
+
+
+def test_host_capacity_check_over_the_distinct_size_columns():
+    """StaticBatch._check_capacity: a batch beyond a capacity raises ValueError naming what overflowed; columns that
+    are copies of one another are checked once against the smallest of their capacities; a column whose B largest values fit
+    is not gathered at all; `-1` (no complex) counts as nothing."""
+    import numpy as np
+    import pytest
+    from cwn_amd.static_batch import StaticBatch
+
+    class _P:
+        pass
+    sb = StaticBatch.__new__(StaticBatch)
+    sb.D, sb.K, sb.B = 3, 4, 8
+    rng = np.random.default_rng(0)
+    cells = rng.integers(5, 30, size=(100, 3))
+    meta = np.zeros((100, 9 + 12), dtype=np.int64)
+    meta[:, 0:9:3] = cells
+    meta[:, 9] = cells[:, 0] * 2          # upper_index of dim 0
+    meta[:, 10] = cells[:, 0] * 2         # its shared-cell vector: a copy
+    meta[:, 11] = cells[:, 1]             # b_rowptr of dim 1 = cells of dim 1: a copy of a cell column
+    meta[:, 12] = 1                       # y
+    pk = _P()
+    pk._meta = meta
+    pk._klist = [(0, 'upper_index', None), (0, 'shared_coboundaries', None), (1, 'b_rowptr', None), (-1, 'y', None)]
+    sb.packed, sb.cap_cells, sb._caps, sb._cap_cols = pk, [150, 10 ** 6, 10 ** 6], [300, 310, 10 ** 6, 8], None
+    heavy = np.argsort(-cells[:, 0])[:8]
+    light = np.argsort(cells[:, 0])[:8]
+    host = np.full((3, 8), -1, dtype=np.int64)
+    host[0], host[1, :4], host[2] = light, light[:4], heavy
+    with pytest.raises(ValueError, match='batch 2: .* cells of dimension 0 exceed the capacity 150'):
+        sb._check_capacity(host)
+    sb._check_capacity(host[:2])                                  # the light batches pass, the short one too
+    checked = sorted(c for _, _, c in sb._cap_cols)
+    assert checked == [0, 3], checked       # cells of dim 0, and ONE of the two entry columns (cap 300 < 310); y and the huge caps: skipped
+    sb.cap_cells[0] = 10 ** 6                                     # now the entry column decides: 2 x cells > 300
+    sb._cap_cols = None
+    with pytest.raises(ValueError, match="elements of 'upper_index' \\(dimension 0\\) exceed the capacity 300"):
+        sb._check_capacity(host)
