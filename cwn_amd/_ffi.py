@@ -191,13 +191,15 @@ class EmbedTable(C.Structure):
 class HeadDim(C.Structure):
     """cwn_head_dim (include/cwn_hip.h)."""
     _fields_ = [('x', C.c_void_p), ('cell_ptr', C.c_void_p), ('w1t', C.c_void_p), ('b1', C.c_void_p),
-                ('pooled_out', C.c_void_p), ('h_out', C.c_void_p), ('n_cells', C.c_int64), ('ldx', C.c_int64)]
+                ('pooled_out', C.c_void_p), ('h_out', C.c_void_p), ('n_cells', C.c_int64), ('ldx', C.c_int64),
+                ('x_more', C.c_void_p * 7), ('n_parts', C.c_int32), ('pad_', C.c_int32)]
 
 
 class HeadBwdDim(C.Structure):
     """cwn_head_bwd_dim (include/cwn_hip.h)."""
     _fields_ = [('h', C.c_void_p), ('w1', C.c_void_p), ('cell_ptr', C.c_void_p), ('dx', C.c_void_p),
-                ('dh_out', C.c_void_p), ('n_cells', C.c_int64), ('lddx', C.c_int64)]
+                ('dh_out', C.c_void_p), ('n_cells', C.c_int64), ('lddx', C.c_int64),
+                ('dx_more', C.c_void_p * 7), ('n_parts', C.c_int32), ('pad_', C.c_int32)]
 
 
 ERR_BIT_BLOCK = 8         # = CWN_ERR_BIT_BLOCK
@@ -226,6 +228,7 @@ class Dropout(C.Structure):
 
 
 HEAD_DROP_NONE, HEAD_DROP_LIN1, HEAD_DROP_FINAL, HEAD_DROP_LIN2 = range(4)      # = CWN_HEAD_DROP_*
+HEAD_MAX_PARTS = 8         # = CWN_HEAD_MAX_PARTS
 
 
 class NormDesc(C.Structure):
@@ -392,10 +395,11 @@ def lib():
                                       C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cwn_head_f32.restype = C.c_int
     L.cwn_head_f32.argtypes = [C.POINTER(HeadDim), C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                               C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Dropout), C.c_int32, C.c_void_p]
+                               C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Dropout), C.c_int32, C.c_void_p,
+                               C.c_int32, C.c_void_p]
     L.cwn_head_bwd_f32.restype = C.c_int
     L.cwn_head_bwd_f32.argtypes = [C.POINTER(HeadBwdDim), C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                   C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Dropout), C.c_int32, C.c_void_p]
+                                   C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Dropout), C.c_int32, C.c_int32, C.c_void_p]
     L.cwn_lift_create.restype = C.c_void_p
     L.cwn_lift_create.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
     L.cwn_lift_size.restype = C.c_int64

@@ -292,7 +292,18 @@ struct HeadArgs {
     int32_t n_dims, K, H2, O, mean_readout, mean_final;
     cwn_dropout drop;                              // the head's dropout (cwn_dropout.h) at position drop_pos (CWN_HEAD_DROP_*)
     int32_t drop_pos;
+    float* partials;                               // [C][P][CWN_HEAD_MAX_DIMS][K] (head_pool_kernel wrote them), or NULL
+    int32_t pool_split;                            // P
 };
+
+// the source of columns 4 l .. 4 l + 3 of row r of dimension D: the matrix itself, or -- a jumping-knowledge concatenation
+// that is never materialised -- the block's own matrix (cwn_head_dim.x_more)
+__device__ __forceinline__ const float* head_row(const cwn_head_dim& D, int64_t r, int col, int Kp) {
+    if (D.n_parts <= 1) return D.x + r * D.ldx + col;
+    const int q = col / Kp;
+    const float* base = q == 0 ? D.x : D.x_more[q - 1];
+    return base + r * D.ldx + (col - q * Kp);
+}
 
 __host__ __device__ constexpr size_t head_lds_floats(int K, int H2) {
     return (size_t)CWN_HEAD_MAX_DIMS * kPartFloats + (size_t)CWN_HEAD_MAX_DIMS * K + (size_t)CWN_HEAD_MAX_DIMS * 4 * kHeadThreads + H2;
@@ -315,8 +326,10 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
     const int G = K / 4, NG = kHeadThreads / G;
     const int g = tid / G, l = tid - g * G;
     int64_t r0[CWN_HEAD_MAX_DIMS], r1[CWN_HEAD_MAX_DIMS];
+    int Kp[CWN_HEAD_MAX_DIMS];
 #pragma unroll
     for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d) {
+        Kp[d] = (d < nd && A.d[d].n_parts > 1) ? K / A.d[d].n_parts : K;
         r0[d] = r1[d] = 0;
         if (d < nd && A.d[d].x != nullptr && A.d[d].n_cells > 0) {
             const int64_t a = A.d[d].cell_ptr[c], b = A.d[d].cell_ptr[c + 1];
@@ -324,7 +337,15 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
             r1[d] = b < r0[d] ? r0[d] : (b > A.d[d].n_cells ? A.d[d].n_cells : b);
         }
     }
-    if (g < NG) {
+    const bool from_partials = A.partials != nullptr;      // (uniform) large complexes: head_pool_kernel summed the rows
+    if (from_partials) {
+        const float* mine = A.partials + (size_t)c * A.pool_split * CWN_HEAD_MAX_DIMS * K;
+        for (int i = tid; i < CWN_HEAD_MAX_DIMS * K; i += kHeadThreads) {
+            float s = 0.f;
+            for (int q = 0; q < A.pool_split; ++q) s += mine[(size_t)q * CWN_HEAD_MAX_DIMS * K + i];     // chunk order: fixed
+            part[(size_t)(i / K) * kPartFloats + (i % K)] = s;                                           // as row group 0's partial
+        }
+    } else if (g < NG) {
         // the first two rows of every dimension are requested before any is added: a molecule gives a row group one
         // or two rows per dimension, and three dimensions one after the other would be three memory round trips
         float4 v[CWN_HEAD_MAX_DIMS][2];
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
             for (int u = 0; u < 2; ++u) {
                 v[d][u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 const int64_t r = r0[d] + g + (int64_t)u * NG;
-                if (r < r1[d]) v[d][u] = *reinterpret_cast<const float4*>(A.d[d].x + r * A.d[d].ldx + 4 * l);
+                if (r < r1[d]) v[d][u] = *reinterpret_cast<const float4*>(head_row(A.d[d], r, 4 * l, Kp[d]));
             }
 #pragma unroll
         for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d) {
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
                 for (int u = 0; u < 4; ++u) {
                     const int64_t ru = r + (int64_t)u * NG;
                     w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ru < r1[d]) w[u] = *reinterpret_cast<const float4*>(A.d[d].x + ru * A.d[d].ldx + 4 * l);
+                    if (ru < r1[d]) w[u] = *reinterpret_cast<const float4*>(head_row(A.d[d], ru, 4 * l, Kp[d]));
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { acc.x += w[u].x; acc.y += w[u].y; acc.z += w[u].z; acc.w += w[u].w; }
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
     for (int i = tid; i < CWN_HEAD_MAX_DIMS * K; i += kHeadThreads) {
         const int d = i / K, k = i - d * K;
         float s = 0.f;
-        for (int q = 0; q < NG; ++q) s += part[(size_t)d * kPartFloats + (size_t)q * K + k];     // fixed order
+        for (int q = 0; q < (from_partials ? 1 : NG); ++q) s += part[(size_t)d * kPartFloats + (size_t)q * K + k];     // fixed order
         if (A.mean_readout) {
             const int64_t n = r1[d] - r0[d];
             s = s / (float)(n > 0 ? n : 1);
@@ -435,6 +456,57 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
     }
 }
 
+// The row sums of LARGE complexes ahead of the head launch (cwn_head_f32: pool_split = P > 1): workgroup (c, p) sums chunk p
+// of the rows of complex c in every dimension -- K / 4 lanes a row, row groups side by side, four rows in flight per group, the
+// groups' partials summed in group order -- and stores [CWN_HEAD_MAX_DIMS][K] floats.  A REDDIT-like complex has ~4 000 cells
+// of 1 KiB (4 layers x 64 under jumping knowledge): one workgroup pulled 4 MB through its CU in 68 us while 224 CUs idled.
+__global__ __launch_bounds__(kHeadThreads) void head_pool_kernel(HeadArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int K = A.K, nd = A.n_dims, P = A.pool_split;
+    float* const part = sm;                                  // [NG][K]
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    const int p = blockIdx.y;
+    const int G = K / 4, NG = kHeadThreads / G;
+    const int g = tid / G, l = tid - g * G;
+    float* const out = A.partials + ((size_t)c * P + p) * CWN_HEAD_MAX_DIMS * K;
+    for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d) {
+        int64_t a = 0, b = 0;
+        if (d < nd && A.d[d].x != nullptr && A.d[d].n_cells > 0) {
+            const int64_t s0 = A.d[d].cell_ptr[c], s1 = A.d[d].cell_ptr[c + 1];
+            const int64_t lo = s0 < 0 ? 0 : (s0 > A.d[d].n_cells ? A.d[d].n_cells : s0);
+            const int64_t hi = s1 < lo ? lo : (s1 > A.d[d].n_cells ? A.d[d].n_cells : s1);
+            const int64_t chunk = (hi - lo + P - 1) / P;
+            a = lo + (int64_t)p * chunk;
+            b = a + chunk < hi ? a + chunk : hi;
+            if (a > hi) a = hi;
+        }
+        const int Kp = (d < nd && A.d[d].n_parts > 1) ? K / A.d[d].n_parts : K;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < NG) {
+            for (int64_t r = a + g; r < b; r += 4 * (int64_t)NG) {
+                float4 w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t ru = r + (int64_t)u * NG;
+                    w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ru < b) w[u] = *reinterpret_cast<const float4*>(head_row(A.d[d], ru, 4 * l, Kp));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += w[u].x; acc.y += w[u].y; acc.z += w[u].z; acc.w += w[u].w; }
+            }
+            *reinterpret_cast<float4*>(part + (size_t)g * K + 4 * l) = acc;
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += kHeadThreads) {
+            float s = 0.f;
+            for (int q = 0; q < NG; ++q) s += part[(size_t)q * K + k];      // fixed order
+            out[(size_t)d * K + k] = s;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // head, backward (training): per complex  ds = W2^T g_out  ->  dh_d = ds . [h_d > 0]  ->  dpooled_d = W1_d^T dh_d  ->  every
 // row of the complex in x_d gets dpooled_d (/ count for a mean readout).  The weight gradients are sums over the
@@ -449,6 +521,7 @@ struct HeadBwdArgs {
     int32_t n_dims, K, H2, O, mean_readout, mean_final;
     cwn_dropout drop;
     int32_t drop_pos;
+    int32_t row_split;                            // P: workgroup (c, p) writes chunk p of the complex's rows
 };
 
 __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs A) {
@@ -472,7 +545,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs A) {
             float v = A.d[d].h[c * H2 + tid] > 0.f ? ds : 0.f;
             if (dpos == CWN_HEAD_DROP_FINAL) v *= drop.mul1(((uint64_t)d * (uint64_t)A.C + (uint64_t)c) * (uint64_t)H2 + (uint64_t)tid);
             dh[d * H2 + tid] = v;
-            if (A.d[d].dh_out != nullptr) A.d[d].dh_out[c * H2 + tid] = v;
+            if (A.d[d].dh_out != nullptr && blockIdx.y == 0) A.d[d].dh_out[c * H2 + tid] = v;
         }
     }
     __syncthreads();
@@ -518,11 +591,20 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs A) {
             dp[tid] = v;
         }
         __syncthreads();
-        // 4. every row of the complex gets it
+        // 4. every row of the complex gets it (this workgroup: its chunk of the rows; a concatenation: every block to its matrix)
         if (g < NG) {
             const float4 v = *reinterpret_cast<const float4*>(dp + 4 * l);
-            for (int64_t r = r0 + g; r < r1; r += NG)
-                cwn::store_result4(A.d[d].dx + r * A.d[d].lddx + 4 * l, v.x, v.y, v.z, v.w);
+            const int64_t chunk = (r1 - r0 + A.row_split - 1) / A.row_split;
+            const int64_t a = r0 + (int64_t)blockIdx.y * chunk, b = a + chunk < r1 ? a + chunk : r1;
+            float* base = A.d[d].dx;
+            int col = 4 * l;
+            if (A.d[d].n_parts > 1) {
+                const int Kp = K / A.d[d].n_parts, q = col / Kp;
+                base = q == 0 ? A.d[d].dx : A.d[d].dx_more[q - 1];
+                col -= q * Kp;
+            }
+            for (int64_t r = a + g; r < b; r += NG)
+                cwn::store_result4(base + r * A.d[d].lddx + col, v.x, v.y, v.z, v.w);
         }
         __syncthreads();                       // `part` / `dp` are reused by the next dimension
     }
@@ -532,7 +614,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs A) {
 
 extern "C" int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims, int n_dims, int64_t C, int32_t K, int32_t H2,
                                 int32_t mean_readout, int32_t mean_final, const float* w2, int32_t O, const float* g_out,
-                                const cwn_dropout* drop, int32_t drop_pos, cwn_stream_t stream_) {
+                                const cwn_dropout* drop, int32_t drop_pos, int32_t row_split, cwn_stream_t stream_) {
+    if (row_split < 1) row_split = 1;
+    if (row_split > 64) return CWN_ERR_BAD_ARG;
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_HEAD_MAX_DIMS || C < 0 || O < 1) return CWN_ERR_BAD_ARG;
     if (K < 4 || (K & 3) != 0 || K > 4 * kHeadThreads || H2 < 4 || (H2 & 3) != 0 || H2 > kHeadThreads) return CWN_ERR_BAD_ARG;
     if (C == 0) return CWN_OK;
@@ -542,9 +626,13 @@ extern "C" int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims, int n_dims, int64_
     for (int d = 0; d < n_dims; ++d) {
         const cwn_head_bwd_dim& D = dims[d];
         if (D.h == nullptr || D.n_cells < 0) return CWN_ERR_BAD_ARG;
-        if (D.dx != nullptr && D.n_cells > 0 && (D.cell_ptr == nullptr || D.w1 == nullptr || D.lddx < K || (D.lddx & 3) != 0))
+        const int np = D.n_parts > 1 ? D.n_parts : 1;
+        if (np > CWN_HEAD_MAX_PARTS || K % np != 0 || ((K / np) & 3) != 0) return CWN_ERR_BAD_ARG;
+        if (D.dx != nullptr && D.n_cells > 0 && (D.cell_ptr == nullptr || D.w1 == nullptr || D.lddx < K / np || (D.lddx & 3) != 0))
             return CWN_ERR_BAD_ARG;
         if (!al16(D.dx) || !al16(D.w1)) return CWN_ERR_ALIGN;
+        for (int q = 1; q < np; ++q)
+            if (D.dx != nullptr && (D.dx_more[q - 1] == nullptr || !al16(D.dx_more[q - 1]))) return CWN_ERR_BAD_ARG;
         A.d[d] = D;
     }
     A.w2 = w2; A.g_out = g_out;
@@ -557,8 +645,9 @@ extern "C" int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims, int n_dims, int64_
     A.n_dims = n_dims; A.K = K; A.H2 = H2; A.O = O;
     A.mean_readout = mean_readout ? 1 : 0;
     A.mean_final = mean_final ? 1 : 0;
+    A.row_split = row_split;
     const size_t lds = ((size_t)CWN_HEAD_MAX_DIMS * H2 + 4 * kHeadThreads + K) * sizeof(float);
-    head_bwd_kernel<<<dim3((unsigned)C), dim3(kHeadThreads), lds, (hipStream_t)stream_>>>(A);
+    head_bwd_kernel<<<dim3((unsigned)C, (unsigned)row_split), dim3(kHeadThreads), lds, (hipStream_t)stream_>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
@@ -602,7 +691,10 @@ extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, flo
 
 extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
                             int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, float* s_out,
-                            const cwn_dropout* drop, int32_t drop_pos, cwn_stream_t stream_) {
+                            const cwn_dropout* drop, int32_t drop_pos, float* pool_partials, int32_t pool_split,
+                            cwn_stream_t stream_) {
+    if (pool_partials == nullptr || pool_split < 2) { pool_partials = nullptr; pool_split = 1; }
+    if (pool_split > 64 || !al16(pool_partials)) return CWN_ERR_BAD_ARG;
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_HEAD_MAX_DIMS || C < 0 || O < 1) return CWN_ERR_BAD_ARG;
     // K / 4 lanes a row inside 512 threads; output j by thread j
     if (K < 4 || (K & 3) != 0 || K > 4 * kHeadThreads || H2 < 4 || (H2 & 3) != 0 || H2 > kHeadThreads) return CWN_ERR_BAD_ARG;
@@ -613,8 +705,12 @@ extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int
     for (int d = 0; d < n_dims; ++d) {
         const cwn_head_dim& D = dims[d];
         if (D.w1t == nullptr || D.n_cells < 0) return CWN_ERR_BAD_ARG;
-        if (D.x != nullptr && D.n_cells > 0 && (D.cell_ptr == nullptr || D.ldx < K || (D.ldx & 3) != 0)) return CWN_ERR_BAD_ARG;
+        const int np = D.n_parts > 1 ? D.n_parts : 1;
+        if (np > CWN_HEAD_MAX_PARTS || K % np != 0 || ((K / np) & 3) != 0) return CWN_ERR_BAD_ARG;
+        if (D.x != nullptr && D.n_cells > 0 && (D.cell_ptr == nullptr || D.ldx < K / np || (D.ldx & 3) != 0)) return CWN_ERR_BAD_ARG;
         if (!al16(D.x) || !al16(D.w1t)) return CWN_ERR_ALIGN;
+        for (int q = 1; q < np; ++q)
+            if (D.x != nullptr && (D.x_more[q - 1] == nullptr || !al16(D.x_more[q - 1]))) return CWN_ERR_BAD_ARG;
         A.d[d] = D;
     }
     A.w2 = w2; A.b2 = b2; A.out = out;
@@ -628,8 +724,13 @@ extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int
     A.n_dims = n_dims; A.K = K; A.H2 = H2; A.O = O;
     A.mean_readout = mean_readout ? 1 : 0;
     A.mean_final = mean_final ? 1 : 0;
+    A.partials = pool_partials;
+    A.pool_split = pool_split;
     const size_t lds = head_lds_floats(K, H2) * sizeof(float);
     if (lds > 64 * 1024) return CWN_ERR_BAD_ARG;
+    if (pool_partials != nullptr)
+        head_pool_kernel<<<dim3((unsigned)C, (unsigned)pool_split), dim3(kHeadThreads), (size_t)kPartFloats * sizeof(float),
+                           (hipStream_t)stream_>>>(A);
     head_kernel<<<dim3((unsigned)C), dim3(kHeadThreads), lds, (hipStream_t)stream_>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

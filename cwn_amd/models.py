@@ -219,10 +219,14 @@ class _SparseCINStack(torch.nn.Module):
                 for i, x in enumerate(xs):
                     jump_xs[i] += [x]
         if self.jump_mode == 'cat':
-            xs = [torch.cat(j, dim=-1) for j in jump_xs]
+            # (the fused head reads the layers' outputs block by block: the concatenation of mp/models.py:222-232 is only
+            #  written when that head does not apply)
+            xs = [list(j) if len(j) > 1 else j[0] for j in jump_xs]
         elif self.jump_mode == 'max':
             xs = [torch.stack(j, dim=-1).max(dim=-1)[0] for j in jump_xs]
         fused = self._head_fused(xs, data, include_partial, res)
+        if fused is None and self.jump_mode == 'cat':
+            xs = [torch.cat(x, dim=-1) if isinstance(x, list) else x for x in xs]
         if fused is not None:
             if include_partial:
                 res['out'] = fused
@@ -267,7 +271,9 @@ class _SparseCINStack(torch.nn.Module):
         """Readout, lin1s (+ReLU), final readout and lin2 in ONE launch, one workgroup per complex (ops.head,
         csrc/cwn_ends.hip) -- 5 launches / 43 us of a 167 us forward at the ZINC batch of 128 before.  Inference
         (no autograd, no active dropout) on a batch that carries the collate's per-complex tables; None otherwise."""
-        if not ops.FUSED_ENDS or self.nonlinearity != 'relu' or not xs or not xs[0].is_cuda:
+        first = lambda x: x[0] if isinstance(x, list) else x
+        width = lambda x: sum(int(b.size(1)) for b in x) if isinstance(x, list) else int(x.size(1))
+        if not ops.FUSED_ENDS or self.nonlinearity != 'relu' or not xs or not first(xs[0]).is_cuda:
             return None
         if self.readout not in ('sum', 'mean') or self.final_readout not in ('sum', 'mean'):
             return None
@@ -281,7 +287,7 @@ class _SparseCINStack(torch.nn.Module):
             return None
         lins = [self.lin1s[d] for d in rd]
         train = torch.is_grad_enabled() and (any(p.requires_grad for l in lins + [self.lin2] for p in l.parameters())
-                                             or any(x.requires_grad for x in xs))
+                                             or any(b.requires_grad for x in xs for b in (x if isinstance(x, list) else [x])))
         if train and (not ops.FUSED_HEAD_TRAINING or any(d >= len(xs) for d in rd) or self.lin2.bias is None
                       or len({l.bias is None for l in lins}) != 1):
             return None              # (absent dimensions: the unfused autograd path; bias-free lin1s -- jump_mode 'cat' -- ride along)
@@ -291,10 +297,13 @@ class _SparseCINStack(torch.nn.Module):
         K, H2 = lins[0].in_features, lins[0].out_features
         if K % 4 != 0 or K > 2048 or H2 % 4 != 0 or H2 > 512 or any(l.in_features != K or l.out_features != H2 for l in lins):
             return None
-        if any(x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != K for x in xs):
+        if any(first(x).dtype != torch.float32 or first(x).dim() != 2 or width(x) != K for x in xs):
             return None
-        dev = xs[0].device
-        hx = [xs[d] if d < len(xs) and d < plan.n_dims and xs[d].size(0) == int(plan.cell_ptr[d][-1]) else None for d in rd]
+        if any(isinstance(x, list) and (len(x) > _ffi.HEAD_MAX_PARTS or any(b.size(1) != x[0].size(1) or b.size(1) % 4 for b in x))
+               for x in xs):
+            return None
+        dev = first(xs[0]).device
+        hx = [xs[d] if d < len(xs) and d < plan.n_dims and first(xs[d]).size(0) == int(plan.cell_ptr[d][-1]) else None for d in rd]
         if any(d < len(xs) and h is None for d, h in zip(rd, hx)):
             return None                    # a feature matrix that is not the batch's own rows
         ptrs = [plan.cell_ptr_device(d, dev) if h is not None else None for d, h in zip(rd, hx)]

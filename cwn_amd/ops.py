@@ -751,26 +751,65 @@ def _transpose_many(weights: Sequence[Tensor]) -> None:
         _w1t_cache[id(w)] = (weakref.ref(w), (w._version, STATE_EPOCH), both[k * K: (k + 1) * K])
 
 
-def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexes: int, lin1_weights: Sequence[Tensor],
+HEAD_POOL_SPLIT = os.environ.get('CWN_HEAD_POOL_SPLIT', 'auto')       # 'auto' | 1 (never) | P
+
+
+def head_split(rows_total: int, n_complexes: int) -> int:
+    """Row chunks per complex for the head's pooling / its backward's broadcast: 1 for molecules; for complexes of thousands
+    of cells (REDDIT-like) enough workgroups to fill the chip (at most 32, ~128 rows per chunk at least)."""
+    if HEAD_POOL_SPLIT != 'auto':
+        return max(1, min(64, int(HEAD_POOL_SPLIT)))
+    if n_complexes <= 0:
+        return 1
+    per = rows_total / n_complexes
+    if per < 512 or n_complexes >= 512:
+        return 1
+    return int(max(1, min(32, min(per // 128, -(-512 // n_complexes)))))
+
+
+def _head_parts(x):
+    """x of one dimension: a tensor, None, or the list of a jumping-knowledge concatenation's blocks -> (blocks, width)."""
+    if x is None:
+        return None, 0
+    blocks = list(x) if isinstance(x, (list, tuple)) else [x]
+    blocks = [_f32c(b, 'x') for b in blocks]
+    if len(blocks) > 1:
+        w = int(blocks[0].size(1))
+        if any(b.size(1) != w or b.size(0) != blocks[0].size(0) or b.stride(0) != blocks[0].stride(0) for b in blocks) \
+                or len(blocks) > _ffi.HEAD_MAX_PARTS or w % 4 != 0:
+            blocks = [torch.cat(blocks, dim=-1)]
+    return blocks, sum(int(b.size(1)) for b in blocks)
+
+
+def head(xs: Sequence, cell_ptrs: Sequence[Tensor], n_complexes: int, lin1_weights: Sequence[Tensor],
          lin1_biases: Sequence[Optional[Tensor]], lin2_weight: Tensor, lin2_bias: Optional[Tensor],
          mean_readout: bool = False, mean_final: bool = False, want_pooled: bool = False, want_hidden: bool = False,
          drop: Optional['_ffi.Dropout'] = None, drop_pos: int = 0):
     """pool_complex + lin1s (+ReLU) + final readout + lin2 in ONE launch (cwn_head_f32), one workgroup per complex.
-    xs[d]: [N_d, K] or None (dimension absent from the batch: pooled zeros, mp/nn.py:55-56); cell_ptrs[d]: device
-    int64 [C + 1], the collate's `ptr`.  Returns out [C, O] (and the pooled [C, K] per dimension)."""
-    x0 = next(x for x in xs if x is not None)
+    xs[d]: [N_d, K], None (dimension absent from the batch: pooled zeros, mp/nn.py:55-56), or a LIST of matrices [N_d, K / n]
+    -- the layer outputs of a jumping-knowledge model (jump_mode 'cat'), read block by block: the concatenation is never
+    written; cell_ptrs[d]: device int64 [C + 1], the collate's `ptr`.  Complexes of thousands of cells: their rows are summed
+    by `head_split` workgroups each in a launch ahead (cwn_head_f32: pool_partials).  Returns out [C, O] (and the pooled
+    [C, K] per dimension)."""
+    parts = [_head_parts(x) for x in xs]
+    x0 = next(b[0] for b, _ in parts if b is not None)
     _ffi.require_gpu(x0, 'x')
     dev = x0.device
     K, H2, O = int(lin1_weights[0].size(1)), int(lin1_weights[0].size(0)), int(lin2_weight.size(0))
     _transpose_many(lin1_weights)
     keep, dims, pooled, hidden = [], [], [], []
-    for d, x in enumerate(xs):
+    rows_total = 0
+    for d, (blocks, width) in enumerate(parts):
         D = _ffi.HeadDim()
-        if x is not None:
-            x = _f32c(x, 'x')
-            if x.size(1) != K:
-                raise ValueError(f'dim {d}: {x.size(1)} features for a lin1 of {K} inputs')
+        if blocks is not None:
+            if width != K:
+                raise ValueError(f'dim {d}: {width} features for a lin1 of {K} inputs')
+            x = blocks[0]
             D.x, D.cell_ptr, D.n_cells, D.ldx = x.data_ptr(), cell_ptrs[d].data_ptr(), int(x.size(0)), int(x.stride(0))
+            D.n_parts = len(blocks)
+            for q, b in enumerate(blocks[1:]):
+                D.x_more[q] = b.data_ptr()
+            rows_total += int(x.size(0))
         w1t = _transposed(lin1_weights[d])
         b1 = None if lin1_biases[d] is None else _f32c(lin1_biases[d].detach(), 'lin1 bias')
         D.w1t, D.b1 = w1t.data_ptr(), _ffi.ptr(b1)
@@ -782,17 +821,19 @@ def head(xs: Sequence[Optional[Tensor]], cell_ptrs: Sequence[Tensor], n_complexe
             ho = torch.empty(n_complexes, H2, dtype=torch.float32, device=dev)
             hidden.append(ho)
             D.h_out = ho.data_ptr()
-        keep += [x, w1t, b1]
+        keep += [blocks, w1t, b1]
         dims.append(D)
     w2 = _f32c(lin2_weight.detach(), 'lin2 weight')
     b2 = None if lin2_bias is None else _f32c(lin2_bias.detach(), 'lin2 bias')
     out = torch.empty(n_complexes, O, dtype=torch.float32, device=dev)
     s_out = torch.empty(n_complexes, H2, dtype=torch.float32, device=dev) if want_hidden else None
+    P = head_split(rows_total, n_complexes)
+    partials = torch.empty(n_complexes * P * 3 * K, dtype=torch.float32, device=dev) if P > 1 else None
     arr = (_ffi.HeadDim * len(dims))(*dims)
     _ffi.check(_ffi.lib().cwn_head_f32(arr, len(dims), n_complexes, K, H2, 1 if mean_readout else 0,
                                        1 if mean_final else 0, w2.data_ptr(), _ffi.ptr(b2), O, out.data_ptr(),
-                                       _ffi.ptr(s_out), drop, int(drop_pos) if drop is not None else 0, _ffi.stream_ptr(dev)),
-               'cwn_head_f32')
+                                       _ffi.ptr(s_out), drop, int(drop_pos) if drop is not None else 0, _ffi.ptr(partials), P,
+                                       _ffi.stream_ptr(dev)), 'cwn_head_f32')
     if want_hidden:
         return out, pooled, hidden, s_out
     return (out, pooled) if want_pooled else out
@@ -803,23 +844,33 @@ class _HeadTrain(torch.autograd.Function):
     pooled vectors, the pre-activations and the hidden vector; backward = ONE launch per complex (cwn_head_bwd_f32:
     dL/dx of every dimension) + the weight gradients as [C, .]^T [C, .] products through cwn_gemm_tn_f32 (deferred and
     merged with the step's other weight gradients inside accumulate_into_grad).  Replaces 5 forward and 16 backward
-    launches of the unfused path (readout, two grouped GEMMs, ReLU masks, adds)."""
+    launches of the unfused path (readout, two grouped GEMMs, ReLU masks, adds).  A dimension's x may be the blocks of a
+    jumping-knowledge concatenation (meta: blocks per dimension): every block is an input of its own and gets its own
+    gradient -- no torch.cat forward, no strided slice copies and adds backward."""
 
     @staticmethod
     def forward(ctx, meta, *tensors):
         n_dims, cell_ptrs, C, mean_readout, mean_final = meta[:5]
         drop_p, drop_pos = meta[5:7] if len(meta) > 5 else (0.0, 0)
-        xs = tensors[:n_dims]
-        w1s = tensors[n_dims:2 * n_dims]
-        b1s = tensors[2 * n_dims:3 * n_dims]
-        w2, b2 = tensors[3 * n_dims], tensors[3 * n_dims + 1]
+        counts = list(meta[7]) if len(meta) > 7 else [1] * n_dims
+        n_x = sum(counts)
+        flat = tensors[:n_x]
+        xs, o = [], 0
+        for cnt in counts:
+            blk = list(flat[o:o + cnt])
+            o += cnt
+            xs.append(None if blk[0] is None else (blk[0] if cnt == 1 else blk))
+        w1s = tensors[n_x:n_x + n_dims]
+        b1s = tensors[n_x + n_dims:n_x + 2 * n_dims]
+        w2, b2 = tensors[n_x + 2 * n_dims], tensors[n_x + 2 * n_dims + 1]
         # the head's dropout (`apply_dropout_before`): multipliers derived in the kernel, re-derived by the backward
-        ctx.drop = dropout_record(next(x for x in xs if x is not None).device, drop_p, tag=('head', int(drop_pos))) if drop_p > 0 and drop_pos else None
+        first = next(t for t in flat if t is not None)
+        ctx.drop = dropout_record(first.device, drop_p, tag=('head', int(drop_pos))) if drop_p > 0 and drop_pos else None
         ctx.drop_pos = int(drop_pos)
         out, pooled, hidden, s_out = head(xs, cell_ptrs, C, w1s, b1s, w2, b2, mean_readout, mean_final, want_hidden=True,
                                           drop=ctx.drop, drop_pos=ctx.drop_pos)
-        ctx.meta = meta
-        ctx.shapes = [None if x is None else (int(x.size(0)), int(x.size(1))) for x in xs]
+        ctx.meta, ctx.counts = meta, counts
+        ctx.shapes = [None if x is None else (int(x.size(0)), int(x.size(1))) for x in flat]
         ctx.params = (w1s, b1s, w2, b2)
         ctx.save_for_backward(*pooled, *hidden, s_out)
         ctx.mark_non_differentiable(*pooled)
@@ -829,40 +880,52 @@ class _HeadTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, *_):
         n_dims, cell_ptrs, C, mean_readout, mean_final = ctx.meta[:5]
+        counts = ctx.counts
+        n_x = sum(counts)
         saved = ctx.saved_tensors
         pooled, hidden, s_out = saved[:n_dims], saved[n_dims:2 * n_dims], saved[2 * n_dims]
         w1s, b1s, w2, b2 = ctx.params
         if g_out is None:
-            return (None,) * (1 + 3 * n_dims + 2)
+            return (None,) * (1 + n_x + 2 * n_dims + 2)
         dev = g_out.device
         g_out = _f32c(g_out, 'grad')
         K, H2, O = int(w1s[0].size(1)), int(w1s[0].size(0)), int(w2.size(0))
-        dims, dxs, dhs, keep = [], [], [], []
+        dims, dxs, dhs, keep = [], [None] * n_x, [], []
+        o, rows_total = 0, 0
         for d in range(n_dims):
+            cnt = counts[d]
             D = _ffi.HeadBwdDim(h=hidden[d].data_ptr())
             dh = torch.empty(C, H2, dtype=torch.float32, device=dev)
             dhs.append(dh)
             D.dh_out = dh.data_ptr()
-            dx = None
-            if ctx.shapes[d] is not None and ctx.needs_input_grad[1 + d]:
+            if ctx.shapes[o] is not None and any(ctx.needs_input_grad[1 + o + q] for q in range(cnt)):
                 w1 = _f32c(w1s[d].detach(), 'lin1 weight')
-                dx = torch.empty(ctx.shapes[d][0], K, dtype=torch.float32, device=dev)
-                D.w1, D.cell_ptr, D.dx, D.n_cells, D.lddx = w1.data_ptr(), cell_ptrs[d].data_ptr(), dx.data_ptr(), dx.size(0), K
+                rows, Kp = ctx.shapes[o]
+                # (all blocks of a dimension in one buffer: one allocation, equal row strides)
+                buf = torch.empty(cnt, rows, Kp, dtype=torch.float32, device=dev)
+                D.w1, D.cell_ptr, D.dx, D.n_cells, D.lddx = w1.data_ptr(), cell_ptrs[d].data_ptr(), buf[0].data_ptr(), rows, Kp
+                D.n_parts = cnt
+                for q in range(1, cnt):
+                    D.dx_more[q - 1] = buf[q].data_ptr()
+                for q in range(cnt):
+                    if ctx.needs_input_grad[1 + o + q]:
+                        dxs[o + q] = buf[q]
                 keep.append(w1)
-            dxs.append(dx)
+                rows_total += rows
+            o += cnt
             dims.append(D)
         w2c = _f32c(w2.detach(), 'lin2 weight')
         arr = (_ffi.HeadBwdDim * n_dims)(*dims)
         _ffi.check(_ffi.lib().cwn_head_bwd_f32(arr, n_dims, C, K, H2, 1 if mean_readout else 0, 1 if mean_final else 0,
                                                w2c.data_ptr(), O, g_out.data_ptr(), ctx.drop, ctx.drop_pos if ctx.drop is not None else 0,
-                                               _ffi.stream_ptr(dev)), 'cwn_head_bwd_f32')
+                                               head_split(rows_total, C), _ffi.stream_ptr(dev)), 'cwn_head_bwd_f32')
         # weight gradients: sums over the complexes = dZ^T X on [C, .] matrices; in-place targets when the caller owns them
         jobs = [(dhs[d], pooled[d], w1s[d], b1s[d]) for d in range(n_dims)] + [(g_out, s_out, w2, b2)]
         grads_w, grads_b, descs, scratch = [], [], [], []
         in_place = True
         for k, (dZ, X, W, b) in enumerate(jobs):
-            nW = ctx.needs_input_grad[1 + n_dims + k] if k < n_dims else ctx.needs_input_grad[1 + 3 * n_dims]
-            nb = b is not None and (ctx.needs_input_grad[1 + 2 * n_dims + k] if k < n_dims else ctx.needs_input_grad[2 + 3 * n_dims])
+            nW = ctx.needs_input_grad[1 + n_x + k] if k < n_dims else ctx.needs_input_grad[1 + n_x + 2 * n_dims]
+            nb = b is not None and (ctx.needs_input_grad[1 + n_x + n_dims + k] if k < n_dims else ctx.needs_input_grad[2 + n_x + 2 * n_dims])
             tw = _grad_target(W) if nW else None
             tb = _grad_target(b) if nb else None
             dW = tw if tw is not None else torch.zeros(W.shape, dtype=torch.float32, device=dev)
@@ -881,10 +944,21 @@ class _HeadTrain(torch.autograd.Function):
 
 def head_train(xs, cell_ptrs, n_complexes, lin1_weights, lin1_biases, lin2_weight, lin2_bias, mean_readout=False,
                mean_final=False, drop_p: float = 0.0, drop_pos: int = 0):
-    """(out, pooled list) with autograd: see _HeadTrain.  drop_p / drop_pos (_ffi.HEAD_DROP_*): the head's dropout, in-kernel."""
+    """(out, pooled list) with autograd: see _HeadTrain.  drop_p / drop_pos (_ffi.HEAD_DROP_*): the head's dropout, in-kernel.
+    xs[d] may be a list of blocks (jumping knowledge, jump_mode 'cat')."""
     n = len(xs)
-    meta = (n, list(cell_ptrs), int(n_complexes), bool(mean_readout), bool(mean_final), float(drop_p), int(drop_pos))
-    res = _HeadTrain.apply(meta, *xs, *lin1_weights, *lin1_biases, lin2_weight, lin2_bias)
+    flat, counts = [], []
+    for x in xs:
+        blk = list(x) if isinstance(x, (list, tuple)) else [x]
+        if len(blk) > 1:
+            w = int(blk[0].size(1))
+            if (len(blk) > _ffi.HEAD_MAX_PARTS or w % 4 != 0 or
+                    any(b.size(1) != w or b.size(0) != blk[0].size(0) or b.dtype != torch.float32 for b in blk)):
+                blk = [torch.cat(blk, dim=-1)]
+        flat += blk
+        counts.append(len(blk))
+    meta = (n, list(cell_ptrs), int(n_complexes), bool(mean_readout), bool(mean_final), float(drop_p), int(drop_pos), tuple(counts))
+    res = _HeadTrain.apply(meta, *flat, *lin1_weights, *lin1_biases, lin2_weight, lin2_bias)
     return res[0], list(res[1:])
 
 

@@ -1099,6 +1099,7 @@ int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, float* x0, con
  * fixed order; a complex's result does not depend on the rest of the batch.
  * ------------------------------------------------------------------------------------------ */
 #define CWN_HEAD_MAX_DIMS 3
+#define CWN_HEAD_MAX_PARTS 8
 typedef struct cwn_head_dim {
     const float* x;             /* [n_cells, K], row stride ldx (multiple of 4), or NULL */
     const int64_t* cell_ptr;    /* device [C + 1] */
@@ -1107,6 +1108,12 @@ typedef struct cwn_head_dim {
     float* pooled_out;          /* [C, K] or NULL */
     float* h_out;               /* [C, H2] or NULL: W1_d pooled_d + b1_d BEFORE the ReLU (training: the backward's mask) */
     int64_t n_cells, ldx;
+    /* Jumping knowledge, jump_mode 'cat' (mp/models.py:222-232: the readout of torch.cat(layer outputs, -1)) WITHOUT the
+     * concatenation: n_parts > 1 -- the K columns are n_parts blocks of K / n_parts, block 0 read from x, block q from
+     * x_more[q - 1], each [n_cells, K / n_parts] with row stride ldx (a layer's own output matrix).  0 / 1: x is [n_cells, K]. */
+    const float* x_more[CWN_HEAD_MAX_PARTS - 1];
+    int32_t n_parts;
+    int32_t pad_;
 } cwn_head_dim;
 
 /* s_out (optional, training): [C, H2] the hidden vector lin2 multiplies (sum / mean over the dimensions).
@@ -1115,9 +1122,14 @@ typedef struct cwn_head_dim {
  * relu(h_d) before the sum over the dimensions (element (d C + c) H2 + j), CWN_HEAD_DROP_LIN2 on the summed hidden vector
  * (element c H2 + j; s_out holds the dropped vector). */
 enum { CWN_HEAD_DROP_NONE = 0, CWN_HEAD_DROP_LIN1 = 1, CWN_HEAD_DROP_FINAL = 2, CWN_HEAD_DROP_LIN2 = 3 };
+/* pool_partials / pool_split (round 5): LARGE complexes (REDDIT-like: thousands of cells per complex, 32 complexes per batch --
+ * one workgroup per complex pulled 4 MB through one CU).  pool_split = P > 1 and pool_partials = device fp32
+ * [C][P][CWN_HEAD_MAX_DIMS][K]: a first launch of C x P workgroups sums P row chunks of every complex into the partials
+ * (plain stores), the head launch adds them in chunk order (deterministic) instead of reading the rows.  P = 1 / NULL: one
+ * launch as before. */
 int cwn_head_f32(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
                  int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, float* s_out,
-                 const cwn_dropout* drop, int32_t drop_pos, cwn_stream_t stream);
+                 const cwn_dropout* drop, int32_t drop_pos, float* pool_partials, int32_t pool_split, cwn_stream_t stream);
 
 /* Backward of the same head for the training step (exp/train_utils.py:62-73), one workgroup per complex, given
  * g_out = dL/dout [C, O] and what the forward left (h_out per dimension):
@@ -1133,13 +1145,18 @@ typedef struct cwn_head_bwd_dim {
     float* dx;                  /* [n_cells, K], row stride lddx, or NULL */
     float* dh_out;              /* [C, H2] or NULL */
     int64_t n_cells, lddx;
+    float* dx_more[CWN_HEAD_MAX_PARTS - 1];   /* n_parts > 1: block q of dpooled goes to the rows of dx (q = 0) / dx_more[q - 1], each */
+    int32_t n_parts;                          /* [n_cells, K / n_parts] with row stride lddx (cwn_head_dim.x_more) */
+    int32_t pad_;
 } cwn_head_bwd_dim;
 
 /* drop / drop_pos: the forward's (the same multipliers are re-derived: ds, dh_d or dpooled_d is multiplied where the forward
  * multiplied the value). */
+/* row_split = P >= 1: C x P workgroups, every one of a complex derives ds / dh / dpooled (a few thousand FMAs) and writes ITS
+ * chunk of the complex's rows (the broadcast of dpooled over thousands of cells is what a large complex costs). */
 int cwn_head_bwd_f32(const cwn_head_bwd_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
                      int32_t mean_final, const float* w2, int32_t O, const float* g_out, const cwn_dropout* drop,
-                     int32_t drop_pos, cwn_stream_t stream);
+                     int32_t drop_pos, int32_t row_split, cwn_stream_t stream);
 
 /* The loss of a training step and its gradient in one launch (exp/train_utils.py:62-73 with the elementwise-mean
  * criteria of :20-31): loss[0] = mean_i l(pred_i, y_i), grad_i = dl/dpred_i / n over n contiguous fp32 elements.

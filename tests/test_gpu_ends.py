@@ -312,3 +312,54 @@ def test_training_head_matches_the_unfused_autograd_path(hidden, readout, final_
         gate(grads[True][2][f'lin1s.{d}.weight'], lin[d][0].grad, f'dL/dlin1s.{d}.weight vs float64', tol=2e-5)
     gate(grads[True][2]['lin2.weight'], w2.grad, 'dL/dlin2.weight vs float64', tol=2e-5)
     gate(grads[True][2]['lin2.bias'], b2.grad, 'dL/dlin2.bias vs float64', tol=2e-5)
+
+
+@pytest.mark.parametrize('split', ['1', '4'])
+def test_head_over_the_blocks_of_a_jumping_knowledge_concatenation(split):
+    """jump_mode 'cat' (mp/models.py:222-232) without the concatenation (round 5): cwn_head_f32 reads the layers' outputs block
+    by block (cwn_head_dim.x_more) -- forward BIT-identical to the head over torch.cat (the same rows in the same order through
+    the same lanes); with the rows of a complex summed by several workgroups ahead of the head launch (pool_partials: the form
+    for complexes of thousands of cells) within the gate of the float64 result.  Backward (cwn_head_bwd_f32 with dx_more and
+    a row split): every block's gradient = its columns of the gradient of the concatenation; weight gradients alike."""
+    from cwn_amd import ops
+    from cwn_amd.synthetic import zinc_like_batch
+    K0, n_parts, H2, O = 64, 4, 128, 2
+    K = K0 * n_parts
+    b = zinc_like_batch(24, seed=12, max_ring=6, device=DEV)
+    plan, C = b.block_plan(), b.num_complexes
+    g = torch.Generator().manual_seed(2)
+    blocks = [[torch.randn(b.cochains[d].num_cells, K0, generator=g).to(DEV).requires_grad_(True) for _ in range(n_parts)] for d in range(3)]
+    lin1 = [torch.nn.Linear(K, H2, bias=False).to(DEV) for _ in range(3)]       # (JK cat: bias-free lin1s, mp/models.py:176-181)
+    lin2 = torch.nn.Linear(H2, O).to(DEV)
+    ptrs = [plan.cell_ptr_device(d, torch.device(DEV)) for d in range(3)]
+    params = [q for l in lin1 + [lin2] for q in l.parameters()]
+    prev = ops.HEAD_POOL_SPLIT
+    ops.HEAD_POOL_SPLIT = split
+    try:
+        def run(xs):
+            for t in [x for blk in blocks for x in blk] + params:
+                t.grad = None
+            out, _ = ops.head_train(xs, ptrs, C, [l.weight for l in lin1], [None] * 3, lin2.weight, lin2.bias, mean_readout=False,
+                                    mean_final=False)
+            w = torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)
+            (out * w).sum().backward()
+            return out.detach().clone(), [[x.grad.clone() for x in blk] for blk in blocks], [q.grad.clone() for q in params]
+        out_p, gx_p, gp_p = run([list(blk) for blk in blocks])
+        ops.HEAD_POOL_SPLIT = '1'
+        cats = [torch.cat([x for x in blk], dim=-1) for blk in blocks]
+        out_c, gx_c, gp_c = run(cats)
+    finally:
+        ops.HEAD_POOL_SPLIT = prev
+    if split == '1':
+        assert torch.equal(out_p, out_c)
+    # float64 reference of the concatenated form
+    cd = [c.detach().double() for c in cats]
+    pooled = [torch.stack([cd[d][int(ptrs[d][c]):int(ptrs[d][c + 1])].sum(0) for c in range(C)]) for d in range(3)]
+    ref = sum(torch.relu(pooled[d] @ lin1[d].weight.detach().double().t()) for d in range(3)) @ lin2.weight.detach().double().t() \
+        + lin2.bias.detach().double()
+    gate(out_p, ref, f'JK head over blocks, pool split {split}: prediction vs float64')
+    for d in range(3):
+        for q in range(n_parts):
+            gate(gx_p[d][q], gx_c[d][q].double(), f'JK head, pool split {split}: dL/d(block {q} of dim {d}) vs the concatenated form')
+    for a, c in zip(gp_p, gp_c):
+        gate(a, c.double(), f'JK head, pool split {split}: a weight gradient vs the concatenated form')
