@@ -292,8 +292,9 @@ struct HeadArgs {
     int32_t n_dims, K, H2, O, mean_readout, mean_final;
     cwn_dropout drop;                              // the head's dropout (cwn_dropout.h) at position drop_pos (CWN_HEAD_DROP_*)
     int32_t drop_pos;
-    float* partials;                               // [C][P][CWN_HEAD_MAX_DIMS][K] (head_pool_kernel wrote them), or NULL
-    int32_t pool_split;                            // P
+    float* partials;                               // chunk sums [slots][K] (head_pool_kernel wrote them), or NULL
+    int64_t slot_base[CWN_HEAD_MAX_DIMS];          // first slot of dimension d: chunk j of complex c sits at slot_base[d] + r0 / kHeadChunk + c + j
+    int32_t pool_split;                            // P: workgroups per complex of head_pool_kernel
 };
 
 // the source of columns 4 l .. 4 l + 3 of row r of dimension D: the matrix itself, or -- a jumping-knowledge concatenation
@@ -304,6 +305,30 @@ __device__ __forceinline__ const float* head_row(const cwn_head_dim& D, int64_t 
     const float* base = q == 0 ? D.x : D.x_more[q - 1];
     return base + r * D.ldx + (col - q * Kp);
 }
+
+// THE ORDER in which the rows of a complex are summed, whichever launch does it (so that a complex's pooled vector is the same
+// bits in a batch of molecules, in a static batch of another capacity, with its rows summed by one workgroup or by many):
+// chunks of kHeadChunk consecutive rows; inside a chunk row group g adds rows a + g, a + g + NG, ... one after the other, the
+// NG group partials are added in group order; the chunk sums are added in chunk order.  (A complex of at most kHeadChunk
+// cells per dimension -- every molecule -- is one chunk: the order this kernel has always had.)
+constexpr int kHeadChunk = CWN_HEAD_CHUNK;
+
+__device__ __forceinline__ float4 head_group_sum(const cwn_head_dim& D, int64_t a, int64_t b, int g, int NG, int l, int Kp) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = a + g; r < b; r += 4 * (int64_t)NG) {
+        float4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t ru = r + (int64_t)u * NG;
+            w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ru < b) w[u] = *reinterpret_cast<const float4*>(head_row(D, ru, 4 * l, Kp));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += w[u].x; acc.y += w[u].y; acc.z += w[u].z; acc.w += w[u].w; }
+    }
+    return acc;
+}
+
 
 __host__ __device__ constexpr size_t head_lds_floats(int K, int H2) {
     return (size_t)CWN_HEAD_MAX_DIMS * kPartFloats + (size_t)CWN_HEAD_MAX_DIMS * K + (size_t)CWN_HEAD_MAX_DIMS * 4 * kHeadThreads + H2;
@@ -337,13 +362,45 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
             r1[d] = b < r0[d] ? r0[d] : (b > A.d[d].n_cells ? A.d[d].n_cells : b);
         }
     }
-    const bool from_partials = A.partials != nullptr;      // (uniform) large complexes: head_pool_kernel summed the rows
-    if (from_partials) {
-        const float* mine = A.partials + (size_t)c * A.pool_split * CWN_HEAD_MAX_DIMS * K;
-        for (int i = tid; i < CWN_HEAD_MAX_DIMS * K; i += kHeadThreads) {
-            float s = 0.f;
-            for (int q = 0; q < A.pool_split; ++q) s += mine[(size_t)q * CWN_HEAD_MAX_DIMS * K + i];     // chunk order: fixed
-            part[(size_t)(i / K) * kPartFloats + (i % K)] = s;                                           // as row group 0's partial
+    const bool from_partials = A.partials != nullptr;      // (uniform) head_pool_kernel summed the rows, chunk by chunk
+    bool big = false;                                      // (uniform) a complex of more than one chunk, summed here
+#pragma unroll
+    for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d) big = big || (r1[d] - r0[d] > kHeadChunk);
+    if (from_partials || big) {
+        float* const tmp = hpart;                          // [NG][K] group partials of one chunk (phase 2 has not begun)
+        for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d) {
+            const int64_t nch = (r1[d] - r0[d] + kHeadChunk - 1) / kHeadChunk;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};           // columns tid, tid + 512, ... (K <= 2048)
+            if (from_partials) {
+                const float* mine = A.partials + (size_t)(A.slot_base[d] + r0[d] / kHeadChunk + c) * K;
+                for (int64_t j = 0; j < nch; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = tid + u * kHeadThreads;
+                        if (k < K) acc[u] += mine[(size_t)j * K + k];
+                    }
+            } else {
+                for (int64_t j = 0; j < nch; ++j) {
+                    const int64_t a = r0[d] + j * kHeadChunk, b = a + kHeadChunk < r1[d] ? a + kHeadChunk : r1[d];
+                    if (g < NG) *reinterpret_cast<float4*>(tmp + (size_t)g * K + 4 * l) = head_group_sum(A.d[d], a, b, g, NG, l, Kp[d]);
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = tid + u * kHeadThreads;
+                        if (k < K) {
+                            float t = 0.f;
+                            for (int q = 0; q < NG; ++q) t += tmp[(size_t)q * K + k];
+                            acc[u] += t;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = tid + u * kHeadThreads;
+                if (k < K) part[(size_t)d * kPartFloats + k] = acc[u];                 // as row group 0's partial
+            }
         }
     } else if (g < NG) {
         // the first two rows of every dimension are requested before any is added: a molecule gives a row group one
@@ -379,7 +436,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
     for (int i = tid; i < CWN_HEAD_MAX_DIMS * K; i += kHeadThreads) {
         const int d = i / K, k = i - d * K;
         float s = 0.f;
-        for (int q = 0; q < (from_partials ? 1 : NG); ++q) s += part[(size_t)d * kPartFloats + (size_t)q * K + k];     // fixed order
+        for (int q = 0; q < ((from_partials || big) ? 1 : NG); ++q) s += part[(size_t)d * kPartFloats + (size_t)q * K + k];     // fixed order
         if (A.mean_readout) {
             const int64_t n = r1[d] - r0[d];
             s = s / (float)(n > 0 ? n : 1);
@@ -469,41 +526,25 @@ __global__ __launch_bounds__(kHeadThreads) void head_pool_kernel(HeadArgs A) {
     const int p = blockIdx.y;
     const int G = K / 4, NG = kHeadThreads / G;
     const int g = tid / G, l = tid - g * G;
-    float* const out = A.partials + ((size_t)c * P + p) * CWN_HEAD_MAX_DIMS * K;
-    for (int d = 0; d < CWN_HEAD_MAX_DIMS; ++d) {
-        int64_t a = 0, b = 0;
-        if (d < nd && A.d[d].x != nullptr && A.d[d].n_cells > 0) {
-            const int64_t s0 = A.d[d].cell_ptr[c], s1 = A.d[d].cell_ptr[c + 1];
-            const int64_t lo = s0 < 0 ? 0 : (s0 > A.d[d].n_cells ? A.d[d].n_cells : s0);
-            const int64_t hi = s1 < lo ? lo : (s1 > A.d[d].n_cells ? A.d[d].n_cells : s1);
-            const int64_t chunk = (hi - lo + P - 1) / P;
-            a = lo + (int64_t)p * chunk;
-            b = a + chunk < hi ? a + chunk : hi;
-            if (a > hi) a = hi;
-        }
-        const int Kp = (d < nd && A.d[d].n_parts > 1) ? K / A.d[d].n_parts : K;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < NG) {
-            for (int64_t r = a + g; r < b; r += 4 * (int64_t)NG) {
-                float4 w[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t ru = r + (int64_t)u * NG;
-                    w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ru < b) w[u] = *reinterpret_cast<const float4*>(head_row(A.d[d], ru, 4 * l, Kp));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { acc.x += w[u].x; acc.y += w[u].y; acc.z += w[u].z; acc.w += w[u].w; }
+    for (int d = 0; d < nd; ++d) {
+        if (A.d[d].x == nullptr || A.d[d].n_cells <= 0) continue;                        // (uniform)
+        const int64_t s0 = A.d[d].cell_ptr[c], s1 = A.d[d].cell_ptr[c + 1];
+        const int64_t lo = s0 < 0 ? 0 : (s0 > A.d[d].n_cells ? A.d[d].n_cells : s0);
+        const int64_t hi = s1 < lo ? lo : (s1 > A.d[d].n_cells ? A.d[d].n_cells : s1);
+        const int64_t nch = (hi - lo + kHeadChunk - 1) / kHeadChunk;
+        const int Kp = A.d[d].n_parts > 1 ? K / A.d[d].n_parts : K;
+        float* const out = A.partials + (size_t)(A.slot_base[d] + lo / kHeadChunk + c) * K;
+        for (int64_t j = p; j < nch; j += P) {                                           // this workgroup's chunks
+            const int64_t a = lo + j * kHeadChunk, b = a + kHeadChunk < hi ? a + kHeadChunk : hi;
+            if (g < NG) *reinterpret_cast<float4*>(part + (size_t)g * K + 4 * l) = head_group_sum(A.d[d], a, b, g, NG, l, Kp);
+            __syncthreads();
+            for (int k = tid; k < K; k += kHeadThreads) {
+                float t = 0.f;
+                for (int q = 0; q < NG; ++q) t += part[(size_t)q * K + k];                // group order
+                out[(size_t)j * K + k] = t;
             }
-            *reinterpret_cast<float4*>(part + (size_t)g * K + 4 * l) = acc;
+            __syncthreads();
         }
-        __syncthreads();
-        for (int k = tid; k < K; k += kHeadThreads) {
-            float s = 0.f;
-            for (int q = 0; q < NG; ++q) s += part[(size_t)q * K + k];      // fixed order
-            out[(size_t)d * K + k] = s;
-        }
-        __syncthreads();
     }
 }
 
@@ -689,11 +730,18 @@ extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, flo
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
+extern "C" int64_t cwn_head_pool_floats(const cwn_head_dim* dims, int n_dims, int64_t C, int32_t K) {
+    if (dims == nullptr || n_dims < 1 || n_dims > CWN_HEAD_MAX_DIMS || C < 0 || K <= 0) return 0;
+    int64_t slots = 0;
+    for (int d = 0; d < n_dims; ++d) slots += (dims[d].n_cells > 0 ? dims[d].n_cells : 0) / kHeadChunk + C + 1;
+    return slots * K;
+}
+
 extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
                             int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, float* s_out,
-                            const cwn_dropout* drop, int32_t drop_pos, float* pool_partials, int32_t pool_split,
-                            cwn_stream_t stream_) {
-    if (pool_partials == nullptr || pool_split < 2) { pool_partials = nullptr; pool_split = 1; }
+                            const cwn_dropout* drop, int32_t drop_pos, float* pool_partials, int64_t pool_partials_floats,
+                            int32_t pool_split, cwn_stream_t stream_) {
+    if (pool_partials == nullptr || pool_split < 1) { pool_partials = nullptr; pool_split = 1; }
     if (pool_split > 64 || !al16(pool_partials)) return CWN_ERR_BAD_ARG;
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_HEAD_MAX_DIMS || C < 0 || O < 1) return CWN_ERR_BAD_ARG;
     // K / 4 lanes a row inside 512 threads; output j by thread j
@@ -726,6 +774,14 @@ extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int
     A.mean_final = mean_final ? 1 : 0;
     A.partials = pool_partials;
     A.pool_split = pool_split;
+    if (pool_partials != nullptr) {
+        int64_t slots = 0;
+        for (int d = 0; d < n_dims; ++d) {
+            A.slot_base[d] = slots;
+            slots += dims[d].n_cells / kHeadChunk + C + 1;
+        }
+        if (pool_partials_floats < slots * K) return CWN_ERR_WORKSPACE;
+    }
     const size_t lds = head_lds_floats(K, H2) * sizeof(float);
     if (lds > 64 * 1024) return CWN_ERR_BAD_ARG;
     if (pool_partials != nullptr)

@@ -828,11 +828,12 @@ def head(xs: Sequence, cell_ptrs: Sequence[Tensor], n_complexes: int, lin1_weigh
     out = torch.empty(n_complexes, O, dtype=torch.float32, device=dev)
     s_out = torch.empty(n_complexes, H2, dtype=torch.float32, device=dev) if want_hidden else None
     P = head_split(rows_total, n_complexes)
-    partials = torch.empty(n_complexes * P * 3 * K, dtype=torch.float32, device=dev) if P > 1 else None
     arr = (_ffi.HeadDim * len(dims))(*dims)
+    n_part = int(_ffi.lib().cwn_head_pool_floats(arr, len(dims), n_complexes, K)) if P > 1 else 0
+    partials = torch.empty(n_part, dtype=torch.float32, device=dev) if P > 1 else None
     _ffi.check(_ffi.lib().cwn_head_f32(arr, len(dims), n_complexes, K, H2, 1 if mean_readout else 0,
                                        1 if mean_final else 0, w2.data_ptr(), _ffi.ptr(b2), O, out.data_ptr(),
-                                       _ffi.ptr(s_out), drop, int(drop_pos) if drop is not None else 0, _ffi.ptr(partials), P,
+                                       _ffi.ptr(s_out), drop, int(drop_pos) if drop is not None else 0, _ffi.ptr(partials), n_part, P,
                                        _ffi.stream_ptr(dev)), 'cwn_head_f32')
     if want_hidden:
         return out, pooled, hidden, s_out

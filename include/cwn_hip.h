@@ -1122,14 +1122,19 @@ typedef struct cwn_head_dim {
  * relu(h_d) before the sum over the dimensions (element (d C + c) H2 + j), CWN_HEAD_DROP_LIN2 on the summed hidden vector
  * (element c H2 + j; s_out holds the dropped vector). */
 enum { CWN_HEAD_DROP_NONE = 0, CWN_HEAD_DROP_LIN1 = 1, CWN_HEAD_DROP_FINAL = 2, CWN_HEAD_DROP_LIN2 = 3 };
-/* pool_partials / pool_split (round 5): LARGE complexes (REDDIT-like: thousands of cells per complex, 32 complexes per batch --
- * one workgroup per complex pulled 4 MB through one CU).  pool_split = P > 1 and pool_partials = device fp32
- * [C][P][CWN_HEAD_MAX_DIMS][K]: a first launch of C x P workgroups sums P row chunks of every complex into the partials
- * (plain stores), the head launch adds them in chunk order (deterministic) instead of reading the rows.  P = 1 / NULL: one
- * launch as before. */
+/* THE ORDER of the row sums: chunks of CWN_HEAD_CHUNK consecutive rows of a complex; inside a chunk 512 / (K / 4) row groups add
+ * every (512 / (K / 4))-th row one after the other and are added in group order; chunk sums are added in chunk order -- the same
+ * bits whichever launch forms them.  pool_partials / pool_split (round 5): LARGE complexes (REDDIT-like: thousands of cells per
+ * complex, 32 complexes per batch -- one workgroup per complex pulled 4 MB through one CU): with pool_partials (device fp32,
+ * at least cwn_head_pool_floats(...) floats) a first launch of C x pool_split workgroups writes the chunk sums (workgroup (c, p):
+ * chunks p, p + P, ... of complex c; plain stores) and the head launch adds them in chunk order instead of reading the rows.
+ * NULL: one launch, which sums a large complex chunk by chunk itself (the same result). */
+#define CWN_HEAD_CHUNK 256
+int64_t cwn_head_pool_floats(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K);
 int cwn_head_f32(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
                  int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, float* s_out,
-                 const cwn_dropout* drop, int32_t drop_pos, float* pool_partials, int32_t pool_split, cwn_stream_t stream);
+                 const cwn_dropout* drop, int32_t drop_pos, float* pool_partials, int64_t pool_partials_floats, int32_t pool_split,
+                 cwn_stream_t stream);
 
 /* Backward of the same head for the training step (exp/train_utils.py:62-73), one workgroup per complex, given
  * g_out = dL/dout [C, O] and what the forward left (h_out per dimension):

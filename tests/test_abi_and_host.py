@@ -127,11 +127,11 @@ def test_argument_errors_without_gpu():
     assert lib.cwn_embed_front_f32(tv, 4, None, None, 0, None, None, None, 0, 0, None, None, None, 0, 64, 1, ctypes.byref(err), None, None) == 1  # rows, no table
     assert lib.cwn_loss_f32(0, None, None, 4, None, None, None, None) == 1 and lib.cwn_loss_f32(7, None, None, 4, None, None, None, None) == 1
     hd = (_ffi.HeadDim * 1)(_ffi.HeadDim())
-    assert lib.cwn_head_f32(None, 1, 4, 128, 256, 0, 0, None, None, 1, None, None, None, 0, None, 1, None) == 1
-    assert lib.cwn_head_f32(hd, 1, 0, 128, 256, 0, 0, None, None, 1, None, None, None, 0, None, 1, None) == 0          # no complexes
-    assert lib.cwn_head_f32(hd, 1, 4, 130, 256, 0, 0, None, None, 1, None, None, None, 0, None, 1, None) == 1          # K % 4
-    assert lib.cwn_head_f32(hd, 1, 4, 128, 1024, 0, 0, None, None, 1, None, None, None, 0, None, 1, None) == 1         # H2 beyond a workgroup
-    assert lib.cwn_head_f32(hd, 4, 4, 128, 256, 0, 0, None, None, 1, None, None, None, 0, None, 1, None) == 1    # more than 3 dimensions
+    assert lib.cwn_head_f32(None, 1, 4, 128, 256, 0, 0, None, None, 1, None, None, None, 0, None, 0, 1, None) == 1
+    assert lib.cwn_head_f32(hd, 1, 0, 128, 256, 0, 0, None, None, 1, None, None, None, 0, None, 0, 1, None) == 0          # no complexes
+    assert lib.cwn_head_f32(hd, 1, 4, 130, 256, 0, 0, None, None, 1, None, None, None, 0, None, 0, 1, None) == 1          # K % 4
+    assert lib.cwn_head_f32(hd, 1, 4, 128, 1024, 0, 0, None, None, 1, None, None, None, 0, None, 0, 1, None) == 1         # H2 beyond a workgroup
+    assert lib.cwn_head_f32(hd, 4, 4, 128, 256, 0, 0, None, None, 1, None, None, None, 0, None, 0, 1, None) == 1    # more than 3 dimensions
     hb = (_ffi.HeadBwdDim * 1)(_ffi.HeadBwdDim())
     assert lib.cwn_head_bwd_f32(None, 1, 4, 128, 256, 0, 0, None, 1, None, None, 0, 1, None) == 1
     assert lib.cwn_head_bwd_f32(hb, 1, 0, 128, 256, 0, 0, None, 1, None, None, 0, 1, None) == 0             # no complexes

@@ -350,8 +350,7 @@ def test_head_over_the_blocks_of_a_jumping_knowledge_concatenation(split):
         out_c, gx_c, gp_c = run(cats)
     finally:
         ops.HEAD_POOL_SPLIT = prev
-    if split == '1':
-        assert torch.equal(out_p, out_c)
+    assert torch.equal(out_p, out_c)           # (the same bits however many workgroups sum a complex's rows: one order, cwn_hip.h)
     # float64 reference of the concatenated form
     cd = [c.detach().double() for c in cats]
     pooled = [torch.stack([cd[d][int(ptrs[d][c]):int(ptrs[d][c + 1])].sum(0) for c in range(C)]) for d in range(3)]
@@ -363,3 +362,46 @@ def test_head_over_the_blocks_of_a_jumping_knowledge_concatenation(split):
             gate(gx_p[d][q], gx_c[d][q].double(), f'JK head, pool split {split}: dL/d(block {q} of dim {d}) vs the concatenated form')
     for a, c in zip(gp_p, gp_c):
         gate(a, c.double(), f'JK head, pool split {split}: a weight gradient vs the concatenated form')
+
+
+def test_large_complexes_pool_to_the_same_bits_by_one_workgroup_or_by_many():
+    """REDDIT-like complexes (hundreds to thousands of cells: several chunks of CWN_HEAD_CHUNK rows): the head's prediction and
+    the pooled vectors are bit-identical whether one workgroup sums a complex chunk by chunk inside the head launch or
+    head_pool_kernel's C x P workgroups do (P = 2, 8, 32), and a complex's rows give the same bits alone and inside a batch."""
+    from cwn_amd import ops
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import reddit_like_complexes
+    pool = reddit_like_complexes(6, seed=4, n_lo=150, n_hi=700)
+    b = ComplexBatch.from_complex_list(pool, max_dim=2).to(DEV)
+    plan, C = b.block_plan(), b.num_complexes
+    K, H2 = 128, 64
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(b.cochains[d].num_cells, K, generator=g).to(DEV) for d in range(3)]
+    assert max(int(plan.cell_ptr[d][c + 1] - plan.cell_ptr[d][c]) for d in range(3) for c in range(C)) > 600
+    lin1 = [torch.nn.Linear(K, H2).to(DEV) for _ in range(3)]
+    lin2 = torch.nn.Linear(H2, 2).to(DEV)
+    ptrs = [plan.cell_ptr_device(d, torch.device(DEV)) for d in range(3)]
+    prev, outs = ops.HEAD_POOL_SPLIT, {}
+    try:
+        for split in ('1', '2', '8', '32'):
+            ops.HEAD_POOL_SPLIT = split
+            with torch.no_grad():
+                outs[split] = ops.head(xs, ptrs, C, [l.weight for l in lin1], [l.bias for l in lin1], lin2.weight, lin2.bias,
+                                       mean_readout=True, want_pooled=True)
+        ops.HEAD_POOL_SPLIT = '8'
+        b1 = ComplexBatch.from_complex_list(pool[3:4], max_dim=2).to(DEV)        # one complex alone
+        p1 = b1.block_plan()
+        lo = [int(plan.cell_ptr[d][3]) for d in range(3)]
+        hi = [int(plan.cell_ptr[d][4]) for d in range(3)]
+        with torch.no_grad():
+            alone = ops.head([xs[d][lo[d]:hi[d]].contiguous() for d in range(3)], [p1.cell_ptr_device(d, torch.device(DEV)) for d in range(3)], 1,
+                             [l.weight for l in lin1], [l.bias for l in lin1], lin2.weight, lin2.bias, mean_readout=True)
+    finally:
+        ops.HEAD_POOL_SPLIT = prev
+    for split in ('2', '8', '32'):
+        assert torch.equal(outs[split][0], outs['1'][0]), split
+        for d in range(3):
+            assert torch.equal(outs[split][1][d], outs['1'][1][d]), (split, d)
+    assert torch.equal(alone[0], outs['1'][0][3])
+    ref = torch.stack([xs[0].double()[int(ptrs[0][c]):int(ptrs[0][c + 1])].mean(0) for c in range(C)])
+    gate(outs['8'][1][0], ref, 'pooled vertices of REDDIT-like complexes (8 workgroups per complex) vs float64')
