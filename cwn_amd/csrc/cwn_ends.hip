@@ -308,23 +308,23 @@ __device__ __forceinline__ const float* head_row(const cwn_head_dim& D, int64_t 
 
 // THE ORDER in which the rows of a complex are summed, whichever launch does it (so that a complex's pooled vector is the same
 // bits in a batch of molecules, in a static batch of another capacity, with its rows summed by one workgroup or by many):
-// chunks of kHeadChunk consecutive rows; inside a chunk row group g adds rows a + g, a + g + NG, ... one after the other, the
+// chunks of kHeadChunk (= CWN_HEAD_CHUNK) consecutive rows; inside a chunk row group g adds rows a + g, a + g + NG, ... one after the other, the
 // NG group partials are added in group order; the chunk sums are added in chunk order.  (A complex of at most kHeadChunk
 // cells per dimension -- every molecule -- is one chunk: the order this kernel has always had.)
 constexpr int kHeadChunk = CWN_HEAD_CHUNK;
 
 __device__ __forceinline__ float4 head_group_sum(const cwn_head_dim& D, int64_t a, int64_t b, int g, int NG, int l, int Kp) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t r = a + g; r < b; r += 4 * (int64_t)NG) {
-        float4 w[4];
+    for (int64_t r = a + g; r < b; r += 8 * (int64_t)NG) {          // eight rows in flight, added one after the other
+        float4 w[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int64_t ru = r + (int64_t)u * NG;
             w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ru < b) w[u] = *reinterpret_cast<const float4*>(head_row(D, ru, 4 * l, Kp));
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { acc.x += w[u].x; acc.y += w[u].y; acc.z += w[u].z; acc.w += w[u].w; }
+        for (int u = 0; u < 8; ++u) { acc.x += w[u].x; acc.y += w[u].y; acc.z += w[u].z; acc.w += w[u].w; }
     }
     return acc;
 }

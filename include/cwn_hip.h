@@ -1129,7 +1129,7 @@ enum { CWN_HEAD_DROP_NONE = 0, CWN_HEAD_DROP_LIN1 = 1, CWN_HEAD_DROP_FINAL = 2, 
  * at least cwn_head_pool_floats(...) floats) a first launch of C x pool_split workgroups writes the chunk sums (workgroup (c, p):
  * chunks p, p + P, ... of complex c; plain stores) and the head launch adds them in chunk order instead of reading the rows.
  * NULL: one launch, which sums a large complex chunk by chunk itself (the same result). */
-#define CWN_HEAD_CHUNK 256
+#define CWN_HEAD_CHUNK 128
 int64_t cwn_head_pool_floats(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K);
 int cwn_head_f32(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K, int32_t H2, int32_t mean_readout,
                  int32_t mean_final, const float* w2, const float* b2, int32_t O, float* out, float* s_out,
