@@ -470,6 +470,34 @@ class _EmbeddingSum(torch.autograd.Function):
         return (None,) + tuple(_embedding_table_grads(ctx.tables, idx, g))
 
 
+DETERMINISTIC = False
+
+
+def deterministic(on: bool = True) -> None:
+    """Bit-reproducible TRAINING arithmetic (DDP debugging: two runs, graph vs eager, rank vs rank give torch.equal gradients):
+    every sum whose order the fast path leaves to the arrival order of atomics takes its ordered form --
+      weight gradients: per-band partial tiles + a reduce in band order (cwn_gemm_tn_f32 with a workspace: _ffi.DETERMINISTIC_TN);
+      BatchNorm(train) statistics: per-band partials summed in band order by cwn_bn_finalize_f32 (dense_train.LIVE_BN = False);
+      BatchNorm backward sums: the one-launch column-owning form cwn_norm_bwd_f32 (dense_train.FUSED_NORM_BACKWARD; matrices
+        of at most 4096 rows -- larger ones keep the atomic reduce) and no slot sums (LIVE_BN_BWD = False);
+      embedding-table gradients: a destination-sorted plan keyed on the table row + one segmented reduce in cell order (the
+        fused front backward and the band kernels add with atomics).
+    Costs ~10 % of a ZINC-128 step.  Everything else on the path is ordered by construction (stable CSR order, owner-form
+    backward, fixed trees).  Also settable with CWN_DETERMINISTIC=1."""
+    global DETERMINISTIC, FUSED_FRONT_BACKWARD
+    from . import dense_train
+    if on:
+        deterministic._saved = (_ffi.DETERMINISTIC_TN, dense_train.LIVE_BN, dense_train.LIVE_BN_BWD, dense_train.FUSED_NORM_BACKWARD,
+                                FUSED_FRONT_BACKWARD)
+        _ffi.DETERMINISTIC_TN, dense_train.LIVE_BN, dense_train.LIVE_BN_BWD, dense_train.FUSED_NORM_BACKWARD = True, False, False, True
+        FUSED_FRONT_BACKWARD = False
+    elif getattr(deterministic, '_saved', None) is not None:
+        (_ffi.DETERMINISTIC_TN, dense_train.LIVE_BN, dense_train.LIVE_BN_BWD, dense_train.FUSED_NORM_BACKWARD,
+         FUSED_FRONT_BACKWARD) = deterministic._saved
+        deterministic._saved = None
+    DETERMINISTIC = bool(on)
+
+
 def _embedding_table_grads(tables, idx: Tensor, g: Tensor) -> List[Optional[Tensor]]:
     """d(table) of out[i] = sum_c table_c[idx[i, c]] given g = d out: cwn_embedding_bwd_f32 into one zeroed buffer, handed
     back as per-table views -- or added into the parameters' .grad directly where those are allocated (then None)."""
@@ -485,6 +513,28 @@ def _embedding_table_grads(tables, idx: Tensor, g: Tensor) -> List[Optional[Tens
         idx = idx.to(torch.long)
     idx = idx.contiguous()
     f32, n_dev = (1 if idx.dtype == torch.float32 else 0), _ffi.dyn(idx.size(0))
+    if DETERMINISTIC and n_dev is None:
+        # ordered form (ops.deterministic): dW[v] = the sum of g over the cells that looked row v up IN CELL ORDER -- a
+        # destination-sorted plan keyed on the table row (stable: entry order = cell order) and one segmented reduce; no atomics
+        li = idx.to(torch.long)
+        Cn = int(li.size(1))
+        offs = _EmbeddingSum._columns(tables, g.device)[0]          # (cached device array: nothing is uploaded inside a capture)
+        rows = (li + offs if offs is not None else li).reshape(-1).contiguous()
+        cells = torch.arange(li.size(0), device=g.device).repeat_interleave(Cn) if Cn > 1 else torch.arange(li.size(0), device=g.device)
+        from .csr import build_many
+        adj = Adjacency(rows, cells, V, int(li.size(0)))
+        build_many([adj], validate=False)
+        dW = run_aggregate([AggSpec(adj=adj, n_dst=V, F=H, A=g, ia=adj.col)], g.device)[0]
+        if len(tables) == 1:
+            t = _grad_target(tables[0])
+            if t is not None and t.dtype == torch.float32 and tuple(t.shape) == (V, H):
+                t.add_(dW)
+                return [None]
+        views, o = [], 0
+        for n in sizes:
+            views.append(dW[o:o + n])
+            o += n
+        return views
     off, size = _EmbeddingSum._columns(tables, g.device)
     if len(tables) == 1:
         # one table whose .grad is allocated: the kernel ADDS its band partials (fp32 atomics) -- straight into the gradient
@@ -2329,3 +2379,7 @@ class LayerLaunch:
             if rc != 0:
                 _ffi.check(rc, 'cwn_layer_fused_f32')
         return list(outs)
+
+
+if os.environ.get('CWN_DETERMINISTIC') == '1':
+    deterministic(True)

@@ -43,4 +43,4 @@ bash tools/prof_train.sh 128 200 > /dev/null 2>&1; cp gpurun_out/prof_train_128.
 head -8 "$OUT/r5_${TAG}_train_step.md" | cut -c1-140
 bash tools/prof_train_wl.sh 512 molhiv 0.5 molhiv_drop 160 > /dev/null 2>&1; cp gpurun_out/prof_train_molhiv_drop.md "$OUT/r5_${TAG}_train_step_molhiv_dropout.md"
 grep -c "dropout\|Dropout" "$OUT/r5_${TAG}_train_step_molhiv_dropout.md" | sed 's/^/at::native dropout kernels in the molhiv step: /'
-python tools/collect_traffic.py 128 2048 > /dev/null 2>&1 && cp profiles/r5_traffic.json profiles/r5_pmc_fetch_write_raw.json "$OUT/" && cat profiles/r5_traffic.json | head -30
+python tools/collect_traffic.py 128 2048 molhiv:512 reddit:32 > /dev/null 2>&1 && cp profiles/r5_traffic.json profiles/r5_pmc_fetch_write_raw.json "$OUT/" && cat profiles/r5_traffic.json | head -30
