@@ -1021,7 +1021,8 @@ def head_train(xs, cell_ptrs, n_complexes, lin1_weights, lin1_biases, lin2_weigh
 # gradient re-derives it -- cwn_norm_act_f32 / cwn_norm_bwd_reduce_f32 for a conv layer's output, cwn_head_f32 / _bwd for the
 # head's positions, cwn_dropout_f32 (a launch of its own, the same multipliers) everywhere else.  {seed, step} live in device
 # memory: a TrainStep's opening launch (cwn_step_begin) advances `step`, so a replayed graph never repeats a mask; `site` is a
-# host counter, new for every application (baked into a captured launch).
+# host counter, new for every application (baked into a captured launch) and restarted by every step bracket (ops.step_arena):
+# an eager step and the replay of its capture draw the same masks.
 _drop_states: Dict[torch.device, Tensor] = {}
 _drop_site = 0
 DROPOUT_TRACE: Optional[list] = None          # tests: a list that receives (site, p, tag) of every application
@@ -1041,6 +1042,8 @@ def dropout_state(device) -> Tensor:
 
 def dropout_seed(seed: int, device=None) -> None:
     """Re-seed (and rewind) the dropout stream of `device` (default: every device that has one, and the current one)."""
+    global _drop_site
+    _drop_site = 0
     devs = [torch.device(device)] if device is not None else (list(_drop_states) or [torch.device('cuda', torch.cuda.current_device())])
     for d in devs:
         dropout_state(d).copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
@@ -1954,6 +1957,9 @@ class step_arena:
         if flat is not None and (flat.dtype != torch.float32 or not flat.is_contiguous() or flat.data_ptr() % 16 or (4 * flat.numel()) % 16):
             flat.zero_()
             flat = None
+        global _drop_site
+        _drop_site = 0                           # (sites number the applications of ONE step: the step counter tells steps apart --
+                                                 #  an eager step and its captured replay then draw the same masks)
         ds = _drop_states.get(self.device)       # (exists once a dropout has been applied on this device: fresh masks per step)
         if a.high or flat is not None or self.counter is not None or ds is not None:
             _ffi.check(_ffi.lib().cwn_step_begin(_ffi.ptr(flat), 0 if flat is None else 4 * flat.numel(), a.buf.data_ptr(),
