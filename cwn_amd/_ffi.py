@@ -655,6 +655,8 @@ def _flush_descs(descs, device) -> None:
         return (ok(d.dZ) and ok(d.X) and ok(d.X2) and d.lddz % 4 == 0 and d.ldx % 4 == 0 and (d.K2 == 0 or d.ldx2 % 4 == 0)
                 and d.N % 4 == 0 and d.K % 4 == 0 and d.K2 % 4 == 0)
     fast, slow = [d for d in descs if vec(d)], [d for d in descs if not vec(d)]
+    # (which TILE a launch runs on -- 64 x 64 fp32 MFMA at hidden 64, 128 x 128 bf16-split above -- cwn_gemm_tn_f32 decides by
+    #  the majority of its descriptors)
     for part in (fast, slow):
         if part:
             gemm_tn(part, device)               # (the operands stay referenced by `q` until here)

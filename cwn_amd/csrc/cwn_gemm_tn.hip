@@ -570,7 +570,15 @@ extern "C" int cwn_gemm_tn_f32(const cwn_gemm_tn_desc* descs, int n, void* works
         B.d[i] = D;
     }
     static const bool split_off = getenv("CWN_TN_SPLIT") != nullptr && atoi(getenv("CWN_TN_SPLIT")) == 0;
-    const bool split = fast && !split_off;           // the bf16-split kernel: 128 x 128 tiles, 32-row chunks, two per CU
+    // the bf16-split kernel (128 x 128 tiles, 32-row chunks) when most descriptors fill its tile: at hidden 64 -- every dW at most
+    // 64 rows -- a 128 x 128 tile is a quarter full and the launch is the same memory pipeline for half the useful bytes; the
+    // fp32-MFMA kernel's 64 x 64 tiles, four workgroups deep per CU, are faster there (round 5, graph-replayed training steps:
+    // molhiv-512 0.802 -> 0.756 ms, reddit-32 1.597 -> 1.449 ms with CWN_TN_SPLIT=0; ZINC-128 at hidden 128 keeps the split form)
+    // (by majority: a hidden-64 model's launch holds forty gradients of 64 rows and the head's three of 128)
+    int n_wide = 0;
+    for (int i = 0; i < n; ++i) n_wide += descs[i].N > 64 ? 1 : 0;
+    static const bool split_force = getenv("CWN_TN_SPLIT") != nullptr && atoi(getenv("CWN_TN_SPLIT")) == 2;
+    const bool split = fast && !split_off && (2 * n_wide >= n || split_force);
     const int tile = split ? kTile2 : kTile;
     for (int i = 0; i < n; ++i) {
         if ((descs[i].N + tile - 1) / tile > INT16_MAX || (descs[i].K + descs[i].K2 + tile - 1) / tile > INT16_MAX) return CWN_ERR_TOO_LARGE;
