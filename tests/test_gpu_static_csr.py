@@ -278,3 +278,19 @@ def test_routed_epoch_over_a_dataset_with_a_heavy_tail():
     ref = TrainStep(m2, [p.collate(epoch[a2[0]])], task_type='bin_classification', lr=1e-3, use_graph=False)
     want = float(ref.step(0))
     assert abs(float(losses[a2[0]]) - want) <= 1e-5 * max(1.0, abs(want)), (float(losses[a2[0]]), want)
+
+
+@pytest.mark.parametrize('script,args,must', [('train_molhiv_like.py', ['768', '2'], ['held-out accuracy', 'epoch 1:', 'streaming path']),
+                                               ('train_reddit_like.py', ['96', '2'], ['held-out accuracy', 'epoch 1:'])])
+def test_the_config_3_and_config_5_example_scripts_run(script, args, must):
+    """examples/train_molhiv_like.py (config 3 as cwn-molhiv.sh trains it: dropout 0.5, BCE, routed over the heavy tail) and
+    examples/train_reddit_like.py (config 5: csr-mode static batches, cross-entropy) end to end at a small size."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pr = subprocess.run([sys.executable, os.path.join(root, 'examples', script)] + args, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2500:]
+    for m in must:
+        assert m in pr.stdout, pr.stdout[-2000:]
+    print(pr.stdout[-800:])
