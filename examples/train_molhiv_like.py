@@ -9,7 +9,8 @@ the blocked layer kernel holds):
                   derived inside the kernels (no mask tensors), fresh per replayed step
               --> RoutedForward: the evaluation pass (eval mode: dropout off)
 
-    python examples/train_molhiv_like.py [n_molecules] [epochs]        (needs an MI355X; synthetic molecules, a learnable toy label)
+    python examples/train_molhiv_like.py [n_molecules] [epochs] [tail]     (needs an MI355X; synthetic molecules, a toy label;
+    tail = the share of 120 - 220-atom molecules, default 2e-3)
 """
 import os
 import sys
@@ -29,9 +30,10 @@ from cwn_amd.synthetic import molhiv_like_complexes                       # noqa
 def main():
     n_mol = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    tail = float(sys.argv[3]) if len(sys.argv) > 3 else 2e-3
     dev = torch.device('cuda', 0)
     t0 = time.perf_counter()
-    pool = molhiv_like_complexes(n_mol, seed=0, max_ring=6, tail=2e-3)
+    pool = molhiv_like_complexes(n_mol, seed=0, max_ring=6, tail=tail)
     for c in pool:          # a toy label a model can learn: does the molecule have more than two rings?
         c.y = torch.tensor([[float(c.cochains[2].num_cells > 2 if c.dimension >= 2 else 0.0)]])
     packed = PackedComplexes(pool, dev, max_dim=2, with_csr=True)

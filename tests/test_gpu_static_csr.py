@@ -280,7 +280,7 @@ def test_routed_epoch_over_a_dataset_with_a_heavy_tail():
     assert abs(float(losses[a2[0]]) - want) <= 1e-5 * max(1.0, abs(want)), (float(losses[a2[0]]), want)
 
 
-@pytest.mark.parametrize('script,args,must', [('train_molhiv_like.py', ['768', '2'], ['held-out accuracy', 'epoch 1:', 'streaming path']),
+@pytest.mark.parametrize('script,args,must', [('train_molhiv_like.py', ['768', '2', '0.01'], ['held-out accuracy', 'epoch 1:', 'streaming path']),
                                                ('train_reddit_like.py', ['96', '2'], ['held-out accuracy', 'epoch 1:'])])
 def test_the_config_3_and_config_5_example_scripts_run(script, args, must):
     """examples/train_molhiv_like.py (config 3 as cwn-molhiv.sh trains it: dropout 0.5, BCE, routed over the heavy tail) and
