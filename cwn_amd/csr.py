@@ -81,7 +81,7 @@ class Adjacency:
             n_long=_ffi.ptr(self.n_long),
             # a static buffer (cwn_amd/static_batch.py, mode 'csr'): n_entries is its capacity, the batch's own count is in
             # device memory -- looked up like every other dynamic row count (_ffi.dynamic_rows)
-            e_dev=_ffi.dyn(self.n_entries))
+            e_dev=getattr(self, 'e_dev_ptr', None) or _ffi.dyn(self.n_entries))
 
     # ---- transposes for the backward pass ----------------------------------------------
     def transposes(self) -> List['Adjacency']:

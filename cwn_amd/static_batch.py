@@ -377,6 +377,7 @@ class StaticBatch:
                 ui = cb.upper_index
                 if self.mode == 'csr':
                     adj = csr.Adjacency(ui[1], ui[0], self.cap_cells[d], self.cap_cells[d], cb.shared_coboundaries, self.cap_cells[d + 1])
+                    adj.e_dev_ptr = self.size_ptr(8 + self.k_of(d, 'upper_index'), j)       # the slot's live entry count
                     self._slot_adjs.setdefault(j, []).append(adj)
                     self._register(ui, adj)
                 else:
@@ -385,6 +386,7 @@ class StaticBatch:
             if self.mode == 'csr' and d > 0 and getattr(cb, 'lower_index', None) is not None:
                 li = cb.lower_index
                 adj = csr.Adjacency(li[1], li[0], self.cap_cells[d], self.cap_cells[d], cb.shared_boundaries, self.cap_cells[d - 1])
+                adj.e_dev_ptr = self.size_ptr(8 + self.k_of(d, 'lower_index'), j)
                 self._slot_adjs.setdefault(j, []).append(adj)
                 self._register(li, adj)
         plan = StaticBlockPlan(self, j)
@@ -662,18 +664,21 @@ class StaticBatch:
         for key in self._families:
             self._launch_family(key, n)
         if self.mode == 'csr':
-            # the CSR plans of the upper / lower adjacencies (and, for a training step, their transposes) of every slot:
-            # cwn_csr_build over the capacity-sized entries with the count in device memory -- one batched call per slot
+            # the CSR plans of the upper / lower adjacencies (and, for a training step, their transposes) of ALL slots in
+            # batched cwn_csr_build calls (<= 8 plans each: one launch sequence per eight plans, not per slot) over the
+            # capacity-sized entries, every plan with the address of ITS slot's live entry count (cwn_csr_desc.e_dev)
+            todo = []
             for j in range(n):
-                todo = []
                 for adj in self._slot_adjs.get(j, []):
                     todo.append(adj)
                     if self.build_backward:
                         adj.transposes()
-                        todo += [t for t in (adj._t_src, adj._t_aux) if t is not None]
-                if todo:
-                    with self.slots[j].dynamic():
-                        csr.build_many(todo, validate=False, force=True)
+                        for t in (adj._t_src, adj._t_aux):
+                            if t is not None:
+                                t.e_dev_ptr = adj.e_dev_ptr
+                                todo.append(t)
+            if todo:
+                csr.build_many(todo, validate=False, force=True)
 
     # ---- the reference tables (tests) -----------------------------------------------------------------------------------
     def host_tables(self, idx: Sequence[int]) -> np.ndarray:
