@@ -257,7 +257,7 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
         torch.cuda.synchronize()
         return {'ms_per_step': round((time.perf_counter() - t0) / (n * S) * 1e3, 5),
                 'launches': 'cwn_collate_tables + cwn_collate_guard + cwn_collate_slots + ' +
-                            ('cwn_csr_build per slot' if mode == 'csr' else 'cwn_layer_items_build_dev (forward [+ backward] tables)')}
+                            ('batched cwn_csr_build calls over all slots' if mode == 'csr' else 'cwn_layer_items_build_dev (forward [+ backward] tables)')}
 
     ROUTED = os.environ.get('CWN_BENCH_ROUTED') == '1' and mode == 'blocked'
     if ROUTED:

@@ -1035,8 +1035,14 @@ def dropout_state(device) -> Tensor:
         device = torch.device('cuda', torch.cuda.current_device())
     t = _drop_states.get(device)
     if t is None:
-        seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
-        t = _drop_states[device] = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        seed = int(torch.initial_seed())
+        try:                                   # data parallel: every rank its own stream (ranks usually share torch's seed)
+            import torch.distributed as _dist
+            if _dist.is_available() and _dist.is_initialized():
+                seed += 0x9E3779B97F4A7C15 * int(_dist.get_rank())
+        except Exception:
+            pass
+        t = _drop_states[device] = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
     return t
 
 

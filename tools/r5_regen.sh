@@ -39,6 +39,15 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_scope -- python "$ROOT/bench.py" -
 cd "$ROOT"
 python profiles/summarize_rocprof.py "$(ls /tmp/prof_scope/*/*results.db | head -1)" 30 > "$OUT/r5_${TAG}_propagate_scope.md"
 head -6 "$OUT/r5_${TAG}_propagate_scope.md" | cut -c1-140
+for WL in molhiv reddit; do
+  cd /tmp; rm -rf /tmp/prof_scope_$WL
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_scope_$WL -- python "$ROOT/bench.py" --workload $WL --only-primary --no-cpu > /dev/null 2>&1
+  cd "$ROOT"
+  python profiles/summarize_rocprof.py "$(ls /tmp/prof_scope_$WL/*/*results.db | head -1)" 12 > "$OUT/r5_${TAG}_propagate_scope_$WL.md"
+  head -4 "$OUT/r5_${TAG}_propagate_scope_$WL.md" | cut -c1-140
+done
+bash tools/prof_forward_wl.sh reddit 50 > /dev/null 2>&1; cp gpurun_out/prof_fwd_reddit.md "$OUT/r5_${TAG}_forward_reddit.md"
+bash tools/prof_train_wl.sh 32 reddit 0.0 reddit 120 > /dev/null 2>&1; cp gpurun_out/prof_train_reddit.md "$OUT/r5_${TAG}_train_step_reddit.md"
 bash tools/prof_train.sh 128 200 > /dev/null 2>&1; cp gpurun_out/prof_train_128.md "$OUT/r5_${TAG}_train_step.md"
 head -8 "$OUT/r5_${TAG}_train_step.md" | cut -c1-140
 bash tools/prof_train_wl.sh 512 molhiv 0.5 molhiv_drop 160 > /dev/null 2>&1; cp gpurun_out/prof_train_molhiv_drop.md "$OUT/r5_${TAG}_train_step_molhiv_dropout.md"
