@@ -23,6 +23,14 @@ The JSON line also carries `roofline` (dominant kernel: layer_kernel<F, load>, c
 complex-blocked launch serves; aggregate_kernel on the CSR path), `cpu_baseline` (oracle timed on the host cores, rank 0,
 N=1 only) and `secondary` (full model forward, training step, the same three scopes on batches never seen before, other
 workloads).
+
+Environment (exploration and the sub-runs of `secondary.workloads`; the driver sets none of them): CWN_BENCH_SKIP=leg,leg,...
+(eager, concurrent, collate, train, fresh, workloads, roofline, full); CWN_BENCH_ATOMS=lo,hi | zinc (molecule sizes);
+CWN_BENCH_MODEL=cinpp (EmbedCINpp on the ZINC workload); CWN_BENCH_MOLHIV_TAIL=p (share of 120 - 220-atom molecules) with
+CWN_BENCH_ROUTED=1 (the never-seen-batch legs through StaticRouter); CWN_BENCH_DROPOUT=p (molhiv model; default 0.5 = the
+reference's script); CWN_BENCH_FRESH_BATCHES / _SLOTS / _EPOCHS; CWN_BENCH_FORCE_DP=1 (world-1 RCCL group, the data-parallel
+form of the training step forced) with CWN_BENCH_TRAIN_GRAPH=1; CWN_BENCH_SHARE_GPU=1 (N ranks over gloo on one GPU: control
+flow only); CWN_BENCH_TRACE, CWN_BENCH_OVERLAP, CWN_BENCH_MIN_REGION_S, CWN_BENCH_DP_DEADLINE_S.
 """
 import argparse
 import json
