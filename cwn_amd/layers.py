@@ -147,6 +147,7 @@ def _two_per_cu_wins(n0: int, n1: int) -> bool:
 
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
 _BLOCKED_CACHE = weakref.WeakKeyDictionary()
+_MLP_CACHE = weakref.WeakKeyDictionary()          # layer module -> (ops.MlpLaunch, (start, dims, outputs), BatchNorm modules)
 
 
 def _fold_norm(norm, width: int):
@@ -810,7 +811,7 @@ class SparseCINConv(torch.nn.Module):
             if len(cache) > 64:
                 cache.clear()
             cache[ckey] = ent
-        self.blocked_reason = None
+        self.__dict__['blocked_reason'] = None        # (plain attributes: Module.__setattr__ costs ~1 us each, per layer per call)
         table, key = ent['table'], ent['key']
         # the layers of one forward share their index tensors (mp/molec_models.py:110-116): the first
         # launch on them stores every item's sorted adjacency, the following ones load it back
@@ -1005,6 +1006,17 @@ class SparseCINConv(torch.nn.Module):
         the caller runs the torch modules instead."""
         if torch.is_grad_enabled():
             return None
+        ent = _MLP_CACHE.get(self)
+        if ent is not None:
+            # the prepared launch of this layer's networks (ops.MlpLaunch): per call only the rows are looked at
+            launch, shape, norms = ent
+            if (shape == (start, len(plans), len(outs)) and FUSED_UPDATE_MLP and not ops.GEMM_EXACT
+                    and not any(m.training for m in norms) and None not in plans[start:] and launch.current()):
+                res = launch.run(outs[0::2], outs[1::2])
+                if res is not None:
+                    return res
+            else:
+                del _MLP_CACHE[self]
         active = list(range(start, len(plans)))
         if not active or any(plans[d] is None for d in active) or len(outs) != 2 * len(active):
             return None
@@ -1038,6 +1050,18 @@ class SparseCINConv(torch.nn.Module):
                                 folds=[folds[0][0], folds[0][1], folds[1][0], folds[1][1], folds[2][0]])
                      for i, (up, bd, cb, folds) in enumerate(chains)]
             if ops.update_mlp_applies(mdims):
+                sources, norms = [], []
+                for up, bd, cb, _ in chains:
+                    for lin, norm in up + bd + cb:
+                        sources += [lin.weight, lin.bias]
+                        if isinstance(norm, BN):
+                            norms.append(norm)
+                            sources += [norm.weight, norm.bias, norm.running_mean, norm.running_var]
+                launch = ops.MlpLaunch(mdims, sources)
+                _MLP_CACHE[self] = (launch, (start, len(plans), len(outs)), norms)
+                res = launch.run(hs_up, hs_bd)
+                if res is not None:
+                    return res
                 return ops.update_mlp(mdims)
         for st in range(depth):
             gemms = []
@@ -1098,7 +1122,7 @@ class SparseCINConv(torch.nn.Module):
 
     def _finish_dropout(self, out: List[Tensor], start: int) -> List[Tensor]:
         p, done = self._out_drop, self._out_dropped
-        self._out_drop, self._out_dropped = 0.0, False
+        self.__dict__['_out_drop'], self.__dict__['_out_dropped'] = 0.0, False
         if p <= 0.0 or done:
             return out
         return [x if dim < start or x is None else ops.dropout(x, p, True) for dim, x in enumerate(out)]
@@ -1106,7 +1130,7 @@ class SparseCINConv(torch.nn.Module):
     def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0, out_dropout: float = 0.0):
         assert len(cochain_params) <= self.max_dim + 1
         n = len(cochain_params)
-        self._out_drop, self._out_dropped = (float(out_dropout) if self.training else 0.0), False
+        self.__dict__['_out_drop'], self.__dict__['_out_dropped'] = (float(out_dropout) if self.training else 0.0), False
         plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
         dense = self._dense_eval(plans, outs, start_to_process)
         if dense is None:
@@ -1435,7 +1459,7 @@ class CINppConv(SparseCINConv):
     def forward(self, *cochain_params: CochainMessagePassingParams, start_to_process=0, out_dropout: float = 0.0):
         """mp/layers.py:418-427."""
         assert len(cochain_params) <= self.max_dim + 1
-        self._out_drop, self._out_dropped = (float(out_dropout) if self.training else 0.0), False
+        self.__dict__['_out_drop'], self.__dict__['_out_dropped'] = (float(out_dropout) if self.training else 0.0), False
         plans, outs = self.propagate_all(*cochain_params, start_to_process=start_to_process)
         dense = self._dense_eval(plans, outs, start_to_process)
         if dense is None:

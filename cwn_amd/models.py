@@ -16,8 +16,20 @@ from torch.nn import BatchNorm1d as BN, Embedding, Identity, LayerNorm as LN, Li
 from . import _ffi, layers, ops
 from .layers import reset as reset_net
 from .complex import ComplexBatch
-from .csr import cached_adjacency
+from .csr import cached_adjacency, deferred_checks
 from .layers import CINConv, EdgeCINConv, EmbedVEWithReduce, InitReduceConv, SparseCINConv
+
+
+def _one_check(forward):
+    """A model's forward reads the device's error word once, at its end (csr.deferred_checks), instead of once per validated
+    launch in the middle of its launches."""
+    import functools
+
+    @functools.wraps(forward)
+    def wrapped(self, data, *args, **kwargs):
+        with deferred_checks():
+            return forward(self, data, *args, **kwargs)
+    return wrapped
 
 
 def get_nonlinearity(nonlinearity, return_module=True):
@@ -341,6 +353,7 @@ class SparseCIN(_SparseCINStack):
                     jump_mode, nonlinearity, readout, train_eps, final_hidden_multiplier, readout_dims,
                     final_readout, apply_dropout_before, use_coboundaries, graph_norm)
 
+    @_one_check
     def forward(self, data: ComplexBatch, include_partial=False):
         return self._convs_and_head(data, include_partial, {})
 
@@ -366,6 +379,7 @@ class EmbedSparseCIN(_SparseCINStack):
                     nonlinearity, readout, train_eps, final_hidden_multiplier, readout_dims,
                     final_readout, apply_dropout_before, use_coboundaries, graph_norm)
 
+    @_one_check
     def forward(self, data: ComplexBatch, include_partial=False):
         assert data.cochains[0].x.size(-1) == 1
         if 1 in data.cochains and data.cochains[1].x is not None:
@@ -420,6 +434,7 @@ class OGBEmbedSparseCIN(_SparseCINStack):
                     nonlinearity, readout, train_eps, final_hidden_multiplier, readout_dims,
                     final_readout, apply_dropout_before, use_coboundaries, graph_norm)
 
+    @_one_check
     def forward(self, data: ComplexBatch, include_partial=False):
         params = data.get_all_cochain_params(max_dim=self.max_dim, include_down_features=False)
         xs = list(self.init_conv(*params))
@@ -489,6 +504,7 @@ class _CIN0Stack(torch.nn.Module):
     def _params(self, data: ComplexBatch):
         return data.get_all_cochain_params(max_dim=self.max_dim)
 
+    @_one_check
     def forward(self, data: ComplexBatch):
         act = get_nonlinearity(self.nonlinearity, return_module=False)
         xs, kept = None, None
@@ -582,6 +598,7 @@ class Dummy(torch.nn.Module):
     def reset_parameters(self):
         self.lin.reset_parameters()
 
+    @_one_check
     def forward(self, data: ComplexBatch):
         xs = None
         for conv in self.convs:
@@ -626,6 +643,7 @@ class EdgeOrient(torch.nn.Module):
         self.lin1.reset_parameters()
         self.lin2.reset_parameters()
 
+    @_one_check
     def forward(self, data, include_partial=False):
         if self.fully_invar:
             data.x = torch.abs(data.x)

@@ -1643,6 +1643,28 @@ def state_changed() -> None:
     STATE_EPOCH += 1
 
 
+# Prepared launches (LayerLaunch, MlpLaunch: records derived once from a layer's parameters) are checked per call against the
+# tensors they were derived from -- address and version counter, which every in-place write bumps -- and against this counter,
+# which moves whenever ANY module, parameter or buffer is (re)registered anywhere in the process (torch's global registration
+# hooks): a replaced submodule or parameter object is invisible to the version counters of the old ones.
+STRUCT_EPOCH = 0
+
+
+def _struct_changed(*_args) -> None:
+    global STRUCT_EPOCH
+    STRUCT_EPOCH += 1
+
+
+def _install_struct_hooks() -> None:
+    from torch.nn.modules import module as _m
+    for reg in (_m.register_module_module_registration_hook, _m.register_module_parameter_registration_hook,
+                _m.register_module_buffer_registration_hook):
+        reg(_struct_changed)
+
+
+_install_struct_hooks()
+
+
 def weights_changed() -> None:
     """A raw-pointer writer has changed parameters (FlatAdam.step, every replay of a captured training step)."""
     global WEIGHT_EPOCH
@@ -1815,6 +1837,86 @@ def update_mlp(dims: Sequence[MlpDim]) -> List[Tensor]:
         keep += packed + [xu, xb]
     _ffi.check(_ffi.lib().cwn_update_mlp_f32(arr, len(dims), F, _ffi.stream_ptr(dev)), 'cwn_update_mlp_f32')
     return outs
+
+
+class MlpLaunch:
+    """A prepared cwn_update_mlp_f32 call for one layer (round 5: the eager forward spent 3/4 of its host time re-deriving
+    this record on every call): packed weights, biases and folded norms of every dimension filled in once; `run` fills in
+    the rows of this call and launches.  `sources`: every tensor the record was derived from (Linear weights and biases, the
+    BatchNorm tensors behind the folds) -- `current()` is false as soon as one of them was written in place, moved, or the
+    module tree changed (STRUCT_EPOCH), or a raw-pointer writer ran (STATE_EPOCH)."""
+
+    def __init__(self, dims: Sequence[MlpDim], sources: Sequence[Tensor]):
+        self.n = len(dims)
+        self.F = F = int(dims[0].x_up.size(1))
+        self.dev = dims[0].x_up.device
+        self.arr = (_ffi.MlpDim * self.n)()
+        self.keep = []
+        for i, D in enumerate(dims):
+            a = self.arr[i]
+            packed = []
+            for l in D.linears[:4]:
+                packed += list(pack_mlp_weight(l.weight))
+            packed += list(pack_mlp_weight(D.linears[4].weight))
+            for k, pk in enumerate(packed):
+                a.w_packed[k] = pk.data_ptr()
+            for s_, (lin, (sc, sh)) in enumerate(zip(D.linears, D.folds)):
+                b = None if lin.bias is None else _f32c(lin.bias, 'bias')
+                a.bias[s_], a.scale[s_], a.shift[s_] = _ffi.ptr(b), _ffi.ptr(sc), _ffi.ptr(sh)
+                self.keep += [b, sc, sh]
+            a.ldy = F
+            self.keep += packed
+        self.sources = [t for t in sources if t is not None]
+        self.marks = [(t.data_ptr(), t._version) for t in self.sources]
+        self.epochs = (STATE_EPOCH, STRUCT_EPOCH)
+        self.cap = int(_ffi.lib().cwn_update_mlp_max_rows())
+        self.fn = _ffi.lib().cwn_update_mlp_f32
+        from . import _cext
+        X = _cext.ext()
+        self._c = None if X is None else X.MlpCall(C.addressof(self.arr), C.sizeof(self.arr), self.n, F, self.cap,
+                                                   _cext.fn_address(self.fn), self.dev.index, self.sources, *self.epochs)
+
+    def current(self) -> bool:
+        if self._c is not None:
+            return self._c.current(STATE_EPOCH, STRUCT_EPOCH)
+        if self.epochs != (STATE_EPOCH, STRUCT_EPOCH):
+            return False
+        for t, (p, v) in zip(self.sources, self.marks):
+            if t._version != v or t.data_ptr() != p:
+                return False
+        return True
+
+    def run(self, xs_up: Sequence[Tensor], xs_b: Sequence[Tensor]) -> Optional[List[Tensor]]:
+        """None: these inputs are not what the launch takes (more rows than a launch serves, another width / dtype /
+        device) -- the caller then goes the long way, which raises where something is wrong."""
+        F, n = self.F, self.n
+        if self._c is not None and not _ffi.DYN_ROWS:
+            return self._c.run(list(xs_up), list(xs_b))
+        if len(xs_up) != n or len(xs_b) != n:
+            return None
+        rows = []
+        for xu, xb in zip(xs_up, xs_b):
+            M = xu.size(0)
+            if (M > self.cap or xb.size(0) != M or xu.dim() != 2 or xb.dim() != 2 or xu.size(1) != F or xb.size(1) != F
+                    or xu.dtype != torch.float32 or xb.dtype != torch.float32 or xu.device != self.dev or xb.device != self.dev):
+                return None
+            rows.append(M)
+        buf = torch.empty(sum(rows), F, dtype=torch.float32, device=self.dev)
+        outs = buf.split(rows)
+        base, off, hold = buf.data_ptr(), 0, []
+        for i in range(n):
+            xu, xb, M = _rowmajor(xs_up[i], 'x_up'), _rowmajor(xs_b[i], 'x_b'), rows[i]
+            hold += [xu, xb]                       # (a contiguous copy lives until the launch is enqueued)
+            a = self.arr[i]
+            a.x_up, a.x_b, a.y, a.M = xu.data_ptr(), xb.data_ptr(), base + off * 4 * F, M
+            a.ldx_up = xu.stride(0) if M > 1 else F
+            a.ldx_b = xb.stride(0) if M > 1 else F
+            a.m_dev = _ffi.dyn(M)
+            off += M
+        rc = self.fn(self.arr, n, F, _ffi.stream_ptr(self.dev))
+        if rc != 0:
+            _ffi.check(rc, 'cwn_update_mlp_f32')
+        return list(outs)
 
 
 _packed_mlp_weights = {}
@@ -2283,6 +2385,11 @@ class LayerLaunch:
         self.err = _err_flag(self.dev)
         self._err_ptr = self.err.data_ptr()
         self.fn = _ffi.lib().cwn_layer_fused_f32
+        # the per-call part in C++ when the compiled binding is there (csrc/cwn_torch_ext.cpp keeps a copy of the array)
+        from . import _cext
+        X = _cext.ext()
+        self._c = None if X is None else X.LayerCall(C.addressof(self.arr), C.sizeof(self.arr), self.n, self.F,
+                                                     self.rows, self._err_ptr, _cext.fn_address(self.fn), self.dev.index)
 
     def _attach_big(self, dims: Sequence[LayerDim], table) -> None:
         """BIG records (include/cwn_hip.h): complexes no workgroup's LDS holds are streamed by their workgroup, which
@@ -2359,6 +2466,13 @@ class LayerLaunch:
         """`ys` (training forward): per dimension (Y1 matrix or None, Y2 matrix or None), [n_cells, F] fp32 -- every item
         also writes its rows of the message products there (CWN_LAYER_STORE_Y)."""
         F = self.F
+        if self._c is not None:
+            c = self._c
+            cached = (int(csr_mode) & (_ffi.LAYER_CSR_STORE | _ffi.LAYER_CSR_LOAD)) != 0
+            if not c.has_plans(cached):
+                plans = self._plans[cached] = [t.c_plan(with_cache=cached) for t in self.parts]
+                c.set_plans(cached, [C.addressof(p) for p in plans], C.sizeof(plans[0]))
+            return c.run(xs, int(csr_mode), ys)
         for d in range(self.n):
             y1, y2 = ys[d] if ys is not None else (None, None)
             a = self.arr[d]

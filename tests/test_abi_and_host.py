@@ -743,3 +743,56 @@ def test_device_collate_descriptors_reproduce_the_reference_layout_on_the_cpu():
                     assert key not in rc.__slices__ or sl == rc.__slices__[key], (name, d, key)
                 yv, ry = cb['y'], rc['y']
                 assert (yv is None) == (ry is None) and (yv is None or torch.equal(yv.view(-1), ry.view(-1))), (name, d)
+
+
+def test_compiled_binding_module_loads_and_matches_the_abi():
+    """cwn_amd/_cwn_torch_ext.so (csrc/cwn_torch_ext.cpp, built by build()): loads without a GPU, was compiled against this
+    header, registers its torch.library ops; its descriptor-size guards refuse an array of another size."""
+    import ctypes
+    import torch
+    from cwn_amd import _build_ext, _cext, _ffi
+    _build_ext.build(verbose=False)
+    X = _cext.ext()
+    assert X is not None and int(X.abi_version) == _ffi.ABI_VERSION == _ffi.lib().cwn_abi_version()
+    assert _cext.active() == 'compiled'
+    with _cext.binding('ctypes'):
+        assert _cext.ext() is None and _cext.active() == 'ctypes'
+    assert _cext.ext() is X
+    assert hasattr(torch.ops.cwn, 'layer_fused') and hasattr(torch.ops.cwn, 'update_mlp')
+    fn = _cext.fn_address(_ffi.lib().cwn_layer_fused_f32)
+    arr = (_ffi.LayerDim * 2)()
+    with pytest.raises(ValueError, match='ABI'):
+        X.LayerCall(ctypes.addressof(arr), ctypes.sizeof(arr) - 8, 2, 64, [3, 4], 0, fn, 0)
+    c = X.LayerCall(ctypes.addressof(arr), ctypes.sizeof(arr), 2, 64, [3, 4], 0, fn, 0)
+    assert not c.has_plans(False) and not c.has_plans(True)
+    with pytest.raises(ValueError, match='one feature tensor per dimension'):
+        c.run([torch.zeros(3, 64)], 0, None)
+    with pytest.raises(ValueError, match='plans'):
+        c.run([torch.zeros(3, 64), torch.zeros(4, 64)], 0, None)
+    marr = (_ffi.MlpDim * 1)()
+    mfn = _cext.fn_address(_ffi.lib().cwn_update_mlp_f32)
+    src = [torch.zeros(4), torch.ones(2, 2)]
+    m = X.MlpCall(ctypes.addressof(marr), ctypes.sizeof(marr), 1, 64, 1 << 20, mfn, 0, src, 5, 7)
+    assert m.current(5, 7) and not m.current(6, 7) and not m.current(5, 8)
+    src[1].mul_(2.0)
+    assert not m.current(5, 7)
+    assert m.run([torch.zeros(3, 64)], [torch.zeros(3, 64)]) is None          # CPU tensors: not what the launch takes
+
+
+def test_struct_epoch_moves_when_a_module_tree_changes():
+    import torch
+    from cwn_amd import ops
+    e0 = ops.STRUCT_EPOCH
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.ReLU())
+    e1 = ops.STRUCT_EPOCH
+    assert e1 > e0
+    net[0].weight.data.mul_(2.0)
+    assert ops.STRUCT_EPOCH == e1                 # values are the version counters' business
+    net[0] = torch.nn.Linear(4, 4)
+    e2 = ops.STRUCT_EPOCH
+    assert e2 > e1
+    net[0].bias = torch.nn.Parameter(torch.zeros(4))
+    assert ops.STRUCT_EPOCH > e2
+    e3 = ops.STRUCT_EPOCH
+    net.register_buffer('k', torch.zeros(1))
+    assert ops.STRUCT_EPOCH > e3

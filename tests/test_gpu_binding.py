@@ -1,0 +1,203 @@
+"""The compiled binding of the eager path (csrc/cwn_torch_ext.cpp) against the ctypes binding: the same
+launches through both, bit for bit; the same exceptions; prepared launches that notice when their parameters change.
+mp/layers.py:184-199 is what a user layer calls per forward -- the path these launches serve."""
+import pytest
+import torch
+
+from cwn_amd import _cext, csr, layers, ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+
+
+def _model_and_batch(B=24, hidden=128, L=2):
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import zinc_like_complexes
+    torch.manual_seed(0)
+    model = EmbedSparseCIN(28, 4, 1, L, hidden, dropout_rate=0.0, max_dim=2, embed_edge=True, use_coboundaries=True).to(DEV).eval()
+    with torch.no_grad():                      # running statistics that are not the identity
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0.0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+    b = ComplexBatch.from_complex_list(zinc_like_complexes(B, 5, 6), max_dim=2).to(DEV)
+    x0 = [None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3)]
+
+    def fwd():
+        for d in range(3):
+            b.cochains[d]._x = x0[d]
+        return model(b)
+    return model, b, fwd
+
+
+def _forget(model):
+    for conv in model.convs:
+        layers._BLOCKED_CACHE.pop(conv, None)
+        layers._MLP_CACHE.pop(conv, None)
+
+
+def test_the_module_is_built_and_speaks_this_abi():
+    from cwn_amd import _ffi
+    X = _cext.ext()
+    assert X is not None, 'cwn_amd/_cwn_torch_ext.so is missing: python -m cwn_amd._build_ext (build() does it)'
+    assert int(X.abi_version) == _ffi.ABI_VERSION and _cext.active() == 'compiled'
+
+
+@pytest.mark.parametrize('hidden', [64, 128])
+def test_eager_forward_is_bit_identical_through_both_bindings(hidden):
+    model, b, fwd = _model_and_batch(hidden=hidden)
+    outs = {}
+    with torch.no_grad():
+        for which in ('ctypes', 'compiled'):
+            _forget(model)
+            with _cext.binding(which):
+                first = fwd().clone()                 # builds the prepared launches with this binding
+                second = fwd().clone()                # ... and runs them again from the caches
+            assert torch.equal(first, second)
+            ent = layers._BLOCKED_CACHE[model.convs[0]]
+            launch = next(iter(ent.values()))['launch']
+            assert (launch._c is not None) == (which == 'compiled')
+            assert (layers._MLP_CACHE[model.convs[0]][0]._c is not None) == (which == 'compiled')
+            outs[which] = first
+    assert torch.equal(outs['ctypes'], outs['compiled'])
+    print(f'[gate] eager EmbedSparseCIN forward (hidden {hidden}): ctypes and compiled bindings torch.equal, cached launches equal to fresh ones')
+
+
+def test_training_forward_through_the_compiled_binding_stores_the_products():
+    """LayerLaunch.run(ys=...) -- the training forward of the blocked kernel (CWN_LAYER_STORE_Y) -- through both bindings, in
+    the deterministic mode: the output and every gradient of one forward + backward equal."""
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import zinc_like_complexes
+    res = {}
+    ops.deterministic(True)
+    try:
+        for which in ('ctypes', 'compiled'):
+            torch.manual_seed(1)
+            model = EmbedSparseCIN(28, 4, 1, 2, 64, dropout_rate=0.0, max_dim=2, embed_edge=True, use_coboundaries=True).to(DEV).train()
+            b = ComplexBatch.from_complex_list(zinc_like_complexes(16, 7, 6), max_dim=2).to(DEV)
+            with _cext.binding(which):
+                out = model(b)
+                out.abs().sum().backward()
+            res[which] = (out.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None])
+    finally:
+        ops.deterministic(False)
+    assert torch.equal(res['ctypes'][0], res['compiled'][0])
+    ga, gc = res['ctypes'][1], res['compiled'][1]
+    assert len(ga) == len(gc) > 20 and all(torch.equal(a, c) for a, c in zip(ga, gc))
+
+
+def test_torch_library_ops_run_the_same_launches():
+    X = _cext.ext()
+    model, b, fwd = _model_and_batch()
+    with torch.no_grad():
+        _forget(model)
+        fwd()
+        conv = model.convs[1]
+        launch = next(iter(layers._BLOCKED_CACHE[conv].values()))['launch']
+        xs = [torch.randn(r, launch.F, device=DEV) for r in launch.rows]
+        want = launch.run(xs, 0)
+        h = X.layer_register(launch._c)
+        got = torch.ops.cwn.layer_fused(xs, h, 0)
+        assert len(got) == len(want) and all(torch.equal(g, w) for g, w in zip(got, want))
+        mlp = layers._MLP_CACHE[conv][0]
+        hm = X.mlp_register(mlp._c)
+        want2 = mlp.run(want[0::2], want[1::2])
+        got2 = torch.ops.cwn.update_mlp(list(want[0::2]), list(want[1::2]), hm)
+        assert all(torch.equal(g, w) for g, w in zip(got2, want2))
+        X.release(h)
+        X.release(hm)
+        with pytest.raises(RuntimeError, match='unknown handle'):
+            torch.ops.cwn.layer_fused(xs, h, 0)
+
+
+def test_argument_errors_are_the_ctypes_bindings():
+    model, b, fwd = _model_and_batch()
+    with torch.no_grad():
+        for which in ('ctypes', 'compiled'):
+            _forget(model)
+            with _cext.binding(which):
+                fwd()
+            launch = next(iter(layers._BLOCKED_CACHE[model.convs[0]].values()))['launch']
+            xs = [torch.randn(r, launch.F, device=DEV) for r in launch.rows]
+            with pytest.raises(ValueError, match='rows / width'):
+                launch.run([xs[0][:-1]] + xs[1:], 0)
+            with pytest.raises(TypeError, match='float32'):
+                launch.run([xs[0].double()] + xs[1:], 0)
+            # a non-contiguous feature matrix is taken (copied), as before
+            wide = torch.randn(launch.rows[0], 2 * launch.F, device=DEV)
+            got = launch.run([wide[:, ::2]] + xs[1:], 0)
+            want = launch.run([wide[:, ::2].contiguous()] + xs[1:], 0)
+            assert all(torch.equal(g, w) for g, w in zip(got, want))
+    csr.check_errors(DEV)
+
+
+@pytest.mark.parametrize('which', ['ctypes', 'compiled'])
+def test_prepared_update_launch_notices_what_changes_under_it(which):
+    """ops.MlpLaunch is derived once from a layer's parameters: an in-place write to ANY of them (here: one BatchNorm bias, one
+    running variance), a replaced submodule, a switch to training mode -- each must be seen by the next call."""
+    model, b, fwd = _model_and_batch(hidden=64)
+    with torch.no_grad(), _cext.binding(which):
+        _forget(model)
+        base = fwd().clone()
+        conv = model.convs[0]
+        first = layers._MLP_CACHE[conv][0]
+        assert torch.equal(fwd(), base) and layers._MLP_CACHE[conv][0] is first          # reused
+
+        def fresh():
+            _forget(model)
+            return fwd().clone()
+        bn = conv.mp_levels[1].update_up_nn[1]
+        bn.bias.add_(0.5)                                                               # (1) in place, one tensor
+        got = fwd().clone()
+        assert layers._MLP_CACHE[conv][0] is not first and not torch.equal(got, base)
+        assert torch.equal(got, fresh())
+        conv.mp_levels[0].combine_nn[1].running_var.mul_(2.0)                          # (2) a buffer
+        got = fwd().clone()
+        assert torch.equal(got, fresh())
+        lin = conv.mp_levels[2].update_boundaries_nn[0]                                # (3) a replaced submodule
+        new = torch.nn.Linear(lin.in_features, lin.out_features).to(DEV)
+        held = layers._MLP_CACHE[conv][0]
+        conv.mp_levels[2].update_boundaries_nn[0] = new
+        got = fwd().clone()
+        assert layers._MLP_CACHE[conv][0] is not held
+        assert torch.equal(got, fresh())
+        lin2 = conv.mp_levels[0].msg_up_nn[1]                                          # (4) the message weight (LayerLaunch's side)
+        lin2.weight.mul_(1.5)
+        got = fwd().clone()
+        assert torch.equal(got, fresh())
+        model.train()                                                                  # (5) batch statistics: not this launch's
+        held = layers._MLP_CACHE[conv][0]
+        got = fwd().clone()
+        assert not torch.equal(got, base)
+        assert torch.equal(got, fresh())
+        model.eval()
+        assert torch.equal(fwd(), fresh())
+
+
+def test_a_forward_reads_the_error_word_once_at_its_end():
+    """csr.deferred_checks: the front's range check no longer syncs in the middle of a forward; the IndexError still comes out of
+    the same call."""
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    model, b, fwd = _model_and_batch()
+    with torch.no_grad():
+        fwd()
+        n = [0]
+        real = torch.Tensor.item
+
+        def counting(self):
+            n[0] += 1
+            return real(self)
+        torch.Tensor.item = counting
+        try:
+            fwd()
+        finally:
+            torch.Tensor.item = real
+        assert n[0] <= 1, n[0]
+        b2 = ComplexBatch.from_complex_list(zinc_like_complexes(8, 9, 6), max_dim=2).to(DEV)
+        b2.cochains[0].x[3, 0] = 28.0
+        with pytest.raises(IndexError):
+            model(b2)
+    csr._err_flag(DEV).zero_()
