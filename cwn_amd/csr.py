@@ -252,8 +252,13 @@ def check_errors(dev) -> None:
     err = _err_flag(dev)
     flag = int(err.item())
     if flag:
+        global ERROR_EPOCH
+        ERROR_EPOCH += 1
         err.zero_()
         raise IndexError(_describe(flag))
+
+
+ERROR_EPOCH = 0      # moves with every raised IndexError: "these indices were checked" marks taken before it are void
 
 
 # ---- cache keyed on the identity of the reference-style index tensor ---------------------------

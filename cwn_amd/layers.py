@@ -148,6 +148,12 @@ def _two_per_cu_wins(n0: int, n1: int) -> bool:
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
 _BLOCKED_CACHE = weakref.WeakKeyDictionary()
 _MLP_CACHE = weakref.WeakKeyDictionary()          # layer module -> (ops.MlpLaunch, (start, dims, outputs), BatchNorm modules)
+_FRONT_CACHE = weakref.WeakKeyDictionary()        # embedding front module -> (ops.FrontLaunch, (rings?, reduce))
+
+
+def _ffi_dyn() -> bool:
+    from . import _ffi
+    return bool(_ffi.DYN_ROWS)
 
 
 def _fold_norm(norm, width: int):
@@ -1661,6 +1667,14 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
         (training) the same launch behind ops._EmbedFrontTrain.  None otherwise (the caller runs the separate launches)."""
         if not ops.FUSED_ENDS or e_params is None or v_params.x is None or not v_params.x.is_cuda:
             return None
+        infer = not torch.is_grad_enabled()
+        bi1, bi2 = e_params.boundary_index, (c_params.boundary_index if c_params is not None else None)
+        ent = _FRONT_CACHE.get(self) if infer else None
+        if (ent is not None and ent[1] == (c_params is not None, self.init_reduce.reduce) and ent[0].current(bi1, bi2)
+                and (ent[0].te is not None) == (e_params.x is not None)):
+            xs = ent[0].run(v_params.x, e_params.x)
+            if xs is not None:
+                return xs if c_params is not None else xs[:2]
         if self.init_reduce.reduce not in ('add', 'sum'):
             return None
         vt = _embedding_tables(self.v_embed_layer)
@@ -1703,7 +1717,16 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
                 return None               # tables beyond the LDS-table backward kernel: the generic path
             xs = ops.embed_front_train(vt, v_params.x, et, e_params.x if et is not None else None, n1, adj1, n2, adj2, halve=True)
         else:
-            xs = ops.embed_front(vt, v_params.x, et, e_params.x if et is not None else None, n1, adj1, n2, adj2, halve=True)
+            ex = e_params.x if et is not None else None
+            if infer and not _ffi_dyn() and all(f is None or (f.dim() == 2 and f.is_contiguous() and f.dtype in (torch.float32, torch.long))
+                                                for f in (v_params.x, ex)):
+                # the prepared form of this launch for the next call on this batch (ops.FrontLaunch)
+                launch = ops.FrontLaunch(vt, et, n0, n1, adj1, n2, adj2, True, bi1, bi2, v_params.x, ex)
+                _FRONT_CACHE[self] = (launch, (c_params is not None, self.init_reduce.reduce))
+                xs = launch.run(v_params.x, ex)
+                if xs is not None:
+                    return xs if c_params is not None else xs[:2]
+            xs = ops.embed_front(vt, v_params.x, et, ex, n1, adj1, n2, adj2, halve=True)
         return xs if c_params is not None else xs[:2]
 
     def reset_parameters(self):

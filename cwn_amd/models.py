@@ -9,6 +9,8 @@ mp/models.py:120-260 for non-embedded inputs (REDDIT-like config).  The readout
 """
 from typing import List
 
+import weakref
+
 import torch
 import torch.nn.functional as F
 from torch.nn import BatchNorm1d as BN, Embedding, Identity, LayerNorm as LN, Linear
@@ -18,6 +20,9 @@ from .layers import reset as reset_net
 from .complex import ComplexBatch
 from .csr import cached_adjacency, deferred_checks
 from .layers import CINConv, EdgeCINConv, EmbedVEWithReduce, InitReduceConv, SparseCINConv
+
+
+_HEAD_CACHE = weakref.WeakKeyDictionary()      # model -> (ops.HeadLaunch, the batch's BlockPlan, head signature, readout dims)
 
 
 def _one_check(forward):
@@ -285,6 +290,16 @@ class _SparseCINStack(torch.nn.Module):
         (no autograd, no active dropout) on a batch that carries the collate's per-complex tables; None otherwise."""
         first = lambda x: x[0] if isinstance(x, list) else x
         width = lambda x: sum(int(b.size(1)) for b in x) if isinstance(x, list) else int(x.size(1))
+        # the prepared launch of (this model, this batch): ops.HeadLaunch -- inference without side outputs
+        plain = not include_partial and not torch.is_grad_enabled() and not (self.training and self.dropout_rate > 0)
+        sig = (self.readout, self.final_readout, tuple(self.readout_dims), self.nonlinearity, self.jump_mode, ops.FUSED_ENDS)
+        ent = _HEAD_CACHE.get(self) if plain else None
+        tried = False
+        if ent is not None and ent[2] == sig and ent[1] is data.block_plan() and ent[0].current():
+            tried = True
+            out = ent[0].run([xs[d] if d < len(xs) else None for d in ent[3]])
+            if out is not None:
+                return out
         if not ops.FUSED_ENDS or self.nonlinearity != 'relu' or not xs or not first(xs[0]).is_cuda:
             return None
         if self.readout not in ('sum', 'mean') or self.final_readout not in ('sum', 'mean'):
@@ -327,6 +342,13 @@ class _SparseCINStack(torch.nn.Module):
                 for k in range(len(rd)):
                     res[f'pool_{k}'] = pooled[k]
             return out
+        if plain and not tried and not _ffi.DYN_ROWS:
+            launch = ops.HeadLaunch(hx, ptrs, plan.C, [l.weight for l in lins], [l.bias for l in lins], self.lin2.weight,
+                                    self.lin2.bias, self.readout == 'mean', self.final_readout == 'mean')
+            _HEAD_CACHE[self] = (launch, plan, sig, rd)
+            out = launch.run(hx)
+            if out is not None:
+                return out
         got = ops.head(hx, ptrs, plan.C, [l.weight for l in lins], [l.bias for l in lins], self.lin2.weight, self.lin2.bias,
                        mean_readout=self.readout == 'mean', mean_final=self.final_readout == 'mean',
                        want_pooled=include_partial, drop=ops.dropout_record(dev, drop_p, tag=('head', drop_pos)) if drop_p > 0 else None, drop_pos=drop_pos)

@@ -637,6 +637,91 @@ def embed_front(v_weights: Sequence[Tensor], v_feats: Tensor, e_weights: Optiona
     return [x0, x1, x2]
 
 
+def _marks(tensors):
+    """What `current()` of a prepared launch compares: (tensors, [(address, version)]) -- in C++ when the compiled binding is
+    there (csrc/cwn_torch_ext.cpp: TensorMarks)."""
+    from . import _cext
+    ts = [t for t in tensors if t is not None]
+    X = _cext.ext()
+    if X is not None:
+        return X.TensorMarks(ts)
+    return (ts, [(t.data_ptr(), t._version) for t in ts])
+
+
+def _marks_current(m) -> bool:
+    if not isinstance(m, tuple):
+        return m.current()
+    for t, (p, v) in zip(*m):
+        if t._version != v or t.data_ptr() != p:
+            return False
+    return True
+
+
+class FrontLaunch:
+    """A prepared cwn_embed_front_f32 call (inference) for one (front module, batch): tables, plans and sizes resolved once;
+    `run` takes the two feature tensors.  The range check of a feature tensor (one read of the device's error word) is made
+    once per tensor VERSION: a batch that is run again is not checked again."""
+
+    def __init__(self, v_weights, e_weights, n0, n1, adj1, n2, adj2, halve, bi1, bi2, v_feats, e_feats):
+        from .csr import _err_flag
+        for f in (v_feats, e_feats):
+            if f is not None and (f.dim() != 2 or f.dtype not in (torch.float32, torch.long) or not f.is_contiguous()):
+                raise ValueError('FrontLaunch: 2-D contiguous float32 / int64 feature tensors (the caller converts others per call)')
+        self.dev = dev = v_feats.device
+        self.n = (int(n0), int(n1), int(n2))
+        self.H = H = int(v_weights[0].size(1))
+        self.keep: list = []
+        self.tv = _embed_table(v_weights, v_feats, self.keep)
+        self.te = _embed_table(e_weights, e_feats, self.keep) if e_weights is not None else None
+        self.dtypes = (v_feats.dtype, None if e_feats is None else e_feats.dtype)
+        self.adjs, self.bi = (adj1, adj2), (bi1, bi2)
+        self.marks = _marks(list(v_weights) + list(e_weights or []) + [bi1, bi2])       # (the plans belong to the indices' values)
+        self.epochs = (STATE_EPOCH, STRUCT_EPOCH)
+        self.err = _err_flag(dev)
+        p = _ffi.ptr
+        self.tail = (p(adj1.rowptr) if adj1 is not None else None, p(adj1.col) if adj1 is not None else None,
+                     adj1.n_entries if adj1 is not None else 0)
+        self.tail2 = (p(adj2.rowptr) if adj2 is not None else None, p(adj2.col) if adj2 is not None else None,
+                      adj2.n_entries if adj2 is not None else 0, H, 1 if halve else 0, self.err.data_ptr())
+        self.fn = _ffi.lib().cwn_embed_front_f32
+        self._seen = None
+
+    def current(self, bi1, bi2) -> bool:
+        return (bi1 is self.bi[0] and bi2 is self.bi[1] and self.epochs == (STATE_EPOCH, STRUCT_EPOCH) and not _ffi.DYN_ROWS
+                and _marks_current(self.marks))
+
+    def run(self, v_feats: Tensor, e_feats: Optional[Tensor]) -> Optional[List[Tensor]]:
+        n0, n1, n2 = self.n
+        for f, n, dt, tab in ((v_feats, n0, self.dtypes[0], self.tv), (e_feats, n1, self.dtypes[1], self.te)):
+            if tab is None:
+                if f is not None:
+                    return None
+                continue
+            if (f is None or f.dtype != dt or f.dim() != 2 or f.size(0) != n or f.size(1) != tab.cols or not f.is_contiguous()
+                    or f.device != self.dev):
+                return None
+        from . import csr
+        buf = torch.empty(n0 + n1 + n2, self.H, dtype=torch.float32, device=self.dev)
+        x0, x1, x2 = buf[:n0], buf[n0:n0 + n1], buf[n0 + n1:]
+        for adj in self.adjs:
+            if adj is not None and adj.ready is not None:
+                torch.cuda.current_stream(self.dev).wait_event(adj.ready)
+        self.tv.src = v_feats.data_ptr()
+        if self.te is not None:
+            self.te.src = e_feats.data_ptr()
+        rc = self.fn(self.tv, n0, x0.data_ptr(), self.te, n1, x1.data_ptr(), *self.tail, n2, x2.data_ptr(), *self.tail2, None,
+                     _ffi.stream_ptr(self.dev))
+        if rc != 0:
+            _ffi.check(rc, 'cwn_embed_front_f32')
+        if csr.VALIDATE_INDICES and not torch.cuda.is_current_stream_capturing():
+            seen = (id(v_feats), v_feats._version, id(e_feats), None if e_feats is None else e_feats._version, csr.ERROR_EPOCH)
+            if self._seen is None or self._seen[0] != seen or self._seen[1]() is not v_feats or \
+                    (e_feats is not None and self._seen[2]() is not e_feats):
+                self._seen = (seen, weakref.ref(v_feats), None if e_feats is None else weakref.ref(e_feats))
+                csr.check_errors(self.dev)
+        return [x0, x1, x2]
+
+
 def _front_counts(n0: int, n1: int, n2: int) -> Optional[int]:
     """Device address of the int64 triple (actual n0, n1, n2) when the three row counts are the capacities of a static batch
     (_ffi.dynamic_rows: static_graph.StaticBatch keeps the three counts consecutive in memory), else None."""
@@ -888,6 +973,78 @@ def head(xs: Sequence, cell_ptrs: Sequence[Tensor], n_complexes: int, lin1_weigh
     if want_hidden:
         return out, pooled, hidden, s_out
     return (out, pooled) if want_pooled else out
+
+
+class HeadLaunch:
+    """A prepared cwn_head_f32 call (inference: no dropout, no side outputs) for one (model, batch): transposed weights, the
+    batch's `ptr` tables, the pooling split resolved once; `run` takes the feature matrices (or jumping-knowledge blocks)."""
+
+    def __init__(self, hx, cell_ptrs, n_complexes, lin1_weights, lin1_biases, lin2_weight, lin2_bias, mean_readout, mean_final):
+        parts = [_head_parts(x) for x in hx]
+        x0 = next(b[0] for b, _ in parts if b is not None)
+        self.dev = dev = x0.device
+        self.C = int(n_complexes)
+        self.K, self.H2, self.O = int(lin1_weights[0].size(1)), int(lin1_weights[0].size(0)), int(lin2_weight.size(0))
+        _transpose_many(lin1_weights)
+        self.keep, self.shapes = [], []
+        self.arr = (_ffi.HeadDim * len(parts))()
+        rows_total = 0
+        for d, (blocks, width) in enumerate(parts):
+            D = self.arr[d]
+            if blocks is not None:
+                if width != self.K:
+                    raise ValueError(f'dim {d}: {width} features for a lin1 of {self.K} inputs')
+                x = blocks[0]
+                D.cell_ptr, D.n_cells, D.n_parts = cell_ptrs[d].data_ptr(), int(x.size(0)), len(blocks)
+                rows_total += int(x.size(0))
+                self.shapes.append((len(blocks), int(x.size(0)), int(x.size(1))))
+            else:
+                self.shapes.append(None)
+            w1t = _transposed(lin1_weights[d])
+            b1 = None if lin1_biases[d] is None else _f32c(lin1_biases[d].detach(), 'lin1 bias')
+            D.w1t, D.b1 = w1t.data_ptr(), _ffi.ptr(b1)
+            self.keep += [w1t, b1, cell_ptrs[d]]
+        self.w2 = _f32c(lin2_weight.detach(), 'lin2 weight')
+        self.b2 = None if lin2_bias is None else _f32c(lin2_bias.detach(), 'lin2 bias')
+        self.P = head_split(rows_total, self.C)
+        self.n_part = int(_ffi.lib().cwn_head_pool_floats(self.arr, len(parts), self.C, self.K)) if self.P > 1 else 0
+        self.flags = (1 if mean_readout else 0, 1 if mean_final else 0)
+        self.marks = _marks(list(lin1_weights) + list(lin1_biases) + [lin2_weight, lin2_bias])
+        self.epochs = (STATE_EPOCH, STRUCT_EPOCH)
+        self.fn = _ffi.lib().cwn_head_f32
+
+    def current(self) -> bool:
+        return self.epochs == (STATE_EPOCH, STRUCT_EPOCH) and not _ffi.DYN_ROWS and _marks_current(self.marks)
+
+    def run(self, hx) -> Optional[Tensor]:
+        if len(hx) != len(self.shapes):
+            return None
+        for d, (x, shape) in enumerate(zip(hx, self.shapes)):
+            if (x is None) != (shape is None):
+                return None
+            if x is None:
+                continue
+            blocks = x if isinstance(x, (list, tuple)) else (x,)
+            n_b, rows, w = shape
+            if len(blocks) != n_b:
+                return None
+            ld = blocks[0].stride(0)
+            for b in blocks:
+                if (b.dtype != torch.float32 or b.dim() != 2 or b.size(0) != rows or b.size(1) != w or b.device != self.dev
+                        or (w > 1 and b.stride(1) != 1) or b.stride(0) != ld or (rows > 1 and ld < w)):
+                    return None
+            D = self.arr[d]
+            D.x, D.ldx = blocks[0].data_ptr(), ld
+            for q in range(1, n_b):
+                D.x_more[q - 1] = blocks[q].data_ptr()
+        out = torch.empty(self.C, self.O, dtype=torch.float32, device=self.dev)
+        partials = torch.empty(self.n_part, dtype=torch.float32, device=self.dev) if self.P > 1 else None
+        rc = self.fn(self.arr, len(self.shapes), self.C, self.K, self.H2, self.flags[0], self.flags[1], self.w2.data_ptr(),
+                     _ffi.ptr(self.b2), self.O, out.data_ptr(), None, None, 0, _ffi.ptr(partials), self.n_part, self.P,
+                     _ffi.stream_ptr(self.dev))
+        if rc != 0:
+            _ffi.check(rc, 'cwn_head_f32')
+        return out
 
 
 class _HeadTrain(torch.autograd.Function):

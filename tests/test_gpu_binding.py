@@ -201,3 +201,90 @@ def test_a_forward_reads_the_error_word_once_at_its_end():
         with pytest.raises(IndexError):
             model(b2)
     csr._err_flag(DEV).zero_()
+
+
+def test_prepared_front_and_head_launches_equal_the_long_way_and_notice_changes():
+    """ops.FrontLaunch / ops.HeadLaunch: a second forward of a batch runs the prepared launches (no new entries), its output is
+    the first forward's bit for bit; another batch, a changed embedding table or head weight, an include_partial call go the
+    long way and come out right."""
+    from cwn_amd import models
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    model, b, fwd = _model_and_batch()
+    with torch.no_grad():
+        first = fwd().clone()
+        front, head = layers._FRONT_CACHE[model.init_conv][0], models._HEAD_CACHE[model][0]
+        again = fwd().clone()
+        assert torch.equal(first, again)
+        assert layers._FRONT_CACHE[model.init_conv][0] is front and models._HEAD_CACHE[model][0] is head
+        # reference for everything below: the same model with the prepared launches forgotten
+        def fresh(batch_fwd):
+            layers._FRONT_CACHE.pop(model.init_conv, None)
+            models._HEAD_CACHE.pop(model, None)
+            _forget(model)
+            return batch_fwd().clone()
+        model.v_embed_init.weight[3].add_(1.0)                      # an embedding row, in place
+        got = fwd().clone()
+        assert not torch.equal(got, first) and torch.equal(got, fresh(fwd))
+        model.lin2.bias.add_(0.25)
+        got = fwd().clone()
+        assert torch.equal(got, fresh(fwd))
+        model.lin1s[1].weight.mul_(0.5)
+        got = fwd().clone()
+        assert torch.equal(got, fresh(fwd))
+        # another batch through the same model, then the first one again
+        b2 = ComplexBatch.from_complex_list(zinc_like_complexes(17, 11, 6), max_dim=2).to(DEV)
+        x2 = [None if b2.cochains[d].x is None else b2.cochains[d].x.clone() for d in range(3)]
+
+        def fwd2():
+            for d in range(3):
+                b2.cochains[d]._x = x2[d]
+            return model(b2)
+        o2 = fwd2().clone()
+        o1 = fwd().clone()
+        assert torch.equal(o2, fresh(fwd2)) and torch.equal(o1, fresh(fwd))
+        # side outputs: not the prepared launch's business
+        for d in range(3):
+            b2.cochains[d]._x = x2[d]
+        out, res = model(b2, include_partial=True)
+        assert torch.equal(out, o2) and 'pool_0' in res and 'layer0_0' in res
+    csr.check_errors(DEV)
+
+
+def test_the_front_checks_each_feature_version_once():
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    model, b, fwd = _model_and_batch()
+    n = [0]
+    real = torch.Tensor.item
+
+    def counting(self):
+        n[0] += 1
+        return real(self)
+    with torch.no_grad():
+        fwd()
+        fwd()
+        torch.Tensor.item = counting
+        try:
+            fwd()
+            fwd()
+        finally:
+            torch.Tensor.item = real
+        assert n[0] == 0, n[0]                        # the batch's features were checked when they were first seen
+    # a bad atom type written INTO a checked tensor is a new version: checked again, raised from that forward
+    b3 = ComplexBatch.from_complex_list(zinc_like_complexes(24, 5, 6), max_dim=2).to(DEV)
+    x3 = [None if b3.cochains[d].x is None else b3.cochains[d].x.clone() for d in range(3)]
+    with torch.no_grad():
+        def fwd3():
+            for d in range(3):
+                b3.cochains[d]._x = x3[d]
+            return model(b3)
+        fwd3()
+        fwd3()
+        x3[0][5, 0] = 31.0
+        with pytest.raises(IndexError):
+            fwd3()
+        x3[0][5, 0] = 2.0
+        good = fwd3().clone()
+        assert torch.isfinite(good).all()
+    csr._err_flag(DEV).zero_()

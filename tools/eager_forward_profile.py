@@ -21,9 +21,42 @@ with torch.no_grad():
     for _ in range(300): fwd()
     torch.cuda.synchronize()
     print(f'eager model(batch): {(time.perf_counter() - t0) / 300 * 1e6:.0f} us')
-    import cProfile, pstats
-    pr = cProfile.Profile(); pr.enable()
-    for _ in range(100): fwd()
-    pr.disable()
-    pstats.Stats(pr).sort_stats('tottime').print_stats(22)
-    pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
+    # real host time per segment (perf_counter around the model's pieces; cProfile inflates everything ~2 x)
+    T = {}
+    def timed(obj, name, label):
+        fn = getattr(obj, name)
+        def wrapped(*a, **k):
+            t = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                T[label] = T.get(label, 0.0) + time.perf_counter() - t
+        setattr(obj, name, wrapped)
+    timed(model.init_conv, 'forward', 'front (init_conv)')
+    timed(model, '_head_fused', 'head (_head_fused)')
+    for conv in model.convs:
+        timed(conv, 'propagate_all', 'conv: propagate_all')
+        timed(conv, '_dense_eval', 'conv: _dense_eval')
+        timed(conv, 'forward', 'conv: forward (incl. the two above)')
+    timed(b, 'get_all_cochain_params', 'batch.get_all_cochain_params (5 calls)')
+    timed(b, 'set_xs', 'batch.set_xs (5 calls)')
+    from cwn_amd import csr
+    real_check = csr.check_errors
+    def check(dev):
+        t = time.perf_counter(); real_check(dev); T['error word (sync)'] = T.get('error word (sync)', 0.0) + time.perf_counter() - t
+    csr.check_errors = check
+    for _ in range(20): fwd()
+    torch.cuda.synchronize(); T.clear()
+    t0 = time.perf_counter()
+    for _ in range(300): fwd()
+    torch.cuda.synchronize()
+    print(f'with segment timers: {(time.perf_counter() - t0) / 300 * 1e6:.0f} us')
+    for k, v in sorted(T.items(), key=lambda kv: -kv[1]):
+        print(f'  {v / 300 * 1e6:7.1f} us  {k}')
+    if os.environ.get('CPROFILE'):
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+        for _ in range(100): fwd()
+        pr.disable()
+        pstats.Stats(pr).sort_stats('tottime').print_stats(22)
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
