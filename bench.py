@@ -684,16 +684,26 @@ def main():
     if use_graph and not args.only_primary and 'eager' not in SKIP:
         try:
             esteps = max(args.steps // 4, 10)
-            dte = timed(propagate_scope, esteps, 3, False)['dt']
+            te_ = timed(propagate_scope, esteps, 3, False, MIN_REGION_S)      # (regions of >= 50 ms, as the headline's)
+            dte = te_['dt'] / te_['rounds']
             ecells = torch.tensor([sum(stats[(3 + i) % len(stats)]['cells'] for i in range(esteps)) * L],
                                   device=dev, dtype=torch.float64)
             if dist is not None:
                 dist.all_reduce(ecells)
+            from cwn_amd import _cext
             eager = {'cells_per_s': round(float(ecells.item()) / dte, 1), 'ms_per_step': round(dte / esteps * 1e3, 5),
+                     'binding': _cext.active(),
                      'note': ('same step through the reference-shaped API (set_xs, get_all_cochain_params, conv): one '
-                              'Python/ctypes call per layer launch' if BLOCKED else
-                              'same step, one Python/ctypes call per launch and a validated (synchronising) plan build')
+                              'Python call per layer launch, the per-call part of a prepared launch in C++ '
+                              '(cwn_amd/_cwn_torch_ext.so; ctypes when it is not built)' if BLOCKED else
+                              'same step, one Python call per launch and a validated (synchronising) plan build')
                              + ': host-bound; the headline replays the step from a hipGraph'}
+            # ... and the whole model eagerly, model(batch) (r4: 0.91 ms, 8 x the replay; prepared launches + one range check
+            # per forward in round 5)
+            fsteps = max(args.steps // 4, 10)
+            tf_ = timed(full_forward, fsteps, 3, False, MIN_REGION_S)
+            dtf = tf_['dt'] / tf_['rounds']
+            eager['full_forward_ms'] = round(dtf / fsteps * 1e3, 5)
         except Exception as e:
             print(f'[bench] eager leg failed: {type(e).__name__}: {e}', file=sys.stderr)
     full_steps = max(args.steps // 4, 10)

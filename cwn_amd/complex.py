@@ -25,6 +25,11 @@ from .cell_mp import CochainMessagePassingParams, IndexedRows
 INDEX_KEYS = ('upper_index', 'lower_index', 'shared_boundaries', 'shared_coboundaries', 'boundary_index')
 
 
+def _rows(src, index):
+    from . import ops
+    return ops.gather_rows(src, index)   # HIP gather kernel; GPU only, like everything else
+
+
 class Cochain(object):
     """Vector-valued signal on the k-cells of a complex (data/complex.py:36-92).
 
@@ -405,23 +410,19 @@ class Complex(object):
         x = cells._x
         lazy = self.lazy_attrs
 
-        def rows(src, index):
-            from . import ops
-            return ops.gather_rows(src, index)   # HIP gather kernel; GPU only, like everything else
-
         upper_index, upper_features = None, None
         up_c = cochains.get(dim + 1)
         if cells.upper_index is not None and up_c is not None:
             upper_index = cells.upper_index
             xu = up_c._x
             if xu is not None and (dim < max_dim or include_top_features):
-                upper_features = IndexedRows(xu, cells.shared_coboundaries) if lazy else rows(xu, cells.shared_coboundaries)
+                upper_features = IndexedRows(xu, cells.shared_coboundaries) if lazy else _rows(xu, cells.shared_coboundaries)
         lower_index, lower_features = None, None
         down_x = cochains[dim - 1]._x if dim > 0 else None
         if include_down_features and cells.lower_index is not None:
             lower_index = cells.lower_index
             if down_x is not None:
-                lower_features = IndexedRows(down_x, cells.shared_boundaries) if lazy else rows(down_x, cells.shared_boundaries)
+                lower_features = IndexedRows(down_x, cells.shared_boundaries) if lazy else _rows(down_x, cells.shared_boundaries)
         boundary_index, boundary_features = None, None
         if include_boundary_features and cells.boundary_index is not None:
             boundary_index = cells.boundary_index

@@ -148,7 +148,7 @@ def _two_per_cu_wins(n0: int, n1: int) -> bool:
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
 _BLOCKED_CACHE = weakref.WeakKeyDictionary()
 _MLP_CACHE = weakref.WeakKeyDictionary()          # layer module -> (ops.MlpLaunch, (start, dims, outputs), BatchNorm modules)
-_FRONT_CACHE = weakref.WeakKeyDictionary()        # embedding front module -> (ops.FrontLaunch, (rings?, reduce))
+_FRONT_CACHE = weakref.WeakKeyDictionary()        # embedding front module -> {id(boundary_index_1): (ops.FrontLaunch, (rings?, reduce))}
 
 
 def _ffi_dyn() -> bool:
@@ -1669,7 +1669,7 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
             return None
         infer = not torch.is_grad_enabled()
         bi1, bi2 = e_params.boundary_index, (c_params.boundary_index if c_params is not None else None)
-        ent = _FRONT_CACHE.get(self) if infer else None
+        ent = _FRONT_CACHE.get(self, {}).get(id(bi1)) if infer else None
         if (ent is not None and ent[1] == (c_params is not None, self.init_reduce.reduce) and ent[0].current(bi1, bi2)
                 and (ent[0].te is not None) == (e_params.x is not None)):
             xs = ent[0].run(v_params.x, e_params.x)
@@ -1722,7 +1722,10 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
                                                 for f in (v_params.x, ex)):
                 # the prepared form of this launch for the next call on this batch (ops.FrontLaunch)
                 launch = ops.FrontLaunch(vt, et, n0, n1, adj1, n2, adj2, True, bi1, bi2, v_params.x, ex)
-                _FRONT_CACHE[self] = (launch, (c_params is not None, self.init_reduce.reduce))
+                cache = _FRONT_CACHE.setdefault(self, {})            # (per batch, like _BLOCKED_CACHE: loops over a few batches)
+                if len(cache) >= 16:
+                    cache.clear()
+                cache[id(bi1)] = (launch, (c_params is not None, self.init_reduce.reduce))
                 xs = launch.run(v_params.x, ex)
                 if xs is not None:
                     return xs if c_params is not None else xs[:2]

@@ -22,7 +22,7 @@ from .csr import cached_adjacency, deferred_checks
 from .layers import CINConv, EdgeCINConv, EmbedVEWithReduce, InitReduceConv, SparseCINConv
 
 
-_HEAD_CACHE = weakref.WeakKeyDictionary()      # model -> (ops.HeadLaunch, the batch's BlockPlan, head signature, readout dims)
+_HEAD_CACHE = weakref.WeakKeyDictionary()      # model -> {id(plan): (ops.HeadLaunch, the batch's BlockPlan, head signature, readout dims)}
 
 
 def _one_check(forward):
@@ -293,9 +293,10 @@ class _SparseCINStack(torch.nn.Module):
         # the prepared launch of (this model, this batch): ops.HeadLaunch -- inference without side outputs
         plain = not include_partial and not torch.is_grad_enabled() and not (self.training and self.dropout_rate > 0)
         sig = (self.readout, self.final_readout, tuple(self.readout_dims), self.nonlinearity, self.jump_mode, ops.FUSED_ENDS)
-        ent = _HEAD_CACHE.get(self) if plain else None
+        plan = data.block_plan() if plain else None
+        ent = _HEAD_CACHE.get(self, {}).get(id(plan)) if plan is not None else None
         tried = False
-        if ent is not None and ent[2] == sig and ent[1] is data.block_plan() and ent[0].current():
+        if ent is not None and ent[2] == sig and ent[1] is plan and ent[0].current():
             tried = True
             out = ent[0].run([xs[d] if d < len(xs) else None for d in ent[3]])
             if out is not None:
@@ -345,7 +346,10 @@ class _SparseCINStack(torch.nn.Module):
         if plain and not tried and not _ffi.DYN_ROWS:
             launch = ops.HeadLaunch(hx, ptrs, plan.C, [l.weight for l in lins], [l.bias for l in lins], self.lin2.weight,
                                     self.lin2.bias, self.readout == 'mean', self.final_readout == 'mean')
-            _HEAD_CACHE[self] = (launch, plan, sig, rd)
+            cache = _HEAD_CACHE.setdefault(self, {})
+            if len(cache) >= 16:
+                cache.clear()
+            cache[id(plan)] = (launch, plan, sig, rd)
             out = launch.run(hx)
             if out is not None:
                 return out

@@ -31,6 +31,11 @@ def _model_and_batch(B=24, hidden=128, L=2):
     return model, b, fwd
 
 
+def _only(d):
+    assert len(d) == 1
+    return next(iter(d.values()))
+
+
 def _forget(model):
     for conv in model.convs:
         layers._BLOCKED_CACHE.pop(conv, None)
@@ -213,10 +218,10 @@ def test_prepared_front_and_head_launches_equal_the_long_way_and_notice_changes(
     model, b, fwd = _model_and_batch()
     with torch.no_grad():
         first = fwd().clone()
-        front, head = layers._FRONT_CACHE[model.init_conv][0], models._HEAD_CACHE[model][0]
+        front, head = _only(layers._FRONT_CACHE[model.init_conv])[0], _only(models._HEAD_CACHE[model])[0]
         again = fwd().clone()
         assert torch.equal(first, again)
-        assert layers._FRONT_CACHE[model.init_conv][0] is front and models._HEAD_CACHE[model][0] is head
+        assert _only(layers._FRONT_CACHE[model.init_conv])[0] is front and _only(models._HEAD_CACHE[model])[0] is head
         # reference for everything below: the same model with the prepared launches forgotten
         def fresh(batch_fwd):
             layers._FRONT_CACHE.pop(model.init_conv, None)

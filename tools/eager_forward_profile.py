@@ -8,12 +8,18 @@ from cwn_amd.synthetic import zinc_like_complexes
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 model = EmbedSparseCIN(28, 4, 1, 4, 128, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(dev).eval()
-b = ComplexBatch.from_complex_list(zinc_like_complexes(128, 0, 6), max_dim=2).to(dev)
-x0 = [None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3)]
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # distinct batches cycled (bench.py cycles its --num-batches)
+bs = [ComplexBatch.from_complex_list(zinc_like_complexes(128, i, 6), max_dim=2).to(dev) for i in range(NB)]
+x0s = [[None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3)] for b in bs]
+b = bs[0]
+_i = [0]
 def fwd():
+    k = _i[0] % NB
+    _i[0] += 1
+    bb = bs[k]
     for d in range(3):        # (the model overwrites the batch's features layer by layer, as the reference does)
-        b.cochains[d]._x = x0[d]
-    return model(b)
+        bb.cochains[d]._x = x0s[k][d]
+    return model(bb)
 with torch.no_grad():
     for _ in range(20): fwd()
     torch.cuda.synchronize()
@@ -38,8 +44,9 @@ with torch.no_grad():
         timed(conv, 'propagate_all', 'conv: propagate_all')
         timed(conv, '_dense_eval', 'conv: _dense_eval')
         timed(conv, 'forward', 'conv: forward (incl. the two above)')
-    timed(b, 'get_all_cochain_params', 'batch.get_all_cochain_params (5 calls)')
-    timed(b, 'set_xs', 'batch.set_xs (5 calls)')
+    for bb in bs:
+        timed(bb, 'get_all_cochain_params', 'batch.get_all_cochain_params (5 calls)')
+        timed(bb, 'set_xs', 'batch.set_xs (5 calls)')
     from cwn_amd import csr
     real_check = csr.check_errors
     def check(dev):
