@@ -104,13 +104,20 @@ class StaticBlockPlan:
         self.n_dims = owner.D
         self.C = owner.B
         self.device = owner.device
-        self.variant, self.group = owner.variant, owner.group
         self.cell_ptr = [np.array([0, owner.cap_cells[d]], dtype=np.int64) for d in range(owner.D)]
         self.up_ptr = [(np.array([0, owner.cap_key(d, 'upper_index')]) if owner.k_of(d, 'upper_index') >= 0 else None)
                        for d in range(owner.D)]
         self.b_ptr = [(np.array([0, owner.cap_key(d, 'boundary_index')]) if owner.k_of(d, 'boundary_index') >= 0 else None)
                       for d in range(owner.D)]
         self.validated = True           # (index VALUES are checked by every blocked launch; the sticky word is read by the caller)
+
+    @property
+    def variant(self) -> int:
+        return self.owner.variant
+
+    @property
+    def group(self) -> int:
+        return self.owner.group
 
     # ---- what the model code asks -------------------------------------------------------------------------------
     def cell_ptr_device(self, d: int, device) -> torch.Tensor:
@@ -200,7 +207,7 @@ class StaticBatch:
     dataset's sizes needs with a wide margin (mean x B + 6 sigma sqrt(B), at most the sum of the B largest), and
     `fits(batches)` tells the caller which batches the buffers hold."""
 
-    def __init__(self, packed: PackedComplexes, batch_size: int, caps: Optional[dict] = None, variant: int = 0,
+    def __init__(self, packed: PackedComplexes, batch_size: int, caps: Optional[dict] = None, variant: Optional[int] = None,
                  group: Optional[int] = None, indices: Optional[Sequence[int]] = None, slots: int = 1, mode: str = 'blocked'):
         """mode 'blocked' (default): the complex-blocked launches of SparseCINConv are the only path -- item tables cut on the
         device, no CSR of the upper adjacencies; a complex beyond one workgroup does not fit.  mode 'csr' (round 5): every
@@ -217,16 +224,26 @@ class StaticBatch:
             raise ValueError('StaticBatch needs a PackedComplexes built with with_csr=True')
         if packed.device.type != 'cuda':
             raise _ffi.CwnError('StaticBatch needs the packed dataset on the GPU')
-        if variant not in (0, 1):
-            raise ValueError('variant 0 (one 16-wave workgroup per CU) or 1 (the two-per-CU form)')
+        if variant not in (None, 0, 1):
+            raise ValueError('variant 0 (one 16-wave workgroup per CU), 1 (the two-per-CU form) or None (chosen when the first '
+                             'item table is cut: _pick_variant)')
         self.packed, self.B, self.S = packed, int(batch_size), int(slots)
         if self.S < 1 or self.S > 64:
             raise ValueError('1 .. 64 slots')
         self.device = packed.device
         self.D = packed.max_dim + 1
         self.K = len(packed._klist)
-        self.variant = int(variant)
-        self.group = int(group) if group is not None else max(1, self.B // (256 if variant == 1 else 128))
+        # the form of the complex-blocked launches and the complexes per item of the device-side cut.  Measured (round 5,
+        # tools/sweep_static_group.py; propagate scope over never-seen batches, share of the fixed-batch replay whose table the
+        # host builder packs): ONE complex per item in every case (ZINC-512: two-per-CU 0.98 / 0.94 at 1 / 2 complexes per
+        # item, 16-wave 0.78 / 0.80 at 2 / 4; molhiv-512: 0.81 / 0.79 / 0.75 at 1 / 2 / 3 against 0.65 / 0.70 / 0.70 / 0.62 at
+        # 1 / 2 / 3 / 4), and the two-per-CU form as soon as a batch has more items than the chip has CUs (ZINC-256: 1.01
+        # against 0.94; ZINC-2048: 0.90; molhiv-2048: 0.63) -- until round 5 the default was the 16-wave form with B / 128
+        # complexes per item (molhiv-512: 0.62).
+        self._variant_arg = None if variant is None else int(variant)
+        self.variant = 0 if variant is None else int(variant)       # (None: settled by the first forward table, _pick_variant)
+        self._variant_settled = variant is not None
+        self.group = int(group) if group is not None else 1
         B, D, K, S = self.B, self.D, self.K, self.S
         dev = self.device
         meta = packed._meta if indices is None else packed._meta[np.asarray(indices, dtype=np.int64)]
@@ -460,9 +477,29 @@ class StaticBatch:
                 self._launch_family(key, self.S)       # cut for the batches the buffers hold now
         return self._families[key]
 
+    def _pick_variant(self, F: int, has_up, has_b) -> None:
+        """variant=None: the two-per-CU form when a batch has more items than the chip has CUs (B > 128: two sets of items per
+        complex) AND every complex of the dataset fits its smaller workgroup (80 KiB of LDS: ~30 atoms at width 128) -- one
+        form per static batch, settled by the first forward table that is cut."""
+        if self._variant_settled:
+            return
+        self._variant_settled = True
+        if self.B <= 128 or F not in (64, 128):
+            return
+        from .blockplan import single_fit_forward
+        meta, D = self.packed._meta, self.D
+        col = lambda d, key: (meta[:, 3 * D + self.k_of(d, key)] if self.k_of(d, key) >= 0 else None)
+        ok = single_fit_forward([meta[:, 3 * d] for d in range(D)], [col(d, 'upper_index') for d in range(D)],
+                                [col(d, 'boundary_index') for d in range(D)], F, has_up, has_b, 1,
+                                128 if F == 64 else 80, 128 if F == 64 else 48)
+        if bool(ok.all()):
+            self.variant = 1
+
     def _make_family(self, kind: str, F: int, has_up, has_b):
         if self.mode == 'csr':
             return None                        # (no item tables: the layers take their CSR path)
+        if kind == 'fwd':
+            self._pick_variant(F, has_up, has_b)
         if F not in (64, 128) or any(has_up[d] and (d + 1 >= self.D or self.k_of(d, 'upper_index') < 0) for d in range(self.D)):
             return None
         S, B, dev = self.S, self.B, self.device

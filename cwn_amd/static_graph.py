@@ -364,7 +364,7 @@ class StaticRouter:
     120 - 220-atom molecules into ~one batch in seven at batch 512) to the streaming path.  Both run captured graphs; the
     host's work per epoch is this split (numpy over the per-complex sizes) and two permutation uploads."""
 
-    def __init__(self, packed, batch_size: int, slots: int = 8, caps: Optional[dict] = None, variant: int = 0):
+    def __init__(self, packed, batch_size: int, slots: int = 8, caps: Optional[dict] = None, variant: Optional[int] = None):
         self.blocked = StaticBatch(packed, batch_size, caps=caps, variant=variant, slots=slots, mode='blocked')
         self.csr = StaticBatch(packed, batch_size, caps=caps, slots=slots, mode='csr')
         self.S = int(slots)

@@ -137,8 +137,8 @@ def _model(hidden=128, layers=2, seed=0):
                           embed_edge=True, use_coboundaries=True, graph_norm='bn').to(DEV)
 
 
-@pytest.mark.parametrize('hidden', [128, 64])
-def test_static_forward_replays_one_graph_for_unseen_batches_bit_identically(hidden):
+@pytest.mark.parametrize('hidden,variant', [(128, None), (64, None), (128, 1), (64, 1)])
+def test_static_forward_replays_one_graph_for_unseen_batches_bit_identically(hidden, variant):
     """StaticForward: the whole eval forward (front, layers, update networks, head) captured ONCE; batches of 48, 48, 17, 1
     and 48 complexes it has never seen give predictions bit-identical to model(collate(batch)) -- the per-batch launches
     with host-built tables -- and inside the gate of ... nothing else: equality is the bar (every kernel's result per row /
@@ -149,7 +149,7 @@ def test_static_forward_replays_one_graph_for_unseen_batches_bit_identically(hid
     pool, p = _packed(n_hi=28)
     model = _model(hidden).eval()
     B = 48
-    sb = StaticBatch(p, B)
+    sb = StaticBatch(p, B, variant=variant)          # (1: the two-per-CU form of the blocked launch, the default beyond 128 complexes)
     sf = StaticForward(model, sb)
     graphs = set()
     with torch.no_grad():
@@ -161,6 +161,36 @@ def test_static_forward_replays_one_graph_for_unseen_batches_bit_identically(hid
     assert len(graphs) == 1
     csr.check_errors(DEV)
     assert sb.fits(_batches(len(pool), B, 11, sizes=[B, 17])).all()
+    assert sb.variant == (variant or 0) and sb.group == 1
+
+
+def test_static_batch_picks_the_two_per_cu_form_beyond_128_complexes_when_the_dataset_fits_it():
+    """variant=None: B <= 128 -> the 16-wave form; B > 128 and every molecule within the two-per-CU workgroup -> that form (and
+    the forward still bit-identical to per-batch launches); one 40-atom molecule in the dataset -> the 16-wave form."""
+    from cwn_amd import csr
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward
+    from cwn_amd.synthetic import zinc_like_complexes
+    pool, p = _packed(n=400, n_hi=24)
+    model = _model(128).eval()
+    B = 160
+    sb = StaticBatch(p, B)
+    sf = StaticForward(model, sb)
+    with torch.no_grad():
+        for idx in _batches(len(pool), B, 3, sizes=[B, 77, B]):
+            assert torch.equal(sf.run(idx).clone(), model(p.collate(idx)))
+    assert sb.variant == 1                 # (settled by the first forward table that was cut)
+    csr.check_errors(DEV)
+    big = zinc_like_complexes(1, 5, 6, n_lo=40, n_hi=40)
+    p2 = PackedComplexes(pool + big, DEV, max_dim=2, with_csr=True)
+    with torch.no_grad():
+        sb2 = StaticBatch(p2, B)
+        StaticForward(model, sb2).run(np.arange(B))
+        assert sb2.variant == 0
+        sb3 = StaticBatch(p, 128)
+        StaticForward(model, sb3).run(np.arange(100))
+        assert sb3.variant == 0
 
 
 def test_static_forward_over_an_epoch_needs_nothing_from_the_host_per_step():
@@ -183,7 +213,8 @@ def test_static_forward_over_an_epoch_needs_nothing_from_the_host_per_step():
                 assert torch.equal(got, model(p.collate(idx)))
 
 
-def test_static_train_step_matches_the_per_batch_step():
+@pytest.mark.parametrize('variant', [None, 1])
+def test_static_train_step_matches_the_per_batch_step(variant):
     """StaticTrainStep: zero_grad, forward, loss, backward and Adam of exp/train_utils.py:57-75 captured ONCE and replayed on
     three batches it has never seen (48, 48, 20 complexes) against TrainStep's eager per-batch step from the same state:
     loss, the flat gradient after every step and the parameters after the last (the weight-gradient / BatchNorm-backward
@@ -197,7 +228,7 @@ def test_static_train_step_matches_the_per_batch_step():
     m1, m2 = _model(128, 2, seed=4), _model(128, 2, seed=4)
     m2.load_state_dict(m1.state_dict())
     batches = _batches(len(pool), B, 13, sizes=[B, B, 20])
-    sb = StaticBatch(p, B)
+    sb = StaticBatch(p, B, variant=variant)
     sb.set_batch(batches[0])
     st = StaticTrainStep(m1, sb, lr=1e-3)
     ref = TrainStep(m2, [p.collate(idx) for idx in batches], lr=1e-3, use_graph=False)
