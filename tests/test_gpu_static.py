@@ -357,7 +357,8 @@ def test_static_train_two_slots_and_an_empty_slot_changes_nothing():
     assert worst < 2 * 1e-3 * 3 * 1.1, worst
 
 
-def test_static_forward_and_train_step_on_the_molhiv_like_configuration():
+@pytest.mark.parametrize('variant', [None, 1])
+def test_static_forward_and_train_step_on_the_molhiv_like_configuration(variant):
     """BASELINE configs[2] through the static path: OGBEmbedSparseCIN (nine atom-feature tables, three bond-feature tables,
     hidden 64, mean readout; exp/scripts/cwn-molhiv.sh:9-32) -- the eval forward of unseen batches bit-identical to the
     per-batch launches, and a captured training step (regression loss on synthetic targets) against TrainStep's eager
@@ -382,7 +383,7 @@ def test_static_forward_and_train_step_on_the_molhiv_like_configuration():
     B = 40
     batches = _batches(len(pool), B, 5, sizes=[B, B, 23])
     model = make().eval()
-    sb = StaticBatch(p, B)
+    sb = StaticBatch(p, B, variant=variant)       # (1: what a batch of 512 gets by default -- the bench's molhiv legs)
     assert sb.fits(batches).all()
     sf = StaticForward(model, sb)
     with torch.no_grad():
@@ -394,7 +395,7 @@ def test_static_forward_and_train_step_on_the_molhiv_like_configuration():
     # training
     m1, m2 = make(2), make(2)
     m2.load_state_dict(m1.state_dict())
-    sb2 = StaticBatch(p, B)
+    sb2 = StaticBatch(p, B, variant=variant)
     sb2.set_batch(batches[0])
     st = StaticTrainStep(m1, sb2, lr=1e-3)
     ref = TrainStep(m2, [p.collate(idx) for idx in batches], lr=1e-3, use_graph=False)
@@ -404,7 +405,7 @@ def test_static_forward_and_train_step_on_the_molhiv_like_configuration():
         torch.cuda.synchronize()
         assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l2))), (j, float(l1), float(l2))
         rel = float((st.bucket.flat - ref.bucket.flat).norm() / ref.bucket.flat.norm())
-        print(f'[static train, molhiv-like] step {j}: loss {float(l1):.6f} vs {float(l2):.6f}, relative L2 distance of the gradient {rel:.2e}')
+        print(f'[static train, molhiv-like, variant {variant}] step {j}: loss {float(l1):.6f} vs {float(l2):.6f}, relative L2 distance of the gradient {rel:.2e}')
         assert rel < 2e-5, (j, rel)
         if j + 1 < len(batches):                     # (every step from ONE state: test_static_train_step_matches_the_per_batch_step)
             ref.opt.flat_p.copy_(st.opt.flat_p)
