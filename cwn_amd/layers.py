@@ -806,12 +806,13 @@ class SparseCINConv(torch.nn.Module):
                 return None
             dims, plan, table, key = args
             ckey = id(plan)
-            ent = dict(plan=plan, table=table, key=key, F=int(dims[0].x.size(1)), epoch=ops.STATE_EPOCH,
+            lins = [self.mp_levels[d].msg_up_nn[1] for d, D in enumerate(dims) if D.msg_w_packed is not None]
+            ent = dict(plan=plan, table=table, key=key, F=int(dims[0].x.size(1)), epochs=(ops.STATE_EPOCH, ops.STRUCT_EPOCH),
                        idx=[(c.up_index, c.boundary_index, getattr(c.kwargs.get('up_attr'), 'index', None))
                             for c in cochain_params],
-                       lins=[(d, self.mp_levels[d].msg_up_nn[1]) for d, D in enumerate(dims) if D.msg_w_packed is not None],
-                       wver=[self.mp_levels[d].msg_up_nn[1].weight._version for d, D in enumerate(dims)
-                             if D.msg_w_packed is not None],
+                       # the packed weights follow the message weights' versions; bias / eps are read in place (their addresses)
+                       marks=ops._marks([t for lin in lins for t in (lin.weight, lin.bias)]
+                                        + [t for d in range(n) for t in (self.mp_levels[d].eps1, self.mp_levels[d].eps2)]),   # (no ModuleList slice: a new container moves STRUCT_EPOCH)
                        launch=ops.LayerLaunch(dims, table))
             cache = _BLOCKED_CACHE.setdefault(self, {})
             if len(cache) > 64:
@@ -822,7 +823,17 @@ class SparseCINConv(torch.nn.Module):
         # the layers of one forward share their index tensors (mp/molec_models.py:110-116): the first
         # launch on them stores every item's sorted adjacency, the following ones load it back
         mode = _ffi.LAYER_CSR_LOAD if (CSR_REUSE and table.csr_key == key) else (_ffi.LAYER_CSR_STORE if CSR_REUSE else 0)
-        outs = ent['launch'].run([c.x for c in cochain_params], mode)
+        try:
+            outs = ent['launch'].run([c.x for c in cochain_params], mode)
+        except (ValueError, TypeError):
+            # features of another shape / type than the prepared launch takes (its own check, in C++ when the compiled
+            # binding runs it): the long way decides what serves them
+            _BLOCKED_CACHE.get(self, {}).pop(id(ent['plan']), None)
+            args = self._blocked_args(cochain_params, start_to_process)
+            if isinstance(args, str):
+                self.blocked_reason = args
+                return None
+            raise
         if mode == _ffi.LAYER_CSR_STORE:
             table.csr_key = key
         plan = ent['plan']
@@ -886,29 +897,24 @@ class SparseCINConv(torch.nn.Module):
         if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
                                         or any(c.x.requires_grad for c in cochain_params)):
             return False
-        F, n = ent['F'], len(cochain_params)
+        n = len(cochain_params)
         if n != len(ent['idx']) or cochain_params[0].block_plan is not ent['plan']:
             return False
+        if ent['epochs'] != (ops.STATE_EPOCH, ops.STRUCT_EPOCH):
+            return False              # a training kernel wrote the parameters (ops.state_changed) / a module tree changed
         for d, c in enumerate(cochain_params):
             up, bi, sh = ent['idx'][d]
-            if c.up_index is not up or c.boundary_index is not bi or getattr(c.kwargs.get('up_attr'), 'index', None) is not sh:
+            kw = c.kwargs
+            attr = kw.get('up_attr')
+            if c.up_index is not up or c.boundary_index is not bi or getattr(attr, 'index', None) is not sh:
                 return False          # other index tensors than the prepared launch points at
-            x = c.x
-            if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != F:
+            if up is not None and (not isinstance(attr, IndexedRows) or d + 1 >= n or attr.src is not cochain_params[d + 1].x):
                 return False
-            attr = c.kwargs.get('up_attr')
-            if c.up_index is not None and (not isinstance(attr, IndexedRows) or d + 1 >= n
-                                           or attr.src is not cochain_params[d + 1].x):
-                return False
-            b_attr = c.kwargs.get('boundary_attr')
+            b_attr = kw.get('boundary_attr')
             if b_attr is not None and (d == 0 or b_attr is not cochain_params[d - 1].x):
                 return False
-        if ent['epoch'] != ops.STATE_EPOCH:
-            return False              # a training kernel wrote the parameters (ops.state_changed)
-        for (d, lin), ver in zip(ent['lins'], ent['wver']):
-            if lin.weight._version != ver:
-                return False          # weights changed: rebuild (re-pack) through _blocked_args
-        return True
+        # (the features' shape / type / device: the launch's own check -- LayerLaunch.run raises, _propagate_blocked falls back)
+        return ops._marks_current(ent['marks'])   # weights changed: rebuild (re-pack) through _blocked_args
 
     def _blocked_args(self, cochain_params, start_to_process, training=False):
         if not BLOCKED_LAYER:

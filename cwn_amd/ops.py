@@ -2644,7 +2644,7 @@ class LayerLaunch:
             x = xs[d]
             if not x.is_contiguous():
                 x = x.contiguous()
-            if x.size(0) != self.rows[d] or x.size(1) != F:
+            if x.dim() != 2 or x.size(0) != self.rows[d] or x.size(1) != F:
                 raise ValueError('feature rows / width do not match the batch this launch was prepared for')
             if x.dtype != torch.float32 or x.device != self.dev:
                 raise TypeError('features must be float32 tensors on the GPU this launch was prepared for')

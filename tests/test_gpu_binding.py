@@ -58,8 +58,13 @@ def test_eager_forward_is_bit_identical_through_both_bindings(hidden):
             _forget(model)
             with _cext.binding(which):
                 first = fwd().clone()                 # builds the prepared launches with this binding
+                built = [next(iter(layers._BLOCKED_CACHE[c].values()))['launch'] for c in model.convs] + \
+                        [layers._MLP_CACHE[c][0] for c in model.convs]
                 second = fwd().clone()                # ... and runs them again from the caches
+                again = [next(iter(layers._BLOCKED_CACHE[c].values()))['launch'] for c in model.convs] + \
+                        [layers._MLP_CACHE[c][0] for c in model.convs]
             assert torch.equal(first, second)
+            assert all(a is b_ for a, b_ in zip(built, again))       # (nothing in a forward invalidates its own prepared launches)
             ent = layers._BLOCKED_CACHE[model.convs[0]]
             launch = next(iter(ent.values()))['launch']
             assert (launch._c is not None) == (which == 'compiled')
