@@ -27,6 +27,7 @@
 // stream at every size measured.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <mutex>
 #include "../../include/cwn_hip.h"
 #include "cwn_split.h"
@@ -37,14 +38,18 @@ namespace {
 using cwn::frag_cd;
 
 constexpr int kThreads = 512;
-constexpr int kV = 2;                             // float4 of an input tile per thread
-constexpr int kRT = 2;                            // 16-row tiles per wave
 
-// F = the width of every Linear (64 or 128).  A workgroup takes TM = 4096 / F rows (32 / 64): 8 waves x two
-// 16 x 16 tiles cover its TM x F output either way -- wave w owns column tile w % (F / 16) and the row tiles
-// 2 (w / (F / 16)), + 1.
-template <int F> struct Shape {
-    static constexpr int kTM = 4096 / F;
+// F = the width of every Linear (64 or 128); RT = 16-row tiles per wave (= float4 of an input tile per thread).  RT = 2 is
+// the form of rounds 2 - 4: a workgroup takes TM = 4096 / F rows (32 / 64) -- 8 waves x two 16 x 16 tiles cover its TM x F
+// output, wave w owns column tile w % (F / 16) and the row tiles 2 (w / (F / 16)), + 1 -- and owns its CU (130 - 138 KB of
+// LDS).  RT = 1 (round 5, F = 64 only): half the rows, 69 KB and <= 128 registers, TWO workgroups per CU -- for launches of
+// several rounds of workgroups (a REDDIT-like batch: 1185 workgroups, each a dependent chain of 9.7 us; the chain of one now
+// hides under the other's).  At F = 128 the same trade is a loss: a workgroup streams 576 KB of packed weights whatever its
+// rows, and L2 -> CU is what bounds that launch.  Per row the arithmetic is the same instruction sequence: the
+// two forms give bit-identical results.
+template <int F, int RT> struct Shape {
+    static constexpr int kRT = RT, kV = RT;
+    static constexpr int kTM = RT * 2048 / F;
     static constexpr int kNCT = F / 16;
     static constexpr int kKS = F / 32;
     static constexpr int kRowStride = F + 8;          // bf16 elements per LDS row (fragment reads conflict-free)
@@ -83,10 +88,11 @@ unsigned long long* g_mlp_stamps = nullptr;
 // 16 x 16 tile: 21.0 us -- two waves per column tile request the same weight, 192 KB a stage, and the address
 // unit (64 B per clock and CU) became the bound; and in every form the epilogue constants requested BEHIND
 // the next weight made each stage wait for that weight (loads return in order).
-template <int F>
-__global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
-    using S = Shape<F>;
+template <int F, int RT>
+__global__ __launch_bounds__(kThreads, RT == 1 ? 2 : 1) void update_mlp_kernel(MlpBatch B) {
+    using S = Shape<F, RT>;
     constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
+    constexpr int kRT = S::kRT, kV = S::kV;
     constexpr size_t kPlaneElems = S::kPlaneElems, kBufBytes = S::kBufBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* const bufA = reinterpret_cast<uint16_t*>(smem);                   // x_up, later h_b
@@ -228,6 +234,9 @@ __global__ __launch_bounds__(kThreads) void update_mlp_kernel(MlpBatch B) {
     // (VALU + LDS: bias, folded norm, ReLU, split into planes) sits in the instruction stream behind the MFMAs
     // of the OTHER branch's stage and runs while the matrix pipe works on them; the weight of the next
     // multiplication streams in k step by k step meanwhile.  Weight order: 1u, 1b, 2u, 2b, c(up half), c(b half).
+    // (round 5, tried at width 64 and dropped: all six weights requested up front into registers of their own -- a wave's
+    // slice of a weight is 24 registers, 214 in all without scratch -- instead of streaming one multiplication ahead: SLOWER,
+    // 23.3 -> 26.2 us per launch at the molhiv batch, 0.376 -> 0.391 ms REDDIT forward: the stages do not wait for weights.)
     MLP_STAMP(0);
     request_rows(vU, D.x_up, D.ldx_up);
     request_consts(cU, 0);
@@ -299,20 +308,30 @@ __global__ __launch_bounds__(256) void pack_mlp_weights_kernel(const float* __re
     *reinterpret_cast<uint4*>(dst + 2048) = pl;
 }
 
-template <int F>
+template <int F, int RT>
 int launch_mlp(MlpBatch& B, int64_t blocks, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&update_mlp_kernel<F>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Shape<F>::kLdsBytes);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&update_mlp_kernel<F, RT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Shape<F, RT>::kLdsBytes);
     });
     if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
 #ifdef CWN_MLP_TIMING
     B.stamps = g_mlp_stamps;
 #endif
-    update_mlp_kernel<F><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F>::kLdsBytes, stream>>>(B);
+    update_mlp_kernel<F, RT><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F, RT>::kLdsBytes, stream>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
+// rows per workgroup at F = 64: CWN_MLP_ROWS = 64 | 32 | auto (default; read once)
+int mlp_rows_mode() {
+    static const int mode = [] {
+        const char* e = getenv("CWN_MLP_ROWS");
+        if (e == nullptr) return 0;
+        return e[0] == '3' ? 32 : (e[0] == '6' ? 64 : 0);
+    }();
+    return mode;
 }
 
 }  // namespace
@@ -329,7 +348,14 @@ extern "C" int cwn_update_mlp_pack_weights_f32(const float* W, int64_t ldw, int3
 
 extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, int32_t F, cwn_stream_t stream_) {
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS || (F != 64 && F != 128)) return CWN_ERR_BAD_ARG;
-    const int TM = 4096 / F;
+    // F = 64: half-size workgroups, two per CU, once the launch is more than one round of full-size ones (see Shape)
+    int TM = 4096 / F;
+    if (F == 64) {
+        int64_t full = 0;
+        for (int i = 0; i < n_dims; ++i) full += dims[i].M > 0 ? (dims[i].M + TM - 1) / TM : 0;
+        const int mode = mlp_rows_mode();
+        if (mode == 32 || (mode == 0 && full > 256)) TM = 32;
+    }
     MlpBatch B{};
     B.n = n_dims;
     int64_t blocks = 0;
@@ -355,5 +381,6 @@ extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, int32_t F
     }
     for (int i = n_dims; i <= CWN_LAYER_MAX_DIMS; ++i) B.blk_start[i] = (int32_t)blocks;
     if (blocks == 0) return CWN_OK;
-    return F == 128 ? launch_mlp<128>(B, blocks, (hipStream_t)stream_) : launch_mlp<64>(B, blocks, (hipStream_t)stream_);
+    if (F == 128) return launch_mlp<128, 2>(B, blocks, (hipStream_t)stream_);
+    return TM == 32 ? launch_mlp<64, 1>(B, blocks, (hipStream_t)stream_) : launch_mlp<64, 2>(B, blocks, (hipStream_t)stream_);
 }

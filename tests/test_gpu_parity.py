@@ -1473,7 +1473,7 @@ def test_gemm_split_packed_weight_is_bit_identical(M):
 
 
 @pytest.mark.parametrize('F', [128, 64])
-@pytest.mark.parametrize('rows', [(3165, 3341, 304), (1, 33, 0), (64, 31, 32), (65, 129, 63)])
+@pytest.mark.parametrize('rows', [(3165, 3341, 304), (1, 33, 0), (64, 31, 32), (65, 129, 63), (9001, 11000, 1203)])
 def test_fused_update_mlp_vs_float64_and_three_launch_path(rows, F):
     """cwn_update_mlp_f32 (csrc/cwn_mlp.hip): update_up_nn, update_boundaries_nn and combine_nn of every
     dimension (mp/layers.py:193-199, :303-325) in one launch, against the same networks evaluated in float64
@@ -1527,6 +1527,20 @@ def test_fused_update_mlp_vs_float64_and_three_launch_path(rows, F):
         assert got[d].shape == (rows[d], F)
         gate(got[d], ref[d], f'fused update MLP dim {d} ({rows[d]} rows) vs float64')
         gate(three[d], ref[d], f'three-launch update MLP dim {d} vs float64')
+    if sum(rows) > 256 * 64 and F == 64:
+        # round 5: a launch of more than one round of workgroups runs half-size workgroups, two per CU (csrc/cwn_mlp.hip:
+        # Shape<64, 1>); the same rows in pieces of one round each run the full-size form -- per row the same arithmetic
+        pieces = []
+        with torch.no_grad():
+            for d in range(3):
+                parts = []
+                for lo in range(0, rows[d], 4096):
+                    sub = [torch.zeros(0, F, device=DEV)] * 6
+                    sub[2 * d], sub[2 * d + 1] = dev_outs[2 * d][lo:lo + 4096], dev_outs[2 * d + 1][lo:lo + 4096]
+                    parts.append(conv._dense_eval(plans, sub)[d])
+                pieces.append(torch.cat(parts))
+        assert all(torch.equal(a, b) for a, b in zip(got, pieces))
+        print(f'[gate] fused update MLP, {sum(rows)} rows at width 64: the two-per-CU form bit-identical to the full-size form')
 
 
 def test_gemm_split_path_identity_is_exact_and_fallbacks_are_untouched():
