@@ -39,25 +39,39 @@ using cwn::frag_cd;
 
 constexpr int kThreads = 512;
 
-// F = the width of every Linear (64 or 128); RT = 16-row tiles per wave (= float4 of an input tile per thread).  RT = 2 is
-// the form of rounds 2 - 4: a workgroup takes TM = 4096 / F rows (32 / 64) -- 8 waves x two 16 x 16 tiles cover its TM x F
-// output, wave w owns column tile w % (F / 16) and the row tiles 2 (w / (F / 16)), + 1 -- and owns its CU (130 - 138 KB of
-// LDS).  RT = 1 (round 5, F = 64 only): half the rows, 69 KB and <= 128 registers, TWO workgroups per CU -- for launches of
-// several rounds of workgroups (a REDDIT-like batch: 1185 workgroups, each a dependent chain of 9.7 us; the chain of one now
-// hides under the other's).  At F = 128 the same trade is a loss: a workgroup streams 576 KB of packed weights whatever its
-// rows, and L2 -> CU is what bounds that launch.  Per row the arithmetic is the same instruction sequence: the
-// two forms give bit-identical results.
-template <int F, int RT> struct Shape {
+// F = the width of every Linear (64 or 128).  A workgroup takes TM = 4096 / F rows (32 / 64): 8 waves x two 16 x 16 tiles
+// (RT = 2) cover its TM x F output -- wave w owns column tile w % (F / 16) and the row tiles 2 (w / (F / 16)), + 1.
+// Two schedules of the same arithmetic (bit-identical results):
+//   SEQ = false (rounds 2 - 4): the two branches ALTERNATE, the epilogue of a stage under the other branch's MFMAs; five
+//     plane buffers, 130 - 138 KB of LDS: the workgroup owns its CU.  The shortest chain per workgroup -- the form of a
+//     launch that is one round of workgroups (ZINC-128: 214 on 256 CUs).
+//   SEQ = true (round 5): the branches one after the other through THREE buffers (78 KB) within 128 registers: TWO
+//     workgroups per CU.  The stamps (tools/time_mlp_phases.py) say a workgroup is a chain of latencies -- load + split
+//     4.5 k cycles, six multiplications of ~1.1 k (the matrix pipe would need 0.77 k), four epilogues of ~1.1 k, at
+//     width 64 -- of which the pipe is busy for 29 %: in a launch of several rounds (REDDIT-like batches: 1142 workgroups;
+//     ZINC-2048: 3400) a second workgroup on the CU fills the rest.  (Half-SIZE workgroups, two per CU, were measured first:
+//     a half-size workgroup is the same chain of latencies, 15.5 k cycles against 16.1 k -- no gain.)
+template <int F, int RT, bool SEQ> struct Shape {
     static constexpr int kRT = RT, kV = RT;
     static constexpr int kTM = RT * 2048 / F;
     static constexpr int kNCT = F / 16;
     static constexpr int kKS = F / 32;
-    static constexpr int kRowStride = F + 8;          // bf16 elements per LDS row (fragment reads conflict-free)
+    // bf16 elements per LDS row.  F + 8: 16 bytes of padding make the fragment reads (16 rows x 16 B per quarter wave)
+    // conflict-free.  Sequential schedule at width 64: three padded buffers of 64 rows are 2 KB beyond half a CU, so the
+    // rows are unpadded and the 16-byte chunks of a row XOR-swizzled with (row >> 1) & 7 instead (col(): rows r, r + 1 differ
+    // in bank half, the eight row pairs of a fragment read in chunk).
+    static constexpr bool kSwizzle = SEQ && F == 64;
+    static constexpr int kRowStride = kSwizzle ? F : F + 8;
+    static __device__ __forceinline__ int col(int row, int c) {
+        if constexpr (kSwizzle) return (((c >> 3) ^ ((row >> 1) & 7)) << 3) | (c & 7);
+        else return c;
+    }
     static constexpr int kChunksPerTile = kKS * 3;    // packed weight: 1-KiB chunks per 16-column tile (k steps x planes)
     static constexpr size_t kPlaneElems = (size_t)kTM * kRowStride;
     static constexpr size_t kBufBytes = 3 * kPlaneElems * 2;   // three planes
-    static constexpr size_t kLdsBytes = 5 * kBufBytes;         // x_up / h_b, x_b, h1_up, h1_b, h_up
+    static constexpr size_t kLdsBytes = (SEQ ? 3 : 5) * kBufBytes;   // alternating: x_up / h_b, x_b, h1_up, h1_b, h_up
     static_assert(kTM * (F / 4) == kV * kThreads && (kTM / 16) * kNCT == 8 * kRT, "tile shape");
+    static_assert(!SEQ || 2 * kLdsBytes <= 160 * 1024, "two workgroups per CU");
 };
 
 struct MlpBatch {
@@ -88,9 +102,9 @@ unsigned long long* g_mlp_stamps = nullptr;
 // 16 x 16 tile: 21.0 us -- two waves per column tile request the same weight, 192 KB a stage, and the address
 // unit (64 B per clock and CU) became the bound; and in every form the epilogue constants requested BEHIND
 // the next weight made each stage wait for that weight (loads return in order).
-template <int F, int RT>
-__global__ __launch_bounds__(kThreads, RT == 1 ? 2 : 1) void update_mlp_kernel(MlpBatch B) {
-    using S = Shape<F, RT>;
+template <int F, int RT, bool SEQ>
+__global__ __launch_bounds__(kThreads, SEQ ? 2 : 1) void update_mlp_kernel(MlpBatch B) {
+    using S = Shape<F, RT, SEQ>;
     constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
     constexpr int kRT = S::kRT, kV = S::kV;
     constexpr size_t kPlaneElems = S::kPlaneElems, kBufBytes = S::kBufBytes;
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(kThreads, RT == 1 ? 2 : 1) void update_mlp_kernel(M
             const int idx = threadIdx.x + i * kThreads, r = idx / (F / 4), c4 = idx % (F / 4);
             uint2 ph, pm, pl;
             cwn::split4(v[i], ph, pm, pl);
-            uint16_t* dst = buf + (size_t)r * kRowStride + c4 * 4;
+            uint16_t* dst = buf + (size_t)r * kRowStride + S::col(r, c4 * 4);
             *reinterpret_cast<uint2*>(dst) = ph;
             *reinterpret_cast<uint2*>(dst + kPlaneElems) = pm;
             *reinterpret_cast<uint2*>(dst + 2 * kPlaneElems) = pl;
@@ -172,7 +186,8 @@ __global__ __launch_bounds__(kThreads, RT == 1 ? 2 : 1) void update_mlp_kernel(M
         for (int ks = 0; ks < kKS; ++ks) {
 #pragma unroll
             for (int rt = 0; rt < kRT; ++rt) {
-                const uint16_t* p = buf + (size_t)((rt0 + rt) * 16 + l15) * kRowStride + ks * 32 + kq * 8;
+                const int row = (rt0 + rt) * 16 + l15;
+                const uint16_t* p = buf + (size_t)row * kRowStride + S::col(row, ks * 32 + kq * 8);
                 const uint4 xh = *reinterpret_cast<const uint4*>(p);
                 const uint4 xm = *reinterpret_cast<const uint4*>(p + kPlaneElems);
                 const uint4 xl = *reinterpret_cast<const uint4*>(p + 2 * kPlaneElems);
@@ -219,7 +234,7 @@ __global__ __launch_bounds__(kThreads, RT == 1 ? 2 : 1) void update_mlp_kernel(M
             if (buf != nullptr) {
                 uint2 ph, pm, pl;
                 cwn::split4(make_float4(y[0], y[1], y[2], y[3]), ph, pm, pl);
-                uint16_t* dst = buf + (size_t)r * kRowStride + n0;
+                uint16_t* dst = buf + (size_t)r * kRowStride + S::col(r, n0);
                 *reinterpret_cast<uint2*>(dst) = ph;
                 *reinterpret_cast<uint2*>(dst + kPlaneElems) = pm;
                 *reinterpret_cast<uint2*>(dst + 2 * kPlaneElems) = pl;
@@ -237,6 +252,48 @@ __global__ __launch_bounds__(kThreads, RT == 1 ? 2 : 1) void update_mlp_kernel(M
     // (round 5, tried at width 64 and dropped: all six weights requested up front into registers of their own -- a wave's
     // slice of a weight is 24 registers, 214 in all without scratch -- instead of streaming one multiplication ahead: SLOWER,
     // 23.3 -> 26.2 us per launch at the molhiv batch, 0.376 -> 0.391 ms REDDIT forward: the stages do not wait for weights.)
+    if constexpr (SEQ) {
+        // one branch after the other through three buffers; weights in the order they are packed: 1u, 2u, 1b, 2b, c(up), c(b)
+        uint16_t* const b0 = bufA;         // x_up, later h_up
+        uint16_t* const b1 = bufC;         // x_b, later h_b
+        uint16_t* const b2 = bufB;         // the stage-1 outputs
+        MLP_STAMP(0);
+        request_rows(vU, D.x_up, D.ldx_up);
+        request_consts(cU, 0);
+        request_weight(wfA, 0);
+        request_rows(vB, D.x_b, D.ldx_b);
+        stage_rows(vU, b0);
+        stage_rows(vB, b1);
+        lds_barrier();
+        MLP_STAMP(1);
+        clear(accU); multiply(accU, b0, wfA, wfB, 1);       // stage 1, upper branch     (W2u streams in)
+        MLP_STAMP(2);
+        finish(accU, cU, b2);
+        request_consts(cU, 1);
+        lds_barrier();
+        clear(accU); multiply(accU, b2, wfB, wfA, 2);       // stage 2, upper branch     (W1b streams in)
+        finish(accU, cU, b0);                               // h_up (x_up's planes are dead)
+        request_consts(cU, 2);
+        lds_barrier();
+        MLP_STAMP(3);
+        clear(accU); multiply(accU, b1, wfA, wfB, 3);       // stage 1, boundary branch  (W2b streams in)
+        finish(accU, cU, b2);
+        request_consts(cU, 3);
+        lds_barrier();
+        MLP_STAMP(4);
+        clear(accU); multiply(accU, b2, wfB, wfA, 4);       // stage 2, boundary branch  (Wc, upper half)
+        finish(accU, cU, b1);                               // h_b
+        request_consts(cU, 4);
+        lds_barrier();
+        MLP_STAMP(5);
+        clear(accU); multiply(accU, b0, wfA, wfB, 5);       // combine: Wc[:, :F] h_up   (Wc, boundary half) ...
+        MLP_STAMP(6);
+        multiply(accU, b1, wfB, wfA, -1);                   // ... + Wc[:, F:] h_b (cat order of mp/layers.py:199)
+        MLP_STAMP(7);
+        finish(accU, cU, nullptr);
+        MLP_STAMP(8);
+        return;
+    }
     MLP_STAMP(0);
     request_rows(vU, D.x_up, D.ldx_up);
     request_consts(cU, 0);
@@ -308,28 +365,29 @@ __global__ __launch_bounds__(256) void pack_mlp_weights_kernel(const float* __re
     *reinterpret_cast<uint4*>(dst + 2048) = pl;
 }
 
-template <int F, int RT>
+template <int F, int RT, bool SEQ>
 int launch_mlp(MlpBatch& B, int64_t blocks, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&update_mlp_kernel<F, RT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Shape<F, RT>::kLdsBytes);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&update_mlp_kernel<F, RT, SEQ>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Shape<F, RT, SEQ>::kLdsBytes);
     });
     if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
 #ifdef CWN_MLP_TIMING
     B.stamps = g_mlp_stamps;
 #endif
-    update_mlp_kernel<F, RT><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F, RT>::kLdsBytes, stream>>>(B);
+    update_mlp_kernel<F, RT, SEQ><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F, RT, SEQ>::kLdsBytes, stream>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
-// rows per workgroup at F = 64: CWN_MLP_ROWS = 64 | 32 | auto (default; read once)
-int mlp_rows_mode() {
+// which schedule: CWN_MLP_FORM = 5 (alternating, five buffers) | 3 (sequential, three buffers, two per CU) | auto (default;
+// read once): the sequential form for launches of more workgroups than the chip has CUs
+int mlp_form_mode() {
     static const int mode = [] {
-        const char* e = getenv("CWN_MLP_ROWS");
+        const char* e = getenv("CWN_MLP_FORM");
         if (e == nullptr) return 0;
-        return e[0] == '3' ? 32 : (e[0] == '6' ? 64 : 0);
+        return e[0] == '3' ? 3 : (e[0] == '5' ? 5 : 0);
     }();
     return mode;
 }
@@ -348,14 +406,7 @@ extern "C" int cwn_update_mlp_pack_weights_f32(const float* W, int64_t ldw, int3
 
 extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, int32_t F, cwn_stream_t stream_) {
     if (dims == nullptr || n_dims < 1 || n_dims > CWN_LAYER_MAX_DIMS || (F != 64 && F != 128)) return CWN_ERR_BAD_ARG;
-    // F = 64: half-size workgroups, two per CU, once the launch is more than one round of full-size ones (see Shape)
-    int TM = 4096 / F;
-    if (F == 64) {
-        int64_t full = 0;
-        for (int i = 0; i < n_dims; ++i) full += dims[i].M > 0 ? (dims[i].M + TM - 1) / TM : 0;
-        const int mode = mlp_rows_mode();
-        if (mode == 32 || (mode == 0 && full > 256)) TM = 32;
-    }
+    const int TM = 4096 / F;
     MlpBatch B{};
     B.n = n_dims;
     int64_t blocks = 0;
@@ -381,6 +432,9 @@ extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, int32_t F
     }
     for (int i = n_dims; i <= CWN_LAYER_MAX_DIMS; ++i) B.blk_start[i] = (int32_t)blocks;
     if (blocks == 0) return CWN_OK;
-    if (F == 128) return launch_mlp<128, 2>(B, blocks, (hipStream_t)stream_);
-    return TM == 32 ? launch_mlp<64, 1>(B, blocks, (hipStream_t)stream_) : launch_mlp<64, 2>(B, blocks, (hipStream_t)stream_);
+    const int mode = mlp_form_mode();
+    const bool seq = mode == 3 || (mode == 0 && blocks > 256);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (F == 128) return seq ? launch_mlp<128, 2, true>(B, blocks, stream) : launch_mlp<128, 2, false>(B, blocks, stream);
+    return seq ? launch_mlp<64, 2, true>(B, blocks, stream) : launch_mlp<64, 2, false>(B, blocks, stream);
 }

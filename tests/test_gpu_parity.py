@@ -1527,9 +1527,10 @@ def test_fused_update_mlp_vs_float64_and_three_launch_path(rows, F):
         assert got[d].shape == (rows[d], F)
         gate(got[d], ref[d], f'fused update MLP dim {d} ({rows[d]} rows) vs float64')
         gate(three[d], ref[d], f'three-launch update MLP dim {d} vs float64')
-    if sum(rows) > 256 * 64 and F == 64:
-        # round 5: a launch of more than one round of workgroups runs half-size workgroups, two per CU (csrc/cwn_mlp.hip:
-        # Shape<64, 1>); the same rows in pieces of one round each run the full-size form -- per row the same arithmetic
+    if sum(-(-r // (4096 // F)) for r in rows) > 256:
+        # round 5: a launch of more workgroups than the chip has CUs runs the sequential schedule, two workgroups per CU
+        # (csrc/cwn_mlp.hip: Shape<F, 2, true>); the same rows in pieces of one round each run the alternating one -- per row
+        # the same arithmetic
         pieces = []
         with torch.no_grad():
             for d in range(3):
@@ -1540,7 +1541,7 @@ def test_fused_update_mlp_vs_float64_and_three_launch_path(rows, F):
                     parts.append(conv._dense_eval(plans, sub)[d])
                 pieces.append(torch.cat(parts))
         assert all(torch.equal(a, b) for a, b in zip(got, pieces))
-        print(f'[gate] fused update MLP, {sum(rows)} rows at width 64: the two-per-CU form bit-identical to the full-size form')
+        print(f'[gate] fused update MLP, {sum(rows)} rows at width {F}: the two-per-CU schedule bit-identical to the alternating one')
 
 
 def test_gemm_split_path_identity_is_exact_and_fallbacks_are_untouched():

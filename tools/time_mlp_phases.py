@@ -11,14 +11,15 @@ L = _ffi.lib()
 L.cwn_mlp_debug_stamps.argtypes = [C.c_void_p]
 L.cwn_mlp_debug_stamps.restype = None
 torch.manual_seed(0)
-F = 128
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 conv = SparseCINConv(F, F, F, None, None, None, None, max_dim=2, hidden=F, act_module=torch.nn.ReLU, layer_dim=F,
                      use_coboundaries=True).to(dev).eval()
-rows = (3165, 3341, 304)
+rows = tuple(int(a) for a in sys.argv[2:5]) if len(sys.argv) > 4 else (3165, 3341, 304)
+TM = int(os.environ.get('TM', 4096 // F))
 outs = []
 for n in rows:
     outs += [torch.randn(n, F, device=dev), torch.randn(n, F, device=dev)]
-nblk = sum((n + 31) // 32 for n in rows)
+nblk = sum((n + TM - 1) // TM for n in rows)
 stamps = torch.zeros(nblk, 16, dtype=torch.int64, device=dev)
 L.cwn_mlp_debug_stamps(stamps.data_ptr())
 with torch.no_grad():
@@ -39,3 +40,10 @@ names = ['rows + W0 + split (both branches)', 'multiply 1u', 'multiply 1b + fini
 print(f'whole: mean {np.mean(st[:, 8] - st[:, 0]):.0f} max {np.max(st[:, 8] - st[:, 0])}')
 for k, nm in enumerate(names):
     print(f'  {nm:40s} mean {d[:, k].mean():8.0f}  max {d[:, k].max():8d}')
+
+# when do the workgroups start and end (ticks from the first start): rounds of the launch
+t0 = st[:, 0].min()
+start, end = np.sort(st[:, 0] - t0), np.sort(st[:, 8] - t0)
+q = [0, 10, 25, 50, 75, 90, 100]
+print('start percentiles', [int(np.percentile(start, p)) for p in q])
+print('end   percentiles', [int(np.percentile(end, p)) for p in q])
