@@ -166,7 +166,10 @@ def _fold_norm(norm, width: int):
     if (not isinstance(norm, BN) or norm.training or norm.running_mean is None
             or norm.num_features != width):
         return None     # batch statistics (training) are not a fixed affine
-    tensors = [t for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var) if t is not None]
+    # (num_batches_tracked: torch's native batch_norm writes the running statistics of a TRAINING-mode forward without moving
+    # their version counters; the module's own `num_batches_tracked.add_(1)` does move one -- found by tools/fuzz_round5.py in
+    # round 5: an eval forward after a training-mode forward through the torch modules folded the OLD statistics)
+    tensors = [t for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.num_batches_tracked) if t is not None]
     key = (ops.STATE_EPOCH,) + tuple((t.data_ptr(), t._version) for t in tensors)
     hit = getattr(norm, '_cwn_fold', None)
     if hit is not None and hit[0] == key:
@@ -1068,7 +1071,7 @@ class SparseCINConv(torch.nn.Module):
                         sources += [lin.weight, lin.bias]
                         if isinstance(norm, BN):
                             norms.append(norm)
-                            sources += [norm.weight, norm.bias, norm.running_mean, norm.running_var]
+                            sources += [norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.num_batches_tracked]
                 launch = ops.MlpLaunch(mdims, sources)
                 _MLP_CACHE[self] = (launch, (start, len(plans), len(outs)), norms)
                 res = launch.run(hs_up, hs_bd)

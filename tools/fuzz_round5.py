@@ -4,7 +4,9 @@
   * cwn_embedding_bwd_f32 (the ballot form over several tables) vs index_add in float64;
   * cwn_dropout_f32 vs the numpy Philox restatement (tests/_philox_ref.py), odd shapes and strides;
   * cwn_head_f32 / cwn_head_bwd_f32 with jumping-knowledge blocks, split pooling, empty complexes and absent dimensions vs float64;
-  * cwn_loss_cols_f32(CWN_LOSS_CE) vs torch.nn.functional.cross_entropy in float64.
+  * cwn_loss_cols_f32(CWN_LOSS_CE) vs torch.nn.functional.cross_entropy in float64;
+  * the prepared launches of the eager forward (both bindings) vs a deep copy of the model that has none, while parameters,
+    submodules and the mode change under them.
 
 usage: python tools/fuzz_round5.py [rounds] [seed]      (prints one line per failure, exits non-zero if any)"""
 import os
@@ -184,16 +186,98 @@ def fuzz_ce():
     check(ok, f'cross-entropy rows={rows} cols={cols}')
 
 
+_prep = {}
+
+
+def fuzz_prepared():
+    """The prepared launches of the eager forward (ops.LayerLaunch / MlpLaunch / FrontLaunch / HeadLaunch and their caches in
+    layers / models): a model is run over a few batches in random order while, between calls, a random parameter or buffer is
+    written in place, a submodule replaced, the mode switched or the binding changed -- every output must equal that of a deep
+    copy of the model made at that moment (a copy has no prepared launches: it goes the long way)."""
+    import copy
+    from cwn_amd import _cext
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import zinc_like_complexes
+    if not _prep or rng.random() < 0.05:
+        hidden = int(rng.choice([64, 128]))
+        torch.manual_seed(int(rng.integers(0, 1 << 30)))
+        model = EmbedSparseCIN(28, 4, int(rng.integers(1, 3)), int(rng.integers(1, 4)), hidden, dropout_rate=0.0, max_dim=2,
+                               jump_mode=rng.choice([None, 'cat']), readout=str(rng.choice(['sum', 'mean'])), embed_edge=True,
+                               use_coboundaries=True).to(dev).eval()
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.normal_(0.0, 0.3)
+                    m.running_var.uniform_(0.5, 1.5)
+        bs = [ComplexBatch.from_complex_list(zinc_like_complexes(int(rng.integers(1, 40)), int(rng.integers(0, 1 << 20)), 6, n_lo=6, n_hi=26),
+                                             max_dim=2).to(dev) for _ in range(3)]
+        x0 = [[None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3)] for b in bs]
+        _prep.clear()
+        _prep.update(model=model, bs=bs, x0=x0, cfg=f'hidden {hidden} layers {len(model.convs)} jump {model.jump_mode} readout {model.readout} '
+                                                    f'edge table {model.e_embed_init is not None}')
+    model, bs, x0 = _prep['model'], _prep['bs'], _prep['x0']
+    what = int(rng.integers(0, 8))
+    with torch.no_grad():
+        params = [p for p in model.parameters()] + [b for b in model.buffers() if b.dtype.is_floating_point]
+        if what == 0:
+            t = params[int(rng.integers(0, len(params)))]
+            t.mul_(1.0 + 0.1 * float(rng.random()))
+        elif what == 1:
+            conv = model.convs[int(rng.integers(0, len(model.convs)))]
+            lvl = conv.mp_levels[int(rng.integers(0, 3))]
+            net = [lvl.update_up_nn, lvl.update_boundaries_nn, lvl.combine_nn][int(rng.integers(0, 3))]
+            old = net[0]
+            net[0] = torch.nn.Linear(old.in_features, old.out_features).to(dev)
+            _prep['last'] = f'replaced conv {model.convs.index(conv) if hasattr(model.convs, "index") else "?"} dim {list(conv.mp_levels).index(lvl)} net {[id(n) for n in (lvl.update_up_nn, lvl.update_boundaries_nn, lvl.combine_nn)].index(id(net))}'
+        elif what == 2:
+            model.train(bool(rng.random() < 0.3))
+    k = int(rng.integers(0, len(bs)))
+
+    def run(m, which):
+        for d in range(3):
+            bs[k].cochains[d]._x = x0[k][d]
+        with torch.no_grad(), _cext.binding(which):
+            return m(bs[k]).clone()
+    which = 'compiled' if (rng.random() < 0.7 and _cext.ext() is not None) else 'ctypes'
+    # (the copy first: building ANY module moves ops.STRUCT_EPOCH, so the model's first run below rebuilds its launches and
+    #  the second runs them from the caches -- both must equal the copy's)
+    ref = run(copy.deepcopy(model), 'ctypes')
+    got1 = run(model, which)
+    got2 = run(model, which)
+    if not (torch.equal(got1, ref) and torch.equal(got2, ref)) and not _prep.get('diag'):
+        _prep['diag'] = True                       # the first failure: which stage of the forward differs, and whose update launch
+
+        def partial(m):
+            for d in range(3):
+                bs[k].cochains[d]._x = x0[k][d]
+            with torch.no_grad():
+                return {kk: v.clone() for kk, v in m(bs[k], include_partial=True)[1].items()}
+        cp = copy.deepcopy(model)
+        a, c = partial(model), partial(cp)
+        print('  first difference by stage (model vs a fresh copy):',
+              {kk: float((a[kk] - c[kk]).abs().max()) for kk in a if not torch.equal(a[kk], c[kk])}, flush=True)
+        sd, sc = model.state_dict(), cp.state_dict()
+        print('  state_dict differences:', [kk for kk in sd if not torch.equal(sd[kk], sc[kk])], flush=True)
+    check(torch.equal(got1, ref) and torch.equal(got2, ref),
+          f'prepared launches: change {what}, batch {k}, binding {which}, training {model.training}, max|delta| '
+          f'{float((got1 - ref).abs().max()):.2e} / {float((got2 - ref).abs().max()):.2e}; {_prep["cfg"]}; {_prep.get("last")}')
+    model.eval()
+
+
 for r in range(ROUNDS):
-    for fn in (fuzz_csr, fuzz_embedding, fuzz_dropout, fuzz_head, fuzz_ce):
+    for fn in (fuzz_csr, fuzz_embedding, fuzz_dropout, fuzz_head, fuzz_ce, fuzz_prepared):
         try:
             fn()
         except Exception as e:                       # an exception is a failure of the case, not of the run
+            if not fails:
+                import traceback
+                traceback.print_exc()
             check(False, f'{fn.__name__} raised {type(e).__name__}: {e}')
 torch.cuda.synchronize()
 try:
     csr.check_errors(dev)
 except IndexError as e:
     check(False, f'device error word: {e}')
-print(f'{ROUNDS} rounds x 5 kernels: {len(fails)} failures')
+print(f'{ROUNDS} rounds x 6 checks: {len(fails)} failures')
 sys.exit(1 if fails else 0)
