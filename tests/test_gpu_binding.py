@@ -24,10 +24,10 @@ def _model_and_batch(B=24, hidden=128, L=2):
     b = ComplexBatch.from_complex_list(zinc_like_complexes(B, 5, 6), max_dim=2).to(DEV)
     x0 = [None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3)]
 
-    def fwd():
+    def fwd(m=None):
         for d in range(3):
             b.cochains[d]._x = x0[d]
-        return model(b)
+        return (m or model)(b)
     return model, b, fwd
 
 
@@ -184,6 +184,10 @@ def test_prepared_update_launch_notices_what_changes_under_it(which):
         assert torch.equal(got, fresh())
         model.eval()
         assert torch.equal(fwd(), fresh())
+        # ... and the running statistics that training-mode forward wrote (torch's native batch_norm: without moving their
+        # version counters) are the ones the next eval forward folds: a deep copy has no cached fold
+        import copy
+        assert torch.equal(fwd(), fwd(copy.deepcopy(model)))
 
 
 def test_a_forward_reads_the_error_word_once_at_its_end():
