@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_update_mlp_pack_weights_both_many_f32', 'cwn_layer_pack_weights_both_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_ex_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_slots', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_collate_guard', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
@@ -125,7 +125,7 @@ class MlpDim(C.Structure):
     _fields_ = [('x_up', C.c_void_p), ('x_b', C.c_void_p), ('w_packed', C.c_void_p * 6),
                 ('bias', C.c_void_p * 5), ('scale', C.c_void_p * 5), ('shift', C.c_void_p * 5),
                 ('y', C.c_void_p), ('M', C.c_int64), ('ldx_up', C.c_int64), ('ldx_b', C.c_int64), ('ldy', C.c_int64),
-                ('m_dev', C.c_void_p)]
+                ('m_dev', C.c_void_p), ('in_width', C.c_int32), ('pad_', C.c_int32)]
 
 
 BN_SLOTS = 4                   # = CWN_BN_SLOTS

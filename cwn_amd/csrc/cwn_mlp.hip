@@ -130,12 +130,20 @@ __global__ __launch_bounds__(kThreads, SEQ ? 2 : 1) void update_mlp_kernel(MlpBa
     // an input tile: TM rows x 32 float4, two per thread, row-contiguous; rows past M are clamped, not guarded
     typedef float4 RowRegs[kV];
     RowRegs vU, vB;
+    // (narrow input -- cwn_mlp_dim.in_width columns, the rest of the tile zero: the first weight is zero-padded to match)
+    const int in_w = D.in_width > 0 && D.in_width < F ? D.in_width : F;          // (uniform)
     auto request_rows = [&](RowRegs& v, const float* X, int64_t ld) {
 #pragma unroll
         for (int i = 0; i < kV; ++i) {
             const int idx = threadIdx.x + i * kThreads, r = idx / (F / 4), c4 = idx % (F / 4);
             const int64_t row = row0 + r < D.M ? row0 + r : D.M - 1;
-            v[i] = reinterpret_cast<const float4*>(X + row * ld)[c4];
+            if (in_w == F) {
+                v[i] = reinterpret_cast<const float4*>(X + row * ld)[c4];
+            } else {
+                const float* src = X + row * ld + c4 * 4;
+                const int left = in_w - c4 * 4;
+                v[i] = make_float4(left > 0 ? src[0] : 0.f, left > 1 ? src[1] : 0.f, left > 2 ? src[2] : 0.f, left > 3 ? src[3] : 0.f);
+            }
         }
     };
     auto stage_rows = [&](const RowRegs& v, uint16_t* buf) {   // split the tile ONCE per element into the three planes
@@ -418,8 +426,16 @@ extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, int32_t F
         B.d[i] = D;
         if (D.M == 0) continue;
         if (D.x_up == nullptr || D.x_b == nullptr || D.y == nullptr) return CWN_ERR_BAD_ARG;
-        if (D.ldx_up < F || D.ldx_b < F || D.ldy < F || D.ldx_up % 4 || D.ldx_b % 4 || D.ldy % 4) return CWN_ERR_BAD_ARG;
-        if (!(al16(D.x_up) && al16(D.x_b) && al16(D.y))) return CWN_ERR_ALIGN;
+        if (D.in_width < 0 || D.in_width > F) return CWN_ERR_BAD_ARG;
+        const bool narrow = D.in_width > 0 && D.in_width < F;
+        if (D.ldy < F || D.ldy % 4) return CWN_ERR_BAD_ARG;
+        if (narrow) {
+            if (D.ldx_up < D.in_width || D.ldx_b < D.in_width) return CWN_ERR_BAD_ARG;
+            if (((uintptr_t)D.x_up & 3u) || ((uintptr_t)D.x_b & 3u) || !al16(D.y)) return CWN_ERR_ALIGN;
+        } else {
+            if (D.ldx_up < F || D.ldx_b < F || D.ldx_up % 4 || D.ldx_b % 4) return CWN_ERR_BAD_ARG;
+            if (!(al16(D.x_up) && al16(D.x_b) && al16(D.y))) return CWN_ERR_ALIGN;
+        }
         for (int k = 0; k < 6; ++k) {
             if (D.w_packed[k] == nullptr) return CWN_ERR_BAD_ARG;
             if (!al16(D.w_packed[k])) return CWN_ERR_ALIGN;

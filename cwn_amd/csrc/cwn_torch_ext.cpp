@@ -169,7 +169,8 @@ class MlpCall {
             const at::Tensor &u = xs_up[i], &b = xs_b[i];
             if (u.dim() != 2 || b.dim() != 2) return py::none();
             const int64_t M = u.size(0);
-            if (M > cap_ || b.size(0) != M || u.size(1) != F_ || b.size(1) != F_ || u.scalar_type() != at::kFloat ||
+            const int64_t w = dims_[i].in_width > 0 && dims_[i].in_width < F_ ? dims_[i].in_width : F_;    // (narrow inputs)
+            if (M > cap_ || b.size(0) != M || u.size(1) != w || b.size(1) != w || u.scalar_type() != at::kFloat ||
                 b.scalar_type() != at::kFloat || !u.device().is_cuda() || u.device().index() != dev_ || b.device() != u.device())
                 return py::none();
             rows[i] = M;
@@ -189,8 +190,8 @@ class MlpCall {
             a.x_b = b.data_ptr<float>();
             a.y = base + off * F_;
             a.M = rows[i];
-            a.ldx_up = rows[i] > 1 ? u.stride(0) : F_;
-            a.ldx_b = rows[i] > 1 ? b.stride(0) : F_;
+            a.ldx_up = rows[i] > 1 ? u.stride(0) : u.size(1);
+            a.ldx_b = rows[i] > 1 ? b.stride(0) : b.size(1);
             a.m_dev = nullptr;                   // (capacity-sized launches -- _ffi.DYN_ROWS -- stay on the ctypes path)
             off += rows[i];
         }

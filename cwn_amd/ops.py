@@ -899,7 +899,8 @@ def head_split(rows_total: int, n_complexes: int) -> int:
     per = rows_total / n_complexes
     if per < 512 or n_complexes >= 512:
         return 1
-    return int(max(1, min(32, min(per // 128, -(-512 // n_complexes)))))
+    # (one 128-row chunk per workgroup and dimension where the chip has room: REDDIT-32 forward 0.340 -> 0.332 ms against two)
+    return int(max(1, min(32, min(per // 128, -(-1024 // n_complexes)))))
 
 
 def _head_parts(x):
@@ -1954,36 +1955,66 @@ class MlpDim:
 def update_mlp_applies(dims: Sequence[MlpDim]) -> bool:
     """The fused update / combine launch serves networks whose Linear layers are all 64 or all 128 wide."""
     cap = int(_ffi.lib().cwn_update_mlp_max_rows())
-    F = int(dims[0].x_up.size(1))
+    if any(len(D.linears) != 5 for D in dims):
+        return False
+    F = mlp_width(dims)
     if F not in (64, 128):
         return False
     for D in dims:
-        if D.x_up.size(0) > cap or D.x_up.size(1) != F or D.x_b.size(1) != F or len(D.linears) != 5:
+        w_in = int(D.x_up.size(1))           # (narrower than F: the first layer of a model over raw features, cwn_mlp_dim.in_width)
+        if D.x_up.size(0) > cap or w_in > F or w_in < 1 or D.x_b.size(1) != w_in:
             return False
-        if any(tuple(l.weight.shape) != (F, F) for l in D.linears[:4]) or tuple(D.linears[4].weight.shape) != (F, 2 * F):
+        shapes = [tuple(l.weight.shape) for l in D.linears]
+        if shapes != [(F, w_in), (F, F), (F, w_in), (F, F), (F, 2 * F)]:
             return False
     return True
+
+
+def mlp_width(dims: Sequence[MlpDim]) -> int:
+    """F of cwn_update_mlp_f32: the width of the second Linear of the upper branch (the inputs may be narrower)."""
+    return int(dims[0].linears[1].weight.size(0))
+
+
+_padded_weights = {}
+
+
+def _mlp_first_weight(weight: Tensor, F: int) -> Tensor:
+    """A first-stage weight [F, w_in] as the [F, F] matrix the launch multiplies: itself, or -- w_in < F -- zero-padded
+    (cached per weight version; the input tile's other columns are zeros too)."""
+    if weight.size(1) == F:
+        return weight
+    key = id(weight)
+    ver = (weight.data_ptr(), weight._version, STATE_EPOCH, tuple(weight.shape))
+    hit = _padded_weights.get(key)
+    if hit is not None and hit[0] == ver and hit[1]() is weight:
+        return hit[2]
+    pad = torch.zeros(F, F, dtype=torch.float32, device=weight.device)
+    pad[:, :weight.size(1)] = weight.detach()
+    _padded_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _padded_weights.pop(k, None)), pad)
+    return pad
 
 
 def update_mlp(dims: Sequence[MlpDim]) -> List[Tensor]:
     """mp/layers.py:193-199 for every dimension in ONE launch (csrc/cwn_mlp.hip); inference only."""
     dev = dims[0].x_up.device
-    F = int(dims[0].x_up.size(1))
+    F = mlp_width(dims)
     arr = (_ffi.MlpDim * len(dims))()
     outs, keep = [], []
     for i, D in enumerate(dims):
         xu, xb = _rowmajor(D.x_up, 'x_up'), _rowmajor(D.x_b, 'x_b')
+        w_in = int(xu.size(1))
         y = torch.empty(xu.size(0), F, dtype=torch.float32, device=dev)
         outs.append(y)
         a = arr[i]
         a.x_up, a.x_b, a.y, a.M = xu.data_ptr(), xb.data_ptr(), y.data_ptr(), xu.size(0)
-        a.ldx_up = xu.stride(0) if xu.size(0) > 1 else F
-        a.ldx_b = xb.stride(0) if xb.size(0) > 1 else F
+        a.ldx_up = xu.stride(0) if xu.size(0) > 1 else w_in
+        a.ldx_b = xb.stride(0) if xb.size(0) > 1 else w_in
         a.ldy = F
+        a.in_width = w_in if w_in < F else 0
         a.m_dev = _ffi.dyn(xu.size(0))
         packed = []
-        for l in D.linears[:4]:
-            packed += list(pack_mlp_weight(l.weight))
+        for k_, l in enumerate(D.linears[:4]):
+            packed += list(pack_mlp_weight(_mlp_first_weight(l.weight, F) if k_ in (0, 2) else l.weight))
         packed += list(pack_mlp_weight(D.linears[4].weight))
         for k, pk in enumerate(packed):
             a.w_packed[k] = pk.data_ptr()
@@ -2005,15 +2036,19 @@ class MlpLaunch:
 
     def __init__(self, dims: Sequence[MlpDim], sources: Sequence[Tensor]):
         self.n = len(dims)
-        self.F = F = int(dims[0].x_up.size(1))
+        self.F = F = mlp_width(dims)
         self.dev = dims[0].x_up.device
         self.arr = (_ffi.MlpDim * self.n)()
         self.keep = []
+        self.w_in = [int(D.x_up.size(1)) for D in dims]            # input columns per dimension (< F: cwn_mlp_dim.in_width)
         for i, D in enumerate(dims):
             a = self.arr[i]
+            a.in_width = self.w_in[i] if self.w_in[i] < F else 0
             packed = []
-            for l in D.linears[:4]:
-                packed += list(pack_mlp_weight(l.weight))
+            for k_, l in enumerate(D.linears[:4]):
+                first = _mlp_first_weight(l.weight, F) if k_ in (0, 2) else l.weight
+                self.keep.append(first)
+                packed += list(pack_mlp_weight(first))
             packed += list(pack_mlp_weight(D.linears[4].weight))
             for k, pk in enumerate(packed):
                 a.w_packed[k] = pk.data_ptr()
@@ -2052,9 +2087,9 @@ class MlpLaunch:
         if len(xs_up) != n or len(xs_b) != n:
             return None
         rows = []
-        for xu, xb in zip(xs_up, xs_b):
+        for xu, xb, w in zip(xs_up, xs_b, self.w_in):
             M = xu.size(0)
-            if (M > self.cap or xb.size(0) != M or xu.dim() != 2 or xb.dim() != 2 or xu.size(1) != F or xb.size(1) != F
+            if (M > self.cap or xb.size(0) != M or xu.dim() != 2 or xb.dim() != 2 or xu.size(1) != w or xb.size(1) != w
                     or xu.dtype != torch.float32 or xb.dtype != torch.float32 or xu.device != self.dev or xb.device != self.dev):
                 return None
             rows.append(M)
@@ -2066,8 +2101,8 @@ class MlpLaunch:
             hold += [xu, xb]                       # (a contiguous copy lives until the launch is enqueued)
             a = self.arr[i]
             a.x_up, a.x_b, a.y, a.M = xu.data_ptr(), xb.data_ptr(), base + off * 4 * F, M
-            a.ldx_up = xu.stride(0) if M > 1 else F
-            a.ldx_b = xb.stride(0) if M > 1 else F
+            a.ldx_up = xu.stride(0) if M > 1 else self.w_in[i]
+            a.ldx_b = xb.stride(0) if M > 1 else self.w_in[i]
             a.m_dev = _ffi.dyn(M)
             off += M
         rc = self.fn(self.arr, n, F, _ffi.stream_ptr(self.dev))

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 20
+#define CWN_ABI_VERSION 21
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -531,6 +531,11 @@ typedef struct cwn_mlp_dim {
     float* y;                   /* [M, F], row stride ldy */
     int64_t M, ldx_up, ldx_b, ldy;
     const int64_t* m_dev;       /* or NULL: actual rows (M = capacity) */
+    int32_t in_width;           /* 0 (= F) or 1 .. F - 1: x_up / x_b have only this many columns (round 5: the first layer of a
+                                   model over raw features -- REDDIT-BINARY's one constant feature, mp/models.py:112-260); the
+                                   first weight of each branch is then the zero-padded [F, F] form of Linear(in_width -> F), the
+                                   row strides may be any value >= in_width and the two pointers need 4-byte alignment only */
+    int32_t pad_;
 } cwn_mlp_dim;
 
 int cwn_update_mlp_f32(const cwn_mlp_dim* dims_host, int n_dims, int32_t F, cwn_stream_t stream);

@@ -1544,6 +1544,65 @@ def test_fused_update_mlp_vs_float64_and_three_launch_path(rows, F):
         print(f'[gate] fused update MLP, {sum(rows)} rows at width {F}: the two-per-CU schedule bit-identical to the alternating one')
 
 
+@pytest.mark.parametrize('F', [64, 128])
+@pytest.mark.parametrize('w_in', [1, 3, 20])
+@pytest.mark.parametrize('rows', [(3165, 7000, 304), (70, 0, 3)])
+def test_fused_update_mlp_over_narrow_inputs(rows, w_in, F):
+    """The first layer of a model over raw features (REDDIT-BINARY: one constant feature, mp/models.py:112-260; exp/scripts/
+    mpsn-redditb.sh): update networks Linear(w_in -> F) ... with w_in < F.  cwn_update_mlp_f32 takes the narrow rows as they are
+    (cwn_mlp_dim.in_width; the first weights zero-padded once per version) -- against float64 and against the grouped launches
+    it replaces (three generic GEMM launches, 84 us of a 0.34 ms REDDIT-32 forward)."""
+    from cwn_amd import layers
+    from cwn_amd.layers import SparseCINConv
+    torch.manual_seed(sum(rows) + F + w_in)
+    conv = SparseCINConv(w_in, w_in, w_in, None, None, None, None, max_dim=2, hidden=F, act_module=torch.nn.ReLU,
+                         layer_dim=w_in, use_coboundaries=False, graph_norm=torch.nn.Identity).eval()
+    g = torch.Generator().manual_seed(1)
+    outs = []
+    for n in rows:
+        outs += [torch.randn(n, w_in, generator=g) * 2, torch.randn(n, w_in, generator=g) * 2]
+    conv64 = copy.deepcopy(conv).double()
+    ref = []
+    with torch.no_grad():
+        for d in range(3):
+            lvl = conv64.mp_levels[d]
+            if rows[d] == 0:
+                ref.append(torch.zeros(0, F, dtype=torch.float64))
+                continue
+            ref.append(lvl.combine_nn(torch.cat([lvl.update_up_nn(outs[2 * d].double()), lvl.update_boundaries_nn(outs[2 * d + 1].double())], dim=-1)))
+    conv = conv.to(DEV)
+    dev_outs = [o.to(DEV) for o in outs]
+
+    def run(fused):
+        prev = layers.FUSED_UPDATE_MLP
+        layers.FUSED_UPDATE_MLP = fused
+        try:
+            with torch.no_grad():
+                return conv._dense_eval(['blocked'] * 3, dev_outs)
+        finally:
+            layers.FUSED_UPDATE_MLP = prev
+    three, got, again = run(False), run(True), run(True)
+    assert conv in layers._MLP_CACHE and layers._MLP_CACHE[conv][0].w_in == [w_in] * 3       # the one-launch form served it
+    for d in range(3):
+        assert got[d].shape == (rows[d], F) and torch.equal(got[d], again[d])
+        gate(got[d], ref[d], f'fused update MLP over {w_in}-wide inputs, width {F}, dim {d} ({rows[d]} rows) vs float64')
+        gate(three[d], ref[d], f'three-launch form, dim {d} vs float64')
+    # a strided view (columns of a wider matrix) is taken as it is
+    wide = [torch.randn(n, w_in + 5, generator=g).to(DEV) for n in rows for _ in range(2)]
+    with torch.no_grad():
+        a = conv._dense_eval(['blocked'] * 3, [w[:, 2:2 + w_in] for w in wide])
+        b = conv._dense_eval(['blocked'] * 3, [w[:, 2:2 + w_in].contiguous() for w in wide])
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    # the first weight written in place: the padded form follows
+    with torch.no_grad():
+        conv.mp_levels[1].update_up_nn[0].weight.mul_(2.0)
+        c = conv._dense_eval(['blocked'] * 3, dev_outs)
+    assert not torch.equal(c[1], got[1]) or rows[1] == 0
+    layers._MLP_CACHE.pop(conv, None)
+    with torch.no_grad():
+        assert all(torch.equal(u, v) for u, v in zip(c, conv._dense_eval(['blocked'] * 3, dev_outs)))
+
+
 def test_gemm_split_path_identity_is_exact_and_fallbacks_are_untouched():
     from cwn_amd import ops
     g = torch.Generator().manual_seed(3)
