@@ -102,7 +102,10 @@ unsigned long long* g_mlp_stamps = nullptr;
 // 16 x 16 tile: 21.0 us -- two waves per column tile request the same weight, 192 KB a stage, and the address
 // unit (64 B per clock and CU) became the bound; and in every form the epilogue constants requested BEHIND
 // the next weight made each stage wait for that weight (loads return in order).
-template <int F, int RT, bool SEQ>
+// NARROW: some dimension's inputs have fewer than F columns (cwn_mlp_dim.in_width) -- a build of its own, so that the row loads
+// of the common form stay one unconditional 16-byte load (with the test inside, uniform as it is, the ZINC-128 launch went
+// 10.7 -> 12.0 us: the compiler schedules loads behind a branch differently).
+template <int F, int RT, bool SEQ, bool NARROW>
 __global__ __launch_bounds__(kThreads, SEQ ? 2 : 1) void update_mlp_kernel(MlpBatch B) {
     using S = Shape<F, RT, SEQ>;
     constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
@@ -131,13 +134,13 @@ __global__ __launch_bounds__(kThreads, SEQ ? 2 : 1) void update_mlp_kernel(MlpBa
     typedef float4 RowRegs[kV];
     RowRegs vU, vB;
     // (narrow input -- cwn_mlp_dim.in_width columns, the rest of the tile zero: the first weight is zero-padded to match)
-    const int in_w = D.in_width > 0 && D.in_width < F ? D.in_width : F;          // (uniform)
+    const int in_w = NARROW && D.in_width > 0 && D.in_width < F ? D.in_width : F;          // (uniform)
     auto request_rows = [&](RowRegs& v, const float* X, int64_t ld) {
 #pragma unroll
         for (int i = 0; i < kV; ++i) {
             const int idx = threadIdx.x + i * kThreads, r = idx / (F / 4), c4 = idx % (F / 4);
             const int64_t row = row0 + r < D.M ? row0 + r : D.M - 1;
-            if (in_w == F) {
+            if (!NARROW || in_w == F) {
                 v[i] = reinterpret_cast<const float4*>(X + row * ld)[c4];
             } else {
                 const float* src = X + row * ld + c4 * 4;
@@ -373,19 +376,19 @@ __global__ __launch_bounds__(256) void pack_mlp_weights_kernel(const float* __re
     *reinterpret_cast<uint4*>(dst + 2048) = pl;
 }
 
-template <int F, int RT, bool SEQ>
+template <int F, int RT, bool SEQ, bool NARROW>
 int launch_mlp(MlpBatch& B, int64_t blocks, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&update_mlp_kernel<F, RT, SEQ>),
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&update_mlp_kernel<F, RT, SEQ, NARROW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Shape<F, RT, SEQ>::kLdsBytes);
     });
     if (attr_err != hipSuccess) return CWN_ERR_LAUNCH;
 #ifdef CWN_MLP_TIMING
     B.stamps = g_mlp_stamps;
 #endif
-    update_mlp_kernel<F, RT, SEQ><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F, RT, SEQ>::kLdsBytes, stream>>>(B);
+    update_mlp_kernel<F, RT, SEQ, NARROW><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F, RT, SEQ>::kLdsBytes, stream>>>(B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
@@ -451,6 +454,12 @@ extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, int32_t F
     const int mode = mlp_form_mode();
     const bool seq = mode == 3 || (mode == 0 && blocks > 256);
     hipStream_t stream = (hipStream_t)stream_;
-    if (F == 128) return seq ? launch_mlp<128, 2, true>(B, blocks, stream) : launch_mlp<128, 2, false>(B, blocks, stream);
-    return seq ? launch_mlp<64, 2, true>(B, blocks, stream) : launch_mlp<64, 2, false>(B, blocks, stream);
+    bool narrow = false;
+    for (int i = 0; i < n_dims; ++i) narrow = narrow || (dims[i].M > 0 && dims[i].in_width > 0 && dims[i].in_width < F);
+    if (narrow) {
+        if (F == 128) return seq ? launch_mlp<128, 2, true, true>(B, blocks, stream) : launch_mlp<128, 2, false, true>(B, blocks, stream);
+        return seq ? launch_mlp<64, 2, true, true>(B, blocks, stream) : launch_mlp<64, 2, false, true>(B, blocks, stream);
+    }
+    if (F == 128) return seq ? launch_mlp<128, 2, true, false>(B, blocks, stream) : launch_mlp<128, 2, false, false>(B, blocks, stream);
+    return seq ? launch_mlp<64, 2, true, false>(B, blocks, stream) : launch_mlp<64, 2, false, false>(B, blocks, stream);
 }

@@ -45,10 +45,10 @@ def test_headline_kernels_keep_their_registers(table):
     assert len(mlp) >= 3              # <128>, <64>: alternating, one workgroup per CU; sequential (round 5): two per CU
     for n, v in mlp.items():
         # 512 threads = two waves per SIMD; the sequential schedule shares its CU with a second workgroup: four per SIMD
-        two_per_cu = n.endswith('Lb1EE') or 'Lb1E' in n
+        two_per_cu = 'Li2ELb1E' in n               # update_mlp_kernel<F, RT = 2, SEQ = true, NARROW>
         assert v['max_flat_workgroup_size'] == 512 and v['vgpr_count'] <= (128 if two_per_cu else 256), (n, v)
         assert v['vgpr_spill_count'] == v['sgpr_spill_count'] == v['private_segment_fixed_size'] == 0, (n, v)
-    assert any('Lb1E' in n for n in mlp)
+    assert any('Li2ELb1E' in n for n in mlp) and len(mlp) == 8
     for n, v in table.items():
         if n.startswith(('gemm_split_kernel<', 'gemm_tn_kernel<', 'norm_kernel<', 'gather_rows_kernel<')) or 'collate_kernel' in n:
             assert v['vgpr_spill_count'] == 0 and v['private_segment_fixed_size'] == 0, (n, v)
