@@ -822,3 +822,81 @@ def test_folded_batchnorm_follows_a_training_mode_forward_of_the_torch_module():
     assert torch.allclose(sc2, want) and torch.allclose(sh2, bn.bias - bn.running_mean * want)
     assert not torch.allclose(sc1, sc2)
     assert _fold_norm(bn.train(), 8) is None                              # batch statistics are not a fixed affine
+
+
+def test_round5_host_helpers_head_split_padded_first_weight_and_narrow_shapes():
+    """Pure host logic added in round 5: the head's pooling split (bounded, 1 for molecules), the zero-padded first weight of an
+    update network over narrow inputs (cached per weight version), and which Linear shapes the one-launch update form takes."""
+    import torch
+    from cwn_amd import ops
+    # pooling split: molecules never split; REDDIT-like complexes of thousands of cells: one 128-row chunk per workgroup at most
+    assert ops.head_split(6800, 128) == 1 and ops.head_split(28000, 512) == 1 and ops.head_split(0, 0) == 1
+    p = ops.head_split(73000, 32)
+    assert 8 <= p <= 32 and p <= 73000 / 32 / 128 + 1
+    assert ops.head_split(10 ** 7, 2) == 32
+    # the padded first weight
+    w = torch.nn.Parameter(torch.randn(64, 3))
+    pad = ops._mlp_first_weight(w, 64)
+    assert pad.shape == (64, 64) and torch.equal(pad[:, :3], w.detach()) and float(pad[:, 3:].abs().max()) == 0.0
+    assert ops._mlp_first_weight(w, 64) is pad                              # cached
+    with torch.no_grad():
+        w.mul_(2.0)
+    pad2 = ops._mlp_first_weight(w, 64)
+    assert pad2 is not pad and torch.equal(pad2[:, :3], w.detach())         # ... per version
+    full = torch.nn.Parameter(torch.randn(64, 64))
+    assert ops._mlp_first_weight(full, 64) is full
+    # shapes of the one-launch update form
+    def dim(w_in, F, rows=5, bad=None):
+        lin = lambda i, o: torch.nn.Linear(i, o)
+        lins = [lin(w_in, F), lin(F, F), lin(w_in, F), lin(F, F), lin(2 * F, F)]
+        if bad is not None:
+            lins[bad] = lin(F + 1, F)
+        return ops.MlpDim(x_up=torch.zeros(rows, w_in), x_b=torch.zeros(rows, w_in), linears=lins, folds=[(None, None)] * 5)
+    assert ops.update_mlp_applies([dim(64, 64)]) and ops.update_mlp_applies([dim(1, 64)]) and ops.update_mlp_applies([dim(20, 128), dim(20, 128)])
+    assert not ops.update_mlp_applies([dim(64, 96)])                        # widths other than 64 / 128
+    assert not ops.update_mlp_applies([dim(130, 128)])                      # wider than the networks
+    assert not ops.update_mlp_applies([dim(64, 64, bad=1)]) and not ops.update_mlp_applies([dim(64, 64, bad=4)])
+    assert ops.mlp_width([dim(1, 128)]) == 128
+
+
+def test_deferred_checks_read_the_error_word_once_and_not_after_an_exception(monkeypatch):
+    """csr.deferred_checks: inside the block check_errors only notes the device; the block's end reads the word once per device;
+    a block left by an exception reads nothing; nesting reads at the outermost end."""
+    import torch
+    from cwn_amd import csr
+    reads = []
+
+    class Word:
+        def __init__(self, v):
+            self.v = v
+
+        def item(self):
+            reads.append(self.v)
+            return self.v
+
+        def zero_(self):
+            self.v = 0
+    word = Word(0)
+    monkeypatch.setattr(csr, '_err_flag', lambda dev: word)
+    dev = torch.device('cpu')
+    csr.check_errors(dev)
+    assert reads == [0]
+    with csr.deferred_checks():
+        csr.check_errors(dev)
+        with csr.deferred_checks():
+            csr.check_errors(dev)
+        assert reads == [0]                       # nothing read inside, nor at the inner end
+    assert reads == [0, 0]                        # once at the outermost end
+    with pytest.raises(RuntimeError):
+        with csr.deferred_checks():
+            csr.check_errors(dev)
+            raise RuntimeError('the forward failed')
+    assert reads == [0, 0]                        # a block left by an exception reads nothing ...
+    csr.check_errors(dev)
+    assert reads == [0, 0, 0]                     # ... and leaves nothing pending
+    word.v = 2
+    e0 = csr.ERROR_EPOCH
+    with pytest.raises(IndexError, match='source index'):
+        with csr.deferred_checks():
+            csr.check_errors(dev)
+    assert word.v == 0 and csr.ERROR_EPOCH == e0 + 1
