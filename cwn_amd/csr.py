@@ -10,6 +10,8 @@ batched call as well).
 import weakref
 from typing import List, Optional, Sequence
 
+import threading
+
 import torch
 
 from . import _ffi
@@ -217,7 +219,12 @@ def _describe(flag: int) -> str:
     return 'index out of range in adjacency: ' + ', '.join(what)
 
 
-_deferred = [0, []]         # nesting depth of deferred_checks, devices with a check pending
+class _Deferred(threading.local):       # per thread: nesting depth of deferred_checks, devices with a check pending
+    def __init__(self):
+        self.depth, self.pending = 0, []
+
+
+_deferred = _Deferred()
 
 
 class deferred_checks:
@@ -228,13 +235,13 @@ class deferred_checks:
     forward -- after its launches are enqueued; nothing is read when the block is left by an exception."""
 
     def __enter__(self):
-        _deferred[0] += 1
+        _deferred.depth += 1
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        _deferred[0] -= 1
-        if _deferred[0] == 0:
-            pending, _deferred[1] = _deferred[1], []
+        _deferred.depth -= 1
+        if _deferred.depth == 0:
+            pending, _deferred.pending = _deferred.pending, []
             if exc_type is None:
                 for dev in pending:
                     check_errors(dev)
@@ -245,9 +252,9 @@ def check_errors(dev) -> None:
     """Raise the IndexError of any out-of-range index seen by plan builds that skipped the host
     sync (overlap mode / stream capture).  One device sync."""
     dev = torch.device(dev)
-    if _deferred[0] > 0:
-        if dev not in _deferred[1]:
-            _deferred[1].append(dev)
+    if _deferred.depth > 0:
+        if dev not in _deferred.pending:
+            _deferred.pending.append(dev)
         return
     err = _err_flag(dev)
     flag = int(err.item())
