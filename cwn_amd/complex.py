@@ -81,7 +81,10 @@ class Cochain(object):
     @x.setter
     def x(self, new_x):
         if new_x is not None:
-            assert self.num_cells == (new_x.size(0) if torch.is_tensor(new_x) else len(new_x))
+            n = self.__num_cells__                    # (the common case without the property's detours: set_xs per layer)
+            if n is None:
+                n = self.num_cells
+            assert n == (new_x.size(0) if isinstance(new_x, Tensor) else len(new_x))
         self._x = new_x
 
     @property
@@ -428,10 +431,13 @@ class Complex(object):
             boundary_index = cells.boundary_index
             if down_x is not None:
                 boundary_features = down_x
-        params = CochainMessagePassingParams(x, upper_index, lower_index, up_attr=upper_features,
-                                             down_attr=lower_features,
-                                             boundary_attr=boundary_features,
-                                             boundary_index=boundary_index)
+        # (= CochainMessagePassingParams(x, upper_index, lower_index, up_attr=..., down_attr=..., boundary_attr=...,
+        #  boundary_index=...), mp/cell_mp.py:527-550, field by field: this runs once per dimension per layer of an eager forward)
+        params = CochainMessagePassingParams.__new__(CochainMessagePassingParams)
+        params.x, params.up_index, params.down_index = x, upper_index, lower_index
+        params.kwargs = {'up_attr': upper_features, 'down_attr': lower_features, 'boundary_attr': boundary_features,
+                         'boundary_index': boundary_index}
+        params.boundary_index, params.boundary_attr = boundary_index, boundary_features
         # engine extension: what the co-boundary stream of this dimension reads -- the
         # next dimension's boundary_index (row 0 = a cell of THIS dimension, row 1 = its coface) and the
         # cofaces' features.  Plain attributes: the reference's kwargs are left as they are.
@@ -439,7 +445,8 @@ class Complex(object):
         if up_c is not None and up_c.boundary_index is not None:
             params.coboundary_index = up_c.boundary_index
             params.coboundary_attr = up_c._x
-        params.num_cells = cells.num_cells   # engine extension: sizes without a device sync
+        n_cells = cells.__num_cells__
+        params.num_cells = n_cells if n_cells is not None else cells.num_cells   # engine extension: sizes without a device sync
         params.block_plan = self.block_plan() if _plan is False else _plan  # engine extension: the batch's item table (or None)
         return params
 

@@ -145,10 +145,57 @@ def _two_per_cu_wins(n0: int, n1: int) -> bool:
     return 1.3 * r1 < r0
 
 
+class ByModule:
+    """A mapping keyed by a module's IDENTITY that forgets a module when it dies -- weakref.WeakKeyDictionary's job at a plain
+    dict's price: `get` there builds a weak reference per call (~0.7 us; five look-ups per layer of an eager forward).  An
+    entry holds a weak reference with a callback of its own, so a recycled id() never answers for another module."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, module, default=None):
+        hit = self._d.get(id(module))
+        return hit[1] if hit is not None and hit[0]() is module else default
+
+    def __contains__(self, module) -> bool:
+        hit = self._d.get(id(module))
+        return hit is not None and hit[0]() is module
+
+    def __getitem__(self, module):
+        hit = self._d.get(id(module))
+        if hit is None or hit[0]() is not module:
+            raise KeyError(module)
+        return hit[1]
+
+    def __setitem__(self, module, value) -> None:
+        key = id(module)
+        self._d[key] = (weakref.ref(module, lambda _r, k=key, d=self._d: d.pop(k, None) if (d.get(k) or (None,))[0] is _r else None), value)
+
+    def __delitem__(self, module) -> None:
+        if module not in self:
+            raise KeyError(module)
+        del self._d[id(module)]
+
+    def pop(self, module, *default):
+        if module in self:
+            return self._d.pop(id(module))[1]
+        if default:
+            return default[0]
+        raise KeyError(module)
+
+    def setdefault(self, module, default):
+        if module not in self:
+            self[module] = default
+        return self._d[id(module)][1]
+
+    def __len__(self) -> int:
+        return len(self._d)
+
+
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
-_BLOCKED_CACHE = weakref.WeakKeyDictionary()
-_MLP_CACHE = weakref.WeakKeyDictionary()          # layer module -> (ops.MlpLaunch, (start, dims, outputs), BatchNorm modules)
-_FRONT_CACHE = weakref.WeakKeyDictionary()        # embedding front module -> {id(boundary_index_1): (ops.FrontLaunch, (rings?, reduce))}
+_BLOCKED_CACHE = ByModule()
+_MLP_CACHE = ByModule()            # layer module -> (ops.MlpLaunch, (start, dims, outputs), BatchNorm modules)
+_FRONT_CACHE = ByModule()          # embedding front module -> {id(boundary_index_1): (ops.FrontLaunch, (rings?, reduce))}
 
 
 def _ffi_dyn() -> bool:

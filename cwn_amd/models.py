@@ -22,7 +22,7 @@ from .csr import cached_adjacency, deferred_checks
 from .layers import CINConv, EdgeCINConv, EmbedVEWithReduce, InitReduceConv, SparseCINConv
 
 
-_HEAD_CACHE = weakref.WeakKeyDictionary()      # model -> {id(plan): (ops.HeadLaunch, the batch's BlockPlan, head signature, readout dims)}
+_HEAD_CACHE = layers.ByModule()      # model -> {id(plan): (ops.HeadLaunch, the batch's BlockPlan, head signature, readout dims)}
 
 
 def _one_check(forward):

@@ -900,3 +900,35 @@ def test_deferred_checks_read_the_error_word_once_and_not_after_an_exception(mon
         with csr.deferred_checks():
             csr.check_errors(dev)
     assert word.v == 0 and csr.ERROR_EPOCH == e0 + 1
+
+
+def test_by_module_mapping_forgets_dead_modules_and_never_answers_for_a_recycled_id():
+    """layers.ByModule (the prepared launches' caches: a plain dict keyed by id(module) with a weak reference per entry)."""
+    import gc
+    import torch
+    from cwn_amd.layers import ByModule
+    c = ByModule()
+    m1, m2 = torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+    assert c.get(m1) is None and m1 not in c and len(c) == 0
+    c[m1] = 'a'
+    assert c[m1] == 'a' and m1 in c and m2 not in c and c.get(m2, 7) == 7
+    d = c.setdefault(m2, {})
+    d['k'] = 1
+    assert c.setdefault(m2, {}) is d
+    assert c.pop(m1) == 'a' and c.pop(m1, None) is None
+    with pytest.raises(KeyError):
+        c.pop(m1)
+    with pytest.raises(KeyError):
+        c[m1]
+    c[m1] = 'b'
+    c[m1] = 'c'                      # (the replaced entry's weak reference must not take the new entry with it)
+    gc.collect()
+    assert c[m1] == 'c'
+    del c[m1]
+    del m2
+    gc.collect()
+    assert len(c) == 0
+    import copy
+    net = torch.nn.Sequential(torch.nn.Linear(2, 2))
+    c[net] = 'x'
+    assert copy.deepcopy(net) not in c           # a copy is another module: it has no prepared launches
