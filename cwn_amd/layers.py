@@ -191,6 +191,12 @@ class ByModule:
     def __len__(self) -> int:
         return len(self._d)
 
+    def clear(self) -> None:
+        self._d.clear()
+
+    def values(self):
+        return [v for _r, v in self._d.values()]
+
 
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
 _BLOCKED_CACHE = ByModule()
