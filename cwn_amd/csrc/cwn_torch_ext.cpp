@@ -73,6 +73,9 @@ class TensorMarks {
 };
 
 // ---- cwn_layer_fused_f32 over a prepared descriptor array (ops.LayerLaunch) --------------------------------------------------
+// (A prepared launch patches ITS copy of the array per call: one caller at a time, like its ctypes form -- two streams that
+// want the same layer concurrently prepare two launches.  A handle from layer_register / mlp_register keeps the C++ object alive,
+// not the tensors its descriptors point at: those belong to the Python launch object.)
 class LayerCall {
  public:
     LayerCall(uintptr_t arr, int64_t arr_bytes, int n, int F, std::vector<int64_t> rows, uintptr_t err, uintptr_t fn, int dev)
