@@ -122,6 +122,129 @@ def gemm_roofline(flops, us, split, io_bytes, narrow, traffic):
             'frac_of_fp32_mfma_peak_157': round(tf / MFMA_F32_PEAK_TF, 4)}
 
 
+LINE_BUDGET = 6144          # bytes: the driver keeps a bounded tail of stdout and parses ONE line (round 5's 22 KB line was lost)
+
+
+def _pick(d, keys):
+    return None if not isinstance(d, dict) else {k: d[k] for k in keys if d.get(k) is not None}
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 1] + '~'
+
+
+def _rocprof_avg_us(full):
+    """Average duration of the roofline kernel in the committed rocprofv3 --kernel-trace --stats summary of the same
+    command (profiles/r*_kernel_avg.json, written by tools/collect_kernel_avg.py from the .md summaries); None when no
+    summary covers this workload."""
+    try:
+        cfg = full.get('config') or {}
+        tj = load_profile_json('kernel_avg')
+        return (tj.get('entries') or {}).get(cfg.get('key'), {}).get('avg_us')
+    except (OSError, ValueError, KeyError, AttributeError):
+        return None
+
+
+def slim_line(full, detail_path=None):
+    """The ONE stdout line: the contract's keys + `roofline`, `cpu_baseline`, scalars of the secondary legs.  Everything
+    else lives in `detail_path` (bench_detail.json) and on stderr.  Always shorter than LINE_BUDGET bytes: the optional
+    blocks are dropped one by one (least important first) should a future leg outgrow it."""
+    rf = full.get('roofline') or None
+    roofline = None
+    if rf:
+        roofline = _pick(rf, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us',
+                              'algorithmic_bytes_per_launch', 'compulsory_bytes_per_launch', 'frac_vs_pmc_traffic',
+                              'launches_per_step', 'share_of_step', 'residency'))
+        roofline['traffic'] = rf.get('traffic')           # (null = no PMC pass covers this configuration: stated, not dropped)
+        roofline['kernel'] = _short(rf.get('kernel'), 96)
+        roofline['avg_launch_us_source'] = 'hip events (graph replay of back-to-back launches, this run)'
+        rp = _rocprof_avg_us(full)
+        if rp and rf.get('algorithmic_bytes_per_launch'):
+            roofline['avg_launch_us_rocprof'] = rp
+            roofline['frac_rocprof'] = round(rf['algorithmic_bytes_per_launch'] / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline['traffic_source'] = 'profiles/*_traffic.json (committed PMC pass, same kernel + batch)'
+    cb = full.get('cpu_baseline') or None
+    cpu = None
+    if cb:
+        cpu = _pick(cb, ('value', 'unit', 'cores', 'kind', 'cpu_model', 'gpu_over_cpu', 'full_forward_cells_per_s',
+                         'train_fwd_bwd_cells_per_s'))
+        cpu['sample'] = _short(cb.get('sample'), 200)
+    cfg = _pick(full.get('config'), ('workload', 'batch_per_gpu', 'hidden', 'layers', 'cells_per_batch', 'N', 'E_up', 'B',
+                                     'launch', 'layer_kernel', 'parallelism'))
+    if cfg:
+        cfg['workload'] = _short(cfg.get('workload'), 200)
+        cfg['layer_kernel'] = _short(cfg.get('layer_kernel'), 80)
+    sec = full.get('secondary') or {}
+    fb = sec.get('fresh_batches') or {}
+    secondary = {
+        'full_forward_ms': sec.get('full_forward_ms'),
+        'full_forward_cells_per_s': sec.get('full_forward_cells_per_s'),
+        'forward_breakdown_us': sec.get('forward_breakdown'),
+        'train_step_ms': (sec.get('train_step') or {}).get('ms_per_step'),
+        'train_step_cells_per_s': (sec.get('train_step') or {}).get('cells_per_s'),
+        'eager_ms_per_step': (sec.get('eager_launches') or {}).get('ms_per_step'),
+        'eager_full_forward_ms': (sec.get('eager_launches') or {}).get('full_forward_ms'),
+        'concurrent_streams_cells_per_s': (sec.get('concurrent_streams') or {}).get('cells_per_s'),
+        'collate_device_ms': (sec.get('collate') or {}).get('device_ms_per_batch'),
+        'collate_cpu_oracle_ms': (sec.get('collate') or {}).get('cpu_oracle_ms_per_batch'),
+        'fresh_batches': {k: _pick(fb.get(k), ('cells_per_s', 'ms_per_step', 'vs_fixed_batch_replay'))
+                          for k in ('propagate', 'forward', 'train') if isinstance(fb.get(k), dict)} or None,
+    }
+    wls = {}
+    for name, w in (sec.get('workloads') or {}).items():
+        if not isinstance(w, dict):
+            continue
+        if 'failed' in w:
+            wls[name] = {'failed': _short(w['failed'], 80)}
+            continue
+        e = {'value': w.get('value'), 'ms_per_step': w.get('ms_per_step'),
+             'frac': (w.get('roofline') or {}).get('frac'), 'frac_step': (w.get('roofline_step') or {}).get('frac'),
+             'forward_ms': w.get('full_forward_ms'), 'train_ms': w.get('train_step_ms')}
+        f2 = w.get('fresh_batches') or {}
+        for k in ('propagate', 'forward', 'train'):
+            v = (f2.get(k) or {}).get('vs_fixed_batch_replay') if isinstance(f2.get(k), dict) else None
+            if v is not None:
+                e['fresh_' + k] = v
+        wls[name] = {k: v for k, v in e.items() if v is not None}
+    secondary['workloads'] = wls or None
+    secondary = {k: v for k, v in secondary.items() if v is not None}
+    out = {k: full.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                    'scaling', 'vs_baseline', 'dtype', 'data')}
+    out['config'] = cfg
+    out['roofline'] = roofline
+    out['roofline_step'] = _pick(full.get('roofline_step'), ('bound', 'achieved', 'peak', 'unit', 'frac', 'algorithmic_bytes_per_step'))
+    out['roofline_mlp'] = _pick(full.get('roofline_mlp'), ('bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us'))
+    out['cpu_baseline'] = cpu
+    mg = full.get('multi_gpu') or {}
+    out['multi_gpu'] = _pick(mg, ('rccl_ranks', 'backend', 'train_ms_per_step', 'exposed_allreduce_ms_per_step', 'bucket_bytes'))
+    out['timing'] = _pick(full.get('timing'), ('rounds', 'timed_steps', 'timed_region_ms', 'ms_per_step_single_K_step_region'))
+    out['secondary'] = secondary
+    out['leg_seconds'] = full.get('leg_seconds')
+    out['detail'] = detail_path
+    for drop in ('leg_seconds', 'timing', 'roofline_mlp', ('secondary', 'workloads'), ('secondary', 'fresh_batches'), 'secondary'):
+        if len(json.dumps(out)) < LINE_BUDGET:
+            break
+        if isinstance(drop, tuple):
+            (out.get(drop[0]) or {}).pop(drop[1], None)
+        else:
+            out.pop(drop, None)
+    return out
+
+
+def emit(full):
+    """Detail to bench_detail.json (beside this file; CWN_BENCH_DETAIL overrides) and to stderr, the slim line to stdout."""
+    path = os.environ.get('CWN_BENCH_DETAIL', os.path.join(ROOT, 'bench_detail.json'))
+    try:
+        with open(path, 'w') as fh:
+            json.dump(full, fh, indent=1)
+        shown = os.path.relpath(path, ROOT)
+    except OSError as e:
+        print(f'[bench] could not write {path}: {e}', file=sys.stderr)
+        shown = None
+    print('[bench detail] ' + json.dumps(full), file=sys.stderr, flush=True)
+    print(json.dumps(slim_line(full, shown)), flush=True)
+
+
 def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixed_forward_ms, fixed_train_ms, task='regression', mode='blocked'):
     """secondary.fresh_batches: propagate scope, full forward and full training step over >= 64 distinct shuffled batches per
     epoch drawn by cwn_amd.packed.PackedLoader, each scope ONE captured graph over a StaticBatch (see the call site)."""
@@ -340,9 +463,43 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
     return out
 
 
+def self_launch(n):
+    """Re-exec this command line under torch.distributed.run with n ranks on this node (127.0.0.1 rendezvous on a free
+    port); the children see WORLD_SIZE and run main() as ranks.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    if not os.environ.get('CWN_BENCH_SHARE_GPU') == '1' and torch.cuda.device_count() < n:
+        raise SystemExit(f'bench.py: --gpus {n} but this node shows {torch.cuda.device_count()} GPU(s) '
+                         '(CWN_BENCH_SHARE_GPU=1 runs the ranks on one GPU over gloo: control flow only)')
+    s_ = socket.socket()
+    s_.bind(('127.0.0.1', 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] --gpus %d without WORLD_SIZE: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    LEGS = {}
+    t_leg = [time.perf_counter()]
+
+    def mark(name):
+        """wall seconds since the previous mark, filed under `name` (the line's `leg_seconds`: where a default run goes)"""
+        now = time.perf_counter()
+        LEGS[name] = LEGS.get(name, 0.0) + now - t_leg[0]
+        t_leg[0] = now
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` by itself: launch the N ranks the contract describes (one process per GPU over RCCL)
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} '
+                         f'(or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
@@ -376,6 +533,8 @@ def main():
         dist = None
 
     # what a first multi-GPU run needs to read off the line: how many ranks talk over what, which device each one holds
+    if dist is not None:
+        world = dist.get_world_size()       # what the line reports is what the group holds
     MULTI = {'rccl_ranks': world, 'backend': None if dist is None else dist.get_backend(),
              'forced_data_parallel_form_on_one_rank': bool(world == 1 and dist is not None),
              'transport': None if dist is None else ('gloo over one shared GPU (CWN_BENCH_SHARE_GPU: control-flow test)' if share
@@ -630,6 +789,7 @@ def main():
             wall = max_over_ranks(wall)
         return {'dt': wall, 'rounds': rounds_, 'round_ms': round_ms, 'k_region_s': k_wall}
 
+    mark('setup')
     use_graph = not args.no_graph
     MIN_REGION_S = float(os.environ.get('CWN_BENCH_MIN_REGION_S', '0.05'))
     try:
@@ -661,6 +821,7 @@ def main():
         dist.all_reduce(cells_total)
     value = float(cells_total.item()) / dt
 
+    mark('primary')
     # secondary: the full model forward (embedding, 4 conv layers incl. MLPs/BN, readout, head)
     SKIP = set(filter(None, os.environ.get('CWN_BENCH_SKIP', '').split(',')))   # debugging: legs to skip
     if args.brief:
@@ -678,6 +839,7 @@ def main():
         print(f'[bench] full-forward graph capture failed ({type(e).__name__}); eager', file=sys.stderr)
         torch.cuda.synchronize()
         dt_full = timed(full_forward, max(args.steps // 4, 10), max(args.warmup // 4, 3), False)['dt']
+    mark('full_forward')
     # secondary: the SAME propagate-scope step launched eagerly (Python + ctypes per launch, no graph):
     # what a caller pays today when every batch has new shapes and nothing can be replayed
     eager = None
@@ -712,6 +874,7 @@ def main():
     if dist is not None:
         dist.all_reduce(full_cells)
 
+    mark('eager')
     # ---- rooflines: both kernels of a layer are measured live; the one with the larger share of the
     # step is `roofline` (dominant), the other `roofline_other` ---------------------------------------
     roofline = roofline_other = r_plan = roofline_mlp = None
@@ -953,6 +1116,7 @@ def main():
                          'cells_per_s_at_6290': round(stats[0]['cells'] * L / (step_bytes / 6290e9), 1),
                          'note': 'SURVEY.md 8(d): gather-counted bytes of all layers of one step / ms_per_step'}
 
+    mark('roofline')
     # ---- CPU baseline: the oracle on the host cores, bounded sample -----------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -1068,6 +1232,7 @@ def main():
                         'full_forward_cells_per_s': None if cpu_full is None else round(cpu_full, 1),
                         'train_fwd_bwd_cells_per_s': None if cpu_train is None else round(cpu_train, 1)}
 
+    mark('cpu_baseline')
     # secondary: independent batches overlapped on the GPU (serving-style): S streams, each replaying
     # the step graph of its own batch; same kernels, same per-step work, K steps in total
     concurrent = None
@@ -1115,6 +1280,7 @@ def main():
             print(f'[bench] concurrent-streams leg failed: {type(e).__name__}: {e}', file=sys.stderr)
             torch.cuda.synchronize()
 
+    mark('concurrent')
     full_cells_total = float(full_cells.item())      # read here: result_line may run on the deadline thread, which must not touch the device
 
     def result_line(train, collate):
@@ -1132,6 +1298,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic', 'timing': timing,
             'config': {'workload': {'zinc': f'ZINC-like ring-lift (max_ring=6), {L}-layer SparseCIN propagate scope (hidden {H}, coboundary messages), batch {args.batch} per GPU [BASELINE configs[1]]', 'molhiv': f'ogbg-molhiv-like ring-lift (max_ring=6), {L}-layer OGBEmbedSparseCIN propagate scope (hidden {H}), batch {args.batch} per GPU [BASELINE configs[2]]', 'reddit': f'REDDIT-BINARY-like clique-lift (dim 2, hubs of degree >= 100), {L}-layer SparseCIN propagate scope (hidden {H}, no coboundaries, norm id, JK cat), batch {args.batch} per GPU [BASELINE configs[4]]'}[WL],
+                       'key': f'{"zinc_cinpp" if CINPP else WL}:{args.batch}:{H}',
                        'batch_per_gpu': args.batch, 'hidden': H, 'layers': L,
                        'cells_per_batch': s0['cells'], 'N': [s0['N0'], s0['N1'], s0['N2']],
                        'E_up': [s0['E_up0'], s0['E_up1'], s0['E_up2']],
@@ -1168,7 +1335,7 @@ def main():
                 return
             if rank == 0 and not printed.is_set():
                 why = f'not finished {deadline:.0f} s after the single-GPU legs: skipped'
-                print(json.dumps(result_line({'skipped': why}, None)), flush=True)
+                emit(result_line({'skipped': why}, None))
             print(f'[bench] rank {rank}: data-parallel legs passed their deadline, leaving', file=sys.stderr, flush=True)
             os._exit(0)
         threading.Thread(target=_deadline, daemon=True).start()
@@ -1279,6 +1446,7 @@ def main():
             print(f'[bench] train-step leg failed: {type(e).__name__}: {e}', file=sys.stderr)
             torch.cuda.synchronize()
 
+    mark('train')
     # secondary: building the batch itself -- device-side collate from the HBM-resident packed
     # dataset vs the reference-style CPU collate (oracle restatement of data/complex.py:323-458)
     collate = None
@@ -1356,6 +1524,7 @@ def main():
         except Exception as e:
             print(f'[bench] collate leg failed: {type(e).__name__}: {e}', file=sys.stderr)
 
+    mark('collate')
     # secondary: the reference's loop as it really runs -- every step a batch it has never seen (data/data_loading.py:84-111
     # shuffles, exp/train_utils.py:35-75 steps through).  ONE captured graph per scope serves every batch of an epoch: the
     # collate, the segment tables, the item tables and every row count are device-side (cwn_amd/static_batch.py), the epoch's
@@ -1374,6 +1543,7 @@ def main():
             fresh = {'failed': f'{type(e).__name__}: {e}'}
             torch.cuda.synchronize()
 
+    mark('fresh')
     # secondary: BASELINE configs[2] and configs[4] (molhiv-512, REDDIT-32) in the same default run -- value + roofline of
     # each from a `--brief` child process of this file (they existed only as builder-run files)
     workloads = None
@@ -1408,11 +1578,19 @@ def main():
                 if wl == 'zinc_cinpp':
                     env_['CWN_BENCH_MODEL'] = 'cinpp'
                     env_['CWN_BENCH_SKIP'] = 'eager,concurrent,collate,workloads,roofline'
+                import tempfile
+                fd_, det_ = tempfile.mkstemp(prefix=f'cwn_bench_{wl}_', suffix='.json')
+                os.close(fd_)
+                env_['CWN_BENCH_DETAIL'] = det_
+                t_wl = time.perf_counter()
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env_)
+                LEGS['workload:' + wl] = time.perf_counter() - t_wl
                 line = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
                 if pr.returncode != 0 or not line:
                     raise RuntimeError(f'rc {pr.returncode}: {pr.stderr[-300:]}')
-                d_ = json.loads(line[-1])
+                with open(det_) as fh_:
+                    d_ = json.load(fh_)      # (the child's stdout line is the slim one; its detail file has the rest)
+                os.unlink(det_)
                 workloads[wl] = {'value': d_['value'], 'unit': d_['unit'], 'ms_per_step': d_['ms_per_step'],
                                  'workload': d_['config']['workload'], 'layer_kernel': d_['config']['layer_kernel'],
                                  'layer_kernel_form': d_['config'].get('layer_kernel_form'),
@@ -1434,6 +1612,7 @@ def main():
                 workloads[wl] = {'failed': f'{type(e).__name__}: {e}'}
                 print(f'[bench] workload {wl} failed: {type(e).__name__}: {e}', file=sys.stderr)
 
+    mark('workloads')
     if rank == 0:
         printed.set()
         if dist is not None:
@@ -1447,7 +1626,8 @@ def main():
         line_ = result_line(train, collate)
         line_['secondary']['workloads'] = workloads
         line_['secondary']['fresh_batches'] = fresh
-        print(json.dumps(line_), flush=True)
+        line_['leg_seconds'] = {k: round(v, 1) for k, v in LEGS.items()}
+        emit(line_)
     if dist is not None:
         dist.barrier()      # rank 0 runs the roofline / collate legs alone; leave together
         finished.set()

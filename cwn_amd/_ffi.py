@@ -691,3 +691,17 @@ def gemm_tn(descs: Sequence[GemmTnDesc], device, keep=None, deferrable: bool = F
             ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
         check(L.cwn_gemm_tn_f32(arr, len(chunk), None if ws is None else ws.data_ptr(), nbytes, s),
               'cwn_gemm_tn_f32')
+
+
+import itertools as _itertools
+_no_version = _itertools.count(1)
+
+
+def tver(t) -> int:
+    """Version counter of a tensor, for the caches keyed on (tensor, version).  Inference tensors (created under
+    torch.inference_mode()) keep none -- torch raises on `_version` -- and may still be written in place inside that mode:
+    they get a value no earlier call returned, so every such cache MISSES and the uncached path runs (slower, never stale)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -next(_no_version)

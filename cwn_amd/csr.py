@@ -82,8 +82,9 @@ class Adjacency:
             aux_out=_ffi.ptr(self.aux), long_rows=_ffi.ptr(self.long_rows),
             n_long=_ffi.ptr(self.n_long),
             # a static buffer (cwn_amd/static_batch.py, mode 'csr'): n_entries is its capacity, the batch's own count is in
-            # device memory -- looked up like every other dynamic row count (_ffi.dynamic_rows)
-            e_dev=getattr(self, 'e_dev_ptr', None) or _ffi.dyn(self.n_entries))
+            # device memory at the address the static batch TAGGED this plan with -- never looked up by value (an unrelated
+            # plan whose entry count happens to equal a mapped capacity must not pick up another tensor's live count)
+            e_dev=getattr(self, 'e_dev_ptr', None))
 
     # ---- transposes for the backward pass ----------------------------------------------
     def transposes(self) -> List['Adjacency']:
@@ -178,6 +179,9 @@ def build_many(adjs: Sequence[Adjacency], overlap: bool = False, validate: bool 
     adjs = [a for a in adjs if force or not a.built]
     if not adjs:
         return
+    if force:
+        for a in adjs:
+            a._counts = None          # (row counts of the batch the buffers held before: reduce='mean' divides by them)
     dev = adjs[0].device
     if overlap:
         main, side = torch.cuda.current_stream(dev), side_stream(dev)
@@ -280,7 +284,7 @@ def cached_adjacency(index: torch.Tensor, n_dst: int, n_src: int,
     dies.  A plan that carries a shared-cell (aux) index also serves requests without one."""
     key = id(index)
     hit = _cache.get(key)
-    ver = (index._version, n_dst, n_src)
+    ver = (_ffi.tver(index), n_dst, n_src)
     if hit is not None and hit[0] == ver and hit[1]() is index:
         adj = hit[2]
         if aux_index is None or (adj.aux_index is not None and adj.n_aux == n_aux and

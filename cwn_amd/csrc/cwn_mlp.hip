@@ -106,7 +106,9 @@ unsigned long long* g_mlp_stamps = nullptr;
 // of the common form stay one unconditional 16-byte load (with the test inside, uniform as it is, the ZINC-128 launch went
 // 10.7 -> 12.0 us: the compiler schedules loads behind a branch differently).
 template <int F, int RT, bool SEQ, bool NARROW>
-__global__ __launch_bounds__(kThreads, SEQ ? 2 : 1) void update_mlp_kernel(MlpBatch B) {
+// (HIP's second __launch_bounds__ argument is the minimum number of WAVES per SIMD, not CUDA's blocks per multiprocessor: two
+// resident 8-wave workgroups are four waves a SIMD -- the compiler then holds the sequential build to 128 registers)
+__global__ __launch_bounds__(kThreads, SEQ ? 4 : 1) void update_mlp_kernel(MlpBatch B) {
     using S = Shape<F, RT, SEQ>;
     constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
     constexpr int kRT = S::kRT, kV = S::kV;
@@ -452,7 +454,14 @@ extern "C" int cwn_update_mlp_f32(const cwn_mlp_dim* dims, int n_dims, int32_t F
     for (int i = n_dims; i <= CWN_LAYER_MAX_DIMS; ++i) B.blk_start[i] = (int32_t)blocks;
     if (blocks == 0) return CWN_OK;
     const int mode = mlp_form_mode();
-    const bool seq = mode == 3 || (mode == 0 && blocks > 256);
+    // more workgroups than the chip has CUs (one round of the alternating form): the sequential two-per-CU form
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    const bool seq = mode == 3 || (mode == 0 && blocks > n_cu);
     hipStream_t stream = (hipStream_t)stream_;
     bool narrow = false;
     for (int i = 0; i < n_dims; ++i) narrow = narrow || (dims[i].M > 0 && dims[i].in_width > 0 && dims[i].in_width < F);

@@ -668,11 +668,11 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pre
     if (kind == CWN_LOSS_CE) {
         // torch.nn.CrossEntropyLoss() (exp/train_utils.py:21-22, REDDIT-BINARY / the TU datasets): pred [rows, cols] logits, y the
         // class of every row as int64; loss = mean over the rows with a class >= 0 of logsumexp(row) - row[class] (a negative
-        // class = torch's ignore_index), grad = (softmax(row) - onehot) / rows counted.  A thread per row, fixed reduction tree.
+        // class = torch's ignore_index; a class >= cols poisons the loss with NaN), grad = (softmax(row) - onehot) / rows counted.  A thread per row, fixed reduction tree.
         const int64_t* cls = reinterpret_cast<const int64_t*>(y);
         const int64_t rows = n / cols, rows_cap = n_cap / cols;
         int valid = 0;
-        for (int64_t r = threadIdx.x; r < rows; r += 256) valid += (cls[r] >= 0 && cls[r] < cols) ? 1 : 0;
+        for (int64_t r = threadIdx.x; r < rows; r += 256) valid += cls[r] >= 0 ? 1 : 0;
         cnt[threadIdx.x] = valid;
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {
@@ -686,8 +686,15 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pre
             const float* p = pred + r * cols;
             float* g = grad + r * cols;
             const int64_t c = cls[r];
-            if (!(c >= 0 && c < cols)) {
+            if (c < 0) {                                   // ignored row (torch's ignore_index is negative)
                 for (int64_t j = 0; j < cols; ++j) g[j] = 0.f;
+                continue;
+            }
+            if (c >= cols) {
+                // a class the logits have no column for: torch.nn.CrossEntropyLoss asserts on the device.  Never a silent
+                // smaller denominator: the loss and this row's gradient are NaN, the caller sees a non-finite step.
+                s = __builtin_nanf("");
+                for (int64_t j = 0; j < cols; ++j) g[j] = __builtin_nanf("");
                 continue;
             }
             float m = p[0];

@@ -56,13 +56,20 @@ inline at::Tensor row_major(const at::Tensor& t) {      // ops._rowmajor
 // ---- tensors a prepared record was derived from: unchanged since? ------------------------------------------------------------
 class TensorMarks {
  public:
+    // An inference tensor keeps no version counter (at::Tensor::_version() throws) and may be written in place inside
+    // torch.inference_mode(): marks over one are never current, the caller prepares its launch again (_ffi.tver's rule).
     explicit TensorMarks(std::vector<at::Tensor> ts) : ts_(std::move(ts)) {
         marks_.reserve(ts_.size());
-        for (const auto& t : ts_) marks_.emplace_back(t.data_ptr(), t._version());
+        for (const auto& t : ts_) {
+            if (t.is_inference()) { untracked_ = true; marks_.emplace_back(t.data_ptr(), -1); continue; }
+            marks_.emplace_back(t.data_ptr(), static_cast<int64_t>(t._version()));
+        }
     }
     bool current() const {
+        if (untracked_) return false;
         for (size_t i = 0; i < ts_.size(); ++i)
-            if (ts_[i]._version() != marks_[i].second || ts_[i].data_ptr() != marks_[i].first) return false;
+            if (ts_[i].is_inference() || static_cast<int64_t>(ts_[i]._version()) != marks_[i].second ||
+                ts_[i].data_ptr() != marks_[i].first) return false;
         return true;
     }
     size_t size() const { return ts_.size(); }
@@ -70,6 +77,7 @@ class TensorMarks {
  private:
     std::vector<at::Tensor> ts_;
     std::vector<std::pair<void*, int64_t>> marks_;
+    bool untracked_ = false;
 };
 
 // ---- cwn_layer_fused_f32 over a prepared descriptor array (ops.LayerLaunch) --------------------------------------------------

@@ -223,7 +223,7 @@ def _fold_norm(norm, width: int):
     # their version counters; the module's own `num_batches_tracked.add_(1)` does move one -- found by tools/fuzz_round5.py in
     # round 5: an eval forward after a training-mode forward through the torch modules folded the OLD statistics)
     tensors = [t for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.num_batches_tracked) if t is not None]
-    key = (ops.STATE_EPOCH,) + tuple((t.data_ptr(), t._version) for t in tensors)
+    key = (ops.STATE_EPOCH,) + tuple((t.data_ptr(), ops._ffi.tver(t)) for t in tensors)
     hit = getattr(norm, '_cwn_fold', None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -1063,7 +1063,7 @@ class SparseCINConv(torch.nn.Module):
             return 'a complex does not fit one workgroup (row / entry caps)'
         if table.variant == 0 and table.n_items > BLOCKED_MAX_ITEMS:     # (a MixedTable's variant is 'mixed')
             return f'{table.n_items} items: beyond the range where one workgroup per item beats the streaming CSR path'
-        key = tuple((id(t), t._version) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
+        key = tuple((id(t), ops._ffi.tver(t)) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
         return dims, plan, table, key
 
     def _dense_eval(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:

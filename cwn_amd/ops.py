@@ -584,7 +584,7 @@ def _embed_table(weights: Sequence[Tensor], feats: Tensor, keep: list) -> _ffi.E
     if len(weights) == 1:
         W = _f32c(weights[0].detach(), 'embedding table')
     else:
-        key = tuple((id(w), w._version) for w in weights) + (STATE_EPOCH,)
+        key = tuple((id(w), _ffi.tver(w)) for w in weights) + (STATE_EPOCH,)
         hit = _table_cache.get(key)
         if hit is None:
             if len(_table_cache) > 32:
@@ -645,14 +645,14 @@ def _marks(tensors):
     X = _cext.ext()
     if X is not None:
         return X.TensorMarks(ts)
-    return (ts, [(t.data_ptr(), t._version) for t in ts])
+    return (ts, [(t.data_ptr(), _ffi.tver(t)) for t in ts])
 
 
 def _marks_current(m) -> bool:
     if not isinstance(m, tuple):
         return m.current()
     for t, (p, v) in zip(*m):
-        if t._version != v or t.data_ptr() != p:
+        if _ffi.tver(t) != v or t.data_ptr() != p:
             return False
     return True
 
@@ -714,7 +714,7 @@ class FrontLaunch:
         if rc != 0:
             _ffi.check(rc, 'cwn_embed_front_f32')
         if csr.VALIDATE_INDICES and not torch.cuda.is_current_stream_capturing():
-            seen = (id(v_feats), v_feats._version, id(e_feats), None if e_feats is None else e_feats._version, csr.ERROR_EPOCH)
+            seen = (id(v_feats), _ffi.tver(v_feats), id(e_feats), None if e_feats is None else _ffi.tver(e_feats), csr.ERROR_EPOCH)
             if self._seen is None or self._seen[0] != seen or self._seen[1]() is not v_feats or \
                     (e_feats is not None and self._seen[2]() is not e_feats):
                 self._seen = (seen, weakref.ref(v_feats), None if e_feats is None else weakref.ref(e_feats))
@@ -737,9 +737,9 @@ def _long_index(feats: Tensor) -> Tensor:
     """The integer features of a batch as int64 [n, cols] (what cwn_embedding_bwd_f32 indexes with), converted once per
     feature tensor (they do not change between the steps that reuse a batch)."""
     hit = getattr(feats, '_cwn_long', None)
-    if hit is None or hit[0] != feats._version:
+    if hit is None or hit[0] != _ffi.tver(feats):
         f = feats if feats.dim() == 2 else feats.unsqueeze(1)
-        hit = (feats._version, f.to(torch.long).contiguous())
+        hit = (_ffi.tver(feats), f.to(torch.long).contiguous())
         try:
             feats._cwn_long = hit
         except AttributeError:
@@ -863,19 +863,19 @@ def _transposed(weight: Tensor) -> Tensor:
     """lin1's weight [H2, K] as [K, H2] (what cwn_head_f32 reads coalesced), once per weight version."""
     key = id(weight)
     hit = _w1t_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, STATE_EPOCH):
+    if hit is not None and hit[0]() is weight and hit[1] == (_ffi.tver(weight), STATE_EPOCH):
         return hit[2]
     if len(_w1t_cache) > 64:
         _w1t_cache.clear()
     t = _f32c(weight.detach(), 'lin1 weight').t().contiguous()
-    _w1t_cache[key] = (weakref.ref(weight), (weight._version, STATE_EPOCH), t)
+    _w1t_cache[key] = (weakref.ref(weight), (_ffi.tver(weight), STATE_EPOCH), t)
     return t
 
 
 def _transpose_many(weights: Sequence[Tensor]) -> None:
     """The transposes of all of a head's lin1 weights that `_transposed` would miss, in ONE launch (a training step changes
     every weight: three copy launches per step otherwise)."""
-    stale = [w for w in weights if not ((h := _w1t_cache.get(id(w))) is not None and h[0]() is w and h[1] == (w._version, STATE_EPOCH))]
+    stale = [w for w in weights if not ((h := _w1t_cache.get(id(w))) is not None and h[0]() is w and h[1] == (_ffi.tver(w), STATE_EPOCH))]
     if len(stale) < 2 or len({(tuple(w.shape), w.dtype, w.device) for w in stale}) != 1 or stale[0].dtype != torch.float32:
         return
     if len(_w1t_cache) > 64:
@@ -883,7 +883,7 @@ def _transpose_many(weights: Sequence[Tensor]) -> None:
     K = int(stale[0].size(1))
     both = torch.cat([w.detach().t() for w in stale], dim=0)          # [n K, H2], one kernel
     for k, w in enumerate(stale):
-        _w1t_cache[id(w)] = (weakref.ref(w), (w._version, STATE_EPOCH), both[k * K: (k + 1) * K])
+        _w1t_cache[id(w)] = (weakref.ref(w), (_ffi.tver(w), STATE_EPOCH), both[k * K: (k + 1) * K])
 
 
 HEAD_POOL_SPLIT = os.environ.get('CWN_HEAD_POOL_SPLIT', 'auto')       # 'auto' | 1 (never) | P
@@ -1847,7 +1847,7 @@ def pack_layer_weight(weight: Tensor, fresh: bool = False) -> Tensor:
     import weakref
     w = weight.detach()
     key = id(weight)
-    ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
+    ver = (w.data_ptr(), _ffi.tver(weight), STATE_EPOCH, tuple(w.shape), w.device)
     hit = _packed_weights.get(key)
     if hit is not None and hit[1]() is weight:
         if not fresh and hit[0] == ver:
@@ -1909,7 +1909,7 @@ def pack_layer_weights_many(weights: Sequence[Tensor], transposed: bool = False)
                        'cwn_layer_pack_weights_many_f32')
         for (weight, w), out in zip(ws, outs):
             key = id(weight)
-            ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
+            ver = (w.data_ptr(), _ffi.tver(weight), STATE_EPOCH, tuple(w.shape), w.device)
             _packed_weights[key] = (ver, weakref.ref(weight, lambda _r, k=key: _packed_weights.pop(k, None)), out, _pack_token)
         if transposed:
             for (weight, w), out in zip(ws, outs_t):
@@ -1929,7 +1929,7 @@ def pack_gemm_weight(weight: Tensor) -> Optional[Tensor]:
     if w.dim() != 2 or tuple(w.shape) != (128, 128) or not w.is_cuda or w.dtype != torch.float32:
         return None
     key = id(weight)
-    ver = (w.data_ptr(), weight._version, STATE_EPOCH, w.device)
+    ver = (w.data_ptr(), _ffi.tver(weight), STATE_EPOCH, w.device)
     hit = _packed_gemm_weights.get(key)
     if hit is not None and hit[0] == ver and hit[1]() is weight:
         return hit[2]
@@ -1984,7 +1984,7 @@ def _mlp_first_weight(weight: Tensor, F: int) -> Tensor:
     if weight.size(1) == F:
         return weight
     key = id(weight)
-    ver = (weight.data_ptr(), weight._version, STATE_EPOCH, tuple(weight.shape))
+    ver = (weight.data_ptr(), _ffi.tver(weight), STATE_EPOCH, tuple(weight.shape))
     hit = _padded_weights.get(key)
     if hit is not None and hit[0] == ver and hit[1]() is weight:
         return hit[2]
@@ -2059,7 +2059,7 @@ class MlpLaunch:
             a.ldy = F
             self.keep += packed
         self.sources = [t for t in sources if t is not None]
-        self.marks = [(t.data_ptr(), t._version) for t in self.sources]
+        self.marks = [(t.data_ptr(), _ffi.tver(t)) for t in self.sources]
         self.epochs = (STATE_EPOCH, STRUCT_EPOCH)
         self.cap = int(_ffi.lib().cwn_update_mlp_max_rows())
         self.fn = _ffi.lib().cwn_update_mlp_f32
@@ -2074,7 +2074,7 @@ class MlpLaunch:
         if self.epochs != (STATE_EPOCH, STRUCT_EPOCH):
             return False
         for t, (p, v) in zip(self.sources, self.marks):
-            if t._version != v or t.data_ptr() != p:
+            if _ffi.tver(t) != v or t.data_ptr() != p:
                 return False
         return True
 
@@ -2120,7 +2120,7 @@ def pack_mlp_weight(weight: Tensor):
     import weakref
     w = weight.detach()
     key = id(weight)
-    ver = (w.data_ptr(), weight._version, STATE_EPOCH, tuple(w.shape), w.device)
+    ver = (w.data_ptr(), _ffi.tver(weight), STATE_EPOCH, tuple(w.shape), w.device)
     hit = _packed_mlp_weights.get(key)
     if hit is not None and hit[0] == ver and hit[1]() is weight:
         return hit[2]
@@ -2207,7 +2207,7 @@ def pack_stage_weights_many(weights: Sequence[Tensor], transposed: bool = True, 
             for (weight, w, c0), o, ot in zip(part, outs, outs_t):
                 # (a weak reference to the tensor that was packed: an entry whose weight has died -- a layer that is gone, its
                 #  storage address handed to a NEW parameter of the same shape -- is not served, ADVICE r3 / round 4's CIN++ tests)
-                _packed_stage[_stage_key(w, c0)] = (_stage_token, o, ot, weight._version, WEIGHT_EPOCH, weakref.ref(weight))
+                _packed_stage[_stage_key(w, c0)] = (_stage_token, o, ot, _ffi.tver(weight), WEIGHT_EPOCH, weakref.ref(weight))
 
 
 # ---- the step arena: the zeroed scratch of a training step ------------------------------------------------------------
@@ -2295,7 +2295,7 @@ def packed_stage_block(weight: Tensor, col0: int, transposed: bool = False) -> O
     # (an entry is keyed on the weight's STORAGE -- the backward sees its saved weights re-wrapped -- so it must
     # also prove that nothing has written that storage since: the tensor version (torch optimizers, in-place ops) and the
     # parameter epoch (FlatAdam / a replayed step write through raw pointers).  A miss sends the caller to cwn_gemm_f32.)
-    if hit is not None and hit[0] == _stage_token and hit[3] == weight._version and hit[4] == WEIGHT_EPOCH:
+    if hit is not None and hit[0] == _stage_token and hit[3] == _ffi.tver(weight) and hit[4] == WEIGHT_EPOCH:
         # ... and that the tensor that was packed is alive AND still owns that storage (a Parameter re-pointed by
         # `.data =` / load_state_dict(assign=True) stays alive while its old storage is recycled for another weight of the
         # same shape and version)
@@ -2589,7 +2589,7 @@ class LayerLaunch:
         once per batch from slices of the batch's own index tensors (the table records where each complex's entries
         lie), cached on the table for all layers -- and (b) scratch matrices for Y1 / Y2."""
         from .csr import Adjacency, build_many
-        key = tuple((id(t), t._version) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
+        key = tuple((id(t), _ffi.tver(t)) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
         ctx = table.big_ctx
         if ctx is None or ctx['key'] != key or ctx['F'] != self.F:
             recs = table.big_records

@@ -440,7 +440,7 @@ class StaticBatch:
     def _register(self, index: torch.Tensor, adj) -> None:
         import weakref
         key = id(index)
-        csr._cache[key] = ((index._version, adj.n_dst, adj.n_val), weakref.ref(index, lambda _r, k=key: csr._cache.pop(k, None)), adj)
+        csr._cache[key] = ((_ffi.tver(index), adj.n_dst, adj.n_val), weakref.ref(index, lambda _r, k=key: csr._cache.pop(k, None)), adj)
         self._adjs.append((index, adj))          # (the view tensors the cache is keyed on stay alive with the batch)
 
     def _n_sets(self, has_up) -> int:

@@ -69,7 +69,7 @@ class StaticPropagate:
         self.outs: Optional[List[List[torch.Tensor]]] = None
         self.n_cells = [0, 0, 0]
         # the packed weights above are baked into the launches (and later the graph): inference over fixed weights
-        self._weights = [(conv.mp_levels[d].msg_up_nn[1].weight, conv.mp_levels[d].msg_up_nn[1].weight._version)
+        self._weights = [(conv.mp_levels[d].msg_up_nn[1].weight, _ffi.tver(conv.mp_levels[d].msg_up_nn[1].weight))
                          for conv in self.convs for d in range(2)]
         self._epoch = ops.STATE_EPOCH
 
@@ -124,7 +124,7 @@ class StaticPropagate:
     def replay(self) -> List[List[torch.Tensor]]:
         """[layer][out_up_0, out_b_0, out_up_1, ...] restricted to the loaded batch's cells.  The first
         call captures the graph; every later call (any batch that fits) replays it."""
-        if self._epoch != ops.STATE_EPOCH or any(w._version != v for w, v in self._weights):
+        if self._epoch != ops.STATE_EPOCH or any(_ffi.tver(w) != v for w, v in self._weights):
             raise RuntimeError('StaticPropagate: the layer weights changed since this object packed them; build a new one')
         with torch.no_grad():
             if self.graph is None:
@@ -190,8 +190,8 @@ class StaticForward:
         self._stamp = None
 
     def _state(self):
-        return (ops.STATE_EPOCH,) + tuple(p._version for p in self.model.parameters()) + \
-            tuple(b._version for b in self.model.buffers())
+        return (ops.STATE_EPOCH,) + tuple(_ffi.tver(p) for p in self.model.parameters()) + \
+            tuple(_ffi.tver(b) for b in self.model.buffers())
 
     def _run(self) -> List[torch.Tensor]:
         self.sb.fill()

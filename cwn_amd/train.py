@@ -420,6 +420,12 @@ class TrainStep:
             # graphed run takes exactly the steps an eager run takes
             keep = [t.detach().clone() for t in self._state_tensors()]
             n_before = len(keep)
+            # ... including the device-side dropout stream {seed, step}: every warm-up step's opening launch advances `step`
+            # (ops.step_arena), and the masks of a graphed run must be the ones an eager run draws on the same seed
+            from . import ops as _ops
+            dev_ = next(self.model.parameters()).device
+            ds_before = _ops._drop_states.get(dev_)
+            ds_keep = None if ds_before is None else ds_before.clone()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -432,6 +438,12 @@ class TrainStep:
                     t.copy_(old)
                 for t in now[n_before:]:          # optimiser state created by the warm-up
                     t.zero_()
+                ds_now = _ops._drop_states.get(dev_)
+                if ds_now is not None:
+                    if ds_keep is not None:
+                        ds_now.copy_(ds_keep)
+                    else:                         # created by the warm-up: its seed stays, its step counter rewinds
+                        ds_now[1] = 0
             torch.cuda.synchronize()
             self._warm = True
         g1 = torch.cuda.CUDAGraph()

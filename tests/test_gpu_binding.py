@@ -302,3 +302,25 @@ def test_the_front_checks_each_feature_version_once():
         good = fwd3().clone()
         assert torch.isfinite(good).all()
     csr._err_flag(DEV).zero_()
+
+
+@pytest.mark.parametrize('which', ['ctypes', 'compiled'])
+def test_forward_under_inference_mode_over_a_batch_built_inside_it(which):
+    """the prepared-launch caches read `Tensor._version` of batch tensors; inference tensors keep none
+    (torch raises).  `with torch.inference_mode(): model(batch.to(dev))` must run -- uncached -- and give the no_grad result."""
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    model, b, fwd = _model_and_batch(B=12, hidden=64)
+    with torch.no_grad():
+        ref = fwd().clone()
+    _forget(model)
+    with _cext.binding(which), torch.inference_mode():
+        bi = ComplexBatch.from_complex_list(zinc_like_complexes(12, 5, 6), max_dim=2).to(DEV)
+        assert bi.cochains[0].x.is_inference() and bi.cochains[0].upper_index.is_inference()
+        x0 = [None if bi.cochains[d].x is None else bi.cochains[d].x.clone() for d in range(3)]
+        out1 = model(bi).clone()
+        for d in range(3):
+            bi.cochains[d]._x = x0[d]
+        out2 = model(bi).clone()
+    assert torch.equal(out1, ref) and torch.equal(out2, ref)
+    print(f'[gate] forward under torch.inference_mode() ({which} binding): torch.equal to the no_grad forward, twice')
