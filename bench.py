@@ -122,6 +122,17 @@ def gemm_roofline(flops, us, split, io_bytes, narrow, traffic):
             'frac_of_fp32_mfma_peak_157': round(tf / MFMA_F32_PEAK_TF, 4)}
 
 
+def gen_complexes(spec):
+    """One synthetic batch from a spec (kind, batch, seed, kwargs): what `gen(seed)` of main() returns."""
+    kind, batch, seed, kw = spec
+    from cwn_amd import synthetic as S
+    if kind == 'zinc':
+        return S.zinc_like_complexes(batch, seed, 6, **kw)
+    if kind == 'molhiv':
+        return S.molhiv_like_complexes(batch, seed, 6, **kw)
+    return S.reddit_like_complexes(batch, seed)
+
+
 LINE_BUDGET = 6144          # bytes: the driver keeps a bounded tail of stdout and parses ONE line (round 5's 22 KB line was lost)
 
 
@@ -255,7 +266,9 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
     from cwn_amd.static_batch import StaticBatch
     from cwn_amd.static_graph import StaticTrainStep
     # (mode 'csr' -- REDDIT-like hub complexes, CIN++ layers: large batches, a smaller pool and fewer steps per replay)
-    NB = int(os.environ.get('CWN_BENCH_FRESH_BATCHES', '64' if mode == 'blocked' else '16'))
+    # (distinct batches per epoch: 64 at the headline's batch size; the pool is generated in pure Python -- ~1 ms a molecule --
+    #  so the batch-512 workloads of the default run draw 24: CWN_BENCH_FRESH_BATCHES=64 for the long form)
+    NB = int(os.environ.get('CWN_BENCH_FRESH_BATCHES', ('64' if args.batch <= 128 else '24') if mode == 'blocked' else '16'))
     S = int(os.environ.get('CWN_BENCH_FRESH_SLOTS', '16' if mode == 'blocked' else '8'))      # (8: 634 M cells/s on the propagate scope, 16: 659 M, 32: 668 M)
     EPOCHS = int(os.environ.get('CWN_BENCH_FRESH_EPOCHS', '6'))
     B = args.batch
@@ -580,10 +593,10 @@ def main():
         # e.g. 9,38 for the spread of the real ZINC subset (mixed launches / big items)
         # ... or 'zinc': the size statistics of the real ZINC-12k subset (9 - 37 atoms, mean 23.2: cwn_amd/synthetic.py)
         if os.environ.get('CWN_BENCH_ATOMS') == 'zinc':
-            gen = lambda seed: zinc_like_complexes(args.batch, seed, 6, size_dist='zinc')
+            GEN_KIND, GEN_KW = 'zinc', dict(size_dist='zinc')
         else:
             atoms = tuple(int(v) for v in os.environ.get('CWN_BENCH_ATOMS', '18,30').split(','))
-            gen = lambda seed: zinc_like_complexes(args.batch, seed, 6, n_lo=atoms[0], n_hi=atoms[1])
+            GEN_KIND, GEN_KW = 'zinc', dict(n_lo=atoms[0], n_hi=atoms[1])
         coboundary = True
     elif WL == 'molhiv':  # exp/scripts/cwn-molhiv.sh:9-32, batch per BASELINE.json
         # (--drop_rate 0.5 --indrop_rate 0.0 --drop_position lin2: after every conv layer and before lin2, in TRAINING mode --
@@ -593,7 +606,7 @@ def main():
                                   init_reduce='sum', embed_edge=True, use_coboundaries=True, graph_norm='bn')
         # CWN_BENCH_MOLHIV_TAIL (the `molhiv_real_tail` entry of secondary.workloads: 5e-4): the dataset's molecules of 120 - 220 atoms
         MTAIL = float(os.environ.get('CWN_BENCH_MOLHIV_TAIL', '0'))
-        gen = lambda seed: molhiv_like_complexes(args.batch, seed, 6, tail=MTAIL)
+        GEN_KIND, GEN_KW = 'molhiv', dict(tail=MTAIL)
         coboundary = True
     else:                 # exp/scripts/mpsn-redditb.sh:6-28
         model = SparseCIN(1, 2, L, H, dropout_rate=0.0, max_dim=2, jump_mode='cat', readout='sum',
@@ -601,8 +614,11 @@ def main():
         with torch.no_grad():
             for p_ in model.parameters():
                 p_.mul_(0.3)      # no norm layer and degrees up to 300: keep activations finite
-        gen = lambda seed: reddit_like_complexes(args.batch, seed)
+        GEN_KIND, GEN_KW = 'reddit', {}
         coboundary = False
+    def gen(seed):
+        return gen_complexes(gen.spec(seed))
+    gen.spec = lambda seed: (GEN_KIND, args.batch, seed, GEN_KW)
     model = model.to(dev).eval()
     # the criterion of the training legs: exp/scripts/cwn-zinc.sh --task_type regression (L1), cwn-molhiv.sh bin_classification
     # (BCE with logits), mpsn-redditb.sh classification (CrossEntropyLoss, exp/train_utils.py:21-22)
@@ -610,12 +626,13 @@ def main():
     DROP = float(getattr(model, 'dropout_rate', 0.0)) if getattr(model, 'conv_dropout', False) else 0.0
 
     # ---- synthetic batches, resident in HBM ---------------------------------------------------
-    cpu_batches = [ComplexBatch.from_complex_list(gen(1000 * rank + i), max_dim=2) for i in range(args.num_batches)]
+    fixed = [gen(1000 * rank + i) for i in range(args.num_batches)]
+    cpu_batches = [ComplexBatch.from_complex_list(cs, max_dim=2) for cs in fixed]
     stats = [batch_stats(b) for b in cpu_batches]
     types = [tuple(None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3))
              for b in cpu_batches]
-    batches = [ComplexBatch.from_complex_list(gen(1000 * rank + i), max_dim=2).to(dev)   # .to() is in place
-               for i in range(args.num_batches)]
+    batches = [ComplexBatch.from_complex_list(cs, max_dim=2).to(dev) for cs in fixed]   # .to() is in place
+    del fixed
     types_dev = [tuple(None if t is None else t.to(dev) for t in ts) for ts in types]
 
     def reset_inputs(bi):
@@ -826,7 +843,7 @@ def main():
     SKIP = set(filter(None, os.environ.get('CWN_BENCH_SKIP', '').split(',')))   # debugging: legs to skip
     if args.brief:
         args.no_cpu = True
-        SKIP |= {'full', 'eager', 'concurrent', 'train', 'collate', 'workloads'}
+        SKIP |= {'full', 'eager', 'concurrent', 'train', 'collate', 'workloads', 'fresh'}
     if args.only_primary:
         args.no_cpu = True
     try:
@@ -1156,7 +1173,7 @@ def main():
                 torch.set_num_threads(th)
                 cpu_step()
                 k, t0 = 0, time.perf_counter()
-                while time.perf_counter() - t0 < 0.8:
+                while time.perf_counter() - t0 < 0.5:
                     cpu_step()
                     k += 1
                 trials[th] = k / (time.perf_counter() - t0)
@@ -1187,7 +1204,7 @@ def main():
                 torch.set_num_threads(threads)
                 O.sparse_cin_model_forward(state, ocx_full, L, **okw)
                 k, t0 = 0, time.perf_counter()
-                while time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
+                while time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 5):
                     O.sparse_cin_model_forward(state, ocx_full, L, **okw)
                     k += 1
                 cpu_full = stats[0]['cells'] * L * k / (time.perf_counter() - t0)
@@ -1209,7 +1226,7 @@ def main():
             torch.set_num_threads(threads)
             cpu_train_step()
             k, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
+            while time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 5):
                 cpu_train_step()
                 k += 1
             cpu_train = stats[0]['cells'] * L * k / (time.perf_counter() - t0)
@@ -1595,6 +1612,7 @@ def main():
                                  'workload': d_['config']['workload'], 'layer_kernel': d_['config']['layer_kernel'],
                                  'layer_kernel_form': d_['config'].get('layer_kernel_form'),
                                  'cells_per_batch': d_['config']['cells_per_batch'], 'timing': d_.get('timing'),
+                                 'leg_seconds': d_.get('leg_seconds'),
                                  'roofline': {k: (d_['roofline'] or {}).get(k) for k in
                                               ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us',
                                                'algorithmic_bytes_per_launch', 'traffic', 'frac_vs_pmc_traffic')},
