@@ -122,8 +122,9 @@ enum { T_DIM = 0, T_R0, T_N, T_BE0, T_BNE, T_SR0, T_SN, T_INTS };
 // per-dimension descriptors selected field by field in the kernel (dim == 0 ? .. : ..) the compiler
 // ran out of SGPRs and reloaded kernel arguments ten times, one wait each.
 enum { S_XG = 0, S_XC, S_UP_INDEX, S_UP_SHARED, S_UP_E, S_WP, S_MSG_BIAS, S_PAD, S_TASK0 };
-enum { ST_X = 0, ST_XS, ST_OUT_UP, ST_OUT_B, ST_B_INDEX, ST_B_E, ST_EPS1, ST_EPS2, ST_FIELDS };
-constexpr int kSetFields = S_TASK0 + 2 * ST_FIELDS;         // 24 fields of 8 bytes
+// (ST_OUT_D / ST_EPS3: the third output of a CIN++ layer, out_down = (1 + eps) x -- mp/layers.py:253 with the lower stream off)
+enum { ST_X = 0, ST_XS, ST_OUT_UP, ST_OUT_B, ST_B_INDEX, ST_B_E, ST_EPS1, ST_EPS2, ST_OUT_D, ST_EPS3, ST_FIELDS };
+constexpr int kSetFields = S_TASK0 + 2 * ST_FIELDS;         // 28 fields of 8 bytes
 constexpr int kMaxSets = CWN_LAYER_MAX_DIMS;
 
 // what a BIG item (include/cwn_hip.h) reads besides its set record: the caller's CSR of the big complexes' entries
@@ -656,6 +657,9 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
                 if (t_n[t] == 0) continue;                        // uniform
                 const gcf_p e1p = (gcf_p)sfld(S_TASK0 + t * ST_FIELDS + ST_EPS1), e2p = (gcf_p)sfld(S_TASK0 + t * ST_FIELDS + ST_EPS2);
                 const float eps1 = e1p != (gcf_p)0 ? *e1p : 0.f, eps2 = e2p != (gcf_p)0 ? *e2p : 0.f;
+                const gcf_p e3p = (gcf_p)sfld(S_TASK0 + t * ST_FIELDS + ST_EPS3);
+                const float eps3 = e3p != (gcf_p)0 ? *e3p : 0.f;
+                const gb_p o_d = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_D);
                 const gcb_p xt = (gcb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_X), xs = (gcb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_XS);
                 const gb_p o_up = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_UP), o_b = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_B);
                 const Seg B_ = sb[t];
@@ -683,6 +687,8 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
                         }
                     }
                     stg4o(o_b, (uint32_t)row * kRowB + fB, axpy4(ab, 1.0f + eps2, xi));
+                    if (o_d != (gb_p)0)
+                        stg4o(o_d, (uint32_t)row * kRowB + fB, axpy4(make_float4(0.f, 0.f, 0.f, 0.f), 1.0f + eps3, xi));
                     float4 au = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (upper) {
                         const int s_ = su.rp[r], e_ = su.rp[r + 1];
@@ -771,11 +777,13 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
     if constexpr (MODE == kLoad)      // the item's finished CSR, stored by an earlier layer of this batch
         csr_img = ldgu4((gcb_p)A.csr_cache + (size_t)blockIdx.x * kCsrSlot + (size_t)min(tid, kCsrSlot / 16 - 1) * 16);
     float epsv;
-    {   // lane 0..3 of every wave -> eps1, eps2 of task 0, eps1, eps2 of task 1 (NULL = 0)
-        const int k = S_TASK0 + ((lane & 2) ? ST_FIELDS : 0) + ST_EPS1 + (lane & 1);
+    {   // lane 0..3 of every wave -> eps1, eps2 of task 0, eps1, eps2 of task 1; lanes 4, 5 -> eps3 of task 0, 1 (NULL = 0)
+        static_assert(ST_EPS2 == ST_EPS1 + 1, "eps1, eps2 are consecutive fields");
+        const int k = lane < 4 ? S_TASK0 + ((lane & 2) ? ST_FIELDS : 0) + ST_EPS1 + (lane & 1)
+                               : S_TASK0 + ((lane & 1) ? ST_FIELDS : 0) + ST_EPS3;
         const uint64_t bits = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(4 * k, srec_lo) |
                               ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(4 * k, srec_hi) << 32);
-        const gcf_p ep = lane < 4 ? (gcf_p)bits : (gcf_p)0;
+        const gcf_p ep = lane < 6 ? (gcf_p)bits : (gcf_p)0;
         const float v = *(ep != (gcf_p)0 ? ep : dummy);
         epsv = ep != (gcf_p)0 ? v : 0.0f;
     }
@@ -994,6 +1002,8 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
     eps2[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 1));
     eps1[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 2));
     eps2[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 3));
+    const float eps3[2] = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 4)),
+                           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, epsv), 5))};
     // ---- 5. boundary stream and self terms of BOTH tasks in one pass, out of LDS (W is still landing) ---
     // Lane group gq finishes row gq + k kNG of task 0 and of task 1 together: two independent chains
     // (row pointers -> source numbers -> source rows) in flight, where two passes ran them one after the
@@ -1003,11 +1013,15 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
 #endif
     constexpr int kNR = CWN_LAYER_NR;                          // destination rows per lane group in flight (phase 7)
     {
-        gb_p out_up[2], out_b[2];
+        gb_p out_up[2], out_b[2], out_d[2];
+        bool has_d[2];                               // (uniform) the layer wants out_down = (1 + eps3) x of this task's rows
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             out_up[t] = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_UP) + (size_t)t_r0[t] * kRowB;
             out_b[t] = (gb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_B) + (size_t)t_r0[t] * kRowB;
+            const uint64_t od = sfld(S_TASK0 + t * ST_FIELDS + ST_OUT_D);
+            has_d[t] = od != 0;
+            out_d[t] = (gb_p)od + (size_t)t_r0[t] * kRowB;
         }
         const uint16_t* const cols[2] = {scol + b1, scol + b2};
         // Task 1's cells are the staged rows from R1 on, and a lane group finishes the rows IT loaded (their self terms wait in
@@ -1049,6 +1063,21 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
                     stg4o(out_b[t], off, axpy4(acc[t], 1.0f + eps2[t], xi[t]));
                     if (!(has_gemm && t == 0))   // no upper adjacency in this dimension: zeros + self term
                         stg4o(out_up[t], off, axpy4(make_float4(0.f, 0.f, 0.f, 0.f), 1.0f + eps1[t], xi[t]));
+                    if (!kW8 && has_d[t])
+                        stg4o(out_d[t], off, axpy4(make_float4(0.f, 0.f, 0.f, 0.f), 1.0f + eps3[t], xi[t]));
+                }
+            }
+        }
+        if constexpr (kW8) {
+            // the two-per-CU form lives on exactly 128 registers (the store above, inline, spilled four of them): a pass of its
+            // own over the task's rows, re-read from L2 -- taken by CIN++ layers only (uniform branch), same values, same product
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (!has_d[t]) continue;
+                const gcb_p xt = (gcb_p)sfld(S_TASK0 + t * ST_FIELDS + ST_X) + (size_t)t_r0[t] * kRowB;
+                for (int r = gq; r < t_n[t]; r += G::kNG) {
+                    const float4 v = ldg4o(xt, (uint32_t)r * kRowB + fB);
+                    stg4o(out_d[t], (uint32_t)r * kRowB + fB, axpy4(make_float4(0.f, 0.f, 0.f, 0.f), 1.0f + eps3[t], v));
                 }
             }
         }
@@ -1461,7 +1490,7 @@ extern "C" int CWN_FN(launch)(const cwn_layer_dim* dims, int n_dims, int32_t F, 
                            d + 1 >= n_dims))
             return CWN_ERR_BAD_ARG;
         if (D.n_b > 0 && (D.b_index == nullptr || d == 0)) return CWN_ERR_BAD_ARG;
-        if (!(al16(D.x) && al16(D.out_up) && al16(D.out_b) && al16(D.msg_w_packed) && al16(D.msg_bias)))
+        if (!(al16(D.x) && al16(D.out_up) && al16(D.out_b) && al16(D.out_down) && al16(D.msg_w_packed) && al16(D.msg_bias)))
             return CWN_ERR_ALIGN;
         // the table may not address more than the tensors hold: the kernel forms addresses from it
         if (plan->cells_end[d] < 0 || plan->cells_end[d] > D.n_cells || plan->up_end[d] < 0 ||
@@ -1520,6 +1549,8 @@ extern "C" int CWN_FN(launch)(const cwn_layer_dim* dims, int n_dims, int32_t F, 
             T[ST_B_E] = (uint64_t)D.n_b;
             T[ST_EPS1] = (uint64_t)(uintptr_t)D.eps1;
             T[ST_EPS2] = (uint64_t)(uintptr_t)D.eps2;
+            T[ST_OUT_D] = (uint64_t)(uintptr_t)D.out_down;
+            T[ST_EPS3] = (uint64_t)(uintptr_t)D.eps3;
         }
         d += tasks[1] >= 0 ? 2 : 1;
     }

@@ -86,8 +86,12 @@ class TensorMarks {
 // not the tensors its descriptors point at: those belong to the Python launch object.)
 class LayerCall {
  public:
-    LayerCall(uintptr_t arr, int64_t arr_bytes, int n, int F, std::vector<int64_t> rows, uintptr_t err, uintptr_t fn, int dev)
-        : n_(n), F_(F), dev_(dev), rows_(std::move(rows)), err_(reinterpret_cast<int32_t*>(err)), fn_(reinterpret_cast<fused_fn>(fn)) {
+    // n_out: outputs per dimension -- 2 (out_up, out_b) or 3 (out_up, out_down, out_b: a CIN++ layer, cwn_layer_dim.out_down)
+    LayerCall(uintptr_t arr, int64_t arr_bytes, int n, int F, std::vector<int64_t> rows, uintptr_t err, uintptr_t fn, int dev,
+              int n_out)
+        : n_(n), F_(F), dev_(dev), n_out_(n_out), rows_(std::move(rows)), err_(reinterpret_cast<int32_t*>(err)),
+          fn_(reinterpret_cast<fused_fn>(fn)) {
+        if (n_out != 2 && n_out != 3) throw py::value_error("LayerCall: two or three outputs per dimension");
         if (n < 1 || n > CWN_LAYER_MAX_DIMS || (int64_t)rows_.size() != n || arr_bytes != (int64_t)(n * sizeof(cwn_layer_dim)) || fn == 0)
             throw py::value_error("LayerCall: descriptor array does not match include/cwn_hip.h (ABI mismatch?)");
         dims_.resize(n);
@@ -95,8 +99,7 @@ class LayerCall {
         total_ = 0;
         for (int d = 0; d < n; ++d) {
             big_y_.emplace_back(dims_[d].big_y1, dims_[d].big_y2);
-            sizes_.push_back(rows_[d]);
-            sizes_.push_back(rows_[d]);
+            for (int k = 0; k < n_out_; ++k) sizes_.push_back(rows_[d]);
             total_ += rows_[d];
         }
     }
@@ -120,15 +123,16 @@ class LayerCall {
             check_feature(xs[d], rows_[d], F_, dev_, "cwn_layer_fused_f32");
             hold.push_back(xs[d].is_contiguous() ? xs[d] : xs[d].contiguous());
         }
-        at::Tensor buf = at::empty({2 * total_, (int64_t)F_}, at::TensorOptions().dtype(at::kFloat).device(at::kCUDA, dev_));
+        at::Tensor buf = at::empty({n_out_ * total_, (int64_t)F_}, at::TensorOptions().dtype(at::kFloat).device(at::kCUDA, dev_));
         float* base = buf.data_ptr<float>();
         int64_t off = 0;
         for (int d = 0; d < n_; ++d) {
             cwn_layer_dim& a = dims_[d];
             a.x = hold[d].data_ptr<float>();
             a.out_up = base + off * F_;
-            a.out_b = base + (off + rows_[d]) * F_;
-            off += 2 * rows_[d];
+            a.out_b = base + (off + (n_out_ - 1) * rows_[d]) * F_;
+            a.out_down = n_out_ == 3 ? base + (off + rows_[d]) * F_ : nullptr;
+            off += n_out_ * rows_[d];
             a.big_y1 = big_y_[d].first;
             a.big_y2 = big_y_[d].second;
             if (ys) {
@@ -146,7 +150,7 @@ class LayerCall {
     }
 
  private:
-    int n_, F_, dev_;
+    int n_, F_, dev_, n_out_;
     std::vector<int64_t> rows_, sizes_;
     int64_t total_;
     int32_t* err_;
@@ -287,7 +291,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("current", &TensorMarks::current)
         .def("__len__", &TensorMarks::size);
     py::class_<LayerCall, std::shared_ptr<LayerCall>>(m, "LayerCall")
-        .def(py::init<uintptr_t, int64_t, int, int, std::vector<int64_t>, uintptr_t, uintptr_t, int>())
+        .def(py::init<uintptr_t, int64_t, int, int, std::vector<int64_t>, uintptr_t, uintptr_t, int, int>())
         .def("has_plans", &LayerCall::has_plans)
         .def("set_plans", &LayerCall::set_plans)
         .def("run", &LayerCall::run, py::arg("xs"), py::arg("csr_mode") = 0, py::arg("ys") = py::none());

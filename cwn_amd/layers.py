@@ -868,7 +868,7 @@ class SparseCINConv(torch.nn.Module):
                             for c in cochain_params],
                        # the packed weights follow the message weights' versions; bias / eps are read in place (their addresses)
                        marks=ops._marks([t for lin in lins for t in (lin.weight, lin.bias)]
-                                        + [t for d in range(n) for t in (self.mp_levels[d].eps1, self.mp_levels[d].eps2)]),   # (no ModuleList slice: a new container moves STRUCT_EPOCH)
+                                        + self._blocked_eps(n)),   # (no ModuleList slice: a new container moves STRUCT_EPOCH)
                        launch=ops.LayerLaunch(dims, table))
             cache = _BLOCKED_CACHE.setdefault(self, {})
             if len(cache) > 64:
@@ -1001,7 +1001,10 @@ class SparseCINConv(torch.nn.Module):
                 return f'dim {d}: reduce is not add'
             if not lvl._boundary_fusable() or lvl.up_msg_size != F:
                 return f'dim {d}: boundary message network / message width'
-            D = ops.LayerDim(x=x, eps1=lvl.eps1, eps2=lvl.eps2)
+            D = ops.LayerDim(x=x, eps1=lvl.eps1, eps2=lvl._boundary_eps())
+            why = self._blocked_dim_extra(D, lvl, c, d)       # (CIN++: the third output; a stream the launch does not have)
+            if why is not None:
+                return why
             up = c.up_index is not None and c.up_index.size(1) > 0
             if c.up_index is not None:
                 attr = c.kwargs.get('up_attr')
@@ -1065,6 +1068,14 @@ class SparseCINConv(torch.nn.Module):
             return f'{table.n_items} items: beyond the range where one workgroup per item beats the streaming CSR path'
         key = tuple((id(t), ops._ffi.tver(t)) for D in dims for t in (D.up_index, D.up_shared, D.b_index) if t is not None)
         return dims, plan, table, key
+
+    def _blocked_dim_extra(self, D, lvl, cochain, d: int) -> Optional[str]:
+        """Hook of `_blocked_args`: what a subclass adds to the launch's descriptor of dimension d, or why it cannot."""
+        return None
+
+    def _blocked_eps(self, n: int) -> List[Tensor]:
+        """The eps tensors a prepared launch reads in place (its marks follow their versions)."""
+        return [t for d in range(n) for t in (self.mp_levels[d].eps1, self.mp_levels[d].eps2)]
 
     def _dense_eval(self, plans, outs, start: int = 0) -> Optional[List[Tensor]]:
         """The update / combine networks of ALL dimensions (mp/layers.py:193-199) as three grouped
@@ -1412,23 +1423,42 @@ class CINppConv(SparseCINConv):
                 eps=eps, train_eps=train_eps, feed_down_attr=feed_down_attr,
                 update_coboundaries_nn=_update_mlp(ld, hid, graph_norm, act) if coboundary_stream else None))
 
-    # The blocked layer kernel and cwn_update_mlp_f32 are built for SparseCINConv's two streams (upper + boundary, a 2F-wide
-    # combine): CIN++ takes the grouped message GEMM + ONE aggregation launch for the three (four) streams of all dimensions
-    # -- one autograd node in training (ops.gemm_aggregate) -- and its dense networks through _dense_eval / _dense_train.
-    def _propagate_blocked(self, cochain_params, start_to_process):
-        self.blocked_reason = 'CIN++: three streams per dimension (the blocked kernel has two)'
+    # Round 6: the layer as the reference's molecular models run it -- lower stream OFF (the quirk: include_down_features=False,
+    # mp/molec_models.py:111 -> down_index None -> out_down = zeros + (1 + eps2) x, mp/layers.py:253) -- takes the blocked launch
+    # of SparseCINConv: upper + boundary streams as there (boundary self term with eps3, :254), and the launch writes the
+    # third output (1 + eps2) x from the registers that hold the row (cwn_layer_dim.out_down, ABI 22).  Outputs per dimension
+    # in the order of torch.cat in :260: [out_up, out_down, out_b].  With `feed_down_attr` (a real lower adjacency) or the
+    # co-boundary stream the layer keeps the grouped message GEMM + ONE aggregation launch for its three (four) streams.
+    def _blocked_dim_extra(self, D, lvl, cochain, d: int) -> Optional[str]:
+        if lvl._down_active(cochain):
+            return f'dim {d}: CIN++ with a lower-adjacency stream (the blocked launch has upper + boundary + the self-only third)'
+        if lvl.update_coboundaries_nn is not None:
+            return f'dim {d}: CIN++ with the co-boundary stream (four streams)'
+        D.eps3, D.want_down = lvl.eps2, True
         return None
 
+    def _blocked_eps(self, n: int) -> List[Tensor]:
+        return [t for d in range(n) for t in (self.mp_levels[d].eps1, self.mp_levels[d].eps2, self.mp_levels[d].eps3)]
+
+    def _blocked_still_valid(self, ent, cochain_params) -> bool:
+        if any(self.mp_levels[d]._down_active(c) for d, c in enumerate(cochain_params)):
+            return False         # a lower adjacency has appeared: `_blocked_args` says why the launch does not serve it
+        return super()._blocked_still_valid(ent, cochain_params)
+
     def _propagate_blocked_train(self, cochain_params, start_to_process, specs, owner):
-        return None
+        return None             # (training: the streaming autograd node, ops.gemm_aggregate)
+
+    @staticmethod
+    def _n_streams(plan) -> int:
+        return 3 if isinstance(plan, str) else len(plan)       # ('blocked': the launch's three outputs)
 
     def _update_chains(self, plans, outs, start: int):
         """(active dimensions, streams per dimension, [dim][stream] -> [(Linear, norm), ...]) or None."""
         active = list(range(start, len(plans)))
         if not active or any(plans[d] is None for d in active):
             return None
-        nb = len(plans[active[0]])
-        if any(len(plans[d]) != nb for d in active) or len(outs) != nb * len(active):
+        nb = self._n_streams(plans[active[0]])
+        if any(self._n_streams(plans[d]) != nb for d in active) or len(outs) != nb * len(active):
             return None
         chains = []
         for d in active:
@@ -1543,7 +1573,7 @@ class CINppConv(SparseCINConv):
             elif plans[dim] is None:
                 out.append(self.mp_levels[dim].forward_unfused(cochain))
             else:
-                m = len(plans[dim])
+                m = self._n_streams(plans[dim])
                 out.append(self.mp_levels[dim].finish(*outs[k:k + m]))
                 k += m
         return self._finish_dropout(out, start_to_process)

@@ -1781,6 +1781,10 @@ class LayerDim:
     msg_bias: Optional[Tensor] = None
     eps1: Optional[Tensor] = None
     eps2: Optional[Tensor] = None
+    # a CIN++ layer (mp/layers.py:243-260, lower stream off): the launch also writes out_down = (1 + eps3) x and returns
+    # [out_up, out_down, out_b] per dimension -- the order of torch.cat in :260
+    eps3: Optional[Tensor] = None
+    want_down: bool = False
 
 
 # Prepared forms of model state -- packed weights, BatchNorm folded into an affine, prepared launches -- are
@@ -2429,7 +2433,8 @@ def run_stage(gemms: Sequence['Gemm'], device) -> Optional[List[Tensor]]:
 
 
 def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tensor]:
-    """[out_up_0, out_b_0, out_up_1, out_b_1, ...]; no autograd (inference path).  `table` is one of the
+    """[out_up_0, out_b_0, out_up_1, out_b_1, ...] ([out_up_d, out_down_d, out_b_d] for a dimension with `want_down`); no
+    autograd (inference path).  `table` is one of the
     batch's item tables (cwn_amd/blockplan.py: ItemTable); csr_mode 0 sorts the COO entries in the
     kernel, _ffi.LAYER_CSR_STORE also stores every item's CSR in the table's cache, _ffi.LAYER_CSR_LOAD
     reads it back instead (same index tensors as the storing call).  Index errors go to the sticky
@@ -2451,15 +2456,18 @@ def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tens
         e1, e2 = _f32c(D.eps1, 'eps1'), _f32c(D.eps2, 'eps2')
         out_up = torch.empty_like(x)
         out_b = torch.empty_like(x)
-        outs += [out_up, out_b]
-        keep += [x, w, b, e1, e2]
+        out_d = torch.empty_like(x) if D.want_down else None
+        e3 = _f32c(D.eps3, 'eps3') if D.want_down else None
+        outs += [out_up, out_b] if out_d is None else [out_up, out_d, out_b]
+        keep += [x, w, b, e1, e2, e3]
         e_up = 0 if up is None else int(up.size(1))
         arr[d] = _ffi.LayerDim(x=x.data_ptr(), up_index=_ffi.ptr(up) if e_up else None,
                                up_shared=_ffi.ptr(sh) if e_up else None,
                                b_index=_ffi.ptr(bi) if bi is not None and bi.size(1) else None,
                                msg_w_packed=_ffi.ptr(w), msg_bias=_ffi.ptr(b), eps1=_ffi.ptr(e1), eps2=_ffi.ptr(e2),
                                out_up=out_up.data_ptr(), out_b=out_b.data_ptr(), n_cells=x.size(0),
-                               e_up=e_up, n_b=0 if bi is None else int(bi.size(1)))
+                               e_up=e_up, n_b=0 if bi is None else int(bi.size(1)),
+                               out_down=_ffi.ptr(out_d), eps3=_ffi.ptr(e3))
     plan = table.c_plan(with_cache=csr_mode != 0)
     _ffi.check(_ffi.lib().cwn_layer_fused_f32(arr, len(dims), F, plan, int(csr_mode), _err_flag(dev).data_ptr(),
                                                _ffi.stream_ptr(dev)), 'cwn_layer_fused_f32')
@@ -2556,9 +2564,10 @@ class LayerLaunch:
                     raise TypeError(f'{name} must be a contiguous int64 GPU tensor')
             w, b = D.msg_w_packed, _f32c(D.msg_bias, 'msg_bias')
             e1, e2 = _f32c(D.eps1, 'eps1'), _f32c(D.eps2, 'eps2')
-            self.keep += [up, sh, bi, w, b, e1, e2]
+            e3 = _f32c(D.eps3, 'eps3') if D.want_down else None
+            self.keep += [up, sh, bi, w, b, e1, e2, e3]
             e_up = 0 if up is None else int(up.size(1))
-            self.arr[d] = _ffi.LayerDim(up_index=_ffi.ptr(up) if e_up else None, up_shared=_ffi.ptr(sh) if e_up else None,
+            self.arr[d] = _ffi.LayerDim(eps3=_ffi.ptr(e3), up_index=_ffi.ptr(up) if e_up else None, up_shared=_ffi.ptr(sh) if e_up else None,
                                         b_index=_ffi.ptr(bi) if bi is not None and bi.size(1) else None,
                                         msg_w_packed=_ffi.ptr(w), msg_bias=_ffi.ptr(b), eps1=_ffi.ptr(e1),
                                         eps2=_ffi.ptr(e2), n_cells=int(D.x.size(0)), e_up=e_up,
@@ -2569,7 +2578,12 @@ class LayerLaunch:
                 self._attach_big(dims, part)
         self._big_y = [(self.arr[d].big_y1, self.arr[d].big_y2) for d in range(self.n)]     # the BIG records' scratch
         self.total_rows = sum(self.rows)
-        self._sizes = [r for r in self.rows for _ in range(2)]          # rows of out_up_d, out_b_d, in output order
+        # outputs per dimension: (out_up, out_b), or (out_up, out_down, out_b) when the layer wants the third (all or none)
+        downs = [bool(D.want_down) for D in dims]
+        if any(downs) and not all(downs):
+            raise ValueError('want_down: every dimension of a layer or none')
+        self.n_out = 3 if downs[0] else 2
+        self._sizes = [r for r in self.rows for _ in range(self.n_out)]   # rows of the outputs, in output order
         self._off = [sum(self._sizes[:i]) for i in range(len(self._sizes))]
         self.dev = dims[0].x.device
         self._plans = {}
@@ -2581,7 +2595,8 @@ class LayerLaunch:
         from . import _cext
         X = _cext.ext()
         self._c = None if X is None else X.LayerCall(C.addressof(self.arr), C.sizeof(self.arr), self.n, self.F,
-                                                     self.rows, self._err_ptr, _cext.fn_address(self.fn), self.dev.index)
+                                                     self.rows, self._err_ptr, _cext.fn_address(self.fn), self.dev.index,
+                                                     self.n_out)
 
     def _attach_big(self, dims: Sequence[LayerDim], table) -> None:
         """BIG records (include/cwn_hip.h): complexes no workgroup's LDS holds are streamed by their workgroup, which
@@ -2672,7 +2687,8 @@ class LayerLaunch:
             a.big_y2 = y2.data_ptr() if y2 is not None else self._big_y[d][1]
         if ys is not None:
             csr_mode = int(csr_mode) | _ffi.LAYER_STORE_Y
-        buf = torch.empty(2 * self.total_rows, F, dtype=torch.float32, device=self.dev)   # all six outputs
+        k = self.n_out
+        buf = torch.empty(k * self.total_rows, F, dtype=torch.float32, device=self.dev)   # all six (nine) outputs
         outs = buf.split(self._sizes)                       # one call: [out_up_0, out_b_0, out_up_1, ...]
         base, row_b = buf.data_ptr(), 4 * F
         for d in range(self.n):
@@ -2685,8 +2701,10 @@ class LayerLaunch:
                 raise TypeError('features must be float32 tensors on the GPU this launch was prepared for')
             a = self.arr[d]
             a.x = x.data_ptr()
-            a.out_up = base + self._off[2 * d] * row_b
-            a.out_b = base + self._off[2 * d + 1] * row_b
+            a.out_up = base + self._off[k * d] * row_b
+            a.out_b = base + self._off[k * d + k - 1] * row_b
+            if k == 3:
+                a.out_down = base + self._off[k * d + 1] * row_b
         cached = (int(csr_mode) & (_ffi.LAYER_CSR_STORE | _ffi.LAYER_CSR_LOAD)) != 0
         plans = self._plans.get(cached)
         if plans is None:

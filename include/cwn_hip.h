@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 21
+#define CWN_ABI_VERSION 22
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -300,6 +300,12 @@ typedef struct cwn_layer_dim {
     const int32_t* big_b_col;       /* boundary cell (dim d - 1) */
     float* big_y1;
     float* big_y2;
+    /* A THIRD output (ABI 22; NULL = not wanted): out_down[i] = (1 + eps3) x_i -- what CINppCochainConv.forward
+     * (mp/layers.py:243-260) feeds update_down_nn when the lower stream is off, which is how the reference's molecular CIN++
+     * models run it (include_down_features=False: down_index is None, propagate() returns zeros, :253 adds the self term).
+     * Written by the workgroup that owns the row, from the registers that hold it: no extra read. */
+    float* out_down;           /* [n_cells, F] or NULL */
+    const float* eps3;         /* device scalar or NULL (= 0) */
 } cwn_layer_dim;
 
 /* The weight of the message Linear in the form the kernel's matrix-core loop reads it: the exact

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 21
+    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 22
     assert lib.cwn_target_arch() == b'gfx950'
     assert lib.cwn_error_string(0) == b'ok'
 
@@ -762,8 +762,10 @@ def test_compiled_binding_module_loads_and_matches_the_abi():
     fn = _cext.fn_address(_ffi.lib().cwn_layer_fused_f32)
     arr = (_ffi.LayerDim * 2)()
     with pytest.raises(ValueError, match='ABI'):
-        X.LayerCall(ctypes.addressof(arr), ctypes.sizeof(arr) - 8, 2, 64, [3, 4], 0, fn, 0)
-    c = X.LayerCall(ctypes.addressof(arr), ctypes.sizeof(arr), 2, 64, [3, 4], 0, fn, 0)
+        X.LayerCall(ctypes.addressof(arr), ctypes.sizeof(arr) - 8, 2, 64, [3, 4], 0, fn, 0, 2)
+    with pytest.raises(ValueError, match='two or three outputs'):
+        X.LayerCall(ctypes.addressof(arr), ctypes.sizeof(arr), 2, 64, [3, 4], 0, fn, 0, 4)
+    c = X.LayerCall(ctypes.addressof(arr), ctypes.sizeof(arr), 2, 64, [3, 4], 0, fn, 0, 2)
     assert not c.has_plans(False) and not c.has_plans(True)
     with pytest.raises(ValueError, match='one feature tensor per dimension'):
         c.run([torch.zeros(3, 64)], 0, None)

@@ -1,0 +1,183 @@
+"""CIN++ layers (mp/layers.py:216-260, 344-427) through the complex-blocked launch (round 6).
+
+As the reference's molecular CIN++ models run the layer -- include_down_features=False (mp/molec_models.py:111), so down_index
+is None and out_down = zeros + (1 + eps2) x (:253) -- the propagate scope is the SparseCIN one plus a third output per
+dimension, which the launch writes from the registers that hold the row (cwn_layer_dim.out_down).  Checked here:
+  * bit-identical to the streaming path (grouped GEMM + one aggregation launch over three streams) in every form of the launch
+    (16 waves, two per CU, BIG records, mixed), sort / store / load modes;
+  * against the float64 oracle (the SparseCIN scope of tests/test_gpu_blocked.py + the third output);
+  * the whole EmbedCINpp forward equal to the streaming path's, and the reference-generated goldens (tests/test_gpu_parity.py::
+    test_embed_cinpp_whole_stack_golden) through it at hidden 64;
+  * a lower adjacency (feed_down_attr) or the co-boundary stream keeps the layer off the blocked launch, with a reason."""
+import pytest
+import torch
+
+from tests.test_gpu_blocked import _batch, _gate, cpu
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _conv(F, seed=0, eps=0.0, **kw):
+    from cwn_amd.layers import CINppConv
+    torch.manual_seed(seed)
+    conv = CINppConv(F, F, F, None, None, None, None, None, None, max_dim=2, hidden=F, eps=eps, train_eps=True,
+                     act_module=torch.nn.ReLU, layer_dim=F, use_coboundaries=True, **kw)
+    with torch.no_grad():                # three different eps per level: a swapped pair would show
+        for d, lvl in enumerate(conv.mp_levels):
+            lvl.eps1.fill_(eps + 0.125 * d)
+            lvl.eps2.fill_(eps + 0.5 + 0.0625 * d)
+            lvl.eps3.fill_(eps - 0.25 + 0.03125 * d)
+    return conv.to(DEV).eval()
+
+
+def _run(conv, b, blocked):
+    from cwn_amd import layers
+    prev = layers.BLOCKED_LAYER
+    layers.BLOCKED_LAYER = blocked
+    try:
+        with torch.no_grad():
+            params = b.get_all_cochain_params(max_dim=2, include_down_features=False)
+            plans, outs = conv.propagate_all(*params)
+        assert (plans[0] == 'blocked') == blocked, getattr(conv, 'blocked_reason', None)
+    finally:
+        layers.BLOCKED_LAYER = prev
+    return outs
+
+
+@pytest.mark.parametrize('kind,n,F,variant', [('zinc', 128, 128, '0'), ('zinc', 300, 128, '1'), ('zinc', 1, 128, '0'), ('zinctrees', 40, 128, '0'),
+                                              ('molhiv', 96, 64, '0'), ('molhiv', 400, 64, '1')])
+def test_cinpp_blocked_is_bit_identical_to_the_streaming_path(kind, n, F, variant):
+    from cwn_amd import csr, layers
+    b = _batch(kind, n, F, seed=61)
+    conv = _conv(F, seed=62, eps=0.25)
+    prev = layers.LAYER_VARIANT
+    try:
+        layers.LAYER_VARIANT = variant
+        layers._BLOCKED_CACHE.clear()
+        b.block_plan().forget_csr()
+        first = _run(conv, b, blocked=True)       # sorts + stores the per-item CSR
+        second = _run(conv, b, blocked=True)      # loads it
+        with torch.no_grad():
+            table = conv._blocked_args(b.get_all_cochain_params(max_dim=2, include_down_features=False), 0)[2]
+        assert table.variant == int(variant)
+    finally:
+        layers.LAYER_VARIANT = prev
+        layers._BLOCKED_CACHE.clear()
+    csr._cache.clear()
+    plain = _run(conv, b, blocked=False)
+    assert len(first) == len(plain) == 9
+    for i, (f, s, p) in enumerate(zip(first, second, plain)):
+        assert torch.equal(f, s), (i, 'store vs load')
+        if F == 128 or i % 3 == 1:          # (width 64: the streaming path multiplies on fp32 MFMA; the third output has no product)
+            assert torch.equal(f, p), (i, (f - p).abs().max().item())
+        else:
+            _gate(f, cpu(p).double(), f'{kind}-{n} F={F} stream {i} vs streaming path')
+    # the third output against its definition, in float64
+    for d in range(3):
+        x = cpu(b.cochains[d].x).double()
+        want = (1.0 + float(conv.mp_levels[d].eps2)) * x
+        _gate(first[3 * d + 1], want, f'out_down[{d}]')
+        assert torch.equal(first[3 * d + 1], (1.0 + conv.mp_levels[d].eps2) * b.cochains[d].x)
+    print(f'[gate] CIN++ {kind}-{n} F={F} variant {variant}: nine outputs torch.equal across sort / load'
+          + (' and to the streaming path' if F == 128 else '; third output torch.equal to (1 + eps2) x'))
+
+
+def test_cinpp_blocked_with_big_records_and_mixed_launches():
+    from cwn_amd import csr, layers
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    F = 128
+    small, large = zinc_like_complexes(300, 71, 6), zinc_like_complexes(12, 72, 6, n_lo=28, n_hi=70)
+    cxs = []
+    for i, c in enumerate(small):
+        cxs.append(c)
+        if i % 23 == 5 and large:
+            cxs.append(large.pop())
+    cxs += large
+    b = ComplexBatch.from_complex_list(cxs, max_dim=2).to(DEV)
+    g = torch.Generator().manual_seed(73)
+    for d in range(3):
+        b.cochains[d].x = torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV)
+    conv = _conv(F, seed=74, eps=0.1)
+    keep = (layers.BIG_ITEMS, layers.LAYER_VARIANT)
+    outs = {}
+    try:
+        for variant in ('0', 'mixed'):
+            layers.BIG_ITEMS, layers.LAYER_VARIANT = 'always', variant
+            layers._BLOCKED_CACHE.clear()
+            with torch.no_grad():
+                table = conv._blocked_args(b.get_all_cochain_params(max_dim=2, include_down_features=False), 0)[2]
+            assert (table.variant == 'mixed') == (variant == 'mixed'), table.variant
+            assert getattr(table, 'n_big', 0) or any(getattr(p, 'n_big', 0) for p in getattr(table, 'parts', []))
+            outs[variant] = _run(conv, b, blocked=True)
+    finally:
+        layers.BIG_ITEMS, layers.LAYER_VARIANT = keep
+        layers._BLOCKED_CACHE.clear()
+    csr._cache.clear()
+    plain = _run(conv, b, blocked=False)
+    for v, got in outs.items():
+        for i, (f, p) in enumerate(zip(got, plain)):
+            assert torch.equal(f, p), (v, i, (f - p).abs().max().item())
+    print('[gate] CIN++ with BIG records, 16-wave and mixed launches: nine outputs torch.equal to the streaming path')
+
+
+@pytest.mark.parametrize('H', [64, 128])
+def test_embed_cinpp_forward_blocked_equals_streaming(H):
+    from cwn_amd import csr, layers
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import EmbedCINpp
+    from cwn_amd.synthetic import zinc_like_complexes
+    torch.manual_seed(5)
+    model = EmbedCINpp(28, 4, 1, 3, H, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu', readout='sum',
+                       train_eps=True, final_hidden_multiplier=2, final_readout='sum', init_reduce='sum', embed_edge=True,
+                       use_coboundaries=True, graph_norm='bn').to(DEV).eval()
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0.0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+        for conv in model.convs:
+            for d, lvl in enumerate(conv.mp_levels):
+                lvl.eps1.fill_(0.1 + 0.01 * d); lvl.eps2.fill_(-0.2); lvl.eps3.fill_(0.3)
+    b = ComplexBatch.from_complex_list(zinc_like_complexes(64, 9, 6), max_dim=2).to(DEV)
+    x0 = [None if b.cochains[d].x is None else b.cochains[d].x.clone() for d in range(3)]
+
+    def fwd(blocked):
+        prev = layers.BLOCKED_LAYER
+        layers.BLOCKED_LAYER = blocked
+        layers._BLOCKED_CACHE.clear()
+        csr._cache.clear()
+        try:
+            for d in range(3):
+                b.cochains[d]._x = x0[d]
+            with torch.no_grad():
+                y, res = model(b, include_partial=True)
+            reason = [getattr(c, 'blocked_reason', 'x') for c in model.convs]
+        finally:
+            layers.BLOCKED_LAYER = prev
+        return y, res, reason
+    yb, rb, why_b = fwd(True)
+    ys, rs, why_s = fwd(False)
+    assert all(w is None for w in why_b), why_b
+    assert all(w is not None for w in why_s)
+    for k in rs:
+        if H == 128:
+            assert torch.equal(rb[k], rs[k]), (k, (rb[k] - rs[k]).abs().max().item())
+        else:
+            _gate(rb[k], cpu(rs[k]).double(), f'EmbedCINpp H={H} {k}: blocked vs streaming')
+    _gate(yb, cpu(ys).double(), f'EmbedCINpp H={H} out: blocked vs streaming')
+    print(f'[gate] EmbedCINpp forward (hidden {H}): blocked propagate ' + ('torch.equal to' if H == 128 else 'within 1e-5 of') + ' the streaming path')
+
+
+def test_cinpp_layers_with_other_streams_stay_off_the_blocked_launch():
+    b = _batch('zinc', 16, 64, seed=81)
+    for kw, word in ((dict(coboundary_stream=True), 'co-boundary'),):
+        conv = _conv(64, seed=82, **kw)
+        with torch.no_grad():
+            got = conv._blocked_args(b.get_all_cochain_params(max_dim=2, include_down_features=False), 0)
+        assert isinstance(got, str) and word in got, got
+    conv = _conv(64, seed=83, feed_down_attr=True)
+    with torch.no_grad():
+        got = conv._blocked_args(b.get_all_cochain_params(max_dim=2, include_down_features=True), 0)
+    assert isinstance(got, str) and 'lower-adjacency' in got, got
