@@ -19,7 +19,7 @@ REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 22
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
-           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_update_mlp_pack_weights_both_many_f32', 'cwn_layer_pack_weights_both_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_ex_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_slots', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_collate_guard', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
+           'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp3_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_update_mlp_pack_weights_both_many_f32', 'cwn_layer_pack_weights_both_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_ex_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_slots', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_collate_guard', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
            'cwn_bn_finalize_f32', 'cwn_step_begin', 'cwn_dropout_f32', 'cwn_embed_front_bwd_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_loss_cols_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_head_pool_floats', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
@@ -127,6 +127,13 @@ class MlpDim(C.Structure):
                 ('bias', C.c_void_p * 5), ('scale', C.c_void_p * 5), ('shift', C.c_void_p * 5),
                 ('y', C.c_void_p), ('M', C.c_int64), ('ldx_up', C.c_int64), ('ldx_b', C.c_int64), ('ldy', C.c_int64),
                 ('m_dev', C.c_void_p), ('in_width', C.c_int32), ('pad_', C.c_int32)]
+
+
+class Mlp3Dim(C.Structure):
+    """cwn_mlp3_dim (include/cwn_hip.h): the three update networks + the 3F-wide combine of a CIN++ layer."""
+    _fields_ = [('x', C.c_void_p * 3), ('ldx', C.c_int64 * 3), ('w_packed', C.c_void_p * 9),
+                ('bias', C.c_void_p * 7), ('scale', C.c_void_p * 7), ('shift', C.c_void_p * 7),
+                ('y', C.c_void_p), ('M', C.c_int64), ('ldy', C.c_int64), ('m_dev', C.c_void_p)]
 
 
 BN_SLOTS = 4                   # = CWN_BN_SLOTS
@@ -307,6 +314,7 @@ def lib():
     L.cwn_layer_fused_lds_bytes.restype = C.c_size_t
     L.cwn_layer_fused_lds_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.cwn_update_mlp_f32.argtypes = [C.POINTER(MlpDim), C.c_int, C.c_int32, C.c_void_p]
+    L.cwn_update_mlp3_f32.argtypes = [C.POINTER(Mlp3Dim), C.c_int, C.c_int32, C.c_void_p]
     L.cwn_update_mlp_packed_weight_bytes.restype = C.c_size_t
     L.cwn_update_mlp_packed_weight_bytes.argtypes = [C.c_int32]
     L.cwn_update_mlp_pack_weights_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]

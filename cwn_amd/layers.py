@@ -1489,6 +1489,22 @@ class CINppConv(SparseCINConv):
         folds = [[_fold_norm(norm, lin.out_features) for lin, norm in st] for st in flat]
         if any(f is None for fs in folds for f in fs) or any(lin.in_features > ops.GEMM_MAX_K for st in flat for lin, _ in st):
             return None
+        if nb == 3 and FUSED_UPDATE_MLP and not ops.GEMM_EXACT and all(len(st) == 2 for st in flat):
+            # three update networks + the 3F-wide combine of every dimension in ONE launch (csrc/cwn_mlp3.hip, round 6): the
+            # activations between the seven Linear layers stay in LDS, the combine is accumulated branch by branch
+            mdims = []
+            for k, d in enumerate(active):
+                cb = _mlp_stages(self.mp_levels[d].combine_nn)
+                cfold = None if cb is None or len(cb) != 1 else _fold_norm(cb[0][1], cb[0][0].out_features)
+                if cfold is None:
+                    mdims = None
+                    break
+                sts, fs = flat[nb * k: nb * (k + 1)], folds[nb * k: nb * (k + 1)]
+                mdims.append(ops.Mlp3Dim(xs=list(outs[nb * k: nb * (k + 1)]),
+                                         linears=[st[j][0] for st in sts for j in range(2)] + [cb[0][0]],
+                                         folds=[f[j] for f in fs for j in range(2)] + [cfold]))
+            if mdims and ops.update_mlp3_applies(mdims):
+                return ops.update_mlp3(mdims)
         hs, dev = list(outs), outs[0].device
         for s in range(len(flat[0])):
             gemms = [ops.Gemm(X=h, W=st[s][0].weight, bias=st[s][0].bias, relu=True, out_scale=fs[s][0], out_shift=fs[s][1],

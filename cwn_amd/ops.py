@@ -2031,6 +2031,66 @@ def update_mlp(dims: Sequence[MlpDim]) -> List[Tensor]:
     return outs
 
 
+@dataclass
+class Mlp3Dim:
+    """One cochain dimension of cwn_update_mlp3_f32 (cwn_mlp3_dim in include/cwn_hip.h): the three outputs of a CIN++ layer's
+    propagate step (up, down, boundaries), the seven Linear layers in the order (1u, 2u, 1d, 2d, 1b, 2b, combine) and their
+    folded norms."""
+    xs: Sequence[Tensor]                                       # three [M, F]
+    linears: Sequence[torch.nn.Linear]                         # seven modules
+    folds: Sequence[tuple]                                     # seven (scale, shift) pairs, (None, None) = identity
+
+
+def update_mlp3_applies(dims: Sequence[Mlp3Dim]) -> bool:
+    cap = int(_ffi.lib().cwn_update_mlp_max_rows())
+    if not dims or any(len(D.linears) != 7 or len(D.xs) != 3 or len(D.folds) != 7 for D in dims):
+        return False
+    F = int(dims[0].linears[1].weight.size(0))
+    if F not in (64, 128):
+        return False
+    for D in dims:
+        if any(x.dim() != 2 or x.size(1) != F or x.size(0) != D.xs[0].size(0) or x.size(0) > cap or x.dtype != torch.float32
+               or not x.is_cuda for x in D.xs):
+            return False
+        if [tuple(l.weight.shape) for l in D.linears] != [(F, F)] * 6 + [(F, 3 * F)]:
+            return False
+    return True
+
+
+def update_mlp3(dims: Sequence[Mlp3Dim]) -> List[Tensor]:
+    """mp/layers.py:255-260 for every dimension in ONE launch (csrc/cwn_mlp3.hip); inference only.  The packed weights are
+    cached per weight version (pack_mlp_weight); the descriptor itself is a few microseconds of host time."""
+    dev = dims[0].xs[0].device
+    F = int(dims[0].linears[1].weight.size(0))
+    n = len(dims)
+    arr = (_ffi.Mlp3Dim * n)()
+    rows = [int(D.xs[0].size(0)) for D in dims]
+    buf = torch.empty(sum(rows), F, dtype=torch.float32, device=dev)
+    outs = list(buf.split(rows))
+    keep, off = [], 0
+    for i, D in enumerate(dims):
+        a = arr[i]
+        for k in range(3):
+            x = _rowmajor(D.xs[k], 'x')
+            keep.append(x)
+            a.x[k] = x.data_ptr()
+            a.ldx[k] = x.stride(0) if x.size(0) > 1 else F
+        a.y, a.M, a.ldy = buf.data_ptr() + off * 4 * F, rows[i], F
+        a.m_dev = _ffi.dyn(rows[i])
+        off += rows[i]
+        wc = pack_mlp_weight(D.linears[6].weight)               # the three F-column blocks of the combine weight
+        for k in range(3):
+            a.w_packed[3 * k] = pack_mlp_weight(D.linears[2 * k].weight)[0].data_ptr()
+            a.w_packed[3 * k + 1] = pack_mlp_weight(D.linears[2 * k + 1].weight)[0].data_ptr()
+            a.w_packed[3 * k + 2] = wc[k].data_ptr()
+        for s_, (lin, (sc, sh)) in enumerate(zip(D.linears, D.folds)):
+            b = None if lin.bias is None else _f32c(lin.bias, 'bias')
+            a.bias[s_], a.scale[s_], a.shift[s_] = _ffi.ptr(b), _ffi.ptr(sc), _ffi.ptr(sh)
+            keep += [b, sc, sh]
+    _ffi.check(_ffi.lib().cwn_update_mlp3_f32(arr, n, F, _ffi.stream_ptr(dev)), 'cwn_update_mlp3_f32')
+    return outs
+
+
 class MlpLaunch:
     """A prepared cwn_update_mlp_f32 call for one layer (round 5: the eager forward spent 3/4 of its host time re-deriving
     this record on every call): packed weights, biases and folded norms of every dimension filled in once; `run` fills in
@@ -2119,8 +2179,8 @@ _packed_mlp_weights = {}
 
 
 def pack_mlp_weight(weight: Tensor):
-    """An [F, F] weight -- or the column halves of an [F, 2F] combine weight -- in the form cwn_update_mlp_f32
-    streams (cwn_update_mlp_pack_weights_f32); a tuple of one or two buffers, cached per weight version."""
+    """An [F, F] weight -- or the F-column blocks of an [F, 2F] / [F, 3F] combine weight -- in the form cwn_update_mlp_f32 /
+    cwn_update_mlp3_f32 stream (cwn_update_mlp_pack_weights_f32); a tuple of one to three buffers, cached per weight version."""
     import weakref
     w = weight.detach()
     key = id(weight)
@@ -2132,8 +2192,8 @@ def pack_mlp_weight(weight: Tensor):
     F = int(w.size(0))
     L = _ffi.lib()
     n = int(L.cwn_update_mlp_packed_weight_bytes(F))
-    if n == 0 or w.size(1) not in (F, 2 * F):
-        raise ValueError('expected an [F, F] or [F, 2F] weight with F in (64, 128)')
+    if n == 0 or w.size(1) not in (F, 2 * F, 3 * F):
+        raise ValueError('expected an [F, F], [F, 2F] or [F, 3F] weight with F in (64, 128)')
     parts = []
     for c0 in range(0, w.size(1), F):
         out = torch.empty(n, dtype=torch.uint8, device=w.device)

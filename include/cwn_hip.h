@@ -558,6 +558,33 @@ int cwn_update_mlp_pack_weights_many_f32(const float* const* W, const int64_t* l
                                          cwn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The same for a CIN++ layer (ABI 22): THREE update networks and a 3F-wide combine, all dimensions, ONE launch (inference):
+ *
+ *     h_k = relu(bn(W2_k relu(bn(W1_k x_k + b1_k)) + b2_k))     k = up, down, boundaries     (mp/layers.py:383-410)
+ *     y   = relu(bn(Wc [h_up | h_down | h_b] + bc))                                          (:411-414, :255-260)
+ *
+ * x[k]: the three outputs of the propagate step (cwn_layer_fused_f32 with cwn_layer_dim.out_down: out_up, out_down, out_b),
+ * [M, F] with row stride ldx[k].  w_packed (cwn_update_mlp_pack_weights_f32), in the order the launch multiplies: per branch
+ * k its W1_k, W2_k and the k-th F-column block of the combine weight (ldw = 3F): [W1u, W2u, Wc[:, 0:F], W1d, W2d, Wc[:, F:2F],
+ * W1b, W2b, Wc[:, 2F:3F]].  bias / scale / shift per stage in the order (1u, 2u, 1d, 2d, 1b, 2b, c); NULL as in cwn_mlp_dim.
+ * The combine is accumulated branch by branch in the order of the cat, so three plane buffers serve three branches (two
+ * workgroups per CU).  Same limits, alignment and arithmetic as cwn_update_mlp_f32; no narrow inputs (in_width).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cwn_mlp3_dim {
+    const float* x[3];          /* [M, F] each */
+    int64_t ldx[3];
+    const void* w_packed[9];
+    const float* bias[7];       /* [F] or NULL */
+    const float* scale[7];      /* [F] or NULL (then shift NULL too) */
+    const float* shift[7];
+    float* y;                   /* [M, F], row stride ldy */
+    int64_t M, ldy;
+    const int64_t* m_dev;       /* or NULL: actual rows (M = capacity) */
+} cwn_mlp3_dim;
+
+int cwn_update_mlp3_f32(const cwn_mlp3_dim* dims_host, int n_dims, int32_t F, cwn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * A BatchNorm1d(train) WITHOUT a launch of its own (round 4; torch.nn.BatchNorm1d inside update_up_nn / update_boundaries_nn /
  * combine_nn, mp/layers.py:303-325, exp/train_utils.py:57-75 in training mode): the launch that PRODUCES the pre-normalisation
  * values adds its workgroups' column sums into `slots` (fp64 atomics, one coalesced instruction per 64 columns and workgroup,

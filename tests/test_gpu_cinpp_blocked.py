@@ -177,7 +177,60 @@ def test_cinpp_layers_with_other_streams_stay_off_the_blocked_launch():
         with torch.no_grad():
             got = conv._blocked_args(b.get_all_cochain_params(max_dim=2, include_down_features=False), 0)
         assert isinstance(got, str) and word in got, got
+    # a real lower adjacency (the synthetic batches above carry none: without one the layer's lower stream is its self term)
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    bd = ComplexBatch.from_complex_list(zinc_like_complexes(16, 81, 6, include_down_adj=True), max_dim=2).to(DEV)
+    g = torch.Generator().manual_seed(84)
+    for d in range(3):
+        bd.cochains[d].x = torch.randn(bd.cochains[d].num_cells, 64, generator=g).to(DEV)
     conv = _conv(64, seed=83, feed_down_attr=True)
     with torch.no_grad():
-        got = conv._blocked_args(b.get_all_cochain_params(max_dim=2, include_down_features=True), 0)
-    assert isinstance(got, str) and 'lower-adjacency' in got, got
+        got = conv._blocked_args(bd.get_all_cochain_params(max_dim=2, include_down_features=True), 0)
+        assert isinstance(got, str) and 'lower-adjacency' in got, got
+        # ... and the same layer over params without it (include_down_features=False: down_index None) takes the launch
+        assert not isinstance(conv._blocked_args(bd.get_all_cochain_params(max_dim=2, include_down_features=False), 0), str)
+
+
+@pytest.mark.parametrize('F,rows', [(128, (3165, 3341, 304)), (64, (1, 65, 130)), (128, (31, 32, 33)), (64, (20000, 7, 0))])
+def test_fused_update_mlp3_vs_float64_and_the_grouped_launches(F, rows):
+    """cwn_update_mlp3_f32 (csrc/cwn_mlp3.hip): update_up_nn / update_down_nn / update_boundaries_nn + the 3F-wide combine_nn
+    of every dimension in one launch (mp/layers.py:255-260) against the same torch modules evaluated in float64, and against
+    the path it replaces (two grouped GEMM launches + torch.cat + combine_nn as torch modules)."""
+    import copy
+    from cwn_amd import layers, ops
+    conv = _conv(F, seed=91)
+    with torch.no_grad():
+        for m in conv.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0.0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0.0, 0.2)
+    g = torch.Generator().manual_seed(92)
+    outs = [torch.randn(r, F, generator=g).to(DEV) for r in rows for _ in range(3)]
+    plans = ['blocked'] * 3
+    calls = []
+    orig = ops.update_mlp3
+    ops.update_mlp3 = lambda dims: (calls.append(len(dims)), orig(dims))[1]
+    try:
+        with torch.no_grad():
+            fused = conv._dense_eval(plans, outs, 0)
+            prev, layers.FUSED_UPDATE_MLP = layers.FUSED_UPDATE_MLP, False
+            try:
+                grouped = conv._dense_eval(plans, outs, 0)
+            finally:
+                layers.FUSED_UPDATE_MLP = prev
+    finally:
+        ops.update_mlp3 = orig
+    assert calls == [3], calls
+    ref = copy.deepcopy(conv).double().cpu().eval()
+    for d in range(3):
+        lvl = ref.mp_levels[d]
+        xs = [cpu(outs[3 * d + k]).double() for k in range(3)]
+        with torch.no_grad():
+            want = lvl.combine_nn(torch.cat([lvl.update_up_nn(xs[0]), lvl.update_down_nn(xs[1]), lvl.update_boundaries_nn(xs[2])], dim=-1)) \
+                if rows[d] else torch.zeros(0, F, dtype=torch.float64)
+        _gate(fused[d], want, f'update_mlp3 F={F} dim {d} ({rows[d]} rows) vs float64')
+        _gate(grouped[d], want, f'grouped launches F={F} dim {d} vs float64')
+        assert fused[d].shape == (rows[d], F)
