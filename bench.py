@@ -67,13 +67,13 @@ def parse():
     return p.parse_args()
 
 
-def layer_algorithmic_bytes(stats, F, coboundary=True):
+def layer_algorithmic_bytes(stats, F, coboundary=True, out_streams=2):
     """SURVEY.md §8d, per conv layer (all three propagate calls): int64 indices as delivered,
-    gather-counted fp32 rows, two output streams per dimension."""
+    gather-counted fp32 rows, `out_streams` output streams per dimension (2 for SparseCIN; 3 for CIN++: up, down, boundaries)."""
     total = 0
     for d in range(3):
         e_up, b, n = stats[f'E_up{d}'], stats[f'B{d}'], stats[f'N{d}']
-        total += e_up * (16 + 4 * F) + b * (16 + 4 * F) + 4 * F * n * 2
+        total += e_up * (16 + 4 * F) + b * (16 + 4 * F) + 4 * F * n * out_streams
         if coboundary:
             total += e_up * (8 + 4 * F)
     return total
@@ -925,7 +925,7 @@ def main():
 
         b, feats = batches[0], layer_inputs[0]
         step_us = dt / args.steps * 1e6
-        alg = layer_algorithmic_bytes(stats[0], H, coboundary=coboundary)
+        alg = layer_algorithmic_bytes(stats[0], H, coboundary=coboundary, out_streams=3 if CINPP else 2)
         if BLOCKED:
             # ONE kernel per layer: layer_kernel (csrc/cwn_layer.hip).  Launch 0 of a step reads and sorts
             # the COO entries and stores every item's CSR ("store"), launches 1.. load it back ("load").
@@ -957,7 +957,7 @@ def main():
             layer_us = ((L - 1) * load_us + store_us) / L
             roofline = {
                 'bound': 'hbm',
-                'kernel': f'layer_kernel<{H}, load> (complex-blocked SparseCIN propagate step: message GEMMs on the '
+                'kernel': f'layer_kernel<{H}, load> (complex-blocked ' + ('CIN++' if CINPP else 'SparseCIN') + ' propagate step: message GEMMs on the '
                           'bf16 matrix pipe into LDS, per-complex CSR, both reductions + self terms out of LDS)',
                 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                 'traffic': traffic,
@@ -984,22 +984,23 @@ def main():
                     conv1 = model.convs[1]
                     if conv1._dense_eval(plans_, outs_, 0) is not None and layers_mod.FUSED_UPDATE_MLP:
                         mlp_us = replay_us(lambda: conv1._dense_eval(plans_, outs_, 0), args.kernel_reps)
-                        mflops = 2.0 * s0_['cells'] * 6 * H * H          # five Linear layers per cell, the combine is 2H wide
+                        mflops = 2.0 * s0_['cells'] * (9 if CINPP else 6) * H * H     # five Linear layers per cell, the combine 2H wide (CIN++: seven, 3H)
                         mtf = mflops / (mlp_us * 1e-6) / 1e12
                         roofline_mlp = {
-                            'bound': 'mfma', 'kernel': f'update_mlp_kernel<{H}> (update_up_nn, update_boundaries_nn, combine_nn of all '
+                            'bound': 'mfma', 'kernel': (f'update_mlp3_kernel<{H}> (update_up_nn, update_down_nn, update_boundaries_nn, 3H-wide combine_nn' if CINPP else
+                                                        f'update_mlp_kernel<{H}> (update_up_nn, update_boundaries_nn, combine_nn') + ' of all '
                                                        'dimensions in one launch; exact 3-way bf16 split, six MFMAs per product term)',
                             'achieved': round(mtf, 2), 'peak': round(MFMA_BF16_PEAK_TF / 6.0, 1), 'unit': 'TFLOP/s',
                             'frac': round(mtf / (MFMA_BF16_PEAK_TF / 6.0), 4), 'traffic': None,
                             'frac_of_fp32_mfma_peak_157': round(mtf / MFMA_F32_PEAK_TF, 4),
                             'algorithmic_flops_per_launch': int(mflops), 'avg_launch_us': round(mlp_us, 3),
-                            'weight_stream_bytes_per_launch': int(-(-s0_['N0'] // (4096 // H)) + -(-s0_['N1'] // (4096 // H)) + -(-s0_['N2'] // (4096 // H))) * 6 * H * H * 6,
+                            'weight_stream_bytes_per_launch': int(-(-s0_['N0'] // (4096 // H)) + -(-s0_['N1'] // (4096 // H)) + -(-s0_['N2'] // (4096 // H))) * (9 if CINPP else 6) * H * H * 6,
                             'note': 'fp32-equivalent FLOPs (2 M N K per Linear) / launch time; every workgroup streams the six packed '
                                     'weights out of L2 (weight_stream_bytes_per_launch), which is what bounds it at this batch size'}
                         # what actually bounds it: a CU receives ~77.5 GB/s (~35 B per clock) from L2 whatever the other CUs do
                         # (profiles/r3_l2_stream.txt: 32 ... 256 workgroups streaming one 576-KB buffer, same or spread
                         # addresses, tools/proto/l2_stream.hip), and a workgroup needs its 6 weights + its two input tiles
-                        wg_bytes = 6 * H * H * 6 + 2 * (4096 // H) * H * 4
+                        wg_bytes = (9 if CINPP else 6) * H * H * 6 + (3 if CINPP else 2) * (4096 // H) * H * 4
                         floor_us = wg_bytes / L2_TO_CU_BYTES_PER_US
                         roofline_mlp['l2_to_cu_stream'] = {
                             'bytes_per_workgroup': wg_bytes, 'measured_cap_GB_per_s_per_CU': round(L2_TO_CU_BYTES_PER_US / 1e3, 1),
@@ -1125,7 +1126,7 @@ def main():
     # the number a faster step moves: algorithmic bytes of the WHOLE step over the step time
     roofline_step = None
     if rank == 0:
-        step_bytes = L * layer_algorithmic_bytes(stats[0], H, coboundary=coboundary)
+        step_bytes = L * layer_algorithmic_bytes(stats[0], H, coboundary=coboundary, out_streams=3 if CINPP else 2)
         sgbs = step_bytes / (dt / args.steps) / 1e9
         roofline_step = {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes), 'achieved': round(sgbs, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(sgbs / HBM_PEAK_GBS, 4),
@@ -1314,7 +1315,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 5),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic', 'timing': timing,
-            'config': {'workload': {'zinc': f'ZINC-like ring-lift (max_ring=6), {L}-layer SparseCIN propagate scope (hidden {H}, coboundary messages), batch {args.batch} per GPU [BASELINE configs[1]]', 'molhiv': f'ogbg-molhiv-like ring-lift (max_ring=6), {L}-layer OGBEmbedSparseCIN propagate scope (hidden {H}), batch {args.batch} per GPU [BASELINE configs[2]]', 'reddit': f'REDDIT-BINARY-like clique-lift (dim 2, hubs of degree >= 100), {L}-layer SparseCIN propagate scope (hidden {H}, no coboundaries, norm id, JK cat), batch {args.batch} per GPU [BASELINE configs[4]]'}[WL],
+            'config': {'workload': {'zinc': f'ZINC-like ring-lift (max_ring=6), {L}-layer ' + ('CIN++ (EmbedCINpp, mp/molec_models.py:167-199; three outputs per dimension)' if CINPP else 'SparseCIN') + f' propagate scope (hidden {H}, coboundary messages), batch {args.batch} per GPU [BASELINE configs[1]' + (' with CINppConv layers]' if CINPP else ']'), 'molhiv': f'ogbg-molhiv-like ring-lift (max_ring=6), {L}-layer OGBEmbedSparseCIN propagate scope (hidden {H}), batch {args.batch} per GPU [BASELINE configs[2]]', 'reddit': f'REDDIT-BINARY-like clique-lift (dim 2, hubs of degree >= 100), {L}-layer SparseCIN propagate scope (hidden {H}, no coboundaries, norm id, JK cat), batch {args.batch} per GPU [BASELINE configs[4]]'}[WL],
                        'key': f'{"zinc_cinpp" if CINPP else WL}:{args.batch}:{H}',
                        'batch_per_gpu': args.batch, 'hidden': H, 'layers': L,
                        'cells_per_batch': s0['cells'], 'N': [s0['N0'], s0['N1'], s0['N2']],
@@ -1594,7 +1595,6 @@ def main():
                     env_['CWN_BENCH_SKIP'] = 'eager,concurrent,collate,workloads,roofline'
                 if wl == 'zinc_cinpp':
                     env_['CWN_BENCH_MODEL'] = 'cinpp'
-                    env_['CWN_BENCH_SKIP'] = 'eager,concurrent,collate,workloads,roofline'
                 import tempfile
                 fd_, det_ = tempfile.mkstemp(prefix=f'cwn_bench_{wl}_', suffix='.json')
                 os.close(fd_)

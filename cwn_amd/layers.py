@@ -1445,8 +1445,9 @@ class CINppConv(SparseCINConv):
             return False         # a lower adjacency has appeared: `_blocked_args` says why the launch does not serve it
         return super()._blocked_still_valid(ent, cochain_params)
 
-    def _propagate_blocked_train(self, cochain_params, start_to_process, specs, owner):
-        return None             # (training: the streaming autograd node, ops.gemm_aggregate)
+    # (training: SparseCINConv._propagate_blocked_train serves this layer too -- the launch stores Y1 / Y2 and writes the third
+    #  output; the blocked backward launch takes the gradients of out_up / out_b and ops._blocked_backward_impl adds
+    #  (1 + eps2) g_down onto dx)
 
     @staticmethod
     def _n_streams(plan) -> int:

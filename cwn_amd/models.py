@@ -197,7 +197,7 @@ class _SparseCINStack(torch.nn.Module):
         jump_xs, xs = None, None
         if torch.is_grad_enabled() and layers.BLOCKED_TRAIN_FORWARD and layers.BLOCKED_LAYER:
             # training forward through the blocked layer kernel: the message weights of all layers packed in one launch
-            ws = [lvl.msg_up_nn[1].weight for conv in self.convs if not isinstance(conv, layers.CINppConv)
+            ws = [lvl.msg_up_nn[1].weight for conv in self.convs          # (CIN++ layers too: round 6)
                   for lvl in getattr(conv, 'mp_levels', [])
                   if getattr(lvl, '_up_kind', lambda: None)() == 'cat_linear_relu' and lvl.msg_up_nn[1].weight.is_cuda]
             if ws:

@@ -1664,9 +1664,11 @@ def _blocked_backward_impl(ctx, gs, ys, g_tensors, g_needs, s_tensors, s_needs):
     if BLOCKED_BACKWARD == 2 and bwd_table is None:
         return None                        # some complex is beyond the owner form's workgroup: the streaming backward
     n, ng = len(dims), ctx.ng
-    if len(ctx.streams) != 2 * n or len(gs) != 2 * n:
+    # outputs per dimension: (up, b), or (up, down, b) of a CIN++ layer (LayerDim.want_down: out_down = (1 + eps3) x)
+    k_out = 3 if getattr(dims[0], 'want_down', False) else 2
+    if len(ctx.streams) != k_out * n or len(gs) != k_out * n:
         return None
-    if any(s_needs[4 * k + 3] and s_tensors[4 * k + 3] is not None for k in range(2 * n)):
+    if any(s_needs[4 * k + 3] and s_tensors[4 * k + 3] is not None for k in range(k_out * n)):
         return None                        # trainable eps: its gradient is a reduction the launch does not take
     # transposed packed weight of every dimension with an upper adjacency (packed with the forward's weights)
     wt_of = [None] * n
@@ -1679,11 +1681,23 @@ def _blocked_backward_impl(ctx, gs, ys, g_tensors, g_needs, s_tensors, s_needs):
     ys_of = [[None, None] for _ in range(n)]
     for gi, (d, which) in enumerate(ydims):
         ys_of[d][0 if which == 'y1' else 1] = ys[gi]
-    res = layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[2 * d], gs[2 * d + 1]) for d in range(n)], wt_of,
+    res = layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[k_out * d], gs[k_out * d + k_out - 1]) for d in range(n)], wt_of,
                          bwd_table=bwd_table if BLOCKED_BACKWARD == 2 else None)
     if res is None:
         return None
     dxs, gys = res
+    if k_out == 3:
+        # the third output's piece: d out_down / d x = (1 + eps3) -- one fused multiply-add per dimension onto the launch's dx
+        # (the scale stays a device scalar: no host read inside a captured step)
+        for d in range(n):
+            g_down = gs[3 * d + 1]
+            if g_down is not None:
+                e3 = dims[d].eps3
+                scale = (1.0 + e3.detach().to(torch.float32)).view(1, 1) if e3 is not None else None
+                if scale is None:
+                    dxs[d].add_(g_down)
+                else:
+                    dxs[d].addcmul_(g_down, scale)
     g_of = [gys[d][0 if which == 'y1' else 1] for (d, which) in ydims]
     # weight (and bias) gradients of the message Linear: gY^T x through the merged weight-gradient launches; dX is done
     needs_w = list(g_needs)

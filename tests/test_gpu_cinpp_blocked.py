@@ -234,3 +234,100 @@ def test_fused_update_mlp3_vs_float64_and_the_grouped_launches(F, rows):
         _gate(fused[d], want, f'update_mlp3 F={F} dim {d} ({rows[d]} rows) vs float64')
         _gate(grouped[d], want, f'grouped launches F={F} dim {d} vs float64')
         assert fused[d].shape == (rows[d], F)
+
+
+@pytest.mark.parametrize('kind,n,F', [('zinc', 64, 128), ('zinc', 300, 128), ('molhiv', 96, 64)])
+def test_cinpp_training_step_through_the_blocked_launches(kind, n, F):
+    """With autograd on, a CIN++ layer's propagate step runs as the blocked launch (CWN_LAYER_STORE_Y + the third output) and its
+    backward as the owner-form launch + (1 + eps2) g_down added onto dx (ops._blocked_backward_impl): outputs and gradients
+    of the streaming autograd node (grouped GEMM + one aggregation launch over three streams)."""
+    from cwn_amd import layers, ops
+    b = _batch(kind, n, F, seed=15)
+    from cwn_amd.layers import CINppConv
+    torch.manual_seed(16)
+    conv = CINppConv(F, F, F, None, None, None, None, None, None, max_dim=2, hidden=F, eps=0.25, train_eps=False,
+                     act_module=torch.nn.ReLU, layer_dim=F, use_coboundaries=True).to(DEV).train()
+    with torch.no_grad():
+        for d, lvl in enumerate(conv.mp_levels):
+            lvl.eps1.fill_(0.25 + 0.125 * d); lvl.eps2.fill_(0.75 - 0.0625 * d); lvl.eps3.fill_(-0.5 + 0.03125 * d)
+    g = torch.Generator().manual_seed(13)
+    ws = [torch.randn(b.cochains[d].num_cells, F, generator=g).to(DEV) for d in range(3) for _ in range(3)]
+    captured = {}
+    orig = ops.gemm_aggregate
+
+    def spy(specs, make_streams, precomputed=None):
+        captured['pre'] = precomputed
+        return orig(specs, make_streams, precomputed=precomputed)
+
+    def run(flag):
+        layers.BLOCKED_TRAIN_FORWARD = flag
+        ops.gemm_aggregate = spy
+        if flag:
+            ops.pack_layer_weights_many([conv.mp_levels[d].msg_up_nn[1].weight for d in range(2)], transposed=True)
+        try:
+            conv.zero_grad(set_to_none=True)
+            xin = [b.cochains[d].x.detach().clone().requires_grad_() for d in range(3)]
+            b.set_xs(xin)
+            plans, outs = conv.propagate_all(*b.get_all_cochain_params(max_dim=2, include_down_features=False))
+            assert len(outs) == 9
+            sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+            return outs, xin, {k: v.grad.clone() for k, v in conv.named_parameters() if v.grad is not None}, captured.get('pre')
+        finally:
+            layers.BLOCKED_TRAIN_FORWARD = True
+            ops.gemm_aggregate = orig
+
+    before = list(ops.BLOCKED_BACKWARD_LAUNCHES)
+    outs1, x1, g1, pre1 = run(True)
+    assert ops.BLOCKED_BACKWARD_LAUNCHES[1] == before[1] + 1, 'the owner-form backward launch did not run'
+    outs0, x0, g0, pre0 = run(False)
+    assert pre1 is not None and pre0 is None, 'the training forward did not take the blocked kernel'
+    for i, (a, c) in enumerate(zip(outs1, outs0)):
+        if F == 128 or i % 3 == 1:
+            assert torch.equal(a, c), i
+        else:
+            torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5 * max(1.0, float(c.abs().max())))
+    for a, c in zip(x1, x0):
+        torch.testing.assert_close(a.grad, c.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(c.grad.abs().max())))
+    assert g1.keys() == g0.keys() and g1
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=1e-4, atol=1e-4 * max(1.0, float(g0[k].abs().max())), msg=k)
+    # dx against float64 for the part that is new here: the third output's piece
+    for d in range(3):
+        piece = (1.0 + float(conv.mp_levels[d].eps2)) * cpu(ws[3 * d + 1]).double()
+        rest = cpu(x0[d].grad).double() - piece            # (what the other two outputs contribute, by the streaming path)
+        _gate(x1[d].grad, rest + piece, f'CIN++ blocked backward dx[{d}]')
+    print(f'[gate] CIN++ training step {kind}-{n} F={F}: blocked forward + owner-form backward = the streaming autograd node')
+
+
+def test_static_blocked_batch_serves_embed_cinpp_forward_and_training():
+    """a static batch in mode 'blocked' for EmbedCINpp -- one captured graph for every batch of an epoch."""
+    import copy
+    from cwn_amd.models import EmbedCINpp
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward, StaticTrainStep
+    from cwn_amd.synthetic import zinc_like_complexes
+    torch.manual_seed(21)
+    H, B = 64, 12
+    model = EmbedCINpp(28, 4, 1, 2, H, dropout_rate=0.0, max_dim=2, jump_mode=None, nonlinearity='relu', readout='sum',
+                       final_hidden_multiplier=2, final_readout='sum', init_reduce='sum', embed_edge=True,
+                       use_coboundaries=True, graph_norm='bn').to(DEV).eval()
+    pool = zinc_like_complexes(60, 22, 6)
+    packed = PackedComplexes(pool, torch.device(DEV), max_dim=2, with_csr=True)
+    sb = StaticBatch(packed, B, slots=2, mode='blocked')
+    sf = StaticForward(model, sb)
+    batches = [list(range(0, 12)), list(range(20, 29)), list(range(30, 42)), list(range(50, 55))]
+    with torch.no_grad():
+        for lo in (0, 2):
+            outs = sf.run_many(batches[lo: lo + 2])
+            for idx, got in zip(batches[lo: lo + 2], outs):
+                want = model(packed.collate(idx))
+                assert torch.equal(got, want), (idx[0], (got - want).abs().max().item())
+    tmodel = copy.deepcopy(model).train()
+    ts = StaticTrainStep(tmodel, sb, task_type='regression')
+    sb.set_batches(batches[:2])
+    before = [p.detach().clone() for p in tmodel.parameters()]
+    losses = ts.step()
+    assert all(bool(torch.isfinite(l).item()) for l in losses)
+    assert any(not torch.equal(p, q) for p, q in zip(tmodel.parameters(), before))
+    print('[gate] EmbedCINpp over a static batch in mode blocked: replayed forward torch.equal to per-batch launches; a captured training step runs')

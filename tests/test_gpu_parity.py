@@ -2780,7 +2780,8 @@ def test_cinpp_fused_streams_match_the_hook_path(F, proper):
                 if isinstance(m, torch.nn.BatchNorm1d):
                     m.reset_running_stats()
         o1, gx1, gp1, st1 = run(True, train)
-        assert conv.blocked_reason is None or 'CIN++' in conv.blocked_reason or 'autograd' in conv.blocked_reason
+        # (round 6: at widths 64 / 128 the default layer now takes the blocked launches -- tests/test_gpu_cinpp_blocked.py; here
+        #  the fused STREAMS are what is compared with the hooks, whichever launch serves them)
         if train:
             for m in conv.modules():
                 if isinstance(m, torch.nn.BatchNorm1d):
