@@ -2835,7 +2835,9 @@ def test_bench_multi_rank_control_flow_on_one_gpu(tmp_path, world, with_train):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, CWN_BENCH_SHARE_GPU='1', CWN_BENCH_MIN_REGION_S='0.005',
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix='cwn_bench_'), 'detail.json')     # (the stdout line is the slim one)
+    env = dict(os.environ, CWN_BENCH_SHARE_GPU='1', CWN_BENCH_MIN_REGION_S='0.005', CWN_BENCH_DETAIL=detail,
                CWN_BENCH_SKIP='concurrent,full,eager' + ('' if with_train else ',train'))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
@@ -2852,8 +2854,11 @@ def test_bench_multi_rank_control_flow_on_one_gpu(tmp_path, world, with_train):
         < 0.2 * d['value']
     assert d['roofline'] is not None and 0 < d['roofline']['frac'] < 1
     assert d['timing']['rounds'] >= 1 and d['timing']['timed_steps'] == d['timing']['rounds'] * 8
+    assert len(lines[0]) < 6144 and d['multi_gpu']['rccl_ranks'] == world
     if with_train:
-        tr = d['secondary']['train_step']
+        assert d['secondary']['train_step_ms'] > 0
+        with open(detail) as fh:
+            tr = json.load(fh)['secondary']['train_step']
         assert tr is not None and 'skipped' not in tr and tr['ms_per_step'] > 0 and tr['backward_pieces'] >= 1, tr
 
 
