@@ -90,7 +90,7 @@ MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (never th
 
 def load_profile_json(stem):
     """profiles/r<N>_<stem>.json of the latest round that has one (PMC traffic of the kernels, tools/collect_traffic.py)."""
-    for r in (5, 4, 3, 2):
+    for r in (6, 5, 4, 3, 2):
         path = os.path.join(ROOT, 'profiles', f'r{r}_{stem}.json')
         if os.path.exists(path):
             with open(path) as fh:

@@ -343,20 +343,22 @@ class Complex(object):
 
     # ---- engine extension: convert every adjacency once per batch -----------------------------
     def prepare(self, max_dim: int = 2, include_down: bool = False, backward: bool = False,
-                overlap: bool = False):
+                overlap: bool = False, upper: bool = True):
         """Build the int32 CSR plans of all upper / boundary (and optionally lower) adjacencies with
         one batched call and register them in the plan cache `propagate` looks up.  Optional: a
         propagate call on an unprepared complex builds its plans on first use.  `overlap=True`
-        runs the build on a side stream (see csr.build_many)."""
+        runs the build on a side stream (see csr.build_many).  `upper=False`: the boundary adjacencies only -- for a caller
+        that knows its layers take the complex-blocked launches, which read the int64 entries themselves (a training step over a
+        fixed model: cwn_amd/train.py; a plan that is needed after all is still built on first use)."""
         from .csr import build_many, cached_adjacency
         todo = []
         for dim in range(min(max_dim, self.dimension) + 1):
             c = self.cochains[dim]
             n = c.num_cells
             specs = []
-            if (dim + 1) in self.cochains and c.upper_index is not None:
+            if upper and (dim + 1) in self.cochains and c.upper_index is not None:
                 specs.append((c.upper_index, n, n, c.shared_coboundaries, self.cochains[dim + 1].num_cells))
-            if include_down and c.lower_index is not None:
+            if upper and include_down and c.lower_index is not None:
                 specs.append((c.lower_index, n, n, c.shared_boundaries, self.cochains[dim - 1].num_cells))
             if c.boundary_index is not None and dim > 0:
                 specs.append((c.boundary_index, n, self.cochains[dim - 1].num_cells, None, 0))

@@ -231,6 +231,10 @@ class TrainStep:
         # a new batch needs its adjacency plans (forward + transposed) built: part of the step
         # unless the caller trains on a fixed set of batches and says so
         self.rebuild_plans = rebuild_plans
+        # set by the warm-up of the first capture: every layer of every batch took the complex-blocked launches forward AND
+        # backward, so a step's plan build leaves the upper adjacencies out (one csr launch per step instead of two: the ten
+        # plans of a ZINC batch -- 4 + 6 transposes -- are two batched calls, the four boundary ones are one)
+        self._skip_upper_plans = False
 
     def _count_at_begin(self) -> bool:
         """May the step's opening launch advance FlatAdam's counter (it knows whether the step is real)?"""
@@ -342,7 +346,7 @@ class TrainStep:
         if self.staged is None:
             b = self._restore(i)
             if self.rebuild_plans:
-                b.forget_plans().prepare(backward=True)
+                b.forget_plans().prepare(backward=True, upper=not self._skip_upper_plans)
             # zero_grad + what the step's kernels need zero on entry + the optimizer's step counter: one launch
             try:
                 with self._begin():
@@ -361,7 +365,7 @@ class TrainStep:
                 if j == 0:
                     b = self._restore(i)
                     if self.rebuild_plans:
-                        b.forget_plans().prepare(backward=True)
+                        b.forget_plans().prepare(backward=True, upper=not self._skip_upper_plans)
                     self._arena = self._begin()
                     self._arena.__enter__()
                     self.staged.begin()
@@ -428,10 +432,15 @@ class TrainStep:
             ds_keep = None if ds_before is None else ds_before.clone()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
+            n_blocked = _ops.BLOCKED_BACKWARD_LAUNCHES[1]
             with torch.cuda.stream(s):
                 for k in range(len(self.batches)):
                     self._eager(k)
             torch.cuda.current_stream().wait_stream(s)
+            n_convs = len(list(getattr(self.model, 'convs', [])))
+            if (self.rebuild_plans and n_convs and os.environ.get('CWN_TRAIN_UPPER_PLANS') != '1'
+                    and _ops.BLOCKED_BACKWARD_LAUNCHES[1] - n_blocked == n_convs * len(self.batches)):
+                self._skip_upper_plans = True
             with torch.no_grad():
                 now = self._state_tensors()
                 for t, old in zip(now[:n_before], keep):

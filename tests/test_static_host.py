@@ -103,14 +103,21 @@ def test_device_table_layout_is_the_host_collate_layout():
 
 
 def test_static_drivers_refuse_layers_that_need_a_per_batch_csr_plan():
-    """StaticForward / StaticTrainStep serve SparseCINConv stacks; a CIN++ model (streaming aggregation over a CSR plan of the
-    upper adjacency, built per batch on the host's sizes) is refused at construction, not handed capacity-sized buffers."""
+    """StaticForward / StaticTrainStep in mode 'blocked' serve SparseCINConv stacks and (round 6) CIN++ stacks as the reference's
+    molecular models run them (lower stream off: the blocked layer launch writes their third output).  A CIN++ layer with the
+    lower-adjacency stream on (streaming aggregation over a CSR plan of the lower adjacency, built per batch on the host's
+    sizes) is refused at construction, not handed capacity-sized buffers."""
+    from cwn_amd.layers import CINppConv
     from cwn_amd.models import EmbedCINpp, EmbedSparseCIN
     from cwn_amd.static_graph import refuse_unsupported_layers
     kw = dict(dropout_rate=0.0, max_dim=2, embed_edge=True, use_coboundaries=True)
     refuse_unsupported_layers(EmbedSparseCIN(28, 4, 1, 2, 16, **kw), 'StaticForward')
+    model = EmbedCINpp(28, 4, 1, 2, 16, **kw)
+    refuse_unsupported_layers(model, 'StaticForward')
+    conv = next(m for m in model.modules() if isinstance(m, CINppConv))
+    conv.mp_levels[1].use_down_msg = True
     with pytest.raises(NotImplementedError, match='CINppConv'):
-        refuse_unsupported_layers(EmbedCINpp(28, 4, 1, 2, 16, **kw), 'StaticForward')
+        refuse_unsupported_layers(model, 'StaticForward')
 
 
 def test_host_capacity_check_over_the_distinct_size_columns():

@@ -3,7 +3,7 @@ section prescribes: separate rocprofv3 passes for FETCH_SIZE and WRITE_SIZE (wit
 only), counters in KiB, gfx950 FETCH_SIZE doubled for wide coalesced streams, WRITE_SIZE as is.
 Run ON the GPU box from the repo root:   python tools/collect_traffic.py [batch | workload:batch ...]
 (a bare batch = the ZINC workload; `molhiv:512` / `reddit:32`: the dominant kernel of that workload's propagate scope)
-Writes profiles/r5_pmc_fetch_write_raw.json and profiles/r5_traffic.json (the dominant kernel of the
+Writes profiles/r6_pmc_fetch_write_raw.json and profiles/r6_traffic.json (the dominant kernel of the
 propagate scope: layer_kernel<F, 2>, the variant that loads the per-item CSR; the first launch of a
 step is layer_kernel<F, 1>)."""
 import csv
@@ -77,9 +77,9 @@ def main():
     # profiles/ is what bench.py reads; gpurun_out/ is what travels back from the GPU box
     for d in ('profiles', 'gpurun_out'):
         os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-        with open(os.path.join(ROOT, d, 'r5_pmc_fetch_write_raw.json'), 'w') as fh:
+        with open(os.path.join(ROOT, d, 'r6_pmc_fetch_write_raw.json'), 'w') as fh:
             json.dump(raw, fh, indent=1)
-        with open(os.path.join(ROOT, d, 'r5_traffic.json'), 'w') as fh:
+        with open(os.path.join(ROOT, d, 'r6_traffic.json'), 'w') as fh:
             json.dump(traffic, fh, indent=1)
     print(json.dumps(traffic['entries']))
 

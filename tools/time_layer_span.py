@@ -109,3 +109,36 @@ order = np.argsort(np.where(wg_live[i], s_wg[i], big))
 rel = (s_wg[i][order] - s_wg[i][order[0]]) * TICK
 q = [0, 31, 63, 127, 191, min(255, len(order) - 1)]
 print(f'\nlaunch {i}: start time of the k-th workgroup to start (us after the first): ' + ', '.join(f'k={k}: {rel[k]:.2f}' for k in q if k < len(rel)))
+
+# ---- round 6: WHICH workgroups are the slow ones?  chain length against what the item holds -----------
+it = table.items.cpu().numpy().astype(np.int64)             # [n_items][32] records (include/cwn_hip.h)
+i = N_LAUNCH // 2
+chain_us = (e_wg[i] - s_wg[i]) * TICK
+g_dim, n_g, n_c, e_up = it[:, 1], it[:, 3], it[:, 5], it[:, 7]
+b0, b1 = it[:, 9 + 4], it[:, 16 + 4]
+n_t1 = it[:, 16 + 2]
+tiles = -(-n_g // 16) + -(-n_c // 16)
+rounds = np.maximum(-(-n_g // 32), -(-n_t1 // 32))            # rounds of the reduce phases (32 lane groups at F = 128)
+print(f'\n## launch {i}: chain of a workgroup against what its item holds\n')
+print('| set | items | chain mean / max us | cells g (mean / max) | row tiles (mean / max) | entries up + boundary (mean / max) |')
+print('|---|---|---|---|---|---|')
+for g in sorted(set(g_dim.tolist())):
+    m = (g_dim == g) & wg_live[i]
+    ent = (e_up + b0 + b1)[m]
+    print(f'| g = {g} | {int(m.sum())} | {chain_us[m].mean():.2f} / {chain_us[m].max():.2f} | {n_g[m].mean():.1f} / {n_g[m].max()} | '
+          f'{tiles[m].mean():.2f} / {tiles[m].max()} | {ent.mean():.0f} / {ent.max()} |')
+print('\nchain by number of 16-row tiles the item multiplies (all sets):')
+for t in sorted(set(tiles[wg_live[i]].tolist())):
+    m = (tiles == t) & wg_live[i]
+    print(f'  {t} tiles: {int(m.sum()):3d} items, chain mean {chain_us[m].mean():.2f} us, max {chain_us[m].max():.2f}')
+print('\nchain by rounds of the reduce phases (cells of a task beyond 32 take a second round):')
+for r in sorted(set(rounds[wg_live[i]].tolist())):
+    m = (rounds == r) & wg_live[i]
+    print(f'  {r} round(s): {int(m.sum()):3d} items, chain mean {chain_us[m].mean():.2f} us, max {chain_us[m].max():.2f}')
+order = np.argsort(-np.where(wg_live[i], chain_us, 0))[:12]
+print('\nthe twelve longest chains: workgroup | set | chain us | cells g | cells g+1 | tiles | up entries | boundary entries (task 0 + 1) | started at us')
+S0 = s_wg[i][wg_live[i]].min()
+for w in order:
+    print(f'  {int(w):4d} | g = {int(g_dim[w])} | {chain_us[w]:.2f} | {int(n_g[w])} | {int(n_c[w])} | {int(tiles[w])} | {int(e_up[w])} | {int(b0[w])} + {int(b1[w])} | {(s_wg[i][w] - S0) * TICK:.2f}')
+cc = np.corrcoef(np.stack([chain_us[wg_live[i]], tiles[wg_live[i]], (e_up + b0 + b1)[wg_live[i]], n_g[wg_live[i]]]))[0]
+print(f'\ncorrelation of the chain with: row tiles {cc[1]:.2f}, entries {cc[2]:.2f}, cells of g {cc[3]:.2f}')
