@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
     // same MFMA order per tile, same entry order, same epilogue arithmetic: bit-identical to every other path.  It
     // is the slow way to do a complex (~2.5 x the matrix-pipe time for the redundant splits, L2 round trips instead
     // of LDS) -- and it keeps ONE oversized molecule from sending its whole batch to the two-kernel path.
-    if ((fld(I_FLAGS) & CWN_LAYER_ITEM_BIG) != 0) {
+    if (__builtin_expect((fld(I_FLAGS) & CWN_LAYER_ITEM_BIG) != 0, 0)) {
         if constexpr (kW8) {
             if (tid == 0) atomicOr(A.err, CWN_ERR_BIT_BLOCK);      // big items ride in the 16-wave form only
             return;

@@ -32,8 +32,9 @@ def _conv(F, seed=0, eps=0.0, train_eps=False):
 def _batch(kind, n, F, seed=0, integer=False):
     from cwn_amd.complex import ComplexBatch
     from cwn_amd.synthetic import zinc_like_complexes, molhiv_like_complexes
-    gen = zinc_like_complexes if kind in ('zinc', 'zinctrees') else molhiv_like_complexes
-    cxs = gen(n, seed, 6)
+    gen = zinc_like_complexes if kind in ('zinc', 'zinctrees', 'zincwide') else molhiv_like_complexes
+    # 'zincwide': molecules of 26 .. 40 atoms -- items of 33 .. 48 cells (one round of the reduce passes' lane groups plus a few)
+    cxs = gen(n, seed, 6, n_lo=26, n_hi=40) if kind == 'zincwide' else gen(n, seed, 6)
     if kind == 'zinctrees':            # some molecules without a ring (no 2-cells, no upper adjacency of their edges)
         trees = [c for c in zinc_like_complexes(3 * n, seed + 1, 2) if 2 not in c.cochains or c.cochains[2].num_cells == 0][:max(1, n // 4)]
         cxs = cxs[: n // 2] + trees + cxs[n // 2:]
@@ -118,6 +119,37 @@ def test_blocked_layer_bit_identical_to_two_kernel_path(kind, n):
     plain = _run(conv, b, blocked=False)
     for i, (f, p) in enumerate(zip(fused, plain)):
         assert torch.equal(f, p), (i, (f - p).abs().max().item())
+
+
+def test_blocked_layer_items_one_round_plus_a_few_cells():
+    """Round 6: at F = 128 a round of the reduce passes is 32 lane groups; an item of 33 .. 48 edges (or 33 .. 64 cells in the
+    upper reduce) no longer takes a second round -- its overflow cells ride as the second chain of the lane groups that loaded
+    them (csrc/cwn_layer.hip, CWN_LAYER_MERGE2).  The batch holds such items, items beyond them (49+ edges: the generic two
+    rounds) and ordinary ones; every output bit equals the two-kernel path's, in sort / store and load mode."""
+    from cwn_amd import csr, layers
+    b = _batch('zincwide', 96, 128, seed=71)
+    n_v = torch.bincount(cpu(b.cochains[0].batch))
+    n_e = torch.bincount(cpu(b.cochains[1].batch))
+    assert int(((n_e > 32) & (n_e <= 48)).sum()) >= 10 and int((n_v > 32).sum()) >= 5 and int((n_e <= 32).sum()) >= 5, (n_v, n_e)
+    conv = _conv(128, seed=72, eps=0.375)
+    keep, layers.LAYER_VARIANT = layers.LAYER_VARIANT, '0'           # the 16-wave form (the two-per-CU form always ran two chains)
+    try:
+        layers._BLOCKED_CACHE.clear()
+        b.block_plan().forget_csr()
+        first = _run(conv, b, blocked=True)
+        second = _run(conv, b, blocked=True)
+    finally:
+        layers.LAYER_VARIANT = keep
+        layers._BLOCKED_CACHE.clear()
+    csr._cache.clear()
+    plain = _run(conv, b, blocked=False)
+    for i, (f, s2, p) in enumerate(zip(first, second, plain)):
+        assert torch.equal(f, s2), (i, 'store vs load')
+        assert torch.equal(f, p), (i, (f - p).abs().max().item())
+    ref = _oracle_scope(conv, b)
+    for d in range(3):
+        _gate(first[2 * d], ref[d][0], f'zincwide out_up[{d}]')
+        _gate(first[2 * d + 1], ref[d][1], f'zincwide out_b[{d}]')
 
 
 @pytest.mark.parametrize('F', [64, 128])

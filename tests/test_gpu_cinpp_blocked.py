@@ -46,6 +46,7 @@ def _run(conv, b, blocked):
 
 
 @pytest.mark.parametrize('kind,n,F,variant', [('zinc', 128, 128, '0'), ('zinc', 300, 128, '1'), ('zinc', 1, 128, '0'), ('zinctrees', 40, 128, '0'),
+                                              ('zincwide', 64, 128, '0'),
                                               ('molhiv', 96, 64, '0'), ('molhiv', 400, 64, '1')])
 def test_cinpp_blocked_is_bit_identical_to_the_streaming_path(kind, n, F, variant):
     from cwn_amd import csr, layers
