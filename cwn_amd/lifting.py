@@ -86,10 +86,11 @@ def ring_lift(n: int, bonds: Sequence[Tuple[int, int]], vx: torch.Tensor,
 def clique_lift(n: int, edges: Sequence[Tuple[int, int]], vx: torch.Tensor, max_dim: int = 2,
                 init_method: str = 'sum', y: Optional[torch.Tensor] = None,
                 include_down_adj: bool = False) -> Complex:
-    """data/utils.py:224-272 (expansion_dim <= 2); higher-cell features = reduce of the vertices'
-    features (construct_features, :141-156)."""
+    """data/utils.py:224-272; higher-cell features = reduce of the vertices' features (construct_features, :141-156).
+    Up to dimension 2 (every configuration of BASELINE.json) the native routine lifts; `max_dim > 2` takes
+    `clique_lift_general` below."""
     if max_dim > 2:
-        raise NotImplementedError('clique lift up to dimension 2')
+        return clique_lift_general(n, edges, vx, max_dim, init_method, y, include_down_adj)
     L = Lift(CLIQUE, n, edges, 0, include_down_adj) if max_dim >= 2 else Lift(RING, n, edges, 0, include_down_adj)
     red = (lambda f: f.sum(1)) if init_method in ('sum', 'add') else (lambda f: f.mean(1))
     ev = L.array(EDGES).view(-1, 2)
@@ -97,6 +98,83 @@ def clique_lift(n: int, edges: Sequence[Tuple[int, int]], vx: torch.Tensor, max_
     tris = L.cells2()
     tx = red(vx[torch.tensor(tris, dtype=torch.long)]) if tris else None
     return _complex(L, n, vx, ex, tx, include_down_adj, y)
+
+
+def clique_lift_general(n: int, edges: Sequence[Tuple[int, int]], vx: torch.Tensor, max_dim: int,
+                        init_method: str = 'sum', y: Optional[torch.Tensor] = None,
+                        include_down_adj: bool = False) -> Complex:
+    """compute_clique_complex_with_gudhi (data/utils.py:224-272) for ANY expansion dimension, without gudhi: the k-cliques of
+    the graph as the k-1-cells, dimension by dimension (a clique of k + 1 vertices = a clique of k plus a common neighbour
+    larger than its last vertex).  Conventions, the ones the native routine follows up to dimension 2 (pinned there on the
+    reference's expected tensors, tests/test_lifting.py; equal to this function at max_dim = 2, same file):
+      * cells of a dimension are numbered in lexicographic order of their sorted vertex tuples (build_tables, :44-64: the
+        simplex tree is walked depth first);
+      * the boundaries of a cell in the order itertools.combinations drops a vertex (:39-41) = ascending face number;
+      * upper adjacency of dimension k - 1: per k-cell in order, every pair of its faces in both directions, the k-cell as
+        the shared coboundary (build_adj, :121-126); lower adjacency of dimension k + 1: per k-cell in order, every pair of
+        its cofaces (ascending) in both directions, the k-cell as the shared boundary (:128-134);
+      * features of a cell = sum / mean of its vertices' features (construct_features, :141-156); the complex's dimension
+        is the largest one that has a cell (:247).
+    Host Python (numpy): input preparation outside every configuration of BASELINE.json -- the reference's own is Python."""
+    import itertools
+    if n < 0:
+        raise ValueError('invalid graph for lifting')
+    es = set()
+    for u, v in edges:
+        u, v = int(u), int(v)
+        if u < 0 or v < 0 or u >= n or v >= n or u == v:
+            raise ValueError('invalid graph for lifting (vertex out of range or self loop)')
+        es.add((min(u, v), max(u, v)))
+    nbr = [set() for _ in range(n)]
+    for u, v in es:
+        nbr[u].add(v)
+        nbr[v].add(u)
+    cells = [[(v,) for v in range(n)], sorted(es)]
+    while len(cells) <= max_dim and cells[-1]:
+        nxt = []
+        for c in cells[-1]:
+            common = set.intersection(*(nbr[v] for v in c))
+            nxt.extend(c + (w,) for w in sorted(common) if w > c[-1])
+        cells.append(nxt)                      # (generated from a sorted list by appending ascending vertices: sorted)
+    while len(cells) > 1 and not cells[-1]:
+        cells.pop()
+    dim = len(cells) - 1
+    ids = [{c: i for i, c in enumerate(level)} for level in cells]
+    faces = [None] + [[[ids[k - 1][f] for f in itertools.combinations(c, k)] for c in cells[k]] for k in range(1, dim + 1)]
+    red = (lambda f: f.sum(1)) if init_method in ('sum', 'add') else (lambda f: f.mean(1))
+
+    def pairs(groups):
+        """[(shared, members)] -> index [2, L], shared [L]: every pair of members in both directions"""
+        a, b, sh = [], [], []
+        for g, members in groups:
+            for i, j in itertools.combinations(members, 2):
+                a += [i, j]
+                b += [j, i]
+                sh += [g, g]
+        if not a:
+            return None, None
+        return torch.tensor([a, b], dtype=torch.long), torch.tensor(sh, dtype=torch.long)
+
+    cochains = []
+    for k in range(dim + 1):
+        up_index = cob = low_index = bnd = b_index = None
+        if k < dim:
+            up_index, cob = pairs(enumerate(faces[k + 1]))
+        if k > 0:
+            b_index = torch.tensor([[f for fs in faces[k] for f in fs], [c for c, fs in enumerate(faces[k]) for _ in fs]],
+                                   dtype=torch.long)
+            if include_down_adj:
+                cof = [[] for _ in cells[k - 1]]
+                for c, fs in enumerate(faces[k]):
+                    for f in fs:
+                        cof[f].append(c)
+                low_index, bnd = pairs(enumerate(cof))
+        x = vx if k == 0 else red(vx[torch.tensor(cells[k], dtype=torch.long)])
+        cochains.append(Cochain(dim=k, x=x, upper_index=up_index, shared_coboundaries=cob, lower_index=low_index,
+                                shared_boundaries=bnd, boundary_index=b_index, num_cells=len(cells[k]),
+                                num_cells_down=len(cells[k - 1]) if k > 0 else None,
+                                num_cells_up=len(cells[k + 1]) if k < dim else 0))
+    return Complex(*cochains, y=y, dimension=dim)
 
 
 def induced_cycles(n: int, bonds: Sequence[Tuple[int, int]], max_k: int):
@@ -344,8 +422,48 @@ def pack_graph_dataset_with_rings(graphs, max_ring_size: int = 7, include_down_a
 def pack_graph_dataset_with_cliques(graphs, expansion_dim: int = 2, include_down_adj: bool = True,
                                     init_method: str = 'sum', n_threads: int = 0, device='cuda', with_csr: bool = False):
     """convert_graph_dataset_with_gudhi (data/utils.py:275-297) for expansion_dim <= 2, packed like
-    pack_graph_dataset_with_rings; higher cells take the reduce of their vertices' features (:141-155)."""
+    pack_graph_dataset_with_rings; higher cells take the reduce of their vertices' features (:141-155).  (Beyond dimension 2:
+    `clique_lift(..., max_dim=k)` per graph gives the list of Complex objects the reference's function returns; the packed
+    form and the kernels behind it hold the three dimensions every configuration of BASELINE.json uses.)"""
     if expansion_dim > 2:
-        raise NotImplementedError('clique lift up to dimension 2')
+        raise NotImplementedError('the packed dataset holds dimensions 0 .. 2; lift per graph with clique_lift(max_dim=k) '
+                                  'for a list of Complex objects of higher dimension')
     kind = CLIQUE if expansion_dim >= 2 else RING
     return _pack_dataset(kind, graphs, 0, include_down_adj, init_method, True, True, n_threads, device, with_csr=with_csr)
+
+
+def convert_graph_dataset_with_cliques(graphs, expansion_dim: int, include_down_adj: bool = True, init_method: str = 'sum'):
+    """convert_graph_dataset_with_gudhi (data/utils.py:275-297) as the reference returns it -- (list of Complex, dimension,
+    num_features per dimension) -- for ANY expansion dimension: `clique_lift` per graph (native up to dimension 2,
+    `clique_lift_general` beyond).  `graphs`: PyG-Data-like objects or dicts with x, edge_index, y, num_nodes.  A vertex-level
+    label (one row per vertex) goes to the vertices' cochain, a graph-level one to the complex (extract_labels, :159-175)."""
+    dimension, complexes = -1, []
+    num_features = [None] * (expansion_dim + 1)
+    for g in graphs:
+        x = torch.as_tensor(_field(g, 'x'))
+        n = _field(g, 'num_nodes')
+        n = int(n) if n is not None else int(x.size(0))
+        ei = torch.as_tensor(_field(g, 'edge_index')).view(2, -1)
+        y = _field(g, 'y')
+        v_y = complex_y = None
+        if y is not None:
+            y = torch.as_tensor(y)
+            if y.size(0) == 1:
+                complex_y = y
+            else:
+                if y.size(0) != n:
+                    raise ValueError('y is one row (the graph) or one row per vertex')
+                v_y = y
+        cx = clique_lift(n, ei.t().tolist(), x, max_dim=expansion_dim, init_method=init_method, y=complex_y,
+                         include_down_adj=include_down_adj)
+        if v_y is not None:
+            cx.cochains[0].y = v_y
+        dimension = max(dimension, cx.dimension)
+        for d in range(cx.dimension + 1):
+            f = cx.cochains[d].num_features
+            if num_features[d] is None:
+                num_features[d] = f
+            elif num_features[d] != f:
+                raise ValueError(f'graphs disagree on the number of features in dimension {d}')
+        complexes.append(cx)
+    return complexes, dimension, num_features[:dimension + 1]

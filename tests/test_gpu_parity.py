@@ -1126,14 +1126,18 @@ def test_jumping_knowledge_max_vs_oracle():
         SparseCIN(1, 2, 3, 16, jump_mode='lstm')
 
 
-def test_reddit_like_full_size_vs_oracle():
+@pytest.mark.parametrize('readout', ['sum', 'mean'])
+def test_reddit_like_full_size_vs_oracle(readout):
     """BASELINE config 5: REDDIT-like clique complexes (hubs of degree >= 100: skewed segments,
-    F = 1 inputs), SparseCIN hidden 64, 4 layers, no coboundaries, norm id, JK cat, batch 32."""
+    F = 1 inputs), SparseCIN hidden 64, 4 layers, no coboundaries, norm id, JK cat, batch 32.
+    `readout='mean'` is the NORMALISED variant: with `sum` the pooled rows are sums over thousands of
+    cells (|ref|_inf 30 .. 80) and two of them pass the relative gate only (1.2e-5 absolute); pooled as means every compared
+    tensor is O(1) and the north star's ABSOLUTE 1e-5 is asserted -- scale, not arithmetic, is what exceeded it."""
     from cwn_amd.complex import ComplexBatch
     from cwn_amd.models import SparseCIN
     from cwn_amd.synthetic import reddit_like_complexes, batch_stats
     torch.manual_seed(0)
-    model = SparseCIN(1, 2, 4, 64, dropout_rate=0.0, max_dim=2, jump_mode='cat', readout='sum',
+    model = SparseCIN(1, 2, 4, 64, dropout_rate=0.0, max_dim=2, jump_mode='cat', readout=readout,
                       use_coboundaries=False, graph_norm='id').eval()
     with torch.no_grad():            # keep activations O(1) without a norm layer (degrees reach 300)
         for p in model.parameters():
@@ -1146,7 +1150,7 @@ def test_reddit_like_full_size_vs_oracle():
     for c in ocx['cochains']:
         c['x'] = c['x'].double()
     ref, rpart = O.sparse_cin_model_forward(to_double(state), ocx, 4, use_coboundaries=False, norm='id',
-                                            jump_mode='cat', embed=None)
+                                            jump_mode='cat', embed=None, readout=readout)
     # the propagate outputs of the first layer are integer-valued (all-ones features): exact
     prm = b.to(DEV).get_cochain_params(dim=0, include_down_features=False)
     up, _, _ = run_base(prm)
@@ -1155,9 +1159,12 @@ def test_reddit_like_full_size_vs_oracle():
     model = model.to(DEV)
     with torch.no_grad():
         y, res = model(b, include_partial=True)
+    worst = 0.0
     for k, v in rpart.items():
-        gate(res[k], v, f'REDDIT-32 {k} vs float64 oracle')
-    gate(y, ref, 'REDDIT-32 prediction vs float64 oracle')
+        worst = max(worst, gate(res[k], v, f'REDDIT-32 (readout {readout}) {k} vs float64 oracle'))
+    worst = max(worst, gate(y, ref, f'REDDIT-32 (readout {readout}) prediction vs float64 oracle'))
+    if readout == 'mean':
+        assert worst <= 1e-5, worst           # the absolute bar, on every compared tensor
 
 
 # ------------------------------------------------------------------------------------------------
