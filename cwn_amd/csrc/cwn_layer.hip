@@ -418,8 +418,15 @@ __device__ __forceinline__ float4 axpy4(const float4& acc, float s, const float4
 #else
 #define CWN_LAYER_OCCUPANCY
 #endif
+// The first three arguments are COPIES of A.items / A.set_start1 / A.set_start2: everything the workgroup needs to request its
+// item record.  As leading scalar arguments they can be PRELOADED into SGPRs by the dispatcher (csrc/Makefile:
+// -mllvm -amdgpu-kernarg-preload-count; a by-value struct is never preloaded -- round 4's experiment with the flag moved
+// nothing because nothing was preloaded), so the record request does not wait for a scalar load of the kernel-argument
+// segment first: one dependent memory round trip less in front of the chain.  kArgsOff = where A then starts.
+constexpr int kArgsOff = 16;
 template <int F, int MODE>
-__global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(LayerArgs A) {
+__global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(const int32_t* items_pre, int32_t set_start1_pre,
+                                                                             int32_t set_start2_pre, LayerArgs A) {
     using G = Geo<F>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -434,9 +441,9 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
     // occupy two VGPRs instead of ~60 SGPRs (the scalar-load form of this spilled SGPRs to VGPR lanes
     // and back: 130 v_readlane / v_writelane in the load phase alone).  The set follows from the
     // workgroup index (items are ordered by set), so the two loads do not depend on each other.
-    const int set = ((int)blockIdx.x >= A.set_start1 ? 1 : 0) + ((int)blockIdx.x >= A.set_start2 ? 1 : 0);
-    const int32_t itv = A.items[(size_t)blockIdx.x * CWN_LAYER_ITEM_INTS + (lane & (CWN_LAYER_ITEM_INTS - 1))];
-    const uint64_t srec = ((gcu64_p)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr())[set * kSetFields + min(lane, kSetFields - 1)];
+    const int set = ((int)blockIdx.x >= set_start1_pre ? 1 : 0) + ((int)blockIdx.x >= set_start2_pre ? 1 : 0);
+    const int32_t itv = items_pre[(size_t)blockIdx.x * CWN_LAYER_ITEM_INTS + (lane & (CWN_LAYER_ITEM_INTS - 1))];
+    const uint64_t srec = ((gcu64_p)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + kArgsOff))[set * kSetFields + min(lane, kSetFields - 1)];
     // The packed weight depends on the SET only, and while the two records travel (and are taken apart) the
     // address unit of this CU has nothing to do: the first kWEarly k-steps of this wave's slice are requested
     // now, their address from ONE scalar load of the set record's weight field.  (All of it here was
@@ -448,7 +455,8 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(Lay
     constexpr int kWEarly = CWN_LAYER_WEARLY < 0 ? G::kKS / 2 : (CWN_LAYER_WEARLY < G::kKS ? CWN_LAYER_WEARLY : G::kKS);
     __builtin_amdgcn_sched_barrier(0);       // both record loads leave before the scalar load below is waited for
     const uint64_t wp_bits =
-        ((const __attribute__((address_space(4))) uint64_t*)__builtin_amdgcn_kernarg_segment_ptr())[set * kSetFields + S_WP];
+        ((const __attribute__((address_space(4))) uint64_t*)((const __attribute__((address_space(4))) unsigned char*)
+                                                             __builtin_amdgcn_kernarg_segment_ptr() + kArgsOff))[set * kSetFields + S_WP];
     // chunk (ks, plane) of product h and column tile ct is the 1-KiB block number ((ks * 3 + plane) * 2 + h) * kNCT + ct:
     // the waves of a workgroup, which walk their chunks in step, read CONSECUTIVE kilobytes (all L2 channels)
     // instead of sixteen blocks 24 KB apart (a multiple of the channel interleave: the same few channels)
@@ -1337,7 +1345,8 @@ int launch(LayerArgs& A, int64_t n_items, hipStream_t stream) {
         if (A.big[0].y1 != nullptr || A.big[1].y1 != nullptr || A.big[2].y1 != nullptr) lds = lds > 96 * 1024 ? lds : 96 * 1024;
         A.lds_limit = (int32_t)lds;
     }
-    layer_kernel<F, MODE><<<dim3((unsigned)n_items), dim3(kThreads), lds, stream>>>(A);
+    static_assert(alignof(LayerArgs) == 8 && sizeof(const int32_t*) + 2 * sizeof(int32_t) == kArgsOff, "where A starts in the kernel-argument segment");
+    layer_kernel<F, MODE><<<dim3((unsigned)n_items), dim3(kThreads), lds, stream>>>(A.items, A.set_start1, A.set_start2, A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
