@@ -590,7 +590,7 @@ def main():
                        final_hidden_multiplier=2, final_readout='sum', init_reduce='sum',
                        embed_edge=True, use_coboundaries=True, graph_norm='bn')
         # CWN_BENCH_ATOMS=lo,hi (exploration, never the headline): molecule sizes other than the generator's 18 - 30 atoms,
-        # e.g. 9,38 for the spread of the real ZINC subset (mixed launches / big items)
+        # e.g. 9,38 for the spread of the real ZINC subset (mixed launches / big items, docs/history/DESIGN_rounds1-5.md 4.0b-c)
         # ... or 'zinc': the size statistics of the real ZINC-12k subset (9 - 37 atoms, mean 23.2: cwn_amd/synthetic.py)
         if os.environ.get('CWN_BENCH_ATOMS') == 'zinc':
             GEN_KIND, GEN_KW = 'zinc', dict(size_dist='zinc')
@@ -1570,7 +1570,7 @@ def main():
         import subprocess
         workloads = {}
         # (+ the headline's own workload at batch 2048: the range where a launch has many items per CU and takes the
-        # two-per-CU form of the layer kernel -- DESIGN.md 4.0b)
+        # two-per-CU form of the layer kernel -- DESIGN.md 4.0)
         # (+ the headline's workload with the molecule sizes of the REAL ZINC subset -- 9 - 37 atoms, ~2 % beyond the 32 one
         # workgroup held at width 128 until round 4 (BIG records then; they fit since) -- at batch 128 and 2048: VERDICT r3 item 5)
         for wl in ('molhiv', 'molhiv_real_tail', 'reddit', 'zinc_cinpp', 'zinc_batch2048', 'zinc_real_spread', 'zinc_real_spread_batch2048'):

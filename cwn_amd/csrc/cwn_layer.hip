@@ -45,7 +45,7 @@
 //     compiler wait with vmcnt(0) (= for the 200 KB issued later) wherever an early result is used;
 //   * fragment-shaped loads of the fp32 weight (16 rows x 32 B per quarter wave) run the address unit
 //     at 1/8 rate: issuing the loads alone took 6 us.  Hence the packed weight.
-//   (the rest of the list: DESIGN.md 4.0)
+//   (the rest of the list: docs/history/DESIGN_rounds1-5.md 4.0)
 // HBM traffic = the item's x rows once, its COO entries once, the two output streams once.  No
 // global atomics, no zero-fill pass; sums are sequential in the original entry order (deterministic, the
 // order a sequential index_add_ visits them).  Results are bit-identical to the two-kernel path

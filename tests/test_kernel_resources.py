@@ -1,6 +1,6 @@
 """Build-time facts about the kernels of the built library, read from the code objects' metadata (no GPU): the
 kernels of the headline path keep their registers (a spill there is a scratch round trip behind a full
-`s_waitcnt vmcnt(0)` -- DESIGN.md 4.0 lost 4 us per step to four spilled registers once), fit the occupancy they
+`s_waitcnt vmcnt(0)` -- docs/history/DESIGN_rounds1-5.md 4.0 lost 4 us per step to four spilled registers once), fit the occupancy they
 were written for, and no kernel starts spilling unnoticed."""
 import os
 import sys
