@@ -109,14 +109,15 @@ __device__ __forceinline__ void add_masked(float4& acc, const float4& a, const f
 }
 
 template <int F>
-__global__ __launch_bounds__(kThreads) void layer_bwd_own_kernel(OwnArgs A) {
+// (items_pre = A.items as a LEADING scalar argument: preloaded into SGPRs by the dispatcher, csrc/Makefile PRELOAD)
+__global__ __launch_bounds__(kThreads) void layer_bwd_own_kernel(const int32_t* items_pre, OwnArgs A) {
     using G = Geo<F>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     CWN_STAMP(0);
-    const int32_t* const it = A.items + (size_t)blockIdx.x * CWN_LAYER_BWD_ITEM_INTS;
+    const int32_t* const it = items_pre + (size_t)blockIdx.x * CWN_LAYER_BWD_ITEM_INTS;
     const int flags = it[bo::R_FLAGS], d = it[bo::R_DIM];
     const int o_r0 = it[bo::R_OWN_R0], n_o = it[bo::R_OWN_N], a_r0 = it[bo::R_ABOVE_R0], n_a = it[bo::R_ABOVE_N];
     const int b_r0 = it[bo::R_BELOW_R0], n_b = it[bo::R_BELOW_N];
@@ -575,10 +576,10 @@ int launch(const OwnArgs& A, int64_t n_items, hipStream_t stream) {
 #ifdef CWN_LBWD_TIMING
     OwnArgs B = A;
     B.stamps = g_stamps;
-    layer_bwd_own_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), (size_t)A.lds_bytes, stream>>>(B);
+    layer_bwd_own_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), (size_t)A.lds_bytes, stream>>>(B.items, B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 #endif
-    layer_bwd_own_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), (size_t)A.lds_bytes, stream>>>(A);
+    layer_bwd_own_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), (size_t)A.lds_bytes, stream>>>(A.items, A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 

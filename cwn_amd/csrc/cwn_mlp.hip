@@ -108,7 +108,9 @@ unsigned long long* g_mlp_stamps = nullptr;
 template <int F, int RT, bool SEQ, bool NARROW>
 // (HIP's second __launch_bounds__ argument is the minimum number of WAVES per SIMD, not CUDA's blocks per multiprocessor: two
 // resident 8-wave workgroups are four waves a SIMD -- the compiler then holds the sequential build to 128 registers)
-__global__ __launch_bounds__(kThreads, SEQ ? 4 : 1) void update_mlp_kernel(MlpBatch B) {
+// (n_pre, bs1_pre, bs2_pre: copies of B.n, B.blk_start[1], B.blk_start[2] as LEADING scalar arguments -- preloaded into SGPRs by the
+//  dispatcher, csrc/Makefile PRELOAD -- so the workgroup knows its dimension without a scalar load of the argument segment)
+__global__ __launch_bounds__(kThreads, SEQ ? 4 : 1) void update_mlp_kernel(int32_t n_pre, int32_t bs1_pre, int32_t bs2_pre, MlpBatch B) {
     using S = Shape<F, RT, SEQ>;
     constexpr int TM = S::kTM, kRowStride = S::kRowStride, kChunksPerTile = S::kChunksPerTile, kKS = S::kKS;
     constexpr int kRT = S::kRT, kV = S::kV;
@@ -119,12 +121,12 @@ __global__ __launch_bounds__(kThreads, SEQ ? 4 : 1) void update_mlp_kernel(MlpBa
     uint16_t* const bufB = reinterpret_cast<uint16_t*>(smem + 2 * kBufBytes);   // stage-1 output, upper branch
     uint16_t* const bufD = reinterpret_cast<uint16_t*>(smem + 3 * kBufBytes);   // stage-1 output, boundary branch
     uint16_t* const bufU = reinterpret_cast<uint16_t*>(smem + 4 * kBufBytes);   // h_up
-    int di = 0;
-#pragma unroll
-    for (int i = 1; i < CWN_LAYER_MAX_DIMS; ++i)
-        if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
+    static_assert(CWN_LAYER_MAX_DIMS == 3, "two preloaded block starts");
+    int di = 0, blk0 = 0;
+    if (1 < n_pre && (int)blockIdx.x >= bs1_pre) { di = 1; blk0 = bs1_pre; }
+    if (2 < n_pre && (int)blockIdx.x >= bs2_pre) { di = 2; blk0 = bs2_pre; }
     const cwn_mlp_dim& D = B.d[di];
-    const int64_t row0 = (int64_t)((int)blockIdx.x - B.blk_start[di]) * TM;
+    const int64_t row0 = (int64_t)((int)blockIdx.x - blk0) * TM;
     // rows that exist (include/cwn_hip.h, "device-side row counts"; D.M is then the capacity: it bounds the addresses)
     const int64_t Mv = D.m_dev != nullptr ? *D.m_dev : D.M;
     if (row0 >= Mv) return;                         // (uniform) a tile past the batch's own rows
@@ -390,7 +392,8 @@ int launch_mlp(MlpBatch& B, int64_t blocks, hipStream_t stream) {
 #ifdef CWN_MLP_TIMING
     B.stamps = g_mlp_stamps;
 #endif
-    update_mlp_kernel<F, RT, SEQ, NARROW><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F, RT, SEQ>::kLdsBytes, stream>>>(B);
+    update_mlp_kernel<F, RT, SEQ, NARROW><<<dim3((unsigned)blocks), dim3(kThreads), Shape<F, RT, SEQ>::kLdsBytes, stream>>>(
+        B.n, B.blk_start[1], B.blk_start[2], B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
