@@ -276,12 +276,39 @@ ERROR_EPOCH = 0      # moves with every raised IndexError: "these indices were c
 _cache = {}
 
 
+_defer = threading.local()
+
+
+class deferred_builds:
+    """Inside this context `cached_adjacency` hands out plans WITHOUT building them (round 6): the caller knows that the launches it
+    is about to describe may never read them -- the training forward through the complex-blocked launch, whose backward is the
+    owner-form launch over its own item table (cwn_amd/layers.py propagate_all) -- and every reader of a plan builds it on
+    demand (`ensure_built`: ops.run_aggregate, the streaming backward).  Two CSR builds per training step at ZINC-128."""
+
+    def __enter__(self):
+        self.prev = getattr(_defer, 'on', False)
+        _defer.on = True
+        return self
+
+    def __exit__(self, *exc):
+        _defer.on = self.prev
+        return False
+
+
+def ensure_built(adj: Optional['Adjacency']) -> Optional['Adjacency']:
+    """`adj`, built (a plan handed out under `deferred_builds` and wanted after all)."""
+    if adj is not None and not adj.built:
+        build_many([adj])
+    return adj
+
+
 def cached_adjacency(index: torch.Tensor, n_dst: int, n_src: int,
                      aux_index: Optional[torch.Tensor] = None, n_aux: int = 0,
                      build: bool = True) -> Adjacency:
     """propagate() is called with the same index tensors by every layer (mp/molec_models.py:110);
     convert each one once.  Keyed on tensor identity + version counter, evicted when the tensor
     dies.  A plan that carries a shared-cell (aux) index also serves requests without one."""
+    build = build and not getattr(_defer, 'on', False)
     key = id(index)
     hit = _cache.get(key)
     ver = (_ffi.tver(index), n_dst, n_src)

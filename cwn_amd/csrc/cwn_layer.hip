@@ -465,7 +465,13 @@ __global__ __launch_bounds__(kThreads) CWN_LAYER_OCCUPANCY void layer_kernel(con
     const uint32_t won = wp_bits != 0 ? 1024u : 0u;
     const uint32_t wlane = (uint32_t)lane * 16;
     auto wload = [&](int h, int ks, int pl) {
+#if defined(CWN_LAYER_EXP_NOWEIGHT) && CWN_LAYER_EXP_NOWEIGHT == 2      // headroom experiment (wrong results): no weight traffic at all
+        return make_uint4(wlane + (uint32_t)ks, wlane ^ (uint32_t)pl, wlane + (uint32_t)h, wlane);
+#elif defined(CWN_LAYER_EXP_NOWEIGHT)                                    // ... every chunk = the same KiB (L1 hits; the address unit still works)
+        return ldgu4o(wbase, wlane + (uint32_t)(((ks * 3 + pl) * 2 + h) * G::kNCT) * 0u * won);
+#else
         return ldgu4o(wbase, wlane + (uint32_t)(((ks * 3 + pl) * 2 + h) * G::kNCT) * won);
+#endif
     };
 #pragma unroll
     for (int hh = 0; hh < kWSets; ++hh) {

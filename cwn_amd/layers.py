@@ -823,9 +823,15 @@ class SparseCINConv(torch.nn.Module):
         pre = self._propagate_blocked_train(cochain_params, start_to_process, specs, owner) if specs else None
 
         def make_streams(ys):
-            for dim in range(start_to_process, n):
-                mine = [y for y, o in zip(ys, owner) if o == dim]
-                plans[dim] = self.mp_levels[dim].streams(cochain_params[dim], mine or None)
+            # the forward has run as the blocked launch: the streams only DESCRIBE the step for the autograd node, and its
+            # backward is the owner-form launch over its own item table -- the CSR plans of the adjacencies are built when
+            # somebody reads them (csr.deferred_builds; ops.gemm_aggregate builds them at once when the backward will)
+            from .csr import deferred_builds
+            import contextlib
+            with (deferred_builds() if pre is not None else contextlib.nullcontext()):
+                for dim in range(start_to_process, n):
+                    mine = [y for y, o in zip(ys, owner) if o == dim]
+                    plans[dim] = self.mp_levels[dim].streams(cochain_params[dim], mine or None)
             return [st for p in plans if p is not None for st in p]
 
         if specs:       # (training: ONE autograd node around the products and the aggregation, ops._GemmAggregate)

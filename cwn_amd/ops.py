@@ -82,6 +82,10 @@ def run_aggregate(specs: Sequence[AggSpec], device) -> List[Tensor]:
             s.out = torch.empty(s.n_dst, s.F, dtype=torch.float32, device=device)
     live = [s for s in specs if s.n_dst > 0]
     if live:
+        late = [s.adj for s in live if s.adj is not None and not s.adj.built]     # handed out under csr.deferred_builds
+        if late:
+            from .csr import build_many
+            build_many(late)
         wait_ready([s.adj for s in live])      # plans built on the side stream (csr.build_many)
         _ffi.aggregate([s.desc() for s in live], device)
     return [s.out for s in specs]
@@ -174,6 +178,9 @@ def _aggregate_backward(streams, tensors, needs, gs, max_outs, device) -> List[O
         adj, op = st.adj, st.msg_op
         if adj is None or not (need_A or need_B):
             continue
+        if not adj.built:                       # (handed out under csr.deferred_builds, wanted after all)
+            from .csr import ensure_built
+            ensure_built(adj)
         if st.reduce == 'max':
             out_k = max_outs[sum(1 for s_ in streams[:k] if s_.reduce == 'max')]
             if op != MSG_A:
@@ -424,6 +431,27 @@ def embedding_sum(weights: Sequence[Tensor], idx: Tensor) -> Tensor:
     return _EmbeddingSum.apply(idx.contiguous(), *weights)
 
 
+def _adjacent_rows(tensors: Sequence[Tensor]) -> Optional[Tensor]:
+    """The row-wise concatenation of `tensors` WITHOUT a copy when they already lie back to back in one storage -- the
+    per-column tables of an OGB-style encoder re-homed into FlatAdam's parameter buffer (cwn_amd/train.py: consecutive
+    parameters, every one a multiple of 16 bytes), and their gradients in the flat bucket: one [sum V, H] view over all of
+    them.  None when they do not (the caller concatenates).  A training step changes every table, so the copy was a launch per
+    encoder and step (molhiv-512: 2 x torch.cat forward, 2 x zero-fill + 2 x _foreach_add_ backward: round 6)."""
+    t0 = tensors[0]
+    if t0.dim() != 2 or t0.dtype != torch.float32 or not t0.is_contiguous():
+        return None
+    H, end, rows = int(t0.size(1)), t0.data_ptr(), 0
+    for t in tensors:
+        if (t.dim() != 2 or t.dtype != torch.float32 or not t.is_contiguous() or int(t.size(1)) != H or t.data_ptr() != end
+                or t.device != t0.device or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr()):
+            return None
+        end += t.numel() * 4
+        rows += int(t.size(0))
+    if end > t0.untyped_storage().data_ptr() + t0.untyped_storage().nbytes():
+        return None
+    return t0.as_strided((rows, H), (H, 1))
+
+
 class _EmbeddingSum(torch.autograd.Function):
     """Forward: cwn_embedding_fwd_f32.  Backward: cwn_embedding_bwd_f32 into one zeroed buffer,
     handed back as per-table views (or added into the parameters' .grad directly when they are
@@ -449,7 +477,9 @@ class _EmbeddingSum(torch.autograd.Function):
     def forward(ctx, idx, *weights):
         from .csr import _err_flag, VALIDATE_INDICES, check_errors
         dev = idx.device
-        W = weights[0] if len(weights) == 1 else torch.cat([w.detach() for w in weights], 0)
+        W = weights[0] if len(weights) == 1 else _adjacent_rows([w.detach() for w in weights])
+        if W is None:
+            W = torch.cat([w.detach() for w in weights], 0)
         W = _f32c(W.detach(), 'embedding table')
         off, size = _EmbeddingSum._columns(weights, dev)
         N, Cn = idx.shape
@@ -545,6 +575,16 @@ def _embedding_table_grads(tables, idx: Tensor, g: Tensor) -> List[Optional[Tens
                 g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), t.data_ptr(), idx.size(0),
                 idx.size(1), H, V, f32, n_dev, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
             return [None]
+    else:
+        # several tables whose .grad tensors lie back to back (views of the flat gradient bucket): the kernel adds into all of
+        # them as ONE [V, H] matrix -- no zeroed scratch, no per-table views, no _foreach_add_ behind it
+        targets = [_grad_target(w) for w in tables]
+        flat_t = _adjacent_rows(targets) if all(t is not None for t in targets) else None
+        if flat_t is not None and tuple(flat_t.shape) == (V, H):
+            _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
+                g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), flat_t.data_ptr(), idx.size(0),
+                idx.size(1), H, V, f32, n_dev, _ffi.stream_ptr(g.device)), 'cwn_embedding_bwd_f32')
+            return [None] * len(tables)
     dW = torch.zeros(V, H, dtype=torch.float32, device=g.device)
     _ffi.check(_ffi.lib().cwn_embedding_bwd_f32(
         g.data_ptr(), idx.data_ptr(), _ffi.ptr(off), _ffi.ptr(size), dW.data_ptr(), idx.size(0),
@@ -589,7 +629,9 @@ def _embed_table(weights: Sequence[Tensor], feats: Tensor, keep: list) -> _ffi.E
         if hit is None:
             if len(_table_cache) > 32:
                 _table_cache.clear()
-            hit = (torch.cat([w.detach() for w in weights], 0).contiguous(), [weakref.ref(w) for w in weights])
+            flat_w = _adjacent_rows([w.detach() for w in weights])
+            hit = ((flat_w if flat_w is not None else torch.cat([w.detach() for w in weights], 0).contiguous()),
+                   [weakref.ref(w) for w in weights])
             _table_cache[key] = hit
         W = hit[0]
     off, size = _EmbeddingSum._columns(weights, dev)

@@ -881,3 +881,56 @@ def test_blocked_layer_on_rings_up_to_eighteen(F):
             assert torch.equal(blocked[2 * d], streamed[2 * d]) and torch.equal(blocked[2 * d + 1], streamed[2 * d + 1])
         else:
             _gate(streamed[2 * d], ref[d][0], f'max_ring 18, F = {F}: two-kernel out_up[{d}]')
+
+
+def test_blocked_training_step_builds_no_plans_of_the_upper_adjacencies():
+    """Round 6: a training step whose forward runs as the blocked launch and whose backward is the owner-form launch reads no CSR
+    plan of an upper adjacency -- the streams that describe the step to autograd get their plans UNBUILT (csr.deferred_builds)
+    and nobody asks for them: one batched build per step (the boundary adjacencies, Complex.prepare(upper=False)), where there
+    were three.  A reader that does want such a plan builds it on demand: the same batch through the streaming path afterwards."""
+    from cwn_amd import csr, layers
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import zinc_like_complexes
+    from cwn_amd.train import TrainStep
+    torch.manual_seed(0)
+    model = EmbedSparseCIN(28, 4, 1, 2, 64, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV)
+    batches = [ComplexBatch.from_complex_list(zinc_like_complexes(24, i, 6), max_dim=2).to(DEV) for i in range(2)]
+    for b in batches:
+        b.y = torch.zeros(b.num_complexes, 1, device=DEV)
+    ts = TrainStep(model, batches, task_type='regression', use_graph=True)
+    for i in range(3):
+        ts.step(i % 2)            # (the capture's warm-up settles _skip_upper_plans)
+    assert ts._skip_upper_plans
+    ts2 = TrainStep(model, batches, task_type='regression', use_graph=False)
+    ts2._skip_upper_plans = True
+    ts2.step(0)
+    calls, orig = [], csr.build_many
+
+    def traced(adjs, *a, **k):
+        adjs = [x for x in adjs if k.get('force') or not x.built]
+        if adjs:
+            calls.append([(x.n_dst, x.n_entries) for x in adjs])
+        return orig(adjs, *a, **k)
+    csr.build_many = traced
+    import cwn_amd.complex as cx_mod
+    try:
+        loss = ts2.step(1)
+        torch.cuda.synchronize()
+    finally:
+        csr.build_many = orig
+    assert len(calls) == 1, calls            # Complex.prepare(backward=True, upper=False): the boundary adjacencies (+ transposes)
+    assert torch.isfinite(loss)
+    # the same batch on the streaming path: the plans are built when they are read
+    model.eval()
+    x0 = [None if batches[1].cochains[d].x is None else batches[1].cochains[d].x.clone() for d in range(3)]
+    keep, layers.BLOCKED_LAYER = layers.BLOCKED_LAYER, False
+    try:
+        with torch.no_grad():
+            want = model(batches[1])
+    finally:
+        layers.BLOCKED_LAYER = keep
+    batches[1].set_xs(x0)             # (the forward leaves its embeddings in the batch)
+    with torch.no_grad():
+        got = model(batches[1])
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
