@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')
 MAX_DESCS = 8
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp3_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_update_mlp_pack_weights_both_many_f32', 'cwn_layer_pack_weights_both_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_ex_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_slots', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_collate_guard', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
@@ -78,12 +78,17 @@ class LayerDim(C.Structure):
                 ('out_down', C.c_void_p), ('eps3', C.c_void_p)]
 
 
+class BnBwdLive(C.Structure):
+    """cwn_bn_bwd_live (include/cwn_hip.h)."""
+    _fields_ = [('z', C.c_void_p), ('aff', C.c_void_p), ('slots', C.c_void_p), ('ldz', C.c_int64)]
+
+
 class LayerBwdDim(C.Structure):
     """cwn_layer_bwd_dim (include/cwn_hip.h)."""
     _fields_ = [('g_up', C.c_void_p), ('g_b', C.c_void_p), ('y1', C.c_void_p), ('y2', C.c_void_p), ('up_index', C.c_void_p),
                 ('up_shared', C.c_void_p), ('b_index', C.c_void_p), ('wt_packed', C.c_void_p), ('eps1', C.c_void_p),
                 ('eps2', C.c_void_p), ('dx', C.c_void_p), ('gy1', C.c_void_p), ('gy2', C.c_void_p),
-                ('n_cells', C.c_int64), ('e_up', C.c_int64), ('n_b', C.c_int64)]
+                ('n_cells', C.c_int64), ('e_up', C.c_int64), ('n_b', C.c_int64), ('out_bn', BnBwdLive)]
 
 
 class LayerPlan(C.Structure):
@@ -161,11 +166,6 @@ class StageExtra(C.Structure):
     """cwn_stage_extra (include/cwn_hip.h): a third / fourth K-block of a cwn_dense_stage_ex_f32 product."""
     _fields_ = [('X', C.c_void_p), ('w_packed', C.c_void_p), ('ldx', C.c_int64), ('relu', C.c_int32), ('pad_', C.c_int32),
                 ('bn', BnLive)]
-
-
-class BnBwdLive(C.Structure):
-    """cwn_bn_bwd_live (include/cwn_hip.h)."""
-    _fields_ = [('z', C.c_void_p), ('aff', C.c_void_p), ('slots', C.c_void_p), ('ldz', C.c_int64)]
 
 
 class FrontBwd(C.Structure):

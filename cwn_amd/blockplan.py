@@ -29,6 +29,7 @@ def gemm_rows_cap(F: int) -> int:
 
 
 LDS_BYTES = 160 * 1024
+BWD_LDS_BYTES = 160 * 1024 - 2048      # csrc/cwn_layer_bwd_own.h kLdsCap: an item of the owner-form backward (the launch keeps 2 KiB for the BatchNorm sums)
 _IDX_BYTES = ((3 * (TASK_ROWS + 2) * 4 + 15) // 16 * 16 + 3 * MAX_ENTRIES * 2 + 3 * (TASK_ROWS + 2) * 2 + 15) // 16 * 16
 
 
@@ -412,7 +413,7 @@ def bwd_layout_total(F: int, flags: int, n_o, n_a, n_b, ne_a, ne_b, ne_bd):
 
 
 def single_fit_backward(cells: Sequence[np.ndarray], up_len: Sequence[Optional[np.ndarray]], b_len: Sequence[Optional[np.ndarray]],
-                        F: int, has_up: Sequence[bool], has_b: Sequence[bool], lds_cap: int = LDS_BYTES) -> np.ndarray:
+                        F: int, has_up: Sequence[bool], has_b: Sequence[bool], lds_cap: int = BWD_LDS_BYTES) -> np.ndarray:
     """bool per complex: does it fit one workgroup of cwn_layer_bwd_own_f32 in every set?  = items_bwd_kernel's classify >= 0."""
     n_dims = len(cells)
     cells = [np.asarray(c, dtype=np.int64) for c in cells]

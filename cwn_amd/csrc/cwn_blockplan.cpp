@@ -321,7 +321,7 @@ extern "C" int64_t cwn_layer_bwd_items_build(const cwn_layer_sizes* in, int32_t 
             const bool need_a = pa || top || bd > 0;
             const bo::Layout L = bo::layout(F, flags, (int)n_o, need_a ? (int)n_a : 0, (int)n_b, (int)ea, (int)eb, (int)bd);
             if (Lout != nullptr) *Lout = L;
-            return L.total <= 160 * 1024;
+            return L.total <= bo::kLdsCap;
         };
         recs.clear();
         weight.clear();

@@ -475,7 +475,7 @@ extern "C" int cwn_layer_bwd_items_build_dev(const cwn_layer_sizes_dev* in, int3
     const int rc = fill_common(in, F, group, err_flag, A);
     if (rc != CWN_OK) return rc;
     if (plan == nullptr || plan->items == nullptr || ((uintptr_t)plan->items & 15u)) return CWN_ERR_BAD_ARG;
-    if (plan->lds_bytes <= 0 || plan->lds_bytes > 160 * 1024) return CWN_ERR_BAD_ARG;
+    if (plan->lds_bytes <= 0 || plan->lds_bytes > cwn_bwd_own::kLdsCap) return CWN_ERR_BAD_ARG;
     if (plan->n_items != (int64_t)A.n_sets * in->cap_complexes) return CWN_ERR_BAD_ARG;     // one region of cap_complexes records per set
     A.items = const_cast<int32_t*>(plan->items);
     A.bwd_lds = plan->lds_bytes;

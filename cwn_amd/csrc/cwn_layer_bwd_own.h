@@ -20,6 +20,8 @@ enum {
 enum { F_PA = 1, F_PB = 2, F_TOP = 4 };
 
 constexpr int kThreads = 1024;
+// what an item's layout may take: the CU's 160 KiB less the launch's scratch for the BatchNorm sums (cwn_layer_bwd_dim.out_bn: [4][F] floats)
+constexpr int kLdsCap = 160 * 1024 - 2048;
 
 CWN_BWD_HD int pad16i(int n) { return (n + 15) & ~15; }
 CWN_BWD_HD int pad4i(int n) { return (n + 3) & ~3; }

@@ -36,6 +36,8 @@ using cwn::frag_cd;
 
 constexpr int kThreads = bo::kThreads;
 constexpr int kWaves = kThreads / 64;
+constexpr int kBnScratch = 160 * 1024 - bo::kLdsCap;   // [4][F] floats behind the item's LDS (cwn_layer_bwd_dim.out_bn)
+static_assert(kBnScratch >= 4 * 128 * 4, "scratch of the BatchNorm sums");
 
 struct OwnArgs {
     cwn_layer_bwd_dim d[CWN_LAYER_MAX_DIMS];
@@ -43,7 +45,8 @@ struct OwnArgs {
     int32_t* err;
     int32_t lds_bytes;
     int32_t n_dims;
-    int32_t dbg;          // timing experiments (CWN_LBWD_DBG): 1 no entry walk, 2 no matrix cores, 4 no gY store
+    int32_t dbg;          // timing experiments (CWN_LBWD_DBG): 1 no entry walk, 2 no matrix cores, 4 no gY store, 8 no slot atomics,
+                          // 16 no z / constant loads of the BatchNorm sums, 32 no BatchNorm sums at all
 #ifdef CWN_LBWD_TIMING
     unsigned long long* stamps;              // [n_items][32]: [0, 16) points seen by wave 0 (first product), [16, 32) by the first wave of the second
 #endif
@@ -502,6 +505,37 @@ __global__ __launch_bounds__(kThreads) void layer_bwd_own_kernel(const int32_t* 
             if (4 * kq + r < n_rows_left) o[(size_t)r * YS] += acc[r];
     };
     const int T = L.RO / 16;
+    // ---- (round 6) the REDUCE half of the BatchNorm backward of the stage whose OUTPUT x_d is (include/cwn_hip.h:
+    // cwn_layer_bwd_dim.out_bn): the rows of dx this workgroup owns are that stage's dy, complete -- their column sums of
+    // dx * mask and dx * mask * xhat leave from here, and the previous layer's backward launches no reduce of its own.
+    // Scratch [own: F sums of dyh | F of dyh * xhat | top rows: the same two] behind the item's LDS, zeroed here (two
+    // barriers in front of its first add); z of the owned rows and the stage's constants are requested behind the products,
+    // in front of the last barrier (across the products the registers do not exist: 128 of 128).
+    // (the records are read where they are used -- behind the products: read here their fields were live, in registers this
+    // kernel does not have, across the whole matrix-core phase)
+    float* const bn_sc = reinterpret_cast<float*>(smem + A.lds_bytes);
+    if (tid < 4 * F) bn_sc[tid] = 0.f;
+    float4 zo[G::kMaxOwn], zt = zero4();
+    float4 oa[4], ta[4];                                 // scale, shift, mean, rstd at this lane's four columns
+    bool live_o = false, live_t = false;
+    auto request_bn = [&]() {
+        const cwn_bn_bwd_live& LBo = A.d[d].out_bn;
+        const cwn_bn_bwd_live& LBt = A.d[d + 1 < A.n_dims ? d + 1 : d].out_bn;
+        live_o = LBo.slots != nullptr && !(A.dbg & 32);
+        live_t = TOP && n_a > 0 && LBt.slots != nullptr && !(A.dbg & 32);
+        if (live_o && !(A.dbg & 16)) {
+#pragma unroll
+            for (int k = 0; k < G::kMaxOwn; ++k)
+                if (k * G::kNG < n_o) zo[k] = ld4(LBo.z + (size_t)(o_r0 + min(gq + k * G::kNG, n_o - 1)) * LBo.ldz + f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) oa[q] = ld4(LBo.aff + q * F + f);
+        }
+        if (live_t) {
+            zt = ld4(LBt.z + (size_t)(a_r0 + min(gq, n_a - 1)) * LBt.ldz + f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ta[q] = ld4(LBt.aff + q * F + f);
+        }
+    };
     // Two code paths (the branch is wave-uniform; both meet the same two barriers): the waves of the SECOND product add
     // first, tile by tile, and then run the third; the waves of the FIRST keep their tiles until the barrier.
     if (my_h == 1) {
@@ -523,6 +557,7 @@ __global__ __launch_bounds__(kThreads) void layer_bwd_own_kernel(const int32_t* 
             }
         }
         CWN_STAMP(11);
+        request_bn();
         __syncthreads();
     } else {
         frag_cd accs[G::kMaxTiles];
@@ -544,17 +579,96 @@ __global__ __launch_bounds__(kThreads) void layer_bwd_own_kernel(const int32_t* 
             }
         }
         CWN_STAMP(11);
+        request_bn();
         __syncthreads();
     }
     CWN_STAMP(12);
 
-    // ---- 5. the rows of dx, once ----------------------------------------------------------------------------------------
+    // ---- 5. the rows of dx, once (+ their share of the BatchNorm sums) -------------------------------------------------
+    auto bn_add = [&](float (&a1)[4], float (&a2)[4], const float4& dxv, const float4& zv, const float4 (&c)[4]) {
+        const float d_[4] = {dxv.x, dxv.y, dxv.z, dxv.w}, z_[4] = {zv.x, zv.y, zv.z, zv.w};
+        const float sc[4] = {c[0].x, c[0].y, c[0].z, c[0].w}, sh[4] = {c[1].x, c[1].y, c[1].z, c[1].w};
+        const float mu[4] = {c[2].x, c[2].y, c[2].z, c[2].w}, rs[4] = {c[3].x, c[3].y, c[3].z, c[3].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                    // (cwn_stage.hip's producer epilogue: the same arithmetic)
+            const float y = z_[q] * sc[q] + sh[q];
+            const float dyh = y > 0.f ? d_[q] : 0.f;
+            a1[q] += dyh;
+            a2[q] += dyh * ((z_[q] - mu[q]) * rs[q]);
+        }
+    };
+    float o1[4] = {0.f, 0.f, 0.f, 0.f}, o2[4] = {0.f, 0.f, 0.f, 0.f}, t1_[4] = {0.f, 0.f, 0.f, 0.f}, t2_[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < G::kMaxOwn; ++k) {
         const int r = gq + k * G::kNG;
-        if (r < n_o) st4(Dd.dx + (size_t)(o_r0 + r) * F + f, ld4(O + (size_t)r * YS + f));
+        if (r < n_o) {
+            const float4 v = ld4(O + (size_t)r * YS + f);
+            st4(Dd.dx + (size_t)(o_r0 + r) * F + f, v);
+            if (live_o) bn_add(o1, o2, v, zo[k], oa);
+        }
     }
-    if (TOP && gq < n_a) st4(Da.dx + (size_t)(a_r0 + gq) * F + f, ld4(O + (size_t)(L.RO + gq) * YS + f));
+    if (TOP && gq < n_a) {
+        const float4 v = ld4(O + (size_t)(L.RO + gq) * YS + f);
+        st4(Da.dx + (size_t)(a_r0 + gq) * F + f, v);
+        if (live_t) bn_add(t1_, t2_, v, zt, ta);
+    }
+    if (live_o || live_t) {                              // (uniform over the workgroup)
+        // lane groups of a wave -> its first group (xor tree), waves -> workgroup through LDS, 4 F threads -> the slots
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int off = G::kG; off < 64; off <<= 1) {
+                o1[q] += __shfl_xor(o1[q], off, 64);
+                o2[q] += __shfl_xor(o2[q], off, 64);
+                t1_[q] += __shfl_xor(t1_[q], off, 64);
+                t2_[q] += __shfl_xor(t2_[q], off, 64);
+            }
+        }
+        // Waves -> workgroup.  LDS float atomics would be the short form -- and measured ~10 us per launch: ds_add_f32 takes its
+        // lanes one by one (256 wave instructions, ~100 cycles each).  The region of the staged rows / planes is dead behind the
+        // last barrier: every wave stores its 4 F partial sums there, 4 F threads add the sixteen in wave order.  An item whose
+        // region is smaller than that (a few cells) keeps the atomics.
+        float* const part = reinterpret_cast<float*>(smem);                 // [kWaves][4 F]
+        const bool wide = (size_t)L.o_off >= (size_t)kWaves * 4 * F * sizeof(float);
+        if (lane < G::kG) {
+            if (wide) {
+                float* const w = part + (size_t)wave * 4 * F + f;
+                st4(w, make_float4(o1[0], o1[1], o1[2], o1[3]));
+                st4(w + F, make_float4(o2[0], o2[1], o2[2], o2[3]));
+                st4(w + 2 * F, make_float4(t1_[0], t1_[1], t1_[2], t1_[3]));
+                st4(w + 3 * F, make_float4(t2_[0], t2_[1], t2_[2], t2_[3]));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (live_o) {
+                        __hip_atomic_fetch_add(bn_sc + f + q, o1[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(bn_sc + F + f + q, o2[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (live_t) {
+                        __hip_atomic_fetch_add(bn_sc + 2 * F + f + q, t1_[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(bn_sc + 3 * F + f + q, t2_[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        // (a barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global STORE -- the rows of
+        // dx and of gY this workgroup has just written)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float total = 0.f;
+        if (tid < 4 * F) {
+            if (wide) {
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) total += part[(size_t)w * 4 * F + tid];
+            } else {
+                total = bn_sc[tid];
+            }
+        }
+        const int slot = (int)(blockIdx.x % CWN_BN_SLOTS);
+        if (live_o && tid < 2 * F && !(A.dbg & 8)) unsafeAtomicAdd(A.d[d].out_bn.slots + (size_t)slot * 2 * F + tid, total);
+        if (live_t && tid >= 2 * F && tid < 4 * F && !(A.dbg & 8))
+            unsafeAtomicAdd(A.d[d + 1 < A.n_dims ? d + 1 : d].out_bn.slots + (size_t)slot * 2 * F + (tid - 2 * F), total);
+    }
     CWN_STAMP(13);
 }
 
@@ -576,10 +690,10 @@ int launch(const OwnArgs& A, int64_t n_items, hipStream_t stream) {
 #ifdef CWN_LBWD_TIMING
     OwnArgs B = A;
     B.stamps = g_stamps;
-    layer_bwd_own_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), (size_t)A.lds_bytes, stream>>>(B.items, B);
+    layer_bwd_own_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), (size_t)A.lds_bytes + kBnScratch, stream>>>(B.items, B);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 #endif
-    layer_bwd_own_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), (size_t)A.lds_bytes, stream>>>(A.items, A);
+    layer_bwd_own_kernel<F><<<dim3((unsigned)n_items), dim3(kThreads), (size_t)A.lds_bytes + kBnScratch, stream>>>(A.items, A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 
@@ -598,7 +712,7 @@ extern "C" int cwn_layer_bwd_own_f32(const cwn_layer_bwd_dim* dims, int n_dims, 
     if (n_items == 0) return CWN_OK;
     if (plan->items == nullptr || err_flag == nullptr) return CWN_ERR_BAD_ARG;
     if (n_items >= INT32_MAX) return CWN_ERR_TOO_LARGE;
-    if (plan->lds_bytes <= 0 || plan->lds_bytes > 160 * 1024) return CWN_ERR_TOO_LARGE;
+    if (plan->lds_bytes <= 0 || plan->lds_bytes + kBnScratch > 160 * 1024) return CWN_ERR_TOO_LARGE;
     if (!al16(plan->items)) return CWN_ERR_ALIGN;
     OwnArgs A{};
     for (int d = 0; d < n_dims; ++d) {
@@ -612,6 +726,10 @@ extern "C" int cwn_layer_bwd_own_f32(const cwn_layer_bwd_dim* dims, int n_dims, 
         if (!(al16(D.g_up) && al16(D.g_b) && al16(D.y1) && al16(D.y2) && al16(D.dx) && al16(D.gy1) && al16(D.gy2) &&
               al16(D.wt_packed)))
             return CWN_ERR_ALIGN;
+        if (D.out_bn.slots != nullptr) {     // the stage whose output x_d is: z [n_cells, F] (16-byte rows), aff [4][F]
+            if (D.out_bn.z == nullptr || D.out_bn.aff == nullptr || D.out_bn.ldz < F || (D.out_bn.ldz & 3)) return CWN_ERR_BAD_ARG;
+            if (!(al16(D.out_bn.z) && al16(D.out_bn.aff)) || ((uintptr_t)D.out_bn.slots & 3u)) return CWN_ERR_ALIGN;
+        }
         if (plan->cells_end[d] < 0 || plan->cells_end[d] > D.n_cells || plan->up_end[d] < 0 || plan->up_end[d] > D.e_up ||
             plan->b_end[d] < 0 || plan->b_end[d] > D.n_b)
             return CWN_ERR_BAD_ARG;

@@ -314,6 +314,24 @@ class _DenseTrain(torch.autograd.Function):
         ctx.drop_sites = drop_sites
         if acts:
             _ffi.norm_act(acts, dev)
+        # (round 6) the outputs of the combine stage are the NEXT conv layer's inputs: registered so that the blocked backward of
+        # that layer takes over the reduce half of this stage's BatchNorm backward (ops.bn_out_register; the slot sums live in
+        # the step's zeroed scratch).  Not with an output dropout (dy then arrives w.r.t. the dropped activation).
+        ctx.bn_ext = None
+        if (plan.cb is not None and live and LIVE_BN_BWD and ops.BN_BWD_FUSE and not FUSED_NORM_BACKWARD and plan.out_drop == 0.0
+                and ops.STAGE_KERNEL and ops.BLOCKED_BACKWARD == 2):
+            ext = []
+            for i, (z, h) in enumerate(zip(Z3, H)):
+                st = plan.cb[i]
+                Fw = int(z.size(1)) if z.dim() == 2 else 0
+                if (not st.is_bn or Fw not in (64, 128) or not z.numel() or z.stride(1) != 1 or z.stride(0) % 4
+                        or z.data_ptr() % 16):
+                    ext.append(None)
+                    continue
+                slots = ops.zeros_scratch(4 * _ffi.BN_SLOTS * 2 * Fw, dev).view(torch.float32)[:_ffi.BN_SLOTS * 2 * Fw]
+                slots = slots.view(_ffi.BN_SLOTS, 2, Fw)
+                ext.append((ops.bn_out_register(h, z, aff_of[id(st)], slots), slots))
+            ctx.bn_ext = ext
         if bns:
             ops.state_changed()      # bn_finalize wrote the running statistics (and the batch counters) through raw pointers
         ctx.plan = plan
@@ -509,6 +527,14 @@ class _DenseTrain(torch.autograd.Function):
                     drop_of[id(plan.cb[i])] = (rec, dH[i])
                 else:                                             # no reduce launch (an identity norm): a launch of its own
                     dH[i] = dH_in[i] = ops.dropout_apply(dH[i], rec)
+            # (round 6) a dy that IS the dx the next layer's blocked backward returned comes with its column sums in the slots this
+            # stage's forward registered (ops.bn_out_register): no reduce launch for it
+            if live_bwd and getattr(ctx, 'bn_ext', None):
+                for i, e in enumerate(ctx.bn_ext):
+                    if e is not None and dH_in[i].numel() and ops.bn_sums_ready(dH_in[i], e[0]):
+                        bslot_of[id(plan.cb[i])] = e[1]
+                        filled.add(id(plan.cb[i]))
+                        ops.BN_BWD_FUSED[0] += 1
             pend3 = norm_backward([(plan.cb[i], dH_in[i], Z3[i]) for i in range(nd)], lazy=True)
             lazy3 = bool(pend3) and isinstance(pend3[0], tuple)
             dZ3 = [p[0] for p in pend3] if lazy3 else pend3

@@ -1724,7 +1724,8 @@ def _blocked_backward_impl(ctx, gs, ys, g_tensors, g_needs, s_tensors, s_needs):
     for gi, (d, which) in enumerate(ydims):
         ys_of[d][0 if which == 'y1' else 1] = ys[gi]
     res = layer_backward(dims, table, [tuple(p) for p in ys_of], [(gs[k_out * d], gs[k_out * d + k_out - 1]) for d in range(n)], wt_of,
-                         bwd_table=bwd_table if BLOCKED_BACKWARD == 2 else None)
+                         bwd_table=bwd_table if BLOCKED_BACKWARD == 2 else None,
+                         fuse_bn=k_out == 2)       # (a CIN++ layer adds its third output's piece onto dx AFTER the launch)
     if res is None:
         return None
     dxs, gys = res
@@ -2386,6 +2387,7 @@ class step_arena:
                                                  (a.high + 15) // 16 * 16, _ffi.ptr(self.counter), _ffi.ptr(self.active),
                                                  _ffi.ptr(ds), _ffi.stream_ptr(self.device)), 'cwn_step_begin')
         a.used, a.active = 0, True
+        bn_registry_clear()                      # (entries name tensors of the previous step)
         return self
 
     def __exit__(self, *exc):
@@ -2590,6 +2592,44 @@ def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tens
     return outs
 
 
+# ---- the reduce half of a conv layer's OUTPUT BatchNorm, taken over by the blocked backward of the NEXT layer (round 6) ----------
+# The combine network of a SparseCINConv ends in Linear -> BatchNorm -> ReLU (mp/layers.py:322-325) and its output H is the next
+# conv layer's input x.  Autograd hands the next layer's dx to this layer's backward as dy, and the BatchNorm backward begins with
+# two column sums over dy (d beta, d gamma) -- a launch of its own, cwn_norm_bwd_reduce_f32, 5.9 us x 4 per ZINC step, because
+# the producer of dy was a launch "on the other side of autograd".  It need not be: dense_train's forward REGISTERS H here
+# (pre-normalisation z, the stage's constants, a zeroed slot buffer, a token); the blocked backward of the layer that reads H as
+# its x looks its inputs up, lets cwn_layer_bwd_own_f32 add the sums of the dx rows every workgroup owns into the slots
+# (cwn_layer_bwd_dim.out_bn) and MARKS the dx tensor it returns with the token; dense_train's backward, handed exactly that
+# tensor as dy (same address: autograd adds nothing when H has one consumer), takes the slot sums and launches no reduce.
+# Anything else -- another consumer, a copy, a stale entry -- misses and runs the reduce as before.
+BN_BWD_FUSE = os.environ.get('CWN_BN_BWD_FUSE', '1') != '0'
+BN_BWD_FUSED = [0]                         # reduce launches taken over so far (tests: the path that ran)
+_bn_out: Dict[int, tuple] = {}             # H.data_ptr() -> (token, z, aff, slots, shape of H)
+_bn_sums: Dict[int, object] = {}           # dx.data_ptr() -> token
+
+
+def bn_registry_clear() -> None:
+    _bn_out.clear()
+    _bn_sums.clear()
+
+
+def bn_out_register(h: Tensor, z: Tensor, aff: Tensor, slots: Tensor) -> object:
+    if len(_bn_out) > 256 or len(_bn_sums) > 256:       # (steps outside a step_arena bracket: nothing clears them)
+        bn_registry_clear()
+    token = object()
+    _bn_out[h.data_ptr()] = (token, z, aff, slots, tuple(h.shape))
+    return token
+
+
+def bn_out_lookup(x: Tensor) -> Optional[tuple]:
+    e = _bn_out.get(x.data_ptr()) if (BN_BWD_FUSE and x is not None) else None
+    return e if (e is not None and e[4] == tuple(x.shape) and x.is_contiguous()) else None
+
+
+def bn_sums_ready(dy: Tensor, token) -> bool:
+    return token is not None and _bn_sums.get(dy.data_ptr()) is token
+
+
 # The backward of the propagate step as ONE launch.  Two forms:
 #   2 (default) the OWNER form (cwn_layer_bwd_own_f32, csrc/cwn_layer_bwd_own.hip) over a table of its own
 #     (blockplan.BlockPlan.bwd_items): an item owns the rows of one dimension for a range of complexes and gathers
@@ -2604,7 +2644,7 @@ BLOCKED_BACKWARD = int(os.environ.get('CWN_BLOCKED_BACKWARD', '2') or 0)
 BLOCKED_BACKWARD_LAUNCHES = [0, 0]         # launches of the atomic / owner form so far (tests: the path that ran)
 
 
-def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of, bwd_table=None) -> Optional[Tuple[List[Tensor], List]]:
+def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of, bwd_table=None, fuse_bn: bool = False) -> Optional[Tuple[List[Tensor], List]]:
     """cwn_layer_bwd_f32: the backward of one propagate step over the item table of its forward launch.  dims: the
     LayerDim list of the forward; ys_of[d] = (Y1_d or None, Y2 stored at dimension d or None); gs_of[d] = (dL/d out_up_d,
     dL/d out_b_d), None = zero; wt_of[d] = transposed packed weight or None.  Returns ([dx_d], [(gY1_d, gY2 at d)]) or
@@ -2647,9 +2687,24 @@ def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of, bwd_tab
                                   n_cells=rows[d], e_up=e_up, n_b=n_b)
     from .csr import _err_flag
     if own:
+        # x_d registered as the output of a BatchNorm stage (bn_out_register): this launch takes the reduce of its backward
+        marks = []
+        if fuse_bn and F in (64, 128):
+            for d, D in enumerate(dims):
+                e = bn_out_lookup(D.x)
+                if e is None or rows[d] == 0:
+                    continue
+                token, z, aff, slots, _ = e
+                if (z.shape != D.x.shape or z.stride(1) != 1 or z.stride(0) % 4 or z.data_ptr() % 16 or aff.data_ptr() % 16
+                        or aff.numel() != 4 * F or slots.numel() != _ffi.BN_SLOTS * 2 * F):
+                    continue
+                arr[d].out_bn = _ffi.BnBwdLive(z=z.data_ptr(), aff=aff.data_ptr(), slots=slots.data_ptr(), ldz=z.stride(0))
+                marks.append((d, token))
         _ffi.check(L.cwn_layer_bwd_own_f32(arr, n, F, bwd_table.c_plan(), _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)),
                    'cwn_layer_bwd_own_f32')
         BLOCKED_BACKWARD_LAUNCHES[1] += 1
+        for d, token in marks:
+            _bn_sums[dxs[d].data_ptr()] = token
         return dxs, gys
     plan = table.c_plan(with_cache=False)
     _ffi.check(L.cwn_layer_bwd_f32(arr, n, F, plan, _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)), 'cwn_layer_bwd_f32')

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import _ffi, csr
-from .blockplan import BwdItemTable, ITEM_INTS, ItemTable, LDS_BYTES, gemm_rows_cap, lds_bytes
+from .blockplan import BWD_LDS_BYTES, BwdItemTable, ITEM_INTS, ItemTable, LDS_BYTES, gemm_rows_cap, lds_bytes
 from .complex import CochainBatch, ComplexBatch
 from .packed import _CSR_KEYS, PackedComplexes
 
@@ -530,7 +530,7 @@ class StaticBatch:
             store = torch.zeros(S, n_items, _ffi.LAYER_BWD_ITEM_INTS, dtype=torch.int32, device=dev)
             fam = []
             for j in range(S):
-                t = BwdItemTable(np.zeros((0, _ffi.LAYER_BWD_ITEM_INTS), dtype=np.int32), LDS_BYTES, list(self.cap_cells), cap_up,
+                t = BwdItemTable(np.zeros((0, _ffi.LAYER_BWD_ITEM_INTS), dtype=np.int32), BWD_LDS_BYTES, list(self.cap_cells), cap_up,
                                  cap_b, None)
                 t.items, t.n_items, t.device = store[j], n_items, dev
                 fam.append(t)

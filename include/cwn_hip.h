@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 22
+#define CWN_ABI_VERSION 23
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -382,6 +382,16 @@ int cwn_layer_fused_f32(const cwn_layer_dim* dims_host, int n_dims, int32_t F, c
  * An index that leaves its item sets bit 3 of *err_flag.  cwn_layer_bwd_lds_bytes: the launch's LDS for a table whose
  * largest item stages max_gemm_rows rows, 0 = beyond a CU (CWN_ERR_TOO_LARGE from the launch: the caller keeps the
  * streaming backward). */
+/* The REDUCE half of a BatchNorm backward taken over by the launch that PRODUCES the stage's dy (cwn_dense_stage_bwd_f32's
+ * out_bn / out_bn2 below; cwn_layer_bwd_own_f32's out_bn, round 6): the launch adds, from its epilogue, the column sums of
+ * dyh = dx * [z * scale + shift > 0] and of dyh * xhat (xhat = (z - mean) * rstd) over its rows into slot row
+ * (workgroup number mod CWN_BN_SLOTS) with fp32 atomics; the consumer sums the slots in its prologue (s_slots). */
+typedef struct cwn_bn_bwd_live {
+    const float* z;          /* [M, F] (row stride ldz) pre-normalisation values of the stage that receives dx as its dy */
+    const float* aff;        /* [4][F]: scale, shift, mean, rstd of its BatchNorm (cwn_bn_live.aff) */
+    float* slots;            /* [CWN_BN_SLOTS][2][F]; NULL: unused */
+    int64_t ldz;
+} cwn_bn_bwd_live;
 typedef struct cwn_layer_bwd_dim {
     const float* g_up;
     const float* g_b;
@@ -397,6 +407,11 @@ typedef struct cwn_layer_bwd_dim {
     float* gy1;
     float* gy2;
     int64_t n_cells, e_up, n_b;
+    /* (ABI 23; cwn_layer_bwd_own_f32 only, all-zero = unused) x_d is the OUTPUT of a Linear -> BatchNorm -> ReLU stage -- the
+     * combine network of the previous conv layer, mp/layers.py:322-325 -- whose backward begins with the column sums of
+     * dx_d * mask and dx_d * mask * xhat: every workgroup adds the sums of the rows of dx_d it owns into out_bn.slots (z, aff
+     * of that stage), and the previous layer's backward launches no reduce (cwn_norm_bwd_reduce_f32: 5.9 us, four per ZINC step). */
+    cwn_bn_bwd_live out_bn;
 } cwn_layer_bwd_dim;
 size_t cwn_layer_bwd_lds_bytes(int32_t F, int32_t max_gemm_rows);
 int cwn_layer_bwd_f32(const cwn_layer_bwd_dim* dims_host, int n_dims, int32_t F, const cwn_layer_plan* plan_host,
@@ -701,12 +716,6 @@ int cwn_update_mlp_pack_weights_t_many_f32(const float* const* W, const int64_t*
  * instead of two): out[e] as cwn_update_mlp_pack_weights_many_f32, out_t[e] as cwn_update_mlp_pack_weights_t_many_f32. */
 int cwn_update_mlp_pack_weights_both_many_f32(const float* const* W, const int64_t* ldw, int32_t F, void* const* out,
                                               void* const* out_t, int32_t n, cwn_stream_t stream);
-typedef struct cwn_bn_bwd_live {
-    const float* z;          /* [M, F] (row stride ldz) pre-normalisation values of the stage that receives dx as its dy */
-    const float* aff;        /* [4][F]: scale, shift, mean, rstd of its BatchNorm (cwn_bn_live.aff) */
-    float* slots;            /* [CWN_BN_SLOTS][2][F]; NULL: unused */
-    int64_t ldz;
-} cwn_bn_bwd_live;
 typedef struct cwn_stage_bwd_desc {
     const float* dy;         /* [M, F] */
     const float* z;          /* [M, F] */
