@@ -46,8 +46,8 @@ def fuzz_csr():
     kt, vt, at = (torch.from_numpy(a).to(dev) for a in (key, val, aux))
     adj = csr.Adjacency(kt, vt, cap_n, cap_n, at, max(1, cap_n // 2))
     e_dev = torch.tensor([E], dtype=torch.int64, device=dev)
-    with _ffi.dynamic_rows({cap_E: e_dev.data_ptr()}):
-        csr.build_many([adj], validate=False)
+    adj.e_dev_ptr = e_dev.data_ptr()        # (round 6, ADVICE r5: the live entry count is an explicit tag of the adjacency, as a
+    csr.build_many([adj], validate=False)   #  static batch sets it -- no longer looked up through the capacity)
     ref = csr.Adjacency(kt[:E].contiguous(), vt[:E].contiguous(), n, n, at[:E].contiguous(), max(1, n // 2))
     csr.build_many([ref], validate=False)
     torch.cuda.synchronize()

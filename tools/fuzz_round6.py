@@ -1,0 +1,66 @@
+"""Randomised check of what round 6 added to the training step: the reduce half of a conv layer's output BatchNorm backward taken
+over by the next layer's blocked backward launch (cwn_layer_bwd_dim.out_bn; ops.bn_out_register) -- the same step with the
+take-over on and off over random widths, depths, batch sizes and molecule sizes (tiny molecules: the kernel's second way through
+LDS; molecules beyond a workgroup: the streaming backward, nothing taken over), eager and captured.
+
+usage: python tools/fuzz_round6.py [rounds] [seed]      (prints one line per failure, exits non-zero if any)"""
+import copy
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from cwn_amd import ops
+from cwn_amd.complex import ComplexBatch
+from cwn_amd.models import EmbedSparseCIN
+from cwn_amd.synthetic import zinc_like_complexes
+from cwn_amd.train import TrainStep
+
+dev = torch.device('cuda', 0)
+ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+fails = 0
+taken_total = 0
+for r in range(ROUNDS):
+    hidden = int(rng.choice([64, 128]))
+    layers = int(rng.integers(2, 5))
+    B = int(rng.integers(1, 200))
+    n_lo = int(rng.integers(3, 30))
+    n_hi = n_lo + int(rng.integers(0, 40 if hidden == 64 else 18))
+    graph = bool(rng.random() < 0.4)
+    torch.manual_seed(int(rng.integers(1 << 30)))
+    model = EmbedSparseCIN(28, 4, 1, layers, hidden, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(dev).train()
+    b = ComplexBatch.from_complex_list(zinc_like_complexes(B, int(rng.integers(1 << 30)), 6, n_lo=n_lo, n_hi=n_hi), max_dim=2).to(dev)
+    b.y = torch.randn(b.num_complexes, 1, device=dev)
+    grads, taken = [], []
+    for fuse in (False, True):
+        m = copy.deepcopy(model)
+        keep, ops.BN_BWD_FUSE = ops.BN_BWD_FUSE, fuse
+        try:
+            n0 = ops.BN_BWD_FUSED[0]
+            ts = TrainStep(m, [b], task_type='regression', use_graph=graph, lr=0.0)
+            for _ in range(3 if graph else 1):
+                ts.step(0)
+            torch.cuda.synchronize()
+            taken.append(ops.BN_BWD_FUSED[0] - n0)
+        finally:
+            ops.BN_BWD_FUSE = keep
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    worst, where = 0.0, ''
+    for n in grads[0]:
+        ref = grads[0][n]
+        e = float((grads[1][n] - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        if not np.isfinite(e):
+            e = float('inf')
+        if e > worst:
+            worst, where = e, n
+    ok = worst <= 5e-5 and taken[0] == 0
+    taken_total += taken[1]
+    if not ok:
+        fails += 1
+    print(f'{"ok  " if ok else "FAIL"} hidden {hidden} x {layers}, batch {B}, atoms {n_lo}-{n_hi}, {"graph" if graph else "eager"}: '
+          f'taken over {taken[1]}, max difference {worst:.2e} {where if not ok else ""}', flush=True)
+print(f'{ROUNDS} rounds, {fails} failures, {taken_total} reduce stages taken over')
+sys.exit(1 if fails else 0)
