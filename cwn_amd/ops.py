@@ -2614,7 +2614,9 @@ def bn_registry_clear() -> None:
 
 
 def bn_out_register(h: Tensor, z: Tensor, aff: Tensor, slots: Tensor) -> object:
-    if len(_bn_out) > 256 or len(_bn_sums) > 256:       # (steps outside a step_arena bracket: nothing clears them)
+    # (steps outside a step_arena bracket: nothing clears the registry, and an entry keeps its z / constants / slots alive -- a
+    #  few forwards' worth at most: an entry older than that names tensors whose backward has long run or never will)
+    if len(_bn_out) >= 32 or len(_bn_sums) >= 32:
         bn_registry_clear()
     token = object()
     _bn_out[h.data_ptr()] = (token, z, aff, slots, tuple(h.shape))
