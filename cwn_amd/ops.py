@@ -2604,8 +2604,8 @@ def layer_fused(dims: Sequence[LayerDim], table, csr_mode: int = 0) -> List[Tens
 # Anything else -- another consumer, a copy, a stale entry -- misses and runs the reduce as before.
 BN_BWD_FUSE = os.environ.get('CWN_BN_BWD_FUSE', '1') != '0'
 BN_BWD_FUSED = [0]                         # reduce launches taken over so far (tests: the path that ran)
-_bn_out: Dict[int, tuple] = {}             # H.data_ptr() -> (token, z, aff, slots, shape of H)
-_bn_sums: Dict[int, object] = {}           # dx.data_ptr() -> token
+_bn_out: Dict[tuple, tuple] = {}           # (device, H.data_ptr()) -> (token, z, aff, slots, shape of H)
+_bn_sums: Dict[tuple, object] = {}         # (device, dx.data_ptr()) -> token
 
 
 def bn_registry_clear() -> None:
@@ -2619,17 +2619,17 @@ def bn_out_register(h: Tensor, z: Tensor, aff: Tensor, slots: Tensor) -> object:
     if len(_bn_out) >= 32 or len(_bn_sums) >= 32:
         bn_registry_clear()
     token = object()
-    _bn_out[h.data_ptr()] = (token, z, aff, slots, tuple(h.shape))
+    _bn_out[(h.device.index, h.data_ptr())] = (token, z, aff, slots, tuple(h.shape))
     return token
 
 
 def bn_out_lookup(x: Tensor) -> Optional[tuple]:
-    e = _bn_out.get(x.data_ptr()) if (BN_BWD_FUSE and x is not None) else None
+    e = _bn_out.get((x.device.index, x.data_ptr())) if (BN_BWD_FUSE and x is not None) else None
     return e if (e is not None and e[4] == tuple(x.shape) and x.is_contiguous()) else None
 
 
 def bn_sums_ready(dy: Tensor, token) -> bool:
-    return token is not None and _bn_sums.get(dy.data_ptr()) is token
+    return token is not None and _bn_sums.get((dy.device.index, dy.data_ptr())) is token
 
 
 # The backward of the propagate step as ONE launch.  Two forms:
@@ -2706,7 +2706,7 @@ def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of, bwd_tab
                    'cwn_layer_bwd_own_f32')
         BLOCKED_BACKWARD_LAUNCHES[1] += 1
         for d, token in marks:
-            _bn_sums[dxs[d].data_ptr()] = token
+            _bn_sums[(dxs[d].device.index, dxs[d].data_ptr())] = token
         return dxs, gys
     plan = table.c_plan(with_cache=False)
     _ffi.check(L.cwn_layer_bwd_f32(arr, n, F, plan, _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)), 'cwn_layer_bwd_f32')
