@@ -535,6 +535,7 @@ class _DenseTrain(torch.autograd.Function):
                         bslot_of[id(plan.cb[i])] = e[1]
                         filled.add(id(plan.cb[i]))
                         ops.BN_BWD_FUSED[0] += 1
+                        ctx.bn_ext[i] = None            # (one shot: a second backward over this forward reduces by itself)
             pend3 = norm_backward([(plan.cb[i], dH_in[i], Z3[i]) for i in range(nd)], lazy=True)
             lazy3 = bool(pend3) and isinstance(pend3[0], tuple)
             dZ3 = [p[0] for p in pend3] if lazy3 else pend3

@@ -2707,6 +2707,9 @@ def layer_backward(dims: Sequence[LayerDim], table, ys_of, gs_of, wt_of, bwd_tab
         BLOCKED_BACKWARD_LAUNCHES[1] += 1
         for d, token in marks:
             _bn_sums[(dxs[d].device.index, dxs[d].data_ptr())] = token
+            # one shot: the slots now hold this backward's sums -- a SECOND backward over the same forward (retain_graph) finds no
+            # entry, adds nothing onto them, marks nothing, and the stage's own reduce launch runs
+            _bn_out.pop((dims[d].x.device.index, dims[d].x.data_ptr()), None)
         return dxs, gys
     plan = table.c_plan(with_cache=False)
     _ffi.check(L.cwn_layer_bwd_f32(arr, n, F, plan, _err_flag(dev).data_ptr(), _ffi.stream_ptr(dev)), 'cwn_layer_bwd_f32')

@@ -124,3 +124,31 @@ def test_not_taken_over_with_an_output_dropout_or_a_second_consumer():
     for n in outs[0]:
         err = float((outs[0][n] - outs[1][n]).abs().max()) / max(1.0, float(outs[0][n].abs().max()))
         assert err <= 2e-5, (n, err)
+
+
+def test_a_second_backward_over_the_same_forward_reduces_by_itself():
+    """retain_graph: the slots hold the FIRST backward's sums -- the take-over is one shot, the second backward launches its own
+    reduce and gives the same gradients."""
+    from cwn_amd import ops
+    from cwn_amd.complex import ComplexBatch
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.synthetic import zinc_like_complexes
+    torch.manual_seed(6)
+    model = EmbedSparseCIN(28, 4, 1, 3, 64, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV).train()
+    b = ComplexBatch.from_complex_list(zinc_like_complexes(40, 11, 6), max_dim=2).to(DEV)
+    ops.bn_registry_clear()
+    loss = model(b).square().mean()
+    n0 = ops.BN_BWD_FUSED[0]
+    loss.backward(retain_graph=True)
+    first = ops.BN_BWD_FUSED[0] - n0
+    g1 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    second = ops.BN_BWD_FUSED[0] - n0 - first
+    torch.cuda.synchronize()
+    assert first == 6 and second == 0, (first, second)
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        err = float((p.grad - g1[n]).abs().max()) / max(1.0, float(g1[n].abs().max()))
+        assert err <= 2e-5, (n, err)
