@@ -353,6 +353,7 @@ extern "C" int cwn_layer_bwd_f32(const cwn_layer_bwd_dim* dims, int n_dims, int3
         const cwn_layer_bwd_dim& D = dims[d];
         if (D.n_cells < 0 || D.e_up < 0 || D.n_b < 0) return CWN_ERR_BAD_ARG;
         if (D.n_cells > 0 && D.dx == nullptr) return CWN_ERR_BAD_ARG;
+        if (D.out_bn.slots != nullptr) return CWN_ERR_BAD_ARG;       // (the BatchNorm sums are the owner form's: a dx row has one writer there)
         if (D.e_up > 0 && (D.up_index == nullptr || D.up_shared == nullptr || D.wt_packed == nullptr || D.y1 == nullptr ||
                            d + 1 >= n_dims || dims[d + 1].y2 == nullptr))
             return CWN_ERR_BAD_ARG;
