@@ -432,8 +432,12 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
                 same = all(bool(torch.allclose(outs[k], model(packed.collate(bs[k])), rtol=0, atol=1e-5 * max(1.0, float(outs[k].abs().max()))))
                            for k in (list(a_[:2]) + list(b_[:2])))
                 cps, ms = timed_epochs(rf.run_epoch)
+            n_pool = int(sum(int((~rf.mask[np.asarray(ix)]).sum()) for ix in bs)) if rf.fbig is not None else 0
             return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'equal_to_per_batch_launches_1e-5': same,
-                    'batches_on_the_blocked_path': len(a_), 'batches_on_the_streaming_path': len(b_),
+                    'batches_without_a_complex_beyond_a_workgroup': len(a_), 'batches_with_one': len(b_),
+                    # (round 6, RoutedForward(regroup=True): those batches keep the blocked path for the complexes that fit; the
+                    #  others are pooled over the epoch into a csr-mode static batch of their own)
+                    'regrouped': rf.fbig is not None, 'complexes_pooled_per_epoch': n_pool,
                     'vs_fixed_batch_replay': round(fixed_forward_ms / ms, 4) if fixed_forward_ms else None}
 
         def leg_train_routed():

@@ -562,6 +562,11 @@ class StaticBatch:
         col = lambda d, key: (meta[:, 3 * D + self.k_of(d, key)] if self.k_of(d, key) >= 0 else None)
         up_len = [col(d, 'upper_index') for d in range(D)]
         b_len = [col(d, 'boundary_index') for d in range(D)]
+        # (cached per set of tables cut so far: a router asks once per epoch and batch list)
+        stamp = tuple(sorted((repr(k), fam is not None, self.variant) for k, fam in self._families.items()))
+        hit = getattr(self, '_fit_mask_cache', None)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
         ok = np.ones(meta.shape[0], dtype=bool)
         for key, fam in self._families.items():
             if fam is None:
@@ -571,6 +576,7 @@ class StaticBatch:
                 ok &= single_fit_forward(cells, up_len, b_len, F, hu, hb, self.variant, fam[0].max_rows, fam[0].max_src)
             else:
                 ok &= single_fit_backward(cells, up_len, b_len, F, hu, hb)
+        self._fit_mask_cache = (stamp, ok)
         return ok
 
     # ---- which batches fit ------------------------------------------------------------------------------------------
@@ -578,21 +584,29 @@ class StaticBatch:
         """bool per batch (index arrays): every array of the batch within its capacity, every complex within what one
         workgroup of the item tables cut so far holds, and at least two cells of every dimension the dataset has
         (BatchNorm in training mode needs them; the reference raises below two)."""
+        cap_ok, single_ok = self.fits_detail(batches)
+        return cap_ok & single_ok
+
+    def fits_detail(self, batches: Sequence[np.ndarray]):
+        """(capacities + the two-cell rule hold, every complex fits one workgroup): the two halves of `fits`, bool per batch --
+        a router that may take the complexes beyond a workgroup OUT of a batch (static_graph.RoutedForward) asks which half failed."""
         meta, D, K = self.packed._meta, self.D, self.K
-        ok = np.ones(len(batches), dtype=bool)
+        cap_ok = np.ones(len(batches), dtype=bool)
+        single_ok = np.ones(len(batches), dtype=bool)
         caps_cells = np.asarray(self.cap_cells, dtype=np.int64)
         caps_keys = np.asarray(self._caps, dtype=np.int64)
         single = self.fit_mask()
         for i, idx in enumerate(batches):
             idx = np.asarray(idx, dtype=np.int64)
             if idx.size == 0 or idx.size > self.B:
-                ok[i] = False
+                cap_ok[i] = False
                 continue
             m = meta[idx]
             cells = m[:, 0:3 * D:3].sum(axis=0)
             lens = m[:, 3 * D:3 * D + K].sum(axis=0)
-            ok[i] = bool((cells <= caps_cells).all() and (lens <= caps_keys).all() and (cells >= 2).all() and single[idx].all())
-        return ok
+            cap_ok[i] = bool((cells <= caps_cells).all() and (lens <= caps_keys).all() and (cells >= 2).all())
+            single_ok[i] = bool(single[idx].all())
+        return cap_ok, single_ok
 
     # ---- filling ------------------------------------------------------------------------------------------------------
     def _host_perm(self, batches: Sequence[np.ndarray], n: int) -> np.ndarray:

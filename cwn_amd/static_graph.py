@@ -397,17 +397,127 @@ class StaticRouter:
 
 class RoutedForward:
     """model(batch) in eval mode for every batch of an epoch through a StaticRouter: run_epoch(batches) -> predictions in the
-    order of `batches`."""
+    order of `batches`.
 
-    def __init__(self, model: torch.nn.Module, router: StaticRouter):
+    regroup (default; round 6): in eval mode a complex's prediction does not depend on the batch it sits in (BatchNorm uses its
+    running statistics, every kernel of the path works complex by complex or row by row) -- so ONE molecule beyond a workgroup
+    need not send the 511 others of its batch to the streaming path.  The batch keeps the blocked path for the complexes that
+    fit; the ones that do not are pooled over the whole epoch into a few small batches of a csr-mode static batch of their own
+    (capacities from THEIR sizes), and the predictions are put back in place.  ogbg-molhiv-like sizes at batch 512: a third of
+    the batches hold such a molecule; 21 whole batches on the streaming path became one or two pooled ones.  Within the
+    gate of what the per-batch launches give (the two paths share the layer kernel's arithmetic bit for bit, not the update
+    networks').  Batches that exceed the blocked buffers' CAPACITIES go to the streaming path whole, as before."""
+
+    def __init__(self, model: torch.nn.Module, router: StaticRouter, regroup: bool = True, pool_batch: int = 32):
         self.router = router
         self.fa, self.fb = StaticForward(model, router.blocked), StaticForward(model, router.csr)
         # capture now, over the EMPTY batches the buffers hold: the item tables the model asks for are cut, and
         # StaticBatch.fits() -- the router's test -- knows what one workgroup holds for this model
         self.fa.replay()
         self.fb.replay()
+        self.mask = router.blocked.fit_mask()
+        self.fbig = None
+        big = np.nonzero(~self.mask)[0]
+        if regroup and big.size:
+            packed = router.blocked.packed
+            self.big = StaticBatch(packed, int(min(pool_batch, max(1, big.size))), slots=1, mode='csr', indices=big)
+            self.fbig = StaticForward(model, self.big)
+            self.fbig.replay()
+
+    def _pool(self, pos: np.ndarray, ids: Optional[np.ndarray] = None) -> List[np.ndarray]:
+        """Contiguous ranges of the pooled list, in order, each a batch the pool's buffers hold (its capacities are a statistical
+        bound over the complexes that do not fit a workgroup: a range beyond them is halved)."""
+        ids = self._pool_ids if ids is None else ids
+        todo, out = [pos[k: k + self.big.B] for k in range(0, pos.size, self.big.B)][::-1], []
+        while todo:
+            c = todo.pop()
+            if c.size == 0:
+                continue
+            if c.size == 1 or bool(self.big.fits([ids[c]])[0]):
+                out.append(c)
+            else:
+                todo += [c[c.size // 2:], c[: c.size // 2]]          # (popped first half first: the order of the list stays)
+        return out
 
     def run_epoch(self, batches: Sequence[np.ndarray]) -> List[torch.Tensor]:
+        batches = [np.asarray(b, dtype=np.int64) for b in batches]
+        if self.fbig is None:
+            return self._run_whole(batches)
+        sb = self.router.blocked
+        cap_ok, single_ok = sb.fits_detail(batches)
+        # per unit of work (batch, positions, complexes): a whole batch on the blocked path, the fitting part of a batch there
+        # (a part of a batch within the capacities is within them too), a whole batch on the streaming path; the complexes of
+        # the split batches that do not fit: pooled
+        a_units, b_units, pooled = [], [], []
+        for i, idx in enumerate(batches):
+            if cap_ok[i] and single_ok[i]:
+                a_units.append((i, None, idx))
+                continue
+            m = self.mask[idx]
+            if not cap_ok[i] or int(m.sum()) < 2:
+                b_units.append((i, None, idx))                       # capacity, not the size of a complex (or nothing left)
+            else:
+                a_units.append((i, np.nonzero(m)[0], idx[m]))
+                pooled.append((i, np.nonzero(~m)[0], idx[~m]))
+        # every position list of the epoch in ONE upload, before the first replay (an upload per batch would put a host
+        # synchronisation between the replays)
+        dev = sb.device
+        pos_host = [u[1] for u in a_units if u[1] is not None]
+        owner = np.concatenate([np.full(q[2].size, q[0], dtype=np.int64) for q in pooled]) if pooled else np.zeros(0, np.int64)
+        where = np.concatenate([q[1] for q in pooled]) if pooled else np.zeros(0, np.int64)
+        flat = np.concatenate(pos_host + [where]) if (pos_host or pooled) else np.zeros(0, np.int64)
+        flat_dev = torch.as_tensor(flat, device=dev) if flat.size else None      # (with the permutations: in front of the replays)
+        offs, o = {}, 0
+        for u in a_units:
+            if u[1] is not None:
+                offs[u[0]] = (o, o + u[1].size)
+                o += u[1].size
+        where_dev = flat_dev[o:] if pooled else None
+        out: List[Optional[torch.Tensor]] = [None] * len(batches)
+
+        def blank(i, rows):
+            if out[i] is None:
+                out[i] = torch.empty((len(batches[i]),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+            return out[i]
+
+        # every upload of the epoch (the three permutations) before the first replay: an upload between replays waits for them
+        plan = []
+        for units, sf, static in ((a_units, self.fa, sb), (b_units, self.fb, self.router.csr)):
+            if units:
+                plan.append((units, sf, static, static.set_epoch([u[2] for u in units])))
+        chunks, n_big = [], 0
+        if pooled:
+            ids = np.concatenate([q[2] for q in pooled])
+            chunks = self._pool(np.arange(ids.size), ids)            # (contiguous ranges of the pooled list)
+            n_big = self.big.set_epoch([ids[c] for c in chunks])
+        for units, sf, static, n_rep in plan:
+            S = static.S
+            for r in range(n_rep):
+                outs = sf.replay()
+                for j in range(S):
+                    k = r * S + j
+                    if k < len(units):
+                        i, pos, idx = units[k]
+                        rows = outs[j][:len(idx)]
+                        if pos is None:
+                            out[i] = rows.clone()
+                        else:
+                            lo, hi = offs[i]
+                            blank(i, rows).index_copy_(0, flat_dev[lo:hi], rows)
+        for r in range(n_big):
+            rows = self.fbig.replay()[0]
+            c0, c1 = int(chunks[r][0]), int(chunks[r][-1]) + 1
+            # (the pooled list is ordered by batch: one indexed copy per batch the chunk touches)
+            s_ = c0
+            while s_ < c1:
+                e_ = s_
+                while e_ < c1 and owner[e_] == owner[s_]:
+                    e_ += 1
+                blank(int(owner[s_]), rows).index_copy_(0, where_dev[s_:e_], rows[s_ - c0: e_ - c0])
+                s_ = e_
+        return out
+
+    def _run_whole(self, batches: Sequence[np.ndarray]) -> List[torch.Tensor]:
         a, b, na, nb = self.router.set_epoch(batches)
         out: List[Optional[torch.Tensor]] = [None] * len(batches)
         S = self.router.S

@@ -293,3 +293,43 @@ def test_the_config_3_and_config_5_example_scripts_run(script, args, must):
     for m in must:
         assert m in pr.stdout, pr.stdout[-2000:]
     print(pr.stdout[-800:])
+
+
+def test_routed_forward_regroups_the_complexes_beyond_a_workgroup():
+    """Round 6: in eval mode ONE molecule beyond a workgroup no longer sends its whole batch to the streaming path -- the batch
+    keeps the blocked path for the complexes that fit, the others are pooled over the epoch into a small csr-mode static batch,
+    the predictions are put back in place: equal to the whole-batch routing and to model(collate) within the gate, and independent
+    of the order of the epoch bit for bit."""
+    from cwn_amd.models import OGBEmbedSparseCIN
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_graph import RoutedForward, StaticRouter
+    from cwn_amd.synthetic import molhiv_like_complexes
+    pool = molhiv_like_complexes(300, seed=7, max_ring=6, tail=0.02)
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+    B, S = 32, 2
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(pool))
+    epoch = [perm[k * B:(k + 1) * B] for k in range(9)] + [perm[288:300]]      # (a ragged last batch)
+    torch.manual_seed(4)
+    model = OGBEmbedSparseCIN(1, 2, 64, dropout_rate=0.0, max_dim=2, readout='mean', final_readout='sum', init_reduce='sum',
+                              embed_edge=True, use_coboundaries=True, graph_norm='bn').to(DEV).eval()
+    whole = RoutedForward(model, StaticRouter(p, B, slots=S), regroup=False)
+    re = RoutedForward(model, StaticRouter(p, B, slots=S), regroup=True, pool_batch=4)
+    assert re.fbig is not None and 2 <= int((~re.mask).sum()) <= 20
+    with torch.no_grad():
+        a = whole.run_epoch(epoch)
+        b = re.run_epoch(epoch)
+        b2 = re.run_epoch(epoch[::-1])[::-1]                 # (another order of the epoch: the same predictions)
+        for k, idx in enumerate(epoch):
+            assert a[k].shape == b[k].shape == (len(idx), 1)
+            # (a batch that used to take the streaming path whole now takes the blocked path for most of its complexes: the two
+            #  paths share the layer kernel's arithmetic, not the update networks' -- equal within the gate, not bit for bit)
+            assert float((a[k] - b[k]).abs().max()) <= 1e-5 * max(1.0, float(a[k].abs().max())), k
+            assert torch.equal(b[k], b2[k]), k               # a complex's prediction does not depend on its batch mates
+            want = model(p.collate(idx))
+            err = float((b[k] - want).abs().max())
+            assert err <= 1e-5 * max(1.0, float(want.abs().max())), (k, err)
+    n_split = sum(1 for idx in epoch if not re.mask[idx].all())
+    print(f'[router] {n_split} of {len(epoch)} batches hold a complex beyond a workgroup: their other complexes stay on the blocked path, '
+          f'{int(sum((~re.mask[idx]).sum() for idx in epoch))} complexes pooled')
+    assert n_split >= 2
