@@ -370,7 +370,26 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
             outs = sf.replay()
             # the first batches of an epoch against the per-batch launches, bit for bit
             same = all(bool(torch.equal(outs[j][:len(bs[j])], model(packed.collate(bs[j])))) for j in range(min(S, 3)))
-            cps, ms = run_epochs(sf.replay)
+            # (an epoch that is not a multiple of S ends with a SHORTER replay -- StaticForward.slots_for -- instead of empty slots)
+            def run_epochs_sf():
+                def one(bs):
+                    sb.set_epoch(bs)
+                    k = 0
+                    while k < len(bs):
+                        n = sf.slots_for(len(bs) - k)
+                        sf.replay(n)
+                        k += n
+                one(epoch(1))
+                torch.cuda.synchronize()
+                t0, total = time.perf_counter(), 0.0
+                for e in range(EPOCHS):
+                    bs_ = epoch(2 + e)
+                    one(bs_)
+                    total += cells(bs_)
+                torch.cuda.synchronize()
+                dt_ = time.perf_counter() - t0
+                return total / dt_, dt_ / (EPOCHS * NB) * 1e3
+            cps, ms = run_epochs_sf()
         return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'bit_identical_to_per_batch_launches': same,
                 'vs_fixed_batch_replay': round(fixed_forward_ms / ms, 4) if fixed_forward_ms else None}
 

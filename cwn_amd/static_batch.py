@@ -24,6 +24,7 @@ cwn_amd/static_graph.py captures a forward / a training step over it once.
 from typing import Dict, List, Optional, Sequence
 
 import ctypes as C
+import os
 import numpy as np
 import torch
 
@@ -659,11 +660,43 @@ class StaticBatch:
         epoch of one replay."""
         if len(batches) > self.S or len(batches) == 0:
             raise ValueError(f'1 .. {self.S} batches')
-        self.idx[:self.S * self.B].copy_(torch.from_numpy(self._host_perm(batches, self.S).reshape(-1)))
+        self._upload(self._host_perm(batches, self.S).reshape(-1))
         self.cursor.zero_()
 
     def set_batch(self, idx: Sequence[int]) -> None:
         self.set_batches([idx])
+
+    def _upload(self, host: np.ndarray) -> None:
+        """The complex numbers of the next fills into `idx`, WITHOUT stopping the host behind the GPU (round 6).  A pageable copy
+        on the compute stream waits for everything in front of it -- the whole previous epoch -- so the host prepared epoch
+        e + 1 only after epoch e had finished (~1 ms of host work per epoch outside the GPU's shadow).  Here the host -> device
+        copy runs on a SIDE stream into one of two staging buffers (the host waits for the copy alone), and the compute stream
+        takes it over with a device -> device copy behind an event: in stream order behind the replays that still read the
+        previous numbers.  (A pinned, non-blocking copy on the compute stream was tried first: it goes through the DMA engine,
+        and the queue switch cost the short replays of the propagate scope 0.4 ms per epoch.)"""
+        n = int(host.size)
+        if os.environ.get('CWN_STATIC_BLOCKING_UPLOAD') == '1':       # (A/B: the pageable copy of rounds 4 - 5)
+            self.idx[:n].copy_(torch.from_numpy(host))
+            return
+        st = self.__dict__.get('_up')
+        if st is None or st['bufs'][0].numel() < max(n, self.idx.numel()):
+            st = self._up = {'stream': torch.cuda.Stream(device=self.device), 'k': 0, 'ev': [None, None],
+                             'bufs': [torch.empty(max(n, self.idx.numel()), dtype=torch.int64, device=self.device) for _ in range(2)]}
+        k = st['k']
+        st['k'] = k ^ 1
+        side, buf = st['stream'], st['bufs'][k]
+        with torch.cuda.stream(side):
+            if st['ev'][k] is not None:
+                side.wait_event(st['ev'][k])             # (the copy that read this buffer two uploads ago)
+            buf[:n].copy_(torch.from_numpy(host))
+            up = torch.cuda.Event()
+            up.record(side)
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(up)
+        self.idx[:n].copy_(buf[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        st['ev'][k] = ev
 
     def reserve_epoch(self, n_batches: int) -> None:
         """Size the permutation buffer for epochs of up to n_batches batches (before the first fill / capture: a captured
@@ -686,7 +719,7 @@ class StaticBatch:
         if len(batches) > self.n_batches:
             raise RuntimeError(f'set_epoch: {len(batches)} batches, the permutation buffer a captured step reads holds '
                                f'{self.n_batches}: reserve_epoch(n) before the first fill')
-        self.idx.copy_(torch.from_numpy(self._host_perm(batches, self.n_batches).reshape(-1)))
+        self._upload(self._host_perm(batches, self.n_batches).reshape(-1))
         self.cursor.zero_()
         return -(-len(batches) // self.S)
 

@@ -192,18 +192,24 @@ class StaticForward:
     def __init__(self, model: torch.nn.Module, static: StaticBatch):
         refuse_unsupported_layers(model, 'StaticForward', static)
         self.model, self.sb = model, static
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.outs: Optional[List[torch.Tensor]] = None
-        self._stamp = None
+        # one captured graph per number of slots it runs (round 6): S for the body of an epoch, a power of two below it for its
+        # tail -- an epoch of 65 batches at S = 16 used to end with one batch and FIFTEEN empty slots, each a full sequence
+        # of launches over zero rows (~0.1 ms at the molhiv sizes)
+        self._graphs = {}                 # n_slots -> (graph, outs, stamp)
+
+    # (the graph / outputs of the full replay: what round 5's callers read)
+    graph = property(lambda self: self._graphs.get(self.sb.S, (None, None, None))[0])
+    outs = property(lambda self: self._graphs.get(self.sb.S, (None, None, None))[1])
 
     def _state(self):
         return (ops.STATE_EPOCH,) + tuple(_ffi.tver(p) for p in self.model.parameters()) + \
             tuple(_ffi.tver(b) for b in self.model.buffers())
 
-    def _run(self) -> List[torch.Tensor]:
-        self.sb.fill()
+    def _run(self, n_slots: Optional[int] = None) -> List[torch.Tensor]:
+        n = self.sb.S if n_slots is None else int(n_slots)
+        self.sb.fill(n)
         outs = []
-        for slot in self.sb.slots:
+        for slot in self.sb.slots[:n]:
             slot.restore()
             with slot.dynamic():
                 outs.append(self.model(slot.batch))
@@ -215,27 +221,57 @@ class StaticForward:
         with torch.no_grad():
             return self._run()
 
-    def replay(self) -> List[torch.Tensor]:
-        """Per slot the predictions [capacity, out]; rows past a batch's complexes are not meaningful."""
+    def slots_for(self, n_batches: int) -> int:
+        """The slots the replay that serves `n_batches` remaining batches runs: S, or the power of two that holds a shorter tail."""
+        S = self.sb.S
+        if n_batches >= S:
+            return S
+        n = 1
+        while n < n_batches:
+            n <<= 1
+        return min(n, S)
+
+    def replay(self, n_slots: Optional[int] = None) -> List[torch.Tensor]:
+        """Per slot the predictions [capacity, out]; rows past a batch's complexes are not meaningful.  n_slots < S: the first
+        n_slots slots only, taking the next n_slots batches of the epoch (the tail of an epoch: slots_for)."""
         if self.model.training:
             raise RuntimeError('StaticForward: model.eval() first (training-mode layers have no static inference form)')
-        if self.graph is None or self._stamp != self._state():
+        n = self.sb.S if n_slots is None else int(n_slots)
+        if not (1 <= n <= self.sb.S):
+            raise ValueError(f'1 .. {self.sb.S} slots')
+        hit = self._graphs.get(n)
+        state = self._state()
+        if hit is None or hit[2] != state:
             with torch.no_grad():
                 cur = self.sb.cursor.clone()
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     for _ in range(2):            # warm-up outside the capture: packed weights, prepared launches, item tables
-                        self._run()
+                        self._run(n)
                         self.sb.cursor.copy_(cur)
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
-                    self.outs = self._run()
-            self._stamp = self._state()
-        self.graph.replay()
-        return self.outs
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
+                    outs = self._run(n)
+            hit = self._graphs[n] = (graph, outs, self._state())
+        hit[0].replay()
+        return hit[1]
+
+    def run_epoch(self, batches: Sequence[np.ndarray]) -> List[torch.Tensor]:
+        """Predictions of every batch of `batches` (views of the replays' outputs: valid until the next replay of the same
+        length overwrites them -- clone what must live longer; the LAST replay's are safe until the next call)."""
+        n_full = self.sb.set_epoch(batches)
+        res: List[torch.Tensor] = []
+        done = 0
+        while done < len(batches):
+            n = self.slots_for(len(batches) - done)
+            outs = self.replay(n)
+            for j in range(min(n, len(batches) - done)):
+                res.append(outs[j][:len(batches[done + j])].clone())
+            done += n
+        return res
 
     def run(self, idx: Sequence[int]) -> torch.Tensor:
         """Predictions of the complexes `idx` (one batch, slot 0; the other slots run empty batches)."""
@@ -466,7 +502,15 @@ class RoutedForward:
         owner = np.concatenate([np.full(q[2].size, q[0], dtype=np.int64) for q in pooled]) if pooled else np.zeros(0, np.int64)
         where = np.concatenate([q[1] for q in pooled]) if pooled else np.zeros(0, np.int64)
         flat = np.concatenate(pos_host + [where]) if (pos_host or pooled) else np.zeros(0, np.int64)
-        flat_dev = torch.as_tensor(flat, device=dev) if flat.size else None      # (with the permutations: in front of the replays)
+        flat_dev = None
+        if flat.size:          # (as StaticBatch._upload: the host -> device copy on a side stream, the compute stream behind its event)
+            side = self.__dict__.setdefault('_side', torch.cuda.Stream(device=dev))
+            with torch.cuda.stream(side):
+                flat_dev = torch.as_tensor(flat, device=dev)
+                up = torch.cuda.Event()
+                up.record(side)
+            torch.cuda.current_stream(dev).wait_event(up)
+            flat_dev.record_stream(torch.cuda.current_stream(dev))
         offs, o = {}, 0
         for u in a_units:
             if u[1] is not None:
@@ -491,19 +535,19 @@ class RoutedForward:
             chunks = self._pool(np.arange(ids.size), ids)            # (contiguous ranges of the pooled list)
             n_big = self.big.set_epoch([ids[c] for c in chunks])
         for units, sf, static, n_rep in plan:
-            S = static.S
-            for r in range(n_rep):
-                outs = sf.replay()
-                for j in range(S):
-                    k = r * S + j
-                    if k < len(units):
-                        i, pos, idx = units[k]
-                        rows = outs[j][:len(idx)]
-                        if pos is None:
-                            out[i] = rows.clone()
-                        else:
-                            lo, hi = offs[i]
-                            blank(i, rows).index_copy_(0, flat_dev[lo:hi], rows)
+            k = 0
+            while k < len(units):
+                n = sf.slots_for(len(units) - k)                     # (S, or a shorter replay for the tail of the epoch)
+                outs = sf.replay(n)
+                for j in range(min(n, len(units) - k)):
+                    i, pos, idx = units[k + j]
+                    rows = outs[j][:len(idx)]
+                    if pos is None:
+                        out[i] = rows.clone()
+                    else:
+                        lo, hi = offs[i]
+                        blank(i, rows).index_copy_(0, flat_dev[lo:hi], rows)
+                k += n
         for r in range(n_big):
             rows = self.fbig.replay()[0]
             c0, c1 = int(chunks[r][0]), int(chunks[r][-1]) + 1
@@ -520,14 +564,14 @@ class RoutedForward:
     def _run_whole(self, batches: Sequence[np.ndarray]) -> List[torch.Tensor]:
         a, b, na, nb = self.router.set_epoch(batches)
         out: List[Optional[torch.Tensor]] = [None] * len(batches)
-        S = self.router.S
-        for order, n_rep, sf in ((a, na, self.fa), (b, nb, self.fb)):
-            for r in range(n_rep):
-                outs = sf.replay()
-                for j in range(S):
-                    k = r * S + j
-                    if k < len(order):
-                        out[order[k]] = outs[j][:len(batches[order[k]])].clone()
+        for order, sf in ((a, self.fa), (b, self.fb)):
+            k = 0
+            while k < len(order):
+                n = sf.slots_for(len(order) - k)
+                outs = sf.replay(n)
+                for j in range(min(n, len(order) - k)):
+                    out[order[k + j]] = outs[j][:len(batches[order[k + j]])].clone()
+                k += n
         return out
 
 

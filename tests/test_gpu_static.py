@@ -657,3 +657,35 @@ def test_data_parallel_form_leaves_an_empty_tail_slot_alone():
     assert torch.equal(st.opt.exp_avg, mom)
     for a, b in zip(m.parameters(), keep):
         assert torch.equal(a.detach(), b)
+
+
+def test_static_forward_short_replay_for_the_tail_of_an_epoch():
+    """Round 6: an epoch that is not a multiple of S ends with a replay over a power-of-two number of slots instead of S - r empty
+    ones; StaticForward.run_epoch returns every batch's predictions, bit for bit the per-batch launches', whatever the split."""
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticForward
+    from cwn_amd.synthetic import zinc_like_complexes
+    torch.manual_seed(1)
+    pool = zinc_like_complexes(230, 3, 6)
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+    model = EmbedSparseCIN(28, 4, 1, 2, 64, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV).eval()
+    B, S = 16, 8
+    sb = StaticBatch(p, B, slots=S)
+    sf = StaticForward(model, sb)
+    perm = np.random.default_rng(2).permutation(len(pool))
+    batches = [perm[k * B:(k + 1) * B] for k in range(14)] + [perm[224:230]]     # 15 batches: 8 + 4 + 2 + 1, the last one ragged
+    assert [sf.slots_for(n) for n in (15, 8, 7, 5, 3, 2, 1)] == [8, 8, 8, 8, 4, 2, 1]
+    with torch.no_grad():
+        got = sf.run_epoch(batches)
+        assert sorted(sf._graphs) == [1, 2, 4, 8] or sorted(sf._graphs) == [8]      # (7 left -> 8 slots: one replay with one empty slot)
+        for k, idx in enumerate(batches):
+            want = model(p.collate(idx))
+            assert torch.equal(got[k], want), k
+        # a second epoch in another order through the same graphs
+        got2 = sf.run_epoch(batches[::-1])[::-1]
+        for k in range(len(batches)):
+            assert torch.equal(got2[k], got[k]), k
+        got3 = sf.run_epoch(batches[:11])            # 8 + 4 (3 left -> 4 slots)
+        assert len(got3) == 11 and all(torch.equal(got3[k], got[k]) for k in range(11))
