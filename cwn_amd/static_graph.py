@@ -306,9 +306,21 @@ class StaticTrainStep(TrainStep):
 
     def _forward_backward(self, i: int, pieces=None):
         if i == 0:
-            self.sb.fill()
+            self.sb.fill(getattr(self, '_n_fill', None))          # (None: all slots; a tail replay: the slots it runs)
         with self.sb.slots[i].dynamic():
             return super()._forward_backward(i, pieces)
+
+    def slots_for(self, n_batches: int) -> int:
+        """The slots the replay that serves `n_batches` remaining batches runs: S, or the power of two that holds a shorter tail
+        (round 6: an epoch that is not a multiple of S ends with a shorter captured sequence, not with empty slots -- an empty
+        slot of a training step is still ~55 launches)."""
+        S = self.sb.S
+        if n_batches >= S or self.world > 1 or self.staged is not None:
+            return S
+        n = 1
+        while n < n_batches:
+            n <<= 1
+        return min(n, S)
 
     def _loss(self, b) -> torch.Tensor:
         """The criterion over the complexes that EXIST: only the fused form knows the device-side count (a framework criterion
@@ -368,9 +380,10 @@ class StaticTrainStep(TrainStep):
         self.sb.cursor.copy_(cur)
         return res
 
-    def step(self, i: int = 0) -> List[torch.Tensor]:
+    def step(self, i: int = 0, n_slots: Optional[int] = None) -> List[torch.Tensor]:
         """S steps, one per slot, on the next S batches (set_epoch) / the batches of set_batches.  Returns the loss tensors of
-        the captured steps (overwritten by the next replay; NaN for an empty batch)."""
+        the captured steps (overwritten by the next replay; NaN for an empty batch).  n_slots < S (slots_for): the first n_slots
+        slots only, on the next n_slots batches -- the tail of an epoch."""
         S = self.sb.S
         if S == 1:
             return [super().step(0)]
@@ -378,21 +391,43 @@ class StaticTrainStep(TrainStep):
             # data parallel: no collective is captured (train.TrainStep: graph(forward + backward [pieces]) -> all-reduce ->
             # graph(Adam) per step), so the S steps of a fill are S replays of those graphs; slot 0's first piece holds the fill
             return [TrainStep.step(self, j) for j in range(S)]
-        key = ('seq',) + tuple(range(S))
+        n = S if n_slots is None else int(n_slots)
+        if not (1 <= n <= S):
+            raise ValueError(f'1 .. {S} slots')
+        key = ('seq',) + tuple(range(n))
         if key not in self._graphs:
             cur = self.sb.cursor.clone()
-            for j in range(S):                        # warm-up + the one-step graphs TrainStep.steps builds on
+            for j in range(n):                        # warm-up + the one-step graphs TrainStep.steps builds on
                 if j not in self._graphs:
                     self._graphs[j] = self._capture(j)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
-                losses = [self._eager(j) for j in range(S)]
+            self._n_fill = n
+            try:
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                    losses = [self._eager(j) for j in range(n)]
+            finally:
+                self._n_fill = None
             self._graphs[key] = (g, losses)
             self.sb.cursor.copy_(cur)
         g, losses = self._graphs[key]
         ops.weights_changed()
         g.replay()
         return losses
+
+    def run_epoch(self, batches: Sequence[np.ndarray], keep_losses: bool = True) -> List[Optional[torch.Tensor]]:
+        """One optimisation step per batch of `batches`, S at a time and a shorter replay for the tail; the losses in order
+        (clones) or None."""
+        self.sb.set_epoch(batches)
+        out: List[Optional[torch.Tensor]] = [None] * len(batches)
+        k = 0
+        while k < len(batches):
+            n = self.slots_for(len(batches) - k)
+            losses = self.step(n_slots=n)
+            if keep_losses:
+                for j in range(min(n, len(batches) - k)):
+                    out[k + j] = losses[j].clone()
+            k += n
+        return out
 
     def step_on(self, batches: Sequence[Sequence[int]]) -> List[torch.Tensor]:
         """Steps on the given batches (<= S index lists; the remaining slots run empty)."""
@@ -594,13 +629,13 @@ class RoutedTrainStep:
     def run_epoch(self, batches: Sequence[np.ndarray], keep_losses: bool = True) -> List[Optional[torch.Tensor]]:
         a, b, na, nb = self.router.set_epoch(batches)
         out: List[Optional[torch.Tensor]] = [None] * len(batches)
-        S = self.router.S
-        for order, n_rep, ts in ((a, na, self.ta), (b, nb, self.tb)):
-            for r in range(n_rep):
-                losses = ts.step()
+        for order, ts in ((a, self.ta), (b, self.tb)):
+            k = 0
+            while k < len(order):
+                n = ts.slots_for(len(order) - k)                 # (S, or a shorter captured sequence for the tail of the epoch)
+                losses = ts.step(n_slots=n)
                 if keep_losses:
-                    for j in range(S):
-                        k = r * S + j
-                        if k < len(order):
-                            out[order[k]] = losses[j].clone()
+                    for j in range(min(n, len(order) - k)):
+                        out[order[k + j]] = losses[j].clone()
+                k += n
         return out

@@ -689,3 +689,43 @@ def test_static_forward_short_replay_for_the_tail_of_an_epoch():
             assert torch.equal(got2[k], got[k]), k
         got3 = sf.run_epoch(batches[:11])            # 8 + 4 (3 left -> 4 slots)
         assert len(got3) == 11 and all(torch.equal(got3[k], got[k]) for k in range(11))
+
+
+def test_static_train_step_short_replay_for_the_tail_of_an_epoch():
+    """Round 6: StaticTrainStep.run_epoch takes one optimisation step per batch -- S at a time and a shorter captured sequence
+    for the tail -- and ends where the same epoch through full replays with empty slots ends (an empty slot's step changes
+    nothing): the same parameters, Adam's counter = the number of batches."""
+    import copy
+    from cwn_amd.models import EmbedSparseCIN
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.static_graph import StaticTrainStep
+    from cwn_amd.synthetic import zinc_like_complexes
+    torch.manual_seed(2)
+    pool = zinc_like_complexes(176, 5, 6)
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+    model = EmbedSparseCIN(28, 4, 1, 2, 64, dropout_rate=0.0, embed_edge=True, use_coboundaries=True).to(DEV).train()
+    B, S = 16, 4
+    perm = np.random.default_rng(3).permutation(len(pool))
+    batches = [perm[k * B:(k + 1) * B] for k in range(11)]              # 4 + 4 + (3 -> a replay of 4 slots) ... and 9: 4 + 4 + 1
+    m1, m2, m3 = copy.deepcopy(model), copy.deepcopy(model), copy.deepcopy(model)
+    t1 = StaticTrainStep(m1, StaticBatch(p, B, slots=S), task_type='regression', lr=1e-3)
+    t2 = StaticTrainStep(m2, StaticBatch(p, B, slots=S), task_type='regression', lr=1e-3)
+    t3 = StaticTrainStep(m3, StaticBatch(p, B, slots=S), task_type='regression', lr=1e-3)
+    assert [t1.slots_for(n) for n in (9, 4, 3, 2, 1)] == [4, 4, 4, 2, 1]
+    for ep in (batches[:9], batches[:10], batches):
+        l1 = t1.run_epoch(ep)
+        for t in (t2, t3):
+            t.sb.set_epoch(ep)
+            for _ in range(-(-len(ep) // S)):
+                t.step()                                          # full replays: the tail's empty slots change nothing
+        assert len(l1) == len(ep) and all(bool(torch.isfinite(x)) for x in l1)
+    torch.cuda.synchronize()
+    assert int(t1.opt.t) == int(t2.opt.t) == int(t3.opt.t) == 9 + 10 + 11
+    # Thirty Adam steps over weight gradients summed by fp32 atomics: two runs of the SAME sequence (m2, m3) drift apart by
+    # ~1e-2 (a parameter whose gradient is noise moves by lr per step in either direction) -- the tail replays (m1) must be
+    # no further from them than they are from each other
+    dist = lambda a, b: max(float((x - y).abs().max()) for (_, x), (_, y) in zip(a.named_parameters(), b.named_parameters()))
+    floor = dist(m2, m3)
+    print(f'[static tail] full vs full {floor:.3e}, tail vs full {dist(m1, m2):.3e}')
+    assert dist(m1, m2) <= 2.0 * floor + 1e-4, (dist(m1, m2), floor)
