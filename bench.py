@@ -291,10 +291,10 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
     w_in = [int(getattr(conv.mp_levels[0].update_up_nn[0], 'in_features', H)) for conv in model.convs]
     feats = [[torch.randn(sb.cap_cells[d], w_in[l], generator=g_).to(dev) for d in range(3)] for l in range(L)]
 
-    def prop_steps():
-        sb.fill()
+    def prop_steps(n_slots=None):
+        sb.fill(n_slots)
         keep = []
-        for slot in sb.slots:
+        for slot in (sb.slots if n_slots is None else sb.slots[:n_slots]):
             b, outs = slot.batch, None
             with slot.dynamic():
                 for l, conv in enumerate(model.convs):
@@ -357,6 +357,32 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
 
     def leg_propagate():
         g, keep = graph_of(prop_steps)
+        # (an epoch that is not a multiple of S ends with a SHORTER captured sequence, as StaticForward / StaticTrainStep do)
+        tail_n, g_tail = NB % S, None
+        if tail_n:
+            n_ = 1
+            while n_ < tail_n:
+                n_ <<= 1
+            g_tail, keep_tail = graph_of(lambda: prop_steps(min(n_, S)))
+            keep = (keep, keep_tail)
+
+        def run_epochs(_replay):
+            def one(bs):
+                sb.set_epoch(bs)
+                for _ in range(len(bs) // S):
+                    g.replay()
+                if len(bs) % S:
+                    (g_tail if (g_tail is not None and len(bs) % S == tail_n) else g).replay()
+            one(epoch(1))
+            torch.cuda.synchronize()
+            t0, total = time.perf_counter(), 0.0
+            for e in range(EPOCHS):
+                bs_ = epoch(2 + e)
+                one(bs_)
+                total += cells(bs_)
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0
+            return total / dt_, dt_ / (EPOCHS * NB) * 1e3
         cps, ms = run_epochs(g.replay)
         return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5),
                 'vs_fixed_batch_replay': round(cps / fixed_cells_per_s, 4) if fixed_cells_per_s else None}
