@@ -50,9 +50,7 @@ def main():
         assert sb.fits(batches).all()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        losses = []
-        for _ in range(sb.set_epoch(batches)):
-            losses += [l.detach().clone() for l in step.step()]
+        losses = step.run_epoch(batches)             # (S steps per replay, a shorter captured sequence for the epoch's tail)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f'epoch {epoch}: {len(batches)} steps in {dt * 1e3:.1f} ms ({dt / len(batches) * 1e3:.3f} ms / step), '

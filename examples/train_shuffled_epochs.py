@@ -65,10 +65,8 @@ def main():
         assert sb.fits(batches).all(), 'a molecule beyond a workgroup: route its batch through PackedComplexes.collate'
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        losses = []
-        for _ in range(sb.set_epoch(batches)):
-            losses += step.step()                       # device tensors: no sync here
-        losses = torch.stack([l.detach().clone() for l in losses[:len(batches) % S or S]])   # (the last replay's real slots)
+        losses = torch.stack(step.run_epoch(batches)[-S:])      # (device tensors: no sync here; S steps per replay, a shorter
+                                                                #  captured sequence for the tail of the epoch)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f'epoch {epoch}: {len(batches)} steps in {dt * 1e3:.1f} ms ({dt / len(batches) * 1e3:.3f} ms / step), '
