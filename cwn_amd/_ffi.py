@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CWN_HIP_LIB') or os.path.join(_HERE, 'libcwn_hip.so')   # override: A/B experiments
 
 MAX_DESCS = 8
+CSR_MAX_DESCS = 16             # = CWN_CSR_MAX_DESCS
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
 ABI_VERSION = 23

@@ -170,7 +170,7 @@ def wait_ready(adjs) -> None:
 
 
 def build_many(adjs: Sequence[Adjacency], overlap: bool = False, validate: bool = True, force: bool = False) -> None:
-    """Build any number of adjacencies with batched C-ABI calls (<= MAX_DESCS per call; each call is
+    """Build any number of adjacencies with batched C-ABI calls (<= CSR_MAX_DESCS per call; each call is
     one launch for small inputs, a fixed sequence of 5-7 launches otherwise, whatever the number of
     index tensors).  `overlap=True` enqueues the build on a side stream and tags every plan with
     an event that the first aggregation using it waits on, so the integer work runs underneath
@@ -199,8 +199,8 @@ def build_many(adjs: Sequence[Adjacency], overlap: bool = False, validate: bool 
     L = _ffi.lib()
     capturing = torch.cuda.is_current_stream_capturing()
     err = _err_flag(dev)
-    for i in range(0, len(adjs), _ffi.MAX_DESCS):
-        chunk = adjs[i:i + _ffi.MAX_DESCS]
+    for i in range(0, len(adjs), _ffi.CSR_MAX_DESCS):
+        chunk = adjs[i:i + _ffi.CSR_MAX_DESCS]
         arr = (_ffi.CsrDesc * len(chunk))(*[a._desc() for a in chunk])
         nbytes = L.cwn_csr_workspace_bytes(arr, len(chunk))
         ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)

@@ -1,6 +1,6 @@
 // cwn_csr.hip -- COO (int64, as delivered) -> destination-sorted int32 CSR, gfx950.
 //
-// One fixed launch sequence builds up to CWN_MAX_DESCS structures at once (all adjacencies of a
+// One fixed launch sequence builds up to CWN_CSR_MAX_DESCS structures at once (all adjacencies of a
 // batched complex), so the cost per batch is 5-6 launches regardless of how many index tensors
 // there are (inputs that fit LDS take the ONE-launch path further down instead):
 //   1. zero_words_kernel       zero the per-destination counters of every descriptor (a kernel, not a memset node: see there)
@@ -28,14 +28,14 @@ constexpr int kScanTile = 4096;        // counts per block in the multi-block sc
 constexpr int64_t kSingleScanMax = 1 << 14;   // two trips of the single-block scan; above: tiled
 
 struct CsrBatch {
-    cwn_csr_desc d[CWN_MAX_DESCS];
-    int32_t* cnt[CWN_MAX_DESCS];        // [n_dst] counters (workspace)
-    int32_t* slot[CWN_MAX_DESCS];       // [E] arrival slot, later reused as tmp (row-grouped ids)
-    int32_t* tmp[CWN_MAX_DESCS];        // [E]
-    int32_t* rows[CWN_MAX_DESCS];       // [E] destination row of tmp[p] (saves emit a dependent load)
-    int32_t* tile_sums[CWN_MAX_DESCS];  // [tiles] multi-block scan only
-    int64_t blk_start[CWN_MAX_DESCS + 1];  // block prefix for the entry-parallel kernels
-    int64_t tile_start[CWN_MAX_DESCS + 1]; // block prefix for the tile-parallel scan kernels
+    cwn_csr_desc d[CWN_CSR_MAX_DESCS];
+    int32_t* cnt[CWN_CSR_MAX_DESCS];        // [n_dst] counters (workspace)
+    int32_t* slot[CWN_CSR_MAX_DESCS];       // [E] arrival slot, later reused as tmp (row-grouped ids)
+    int32_t* tmp[CWN_CSR_MAX_DESCS];        // [E]
+    int32_t* rows[CWN_CSR_MAX_DESCS];       // [E] destination row of tmp[p] (saves emit a dependent load)
+    int32_t* tile_sums[CWN_CSR_MAX_DESCS];  // [tiles] multi-block scan only
+    int64_t blk_start[CWN_CSR_MAX_DESCS + 1];  // block prefix for the entry-parallel kernels
+    int64_t tile_start[CWN_CSR_MAX_DESCS + 1]; // block prefix for the tile-parallel scan kernels
     int n;
     int dbg;   // timing experiments (CWN_CSR_DBG): 1 no rowptr stores, 2 no long-row notes, 4 no loads
 };
@@ -50,7 +50,7 @@ __device__ __forceinline__ int64_t live_entries(const cwn_csr_desc& D) {
 __device__ __forceinline__ int find_desc(const int64_t* start, int n, int64_t b) {
     int d = 0;
 #pragma unroll
-    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+    for (int i = 1; i < CWN_CSR_MAX_DESCS; ++i)
         if (i < n && b >= start[i]) d = i;
     return d;
 }
@@ -352,8 +352,8 @@ constexpr size_t kSmallLdsBytes = 150 * 1024;
 constexpr int kMaxParts = CWN_LONG_PARTS;
 
 struct SmallBatch {
-    cwn_csr_desc d[CWN_MAX_DESCS];
-    int32_t part_start[CWN_MAX_DESCS + 1];   // first workgroup of each descriptor
+    cwn_csr_desc d[CWN_CSR_MAX_DESCS];
+    int32_t part_start[CWN_CSR_MAX_DESCS + 1];   // first workgroup of each descriptor
     int32_t n;
 };
 
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kSmallThreads) void csr_small_kernel(SmallBatch B, 
     constexpr int U = 8;   // independent global loads in flight per thread and phase
     int di = 0;
 #pragma unroll
-    for (int i = 1; i < CWN_MAX_DESCS; ++i)
+    for (int i = 1; i < CWN_CSR_MAX_DESCS; ++i)
         if (i < B.n && (int)blockIdx.x >= B.part_start[i]) di = i;
     const cwn_csr_desc& D = B.d[di];
     const int parts = B.part_start[di + 1] - B.part_start[di];
@@ -512,8 +512,8 @@ __global__ __launch_bounds__(256) void zero_words_kernel(uint4* __restrict__ p, 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-    size_t cnt_off[CWN_MAX_DESCS], slot_off[CWN_MAX_DESCS], tmp_off[CWN_MAX_DESCS],
-        rows_off[CWN_MAX_DESCS], tiles_off[CWN_MAX_DESCS];
+    size_t cnt_off[CWN_CSR_MAX_DESCS], slot_off[CWN_CSR_MAX_DESCS], tmp_off[CWN_CSR_MAX_DESCS],
+        rows_off[CWN_CSR_MAX_DESCS], tiles_off[CWN_CSR_MAX_DESCS];
     size_t cnt_total;  // the leading region that must be zeroed
     size_t total;
 };
@@ -543,13 +543,13 @@ WsLayout layout(const cwn_csr_desc* d, int n) {
 }  // namespace
 
 extern "C" size_t cwn_csr_workspace_bytes(const cwn_csr_desc* descs, int n) {
-    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS) return 0;
+    if (descs == nullptr || n <= 0 || n > CWN_CSR_MAX_DESCS) return 0;
     return layout(descs, n).total;
 }
 
 extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, size_t ws_bytes,
                              int32_t* err_flag, cwn_stream_t stream_) {
-    if (descs == nullptr || n <= 0 || n > CWN_MAX_DESCS || err_flag == nullptr) return CWN_ERR_BAD_ARG;
+    if (descs == nullptr || n <= 0 || n > CWN_CSR_MAX_DESCS || err_flag == nullptr) return CWN_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     int64_t max_dst = 0;
     for (int i = 0; i < n; ++i) {
@@ -589,7 +589,7 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
             S.part_start[i] = blocks;
             blocks += small_parts(descs[i].n_entries, descs[i].n_dst);
         }
-        for (int i = n; i <= CWN_MAX_DESCS; ++i) S.part_start[i] = blocks;
+        for (int i = n; i <= CWN_CSR_MAX_DESCS; ++i) S.part_start[i] = blocks;
         csr_small_kernel<<<dim3(blocks), dim3(kSmallThreads), align_up(small_bytes, 16), stream>>>(S, err_flag);
         return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
     }
@@ -614,7 +614,7 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
         blocks += (descs[i].n_entries + kThreads - 1) / kThreads;
         tiles += descs[i].n_dst > 0 ? (descs[i].n_dst + kScanTile - 1) / kScanTile : 1;   // >= 1: rowptr[0]
     }
-    for (int i = n; i <= CWN_MAX_DESCS; ++i) {
+    for (int i = n; i <= CWN_CSR_MAX_DESCS; ++i) {
         B.blk_start[i] = blocks;
         B.tile_start[i] = tiles;
     }

@@ -51,6 +51,8 @@ enum {
 };
 
 #define CWN_MAX_DESCS 8 /* descriptors per batched call (one kernel launch covers all of them) */
+#define CWN_CSR_MAX_DESCS 16 /* ... of cwn_csr_build / cwn_csr_workspace_bytes (ABI 23: the plans of two slots of a static batch,
+                              * or of a training step's adjacencies AND their transposes, in one launch sequence) */
 
 int cwn_abi_version(void);
 const char* cwn_error_string(int code);

@@ -116,7 +116,7 @@ def test_csr_build_hub_rows_and_batched_call():
     idx = torch.stack([src, dst])
     adjs = [Adjacency.from_index(idx.to(DEV), n, n, build=False)]
     others = []
-    for k in range(10):   # > CWN_MAX_DESCS descriptors -> two C-ABI calls
+    for k in range(19):   # > CWN_CSR_MAX_DESCS descriptors -> two C-ABI calls
         e = 100 * (k + 1)
         i2 = torch.stack([torch.randint(0, 50, (e,), generator=g), torch.randint(0, 60, (e,), generator=g)])
         others.append(i2)
