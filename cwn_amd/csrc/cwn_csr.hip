@@ -642,3 +642,42 @@ extern "C" int cwn_csr_build(const cwn_csr_desc* descs, int n, void* workspace, 
     }
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
+
+// ---- the long-row lists of structures that were not built here (include/cwn_hip.h: cwn_csr_long_rows) -----------------------
+namespace {
+struct LongBatch { cwn_long_rows_desc d[CWN_CSR_MAX_DESCS]; };
+
+__global__ __launch_bounds__(1024) void long_rows_kernel(LongBatch B) {
+    __shared__ int count;
+    const cwn_long_rows_desc D = B.d[blockIdx.x];          // (a small struct, a launch-constant index per workgroup)
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    int64_t n = D.n_rows;
+    if (D.m_dev != nullptr) {
+        const int64_t m = *D.m_dev;
+        n = m < 0 ? 0 : (m < n ? m : n);
+    }
+    for (int64_t r = threadIdx.x; r < n; r += blockDim.x) {
+        if (D.rowptr[r + 1] - D.rowptr[r] > CWN_LONG_ROW) {
+            const int p = atomicAdd(&count, 1);
+            if (p < D.long_cap) D.long_rows[p] = (int32_t)r;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < CWN_LONG_PARTS)
+        D.n_long[threadIdx.x] = threadIdx.x == 0 ? (int32_t)(count < D.long_cap ? count : D.long_cap) : 0;
+}
+}  // namespace
+
+extern "C" int cwn_csr_long_rows(const cwn_long_rows_desc* descs, int n, cwn_stream_t stream_) {
+    if (descs == nullptr || n <= 0 || n > CWN_CSR_MAX_DESCS) return CWN_ERR_BAD_ARG;
+    LongBatch B{};
+    for (int i = 0; i < n; ++i) {
+        const cwn_long_rows_desc& D = descs[i];
+        if (D.rowptr == nullptr || D.long_rows == nullptr || D.n_long == nullptr || D.n_rows < 0 || D.long_cap < 1) return CWN_ERR_BAD_ARG;
+        if (D.n_rows >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+        B.d[i] = D;
+    }
+    long_rows_kernel<<<dim3((unsigned)n), dim3(1024), 0, (hipStream_t)stream_>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}

@@ -281,7 +281,14 @@ __global__ __launch_bounds__(kThreads, (KP <= 128 && RT == 2 && !(CWN_GEMM_NOSPI
         if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
     const cwn_gemm_desc& D = B.d[di];
     const int nblk = B.blk_start[di + 1] - B.blk_start[di];
-    const int tiles_n = B.n_tiles_n[di], tiles = B.n_tiles[di];
+    const int tiles_n = B.n_tiles_n[di];
+    int tiles = B.n_tiles[di];
+    if (D.m_dev != nullptr) {        // (uniform) a static batch: the row tiles below the rows that exist -- a PREFIX of the tile numbers
+        const int64_t mv = *D.m_dev;
+        const int64_t live = (mv < 0 ? 0 : (mv < D.M ? mv : D.M));
+        const int64_t t = (live + BM - 1) / BM * tiles_n;
+        tiles = t < tiles ? (int)t : tiles;
+    }
     const bool vec = FAST;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wn = wave % WN, wm = wave / WN;     // the wave's 32 x 32 patch inside the tile
@@ -665,6 +672,7 @@ extern "C" int cwn_gemm_f32(const cwn_gemm_desc* descs, int n, cwn_stream_t stre
         if (D.in_scale2 != nullptr && D.K2 == 0) return CWN_ERR_BAD_ARG;
         if ((D.out_scale == nullptr) != (D.out_shift == nullptr)) return CWN_ERR_BAD_ARG;
         if ((D.col_sum == nullptr) != (D.col_sumsq == nullptr)) return CWN_ERR_BAD_ARG;
+        if (D.m_dev != nullptr && (D.col_sum != nullptr || D.bnb != nullptr)) return CWN_ERR_BAD_ARG;   // (include/cwn_hip.h: m_dev)
         if (D.ldx < D.K || (D.ldw < (D.w_trans ? D.N : D.K + D.K2) && !(D.flags & CWN_GEMM_W_PACKED)) || D.ldy < D.N ||
             (D.K2 > 0 && D.ldx2 < D.K2))
             return CWN_ERR_BAD_ARG;

@@ -60,7 +60,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_split_kernel(SplitBatch B) {
     const cwn_gemm_desc D = B.d[di];         // by value (see cwn_aggregate.hip)
     const int blk = blockIdx.x - B.blk_start[di];
     const int nblk = B.blk_start[di + 1] - B.blk_start[di];
-    const int tiles = B.n_tiles[di];
+    int tiles = B.n_tiles[di];
+    if (D.m_dev != nullptr) {                // (uniform) a static batch: the 64-row tiles below the rows that exist
+        const int64_t mv = *D.m_dev;
+        const int64_t live = (mv < 0 ? 0 : (mv < D.M ? mv : D.M));
+        const int64_t t = (live + TM - 1) / TM;
+        tiles = t < tiles ? (int)t : tiles;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
 

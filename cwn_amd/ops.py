@@ -1394,6 +1394,8 @@ class Gemm:
             ldw=W.stride(0) if W.size(0) > 1 else W.size(1), ldy=Y.stride(0) if Y.size(0) > 1 else Y.size(1),
             N=W.size(1 if self.w_trans else 0), K=K, K2=K2, relu=int(self.relu), in_relu=int(self.in_relu),
             w_trans=int(self.w_trans), bnb=None if self.bnb is None else C.pointer(self.bnb),
+            # (a static batch: the rows that exist -- the launch walks the row tiles below the device-side count only)
+            m_dev=_ffi.dyn(X.size(0)) if (cs is None and self.bnb is None) else None,
             flags=(_ffi.GEMM_EXACT if (self.exact or GEMM_EXACT) else 0) | (_ffi.GEMM_W_PACKED if packed else 0)
             | (_ffi.GEMM_ADD_OUT if self.add_out else 0) | (int(self.debug) << 8))
 

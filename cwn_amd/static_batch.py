@@ -220,6 +220,7 @@ class StaticBatch:
             raise ValueError("mode 'blocked' or 'csr'")
         self.mode = mode
         self.build_backward = False          # (StaticTrainStep: the fill also builds the transposed plans)
+        self._slot_long: Dict = {}           # slot -> the collated plans whose long-row lists the fill writes (mode 'csr')
         self._cap_cols = None                # (_check_capacity: the distinct size columns a batch can exceed)
         if not packed.with_csr:
             raise ValueError('StaticBatch needs a PackedComplexes built with with_csr=True')
@@ -390,6 +391,16 @@ class StaticBatch:
                 adj = _CollatedAdjacency(bi, 1, self.cap_cells[d], self.cap_cells[d - 1], bufs[(d, 'b_rowptr')], bufs[(d, 'b_col')])
                 adj._t_src = _CollatedAdjacency(bi, 0, self.cap_cells[d - 1], self.cap_cells[d], bufs[(d, 'bt_rowptr')],
                                                 bufs[(d, 'bt_col')])
+                if self.mode == 'csr':
+                    # the TRANSPOSE has hub rows on REDDIT-like complexes (a vertex of degree 300 is the boundary of 300 edges):
+                    # its long-row lists, which the collate does not bring, are written by the fill (cwn_csr_long_rows) when a
+                    # training step reads this plan -- without them the streaming backward walked every hub row with one lane
+                    # group (round 6: 54 against 37 us per backward aggregation launch)
+                    t = adj._t_src
+                    t.long_rows = torch.zeros(csr.LONG_PARTS, t.long_cap, dtype=torch.int32, device=bi.device)
+                    t.n_long = torch.zeros(csr.LONG_PARTS, dtype=torch.int32, device=bi.device)
+                    t.rows_dev_ptr = self.size_ptr(d - 1, j)
+                    self._slot_long.setdefault(j, []).append(t)
                 self._register(bi, adj)
             if cb.upper_index is not None and d + 1 < D:
                 ui = cb.upper_index
@@ -763,6 +774,14 @@ class StaticBatch:
                                 todo.append(t)
             if todo:
                 csr.build_many(todo, validate=False, force=True)
+            if self.build_backward:
+                lists = [t for j in range(n) for t in self._slot_long.get(j, [])]
+                for i in range(0, len(lists), _ffi.CSR_MAX_DESCS):
+                    chunk = lists[i:i + _ffi.CSR_MAX_DESCS]
+                    arr = (_ffi.LongRowsDesc * len(chunk))(*[
+                        _ffi.LongRowsDesc(rowptr=t.rowptr.data_ptr(), n_rows=t.n_dst, m_dev=t.rows_dev_ptr, long_rows=t.long_rows.data_ptr(),
+                                          n_long=t.n_long.data_ptr(), long_cap=t.long_cap) for t in chunk])
+                    _ffi.check(L.cwn_csr_long_rows(arr, len(chunk), s), 'cwn_csr_long_rows')
 
     # ---- the reference tables (tests) -----------------------------------------------------------------------------------
     def host_tables(self, idx: Sequence[int]) -> np.ndarray:

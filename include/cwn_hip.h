@@ -115,6 +115,22 @@ size_t cwn_csr_workspace_bytes(const cwn_csr_desc* descs_host, int n);
 int cwn_csr_build(const cwn_csr_desc* descs_host, int n, void* workspace, size_t workspace_bytes,
                   int32_t* err_flag, cwn_stream_t stream);
 
+/* The long-row lists of CSR structures that cwn_csr_build did NOT build (ABI 23): a static batch takes the CSR of a boundary
+ * adjacency and of its TRANSPOSE as the concatenation of the per-complex CSRs kept with the dataset (cwn_collate_slots) -- and
+ * the transpose of a REDDIT-like boundary has hub rows (a vertex of degree 300 is the boundary of 300 edges) that
+ * cwn_aggregate_f32 then walked with one lane group each: its backward launch 54 against 37 us.  One workgroup per structure:
+ * rows r < *m_dev (or n_rows) with rowptr[r + 1] - rowptr[r] > CWN_LONG_ROW go to sub-list 0 of long_rows, n_long[0] = their
+ * number, n_long[1 ..] = 0; more than long_cap of them: the first long_cap (the others are walked the slow way). */
+typedef struct cwn_long_rows_desc {
+    const int32_t* rowptr;   /* [n_rows + 1] */
+    int64_t n_rows;          /* capacity */
+    const int64_t* m_dev;    /* or NULL: rows that exist */
+    int32_t* long_rows;      /* [CWN_LONG_PARTS][long_cap] out */
+    int32_t* n_long;         /* [CWN_LONG_PARTS] out */
+    int64_t long_cap;
+} cwn_long_rows_desc;
+int cwn_csr_long_rows(const cwn_long_rows_desc* descs_host, int n, cwn_stream_t stream);   /* n <= CWN_CSR_MAX_DESCS */
+
 /* ------------------------------------------------------------------------------------------
  * K1: row gather.  out[e, :] = src[idx[e], :]
  * Replaces  src.index_select(node_dim, index[dim])   mp/cell_mp.py:198   (and the up_attr /
@@ -823,6 +839,10 @@ typedef struct cwn_gemm_desc {
     int32_t pad_;
     const cwn_gemm_bnb* bnb;  /* HOST pointer or NULL, see the struct above: w_trans launches with 16-byte aligned operands and
                                K <= 128 (the launch's tile shapes for K <= 128: any N); CWN_ERR_BAD_ARG otherwise */
+    const int64_t* m_dev;     /* (ABI 23) or NULL: the rows that exist (M = capacity, see "Conventions"): the workgroups walk the
+                               * row tiles below *m_dev only -- a static batch's message products used to be taken over the
+                               * CAPACITY of its buffers (REDDIT-32: 1.46 x the batch).  Not with col_sum / col_sumsq or bnb
+                               * (CWN_ERR_BAD_ARG): those launches have cwn_dense_stage_f32's own count */
 } cwn_gemm_desc;
 
 /* cwn_gemm_desc.flags.  EXACT: keep this launch on the exact fp32-MFMA kernel (bitwise an fmaf chain

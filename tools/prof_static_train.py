@@ -21,17 +21,27 @@ with torch.no_grad():
 B, S = 32, 4
 pool = [c for i in range(4) for c in reddit_like_complexes(B, 50 + i)]
 if which == 'fixed':
-    bs = [ComplexBatch.from_complex_list(pool[i * B:(i + 1) * B], max_dim=2).to(dev) for i in range(2)]
+    bs = [ComplexBatch.from_complex_list(pool[i * B:(i + 1) * B], max_dim=2).to(dev) for i in range(4)]      # (the static run's four batches)
     for b in bs:
         b.y = torch.zeros(b.num_complexes, dtype=torch.long, device=dev)
     ts = TrainStep(model, bs, task_type='classification', use_graph=True)
     for i in range(24):
-        ts.step(i % 2)
+        ts.step(i % 4)
 else:
     for c in pool:
         c.y = torch.zeros(1, dtype=torch.long)
     packed = PackedComplexes(pool, dev, max_dim=2, with_csr=True)
-    sb = StaticBatch(packed, B, slots=S, mode='csr')
+    caps = None
+    if os.environ.get('TIGHT_CAPS') == '1':      # (experiment: capacities = the largest of these four batches, not the 6-sigma bound)
+        m = packed._meta
+        D = packed.max_dim + 1
+        per = [m[k * B:(k + 1) * B] for k in range(4)]
+        caps = {'cells': [int(max(int(x[:, 3 * d].sum()) for x in per)) + 8 + d for d in range(D)]}
+        for k, (d, key, pk) in enumerate(packed._klist):
+            if key in ('upper_index', 'lower_index', 'boundary_index'):
+                caps[(d, key)] = int(max(int(x[:, 3 * D + k].sum()) for x in per)) + 16 + k
+    sb = StaticBatch(packed, B, slots=S, mode='csr', caps=caps)
+    print('capacities', sb.cap_cells)
     ts = StaticTrainStep(model, sb, task_type='classification', lr=1e-3)
     perm = np.arange(len(pool))
     for e in range(6):
