@@ -333,3 +333,35 @@ def test_routed_forward_regroups_the_complexes_beyond_a_workgroup():
     print(f'[router] {n_split} of {len(epoch)} batches hold a complex beyond a workgroup: their other complexes stay on the blocked path, '
           f'{int(sum((~re.mask[idx]).sum() for idx in epoch))} complexes pooled')
     assert n_split >= 2
+
+
+def test_long_row_lists_of_the_collated_transposed_boundary_plans():
+    """Round 6 (cwn_csr_long_rows): the TRANSPOSE of a REDDIT-like boundary adjacency has hub rows (a vertex of degree 300 is the
+    boundary of 300 edges); a csr-mode static batch takes that CSR from the dataset's per-complex CSRs, and its fill now lists
+    the rows beyond CWN_LONG_ROW entries for the aggregation kernel's whole-workgroup path -- exactly the rows with more than 64
+    entries among the batch's OWN rows, for every slot."""
+    from cwn_amd import csr
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.synthetic import reddit_like_complexes
+    pool = reddit_like_complexes(12, 3, n_lo=150, n_hi=400)
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+    sb = StaticBatch(p, 4, slots=2, mode='csr')
+    sb.build_backward = True
+    sb.set_batches([np.array([0, 5, 7, 2]), np.array([9, 1, 3])])
+    sb.fill()
+    torch.cuda.synchronize()
+    seen = 0
+    for j in range(2):
+        for t in sb._slot_long[j]:
+            rows = sb.slots[j].sizes()
+            rp = t.rowptr.cpu().numpy().astype(np.int64)
+            # (rows of this plan = cells of the dimension BELOW the adjacency's)
+            d_rows = [d for d in range(3) if sb.cap_cells[d] == t.n_dst][0]
+            m = int(rows[d_rows])
+            want = sorted(np.nonzero((rp[1:m + 1] - rp[:m]) > csr.LONG_ROW)[0].tolist())
+            nl = t.n_long.cpu().numpy()
+            got = sorted(t.long_rows[0, :int(nl[0])].cpu().numpy().tolist())
+            assert nl[1:].sum() == 0 and got == want, (j, d_rows, len(got), len(want))
+            seen += len(want)
+    assert seen > 0            # (the vertices' plan has hubs)
