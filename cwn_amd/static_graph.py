@@ -202,8 +202,13 @@ class StaticForward:
     outs = property(lambda self: self._graphs.get(self.sb.S, (None, None, None))[1])
 
     def _state(self):
-        return (ops.STATE_EPOCH,) + tuple(_ffi.tver(p) for p in self.model.parameters()) + \
-            tuple(_ffi.tver(b) for b in self.model.buffers())
+        # (the list of the model's tensors is walked out of the module tree once per STRUCT_EPOCH -- torch's registration hooks
+        #  move it when any module / parameter / buffer is (re)registered --, their version counters on every call: walking the
+        #  tree cost 0.75 ms per replay, more than the replay of an epoch's one-slot tail)
+        if getattr(self, '_tensors_epoch', None) != ops.STRUCT_EPOCH:
+            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
+            self._tensors_epoch = ops.STRUCT_EPOCH
+        return (ops.STATE_EPOCH, ops.STRUCT_EPOCH) + tuple(_ffi.tver(t) for t in self._tensors)
 
     def _run(self, n_slots: Optional[int] = None) -> List[torch.Tensor]:
         n = self.sb.S if n_slots is None else int(n_slots)
