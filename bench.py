@@ -319,25 +319,32 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
                 keep = fn()
         return g, keep
 
-    def run_epochs(replay):
-        """EPOCHS epochs of NB fresh batches each (the per-epoch permutation upload is inside the timed region)"""
-        total = 0.0
-        n_rep = sb.set_epoch(epoch(1))
-        for _ in range(n_rep):
-            replay()
+    MIN_MS = float(os.environ.get('CWN_BENCH_FRESH_MIN_MS', '40'))
+    epochs_used = [EPOCHS]
+
+    def time_epochs(one):
+        """`one(batches)` runs an epoch of NB never-seen batches (the per-epoch permutation upload included).  Timed: at least
+        EPOCHS epochs and at least MIN_MS of them (an epoch of the propagate scope lasts ~1 ms: the host's start-up before the
+        first replay -- drawing the permutation, the upload -- would be 5 % of a 6-epoch region); every epoch its own
+        permutation.  -> cells / s, ms per step, epochs"""
+        one(epoch(1))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for e in range(EPOCHS):
-            bs = epoch(2 + e)
-            n_rep = sb.set_epoch(bs)
-            for _ in range(n_rep):
-                replay()
-            total += cells(bs)
+        one(epoch(1))
+        torch.cuda.synchronize()
+        n = int(min(96, max(EPOCHS, -(-MIN_MS * 1e-3 // max(time.perf_counter() - t0, 1e-5)))))
+        epochs_used[0] = max(epochs_used[0], n)
+        t0, seen = time.perf_counter(), []
+        for e in range(n):
+            bs_ = epoch(2 + e)
+            one(bs_)
+            seen.append(bs_)
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
-        return total / dt_, dt_ / (EPOCHS * NB) * 1e3
+        total = sum(cells(bs_) for bs_ in seen)          # (the bench's own bookkeeping: after the clock stops)
+        return total / dt_, dt_ / (n * NB) * 1e3, n
 
-    out = {'distinct_batches_per_epoch': NB, 'epochs_timed': EPOCHS, 'batch': B, 'dataset_complexes': len(pool),
+    out = {'distinct_batches_per_epoch': NB, 'epochs_timed_at_least': EPOCHS, 'timed_region_ms_at_least': MIN_MS, 'batch': B, 'dataset_complexes': len(pool),
            'steps_per_replay': S, 'capacities': {'cells': list(sb.cap_cells), 'complexes': B}, 'static_batch_mode': mode,
            'host_work_per_step': 'one hipGraph replay per %d steps (a StaticBatch of %d slots: the fill launches cut the tables, '
                                  'arrays and item tables of %d batches at once); the epoch\'s permutation is uploaded once per '
@@ -366,25 +373,14 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
             g_tail, keep_tail = graph_of(lambda: prop_steps(min(n_, S)))
             keep = (keep, keep_tail)
 
-        def run_epochs(_replay):
-            def one(bs):
-                sb.set_epoch(bs)
-                for _ in range(len(bs) // S):
-                    g.replay()
-                if len(bs) % S:
-                    (g_tail if (g_tail is not None and len(bs) % S == tail_n) else g).replay()
-            one(epoch(1))
-            torch.cuda.synchronize()
-            t0, total = time.perf_counter(), 0.0
-            for e in range(EPOCHS):
-                bs_ = epoch(2 + e)
-                one(bs_)
-                total += cells(bs_)
-            torch.cuda.synchronize()
-            dt_ = time.perf_counter() - t0
-            return total / dt_, dt_ / (EPOCHS * NB) * 1e3
-        cps, ms = run_epochs(g.replay)
-        return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5),
+        def one(bs):
+            sb.set_epoch(bs)
+            for _ in range(len(bs) // S):
+                g.replay()
+            if len(bs) % S:
+                (g_tail if (g_tail is not None and len(bs) % S == tail_n) else g).replay()
+        cps, ms, n_ep = time_epochs(one)
+        return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'epochs_timed': n_ep,
                 'vs_fixed_batch_replay': round(cps / fixed_cells_per_s, 4) if fixed_cells_per_s else None}
 
     def leg_forward():
@@ -397,26 +393,15 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
             # the first batches of an epoch against the per-batch launches, bit for bit
             same = all(bool(torch.equal(outs[j][:len(bs[j])], model(packed.collate(bs[j])))) for j in range(min(S, 3)))
             # (an epoch that is not a multiple of S ends with a SHORTER replay -- StaticForward.slots_for -- instead of empty slots)
-            def run_epochs_sf():
-                def one(bs):
-                    sb.set_epoch(bs)
-                    k = 0
-                    while k < len(bs):
-                        n = sf.slots_for(len(bs) - k)
-                        sf.replay(n)
-                        k += n
-                one(epoch(1))
-                torch.cuda.synchronize()
-                t0, total = time.perf_counter(), 0.0
-                for e in range(EPOCHS):
-                    bs_ = epoch(2 + e)
-                    one(bs_)
-                    total += cells(bs_)
-                torch.cuda.synchronize()
-                dt_ = time.perf_counter() - t0
-                return total / dt_, dt_ / (EPOCHS * NB) * 1e3
-            cps, ms = run_epochs_sf()
-        return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'bit_identical_to_per_batch_launches': same,
+            def one(bs):
+                sb.set_epoch(bs)
+                k = 0
+                while k < len(bs):
+                    n = sf.slots_for(len(bs) - k)
+                    sf.replay(n)
+                    k += n
+            cps, ms, n_ep = time_epochs(one)
+        return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'epochs_timed': n_ep, 'bit_identical_to_per_batch_launches': same,
                 'vs_fixed_batch_replay': round(fixed_forward_ms / ms, 4) if fixed_forward_ms else None}
 
     def leg_train():
@@ -425,21 +410,10 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
         ts = StaticTrainStep(tmodel, sb, task_type=task)
         ts.step()
         # (an epoch that is not a multiple of S ends with a SHORTER captured sequence -- StaticTrainStep.slots_for -- not with empty slots)
-        def run_epochs_ts():
-            ts.run_epoch(epoch(1), keep_losses=False)
-            torch.cuda.synchronize()
-            t0, total = time.perf_counter(), 0.0
-            for e in range(EPOCHS):
-                bs_ = epoch(2 + e)
-                ts.run_epoch(bs_, keep_losses=False)
-                total += cells(bs_)
-            torch.cuda.synchronize()
-            dt_ = time.perf_counter() - t0
-            return total / dt_, dt_ / (EPOCHS * NB) * 1e3
-        cps, ms = run_epochs_ts()
+        cps, ms, n_ep = time_epochs(lambda bs: ts.run_epoch(bs, keep_losses=False))
         sb.set_epoch(epoch(1))
         finite = all(bool(torch.isfinite(l).item()) for l in ts.step())
-        return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'loss_finite': finite,
+        return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'epochs_timed': n_ep, 'loss_finite': finite,
                 'vs_fixed_batch_replay': round(fixed_train_ms / ms, 4) if fixed_train_ms else None}
 
     def leg_fill():
@@ -466,19 +440,6 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
         # csr-mode static batch (cwn_amd/static_graph.py: StaticRouter), one optimizer state
         from cwn_amd.static_graph import RoutedForward, RoutedTrainStep, StaticRouter
 
-        def timed_epochs(run):
-            run(epoch(1))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            tot = 0.0
-            for e in range(EPOCHS):
-                bs = epoch(2 + e)
-                run(bs)
-                tot += cells(bs)
-            torch.cuda.synchronize()
-            dt_ = time.perf_counter() - t0
-            return tot / dt_, dt_ / (EPOCHS * NB) * 1e3
-
         def leg_forward_routed():
             router = StaticRouter(packed, B, slots=S)
             rf = RoutedForward(model, router)
@@ -488,9 +449,9 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
                 outs = rf.run_epoch(bs)
                 same = all(bool(torch.allclose(outs[k], model(packed.collate(bs[k])), rtol=0, atol=1e-5 * max(1.0, float(outs[k].abs().max()))))
                            for k in (list(a_[:2]) + list(b_[:2])))
-                cps, ms = timed_epochs(rf.run_epoch)
+                cps, ms, n_ep = time_epochs(rf.run_epoch)
             n_pool = int(sum(int((~rf.mask[np.asarray(ix)]).sum()) for ix in bs)) if rf.fbig is not None else 0
-            return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'equal_to_per_batch_launches_1e-5': same,
+            return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'epochs_timed': n_ep, 'equal_to_per_batch_launches_1e-5': same,
                     'batches_without_a_complex_beyond_a_workgroup': len(a_), 'batches_with_one': len(b_),
                     # (round 6, RoutedForward(regroup=True): those batches keep the blocked path for the complexes that fit; the
                     #  others are pooled over the epoch into a csr-mode static batch of their own)
@@ -501,9 +462,9 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
             tmodel = copy.deepcopy(model).train()
             router = StaticRouter(packed, B, slots=S)
             rt = RoutedTrainStep(tmodel, router, task_type=task)
-            cps, ms = timed_epochs(lambda bs: rt.run_epoch(bs, keep_losses=False))
+            cps, ms, n_ep = time_epochs(lambda bs: rt.run_epoch(bs, keep_losses=False))
             finite = all(bool(torch.isfinite(l).item()) for l in rt.run_epoch(epoch(1)) if l is not None)
-            return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'loss_finite': finite,
+            return {'cells_per_s': round(cps, 1), 'ms_per_step': round(ms, 5), 'epochs_timed': n_ep, 'loss_finite': finite,
                     'adam_steps': int(rt.opt.t), 'vs_fixed_batch_replay': round(fixed_train_ms / ms, 4) if fixed_train_ms else None}
 
         out['routed'] = True
@@ -516,10 +477,10 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
             out['device_error_word'] = str(e)
         out['every_batch_within_capacity'] = True       # (the router raises otherwise)
         return out
-    leg('propagate', leg_propagate)
-    leg('forward', leg_forward)
-    leg('train', leg_train)
-    leg('fill', leg_fill)
+    LEGS = os.environ.get('CWN_BENCH_FRESH_LEGS', 'propagate,forward,train,fill').split(',')      # (profiling: one leg alone)
+    for name_, fn_ in (('propagate', leg_propagate), ('forward', leg_forward), ('train', leg_train), ('fill', leg_fill)):
+        if name_ in LEGS:
+            leg(name_, fn_)
     try:
         f_ms = out['fill']['ms_per_step']
         for k, fixed in (('forward', fixed_forward_ms), ('train', fixed_train_ms)):
@@ -527,7 +488,7 @@ def fresh_batches_leg(args, model, gen, dev, H, L, rank, fixed_cells_per_s, fixe
                 out[k]['vs_fixed_batch_replay_plus_fill'] = round((fixed + f_ms) / out[k]['ms_per_step'], 4)
     except (KeyError, TypeError):
         pass
-    all_fit = all_fit and all(bool(sb.fits(epoch(e)).all()) for e in range(2 + EPOCHS))      # (now incl. the backward table)
+    all_fit = all_fit and all(bool(sb.fits(epoch(e)).all()) for e in range(2 + epochs_used[0]))      # (now incl. the backward table)
     out['every_batch_within_capacity'] = all_fit
     try:
         csr.check_errors(dev)

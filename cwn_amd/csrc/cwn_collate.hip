@@ -22,39 +22,73 @@ struct CollateBatch {
     int32_t n;
 };
 
+// One segment, `step` lanes on it (lane `l` of them): four elements requested before the first is stored (dst and src never
+// overlap: a batched array and the packed dataset).
+template <typename T>
+__device__ __forceinline__ void copy_seg(T* __restrict__ dst, const T* __restrict__ src, int64_t len, T a, int l, int step) {
+    for (int64_t q = l; q < len; q += 4 * step) {
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = q + u * step < len ? src[q + u * step] : T(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (q + u * step < len) dst[q + u * step] = v[u] + a;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void fill_seg(T* __restrict__ dst, int64_t len, T v, int l, int step) {
+    for (int64_t q = l; q < len; q += step) dst[q] = v;
+}
+
+// SPW segments per wave.  1: a wave per (array, complex).  4 (batches of many small complexes: a molecule's arrays are tens
+// of elements, a 64-lane pass leaves most lanes idle and the launch is ~10^5 waves of three dependent round trips each):
+// every 16 lanes read the table entries of their own segment in ONE round trip, then either copy it themselves (all four
+// short) or the whole wave takes the four in turn (any of them long), the entries passed by lane shuffles.
+template <int SPW>
 __global__ __launch_bounds__(kThreads) void collate_kernel(CollateBatch B, int64_t n_seg) {
+    constexpr int GL = 64 / SPW;                     // lanes per segment
     const int di = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * kSegPerWg + (threadIdx.x >> 6);
+    const int sub = lane / GL, sl = lane % GL;
+    const int64_t s = ((int64_t)blockIdx.x * kSegPerWg + (threadIdx.x >> 6)) * SPW + sub;
     const int64_t slot = blockIdx.z;
     if (B.cursor != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
         *B.cursor += (int64_t)gridDim.z;             // (the tables of this launch were cut by an EARLIER launch: no reader left)
-    if (s >= n_seg) return;                          // (a whole wave)
+    if (s - sub >= n_seg) return;                    // (a whole wave)
     const cwn_collate_desc& D = B.d[di];
     const int64_t tab_off = slot * B.table_slot_stride;
-    const int64_t d0 = D.dst_start[tab_off + s], len = D.dst_start[tab_off + s + 1] - d0;
-    if (len <= 0) return;
-    const int64_t s0 = D.op == CWN_COLLATE_SEGID64 ? 0 : D.src_start[tab_off + s];
+    const bool live = s < n_seg;
+    const int64_t d0 = live ? D.dst_start[tab_off + s] : 0;
+    int64_t len = live ? D.dst_start[tab_off + s + 1] - d0 : 0;
+    if (len < 0) len = 0;
+    const int64_t s0 = (D.op == CWN_COLLATE_SEGID64 || !live) ? 0 : D.src_start[tab_off + s];
+    int64_t add[2] = {0, 0};
+    if (D.add != nullptr && live) {
+        add[0] = D.add[tab_off + s];
+        if (D.n_rows > 1) add[1] = D.add[tab_off + n_seg + s];
+    }
     char* const dst_base = (char*)D.dst + slot * B.dst_slot_bytes[di];
-    for (int r = 0; r < D.n_rows; ++r) {
-        const int64_t add = D.add != nullptr ? D.add[tab_off + (int64_t)r * n_seg + s] : 0;
-        if (D.op == CWN_COLLATE_COPY32) {
-            const int32_t* src = (const int32_t*)D.src + r * D.src_row_stride + s0;
-            int32_t* dst = (int32_t*)dst_base + r * D.dst_row_stride + d0;
-            for (int64_t q = lane; q < len; q += 64) dst[q] = src[q];
-        } else if (D.op == CWN_COLLATE_ADD32) {
-            const int32_t* src = (const int32_t*)D.src + r * D.src_row_stride + s0;
-            int32_t* dst = (int32_t*)dst_base + r * D.dst_row_stride + d0;
-            const int32_t a = (int32_t)add;
-            for (int64_t q = lane; q < len; q += 64) dst[q] = src[q] + a;
-        } else if (D.op == CWN_COLLATE_SEGID64) {
-            int64_t* dst = (int64_t*)dst_base + r * D.dst_row_stride + d0;
-            for (int64_t q = lane; q < len; q += 64) dst[q] = s;
-        } else {
-            const int64_t* src = (const int64_t*)D.src + r * D.src_row_stride + s0;
-            int64_t* dst = (int64_t*)dst_base + r * D.dst_row_stride + d0;
-            const int64_t a = D.op == CWN_COLLATE_ADD64 ? add : 0;
-            for (int64_t q = lane; q < len; q += 64) dst[q] = src[q] + a;
+    bool own = true;                                 // every group copies its own segment
+    if (SPW > 1) own = __all(len <= 8 * GL);
+    for (int g = 0; g < (own ? 1 : SPW); ++g) {
+        // (own: this lane's group and entries; otherwise the wave on the entries of group g)
+        const int64_t d0_ = own ? d0 : __shfl(d0, g * GL, 64), len_ = own ? len : __shfl(len, g * GL, 64);
+        const int64_t s0_ = own ? s0 : __shfl(s0, g * GL, 64), seg_ = own ? s : __shfl(s, g * GL, 64);
+        const int l = own ? sl : lane, step = own ? GL : 64;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r >= D.n_rows) break;
+            const int64_t a_ = own ? add[r] : __shfl(add[r], g * GL, 64);
+            if (len_ <= 0) continue;
+            if (D.op == CWN_COLLATE_COPY32 || D.op == CWN_COLLATE_ADD32) {
+                copy_seg<int32_t>((int32_t*)dst_base + r * D.dst_row_stride + d0_, (const int32_t*)D.src + r * D.src_row_stride + s0_,
+                                  len_, D.op == CWN_COLLATE_ADD32 ? (int32_t)a_ : 0, l, step);
+            } else if (D.op == CWN_COLLATE_SEGID64) {
+                fill_seg<int64_t>((int64_t*)dst_base + r * D.dst_row_stride + d0_, len_, seg_, l, step);
+            } else {
+                copy_seg<int64_t>((int64_t*)dst_base + r * D.dst_row_stride + d0_, (const int64_t*)D.src + r * D.src_row_stride + s0_,
+                                  len_, D.op == CWN_COLLATE_ADD64 ? a_ : 0, l, step);
+            }
         }
     }
 }
@@ -237,7 +271,15 @@ extern "C" int cwn_collate_slots(const cwn_collate_desc* descs, int n, int64_t n
         if ((D.op == CWN_COLLATE_ADD64 || D.op == CWN_COLLATE_ADD32) && D.add == nullptr) return CWN_ERR_BAD_ARG;
         B.d[i] = D;
     }
-    collate_kernel<<<dim3((unsigned)((n_seg + kSegPerWg - 1) / kSegPerWg), (unsigned)n, (unsigned)n_slots), dim3(kThreads), 0,
-                     (hipStream_t)stream_>>>(B, n_seg);
+    // four segments per wave where that still leaves the chip more waves than it holds (256 CUs x 32)
+    const int64_t waves1 = n_seg * n * n_slots;
+    if (waves1 >= 4 * 8192 && n_seg >= 64) {
+        constexpr int per = kSegPerWg * 4;
+        collate_kernel<4><<<dim3((unsigned)((n_seg + per - 1) / per), (unsigned)n, (unsigned)n_slots), dim3(kThreads), 0,
+                            (hipStream_t)stream_>>>(B, n_seg);
+    } else {
+        collate_kernel<1><<<dim3((unsigned)((n_seg + kSegPerWg - 1) / kSegPerWg), (unsigned)n, (unsigned)n_slots), dim3(kThreads), 0,
+                            (hipStream_t)stream_>>>(B, n_seg);
+    }
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
