@@ -70,6 +70,43 @@ def test_device_tables_equal_the_host_tables_and_the_collate_its_per_batch_form(
     csr.check_errors(DEV)
 
 
+def test_collate_of_many_small_complexes_with_a_few_large_ones_over_eight_slots():
+    """The form of the collate launch that gives a wave FOUR segments (batches of many small complexes over several slots:
+    csrc/cwn_collate.hip): tiny molecules (every 16 lanes copy their own segment), with a few large ones among them (a wave
+    that meets a long segment takes its four in turn), a short last batch (segments past the batch inside a wave) -- every
+    slot's arrays against PackedComplexes.collate of the same complexes."""
+    from cwn_amd.packed import PackedComplexes
+    from cwn_amd.static_batch import StaticBatch
+    from cwn_amd.synthetic import zinc_like_complexes
+    pool = zinc_like_complexes(1500, seed=5, max_ring=6, n_lo=3, n_hi=10) + zinc_like_complexes(40, seed=6, max_ring=6, n_lo=70, n_hi=90)
+    p = PackedComplexes(pool, DEV, max_dim=2, with_csr=True)
+    B, S = 256, 8
+    sb = StaticBatch(p, B, slots=S)
+    batches = _batches(len(pool), B, 11, sizes=[B] * 5 + [B - 3])
+    assert bool(sb.fits(batches).all())
+    sb.set_epoch(batches)
+    sb.fill()
+    torch.cuda.synchronize()
+    for j, idx in enumerate(batches):
+        slot = sb.slots[j]
+        ref = p.collate(idx)
+        n = [ref.cochains[d].num_cells for d in range(3)]
+        for d in range(3):
+            rc, sc = ref.cochains[d], slot.batch.cochains[d]
+            if rc.x is not None:
+                assert torch.equal(sc._x[:n[d]], rc.x), (j, d)
+            assert torch.equal(sc.batch[:n[d]], rc.batch), (j, d)
+            for key in ('upper_index', 'boundary_index'):
+                a = getattr(rc, key)
+                if a is not None:
+                    assert torch.equal(getattr(sc, key)[:, :a.size(1)], a), (j, d, key)
+            if rc.shared_coboundaries is not None:
+                assert torch.equal(sc.shared_coboundaries[:rc.shared_coboundaries.numel()], rc.shared_coboundaries), (j, d)
+        assert torch.equal(slot.batch.y[:len(idx)], ref.y.view(-1))
+    from cwn_amd import csr
+    csr.check_errors(DEV)
+
+
 def test_epoch_cursor_takes_the_batches_in_order():
     """set_epoch uploads the complex numbers of a whole epoch once; every fill then takes the next batch by itself (the
     device-side cursor): the tables after fill j are those of batch j."""
