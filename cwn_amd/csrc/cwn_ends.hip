@@ -46,93 +46,57 @@ struct FrontArgs {
 
 __device__ __forceinline__ int64_t clampi(int64_t v, int64_t n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
 
-// sum over the index columns of one row of a table set, 4 features at h.  An index outside its own table sets
-// bit 1 of the sticky word and contributes nothing (as cwn_embedding_fwd_f32).  LEVEL BY LEVEL: the integer features of
-// all columns, then all table rows, the adds in column order (bit-identical to the column loop).  Walked column by column
-// (round 3's first form) a row of the OGB encoders -- 9 atom columns, each a chain feature -> column size -> column offset
-// -> table row -- was ~30 dependent round trips: 65 us per launch at the molhiv batch of 512, where the launches it
-// replaced took 25.  The column layout of a table set sits in LDS (FrontLayout), staged once per workgroup.
-constexpr int kMaxCols = 16;          // the layout's bound; the kernel is instantiated for 1 (one table per cell type: ZINC) and 16
+// ---- ONE table per cell type (torch.nn.Embedding: the ZINC models): the whole front in one launch -------------------------
+// (Several tables per cell type -- the OGB encoders -- take the two launches further down: walked in this kernel a ring row
+// was 108 table rows behind a chain of seven dependent loads.)
+constexpr int kMaxCols = 16;          // columns of a table set (cwn_embed_table.cols)
 
-struct FrontLayout {                   // [0]: vertex tables, [1]: edge tables
-    int64_t off[2][kMaxCols], size[2][kMaxCols];
-};
-
-template <int MAXC>
-__device__ __forceinline__ float4 emb_row(const cwn_embed_table& T, const FrontLayout& L, int which, int64_t r, int H, int h,
-                                          int32_t* err) {
-    int64_t id[MAXC];
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        id[c] = 0;
-        if (c < T.cols)
-            id[c] = T.src_is_f32 ? (int64_t)reinterpret_cast<const float*>(T.src)[r * T.cols + c]     // .to(torch.long): truncation
-                                 : reinterpret_cast<const int64_t*>(T.src)[r * T.cols + c];
-    }
-    float4 w[MAXC];
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        w[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < T.cols) {
-            const bool ok = id[c] >= 0 && id[c] < (MAXC == 1 ? T.V : L.size[which][c]);
-            if (!ok && h == 0) atomicOr(err, 2);
-            if (ok) w[c] = *reinterpret_cast<const float4*>(T.W + (id[c] + (MAXC == 1 ? 0 : L.off[which][c])) * H + h);
-        }
-    }
+// one row of a single table, 4 features at h.  An index outside the table sets bit 1 of the sticky word and contributes
+// nothing (as cwn_embedding_fwd_f32)
+__device__ __forceinline__ float4 emb_row(const cwn_embed_table& T, int64_t r, int H, int h, int32_t* err) {
+    const int64_t id = T.src_is_f32 ? (int64_t)reinterpret_cast<const float*>(T.src)[r]     // .to(torch.long): truncation
+                                    : reinterpret_cast<const int64_t*>(T.src)[r];
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool ok = id >= 0 && id < T.V;
+    if (!ok && h == 0) atomicOr(err, 2);
+    if (ok) w = *reinterpret_cast<const float4*>(T.W + id * H + h);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-        if (c < T.cols) { acc.x += w[c].x; acc.y += w[c].y; acc.z += w[c].z; acc.w += w[c].w; }
+    acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
     return acc;
 }
 
 // the same for TWO rows at once (the two boundary vertices of an edge): features of both, then table rows of both
-template <int MAXC>
-__device__ __forceinline__ void emb_row_pair(const cwn_embed_table& T, const FrontLayout& L, int which, int64_t r0, int64_t r1, int H,
-                                             int h, int32_t* err, float4& a0, float4& a1) {
-    int64_t id[2][MAXC];
+__device__ __forceinline__ void emb_row_pair(const cwn_embed_table& T, int64_t r0, int64_t r1, int H, int h, int32_t* err, float4& a0,
+                                             float4& a1) {
+    int64_t id[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+        const int64_t r = q == 0 ? r0 : r1;
+        id[q] = T.src_is_f32 ? (int64_t)reinterpret_cast<const float*>(T.src)[r] : reinterpret_cast<const int64_t*>(T.src)[r];
+    }
+    float4 w[2];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int64_t r = q == 0 ? r0 : r1;
-            id[q][c] = 0;
-            if (c < T.cols)
-                id[q][c] = T.src_is_f32 ? (int64_t)reinterpret_cast<const float*>(T.src)[r * T.cols + c]
-                                        : reinterpret_cast<const int64_t*>(T.src)[r * T.cols + c];
-        }
-    float4 w[2][MAXC];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            w[q][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < T.cols) {
-                const bool ok = id[q][c] >= 0 && id[q][c] < (MAXC == 1 ? T.V : L.size[which][c]);
-                if (!ok && h == 0) atomicOr(err, 2);
-                if (ok) w[q][c] = *reinterpret_cast<const float4*>(T.W + (id[q][c] + (MAXC == 1 ? 0 : L.off[which][c])) * H + h);
-            }
-        }
+    for (int q = 0; q < 2; ++q) {
+        w[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = id[q] >= 0 && id[q] < T.V;
+        if (!ok && h == 0) atomicOr(err, 2);
+        if (ok) w[q] = *reinterpret_cast<const float4*>(T.W + id[q] * H + h);
+    }
     a0 = a1 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-        if (c < T.cols) {
-            a0.x += w[0][c].x; a0.y += w[0][c].y; a0.z += w[0][c].z; a0.w += w[0][c].w;
-            a1.x += w[1][c].x; a1.y += w[1][c].y; a1.z += w[1][c].z; a1.w += w[1][c].w;
-        }
+    a0.x += w[0].x; a0.y += w[0].y; a0.z += w[0].z; a0.w += w[0].w;
+    a1.x += w[1].x; a1.y += w[1].y; a1.z += w[1].z; a1.w += w[1].w;
 }
 
 // red1[e] = sum of the embedded boundary vertices of edge e, in CSR order; two boundary vertices at a time (an edge has
 // exactly two)
-template <int MAXC>
-__device__ __forceinline__ float4 reduce_edge(const FrontArgs& A, const FrontLayout& L, int64_t e, int h) {
+__device__ __forceinline__ float4 reduce_edge(const FrontArgs& A, int64_t e, int h) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (A.rowptr1 == nullptr) return acc;
     const int s = A.rowptr1[e], t = A.rowptr1[e + 1];
     for (int p = s; p < t; p += 2) {
         const int64_t v0 = clampi(A.col1[p], A.n0), v1 = clampi(A.col1[p + 1 < t ? p + 1 : p], A.n0);   // the plan build reported bad ones; never fault
         float4 w0, w1;
-        emb_row_pair<MAXC>(A.tv, L, 0, v0, v1, A.H, h, A.err, w0, w1);
+        emb_row_pair(A.tv, v0, v1, A.H, h, A.err, w0, w1);
         acc.x += w0.x; acc.y += w0.y; acc.z += w0.z; acc.w += w0.w;
         if (p + 1 < t) { acc.x += w1.x; acc.y += w1.y; acc.z += w1.z; acc.w += w1.w; }
     }
@@ -146,82 +110,52 @@ __device__ __forceinline__ float4 reduce_edge(const FrontArgs& A, const FrontLay
 // sequential walk).  An edge has two boundary vertices; further ones (any other CSR1) take the sequential tail.
 constexpr int kChunk = 8;
 
-template <int MAXC>
-__device__ __forceinline__ float4 ring_chunk(const FrontArgs& A, const FrontLayout& L, int p0, int n, int h, float4 acc) {
-    constexpr bool one_col = MAXC == 1;
+__device__ __forceinline__ float4 ring_chunk(const FrontArgs& A, int p0, int n, int h, float4 acc) {
     int64_t e[kChunk];
     int s1[kChunk], t1[kChunk];
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) e[u] = clampi(A.col2[p0 + (u < n ? u : 0)], A.n1);
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) { s1[u] = A.rowptr1[e[u]]; t1[u] = A.rowptr1[e[u] + 1]; }
-    if constexpr (one_col) {
-        // one table (ZINC): vertex numbers, integer features and table rows of both endpoints of every edge, level by level
-        int64_t v[kChunk][2], id[kChunk][2];
-        float4 w[kChunk][2];
+    // vertex numbers, integer features and table rows of both endpoints of every edge, level by level
+    int64_t v[kChunk][2], id[kChunk][2];
+    float4 w[kChunk][2];
 #pragma unroll
-        for (int u = 0; u < kChunk; ++u)
+    for (int u = 0; u < kChunk; ++u)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) v[u][q] = clampi(A.col1[s1[u] + q < t1[u] ? s1[u] + q : (t1[u] > s1[u] ? t1[u] - 1 : 0)], A.n0);
+        for (int q = 0; q < 2; ++q) v[u][q] = clampi(A.col1[s1[u] + q < t1[u] ? s1[u] + q : (t1[u] > s1[u] ? t1[u] - 1 : 0)], A.n0);
 #pragma unroll
-        for (int u = 0; u < kChunk; ++u)
+    for (int u = 0; u < kChunk; ++u)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                id[u][q] = A.tv.src_is_f32 ? (int64_t)reinterpret_cast<const float*>(A.tv.src)[v[u][q]]
-                                           : reinterpret_cast<const int64_t*>(A.tv.src)[v[u][q]];
+        for (int q = 0; q < 2; ++q)
+            id[u][q] = A.tv.src_is_f32 ? (int64_t)reinterpret_cast<const float*>(A.tv.src)[v[u][q]]
+                                       : reinterpret_cast<const int64_t*>(A.tv.src)[v[u][q]];
 #pragma unroll
-        for (int u = 0; u < kChunk; ++u)
+    for (int u = 0; u < kChunk; ++u)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const bool ok = id[u][q] >= 0 && id[u][q] < A.tv.V;
-                if (!ok && h == 0 && u < n && s1[u] + q < t1[u]) atomicOr(A.err, 2);
-                w[u][q] = *reinterpret_cast<const float4*>(A.tv.W + (ok ? id[u][q] : 0) * A.H + h);
-                if (!ok) w[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-        for (int u = 0; u < kChunk; ++u) {
-            if (u >= n) break;
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (s1[u] + q < t1[u]) { r.x += w[u][q].x; r.y += w[u][q].y; r.z += w[u][q].z; r.w += w[u][q].w; }
-            for (int p = s1[u] + 2; p < t1[u]; ++p) {                   // not a 1-cell's boundary: the plain walk
-                const float4 x = emb_row<MAXC>(A.tv, L, 0, clampi(A.col1[p], A.n0), A.H, h, A.err);
-                r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
-            }
-            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        for (int q = 0; q < 2; ++q) {
+            const bool ok = id[u][q] >= 0 && id[u][q] < A.tv.V;
+            if (!ok && h == 0 && u < n && s1[u] + q < t1[u]) atomicOr(A.err, 2);
+            w[u][q] = *reinterpret_cast<const float4*>(A.tv.W + (ok ? id[u][q] : 0) * A.H + h);
+            if (!ok) w[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    } else {
-        // several tables per vertex (OGB): the vertex numbers of all edges of the chunk first, then edge by edge both
-        // endpoints at once (features of both, table rows of both)
-        int64_t v[kChunk][2];
 #pragma unroll
-        for (int u = 0; u < kChunk; ++u)
+    for (int u = 0; u < kChunk; ++u) {
+        if (u >= n) break;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) v[u][q] = clampi(A.col1[s1[u] + q < t1[u] ? s1[u] + q : (t1[u] > s1[u] ? t1[u] - 1 : 0)], A.n0);
-#pragma unroll
-        for (int u = 0; u < kChunk; ++u) {
-            if (u >= n) break;
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t1[u] > s1[u]) {
-                float4 w0, w1;
-                emb_row_pair<MAXC>(A.tv, L, 0, v[u][0], v[u][1], A.H, h, A.err, w0, w1);
-                r = w0;
-                if (s1[u] + 1 < t1[u]) { r.x += w1.x; r.y += w1.y; r.z += w1.z; r.w += w1.w; }
-            }
-            for (int p = s1[u] + 2; p < t1[u]; ++p) {                   // not a 1-cell's boundary: the plain walk
-                const float4 x = emb_row<MAXC>(A.tv, L, 0, clampi(A.col1[p], A.n0), A.H, h, A.err);
-                r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
-            }
-            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        for (int q = 0; q < 2; ++q)
+            if (s1[u] + q < t1[u]) { r.x += w[u][q].x; r.y += w[u][q].y; r.z += w[u][q].z; r.w += w[u][q].w; }
+        for (int p = s1[u] + 2; p < t1[u]; ++p) {                   // not a 1-cell's boundary: the plain walk
+            const float4 x = emb_row(A.tv, clampi(A.col1[p], A.n0), A.H, h, A.err);
+            r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
         }
+        acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
     }
     return acc;
 }
 
-template <int MAXC>
 __global__ __launch_bounds__(256) void embed_front_kernel(FrontArgs A) {
-    __shared__ FrontLayout L;
     // device-side row counts: the ROW -> (dimension, cell) mapping below follows the capacities (the grid was sized with
     // them); a cell past its dimension's actual count leaves
     // (the index clamps of the reductions keep the capacities: they are there so that no address leaves the buffers)
@@ -233,16 +167,6 @@ __global__ __launch_bounds__(256) void embed_front_kernel(FrontArgs A) {
         live1 = d1 < live1 ? d1 : live1;
         live2 = d2 < live2 ? d2 : live2;
     }
-    if constexpr (MAXC > 1) {            // (one table per cell type: its size is T.V, no offsets -- nothing to stage)
-        if (threadIdx.x < 2 * kMaxCols) {
-            const int which = threadIdx.x / kMaxCols, c = threadIdx.x % kMaxCols;
-            const cwn_embed_table& T = which == 0 ? A.tv : A.te;
-            const bool on = (which == 0 || A.has_te) && c < T.cols;
-            L.off[which][c] = on && T.col_off != nullptr ? T.col_off[c] : 0;
-            L.size[which][c] = on ? (T.col_size != nullptr ? T.col_size[c] : T.V) : 0;
-        }
-        __syncthreads();
-    }
     const int G = A.G, gl = threadIdx.x & (G - 1);
     const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
     if (row >= cap0 + cap1 + A.n2) return;
@@ -251,23 +175,149 @@ __global__ __launch_bounds__(256) void embed_front_kernel(FrontArgs A) {
         float4 v;
         float* dst;
         if (row < cap0) {
-            v = emb_row<MAXC>(A.tv, L, 0, row, A.H, h, A.err);
+            v = emb_row(A.tv, row, A.H, h, A.err);
             dst = A.x0 + row * A.H + h;
         } else if (row < cap0 + cap1) {
             const int64_t e = row - cap0;
-            v = A.has_te ? emb_row<MAXC>(A.te, L, 1, e, A.H, h, A.err) : reduce_edge<MAXC>(A, L, e, h);
+            v = A.has_te ? emb_row(A.te, e, A.H, h, A.err) : reduce_edge(A, e, h);
             dst = A.x1 + e * A.H + h;
         } else {
             const int64_t r = row - cap0 - cap1;
             v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (A.rowptr2 != nullptr && A.rowptr1 != nullptr) {
                 const int s = A.rowptr2[r], t = A.rowptr2[r + 1];
-                for (int p = s; p < t; p += kChunk) v = ring_chunk<MAXC>(A, L, p, min(kChunk, t - p), h, v);
+                for (int p = s; p < t; p += kChunk) v = ring_chunk(A, p, min(kChunk, t - p), h, v);
             }
             if (A.halve) { v.x *= 0.5f; v.y *= 0.5f; v.z *= 0.5f; v.w *= 0.5f; }
             dst = A.x2 + r * A.H + h;
         }
         cwn::store_result4(dst, v.x, v.y, v.z, v.w);
+    }
+}
+
+// ---- several tables per cell type (the OGB encoders: 9 atom + 3 bond columns): the reductions read x0 ----------------------
+// In one launch a ring row walks 12 vertices of 9 columns each (108 table rows behind a chain of seven dependent loads): 44 - 60
+// us at the molhiv batch of 512, against ~25 for the separate launches it was meant to replace.  Two launches instead: the
+// embeddings of both cell types by embed_pair_kernel (rows of dimensions 0 and 1 only), then THIS kernel for the rows
+// that reduce -- edges without a table of their own, rings -- from the x0 rows the first launch wrote (in L2):
+//     x1[e] = sum_{v in row e of CSR1} x0[v]                        (no edge table)
+//     x2[r] = (halve ? 1/2 : 1) sum_{e in row r of CSR2} (sum_{v in row e of CSR1} x0[v])
+// the adds in CSR order, every level of a chunk of kChunk edges requested before the next needs it -- bit-identical to the
+// separate launches (an x0 row IS the column sum they make).
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// the embeddings of both cell types in one launch, the columns of a row in a plain loop (cwn_embedding_fwd_f32's walk: the
+// 16-column form of embed_front_kernel that round 3 unrolled held 116 registers and took 22 us for the rows this takes 10 for)
+__device__ __forceinline__ float4 embed_cols(const float* __restrict__ W, const void* __restrict__ src, const int64_t* __restrict__ col_off,
+                                             const int64_t* __restrict__ col_size, int64_t V, int cols, bool f32, int64_t r, int H, int h,
+                                             int32_t* err) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < cols; ++c) {
+        int64_t v = f32 ? (int64_t)reinterpret_cast<const float*>(src)[r * cols + c] : reinterpret_cast<const int64_t*>(src)[r * cols + c];
+        const int64_t lim = col_size != nullptr ? col_size[c] : V;   // per TABLE, not per concatenation
+        if (v < 0 || v >= lim) {
+            if (h == 0) atomicOr(err, 2);
+            continue;
+        }
+        if (col_off != nullptr) v += col_off[c];
+        const float4 w = ld4(W + v * H + h);
+        acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void embed_pair_kernel(FrontArgs A) {
+    const int64_t cap0 = A.n0, cap1 = A.has_te ? A.n1 : 0;
+    int64_t live0 = cap0, live1 = cap1;
+    if (A.n_dev != nullptr) {
+        const int64_t d0 = A.n_dev[0], d1 = A.n_dev[1];
+        live0 = d0 < live0 ? d0 : live0;
+        live1 = d1 < live1 ? d1 : live1;
+    }
+    const int G = A.G, gl = threadIdx.x & (G - 1);
+    const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    if (row >= cap0 + cap1) return;
+    if (row < cap0 ? row >= live0 : row - cap0 >= live1) return;
+    for (int h = 4 * gl; h < A.H; h += 4 * G) {
+        if (row < cap0) {
+            const float4 v = embed_cols(A.tv.W, A.tv.src, A.tv.col_off, A.tv.col_size, A.tv.V, A.tv.cols, A.tv.src_is_f32 != 0, row, A.H, h, A.err);
+            cwn::store_result4(A.x0 + row * A.H + h, v.x, v.y, v.z, v.w);
+        } else {
+            const int64_t e = row - cap0;
+            const float4 v = embed_cols(A.te.W, A.te.src, A.te.col_off, A.te.col_size, A.te.V, A.te.cols, A.te.src_is_f32 != 0, e, A.H, h, A.err);
+            cwn::store_result4(A.x1 + e * A.H + h, v.x, v.y, v.z, v.w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void front_reduce_kernel(FrontArgs A) {
+    const int64_t cap1 = A.has_te ? 0 : A.n1;          // edge rows of this launch
+    int64_t live0 = A.n0, live1 = A.n1, live2 = A.n2;
+    if (A.n_dev != nullptr) {
+        const int64_t d0 = A.n_dev[0], d1 = A.n_dev[1], d2 = A.n_dev[2];
+        live0 = d0 < live0 ? d0 : live0;
+        live1 = d1 < live1 ? d1 : live1;
+        live2 = d2 < live2 ? d2 : live2;
+    }
+    const int G = A.G, gl = threadIdx.x & (G - 1);
+    const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    if (row >= cap1 + A.n2) return;
+    if (row < cap1 ? row >= live1 : row - cap1 >= live2) return;
+    for (int h = 4 * gl; h < A.H; h += 4 * G) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* dst;
+        if (row < cap1) {
+            dst = A.x1 + row * A.H + h;
+            if (A.rowptr1 != nullptr) {
+                const int s = A.rowptr1[row], t = A.rowptr1[row + 1];
+                for (int p = s; p < t; p += 2) {
+                    const int64_t v0 = clampi(A.col1[p], A.n0), v1 = clampi(A.col1[p + 1 < t ? p + 1 : p], A.n0);
+                    const float4 w0 = ld4(A.x0 + v0 * A.H + h), w1 = ld4(A.x0 + v1 * A.H + h);
+                    acc.x += w0.x; acc.y += w0.y; acc.z += w0.z; acc.w += w0.w;
+                    if (p + 1 < t) { acc.x += w1.x; acc.y += w1.y; acc.z += w1.z; acc.w += w1.w; }
+                }
+            }
+        } else {
+            const int64_t r = row - cap1;
+            dst = A.x2 + r * A.H + h;
+            if (A.rowptr2 != nullptr && A.rowptr1 != nullptr) {
+                const int s2 = A.rowptr2[r], t2 = A.rowptr2[r + 1];
+                for (int p0 = s2; p0 < t2; p0 += kChunk) {
+                    const int n = min(kChunk, t2 - p0);
+                    int64_t e[kChunk], v[kChunk][2];
+                    int s1[kChunk], t1[kChunk];
+                    float4 w[kChunk][2];
+#pragma unroll
+                    for (int u = 0; u < kChunk; ++u) e[u] = clampi(A.col2[p0 + (u < n ? u : 0)], A.n1);
+#pragma unroll
+                    for (int u = 0; u < kChunk; ++u) { s1[u] = A.rowptr1[e[u]]; t1[u] = A.rowptr1[e[u] + 1]; }
+#pragma unroll
+                    for (int u = 0; u < kChunk; ++u)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            v[u][q] = clampi(A.col1[s1[u] + q < t1[u] ? s1[u] + q : (t1[u] > s1[u] ? t1[u] - 1 : 0)], A.n0);
+#pragma unroll
+                    for (int u = 0; u < kChunk; ++u)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) w[u][q] = ld4(A.x0 + v[u][q] * A.H + h);
+#pragma unroll
+                    for (int u = 0; u < kChunk; ++u) {
+                        if (u >= n) break;
+                        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            if (s1[u] + q < t1[u]) { x.x += w[u][q].x; x.y += w[u][q].y; x.z += w[u][q].z; x.w += w[u][q].w; }
+                        for (int p = s1[u] + 2; p < t1[u]; ++p) {                   // not a 1-cell's boundary: the plain walk
+                            const float4 y = ld4(A.x0 + clampi(A.col1[p], A.n0) * A.H + h);
+                            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+                        }
+                        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+                    }
+                }
+            }
+            if (A.halve) { acc.x *= 0.5f; acc.y *= 0.5f; acc.z *= 0.5f; acc.w *= 0.5f; }
+        }
+        cwn::store_result4(dst, acc.x, acc.y, acc.z, acc.w);
     }
 }
 
@@ -725,8 +775,15 @@ extern "C" int cwn_embed_front_f32(const cwn_embed_table* v_tab, int64_t n0, flo
     const int64_t rows = n0 + n1 + n2, per = 256 / G, blocks = (rows + per - 1) / per;
     if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
     const bool single = A.tv.cols == 1 && (!A.has_te || A.te.cols == 1);
-    if (single) embed_front_kernel<1><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(A);
-    else embed_front_kernel<kMaxCols><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(A);
+    if (single) {
+        embed_front_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(A);
+        return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+    }
+    // several tables per cell type: the embeddings, then the rows that reduce from x0 (front_reduce_kernel)
+    const int64_t e_rows = n0 + (A.has_te ? n1 : 0), e_blocks = (e_rows + per - 1) / per;
+    if (e_rows > 0) embed_pair_kernel<<<dim3((unsigned)e_blocks), dim3(256), 0, (hipStream_t)stream_>>>(A);
+    const int64_t r_rows = (A.has_te ? 0 : n1) + n2, r_blocks = (r_rows + per - 1) / per;
+    if (r_rows > 0) front_reduce_kernel<<<dim3((unsigned)r_blocks), dim3(256), 0, (hipStream_t)stream_>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }
 

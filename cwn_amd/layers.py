@@ -201,6 +201,7 @@ class ByModule:
 # prepared launches per (layer module, batch): kept OUTSIDE the modules (ctypes records do not deepcopy / pickle)
 _BLOCKED_CACHE = ByModule()
 _MLP_CACHE = ByModule()            # layer module -> (ops.MlpLaunch, (start, dims, outputs), BatchNorm modules)
+FUSED_OGB_FRONT = os.environ.get('CWN_FUSED_OGB_FRONT', '1') != '0'      # (A/B: '0' = the separate launches of the OGB encoders' front)
 _FRONT_CACHE = ByModule()          # embedding front module -> {id(boundary_index_1): (ops.FrontLaunch, (rings?, reduce))}
 
 
@@ -1796,12 +1797,14 @@ class AbstractEmbedVEWithReduce(torch.nn.Module, ABC):
         et = _embedding_tables(self.e_embed_layer) if e_params.x is not None else None
         if vt is None or (e_params.x is not None and et is None):
             return None
-        if len(vt) > 1 or (et is not None and len(et) > 1):
-            # OGB-style encoders (a table per integer feature column: 9 + 3 at molhiv): the one-launch form is SLOWER there
-            # -- 44 - 60 us per launch at the molhiv batch of 512 against ~25 for the separate launches (every vertex row
-            # walks nine columns, every ring row twelve vertices of nine); measured, so the separate launches keep it
-            return None
         train = torch.is_grad_enabled() and any(w.requires_grad for w in vt + (et or []))
+        if (len(vt) > 1 or (et is not None and len(et) > 1)) and not FUSED_OGB_FRONT:
+            # OGB-style encoders (a table per integer feature column: 9 + 3 at molhiv).  ONE launch is slower there (44 - 60
+            # us at the molhiv batch of 512: every ring row walks twelve vertices of nine columns), so cwn_embed_front_f32
+            # makes it two -- the embeddings of both cell types, then the reductions from the x0 rows (round 6: 15 us against
+            # the 40 us of the seven separate launches; in training the same forward behind ops._EmbedFrontTrain, whose
+            # backward is the launches the separate path's autograd ran).
+            return None
         if train and not ops.FUSED_FRONT_TRAINING:
             return None
         H = int(vt[0].size(1))

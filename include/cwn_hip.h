@@ -1139,6 +1139,9 @@ int cwn_embed_front_bwd_f32(const cwn_front_bwd* args_host, cwn_stream_t stream)
  * int32; nb1 / nb2 = their entry counts; a NULL pair or no entries = no reduction: zeros); sums run in CSR (= entry)
  * order.  H % 4 == 0; outputs [n_d, H]
  * contiguous, 16-B aligned.  An index outside its own table sets bit 1 of *err_flag and contributes nothing.
+ * One launch when every table set is one table (torch.nn.Embedding: ZINC); table sets of several columns (the OGB
+ * encoders, 9 + 3 at molhiv) take two on the same stream -- the embeddings of both cell types, then the rows that reduce,
+ * from the x0 rows just written -- with the same results (x0 must not alias x1 / x2).
  * ------------------------------------------------------------------------------------------ */
 typedef struct cwn_embed_table {
     const float* W;            /* [V, H]: the row-wise concatenation of the tables */
