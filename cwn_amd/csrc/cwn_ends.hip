@@ -567,34 +567,52 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs A) {
 // of the rows of complex c in every dimension -- K / 4 lanes a row, row groups side by side, four rows in flight per group, the
 // groups' partials summed in group order -- and stores [CWN_HEAD_MAX_DIMS][K] floats.  A REDDIT-like complex has ~4 000 cells
 // of 1 KiB (4 layers x 64 under jumping knowledge): one workgroup pulled 4 MB through its CU in 68 us while 224 CUs idled.
-__global__ __launch_bounds__(kHeadThreads) void head_pool_kernel(HeadArgs A) {
+// One workgroup per SLOT of the partials (slot_base[d] + lo / chunk + c + j = chunk j of complex c in dimension d; the gaps of
+// that numbering -- at most C + 1 per dimension -- leave at once): the slot's complex by a binary search over the `ptr` table
+// (in LDS while it fits), then the chunk's 128 rows.  (Until round 6 the grid was (complex, P): a launch lasted as long as the
+// LARGEST complex's chunks over P workgroups -- REDDIT-32, sizes 1 : 3 across a batch: 40 us, most workgroups idle.)
+constexpr int kPoolPtrLds = 2048;                 // `ptr` entries staged in LDS (int64); beyond: searched in global memory
+
+__global__ __launch_bounds__(kHeadThreads) void head_pool_kernel(HeadArgs A, int64_t n_slots) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int K = A.K, nd = A.n_dims, P = A.pool_split;
+    const int K = A.K, nd = A.n_dims;
     float* const part = sm;                                  // [NG][K]
+    int64_t* const ptr_lds = reinterpret_cast<int64_t*>(sm + kPartFloats);
     const int tid = threadIdx.x;
-    const int64_t c = blockIdx.x;
-    const int p = blockIdx.y;
+    const int64_t s = blockIdx.x;
+    if (s >= n_slots) return;
+    const int d = (nd > 2 && s >= A.slot_base[2]) ? 2 : ((nd > 1 && s >= A.slot_base[1]) ? 1 : 0);
+    if (A.d[d].x == nullptr || A.d[d].n_cells <= 0) return;                                  // (uniform)
+    const int64_t local = s - A.slot_base[d], n_cells = A.d[d].n_cells, C = A.C;
+    const int64_t* cp = A.d[d].cell_ptr;
+    if (C + 1 <= kPoolPtrLds) {
+        for (int64_t i = tid; i <= C; i += kHeadThreads) ptr_lds[i] = cp[i];
+        __syncthreads();
+        cp = ptr_lds;
+    }
+    auto clamp_lo = [&](int64_t v) { return v < 0 ? 0 : (v > n_cells ? n_cells : v); };
+    // the last complex whose first slot (lo / chunk + c, increasing in c) is not beyond this one
+    int64_t c0 = 0, c1 = C - 1;
+    while (c0 < c1) {
+        const int64_t m = (c0 + c1 + 1) >> 1;
+        if (clamp_lo(cp[m]) / kHeadChunk + m <= local) c0 = m; else c1 = m - 1;
+    }
+    const int64_t c = c0;
+    const int64_t lo = clamp_lo(cp[c]), h1 = cp[c + 1];
+    const int64_t hi = h1 < lo ? lo : (h1 > n_cells ? n_cells : h1);
+    const int64_t j = local - (lo / kHeadChunk + c);
+    if (j < 0 || j >= (hi - lo + kHeadChunk - 1) / kHeadChunk) return;                       // a gap of the numbering (uniform)
     const int G = K / 4, NG = kHeadThreads / G;
     const int g = tid / G, l = tid - g * G;
-    for (int d = 0; d < nd; ++d) {
-        if (A.d[d].x == nullptr || A.d[d].n_cells <= 0) continue;                        // (uniform)
-        const int64_t s0 = A.d[d].cell_ptr[c], s1 = A.d[d].cell_ptr[c + 1];
-        const int64_t lo = s0 < 0 ? 0 : (s0 > A.d[d].n_cells ? A.d[d].n_cells : s0);
-        const int64_t hi = s1 < lo ? lo : (s1 > A.d[d].n_cells ? A.d[d].n_cells : s1);
-        const int64_t nch = (hi - lo + kHeadChunk - 1) / kHeadChunk;
-        const int Kp = A.d[d].n_parts > 1 ? K / A.d[d].n_parts : K;
-        float* const out = A.partials + (size_t)(A.slot_base[d] + lo / kHeadChunk + c) * K;
-        for (int64_t j = p; j < nch; j += P) {                                           // this workgroup's chunks
-            const int64_t a = lo + j * kHeadChunk, b = a + kHeadChunk < hi ? a + kHeadChunk : hi;
-            if (g < NG) *reinterpret_cast<float4*>(part + (size_t)g * K + 4 * l) = head_group_sum(A.d[d], a, b, g, NG, l, Kp);
-            __syncthreads();
-            for (int k = tid; k < K; k += kHeadThreads) {
-                float t = 0.f;
-                for (int q = 0; q < NG; ++q) t += part[(size_t)q * K + k];                // group order
-                out[(size_t)j * K + k] = t;
-            }
-            __syncthreads();
-        }
+    const int Kp = A.d[d].n_parts > 1 ? K / A.d[d].n_parts : K;
+    const int64_t a = lo + j * kHeadChunk, b = a + kHeadChunk < hi ? a + kHeadChunk : hi;
+    if (g < NG) *reinterpret_cast<float4*>(part + (size_t)g * K + 4 * l) = head_group_sum(A.d[d], a, b, g, NG, l, Kp);
+    __syncthreads();
+    float* const out = A.partials + (size_t)s * K;
+    for (int k = tid; k < K; k += kHeadThreads) {
+        float t = 0.f;
+        for (int q = 0; q < NG; ++q) t += part[(size_t)q * K + k];                            // group order
+        out[k] = t;
     }
 }
 
@@ -841,9 +859,13 @@ extern "C" int cwn_head_f32(const cwn_head_dim* dims, int n_dims, int64_t C, int
     }
     const size_t lds = head_lds_floats(K, H2) * sizeof(float);
     if (lds > 64 * 1024) return CWN_ERR_BAD_ARG;
-    if (pool_partials != nullptr)
-        head_pool_kernel<<<dim3((unsigned)C, (unsigned)pool_split), dim3(kHeadThreads), (size_t)kPartFloats * sizeof(float),
-                           (hipStream_t)stream_>>>(A);
+    if (pool_partials != nullptr) {
+        int64_t n_slots = 0;
+        for (int d = 0; d < n_dims; ++d) n_slots += dims[d].n_cells / kHeadChunk + C + 1;
+        if (n_slots >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+        head_pool_kernel<<<dim3((unsigned)n_slots), dim3(kHeadThreads), (size_t)kPartFloats * sizeof(float) + kPoolPtrLds * sizeof(int64_t),
+                           (hipStream_t)stream_>>>(A, n_slots);
+    }
     head_kernel<<<dim3((unsigned)C), dim3(kHeadThreads), lds, (hipStream_t)stream_>>>(A);
     return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
 }

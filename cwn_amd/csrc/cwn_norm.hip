@@ -868,26 +868,43 @@ __global__ __launch_bounds__(256) void embedding_bwd_cols_kernel(const float* __
     __syncthreads();
     constexpr int kG = 256 / H > 0 ? 256 / H : 1;                   // feature groups (H = 64: 4, 128: 2, 256: 1)
     const int h = tid % H, q = tid / H;
-    for (int c = 0; c < cols; ++c) {
-        const int64_t lim = col_size != nullptr ? col_size[c] : V, off = col_off != nullptr ? col_off[c] : 0;
-        int64_t id = lane < n ? emb_index(src, src_f32, (r0 + lane) * cols + c) : -1;     // every wave holds all 64 cells
-        if (id < 0 || id >= lim) id = -1;                                                  // (flagged by the forward)
-        unsigned long long todo = __ballot(id >= 0);
-        int it = 0;
-        while (todo != 0ull) {                                                             // (uniform across the workgroup)
-            const int leader = __builtin_ctzll(todo);
-            const int64_t v = __shfl(id, leader, 64);
-            const unsigned long long bal = __ballot(id == v);
-            todo &= ~bal;
-            if ((it++ % kG) != q) continue;
-            unsigned long long m = bal;
-            float acc = 0.f;
-            while (m != 0ull) {
-                const int r = __builtin_ctzll(m);
-                m &= m - 1ull;
-                acc += rows[r][h];
+    // the indices of kColChunk columns are REQUESTED together (with their table bounds) before the first is walked: a column's
+    // walk ends in atomics, which the compiler will not move a load across (molhiv-512: bond tables 18.5 -> 13.9 us, atom tables
+    // 31 -> 29: what is left there is the ~650 k global atomics of the launch -- splitting a value's cells over the feature
+    // groups instead of the values, four times the atomics, took 56 us)
+    constexpr int kColChunk = 8;
+    for (int c0 = 0; c0 < cols; c0 += kColChunk) {
+        int64_t ids[kColChunk], lims[kColChunk], offs[kColChunk];
+#pragma unroll
+        for (int u = 0; u < kColChunk; ++u) {
+            const int c = c0 + u < cols ? c0 + u : cols - 1;
+            ids[u] = lane < n ? emb_index(src, src_f32, (r0 + lane) * cols + c) : -1;     // every wave holds all 64 cells
+            lims[u] = col_size != nullptr ? col_size[c] : V;
+            offs[u] = col_off != nullptr ? col_off[c] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kColChunk; ++u) {
+            if (c0 + u >= cols) break;                                                         // (uniform)
+            int64_t id = ids[u];
+            const int64_t off = offs[u];
+            if (id < 0 || id >= lims[u]) id = -1;                                              // (flagged by the forward)
+            unsigned long long todo = __ballot(id >= 0);
+            int it = 0;
+            while (todo != 0ull) {                                                             // (uniform across the workgroup)
+                const int leader = __builtin_ctzll(todo);
+                const int64_t v = __shfl(id, leader, 64);
+                const unsigned long long bal = __ballot(id == v);
+                todo &= ~bal;
+                if ((it++ % kG) != q) continue;
+                unsigned long long m = bal;
+                float acc = 0.f;
+                while (m != 0ull) {
+                    const int r = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    acc += rows[r][h];
+                }
+                if (acc != 0.f) atomicAdd(dW + (size_t)(off + v) * H + h, acc);
             }
-            if (acc != 0.f) atomicAdd(dW + (size_t)(off + v) * H + h, acc);
         }
     }
 }

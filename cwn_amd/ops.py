@@ -942,6 +942,7 @@ def head_split(rows_total: int, n_complexes: int) -> int:
     if per < 512 or n_complexes >= 512:
         return 1
     # (one 128-row chunk per workgroup and dimension where the chip has room: REDDIT-32 forward 0.340 -> 0.332 ms against two)
+    # (the pooling launch only asks whether this is > 1: it runs one workgroup per 128-row chunk of the whole batch)
     return int(max(1, min(32, min(per // 128, -(-1024 // n_complexes)))))
 
 

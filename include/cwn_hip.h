@@ -1198,8 +1198,9 @@ enum { CWN_HEAD_DROP_NONE = 0, CWN_HEAD_DROP_LIN1 = 1, CWN_HEAD_DROP_FINAL = 2, 
  * every (512 / (K / 4))-th row one after the other and are added in group order; chunk sums are added in chunk order -- the same
  * bits whichever launch forms them.  pool_partials / pool_split (round 5): LARGE complexes (REDDIT-like: thousands of cells per
  * complex, 32 complexes per batch -- one workgroup per complex pulled 4 MB through one CU): with pool_partials (device fp32,
- * at least cwn_head_pool_floats(...) floats) a first launch of C x pool_split workgroups writes the chunk sums (workgroup (c, p):
- * chunks p, p + P, ... of complex c; plain stores) and the head launch adds them in chunk order instead of reading the rows.
+ * at least cwn_head_pool_floats(...) floats) and pool_split > 1 a first launch writes the chunk sums -- one workgroup per
+ * chunk of the whole batch (round 6; before: C x pool_split workgroups, a launch as long as the largest complex), plain
+ * stores -- and the head launch adds them in chunk order instead of reading the rows.
  * NULL: one launch, which sums a large complex chunk by chunk itself (the same result). */
 #define CWN_HEAD_CHUNK 128
 int64_t cwn_head_pool_floats(const cwn_head_dim* dims_host, int n_dims, int64_t C, int32_t K);
