@@ -17,11 +17,11 @@ MAX_DESCS = 8
 CSR_MAX_DESCS = 16             # = CWN_CSR_MAX_DESCS
 MSG_A, MSG_A_PLUS_B, MSG_A_TIMES_B, MSG_RELU_A_PLUS_B, MSG_A_MASK_RELU = range(5)
 REDUCE = {'add': 0, 'sum': 0, 'mean': 1, 'max': 2}
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 EXPORTS = ('cwn_abi_version', 'cwn_error_string', 'cwn_target_arch', 'cwn_csr_workspace_bytes',
            'cwn_csr_build', 'cwn_csr_long_rows', 'cwn_gather_rows_f32', 'cwn_aggregate_f32', 'cwn_gemm_f32', 'cwn_gemm_would_split', 'cwn_gemm_packed_weight_bytes', 'cwn_gemm_pack_weights_f32', 'cwn_update_mlp_f32', 'cwn_update_mlp3_f32', 'cwn_update_mlp_max_rows', 'cwn_update_mlp_packed_weight_bytes', 'cwn_update_mlp_pack_weights_f32', 'cwn_update_mlp_pack_weights_many_f32', 'cwn_update_mlp_pack_weights_t_many_f32', 'cwn_update_mlp_pack_weights_both_many_f32', 'cwn_layer_pack_weights_both_many_f32', 'cwn_dense_stage_f32', 'cwn_dense_stage_ex_f32', 'cwn_dense_stage_bwd_f32', 'cwn_layer_fused_f32', 'cwn_layer_fused_lds_bytes', 'cwn_layer_variant_lds_bytes', 'cwn_layer_round_rows', 'cwn_layer_variant_round_rows', 'cwn_layer_items_check', 'cwn_layer_items_build', 'cwn_layer_pack_weights_f32', 'cwn_layer_pack_weights_many_f32', 'cwn_layer_pack_weights_t_many_f32', 'cwn_layer_bwd_f32', 'cwn_layer_bwd_lds_bytes', 'cwn_layer_bwd_items_build', 'cwn_layer_bwd_own_f32', 'cwn_layer_packed_weight_bytes', 'cwn_collate', 'cwn_collate_slots', 'cwn_collate_tables', 'cwn_collate_tables_len', 'cwn_collate_guard', 'cwn_layer_items_build_dev', 'cwn_layer_bwd_items_build_dev',
-           'cwn_bn_finalize_f32', 'cwn_step_begin', 'cwn_dropout_f32', 'cwn_embed_front_bwd_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
+           'cwn_bn_finalize_f32', 'cwn_step_begin', 'cwn_axpy_eps_f32', 'cwn_dropout_f32', 'cwn_embed_front_bwd_f32', 'cwn_norm_act_f32', 'cwn_norm_bwd_reduce_f32', 'cwn_norm_bwd_apply_f32', 'cwn_norm_bwd_f32',
            'cwn_gemm_tn_f32', 'cwn_gemm_tn_workspace_bytes', 'cwn_adam_f32', 'cwn_loss_f32', 'cwn_loss_cols_f32', 'cwn_embedding_fwd_f32', 'cwn_embedding_bwd_f32', 'cwn_embed_front_f32', 'cwn_head_f32', 'cwn_head_bwd_f32', 'cwn_head_pool_floats', 'cwn_lift_create', 'cwn_lift_size', 'cwn_lift_copy', 'cwn_lift_destroy',
            'cwn_lift_many', 'cwn_lift_many_count', 'cwn_lift_many_lengths', 'cwn_lift_many_copy', 'cwn_lift_many_destroy')
 
@@ -49,6 +49,14 @@ class LongRowsDesc(C.Structure):
     """cwn_long_rows_desc (include/cwn_hip.h)."""
     _fields_ = [('rowptr', C.c_void_p), ('n_rows', C.c_int64), ('m_dev', C.c_void_p), ('long_rows', C.c_void_p),
                 ('n_long', C.c_void_p), ('long_cap', C.c_int64)]
+
+
+AXPY_MAX_DESCS = 8             # CWN_AXPY_MAX_DESCS
+
+
+class AxpyDesc(C.Structure):
+    """cwn_axpy_desc (include/cwn_hip.h)."""
+    _fields_ = [('y', C.c_void_p), ('x', C.c_void_p), ('eps', C.c_void_p), ('n', C.c_int64)]
 
 
 class GemmBnb(C.Structure):
@@ -379,6 +387,8 @@ def lib():
                                                 C.c_void_p]
     L.cwn_embed_front_bwd_f32.restype = C.c_int
     L.cwn_embed_front_bwd_f32.argtypes = [C.POINTER(FrontBwd), C.c_void_p]
+    L.cwn_axpy_eps_f32.restype = C.c_int
+    L.cwn_axpy_eps_f32.argtypes = [C.POINTER(AxpyDesc), C.c_int, C.c_void_p]
     L.cwn_step_begin.restype = C.c_int
     L.cwn_step_begin.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cwn_dropout_f32.restype = C.c_int

@@ -596,6 +596,64 @@ __global__ __launch_bounds__(256) void step_begin_kernel(uint4* __restrict__ a, 
 }
 }  // namespace
 
+// ---- y += (1 + eps) x, several vectors per launch (include/cwn_hip.h: cwn_axpy_eps_f32) --------------------------------------
+namespace {
+constexpr int kAxpyThreads = 256, kAxpyPer = 4;            // float4 per thread
+struct AxpyBatch {
+    cwn_axpy_desc d[CWN_AXPY_MAX_DESCS];
+    int32_t blk_start[CWN_AXPY_MAX_DESCS + 1];
+    int32_t n;
+};
+__global__ __launch_bounds__(kAxpyThreads) void axpy_eps_kernel(AxpyBatch B) {
+    int di = 0;
+#pragma unroll
+    for (int i = 1; i < CWN_AXPY_MAX_DESCS; ++i)
+        if (i < B.n && (int)blockIdx.x >= B.blk_start[i]) di = i;
+    const cwn_axpy_desc& D = B.d[di];
+    const float s = 1.0f + (D.eps != nullptr ? *D.eps : 0.f);
+    const int64_t n4 = D.n / 4;
+    const int64_t base = ((int64_t)blockIdx.x - B.blk_start[di]) * (kAxpyThreads * kAxpyPer) + threadIdx.x;
+    float4 xv[kAxpyPer], yv[kAxpyPer];
+#pragma unroll
+    for (int u = 0; u < kAxpyPer; ++u) {
+        const int64_t i = base + (int64_t)u * kAxpyThreads;
+        if (i < n4) {
+            xv[u] = reinterpret_cast<const float4*>(D.x)[i];
+            yv[u] = reinterpret_cast<const float4*>(D.y)[i];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kAxpyPer; ++u) {
+        const int64_t i = base + (int64_t)u * kAxpyThreads;
+        if (i < n4) {
+            float4 r;
+            r.x = yv[u].x + xv[u].x * s; r.y = yv[u].y + xv[u].y * s; r.z = yv[u].z + xv[u].z * s; r.w = yv[u].w + xv[u].w * s;
+            reinterpret_cast<float4*>(D.y)[i] = r;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int cwn_axpy_eps_f32(const cwn_axpy_desc* descs, int n, cwn_stream_t stream_) {
+    if (descs == nullptr || n < 1 || n > CWN_AXPY_MAX_DESCS) return CWN_ERR_BAD_ARG;
+    AxpyBatch B{};
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const cwn_axpy_desc& D = descs[i];
+        if (D.n < 0 || (D.n & 3) != 0 || (D.n > 0 && (D.y == nullptr || D.x == nullptr))) return CWN_ERR_BAD_ARG;
+        if ((((uintptr_t)D.y) | ((uintptr_t)D.x)) & 15u) return CWN_ERR_ALIGN;
+        B.d[i] = D;
+        B.blk_start[i] = (int32_t)blocks;
+        blocks += (D.n / 4 + kAxpyThreads * kAxpyPer - 1) / (kAxpyThreads * kAxpyPer);
+        if (blocks >= INT32_MAX) return CWN_ERR_TOO_LARGE;
+    }
+    for (int i = n; i <= CWN_AXPY_MAX_DESCS; ++i) B.blk_start[i] = (int32_t)blocks;
+    B.n = n;
+    if (blocks == 0) return CWN_OK;
+    axpy_eps_kernel<<<dim3((unsigned)blocks), dim3(kAxpyThreads), 0, (hipStream_t)stream_>>>(B);
+    return hipGetLastError() == hipSuccess ? CWN_OK : CWN_ERR_LAUNCH;
+}
+
 extern "C" int cwn_step_begin(void* a, int64_t a_bytes, void* b, int64_t b_bytes, int32_t* step, const int64_t* active,
                               int64_t* dropout_state, cwn_stream_t stream_) {
     if (a_bytes < 0 || b_bytes < 0 || (a_bytes & 15) || (b_bytes & 15)) return CWN_ERR_BAD_ARG;

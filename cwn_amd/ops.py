@@ -1735,15 +1735,25 @@ def _blocked_backward_impl(ctx, gs, ys, g_tensors, g_needs, s_tensors, s_needs):
     if k_out == 3:
         # the third output's piece: d out_down / d x = (1 + eps3) -- one fused multiply-add per dimension onto the launch's dx
         # (the scale stays a device scalar: no host read inside a captured step)
+        # -- all dimensions in ONE launch (cwn_axpy_eps_f32, ABI 24; the framework's `1 + eps` and addcmul_ per dimension were 24
+        # launches of a ZINC CIN++ step)
+        todo, keep = [], []
         for d in range(n):
             g_down = gs[3 * d + 1]
-            if g_down is not None:
-                e3 = dims[d].eps3
-                scale = (1.0 + e3.detach().to(torch.float32)).view(1, 1) if e3 is not None else None
-                if scale is None:
-                    dxs[d].add_(g_down)
-                else:
-                    dxs[d].addcmul_(g_down, scale)
+            if g_down is None or dxs[d] is None or dxs[d].numel() == 0:
+                continue
+            e3 = dims[d].eps3
+            e3 = None if e3 is None else _f32c(e3.detach(), 'eps3')
+            g_down = _f32c(g_down, 'gradient of out_down')
+            if not dxs[d].is_contiguous() or dxs[d].numel() % 4 or dxs[d].data_ptr() % 16 or g_down.data_ptr() % 16:
+                dxs[d].add_(g_down) if e3 is None else dxs[d].addcmul_(g_down, (1.0 + e3).view(1, 1))
+                continue
+            keep += [g_down, e3]
+            todo.append(_ffi.AxpyDesc(y=dxs[d].data_ptr(), x=g_down.data_ptr(), eps=_ffi.ptr(e3), n=dxs[d].numel()))
+        for lo in range(0, len(todo), _ffi.AXPY_MAX_DESCS):
+            chunk = todo[lo: lo + _ffi.AXPY_MAX_DESCS]
+            _ffi.check(_ffi.lib().cwn_axpy_eps_f32((_ffi.AxpyDesc * len(chunk))(*chunk), len(chunk), _ffi.stream_ptr(dxs[0].device)),
+                       'cwn_axpy_eps_f32')
     g_of = [gys[d][0 if which == 'y1' else 1] for (d, which) in ydims]
     # weight (and bias) gradients of the message Linear: gY^T x through the merged weight-gradient launches; dX is done
     needs_w = list(g_needs)

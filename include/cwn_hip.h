@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CWN_ABI_VERSION 23
+#define CWN_ABI_VERSION 24
 
 typedef void* cwn_stream_t; /* hipStream_t */
 
@@ -1261,6 +1261,21 @@ int cwn_loss_cols_f32(int32_t kind, const float* pred, const float* y, int64_t n
  * {seed, step} record of cwn_dropout -- its step is advanced by one, unconditionally (a replayed step never repeats a mask). */
 int cwn_step_begin(void* a, int64_t a_bytes, void* b, int64_t b_bytes, int32_t* step, const int64_t* active,
                    int64_t* dropout_state, cwn_stream_t stream);
+
+/* y_i += (1 + *eps_i) * x_i for up to CWN_AXPY_MAX_DESCS vectors in ONE launch (ABI 24) -- the piece of a CIN++ layer's input
+ * gradient that comes through its third output, out_down = zeros + (1 + eps2) x (mp/layers.py:253, lower stream off), added onto
+ * the dx the blocked backward launch wrote: per dimension and layer the framework ran `1 + eps` (a launch over one element) and
+ * an addcmul (24 launches of a ZINC CIN++ training step, 113 us of 1.15 ms).  eps: device float or NULL (= 0), read by the
+ * launch (graph-capturable); n floats, n % 4 == 0, y / x 16-B aligned, y and x of one descriptor must not overlap.  The product
+ * is rounded before the add (as the framework's addcmul). */
+#define CWN_AXPY_MAX_DESCS 8
+typedef struct cwn_axpy_desc {
+    float* y;
+    const float* x;
+    const float* eps;
+    int64_t n;
+} cwn_axpy_desc;
+int cwn_axpy_eps_f32(const cwn_axpy_desc* descs_host, int n, cwn_stream_t stream);
 
 /* torch.optim.Adam's update (no amsgrad; weight_decay is the L2 form) for a whole model in one
  * launch: parameters p, gradients g and the moments m, v are each ONE contiguous fp32 buffer of n

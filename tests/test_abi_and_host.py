@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 23
+    assert lib.cwn_abi_version() == _ffi.ABI_VERSION == 24
     assert lib.cwn_target_arch() == b'gfx950'
     assert lib.cwn_error_string(0) == b'ok'
 

@@ -332,3 +332,27 @@ def test_static_blocked_batch_serves_embed_cinpp_forward_and_training():
     assert all(bool(torch.isfinite(l).item()) for l in losses)
     assert any(not torch.equal(p, q) for p, q in zip(tmodel.parameters(), before))
     print('[gate] EmbedCINpp over a static batch in mode blocked: replayed forward torch.equal to per-batch launches; a captured training step runs')
+
+
+def test_axpy_eps_many_vectors_in_one_launch_equals_addcmul():
+    """cwn_axpy_eps_f32 (ABI 24): y_i += (1 + eps_i) x_i for several vectors per launch -- what adds the third output's piece
+    (1 + eps2) g_down onto the dx of a CIN++ layer -- bit for bit the framework's `y.addcmul_(x, 1 + eps)` / `y.add_(x)`:
+    ragged lengths (a tail shorter than a workgroup's span, an empty vector), eps NULL, more descriptors than one launch takes."""
+    from cwn_amd import _ffi
+    g = torch.Generator().manual_seed(5)
+    sizes = [4, 1024 * 4 + 12, 3340 * 128, 0, 364 * 128, 100, 4096, 40, 8, 16, 20]          # 11 > CWN_AXPY_MAX_DESCS
+    ys = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    xs = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    eps = [None if i % 3 == 2 else torch.randn(1, generator=g).to(DEV) for i in range(len(sizes))]
+    want = [y.clone().add_(x) if e is None else y.clone().addcmul_(x, (1.0 + e)) for y, x, e in zip(ys, xs, eps)]
+    descs = [_ffi.AxpyDesc(y=y.data_ptr(), x=x.data_ptr(), eps=_ffi.ptr(e), n=y.numel()) for y, x, e in zip(ys, xs, eps)]
+    L = _ffi.lib()
+    assert L.cwn_axpy_eps_f32((_ffi.AxpyDesc * len(descs))(*descs), len(descs), _ffi.stream_ptr(DEV)) == 1        # CWN_ERR_BAD_ARG
+    for lo in range(0, len(descs), _ffi.AXPY_MAX_DESCS):
+        chunk = descs[lo: lo + _ffi.AXPY_MAX_DESCS]
+        _ffi.check(L.cwn_axpy_eps_f32((_ffi.AxpyDesc * len(chunk))(*chunk), len(chunk), _ffi.stream_ptr(DEV)), 'cwn_axpy_eps_f32')
+    torch.cuda.synchronize()
+    for i, (y, w) in enumerate(zip(ys, want)):
+        assert torch.equal(y, w), (i, sizes[i])
+    bad = _ffi.AxpyDesc(y=ys[2].data_ptr(), x=xs[2].data_ptr(), eps=None, n=6)              # not a multiple of 4
+    assert L.cwn_axpy_eps_f32((_ffi.AxpyDesc * 1)(bad), 1, _ffi.stream_ptr(DEV)) == 1
