@@ -408,3 +408,32 @@ def test_large_complexes_pool_to_the_same_bits_by_one_workgroup_or_by_many():
     assert torch.equal(alone[0], outs['1'][0][3])
     ref = torch.stack([xs[0].double()[int(ptrs[0][c]):int(ptrs[0][c + 1])].mean(0) for c in range(C)])
     gate(outs['8'][1][0], ref, 'pooled vertices of REDDIT-like complexes (8 workgroups per complex) vs float64')
+
+
+def test_pooling_launch_with_more_complexes_than_its_lds_table_holds():
+    """head_pool_kernel finds a slot's complex by a binary search over the `ptr` table -- staged in LDS up to 2048 entries, read
+    from global memory beyond.  2300 complexes of 1 - 300 cells (forced split): same bits as the head launch pooling by itself,
+    empty complexes and dimensions without cells for some complexes included."""
+    from cwn_amd import ops
+    g = torch.Generator().manual_seed(9)
+    C, K, H2 = 2300, 64, 32
+    sizes = [torch.randint(1, 300, (C,), generator=g), torch.randint(0, 200, (C,), generator=g), torch.randint(0, 3, (C,), generator=g) * 140]
+    sizes[0][17] = 0
+    ptrs = [torch.cat([torch.zeros(1, dtype=torch.long), s.cumsum(0)]).to(DEV) for s in sizes]
+    xs = [torch.randn(int(s.sum()), K, generator=g).to(DEV) for s in sizes]
+    lin1 = [torch.nn.Linear(K, H2).to(DEV) for _ in range(3)]
+    lin2 = torch.nn.Linear(H2, 1).to(DEV)
+    prev, outs = ops.HEAD_POOL_SPLIT, {}
+    try:
+        for split in ('1', '4'):
+            ops.HEAD_POOL_SPLIT = split
+            with torch.no_grad():
+                outs[split] = ops.head(xs, ptrs, C, [l.weight for l in lin1], [l.bias for l in lin1], lin2.weight, lin2.bias,
+                                       mean_readout=False, want_pooled=True)
+    finally:
+        ops.HEAD_POOL_SPLIT = prev
+    assert torch.equal(outs['4'][0], outs['1'][0])
+    for d in range(3):
+        assert torch.equal(outs['4'][1][d], outs['1'][1][d]), d
+    ref = torch.zeros(C, K, dtype=torch.float64).index_add_(0, torch.repeat_interleave(torch.arange(C), sizes[1]), xs[1].double().cpu())
+    gate(outs['4'][1][1], ref, 'pooled edges of 2300 complexes (ptr table searched in global memory) vs float64')
