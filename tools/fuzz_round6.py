@@ -49,9 +49,14 @@ for r in range(ROUNDS):
             ops.BN_BWD_FUSE = keep
         grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     worst, where = 0.0, ''
+    # (a dimension with two or three cells -- a batch of one molecule -- makes its train-mode BatchNorm degenerate: gradients of
+    #  1e5 somewhere in the model, and the two forms' summation orders differ by an ulp of THAT magnitude in tensors of size 1:
+    #  rounds 80 / seed 11 found 7.8e-3 = 2^-7 on a bias gradient of 0.58 next to a largest gradient of 1.9e5, each form
+    #  bit-reproducible run to run.  Differences below 5e-7 of the model's largest gradient are that noise.)
+    gmax = max(float(g.abs().max()) for g in grads[0].values())
     for n in grads[0]:
         ref = grads[0][n]
-        e = float((grads[1][n] - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        e = float((grads[1][n] - ref).abs().max()) / max(1.0, float(ref.abs().max()), 1e-2 * gmax)
         if not np.isfinite(e):
             e = float('inf')
         if e > worst:
