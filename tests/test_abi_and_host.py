@@ -319,7 +319,7 @@ def test_bench_contract_static():
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text, f
     # and nothing that runs on the GPU box reads /root/reference
-    for f in ('bench.py', '__graft_entry__.py', os.path.join('tests', 'test_gpu_parity.py')):
+    for f in ('bench.py', 'bench_fresh.py', '__graft_entry__.py', os.path.join('tests', 'test_gpu_parity.py')):
         assert '/root/reference' not in open(os.path.join(ROOT, f)).read(), f
 
 
