@@ -1748,11 +1748,11 @@ def _blocked_backward_impl(ctx, gs, ys, g_tensors, g_needs, s_tensors, s_needs):
             if not dxs[d].is_contiguous() or dxs[d].numel() % 4 or dxs[d].data_ptr() % 16 or g_down.data_ptr() % 16:
                 dxs[d].add_(g_down) if e3 is None else dxs[d].addcmul_(g_down, (1.0 + e3).view(1, 1))
                 continue
-            keep += [g_down, e3]
+            keep += [g_down, e3, dxs[d]]
             todo.append(_ffi.AxpyDesc(y=dxs[d].data_ptr(), x=g_down.data_ptr(), eps=_ffi.ptr(e3), n=dxs[d].numel()))
         for lo in range(0, len(todo), _ffi.AXPY_MAX_DESCS):
             chunk = todo[lo: lo + _ffi.AXPY_MAX_DESCS]
-            _ffi.check(_ffi.lib().cwn_axpy_eps_f32((_ffi.AxpyDesc * len(chunk))(*chunk), len(chunk), _ffi.stream_ptr(dxs[0].device)),
+            _ffi.check(_ffi.lib().cwn_axpy_eps_f32((_ffi.AxpyDesc * len(chunk))(*chunk), len(chunk), _ffi.stream_ptr(keep[-1].device)),
                        'cwn_axpy_eps_f32')
     g_of = [gys[d][0 if which == 'y1' else 1] for (d, which) in ydims]
     # weight (and bias) gradients of the message Linear: gY^T x through the merged weight-gradient launches; dX is done
